@@ -1,0 +1,119 @@
+"""ctypes binding of libglenet_hip.so (the C ABI declared in include/glenet_hip.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails this
+module raises.  torch is used only as the owner of device memory and streams.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libglenet_hip.so")
+
+_lib = None
+
+c_void_p, c_int, c_float, c_size_t, c_int64 = (
+    ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_int64)
+
+
+class GlxError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GlxError(
+            "libglenet_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.glx_last_error.restype = ctypes.c_char_p
+    lib.glx_abi_version.restype = c_int
+    for name in ("glx_index_workspace_bytes", "glx_sconv_workspace_bytes",
+                 "glx_sconv_wgrad_workspace_bytes", "glx_voxelize_hard_workspace_bytes",
+                 "glx_voxelize_dynamic_workspace_bytes", "glx_nms_workspace_bytes",
+                 "glx_roiaware_pool3d_workspace_bytes", "glx_roipoint_pool3d_workspace_bytes"):
+        if hasattr(lib, name):
+            getattr(lib, name).restype = c_size_t
+    lib.glx_index_words.restype = c_int64
+    _lib = lib
+    return lib
+
+
+def _arg(a):
+    """torch tensor -> device pointer; python scalars pass through; None -> NULL."""
+    if a is None:
+        return c_void_p(0)
+    if isinstance(a, torch.Tensor):
+        return c_void_p(a.data_ptr())
+    if isinstance(a, float):
+        return c_float(a)
+    if isinstance(a, int):
+        return c_int(a)
+    return a
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    """Call an int-returning entry point with the current torch stream appended."""
+    lib = load()
+    fn = getattr(lib, name)
+    rc = fn(*[_arg(a) for a in args], stream_ptr())
+    if rc != 0:
+        raise GlxError("%s failed (%d): %s" % (name, rc, lib.glx_last_error().decode()))
+    return rc
+
+
+def call_nostream(name, *args):
+    lib = load()
+    fn = getattr(lib, name)
+    rc = fn(*[_arg(a) for a in args])
+    if rc != 0:
+        raise GlxError("%s failed (%d): %s" % (name, rc, lib.glx_last_error().decode()))
+    return rc
+
+
+def query(name, *args):
+    """Call a size_t/int64-returning query (no stream)."""
+    lib = load()
+    return int(getattr(lib, name)(*[_arg(a) for a in args]))
+
+
+def size_arg(n):
+    return c_size_t(int(n))
+
+
+def check_cuda(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise GlxError("expected a device tensor (HIP), got %s; there is no CPU path" % t.device)
+        if not t.is_contiguous():
+            raise GlxError("expected a contiguous tensor")
+
+
+class Workspace:
+    """Grow-only device scratch buffer per (device, stream): avoids per-call allocation and
+    keeps stream-ordered reuse safe."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def get(self, nbytes, device):
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+        buf = self._buf.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            self._buf[key] = buf
+        return buf
+
+
+workspace = Workspace()

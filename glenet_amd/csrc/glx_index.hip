@@ -1,0 +1,311 @@
+// Cell index (bitmap + popcount rank) and rule-table generation for sparse convolution.
+//
+// Semantics follow spconv's indice-pair generation as used by the reference at
+// pcdet/models/backbones_3d/spconv_backbone.py:77-117 (SubMConv3d keeps the input
+// set; SparseConv3d reaches every output cell touched by an active input); the data
+// structure is ours: a succinct rank dictionary instead of a hash table, so lookups
+// are collision free, deterministic and the active set enumerates in sorted order.
+#include <stdarg.h>
+
+#include "glx_common.h"
+#include "glx_scan.h"
+
+// ---------------------------------------------------------------- error plumbing
+static thread_local char g_err[512] = "";
+void glx_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* glx_last_error(void) { return g_err; }
+extern "C" int glx_abi_version(void) { return 1; }
+
+// ---------------------------------------------------------------- bitmap + scan
+__global__ void k_set_bits(const int4* __restrict__ idx, int N, GlxGrid g,
+                           unsigned long long* __restrict__ bitmap, int* __restrict__ status) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int4 c = idx[i];  // b, z, y, x
+  if ((unsigned)c.x >= (unsigned)g.B || (unsigned)c.y >= (unsigned)g.D ||
+      (unsigned)c.z >= (unsigned)g.H || (unsigned)c.w >= (unsigned)g.W) {
+    *status = 1;
+    return;
+  }
+  long long l = g.lin(c.x, c.y, c.z, c.w);
+  atomicOr(&bitmap[l >> 6], 1ull << (l & 63));
+}
+
+__global__ void k_scatter_perm(const int4* __restrict__ idx, int N, GlxGrid g,
+                               const unsigned long long* __restrict__ bitmap,
+                               const int* __restrict__ prefix, int* __restrict__ rank_to_row,
+                               int* __restrict__ row_to_rank) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int4 c = idx[i];
+  if ((unsigned)c.x >= (unsigned)g.B || (unsigned)c.y >= (unsigned)g.D ||
+      (unsigned)c.z >= (unsigned)g.H || (unsigned)c.w >= (unsigned)g.W) {
+    if (row_to_rank) row_to_rank[i] = -1;
+    return;
+  }
+  int r = glx_rank_lookup(bitmap, prefix, g.lin(c.x, c.y, c.z, c.w));
+  if (r >= 0 && r < N) rank_to_row[r] = i;
+  if (row_to_rank) row_to_rank[i] = r;
+}
+
+extern "C" int64_t glx_index_words(int B, int D, int H, int W) {
+  GlxGrid g{B, D, H, W};
+  return g.words();
+}
+
+// workspace: block sums of the popcount scan
+extern "C" size_t glx_index_workspace_bytes(int B, int D, int H, int W) {
+  GlxGrid g{B, D, H, W};
+  return glx_scan_workspace_bytes(g.words()) + 256;
+}
+
+int glx_scan_bitmap(const GlxGrid& g, uint64_t* bitmap, int32_t* prefix, int32_t* n_total,
+                    void* workspace, size_t workspace_bytes, hipStream_t st) {
+  PopcWords f{(const unsigned long long*)bitmap};
+  return glx_exclusive_scan(f, g.words(), prefix, n_total, workspace, workspace_bytes, st);
+}
+
+extern "C" int glx_index_build(const int32_t* indices, int N, int B, int D, int H, int W,
+                               uint64_t* bitmap, int32_t* prefix, int32_t* rank_to_row,
+                               int32_t* row_to_rank, int32_t* n_unique, int32_t* status,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(N >= 0 && B > 0 && D > 0 && H > 0 && W > 0, "glx_index_build: bad sizes");
+  GLX_REQUIRE(bitmap && prefix && n_unique && status, "glx_index_build: null output");
+  hipStream_t st = (hipStream_t)stream;
+  GlxGrid g{B, D, H, W};
+  GLX_HIP(hipMemsetAsync(bitmap, 0, (size_t)g.words() * 8, st));
+  GLX_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
+  if (N > 0) {
+    hipLaunchKernelGGL(k_set_bits, dim3(glx_divup(N, 256)), dim3(256), 0, st,
+                       (const int4*)indices, N, g, (unsigned long long*)bitmap, status);
+  }
+  int rc = glx_scan_bitmap(g, bitmap, prefix, n_unique, workspace, workspace_bytes, st);
+  if (rc != GLX_OK) return rc;
+  if (N > 0 && rank_to_row) {
+    hipLaunchKernelGGL(k_scatter_perm, dim3(glx_divup(N, 256)), dim3(256), 0, st,
+                       (const int4*)indices, N, g, (const unsigned long long*)bitmap,
+                       (const int*)prefix, rank_to_row, row_to_rank);
+  }
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// ---------------------------------------------------------------- SubM rules
+// one thread per (output row j, kz, ky): probes the kw cells of one x-row of the window.
+__global__ void k_rules_subm(const int4* __restrict__ idx, int N, GlxGrid g,
+                             const unsigned long long* __restrict__ bitmap,
+                             const int* __restrict__ prefix, const int* __restrict__ rank_to_row,
+                             int kd, int kh, int kw, int* __restrict__ nbr,
+                             int* __restrict__ pair_count) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int zy = kd * kh;
+  int hits = 0;
+  if (t < (long long)N * zy) {
+    int j = (int)(t / zy);
+    int r = (int)(t - (long long)j * zy);
+    int kz = r / kh, ky = r - kz * kh;
+    int4 c = idx[j];
+    int z = c.y + kz - kd / 2, y = c.z + ky - kh / 2;
+    int* dst = nbr + (long long)j * (zy * kw) + (long long)r * kw;
+    bool row_ok = (unsigned)z < (unsigned)g.D && (unsigned)y < (unsigned)g.H;
+    for (int kx = 0; kx < kw; ++kx) {
+      int x = c.w + kx - kw / 2;
+      int v = -1;
+      if (row_ok && (unsigned)x < (unsigned)g.W) {
+        int rk = glx_rank_lookup(bitmap, prefix, g.lin(c.x, z, y, x));
+        if (rk >= 0) {
+          v = rank_to_row ? rank_to_row[rk] : rk;
+          ++hits;
+        }
+      }
+      dst[kx] = v;
+    }
+  }
+  hits = glx_wave_sum(hits);
+  if ((threadIdx.x & 63) == 0 && hits) atomicAdd(pair_count, hits);
+}
+
+extern "C" int glx_rules_subm(const int32_t* indices, int N, int B, int D, int H, int W,
+                              const uint64_t* bitmap, const int32_t* prefix,
+                              const int32_t* rank_to_row, int kd, int kh, int kw, int32_t* nbr,
+                              int32_t* pair_count, void* stream) {
+  GLX_REQUIRE(kd > 0 && kh > 0 && kw > 0 && (kd & 1) && (kh & 1) && (kw & 1),
+              "glx_rules_subm: kernel size must be odd, got (%d,%d,%d)", kd, kh, kw);
+  GLX_REQUIRE(indices && bitmap && prefix && nbr && pair_count, "glx_rules_subm: null pointer");
+  if (N == 0) return GLX_OK;
+  GlxGrid g{B, D, H, W};
+  long long total = (long long)N * kd * kh;
+  hipLaunchKernelGGL(k_rules_subm, dim3(glx_divup(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const int4*)indices, N, g,
+                     (const unsigned long long*)bitmap, (const int*)prefix, rank_to_row, kd, kh,
+                     kw, nbr, pair_count);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// ---------------------------------------------------------------- strided conv
+struct ConvGeom {
+  int kd, kh, kw, sd, sh, sw, pd, ph, pw;
+};
+
+// one thread per (input row, kz, ky): marks reachable output cells.
+__global__ void k_outset_mark(const int4* __restrict__ idx, int N, ConvGeom cg, GlxGrid og,
+                              unsigned long long* __restrict__ obitmap) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int zy = cg.kd * cg.kh;
+  if (t >= (long long)N * zy) return;
+  int i = (int)(t / zy);
+  int r = (int)(t - (long long)i * zy);
+  int kz = r / cg.kh, ky = r - kz * cg.kh;
+  int4 c = idx[i];
+  int nz = c.y + cg.pd - kz, ny = c.z + cg.ph - ky;
+  if (nz < 0 || ny < 0 || nz % cg.sd || ny % cg.sh) return;
+  int oz = nz / cg.sd, oy = ny / cg.sh;
+  if (oz >= og.D || oy >= og.H) return;
+  for (int kx = 0; kx < cg.kw; ++kx) {
+    int nx = c.w + cg.pw - kx;
+    if (nx < 0 || nx % cg.sw) continue;
+    int ox = nx / cg.sw;
+    if (ox >= og.W) continue;
+    long long l = og.lin(c.x, oz, oy, ox);
+    unsigned long long bit = 1ull << (l & 63);
+    // cheap pre-test avoids most redundant atomics (each output is reached ~3x)
+    if (!(obitmap[l >> 6] & bit)) atomicOr(&obitmap[l >> 6], bit);
+  }
+}
+
+extern "C" int glx_outset_build(const int32_t* indices_in, int N_in, int B, int D, int H, int W,
+                                int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph,
+                                int pw, int oD, int oH, int oW, uint64_t* out_bitmap,
+                                int32_t* out_prefix, int32_t* n_out, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(kd > 0 && kh > 0 && kw > 0 && sd > 0 && sh > 0 && sw > 0,
+              "glx_outset_build: bad geometry");
+  GLX_REQUIRE(oD > 0 && oH > 0 && oW > 0, "glx_outset_build: empty output grid");
+  (void)D; (void)H; (void)W;
+  hipStream_t st = (hipStream_t)stream;
+  GlxGrid og{B, oD, oH, oW};
+  GLX_HIP(hipMemsetAsync(out_bitmap, 0, (size_t)og.words() * 8, st));
+  if (N_in > 0) {
+    ConvGeom cg{kd, kh, kw, sd, sh, sw, pd, ph, pw};
+    long long total = (long long)N_in * kd * kh;
+    hipLaunchKernelGGL(k_outset_mark, dim3(glx_divup(total, 256)), dim3(256), 0, st,
+                       (const int4*)indices_in, N_in, cg, og, (unsigned long long*)out_bitmap);
+  }
+  return glx_scan_bitmap(og, out_bitmap, out_prefix, n_out, workspace, workspace_bytes, st);
+}
+
+__global__ void k_outset_emit(const unsigned long long* __restrict__ bitmap,
+                              const int* __restrict__ prefix, long long nwords, GlxGrid g,
+                              int4* __restrict__ out) {
+  long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nwords) return;
+  unsigned long long word = bitmap[w];
+  if (!word) return;
+  int base = prefix[w];
+  while (word) {
+    int bit = __ffsll((long long)word) - 1;
+    word &= word - 1;
+    long long l = (w << 6) + bit;
+    int x = (int)(l % g.W);
+    long long q = l / g.W;
+    int y = (int)(q % g.H);
+    q /= g.H;
+    int z = (int)(q % g.D);
+    int b = (int)(q / g.D);
+    out[base++] = make_int4(b, z, y, x);
+  }
+}
+
+extern "C" int glx_outset_emit(const uint64_t* bitmap, const int32_t* prefix, int B, int D, int H,
+                               int W, int32_t* indices_out, void* stream) {
+  GlxGrid g{B, D, H, W};
+  long long nwords = g.words();
+  hipLaunchKernelGGL(k_outset_emit, dim3(glx_divup(nwords, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const unsigned long long*)bitmap, (const int*)prefix,
+                     nwords, g, (int4*)indices_out);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+__global__ void k_rules_strided(const int4* __restrict__ oidx, int N_out, GlxGrid ig,
+                                const unsigned long long* __restrict__ ibitmap,
+                                const int* __restrict__ iprefix,
+                                const int* __restrict__ irank_to_row, ConvGeom cg,
+                                int* __restrict__ nbr, int* __restrict__ pair_count) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int zy = cg.kd * cg.kh;
+  int hits = 0;
+  if (t < (long long)N_out * zy) {
+    int j = (int)(t / zy);
+    int r = (int)(t - (long long)j * zy);
+    int kz = r / cg.kh, ky = r - kz * cg.kh;
+    int4 c = oidx[j];
+    int z = c.y * cg.sd - cg.pd + kz, y = c.z * cg.sh - cg.ph + ky;
+    bool row_ok = (unsigned)z < (unsigned)ig.D && (unsigned)y < (unsigned)ig.H;
+    int* dst = nbr + (long long)j * (zy * cg.kw) + (long long)r * cg.kw;
+    for (int kx = 0; kx < cg.kw; ++kx) {
+      int x = c.w * cg.sw - cg.pw + kx;
+      int v = -1;
+      if (row_ok && (unsigned)x < (unsigned)ig.W) {
+        int rk = glx_rank_lookup(ibitmap, iprefix, ig.lin(c.x, z, y, x));
+        if (rk >= 0) {
+          v = irank_to_row ? irank_to_row[rk] : rk;
+          ++hits;
+        }
+      }
+      dst[kx] = v;
+    }
+  }
+  hits = glx_wave_sum(hits);
+  if ((threadIdx.x & 63) == 0 && hits) atomicAdd(pair_count, hits);
+}
+
+extern "C" int glx_rules_strided(const int32_t* indices_out, int N_out, int B, int D, int H, int W,
+                                 const uint64_t* in_bitmap, const int32_t* in_prefix,
+                                 const int32_t* in_rank_to_row, int kd, int kh, int kw, int sd,
+                                 int sh, int sw, int pd, int ph, int pw, int32_t* nbr,
+                                 int32_t* pair_count, void* stream) {
+  GLX_REQUIRE(indices_out && in_bitmap && in_prefix && nbr && pair_count,
+              "glx_rules_strided: null pointer");
+  if (N_out == 0) return GLX_OK;
+  GlxGrid ig{B, D, H, W};
+  ConvGeom cg{kd, kh, kw, sd, sh, sw, pd, ph, pw};
+  long long total = (long long)N_out * kd * kh;
+  hipLaunchKernelGGL(k_rules_strided, dim3(glx_divup(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const int4*)indices_out, N_out, ig,
+                     (const unsigned long long*)in_bitmap, (const int*)in_prefix, in_rank_to_row,
+                     cg, nbr, pair_count);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+__global__ void k_rules_invert(const int* __restrict__ nbr, long long total, int K,
+                               int* __restrict__ nbr_in) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  int i = nbr[t];
+  if (i < 0) return;
+  int j = (int)(t / K);
+  int k = (int)(t - (long long)j * K);
+  nbr_in[(long long)i * K + k] = j;
+}
+
+extern "C" int glx_rules_invert(const int32_t* nbr, int N_out, int K, int N_in, int32_t* nbr_in,
+                                void* stream) {
+  GLX_REQUIRE(nbr && nbr_in && K > 0, "glx_rules_invert: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  GLX_HIP(hipMemsetAsync(nbr_in, 0xFF, (size_t)N_in * K * sizeof(int), st));
+  long long total = (long long)N_out * K;
+  if (total > 0) {
+    hipLaunchKernelGGL(k_rules_invert, dim3(glx_divup(total, 256)), dim3(256), 0, st, nbr, total,
+                       K, nbr_in);
+  }
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

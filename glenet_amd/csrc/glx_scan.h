@@ -1,0 +1,116 @@
+// Device-wide exclusive scan (three launches: block sums, scan of sums, write) over a
+// virtual int sequence v[i] = f(i).  Used for popcount ranks of cell bitmaps and for
+// first-seen voxel numbering.  wave64 shuffles inside a wave, LDS across the 4 waves.
+#pragma once
+#include "glx_common.h"
+
+#define SCAN_THREADS 256
+#define SCAN_IPT 8  // items per thread
+#define SCAN_IPB (SCAN_THREADS * SCAN_IPT)
+
+__device__ __forceinline__ int glx_block_exclusive_scan_256(int v, int* total) {
+  __shared__ int wsum[4];
+  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[wid] = inc;
+  __syncthreads();
+  int base = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (w < wid) base += wsum[w];
+  }
+  *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  __syncthreads();
+  return base + inc - v;
+}
+
+struct PopcWords {
+  const unsigned long long* words;
+  __device__ int operator()(long long i) const { return __popcll(words[i]); }
+};
+struct IntArray {
+  const int* a;
+  __device__ int operator()(long long i) const { return a[i]; }
+};
+
+template <class F>
+__global__ void k_scan_block_sums(F f, long long n, int* __restrict__ block_sums) {
+  long long i0 = (long long)blockIdx.x * SCAN_IPB + (long long)threadIdx.x * SCAN_IPT;
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_IPT; ++i)
+    if (i0 + i < n) s += f(i0 + i);
+  int total;
+  glx_block_exclusive_scan_256(s, &total);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of block_sums[n] in place, grand total -> *n_total
+static __global__ void k_scan_of_sums(int* __restrict__ block_sums, int n,
+                                      int* __restrict__ n_total) {
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += SCAN_THREADS) {
+    int i = base + threadIdx.x;
+    int v = (i < n) ? block_sums[i] : 0;
+    int total;
+    int ex = glx_block_exclusive_scan_256(v, &total);
+    int carry = carry_s;
+    if (i < n) block_sums[i] = carry + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_total = carry_s;
+}
+
+template <class F>
+__global__ void k_scan_write(F f, long long n, const int* __restrict__ block_offsets,
+                             int* __restrict__ excl) {
+  long long i0 = (long long)blockIdx.x * SCAN_IPB + (long long)threadIdx.x * SCAN_IPT;
+  int v[SCAN_IPT];
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_IPT; ++i) {
+    v[i] = (i0 + i < n) ? f(i0 + i) : 0;
+    s += v[i];
+  }
+  int total;
+  int ex = glx_block_exclusive_scan_256(s, &total) + block_offsets[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SCAN_IPT; ++i) {
+    if (i0 + i < n) excl[i0 + i] = ex;
+    ex += v[i];
+  }
+}
+
+static inline size_t glx_scan_workspace_bytes(long long n) {
+  long long nblk = (n + SCAN_IPB - 1) / SCAN_IPB;
+  return glx_align((size_t)(nblk > 0 ? nblk : 1) * sizeof(int));
+}
+
+// excl[i] = sum_{i'<i} f(i'), *n_total = sum of all.  workspace >= glx_scan_workspace_bytes(n).
+template <class F>
+static int glx_exclusive_scan(F f, long long n, int* excl, int* n_total, void* workspace,
+                              size_t workspace_bytes, hipStream_t st) {
+  int nblk = glx_divup(n, SCAN_IPB);
+  if (nblk < 1) nblk = 1;
+  if (workspace_bytes < (size_t)nblk * sizeof(int)) {
+    glx_set_error("scan workspace too small: %zu < %zu", workspace_bytes,
+                  (size_t)nblk * sizeof(int));
+    return GLX_EWORKSPACE;
+  }
+  int* bsum = (int*)workspace;
+  hipLaunchKernelGGL((k_scan_block_sums<F>), dim3(nblk), dim3(SCAN_THREADS), 0, st, f, n, bsum);
+  hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(SCAN_THREADS), 0, st, bsum, nblk, n_total);
+  hipLaunchKernelGGL((k_scan_write<F>), dim3(nblk), dim3(SCAN_THREADS), 0, st, f, n,
+                     (const int*)bsum, excl);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

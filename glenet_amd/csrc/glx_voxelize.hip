@@ -1,0 +1,428 @@
+// Point-cloud voxelization on device.
+//
+// Hard voxelization restates the CPU generators the reference calls through
+// VoxelGeneratorWrapper (pcdet/datasets/processor/data_processor.py:15-60 ->
+// spconv.utils.VoxelGeneratorV2 / Point2VoxelCPU3d, third-party): a sequential loop over
+// points with a cell -> voxel-id map.  The sequential "first seen" semantics are
+// reproduced in parallel without a sort:
+//   1. every point sets its cell's bit; a popcount scan ranks the distinct cells;
+//   2. atomicMin per cell finds the first point of each cell;
+//   3. an exclusive scan of "I am my cell's first point" flags over the points numbers the
+//      voxels in first-seen order (frames are stacked, so the scan is per frame after
+//      subtracting the frame base); ids >= max_voxels are dropped exactly like the
+//      generator's `continue`;
+//   4. the first max_points points of a voxel = the max_points smallest point ids of its
+//      cell: an atomicMin cascade over sorted slots.
+// Dynamic voxelization follows DynamicMeanVFE.forward
+// (pcdet/models/backbones_3d/vfe/dynamic_mean_vfe.py:53-72): sorted-unique over the key
+// b*XYZ + x*YZ + y*Z + z is exactly the rank order of a bitmap laid out (b, x, y, z).
+#include "glx_common.h"
+#include "glx_scan.h"
+
+int glx_scan_bitmap(const GlxGrid& g, uint64_t* bitmap, int32_t* prefix, int32_t* n_total,
+                    void* workspace, size_t workspace_bytes, hipStream_t st);
+
+#define VOX_SENT 0x7F7F7F7F
+
+struct VoxGeom {
+  float xmin, ymin, zmin;
+  float vx, vy, vz;
+  int gx, gy, gz;
+};
+
+// cell of a point, reference arithmetic: floor((p - min) / size) in fp32, per axis.
+__device__ __forceinline__ bool vox_cell(const float* __restrict__ p, const VoxGeom& vg, int& cx,
+                                         int& cy, int& cz) {
+  float fx = floorf((p[0] - vg.xmin) / vg.vx);
+  float fy = floorf((p[1] - vg.ymin) / vg.vy);
+  float fz = floorf((p[2] - vg.zmin) / vg.vz);
+  if (!(fx >= 0.f && fx < (float)vg.gx && fy >= 0.f && fy < (float)vg.gy && fz >= 0.f &&
+        fz < (float)vg.gz))
+    return false;
+  cx = (int)fx; cy = (int)fy; cz = (int)fz;
+  return true;
+}
+
+// XMAJOR=false: lin = ((b*gz + z)*gy + y)*gx + x  (hard: coords [b,z,y,x] ascending)
+// XMAJOR=true : lin = ((b*gx + x)*gy + y)*gz + z  (dynamic: DynamicMeanVFE key order)
+template <bool XMAJOR>
+__global__ void k_vox_mark(const float* __restrict__ pts, const int* __restrict__ pbatch, int P,
+                           int C, int B, VoxGeom vg, unsigned long long* __restrict__ bitmap,
+                           long long* __restrict__ cell_lin, int* __restrict__ frame_start) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  int b = pbatch ? pbatch[p] : 0;
+  if (frame_start && (unsigned)b < (unsigned)B) {
+    if (p == 0 || pbatch[p - 1] != b) frame_start[b] = p;  // pbatch != NULL whenever B > 1
+  }
+  int cx, cy, cz;
+  long long l = -1;
+  if ((unsigned)b < (unsigned)B && vox_cell(pts + (long long)p * C, vg, cx, cy, cz)) {
+    l = XMAJOR ? (((long long)b * vg.gx + cx) * vg.gy + cy) * vg.gz + cz
+               : (((long long)b * vg.gz + cz) * vg.gy + cy) * vg.gx + cx;
+    atomicOr(&bitmap[l >> 6], 1ull << (l & 63));
+  }
+  cell_lin[p] = l;
+}
+
+__global__ void k_vox_first_point(const long long* __restrict__ cell_lin, int P,
+                                  const unsigned long long* __restrict__ bitmap,
+                                  const int* __restrict__ prefix, int* __restrict__ cell_rank,
+                                  int* __restrict__ first_pt) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  long long l = cell_lin[p];
+  int r = -1;
+  if (l >= 0) {
+    r = glx_rank_lookup(bitmap, prefix, l);
+    atomicMin(&first_pt[r], p);
+  }
+  cell_rank[p] = r;
+}
+
+__global__ void k_vox_flags(const int* __restrict__ cell_rank, const int* __restrict__ first_pt,
+                            int P, int* __restrict__ flags) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  int r = cell_rank[p];
+  flags[p] = (r >= 0 && first_pt[r] == p) ? 1 : 0;
+}
+
+// single thread: frame bases in the global first-seen numbering and capped output offsets
+__global__ void k_vox_frames(const int* __restrict__ excl, const int* __restrict__ total, int P,
+                             int B, int max_voxels, int* __restrict__ frame_start,
+                             int* __restrict__ frame_base, int* __restrict__ voxel_offset) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int next = P;
+  for (int b = B - 1; b >= 0; --b) {  // empty frames inherit the next frame's start
+    if (frame_start[b] < 0) frame_start[b] = next;
+    next = frame_start[b];
+  }
+  int tot = *total;
+  for (int b = 0; b < B; ++b) frame_base[b] = frame_start[b] < P ? excl[frame_start[b]] : tot;
+  frame_base[B] = tot;
+  int off = 0;
+  for (int b = 0; b < B; ++b) {
+    voxel_offset[b] = off;
+    int cnt = frame_base[b + 1] - frame_base[b];
+    off += cnt < max_voxels ? cnt : max_voxels;
+  }
+  voxel_offset[B] = off;
+}
+
+__global__ void k_vox_assign_rows(const int* __restrict__ flags, const int* __restrict__ excl,
+                                  const int* __restrict__ cell_rank,
+                                  const long long* __restrict__ cell_lin,
+                                  const int* __restrict__ pbatch, int P, VoxGeom vg, int max_voxels,
+                                  const int* __restrict__ frame_base,
+                                  const int* __restrict__ voxel_offset,
+                                  int* __restrict__ row_of_rank, int4* __restrict__ coords) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P || !flags[p]) return;
+  int b = pbatch ? pbatch[p] : 0;
+  int local = excl[p] - frame_base[b];
+  int row = -1;
+  if (local < max_voxels) {
+    row = voxel_offset[b] + local;
+    long long l = cell_lin[p];
+    int x = (int)(l % vg.gx);
+    long long q = l / vg.gx;
+    int y = (int)(q % vg.gy);
+    int z = (int)((q / vg.gy) % vg.gz);
+    coords[row] = make_int4(b, z, y, x);
+  }
+  row_of_rank[cell_rank[p]] = row;
+}
+
+__global__ void k_vox_slots(const int* __restrict__ cell_rank, const int* __restrict__ row_of_rank,
+                            int P, int max_points, int* __restrict__ slots) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  int r = cell_rank[p];
+  if (r < 0) return;
+  int row = row_of_rank[r];
+  if (row < 0) return;
+  int* s = slots + (long long)row * max_points;
+  int v = p;
+  for (int i = 0; i < max_points; ++i) {  // keeps the max_points smallest ids, sorted
+    int old = atomicMin(&s[i], v);
+    if (old == VOX_SENT) break;
+    v = old > v ? old : v;
+  }
+}
+
+__global__ void k_vox_fill(const float* __restrict__ pts, const int* __restrict__ slots,
+                           const int* __restrict__ n_rows_dev, int max_points, int C,
+                           float* __restrict__ voxels, int* __restrict__ num_points) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int n_rows = *n_rows_dev;
+  if (t >= (long long)n_rows * max_points) return;
+  int row = (int)(t / max_points);
+  int s = (int)(t - (long long)row * max_points);
+  int pidx = slots[t];
+  float* dst = voxels + t * C;
+  if (pidx != VOX_SENT) {
+    const float* src = pts + (long long)pidx * C;
+    for (int c = 0; c < C; ++c) dst[c] = src[c];
+  } else {
+    for (int c = 0; c < C; ++c) dst[c] = 0.f;
+  }
+  if (s == 0) {
+    int n = 0;
+    for (int i = 0; i < max_points; ++i) n += slots[(long long)row * max_points + i] != VOX_SENT;
+    num_points[row] = n;
+  }
+}
+
+struct HardWs {
+  uint64_t* bitmap;
+  int32_t* prefix;
+  long long* cell_lin;
+  int *cell_rank, *first_pt, *flags, *excl, *row_of_rank, *slots, *frame_start, *frame_base,
+      *total, *n_unique;
+  void* scan_ws;
+  size_t scan_ws_bytes;
+  size_t bytes;
+};
+
+static HardWs hard_ws_layout(void* base, int P, int B, int gx, int gy, int gz, int max_points,
+                             int max_voxels) {
+  HardWs w;
+  GlxGrid g{B, gz, gy, gx};
+  char* p = (char*)base;
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    void* r = p ? p + off : nullptr;
+    off += glx_align(n);
+    return r;
+  };
+  size_t Pn = P > 0 ? P : 1;
+  w.bitmap = (uint64_t*)take((size_t)g.words() * 8);
+  w.prefix = (int32_t*)take((size_t)g.words() * 4);
+  w.cell_lin = (long long*)take(Pn * 8);
+  w.cell_rank = (int*)take(Pn * 4);
+  w.first_pt = (int*)take(Pn * 4);
+  w.flags = (int*)take(Pn * 4);
+  w.excl = (int*)take(Pn * 4);
+  w.row_of_rank = (int*)take(Pn * 4);
+  w.slots = (int*)take((size_t)B * max_voxels * max_points * 4);
+  w.frame_start = (int*)take((size_t)(B + 1) * 4);
+  w.frame_base = (int*)take((size_t)(B + 1) * 4);
+  w.total = (int*)take(4);
+  w.n_unique = (int*)take(4);
+  size_t s1 = glx_scan_workspace_bytes(g.words()), s2 = glx_scan_workspace_bytes(P);
+  w.scan_ws_bytes = s1 > s2 ? s1 : s2;
+  w.scan_ws = take(w.scan_ws_bytes);
+  w.bytes = off;
+  return w;
+}
+
+extern "C" size_t glx_voxelize_hard_workspace_bytes(int P, int B, int gx, int gy, int gz,
+                                                    int max_points, int max_voxels) {
+  return hard_ws_layout(nullptr, P, B, gx, gy, gz, max_points, max_voxels).bytes + 256;
+}
+
+extern "C" int glx_voxelize_hard(const float* points, const int32_t* point_batch, int P, int C,
+                                 int B, const float* vrange, const float* vsize, int gx, int gy,
+                                 int gz, int max_points, int max_voxels, float* voxels,
+                                 int32_t* coords, int32_t* num_points, int32_t* voxel_offset,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(points && vrange && vsize && voxels && coords && num_points && voxel_offset,
+              "glx_voxelize_hard: null pointer");
+  GLX_REQUIRE(P >= 0 && C >= 3 && B >= 1 && gx > 0 && gy > 0 && gz > 0 && max_points > 0 &&
+                  max_voxels > 0,
+              "glx_voxelize_hard: bad sizes");
+  GLX_REQUIRE(B == 1 || point_batch, "glx_voxelize_hard: point_batch required when B > 1");
+  HardWs w = hard_ws_layout(workspace, P, B, gx, gy, gz, max_points, max_voxels);
+  if (!workspace || workspace_bytes < w.bytes) {
+    glx_set_error("glx_voxelize_hard: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
+    return GLX_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  GlxGrid g{B, gz, gy, gx};
+  VoxGeom vg{vrange[0], vrange[1], vrange[2], vsize[0], vsize[1], vsize[2], gx, gy, gz};
+  const int nb = glx_divup(P > 0 ? P : 1, 256);
+  GLX_HIP(hipMemsetAsync(w.bitmap, 0, (size_t)g.words() * 8, st));
+  GLX_HIP(hipMemsetAsync(w.first_pt, 0x7F, (size_t)(P > 0 ? P : 1) * 4, st));
+  GLX_HIP(hipMemsetAsync(w.row_of_rank, 0xFF, (size_t)(P > 0 ? P : 1) * 4, st));
+  GLX_HIP(hipMemsetAsync(w.slots, 0x7F, (size_t)B * max_voxels * max_points * 4, st));
+  GLX_HIP(hipMemsetAsync(w.frame_start, 0xFF, (size_t)(B + 1) * 4, st));
+  if (P > 0) {
+    hipLaunchKernelGGL((k_vox_mark<false>), dim3(nb), dim3(256), 0, st, points, point_batch, P, C,
+                       B, vg, (unsigned long long*)w.bitmap, w.cell_lin,
+                       point_batch ? w.frame_start : nullptr);
+  }
+  int rc = glx_scan_bitmap(g, w.bitmap, w.prefix, w.n_unique, w.scan_ws, w.scan_ws_bytes, st);
+  if (rc != GLX_OK) return rc;
+  if (P > 0) {
+    hipLaunchKernelGGL(k_vox_first_point, dim3(nb), dim3(256), 0, st, w.cell_lin, P,
+                       (const unsigned long long*)w.bitmap, (const int*)w.prefix, w.cell_rank,
+                       w.first_pt);
+    hipLaunchKernelGGL(k_vox_flags, dim3(nb), dim3(256), 0, st, (const int*)w.cell_rank,
+                       (const int*)w.first_pt, P, w.flags);
+  }
+  IntArray fa{w.flags};
+  rc = glx_exclusive_scan(fa, P, w.excl, w.total, w.scan_ws, w.scan_ws_bytes, st);
+  if (rc != GLX_OK) return rc;
+  if (!point_batch) GLX_HIP(hipMemsetAsync(w.frame_start, 0, 4, st));  // single frame starts at 0
+  hipLaunchKernelGGL(k_vox_frames, dim3(1), dim3(64), 0, st, (const int*)w.excl,
+                     (const int*)w.total, P, B, max_voxels, w.frame_start, w.frame_base,
+                     voxel_offset);
+  if (P > 0) {
+    hipLaunchKernelGGL(k_vox_assign_rows, dim3(nb), dim3(256), 0, st, (const int*)w.flags,
+                       (const int*)w.excl, (const int*)w.cell_rank, (const long long*)w.cell_lin,
+                       point_batch, P, vg, max_voxels, (const int*)w.frame_base,
+                       (const int*)voxel_offset, w.row_of_rank, (int4*)coords);
+    hipLaunchKernelGGL(k_vox_slots, dim3(nb), dim3(256), 0, st, (const int*)w.cell_rank,
+                       (const int*)w.row_of_rank, P, max_points, w.slots);
+    long long cap = (long long)B * max_voxels * max_points;
+    hipLaunchKernelGGL(k_vox_fill, dim3(glx_divup(cap, 256)), dim3(256), 0, st, points,
+                       (const int*)w.slots, (const int*)(voxel_offset + B), max_points, C, voxels,
+                       num_points);
+  }
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// ------------------------------------------------------------------ dynamic + mean
+__global__ void k_dyn_accumulate(const float* __restrict__ pts, const long long* __restrict__ cell_lin,
+                                 int P, int C, const unsigned long long* __restrict__ bitmap,
+                                 const int* __restrict__ prefix, float* __restrict__ sums,
+                                 int* __restrict__ counts) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)P * C) return;
+  int p = (int)(t / C);
+  int c = (int)(t - (long long)p * C);
+  long long l = cell_lin[p];
+  if (l < 0) return;
+  int r = glx_rank_lookup(bitmap, prefix, l);
+  atomicAdd(&sums[(long long)r * C + c], pts[t]);
+  if (c == 0) atomicAdd(&counts[r], 1);
+}
+
+__global__ void k_dyn_emit(const unsigned long long* __restrict__ bitmap,
+                           const int* __restrict__ prefix, long long nwords, int gx, int gy, int gz,
+                           int C, const int* __restrict__ counts, float* __restrict__ feats,
+                           int4* __restrict__ coords) {
+  long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nwords) return;
+  unsigned long long word = bitmap[w];
+  if (!word) return;
+  int r = prefix[w];
+  while (word) {
+    int bit = __ffsll((long long)word) - 1;
+    word &= word - 1;
+    long long l = (w << 6) + bit;  // ((b*gx + x)*gy + y)*gz + z
+    int z = (int)(l % gz);
+    long long q = l / gz;
+    int y = (int)(q % gy);
+    q /= gy;
+    int x = (int)(q % gx);
+    int b = (int)(q / gx);
+    coords[r] = make_int4(b, z, y, x);
+    float inv = (float)counts[r];
+    for (int c = 0; c < C; ++c) feats[(long long)r * C + c] = feats[(long long)r * C + c] / inv;
+    ++r;
+  }
+}
+
+struct DynWs {
+  uint64_t* bitmap;
+  int32_t* prefix;
+  long long* cell_lin;
+  int* counts;
+  void* scan_ws;
+  size_t scan_ws_bytes, bytes;
+};
+
+static DynWs dyn_ws_layout(void* base, int P, int B, int gx, int gy, int gz) {
+  DynWs w;
+  GlxGrid g{B, gx, gy, gz};
+  char* p = (char*)base;
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    void* r = p ? p + off : nullptr;
+    off += glx_align(n);
+    return r;
+  };
+  size_t Pn = P > 0 ? P : 1;
+  w.bitmap = (uint64_t*)take((size_t)g.words() * 8);
+  w.prefix = (int32_t*)take((size_t)g.words() * 4);
+  w.cell_lin = (long long*)take(Pn * 8);
+  w.counts = (int*)take(Pn * 4);
+  w.scan_ws_bytes = glx_scan_workspace_bytes(g.words());
+  w.scan_ws = take(w.scan_ws_bytes);
+  w.bytes = off;
+  return w;
+}
+
+extern "C" size_t glx_voxelize_dynamic_workspace_bytes(int P, int B, int gx, int gy, int gz) {
+  return dyn_ws_layout(nullptr, P, B, gx, gy, gz).bytes + 256;
+}
+
+extern "C" int glx_voxelize_dynamic_mean(const float* points, const int32_t* point_batch, int P,
+                                         int C, int B, const float* vrange, const float* vsize,
+                                         int gx, int gy, int gz, float* features, int32_t* coords,
+                                         int32_t* n_voxels, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(points && vrange && vsize && features && coords && n_voxels,
+              "glx_voxelize_dynamic_mean: null pointer");
+  GLX_REQUIRE(P >= 0 && C >= 3 && B >= 1 && gx > 0 && gy > 0 && gz > 0,
+              "glx_voxelize_dynamic_mean: bad sizes");
+  GLX_REQUIRE(B == 1 || point_batch, "glx_voxelize_dynamic_mean: point_batch required when B > 1");
+  DynWs w = dyn_ws_layout(workspace, P, B, gx, gy, gz);
+  if (!workspace || workspace_bytes < w.bytes) {
+    glx_set_error("glx_voxelize_dynamic_mean: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
+    return GLX_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  GlxGrid g{B, gx, gy, gz};
+  VoxGeom vg{vrange[0], vrange[1], vrange[2], vsize[0], vsize[1], vsize[2], gx, gy, gz};
+  GLX_HIP(hipMemsetAsync(w.bitmap, 0, (size_t)g.words() * 8, st));
+  if (P > 0) {
+    GLX_HIP(hipMemsetAsync(features, 0, (size_t)P * C * 4, st));
+    GLX_HIP(hipMemsetAsync(w.counts, 0, (size_t)P * 4, st));
+    hipLaunchKernelGGL((k_vox_mark<true>), dim3(glx_divup(P, 256)), dim3(256), 0, st, points,
+                       point_batch, P, C, B, vg, (unsigned long long*)w.bitmap, w.cell_lin,
+                       (int*)nullptr);
+  }
+  int rc = glx_scan_bitmap(g, w.bitmap, w.prefix, n_voxels, w.scan_ws, w.scan_ws_bytes, st);
+  if (rc != GLX_OK) return rc;
+  if (P > 0) {
+    long long total = (long long)P * C;
+    hipLaunchKernelGGL(k_dyn_accumulate, dim3(glx_divup(total, 256)), dim3(256), 0, st, points,
+                       (const long long*)w.cell_lin, P, C, (const unsigned long long*)w.bitmap,
+                       (const int*)w.prefix, features, w.counts);
+    long long nwords = g.words();
+    hipLaunchKernelGGL(k_dyn_emit, dim3(glx_divup(nwords, 256)), dim3(256), 0, st,
+                       (const unsigned long long*)w.bitmap, (const int*)w.prefix, nwords, gx, gy,
+                       gz, C, (const int*)w.counts, features, (int4*)coords);
+  }
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// ------------------------------------------------------------------ MeanVFE
+__global__ void k_mean_vfe(const float* __restrict__ voxels, const int* __restrict__ num, int Nv,
+                           int mp, int C, float* __restrict__ out) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)Nv * C) return;
+  int v = (int)(t / C);
+  int c = (int)(t - (long long)v * C);
+  const float* src = voxels + (long long)v * mp * C + c;
+  float s = 0.f;
+  for (int p = 0; p < mp; ++p) s += src[(long long)p * C];
+  float n = (float)num[v];
+  out[t] = s / (n < 1.f ? 1.f : n);
+}
+
+extern "C" int glx_mean_vfe(const float* voxels, const int32_t* num_points, int Nv, int max_points,
+                            int C, float* out, void* stream) {
+  GLX_REQUIRE(voxels && num_points && out && max_points > 0 && C > 0, "glx_mean_vfe: bad arguments");
+  if (Nv == 0) return GLX_OK;
+  long long total = (long long)Nv * C;
+  hipLaunchKernelGGL(k_mean_vfe, dim3(glx_divup(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     voxels, num_points, Nv, max_points, C, out);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

@@ -1,0 +1,437 @@
+"""Host-side mirror of the spconv surface the reference uses.
+
+Mirrors (names, argument meaning, attributes) of the third-party `spconv` package as the
+reference calls it:
+  * SparseConvTensor(features, indices, spatial_shape, batch_size) with .features .indices
+    .spatial_shape .batch_size .dense() .replace_feature()   (spconv_backbone.py:141-146,
+    pcdet/utils/spconv_utils.py:28-34, height_compression.py:21)
+  * SubMConv3d / SparseConv3d / SparseInverseConv3d (spconv_backbone.py:12-17)
+  * SparseSequential / SparseModule (spconv_backbone.py:21,30)
+  * conv.SparseConvolution base class with a 5-D .weight (spconv_utils.py:19-21); the layout
+    is the spconv-1.x one, (kd, kh, kw, Cin, Cout)  (detector3d_template.py:377-384).
+
+All arithmetic runs in libglenet_hip.so through the C ABI; this file only owns tensors,
+caches rule tables per indice_key and wires autograd.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+from torch import nn
+from torch.autograd import Function
+from torch.nn import init
+
+from .. import _lib
+from .._lib import call, query, size_arg, workspace
+
+
+def _triple(v):
+    if isinstance(v, (list, tuple)):
+        assert len(v) == 3, v
+        return tuple(int(x) for x in v)
+    return (int(v),) * 3
+
+
+class CellIndex:
+    """Rank dictionary of one active set on a (B, D, H, W) grid (device resident)."""
+
+    __slots__ = ("grid", "bitmap", "prefix", "rank_to_row", "row_to_rank", "n")
+
+    def __init__(self, grid, bitmap, prefix, rank_to_row, row_to_rank, n):
+        self.grid, self.bitmap, self.prefix = grid, bitmap, prefix
+        self.rank_to_row, self.row_to_rank, self.n = rank_to_row, row_to_rank, n
+
+    @staticmethod
+    def alloc(grid, device):
+        words = query("glx_index_words", *grid)
+        bitmap = torch.empty(words, dtype=torch.int64, device=device)
+        prefix = torch.empty(words, dtype=torch.int32, device=device)
+        return bitmap, prefix
+
+    @staticmethod
+    def build(indices, grid):
+        """indices (N,4) int32 [b,z,y,x] in arbitrary row order -> CellIndex."""
+        _lib.check_cuda(indices)
+        dev = indices.device
+        N = indices.shape[0]
+        bitmap, prefix = CellIndex.alloc(grid, dev)
+        r2row = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+        row2r = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+        meta = torch.zeros(2, dtype=torch.int32, device=dev)  # n_unique, status
+        wsb = query("glx_index_workspace_bytes", *grid)
+        ws = workspace.get(wsb, dev)
+        call("glx_index_build", indices, N, *grid, bitmap, prefix, r2row, row2r, meta[0:1],
+             meta[1:2], ws, size_arg(ws.numel()))
+        n_unique, status = meta.tolist()  # one host sync per distinct active set
+        if status != 0:
+            raise ValueError("SparseConvTensor indices outside spatial_shape/batch_size %s" % (grid,))
+        if n_unique != N:
+            raise ValueError("SparseConvTensor indices contain duplicates (%d unique of %d)"
+                             % (n_unique, N))
+        return CellIndex(grid, bitmap, prefix, r2row, row2r, N)
+
+
+class RuleSet:
+    """Rule table of one conv geometry on one input set (what spconv keeps per indice_key)."""
+
+    def __init__(self):
+        self.nbr = None          # (N_out, K) int32: input row per output row and offset
+        self.nbr_in = None       # (N_in, K) int32 inverse (lazy; strided only)
+        self.K = 0
+        self.N_in = self.N_out = 0
+        self.subm = True
+        self.tile_order_out = None   # spatial order of output rows (None = identity)
+        self.tile_order_in = None
+        self.out_indices = None
+        self.out_spatial_shape = None
+        self.out_index = None    # CellIndex of the output set
+        self.in_index = None
+        self.in_indices = None
+        self.in_spatial_shape = None
+        self.geom = None
+        self._pairs_dev = None
+        self._pairs = None
+
+    @property
+    def pair_count(self):
+        """R = number of (input, output, offset) rules (host sync on first read)."""
+        if self._pairs is None:
+            self._pairs = int(self._pairs_dev.item())
+        return self._pairs
+
+    def inverse_table(self):
+        if self.nbr_in is None:
+            dev = self.nbr.device
+            self.nbr_in = torch.empty((max(self.N_in, 1), self.K), dtype=torch.int32, device=dev)
+            call("glx_rules_invert", self.nbr, self.N_out, self.K, self.N_in, self.nbr_in)
+        return self.nbr_in
+
+
+def build_subm_rules(x, ksize):
+    idx = x._ensure_index()
+    N = x.indices.shape[0]
+    K = ksize[0] * ksize[1] * ksize[2]
+    rs = RuleSet()
+    rs.subm, rs.K, rs.N_in, rs.N_out = True, K, N, N
+    rs.nbr = torch.empty((max(N, 1), K), dtype=torch.int32, device=x.indices.device)
+    rs._pairs_dev = torch.zeros(1, dtype=torch.int32, device=x.indices.device)
+    call("glx_rules_subm", x.indices, N, *idx.grid, idx.bitmap, idx.prefix, idx.rank_to_row,
+         *ksize, rs.nbr, rs._pairs_dev)
+    rs.tile_order_out = rs.tile_order_in = idx.rank_to_row
+    rs.out_indices, rs.out_spatial_shape, rs.out_index = x.indices, list(x.spatial_shape), idx
+    rs.in_index, rs.in_indices, rs.in_spatial_shape = idx, x.indices, list(x.spatial_shape)
+    rs.geom = ("subm", ksize)
+    return rs
+
+
+def build_strided_rules(x, ksize, stride, padding, dilation=(1, 1, 1)):
+    if dilation != (1, 1, 1):
+        raise NotImplementedError("dilation != 1 is not used by the reference backbones")
+    idx = x._ensure_index()
+    dev = x.indices.device
+    B = x.batch_size
+    D, H, W = x.spatial_shape
+    out_shape = [(s + 2 * p - (k - 1) - 1) // st + 1
+                 for s, p, k, st in zip((D, H, W), padding, ksize, stride)]
+    if min(out_shape) <= 0:
+        raise ValueError("SparseConv3d output shape %s is empty" % (out_shape,))
+    ogrid = (B, *out_shape)
+    obitmap, oprefix = CellIndex.alloc(ogrid, dev)
+    n_out_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+    wsb = query("glx_index_workspace_bytes", *ogrid)
+    ws = workspace.get(wsb, dev)
+    N_in = x.indices.shape[0]
+    call("glx_outset_build", x.indices, N_in, B, D, H, W, *ksize, *stride, *padding, *out_shape,
+         obitmap, oprefix, n_out_dev, ws, size_arg(ws.numel()))
+    N_out = int(n_out_dev.item())  # host sync: output row count sizes the next tensors
+    K = ksize[0] * ksize[1] * ksize[2]
+    rs = RuleSet()
+    rs.subm, rs.K, rs.N_in, rs.N_out = False, K, N_in, N_out
+    rs.out_indices = torch.empty((max(N_out, 1), 4), dtype=torch.int32, device=dev)[:N_out]
+    rs.nbr = torch.empty((max(N_out, 1), K), dtype=torch.int32, device=dev)
+    rs._pairs_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+    if N_out > 0:
+        call("glx_outset_emit", obitmap, oprefix, *ogrid, rs.out_indices)
+        call("glx_rules_strided", rs.out_indices, N_out, B, D, H, W, idx.bitmap, idx.prefix,
+             idx.rank_to_row, *ksize, *stride, *padding, rs.nbr, rs._pairs_dev)
+    rs.out_spatial_shape = out_shape
+    rs.out_index = CellIndex(ogrid, obitmap, oprefix, None, None, N_out)  # rows already sorted
+    rs.tile_order_out = None
+    rs.tile_order_in = idx.rank_to_row
+    rs.in_index, rs.in_indices, rs.in_spatial_shape = idx, x.indices, list(x.spatial_shape)
+    rs.geom = ("spconv", ksize, stride, padding)
+    return rs
+
+
+def _sconv(features, weight_kio, bias, nbr, tile_order, n_out):
+    """out[j] = sum_k features[nbr[j,k]] @ weight_kio[k]  (weight (K, Cin, Cout))."""
+    K, cin, cout = weight_kio.shape
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=features.device)
+    if n_out == 0:
+        return out
+    wsb = query("glx_sconv_workspace_bytes", K, cin, cout)
+    ws = workspace.get(wsb, features.device)
+    call("glx_sconv_forward", features, features.shape[0], weight_kio, bias, nbr, tile_order,
+         n_out, K, cin, cout, out, ws, size_arg(ws.numel()))
+    return out
+
+
+class SparseConvFunction(Function):
+    """features (N_in, Cin), weight (K, Cin, Cout), bias (Cout)|None -> (N_out, Cout)."""
+
+    @staticmethod
+    def forward(ctx, features, weight, bias, rules, inverse):
+        features = features.contiguous().float()
+        w = weight.contiguous()
+        _lib.check_cuda(features, w)
+        if inverse:      # SparseInverseConv3d: walk the paired conv's rules backwards
+            nbr, order, n_out = rules.inverse_table(), rules.tile_order_in, rules.N_in
+        else:
+            nbr, order, n_out = rules.nbr, rules.tile_order_out, rules.N_out
+        out = _sconv(features, w, bias, nbr, order, n_out)
+        ctx.rules, ctx.inverse = rules, inverse
+        ctx.save_for_backward(features, w)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        features, w = ctx.saved_tensors
+        rules, inverse = ctx.rules, ctx.inverse
+        grad_out = grad_out.contiguous().float()
+        K, cin, cout = w.shape
+        g_feat = g_w = g_b = None
+        if inverse:
+            fwd_nbr, n_fwd_out = rules.inverse_table(), rules.N_in
+            bwd_nbr, bwd_order, n_bwd_out = rules.nbr, rules.tile_order_out, rules.N_out
+            wt = w.transpose(1, 2).contiguous()
+        elif rules.subm:
+            # nbr_in[i][k] == nbr[i][K-1-k] on a submanifold set: flip the taps instead
+            fwd_nbr, n_fwd_out = rules.nbr, rules.N_out
+            bwd_nbr, bwd_order, n_bwd_out = rules.nbr, rules.tile_order_out, rules.N_in
+            wt = w.flip(0).transpose(1, 2).contiguous()
+        else:
+            fwd_nbr, n_fwd_out = rules.nbr, rules.N_out
+            bwd_nbr, bwd_order, n_bwd_out = rules.inverse_table(), rules.tile_order_in, rules.N_in
+            wt = w.transpose(1, 2).contiguous()
+        if ctx.needs_input_grad[0]:
+            g_feat = _sconv(grad_out, wt, None, bwd_nbr, bwd_order, n_bwd_out)
+        if ctx.needs_input_grad[1]:
+            g_w = torch.empty_like(w)
+            wsb = query("glx_sconv_wgrad_workspace_bytes", n_fwd_out, K, cin, cout)
+            ws = workspace.get(wsb, w.device)
+            call("glx_sconv_wgrad", features, features.shape[0], grad_out, fwd_nbr, n_fwd_out, K,
+                 cin, cout, g_w, ws, size_arg(ws.numel()))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            g_b = grad_out.sum(0)
+        return g_feat, g_w, g_b, None, None
+
+
+class SparseConvTensor:
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None, voxel_num=None,
+                 indice_dict=None, benchmark=False):
+        self.features = features
+        if indices.dtype != torch.int32:
+            indices = indices.int()
+        self.indices = indices.contiguous()
+        self.spatial_shape = [int(s) for s in spatial_shape]
+        self.batch_size = int(batch_size)
+        self.indice_dict = indice_dict if indice_dict is not None else {}
+        self.grid = grid
+        self.voxel_num = voxel_num
+        self.benchmark = benchmark
+        self._index = None
+
+    # -- spconv 2.x API used by pcdet/utils/spconv_utils.py:28-34
+    def replace_feature(self, new_features):
+        t = SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size,
+                             self.grid, self.voxel_num, self.indice_dict, self.benchmark)
+        t._index = self._index
+        return t
+
+    @property
+    def spatial_size(self):
+        n = 1
+        for s in self.spatial_shape:
+            n *= s
+        return n
+
+    def find_indice_pair(self, key):
+        if key is None:
+            return None
+        return self.indice_dict.get(key)
+
+    def _ensure_index(self):
+        if self._index is None:
+            grid = (self.batch_size, *self.spatial_shape)
+            self._index = CellIndex.build(self.indices, grid)
+        return self._index
+
+    def dense(self, channels_first=True):
+        """(B, C, D, H, W) dense tensor (height_compression.py:21-23)."""
+        return DenseFunction.apply(self.features, self, channels_first)
+
+
+class DenseFunction(Function):
+    @staticmethod
+    def forward(ctx, features, st, channels_first):
+        f = features.contiguous().float()
+        _lib.check_cuda(f, st.indices)
+        N, C = f.shape
+        D, H, W = st.spatial_shape
+        out = torch.zeros((st.batch_size, C, D, H, W), dtype=torch.float32, device=f.device)
+        call("glx_dense_scatter", f, st.indices, N, C, st.batch_size, D, H, W, out)
+        ctx.st, ctx.channels_first = st, channels_first
+        return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        st = ctx.st
+        if not ctx.channels_first:
+            g = g.permute(0, 4, 1, 2, 3)
+        i = st.indices.long()
+        gf = g[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]]
+        return gf.contiguous(), None, None
+
+
+class SparseModule(nn.Module):
+    """Marker base class: modules that take and return a SparseConvTensor."""
+    pass
+
+
+class SparseConvolution(SparseModule):
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0,
+                 dilation=1, groups=1, bias=True, subm=False, output_padding=0, transposed=False,
+                 inverse=False, indice_key=None, fused_bn=False, use_hash=False, algo=None):
+        super().__init__()
+        assert ndim == 3, "only 3-D sparse convolution is on the hot path"
+        assert groups == 1
+        self.ndim, self.in_channels, self.out_channels = ndim, in_channels, out_channels
+        self.kernel_size = _triple(kernel_size)
+        self.stride, self.padding, self.dilation = _triple(stride), _triple(padding), _triple(dilation)
+        self.subm, self.inverse, self.transposed = subm, inverse, transposed
+        self.indice_key = indice_key
+        self.conv1x1 = all(k == 1 for k in self.kernel_size)
+        self.weight = nn.Parameter(torch.empty(*self.kernel_size, in_channels, out_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # same recipe as torch.nn.ConvNd / spconv: kaiming_uniform(a=sqrt(5)); the receptive
+        # fan-in is K*Cin for a (k,k,k,Cin,Cout) weight
+        K = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
+        fan_in = K * self.in_channels
+        gain = math.sqrt(2.0 / (1 + 5.0))
+        bound = gain * math.sqrt(3.0 / fan_in)
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            if self.bias is not None:
+                b = 1 / math.sqrt(fan_in)
+                self.bias.uniform_(-b, b)
+
+    def extra_repr(self):
+        return ("{in_channels}, {out_channels}, kernel_size={kernel_size}, stride={stride}, "
+                "padding={padding}, subm={subm}, indice_key={indice_key}").format(**self.__dict__)
+
+    def _rules(self, x):
+        key = self.indice_key
+        if self.inverse:
+            rs = x.find_indice_pair(key)
+            if rs is None:
+                raise ValueError("SparseInverseConv3d needs the indice_key of a previous "
+                                 "SparseConv3d (got %r)" % (key,))
+            return rs
+        rs = x.find_indice_pair(key)
+        if rs is not None:
+            if rs.N_in != x.indices.shape[0]:
+                raise ValueError("indice_key %r was built for %d inputs, tensor has %d"
+                                 % (key, rs.N_in, x.indices.shape[0]))
+            return rs
+        if self.subm:
+            rs = build_subm_rules(x, self.kernel_size)
+        else:
+            rs = build_strided_rules(x, self.kernel_size, self.stride, self.padding, self.dilation)
+        if key is not None:
+            x.indice_dict[key] = rs
+        return rs
+
+    def forward(self, x):
+        assert isinstance(x, SparseConvTensor)
+        K = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
+        w = self.weight.reshape(K, self.in_channels, self.out_channels)
+        rs = self._rules(x)
+        feats = SparseConvFunction.apply(x.features, w, self.bias, rs, self.inverse)
+        if self.inverse:
+            out = SparseConvTensor(feats, rs.in_indices, rs.in_spatial_shape, x.batch_size,
+                                   x.grid, x.voxel_num, x.indice_dict, x.benchmark)
+            out._index = rs.in_index
+        else:
+            out = SparseConvTensor(feats, rs.out_indices, rs.out_spatial_shape, x.batch_size,
+                                   x.grid, x.voxel_num, x.indice_dict, x.benchmark)
+            out._index = rs.out_index
+        return out
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None, use_hash=False, algo=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation,
+                         groups, bias, True, indice_key=indice_key)
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None, use_hash=False, algo=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation,
+                         groups, bias, False, indice_key=indice_key)
+
+
+class SparseInverseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key=None, bias=True,
+                 algo=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, bias=bias, inverse=True,
+                         indice_key=indice_key)
+
+
+def is_spconv_module(m):
+    return isinstance(m, SparseModule)
+
+
+class SparseSequential(SparseModule):
+    """Sequential that applies dense nn.Modules (BatchNorm1d, ReLU, ...) to `.features`
+    (spconv_backbone.py:21-25)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for k, m in args[0].items():
+                self.add_module(k, m)
+        else:
+            for i, m in enumerate(args):
+                self.add_module(str(i), m)
+        for k, m in kwargs.items():
+            self.add_module(k, m)
+
+    def __getitem__(self, idx):
+        mods = list(self._modules.values())
+        return mods[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def add(self, module, name=None):
+        self.add_module(name if name is not None else str(len(self._modules)), module)
+
+    def forward(self, x):
+        for m in self._modules.values():
+            if is_spconv_module(m):
+                x = m(x)
+            elif isinstance(x, SparseConvTensor):
+                if x.indices.shape[0] != 0:
+                    x = x.replace_feature(m(x.features))
+            else:
+                x = m(x)
+        return x

@@ -1,0 +1,97 @@
+"""Device voxelizers (torch tensors in/out, all arithmetic in libglenet_hip.so).
+
+hard_voxelize      semantics of VoxelGeneratorWrapper.generate
+                   (pcdet/datasets/processor/data_processor.py:15-60, spconv generators)
+dynamic_voxelize_mean  semantics of DynamicMeanVFE.forward
+                   (pcdet/models/backbones_3d/vfe/dynamic_mean_vfe.py:37-76)
+mean_vfe           MeanVFE.forward (pcdet/models/backbones_3d/vfe/mean_vfe.py:14-31)
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, query, size_arg, workspace
+
+
+def grid_size_of(point_cloud_range, voxel_size):
+    """round((max - min) / voxel) as data_processor.py:119-120 does (numpy float64 of the
+    python lists)."""
+    r = np.asarray(point_cloud_range, dtype=np.float64)
+    v = np.asarray(voxel_size, dtype=np.float64)
+    return [int(g) for g in np.round((r[3:6] - r[0:3]) / v).astype(np.int64)]
+
+
+def _f32arr(vals):
+    a = np.asarray(vals, dtype=np.float32)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _split_batch(points, batch_idx, batch_size):
+    if batch_idx is None:
+        return None, 1 if batch_size is None else batch_size
+    bi = batch_idx.int().contiguous()
+    return bi, int(batch_size)
+
+
+def hard_voxelize(points, voxel_size, point_cloud_range, max_points, max_voxels, batch_idx=None,
+                  batch_size=None):
+    """points (P, C) float32 device tensor, xyz first; batch_idx (P,) frame ids (stacked frames,
+    non-decreasing) or None for one frame.
+
+    Returns voxels (Nv, max_points, C), coords (Nv, 4) int32 [b, z, y, x], num_points (Nv,) int32,
+    voxel_offset (B+1,) int32 (rows of frame b are voxel_offset[b]:voxel_offset[b+1]).
+    """
+    points = points.contiguous().float()
+    _lib.check_cuda(points)
+    dev = points.device
+    P, C = points.shape
+    bi, B = _split_batch(points, batch_idx, batch_size)
+    gx, gy, gz = grid_size_of(point_cloud_range, voxel_size)
+    rng, rng_p = _f32arr(point_cloud_range)
+    vs, vs_p = _f32arr(voxel_size)
+    cap = B * max_voxels
+    voxels = torch.empty((cap, max_points, C), dtype=torch.float32, device=dev)
+    coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    num = torch.empty((cap,), dtype=torch.int32, device=dev)
+    offs = torch.empty((B + 1,), dtype=torch.int32, device=dev)
+    wsb = query("glx_voxelize_hard_workspace_bytes", P, B, gx, gy, gz, max_points, max_voxels)
+    ws = workspace.get(wsb, dev)
+    call("glx_voxelize_hard", points, bi, P, C, B, rng_p, vs_p, gx, gy, gz, max_points, max_voxels,
+         voxels, coords, num, offs, ws, size_arg(ws.numel()))
+    offs_h = offs.tolist()  # host sync: voxel count sizes the outputs
+    nv = offs_h[-1]
+    return voxels[:nv], coords[:nv], num[:nv], offs
+
+
+def dynamic_voxelize_mean(points, voxel_size, point_cloud_range, batch_idx=None, batch_size=None):
+    """Returns features (Nv, C) = per-voxel mean of all point columns, coords (Nv,4) [b,z,y,x],
+    ordered by ascending key b*XYZ + x*YZ + y*Z + z (torch.unique order of the reference)."""
+    points = points.contiguous().float()
+    _lib.check_cuda(points)
+    dev = points.device
+    P, C = points.shape
+    bi, B = _split_batch(points, batch_idx, batch_size)
+    gx, gy, gz = grid_size_of(point_cloud_range, voxel_size)
+    rng, rng_p = _f32arr(point_cloud_range)
+    vs, vs_p = _f32arr(voxel_size)
+    feats = torch.empty((max(P, 1), C), dtype=torch.float32, device=dev)
+    coords = torch.empty((max(P, 1), 4), dtype=torch.int32, device=dev)
+    nv_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+    wsb = query("glx_voxelize_dynamic_workspace_bytes", P, B, gx, gy, gz)
+    ws = workspace.get(wsb, dev)
+    call("glx_voxelize_dynamic_mean", points, bi, P, C, B, rng_p, vs_p, gx, gy, gz, feats, coords,
+         nv_dev, ws, size_arg(ws.numel()))
+    nv = int(nv_dev.item())
+    return feats[:nv], coords[:nv]
+
+
+def mean_vfe(voxels, num_points):
+    voxels = voxels.contiguous().float()
+    num_points = num_points.int().contiguous()
+    _lib.check_cuda(voxels, num_points)
+    nv, mp, c = voxels.shape
+    out = torch.empty((nv, c), dtype=torch.float32, device=voxels.device)
+    call("glx_mean_vfe", voxels, num_points, nv, mp, c, out)
+    return out

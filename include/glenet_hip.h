@@ -1,0 +1,169 @@
+/*
+ * glenet_hip.h -- C ABI of libglenet_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for GLENet's data-parallel detection hot path:
+ * every entry point takes plain device pointers + sizes + an explicit HIP stream
+ * (passed as void*, NULL = default stream), never allocates, never synchronises
+ * the host unless its comment says so, and returns GLX_OK (0) or a negative GLX_E*
+ * code; glx_last_error() holds the message.  Temporary memory is caller-owned: each
+ * op that needs scratch has a *_workspace_bytes() query.
+ *
+ * Each declaration cites the reference interface (path:line under the GLENet tree)
+ * that it replaces.  "spconv" means the third-party traveller59/spconv package that
+ * the reference imports at pcdet/utils/spconv_utils.py:3-6 (not vendored, unpinned).
+ *
+ * Conventions
+ *   - all tensors row-major contiguous, float32 / int32 unless stated;
+ *   - sparse indices are (N,4) int32 [batch, z, y, x]  (spconv_backbone.py:141-146);
+ *   - boxes are (N,7) float32 [x, y, z, dx, dy, dz, heading] (iou3d_nms_kernel.cu:104);
+ *   - a "grid" is (B, D, H, W) = (batch, z, y, x) cell counts.
+ */
+#ifndef GLENET_HIP_H_
+#define GLENET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLX_OK 0
+#define GLX_EINVAL (-1)     /* bad argument (shape, alignment, unsupported channel count) */
+#define GLX_EHIP (-2)       /* HIP runtime / launch failure */
+#define GLX_EWORKSPACE (-3) /* workspace too small */
+
+/* Message of the last failing call on this host thread ("" if none). */
+const char* glx_last_error(void);
+/* Library ABI version (bumped on any signature change). */
+int glx_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Cell index ("rank dictionary"): one bit per grid cell + per-word exclusive popcount.
+ * rank(cell) = prefix[word] + popc(bits below) enumerates active cells in ascending
+ * linear order (b, z, y, x); it replaces spconv's hash table for rule generation and
+ * the dense (B,Z,Y,X) int32 voxel->point map of pcdet/utils/common_utils.py:226-243.
+ * ------------------------------------------------------------------------------------ */
+
+/* words = ceil(B*D*H*W / 64).  bitmap: words*8 bytes, prefix: words*4 bytes. */
+int64_t glx_index_words(int B, int D, int H, int W);
+size_t glx_index_workspace_bytes(int B, int D, int H, int W);
+
+/* Build the index of N active cells `indices` (N,4).  Outputs:
+ *   bitmap[words] u64, prefix[words] i32, rank_to_row[N] i32, row_to_rank[N] i32,
+ *   n_unique (device int32[1]): number of distinct cells (== N iff no duplicates),
+ *   status (device int32[1]): set non-zero if any index is outside the grid.
+ * Replaces: spconv indice hash build (call sites spconv_backbone.py:78-114). */
+int glx_index_build(const int32_t* indices, int N, int B, int D, int H, int W,
+                    uint64_t* bitmap, int32_t* prefix, int32_t* rank_to_row,
+                    int32_t* row_to_rank, int32_t* n_unique, int32_t* status,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Submanifold rule table: nbr[j*K + k] = input row at offset k of output row j, or -1.
+ * K = kd*kh*kw, k = (kz*kh + ky)*kw + kx, neighbour cell = cell(j) + (k - ksize/2).
+ * pair_count (device int32[1], accumulated: caller zeroes it) = number of valid pairs R.
+ * Replaces: spconv SubMConv3d indice-pair generation (spconv_backbone.py:12,78,85). */
+int glx_rules_subm(const int32_t* indices, int N, int B, int D, int H, int W,
+                   const uint64_t* bitmap, const int32_t* prefix, const int32_t* rank_to_row,
+                   int kd, int kh, int kw, int32_t* nbr, int32_t* pair_count, void* stream);
+
+/* Strided (regular) sparse conv output set: marks every output cell reached by >=1 active
+ * input in out_bitmap, scans it, writes n_out (device int32[1]).  Output rows are
+ * enumerated in ascending linear (b,z,y,x) order.  Out grid = (B, oD, oH, oW).
+ * Replaces: spconv SparseConv3d output index generation (spconv_backbone.py:14,90,97,104,113). */
+int glx_outset_build(const int32_t* indices_in, int N_in, int B, int D, int H, int W,
+                     int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
+                     int oD, int oH, int oW, uint64_t* out_bitmap, int32_t* out_prefix,
+                     int32_t* n_out, void* workspace, size_t workspace_bytes, void* stream);
+/* Decode the set bits of an index into (n,4) indices [b,z,y,x], ascending order. */
+int glx_outset_emit(const uint64_t* bitmap, const int32_t* prefix, int B, int D, int H, int W,
+                    int32_t* indices_out, void* stream);
+/* Rule table of the strided conv: nbr[j*K+k] = input row at cell(j)*stride - pad + k, or -1.
+ * in_rank_to_row may be NULL when input rows are already in ascending cell order. */
+int glx_rules_strided(const int32_t* indices_out, int N_out, int B, int D, int H, int W,
+                      const uint64_t* in_bitmap, const int32_t* in_prefix,
+                      const int32_t* in_rank_to_row, int kd, int kh, int kw, int sd, int sh,
+                      int sw, int pd, int ph, int pw, int32_t* nbr, int32_t* pair_count,
+                      void* stream);
+/* Input-major inverse: nbr_in[i*K+k] = output row j with nbr[j*K+k]==i, else -1. */
+int glx_rules_invert(const int32_t* nbr, int N_out, int K, int N_in, int32_t* nbr_in,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Sparse convolution  out[j,:] = sum_k in[nbr[j,k],:] @ W[k]   (+ bias)
+ * W is (K, Cin, Cout) float32, i.e. spconv-1.x layout (kd,kh,kw,Cin,Cout) flattened
+ * (pcdet/models/detectors/detector3d_template.py:377-384).  tile_order (optional, N_out)
+ * lists output rows in spatial order for gather locality; NULL = identity.
+ * Replaces: spconv SubMConv3d/SparseConv3d forward (spconv_backbone.py:148-156).
+ * The same entry point computes input gradients: pass grad_out as `in`, nbr_in as `nbr`
+ * and the transposed weights (glx_sconv_transpose_weights).
+ * ------------------------------------------------------------------------------------ */
+size_t glx_sconv_workspace_bytes(int K, int Cin, int Cout);
+int glx_sconv_forward(const float* in, int N_in, const float* W, const float* bias,
+                      const int32_t* nbr, const int32_t* tile_order, int N_out, int K, int Cin,
+                      int Cout, float* out, void* workspace, size_t workspace_bytes,
+                      void* stream);
+/* Reference-quality scalar kernel (any channel count); used for tiny Cin and as a
+ * device-side cross-check of the MFMA kernel. */
+int glx_sconv_forward_generic(const float* in, int N_in, const float* W, const float* bias,
+                              const int32_t* nbr, int N_out, int K, int Cin, int Cout,
+                              float* out, void* stream);
+/* Wt[k][co][ci] = W[k][ci][co]. */
+int glx_sconv_transpose_weights(const float* W, int K, int Cin, int Cout, float* Wt,
+                                void* stream);
+/* Weight gradient dW[k] = sum_j in[nbr[j,k],:]^T @ grad_out[j,:]   (K, Cin, Cout).
+ * Replaces: spconv backward wgrad (autograd of spconv_backbone.py convs). */
+size_t glx_sconv_wgrad_workspace_bytes(int N_out, int K, int Cin, int Cout);
+int glx_sconv_wgrad(const float* in, int N_in, const float* grad_out, const int32_t* nbr,
+                    int N_out, int K, int Cin, int Cout, float* dW, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* SparseConvTensor.dense(): out (B, C, D, H, W) must be zero-filled by the caller.
+ * Replaces: spconv dense() (height_compression.py:21). */
+int glx_dense_scatter(const float* features, const int32_t* indices, int N, int C, int B,
+                      int D, int H, int W, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Voxelization.
+ * ------------------------------------------------------------------------------------ */
+
+/* Hard voxelization of a stacked batch of point clouds, on device, with the exact
+ * first-seen ordering of the CPU generators the reference calls
+ * (pcdet/datasets/processor/data_processor.py:15-60 -> spconv.utils.VoxelGeneratorV2 /
+ * Point2VoxelCPU3d; third-party, restated in oracle/):
+ *   per point c = floor((p - range_min) / voxel_size) per axis (fp32), dropped when outside
+ *   [0, grid); a cell becomes voxel #v at its first point in input order, while fewer than
+ *   max_voxels voxels exist in that frame; each voxel keeps its first max_points points.
+ * points (P, C) fp32 with xyz in columns 0..2; point_batch (P) int32 frame id in [0,B) or
+ * NULL when B == 1; frames must be stacked contiguously (frame ids non-decreasing).
+ * vrange = {xmin,ymin,zmin,xmax,ymax,zmax}, vsize = {vx,vy,vz}; grid (gx,gy,gz) cells.
+ * Outputs (capacity B*max_voxels rows, rows of frame b start at voxel_offset[b]):
+ *   voxels (cap, max_points, C) zero padded, coords (cap, 4) int32 [b,z,y,x],
+ *   num_points (cap) int32, voxel_offset (B+1) int32 (device; [B] = total voxels). */
+size_t glx_voxelize_hard_workspace_bytes(int P, int B, int gx, int gy, int gz, int max_points,
+                                         int max_voxels);
+int glx_voxelize_hard(const float* points, const int32_t* point_batch, int P, int C, int B,
+                      const float* vrange, const float* vsize, int gx, int gy, int gz,
+                      int max_points, int max_voxels, float* voxels, int32_t* coords,
+                      int32_t* num_points, int32_t* voxel_offset, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* Dynamic voxelization + per-voxel mean, semantics of DynamicMeanVFE.forward
+ * (pcdet/models/backbones_3d/vfe/dynamic_mean_vfe.py:53-72): voxels enumerate in ascending
+ * key b*XYZ + x*YZ + y*Z + z; features = mean over ALL points of the cell (columns 0..C-1).
+ * Outputs capacity P rows: features (P, C), coords (P,4) [b,z,y,x], n_voxels device int32[1]. */
+size_t glx_voxelize_dynamic_workspace_bytes(int P, int B, int gx, int gy, int gz);
+int glx_voxelize_dynamic_mean(const float* points, const int32_t* point_batch, int P, int C,
+                              int B, const float* vrange, const float* vsize, int gx, int gy,
+                              int gz, float* features, int32_t* coords, int32_t* n_voxels,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
+/* MeanVFE.forward (pcdet/models/backbones_3d/vfe/mean_vfe.py:14-31):
+ * out[v,:] = sum_p voxels[v,p,:] / max(num_points[v], 1). */
+int glx_mean_vfe(const float* voxels, const int32_t* num_points, int Nv, int max_points, int C,
+                 float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLENET_HIP_H_ */

@@ -1,0 +1,442 @@
+"""CPU oracle of GLENet's detection hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package; glenet_amd/ never does (the product path has no CPU fallback).
+
+numpy in / numpy out.  Heavy loops live in glenet_oracle.c (built by oracle/build.py into
+oracle/_build/liboracle.so); small glue that the reference keeps in Python is restated
+here in numpy, each function citing the reference file:line it follows.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_lib = None
+_F = ctypes.POINTER(ctypes.c_float)
+_I = ctypes.POINTER(ctypes.c_int32)
+_L = ctypes.POINTER(ctypes.c_int64)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = _build.LIB
+        if not os.path.exists(path) or (
+                os.path.exists(_build.SRC) and os.path.getmtime(path) < os.path.getmtime(_build.SRC)):
+            _build.build()
+        _lib = ctypes.CDLL(path)
+    return _lib
+
+
+def _f(a):
+    return a.ctypes.data_as(_F)
+
+
+def _i(a):
+    return a.ctypes.data_as(_I)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _ints(v):
+    return (ctypes.c_int * len(v))(*[int(x) for x in v])
+
+
+def _floats(v):
+    return (ctypes.c_float * len(v))(*[float(x) for x in v])
+
+
+# ------------------------------------------------------------------------------ voxelization
+def grid_size_of(point_cloud_range, voxel_size):
+    """data_processor.py:119-120."""
+    r = np.asarray(point_cloud_range, dtype=np.float64)
+    v = np.asarray(voxel_size, dtype=np.float64)
+    return [int(g) for g in np.round((r[3:6] - r[0:3]) / v).astype(np.int64)]
+
+
+def voxelize_hard(points, voxel_size, point_cloud_range, max_points, max_voxels):
+    """One frame.  Returns voxels (Nv,max_points,C), coords (Nv,3) [z,y,x], num_points (Nv,)."""
+    points = _f32(points)
+    P, C = points.shape
+    grid = grid_size_of(point_cloud_range, voxel_size)
+    voxels = np.zeros((max_voxels, max_points, C), np.float32)
+    coords = np.zeros((max_voxels, 3), np.int32)
+    num = np.zeros((max_voxels,), np.int32)
+    nv = lib().orc_voxelize_hard(_f(points), P, C, _floats(point_cloud_range), _floats(voxel_size),
+                                 _ints(grid), max_points, max_voxels, _f(voxels), _i(coords), _i(num))
+    assert nv >= 0
+    return voxels[:nv].copy(), coords[:nv].copy(), num[:nv].copy()
+
+
+def voxelize_hard_batch(frames, voxel_size, point_cloud_range, max_points, max_voxels):
+    """Per-frame generator + collate_batch's batch-index padding (dataset.py:192-197)."""
+    vs, cs, ns = [], [], []
+    for b, pts in enumerate(frames):
+        v, c, n = voxelize_hard(pts, voxel_size, point_cloud_range, max_points, max_voxels)
+        vs.append(v)
+        cs.append(np.concatenate([np.full((len(c), 1), b, np.int32), c], axis=1))
+        ns.append(n)
+    return np.concatenate(vs), np.concatenate(cs), np.concatenate(ns)
+
+
+def mean_vfe(voxels, num_points):
+    voxels, num_points = _f32(voxels), _i32(num_points)
+    nv, mp, c = voxels.shape
+    out = np.zeros((nv, c), np.float32)
+    lib().orc_mean_vfe(_f(voxels), _i(num_points), nv, mp, c, _f(out))
+    return out
+
+
+def voxelize_dynamic_mean(points, batch_idx, voxel_size, point_cloud_range):
+    """DynamicMeanVFE.forward, dynamic_mean_vfe.py:53-72, in numpy (float32 arithmetic).
+    points (P,C) xyz first; returns features (Nv,C), coords (Nv,4) [b,z,y,x]."""
+    points = _f32(points)
+    rng = np.asarray(point_cloud_range, np.float32)
+    vsz = np.asarray(voxel_size, np.float32)
+    grid = np.asarray(grid_size_of(point_cloud_range, voxel_size), np.int64)
+    pc = np.floor((points[:, 0:3] - rng[0:3]) / vsz).astype(np.int32)           # :53
+    mask = ((pc >= 0) & (pc < grid)).all(axis=1)                                  # :54
+    points, pc = points[mask], pc[mask].astype(np.int64)
+    b = np.asarray(batch_idx)[mask].astype(np.int64)
+    sxyz, syz, sz = grid[0] * grid[1] * grid[2], grid[1] * grid[2], grid[2]
+    merge = b * sxyz + pc[:, 0] * syz + pc[:, 1] * sz + pc[:, 2]                # :57-60
+    unq, inv, cnt = np.unique(merge, return_inverse=True, return_counts=True)   # :63
+    sums = np.zeros((len(unq), points.shape[1]), np.float32)
+    np.add.at(sums, inv, points)                                                # scatter_mean :65
+    mean = sums / cnt[:, None].astype(np.float32)
+    coords = np.stack([unq // sxyz, (unq % sxyz) // syz, (unq % syz) // sz, unq % sz], 1)
+    coords = coords[:, [0, 3, 2, 1]].astype(np.int32)                           # :68-72
+    return mean.astype(np.float32), coords
+
+
+# ------------------------------------------------------------------------------ sparse conv
+def _triple(v):
+    return [int(x) for x in v] if isinstance(v, (list, tuple)) else [int(v)] * 3
+
+
+class Rules:
+    """Classic per-offset pair lists (what spconv calls indice pairs)."""
+
+    def __init__(self, pairs_in, pairs_out, n_pairs, out_indices, out_shape, n_in):
+        self.pairs_in, self.pairs_out, self.n_pairs = pairs_in, pairs_out, n_pairs
+        self.out_indices, self.out_shape, self.n_in = out_indices, out_shape, n_in
+
+    @property
+    def R(self):
+        return int(self.n_pairs.sum())
+
+    def nbr_table(self):
+        """(N_out, K) input row per (output row, offset), -1 where absent."""
+        K = len(self.n_pairs)
+        t = np.full((len(self.out_indices), K), -1, np.int32)
+        for k in range(K):
+            n = self.n_pairs[k]
+            t[self.pairs_out[k, :n], k] = self.pairs_in[k, :n]
+        return t
+
+
+def build_rules(indices, spatial_shape, ksize, stride=1, padding=0, subm=True):
+    indices = _i32(indices)
+    ksize, stride, padding = _triple(ksize), _triple(stride), _triple(padding)
+    K = ksize[0] * ksize[1] * ksize[2]
+    N_in = len(indices)
+    shape = [int(s) for s in spatial_shape]
+    if subm:
+        out_idx, oshape = indices, shape
+    else:
+        oshape = [(s + 2 * p - (k - 1) - 1) // st + 1
+                  for s, p, k, st in zip(shape, padding, ksize, stride)]
+        buf = np.zeros((max(N_in, 1) * K, 4), np.int32)
+        n_out = lib().orc_outset_strided(_i(indices), N_in, _ints(shape), _ints(ksize),
+                                         _ints(stride), _ints(padding), _ints(oshape), _i(buf))
+        out_idx = buf[:n_out].copy()
+    N_out = len(out_idx)
+    ld = max(N_in, N_out, 1)
+    pin = np.zeros((K, ld), np.int32)
+    pout = np.zeros((K, ld), np.int32)
+    npairs = np.zeros((K,), np.int32)
+    lib().orc_build_rules(_i(indices), N_in, _i(_i32(out_idx)), N_out, _ints(shape), _ints(ksize),
+                          _ints(stride), _ints(padding), 1 if subm else 0, _i(pin), _i(pout),
+                          _i(npairs))
+    return Rules(pin, pout, npairs, out_idx, oshape, N_in)
+
+
+def sconv_forward(features, weight, rules, bias=None):
+    """features (N_in,Cin), weight (K,Cin,Cout) -> (N_out,Cout)."""
+    features, weight = _f32(features), _f32(weight)
+    K, cin, cout = weight.shape
+    n_out = len(rules.out_indices)
+    out = np.zeros((n_out, cout), np.float32)
+    b = _f(_f32(bias)) if bias is not None else None
+    lib().orc_sconv_forward(_f(features), _f(weight), b, _i(rules.pairs_in), _i(rules.pairs_out),
+                            _i(rules.n_pairs), K, rules.pairs_in.shape[1], n_out, cin, cout, _f(out))
+    return out
+
+
+def sconv_backward(features, weight, grad_out, rules):
+    features, weight, grad_out = _f32(features), _f32(weight), _f32(grad_out)
+    K, cin, cout = weight.shape
+    din = np.zeros_like(features)
+    dw = np.zeros_like(weight)
+    lib().orc_sconv_backward(_f(features), _f(weight), _f(grad_out), _i(rules.pairs_in),
+                             _i(rules.pairs_out), _i(rules.n_pairs), K, rules.pairs_in.shape[1],
+                             len(features), cin, cout, _f(din), _f(dw))
+    return din, dw
+
+
+def dense(features, indices, batch_size, spatial_shape):
+    features, indices = _f32(features), _i32(indices)
+    n, c = features.shape
+    d, h, w = [int(s) for s in spatial_shape]
+    out = np.zeros((batch_size, c, d, h, w), np.float32)
+    lib().orc_dense(_f(features), _i(indices), n, c, batch_size, d, h, w, _f(out))
+    return out
+
+
+# ------------------------------------------------------------------------------ IoU / NMS
+def boxes_overlap_bev(a, b):
+    a, b = _f32(a), _f32(b)
+    out = np.zeros((len(a), len(b)), np.float32)
+    lib().orc_boxes_overlap_bev(_f(a), len(a), _f(b), len(b), _f(out))
+    return out
+
+
+def boxes_iou_bev(a, b):
+    """boxes_bev_iou_cpu, iou3d_nms_utils.py:52-68."""
+    a, b = _f32(a), _f32(b)
+    out = np.zeros((len(a), len(b)), np.float32)
+    lib().orc_boxes_iou_bev(_f(a), len(a), _f(b), len(b), _f(out))
+    return out
+
+
+def boxes_iou3d(a, b):
+    """boxes_iou3d_gpu glue, iou3d_nms_utils.py:88-121 (float32 like torch)."""
+    a, b = _f32(a), _f32(b)
+    a_max = (a[:, 2] + a[:, 5] / 2).reshape(-1, 1)
+    a_min = (a[:, 2] - a[:, 5] / 2).reshape(-1, 1)
+    b_max = (b[:, 2] + b[:, 5] / 2).reshape(1, -1)
+    b_min = (b[:, 2] - b[:, 5] / 2).reshape(1, -1)
+    ov_bev = boxes_overlap_bev(a, b)
+    ov_h = np.clip(np.minimum(a_max, b_max) - np.maximum(a_min, b_min), 0, None)
+    ov3d = ov_bev * ov_h
+    va = (a[:, 3] * a[:, 4] * a[:, 5]).reshape(-1, 1)
+    vb = (b[:, 3] * b[:, 4] * b[:, 5]).reshape(1, -1)
+    return (ov3d / np.clip(va + vb - ov3d, 1e-6, None)).astype(np.float32)
+
+
+def nms_sorted(boxes_sorted, thresh, normal=False):
+    """iou3d_nms_cuda.nms_gpu / nms_normal_gpu on boxes already sorted by score."""
+    boxes_sorted = _f32(boxes_sorted)
+    keep = np.zeros((max(len(boxes_sorted), 1),), np.int64)
+    n = lib().orc_nms(_f(boxes_sorted), len(boxes_sorted), ctypes.c_float(thresh),
+                      1 if normal else 0, keep.ctypes.data_as(_L))
+    return keep[:n].copy()
+
+
+def nms_gpu(boxes, scores, thresh, pre_maxsize=None, normal=False):
+    """nms_gpu / nms_normal_gpu wrappers, iou3d_nms_utils.py:182-197, 276-290.
+    torch.sort(descending) is not stable; callers must use distinct scores."""
+    order = np.argsort(-np.asarray(scores, np.float32), kind="stable")
+    if pre_maxsize is not None and not normal:
+        order = order[:pre_maxsize]
+    keep = nms_sorted(np.asarray(boxes)[order], thresh, normal)
+    return order[keep]
+
+
+def limit_period(val, offset=0.5, period=np.pi):
+    """common_utils.py:21-24 (float32)."""
+    val = np.asarray(val, np.float32)
+    return (val - np.floor(val / np.float32(period) + np.float32(offset)) * np.float32(period)).astype(np.float32)
+
+
+def nms_func(boxes, scores, iou_threshold, score_threshold=0, variance=None):
+    """GLENet variance-voting NMS, iou3d_nms_utils.py:227-273, restated line by line.
+    boxes (N,7) and scores (N,) are float32 copies; returns (scores, boxes)."""
+    boxes = np.array(boxes, np.float32, copy=True)
+    scores = np.array(scores, np.float32, copy=True)
+    undone = scores >= score_threshold                                        # :229
+    ious_all = boxes_iou_bev(boxes, boxes)                                    # :235
+    while undone.sum() > 0:                                                   # :237
+        idx = scores[undone].argmax()
+        idx = undone.nonzero()[0][idx]
+        top_box = boxes[idx:idx + 1]
+        _boxes = boxes[undone]
+        ious = ious_all[undone, idx]
+        if variance is not None:
+            _var = variance[undone, :7]
+            ioumask = ious > iou_threshold
+            klbox = _boxes[ioumask]
+            far = np.abs(klbox[:, 6] - top_box[:, 6]) >= np.pi * 3 / 2
+            if top_box[:, 6] > 0:                                             # :251-254
+                klbox[far, 6] += np.pi * 2
+            else:
+                klbox[far, 6] -= np.pi * 2
+            kliou = ious[ioumask]
+            klvar = _var[ioumask]
+            std_iou_sigma = 0.05
+            pi = (np.exp(-1 * (1 - kliou) ** 2 / std_iou_sigma)).reshape(-1, 1)
+            pi = pi / klvar
+            pi[np.abs(klbox[:, 6] - top_box[:, 6]) >= np.pi / 4, 6] = 0
+            pi = pi / pi.sum(0)
+            boxes[idx, :7] = (pi * klbox[:, :7]).sum(0)                       # :266
+        undone[idx] = False
+        scores[undone] *= (ious_all[undone, idx] < iou_threshold)             # :269
+        undone[scores < score_threshold] = False
+    return scores, boxes
+
+
+def new_nms_gpu(boxes, scores, iou_threshold, score_threshold=0, variance=None):
+    """iou3d_nms_utils.py:200-224."""
+    boxes = np.array(boxes, np.float32, copy=True)
+    boxes[:, 6] = limit_period(boxes[:, 6], offset=0.5, period=np.pi * 2)
+    new_scores, new_boxes = nms_func(boxes, scores, iou_threshold, score_threshold, variance)
+    keep = (new_scores > 0).nonzero()[0]
+    keep = keep[new_scores[keep].argsort()[::-1]]
+    return keep, new_boxes
+
+
+# ---- iou3d (older) library, [x1,y1,x2,y2,ry] boxes
+def iou3d_boxes_overlap_bev(a, b):
+    a, b = _f32(a), _f32(b)
+    out = np.zeros((len(a), len(b)), np.float32)
+    lib().orc_iou3d_boxes_overlap_bev(_f(a), len(a), _f(b), len(b), _f(out))
+    return out
+
+
+def iou3d_boxes_iou_bev(a, b):
+    a, b = _f32(a), _f32(b)
+    out = np.zeros((len(a), len(b)), np.float32)
+    lib().orc_iou3d_boxes_iou_bev(_f(a), len(a), _f(b), len(b), _f(out))
+    return out
+
+
+def iou3d_boxes_aligned_overlap_bev(a, b):
+    a, b = _f32(a), _f32(b)
+    out = np.zeros((len(a), 1), np.float32)
+    lib().orc_iou3d_boxes_aligned_overlap_bev(_f(a), _f(b), len(a), _f(out))
+    return out
+
+
+# ------------------------------------------------------------------------------ point ops
+def points_in_boxes_cpu(points, boxes):
+    """roiaware_pool3d_utils.points_in_boxes_cpu: (N boxes, P points) int32."""
+    points, boxes = _f32(points), _f32(boxes)
+    out = np.zeros((len(boxes), len(points)), np.int32)
+    lib().orc_points_in_boxes_cpu(_f(boxes), len(boxes), _f(points), len(points), _i(out))
+    return out
+
+
+def points_in_boxes_gpu(points, boxes):
+    """points (B,P,3), boxes (B,T,7) -> (B,P) first containing box or -1."""
+    points, boxes = _f32(points), _f32(boxes)
+    B, P, _ = points.shape
+    out = np.zeros((B, P), np.int32)
+    lib().orc_points_in_boxes_gpu(_f(boxes), B, boxes.shape[1], _f(points), P, _i(out))
+    return out
+
+
+def roiaware_pool3d_forward(rois, pts, feat, out_size, max_pts, method):
+    rois, pts, feat = _f32(rois), _f32(pts), _f32(feat)
+    ox, oy, oz = _triple(out_size)
+    N, C = len(rois), feat.shape[1]
+    pooled = np.zeros((N, ox, oy, oz, C), np.float32)
+    argmax = np.zeros((N, ox, oy, oz, C), np.int32)
+    pidx = np.zeros((N, ox, oy, oz, max_pts), np.int32)
+    lib().orc_roiaware_pool3d_forward(_f(rois), N, _f(pts), len(pts), _f(feat), C, ox, oy, oz,
+                                      max_pts, {"max": 0, "avg": 1}[method], _i(argmax), _i(pidx),
+                                      _f(pooled))
+    return pooled, argmax, pidx
+
+
+def roiaware_pool3d_backward(pidx, argmax, grad_out, num_pts, method):
+    pidx, argmax, grad_out = _i32(pidx), _i32(argmax), _f32(grad_out)
+    N, ox, oy, oz, C = grad_out.shape
+    gin = np.zeros((num_pts, C), np.float32)
+    lib().orc_roiaware_pool3d_backward(_i(pidx), _i(argmax), _f(grad_out), N, ox, oy, oz, C,
+                                       pidx.shape[-1], {"max": 0, "avg": 1}[method], _f(gin))
+    return gin
+
+
+def enlarge_box3d(boxes3d, extra_width=(0, 0, 0)):
+    """box_utils.enlarge_box3d, pcdet/utils/box_utils.py:127-139."""
+    b = np.array(boxes3d, np.float32, copy=True)
+    b[:, 3:6] += np.asarray(extra_width, np.float32)[None, :]
+    return b
+
+
+def roipoint_pool3d(points, feats, boxes3d, pool_extra_width, num_sampled):
+    """RoIPointPool3dFunction.forward, roipoint_pool3d_utils.py:31-60."""
+    points, feats, boxes3d = _f32(points), _f32(feats), _f32(boxes3d)
+    B, Np, _ = points.shape
+    M, C = boxes3d.shape[1], feats.shape[2]
+    ew = pool_extra_width if isinstance(pool_extra_width, (list, tuple)) else [pool_extra_width] * 3
+    big = enlarge_box3d(boxes3d.reshape(-1, 7), ew).reshape(B, M, 7)
+    pooled = np.zeros((B, M, num_sampled, 3 + C), np.float32)
+    empty = np.zeros((B, M), np.int32)
+    lib().orc_roipoint_pool3d(_f(points), _f(_f32(big)), _f(feats), B, Np, M, C, num_sampled,
+                              _f(pooled), _i(empty))
+    return pooled, empty
+
+
+def voxel_query(max_range, radius, nsample, xyz, new_xyz, new_coords, point_indices):
+    """VoxelQuery.forward, voxel_query_utils.py:13-43: returns (idx, empty_ball_mask)."""
+    xyz, new_xyz = _f32(xyz), _f32(new_xyz)
+    new_coords, point_indices = _i32(new_coords), _i32(point_indices)
+    M = len(new_coords)
+    B, Z, Y, X = point_indices.shape
+    idx = np.zeros((M, nsample), np.int32)
+    zr, yr, xr = max_range
+    lib().orc_voxel_query(M, Z, Y, X, nsample, ctypes.c_float(radius), zr, yr, xr, _f(new_xyz),
+                          _f(xyz), _i(new_coords), _i(point_indices), _i(idx))
+    empty = idx[:, 0] == -1
+    idx[empty] = 0
+    return idx, empty
+
+
+def ball_query(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt):
+    """BallQuery.forward, pointnet2_utils.py:11-43."""
+    xyz, new_xyz = _f32(xyz), _f32(new_xyz)
+    xbc, nbc = _i32(xyz_batch_cnt), _i32(new_xyz_batch_cnt)
+    M = len(new_xyz)
+    idx = np.zeros((M, nsample), np.int32)
+    lib().orc_ball_query(len(xbc), M, ctypes.c_float(radius), nsample, _f(new_xyz), _i(nbc),
+                         _f(xyz), _i(xbc), _i(idx))
+    empty = idx[:, 0] == -1
+    idx[empty] = 0
+    return idx, empty
+
+
+def group_points(features, features_batch_cnt, idx, idx_batch_cnt):
+    features, idx = _f32(features), _i32(idx)
+    fbc, ibc = _i32(features_batch_cnt), _i32(idx_batch_cnt)
+    M, ns = idx.shape
+    C = features.shape[1]
+    out = np.zeros((M, C, ns), np.float32)
+    lib().orc_group_points(len(ibc), M, C, ns, _f(features), _i(fbc), _i(idx), _i(ibc), _f(out))
+    return out
+
+
+def group_points_grad(grad_out, idx, idx_batch_cnt, features_batch_cnt, N):
+    grad_out, idx = _f32(grad_out), _i32(idx)
+    fbc, ibc = _i32(features_batch_cnt), _i32(idx_batch_cnt)
+    M, C, ns = grad_out.shape
+    g = np.zeros((N, C), np.float32)
+    lib().orc_group_points_grad(len(ibc), M, C, N, ns, _f(grad_out), _i(idx), _i(ibc), _i(fbc), _f(g))
+    return g
+
+
+def generate_voxel2pinds(indices, batch_size, spatial_shape):
+    """common_utils.generate_voxel2pinds, pcdet/utils/common_utils.py:226-243."""
+    indices = np.asarray(indices).astype(np.int64)
+    v2p = -np.ones((batch_size, *[int(s) for s in spatial_shape]), np.int32)
+    v2p[indices[:, 0], indices[:, 1], indices[:, 2], indices[:, 3]] = np.arange(len(indices), dtype=np.int32)
+    return v2p

@@ -1,0 +1,231 @@
+"""GPU parity: voxelization, rule tables and sparse convolution (HIP, through the C ABI)
+against the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from glenet_amd import synth
+from glenet_amd import voxelize as gv
+from glenet_amd.spconv import core as sp
+
+pytestmark = pytest.mark.gpu
+K = synth.KITTI
+
+
+def _rand_sparse(rng, B, D, H, W, density, cin):
+    occ = rng.random((B, D, H, W)) < density
+    idx = np.argwhere(occ).astype(np.int32)
+    idx = idx[rng.permutation(len(idx))]
+    f = rng.normal(size=(len(idx), cin)).astype(np.float32)
+    return idx, f
+
+
+# ------------------------------------------------------------------ voxelization
+@pytest.mark.parametrize("max_voxels,max_points", [(16000, 5), (3000, 5), (40000, 1), (500, 3)])
+def test_hard_voxelize_single_frame_bit_exact(dev, max_voxels, max_points):
+    pts, _ = synth.kitti_frame(0)
+    v, c, n = oracle.voxelize_hard(pts, K["voxel_size"], K["point_cloud_range"], max_points, max_voxels)
+    gv_, gc, gn, offs = gv.hard_voxelize(torch.from_numpy(pts).to(dev), K["voxel_size"],
+                                         K["point_cloud_range"], max_points, max_voxels)
+    assert gv_.shape[0] == len(v)
+    assert np.array_equal(gc.cpu().numpy()[:, 1:], c)          # first-seen order, [z,y,x]
+    assert (gc.cpu().numpy()[:, 0] == 0).all()
+    assert np.array_equal(gn.cpu().numpy(), n)
+    assert np.array_equal(gv_.cpu().numpy(), v)                 # bit-exact copies + zero padding
+    assert offs.tolist() == [0, len(v)]
+
+
+def test_hard_voxelize_batch_and_edges(dev):
+    frames = [synth.kitti_frame(i)[0] for i in range(3)]
+    frames[1] = frames[1][:7]                                   # ragged: tiny frame
+    frames.insert(2, np.zeros((0, 4), np.float32))              # empty frame in the middle
+    # points exactly on the range boundaries / outside
+    edge = np.array([[0.0, -40.0, -3.0, 1], [70.4, 0, 0, 1], [70.3999, 39.9999, 0.9999, 1],
+                     [-0.0001, 0, 0, 1], [10, 10, 1.0, 1], [np.float32(0.05) * 3, 0, 0, 1]], np.float32)
+    frames.append(edge)
+    v, c, n = oracle.voxelize_hard_batch(frames, K["voxel_size"], K["point_cloud_range"], 5, 2000)
+    pts = torch.from_numpy(np.concatenate(frames)).to(dev)
+    bidx = torch.from_numpy(np.concatenate([np.full(len(f), i, np.int32) for i, f in enumerate(frames)])).to(dev)
+    gv_, gc, gn, offs = gv.hard_voxelize(pts, K["voxel_size"], K["point_cloud_range"], 5, 2000,
+                                         batch_idx=bidx, batch_size=len(frames))
+    assert np.array_equal(gc.cpu().numpy(), c)
+    assert np.array_equal(gn.cpu().numpy(), n)
+    assert np.array_equal(gv_.cpu().numpy(), v)
+
+
+def test_hard_voxelize_permutation_property(dev):
+    """Size-independent property at full size: the voxel SET and per-voxel point counts
+    (capped) do not depend on point order when nothing is truncated."""
+    pts, _ = synth.kitti_frame(3)
+    p = torch.from_numpy(pts).to(dev)
+    a = gv.hard_voxelize(p, K["voxel_size"], K["point_cloud_range"], 64, 40000)
+    b = gv.hard_voxelize(p.flip(0).contiguous(), K["voxel_size"], K["point_cloud_range"], 64, 40000)
+
+    def key(c, n):
+        c = c.cpu().numpy().astype(np.int64)
+        lin = (c[:, 1] * 1600 + c[:, 2]) * 1408 + c[:, 3]
+        o = np.argsort(lin)
+        return lin[o], n.cpu().numpy()[o]
+    ka, kb = key(a[1], a[2]), key(b[1], b[2])
+    assert np.array_equal(ka[0], kb[0]) and np.array_equal(ka[1], kb[1])
+    assert int(a[2].sum()) == len(pts)      # every in-range point landed somewhere
+
+
+def test_dynamic_voxelize_mean(dev):
+    frames = [synth.kitti_frame(i)[0] for i in range(2)]
+    pts = np.concatenate(frames)
+    bidx = np.concatenate([np.full(len(f), i, np.int32) for i, f in enumerate(frames)])
+    f, c = oracle.voxelize_dynamic_mean(pts, bidx, K["voxel_size"], K["point_cloud_range"])
+    gf, gc = gv.dynamic_voxelize_mean(torch.from_numpy(pts).to(dev), K["voxel_size"],
+                                      K["point_cloud_range"], torch.from_numpy(bidx).to(dev), 2)
+    assert np.array_equal(gc.cpu().numpy(), c)                 # ascending-key order, bit exact
+    np.testing.assert_allclose(gf.cpu().numpy(), f, rtol=1e-5, atol=1e-5)
+
+
+def test_mean_vfe(dev):
+    pts, _ = synth.kitti_frame(1)
+    v, c, n = oracle.voxelize_hard(pts, K["voxel_size"], K["point_cloud_range"], 5, 16000)
+    out = gv.mean_vfe(torch.from_numpy(v).to(dev), torch.from_numpy(n).to(dev))
+    assert np.array_equal(out.cpu().numpy(), oracle.mean_vfe(v, n))
+
+
+# ------------------------------------------------------------------ rules
+def _gpu_tensor(idx, f, shape, B, dev):
+    return sp.SparseConvTensor(torch.from_numpy(f).to(dev), torch.from_numpy(idx).to(dev), shape, B)
+
+
+@pytest.mark.parametrize("shape,density", [((9, 14, 12), 0.15), ((5, 40, 33), 0.03), ((41, 64, 70), 0.01)])
+def test_subm_rules_bit_exact(dev, shape, density):
+    rng = np.random.default_rng(1)
+    idx, f = _rand_sparse(rng, 3, *shape, density, 4)
+    x = _gpu_tensor(idx, f, shape, 3, dev)
+    rs = sp.build_subm_rules(x, (3, 3, 3))
+    ref = oracle.build_rules(idx, shape, 3, subm=True)
+    assert np.array_equal(rs.nbr.cpu().numpy(), ref.nbr_table())
+    assert rs.pair_count == ref.R
+
+
+@pytest.mark.parametrize("ks,st,pd", [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1)),
+                                      ((3, 1, 1), (2, 1, 1), (0, 0, 0)), ((3, 3, 3), (1, 1, 1), (1, 1, 1))])
+def test_strided_rules_bit_exact(dev, ks, st, pd):
+    rng = np.random.default_rng(2)
+    shape = (11, 30, 27)
+    idx, f = _rand_sparse(rng, 2, *shape, 0.05, 4)
+    x = _gpu_tensor(idx, f, shape, 2, dev)
+    rs = sp.build_strided_rules(x, ks, st, pd)
+    ref = oracle.build_rules(idx, shape, ks, st, pd, subm=False)
+    assert rs.out_spatial_shape == ref.out_shape
+    assert np.array_equal(rs.out_indices.cpu().numpy(), ref.out_indices)   # ascending order
+    assert np.array_equal(rs.nbr.cpu().numpy(), ref.nbr_table())
+    assert rs.pair_count == ref.R
+    # inverse table round trip
+    inv = rs.inverse_table().cpu().numpy()
+    nbr = ref.nbr_table()
+    jj, kk = np.nonzero(nbr >= 0)
+    assert np.array_equal(inv[nbr[jj, kk], kk], jj)
+    assert (inv >= 0).sum() == ref.R
+
+
+def test_index_rejects_duplicates_and_out_of_range(dev):
+    idx = np.array([[0, 1, 1, 1], [0, 1, 1, 1]], np.int32)
+    x = _gpu_tensor(idx, np.zeros((2, 4), np.float32), (4, 4, 4), 1, dev)
+    with pytest.raises(ValueError):
+        x._ensure_index()
+    idx = np.array([[0, 1, 1, 4]], np.int32)
+    x = _gpu_tensor(idx, np.zeros((1, 4), np.float32), (4, 4, 4), 1, dev)
+    with pytest.raises(ValueError):
+        x._ensure_index()
+
+
+# ------------------------------------------------------------------ convolution
+CH = [(4, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (5, 16), (3, 7)]
+
+
+@pytest.mark.parametrize("cin,cout", CH)
+def test_subm_conv_forward(dev, cin, cout):
+    rng = np.random.default_rng(cin * 131 + cout)
+    shape = (9, 30, 28)
+    idx, f = _rand_sparse(rng, 2, *shape, 0.12, cin)
+    w = (rng.normal(size=(27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    ref = oracle.sconv_forward(f, w, oracle.build_rules(idx, shape, 3, subm=True))
+    conv = sp.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key="k").to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(w).reshape(3, 3, 3, cin, cout))
+        out = conv(_gpu_tensor(idx, f, shape, 2, dev))
+    # tolerance: fp32, <= 27*cin products per output, |values| ~ 1 -> 1e-4 absolute
+    np.testing.assert_allclose(out.features.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 32), (32, 64), (64, 64), (64, 128)])
+def test_strided_conv_forward_and_bias(dev, cin, cout):
+    rng = np.random.default_rng(7 + cin)
+    shape = (11, 30, 27)
+    idx, f = _rand_sparse(rng, 2, *shape, 0.06, cin)
+    for ks, st, pd in [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 1, 1), (2, 1, 1), (0, 0, 0))]:
+        kk = ks[0] * ks[1] * ks[2]
+        w = (rng.normal(size=(kk, cin, cout)) / np.sqrt(kk * cin)).astype(np.float32)
+        b = rng.normal(size=(cout,)).astype(np.float32)
+        rules = oracle.build_rules(idx, shape, ks, st, pd, subm=False)
+        ref = oracle.sconv_forward(f, w, rules, bias=b)
+        conv = sp.SparseConv3d(cin, cout, ks, stride=st, padding=pd, bias=True).to(dev)
+        with torch.no_grad():
+            conv.weight.copy_(torch.from_numpy(w).reshape(*ks, cin, cout))
+            conv.bias.copy_(torch.from_numpy(b))
+            out = conv(_gpu_tensor(idx, f, shape, 2, dev))
+        assert np.array_equal(out.indices.cpu().numpy(), rules.out_indices)
+        assert out.spatial_shape == rules.out_shape
+        np.testing.assert_allclose(out.features.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_mfma_kernel_matches_generic_kernel_on_device(dev):
+    """Device-side A/B: MFMA tile kernel vs the scalar kernel on identical inputs."""
+    from glenet_amd._lib import call
+    rng = np.random.default_rng(5)
+    shape = (21, 60, 50)
+    idx, f = _rand_sparse(rng, 2, *shape, 0.05, 64)
+    x = _gpu_tensor(idx, f, shape, 2, dev)
+    rs = sp.build_subm_rules(x, (3, 3, 3))
+    w = torch.from_numpy((rng.normal(size=(27, 64, 64)) / 40).astype(np.float32)).to(dev)
+    a = sp._sconv(x.features, w, None, rs.nbr, rs.tile_order_out, rs.N_out)
+    b = torch.empty_like(a)
+    call("glx_sconv_forward_generic", x.features, rs.N_in, w, None, rs.nbr, rs.N_out, 27, 64, 64, b)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("cin,cout,subm", [(16, 16, True), (32, 64, False), (64, 64, True), (4, 16, True)])
+def test_conv_backward(dev, cin, cout, subm):
+    rng = np.random.default_rng(11 + cin + cout)
+    shape = (9, 24, 20)
+    idx, f = _rand_sparse(rng, 2, *shape, 0.1, cin)
+    w = (rng.normal(size=(27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    if subm:
+        rules = oracle.build_rules(idx, shape, 3, subm=True)
+        conv = sp.SubMConv3d(cin, cout, 3, padding=1, bias=False).to(dev)
+    else:
+        rules = oracle.build_rules(idx, shape, 3, 2, 1, subm=False)
+        conv = sp.SparseConv3d(cin, cout, 3, stride=2, padding=1, bias=False).to(dev)
+    g = rng.normal(size=(len(rules.out_indices), cout)).astype(np.float32)
+    din, dw = oracle.sconv_backward(f, w, g, rules)
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(w).reshape(3, 3, 3, cin, cout))
+    x = _gpu_tensor(idx, f, shape, 2, dev)
+    x.features.requires_grad_(True)
+    out = conv(x)
+    out.features.backward(torch.from_numpy(g).to(dev))
+    np.testing.assert_allclose(x.features.grad.cpu().numpy(), din, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(conv.weight.grad.reshape(27, cin, cout).cpu().numpy(), dw, rtol=1e-3, atol=2e-3)
+
+
+def test_dense_and_empty(dev):
+    rng = np.random.default_rng(3)
+    shape = (2, 20, 18)
+    idx, f = _rand_sparse(rng, 3, *shape, 0.2, 8)
+    x = _gpu_tensor(idx, f, shape, 3, dev)
+    assert np.array_equal(x.dense().cpu().numpy(), oracle.dense(f, idx, 3, shape))
+    # empty input set flows through a conv stack without error
+    e = _gpu_tensor(np.zeros((0, 4), np.int32), np.zeros((0, 16), np.float32), (9, 16, 16), 1, dev)
+    c1 = sp.SubMConv3d(16, 16, 3, padding=1, bias=False).to(dev)
+    c2 = sp.SparseConv3d(16, 32, 3, stride=2, padding=1, bias=False).to(dev)
+    y = c2(c1(e))
+    assert y.features.shape == (0, 32) and y.indices.shape == (0, 4)
