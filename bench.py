@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the hot path (contract: see task brief / DESIGN.md).
+
+Workload at N=1 = BASELINE.json configs[1]: GLENet-VR SECOND sparse backbone
+(VoxelBackBone8x as written in the reference: 8 SubMConv3d + 4 SparseConv3d), forward only,
+batch 4 synthetic KITTI-shaped frames per GPU.  One step = one pass of the hot path over one
+batch whose points are already resident in HBM:
+    hard voxelize (4 frames) -> MeanVFE -> 12 sparse convs (+BN/ReLU) -> dense()/BEV fold.
+N > 1: one process per GPU (torch.distributed, RCCL), every rank runs its own 4 frames
+(weak scaling, frames shard with no data-path collective in a forward pass); the timed
+region is bracketed by barrier + synchronize and the max over ranks is reported.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import contextlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from glenet_amd import backbone as gb  # noqa: E402
+from glenet_amd import synth  # noqa: E402
+from glenet_amd.spconv import core as spcore  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FRAMES_PER_GPU = 4
+
+
+def kernel_name(cin, cout, K):
+    ok = {16, 32, 64, 128}
+    if cin in ok and cout in ok and K <= 27:
+        return "k_sconv_mfma<%d,%d>" % (cin, cout)
+    return "k_sconv_generic"
+
+
+def alg_bytes(R, K, cin, cout):
+    """gather read Cin, scatter read-modify-write 2*Cout, two int32
+    indices per rule, weights once."""
+    return R * (cin + 2 * cout) * 4 + R * 8 + K * cin * cout * 4
+
+
+class ConvProfiler:
+    """Times every sparse-conv launch with HIP events on the launch stream."""
+
+    def __init__(self):
+        self.records = []      # (name, start_evt, end_evt, rules, K, cin, cout)
+        self.enabled = False
+
+    @contextlib.contextmanager
+    def __call__(self, tag, K, cin, cout, n_out, rules):
+        if not self.enabled:
+            yield
+            return
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()            # torch's current stream == the stream the kernel is launched on
+        yield
+        e.record()
+        self.records.append((kernel_name(cin, cout, K), s, e, rules, K, cin, cout))
+
+    def summary(self):
+        per = {}
+        for name, s, e, rules, K, cin, cout in self.records:
+            d = per.setdefault(name, dict(ms=0.0, launches=0, bytes=0))
+            d["ms"] += s.elapsed_time(e)
+            d["launches"] += 1
+            d["bytes"] += alg_bytes(rules.pair_count, K, cin, cout)
+        return per
+
+
+def load_traffic():
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), if any."""
+    p = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(p):
+        with open(p) as f:
+            return json.load(f)
+    return {}
+
+
+def cpu_baseline(frames_np, model):
+    """The CPU oracle (oracle/, a scalar C port) over the same workload: one batch."""
+    import oracle
+    from oracle import backbone as ob
+    K = synth.KITTI
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    t0 = time.perf_counter()
+    v, c, n = oracle.voxelize_hard_batch(frames_np, K["voxel_size"], K["point_cloud_range"],
+                                         K["max_points"], K["max_voxels_train"])
+    f = oracle.mean_vfe(v, n)
+    taps = ob.backbone_forward(sd, f, c, model.sparse_shape)
+    o = taps["out"]
+    oracle.dense(o.features, o.indices, len(frames_np), o.shape)
+    dt = time.perf_counter() - t0
+    return dict(value=len(frames_np) / dt, unit="frames/s", cores=1, kind="port",
+                sample="1 batch of %d synthetic KITTI-shaped frames (the same workload), one pass, "
+                       "%.1f s on %d host cores available" % (len(frames_np), dt, os.cpu_count()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    K = synth.KITTI
+    frames_np = [synth.kitti_frame(rank * FRAMES_PER_GPU + i)[0] for i in range(FRAMES_PER_GPU)]
+    pts = torch.from_numpy(np.concatenate(frames_np)).to(dev)
+    bidx = torch.from_numpy(np.concatenate(
+        [np.full(len(f), i, np.int32) for i, f in enumerate(frames_np)])).to(dev)
+
+    torch.manual_seed(0)
+    grid = gb.gv.grid_size_of(K["point_cloud_range"], K["voxel_size"])
+    model = gb.VoxelBackBone8x(K["num_features"], grid).to(dev).eval()
+    vfe, hc = gb.MeanVFE(), gb.HeightCompression()
+
+    def step():
+        with torch.no_grad():
+            bd = gb.voxelize_batch(pts, bidx, FRAMES_PER_GPU, K, train=True)
+            bd = vfe(bd)
+            bd = model(bd)
+            bd = hc(bd)
+        return bd
+
+    for _ in range(args.warmup):
+        step()
+    prof = ConvProfiler()
+    spcore._profile_hook = prof
+    prof.enabled = True
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bd = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    frames_total = FRAMES_PER_GPU * world * args.steps
+    per = prof.summary()
+    # dominant kernel = the sparse-conv instantiation with the most device time
+    dom = max(per, key=lambda k: per[k]["ms"]) if per else None
+    traffic = load_traffic()
+    roof = None
+    if dom:
+        d = per[dom]
+        achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        roof = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                    traffic=traffic.get(dom),
+                    alg_bytes_per_launch=int(d["bytes"] / d["launches"]),
+                    avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2),
+                    launches=d["launches"])
+        tot_b = sum(v["bytes"] for v in per.values())
+        tot_ms = sum(v["ms"] for v in per.values())
+        roof["all_sparse_conv"] = dict(
+            achieved=round(tot_b / (tot_ms * 1e-3) / 1e9, 1),
+            frac=round(tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            ms_per_step=round(tot_ms / args.steps, 4),
+            per_kernel={k: dict(GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                us_per_launch=round(v["ms"] * 1e3 / v["launches"], 2),
+                                launches_per_step=v["launches"] // args.steps)
+                        for k, v in sorted(per.items())})
+
+    out = None
+    if rank == 0:
+        st = bd["encoded_spconv_tensor"]
+        out = dict(metric="LiDAR frames/sec (sparse backbone fwd) on KITTI-shaped clouds",
+                   value=round(frames_total / dt, 2), unit="frames/s", n_gpus=world,
+                   steps=args.steps, warmup=args.warmup,
+                   ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True,
+                   scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload="configs[1]: VoxelBackBone8x (8 SubMConv3d + 4 SparseConv3d "
+                                        "as in spconv_backbone.py:77-117) fwd-only, batch 4 "
+                                        "KITTI-shaped frames/GPU, 20000 pts/frame, voxel "
+                                        "0.05x0.05x0.1 m; step = voxelize + MeanVFE + backbone + dense()",
+                               frames_per_gpu=FRAMES_PER_GPU, points_per_frame=20000,
+                               voxels_in=int(bd["voxel_coords"].shape[0]),
+                               voxels_out=int(st.indices.shape[0]),
+                               parallelism="dp%d (frames shard, no data-path collective)" % world),
+                   roofline=roof)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames_np, model)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

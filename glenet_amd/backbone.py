@@ -1,0 +1,143 @@
+"""Sparse 3-D backbones of the hot path, built on glenet_amd.spconv.
+
+Our counterpart of the callers in pcdet/models/backbones_3d/spconv_backbone.py: the same
+layer lists, channels, strides, paddings and indice_key sharing (VoxelBackBone8x :77-117,
+VoxelResBackBone8x :191-232; BatchNorm1d eps=1e-3 momentum=0.01 :73), written table-driven.
+The reference modules themselves also run unmodified on glenet_amd.spconv through
+glenet_amd.dropin; this module is what bench.py and the tests drive.
+"""
+from functools import partial
+
+import torch
+from torch import nn
+
+from . import spconv
+from . import voxelize as gv
+
+_norm = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+
+
+def _conv_bn_relu(cin, cout, ksize, key, kind="subm", stride=1, padding=0):
+    if kind == "subm":
+        conv = spconv.SubMConv3d(cin, cout, ksize, padding=padding, bias=False, indice_key=key)
+    else:
+        conv = spconv.SparseConv3d(cin, cout, ksize, stride=stride, padding=padding, bias=False,
+                                   indice_key=key)
+    return spconv.SparseSequential(conv, _norm(cout), nn.ReLU())
+
+
+class ResidualBlock(spconv.SparseModule):
+    """SparseBasicBlock (spconv_backbone.py:30-64): two biased SubM convs + identity."""
+
+    def __init__(self, channels, key):
+        super().__init__()
+        self.conv1 = spconv.SubMConv3d(channels, channels, 3, padding=1, bias=True, indice_key=key)
+        self.bn1 = _norm(channels)
+        self.conv2 = spconv.SubMConv3d(channels, channels, 3, padding=1, bias=True, indice_key=key)
+        self.bn2 = _norm(channels)
+        self.relu = nn.ReLU()
+
+    def forward(self, x):
+        out = self.conv1(x)
+        out = out.replace_feature(self.relu(self.bn1(out.features)))
+        out = self.conv2(out)
+        out = out.replace_feature(self.bn2(out.features))
+        return out.replace_feature(self.relu(out.features + x.features))
+
+
+# stage tables: (cin, cout, padding of the stride-2 conv)
+_PLAIN = dict(stem=16, stages=[(16, 32, 1), (32, 64, 1), (64, 64, (0, 1, 1))], out_in=64)
+_RES = dict(stem=16, stages=[(16, 32, 1), (32, 64, 1), (64, 128, (0, 1, 1))], out_in=128)
+
+
+class SparseBackbone8x(nn.Module):
+    """residual=False -> VoxelBackBone8x (12 sparse convs, 8 rule tables);
+    residual=True  -> VoxelResBackBone8x (17 SubM + 4 strided + conv_input, 9 rule tables)."""
+
+    def __init__(self, input_channels, grid_size, residual=False, last_pad=0):
+        super().__init__()
+        cfg = _RES if residual else _PLAIN
+        gx, gy, gz = [int(g) for g in grid_size]
+        self.sparse_shape = [gz + 1, gy, gx]                       # spconv_backbone.py:75
+        self.residual = residual
+        self.conv_input = _conv_bn_relu(input_channels, cfg["stem"], 3, "subm1", padding=1)
+
+        def body(c, key):
+            if residual:
+                return [ResidualBlock(c, key), ResidualBlock(c, key)]
+            return [_conv_bn_relu(c, c, 3, key, padding=1)]
+
+        if residual:
+            self.conv1 = spconv.SparseSequential(*body(16, "res1"))
+        else:
+            self.conv1 = spconv.SparseSequential(*body(16, "subm1"))
+        stages = []
+        for i, (cin, cout, pad) in enumerate(cfg["stages"], start=2):
+            down = _conv_bn_relu(cin, cout, 3, "spconv%d" % i, kind="spconv", stride=2, padding=pad)
+            if residual:
+                rest = body(cout, "res%d" % i)
+            else:
+                rest = [_conv_bn_relu(cout, cout, 3, "subm%d" % i, padding=1),
+                        _conv_bn_relu(cout, cout, 3, "subm%d" % i, padding=1)]
+            stages.append(spconv.SparseSequential(down, *rest))
+        self.conv2, self.conv3, self.conv4 = stages
+        self.conv_out = _conv_bn_relu(cfg["out_in"], 128, (3, 1, 1), "spconv_down2", kind="spconv",
+                                      stride=(2, 1, 1), padding=last_pad)
+        self.num_point_features = 128
+        self.backbone_channels = {"x_conv1": 16, "x_conv2": 32, "x_conv3": 64,
+                                  "x_conv4": cfg["stages"][-1][1]}
+
+    def forward(self, batch_dict):
+        x = spconv.SparseConvTensor(batch_dict["voxel_features"], batch_dict["voxel_coords"].int(),
+                                    self.sparse_shape, batch_dict["batch_size"])
+        x = self.conv_input(x)
+        c1 = self.conv1(x)
+        c2 = self.conv2(c1)
+        c3 = self.conv3(c2)
+        c4 = self.conv4(c3)
+        out = self.conv_out(c4)
+        batch_dict.update(encoded_spconv_tensor=out, encoded_spconv_tensor_stride=8,
+                          multi_scale_3d_features=dict(x_conv1=c1, x_conv2=c2, x_conv3=c3, x_conv4=c4),
+                          multi_scale_3d_strides=dict(x_conv1=1, x_conv2=2, x_conv3=4, x_conv4=8))
+        return batch_dict
+
+    def sparse_convs(self):
+        return [m for m in self.modules() if isinstance(m, spconv.SparseConvolution)]
+
+
+def VoxelBackBone8x(input_channels, grid_size, **kw):
+    return SparseBackbone8x(input_channels, grid_size, residual=False, **kw)
+
+
+def VoxelResBackBone8x(input_channels, grid_size, **kw):
+    return SparseBackbone8x(input_channels, grid_size, residual=True, **kw)
+
+
+class MeanVFE(nn.Module):
+    """mean_vfe.py:14-31 on device."""
+
+    def forward(self, batch_dict):
+        batch_dict["voxel_features"] = gv.mean_vfe(batch_dict["voxels"], batch_dict["voxel_num_points"])
+        return batch_dict
+
+
+class HeightCompression(nn.Module):
+    """height_compression.py:10-26: dense() then fold depth into channels."""
+
+    def forward(self, batch_dict):
+        dense = batch_dict["encoded_spconv_tensor"].dense()
+        n, c, d, h, w = dense.shape
+        batch_dict["spatial_features"] = dense.view(n, c * d, h, w)
+        batch_dict["spatial_features_stride"] = batch_dict["encoded_spconv_tensor_stride"]
+        return batch_dict
+
+
+def voxelize_batch(points_list_or_stacked, batch_idx, batch_size, cfg, train=True):
+    """Device-side replacement of DataProcessor.transform_points_to_voxels + collate_batch
+    (data_processor.py:117-152, dataset.py:192-197): stacked points -> batch_dict entries."""
+    max_voxels = cfg["max_voxels_train"] if train else cfg["max_voxels_test"]
+    v, c, n, offs = gv.hard_voxelize(points_list_or_stacked, cfg["voxel_size"],
+                                     cfg["point_cloud_range"], cfg["max_points"], max_voxels,
+                                     batch_idx=batch_idx, batch_size=batch_size)
+    return dict(voxels=v, voxel_coords=c, voxel_num_points=n, batch_size=batch_size,
+                voxel_offset=offs)

@@ -136,8 +136,8 @@ extern "C" int glx_rules_subm(const int32_t* indices, int N, int B, int D, int H
                               int32_t* pair_count, void* stream) {
   GLX_REQUIRE(kd > 0 && kh > 0 && kw > 0 && (kd & 1) && (kh & 1) && (kw & 1),
               "glx_rules_subm: kernel size must be odd, got (%d,%d,%d)", kd, kh, kw);
-  GLX_REQUIRE(indices && bitmap && prefix && nbr && pair_count, "glx_rules_subm: null pointer");
   if (N == 0) return GLX_OK;
+  GLX_REQUIRE(indices && bitmap && prefix && nbr && pair_count, "glx_rules_subm: null pointer");
   GlxGrid g{B, D, H, W};
   long long total = (long long)N * kd * kh;
   hipLaunchKernelGGL(k_rules_subm, dim3(glx_divup(total, 256)), dim3(256), 0,
@@ -271,9 +271,9 @@ extern "C" int glx_rules_strided(const int32_t* indices_out, int N_out, int B, i
                                  const int32_t* in_rank_to_row, int kd, int kh, int kw, int sd,
                                  int sh, int sw, int pd, int ph, int pw, int32_t* nbr,
                                  int32_t* pair_count, void* stream) {
+  if (N_out == 0) return GLX_OK;
   GLX_REQUIRE(indices_out && in_bitmap && in_prefix && nbr && pair_count,
               "glx_rules_strided: null pointer");
-  if (N_out == 0) return GLX_OK;
   GlxGrid ig{B, D, H, W};
   ConvGeom cg{kd, kh, kw, sd, sh, sw, pd, ph, pw};
   long long total = (long long)N_out * kd * kh;
@@ -298,9 +298,9 @@ __global__ void k_rules_invert(const int* __restrict__ nbr, long long total, int
 
 extern "C" int glx_rules_invert(const int32_t* nbr, int N_out, int K, int N_in, int32_t* nbr_in,
                                 void* stream) {
-  GLX_REQUIRE(nbr && nbr_in && K > 0, "glx_rules_invert: bad arguments");
+  GLX_REQUIRE(K > 0, "glx_rules_invert: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  GLX_HIP(hipMemsetAsync(nbr_in, 0xFF, (size_t)N_in * K * sizeof(int), st));
+  if (N_in > 0) GLX_HIP(hipMemsetAsync(nbr_in, 0xFF, (size_t)N_in * K * sizeof(int), st));
   long long total = (long long)N_out * K;
   if (total > 0) {
     hipLaunchKernelGGL(k_rules_invert, dim3(glx_divup(total, 256)), dim3(256), 0, st, nbr, total,

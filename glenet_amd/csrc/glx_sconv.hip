@@ -246,9 +246,9 @@ extern "C" int glx_sconv_forward_generic(const float* in, int N_in, const float*
                                          const float* bias, const int32_t* nbr, int N_out, int K,
                                          int Cin, int Cout, float* out, void* stream) {
   (void)N_in;
+  if (N_out == 0) return GLX_OK;
   GLX_REQUIRE(in && W && nbr && out && K > 0 && Cin > 0 && Cout > 0,
               "glx_sconv_forward_generic: bad arguments");
-  if (N_out == 0) return GLX_OK;
   long long total = (long long)N_out * Cout;
   hipLaunchKernelGGL(k_sconv_generic, dim3(glx_divup(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, in, W, bias, nbr, N_out, K, Cin, Cout, out);
@@ -298,15 +298,22 @@ extern "C" size_t glx_sconv_workspace_bytes(int K, int Cin, int Cout) {
 #define SC_TILE_LDS ((SC_ROWS_PER_BLOCK * (SC_MAXK + 1) + SC_ROWS_PER_BLOCK + 4) * sizeof(int))
 
 template <int CI, int CO>
-static int launch_mfma(const float* in, const float* W, const float* bias, const int32_t* nbr,
-                       const int32_t* tile_order, int N_out, int K, float* out, float* Wp,
-                       hipStream_t st) {
+static int pack_weights(const float* W, int K, float* Wp, hipStream_t st) {
   using C = SconvCfg<CI, CO>;
   size_t pbytes = (size_t)K * C::IMG * sizeof(float);
   if (C::QPAD) GLX_HIP(hipMemsetAsync(Wp, 0, pbytes, st));
   int nel = K * CI * CO;
   hipLaunchKernelGGL((k_pack_weights<CI, CO>), dim3(glx_divup(nel, 256)), dim3(256), 0, st, W, K,
                      Wp);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+template <int CI, int CO>
+static int launch_mfma(const float* in, const float* Wp, const float* bias, const int32_t* nbr,
+                       const int32_t* tile_order, int N_out, int K, float* out, hipStream_t st) {
+  using C = SconvCfg<CI, CO>;
+  size_t pbytes = (size_t)K * C::IMG * sizeof(float);
   int ntiles = glx_divup(N_out, SC_ROWS_PER_BLOCK);
   bool resident = pbytes <= SC_RESIDENT_LIMIT;
   size_t lds = (resident ? pbytes : 2 * (size_t)C::IMG * sizeof(float)) + SC_TILE_LDS;
@@ -315,37 +322,60 @@ static int launch_mfma(const float* in, const float* W, const float* bias, const
     auto kern = k_sconv_mfma<CI, CO, true>;
     GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(SC_THREADS), lds, st, in, (const float*)Wp, bias,
-                       nbr, tile_order, N_out, K, out);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SC_THREADS), lds, st, in, Wp, bias, nbr, tile_order,
+                       N_out, K, out);
   } else {
     auto kern = k_sconv_mfma<CI, CO, false>;
     GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
-    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(SC_THREADS), lds, st, in, (const float*)Wp, bias,
-                       nbr, tile_order, N_out, K, out);
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(SC_THREADS), lds, st, in, Wp, bias, nbr,
+                       tile_order, N_out, K, out);
   }
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
 
-extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, const float* bias,
-                                 const int32_t* nbr, const int32_t* tile_order, int N_out, int K,
-                                 int Cin, int Cout, float* out, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
-  GLX_REQUIRE(in && W && nbr && out, "glx_sconv_forward: null pointer");
-  GLX_REQUIRE(K > 0 && Cin > 0 && Cout > 0 && N_out >= 0, "glx_sconv_forward: bad sizes");
-  if (N_out == 0) return GLX_OK;
-  if (!mfma_supported(Cin, Cout, K))
-    return glx_sconv_forward_generic(in, N_in, W, bias, nbr, N_out, K, Cin, Cout, out, stream);
-  size_t need = packed_bytes(K, Cin, Cout);
-  if (!workspace || workspace_bytes < need) {
-    glx_set_error("glx_sconv_forward: workspace %zu < %zu bytes", workspace_bytes, need);
-    return GLX_EWORKSPACE;
-  }
+extern "C" size_t glx_sconv_packed_bytes(int K, int Cin, int Cout) {
+  if (!mfma_supported(Cin, Cout, K)) return 0;
+  return packed_bytes(K, Cin, Cout);
+}
+
+extern "C" int glx_sconv_pack_weights(const float* W, int K, int Cin, int Cout, float* Wp,
+                                      void* stream) {
+  GLX_REQUIRE(W && Wp, "glx_sconv_pack_weights: null pointer");
+  GLX_REQUIRE(mfma_supported(Cin, Cout, K),
+              "glx_sconv_pack_weights: no MFMA kernel for (K=%d, Cin=%d, Cout=%d)", K, Cin, Cout);
   hipStream_t st = (hipStream_t)stream;
   return sc_dispatch(Cin, Cout, [&](auto ci, auto co) {
-    return launch_mfma<decltype(ci)::value, decltype(co)::value>(
-        in, W, bias, nbr, tile_order, N_out, K, out, (float*)workspace, st);
+    return pack_weights<decltype(ci)::value, decltype(co)::value>(W, K, Wp, st);
+  });
+}
+
+extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, const float* Wp,
+                                 const float* bias, const int32_t* nbr, const int32_t* tile_order,
+                                 int N_out, int K, int Cin, int Cout, float* out, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(K > 0 && Cin > 0 && Cout > 0 && N_out >= 0, "glx_sconv_forward: bad sizes");
+  if (N_out == 0) return GLX_OK;
+  GLX_REQUIRE(in && (W || Wp) && nbr && out, "glx_sconv_forward: null pointer");
+  if (!mfma_supported(Cin, Cout, K)) {
+    GLX_REQUIRE(W, "glx_sconv_forward: raw weights required for channels (%d,%d)", Cin, Cout);
+    return glx_sconv_forward_generic(in, N_in, W, bias, nbr, N_out, K, Cin, Cout, out, stream);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (!Wp) {  // pack on the fly into the caller's workspace
+    size_t need = packed_bytes(K, Cin, Cout);
+    if (!workspace || workspace_bytes < need) {
+      glx_set_error("glx_sconv_forward: workspace %zu < %zu bytes", workspace_bytes, need);
+      return GLX_EWORKSPACE;
+    }
+    int rc = glx_sconv_pack_weights(W, K, Cin, Cout, (float*)workspace, stream);
+    if (rc != GLX_OK) return rc;
+    Wp = (const float*)workspace;
+  }
+  return sc_dispatch(Cin, Cout, [&](auto ci, auto co) {
+    return launch_mfma<decltype(ci)::value, decltype(co)::value>(in, Wp, bias, nbr, tile_order,
+                                                                 N_out, K, out, st);
   });
 }
 
@@ -432,7 +462,7 @@ extern "C" int glx_sconv_wgrad(const float* in, int N_in, const float* grad_out,
                                const int32_t* nbr, int N_out, int K, int Cin, int Cout, float* dW,
                                void* workspace, size_t workspace_bytes, void* stream) {
   (void)N_in;
-  GLX_REQUIRE(in && grad_out && nbr && dW, "glx_sconv_wgrad: null pointer");
+  GLX_REQUIRE(dW && (N_out == 0 || (in && grad_out && nbr)), "glx_sconv_wgrad: null pointer");
   GLX_REQUIRE(Cin * Cout <= 64 * WG_THREADS, "glx_sconv_wgrad: Cin*Cout=%d too large", Cin * Cout);
   hipStream_t st = (hipStream_t)stream;
   long long nel_total = (long long)K * Cin * Cout;
@@ -470,8 +500,8 @@ __global__ void k_dense_scatter(const float* __restrict__ f, const int4* __restr
 extern "C" int glx_dense_scatter(const float* features, const int32_t* indices, int N, int C,
                                  int B, int D, int H, int W, float* out, void* stream) {
   (void)B;
-  GLX_REQUIRE(features && indices && out && C > 0, "glx_dense_scatter: bad arguments");
   if (N == 0) return GLX_OK;
+  GLX_REQUIRE(features && indices && out && C > 0, "glx_dense_scatter: bad arguments");
   long long total = (long long)N * C;
   hipLaunchKernelGGL(k_dense_scatter, dim3(glx_divup(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, features, (const int4*)indices, N, C, D, H, W, out);

@@ -163,16 +163,37 @@ def build_strided_rules(x, ksize, stride, padding, dilation=(1, 1, 1)):
     return rs
 
 
-def _sconv(features, weight_kio, bias, nbr, tile_order, n_out):
+_profile_hook = None   # bench.py installs a callable(tag, K, cin, cout, n_out, rules) -> ctx manager
+
+
+def pack_weights(weight_kio):
+    """MFMA-fragment-ordered copy of (K, Cin, Cout) weights, or None when the channel counts
+    run on the scalar kernel."""
+    K, cin, cout = weight_kio.shape
+    nbytes = query("glx_sconv_packed_bytes", K, cin, cout)
+    if nbytes == 0:
+        return None
+    wp = torch.empty(nbytes // 4, dtype=torch.float32, device=weight_kio.device)
+    call("glx_sconv_pack_weights", weight_kio, K, cin, cout, wp)
+    return wp
+
+
+def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rules=None, tag="fwd"):
     """out[j] = sum_k features[nbr[j,k]] @ weight_kio[k]  (weight (K, Cin, Cout))."""
     K, cin, cout = weight_kio.shape
     out = torch.empty((n_out, cout), dtype=torch.float32, device=features.device)
     if n_out == 0:
         return out
-    wsb = query("glx_sconv_workspace_bytes", K, cin, cout)
-    ws = workspace.get(wsb, features.device)
-    call("glx_sconv_forward", features, features.shape[0], weight_kio, bias, nbr, tile_order,
-         n_out, K, cin, cout, out, ws, size_arg(ws.numel()))
+    if packed is None:
+        packed = pack_weights(weight_kio)
+    ws = workspace.get(256, features.device)
+    args = ("glx_sconv_forward", features, features.shape[0], weight_kio, packed, bias, nbr,
+            tile_order, n_out, K, cin, cout, out, ws, size_arg(ws.numel()))
+    if _profile_hook is not None:
+        with _profile_hook(tag, K, cin, cout, n_out, rules):
+            call(*args)
+    else:
+        call(*args)
     return out
 
 
@@ -180,7 +201,7 @@ class SparseConvFunction(Function):
     """features (N_in, Cin), weight (K, Cin, Cout), bias (Cout)|None -> (N_out, Cout)."""
 
     @staticmethod
-    def forward(ctx, features, weight, bias, rules, inverse):
+    def forward(ctx, features, weight, bias, rules, inverse, packed=None):
         features = features.contiguous().float()
         w = weight.contiguous()
         _lib.check_cuda(features, w)
@@ -188,7 +209,7 @@ class SparseConvFunction(Function):
             nbr, order, n_out = rules.inverse_table(), rules.tile_order_in, rules.N_in
         else:
             nbr, order, n_out = rules.nbr, rules.tile_order_out, rules.N_out
-        out = _sconv(features, w, bias, nbr, order, n_out)
+        out = _sconv(features, w, bias, nbr, order, n_out, packed=packed, rules=rules)
         ctx.rules, ctx.inverse = rules, inverse
         ctx.save_for_backward(features, w)
         ctx.has_bias = bias is not None
@@ -215,7 +236,7 @@ class SparseConvFunction(Function):
             bwd_nbr, bwd_order, n_bwd_out = rules.inverse_table(), rules.tile_order_in, rules.N_in
             wt = w.transpose(1, 2).contiguous()
         if ctx.needs_input_grad[0]:
-            g_feat = _sconv(grad_out, wt, None, bwd_nbr, bwd_order, n_bwd_out)
+            g_feat = _sconv(grad_out, wt, None, bwd_nbr, bwd_order, n_bwd_out, rules=rules, tag="dgrad")
         if ctx.needs_input_grad[1]:
             g_w = torch.empty_like(w)
             wsb = query("glx_sconv_wgrad_workspace_bytes", n_fwd_out, K, cin, cout)
@@ -224,7 +245,7 @@ class SparseConvFunction(Function):
                  cin, cout, g_w, ws, size_arg(ws.numel()))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             g_b = grad_out.sum(0)
-        return g_feat, g_w, g_b, None, None
+        return g_feat, g_w, g_b, None, None, None
 
 
 class SparseConvTensor:
@@ -336,6 +357,17 @@ class SparseConvolution(SparseModule):
         return ("{in_channels}, {out_channels}, kernel_size={kernel_size}, stride={stride}, "
                 "padding={padding}, subm={subm}, indice_key={indice_key}").format(**self.__dict__)
 
+    def _packed_weight(self, w):
+        """Packed copy of the weights, refreshed when the parameter changes (optimizer step,
+        load_state_dict, .to())."""
+        tag = (self.weight._version, self.weight.data_ptr(), self.weight.device)
+        cache = self.__dict__.get("_packed_cache")
+        if cache is None or cache[0] != tag:
+            with torch.no_grad():
+                cache = (tag, pack_weights(w.detach().contiguous()))
+            self.__dict__["_packed_cache"] = cache
+        return cache[1]
+
     def _rules(self, x):
         key = self.indice_key
         if self.inverse:
@@ -363,7 +395,8 @@ class SparseConvolution(SparseModule):
         K = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
         w = self.weight.reshape(K, self.in_channels, self.out_channels)
         rs = self._rules(x)
-        feats = SparseConvFunction.apply(x.features, w, self.bias, rs, self.inverse)
+        feats = SparseConvFunction.apply(x.features, w, self.bias, rs, self.inverse,
+                                         self._packed_weight(w))
         if self.inverse:
             out = SparseConvTensor(feats, rs.in_indices, rs.in_spatial_shape, x.batch_size,
                                    x.grid, x.voxel_num, x.indice_dict, x.benchmark)

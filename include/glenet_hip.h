@@ -99,10 +99,17 @@ int glx_rules_invert(const int32_t* nbr, int N_out, int K, int N_in, int32_t* nb
  * and the transposed weights (glx_sconv_transpose_weights).
  * ------------------------------------------------------------------------------------ */
 size_t glx_sconv_workspace_bytes(int K, int Cin, int Cout);
-int glx_sconv_forward(const float* in, int N_in, const float* W, const float* bias,
-                      const int32_t* nbr, const int32_t* tile_order, int N_out, int K, int Cin,
-                      int Cout, float* out, void* workspace, size_t workspace_bytes,
-                      void* stream);
+/* Bytes of the MFMA-fragment-ordered copy of W (0 when (Cin,Cout) has no MFMA kernel, i.e.
+ * channels outside {16,32,64,128} or K > 27: those run the scalar kernel on raw W). */
+size_t glx_sconv_packed_bytes(int K, int Cin, int Cout);
+/* Re-order W (K,Cin,Cout) into Wp (glx_sconv_packed_bytes); do it once per weight update. */
+int glx_sconv_pack_weights(const float* W, int K, int Cin, int Cout, float* Wp, void* stream);
+/* W: raw weights (may be NULL when Wp is given); Wp: packed weights or NULL (then W is packed
+ * into `workspace`, >= glx_sconv_workspace_bytes). */
+int glx_sconv_forward(const float* in, int N_in, const float* W, const float* Wp,
+                      const float* bias, const int32_t* nbr, const int32_t* tile_order, int N_out,
+                      int K, int Cin, int Cout, float* out, void* workspace,
+                      size_t workspace_bytes, void* stream);
 /* Reference-quality scalar kernel (any channel count); used for tiny Cin and as a
  * device-side cross-check of the MFMA kernel. */
 int glx_sconv_forward_generic(const float* in, int N_in, const float* W, const float* bias,

@@ -1,0 +1,74 @@
+"""GPU parity of the whole sparse backbone (config 2 shape) against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from glenet_amd import backbone as gb
+from glenet_amd import synth
+from oracle import backbone as ob
+
+pytestmark = pytest.mark.gpu
+K = synth.KITTI
+
+
+def _condition(model, seed=0):
+    """Random-init weights shrink activations ~3x per layer; rescale so every layer's output is
+    O(1) and the comparison tolerance means something."""
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.05)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) * 0.02 + 0.01)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) * 0.5 + 0.75)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+
+
+@pytest.mark.parametrize("residual,nframes", [(False, 2), (True, 1)])
+def test_backbone_forward_matches_oracle(dev, residual, nframes):
+    torch.manual_seed(1)
+    grid = oracle.grid_size_of(K["point_cloud_range"], K["voxel_size"])
+    model = gb.SparseBackbone8x(4, grid, residual=residual).eval()
+    _condition(model)
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    frames = [synth.kitti_frame(10 + i, num_points=8000)[0] for i in range(nframes)]
+    v, c, n = oracle.voxelize_hard_batch(frames, K["voxel_size"], K["point_cloud_range"], 5, 16000)
+    ref = ob.backbone_forward(sd, oracle.mean_vfe(v, n), c, model.sparse_shape, residual=residual)
+
+    model = model.to(dev)
+    pts = torch.from_numpy(np.concatenate(frames)).to(dev)
+    bidx = torch.from_numpy(np.concatenate([np.full(len(f), i, np.int32) for i, f in enumerate(frames)])).to(dev)
+    with torch.no_grad():
+        bd = gb.voxelize_batch(pts, bidx, nframes, K)
+        assert np.array_equal(bd["voxel_coords"].cpu().numpy(), c)
+        bd = gb.MeanVFE()(bd)
+        bd = model(bd)
+        bd = gb.HeightCompression()(bd)
+    for name in ("x_conv1", "x_conv2", "x_conv3", "x_conv4"):
+        t = bd["multi_scale_3d_features"][name]
+        assert np.array_equal(t.indices.cpu().numpy(), ref[name].indices), name   # bit exact
+        r = ref[name].features
+        np.testing.assert_allclose(t.features.cpu().numpy(), r, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(r).max()))
+    out = bd["encoded_spconv_tensor"]
+    assert np.array_equal(out.indices.cpu().numpy(), ref["out"].indices)
+    r = ref["out"].features
+    assert np.abs(r).max() > 1e-2
+    np.testing.assert_allclose(out.features.cpu().numpy(), r, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(r).max()))
+    dense_ref = oracle.dense(r, ref["out"].indices, nframes, ref["out"].shape)
+    sf = bd["spatial_features"].cpu().numpy()
+    assert sf.shape == (nframes, 256, 200, 176)
+    np.testing.assert_allclose(sf.reshape(dense_ref.shape), dense_ref, rtol=1e-4,
+                               atol=1e-4 * max(1.0, np.abs(r).max()))
+
+
+def test_backbone_state_dict_names_match_reference():
+    """The parameter names are the ones GLENet's checkpoints use (spconv_backbone.py:77-117)."""
+    m = gb.VoxelBackBone8x(4, [1408, 1600, 40])
+    keys = set(m.state_dict().keys())
+    for k in ["conv_input.0.weight", "conv_input.1.running_mean", "conv1.0.0.weight",
+              "conv2.0.0.weight", "conv2.2.1.bias", "conv3.1.0.weight", "conv4.2.0.weight",
+              "conv_out.0.weight", "conv_out.1.weight"]:
+        assert k in keys, k
+    assert tuple(m.state_dict()["conv4.0.0.weight"].shape) == (3, 3, 3, 64, 64)
+    assert tuple(m.state_dict()["conv_out.0.weight"].shape) == (3, 1, 1, 64, 128)
+    assert m.sparse_shape == [41, 1600, 1408]
