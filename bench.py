@@ -36,7 +36,7 @@ FRAMES_PER_GPU = 4
 
 def kernel_name(cin, cout, K):
     ok = {16, 32, 64, 128}
-    if cin in ok and cout in ok and K <= 27:
+    if cin in (ok | {4, 8}) and cout in ok and K <= 27:
         return "k_sconv_mfma<%d,%d>" % (cin, cout)
     return "k_sconv_generic"
 
@@ -48,31 +48,43 @@ def alg_bytes(R, K, cin, cout):
 
 
 class ConvProfiler:
-    """Times every sparse-conv launch with HIP events on the launch stream."""
+    """Kernel-only duration of every sparse-conv launch: the launcher brackets the kernel
+    with two HIP events (hipExtLaunchKernelGGL start/stop) on the stream it is launched on."""
 
     def __init__(self):
-        self.records = []      # (name, start_evt, end_evt, rules, K, cin, cout)
+        import ctypes
+        from glenet_amd import _lib
+        self._lib, self._ct = _lib, ctypes
+        self.records = []      # (name, start_evt, stop_evt, rules, K, cin, cout)
         self.enabled = False
+        self._pool = []
 
-    @contextlib.contextmanager
+    def _event(self):
+        if self._pool:
+            return self._pool.pop()
+        e = self._ct.c_void_p()
+        self._lib.call_nostream("glx_event_create", self._ct.byref(e))
+        return e
+
     def __call__(self, tag, K, cin, cout, n_out, rules):
-        if not self.enabled:
-            yield
+        name = kernel_name(cin, cout, K)
+        if not self.enabled or name == "k_sconv_generic":
             return
-        s = torch.cuda.Event(enable_timing=True)
-        e = torch.cuda.Event(enable_timing=True)
-        s.record()            # torch's current stream == the stream the kernel is launched on
-        yield
-        e.record()
-        self.records.append((kernel_name(cin, cout, K), s, e, rules, K, cin, cout))
+        s, e = self._event(), self._event()
+        self._lib.call_nostream("glx_profile_next_sconv", s, e)
+        self.records.append((name, s, e, rules, K, cin, cout))
 
     def summary(self):
         per = {}
+        ms = self._ct.c_float()
         for name, s, e, rules, K, cin, cout in self.records:
+            self._lib.call_nostream("glx_event_elapsed_ms", s, e, self._ct.byref(ms))
             d = per.setdefault(name, dict(ms=0.0, launches=0, bytes=0))
-            d["ms"] += s.elapsed_time(e)
+            d["ms"] += ms.value
             d["launches"] += 1
             d["bytes"] += alg_bytes(rules.pair_count, K, cin, cout)
+            self._pool += [s, e]
+        self.records = []
         return per
 
 
@@ -143,9 +155,6 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    prof = ConvProfiler()
-    spcore._profile_hook = prof
-    prof.enabled = True
 
     def fence():
         torch.cuda.synchronize()
@@ -153,17 +162,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- headline: exactly K steps between two fences, nothing else in the region
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         bd = step()
     fence()
     dt = time.perf_counter() - t0
-    prof.enabled = False
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # ---- roofline: the same K steps once more with every sparse-conv launch bracketed by HIP
+    # events on its stream (start/stop attached to the dispatch = kernel-only time).  Kept out of
+    # the headline loop because the event-bracketed launches serialise the otherwise async queue.
+    prof = ConvProfiler()
+    spcore._profile_hook = prof
+    prof.enabled = True
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    prof.enabled = False
+    spcore._profile_hook = None
 
     frames_total = FRAMES_PER_GPU * world * args.steps
     per = prof.summary()

@@ -38,10 +38,14 @@ class ResidualBlock(spconv.SparseModule):
         self.relu = nn.ReLU()
 
     def forward(self, x):
-        out = self.conv1(x)
-        out = out.replace_feature(self.relu(self.bn1(out.features)))
-        out = self.conv2(out)
-        out = out.replace_feature(self.bn2(out.features))
+        if spconv.core.can_fuse_bn(self.bn1) and spconv.core.can_fuse_bn(self.bn2):
+            out = self.conv1(x, fused_bn=self.bn1, fused_relu=True)
+            out = self.conv2(out, fused_bn=self.bn2)
+        else:
+            out = self.conv1(x)
+            out = out.replace_feature(self.relu(self.bn1(out.features)))
+            out = self.conv2(out)
+            out = out.replace_feature(self.bn2(out.features))
         return out.replace_feature(self.relu(out.features + x.features))
 
 

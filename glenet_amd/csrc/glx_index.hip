@@ -19,7 +19,27 @@ void glx_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* glx_last_error(void) { return g_err; }
-extern "C" int glx_abi_version(void) { return 1; }
+extern "C" int glx_abi_version(void) { return 2; }
+
+// ---------------------------------------------------------------- timing events (bench)
+extern "C" int glx_event_create(void** event) {
+  GLX_REQUIRE(event, "glx_event_create: null");
+  hipEvent_t e;
+  GLX_HIP(hipEventCreate(&e));
+  *event = (void*)e;
+  return GLX_OK;
+}
+extern "C" int glx_event_destroy(void* event) {
+  GLX_HIP(hipEventDestroy((hipEvent_t)event));
+  return GLX_OK;
+}
+// blocks the host until `stop` has completed
+extern "C" int glx_event_elapsed_ms(void* start, void* stop, float* ms) {
+  GLX_REQUIRE(start && stop && ms, "glx_event_elapsed_ms: null");
+  GLX_HIP(hipEventSynchronize((hipEvent_t)stop));
+  GLX_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return GLX_OK;
+}
 
 // ---------------------------------------------------------------- bitmap + scan
 __global__ void k_set_bits(const int4* __restrict__ idx, int N, GlxGrid g,
@@ -106,8 +126,9 @@ __global__ void k_rules_subm(const int4* __restrict__ idx, int N, GlxGrid g,
   int zy = kd * kh;
   int hits = 0;
   if (t < (long long)N * zy) {
-    int j = (int)(t / zy);
-    int r = (int)(t - (long long)j * zy);
+    int s = (int)(t / zy);   // walk rows in cell order: neighbouring threads probe the same words
+    int r = (int)(t - (long long)s * zy);
+    int j = rank_to_row ? rank_to_row[s] : s;
     int kz = r / kh, ky = r - kz * kh;
     int4 c = idx[j];
     int z = c.y + kz - kd / 2, y = c.z + ky - kh / 2;
@@ -126,8 +147,10 @@ __global__ void k_rules_subm(const int4* __restrict__ idx, int N, GlxGrid g,
       dst[kx] = v;
     }
   }
-  hits = glx_wave_sum(hits);
-  if ((threadIdx.x & 63) == 0 && hits) atomicAdd(pair_count, hits);
+  if (pair_count) {  // optional: a same-address atomic per wave serialises (~12 ns each)
+    hits = glx_wave_sum(hits);
+    if ((threadIdx.x & 63) == 0 && hits) atomicAdd(pair_count, hits);
+  }
 }
 
 extern "C" int glx_rules_subm(const int32_t* indices, int N, int B, int D, int H, int W,
@@ -137,7 +160,7 @@ extern "C" int glx_rules_subm(const int32_t* indices, int N, int B, int D, int H
   GLX_REQUIRE(kd > 0 && kh > 0 && kw > 0 && (kd & 1) && (kh & 1) && (kw & 1),
               "glx_rules_subm: kernel size must be odd, got (%d,%d,%d)", kd, kh, kw);
   if (N == 0) return GLX_OK;
-  GLX_REQUIRE(indices && bitmap && prefix && nbr && pair_count, "glx_rules_subm: null pointer");
+  GLX_REQUIRE(indices && bitmap && prefix && nbr, "glx_rules_subm: null pointer");
   GlxGrid g{B, D, H, W};
   long long total = (long long)N * kd * kh;
   hipLaunchKernelGGL(k_rules_subm, dim3(glx_divup(total, 256)), dim3(256), 0,
@@ -262,8 +285,10 @@ __global__ void k_rules_strided(const int4* __restrict__ oidx, int N_out, GlxGri
       dst[kx] = v;
     }
   }
-  hits = glx_wave_sum(hits);
-  if ((threadIdx.x & 63) == 0 && hits) atomicAdd(pair_count, hits);
+  if (pair_count) {  // optional: a same-address atomic per wave serialises (~12 ns each)
+    hits = glx_wave_sum(hits);
+    if ((threadIdx.x & 63) == 0 && hits) atomicAdd(pair_count, hits);
+  }
 }
 
 extern "C" int glx_rules_strided(const int32_t* indices_out, int N_out, int B, int D, int H, int W,
@@ -272,8 +297,7 @@ extern "C" int glx_rules_strided(const int32_t* indices_out, int N_out, int B, i
                                  int sh, int sw, int pd, int ph, int pw, int32_t* nbr,
                                  int32_t* pair_count, void* stream) {
   if (N_out == 0) return GLX_OK;
-  GLX_REQUIRE(indices_out && in_bitmap && in_prefix && nbr && pair_count,
-              "glx_rules_strided: null pointer");
+  GLX_REQUIRE(indices_out && in_bitmap && in_prefix && nbr, "glx_rules_strided: null pointer");
   GlxGrid ig{B, D, H, W};
   ConvGeom cg{kd, kh, kw, sd, sh, sw, pd, ph, pw};
   long long total = (long long)N_out * kd * kh;

@@ -11,16 +11,13 @@
 // multiplies by W[k], which sits in LDS in MFMA-fragment order, with
 // v_mfma_f32_16x16x4_f32 (exact fp32, bitwise an fmaf chain).  Offsets absent from the
 // whole tile are skipped, so the dense MFMA work tracks the rule count R.
+#include <hip/hip_ext.h>
 #include <type_traits>
 
 #include "glx_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define SC_THREADS 256
-#define SC_WAVES 4
-#define SC_ROWS_PER_WAVE 16
-#define SC_ROWS_PER_BLOCK (SC_WAVES * SC_ROWS_PER_WAVE)
 #define SC_MAXK 27
 
 template <int CIN, int COUT>
@@ -59,179 +56,279 @@ struct FVec<2> { typedef float2 T; };
 template <>
 struct FVec<4> { typedef float4 T; };
 
-template <int CIN, int COUT, bool RESIDENT>
-__global__ __launch_bounds__(SC_THREADS) void k_sconv_mfma(
-    const float* __restrict__ in, const float* __restrict__ Wp, const float* __restrict__ bias,
-    const int* __restrict__ nbr, const int* __restrict__ tile_order, int N_out, int K,
-    float* __restrict__ out) {
+// Epilogue fused into the store of the output tile: y = relu?((acc + bias) * scale + shift).
+struct SconvEpilogue {
+  const float* bias;   // (Cout) or NULL
+  const float* scale;  // (Cout) or NULL  (e.g. eval-mode BatchNorm folded: gamma / sqrt(var+eps))
+  const float* shift;  // (Cout) or NULL
+  int relu;
+};
+
+#define SC_NW 8                      // waves per block
+#define SC_THREADS (SC_NW * 64)
+
+template <int CIN, int COUT>
+struct SconvTile {
   using C = SconvCfg<CIN, COUT>;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  // layout: [weights: RESIDENT ? K*IMG : 2*IMG] [s_nbr: 64*28 ints] [s_rows: 64 ints] [mask: 4]
-  constexpr int WFLOATS_STAGE = C::IMG;
-  float* s_w = smem;
-  const int wfloats = RESIDENT ? K * WFLOATS_STAGE : 2 * WFLOATS_STAGE;
-  int* s_nbr = reinterpret_cast<int*>(smem + wfloats);
-  int* s_rows = s_nbr + SC_ROWS_PER_BLOCK * (SC_MAXK + 1);
-  int* s_mask = s_rows + SC_ROWS_PER_BLOCK;
+  static constexpr int TR = COUT >= 128 ? 128 : 256;          // output rows per block
+  static constexpr int MAXC = TR / (16 * SC_NW);              // chunks per wave per offset
+  static constexpr int ACC_LD = COUT + 4;
+  static constexpr size_t fixed_bytes =
+      (size_t)TR * ACC_LD * 4 + (size_t)SC_MAXK * TR * 5 + (TR + 32 + 32 * (TR / 64)) * 4 + 64;
+  static constexpr int NBUF = (fixed_bytes + 2 * (size_t)C::IMG * 4 <= 160 * 1024) ? 2 : 1;
+  static constexpr size_t lds_bytes = fixed_bytes + (size_t)NBUF * C::IMG * 4;
+};
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, q = lane >> 4;
-
-  if (RESIDENT) {
-    // whole filter bank stays in LDS for every tile this block walks
-    const float4* src = reinterpret_cast<const float4*>(Wp);
-    float4* dst = reinterpret_cast<float4*>(s_w);
-    for (int i = tid; i < K * WFLOATS_STAGE / 4; i += SC_THREADS) dst[i] = src[i];
-  }
-
-  const int ntiles = (N_out + SC_ROWS_PER_BLOCK - 1) / SC_ROWS_PER_BLOCK;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int row0 = tile * SC_ROWS_PER_BLOCK;
-    __syncthreads();  // previous tile done with s_nbr / s_rows / s_mask (and weights landed)
-    if (tid < SC_ROWS_PER_BLOCK) {
-      int p = row0 + tid;
-      s_rows[tid] = (p < N_out) ? (tile_order ? tile_order[p] : p) : -1;
-    }
-    if (tid == 0) s_mask[0] = 0;
-    __syncthreads();
-    // neighbour lists of the block's 64 rows -> LDS, and the per-wave / per-block offset masks
-    unsigned my_mask = 0;
-    for (int e = lane; e < SC_ROWS_PER_WAVE * K; e += 64) {
-      int rr = e / K, kk = e - rr * K;
-      int orow = s_rows[wave * 16 + rr];
-      int v = (orow >= 0) ? nbr[(long long)orow * K + kk] : -1;
-      s_nbr[(wave * 16 + rr) * (SC_MAXK + 1) + kk] = v;
-      if (v >= 0) my_mask |= 1u << kk;
-    }
+// gather the CQ-float slice of up to MAXC chunks of offset k owned by this wave
+template <int CIN, int COUT>
+__device__ __forceinline__ void sc_gather(const float* __restrict__ in, const int* s_pin,
+                                          int k, int cnt, int wave, int r, int q,
+                                          float (&A)[SconvTile<CIN, COUT>::MAXC][SconvCfg<CIN, COUT>::CQ]) {
+  using C = SconvCfg<CIN, COUT>;
+  using T = SconvTile<CIN, COUT>;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) my_mask |= __shfl_xor(my_mask, o, 64);
-    const unsigned wave_mask = __builtin_amdgcn_readfirstlane(my_mask);
-    unsigned block_mask = wave_mask;
-    if (!RESIDENT) {
-      if (lane == 0 && wave_mask) atomicOr(&s_mask[0], wave_mask);
-      __syncthreads();
-      block_mask = (unsigned)s_mask[0];
-    }
-
-    f32x4 acc[C::NT];
+  for (int j = 0; j < T::MAXC; ++j) {
+    const int c = ((wave - k) & (SC_NW - 1)) + j * SC_NW;
+    const int p = c * 16 + r;
+    int irow = -1;
+    if (p < cnt) irow = s_pin[k * T::TR + p];
+    const float* ap = in + (long long)(irow < 0 ? 0 : irow) * CIN + q * C::CQ;
+    if (c * 16 < cnt) {   // wave-uniform: skip the loads of an absent chunk
+      if constexpr (C::CQ % 4 == 0) {
 #pragma unroll
-    for (int c = 0; c < C::NT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int my_nbr_base = (wave * 16 + r) * (SC_MAXK + 1);
-
-    // ---- staged (double buffered) weights: prologue loads first offset
-    constexpr int STAGE_F4 = WFLOATS_STAGE / 4;                       // float4 per image
-    constexpr int STAGE_PER_THREAD = (STAGE_F4 + SC_THREADS - 1) / SC_THREADS;
-    float4 stage_regs[STAGE_PER_THREAD];
-    int buf = 0;
-    unsigned todo = block_mask;
-    if (!RESIDENT && todo) {
-      int k0 = __builtin_ctz(todo);
-      const float4* src = reinterpret_cast<const float4*>(Wp + (size_t)k0 * WFLOATS_STAGE);
-      float4* dst = reinterpret_cast<float4*>(s_w);
-#pragma unroll
-      for (int i = 0; i < STAGE_PER_THREAD; ++i) {
-        int e = tid + i * SC_THREADS;
-        if (e < STAGE_F4) dst[e] = src[e];
-      }
-    }
-
-    while (todo) {
-      const int k = __builtin_ctz(todo);
-      todo &= todo - 1;
-      const float* wimg;
-      if (RESIDENT) {
-        wimg = s_w + (size_t)k * WFLOATS_STAGE;
+        for (int i = 0; i < C::CQ / 4; ++i) {
+          f32x4 v = reinterpret_cast<const f32x4*>(ap)[i];
+          A[j][4 * i + 0] = v[0]; A[j][4 * i + 1] = v[1]; A[j][4 * i + 2] = v[2]; A[j][4 * i + 3] = v[3];
+        }
       } else {
-        __syncthreads();  // image k visible; other buffer free
-        wimg = s_w + buf * WFLOATS_STAGE;
-        if (todo) {  // issue global loads of the next image now, park them in registers
-          int kn = __builtin_ctz(todo);
-          const float4* src = reinterpret_cast<const float4*>(Wp + (size_t)kn * WFLOATS_STAGE);
 #pragma unroll
-          for (int i = 0; i < STAGE_PER_THREAD; ++i) {
-            int e = tid + i * SC_THREADS;
-            if (e < STAGE_F4) stage_regs[i] = src[e];
-          }
-        }
+        for (int i = 0; i < C::CQ; ++i) A[j][i] = ap[i];
       }
-
-      if (wave_mask & (1u << k)) {
-        const int irow = s_nbr[my_nbr_base + k];
-        float a[C::CQ];
-        if (irow >= 0) {
-          const float* ap = in + (long long)irow * CIN + q * C::CQ;
-          if constexpr (C::CQ % 4 == 0) {
+      if (irow < 0) {
 #pragma unroll
-            for (int i = 0; i < C::CQ / 4; ++i) {
-              float4 v = reinterpret_cast<const float4*>(ap)[i];
-              a[4 * i + 0] = v.x; a[4 * i + 1] = v.y; a[4 * i + 2] = v.z; a[4 * i + 3] = v.w;
-            }
-          } else {
-#pragma unroll
-            for (int i = 0; i < C::CQ; ++i) a[i] = ap[i];
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < C::CQ; ++i) a[i] = 0.f;
-        }
-#pragma unroll
-        for (int t = 0; t < C::CQ; ++t) {
-#pragma unroll
-          for (int h = 0; h < C::NH; ++h) {
-            typedef typename FVec<C::NC>::T BV;
-            BV bv = *reinterpret_cast<const BV*>(wimg + (h * 4 + q) * C::QSTRIDE +
-                                                  (t * 16 + r) * C::NC);
-            const float* bp = reinterpret_cast<const float*>(&bv);
-#pragma unroll
-            for (int c = 0; c < C::NC; ++c) {
-              acc[h * C::NC + c] =
-                  __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bp[c], acc[h * C::NC + c], 0, 0, 0);
-            }
-          }
-        }
-      }
-
-      if (!RESIDENT) {
-        if (todo) {
-          float4* dst = reinterpret_cast<float4*>(s_w + (buf ^ 1) * WFLOATS_STAGE);
-#pragma unroll
-          for (int i = 0; i < STAGE_PER_THREAD; ++i) {
-            int e = tid + i * SC_THREADS;
-            if (e < STAGE_F4) dst[e] = stage_regs[i];
-          }
-        }
-        buf ^= 1;
-      }
-    }
-
-    // ---- epilogue: lane (n=r, q) holds rows 4q..4q+3, column 16*ct + n
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int orow = s_rows[wave * 16 + 4 * q + reg];
-      if (orow >= 0) {
-        float* op = out + (long long)orow * COUT + r;
-#pragma unroll
-        for (int ct = 0; ct < C::NT; ++ct) {
-          float v = acc[ct][reg];
-          if (bias) v += bias[ct * 16 + r];
-          op[ct * 16] = v;
-        }
+        for (int i = 0; i < C::CQ; ++i) A[j][i] = 0.f;
       }
     }
   }
 }
 
+// MFMA the wave's chunks of offset k against the staged W[k] and add into the LDS tile
+template <int CIN, int COUT>
+__device__ __forceinline__ void sc_compute(const float* s_w, float* s_acc,
+                                           const unsigned char* s_pslot, int k, int cnt, int wave,
+                                           int r, int q,
+                                           const float (&A)[SconvTile<CIN, COUT>::MAXC][SconvCfg<CIN, COUT>::CQ]) {
+  using C = SconvCfg<CIN, COUT>;
+  using T = SconvTile<CIN, COUT>;
+#pragma unroll
+  for (int j = 0; j < T::MAXC; ++j) {
+    const int c = ((wave - k) & (SC_NW - 1)) + j * SC_NW;
+    if (c * 16 >= cnt) continue;   // wave-uniform
+    // Operands swapped (W^T as the MFMA "A", gathered rows as "B"): D[i = cout][j = pair], so
+    // lane (pair r, q) ends up with 4 CONSECUTIVE output channels 16ct + 4q .. +3 of its pair.
+    f32x4 acc[C::NT];
+#pragma unroll
+    for (int ct = 0; ct < C::NT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < C::CQ; ++t) {
+#pragma unroll
+      for (int h = 0; h < C::NH; ++h) {
+        const float* bp = s_w + (h * 4 + q) * C::QSTRIDE + (t * 16 + r) * C::NC;
+        if constexpr (C::NC == 4) {
+          f32x4 bv = *reinterpret_cast<const f32x4*>(bp);
+          acc[h * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[0], A[j][t], acc[h * 4 + 0], 0, 0, 0);
+          acc[h * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[1], A[j][t], acc[h * 4 + 1], 0, 0, 0);
+          acc[h * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[2], A[j][t], acc[h * 4 + 2], 0, 0, 0);
+          acc[h * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[3], A[j][t], acc[h * 4 + 3], 0, 0, 0);
+        } else if constexpr (C::NC == 2) {
+          float2 bv = *reinterpret_cast<const float2*>(bp);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.x, A[j][t], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.y, A[j][t], acc[1], 0, 0, 0);
+        } else {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bp[0], A[j][t], acc[0], 0, 0, 0);
+        }
+      }
+    }
+    // plain read-modify-write of the LDS tile (no atomics: rows of one offset are distinct and
+    // offsets are separated by the block barrier; LDS float atomics are far slower than this)
+    const int p = c * 16 + r;
+    if (p < cnt) {
+      float* dst = s_acc + (int)s_pslot[k * T::TR + p] * T::ACC_LD + 4 * q;
+#pragma unroll
+      for (int ct = 0; ct < C::NT; ++ct) {
+        f32x4 v = *reinterpret_cast<f32x4*>(dst + ct * 16);
+        v += acc[ct];
+        *reinterpret_cast<f32x4*>(dst + ct * 16) = v;
+      }
+    }
+  }
+}
+
+// Block = 8 waves, TR output rows.  Per kernel offset k the block compacts the rows that have
+// a neighbour at k into a pair list; 16 pairs form one MFMA row tile (the matrix pipe only sees
+// real rules), products are added into an fp32 accumulator tile in LDS.  Rows of one offset are
+// distinct and offsets are separated by a barrier, so every output element is summed in a fixed
+// order: bitwise reproducible, no global atomics.  W[k+1] streams into the second LDS buffer
+// and the next offset's input rows into registers while offset k multiplies.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(SC_THREADS) void k_sconv_mfma(
+    const float* __restrict__ in, const float* __restrict__ Wp, SconvEpilogue ep,
+    const int* __restrict__ nbr, const int* __restrict__ tile_order, int N_out, int K,
+    float* __restrict__ out) {
+  using C = SconvCfg<CIN, COUT>;
+  using T = SconvTile<CIN, COUT>;
+  constexpr int TR = T::TR, ACC_LD = T::ACC_LD, NBUF = T::NBUF, LW = TR / 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_acc = smem;                                        // TR * ACC_LD
+  float* s_w = s_acc + TR * ACC_LD;                           // NBUF * IMG
+  int* s_pin = reinterpret_cast<int*>(s_w + NBUF * C::IMG);   // SC_MAXK * TR
+  int* s_rows = s_pin + SC_MAXK * TR;                         // TR
+  int* s_cnt = s_rows + TR;                                   // 32
+  int* s_wcnt = s_cnt + 32;                                   // LW * 32
+  unsigned char* s_pslot = reinterpret_cast<unsigned char*>(s_wcnt + LW * 32);  // SC_MAXK * TR
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int row0 = blockIdx.x * TR;
+
+  // ---- tile rows, zero accumulators, first weight image
+  int my_row = -1;
+  if (tid < TR) {
+    int p = row0 + tid;
+    my_row = (p < N_out) ? (tile_order ? tile_order[p] : p) : -1;
+    s_rows[tid] = my_row;
+  }
+  for (int i = tid; i < TR * ACC_LD / 4; i += SC_THREADS)
+    reinterpret_cast<f32x4*>(s_acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- neighbour row of every (slot, offset) straight into registers, then compaction
+  int nb[SC_MAXK];
+  if (tid < TR) {
+#pragma unroll
+    for (int k = 0; k < SC_MAXK; ++k)
+      nb[k] = (k < K && my_row >= 0) ? nbr[(long long)my_row * K + k] : -1;
+#pragma unroll
+    for (int k = 0; k < SC_MAXK; ++k) {
+      unsigned long long b = __ballot(nb[k] >= 0);
+      if (lane == 0) s_wcnt[wave * 32 + k] = __popcll(b);
+    }
+  }
+  __syncthreads();
+  if (tid < TR) {
+#pragma unroll
+    for (int k = 0; k < SC_MAXK; ++k) {
+      const bool v = nb[k] >= 0;
+      unsigned long long b = __ballot(v);
+      int base = 0;
+#pragma unroll
+      for (int w = 0; w < LW; ++w) base += (w < wave) ? s_wcnt[w * 32 + k] : 0;
+      if (v) {
+        int pos = k * TR + base + __popcll(b & ((1ull << lane) - 1ull));
+        s_pin[pos] = nb[k];
+        s_pslot[pos] = (unsigned char)tid;
+      }
+      if (wave == LW - 1 && lane == 0) s_cnt[k] = base + __popcll(b);
+    }
+  }
+  __syncthreads();
+  unsigned mask = 0;
+#pragma unroll
+  for (int k = 0; k < SC_MAXK; ++k)
+    if (k < K && s_cnt[k] > 0) mask |= 1u << k;
+  mask = __builtin_amdgcn_readfirstlane(mask);
+
+  // ---- weight staging registers (next image) and input-row registers (ping-pong)
+  constexpr int STAGE_F4 = C::IMG / 4;
+  constexpr int SPT = (STAGE_F4 + SC_THREADS - 1) / SC_THREADS;
+  f32x4 stage_regs[SPT];
+#define SC_STAGE_LOAD(KK)                                                                   \
+  {                                                                                         \
+    const f32x4* src_ = reinterpret_cast<const f32x4*>(Wp + (size_t)(KK) * C::IMG);         \
+    _Pragma("unroll") for (int i_ = 0; i_ < SPT; ++i_) {                                    \
+      int e_ = tid + i_ * SC_THREADS;                                                       \
+      stage_regs[i_] = src_[e_ < STAGE_F4 ? e_ : STAGE_F4 - 1];                             \
+    }                                                                                       \
+  }
+#define SC_STAGE_STORE(BUF)                                                                 \
+  {                                                                                         \
+    f32x4* dst_ = reinterpret_cast<f32x4*>(s_w + (BUF) * C::IMG);                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < SPT; ++i_) {                                    \
+      int e_ = tid + i_ * SC_THREADS;                                                       \
+      if (STAGE_F4 % SC_THREADS == 0 || e_ < STAGE_F4) dst_[e_] = stage_regs[i_];           \
+    }                                                                                       \
+  }
+
+  float A0[T::MAXC][C::CQ], A1[T::MAXC][C::CQ];
+  unsigned rem = mask;
+  int k = -1, cnt = 0;
+  if (rem) {
+    k = __builtin_ctz(rem);
+    rem &= rem - 1;
+    cnt = s_cnt[k];
+    SC_STAGE_LOAD(k);
+    SC_STAGE_STORE(0);
+    sc_gather<CIN, COUT>(in, s_pin, k, cnt, wave, r, q, A0);
+  }
+  __syncthreads();
+
+  int buf = 0;
+  // one phase: prefetch (W image + input rows) of the next offset, multiply the current one
+#define SC_PHASE(CUR, NXT)                                                                  \
+  {                                                                                         \
+    int kn_ = -1, cntn_ = 0;                                                                \
+    if (rem) {                                                                              \
+      kn_ = __builtin_ctz(rem);                                                             \
+      rem &= rem - 1;                                                                       \
+      cntn_ = s_cnt[kn_];                                                                   \
+      SC_STAGE_LOAD(kn_);                                                                   \
+      sc_gather<CIN, COUT>(in, s_pin, kn_, cntn_, wave, r, q, NXT);                         \
+    }                                                                                       \
+    sc_compute<CIN, COUT>(s_w + (NBUF == 2 ? buf : 0) * C::IMG, s_acc, s_pslot, k, cnt,     \
+                          wave, r, q, CUR);                                                 \
+    if (NBUF == 1) __syncthreads();                                                         \
+    if (kn_ >= 0) SC_STAGE_STORE(NBUF == 2 ? (buf ^ 1) : 0);                                \
+    __syncthreads();                                                                        \
+    buf ^= 1;                                                                               \
+    k = kn_;                                                                                \
+    cnt = cntn_;                                                                            \
+  }
+  while (k >= 0) {
+    SC_PHASE(A0, A1);
+    if (k < 0) break;
+    SC_PHASE(A1, A0);
+  }
+#undef SC_PHASE
+#undef SC_STAGE_LOAD
+#undef SC_STAGE_STORE
+
+  // ---- epilogue: coalesced row stores with the fused pointwise tail
+  constexpr int C4 = COUT / 4;
+  for (int i = tid; i < TR * C4; i += SC_THREADS) {
+    int rr = i / C4, c4 = i - rr * C4;
+    int orow = s_rows[rr];
+    if (orow < 0) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(s_acc + rr * ACC_LD + 4 * c4);
+    const int co = 4 * c4;
+    if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + co);
+    if (ep.scale) v *= *reinterpret_cast<const f32x4*>(ep.scale + co);
+    if (ep.shift) v += *reinterpret_cast<const f32x4*>(ep.shift + co);
+    if (ep.relu) {
+      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(out + (long long)orow * COUT + 4 * c4) = v;
+  }
+}
+
 // ------------------------------------------------------------------ generic scalar kernel
 __global__ void k_sconv_generic(const float* __restrict__ in, const float* __restrict__ W,
-                                const float* __restrict__ bias, const int* __restrict__ nbr,
-                                int N_out, int K, int Cin, int Cout, float* __restrict__ out) {
+                                SconvEpilogue ep, const int* __restrict__ nbr, int N_out, int K,
+                                int Cin, int Cout, float* __restrict__ out) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)N_out * Cout) return;
   int j = (int)(t / Cout);
   int co = (int)(t - (long long)j * Cout);
-  float acc = bias ? bias[co] : 0.f;
+  float acc = 0.f;
   for (int k = 0; k < K; ++k) {
     int i = nbr[(long long)j * K + k];
     if (i < 0) continue;
@@ -239,6 +336,10 @@ __global__ void k_sconv_generic(const float* __restrict__ in, const float* __res
     const float* wp = W + ((long long)k * Cin) * Cout + co;
     for (int ci = 0; ci < Cin; ++ci) acc = fmaf(ip[ci], wp[(long long)ci * Cout], acc);
   }
+  if (ep.bias) acc += ep.bias[co];
+  if (ep.scale) acc = acc * ep.scale[co] + (ep.shift ? ep.shift[co] : 0.f);
+  else if (ep.shift) acc += ep.shift[co];
+  if (ep.relu) acc = fmaxf(acc, 0.f);
   out[t] = acc;
 }
 
@@ -250,8 +351,9 @@ extern "C" int glx_sconv_forward_generic(const float* in, int N_in, const float*
   GLX_REQUIRE(in && W && nbr && out && K > 0 && Cin > 0 && Cout > 0,
               "glx_sconv_forward_generic: bad arguments");
   long long total = (long long)N_out * Cout;
+  SconvEpilogue ep{bias, nullptr, nullptr, 0};
   hipLaunchKernelGGL(k_sconv_generic, dim3(glx_divup(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, in, W, bias, nbr, N_out, K, Cin, Cout, out);
+                     (hipStream_t)stream, in, W, ep, nbr, N_out, K, Cin, Cout, out);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
@@ -259,7 +361,7 @@ extern "C" int glx_sconv_forward_generic(const float* in, int N_in, const float*
 // ------------------------------------------------------------------ dispatch
 static bool mfma_supported(int Cin, int Cout, int K) {
   auto okc = [](int c) { return c == 16 || c == 32 || c == 64 || c == 128; };
-  return okc(Cin) && okc(Cout) && K <= SC_MAXK;
+  return (okc(Cin) || Cin == 4 || Cin == 8) && okc(Cout) && K <= SC_MAXK;
 }
 
 template <int CIN, int COUT>
@@ -271,6 +373,7 @@ template <class F>
 static int sc_dispatch(int Cin, int Cout, F&& f) {
 #define SC_CASE(A, B) \
   if (Cin == A && Cout == B) return f(std::integral_constant<int, A>{}, std::integral_constant<int, B>{});
+  SC_CASE(4, 16) SC_CASE(4, 32) SC_CASE(8, 16) SC_CASE(8, 32)
   SC_CASE(16, 16) SC_CASE(16, 32) SC_CASE(16, 64) SC_CASE(16, 128)
   SC_CASE(32, 16) SC_CASE(32, 32) SC_CASE(32, 64) SC_CASE(32, 128)
   SC_CASE(64, 16) SC_CASE(64, 32) SC_CASE(64, 64) SC_CASE(64, 128)
@@ -294,8 +397,14 @@ extern "C" size_t glx_sconv_workspace_bytes(int K, int Cin, int Cout) {
   return glx_align(packed_bytes(K, Cin, Cout)) + 256;
 }
 
-#define SC_RESIDENT_LIMIT (72 * 1024)
-#define SC_TILE_LDS ((SC_ROWS_PER_BLOCK * (SC_MAXK + 1) + SC_ROWS_PER_BLOCK + 4) * sizeof(int))
+// optional per-launch timing: the next sparse-conv launch on this host thread is bracketed by
+// these two HIP events (hipExtLaunchKernelGGL start/stop = exactly the kernel's execution).
+static thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+extern "C" int glx_profile_next_sconv(void* start_event, void* stop_event) {
+  g_prof_start = (hipEvent_t)start_event;
+  g_prof_stop = (hipEvent_t)stop_event;
+  return GLX_OK;
+}
 
 template <int CI, int CO>
 static int pack_weights(const float* W, int K, float* Wp, hipStream_t st) {
@@ -310,26 +419,26 @@ static int pack_weights(const float* W, int K, float* Wp, hipStream_t st) {
 }
 
 template <int CI, int CO>
-static int launch_mfma(const float* in, const float* Wp, const float* bias, const int32_t* nbr,
-                       const int32_t* tile_order, int N_out, int K, float* out, hipStream_t st) {
-  using C = SconvCfg<CI, CO>;
-  size_t pbytes = (size_t)K * C::IMG * sizeof(float);
-  int ntiles = glx_divup(N_out, SC_ROWS_PER_BLOCK);
-  bool resident = pbytes <= SC_RESIDENT_LIMIT;
-  size_t lds = (resident ? pbytes : 2 * (size_t)C::IMG * sizeof(float)) + SC_TILE_LDS;
-  if (resident) {
-    int grid = ntiles < 512 ? ntiles : 512;
-    auto kern = k_sconv_mfma<CI, CO, true>;
+static int launch_mfma(const float* in, const float* Wp, const SconvEpilogue& ep,
+                       const int32_t* nbr, const int32_t* tile_order, int N_out, int K, float* out,
+                       hipStream_t st) {
+  using T = SconvTile<CI, CO>;
+  static bool attr_set = false;   // one instantiation per (CI, CO)
+  auto kern = k_sconv_mfma<CI, CO>;
+  const size_t lds = T::lds_bytes;
+  if (!attr_set) {
     GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(SC_THREADS), lds, st, in, Wp, bias, nbr, tile_order,
-                       N_out, K, out);
+    attr_set = true;
+  }
+  int nblocks = glx_divup(N_out, T::TR);
+  if (g_prof_start && g_prof_stop) {
+    hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(SC_THREADS), lds, st, g_prof_start,
+                          g_prof_stop, 0, in, Wp, ep, nbr, tile_order, N_out, K, out);
+    g_prof_start = g_prof_stop = nullptr;
   } else {
-    auto kern = k_sconv_mfma<CI, CO, false>;
-    GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
-    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(SC_THREADS), lds, st, in, Wp, bias, nbr,
-                       tile_order, N_out, K, out);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(SC_THREADS), lds, st, in, Wp, ep, nbr, tile_order,
+                       N_out, K, out);
   }
   GLX_LAUNCH_CHECK();
   return GLX_OK;
@@ -352,15 +461,21 @@ extern "C" int glx_sconv_pack_weights(const float* W, int K, int Cin, int Cout, 
 }
 
 extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, const float* Wp,
-                                 const float* bias, const int32_t* nbr, const int32_t* tile_order,
+                                 const float* bias, const float* scale, const float* shift,
+                                 int relu, const int32_t* nbr, const int32_t* tile_order,
                                  int N_out, int K, int Cin, int Cout, float* out, void* workspace,
                                  size_t workspace_bytes, void* stream) {
   GLX_REQUIRE(K > 0 && Cin > 0 && Cout > 0 && N_out >= 0, "glx_sconv_forward: bad sizes");
   if (N_out == 0) return GLX_OK;
   GLX_REQUIRE(in && (W || Wp) && nbr && out, "glx_sconv_forward: null pointer");
+  SconvEpilogue ep{bias, scale, shift, relu};
   if (!mfma_supported(Cin, Cout, K)) {
     GLX_REQUIRE(W, "glx_sconv_forward: raw weights required for channels (%d,%d)", Cin, Cout);
-    return glx_sconv_forward_generic(in, N_in, W, bias, nbr, N_out, K, Cin, Cout, out, stream);
+    long long total = (long long)N_out * Cout;
+    hipLaunchKernelGGL(k_sconv_generic, dim3(glx_divup(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, in, W, ep, nbr, N_out, K, Cin, Cout, out);
+    GLX_LAUNCH_CHECK();
+    return GLX_OK;
   }
   hipStream_t st = (hipStream_t)stream;
   if (!Wp) {  // pack on the fly into the caller's workspace
@@ -374,7 +489,7 @@ extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, cons
     Wp = (const float*)workspace;
   }
   return sc_dispatch(Cin, Cout, [&](auto ci, auto co) {
-    return launch_mfma<decltype(ci)::value, decltype(co)::value>(in, Wp, bias, nbr, tile_order,
+    return launch_mfma<decltype(ci)::value, decltype(co)::value>(in, Wp, ep, nbr, tile_order,
                                                                  N_out, K, out, st);
   });
 }

@@ -96,7 +96,7 @@ class RuleSet:
     def pair_count(self):
         """R = number of (input, output, offset) rules (host sync on first read)."""
         if self._pairs is None:
-            self._pairs = int(self._pairs_dev.item())
+            self._pairs = int((self.nbr[:self.N_out] >= 0).sum().item()) if self.N_out else 0
         return self._pairs
 
     def inverse_table(self):
@@ -114,9 +114,8 @@ def build_subm_rules(x, ksize):
     rs = RuleSet()
     rs.subm, rs.K, rs.N_in, rs.N_out = True, K, N, N
     rs.nbr = torch.empty((max(N, 1), K), dtype=torch.int32, device=x.indices.device)
-    rs._pairs_dev = torch.zeros(1, dtype=torch.int32, device=x.indices.device)
     call("glx_rules_subm", x.indices, N, *idx.grid, idx.bitmap, idx.prefix, idx.rank_to_row,
-         *ksize, rs.nbr, rs._pairs_dev)
+         *ksize, rs.nbr, None)
     rs.tile_order_out = rs.tile_order_in = idx.rank_to_row
     rs.out_indices, rs.out_spatial_shape, rs.out_index = x.indices, list(x.spatial_shape), idx
     rs.in_index, rs.in_indices, rs.in_spatial_shape = idx, x.indices, list(x.spatial_shape)
@@ -149,11 +148,10 @@ def build_strided_rules(x, ksize, stride, padding, dilation=(1, 1, 1)):
     rs.subm, rs.K, rs.N_in, rs.N_out = False, K, N_in, N_out
     rs.out_indices = torch.empty((max(N_out, 1), 4), dtype=torch.int32, device=dev)[:N_out]
     rs.nbr = torch.empty((max(N_out, 1), K), dtype=torch.int32, device=dev)
-    rs._pairs_dev = torch.zeros(1, dtype=torch.int32, device=dev)
     if N_out > 0:
         call("glx_outset_emit", obitmap, oprefix, *ogrid, rs.out_indices)
         call("glx_rules_strided", rs.out_indices, N_out, B, D, H, W, idx.bitmap, idx.prefix,
-             idx.rank_to_row, *ksize, *stride, *padding, rs.nbr, rs._pairs_dev)
+             idx.rank_to_row, *ksize, *stride, *padding, rs.nbr, None)
     rs.out_spatial_shape = out_shape
     rs.out_index = CellIndex(ogrid, obitmap, oprefix, None, None, N_out)  # rows already sorted
     rs.tile_order_out = None
@@ -163,7 +161,7 @@ def build_strided_rules(x, ksize, stride, padding, dilation=(1, 1, 1)):
     return rs
 
 
-_profile_hook = None   # bench.py installs a callable(tag, K, cin, cout, n_out, rules) -> ctx manager
+_profile_hook = None   # bench.py installs a callable(tag, K, cin, cout, n_out, rules), run before the launch
 
 
 def pack_weights(weight_kio):
@@ -178,8 +176,9 @@ def pack_weights(weight_kio):
     return wp
 
 
-def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rules=None, tag="fwd"):
-    """out[j] = sum_k features[nbr[j,k]] @ weight_kio[k]  (weight (K, Cin, Cout))."""
+def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rules=None, tag="fwd",
+           scale=None, shift=None, relu=False):
+    """out[j] = relu?((sum_k features[nbr[j,k]] @ weight_kio[k] + bias) * scale + shift)."""
     K, cin, cout = weight_kio.shape
     out = torch.empty((n_out, cout), dtype=torch.float32, device=features.device)
     if n_out == 0:
@@ -187,13 +186,10 @@ def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rule
     if packed is None:
         packed = pack_weights(weight_kio)
     ws = workspace.get(256, features.device)
-    args = ("glx_sconv_forward", features, features.shape[0], weight_kio, packed, bias, nbr,
-            tile_order, n_out, K, cin, cout, out, ws, size_arg(ws.numel()))
     if _profile_hook is not None:
-        with _profile_hook(tag, K, cin, cout, n_out, rules):
-            call(*args)
-    else:
-        call(*args)
+        _profile_hook(tag, K, cin, cout, n_out, rules)
+    call("glx_sconv_forward", features, features.shape[0], weight_kio, packed, bias, scale, shift,
+         1 if relu else 0, nbr, tile_order, n_out, K, cin, cout, out, ws, size_arg(ws.numel()))
     return out
 
 
@@ -390,13 +386,25 @@ class SparseConvolution(SparseModule):
             x.indice_dict[key] = rs
         return rs
 
-    def forward(self, x):
+    def forward(self, x, fused_bn=None, fused_relu=False):
+        """fused_bn / fused_relu: inference-only folding of the eval-mode BatchNorm1d (+ReLU)
+        that follows this conv into the kernel's epilogue (see SparseSequential)."""
         assert isinstance(x, SparseConvTensor)
         K = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
         w = self.weight.reshape(K, self.in_channels, self.out_channels)
         rs = self._rules(x)
-        feats = SparseConvFunction.apply(x.features, w, self.bias, rs, self.inverse,
-                                         self._packed_weight(w))
+        if fused_bn is not None or fused_relu:
+            scale, shift = _bn_affine(fused_bn) if fused_bn is not None else (None, None)
+            if self.inverse:
+                nbr, order, n_out = rs.inverse_table(), rs.tile_order_in, rs.N_in
+            else:
+                nbr, order, n_out = rs.nbr, rs.tile_order_out, rs.N_out
+            feats = _sconv(x.features.contiguous().float(), w.detach().contiguous(), self.bias, nbr,
+                           order, n_out, packed=self._packed_weight(w), rules=rs, scale=scale,
+                           shift=shift, relu=fused_relu)
+        else:
+            feats = SparseConvFunction.apply(x.features, w, self.bias, rs, self.inverse,
+                                             self._packed_weight(w))
         if self.inverse:
             out = SparseConvTensor(feats, rs.in_indices, rs.in_spatial_shape, x.batch_size,
                                    x.grid, x.voxel_num, x.indice_dict, x.benchmark)
@@ -406,6 +414,29 @@ class SparseConvolution(SparseModule):
                                    x.grid, x.voxel_num, x.indice_dict, x.benchmark)
             out._index = rs.out_index
         return out
+
+
+def _bn_affine(bn):
+    """Eval-mode BatchNorm1d as y = x * scale + shift (cached until its tensors change)."""
+    tag = (bn.weight._version if bn.weight is not None else -1,
+           bn.bias._version if bn.bias is not None else -1,
+           bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr())
+    cache = bn.__dict__.get("_glx_affine")
+    if cache is None or cache[0] != tag:
+        with torch.no_grad():
+            inv = torch.rsqrt(bn.running_var.float() + bn.eps)
+            scale = inv * bn.weight.float() if bn.weight is not None else inv
+            shift = -bn.running_mean.float() * scale
+            if bn.bias is not None:
+                shift = shift + bn.bias.float()
+            cache = (tag, scale.contiguous(), shift.contiguous())
+        bn.__dict__["_glx_affine"] = cache
+    return cache[1], cache[2]
+
+
+def can_fuse_bn(bn):
+    return (isinstance(bn, nn.BatchNorm1d) and not bn.training and bn.track_running_stats
+            and not torch.is_grad_enabled())
 
 
 class SubMConv3d(SparseConvolution):
@@ -459,7 +490,16 @@ class SparseSequential(SparseModule):
         self.add_module(name if name is not None else str(len(self._modules)), module)
 
     def forward(self, x):
-        for m in self._modules.values():
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if (isinstance(m, SparseConvolution) and i + 1 < len(mods) and can_fuse_bn(mods[i + 1])
+                    and isinstance(x, SparseConvTensor)):
+                relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                x = m(x, fused_bn=mods[i + 1], fused_relu=relu)
+                i += 3 if relu else 2
+                continue
             if is_spconv_module(m):
                 x = m(x)
             elif isinstance(x, SparseConvTensor):
@@ -467,4 +507,5 @@ class SparseSequential(SparseModule):
                     x = x.replace_feature(m(x.features))
             else:
                 x = m(x)
+            i += 1
         return x

@@ -38,6 +38,11 @@ const char* glx_last_error(void);
 /* Library ABI version (bumped on any signature change). */
 int glx_abi_version(void);
 
+/* HIP events for kernel-only timing (bench.py); glx_event_elapsed_ms blocks until `stop`. */
+int glx_event_create(void** event);
+int glx_event_destroy(void* event);
+int glx_event_elapsed_ms(void* start, void* stop, float* ms);
+
 /* ------------------------------------------------------------------------------------
  * Cell index ("rank dictionary"): one bit per grid cell + per-word exclusive popcount.
  * rank(cell) = prefix[word] + popc(bits below) enumerates active cells in ascending
@@ -61,7 +66,8 @@ int glx_index_build(const int32_t* indices, int N, int B, int D, int H, int W,
 
 /* Submanifold rule table: nbr[j*K + k] = input row at offset k of output row j, or -1.
  * K = kd*kh*kw, k = (kz*kh + ky)*kw + kx, neighbour cell = cell(j) + (k - ksize/2).
- * pair_count (device int32[1], accumulated: caller zeroes it) = number of valid pairs R.
+ * pair_count: NULL, or device int32[1] (caller zeroes it) accumulating the number of valid
+ * pairs R with one atomic per wave (slow: diagnostics only).
  * Replaces: spconv SubMConv3d indice-pair generation (spconv_backbone.py:12,78,85). */
 int glx_rules_subm(const int32_t* indices, int N, int B, int D, int H, int W,
                    const uint64_t* bitmap, const int32_t* prefix, const int32_t* rank_to_row,
@@ -105,11 +111,16 @@ size_t glx_sconv_packed_bytes(int K, int Cin, int Cout);
 /* Re-order W (K,Cin,Cout) into Wp (glx_sconv_packed_bytes); do it once per weight update. */
 int glx_sconv_pack_weights(const float* W, int K, int Cin, int Cout, float* Wp, void* stream);
 /* W: raw weights (may be NULL when Wp is given); Wp: packed weights or NULL (then W is packed
- * into `workspace`, >= glx_sconv_workspace_bytes). */
+ * into `workspace`, >= glx_sconv_workspace_bytes).  Fused pointwise tail on the output tile:
+ * y = relu?((acc + bias) * scale + shift); bias/scale/shift are (Cout) or NULL -- this is how
+ * an eval-mode BatchNorm1d + ReLU that follows the conv (spconv_backbone.py:21-25) is folded. */
 int glx_sconv_forward(const float* in, int N_in, const float* W, const float* Wp,
-                      const float* bias, const int32_t* nbr, const int32_t* tile_order, int N_out,
-                      int K, int Cin, int Cout, float* out, void* workspace,
-                      size_t workspace_bytes, void* stream);
+                      const float* bias, const float* scale, const float* shift, int relu,
+                      const int32_t* nbr, const int32_t* tile_order, int N_out, int K, int Cin,
+                      int Cout, float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* Bracket the NEXT glx_sconv_forward MFMA launch of this host thread with two HIP events
+ * (hipExtLaunchKernelGGL start/stop): kernel-only duration for bench.py's roofline. */
+int glx_profile_next_sconv(void* start_event, void* stop_event);
 /* Reference-quality scalar kernel (any channel count); used for tiny Cin and as a
  * device-side cross-check of the MFMA kernel. */
 int glx_sconv_forward_generic(const float* in, int N_in, const float* W, const float* bias,
