@@ -64,31 +64,31 @@ struct SconvEpilogue {
   int relu;
 };
 
-#define SC_NW 8                      // waves per block
-#define SC_THREADS (SC_NW * 64)
-
-template <int CIN, int COUT>
+// Tile geometry: TR output rows per block, NW waves per block, NBUF LDS weight buffers.
+template <int CIN, int COUT, int TR_, int NW_, int NBUF_>
 struct SconvTile {
   using C = SconvCfg<CIN, COUT>;
-  static constexpr int TR = COUT >= 128 ? 128 : 256;          // output rows per block
-  static constexpr int MAXC = TR / (16 * SC_NW);              // chunks per wave per offset
+  static constexpr int TR = TR_, NW = NW_, NBUF = NBUF_;
+  static constexpr int THREADS = NW * 64;
+  static constexpr int MAXC = (TR + 16 * NW - 1) / (16 * NW);   // chunks per wave per offset
   static constexpr int ACC_LD = COUT + 4;
-  static constexpr size_t fixed_bytes =
-      (size_t)TR * ACC_LD * 4 + (size_t)SC_MAXK * TR * 5 + (TR + 32 + 32 * (TR / 64)) * 4 + 64;
-  static constexpr int NBUF = (fixed_bytes + 2 * (size_t)C::IMG * 4 <= 160 * 1024) ? 2 : 1;
-  static constexpr size_t lds_bytes = fixed_bytes + (size_t)NBUF * C::IMG * 4;
+  static constexpr int LW = TR / 64;                            // waves that own row slots
+  static constexpr size_t lds_bytes = (size_t)TR * ACC_LD * 4 + (size_t)SC_MAXK * TR * 5 +
+                                      (TR + 32 + 32 * LW) * 4 + 64 + (size_t)NBUF * C::IMG * 4;
+  static_assert(LW <= NW, "row-slot waves exceed block");
+  static_assert(TR <= 256, "row slots are stored as bytes");
 };
 
 // gather the CQ-float slice of up to MAXC chunks of offset k owned by this wave
-template <int CIN, int COUT>
+template <int CIN, int COUT, class T>
 __device__ __forceinline__ void sc_gather(const float* __restrict__ in, const int* s_pin,
                                           int k, int cnt, int wave, int r, int q,
-                                          float (&A)[SconvTile<CIN, COUT>::MAXC][SconvCfg<CIN, COUT>::CQ]) {
+                                          float (&A)[T::MAXC][SconvCfg<CIN, COUT>::CQ],
+                                          bool (&valid)[T::MAXC]) {
   using C = SconvCfg<CIN, COUT>;
-  using T = SconvTile<CIN, COUT>;
 #pragma unroll
   for (int j = 0; j < T::MAXC; ++j) {
-    const int c = ((wave - k) & (SC_NW - 1)) + j * SC_NW;
+    const int c = ((wave - k) & (T::NW - 1)) + j * T::NW;
     const int p = c * 16 + r;
     int irow = -1;
     if (p < cnt) irow = s_pin[k * T::TR + p];
@@ -104,26 +104,26 @@ __device__ __forceinline__ void sc_gather(const float* __restrict__ in, const in
 #pragma unroll
         for (int i = 0; i < C::CQ; ++i) A[j][i] = ap[i];
       }
-      if (irow < 0) {
-#pragma unroll
-        for (int i = 0; i < C::CQ; ++i) A[j][i] = 0.f;
-      }
     }
+    valid[j] = irow >= 0;   // zero-fill is applied at use: writing A here would stall on vmcnt(0)
   }
 }
 
 // MFMA the wave's chunks of offset k against the staged W[k] and add into the LDS tile
-template <int CIN, int COUT>
+template <int CIN, int COUT, class T>
 __device__ __forceinline__ void sc_compute(const float* s_w, float* s_acc,
                                            const unsigned char* s_pslot, int k, int cnt, int wave,
                                            int r, int q,
-                                           const float (&A)[SconvTile<CIN, COUT>::MAXC][SconvCfg<CIN, COUT>::CQ]) {
+                                           const float (&A)[T::MAXC][SconvCfg<CIN, COUT>::CQ],
+                                           const bool (&valid)[T::MAXC]) {
   using C = SconvCfg<CIN, COUT>;
-  using T = SconvTile<CIN, COUT>;
 #pragma unroll
   for (int j = 0; j < T::MAXC; ++j) {
-    const int c = ((wave - k) & (SC_NW - 1)) + j * SC_NW;
+    const int c = ((wave - k) & (T::NW - 1)) + j * T::NW;
     if (c * 16 >= cnt) continue;   // wave-uniform
+    float Am[C::CQ];
+#pragma unroll
+    for (int i = 0; i < C::CQ; ++i) Am[i] = valid[j] ? A[j][i] : 0.f;
     // Operands swapped (W^T as the MFMA "A", gathered rows as "B"): D[i = cout][j = pair], so
     // lane (pair r, q) ends up with 4 CONSECUTIVE output channels 16ct + 4q .. +3 of its pair.
     f32x4 acc[C::NT];
@@ -136,16 +136,16 @@ __device__ __forceinline__ void sc_compute(const float* s_w, float* s_acc,
         const float* bp = s_w + (h * 4 + q) * C::QSTRIDE + (t * 16 + r) * C::NC;
         if constexpr (C::NC == 4) {
           f32x4 bv = *reinterpret_cast<const f32x4*>(bp);
-          acc[h * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[0], A[j][t], acc[h * 4 + 0], 0, 0, 0);
-          acc[h * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[1], A[j][t], acc[h * 4 + 1], 0, 0, 0);
-          acc[h * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[2], A[j][t], acc[h * 4 + 2], 0, 0, 0);
-          acc[h * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[3], A[j][t], acc[h * 4 + 3], 0, 0, 0);
+          acc[h * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[0], Am[t], acc[h * 4 + 0], 0, 0, 0);
+          acc[h * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[1], Am[t], acc[h * 4 + 1], 0, 0, 0);
+          acc[h * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[2], Am[t], acc[h * 4 + 2], 0, 0, 0);
+          acc[h * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[3], Am[t], acc[h * 4 + 3], 0, 0, 0);
         } else if constexpr (C::NC == 2) {
           float2 bv = *reinterpret_cast<const float2*>(bp);
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.x, A[j][t], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.y, A[j][t], acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.x, Am[t], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.y, Am[t], acc[1], 0, 0, 0);
         } else {
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bp[0], A[j][t], acc[0], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bp[0], Am[t], acc[0], 0, 0, 0);
         }
       }
     }
@@ -170,14 +170,15 @@ __device__ __forceinline__ void sc_compute(const float* s_w, float* s_acc,
 // distinct and offsets are separated by a barrier, so every output element is summed in a fixed
 // order: bitwise reproducible, no global atomics.  W[k+1] streams into the second LDS buffer
 // and the next offset's input rows into registers while offset k multiplies.
-template <int CIN, int COUT>
-__global__ __launch_bounds__(SC_THREADS) void k_sconv_mfma(
+template <int CIN, int COUT, int TR_, int NW_, int NBUF_>
+__global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
     const float* __restrict__ in, const float* __restrict__ Wp, SconvEpilogue ep,
     const int* __restrict__ nbr, const int* __restrict__ tile_order, int N_out, int K,
     float* __restrict__ out) {
   using C = SconvCfg<CIN, COUT>;
-  using T = SconvTile<CIN, COUT>;
-  constexpr int TR = T::TR, ACC_LD = T::ACC_LD, NBUF = T::NBUF, LW = TR / 64;
+  using T = SconvTile<CIN, COUT, TR_, NW_, NBUF_>;
+  constexpr int TR = T::TR, ACC_LD = T::ACC_LD, NBUF = T::NBUF, LW = T::LW;
+  constexpr int SC_THREADS = T::THREADS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_acc = smem;                                        // TR * ACC_LD
   float* s_w = s_acc + TR * ACC_LD;                           // NBUF * IMG
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_sconv_mfma(
   }
 
   float A0[T::MAXC][C::CQ], A1[T::MAXC][C::CQ];
+  bool V0[T::MAXC], V1[T::MAXC];
   unsigned rem = mask;
   int k = -1, cnt = 0;
   if (rem) {
@@ -268,13 +270,13 @@ __global__ __launch_bounds__(SC_THREADS) void k_sconv_mfma(
     cnt = s_cnt[k];
     SC_STAGE_LOAD(k);
     SC_STAGE_STORE(0);
-    sc_gather<CIN, COUT>(in, s_pin, k, cnt, wave, r, q, A0);
+    sc_gather<CIN, COUT, T>(in, s_pin, k, cnt, wave, r, q, A0, V0);
   }
   __syncthreads();
 
   int buf = 0;
   // one phase: prefetch (W image + input rows) of the next offset, multiply the current one
-#define SC_PHASE(CUR, NXT)                                                                  \
+#define SC_PHASE(CUR, NXT, VCUR, VNXT)                                                                 \
   {                                                                                         \
     int kn_ = -1, cntn_ = 0;                                                                \
     if (rem) {                                                                              \
@@ -282,10 +284,10 @@ __global__ __launch_bounds__(SC_THREADS) void k_sconv_mfma(
       rem &= rem - 1;                                                                       \
       cntn_ = s_cnt[kn_];                                                                   \
       SC_STAGE_LOAD(kn_);                                                                   \
-      sc_gather<CIN, COUT>(in, s_pin, kn_, cntn_, wave, r, q, NXT);                         \
+      sc_gather<CIN, COUT, T>(in, s_pin, kn_, cntn_, wave, r, q, NXT, VNXT);                         \
     }                                                                                       \
-    sc_compute<CIN, COUT>(s_w + (NBUF == 2 ? buf : 0) * C::IMG, s_acc, s_pslot, k, cnt,     \
-                          wave, r, q, CUR);                                                 \
+    sc_compute<CIN, COUT, T>(s_w + (NBUF == 2 ? buf : 0) * C::IMG, s_acc, s_pslot, k, cnt,     \
+                          wave, r, q, CUR, VCUR);                                           \
     if (NBUF == 1) __syncthreads();                                                         \
     if (kn_ >= 0) SC_STAGE_STORE(NBUF == 2 ? (buf ^ 1) : 0);                                \
     __syncthreads();                                                                        \
@@ -294,9 +296,9 @@ __global__ __launch_bounds__(SC_THREADS) void k_sconv_mfma(
     cnt = cntn_;                                                                            \
   }
   while (k >= 0) {
-    SC_PHASE(A0, A1);
+    SC_PHASE(A0, A1, V0, V1);
     if (k < 0) break;
-    SC_PHASE(A1, A0);
+    SC_PHASE(A1, A0, V1, V0);
   }
 #undef SC_PHASE
 #undef SC_STAGE_LOAD
@@ -318,6 +320,400 @@ __global__ __launch_bounds__(SC_THREADS) void k_sconv_mfma(
     }
     *reinterpret_cast<f32x4*>(out + (long long)orow * COUT + 4 * c4) = v;
   }
+}
+
+// ==================================================================== wave-private kernel
+// Default sparse-conv kernel.  Every wave owns TRW consecutive output rows and everything
+// about them (rule compaction, accumulator tile, epilogue), so the kernel has NO barriers and
+// no shared state between waves: a wave streams W[k] fragments from L2 straight into
+// registers (prefetched one phase ahead), gathers 16 rule pairs at a time (prefetched one
+// chunk ahead), multiplies them on the matrix pipe and adds the 16x(16*NTG) result into its
+// private LDS tile with plain ds_read/ds_write (in-order within a wave, so the summation order
+// of every output element is fixed: bitwise reproducible).
+template <int CIN, int COUT>
+struct WpCfg {
+  static constexpr int CQ = CIN / 4;
+  static constexpr int CG0 = 4096 / CIN;                              // cols per W register set
+  static constexpr int CG = COUT < CG0 ? COUT : (CG0 < 16 ? 16 : CG0);
+  static constexpr int NG = COUT / CG;                                 // column groups
+  static constexpr int NTG = CG / 16;                                  // 16-col tiles per group
+  static constexpr int TRW = 48;                                       // rows per wave
+  static constexpr int NWB = 4;                                        // waves per block
+  static constexpr int ACC_LD = COUT + 4;
+  static constexpr int WAVE_LDS_DW =
+      TRW * ACC_LD + SC_MAXK * TRW + 32 + TRW + (SC_MAXK * TRW + 3) / 4;
+  static constexpr size_t lds_bytes = (size_t)NWB * WAVE_LDS_DW * 4;
+  static constexpr int IMG = CIN * COUT;                               // dwords per offset
+};
+
+// W (K, CIN, COUT) -> register-fragment order:
+//   img[k][g][q][t][n][c] = W[k][q*CQ+t][g*CG + c*16 + n]
+template <int CIN, int COUT>
+__global__ void k_pack_weights_wp(const float* __restrict__ W, int K, float* __restrict__ Wp) {
+  using C = WpCfg<CIN, COUT>;
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= K * CIN * COUT) return;
+  int co = e % COUT;
+  int ci = (e / COUT) % CIN;
+  int k = e / (COUT * CIN);
+  int g = co / C::CG, cl = co % C::CG;
+  int c = cl / 16, n = cl % 16;
+  int q = ci / C::CQ, t = ci % C::CQ;
+  Wp[(size_t)k * C::IMG + ((((size_t)g * 4 + q) * C::CQ + t) * 16 + n) * C::NTG + c] = W[e];
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void k_sconv_wp(
+    const float* __restrict__ in, const float* __restrict__ Wp, SconvEpilogue ep,
+    const int* __restrict__ nbr, const int* __restrict__ tile_order, int N_out, int K,
+    float* __restrict__ out) {
+  using C = WpCfg<CIN, COUT>;
+  constexpr int TRW = C::TRW, ACC_LD = C::ACC_LD, CQ = C::CQ, NTG = C::NTG, NG = C::NG;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  float* s_acc = smem + (size_t)wave * C::WAVE_LDS_DW;                 // TRW * ACC_LD
+  int* s_pin = reinterpret_cast<int*>(s_acc + TRW * ACC_LD);           // SC_MAXK * TRW
+  int* s_cnt = s_pin + SC_MAXK * TRW;                                  // 32
+  int* s_rows = s_cnt + 32;                                            // TRW
+  unsigned char* s_pslot = reinterpret_cast<unsigned char*>(s_rows + TRW);  // SC_MAXK * TRW
+  const long long row0 = ((long long)blockIdx.x * C::NWB + wave) * TRW;
+  if (row0 >= N_out) return;     // whole wave idle (no barriers anywhere below)
+
+  // ---- my rows, their neighbour lists (registers), per-offset compaction (wave ballots)
+  int my_row = -1;
+  if (lane < TRW && row0 + lane < N_out) my_row = tile_order ? tile_order[row0 + lane] : (int)(row0 + lane);
+  if (lane < TRW) s_rows[lane] = my_row;
+  for (int i = lane; i < TRW * ACC_LD / 4; i += 64)
+    reinterpret_cast<f32x4*>(s_acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  unsigned mask = 0;
+#pragma unroll
+  for (int k = 0; k < SC_MAXK; ++k) {
+    int nb = (k < K && my_row >= 0) ? nbr[(long long)my_row * K + k] : -1;
+    unsigned long long b = __ballot(nb >= 0);
+    if (nb >= 0) {
+      int pos = k * TRW + __popcll(b & ((1ull << lane) - 1ull));
+      s_pin[pos] = nb;
+      s_pslot[pos] = (unsigned char)lane;
+    }
+    int n = __popcll(b);
+    if (lane == 0) s_cnt[k] = n;
+    if (n) mask |= 1u << k;
+  }
+  mask = __builtin_amdgcn_readfirstlane(mask);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- register sets: W fragment of the current / next phase, input rows of the current / next chunk
+  float Wc[CQ][NTG], Wn[CQ][NTG];
+  float Ac[CQ], An[CQ];
+  bool an_valid = false;
+
+#define WP_LOAD_W(KK, GG)                                                                    \
+  {                                                                                          \
+    const float* wp_ = Wp + (size_t)(KK) * C::IMG + (((size_t)(GG) * 4 + q) * CQ * 16 + r) * NTG; \
+    _Pragma("unroll") for (int t_ = 0; t_ < CQ; ++t_) {                                      \
+      if constexpr (NTG == 4) {                                                              \
+        f32x4 v_ = *reinterpret_cast<const f32x4*>(wp_ + t_ * 16 * NTG);                     \
+        Wn[t_][0] = v_[0]; Wn[t_][1] = v_[1]; Wn[t_][2] = v_[2]; Wn[t_][3] = v_[3];          \
+      } else if constexpr (NTG == 2) {                                                       \
+        float2 v_ = *reinterpret_cast<const float2*>(wp_ + t_ * 16 * NTG);                   \
+        Wn[t_][0] = v_.x; Wn[t_][1] = v_.y;                                                  \
+      } else {                                                                               \
+        Wn[t_][0] = wp_[t_ * 16 * NTG];                                                      \
+      }                                                                                      \
+    }                                                                                        \
+  }
+#define WP_GATHER(KK, CC, CNT)                                                               \
+  {                                                                                          \
+    int p_ = (CC) * 16 + r;                                                                  \
+    int irow_ = (p_ < (CNT)) ? s_pin[(KK) * TRW + p_] : -1;                                  \
+    const float* ap_ = in + (long long)(irow_ < 0 ? 0 : irow_) * CIN + q * CQ;               \
+    if constexpr (CQ % 4 == 0) {                                                             \
+      _Pragma("unroll") for (int i_ = 0; i_ < CQ / 4; ++i_) {                                \
+        f32x4 v_ = reinterpret_cast<const f32x4*>(ap_)[i_];                                  \
+        An[4 * i_ + 0] = v_[0]; An[4 * i_ + 1] = v_[1]; An[4 * i_ + 2] = v_[2]; An[4 * i_ + 3] = v_[3]; \
+      }                                                                                      \
+    } else {                                                                                 \
+      _Pragma("unroll") for (int i_ = 0; i_ < CQ; ++i_) An[i_] = ap_[i_];                    \
+    }                                                                                        \
+    an_valid = irow_ >= 0;                                                                   \
+  }
+
+  unsigned rem = mask;
+  int k = -1, g = 0, cnt = 0;
+  if (rem) {
+    k = __builtin_ctz(rem);
+    rem &= rem - 1;
+    cnt = s_cnt[k];
+    WP_LOAD_W(k, 0);
+    WP_GATHER(k, 0, cnt);
+  }
+  while (k >= 0) {
+    // ---- phase (k, g): promote the prefetched W set, start fetching the next one
+#pragma unroll
+    for (int t = 0; t < CQ; ++t)
+#pragma unroll
+      for (int c = 0; c < NTG; ++c) Wc[t][c] = Wn[t][c];
+    int k2 = k, g2 = g + 1, cnt2 = cnt;
+    if (g2 == NG) {
+      g2 = 0;
+      if (rem) {
+        k2 = __builtin_ctz(rem);
+        rem &= rem - 1;
+        cnt2 = s_cnt[k2];
+      } else {
+        k2 = -1;
+      }
+    }
+    if (k2 >= 0) WP_LOAD_W(k2, g2);
+    const int nc = (cnt + 15) >> 4;
+    for (int c = 0; c < nc; ++c) {
+#pragma unroll
+      for (int i = 0; i < CQ; ++i) Ac[i] = an_valid ? An[i] : 0.f;
+      if (c + 1 < nc) {
+        WP_GATHER(k, c + 1, cnt);
+      } else if (k2 >= 0) {
+        WP_GATHER(k2, 0, cnt2);
+      }
+      // operands swapped: D[i = cout][j = pair]; lane (pair r, q) gets channels 16ct+4q..+3
+      f32x4 acc[NTG];
+#pragma unroll
+      for (int ct = 0; ct < NTG; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < CQ; ++t)
+#pragma unroll
+        for (int ct = 0; ct < NTG; ++ct)
+          acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[t][ct], Ac[t], acc[ct], 0, 0, 0);
+      const int p = c * 16 + r;
+      if (p < cnt) {
+        float* dst = s_acc + (int)s_pslot[k * TRW + p] * ACC_LD + g * C::CG + 4 * q;
+#pragma unroll
+        for (int ct = 0; ct < NTG; ++ct) {
+          f32x4 v = *reinterpret_cast<f32x4*>(dst + ct * 16);
+          v += acc[ct];
+          *reinterpret_cast<f32x4*>(dst + ct * 16) = v;
+        }
+      }
+    }
+    k = k2; g = g2; cnt = cnt2;
+  }
+#undef WP_LOAD_W
+#undef WP_GATHER
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- epilogue: this wave's rows, coalesced float4 stores with the fused pointwise tail
+  constexpr int C4 = COUT / 4;
+  for (int i = lane; i < TRW * C4; i += 64) {
+    int rr = i / C4, c4 = i - rr * C4;
+    int orow = s_rows[rr];
+    if (orow < 0) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(s_acc + rr * ACC_LD + 4 * c4);
+    const int co = 4 * c4;
+    if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + co);
+    if (ep.scale) v *= *reinterpret_cast<const f32x4*>(ep.scale + co);
+    if (ep.shift) v += *reinterpret_cast<const f32x4*>(ep.shift + co);
+    if (ep.relu) {
+      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(out + (long long)orow * COUT + 4 * c4) = v;
+  }
+}
+
+// ==================================================================== register-tile kernel
+// Default sparse-conv kernel.  One wave (= one 64-thread block, so the hardware dispatcher
+// load-balances the very uneven tiles) owns two 16-row output tiles whose accumulators live in
+// registers for the whole kernel: no LDS accumulation, no barriers, no atomics.  For every
+// kernel offset present in either tile the wave streams the W[k] fragment from L2 into
+// registers (prefetched one offset ahead), gathers the 16 neighbour rows of a tile (prefetched
+// one tile ahead; each load instruction reads one full 64-B segment per row) and issues
+// CQ x NTG v_mfma_f32_16x16x4_f32.  Output channels wider than a register set are processed in
+// column groups.  Summation order per output element is fixed: bitwise reproducible.
+template <int CIN, int COUT>
+struct RtCfg {
+  static constexpr int CQ = CIN / 4;
+  static constexpr int CG0 = 4096 / CIN;                              // cols per W register set
+  static constexpr int CG = COUT < CG0 ? COUT : (CG0 < 16 ? 16 : CG0);
+  static constexpr int NG = COUT / CG;                                 // column groups
+  static constexpr int NTG = CG / 16;                                  // 16-col tiles per group
+  static constexpr int IMG = CIN * COUT;                               // dwords per offset
+  static constexpr int ROWS = 32;                                      // rows per wave (2 tiles)
+};
+
+// channel handled by lane quad q at k-step t: for CIN >= 16 step t = 4i+j reads channel
+// 16i + 4q + j (so load i of the gather covers a contiguous 64-B segment of the row).
+template <int CIN>
+__host__ __device__ constexpr int rt_channel(int q, int t) {
+  return CIN >= 16 ? 16 * (t / 4) + 4 * q + (t % 4) : q * (CIN / 4) + t;
+}
+
+// W (K, CIN, COUT) -> img[k][g][q][t][n][c] = W[k][rt_channel(q,t)][g*CG + c*16 + n]
+template <int CIN, int COUT>
+__global__ void k_pack_weights_rt(const float* __restrict__ W, int K, float* __restrict__ Wp) {
+  using C = RtCfg<CIN, COUT>;
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= K * CIN * COUT) return;
+  int c = e % C::NTG;
+  int n = (e / C::NTG) % 16;
+  int t = (e / (C::NTG * 16)) % C::CQ;
+  int q = (e / (C::NTG * 16 * C::CQ)) % 4;
+  int g = (e / (C::NTG * 16 * C::CQ * 4)) % C::NG;
+  int k = e / (C::NTG * 16 * C::CQ * 4 * C::NG);
+  int ci = rt_channel<CIN>(q, t);
+  int co = g * C::CG + c * 16 + n;
+  Wp[e] = W[((size_t)k * CIN + ci) * COUT + co];
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(64, 2) void k_sconv_rt(
+    const float* __restrict__ in, const float* __restrict__ Wp, SconvEpilogue ep,
+    const int* __restrict__ nbr, const int* __restrict__ tile_order, int N_out, int K,
+    float* __restrict__ out) {
+  using C = RtCfg<CIN, COUT>;
+  constexpr int CQ = C::CQ, NTG = C::NTG, NG = C::NG;
+  __shared__ int s_nbr[2 * 16 * (SC_MAXK + 1)];
+  const int lane = threadIdx.x;
+  const int r = lane & 15, q = lane >> 4;
+  const long long row0 = (long long)blockIdx.x * C::ROWS;
+
+  // ---- neighbour table of my 32 rows -> LDS; per-tile offset masks
+  int my_row = -1;      // lanes 0..31: output row of slot `lane`
+  if (lane < 32 && row0 + lane < N_out) my_row = tile_order ? tile_order[row0 + lane] : (int)(row0 + lane);
+  unsigned m0 = 0, m1 = 0;
+  for (int e = lane; e < 32 * K; e += 64) {
+    int slot = e / K, kk = e - slot * K;
+    int orow = __shfl(my_row, slot, 64);
+    int v = orow >= 0 ? nbr[(long long)orow * K + kk] : -1;
+    s_nbr[slot * (SC_MAXK + 1) + kk] = v;
+    if (v >= 0) { if (slot < 16) m0 |= 1u << kk; else m1 |= 1u << kk; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    m0 |= __shfl_xor(m0, o, 64);
+    m1 |= __shfl_xor(m1, o, 64);
+  }
+  m0 = __builtin_amdgcn_readfirstlane(m0);
+  m1 = __builtin_amdgcn_readfirstlane(m1);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int orow0 = __shfl(my_row, r, 64), orow1 = __shfl(my_row, 16 + r, 64);
+
+  float Wc[CQ][NTG], Wn[CQ][NTG];
+  float Ac[CQ], An[CQ];
+  bool an_valid = false;
+
+#define RT_LOAD_W(KK, GG)                                                                    \
+  {                                                                                          \
+    const float* wp_ = Wp + (size_t)(KK) * C::IMG + (((size_t)(GG) * 4 + q) * CQ * 16 + r) * NTG; \
+    _Pragma("unroll") for (int t_ = 0; t_ < CQ; ++t_) {                                      \
+      if constexpr (NTG == 4) {                                                              \
+        f32x4 v_ = *reinterpret_cast<const f32x4*>(wp_ + t_ * 16 * NTG);                     \
+        Wn[t_][0] = v_[0]; Wn[t_][1] = v_[1]; Wn[t_][2] = v_[2]; Wn[t_][3] = v_[3];          \
+      } else if constexpr (NTG == 2) {                                                       \
+        float2 v_ = *reinterpret_cast<const float2*>(wp_ + t_ * 16 * NTG);                   \
+        Wn[t_][0] = v_.x; Wn[t_][1] = v_.y;                                                  \
+      } else if constexpr (NTG == 8) {                                                       \
+        f32x4 v_ = *reinterpret_cast<const f32x4*>(wp_ + t_ * 16 * NTG);                     \
+        f32x4 u_ = *reinterpret_cast<const f32x4*>(wp_ + t_ * 16 * NTG + 4);                 \
+        Wn[t_][0] = v_[0]; Wn[t_][1] = v_[1]; Wn[t_][2] = v_[2]; Wn[t_][3] = v_[3];          \
+        Wn[t_][4] = u_[0]; Wn[t_][5] = u_[1]; Wn[t_][6] = u_[2]; Wn[t_][7] = u_[3];          \
+      } else {                                                                               \
+        Wn[t_][0] = wp_[t_ * 16 * NTG];                                                      \
+      }                                                                                      \
+    }                                                                                        \
+  }
+  // gather tile S (0/1) at offset KK: lane (r,q) reads 16-B pieces q of the row's 64-B segments
+#define RT_GATHER(KK, S)                                                                     \
+  {                                                                                          \
+    int irow_ = s_nbr[((S) * 16 + r) * (SC_MAXK + 1) + (KK)];                                \
+    const float* ap_ = in + (long long)(irow_ < 0 ? 0 : irow_) * CIN;                        \
+    if constexpr (CIN >= 16) {                                                               \
+      _Pragma("unroll") for (int i_ = 0; i_ < CQ / 4; ++i_) {                                \
+        f32x4 v_ = *reinterpret_cast<const f32x4*>(ap_ + 16 * i_ + 4 * q);                   \
+        An[4 * i_ + 0] = v_[0]; An[4 * i_ + 1] = v_[1]; An[4 * i_ + 2] = v_[2]; An[4 * i_ + 3] = v_[3]; \
+      }                                                                                      \
+    } else {                                                                                 \
+      _Pragma("unroll") for (int i_ = 0; i_ < CQ; ++i_) An[i_] = ap_[q * CQ + i_];           \
+    }                                                                                        \
+    an_valid = irow_ >= 0;   /* zeroing happens at promotion time: a write to An here would  \
+                                force a vmcnt(0) wait right behind the prefetch loads */     \
+  }
+  // next (offset, tile) item after (KK, S) in the order k-major, tile-minor
+#define RT_NEXT(KK, S, REM, NK, NS)                                                          \
+  {                                                                                          \
+    NK = -1; NS = 0;                                                                         \
+    if ((S) == 0 && ((m1 >> (KK)) & 1u)) { NK = (KK); NS = 1; }                              \
+    else if (REM) { NK = __builtin_ctz(REM); NS = ((m0 >> NK) & 1u) ? 0 : 1; }              \
+  }
+
+  const unsigned mu = m0 | m1;
+  for (int g = 0; g < NG; ++g) {
+    f32x4 acc0[NTG], acc1[NTG];
+#pragma unroll
+    for (int ct = 0; ct < NTG; ++ct) { acc0[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    unsigned rem = mu;
+    int k = -1, sidx = 0;
+    if (rem) {
+      k = __builtin_ctz(rem);
+      rem &= rem - 1;
+      sidx = ((m0 >> k) & 1u) ? 0 : 1;
+      RT_LOAD_W(k, g);
+      if (sidx == 0) { RT_GATHER(k, 0); } else { RT_GATHER(k, 1); }
+    }
+    bool new_k = true;
+    while (k >= 0) {
+      if (new_k) {   // promote the prefetched W set, start fetching the next offset's
+#pragma unroll
+        for (int t = 0; t < CQ; ++t)
+#pragma unroll
+          for (int c = 0; c < NTG; ++c) Wc[t][c] = Wn[t][c];
+        if (rem) RT_LOAD_W(__builtin_ctz(rem), g);
+      }
+#pragma unroll
+      for (int i = 0; i < CQ; ++i) Ac[i] = an_valid ? An[i] : 0.f;
+      int nk, ns;
+      RT_NEXT(k, sidx, rem, nk, ns);
+      if (nk >= 0) {
+        if (ns == 0) { RT_GATHER(nk, 0); } else { RT_GATHER(nk, 1); }
+      }
+      // operands swapped: D[i = cout][j = row]; lane (row r, q) gets channels 16ct+4q..+3
+      if (sidx == 0) {
+#pragma unroll
+        for (int t = 0; t < CQ; ++t)
+#pragma unroll
+          for (int ct = 0; ct < NTG; ++ct)
+            acc0[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[t][ct], Ac[t], acc0[ct], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int t = 0; t < CQ; ++t)
+#pragma unroll
+          for (int ct = 0; ct < NTG; ++ct)
+            acc1[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[t][ct], Ac[t], acc1[ct], 0, 0, 0);
+      }
+      new_k = nk != k;
+      if (new_k && nk >= 0) rem &= rem - 1;
+      k = nk; sidx = ns;
+    }
+    // ---- epilogue of this column group straight from registers
+#pragma unroll
+    for (int ct = 0; ct < NTG; ++ct) {
+      const int co = g * C::CG + ct * 16 + 4 * q;
+      f32x4 v0 = acc0[ct], v1 = acc1[ct];
+      if (ep.bias) { f32x4 b = *reinterpret_cast<const f32x4*>(ep.bias + co); v0 += b; v1 += b; }
+      if (ep.scale) { f32x4 b = *reinterpret_cast<const f32x4*>(ep.scale + co); v0 *= b; v1 *= b; }
+      if (ep.shift) { f32x4 b = *reinterpret_cast<const f32x4*>(ep.shift + co); v0 += b; v1 += b; }
+      if (ep.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(v0[j], 0.f); v1[j] = fmaxf(v1[j], 0.f); }
+      }
+      if (orow0 >= 0) *reinterpret_cast<f32x4*>(out + (long long)orow0 * COUT + co) = v0;
+      if (orow1 >= 0) *reinterpret_cast<f32x4*>(out + (long long)orow1 * COUT + co) = v1;
+    }
+  }
+#undef RT_LOAD_W
+#undef RT_GATHER
+#undef RT_NEXT
 }
 
 // ------------------------------------------------------------------ generic scalar kernel
@@ -365,8 +761,9 @@ static bool mfma_supported(int Cin, int Cout, int K) {
 }
 
 template <int CIN, int COUT>
-static size_t img_bytes() {
-  return (size_t)SconvCfg<CIN, COUT>::IMG * sizeof(float);
+static size_t img_bytes() {   // block-kernel image + wave-private-kernel image, per offset
+  return (size_t)(SconvCfg<CIN, COUT>::IMG + WpCfg<CIN, COUT>::IMG + RtCfg<CIN, COUT>::IMG) *
+         sizeof(float);
 }
 
 template <class F>
@@ -414,34 +811,120 @@ static int pack_weights(const float* W, int K, float* Wp, hipStream_t st) {
   int nel = K * CI * CO;
   hipLaunchKernelGGL((k_pack_weights<CI, CO>), dim3(glx_divup(nel, 256)), dim3(256), 0, st, W, K,
                      Wp);
+  hipLaunchKernelGGL((k_pack_weights_wp<CI, CO>), dim3(glx_divup(nel, 256)), dim3(256), 0, st, W,
+                     K, Wp + (size_t)K * C::IMG);
+  hipLaunchKernelGGL((k_pack_weights_rt<CI, CO>), dim3(glx_divup(nel, 256)), dim3(256), 0, st, W,
+                     K, Wp + (size_t)K * (C::IMG + WpCfg<CI, CO>::IMG));
   GLX_LAUNCH_CHECK();
   return GLX_OK;
+}
+
+static int g_sconv_variant = -1;   // experiment knob (glx_sconv_set_variant); -1 = default
+extern "C" int glx_sconv_set_variant(int v) {
+  g_sconv_variant = v;
+  return GLX_OK;
+}
+
+template <int CI, int CO, int TR, int NW, int NBUF>
+static int launch_tile(const float* in, const float* Wp, const SconvEpilogue& ep,
+                       const int32_t* nbr, const int32_t* tile_order, int N_out, int K, float* out,
+                       hipStream_t st) {
+  using T = SconvTile<CI, CO, TR, NW, NBUF>;
+  if constexpr (T::lds_bytes > 160 * 1024) {
+    glx_set_error("sparse conv tile (%d,%d,TR=%d,NW=%d,NBUF=%d) needs %zu B of LDS", CI, CO, TR, NW,
+                  NBUF, (size_t)T::lds_bytes);
+    return GLX_EINVAL;
+  } else {
+    static bool attr_set = false;   // one per instantiation
+    auto kern = k_sconv_mfma<CI, CO, TR, NW, NBUF>;
+    const size_t lds = T::lds_bytes;
+    if (!attr_set) {
+      GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+      attr_set = true;
+    }
+    int nblocks = glx_divup(N_out, TR);
+    if (g_prof_start && g_prof_stop) {
+      hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(T::THREADS), lds, st, g_prof_start,
+                            g_prof_stop, 0, in, Wp, ep, nbr, tile_order, N_out, K, out);
+      g_prof_start = g_prof_stop = nullptr;
+    } else {
+      hipLaunchKernelGGL(kern, dim3(nblocks), dim3(T::THREADS), lds, st, in, Wp, ep, nbr,
+                         tile_order, N_out, K, out);
+    }
+    GLX_LAUNCH_CHECK();
+    return GLX_OK;
+  }
 }
 
 template <int CI, int CO>
 static int launch_mfma(const float* in, const float* Wp, const SconvEpilogue& ep,
                        const int32_t* nbr, const int32_t* tile_order, int N_out, int K, float* out,
                        hipStream_t st) {
-  using T = SconvTile<CI, CO>;
-  static bool attr_set = false;   // one instantiation per (CI, CO)
-  auto kern = k_sconv_mfma<CI, CO>;
-  const size_t lds = T::lds_bytes;
-  if (!attr_set) {
-    GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
-    attr_set = true;
+#define SC_GO(TR, NW, NBUF) \
+  return launch_tile<CI, CO, TR, NW, NBUF>(in, Wp, ep, nbr, tile_order, N_out, K, out, st)
+  constexpr bool big = CO >= 128;
+  switch (g_sconv_variant) {
+    case 1: SC_GO(128, 4, 1);
+    case 2: SC_GO(128, 8, 1);
+    case 3: SC_GO(128, 4, 2);
+    case 4: SC_GO(128, 8, 2);
+    case 5: SC_GO(64, 4, 1);
+    case 6: SC_GO(64, 4, 2);
+    case 7: if constexpr (!big) { SC_GO(256, 8, 1); } else { SC_GO(128, 8, 1); }
+    case 0:
+      if constexpr (big) {
+        if constexpr (CI >= 128) { SC_GO(128, 8, 1); } else { SC_GO(128, 8, 2); }
+      } else {
+        SC_GO(256, 8, 2);
+      }
+    default: break;
   }
-  int nblocks = glx_divup(N_out, T::TR);
-  if (g_prof_start && g_prof_stop) {
-    hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(SC_THREADS), lds, st, g_prof_start,
-                          g_prof_stop, 0, in, Wp, ep, nbr, tile_order, N_out, K, out);
-    g_prof_start = g_prof_stop = nullptr;
-  } else {
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(SC_THREADS), lds, st, in, Wp, ep, nbr, tile_order,
-                       N_out, K, out);
+#undef SC_GO
+  if (g_sconv_variant == 8) {   // wave-private LDS-accumulating kernel
+    using C = WpCfg<CI, CO>;
+    static bool attr_set = false;
+    auto kern = k_sconv_wp<CI, CO>;
+    if (!attr_set) {
+      GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)C::lds_bytes));
+      attr_set = true;
+    }
+    const float* Wp2 = Wp + (size_t)K * SconvCfg<CI, CO>::IMG;
+    int nblocks = glx_divup(N_out, C::TRW * C::NWB);
+    if (g_prof_start && g_prof_stop) {
+      hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(C::NWB * 64), C::lds_bytes, st, g_prof_start,
+                            g_prof_stop, 0, in, Wp2, ep, nbr, tile_order, N_out, K, out);
+      g_prof_start = g_prof_stop = nullptr;
+    } else {
+      hipLaunchKernelGGL(kern, dim3(nblocks), dim3(C::NWB * 64), C::lds_bytes, st, in, Wp2, ep, nbr,
+                         tile_order, N_out, K, out);
+    }
+    GLX_LAUNCH_CHECK();
+    return GLX_OK;
   }
-  GLX_LAUNCH_CHECK();
-  return GLX_OK;
+  if (g_sconv_variant == 9) {   // register-tile kernel, one wave per 32 output rows
+    using R = RtCfg<CI, CO>;
+    const float* Wp3 = Wp + (size_t)K * (SconvCfg<CI, CO>::IMG + WpCfg<CI, CO>::IMG);
+    int nblocks = glx_divup(N_out, R::ROWS);
+    auto kern = k_sconv_rt<CI, CO>;
+    if (g_prof_start && g_prof_stop) {
+      hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(64), 0, st, g_prof_start, g_prof_stop, 0, in,
+                            Wp3, ep, nbr, tile_order, N_out, K, out);
+      g_prof_start = g_prof_stop = nullptr;
+    } else {
+      hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64), 0, st, in, Wp3, ep, nbr, tile_order, N_out,
+                         K, out);
+    }
+    GLX_LAUNCH_CHECK();
+    return GLX_OK;
+  }
+  // default (measured best on the KITTI-shaped batch, tools/sconv_sweep.py): block kernel,
+  // 64 rows x 4 waves for narrow outputs, 128 rows x 8 waves for 128 output channels
+#define SC_GO(TR, NW, NBUF) \
+  return launch_tile<CI, CO, TR, NW, NBUF>(in, Wp, ep, nbr, tile_order, N_out, K, out, st)
+  if constexpr (CO >= 128) { SC_GO(128, 8, 1); } else { SC_GO(64, 4, 1); }
+#undef SC_GO
 }
 
 extern "C" size_t glx_sconv_packed_bytes(int K, int Cin, int Cout) {

@@ -1,0 +1,75 @@
+"""Sweep sparse-conv tile variants on the real layer shapes of the KITTI batch (GPU box)."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from glenet_amd import _lib, backbone as gb, synth  # noqa: E402
+from glenet_amd.spconv import core as sp  # noqa: E402
+
+K = synth.KITTI
+dev = torch.device("cuda", 0)
+frames = [synth.kitti_frame(i)[0] for i in range(4)]
+pts = torch.from_numpy(np.concatenate(frames)).to(dev)
+bidx = torch.from_numpy(np.concatenate([np.full(len(f), i, np.int32) for i, f in enumerate(frames)])).to(dev)
+torch.manual_seed(0)
+grid = gb.gv.grid_size_of(K["point_cloud_range"], K["voxel_size"])
+model = gb.VoxelBackBone8x(4, grid).to(dev).eval()
+
+calls = []
+orig = sp._sconv
+
+
+def spy(features, weight_kio, bias, nbr, tile_order, n_out, **kw):
+    calls.append((features, weight_kio, nbr, tile_order, n_out, kw.get("rules")))
+    return orig(features, weight_kio, bias, nbr, tile_order, n_out, **kw)
+
+
+sp._sconv = spy
+with torch.no_grad():
+    bd = gb.voxelize_batch(pts, bidx, 4, K)
+    bd = gb.MeanVFE()(bd)
+    model(bd)
+sp._sconv = orig
+
+
+def ev():
+    e = ctypes.c_void_p()
+    _lib.call_nostream("glx_event_create", ctypes.byref(e))
+    return e
+
+
+variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2,3,4,5,6,7".split(","))]
+seen = set()
+print("layer(cin,cout,N,R)".ljust(34) + "".join(("v%d" % v).rjust(9) for v in variants) + "   alg GB/s @best")
+for f, w, nbr, order, n_out, rules in calls:
+    Kk, cin, cout = w.shape
+    key = (cin, cout, n_out, Kk)
+    if key in seen:
+        continue
+    seen.add(key)
+    packed = sp.pack_weights(w)
+    R = rules.pair_count
+    row = []
+    for v in variants:
+        _lib.call_nostream("glx_sconv_set_variant", v)
+        ts = []
+        try:
+            for it in range(12):
+                s, e = ev(), ev()
+                _lib.call_nostream("glx_profile_next_sconv", s, e)
+                orig(f, w, None, nbr, order, n_out, packed=packed)
+                ms = ctypes.c_float()
+                _lib.call_nostream("glx_event_elapsed_ms", s, e, ctypes.byref(ms))
+                ts.append(ms.value * 1e3)
+            row.append(float(np.median(ts[2:])))
+        except Exception as ex:  # variant does not fit LDS
+            row.append(float("nan"))
+    _lib.call_nostream("glx_sconv_set_variant", -1)
+    best = np.nanmin(row)
+    alg = R * (cin + 2 * cout) * 4 + R * 8 + Kk * cin * cout * 4
+    print(("(%d,%d,%d,%d)" % (cin, cout, n_out, R)).ljust(34) + "".join(("%.1f" % t).rjust(9) for t in row)
+          + "   %.0f" % (alg / best / 1e3))
