@@ -1,0 +1,510 @@
+// Point / box operators of pcdet.ops: points_in_boxes, RoI-aware pooling, RoI point pooling,
+// voxel query, ball query, grouping.  Arithmetic restates the reference CUDA kernels cited at
+// each function (fp32, contraction off); the parallel decomposition is ours.
+#include "glx_common.h"
+
+// ------------------------------------------------------------------ inside test
+// check_pt_in_box3d, pcdet/ops/roiaware_pool3d/src/roiaware_pool3d_kernel.cu:23-36
+// (== roipoint_pool3d_kernel.cu:22-35): z test in double (dz / 2.0), xy in double vs MARGIN.
+struct BoxT {
+  float cx, cy, cz, dx, dy, dz, cosa, sina;
+  __device__ void load(const float* b) {
+    cx = b[0]; cy = b[1]; cz = b[2]; dx = b[3]; dy = b[4]; dz = b[5];
+    cosa = (float)cos((double)(-b[6]));
+    sina = (float)sin((double)(-b[6]));
+  }
+  __device__ __forceinline__ int contains(float x, float y, float z, float margin, float& lx,
+                                          float& ly) const {
+    if (fabsf(z - cz) > dz / 2.0) return 0;
+    float sx = x - cx, sy = y - cy;
+    lx = sx * cosa + sy * (-sina);
+    ly = sx * sina + sy * cosa;
+    return (fabsf(lx) < dx / 2.0 + margin) & (fabsf(ly) < dy / 2.0 + margin);
+  }
+};
+
+#define PIB_MARGIN 1e-5f
+
+// points_in_boxes_kernel, roiaware_pool3d_kernel.cu:313-336: first containing box or -1.
+// boxes of the frame are transformed once into LDS, points stream through.
+__global__ void k_points_in_boxes(int B, int T, int P, const float* __restrict__ boxes,
+                                  const float* __restrict__ pts, int* __restrict__ out) {
+  extern __shared__ BoxT sbox[];
+  const int b = blockIdx.y;
+  for (int k = threadIdx.x; k < T; k += blockDim.x) sbox[k].load(boxes + ((long long)b * T + k) * 7);
+  __syncthreads();
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const float* q = pts + ((long long)b * P + p) * 3;
+  float x = q[0], y = q[1], z = q[2], lx, ly;
+  int r = -1;
+  for (int k = 0; k < T; ++k)
+    if (sbox[k].contains(x, y, z, PIB_MARGIN, lx, ly)) { r = k; break; }
+  out[(long long)b * P + p] = r;
+}
+
+extern "C" int glx_points_in_boxes(const float* boxes, const float* pts, int B, int T, int P,
+                                   int32_t* box_idx_of_points, void* stream) {
+  if (B == 0 || P == 0) return GLX_OK;
+  GLX_REQUIRE(pts && box_idx_of_points && (T == 0 || boxes), "glx_points_in_boxes: null pointer");
+  GLX_REQUIRE((size_t)T * sizeof(BoxT) <= 64 * 1024, "glx_points_in_boxes: %d boxes per frame", T);
+  hipLaunchKernelGGL(k_points_in_boxes, dim3(glx_divup(P, 256), B), dim3(256), T * sizeof(BoxT),
+                     (hipStream_t)stream, B, T, P, boxes, pts, box_idx_of_points);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// ------------------------------------------------------------------ RoI-aware pooling
+// generate_pts_mask_for_box3d + collect_inside_pts_for_box3d (kernel.cu:39-108): per box, the
+// inside points are appended to their voxel's list IN POINT ORDER, at most max_pts-1 each.
+// One wave per box walks the points 64 at a time; inside a batch the rank of a point among
+// earlier lanes of the same voxel keeps the serial order without a serial loop.
+__global__ void k_roiaware_collect(int N, int P, int ox, int oy, int oz, int maxpts,
+                                   const float* __restrict__ rois, const float* __restrict__ pts,
+                                   int* __restrict__ pts_idx_of_voxels) {
+  extern __shared__ int s_cnt[];   // per-voxel fill count of this box (wave-private block)
+  const int box = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int nvox = ox * oy * oz;
+  BoxT bx;
+  bx.load(rois + (long long)box * 7);
+  int* lists = pts_idx_of_voxels + (long long)box * nvox * maxpts;
+  for (int v = lane; v < nvox; v += 64) s_cnt[v] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const float x_res = bx.dx / ox, y_res = bx.dy / oy, z_res = bx.dz / oz;
+  for (int base = 0; base < P; base += 64) {
+    int k = base + lane;
+    int vox = -1;
+    if (k < P) {
+      float x = pts[(long long)k * 3], y = pts[(long long)k * 3 + 1], z = pts[(long long)k * 3 + 2];
+      float lx = 0.f, ly = 0.f;
+      if (bx.contains(x, y, z, PIB_MARGIN, lx, ly)) {
+        float lz = z - bx.cz;
+        unsigned xi = (unsigned)(int)((lx + bx.dx / 2) / x_res);
+        unsigned yi = (unsigned)(int)((ly + bx.dy / 2) / y_res);
+        unsigned zi = (unsigned)(int)((lz + bx.dz / 2) / z_res);
+        xi = min(xi, (unsigned)(ox - 1)) & 0xFF;   // min(max(x,0),o-1) on unsigned, 8-bit fields
+        yi = min(yi, (unsigned)(oy - 1)) & 0xFF;
+        zi = min(zi, (unsigned)(oz - 1)) & 0xFF;
+        vox = (int)((xi * oy + yi) * oz + zi);
+      }
+    }
+    unsigned long long inside = __ballot(vox >= 0);
+    if (!inside) continue;
+    // rank among earlier lanes with the same voxel, and whether I am the last of my voxel
+    int rank = 0;
+    bool last = true;
+    for (unsigned long long m = inside; m;) {
+      int l = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      int v = __shfl(vox, l, 64);
+      if (v == vox) {
+        if (l < lane) ++rank;
+        if (l > lane) last = false;
+      }
+    }
+    int cnt = vox >= 0 ? s_cnt[vox] : 0;      // count before this batch (all lanes read first)
+    __builtin_amdgcn_wave_barrier();
+    if (vox >= 0) {
+      int slot = cnt + rank;
+      if (slot < maxpts - 1) lists[(long long)vox * maxpts + slot + 1] = k;
+      if (last) s_cnt[vox] = min(cnt + rank + 1, maxpts - 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int v = lane; v < nvox; v += 64) lists[(long long)v * maxpts] = s_cnt[v];
+}
+
+// roiaware_maxpool3d / roiaware_avgpool3d, kernel.cu:111-190: thread per (box, voxel, channel)
+__global__ void k_roiaware_pool(int N, int C, int maxpts, int nvox, int method,
+                                const float* __restrict__ feat, const int* __restrict__ lists,
+                                float* __restrict__ pooled, int* __restrict__ argmax) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)N * nvox * C) return;
+  int c = (int)(t % C);
+  long long v = t / C;
+  const int* lst = lists + v * maxpts;
+  int total = lst[0];
+  if (method == 0) {
+    int am = -1;
+    float mv = -INFINITY;
+    for (int k = 1; k <= total; ++k) {
+      float f = feat[(long long)lst[k] * C + c];
+      if (f > mv) { mv = f; am = lst[k]; }
+    }
+    if (am != -1) pooled[t] = mv;
+    argmax[t] = am;
+  } else {
+    float s = 0.f;
+    for (int k = 1; k <= total; ++k) s += feat[(long long)lst[k] * C + c];
+    if (total > 0) pooled[t] = s / total;
+  }
+}
+
+extern "C" int glx_roiaware_pool3d_forward(const float* rois, int N, const float* pts, int P,
+                                           const float* pts_feature, int C, int ox, int oy, int oz,
+                                           int max_pts, int pool_method, int32_t* argmax,
+                                           int32_t* pts_idx_of_voxels, float* pooled,
+                                           void* stream) {
+  if (N == 0) return GLX_OK;
+  GLX_REQUIRE(rois && pts_idx_of_voxels && pooled && argmax, "glx_roiaware_pool3d_forward: null pointer");
+  GLX_REQUIRE(ox > 0 && oy > 0 && oz > 0 && ox < 256 && oy < 256 && oz < 256 && max_pts >= 2,
+              "glx_roiaware_pool3d_forward: out size must be < 256 per axis, max_pts >= 2");
+  hipStream_t st = (hipStream_t)stream;
+  GLX_REQUIRE((size_t)ox * oy * oz * 4 <= 64 * 1024, "glx_roiaware_pool3d_forward: %d voxels per box",
+              ox * oy * oz);
+  if (P > 0)
+    hipLaunchKernelGGL(k_roiaware_collect, dim3(N), dim3(64), (size_t)ox * oy * oz * 4, st, N, P,
+                       ox, oy, oz, max_pts, rois, pts, pts_idx_of_voxels);
+  long long total = (long long)N * ox * oy * oz * C;
+  hipLaunchKernelGGL(k_roiaware_pool, dim3(glx_divup(total, 256)), dim3(256), 0, st, N, C, max_pts,
+                     ox * oy * oz, pool_method, pts_feature, (const int*)pts_idx_of_voxels, pooled,
+                     argmax);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// roiaware_{max,avg}pool3d_backward, kernel.cu:236-286 (float atomics, like the reference)
+__global__ void k_roiaware_backward(long long nvoxC, int C, int maxpts, int method,
+                                    const int* __restrict__ lists, const int* __restrict__ argmax,
+                                    const float* __restrict__ grad_out, float* __restrict__ grad_in) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nvoxC) return;
+  int c = (int)(t % C);
+  long long v = t / C;
+  float g = grad_out[t];
+  if (method == 0) {
+    int a = argmax[t];
+    if (a == -1) return;
+    atomicAdd(grad_in + (long long)a * C + c, g * 1);
+  } else {
+    const int* lst = lists + v * maxpts;
+    int total = lst[0];
+    float cur = 1 / fmaxf((float)total, 1.0f);
+    for (int k = 1; k <= total; ++k) atomicAdd(grad_in + (long long)lst[k] * C + c, g * cur);
+  }
+}
+
+extern "C" int glx_roiaware_pool3d_backward(const int32_t* pts_idx_of_voxels,
+                                            const int32_t* argmax, const float* grad_out, int N,
+                                            int ox, int oy, int oz, int C, int max_pts,
+                                            int pool_method, float* grad_in, void* stream) {
+  if (N == 0) return GLX_OK;
+  GLX_REQUIRE(pts_idx_of_voxels && argmax && grad_out && grad_in, "glx_roiaware_pool3d_backward: null");
+  long long total = (long long)N * ox * oy * oz * C;
+  hipLaunchKernelGGL(k_roiaware_backward, dim3(glx_divup(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, total, C, max_pts, pool_method,
+                     (const int*)pts_idx_of_voxels, (const int*)argmax, grad_out, grad_in);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// ------------------------------------------------------------------ RoI point pooling
+// assign_pts_to_box3d + get_pooled_idx + roipool3d_forward (roipoint_pool3d_kernel.cu:38-134):
+// one wave per (frame, box) collects the first S inside points in point order by ballot
+// compaction, wraps them around if fewer, then gathers xyz + features.
+__global__ void k_roipoint_pool(int B, int Np, int M, int C, int S, const float* __restrict__ xyz,
+                                const float* __restrict__ boxes, const float* __restrict__ feat,
+                                float* __restrict__ pooled, int* __restrict__ empty_flag) {
+  extern __shared__ int s_idx[];   // S
+  const int m = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  BoxT bx;
+  bx.load(boxes + ((long long)b * M + m) * 7);
+  const float* X = xyz + (long long)b * Np * 3;
+  int cnt = 0;
+  for (int base = 0; base < Np && cnt < S; base += 64) {
+    int k = base + lane;
+    bool in = false;
+    if (k < Np) {
+      float lx, ly;
+      in = bx.contains(X[(long long)k * 3], X[(long long)k * 3 + 1], X[(long long)k * 3 + 2],
+                       PIB_MARGIN, lx, ly);
+    }
+    unsigned long long bal = __ballot(in);
+    int pos = cnt + __popcll(bal & ((1ull << lane) - 1ull));
+    if (in && pos < S) s_idx[pos] = k;
+    cnt += __popcll(bal);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (cnt == 0) {
+    if (lane == 0) empty_flag[(long long)b * M + m] = 1;
+    return;
+  }
+  if (cnt > S) cnt = S;
+  const int W = 3 + C;
+  float* dst = pooled + ((long long)b * M + m) * S * W;
+  for (int e = lane; e < S * W; e += 64) {
+    int s = e / W, j = e - s * W;
+    int src = s_idx[s < cnt ? s : s % cnt];
+    dst[e] = j < 3 ? X[(long long)src * 3 + j] : feat[((long long)b * Np + src) * C + (j - 3)];
+  }
+}
+
+extern "C" int glx_roipoint_pool3d(const float* xyz, const float* boxes3d, const float* pts_feature,
+                                   int B, int Np, int M, int C, int S, float* pooled,
+                                   int32_t* empty_flag, void* stream) {
+  if (B == 0 || M == 0) return GLX_OK;
+  GLX_REQUIRE(xyz && boxes3d && pooled && empty_flag && (C == 0 || pts_feature),
+              "glx_roipoint_pool3d: null pointer");
+  GLX_REQUIRE(S > 0 && (size_t)S * 4 <= 64 * 1024, "glx_roipoint_pool3d: bad sample count %d", S);
+  hipLaunchKernelGGL(k_roipoint_pool, dim3(M, B), dim3(64), S * sizeof(int), (hipStream_t)stream,
+                     B, Np, M, C, S, xyz, boxes3d, pts_feature, pooled, empty_flag);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// ------------------------------------------------------------------ voxel query
+// voxel_query_kernel_stack, pointnet2_stack/src/voxel_query_gpu.cu:10-89.  The neighbour
+// window is scanned z, y, x ascending; idx pre-filled with the first hit; -1 marks empty.
+// MAP = dense (B,Z,Y,X) int32 map (reference API) or the rank dictionary of the sparse tensor
+// (no 189 MB map to build and clear per scale).
+template <bool DENSE>
+__global__ void k_voxel_query(int M, int R1, int R2, int R3, int nsample, float radius2,
+                              int zr, int yr, int xr, const float* __restrict__ new_xyz,
+                              const float* __restrict__ xyz, const int* __restrict__ new_coords,
+                              const int* __restrict__ point_indices,
+                              const unsigned long long* __restrict__ bitmap,
+                              const int* __restrict__ prefix, const int* __restrict__ rank_to_row,
+                              int* __restrict__ idx) {
+  int pt = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pt >= M) return;
+  const float nx = new_xyz[(long long)pt * 3], ny = new_xyz[(long long)pt * 3 + 1],
+              nz = new_xyz[(long long)pt * 3 + 2];
+  const int4 nc = reinterpret_cast<const int4*>(new_coords)[pt];   // b z y x
+  int* o = idx + (long long)pt * nsample;
+  int cnt = 0;
+  for (int dz = -zr; dz <= zr; ++dz) {
+    int z = nc.y + dz;
+    if (z < 0 || z >= R1) continue;
+    for (int dy = -yr; dy <= yr; ++dy) {
+      int y = nc.z + dy;
+      if (y < 0 || y >= R2) continue;
+      for (int dx = -xr; dx <= xr; ++dx) {
+        int x = nc.w + dx;
+        if (x < 0 || x >= R3) continue;
+        long long lin = (((long long)nc.x * R1 + z) * R2 + y) * R3 + x;
+        int nb;
+        if (DENSE) {
+          nb = point_indices[lin];
+        } else {
+          nb = glx_rank_lookup(bitmap, prefix, lin);
+          if (nb >= 0 && rank_to_row) nb = rank_to_row[nb];
+        }
+        if (nb < 0) continue;
+        float xp = xyz[(long long)nb * 3], yp = xyz[(long long)nb * 3 + 1], zp = xyz[(long long)nb * 3 + 2];
+        float d2 = (xp - nx) * (xp - nx) + (yp - ny) * (yp - ny) + (zp - nz) * (zp - nz);
+        if (d2 > radius2) continue;
+        if (cnt < nsample) {
+          if (cnt == 0)
+            for (int l = 0; l < nsample; ++l) o[l] = nb;
+          o[cnt] = nb;
+          ++cnt;
+        }
+      }
+    }
+  }
+  if (cnt == 0) o[0] = -1;
+}
+
+extern "C" int glx_voxel_query(int M, int Z, int Y, int X, int nsample, float radius, int z_range,
+                               int y_range, int x_range, const float* new_xyz, const float* xyz,
+                               const int32_t* new_coords, const int32_t* point_indices,
+                               int32_t* idx, void* stream) {
+  if (M == 0) return GLX_OK;
+  GLX_REQUIRE(new_xyz && xyz && new_coords && point_indices && idx, "glx_voxel_query: null pointer");
+  hipLaunchKernelGGL((k_voxel_query<true>), dim3(glx_divup(M, 256)), dim3(256), 0,
+                     (hipStream_t)stream, M, Z, Y, X, nsample, radius * radius, z_range, y_range,
+                     x_range, new_xyz, xyz, new_coords, point_indices,
+                     (const unsigned long long*)nullptr, (const int*)nullptr, (const int*)nullptr,
+                     idx);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+extern "C" int glx_voxel_query_index(int M, int Z, int Y, int X, int nsample, float radius,
+                                     int z_range, int y_range, int x_range, const float* new_xyz,
+                                     const float* xyz, const int32_t* new_coords,
+                                     const uint64_t* bitmap, const int32_t* prefix,
+                                     const int32_t* rank_to_row, int32_t* idx, void* stream) {
+  if (M == 0) return GLX_OK;
+  GLX_REQUIRE(new_xyz && xyz && new_coords && bitmap && prefix && idx, "glx_voxel_query_index: null");
+  hipLaunchKernelGGL((k_voxel_query<false>), dim3(glx_divup(M, 256)), dim3(256), 0,
+                     (hipStream_t)stream, M, Z, Y, X, nsample, radius * radius, z_range, y_range,
+                     x_range, new_xyz, xyz, new_coords, (const int*)nullptr,
+                     (const unsigned long long*)bitmap, (const int*)prefix, rank_to_row, idx);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// ------------------------------------------------------------------ ball query
+// ball_query_kernel_stack, pointnet2_stack/src/ball_query_gpu.cu:16-65 (strict d2 < r2; indices
+// local to the query's frame).
+__device__ __forceinline__ int batch_of(int pt, const int* cnt, int B, int& start_other,
+                                        const int* other_cnt) {
+  int bs = 0, pc = cnt[0];
+  for (int k = 1; k < B; k++) {
+    if (pt < pc) break;
+    pc += cnt[k];
+    bs = k;
+  }
+  start_other = 0;
+  for (int k = 0; k < bs; k++) start_other += other_cnt[k];
+  return bs;
+}
+
+__global__ void k_ball_query(int B, int M, float radius2, int nsample,
+                             const float* __restrict__ new_xyz, const int* __restrict__ new_cnt,
+                             const float* __restrict__ xyz, const int* __restrict__ xyz_cnt,
+                             int* __restrict__ idx) {
+  int pt = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pt >= M) return;
+  int start;
+  int bs = batch_of(pt, new_cnt, B, start, xyz_cnt);
+  const float* X = xyz + (long long)start * 3;
+  const float nx = new_xyz[(long long)pt * 3], ny = new_xyz[(long long)pt * 3 + 1],
+              nz = new_xyz[(long long)pt * 3 + 2];
+  int* o = idx + (long long)pt * nsample;
+  int n = xyz_cnt[bs], cnt = 0;
+  for (int k = 0; k < n; ++k) {
+    float x = X[(long long)k * 3], y = X[(long long)k * 3 + 1], z = X[(long long)k * 3 + 2];
+    float d2 = (nx - x) * (nx - x) + (ny - y) * (ny - y) + (nz - z) * (nz - z);
+    if (d2 < radius2) {
+      if (cnt == 0)
+        for (int l = 0; l < nsample; ++l) o[l] = k;
+      o[cnt] = k;
+      ++cnt;
+      if (cnt >= nsample) break;
+    }
+  }
+  if (cnt == 0) o[0] = -1;
+}
+
+extern "C" int glx_ball_query(int B, int M, float radius, int nsample, const float* new_xyz,
+                              const int32_t* new_xyz_batch_cnt, const float* xyz,
+                              const int32_t* xyz_batch_cnt, int32_t* idx, void* stream) {
+  if (M == 0) return GLX_OK;
+  GLX_REQUIRE(new_xyz && new_xyz_batch_cnt && xyz && xyz_batch_cnt && idx, "glx_ball_query: null");
+  hipLaunchKernelGGL(k_ball_query, dim3(glx_divup(M, 256)), dim3(256), 0, (hipStream_t)stream, B,
+                     M, radius * radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt,
+                     idx);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// ------------------------------------------------------------------ grouping
+// group_points_kernel_stack, pointnet2_stack/src/group_points_gpu.cu:71-101:
+//   out[m, c, s] = features[start(batch of m) + idx[m, s], c]
+// one wave per query: feature rows are read as whole rows (coalesced), transposed through LDS,
+// and written as whole (C, nsample) tiles.
+__global__ void k_group_points(int B, int M, int C, int ns, const float* __restrict__ feat,
+                               const int* __restrict__ feat_cnt, const int* __restrict__ idx,
+                               const int* __restrict__ idx_cnt, float* __restrict__ out) {
+  extern __shared__ float tile[];   // per wave: ns * (C + 1)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (m >= M) return;
+  float* tl = tile + (size_t)wave * ns * (C + 1);
+  int start;
+  batch_of(m, idx_cnt, B, start, feat_cnt);
+  const int* id = idx + (long long)m * ns;
+  for (int e = lane; e < ns * C; e += 64) {
+    int s = e / C, c = e - s * C;
+    tl[s * (C + 1) + c] = feat[((long long)start + id[s]) * C + c];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float* o = out + (long long)m * C * ns;
+  for (int e = lane; e < ns * C; e += 64) {
+    int c = e / ns, s = e - c * ns;
+    o[e] = tl[s * (C + 1) + c];
+  }
+}
+
+extern "C" int glx_group_points(int B, int M, int C, int nsample, const float* features,
+                                const int32_t* features_batch_cnt, const int32_t* idx,
+                                const int32_t* idx_batch_cnt, float* out, void* stream) {
+  if (M == 0 || C == 0) return GLX_OK;
+  GLX_REQUIRE(features && features_batch_cnt && idx && idx_batch_cnt && out, "glx_group_points: null");
+  size_t per_wave = (size_t)nsample * (C + 1) * sizeof(float);
+  GLX_REQUIRE(per_wave <= 40 * 1024, "glx_group_points: nsample*C = %d too large", nsample * C);
+  int waves = per_wave * 4 <= 64 * 1024 ? 4 : 1;
+  hipLaunchKernelGGL(k_group_points, dim3(glx_divup(M, waves)), dim3(64 * waves), per_wave * waves,
+                     (hipStream_t)stream, B, M, C, nsample, features, features_batch_cnt, idx,
+                     idx_batch_cnt, out);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// group_points_grad_kernel_stack, group_points_gpu.cu:15-44: atomicAdd scatter into (N, C);
+// lanes walk channels fastest so each atomic wave-instruction covers contiguous channels of
+// one feature row (cdna_hip_programming.md Guideline 12).
+__global__ void k_group_points_grad(int B, int M, int C, int ns, const float* __restrict__ grad_out,
+                                    const int* __restrict__ idx, const int* __restrict__ idx_cnt,
+                                    const int* __restrict__ feat_cnt,
+                                    float* __restrict__ grad_features) {
+  extern __shared__ float tile[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (m >= M) return;
+  float* tl = tile + (size_t)wave * ns * (C + 1);
+  int start;
+  batch_of(m, idx_cnt, B, start, feat_cnt);
+  const float* g = grad_out + (long long)m * C * ns;
+  for (int e = lane; e < ns * C; e += 64) {
+    int c = e / ns, s = e - c * ns;
+    tl[s * (C + 1) + c] = g[e];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int* id = idx + (long long)m * ns;
+  for (int e = lane; e < ns * C; e += 64) {
+    int s = e / C, c = e - s * C;
+    atomicAdd(grad_features + ((long long)start + id[s]) * C + c, tl[s * (C + 1) + c]);
+  }
+}
+
+extern "C" int glx_group_points_grad(int B, int M, int C, int N, int nsample, const float* grad_out,
+                                     const int32_t* idx, const int32_t* idx_batch_cnt,
+                                     const int32_t* features_batch_cnt, float* grad_features,
+                                     void* stream) {
+  (void)N;
+  if (M == 0 || C == 0) return GLX_OK;
+  GLX_REQUIRE(grad_out && idx && idx_batch_cnt && features_batch_cnt && grad_features,
+              "glx_group_points_grad: null");
+  size_t per_wave = (size_t)nsample * (C + 1) * sizeof(float);
+  GLX_REQUIRE(per_wave <= 40 * 1024, "glx_group_points_grad: nsample*C = %d too large", nsample * C);
+  int waves = per_wave * 4 <= 64 * 1024 ? 4 : 1;
+  hipLaunchKernelGGL(k_group_points_grad, dim3(glx_divup(M, waves)), dim3(64 * waves),
+                     per_wave * waves, (hipStream_t)stream, B, M, C, nsample, grad_out, idx,
+                     idx_batch_cnt, features_batch_cnt, grad_features);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// ------------------------------------------------------------------ (boxes x points) mask
+// points_in_boxes_cpu, pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:143-168: out (N,P)
+// 0/1 with the CPU variant's MARGIN (1e-2); margin is a parameter so the GPU value also fits.
+__global__ void k_points_in_boxes_mask(int N, int P, float margin, const float* __restrict__ boxes,
+                                       const float* __restrict__ pts, int* __restrict__ out) {
+  const int i = blockIdx.y;
+  BoxT bx;
+  bx.load(boxes + (long long)i * 7);
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float lx, ly;
+  out[(long long)i * P + p] =
+      bx.contains(pts[(long long)p * 3], pts[(long long)p * 3 + 1], pts[(long long)p * 3 + 2], margin, lx, ly);
+}
+
+extern "C" int glx_points_in_boxes_mask(const float* boxes, int N, const float* pts, int P,
+                                        float margin, int32_t* out, void* stream) {
+  if (N == 0 || P == 0) return GLX_OK;
+  GLX_REQUIRE(boxes && pts && out, "glx_points_in_boxes_mask: null pointer");
+  hipLaunchKernelGGL(k_points_in_boxes_mask, dim3(glx_divup(P, 256), N), dim3(256), 0,
+                     (hipStream_t)stream, N, P, margin, boxes, pts, out);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

@@ -1,0 +1,72 @@
+"""Register glenet_amd under the import names the reference uses, so GLENet's own Python
+(pcdet/models/backbones_3d/spconv_backbone.py, pcdet/ops/*/ *_utils.py, tools/train.py) runs
+unmodified on the MI355X kernels.
+
+    import glenet_amd.dropin; glenet_amd.dropin.install()
+    # from here on:  import spconv.pytorch as spconv            -> glenet_amd.spconv
+    #                from pcdet.ops.iou3d_nms import iou3d_nms_cuda -> glenet_amd.pcdet_ops...
+
+Only the compiled-extension module names are aliased for pcdet.ops (the reference's *_utils.py
+wrappers stay the reference's own files and call into these); `spconv` and the small part of
+`cumm.tensorview` that data_processor.py:55 touches are provided whole.
+"""
+import importlib
+import sys
+import types
+
+_EXT_MODULES = {
+    "pcdet.ops.iou3d_nms.iou3d_nms_cuda": "glenet_amd.pcdet_ops.iou3d_nms.iou3d_nms_cuda",
+    "pcdet.ops.iou3d.iou3d_cuda": "glenet_amd.pcdet_ops.iou3d.iou3d_cuda",
+    "pcdet.ops.roiaware_pool3d.roiaware_pool3d_cuda": "glenet_amd.pcdet_ops.roiaware_pool3d.roiaware_pool3d_cuda",
+    "pcdet.ops.roipoint_pool3d.roipoint_pool3d_cuda": "glenet_amd.pcdet_ops.roipoint_pool3d.roipoint_pool3d_cuda",
+    "pcdet.ops.pointnet2.pointnet2_stack.pointnet2_stack_cuda":
+        "glenet_amd.pcdet_ops.pointnet2.pointnet2_stack.pointnet2_stack_cuda",
+}
+_SPCONV = {
+    "spconv": "glenet_amd.spconv",
+    "spconv.pytorch": "glenet_amd.spconv.pytorch",
+    "spconv.conv": "glenet_amd.spconv.conv",
+    "spconv.pytorch.conv": "glenet_amd.spconv.conv",
+    "spconv.utils": "glenet_amd.spconv.utils",
+    "spconv.pytorch.utils": "glenet_amd.spconv.utils",
+}
+
+
+def _tensorview_module():
+    tv = types.ModuleType("cumm.tensorview")
+
+    class _Array:
+        def __init__(self, a):
+            self._a = a
+
+        def numpy(self):
+            return self._a
+
+        def numpy_view(self):
+            return self._a
+
+    tv.from_numpy = lambda a: _Array(a)
+    tv.Tensor = _Array
+    return tv
+
+
+def install(spconv=True, ops=True, overwrite=False):
+    """Alias the modules.  Returns the list of names that were registered."""
+    done = []
+    table = {}
+    if spconv:
+        table.update(_SPCONV)
+    if ops:
+        table.update(_EXT_MODULES)
+    for alias, target in table.items():
+        if alias in sys.modules and not overwrite:
+            continue
+        sys.modules[alias] = importlib.import_module(target)
+        done.append(alias)
+    if spconv and ("cumm" not in sys.modules or overwrite):
+        cumm = types.ModuleType("cumm")
+        cumm.tensorview = _tensorview_module()
+        sys.modules["cumm"] = cumm
+        sys.modules["cumm.tensorview"] = cumm.tensorview
+        done += ["cumm", "cumm.tensorview"]
+    return done

@@ -1,0 +1,66 @@
+"""Drop-in for the pybind module `pcdet.ops.iou3d_nms.iou3d_nms_cuda`
+(pcdet/ops/iou3d_nms/src/iou3d_nms_api.cpp:11-17): same function names, positional arguments,
+caller-allocated outputs, int return.  Arithmetic: libglenet_hip.so."""
+import torch
+
+from ... import _lib
+from ..._lib import call, query, size_arg, workspace
+
+
+def _f(t):
+    assert t.dtype == torch.float32 and t.is_contiguous(), "expects contiguous float32"
+    return t
+
+
+def boxes_overlap_bev_gpu(boxes_a, boxes_b, ans_overlap):
+    _lib.check_cuda(boxes_a, boxes_b, ans_overlap)
+    call("glx_boxes_overlap_bev", _f(boxes_a), boxes_a.shape[0], _f(boxes_b), boxes_b.shape[0], 0,
+         _f(ans_overlap))
+    return 1
+
+
+def boxes_iou_bev_gpu(boxes_a, boxes_b, ans_iou):
+    _lib.check_cuda(boxes_a, boxes_b, ans_iou)
+    call("glx_boxes_overlap_bev", _f(boxes_a), boxes_a.shape[0], _f(boxes_b), boxes_b.shape[0], 1,
+         _f(ans_iou))
+    return 1
+
+
+def boxes_iou_bev_cpu(boxes_a, boxes_b, ans_iou):
+    """The reference's CPU entry point (iou3d_cpu.cpp:232-252).  Host tensors in/out; the
+    arithmetic still runs on the GPU (there is no CPU code path in this build), so unlike the
+    reference it must not be called from forked DataLoader workers."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    a, b = boxes_a.float().contiguous().to(dev), boxes_b.float().contiguous().to(dev)
+    out = torch.zeros((a.shape[0], b.shape[0]), dtype=torch.float32, device=dev)
+    boxes_iou_bev_gpu(a, b, out)
+    ans_iou.copy_(out.cpu())
+    return 1
+
+
+def nms_device(boxes, thresh, normal=False):
+    """boxes (N,7) sorted by score -> (keep int64 (N,) on device, num_out int32 (1,) on device)."""
+    _lib.check_cuda(boxes)
+    n = boxes.shape[0]
+    keep = torch.empty(max(n, 1), dtype=torch.int64, device=boxes.device)
+    num = torch.zeros(1, dtype=torch.int32, device=boxes.device)
+    ws = workspace.get(query("glx_nms_workspace_bytes", n), boxes.device)
+    call("glx_nms", _f(boxes), n, float(thresh), 1 if normal else 0, keep, num, ws,
+         size_arg(ws.numel()))
+    return keep, num
+
+
+def _nms_into_cpu_keep(boxes, keep, thresh, normal):
+    k, num = nms_device(boxes, thresh, normal)
+    n = int(num.item())
+    keep[:n] = k[:n].cpu()
+    return n
+
+
+def nms_gpu(boxes, keep, nms_overlap_thresh):
+    """keep: CPU int64 tensor (N), as in iou3d_nms.cpp:90-136; returns the number kept."""
+    return _nms_into_cpu_keep(boxes, keep, nms_overlap_thresh, False)
+
+
+def nms_normal_gpu(boxes, keep, nms_overlap_thresh):
+    return _nms_into_cpu_keep(boxes, keep, nms_overlap_thresh, True)

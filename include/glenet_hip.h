@@ -154,7 +154,8 @@ int glx_dense_scatter(const float* features, const int32_t* indices, int N, int 
  *   max_voxels voxels exist in that frame; each voxel keeps its first max_points points.
  * points (P, C) fp32 with xyz in columns 0..2; point_batch (P) int32 frame id in [0,B) or
  * NULL when B == 1; frames must be stacked contiguously (frame ids non-decreasing).
- * vrange = {xmin,ymin,zmin,xmax,ymax,zmax}, vsize = {vx,vy,vz}; grid (gx,gy,gz) cells.
+ * vrange = {xmin,ymin,zmin,xmax,ymax,zmax}, vsize = {vx,vy,vz} are HOST arrays; grid
+ * (gx,gy,gz) cells.
  * Outputs (capacity B*max_voxels rows, rows of frame b start at voxel_offset[b]):
  *   voxels (cap, max_points, C) zero padded, coords (cap, 4) int32 [b,z,y,x],
  *   num_points (cap) int32, voxel_offset (B+1) int32 (device; [B] = total voxels). */
@@ -180,6 +181,101 @@ int glx_voxelize_dynamic_mean(const float* points, const int32_t* point_batch, i
  * out[v,:] = sum_p voxels[v,p,:] / max(num_points[v], 1). */
 int glx_mean_vfe(const float* voxels, const int32_t* num_points, int Nv, int max_points, int C,
                  float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Rotated boxes: BEV overlap / IoU, NMS, GLENet variance-voting NMS.
+ * ------------------------------------------------------------------------------------ */
+
+/* (N,7) x (M,7) -> (N,M) BEV overlap area (iou == 0) or IoU (iou != 0).
+ * Replaces: iou3d_nms_cuda.boxes_overlap_bev_gpu / boxes_iou_bev_gpu
+ * (pcdet/ops/iou3d_nms/src/iou3d_nms.cpp:49-88, iou3d_nms_kernel.cu:236-260) and
+ * boxes_iou_bev_cpu (iou3d_cpu.cpp:232-252). */
+int glx_boxes_overlap_bev(const float* boxes_a, int N, const float* boxes_b, int M, int iou,
+                          float* out, void* stream);
+/* Same for the older `iou3d` library: boxes (N,5) [x1,y1,x2,y2,ry]
+ * (pcdet/ops/iou3d/src/iou3d.cpp:31-96, iou3d_kernel.cu:270-307). */
+int glx_iou3d_boxes_overlap_bev(const float* boxes_a, int N, const float* boxes_b, int M, int iou,
+                                float* out, void* stream);
+/* out[i] = overlap(a[i], b[i]); replaces iou3d_cuda.boxes_aligned_overlap_bev_gpu
+ * (iou3d.cpp:55-73, iou3d_kernel.cu:284-293). */
+int glx_iou3d_boxes_aligned_overlap_bev(const float* boxes_a, const float* boxes_b, int N,
+                                        float* out, void* stream);
+
+/* Rotated (normal == 0) or axis-aligned (normal != 0) NMS on boxes ALREADY sorted by score.
+ * keep (N) int64 and num_out int32[1] are DEVICE buffers: keep[0..num_out) = indices of the
+ * kept boxes in ascending order.  No host round trip: the suppression matrix (upper triangle
+ * only) stays in `workspace` and is swept on the device.
+ * Replaces: iou3d_nms_cuda.nms_gpu / nms_normal_gpu (iou3d_nms.cpp:90-186, which copy the
+ * matrix to the host and sweep it serially there). */
+size_t glx_nms_workspace_bytes(int N);
+int glx_nms(const float* boxes_sorted, int N, float thresh, int normal, int64_t* keep,
+            int32_t* num_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* GLENet's variance-voting NMS loop (nms_func, pcdet/ops/iou3d_nms/iou3d_nms_utils.py:227-273)
+ * on the device.  boxes (N,7) and scores (N) are updated in place; variance (N, var_stride>=7)
+ * may be NULL; ious (N,N) = BEV IoU of the ORIGINAL boxes; N <= 4096. */
+int glx_nms_vote(float* boxes, float* scores, const float* variance, int var_stride,
+                 const float* ious, int N, float iou_thr, float score_thr, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Point / box operators.
+ * ------------------------------------------------------------------------------------ */
+
+/* boxes (B,T,7), pts (B,P,3) -> (B,P) index of the first box containing the point or -1.
+ * Replaces: roiaware_pool3d_cuda.points_in_boxes_gpu (roiaware_pool3d.cpp:100-118). */
+int glx_points_in_boxes(const float* boxes, const float* pts, int B, int T, int P,
+                        int32_t* box_idx_of_points, void* stream);
+
+/* boxes (N,7), pts (P,3) -> out (N,P) 0/1 inside flags with the given xy MARGIN (1e-2 for the
+ * reference's CPU variant).  Replaces: roiaware_pool3d_cuda.points_in_boxes_cpu
+ * (roiaware_pool3d.cpp:143-168). */
+int glx_points_in_boxes_mask(const float* boxes, int N, const float* pts, int P, float margin,
+                             int32_t* out, void* stream);
+
+/* RoI-aware pooling.  argmax (N,ox,oy,oz,C) i32, pts_idx_of_voxels (N,ox,oy,oz,max_pts) i32 and
+ * pooled (N,ox,oy,oz,C) must arrive zero-filled; pool_method 0 = max, 1 = avg.
+ * Replaces: roiaware_pool3d_cuda.forward / backward (roiaware_pool3d.cpp:29-98). */
+int glx_roiaware_pool3d_forward(const float* rois, int N, const float* pts, int P,
+                                const float* pts_feature, int C, int ox, int oy, int oz,
+                                int max_pts, int pool_method, int32_t* argmax,
+                                int32_t* pts_idx_of_voxels, float* pooled, void* stream);
+int glx_roiaware_pool3d_backward(const int32_t* pts_idx_of_voxels, const int32_t* argmax,
+                                 const float* grad_out, int N, int ox, int oy, int oz, int C,
+                                 int max_pts, int pool_method, float* grad_in, void* stream);
+
+/* RoI point pooling: xyz (B,Np,3), boxes3d (B,M,7) ALREADY enlarged, pts_feature (B,Np,C) ->
+ * pooled (B,M,S,3+C) and empty_flag (B,M), both zero-filled by the caller.
+ * Replaces: roipoint_pool3d_cuda.forward (roipoint_pool3d.cpp:25-55). */
+int glx_roipoint_pool3d(const float* xyz, const float* boxes3d, const float* pts_feature, int B,
+                        int Np, int M, int C, int S, float* pooled, int32_t* empty_flag,
+                        void* stream);
+
+/* Voxel query over the dense (B,Z,Y,X) voxel->point map; idx (M,nsample) arrives zero-filled,
+ * idx[m,0] == -1 marks an empty ball.
+ * Replaces: pointnet2_stack_cuda.voxel_query_wrapper (voxel_query.cpp:28-44). */
+int glx_voxel_query(int M, int Z, int Y, int X, int nsample, float radius, int z_range,
+                    int y_range, int x_range, const float* new_xyz, const float* xyz,
+                    const int32_t* new_coords, const int32_t* point_indices, int32_t* idx,
+                    void* stream);
+/* Same query against the sparse tensor's cell index instead of the dense map (saves building
+ * and clearing the map of pcdet/utils/common_utils.py:226-243 every step). */
+int glx_voxel_query_index(int M, int Z, int Y, int X, int nsample, float radius, int z_range,
+                          int y_range, int x_range, const float* new_xyz, const float* xyz,
+                          const int32_t* new_coords, const uint64_t* bitmap, const int32_t* prefix,
+                          const int32_t* rank_to_row, int32_t* idx, void* stream);
+
+/* Replaces: pointnet2_stack_cuda.ball_query_wrapper (ball_query.cpp:24-43). */
+int glx_ball_query(int B, int M, float radius, int nsample, const float* new_xyz,
+                   const int32_t* new_xyz_batch_cnt, const float* xyz,
+                   const int32_t* xyz_batch_cnt, int32_t* idx, void* stream);
+/* Replaces: pointnet2_stack_cuda.group_points_wrapper / group_points_grad_wrapper
+ * (group_points.cpp:31-69); grad_features (N,C) arrives zero-filled. */
+int glx_group_points(int B, int M, int C, int nsample, const float* features,
+                     const int32_t* features_batch_cnt, const int32_t* idx,
+                     const int32_t* idx_batch_cnt, float* out, void* stream);
+int glx_group_points_grad(int B, int M, int C, int N, int nsample, const float* grad_out,
+                          const int32_t* idx, const int32_t* idx_batch_cnt,
+                          const int32_t* features_batch_cnt, float* grad_features, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,299 @@
+"""GPU parity of the pcdet.ops mirrors (rotated IoU / NMS / voting NMS, point-box operators,
+queries and grouping) against the CPU oracle and the reference's golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from glenet_amd import synth
+from glenet_amd.pcdet_ops.iou3d import iou3d_cuda, iou3d_utils
+from glenet_amd.pcdet_ops.iou3d_nms import iou3d_nms_cuda, iou3d_nms_utils
+from glenet_amd.pcdet_ops.pointnet2.pointnet2_stack import pointnet2_utils, voxel_pool_modules, voxel_query_utils
+from glenet_amd.pcdet_ops.roiaware_pool3d import roiaware_pool3d_utils
+from glenet_amd.pcdet_ops.roipoint_pool3d import roipoint_pool3d_utils
+from glenet_amd.spconv import core as sp
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def ulp_report(a, b):
+    same = (a.view(np.uint32) == b.view(np.uint32)).mean()
+    return same, np.abs(a - b).max()
+
+
+# ------------------------------------------------------------------ rotated IoU
+@pytest.mark.parametrize("kind", ["random", "axis", "dup", "degenerate"])
+def test_iou3d_lib_vs_reference_golden(dev, kind):
+    """HIP kernel vs the output of the reference's compiled iou3d_cpu.cpp (committed fixture)."""
+    g = np.load(os.path.join(GOLD, "iou3d_ref.npz"))
+    a, b = T(g[kind + "_a"], dev), T(g[kind + "_b"], dev)
+    ov = torch.zeros(a.shape[0], b.shape[0], device=dev)
+    iou = torch.zeros_like(ov)
+    iou3d_cuda.boxes_overlap_bev_gpu(a, b, ov)
+    iou3d_cuda.boxes_iou_bev_gpu(a, b, iou)
+    # fp32 geometry with double-rounded trig vs glibc float trig: a few ulp on areas of O(1..25)
+    np.testing.assert_allclose(ov.cpu().numpy(), g[kind + "_overlap"], rtol=1e-5, atol=2e-5)
+    fin = np.isfinite(g[kind + "_iou"])
+    np.testing.assert_allclose(iou.cpu().numpy()[fin], g[kind + "_iou"][fin], rtol=1e-5, atol=2e-6)
+    same, _ = ulp_report(ov.cpu().numpy(), g[kind + "_overlap"])
+    assert same > 0.9, "only %.3f of overlaps bit-identical" % same
+
+
+def test_boxes_iou_bev_and_iou3d_vs_oracle(dev):
+    rng = np.random.default_rng(0)
+    a, b = synth.random_boxes(rng, 300, near_dup=0.5), synth.random_boxes(rng, 77, near_dup=0.5)
+    b[:40] = a[:40] + rng.normal(0, 0.1, (40, 7)).astype(np.float32)
+    ref = oracle.boxes_iou_bev(a, b)
+    got = iou3d_nms_utils.boxes_iou_bev(T(a, dev), T(b, dev)).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=2e-6)
+    same, mx = ulp_report(got, ref)
+    assert same > 0.98 and (ref > 0.01).sum() > 30
+    got3 = iou3d_nms_utils.boxes_iou3d_gpu(T(a, dev), T(b, dev)).cpu().numpy()
+    np.testing.assert_allclose(got3, oracle.boxes_iou3d(a, b), rtol=1e-5, atol=2e-6)
+    # host entry point (numpy in / numpy out, like GT sampling calls it)
+    got_cpu = iou3d_nms_utils.boxes_bev_iou_cpu(a[:20], b[:20])
+    np.testing.assert_allclose(got_cpu, ref[:20, :20], rtol=1e-5, atol=2e-6)
+    # empty inputs
+    e = iou3d_nms_utils.boxes_iou_bev(T(a[:0], dev), T(b, dev))
+    assert e.shape == (0, 77)
+
+
+def test_aligned_iou3d(dev):
+    rng = np.random.default_rng(1)
+    a = synth.random_boxes(rng, 200)
+    b = a + rng.normal(0, 0.15, a.shape).astype(np.float32)
+    got, got_bev = iou3d_utils.boxes_aligned_iou3d_gpu(T(a, dev), T(b, dev), need_bev=True)
+    abev = iou3d_utils.boxes3d_to_bev_torch(torch.from_numpy(a)).numpy()
+    bbev = iou3d_utils.boxes3d_to_bev_torch(torch.from_numpy(b)).numpy()
+    ov = oracle.iou3d_boxes_aligned_overlap_bev(abev, bbev)
+    hmin = np.maximum(a[:, 2] - a[:, 5] / 2, b[:, 2] - b[:, 5] / 2)
+    hmax = np.minimum(a[:, 2] + a[:, 5] / 2, b[:, 2] + b[:, 5] / 2)
+    o3 = ov[:, 0] * np.clip(hmax - hmin, 0, None)
+    ref = o3 / np.clip(a[:, 3] * a[:, 4] * a[:, 5] + b[:, 3] * b[:, 4] * b[:, 5] - o3, 1e-7, None)
+    np.testing.assert_allclose(got.cpu().numpy()[:, 0], ref, rtol=1e-4, atol=1e-5)
+    assert (ref > 0.3).sum() > 50
+
+
+# ------------------------------------------------------------------ NMS
+@pytest.mark.parametrize("n,thr,pre", [(9000, 0.8, None), (2048, 0.7, 1000), (500, 0.1, None), (65, 0.01, None),
+                                       (64, 0.5, None), (1, 0.5, None)])
+def test_nms_keep_bit_identical(dev, n, thr, pre):
+    rng = np.random.default_rng(n)
+    boxes = synth.random_boxes(rng, n, xy_range=60.0 if n > 3000 else 25.0, near_dup=0.6)
+    scores = (rng.permutation(n).astype(np.float32) + 1) / n          # distinct: sort order is unique
+    ref = oracle.nms_gpu(boxes, scores, thr, pre_maxsize=pre)
+    got, _ = iou3d_nms_utils.nms_gpu(T(boxes, dev), T(scores, dev), thr, pre_maxsize=pre)
+    assert got.dtype == torch.int64
+    assert np.array_equal(got.cpu().numpy(), ref)
+    assert 0 < len(ref) <= n
+    refn = oracle.nms_gpu(boxes, scores, thr, normal=True)
+    gotn, _ = iou3d_nms_utils.nms_normal_gpu(T(boxes, dev), T(scores, dev), thr)
+    assert np.array_equal(gotn.cpu().numpy(), refn)
+
+
+def test_nms_raw_extension_signature(dev):
+    """iou3d_nms_cuda.nms_gpu(boxes_sorted (cuda), keep (CPU int64), thr) -> count."""
+    rng = np.random.default_rng(5)
+    boxes = synth.random_boxes(rng, 700, near_dup=0.5)
+    keep = torch.zeros(700, dtype=torch.int64)
+    num = iou3d_nms_cuda.nms_gpu(T(boxes, dev), keep, 0.3)
+    assert np.array_equal(keep[:num].numpy(), oracle.nms_sorted(boxes, 0.3))
+    assert iou3d_nms_cuda.nms_gpu(T(boxes[:0], dev), keep, 0.3) == 0
+
+
+def test_nms_full_size_properties(dev):
+    """Size-independent checks at the training size (9000 proposals): kept set is mutually
+    non-overlapping above thr and idempotent."""
+    rng = np.random.default_rng(11)
+    boxes = synth.random_boxes(rng, 9000, xy_range=70.0, near_dup=0.7)
+    scores = torch.from_numpy(rng.random(9000).astype(np.float32)).to(dev)
+    b = T(boxes, dev)
+    keep, _ = iou3d_nms_utils.nms_gpu(b, scores, 0.8, pre_maxsize=9000)
+    kb = b[keep]
+    m = iou3d_nms_utils.boxes_iou_bev(kb, kb)
+    m.fill_diagonal_(0)
+    assert float(m.max()) <= 0.8
+    keep2, _ = iou3d_nms_utils.nms_gpu(kb, scores[keep], 0.8)
+    assert keep2.numel() == keep.numel()
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_variance_voting_nms_vs_reference_golden(dev, case):
+    g = np.load(os.path.join(GOLD, "nms_func_ref.npz"))
+    boxes, scores = g["c%d_boxes" % case], g["c%d_scores" % case]
+    var = T(g["c%d_var" % case], dev) if ("c%d_var" % case) in g else None
+    thr, sthr = g["c%d_params" % case]
+    keep, _, new_boxes = iou3d_nms_utils.new_nms_gpu(T(boxes, dev), T(scores, dev), float(thr),
+                                                     score_threshold=float(sthr), variance=var)
+    assert np.array_equal(np.asarray(keep), g["c%d_keep" % case])
+    # voted boxes: fp32 weighted means of O(10) values; tolerance = north_star's 1e-4
+    np.testing.assert_allclose(new_boxes, g["c%d_new_boxes" % case], rtol=1e-4, atol=1e-4)
+
+
+def test_variance_voting_nms_larger_vs_oracle(dev):
+    rng = np.random.default_rng(3)
+    n = 1500
+    boxes = synth.random_boxes(rng, n, xy_range=30.0, near_dup=0.7)
+    scores = (rng.permutation(n).astype(np.float32) + 1) / n
+    var = rng.uniform(0.01, 0.3, (n, 7)).astype(np.float32)
+    rk, rb = oracle.new_nms_gpu(boxes, scores, 0.1, 0.1, var)
+    keep, _, nb = iou3d_nms_utils.new_nms_gpu(T(boxes, dev), T(scores, dev), 0.1, score_threshold=0.1,
+                                              variance=T(var, dev))
+    assert np.array_equal(np.asarray(keep), rk)
+    np.testing.assert_allclose(nb, rb, rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------ point / box operators
+def _scene(rng, n_pts=6000, n_box=24):
+    boxes = synth.random_boxes(rng, n_box, xy_range=20.0, near_dup=0.0)
+    pts = rng.uniform([-2, -12, -3], [22, 12, 1], (n_pts, 3)).astype(np.float32)
+    # put a share of the points inside boxes (incl. exactly on faces / centres)
+    for i in range(n_box):
+        k = rng.integers(0, n_pts, 60)
+        local = rng.uniform(-0.5, 0.5, (60, 3)) * boxes[i, 3:6]
+        c, s = np.cos(boxes[i, 6]), np.sin(boxes[i, 6])
+        pts[k, 0] = boxes[i, 0] + local[:, 0] * c - local[:, 1] * s
+        pts[k, 1] = boxes[i, 1] + local[:, 0] * s + local[:, 1] * c
+        pts[k, 2] = boxes[i, 2] + local[:, 2]
+    pts[0] = boxes[0, :3]
+    pts[1] = boxes[0, :3] + [0, 0, boxes[0, 5] / 2]
+    return boxes, pts.astype(np.float32)
+
+
+def test_points_in_boxes(dev):
+    rng = np.random.default_rng(2)
+    boxes, pts = _scene(rng)
+    B = 2
+    bb = np.stack([boxes, np.roll(boxes, 3, 0)])
+    pp = np.stack([pts, pts[::-1].copy()])
+    got = roiaware_pool3d_utils.points_in_boxes_gpu(T(pp, dev), T(bb, dev)).cpu().numpy()
+    ref = oracle.points_in_boxes_gpu(pp, bb)
+    assert np.array_equal(got, ref) and (ref >= 0).sum() > 500
+    got_cpu = roiaware_pool3d_utils.points_in_boxes_cpu(pts, boxes)       # numpy in/out, MARGIN 1e-2
+    assert np.array_equal(got_cpu, oracle.points_in_boxes_cpu(pts, boxes))
+
+
+@pytest.mark.parametrize("method", ["max", "avg"])
+def test_roiaware_pool3d(dev, method):
+    rng = np.random.default_rng(4)
+    boxes, pts = _scene(rng, n_pts=5000, n_box=16)
+    feat = rng.normal(size=(len(pts), 9)).astype(np.float32)
+    pooled, argmax, pidx = oracle.roiaware_pool3d_forward(boxes, pts, feat, (6, 5, 4), 8, method)
+    mod = roiaware_pool3d_utils.RoIAwarePool3d((6, 5, 4), max_pts_each_voxel=8)
+    f = T(feat, dev).requires_grad_(True)
+    out = mod(T(boxes, dev), T(pts, dev), f, pool_method=method)
+    assert np.array_equal(out.detach().cpu().numpy(), pooled)      # copies / same-order sums: exact
+    assert (pidx[..., 0] > 0).sum() > 50 and (pidx[..., 0] == 7).any()     # cap max_pts-1 exercised
+    g = rng.normal(size=pooled.shape).astype(np.float32)
+    out.backward(T(g, dev))
+    gref = oracle.roiaware_pool3d_backward(pidx, argmax, g, len(pts), method)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), gref, rtol=1e-5, atol=1e-5)   # float atomics
+
+
+def test_roipoint_pool3d(dev):
+    rng = np.random.default_rng(6)
+    boxes, pts = _scene(rng, n_pts=4000, n_box=12)
+    boxes[5, :3] = [500, 500, 500]                                    # an empty box
+    B = 2
+    pp = np.stack([pts, pts[::-1].copy()])
+    ff = rng.normal(size=(B, len(pts), 5)).astype(np.float32)
+    bb = np.stack([boxes, boxes])
+    pooled, empty = oracle.roipoint_pool3d(pp, ff, bb, 1.0, 128)
+    mod = roipoint_pool3d_utils.RoIPointPool3d(num_sampled_points=128, pool_extra_width=1.0)
+    gp, ge = mod(T(pp, dev), T(ff, dev), T(bb, dev))
+    assert np.array_equal(ge.cpu().numpy(), empty) and empty[0, 5] == 1
+    assert np.array_equal(gp.cpu().numpy(), pooled)
+    # a box with fewer than 128 points wraps around
+    mod2 = roipoint_pool3d_utils.RoIPointPool3d(num_sampled_points=512, pool_extra_width=0.0)
+    p2, e2 = oracle.roipoint_pool3d(pp, ff, bb, 0.0, 512)
+    gp2, ge2 = mod2(T(pp, dev), T(ff, dev), T(bb, dev))
+    assert np.array_equal(gp2.cpu().numpy(), p2)
+
+
+def _voxel_scene(rng, B, Z, Y, X, density):
+    occ = rng.random((B, Z, Y, X)) < density
+    idx = np.argwhere(occ).astype(np.int32)                      # frames contiguous, sorted
+    xyz = ((idx[:, [3, 2, 1]] + 0.5) * np.array([0.1, 0.1, 0.2])).astype(np.float32)
+    cnt = np.bincount(idx[:, 0], minlength=B).astype(np.int32)
+    return idx, xyz, cnt
+
+
+def test_voxel_query_dense_and_index(dev):
+    rng = np.random.default_rng(7)
+    B, Z, Y, X = 2, 11, 40, 36
+    idx, xyz, cnt = _voxel_scene(rng, B, Z, Y, X, 0.08)
+    v2p = oracle.generate_voxel2pinds(idx, B, [Z, Y, X])
+    M = 600
+    qc = np.stack([np.repeat(np.arange(B), M // B), rng.integers(-1, Z + 1, M), rng.integers(0, Y, M),
+                   rng.integers(0, X, M)], 1).astype(np.int32)
+    qc[:, 1] = np.clip(qc[:, 1], 0, Z - 1)
+    q = ((qc[:, [3, 2, 1]] + rng.random((M, 3))) * np.array([0.1, 0.1, 0.2])).astype(np.float32)
+    for rng_, radius, ns in [((4, 4, 4), 0.4, 16), ((1, 2, 2), 0.25, 4), ((0, 1, 1), 0.05, 8)]:
+        ref, ref_e = oracle.voxel_query(rng_, radius, ns, xyz, q, qc, v2p)
+        got, got_e = voxel_query_utils.voxel_query(rng_, radius, ns, T(xyz, dev), T(q, dev), T(qc, dev), T(v2p, dev))
+        assert np.array_equal(got.cpu().numpy(), ref) and np.array_equal(got_e.cpu().numpy(), ref_e)
+        # same answer from the sparse tensor's own index (rows in shuffled order)
+        perm = rng.permutation(len(idx))
+        inv = np.argsort(perm)
+        st = sp.SparseConvTensor(torch.zeros(len(idx), 1, device=dev), T(idx[perm], dev), [Z, Y, X], B)
+        got2, e2 = voxel_query_utils.voxel_query_sparse(rng_, radius, ns, T(xyz[perm], dev), T(q, dev), T(qc, dev), st)
+        assert np.array_equal(e2.cpu().numpy(), ref_e)
+        assert np.array_equal(perm[got2.cpu().numpy()][~ref_e], ref[~ref_e])
+        assert inv is not None
+    assert ref_e.any() and (~ref_e).any()
+
+
+def test_ball_query_and_grouping(dev):
+    rng = np.random.default_rng(8)
+    cnt = np.array([700, 0, 500], np.int32)                      # a frame without points
+    xyz = rng.uniform(0, 4, (cnt.sum(), 3)).astype(np.float32)
+    ncnt = np.array([60, 0, 40], np.int32)
+    q = rng.uniform(-0.5, 4.5, (ncnt.sum(), 3)).astype(np.float32)
+    feat = rng.normal(size=(cnt.sum(), 32)).astype(np.float32)
+    idx, empty = oracle.ball_query(0.45, 16, xyz, cnt, q, ncnt)
+    gi, ge = pointnet2_utils.ball_query(0.45, 16, T(xyz, dev), T(cnt, dev), T(q, dev), T(ncnt, dev))
+    assert np.array_equal(gi.cpu().numpy(), idx) and np.array_equal(ge.cpu().numpy(), empty)
+    assert empty.any() and not empty.all()
+    ref = oracle.group_points(feat, cnt, idx, ncnt)
+    f = T(feat, dev).requires_grad_(True)
+    out = pointnet2_utils.grouping_operation(f, T(cnt, dev), gi, T(ncnt, dev))
+    assert np.array_equal(out.detach().cpu().numpy(), ref)
+    g = rng.normal(size=ref.shape).astype(np.float32)
+    out.backward(T(g, dev))
+    np.testing.assert_allclose(f.grad.cpu().numpy(), oracle.group_points_grad(g, idx, ncnt, cnt, cnt.sum()),
+                               rtol=1e-5, atol=1e-5)
+    # QueryAndGroup module: relative xyz + features, empty balls zeroed
+    qg = pointnet2_utils.QueryAndGroup(0.45, 16, use_xyz=True)
+    nf, _ = qg(T(xyz, dev), T(cnt, dev), T(q, dev), T(ncnt, dev), T(feat, dev))
+    assert nf.shape == (100, 35, 16)
+    assert float(nf[T(empty, dev)].abs().max()) == 0.0
+
+
+def test_roi_grid_pool_module_dense_equals_sparse(dev):
+    """NeighborVoxelSAModuleMSG: identical output from the dense-map path and the index path."""
+    rng = np.random.default_rng(9)
+    B, Z, Y, X = 2, 5, 24, 20
+    idx, xyz, cnt = _voxel_scene(rng, B, Z, Y, X, 0.15)
+    feats = rng.normal(size=(len(idx), 16)).astype(np.float32)
+    M = 2 * 54
+    qc_xyz = np.stack([np.repeat(np.arange(B), M // B), rng.integers(0, X, M), rng.integers(0, Y, M),
+                       rng.integers(0, Z, M)], 1).astype(np.int32)      # [b, x, y, z] as the head passes it
+    q = ((qc_xyz[:, 1:4] + rng.random((M, 3))) * np.array([0.1, 0.1, 0.2])).astype(np.float32)
+    torch.manual_seed(0)
+    mod = voxel_pool_modules.NeighborVoxelSAModuleMSG(query_ranges=[[2, 2, 2]], radii=[0.4], nsamples=[8],
+                                                      mlps=[[16, 16, 24]]).to(dev).eval()
+    st = sp.SparseConvTensor(T(feats, dev), T(idx, dev), [Z, Y, X], B)
+    v2p = T(oracle.generate_voxel2pinds(idx, B, [Z, Y, X]), dev)
+    args = (T(xyz, dev), T(cnt, dev), T(q, dev), torch.tensor([M // B] * B, dtype=torch.int32, device=dev),
+            T(qc_xyz, dev), T(feats, dev))
+    with torch.no_grad():
+        a = mod(*args, v2p)
+        b = mod(*args, st)
+    assert a.shape == (M, 24) and torch.equal(a, b)
