@@ -360,7 +360,7 @@ def roiaware_pool3d_forward(rois, pts, feat, out_size, max_pts, method):
 def roiaware_pool3d_backward(pidx, argmax, grad_out, num_pts, method):
     pidx, argmax, grad_out = _i32(pidx), _i32(argmax), _f32(grad_out)
     N, ox, oy, oz, C = grad_out.shape
-    gin = np.zeros((num_pts, C), np.float32)
+    gin = np.zeros((int(num_pts), C), np.float32)
     lib().orc_roiaware_pool3d_backward(_i(pidx), _i(argmax), _f(grad_out), N, ox, oy, oz, C,
                                        pidx.shape[-1], {"max": 0, "avg": 1}[method], _f(gin))
     return gin
@@ -430,7 +430,7 @@ def group_points_grad(grad_out, idx, idx_batch_cnt, features_batch_cnt, N):
     fbc, ibc = _i32(features_batch_cnt), _i32(idx_batch_cnt)
     M, C, ns = grad_out.shape
     g = np.zeros((N, C), np.float32)
-    lib().orc_group_points_grad(len(ibc), M, C, N, ns, _f(grad_out), _i(idx), _i(ibc), _i(fbc), _f(g))
+    lib().orc_group_points_grad(len(ibc), M, C, int(N), ns, _f(grad_out), _i(idx), _i(ibc), _i(fbc), _f(g))
     return g
 
 
