@@ -47,6 +47,8 @@ struct GlxGrid {
   int B, D, H, W;
   __host__ __device__ long long cells() const { return (long long)B * D * H * W; }
   __host__ __device__ long long words() const { return (cells() + 63) >> 6; }
+  // one occupancy byte per chunk of 8 bitmap words (512 cells)
+  __host__ __device__ long long chunks() const { return (words() + 7) >> 3; }
   __device__ long long lin(int b, int z, int y, int x) const {
     return (((long long)b * D + z) * H + y) * W + x;
   }

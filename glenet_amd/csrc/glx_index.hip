@@ -43,7 +43,8 @@ extern "C" int glx_event_elapsed_ms(void* start, void* stop, float* ms) {
 
 // ---------------------------------------------------------------- bitmap + scan
 __global__ void k_set_bits(const int4* __restrict__ idx, int N, GlxGrid g,
-                           unsigned long long* __restrict__ bitmap, int* __restrict__ status) {
+                           unsigned long long* __restrict__ bitmap,
+                           unsigned char* __restrict__ chunk_flags, int* __restrict__ status) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   int4 c = idx[i];  // b, z, y, x
@@ -54,6 +55,7 @@ __global__ void k_set_bits(const int4* __restrict__ idx, int N, GlxGrid g,
   }
   long long l = g.lin(c.x, c.y, c.z, c.w);
   atomicOr(&bitmap[l >> 6], 1ull << (l & 63));
+  chunk_flags[l >> 9] = 1;
 }
 
 __global__ void k_scatter_perm(const int4* __restrict__ idx, int N, GlxGrid g,
@@ -84,27 +86,32 @@ extern "C" size_t glx_index_workspace_bytes(int B, int D, int H, int W) {
   return glx_scan_workspace_bytes(g.words()) + 256;
 }
 
-int glx_scan_bitmap(const GlxGrid& g, uint64_t* bitmap, int32_t* prefix, int32_t* n_total,
-                    void* workspace, size_t workspace_bytes, hipStream_t st) {
+int glx_scan_bitmap(const GlxGrid& g, uint64_t* bitmap, const uint8_t* chunk_flags,
+                    int32_t* prefix, int32_t* n_total, void* workspace, size_t workspace_bytes,
+                    hipStream_t st) {
   PopcWords f{(const unsigned long long*)bitmap};
-  return glx_exclusive_scan(f, g.words(), prefix, n_total, workspace, workspace_bytes, st);
+  return glx_exclusive_scan(f, g.words(), prefix, n_total, workspace, workspace_bytes, st,
+                            chunk_flags);
 }
 
 extern "C" int glx_index_build(const int32_t* indices, int N, int B, int D, int H, int W,
-                               uint64_t* bitmap, int32_t* prefix, int32_t* rank_to_row,
-                               int32_t* row_to_rank, int32_t* n_unique, int32_t* status,
-                               void* workspace, size_t workspace_bytes, void* stream) {
+                               uint64_t* bitmap, uint8_t* chunk_flags, int32_t* prefix,
+                               int32_t* rank_to_row, int32_t* row_to_rank, int32_t* n_unique,
+                               int32_t* status, void* workspace, size_t workspace_bytes,
+                               void* stream) {
   GLX_REQUIRE(N >= 0 && B > 0 && D > 0 && H > 0 && W > 0, "glx_index_build: bad sizes");
-  GLX_REQUIRE(bitmap && prefix && n_unique && status, "glx_index_build: null output");
+  GLX_REQUIRE(bitmap && chunk_flags && prefix && n_unique && status, "glx_index_build: null output");
   hipStream_t st = (hipStream_t)stream;
   GlxGrid g{B, D, H, W};
   GLX_HIP(hipMemsetAsync(bitmap, 0, (size_t)g.words() * 8, st));
+  GLX_HIP(hipMemsetAsync(chunk_flags, 0, (size_t)g.chunks(), st));
   GLX_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
   if (N > 0) {
     hipLaunchKernelGGL(k_set_bits, dim3(glx_divup(N, 256)), dim3(256), 0, st,
-                       (const int4*)indices, N, g, (unsigned long long*)bitmap, status);
+                       (const int4*)indices, N, g, (unsigned long long*)bitmap, chunk_flags,
+                       status);
   }
-  int rc = glx_scan_bitmap(g, bitmap, prefix, n_unique, workspace, workspace_bytes, st);
+  int rc = glx_scan_bitmap(g, bitmap, chunk_flags, prefix, n_unique, workspace, workspace_bytes, st);
   if (rc != GLX_OK) return rc;
   if (N > 0 && rank_to_row) {
     hipLaunchKernelGGL(k_scatter_perm, dim3(glx_divup(N, 256)), dim3(256), 0, st,
@@ -176,14 +183,18 @@ struct ConvGeom {
   int kd, kh, kw, sd, sh, sw, pd, ph, pw;
 };
 
-// one thread per (input row, kz, ky): marks reachable output cells.
-__global__ void k_outset_mark(const int4* __restrict__ idx, int N, ConvGeom cg, GlxGrid og,
-                              unsigned long long* __restrict__ obitmap) {
+// one thread per (input row, kz, ky): marks reachable output cells.  Rows are walked in cell
+// order (in_rank_to_row) so neighbouring threads hit the same output words.
+__global__ void k_outset_mark(const int4* __restrict__ idx, const int* __restrict__ in_rank_to_row,
+                              int N, ConvGeom cg, GlxGrid og,
+                              unsigned long long* __restrict__ obitmap,
+                              unsigned char* __restrict__ oflags) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   int zy = cg.kd * cg.kh;
   if (t >= (long long)N * zy) return;
-  int i = (int)(t / zy);
-  int r = (int)(t - (long long)i * zy);
+  int s = (int)(t / zy);
+  int r = (int)(t - (long long)s * zy);
+  int i = in_rank_to_row ? in_rank_to_row[s] : s;
   int kz = r / cg.kh, ky = r - kz * cg.kh;
   int4 c = idx[i];
   int nz = c.y + cg.pd - kz, ny = c.z + cg.ph - ky;
@@ -198,13 +209,17 @@ __global__ void k_outset_mark(const int4* __restrict__ idx, int N, ConvGeom cg, 
     long long l = og.lin(c.x, oz, oy, ox);
     unsigned long long bit = 1ull << (l & 63);
     // cheap pre-test avoids most redundant atomics (each output is reached ~3x)
-    if (!(obitmap[l >> 6] & bit)) atomicOr(&obitmap[l >> 6], bit);
+    if (!(obitmap[l >> 6] & bit)) {
+      atomicOr(&obitmap[l >> 6], bit);
+      oflags[l >> 9] = 1;
+    }
   }
 }
 
 extern "C" int glx_outset_build(const int32_t* indices_in, int N_in, int B, int D, int H, int W,
-                                int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph,
-                                int pw, int oD, int oH, int oW, uint64_t* out_bitmap,
+                                const int32_t* in_rank_to_row, int kd, int kh, int kw, int sd,
+                                int sh, int sw, int pd, int ph, int pw, int oD, int oH, int oW,
+                                uint64_t* out_bitmap, uint8_t* out_chunk_flags,
                                 int32_t* out_prefix, int32_t* n_out, void* workspace,
                                 size_t workspace_bytes, void* stream) {
   GLX_REQUIRE(kd > 0 && kh > 0 && kw > 0 && sd > 0 && sh > 0 && sw > 0,
@@ -213,45 +228,61 @@ extern "C" int glx_outset_build(const int32_t* indices_in, int N_in, int B, int 
   (void)D; (void)H; (void)W;
   hipStream_t st = (hipStream_t)stream;
   GlxGrid og{B, oD, oH, oW};
+  GLX_REQUIRE(out_bitmap && out_chunk_flags && out_prefix && n_out, "glx_outset_build: null output");
   GLX_HIP(hipMemsetAsync(out_bitmap, 0, (size_t)og.words() * 8, st));
+  GLX_HIP(hipMemsetAsync(out_chunk_flags, 0, (size_t)og.chunks(), st));
   if (N_in > 0) {
     ConvGeom cg{kd, kh, kw, sd, sh, sw, pd, ph, pw};
     long long total = (long long)N_in * kd * kh;
     hipLaunchKernelGGL(k_outset_mark, dim3(glx_divup(total, 256)), dim3(256), 0, st,
-                       (const int4*)indices_in, N_in, cg, og, (unsigned long long*)out_bitmap);
+                       (const int4*)indices_in, in_rank_to_row, N_in, cg, og,
+                       (unsigned long long*)out_bitmap, out_chunk_flags);
   }
-  return glx_scan_bitmap(og, out_bitmap, out_prefix, n_out, workspace, workspace_bytes, st);
+  return glx_scan_bitmap(og, out_bitmap, out_chunk_flags, out_prefix, n_out, workspace,
+                         workspace_bytes, st);
 }
 
+// one thread per occupied 8-word chunk: decode the chunk base once (64-bit divisions), then
+// walk the set bits carrying x / y / z / b like an odometer.
 __global__ void k_outset_emit(const unsigned long long* __restrict__ bitmap,
+                              const unsigned char* __restrict__ chunk_flags,
                               const int* __restrict__ prefix, long long nwords, GlxGrid g,
                               int4* __restrict__ out) {
-  long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= nwords) return;
-  unsigned long long word = bitmap[w];
-  if (!word) return;
-  int base = prefix[w];
-  while (word) {
-    int bit = __ffsll((long long)word) - 1;
-    word &= word - 1;
-    long long l = (w << 6) + bit;
-    int x = (int)(l % g.W);
-    long long q = l / g.W;
-    int y = (int)(q % g.H);
-    q /= g.H;
-    int z = (int)(q % g.D);
-    int b = (int)(q / g.D);
-    out[base++] = make_int4(b, z, y, x);
+  long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long w0 = ch << 3;
+  if (w0 >= nwords || !chunk_flags[ch]) return;
+  long long l0 = w0 << 6;
+  int x = (int)(l0 % g.W);
+  long long q = l0 / g.W;
+  int y = (int)(q % g.H);
+  q /= g.H;
+  int z = (int)(q % g.D);
+  int b = (int)(q / g.D);
+  for (int wi = 0; wi < 8 && w0 + wi < nwords; ++wi) {
+    unsigned long long word = bitmap[w0 + wi];
+    int base = word ? prefix[w0 + wi] : 0;
+    int done = 0;   // bits of this word already stepped over
+    while (word) {
+      int bit = __ffsll((long long)word) - 1;
+      word &= word - 1;
+      x += bit - done;
+      done = bit;
+      while (x >= g.W) { x -= g.W; if (++y == g.H) { y = 0; if (++z == g.D) { z = 0; ++b; } } }
+      out[base++] = make_int4(b, z, y, x);
+    }
+    x += 64 - done;
+    while (x >= g.W) { x -= g.W; if (++y == g.H) { y = 0; if (++z == g.D) { z = 0; ++b; } } }
   }
 }
 
-extern "C" int glx_outset_emit(const uint64_t* bitmap, const int32_t* prefix, int B, int D, int H,
-                               int W, int32_t* indices_out, void* stream) {
+extern "C" int glx_outset_emit(const uint64_t* bitmap, const uint8_t* chunk_flags,
+                               const int32_t* prefix, int B, int D, int H, int W,
+                               int32_t* indices_out, void* stream) {
   GlxGrid g{B, D, H, W};
   long long nwords = g.words();
-  hipLaunchKernelGGL(k_outset_emit, dim3(glx_divup(nwords, 256)), dim3(256), 0,
-                     (hipStream_t)stream, (const unsigned long long*)bitmap, (const int*)prefix,
-                     nwords, g, (int4*)indices_out);
+  hipLaunchKernelGGL(k_outset_emit, dim3(glx_divup(g.chunks(), 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const unsigned long long*)bitmap, chunk_flags,
+                     (const int*)prefix, nwords, g, (int4*)indices_out);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

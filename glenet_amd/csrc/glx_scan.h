@@ -38,13 +38,19 @@ struct IntArray {
   __device__ int operator()(long long i) const { return a[i]; }
 };
 
+// skip (optional): one byte per thread chunk of SCAN_IPT items; 0 = the whole chunk is zero, so
+// its items are neither read nor (in k_scan_write) given a prefix.  Lets the popcount scans of
+// the mostly empty LiDAR cell bitmaps touch only the occupied 512-cell chunks.
 template <class F>
-__global__ void k_scan_block_sums(F f, long long n, int* __restrict__ block_sums) {
+__global__ void k_scan_block_sums(F f, long long n, const unsigned char* __restrict__ skip,
+                                  int* __restrict__ block_sums) {
   long long i0 = (long long)blockIdx.x * SCAN_IPB + (long long)threadIdx.x * SCAN_IPT;
   int s = 0;
+  if (!skip || (i0 < n && skip[i0 / SCAN_IPT])) {
 #pragma unroll
-  for (int i = 0; i < SCAN_IPT; ++i)
-    if (i0 + i < n) s += f(i0 + i);
+    for (int i = 0; i < SCAN_IPT; ++i)
+      if (i0 + i < n) s += f(i0 + i);
+  }
   int total;
   glx_block_exclusive_scan_256(s, &total);
   if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
@@ -71,18 +77,20 @@ static __global__ void k_scan_of_sums(int* __restrict__ block_sums, int n,
 }
 
 template <class F>
-__global__ void k_scan_write(F f, long long n, const int* __restrict__ block_offsets,
-                             int* __restrict__ excl) {
+__global__ void k_scan_write(F f, long long n, const unsigned char* __restrict__ skip,
+                             const int* __restrict__ block_offsets, int* __restrict__ excl) {
   long long i0 = (long long)blockIdx.x * SCAN_IPB + (long long)threadIdx.x * SCAN_IPT;
   int v[SCAN_IPT];
   int s = 0;
+  const bool live = !skip || (i0 < n && skip[i0 / SCAN_IPT]);
 #pragma unroll
   for (int i = 0; i < SCAN_IPT; ++i) {
-    v[i] = (i0 + i < n) ? f(i0 + i) : 0;
+    v[i] = (live && i0 + i < n) ? f(i0 + i) : 0;
     s += v[i];
   }
   int total;
   int ex = glx_block_exclusive_scan_256(s, &total) + block_offsets[blockIdx.x];
+  if (!live) return;
 #pragma unroll
   for (int i = 0; i < SCAN_IPT; ++i) {
     if (i0 + i < n) excl[i0 + i] = ex;
@@ -98,7 +106,8 @@ static inline size_t glx_scan_workspace_bytes(long long n) {
 // excl[i] = sum_{i'<i} f(i'), *n_total = sum of all.  workspace >= glx_scan_workspace_bytes(n).
 template <class F>
 static int glx_exclusive_scan(F f, long long n, int* excl, int* n_total, void* workspace,
-                              size_t workspace_bytes, hipStream_t st) {
+                              size_t workspace_bytes, hipStream_t st,
+                              const unsigned char* skip = nullptr) {
   int nblk = glx_divup(n, SCAN_IPB);
   if (nblk < 1) nblk = 1;
   if (workspace_bytes < (size_t)nblk * sizeof(int)) {
@@ -107,9 +116,10 @@ static int glx_exclusive_scan(F f, long long n, int* excl, int* n_total, void* w
     return GLX_EWORKSPACE;
   }
   int* bsum = (int*)workspace;
-  hipLaunchKernelGGL((k_scan_block_sums<F>), dim3(nblk), dim3(SCAN_THREADS), 0, st, f, n, bsum);
+  hipLaunchKernelGGL((k_scan_block_sums<F>), dim3(nblk), dim3(SCAN_THREADS), 0, st, f, n, skip,
+                     bsum);
   hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(SCAN_THREADS), 0, st, bsum, nblk, n_total);
-  hipLaunchKernelGGL((k_scan_write<F>), dim3(nblk), dim3(SCAN_THREADS), 0, st, f, n,
+  hipLaunchKernelGGL((k_scan_write<F>), dim3(nblk), dim3(SCAN_THREADS), 0, st, f, n, skip,
                      (const int*)bsum, excl);
   GLX_LAUNCH_CHECK();
   return GLX_OK;

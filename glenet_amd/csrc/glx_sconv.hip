@@ -72,7 +72,7 @@ struct SconvTile {
   static constexpr int THREADS = NW * 64;
   static constexpr int MAXC = (TR + 16 * NW - 1) / (16 * NW);   // chunks per wave per offset
   static constexpr int ACC_LD = COUT + 4;
-  static constexpr int LW = TR / 64;                            // waves that own row slots
+  static constexpr int LW = (TR + 63) / 64;                     // waves that own row slots
   static constexpr size_t lds_bytes = (size_t)TR * ACC_LD * 4 + (size_t)SC_MAXK * TR * 5 +
                                       (TR + 32 + 32 * LW) * 4 + 64 + (size_t)NBUF * C::IMG * 4;
   static_assert(LW <= NW, "row-slot waves exceed block");
@@ -872,6 +872,10 @@ static int launch_mfma(const float* in, const float* Wp, const SconvEpilogue& ep
     case 5: SC_GO(64, 4, 1);
     case 6: SC_GO(64, 4, 2);
     case 7: if constexpr (!big) { SC_GO(256, 8, 1); } else { SC_GO(128, 8, 1); }
+    case 10: SC_GO(32, 4, 1);
+    case 11: SC_GO(32, 4, 2);
+    case 12: SC_GO(64, 8, 1);
+    case 13: SC_GO(32, 2, 1);
     case 0:
       if constexpr (big) {
         if constexpr (CI >= 128) { SC_GO(128, 8, 1); } else { SC_GO(128, 8, 2); }

@@ -19,8 +19,9 @@
 #include "glx_common.h"
 #include "glx_scan.h"
 
-int glx_scan_bitmap(const GlxGrid& g, uint64_t* bitmap, int32_t* prefix, int32_t* n_total,
-                    void* workspace, size_t workspace_bytes, hipStream_t st);
+int glx_scan_bitmap(const GlxGrid& g, uint64_t* bitmap, const uint8_t* chunk_flags,
+                    int32_t* prefix, int32_t* n_total, void* workspace, size_t workspace_bytes,
+                    hipStream_t st);
 
 #define VOX_SENT 0x7F7F7F7F
 
@@ -48,6 +49,7 @@ __device__ __forceinline__ bool vox_cell(const float* __restrict__ p, const VoxG
 template <bool XMAJOR>
 __global__ void k_vox_mark(const float* __restrict__ pts, const int* __restrict__ pbatch, int P,
                            int C, int B, VoxGeom vg, unsigned long long* __restrict__ bitmap,
+                           unsigned char* __restrict__ chunk_flags,
                            long long* __restrict__ cell_lin, int* __restrict__ frame_start) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
@@ -61,6 +63,7 @@ __global__ void k_vox_mark(const float* __restrict__ pts, const int* __restrict_
     l = XMAJOR ? (((long long)b * vg.gx + cx) * vg.gy + cy) * vg.gz + cz
                : (((long long)b * vg.gz + cz) * vg.gy + cy) * vg.gx + cx;
     atomicOr(&bitmap[l >> 6], 1ull << (l & 63));
+    chunk_flags[l >> 9] = 1;
   }
   cell_lin[p] = l;
 }
@@ -176,6 +179,7 @@ __global__ void k_vox_fill(const float* __restrict__ pts, const int* __restrict_
 
 struct HardWs {
   uint64_t* bitmap;
+  uint8_t* cflags;
   int32_t* prefix;
   long long* cell_lin;
   int *cell_rank, *first_pt, *flags, *excl, *row_of_rank, *slots, *frame_start, *frame_base,
@@ -198,6 +202,7 @@ static HardWs hard_ws_layout(void* base, int P, int B, int gx, int gy, int gz, i
   };
   size_t Pn = P > 0 ? P : 1;
   w.bitmap = (uint64_t*)take((size_t)g.words() * 8);
+  w.cflags = (uint8_t*)take((size_t)g.chunks());
   w.prefix = (int32_t*)take((size_t)g.words() * 4);
   w.cell_lin = (long long*)take(Pn * 8);
   w.cell_rank = (int*)take(Pn * 4);
@@ -243,16 +248,18 @@ extern "C" int glx_voxelize_hard(const float* points, const int32_t* point_batch
   VoxGeom vg{vrange[0], vrange[1], vrange[2], vsize[0], vsize[1], vsize[2], gx, gy, gz};
   const int nb = glx_divup(P > 0 ? P : 1, 256);
   GLX_HIP(hipMemsetAsync(w.bitmap, 0, (size_t)g.words() * 8, st));
+  GLX_HIP(hipMemsetAsync(w.cflags, 0, (size_t)g.chunks(), st));
   GLX_HIP(hipMemsetAsync(w.first_pt, 0x7F, (size_t)(P > 0 ? P : 1) * 4, st));
   GLX_HIP(hipMemsetAsync(w.row_of_rank, 0xFF, (size_t)(P > 0 ? P : 1) * 4, st));
   GLX_HIP(hipMemsetAsync(w.slots, 0x7F, (size_t)B * max_voxels * max_points * 4, st));
   GLX_HIP(hipMemsetAsync(w.frame_start, 0xFF, (size_t)(B + 1) * 4, st));
   if (P > 0) {
     hipLaunchKernelGGL((k_vox_mark<false>), dim3(nb), dim3(256), 0, st, points, point_batch, P, C,
-                       B, vg, (unsigned long long*)w.bitmap, w.cell_lin,
+                       B, vg, (unsigned long long*)w.bitmap, w.cflags, w.cell_lin,
                        point_batch ? w.frame_start : nullptr);
   }
-  int rc = glx_scan_bitmap(g, w.bitmap, w.prefix, w.n_unique, w.scan_ws, w.scan_ws_bytes, st);
+  int rc = glx_scan_bitmap(g, w.bitmap, w.cflags, w.prefix, w.n_unique, w.scan_ws, w.scan_ws_bytes,
+                           st);
   if (rc != GLX_OK) return rc;
   if (P > 0) {
     hipLaunchKernelGGL(k_vox_first_point, dim3(nb), dim3(256), 0, st, w.cell_lin, P,
@@ -328,6 +335,7 @@ __global__ void k_dyn_emit(const unsigned long long* __restrict__ bitmap,
 
 struct DynWs {
   uint64_t* bitmap;
+  uint8_t* flags;
   int32_t* prefix;
   long long* cell_lin;
   int* counts;
@@ -347,6 +355,7 @@ static DynWs dyn_ws_layout(void* base, int P, int B, int gx, int gy, int gz) {
   };
   size_t Pn = P > 0 ? P : 1;
   w.bitmap = (uint64_t*)take((size_t)g.words() * 8);
+  w.flags = (uint8_t*)take((size_t)g.chunks());
   w.prefix = (int32_t*)take((size_t)g.words() * 4);
   w.cell_lin = (long long*)take(Pn * 8);
   w.counts = (int*)take(Pn * 4);
@@ -379,14 +388,15 @@ extern "C" int glx_voxelize_dynamic_mean(const float* points, const int32_t* poi
   GlxGrid g{B, gx, gy, gz};
   VoxGeom vg{vrange[0], vrange[1], vrange[2], vsize[0], vsize[1], vsize[2], gx, gy, gz};
   GLX_HIP(hipMemsetAsync(w.bitmap, 0, (size_t)g.words() * 8, st));
+  GLX_HIP(hipMemsetAsync(w.flags, 0, (size_t)g.chunks(), st));
   if (P > 0) {
     GLX_HIP(hipMemsetAsync(features, 0, (size_t)P * C * 4, st));
     GLX_HIP(hipMemsetAsync(w.counts, 0, (size_t)P * 4, st));
     hipLaunchKernelGGL((k_vox_mark<true>), dim3(glx_divup(P, 256)), dim3(256), 0, st, points,
-                       point_batch, P, C, B, vg, (unsigned long long*)w.bitmap, w.cell_lin,
-                       (int*)nullptr);
+                       point_batch, P, C, B, vg, (unsigned long long*)w.bitmap, w.flags,
+                       w.cell_lin, (int*)nullptr);
   }
-  int rc = glx_scan_bitmap(g, w.bitmap, w.prefix, n_voxels, w.scan_ws, w.scan_ws_bytes, st);
+  int rc = glx_scan_bitmap(g, w.bitmap, w.flags, w.prefix, n_voxels, w.scan_ws, w.scan_ws_bytes, st);
   if (rc != GLX_OK) return rc;
   if (P > 0) {
     long long total = (long long)P * C;

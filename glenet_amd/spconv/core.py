@@ -35,18 +35,19 @@ def _triple(v):
 class CellIndex:
     """Rank dictionary of one active set on a (B, D, H, W) grid (device resident)."""
 
-    __slots__ = ("grid", "bitmap", "prefix", "rank_to_row", "row_to_rank", "n")
+    __slots__ = ("grid", "bitmap", "flags", "prefix", "rank_to_row", "row_to_rank", "n")
 
-    def __init__(self, grid, bitmap, prefix, rank_to_row, row_to_rank, n):
-        self.grid, self.bitmap, self.prefix = grid, bitmap, prefix
+    def __init__(self, grid, bitmap, flags, prefix, rank_to_row, row_to_rank, n):
+        self.grid, self.bitmap, self.flags, self.prefix = grid, bitmap, flags, prefix
         self.rank_to_row, self.row_to_rank, self.n = rank_to_row, row_to_rank, n
 
     @staticmethod
     def alloc(grid, device):
         words = query("glx_index_words", *grid)
         bitmap = torch.empty(words, dtype=torch.int64, device=device)
+        flags = torch.empty((words + 7) // 8, dtype=torch.uint8, device=device)
         prefix = torch.empty(words, dtype=torch.int32, device=device)
-        return bitmap, prefix
+        return bitmap, flags, prefix
 
     @staticmethod
     def build(indices, grid):
@@ -54,13 +55,13 @@ class CellIndex:
         _lib.check_cuda(indices)
         dev = indices.device
         N = indices.shape[0]
-        bitmap, prefix = CellIndex.alloc(grid, dev)
+        bitmap, flags, prefix = CellIndex.alloc(grid, dev)
         r2row = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
         row2r = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
         meta = torch.zeros(2, dtype=torch.int32, device=dev)  # n_unique, status
         wsb = query("glx_index_workspace_bytes", *grid)
         ws = workspace.get(wsb, dev)
-        call("glx_index_build", indices, N, *grid, bitmap, prefix, r2row, row2r, meta[0:1],
+        call("glx_index_build", indices, N, *grid, bitmap, flags, prefix, r2row, row2r, meta[0:1],
              meta[1:2], ws, size_arg(ws.numel()))
         n_unique, status = meta.tolist()  # one host sync per distinct active set
         if status != 0:
@@ -68,7 +69,7 @@ class CellIndex:
         if n_unique != N:
             raise ValueError("SparseConvTensor indices contain duplicates (%d unique of %d)"
                              % (n_unique, N))
-        return CellIndex(grid, bitmap, prefix, r2row, row2r, N)
+        return CellIndex(grid, bitmap, flags, prefix, r2row, row2r, N)
 
 
 class RuleSet:
@@ -135,13 +136,13 @@ def build_strided_rules(x, ksize, stride, padding, dilation=(1, 1, 1)):
     if min(out_shape) <= 0:
         raise ValueError("SparseConv3d output shape %s is empty" % (out_shape,))
     ogrid = (B, *out_shape)
-    obitmap, oprefix = CellIndex.alloc(ogrid, dev)
+    obitmap, oflags, oprefix = CellIndex.alloc(ogrid, dev)
     n_out_dev = torch.zeros(1, dtype=torch.int32, device=dev)
     wsb = query("glx_index_workspace_bytes", *ogrid)
     ws = workspace.get(wsb, dev)
     N_in = x.indices.shape[0]
-    call("glx_outset_build", x.indices, N_in, B, D, H, W, *ksize, *stride, *padding, *out_shape,
-         obitmap, oprefix, n_out_dev, ws, size_arg(ws.numel()))
+    call("glx_outset_build", x.indices, N_in, B, D, H, W, idx.rank_to_row, *ksize, *stride, *padding,
+         *out_shape, obitmap, oflags, oprefix, n_out_dev, ws, size_arg(ws.numel()))
     N_out = int(n_out_dev.item())  # host sync: output row count sizes the next tensors
     K = ksize[0] * ksize[1] * ksize[2]
     rs = RuleSet()
@@ -149,11 +150,11 @@ def build_strided_rules(x, ksize, stride, padding, dilation=(1, 1, 1)):
     rs.out_indices = torch.empty((max(N_out, 1), 4), dtype=torch.int32, device=dev)[:N_out]
     rs.nbr = torch.empty((max(N_out, 1), K), dtype=torch.int32, device=dev)
     if N_out > 0:
-        call("glx_outset_emit", obitmap, oprefix, *ogrid, rs.out_indices)
+        call("glx_outset_emit", obitmap, oflags, oprefix, *ogrid, rs.out_indices)
         call("glx_rules_strided", rs.out_indices, N_out, B, D, H, W, idx.bitmap, idx.prefix,
              idx.rank_to_row, *ksize, *stride, *padding, rs.nbr, None)
     rs.out_spatial_shape = out_shape
-    rs.out_index = CellIndex(ogrid, obitmap, oprefix, None, None, N_out)  # rows already sorted
+    rs.out_index = CellIndex(ogrid, obitmap, oflags, oprefix, None, None, N_out)  # rows already sorted
     rs.tile_order_out = None
     rs.tile_order_in = idx.rank_to_row
     rs.in_index, rs.in_indices, rs.in_spatial_shape = idx, x.indices, list(x.spatial_shape)

@@ -50,7 +50,9 @@ int glx_event_elapsed_ms(void* start, void* stop, float* ms);
  * the dense (B,Z,Y,X) int32 voxel->point map of pcdet/utils/common_utils.py:226-243.
  * ------------------------------------------------------------------------------------ */
 
-/* words = ceil(B*D*H*W / 64).  bitmap: words*8 bytes, prefix: words*4 bytes. */
+/* words = ceil(B*D*H*W / 64).  bitmap: words*8 bytes, prefix: words*4 bytes, chunk_flags:
+ * ceil(words/8) bytes (one occupancy byte per 512 cells: scans and enumerations skip empty
+ * chunks; prefix[] is only defined for words of occupied chunks). */
 int64_t glx_index_words(int B, int D, int H, int W);
 size_t glx_index_workspace_bytes(int B, int D, int H, int W);
 
@@ -60,7 +62,7 @@ size_t glx_index_workspace_bytes(int B, int D, int H, int W);
  *   status (device int32[1]): set non-zero if any index is outside the grid.
  * Replaces: spconv indice hash build (call sites spconv_backbone.py:78-114). */
 int glx_index_build(const int32_t* indices, int N, int B, int D, int H, int W,
-                    uint64_t* bitmap, int32_t* prefix, int32_t* rank_to_row,
+                    uint64_t* bitmap, uint8_t* chunk_flags, int32_t* prefix, int32_t* rank_to_row,
                     int32_t* row_to_rank, int32_t* n_unique, int32_t* status,
                     void* workspace, size_t workspace_bytes, void* stream);
 
@@ -78,12 +80,13 @@ int glx_rules_subm(const int32_t* indices, int N, int B, int D, int H, int W,
  * enumerated in ascending linear (b,z,y,x) order.  Out grid = (B, oD, oH, oW).
  * Replaces: spconv SparseConv3d output index generation (spconv_backbone.py:14,90,97,104,113). */
 int glx_outset_build(const int32_t* indices_in, int N_in, int B, int D, int H, int W,
-                     int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
-                     int oD, int oH, int oW, uint64_t* out_bitmap, int32_t* out_prefix,
-                     int32_t* n_out, void* workspace, size_t workspace_bytes, void* stream);
+                     const int32_t* in_rank_to_row, int kd, int kh, int kw, int sd, int sh, int sw,
+                     int pd, int ph, int pw, int oD, int oH, int oW, uint64_t* out_bitmap,
+                     uint8_t* out_chunk_flags, int32_t* out_prefix, int32_t* n_out,
+                     void* workspace, size_t workspace_bytes, void* stream);
 /* Decode the set bits of an index into (n,4) indices [b,z,y,x], ascending order. */
-int glx_outset_emit(const uint64_t* bitmap, const int32_t* prefix, int B, int D, int H, int W,
-                    int32_t* indices_out, void* stream);
+int glx_outset_emit(const uint64_t* bitmap, const uint8_t* chunk_flags, const int32_t* prefix,
+                    int B, int D, int H, int W, int32_t* indices_out, void* stream);
 /* Rule table of the strided conv: nbr[j*K+k] = input row at cell(j)*stride - pad + k, or -1.
  * in_rank_to_row may be NULL when input rows are already in ascending cell order. */
 int glx_rules_strided(const int32_t* indices_out, int N_out, int B, int D, int H, int W,
