@@ -1,11 +1,15 @@
 #!/usr/bin/env python
-"""bench.py -- headline benchmark of the hot path (contract: see task brief / DESIGN.md).
+"""bench.py -- headline benchmark of the hot path (contract: see task brief / DESIGN.md section 5).
 
 Workload at N=1 = BASELINE.json configs[1]: GLENet-VR SECOND sparse backbone
 (VoxelBackBone8x as written in the reference: 8 SubMConv3d + 4 SparseConv3d), forward only,
 batch 4 synthetic KITTI-shaped frames per GPU.  One step = one pass of the hot path over one
 batch whose points are already resident in HBM:
-    hard voxelize (4 frames) -> MeanVFE -> 12 sparse convs (+BN/ReLU) -> dense()/BEV fold.
+    hard voxelize (4 frames) -> MeanVFE -> rule tables -> 12 sparse convs (+BN/ReLU) -> dense().
+A step has two stages: A (voxelize, VFE, every rule table; it owns the few host read-backs that
+size tensors) and B (the 12 convolutions + dense, no host syncs).  By default they run back to
+back on one stream; --pipeline overlaps stage A of batch i+1 with stage B of batch i on two HIP
+streams / two host threads.  Exactly K steps (K stage-A and K stage-B passes) are timed.
 N > 1: one process per GPU (torch.distributed, RCCL), every rank runs its own 4 frames
 (weak scaling, frames shard with no data-path collective in a forward pass); the timed
 region is bracketed by barrier + synchronize and the max over ranks is reported.
@@ -13,20 +17,22 @@ region is bracketed by barrier + synchronize and the max over ranks is reported.
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import contextlib
 import json
 import os
+import queue
 import sys
+import threading
 import time
+from collections import deque
 
 import numpy as np
 import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from glenet_amd import backbone as gb  # noqa: E402
+from glenet_amd import dist as gdist  # noqa: E402
 from glenet_amd import synth  # noqa: E402
 from glenet_amd.spconv import core as spcore  # noqa: E402
 
@@ -111,31 +117,34 @@ def cpu_baseline(frames_np, model):
     o = taps["out"]
     oracle.dense(o.features, o.indices, len(frames_np), o.shape)
     dt = time.perf_counter() - t0
-    return dict(value=len(frames_np) / dt, unit="frames/s", cores=1, kind="port",
+    return dict(value=round(len(frames_np) / dt, 3), unit="frames/s", cores=1, kind="port",
                 sample="1 batch of %d synthetic KITTI-shaped frames (the same workload), one pass, "
-                       "%.1f s on %d host cores available" % (len(frames_np), dt, os.cpu_count()))
+                       "%.1f s; host has %d cores" % (len(frames_np), dt, os.cpu_count()))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="overlap stage A of batch i+1 with stage B of batch i (2 streams, 2 host "
+                         "threads); off by default: host-side Python makes it unstable")
+    ap.add_argument("--lazy-rules", action="store_true",
+                    help="single stream, rule tables built inside the conv modules on first use")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    rank, local_rank, world = gdist.env_world()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    gdist.init("nccl", device=dev)
 
     K = synth.KITTI
-    frames_np = [synth.kitti_frame(rank * FRAMES_PER_GPU + i)[0] for i in range(FRAMES_PER_GPU)]
+    frame_ids = gdist.frames_for_rank(rank, world, FRAMES_PER_GPU)
+    frames_np = [synth.kitti_frame(i)[0] for i in frame_ids]
     pts = torch.from_numpy(np.concatenate(frames_np)).to(dev)
     bidx = torch.from_numpy(np.concatenate(
         [np.full(len(f), i, np.int32) for i, f in enumerate(frames_np)])).to(dev)
@@ -144,51 +153,88 @@ def main():
     grid = gb.gv.grid_size_of(K["point_cloud_range"], K["voxel_size"])
     model = gb.VoxelBackBone8x(K["num_features"], grid).to(dev).eval()
     vfe, hc = gb.MeanVFE(), gb.HeightCompression()
+    comp_stream = torch.cuda.current_stream(dev)
+    args.no_pipeline = (not args.pipeline) or args.lazy_rules
+    prep_stream = comp_stream if args.no_pipeline else torch.cuda.Stream(dev)
 
-    def step():
-        with torch.no_grad():
+    def prepare():
+        """Stage A: everything that depends only on the points' coordinates (+ the VFE)."""
+        with torch.no_grad(), torch.cuda.stream(prep_stream):
             bd = gb.voxelize_batch(pts, bidx, FRAMES_PER_GPU, K, train=True)
             bd = vfe(bd)
+            if not args.lazy_rules:
+                bd["rule_plan"] = model.plan(bd["voxel_coords"], FRAMES_PER_GPU, index=bd["voxel_index"])
+            ready = torch.cuda.Event()
+            ready.record(prep_stream)
+        return bd, ready
+
+    def compute(bd, ready):
+        """Stage B: the 12 sparse convolutions and dense(); no host syncs."""
+        with torch.no_grad():
+            comp_stream.wait_event(ready)
             bd = model(bd)
             bd = hc(bd)
-        return bd
+            done = torch.cuda.Event()
+            done.record(comp_stream)
+        return bd, done
 
-    for _ in range(args.warmup):
-        step()
+    def run(steps):
+        """Exactly `steps` prepares and `steps` computes.  Stage A runs in its own host thread
+        (its read-backs block only that thread; the GIL is released while it waits), stage B is
+        enqueued by the main thread; a bounded queue lets stage A run at most 2 batches ahead."""
+        alive = deque()          # keep stage-A tensors until stage B has consumed them
+        out = None
+        if args.no_pipeline:
+            for _ in range(steps):
+                cur = prepare()
+                out, done = compute(*cur)
+            return out
+        q = queue.Queue(maxsize=2)
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        def producer():
+            try:
+                torch.cuda.set_device(dev)
+                for _ in range(steps):
+                    q.put(prepare())
+            except BaseException as e:   # surface failures in the consumer
+                q.put(e)
+
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        for _ in range(steps):
+            cur = q.get()
+            if isinstance(cur, BaseException):
+                raise cur
+            out, done = compute(*cur)
+            alive.append((cur, out, done))
+            while len(alive) > 3:
+                alive.popleft()[2].synchronize()
+        th.join()
+        return out
+
+    run(args.warmup)
+    torch.cuda.synchronize(dev)
 
     # ---- headline: exactly K steps between two fences, nothing else in the region
-    fence()
+    gdist.fence(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        bd = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    bd = run(args.steps)
+    gdist.fence(dev)
+    dt = gdist.reduce_max(time.perf_counter() - t0, dev)
 
     # ---- roofline: the same K steps once more with every sparse-conv launch bracketed by HIP
     # events on its stream (start/stop attached to the dispatch = kernel-only time).  Kept out of
-    # the headline loop because the event-bracketed launches serialise the otherwise async queue.
+    # the headline loop because event-bracketed launches serialise the otherwise async queue.
     prof = ConvProfiler()
     spcore._profile_hook = prof
     prof.enabled = True
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
+    run(args.steps)
+    torch.cuda.synchronize(dev)
     prof.enabled = False
     spcore._profile_hook = None
 
     frames_total = FRAMES_PER_GPU * world * args.steps
     per = prof.summary()
-    # dominant kernel = the sparse-conv instantiation with the most device time
     dom = max(per, key=lambda k: per[k]["ms"]) if per else None
     traffic = load_traffic()
     roof = None
@@ -212,7 +258,6 @@ def main():
                                 launches_per_step=v["launches"] // args.steps)
                         for k, v in sorted(per.items())})
 
-    out = None
     if rank == 0:
         st = bd["encoded_spconv_tensor"]
         out = dict(metric="LiDAR frames/sec (sparse backbone fwd) on KITTI-shaped clouds",
@@ -223,16 +268,20 @@ def main():
                    config=dict(workload="configs[1]: VoxelBackBone8x (8 SubMConv3d + 4 SparseConv3d "
                                         "as in spconv_backbone.py:77-117) fwd-only, batch 4 "
                                         "KITTI-shaped frames/GPU, 20000 pts/frame, voxel "
-                                        "0.05x0.05x0.1 m; step = voxelize + MeanVFE + backbone + dense()",
+                                        "0.05x0.05x0.1 m; step = voxelize + MeanVFE + rule tables + "
+                                        "12 sparse convs + dense()",
                                frames_per_gpu=FRAMES_PER_GPU, points_per_frame=20000,
                                voxels_in=int(bd["voxel_coords"].shape[0]),
                                voxels_out=int(st.indices.shape[0]),
+                               pipeline=("off, lazy rules" if args.lazy_rules else "off") if args.no_pipeline
+                               else "2-stage, 2 streams, 2 host threads",
                                parallelism="dp%d (frames shard, no data-path collective)" % world),
                    roofline=roof)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames_np, model)
         print(json.dumps(out), flush=True)
     if world > 1:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
 

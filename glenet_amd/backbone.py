@@ -91,9 +91,18 @@ class SparseBackbone8x(nn.Module):
         self.backbone_channels = {"x_conv1": 16, "x_conv2": 32, "x_conv3": 64,
                                   "x_conv4": cfg["stages"][-1][1]}
 
+    def plan(self, voxel_coords, batch_size, index=None):
+        """Build every rule table of the backbone from the coordinates alone (they do not depend
+        on features), so the convolutions afterwards run back to back without host syncs.
+        Returns the indice_dict to pass as batch_dict["rule_plan"]."""
+        return spconv.core.plan_rules(voxel_coords.int(), self.sparse_shape, batch_size,
+                                      self.sparse_convs(), index=index)
+
     def forward(self, batch_dict):
         x = spconv.SparseConvTensor(batch_dict["voxel_features"], batch_dict["voxel_coords"].int(),
-                                    self.sparse_shape, batch_dict["batch_size"])
+                                    self.sparse_shape, batch_dict["batch_size"],
+                                    indice_dict=batch_dict.get("rule_plan"))
+        x._index = batch_dict.get("voxel_index")
         x = self.conv_input(x)
         c1 = self.conv1(x)
         c2 = self.conv2(c1)
@@ -138,10 +147,13 @@ class HeightCompression(nn.Module):
 
 def voxelize_batch(points_list_or_stacked, batch_idx, batch_size, cfg, train=True):
     """Device-side replacement of DataProcessor.transform_points_to_voxels + collate_batch
-    (data_processor.py:117-152, dataset.py:192-197): stacked points -> batch_dict entries."""
+    (data_processor.py:117-152, dataset.py:192-197): stacked points -> batch_dict entries.  The
+    voxelizer's cell bitmap doubles as the sparse tensor's cell index (grid depth gz + 1)."""
     max_voxels = cfg["max_voxels_train"] if train else cfg["max_voxels_test"]
-    v, c, n, offs = gv.hard_voxelize(points_list_or_stacked, cfg["voxel_size"],
-                                     cfg["point_cloud_range"], cfg["max_points"], max_voxels,
-                                     batch_idx=batch_idx, batch_size=batch_size)
+    gz = gv.grid_size_of(cfg["point_cloud_range"], cfg["voxel_size"])[2]
+    v, c, n, offs, index = gv.hard_voxelize(points_list_or_stacked, cfg["voxel_size"],
+                                            cfg["point_cloud_range"], cfg["max_points"], max_voxels,
+                                            batch_idx=batch_idx, batch_size=batch_size,
+                                            index_depth=gz + 1)
     return dict(voxels=v, voxel_coords=c, voxel_num_points=n, batch_size=batch_size,
-                voxel_offset=offs)
+                voxel_offset=offs, voxel_index=index)

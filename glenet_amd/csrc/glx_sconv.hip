@@ -12,6 +12,7 @@
 // v_mfma_f32_16x16x4_f32 (exact fp32, bitwise an fmaf chain).  Offsets absent from the
 // whole tile are skipped, so the dense MFMA work tracks the rule count R.
 #include <hip/hip_ext.h>
+#include <stdlib.h>
 #include <type_traits>
 
 #include "glx_common.h"
@@ -716,6 +717,412 @@ __global__ __launch_bounds__(64, 2) void k_sconv_rt(
 #undef RT_NEXT
 }
 
+// ==================================================================== column-owner kernel
+// A block owns TR = 128 output rows and compacts them per kernel offset into pair lists (as
+// the block kernel does), but the work is split by OUTPUT COLUMNS: wave (ct, slab) computes the
+// 16-channel tile ct for every pair of its row slab.  Every wave therefore does the same amount
+// of work, only ever touches its own columns of the LDS accumulator tile (no conflicts, no
+// barriers in the main loop, fixed summation order), and needs just a (Cin x 16) slice of W[k],
+// which it streams from L2 straight into registers one offset ahead.  The price is that the
+// waves of a block gather the same input rows (served by L1/L2).
+template <int CIN, int COUT>
+struct CoCfg {
+  static constexpr int CQ = CIN / 4;
+  static constexpr int NT = COUT / 16;                 // column tiles = column owners
+  static constexpr int NW = NT < 4 ? 4 : NT;           // waves per block
+  static constexpr int RS = NW / NT;                   // row slabs
+  static constexpr int TR = 128;
+  static constexpr int TRS = TR / RS;                  // rows per slab (32, 64 or 128)
+  static constexpr int ACC_LD = COUT + 4;
+  static constexpr int IMG = CIN * COUT;
+  static constexpr size_t lds_bytes = (size_t)TR * ACC_LD * 4 + (size_t)SC_MAXK * TR * 5 +
+                                      (size_t)(TR + RS * 32 + 2 * 32) * 4 + 64;
+};
+
+// W (K, CIN, COUT) -> img[k][ct][q][n][t] = W[k][rt_channel(q,t)][ct*16 + n]
+template <int CIN, int COUT>
+__global__ void k_pack_weights_co(const float* __restrict__ W, int K, float* __restrict__ Wp) {
+  using C = CoCfg<CIN, COUT>;
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= K * CIN * COUT) return;
+  int t = e % C::CQ;
+  int n = (e / C::CQ) % 16;
+  int q = (e / (C::CQ * 16)) % 4;
+  int ct = (e / (C::CQ * 64)) % C::NT;
+  int k = e / (C::CQ * 64 * C::NT);
+  Wp[e] = W[((size_t)k * CIN + rt_channel<CIN>(q, t)) * COUT + ct * 16 + n];
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(512) void k_sconv_co(const float* __restrict__ in, const float* __restrict__ Wp,
+                           SconvEpilogue ep, const int* __restrict__ nbr,
+                           const int* __restrict__ tile_order, int N_out, int K,
+                           float* __restrict__ out) {
+  using C = CoCfg<CIN, COUT>;
+  constexpr int CQ = C::CQ, TR = C::TR, TRS = C::TRS, RS = C::RS, ACC_LD = C::ACC_LD;
+  constexpr int THREADS = C::NW * 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_acc = smem;                                          // TR * ACC_LD
+  int* s_pin = reinterpret_cast<int*>(s_acc + TR * ACC_LD);     // SC_MAXK * TR  ([k][slot-in-list])
+  int* s_rows = s_pin + SC_MAXK * TR;                           // TR
+  int* s_cnt = s_rows + TR;                                     // RS * 32
+  int* s_wcnt = s_cnt + RS * 32;                                // 2 * 32 (setup only)
+  unsigned char* s_pslot = reinterpret_cast<unsigned char*>(s_wcnt + 64);   // SC_MAXK * TR
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int row0 = blockIdx.x * TR;
+
+  // ---- setup (threads < TR own one row slot each): rows, neighbour lists, per-slab compaction.
+  // list of (slab, k) lives at s_pin[k * TR + slab * TRS ...]
+  int my_row = -1;
+  if (tid < TR) {
+    int p = row0 + tid;
+    my_row = (p < N_out) ? (tile_order ? tile_order[p] : p) : -1;
+    s_rows[tid] = my_row;
+  }
+  for (int i = tid; i < TR * ACC_LD / 4; i += THREADS)
+    reinterpret_cast<f32x4*>(s_acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int nb[SC_MAXK];
+  const int slab = tid / TRS;                       // my slab (setup threads)
+  // lanes of my wave that belong to my slab
+  const unsigned long long slab_lanes =
+      TRS >= 64 ? ~0ull : (((1ull << TRS) - 1ull) << ((lane / TRS) * TRS));
+  if (tid < TR) {
+#pragma unroll
+    for (int k = 0; k < SC_MAXK; ++k)
+      nb[k] = (k < K && my_row >= 0) ? nbr[(long long)my_row * K + k] : -1;
+    if (TRS > 64) {
+#pragma unroll
+      for (int k = 0; k < SC_MAXK; ++k) {
+        unsigned long long b = __ballot(nb[k] >= 0);
+        if (lane == 0) s_wcnt[wave * 32 + k] = __popcll(b);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < TR) {
+#pragma unroll
+    for (int k = 0; k < SC_MAXK; ++k) {
+      const bool v = nb[k] >= 0;
+      unsigned long long b = __ballot(v) & slab_lanes;
+      int base = (TRS > 64 && (wave & 1)) ? s_wcnt[(wave - 1) * 32 + k] : 0;
+      if (v) {
+        int pos = k * TR + slab * TRS + base + __popcll(b & ((1ull << lane) - 1ull));
+        s_pin[pos] = nb[k];
+        s_pslot[pos] = (unsigned char)tid;
+      }
+      // the last lane group of a slab publishes the slab's count
+      const bool closer = TRS > 64 ? ((wave & 1) && lane == 0) : ((lane % (TRS >= 64 ? 64 : TRS)) == 0);
+      if (closer) s_cnt[slab * 32 + k] = base + __popcll(b);
+    }
+  }
+  __syncthreads();
+
+  // ---- main loop: wave (ct, wslab) walks every offset of its slab, no barriers
+  const int ct = wave % C::NT, wslab = wave / C::NT;
+  unsigned mask = 0;
+#pragma unroll
+  for (int k = 0; k < SC_MAXK; ++k)
+    if (k < K && s_cnt[wslab * 32 + k] > 0) mask |= 1u << k;
+  mask = __builtin_amdgcn_readfirstlane(mask);
+  const int* pin = s_pin + wslab * TRS;
+  const unsigned char* pslot = s_pslot + wslab * TRS;
+
+  // Software pipeline: a wave has only ~16 MFMAs (512 cycles) of work per chunk, far less than
+  // one L2 round trip, so 4 chunk gathers (ring A0..A3) and 2 weight slices (W1, W2) are kept in
+  // flight ahead of the chunk being multiplied.
+  float Wc[CQ], W1[CQ], W2[CQ], Ac[CQ];
+  float A0[CQ], A1[CQ], A2[CQ], A3[CQ];
+  bool v0 = false, v1 = false, v2 = false, v3 = false;
+#define CO_LOAD_W(KK, WDST)                                                                  \
+  {                                                                                          \
+    const float* wp_ = Wp + (size_t)(KK) * C::IMG + (((size_t)ct * 4 + q) * 16 + r) * CQ;    \
+    if constexpr (CQ % 4 == 0) {                                                             \
+      _Pragma("unroll") for (int i_ = 0; i_ < CQ / 4; ++i_) {                                \
+        f32x4 v_ = reinterpret_cast<const f32x4*>(wp_)[i_];                                  \
+        WDST[4 * i_ + 0] = v_[0]; WDST[4 * i_ + 1] = v_[1]; WDST[4 * i_ + 2] = v_[2]; WDST[4 * i_ + 3] = v_[3]; \
+      }                                                                                      \
+    } else {                                                                                 \
+      _Pragma("unroll") for (int i_ = 0; i_ < CQ; ++i_) WDST[i_] = wp_[i_];                  \
+    }                                                                                        \
+  }
+#define CO_GATHER(KK, CC, CNT, ADST, VDST)                                                   \
+  {                                                                                          \
+    int p_ = (CC) * 16 + r;                                                                  \
+    int irow_ = (p_ < (CNT)) ? pin[(KK) * TR + p_] : -1;                                     \
+    const float* ap_ = in + (long long)(irow_ < 0 ? 0 : irow_) * CIN;                        \
+    if constexpr (CIN >= 16) {                                                               \
+      _Pragma("unroll") for (int i_ = 0; i_ < CQ / 4; ++i_) {                                \
+        f32x4 v_ = *reinterpret_cast<const f32x4*>(ap_ + 16 * i_ + 4 * q);                   \
+        ADST[4 * i_ + 0] = v_[0]; ADST[4 * i_ + 1] = v_[1]; ADST[4 * i_ + 2] = v_[2]; ADST[4 * i_ + 3] = v_[3]; \
+      }                                                                                      \
+    } else {                                                                                 \
+      _Pragma("unroll") for (int i_ = 0; i_ < CQ; ++i_) ADST[i_] = ap_[q * CQ + i_];         \
+    }                                                                                        \
+    VDST = irow_ >= 0;                                                                       \
+  }
+  // cursors over the (offset, chunk) items of this slab: P = prefetch, X = compute
+  struct Cur { unsigned rem; int k, c, cnt; };
+  auto cur_init = [&](Cur& u) {
+    u.rem = mask; u.k = -1; u.c = 0; u.cnt = 0;
+    if (u.rem) { u.k = __builtin_ctz(u.rem); u.rem &= u.rem - 1; u.cnt = s_cnt[wslab * 32 + u.k]; }
+  };
+  auto cur_next = [&](Cur& u) {
+    if (++u.c * 16 >= u.cnt) {
+      u.c = 0;
+      if (u.rem) { u.k = __builtin_ctz(u.rem); u.rem &= u.rem - 1; u.cnt = s_cnt[wslab * 32 + u.k]; }
+      else u.k = -1;
+    }
+  };
+  Cur P, X;
+  cur_init(P);
+  cur_init(X);
+  if (P.k >= 0) { CO_GATHER(P.k, P.c, P.cnt, A0, v0); cur_next(P); }
+  if (P.k >= 0) { CO_GATHER(P.k, P.c, P.cnt, A1, v1); cur_next(P); }
+  if (P.k >= 0) { CO_GATHER(P.k, P.c, P.cnt, A2, v2); cur_next(P); }
+  if (P.k >= 0) { CO_GATHER(P.k, P.c, P.cnt, A3, v3); cur_next(P); }
+  // weight slices of the first two offsets
+  {
+    unsigned m2 = mask;
+    if (m2) { CO_LOAD_W(__builtin_ctz(m2), W1); m2 &= m2 - 1; }
+    if (m2) { CO_LOAD_W(__builtin_ctz(m2), W2); }
+  }
+  int curk = -1;
+#define CO_STEP(ABUF, VBUF)                                                                  \
+  if (X.k >= 0) {                                                                            \
+    if (X.k != curk) {   /* new offset: rotate the weight slices, fetch the one 2 offsets ahead */ \
+      curk = X.k;                                                                            \
+      _Pragma("unroll") for (int t_ = 0; t_ < CQ; ++t_) { Wc[t_] = W1[t_]; W1[t_] = W2[t_]; } \
+      unsigned m2_ = X.rem;                                                                  \
+      if (m2_) { m2_ &= m2_ - 1; if (m2_) CO_LOAD_W(__builtin_ctz(m2_), W2); }               \
+    }                                                                                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < CQ; ++i_) Ac[i_] = VBUF ? ABUF[i_] : 0.f;        \
+    const int xk_ = X.k, xc_ = X.c, xcnt_ = X.cnt;                                           \
+    cur_next(X);                                                                             \
+    if (P.k >= 0) { CO_GATHER(P.k, P.c, P.cnt, ABUF, VBUF); cur_next(P); }                   \
+    f32x4 acc0{0.f, 0.f, 0.f, 0.f}, acc1{0.f, 0.f, 0.f, 0.f};                                \
+    _Pragma("unroll") for (int t_ = 0; t_ < CQ; t_ += 2) {                                   \
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[t_], Ac[t_], acc0, 0, 0, 0);            \
+      if (t_ + 1 < CQ) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[t_ + 1], Ac[t_ + 1], acc1, 0, 0, 0); \
+    }                                                                                        \
+    acc0 += acc1;                                                                            \
+    const int p_out_ = xc_ * 16 + r;                                                         \
+    if (p_out_ < xcnt_) {                                                                    \
+      float* dst_ = s_acc + (int)pslot[xk_ * TR + p_out_] * ACC_LD + ct * 16 + 4 * q;        \
+      f32x4 o_ = *reinterpret_cast<f32x4*>(dst_);                                            \
+      o_ += acc0;                                                                            \
+      *reinterpret_cast<f32x4*>(dst_) = o_;                                                  \
+    }                                                                                        \
+  }
+  while (X.k >= 0) {
+    CO_STEP(A0, v0)
+    CO_STEP(A1, v1)
+    CO_STEP(A2, v2)
+    CO_STEP(A3, v3)
+  }
+#undef CO_STEP
+#undef CO_LOAD_W
+#undef CO_GATHER
+  __syncthreads();
+
+  // ---- epilogue: coalesced row stores with the fused pointwise tail
+  constexpr int C4 = COUT / 4;
+  for (int i = tid; i < TR * C4; i += THREADS) {
+    int rr = i / C4, c4 = i - rr * C4;
+    int orow = s_rows[rr];
+    if (orow < 0) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(s_acc + rr * ACC_LD + 4 * c4);
+    const int co = 4 * c4;
+    if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + co);
+    if (ep.scale) v *= *reinterpret_cast<const f32x4*>(ep.scale + co);
+    if (ep.shift) v += *reinterpret_cast<const f32x4*>(ep.shift + co);
+    if (ep.relu) {
+      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(out + (long long)orow * COUT + 4 * c4) = v;
+  }
+}
+
+// ==================================================================== wave-private kernel, deep pipeline
+// k_sconv_wq: every wave owns TRW = 48 consecutive output rows (compaction lists, fp32
+// accumulator tile in LDS, epilogue) and never synchronises with another wave.  Per (offset,
+// 16-pair chunk) item it issues CQ x NTG MFMAs against the full W[k] fragment held in registers.
+// Latency hiding is explicit: the gathers of the next 4 items are always in flight (register
+// ring A0..A3, filled straight by the loads -- absent pairs read a zero row, so there is no
+// select or copy between load and MFMA) and W of the next offset streams into the second
+// register set while the current one multiplies (the two sets swap roles, no copy).
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256, 2) void k_sconv_wq(
+    const float* __restrict__ in, const float* __restrict__ Wp, SconvEpilogue ep,
+    const int* __restrict__ nbr, const int* __restrict__ tile_order,
+    const float* __restrict__ zero_row, int N_out, int K, float* __restrict__ out) {
+  using C = RtCfg<CIN, COUT>;
+  using L = WpCfg<CIN, COUT>;   // LDS layout of the wave-private tile
+  constexpr int TRW = L::TRW, ACC_LD = L::ACC_LD, CQ = C::CQ, NTG = C::NTG, NG = C::NG;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  float* s_acc = smem + (size_t)wave * L::WAVE_LDS_DW;                 // TRW * ACC_LD
+  int* s_pin = reinterpret_cast<int*>(s_acc + TRW * ACC_LD);           // SC_MAXK * TRW
+  int* s_cnt = s_pin + SC_MAXK * TRW;                                  // 32
+  int* s_rows = s_cnt + 32;                                            // TRW
+  unsigned char* s_pslot = reinterpret_cast<unsigned char*>(s_rows + TRW);
+  const long long row0 = ((long long)blockIdx.x * L::NWB + wave) * TRW;
+  if (row0 >= N_out) return;
+
+  int my_row = -1;
+  if (lane < TRW && row0 + lane < N_out) my_row = tile_order ? tile_order[row0 + lane] : (int)(row0 + lane);
+  if (lane < TRW) s_rows[lane] = my_row;
+  for (int i = lane; i < TRW * ACC_LD / 4; i += 64)
+    reinterpret_cast<f32x4*>(s_acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  unsigned mask = 0;
+  int nbv[SC_MAXK];     // all 27 loads in flight at once
+#pragma unroll
+  for (int k = 0; k < SC_MAXK; ++k)
+    nbv[k] = (k < K && my_row >= 0) ? nbr[(long long)my_row * K + k] : -1;
+#pragma unroll
+  for (int k = 0; k < SC_MAXK; ++k) {
+    const int nb = nbv[k];
+    unsigned long long b = __ballot(nb >= 0);
+    if (nb >= 0) {
+      int pos = k * TRW + __popcll(b & ((1ull << lane) - 1ull));
+      s_pin[pos] = nb;
+      s_pslot[pos] = (unsigned char)lane;
+    }
+    int n = __popcll(b);
+    if (lane == 0) s_cnt[k] = n;
+    if (n) mask |= 1u << k;
+  }
+  mask = __builtin_amdgcn_readfirstlane(mask);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  constexpr bool DEEP = CQ * NTG <= 32;   // ring of 4 when registers allow, else 2
+  float Wa[CQ][NTG], Wb[CQ][NTG];
+  float A0[CQ], A1[CQ], A2[DEEP ? CQ : 1], A3[DEEP ? CQ : 1];
+
+#define WQ_LOAD_W(KK, GG, WDST)                                                              \
+  {                                                                                          \
+    const float* wp_ = Wp + (size_t)(KK) * C::IMG + (((size_t)(GG) * 4 + q) * CQ * 16 + r) * NTG; \
+    _Pragma("unroll") for (int t_ = 0; t_ < CQ; ++t_) {                                      \
+      if constexpr (NTG == 4) {                                                              \
+        f32x4 v_ = *reinterpret_cast<const f32x4*>(wp_ + t_ * 16 * NTG);                     \
+        WDST[t_][0] = v_[0]; WDST[t_][1] = v_[1]; WDST[t_][2] = v_[2]; WDST[t_][3] = v_[3];  \
+      } else if constexpr (NTG == 2) {                                                       \
+        float2 v_ = *reinterpret_cast<const float2*>(wp_ + t_ * 16 * NTG);                   \
+        WDST[t_][0] = v_.x; WDST[t_][1] = v_.y;                                              \
+      } else if constexpr (NTG == 8) {                                                       \
+        f32x4 v_ = *reinterpret_cast<const f32x4*>(wp_ + t_ * 16 * NTG);                     \
+        f32x4 u_ = *reinterpret_cast<const f32x4*>(wp_ + t_ * 16 * NTG + 4);                 \
+        WDST[t_][0] = v_[0]; WDST[t_][1] = v_[1]; WDST[t_][2] = v_[2]; WDST[t_][3] = v_[3];  \
+        WDST[t_][4] = u_[0]; WDST[t_][5] = u_[1]; WDST[t_][6] = u_[2]; WDST[t_][7] = u_[3];  \
+      } else {                                                                               \
+        WDST[t_][0] = wp_[t_ * 16 * NTG];                                                    \
+      }                                                                                      \
+    }                                                                                        \
+  }
+#define WQ_GATHER(KK, CC, CNT, ADST)                                                         \
+  {                                                                                          \
+    int p_ = (CC) * 16 + r;                                                                  \
+    const float* ap_ = zero_row;                                                             \
+    if (p_ < (CNT)) ap_ = in + (long long)s_pin[(KK) * TRW + p_] * CIN;                      \
+    if constexpr (CIN >= 16) {                                                               \
+      _Pragma("unroll") for (int i_ = 0; i_ < CQ / 4; ++i_) {                                \
+        f32x4 v_ = *reinterpret_cast<const f32x4*>(ap_ + 16 * i_ + 4 * q);                   \
+        ADST[4 * i_ + 0] = v_[0]; ADST[4 * i_ + 1] = v_[1]; ADST[4 * i_ + 2] = v_[2]; ADST[4 * i_ + 3] = v_[3]; \
+      }                                                                                      \
+    } else {                                                                                 \
+      _Pragma("unroll") for (int i_ = 0; i_ < CQ; ++i_) ADST[i_] = ap_[q * CQ + i_];         \
+    }                                                                                        \
+  }
+  struct Cur { unsigned rem; int k, c, cnt; };
+#define WQ_CUR_INIT(U)                                                                       \
+  { U.rem = mask; U.k = -1; U.c = 0; U.cnt = 0;                                              \
+    if (U.rem) { U.k = __builtin_ctz(U.rem); U.rem &= U.rem - 1; U.cnt = s_cnt[U.k]; } }
+#define WQ_CUR_NEXT(U)                                                                       \
+  { if (++U.c * 16 >= U.cnt) { U.c = 0;                                                      \
+      if (U.rem) { U.k = __builtin_ctz(U.rem); U.rem &= U.rem - 1; U.cnt = s_cnt[U.k]; }     \
+      else U.k = -1; } }
+  // one item: (new offset? swap W sets and prefetch the following offset's W), multiply,
+  // refill this ring slot with the item 4 ahead, add into the LDS tile
+#define WQ_MULT(ABUF, WSET)                                                                  \
+  _Pragma("unroll") for (int t_ = 0; t_ < CQ; ++t_)                                          \
+    _Pragma("unroll") for (int c_ = 0; c_ < NTG; ++c_)                                       \
+      acc[c_] = __builtin_amdgcn_mfma_f32_16x16x4f32(WSET[t_][c_], ABUF[t_], acc[c_], 0, 0, 0);
+#define WQ_STEP(ABUF)                                                                        \
+  if (X.k >= 0) {                                                                            \
+    if (X.k != curk) {                                                                       \
+      curk = X.k;                                                                            \
+      wpar ^= 1;                                                                             \
+      if (X.rem) {                                                                           \
+        if (wpar) { WQ_LOAD_W(__builtin_ctz(X.rem), g, Wa); } else { WQ_LOAD_W(__builtin_ctz(X.rem), g, Wb); } \
+      }                                                                                      \
+    }                                                                                        \
+    f32x4 acc[NTG];                                                                          \
+    _Pragma("unroll") for (int c_ = 0; c_ < NTG; ++c_) acc[c_] = f32x4{0.f, 0.f, 0.f, 0.f};  \
+    if (wpar) { WQ_MULT(ABUF, Wb) } else { WQ_MULT(ABUF, Wa) }                               \
+    const int xk_ = X.k, xc_ = X.c, xcnt_ = X.cnt;                                           \
+    WQ_CUR_NEXT(X);                                                                          \
+    if (P.k >= 0) { WQ_GATHER(P.k, P.c, P.cnt, ABUF); WQ_CUR_NEXT(P); }                      \
+    const int p_out_ = xc_ * 16 + r;                                                         \
+    if (p_out_ < xcnt_) {                                                                    \
+      float* dst_ = s_acc + (int)s_pslot[xk_ * TRW + p_out_] * ACC_LD + g * C::CG + 4 * q;   \
+      _Pragma("unroll") for (int c_ = 0; c_ < NTG; ++c_) {                                   \
+        f32x4 o_ = *reinterpret_cast<f32x4*>(dst_ + c_ * 16);                                \
+        o_ += acc[c_];                                                                       \
+        *reinterpret_cast<f32x4*>(dst_ + c_ * 16) = o_;                                      \
+      }                                                                                      \
+    }                                                                                        \
+  }
+
+  for (int g = 0; g < NG; ++g) {
+    Cur P, X;
+    WQ_CUR_INIT(P);
+    WQ_CUR_INIT(X);
+    if (P.k >= 0) { WQ_GATHER(P.k, P.c, P.cnt, A0); WQ_CUR_NEXT(P); }
+    if (P.k >= 0) { WQ_GATHER(P.k, P.c, P.cnt, A1); WQ_CUR_NEXT(P); }
+    if constexpr (DEEP) {
+      if (P.k >= 0) { WQ_GATHER(P.k, P.c, P.cnt, A2); WQ_CUR_NEXT(P); }
+      if (P.k >= 0) { WQ_GATHER(P.k, P.c, P.cnt, A3); WQ_CUR_NEXT(P); }
+    }
+    // wpar == 1 means "current W is in Wb"; the first offset goes to Wb (wpar flips 0 -> 1)
+    int wpar = 0, curk = -1;
+    if (X.k >= 0) { WQ_LOAD_W(X.k, g, Wb); }
+    while (X.k >= 0) {
+      WQ_STEP(A0)
+      WQ_STEP(A1)
+      if constexpr (DEEP) {
+        WQ_STEP(A2)
+        WQ_STEP(A3)
+      }
+    }
+  }
+#undef WQ_STEP
+#undef WQ_MULT
+#undef WQ_CUR_NEXT
+#undef WQ_CUR_INIT
+#undef WQ_GATHER
+#undef WQ_LOAD_W
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  constexpr int C4 = COUT / 4;
+  for (int i = lane; i < TRW * C4; i += 64) {
+    int rr = i / C4, c4 = i - rr * C4;
+    int orow = s_rows[rr];
+    if (orow < 0) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(s_acc + rr * ACC_LD + 4 * c4);
+    const int co = 4 * c4;
+    if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + co);
+    if (ep.scale) v *= *reinterpret_cast<const f32x4*>(ep.scale + co);
+    if (ep.shift) v += *reinterpret_cast<const f32x4*>(ep.shift + co);
+    if (ep.relu) {
+      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(out + (long long)orow * COUT + 4 * c4) = v;
+  }
+}
+
 // ------------------------------------------------------------------ generic scalar kernel
 __global__ void k_sconv_generic(const float* __restrict__ in, const float* __restrict__ W,
                                 SconvEpilogue ep, const int* __restrict__ nbr, int N_out, int K,
@@ -762,7 +1169,8 @@ static bool mfma_supported(int Cin, int Cout, int K) {
 
 template <int CIN, int COUT>
 static size_t img_bytes() {   // block-kernel image + wave-private-kernel image, per offset
-  return (size_t)(SconvCfg<CIN, COUT>::IMG + WpCfg<CIN, COUT>::IMG + RtCfg<CIN, COUT>::IMG) *
+  return (size_t)(SconvCfg<CIN, COUT>::IMG + WpCfg<CIN, COUT>::IMG + RtCfg<CIN, COUT>::IMG +
+                  CoCfg<CIN, COUT>::IMG) *
          sizeof(float);
 }
 
@@ -815,11 +1223,18 @@ static int pack_weights(const float* W, int K, float* Wp, hipStream_t st) {
                      K, Wp + (size_t)K * C::IMG);
   hipLaunchKernelGGL((k_pack_weights_rt<CI, CO>), dim3(glx_divup(nel, 256)), dim3(256), 0, st, W,
                      K, Wp + (size_t)K * (C::IMG + WpCfg<CI, CO>::IMG));
+  hipLaunchKernelGGL((k_pack_weights_co<CI, CO>), dim3(glx_divup(nel, 256)), dim3(256), 0, st, W,
+                     K, Wp + (size_t)K * (C::IMG + WpCfg<CI, CO>::IMG + RtCfg<CI, CO>::IMG));
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
 
-static int g_sconv_variant = -1;   // experiment knob (glx_sconv_set_variant); -1 = default
+// experiment knob: glx_sconv_set_variant() or env GLX_SCONV_VARIANT; -1 = default kernel choice
+static int env_variant() {
+  const char* e = getenv("GLX_SCONV_VARIANT");
+  return e ? atoi(e) : -1;
+}
+static int g_sconv_variant = env_variant();
 extern "C" int glx_sconv_set_variant(int v) {
   g_sconv_variant = v;
   return GLX_OK;
@@ -860,7 +1275,7 @@ static int launch_tile(const float* in, const float* Wp, const SconvEpilogue& ep
 template <int CI, int CO>
 static int launch_mfma(const float* in, const float* Wp, const SconvEpilogue& ep,
                        const int32_t* nbr, const int32_t* tile_order, int N_out, int K, float* out,
-                       hipStream_t st) {
+                       const float* zero_row, hipStream_t st) {
 #define SC_GO(TR, NW, NBUF) \
   return launch_tile<CI, CO, TR, NW, NBUF>(in, Wp, ep, nbr, tile_order, N_out, K, out, st)
   constexpr bool big = CO >= 128;
@@ -902,6 +1317,50 @@ static int launch_mfma(const float* in, const float* Wp, const SconvEpilogue& ep
       g_prof_start = g_prof_stop = nullptr;
     } else {
       hipLaunchKernelGGL(kern, dim3(nblocks), dim3(C::NWB * 64), C::lds_bytes, st, in, Wp2, ep, nbr,
+                         tile_order, N_out, K, out);
+    }
+    GLX_LAUNCH_CHECK();
+    return GLX_OK;
+  }
+  if (g_sconv_variant == 15) {   // wave-private kernel with the deep software pipeline
+    using L = WpCfg<CI, CO>;
+    static bool attr_set = false;
+    auto kern = k_sconv_wq<CI, CO>;
+    if (!attr_set) {
+      GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)L::lds_bytes));
+      attr_set = true;
+    }
+    const float* Wp3 = Wp + (size_t)K * (SconvCfg<CI, CO>::IMG + WpCfg<CI, CO>::IMG);
+    int nblocks = glx_divup(N_out, L::TRW * L::NWB);
+    if (g_prof_start && g_prof_stop) {
+      hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(L::NWB * 64), L::lds_bytes, st, g_prof_start,
+                            g_prof_stop, 0, in, Wp3, ep, nbr, tile_order, zero_row, N_out, K, out);
+      g_prof_start = g_prof_stop = nullptr;
+    } else {
+      hipLaunchKernelGGL(kern, dim3(nblocks), dim3(L::NWB * 64), L::lds_bytes, st, in, Wp3, ep, nbr,
+                         tile_order, zero_row, N_out, K, out);
+    }
+    GLX_LAUNCH_CHECK();
+    return GLX_OK;
+  }
+  if (g_sconv_variant == 14) {   // column-owner kernel
+    using C = CoCfg<CI, CO>;
+    static bool attr_set = false;
+    auto kern = k_sconv_co<CI, CO>;
+    if (!attr_set) {
+      GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)C::lds_bytes));
+      attr_set = true;
+    }
+    const float* Wp4 = Wp + (size_t)K * (SconvCfg<CI, CO>::IMG + WpCfg<CI, CO>::IMG + RtCfg<CI, CO>::IMG);
+    int nblocks = glx_divup(N_out, C::TR);
+    if (g_prof_start && g_prof_stop) {
+      hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(C::NW * 64), C::lds_bytes, st, g_prof_start,
+                            g_prof_stop, 0, in, Wp4, ep, nbr, tile_order, N_out, K, out);
+      g_prof_start = g_prof_stop = nullptr;
+    } else {
+      hipLaunchKernelGGL(kern, dim3(nblocks), dim3(C::NW * 64), C::lds_bytes, st, in, Wp4, ep, nbr,
                          tile_order, N_out, K, out);
     }
     GLX_LAUNCH_CHECK();
@@ -975,9 +1434,19 @@ extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, cons
     if (rc != GLX_OK) return rc;
     Wp = (const float*)workspace;
   }
+  // first 1 KB of the workspace = the zero row that absent rule pairs gather from
+  const float* zero_row = nullptr;
+  if (workspace && workspace_bytes >= 1024 && Wp != (const float*)workspace) {
+    GLX_HIP(hipMemsetAsync(workspace, 0, 1024, st));
+    zero_row = (const float*)workspace;
+  }
+  if (g_sconv_variant == 15 && !zero_row) {
+    glx_set_error("glx_sconv_forward: variant 15 needs pre-packed weights and >= 1 KB of workspace");
+    return GLX_EWORKSPACE;
+  }
   return sc_dispatch(Cin, Cout, [&](auto ci, auto co) {
     return launch_mfma<decltype(ci)::value, decltype(co)::value>(in, Wp, ep, nbr, tile_order,
-                                                                 N_out, K, out, st);
+                                                                 N_out, K, out, zero_row, st);
   });
 }
 

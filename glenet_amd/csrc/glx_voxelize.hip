@@ -29,6 +29,7 @@ struct VoxGeom {
   float xmin, ymin, zmin;
   float vx, vy, vz;
   int gx, gy, gz;
+  int depth;   // z extent of the bitmap layout (>= gz)
 };
 
 // cell of a point, reference arithmetic: floor((p - min) / size) in fp32, per axis.
@@ -61,7 +62,7 @@ __global__ void k_vox_mark(const float* __restrict__ pts, const int* __restrict_
   long long l = -1;
   if ((unsigned)b < (unsigned)B && vox_cell(pts + (long long)p * C, vg, cx, cy, cz)) {
     l = XMAJOR ? (((long long)b * vg.gx + cx) * vg.gy + cy) * vg.gz + cz
-               : (((long long)b * vg.gz + cz) * vg.gy + cy) * vg.gx + cx;
+               : (((long long)b * vg.depth + cz) * vg.gy + cy) * vg.gx + cx;
     atomicOr(&bitmap[l >> 6], 1ull << (l & 63));
     chunk_flags[l >> 9] = 1;
   }
@@ -131,7 +132,7 @@ __global__ void k_vox_assign_rows(const int* __restrict__ flags, const int* __re
     int x = (int)(l % vg.gx);
     long long q = l / vg.gx;
     int y = (int)(q % vg.gy);
-    int z = (int)((q / vg.gy) % vg.gz);
+    int z = (int)((q / vg.gy) % vg.depth);
     coords[row] = make_int4(b, z, y, x);
   }
   row_of_rank[cell_rank[p]] = row;
@@ -192,7 +193,7 @@ struct HardWs {
 static HardWs hard_ws_layout(void* base, int P, int B, int gx, int gy, int gz, int max_points,
                              int max_voxels) {
   HardWs w;
-  GlxGrid g{B, gz, gy, gx};
+  GlxGrid g{B, gz + 1, gy, gx};   // sized for index_depth up to gz + 1 (the backbone's sparse shape)
   char* p = (char*)base;
   size_t off = 0;
   auto take = [&](size_t n) {
@@ -231,7 +232,10 @@ extern "C" int glx_voxelize_hard(const float* points, const int32_t* point_batch
                                  int B, const float* vrange, const float* vsize, int gx, int gy,
                                  int gz, int max_points, int max_voxels, float* voxels,
                                  int32_t* coords, int32_t* num_points, int32_t* voxel_offset,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
+                                 int index_depth, uint64_t* idx_bitmap, uint8_t* idx_flags,
+                                 int32_t* idx_prefix, int32_t* idx_rank_to_row,
+                                 int32_t* idx_n_unique, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
   GLX_REQUIRE(points && vrange && vsize && voxels && coords && num_points && voxel_offset,
               "glx_voxelize_hard: null pointer");
   GLX_REQUIRE(P >= 0 && C >= 3 && B >= 1 && gx > 0 && gy > 0 && gz > 0 && max_points > 0 &&
@@ -244,8 +248,19 @@ extern "C" int glx_voxelize_hard(const float* points, const int32_t* point_batch
     return GLX_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  GlxGrid g{B, gz, gy, gx};
-  VoxGeom vg{vrange[0], vrange[1], vrange[2], vsize[0], vsize[1], vsize[2], gx, gy, gz};
+  // The cell bitmap may be laid out for a deeper grid (index_depth >= gz) and written into
+  // caller buffers: it is then directly the cell index of the SparseConvTensor built from these
+  // voxels (spatial_shape [index_depth, gy, gx], spconv_backbone.py:75), saving a second build.
+  const int depth = index_depth > 0 ? index_depth : gz;
+  GLX_REQUIRE(depth >= gz && depth <= gz + 1, "glx_voxelize_hard: index_depth must be gz or gz+1");
+  if (idx_bitmap) {
+    GLX_REQUIRE(idx_flags && idx_prefix && idx_rank_to_row && idx_n_unique,
+                "glx_voxelize_hard: incomplete index outputs");
+    w.bitmap = idx_bitmap; w.cflags = idx_flags; w.prefix = idx_prefix;
+    w.row_of_rank = idx_rank_to_row; w.n_unique = idx_n_unique;
+  }
+  GlxGrid g{B, depth, gy, gx};
+  VoxGeom vg{vrange[0], vrange[1], vrange[2], vsize[0], vsize[1], vsize[2], gx, gy, gz, depth};
   const int nb = glx_divup(P > 0 ? P : 1, 256);
   GLX_HIP(hipMemsetAsync(w.bitmap, 0, (size_t)g.words() * 8, st));
   GLX_HIP(hipMemsetAsync(w.cflags, 0, (size_t)g.chunks(), st));
@@ -386,7 +401,7 @@ extern "C" int glx_voxelize_dynamic_mean(const float* points, const int32_t* poi
   }
   hipStream_t st = (hipStream_t)stream;
   GlxGrid g{B, gx, gy, gz};
-  VoxGeom vg{vrange[0], vrange[1], vrange[2], vsize[0], vsize[1], vsize[2], gx, gy, gz};
+  VoxGeom vg{vrange[0], vrange[1], vrange[2], vsize[0], vsize[1], vsize[2], gx, gy, gz, gz};
   GLX_HIP(hipMemsetAsync(w.bitmap, 0, (size_t)g.words() * 8, st));
   GLX_HIP(hipMemsetAsync(w.flags, 0, (size_t)g.chunks(), st));
   if (P > 0) {

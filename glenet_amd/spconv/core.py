@@ -162,6 +162,30 @@ def build_strided_rules(x, ksize, stride, padding, dilation=(1, 1, 1)):
     return rs
 
 
+def plan_rules(indices, spatial_shape, batch_size, convs, index=None):
+    """Rule tables of a whole conv stack (modules in execution order) from coordinates only:
+    returns {indice_key: RuleSet}.  Keys are required (they are how convs find their table)."""
+    x = SparseConvTensor(None, indices, spatial_shape, batch_size)
+    x._index = index
+    for conv in convs:
+        key = conv.indice_key
+        if key is None:
+            raise ValueError("plan_rules needs an indice_key on every conv")
+        if conv.inverse:
+            continue
+        rs = x.indice_dict.get(key)
+        if rs is None:
+            rs = (build_subm_rules(x, conv.kernel_size) if conv.subm else
+                  build_strided_rules(x, conv.kernel_size, conv.stride, conv.padding, conv.dilation))
+            x.indice_dict[key] = rs
+        if not conv.subm:
+            nxt = SparseConvTensor(None, rs.out_indices, rs.out_spatial_shape, batch_size,
+                                   indice_dict=x.indice_dict)
+            nxt._index = rs.out_index
+            x = nxt
+    return x.indice_dict
+
+
 _profile_hook = None   # bench.py installs a callable(tag, K, cin, cout, n_out, rules), run before the launch
 
 

@@ -34,7 +34,7 @@ class VoxelGeneratorV2:
     def generate(self, points, max_voxels=None):
         pts = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32)).to(self.device)
         v, c, n, _ = hard_voxelize(pts, self._voxel_size, self._point_cloud_range,
-                                   self._max_num_points, max_voxels or self._max_voxels)
+                                   self._max_num_points, max_voxels or self._max_voxels)[:4]
         return {"voxels": v.cpu().numpy(), "coordinates": c[:, 1:].cpu().numpy(),
                 "num_points_per_voxel": n.cpu().numpy()}
 

@@ -36,12 +36,15 @@ def _split_batch(points, batch_idx, batch_size):
 
 
 def hard_voxelize(points, voxel_size, point_cloud_range, max_points, max_voxels, batch_idx=None,
-                  batch_size=None):
+                  batch_size=None, index_depth=None):
     """points (P, C) float32 device tensor, xyz first; batch_idx (P,) frame ids (stacked frames,
     non-decreasing) or None for one frame.
 
     Returns voxels (Nv, max_points, C), coords (Nv, 4) int32 [b, z, y, x], num_points (Nv,) int32,
     voxel_offset (B+1,) int32 (rows of frame b are voxel_offset[b]:voxel_offset[b+1]).
+    With index_depth (gz or gz+1) a fifth value is returned: the cell index (glenet_amd.spconv
+    CellIndex) of these voxels on the grid (B, index_depth, gy, gx), or None when max_voxels
+    dropped cells (then the sparse tensor builds its own).
     """
     points = points.contiguous().float()
     _lib.check_cuda(points)
@@ -58,11 +61,24 @@ def hard_voxelize(points, voxel_size, point_cloud_range, max_points, max_voxels,
     offs = torch.empty((B + 1,), dtype=torch.int32, device=dev)
     wsb = query("glx_voxelize_hard_workspace_bytes", P, B, gx, gy, gz, max_points, max_voxels)
     ws = workspace.get(wsb, dev)
+    if index_depth is None:
+        call("glx_voxelize_hard", points, bi, P, C, B, rng_p, vs_p, gx, gy, gz, max_points,
+             max_voxels, voxels, coords, num, offs, 0, None, None, None, None, None, ws,
+             size_arg(ws.numel()))
+        nv = offs.tolist()[-1]  # host sync: voxel count sizes the outputs
+        return voxels[:nv], coords[:nv], num[:nv], offs
+    from .spconv.core import CellIndex
+    grid = (B, int(index_depth), gy, gx)
+    bitmap, flags, prefix = CellIndex.alloc(grid, dev)
+    r2row = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
+    meta = torch.zeros(B + 2, dtype=torch.int32, device=dev)      # voxel_offset (B+1), n_unique
     call("glx_voxelize_hard", points, bi, P, C, B, rng_p, vs_p, gx, gy, gz, max_points, max_voxels,
-         voxels, coords, num, offs, ws, size_arg(ws.numel()))
-    offs_h = offs.tolist()  # host sync: voxel count sizes the outputs
-    nv = offs_h[-1]
-    return voxels[:nv], coords[:nv], num[:nv], offs
+         voxels, coords, num, meta[:B + 1], int(index_depth), bitmap, flags, prefix, r2row,
+         meta[B + 1:], ws, size_arg(ws.numel()))
+    meta_h = meta.tolist()  # the one host sync: voxel count + unique-cell count
+    nv, n_unique = meta_h[B], meta_h[B + 1]
+    index = CellIndex(grid, bitmap, flags, prefix, r2row[:nv], None, nv) if n_unique == nv else None
+    return voxels[:nv], coords[:nv], num[:nv], meta[:B + 1], index
 
 
 def dynamic_voxelize_mean(points, voxel_size, point_cloud_range, batch_idx=None, batch_size=None):

@@ -167,8 +167,14 @@ size_t glx_voxelize_hard_workspace_bytes(int P, int B, int gx, int gy, int gz, i
 int glx_voxelize_hard(const float* points, const int32_t* point_batch, int P, int C, int B,
                       const float* vrange, const float* vsize, int gx, int gy, int gz,
                       int max_points, int max_voxels, float* voxels, int32_t* coords,
-                      int32_t* num_points, int32_t* voxel_offset, void* workspace,
-                      size_t workspace_bytes, void* stream);
+                      int32_t* num_points, int32_t* voxel_offset,
+                      /* optional: also hand out the voxelizer's cell bitmap as the cell index of
+                       * the sparse tensor (B, index_depth, gy, gx), index_depth in {gz, gz+1};
+                       * idx_rank_to_row has P entries (-1 for cells dropped by max_voxels),
+                       * idx_n_unique device int32[1].  Pass 0 / NULLs to skip. */
+                      int index_depth, uint64_t* idx_bitmap, uint8_t* idx_flags,
+                      int32_t* idx_prefix, int32_t* idx_rank_to_row, int32_t* idx_n_unique,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* Dynamic voxelization + per-voxel mean, semantics of DynamicMeanVFE.forward
  * (pcdet/models/backbones_3d/vfe/dynamic_mean_vfe.py:53-72): voxels enumerate in ascending
