@@ -6,10 +6,12 @@ Workload at N=1 = BASELINE.json configs[1]: GLENet-VR SECOND sparse backbone
 batch 4 synthetic KITTI-shaped frames per GPU.  One step = one pass of the hot path over one
 batch whose points are already resident in HBM:
     hard voxelize (4 frames) -> MeanVFE -> rule tables -> 12 sparse convs (+BN/ReLU) -> dense().
-A step has two stages: A (voxelize, VFE, every rule table; it owns the few host read-backs that
-size tensors) and B (the 12 convolutions + dense, no host syncs).  By default they run back to
-back on one stream; --pipeline overlaps stage A of batch i+1 with stage B of batch i on two HIP
-streams / two host threads.  Exactly K steps (K stage-A and K stage-B passes) are timed.
+Default --mode graph: the frame is shape-static (buffers at capacity, live row counts stay on the
+device: glenet_amd.backbone.StaticFramePipeline), so its ~120 launches need no host read-back
+and are recorded once into a HIP graph; a step = copy the batch into the graph's input buffers
++ one graph launch.  --mode static enqueues the same launches from Python each step; --mode
+dynamic is the exact-shape path the spconv mirror uses by default (host read-backs size every
+tensor).  All three compute identical results (tests/test_backbone_gpu.py).
 N > 1: one process per GPU (torch.distributed, RCCL), every rank runs its own 4 frames
 (weak scaling, frames shard with no data-path collective in a forward pass); the timed
 region is bracketed by barrier + synchronize and the max over ranks is reported.
@@ -19,11 +21,8 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
-import queue
 import sys
-import threading
 import time
-from collections import deque
 
 import numpy as np
 import torch
@@ -125,14 +124,11 @@ def cpu_baseline(frames_np, model):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="overlap stage A of batch i+1 with stage B of batch i (2 streams, 2 host "
-                         "threads); off by default: host-side Python makes it unstable")
-    ap.add_argument("--lazy-rules", action="store_true",
-                    help="single stream, rule tables built inside the conv modules on first use")
+    ap.add_argument("--mode", choices=("graph", "static", "dynamic"), default="graph")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the event-bracketed second pass")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -153,88 +149,63 @@ def main():
     grid = gb.gv.grid_size_of(K["point_cloud_range"], K["voxel_size"])
     model = gb.VoxelBackBone8x(K["num_features"], grid).to(dev).eval()
     vfe, hc = gb.MeanVFE(), gb.HeightCompression()
-    comp_stream = torch.cuda.current_stream(dev)
-    args.no_pipeline = (not args.pipeline) or args.lazy_rules
-    prep_stream = comp_stream if args.no_pipeline else torch.cuda.Stream(dev)
+    pipe = gb.StaticFramePipeline(model, K, FRAMES_PER_GPU, pts.shape[0], K["num_features"])
+    pipe.calibrate(pts, bidx)     # output-set capacities of the strided convs, 1.3x this workload
 
-    def prepare():
-        """Stage A: everything that depends only on the points' coordinates (+ the VFE)."""
-        with torch.no_grad(), torch.cuda.stream(prep_stream):
+    def dynamic_step():
+        with torch.no_grad():
             bd = gb.voxelize_batch(pts, bidx, FRAMES_PER_GPU, K, train=True)
             bd = vfe(bd)
-            if not args.lazy_rules:
-                bd["rule_plan"] = model.plan(bd["voxel_coords"], FRAMES_PER_GPU, index=bd["voxel_index"])
-            ready = torch.cuda.Event()
-            ready.record(prep_stream)
-        return bd, ready
+            bd["rule_plan"] = model.plan(bd["voxel_coords"], FRAMES_PER_GPU, index=bd["voxel_index"])
+            return hc(model(bd))
 
-    def compute(bd, ready):
-        """Stage B: the 12 sparse convolutions and dense(); no host syncs."""
-        with torch.no_grad():
-            comp_stream.wait_event(ready)
-            bd = model(bd)
-            bd = hc(bd)
-            done = torch.cuda.Event()
-            done.record(comp_stream)
-        return bd, done
+    def static_step():
+        pipe.load(pts, bidx)
+        return pipe.enqueue()
 
-    def run(steps):
-        """Exactly `steps` prepares and `steps` computes.  Stage A runs in its own host thread
-        (its read-backs block only that thread; the GIL is released while it waits), stage B is
-        enqueued by the main thread; a bounded queue lets stage A run at most 2 batches ahead."""
-        alive = deque()          # keep stage-A tensors until stage B has consumed them
+    def graph_step():
+        pipe.load(pts, bidx)
+        return pipe.replay()
+
+    if args.mode == "graph":
+        pipe.load(pts, bidx)
+        pipe.capture()
+    step = dict(graph=graph_step, static=static_step, dynamic=dynamic_step)[args.mode]
+
+    def run(fn, steps):
         out = None
-        if args.no_pipeline:
-            for _ in range(steps):
-                cur = prepare()
-                out, done = compute(*cur)
-            return out
-        q = queue.Queue(maxsize=2)
-
-        def producer():
-            try:
-                torch.cuda.set_device(dev)
-                for _ in range(steps):
-                    q.put(prepare())
-            except BaseException as e:   # surface failures in the consumer
-                q.put(e)
-
-        th = threading.Thread(target=producer, daemon=True)
-        th.start()
         for _ in range(steps):
-            cur = q.get()
-            if isinstance(cur, BaseException):
-                raise cur
-            out, done = compute(*cur)
-            alive.append((cur, out, done))
-            while len(alive) > 3:
-                alive.popleft()[2].synchronize()
-        th.join()
+            out = fn()
         return out
 
-    run(args.warmup)
+    run(step, args.warmup)
     torch.cuda.synchronize(dev)
 
     # ---- headline: exactly K steps between two fences, nothing else in the region
     gdist.fence(dev)
     t0 = time.perf_counter()
-    bd = run(args.steps)
+    bd = run(step, args.steps)
     gdist.fence(dev)
     dt = gdist.reduce_max(time.perf_counter() - t0, dev)
+    if args.mode != "dynamic":
+        pipe.check()       # capacities held, voxelizer index valid (one read-back, after the clock)
 
-    # ---- roofline: the same K steps once more with every sparse-conv launch bracketed by HIP
-    # events on its stream (start/stop attached to the dispatch = kernel-only time).  Kept out of
-    # the headline loop because event-bracketed launches serialise the otherwise async queue.
-    prof = ConvProfiler()
-    spcore._profile_hook = prof
-    prof.enabled = True
-    run(args.steps)
-    torch.cuda.synchronize(dev)
-    prof.enabled = False
-    spcore._profile_hook = None
+    # ---- roofline: K more steps of the same launches, each sparse-conv kernel bracketed by HIP
+    # events on its stream (hipExtLaunchKernelGGL start/stop = kernel-only time).  Kept out of the
+    # headline loop: event-bracketed launches cannot live in a graph and serialise the queue.
+    per = {}
+    if not args.no_roofline:
+        prof = ConvProfiler()
+        spcore._profile_hook = prof
+        prof.enabled = True
+        run(dynamic_step if args.mode == "dynamic" else static_step, min(args.steps, 50))
+        torch.cuda.synchronize(dev)
+        prof.enabled = False
+        spcore._profile_hook = None
+        per = prof.summary()
+    prof_steps = min(args.steps, 50)
 
     frames_total = FRAMES_PER_GPU * world * args.steps
-    per = prof.summary()
     dom = max(per, key=lambda k: per[k]["ms"]) if per else None
     traffic = load_traffic()
     roof = None
@@ -252,14 +223,16 @@ def main():
         roof["all_sparse_conv"] = dict(
             achieved=round(tot_b / (tot_ms * 1e-3) / 1e9, 1),
             frac=round(tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            ms_per_step=round(tot_ms / args.steps, 4),
+            ms_per_step=round(tot_ms / prof_steps, 4),
             per_kernel={k: dict(GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
                                 us_per_launch=round(v["ms"] * 1e3 / v["launches"], 2),
-                                launches_per_step=v["launches"] // args.steps)
+                                launches_per_step=v["launches"] // prof_steps)
                         for k, v in sorted(per.items())})
 
     if rank == 0:
         st = bd["encoded_spconv_tensor"]
+        n_in = bd["voxel_index"].count.item() if args.mode != "dynamic" else bd["voxel_coords"].shape[0]
+        n_out = st.count.item() if st.count is not None else st.indices.shape[0]
         out = dict(metric="LiDAR frames/sec (sparse backbone fwd) on KITTI-shaped clouds",
                    value=round(frames_total / dt, 2), unit="frames/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup,
@@ -271,10 +244,10 @@ def main():
                                         "0.05x0.05x0.1 m; step = voxelize + MeanVFE + rule tables + "
                                         "12 sparse convs + dense()",
                                frames_per_gpu=FRAMES_PER_GPU, points_per_frame=20000,
-                               voxels_in=int(bd["voxel_coords"].shape[0]),
-                               voxels_out=int(st.indices.shape[0]),
-                               pipeline=("off, lazy rules" if args.lazy_rules else "off") if args.no_pipeline
-                               else "2-stage, 2 streams, 2 host threads",
+                               voxels_in=int(n_in), voxels_out=int(n_out),
+                               mode={"graph": "shape-static frame replayed as one HIP graph",
+                                     "static": "shape-static frame, launches enqueued from Python",
+                                     "dynamic": "exact shapes, host read-backs"}[args.mode],
                                parallelism="dp%d (frames shard, no data-path collective)" % world),
                    roofline=roof)
         if world == 1 and not args.no_cpu_baseline:

@@ -6,6 +6,7 @@ VoxelResBackBone8x :191-232; BatchNorm1d eps=1e-3 momentum=0.01 :73), written ta
 The reference modules themselves also run unmodified on glenet_amd.spconv through
 glenet_amd.dropin; this module is what bench.py and the tests drive.
 """
+from collections import deque
 from functools import partial
 
 import torch
@@ -91,18 +92,23 @@ class SparseBackbone8x(nn.Module):
         self.backbone_channels = {"x_conv1": 16, "x_conv2": 32, "x_conv3": 64,
                                   "x_conv4": cfg["stages"][-1][1]}
 
-    def plan(self, voxel_coords, batch_size, index=None):
+    def plan(self, voxel_coords, batch_size, index=None, capacities=None):
         """Build every rule table of the backbone from the coordinates alone (they do not depend
         on features), so the convolutions afterwards run back to back without host syncs.
-        Returns the indice_dict to pass as batch_dict["rule_plan"]."""
+        Returns the indice_dict to pass as batch_dict["rule_plan"].  With a shape-static index
+        (voxelize_batch(..., static=True)) the plan itself is free of host syncs too."""
+        count = index.count if index is not None else None
         return spconv.core.plan_rules(voxel_coords.int(), self.sparse_shape, batch_size,
-                                      self.sparse_convs(), index=index)
+                                      self.sparse_convs(), index=index, count=count,
+                                      capacities=capacities)
 
     def forward(self, batch_dict):
+        index = batch_dict.get("voxel_index")
         x = spconv.SparseConvTensor(batch_dict["voxel_features"], batch_dict["voxel_coords"].int(),
                                     self.sparse_shape, batch_dict["batch_size"],
-                                    indice_dict=batch_dict.get("rule_plan"))
-        x._index = batch_dict.get("voxel_index")
+                                    indice_dict=batch_dict.get("rule_plan"),
+                                    count=index.count if index is not None else None)
+        x._index = index
         x = self.conv_input(x)
         c1 = self.conv1(x)
         c2 = self.conv2(c1)
@@ -130,7 +136,9 @@ class MeanVFE(nn.Module):
     """mean_vfe.py:14-31 on device."""
 
     def forward(self, batch_dict):
-        batch_dict["voxel_features"] = gv.mean_vfe(batch_dict["voxels"], batch_dict["voxel_num_points"])
+        index = batch_dict.get("voxel_index")
+        batch_dict["voxel_features"] = gv.mean_vfe(batch_dict["voxels"], batch_dict["voxel_num_points"],
+                                                   count=index.count if index is not None else None)
         return batch_dict
 
 
@@ -145,7 +153,7 @@ class HeightCompression(nn.Module):
         return batch_dict
 
 
-def voxelize_batch(points_list_or_stacked, batch_idx, batch_size, cfg, train=True):
+def voxelize_batch(points_list_or_stacked, batch_idx, batch_size, cfg, train=True, static=False):
     """Device-side replacement of DataProcessor.transform_points_to_voxels + collate_batch
     (data_processor.py:117-152, dataset.py:192-197): stacked points -> batch_dict entries.  The
     voxelizer's cell bitmap doubles as the sparse tensor's cell index (grid depth gz + 1)."""
@@ -154,6 +162,99 @@ def voxelize_batch(points_list_or_stacked, batch_idx, batch_size, cfg, train=Tru
     v, c, n, offs, index = gv.hard_voxelize(points_list_or_stacked, cfg["voxel_size"],
                                             cfg["point_cloud_range"], cfg["max_points"], max_voxels,
                                             batch_idx=batch_idx, batch_size=batch_size,
-                                            index_depth=gz + 1)
+                                            index_depth=gz + 1, static=static)
     return dict(voxels=v, voxel_coords=c, voxel_num_points=n, batch_size=batch_size,
                 voxel_offset=offs, voxel_index=index)
+
+
+class StaticFramePipeline:
+    """One batch of the hot path (hard voxelize -> MeanVFE -> rule tables -> sparse backbone ->
+    dense()) as a shape-static, host-sync-free sequence, optionally frozen into a HIP graph.
+
+    Buffers are sized by capacity (B * max_voxels rows; 288 GB of HBM make that free), the live
+    row counts stay on the device, so the ~120 launches of a frame are enqueued without a single
+    read-back; `capture()` records them once (torch.cuda.CUDAGraph = hipGraph) and `replay()`
+    re-issues the whole frame with one call.  Inference only.  `check()` is the after-the-fact
+    validation of the capacities (one host sync; call it whenever the verdict is needed)."""
+
+    def __init__(self, model, cfg, batch_size, num_points, num_features, train_voxel_cap=True,
+                 capacities=None, device=None):
+        self.model, self.cfg, self.B = model, cfg, int(batch_size)
+        self.train_cap, self.capacities = train_voxel_cap, capacities
+        dev = device if device is not None else next(model.parameters()).device
+        self.points = torch.zeros((int(num_points), int(num_features)), dtype=torch.float32, device=dev)
+        # frame id B = "no frame": padding points are dropped by the voxelizer
+        self.batch_idx = torch.full((int(num_points),), self.B, dtype=torch.int32, device=dev)
+        self.vfe, self.hc = MeanVFE(), HeightCompression()
+        self.graph = None
+        self.out = None
+        self.max_in_flight = 4
+        self._inflight = deque()
+
+    def calibrate(self, points, batch_idx, headroom=1.3):
+        """Size the strided convs' output sets from a representative batch: one pass of the exact
+        (host-synchronising) path, capacities = headroom x the observed row counts."""
+        with torch.no_grad():
+            bd = voxelize_batch(points, batch_idx, self.B, self.cfg, train=self.train_cap)
+            plan = self.model.plan(bd["voxel_coords"], self.B, index=bd["voxel_index"])
+        self.capacities = {key: int(rs.N_out * headroom) + 64 for key, rs in plan.items()
+                           if not rs.subm}
+        return self.capacities
+
+    def load(self, points, batch_idx):
+        """Copy a stacked batch (P <= num_points rows) into the static input buffers (async)."""
+        n = points.shape[0]
+        if n > self.points.shape[0]:
+            raise ValueError("batch has %d points, pipeline was sized for %d" % (n, self.points.shape[0]))
+        self.points[:n].copy_(points, non_blocking=True)
+        self.batch_idx[:n].copy_(batch_idx, non_blocking=True)
+        if n < self.points.shape[0]:
+            self.batch_idx[n:].fill_(self.B)
+
+    def enqueue(self):
+        """Launch one frame on the current stream; returns the batch_dict (static buffers)."""
+        with torch.no_grad():
+            bd = voxelize_batch(self.points, self.batch_idx, self.B, self.cfg, train=self.train_cap,
+                                static=True)
+            bd = self.vfe(bd)
+            bd["rule_plan"] = self.model.plan(bd["voxel_coords"], self.B, index=bd["voxel_index"],
+                                              capacities=self.capacities)
+            bd = self.model(bd)
+            bd = self.hc(bd)
+        self.out = bd
+        return bd
+
+    def capture(self, warmup=2):
+        """Warm up (one-time packing / attribute calls must not land in the graph), then record."""
+        side = torch.cuda.Stream(self.points.device)
+        side.wait_stream(torch.cuda.current_stream(self.points.device))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self.enqueue()
+        torch.cuda.current_stream(self.points.device).wait_stream(side)
+        torch.cuda.synchronize(self.points.device)
+        self.check()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            self.enqueue()
+        return self
+
+    def replay(self):
+        """Launch the recorded frame.  At most `max_in_flight` frames are queued: the host waits
+        for frame i - max_in_flight before launching frame i (the usual multi-buffering bound;
+        deeper hipGraph queues also proved unreliable on ROCm 7.2)."""
+        if len(self._inflight) >= self.max_in_flight:
+            self._inflight.popleft().synchronize()
+        self.graph.replay()
+        ev = torch.cuda.Event()
+        ev.record()
+        self._inflight.append(ev)
+        return self.out
+
+    def check(self):
+        spconv.core.check_static(self.out["rule_plan"], self.out["voxel_index"])
+
+    def live(self, st):
+        """Trim a shape-static SparseConvTensor to its live rows (host sync) for inspection."""
+        n = int(st.count.item())
+        return st.features[:n], st.indices[:n]

@@ -8,6 +8,7 @@
 #include <stdarg.h>
 
 #include "glx_common.h"
+#include "glx_fill.h"
 #include "glx_scan.h"
 
 // ---------------------------------------------------------------- error plumbing
@@ -19,7 +20,7 @@ void glx_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* glx_last_error(void) { return g_err; }
-extern "C" int glx_abi_version(void) { return 2; }
+extern "C" int glx_abi_version(void) { return 3; }
 
 // ---------------------------------------------------------------- timing events (bench)
 extern "C" int glx_event_create(void** event) {
@@ -103,9 +104,12 @@ extern "C" int glx_index_build(const int32_t* indices, int N, int B, int D, int 
   GLX_REQUIRE(bitmap && chunk_flags && prefix && n_unique && status, "glx_index_build: null output");
   hipStream_t st = (hipStream_t)stream;
   GlxGrid g{B, D, H, W};
-  GLX_HIP(hipMemsetAsync(bitmap, 0, (size_t)g.words() * 8, st));
-  GLX_HIP(hipMemsetAsync(chunk_flags, 0, (size_t)g.chunks(), st));
-  GLX_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
+  {
+    GlxFillJob jobs[3] = {{bitmap, (size_t)g.words() * 8, 0}, {chunk_flags, (size_t)g.chunks(), 0},
+                          {status, sizeof(int), 0}};
+    int rc = glx_fill_multi(jobs, 3, st);
+    if (rc != GLX_OK) return rc;
+  }
   if (N > 0) {
     hipLaunchKernelGGL(k_set_bits, dim3(glx_divup(N, 256)), dim3(256), 0, st,
                        (const int4*)indices, N, g, (unsigned long long*)bitmap, chunk_flags,
@@ -128,14 +132,16 @@ __global__ void k_rules_subm(const int4* __restrict__ idx, int N, GlxGrid g,
                              const unsigned long long* __restrict__ bitmap,
                              const int* __restrict__ prefix, const int* __restrict__ rank_to_row,
                              int kd, int kh, int kw, int* __restrict__ nbr,
-                             int* __restrict__ pair_count) {
+                             int* __restrict__ pair_count, const int* __restrict__ n_live) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   int zy = kd * kh;
   int hits = 0;
-  if (t < (long long)N * zy) {
-    int s = (int)(t / zy);   // walk rows in cell order: neighbouring threads probe the same words
+  if (n_live) N = min(N, *n_live);
+  int s = (int)(t / zy);   // walk rows in cell order: neighbouring threads probe the same words
+  int j = -1;
+  if (t < (long long)N * zy) j = rank_to_row ? rank_to_row[s] : s;
+  if (j >= 0 && j < N) {   // (a rank without a row only exists when max_voxels dropped cells)
     int r = (int)(t - (long long)s * zy);
-    int j = rank_to_row ? rank_to_row[s] : s;
     int kz = r / kh, ky = r - kz * kh;
     int4 c = idx[j];
     int z = c.y + kz - kd / 2, y = c.z + ky - kh / 2;
@@ -148,7 +154,8 @@ __global__ void k_rules_subm(const int4* __restrict__ idx, int N, GlxGrid g,
         int rk = glx_rank_lookup(bitmap, prefix, g.lin(c.x, z, y, x));
         if (rk >= 0) {
           v = rank_to_row ? rank_to_row[rk] : rk;
-          ++hits;
+          if (v >= N) v = -1;   // beyond the capacity of a shape-static set
+          hits += v >= 0;
         }
       }
       dst[kx] = v;
@@ -163,7 +170,7 @@ __global__ void k_rules_subm(const int4* __restrict__ idx, int N, GlxGrid g,
 extern "C" int glx_rules_subm(const int32_t* indices, int N, int B, int D, int H, int W,
                               const uint64_t* bitmap, const int32_t* prefix,
                               const int32_t* rank_to_row, int kd, int kh, int kw, int32_t* nbr,
-                              int32_t* pair_count, void* stream) {
+                              int32_t* pair_count, const int32_t* n_live, void* stream) {
   GLX_REQUIRE(kd > 0 && kh > 0 && kw > 0 && (kd & 1) && (kh & 1) && (kw & 1),
               "glx_rules_subm: kernel size must be odd, got (%d,%d,%d)", kd, kh, kw);
   if (N == 0) return GLX_OK;
@@ -173,7 +180,7 @@ extern "C" int glx_rules_subm(const int32_t* indices, int N, int B, int D, int H
   hipLaunchKernelGGL(k_rules_subm, dim3(glx_divup(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, (const int4*)indices, N, g,
                      (const unsigned long long*)bitmap, (const int*)prefix, rank_to_row, kd, kh,
-                     kw, nbr, pair_count);
+                     kw, nbr, pair_count, n_live);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
@@ -188,13 +195,15 @@ struct ConvGeom {
 __global__ void k_outset_mark(const int4* __restrict__ idx, const int* __restrict__ in_rank_to_row,
                               int N, ConvGeom cg, GlxGrid og,
                               unsigned long long* __restrict__ obitmap,
-                              unsigned char* __restrict__ oflags) {
+                              unsigned char* __restrict__ oflags, const int* __restrict__ n_live) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   int zy = cg.kd * cg.kh;
+  if (n_live) N = min(N, *n_live);
   if (t >= (long long)N * zy) return;
   int s = (int)(t / zy);
   int r = (int)(t - (long long)s * zy);
   int i = in_rank_to_row ? in_rank_to_row[s] : s;
+  if (i < 0 || i >= N) return;
   int kz = r / cg.kh, ky = r - kz * cg.kh;
   int4 c = idx[i];
   int nz = c.y + cg.pd - kz, ny = c.z + cg.ph - ky;
@@ -220,8 +229,8 @@ extern "C" int glx_outset_build(const int32_t* indices_in, int N_in, int B, int 
                                 const int32_t* in_rank_to_row, int kd, int kh, int kw, int sd,
                                 int sh, int sw, int pd, int ph, int pw, int oD, int oH, int oW,
                                 uint64_t* out_bitmap, uint8_t* out_chunk_flags,
-                                int32_t* out_prefix, int32_t* n_out, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+                                int32_t* out_prefix, int32_t* n_out, const int32_t* n_in_live,
+                                void* workspace, size_t workspace_bytes, void* stream) {
   GLX_REQUIRE(kd > 0 && kh > 0 && kw > 0 && sd > 0 && sh > 0 && sw > 0,
               "glx_outset_build: bad geometry");
   GLX_REQUIRE(oD > 0 && oH > 0 && oW > 0, "glx_outset_build: empty output grid");
@@ -229,72 +238,84 @@ extern "C" int glx_outset_build(const int32_t* indices_in, int N_in, int B, int 
   hipStream_t st = (hipStream_t)stream;
   GlxGrid og{B, oD, oH, oW};
   GLX_REQUIRE(out_bitmap && out_chunk_flags && out_prefix && n_out, "glx_outset_build: null output");
-  GLX_HIP(hipMemsetAsync(out_bitmap, 0, (size_t)og.words() * 8, st));
-  GLX_HIP(hipMemsetAsync(out_chunk_flags, 0, (size_t)og.chunks(), st));
+  {
+    GlxFillJob jobs[2] = {{out_bitmap, (size_t)og.words() * 8, 0},
+                          {out_chunk_flags, (size_t)og.chunks(), 0}};
+    int rc = glx_fill_multi(jobs, 2, st);
+    if (rc != GLX_OK) return rc;
+  }
   if (N_in > 0) {
     ConvGeom cg{kd, kh, kw, sd, sh, sw, pd, ph, pw};
     long long total = (long long)N_in * kd * kh;
     hipLaunchKernelGGL(k_outset_mark, dim3(glx_divup(total, 256)), dim3(256), 0, st,
                        (const int4*)indices_in, in_rank_to_row, N_in, cg, og,
-                       (unsigned long long*)out_bitmap, out_chunk_flags);
+                       (unsigned long long*)out_bitmap, out_chunk_flags, n_in_live);
   }
   return glx_scan_bitmap(og, out_bitmap, out_chunk_flags, out_prefix, n_out, workspace,
                          workspace_bytes, st);
 }
 
-// one thread per occupied 8-word chunk: decode the chunk base once (64-bit divisions), then
-// walk the set bits carrying x / y / z / b like an odometer.
+// one thread per bitmap word of an occupied chunk: decode the word's base cell once, then walk
+// its set bits carrying x / y / z / b like an odometer.  Rows >= capacity are not written.
+template <class IDX>
 __global__ void k_outset_emit(const unsigned long long* __restrict__ bitmap,
                               const unsigned char* __restrict__ chunk_flags,
                               const int* __restrict__ prefix, long long nwords, GlxGrid g,
-                              int4* __restrict__ out) {
-  long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  long long w0 = ch << 3;
-  if (w0 >= nwords || !chunk_flags[ch]) return;
-  long long l0 = w0 << 6;
-  int x = (int)(l0 % g.W);
-  long long q = l0 / g.W;
-  int y = (int)(q % g.H);
-  q /= g.H;
-  int z = (int)(q % g.D);
-  int b = (int)(q / g.D);
-  for (int wi = 0; wi < 8 && w0 + wi < nwords; ++wi) {
-    unsigned long long word = bitmap[w0 + wi];
-    int base = word ? prefix[w0 + wi] : 0;
-    int done = 0;   // bits of this word already stepped over
-    while (word) {
-      int bit = __ffsll((long long)word) - 1;
-      word &= word - 1;
-      x += bit - done;
-      done = bit;
-      while (x >= g.W) { x -= g.W; if (++y == g.H) { y = 0; if (++z == g.D) { z = 0; ++b; } } }
-      out[base++] = make_int4(b, z, y, x);
-    }
-    x += 64 - done;
+                              int capacity, int4* __restrict__ out) {
+  long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nwords || !chunk_flags[w >> 3]) return;
+  unsigned long long word = bitmap[w];
+  if (!word) return;
+  int base = prefix[w];
+  IDX l0 = (IDX)(w << 6);
+  int x = (int)(l0 % (IDX)g.W);
+  IDX q = l0 / (IDX)g.W;
+  int y = (int)(q % (IDX)g.H);
+  q /= (IDX)g.H;
+  int z = (int)(q % (IDX)g.D);
+  int b = (int)(q / (IDX)g.D);
+  int done = 0;   // bits of this word already stepped over
+  while (word) {
+    int bit = __ffsll((long long)word) - 1;
+    word &= word - 1;
+    x += bit - done;
+    done = bit;
     while (x >= g.W) { x -= g.W; if (++y == g.H) { y = 0; if (++z == g.D) { z = 0; ++b; } } }
+    if (base < capacity) out[base] = make_int4(b, z, y, x);
+    ++base;
   }
 }
 
 extern "C" int glx_outset_emit(const uint64_t* bitmap, const uint8_t* chunk_flags,
-                               const int32_t* prefix, int B, int D, int H, int W,
+                               const int32_t* prefix, int B, int D, int H, int W, int capacity,
                                int32_t* indices_out, void* stream) {
   GlxGrid g{B, D, H, W};
   long long nwords = g.words();
-  hipLaunchKernelGGL(k_outset_emit, dim3(glx_divup(g.chunks(), 256)), dim3(256), 0,
-                     (hipStream_t)stream, (const unsigned long long*)bitmap, chunk_flags,
-                     (const int*)prefix, nwords, g, (int4*)indices_out);
+  if (capacity <= 0) return GLX_OK;
+  GLX_REQUIRE(bitmap && chunk_flags && prefix && indices_out, "glx_outset_emit: null pointer");
+  if (g.cells() + 64 < (1ll << 32)) {   // 32-bit divisions are several times cheaper
+    hipLaunchKernelGGL((k_outset_emit<unsigned>), dim3(glx_divup(nwords, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const unsigned long long*)bitmap, chunk_flags,
+                       (const int*)prefix, nwords, g, capacity, (int4*)indices_out);
+  } else {
+    hipLaunchKernelGGL((k_outset_emit<long long>), dim3(glx_divup(nwords, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const unsigned long long*)bitmap, chunk_flags,
+                       (const int*)prefix, nwords, g, capacity, (int4*)indices_out);
+  }
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
 
-__global__ void k_rules_strided(const int4* __restrict__ oidx, int N_out, GlxGrid ig,
+__global__ void k_rules_strided(const int4* __restrict__ oidx, int N_out, int N_in, GlxGrid ig,
                                 const unsigned long long* __restrict__ ibitmap,
                                 const int* __restrict__ iprefix,
                                 const int* __restrict__ irank_to_row, ConvGeom cg,
-                                int* __restrict__ nbr, int* __restrict__ pair_count) {
+                                int* __restrict__ nbr, int* __restrict__ pair_count,
+                                const int* __restrict__ n_live) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   int zy = cg.kd * cg.kh;
   int hits = 0;
+  if (n_live) N_out = min(N_out, *n_live);
   if (t < (long long)N_out * zy) {
     int j = (int)(t / zy);
     int r = (int)(t - (long long)j * zy);
@@ -310,7 +331,8 @@ __global__ void k_rules_strided(const int4* __restrict__ oidx, int N_out, GlxGri
         int rk = glx_rank_lookup(ibitmap, iprefix, ig.lin(c.x, z, y, x));
         if (rk >= 0) {
           v = irank_to_row ? irank_to_row[rk] : rk;
-          ++hits;
+          if (v >= N_in) v = -1;   // beyond the capacity of a shape-static input set
+          hits += v >= 0;
         }
       }
       dst[kx] = v;
@@ -322,20 +344,20 @@ __global__ void k_rules_strided(const int4* __restrict__ oidx, int N_out, GlxGri
   }
 }
 
-extern "C" int glx_rules_strided(const int32_t* indices_out, int N_out, int B, int D, int H, int W,
-                                 const uint64_t* in_bitmap, const int32_t* in_prefix,
+extern "C" int glx_rules_strided(const int32_t* indices_out, int N_out, int N_in, int B, int D,
+                                 int H, int W, const uint64_t* in_bitmap, const int32_t* in_prefix,
                                  const int32_t* in_rank_to_row, int kd, int kh, int kw, int sd,
                                  int sh, int sw, int pd, int ph, int pw, int32_t* nbr,
-                                 int32_t* pair_count, void* stream) {
+                                 int32_t* pair_count, const int32_t* n_out_live, void* stream) {
   if (N_out == 0) return GLX_OK;
   GLX_REQUIRE(indices_out && in_bitmap && in_prefix && nbr, "glx_rules_strided: null pointer");
   GlxGrid ig{B, D, H, W};
   ConvGeom cg{kd, kh, kw, sd, sh, sw, pd, ph, pw};
   long long total = (long long)N_out * kd * kh;
   hipLaunchKernelGGL(k_rules_strided, dim3(glx_divup(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, (const int4*)indices_out, N_out, ig,
+                     (hipStream_t)stream, (const int4*)indices_out, N_out, N_in, ig,
                      (const unsigned long long*)in_bitmap, (const int*)in_prefix, in_rank_to_row,
-                     cg, nbr, pair_count);
+                     cg, nbr, pair_count, n_out_live);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
@@ -355,7 +377,11 @@ extern "C" int glx_rules_invert(const int32_t* nbr, int N_out, int K, int N_in, 
                                 void* stream) {
   GLX_REQUIRE(K > 0, "glx_rules_invert: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (N_in > 0) GLX_HIP(hipMemsetAsync(nbr_in, 0xFF, (size_t)N_in * K * sizeof(int), st));
+  if (N_in > 0) {
+    GlxFillJob job{nbr_in, (size_t)N_in * K * sizeof(int), 0xFF};
+    int rc = glx_fill_multi(&job, 1, st);
+    if (rc != GLX_OK) return rc;
+  }
   long long total = (long long)N_out * K;
   if (total > 0) {
     hipLaunchKernelGGL(k_rules_invert, dim3(glx_divup(total, 256)), dim3(256), 0, st, nbr, total,

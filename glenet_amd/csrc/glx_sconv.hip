@@ -63,6 +63,7 @@ struct SconvEpilogue {
   const float* scale;  // (Cout) or NULL  (e.g. eval-mode BatchNorm folded: gamma / sqrt(var+eps))
   const float* shift;  // (Cout) or NULL
   int relu;
+  const int* n_live;   // NULL, or device int32: rows >= *n_live are neither computed nor written
 };
 
 // Tile geometry: TR output rows per block, NW waves per block, NBUF LDS weight buffers.
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
     const float* __restrict__ in, const float* __restrict__ Wp, SconvEpilogue ep,
     const int* __restrict__ nbr, const int* __restrict__ tile_order, int N_out, int K,
     float* __restrict__ out) {
+  if (ep.n_live) N_out = min(N_out, *ep.n_live);   // device-side row count (capacity launch)
   using C = SconvCfg<CIN, COUT>;
   using T = SconvTile<CIN, COUT, TR_, NW_, NBUF_>;
   constexpr int TR = T::TR, ACC_LD = T::ACC_LD, NBUF = T::NBUF, LW = T::LW;
@@ -368,6 +370,7 @@ __global__ __launch_bounds__(256) void k_sconv_wp(
     const float* __restrict__ in, const float* __restrict__ Wp, SconvEpilogue ep,
     const int* __restrict__ nbr, const int* __restrict__ tile_order, int N_out, int K,
     float* __restrict__ out) {
+  if (ep.n_live) N_out = min(N_out, *ep.n_live);   // device-side row count (capacity launch)
   using C = WpCfg<CIN, COUT>;
   constexpr int TRW = C::TRW, ACC_LD = C::ACC_LD, CQ = C::CQ, NTG = C::NTG, NG = C::NG;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -571,6 +574,7 @@ __global__ __launch_bounds__(64, 2) void k_sconv_rt(
     const float* __restrict__ in, const float* __restrict__ Wp, SconvEpilogue ep,
     const int* __restrict__ nbr, const int* __restrict__ tile_order, int N_out, int K,
     float* __restrict__ out) {
+  if (ep.n_live) N_out = min(N_out, *ep.n_live);   // device-side row count (capacity launch)
   using C = RtCfg<CIN, COUT>;
   constexpr int CQ = C::CQ, NTG = C::NTG, NG = C::NG;
   __shared__ int s_nbr[2 * 16 * (SC_MAXK + 1)];
@@ -758,6 +762,7 @@ __global__ __launch_bounds__(512) void k_sconv_co(const float* __restrict__ in, 
                            SconvEpilogue ep, const int* __restrict__ nbr,
                            const int* __restrict__ tile_order, int N_out, int K,
                            float* __restrict__ out) {
+  if (ep.n_live) N_out = min(N_out, *ep.n_live);   // device-side row count (capacity launch)
   using C = CoCfg<CIN, COUT>;
   constexpr int CQ = C::CQ, TR = C::TR, TRS = C::TRS, RS = C::RS, ACC_LD = C::ACC_LD;
   constexpr int THREADS = C::NW * 64;
@@ -956,6 +961,7 @@ __global__ __launch_bounds__(256, 2) void k_sconv_wq(
     const float* __restrict__ in, const float* __restrict__ Wp, SconvEpilogue ep,
     const int* __restrict__ nbr, const int* __restrict__ tile_order,
     const float* __restrict__ zero_row, int N_out, int K, float* __restrict__ out) {
+  if (ep.n_live) N_out = min(N_out, *ep.n_live);   // device-side row count (capacity launch)
   using C = RtCfg<CIN, COUT>;
   using L = WpCfg<CIN, COUT>;   // LDS layout of the wave-private tile
   constexpr int TRW = L::TRW, ACC_LD = L::ACC_LD, CQ = C::CQ, NTG = C::NTG, NG = C::NG;
@@ -1127,6 +1133,7 @@ __global__ __launch_bounds__(256, 2) void k_sconv_wq(
 __global__ void k_sconv_generic(const float* __restrict__ in, const float* __restrict__ W,
                                 SconvEpilogue ep, const int* __restrict__ nbr, int N_out, int K,
                                 int Cin, int Cout, float* __restrict__ out) {
+  if (ep.n_live) N_out = min(N_out, *ep.n_live);   // device-side row count (capacity launch)
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)N_out * Cout) return;
   int j = (int)(t / Cout);
@@ -1154,7 +1161,7 @@ extern "C" int glx_sconv_forward_generic(const float* in, int N_in, const float*
   GLX_REQUIRE(in && W && nbr && out && K > 0 && Cin > 0 && Cout > 0,
               "glx_sconv_forward_generic: bad arguments");
   long long total = (long long)N_out * Cout;
-  SconvEpilogue ep{bias, nullptr, nullptr, 0};
+  SconvEpilogue ep{bias, nullptr, nullptr, 0, nullptr};
   hipLaunchKernelGGL(k_sconv_generic, dim3(glx_divup(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, in, W, ep, nbr, N_out, K, Cin, Cout, out);
   GLX_LAUNCH_CHECK();
@@ -1409,12 +1416,13 @@ extern "C" int glx_sconv_pack_weights(const float* W, int K, int Cin, int Cout, 
 extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, const float* Wp,
                                  const float* bias, const float* scale, const float* shift,
                                  int relu, const int32_t* nbr, const int32_t* tile_order,
-                                 int N_out, int K, int Cin, int Cout, float* out, void* workspace,
+                                 int N_out, int K, int Cin, int Cout, float* out,
+                                 const int32_t* n_out_live, void* workspace,
                                  size_t workspace_bytes, void* stream) {
   GLX_REQUIRE(K > 0 && Cin > 0 && Cout > 0 && N_out >= 0, "glx_sconv_forward: bad sizes");
   if (N_out == 0) return GLX_OK;
   GLX_REQUIRE(in && (W || Wp) && nbr && out, "glx_sconv_forward: null pointer");
-  SconvEpilogue ep{bias, scale, shift, relu};
+  SconvEpilogue ep{bias, scale, shift, relu, n_out_live};
   if (!mfma_supported(Cin, Cout, K)) {
     GLX_REQUIRE(W, "glx_sconv_forward: raw weights required for channels (%d,%d)", Cin, Cout);
     long long total = (long long)N_out * Cout;
@@ -1436,7 +1444,8 @@ extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, cons
   }
   // first 1 KB of the workspace = the zero row that absent rule pairs gather from
   const float* zero_row = nullptr;
-  if (workspace && workspace_bytes >= 1024 && Wp != (const float*)workspace) {
+  if (g_sconv_variant == 15 && workspace && workspace_bytes >= 1024 &&
+      Wp != (const float*)workspace) {
     GLX_HIP(hipMemsetAsync(workspace, 0, 1024, st));
     zero_row = (const float*)workspace;
   }
@@ -1558,8 +1567,10 @@ extern "C" int glx_sconv_wgrad(const float* in, int N_in, const float* grad_out,
 
 // ------------------------------------------------------------------ dense()
 __global__ void k_dense_scatter(const float* __restrict__ f, const int4* __restrict__ idx, int N,
-                                int C, int D, int H, int W, float* __restrict__ out) {
+                                int C, int D, int H, int W, float* __restrict__ out,
+                                const int* __restrict__ n_live) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_live) N = min(N, *n_live);
   if (t >= (long long)N * C) return;
   int row = (int)(t / C);
   int c = (int)(t - (long long)row * C);
@@ -1569,13 +1580,15 @@ __global__ void k_dense_scatter(const float* __restrict__ f, const int4* __restr
 }
 
 extern "C" int glx_dense_scatter(const float* features, const int32_t* indices, int N, int C,
-                                 int B, int D, int H, int W, float* out, void* stream) {
+                                 int B, int D, int H, int W, float* out, const int32_t* n_live,
+                                 void* stream) {
   (void)B;
   if (N == 0) return GLX_OK;
   GLX_REQUIRE(features && indices && out && C > 0, "glx_dense_scatter: bad arguments");
   long long total = (long long)N * C;
   hipLaunchKernelGGL(k_dense_scatter, dim3(glx_divup(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, features, (const int4*)indices, N, C, D, H, W, out);
+                     (hipStream_t)stream, features, (const int4*)indices, N, C, D, H, W, out,
+                     n_live);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

@@ -17,6 +17,7 @@
 // (pcdet/models/backbones_3d/vfe/dynamic_mean_vfe.py:53-72): sorted-unique over the key
 // b*XYZ + x*YZ + y*Z + z is exactly the rank order of a bitmap laid out (b, x, y, z).
 #include "glx_common.h"
+#include "glx_fill.h"
 #include "glx_scan.h"
 
 int glx_scan_bitmap(const GlxGrid& g, uint64_t* bitmap, const uint8_t* chunk_flags,
@@ -262,12 +263,17 @@ extern "C" int glx_voxelize_hard(const float* points, const int32_t* point_batch
   GlxGrid g{B, depth, gy, gx};
   VoxGeom vg{vrange[0], vrange[1], vrange[2], vsize[0], vsize[1], vsize[2], gx, gy, gz, depth};
   const int nb = glx_divup(P > 0 ? P : 1, 256);
-  GLX_HIP(hipMemsetAsync(w.bitmap, 0, (size_t)g.words() * 8, st));
-  GLX_HIP(hipMemsetAsync(w.cflags, 0, (size_t)g.chunks(), st));
-  GLX_HIP(hipMemsetAsync(w.first_pt, 0x7F, (size_t)(P > 0 ? P : 1) * 4, st));
-  GLX_HIP(hipMemsetAsync(w.row_of_rank, 0xFF, (size_t)(P > 0 ? P : 1) * 4, st));
-  GLX_HIP(hipMemsetAsync(w.slots, 0x7F, (size_t)B * max_voxels * max_points * 4, st));
-  GLX_HIP(hipMemsetAsync(w.frame_start, 0xFF, (size_t)(B + 1) * 4, st));
+  {
+    const size_t Pn = (size_t)(P > 0 ? P : 1);
+    GlxFillJob jobs[6] = {{w.bitmap, (size_t)g.words() * 8, 0},
+                          {w.cflags, (size_t)g.chunks(), 0},
+                          {w.first_pt, Pn * 4, 0x7F},
+                          {w.row_of_rank, Pn * 4, 0xFF},
+                          {w.slots, (size_t)B * max_voxels * max_points * 4, 0x7F},
+                          {w.frame_start, (size_t)(B + 1) * 4, 0xFF}};
+    int frc = glx_fill_multi(jobs, 6, st);
+    if (frc != GLX_OK) return frc;
+  }
   if (P > 0) {
     hipLaunchKernelGGL((k_vox_mark<false>), dim3(nb), dim3(256), 0, st, points, point_batch, P, C,
                        B, vg, (unsigned long long*)w.bitmap, w.cflags, w.cell_lin,
@@ -286,7 +292,11 @@ extern "C" int glx_voxelize_hard(const float* points, const int32_t* point_batch
   IntArray fa{w.flags};
   rc = glx_exclusive_scan(fa, P, w.excl, w.total, w.scan_ws, w.scan_ws_bytes, st);
   if (rc != GLX_OK) return rc;
-  if (!point_batch) GLX_HIP(hipMemsetAsync(w.frame_start, 0, 4, st));  // single frame starts at 0
+  if (!point_batch) {  // single frame starts at 0
+    GlxFillJob job{w.frame_start, 4, 0};
+    rc = glx_fill_multi(&job, 1, st);
+    if (rc != GLX_OK) return rc;
+  }
   hipLaunchKernelGGL(k_vox_frames, dim3(1), dim3(64), 0, st, (const int*)w.excl,
                      (const int*)w.total, P, B, max_voxels, w.frame_start, w.frame_base,
                      voxel_offset);
@@ -402,11 +412,15 @@ extern "C" int glx_voxelize_dynamic_mean(const float* points, const int32_t* poi
   hipStream_t st = (hipStream_t)stream;
   GlxGrid g{B, gx, gy, gz};
   VoxGeom vg{vrange[0], vrange[1], vrange[2], vsize[0], vsize[1], vsize[2], gx, gy, gz, gz};
-  GLX_HIP(hipMemsetAsync(w.bitmap, 0, (size_t)g.words() * 8, st));
-  GLX_HIP(hipMemsetAsync(w.flags, 0, (size_t)g.chunks(), st));
+  {
+    GlxFillJob jobs[4] = {{w.bitmap, (size_t)g.words() * 8, 0},
+                          {w.flags, (size_t)g.chunks(), 0},
+                          {P > 0 ? features : nullptr, (size_t)P * C * 4, 0},
+                          {P > 0 ? w.counts : nullptr, (size_t)P * 4, 0}};
+    int frc = glx_fill_multi(jobs, 4, st);
+    if (frc != GLX_OK) return frc;
+  }
   if (P > 0) {
-    GLX_HIP(hipMemsetAsync(features, 0, (size_t)P * C * 4, st));
-    GLX_HIP(hipMemsetAsync(w.counts, 0, (size_t)P * 4, st));
     hipLaunchKernelGGL((k_vox_mark<true>), dim3(glx_divup(P, 256)), dim3(256), 0, st, points,
                        point_batch, P, C, B, vg, (unsigned long long*)w.bitmap, w.flags,
                        w.cell_lin, (int*)nullptr);
@@ -429,8 +443,9 @@ extern "C" int glx_voxelize_dynamic_mean(const float* points, const int32_t* poi
 
 // ------------------------------------------------------------------ MeanVFE
 __global__ void k_mean_vfe(const float* __restrict__ voxels, const int* __restrict__ num, int Nv,
-                           int mp, int C, float* __restrict__ out) {
+                           int mp, int C, float* __restrict__ out, const int* __restrict__ n_live) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_live) Nv = min(Nv, *n_live);
   if (t >= (long long)Nv * C) return;
   int v = (int)(t / C);
   int c = (int)(t - (long long)v * C);
@@ -442,12 +457,12 @@ __global__ void k_mean_vfe(const float* __restrict__ voxels, const int* __restri
 }
 
 extern "C" int glx_mean_vfe(const float* voxels, const int32_t* num_points, int Nv, int max_points,
-                            int C, float* out, void* stream) {
+                            int C, float* out, const int32_t* n_live, void* stream) {
   GLX_REQUIRE(voxels && num_points && out && max_points > 0 && C > 0, "glx_mean_vfe: bad arguments");
   if (Nv == 0) return GLX_OK;
   long long total = (long long)Nv * C;
   hipLaunchKernelGGL(k_mean_vfe, dim3(glx_divup(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                     voxels, num_points, Nv, max_points, C, out);
+                     voxels, num_points, Nv, max_points, C, out, n_live);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

@@ -12,6 +12,12 @@ reference calls it:
 
 All arithmetic runs in libglenet_hip.so through the C ABI; this file only owns tensors,
 caches rule tables per indice_key and wires autograd.
+
+Shape-static mode (an extension, inference only): a SparseConvTensor may carry `count`, a device
+int32[1] holding the number of live rows, while `features` / `indices` are allocated at a fixed
+capacity.  Every op then takes its row count on the device (the C ABI's n_live arguments), so a
+whole frame runs without host synchronisation and can be captured in a HIP graph;
+`check_static()` verifies afterwards that no capacity was exceeded.
 """
 import math
 from collections import OrderedDict
@@ -35,11 +41,16 @@ def _triple(v):
 class CellIndex:
     """Rank dictionary of one active set on a (B, D, H, W) grid (device resident)."""
 
-    __slots__ = ("grid", "bitmap", "flags", "prefix", "rank_to_row", "row_to_rank", "n")
+    __slots__ = ("grid", "bitmap", "flags", "prefix", "rank_to_row", "row_to_rank", "n", "count",
+                 "unique")
 
-    def __init__(self, grid, bitmap, flags, prefix, rank_to_row, row_to_rank, n):
+    def __init__(self, grid, bitmap, flags, prefix, rank_to_row, row_to_rank, n, count=None,
+                 unique=None):
         self.grid, self.bitmap, self.flags, self.prefix = grid, bitmap, flags, prefix
         self.rank_to_row, self.row_to_rank, self.n = rank_to_row, row_to_rank, n
+        # shape-static mode: n is the capacity, count (device int32[1]) the live rows, unique
+        # (device int32[1]) the number of set bits (must equal count: checked by check_static)
+        self.count, self.unique = count, unique
 
     @staticmethod
     def alloc(grid, device):
@@ -58,7 +69,7 @@ class CellIndex:
         bitmap, flags, prefix = CellIndex.alloc(grid, dev)
         r2row = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
         row2r = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
-        meta = torch.zeros(2, dtype=torch.int32, device=dev)  # n_unique, status
+        meta = torch.empty(2, dtype=torch.int32, device=dev)  # n_unique, status (both written by the call)
         wsb = query("glx_index_workspace_bytes", *grid)
         ws = workspace.get(wsb, dev)
         call("glx_index_build", indices, N, *grid, bitmap, flags, prefix, r2row, row2r, meta[0:1],
@@ -92,15 +103,19 @@ class RuleSet:
         self.geom = None
         self._pairs_dev = None
         self._pairs = None
+        self.count_in = self.count_out = None   # shape-static mode: live rows (device int32[1])
 
     @property
     def pair_count(self):
         """R = number of (input, output, offset) rules (host sync on first read)."""
         if self._pairs is None:
-            self._pairs = int((self.nbr[:self.N_out] >= 0).sum().item()) if self.N_out else 0
+            n = self.N_out if self.count_out is None else min(self.N_out, int(self.count_out.item()))
+            self._pairs = int((self.nbr[:n] >= 0).sum().item()) if n else 0
         return self._pairs
 
     def inverse_table(self):
+        if self.nbr_in is None and self.count_out is not None:
+            raise NotImplementedError("inverse rule tables are not available in shape-static mode")
         if self.nbr_in is None:
             dev = self.nbr.device
             self.nbr_in = torch.empty((max(self.N_in, 1), self.K), dtype=torch.int32, device=dev)
@@ -116,7 +131,8 @@ def build_subm_rules(x, ksize):
     rs.subm, rs.K, rs.N_in, rs.N_out = True, K, N, N
     rs.nbr = torch.empty((max(N, 1), K), dtype=torch.int32, device=x.indices.device)
     call("glx_rules_subm", x.indices, N, *idx.grid, idx.bitmap, idx.prefix, idx.rank_to_row,
-         *ksize, rs.nbr, None)
+         *ksize, rs.nbr, None, x.count)
+    rs.count_in = rs.count_out = x.count
     rs.tile_order_out = rs.tile_order_in = idx.rank_to_row
     rs.out_indices, rs.out_spatial_shape, rs.out_index = x.indices, list(x.spatial_shape), idx
     rs.in_index, rs.in_indices, rs.in_spatial_shape = idx, x.indices, list(x.spatial_shape)
@@ -124,7 +140,11 @@ def build_subm_rules(x, ksize):
     return rs
 
 
-def build_strided_rules(x, ksize, stride, padding, dilation=(1, 1, 1)):
+def build_strided_rules(x, ksize, stride, padding, dilation=(1, 1, 1), out_capacity=None):
+    """out_capacity: shape-static mode only -- rows allocated for the output set.  Default: the
+    safe bound N_in * prod(ceil(k/s)) (clipped to the grid); calibrated capacities
+    (StaticFramePipeline.calibrate) keep the launches tight, check_static() tells if one was
+    exceeded."""
     if dilation != (1, 1, 1):
         raise NotImplementedError("dilation != 1 is not used by the reference backbones")
     idx = x._ensure_index()
@@ -137,24 +157,36 @@ def build_strided_rules(x, ksize, stride, padding, dilation=(1, 1, 1)):
         raise ValueError("SparseConv3d output shape %s is empty" % (out_shape,))
     ogrid = (B, *out_shape)
     obitmap, oflags, oprefix = CellIndex.alloc(ogrid, dev)
-    n_out_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+    n_out_dev = torch.empty(1, dtype=torch.int32, device=dev)
     wsb = query("glx_index_workspace_bytes", *ogrid)
     ws = workspace.get(wsb, dev)
     N_in = x.indices.shape[0]
     call("glx_outset_build", x.indices, N_in, B, D, H, W, idx.rank_to_row, *ksize, *stride, *padding,
-         *out_shape, obitmap, oflags, oprefix, n_out_dev, ws, size_arg(ws.numel()))
-    N_out = int(n_out_dev.item())  # host sync: output row count sizes the next tensors
+         *out_shape, obitmap, oflags, oprefix, n_out_dev, x.count, ws, size_arg(ws.numel()))
+    static = x.count is not None
+    if static:
+        cells = B * out_shape[0] * out_shape[1] * out_shape[2]
+        reach = 1
+        for k, st in zip(ksize, stride):
+            reach *= -(-k // st)
+        N_out = min(int(out_capacity) if out_capacity else N_in * reach, cells)
+    else:
+        N_out = int(n_out_dev.item())  # host sync: output row count sizes the next tensors
     K = ksize[0] * ksize[1] * ksize[2]
     rs = RuleSet()
     rs.subm, rs.K, rs.N_in, rs.N_out = False, K, N_in, N_out
     rs.out_indices = torch.empty((max(N_out, 1), 4), dtype=torch.int32, device=dev)[:N_out]
     rs.nbr = torch.empty((max(N_out, 1), K), dtype=torch.int32, device=dev)
+    if static:
+        rs.count_in, rs.count_out = x.count, n_out_dev
     if N_out > 0:
-        call("glx_outset_emit", obitmap, oflags, oprefix, *ogrid, rs.out_indices)
-        call("glx_rules_strided", rs.out_indices, N_out, B, D, H, W, idx.bitmap, idx.prefix,
-             idx.rank_to_row, *ksize, *stride, *padding, rs.nbr, None)
+        call("glx_outset_emit", obitmap, oflags, oprefix, *ogrid, N_out, rs.out_indices)
+        call("glx_rules_strided", rs.out_indices, N_out, N_in, B, D, H, W, idx.bitmap, idx.prefix,
+             idx.rank_to_row, *ksize, *stride, *padding, rs.nbr, None, rs.count_out)
     rs.out_spatial_shape = out_shape
-    rs.out_index = CellIndex(ogrid, obitmap, oflags, oprefix, None, None, N_out)  # rows already sorted
+    # rows already sorted: rank == row
+    rs.out_index = CellIndex(ogrid, obitmap, oflags, oprefix, None, None, N_out,
+                             count=rs.count_out, unique=rs.count_out)
     rs.tile_order_out = None
     rs.tile_order_in = idx.rank_to_row
     rs.in_index, rs.in_indices, rs.in_spatial_shape = idx, x.indices, list(x.spatial_shape)
@@ -162,11 +194,15 @@ def build_strided_rules(x, ksize, stride, padding, dilation=(1, 1, 1)):
     return rs
 
 
-def plan_rules(indices, spatial_shape, batch_size, convs, index=None):
+def plan_rules(indices, spatial_shape, batch_size, convs, index=None, count=None,
+               capacities=None):
     """Rule tables of a whole conv stack (modules in execution order) from coordinates only:
-    returns {indice_key: RuleSet}.  Keys are required (they are how convs find their table)."""
-    x = SparseConvTensor(None, indices, spatial_shape, batch_size)
+    returns {indice_key: RuleSet}.  Keys are required (they are how convs find their table).
+    count: live rows of `indices` on the device (shape-static mode, no host sync at all);
+    capacities: optional {indice_key: rows} for the output sets of the strided convs."""
+    x = SparseConvTensor(None, indices, spatial_shape, batch_size, count=count)
     x._index = index
+    capacities = capacities or {}
     for conv in convs:
         key = conv.indice_key
         if key is None:
@@ -176,14 +212,33 @@ def plan_rules(indices, spatial_shape, batch_size, convs, index=None):
         rs = x.indice_dict.get(key)
         if rs is None:
             rs = (build_subm_rules(x, conv.kernel_size) if conv.subm else
-                  build_strided_rules(x, conv.kernel_size, conv.stride, conv.padding, conv.dilation))
+                  build_strided_rules(x, conv.kernel_size, conv.stride, conv.padding, conv.dilation,
+                                      out_capacity=capacities.get(key)))
             x.indice_dict[key] = rs
         if not conv.subm:
             nxt = SparseConvTensor(None, rs.out_indices, rs.out_spatial_shape, batch_size,
-                                   indice_dict=x.indice_dict)
+                                   indice_dict=x.indice_dict, count=rs.count_out)
             nxt._index = rs.out_index
             x = nxt
     return x.indice_dict
+
+
+def check_static(indice_dict, index=None):
+    """Host-side verdict of a shape-static frame (one sync): raises if a live row count exceeded
+    its capacity or the voxelizer's cell index held cells that max_voxels dropped."""
+    if index is not None and index.count is not None:
+        n, u = int(index.count.item()), int(index.unique.item())
+        if n > index.n:
+            raise RuntimeError("shape-static frame: %d voxels exceed the capacity %d" % (n, index.n))
+        if u != n:
+            raise RuntimeError("shape-static frame: max_voxels dropped cells (%d of %d kept); "
+                               "use the dynamic path or a larger max_voxels" % (n, u))
+    for key, rs in indice_dict.items():
+        if rs.count_out is not None:
+            n = int(rs.count_out.item())
+            if n > rs.N_out:
+                raise RuntimeError("shape-static frame: rule set %r has %d output rows, capacity %d"
+                                   % (key, n, rs.N_out))
 
 
 _profile_hook = None   # bench.py installs a callable(tag, K, cin, cout, n_out, rules), run before the launch
@@ -202,7 +257,7 @@ def pack_weights(weight_kio):
 
 
 def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rules=None, tag="fwd",
-           scale=None, shift=None, relu=False):
+           scale=None, shift=None, relu=False, n_live=None):
     """out[j] = relu?((sum_k features[nbr[j,k]] @ weight_kio[k] + bias) * scale + shift)."""
     K, cin, cout = weight_kio.shape
     out = torch.empty((n_out, cout), dtype=torch.float32, device=features.device)
@@ -214,7 +269,8 @@ def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rule
     if _profile_hook is not None:
         _profile_hook(tag, K, cin, cout, n_out, rules)
     call("glx_sconv_forward", features, features.shape[0], weight_kio, packed, bias, scale, shift,
-         1 if relu else 0, nbr, tile_order, n_out, K, cin, cout, out, ws, size_arg(ws.numel()))
+         1 if relu else 0, nbr, tile_order, n_out, K, cin, cout, out, n_live, ws,
+         size_arg(ws.numel()))
     return out
 
 
@@ -230,7 +286,10 @@ class SparseConvFunction(Function):
             nbr, order, n_out = rules.inverse_table(), rules.tile_order_in, rules.N_in
         else:
             nbr, order, n_out = rules.nbr, rules.tile_order_out, rules.N_out
-        out = _sconv(features, w, bias, nbr, order, n_out, packed=packed, rules=rules)
+        if rules.count_out is not None and (features.requires_grad or w.requires_grad):
+            raise NotImplementedError("shape-static sparse tensors are inference only")
+        out = _sconv(features, w, bias, nbr, order, n_out, packed=packed, rules=rules,
+                     n_live=rules.count_in if inverse else rules.count_out)
         ctx.rules, ctx.inverse = rules, inverse
         ctx.save_for_backward(features, w)
         ctx.has_bias = bias is not None
@@ -271,8 +330,9 @@ class SparseConvFunction(Function):
 
 class SparseConvTensor:
     def __init__(self, features, indices, spatial_shape, batch_size, grid=None, voxel_num=None,
-                 indice_dict=None, benchmark=False):
+                 indice_dict=None, benchmark=False, count=None):
         self.features = features
+        self.count = count      # shape-static mode: device int32[1] live rows (None = all rows)
         if indices.dtype != torch.int32:
             indices = indices.int()
         self.indices = indices.contiguous()
@@ -287,7 +347,7 @@ class SparseConvTensor:
     # -- spconv 2.x API used by pcdet/utils/spconv_utils.py:28-34
     def replace_feature(self, new_features):
         t = SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size,
-                             self.grid, self.voxel_num, self.indice_dict, self.benchmark)
+                             self.grid, self.voxel_num, self.indice_dict, self.benchmark, self.count)
         t._index = self._index
         return t
 
@@ -305,6 +365,9 @@ class SparseConvTensor:
 
     def _ensure_index(self):
         if self._index is None:
+            if self.count is not None:
+                raise ValueError("a shape-static SparseConvTensor needs the cell index of its "
+                                 "producer (hard_voxelize(..., static=True))")
             grid = (self.batch_size, *self.spatial_shape)
             self._index = CellIndex.build(self.indices, grid)
         return self._index
@@ -322,7 +385,7 @@ class DenseFunction(Function):
         N, C = f.shape
         D, H, W = st.spatial_shape
         out = torch.zeros((st.batch_size, C, D, H, W), dtype=torch.float32, device=f.device)
-        call("glx_dense_scatter", f, st.indices, N, C, st.batch_size, D, H, W, out)
+        call("glx_dense_scatter", f, st.indices, N, C, st.batch_size, D, H, W, out, st.count)
         ctx.st, ctx.channels_first = st, channels_first
         return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
 
@@ -426,17 +489,18 @@ class SparseConvolution(SparseModule):
                 nbr, order, n_out = rs.nbr, rs.tile_order_out, rs.N_out
             feats = _sconv(x.features.contiguous().float(), w.detach().contiguous(), self.bias, nbr,
                            order, n_out, packed=self._packed_weight(w), rules=rs, scale=scale,
-                           shift=shift, relu=fused_relu)
+                           shift=shift, relu=fused_relu,
+                           n_live=rs.count_in if self.inverse else rs.count_out)
         else:
             feats = SparseConvFunction.apply(x.features, w, self.bias, rs, self.inverse,
                                              self._packed_weight(w))
         if self.inverse:
             out = SparseConvTensor(feats, rs.in_indices, rs.in_spatial_shape, x.batch_size,
-                                   x.grid, x.voxel_num, x.indice_dict, x.benchmark)
+                                   x.grid, x.voxel_num, x.indice_dict, x.benchmark, rs.count_in)
             out._index = rs.in_index
         else:
             out = SparseConvTensor(feats, rs.out_indices, rs.out_spatial_shape, x.batch_size,
-                                   x.grid, x.voxel_num, x.indice_dict, x.benchmark)
+                                   x.grid, x.voxel_num, x.indice_dict, x.benchmark, rs.count_out)
             out._index = rs.out_index
         return out
 
@@ -528,6 +592,9 @@ class SparseSequential(SparseModule):
             if is_spconv_module(m):
                 x = m(x)
             elif isinstance(x, SparseConvTensor):
+                if x.count is not None and isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training:
+                    raise NotImplementedError("shape-static sparse tensors are inference only "
+                                              "(batch statistics would include the padding rows)")
                 if x.indices.shape[0] != 0:
                     x = x.replace_feature(m(x.features))
             else:

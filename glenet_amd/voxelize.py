@@ -36,7 +36,7 @@ def _split_batch(points, batch_idx, batch_size):
 
 
 def hard_voxelize(points, voxel_size, point_cloud_range, max_points, max_voxels, batch_idx=None,
-                  batch_size=None, index_depth=None):
+                  batch_size=None, index_depth=None, static=False):
     """points (P, C) float32 device tensor, xyz first; batch_idx (P,) frame ids (stacked frames,
     non-decreasing) or None for one frame.
 
@@ -45,6 +45,9 @@ def hard_voxelize(points, voxel_size, point_cloud_range, max_points, max_voxels,
     With index_depth (gz or gz+1) a fifth value is returned: the cell index (glenet_amd.spconv
     CellIndex) of these voxels on the grid (B, index_depth, gy, gx), or None when max_voxels
     dropped cells (then the sparse tensor builds its own).
+    static=True (needs index_depth): no host synchronisation -- all B*max_voxels rows are
+    returned, the live row count stays on the device as index.count (== voxel_offset[B]); rows
+    beyond it are undefined.  spconv.core.check_static() validates the frame afterwards.
     """
     points = points.contiguous().float()
     _lib.check_cuda(points)
@@ -71,10 +74,14 @@ def hard_voxelize(points, voxel_size, point_cloud_range, max_points, max_voxels,
     grid = (B, int(index_depth), gy, gx)
     bitmap, flags, prefix = CellIndex.alloc(grid, dev)
     r2row = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
-    meta = torch.zeros(B + 2, dtype=torch.int32, device=dev)      # voxel_offset (B+1), n_unique
+    meta = torch.empty(B + 2, dtype=torch.int32, device=dev)      # voxel_offset (B+1), n_unique
     call("glx_voxelize_hard", points, bi, P, C, B, rng_p, vs_p, gx, gy, gz, max_points, max_voxels,
          voxels, coords, num, meta[:B + 1], int(index_depth), bitmap, flags, prefix, r2row,
          meta[B + 1:], ws, size_arg(ws.numel()))
+    if static:
+        index = CellIndex(grid, bitmap, flags, prefix, r2row, None, cap, count=meta[B:B + 1],
+                          unique=meta[B + 1:B + 2])
+        return voxels, coords, num, meta[:B + 1], index
     meta_h = meta.tolist()  # the one host sync: voxel count + unique-cell count
     nv, n_unique = meta_h[B], meta_h[B + 1]
     index = CellIndex(grid, bitmap, flags, prefix, r2row[:nv], None, nv) if n_unique == nv else None
@@ -103,11 +110,12 @@ def dynamic_voxelize_mean(points, voxel_size, point_cloud_range, batch_idx=None,
     return feats[:nv], coords[:nv]
 
 
-def mean_vfe(voxels, num_points):
+def mean_vfe(voxels, num_points, count=None):
+    """count: device int32[1] live rows (shape-static mode), rows beyond it are left undefined."""
     voxels = voxels.contiguous().float()
     num_points = num_points.int().contiguous()
     _lib.check_cuda(voxels, num_points)
     nv, mp, c = voxels.shape
     out = torch.empty((nv, c), dtype=torch.float32, device=voxels.device)
-    call("glx_mean_vfe", voxels, num_points, nv, mp, c, out)
+    call("glx_mean_vfe", voxels, num_points, nv, mp, c, out, count)
     return out

@@ -16,7 +16,12 @@
  *   - all tensors row-major contiguous, float32 / int32 unless stated;
  *   - sparse indices are (N,4) int32 [batch, z, y, x]  (spconv_backbone.py:141-146);
  *   - boxes are (N,7) float32 [x, y, z, dx, dy, dz, heading] (iou3d_nms_kernel.cu:104);
- *   - a "grid" is (B, D, H, W) = (batch, z, y, x) cell counts.
+ *   - a "grid" is (B, D, H, W) = (batch, z, y, x) cell counts;
+ *   - "n_live" arguments (NULL, or a device int32[1]) make an op shape-static: the row count N
+ *     given by the host is then only the CAPACITY of the buffers and the launch, the number of
+ *     live rows is read on the device (min(N, *n_live)) and rows beyond it are neither read nor
+ *     written.  A whole frame (voxelize -> rules -> convs -> dense) then runs without a single
+ *     host synchronisation and can be captured in a HIP graph.
  */
 #ifndef GLENET_HIP_H_
 #define GLENET_HIP_H_
@@ -73,7 +78,8 @@ int glx_index_build(const int32_t* indices, int N, int B, int D, int H, int W,
  * Replaces: spconv SubMConv3d indice-pair generation (spconv_backbone.py:12,78,85). */
 int glx_rules_subm(const int32_t* indices, int N, int B, int D, int H, int W,
                    const uint64_t* bitmap, const int32_t* prefix, const int32_t* rank_to_row,
-                   int kd, int kh, int kw, int32_t* nbr, int32_t* pair_count, void* stream);
+                   int kd, int kh, int kw, int32_t* nbr, int32_t* pair_count,
+                   const int32_t* n_live, void* stream);
 
 /* Strided (regular) sparse conv output set: marks every output cell reached by >=1 active
  * input in out_bitmap, scans it, writes n_out (device int32[1]).  Output rows are
@@ -83,17 +89,20 @@ int glx_outset_build(const int32_t* indices_in, int N_in, int B, int D, int H, i
                      const int32_t* in_rank_to_row, int kd, int kh, int kw, int sd, int sh, int sw,
                      int pd, int ph, int pw, int oD, int oH, int oW, uint64_t* out_bitmap,
                      uint8_t* out_chunk_flags, int32_t* out_prefix, int32_t* n_out,
-                     void* workspace, size_t workspace_bytes, void* stream);
-/* Decode the set bits of an index into (n,4) indices [b,z,y,x], ascending order. */
+                     const int32_t* n_in_live, void* workspace, size_t workspace_bytes,
+                     void* stream);
+/* Decode the set bits of an index into (n,4) indices [b,z,y,x], ascending order; indices_out
+ * has room for `capacity` rows, further cells are dropped (compare n_out with the capacity). */
 int glx_outset_emit(const uint64_t* bitmap, const uint8_t* chunk_flags, const int32_t* prefix,
-                    int B, int D, int H, int W, int32_t* indices_out, void* stream);
+                    int B, int D, int H, int W, int capacity, int32_t* indices_out, void* stream);
 /* Rule table of the strided conv: nbr[j*K+k] = input row at cell(j)*stride - pad + k, or -1.
- * in_rank_to_row may be NULL when input rows are already in ascending cell order. */
-int glx_rules_strided(const int32_t* indices_out, int N_out, int B, int D, int H, int W,
+ * in_rank_to_row may be NULL when input rows are already in ascending cell order; N_in = rows
+ * of the input set (input rows >= N_in are treated as absent). */
+int glx_rules_strided(const int32_t* indices_out, int N_out, int N_in, int B, int D, int H, int W,
                       const uint64_t* in_bitmap, const int32_t* in_prefix,
                       const int32_t* in_rank_to_row, int kd, int kh, int kw, int sd, int sh,
                       int sw, int pd, int ph, int pw, int32_t* nbr, int32_t* pair_count,
-                      void* stream);
+                      const int32_t* n_out_live, void* stream);
 /* Input-major inverse: nbr_in[i*K+k] = output row j with nbr[j*K+k]==i, else -1. */
 int glx_rules_invert(const int32_t* nbr, int N_out, int K, int N_in, int32_t* nbr_in,
                      void* stream);
@@ -120,7 +129,8 @@ int glx_sconv_pack_weights(const float* W, int K, int Cin, int Cout, float* Wp, 
 int glx_sconv_forward(const float* in, int N_in, const float* W, const float* Wp,
                       const float* bias, const float* scale, const float* shift, int relu,
                       const int32_t* nbr, const int32_t* tile_order, int N_out, int K, int Cin,
-                      int Cout, float* out, void* workspace, size_t workspace_bytes, void* stream);
+                      int Cout, float* out, const int32_t* n_out_live, void* workspace,
+                      size_t workspace_bytes, void* stream);
 /* Bracket the NEXT glx_sconv_forward MFMA launch of this host thread with two HIP events
  * (hipExtLaunchKernelGGL start/stop): kernel-only duration for bench.py's roofline. */
 int glx_profile_next_sconv(void* start_event, void* stop_event);
@@ -142,7 +152,7 @@ int glx_sconv_wgrad(const float* in, int N_in, const float* grad_out, const int3
 /* SparseConvTensor.dense(): out (B, C, D, H, W) must be zero-filled by the caller.
  * Replaces: spconv dense() (height_compression.py:21). */
 int glx_dense_scatter(const float* features, const int32_t* indices, int N, int C, int B,
-                      int D, int H, int W, float* out, void* stream);
+                      int D, int H, int W, float* out, const int32_t* n_live, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Voxelization.
@@ -189,7 +199,7 @@ int glx_voxelize_dynamic_mean(const float* points, const int32_t* point_batch, i
 /* MeanVFE.forward (pcdet/models/backbones_3d/vfe/mean_vfe.py:14-31):
  * out[v,:] = sum_p voxels[v,p,:] / max(num_points[v], 1). */
 int glx_mean_vfe(const float* voxels, const int32_t* num_points, int Nv, int max_points, int C,
-                 float* out, void* stream);
+                 float* out, const int32_t* n_live, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Rotated boxes: BEV overlap / IoU, NMS, GLENet variance-voting NMS.

@@ -61,6 +61,80 @@ def test_backbone_forward_matches_oracle(dev, residual, nframes):
                                atol=1e-4 * max(1.0, np.abs(r).max()))
 
 
+def _frames_on(dev, nframes, seed0=20, num_points=9000):
+    frames = [synth.kitti_frame(seed0 + i, num_points=num_points)[0] for i in range(nframes)]
+    pts = torch.from_numpy(np.concatenate(frames)).to(dev)
+    bidx = torch.from_numpy(np.concatenate([np.full(len(f), i, np.int32) for i, f in enumerate(frames)])).to(dev)
+    return pts, bidx
+
+
+@pytest.mark.parametrize("residual", [False, True])
+def test_static_pipeline_and_graph_match_dynamic_path(dev, residual):
+    """The host-sync-free (shape-static) frame and its HIP-graph replay give bit-identical
+    results to the dynamic path, also when the graph is replayed on a different batch."""
+    torch.manual_seed(2)
+    grid = oracle.grid_size_of(K["point_cloud_range"], K["voxel_size"])
+    model = gb.SparseBackbone8x(4, grid, residual=residual).eval().to(dev)
+    _condition(model)
+    nframes = 2
+    pts, bidx = _frames_on(dev, nframes)
+
+    def dynamic(pts, bidx):
+        with torch.no_grad():
+            bd = gb.voxelize_batch(pts, bidx, nframes, K)
+            bd = gb.MeanVFE()(bd)
+            bd = model(bd)
+            return gb.HeightCompression()(bd)
+
+    ref = dynamic(pts, bidx)
+    pipe = gb.StaticFramePipeline(model, K, nframes, pts.shape[0] + 500, 4)   # padded input buffer
+    pipe.load(pts, bidx)
+    bd = pipe.enqueue()
+    torch.cuda.synchronize()
+    pipe.check()
+    for name in ("x_conv1", "x_conv2", "x_conv3", "x_conv4"):
+        f, i = pipe.live(bd["multi_scale_3d_features"][name])
+        r = ref["multi_scale_3d_features"][name]
+        assert torch.equal(i, r.indices), name
+        assert torch.equal(f, r.features), name
+    assert torch.equal(bd["spatial_features"], ref["spatial_features"])
+
+    pipe.capture()
+    pts2, bidx2 = _frames_on(dev, nframes, seed0=40, num_points=8500)
+    ref2 = dynamic(pts2, bidx2)
+    pipe.load(pts2, bidx2)
+    out = pipe.replay()
+    torch.cuda.synchronize()
+    pipe.check()
+    assert torch.equal(out["spatial_features"], ref2["spatial_features"])
+    f, i = pipe.live(out["encoded_spconv_tensor"])
+    assert torch.equal(i, ref2["encoded_spconv_tensor"].indices)
+    assert torch.equal(f, ref2["encoded_spconv_tensor"].features)
+    pipe.load(pts, bidx)                      # and back to the first batch
+    out = pipe.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out["spatial_features"], ref["spatial_features"])
+
+
+def test_static_pipeline_reports_capacity_overflow(dev):
+    grid = oracle.grid_size_of(K["point_cloud_range"], K["voxel_size"])
+    model = gb.SparseBackbone8x(4, grid).eval().to(dev)
+    pts, bidx = _frames_on(dev, 1)
+    pipe = gb.StaticFramePipeline(model, K, 1, pts.shape[0], 4, capacities={"spconv2": 64})
+    pipe.load(pts, bidx)
+    pipe.enqueue()
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="capacity"):
+        pipe.check()
+    tiny = dict(K, max_voxels_train=100)      # max_voxels drops cells -> index unusable, reported
+    pipe = gb.StaticFramePipeline(model, tiny, 1, pts.shape[0], 4)
+    pipe.load(pts, bidx)
+    pipe.enqueue()
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="dropped cells"):
+        pipe.check()
+
+
 def test_backbone_state_dict_names_match_reference():
     """The parameter names are the ones GLENet's checkpoints use (spconv_backbone.py:77-117)."""
     m = gb.VoxelBackBone8x(4, [1408, 1600, 40])
