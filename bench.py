@@ -40,8 +40,11 @@ FRAMES_PER_GPU = 4
 
 
 def kernel_name(cin, cout, K):
+    """Name of the kernel glx_sconv_forward dispatches to (launch_mfma in csrc/glx_sconv.hip)."""
     ok = {16, 32, 64, 128}
     if cin in (ok | {4, 8}) and cout in ok and K <= 27:
+        if cout >= 64 and cin >= 16:
+            return "k_sconv_gemm<%d,%d>" % (cin, cout)
         return "k_sconv_mfma<%d,%d>" % (cin, cout)
     return "k_sconv_generic"
 

@@ -64,68 +64,153 @@ struct SconvEpilogue {
   const float* shift;  // (Cout) or NULL
   int relu;
   const int* n_live;   // NULL, or device int32: rows >= *n_live are neither computed nor written
+  long long* trace;    // NULL, or (blocks, 4 + 8*NW) int64: selects the TRACE build (tools/sconv_tiles.py)
 };
 
-// Tile geometry: TR output rows per block, NW waves per block, NBUF LDS weight buffers.
-template <int CIN, int COUT, int TR_, int NW_, int NBUF_>
+// Column-split weight image: the values a lane needs for ONE 16-column tile, laid out so that a
+// quad of 16 lanes reads 256 consecutive bytes per ds_read_b128 (no padding, no bank conflicts):
+//   CQ % 4 == 0:  img[((tile*4 + q)*(CQ/4) + t/4)*64 + n*4 + t%4] = W[k][q*CQ + t][tile*16 + n]
+//   CQ in {1,2}:  img[((tile*4 + q)*16 + n)*CQ + t]
+template <int CIN, int COUT>
+struct SconvSplitCfg {
+  static constexpr int CQ = CIN / 4, NT = COUT / 16;
+  static constexpr int IMG = CIN * COUT;   // dwords per offset
+  __host__ __device__ static constexpr int idx(int tile, int q, int t, int n) {
+    return CQ % 4 == 0 ? ((tile * 4 + q) * (CQ / 4) + t / 4) * 64 + n * 4 + t % 4
+                       : ((tile * 4 + q) * 16 + n) * CQ + t;
+  }
+};
+
+template <int CIN, int COUT>
+__global__ void k_pack_weights_split(const float* __restrict__ W, int K, float* __restrict__ Wp) {
+  using S = SconvSplitCfg<CIN, COUT>;
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= K * CIN * COUT) return;
+  int co = e % COUT;
+  int ci = (e / COUT) % CIN;
+  int k = e / (COUT * CIN);
+  int q = ci / S::CQ, t = ci % S::CQ;
+  int tile = co / 16, n = co % 16;
+  Wp[(size_t)k * S::IMG + S::idx(tile, q, t, n)] = W[e];
+}
+
+// Tile geometry: TR output rows per block, NW waves per block, NBUF LDS weight buffers, WPG waves
+// per 16-pair chunk.  WPG == 1: a wave multiplies whole chunks (all COUT/16 column tiles) and the
+// chunks of an offset are dealt to the NW waves.  WPG > 1: the column tiles of a chunk are split
+// over WPG waves (each owns TPW tiles), the chunks are dealt to the G = NW/WPG wave groups; with
+// ~1.6 chunks per offset in a 64-row LiDAR tile this keeps every wave (and SIMD) busy on every
+// offset and shortens the per-offset critical path from one chunk to 1/WPG of a chunk.
+template <int CIN, int COUT, int TR_, int NW_, int NBUF_, int WPG_ = 1>
 struct SconvTile {
   using C = SconvCfg<CIN, COUT>;
-  static constexpr int TR = TR_, NW = NW_, NBUF = NBUF_;
+  using S = SconvSplitCfg<CIN, COUT>;
+  static constexpr int TR = TR_, NW = NW_, NBUF = NBUF_, WPG = WPG_;
   static constexpr int THREADS = NW * 64;
-  static constexpr int MAXC = (TR + 16 * NW - 1) / (16 * NW);   // chunks per wave per offset
+  static constexpr int G = NW / WPG;                            // chunk groups
+  static constexpr int TPW = C::NT / WPG;                       // column tiles per wave
+  static constexpr int MAXC = (TR + 16 * G - 1) / (16 * G);     // chunks per wave per offset
+  static constexpr int IMGW = WPG == 1 ? C::IMG : S::IMG;       // LDS weight image, dwords
   static constexpr int ACC_LD = COUT + 4;
   static constexpr int LW = (TR + 63) / 64;                     // waves that own row slots
   static constexpr size_t lds_bytes = (size_t)TR * ACC_LD * 4 + (size_t)SC_MAXK * TR * 5 +
-                                      (TR + 32 + 32 * LW) * 4 + 64 + (size_t)NBUF * C::IMG * 4;
+                                      (TR + 32 + 32 * LW) * 4 + 64 + (size_t)NBUF * IMGW * 4;
   static_assert(LW <= NW, "row-slot waves exceed block");
   static_assert(TR <= 256, "row slots are stored as bytes");
+  static_assert(NW % WPG == 0 && C::NT % WPG == 0 && (G & (G - 1)) == 0, "bad column split");
 };
 
 // gather the CQ-float slice of up to MAXC chunks of offset k owned by this wave
 template <int CIN, int COUT, class T>
 __device__ __forceinline__ void sc_gather(const float* __restrict__ in, const int* s_pin,
-                                          int k, int cnt, int wave, int r, int q,
+                                          int k, int cnt, int grp, int r, int q, int rot,
                                           float (&A)[T::MAXC][SconvCfg<CIN, COUT>::CQ],
                                           bool (&valid)[T::MAXC]) {
   using C = SconvCfg<CIN, COUT>;
 #pragma unroll
   for (int j = 0; j < T::MAXC; ++j) {
-    const int c = ((wave - k) & (T::NW - 1)) + j * T::NW;
+    const int c = ((grp - k - rot) & (T::G - 1)) + j * T::G;
     const int p = c * 16 + r;
     int irow = -1;
     if (p < cnt) irow = s_pin[k * T::TR + p];
     const float* ap = in + (long long)(irow < 0 ? 0 : irow) * CIN + q * C::CQ;
-    if (c * 16 < cnt) {   // wave-uniform: skip the loads of an absent chunk
-      if constexpr (C::CQ % 4 == 0) {
+    // The loads are UNCONDITIONAL (absent pairs / chunks read row 0, an L2 hit): a branch
+    // around them would make the number of loads in flight unknown at compile time and force
+    // s_waitcnt vmcnt(0) before the multiply of the CURRENT offset, i.e. no prefetch at all.
+    if constexpr (C::CQ % 4 == 0) {
 #pragma unroll
-        for (int i = 0; i < C::CQ / 4; ++i) {
-          f32x4 v = reinterpret_cast<const f32x4*>(ap)[i];
-          A[j][4 * i + 0] = v[0]; A[j][4 * i + 1] = v[1]; A[j][4 * i + 2] = v[2]; A[j][4 * i + 3] = v[3];
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < C::CQ; ++i) A[j][i] = ap[i];
+      for (int i = 0; i < C::CQ / 4; ++i) {
+        f32x4 v = reinterpret_cast<const f32x4*>(ap)[i];
+        A[j][4 * i + 0] = v[0]; A[j][4 * i + 1] = v[1]; A[j][4 * i + 2] = v[2]; A[j][4 * i + 3] = v[3];
       }
+    } else {
+#pragma unroll
+      for (int i = 0; i < C::CQ; ++i) A[j][i] = ap[i];
     }
     valid[j] = irow >= 0;   // zero-fill is applied at use: writing A here would stall on vmcnt(0)
   }
 }
 
 // MFMA the wave's chunks of offset k against the staged W[k] and add into the LDS tile
-template <int CIN, int COUT, class T>
+template <int CIN, int COUT, class T, bool TRACE = false>
 __device__ __forceinline__ void sc_compute(const float* s_w, float* s_acc,
-                                           const unsigned char* s_pslot, int k, int cnt, int wave,
-                                           int r, int q,
+                                           const unsigned char* s_pslot, int k, int cnt, int grp,
+                                           int tile0, int r, int q, int rot,
                                            const float (&A)[T::MAXC][SconvCfg<CIN, COUT>::CQ],
-                                           const bool (&valid)[T::MAXC]) {
+                                           const bool (&valid)[T::MAXC], long long* tsub = nullptr) {
   using C = SconvCfg<CIN, COUT>;
+  using S = SconvSplitCfg<CIN, COUT>;
 #pragma unroll
   for (int j = 0; j < T::MAXC; ++j) {
-    const int c = ((wave - k) & (T::NW - 1)) + j * T::NW;
+    const int c = ((grp - k - rot) & (T::G - 1)) + j * T::G;
     if (c * 16 >= cnt) continue;   // wave-uniform
+    long long u0 = 0, u1 = 0, u2 = 0;
+    if constexpr (TRACE) {
+      u0 = clock64();
+      __builtin_amdgcn_s_waitcnt(0x0F70 | 8);   // vmcnt(8): this offset's rows have landed
+      u1 = clock64();
+    }
     float Am[C::CQ];
 #pragma unroll
     for (int i = 0; i < C::CQ; ++i) Am[i] = valid[j] ? A[j][i] : 0.f;
+    if constexpr (T::WPG > 1) {
+      // column split: this wave owns tiles tile0 .. tile0+TPW-1 of the chunk; one dependent
+      // accumulator chain per tile (SrcC forwarding keeps a chain at the full MFMA rate)
+      f32x4 acc[T::TPW];
+#pragma unroll
+      for (int tt = 0; tt < T::TPW; ++tt) {
+        acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* wp = s_w + S::idx(tile0 + tt, q, 0, r);
+        if constexpr (C::CQ % 4 == 0) {
+#pragma unroll
+          for (int t4 = 0; t4 < C::CQ / 4; ++t4) {
+            f32x4 wv = *reinterpret_cast<const f32x4*>(wp + 64 * t4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e], Am[4 * t4 + e], acc[tt], 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < C::CQ; ++t)
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t], Am[t], acc[tt], 0, 0, 0);
+        }
+      }
+      if constexpr (TRACE) {
+        asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[T::TPW - 1]));
+        u2 = clock64();
+        tsub[0] += u1 - u0; tsub[1] += u2 - u1;
+      }
+      const int p = c * 16 + r;
+      if (p < cnt) {
+        float* dst = s_acc + (int)s_pslot[k * T::TR + p] * T::ACC_LD + tile0 * 16 + 4 * q;
+#pragma unroll
+        for (int tt = 0; tt < T::TPW; ++tt) {
+          f32x4 v = *reinterpret_cast<f32x4*>(dst + tt * 16);
+          v += acc[tt];
+          *reinterpret_cast<f32x4*>(dst + tt * 16) = v;
+        }
+      }
+      continue;
+    }
     // Operands swapped (W^T as the MFMA "A", gathered rows as "B"): D[i = cout][j = pair], so
     // lane (pair r, q) ends up with 4 CONSECUTIVE output channels 16ct + 4q .. +3 of its pair.
     f32x4 acc[C::NT];
@@ -151,6 +236,11 @@ __device__ __forceinline__ void sc_compute(const float* s_w, float* s_acc,
         }
       }
     }
+    if constexpr (TRACE) {
+      asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[C::NT - 1]));   // results complete
+      u2 = clock64();
+      tsub[0] += u1 - u0; tsub[1] += u2 - u1;
+    }
     // plain read-modify-write of the LDS tile (no atomics: rows of one offset are distinct and
     // offsets are separated by the block barrier; LDS float atomics are far slower than this)
     const int p = c * 16 + r;
@@ -172,20 +262,21 @@ __device__ __forceinline__ void sc_compute(const float* s_w, float* s_acc,
 // distinct and offsets are separated by a barrier, so every output element is summed in a fixed
 // order: bitwise reproducible, no global atomics.  W[k+1] streams into the second LDS buffer
 // and the next offset's input rows into registers while offset k multiplies.
-template <int CIN, int COUT, int TR_, int NW_, int NBUF_>
+template <int CIN, int COUT, int TR_, int NW_, int NBUF_, int WPG_ = 1, bool TRACE = false>
 __global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
     const float* __restrict__ in, const float* __restrict__ Wp, SconvEpilogue ep,
     const int* __restrict__ nbr, const int* __restrict__ tile_order, int N_out, int K,
     float* __restrict__ out) {
   if (ep.n_live) N_out = min(N_out, *ep.n_live);   // device-side row count (capacity launch)
   using C = SconvCfg<CIN, COUT>;
-  using T = SconvTile<CIN, COUT, TR_, NW_, NBUF_>;
+  using T = SconvTile<CIN, COUT, TR_, NW_, NBUF_, WPG_>;
   constexpr int TR = T::TR, ACC_LD = T::ACC_LD, NBUF = T::NBUF, LW = T::LW;
+  constexpr int IMGW = T::IMGW;
   constexpr int SC_THREADS = T::THREADS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_acc = smem;                                        // TR * ACC_LD
   float* s_w = s_acc + TR * ACC_LD;                           // NBUF * IMG
-  int* s_pin = reinterpret_cast<int*>(s_w + NBUF * C::IMG);   // SC_MAXK * TR
+  int* s_pin = reinterpret_cast<int*>(s_w + NBUF * IMGW);   // SC_MAXK * TR
   int* s_rows = s_pin + SC_MAXK * TR;                         // TR
   int* s_cnt = s_rows + TR;                                   // 32
   int* s_wcnt = s_cnt + 32;                                   // LW * 32
@@ -194,7 +285,29 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int row0 = blockIdx.x * TR;
+  // XCD-aware tile mapping: workgroups are dealt round-robin to the 8 XCDs (block b runs on XCD
+  // b mod 8), each with a private L2.  Rows are in cell order, so a CONTIGUOUS range of tiles
+  // per XCD keeps the neighbour rows that adjacent tiles share in one L2 instead of eight.
+  int tile;
+  {
+    const int nb = gridDim.x, x = blockIdx.x & 7, i = blockIdx.x >> 3;
+    const int qn = nb >> 3, rm = nb & 7;
+    tile = x * qn + (x < rm ? x : rm) + i;
+  }
+  const int row0 = tile * TR;
+  // Chunk c of offset k runs on wave (c + k + rot) mod NW.  rot differs per block: co-resident
+  // blocks start together and walk the offsets in step, so without it the chunk-0 waves of all
+  // of them sit on the same SIMD while the other three idle (measured: 2x slower blocks).
+  const int rot = (int)((blockIdx.x * 0x9E3779B1u) >> 28);
+  const int grp = wave / T::WPG;                  // chunk group of this wave
+  const int tile0 = (wave % T::WPG) * T::TPW;     // first column tile it owns (WPG > 1)
+  // TRACE build (tools/sconv_tiles.py): per-block wall clock + per-wave cycle budget of the
+  // phases of the offset loop.  tph: issue prefetch | multiply | barrier 1 | stage store | barrier 2
+  long long t_start = 0;
+  long long tph[5] = {0, 0, 0, 0, 0};
+  long long tsub[2] = {0, 0};   // inside multiply: wait for the gathered rows | MFMA loop
+  int my_chunks = 0;
+  if constexpr (TRACE) t_start = wall_clock64();
 
   // ---- tile rows, zero accumulators, first weight image
   int my_row = -1;
@@ -243,12 +356,12 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
   mask = __builtin_amdgcn_readfirstlane(mask);
 
   // ---- weight staging registers (next image) and input-row registers (ping-pong)
-  constexpr int STAGE_F4 = C::IMG / 4;
+  constexpr int STAGE_F4 = IMGW / 4;
   constexpr int SPT = (STAGE_F4 + SC_THREADS - 1) / SC_THREADS;
   f32x4 stage_regs[SPT];
 #define SC_STAGE_LOAD(KK)                                                                   \
   {                                                                                         \
-    const f32x4* src_ = reinterpret_cast<const f32x4*>(Wp + (size_t)(KK) * C::IMG);         \
+    const f32x4* src_ = reinterpret_cast<const f32x4*>(Wp + (size_t)(KK) * IMGW);          \
     _Pragma("unroll") for (int i_ = 0; i_ < SPT; ++i_) {                                    \
       int e_ = tid + i_ * SC_THREADS;                                                       \
       stage_regs[i_] = src_[e_ < STAGE_F4 ? e_ : STAGE_F4 - 1];                             \
@@ -256,7 +369,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
   }
 #define SC_STAGE_STORE(BUF)                                                                 \
   {                                                                                         \
-    f32x4* dst_ = reinterpret_cast<f32x4*>(s_w + (BUF) * C::IMG);                           \
+    f32x4* dst_ = reinterpret_cast<f32x4*>(s_w + (BUF) * IMGW);                            \
     _Pragma("unroll") for (int i_ = 0; i_ < SPT; ++i_) {                                    \
       int e_ = tid + i_ * SC_THREADS;                                                       \
       if (STAGE_F4 % SC_THREADS == 0 || e_ < STAGE_F4) dst_[e_] = stage_regs[i_];           \
@@ -273,29 +386,42 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
     cnt = s_cnt[k];
     SC_STAGE_LOAD(k);
     SC_STAGE_STORE(0);
-    sc_gather<CIN, COUT, T>(in, s_pin, k, cnt, wave, r, q, A0, V0);
+    sc_gather<CIN, COUT, T>(in, s_pin, k, cnt, grp, r, q, rot, A0, V0);
   }
   __syncthreads();
 
   int buf = 0;
   // one phase: prefetch (W image + input rows) of the next offset, multiply the current one
+  // The prefetch is issued on every phase, also the last one (then it re-reads the current
+  // offset and is discarded): straight-line code lets the compiler wait with an exact vmcnt.
 #define SC_PHASE(CUR, NXT, VCUR, VNXT)                                                                 \
   {                                                                                         \
-    int kn_ = -1, cntn_ = 0;                                                                \
-    if (rem) {                                                                              \
-      kn_ = __builtin_ctz(rem);                                                             \
-      rem &= rem - 1;                                                                       \
-      cntn_ = s_cnt[kn_];                                                                   \
-      SC_STAGE_LOAD(kn_);                                                                   \
-      sc_gather<CIN, COUT, T>(in, s_pin, kn_, cntn_, wave, r, q, NXT, VNXT);                         \
-    }                                                                                       \
-    sc_compute<CIN, COUT, T>(s_w + (NBUF == 2 ? buf : 0) * C::IMG, s_acc, s_pslot, k, cnt,     \
-                          wave, r, q, CUR, VCUR);                                           \
+    const bool more_ = rem != 0;                                                            \
+    const int kn_ = more_ ? __builtin_ctz(rem) : k;                                         \
+    rem &= rem - 1;                                                                         \
+    const int cntn_ = s_cnt[kn_];                                                           \
+    long long c0_ = 0, c1_ = 0, c2_ = 0, c3_ = 0, c4_ = 0, c5_ = 0;                         \
+    if constexpr (TRACE) c0_ = clock64();                                                   \
+    SC_STAGE_LOAD(kn_);                                                                     \
+    sc_gather<CIN, COUT, T>(in, s_pin, kn_, cntn_, grp, r, q, rot, NXT, VNXT);                   \
+    if constexpr (TRACE) c1_ = clock64();                                                   \
+    sc_compute<CIN, COUT, T, TRACE>(s_w + (NBUF == 2 ? buf : 0) * IMGW, s_acc, s_pslot, k,   \
+                                    cnt, grp, tile0, r, q, rot, CUR, VCUR, tsub);            \
+    if constexpr (TRACE) c2_ = clock64();                                                   \
     if (NBUF == 1) __syncthreads();                                                         \
-    if (kn_ >= 0) SC_STAGE_STORE(NBUF == 2 ? (buf ^ 1) : 0);                                \
+    if constexpr (TRACE) c3_ = clock64();                                                   \
+    SC_STAGE_STORE(NBUF == 2 ? (buf ^ 1) : 0);                                              \
+    if constexpr (TRACE) c4_ = clock64();                                                   \
     __syncthreads();                                                                        \
+    if constexpr (TRACE) {                                                                  \
+      c5_ = clock64();                                                                      \
+      tph[0] += c1_ - c0_; tph[1] += c2_ - c1_; tph[2] += c3_ - c2_; tph[3] += c4_ - c3_;   \
+      tph[4] += c5_ - c4_;                                                                  \
+      _Pragma("unroll") for (int j_ = 0; j_ < T::MAXC; ++j_)                                \
+        my_chunks += (((grp - k - rot) & (T::G - 1)) + j_ * T::G) * 16 < cnt;              \
+    }                                                                                       \
     buf ^= 1;                                                                               \
-    k = kn_;                                                                                \
+    k = more_ ? kn_ : -1;                                                                   \
     cnt = cntn_;                                                                            \
   }
   while (k >= 0) {
@@ -323,462 +449,86 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
     }
     *reinterpret_cast<f32x4*>(out + (long long)orow * COUT + 4 * c4) = v;
   }
+  if constexpr (TRACE) {
+    __syncthreads();
+    constexpr int REC = 4 + 8 * T::NW;   // int64 per block
+    long long* tr = ep.trace + (long long)REC * blockIdx.x;
+    if (tid == 0) {
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      int chunks = 0;
+      for (int kk = 0; kk < K; ++kk) chunks += (s_cnt[kk] + 15) >> 4;
+      tr[0] = t_start; tr[1] = wall_clock64();
+      tr[2] = ((long long)xcc << 32) | hw; tr[3] = chunks;
+    }
+    if (lane == 0) {
+      long long* w = tr + 4 + 8 * wave;
+      w[0] = tph[0]; w[1] = tph[1]; w[2] = tph[2]; w[3] = tph[3]; w[4] = tph[4];
+      w[5] = my_chunks; w[6] = tsub[0]; w[7] = tsub[1];
+    }
+  }
 }
 
-// ==================================================================== wave-private kernel
-// Default sparse-conv kernel.  Every wave owns TRW consecutive output rows and everything
-// about them (rule compaction, accumulator tile, epilogue), so the kernel has NO barriers and
-// no shared state between waves: a wave streams W[k] fragments from L2 straight into
-// registers (prefetched one phase ahead), gathers 16 rule pairs at a time (prefetched one
-// chunk ahead), multiplies them on the matrix pipe and adds the 16x(16*NTG) result into its
-// private LDS tile with plain ds_read/ds_write (in-order within a wave, so the summation order
-// of every output element is fixed: bitwise reproducible).
-template <int CIN, int COUT>
-struct WpCfg {
-  static constexpr int CQ = CIN / 4;
-  static constexpr int CG0 = 4096 / CIN;                              // cols per W register set
-  static constexpr int CG = COUT < CG0 ? COUT : (CG0 < 16 ? 16 : CG0);
-  static constexpr int NG = COUT / CG;                                 // column groups
-  static constexpr int NTG = CG / 16;                                  // 16-col tiles per group
-  static constexpr int TRW = 48;                                       // rows per wave
-  static constexpr int NWB = 4;                                        // waves per block
+// ==================================================================== block implicit GEMM
+// Same output-stationary scheme as k_sconv_mfma (rule compaction per offset, fp32 accumulator tile
+// in LDS, fixed summation order), organised like a blocked GEMM:
+//   * the rows of the NEXT panel of rule pairs are gathered by ALL threads of the block, one
+//     16-byte segment each (a 256-byte row = 16 consecutive lanes), and staged in LDS; MFMA waves
+//     read their operand fragments from LDS, so no wave gathers rows it does not multiply and
+//     nobody waits on vmcnt inside the multiply;
+//   * a 16-pair chunk is split over WPG waves by output-column tile, the G = NW/WPG wave groups
+//     take the chunks of a panel (AP = 16*G pairs): with ~19 pairs per (64-row tile, offset) every
+//     wave has work on every step and the step's critical path is 1/WPG of a chunk.
+template <int CIN, int COUT, int TR_, int NW_, int WPG_>
+struct SconvGemm {
+  using S = SconvSplitCfg<CIN, COUT>;
+  static constexpr int CQ = CIN / 4, NT = COUT / 16;
+  static constexpr int TR = TR_, NW = NW_, WPG = WPG_, THREADS = NW * 64;
+  static constexpr int G = NW / WPG, TPW = NT / WPG;
+  static constexpr int AP = 16 * G;                          // pairs per A panel
+  static constexpr int A_LD = CIN + (CIN >= 16 ? 4 : 0);     // panel row stride (bank spread)
+  static constexpr int SEGS = CIN / 4;                       // 16-byte segments per input row
+  static constexpr int A_SEG = AP * SEGS;
+  static constexpr int GPT = (A_SEG + THREADS - 1) / THREADS;   // gather segments per thread
+  static constexpr int W_F4 = S::IMG / 4;
+  static constexpr int SPT = (W_F4 + THREADS - 1) / THREADS;    // weight f32x4 per thread
   static constexpr int ACC_LD = COUT + 4;
-  static constexpr int WAVE_LDS_DW =
-      TRW * ACC_LD + SC_MAXK * TRW + 32 + TRW + (SC_MAXK * TRW + 3) / 4;
-  static constexpr size_t lds_bytes = (size_t)NWB * WAVE_LDS_DW * 4;
-  static constexpr int IMG = CIN * COUT;                               // dwords per offset
+  static constexpr int LW = (TR + 63) / 64;
+  static constexpr size_t lds_bytes = (size_t)TR * ACC_LD * 4 + (size_t)S::IMG * 4 +
+                                      (size_t)AP * A_LD * 4 + (size_t)SC_MAXK * TR * 5 +
+                                      (TR + 32 + 32 * LW) * 4 + 64;
+  static_assert(NW % WPG == 0 && NT % WPG == 0, "bad column split");
+  static_assert(LW <= NW && TR <= 256, "bad tile");
 };
 
-// W (K, CIN, COUT) -> register-fragment order:
-//   img[k][g][q][t][n][c] = W[k][q*CQ+t][g*CG + c*16 + n]
-template <int CIN, int COUT>
-__global__ void k_pack_weights_wp(const float* __restrict__ W, int K, float* __restrict__ Wp) {
-  using C = WpCfg<CIN, COUT>;
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= K * CIN * COUT) return;
-  int co = e % COUT;
-  int ci = (e / COUT) % CIN;
-  int k = e / (COUT * CIN);
-  int g = co / C::CG, cl = co % C::CG;
-  int c = cl / 16, n = cl % 16;
-  int q = ci / C::CQ, t = ci % C::CQ;
-  Wp[(size_t)k * C::IMG + ((((size_t)g * 4 + q) * C::CQ + t) * 16 + n) * C::NTG + c] = W[e];
-}
-
-template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void k_sconv_wp(
+template <int CIN, int COUT, int TR_, int NW_, int WPG_>
+__global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
     const float* __restrict__ in, const float* __restrict__ Wp, SconvEpilogue ep,
     const int* __restrict__ nbr, const int* __restrict__ tile_order, int N_out, int K,
     float* __restrict__ out) {
-  if (ep.n_live) N_out = min(N_out, *ep.n_live);   // device-side row count (capacity launch)
-  using C = WpCfg<CIN, COUT>;
-  constexpr int TRW = C::TRW, ACC_LD = C::ACC_LD, CQ = C::CQ, NTG = C::NTG, NG = C::NG;
+  if (ep.n_live) N_out = min(N_out, *ep.n_live);
+  using T = SconvGemm<CIN, COUT, TR_, NW_, WPG_>;
+  using S = SconvSplitCfg<CIN, COUT>;
+  constexpr int TR = T::TR, ACC_LD = T::ACC_LD, LW = T::LW, CQ = T::CQ, THREADS = T::THREADS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  float* s_acc = smem + (size_t)wave * C::WAVE_LDS_DW;                 // TRW * ACC_LD
-  int* s_pin = reinterpret_cast<int*>(s_acc + TRW * ACC_LD);           // SC_MAXK * TRW
-  int* s_cnt = s_pin + SC_MAXK * TRW;                                  // 32
-  int* s_rows = s_cnt + 32;                                            // TRW
-  unsigned char* s_pslot = reinterpret_cast<unsigned char*>(s_rows + TRW);  // SC_MAXK * TRW
-  const long long row0 = ((long long)blockIdx.x * C::NWB + wave) * TRW;
-  if (row0 >= N_out) return;     // whole wave idle (no barriers anywhere below)
+  float* s_acc = smem;                                        // TR * ACC_LD
+  float* s_w = s_acc + TR * ACC_LD;                           // IMG
+  float* s_a = s_w + S::IMG;                                  // AP * A_LD
+  int* s_pin = reinterpret_cast<int*>(s_a + T::AP * T::A_LD); // SC_MAXK * TR
+  int* s_rows = s_pin + SC_MAXK * TR;                         // TR
+  int* s_cnt = s_rows + TR;                                   // 32
+  int* s_wcnt = s_cnt + 32;                                   // LW * 32
+  unsigned char* s_pslot = reinterpret_cast<unsigned char*>(s_wcnt + LW * 32);  // SC_MAXK * TR
 
-  // ---- my rows, their neighbour lists (registers), per-offset compaction (wave ballots)
-  int my_row = -1;
-  if (lane < TRW && row0 + lane < N_out) my_row = tile_order ? tile_order[row0 + lane] : (int)(row0 + lane);
-  if (lane < TRW) s_rows[lane] = my_row;
-  for (int i = lane; i < TRW * ACC_LD / 4; i += 64)
-    reinterpret_cast<f32x4*>(s_acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  unsigned mask = 0;
-#pragma unroll
-  for (int k = 0; k < SC_MAXK; ++k) {
-    int nb = (k < K && my_row >= 0) ? nbr[(long long)my_row * K + k] : -1;
-    unsigned long long b = __ballot(nb >= 0);
-    if (nb >= 0) {
-      int pos = k * TRW + __popcll(b & ((1ull << lane) - 1ull));
-      s_pin[pos] = nb;
-      s_pslot[pos] = (unsigned char)lane;
-    }
-    int n = __popcll(b);
-    if (lane == 0) s_cnt[k] = n;
-    if (n) mask |= 1u << k;
-  }
-  mask = __builtin_amdgcn_readfirstlane(mask);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-
-  // ---- register sets: W fragment of the current / next phase, input rows of the current / next chunk
-  float Wc[CQ][NTG], Wn[CQ][NTG];
-  float Ac[CQ], An[CQ];
-  bool an_valid = false;
-
-#define WP_LOAD_W(KK, GG)                                                                    \
-  {                                                                                          \
-    const float* wp_ = Wp + (size_t)(KK) * C::IMG + (((size_t)(GG) * 4 + q) * CQ * 16 + r) * NTG; \
-    _Pragma("unroll") for (int t_ = 0; t_ < CQ; ++t_) {                                      \
-      if constexpr (NTG == 4) {                                                              \
-        f32x4 v_ = *reinterpret_cast<const f32x4*>(wp_ + t_ * 16 * NTG);                     \
-        Wn[t_][0] = v_[0]; Wn[t_][1] = v_[1]; Wn[t_][2] = v_[2]; Wn[t_][3] = v_[3];          \
-      } else if constexpr (NTG == 2) {                                                       \
-        float2 v_ = *reinterpret_cast<const float2*>(wp_ + t_ * 16 * NTG);                   \
-        Wn[t_][0] = v_.x; Wn[t_][1] = v_.y;                                                  \
-      } else {                                                                               \
-        Wn[t_][0] = wp_[t_ * 16 * NTG];                                                      \
-      }                                                                                      \
-    }                                                                                        \
-  }
-#define WP_GATHER(KK, CC, CNT)                                                               \
-  {                                                                                          \
-    int p_ = (CC) * 16 + r;                                                                  \
-    int irow_ = (p_ < (CNT)) ? s_pin[(KK) * TRW + p_] : -1;                                  \
-    const float* ap_ = in + (long long)(irow_ < 0 ? 0 : irow_) * CIN + q * CQ;               \
-    if constexpr (CQ % 4 == 0) {                                                             \
-      _Pragma("unroll") for (int i_ = 0; i_ < CQ / 4; ++i_) {                                \
-        f32x4 v_ = reinterpret_cast<const f32x4*>(ap_)[i_];                                  \
-        An[4 * i_ + 0] = v_[0]; An[4 * i_ + 1] = v_[1]; An[4 * i_ + 2] = v_[2]; An[4 * i_ + 3] = v_[3]; \
-      }                                                                                      \
-    } else {                                                                                 \
-      _Pragma("unroll") for (int i_ = 0; i_ < CQ; ++i_) An[i_] = ap_[i_];                    \
-    }                                                                                        \
-    an_valid = irow_ >= 0;                                                                   \
-  }
-
-  unsigned rem = mask;
-  int k = -1, g = 0, cnt = 0;
-  if (rem) {
-    k = __builtin_ctz(rem);
-    rem &= rem - 1;
-    cnt = s_cnt[k];
-    WP_LOAD_W(k, 0);
-    WP_GATHER(k, 0, cnt);
-  }
-  while (k >= 0) {
-    // ---- phase (k, g): promote the prefetched W set, start fetching the next one
-#pragma unroll
-    for (int t = 0; t < CQ; ++t)
-#pragma unroll
-      for (int c = 0; c < NTG; ++c) Wc[t][c] = Wn[t][c];
-    int k2 = k, g2 = g + 1, cnt2 = cnt;
-    if (g2 == NG) {
-      g2 = 0;
-      if (rem) {
-        k2 = __builtin_ctz(rem);
-        rem &= rem - 1;
-        cnt2 = s_cnt[k2];
-      } else {
-        k2 = -1;
-      }
-    }
-    if (k2 >= 0) WP_LOAD_W(k2, g2);
-    const int nc = (cnt + 15) >> 4;
-    for (int c = 0; c < nc; ++c) {
-#pragma unroll
-      for (int i = 0; i < CQ; ++i) Ac[i] = an_valid ? An[i] : 0.f;
-      if (c + 1 < nc) {
-        WP_GATHER(k, c + 1, cnt);
-      } else if (k2 >= 0) {
-        WP_GATHER(k2, 0, cnt2);
-      }
-      // operands swapped: D[i = cout][j = pair]; lane (pair r, q) gets channels 16ct+4q..+3
-      f32x4 acc[NTG];
-#pragma unroll
-      for (int ct = 0; ct < NTG; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t = 0; t < CQ; ++t)
-#pragma unroll
-        for (int ct = 0; ct < NTG; ++ct)
-          acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[t][ct], Ac[t], acc[ct], 0, 0, 0);
-      const int p = c * 16 + r;
-      if (p < cnt) {
-        float* dst = s_acc + (int)s_pslot[k * TRW + p] * ACC_LD + g * C::CG + 4 * q;
-#pragma unroll
-        for (int ct = 0; ct < NTG; ++ct) {
-          f32x4 v = *reinterpret_cast<f32x4*>(dst + ct * 16);
-          v += acc[ct];
-          *reinterpret_cast<f32x4*>(dst + ct * 16) = v;
-        }
-      }
-    }
-    k = k2; g = g2; cnt = cnt2;
-  }
-#undef WP_LOAD_W
-#undef WP_GATHER
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-
-  // ---- epilogue: this wave's rows, coalesced float4 stores with the fused pointwise tail
-  constexpr int C4 = COUT / 4;
-  for (int i = lane; i < TRW * C4; i += 64) {
-    int rr = i / C4, c4 = i - rr * C4;
-    int orow = s_rows[rr];
-    if (orow < 0) continue;
-    f32x4 v = *reinterpret_cast<const f32x4*>(s_acc + rr * ACC_LD + 4 * c4);
-    const int co = 4 * c4;
-    if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + co);
-    if (ep.scale) v *= *reinterpret_cast<const f32x4*>(ep.scale + co);
-    if (ep.shift) v += *reinterpret_cast<const f32x4*>(ep.shift + co);
-    if (ep.relu) {
-      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-    }
-    *reinterpret_cast<f32x4*>(out + (long long)orow * COUT + 4 * c4) = v;
-  }
-}
-
-// ==================================================================== register-tile kernel
-// Default sparse-conv kernel.  One wave (= one 64-thread block, so the hardware dispatcher
-// load-balances the very uneven tiles) owns two 16-row output tiles whose accumulators live in
-// registers for the whole kernel: no LDS accumulation, no barriers, no atomics.  For every
-// kernel offset present in either tile the wave streams the W[k] fragment from L2 into
-// registers (prefetched one offset ahead), gathers the 16 neighbour rows of a tile (prefetched
-// one tile ahead; each load instruction reads one full 64-B segment per row) and issues
-// CQ x NTG v_mfma_f32_16x16x4_f32.  Output channels wider than a register set are processed in
-// column groups.  Summation order per output element is fixed: bitwise reproducible.
-template <int CIN, int COUT>
-struct RtCfg {
-  static constexpr int CQ = CIN / 4;
-  static constexpr int CG0 = 4096 / CIN;                              // cols per W register set
-  static constexpr int CG = COUT < CG0 ? COUT : (CG0 < 16 ? 16 : CG0);
-  static constexpr int NG = COUT / CG;                                 // column groups
-  static constexpr int NTG = CG / 16;                                  // 16-col tiles per group
-  static constexpr int IMG = CIN * COUT;                               // dwords per offset
-  static constexpr int ROWS = 32;                                      // rows per wave (2 tiles)
-};
-
-// channel handled by lane quad q at k-step t: for CIN >= 16 step t = 4i+j reads channel
-// 16i + 4q + j (so load i of the gather covers a contiguous 64-B segment of the row).
-template <int CIN>
-__host__ __device__ constexpr int rt_channel(int q, int t) {
-  return CIN >= 16 ? 16 * (t / 4) + 4 * q + (t % 4) : q * (CIN / 4) + t;
-}
-
-// W (K, CIN, COUT) -> img[k][g][q][t][n][c] = W[k][rt_channel(q,t)][g*CG + c*16 + n]
-template <int CIN, int COUT>
-__global__ void k_pack_weights_rt(const float* __restrict__ W, int K, float* __restrict__ Wp) {
-  using C = RtCfg<CIN, COUT>;
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= K * CIN * COUT) return;
-  int c = e % C::NTG;
-  int n = (e / C::NTG) % 16;
-  int t = (e / (C::NTG * 16)) % C::CQ;
-  int q = (e / (C::NTG * 16 * C::CQ)) % 4;
-  int g = (e / (C::NTG * 16 * C::CQ * 4)) % C::NG;
-  int k = e / (C::NTG * 16 * C::CQ * 4 * C::NG);
-  int ci = rt_channel<CIN>(q, t);
-  int co = g * C::CG + c * 16 + n;
-  Wp[e] = W[((size_t)k * CIN + ci) * COUT + co];
-}
-
-template <int CIN, int COUT>
-__global__ __launch_bounds__(64, 2) void k_sconv_rt(
-    const float* __restrict__ in, const float* __restrict__ Wp, SconvEpilogue ep,
-    const int* __restrict__ nbr, const int* __restrict__ tile_order, int N_out, int K,
-    float* __restrict__ out) {
-  if (ep.n_live) N_out = min(N_out, *ep.n_live);   // device-side row count (capacity launch)
-  using C = RtCfg<CIN, COUT>;
-  constexpr int CQ = C::CQ, NTG = C::NTG, NG = C::NG;
-  __shared__ int s_nbr[2 * 16 * (SC_MAXK + 1)];
-  const int lane = threadIdx.x;
-  const int r = lane & 15, q = lane >> 4;
-  const long long row0 = (long long)blockIdx.x * C::ROWS;
-
-  // ---- neighbour table of my 32 rows -> LDS; per-tile offset masks
-  int my_row = -1;      // lanes 0..31: output row of slot `lane`
-  if (lane < 32 && row0 + lane < N_out) my_row = tile_order ? tile_order[row0 + lane] : (int)(row0 + lane);
-  unsigned m0 = 0, m1 = 0;
-  for (int e = lane; e < 32 * K; e += 64) {
-    int slot = e / K, kk = e - slot * K;
-    int orow = __shfl(my_row, slot, 64);
-    int v = orow >= 0 ? nbr[(long long)orow * K + kk] : -1;
-    s_nbr[slot * (SC_MAXK + 1) + kk] = v;
-    if (v >= 0) { if (slot < 16) m0 |= 1u << kk; else m1 |= 1u << kk; }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    m0 |= __shfl_xor(m0, o, 64);
-    m1 |= __shfl_xor(m1, o, 64);
-  }
-  m0 = __builtin_amdgcn_readfirstlane(m0);
-  m1 = __builtin_amdgcn_readfirstlane(m1);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  const int orow0 = __shfl(my_row, r, 64), orow1 = __shfl(my_row, 16 + r, 64);
-
-  float Wc[CQ][NTG], Wn[CQ][NTG];
-  float Ac[CQ], An[CQ];
-  bool an_valid = false;
-
-#define RT_LOAD_W(KK, GG)                                                                    \
-  {                                                                                          \
-    const float* wp_ = Wp + (size_t)(KK) * C::IMG + (((size_t)(GG) * 4 + q) * CQ * 16 + r) * NTG; \
-    _Pragma("unroll") for (int t_ = 0; t_ < CQ; ++t_) {                                      \
-      if constexpr (NTG == 4) {                                                              \
-        f32x4 v_ = *reinterpret_cast<const f32x4*>(wp_ + t_ * 16 * NTG);                     \
-        Wn[t_][0] = v_[0]; Wn[t_][1] = v_[1]; Wn[t_][2] = v_[2]; Wn[t_][3] = v_[3];          \
-      } else if constexpr (NTG == 2) {                                                       \
-        float2 v_ = *reinterpret_cast<const float2*>(wp_ + t_ * 16 * NTG);                   \
-        Wn[t_][0] = v_.x; Wn[t_][1] = v_.y;                                                  \
-      } else if constexpr (NTG == 8) {                                                       \
-        f32x4 v_ = *reinterpret_cast<const f32x4*>(wp_ + t_ * 16 * NTG);                     \
-        f32x4 u_ = *reinterpret_cast<const f32x4*>(wp_ + t_ * 16 * NTG + 4);                 \
-        Wn[t_][0] = v_[0]; Wn[t_][1] = v_[1]; Wn[t_][2] = v_[2]; Wn[t_][3] = v_[3];          \
-        Wn[t_][4] = u_[0]; Wn[t_][5] = u_[1]; Wn[t_][6] = u_[2]; Wn[t_][7] = u_[3];          \
-      } else {                                                                               \
-        Wn[t_][0] = wp_[t_ * 16 * NTG];                                                      \
-      }                                                                                      \
-    }                                                                                        \
-  }
-  // gather tile S (0/1) at offset KK: lane (r,q) reads 16-B pieces q of the row's 64-B segments
-#define RT_GATHER(KK, S)                                                                     \
-  {                                                                                          \
-    int irow_ = s_nbr[((S) * 16 + r) * (SC_MAXK + 1) + (KK)];                                \
-    const float* ap_ = in + (long long)(irow_ < 0 ? 0 : irow_) * CIN;                        \
-    if constexpr (CIN >= 16) {                                                               \
-      _Pragma("unroll") for (int i_ = 0; i_ < CQ / 4; ++i_) {                                \
-        f32x4 v_ = *reinterpret_cast<const f32x4*>(ap_ + 16 * i_ + 4 * q);                   \
-        An[4 * i_ + 0] = v_[0]; An[4 * i_ + 1] = v_[1]; An[4 * i_ + 2] = v_[2]; An[4 * i_ + 3] = v_[3]; \
-      }                                                                                      \
-    } else {                                                                                 \
-      _Pragma("unroll") for (int i_ = 0; i_ < CQ; ++i_) An[i_] = ap_[q * CQ + i_];           \
-    }                                                                                        \
-    an_valid = irow_ >= 0;   /* zeroing happens at promotion time: a write to An here would  \
-                                force a vmcnt(0) wait right behind the prefetch loads */     \
-  }
-  // next (offset, tile) item after (KK, S) in the order k-major, tile-minor
-#define RT_NEXT(KK, S, REM, NK, NS)                                                          \
-  {                                                                                          \
-    NK = -1; NS = 0;                                                                         \
-    if ((S) == 0 && ((m1 >> (KK)) & 1u)) { NK = (KK); NS = 1; }                              \
-    else if (REM) { NK = __builtin_ctz(REM); NS = ((m0 >> NK) & 1u) ? 0 : 1; }              \
-  }
-
-  const unsigned mu = m0 | m1;
-  for (int g = 0; g < NG; ++g) {
-    f32x4 acc0[NTG], acc1[NTG];
-#pragma unroll
-    for (int ct = 0; ct < NTG; ++ct) { acc0[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    unsigned rem = mu;
-    int k = -1, sidx = 0;
-    if (rem) {
-      k = __builtin_ctz(rem);
-      rem &= rem - 1;
-      sidx = ((m0 >> k) & 1u) ? 0 : 1;
-      RT_LOAD_W(k, g);
-      if (sidx == 0) { RT_GATHER(k, 0); } else { RT_GATHER(k, 1); }
-    }
-    bool new_k = true;
-    while (k >= 0) {
-      if (new_k) {   // promote the prefetched W set, start fetching the next offset's
-#pragma unroll
-        for (int t = 0; t < CQ; ++t)
-#pragma unroll
-          for (int c = 0; c < NTG; ++c) Wc[t][c] = Wn[t][c];
-        if (rem) RT_LOAD_W(__builtin_ctz(rem), g);
-      }
-#pragma unroll
-      for (int i = 0; i < CQ; ++i) Ac[i] = an_valid ? An[i] : 0.f;
-      int nk, ns;
-      RT_NEXT(k, sidx, rem, nk, ns);
-      if (nk >= 0) {
-        if (ns == 0) { RT_GATHER(nk, 0); } else { RT_GATHER(nk, 1); }
-      }
-      // operands swapped: D[i = cout][j = row]; lane (row r, q) gets channels 16ct+4q..+3
-      if (sidx == 0) {
-#pragma unroll
-        for (int t = 0; t < CQ; ++t)
-#pragma unroll
-          for (int ct = 0; ct < NTG; ++ct)
-            acc0[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[t][ct], Ac[t], acc0[ct], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int t = 0; t < CQ; ++t)
-#pragma unroll
-          for (int ct = 0; ct < NTG; ++ct)
-            acc1[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[t][ct], Ac[t], acc1[ct], 0, 0, 0);
-      }
-      new_k = nk != k;
-      if (new_k && nk >= 0) rem &= rem - 1;
-      k = nk; sidx = ns;
-    }
-    // ---- epilogue of this column group straight from registers
-#pragma unroll
-    for (int ct = 0; ct < NTG; ++ct) {
-      const int co = g * C::CG + ct * 16 + 4 * q;
-      f32x4 v0 = acc0[ct], v1 = acc1[ct];
-      if (ep.bias) { f32x4 b = *reinterpret_cast<const f32x4*>(ep.bias + co); v0 += b; v1 += b; }
-      if (ep.scale) { f32x4 b = *reinterpret_cast<const f32x4*>(ep.scale + co); v0 *= b; v1 *= b; }
-      if (ep.shift) { f32x4 b = *reinterpret_cast<const f32x4*>(ep.shift + co); v0 += b; v1 += b; }
-      if (ep.relu) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(v0[j], 0.f); v1[j] = fmaxf(v1[j], 0.f); }
-      }
-      if (orow0 >= 0) *reinterpret_cast<f32x4*>(out + (long long)orow0 * COUT + co) = v0;
-      if (orow1 >= 0) *reinterpret_cast<f32x4*>(out + (long long)orow1 * COUT + co) = v1;
-    }
-  }
-#undef RT_LOAD_W
-#undef RT_GATHER
-#undef RT_NEXT
-}
-
-// ==================================================================== column-owner kernel
-// A block owns TR = 128 output rows and compacts them per kernel offset into pair lists (as
-// the block kernel does), but the work is split by OUTPUT COLUMNS: wave (ct, slab) computes the
-// 16-channel tile ct for every pair of its row slab.  Every wave therefore does the same amount
-// of work, only ever touches its own columns of the LDS accumulator tile (no conflicts, no
-// barriers in the main loop, fixed summation order), and needs just a (Cin x 16) slice of W[k],
-// which it streams from L2 straight into registers one offset ahead.  The price is that the
-// waves of a block gather the same input rows (served by L1/L2).
-template <int CIN, int COUT>
-struct CoCfg {
-  static constexpr int CQ = CIN / 4;
-  static constexpr int NT = COUT / 16;                 // column tiles = column owners
-  static constexpr int NW = NT < 4 ? 4 : NT;           // waves per block
-  static constexpr int RS = NW / NT;                   // row slabs
-  static constexpr int TR = 128;
-  static constexpr int TRS = TR / RS;                  // rows per slab (32, 64 or 128)
-  static constexpr int ACC_LD = COUT + 4;
-  static constexpr int IMG = CIN * COUT;
-  static constexpr size_t lds_bytes = (size_t)TR * ACC_LD * 4 + (size_t)SC_MAXK * TR * 5 +
-                                      (size_t)(TR + RS * 32 + 2 * 32) * 4 + 64;
-};
-
-// W (K, CIN, COUT) -> img[k][ct][q][n][t] = W[k][rt_channel(q,t)][ct*16 + n]
-template <int CIN, int COUT>
-__global__ void k_pack_weights_co(const float* __restrict__ W, int K, float* __restrict__ Wp) {
-  using C = CoCfg<CIN, COUT>;
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= K * CIN * COUT) return;
-  int t = e % C::CQ;
-  int n = (e / C::CQ) % 16;
-  int q = (e / (C::CQ * 16)) % 4;
-  int ct = (e / (C::CQ * 64)) % C::NT;
-  int k = e / (C::CQ * 64 * C::NT);
-  Wp[e] = W[((size_t)k * CIN + rt_channel<CIN>(q, t)) * COUT + ct * 16 + n];
-}
-
-template <int CIN, int COUT>
-__global__ __launch_bounds__(512) void k_sconv_co(const float* __restrict__ in, const float* __restrict__ Wp,
-                           SconvEpilogue ep, const int* __restrict__ nbr,
-                           const int* __restrict__ tile_order, int N_out, int K,
-                           float* __restrict__ out) {
-  if (ep.n_live) N_out = min(N_out, *ep.n_live);   // device-side row count (capacity launch)
-  using C = CoCfg<CIN, COUT>;
-  constexpr int CQ = C::CQ, TR = C::TR, TRS = C::TRS, RS = C::RS, ACC_LD = C::ACC_LD;
-  constexpr int THREADS = C::NW * 64;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_acc = smem;                                          // TR * ACC_LD
-  int* s_pin = reinterpret_cast<int*>(s_acc + TR * ACC_LD);     // SC_MAXK * TR  ([k][slot-in-list])
-  int* s_rows = s_pin + SC_MAXK * TR;                           // TR
-  int* s_cnt = s_rows + TR;                                     // RS * 32
-  int* s_wcnt = s_cnt + RS * 32;                                // 2 * 32 (setup only)
-  unsigned char* s_pslot = reinterpret_cast<unsigned char*>(s_wcnt + 64);   // SC_MAXK * TR
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int row0 = blockIdx.x * TR;
+  const int grp = wave / T::WPG;
+  const int tile0 = (wave % T::WPG) * T::TPW;
 
-  // ---- setup (threads < TR own one row slot each): rows, neighbour lists, per-slab compaction.
-  // list of (slab, k) lives at s_pin[k * TR + slab * TRS ...]
+  // ---- tile rows, zero accumulators, rule compaction (as in k_sconv_mfma)
   int my_row = -1;
   if (tid < TR) {
     int p = row0 + tid;
@@ -788,20 +538,15 @@ __global__ __launch_bounds__(512) void k_sconv_co(const float* __restrict__ in, 
   for (int i = tid; i < TR * ACC_LD / 4; i += THREADS)
     reinterpret_cast<f32x4*>(s_acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   int nb[SC_MAXK];
-  const int slab = tid / TRS;                       // my slab (setup threads)
-  // lanes of my wave that belong to my slab
-  const unsigned long long slab_lanes =
-      TRS >= 64 ? ~0ull : (((1ull << TRS) - 1ull) << ((lane / TRS) * TRS));
   if (tid < TR) {
+    const int* np = nbr + (long long)(my_row < 0 ? 0 : my_row) * K;
 #pragma unroll
-    for (int k = 0; k < SC_MAXK; ++k)
-      nb[k] = (k < K && my_row >= 0) ? nbr[(long long)my_row * K + k] : -1;
-    if (TRS > 64) {
+    for (int k = 0; k < SC_MAXK; ++k) nb[k] = np[k < K ? k : K - 1];   // branch-free: 27 loads in flight
 #pragma unroll
-      for (int k = 0; k < SC_MAXK; ++k) {
-        unsigned long long b = __ballot(nb[k] >= 0);
-        if (lane == 0) s_wcnt[wave * 32 + k] = __popcll(b);
-      }
+    for (int k = 0; k < SC_MAXK; ++k) {
+      if (k >= K || my_row < 0) nb[k] = -1;
+      unsigned long long b = __ballot(nb[k] >= 0);
+      if (lane == 0) s_wcnt[wave * 32 + k] = __popcll(b);
     }
   }
   __syncthreads();
@@ -809,311 +554,154 @@ __global__ __launch_bounds__(512) void k_sconv_co(const float* __restrict__ in, 
 #pragma unroll
     for (int k = 0; k < SC_MAXK; ++k) {
       const bool v = nb[k] >= 0;
-      unsigned long long b = __ballot(v) & slab_lanes;
-      int base = (TRS > 64 && (wave & 1)) ? s_wcnt[(wave - 1) * 32 + k] : 0;
+      unsigned long long b = __ballot(v);
+      int base = 0;
+#pragma unroll
+      for (int w = 0; w < LW; ++w) base += (w < wave) ? s_wcnt[w * 32 + k] : 0;
       if (v) {
-        int pos = k * TR + slab * TRS + base + __popcll(b & ((1ull << lane) - 1ull));
+        int pos = k * TR + base + __popcll(b & ((1ull << lane) - 1ull));
         s_pin[pos] = nb[k];
         s_pslot[pos] = (unsigned char)tid;
       }
-      // the last lane group of a slab publishes the slab's count
-      const bool closer = TRS > 64 ? ((wave & 1) && lane == 0) : ((lane % (TRS >= 64 ? 64 : TRS)) == 0);
-      if (closer) s_cnt[slab * 32 + k] = base + __popcll(b);
+      if (wave == LW - 1 && lane == 0) s_cnt[k] = base + __popcll(b);
     }
   }
   __syncthreads();
-
-  // ---- main loop: wave (ct, wslab) walks every offset of its slab, no barriers
-  const int ct = wave % C::NT, wslab = wave / C::NT;
   unsigned mask = 0;
 #pragma unroll
   for (int k = 0; k < SC_MAXK; ++k)
-    if (k < K && s_cnt[wslab * 32 + k] > 0) mask |= 1u << k;
+    if (k < K && s_cnt[k] > 0) mask |= 1u << k;
   mask = __builtin_amdgcn_readfirstlane(mask);
-  const int* pin = s_pin + wslab * TRS;
-  const unsigned char* pslot = s_pslot + wslab * TRS;
 
-  // Software pipeline: a wave has only ~16 MFMAs (512 cycles) of work per chunk, far less than
-  // one L2 round trip, so 4 chunk gathers (ring A0..A3) and 2 weight slices (W1, W2) are kept in
-  // flight ahead of the chunk being multiplied.
-  float Wc[CQ], W1[CQ], W2[CQ], Ac[CQ];
-  float A0[CQ], A1[CQ], A2[CQ], A3[CQ];
-  bool v0 = false, v1 = false, v2 = false, v3 = false;
-#define CO_LOAD_W(KK, WDST)                                                                  \
-  {                                                                                          \
-    const float* wp_ = Wp + (size_t)(KK) * C::IMG + (((size_t)ct * 4 + q) * 16 + r) * CQ;    \
-    if constexpr (CQ % 4 == 0) {                                                             \
-      _Pragma("unroll") for (int i_ = 0; i_ < CQ / 4; ++i_) {                                \
-        f32x4 v_ = reinterpret_cast<const f32x4*>(wp_)[i_];                                  \
-        WDST[4 * i_ + 0] = v_[0]; WDST[4 * i_ + 1] = v_[1]; WDST[4 * i_ + 2] = v_[2]; WDST[4 * i_ + 3] = v_[3]; \
-      }                                                                                      \
-    } else {                                                                                 \
-      _Pragma("unroll") for (int i_ = 0; i_ < CQ; ++i_) WDST[i_] = wp_[i_];                  \
-    }                                                                                        \
+  // ---- staging registers: next weight image and next panel of gathered rows
+  f32x4 wreg[T::SPT];
+  f32x4 areg[T::GPT];
+#define GM_LOAD_W(KK)                                                                       \
+  {                                                                                         \
+    const f32x4* src_ = reinterpret_cast<const f32x4*>(Wp + (size_t)(KK) * S::IMG);         \
+    _Pragma("unroll") for (int i_ = 0; i_ < T::SPT; ++i_) {                                 \
+      int e_ = tid + i_ * THREADS;                                                          \
+      wreg[i_] = src_[e_ < T::W_F4 ? e_ : T::W_F4 - 1];                                     \
+    }                                                                                       \
   }
-#define CO_GATHER(KK, CC, CNT, ADST, VDST)                                                   \
-  {                                                                                          \
-    int p_ = (CC) * 16 + r;                                                                  \
-    int irow_ = (p_ < (CNT)) ? pin[(KK) * TR + p_] : -1;                                     \
-    const float* ap_ = in + (long long)(irow_ < 0 ? 0 : irow_) * CIN;                        \
-    if constexpr (CIN >= 16) {                                                               \
-      _Pragma("unroll") for (int i_ = 0; i_ < CQ / 4; ++i_) {                                \
-        f32x4 v_ = *reinterpret_cast<const f32x4*>(ap_ + 16 * i_ + 4 * q);                   \
-        ADST[4 * i_ + 0] = v_[0]; ADST[4 * i_ + 1] = v_[1]; ADST[4 * i_ + 2] = v_[2]; ADST[4 * i_ + 3] = v_[3]; \
-      }                                                                                      \
-    } else {                                                                                 \
-      _Pragma("unroll") for (int i_ = 0; i_ < CQ; ++i_) ADST[i_] = ap_[q * CQ + i_];         \
-    }                                                                                        \
-    VDST = irow_ >= 0;                                                                       \
+#define GM_STORE_W()                                                                        \
+  {                                                                                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < T::SPT; ++i_) {                                 \
+      int e_ = tid + i_ * THREADS;                                                          \
+      if (T::W_F4 % THREADS == 0 || e_ < T::W_F4) reinterpret_cast<f32x4*>(s_w)[e_] = wreg[i_]; \
+    }                                                                                       \
   }
-  // cursors over the (offset, chunk) items of this slab: P = prefetch, X = compute
-  struct Cur { unsigned rem; int k, c, cnt; };
-  auto cur_init = [&](Cur& u) {
-    u.rem = mask; u.k = -1; u.c = 0; u.cnt = 0;
-    if (u.rem) { u.k = __builtin_ctz(u.rem); u.rem &= u.rem - 1; u.cnt = s_cnt[wslab * 32 + u.k]; }
-  };
-  auto cur_next = [&](Cur& u) {
-    if (++u.c * 16 >= u.cnt) {
-      u.c = 0;
-      if (u.rem) { u.k = __builtin_ctz(u.rem); u.rem &= u.rem - 1; u.cnt = s_cnt[wslab * 32 + u.k]; }
-      else u.k = -1;
+#define GM_LOAD_A(KK, PB, CNT)                                                              \
+  {                                                                                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < T::GPT; ++i_) {                                 \
+      int e_ = tid + i_ * THREADS;                                                          \
+      int pair_ = e_ / T::SEGS, seg_ = e_ - pair_ * T::SEGS;                                \
+      int p_ = (PB) + pair_;                                                                \
+      int irow_ = 0;                                                                        \
+      if (p_ < (CNT) && pair_ < T::AP) irow_ = s_pin[(KK) * TR + p_];                       \
+      areg[i_] = *reinterpret_cast<const f32x4*>(in + (long long)irow_ * CIN + seg_ * 4);   \
+    }                                                                                       \
+  }
+#define GM_STORE_A()                                                                        \
+  {                                                                                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < T::GPT; ++i_) {                                 \
+      int e_ = tid + i_ * THREADS;                                                          \
+      int pair_ = e_ / T::SEGS, seg_ = e_ - pair_ * T::SEGS;                                \
+      if (T::A_SEG % THREADS == 0 || e_ < T::A_SEG)                                         \
+        *reinterpret_cast<f32x4*>(s_a + pair_ * T::A_LD + seg_ * 4) = areg[i_];             \
+    }                                                                                       \
+  }
+
+  if (mask) {
+    int k = __builtin_ctz(mask);
+    unsigned rem = mask & (mask - 1);
+    int cnt = s_cnt[k], pb = 0;
+    GM_LOAD_W(k);
+    GM_LOAD_A(k, 0, cnt);
+    GM_STORE_W();
+    GM_STORE_A();
+    __syncthreads();
+    while (true) {
+      // ---- what comes next: another panel of this offset, or the first panel of the next one
+      bool has_next = true, new_w = false;
+      int kn = k, pbn = pb + T::AP, cntn = cnt;
+      if (pbn >= cnt) {
+        if (rem) {
+          kn = __builtin_ctz(rem);
+          rem &= rem - 1;
+          pbn = 0;
+          cntn = s_cnt[kn];
+          new_w = true;
+        } else {
+          has_next = false;
+        }
+      }
+      if (has_next) {
+        GM_LOAD_A(kn, pbn, cntn);
+        if (new_w) GM_LOAD_W(kn);
+      }
+      // ---- multiply this wave's chunk of the current panel by its column tiles
+      const int pbase = pb + grp * 16;
+      if (pbase < cnt) {   // wave-uniform
+        const float* arow = s_a + (grp * 16 + r) * T::A_LD + q * CQ;
+        float Am[CQ];
+        if constexpr (CQ % 4 == 0) {
+#pragma unroll
+          for (int i = 0; i < CQ / 4; ++i) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(arow + 4 * i);
+            Am[4 * i + 0] = v[0]; Am[4 * i + 1] = v[1]; Am[4 * i + 2] = v[2]; Am[4 * i + 3] = v[3];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < CQ; ++i) Am[i] = arow[i];
+        }
+        f32x4 acc[T::TPW];
+#pragma unroll
+        for (int tt = 0; tt < T::TPW; ++tt) {
+          acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const float* wp = s_w + S::idx(tile0 + tt, q, 0, r);
+          if constexpr (CQ % 4 == 0) {
+#pragma unroll
+            for (int t4 = 0; t4 < CQ / 4; ++t4) {
+              f32x4 wv = *reinterpret_cast<const f32x4*>(wp + 64 * t4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e], Am[4 * t4 + e], acc[tt], 0, 0, 0);
+            }
+          } else {
+#pragma unroll
+            for (int t = 0; t < CQ; ++t)
+              acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t], Am[t], acc[tt], 0, 0, 0);
+          }
+        }
+        const int p = pbase + r;
+        if (p < cnt) {
+          float* dst = s_acc + (int)s_pslot[k * TR + p] * ACC_LD + tile0 * 16 + 4 * q;
+#pragma unroll
+          for (int tt = 0; tt < T::TPW; ++tt) {
+            f32x4 v = *reinterpret_cast<f32x4*>(dst + tt * 16);
+            v += acc[tt];
+            *reinterpret_cast<f32x4*>(dst + tt * 16) = v;
+          }
+        }
+      }
+      if (!has_next) break;
+      __syncthreads();   // everyone is done reading the panel and the weight image
+      GM_STORE_A();
+      if (new_w) GM_STORE_W();
+      __syncthreads();
+      k = kn; pb = pbn; cnt = cntn;
     }
-  };
-  Cur P, X;
-  cur_init(P);
-  cur_init(X);
-  if (P.k >= 0) { CO_GATHER(P.k, P.c, P.cnt, A0, v0); cur_next(P); }
-  if (P.k >= 0) { CO_GATHER(P.k, P.c, P.cnt, A1, v1); cur_next(P); }
-  if (P.k >= 0) { CO_GATHER(P.k, P.c, P.cnt, A2, v2); cur_next(P); }
-  if (P.k >= 0) { CO_GATHER(P.k, P.c, P.cnt, A3, v3); cur_next(P); }
-  // weight slices of the first two offsets
-  {
-    unsigned m2 = mask;
-    if (m2) { CO_LOAD_W(__builtin_ctz(m2), W1); m2 &= m2 - 1; }
-    if (m2) { CO_LOAD_W(__builtin_ctz(m2), W2); }
   }
-  int curk = -1;
-#define CO_STEP(ABUF, VBUF)                                                                  \
-  if (X.k >= 0) {                                                                            \
-    if (X.k != curk) {   /* new offset: rotate the weight slices, fetch the one 2 offsets ahead */ \
-      curk = X.k;                                                                            \
-      _Pragma("unroll") for (int t_ = 0; t_ < CQ; ++t_) { Wc[t_] = W1[t_]; W1[t_] = W2[t_]; } \
-      unsigned m2_ = X.rem;                                                                  \
-      if (m2_) { m2_ &= m2_ - 1; if (m2_) CO_LOAD_W(__builtin_ctz(m2_), W2); }               \
-    }                                                                                        \
-    _Pragma("unroll") for (int i_ = 0; i_ < CQ; ++i_) Ac[i_] = VBUF ? ABUF[i_] : 0.f;        \
-    const int xk_ = X.k, xc_ = X.c, xcnt_ = X.cnt;                                           \
-    cur_next(X);                                                                             \
-    if (P.k >= 0) { CO_GATHER(P.k, P.c, P.cnt, ABUF, VBUF); cur_next(P); }                   \
-    f32x4 acc0{0.f, 0.f, 0.f, 0.f}, acc1{0.f, 0.f, 0.f, 0.f};                                \
-    _Pragma("unroll") for (int t_ = 0; t_ < CQ; t_ += 2) {                                   \
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[t_], Ac[t_], acc0, 0, 0, 0);            \
-      if (t_ + 1 < CQ) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[t_ + 1], Ac[t_ + 1], acc1, 0, 0, 0); \
-    }                                                                                        \
-    acc0 += acc1;                                                                            \
-    const int p_out_ = xc_ * 16 + r;                                                         \
-    if (p_out_ < xcnt_) {                                                                    \
-      float* dst_ = s_acc + (int)pslot[xk_ * TR + p_out_] * ACC_LD + ct * 16 + 4 * q;        \
-      f32x4 o_ = *reinterpret_cast<f32x4*>(dst_);                                            \
-      o_ += acc0;                                                                            \
-      *reinterpret_cast<f32x4*>(dst_) = o_;                                                  \
-    }                                                                                        \
-  }
-  while (X.k >= 0) {
-    CO_STEP(A0, v0)
-    CO_STEP(A1, v1)
-    CO_STEP(A2, v2)
-    CO_STEP(A3, v3)
-  }
-#undef CO_STEP
-#undef CO_LOAD_W
-#undef CO_GATHER
+#undef GM_LOAD_W
+#undef GM_STORE_W
+#undef GM_LOAD_A
+#undef GM_STORE_A
   __syncthreads();
 
   // ---- epilogue: coalesced row stores with the fused pointwise tail
   constexpr int C4 = COUT / 4;
   for (int i = tid; i < TR * C4; i += THREADS) {
-    int rr = i / C4, c4 = i - rr * C4;
-    int orow = s_rows[rr];
-    if (orow < 0) continue;
-    f32x4 v = *reinterpret_cast<const f32x4*>(s_acc + rr * ACC_LD + 4 * c4);
-    const int co = 4 * c4;
-    if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + co);
-    if (ep.scale) v *= *reinterpret_cast<const f32x4*>(ep.scale + co);
-    if (ep.shift) v += *reinterpret_cast<const f32x4*>(ep.shift + co);
-    if (ep.relu) {
-      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-    }
-    *reinterpret_cast<f32x4*>(out + (long long)orow * COUT + 4 * c4) = v;
-  }
-}
-
-// ==================================================================== wave-private kernel, deep pipeline
-// k_sconv_wq: every wave owns TRW = 48 consecutive output rows (compaction lists, fp32
-// accumulator tile in LDS, epilogue) and never synchronises with another wave.  Per (offset,
-// 16-pair chunk) item it issues CQ x NTG MFMAs against the full W[k] fragment held in registers.
-// Latency hiding is explicit: the gathers of the next 4 items are always in flight (register
-// ring A0..A3, filled straight by the loads -- absent pairs read a zero row, so there is no
-// select or copy between load and MFMA) and W of the next offset streams into the second
-// register set while the current one multiplies (the two sets swap roles, no copy).
-template <int CIN, int COUT>
-__global__ __launch_bounds__(256, 2) void k_sconv_wq(
-    const float* __restrict__ in, const float* __restrict__ Wp, SconvEpilogue ep,
-    const int* __restrict__ nbr, const int* __restrict__ tile_order,
-    const float* __restrict__ zero_row, int N_out, int K, float* __restrict__ out) {
-  if (ep.n_live) N_out = min(N_out, *ep.n_live);   // device-side row count (capacity launch)
-  using C = RtCfg<CIN, COUT>;
-  using L = WpCfg<CIN, COUT>;   // LDS layout of the wave-private tile
-  constexpr int TRW = L::TRW, ACC_LD = L::ACC_LD, CQ = C::CQ, NTG = C::NTG, NG = C::NG;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  float* s_acc = smem + (size_t)wave * L::WAVE_LDS_DW;                 // TRW * ACC_LD
-  int* s_pin = reinterpret_cast<int*>(s_acc + TRW * ACC_LD);           // SC_MAXK * TRW
-  int* s_cnt = s_pin + SC_MAXK * TRW;                                  // 32
-  int* s_rows = s_cnt + 32;                                            // TRW
-  unsigned char* s_pslot = reinterpret_cast<unsigned char*>(s_rows + TRW);
-  const long long row0 = ((long long)blockIdx.x * L::NWB + wave) * TRW;
-  if (row0 >= N_out) return;
-
-  int my_row = -1;
-  if (lane < TRW && row0 + lane < N_out) my_row = tile_order ? tile_order[row0 + lane] : (int)(row0 + lane);
-  if (lane < TRW) s_rows[lane] = my_row;
-  for (int i = lane; i < TRW * ACC_LD / 4; i += 64)
-    reinterpret_cast<f32x4*>(s_acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  unsigned mask = 0;
-  int nbv[SC_MAXK];     // all 27 loads in flight at once
-#pragma unroll
-  for (int k = 0; k < SC_MAXK; ++k)
-    nbv[k] = (k < K && my_row >= 0) ? nbr[(long long)my_row * K + k] : -1;
-#pragma unroll
-  for (int k = 0; k < SC_MAXK; ++k) {
-    const int nb = nbv[k];
-    unsigned long long b = __ballot(nb >= 0);
-    if (nb >= 0) {
-      int pos = k * TRW + __popcll(b & ((1ull << lane) - 1ull));
-      s_pin[pos] = nb;
-      s_pslot[pos] = (unsigned char)lane;
-    }
-    int n = __popcll(b);
-    if (lane == 0) s_cnt[k] = n;
-    if (n) mask |= 1u << k;
-  }
-  mask = __builtin_amdgcn_readfirstlane(mask);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-
-  constexpr bool DEEP = CQ * NTG <= 32;   // ring of 4 when registers allow, else 2
-  float Wa[CQ][NTG], Wb[CQ][NTG];
-  float A0[CQ], A1[CQ], A2[DEEP ? CQ : 1], A3[DEEP ? CQ : 1];
-
-#define WQ_LOAD_W(KK, GG, WDST)                                                              \
-  {                                                                                          \
-    const float* wp_ = Wp + (size_t)(KK) * C::IMG + (((size_t)(GG) * 4 + q) * CQ * 16 + r) * NTG; \
-    _Pragma("unroll") for (int t_ = 0; t_ < CQ; ++t_) {                                      \
-      if constexpr (NTG == 4) {                                                              \
-        f32x4 v_ = *reinterpret_cast<const f32x4*>(wp_ + t_ * 16 * NTG);                     \
-        WDST[t_][0] = v_[0]; WDST[t_][1] = v_[1]; WDST[t_][2] = v_[2]; WDST[t_][3] = v_[3];  \
-      } else if constexpr (NTG == 2) {                                                       \
-        float2 v_ = *reinterpret_cast<const float2*>(wp_ + t_ * 16 * NTG);                   \
-        WDST[t_][0] = v_.x; WDST[t_][1] = v_.y;                                              \
-      } else if constexpr (NTG == 8) {                                                       \
-        f32x4 v_ = *reinterpret_cast<const f32x4*>(wp_ + t_ * 16 * NTG);                     \
-        f32x4 u_ = *reinterpret_cast<const f32x4*>(wp_ + t_ * 16 * NTG + 4);                 \
-        WDST[t_][0] = v_[0]; WDST[t_][1] = v_[1]; WDST[t_][2] = v_[2]; WDST[t_][3] = v_[3];  \
-        WDST[t_][4] = u_[0]; WDST[t_][5] = u_[1]; WDST[t_][6] = u_[2]; WDST[t_][7] = u_[3];  \
-      } else {                                                                               \
-        WDST[t_][0] = wp_[t_ * 16 * NTG];                                                    \
-      }                                                                                      \
-    }                                                                                        \
-  }
-#define WQ_GATHER(KK, CC, CNT, ADST)                                                         \
-  {                                                                                          \
-    int p_ = (CC) * 16 + r;                                                                  \
-    const float* ap_ = zero_row;                                                             \
-    if (p_ < (CNT)) ap_ = in + (long long)s_pin[(KK) * TRW + p_] * CIN;                      \
-    if constexpr (CIN >= 16) {                                                               \
-      _Pragma("unroll") for (int i_ = 0; i_ < CQ / 4; ++i_) {                                \
-        f32x4 v_ = *reinterpret_cast<const f32x4*>(ap_ + 16 * i_ + 4 * q);                   \
-        ADST[4 * i_ + 0] = v_[0]; ADST[4 * i_ + 1] = v_[1]; ADST[4 * i_ + 2] = v_[2]; ADST[4 * i_ + 3] = v_[3]; \
-      }                                                                                      \
-    } else {                                                                                 \
-      _Pragma("unroll") for (int i_ = 0; i_ < CQ; ++i_) ADST[i_] = ap_[q * CQ + i_];         \
-    }                                                                                        \
-  }
-  struct Cur { unsigned rem; int k, c, cnt; };
-#define WQ_CUR_INIT(U)                                                                       \
-  { U.rem = mask; U.k = -1; U.c = 0; U.cnt = 0;                                              \
-    if (U.rem) { U.k = __builtin_ctz(U.rem); U.rem &= U.rem - 1; U.cnt = s_cnt[U.k]; } }
-#define WQ_CUR_NEXT(U)                                                                       \
-  { if (++U.c * 16 >= U.cnt) { U.c = 0;                                                      \
-      if (U.rem) { U.k = __builtin_ctz(U.rem); U.rem &= U.rem - 1; U.cnt = s_cnt[U.k]; }     \
-      else U.k = -1; } }
-  // one item: (new offset? swap W sets and prefetch the following offset's W), multiply,
-  // refill this ring slot with the item 4 ahead, add into the LDS tile
-#define WQ_MULT(ABUF, WSET)                                                                  \
-  _Pragma("unroll") for (int t_ = 0; t_ < CQ; ++t_)                                          \
-    _Pragma("unroll") for (int c_ = 0; c_ < NTG; ++c_)                                       \
-      acc[c_] = __builtin_amdgcn_mfma_f32_16x16x4f32(WSET[t_][c_], ABUF[t_], acc[c_], 0, 0, 0);
-#define WQ_STEP(ABUF)                                                                        \
-  if (X.k >= 0) {                                                                            \
-    if (X.k != curk) {                                                                       \
-      curk = X.k;                                                                            \
-      wpar ^= 1;                                                                             \
-      if (X.rem) {                                                                           \
-        if (wpar) { WQ_LOAD_W(__builtin_ctz(X.rem), g, Wa); } else { WQ_LOAD_W(__builtin_ctz(X.rem), g, Wb); } \
-      }                                                                                      \
-    }                                                                                        \
-    f32x4 acc[NTG];                                                                          \
-    _Pragma("unroll") for (int c_ = 0; c_ < NTG; ++c_) acc[c_] = f32x4{0.f, 0.f, 0.f, 0.f};  \
-    if (wpar) { WQ_MULT(ABUF, Wb) } else { WQ_MULT(ABUF, Wa) }                               \
-    const int xk_ = X.k, xc_ = X.c, xcnt_ = X.cnt;                                           \
-    WQ_CUR_NEXT(X);                                                                          \
-    if (P.k >= 0) { WQ_GATHER(P.k, P.c, P.cnt, ABUF); WQ_CUR_NEXT(P); }                      \
-    const int p_out_ = xc_ * 16 + r;                                                         \
-    if (p_out_ < xcnt_) {                                                                    \
-      float* dst_ = s_acc + (int)s_pslot[xk_ * TRW + p_out_] * ACC_LD + g * C::CG + 4 * q;   \
-      _Pragma("unroll") for (int c_ = 0; c_ < NTG; ++c_) {                                   \
-        f32x4 o_ = *reinterpret_cast<f32x4*>(dst_ + c_ * 16);                                \
-        o_ += acc[c_];                                                                       \
-        *reinterpret_cast<f32x4*>(dst_ + c_ * 16) = o_;                                      \
-      }                                                                                      \
-    }                                                                                        \
-  }
-
-  for (int g = 0; g < NG; ++g) {
-    Cur P, X;
-    WQ_CUR_INIT(P);
-    WQ_CUR_INIT(X);
-    if (P.k >= 0) { WQ_GATHER(P.k, P.c, P.cnt, A0); WQ_CUR_NEXT(P); }
-    if (P.k >= 0) { WQ_GATHER(P.k, P.c, P.cnt, A1); WQ_CUR_NEXT(P); }
-    if constexpr (DEEP) {
-      if (P.k >= 0) { WQ_GATHER(P.k, P.c, P.cnt, A2); WQ_CUR_NEXT(P); }
-      if (P.k >= 0) { WQ_GATHER(P.k, P.c, P.cnt, A3); WQ_CUR_NEXT(P); }
-    }
-    // wpar == 1 means "current W is in Wb"; the first offset goes to Wb (wpar flips 0 -> 1)
-    int wpar = 0, curk = -1;
-    if (X.k >= 0) { WQ_LOAD_W(X.k, g, Wb); }
-    while (X.k >= 0) {
-      WQ_STEP(A0)
-      WQ_STEP(A1)
-      if constexpr (DEEP) {
-        WQ_STEP(A2)
-        WQ_STEP(A3)
-      }
-    }
-  }
-#undef WQ_STEP
-#undef WQ_MULT
-#undef WQ_CUR_NEXT
-#undef WQ_CUR_INIT
-#undef WQ_GATHER
-#undef WQ_LOAD_W
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-
-  constexpr int C4 = COUT / 4;
-  for (int i = lane; i < TRW * C4; i += 64) {
     int rr = i / C4, c4 = i - rr * C4;
     int orow = s_rows[rr];
     if (orow < 0) continue;
@@ -1161,7 +749,7 @@ extern "C" int glx_sconv_forward_generic(const float* in, int N_in, const float*
   GLX_REQUIRE(in && W && nbr && out && K > 0 && Cin > 0 && Cout > 0,
               "glx_sconv_forward_generic: bad arguments");
   long long total = (long long)N_out * Cout;
-  SconvEpilogue ep{bias, nullptr, nullptr, 0, nullptr};
+  SconvEpilogue ep{bias, nullptr, nullptr, 0, nullptr, nullptr};
   hipLaunchKernelGGL(k_sconv_generic, dim3(glx_divup(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, in, W, ep, nbr, N_out, K, Cin, Cout, out);
   GLX_LAUNCH_CHECK();
@@ -1175,10 +763,8 @@ static bool mfma_supported(int Cin, int Cout, int K) {
 }
 
 template <int CIN, int COUT>
-static size_t img_bytes() {   // block-kernel image + wave-private-kernel image, per offset
-  return (size_t)(SconvCfg<CIN, COUT>::IMG + WpCfg<CIN, COUT>::IMG + RtCfg<CIN, COUT>::IMG +
-                  CoCfg<CIN, COUT>::IMG) *
-         sizeof(float);
+static size_t img_bytes() {   // both LDS images (whole-chunk and column-split layout) of one offset
+  return (size_t)(SconvCfg<CIN, COUT>::IMG + SconvSplitCfg<CIN, COUT>::IMG) * sizeof(float);
 }
 
 template <class F>
@@ -1221,17 +807,14 @@ extern "C" int glx_profile_next_sconv(void* start_event, void* stop_event) {
 template <int CI, int CO>
 static int pack_weights(const float* W, int K, float* Wp, hipStream_t st) {
   using C = SconvCfg<CI, CO>;
-  size_t pbytes = (size_t)K * C::IMG * sizeof(float);
-  if (C::QPAD) GLX_HIP(hipMemsetAsync(Wp, 0, pbytes, st));
+  using S = SconvSplitCfg<CI, CO>;
+  size_t pbytes = (size_t)K * (C::IMG + S::IMG) * sizeof(float);
+  GLX_HIP(hipMemsetAsync(Wp, 0, pbytes, st));   // padding dwords of both images
   int nel = K * CI * CO;
   hipLaunchKernelGGL((k_pack_weights<CI, CO>), dim3(glx_divup(nel, 256)), dim3(256), 0, st, W, K,
                      Wp);
-  hipLaunchKernelGGL((k_pack_weights_wp<CI, CO>), dim3(glx_divup(nel, 256)), dim3(256), 0, st, W,
-                     K, Wp + (size_t)K * C::IMG);
-  hipLaunchKernelGGL((k_pack_weights_rt<CI, CO>), dim3(glx_divup(nel, 256)), dim3(256), 0, st, W,
-                     K, Wp + (size_t)K * (C::IMG + WpCfg<CI, CO>::IMG));
-  hipLaunchKernelGGL((k_pack_weights_co<CI, CO>), dim3(glx_divup(nel, 256)), dim3(256), 0, st, W,
-                     K, Wp + (size_t)K * (C::IMG + WpCfg<CI, CO>::IMG + RtCfg<CI, CO>::IMG));
+  hipLaunchKernelGGL((k_pack_weights_split<CI, CO>), dim3(glx_divup(nel, 256)), dim3(256), 0, st,
+                     W, K, Wp + (size_t)K * C::IMG);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
@@ -1242,23 +825,32 @@ static int env_variant() {
   return e ? atoi(e) : -1;
 }
 static int g_sconv_variant = env_variant();
+// profiling aid (tools/sconv_tiles.py): per-block timeline of the block kernel
+static long long* g_sconv_trace = nullptr;
+extern "C" int glx_sconv_set_trace(void* trace) {
+  g_sconv_trace = (long long*)trace;
+  return GLX_OK;
+}
 extern "C" int glx_sconv_set_variant(int v) {
   g_sconv_variant = v;
   return GLX_OK;
 }
 
-template <int CI, int CO, int TR, int NW, int NBUF>
+template <int CI, int CO, int TR, int NW, int NBUF, int WPG_REQ = 1>
 static int launch_tile(const float* in, const float* Wp, const SconvEpilogue& ep,
                        const int32_t* nbr, const int32_t* tile_order, int N_out, int K, float* out,
                        hipStream_t st) {
-  using T = SconvTile<CI, CO, TR, NW, NBUF>;
+  // the column split cannot exceed the number of 16-column tiles
+  constexpr int WPG = WPG_REQ < CO / 16 ? WPG_REQ : CO / 16;
+  using T = SconvTile<CI, CO, TR, NW, NBUF, WPG>;
+  if (WPG > 1) Wp += (size_t)K * SconvCfg<CI, CO>::IMG;   // second image of the packed buffer
   if constexpr (T::lds_bytes > 160 * 1024) {
     glx_set_error("sparse conv tile (%d,%d,TR=%d,NW=%d,NBUF=%d) needs %zu B of LDS", CI, CO, TR, NW,
                   NBUF, (size_t)T::lds_bytes);
     return GLX_EINVAL;
   } else {
     static bool attr_set = false;   // one per instantiation
-    auto kern = k_sconv_mfma<CI, CO, TR, NW, NBUF>;
+    auto kern = k_sconv_mfma<CI, CO, TR, NW, NBUF, WPG>;
     const size_t lds = T::lds_bytes;
     if (!attr_set) {
       GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1266,7 +858,18 @@ static int launch_tile(const float* in, const float* Wp, const SconvEpilogue& ep
       attr_set = true;
     }
     int nblocks = glx_divup(N_out, TR);
-    if (g_prof_start && g_prof_stop) {
+    if (ep.trace) {   // profiling build of the same kernel, (4 + 8*NW) int64 per block
+      if constexpr (NBUF == 1 && ((TR == 64 && NW == 4) || (TR == 64 && NW == 8 && WPG_REQ == 4))) {
+        auto tkern = k_sconv_mfma<CI, CO, TR, NW, NBUF, WPG, true>;
+        GLX_HIP(hipFuncSetAttribute((const void*)tkern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        hipLaunchKernelGGL(tkern, dim3(nblocks), dim3(T::THREADS), lds, st, in, Wp, ep, nbr,
+                           tile_order, N_out, K, out);
+      } else {
+        glx_set_error("sparse conv trace build exists for the default tiles only");
+        return GLX_EINVAL;
+      }
+    } else if (g_prof_start && g_prof_stop) {
       hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(T::THREADS), lds, st, g_prof_start,
                             g_prof_stop, 0, in, Wp, ep, nbr, tile_order, N_out, K, out);
       g_prof_start = g_prof_stop = nullptr;
@@ -1279,10 +882,44 @@ static int launch_tile(const float* in, const float* Wp, const SconvEpilogue& ep
   }
 }
 
+template <int CI, int CO, int TR, int NW, int WPG_REQ>
+static int launch_gemm(const float* in, const float* Wp, const SconvEpilogue& ep,
+                       const int32_t* nbr, const int32_t* tile_order, int N_out, int K, float* out,
+                       hipStream_t st) {
+  constexpr int WPG = WPG_REQ < CO / 16 ? WPG_REQ : CO / 16;
+  using T = SconvGemm<CI, CO, TR, NW, WPG>;
+  if constexpr (T::lds_bytes > 160 * 1024 || CI < 4) {
+    glx_set_error("sparse conv GEMM tile (%d,%d,TR=%d,NW=%d) needs %zu B of LDS", CI, CO, TR, NW,
+                  (size_t)T::lds_bytes);
+    return GLX_EINVAL;
+  } else {
+    static bool attr_set = false;
+    auto kern = k_sconv_gemm<CI, CO, TR, NW, WPG>;
+    const size_t lds = T::lds_bytes;
+    if (!attr_set) {
+      GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+      attr_set = true;
+    }
+    const float* Wsplit = Wp + (size_t)K * SconvCfg<CI, CO>::IMG;   // second image of the packed buffer
+    int nblocks = glx_divup(N_out, TR);
+    if (g_prof_start && g_prof_stop) {
+      hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(T::THREADS), lds, st, g_prof_start,
+                            g_prof_stop, 0, in, Wsplit, ep, nbr, tile_order, N_out, K, out);
+      g_prof_start = g_prof_stop = nullptr;
+    } else {
+      hipLaunchKernelGGL(kern, dim3(nblocks), dim3(T::THREADS), lds, st, in, Wsplit, ep, nbr,
+                         tile_order, N_out, K, out);
+    }
+    GLX_LAUNCH_CHECK();
+    return GLX_OK;
+  }
+}
+
 template <int CI, int CO>
 static int launch_mfma(const float* in, const float* Wp, const SconvEpilogue& ep,
                        const int32_t* nbr, const int32_t* tile_order, int N_out, int K, float* out,
-                       const float* zero_row, hipStream_t st) {
+                       hipStream_t st) {
 #define SC_GO(TR, NW, NBUF) \
   return launch_tile<CI, CO, TR, NW, NBUF>(in, Wp, ep, nbr, tile_order, N_out, K, out, st)
   constexpr bool big = CO >= 128;
@@ -1297,6 +934,20 @@ static int launch_mfma(const float* in, const float* Wp, const SconvEpilogue& ep
     case 10: SC_GO(32, 4, 1);
     case 11: SC_GO(32, 4, 2);
     case 12: SC_GO(64, 8, 1);
+    // block implicit GEMM with LDS-staged gathers: (TR, NW, WPG)
+    case 30: return launch_gemm<CI, CO, 64, 8, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
+    case 31: return launch_gemm<CI, CO, 64, 4, 2>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
+    case 32: return launch_gemm<CI, CO, 64, 4, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
+    case 33: return launch_gemm<CI, CO, 128, 8, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
+    case 34: return launch_gemm<CI, CO, 32, 4, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
+    case 35: return launch_gemm<CI, CO, 64, 8, 2>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
+    // column-split tiles (WPG = waves per chunk)
+    case 20: return launch_tile<CI, CO, 64, 8, 1, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
+    case 21: return launch_tile<CI, CO, 64, 8, 2, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
+    case 22: return launch_tile<CI, CO, 32, 4, 1, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
+    case 23: return launch_tile<CI, CO, 64, 8, 1, 2>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
+    case 24: return launch_tile<CI, CO, 128, 8, 1, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
+    case 25: return launch_tile<CI, CO, 64, 4, 1, 2>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
     case 13: SC_GO(32, 2, 1);
     case 0:
       if constexpr (big) {
@@ -1307,94 +958,18 @@ static int launch_mfma(const float* in, const float* Wp, const SconvEpilogue& ep
     default: break;
   }
 #undef SC_GO
-  if (g_sconv_variant == 8) {   // wave-private LDS-accumulating kernel
-    using C = WpCfg<CI, CO>;
-    static bool attr_set = false;
-    auto kern = k_sconv_wp<CI, CO>;
-    if (!attr_set) {
-      GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)C::lds_bytes));
-      attr_set = true;
-    }
-    const float* Wp2 = Wp + (size_t)K * SconvCfg<CI, CO>::IMG;
-    int nblocks = glx_divup(N_out, C::TRW * C::NWB);
-    if (g_prof_start && g_prof_stop) {
-      hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(C::NWB * 64), C::lds_bytes, st, g_prof_start,
-                            g_prof_stop, 0, in, Wp2, ep, nbr, tile_order, N_out, K, out);
-      g_prof_start = g_prof_stop = nullptr;
-    } else {
-      hipLaunchKernelGGL(kern, dim3(nblocks), dim3(C::NWB * 64), C::lds_bytes, st, in, Wp2, ep, nbr,
-                         tile_order, N_out, K, out);
-    }
-    GLX_LAUNCH_CHECK();
-    return GLX_OK;
+  // default (measured best per shape on the KITTI-shaped batch, tools/sconv_sweep.py):
+  //   Cout >= 64: block implicit GEMM (LDS-staged gathers, column split over 4 waves), 64-row
+  //               tiles, 8 waves (4 for Cout = 128: its two 16-column tiles per wave);
+  //   Cout <= 32: whole-chunk waves with register gathers (little MFMA work per rule pair, the
+  //               second LDS hop does not pay), 64 rows x 4 waves.
+  if constexpr (CO >= 128) {
+    return launch_gemm<CI, CO, 64, 4, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
+  } else if constexpr (CO >= 64 && CI >= 16) {
+    return launch_gemm<CI, CO, 64, 8, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
+  } else {
+    return launch_tile<CI, CO, 64, 4, 1>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
   }
-  if (g_sconv_variant == 15) {   // wave-private kernel with the deep software pipeline
-    using L = WpCfg<CI, CO>;
-    static bool attr_set = false;
-    auto kern = k_sconv_wq<CI, CO>;
-    if (!attr_set) {
-      GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)L::lds_bytes));
-      attr_set = true;
-    }
-    const float* Wp3 = Wp + (size_t)K * (SconvCfg<CI, CO>::IMG + WpCfg<CI, CO>::IMG);
-    int nblocks = glx_divup(N_out, L::TRW * L::NWB);
-    if (g_prof_start && g_prof_stop) {
-      hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(L::NWB * 64), L::lds_bytes, st, g_prof_start,
-                            g_prof_stop, 0, in, Wp3, ep, nbr, tile_order, zero_row, N_out, K, out);
-      g_prof_start = g_prof_stop = nullptr;
-    } else {
-      hipLaunchKernelGGL(kern, dim3(nblocks), dim3(L::NWB * 64), L::lds_bytes, st, in, Wp3, ep, nbr,
-                         tile_order, zero_row, N_out, K, out);
-    }
-    GLX_LAUNCH_CHECK();
-    return GLX_OK;
-  }
-  if (g_sconv_variant == 14) {   // column-owner kernel
-    using C = CoCfg<CI, CO>;
-    static bool attr_set = false;
-    auto kern = k_sconv_co<CI, CO>;
-    if (!attr_set) {
-      GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)C::lds_bytes));
-      attr_set = true;
-    }
-    const float* Wp4 = Wp + (size_t)K * (SconvCfg<CI, CO>::IMG + WpCfg<CI, CO>::IMG + RtCfg<CI, CO>::IMG);
-    int nblocks = glx_divup(N_out, C::TR);
-    if (g_prof_start && g_prof_stop) {
-      hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(C::NW * 64), C::lds_bytes, st, g_prof_start,
-                            g_prof_stop, 0, in, Wp4, ep, nbr, tile_order, N_out, K, out);
-      g_prof_start = g_prof_stop = nullptr;
-    } else {
-      hipLaunchKernelGGL(kern, dim3(nblocks), dim3(C::NW * 64), C::lds_bytes, st, in, Wp4, ep, nbr,
-                         tile_order, N_out, K, out);
-    }
-    GLX_LAUNCH_CHECK();
-    return GLX_OK;
-  }
-  if (g_sconv_variant == 9) {   // register-tile kernel, one wave per 32 output rows
-    using R = RtCfg<CI, CO>;
-    const float* Wp3 = Wp + (size_t)K * (SconvCfg<CI, CO>::IMG + WpCfg<CI, CO>::IMG);
-    int nblocks = glx_divup(N_out, R::ROWS);
-    auto kern = k_sconv_rt<CI, CO>;
-    if (g_prof_start && g_prof_stop) {
-      hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(64), 0, st, g_prof_start, g_prof_stop, 0, in,
-                            Wp3, ep, nbr, tile_order, N_out, K, out);
-      g_prof_start = g_prof_stop = nullptr;
-    } else {
-      hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64), 0, st, in, Wp3, ep, nbr, tile_order, N_out,
-                         K, out);
-    }
-    GLX_LAUNCH_CHECK();
-    return GLX_OK;
-  }
-  // default (measured best on the KITTI-shaped batch, tools/sconv_sweep.py): block kernel,
-  // 64 rows x 4 waves for narrow outputs, 128 rows x 8 waves for 128 output channels
-#define SC_GO(TR, NW, NBUF) \
-  return launch_tile<CI, CO, TR, NW, NBUF>(in, Wp, ep, nbr, tile_order, N_out, K, out, st)
-  if constexpr (CO >= 128) { SC_GO(128, 8, 1); } else { SC_GO(64, 4, 1); }
-#undef SC_GO
 }
 
 extern "C" size_t glx_sconv_packed_bytes(int K, int Cin, int Cout) {
@@ -1422,7 +997,7 @@ extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, cons
   GLX_REQUIRE(K > 0 && Cin > 0 && Cout > 0 && N_out >= 0, "glx_sconv_forward: bad sizes");
   if (N_out == 0) return GLX_OK;
   GLX_REQUIRE(in && (W || Wp) && nbr && out, "glx_sconv_forward: null pointer");
-  SconvEpilogue ep{bias, scale, shift, relu, n_out_live};
+  SconvEpilogue ep{bias, scale, shift, relu, n_out_live, g_sconv_trace};
   if (!mfma_supported(Cin, Cout, K)) {
     GLX_REQUIRE(W, "glx_sconv_forward: raw weights required for channels (%d,%d)", Cin, Cout);
     long long total = (long long)N_out * Cout;
@@ -1442,20 +1017,9 @@ extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, cons
     if (rc != GLX_OK) return rc;
     Wp = (const float*)workspace;
   }
-  // first 1 KB of the workspace = the zero row that absent rule pairs gather from
-  const float* zero_row = nullptr;
-  if (g_sconv_variant == 15 && workspace && workspace_bytes >= 1024 &&
-      Wp != (const float*)workspace) {
-    GLX_HIP(hipMemsetAsync(workspace, 0, 1024, st));
-    zero_row = (const float*)workspace;
-  }
-  if (g_sconv_variant == 15 && !zero_row) {
-    glx_set_error("glx_sconv_forward: variant 15 needs pre-packed weights and >= 1 KB of workspace");
-    return GLX_EWORKSPACE;
-  }
   return sc_dispatch(Cin, Cout, [&](auto ci, auto co) {
     return launch_mfma<decltype(ci)::value, decltype(co)::value>(in, Wp, ep, nbr, tile_order,
-                                                                 N_out, K, out, zero_row, st);
+                                                                 N_out, K, out, st);
   });
 }
 
