@@ -1,4 +1,6 @@
-// Device-wide exclusive scan (three launches: block sums, scan of sums, write) over a
+// Device-wide exclusive scan (two launches: block sums, then a write pass in which every block
+// re-derives its own offset from the block sums -- cheaper than a third launch for the <= a few
+// thousand blocks of the cell bitmaps, and free of cross-block synchronisation) over a
 // virtual int sequence v[i] = f(i).  Used for popcount ranks of cell bitmaps and for
 // first-seen voxel numbering.  wave64 shuffles inside a wave, LDS across the 4 waves.
 #pragma once
@@ -56,30 +58,25 @@ __global__ void k_scan_block_sums(F f, long long n, const unsigned char* __restr
   if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-// single block: exclusive scan of block_sums[n] in place, grand total -> *n_total
-static __global__ void k_scan_of_sums(int* __restrict__ block_sums, int n,
-                                      int* __restrict__ n_total) {
-  __shared__ int carry_s;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < n; base += SCAN_THREADS) {
-    int i = base + threadIdx.x;
-    int v = (i < n) ? block_sums[i] : 0;
-    int total;
-    int ex = glx_block_exclusive_scan_256(v, &total);
-    int carry = carry_s;
-    if (i < n) block_sums[i] = carry + ex;
-    __syncthreads();
-    if (threadIdx.x == 0) carry_s = carry + total;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *n_total = carry_s;
-}
-
 template <class F>
 __global__ void k_scan_write(F f, long long n, const unsigned char* __restrict__ skip,
-                             const int* __restrict__ block_offsets, int* __restrict__ excl) {
+                             const int* __restrict__ block_sums, int* __restrict__ excl,
+                             int* __restrict__ n_total) {
   long long i0 = (long long)blockIdx.x * SCAN_IPB + (long long)threadIdx.x * SCAN_IPT;
+  const bool last = blockIdx.x == gridDim.x - 1;
+  // with skip flags (cell bitmaps) a block whose own sum is zero has no prefix anyone reads
+  // (the last block still reports the total); without them every item gets its prefix
+  if (skip && !last && block_sums[blockIdx.x] == 0) return;
+  // offset of this block = sum of the sums of the blocks before it
+  __shared__ int s_off;
+  {
+    int part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += SCAN_THREADS) part += block_sums[b];
+    int tot;
+    glx_block_exclusive_scan_256(part, &tot);
+    if (threadIdx.x == 0) s_off = tot;
+    __syncthreads();
+  }
   int v[SCAN_IPT];
   int s = 0;
   const bool live = !skip || (i0 < n && skip[i0 / SCAN_IPT]);
@@ -89,7 +86,8 @@ __global__ void k_scan_write(F f, long long n, const unsigned char* __restrict__
     s += v[i];
   }
   int total;
-  int ex = glx_block_exclusive_scan_256(s, &total) + block_offsets[blockIdx.x];
+  int ex = glx_block_exclusive_scan_256(s, &total) + s_off;
+  if (last && threadIdx.x == 0) *n_total = s_off + total;
   if (!live) return;
 #pragma unroll
   for (int i = 0; i < SCAN_IPT; ++i) {
@@ -118,9 +116,8 @@ static int glx_exclusive_scan(F f, long long n, int* excl, int* n_total, void* w
   int* bsum = (int*)workspace;
   hipLaunchKernelGGL((k_scan_block_sums<F>), dim3(nblk), dim3(SCAN_THREADS), 0, st, f, n, skip,
                      bsum);
-  hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(SCAN_THREADS), 0, st, bsum, nblk, n_total);
   hipLaunchKernelGGL((k_scan_write<F>), dim3(nblk), dim3(SCAN_THREADS), 0, st, f, n, skip,
-                     (const int*)bsum, excl);
+                     (const int*)bsum, excl, n_total);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

@@ -1156,3 +1156,54 @@ extern "C" int glx_dense_scatter(const float* features, const int32_t* indices, 
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
+
+// dense() in one pass: every output element is written exactly once (the feature of the cell's
+// row, or zero), so the caller does not zero-fill the 144 MB BEV tensor first.  One thread per
+// cell (consecutive x -> coalesced stores for each channel), the row is found through the cell
+// index of the sparse tensor.
+__global__ void k_dense_from_index(const float* __restrict__ f, int N, int C,
+                                   const unsigned long long* __restrict__ bitmap,
+                                   const int* __restrict__ prefix,
+                                   const int* __restrict__ rank_to_row, GlxGrid g,
+                                   float* __restrict__ out) {
+  long long cell = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= g.cells()) return;
+  int x = (int)(cell % g.W);
+  long long t = cell / g.W;
+  int y = (int)(t % g.H);
+  t /= g.H;
+  int z = (int)(t % g.D);
+  int b = (int)(t / g.D);
+  int row = glx_rank_lookup(bitmap, prefix, cell);
+  if (row >= 0 && rank_to_row) row = rank_to_row[row];
+  if (row >= N) row = -1;
+  const long long cstride = (long long)g.D * g.H * g.W;
+  float* o = out + (((long long)b * C) * g.D + z) * g.H * g.W + (long long)y * g.W + x;
+  if (row < 0) {
+    for (int c = 0; c < C; ++c) o[c * cstride] = 0.f;
+    return;
+  }
+  const float* src = f + (long long)row * C;
+  if ((C & 3) == 0) {
+    for (int c = 0; c < C; c += 4) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+      o[(c + 0) * cstride] = v[0]; o[(c + 1) * cstride] = v[1];
+      o[(c + 2) * cstride] = v[2]; o[(c + 3) * cstride] = v[3];
+    }
+  } else {
+    for (int c = 0; c < C; ++c) o[c * cstride] = src[c];
+  }
+}
+
+extern "C" int glx_dense_from_index(const float* features, int N, int C, const uint64_t* bitmap,
+                                    const int32_t* prefix, const int32_t* rank_to_row, int B,
+                                    int D, int H, int W, float* out, void* stream) {
+  GLX_REQUIRE(features && bitmap && prefix && out && C > 0 && B > 0 && D > 0 && H > 0 && W > 0,
+              "glx_dense_from_index: bad arguments");
+  GlxGrid g{B, D, H, W};
+  hipLaunchKernelGGL(k_dense_from_index, dim3(glx_divup(g.cells(), 256)), dim3(256), 0,
+                     (hipStream_t)stream, features, N, C, (const unsigned long long*)bitmap,
+                     (const int*)prefix, rank_to_row, g, out);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

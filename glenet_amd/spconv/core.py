@@ -384,8 +384,15 @@ class DenseFunction(Function):
         _lib.check_cuda(f, st.indices)
         N, C = f.shape
         D, H, W = st.spatial_shape
-        out = torch.zeros((st.batch_size, C, D, H, W), dtype=torch.float32, device=f.device)
-        call("glx_dense_scatter", f, st.indices, N, C, st.batch_size, D, H, W, out, st.count)
+        idx = st._index
+        if idx is not None and N > 0 and (st.count is None or idx.count is st.count):
+            # one pass over the output (value or zero per element) through the cell index
+            out = torch.empty((st.batch_size, C, D, H, W), dtype=torch.float32, device=f.device)
+            call("glx_dense_from_index", f, N, C, idx.bitmap, idx.prefix, idx.rank_to_row,
+                 st.batch_size, D, H, W, out)
+        else:
+            out = torch.zeros((st.batch_size, C, D, H, W), dtype=torch.float32, device=f.device)
+            call("glx_dense_scatter", f, st.indices, N, C, st.batch_size, D, H, W, out, st.count)
         ctx.st, ctx.channels_first = st, channels_first
         return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
 

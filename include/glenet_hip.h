@@ -154,6 +154,13 @@ int glx_sconv_wgrad(const float* in, int N_in, const float* grad_out, const int3
 int glx_dense_scatter(const float* features, const int32_t* indices, int N, int C, int B,
                       int D, int H, int W, float* out, const int32_t* n_live, void* stream);
 
+/* Same result without the caller's zero fill: every element of out is written once, rows are
+ * found through the tensor's cell index (bitmap / prefix / rank_to_row or NULL when rows are in
+ * cell order); N = rows of `features` (cells whose row is >= N read as empty). */
+int glx_dense_from_index(const float* features, int N, int C, const uint64_t* bitmap,
+                         const int32_t* prefix, const int32_t* rank_to_row, int B, int D, int H,
+                         int W, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Voxelization.
  * ------------------------------------------------------------------------------------ */
