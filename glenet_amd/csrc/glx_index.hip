@@ -221,12 +221,69 @@ __global__ void k_outset_mark(const int4* __restrict__ idx, const int* __restric
       for (int ox = x0; ox <= x1; ++ox) {
         long long l = og.lin(c.x, oz, oy, ox);
         unsigned long long bit = 1ull << (l & 63);
-        // cheap pre-test avoids most redundant atomics (each output is reached several times)
+        // cheap pre-test avoids most redundant atomics (each output is reached several times;
+        // same-address atomics serialise in L2)
         if (!(obitmap[l >> 6] & bit)) {
           atomicOr(&obitmap[l >> 6], bit);
           oflags[l >> 9] = 1;
         }
       }
+}
+
+// Variant for the common geometry where every axis range has at most 2 cells: the lanes of a
+// wave walk the input rows in cell order, so neighbouring lanes target the same output word.
+// Their bits are OR-ed across the wave first (segmented by word: equal words are contiguous in
+// lane order) and only the first lane of each segment issues the atomic.
+__global__ void k_outset_mark_agg(const int4* __restrict__ idx,
+                                  const int* __restrict__ in_rank_to_row, int N, ConvGeom cg,
+                                  GlxGrid og, unsigned long long* __restrict__ obitmap,
+                                  unsigned char* __restrict__ oflags,
+                                  const int* __restrict__ n_live) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_live) N = min(N, *n_live);
+  int i = -1;
+  if (s < N) i = in_rank_to_row ? in_rank_to_row[s] : s;
+  const bool act = i >= 0 && i < N;
+  int4 c = act ? idx[i] : make_int4(0, 0, 0, 0);
+  int z0, z1, y0, y1, x0, x1;
+  outset_axis_range(c.y, cg.kd, cg.sd, cg.pd, og.D, z0, z1);
+  outset_axis_range(c.z, cg.kh, cg.sh, cg.ph, og.H, y0, y1);
+  outset_axis_range(c.w, cg.kw, cg.sw, cg.pw, og.W, x0, x1);
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int dz = 0; dz < 2; ++dz) {
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      const int oz = z0 + dz, oy = y0 + dy;
+      const bool on = act && oz <= z1 && oy <= y1 && x0 <= x1;
+      // up to two cells x0, x0+1 of one output x-row: one or two words
+      long long l0 = on ? og.lin(c.x, oz, oy, x0) : -1;
+      long long w = on ? (l0 >> 6) : -1 - lane;          // inactive lanes never match a neighbour
+      unsigned long long m = 0, m2 = 0;
+      if (on) {
+        m = 1ull << (l0 & 63);
+        if (x1 > x0) {
+          if (((l0 + 1) >> 6) == w) m |= 1ull << ((l0 + 1) & 63);
+          else m2 = 1ull;                                // spills into bit 0 of the next word
+        }
+      }
+      if (m2) {   // rare: handle the spill directly
+        if (!(obitmap[w + 1] & 1ull)) { atomicOr(&obitmap[w + 1], 1ull); oflags[(w + 1) >> 3] = 1; }
+      }
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        long long wn = __shfl_down(w, o, 64);
+        unsigned long long mn = __shfl_down(m, o, 64);
+        if (lane + o < 64 && wn == w) m |= mn;
+      }
+      long long wp = __shfl_up(w, 1, 64);
+      const bool head = on && (lane == 0 || wp != w);
+      if (head && (obitmap[w] & m) != m) {
+        atomicOr(&obitmap[w], m);
+        oflags[w >> 3] = 1;
+      }
+    }
+  }
 }
 
 extern "C" int glx_outset_build(const int32_t* indices_in, int N_in, int B, int D, int H, int W,
@@ -250,9 +307,16 @@ extern "C" int glx_outset_build(const int32_t* indices_in, int N_in, int B, int 
   }
   if (N_in > 0) {
     ConvGeom cg{kd, kh, kw, sd, sh, sw, pd, ph, pw};
-    hipLaunchKernelGGL(k_outset_mark, dim3(glx_divup(N_in, 256)), dim3(256), 0, st,
-                       (const int4*)indices_in, in_rank_to_row, N_in, cg, og,
-                       (unsigned long long*)out_bitmap, out_chunk_flags, n_in_live);
+    auto reach = [](int k, int s) { return (k + s - 1) / s; };
+    if (reach(kd, sd) <= 2 && reach(kh, sh) <= 2 && reach(kw, sw) <= 2) {
+      hipLaunchKernelGGL(k_outset_mark_agg, dim3(glx_divup(N_in, 256)), dim3(256), 0, st,
+                         (const int4*)indices_in, in_rank_to_row, N_in, cg, og,
+                         (unsigned long long*)out_bitmap, out_chunk_flags, n_in_live);
+    } else {
+      hipLaunchKernelGGL(k_outset_mark, dim3(glx_divup(N_in, 256)), dim3(256), 0, st,
+                         (const int4*)indices_in, in_rank_to_row, N_in, cg, og,
+                         (unsigned long long*)out_bitmap, out_chunk_flags, n_in_live);
+    }
   }
   return glx_scan_bitmap(og, out_bitmap, out_chunk_flags, out_prefix, n_out, workspace,
                          workspace_bytes, st);

@@ -1159,39 +1159,87 @@ extern "C" int glx_dense_scatter(const float* features, const int32_t* indices, 
 
 // dense() in one pass: every output element is written exactly once (the feature of the cell's
 // row, or zero), so the caller does not zero-fill the 144 MB BEV tensor first.  One thread per
-// cell (consecutive x -> coalesced stores for each channel), the row is found through the cell
-// index of the sparse tensor.
-__global__ void k_dense_from_index(const float* __restrict__ f, int N, int C,
+// XV consecutive cells along x: per channel it stores XV floats (16 B per lane when XV = 4, the
+// store width that reaches HBM write bandwidth); rows are found through the cell index.
+// blockIdx.y splits the channels into groups of CG so that even the small BEV grid (70 k
+// x-quads) fills the chip with enough waves to keep the store queues busy.
+template <int XV>
+__global__ void k_dense_from_index(const float* __restrict__ f, int N, int C, int CG,
                                    const unsigned long long* __restrict__ bitmap,
                                    const int* __restrict__ prefix,
                                    const int* __restrict__ rank_to_row, GlxGrid g,
                                    float* __restrict__ out) {
-  long long cell = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (cell >= g.cells()) return;
-  int x = (int)(cell % g.W);
-  long long t = cell / g.W;
+  long long grp = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int wq = g.W / XV;   // XV divides W
+  if (grp >= (long long)g.B * g.D * g.H * wq) return;
+  int xg = (int)(grp % wq);
+  long long t = grp / wq;
   int y = (int)(t % g.H);
   t /= g.H;
   int z = (int)(t % g.D);
   int b = (int)(t / g.D);
-  int row = glx_rank_lookup(bitmap, prefix, cell);
-  if (row >= 0 && rank_to_row) row = rank_to_row[row];
-  if (row >= N) row = -1;
+  const long long cell0 = g.lin(b, z, y, xg * XV);
+  int row[XV];
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < XV; ++i) {
+    int rk = glx_rank_lookup(bitmap, prefix, cell0 + i);
+    if (rk >= 0 && rank_to_row) rk = rank_to_row[rk];
+    if (rk >= N) rk = -1;
+    row[i] = rk;
+    any |= rk >= 0;
+  }
   const long long cstride = (long long)g.D * g.H * g.W;
-  float* o = out + (((long long)b * C) * g.D + z) * g.H * g.W + (long long)y * g.W + x;
-  if (row < 0) {
-    for (int c = 0; c < C; ++c) o[c * cstride] = 0.f;
+  float* o = out + (((long long)b * C) * g.D + z) * g.H * g.W + (long long)y * g.W + xg * XV;
+  typedef float fvec __attribute__((ext_vector_type(XV)));
+  const int c_lo = blockIdx.y * CG, c_hi = min(C, c_lo + CG);
+  if (!any) {
+    fvec zero = 0.f;
+    for (int c = c_lo; c < c_hi; ++c) *reinterpret_cast<fvec*>(o + c * cstride) = zero;
     return;
   }
-  const float* src = f + (long long)row * C;
-  if ((C & 3) == 0) {
-    for (int c = 0; c < C; c += 4) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
-      o[(c + 0) * cstride] = v[0]; o[(c + 1) * cstride] = v[1];
-      o[(c + 2) * cstride] = v[2]; o[(c + 3) * cstride] = v[3];
+  if (CG == 16 && c_hi - c_lo == 16 && (C & 3) == 0) {
+    // all 16 row loads in flight at once (unconditional, absent cells read row 0 and are zeroed
+    // afterwards): one memory latency per thread instead of one per load
+    f32x4 v[XV][4];
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const float* src = f + (long long)(row[i] < 0 ? 0 : row[i]) * C + c_lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[i][j] = *reinterpret_cast<const f32x4*>(src + 4 * j);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        fvec w;
+#pragma unroll
+        for (int i = 0; i < XV; ++i) w[i] = row[i] >= 0 ? v[i][j][e] : 0.f;
+        *reinterpret_cast<fvec*>(o + (c_lo + 4 * j + e) * cstride) = w;
+      }
+    }
+  } else if ((C & 3) == 0 && (CG & 3) == 0) {
+    for (int c = c_lo; c < c_hi; c += 4) {
+      f32x4 v[XV];
+#pragma unroll
+      for (int i = 0; i < XV; ++i)
+        v[i] = row[i] >= 0 ? *reinterpret_cast<const f32x4*>(f + (long long)row[i] * C + c)
+                           : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        fvec w;
+#pragma unroll
+        for (int i = 0; i < XV; ++i) w[i] = v[i][j];
+        *reinterpret_cast<fvec*>(o + (c + j) * cstride) = w;
+      }
     }
   } else {
-    for (int c = 0; c < C; ++c) o[c * cstride] = src[c];
+    for (int c = c_lo; c < c_hi; ++c) {
+      fvec w;
+#pragma unroll
+      for (int i = 0; i < XV; ++i) w[i] = row[i] >= 0 ? f[(long long)row[i] * C + c] : 0.f;
+      *reinterpret_cast<fvec*>(o + c * cstride) = w;
+    }
   }
 }
 
@@ -1201,9 +1249,17 @@ extern "C" int glx_dense_from_index(const float* features, int N, int C, const u
   GLX_REQUIRE(features && bitmap && prefix && out && C > 0 && B > 0 && D > 0 && H > 0 && W > 0,
               "glx_dense_from_index: bad arguments");
   GlxGrid g{B, D, H, W};
-  hipLaunchKernelGGL(k_dense_from_index, dim3(glx_divup(g.cells(), 256)), dim3(256), 0,
-                     (hipStream_t)stream, features, N, C, (const unsigned long long*)bitmap,
-                     (const int*)prefix, rank_to_row, g, out);
+  const int CG = C >= 16 ? 16 : C;   // channels per thread
+  const int ngrp = glx_divup(C, CG);
+  if (W % 4 == 0 && ((uintptr_t)out & 15) == 0) {
+    hipLaunchKernelGGL((k_dense_from_index<4>), dim3(glx_divup(g.cells() / 4, 256), ngrp),
+                       dim3(256), 0, (hipStream_t)stream, features, N, C, CG,
+                       (const unsigned long long*)bitmap, (const int*)prefix, rank_to_row, g, out);
+  } else {
+    hipLaunchKernelGGL((k_dense_from_index<1>), dim3(glx_divup(g.cells(), 256), ngrp), dim3(256),
+                       0, (hipStream_t)stream, features, N, C, CG,
+                       (const unsigned long long*)bitmap, (const int*)prefix, rank_to_row, g, out);
+  }
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
