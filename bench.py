@@ -132,6 +132,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=("graph", "static", "dynamic"), default="graph")
     ap.add_argument("--no-roofline", action="store_true", help="skip the event-bracketed second pass")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="graph mode: number of frame pipelines replayed round-robin on their own "
+                         "HIP streams (consecutive batches overlap on the GPU)")
+    ap.add_argument("--serial-plan", action="store_true",
+                    help="build the rule tables on the main stream (no overlap with the convolutions)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -152,8 +157,16 @@ def main():
     grid = gb.gv.grid_size_of(K["point_cloud_range"], K["voxel_size"])
     model = gb.VoxelBackBone8x(K["num_features"], grid).to(dev).eval()
     vfe, hc = gb.MeanVFE(), gb.HeightCompression()
-    pipe = gb.StaticFramePipeline(model, K, FRAMES_PER_GPU, pts.shape[0], K["num_features"])
-    pipe.calibrate(pts, bidx)     # output-set capacities of the strided convs, 1.3x this workload
+    nstreams = max(1, args.streams) if args.mode == "graph" else 1
+    pipes = []
+    for _ in range(nstreams):
+        p_ = gb.StaticFramePipeline(model, K, FRAMES_PER_GPU, pts.shape[0], K["num_features"])
+        p_.calibrate(pts, bidx)   # output-set capacities of the strided convs, 1.3x this workload
+        p_.overlap_plan = not args.serial_plan
+        pipes.append(p_)
+    pipe = pipes[0]
+    streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
+    turn = [0]
 
     def dynamic_step():
         with torch.no_grad():
@@ -167,12 +180,17 @@ def main():
         return pipe.enqueue()
 
     def graph_step():
-        pipe.load(pts, bidx)
-        return pipe.replay()
+        """Batch i goes to pipeline i mod S on stream i mod S: consecutive batches overlap."""
+        i = turn[0] % nstreams
+        turn[0] += 1
+        with torch.cuda.stream(streams[i]):
+            pipes[i].load(pts, bidx)
+            return pipes[i].replay()
 
     if args.mode == "graph":
-        pipe.load(pts, bidx)
-        pipe.capture()
+        for p_ in pipes:
+            p_.load(pts, bidx)
+            p_.capture()
     step = dict(graph=graph_step, static=static_step, dynamic=dynamic_step)[args.mode]
 
     def run(fn, steps):
@@ -191,7 +209,8 @@ def main():
     gdist.fence(dev)
     dt = gdist.reduce_max(time.perf_counter() - t0, dev)
     if args.mode != "dynamic":
-        pipe.check()       # capacities held, voxelizer index valid (one read-back, after the clock)
+        for p_ in pipes:   # capacities held, voxelizer index valid (one read-back, after the clock)
+            p_.check()
 
     # ---- roofline: K more steps of the same launches, each sparse-conv kernel bracketed by HIP
     # events on its stream (hipExtLaunchKernelGGL start/stop = kernel-only time).  Kept out of the
@@ -248,7 +267,8 @@ def main():
                                         "12 sparse convs + dense()",
                                frames_per_gpu=FRAMES_PER_GPU, points_per_frame=20000,
                                voxels_in=int(n_in), voxels_out=int(n_out),
-                               mode={"graph": "shape-static frame replayed as one HIP graph",
+                               mode={"graph": "shape-static frame replayed as one HIP graph, %d frame "
+                                              "pipeline(s) on their own streams" % nstreams,
                                      "static": "shape-static frame, launches enqueued from Python",
                                      "dynamic": "exact shapes, host read-backs"}[args.mode],
                                parallelism="dp%d (frames shard, no data-path collective)" % world),

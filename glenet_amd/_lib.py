@@ -106,9 +106,24 @@ class Workspace:
 
     def __init__(self):
         self._buf = {}
+        self._scope = None
+
+    def scoped(self, tag):
+        """Context manager: buffers handed out inside are private to `tag` (e.g. one frame
+        pipeline whose recorded launches may run concurrently with another pipeline's)."""
+        ws = self
+
+        class _Scope:
+            def __enter__(self):
+                self.prev, ws._scope = ws._scope, tag
+
+            def __exit__(self, *exc):
+                ws._scope = self.prev
+
+        return _Scope()
 
     def get(self, nbytes, device):
-        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, self._scope)
         buf = self._buf.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

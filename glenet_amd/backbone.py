@@ -92,7 +92,7 @@ class SparseBackbone8x(nn.Module):
         self.backbone_channels = {"x_conv1": 16, "x_conv2": 32, "x_conv3": 64,
                                   "x_conv4": cfg["stages"][-1][1]}
 
-    def plan(self, voxel_coords, batch_size, index=None, capacities=None):
+    def plan(self, voxel_coords, batch_size, index=None, capacities=None, events=False):
         """Build every rule table of the backbone from the coordinates alone (they do not depend
         on features), so the convolutions afterwards run back to back without host syncs.
         Returns the indice_dict to pass as batch_dict["rule_plan"].  With a shape-static index
@@ -100,7 +100,7 @@ class SparseBackbone8x(nn.Module):
         count = index.count if index is not None else None
         return spconv.core.plan_rules(voxel_coords.int(), self.sparse_shape, batch_size,
                                       self.sparse_convs(), index=index, count=count,
-                                      capacities=capacities)
+                                      capacities=capacities, events=events)
 
     def forward(self, batch_dict):
         index = batch_dict.get("voxel_index")
@@ -190,6 +190,10 @@ class StaticFramePipeline:
         self.out = None
         self.max_in_flight = 4
         self._inflight = deque()
+        # rule tables depend on coordinates only: they are built on a second stream and overlap
+        # the convolutions of the levels above them (parallel branches of the HIP graph)
+        self.plan_stream = torch.cuda.Stream(dev)
+        self.overlap_plan = True
 
     def calibrate(self, points, batch_idx, headroom=1.3):
         """Size the strided convs' output sets from a representative batch: one pass of the exact
@@ -213,14 +217,27 @@ class StaticFramePipeline:
 
     def enqueue(self):
         """Launch one frame on the current stream; returns the batch_dict (static buffers)."""
-        with torch.no_grad():
+        from ._lib import workspace
+        with torch.no_grad(), workspace.scoped(id(self)):
             bd = voxelize_batch(self.points, self.batch_idx, self.B, self.cfg, train=self.train_cap,
                                 static=True)
-            bd = self.vfe(bd)
-            bd["rule_plan"] = self.model.plan(bd["voxel_coords"], self.B, index=bd["voxel_index"],
-                                              capacities=self.capacities)
-            bd = self.model(bd)
-            bd = self.hc(bd)
+            if self.overlap_plan:
+                cur = torch.cuda.current_stream(self.points.device)
+                self.plan_stream.wait_stream(cur)            # fork after the voxelizer
+                with torch.cuda.stream(self.plan_stream):
+                    plan = self.model.plan(bd["voxel_coords"], self.B, index=bd["voxel_index"],
+                                           capacities=self.capacities, events=True)
+                bd = self.vfe(bd)
+                bd["rule_plan"] = plan
+                bd = self.model(bd)                          # each conv waits for its rule set
+                bd = self.hc(bd)
+                cur.wait_stream(self.plan_stream)            # join
+            else:
+                bd = self.vfe(bd)
+                bd["rule_plan"] = self.model.plan(bd["voxel_coords"], self.B,
+                                                  index=bd["voxel_index"], capacities=self.capacities)
+                bd = self.model(bd)
+                bd = self.hc(bd)
         self.out = bd
         return bd
 

@@ -104,6 +104,7 @@ class RuleSet:
         self._pairs_dev = None
         self._pairs = None
         self.count_in = self.count_out = None   # shape-static mode: live rows (device int32[1])
+        self.ready = None        # event recorded after the build when it ran on another stream
 
     @property
     def pair_count(self):
@@ -195,11 +196,13 @@ def build_strided_rules(x, ksize, stride, padding, dilation=(1, 1, 1), out_capac
 
 
 def plan_rules(indices, spatial_shape, batch_size, convs, index=None, count=None,
-               capacities=None):
+               capacities=None, events=False):
     """Rule tables of a whole conv stack (modules in execution order) from coordinates only:
     returns {indice_key: RuleSet}.  Keys are required (they are how convs find their table).
     count: live rows of `indices` on the device (shape-static mode, no host sync at all);
-    capacities: optional {indice_key: rows} for the output sets of the strided convs."""
+    capacities: optional {indice_key: rows} for the output sets of the strided convs;
+    events: record an event after each rule set (RuleSet.ready) -- for plans built on a side
+    stream while the convolutions of the previous levels run on the main one."""
     x = SparseConvTensor(None, indices, spatial_shape, batch_size, count=count)
     x._index = index
     capacities = capacities or {}
@@ -214,6 +217,9 @@ def plan_rules(indices, spatial_shape, batch_size, convs, index=None, count=None
             rs = (build_subm_rules(x, conv.kernel_size) if conv.subm else
                   build_strided_rules(x, conv.kernel_size, conv.stride, conv.padding, conv.dilation,
                                       out_capacity=capacities.get(key)))
+            if events:
+                rs.ready = torch.cuda.Event()
+                rs.ready.record()
             x.indice_dict[key] = rs
         if not conv.subm:
             nxt = SparseConvTensor(None, rs.out_indices, rs.out_spatial_shape, batch_size,
@@ -488,6 +494,8 @@ class SparseConvolution(SparseModule):
         K = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
         w = self.weight.reshape(K, self.in_channels, self.out_channels)
         rs = self._rules(x)
+        if rs.ready is not None:       # built on another stream: order this stream after it
+            torch.cuda.current_stream(x.indices.device).wait_event(rs.ready)
         if fused_bn is not None or fused_relu:
             scale, shift = _bn_affine(fused_bn) if fused_bn is not None else (None, None)
             if self.inverse:

@@ -116,6 +116,41 @@ def test_static_pipeline_and_graph_match_dynamic_path(dev, residual):
     assert torch.equal(out["spatial_features"], ref["spatial_features"])
 
 
+def test_two_pipelines_replay_concurrently(dev):
+    """Two captured frame pipelines replayed on their own streams at the same time (what
+    bench.py does to overlap consecutive batches) do not disturb each other."""
+    torch.manual_seed(3)
+    grid = oracle.grid_size_of(K["point_cloud_range"], K["voxel_size"])
+    model = gb.SparseBackbone8x(4, grid).eval().to(dev)
+    _condition(model)
+    nframes = 2
+    batches = [_frames_on(dev, nframes, seed0=60 + 10 * i, num_points=9000 - 500 * i) for i in range(2)]
+    refs = []
+    with torch.no_grad():
+        for pts, bidx in batches:
+            bd = gb.voxelize_batch(pts, bidx, nframes, K)
+            bd = gb.HeightCompression()(model(gb.MeanVFE()(bd)))
+            refs.append(bd["spatial_features"].clone())
+    pipes, streams = [], []
+    for pts, bidx in batches:
+        p = gb.StaticFramePipeline(model, K, nframes, 9000 * nframes, 4)
+        p.calibrate(pts, bidx)
+        p.load(pts, bidx)
+        p.capture()
+        pipes.append(p)
+        streams.append(torch.cuda.Stream(dev))
+    torch.cuda.synchronize()
+    for it in range(6):
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                pipes[i].load(*batches[(i + it) % 2])
+                pipes[i].replay()
+        torch.cuda.synchronize()
+        for i in (0, 1):
+            pipes[i].check()
+            assert torch.equal(pipes[i].out["spatial_features"], refs[(i + it) % 2]), (it, i)
+
+
 def test_static_pipeline_reports_capacity_overflow(dev):
     grid = oracle.grid_size_of(K["point_cloud_range"], K["voxel_size"])
     model = gb.SparseBackbone8x(4, grid).eval().to(dev)
