@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=("graph", "static", "dynamic"), default="graph")
     ap.add_argument("--no-roofline", action="store_true", help="skip the event-bracketed second pass")
+    ap.add_argument("--no-train", action="store_true", help="skip the fwd+bwd side measurement")
     ap.add_argument("--streams", type=int, default=2,
                     help="graph mode: number of frame pipelines replayed round-robin on their own "
                          "HIP streams (consecutive batches overlap on the GPU)")
@@ -227,6 +228,31 @@ def main():
         per = prof.summary()
     prof_steps = min(args.steps, 50)
 
+    # ---- side measurement (not `value`): forward + backward of the same backbone in training
+    # mode (BatchNorm batch statistics, autograd through the sparse convs: dgrad = the forward
+    # kernels on transposed weights, wgrad = k_wgrad_mfma), exact-shape path, loss = mean(out^2)
+    fwd_bwd = None
+    if not args.no_train:
+        tmodel = gb.VoxelBackBone8x(K["num_features"], grid).to(dev).train()
+        tmodel.load_state_dict(model.state_dict())
+
+        def train_step():
+            bd_ = gb.voxelize_batch(pts, bidx, FRAMES_PER_GPU, K, train=True)
+            bd_ = hc(tmodel(vfe(bd_)))
+            tmodel.zero_grad(set_to_none=True)
+            bd_["spatial_features"].square().mean().backward()
+
+        run(train_step, 3)
+        gdist.fence(dev)
+        t1 = time.perf_counter()
+        run(train_step, 20)
+        gdist.fence(dev)
+        dtt = gdist.reduce_max(time.perf_counter() - t1, dev)
+        fwd_bwd = dict(frames_per_s=round(FRAMES_PER_GPU * world * 20 / dtt, 1),
+                       ms_per_step=round(dtt / 20 * 1e3, 3), steps=20,
+                       note="training-mode backbone fwd+bwd, exact-shape path (host read-backs), "
+                            "not the headline workload")
+
     frames_total = FRAMES_PER_GPU * world * args.steps
     dom = max(per, key=lambda k: per[k]["ms"]) if per else None
     traffic = load_traffic()
@@ -272,7 +298,7 @@ def main():
                                      "static": "shape-static frame, launches enqueued from Python",
                                      "dynamic": "exact shapes, host read-backs"}[args.mode],
                                parallelism="dp%d (frames shard, no data-path collective)" % world),
-                   roofline=roof)
+                   roofline=roof, fwd_bwd=fwd_bwd)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames_np, model)
         print(json.dumps(out), flush=True)

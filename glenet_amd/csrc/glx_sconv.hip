@@ -1097,9 +1097,126 @@ __global__ void k_wgrad_reduce(const float* __restrict__ slabs, int nchunks, lon
   dW[e] = s;
 }
 
+// MFMA weight gradient.  grid (slices, K): block (s, k) owns kernel offset k over a slice of the
+// output rows and keeps the whole dW[k] (Cin x Cout) in registers -- the contraction runs over rule
+// pairs, 4 per v_mfma_f32_16x16x4_f32 (A[i = ci][kk = pair], B[kk = pair][j = co]).  Per batch of 256
+// rows it compacts the pairs present at offset k (ballots), then per panel of <= 64 pairs all
+// threads gather the input rows and the grad rows into LDS ([pair][channel], row stride C+16 so
+// the four pair rows of one MFMA step sit in different bank quarters) and each wave multiplies
+// its 16x16 tiles.  One slab per block, summed in fixed order by k_wgrad_reduce: deterministic.
+#define WGM_THREADS 256
+#define WGM_PANEL 64
+#define WGM_BATCH 256
+
+template <int CIN, int COUT>
+struct WgradCfg {
+  static constexpr int CINP = CIN < 16 ? 16 : CIN;       // Cin 4 / 8 ride in a zero-padded 16-row tile
+  static constexpr int MI = CINP / 16, NI = COUT / 16, TILES = MI * NI;
+  static constexpr int TPW = (TILES + 3) / 4;            // tiles per wave (4 waves)
+  static constexpr int A_LD = CINP + 16, B_LD = COUT + 16;
+  static constexpr size_t lds_bytes = (size_t)WGM_PANEL * (A_LD + B_LD) * 4 + WGM_BATCH * 8 + 64;
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(WGM_THREADS) void k_wgrad_mfma(
+    const float* __restrict__ in, const float* __restrict__ gout, const int* __restrict__ nbr,
+    int N_out, int K, int rows_per_slice, float* __restrict__ slabs) {
+  using T = WgradCfg<CIN, COUT>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_a = smem;                                   // WGM_PANEL * A_LD   (input rows)
+  float* s_b = s_a + WGM_PANEL * T::A_LD;              // WGM_PANEL * B_LD   (grad rows)
+  int* s_pi = reinterpret_cast<int*>(s_b + WGM_PANEL * T::B_LD);   // WGM_BATCH input rows
+  int* s_pj = s_pi + WGM_BATCH;                                    // WGM_BATCH output rows
+  int* s_wc = s_pj + WGM_BATCH;                                    // 4 wave counts + total
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, kk = lane >> 4;
+  const int k = blockIdx.y;
+  const int j_lo = blockIdx.x * rows_per_slice;
+  const int j_hi = min(N_out, j_lo + rows_per_slice);
+
+  f32x4 acc[T::TPW];
+#pragma unroll
+  for (int u = 0; u < T::TPW; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (T::CINP != CIN) {   // the padding channels stay zero for the whole kernel
+    for (int e = tid; e < WGM_PANEL * T::A_LD; e += WGM_THREADS) s_a[e] = 0.f;
+    __syncthreads();
+  }
+
+  for (int jb = j_lo; jb < j_hi; jb += WGM_BATCH) {
+    // ---- compact the pairs of offset k among rows jb .. jb+255
+    const int j = jb + tid;
+    int i = -1;
+    if (j < j_hi) i = nbr[(long long)j * K + k];
+    const unsigned long long bal = __ballot(i >= 0);
+    if (lane == 0) s_wc[wave] = __popcll(bal);
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) base += (w < wave) ? s_wc[w] : 0;
+    const int cnt = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+    if (i >= 0) {
+      int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+      s_pi[pos] = i;
+      s_pj[pos] = j;
+    }
+    __syncthreads();
+    // ---- panels of up to 64 pairs
+    for (int p0 = 0; p0 < cnt; p0 += WGM_PANEL) {
+      const int np = min(WGM_PANEL, cnt - p0);
+      const int np4 = (np + 3) & ~3;                    // rows up to the next multiple of 4 are zeroed
+      constexpr int SEG_A = CIN / 4, SEG_B = COUT / 4;
+      for (int e = tid; e < np4 * SEG_A; e += WGM_THREADS) {
+        int pr = e / SEG_A, sg = e - pr * SEG_A;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (pr < np) v = *reinterpret_cast<const f32x4*>(in + (long long)s_pi[p0 + pr] * CIN + sg * 4);
+        *reinterpret_cast<f32x4*>(s_a + pr * T::A_LD + sg * 4) = v;
+      }
+      for (int e = tid; e < np4 * SEG_B; e += WGM_THREADS) {
+        int pr = e / SEG_B, sg = e - pr * SEG_B;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (pr < np) v = *reinterpret_cast<const f32x4*>(gout + (long long)s_pj[p0 + pr] * COUT + sg * 4);
+        *reinterpret_cast<f32x4*>(s_b + pr * T::B_LD + sg * 4) = v;
+      }
+      __syncthreads();
+      for (int st = 0; st < np4; st += 4) {
+        const float* ar = s_a + (st + kk) * T::A_LD + n;
+        const float* br = s_b + (st + kk) * T::B_LD + n;
+#pragma unroll
+        for (int u = 0; u < T::TPW; ++u) {
+          const int t = wave + 4 * u;
+          if (T::TILES % 4 == 0 || t < T::TILES) {
+            const int mi = t / T::NI, ni = t - mi * T::NI;
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[mi * 16], br[ni * 16], acc[u], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- slab of this block: dW[k] partial, (Cin, Cout) row-major
+  float* dst = slabs + ((long long)blockIdx.x * K + k) * (CIN * COUT);
+#pragma unroll
+  for (int u = 0; u < T::TPW; ++u) {
+    const int t = wave + 4 * u;
+    if (T::TILES % 4 == 0 || t < T::TILES) {
+      const int mi = t / T::NI, ni = t - mi * T::NI;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (T::CINP == CIN || mi * 16 + 4 * kk + e < CIN)
+          dst[(mi * 16 + 4 * kk + e) * COUT + ni * 16 + n] = acc[u][e];
+    }
+  }
+}
+
+static int wgrad_slices(int K) {
+  int s = 864 / (K > 0 ? K : 1);   // ~3 blocks per CU
+  return s < 1 ? 1 : (s > 512 ? 512 : s);
+}
+
 extern "C" size_t glx_sconv_wgrad_workspace_bytes(int N_out, int K, int Cin, int Cout) {
   (void)N_out;
-  return glx_align((size_t)WG_CHUNKS * K * Cin * Cout * sizeof(float)) + 256;
+  int chunks = wgrad_slices(K) > WG_CHUNKS ? wgrad_slices(K) : WG_CHUNKS;
+  return glx_align((size_t)chunks * K * Cin * Cout * sizeof(float)) + 256;
 }
 
 extern "C" int glx_sconv_wgrad(const float* in, int N_in, const float* grad_out,
@@ -1114,10 +1231,38 @@ extern "C" int glx_sconv_wgrad(const float* in, int N_in, const float* grad_out,
     GLX_HIP(hipMemsetAsync(dW, 0, nel_total * sizeof(float), st));
     return GLX_OK;
   }
-  size_t need = (size_t)WG_CHUNKS * nel_total * sizeof(float);
+  size_t need = glx_sconv_wgrad_workspace_bytes(N_out, K, Cin, Cout) - 256;
   if (!workspace || workspace_bytes < need) {
     glx_set_error("glx_sconv_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
     return GLX_EWORKSPACE;
+  }
+  auto okc = [](int c) { return c == 16 || c == 32 || c == 64 || c == 128; };
+  if ((okc(Cin) || Cin == 4 || Cin == 8) && okc(Cout) && !getenv("GLX_WGRAD_SCALAR")) {
+    const int S = wgrad_slices(K);
+    int rps = glx_divup(N_out, S);
+    rps = (rps + WGM_BATCH - 1) / WGM_BATCH * WGM_BATCH;
+    const int slices = glx_divup(N_out, rps);
+    int rc = sc_dispatch(Cin, Cout, [&](auto ci, auto co) {
+      constexpr int CI = decltype(ci)::value, CO = decltype(co)::value;
+      {
+        using T = WgradCfg<CI, CO>;
+        auto kern = k_wgrad_mfma<CI, CO>;
+        static bool attr_set = false;
+        if (!attr_set) {
+          GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)T::lds_bytes));
+          attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(slices, K), dim3(WGM_THREADS), T::lds_bytes, st, in, grad_out,
+                           nbr, N_out, K, rps, (float*)workspace);
+      }
+      return GLX_OK;
+    });
+    if (rc != GLX_OK) return rc;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(glx_divup(nel_total, 256)), dim3(256), 0, st,
+                       (const float*)workspace, slices, nel_total, dW);
+    GLX_LAUNCH_CHECK();
+    return GLX_OK;
   }
   int rows_per_chunk = glx_divup(N_out, WG_CHUNKS);
   hipLaunchKernelGGL(k_wgrad_partial, dim3(WG_CHUNKS, K), dim3(WG_THREADS),

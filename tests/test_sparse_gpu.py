@@ -217,6 +217,28 @@ def test_conv_backward(dev, cin, cout, subm):
     np.testing.assert_allclose(conv.weight.grad.reshape(27, cin, cout).cpu().numpy(), dw, rtol=1e-3, atol=2e-3)
 
 
+def test_conv_backward_conv_out_geometry(dev):
+    """(3,1,1) kernel, stride (2,1,1), 64 -> 128: the backbone's conv_out (spconv_backbone.py:113-114),
+    K = 3 exercises the many-slices branch of the MFMA weight gradient."""
+    rng = np.random.default_rng(5)
+    shape = (5, 30, 26)
+    idx, f = _rand_sparse(rng, 2, *shape, 0.15, 64)
+    w = (rng.normal(size=(3, 64, 128)) / np.sqrt(3 * 64)).astype(np.float32)
+    rules = oracle.build_rules(idx, shape, (3, 1, 1), (2, 1, 1), 0, subm=False)
+    conv = sp.SparseConv3d(64, 128, (3, 1, 1), stride=(2, 1, 1), padding=0, bias=False).to(dev)
+    g = rng.normal(size=(len(rules.out_indices), 128)).astype(np.float32)
+    din, dw = oracle.sconv_backward(f, w, g, rules)
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(w).reshape(3, 1, 1, 64, 128))
+    x = _gpu_tensor(idx, f, shape, 2, dev)
+    x.features.requires_grad_(True)
+    out = conv(x)
+    assert np.array_equal(out.indices.cpu().numpy(), rules.out_indices)
+    out.features.backward(torch.from_numpy(g).to(dev))
+    np.testing.assert_allclose(x.features.grad.cpu().numpy(), din, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(conv.weight.grad.reshape(3, 64, 128).cpu().numpy(), dw, rtol=1e-3, atol=2e-3)
+
+
 def test_dense_and_empty(dev):
     rng = np.random.default_rng(3)
     shape = (2, 20, 18)
