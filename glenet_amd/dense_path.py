@@ -1,0 +1,238 @@
+"""The dense (MFMA) side of the hot path: SURVEY.md section 8 rows a21-a23.
+
+`north_star` keeps these on PyTorch-ROCm (MIOpen / hipBLASLt drive the matrix cores); what this
+module owns is the *shape* of the work and the parameter names, so that GLENet checkpoints load
+and the harness (bench / tests) can run the whole detector data flow:
+
+  BEVBackbone   layer list of BaseBEVBackbone   (pcdet/models/backbones_2d/base_bev_backbone.py:6-112)
+  AnchorHead    the three 1x1 convs of AnchorHeadSingle (pcdet/models/dense_heads/anchor_head_single.py:41-58)
+  RoIFCStack    shared / cls / reg FC towers of VoxelRCNNHead (pcdet/models/roi_heads/voxelrcnn_head.py:22-66)
+  CVAE          PointNet encoders + box decoder of the label-uncertainty generator
+                (cvae_uncertainty/point_net.py:10-49, cvae_uncertainty/model.py:33-142,150-265)
+
+Every module is table-driven (one builder, several shapes).  Parity with the reference's own
+modules is pinned by tests/golden/dense_path_ref.npz (state dicts + outputs produced by the
+reference code on CPU, see tests/golden/make_golden.py).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+def _bn2d(c):
+    return nn.BatchNorm2d(c, eps=1e-3, momentum=0.01)      # base_bev_backbone.py:37
+
+
+class BEVBackbone(nn.Module):
+    """blocks[i] = ZeroPad2d(1) + conv3x3(stride s_i, pad 0) + BN + ReLU + n_i x (conv3x3 + BN + ReLU);
+    deblocks[i] = ConvTranspose2d(k = stride = u_i) + BN + ReLU; outputs concatenated on channels."""
+
+    def __init__(self, input_channels, layer_nums=(5, 5), layer_strides=(1, 2), num_filters=(64, 128),
+                 upsample_strides=(1, 2), num_upsample_filters=(128, 128)):
+        super().__init__()
+        assert len(layer_nums) == len(layer_strides) == len(num_filters)
+        assert len(upsample_strides) == len(num_upsample_filters)
+        self.blocks, self.deblocks = nn.ModuleList(), nn.ModuleList()
+        cin = input_channels
+        for i, (n, s, c) in enumerate(zip(layer_nums, layer_strides, num_filters)):
+            seq = [nn.ZeroPad2d(1), nn.Conv2d(cin, c, 3, stride=s, padding=0, bias=False), _bn2d(c), nn.ReLU()]
+            for _ in range(n):
+                seq += [nn.Conv2d(c, c, 3, padding=1, bias=False), _bn2d(c), nn.ReLU()]
+            self.blocks.append(nn.Sequential(*seq))
+            if i < len(upsample_strides):
+                u, cu = upsample_strides[i], num_upsample_filters[i]
+                if u >= 1:
+                    up = nn.ConvTranspose2d(c, cu, int(u), stride=int(u), bias=False)
+                else:                                   # fractional stride = strided conv (:57-66)
+                    k = int(round(1.0 / u))
+                    up = nn.Conv2d(c, cu, k, stride=k, bias=False)
+                self.deblocks.append(nn.Sequential(up, _bn2d(cu), nn.ReLU()))
+            cin = c
+        self.num_bev_features = sum(num_upsample_filters)
+        if len(upsample_strides) > len(layer_nums):     # one more deblock on the concatenation (:70-75)
+            u, c = int(upsample_strides[-1]), self.num_bev_features
+            self.deblocks.append(nn.Sequential(nn.ConvTranspose2d(c, c, u, stride=u, bias=False), _bn2d(c),
+                                               nn.ReLU()))
+
+    def forward(self, data_dict):
+        x0 = data_dict["spatial_features"]
+        x, ups = x0, []
+        for i, blk in enumerate(self.blocks):
+            x = blk(x)
+            data_dict["spatial_features_%dx" % int(x0.shape[2] / x.shape[2])] = x
+            ups.append(self.deblocks[i](x) if len(self.deblocks) > 0 else x)
+        x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
+        if len(self.deblocks) > len(self.blocks):
+            x = self.deblocks[-1](x)
+        data_dict["spatial_features_2d"] = x
+        return data_dict
+
+    @staticmethod
+    def flops_per_frame(h, w, input_channels=256, layer_nums=(5, 5), layer_strides=(1, 2),
+                        num_filters=(64, 128), upsample_strides=(1, 2), num_upsample_filters=(128, 128)):
+        """Multiply-add x2 of one forward pass."""
+        total, cin = 0, input_channels
+        for n, s, c, u, cu in zip(layer_nums, layer_strides, num_filters, upsample_strides, num_upsample_filters):
+            h, w = h // s, w // s
+            total += 2 * h * w * 9 * cin * c + n * 2 * h * w * 9 * c * c
+            total += 2 * h * w * c * cu * int(u) * int(u)
+            cin = c
+        return total
+
+
+class AnchorHead(nn.Module):
+    """conv_cls / conv_box / conv_dir_cls, 1x1, with AnchorHeadSingle's bias init (:60-62)."""
+
+    def __init__(self, input_channels, num_class=3, num_anchors_per_location=6, code_size=7, num_dir_bins=2):
+        super().__init__()
+        self.num_class, self.code_size = num_class, code_size
+        self.conv_cls = nn.Conv2d(input_channels, num_anchors_per_location * num_class, 1)
+        self.conv_box = nn.Conv2d(input_channels, num_anchors_per_location * code_size, 1)
+        self.conv_dir_cls = (nn.Conv2d(input_channels, num_anchors_per_location * num_dir_bins, 1)
+                             if num_dir_bins else None)
+        nn.init.constant_(self.conv_cls.bias, -math.log((1 - 0.01) / 0.01))
+        nn.init.normal_(self.conv_box.weight, mean=0, std=0.001)
+
+    def forward(self, data_dict):
+        x = data_dict["spatial_features_2d"]
+        data_dict["cls_preds"] = self.conv_cls(x).permute(0, 2, 3, 1).contiguous()      # (B,H,W,A*cls)
+        data_dict["box_preds"] = self.conv_box(x).permute(0, 2, 3, 1).contiguous()
+        if self.conv_dir_cls is not None:
+            data_dict["dir_cls_preds"] = self.conv_dir_cls(x).permute(0, 2, 3, 1).contiguous()
+        return data_dict
+
+
+def _fc_tower(cin, widths, dp_ratio):
+    layers = []
+    for k, w in enumerate(widths):
+        layers += [nn.Linear(cin, w, bias=False), nn.BatchNorm1d(w), nn.ReLU(inplace=True)]
+        cin = w
+        if k != len(widths) - 1 and dp_ratio > 0:
+            layers.append(nn.Dropout(dp_ratio))
+    return nn.Sequential(*layers), cin
+
+
+class RoIFCStack(nn.Module):
+    """shared_fc_layer -> (cls_fc_layers -> cls_pred_layer, reg_fc_layers -> reg_pred_layer)."""
+
+    def __init__(self, pooled_channels, grid_size=6, shared_fc=(256, 256), cls_fc=(256, 256),
+                 reg_fc=(256, 256), dp_ratio=0.3, num_class=1, code_size=7):
+        super().__init__()
+        pre = grid_size ** 3 * pooled_channels
+        self.shared_fc_layer, pre = _fc_tower(pre, shared_fc, dp_ratio)
+        self.cls_fc_layers, c = _fc_tower(pre, cls_fc, dp_ratio)
+        self.cls_pred_layer = nn.Linear(c, num_class, bias=True)
+        self.reg_fc_layers, c = _fc_tower(pre, reg_fc, dp_ratio)
+        self.reg_pred_layer = nn.Linear(c, code_size * num_class, bias=True)
+
+    def forward(self, pooled):
+        """pooled (R, G^3, C) or (R, G^3*C) -> rcnn_cls (R, num_class), rcnn_reg (R, code*num_class)."""
+        shared = self.shared_fc_layer(pooled.reshape(pooled.shape[0], -1))
+        return self.cls_pred_layer(self.cls_fc_layers(shared)), self.reg_pred_layer(self.reg_fc_layers(shared))
+
+
+# ------------------------------------------------------------------------------ CVAE
+class PointFeat(nn.Module):
+    """Shared point MLP (Conv1d k=1 = GEMM) + max over points; no ReLU after the last BN
+    (point_net.py:22-28).  widths (64,128,512) = PointNetfeat(x=1), (8,8,8) = SimPointNetfeat(x=0.5)."""
+
+    def __init__(self, pts_dim, widths=(64, 128, 512)):
+        super().__init__()
+        self.output_channel = widths[2]
+        self.conv1 = nn.Conv1d(pts_dim, widths[0], 1)
+        self.conv2 = nn.Conv1d(widths[0], widths[1], 1)
+        self.conv3 = nn.Conv1d(widths[1], widths[2], 1)
+        self.bn1, self.bn2, self.bn3 = nn.BatchNorm1d(widths[0]), nn.BatchNorm1d(widths[1]), nn.BatchNorm1d(widths[2])
+
+    def forward(self, x):                       # x (B, pts_dim, P)
+        x = F.relu(self.bn1(self.conv1(x)))
+        x = F.relu(self.bn2(self.conv2(x)))
+        x = self.bn3(self.conv3(x))
+        return x.max(dim=2)[0]
+
+
+class LatentEncoder(nn.Module):
+    """Encoder_x (cond_dim = 0) / Encoder_xy (cond_dim = 8): point feature (+ encoded box) ->
+    mu, logvar of the latent Gaussian; scale of the distribution is exp(logvar) + 3e-22 (model.py:49,77)."""
+
+    def __init__(self, input_channels, latent_size, cond_dim=0, widths=(64, 128, 512)):
+        super().__init__()
+        self.fe = PointFeat(input_channels, widths)
+        self.fc1 = nn.Linear(widths[2] + cond_dim, latent_size)
+        self.fc2 = nn.Linear(widths[2] + cond_dim, latent_size)
+
+    def forward(self, points, cond=None):
+        h = self.fe(points)
+        if cond is not None:
+            h = torch.cat([h, cond], dim=1)
+        mu, logvar = self.fc1(h), self.fc2(h)
+        dist = torch.distributions.Independent(torch.distributions.Normal(mu, torch.exp(logvar) + 3e-22), 1)
+        return dist, mu, logvar
+
+
+class BoxDecoder(nn.Module):
+    """Object_feat_encoder (model.py:82-142): small point feature + latent z -> 3 centre, 3 size,
+    1 heading residual, num_bins direction logits."""
+
+    def __init__(self, input_channels, latent_dim, num_bins=2, width=64):
+        super().__init__()
+        self.fe = PointFeat(input_channels, (8, 8, 8))
+        self.fc1, self.fc2 = nn.Linear(8 + latent_dim, width), nn.Linear(width, width)
+        self.bn1, self.bn2 = nn.BatchNorm1d(width), nn.BatchNorm1d(width)
+        self.fc_s1, self.fc_s2 = nn.Linear(width, width), nn.Linear(width, 3, bias=False)
+        self.fc_ce1, self.fc_ce2 = nn.Linear(width, width), nn.Linear(width, 3, bias=False)
+        self.fc_hr1, self.fc_hr2 = nn.Linear(width, width), nn.Linear(width, 1, bias=False)
+        self.fc_dir1, self.fc_dir2 = nn.Linear(width, width), nn.Linear(width, num_bins, bias=False)
+
+    def forward(self, points, z):
+        h = torch.cat([self.fe(points), z], dim=1)
+        h = F.relu(self.bn1(self.fc1(h)))
+        h = F.relu(self.bn2(self.fc2(h)))
+        head = lambda a, b: b(F.relu(a(h)))                                   # noqa: E731
+        return torch.cat([head(self.fc_ce1, self.fc_ce2), head(self.fc_s1, self.fc_s2),
+                          head(self.fc_hr1, self.fc_hr2), head(self.fc_dir1, self.fc_dir2)], dim=1)
+
+
+def limit_period(val, offset=0.5, period=np.pi):
+    return val - torch.floor(val / period + offset) * period                  # common_utils.py:35-38
+
+
+class CVAE(nn.Module):
+    """Generator of cvae_uncertainty/model.py: x_encoder (prior), xy_encoder (posterior), obj_encoder
+    (decoder).  `sample()` is its eval-mode forward (:245-265) with an explicit noise tensor, so the
+    30 latent samples per object of predict.sh:8-11 are 30 calls / one batched call."""
+
+    def __init__(self, input_channels=4, latent_dim=8, num_dir_bins=2, dir_offset=0.78539, dir_limit_offset=0.0):
+        super().__init__()
+        self.latent_dim, self.num_dir_bins = latent_dim, num_dir_bins
+        self.dir_offset, self.dir_limit_offset = dir_offset, dir_limit_offset
+        self.obj_encoder = BoxDecoder(input_channels, latent_dim, num_dir_bins)
+        self.xy_encoder = LatentEncoder(input_channels, latent_dim, cond_dim=8)
+        self.x_encoder = LatentEncoder(input_channels, latent_dim)
+
+    @staticmethod
+    def reparametrize(mu, logvar, eps):
+        return eps * torch.exp(0.5 * logvar) + mu                              # model.py:194-198
+
+    def sample(self, points, eps=None):
+        """points (B, C, P) -> boxes (B, 7 + num_dir_bins) with the heading decoded from its bin."""
+        _, mu, logvar = self.x_encoder(points)
+        if eps is None:
+            eps = torch.randn_like(mu)
+        pred = self.obj_encoder(points, self.reparametrize(mu, logvar, eps))
+        period = 2 * np.pi / self.num_dir_bins
+        labels = pred[:, -self.num_dir_bins:].max(dim=-1)[1]
+        rot = limit_period(pred[:, 6] - self.dir_offset, self.dir_limit_offset, period)
+        pred = pred.clone()
+        pred[:, 6] = rot + self.dir_offset + period * labels.to(pred.dtype)
+        return pred
+
+    def posterior_prior(self, points, gt_boxes_input):
+        """Training-side encoders: (posterior, prior) distributions and their KL (model.py:205-212)."""
+        post, mu_xy, logvar_xy = self.xy_encoder(points, gt_boxes_input)
+        prior, mu_x, logvar_x = self.x_encoder(points)
+        kl = torch.distributions.kl.kl_divergence(post, prior)
+        return post, prior, kl, (mu_xy, logvar_xy, mu_x, logvar_x)

@@ -19,6 +19,9 @@ committed, this script is committed, nothing of the reference is copied.
                          suppression strictness, output ordering) given the oracle's IoU matrix;
                          the IoU arithmetic itself is pinned by iou3d_ref.npz (shared helpers).
   limit_period / boxes3d_to_bev_torch outputs of the reference are stored alongside.
+  dense_path_ref.npz the reference's dense-path modules (BEV backbone, CVAE networks, RoI-grid
+                     geometry helpers) run on CPU: see make_dense_path_ref() for what is imported
+                     and which placeholders stand in for uninstalled / CUDA-only imports.
 """
 import importlib
 import os
@@ -128,6 +131,124 @@ def make_nms_func_ref():
     print("nms_func_ref.npz keeps:", [len(out["c%d_keep" % c]) for c in range(4)])
 
 
+class Cfg(dict):
+    """Minimal stand-in for the EasyDict the reference's configs are (attribute access + .get)."""
+    __getattr__ = dict.__getitem__
+
+
+def _load_by_path(name, relpath):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _randomise_bn(module, gen):
+    for m in module.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=gen) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=gen) * 0.5 + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=gen) * 0.5 + 0.75)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=gen) * 0.1)
+
+
+def _state(prefix, module):
+    return {"%s/%s" % (prefix, k): v.detach().numpy() for k, v in module.state_dict().items()}
+
+
+def make_dense_path_ref():
+    """dense_path_ref.npz: the reference's own dense-path modules run on CPU (eval mode, seeded):
+      * BaseBEVBackbone (pcdet/models/backbones_2d/base_bev_backbone.py), loaded by file path --
+        it imports torch / numpy only; config = a dict with attribute access (EasyDict is not
+        installed here);
+      * PointNetfeat / SimPointNetfeat (cvae_uncertainty/point_net.py, torch only);
+      * Encoder_x / Encoder_xy / Object_feat_encoder / Generator.forward (eval path) of
+        cvae_uncertainty/model.py.  Placeholders, disclosed: `torchvision.models` (imported,
+        unused; not installed) -> empty module; `pcdet.utils.loss_utils` -> a module with two empty
+        nn.Module classes named WeightedSmoothL1Loss / WeightedCrossEntropyLoss (only constructed,
+        never called in eval mode; the real file pulls in the CUDA extensions);
+        Generator.reparametrize (allocates torch.cuda.FloatTensor noise) -> the same formula
+        eps * exp(0.5 logvar) + mu with a stored eps, so the run is reproducible on CPU;
+      * common_utils.get_voxel_centers / rotate_points_along_z (pure torch) and
+        VoxelRCNNHead.get_dense_grid_points / get_global_grid_points_of_roi semantics are pinned
+        through common_utils only (the head class itself needs the whole pcdet package)."""
+    import importlib.util
+    gen = torch.Generator().manual_seed(1234)
+    out = {}
+    # ---- BEV backbone
+    bev = _load_by_path("ref_base_bev_backbone", "pcdet/models/backbones_2d/base_bev_backbone.py")
+    cfg = Cfg(LAYER_NUMS=[1, 2], LAYER_STRIDES=[1, 2], NUM_FILTERS=[8, 16], UPSAMPLE_STRIDES=[1, 2],
+              NUM_UPSAMPLE_FILTERS=[8, 8])
+    torch.manual_seed(1)
+    m = bev.BaseBEVBackbone(cfg, 6).eval()
+    _randomise_bn(m, gen)
+    x = torch.randn(2, 6, 12, 10, generator=gen)
+    with torch.no_grad():
+        y = m({"spatial_features": x})["spatial_features_2d"]
+    out.update(_state("bev", m))
+    out["bev_in"], out["bev_out"] = x.numpy(), y.numpy()
+    # ---- CVAE pieces
+    sys.modules.setdefault("SharedArray", types.ModuleType("SharedArray"))
+    tv = types.ModuleType("torchvision")
+    tv.models = types.ModuleType("torchvision.models")
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.models", tv.models)
+    for name, path in (("pcdet", "pcdet"), ("pcdet.utils", "pcdet/utils")):
+        mod = types.ModuleType(name)
+        mod.__path__ = [os.path.join(REF, path)]
+        sys.modules[name] = mod
+    lu = types.ModuleType("pcdet.utils.loss_utils")
+
+    class _Loss(torch.nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+    lu.WeightedSmoothL1Loss = lu.WeightedCrossEntropyLoss = _Loss
+    sys.modules["pcdet.utils.loss_utils"] = lu
+    sys.modules["pcdet.utils"].loss_utils = lu
+    common = importlib.import_module("pcdet.utils.common_utils")
+    sys.modules["pcdet.utils"].common_utils = common
+    sys.path.insert(0, os.path.join(REF, "cvae_uncertainty"))
+    cvae = importlib.import_module("model")
+    mcfg = Cfg(LATENT_DIM=8, DIR_OFFSET=0.78539, DIR_LIMIT_OFFSET=0.0, NUM_DIR_BINS=2,
+               LOSS_CONFIG=Cfg(LOSS_WEIGHTS={"code_weights": [1.0] * 7, "latent_weight": 10}))
+    torch.manual_seed(2)
+    g = cvae.Generator(mcfg, 4, 1).eval()
+    _randomise_bn(g, gen)
+    pts = torch.randn(5, 4, 64, generator=gen)
+    eps = torch.randn(5, 8, generator=gen)
+    cond = torch.randn(5, 8, generator=gen)
+    g.reparametrize = lambda mu, logvar: eps * torch.exp(0.5 * logvar) + mu
+    with torch.no_grad():
+        box = g({"points": pts, "gt_boxes_input": cond, "gt_boxes": torch.zeros(5, 7)}).clone()
+        _, mu_x, logvar_x = g.x_encoder(pts)
+        post, mu_xy, logvar_xy = g.xy_encoder(pts, cond)
+        prior, _, _ = g.x_encoder(pts)
+        kl = g.kl_divergence(post, prior)
+        dec = g.obj_encoder(pts, eps)
+    out.update({k: v for k, v in _state("cvae", g).items() if "global_step" not in k})
+    out.update(cvae_points=pts.numpy(), cvae_eps=eps.numpy(), cvae_cond=cond.numpy(), cvae_box=box.numpy(),
+               cvae_mu_x=mu_x.numpy(), cvae_logvar_x=logvar_x.numpy(), cvae_mu_xy=mu_xy.numpy(),
+               cvae_logvar_xy=logvar_xy.numpy(), cvae_kl=kl.numpy(), cvae_dec=dec.numpy())
+    # ---- geometry glue of the RoI grid pool
+    coords = torch.randint(0, 40, (50, 3), generator=gen)
+    vs, rng_ = [0.05, 0.05, 0.1], [0, -40, -3, 70.4, 40, 1]
+    out["vc_coords"] = coords.numpy()
+    for stride in (1, 2, 4, 8):
+        out["vc_centers_%d" % stride] = common.get_voxel_centers(coords, stride, vs, rng_).numpy()
+    p = torch.randn(7, 216, 3, generator=gen)
+    ang = torch.rand(7, generator=gen) * 6.28 - 3.14
+    out["rot_points"], out["rot_angle"] = p.numpy(), ang.numpy()
+    out["rot_out"] = common.rotate_points_along_z(p.clone(), ang).numpy()
+    np.savez_compressed(os.path.join(HERE, "dense_path_ref.npz"), **out)
+    print("dense_path_ref.npz", len(out), "arrays; bev_out", out["bev_out"].shape, "cvae_box", out["cvae_box"].shape)
+
+
 if __name__ == "__main__":
-    make_iou3d_ref()
-    make_nms_func_ref()
+    only = sys.argv[1:] or ["iou3d", "nms", "dense"]
+    if "iou3d" in only:
+        make_iou3d_ref()
+    if "nms" in only:
+        make_nms_func_ref()
+    if "dense" in only:
+        make_dense_path_ref()

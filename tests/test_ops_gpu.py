@@ -297,3 +297,52 @@ def test_roi_grid_pool_module_dense_equals_sparse(dev):
         a = mod(*args, v2p)
         b = mod(*args, st)
     assert a.shape == (M, 24) and torch.equal(a, b)
+
+
+def test_roi_grid_pool_harness_vs_reference_formulation(dev):
+    """glenet_amd.roi_grid.RoIGridPool == the reference's roi_grid_pool data flow restated with
+    its own pieces: dense voxel->point map per scale, grid coords by float floor division, per-batch
+    counts (voxelrcnn_head.py:106-191), on two scales of a synthetic scene."""
+    from glenet_amd import roi_grid as rg
+    rng = np.random.default_rng(21)
+    B, vs, pcr = 2, [0.1, 0.1, 0.2], [0.0, 0.0, 0.0, 4.0, 4.8, 2.0]
+    shapes = {"x_conv1": (10, 48, 40), "x_conv2": (5, 24, 20)}
+    strides = {"x_conv1": 1, "x_conv2": 2}
+    feats, tensors = {}, {}
+    for name, (Z, Y, X) in shapes.items():
+        idx, _, _ = _voxel_scene(rng, B, Z, Y, X, 0.12)
+        f = rng.normal(size=(len(idx), 8)).astype(np.float32)
+        feats[name] = (idx, f)
+        tensors[name] = sp.SparseConvTensor(T(f, dev), T(idx, dev), [Z, Y, X], B)
+    cfg = {n: dict(mlps=[[8, 12]], query_ranges=[[2, 2, 2]], radii=[0.3 * strides[n]], nsamples=[8])
+           for n in shapes}
+    torch.manual_seed(4)
+    pool = rg.RoIGridPool({n: 8 for n in shapes}, cfg, 3, vs, pcr).to(dev).eval()
+    rois = np.concatenate([rng.uniform([0.5, 0.5, 0.4], [3.5, 4.3, 1.6], (B, 5, 3)),
+                           rng.uniform(0.4, 1.2, (B, 5, 3)), rng.uniform(-3, 3, (B, 5, 1))], -1).astype(np.float32)
+    with torch.no_grad():
+        got = pool(T(rois, dev), tensors, strides, B)
+        # reference formulation
+        grid, _ = rg.global_grid_points_of_roi(T(rois, dev), 3)
+        grid = grid.view(B, -1, 3)
+        gc = torch.cat([(grid[..., i:i + 1] - pcr[i]) // vs[i] for i in range(3)], -1)
+        bidx = torch.zeros(B, gc.shape[1], 1, device=dev)
+        for b in range(B):
+            bidx[b] = b
+        cnt_new = torch.full((B,), gc.shape[1], dtype=torch.int32, device=dev)
+        want = []
+        for k, name in enumerate(shapes):
+            idx, f = feats[name]
+            st = tensors[name]
+            xyz = rg.get_voxel_centers(st.indices[:, 1:4], strides[name], vs, pcr)
+            cnt = torch.tensor([(idx[:, 0] == b).sum() for b in range(B)], dtype=torch.int32, device=dev)
+            v2p = T(oracle.generate_voxel2pinds(idx, B, list(shapes[name])), dev)
+            coords = torch.cat([bidx, gc // strides[name]], -1).int()
+            o = pool.roi_grid_pool_layers[k](xyz=xyz.contiguous(), xyz_batch_cnt=cnt,
+                                             new_xyz=grid.reshape(-1, 3).contiguous(), new_xyz_batch_cnt=cnt_new,
+                                             new_coords=coords.view(-1, 4).contiguous(), features=st.features,
+                                             voxel2point_indices=v2p)
+            want.append(o.view(-1, 27, o.shape[-1]))
+        want = torch.cat(want, -1)
+    assert got.shape == (B * 5, 27, 24) and torch.equal(got, want)
+    assert float(got.abs().max()) > 0
