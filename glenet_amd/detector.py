@@ -1,0 +1,154 @@
+"""Harness of the two-stage detector data flow (GLENet-VR = Voxel-RCNN, BASELINE config 3), our
+counterpart of the Python callers listed in SURVEY.md section 8c.  It exists to drive the hot-path
+kernels in the order and with the shapes the reference drives them; it is not a training system.
+
+  generate_anchors      AnchorGenerator.generate_anchors   (dense_heads/target_assigner/anchor_generator.py:17-61)
+  decode_boxes          ResidualCoder.decode_torch         (utils/box_coder_utils.py:46-77)
+  predicted_boxes       AnchorHeadTemplate.generate_predicted_boxes (dense_heads/anchor_head_template.py:233-279)
+  proposal_layer        RoIHeadTemplate.proposal_layer + class_agnostic_nms
+                        (roi_heads/roi_head_template.py:52-128, model_utils/model_nms_utils.py:6-62)
+  refine_boxes          RoIHeadTemplate.generate_predicted_boxes (roi_head_template.py:288-316)
+  VoxelRCNNFlow         Detector3DTemplate module order for GLENet_VR.yaml: MeanVFE -> VoxelBackBone8x
+                        -> HeightCompression -> BaseBEVBackbone -> AnchorHeadSingle -> VoxelRCNNHead
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from . import backbone as gb
+from . import dense_path as dp
+from . import roi_grid as rg
+from .pcdet_ops.iou3d_nms import iou3d_nms_utils
+
+
+def generate_anchors(anchor_range, grid_size_xy, anchor_sizes, anchor_rotations, anchor_bottom_heights,
+                     align_center=False, device="cpu"):
+    """One anchor set -> (nz, ny, nx, n_size, n_rot, 7) [x,y,z,dx,dy,dz,ry], z lifted to the box
+    centre; x/y positions cover the range end to end ((grid-1) intervals) unless align_center."""
+    gx, gy = grid_size_xy
+    r = anchor_range
+    if align_center:
+        sx, sy = (r[3] - r[0]) / gx, (r[4] - r[1]) / gy
+        ox, oy = sx / 2, sy / 2
+    else:
+        sx, sy = (r[3] - r[0]) / (gx - 1), (r[4] - r[1]) / (gy - 1)
+        ox = oy = 0
+    xs = torch.arange(r[0] + ox, r[3] + 1e-5, step=sx, dtype=torch.float32, device=device)
+    ys = torch.arange(r[1] + oy, r[4] + 1e-5, step=sy, dtype=torch.float32, device=device)
+    zs = torch.tensor(anchor_bottom_heights, dtype=torch.float32, device=device)
+    sizes = torch.tensor(anchor_sizes, dtype=torch.float32, device=device)
+    rots = torch.tensor(anchor_rotations, dtype=torch.float32, device=device)
+    nz, ny, nx, ns, nr = len(zs), len(ys), len(xs), len(sizes), len(rots)
+    a = torch.empty((nz, ny, nx, ns, nr, 7), dtype=torch.float32, device=device)
+    a[..., 0] = xs.view(1, 1, nx, 1, 1)
+    a[..., 1] = ys.view(1, ny, 1, 1, 1)
+    a[..., 2] = zs.view(nz, 1, 1, 1, 1)
+    a[..., 3:6] = sizes.view(1, 1, 1, ns, 1, 3)
+    a[..., 6] = rots.view(1, 1, 1, 1, nr)
+    a[..., 2] += a[..., 5] / 2
+    return a
+
+
+def decode_boxes(enc, anchors):
+    """Residual box code -> boxes: xy scaled by the anchor's BEV diagonal, z by its height, sizes
+    exponential, heading additive; extra code channels additive."""
+    xa, ya, za, dxa, dya, dza, ra = [anchors[..., i:i + 1] for i in range(7)]
+    xt, yt, zt, dxt, dyt, dzt, rt = [enc[..., i:i + 1] for i in range(7)]
+    diag = torch.sqrt(dxa ** 2 + dya ** 2)
+    out = [xt * diag + xa, yt * diag + ya, zt * dza + za, torch.exp(dxt) * dxa, torch.exp(dyt) * dya,
+           torch.exp(dzt) * dza, rt + ra]
+    if enc.shape[-1] > 7:
+        out.append(enc[..., 7:] + anchors[..., 7:])
+    return torch.cat(out, dim=-1)
+
+
+def predicted_boxes(cls_preds, box_preds, dir_cls_preds, anchors, dir_offset=0.78539, dir_limit_offset=0.0,
+                    num_dir_bins=2):
+    """Head maps (B,H,W,A*c) + anchors (.., 7) -> batch_cls_preds (B,N,cls), batch_box_preds (B,N,7)."""
+    B = cls_preds.shape[0]
+    anc = anchors.reshape(1, -1, anchors.shape[-1])
+    n = anc.shape[1]
+    boxes = decode_boxes(box_preds.reshape(B, n, -1), anc.expand(B, n, anc.shape[-1]))
+    if dir_cls_preds is not None:
+        labels = dir_cls_preds.reshape(B, n, -1).max(dim=-1)[1]
+        period = 2 * np.pi / num_dir_bins
+        rot = dp.limit_period(boxes[..., 6] - dir_offset, dir_limit_offset, period)
+        boxes[..., 6] = rot + dir_offset + period * labels.to(boxes.dtype)
+    return cls_preds.reshape(B, n, -1).float(), boxes
+
+
+def proposal_layer(batch_box_preds, batch_cls_preds, nms_pre_maxsize, nms_post_maxsize, nms_thresh,
+                   normalized=False):
+    """Per frame: class-max score, top-k, rotated NMS (device-side keep list), zero padding to
+    nms_post_maxsize.  Returns rois (B,P,7+), roi_scores (B,P), roi_labels (B,P) 1-based."""
+    B = batch_box_preds.shape[0]
+    if not normalized:
+        batch_cls_preds = torch.sigmoid(batch_cls_preds)
+    rois = batch_box_preds.new_zeros((B, nms_post_maxsize, batch_box_preds.shape[-1]))
+    scores = batch_box_preds.new_zeros((B, nms_post_maxsize))
+    labels = batch_box_preds.new_zeros((B, nms_post_maxsize), dtype=torch.long)
+    for b in range(B):
+        s, lab = batch_cls_preds[b].max(dim=1)
+        top, order = torch.topk(s, k=min(nms_pre_maxsize, s.shape[0]))
+        cand = batch_box_preds[b][order]
+        keep, _ = iou3d_nms_utils.nms_gpu(cand[:, 0:7], top, nms_thresh)
+        sel = order[keep[:nms_post_maxsize]]
+        k = sel.shape[0]
+        rois[b, :k], scores[b, :k], labels[b, :k] = batch_box_preds[b][sel], s[sel], lab[sel]
+    return rois, scores, labels + 1
+
+
+def refine_boxes(rois, box_preds):
+    """RoI-frame residuals -> boxes in the LiDAR frame: decode against the RoI moved to the origin,
+    rotate by the RoI heading, translate by its centre."""
+    B, R = rois.shape[0], rois.shape[1]
+    local = rois.clone().detach()
+    local[..., 0:3] = 0
+    boxes = decode_boxes(box_preds.view(B, R, -1), local).view(B * R, -1)
+    boxes = rg.rotate_points_along_z(boxes.unsqueeze(1), rois[..., 6].reshape(-1)).squeeze(1)
+    boxes[:, 0:3] += rois[..., 0:3].reshape(-1, 3)
+    return boxes.view(B, R, -1)
+
+
+class VoxelRCNNFlow(nn.Module):
+    """GLENet-VR inference data flow on one batch of stacked device points."""
+
+    POOL = {n: dict(mlps=[[32, 32]], query_ranges=[[4, 4, 4]], radii=[r], nsamples=[16])
+            for n, r in (("x_conv2", 0.4), ("x_conv3", 0.8), ("x_conv4", 1.6))}      # GLENet_VR.yaml:117-139
+
+    def __init__(self, cfg, num_point_features=4, nms_pre=2048, nms_post=100, nms_thresh=0.7):
+        super().__init__()
+        self.cfg = cfg
+        self.nms = (nms_pre, nms_post, nms_thresh)                                   # GLENet_VR.yaml:108-115
+        grid = gb.gv.grid_size_of(cfg["point_cloud_range"], cfg["voxel_size"])
+        self.vfe = gb.MeanVFE()
+        self.backbone_3d = gb.VoxelBackBone8x(num_point_features, grid)
+        self.map_to_bev = gb.HeightCompression()
+        self.backbone_2d = dp.BEVBackbone(256)
+        self.dense_head = dp.AnchorHead(self.backbone_2d.num_bev_features, num_class=1,
+                                        num_anchors_per_location=2)
+        self.roi_pool = rg.RoIGridPool(self.backbone_3d.backbone_channels, self.POOL, 6, cfg["voxel_size"],
+                                       cfg["point_cloud_range"])
+        self.roi_fc = dp.RoIFCStack(self.roi_pool.num_features, 6)
+        self.feature_map = (grid[0] // 8, grid[1] // 8)
+        self._anchors = None
+
+    def anchors(self, device):
+        if self._anchors is None or self._anchors.device != device:
+            self._anchors = generate_anchors(self.cfg["point_cloud_range"], self.feature_map, [[3.9, 1.6, 1.56]],
+                                             [0, 1.57], [-1.78], device=device)           # GLENet_VR.yaml:66-77
+        return self._anchors
+
+    def forward(self, points, batch_idx, batch_size):
+        bd = gb.voxelize_batch(points, batch_idx, batch_size, self.cfg, train=False)
+        bd = self.map_to_bev(self.backbone_3d(self.vfe(bd)))
+        bd = self.dense_head(self.backbone_2d(bd))
+        cls, boxes = predicted_boxes(bd["cls_preds"], bd["box_preds"], bd.get("dir_cls_preds"),
+                                     self.anchors(points.device))
+        rois, roi_scores, roi_labels = proposal_layer(boxes, cls, *self.nms)
+        pooled = self.roi_pool(rois, bd["multi_scale_3d_features"], bd["multi_scale_3d_strides"], batch_size)
+        rcnn_cls, rcnn_reg = self.roi_fc(pooled)
+        bd.update(rois=rois, roi_scores=roi_scores, roi_labels=roi_labels,
+                  batch_cls_preds=rcnn_cls.view(batch_size, -1, rcnn_cls.shape[-1]),
+                  batch_box_preds=refine_boxes(rois, rcnn_reg))
+        return bd

@@ -1,0 +1,45 @@
+"""Harness of the two-stage data flow: pure-torch pieces on CPU, the full flow on GPU."""
+import numpy as np
+import pytest
+import torch
+
+from glenet_amd import detector as det
+from glenet_amd import synth
+
+
+def test_anchor_layout_and_box_decode_cpu():
+    a = det.generate_anchors([0, -40, -3, 70.4, 40, 1], (176, 200), [[3.9, 1.6, 1.56]], [0, 1.57], [-1.78])
+    assert a.shape == (1, 200, 176, 1, 2, 7)                       # 70 400 anchors (GLENet_VR.yaml:63-73)
+    np.testing.assert_allclose(a[0, 0, 0, 0, 0].numpy(), [0, -40, -1.78 + 0.78, 3.9, 1.6, 1.56, 0], atol=1e-6)
+    np.testing.assert_allclose(a[0, -1, -1, 0, 1, :2].numpy(), [70.4, 40], atol=1e-4)
+    assert float(a[0, 0, 1, 0, 0, 0]) == pytest.approx(70.4 / 175)
+    enc = torch.zeros(3, 7)
+    anc = a.reshape(-1, 7)[:3]
+    assert torch.equal(det.decode_boxes(enc, anc), anc)             # zero residual = the anchor
+    enc[0] = torch.tensor([0.1, -0.2, 0.5, np.log(2.0), 0.0, np.log(0.5), 0.3])
+    d = det.decode_boxes(enc, anc)[0]
+    diag = np.sqrt(3.9 ** 2 + 1.6 ** 2)
+    np.testing.assert_allclose(d.numpy(), [anc[0, 0] + 0.1 * diag, anc[0, 1] - 0.2 * diag, anc[0, 2] + 0.5 * 1.56,
+                                           7.8, 1.6, 0.78, 0.3], rtol=1e-6, atol=1e-6)
+    rois = torch.tensor([[[10.0, 2.0, -1.0, 4.0, 2.0, 1.5, np.pi / 2]]])
+    out = det.refine_boxes(rois, torch.zeros(1, 7))
+    np.testing.assert_allclose(out[0, 0].numpy(), rois[0, 0].numpy(), atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_voxel_rcnn_flow_runs_on_the_kernels(dev):
+    torch.manual_seed(0)
+    K = synth.KITTI
+    frames = [synth.kitti_frame(70 + i, num_points=6000)[0] for i in range(2)]
+    pts = torch.from_numpy(np.concatenate(frames)).to(dev)
+    bidx = torch.from_numpy(np.concatenate([np.full(len(f), i, np.int32) for i, f in enumerate(frames)])).to(dev)
+    flow = det.VoxelRCNNFlow(K).to(dev).eval()
+    with torch.no_grad():
+        out = flow(pts, bidx, 2)
+    assert out["spatial_features_2d"].shape == (2, 256, 200, 176)
+    assert out["rois"].shape == (2, 100, 7) and out["batch_box_preds"].shape == (2, 100, 7)
+    assert out["batch_cls_preds"].shape == (2, 100, 1)
+    assert torch.isfinite(out["batch_box_preds"]).all() and torch.isfinite(out["batch_cls_preds"]).all()
+    # proposals are padded with zeros behind the kept ones and carry 1-based labels
+    n_kept = (out["rois"].abs().sum(-1) > 0).sum(1)
+    assert (n_kept > 0).all() and (out["roi_labels"] == 1).all()
