@@ -10,6 +10,7 @@
 // host and sweeps it serially (iou3d_nms.cpp:90-136).  Here only the upper triangle is
 // computed and the sweep runs on the device in one wave, 64 boxes per step.
 #include "glx_common.h"
+#include "glx_fill.h"
 
 struct P2 {
   float x, y;
@@ -321,7 +322,9 @@ extern "C" int glx_nms(const float* boxes_sorted, int N, float thresh, int norma
   GLX_REQUIRE(keep && num_out, "glx_nms: null output");
   hipStream_t st = (hipStream_t)stream;
   if (N == 0) {
-    GLX_HIP(hipMemsetAsync(num_out, 0, sizeof(int), st));
+    GlxFillJob job{num_out, sizeof(int), 0};
+    int frc = glx_fill_multi(&job, 1, st);
+    if (frc != GLX_OK) return frc;
     return GLX_OK;
   }
   GLX_REQUIRE(boxes_sorted, "glx_nms: null boxes");

@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "glx_common.h"
+#include "glx_fill.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -809,7 +810,11 @@ static int pack_weights(const float* W, int K, float* Wp, hipStream_t st) {
   using C = SconvCfg<CI, CO>;
   using S = SconvSplitCfg<CI, CO>;
   size_t pbytes = (size_t)K * (C::IMG + S::IMG) * sizeof(float);
-  GLX_HIP(hipMemsetAsync(Wp, 0, pbytes, st));   // padding dwords of both images
+  {   // padding dwords of both images
+    GlxFillJob job{Wp, pbytes, 0};
+    int frc = glx_fill_multi(&job, 1, st);
+    if (frc != GLX_OK) return frc;
+  }
   int nel = K * CI * CO;
   hipLaunchKernelGGL((k_pack_weights<CI, CO>), dim3(glx_divup(nel, 256)), dim3(256), 0, st, W, K,
                      Wp);
@@ -1228,8 +1233,8 @@ extern "C" int glx_sconv_wgrad(const float* in, int N_in, const float* grad_out,
   hipStream_t st = (hipStream_t)stream;
   long long nel_total = (long long)K * Cin * Cout;
   if (N_out == 0) {
-    GLX_HIP(hipMemsetAsync(dW, 0, nel_total * sizeof(float), st));
-    return GLX_OK;
+    GlxFillJob job{dW, (size_t)nel_total * sizeof(float), 0};
+    return glx_fill_multi(&job, 1, st);
   }
   size_t need = glx_sconv_wgrad_workspace_bytes(N_out, K, Cin, Cout) - 256;
   if (!workspace || workspace_bytes < need) {

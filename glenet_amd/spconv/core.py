@@ -262,6 +262,17 @@ def pack_weights(weight_kio):
     return wp
 
 
+_MFMA_CIN = (4, 8, 16, 32, 64, 128)
+
+
+def _cin_padding(cin):
+    """Input channel counts the MFMA kernels do not tile (e.g. Waymo's 5 point features,
+    waymo_dataset.yaml:55-59) are zero-padded to the next supported width: exact, differentiable
+    (F.pad) and far cheaper than the scalar fallback."""
+    target = next((c for c in _MFMA_CIN if c >= cin), None)
+    return 0 if target is None else target - cin
+
+
 def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rules=None, tag="fwd",
            scale=None, shift=None, relu=False, n_live=None):
     """out[j] = relu?((sum_k features[nbr[j,k]] @ weight_kio[k] + bias) * scale + shift)."""
@@ -493,6 +504,11 @@ class SparseConvolution(SparseModule):
         assert isinstance(x, SparseConvTensor)
         K = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
         w = self.weight.reshape(K, self.in_channels, self.out_channels)
+        x_features = x.features
+        pad = _cin_padding(self.in_channels)
+        if pad:
+            w = torch.nn.functional.pad(w, (0, 0, 0, pad))
+            x_features = torch.nn.functional.pad(x_features, (0, pad))
         rs = self._rules(x)
         if rs.ready is not None:       # built on another stream: order this stream after it
             torch.cuda.current_stream(x.indices.device).wait_event(rs.ready)
@@ -502,12 +518,12 @@ class SparseConvolution(SparseModule):
                 nbr, order, n_out = rs.inverse_table(), rs.tile_order_in, rs.N_in
             else:
                 nbr, order, n_out = rs.nbr, rs.tile_order_out, rs.N_out
-            feats = _sconv(x.features.contiguous().float(), w.detach().contiguous(), self.bias, nbr,
+            feats = _sconv(x_features.contiguous().float(), w.detach().contiguous(), self.bias, nbr,
                            order, n_out, packed=self._packed_weight(w), rules=rs, scale=scale,
                            shift=shift, relu=fused_relu,
                            n_live=rs.count_in if self.inverse else rs.count_out)
         else:
-            feats = SparseConvFunction.apply(x.features, w, self.bias, rs, self.inverse,
+            feats = SparseConvFunction.apply(x_features, w, self.bias, rs, self.inverse,
                                              self._packed_weight(w))
         if self.inverse:
             out = SparseConvTensor(feats, rs.in_indices, rs.in_spatial_shape, x.batch_size,

@@ -239,6 +239,29 @@ def test_conv_backward_conv_out_geometry(dev):
     np.testing.assert_allclose(conv.weight.grad.reshape(3, 64, 128).cpu().numpy(), dw, rtol=1e-3, atol=2e-3)
 
 
+def test_conv_with_five_input_channels_is_padded_not_scalar(dev):
+    """Waymo point features (C = 5): forward and both gradients equal the oracle."""
+    rng = np.random.default_rng(31)
+    shape = (7, 20, 18)
+    idx, f = _rand_sparse(rng, 1, *shape, 0.12, 5)
+    w = (rng.normal(size=(27, 5, 16)) / np.sqrt(27 * 5)).astype(np.float32)
+    rules = oracle.build_rules(idx, shape, 3, subm=True)
+    conv = sp.SubMConv3d(5, 16, 3, padding=1, bias=False).to(dev)
+    g = rng.normal(size=(len(idx), 16)).astype(np.float32)
+    ref = oracle.sconv_forward(f, w, rules)
+    din, dw = oracle.sconv_backward(f, w, g, rules)
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(w).reshape(3, 3, 3, 5, 16))
+    x = _gpu_tensor(idx, f, shape, 1, dev)
+    x.features.requires_grad_(True)
+    out = conv(x)
+    np.testing.assert_allclose(out.features.detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+    out.features.backward(torch.from_numpy(g).to(dev))
+    assert x.features.grad.shape == (len(idx), 5) and conv.weight.grad.shape == (3, 3, 3, 5, 16)
+    np.testing.assert_allclose(x.features.grad.cpu().numpy(), din, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(conv.weight.grad.reshape(27, 5, 16).cpu().numpy(), dw, rtol=1e-3, atol=2e-3)
+
+
 def test_dense_and_empty(dev):
     rng = np.random.default_rng(3)
     shape = (2, 20, 18)
