@@ -181,3 +181,22 @@ def test_backbone_state_dict_names_match_reference():
     assert tuple(m.state_dict()["conv4.0.0.weight"].shape) == (3, 3, 3, 64, 64)
     assert tuple(m.state_dict()["conv_out.0.weight"].shape) == (3, 1, 1, 64, 128)
     assert m.sparse_shape == [41, 1600, 1408]
+
+
+def test_device_data_processor_matches_oracle_on_the_same_point_order(dev):
+    """mask -> shuffle -> voxelize on the device: the voxels equal the oracle's voxelization of the
+    points in the order the device step produced (first-seen semantics depend on it)."""
+    from glenet_amd.data_pipeline import DeviceDataProcessor, mask_points_by_range
+    frames = [synth.kitti_frame(90 + i, num_points=7000)[0] for i in range(2)]
+    frames[0][:50, 0] = -5.0                                       # points outside the x range
+    pts = torch.from_numpy(np.concatenate(frames)).to(dev)
+    bidx = torch.from_numpy(np.concatenate([np.full(len(f), i, np.int32) for i, f in enumerate(frames)])).to(dev)
+    proc = DeviceDataProcessor(K, training=True, shuffle=True, seed=5)
+    bd = proc(pts, bidx, 2)
+    p, b = bd["points"].cpu().numpy(), bd["point_batch_idx"].cpu().numpy()
+    assert len(p) == int(mask_points_by_range(pts, K["point_cloud_range"]).sum()) and (np.diff(b) >= 0).all()
+    assert not np.array_equal(p[b == 0], frames[0][frames[0][:, 0] >= 0][:len(p[b == 0])])   # shuffled
+    v, c, n = oracle.voxelize_hard_batch([p[b == i] for i in range(2)], K["voxel_size"],
+                                         K["point_cloud_range"], 5, 16000)
+    assert np.array_equal(bd["voxel_coords"].cpu().numpy(), c)
+    assert np.array_equal(bd["voxels"].cpu().numpy(), v) and np.array_equal(bd["voxel_num_points"].cpu().numpy(), n)
