@@ -321,35 +321,65 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
     reinterpret_cast<f32x4*>(s_acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- neighbour row of every (slot, offset) straight into registers, then compaction
-  int nb[SC_MAXK];
-  if (tid < TR) {
+  if constexpr (TR == 64) {
+    // one wave spans the whole tile (lane = row slot): every wave compacts a share of the
+    // offsets on its own -- no cross-wave prefix, 1/NW of the serial ballot work per wave
+    const int prow = row0 + lane;
+    const int lrow = (prow < N_out) ? (tile_order ? tile_order[prow] : prow) : -1;
+    const int* np = nbr + (long long)(lrow < 0 ? 0 : lrow) * K;
+    constexpr int KPW = (SC_MAXK + T::NW - 1) / T::NW;
+    int nbv[KPW];
 #pragma unroll
-    for (int k = 0; k < SC_MAXK; ++k)
-      nb[k] = (k < K && my_row >= 0) ? nbr[(long long)my_row * K + k] : -1;
-#pragma unroll
-    for (int k = 0; k < SC_MAXK; ++k) {
-      unsigned long long b = __ballot(nb[k] >= 0);
-      if (lane == 0) s_wcnt[wave * 32 + k] = __popcll(b);
+    for (int u = 0; u < KPW; ++u) {
+      const int kq = wave + u * T::NW;
+      nbv[u] = np[kq < K ? kq : 0];                     // branch-free: all loads in flight
     }
-  }
-  __syncthreads();
-  if (tid < TR) {
 #pragma unroll
-    for (int k = 0; k < SC_MAXK; ++k) {
-      const bool v = nb[k] >= 0;
-      unsigned long long b = __ballot(v);
-      int base = 0;
-#pragma unroll
-      for (int w = 0; w < LW; ++w) base += (w < wave) ? s_wcnt[w * 32 + k] : 0;
-      if (v) {
-        int pos = k * TR + base + __popcll(b & ((1ull << lane) - 1ull));
-        s_pin[pos] = nb[k];
-        s_pslot[pos] = (unsigned char)tid;
+    for (int u = 0; u < KPW; ++u) {
+      const int kq = wave + u * T::NW;
+      if (kq < SC_MAXK) {
+        const bool v = kq < K && lrow >= 0 && nbv[u] >= 0;
+        const unsigned long long bal = __ballot(v);
+        if (v) {
+          const int pos = kq * TR + __popcll(bal & ((1ull << lane) - 1ull));
+          s_pin[pos] = nbv[u];
+          s_pslot[pos] = (unsigned char)lane;
+        }
+        if (lane == 0) s_cnt[kq] = __popcll(bal);
       }
-      if (wave == LW - 1 && lane == 0) s_cnt[k] = base + __popcll(b);
     }
+    __syncthreads();
+  } else {
+    int nb[SC_MAXK];
+    if (tid < TR) {
+#pragma unroll
+      for (int k = 0; k < SC_MAXK; ++k)
+        nb[k] = (k < K && my_row >= 0) ? nbr[(long long)my_row * K + k] : -1;
+#pragma unroll
+      for (int k = 0; k < SC_MAXK; ++k) {
+        unsigned long long b = __ballot(nb[k] >= 0);
+        if (lane == 0) s_wcnt[wave * 32 + k] = __popcll(b);
+      }
+    }
+    __syncthreads();
+    if (tid < TR) {
+#pragma unroll
+      for (int k = 0; k < SC_MAXK; ++k) {
+        const bool v = nb[k] >= 0;
+        unsigned long long b = __ballot(v);
+        int base = 0;
+#pragma unroll
+        for (int w = 0; w < LW; ++w) base += (w < wave) ? s_wcnt[w * 32 + k] : 0;
+        if (v) {
+          int pos = k * TR + base + __popcll(b & ((1ull << lane) - 1ull));
+          s_pin[pos] = nb[k];
+          s_pslot[pos] = (unsigned char)tid;
+        }
+        if (wave == LW - 1 && lane == 0) s_cnt[k] = base + __popcll(b);
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   unsigned mask = 0;
 #pragma unroll
   for (int k = 0; k < SC_MAXK; ++k)
@@ -503,7 +533,7 @@ struct SconvGemm {
   static_assert(LW <= NW && TR <= 256, "bad tile");
 };
 
-template <int CIN, int COUT, int TR_, int NW_, int WPG_>
+template <int CIN, int COUT, int TR_, int NW_, int WPG_, bool TRACE = false>
 __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
     const float* __restrict__ in, const float* __restrict__ Wp, SconvEpilogue ep,
     const int* __restrict__ nbr, const int* __restrict__ tile_order, int N_out, int K,
@@ -528,6 +558,11 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
   const int row0 = blockIdx.x * TR;
   const int grp = wave / T::WPG;
   const int tile0 = (wave % T::WPG) * T::TPW;
+  // TRACE build: tph = issue loads | multiply | barrier 1 | wait + stage store | barrier 2 (cycles)
+  long long t_start = 0, t_loop = 0;
+  long long tph[5] = {0, 0, 0, 0, 0};
+  int my_chunks = 0, n_steps = 0;
+  if constexpr (TRACE) t_start = wall_clock64();
 
   // ---- tile rows, zero accumulators, rule compaction (as in k_sconv_mfma)
   int my_row = -1;
@@ -538,36 +573,66 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
   }
   for (int i = tid; i < TR * ACC_LD / 4; i += THREADS)
     reinterpret_cast<f32x4*>(s_acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int nb[SC_MAXK];
-  if (tid < TR) {
-    const int* np = nbr + (long long)(my_row < 0 ? 0 : my_row) * K;
+  if constexpr (TR == 64) {
+    // one wave spans the whole tile (lane = row slot), so every wave compacts a share of the
+    // offsets on its own: no cross-wave prefix, 1/NW of the serial ballot work per wave
+    const int prow = row0 + lane;
+    const int lrow = (prow < N_out) ? (tile_order ? tile_order[prow] : prow) : -1;
+    const int* np = nbr + (long long)(lrow < 0 ? 0 : lrow) * K;
+    constexpr int KPW = (SC_MAXK + T::NW - 1) / T::NW;
+    int nbv[KPW];
 #pragma unroll
-    for (int k = 0; k < SC_MAXK; ++k) nb[k] = np[k < K ? k : K - 1];   // branch-free: 27 loads in flight
-#pragma unroll
-    for (int k = 0; k < SC_MAXK; ++k) {
-      if (k >= K || my_row < 0) nb[k] = -1;
-      unsigned long long b = __ballot(nb[k] >= 0);
-      if (lane == 0) s_wcnt[wave * 32 + k] = __popcll(b);
+    for (int u = 0; u < KPW; ++u) {
+      const int k = wave + u * T::NW;
+      nbv[u] = np[k < K ? k : 0];                       // branch-free: all loads in flight
     }
-  }
-  __syncthreads();
-  if (tid < TR) {
 #pragma unroll
-    for (int k = 0; k < SC_MAXK; ++k) {
-      const bool v = nb[k] >= 0;
-      unsigned long long b = __ballot(v);
-      int base = 0;
-#pragma unroll
-      for (int w = 0; w < LW; ++w) base += (w < wave) ? s_wcnt[w * 32 + k] : 0;
-      if (v) {
-        int pos = k * TR + base + __popcll(b & ((1ull << lane) - 1ull));
-        s_pin[pos] = nb[k];
-        s_pslot[pos] = (unsigned char)tid;
+    for (int u = 0; u < KPW; ++u) {
+      const int k = wave + u * T::NW;
+      if (k < SC_MAXK) {
+        const bool v = k < K && lrow >= 0 && nbv[u] >= 0;
+        const unsigned long long bal = __ballot(v);
+        if (v) {
+          const int pos = k * TR + __popcll(bal & ((1ull << lane) - 1ull));
+          s_pin[pos] = nbv[u];
+          s_pslot[pos] = (unsigned char)lane;
+        }
+        if (lane == 0) s_cnt[k] = __popcll(bal);
       }
-      if (wave == LW - 1 && lane == 0) s_cnt[k] = base + __popcll(b);
     }
+    __syncthreads();
+  } else {
+    int nb[SC_MAXK];
+    if (tid < TR) {
+      const int* np = nbr + (long long)(my_row < 0 ? 0 : my_row) * K;
+#pragma unroll
+      for (int k = 0; k < SC_MAXK; ++k) nb[k] = np[k < K ? k : K - 1];   // branch-free: 27 loads in flight
+#pragma unroll
+      for (int k = 0; k < SC_MAXK; ++k) {
+        if (k >= K || my_row < 0) nb[k] = -1;
+        unsigned long long b = __ballot(nb[k] >= 0);
+        if (lane == 0) s_wcnt[wave * 32 + k] = __popcll(b);
+      }
+    }
+    __syncthreads();
+    if (tid < TR) {
+#pragma unroll
+      for (int k = 0; k < SC_MAXK; ++k) {
+        const bool v = nb[k] >= 0;
+        unsigned long long b = __ballot(v);
+        int base = 0;
+#pragma unroll
+        for (int w = 0; w < LW; ++w) base += (w < wave) ? s_wcnt[w * 32 + k] : 0;
+        if (v) {
+          int pos = k * TR + base + __popcll(b & ((1ull << lane) - 1ull));
+          s_pin[pos] = nb[k];
+          s_pslot[pos] = (unsigned char)tid;
+        }
+        if (wave == LW - 1 && lane == 0) s_cnt[k] = base + __popcll(b);
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   unsigned mask = 0;
 #pragma unroll
   for (int k = 0; k < SC_MAXK; ++k)
@@ -622,7 +687,10 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
     GM_STORE_W();
     GM_STORE_A();
     __syncthreads();
+    if constexpr (TRACE) t_loop = wall_clock64();
     while (true) {
+      long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+      if constexpr (TRACE) c0 = clock64();
       // ---- what comes next: another panel of this offset, or the first panel of the next one
       bool has_next = true, new_w = false;
       int kn = k, pbn = pb + T::AP, cntn = cnt;
@@ -641,8 +709,10 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
         GM_LOAD_A(kn, pbn, cntn);
         if (new_w) GM_LOAD_W(kn);
       }
+      if constexpr (TRACE) c1 = clock64();
       // ---- multiply this wave's chunk of the current panel by its column tiles
       const int pbase = pb + grp * 16;
+      if constexpr (TRACE) { my_chunks += pbase < cnt; ++n_steps; }
       if (pbase < cnt) {   // wave-uniform
         const float* arow = s_a + (grp * 16 + r) * T::A_LD + q * CQ;
         float Am[CQ];
@@ -686,11 +756,24 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
           }
         }
       }
-      if (!has_next) break;
+      if constexpr (TRACE) c2 = clock64();
+      if (!has_next) {
+        if constexpr (TRACE) { tph[0] += c1 - c0; tph[1] += c2 - c1; }
+        break;
+      }
       __syncthreads();   // everyone is done reading the panel and the weight image
+      if constexpr (TRACE) c3 = clock64();
       GM_STORE_A();
       if (new_w) GM_STORE_W();
+      if constexpr (TRACE) {
+        __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) lgkmcnt(0): stores issued and landed
+        c4 = clock64();
+      }
       __syncthreads();
+      if constexpr (TRACE) {
+        long long c5 = clock64();
+        tph[0] += c1 - c0; tph[1] += c2 - c1; tph[2] += c3 - c2; tph[3] += c4 - c3; tph[4] += c5 - c4;
+      }
       k = kn; pb = pbn; cnt = cntn;
     }
   }
@@ -715,6 +798,25 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
       v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
     }
     *reinterpret_cast<f32x4*>(out + (long long)orow * COUT + 4 * c4) = v;
+  }
+  if constexpr (TRACE) {
+    __syncthreads();
+    constexpr int REC = 4 + 8 * T::NW;
+    long long* tr = ep.trace + (long long)REC * blockIdx.x;
+    if (tid == 0) {
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      int chunks = 0;
+      for (int kk = 0; kk < K; ++kk) chunks += (s_cnt[kk] + 15) >> 4;
+      tr[0] = t_start; tr[1] = wall_clock64();
+      tr[2] = ((long long)xcc << 32) | hw; tr[3] = chunks;
+    }
+    if (lane == 0) {
+      long long* w = tr + 4 + 8 * wave;
+      w[0] = tph[0]; w[1] = tph[1]; w[2] = tph[2]; w[3] = tph[3]; w[4] = tph[4];
+      w[5] = my_chunks; w[6] = (t_loop - t_start) * 22; w[7] = n_steps;   // setup in ~cycles (100 MHz x 22)
+    }
   }
 }
 
@@ -908,7 +1010,18 @@ static int launch_gemm(const float* in, const float* Wp, const SconvEpilogue& ep
     }
     const float* Wsplit = Wp + (size_t)K * SconvCfg<CI, CO>::IMG;   // second image of the packed buffer
     int nblocks = glx_divup(N_out, TR);
-    if (g_prof_start && g_prof_stop) {
+    if (ep.trace) {
+      if constexpr (CI == 64 && CO == 64 && TR == 64 && NW == 8) {
+        auto tkern = k_sconv_gemm<CI, CO, TR, NW, WPG, true>;
+        GLX_HIP(hipFuncSetAttribute((const void*)tkern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        hipLaunchKernelGGL(tkern, dim3(nblocks), dim3(T::THREADS), lds, st, in, Wsplit, ep, nbr,
+                           tile_order, N_out, K, out);
+      } else {
+        glx_set_error("sparse conv GEMM trace build exists for <64,64,64,8> only");
+        return GLX_EINVAL;
+      }
+    } else if (g_prof_start && g_prof_stop) {
       hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(T::THREADS), lds, st, g_prof_start,
                             g_prof_stop, 0, in, Wsplit, ep, nbr, tile_order, N_out, K, out);
       g_prof_start = g_prof_stop = nullptr;
