@@ -147,9 +147,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     rank, local_rank, world = gdist.env_world()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    gdist.init("nccl", device=dev)
+    # one process per GPU; GLX_DIST_BACKEND=gloo + fewer GPUs than ranks is a plumbing test mode
+    # (ranks share a device, collectives on the host) -- never used for reported numbers
+    backend = os.environ.get("GLX_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    gdist.init(backend, device=dev)
 
     K = synth.KITTI
     frame_ids = gdist.frames_for_rank(rank, world, FRAMES_PER_GPU)

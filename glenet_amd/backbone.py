@@ -268,6 +268,22 @@ class StaticFramePipeline:
         self._inflight.append(ev)
         return self.out
 
+    def run_checked(self, points, batch_idx):
+        """load + replay + verdict for one batch; when a capacity was exceeded (or max_voxels
+        dropped cells) the batch is recomputed on the exact-shape path, so the result is always
+        right.  Costs one host synchronisation per batch -- the throughput loop uses replay()
+        and check() every so often instead."""
+        self.load(points, batch_idx)
+        out = self.replay() if self.graph is not None else self.enqueue()
+        torch.cuda.current_stream(self.points.device).synchronize()
+        try:
+            self.check()
+            return out
+        except RuntimeError:
+            with torch.no_grad():
+                bd = voxelize_batch(points, batch_idx, self.B, self.cfg, train=self.train_cap)
+                return self.hc(self.model(self.vfe(bd)))
+
     def check(self):
         spconv.core.check_static(self.out["rule_plan"], self.out["voxel_index"])
 

@@ -40,11 +40,18 @@ def fence(device=None):
         torch.cuda.synchronize(device)
 
 
+def _coll_device(device):
+    """Collectives run on device tensors under RCCL and on host tensors under gloo."""
+    if device is None or dist.get_backend() == "gloo":
+        return "cpu"
+    return device
+
+
 def reduce_max(value, device=None):
     """MAX over ranks of a python float (the slowest rank's time is the job's time)."""
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    t = torch.tensor([value], dtype=torch.float64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -52,7 +59,7 @@ def reduce_max(value, device=None):
 def reduce_sum_int(value, device=None):
     if not (dist.is_available() and dist.is_initialized()):
         return int(value)
-    t = torch.tensor([value], dtype=torch.int64, device=device if device is not None else "cpu")
+    t = torch.tensor([value], dtype=torch.int64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
 

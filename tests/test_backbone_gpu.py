@@ -151,6 +151,26 @@ def test_two_pipelines_replay_concurrently(dev):
             assert torch.equal(pipes[i].out["spatial_features"], refs[(i + it) % 2]), (it, i)
 
 
+def test_run_checked_falls_back_when_a_capacity_is_exceeded(dev):
+    grid = oracle.grid_size_of(K["point_cloud_range"], K["voxel_size"])
+    model = gb.SparseBackbone8x(4, grid).eval().to(dev)
+    _condition(model)
+    small, _ = _frames_on(dev, 1, seed0=81, num_points=1500), None
+    big = _frames_on(dev, 1, seed0=82, num_points=9000)
+    pipe = gb.StaticFramePipeline(model, K, 1, 9000, 4)
+    pipe.calibrate(*small)                       # capacities sized for the small cloud
+    pipe.load(*small)
+    pipe.capture()
+    with torch.no_grad():
+        ref = gb.HeightCompression()(model(gb.MeanVFE()(gb.voxelize_batch(*big, 1, K))))["spatial_features"]
+    out = pipe.run_checked(*big)                 # overflows -> exact-shape path
+    assert torch.equal(out["spatial_features"], ref)
+    with torch.no_grad():
+        ref_s = gb.HeightCompression()(model(gb.MeanVFE()(gb.voxelize_batch(*small, 1, K))))["spatial_features"]
+    out = pipe.run_checked(*small)               # fits -> graph result
+    assert torch.equal(out["spatial_features"], ref_s)
+
+
 def test_static_pipeline_reports_capacity_overflow(dev):
     grid = oracle.grid_size_of(K["point_cloud_range"], K["voxel_size"])
     model = gb.SparseBackbone8x(4, grid).eval().to(dev)

@@ -1,10 +1,15 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/dbg; mkdir -p $OUT; cd $R
-timeout 900 python -m pytest tests/test_sparse_gpu.py tests/test_backbone_gpu.py -x -q -m gpu 2>&1 | tail -2
-timeout 600 python tools/sconv_sweep.py -1 2>&1 | grep -v amdgpu.ids
-timeout 600 python bench.py --no-cpu-baseline --no-train > $OUT/bench_full.json 2> $OUT/bench_full.err; echo "rc=$?"
+GLX_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 100 --warmup 10 > $OUT/bench_2rank.json 2> $OUT/bench_2rank.err; echo "2-rank rc=$?"
 python - <<'PY'
 import json
-b=json.load(open("gpurun_out/dbg/bench_full.json"))
-print(b["value"], b["ms_per_step"], b["roofline"]["kernel"], b["roofline"]["frac"], b["roofline"]["all_sparse_conv"]["ms_per_step"], b["roofline"]["all_sparse_conv"]["frac"])
+for l in open("gpurun_out/dbg/bench_2rank.json"):
+    if l.startswith("{"):
+        b=json.loads(l); print(b["n_gpus"], b["value"], b["ms_per_step"], b["config"]["parallelism"], b.get("cpu_baseline"), b["fwd_bwd"])
+PY
+tail -4 $OUT/bench_2rank.err | grep -v amdgpu.ids | cut -c1-200
+timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "default rc=$?"
+python - <<'PY'
+import json
+b=json.load(open("gpurun_out/dbg/bench_default.json")); print(b["value"], b["ms_per_step"], b["cpu_baseline"], b["fwd_bwd"]["frames_per_s"])
 PY
