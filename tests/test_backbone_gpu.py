@@ -220,3 +220,28 @@ def test_device_data_processor_matches_oracle_on_the_same_point_order(dev):
                                          K["point_cloud_range"], 5, 16000)
     assert np.array_equal(bd["voxel_coords"].cpu().numpy(), c)
     assert np.array_equal(bd["voxels"].cpu().numpy(), v) and np.array_equal(bd["voxel_num_points"].cpu().numpy(), n)
+
+
+def test_waymo_shaped_residual_backbone_matches_oracle(dev):
+    """Config-5 shape: 5 point features (zero-padded to 8 input channels on the MFMA path), Waymo
+    grid [41,1504,1504], VoxelResBackBone8x (biased residual blocks), one frame of 30 k points."""
+    W = synth.WAYMO
+    torch.manual_seed(6)
+    grid = oracle.grid_size_of(W["point_cloud_range"], W["voxel_size"])
+    model = gb.SparseBackbone8x(5, grid, residual=True).eval()
+    _condition(model)
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    frame = synth.waymo_frame(3, num_points=30000)[0]
+    v, c, n = oracle.voxelize_hard_batch([frame], W["voxel_size"], W["point_cloud_range"], 5, 150000)
+    ref = ob.backbone_forward(sd, oracle.mean_vfe(v, n), c, model.sparse_shape, residual=True)
+    model = model.to(dev)
+    pts = torch.from_numpy(frame).to(dev)
+    bidx = torch.zeros(len(frame), dtype=torch.int32, device=dev)
+    with torch.no_grad():
+        bd = gb.voxelize_batch(pts, bidx, 1, W, train=False)
+        assert np.array_equal(bd["voxel_coords"].cpu().numpy(), c)
+        bd = model(gb.MeanVFE()(bd))
+    out = bd["encoded_spconv_tensor"]
+    assert np.array_equal(out.indices.cpu().numpy(), ref["out"].indices)
+    r = ref["out"].features
+    np.testing.assert_allclose(out.features.cpu().numpy(), r, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(r).max()))
