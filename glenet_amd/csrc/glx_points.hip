@@ -508,3 +508,226 @@ extern "C" int glx_points_in_boxes_mask(const float* boxes, int N, const float* 
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
+
+// ====================================================================================
+// PV-RCNN set-abstraction operators
+// ====================================================================================
+
+// Farthest point sampling, one block of 1024 threads per frame.  Every thread keeps its points
+// (k = t, t+1024, ...: the assignment of the reference kernel, which fixes the tie rule) and their
+// running min-distances in REGISTERS for clouds up to 16 K points (no global traffic inside the
+// m-1 dependent iterations; the reference re-reads xyz and temp from global memory each time);
+// larger clouds fall back to the caller's temp buffer.  Reduction: (value, thread) pairs, greater
+// value wins, equal values keep the lower thread -- the net effect of the reference's tree
+// (__update keeps idx1 on ties, sampling_gpu.cu:16-21).  The winner publishes its coordinates
+// through LDS, so the next iteration starts without a global load.
+#define FPS_THREADS 1024
+#define FPS_DPT 16
+
+struct FpsBest {
+  float v;
+  int t;   // owning thread
+  int i;   // point index inside the frame
+};
+
+__device__ __forceinline__ FpsBest fps_pick(FpsBest a, FpsBest b) {
+  return (b.v > a.v || (b.v == a.v && b.t < a.t)) ? b : a;
+}
+
+template <bool REGS>
+__global__ __launch_bounds__(FPS_THREADS) void k_stack_fps(
+    int B, const float* __restrict__ xyz, const int* __restrict__ xyz_batch_cnt,
+    float* __restrict__ temp, const int* __restrict__ num_sampled, int* __restrict__ idxs) {
+  __shared__ float s_v[FPS_THREADS / 64];
+  __shared__ int s_t[FPS_THREADS / 64], s_i[FPS_THREADS / 64];
+  __shared__ float s_pt[3];
+  __shared__ int s_old;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  long long start = 0, ostart = 0;
+  for (int k = 0; k < b; ++k) { start += xyz_batch_cnt[k]; ostart += num_sampled[k]; }
+  const float* X = xyz + start * 3;
+  float* T = temp + start;
+  int* O = idxs + ostart;
+  const int n = xyz_batch_cnt[b], m = num_sampled[b];
+  if (m <= 0 || n <= 0) return;
+  float px[FPS_DPT], py[FPS_DPT], pz[FPS_DPT], pt[FPS_DPT];
+  if (REGS) {
+#pragma unroll
+    for (int j = 0; j < FPS_DPT; ++j) {
+      int k = tid + j * FPS_THREADS;
+      bool ok = k < n;
+      px[j] = ok ? X[k * 3] : 0.f; py[j] = ok ? X[k * 3 + 1] : 0.f; pz[j] = ok ? X[k * 3 + 2] : 0.f;
+      pt[j] = ok ? T[k] : -2.f;   // never selected
+    }
+  }
+  if (tid == 0) {
+    O[0] = (int)start;
+    s_pt[0] = X[0]; s_pt[1] = X[1]; s_pt[2] = X[2];
+  }
+  __syncthreads();
+  for (int s = 1; s < m; ++s) {
+    const float x1 = s_pt[0], y1 = s_pt[1], z1 = s_pt[2];
+    FpsBest best{-1.f, tid, 0};
+    if (REGS) {
+#pragma unroll
+      for (int j = 0; j < FPS_DPT; ++j) {
+        float dx = px[j] - x1, dy = py[j] - y1, dz = pz[j] - z1;
+        float d = dx * dx + dy * dy + dz * dz;
+        float d2 = fminf(d, pt[j]);
+        if (pt[j] >= 0.f) pt[j] = d2; else d2 = -2.f;
+        if (d2 > best.v) { best.v = d2; best.i = tid + j * FPS_THREADS; }
+      }
+    } else {
+      for (int k = tid; k < n; k += FPS_THREADS) {
+        float dx = X[k * 3] - x1, dy = X[k * 3 + 1] - y1, dz = X[k * 3 + 2] - z1;
+        float d = dx * dx + dy * dy + dz * dz;
+        float d2 = fminf(d, T[k]);
+        T[k] = d2;
+        if (d2 > best.v) { best.v = d2; best.i = k; }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      FpsBest other{__shfl_xor(best.v, o, 64), __shfl_xor(best.t, o, 64), __shfl_xor(best.i, o, 64)};
+      best = fps_pick(best, other);
+    }
+    if (lane == 0) { s_v[wave] = best.v; s_t[wave] = best.t; s_i[wave] = best.i; }
+    __syncthreads();
+    if (wave == 0) {
+      FpsBest w = lane < FPS_THREADS / 64 ? FpsBest{s_v[lane], s_t[lane], s_i[lane]}
+                                          : FpsBest{-3.f, 1 << 30, 0};
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        FpsBest other{__shfl_xor(w.v, o, 64), __shfl_xor(w.t, o, 64), __shfl_xor(w.i, o, 64)};
+        w = fps_pick(w, other);
+      }
+      if (lane == 0) {
+        s_old = w.i;
+        O[s] = w.i + (int)start;
+        s_pt[0] = X[w.i * 3]; s_pt[1] = X[w.i * 3 + 1]; s_pt[2] = X[w.i * 3 + 2];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int glx_stack_fps(const float* xyz, const int32_t* xyz_batch_cnt, int B, int max_points,
+                             const int32_t* num_sampled, float* temp, int32_t* idxs, void* stream) {
+  if (B <= 0) return GLX_OK;
+  GLX_REQUIRE(xyz && xyz_batch_cnt && num_sampled && temp && idxs, "glx_stack_fps: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (max_points > 0 && max_points <= FPS_THREADS * FPS_DPT) {
+    hipLaunchKernelGGL((k_stack_fps<true>), dim3(B), dim3(FPS_THREADS), 0, st, B, xyz, xyz_batch_cnt,
+                       temp, num_sampled, idxs);
+  } else {
+    hipLaunchKernelGGL((k_stack_fps<false>), dim3(B), dim3(FPS_THREADS), 0, st, B, xyz,
+                       xyz_batch_cnt, temp, num_sampled, idxs);
+  }
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// three nearest known points of the same frame: grid (blocks over the frame's queries, frame);
+// the frame's known points stream through LDS in tiles shared by the 256 queries of the block.
+#define TNN_THREADS 256
+#define TNN_TILE 1024
+
+__global__ __launch_bounds__(TNN_THREADS) void k_three_nn(
+    int B, const float* __restrict__ unknown, const int* __restrict__ unknown_batch_cnt,
+    const float* __restrict__ known, const int* __restrict__ known_batch_cnt,
+    float* __restrict__ dist2, int* __restrict__ idx) {
+  __shared__ float s_k[TNN_TILE * 3];
+  const int b = blockIdx.y;
+  long long ustart = 0, kstart = 0;
+  for (int k = 0; k < b; ++k) { ustart += unknown_batch_cnt[k]; kstart += known_batch_cnt[k]; }
+  const int nu = unknown_batch_cnt[b], nk = known_batch_cnt[b];
+  if ((long long)blockIdx.x * TNN_THREADS >= nu) return;   // block-uniform
+  const int q = blockIdx.x * TNN_THREADS + threadIdx.x;
+  const bool act = q < nu;
+  const float* up = unknown + (ustart + (act ? q : 0)) * 3;
+  const float ux = up[0], uy = up[1], uz = up[2];
+  double b1 = 1e40, b2 = 1e40, b3 = 1e40;
+  int i1 = 0, i2 = 0, i3 = 0;
+  const float* Kp = known + kstart * 3;
+  for (int t0 = 0; t0 < nk; t0 += TNN_TILE) {
+    const int tn = min(TNN_TILE, nk - t0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < tn * 3; e += TNN_THREADS) s_k[e] = Kp[(long long)t0 * 3 + e];
+    __syncthreads();
+    if (act) {
+      for (int k = 0; k < tn; ++k) {
+        float x = s_k[k * 3], y = s_k[k * 3 + 1], z = s_k[k * 3 + 2];
+        float d = (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
+        if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = t0 + k; }
+        else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = t0 + k; }
+        else if (d < b3) { b3 = d; i3 = t0 + k; }
+      }
+    }
+  }
+  if (act) {
+    float* dp = dist2 + (ustart + q) * 3;
+    int* ip = idx + (ustart + q) * 3;
+    dp[0] = (float)b1; dp[1] = (float)b2; dp[2] = (float)b3;
+    ip[0] = i1 + (int)kstart; ip[1] = i2 + (int)kstart; ip[2] = i3 + (int)kstart;
+  }
+}
+
+extern "C" int glx_three_nn(int B, int N, int max_queries_per_frame, const float* unknown,
+                            const int32_t* unknown_batch_cnt, const float* known,
+                            const int32_t* known_batch_cnt, float* dist2, int32_t* idx, void* stream) {
+  if (N <= 0 || B <= 0) return GLX_OK;
+  GLX_REQUIRE(unknown && unknown_batch_cnt && known && known_batch_cnt && dist2 && idx,
+              "glx_three_nn: null pointer");
+  const int per = max_queries_per_frame > 0 ? max_queries_per_frame : N;
+  hipLaunchKernelGGL(k_three_nn, dim3(glx_divup(per, TNN_THREADS), B), dim3(TNN_THREADS), 0,
+                     (hipStream_t)stream, B, unknown, unknown_batch_cnt, known, known_batch_cnt,
+                     dist2, idx);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+__global__ void k_three_interpolate(int N, int C, const float* __restrict__ f,
+                                    const int* __restrict__ idx, const float* __restrict__ w,
+                                    float* __restrict__ out) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)N * C) return;
+  int p = (int)(t / C), c = (int)(t - (long long)p * C);
+  const int* ip = idx + (long long)p * 3;
+  const float* wp = w + (long long)p * 3;
+  out[t] = wp[0] * f[(long long)ip[0] * C + c] + wp[1] * f[(long long)ip[1] * C + c] +
+           wp[2] * f[(long long)ip[2] * C + c];
+}
+
+__global__ void k_three_interpolate_grad(int N, int C, const float* __restrict__ g,
+                                         const int* __restrict__ idx, const float* __restrict__ w,
+                                         float* __restrict__ gf) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)N * C) return;
+  int p = (int)(t / C), c = (int)(t - (long long)p * C);
+  const int* ip = idx + (long long)p * 3;
+  const float* wp = w + (long long)p * 3;
+  const float v = g[t];
+  atomicAdd(gf + (long long)ip[0] * C + c, v * wp[0]);
+  atomicAdd(gf + (long long)ip[1] * C + c, v * wp[1]);
+  atomicAdd(gf + (long long)ip[2] * C + c, v * wp[2]);
+}
+
+extern "C" int glx_three_interpolate(int N, int C, const float* features, const int32_t* idx,
+                                     const float* weight, float* out, void* stream) {
+  if (N <= 0 || C <= 0) return GLX_OK;
+  GLX_REQUIRE(features && idx && weight && out, "glx_three_interpolate: null pointer");
+  hipLaunchKernelGGL(k_three_interpolate, dim3(glx_divup((long long)N * C, 256)), dim3(256), 0,
+                     (hipStream_t)stream, N, C, features, idx, weight, out);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+extern "C" int glx_three_interpolate_grad(int N, int C, const float* grad_out, const int32_t* idx,
+                                          const float* weight, float* grad_features, void* stream) {
+  if (N <= 0 || C <= 0) return GLX_OK;
+  GLX_REQUIRE(grad_out && idx && weight && grad_features, "glx_three_interpolate_grad: null pointer");
+  hipLaunchKernelGGL(k_three_interpolate_grad, dim3(glx_divup((long long)N * C, 256)), dim3(256), 0,
+                     (hipStream_t)stream, N, C, grad_out, idx, weight, grad_features);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

@@ -43,6 +43,45 @@ def group_points_grad_wrapper(B, M, C, N, nsample, grad_out, idx, idx_batch_cnt,
     return 1
 
 
+def stack_farthest_point_sampling_wrapper(xyz, temp, xyz_batch_cnt, idxs, num_sampled_points):
+    """sampling.cpp:40-60: xyz (N,3), temp (N) filled with 1e10, idxs (sum m) int32 out."""
+    _lib.check_cuda(xyz, temp, xyz_batch_cnt, idxs, num_sampled_points)
+    n = xyz.shape[0]
+    call("glx_stack_fps", xyz, xyz_batch_cnt, xyz_batch_cnt.shape[0], n if n <= 16384 else 0,
+         num_sampled_points, temp, idxs)
+    return 1
+
+
+def farthest_point_sampling_wrapper(B, N, m, xyz, temp, idx):
+    """sampling.cpp:24-37 (batched layout): xyz (B,N,3), temp (B,N), idx (B,m) with per-frame
+    LOCAL indices -- the stacked kernel on B equal frames, rebased."""
+    _lib.check_cuda(xyz, temp, idx)
+    import torch
+    cnt = torch.full((B,), N, dtype=torch.int32, device=xyz.device)
+    ms = torch.full((B,), m, dtype=torch.int32, device=xyz.device)
+    flat = torch.empty(B * m, dtype=torch.int32, device=xyz.device)
+    call("glx_stack_fps", xyz.view(-1, 3), cnt, B, N if N <= 16384 else 0, ms, temp.view(-1), flat)
+    idx.copy_(flat.view(B, m) - (torch.arange(B, device=xyz.device, dtype=torch.int32) * N).view(B, 1))
+    return 1
+
+
+def three_nn_wrapper(unknown, unknown_batch_cnt, known, known_batch_cnt, dist2, idx):
+    """interpolate.cpp:35-63: dist2 (N,3) squared distances, idx (N,3) global indices."""
+    _lib.check_cuda(unknown, unknown_batch_cnt, known, known_batch_cnt, dist2, idx)
+    call("glx_three_nn", unknown_batch_cnt.shape[0], unknown.shape[0], 0, unknown, unknown_batch_cnt,
+         known, known_batch_cnt, dist2, idx)
+
+
+def three_interpolate_wrapper(features, idx, weight, out):
+    _lib.check_cuda(features, idx, weight, out)
+    call("glx_three_interpolate", idx.shape[0], features.shape[1], features, idx, weight, out)
+
+
+def three_interpolate_grad_wrapper(grad_out, idx, weight, grad_features):
+    _lib.check_cuda(grad_out, idx, weight, grad_features)
+    call("glx_three_interpolate_grad", idx.shape[0], grad_out.shape[1], grad_out, idx, weight, grad_features)
+
+
 def _next_tier(name):
     def f(*a, **k):
         raise NotImplementedError("%s: PV-RCNN(++) operator, not on GLENet's hot path "
@@ -50,9 +89,7 @@ def _next_tier(name):
     return f
 
 
-for _n in ("farthest_point_sampling_wrapper", "stack_farthest_point_sampling_wrapper",
-           "three_nn_wrapper", "three_interpolate_wrapper", "three_interpolate_grad_wrapper",
-           "query_stacked_local_neighbor_idxs_wrapper_stack",
+for _n in ("query_stacked_local_neighbor_idxs_wrapper_stack",
            "query_three_nn_by_stacked_local_idxs_wrapper_stack", "vector_pool_wrapper",
            "vector_pool_grad_wrapper"):
     globals()[_n] = _next_tier(_n)

@@ -84,3 +84,93 @@ class QueryAndGroup(nn.Module):
         grouped = grouping_operation(features, xyz_batch_cnt, idx, new_xyz_batch_cnt)
         grouped[empty] = 0
         return (torch.cat([rel, grouped], dim=1) if self.use_xyz else grouped), idx
+
+
+class StackFarthestPointSampling(Function):
+    """pointnet2_utils.py:190-222: xyz (N1+N2+..,3), xyz_batch_cnt, npoint (int | list | tensor)
+    -> (sum npoint,) int32 indices into the stacked xyz."""
+
+    @staticmethod
+    def forward(ctx, xyz, xyz_batch_cnt, npoint):
+        assert xyz.is_contiguous() and xyz.shape[1] == 3
+        B = len(xyz_batch_cnt)
+        if not isinstance(npoint, torch.Tensor):
+            npoint = torch.tensor(npoint if isinstance(npoint, list) else [npoint] * B, device=xyz.device)
+        npoint = npoint.int().contiguous()
+        temp = torch.full((xyz.shape[0],), 1e10, dtype=torch.float32, device=xyz.device)
+        out = torch.empty(int(npoint.sum().item()), dtype=torch.int32, device=xyz.device)
+        pointnet2.stack_farthest_point_sampling_wrapper(xyz, temp, _int(xyz_batch_cnt), out, npoint)
+        ctx.mark_non_differentiable(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None
+
+
+stack_farthest_point_sample = StackFarthestPointSampling.apply
+
+
+class FarthestPointSampling(Function):
+    """pointnet2_utils.py:162-187: xyz (B,N,3) -> (B,npoint) int32 per-frame indices."""
+
+    @staticmethod
+    def forward(ctx, xyz, npoint):
+        assert xyz.is_contiguous()
+        B, N, _ = xyz.shape
+        out = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
+        pointnet2.farthest_point_sampling_wrapper(B, N, npoint, xyz, temp, out)
+        ctx.mark_non_differentiable(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None
+
+
+farthest_point_sample = furthest_point_sample = FarthestPointSampling.apply
+
+
+class ThreeNN(Function):
+    """pointnet2_utils.py:227-258 -> (dist (N,3) euclidean, idx (N,3) int32 global)."""
+
+    @staticmethod
+    def forward(ctx, unknown, unknown_batch_cnt, known, known_batch_cnt):
+        assert unknown.dim() == 2 and unknown.shape[1] == 3 and known.dim() == 2 and known.shape[1] == 3
+        assert len(unknown_batch_cnt) == len(known_batch_cnt)
+        dist2 = unknown.new_zeros(unknown.shape)
+        idx = torch.zeros(unknown.shape, dtype=torch.int32, device=unknown.device)
+        pointnet2.three_nn_wrapper(unknown.contiguous(), _int(unknown_batch_cnt), known.contiguous(),
+                                   _int(known_batch_cnt), dist2, idx)
+        ctx.mark_non_differentiable(idx)
+        return torch.sqrt(dist2), idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None, None, None
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    """pointnet2_utils.py:264-300: features (M,C), idx (N,3), weight (N,3) -> (N,C)."""
+
+    @staticmethod
+    def forward(ctx, features, idx, weight):
+        assert idx.shape[0] == weight.shape[0] and idx.shape[1] == weight.shape[1] == 3
+        ctx.save = (idx, weight, features.shape[0])
+        out = features.new_zeros((idx.shape[0], features.shape[1]))
+        pointnet2.three_interpolate_wrapper(features.contiguous(), _int(idx), weight.contiguous(), out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight, M = ctx.save
+        g = grad_out.new_zeros((M, grad_out.shape[1]))
+        pointnet2.three_interpolate_grad_wrapper(grad_out.contiguous(), _int(idx), weight.contiguous(), g)
+        return g, None, None
+
+
+three_interpolate = ThreeInterpolate.apply

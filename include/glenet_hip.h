@@ -303,6 +303,30 @@ int glx_group_points_grad(int B, int M, int C, int N, int nsample, const float* 
                           const int32_t* idx, const int32_t* idx_batch_cnt,
                           const int32_t* features_batch_cnt, float* grad_features, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * PV-RCNN set-abstraction operators (same extension module in the reference).
+ * ------------------------------------------------------------------------------------ */
+
+/* Stacked farthest point sampling: frame b contributes num_sampled[b] indices (global, into the
+ * stacked xyz), starting with its first point.  temp (N) arrives filled with 1e10; max_points = an
+ * upper bound of the largest frame (<= 16384 keeps the distances in registers; 0 = unknown).
+ * Replaces: pointnet2_stack_cuda.stack_farthest_point_sampling_wrapper (sampling.cpp:40-60) and,
+ * with B equal-sized frames, farthest_point_sampling_wrapper (sampling.cpp:24-37). */
+int glx_stack_fps(const float* xyz, const int32_t* xyz_batch_cnt, int B, int max_points,
+                  const int32_t* num_sampled, float* temp, int32_t* idxs, void* stream);
+/* Squared distances + global indices of the 3 nearest known points of the same frame.
+ * max_queries_per_frame bounds unknown_batch_cnt[] (0 = N).
+ * Replaces: pointnet2_stack_cuda.three_nn_wrapper (interpolate.cpp:35-63). */
+int glx_three_nn(int B, int N, int max_queries_per_frame, const float* unknown,
+                 const int32_t* unknown_batch_cnt, const float* known,
+                 const int32_t* known_batch_cnt, float* dist2, int32_t* idx, void* stream);
+/* out[p,:] = sum_j weight[p,j] * features[idx[p,j],:]; grad_features (M,C) arrives zero-filled.
+ * Replaces: three_interpolate_wrapper / three_interpolate_grad_wrapper (interpolate.cpp:66-110). */
+int glx_three_interpolate(int N, int C, const float* features, const int32_t* idx,
+                          const float* weight, float* out, void* stream);
+int glx_three_interpolate_grad(int N, int C, const float* grad_out, const int32_t* idx,
+                               const float* weight, float* grad_features, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

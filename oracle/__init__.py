@@ -440,3 +440,37 @@ def generate_voxel2pinds(indices, batch_size, spatial_shape):
     v2p = -np.ones((batch_size, *[int(s) for s in spatial_shape]), np.int32)
     v2p[indices[:, 0], indices[:, 1], indices[:, 2], indices[:, 3]] = np.arange(len(indices), dtype=np.int32)
     return v2p
+
+
+def stack_farthest_point_sample(xyz, xyz_batch_cnt, npoint):
+    """StackFarthestPointSampling.forward, pointnet2_utils.py:190-218 -> (sum npoint,) global indices."""
+    xyz, xbc = _f32(xyz), _i32(xyz_batch_cnt)
+    npt = _i32(np.full(len(xbc), npoint) if np.isscalar(npoint) else npoint)
+    temp = np.full(len(xyz), 1e10, np.float32)
+    out = np.zeros(int(npt.sum()), np.int32)
+    lib().orc_stack_fps(len(xbc), _f(xyz), _i(xbc), _f(temp), _i(npt), _i(out))
+    return out
+
+
+def three_nn(unknown, unknown_batch_cnt, known, known_batch_cnt):
+    """ThreeNN.forward, pointnet2_utils.py:227-254 -> (dist (N,3) = sqrt of the kernel's dist2, idx (N,3))."""
+    unknown, known = _f32(unknown), _f32(known)
+    ubc, kbc = _i32(unknown_batch_cnt), _i32(known_batch_cnt)
+    d2 = np.zeros((len(unknown), 3), np.float32)
+    idx = np.zeros((len(unknown), 3), np.int32)
+    lib().orc_three_nn(len(ubc), len(unknown), _f(unknown), _i(ubc), _f(known), _i(kbc), _f(d2), _i(idx))
+    return np.sqrt(d2), idx
+
+
+def three_interpolate(features, idx, weight):
+    features, idx, weight = _f32(features), _i32(idx), _f32(weight)
+    out = np.zeros((len(idx), features.shape[1]), np.float32)
+    lib().orc_three_interpolate(len(idx), features.shape[1], _f(features), _i(idx), _f(weight), _f(out))
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, M):
+    grad_out, idx, weight = _f32(grad_out), _i32(idx), _f32(weight)
+    g = np.zeros((int(M), grad_out.shape[1]), np.float32)
+    lib().orc_three_interpolate_grad(len(idx), grad_out.shape[1], _f(grad_out), _i(idx), _f(weight), _f(g))
+    return g

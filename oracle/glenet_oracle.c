@@ -828,3 +828,96 @@ ORC_API void orc_group_points_grad(int B, int M, int C, int N, int nsample, cons
             grad_out[((size_t)pt * C + c) * nsample + s];
   }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * PV-RCNN set-abstraction operators.
+ * ------------------------------------------------------------------------------------------ */
+
+/* stack_farthest_point_sampling_kernel<1024>, pointnet2_stack/src/sampling_gpu.cu:187-302.
+ * Frame b: sample 0 is its first point; then m-1 times: temp[k] = min(temp[k], d(k, last)),
+ * next = argmax temp.  Tie rule of the 1024-thread reduction restated: thread t scans
+ * k = t, t+1024, ... with a strict '>' (first maximum of its sequence), the tree keeps the LOWER
+ * thread on equal values (__update :16-21) -> among equal maxima the winner has the smallest
+ * k mod 1024, then the smallest k.  temp arrives filled with 1e10 (pointnet2_utils.py:214). */
+ORC_API void orc_stack_fps(int B, const float* xyz, const int32_t* xyz_batch_cnt, float* temp,
+                           const int32_t* num_sampled, int32_t* idxs) {
+  size_t start = 0, ostart = 0;
+  for (int b = 0; b < B; ++b) {
+    const float* X = xyz + start * 3;
+    float* T = temp + start;
+    int32_t* O = idxs + ostart;
+    int n = xyz_batch_cnt[b], m = num_sampled[b];
+    int old = 0;
+    if (m > 0) O[0] = (int32_t)start;
+    for (int j = 1; j < m; ++j) {
+      float x1 = X[old * 3], y1 = X[old * 3 + 1], z1 = X[old * 3 + 2];
+      float best = -1.f;
+      int besti = 0, bestt = 1 << 30;
+      for (int t = 0; t < 1024 && t < n; ++t) {
+        float tb = -1.f;
+        int ti = 0;
+        for (int k = t; k < n; k += 1024) {
+          float x2 = X[k * 3], y2 = X[k * 3 + 1], z2 = X[k * 3 + 2];
+          float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+          float d2 = d < T[k] ? d : T[k];
+          T[k] = d2;
+          if (d2 > tb) { tb = d2; ti = k; }
+        }
+        if (tb > best || (tb == best && t < bestt)) { best = tb; besti = ti; bestt = t; }
+      }
+      old = besti;
+      O[j] = (int32_t)(old + start);
+    }
+    start += n;
+    ostart += m;
+  }
+}
+
+/* three_nn_kernel_stack, pointnet2_stack/src/interpolate_gpu.cu:16-76: squared distances and
+ * GLOBAL indices of the three nearest known points of the same frame (strict '<', ascending k). */
+ORC_API void orc_three_nn(int B, int N, const float* unknown, const int32_t* unknown_batch_cnt,
+                          const float* known, const int32_t* known_batch_cnt, float* dist2,
+                          int32_t* idx) {
+  for (int pt = 0; pt < N; ++pt) {
+    int bs = 0, pc = unknown_batch_cnt[0];
+    for (int k = 1; k < B; k++) {
+      if (pt < pc) break;
+      pc += unknown_batch_cnt[k];
+      bs = k;
+    }
+    int start = 0;
+    for (int k = 0; k < bs; k++) start += known_batch_cnt[k];
+    const float* Kp = known + (size_t)start * 3;
+    int n = known_batch_cnt[bs];
+    float ux = unknown[pt * 3], uy = unknown[pt * 3 + 1], uz = unknown[pt * 3 + 2];
+    double b1 = 1e40, b2 = 1e40, b3 = 1e40;
+    int i1 = 0, i2 = 0, i3 = 0;
+    for (int k = 0; k < n; ++k) {
+      float x = Kp[k * 3], y = Kp[k * 3 + 1], z = Kp[k * 3 + 2];
+      float d = (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
+      if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k; }
+      else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = k; }
+      else if (d < b3) { b3 = d; i3 = k; }
+    }
+    dist2[pt * 3] = (float)b1; dist2[pt * 3 + 1] = (float)b2; dist2[pt * 3 + 2] = (float)b3;
+    idx[pt * 3] = i1 + start; idx[pt * 3 + 1] = i2 + start; idx[pt * 3 + 2] = i3 + start;
+  }
+}
+
+/* three_interpolate_kernel_stack / _grad_, interpolate_gpu.cu:100-160 */
+ORC_API void orc_three_interpolate(int N, int C, const float* features, const int32_t* idx,
+                                   const float* weight, float* out) {
+  for (int p = 0; p < N; ++p)
+    for (int c = 0; c < C; ++c)
+      out[(size_t)p * C + c] = weight[p * 3] * features[(size_t)idx[p * 3] * C + c] +
+                               weight[p * 3 + 1] * features[(size_t)idx[p * 3 + 1] * C + c] +
+                               weight[p * 3 + 2] * features[(size_t)idx[p * 3 + 2] * C + c];
+}
+
+ORC_API void orc_three_interpolate_grad(int N, int C, const float* grad_out, const int32_t* idx,
+                                        const float* weight, float* grad_features) {
+  for (int p = 0; p < N; ++p)
+    for (int c = 0; c < C; ++c)
+      for (int j = 0; j < 3; ++j)
+        grad_features[(size_t)idx[p * 3 + j] * C + c] += grad_out[(size_t)p * C + c] * weight[p * 3 + j];
+}

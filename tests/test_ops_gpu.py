@@ -346,3 +346,51 @@ def test_roi_grid_pool_harness_vs_reference_formulation(dev):
         want = torch.cat(want, -1)
     assert got.shape == (B * 5, 27, 24) and torch.equal(got, want)
     assert float(got.abs().max()) > 0
+
+
+def test_farthest_point_sampling_bit_identical(dev):
+    """Stacked + batched FPS vs the oracle (same tie rule as the reference's 1024-thread tree);
+    duplicate points force ties; one frame > 16 K points takes the global-temp path."""
+    rng = np.random.default_rng(13)
+    cnt = [5000, 700, 17000]
+    xyz = rng.normal(size=(sum(cnt), 3)).astype(np.float32)
+    xyz[5000 + 10:5000 + 200] = xyz[5000 + 5]                      # exact duplicates in frame 1
+    xyz[100:2100] = np.round(xyz[100:2100], 1)                      # many equal distances in frame 0
+    npoint = [256, 300, 128]
+    want = oracle.stack_farthest_point_sample(xyz, cnt, npoint)
+    got = pointnet2_utils.stack_farthest_point_sample(T(xyz, dev), torch.tensor(cnt, dtype=torch.int32, device=dev),
+                                                      npoint).cpu().numpy()
+    assert np.array_equal(got, want)
+    small = [5000, 700, 6000]
+    xs = xyz[:sum(small)]
+    want = oracle.stack_farthest_point_sample(xs, small, 64)
+    got = pointnet2_utils.stack_farthest_point_sample(T(xs, dev), torch.tensor(small, dtype=torch.int32, device=dev), 64)
+    assert np.array_equal(got.cpu().numpy(), want)
+    xb = rng.normal(size=(3, 2048, 3)).astype(np.float32)
+    gotb = pointnet2_utils.farthest_point_sample(T(xb, dev), 100).cpu().numpy()
+    for b in range(3):
+        assert np.array_equal(gotb[b], oracle.stack_farthest_point_sample(xb[b], [2048], 100))
+
+
+def test_three_nn_and_interpolate(dev):
+    rng = np.random.default_rng(14)
+    ucnt, kcnt = [700, 1300], [900, 2500]
+    unknown = rng.uniform(-5, 5, (sum(ucnt), 3)).astype(np.float32)
+    known = rng.uniform(-5, 5, (sum(kcnt), 3)).astype(np.float32)
+    known[5] = known[6] = known[7] = known[8]                      # equal distances: ascending index wins
+    feats = rng.normal(size=(sum(kcnt), 24)).astype(np.float32)
+    d_ref, i_ref = oracle.three_nn(unknown, ucnt, known, kcnt)
+    d, i = pointnet2_utils.three_nn(T(unknown, dev), torch.tensor(ucnt, dtype=torch.int32, device=dev),
+                                    T(known, dev), torch.tensor(kcnt, dtype=torch.int32, device=dev))
+    assert np.array_equal(i.cpu().numpy(), i_ref)
+    np.testing.assert_array_equal(d.cpu().numpy(), d_ref)
+    w = 1.0 / (d_ref + 1e-8)
+    w = (w / w.sum(1, keepdims=True)).astype(np.float32)
+    f = T(feats, dev).requires_grad_(True)
+    out = pointnet2_utils.three_interpolate(f, i, T(w, dev))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), oracle.three_interpolate(feats, i_ref, w),
+                               rtol=1e-6, atol=1e-6)
+    g = rng.normal(size=out.shape).astype(np.float32)
+    out.backward(T(g, dev))
+    np.testing.assert_allclose(f.grad.cpu().numpy(), oracle.three_interpolate_grad(g, i_ref, w, len(feats)),
+                               rtol=1e-4, atol=1e-5)
