@@ -148,10 +148,64 @@ class PointFeat(nn.Module):
         self.bn1, self.bn2, self.bn3 = nn.BatchNorm1d(widths[0]), nn.BatchNorm1d(widths[1]), nn.BatchNorm1d(widths[2])
 
     def forward(self, x):                       # x (B, pts_dim, P)
+        if self._fusable(x):
+            return self._forward_fused(x)
         x = F.relu(self.bn1(self.conv1(x)))
         x = F.relu(self.bn2(self.conv2(x)))
         x = self.bn3(self.conv3(x))
         return x.max(dim=2)[0]
+
+    # ---- eval-mode fast path: one hand-written MFMA kernel for the whole extractor
+    def _fusable(self, x):
+        widths = (self.conv1.out_channels, self.conv2.out_channels, self.conv3.out_channels)
+        return (x.is_cuda and not self.training and not torch.is_grad_enabled() and x.dtype == torch.float32
+                and (widths == (64, 128, 512) or max(widths) <= 16) and self.conv1.in_channels <= 8)
+
+    @staticmethod
+    def _fold(conv, bn):
+        """Conv1d(k=1) followed by eval-mode BatchNorm1d as one affine map (W, b)."""
+        s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        w = conv.weight[:, :, 0] * s[:, None]
+        b = (conv.bias - bn.running_mean) * s + bn.bias
+        return w.float().contiguous(), b.float().contiguous()
+
+    def _packed(self):
+        """Folded weights in the kernel's MFMA fragment order (csrc/glx_pointnet.hip), cached until
+        a parameter or running statistic changes."""
+        tensors = [t for m in (self.conv1, self.bn1, self.conv2, self.bn2, self.conv3, self.bn3)
+                   for t in (m.weight, m.bias)] + [self.bn1.running_mean, self.bn1.running_var,
+                                                   self.bn2.running_mean, self.bn2.running_var,
+                                                   self.bn3.running_mean, self.bn3.running_var]
+        tag = tuple((t._version, t.data_ptr()) for t in tensors)
+        cache = self.__dict__.get("_glx_packed")
+        if cache is None or cache[0] != tag:
+            with torch.no_grad():
+                w1, b1 = self._fold(self.conv1, self.bn1)
+                w2, b2 = self._fold(self.conv2, self.bn2)
+                w3, b3 = self._fold(self.conv3, self.bn3)
+                if w3.shape[0] == 512:
+                    # [tile_out, i, tile_in, q, e] -> [tile_out, tile_in, q, i, e]: lane = 16 q + i
+                    w2p = w2.view(8, 16, 4, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
+                    w3p = w3.view(32, 16, 8, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
+                else:
+                    w2p, w3p = w2, w3                      # narrow extractor: plain row-major
+            cache = (tag, (w1, b1, w2p, b2, w3p, b3))
+            self.__dict__["_glx_packed"] = cache
+        return cache[1]
+
+    def _forward_fused(self, x):
+        from ._lib import call
+        x = x.contiguous()
+        B, cin, P = x.shape
+        w1, b1, w2p, b2, w3p, b3 = self._packed()
+        c3 = self.conv3.out_channels
+        out = torch.empty((B, c3), dtype=torch.float32, device=x.device)
+        if c3 == 512:
+            call("glx_pointnet_feat", x, B, cin, P, w1, b1, w2p, b2, w3p, b3, out)
+        else:
+            call("glx_pointnet_feat_small", x, B, cin, P, self.conv1.out_channels, self.conv2.out_channels,
+                 c3, w1, b1, w2p, b2, w3p, b3, out)
+        return out
 
 
 class LatentEncoder(nn.Module):

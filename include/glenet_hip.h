@@ -327,6 +327,23 @@ int glx_three_interpolate(int N, int C, const float* features, const int32_t* id
 int glx_three_interpolate_grad(int N, int C, const float* grad_out, const int32_t* idx,
                                const float* weight, float* grad_features, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * CVAE label-uncertainty generator (BASELINE config 4): the PointNet feature extractor as ONE
+ * kernel.  out[b,:] = max_p W3 relu(W2 relu(W1 x[b,:,p] + b1) + b2) + b3 with widths 64/128/512;
+ * points (B, Cin<=8, P); (W, b) = Conv1d(k=1) + eval-mode BatchNorm1d folded; W2p / W3p in MFMA
+ * fragment order [tile_out][tile_in][q][i][e] (see csrc/glx_pointnet.hip).
+ * Replaces: PointNetfeat.forward (cvae_uncertainty/point_net.py:10-28) in eval mode.
+ * ------------------------------------------------------------------------------------ */
+size_t glx_pointnet_feat_lds_bytes(void);
+int glx_pointnet_feat(const float* points, int B, int Cin, int P, const float* W1, const float* b1,
+                      const float* W2p, const float* b2, const float* W3p, const float* b3,
+                      float* out, void* stream);
+/* Same function for narrow extractors (all widths <= 16, e.g. SimPointNetfeat 8/8/8,
+ * point_net.py:31-49); W1 (C1,Cin), W2 (C2,C1), W3 (C3,C2) row-major, folded like above. */
+int glx_pointnet_feat_small(const float* points, int B, int Cin, int P, int C1, int C2, int C3,
+                            const float* W1, const float* b1, const float* W2, const float* b2,
+                            const float* W3, const float* b3, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -394,3 +394,30 @@ def test_three_nn_and_interpolate(dev):
     out.backward(T(g, dev))
     np.testing.assert_allclose(f.grad.cpu().numpy(), oracle.three_interpolate_grad(g, i_ref, w, len(feats)),
                                rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("cin,P,B,widths", [(4, 512, 9, (64, 128, 512)), (5, 200, 3, (64, 128, 512)),
+                                              (4, 128, 1, (64, 128, 512)), (4, 512, 7, (8, 8, 8)),
+                                              (5, 300, 2, (16, 8, 12))])
+def test_fused_pointnet_feat_matches_torch_modules(dev, cin, P, B, widths):
+    """glx_pointnet_feat (one MFMA kernel) == the unfused Conv1d/BatchNorm1d/ReLU/max modules in
+    fp32, also when P is not a multiple of the 128-point pass and for 5 point features."""
+    from glenet_amd import dense_path as dp
+    torch.manual_seed(cin * 100 + P)
+    m = dp.PointFeat(cin, widths).to(dev).eval()
+    g = torch.Generator().manual_seed(1)
+    for bn in (m.bn1, m.bn2, m.bn3):
+        bn.running_mean.copy_((torch.randn(bn.num_features, generator=g) * 0.2).to(dev))
+        bn.running_var.copy_((torch.rand(bn.num_features, generator=g) + 0.5).to(dev))
+        bn.weight.data.copy_((torch.rand(bn.num_features, generator=g) - 0.3).to(dev))   # some negative scales
+        bn.bias.data.copy_((torch.randn(bn.num_features, generator=g) * 0.1).to(dev))
+    x = torch.randn(B, cin, P, device=dev)
+    with torch.no_grad():
+        fused = m(x)
+        z = torch.relu(m.bn1(m.conv1(x)))
+        z = torch.relu(m.bn2(m.conv2(z)))
+        ref = m.bn3(m.conv3(z)).max(dim=2)[0]
+    assert fused.shape == (B, widths[2])
+    np.testing.assert_allclose(fused.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    # the module falls back to the torch path when gradients are needed
+    assert m(x.requires_grad_(True)).requires_grad

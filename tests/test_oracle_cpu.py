@@ -264,3 +264,34 @@ def test_library_exports_every_declared_symbol():
     lib.glx_sconv_packed_bytes.restype = ctypes.c_size_t
     assert lib.glx_sconv_packed_bytes(27, 64, 64) > 27 * 64 * 64 * 4
     assert lib.glx_sconv_packed_bytes(27, 5, 16) == 0
+
+
+def test_set_abstraction_oracle_vs_independent_numpy():
+    """FPS / three_nn / three_interpolate restatements against plain numpy formulations."""
+    rng = np.random.default_rng(3)
+    xyz = rng.normal(size=(2500, 3)).astype(np.float32)
+    cnt = [1500, 1000]
+    got = oracle.stack_farthest_point_sample(xyz, cnt, [48, 32])
+
+    def fps(X, m):
+        t, o = np.full(len(X), 1e10, np.float32), [0]
+        for _ in range(m - 1):
+            d = ((X - X[o[-1]]) ** 2).astype(np.float32)
+            t = np.minimum(t, (d[:, 0] + d[:, 1]) + d[:, 2])
+            o.append(int(t.argmax()))
+        return np.array(o)
+
+    assert np.array_equal(got[:48], fps(xyz[:1500], 48)) and np.array_equal(got[48:], fps(xyz[1500:], 32) + 1500)
+    d, i = oracle.three_nn(xyz[:100], [60, 40], xyz[100:400], [200, 100])
+    D = ((xyz[:60, None] - xyz[None, 100:300]) ** 2).sum(-1)
+    j = np.argsort(D, 1, kind="stable")[:, :3]
+    assert np.array_equal(i[:60], j)
+    np.testing.assert_allclose(d[:60] ** 2, np.take_along_axis(D, j, 1), rtol=1e-5)
+    f = rng.normal(size=(300, 5)).astype(np.float32)
+    w = rng.random((100, 3)).astype(np.float32)
+    out = oracle.three_interpolate(f, i, w)
+    np.testing.assert_allclose(out, (f[i] * w[:, :, None]).sum(1), rtol=1e-6, atol=1e-6)
+    g = rng.normal(size=(100, 5)).astype(np.float32)
+    gf = np.zeros_like(f)
+    np.add.at(gf, i.reshape(-1), (g[:, None, :] * w[:, :, None]).reshape(-1, 5))
+    np.testing.assert_allclose(oracle.three_interpolate_grad(g, i, w, 300), gf, rtol=1e-5, atol=1e-6)
