@@ -245,3 +245,36 @@ def test_waymo_shaped_residual_backbone_matches_oracle(dev):
     assert np.array_equal(out.indices.cpu().numpy(), ref["out"].indices)
     r = ref["out"].features
     np.testing.assert_allclose(out.features.cpu().numpy(), r, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(r).max()))
+
+
+def test_static_pipeline_handles_empty_frames(dev):
+    """A frame without a single in-range point, and a whole empty batch, through the captured graph."""
+    grid = oracle.grid_size_of(K["point_cloud_range"], K["voxel_size"])
+    model = gb.SparseBackbone8x(4, grid).eval().to(dev)
+    _condition(model)
+    pts, bidx = _frames_on(dev, 2, seed0=95, num_points=4000)
+    pipe = gb.StaticFramePipeline(model, K, 2, pts.shape[0], 4)
+    pipe.load(pts, bidx)
+    pipe.capture()
+    half = pts.clone()
+    half[bidx == 1, 0] = -100.0                      # frame 1 entirely out of range
+    with torch.no_grad():
+        ref = gb.HeightCompression()(model(gb.MeanVFE()(gb.voxelize_batch(half, bidx, 2, K))))["spatial_features"]
+    pipe.load(half, bidx)
+    out = pipe.replay()
+    torch.cuda.synchronize()
+    pipe.check()
+    assert torch.equal(out["spatial_features"], ref) and float(ref[1].abs().max()) == 0.0
+    none = pts.clone()
+    none[:, 0] = -100.0
+    pipe.load(none, bidx)
+    out = pipe.replay()
+    torch.cuda.synchronize()
+    pipe.check()
+    assert int(out["voxel_index"].count.item()) == 0 and float(out["spatial_features"].abs().max()) == 0.0
+    pipe.load(pts, bidx)                              # and it recovers
+    out = pipe.replay()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = gb.HeightCompression()(model(gb.MeanVFE()(gb.voxelize_batch(pts, bidx, 2, K))))["spatial_features"]
+    assert torch.equal(out["spatial_features"], ref)
