@@ -1040,39 +1040,17 @@ static int launch_mfma(const float* in, const float* Wp, const SconvEpilogue& ep
                        hipStream_t st) {
 #define SC_GO(TR, NW, NBUF) \
   return launch_tile<CI, CO, TR, NW, NBUF>(in, Wp, ep, nbr, tile_order, N_out, K, out, st)
-  constexpr bool big = CO >= 128;
+  // sweep knob (tools/sconv_sweep.py): the tile shapes that were competitive on some layer;
+  // the many others that were measured and lost are listed in profiles/r01_summary.md
   switch (g_sconv_variant) {
-    case 1: SC_GO(128, 4, 1);
     case 2: SC_GO(128, 8, 1);
-    case 3: SC_GO(128, 4, 2);
-    case 4: SC_GO(128, 8, 2);
     case 5: SC_GO(64, 4, 1);
     case 6: SC_GO(64, 4, 2);
-    case 7: if constexpr (!big) { SC_GO(256, 8, 1); } else { SC_GO(128, 8, 1); }
-    case 10: SC_GO(32, 4, 1);
-    case 11: SC_GO(32, 4, 2);
-    case 12: SC_GO(64, 8, 1);
-    // block implicit GEMM with LDS-staged gathers: (TR, NW, WPG)
+    case 23: return launch_tile<CI, CO, 64, 8, 1, 2>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
     case 30: return launch_gemm<CI, CO, 64, 8, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
     case 31: return launch_gemm<CI, CO, 64, 4, 2>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
     case 32: return launch_gemm<CI, CO, 64, 4, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
     case 33: return launch_gemm<CI, CO, 128, 8, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
-    case 34: return launch_gemm<CI, CO, 32, 4, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
-    case 35: return launch_gemm<CI, CO, 64, 8, 2>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
-    // column-split tiles (WPG = waves per chunk)
-    case 20: return launch_tile<CI, CO, 64, 8, 1, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
-    case 21: return launch_tile<CI, CO, 64, 8, 2, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
-    case 22: return launch_tile<CI, CO, 32, 4, 1, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
-    case 23: return launch_tile<CI, CO, 64, 8, 1, 2>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
-    case 24: return launch_tile<CI, CO, 128, 8, 1, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
-    case 25: return launch_tile<CI, CO, 64, 4, 1, 2>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
-    case 13: SC_GO(32, 2, 1);
-    case 0:
-      if constexpr (big) {
-        if constexpr (CI >= 128) { SC_GO(128, 8, 1); } else { SC_GO(128, 8, 2); }
-      } else {
-        SC_GO(256, 8, 2);
-      }
     default: break;
   }
 #undef SC_GO

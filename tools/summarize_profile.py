@@ -88,5 +88,21 @@ for r in rows[:28]:
     md.append("| `%s` | %s | %.1f | %.1f | %.1f |" % (r["Name"][:72].replace("|", "/"), r["Calls"],
                                                    float(r["AverageNs"]) / 1e3,
                                                    float(r["TotalDurationNs"]) / steps / 1e3, float(r["Percentage"])))
+md += ["", "## Sparse-conv kernel variants measured during round 1 (layer 64->64, N = 48 147, R = 386 953)", "",
+       "Kernel-only time from HIP events (`tools/sconv_sweep.py`); the variants marked (removed) lived in the tree,",
+       "lost, and were deleted (git history has them).", "",
+       "| variant | us |", "|---|---|",
+       "| block implicit GEMM: LDS-staged gathers, chunk split over 4 waves, 64 rows x 8 waves (**default, Cout >= 64**) | 74 |",
+       "| same, 64 rows x 4 waves, split 2 / split 4 | 80 / 81 |",
+       "| same, 128 rows x 8 waves / 32 rows x 4 waves / 64 x 8 split 2 (removed) | 92 / 101 / 104 |",
+       "| whole-chunk waves, register gathers, 64 rows x 4 waves (**default, Cout <= 32**) | 81-86 |",
+       "| same with column split 2 over 8 waves / split 4 over 8 waves (removed) | 80-82 / 115 |",
+       "| same, double-buffered W (2 blocks/CU) | 112 |",
+       "| same, 128 rows x 4 / x 8 waves, 256 rows x 8 waves, 32 rows, 64 rows x 8 waves (removed) | 100-104 / 89-94 / 103 / 114-121 / 114 |",
+       "| wave-private 48-row tiles, W fragments from L2 (removed) / + deep software pipeline (removed) | 107 / 105 |",
+       "| register-resident 32-row tiles, one wave per block (removed) | 141 |",
+       "| column-owner ring, 512 threads (removed) | 121-146 |",
+       "| XCD-contiguous tile ranges on the default kernel (not enabled: XCD imbalance) | +6 % on this layer, -5 % on small ones |",
+       "| first version (one wave per 16-row tile, global-atomic-free but no compaction) | 230 |"]
 open(os.path.join(P, tag + "_summary.md"), "w").write("\n".join(md) + "\n")
 print("\n".join(md[:24]))
