@@ -66,7 +66,20 @@ struct SconvEpilogue {
   int relu;
   const int* n_live;   // NULL, or device int32: rows >= *n_live are neither computed nor written
   long long* trace;    // NULL, or (blocks, 4 + 8*NW) int64: selects the TRACE build (tools/sconv_tiles.py)
+  int xcd_group;       // GEMM kernel: tiles per XCD-local group (0 = identity block -> tile map)
 };
+
+// Block b runs on XCD b mod 8.  Deal the tiles to the XCDs in groups of `g` consecutive tiles:
+// neighbouring tiles (which share neighbour rows) meet in one L2, while every XCD still gets
+// tiles from all over the cloud (a contiguous 1/8 per XCD was measured 6 % slower on the largest
+// layer: LiDAR density differs between eighths).  Tail tiles keep the identity mapping.
+__device__ __forceinline__ int sc_xcd_tile(int b, int nb, int g) {
+  if (g <= 0) return b;
+  const int full = (nb / (8 * g)) * (8 * g);
+  if (b >= full) return b;
+  const int x = b & 7, i = b >> 3;
+  return ((i / g) * 8 + x) * g + (i % g);
+}
 
 // Column-split weight image: the values a lane needs for ONE 16-column tile, laid out so that a
 // quad of 16 lanes reads 256 consecutive bytes per ds_read_b128 (no padding, no bank conflicts):
@@ -555,7 +568,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int row0 = blockIdx.x * TR;
+  const int row0 = sc_xcd_tile(blockIdx.x, gridDim.x, ep.xcd_group) * TR;
   const int grp = wave / T::WPG;
   const int tile0 = (wave % T::WPG) * T::TPW;
   // TRACE build: tph = issue loads | multiply | barrier 1 | wait + stage store | barrier 2 (cycles)
@@ -852,7 +865,7 @@ extern "C" int glx_sconv_forward_generic(const float* in, int N_in, const float*
   GLX_REQUIRE(in && W && nbr && out && K > 0 && Cin > 0 && Cout > 0,
               "glx_sconv_forward_generic: bad arguments");
   long long total = (long long)N_out * Cout;
-  SconvEpilogue ep{bias, nullptr, nullptr, 0, nullptr, nullptr};
+  SconvEpilogue ep{bias, nullptr, nullptr, 0, nullptr, nullptr, 0};
   hipLaunchKernelGGL(k_sconv_generic, dim3(glx_divup(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, in, W, ep, nbr, N_out, K, Cin, Cout, out);
   GLX_LAUNCH_CHECK();
@@ -936,6 +949,15 @@ static int g_sconv_variant = env_variant();
 static long long* g_sconv_trace = nullptr;
 extern "C" int glx_sconv_set_trace(void* trace) {
   g_sconv_trace = (long long*)trace;
+  return GLX_OK;
+}
+static int env_xcd_group() {
+  const char* e = getenv("GLX_SCONV_XCD_GROUP");
+  return e ? atoi(e) : 0;
+}
+static int g_sconv_xcd_group = env_xcd_group();
+extern "C" int glx_sconv_set_xcd_group(int g) {
+  g_sconv_xcd_group = g;
   return GLX_OK;
 }
 extern "C" int glx_sconv_set_variant(int v) {
@@ -1093,7 +1115,7 @@ extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, cons
   GLX_REQUIRE(K > 0 && Cin > 0 && Cout > 0 && N_out >= 0, "glx_sconv_forward: bad sizes");
   if (N_out == 0) return GLX_OK;
   GLX_REQUIRE(in && (W || Wp) && nbr && out, "glx_sconv_forward: null pointer");
-  SconvEpilogue ep{bias, scale, shift, relu, n_out_live, g_sconv_trace};
+  SconvEpilogue ep{bias, scale, shift, relu, n_out_live, g_sconv_trace, g_sconv_xcd_group};
   if (!mfma_supported(Cin, Cout, K)) {
     GLX_REQUIRE(W, "glx_sconv_forward: raw weights required for channels (%d,%d)", Cin, Cout);
     long long total = (long long)N_out * Cout;

@@ -42,6 +42,7 @@ def ev():
     return e
 
 
+_lib.call_nostream("glx_sconv_set_xcd_group", int(os.environ.get("XCD_GROUP", "0")))
 variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2,3,4,5,6,7".split(","))]
 seen = set()
 print("layer(cin,cout,N,R)".ljust(34) + "".join(("v%d" % v).rjust(9) for v in variants) + "   alg GB/s @best")
