@@ -5,12 +5,14 @@
 // Semantics: spconv SubMConv3d / SparseConv3d forward as called from
 // pcdet/models/backbones_3d/spconv_backbone.py:148-156 (third-party arithmetic; the
 // algorithm is the published gather-GEMM-scatter, restated output-stationary so the
-// scatter-add disappears).  One wave owns a 16-row output tile; for each kernel offset
-// present in the tile it gathers the 16 neighbour rows straight into registers (each
-// lane loads a contiguous Cin/4 slice, so a row is one or two full cache lines) and
-// multiplies by W[k], which sits in LDS in MFMA-fragment order, with
-// v_mfma_f32_16x16x4_f32 (exact fp32, bitwise an fmaf chain).  Offsets absent from the
-// whole tile are skipped, so the dense MFMA work tracks the rule count R.
+// scatter-add disappears).  A block owns TR output rows, compacts their rule pairs per kernel
+// offset (wave ballots) so the matrix pipe only multiplies real rules, multiplies 16-pair chunks
+// by W[k] (LDS, MFMA-fragment order) with v_mfma_f32_16x16x4_f32 (exact fp32, bitwise an fmaf
+// chain) and sums into an fp32 accumulator tile in LDS; bias / BatchNorm / ReLU ride in the
+// epilogue.  Two kernels share that scheme:
+//   k_sconv_mfma   whole-chunk (or column-split) waves gather their rows into registers;
+//   k_sconv_gemm   all threads gather the next pair panel into LDS, chunks split over 4 waves.
+// Weight gradient: k_wgrad_mfma (offset-stationary).  dense(): k_dense_from_index.
 #include <hip/hip_ext.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -270,12 +272,13 @@ __device__ __forceinline__ void sc_compute(const float* s_w, float* s_acc,
   }
 }
 
-// Block = 8 waves, TR output rows.  Per kernel offset k the block compacts the rows that have
+// Block = NW waves, TR output rows.  Per kernel offset k the block compacts the rows that have
 // a neighbour at k into a pair list; 16 pairs form one MFMA row tile (the matrix pipe only sees
 // real rules), products are added into an fp32 accumulator tile in LDS.  Rows of one offset are
 // distinct and offsets are separated by a barrier, so every output element is summed in a fixed
-// order: bitwise reproducible, no global atomics.  W[k+1] streams into the second LDS buffer
-// and the next offset's input rows into registers while offset k multiplies.
+// order: bitwise reproducible, no global atomics.  W[k+1] is parked in registers (NBUF = 1) or
+// streams into a second LDS buffer (NBUF = 2) and the next offset's input rows are gathered into
+// registers while offset k multiplies.
 template <int CIN, int COUT, int TR_, int NW_, int NBUF_, int WPG_ = 1, bool TRACE = false>
 __global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
     const float* __restrict__ in, const float* __restrict__ Wp, SconvEpilogue ep,
