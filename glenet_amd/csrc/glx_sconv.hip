@@ -571,7 +571,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int row0 = sc_xcd_tile(blockIdx.x, gridDim.x, ep.xcd_group) * TR;
+  const int row0 = sc_xcd_tile(blockIdx.x, gridDim.x, ep.xcd_group & 0xFF) * TR;
   const int grp = wave / T::WPG;
   const int tile0 = (wave % T::WPG) * T::TPW;
   // TRACE build: tph = issue loads | multiply | barrier 1 | wait + stage store | barrier 2 (cycles)
@@ -729,7 +729,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
       // ---- multiply this wave's chunk of the current panel by its column tiles
       const int pbase = pb + grp * 16;
       if constexpr (TRACE) { my_chunks += pbase < cnt; ++n_steps; }
-      if (pbase < cnt) {   // wave-uniform
+      if (pbase < cnt && !(TRACE && (ep.xcd_group & 0x100))) {   // wave-uniform (0x100: ablate the multiply)
         const float* arow = s_a + (grp * 16 + r) * T::A_LD + q * CQ;
         float Am[CQ];
         if constexpr (CQ % 4 == 0) {
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
           }
         }
         const int p = pbase + r;
-        if (p < cnt) {
+        if (p < cnt && !(TRACE && (ep.xcd_group & 0x200))) {   // 0x200: ablate the accumulate
           float* dst = s_acc + (int)s_pslot[k * TR + p] * ACC_LD + tile0 * 16 + 4 * q;
 #pragma unroll
           for (int tt = 0; tt < T::TPW; ++tt) {
@@ -770,6 +770,8 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
             v += acc[tt];
             *reinterpret_cast<f32x4*>(dst + tt * 16) = v;
           }
+        } else if (TRACE) {
+          asm volatile("" ::"v"(acc[0]));
         }
       }
       if constexpr (TRACE) c2 = clock64();

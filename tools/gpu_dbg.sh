@@ -1,3 +1,3 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; cd $R
-for g in 0 2 4 8 16 32; do echo "== XCD_GROUP=$g"; XCD_GROUP=$g timeout 600 python tools/sconv_sweep.py -1 2>&1 | grep "^(32,64\|^(64,"; done
+for a in 0 0x200 0x100; do echo "== ABLATE=$a"; ABLATE=$a ONLY6464=1 GEMM=1 NW=8 python tools/sconv_tiles.py 2>&1 | grep -v amdgpu.ids | grep "layer\|duration\|phase\|setup" | head -4; done

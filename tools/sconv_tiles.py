@@ -38,6 +38,7 @@ TR = int(os.environ.get("TR", "64"))
 NW = int(os.environ.get("NW", "4"))
 VARIANT = int(os.environ.get("VARIANT", "-1"))   # e.g. VARIANT=20 NW=8 for the column-split tile
 _lib.call_nostream("glx_sconv_set_variant", VARIANT)
+_lib.call_nostream("glx_sconv_set_xcd_group", int(os.environ.get("ABLATE", "0"), 0))   # 0x100 / 0x200: TRACE-build ablations
 seen = set()
 for f, w, nbr, order, n_out, rules in calls:
     Kk, cin, cout = w.shape
