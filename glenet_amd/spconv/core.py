@@ -20,6 +20,7 @@ whole frame runs without host synchronisation and can be captured in a HIP graph
 `check_static()` verifies afterwards that no capacity was exceeded.
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -105,6 +106,7 @@ class RuleSet:
         self._pairs = None
         self.count_in = self.count_out = None   # shape-static mode: live rows (device int32[1])
         self.ready = None        # event recorded after the build when it ran on another stream
+        self._book = None
 
     @property
     def pair_count(self):
@@ -113,6 +115,16 @@ class RuleSet:
             n = self.N_out if self.count_out is None else min(self.N_out, int(self.count_out.item()))
             self._pairs = int((self.nbr[:n] >= 0).sum().item()) if n else 0
         return self._pairs
+
+    def book(self):
+        """Rulebook of the forward table (glx_rulebook_build): compacted pair lists per 64-row
+        tile and offset, built once and shared by every conv that uses this rule set."""
+        if self._book is None and self.N_out > 0:
+            nbytes = query("glx_rulebook_bytes", self.N_out, self.K)
+            self._book = torch.empty(nbytes, dtype=torch.uint8, device=self.nbr.device)
+            call("glx_rulebook_build", self.nbr, self.tile_order_out, self.N_out, self.K,
+                 self.count_out, self._book, size_arg(nbytes))
+        return self._book
 
     def inverse_table(self):
         if self.nbr_in is None and self.count_out is not None:
@@ -217,10 +229,14 @@ def plan_rules(indices, spatial_shape, batch_size, convs, index=None, count=None
             rs = (build_subm_rules(x, conv.kernel_size) if conv.subm else
                   build_strided_rules(x, conv.kernel_size, conv.stride, conv.padding, conv.dilation,
                                       out_capacity=capacities.get(key)))
-            if events:
-                rs.ready = torch.cuda.Event()
-                rs.ready.record()
             x.indice_dict[key] = rs
+        new_work = rs.ready is None
+        if USE_RULEBOOK and rulebook_eligible(conv.in_channels, conv.out_channels, rs.K) and rs._book is None:
+            rs.book()          # built here (plan stream), before the event the convs wait on
+            new_work = True
+        if events and new_work:
+            rs.ready = torch.cuda.Event()
+            rs.ready.record()
         if not conv.subm:
             nxt = SparseConvTensor(None, rs.out_indices, rs.out_spatial_shape, batch_size,
                                    indice_dict=x.indice_dict, count=rs.count_out)
@@ -273,9 +289,19 @@ def _cin_padding(cin):
     return 0 if target is None else target - cin
 
 
+USE_RULEBOOK = os.environ.get("GLX_SCONV_RULEBOOK", "0") == "1"   # opt-in: see k_sconv_rb
+
+
+def rulebook_eligible(cin, cout, K):
+    """Layers that run the rulebook kernel (k_sconv_rb): the wide ones, where the per-launch
+    rule compaction and the LDS weight staging of the block kernels cost the most."""
+    return cout >= 64 and cin >= 16 and cin in _MFMA_CIN and K <= 27
+
+
 def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rules=None, tag="fwd",
-           scale=None, shift=None, relu=False, n_live=None):
-    """out[j] = relu?((sum_k features[nbr[j,k]] @ weight_kio[k] + bias) * scale + shift)."""
+           scale=None, shift=None, relu=False, n_live=None, book=None):
+    """out[j] = relu?((sum_k features[nbr[j,k]] @ weight_kio[k] + bias) * scale + shift).
+    book: rulebook of (nbr, tile_order, n_out) -> the streaming rulebook kernel."""
     K, cin, cout = weight_kio.shape
     out = torch.empty((n_out, cout), dtype=torch.float32, device=features.device)
     if n_out == 0:
@@ -285,6 +311,10 @@ def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rule
     ws = workspace.get(256, features.device)
     if _profile_hook is not None:
         _profile_hook(tag, K, cin, cout, n_out, rules)
+    if book is not None and packed is not None:
+        call("glx_sconv_forward_rb", features, packed, bias, scale, shift, 1 if relu else 0, book,
+             tile_order, n_out, K, cin, cout, out, n_live)
+        return out
     call("glx_sconv_forward", features, features.shape[0], weight_kio, packed, bias, scale, shift,
          1 if relu else 0, nbr, tile_order, n_out, K, cin, cout, out, n_live, ws,
          size_arg(ws.numel()))
@@ -305,8 +335,10 @@ class SparseConvFunction(Function):
             nbr, order, n_out = rules.nbr, rules.tile_order_out, rules.N_out
         if rules.count_out is not None and (features.requires_grad or w.requires_grad):
             raise NotImplementedError("shape-static sparse tensors are inference only")
+        book = rules.book() if (USE_RULEBOOK and not inverse
+                                and rulebook_eligible(w.shape[1], w.shape[2], w.shape[0])) else None
         out = _sconv(features, w, bias, nbr, order, n_out, packed=packed, rules=rules,
-                     n_live=rules.count_in if inverse else rules.count_out)
+                     n_live=rules.count_in if inverse else rules.count_out, book=book)
         ctx.rules, ctx.inverse = rules, inverse
         ctx.save_for_backward(features, w)
         ctx.has_bias = bias is not None
@@ -521,7 +553,9 @@ class SparseConvolution(SparseModule):
             feats = _sconv(x_features.contiguous().float(), w.detach().contiguous(), self.bias, nbr,
                            order, n_out, packed=self._packed_weight(w), rules=rs, scale=scale,
                            shift=shift, relu=fused_relu,
-                           n_live=rs.count_in if self.inverse else rs.count_out)
+                           n_live=rs.count_in if self.inverse else rs.count_out,
+                           book=rs.book() if (USE_RULEBOOK and not self.inverse and rulebook_eligible(
+                               w.shape[1], w.shape[2], K)) else None)
         else:
             feats = SparseConvFunction.apply(x_features, w, self.bias, rs, self.inverse,
                                              self._packed_weight(w))

@@ -1,3 +1,4 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; cd $R
-for a in 0 0x200 0x100; do echo "== ABLATE=$a"; ABLATE=$a ONLY6464=1 GEMM=1 NW=8 python tools/sconv_tiles.py 2>&1 | grep -v amdgpu.ids | grep "layer\|duration\|phase\|setup" | head -4; done
+timeout 900 python -m pytest tests/test_sparse_gpu.py -x -q -m gpu 2>&1 | tail -3
+for v in -1 41; do echo "== rb variant $v"; RB_VARIANT=$v timeout 600 python tools/sconv_sweep.py -1 2>&1 | grep "rulebook"; done
