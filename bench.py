@@ -250,7 +250,7 @@ def main():
             tmodel.zero_grad(set_to_none=True)
             bd_["spatial_features"].square().mean().backward()
 
-        run(train_step, 3)
+        run(train_step, 6)
         gdist.fence(dev)
         t1 = time.perf_counter()
         run(train_step, 20)

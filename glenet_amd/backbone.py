@@ -43,10 +43,17 @@ class ResidualBlock(spconv.SparseModule):
             out = self.conv1(x, fused_bn=self.bn1, fused_relu=True)
             out = self.conv2(out, fused_bn=self.bn2)
         else:
+            core = spconv.core
             out = self.conv1(x)
-            out = out.replace_feature(self.relu(self.bn1(out.features)))
+            if core.can_fuse_train_bn(self.bn1, out.features):     # training: fused BN(+ReLU) kernels
+                out = out.replace_feature(core.fused_train_bn(self.bn1, out.features, True))
+            else:
+                out = out.replace_feature(self.relu(self.bn1(out.features)))
             out = self.conv2(out)
-            out = out.replace_feature(self.bn2(out.features))
+            if core.can_fuse_train_bn(self.bn2, out.features):
+                out = out.replace_feature(core.fused_train_bn(self.bn2, out.features, False))
+            else:
+                out = out.replace_feature(self.bn2(out.features))
         return out.replace_feature(self.relu(out.features + x.features))
 
 

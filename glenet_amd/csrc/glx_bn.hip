@@ -1,0 +1,279 @@
+// Training-mode BatchNorm1d (+ ReLU) over the rows of a sparse tensor's feature matrix (N, C):
+// the nn.BatchNorm1d / nn.ReLU pairs that follow every sparse conv in the backbone
+// (pcdet/models/backbones_3d/spconv_backbone.py:21-25, eps 1e-3, momentum 0.01).  In eval mode
+// they are folded into the conv epilogue; in training mode PyTorch spends more device time on
+// them (per layer: statistics 41 us + transform + ReLU + three backward kernels) than on the
+// convolutions.  Here: forward = column statistics (fp64 partial sums, fixed reduction order,
+// so bitwise reproducible) + a one-block finalize + one fused normalise/affine/ReLU pass; backward
+// = column sums of dz and dz*xhat + finalize + one fused dx pass.  HBM-bound (x is read twice).
+#include "glx_common.h"
+
+typedef float bf32x4 __attribute__((ext_vector_type(4)));
+
+#define BN_THREADS 256
+#define BN_MAXC 512
+#define BN_SLABS 64    // row slabs = blocks of the statistics kernels (every apply block re-reads them)
+
+// partial[slab][2][C] (fp64): column sums of (a, a*b) over the slab's rows.
+//   forward : a = x,  b = x                         -> sum x, sum x^2
+//   backward: a = dz, b = xhat = (x - mean)*invstd  -> sum dz, sum dz*xhat   (dz = dy * [y > 0])
+template <bool BWD>
+__global__ __launch_bounds__(BN_THREADS) void k_bn_partial(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+    const float* __restrict__ mean, const float* __restrict__ invstd, int relu, int N, int C,
+    const int* __restrict__ n_live, double* __restrict__ partial) {
+  if (n_live) N = min(N, *n_live);
+  const int c4n = C >> 2;                       // float4 columns
+  const int col = threadIdx.x % c4n, rlane = threadIdx.x / c4n;
+  const int rstep = BN_THREADS / c4n;           // rows covered per pass by the block
+  const int rows_per_slab = (N + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rows_per_slab, r1 = min(N, r0 + rows_per_slab);
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  bf32x4 mu = bf32x4{0, 0, 0, 0}, is = mu;
+  if (BWD) {
+    mu = *reinterpret_cast<const bf32x4*>(mean + 4 * col);
+    is = *reinterpret_cast<const bf32x4*>(invstd + 4 * col);
+  }
+  if (rlane < rstep) {
+    for (int r = r0 + rlane; r < r1; r += rstep) {
+      const long long o = (long long)r * C + 4 * col;
+      bf32x4 xv = *reinterpret_cast<const bf32x4*>(x + o);
+      if (BWD) {
+        bf32x4 g = *reinterpret_cast<const bf32x4*>(dy + o);
+        if (relu) {
+          bf32x4 yv = *reinterpret_cast<const bf32x4*>(y + o);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) g[i] = yv[i] > 0.f ? g[i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          s0[i] += (double)g[i];
+          s1[i] += (double)g[i] * (double)((xv[i] - mu[i]) * is[i]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          s0[i] += (double)xv[i];
+          s1[i] += (double)xv[i] * (double)xv[i];
+        }
+      }
+    }
+  }
+  // fixed-order reduction over the row lanes of the block
+  __shared__ double red[2][BN_THREADS][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { red[0][threadIdx.x][i] = s0[i]; red[1][threadIdx.x][i] = s1[i]; }
+  __syncthreads();
+  if (threadIdx.x < c4n) {
+    double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+    for (int l = 0; l < rstep; ++l) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a0[i] += red[0][l * c4n + threadIdx.x][i];
+        a1[i] += red[1][l * c4n + threadIdx.x][i];
+      }
+    }
+    double* p = partial + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { p[4 * threadIdx.x + i] = a0[i]; p[C + 4 * threadIdx.x + i] = a1[i]; }
+  }
+}
+
+// column sums of the slab partials, all 256 threads busy: thread (c, g) adds slabs g, g+G, ...
+// in a fixed order, then the G groups are combined in LDS.
+__device__ __forceinline__ void bn_column_sums(const double* __restrict__ partial, int slabs, int C,
+                                               int c, int g, int G, double (*s_red)[2],
+                                               double& s, double& ss) {
+  s = 0; ss = 0;
+  for (int b = g; b < slabs; b += G) { s += partial[(size_t)b * 2 * C + c]; ss += partial[(size_t)b * 2 * C + C + c]; }
+  s_red[threadIdx.x][0] = s;
+  s_red[threadIdx.x][1] = ss;
+  __syncthreads();
+  if (g == 0) {
+    for (int k = 1; k < G; ++k) { s += s_red[k * C + c][0]; ss += s_red[k * C + c][1]; }
+  }
+  __syncthreads();
+}
+
+// one block: statistics -> scale / shift (coef[0..C), coef[C..2C)), saved mean / invstd, running stats
+__global__ __launch_bounds__(BN_THREADS) void k_bn_finalize_fwd(
+    const double* __restrict__ partial, int slabs, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float momentum, int N, int C,
+    const int* __restrict__ n_live, float* __restrict__ coef, float* __restrict__ save_mean,
+    float* __restrict__ save_invstd, float* __restrict__ running_mean,
+    float* __restrict__ running_var) {
+  __shared__ double s_red[BN_THREADS][2];
+  int n = N;
+  if (n_live) n = min(N, *n_live);
+  const int CB = C < BN_THREADS ? C : BN_THREADS;      // channels per pass
+  const int G = BN_THREADS / CB;
+  for (int c0 = 0; c0 < C; c0 += CB) {
+    const int c = c0 + threadIdx.x % CB, g = threadIdx.x / CB;
+    double s, ss;
+    bn_column_sums(partial, slabs, C, c, g, G, s_red, s, ss);
+    if (g == 0) {
+      const double cnt = n > 0 ? (double)n : 1.0;
+      const double m = s / cnt;
+      double var = ss / cnt - m * m;
+      if (var < 0) var = 0;
+      const float is = (float)(1.0 / sqrt(var + (double)eps));
+      const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+      coef[c] = is * gm;
+      coef[C + c] = bt - (float)m * is * gm;
+      save_mean[c] = (float)m;
+      save_invstd[c] = is;
+      if (running_mean) {   // nn.BatchNorm semantics: unbiased variance in the running estimate
+        const double unb = n > 1 ? var * cnt / (cnt - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void k_bn_forward_apply(
+    const float* __restrict__ x, const float* __restrict__ coef, int relu, int N, int C,
+    const int* __restrict__ n_live, float* __restrict__ y) {
+  __shared__ float s_scale[BN_MAXC], s_shift[BN_MAXC];
+  int n = N;
+  if (n_live) n = min(N, *n_live);
+  for (int c = threadIdx.x; c < C; c += BN_THREADS) { s_scale[c] = coef[c]; s_shift[c] = coef[C + c]; }
+  __syncthreads();
+  const long long total4 = (long long)n * C / 4;
+  const int c4n = C >> 2;
+  for (long long e = (long long)blockIdx.x * BN_THREADS + threadIdx.x; e < total4;
+       e += (long long)gridDim.x * BN_THREADS) {
+    const int c = (int)(e % c4n) * 4;
+    bf32x4 v = reinterpret_cast<const bf32x4*>(x)[e];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float t = v[i] * s_scale[c + i] + s_shift[c + i];
+      v[i] = relu ? fmaxf(t, 0.f) : t;
+    }
+    reinterpret_cast<bf32x4*>(y)[e] = v;
+  }
+}
+
+// one block: dgamma / dbeta and the coefficients of dx = a * (dz - b - xhat * cc)
+__global__ __launch_bounds__(BN_THREADS) void k_bn_finalize_bwd(
+    const double* __restrict__ partial, int slabs, const float* __restrict__ gamma,
+    const float* __restrict__ invstd, int N, int C, const int* __restrict__ n_live,
+    float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double s_red[BN_THREADS][2];
+  int n = N;
+  if (n_live) n = min(N, *n_live);
+  const int CB = C < BN_THREADS ? C : BN_THREADS;
+  const int G = BN_THREADS / CB;
+  for (int c0 = 0; c0 < C; c0 += CB) {
+    const int c = c0 + threadIdx.x % CB, g = threadIdx.x / CB;
+    double s, sx;
+    bn_column_sums(partial, slabs, C, c, g, G, s_red, s, sx);
+    if (g == 0) {
+      const double cnt = n > 0 ? (double)n : 1.0;
+      coef[c] = (gamma ? gamma[c] : 1.f) * invstd[c];
+      coef[C + c] = (float)(s / cnt);
+      coef[2 * C + c] = (float)(sx / cnt);
+      if (dgamma) dgamma[c] = (float)sx;
+      if (dbeta) dbeta[c] = (float)s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void k_bn_backward_apply(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+    const float* __restrict__ coef, const float* __restrict__ mean, const float* __restrict__ invstd,
+    int relu, int N, int C, const int* __restrict__ n_live, float* __restrict__ dx) {
+  __shared__ float s_a[BN_MAXC], s_b[BN_MAXC], s_c[BN_MAXC], s_mu[BN_MAXC], s_is[BN_MAXC];
+  int n = N;
+  if (n_live) n = min(N, *n_live);
+  for (int c = threadIdx.x; c < C; c += BN_THREADS) {
+    s_a[c] = coef[c]; s_b[c] = coef[C + c]; s_c[c] = coef[2 * C + c];
+    s_mu[c] = mean[c]; s_is[c] = invstd[c];
+  }
+  __syncthreads();
+  const long long total4 = (long long)n * C / 4;
+  const int c4n = C >> 2;
+  for (long long e = (long long)blockIdx.x * BN_THREADS + threadIdx.x; e < total4;
+       e += (long long)gridDim.x * BN_THREADS) {
+    const int c = (int)(e % c4n) * 4;
+    bf32x4 xv = reinterpret_cast<const bf32x4*>(x)[e];
+    bf32x4 g = reinterpret_cast<const bf32x4*>(dy)[e];
+    if (relu) {
+      bf32x4 yv = reinterpret_cast<const bf32x4*>(y)[e];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g[i] = yv[i] > 0.f ? g[i] : 0.f;
+    }
+    bf32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float xh = (xv[i] - s_mu[c + i]) * s_is[c + i];
+      o[i] = s_a[c + i] * (g[i] - s_b[c + i] - xh * s_c[c + i]);
+    }
+    reinterpret_cast<bf32x4*>(dx)[e] = o;
+  }
+}
+
+static bool bn_channels_ok(int C) { return C >= 4 && C <= BN_MAXC && (C & 3) == 0 && BN_THREADS % (C >> 2) == 0; }
+
+// workspace: slab partials (fp64) + 3*C coefficient floats
+static size_t bn_coef_offset(int C) { return glx_align((size_t)BN_SLABS * 2 * C * sizeof(double)); }
+extern "C" size_t glx_bn_workspace_bytes(int C) { return bn_coef_offset(C) + glx_align((size_t)3 * C * sizeof(float)) + 256; }
+
+extern "C" int glx_bn_relu_train_forward(const float* x, int N, int C, const float* gamma,
+                                         const float* beta, float eps, float momentum, int relu,
+                                         float* running_mean, float* running_var, float* y,
+                                         float* save_mean, float* save_invstd,
+                                         const int32_t* n_live, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(bn_channels_ok(C), "glx_bn_relu_train_forward: C=%d must be a multiple of 4 dividing 1024, <= 512", C);
+  GLX_REQUIRE(y && save_mean && save_invstd && (N == 0 || x), "glx_bn_relu_train_forward: null pointer");
+  if (!workspace || workspace_bytes < glx_bn_workspace_bytes(C) - 256) {
+    glx_set_error("glx_bn_relu_train_forward: workspace %zu < %zu bytes", workspace_bytes,
+                  glx_bn_workspace_bytes(C) - 256);
+    return GLX_EWORKSPACE;
+  }
+  if (N <= 0) return GLX_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int slabs = glx_divup(N, 8) > BN_SLABS ? BN_SLABS : glx_divup(N, 8);
+  hipLaunchKernelGGL((k_bn_partial<false>), dim3(slabs), dim3(BN_THREADS), 0, st, x, nullptr, nullptr,
+                     nullptr, nullptr, 0, N, C, n_live, (double*)workspace);
+  const int want = glx_divup((long long)N * C / 4, BN_THREADS * 4);
+  const int blocks = want > 512 ? 512 : want;
+  float* coef = (float*)((char*)workspace + bn_coef_offset(C));
+  hipLaunchKernelGGL(k_bn_finalize_fwd, dim3(1), dim3(BN_THREADS), 0, st, (const double*)workspace,
+                     slabs, gamma, beta, eps, momentum, N, C, n_live, coef, save_mean, save_invstd,
+                     running_mean, running_var);
+  hipLaunchKernelGGL(k_bn_forward_apply, dim3(blocks < 1 ? 1 : blocks), dim3(BN_THREADS), 0, st, x,
+                     (const float*)coef, relu, N, C, n_live, y);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+extern "C" int glx_bn_relu_backward(const float* x, const float* dy, const float* y, int N, int C,
+                                    const float* gamma, const float* save_mean,
+                                    const float* save_invstd, int relu, float* dx, float* dgamma,
+                                    float* dbeta, const int32_t* n_live, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(bn_channels_ok(C), "glx_bn_relu_backward: C=%d not supported", C);
+  GLX_REQUIRE(save_mean && save_invstd && (N == 0 || (x && dy && dx)) && (!relu || y || N == 0),
+              "glx_bn_relu_backward: null pointer");
+  if (!workspace || workspace_bytes < glx_bn_workspace_bytes(C) - 256) {
+    glx_set_error("glx_bn_relu_backward: workspace %zu < %zu bytes", workspace_bytes,
+                  glx_bn_workspace_bytes(C) - 256);
+    return GLX_EWORKSPACE;
+  }
+  if (N <= 0) return GLX_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int slabs = glx_divup(N, 8) > BN_SLABS ? BN_SLABS : glx_divup(N, 8);
+  hipLaunchKernelGGL((k_bn_partial<true>), dim3(slabs), dim3(BN_THREADS), 0, st, x, dy, y, save_mean,
+                     save_invstd, relu, N, C, n_live, (double*)workspace);
+  const int want = glx_divup((long long)N * C / 4, BN_THREADS * 4);
+  const int blocks = want > 512 ? 512 : want;
+  float* coef = (float*)((char*)workspace + bn_coef_offset(C));
+  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(1), dim3(BN_THREADS), 0, st, (const double*)workspace,
+                     slabs, gamma, save_invstd, N, C, n_live, coef, dgamma, dbeta);
+  hipLaunchKernelGGL(k_bn_backward_apply, dim3(blocks < 1 ? 1 : blocks), dim3(BN_THREADS), 0, st, x,
+                     dy, y, (const float*)coef, save_mean, save_invstd, relu, N, C, n_live, dx);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

@@ -588,6 +588,62 @@ def _bn_affine(bn):
     return cache[1], cache[2]
 
 
+class FusedBNReLU(Function):
+    """Training-mode BatchNorm1d (+ReLU) on (N, C) features in two launches forward and two
+    backward (csrc/glx_bn.hip); numerics of nn.BatchNorm1d(eps, momentum) + nn.ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu):
+        x = x.contiguous().float()
+        N, C = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = workspace.get(query("glx_bn_workspace_bytes", C), x.device)
+        call("glx_bn_relu_train_forward", x, N, C, weight, bias, ctypes_float(eps), ctypes_float(momentum),
+             1 if relu else 0, running_mean, running_var, y, mean, invstd, None, ws, size_arg(ws.numel()))
+        ctx.save_for_backward(x, y, weight, mean, invstd)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, mean, invstd = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        N, C = x.shape
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = workspace.get(query("glx_bn_workspace_bytes", C), x.device)
+        call("glx_bn_relu_backward", x, dy, y, N, C, weight, mean, invstd, 1 if ctx.relu else 0, dx,
+             dgamma, dbeta, None, ws, size_arg(ws.numel()))
+        return dx, (dgamma if weight is not None else None), (dbeta if weight is not None else None), \
+            None, None, None, None, None
+
+
+def ctypes_float(v):
+    import ctypes
+    return ctypes.c_float(float(v))
+
+
+USE_FUSED_TRAIN_BN = os.environ.get("GLX_FUSED_BN", "1") != "0"
+
+
+def can_fuse_train_bn(bn, features):
+    """Training-mode BatchNorm1d that the fused kernels cover (else nn.BatchNorm1d runs)."""
+    c = bn.num_features
+    return (USE_FUSED_TRAIN_BN and isinstance(bn, nn.BatchNorm1d) and bn.training and bn.affine and bn.momentum is not None
+            and features.is_cuda and features.shape[0] > 1 and c % 4 == 0 and c <= 512 and 1024 % c == 0)
+
+
+def fused_train_bn(bn, features, relu):
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    out = FusedBNReLU.apply(features, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, relu)
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return out
+
+
 def can_fuse_bn(bn):
     return (isinstance(bn, nn.BatchNorm1d) and not bn.training and bn.track_running_stats
             and not torch.is_grad_enabled())
@@ -653,6 +709,12 @@ class SparseSequential(SparseModule):
                 relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
                 x = m(x, fused_bn=mods[i + 1], fused_relu=relu)
                 i += 3 if relu else 2
+                continue
+            if (isinstance(x, SparseConvTensor) and isinstance(m, nn.BatchNorm1d) and x.count is None
+                    and x.indices.shape[0] > 1 and can_fuse_train_bn(m, x.features)):
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = x.replace_feature(fused_train_bn(m, x.features, relu))
+                i += 2 if relu else 1
                 continue
             if is_spconv_module(m):
                 x = m(x)

@@ -318,6 +318,25 @@ int glx_group_points_grad(int B, int M, int C, int N, int nsample, const float* 
                           const int32_t* features_batch_cnt, float* grad_features, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Training-mode BatchNorm1d (+ ReLU) over sparse-tensor features x (N, C), C a multiple of 4 that
+ * divides 1024 (16 ... 512).  Semantics of nn.BatchNorm1d(eps, momentum) followed by nn.ReLU as
+ * the backbone applies them after every sparse conv (spconv_backbone.py:21-25,73): batch
+ * statistics (biased variance) normalise, the running estimates take the unbiased variance.
+ * Deterministic (fixed reduction order, fp64 partial sums).  relu = 0 gives plain BatchNorm.
+ * ------------------------------------------------------------------------------------ */
+size_t glx_bn_workspace_bytes(int C);
+int glx_bn_relu_train_forward(const float* x, int N, int C, const float* gamma, const float* beta,
+                              float eps, float momentum, int relu, float* running_mean,
+                              float* running_var, float* y, float* save_mean, float* save_invstd,
+                              const int32_t* n_live, void* workspace, size_t workspace_bytes,
+                              void* stream);
+/* dx (N,C), dgamma (C), dbeta (C) from dy and the forward's x, y (needed when relu), mean, invstd. */
+int glx_bn_relu_backward(const float* x, const float* dy, const float* y, int N, int C,
+                         const float* gamma, const float* save_mean, const float* save_invstd,
+                         int relu, float* dx, float* dgamma, float* dbeta, const int32_t* n_live,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * PV-RCNN set-abstraction operators (same extension module in the reference).
  * ------------------------------------------------------------------------------------ */
 

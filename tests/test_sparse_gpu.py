@@ -292,3 +292,32 @@ def test_dense_and_empty(dev):
     c2 = sp.SparseConv3d(16, 32, 3, stride=2, padding=1, bias=False).to(dev)
     y = c2(c1(e))
     assert y.features.shape == (0, 32) and y.indices.shape == (0, 4)
+
+
+@pytest.mark.parametrize("C,relu,N", [(16, True, 5000), (64, True, 48000), (128, False, 777), (32, True, 2)])
+def test_fused_train_batchnorm_matches_torch(dev, C, relu, N):
+    """glx_bn_relu_train_forward / _backward vs nn.BatchNorm1d (+ nn.ReLU) in training mode:
+    outputs, running statistics, input and affine gradients."""
+    torch.manual_seed(C + N)
+    x = (torch.randn(N, C, device=dev) * 2 + 0.5)
+    bn_ref = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).to(dev).train()
+    bn = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).to(dev).train()
+    with torch.no_grad():
+        bn_ref.weight.copy_(torch.rand(C) + 0.5); bn_ref.bias.copy_(torch.randn(C) * 0.2)
+        bn.load_state_dict(bn_ref.state_dict())
+    xr = x.clone().requires_grad_(True)
+    yr = bn_ref(xr)
+    yr = torch.relu(yr) if relu else yr
+    xf = x.clone().requires_grad_(True)
+    assert sp.can_fuse_train_bn(bn, xf)
+    yf = sp.fused_train_bn(bn, xf, relu)
+    np.testing.assert_allclose(yf.detach().cpu().numpy(), yr.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), bn_ref.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), bn_ref.running_var.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == 1
+    g = torch.randn(N, C, device=dev)
+    yr.backward(g)
+    yf.backward(g)
+    np.testing.assert_allclose(xf.grad.cpu().numpy(), xr.grad.cpu().numpy(), rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(bn.weight.grad.cpu().numpy(), bn_ref.weight.grad.cpu().numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(bn.bias.grad.cpu().numpy(), bn_ref.bias.grad.cpu().numpy(), rtol=1e-4, atol=1e-3)

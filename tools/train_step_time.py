@@ -29,7 +29,8 @@ def step(backward):
         bd["spatial_features"].square().mean().backward()
 
 
-for name, bw in (("fwd (train mode, BN batch stats)", False), ("fwd+bwd", True)):
+for name, bw in (("fwd (train mode, BN batch stats)", False), ("fwd+bwd", True),
+                 ("fwd again", False), ("fwd+bwd again", True)):
     for _ in range(3):
         step(bw)
     torch.cuda.synchronize()
