@@ -151,6 +151,101 @@ __device__ __forceinline__ float box_area(const float* b) {
   return OLD ? (b[2] - b[0]) * (b[3] - b[1]) : b[3] * b[4];
 }
 
+// ---- prepared boxes: the per-box part of the rotated overlap (corners' frame, heading trig in
+// double rounded once, bounding radius) computed ONCE per box instead of once per pair.
+struct PBox {
+  float cx, cy, hx, hy, c, s, rad, area;
+};
+
+__global__ void k_nms_prepare(const float* __restrict__ boxes, int N, PBox* __restrict__ pb) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float* b = boxes + (long long)i * 7;
+  PBox p;
+  p.cx = b[0]; p.cy = b[1];
+  p.hx = b[3] / 2; p.hy = b[4] / 2;
+  p.c = f_cos(b[6]); p.s = f_sin(b[6]);
+  // cos(-a) == cos(a), sin(-a) == -sin(a) exactly (even / odd, also after rounding), so the inverse
+  // rotation of the reference's inside test needs no second evaluation
+  p.rad = sqrtf(p.hx * p.hx + p.hy * p.hy);
+  p.area = b[3] * b[4];
+  pb[i] = p;
+}
+
+__device__ __forceinline__ RBox<false> rbox_from(const PBox& p) {
+  RBox<false> r;
+  r.hx = p.hx; r.hy = p.hy;
+  r.x1 = p.cx - p.hx; r.y1 = p.cy - p.hy; r.x2 = p.cx + p.hx; r.y2 = p.cy + p.hy;
+  r.cx = p.cx; r.cy = p.cy;
+  r.c = p.c; r.s = p.s; r.nc = p.c; r.ns = -p.s;
+  return r;
+}
+
+// Boxes whose centres are further apart than the sum of their bounding radii (+ the 1e-2 margin
+// of the corner-inside test, + slack for rounding) share no intersection point and no contained
+// corner: the reference routine returns exactly 0 for them, so they can be skipped.
+__device__ __forceinline__ bool pbox_far(const PBox& a, const PBox& b) {
+  const float dx = a.cx - b.cx, dy = a.cy - b.cy, reach = a.rad + b.rad + 0.05f;
+  return dx * dx + dy * dy > reach * reach;
+}
+
+// (N, M) overlap / IoU matrix in the iou3d_nms convention, one block per 64 x 64 tile: the 128 boxes
+// of the tile are prepared once in LDS (trig per box, not per pair), pairs that are exactly zero by
+// the far-apart test are written as 0 straight away, the survivors are queued and evaluated
+// densely (a thread per surviving pair) -- same two-phase scheme as k_nms_mask.
+__global__ __launch_bounds__(256) void k_pairwise_tile(const float* __restrict__ a, int N,
+                                                       const float* __restrict__ b, int M, int mode,
+                                                       float* __restrict__ out) {
+  __shared__ PBox s_row[64], s_col[64];
+  __shared__ unsigned short s_q[64 * 64];
+  __shared__ int s_n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+  if (tid == 0) s_n = 0;
+  if (tid < 128) {
+    const bool isrow = tid < 64;
+    const int idx = isrow ? i0 + tid : j0 + tid - 64;
+    const int lim = isrow ? N : M;
+    if (idx < lim) {
+      const float* bx = (isrow ? a : b) + (long long)idx * 7;
+      PBox p;
+      p.cx = bx[0]; p.cy = bx[1];
+      p.hx = bx[3] / 2; p.hy = bx[4] / 2;
+      p.c = f_cos(bx[6]); p.s = f_sin(bx[6]);
+      p.rad = sqrtf(p.hx * p.hx + p.hy * p.hy);
+      p.area = bx[3] * bx[4];
+      (isrow ? s_row : s_col)[isrow ? tid : tid - 64] = p;
+    }
+  }
+  __syncthreads();
+  const int j = j0 + lane;
+  const bool jok = j < M;
+  const PBox B = s_col[jok ? lane : 0];
+  for (int it = 0; it < 16; ++it) {
+    const int rl = wave * 16 + it, i = i0 + rl;
+    if (i >= N) break;   // wave-uniform
+    const PBox A = s_row[rl];
+    const bool pass = jok && !pbox_far(A, B);
+    if (jok && !pass) out[(long long)i * M + j] = 0.f;
+    const unsigned long long bal = __ballot(pass);
+    if (bal) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&s_n, __popcll(bal));
+      base = __shfl(base, 0, 64);
+      if (pass) s_q[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)((rl << 6) | lane);
+    }
+  }
+  __syncthreads();
+  const int n = s_n;
+  for (int e = tid; e < n; e += 256) {
+    const int rl = s_q[e] >> 6, cl = s_q[e] & 63;
+    const PBox A = s_row[rl], Bq = s_col[cl];
+    float v = box_overlap<false>(rbox_from(A), rbox_from(Bq));
+    if (mode == 1) v = v / fmaxf(A.area + Bq.area - v, IOU_EPS);
+    out[(long long)(i0 + rl) * M + j0 + cl] = v;
+  }
+}
+
 // mode 0: overlap area, 1: IoU
 template <bool OLD, int STRIDE>
 __global__ void k_pairwise(const float* __restrict__ a, int N, const float* __restrict__ b, int M,
@@ -181,9 +276,8 @@ extern "C" int glx_boxes_overlap_bev(const float* boxes_a, int N, const float* b
                                      int iou, float* out, void* stream) {
   if (N == 0 || M == 0) return GLX_OK;
   GLX_REQUIRE(boxes_a && boxes_b && out, "glx_boxes_overlap_bev: null pointer");
-  dim3 grid(glx_divup(M, 16), glx_divup(N, 16)), block(16, 16);
-  hipLaunchKernelGGL((k_pairwise<false, 7>), grid, block, 0, (hipStream_t)stream, boxes_a, N,
-                     boxes_b, M, iou ? 1 : 0, out);
+  hipLaunchKernelGGL(k_pairwise_tile, dim3(glx_divup(M, 64), glx_divup(N, 64)), dim3(256), 0,
+                     (hipStream_t)stream, boxes_a, N, boxes_b, M, iou ? 1 : 0, out);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
@@ -231,90 +325,161 @@ __device__ __forceinline__ float iou_normal(const float* a, const float* b) {
   return interS / fmaxf(Sa + Sb - interS, IOU_EPS);
 }
 
-// Upper-triangular suppression matrix: block (col tile c >= row tile r), 64 threads = 64 rows.
-// mask[i][c] bit j = iou(box i, box 64c+j) > thresh for 64c+j > i  (nms_kernel, :267-311).
+// Upper-triangular suppression matrix, one block per 64 x 64 tile (col tile c >= row tile r)
+// (nms_kernel, iou3d_nms_kernel.cu:267-311).  Two phases, because a wave that runs the rotated
+// overlap for one surviving lane out of 64 wastes the other 63:
+//   1. lane = column box, every wave walks 16 rows: pairs that pass the exact far-apart test are
+//      appended to a queue in LDS (ballot + one LDS atomic per wave-row);
+//   2. the queue is processed densely, a thread per surviving pair; hits are OR-ed into the
+//      tile's 64 mask words in LDS.
+// Layout: maskT[c][i] (column-block major) -- the sweep reads one column block for many rows.
 template <bool NORMAL>
-__global__ void k_nms_mask(const float* __restrict__ boxes, int N, float thresh, int col_blocks,
-                           unsigned long long* __restrict__ mask) {
-  // linear block id -> (r, c) with c >= r
-  int b = blockIdx.x;
-  int r = 0;
-  // rows r has (col_blocks - r) tiles; find r by subtraction (col_blocks <= ~1000: cheap)
-  int rem = b;
-  while (rem >= col_blocks - r) { rem -= col_blocks - r; ++r; }
+__global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxes,
+                                                  const PBox* __restrict__ pb, int N, float thresh,
+                                                  int col_blocks,
+                                                  unsigned long long* __restrict__ maskT) {
+  int rem = blockIdx.x, r = 0;
+  while (rem >= col_blocks - r) { rem -= col_blocks - r; ++r; }   // linear id -> (r, c >= r)
   const int c = r + rem;
-  __shared__ float sb[64 * 7];
-  const int t = threadIdx.x;
-  const int jbase = c * 64;
-  const int col_size = min(N - jbase, 64);
-  if (t < col_size)
-    for (int e = 0; e < 7; ++e) sb[t * 7 + e] = boxes[(long long)(jbase + t) * 7 + e];
-  __syncthreads();
-  const int i = r * 64 + t;
-  if (i >= N) return;
-  unsigned long long bits = 0;
-  const float* bi = boxes + (long long)i * 7;
-  int start = (r == c) ? t + 1 : 0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ unsigned long long s_bits[64];
+  __shared__ unsigned short s_q[64 * 64];
+  __shared__ int s_n;
+  __shared__ PBox s_col[64];
+  if (tid < 64) s_bits[tid] = 0ull;
+  if (tid == 0) s_n = 0;
+  const int j = c * 64 + lane;
+  const bool jok = j < N;
   if (NORMAL) {
-    for (int j = start; j < col_size; ++j)
-      if (iou_normal(bi, sb + j * 7) > thresh) bits |= 1ull << j;
+    __syncthreads();
+    float bj[7];
+    if (jok) {
+#pragma unroll
+      for (int e = 0; e < 7; ++e) bj[e] = boxes[(long long)j * 7 + e];
+    }
+    for (int it = 0; it < 16; ++it) {
+      const int rl = wave * 16 + it, i = r * 64 + rl;
+      if (i >= N) break;
+      const bool hit = jok && j > i && iou_normal(boxes + (long long)i * 7, bj) > thresh;
+      const unsigned long long bits = __ballot(hit);
+      if (lane == 0) s_bits[rl] = bits;
+    }
   } else {
-    RBox<false> A;
-    A.load(bi);
-    float sa = bi[3] * bi[4];
-    for (int j = start; j < col_size; ++j) {
-      RBox<false> B;
-      B.load(sb + j * 7);
-      float s = box_overlap<false>(A, B);
-      float iou = s / fmaxf(sa + sb[j * 7 + 3] * sb[j * 7 + 4] - s, IOU_EPS);
-      if (iou > thresh) bits |= 1ull << j;
+    if (wave == 0 && jok) s_col[lane] = pb[j];
+    __syncthreads();
+    const PBox B = s_col[jok ? lane : 0];
+    for (int it = 0; it < 16; ++it) {
+      const int rl = wave * 16 + it, i = r * 64 + rl;
+      if (i >= N) break;   // wave-uniform
+      const PBox A = pb[i];   // uniform address: one broadcast load
+      const bool pass = jok && j > i && (thresh < 0.f || !pbox_far(A, B));
+      const unsigned long long bal = __ballot(pass);
+      if (bal) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_n, __popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (pass) s_q[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)((rl << 6) | lane);
+      }
+    }
+    __syncthreads();
+    const int n = s_n;
+    for (int e = tid; e < n; e += 256) {
+      const int rl = s_q[e] >> 6, cl = s_q[e] & 63;
+      const PBox A = pb[r * 64 + rl], Bq = s_col[cl];
+      const float sgm = box_overlap<false>(rbox_from(A), rbox_from(Bq));
+      if (sgm / fmaxf(A.area + Bq.area - sgm, IOU_EPS) > thresh) atomicOr(&s_bits[rl], 1ull << cl);
     }
   }
-  mask[(long long)i * col_blocks + c] = bits;
+  __syncthreads();
+  if (tid < 64 && r * 64 + tid < N) maskT[(long long)c * N + r * 64 + tid] = s_bits[tid];
 }
 
-// One wave sweeps the matrix 64 boxes at a time (host loop of iou3d_nms.cpp:119-132):
-// lane j holds the removed-bits of column word j, j+64, ... ; inside a 64-box word the greedy
-// chain runs on the diagonal tile only.
-__global__ void k_nms_sweep(const unsigned long long* __restrict__ mask, int N, int col_blocks,
-                            long long* __restrict__ keep, int* __restrict__ num_out) {
-  extern __shared__ unsigned long long remv[];   // col_blocks words
-  const int lane = threadIdx.x;
-  for (int w = lane; w < col_blocks; w += 64) remv[w] = 0ull;
+// Greedy sweep of the matrix, 64 boxes per step (host loop of iou3d_nms.cpp:119-132), one block of
+// 256 threads.  The removed-word of column block b is evaluated ON DEMAND: OR over the boxes kept
+// so far of maskT[b][box] -- all threads gather from one contiguous column block (L2-friendly) and
+// combine with a wave reduction + LDS; then wave 0 resolves the diagonal tile and appends the newly
+// kept boxes.  Same greedy order as the reference, so the keep list is identical.
+#define SWEEP_THREADS 1024
+__global__ __launch_bounds__(SWEEP_THREADS) void k_nms_sweep(
+    const unsigned long long* __restrict__ maskT, int N, int col_blocks,
+    long long* __restrict__ keep, int* __restrict__ num_out) {
+  extern __shared__ int s_keep[];   // kept boxes so far (the gather list of every later step)
+  __shared__ unsigned long long s_part[SWEEP_THREADS / 64];
+  __shared__ int s_num;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_num = 0;
+  // diagonal word of block 0, one step ahead from here on (its load latency hides behind the gather)
+  unsigned long long diag = (wave == 0 && lane < min(64, N)) ? maskT[lane] : 0ull;
   __syncthreads();
-  int num = 0;
   for (int b = 0; b < col_blocks; ++b) {
     const int base = b * 64;
     const int nb = min(64, N - base);
-    // diagonal tile: lane j holds row (base+j)'s word b (bits of later boxes in this word)
-    unsigned long long diag = (lane < nb) ? mask[(long long)(base + lane) * col_blocks + b] : 0ull;
-    unsigned long long cur = remv[b];
-    unsigned long long kept = 0ull;
-    for (int j = 0; j < nb; ++j) {
-      unsigned long long dj = __shfl(diag, j, 64);
-      if (!((cur >> j) & 1ull)) {
-        kept |= 1ull << j;
-        cur |= dj;
-      }
+    const int num = s_num;
+    // removed bits of this block from every box kept so far (all of them precede `base`):
+    // independent gathers from one contiguous column block, up to 4 in flight per thread
+    const unsigned long long* col = maskT + (long long)b * N;
+    unsigned long long acc = 0ull;
+    int e = tid;
+    for (; e + 3 * SWEEP_THREADS < num; e += 4 * SWEEP_THREADS) {
+      const unsigned long long v0 = col[s_keep[e]], v1 = col[s_keep[e + SWEEP_THREADS]],
+                               v2 = col[s_keep[e + 2 * SWEEP_THREADS]],
+                               v3 = col[s_keep[e + 3 * SWEEP_THREADS]];
+      acc |= (v0 | v1) | (v2 | v3);
     }
-    // emit kept indices in order, OR their rows into the later words
-    unsigned long long k2 = kept;
-    while (k2) {
-      int j = __ffsll((long long)k2) - 1;
-      k2 &= k2 - 1;
-      if (lane == 0) keep[num] = base + j;
-      ++num;
-      const unsigned long long* row = mask + (long long)(base + j) * col_blocks;
-      for (int w = b + 1 + lane; w < col_blocks; w += 64) remv[w] |= row[w];
+    for (; e < num; e += SWEEP_THREADS) acc |= col[s_keep[e]];
+    unsigned long long diag_next = 0ull;
+    if (wave == 0 && b + 1 < col_blocks && base + 64 + lane < N)
+      diag_next = maskT[(long long)(b + 1) * N + base + 64 + lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc |= __shfl_xor(acc, o, 64);
+    if (lane == 0) s_part[wave] = acc;
+    __syncthreads();
+    if (wave == 0) {
+      unsigned long long cur = (lane < SWEEP_THREADS / 64) ? s_part[lane] : 0ull;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) cur |= __shfl_xor(cur, o, 64);
+      // greedy chain inside the 64-box word on the scalar unit: lane jj's diagonal word is read
+      // with v_readlane (uniform index), the removed set lives in an SGPR pair
+      const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+      unsigned clo = __builtin_amdgcn_readfirstlane((unsigned)cur);
+      unsigned chi = __builtin_amdgcn_readfirstlane((unsigned)(cur >> 32));
+      unsigned klo = 0u, khi = 0u;
+#pragma unroll
+      for (int jj = 0; jj < 32; ++jj) {
+        const unsigned rl = __builtin_amdgcn_readlane(dlo, jj), rh = __builtin_amdgcn_readlane(dhi, jj);
+        const bool fr = !((clo >> jj) & 1u);
+        klo |= fr ? (1u << jj) : 0u;
+        clo |= fr ? rl : 0u;
+        chi |= fr ? rh : 0u;
+      }
+#pragma unroll
+      for (int jj = 0; jj < 32; ++jj) {
+        const unsigned rh = __builtin_amdgcn_readlane(dhi, 32 + jj);   // bits above 32+jj only
+        const bool fr = !((chi >> jj) & 1u);
+        khi |= fr ? (1u << jj) : 0u;
+        chi |= fr ? rh : 0u;
+      }
+      unsigned long long kept = ((unsigned long long)khi << 32) | klo;
+      if (nb < 64) kept &= (1ull << nb) - 1ull;
+      if ((kept >> lane) & 1ull) {
+        const int pos = num + __popcll(kept & ((1ull << lane) - 1ull));
+        s_keep[pos] = base + lane;
+        keep[pos] = base + lane;
+      }
+      if (lane == 0) s_num = num + __popcll(kept);
+      diag = diag_next;
     }
     __syncthreads();
   }
-  if (lane == 0) *num_out = num;
+  if (tid == 0) *num_out = s_num;
 }
 
-extern "C" size_t glx_nms_workspace_bytes(int N) {
+static size_t nms_mask_bytes(int N) {
   size_t cb = (size_t)((N + 63) / 64);
-  return glx_align((size_t)(N > 0 ? N : 1) * cb * 8) + 256;
+  return glx_align((size_t)(N > 0 ? N : 1) * cb * 8);
+}
+extern "C" size_t glx_nms_workspace_bytes(int N) {   // suppression matrix + prepared boxes
+  return nms_mask_bytes(N) + glx_align((size_t)(N > 0 ? N : 1) * sizeof(PBox)) + 256;
 }
 
 extern "C" int glx_nms(const float* boxes_sorted, int N, float thresh, int normal, int64_t* keep,
@@ -329,22 +494,33 @@ extern "C" int glx_nms(const float* boxes_sorted, int N, float thresh, int norma
   }
   GLX_REQUIRE(boxes_sorted, "glx_nms: null boxes");
   int col_blocks = (N + 63) / 64;
-  size_t need = (size_t)N * col_blocks * 8;
+  size_t need = glx_nms_workspace_bytes(N) - 256;
   if (!workspace || workspace_bytes < need) {
     glx_set_error("glx_nms: workspace %zu < %zu bytes", workspace_bytes, need);
     return GLX_EWORKSPACE;
   }
   unsigned long long* mask = (unsigned long long*)workspace;
-  // lower-triangle words are never written by the mask kernel but the sweep only reads
-  // words >= the row's own block, so no clearing is needed.
+  PBox* pb = (PBox*)((char*)workspace + nms_mask_bytes(N));
+  // words of the lower triangle (row block > column block) are never written and never read:
+  // the sweep ORs column block b only over boxes kept BEFORE block b, plus the diagonal tile.
   int ntiles = col_blocks * (col_blocks + 1) / 2;
-  if (normal)
-    hipLaunchKernelGGL((k_nms_mask<true>), dim3(ntiles), dim3(64), 0, st, boxes_sorted, N, thresh,
-                       col_blocks, mask);
-  else
-    hipLaunchKernelGGL((k_nms_mask<false>), dim3(ntiles), dim3(64), 0, st, boxes_sorted, N, thresh,
-                       col_blocks, mask);
-  hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), (size_t)col_blocks * 8, st,
+  if (normal) {
+    hipLaunchKernelGGL((k_nms_mask<true>), dim3(ntiles), dim3(256), 0, st, boxes_sorted,
+                       (const PBox*)nullptr, N, thresh, col_blocks, mask);
+  } else {
+    hipLaunchKernelGGL(k_nms_prepare, dim3(glx_divup(N, 256)), dim3(256), 0, st, boxes_sorted, N, pb);
+    hipLaunchKernelGGL((k_nms_mask<false>), dim3(ntiles), dim3(256), 0, st, boxes_sorted,
+                       (const PBox*)pb, N, thresh, col_blocks, mask);
+  }
+  GLX_REQUIRE((size_t)N * 4 <= 150 * 1024, "glx_nms: N = %d exceeds the %d boxes the sweep keeps in LDS", N,
+              150 * 1024 / 4);
+  static bool sweep_attr = false;
+  if (!sweep_attr) {
+    GLX_HIP(hipFuncSetAttribute((const void*)k_nms_sweep, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                150 * 1024));
+    sweep_attr = true;
+  }
+  hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(SWEEP_THREADS), (size_t)N * 4, st,
                      (const unsigned long long*)mask, N, col_blocks, (long long*)keep, num_out);
   GLX_LAUNCH_CHECK();
   return GLX_OK;

@@ -1,0 +1,58 @@
+"""Config-3 shaped inference data flow on one GPU (eager): voxelize -> sparse backbone -> BEV
+backbone + anchor head -> proposals (device NMS) -> RoI-grid pool -> FC refine, 4 frames."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from glenet_amd import detector as det, synth  # noqa: E402
+
+K = synth.KITTI
+dev = torch.device("cuda", 0)
+B = 4
+frames = [synth.kitti_frame(i)[0] for i in range(B)]
+pts = torch.from_numpy(np.concatenate(frames)).to(dev)
+bidx = torch.from_numpy(np.concatenate([np.full(len(f), i, np.int32) for i, f in enumerate(frames)])).to(dev)
+torch.manual_seed(0)
+torch.backends.cudnn.benchmark = True
+flow = det.VoxelRCNNFlow(K).to(dev).eval()
+
+
+def stage_times():
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    from glenet_amd import backbone as gb
+    with torch.no_grad():
+        ev[0].record()
+        bd = gb.voxelize_batch(pts, bidx, B, K, train=False)
+        bd = flow.map_to_bev(flow.backbone_3d(flow.vfe(bd)))
+        ev[1].record()
+        bd = flow.dense_head(flow.backbone_2d(bd))
+        ev[2].record()
+        cls, boxes = det.predicted_boxes(bd["cls_preds"], bd["box_preds"], bd.get("dir_cls_preds"),
+                                         flow.anchors(dev))
+        rois, _, _ = det.proposal_layer(boxes, cls, *flow.nms)
+        ev[3].record()
+        pooled = flow.roi_pool(rois, bd["multi_scale_3d_features"], bd["multi_scale_3d_strides"], B)
+        flow.roi_fc(pooled)
+        ev[4].record()
+    torch.cuda.synchronize()
+    return [ev[i].elapsed_time(ev[i + 1]) for i in range(4)]
+
+
+with torch.no_grad():
+    for _ in range(5):
+        flow(pts, bidx, B)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 30
+    for _ in range(n):
+        flow(pts, bidx, B)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+st = np.mean([stage_times() for _ in range(5)], axis=0)
+print("two-stage inference flow, %d frames: %.2f ms/step = %.0f frames/s (eager, exact shapes)" % (B, dt * 1e3, B / dt))
+print("  stages (ms): voxelize+sparse backbone+dense %.2f | BEV backbone+head (MIOpen fp32) %.2f | "
+      "decode+top-k+NMS %.2f | RoI-grid pool+FC %.2f" % tuple(st))
