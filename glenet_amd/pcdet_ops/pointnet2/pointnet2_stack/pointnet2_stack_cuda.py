@@ -93,3 +93,13 @@ for _n in ("query_stacked_local_neighbor_idxs_wrapper_stack",
            "query_three_nn_by_stacked_local_idxs_wrapper_stack", "vector_pool_wrapper",
            "vector_pool_grad_wrapper"):
     globals()[_n] = _next_tier(_n)
+
+
+def voxel_pool_agg_wrapper(M, nsample, Cm, Co, feats, xyz, new_xyz, idx, empty, w_pos, b_pos, w_out,
+                           b_out, out):
+    """Fused grouping + position MLP + ReLU + max-pool + output MLP of one RoI-grid pooling scale
+    (inference; no reference counterpart -- it replaces the tensor ops of
+    voxel_pool_modules.py:88-108)."""
+    _lib.check_cuda(feats, xyz, new_xyz, idx, empty, w_pos, b_pos, w_out, b_out, out)
+    call("glx_voxel_pool_agg", feats, xyz, new_xyz, idx, empty, M, nsample, Cm, Co, w_pos, b_pos,
+         w_out, b_out, out)

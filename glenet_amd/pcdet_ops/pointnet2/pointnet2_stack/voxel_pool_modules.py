@@ -46,6 +46,8 @@ class NeighborVoxelSAModuleMSG(nn.Module):
         coords of the grid points, features (N,C), voxel2point_indices: dense (B,Z,Y,X) map or the
         SparseConvTensor itself -> (M, sum of mlps[k][-1])."""
         coords_bzyx = new_coords[:, [0, 3, 2, 1]].contiguous()      # voxel_pool_modules.py:84
+        if self._fusable(features):
+            return self._forward_fused(xyz, new_xyz, coords_bzyx, features, voxel2point_indices)
         outs = []
         for grouper, mlp_in, mlp_pos, mlp_out in zip(self.groupers, self.mlps_in, self.mlps_pos,
                                                      self.mlps_out):
@@ -65,3 +67,56 @@ class NeighborVoxelSAModuleMSG(nn.Module):
                 raise NotImplementedError
             outs.append(mlp_out(x).squeeze(0).t())
         return torch.cat(outs, dim=1)
+
+    # ---- inference fast path: one kernel per scale after the voxel query (csrc/glx_points.hip,
+    # k_voxel_pool_agg).  Same arithmetic with the eval-mode BatchNorms folded into the 1x1 convs;
+    # the (M, C, ns) grouped tensors are never materialised.
+    USE_FUSED = True
+
+    def _fusable(self, features):
+        return (self.USE_FUSED and not self.training and not torch.is_grad_enabled()
+                and features.is_cuda and features.dtype == torch.float32
+                and self.pool_method == 'max_pool'
+                and all(m[0].out_channels <= 64 for m in self.mlps_out)
+                and all(m[0].out_channels <= 64 for m in self.mlps_in))
+
+    @staticmethod
+    def _fold(conv, bn):
+        s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        w = conv.weight.reshape(conv.out_channels, conv.in_channels) * s[:, None]
+        b = bn.bias - bn.running_mean * s
+        if conv.bias is not None:
+            b = b + conv.bias * s
+        return w.float().contiguous(), b.float().contiguous()
+
+    def _folded(self):
+        mods = [m for seq in (*self.mlps_in, *self.mlps_pos, *self.mlps_out) for m in (seq[0], seq[1])]
+        tensors = [t for m in mods for t in (m.weight, m.bias) if t is not None]
+        tensors += [t for m in mods if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d))
+                    for t in (m.running_mean, m.running_var)]
+        tag = tuple((t._version, t.data_ptr()) for t in tensors)
+        cache = self.__dict__.get("_glx_folded")
+        if cache is None or cache[0] != tag:
+            with torch.no_grad():
+                cache = (tag, [tuple(self._fold(seq[0], seq[1]) for seq in (a, b, c))
+                               for a, b, c in zip(self.mlps_in, self.mlps_pos, self.mlps_out)])
+            self.__dict__["_glx_folded"] = cache
+        return cache[1]
+
+    def _forward_fused(self, xyz, new_xyz, coords_bzyx, features, voxel2point_indices):
+        from . import pointnet2_stack_cuda as pointnet2
+        m = new_xyz.shape[0]
+        xyz, new_xyz = xyz.contiguous(), new_xyz.contiguous()
+        widths = [seq[0].out_channels for seq in self.mlps_out]
+        out = torch.empty((m, sum(widths)), dtype=torch.float32, device=features.device)
+        outs = []
+        for grouper, ((w_in, b_in), (w_pos, b_pos), (w_out, b_out)) in zip(self.groupers, self._folded()):
+            feats = torch.addmm(b_in, features, w_in.t())                               # (N, c_mid)
+            idx = voxel_query_utils.voxel_query_raw(grouper.max_range, grouper.radius, grouper.nsample,
+                                                    xyz, new_xyz, coords_bzyx, voxel2point_indices)
+            o = out if len(widths) == 1 else torch.empty((m, w_out.shape[0]), dtype=torch.float32,
+                                                         device=features.device)
+            pointnet2.voxel_pool_agg_wrapper(m, grouper.nsample, w_out.shape[1], w_out.shape[0], feats,
+                                             xyz, new_xyz, idx, None, w_pos, b_pos, w_out, b_out, o)
+            outs.append(o)
+        return out if len(widths) == 1 else torch.cat(outs, dim=1)

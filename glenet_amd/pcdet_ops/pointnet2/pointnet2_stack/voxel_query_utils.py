@@ -49,6 +49,26 @@ def voxel_query_sparse(max_range, radius, nsample, xyz, new_xyz, new_coords, spa
     return idx, empty
 
 
+def voxel_query_raw(max_range, radius, nsample, xyz, new_xyz, new_coords, source):
+    """The query kernel's own output: (M, nsample) GLOBAL row indices, idx[m,0] == -1 for an empty
+    ball (the other slots of such a row are unspecified).  source: dense (B,Z,Y,X) map or a
+    SparseConvTensor."""
+    m = new_coords.shape[0]
+    idx = torch.empty((m, nsample), dtype=torch.int32, device=xyz.device)
+    zr, yr, xr = max_range
+    if torch.is_tensor(source):
+        z, y, x = source.shape[1:4]
+        pointnet2.voxel_query_wrapper(m, z, y, x, nsample, radius, zr, yr, xr, new_xyz, xyz,
+                                      new_coords, source.contiguous(), idx)
+    else:
+        index = source._ensure_index()
+        z, y, x = source.spatial_shape
+        pointnet2.voxel_query_index_wrapper(m, z, y, x, nsample, radius, zr, yr, xr, new_xyz, xyz,
+                                            new_coords, index.bitmap, index.prefix, index.rank_to_row,
+                                            idx)
+    return idx
+
+
 def rebase_to_frames(idx, xyz_batch_cnt, empty_mask):
     """Global -> per-frame indices (voxel_query_utils.py:85-91; equal M per frame, as there)."""
     b = xyz_batch_cnt.shape[0]

@@ -317,6 +317,19 @@ int glx_group_points_grad(int B, int M, int C, int N, int nsample, const float* 
                           const int32_t* idx, const int32_t* idx_batch_cnt,
                           const int32_t* features_batch_cnt, float* grad_features, void* stream);
 
+/* RoI-grid pooling aggregation of one scale after its voxel query, inference: out[m,:] =
+ * relu(Wout . max_s relu(feats[idx[m,s],:] + Wpos . (xyz[idx[m,s]] - new_xyz[m]) + bpos) + bout);
+ * empty[m] != 0 (or, with empty == NULL, idx[m,0] < 0 as glx_voxel_query leaves it): the ball is
+ * empty (features and offsets count as 0).  idx (M,nsample) indexes the
+ * stacked feats (N,Cm) / xyz (N,3) GLOBALLY; Wpos (Cm,3), Wout (Co,Cm) with the eval-mode
+ * BatchNorms folded; Cm, Co <= 64.
+ * Replaces: group_points x2 + mask + pos-MLP + ReLU + max-pool + out-MLP of
+ * NeighborVoxelSAModuleMSG.forward (pcdet/ops/pointnet2/pointnet2_stack/voxel_pool_modules.py:88-108). */
+int glx_voxel_pool_agg(const float* feats, const float* xyz, const float* new_xyz, const int32_t* idx,
+                       const uint8_t* empty, int M, int nsample, int Cm, int Co, const float* Wpos,
+                       const float* bpos, const float* Wout, const float* bout, float* out,
+                       void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Training-mode BatchNorm1d (+ ReLU) over sparse-tensor features x (N, C), C a multiple of 4 that
  * divides 1024 (16 ... 512).  Semantics of nn.BatchNorm1d(eps, momentum) followed by nn.ReLU as

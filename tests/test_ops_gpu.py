@@ -299,6 +299,52 @@ def test_roi_grid_pool_module_dense_equals_sparse(dev):
     assert a.shape == (M, 24) and torch.equal(a, b)
 
 
+@pytest.mark.parametrize("mlps", [[[16, 32, 32]], [[16, 48, 64], [16, 16, 24]]])
+def test_roi_grid_pool_fused_aggregation_matches_module_path(dev, mlps):
+    """Inference fast path (k_voxel_pool_agg: grouping + position MLP + ReLU + max + output MLP in
+    one kernel, BatchNorms folded) vs the module's own tensor-op path that follows
+    voxel_pool_modules.py:88-108; empty balls present; tolerance 1e-5 relative (folded affine)."""
+    rng = np.random.default_rng(31)
+    B, Z, Y, X = 2, 5, 24, 20
+    idx, xyz, cnt = _voxel_scene(rng, B, Z, Y, X, 0.08)
+    feats = rng.normal(size=(len(idx), 16)).astype(np.float32)
+    M = 2 * 301
+    qc_xyz = np.stack([np.repeat(np.arange(B), M // B), rng.integers(0, X, M), rng.integers(0, Y, M),
+                       rng.integers(0, Z, M)], 1).astype(np.int32)
+    q = ((qc_xyz[:, 1:4] + rng.random((M, 3))) * np.array([0.1, 0.1, 0.2])).astype(np.float32)
+    torch.manual_seed(3)
+    n = len(mlps)
+    mod = voxel_pool_modules.NeighborVoxelSAModuleMSG(
+        query_ranges=[[1, 1, 1], [2, 2, 2]][:n], radii=[0.25, 0.4][:n], nsamples=[16, 8][:n],
+        mlps=mlps).to(dev)
+    for m in mod.modules():                       # non-trivial running statistics and affine
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            m.running_mean.normal_(0, 0.3)
+            m.running_var.uniform_(0.5, 2.0)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    mod.eval()
+    st = sp.SparseConvTensor(T(feats, dev), T(idx, dev), [Z, Y, X], B)
+    args = (T(xyz, dev), T(cnt, dev), T(q, dev), torch.tensor([M // B] * B, dtype=torch.int32, device=dev),
+            T(qc_xyz, dev), T(feats, dev))
+    with torch.no_grad():
+        assert mod._fusable(args[-1])
+        fused = mod(*args, st)
+        v2p = T(oracle.generate_voxel2pinds(idx, B, [Z, Y, X]), dev)
+        fused_dense = mod(*args, v2p)
+        mod.USE_FUSED = False
+        plain = mod(*args, st)
+        _, _, empty = mod.groupers[0](args[4][:, [0, 3, 2, 1]].contiguous(), args[0], args[1], args[2],
+                                      args[3], T(feats, dev), st)
+    assert bool(empty.any()) and not bool(empty.all())
+    assert fused.shape == plain.shape == (M, sum(m[-1] for m in mlps))
+    assert torch.equal(fused, fused_dense)
+    np.testing.assert_allclose(fused.cpu().numpy(), plain.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    with torch.enable_grad():                     # training / autograd keeps the tensor-op path
+        mod.USE_FUSED = True
+        assert not mod._fusable(args[-1])
+
+
 def test_roi_grid_pool_harness_vs_reference_formulation(dev):
     """glenet_amd.roi_grid.RoIGridPool == the reference's roi_grid_pool data flow restated with
     its own pieces: dense voxel->point map per scale, grid coords by float floor division, per-batch
