@@ -257,54 +257,109 @@ extern "C" int glx_roipoint_pool3d(const float* xyz, const float* boxes3d, const
 }
 
 // ------------------------------------------------------------------ voxel query
-// voxel_query_kernel_stack, pointnet2_stack/src/voxel_query_gpu.cu:10-89.  The neighbour
-// window is scanned z, y, x ascending; idx pre-filled with the first hit; -1 marks empty.
-// MAP = dense (B,Z,Y,X) int32 map (reference API) or the rank dictionary of the sparse tensor
-// (no 189 MB map to build and clear per scale).
-template <bool DENSE>
-__global__ void k_voxel_query(int M, int R1, int R2, int R3, int nsample, float radius2,
-                              int zr, int yr, int xr, const float* __restrict__ new_xyz,
-                              const float* __restrict__ xyz, const int* __restrict__ new_coords,
-                              const int* __restrict__ point_indices,
-                              const unsigned long long* __restrict__ bitmap,
-                              const int* __restrict__ prefix, const int* __restrict__ rank_to_row,
-                              int* __restrict__ idx) {
-  int pt = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pt >= M) return;
-  const float nx = new_xyz[(long long)pt * 3], ny = new_xyz[(long long)pt * 3 + 1],
-              nz = new_xyz[(long long)pt * 3 + 2];
-  const int4 nc = reinterpret_cast<const int4*>(new_coords)[pt];   // b z y x
-  int* o = idx + (long long)pt * nsample;
-  int cnt = 0;
-  for (int dz = -zr; dz <= zr; ++dz) {
-    int z = nc.y + dz;
-    if (z < 0 || z >= R1) continue;
-    for (int dy = -yr; dy <= yr; ++dy) {
-      int y = nc.z + dy;
-      if (y < 0 || y >= R2) continue;
-      for (int dx = -xr; dx <= xr; ++dx) {
-        int x = nc.w + dx;
-        if (x < 0 || x >= R3) continue;
-        long long lin = (((long long)nc.x * R1 + z) * R2 + y) * R3 + x;
-        int nb;
+// voxel_query_kernel_stack, pointnet2_stack/src/voxel_query_gpu.cu:10-89: the neighbour window is
+// scanned z, y, x ascending, the first nsample cells whose centre lies within the radius are kept,
+// unused slots repeat the first hit, -1 in slot 0 marks an empty ball.  MAP = dense (B,Z,Y,X)
+// int32 map (reference API) or the rank dictionary of the sparse tensor (no 189 MB map to build
+// and clear per scale).
+// The reference walks the (2r+1)^3 window with one thread per grid point: 729 dependent lookups in
+// a row and 1.7 waves per SIMD at the Voxel-RCNN sizes -- latency-bound.  Here G lanes share a grid
+// point and test G consecutive window cells per step; the scan order is kept by ranking the hits
+// of a step with a ballot (slot = hits so far + hits in lower lanes), so the output is identical.
+// CEN: the neighbour positions are not read from an xyz array but rebuilt from the sparse tensor's
+// own (N,4) [b,z,y,x] indices, rounding step by step like get_voxel_centers
+// (pcdet/utils/common_utils.py:66-82): (i + 0.5) * (voxel * stride) + range_min -- one 16-byte
+// gather instead of three 4-byte ones and no centres tensor.  new_coords are then the STRIDE-1
+// voxel coordinates of the grid points and are floor-divided by coord_stride here
+// (voxelrcnn_head.py:167).
+struct VoxelCentres {
+  const int* indices;
+  float vsx, vsy, vsz, r0x, r0y, r0z;
+};
+
+__device__ __forceinline__ void glx_voxel_centre(const VoxelCentres& g, long long row, float& x,
+                                                 float& y, float& z) {
+  const int4 c = reinterpret_cast<const int4*>(g.indices)[row];      // b z y x
+  x = __fadd_rn(__fmul_rn(__fadd_rn((float)c.w, 0.5f), g.vsx), g.r0x);
+  y = __fadd_rn(__fmul_rn(__fadd_rn((float)c.z, 0.5f), g.vsy), g.r0y);
+  z = __fadd_rn(__fmul_rn(__fadd_rn((float)c.y, 0.5f), g.vsz), g.r0z);
+}
+
+__device__ __forceinline__ int glx_floordiv(int a, int b) {          // b > 0
+  return a >= 0 ? a / b : -((-a + b - 1) / b);
+}
+
+template <bool DENSE, int G, bool CEN>
+__global__ __launch_bounds__(256) void k_voxel_query(
+    int M, int R1, int R2, int R3, int nsample, float radius2, int zr, int yr, int xr,
+    const float* __restrict__ new_xyz, const float* __restrict__ xyz, const int* __restrict__ new_coords,
+    const int* __restrict__ point_indices, const unsigned long long* __restrict__ bitmap,
+    const int* __restrict__ prefix, const int* __restrict__ rank_to_row, int* __restrict__ idx,
+    VoxelCentres cen, int coord_stride) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane % G, sub = lane / G;
+  const long long pt = ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (64 / G) + sub;
+  const bool live = pt < M;
+  const int wy = 2 * yr + 1, wx = 2 * xr + 1;
+  const int W = (2 * zr + 1) * wy * wx;
+  const float inv_x = 1.f / wx, inv_y = 1.f / wy;
+  float nx = 0.f, ny = 0.f, nz = 0.f;
+  int4 nc = make_int4(0, 0, 0, 0);                                   // b z y x
+  if (live) {
+    nx = new_xyz[pt * 3], ny = new_xyz[pt * 3 + 1], nz = new_xyz[pt * 3 + 2];
+    nc = reinterpret_cast<const int4*>(new_coords)[pt];
+    if (CEN && coord_stride > 1) {
+      nc.y = glx_floordiv(nc.y, coord_stride);
+      nc.z = glx_floordiv(nc.z, coord_stride);
+      nc.w = glx_floordiv(nc.w, coord_stride);
+    }
+  }
+  int* o = idx + (live ? pt : 0) * nsample;
+  int cnt = live ? 0 : nsample, first = -1;
+  for (int base = 0; base < W; base += G) {
+    if (!__any(cnt < nsample)) break;
+    const int w = base + g;
+    int nb = -1;
+    if (cnt < nsample && w < W) {
+      const int t = (int)((w + 0.5f) * inv_x);                       // w / wx (exact: w < 2^20)
+      const int q = (int)((t + 0.5f) * inv_y);
+      const int z = nc.y + q - zr, y = nc.z + (t - q * wy) - yr, x = nc.w + (w - t * wx) - xr;
+      if (z >= 0 && z < R1 && y >= 0 && y < R2 && x >= 0 && x < R3) {
+        const long long lin = (((long long)nc.x * R1 + z) * R2 + y) * R3 + x;
         if (DENSE) {
           nb = point_indices[lin];
         } else {
           nb = glx_rank_lookup(bitmap, prefix, lin);
           if (nb >= 0 && rank_to_row) nb = rank_to_row[nb];
         }
-        if (nb < 0) continue;
-        float xp = xyz[(long long)nb * 3], yp = xyz[(long long)nb * 3 + 1], zp = xyz[(long long)nb * 3 + 2];
-        float d2 = (xp - nx) * (xp - nx) + (yp - ny) * (yp - ny) + (zp - nz) * (zp - nz);
-        if (d2 > radius2) continue;
-        if (cnt == 0)
-          for (int l = 0; l < nsample; ++l) o[l] = nb;
-        o[cnt] = nb;
-        if (++cnt == nsample) return;            // further hits are ignored by the reference too
+        if (nb >= 0) {
+          float xp, yp, zp;
+          if (CEN) {
+            glx_voxel_centre(cen, nb, xp, yp, zp);
+          } else {
+            xp = xyz[(long long)nb * 3], yp = xyz[(long long)nb * 3 + 1], zp = xyz[(long long)nb * 3 + 2];
+          }
+          const float d2 = (xp - nx) * (xp - nx) + (yp - ny) * (yp - ny) + (zp - nz) * (zp - nz);
+          if (d2 > radius2) nb = -1;
+        }
       }
     }
+    const unsigned long long hits = __ballot(nb >= 0);
+    const unsigned bits = (unsigned)(hits >> (sub * G)) & ((1u << G) - 1u);
+    const int lead = __shfl(nb, bits ? sub * G + __ffs(bits) - 1 : lane, 64);
+    if (bits) {
+      const int pos = cnt + __popc(bits & ((1u << g) - 1u));
+      if (nb >= 0 && pos < nsample) o[pos] = nb;
+      if (first < 0) first = lead;
+      cnt += __popc(bits);
+    }
   }
-  if (cnt == 0) o[0] = -1;
+  if (!live) return;
+  if (first < 0) {
+    if (g == 0) o[0] = -1;
+  } else {
+    for (int l = cnt + g; l < nsample; l += G) o[l] = first;
+  }
 }
 
 extern "C" int glx_voxel_query(int M, int Z, int Y, int X, int nsample, float radius, int z_range,
@@ -313,11 +368,11 @@ extern "C" int glx_voxel_query(int M, int Z, int Y, int X, int nsample, float ra
                                int32_t* idx, void* stream) {
   if (M == 0) return GLX_OK;
   GLX_REQUIRE(new_xyz && xyz && new_coords && point_indices && idx, "glx_voxel_query: null pointer");
-  hipLaunchKernelGGL((k_voxel_query<true>), dim3(glx_divup(M, 256)), dim3(256), 0,
+  hipLaunchKernelGGL((k_voxel_query<true, 8, false>), dim3(glx_divup(M, 32)), dim3(256), 0,
                      (hipStream_t)stream, M, Z, Y, X, nsample, radius * radius, z_range, y_range,
                      x_range, new_xyz, xyz, new_coords, point_indices,
                      (const unsigned long long*)nullptr, (const int*)nullptr, (const int*)nullptr,
-                     idx);
+                     idx, VoxelCentres{}, 1);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
@@ -329,10 +384,11 @@ extern "C" int glx_voxel_query_index(int M, int Z, int Y, int X, int nsample, fl
                                      const int32_t* rank_to_row, int32_t* idx, void* stream) {
   if (M == 0) return GLX_OK;
   GLX_REQUIRE(new_xyz && xyz && new_coords && bitmap && prefix && idx, "glx_voxel_query_index: null");
-  hipLaunchKernelGGL((k_voxel_query<false>), dim3(glx_divup(M, 256)), dim3(256), 0,
+  hipLaunchKernelGGL((k_voxel_query<false, 8, false>), dim3(glx_divup(M, 32)), dim3(256), 0,
                      (hipStream_t)stream, M, Z, Y, X, nsample, radius * radius, z_range, y_range,
                      x_range, new_xyz, xyz, new_coords, (const int*)nullptr,
-                     (const unsigned long long*)bitmap, (const int*)prefix, rank_to_row, idx);
+                     (const unsigned long long*)bitmap, (const int*)prefix, rank_to_row, idx,
+                     VoxelCentres{}, 1);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
@@ -740,12 +796,12 @@ extern "C" int glx_three_interpolate_grad(int N, int C, const float* grad_out, c
 // materialises (M, C, ns) tensors four times per scale (group, mask, pos-MLP, ReLU) before the
 // max -- 177 MB each at the GLENet-VR sizes; here a grid point's 16 neighbours are reduced in
 // registers: lanes = channels (coalesced 128-B row gathers), a wave holds 64/LP grid points.
-template <int LP>
+template <int LP, bool CEN>
 __global__ __launch_bounds__(256) void k_voxel_pool_agg(
     const float* __restrict__ feats, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
     const int* __restrict__ idx, const unsigned char* __restrict__ empty, int M, int ns, int Cm, int Co,
     const float* __restrict__ Wpos, const float* __restrict__ bpos, const float* __restrict__ Wout,
-    const float* __restrict__ bout, float* __restrict__ out) {
+    const float* __restrict__ bout, float* __restrict__ out, int out_stride, VoxelCentres cen) {
   extern __shared__ float s_wout[];            // [c][o] : Cm * Co
   for (int e = threadIdx.x; e < Cm * Co; e += blockDim.x) {
     int o = e / Cm, c = e - o * Cm;           // Wout is (Co, Cm) row-major
@@ -770,7 +826,13 @@ __global__ __launch_bounds__(256) void k_voxel_pool_agg(
       for (int s = 0; s < ns; ++s) {
         const long long i = idx[m * ns + s];
         const float f = cok ? feats[i * Cm + c] : 0.f;
-        const float rx = xyz[i * 3] - qx, ry = xyz[i * 3 + 1] - qy, rz = xyz[i * 3 + 2] - qz;
+        float px, py, pz;
+        if (CEN) {
+          glx_voxel_centre(cen, i, px, py, pz);
+        } else {
+          px = xyz[i * 3], py = xyz[i * 3 + 1], pz = xyz[i * 3 + 2];
+        }
+        const float rx = px - qx, ry = py - qy, rz = pz - qz;
         float t = wx * rx;                       // conv (no bias) then the folded BN shift
         t = fmaf(wy, ry, t);
         t = fmaf(wz, rz, t);
@@ -784,7 +846,27 @@ __global__ __launch_bounds__(256) void k_voxel_pool_agg(
     const float vk = __shfl(v, sub * LP + k, 64);
     if (c < Co) acc = fmaf(s_wout[k * Co + c], vk, acc);
   }
-  if (live && c < Co) out[m * Co + c] = fmaxf(acc, 0.f);
+  if (live && c < Co) out[m * out_stride + c] = fmaxf(acc, 0.f);
+}
+
+static int voxel_pool_agg_launch(const float* feats, const float* xyz, const float* new_xyz,
+                                 const int32_t* idx, const uint8_t* empty, int M, int nsample, int Cm,
+                                 int Co, const float* Wpos, const float* bpos, const float* Wout,
+                                 const float* bout, float* out, int out_stride, const VoxelCentres* cen,
+                                 void* stream) {
+  const int LP = (Cm <= 32 && Co <= 32) ? 32 : 64;
+  const dim3 grid(glx_divup(M, 4 * (64 / LP))), block(256);
+  const size_t lds = (size_t)Cm * Co * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+#define GLX_AGG(LPV, CENV)                                                                        \
+  hipLaunchKernelGGL((k_voxel_pool_agg<LPV, CENV>), grid, block, lds, st, feats, xyz, new_xyz, idx, \
+                     empty, M, nsample, Cm, Co, Wpos, bpos, Wout, bout, out, out_stride,          \
+                     cen ? *cen : VoxelCentres{})
+  if (LP == 32) { if (cen) GLX_AGG(32, true); else GLX_AGG(32, false); }
+  else          { if (cen) GLX_AGG(64, true); else GLX_AGG(64, false); }
+#undef GLX_AGG
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
 }
 
 extern "C" int glx_voxel_pool_agg(const float* feats, const float* xyz, const float* new_xyz,
@@ -796,18 +878,117 @@ extern "C" int glx_voxel_pool_agg(const float* feats, const float* xyz, const fl
               "glx_voxel_pool_agg: null pointer");
   GLX_REQUIRE(Cm >= 1 && Cm <= 64 && Co >= 1 && Co <= 64 && nsample >= 1,
               "glx_voxel_pool_agg: channel widths must be 1..64");
-  const int LP = (Cm <= 32 && Co <= 32) ? 32 : 64;
-  const int ppb = 4 * (64 / LP);
-  const size_t lds = (size_t)Cm * Co * sizeof(float);
-  if (LP == 32) {
-    hipLaunchKernelGGL((k_voxel_pool_agg<32>), dim3(glx_divup(M, ppb)), dim3(256), lds,
-                       (hipStream_t)stream, feats, xyz, new_xyz, idx, empty, M, nsample, Cm, Co, Wpos,
-                       bpos, Wout, bout, out);
-  } else {
-    hipLaunchKernelGGL((k_voxel_pool_agg<64>), dim3(glx_divup(M, ppb)), dim3(256), lds,
-                       (hipStream_t)stream, feats, xyz, new_xyz, idx, empty, M, nsample, Cm, Co, Wpos,
-                       bpos, Wout, bout, out);
-  }
+  return voxel_pool_agg_launch(feats, xyz, new_xyz, idx, empty, M, nsample, Cm, Co, Wpos, bpos, Wout,
+                               bout, out, Co, nullptr, stream);
+}
+
+// ------------------------------------------------------------------ RoI-grid pooling, whole stage
+// VoxelRCNNHead.roi_grid_pool (pcdet/models/roi_heads/voxelrcnn_head.py:106-191) for inference in
+// 1 + 2 x scales launches: grid points + their stride-1 voxel coordinates from the RoIs, then per
+// scale a query and an aggregation that rebuild voxel centres from the sparse tensor's indices.
+//
+// Grid points: get_dense_grid_points + rotate_points_along_z + centre (voxelrcnn_head.py:191-215,
+// common_utils.py:35-57), rounding step by step in fp32: ((i + 0.5) * (1/G)) * size - size * 0.5,
+// x' = x cos - y sin, y' = x sin + y cos, + centre.  (The reference rotates with a batched 3x3
+// matmul whose summation may contract to fma: 1 ulp.)  Voxel coordinates: the reference's float
+// floor division `(p - range_min) // voxel` restated from ATen's div_floor kernel for a scalar
+// divisor: fmod, (a - mod) * (1/b), sign fix, floor with the > 0.5 round-up.
+__device__ __forceinline__ float glx_div_floor(float a, float b, float inv_b) {
+  const float mod = fmodf(a, b);
+  float div = __fmul_rn(__fsub_rn(a, mod), inv_b);
+  if (mod != 0.f && ((b < 0.f) != (mod < 0.f))) div = __fsub_rn(div, 1.f);
+  if (div == 0.f) return copysignf(0.f, __fmul_rn(a, inv_b));
+  float fl = floorf(div);
+  if (__fsub_rn(div, fl) > 0.5f) fl = __fadd_rn(fl, 1.f);
+  return fl;
+}
+
+struct RoiGridGeom {
+  float r0x, r0y, r0z, vx, vy, vz, ivx, ivy, ivz;
+};
+
+__global__ void k_roi_grid_points(const float* __restrict__ rois, int n_rois, int cols,
+                                  int rois_per_frame, int G, float inv_g, RoiGridGeom gm,
+                                  float* __restrict__ grid_xyz, int* __restrict__ coords) {
+  const int G3 = G * G * G;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n_rois * G3) return;
+  const int r = (int)(t / G3), k = (int)(t - (long long)r * G3);
+  const int ix = k / (G * G), iy = (k / G) % G, iz = k % G;          // nonzero() order: x-major
+  const float* b = rois + (long long)r * cols;
+  const float dx = b[3], dy = b[4], dz = b[5];
+  float sn, cs;
+  sn = sinf(b[6]);
+  cs = cosf(b[6]);
+  const float lx = __fsub_rn(__fmul_rn(__fmul_rn(__fadd_rn((float)ix, 0.5f), inv_g), dx), __fmul_rn(dx, 0.5f));
+  const float ly = __fsub_rn(__fmul_rn(__fmul_rn(__fadd_rn((float)iy, 0.5f), inv_g), dy), __fmul_rn(dy, 0.5f));
+  const float lz = __fsub_rn(__fmul_rn(__fmul_rn(__fadd_rn((float)iz, 0.5f), inv_g), dz), __fmul_rn(dz, 0.5f));
+  const float gx = __fadd_rn(__fsub_rn(__fmul_rn(lx, cs), __fmul_rn(ly, sn)), b[0]);
+  const float gy = __fadd_rn(__fadd_rn(__fmul_rn(lx, sn), __fmul_rn(ly, cs)), b[1]);
+  const float gz = __fadd_rn(lz, b[2]);
+  grid_xyz[t * 3] = gx, grid_xyz[t * 3 + 1] = gy, grid_xyz[t * 3 + 2] = gz;
+  int4 c;
+  c.x = r / rois_per_frame;
+  c.y = (int)glx_div_floor(__fsub_rn(gz, gm.r0z), gm.vz, gm.ivz);
+  c.z = (int)glx_div_floor(__fsub_rn(gy, gm.r0y), gm.vy, gm.ivy);
+  c.w = (int)glx_div_floor(__fsub_rn(gx, gm.r0x), gm.vx, gm.ivx);
+  reinterpret_cast<int4*>(coords)[t] = c;                             // b z y x at stride 1
+}
+
+extern "C" int glx_roi_grid_points(const float* rois, int n_rois, int cols, int rois_per_frame,
+                                   int grid_size, const float* range_min, const float* voxel_size,
+                                   float* grid_xyz, int32_t* coords, void* stream) {
+  if (n_rois <= 0) return GLX_OK;
+  GLX_REQUIRE(rois && range_min && voxel_size && grid_xyz && coords, "glx_roi_grid_points: null pointer");
+  GLX_REQUIRE(cols >= 7 && rois_per_frame >= 1 && grid_size >= 1 && grid_size <= 32,
+              "glx_roi_grid_points: rois need >= 7 columns, grid_size 1..32");
+  RoiGridGeom gm{range_min[0], range_min[1], range_min[2], voxel_size[0], voxel_size[1], voxel_size[2],
+                 1.f / voxel_size[0], 1.f / voxel_size[1], 1.f / voxel_size[2]};
+  const long long total = (long long)n_rois * grid_size * grid_size * grid_size;
+  hipLaunchKernelGGL(k_roi_grid_points, dim3((unsigned)glx_divup(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, rois, n_rois, cols, rois_per_frame, grid_size,
+                     1.f / (float)grid_size, gm, grid_xyz, coords);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
+}
+
+static VoxelCentres make_centres(const int32_t* indices, const float* range_min, const float* voxel_size,
+                                 int stride) {
+  // tensor(voxel_size).float() * downsample_times, as get_voxel_centers forms it
+  return VoxelCentres{indices, voxel_size[0] * (float)stride, voxel_size[1] * (float)stride,
+                      voxel_size[2] * (float)stride, range_min[0], range_min[1], range_min[2]};
+}
+
+extern "C" int glx_roi_grid_query(int M, int Z, int Y, int X, int nsample, float radius, int z_range,
+                                  int y_range, int x_range, const float* grid_xyz,
+                                  const int32_t* coords, int stride, const int32_t* indices,
+                                  const float* range_min, const float* voxel_size,
+                                  const uint64_t* bitmap, const int32_t* prefix,
+                                  const int32_t* rank_to_row, int32_t* idx, void* stream) {
+  if (M == 0) return GLX_OK;
+  GLX_REQUIRE(grid_xyz && coords && indices && range_min && voxel_size && bitmap && prefix && idx,
+              "glx_roi_grid_query: null pointer");
+  GLX_REQUIRE(stride >= 1 && nsample >= 1, "glx_roi_grid_query: stride and nsample must be >= 1");
+  hipLaunchKernelGGL((k_voxel_query<false, 8, true>), dim3(glx_divup(M, 32)), dim3(256), 0,
+                     (hipStream_t)stream, M, Z, Y, X, nsample, radius * radius, z_range, y_range,
+                     x_range, grid_xyz, (const float*)nullptr, coords, (const int*)nullptr,
+                     (const unsigned long long*)bitmap, (const int*)prefix, rank_to_row, idx,
+                     make_centres(indices, range_min, voxel_size, stride), stride);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+extern "C" int glx_roi_grid_agg(const float* feats, const int32_t* indices, int stride,
+                                const float* range_min, const float* voxel_size, const float* grid_xyz,
+                                const int32_t* idx, int M, int nsample, int Cm, int Co,
+                                const float* Wpos, const float* bpos, const float* Wout,
+                                const float* bout, float* out, int out_stride, void* stream) {
+  if (M <= 0) return GLX_OK;
+  GLX_REQUIRE(feats && indices && range_min && voxel_size && grid_xyz && idx && Wpos && bpos && Wout &&
+                  bout && out, "glx_roi_grid_agg: null pointer");
+  GLX_REQUIRE(Cm >= 1 && Cm <= 64 && Co >= 1 && Co <= 64 && nsample >= 1 && out_stride >= Co,
+              "glx_roi_grid_agg: channel widths must be 1..64, out_stride >= Co");
+  const VoxelCentres cen = make_centres(indices, range_min, voxel_size, stride);
+  return voxel_pool_agg_launch(feats, nullptr, grid_xyz, idx, nullptr, M, nsample, Cm, Co, Wpos, bpos,
+                               Wout, bout, out, out_stride, &cen, stream);
 }

@@ -70,11 +70,13 @@ class RoIGridPool(nn.Module):
         """Voxel coordinates of grid points at stride 1: float floor division on f32, as the
         reference does (`//` on tensors, voxelrcnn_head.py:130-134)."""
         r, v = self.point_cloud_range, self.voxel_size
-        return torch.stack([torch.floor((roi_grid_xyz[..., i] - r[i]) / v[i]) for i in range(3)], dim=-1)
+        return torch.stack([(roi_grid_xyz[..., i] - r[i]) // v[i] for i in range(3)], dim=-1)
 
     def forward(self, rois, multi_scale_3d_features, multi_scale_3d_strides, batch_size):
         """rois (B, R, 7+) -> (B*R, G^3, sum C_out)."""
         B = batch_size
+        if self._fusable(rois, multi_scale_3d_features):
+            return self._forward_fused(rois, multi_scale_3d_features, multi_scale_3d_strides, B)
         grid_xyz, _ = global_grid_points_of_roi(rois, self.grid_size)           # (B*R, G^3, 3)
         grid_xyz = grid_xyz.reshape(B, -1, 3)
         coords1 = self.grid_coords(grid_xyz)                                      # (B, R*G^3, 3) float
@@ -89,10 +91,63 @@ class RoIGridPool(nn.Module):
             ind, feats = st.indices[:n], st.features[:n]
             xyz = get_voxel_centers(ind[:, 1:4], stride, self.voxel_size, self.point_cloud_range)
             xyz_cnt = torch.bincount(ind[:, 0].long(), minlength=B).int()
-            coords = torch.cat([bcol, torch.floor(coords1 / stride)], dim=-1).int()   # [b, x, y, z]
+            coords = torch.cat([bcol, coords1 // stride], dim=-1).int()              # [b, x, y, z]
             out = layer(xyz=xyz.contiguous(), xyz_batch_cnt=xyz_cnt,
                         new_xyz=grid_xyz.reshape(-1, 3).contiguous(), new_xyz_batch_cnt=new_cnt,
                         new_coords=coords.reshape(-1, 4).contiguous(), features=feats.contiguous(),
                         voxel2point_indices=st)
             pooled.append(out.view(-1, self.grid_size ** 3, out.shape[-1]))
         return torch.cat(pooled, dim=-1)
+
+    # ---- inference fast path: 1 + 3 launches per scale (csrc/glx_points.hip) -- grid points and
+    # their voxel coordinates in one kernel, then per scale mlp_in (one GEMM), the voxel query and
+    # the fused aggregation, both rebuilding voxel centres from the sparse tensor's indices and
+    # writing straight into the concatenated output.  No centres, counts, coordinate or grouped
+    # tensors, no host synchronisation.
+    USE_FUSED = True
+
+    def _fusable(self, rois, tensors):
+        if not (self.USE_FUSED and not self.training and not torch.is_grad_enabled() and rois.is_cuda
+                and rois.dtype == torch.float32):
+            return False
+        for layer, name in zip(self.roi_grid_pool_layers, self.sources):
+            st = tensors[name]
+            if st.count is not None or not layer._fusable(st.features):
+                return False
+        return True
+
+    def _forward_fused(self, rois, tensors, strides, B):
+        import ctypes
+        from . import _lib
+        f3 = ctypes.c_float * 3
+        rmin, vsz = f3(*self.point_cloud_range[0:3]), f3(*self.voxel_size)
+        rois2 = rois.reshape(-1, rois.shape[-1]).contiguous()
+        n, g3 = rois2.shape[0], self.grid_size ** 3
+        m = n * g3
+        dev = rois.device
+        grid_xyz = torch.empty((m, 3), dtype=torch.float32, device=dev)
+        coords = torch.empty((m, 4), dtype=torch.int32, device=dev)
+        _lib.call("glx_roi_grid_points", rois2, n, rois2.shape[1], n // B, self.grid_size, rmin, vsz,
+                  grid_xyz, coords)
+        out = torch.empty((m, self.num_features), dtype=torch.float32, device=dev)
+        col = 0
+        for layer, name in zip(self.roi_grid_pool_layers, self.sources):
+            st = tensors[name]
+            index = st._ensure_index()
+            z, y, x = st.spatial_shape
+            ind, feats_src = st.indices.contiguous(), st.features.contiguous()
+            _lib.check_cuda(ind, feats_src)
+            for grouper, ((w_in, b_in), (w_pos, b_pos), (w_out, b_out)) in zip(layer.groupers,
+                                                                               layer._folded()):
+                feats = torch.addmm(b_in, feats_src, w_in.t())
+                idx = torch.empty((m, grouper.nsample), dtype=torch.int32, device=dev)
+                zr, yr, xr = grouper.max_range
+                _lib.call("glx_roi_grid_query", m, z, y, x, grouper.nsample, float(grouper.radius), zr,
+                          yr, xr, grid_xyz, coords, int(strides[name]), ind, rmin, vsz, index.bitmap,
+                          index.prefix, index.rank_to_row, idx)
+                co, cm = w_out.shape
+                _lib.call("glx_roi_grid_agg", feats, ind, int(strides[name]), rmin, vsz, grid_xyz, idx,
+                          m, grouper.nsample, cm, co, w_pos, b_pos, w_out, b_out, out[:, col:],
+                          self.num_features)
+                col += co
+        return out.view(n, g3, self.num_features)

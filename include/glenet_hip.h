@@ -330,6 +330,32 @@ int glx_voxel_pool_agg(const float* feats, const float* xyz, const float* new_xy
                        const float* bpos, const float* Wout, const float* bout, float* out,
                        void* stream);
 
+/* RoI-grid pooling of a whole stage, inference (VoxelRCNNHead.roi_grid_pool,
+ * pcdet/models/roi_heads/voxelrcnn_head.py:106-191), without the centres / coordinate / count
+ * tensors the reference builds per scale.  range_min, voxel_size: HOST float[3] (x,y,z).
+ *
+ * glx_roi_grid_points: rois (n_rois, cols >= 7) [x,y,z,dx,dy,dz,heading,..] -> grid_xyz
+ *   (n_rois*G^3, 3) and coords (n_rois*G^3, 4) int32 [frame, z, y, x], the STRIDE-1 voxel
+ *   coordinates `(p - range_min) // voxel_size` (float floor division as ATen evaluates it);
+ *   frame = roi / rois_per_frame.  Replaces get_global_grid_points_of_roi + lines 128-141.
+ * glx_roi_grid_query: voxel query of one scale: coords are floor-divided by `stride`, voxel
+ *   centres are rebuilt from the sparse tensor's indices (N,4) [b,z,y,x] as get_voxel_centers
+ *   does ((i + 0.5) * voxel*stride + range_min).  Output as glx_voxel_query_index.
+ * glx_roi_grid_agg: glx_voxel_pool_agg with the same on-the-fly centres, writing its Co columns
+ *   into a wider row-major output (row pitch out_stride floats; pass out + column offset). */
+int glx_roi_grid_points(const float* rois, int n_rois, int cols, int rois_per_frame, int grid_size,
+                        const float* range_min, const float* voxel_size, float* grid_xyz,
+                        int32_t* coords, void* stream);
+int glx_roi_grid_query(int M, int Z, int Y, int X, int nsample, float radius, int z_range,
+                       int y_range, int x_range, const float* grid_xyz, const int32_t* coords,
+                       int stride, const int32_t* indices, const float* range_min,
+                       const float* voxel_size, const uint64_t* bitmap, const int32_t* prefix,
+                       const int32_t* rank_to_row, int32_t* idx, void* stream);
+int glx_roi_grid_agg(const float* feats, const int32_t* indices, int stride, const float* range_min,
+                     const float* voxel_size, const float* grid_xyz, const int32_t* idx, int M,
+                     int nsample, int Cm, int Co, const float* Wpos, const float* bpos,
+                     const float* Wout, const float* bout, float* out, int out_stride, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Training-mode BatchNorm1d (+ ReLU) over sparse-tensor features x (N, C), C a multiple of 4 that
  * divides 1024 (16 ... 512).  Semantics of nn.BatchNorm1d(eps, momentum) followed by nn.ReLU as

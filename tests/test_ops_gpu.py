@@ -367,6 +367,10 @@ def test_roi_grid_pool_harness_vs_reference_formulation(dev):
     rois = np.concatenate([rng.uniform([0.5, 0.5, 0.4], [3.5, 4.3, 1.6], (B, 5, 3)),
                            rng.uniform(0.4, 1.2, (B, 5, 3)), rng.uniform(-3, 3, (B, 5, 1))], -1).astype(np.float32)
     with torch.no_grad():
+        fused = pool(T(rois, dev), tensors, strides, B)          # inference fast path (3 kernels / scale)
+        pool.USE_FUSED = False
+        for layer in pool.roi_grid_pool_layers:
+            layer.USE_FUSED = False
         got = pool(T(rois, dev), tensors, strides, B)
         # reference formulation
         grid, _ = rg.global_grid_points_of_roi(T(rois, dev), 3)
@@ -392,6 +396,43 @@ def test_roi_grid_pool_harness_vs_reference_formulation(dev):
         want = torch.cat(want, -1)
     assert got.shape == (B * 5, 27, 24) and torch.equal(got, want)
     assert float(got.abs().max()) > 0
+    # fast path: same arithmetic with folded BatchNorms; sin/cos may differ by an ulp
+    np.testing.assert_allclose(fused.cpu().numpy(), got.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_roi_grid_points_and_floor_division_coords(dev):
+    """glx_roi_grid_points vs get_global_grid_points_of_roi restated in torch (<= 2 ulp: sin/cos)
+    and its voxel coordinates vs torch's own float floor division `//` on the SAME points, exactly
+    (voxelrcnn_head.py:128-134).  Zero-size RoIs centred on multiples of the voxel size put every
+    grid point on a cell boundary, where floor(a / b) and a // b part ways."""
+    import ctypes
+    from glenet_amd import _lib, roi_grid as rg
+    rng = np.random.default_rng(77)
+    vs, pcr = [0.05, 0.05, 0.1], [0.0, -40.0, -3.0]
+    G, B, R = 6, 2, 300
+    rois = np.concatenate([rng.uniform([0, -40, -3], [70.4, 40, 1], (B * R, 3)),
+                           rng.uniform(0.3, 5.0, (B * R, 3)), rng.uniform(-4, 4, (B * R, 1))], -1).astype(np.float32)
+    k = rng.integers(0, 1400, (200, 3))
+    rois[:200, 0:3] = (k * np.array(vs) + np.array(pcr)).astype(np.float32)      # on cell boundaries
+    rois[:200, 3:6] = 0
+    rois[200:260, 0] = rng.uniform(-3, 0, 60)                                    # outside the range
+    r = T(rois, dev)
+    f3 = ctypes.c_float * 3
+    xyz = torch.empty((B * R * G ** 3, 3), dtype=torch.float32, device=dev)
+    coords = torch.empty((B * R * G ** 3, 4), dtype=torch.int32, device=dev)
+    _lib.call("glx_roi_grid_points", r, B * R, 7, R, G, f3(*pcr), f3(*vs), xyz, coords)
+    want_xyz, _ = rg.global_grid_points_of_roi(r, G)
+    np.testing.assert_allclose(xyz.cpu().numpy(), want_xyz.reshape(-1, 3).cpu().numpy(), rtol=0, atol=2e-5)
+    assert torch.equal(xyz[:200 * G ** 3], want_xyz[:200].reshape(-1, 3))      # no rotation involved
+    want_c = torch.stack([(xyz[:, i] - pcr[i]) // vs[i] for i in range(3)], -1).int()
+    assert torch.equal(coords[:, [3, 2, 1]], want_c)
+    assert torch.equal(coords[:, 0], torch.arange(B * R * G ** 3, device=dev).int() // (R * G ** 3))
+    assert int((want_c < 0).sum()) > 0
+    # at every stride the in-kernel integer floor division == torch's `//` on the float coords
+    for stride in (2, 4, 8):
+        a = (want_c.float() // stride).int()
+        b = torch.div(want_c, stride, rounding_mode="floor")
+        assert torch.equal(a, b)
 
 
 def test_farthest_point_sampling_bit_identical(dev):
