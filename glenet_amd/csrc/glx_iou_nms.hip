@@ -160,6 +160,8 @@ struct PBox {
 __global__ void k_nms_prepare(const float* __restrict__ boxes, int N, PBox* __restrict__ pb) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
+  boxes += (long long)blockIdx.y * N * 7;     // blockIdx.y = frame of a batched call
+  pb += (long long)blockIdx.y * N;
   const float* b = boxes + (long long)i * 7;
   PBox p;
   p.cx = b[0]; p.cy = b[1];
@@ -341,6 +343,9 @@ __global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxe
   int rem = blockIdx.x, r = 0;
   while (rem >= col_blocks - r) { rem -= col_blocks - r; ++r; }   // linear id -> (r, c >= r)
   const int c = r + rem;
+  boxes += (long long)blockIdx.y * N * 7;                         // blockIdx.y = frame
+  if (!NORMAL) pb += (long long)blockIdx.y * N;
+  maskT += (long long)blockIdx.y * N * col_blocks;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   __shared__ unsigned long long s_bits[64];
   __shared__ unsigned short s_q[64 * 64];
@@ -402,7 +407,10 @@ __global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxe
 #define SWEEP_THREADS 1024
 __global__ __launch_bounds__(SWEEP_THREADS) void k_nms_sweep(
     const unsigned long long* __restrict__ maskT, int N, int col_blocks,
-    long long* __restrict__ keep, int* __restrict__ num_out) {
+    long long* __restrict__ keep, int* __restrict__ num_out, int max_keep) {
+  maskT += (long long)blockIdx.x * N * col_blocks;               // blockIdx.x = frame
+  keep += (long long)blockIdx.x * N;
+  num_out += blockIdx.x;
   extern __shared__ int s_keep[];   // kept boxes so far (the gather list of every later step)
   __shared__ unsigned long long s_part[SWEEP_THREADS / 64];
   __shared__ int s_num;
@@ -415,6 +423,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_nms_sweep(
     const int base = b * 64;
     const int nb = min(64, N - base);
     const int num = s_num;
+    if (num >= max_keep) break;      // uniform: the caller only wants the first max_keep survivors
     // removed bits of this block from every box kept so far (all of them precede `base`):
     // independent gathers from one contiguous column block, up to 4 in flight per thread
     const unsigned long long* col = maskT + (long long)b * N;
@@ -482,34 +491,41 @@ extern "C" size_t glx_nms_workspace_bytes(int N) {   // suppression matrix + pre
   return nms_mask_bytes(N) + glx_align((size_t)(N > 0 ? N : 1) * sizeof(PBox)) + 256;
 }
 
-extern "C" int glx_nms(const float* boxes_sorted, int N, float thresh, int normal, int64_t* keep,
-                       int32_t* num_out, void* workspace, size_t workspace_bytes, void* stream) {
+// Batched form: `frames` independent box lists of N boxes each (boxes (F,N,7), keep (F,N),
+// num_out (F)), every kernel launched once with the frame on a grid axis -- the single-block sweeps
+// of the frames run side by side.  max_keep > 0 stops a frame's sweep once that many boxes are
+// kept (the caller truncates to NMS_POST_MAXSIZE anyway; the kept prefix is unchanged).
+extern "C" int glx_nms_batch(const float* boxes_sorted, int frames, int N, float thresh, int normal,
+                             int max_keep, int64_t* keep, int32_t* num_out, void* workspace,
+                             size_t workspace_bytes, void* stream) {
   GLX_REQUIRE(keep && num_out, "glx_nms: null output");
+  GLX_REQUIRE(frames >= 1 && frames <= 65535, "glx_nms: frames must be 1..65535");
   hipStream_t st = (hipStream_t)stream;
   if (N == 0) {
-    GlxFillJob job{num_out, sizeof(int), 0};
-    int frc = glx_fill_multi(&job, 1, st);
-    if (frc != GLX_OK) return frc;
-    return GLX_OK;
+    GlxFillJob job{num_out, sizeof(int) * (size_t)frames, 0};
+    return glx_fill_multi(&job, 1, st);
   }
   GLX_REQUIRE(boxes_sorted, "glx_nms: null boxes");
   int col_blocks = (N + 63) / 64;
-  size_t need = glx_nms_workspace_bytes(N) - 256;
+  const size_t mask_b = nms_mask_bytes(N), pb_b = glx_align((size_t)N * sizeof(PBox));
+  size_t need = (size_t)frames * (mask_b + pb_b);
   if (!workspace || workspace_bytes < need) {
     glx_set_error("glx_nms: workspace %zu < %zu bytes", workspace_bytes, need);
     return GLX_EWORKSPACE;
   }
+  // frame f: mask words at f * N * col_blocks, prepared boxes at f * N (dense, as the kernels index)
   unsigned long long* mask = (unsigned long long*)workspace;
-  PBox* pb = (PBox*)((char*)workspace + nms_mask_bytes(N));
+  PBox* pb = (PBox*)((char*)workspace + (size_t)frames * mask_b);
   // words of the lower triangle (row block > column block) are never written and never read:
   // the sweep ORs column block b only over boxes kept BEFORE block b, plus the diagonal tile.
   int ntiles = col_blocks * (col_blocks + 1) / 2;
   if (normal) {
-    hipLaunchKernelGGL((k_nms_mask<true>), dim3(ntiles), dim3(256), 0, st, boxes_sorted,
+    hipLaunchKernelGGL((k_nms_mask<true>), dim3(ntiles, frames), dim3(256), 0, st, boxes_sorted,
                        (const PBox*)nullptr, N, thresh, col_blocks, mask);
   } else {
-    hipLaunchKernelGGL(k_nms_prepare, dim3(glx_divup(N, 256)), dim3(256), 0, st, boxes_sorted, N, pb);
-    hipLaunchKernelGGL((k_nms_mask<false>), dim3(ntiles), dim3(256), 0, st, boxes_sorted,
+    hipLaunchKernelGGL(k_nms_prepare, dim3(glx_divup(N, 256), frames), dim3(256), 0, st, boxes_sorted,
+                       N, pb);
+    hipLaunchKernelGGL((k_nms_mask<false>), dim3(ntiles, frames), dim3(256), 0, st, boxes_sorted,
                        (const PBox*)pb, N, thresh, col_blocks, mask);
   }
   GLX_REQUIRE((size_t)N * 4 <= 150 * 1024, "glx_nms: N = %d exceeds the %d boxes the sweep keeps in LDS", N,
@@ -520,10 +536,17 @@ extern "C" int glx_nms(const float* boxes_sorted, int N, float thresh, int norma
                                 150 * 1024));
     sweep_attr = true;
   }
-  hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(SWEEP_THREADS), (size_t)N * 4, st,
-                     (const unsigned long long*)mask, N, col_blocks, (long long*)keep, num_out);
+  hipLaunchKernelGGL(k_nms_sweep, dim3(frames), dim3(SWEEP_THREADS), (size_t)N * 4, st,
+                     (const unsigned long long*)mask, N, col_blocks, (long long*)keep, num_out,
+                     max_keep > 0 ? max_keep : 0x7fffffff);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
+}
+
+extern "C" int glx_nms(const float* boxes_sorted, int N, float thresh, int normal, int64_t* keep,
+                       int32_t* num_out, void* workspace, size_t workspace_bytes, void* stream) {
+  return glx_nms_batch(boxes_sorted, 1, N, thresh, normal, 0, keep, num_out, workspace,
+                       workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------ GLENet variance-voting NMS

@@ -130,8 +130,64 @@ class RoIFCStack(nn.Module):
 
     def forward(self, pooled):
         """pooled (R, G^3, C) or (R, G^3*C) -> rcnn_cls (R, num_class), rcnn_reg (R, code*num_class)."""
-        shared = self.shared_fc_layer(pooled.reshape(pooled.shape[0], -1))
+        x = pooled.reshape(pooled.shape[0], -1)
+        if self.USE_FUSED and x.is_cuda and not self.training and not torch.is_grad_enabled() \
+                and x.dtype == torch.float32:
+            return self._forward_folded(x)
+        shared = self.shared_fc_layer(x)
         return self.cls_pred_layer(self.cls_fc_layers(shared)), self.reg_pred_layer(self.reg_fc_layers(shared))
+
+    # ---- inference: eval-mode BatchNorm folded into each Linear (one library GEMM + ReLU per layer
+    # instead of GEMM + 4 normalisation kernels), and the first layer -- (R, 20736) x (20736, 256)
+    # with R of a few hundred rows, which hipBLASLt runs on ~32 workgroups -- split along K into a
+    # batched GEMM whose partial sums are reduced afterwards (~1 000 workgroups).
+    USE_FUSED = True
+    SPLIT_K_MIN = 4096
+
+    def _folded(self):
+        towers = (self.shared_fc_layer, self.cls_fc_layers, self.reg_fc_layers)
+        pairs = [(seq[i], seq[i + 1]) for seq in towers for i in range(len(seq))
+                 if isinstance(seq[i], nn.Linear)]
+        tensors = [t for lin, bn in pairs for t in (lin.weight, bn.weight, bn.bias, bn.running_mean,
+                                                    bn.running_var)]
+        tag = tuple((t._version, t.data_ptr()) for t in tensors)
+        cache = self.__dict__.get("_glx_folded")
+        if cache is None or cache[0] != tag:
+            with torch.no_grad():
+                folded = []
+                for lin, bn in pairs:
+                    s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                    folded.append(((lin.weight * s[:, None]).float().contiguous(),
+                                   (bn.bias - bn.running_mean * s).float().contiguous()))
+            n = [sum(isinstance(m, nn.Linear) for m in seq) for seq in towers]
+            cache = (tag, (folded[:n[0]], folded[n[0]:n[0] + n[1]], folded[n[0] + n[1]:]))
+            self.__dict__["_glx_folded"] = cache
+        return cache[1]
+
+    @classmethod
+    def _affine_relu(cls, x, w, b):
+        k = x.shape[1]
+        split = next((s for s in (32, 27, 24, 16, 12, 8) if k % s == 0), 0) \
+            if (k >= cls.SPLIT_K_MIN and x.shape[0] <= 4096) else 0
+        if split:
+            xs = x.view(x.shape[0], split, k // split).transpose(0, 1)              # (S, R, k/S) view
+            ws = w.view(w.shape[0], split, k // split).permute(1, 2, 0)             # (S, k/S, out) view
+            y = torch.bmm(xs, ws).sum(0).add_(b)
+        else:
+            y = torch.addmm(b, x, w.t())
+        return torch.relu_(y)
+
+    def _forward_folded(self, x):
+        shared_w, cls_w, reg_w = self._folded()
+        x = x.contiguous()
+        for w, b in shared_w:
+            x = self._affine_relu(x, w, b)
+        c = r = x
+        for w, b in cls_w:
+            c = self._affine_relu(c, w, b)
+        for w, b in reg_w:
+            r = self._affine_relu(r, w, b)
+        return self.cls_pred_layer(c), self.reg_pred_layer(r)
 
 
 # ------------------------------------------------------------------------------ CVAE

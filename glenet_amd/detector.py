@@ -84,6 +84,9 @@ def proposal_layer(batch_box_preds, batch_cls_preds, nms_pre_maxsize, nms_post_m
     B = batch_box_preds.shape[0]
     if not normalized:
         batch_cls_preds = torch.sigmoid(batch_cls_preds)
+    if BATCHED_PROPOSALS and batch_box_preds.is_cuda and not torch.is_grad_enabled():
+        return _proposal_layer_batched(batch_box_preds, batch_cls_preds, nms_pre_maxsize,
+                                       nms_post_maxsize, nms_thresh)
     rois = batch_box_preds.new_zeros((B, nms_post_maxsize, batch_box_preds.shape[-1]))
     scores = batch_box_preds.new_zeros((B, nms_post_maxsize))
     labels = batch_box_preds.new_zeros((B, nms_post_maxsize), dtype=torch.long)
@@ -95,6 +98,34 @@ def proposal_layer(batch_box_preds, batch_cls_preds, nms_pre_maxsize, nms_post_m
         sel = order[keep[:nms_post_maxsize]]
         k = sel.shape[0]
         rois[b, :k], scores[b, :k], labels[b, :k] = batch_box_preds[b][sel], s[sel], lab[sel]
+    return rois, scores, labels + 1
+
+
+BATCHED_PROPOSALS = True
+
+
+def _proposal_layer_batched(batch_box_preds, scores_all, nms_pre_maxsize, nms_post_maxsize, nms_thresh):
+    """Same result as the per-frame loop above without its host round trips: batched class-max and
+    top-k (already in descending order, so the NMS wrapper's own sort is the identity), ONE batched
+    NMS launch sequence whose sweeps stop at nms_post_maxsize survivors, and a masked gather in
+    place of the variable-length slice."""
+    from .pcdet_ops.iou3d_nms import iou3d_nms_cuda
+    B, A, C = batch_box_preds.shape
+    s, lab = scores_all.max(dim=2)                                              # (B, A)
+    k = min(nms_pre_maxsize, A)
+    top, order = torch.topk(s, k=k, dim=1)
+    cand = torch.gather(batch_box_preds, 1, order.unsqueeze(-1).expand(B, k, C))
+    keep, num = iou3d_nms_cuda.nms_device_batch(cand[..., 0:7].contiguous(), nms_thresh,
+                                                max_keep=nms_post_maxsize)
+    p = nms_post_maxsize
+    if keep.shape[1] < p:
+        keep = torch.nn.functional.pad(keep, (0, p - keep.shape[1]))
+    slot = torch.arange(p, device=keep.device)
+    valid = slot[None, :] < num[:, None]                                        # (B, P)
+    sel = torch.where(valid, keep[:, :p], torch.zeros_like(keep[:, :p]))        # into the top-k list
+    rois = torch.gather(cand, 1, sel.unsqueeze(-1).expand(B, p, C)) * valid.unsqueeze(-1)
+    scores = torch.gather(top, 1, sel) * valid
+    labels = torch.gather(torch.gather(lab, 1, order), 1, sel) * valid
     return rois, scores, labels + 1
 
 

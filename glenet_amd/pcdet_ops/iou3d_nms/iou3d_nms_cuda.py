@@ -50,6 +50,22 @@ def nms_device(boxes, thresh, normal=False):
     return keep, num
 
 
+def nms_device_batch(boxes, thresh, normal=False, max_keep=0):
+    """boxes (F,N,7), every frame sorted by score -> (keep int64 (F,N), num_out int32 (F,)), both
+    on the device; one launch sequence for all frames.  max_keep > 0: a frame's sweep stops once
+    that many boxes are kept (keep[f, :min(num, max_keep)] is what the full sweep would give)."""
+    _lib.check_cuda(boxes)
+    f, n = boxes.shape[0], boxes.shape[1]
+    keep = torch.empty((f, max(n, 1)), dtype=torch.int64, device=boxes.device)
+    num = torch.zeros(f, dtype=torch.int32, device=boxes.device)
+    if f == 0:
+        return keep, num
+    ws = workspace.get(f * query("glx_nms_workspace_bytes", n), boxes.device)
+    call("glx_nms_batch", _f(boxes), f, n, float(thresh), 1 if normal else 0, int(max_keep), keep, num,
+         ws, size_arg(ws.numel()))
+    return keep, num
+
+
 def _nms_into_cpu_keep(boxes, keep, thresh, normal):
     k, num = nms_device(boxes, thresh, normal)
     n = int(num.item())

@@ -250,6 +250,14 @@ int glx_iou3d_boxes_aligned_overlap_bev(const float* boxes_a, const float* boxes
 size_t glx_nms_workspace_bytes(int N);
 int glx_nms(const float* boxes_sorted, int N, float thresh, int normal, int64_t* keep,
             int32_t* num_out, void* workspace, size_t workspace_bytes, void* stream);
+/* `frames` independent lists of N boxes in one launch sequence: boxes_sorted (frames,N,7), keep
+ * (frames,N), num_out (frames); workspace >= frames * glx_nms_workspace_bytes(N).  max_keep > 0
+ * ends a frame's sweep once that many boxes are kept (post-NMS truncation, e.g. NMS_POST_MAXSIZE of
+ * class_agnostic_nms, pcdet/models/model_utils/model_nms_utils.py:6-24): num_out may then be any
+ * value >= max_keep and keep[f, 0..max_keep) is the prefix the full sweep would produce. */
+int glx_nms_batch(const float* boxes_sorted, int frames, int N, float thresh, int normal,
+                  int max_keep, int64_t* keep, int32_t* num_out, void* workspace,
+                  size_t workspace_bytes, void* stream);
 
 /* GLENet's variance-voting NMS loop (nms_func, pcdet/ops/iou3d_nms/iou3d_nms_utils.py:227-273)
  * on the device.  boxes (N,7) and scores (N) are updated in place; variance (N, var_stride>=7)

@@ -43,3 +43,53 @@ def test_voxel_rcnn_flow_runs_on_the_kernels(dev):
     # proposals are padded with zeros behind the kept ones and carry 1-based labels
     n_kept = (out["rois"].abs().sum(-1) > 0).sum(1)
     assert (n_kept > 0).all() and (out["roi_labels"] == 1).all()
+
+
+@pytest.mark.gpu
+def test_batched_proposal_layer_equals_per_frame_loop(dev):
+    """The sync-free batched proposal path (one batched NMS launch sequence stopping at
+    NMS_POST_MAXSIZE) returns exactly what the per-frame loop does; one frame keeps fewer boxes than
+    the padding size."""
+    rng = np.random.default_rng(12)
+    B, A = 3, 5000
+    boxes = np.stack([synth.random_boxes(rng, A, xy_range=[30.0, 30.0, 2.0][b], near_dup=0.5) for b in range(B)])
+    logits = rng.normal(size=(B, A, 2)).astype(np.float32) * 3
+    bx, lg = torch.from_numpy(boxes).to(dev), torch.from_numpy(logits).to(dev)
+    with torch.no_grad():
+        det.BATCHED_PROPOSALS = True
+        a = det.proposal_layer(bx, lg, 1024, 100, 0.3)
+        det.BATCHED_PROPOSALS = False
+        try:
+            b = det.proposal_layer(bx, lg, 1024, 100, 0.3)
+        finally:
+            det.BATCHED_PROPOSALS = True
+    for u, v in zip(a, b):
+        assert u.shape == v.shape and u.dtype == v.dtype and torch.equal(u, v)
+    kept = (a[0].abs().sum(-1) > 0).sum(1)
+    assert int(kept.min()) < 100 and int(kept.max()) == 100
+
+
+@pytest.mark.gpu
+def test_roi_fc_stack_folded_inference_path(dev):
+    """RoIFCStack on the device in eval mode (BatchNorm folded into the Linear layers, first layer
+    split along K) vs its own module-by-module path; fp32 sums of 20 736 terms in a different
+    order: tolerance 2e-4 of the output scale."""
+    from glenet_amd import dense_path as dp
+    torch.manual_seed(5)
+    fc = dp.RoIFCStack(96, 6).to(dev)
+    for m in fc.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 2.0)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    fc.eval()
+    x = torch.randn(300, 216, 96, device=dev)
+    with torch.no_grad():
+        got = fc(x)
+        fc.USE_FUSED = False
+        want = fc(x)
+    for g, w in zip(got, want):
+        assert g.shape == w.shape
+        scale = float(w.abs().max())
+        assert float((g - w).abs().max()) <= 2e-4 * scale

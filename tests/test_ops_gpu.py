@@ -108,6 +108,27 @@ def test_nms_raw_extension_signature(dev):
     assert iou3d_nms_cuda.nms_gpu(T(boxes[:0], dev), keep, 0.3) == 0
 
 
+@pytest.mark.parametrize("normal", [False, True])
+def test_nms_batched_frames_and_early_stop(dev, normal):
+    """glx_nms_batch: every frame's keep list == the oracle's for that frame (bit-identical), and with
+    max_keep the kept prefix is unchanged while the sweep may stop early."""
+    rng = np.random.default_rng(404)
+    F, n, thr = 5, 1500, 0.55
+    boxes = np.stack([synth.random_boxes(rng, n, xy_range=8.0 + 10 * f, near_dup=0.6) for f in range(F)])
+    full_k, full_n = iou3d_nms_cuda.nms_device_batch(T(boxes, dev), thr, normal=normal)
+    cut_k, cut_n = iou3d_nms_cuda.nms_device_batch(T(boxes, dev), thr, normal=normal, max_keep=100)
+    for f in range(F):
+        ref = oracle.nms_sorted(boxes[f], thr, normal=normal)
+        m = int(full_n[f])
+        assert m == len(ref) and np.array_equal(full_k[f, :m].cpu().numpy(), ref)
+        c = int(cut_n[f])
+        assert c >= min(100, m) and c <= m
+        assert np.array_equal(cut_k[f, :min(100, m)].cpu().numpy(), ref[:100])
+    assert len({int(v) for v in full_n}) > 1                     # frames differ
+    k0, n0 = iou3d_nms_cuda.nms_device_batch(T(boxes[:, :0], dev), thr)
+    assert n0.tolist() == [0] * F
+
+
 def test_nms_full_size_properties(dev):
     """Size-independent checks at the training size (9000 proposals): kept set is mutually
     non-overlapping above thr and idempotent."""
