@@ -173,9 +173,14 @@ class VoxelRCNNFlow(nn.Module):
     def forward(self, points, batch_idx, batch_size):
         bd = gb.voxelize_batch(points, batch_idx, batch_size, self.cfg, train=False)
         bd = self.map_to_bev(self.backbone_3d(self.vfe(bd)))
+        return self.second_stage(bd, batch_size)
+
+    def second_stage(self, bd, batch_size):
+        """Everything after map_to_bev: BEV backbone + anchor head, proposals, RoI-grid pooling,
+        FC refinement.  Free of host synchronisation in eval mode on the device."""
         bd = self.dense_head(self.backbone_2d(bd))
         cls, boxes = predicted_boxes(bd["cls_preds"], bd["box_preds"], bd.get("dir_cls_preds"),
-                                     self.anchors(points.device))
+                                     self.anchors(bd["spatial_features"].device))
         rois, roi_scores, roi_labels = proposal_layer(boxes, cls, *self.nms)
         pooled = self.roi_pool(rois, bd["multi_scale_3d_features"], bd["multi_scale_3d_strides"], batch_size)
         rcnn_cls, rcnn_reg = self.roi_fc(pooled)
@@ -183,3 +188,37 @@ class VoxelRCNNFlow(nn.Module):
                   batch_cls_preds=rcnn_cls.view(batch_size, -1, rcnn_cls.shape[-1]),
                   batch_box_preds=refine_boxes(rois, rcnn_reg))
         return bd
+
+
+class StaticDetectorPipeline(gb.StaticFramePipeline):
+    """The whole two-stage inference flow as one shape-static launch sequence / HIP graph: the
+    sparse-backbone pipeline of glenet_amd.backbone.StaticFramePipeline followed by
+    VoxelRCNNFlow.second_stage.  Proposals are padded to NMS_POST_MAXSIZE by construction and the
+    RoI-grid kernels take the sparse tensors at their capacity (only live rows are reachable through
+    the cell index), so no stage needs a row count on the host."""
+
+    def __init__(self, flow, batch_size, num_points, num_features=4, capacities=None, device=None):
+        super().__init__(flow.backbone_3d, flow.cfg, batch_size, num_points, num_features,
+                         train_voxel_cap=False, capacities=capacities, device=device)
+        self.flow = flow
+
+    def enqueue(self):
+        from ._lib import workspace
+        bd = super().enqueue()
+        with torch.no_grad(), workspace.scoped(id(self)):
+            bd = self.flow.second_stage(bd, self.B)
+        self.out = bd
+        return bd
+
+    def run_checked(self, points, batch_idx):
+        """load + replay + capacity verdict; recomputed on the exact-shape flow when a capacity was
+        exceeded (one host synchronisation per batch)."""
+        self.load(points, batch_idx)
+        out = self.replay() if self.graph is not None else self.enqueue()
+        torch.cuda.current_stream(self.points.device).synchronize()
+        try:
+            self.check()
+            return out
+        except RuntimeError:
+            with torch.no_grad():
+                return self.flow(points, batch_idx, self.B)

@@ -112,7 +112,7 @@ class RoIGridPool(nn.Module):
             return False
         for layer, name in zip(self.roi_grid_pool_layers, self.sources):
             st = tensors[name]
-            if st.count is not None or not layer._fusable(st.features):
+            if not layer._fusable(st.features) or (st.count is not None and st._index is None):
                 return False
         return True
 
