@@ -69,10 +69,16 @@ for f, w, nbr, order, n_out, rules in calls:
             ts.append(ms.value * 1e3)
         rb_us = float(np.median(ts[2:]))
         _lib.call_nostream("glx_sconv_set_variant", -1)
+    _lib.call_nostream("glx_sconv_set_variant", -1)
+    ref_out = orig(f, w, None, nbr, order, n_out, packed=packed)
     for v in variants:
         _lib.call_nostream("glx_sconv_set_variant", v)
         ts = []
         try:
+            got = orig(f, w, None, nbr, order, n_out, packed=packed)
+            if not torch.equal(got, ref_out):
+                print("  !! variant %d differs from the default on %s: max |d| %.3g" % (
+                    v, key, float((got - ref_out).abs().max())))
             for it in range(12):
                 s, e = ev(), ev()
                 _lib.call_nostream("glx_profile_next_sconv", s, e)
