@@ -238,17 +238,31 @@ def main():
 
     # ---- side measurement (not `value`): forward + backward of the same backbone in training
     # mode (BatchNorm batch statistics, autograd through the sparse convs: dgrad = the forward
-    # kernels on transposed weights, wgrad = k_wgrad_mfma), exact-shape path, loss = mean(out^2)
+    # kernels on transposed weights, wgrad = k_wgrad_mfma), loss = mean(out^2), gradients of every
+    # parameter; shape-static step replayed as one HIP graph (StaticTrainPipeline) unless
+    # --mode dynamic asks for the exact-shape path with its host read-backs
     fwd_bwd = None
     if not args.no_train:
         tmodel = gb.VoxelBackBone8x(K["num_features"], grid).to(dev).train()
         tmodel.load_state_dict(model.state_dict())
-
-        def train_step():
-            bd_ = gb.voxelize_batch(pts, bidx, FRAMES_PER_GPU, K, train=True)
-            bd_ = hc(tmodel(vfe(bd_)))
-            tmodel.zero_grad(set_to_none=True)
-            bd_["spatial_features"].square().mean().backward()
+        if args.mode == "dynamic":
+            def train_step():
+                bd_ = gb.voxelize_batch(pts, bidx, FRAMES_PER_GPU, K, train=True)
+                bd_ = hc(tmodel(vfe(bd_)))
+                tmodel.zero_grad(set_to_none=True)
+                bd_["spatial_features"].square().mean().backward()
+            tnote = "exact-shape path (host read-backs)"
+        else:
+            tpipe = gb.StaticTrainPipeline(tmodel, K, FRAMES_PER_GPU, pts.shape[0], K["num_features"])
+            tpipe.calibrate(pts, bidx)
+            tpipe.load(pts, bidx)
+            if args.mode == "graph":
+                tpipe.capture()
+                train_step = tpipe.replay
+                tnote = "shape-static step replayed as one HIP graph"
+            else:
+                train_step = tpipe.enqueue
+                tnote = "shape-static step, eager launches"
 
         run(train_step, 6)
         gdist.fence(dev)
@@ -256,10 +270,11 @@ def main():
         run(train_step, 20)
         gdist.fence(dev)
         dtt = gdist.reduce_max(time.perf_counter() - t1, dev)
+        if args.mode != "dynamic":
+            tpipe.check()
         fwd_bwd = dict(frames_per_s=round(FRAMES_PER_GPU * world * 20 / dtt, 1),
                        ms_per_step=round(dtt / 20 * 1e3, 3), steps=20,
-                       note="training-mode backbone fwd+bwd, exact-shape path (host read-backs), "
-                            "not the headline workload")
+                       note="training-mode backbone fwd+bwd, " + tnote + ", not the headline workload")
 
     frames_total = FRAMES_PER_GPU * world * args.steps
     dom = max(per, key=lambda k: per[k]["ms"]) if per else None

@@ -46,12 +46,12 @@ class ResidualBlock(spconv.SparseModule):
             core = spconv.core
             out = self.conv1(x)
             if core.can_fuse_train_bn(self.bn1, out.features):     # training: fused BN(+ReLU) kernels
-                out = out.replace_feature(core.fused_train_bn(self.bn1, out.features, True))
+                out = out.replace_feature(core.fused_train_bn(self.bn1, out.features, True, out.count))
             else:
                 out = out.replace_feature(self.relu(self.bn1(out.features)))
             out = self.conv2(out)
             if core.can_fuse_train_bn(self.bn2, out.features):
-                out = out.replace_feature(core.fused_train_bn(self.bn2, out.features, False))
+                out = out.replace_feature(core.fused_train_bn(self.bn2, out.features, False, out.count))
             else:
                 out = out.replace_feature(self.bn2(out.features))
         return out.replace_feature(self.relu(out.features + x.features))
@@ -298,3 +298,59 @@ class StaticFramePipeline:
         """Trim a shape-static SparseConvTensor to its live rows (host sync) for inspection."""
         n = int(st.count.item())
         return st.features[:n], st.indices[:n]
+
+
+class StaticTrainPipeline(StaticFramePipeline):
+    """Forward + backward (+ optimizer step) of the sparse backbone as one shape-static launch
+    sequence / HIP graph.  The autograd Functions take the device row counts of the shape-static
+    rule sets (dgrad = the forward kernels with n_live, k_wgrad_mfma and the fused BatchNorm kernels
+    read *n_live, dense()'s adjoint is glx_dense_gather), so the ~600 launches of a training step
+    are enqueued without a read-back and replayed with one call.  Rows past a live count carry
+    undefined values in activations and gradients alike; no kernel reads them.
+
+    loss_fn(batch_dict) -> scalar tensor; default mean(spatial_features^2) (a stand-in for the
+    dense head's loss).  Parameter gradients are left in `.grad` (rewritten by every replay)."""
+
+    def __init__(self, model, cfg, batch_size, num_points, num_features, loss_fn=None, optimizer=None,
+                 train_voxel_cap=True, capacities=None, device=None):
+        super().__init__(model, cfg, batch_size, num_points, num_features,
+                         train_voxel_cap=train_voxel_cap, capacities=capacities, device=device)
+        self.loss_fn = loss_fn if loss_fn is not None else (lambda bd: bd["spatial_features"].square().mean())
+        self.optimizer = optimizer
+        self.loss = None
+
+    def enqueue(self):
+        from ._lib import workspace
+        dev = self.points.device
+        # release the previous step's autograd graph first: its AccumulateGrad nodes remember the
+        # stream they were created on, and a node of an earlier eager step (default stream) that is
+        # still alive makes backward synchronise with that stream -- inside a capture this tears
+        # the capture down (a segfault in hipStreamEndCapture on ROCm 7.2).  Callers that keep
+        # their own reference to an earlier loss / batch_dict must drop it before capture().
+        self.out = self.loss = None
+        with workspace.scoped(id(self)):
+            with torch.no_grad():
+                bd = voxelize_batch(self.points, self.batch_idx, self.B, self.cfg, train=self.train_cap,
+                                    static=True)
+                cur = torch.cuda.current_stream(dev)
+                if self.overlap_plan:
+                    self.plan_stream.wait_stream(cur)
+                    with torch.cuda.stream(self.plan_stream):
+                        plan = self.model.plan(bd["voxel_coords"], self.B, index=bd["voxel_index"],
+                                               capacities=self.capacities, events=True)
+                else:
+                    plan = self.model.plan(bd["voxel_coords"], self.B, index=bd["voxel_index"],
+                                           capacities=self.capacities)
+                bd = self.vfe(bd)
+            bd["rule_plan"] = plan
+            self.model.zero_grad(set_to_none=True)      # .grad tensors are (re)created by backward
+            with torch.enable_grad():
+                bd = self.hc(self.model(bd))
+                loss = self.loss_fn(bd)
+            if self.overlap_plan:
+                cur.wait_stream(self.plan_stream)
+            loss.backward()
+            if self.optimizer is not None:
+                self.optimizer.step()
+        self.out, self.loss = bd, loss
+        return bd

@@ -20,7 +20,7 @@ void glx_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* glx_last_error(void) { return g_err; }
-extern "C" int glx_abi_version(void) { return 3; }
+extern "C" int glx_abi_version(void) { return 4; }
 
 // ---------------------------------------------------------------- timing events (bench)
 extern "C" int glx_event_create(void** event) {
@@ -430,8 +430,9 @@ extern "C" int glx_rules_strided(const int32_t* indices_out, int N_out, int N_in
 }
 
 __global__ void k_rules_invert(const int* __restrict__ nbr, long long total, int K,
-                               int* __restrict__ nbr_in) {
+                               int* __restrict__ nbr_in, const int* __restrict__ n_live) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_live) total = min(total, (long long)*n_live * K);   // rows past the live count are undefined
   if (t >= total) return;
   int i = nbr[t];
   if (i < 0) return;
@@ -441,7 +442,7 @@ __global__ void k_rules_invert(const int* __restrict__ nbr, long long total, int
 }
 
 extern "C" int glx_rules_invert(const int32_t* nbr, int N_out, int K, int N_in, int32_t* nbr_in,
-                                void* stream) {
+                                const int32_t* n_out_live, void* stream) {
   GLX_REQUIRE(K > 0, "glx_rules_invert: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   if (N_in > 0) {
@@ -452,7 +453,7 @@ extern "C" int glx_rules_invert(const int32_t* nbr, int N_out, int K, int N_in, 
   long long total = (long long)N_out * K;
   if (total > 0) {
     hipLaunchKernelGGL(k_rules_invert, dim3(glx_divup(total, 256)), dim3(256), 0, st, nbr, total,
-                       K, nbr_in);
+                       K, nbr_in, n_out_live);
   }
   GLX_LAUNCH_CHECK();
   return GLX_OK;

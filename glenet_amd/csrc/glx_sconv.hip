@@ -1575,7 +1575,8 @@ struct WgradCfg {
 template <int CIN, int COUT>
 __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_mfma(
     const float* __restrict__ in, const float* __restrict__ gout, const int* __restrict__ nbr,
-    int N_out, int K, int rows_per_slice, float* __restrict__ slabs) {
+    int N_out, int K, int rows_per_slice, float* __restrict__ slabs, const int* __restrict__ n_live) {
+  if (n_live) N_out = min(N_out, *n_live);   // shape-static set: rows past the live count are undefined
   using T = WgradCfg<CIN, COUT>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_a = smem;                                   // WGM_PANEL * A_LD   (input rows)
@@ -1676,7 +1677,8 @@ extern "C" size_t glx_sconv_wgrad_workspace_bytes(int N_out, int K, int Cin, int
 
 extern "C" int glx_sconv_wgrad(const float* in, int N_in, const float* grad_out,
                                const int32_t* nbr, int N_out, int K, int Cin, int Cout, float* dW,
-                               void* workspace, size_t workspace_bytes, void* stream) {
+                               const int32_t* n_out_live, void* workspace, size_t workspace_bytes,
+                               void* stream) {
   (void)N_in;
   GLX_REQUIRE(dW && (N_out == 0 || (in && grad_out && nbr)), "glx_sconv_wgrad: null pointer");
   GLX_REQUIRE(Cin * Cout <= 64 * WG_THREADS, "glx_sconv_wgrad: Cin*Cout=%d too large", Cin * Cout);
@@ -1709,7 +1711,7 @@ extern "C" int glx_sconv_wgrad(const float* in, int N_in, const float* grad_out,
           attr_set = true;
         }
         hipLaunchKernelGGL(kern, dim3(slices, K), dim3(WGM_THREADS), T::lds_bytes, st, in, grad_out,
-                           nbr, N_out, K, rps, (float*)workspace);
+                           nbr, N_out, K, rps, (float*)workspace, n_out_live);
       }
       return GLX_OK;
     });
@@ -1719,6 +1721,7 @@ extern "C" int glx_sconv_wgrad(const float* in, int N_in, const float* grad_out,
     GLX_LAUNCH_CHECK();
     return GLX_OK;
   }
+  GLX_REQUIRE(!n_out_live, "glx_sconv_wgrad: (Cin=%d, Cout=%d) has no shape-static kernel", Cin, Cout);
   int rows_per_chunk = glx_divup(N_out, WG_CHUNKS);
   hipLaunchKernelGGL(k_wgrad_partial, dim3(WG_CHUNKS, K), dim3(WG_THREADS),
                      (Cin + Cout) * sizeof(float), st, in, grad_out, nbr, N_out, K, Cin, Cout,
@@ -1753,6 +1756,34 @@ extern "C" int glx_dense_scatter(const float* features, const int32_t* indices, 
   hipLaunchKernelGGL(k_dense_scatter, dim3(glx_divup(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, features, (const int4*)indices, N, C, D, H, W, out,
                      n_live);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// Adjoint of dense(): grad_features[row, c] = grad_dense[b, c, z, y, x] of the row's cell (the
+// autograd gather the reference gets from torch indexing; here it honours the live-row count of a
+// shape-static tensor, whose padding rows carry undefined coordinates).
+__global__ void k_dense_gather(const float* __restrict__ g, const int4* __restrict__ idx, int N, int C,
+                               int B, int D, int H, int W, float* __restrict__ out,
+                               const int* __restrict__ n_live) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_live) N = min(N, *n_live);
+  if (t >= (long long)N * C) return;
+  const int row = (int)(t / C), c = (int)(t - (long long)row * C);
+  const int4 p = idx[row];
+  if ((unsigned)p.x >= (unsigned)B || (unsigned)p.y >= (unsigned)D || (unsigned)p.z >= (unsigned)H ||
+      (unsigned)p.w >= (unsigned)W) { out[t] = 0.f; return; }
+  out[t] = g[((((long long)p.x * C + c) * D + p.y) * H + p.z) * W + p.w];
+}
+
+extern "C" int glx_dense_gather(const float* grad_dense, const int32_t* indices, int N, int C, int B,
+                                int D, int H, int W, float* grad_features, const int32_t* n_live,
+                                void* stream) {
+  if (N == 0) return GLX_OK;
+  GLX_REQUIRE(grad_dense && indices && grad_features && C > 0, "glx_dense_gather: bad arguments");
+  long long total = (long long)N * C;
+  hipLaunchKernelGGL(k_dense_gather, dim3(glx_divup(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     grad_dense, (const int4*)indices, N, C, B, D, H, W, grad_features, n_live);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

@@ -127,12 +127,11 @@ class RuleSet:
         return self._book
 
     def inverse_table(self):
-        if self.nbr_in is None and self.count_out is not None:
-            raise NotImplementedError("inverse rule tables are not available in shape-static mode")
         if self.nbr_in is None:
             dev = self.nbr.device
             self.nbr_in = torch.empty((max(self.N_in, 1), self.K), dtype=torch.int32, device=dev)
-            call("glx_rules_invert", self.nbr, self.N_out, self.K, self.N_in, self.nbr_in)
+            call("glx_rules_invert", self.nbr, self.N_out, self.K, self.N_in, self.nbr_in,
+                 self.count_out)
         return self.nbr_in
 
 
@@ -333,8 +332,6 @@ class SparseConvFunction(Function):
             nbr, order, n_out = rules.inverse_table(), rules.tile_order_in, rules.N_in
         else:
             nbr, order, n_out = rules.nbr, rules.tile_order_out, rules.N_out
-        if rules.count_out is not None and (features.requires_grad or w.requires_grad):
-            raise NotImplementedError("shape-static sparse tensors are inference only")
         book = rules.book() if (USE_RULEBOOK and not inverse
                                 and rulebook_eligible(w.shape[1], w.shape[2], w.shape[0])) else None
         out = _sconv(features, w, bias, nbr, order, n_out, packed=packed, rules=rules,
@@ -351,29 +348,37 @@ class SparseConvFunction(Function):
         grad_out = grad_out.contiguous().float()
         K, cin, cout = w.shape
         g_feat = g_w = g_b = None
+        # live_fwd / live_bwd: device row counts of a shape-static rule set (None = exact shapes);
+        # rows past them hold undefined data in every tensor and are never read by the kernels
         if inverse:
-            fwd_nbr, n_fwd_out = rules.inverse_table(), rules.N_in
-            bwd_nbr, bwd_order, n_bwd_out = rules.nbr, rules.tile_order_out, rules.N_out
+            fwd_nbr, n_fwd_out, live_fwd = rules.inverse_table(), rules.N_in, rules.count_in
+            bwd_nbr, bwd_order, n_bwd_out, live_bwd = rules.nbr, rules.tile_order_out, rules.N_out, rules.count_out
             wt = w.transpose(1, 2).contiguous()
         elif rules.subm:
             # nbr_in[i][k] == nbr[i][K-1-k] on a submanifold set: flip the taps instead
-            fwd_nbr, n_fwd_out = rules.nbr, rules.N_out
-            bwd_nbr, bwd_order, n_bwd_out = rules.nbr, rules.tile_order_out, rules.N_in
+            fwd_nbr, n_fwd_out, live_fwd = rules.nbr, rules.N_out, rules.count_out
+            bwd_nbr, bwd_order, n_bwd_out, live_bwd = rules.nbr, rules.tile_order_out, rules.N_in, rules.count_in
             wt = w.flip(0).transpose(1, 2).contiguous()
         else:
-            fwd_nbr, n_fwd_out = rules.nbr, rules.N_out
-            bwd_nbr, bwd_order, n_bwd_out = rules.inverse_table(), rules.tile_order_in, rules.N_in
+            fwd_nbr, n_fwd_out, live_fwd = rules.nbr, rules.N_out, rules.count_out
+            bwd_nbr, bwd_order, n_bwd_out, live_bwd = (rules.inverse_table(), rules.tile_order_in, rules.N_in,
+                                                       rules.count_in)
             wt = w.transpose(1, 2).contiguous()
         if ctx.needs_input_grad[0]:
-            g_feat = _sconv(grad_out, wt, None, bwd_nbr, bwd_order, n_bwd_out, rules=rules, tag="dgrad")
+            g_feat = _sconv(grad_out, wt, None, bwd_nbr, bwd_order, n_bwd_out, rules=rules, tag="dgrad",
+                            n_live=live_bwd)
         if ctx.needs_input_grad[1]:
             g_w = torch.empty_like(w)
             wsb = query("glx_sconv_wgrad_workspace_bytes", n_fwd_out, K, cin, cout)
             ws = workspace.get(wsb, w.device)
             call("glx_sconv_wgrad", features, features.shape[0], grad_out, fwd_nbr, n_fwd_out, K,
-                 cin, cout, g_w, ws, size_arg(ws.numel()))
+                 cin, cout, g_w, live_fwd, ws, size_arg(ws.numel()))
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            g_b = grad_out.sum(0)
+            if live_fwd is None:
+                g_b = grad_out.sum(0)
+            else:   # rows past the live count are undefined (possibly NaN): select, do not multiply
+                live = torch.arange(grad_out.shape[0], device=grad_out.device) < live_fwd
+                g_b = torch.where(live[:, None], grad_out, grad_out.new_zeros(())).sum(0)
         return g_feat, g_w, g_b, None, None, None
 
 
@@ -450,9 +455,12 @@ class DenseFunction(Function):
         st = ctx.st
         if not ctx.channels_first:
             g = g.permute(0, 4, 1, 2, 3)
-        i = st.indices.long()
-        gf = g[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]]
-        return gf.contiguous(), None, None
+        g = g.contiguous().float()
+        n, c = st.indices.shape[0], g.shape[1]
+        d, h, w = st.spatial_shape
+        gf = torch.empty((n, c), dtype=torch.float32, device=g.device)
+        call("glx_dense_gather", g, st.indices, n, c, st.batch_size, d, h, w, gf, st.count)
+        return gf, None, None
 
 
 class SparseModule(nn.Module):
@@ -593,7 +601,7 @@ class FusedBNReLU(Function):
     backward (csrc/glx_bn.hip); numerics of nn.BatchNorm1d(eps, momentum) + nn.ReLU."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, count=None):
         x = x.contiguous().float()
         N, C = x.shape
         y = torch.empty_like(x)
@@ -601,9 +609,9 @@ class FusedBNReLU(Function):
         invstd = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = workspace.get(query("glx_bn_workspace_bytes", C), x.device)
         call("glx_bn_relu_train_forward", x, N, C, weight, bias, ctypes_float(eps), ctypes_float(momentum),
-             1 if relu else 0, running_mean, running_var, y, mean, invstd, None, ws, size_arg(ws.numel()))
+             1 if relu else 0, running_mean, running_var, y, mean, invstd, count, ws, size_arg(ws.numel()))
         ctx.save_for_backward(x, y, weight, mean, invstd)
-        ctx.relu = relu
+        ctx.relu, ctx.count = relu, count
         return y
 
     @staticmethod
@@ -616,9 +624,9 @@ class FusedBNReLU(Function):
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = workspace.get(query("glx_bn_workspace_bytes", C), x.device)
         call("glx_bn_relu_backward", x, dy, y, N, C, weight, mean, invstd, 1 if ctx.relu else 0, dx,
-             dgamma, dbeta, None, ws, size_arg(ws.numel()))
+             dgamma, dbeta, ctx.count, ws, size_arg(ws.numel()))
         return dx, (dgamma if weight is not None else None), (dbeta if weight is not None else None), \
-            None, None, None, None, None
+            None, None, None, None, None, None
 
 
 def ctypes_float(v):
@@ -636,9 +644,10 @@ def can_fuse_train_bn(bn, features):
             and features.is_cuda and features.shape[0] > 1 and c % 4 == 0 and c <= 512 and 1024 % c == 0)
 
 
-def fused_train_bn(bn, features, relu):
+def fused_train_bn(bn, features, relu, count=None):
+    """count: device int32 live-row count of a shape-static tensor (statistics over live rows)."""
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    out = FusedBNReLU.apply(features, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, relu)
+    out = FusedBNReLU.apply(features, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, relu, count)
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     return out
@@ -710,18 +719,18 @@ class SparseSequential(SparseModule):
                 x = m(x, fused_bn=mods[i + 1], fused_relu=relu)
                 i += 3 if relu else 2
                 continue
-            if (isinstance(x, SparseConvTensor) and isinstance(m, nn.BatchNorm1d) and x.count is None
+            if (isinstance(x, SparseConvTensor) and isinstance(m, nn.BatchNorm1d)
                     and x.indices.shape[0] > 1 and can_fuse_train_bn(m, x.features)):
                 relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                x = x.replace_feature(fused_train_bn(m, x.features, relu))
+                x = x.replace_feature(fused_train_bn(m, x.features, relu, x.count))
                 i += 2 if relu else 1
                 continue
             if is_spconv_module(m):
                 x = m(x)
             elif isinstance(x, SparseConvTensor):
                 if x.count is not None and isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training:
-                    raise NotImplementedError("shape-static sparse tensors are inference only "
-                                              "(batch statistics would include the padding rows)")
+                    raise NotImplementedError("shape-static training needs the fused BatchNorm kernels "
+                                              "(torch's batch statistics would include the padding rows)")
                 if x.indices.shape[0] != 0:
                     x = x.replace_feature(m(x.features))
             else:

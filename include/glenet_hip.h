@@ -103,9 +103,10 @@ int glx_rules_strided(const int32_t* indices_out, int N_out, int N_in, int B, in
                       const int32_t* in_rank_to_row, int kd, int kh, int kw, int sd, int sh,
                       int sw, int pd, int ph, int pw, int32_t* nbr, int32_t* pair_count,
                       const int32_t* n_out_live, void* stream);
-/* Input-major inverse: nbr_in[i*K+k] = output row j with nbr[j*K+k]==i, else -1. */
+/* Input-major inverse: nbr_in[i*K+k] = output row j with nbr[j*K+k]==i, else -1.
+ * n_out_live (device int32, may be NULL): live output rows of a shape-static rule set. */
 int glx_rules_invert(const int32_t* nbr, int N_out, int K, int N_in, int32_t* nbr_in,
-                     void* stream);
+                     const int32_t* n_out_live, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Sparse convolution  out[j,:] = sum_k in[nbr[j,k],:] @ W[k]   (+ bias)
@@ -160,13 +161,19 @@ int glx_sconv_transpose_weights(const float* W, int K, int Cin, int Cout, float*
  * Replaces: spconv backward wgrad (autograd of spconv_backbone.py convs). */
 size_t glx_sconv_wgrad_workspace_bytes(int N_out, int K, int Cin, int Cout);
 int glx_sconv_wgrad(const float* in, int N_in, const float* grad_out, const int32_t* nbr,
-                    int N_out, int K, int Cin, int Cout, float* dW, void* workspace,
-                    size_t workspace_bytes, void* stream);
+                    int N_out, int K, int Cin, int Cout, float* dW, const int32_t* n_out_live,
+                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* SparseConvTensor.dense(): out (B, C, D, H, W) must be zero-filled by the caller.
  * Replaces: spconv dense() (height_compression.py:21). */
 int glx_dense_scatter(const float* features, const int32_t* indices, int N, int C, int B,
                       int D, int H, int W, float* out, const int32_t* n_live, void* stream);
+
+/* Adjoint of dense(): grad_features (N, C) gathered from grad_dense (B, C, D, H, W) at the rows'
+ * cells; rows >= *n_live (shape-static tensors) are left untouched.
+ * Replaces: the autograd of spconv's dense() (advanced indexing in torch). */
+int glx_dense_gather(const float* grad_dense, const int32_t* indices, int N, int C, int B, int D,
+                     int H, int W, float* grad_features, const int32_t* n_live, void* stream);
 
 /* Same result without the caller's zero fill: every element of out is written once, rows are
  * found through the tensor's cell index (bitmap / prefix / rank_to_row or NULL when rows are in

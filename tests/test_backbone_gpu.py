@@ -278,3 +278,72 @@ def test_static_pipeline_handles_empty_frames(dev):
     with torch.no_grad():
         ref = gb.HeightCompression()(model(gb.MeanVFE()(gb.voxelize_batch(pts, bidx, 2, K))))["spatial_features"]
     assert torch.equal(out["spatial_features"], ref)
+
+
+@pytest.mark.parametrize("residual", [False, True])
+def test_static_training_step_matches_exact_shape_autograd(dev, residual):
+    """StaticTrainPipeline (capacity-sized buffers, device row counts, no read-back) enqueued and
+    replayed as a HIP graph: loss, every parameter gradient and the BatchNorm running statistics
+    equal the exact-shape autograd path (same kernels; the weight-gradient slices and nothing else
+    depend on the buffer size -> 1e-5 relative), on a second batch through the recorded graph too."""
+    torch.manual_seed(3)
+    grid = oracle.grid_size_of(K["point_cloud_range"], K["voxel_size"])
+    B = 2
+
+    def batch(seed, npts):
+        frames = [synth.kitti_frame(seed + i, num_points=npts)[0] for i in range(B)]
+        pts = torch.from_numpy(np.concatenate(frames)).to(dev)
+        bidx = torch.from_numpy(np.concatenate([np.full(len(f), i, np.int32) for i, f in enumerate(frames)])).to(dev)
+        return pts, bidx
+
+    model = gb.SparseBackbone8x(4, grid, residual=residual).to(dev).train()
+    _condition(model)
+    state0 = {k: v.clone() for k, v in model.state_dict().items()}
+    loss_fn = lambda bd: (bd["spatial_features"] * 3.0).square().mean()   # noqa: E731
+
+    def exact(pts, bidx):
+        model.load_state_dict(state0)
+        model.zero_grad(set_to_none=True)
+        bd = gb.HeightCompression()(model(gb.MeanVFE()(gb.voxelize_batch(pts, bidx, B, K, train=True))))
+        loss = loss_fn(bd)
+        loss.backward()
+        grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+        stats = {n: b.clone() for n, b in model.named_buffers()}
+        return loss.detach().clone(), grads, stats
+
+    def compare(pipe, ref):
+        loss, grads, stats = ref
+        torch.cuda.synchronize()
+        pipe.check()
+        np.testing.assert_allclose(float(pipe.loss.detach()), float(loss), rtol=1e-5)
+        # absolute floor from the largest gradient of the model: a conv bias in front of a
+        # BatchNorm has an exactly-zero gradient, what both paths return there is rounding noise
+        gmax = max(float(v.abs().max()) for v in grads.values())
+        for n, p in model.named_parameters():
+            g, w = p.grad.cpu().numpy(), grads[n].cpu().numpy()
+            assert np.isfinite(g).all(), n
+            np.testing.assert_allclose(g, w, rtol=2e-4, atol=2e-5 * max(gmax * 1e-2, np.abs(w).max()), err_msg=n)
+        for n, b in model.named_buffers():
+            np.testing.assert_allclose(b.cpu().numpy(), stats[n].cpu().numpy(), rtol=1e-5, atol=1e-7, err_msg=n)
+
+    a, b2 = batch(20, 9000), batch(60, 7000)
+    ref_a, ref_b = exact(*a), exact(*b2)
+    assert float(ref_a[0]) > 0 and max(float(g.abs().max()) for g in ref_a[1].values()) > 0
+
+    pipe = gb.StaticTrainPipeline(model, K, B, a[0].shape[0] + 1000, 4, loss_fn=loss_fn)
+    pipe.calibrate(*a)
+    model.load_state_dict(state0)
+    pipe.load(*a)
+    pipe.enqueue()
+    compare(pipe, ref_a)
+
+    model.load_state_dict(state0)
+    pipe.capture(warmup=1)
+    model.load_state_dict(state0)
+    pipe.load(*b2)
+    pipe.replay()
+    compare(pipe, ref_b)
+    model.load_state_dict(state0)
+    pipe.load(*a)
+    pipe.replay()
+    compare(pipe, ref_a)

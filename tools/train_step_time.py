@@ -41,3 +41,23 @@ for name, bw in (("fwd (train mode, BN batch stats)", False), ("fwd+bwd", True),
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     print("%-36s %8.3f ms/step  %8.1f frames/s" % (name, dt * 1e3, 4 / dt))
+
+# ---- the same step on the shape-static path: no read-backs, then replayed as one HIP graph
+pipe = gb.StaticTrainPipeline(model, K, 4, pts.shape[0], 4)
+pipe.calibrate(pts, bidx)
+pipe.load(pts, bidx)
+for name, graph in (("fwd+bwd shape-static, eager", False), ("fwd+bwd shape-static, HIP graph", True)):
+    if graph:
+        pipe.capture()
+    fn = pipe.replay if graph else pipe.enqueue
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 20
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    pipe.check()
+    print("%-36s %8.3f ms/step  %8.1f frames/s" % (name, dt * 1e3, 4 / dt))
