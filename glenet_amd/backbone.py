@@ -318,6 +318,7 @@ class StaticTrainPipeline(StaticFramePipeline):
         self.loss_fn = loss_fn if loss_fn is not None else (lambda bd: bd["spatial_features"].square().mean())
         self.optimizer = optimizer
         self.loss = None
+        self.overlap_wgrad = True
 
     def enqueue(self):
         from ._lib import workspace
@@ -349,7 +350,14 @@ class StaticTrainPipeline(StaticFramePipeline):
                 loss = self.loss_fn(bd)
             if self.overlap_plan:
                 cur.wait_stream(self.plan_stream)
-            loss.backward()
+            if self.overlap_wgrad:     # weight gradients next to the input-gradient chain
+                spconv.core.WGRAD_STREAM = self.plan_stream
+            try:
+                loss.backward()
+            finally:
+                spconv.core.WGRAD_STREAM = None
+            if self.overlap_wgrad:
+                cur.wait_stream(self.plan_stream)
             if self.optimizer is not None:
                 self.optimizer.step()
         self.out, self.loss = bd, loss

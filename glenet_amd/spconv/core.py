@@ -19,6 +19,7 @@ capacity.  Every op then takes its row count on the device (the C ABI's n_live a
 whole frame runs without host synchronisation and can be captured in a HIP graph;
 `check_static()` verifies afterwards that no capacity was exceeded.
 """
+import contextlib
 import math
 import os
 from collections import OrderedDict
@@ -324,7 +325,7 @@ class SparseConvFunction(Function):
     """features (N_in, Cin), weight (K, Cin, Cout), bias (Cout)|None -> (N_out, Cout)."""
 
     @staticmethod
-    def forward(ctx, features, weight, bias, rules, inverse, packed=None):
+    def forward(ctx, features, weight, bias, rules, inverse, packed=None, side_ok=False):
         features = features.contiguous().float()
         w = weight.contiguous()
         _lib.check_cuda(features, w)
@@ -336,7 +337,7 @@ class SparseConvFunction(Function):
                                 and rulebook_eligible(w.shape[1], w.shape[2], w.shape[0])) else None
         out = _sconv(features, w, bias, nbr, order, n_out, packed=packed, rules=rules,
                      n_live=rules.count_in if inverse else rules.count_out, book=book)
-        ctx.rules, ctx.inverse = rules, inverse
+        ctx.rules, ctx.inverse, ctx.side_ok = rules, inverse, side_ok
         ctx.save_for_backward(features, w)
         ctx.has_bias = bias is not None
         return out
@@ -364,22 +365,31 @@ class SparseConvFunction(Function):
             bwd_nbr, bwd_order, n_bwd_out, live_bwd = (rules.inverse_table(), rules.tile_order_in, rules.N_in,
                                                        rules.count_in)
             wt = w.transpose(1, 2).contiguous()
+        if ctx.needs_input_grad[1]:
+            side = WGRAD_STREAM if ctx.side_ok else None
+            if side is not None:
+                # the weight gradient is a leaf of the backward pass: it runs on a second stream
+                # next to the input-gradient chain (whoever set WGRAD_STREAM joins it afterwards)
+                cur = torch.cuda.current_stream(w.device)
+                side.wait_stream(cur)
+                for t in (features, grad_out, fwd_nbr):
+                    t.record_stream(side)
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                g_w = torch.empty_like(w)
+                wsb = query("glx_sconv_wgrad_workspace_bytes", n_fwd_out, K, cin, cout)
+                ws = workspace.get(wsb, w.device)
+                call("glx_sconv_wgrad", features, features.shape[0], grad_out, fwd_nbr, n_fwd_out, K,
+                     cin, cout, g_w, live_fwd, ws, size_arg(ws.numel()))
         if ctx.needs_input_grad[0]:
             g_feat = _sconv(grad_out, wt, None, bwd_nbr, bwd_order, n_bwd_out, rules=rules, tag="dgrad",
                             n_live=live_bwd)
-        if ctx.needs_input_grad[1]:
-            g_w = torch.empty_like(w)
-            wsb = query("glx_sconv_wgrad_workspace_bytes", n_fwd_out, K, cin, cout)
-            ws = workspace.get(wsb, w.device)
-            call("glx_sconv_wgrad", features, features.shape[0], grad_out, fwd_nbr, n_fwd_out, K,
-                 cin, cout, g_w, live_fwd, ws, size_arg(ws.numel()))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             if live_fwd is None:
                 g_b = grad_out.sum(0)
             else:   # rows past the live count are undefined (possibly NaN): select, do not multiply
                 live = torch.arange(grad_out.shape[0], device=grad_out.device) < live_fwd
                 g_b = torch.where(live[:, None], grad_out, grad_out.new_zeros(())).sum(0)
-        return g_feat, g_w, g_b, None, None, None
+        return g_feat, g_w, g_b, None, None, None, None
 
 
 class SparseConvTensor:
@@ -565,8 +575,10 @@ class SparseConvolution(SparseModule):
                            book=rs.book() if (USE_RULEBOOK and not self.inverse and rulebook_eligible(
                                w.shape[1], w.shape[2], K)) else None)
         else:
+            # side_ok: the weight gradient may run on WGRAD_STREAM only when nothing but views
+            # separates it from the parameter (a padded weight's backward copies on the main stream)
             feats = SparseConvFunction.apply(x_features, w, self.bias, rs, self.inverse,
-                                             self._packed_weight(w))
+                                             self._packed_weight(w), not pad)
         if self.inverse:
             out = SparseConvTensor(feats, rs.in_indices, rs.in_spatial_shape, x.batch_size,
                                    x.grid, x.voxel_num, x.indice_dict, x.benchmark, rs.count_in)
@@ -635,6 +647,9 @@ def ctypes_float(v):
 
 
 USE_FUSED_TRAIN_BN = os.environ.get("GLX_FUSED_BN", "1") != "0"
+# stream for the weight-gradient kernels of SparseConvFunction.backward (None = the current one).
+# Set by StaticTrainPipeline around its backward pass; the setter waits for it afterwards.
+WGRAD_STREAM = None
 
 
 def can_fuse_train_bn(bn, features):
