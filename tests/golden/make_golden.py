@@ -19,6 +19,8 @@ committed, this script is committed, nothing of the reference is copied.
                          suppression strictness, output ordering) given the oracle's IoU matrix;
                          the IoU arithmetic itself is pinned by iou3d_ref.npz (shared helpers).
   limit_period / boxes3d_to_bev_torch outputs of the reference are stored alongside.
+  detector_glue_ref.npz  box coder, anchor generator and the two generate_predicted_boxes statement
+                     sequences of the detection heads (see make_detector_glue_ref()).
   dense_path_ref.npz the reference's dense-path modules (BEV backbone, CVAE networks, RoI-grid
                      geometry helpers) run on CPU: see make_dense_path_ref() for what is imported
                      and which placeholders stand in for uninstalled / CUDA-only imports.
@@ -244,8 +246,83 @@ def make_dense_path_ref():
     print("dense_path_ref.npz", len(out), "arrays; bev_out", out["bev_out"].shape, "cvae_box", out["cvae_box"].shape)
 
 
+def make_detector_glue_ref():
+    """detector_glue_ref.npz: the box arithmetic between the kernels of the two-stage flow, from the
+    reference's own pure-torch code:
+      * ResidualCoder.decode_torch (pcdet/utils/box_coder_utils.py:45-78), loaded by file path;
+      * AnchorGenerator.generate_anchors (pcdet/models/dense_heads/target_assigner/
+        anchor_generator.py:17-60), loaded by file path.  It calls `.cuda()` on the tensors it
+        creates; there is no GPU here, so for the duration of that call torch.Tensor.cuda is a
+        no-op (disclosed placeholder; the arithmetic is untouched);
+      * the statement sequences of AnchorHeadTemplate.generate_predicted_boxes
+        (anchor_head_template.py:254-273) and RoIHeadTemplate.generate_predicted_boxes
+        (roi_head_template.py:299-316) executed here with the reference's decode_torch,
+        common_utils.limit_period and common_utils.rotate_points_along_z (the classes themselves
+        import the CUDA extensions)."""
+    gen = torch.Generator().manual_seed(77)
+    out = {}
+    bc = _load_by_path("ref_box_coder_utils", "pcdet/utils/box_coder_utils.py")
+    ag = _load_by_path("ref_anchor_generator", "pcdet/models/dense_heads/target_assigner/anchor_generator.py")
+    sys.modules.setdefault("SharedArray", types.ModuleType("SharedArray"))
+    for name, path in (("pcdet", "pcdet"), ("pcdet.utils", "pcdet/utils")):
+        if name not in sys.modules:
+            mod = types.ModuleType(name)
+            mod.__path__ = [os.path.join(REF, path)]
+            sys.modules[name] = mod
+    common = importlib.import_module("pcdet.utils.common_utils")
+    coder = bc.ResidualCoder()
+    # ---- anchors: the GLENet-VR car anchor set (GLENet_VR.yaml:66-77) on a reduced feature map
+    cfg = [dict(anchor_sizes=[[3.9, 1.6, 1.56]], anchor_rotations=[0, 1.57], anchor_bottom_heights=[-1.78],
+                align_center=False)]
+    rng_ = [0, -40.0, -3, 70.4, 40.0, 1]
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        anchors, per_loc = ag.AnchorGenerator(rng_, cfg).generate_anchors([[22, 25]])
+        cfg2 = [dict(anchor_sizes=[[0.8, 0.6, 1.73]], anchor_rotations=[0, 1.57], anchor_bottom_heights=[-0.6],
+                     align_center=True)]
+        anchors2, _ = ag.AnchorGenerator(rng_, cfg2).generate_anchors([[11, 13]])
+    finally:
+        torch.Tensor.cuda = real_cuda
+    out["anchors_car"], out["anchors_ped_aligned"] = anchors[0].numpy(), anchors2[0].numpy()
+    out["anchors_per_location"] = np.array(per_loc)
+    # ---- first stage: head maps -> boxes (anchor_head_template.py:254-273)
+    B = 2
+    a = anchors[0]
+    n = a.view(-1, 7).shape[0]
+    box_preds = torch.randn(B, 25, 22, 14, generator=gen) * 0.3
+    dir_preds = torch.randn(B, 25, 22, 4, generator=gen)
+    batch_anchors = a.view(1, -1, 7).repeat(B, 1, 1)
+    boxes = coder.decode_torch(box_preds.view(B, n, -1), batch_anchors)
+    dir_labels = torch.max(dir_preds.view(B, n, -1), dim=-1)[1]
+    period = 2 * np.pi / 2
+    dir_rot = common.limit_period(boxes[..., 6] - 0.78539, 0.0, period)
+    boxes[..., 6] = dir_rot + 0.78539 + period * dir_labels.to(boxes.dtype)
+    out["head_box_preds"], out["head_dir_preds"], out["head_boxes"] = box_preds.numpy(), dir_preds.numpy(), boxes.numpy()
+    # ---- plain decode on arbitrary anchors (+ an extra code channel)
+    anc = torch.cat([torch.randn(40, 3, generator=gen) * 10, torch.rand(40, 3, generator=gen) * 3 + 0.5,
+                     torch.rand(40, 2, generator=gen) * 6 - 3], -1)
+    enc = torch.randn(40, 8, generator=gen) * 0.5
+    out["dec_anchors"], out["dec_enc"], out["dec_out"] = anc.numpy(), enc.numpy(), coder.decode_torch(enc, anc).numpy()
+    # ---- second stage: RoI-frame residuals -> LiDAR-frame boxes (roi_head_template.py:299-316)
+    rois = torch.cat([torch.randn(B, 9, 3, generator=gen) * 10, torch.rand(B, 9, 3, generator=gen) * 3 + 0.5,
+                      torch.rand(B, 9, 1, generator=gen) * 6 - 3], -1)
+    reg = torch.randn(B * 9, 7, generator=gen) * 0.2
+    roi_ry, roi_xyz = rois[:, :, 6].view(-1), rois[:, :, 0:3].view(-1, 3)
+    local = rois.clone().detach()
+    local[:, :, 0:3] = 0
+    bp = coder.decode_torch(reg.view(B, -1, 7), local).view(-1, 7)
+    bp = common.rotate_points_along_z(bp.unsqueeze(dim=1), roi_ry).squeeze(dim=1)
+    bp[:, 0:3] += roi_xyz
+    out["roi_rois"], out["roi_reg"], out["roi_boxes"] = rois.numpy(), reg.numpy(), bp.view(B, -1, 7).numpy()
+    np.savez_compressed(os.path.join(HERE, "detector_glue_ref.npz"), **out)
+    print("detector_glue_ref.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    only = sys.argv[1:] or ["iou3d", "nms", "dense"]
+    only = sys.argv[1:] or ["iou3d", "nms", "dense", "glue"]
+    if "glue" in only:
+        make_detector_glue_ref()
     if "iou3d" in only:
         make_iou3d_ref()
     if "nms" in only:

@@ -132,3 +132,38 @@ def test_static_detector_pipeline_and_graph_match_the_eager_flow(dev):
     same(out, want2)
     out = pipe.run_checked(pts, bidx)
     same(out, want)
+
+
+# ------------------------------------------------------------------ reference-generated goldens
+def _glue():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "detector_glue_ref.npz"))
+
+
+def test_anchor_generator_matches_reference_golden():
+    """generate_anchors == AnchorGenerator.generate_anchors of the reference (fixture generated
+    from /root/reference, tests/golden/make_golden.py), end-to-end and centre-aligned layouts."""
+    g = _glue()
+    rng = [0, -40.0, -3, 70.4, 40.0, 1]
+    a = det.generate_anchors(rng, (22, 25), [[3.9, 1.6, 1.56]], [0, 1.57], [-1.78])
+    assert a.shape == g["anchors_car"].shape and np.array_equal(a.numpy(), g["anchors_car"])
+    b = det.generate_anchors(rng, (11, 13), [[0.8, 0.6, 1.73]], [0, 1.57], [-0.6], align_center=True)
+    assert np.array_equal(b.numpy(), g["anchors_ped_aligned"])
+    assert int(g["anchors_per_location"][0]) == 2
+
+
+def test_box_decode_matches_reference_golden():
+    """decode_boxes == ResidualCoder.decode_torch (extra code channel included); predicted_boxes ==
+    AnchorHeadTemplate.generate_predicted_boxes' statement sequence (direction classifier);
+    refine_boxes == RoIHeadTemplate.generate_predicted_boxes.  north_star tolerance 1e-4 on box
+    regressions; the first two are the same arithmetic in the same order -> exact."""
+    g = _glue()
+    out = det.decode_boxes(torch.from_numpy(g["dec_enc"]), torch.from_numpy(g["dec_anchors"]))
+    assert np.array_equal(out.numpy(), g["dec_out"])
+    anchors = torch.from_numpy(g["anchors_car"])
+    cls = torch.zeros(2, 25, 22, 2)
+    _, boxes = det.predicted_boxes(cls, torch.from_numpy(g["head_box_preds"]), torch.from_numpy(g["head_dir_preds"]),
+                                   anchors)
+    np.testing.assert_allclose(boxes.numpy(), g["head_boxes"], rtol=0, atol=1e-6)
+    ref = det.refine_boxes(torch.from_numpy(g["roi_rois"]), torch.from_numpy(g["roi_reg"]))
+    np.testing.assert_allclose(ref.numpy(), g["roi_boxes"], rtol=1e-6, atol=1e-5)
