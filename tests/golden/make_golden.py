@@ -315,6 +315,31 @@ def make_detector_glue_ref():
     bp = common.rotate_points_along_z(bp.unsqueeze(dim=1), roi_ry).squeeze(dim=1)
     bp[:, 0:3] += roi_xyz
     out["roi_rois"], out["roi_reg"], out["roi_boxes"] = rois.numpy(), reg.numpy(), bp.view(B, -1, 7).numpy()
+    # ---- MeanVFE.forward (pcdet/models/backbones_3d/vfe/mean_vfe.py:14-31): the two files of the
+    # vfe package it needs, loaded as a package of their own (the real package __init__ pulls in
+    # torch_scatter-based VFEs that are not installed here)
+    from importlib import util as ilu
+    pkg = types.ModuleType("refvfe")
+    pkg.__path__ = [os.path.join(REF, "pcdet/models/backbones_3d/vfe")]
+    sys.modules["refvfe"] = pkg
+    for name in ("vfe_template", "mean_vfe"):
+        spec = ilu.spec_from_file_location("refvfe." + name, os.path.join(pkg.__path__[0], name + ".py"))
+        mod = ilu.module_from_spec(spec)
+        sys.modules["refvfe." + name] = mod
+        spec.loader.exec_module(mod)
+    vfe = sys.modules["refvfe.mean_vfe"].MeanVFE(None, 4)
+    voxels = torch.randn(300, 5, 4, generator=gen) * 20
+    num = torch.randint(0, 6, (300,), generator=gen)          # includes empty voxels (clamp_min 1)
+    for i in range(300):
+        voxels[i, int(num[i]):] = 0
+    out["vfe_voxels"], out["vfe_num"] = voxels.numpy(), num.numpy().astype(np.int32)
+    out["vfe_out"] = vfe({"voxels": voxels, "voxel_num_points": num})["voxel_features"].numpy()
+    # ---- common_utils.mask_points_by_range (common_utils.py:60-63), points on the range borders
+    pts = torch.randn(500, 4, generator=gen) * 30
+    pts[:20, 0] = torch.tensor([0.0, 70.4] * 10)
+    pts[20:40, 1] = torch.tensor([-40.0, 40.0] * 10)
+    out["mask_points"] = pts.numpy()
+    out["mask_out"] = common.mask_points_by_range(pts, rng_).numpy()
     np.savez_compressed(os.path.join(HERE, "detector_glue_ref.npz"), **out)
     print("detector_glue_ref.npz", {k: v.shape for k, v in out.items()})
 

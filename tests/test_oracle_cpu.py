@@ -295,3 +295,17 @@ def test_set_abstraction_oracle_vs_independent_numpy():
     gf = np.zeros_like(f)
     np.add.at(gf, i.reshape(-1), (g[:, None, :] * w[:, :, None]).reshape(-1, 5))
     np.testing.assert_allclose(oracle.three_interpolate_grad(g, i, w, 300), gf, rtol=1e-5, atol=1e-6)
+
+
+def test_mean_vfe_and_range_mask_match_reference_golden():
+    """oracle.mean_vfe == the reference's MeanVFE.forward (empty voxels: clamp_min(1)) and
+    glenet_amd.data_pipeline.mask_points_by_range == common_utils.mask_points_by_range (inclusive
+    borders); fixture generated from /root/reference (tests/golden/make_golden.py glue)."""
+    import torch
+    from glenet_amd import data_pipeline
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "detector_glue_ref.npz"))
+    got = oracle.mean_vfe(g["vfe_voxels"], g["vfe_num"])
+    np.testing.assert_allclose(got, g["vfe_out"], rtol=1e-6, atol=1e-6)
+    assert (g["vfe_num"] == 0).any()
+    m = data_pipeline.mask_points_by_range(torch.from_numpy(g["mask_points"]), [0, -40.0, -3, 70.4, 40.0, 1])
+    assert np.array_equal(m.numpy(), g["mask_out"]) and g["mask_out"][:40].any() and not g["mask_out"].all()
