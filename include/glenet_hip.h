@@ -305,8 +305,10 @@ int glx_roipoint_pool3d(const float* xyz, const float* boxes3d, const float* pts
                         int Np, int M, int C, int S, float* pooled, int32_t* empty_flag,
                         void* stream);
 
-/* Voxel query over the dense (B,Z,Y,X) voxel->point map; idx (M,nsample) arrives zero-filled,
- * idx[m,0] == -1 marks an empty ball.
+/* Voxel query over the dense (B,Z,Y,X) voxel->point map: the first nsample cells of the
+ * (2r+1)^3 window (z, y, x ascending) whose centre is within `radius`; unused slots repeat the
+ * first hit; idx[m,0] == -1 marks an empty ball (the other slots of such a row are left as they
+ * arrived -- the reference passes a zero-filled idx).
  * Replaces: pointnet2_stack_cuda.voxel_query_wrapper (voxel_query.cpp:28-44). */
 int glx_voxel_query(int M, int Z, int Y, int X, int nsample, float radius, int z_range,
                     int y_range, int x_range, const float* new_xyz, const float* xyz,
