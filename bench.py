@@ -264,6 +264,15 @@ def main():
                 train_step = tpipe.enqueue
                 tnote = "shape-static step, eager launches"
 
+        if world > 1:       # data-parallel training: one flat RCCL all-reduce of the gradients per step
+            bucket = gdist.GradBucket(tmodel.parameters())
+            local_step = train_step
+
+            def train_step():
+                local_step()
+                bucket.allreduce_()
+            tnote += ", + one flat all-reduce of all gradients (RCCL)"
+
         run(train_step, 6)
         gdist.fence(dev)
         t1 = time.perf_counter()

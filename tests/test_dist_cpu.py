@@ -67,3 +67,46 @@ def test_single_process_defaults():
     assert gdist.env_world() == (0, 0, 1)
     assert gdist.frames_for_rank(0, 1, 4) == [0, 1, 2, 3]
     assert gdist.reduce_max(1.5) == 1.5 and gdist.job_throughput(8, 2.0) == 4.0
+
+
+def _grad_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from glenet_amd import dist as gdist
+    gdist.init(backend="gloo")
+    torch.manual_seed(0)                                  # same parameters on every rank
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3, bias=False))
+    net[2].weight.requires_grad_(rank >= 0)
+    frozen = torch.nn.Parameter(torch.ones(4), requires_grad=False)
+    bucket = gdist.GradBucket(list(net.parameters()) + [frozen])
+    x = torch.full((2, 5), float(rank + 1))              # rank-dependent data -> different gradients
+    net(x).square().sum().backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    bucket.allreduce_()
+    q.put((rank, [g.numpy() for g in local], [p.grad.numpy().copy() for p in net.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_bucket_allreduce():
+    """GradBucket: one flat all-reduce leaves every rank with the mean of the ranks' gradients."""
+    import numpy as np
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, l0, a0), (_, l1, a1) = res
+    assert any(not np.allclose(x, y) for x, y in zip(l0, l1))       # the ranks really differed
+    for x, y, u, v in zip(l0, l1, a0, a1):
+        np.testing.assert_allclose(u, (x + y) / 2, rtol=1e-6, atol=1e-7)
+        assert np.array_equal(u, v)
