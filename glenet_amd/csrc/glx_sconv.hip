@@ -1569,7 +1569,7 @@ struct WgradCfg {
   static constexpr int MI = CINP / 16, NI = COUT / 16, TILES = MI * NI;
   static constexpr int TPW = (TILES + 3) / 4;            // tiles per wave (4 waves)
   static constexpr int A_LD = CINP + 16, B_LD = COUT + 16;
-  static constexpr size_t lds_bytes = (size_t)WGM_PANEL * (A_LD + B_LD) * 4 + WGM_BATCH * 8 + 64;
+  static constexpr size_t lds_bytes = (size_t)WGM_PANEL * (A_LD + B_LD) * 4 + (WGM_BATCH + WGM_PANEL) * 8 + 64;
 };
 
 template <int CIN, int COUT>
@@ -1581,9 +1581,10 @@ __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_mfma(
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_a = smem;                                   // WGM_PANEL * A_LD   (input rows)
   float* s_b = s_a + WGM_PANEL * T::A_LD;              // WGM_PANEL * B_LD   (grad rows)
-  int* s_pi = reinterpret_cast<int*>(s_b + WGM_PANEL * T::B_LD);   // WGM_BATCH input rows
-  int* s_pj = s_pi + WGM_BATCH;                                    // WGM_BATCH output rows
-  int* s_wc = s_pj + WGM_BATCH;                                    // 4 wave counts + total
+  constexpr int LIST = WGM_BATCH + WGM_PANEL;                      // carried pairs + one batch
+  int* s_pi = reinterpret_cast<int*>(s_b + WGM_PANEL * T::B_LD);   // LIST input rows
+  int* s_pj = s_pi + LIST;                                         // LIST output rows
+  int* s_wc = s_pj + LIST;                                         // 4 wave counts + total
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, kk = lane >> 4;
   const int k = blockIdx.y;
@@ -1598,15 +1599,51 @@ __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_mfma(
     __syncthreads();
   }
 
+  // Pairs are streamed: every batch of 256 rows appends the pairs it has at offset k to a list in
+  // LDS, FULL panels of 64 pairs are multiplied as soon as they exist and the remainder (< 64) is
+  // carried into the next batch.  (Per-batch panels wasted half of their gathers and barriers: a
+  // batch yields ~66-76 pairs, i.e. one full panel and one with a handful of pairs.)
+  auto panel = [&](int p0, int np) {
+    const int np4 = (np + 3) & ~3;                    // rows up to the next multiple of 4 are zeroed
+    constexpr int SEG_A = CIN / 4, SEG_B = COUT / 4;
+    for (int e = tid; e < np4 * SEG_A; e += WGM_THREADS) {
+      int pr = e / SEG_A, sg = e - pr * SEG_A;
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (pr < np) v = *reinterpret_cast<const f32x4*>(in + (long long)s_pi[p0 + pr] * CIN + sg * 4);
+      *reinterpret_cast<f32x4*>(s_a + pr * T::A_LD + sg * 4) = v;
+    }
+    for (int e = tid; e < np4 * SEG_B; e += WGM_THREADS) {
+      int pr = e / SEG_B, sg = e - pr * SEG_B;
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (pr < np) v = *reinterpret_cast<const f32x4*>(gout + (long long)s_pj[p0 + pr] * COUT + sg * 4);
+      *reinterpret_cast<f32x4*>(s_b + pr * T::B_LD + sg * 4) = v;
+    }
+    __syncthreads();
+    for (int st = 0; st < np4; st += 4) {
+      const float* ar = s_a + (st + kk) * T::A_LD + n;
+      const float* br = s_b + (st + kk) * T::B_LD + n;
+#pragma unroll
+      for (int u = 0; u < T::TPW; ++u) {
+        const int t = wave + 4 * u;
+        if (T::TILES % 4 == 0 || t < T::TILES) {
+          const int mi = t / T::NI, ni = t - mi * T::NI;
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[mi * 16], br[ni * 16], acc[u], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  };
+
+  int have = 0;                                       // pairs waiting in s_pi / s_pj [0, have)
   for (int jb = j_lo; jb < j_hi; jb += WGM_BATCH) {
-    // ---- compact the pairs of offset k among rows jb .. jb+255
+    // ---- append the pairs of offset k among rows jb .. jb+255
     const int j = jb + tid;
     int i = -1;
     if (j < j_hi) i = nbr[(long long)j * K + k];
     const unsigned long long bal = __ballot(i >= 0);
     if (lane == 0) s_wc[wave] = __popcll(bal);
     __syncthreads();
-    int base = 0;
+    int base = have;
 #pragma unroll
     for (int w = 0; w < 4; ++w) base += (w < wave) ? s_wc[w] : 0;
     const int cnt = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
@@ -1615,40 +1652,21 @@ __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_mfma(
       s_pi[pos] = i;
       s_pj[pos] = j;
     }
+    have += cnt;
     __syncthreads();
-    // ---- panels of up to 64 pairs
-    for (int p0 = 0; p0 < cnt; p0 += WGM_PANEL) {
-      const int np = min(WGM_PANEL, cnt - p0);
-      const int np4 = (np + 3) & ~3;                    // rows up to the next multiple of 4 are zeroed
-      constexpr int SEG_A = CIN / 4, SEG_B = COUT / 4;
-      for (int e = tid; e < np4 * SEG_A; e += WGM_THREADS) {
-        int pr = e / SEG_A, sg = e - pr * SEG_A;
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (pr < np) v = *reinterpret_cast<const f32x4*>(in + (long long)s_pi[p0 + pr] * CIN + sg * 4);
-        *reinterpret_cast<f32x4*>(s_a + pr * T::A_LD + sg * 4) = v;
-      }
-      for (int e = tid; e < np4 * SEG_B; e += WGM_THREADS) {
-        int pr = e / SEG_B, sg = e - pr * SEG_B;
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (pr < np) v = *reinterpret_cast<const f32x4*>(gout + (long long)s_pj[p0 + pr] * COUT + sg * 4);
-        *reinterpret_cast<f32x4*>(s_b + pr * T::B_LD + sg * 4) = v;
-      }
+    int p0 = 0;
+    for (; have - p0 >= WGM_PANEL; p0 += WGM_PANEL) panel(p0, WGM_PANEL);
+    if (p0 > 0) {                                     // carry the remainder to the front of the list
+      const int left = have - p0;
+      int ci = 0, cj = 0;
+      if (tid < left) { ci = s_pi[p0 + tid]; cj = s_pj[p0 + tid]; }
       __syncthreads();
-      for (int st = 0; st < np4; st += 4) {
-        const float* ar = s_a + (st + kk) * T::A_LD + n;
-        const float* br = s_b + (st + kk) * T::B_LD + n;
-#pragma unroll
-        for (int u = 0; u < T::TPW; ++u) {
-          const int t = wave + 4 * u;
-          if (T::TILES % 4 == 0 || t < T::TILES) {
-            const int mi = t / T::NI, ni = t - mi * T::NI;
-            acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[mi * 16], br[ni * 16], acc[u], 0, 0, 0);
-          }
-        }
-      }
+      if (tid < left) { s_pi[tid] = ci; s_pj[tid] = cj; }
+      have = left;
       __syncthreads();
     }
   }
+  if (have > 0) panel(0, have);
   // ---- slab of this block: dW[k] partial, (Cin, Cout) row-major
   float* dst = slabs + ((long long)blockIdx.x * K + k) * (CIN * COUT);
 #pragma unroll
