@@ -1683,7 +1683,8 @@ __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_mfma(
 }
 
 static int wgrad_slices(int K) {
-  int s = 864 / (K > 0 ? K : 1);   // ~3 blocks per CU
+  int s = 768 / (K > 0 ? K : 1);   // 3 blocks per CU x 256 CUs: the whole grid is resident at once (864
+                                   // blocks ran as one full wave plus a 12 % tail that doubled the time)
   return s < 1 ? 1 : (s > 512 ? 512 : s);
 }
 
