@@ -1603,43 +1603,84 @@ __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_mfma(
   // LDS, FULL panels of 64 pairs are multiplied as soon as they exist and the remainder (< 64) is
   // carried into the next batch.  (Per-batch panels wasted half of their gathers and barriers: a
   // batch yields ~66-76 pairs, i.e. one full panel and one with a handful of pairs.)
-  auto panel = [&](int p0, int np) {
-    const int np4 = (np + 3) & ~3;                    // rows up to the next multiple of 4 are zeroed
-    constexpr int SEG_A = CIN / 4, SEG_B = COUT / 4;
-    for (int e = tid; e < np4 * SEG_A; e += WGM_THREADS) {
-      int pr = e / SEG_A, sg = e - pr * SEG_A;
-      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (pr < np) v = *reinterpret_cast<const f32x4*>(in + (long long)s_pi[p0 + pr] * CIN + sg * 4);
-      *reinterpret_cast<f32x4*>(s_a + pr * T::A_LD + sg * 4) = v;
-    }
-    for (int e = tid; e < np4 * SEG_B; e += WGM_THREADS) {
-      int pr = e / SEG_B, sg = e - pr * SEG_B;
-      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (pr < np) v = *reinterpret_cast<const f32x4*>(gout + (long long)s_pj[p0 + pr] * COUT + sg * 4);
-      *reinterpret_cast<f32x4*>(s_b + pr * T::B_LD + sg * 4) = v;
-    }
-    __syncthreads();
-    for (int st = 0; st < np4; st += 4) {
-      const float* ar = s_a + (st + kk) * T::A_LD + n;
-      const float* br = s_b + (st + kk) * T::B_LD + n;
+  // Two-stage pipeline over panels: the rows of panel p are requested into registers, the panel
+  // already in LDS (p-1) is multiplied while they are in flight, then the registers are stored.
+  constexpr int SEG_A = CIN / 4, SEG_B = COUT / 4;
+  constexpr int RA = (WGM_PANEL * SEG_A + WGM_THREADS - 1) / WGM_THREADS;
+  constexpr int RB = (WGM_PANEL * SEG_B + WGM_THREADS - 1) / WGM_THREADS;
+  int staged = 0;                                     // rows (multiple of 4) of the panel in LDS, 0 = none
+  auto multiply_staged = [&]() {
+    // 4 MFMA steps (16 pairs) per trip with all their operand reads issued first: one read pair
+    // per MFMA with a wait in between left the matrix pipe idle for most of an LDS latency each time
+    for (int st = 0; st < staged; st += 16) {
+      float av[4][T::TPW], bv[4][T::TPW];
 #pragma unroll
-      for (int u = 0; u < T::TPW; ++u) {
-        const int t = wave + 4 * u;
-        if (T::TILES % 4 == 0 || t < T::TILES) {
-          const int mi = t / T::NI, ni = t - mi * T::NI;
-          acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[mi * 16], br[ni * 16], acc[u], 0, 0, 0);
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const float* ar = s_a + (st + 4 * s4 + kk) * T::A_LD + n;
+        const float* br = s_b + (st + 4 * s4 + kk) * T::B_LD + n;
+#pragma unroll
+        for (int u = 0; u < T::TPW; ++u) {
+          const int t = wave + 4 * u;
+          av[s4][u] = bv[s4][u] = 0.f;
+          if (T::TILES % 4 == 0 || t < T::TILES) {
+            const int mi = t / T::NI, ni = t - mi * T::NI;
+            av[s4][u] = ar[mi * 16];
+            if (4 % T::NI != 0 || u == 0) bv[s4][u] = br[ni * 16];   // NI | 4: every tile of a wave shares ni
+            else bv[s4][u] = bv[s4][0];
+          }
+        }
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+        for (int u = 0; u < T::TPW; ++u) {
+          const int t = wave + 4 * u;
+          if (T::TILES % 4 == 0 || t < T::TILES)
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4][u], bv[s4][u], acc[u], 0, 0, 0);
         }
       }
     }
+  };
+  auto panel = [&](int p0, int np) {
+    const int np4 = (np + 15) & ~15;                  // rows up to the next multiple of 16 are zeroed
+    f32x4 ra[RA], rb[RB];
+#pragma unroll
+    for (int it = 0; it < RA; ++it) {
+      const int e = tid + it * WGM_THREADS, pr = e / SEG_A, sg = e - pr * SEG_A;
+      ra[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (pr < np) ra[it] = *reinterpret_cast<const f32x4*>(in + (long long)s_pi[p0 + pr] * CIN + sg * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < RB; ++it) {
+      const int e = tid + it * WGM_THREADS, pr = e / SEG_B, sg = e - pr * SEG_B;
+      rb[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (pr < np) rb[it] = *reinterpret_cast<const f32x4*>(gout + (long long)s_pj[p0 + pr] * COUT + sg * 4);
+    }
+    if (staged) multiply_staged();                    // panel p-1, while the loads of panel p fly
     __syncthreads();
+#pragma unroll
+    for (int it = 0; it < RA; ++it) {
+      const int e = tid + it * WGM_THREADS, pr = e / SEG_A, sg = e - pr * SEG_A;
+      if (pr < np4) *reinterpret_cast<f32x4*>(s_a + pr * T::A_LD + sg * 4) = ra[it];
+    }
+#pragma unroll
+    for (int it = 0; it < RB; ++it) {
+      const int e = tid + it * WGM_THREADS, pr = e / SEG_B, sg = e - pr * SEG_B;
+      if (pr < np4) *reinterpret_cast<f32x4*>(s_b + pr * T::B_LD + sg * 4) = rb[it];
+    }
+    __syncthreads();
+    staged = np4;
   };
 
   int have = 0;                                       // pairs waiting in s_pi / s_pj [0, have)
+  int i_next = -1;                                    // neighbour of the NEXT batch's row, one batch ahead
+  if (j_lo + tid < j_hi) i_next = nbr[(long long)(j_lo + tid) * K + k];
   for (int jb = j_lo; jb < j_hi; jb += WGM_BATCH) {
     // ---- append the pairs of offset k among rows jb .. jb+255
     const int j = jb + tid;
-    int i = -1;
-    if (j < j_hi) i = nbr[(long long)j * K + k];
+    const int i = i_next;
+    i_next = -1;
+    if (j + WGM_BATCH < j_hi) i_next = nbr[(long long)(j + WGM_BATCH) * K + k];
     const unsigned long long bal = __ballot(i >= 0);
     if (lane == 0) s_wc[wave] = __popcll(bal);
     __syncthreads();
@@ -1667,6 +1708,7 @@ __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_mfma(
     }
   }
   if (have > 0) panel(0, have);
+  if (staged) multiply_staged();
   // ---- slab of this block: dW[k] partial, (Cin, Cout) row-major
   float* dst = slabs + ((long long)blockIdx.x * K + k) * (CIN * COUT);
 #pragma unroll
