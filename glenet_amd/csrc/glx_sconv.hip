@@ -1562,6 +1562,7 @@ __global__ void k_wgrad_reduce(const float* __restrict__ slabs, int nchunks, lon
 #define WGM_THREADS 256
 #define WGM_PANEL 64
 #define WGM_BATCH 256
+#define WGM_TRIP 8      // MFMA steps whose operand reads are issued together
 
 template <int CIN, int COUT>
 struct WgradCfg {
@@ -1610,12 +1611,12 @@ __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_mfma(
   constexpr int RB = (WGM_PANEL * SEG_B + WGM_THREADS - 1) / WGM_THREADS;
   int staged = 0;                                     // rows (multiple of 4) of the panel in LDS, 0 = none
   auto multiply_staged = [&]() {
-    // 4 MFMA steps (16 pairs) per trip with all their operand reads issued first: one read pair
+    // WGM_TRIP MFMA steps (4 pairs each) per trip with all their operand reads issued first: one read pair
     // per MFMA with a wait in between left the matrix pipe idle for most of an LDS latency each time
-    for (int st = 0; st < staged; st += 16) {
-      float av[4][T::TPW], bv[4][T::TPW];
+    for (int st = 0; st < staged; st += 4 * WGM_TRIP) {
+      float av[WGM_TRIP][T::TPW], bv[WGM_TRIP][T::TPW];
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
+      for (int s4 = 0; s4 < WGM_TRIP; ++s4) {
         const float* ar = s_a + (st + 4 * s4 + kk) * T::A_LD + n;
         const float* br = s_b + (st + 4 * s4 + kk) * T::B_LD + n;
 #pragma unroll
@@ -1631,7 +1632,7 @@ __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_mfma(
         }
       }
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
+      for (int s4 = 0; s4 < WGM_TRIP; ++s4) {
 #pragma unroll
         for (int u = 0; u < T::TPW; ++u) {
           const int t = wave + 4 * u;
@@ -1642,7 +1643,7 @@ __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_mfma(
     }
   };
   auto panel = [&](int p0, int np) {
-    const int np4 = (np + 15) & ~15;                  // rows up to the next multiple of 16 are zeroed
+    const int np4 = (np + 4 * WGM_TRIP - 1) / (4 * WGM_TRIP) * (4 * WGM_TRIP);   // zero rows up to a whole trip
     f32x4 ra[RA], rb[RB];
 #pragma unroll
     for (int it = 0; it < RA; ++it) {
