@@ -97,6 +97,7 @@ md += ["", "## Sparse-conv kernel variants measured during round 1 (layer 64->64
        "| same, 128 rows x 8 waves / 32 rows x 4 waves / 64 x 8 split 2 (removed) | 92 / 101 / 104 |",
        "| same, 80 / 96 / 112 rows x 8 waves, 96 rows x 12 waves (removed; 2 blocks per CU) | 106 / 85 / 86 / 87 |",
        "| same, software-pipelined loads 2 / 3 / 4 steps ahead, exact `vmcnt(8/7/6)` (removed) | 77 / 77 / 103 |",
+       "| same, every LDS read of a chunk (fragments, slot, accumulator row) hoisted above the MFMA chain with `sched_barrier` (removed) | 78 |",
        "| whole-chunk waves, register gathers, 64 rows x 4 waves (**default, Cout <= 32**) | 81-86 |",
        "| same with column split 2 over 8 waves / split 4 over 8 waves (removed) | 80-82 / 115 |",
        "| same, double-buffered W (2 blocks/CU) | 112 |",
