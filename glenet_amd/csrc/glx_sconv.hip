@@ -1725,15 +1725,21 @@ __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_mfma(
   }
 }
 
-static int wgrad_slices(int K) {
-  int s = 768 / (K > 0 ? K : 1);   // 3 blocks per CU x 256 CUs: the whole grid is resident at once (864
-                                   // blocks ran as one full wave plus a 12 % tail that doubled the time)
+// Row slices of the weight-gradient grid: as many blocks as are resident at once (LDS-limited
+// blocks per CU x 256 CUs) divided by the K offsets -- a block's work is a serial chain of row
+// batches, so the kernel takes as long as one block, and a partial second wave of blocks doubles it.
+static int wgrad_slices(int K, int Cin, int Cout) {
+  const int cinp = Cin < 16 ? 16 : Cin;
+  const size_t lds = (size_t)WGM_PANEL * (cinp + 16 + Cout + 16) * 4 + (WGM_BATCH + WGM_PANEL) * 8 + 64;
+  int per_cu = (int)((160 * 1024) / lds);
+  per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);       // 8 x 256 threads = the CU's wave slots
+  int s = per_cu * 256 / (K > 0 ? K : 1);
   return s < 1 ? 1 : (s > 512 ? 512 : s);
 }
 
 extern "C" size_t glx_sconv_wgrad_workspace_bytes(int N_out, int K, int Cin, int Cout) {
   (void)N_out;
-  int chunks = wgrad_slices(K) > WG_CHUNKS ? wgrad_slices(K) : WG_CHUNKS;
+  int chunks = wgrad_slices(K, Cin, Cout) > WG_CHUNKS ? wgrad_slices(K, Cin, Cout) : WG_CHUNKS;
   return glx_align((size_t)chunks * K * Cin * Cout * sizeof(float)) + 256;
 }
 
@@ -1757,7 +1763,7 @@ extern "C" int glx_sconv_wgrad(const float* in, int N_in, const float* grad_out,
   }
   auto okc = [](int c) { return c == 16 || c == 32 || c == 64 || c == 128; };
   if ((okc(Cin) || Cin == 4 || Cin == 8) && okc(Cout) && !getenv("GLX_WGRAD_SCALAR")) {
-    const int S = wgrad_slices(K);
+    const int S = wgrad_slices(K, Cin, Cout);
     int rps = glx_divup(N_out, S);
     rps = (rps + WGM_BATCH - 1) / WGM_BATCH * WGM_BATCH;
     const int slices = glx_divup(N_out, rps);
