@@ -37,19 +37,6 @@ struct SconvCfg {
 
 // W (K, CIN, COUT) -> per-offset LDS images in MFMA fragment order:
 //   img[(h*4+q)*QSTRIDE + (t*16+n)*NC + c] = W[k][q*CQ+t][(h*NC+c)*16+n]
-template <int CIN, int COUT>
-__global__ void k_pack_weights(const float* __restrict__ W, int K, float* __restrict__ Wp) {
-  using C = SconvCfg<CIN, COUT>;
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= K * CIN * COUT) return;
-  int co = e % COUT;
-  int ci = (e / COUT) % CIN;
-  int k = e / (COUT * CIN);
-  int q = ci / C::CQ, t = ci % C::CQ;
-  int ct = co / 16, n = co % 16;
-  int h = ct / C::NC, c = ct % C::NC;
-  Wp[(size_t)k * C::IMG + (h * 4 + q) * C::QSTRIDE + (t * 16 + n) * C::NC + c] = W[e];
-}
 
 template <int N>
 struct FVec;
@@ -97,17 +84,26 @@ struct SconvSplitCfg {
   }
 };
 
+// Both packed images in one launch.  view: bit 0 = the source is the (K, COUT, CIN) weight of the
+// conv this one is the adjoint of (read transposed), bit 1 = kernel taps reversed (the input
+// gradient of a submanifold conv walks the same rule table with flipped taps).
 template <int CIN, int COUT>
-__global__ void k_pack_weights_split(const float* __restrict__ W, int K, float* __restrict__ Wp) {
+__global__ void k_pack_weights(const float* __restrict__ W, int K, float* __restrict__ Wp,
+                               float* __restrict__ Wsplit, int view) {
+  using C = SconvCfg<CIN, COUT>;
   using S = SconvSplitCfg<CIN, COUT>;
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= K * CIN * COUT) return;
   int co = e % COUT;
   int ci = (e / COUT) % CIN;
   int k = e / (COUT * CIN);
-  int q = ci / S::CQ, t = ci % S::CQ;
-  int tile = co / 16, n = co % 16;
-  Wp[(size_t)k * S::IMG + S::idx(tile, q, t, n)] = W[e];
+  const int ks = (view & 2) ? K - 1 - k : k;
+  const float w = (view & 1) ? W[((size_t)ks * COUT + co) * CIN + ci] : W[((size_t)ks * CIN + ci) * COUT + co];
+  int q = ci / C::CQ, t = ci % C::CQ;
+  int ct = co / 16, n = co % 16;
+  int h = ct / C::NC, c = ct % C::NC;
+  Wp[(size_t)k * C::IMG + (h * 4 + q) * C::QSTRIDE + (t * 16 + n) * C::NC + c] = w;
+  Wsplit[(size_t)k * S::IMG + S::idx(ct, ci / S::CQ, ci % S::CQ, n)] = w;
 }
 
 // Tile geometry: TR output rows per block, NW waves per block, NBUF LDS weight buffers, WPG waves
@@ -1200,7 +1196,7 @@ extern "C" int glx_profile_next_sconv(void* start_event, void* stop_event) {
 }
 
 template <int CI, int CO>
-static int pack_weights(const float* W, int K, float* Wp, hipStream_t st) {
+static int pack_weights(const float* W, int K, float* Wp, int view, hipStream_t st) {
   using C = SconvCfg<CI, CO>;
   using S = SconvSplitCfg<CI, CO>;
   size_t pbytes = (size_t)K * (C::IMG + S::IMG) * sizeof(float);
@@ -1211,9 +1207,7 @@ static int pack_weights(const float* W, int K, float* Wp, hipStream_t st) {
   }
   int nel = K * CI * CO;
   hipLaunchKernelGGL((k_pack_weights<CI, CO>), dim3(glx_divup(nel, 256)), dim3(256), 0, st, W, K,
-                     Wp);
-  hipLaunchKernelGGL((k_pack_weights_split<CI, CO>), dim3(glx_divup(nel, 256)), dim3(256), 0, st,
-                     W, K, Wp + (size_t)K * C::IMG);
+                     Wp, Wp + (size_t)K * C::IMG, view);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
@@ -1410,15 +1404,21 @@ extern "C" size_t glx_sconv_packed_bytes(int K, int Cin, int Cout) {
   return packed_bytes(K, Cin, Cout);
 }
 
-extern "C" int glx_sconv_pack_weights(const float* W, int K, int Cin, int Cout, float* Wp,
-                                      void* stream) {
+extern "C" int glx_sconv_pack_weights_view(const float* W, int K, int Cin, int Cout, int transposed,
+                                           int flip_taps, float* Wp, void* stream) {
   GLX_REQUIRE(W && Wp, "glx_sconv_pack_weights: null pointer");
   GLX_REQUIRE(mfma_supported(Cin, Cout, K),
               "glx_sconv_pack_weights: no MFMA kernel for (K=%d, Cin=%d, Cout=%d)", K, Cin, Cout);
   hipStream_t st = (hipStream_t)stream;
+  const int view = (transposed ? 1 : 0) | (flip_taps ? 2 : 0);
   return sc_dispatch(Cin, Cout, [&](auto ci, auto co) {
-    return pack_weights<decltype(ci)::value, decltype(co)::value>(W, K, Wp, st);
+    return pack_weights<decltype(ci)::value, decltype(co)::value>(W, K, Wp, view, st);
   });
+}
+
+extern "C" int glx_sconv_pack_weights(const float* W, int K, int Cin, int Cout, float* Wp,
+                                      void* stream) {
+  return glx_sconv_pack_weights_view(W, K, Cin, Cout, 0, 0, Wp, stream);
 }
 
 extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, const float* Wp,

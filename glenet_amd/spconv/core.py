@@ -266,15 +266,18 @@ def check_static(indice_dict, index=None):
 _profile_hook = None   # bench.py installs a callable(tag, K, cin, cout, n_out, rules), run before the launch
 
 
-def pack_weights(weight_kio):
+def pack_weights(weight_kio, adjoint=False, flip=False):
     """MFMA-fragment-ordered copy of (K, Cin, Cout) weights, or None when the channel counts
-    run on the scalar kernel."""
+    run on the scalar kernel.  adjoint: pack the weights of the input-gradient conv (Cout -> Cin)
+    straight from the forward weights, with the taps reversed when flip (submanifold)."""
     K, cin, cout = weight_kio.shape
+    if adjoint:
+        cin, cout = cout, cin
     nbytes = query("glx_sconv_packed_bytes", K, cin, cout)
     if nbytes == 0:
         return None
     wp = torch.empty(nbytes // 4, dtype=torch.float32, device=weight_kio.device)
-    call("glx_sconv_pack_weights", weight_kio, K, cin, cout, wp)
+    call("glx_sconv_pack_weights_view", weight_kio, K, cin, cout, 1 if adjoint else 0, 1 if flip else 0, wp)
     return wp
 
 
@@ -299,10 +302,11 @@ def rulebook_eligible(cin, cout, K):
 
 
 def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rules=None, tag="fwd",
-           scale=None, shift=None, relu=False, n_live=None, book=None):
+           scale=None, shift=None, relu=False, n_live=None, book=None, dims=None):
     """out[j] = relu?((sum_k features[nbr[j,k]] @ weight_kio[k] + bias) * scale + shift).
-    book: rulebook of (nbr, tile_order, n_out) -> the streaming rulebook kernel."""
-    K, cin, cout = weight_kio.shape
+    book: rulebook of (nbr, tile_order, n_out) -> the streaming rulebook kernel.
+    weight_kio may be None when `packed` and dims = (K, Cin, Cout) are given."""
+    K, cin, cout = dims if dims is not None else weight_kio.shape
     out = torch.empty((n_out, cout), dtype=torch.float32, device=features.device)
     if n_out == 0:
         return out
@@ -354,17 +358,17 @@ class SparseConvFunction(Function):
         if inverse:
             fwd_nbr, n_fwd_out, live_fwd = rules.inverse_table(), rules.N_in, rules.count_in
             bwd_nbr, bwd_order, n_bwd_out, live_bwd = rules.nbr, rules.tile_order_out, rules.N_out, rules.count_out
-            wt = w.transpose(1, 2).contiguous()
+            flip = False
         elif rules.subm:
             # nbr_in[i][k] == nbr[i][K-1-k] on a submanifold set: flip the taps instead
             fwd_nbr, n_fwd_out, live_fwd = rules.nbr, rules.N_out, rules.count_out
             bwd_nbr, bwd_order, n_bwd_out, live_bwd = rules.nbr, rules.tile_order_out, rules.N_in, rules.count_in
-            wt = w.flip(0).transpose(1, 2).contiguous()
+            flip = True
         else:
             fwd_nbr, n_fwd_out, live_fwd = rules.nbr, rules.N_out, rules.count_out
             bwd_nbr, bwd_order, n_bwd_out, live_bwd = (rules.inverse_table(), rules.tile_order_in, rules.N_in,
                                                        rules.count_in)
-            wt = w.transpose(1, 2).contiguous()
+            flip = False
         if ctx.needs_input_grad[1]:
             side = WGRAD_STREAM if ctx.side_ok else None
             if side is not None:
@@ -381,8 +385,16 @@ class SparseConvFunction(Function):
                 call("glx_sconv_wgrad", features, features.shape[0], grad_out, fwd_nbr, n_fwd_out, K,
                      cin, cout, g_w, live_fwd, ws, size_arg(ws.numel()))
         if ctx.needs_input_grad[0]:
-            g_feat = _sconv(grad_out, wt, None, bwd_nbr, bwd_order, n_bwd_out, rules=rules, tag="dgrad",
-                            n_live=live_bwd)
+            # input gradient = the same kernels on the adjoint weights (Cout -> Cin, taps flipped on
+            # a submanifold set), packed from the forward weights in one launch
+            wp_t = pack_weights(w, adjoint=True, flip=flip)
+            if wp_t is not None:
+                g_feat = _sconv(grad_out, None, None, bwd_nbr, bwd_order, n_bwd_out, packed=wp_t, rules=rules,
+                                tag="dgrad", n_live=live_bwd, dims=(K, cout, cin))
+            else:       # channel counts of the scalar kernel: materialise the adjoint weights
+                wt = (w.flip(0) if flip else w).transpose(1, 2).contiguous()
+                g_feat = _sconv(grad_out, wt, None, bwd_nbr, bwd_order, n_bwd_out, rules=rules, tag="dgrad",
+                                n_live=live_bwd)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             if live_fwd is None:
                 g_b = grad_out.sum(0)

@@ -123,6 +123,12 @@ size_t glx_sconv_workspace_bytes(int K, int Cin, int Cout);
 size_t glx_sconv_packed_bytes(int K, int Cin, int Cout);
 /* Re-order W (K,Cin,Cout) into Wp (glx_sconv_packed_bytes); do it once per weight update. */
 int glx_sconv_pack_weights(const float* W, int K, int Cin, int Cout, float* Wp, void* stream);
+/* Same for the ADJOINT conv, straight from the forward weights: (Cin, Cout) are the dimensions of
+ * the conv that will run; transposed != 0: W is stored (K, Cout, Cin) (the weights of the conv this
+ * one is the input gradient of); flip_taps != 0: tap k reads W[K-1-k] (input gradient of a
+ * submanifold conv on its own rule table).  One launch instead of flip + transpose + copy + pack. */
+int glx_sconv_pack_weights_view(const float* W, int K, int Cin, int Cout, int transposed,
+                                int flip_taps, float* Wp, void* stream);
 /* W: raw weights (may be NULL when Wp is given); Wp: packed weights or NULL (then W is packed
  * into `workspace`, >= glx_sconv_workspace_bytes).  Fused pointwise tail on the output tile:
  * y = relu?((acc + bias) * scale + shift); bias/scale/shift are (Cout) or NULL -- this is how
