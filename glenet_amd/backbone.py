@@ -345,9 +345,15 @@ class StaticTrainPipeline(StaticFramePipeline):
                 bd = self.vfe(bd)
             bd["rule_plan"] = plan
             self.model.zero_grad(set_to_none=True)      # .grad tensors are (re)created by backward
-            with torch.enable_grad():
-                bd = self.hc(self.model(bd))
-                loss = self.loss_fn(bd)
+            spconv.core.DEFERRED_COUNTERS = counters = []
+            try:
+                with torch.enable_grad():
+                    bd = self.hc(self.model(bd))
+                    loss = self.loss_fn(bd)
+            finally:
+                spconv.core.DEFERRED_COUNTERS = None
+            if counters:
+                torch._foreach_add_(counters, 1)
             if self.overlap_plan:
                 cur.wait_stream(self.plan_stream)
             if self.overlap_wgrad:     # weight gradients next to the input-gradient chain

@@ -93,6 +93,9 @@ __global__ void k_pack_weights(const float* __restrict__ W, int K, float* __rest
   using C = SconvCfg<CIN, COUT>;
   using S = SconvSplitCfg<CIN, COUT>;
   int e = blockIdx.x * blockDim.x + threadIdx.x;
+  // padding dwords of the first image (bank spread between its (h,q) blocks): zeroed here instead
+  // of by a fill launch in front of every pack
+  if (C::QPAD > 0 && e < K * C::IMG && (e % C::QSTRIDE) >= C::QSTRIDE - C::QPAD) Wp[e] = 0.f;
   if (e >= K * CIN * COUT) return;
   int co = e % COUT;
   int ci = (e / COUT) % CIN;
@@ -1199,14 +1202,9 @@ template <int CI, int CO>
 static int pack_weights(const float* W, int K, float* Wp, int view, hipStream_t st) {
   using C = SconvCfg<CI, CO>;
   using S = SconvSplitCfg<CI, CO>;
-  size_t pbytes = (size_t)K * (C::IMG + S::IMG) * sizeof(float);
-  {   // padding dwords of both images
-    GlxFillJob job{Wp, pbytes, 0};
-    int frc = glx_fill_multi(&job, 1, st);
-    if (frc != GLX_OK) return frc;
-  }
-  int nel = K * CI * CO;
-  hipLaunchKernelGGL((k_pack_weights<CI, CO>), dim3(glx_divup(nel, 256)), dim3(256), 0, st, W, K,
+  static_assert(S::IMG == CI * CO, "the split image has no padding");
+  const int nel = K * CI * CO, cover = K * C::IMG > nel ? K * C::IMG : nel;   // C::IMG >= CI*CO (padding)
+  hipLaunchKernelGGL((k_pack_weights<CI, CO>), dim3(glx_divup(cover, 256)), dim3(256), 0, st, W, K,
                      Wp, Wp + (size_t)K * C::IMG, view);
   GLX_LAUNCH_CHECK();
   return GLX_OK;

@@ -662,6 +662,9 @@ USE_FUSED_TRAIN_BN = os.environ.get("GLX_FUSED_BN", "1") != "0"
 # stream for the weight-gradient kernels of SparseConvFunction.backward (None = the current one).
 # Set by StaticTrainPipeline around its backward pass; the setter waits for it afterwards.
 WGRAD_STREAM = None
+# list collecting the num_batches_tracked buffers of the fused BatchNorms of a step, so that the
+# caller bumps them with ONE multi-tensor add instead of a tiny kernel per layer (None = bump at once)
+DEFERRED_COUNTERS = None
 
 
 def can_fuse_train_bn(bn, features):
@@ -676,7 +679,10 @@ def fused_train_bn(bn, features, relu, count=None):
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     out = FusedBNReLU.apply(features, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, relu, count)
     if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+        if DEFERRED_COUNTERS is not None:
+            DEFERRED_COUNTERS.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked += 1
     return out
 
 
