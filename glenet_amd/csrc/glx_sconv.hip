@@ -1545,8 +1545,18 @@ __global__ void k_wgrad_reduce(const float* __restrict__ slabs, int nchunks, lon
                                float* __restrict__ dW) {
   long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nel_total) return;
+  // fixed summation order (deterministic), eight slab loads in flight at a time: a thread's loop is
+  // a chain of dependent L2 reads otherwise (16 us for the 75 slabs of a 16x16 layer)
   float s = 0.f;
-  for (int c = 0; c < nchunks; ++c) s += slabs[(long long)c * nel_total + e];
+  int c = 0;
+  for (; c + 8 <= nchunks; c += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = slabs[(long long)(c + u) * nel_total + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; c < nchunks; ++c) s += slabs[(long long)c * nel_total + e];
   dW[e] = s;
 }
 
