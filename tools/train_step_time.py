@@ -61,3 +61,24 @@ for name, graph in (("fwd+bwd shape-static, eager", False), ("fwd+bwd shape-stat
     dt = (time.perf_counter() - t0) / n
     pipe.check()
     print("%-36s %8.3f ms/step  %8.1f frames/s" % (name, dt * 1e3, 4 / dt))
+
+# ---- with the optimizer inside the graph (Adam, capturable): a complete backbone training step
+import copy  # noqa: E402
+model2 = copy.deepcopy(model)
+opt = torch.optim.Adam(model2.parameters(), lr=1e-4, capturable=True, foreach=True)  # fused=True does not update under replay (ROCm 7.2 / torch 2.10)
+pipe2 = gb.StaticTrainPipeline(model2, K, 4, pts.shape[0], 4, optimizer=opt)
+pipe2.calibrate(pts, bidx)
+pipe2.load(pts, bidx)
+pipe2.capture()
+for _ in range(3):
+    pipe2.replay()
+torch.cuda.synchronize()
+l0 = float(pipe2.loss.detach())
+t0 = time.perf_counter()
+for _ in range(20):
+    pipe2.replay()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 20
+pipe2.check()
+print("%-36s %8.3f ms/step  %8.1f frames/s   (loss %.5f -> %.5f over 20 steps)" % (
+    "fwd+bwd+Adam, HIP graph", dt * 1e3, 4 / dt, l0, float(pipe2.loss.detach())))
