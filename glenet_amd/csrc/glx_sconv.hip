@@ -56,6 +56,7 @@ struct SconvEpilogue {
   const int* n_live;   // NULL, or device int32: rows >= *n_live are neither computed nor written
   long long* trace;    // NULL, or (blocks, 4 + 8*NW) int64: selects the TRACE build (tools/sconv_tiles.py)
   int xcd_group;       // GEMM kernel: tiles per XCD-local group (0 = identity block -> tile map)
+  int out_ld;          // row pitch of `out` in floats (0 = COUT): a launch may own a column slice of wider rows
 };
 
 // Block b runs on XCD b mod 8.  Deal the tiles to the XCDs in groups of `g` consecutive tiles:
@@ -89,7 +90,7 @@ struct SconvSplitCfg {
 // gradient of a submanifold conv walks the same rule table with flipped taps).
 template <int CIN, int COUT>
 __global__ void k_pack_weights(const float* __restrict__ W, int K, float* __restrict__ Wp,
-                               float* __restrict__ Wsplit, int view) {
+                               float* __restrict__ Wsplit, int view, int src_cout, int co_off) {
   using C = SconvCfg<CIN, COUT>;
   using S = SconvSplitCfg<CIN, COUT>;
   int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -101,7 +102,9 @@ __global__ void k_pack_weights(const float* __restrict__ W, int K, float* __rest
   int ci = (e / COUT) % CIN;
   int k = e / (COUT * CIN);
   const int ks = (view & 2) ? K - 1 - k : k;
-  const float w = (view & 1) ? W[((size_t)ks * COUT + co) * CIN + ci] : W[((size_t)ks * CIN + ci) * COUT + co];
+  // src_cout / co_off: this image covers columns [co_off, co_off + COUT) of a conv with src_cout outputs
+  const float w = (view & 1) ? W[((size_t)ks * src_cout + co_off + co) * CIN + ci]
+                             : W[((size_t)ks * CIN + ci) * src_cout + co_off + co];
   int q = ci / C::CQ, t = ci % C::CQ;
   int ct = co / 16, n = co % 16;
   int h = ct / C::NC, c = ct % C::NC;
@@ -814,7 +817,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
     if (ep.relu) {
       v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
     }
-    *reinterpret_cast<f32x4*>(out + (long long)orow * COUT + 4 * c4) = v;
+    *reinterpret_cast<f32x4*>(out + (long long)orow * (ep.out_ld ? ep.out_ld : COUT) + 4 * c4) = v;
   }
   if constexpr (TRACE) {
     __syncthreads();
@@ -1143,7 +1146,7 @@ extern "C" int glx_sconv_forward_generic(const float* in, int N_in, const float*
   GLX_REQUIRE(in && W && nbr && out && K > 0 && Cin > 0 && Cout > 0,
               "glx_sconv_forward_generic: bad arguments");
   long long total = (long long)N_out * Cout;
-  SconvEpilogue ep{bias, nullptr, nullptr, 0, nullptr, nullptr, 0};
+  SconvEpilogue ep{bias, nullptr, nullptr, 0, nullptr, nullptr, 0, 0};
   hipLaunchKernelGGL(k_sconv_generic, dim3(glx_divup(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, in, W, ep, nbr, N_out, K, Cin, Cout, out);
   GLX_LAUNCH_CHECK();
@@ -1160,6 +1163,10 @@ template <int CIN, int COUT>
 static size_t img_bytes() {   // both LDS images (whole-chunk and column-split layout) of one offset
   return (size_t)(SconvCfg<CIN, COUT>::IMG + SconvSplitCfg<CIN, COUT>::IMG) * sizeof(float);
 }
+// A 128 -> 128 conv runs as two column halves (launch_mfma): its 64 KB weight image per offset would
+// leave ONE 4-wave block per CU.  The packed buffer then also holds the two (128, 64) half images.
+template <int CIN, int COUT>
+static constexpr bool sc_column_halves() { return CIN >= 128 && COUT >= 128; }
 
 template <class F>
 static int sc_dispatch(int Cin, int Cout, F&& f) {
@@ -1178,7 +1185,9 @@ static int sc_dispatch(int Cin, int Cout, F&& f) {
 static size_t packed_bytes(int K, int Cin, int Cout) {
   size_t b = 0;
   sc_dispatch(Cin, Cout, [&](auto ci, auto co) {
-    b = (size_t)K * img_bytes<decltype(ci)::value, decltype(co)::value>();
+    constexpr int CI = decltype(ci)::value, CO = decltype(co)::value;
+    b = (size_t)K * img_bytes<CI, CO>();
+    if constexpr (sc_column_halves<CI, CO>()) b += 2 * (size_t)K * img_bytes<CI, CO / 2>();
     return 0;
   });
   return b;
@@ -1205,7 +1214,16 @@ static int pack_weights(const float* W, int K, float* Wp, int view, hipStream_t 
   static_assert(S::IMG == CI * CO, "the split image has no padding");
   const int nel = K * CI * CO, cover = K * C::IMG > nel ? K * C::IMG : nel;   // C::IMG >= CI*CO (padding)
   hipLaunchKernelGGL((k_pack_weights<CI, CO>), dim3(glx_divup(cover, 256)), dim3(256), 0, st, W, K,
-                     Wp, Wp + (size_t)K * C::IMG, view);
+                     Wp, Wp + (size_t)K * C::IMG, view, CO, 0);
+  if constexpr (sc_column_halves<CI, CO>()) {
+    using CH = SconvCfg<CI, CO / 2>;
+    const size_t half = (size_t)K * img_bytes<CI, CO / 2>() / sizeof(float);
+    float* base = Wp + (size_t)K * img_bytes<CI, CO>() / sizeof(float);
+    const int nh = K * CI * (CO / 2), ch = K * CH::IMG > nh ? K * CH::IMG : nh;
+    for (int h = 0; h < 2; ++h)
+      hipLaunchKernelGGL((k_pack_weights<CI, CO / 2>), dim3(glx_divup(ch, 256)), dim3(256), 0, st, W, K,
+                         base + h * half, base + h * half + (size_t)K * CH::IMG, view, CO, h * (CO / 2));
+  }
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
@@ -1388,7 +1406,22 @@ static int launch_mfma(const float* in, const float* Wp, const SconvEpilogue& ep
   //               tiles, 8 waves (4 for Cout = 128: its two 16-column tiles per wave);
   //   Cout <= 32: whole-chunk waves with register gathers (little MFMA work per rule pair, the
   //               second LDS hop does not pay), 64 rows x 4 waves.
-  if constexpr (CO >= 128) {
+  if constexpr (sc_column_halves<CI, CO>()) {
+    // two launches of the (CI, CO/2) kernel, each writing its column half of the CO-wide rows
+    const float* base = Wp + (size_t)K * img_bytes<CI, CO>() / sizeof(float);
+    const size_t half = (size_t)K * img_bytes<CI, CO / 2>() / sizeof(float);
+    for (int h = 0; h < 2; ++h) {
+      SconvEpilogue eh = ep;
+      const int off = h * (CO / 2);
+      eh.bias = ep.bias ? ep.bias + off : nullptr;
+      eh.scale = ep.scale ? ep.scale + off : nullptr;
+      eh.shift = ep.shift ? ep.shift + off : nullptr;
+      eh.out_ld = CO;
+      int rc = launch_gemm<CI, CO / 2, 64, 8, 4>(in, base + h * half, eh, nbr, tile_order, N_out, K, out + off, st);
+      if (rc != GLX_OK) return rc;
+    }
+    return GLX_OK;
+  } else if constexpr (CO >= 128) {
     return launch_gemm<CI, CO, 64, 4, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
   } else if constexpr (CO >= 64 && CI >= 16) {
     return launch_gemm<CI, CO, 64, 8, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
@@ -1428,7 +1461,7 @@ extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, cons
   GLX_REQUIRE(K > 0 && Cin > 0 && Cout > 0 && N_out >= 0, "glx_sconv_forward: bad sizes");
   if (N_out == 0) return GLX_OK;
   GLX_REQUIRE(in && (W || Wp) && nbr && out, "glx_sconv_forward: null pointer");
-  SconvEpilogue ep{bias, scale, shift, relu, n_out_live, g_sconv_trace, g_sconv_xcd_group};
+  SconvEpilogue ep{bias, scale, shift, relu, n_out_live, g_sconv_trace, g_sconv_xcd_group, 0};
   if (!mfma_supported(Cin, Cout, K)) {
     GLX_REQUIRE(W, "glx_sconv_forward: raw weights required for channels (%d,%d)", Cin, Cout);
     long long total = (long long)N_out * Cout;
@@ -1466,7 +1499,7 @@ extern "C" int glx_sconv_forward_rb(const float* in, const float* Wp, const floa
   GLX_REQUIRE(in && Wp && book && out, "glx_sconv_forward_rb: null pointer");
   GLX_REQUIRE(mfma_supported(Cin, Cout, K) && Cin >= 16,
               "glx_sconv_forward_rb: channels (%d,%d) not supported", Cin, Cout);
-  SconvEpilogue ep{bias, scale, shift, relu, n_out_live, nullptr, 0};
+  SconvEpilogue ep{bias, scale, shift, relu, n_out_live, nullptr, 0, 0};
   hipStream_t st = (hipStream_t)stream;
   return sc_dispatch(Cin, Cout, [&](auto ci, auto co) {
     constexpr int CI = decltype(ci)::value, CO = decltype(co)::value;
