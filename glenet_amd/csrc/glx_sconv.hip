@@ -398,11 +398,8 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
     }
     __syncthreads();
   }
-  unsigned mask = 0;
-#pragma unroll
-  for (int k = 0; k < SC_MAXK; ++k)
-    if (k < K && s_cnt[k] > 0) mask |= 1u << k;
-  mask = __builtin_amdgcn_readfirstlane(mask);
+  // offsets that have pairs: one LDS read per lane + a ballot (27 dependent reads otherwise)
+  const unsigned mask = (unsigned)__ballot(lane < K && lane < SC_MAXK && s_cnt[lane < SC_MAXK ? lane : 0] > 0);
 
   // ---- weight staging registers (next image) and input-row registers (ping-pong)
   constexpr int STAGE_F4 = IMGW / 4;
@@ -651,11 +648,8 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
     }
     __syncthreads();
   }
-  unsigned mask = 0;
-#pragma unroll
-  for (int k = 0; k < SC_MAXK; ++k)
-    if (k < K && s_cnt[k] > 0) mask |= 1u << k;
-  mask = __builtin_amdgcn_readfirstlane(mask);
+  // offsets that have pairs: one LDS read per lane + a ballot (27 dependent reads otherwise)
+  const unsigned mask = (unsigned)__ballot(lane < K && lane < SC_MAXK && s_cnt[lane < SC_MAXK ? lane : 0] > 0);
 
   // ---- staging registers: next weight image and next panel of gathered rows
   f32x4 wreg[T::SPT];
