@@ -330,8 +330,8 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
 
   // ---- tile rows, zero accumulators, first weight image
   int my_row = -1;
-  if (tid < TR) {
-    int p = row0 + tid;
+  if (TR != 64 && tid < TR) {      // TR == 64: wave 0 stores the rows it loads for the compaction below
+    int p = row0 + tid;            // (a second, dependent global load in front of the neighbour loads otherwise)
     my_row = (p < N_out) ? (tile_order ? tile_order[p] : p) : -1;
     s_rows[tid] = my_row;
   }
@@ -352,6 +352,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
       const int kq = wave + u * T::NW;
       nbv[u] = np[kq < K ? kq : 0];                     // branch-free: all loads in flight
     }
+    if (wave == 0) s_rows[lane] = lrow;
 #pragma unroll
     for (int u = 0; u < KPW; ++u) {
       const int kq = wave + u * T::NW;
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
 
   // ---- tile rows, zero accumulators, rule compaction (as in k_sconv_mfma)
   int my_row = -1;
-  if (tid < TR) {
+  if (TR != 64 && tid < TR) {      // TR == 64: wave 0 stores the rows it loads for the compaction below
     int p = row0 + tid;
     my_row = (p < N_out) ? (tile_order ? tile_order[p] : p) : -1;
     s_rows[tid] = my_row;
@@ -601,6 +602,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
       const int k = wave + u * T::NW;
       nbv[u] = np[k < K ? k : 0];                       // branch-free: all loads in flight
     }
+    if (wave == 0) s_rows[lane] = lrow;
 #pragma unroll
     for (int u = 0; u < KPW; ++u) {
       const int k = wave + u * T::NW;
