@@ -234,6 +234,9 @@ __device__ __forceinline__ void sc_compute(const float* s_w, float* s_acc,
     f32x4 acc[C::NT];
 #pragma unroll
     for (int ct = 0; ct < C::NT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // all W fragments of the chunk are read before the first MFMA (one exposed LDS latency per
+    // chunk instead of one per k-step pair: the ISA had ds_read -> s_waitcnt -> 4 MFMAs, four times)
+    float bw[C::CQ][C::NH][C::NC];
 #pragma unroll
     for (int t = 0; t < C::CQ; ++t) {
 #pragma unroll
@@ -241,17 +244,23 @@ __device__ __forceinline__ void sc_compute(const float* s_w, float* s_acc,
         const float* bp = s_w + (h * 4 + q) * C::QSTRIDE + (t * 16 + r) * C::NC;
         if constexpr (C::NC == 4) {
           f32x4 bv = *reinterpret_cast<const f32x4*>(bp);
-          acc[h * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[0], Am[t], acc[h * 4 + 0], 0, 0, 0);
-          acc[h * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[1], Am[t], acc[h * 4 + 1], 0, 0, 0);
-          acc[h * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[2], Am[t], acc[h * 4 + 2], 0, 0, 0);
-          acc[h * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[3], Am[t], acc[h * 4 + 3], 0, 0, 0);
+          bw[t][h][0] = bv[0]; bw[t][h][1] = bv[1]; bw[t][h][2] = bv[2]; bw[t][h][3] = bv[3];
         } else if constexpr (C::NC == 2) {
           float2 bv = *reinterpret_cast<const float2*>(bp);
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.x, Am[t], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.y, Am[t], acc[1], 0, 0, 0);
+          bw[t][h][0] = bv.x; bw[t][h][1] = bv.y;
         } else {
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bp[0], Am[t], acc[0], 0, 0, 0);
+          bw[t][h][0] = bp[0];
         }
+      }
+    }
+    if constexpr (C::CQ * C::NH * C::NC <= 32) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < C::CQ; ++t) {
+#pragma unroll
+      for (int h = 0; h < C::NH; ++h) {
+#pragma unroll
+        for (int e = 0; e < C::NC; ++e)
+          acc[h * C::NC + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[t][h][e], Am[t], acc[h * C::NC + e], 0, 0, 0);
       }
     }
     if constexpr (TRACE) {
