@@ -1,0 +1,96 @@
+// GLENet's KL regression loss of the RoI head (VoxelRCNNKLLabelIoUHead.get_box_reg_layer_loss,
+// pcdet/models/roi_heads/voxelrcnn_kl_label_iou_head.py:93-138; "ad hoc, in fact it's kl loss"):
+//   t     = ResidualCoder.encode_torch(gt in the RoI frame, RoI moved to the origin with heading 0)
+//           (box_coder_utils.py:13-43: sizes clamped at 1e-5, xy by the BEV diagonal, z by the height,
+//            log size ratios, heading difference)
+//   src   = smooth_l1((reg - t) * code_weight, beta)            (loss_utils.py:100-130; NaN targets ignored)
+//   s     = max(reg_std, -50),  lv = log(label_variance + 1e-10)
+//   loss  = sum_fg [ exp(-s) * src + exp(lv - s) - 0.5 * (lv - s) ] / max(#fg, 1) * weight
+// The reference evaluates this with ~40 tensor kernels and three host read-backs (`.item()`) per
+// step; here one block computes the loss, its three reported parts and both gradients (d/dreg,
+// d/dreg_std) in two passes over the (R, 7) elements, sums in fp64 in a fixed tree order.
+#include "glx_common.h"
+
+#define KL_THREADS 256
+
+__device__ __forceinline__ double kl_block_sum(double v, double* red) {
+  const int t = threadIdx.x;
+  red[t] = v;
+  __syncthreads();
+  for (int s = KL_THREADS / 2; s > 0; s >>= 1) {
+    if (t < s) red[t] += red[t + s];
+    __syncthreads();
+  }
+  const double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+struct KlCodeWeights { float w[7]; };
+
+__global__ __launch_bounds__(KL_THREADS) void k_kl_reg_loss(
+    const float* __restrict__ reg, const float* __restrict__ reg_std, const float* __restrict__ rois,
+    const float* __restrict__ gt, const float* __restrict__ label_var, const float* __restrict__ fg,
+    int R, KlCodeWeights cw, float beta, float weight, float* __restrict__ out,
+    float* __restrict__ grad_reg, float* __restrict__ grad_std) {
+  __shared__ double red[KL_THREADS];
+  double c = 0;
+  for (int i = threadIdx.x; i < R; i += KL_THREADS) c += fg[i] > 0.f ? 1.0 : 0.0;
+  const double nfg = kl_block_sum(c, red);
+  const float scale = weight / (float)(nfg > 1.0 ? nfg : 1.0);
+  double s_src = 0, s_sq = 0, s_log = 0;
+  for (int e = threadIdx.x; e < R * 7; e += KL_THREADS) {
+    const int i = e / 7, k = e - i * 7;
+    const float* a = rois + (long long)i * 7;
+    const float* g = gt + (long long)i * 7;
+    const float dxa = fmaxf(a[3], 1e-5f), dya = fmaxf(a[4], 1e-5f), dza = fmaxf(a[5], 1e-5f);
+    float t;
+    if (k < 2) t = g[k] / sqrtf(dxa * dxa + dya * dya);            // anchor centre is the origin
+    else if (k == 2) t = g[2] / dza;
+    else if (k < 6) t = logf(fmaxf(g[k], 1e-5f) / (k == 3 ? dxa : (k == 4 ? dya : dza)));
+    else t = g[6];                                                  // anchor heading is 0
+    const float x = reg[e];
+    if (isnan(t)) t = x;
+    const float diff = (x - t) * cw.w[k];
+    const float n = fabsf(diff);
+    const float src = beta < 1e-5f ? n : (n < beta ? 0.5f * n * n / beta : n - 0.5f * beta);
+    const float dsrc = beta < 1e-5f ? (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f))
+                                    : (n < beta ? diff / beta : (diff > 0.f ? 1.f : -1.f));
+    const float sraw = reg_std[e];
+    const bool clamped = sraw < -50.f;
+    const float s = clamped ? -50.f : sraw;
+    const float lv = logf(label_var[e] + 1e-10f);
+    const float m = fg[i] > 0.f ? 1.f : 0.f;
+    const float es = expf(-s), sq = expf(lv - s);
+    s_src += (double)(es * src * m);
+    s_sq += (double)(sq * m);
+    s_log += (double)(-0.5f * (lv - s) * m);
+    if (grad_reg) grad_reg[e] = m * es * dsrc * cw.w[k] * scale;
+    if (grad_std) grad_std[e] = clamped ? 0.f : m * (-es * src - sq + 0.5f) * scale;
+  }
+  const double a_src = kl_block_sum(s_src, red), a_sq = kl_block_sum(s_sq, red), a_log = kl_block_sum(s_log, red);
+  if (threadIdx.x == 0) {
+    out[1] = (float)a_src * scale;
+    out[2] = (float)a_sq * scale;
+    out[3] = (float)a_log * scale;
+    out[0] = out[1] + out[2] + out[3];
+    out[4] = (float)nfg;
+  }
+}
+
+extern "C" int glx_kl_reg_loss(const float* rcnn_reg, const float* rcnn_reg_std, const float* rois,
+                               const float* gt_of_rois, const float* gt_uncertainty,
+                               const float* fg_mask, int R, const float* code_weights, float beta,
+                               float weight, float* out5, float* grad_reg, float* grad_std,
+                               void* stream) {
+  GLX_REQUIRE(out5, "glx_kl_reg_loss: null output");
+  GLX_REQUIRE(R == 0 || (rcnn_reg && rcnn_reg_std && rois && gt_of_rois && gt_uncertainty && fg_mask),
+              "glx_kl_reg_loss: null pointer");
+  KlCodeWeights cw;
+  for (int k = 0; k < 7; ++k) cw.w[k] = code_weights ? code_weights[k] : 1.f;
+  hipLaunchKernelGGL(k_kl_reg_loss, dim3(1), dim3(KL_THREADS), 0, (hipStream_t)stream, rcnn_reg,
+                     rcnn_reg_std, rois, gt_of_rois, gt_uncertainty, fg_mask, R, cw, beta, weight, out5,
+                     grad_reg, grad_std);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

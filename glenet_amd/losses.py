@@ -1,0 +1,82 @@
+"""GLENet's KL regression loss of the RoI head (the "KL loss" of BASELINE config 3): our counterpart
+of VoxelRCNNKLLabelIoUHead.get_box_reg_layer_loss, lines 96-138
+(pcdet/models/roi_heads/voxelrcnn_kl_label_iou_head.py), without its corner-loss tail.
+
+On the device the whole expression -- ResidualCoder.encode_torch of the ground truth against the RoI
+moved to the origin, code-weighted smooth-L1, the variance terms, the foreground-normalised sum -- and
+both gradients are ONE kernel (csrc/glx_loss.hip) and no host read-back (the reference reads
+`fg_sum` and four tb_dict scalars back every step).  `kl_reg_loss_torch` is the same arithmetic in
+tensor ops, statement by statement like the reference; it is what runs for CPU tensors."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def kl_reg_loss_torch(rcnn_reg, rcnn_reg_std, rois, gt_of_rois, gt_uncertainty, reg_valid_mask,
+                      code_weights=None, beta=1.0 / 9.0, weight=1.0):
+    """-> (loss, {'src','square','log'}), tensor ops only (reference statement order)."""
+    r = rcnn_reg.shape[0]
+    anchors = rois.detach().reshape(r, 7).clone()
+    anchors[:, 0:3] = 0
+    anchors[:, 6] = 0
+    boxes = gt_of_rois.reshape(r, 7).clone()
+    anchors[:, 3:6] = torch.clamp_min(anchors[:, 3:6], min=1e-5)          # box_coder_utils.py:22-23
+    boxes[:, 3:6] = torch.clamp_min(boxes[:, 3:6], min=1e-5)
+    xa, ya, za, dxa, dya, dza, ra = torch.split(anchors, 1, dim=-1)
+    xg, yg, zg, dxg, dyg, dzg, rg = torch.split(boxes, 1, dim=-1)
+    diagonal = torch.sqrt(dxa ** 2 + dya ** 2)
+    target = torch.cat([(xg - xa) / diagonal, (yg - ya) / diagonal, (zg - za) / dza, torch.log(dxg / dxa),
+                        torch.log(dyg / dya), torch.log(dzg / dza), rg - ra], dim=-1)
+    target = torch.where(torch.isnan(target), rcnn_reg, target)           # loss_utils.py:123
+    diff = rcnn_reg - target
+    if code_weights is not None:
+        diff = diff * torch.as_tensor(code_weights, dtype=diff.dtype, device=diff.device).view(1, -1)
+    n = torch.abs(diff)
+    src = n if beta < 1e-5 else torch.where(n < beta, 0.5 * n ** 2 / beta, n - 0.5 * beta)
+    label_var_log = torch.log(gt_uncertainty.reshape(r, 7) + 1e-10)
+    fg = (reg_valid_mask.reshape(-1) > 0)
+    fg_sum = fg.long().sum().clamp(min=1)
+    std = torch.where(rcnn_reg_std < -50, torch.full_like(rcnn_reg_std, -50.0).detach(), rcnn_reg_std)
+    m = fg.unsqueeze(-1).float()
+    l_src = (torch.exp(-std) * src * m).sum() / fg_sum * weight
+    l_sq = (torch.exp(label_var_log - std) * m).sum() / fg_sum * weight
+    l_log = (-0.5 * (label_var_log - std) * m).sum() / fg_sum * weight
+    return l_src + l_sq + l_log, {"src": l_src.detach(), "square": l_sq.detach(), "log": l_log.detach()}
+
+
+class _KLRegLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rcnn_reg, rcnn_reg_std, rois, gt_of_rois, gt_uncertainty, fg, code_weights, beta, weight):
+        args = [t.contiguous().float() for t in (rcnn_reg, rcnn_reg_std, rois.detach(), gt_of_rois, gt_uncertainty, fg)]
+        _lib.check_cuda(*args)
+        r = args[0].shape[0]
+        out = torch.empty(5, dtype=torch.float32, device=args[0].device)
+        g_reg, g_std = torch.empty_like(args[0]), torch.empty_like(args[1])
+        cw = (ctypes.c_float * 7)(*[float(v) for v in code_weights]) if code_weights is not None else None
+        _lib.call("glx_kl_reg_loss", *args, r, cw, ctypes.c_float(beta), ctypes.c_float(weight), out, g_reg, g_std)
+        ctx.save_for_backward(g_reg, g_std)
+        return out[0], out[1:5]
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_parts):
+        g_reg, g_std = ctx.saved_tensors
+        return g_reg * g_loss, g_std * g_loss, None, None, None, None, None, None, None
+
+
+def kl_reg_loss(rcnn_reg, rcnn_reg_std, rois, gt_of_rois, gt_uncertainty, reg_valid_mask, code_weights=None,
+                beta=1.0 / 9.0, weight=1.0):
+    """rcnn_reg, rcnn_reg_std (R,7); rois (B,N,7) or (R,7); gt_of_rois in the RoI frame; gt_uncertainty
+    = label variances; reg_valid_mask (R) -> (loss, parts) with parts['src'|'square'|'log'|'fg']
+    (device scalars: no read-back)."""
+    if not rcnn_reg.is_cuda:
+        return kl_reg_loss_torch(rcnn_reg, rcnn_reg_std, rois, gt_of_rois, gt_uncertainty, reg_valid_mask,
+                                 code_weights, beta, weight)
+    r = rcnn_reg.shape[0]
+    fg = (reg_valid_mask.reshape(-1) > 0).float()
+    loss, parts = _KLRegLoss.apply(rcnn_reg.reshape(r, 7), rcnn_reg_std.reshape(r, 7), rois.reshape(r, 7),
+                                   gt_of_rois.reshape(r, 7), gt_uncertainty.reshape(r, 7), fg, code_weights,
+                                   float(beta), float(weight))
+    parts = parts.detach()
+    return loss, {"src": parts[0], "square": parts[1], "log": parts[2], "fg": parts[3]}

@@ -379,6 +379,19 @@ int glx_roi_grid_agg(const float* feats, const int32_t* indices, int stride, con
                      int nsample, int Cm, int Co, const float* Wpos, const float* bpos,
                      const float* Wout, const float* bout, float* out, int out_stride, void* stream);
 
+/* GLENet's KL regression loss of the RoI head and its gradients in one launch.
+ * rcnn_reg, rcnn_reg_std, rois, gt_of_rois (RoI frame), gt_uncertainty (label variances): (R,7);
+ * fg_mask (R) float, > 0 = foreground; code_weights: HOST float[7] or NULL (= 1).
+ * out5 (device float[5]) = { loss, src part, square part, log part, #foreground };
+ * grad_reg / grad_std (R,7) or NULL = d loss / d rcnn_reg, d loss / d rcnn_reg_std.
+ * Replaces: VoxelRCNNKLLabelIoUHead.get_box_reg_layer_loss lines 96-138
+ * (pcdet/models/roi_heads/voxelrcnn_kl_label_iou_head.py) incl. ResidualCoder.encode_torch
+ * (box_coder_utils.py:13-43) and WeightedSmoothL1Loss (loss_utils.py:100-130). */
+int glx_kl_reg_loss(const float* rcnn_reg, const float* rcnn_reg_std, const float* rois,
+                    const float* gt_of_rois, const float* gt_uncertainty, const float* fg_mask, int R,
+                    const float* code_weights, float beta, float weight, float* out5,
+                    float* grad_reg, float* grad_std, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Training-mode BatchNorm1d (+ ReLU) over sparse-tensor features x (N, C), C a multiple of 4 that
  * divides 1024 (16 ... 512).  Semantics of nn.BatchNorm1d(eps, momentum) followed by nn.ReLU as

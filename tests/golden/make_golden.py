@@ -21,6 +21,7 @@ committed, this script is committed, nothing of the reference is copied.
   limit_period / boxes3d_to_bev_torch outputs of the reference are stored alongside.
   detector_glue_ref.npz  box coder, anchor generator and the two generate_predicted_boxes statement
                      sequences of the detection heads (see make_detector_glue_ref()).
+  kl_loss_ref.npz    GLENet's KL regression loss of the RoI head + gradients (make_kl_loss_ref()).
   dense_path_ref.npz the reference's dense-path modules (BEV backbone, CVAE networks, RoI-grid
                      geometry helpers) run on CPU: see make_dense_path_ref() for what is imported
                      and which placeholders stand in for uninstalled / CUDA-only imports.
@@ -344,8 +345,82 @@ def make_detector_glue_ref():
     print("detector_glue_ref.npz", {k: v.shape for k, v in out.items()})
 
 
+def make_kl_loss_ref():
+    """kl_loss_ref.npz: GLENet's KL regression loss of the RoI head, from the reference's own code:
+    the statement sequence of VoxelRCNNKLLabelIoUHead.get_box_reg_layer_loss lines 96-138
+    (pcdet/models/roi_heads/voxelrcnn_kl_label_iou_head.py) executed with the reference's
+    ResidualCoder.encode_torch (box_coder_utils.py, loaded by path) and WeightedSmoothL1Loss
+    (pcdet/utils/loss_utils.py, imported unmodified), plus autograd gradients w.r.t. rcnn_reg and
+    rcnn_reg_std.  Placeholders, disclosed: `SharedArray` and the compiled extension
+    `pcdet.ops.roiaware_pool3d.roiaware_pool3d_cuda` (imported by box_utils, unused here) -> empty
+    modules; WeightedSmoothL1Loss.__init__ moves its code weights with `.cuda()` -> a no-op for the
+    duration of the constructor.  The head class itself needs the whole pcdet package."""
+    gen = torch.Generator().manual_seed(2024)
+    sys.modules.setdefault("SharedArray", types.ModuleType("SharedArray"))
+    for name, path in (("pcdet", "pcdet"), ("pcdet.utils", "pcdet/utils"), ("pcdet.ops", "pcdet/ops"),
+                       ("pcdet.ops.roiaware_pool3d", "pcdet/ops/roiaware_pool3d")):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(REF, path)]
+            sys.modules[name] = m
+    sys.modules.setdefault("pcdet.ops.roiaware_pool3d.roiaware_pool3d_cuda",
+                           types.ModuleType("pcdet.ops.roiaware_pool3d.roiaware_pool3d_cuda"))
+    loss_utils = importlib.import_module("pcdet.utils.loss_utils")
+    bc = _load_by_path("ref_box_coder_utils2", "pcdet/utils/box_coder_utils.py")
+    coder = bc.ResidualCoder()
+    code_weights = [1.0, 1.0, 1.0, 0.8, 1.2, 1.0, 1.5]
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        reg_loss_func = loss_utils.WeightedSmoothL1Loss(code_weights=code_weights)
+    finally:
+        torch.Tensor.cuda = real_cuda
+    B, N, cs = 2, 96, 7
+    rois = torch.cat([torch.randn(B, N, 3, generator=gen) * 10, torch.rand(B, N, 3, generator=gen) * 3 + 0.5,
+                      torch.rand(B, N, 1, generator=gen) * 6 - 3], -1)
+    gt_ct = torch.cat([torch.randn(B, N, 3, generator=gen) * 0.4, torch.rand(B, N, 3, generator=gen) * 3 + 0.5,
+                       torch.randn(B, N, 1, generator=gen) * 0.3], -1)
+    gt_ct[0, 3, 3:6] = 0                                     # degenerate box: sizes clamp at 1e-5
+    unc = torch.rand(B, N, cs, generator=gen) * 0.2 + 1e-3
+    reg = (torch.randn(B * N, cs, generator=gen) * 0.3).requires_grad_(True)
+    std = (torch.randn(B * N, cs, generator=gen) * 1.5).detach()
+    std[5, 2] = -80.0                                        # below the -50 clamp
+    std.requires_grad_(True)
+    valid = (torch.rand(B * N, generator=gen) > 0.4).long()
+    weight = 1.0
+    # ---- the reference's statements (voxelrcnn_kl_label_iou_head.py:96-138)
+    reg_valid_mask = valid.view(-1)
+    rcnn_batch_size = gt_ct.view(-1, cs).shape[0]
+    label_var_log = torch.log(unc + 1e-10)
+    fg_mask = (reg_valid_mask > 0)
+    fg_sum = fg_mask.long().sum().item()
+    rois_anchor = rois.clone().detach().view(-1, cs)
+    rois_anchor[:, 0:3] = 0
+    rois_anchor[:, 6] = 0
+    reg_targets = coder.encode_torch(gt_ct.clone().view(rcnn_batch_size, cs), rois_anchor)
+    src = reg_loss_func(reg.view(rcnn_batch_size, -1).unsqueeze(dim=0), reg_targets.unsqueeze(dim=0))
+    src = src.view(rcnn_batch_size, -1)
+    label_var_log = label_var_log.view(rcnn_batch_size, -1)
+    std_used = std.clone()                                    # the reference clamps its tensor in place
+    std_used[std_used < -50] = -50
+    l_src = (torch.exp(-std_used) * src * fg_mask.unsqueeze(dim=-1).float()).sum() / max(fg_sum, 1) * weight
+    l_sq = (torch.exp(label_var_log - std_used) * fg_mask.unsqueeze(dim=-1).float()).sum() / max(fg_sum, 1) * weight
+    l_log = (-0.5 * (label_var_log - std_used) * fg_mask.unsqueeze(dim=-1).float()).sum() / max(fg_sum, 1) * weight
+    loss = l_src + l_sq + l_log
+    loss.backward()
+    out = dict(rois=rois.numpy(), gt_of_rois=gt_ct.numpy(), gt_uncertainty=unc.numpy(), rcnn_reg=reg.detach().numpy(),
+               rcnn_reg_std=std.detach().numpy(), reg_valid_mask=valid.numpy(), code_weights=np.array(code_weights, np.float32),
+               beta=np.float32(reg_loss_func.beta), loss=loss.detach().numpy(), loss_src=l_src.detach().numpy(),
+               loss_square=l_sq.detach().numpy(), loss_log=l_log.detach().numpy(), grad_reg=reg.grad.numpy(),
+               grad_std=std.grad.numpy(), reg_targets=reg_targets.numpy(), fg_sum=np.int64(fg_sum))
+    np.savez_compressed(os.path.join(HERE, "kl_loss_ref.npz"), **out)
+    print("kl_loss_ref.npz loss", float(loss), "fg", fg_sum)
+
+
 if __name__ == "__main__":
-    only = sys.argv[1:] or ["iou3d", "nms", "dense", "glue"]
+    only = sys.argv[1:] or ["iou3d", "nms", "dense", "glue", "kl"]
+    if "kl" in only:
+        make_kl_loss_ref()
     if "glue" in only:
         make_detector_glue_ref()
     if "iou3d" in only:
