@@ -94,3 +94,104 @@ extern "C" int glx_kl_reg_loss(const float* rcnn_reg, const float* rcnn_reg_std,
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
+
+// ------------------------------------------------------------------ corner loss of the RoI head
+// The CORNER_LOSS_REGULARIZATION tail of get_box_reg_layer_loss (voxelrcnn_kl_label_iou_head.py:148-172):
+// foreground RoIs only -- decode the regression against the RoI at the origin (ResidualCoder.decode_torch,
+// box_coder_utils.py:45-78), rotate the centre by the RoI heading and translate
+// (common_utils.rotate_points_along_z), then get_corner_loss_lidar (loss_utils.py:210-233): 8 corners
+// (box_utils.boxes_to_corners_3d template order), distance to the ground-truth corners and to those of
+// the ground truth turned by pi, the smaller one through smooth-L1 (beta 1), mean over corners, mean
+// over the foreground RoIs.  One thread per RoI computes the row loss and d loss / d rcnn_reg[row, 0:7]
+// analytically (the reference: ~60 tensor kernels forward, as many backward).
+__device__ __forceinline__ void corner_of(int j, float dx, float dy, float dz, float ch, float sh, float cx,
+                                          float cy, float cz, float& x, float& y, float& z, float& lx,
+                                          float& ly) {
+  // template rows of boxes_to_corners_3d: (1,1,-1),(1,-1,-1),(-1,-1,-1),(-1,1,-1),(1,1,1),(1,-1,1),(-1,-1,1),(-1,1,1), halved
+  const float tx = (j & 3) < 2 ? 0.5f : -0.5f;
+  const float ty = ((j & 3) == 0 || (j & 3) == 3) ? 0.5f : -0.5f;
+  const float tz = j < 4 ? -0.5f : 0.5f;
+  lx = dx * tx;
+  ly = dy * ty;
+  x = lx * ch - ly * sh + cx;
+  y = lx * sh + ly * ch + cy;
+  z = dz * tz + cz;
+}
+
+__global__ __launch_bounds__(KL_THREADS) void k_corner_loss(
+    const float* __restrict__ reg, const float* __restrict__ rois, const float* __restrict__ gt,
+    const float* __restrict__ fg, int R, float weight, float* __restrict__ out,
+    float* __restrict__ grad_reg) {
+  __shared__ double red[KL_THREADS];
+  double c = 0;
+  for (int i = threadIdx.x; i < R; i += KL_THREADS) c += fg[i] > 0.f ? 1.0 : 0.0;
+  const double nfg = kl_block_sum(c, red);
+  const float scale = nfg > 0.0 ? weight / (float)nfg : 0.f;
+  double acc = 0;
+  for (int i = threadIdx.x; i < R; i += KL_THREADS) {
+    float g7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (fg[i] > 0.f) {
+      const float* a = rois + (long long)i * 7;
+      const float* r = reg + (long long)i * 7;
+      const float* q = gt + (long long)i * 7;
+      const float dxa = a[3], dya = a[4], dza = a[5], ra = a[6];
+      const float diag = sqrtf(dxa * dxa + dya * dya);
+      const float xl = r[0] * diag, yl = r[1] * diag, zl = r[2] * dza;
+      const float dx = expf(r[3]) * dxa, dy = expf(r[4]) * dya, dz = expf(r[5]) * dza;
+      const float h = r[6] + ra;
+      const float ca = cosf(ra), sa = sinf(ra);
+      const float cx = xl * ca - yl * sa + a[0], cy = xl * sa + yl * ca + a[1], cz = zl + a[2];
+      const float ch = cosf(h), sh = sinf(h);
+      const float gch = cosf(q[6]), gsh = sinf(q[6]);
+      const float fch = cosf(q[6] + 3.14159265358979323846f), fsh = sinf(q[6] + 3.14159265358979323846f);
+      float row = 0.f, gcx = 0.f, gcy = 0.f, gcz = 0.f, gdx = 0.f, gdy = 0.f, gdz = 0.f, gh = 0.f;
+      for (int j = 0; j < 8; ++j) {
+        float px, py, pz, lx, ly, qx, qy, qz, fx, fy, fz, t0, t1;
+        corner_of(j, dx, dy, dz, ch, sh, cx, cy, cz, px, py, pz, lx, ly);
+        corner_of(j, q[3], q[4], q[5], gch, gsh, q[0], q[1], q[2], qx, qy, qz, t0, t1);
+        corner_of(j, q[3], q[4], q[5], fch, fsh, q[0], q[1], q[2], fx, fy, fz, t0, t1);
+        const float d1 = sqrtf((px - qx) * (px - qx) + (py - qy) * (py - qy) + (pz - qz) * (pz - qz));
+        const float d2 = sqrtf((px - fx) * (px - fx) + (py - fy) * (py - fy) + (pz - fz) * (pz - fz));
+        const bool first = d1 <= d2;
+        const float d = first ? d1 : d2;
+        const float ex = px - (first ? qx : fx), ey = py - (first ? qy : fy), ez = pz - (first ? qz : fz);
+        row += d < 1.f ? 0.5f * d * d : d - 0.5f;
+        const float k = d < 1.f ? 1.f : 1.f / d;                // d smooth_l1 / d d, times 1/d of the norm
+        const float Gx = k * ex, Gy = k * ey, Gz = k * ez;
+        const float tx = (j & 3) < 2 ? 0.5f : -0.5f;
+        const float ty = ((j & 3) == 0 || (j & 3) == 3) ? 0.5f : -0.5f;
+        const float tz = j < 4 ? -0.5f : 0.5f;
+        gcx += Gx; gcy += Gy; gcz += Gz;
+        gdx += Gx * tx * ch + Gy * tx * sh;
+        gdy += -Gx * ty * sh + Gy * ty * ch;
+        gdz += Gz * tz;
+        gh += Gx * (-lx * sh - ly * ch) + Gy * (lx * ch - ly * sh);
+      }
+      acc += (double)(row * 0.125f);
+      const float s8 = scale * 0.125f;
+      const float gxl = gcx * ca + gcy * sa, gyl = -gcx * sa + gcy * ca;
+      g7[0] = gxl * diag * s8; g7[1] = gyl * diag * s8; g7[2] = gcz * dza * s8;
+      g7[3] = gdx * dx * s8; g7[4] = gdy * dy * s8; g7[5] = gdz * dz * s8; g7[6] = gh * s8;
+    }
+    if (grad_reg) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) grad_reg[(long long)i * 7 + k] = g7[k];
+    }
+  }
+  const double total = kl_block_sum(acc, red);
+  if (threadIdx.x == 0) {
+    out[0] = (float)total * scale;
+    out[1] = (float)nfg;
+  }
+}
+
+extern "C" int glx_corner_loss(const float* rcnn_reg, const float* rois, const float* gt_of_rois_src,
+                               const float* fg_mask, int R, float weight, float* out2, float* grad_reg,
+                               void* stream) {
+  GLX_REQUIRE(out2, "glx_corner_loss: null output");
+  GLX_REQUIRE(R == 0 || (rcnn_reg && rois && gt_of_rois_src && fg_mask), "glx_corner_loss: null pointer");
+  hipLaunchKernelGGL(k_corner_loss, dim3(1), dim3(KL_THREADS), 0, (hipStream_t)stream, rcnn_reg, rois,
+                     gt_of_rois_src, fg_mask, R, weight, out2, grad_reg);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

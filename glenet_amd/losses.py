@@ -80,3 +80,66 @@ def kl_reg_loss(rcnn_reg, rcnn_reg_std, rois, gt_of_rois, gt_uncertainty, reg_va
                                    float(beta), float(weight))
     parts = parts.detach()
     return loss, {"src": parts[0], "square": parts[1], "log": parts[2], "fg": parts[3]}
+
+
+# ------------------------------------------------------------------ corner-loss regularisation
+def _corners(boxes):
+    """boxes_to_corners_3d (pcdet/utils/box_utils.py:28-53): (N,7) -> (N,8,3)."""
+    template = boxes.new_tensor(([1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1],
+                                 [1, 1, 1], [1, -1, 1], [-1, -1, 1], [-1, 1, 1])) / 2
+    c = boxes[:, None, 3:6].repeat(1, 8, 1) * template[None, :, :]
+    cs, sn = torch.cos(boxes[:, 6]), torch.sin(boxes[:, 6])
+    x = c[..., 0] * cs[:, None] - c[..., 1] * sn[:, None]
+    y = c[..., 0] * sn[:, None] + c[..., 1] * cs[:, None]
+    return torch.stack([x, y, c[..., 2]], dim=-1) + boxes[:, None, 0:3]
+
+
+def corner_loss_torch(rcnn_reg, rois, gt_of_rois_src, reg_valid_mask, weight=1.0):
+    """The reference's statements (voxelrcnn_kl_label_iou_head.py:148-172) in tensor ops."""
+    fg = reg_valid_mask.reshape(-1) > 0
+    if int(fg.sum()) == 0:
+        return rcnn_reg.sum() * 0.0
+    reg = rcnn_reg.reshape(-1, 7)[fg]
+    roi = rois.reshape(-1, 7)[fg].detach()
+    gt = gt_of_rois_src.reshape(-1, 7)[fg]
+    dxa, dya, dza, ra = roi[:, 3], roi[:, 4], roi[:, 5], roi[:, 6]
+    diag = torch.sqrt(dxa ** 2 + dya ** 2)
+    xl, yl, zl = reg[:, 0] * diag, reg[:, 1] * diag, reg[:, 2] * dza
+    ca, sa = torch.cos(ra), torch.sin(ra)
+    pred = torch.stack([xl * ca - yl * sa + roi[:, 0], xl * sa + yl * ca + roi[:, 1], zl + roi[:, 2],
+                        torch.exp(reg[:, 3]) * dxa, torch.exp(reg[:, 4]) * dya, torch.exp(reg[:, 5]) * dza,
+                        reg[:, 6] + ra], dim=-1)
+    flip = gt.clone()
+    flip[:, 6] += 3.141592653589793
+    pc = _corners(pred)
+    d = torch.min(torch.norm(pc - _corners(gt), dim=2), torch.norm(pc - _corners(flip), dim=2))
+    loss = torch.where(d < 1.0, 0.5 * d ** 2, d - 0.5).mean(dim=1)
+    return loss.mean() * weight
+
+
+class _CornerLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rcnn_reg, rois, gt_src, fg, weight):
+        args = [t.contiguous().float() for t in (rcnn_reg, rois.detach(), gt_src, fg)]
+        _lib.check_cuda(*args)
+        out = torch.empty(2, dtype=torch.float32, device=args[0].device)
+        g_reg = torch.empty_like(args[0])
+        _lib.call("glx_corner_loss", *args, args[0].shape[0], ctypes.c_float(weight), out, g_reg)
+        ctx.save_for_backward(g_reg)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        (g_reg,) = ctx.saved_tensors
+        return g_reg * g_loss, None, None, None, None
+
+
+def corner_loss(rcnn_reg, rois, gt_of_rois_src, reg_valid_mask, weight=1.0):
+    """Mean corner loss over the foreground RoIs (0 when there are none, where the reference skips
+    the term); device tensors: one kernel, no read-back of the foreground count."""
+    if not rcnn_reg.is_cuda:
+        return corner_loss_torch(rcnn_reg, rois, gt_of_rois_src, reg_valid_mask, weight)
+    r = rcnn_reg.shape[0]
+    fg = (reg_valid_mask.reshape(-1) > 0).float()
+    return _CornerLoss.apply(rcnn_reg.reshape(r, 7), rois.reshape(r, 7), gt_of_rois_src.reshape(r, 7), fg,
+                             float(weight))

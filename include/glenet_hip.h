@@ -392,6 +392,16 @@ int glx_kl_reg_loss(const float* rcnn_reg, const float* rcnn_reg_std, const floa
                     const float* code_weights, float beta, float weight, float* out5,
                     float* grad_reg, float* grad_std, void* stream);
 
+/* Corner-loss regularisation of the same head (lines 148-172): foreground RoIs only; rois (R,7) in
+ * the LiDAR frame, gt_of_rois_src (R,7) the matched ground-truth boxes in the LiDAR frame.
+ * out2 (device float[2]) = { mean corner loss over the foreground RoIs * weight, #foreground };
+ * grad_reg (R,7) or NULL = d loss / d rcnn_reg (zero rows for background).
+ * Replaces: decode_torch + rotate_points_along_z + loss_utils.get_corner_loss_lidar
+ * (pcdet/utils/loss_utils.py:210-233, box_utils.boxes_to_corners_3d) and their autograd. */
+int glx_corner_loss(const float* rcnn_reg, const float* rois, const float* gt_of_rois_src,
+                    const float* fg_mask, int R, float weight, float* out2, float* grad_reg,
+                    void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Training-mode BatchNorm1d (+ ReLU) over sparse-tensor features x (N, C), C a multiple of 4 that
  * divides 1024 (16 ... 512).  Semantics of nn.BatchNorm1d(eps, momentum) followed by nn.ReLU as

@@ -408,11 +408,36 @@ def make_kl_loss_ref():
     l_log = (-0.5 * (label_var_log - std_used) * fg_mask.unsqueeze(dim=-1).float()).sum() / max(fg_sum, 1) * weight
     loss = l_src + l_sq + l_log
     loss.backward()
+    # ---- corner-loss regularisation, lines 148-172, with the reference's decode_torch,
+    # common_utils.rotate_points_along_z and loss_utils.get_corner_loss_lidar
+    common = importlib.import_module("pcdet.utils.common_utils")
+    reg_c = reg.detach().clone().requires_grad_(True)
+    gt_src = torch.cat([rois[..., 0:3] + torch.randn(B, N, 3, generator=gen) * 0.5,
+                        rois[..., 3:6] * (1 + torch.randn(B, N, 3, generator=gen) * 0.1),
+                        rois[..., 6:7] + torch.randn(B, N, 1, generator=gen) * 0.4], -1)
+    gt_src[1, 7, 6] += 3.0                                    # nearly opposite heading: the flipped branch wins
+    gt_of_rois_src = gt_src.view(-1, cs)
+    fg_rcnn_reg = reg_c.view(rcnn_batch_size, -1)[fg_mask]
+    fg_roi_boxes3d = rois.view(-1, cs)[fg_mask]
+    fg_roi_boxes3d = fg_roi_boxes3d.view(1, -1, cs)
+    batch_anchors = fg_roi_boxes3d.clone().detach()
+    roi_ry = fg_roi_boxes3d[:, :, 6].view(-1)
+    roi_xyz = fg_roi_boxes3d[:, :, 0:3].view(-1, 3)
+    batch_anchors[:, :, 0:3] = 0
+    rcnn_boxes3d = coder.decode_torch(fg_rcnn_reg.view(batch_anchors.shape[0], -1, cs), batch_anchors).view(-1, cs)
+    rcnn_boxes3d = common.rotate_points_along_z(rcnn_boxes3d.unsqueeze(dim=1), roi_ry).squeeze(dim=1)
+    rcnn_boxes3d[:, 0:3] += roi_xyz
+    loss_corner = loss_utils.get_corner_loss_lidar(rcnn_boxes3d[:, 0:7], gt_of_rois_src[fg_mask][:, 0:7])
+    loss_corner = loss_corner.mean() * 1.0
+    loss_corner.backward()
+    corner = dict(gt_of_rois_src=gt_src.numpy(), loss_corner=loss_corner.detach().numpy(),
+                  grad_reg_corner=reg_c.grad.numpy())
     out = dict(rois=rois.numpy(), gt_of_rois=gt_ct.numpy(), gt_uncertainty=unc.numpy(), rcnn_reg=reg.detach().numpy(),
                rcnn_reg_std=std.detach().numpy(), reg_valid_mask=valid.numpy(), code_weights=np.array(code_weights, np.float32),
                beta=np.float32(reg_loss_func.beta), loss=loss.detach().numpy(), loss_src=l_src.detach().numpy(),
                loss_square=l_sq.detach().numpy(), loss_log=l_log.detach().numpy(), grad_reg=reg.grad.numpy(),
                grad_std=std.grad.numpy(), reg_targets=reg_targets.numpy(), fg_sum=np.int64(fg_sum))
+    out.update(corner)
     np.savez_compressed(os.path.join(HERE, "kl_loss_ref.npz"), **out)
     print("kl_loss_ref.npz loss", float(loss), "fg", fg_sum)
 
