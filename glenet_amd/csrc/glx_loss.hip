@@ -195,3 +195,50 @@ extern "C" int glx_corner_loss(const float* rcnn_reg, const float* rois, const f
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
+
+// ------------------------------------------------------------------ canonical transformation
+// RoIHeadTemplate.assign_targets, lines 140-159 (pcdet/models/roi_heads/roi_head_template.py): the
+// matched ground-truth box of every RoI expressed in the RoI's frame -- centre difference rotated by
+// -roi_ry (common_utils.rotate_points_along_z), heading difference folded into [-pi/2, pi/2] (a
+// ground truth pointing the other way round is turned by pi).  Extra channels (class id, ...) pass
+// through.  ~25 tensor kernels in the reference, one launch here.
+__device__ __forceinline__ float glx_pymod(float a, float m) {    // python / torch `%` for m > 0
+  float r = fmodf(a, m);
+  if (r != 0.f && r < 0.f) r += m;
+  return r;
+}
+
+__global__ void k_roi_canonical_gt(const float* __restrict__ rois, int roi_cols,
+                                   const float* __restrict__ gt, int gt_cols, int R,
+                                   float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  const float PI = 3.14159265358979323846f, TWO_PI = (float)(2.0 * 3.14159265358979323846);
+  const float* a = rois + (long long)i * roi_cols;
+  const float* g = gt + (long long)i * gt_cols;
+  float* o = out + (long long)i * gt_cols;
+  const float ry = glx_pymod(a[6], TWO_PI);
+  const float x = g[0] - a[0], y = g[1] - a[1], z = g[2] - a[2];
+  const float cs = cosf(-ry), sn = sinf(-ry);
+  o[0] = x * cs - y * sn;
+  o[1] = x * sn + y * cs;
+  o[2] = z;
+  o[3] = g[3]; o[4] = g[4]; o[5] = g[5];
+  float h = glx_pymod(g[6] - ry, TWO_PI);
+  if (h > (float)(3.14159265358979323846 * 0.5) && h < (float)(3.14159265358979323846 * 1.5)) h = glx_pymod(h + PI, TWO_PI);
+  if (h > PI) h = h - TWO_PI;
+  h = fminf(fmaxf(h, (float)(-3.14159265358979323846 / 2)), (float)(3.14159265358979323846 / 2));
+  o[6] = h;
+  for (int k = 7; k < gt_cols; ++k) o[k] = g[k];
+}
+
+extern "C" int glx_roi_canonical_gt(const float* rois, int roi_cols, const float* gt_of_rois, int gt_cols,
+                                    int R, float* out, void* stream) {
+  if (R <= 0) return GLX_OK;
+  GLX_REQUIRE(rois && gt_of_rois && out && roi_cols >= 7 && gt_cols >= 7,
+              "glx_roi_canonical_gt: need >= 7 columns and non-null pointers");
+  hipLaunchKernelGGL(k_roi_canonical_gt, dim3(glx_divup(R, 256)), dim3(256), 0, (hipStream_t)stream, rois,
+                     roi_cols, gt_of_rois, gt_cols, R, out);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

@@ -143,3 +143,37 @@ def corner_loss(rcnn_reg, rois, gt_of_rois_src, reg_valid_mask, weight=1.0):
     fg = (reg_valid_mask.reshape(-1) > 0).float()
     return _CornerLoss.apply(rcnn_reg.reshape(r, 7), rois.reshape(r, 7), gt_of_rois_src.reshape(r, 7), fg,
                              float(weight))
+
+
+# ------------------------------------------------------------------ canonical transformation
+def canonical_gt_of_rois_torch(rois, gt_of_rois):
+    """RoIHeadTemplate.assign_targets lines 140-159 in tensor ops (rois (B,N,7+), gt (B,N,7+C))."""
+    import numpy as np
+    gt = gt_of_rois.clone()
+    roi_center = rois[:, :, 0:3]
+    roi_ry = rois[:, :, 6] % (2 * np.pi)
+    gt[:, :, 0:3] = gt[:, :, 0:3] - roi_center
+    gt[:, :, 6] = gt[:, :, 6] - roi_ry
+    c, s = torch.cos(-roi_ry), torch.sin(-roi_ry)
+    x, y = gt[:, :, 0].clone(), gt[:, :, 1].clone()
+    gt[:, :, 0] = x * c - y * s
+    gt[:, :, 1] = x * s + y * c
+    h = gt[:, :, 6] % (2 * np.pi)
+    opposite = (h > np.pi * 0.5) & (h < np.pi * 1.5)
+    h[opposite] = (h[opposite] + np.pi) % (2 * np.pi)
+    flag = h > np.pi
+    h[flag] = h[flag] - np.pi * 2
+    gt[:, :, 6] = torch.clamp(h, min=-np.pi / 2, max=np.pi / 2)
+    return gt
+
+
+def canonical_gt_of_rois(rois, gt_of_rois):
+    """-> gt_of_rois in the RoI frame, same shape; one kernel on the device."""
+    if not rois.is_cuda:
+        return canonical_gt_of_rois_torch(rois, gt_of_rois)
+    r = rois.shape[0] * rois.shape[1]
+    a, g = rois.contiguous().float(), gt_of_rois.contiguous().float()
+    _lib.check_cuda(a, g)
+    out = torch.empty_like(g)
+    _lib.call("glx_roi_canonical_gt", a, a.shape[-1], g, g.shape[-1], r, out)
+    return out

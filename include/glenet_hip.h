@@ -402,6 +402,14 @@ int glx_corner_loss(const float* rcnn_reg, const float* rois, const float* gt_of
                     const float* fg_mask, int R, float weight, float* out2, float* grad_reg,
                     void* stream);
 
+/* Canonical transformation of the matched ground truth into the RoI frame: rois (R, roi_cols >= 7),
+ * gt_of_rois (R, gt_cols >= 7) -> out (R, gt_cols): centre difference rotated by -heading(roi),
+ * heading difference folded into [-pi/2, pi/2] (turned by pi when it points the other way), other
+ * channels copied.  Replaces: RoIHeadTemplate.assign_targets lines 140-159
+ * (pcdet/models/roi_heads/roi_head_template.py). */
+int glx_roi_canonical_gt(const float* rois, int roi_cols, const float* gt_of_rois, int gt_cols, int R,
+                         float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Training-mode BatchNorm1d (+ ReLU) over sparse-tensor features x (N, C), C a multiple of 4 that
  * divides 1024 (16 ... 512).  Semantics of nn.BatchNorm1d(eps, momentum) followed by nn.ReLU as

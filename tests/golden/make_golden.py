@@ -437,6 +437,27 @@ def make_kl_loss_ref():
                beta=np.float32(reg_loss_func.beta), loss=loss.detach().numpy(), loss_src=l_src.detach().numpy(),
                loss_square=l_sq.detach().numpy(), loss_log=l_log.detach().numpy(), grad_reg=reg.grad.numpy(),
                grad_std=std.grad.numpy(), reg_targets=reg_targets.numpy(), fg_sum=np.int64(fg_sum))
+    # ---- canonical transformation, roi_head_template.py:140-159, the reference's statements
+    rois_c = torch.cat([torch.randn(B, N, 3, generator=gen) * 10, torch.rand(B, N, 3, generator=gen) * 3 + 0.5,
+                        torch.rand(B, N, 1, generator=gen) * 14 - 7], -1)            # headings beyond +-2 pi too
+    gt_c = torch.cat([rois_c[..., 0:3] + torch.randn(B, N, 3, generator=gen), torch.rand(B, N, 3, generator=gen) * 3 + 0.5,
+                      torch.rand(B, N, 1, generator=gen) * 14 - 7, torch.randint(1, 4, (B, N, 1), generator=gen).float()], -1)
+    gt_c[0, 0, 6] = rois_c[0, 0, 6] + float(np.pi / 2)        # on the fold
+    gt_of_rois = gt_c.clone()
+    roi_center = rois_c[:, :, 0:3]
+    roi_ry = rois_c[:, :, 6] % (2 * np.pi)
+    gt_of_rois[:, :, 0:3] = gt_of_rois[:, :, 0:3] - roi_center
+    gt_of_rois[:, :, 6] = gt_of_rois[:, :, 6] - roi_ry
+    gt_of_rois = common.rotate_points_along_z(points=gt_of_rois.view(-1, 1, gt_of_rois.shape[-1]),
+                                              angle=-roi_ry.view(-1)).view(B, -1, gt_of_rois.shape[-1])
+    heading_label = gt_of_rois[:, :, 6] % (2 * np.pi)
+    opposite_flag = (heading_label > np.pi * 0.5) & (heading_label < np.pi * 1.5)
+    heading_label[opposite_flag] = (heading_label[opposite_flag] + np.pi) % (2 * np.pi)
+    flag = heading_label > np.pi
+    heading_label[flag] = heading_label[flag] - np.pi * 2
+    heading_label = torch.clamp(heading_label, min=-np.pi / 2, max=np.pi / 2)
+    gt_of_rois[:, :, 6] = heading_label
+    out.update(canon_rois=rois_c.numpy(), canon_gt=gt_c.numpy(), canon_out=gt_of_rois.numpy())
     out.update(corner)
     np.savez_compressed(os.path.join(HERE, "kl_loss_ref.npz"), **out)
     print("kl_loss_ref.npz loss", float(loss), "fg", fg_sum)

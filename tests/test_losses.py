@@ -73,3 +73,23 @@ def test_corner_loss_kernel_matches_reference_golden(dev):
     l0 = losses.corner_loss(reg2, rois, torch.from_numpy(G["gt_of_rois_src"]).to(dev), torch.zeros_like(valid))
     l0.backward()
     assert float(l0.detach()) == 0.0 and float(reg2.grad.abs().max()) == 0.0
+
+
+def _canon_close(got, want):
+    # headings on the +-pi/2 fold may land on either side: compare them modulo pi
+    np.testing.assert_allclose(got[..., [0, 1, 2, 3, 4, 5, 7]], want[..., [0, 1, 2, 3, 4, 5, 7]], rtol=1e-5, atol=1e-5)
+    dh = np.abs(got[..., 6] - want[..., 6])
+    assert (np.minimum(dh, np.abs(dh - np.pi)) < 1e-5).all()
+    assert (np.abs(got[..., 6]) <= np.pi / 2 + 1e-6).all()
+
+
+def test_canonical_gt_tensor_ops_match_reference_golden():
+    got = losses.canonical_gt_of_rois(torch.from_numpy(G["canon_rois"]), torch.from_numpy(G["canon_gt"]))
+    _canon_close(got.numpy(), G["canon_out"])
+
+
+@pytest.mark.gpu
+def test_canonical_gt_kernel_matches_reference_golden(dev):
+    got = losses.canonical_gt_of_rois(torch.from_numpy(G["canon_rois"]).to(dev), torch.from_numpy(G["canon_gt"]).to(dev))
+    assert got.shape == G["canon_out"].shape
+    _canon_close(got.cpu().numpy(), G["canon_out"])

@@ -1,0 +1,50 @@
+"""RoI-head loss glue on the GPU box: the reference's tensor-op sequences (glenet_amd.losses.*_torch,
+statement-for-statement mirrors) vs the fused kernels, forward + backward, 512 RoIs (4 frames x 128)."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from glenet_amd import losses  # noqa: E402
+
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+B, N = 4, 128
+rois = torch.cat([torch.randn(B, N, 3) * 10, torch.rand(B, N, 3) * 3 + 0.5, torch.rand(B, N, 1) * 6 - 3], -1).to(dev)
+gt_src = torch.cat([rois[..., :3].cpu() + torch.randn(B, N, 3) * 0.5, rois[..., 3:6].cpu() * 1.1,
+                    rois[..., 6:7].cpu() + 0.2, torch.ones(B, N, 1)], -1).to(dev)
+unc = (torch.rand(B, N, 7) * 0.2 + 1e-3).to(dev)
+valid = (torch.rand(B * N) > 0.4).long().to(dev)
+reg = (torch.randn(B * N, 7) * 0.3).to(dev).requires_grad_(True)
+std = torch.randn(B * N, 7).to(dev).requires_grad_(True)
+
+
+def timeit(fn, n=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e6
+
+
+def step(canon, kl, corner):
+    reg.grad = std.grad = None
+    gt_ct = canon(rois, gt_src)[..., :7]
+    l1, _ = kl(reg, std, rois, gt_ct, unc, valid)
+    l2 = corner(reg, rois, gt_src[..., :7], valid)
+    (l1 + l2).backward()
+    return l1, l2
+
+
+a = step(losses.canonical_gt_of_rois_torch, losses.kl_reg_loss_torch, losses.corner_loss_torch)
+b = step(losses.canonical_gt_of_rois, losses.kl_reg_loss, losses.corner_loss)
+print("losses (tensor ops) %.6f %.6f | (kernels) %.6f %.6f" % (float(a[0]), float(a[1]), float(b[0]), float(b[1])))
+t_ref = timeit(lambda: step(losses.canonical_gt_of_rois_torch, losses.kl_reg_loss_torch, losses.corner_loss_torch))
+t_k = timeit(lambda: step(losses.canonical_gt_of_rois, losses.kl_reg_loss, losses.corner_loss))
+print("canonical transform + KL reg loss + corner loss, fwd+bwd, %d RoIs: tensor ops %.0f us -> fused kernels %.0f us"
+      % (B * N, t_ref, t_k))
