@@ -242,3 +242,197 @@ extern "C" int glx_roi_canonical_gt(const float* rois, int roi_cols, const float
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
+
+// ------------------------------------------------------------------ anchor target assignment
+// AxisAlignedTargetAssigner.assign_targets_single (pcdet/models/dense_heads/target_assigner/
+// axis_aligned_target_assigner.py:133-213) for one anchor class, all frames of the batch, without
+// sampling (POS_FRACTION < 0) and with the nearest-BEV IoU (match_height False):
+//   iou(a, g) = box_utils.boxes3d_nearest_bev_iou (box_utils.py:249-298): both boxes snapped to the
+//               nearer axis (|limit_period(heading, 0.5, pi)| < pi/4 keeps (dx,dy), else swaps them),
+//               axis-aligned IoU with the union clamped at 1e-6;
+//   an anchor is positive when its best IoU >= matched_threshold or when it attains some ground
+//   truth's best IoU (ties included; ground truths whose best IoU is 0 match nothing); it is
+//   background when its best IoU < unmatched_threshold and it is not such a forced match; the rest
+//   is "don't care" (-1).  Positives get the residual encoding of their best ground truth
+//   (ResidualCoder.encode_torch) and weight 1 / #(labels >= 0) (NORM_BY_NUM_EXAMPLES) or 1.
+// The reference runs this per frame and class in ~70 tensor kernels over (N x M) matrices with
+// `.nonzero()` / boolean-index host synchronisations; here: 3 launches per class for the whole batch.
+struct AlignedBev { float x1, y1, x2, y2, area; };
+
+__device__ __forceinline__ AlignedBev aligned_bev(const float* b) {
+  const float PI = (float)3.14159265358979323846;
+  const float rot = fabsf(b[6] - floorf(b[6] / PI + 0.5f) * PI);
+  const bool keep = rot < (float)(3.14159265358979323846 / 4);
+  const float dx = keep ? b[3] : b[4], dy = keep ? b[4] : b[3];
+  AlignedBev r;
+  r.x1 = b[0] - dx / 2; r.y1 = b[1] - dy / 2; r.x2 = b[0] + dx / 2; r.y2 = b[1] + dy / 2;
+  r.area = (r.x2 - r.x1) * (r.y2 - r.y1);
+  return r;
+}
+
+__device__ __forceinline__ float bev_iou(const AlignedBev& a, const AlignedBev& b) {
+  const float xl = fmaxf(fminf(a.x2, b.x2) - fmaxf(a.x1, b.x1), 0.f);
+  const float yl = fmaxf(fminf(a.y2, b.y2) - fmaxf(a.y1, b.y1), 0.f);
+  const float inter = xl * yl;
+  return inter / fmaxf(a.area + b.area - inter, 1e-6f);
+}
+
+#define TA_MAXGT 128
+
+// per frame: rows of gt considered = up to the last row whose 8 values do not sum to 0 (at least
+// row 0), as the reference trims its zero padding; also clears the per-frame scratch
+__global__ void k_assign_prepare(const float* __restrict__ gt, int B, int M, int gt_cols,
+                                 int* __restrict__ n_valid, int* __restrict__ gmax,
+                                 int* __restrict__ num_examples) {
+  const int b = blockIdx.x;
+  __shared__ int s_last;
+  if (threadIdx.x == 0) s_last = 0;
+  __syncthreads();
+  for (int j = threadIdx.x; j < M; j += blockDim.x) {
+    const float* g = gt + ((long long)b * M + j) * gt_cols;
+    float s = 0.f;
+    for (int c = 0; c < gt_cols; ++c) s += g[c];
+    if (s != 0.f) atomicMax(&s_last, j);
+    gmax[b * TA_MAXGT + (j < TA_MAXGT ? j : 0)] = 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { n_valid[b] = s_last + 1; num_examples[b] = 0; }
+}
+
+__global__ __launch_bounds__(256) void k_assign_iou_max(
+    const float* __restrict__ anchors, int N, const float* __restrict__ gt, int M, int gt_cols, int cls,
+    const int* __restrict__ n_valid, float* __restrict__ amax, int* __restrict__ aarg,
+    int* __restrict__ gmax) {
+  const int b = blockIdx.y;
+  __shared__ AlignedBev s_g[TA_MAXGT];
+  __shared__ int s_ok[TA_MAXGT], s_gmax[TA_MAXGT];
+  const int nv = min(n_valid[b], M);
+  for (int j = threadIdx.x; j < nv; j += blockDim.x) {
+    const float* g = gt + ((long long)b * M + j) * gt_cols;
+    s_g[j] = aligned_bev(g);
+    s_ok[j] = (int)g[gt_cols - 1] == cls;
+    s_gmax[j] = 0;
+  }
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) {
+    const AlignedBev a = aligned_bev(anchors + (long long)i * 7);
+    float best = -1.f;
+    int arg = -1;
+    for (int j = 0; j < nv; ++j) {
+      if (!s_ok[j]) continue;
+      const float v = bev_iou(a, s_g[j]);
+      if (v > best) { best = v; arg = j; }                 // first maximum, as torch.argmax
+      if (v > 0.f) atomicMax(&s_gmax[j], __float_as_int(v));
+    }
+    amax[(long long)b * N + i] = best;
+    aarg[(long long)b * N + i] = arg;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < nv; j += blockDim.x)
+    if (s_gmax[j] > 0) atomicMax(&gmax[b * TA_MAXGT + j], s_gmax[j]);
+}
+
+__global__ __launch_bounds__(256) void k_assign_labels(
+    const float* __restrict__ anchors, int N, const float* __restrict__ gt, int M, int gt_cols, int cls,
+    float matched, float unmatched, const int* __restrict__ n_valid, const float* __restrict__ amax,
+    const int* __restrict__ aarg, const int* __restrict__ gmax, int* __restrict__ labels,
+    float* __restrict__ targets, int* __restrict__ num_examples) {
+  const int b = blockIdx.y;
+  __shared__ AlignedBev s_g[TA_MAXGT];
+  __shared__ int s_ok[TA_MAXGT];
+  __shared__ float s_gm[TA_MAXGT];
+  __shared__ int s_cnt;
+  const int nv = min(n_valid[b], M);
+  if (threadIdx.x == 0) s_cnt = 0;
+  for (int j = threadIdx.x; j < nv; j += blockDim.x) {
+    const float* g = gt + ((long long)b * M + j) * gt_cols;
+    s_g[j] = aligned_bev(g);
+    s_ok[j] = (int)g[gt_cols - 1] == cls;
+    const int gm = gmax[b * TA_MAXGT + j];
+    s_gm[j] = gm == 0 ? -1.f : __int_as_float(gm);          // a ground truth nobody overlaps matches nothing
+  }
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int lab = -2;
+  if (i < N) {
+    const float* an = anchors + (long long)i * 7;
+    const float best = amax[(long long)b * N + i];
+    const int arg = aarg[(long long)b * N + i];
+    float t[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (arg < 0) {
+      lab = 0;                                               // no ground truth of this class in the frame
+    } else {
+      const AlignedBev a = aligned_bev(an);
+      bool forced = false;
+      for (int j = 0; j < nv; ++j)
+        if (s_ok[j] && bev_iou(a, s_g[j]) == s_gm[j]) forced = true;
+      lab = (forced || best >= matched) ? cls : (best < unmatched ? 0 : -1);
+      if (lab > 0) {                                         // ResidualCoder.encode_torch(gt[arg], anchor)
+        const float* g = gt + ((long long)b * M + arg) * gt_cols;
+        const float dxa = fmaxf(an[3], 1e-5f), dya = fmaxf(an[4], 1e-5f), dza = fmaxf(an[5], 1e-5f);
+        const float dxg = fmaxf(g[3], 1e-5f), dyg = fmaxf(g[4], 1e-5f), dzg = fmaxf(g[5], 1e-5f);
+        const float diag = sqrtf(dxa * dxa + dya * dya);
+        t[0] = (g[0] - an[0]) / diag; t[1] = (g[1] - an[1]) / diag; t[2] = (g[2] - an[2]) / dza;
+        t[3] = logf(dxg / dxa); t[4] = logf(dyg / dya); t[5] = logf(dzg / dza);
+        t[6] = g[6] - an[6];
+      }
+    }
+    labels[(long long)b * N + i] = lab;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) targets[((long long)b * N + i) * 7 + k] = t[k];
+  }
+  const unsigned long long bal = __ballot(lab >= 0);
+  if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&s_cnt, __popcll(bal));
+  __syncthreads();
+  if (threadIdx.x == 0 && s_cnt) atomicAdd(&num_examples[b], s_cnt);
+}
+
+__global__ void k_assign_weights(const int* __restrict__ labels, int N, const int* __restrict__ num_examples,
+                                 int norm, float* __restrict__ w) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int n = num_examples[b];
+  const float pos = norm ? 1.0f / (float)(n > 1 ? n : 1) : 1.0f;
+  w[(long long)b * N + i] = labels[(long long)b * N + i] > 0 ? pos : 0.f;
+}
+
+extern "C" size_t glx_assign_targets_workspace_bytes(int B, int N) {
+  return glx_align((size_t)B * N * 8) + glx_align((size_t)B * (TA_MAXGT + 2) * 4) + 256;
+}
+
+extern "C" int glx_assign_targets(const float* anchors, int N, const float* gt_boxes, int B, int M,
+                                  int gt_cols, int class_id, float matched_threshold,
+                                  float unmatched_threshold, int norm_by_num_examples,
+                                  int32_t* box_cls_labels, float* box_reg_targets, float* reg_weights,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  if (B <= 0 || N <= 0) return GLX_OK;
+  GLX_REQUIRE(anchors && gt_boxes && box_cls_labels && box_reg_targets && reg_weights,
+              "glx_assign_targets: null pointer");
+  GLX_REQUIRE(M >= 1 && M <= TA_MAXGT && gt_cols >= 8 && B <= 65535,
+              "glx_assign_targets: 1..%d ground-truth rows of >= 8 columns (box + class)", TA_MAXGT);
+  const size_t need = glx_assign_targets_workspace_bytes(B, N) - 256;
+  if (!workspace || workspace_bytes < need) {
+    glx_set_error("glx_assign_targets: workspace %zu < %zu bytes", workspace_bytes, need);
+    return GLX_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* amax = (float*)workspace;
+  int* aarg = (int*)(amax + (size_t)B * N);
+  int* gmax = (int*)((char*)workspace + glx_align((size_t)B * N * 8));
+  int* n_valid = gmax + (size_t)B * TA_MAXGT;
+  int* num_examples = n_valid + B;
+  hipLaunchKernelGGL(k_assign_prepare, dim3(B), dim3(128), 0, st, gt_boxes, B, M, gt_cols, n_valid, gmax,
+                     num_examples);
+  const dim3 grid(glx_divup(N, 256), B);
+  hipLaunchKernelGGL(k_assign_iou_max, grid, dim3(256), 0, st, anchors, N, gt_boxes, M, gt_cols, class_id,
+                     (const int*)n_valid, amax, aarg, gmax);
+  hipLaunchKernelGGL(k_assign_labels, grid, dim3(256), 0, st, anchors, N, gt_boxes, M, gt_cols, class_id,
+                     matched_threshold, unmatched_threshold, (const int*)n_valid, (const float*)amax,
+                     (const int*)aarg, (const int*)gmax, box_cls_labels, box_reg_targets, num_examples);
+  hipLaunchKernelGGL(k_assign_weights, grid, dim3(256), 0, st, (const int*)box_cls_labels, N,
+                     (const int*)num_examples, norm_by_num_examples, reg_weights);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

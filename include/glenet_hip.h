@@ -410,6 +410,19 @@ int glx_corner_loss(const float* rcnn_reg, const float* rois, const float* gt_of
 int glx_roi_canonical_gt(const float* rois, int roi_cols, const float* gt_of_rois, int gt_cols, int R,
                          float* out, void* stream);
 
+/* Anchor target assignment of the dense head for ONE anchor class and all B frames: anchors (N,7)
+ * shared by the frames, gt_boxes (B, M <= 128, gt_cols >= 8) zero-padded, last column = class id
+ * (1-based).  Outputs per frame: box_cls_labels (B,N) int32 {class_id, 0, -1}, box_reg_targets
+ * (B,N,7), reg_weights (B,N).  No sampling (POS_FRACTION < 0), nearest-BEV IoU (match_height off).
+ * Replaces: AxisAlignedTargetAssigner.assign_targets_single + the per-frame trimming / class mask of
+ * assign_targets (pcdet/models/dense_heads/target_assigner/axis_aligned_target_assigner.py:36-213),
+ * box_utils.boxes3d_nearest_bev_iou and ResidualCoder.encode_torch. */
+size_t glx_assign_targets_workspace_bytes(int B, int N);
+int glx_assign_targets(const float* anchors, int N, const float* gt_boxes, int B, int M, int gt_cols,
+                       int class_id, float matched_threshold, float unmatched_threshold,
+                       int norm_by_num_examples, int32_t* box_cls_labels, float* box_reg_targets,
+                       float* reg_weights, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Training-mode BatchNorm1d (+ ReLU) over sparse-tensor features x (N, C), C a multiple of 4 that
  * divides 1024 (16 ... 512).  Semantics of nn.BatchNorm1d(eps, momentum) followed by nn.ReLU as

@@ -21,6 +21,8 @@ committed, this script is committed, nothing of the reference is copied.
   limit_period / boxes3d_to_bev_torch outputs of the reference are stored alongside.
   detector_glue_ref.npz  box coder, anchor generator and the two generate_predicted_boxes statement
                      sequences of the detection heads (see make_detector_glue_ref()).
+  target_assign_ref.npz  the reference's AxisAlignedTargetAssigner on a reduced feature map, two
+                     anchor classes, three frames (make_target_assign_ref()).
   kl_loss_ref.npz    GLENet's KL regression loss of the RoI head + gradients (make_kl_loss_ref()).
   dense_path_ref.npz the reference's dense-path modules (BEV backbone, CVAE networks, RoI-grid
                      geometry helpers) run on CPU: see make_dense_path_ref() for what is imported
@@ -463,8 +465,91 @@ def make_kl_loss_ref():
     print("kl_loss_ref.npz loss", float(loss), "fg", fg_sum)
 
 
+def make_target_assign_ref():
+    """target_assign_ref.npz: the reference's AxisAlignedTargetAssigner (imported unmodified from
+    pcdet/models/dense_heads/target_assigner/axis_aligned_target_assigner.py, with its own
+    box_utils.boxes3d_nearest_bev_iou and ResidualCoder) run on CPU: two anchor classes on a reduced
+    feature map, 3 frames (one without ground truth of the first class, one with zero padding only).
+    Placeholders, disclosed: `SharedArray`, the compiled extensions `iou3d_nms_cuda` and
+    `roiaware_pool3d_cuda` (imported by iou3d_nms_utils / box_utils, not called on this path) ->
+    empty modules; package __init__ files of pcdet.models.* are bypassed with path-only packages."""
+    gen = torch.Generator().manual_seed(909)
+    sys.modules.setdefault("SharedArray", types.ModuleType("SharedArray"))
+    for name, path in (("pcdet", "pcdet"), ("pcdet.utils", "pcdet/utils"), ("pcdet.ops", "pcdet/ops"),
+                       ("pcdet.ops.roiaware_pool3d", "pcdet/ops/roiaware_pool3d"),
+                       ("pcdet.ops.iou3d_nms", "pcdet/ops/iou3d_nms"), ("pcdet.models", "pcdet/models"),
+                       ("pcdet.models.dense_heads", "pcdet/models/dense_heads"),
+                       ("pcdet.models.dense_heads.target_assigner", "pcdet/models/dense_heads/target_assigner")):
+        m = sys.modules.get(name)
+        if m is None or not hasattr(m, "__path__"):
+            m = types.ModuleType(name)
+            sys.modules[name] = m
+        m.__path__ = [os.path.join(REF, path)]
+    for ext in ("pcdet.ops.roiaware_pool3d.roiaware_pool3d_cuda", "pcdet.ops.iou3d_nms.iou3d_nms_cuda"):
+        sys.modules.setdefault(ext, types.ModuleType(ext))
+    ata = importlib.import_module("pcdet.models.dense_heads.target_assigner.axis_aligned_target_assigner")
+    ag = _load_by_path("ref_anchor_generator2", "pcdet/models/dense_heads/target_assigner/anchor_generator.py")
+    bc = _load_by_path("ref_box_coder_utils3", "pcdet/utils/box_coder_utils.py")
+    gcfg = [dict(class_name="Car", anchor_sizes=[[3.9, 1.6, 1.56]], anchor_rotations=[0, 1.57],
+                 anchor_bottom_heights=[-1.78], align_center=False, feature_map_stride=8,
+                 matched_threshold=0.6, unmatched_threshold=0.45),
+            dict(class_name="Cyclist", anchor_sizes=[[1.76, 0.6, 1.73]], anchor_rotations=[0, 1.57],
+                 anchor_bottom_heights=[-0.6], align_center=False, feature_map_stride=8,
+                 matched_threshold=0.5, unmatched_threshold=0.35)]
+    rng_ = [0, -40.0, -3, 70.4, 40.0, 1]
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        anchors, _ = ag.AnchorGenerator(rng_, gcfg).generate_anchors([[44, 50], [44, 50]])
+    finally:
+        torch.Tensor.cuda = real_cuda
+    out = {}
+    for norm in (False, True):
+        cfg = Cfg(ANCHOR_GENERATOR_CONFIG=gcfg, TARGET_ASSIGNER_CONFIG=Cfg(POS_FRACTION=-1.0, SAMPLE_SIZE=512,
+                                                                         NORM_BY_NUM_EXAMPLES=norm,
+                                                                         MATCH_HEIGHT=False))
+        assigner = ata.AxisAlignedTargetAssigner(cfg, ["Car", "Pedestrian", "Cyclist"], bc.ResidualCoder(),
+                                                 match_height=False)
+        if not norm:
+            B, M = 3, 12
+            gt = torch.zeros(B, M, 8)
+            for b, n_gt in enumerate((9, 5, 0)):
+                ctr = torch.stack([torch.rand(n_gt, generator=gen) * 68 + 1, torch.rand(n_gt, generator=gen) * 76 - 38,
+                                   torch.rand(n_gt, generator=gen) * 1.0 - 1.5], -1)
+                cls = torch.randint(0, 2, (n_gt,), generator=gen) * 2 + 1            # 1 = Car, 3 = Cyclist
+                if b == 1:
+                    cls[:] = 3                                                       # no Car in frame 1
+                size = torch.where(cls[:, None] == 1, torch.tensor([[3.9, 1.6, 1.56]]), torch.tensor([[1.76, 0.6, 1.73]]))
+                size = size * (1 + torch.randn(n_gt, 3, generator=gen) * 0.08)
+                head = torch.rand(n_gt, 1, generator=gen) * 6.28 - 3.14
+                gt[b, :n_gt] = torch.cat([ctr, size, head, cls[:, None].float()], -1)
+            # one ground truth sits exactly on an anchor (IoU 1, several anchors tie on another one)
+            a0 = anchors[0].view(-1, 7)[1234]
+            gt[0, 0, :7] = a0
+            gt[0, 0, 7] = 1
+            # ground truths a little off an anchor: IoUs on both sides of the matched / unmatched thresholds
+            flat = anchors[0].view(-1, 7)
+            for r, (idx, jit) in enumerate(((777, 0.15), (2020, 0.3), (3131, 0.45), (4040, 0.6), (1515, 0.8)), start=1):
+                gt[0, r, :7] = flat[idx]
+                gt[0, r, 0] += jit
+                gt[0, r, 1] -= jit * 0.5
+                gt[0, r, 7] = 1
+            out["anchors_car"], out["anchors_cyc"], out["gt"] = anchors[0].numpy(), anchors[1].numpy(), gt.numpy()
+        res = assigner.assign_targets(anchors, gt.clone())
+        tag = "norm" if norm else "plain"
+        out["labels_" + tag] = res["box_cls_labels"].numpy()
+        out["targets_" + tag] = res["box_reg_targets"].numpy()
+        out["weights_" + tag] = res["reg_weights"].numpy()
+    np.savez_compressed(os.path.join(HERE, "target_assign_ref.npz"), **out)
+    lab = out["labels_plain"]
+    print("target_assign_ref.npz anchors/frame", lab.shape[1], "positives per frame", (lab > 0).sum(1),
+          "dont-care", (lab < 0).sum(1))
+
+
 if __name__ == "__main__":
-    only = sys.argv[1:] or ["iou3d", "nms", "dense", "glue", "kl"]
+    only = sys.argv[1:] or ["iou3d", "nms", "dense", "glue", "kl", "assign"]
+    if "assign" in only:
+        make_target_assign_ref()
     if "kl" in only:
         make_kl_loss_ref()
     if "glue" in only:
