@@ -48,3 +48,21 @@ t_ref = timeit(lambda: step(losses.canonical_gt_of_rois_torch, losses.kl_reg_los
 t_k = timeit(lambda: step(losses.canonical_gt_of_rois, losses.kl_reg_loss, losses.corner_loss))
 print("canonical transform + KL reg loss + corner loss, fwd+bwd, %d RoIs: tensor ops %.0f us -> fused kernels %.0f us"
       % (B * N, t_ref, t_k))
+
+# ---- anchor target assignment at the GLENet-VR size: 200 x 176 x 2 car anchors, 4 frames, 20 ground truths
+from glenet_amd import detector as det, target_assign  # noqa: E402
+anchors = det.generate_anchors([0, -40.0, -3, 70.4, 40.0, 1], (176, 200), [[3.9, 1.6, 1.56]], [0, 1.57], [-1.78], device=dev)
+gt = torch.zeros(4, 40, 8, device=dev)
+for b in range(4):
+    n = 20
+    gt[b, :n, 0] = torch.rand(n, device=dev) * 68 + 1
+    gt[b, :n, 1] = torch.rand(n, device=dev) * 76 - 38
+    gt[b, :n, 2] = -1.0
+    gt[b, :n, 3:6] = torch.tensor([3.9, 1.6, 1.56], device=dev) * (1 + torch.randn(n, 3, device=dev) * 0.05)
+    gt[b, :n, 6] = torch.rand(n, device=dev) * 6.28 - 3.14
+    gt[b, :n, 7] = 1
+fn = lambda: target_assign.assign_targets([anchors], gt, [1], [0.6], [0.45])   # noqa: E731
+out = fn()
+lab = out["box_cls_labels"]
+print("anchor target assignment, 4 frames x %d anchors x 20 ground truths: %.0f us; positives/frame %s"
+      % (lab.shape[1], timeit(fn), (lab > 0).sum(1).tolist()))
