@@ -10,6 +10,7 @@
 // step; here one block computes the loss, its three reported parts and both gradients (d/dreg,
 // d/dreg_std) in two passes over the (R, 7) elements, sums in fp64 in a fixed tree order.
 #include "glx_common.h"
+#include "glx_fill.h"
 
 #define KL_THREADS 256
 
@@ -433,6 +434,175 @@ extern "C" int glx_assign_targets(const float* anchors, int N, const float* gt_b
                      (const int*)aarg, (const int*)gmax, box_cls_labels, box_reg_targets, num_examples);
   hipLaunchKernelGGL(k_assign_weights, grid, dim3(256), 0, st, (const int*)box_cls_labels, N,
                      (const int*)num_examples, norm_by_num_examples, reg_weights);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// ------------------------------------------------------------------ dense (anchor) head loss
+// AnchorHeadTemplate.get_loss (pcdet/models/dense_heads/anchor_head_template.py:108-232) for a
+// class-count C head with NUM_DIR_BINS = 2, all three terms and their gradients:
+//   cls: SigmoidFocalClassificationLoss(alpha, gamma = 2) on the logits against the one-hot of the
+//        anchor's label (don't-care anchors have weight 0), weights 1 / max(#positives of the frame, 1);
+//   loc: add_sin_difference on the heading channel, code-weighted smooth-L1 (beta 1/9), positives only,
+//        same normaliser;
+//   dir: 2-bin softmax cross-entropy of the direction logits against
+//        floor(limit_period(target_heading + anchor_heading - dir_offset, 0, 2 pi) / pi), positives only.
+// Each term is summed over anchors and frames and divided by the batch size, then weighted.
+// Pass 1 counts the positives per frame, pass 2 writes per-block partial sums (fp64) and the three
+// gradients, pass 3 reduces the partials in a fixed order.
+#define RPN_THREADS 256
+
+__global__ void k_rpn_count_pos(const int* __restrict__ labels, int A, int* __restrict__ npos) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool pos = i < A && labels[(long long)b * A + i] > 0;
+  const unsigned long long bal = __ballot(pos);
+  if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&npos[b], __popcll(bal));
+}
+
+struct RpnParams {
+  float alpha, beta, dir_offset, cls_w, loc_w, dir_w;
+  float cw[7];
+  int num_class, class_agnostic;
+};
+
+__global__ __launch_bounds__(RPN_THREADS) void k_rpn_loss(
+    const float* __restrict__ cls_preds, const float* __restrict__ box_preds,
+    const float* __restrict__ dir_preds, const int* __restrict__ labels,
+    const float* __restrict__ reg_targets, const float* __restrict__ anchors, int B, int A,
+    const int* __restrict__ npos, RpnParams p, double* __restrict__ partial,
+    float* __restrict__ g_cls, float* __restrict__ g_box, float* __restrict__ g_dir) {
+  __shared__ double red[RPN_THREADS];
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int C = p.num_class;
+  double l_cls = 0, l_loc = 0, l_dir = 0;
+  if (i < A) {
+    const long long e = (long long)b * A + i;
+    int lab = labels[e];
+    const float norm = 1.0f / fmaxf((float)npos[b], 1.0f);
+    const bool pos = lab > 0;
+    const float w_cls = lab >= 0 ? norm : 0.f;               // positives and negatives, not don't-care
+    if (p.class_agnostic && pos) lab = 1;
+    const float inv_b = 1.0f / (float)B;
+    // ---- classification
+    for (int c = 0; c < C; ++c) {
+      const float x = cls_preds[e * C + c];
+      const float z = (lab == c + 1) ? 1.f : 0.f;
+      const float ps = 1.f / (1.f + expf(-x));
+      const float aw = z * p.alpha + (1.f - z) * (1.f - p.alpha);
+      const float pt = z * (1.f - ps) + (1.f - z) * ps;
+      const float bce = fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));
+      l_cls += (double)(aw * (pt * pt) * bce * w_cls);
+      if (g_cls) {
+        const float dpt = (1.f - 2.f * z) * ps * (1.f - ps);
+        g_cls[e * C + c] = w_cls * aw * (2.f * pt * dpt * bce + pt * pt * (ps - z)) * inv_b * p.cls_w;
+      }
+    }
+    // ---- localisation + direction (positives only)
+    float gb[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gd0 = 0.f, gd1 = 0.f;
+    if (pos) {
+      const float* bp = box_preds + e * 7;
+      const float* tg = reg_targets + e * 7;
+      for (int k = 0; k < 7; ++k) {
+        float diff, dd = 1.f;
+        if (k == 6) {
+          const float sa = sinf(bp[6]), ca = cosf(bp[6]), sb = sinf(tg[6]), cb = cosf(tg[6]);
+          diff = sa * cb - ca * sb;
+          dd = ca * cb + sa * sb;
+        } else {
+          float t = tg[k];
+          if (isnan(t)) t = bp[k];
+          diff = bp[k] - t;
+        }
+        diff *= p.cw[k];
+        const float n = fabsf(diff);
+        l_loc += (double)((n < p.beta ? 0.5f * n * n / p.beta : n - 0.5f * p.beta) * norm);
+        const float ds = n < p.beta ? diff / p.beta : (diff > 0.f ? 1.f : -1.f);
+        gb[k] = ds * p.cw[k] * dd * norm * inv_b * p.loc_w;
+      }
+      if (dir_preds) {
+        const float TWO_PI = (float)(2.0 * 3.14159265358979323846);
+        const float rot = tg[6] + anchors[(long long)i * 7 + 6];
+        const float v = rot - p.dir_offset;
+        const float off = v - floorf(v / TWO_PI + 0.f) * TWO_PI;
+        int bin = (int)floorf(off / (float)(2.0 * 3.14159265358979323846 / 2));
+        bin = bin < 0 ? 0 : (bin > 1 ? 1 : bin);
+        const float d0 = dir_preds[e * 2], d1 = dir_preds[e * 2 + 1];
+        const float m = fmaxf(d0, d1);
+        const float lse = m + logf(expf(d0 - m) + expf(d1 - m));
+        l_dir += (double)((lse - (bin ? d1 : d0)) * norm);
+        const float s0 = expf(d0 - lse), s1 = expf(d1 - lse);
+        gd0 = (s0 - (bin == 0 ? 1.f : 0.f)) * norm * inv_b * p.dir_w;
+        gd1 = (s1 - (bin == 1 ? 1.f : 0.f)) * norm * inv_b * p.dir_w;
+      }
+    }
+    if (g_box) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) g_box[e * 7 + k] = gb[k];
+    }
+    if (g_dir) { g_dir[e * 2] = gd0; g_dir[e * 2 + 1] = gd1; }
+  }
+  const long long blk = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+  const double a = kl_block_sum(l_cls, red), c = kl_block_sum(l_loc, red), d = kl_block_sum(l_dir, red);
+  if (threadIdx.x == 0) { partial[blk * 3] = a; partial[blk * 3 + 1] = c; partial[blk * 3 + 2] = d; }
+}
+
+__global__ __launch_bounds__(RPN_THREADS) void k_rpn_finish(const double* __restrict__ partial, int nblk,
+                                                            int B, RpnParams p, float* __restrict__ out) {
+  __shared__ double red[RPN_THREADS];
+  double s[3] = {0, 0, 0};
+  for (int i = threadIdx.x; i < nblk; i += RPN_THREADS)
+    for (int k = 0; k < 3; ++k) s[k] += partial[(long long)i * 3 + k];
+  const double a = kl_block_sum(s[0], red), c = kl_block_sum(s[1], red), d = kl_block_sum(s[2], red);
+  if (threadIdx.x == 0) {
+    out[1] = (float)(a / B) * p.cls_w;
+    out[2] = (float)(c / B) * p.loc_w;
+    out[3] = (float)(d / B) * p.dir_w;
+    out[0] = out[1] + out[2] + out[3];
+  }
+}
+
+extern "C" size_t glx_rpn_loss_workspace_bytes(int B, int A) {
+  return glx_align((size_t)B * glx_divup(A, RPN_THREADS) * 3 * sizeof(double)) + glx_align((size_t)B * 4) + 256;
+}
+
+extern "C" int glx_rpn_loss(const float* cls_preds, const float* box_preds, const float* dir_preds,
+                            const int32_t* box_cls_labels, const float* box_reg_targets,
+                            const float* anchors, int B, int A, int num_class, int class_agnostic,
+                            float alpha, float beta, const float* code_weights, float dir_offset,
+                            float cls_weight, float loc_weight, float dir_weight, float* out4,
+                            float* grad_cls, float* grad_box, float* grad_dir, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(out4, "glx_rpn_loss: null output");
+  if (B <= 0 || A <= 0) return GLX_OK;
+  GLX_REQUIRE(cls_preds && box_preds && box_cls_labels && box_reg_targets && (anchors || !dir_preds),
+              "glx_rpn_loss: null pointer");
+  GLX_REQUIRE(num_class >= 1 && B <= 65535, "glx_rpn_loss: bad sizes");
+  const size_t need = glx_rpn_loss_workspace_bytes(B, A) - 256;
+  if (!workspace || workspace_bytes < need) {
+    glx_set_error("glx_rpn_loss: workspace %zu < %zu bytes", workspace_bytes, need);
+    return GLX_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int nbx = glx_divup(A, RPN_THREADS);
+  double* partial = (double*)workspace;
+  int* npos = (int*)((char*)workspace + glx_align((size_t)B * nbx * 3 * sizeof(double)));
+  GlxFillJob job{npos, (size_t)B * sizeof(int), 0};
+  int rc = glx_fill_multi(&job, 1, st);
+  if (rc != GLX_OK) return rc;
+  RpnParams p;
+  p.alpha = alpha; p.beta = beta; p.dir_offset = dir_offset;
+  p.cls_w = cls_weight; p.loc_w = loc_weight; p.dir_w = dir_weight;
+  for (int k = 0; k < 7; ++k) p.cw[k] = code_weights ? code_weights[k] : 1.f;
+  p.num_class = num_class; p.class_agnostic = class_agnostic;
+  const dim3 grid(nbx, B);
+  hipLaunchKernelGGL(k_rpn_count_pos, grid, dim3(RPN_THREADS), 0, st, box_cls_labels, A, npos);
+  hipLaunchKernelGGL(k_rpn_loss, grid, dim3(RPN_THREADS), 0, st, cls_preds, box_preds, dir_preds,
+                     box_cls_labels, box_reg_targets, anchors, B, A, (const int*)npos, p, partial, grad_cls,
+                     grad_box, grad_dir);
+  hipLaunchKernelGGL(k_rpn_finish, dim3(1), dim3(RPN_THREADS), 0, st, (const double*)partial, nbx * B, B, p,
+                     out4);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

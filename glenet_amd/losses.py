@@ -177,3 +177,55 @@ def canonical_gt_of_rois(rois, gt_of_rois):
     out = torch.empty_like(g)
     _lib.call("glx_roi_canonical_gt", a, a.shape[-1], g, g.shape[-1], r, out)
     return out
+
+
+# ------------------------------------------------------------------ dense (anchor) head loss
+class _RpnLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cls_preds, box_preds, dir_preds, labels, reg_targets, anchors, cfg):
+        from ._lib import query, size_arg, workspace
+        B, A = labels.shape
+        cp = cls_preds.reshape(B, A, -1).contiguous().float()
+        bp = box_preds.reshape(B, A, 7).contiguous().float()
+        dp = dir_preds.reshape(B, A, 2).contiguous().float() if dir_preds is not None else None
+        lab = labels.contiguous().int()
+        tg = reg_targets.reshape(B, A, 7).contiguous().float()
+        an = anchors.reshape(-1, anchors.shape[-1])[:, 0:7].contiguous().float()
+        _lib.check_cuda(cp, bp, dp, lab, tg, an)
+        out = torch.empty(4, dtype=torch.float32, device=cp.device)
+        g_cls, g_box = torch.empty_like(cp), torch.empty_like(bp)
+        g_dir = torch.empty_like(dp) if dp is not None else None
+        cw = (ctypes.c_float * 7)(*[float(v) for v in cfg["code_weights"]])
+        ws = workspace.get(query("glx_rpn_loss_workspace_bytes", B, A), cp.device)
+        _lib.call("glx_rpn_loss", cp, bp, dp, lab, tg, an, B, A, cp.shape[-1], 1 if cp.shape[-1] == 1 else 0,
+                  ctypes.c_float(cfg["alpha"]), ctypes.c_float(cfg["beta"]), cw, ctypes.c_float(cfg["dir_offset"]),
+                  ctypes.c_float(cfg["cls_weight"]), ctypes.c_float(cfg["loc_weight"]), ctypes.c_float(cfg["dir_weight"]),
+                  out, g_cls, g_box, g_dir, ws, size_arg(ws.numel()))
+        ctx.save_for_backward(g_cls, g_box, g_dir if g_dir is not None else g_box)
+        ctx.has_dir = g_dir is not None
+        ctx.shapes = (cls_preds.shape, box_preds.shape, dir_preds.shape if dir_preds is not None else None)
+        return out[0], out[1:4]
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_parts):
+        g_cls, g_box, g_dir = ctx.saved_tensors
+        s = ctx.shapes
+        return ((g_cls * g_loss).reshape(s[0]), (g_box * g_loss).reshape(s[1]),
+                (g_dir * g_loss).reshape(s[2]) if ctx.has_dir else None, None, None, None, None)
+
+
+def rpn_loss(cls_preds, box_preds, dir_preds, box_cls_labels, box_reg_targets, anchors, code_weights=(1.0,) * 7,
+             cls_weight=1.0, loc_weight=2.0, dir_weight=0.2, dir_offset=0.78539, alpha=0.25, beta=1.0 / 9.0):
+    """AnchorHeadTemplate.get_loss on the device in three launches: cls_preds (B,H,W,A*C), box_preds
+    (B,H,W,A*7), dir_preds (B,H,W,A*2) or None, box_cls_labels (B,N) int, box_reg_targets (B,N,7), anchors
+    (..., 7) with N entries -> (rpn_loss, {'rpn_loss_cls','rpn_loss_loc','rpn_loss_dir'}) as device scalars
+    (no `.item()`), gradients through autograd.  Defaults = GLENet_VR.yaml:84-90, DIR_OFFSET 0.78539,
+    2 direction bins."""
+    B, N = box_cls_labels.shape
+    cfg = dict(code_weights=code_weights, cls_weight=cls_weight, loc_weight=loc_weight, dir_weight=dir_weight,
+               dir_offset=dir_offset, alpha=alpha, beta=beta)
+    loss, parts = _RpnLoss.apply(cls_preds.reshape(B, N, -1), box_preds.reshape(B, N, 7),
+                                 dir_preds.reshape(B, N, 2) if dir_preds is not None else None, box_cls_labels,
+                                 box_reg_targets, anchors, cfg)
+    parts = parts.detach()
+    return loss, {"rpn_loss_cls": parts[0], "rpn_loss_loc": parts[1], "rpn_loss_dir": parts[2]}

@@ -423,6 +423,21 @@ int glx_assign_targets(const float* anchors, int N, const float* gt_boxes, int B
                        int norm_by_num_examples, int32_t* box_cls_labels, float* box_reg_targets,
                        float* reg_weights, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Loss of the dense (anchor) head and its gradients: cls_preds (B,A,num_class) logits, box_preds
+ * (B,A,7), dir_preds (B,A,2) or NULL, box_cls_labels (B,A) int32 {class, 0, -1}, box_reg_targets
+ * (B,A,7), anchors (A,7).  out4 (device) = { total, cls, loc, dir } already weighted; grad_* (same
+ * shapes as the predictions, may be NULL) = d total / d prediction.  code_weights: HOST float[7]/NULL.
+ * Replaces: AnchorHeadTemplate.get_cls_layer_loss / get_box_reg_layer_loss / get_loss
+ * (pcdet/models/dense_heads/anchor_head_template.py:108-232) with SigmoidFocalClassificationLoss,
+ * WeightedSmoothL1Loss and WeightedCrossEntropyLoss (pcdet/utils/loss_utils.py:7-207). */
+size_t glx_rpn_loss_workspace_bytes(int B, int A);
+int glx_rpn_loss(const float* cls_preds, const float* box_preds, const float* dir_preds,
+                 const int32_t* box_cls_labels, const float* box_reg_targets, const float* anchors,
+                 int B, int A, int num_class, int class_agnostic, float alpha, float beta,
+                 const float* code_weights, float dir_offset, float cls_weight, float loc_weight,
+                 float dir_weight, float* out4, float* grad_cls, float* grad_box, float* grad_dir,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Training-mode BatchNorm1d (+ ReLU) over sparse-tensor features x (N, C), C a multiple of 4 that
  * divides 1024 (16 ... 512).  Semantics of nn.BatchNorm1d(eps, momentum) followed by nn.ReLU as

@@ -540,8 +540,47 @@ def make_target_assign_ref():
         out["labels_" + tag] = res["box_cls_labels"].numpy()
         out["targets_" + tag] = res["box_reg_targets"].numpy()
         out["weights_" + tag] = res["reg_weights"].numpy()
+    # ---- loss of the dense head on these targets: the reference's AnchorHeadTemplate methods
+    # (get_cls_layer_loss / get_box_reg_layer_loss / get_loss, anchor_head_template.py:108-232) called
+    # UNMODIFIED on an instance created without __init__ (the constructor needs the whole model
+    # config and calls .cuda()); its attributes are set by hand, the loss modules are the reference's.
+    aht = importlib.import_module("pcdet.models.dense_heads.anchor_head_template")
+    loss_utils = importlib.import_module("pcdet.utils.loss_utils")
+    head = object.__new__(aht.AnchorHeadTemplate)
+    torch.nn.Module.__init__(head)
+    code_weights = [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        head.build_losses(Cfg(LOSS_WEIGHTS={"code_weights": code_weights}))
+    finally:
+        torch.Tensor.cuda = real_cuda
+    car = [anchors[0]]
+    res = ata.AxisAlignedTargetAssigner(
+        Cfg(ANCHOR_GENERATOR_CONFIG=gcfg[:1], TARGET_ASSIGNER_CONFIG=Cfg(POS_FRACTION=-1.0, SAMPLE_SIZE=512,
+                                                                         NORM_BY_NUM_EXAMPLES=False, MATCH_HEIGHT=False)),
+        ["Car", "Pedestrian", "Cyclist"], bc.ResidualCoder(), match_height=False).assign_targets(car, gt.clone())
+    Bn, A = res["box_cls_labels"].shape
+    cls_preds = (torch.randn(Bn, 50, 44, 2, generator=gen) * 2).requires_grad_(True)
+    box_preds = (torch.randn(Bn, 50, 44, 14, generator=gen) * 0.3).requires_grad_(True)
+    dir_preds = torch.randn(Bn, 50, 44, 4, generator=gen).requires_grad_(True)
+    head.num_class, head.num_anchors_per_location, head.use_multihead = 1, 2, False
+    head.anchors = car
+    head.model_cfg = Cfg(DIR_OFFSET=0.78539, NUM_DIR_BINS=2,
+                         LOSS_CONFIG=Cfg(LOSS_WEIGHTS={"cls_weight": 1.0, "loc_weight": 2.0, "dir_weight": 0.2,
+                                                       "code_weights": code_weights}))
+    head.forward_ret_dict = dict(cls_preds=cls_preds, box_preds=box_preds, dir_cls_preds=dir_preds,
+                                 box_cls_labels=res["box_cls_labels"].clone(), box_reg_targets=res["box_reg_targets"])
+    rpn_loss, tb = head.get_loss()
+    rpn_loss.backward()
+    out.update(rpn_labels=res["box_cls_labels"].numpy(), rpn_targets=res["box_reg_targets"].numpy(),
+               rpn_cls_preds=cls_preds.detach().numpy(), rpn_box_preds=box_preds.detach().numpy(),
+               rpn_dir_preds=dir_preds.detach().numpy(), rpn_loss=np.float32(tb["rpn_loss"]),
+               rpn_loss_cls=np.float32(tb["rpn_loss_cls"]), rpn_loss_loc=np.float32(tb["rpn_loss_loc"]),
+               rpn_loss_dir=np.float32(tb["rpn_loss_dir"]), rpn_grad_cls=cls_preds.grad.numpy(),
+               rpn_grad_box=box_preds.grad.numpy(), rpn_grad_dir=dir_preds.grad.numpy())
     np.savez_compressed(os.path.join(HERE, "target_assign_ref.npz"), **out)
     lab = out["labels_plain"]
+    print("rpn loss", tb)
     print("target_assign_ref.npz anchors/frame", lab.shape[1], "positives per frame", (lab > 0).sum(1),
           "dont-care", (lab < 0).sum(1))
 

@@ -27,3 +27,25 @@ def test_anchor_target_assignment_matches_reference_golden(dev, norm):
     np.testing.assert_allclose(out["box_reg_targets"].cpu().numpy(), G["targets_" + tag], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(out["reg_weights"].cpu().numpy(), G["weights_" + tag], rtol=1e-7, atol=0)
     assert (lab > 0).sum() > 10 and (lab < 0).sum() > 0 and (lab[2] == 0).all()
+
+
+def test_dense_head_loss_kernel_matches_reference_golden(dev):
+    """glx_rpn_loss (focal classification + sin-difference smooth-L1 + direction cross-entropy, all
+    gradients) vs the reference's AnchorHeadTemplate.get_loss called unmodified on the same tensors
+    (fixture: make_golden.py assign); targets come from our own assignment of the same ground truth."""
+    from glenet_amd import losses
+    anchors = torch.from_numpy(G["anchors_car"]).to(dev)
+    tgt = target_assign.assign_targets([anchors], torch.from_numpy(G["gt"]).to(dev), [1], [0.6], [0.45])
+    assert np.array_equal(tgt["box_cls_labels"].cpu().numpy(), G["rpn_labels"])
+    cls = torch.from_numpy(G["rpn_cls_preds"]).to(dev).requires_grad_(True)
+    box = torch.from_numpy(G["rpn_box_preds"]).to(dev).requires_grad_(True)
+    dr = torch.from_numpy(G["rpn_dir_preds"]).to(dev).requires_grad_(True)
+    loss, parts = losses.rpn_loss(cls, box, dr, tgt["box_cls_labels"], tgt["box_reg_targets"], anchors)
+    np.testing.assert_allclose(float(loss.detach()), float(G["rpn_loss"]), rtol=2e-5)
+    for k in ("rpn_loss_cls", "rpn_loss_loc", "rpn_loss_dir"):
+        np.testing.assert_allclose(float(parts[k]), float(G[k]), rtol=2e-5, atol=1e-7)
+    loss.backward()
+    for t, k in ((cls, "rpn_grad_cls"), (box, "rpn_grad_box"), (dr, "rpn_grad_dir")):
+        w = G[k]
+        np.testing.assert_allclose(t.grad.cpu().numpy(), w, rtol=1e-4, atol=1e-6 * max(1e-3, np.abs(w).max()))
+        assert np.abs(w).max() > 0
