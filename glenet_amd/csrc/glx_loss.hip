@@ -606,3 +606,39 @@ extern "C" int glx_rpn_loss(const float* cls_preds, const float* box_preds, cons
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
+
+// ------------------------------------------------------------------ RoI classification loss
+// RoIHeadTemplate.get_box_cls_layer_loss, CLS_LOSS = BinaryCrossEntropy (roi_head_template.py:246-272):
+// F.binary_cross_entropy(sigmoid(rcnn_cls), soft IoU labels) over the RoIs whose label is >= 0,
+// divided by max(#valid, 1); torch's conventions kept: log terms clamped at -100, the gradient's
+// p(1-p) denominator clamped at 1e-12.  One block, loss + gradient.
+__global__ __launch_bounds__(KL_THREADS) void k_rcnn_cls_loss(const float* __restrict__ logits,
+                                                              const float* __restrict__ labels, int R,
+                                                              float weight, float* __restrict__ out,
+                                                              float* __restrict__ grad) {
+  __shared__ double red[KL_THREADS];
+  double c = 0;
+  for (int i = threadIdx.x; i < R; i += KL_THREADS) c += labels[i] >= 0.f ? 1.0 : 0.0;
+  const double nv = kl_block_sum(c, red);
+  const float scale = weight / (float)(nv > 1.0 ? nv : 1.0);
+  double acc = 0;
+  for (int i = threadIdx.x; i < R; i += KL_THREADS) {
+    const float y = labels[i];
+    const float p = 1.f / (1.f + expf(-logits[i]));
+    const float m = y >= 0.f ? 1.f : 0.f;
+    const float l = -(y * fmaxf(logf(p), -100.f) + (1.f - y) * fmaxf(logf(1.f - p), -100.f));
+    acc += (double)(l * m);
+    if (grad) grad[i] = m * (p - y) / fmaxf((1.f - p) * p, 1e-12f) * (p * (1.f - p)) * scale;
+  }
+  const double total = kl_block_sum(acc, red);
+  if (threadIdx.x == 0) { out[0] = (float)total * scale; out[1] = (float)nv; }
+}
+
+extern "C" int glx_rcnn_cls_loss(const float* rcnn_cls, const float* rcnn_cls_labels, int R, float weight,
+                                 float* out2, float* grad, void* stream) {
+  GLX_REQUIRE(out2 && (R == 0 || (rcnn_cls && rcnn_cls_labels)), "glx_rcnn_cls_loss: null pointer");
+  hipLaunchKernelGGL(k_rcnn_cls_loss, dim3(1), dim3(KL_THREADS), 0, (hipStream_t)stream, rcnn_cls,
+                     rcnn_cls_labels, R, weight, out2, grad);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

@@ -229,3 +229,33 @@ def rpn_loss(cls_preds, box_preds, dir_preds, box_cls_labels, box_reg_targets, a
                                  box_reg_targets, anchors, cfg)
     parts = parts.detach()
     return loss, {"rpn_loss_cls": parts[0], "rpn_loss_loc": parts[1], "rpn_loss_dir": parts[2]}
+
+
+# ------------------------------------------------------------------ RoI classification loss
+class _RcnnClsLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rcnn_cls, labels, weight):
+        x, y = rcnn_cls.reshape(-1).contiguous().float(), labels.reshape(-1).contiguous().float()
+        _lib.check_cuda(x, y)
+        out = torch.empty(2, dtype=torch.float32, device=x.device)
+        g = torch.empty_like(x)
+        _lib.call("glx_rcnn_cls_loss", x, y, x.shape[0], ctypes.c_float(weight), out, g)
+        ctx.save_for_backward(g)
+        ctx.shape = rcnn_cls.shape
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        (g,) = ctx.saved_tensors
+        return (g * g_loss).reshape(ctx.shape), None, None
+
+
+def rcnn_cls_loss(rcnn_cls, rcnn_cls_labels, weight=1.0):
+    """get_box_cls_layer_loss with CLS_LOSS = BinaryCrossEntropy; CPU tensors take the reference's
+    tensor-op formula."""
+    if not rcnn_cls.is_cuda:
+        flat, lab = rcnn_cls.view(-1), rcnn_cls_labels.view(-1)
+        bl = torch.nn.functional.binary_cross_entropy(torch.sigmoid(flat), lab.float().clamp(min=0), reduction="none")
+        valid = (lab >= 0).float()
+        return (bl * valid).sum() / torch.clamp(valid.sum(), min=1.0) * weight
+    return _RcnnClsLoss.apply(rcnn_cls, rcnn_cls_labels, float(weight))

@@ -438,6 +438,12 @@ int glx_rpn_loss(const float* cls_preds, const float* box_preds, const float* di
                  float dir_weight, float* out4, float* grad_cls, float* grad_box, float* grad_dir,
                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* RoI classification loss (BinaryCrossEntropy on soft IoU labels, label < 0 = ignored): rcnn_cls (R)
+ * logits, rcnn_cls_labels (R) float.  out2 (device) = { loss * weight, #valid }; grad (R) or NULL.
+ * Replaces: RoIHeadTemplate.get_box_cls_layer_loss (pcdet/models/roi_heads/roi_head_template.py:246-272). */
+int glx_rcnn_cls_loss(const float* rcnn_cls, const float* rcnn_cls_labels, int R, float weight,
+                      float* out2, float* grad, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Training-mode BatchNorm1d (+ ReLU) over sparse-tensor features x (N, C), C a multiple of 4 that
  * divides 1024 (16 ... 512).  Semantics of nn.BatchNorm1d(eps, momentum) followed by nn.ReLU as

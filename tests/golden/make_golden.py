@@ -460,6 +460,32 @@ def make_kl_loss_ref():
     heading_label = torch.clamp(heading_label, min=-np.pi / 2, max=np.pi / 2)
     gt_of_rois[:, :, 6] = heading_label
     out.update(canon_rois=rois_c.numpy(), canon_gt=gt_c.numpy(), canon_out=gt_of_rois.numpy())
+    # ---- RoI classification loss: RoIHeadTemplate.get_box_cls_layer_loss called unmodified on an
+    # instance created without its constructor (roi_head_template.py:246-272)
+    for name, path in (("pcdet.models", "pcdet/models"), ("pcdet.models.roi_heads", "pcdet/models/roi_heads"),
+                       ("pcdet.models.roi_heads.target_assigner", "pcdet/models/roi_heads/target_assigner"),
+                       ("pcdet.models.model_utils", "pcdet/models/model_utils"),
+                       ("pcdet.ops.iou3d_nms", "pcdet/ops/iou3d_nms")):
+        m = sys.modules.get(name)
+        if m is None or not hasattr(m, "__path__"):
+            m = types.ModuleType(name)
+            sys.modules[name] = m
+        m.__path__ = [os.path.join(REF, path)]
+    sys.modules.setdefault("pcdet.ops.iou3d_nms.iou3d_nms_cuda", types.ModuleType("pcdet.ops.iou3d_nms.iou3d_nms_cuda"))
+    rht = importlib.import_module("pcdet.models.roi_heads.roi_head_template")
+    rhead = object.__new__(rht.RoIHeadTemplate)
+    torch.nn.Module.__init__(rhead)
+    rhead.model_cfg = Cfg(LOSS_CONFIG=Cfg(CLS_LOSS="BinaryCrossEntropy", LOSS_WEIGHTS={"rcnn_cls_weight": 1.0}))
+    cls_logits = (torch.randn(B * N, 1, generator=gen) * 2.5).requires_grad_(True)
+    cls_logits.data[3] = 40.0                                  # saturated: p(1-p) under the 1e-12 clamp
+    cls_labels = torch.rand(B, N, generator=gen)
+    cls_labels[cls_labels < 0.25] = 0.0
+    cls_labels[cls_labels > 0.8] = 1.0
+    # (no -1 labels: CLS_SCORE_TYPE roi_iou never produces them and torch's BCE rejects them)
+    l_cls, tb_cls = rhead.get_box_cls_layer_loss(dict(rcnn_cls=cls_logits, rcnn_cls_labels=cls_labels))
+    l_cls.backward()
+    out.update(cls_logits=cls_logits.detach().numpy(), cls_labels=cls_labels.numpy(),
+               cls_loss=np.float32(tb_cls["rcnn_loss_cls"]), cls_grad=cls_logits.grad.numpy())
     out.update(corner)
     np.savez_compressed(os.path.join(HERE, "kl_loss_ref.npz"), **out)
     print("kl_loss_ref.npz loss", float(loss), "fg", fg_sum)

@@ -93,3 +93,30 @@ def test_canonical_gt_kernel_matches_reference_golden(dev):
     got = losses.canonical_gt_of_rois(torch.from_numpy(G["canon_rois"]).to(dev), torch.from_numpy(G["canon_gt"]).to(dev))
     assert got.shape == G["canon_out"].shape
     _canon_close(got.cpu().numpy(), G["canon_out"])
+
+
+def test_rcnn_cls_loss_tensor_ops_match_reference_golden():
+    x = torch.from_numpy(G["cls_logits"]).requires_grad_(True)
+    loss = losses.rcnn_cls_loss(x, torch.from_numpy(G["cls_labels"]))
+    np.testing.assert_allclose(float(loss.detach()), float(G["cls_loss"]), rtol=1e-6)
+    loss.backward()
+    np.testing.assert_allclose(x.grad.numpy(), G["cls_grad"], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_rcnn_cls_loss_kernel_matches_reference_golden(dev):
+    x = torch.from_numpy(G["cls_logits"]).to(dev).requires_grad_(True)
+    loss = losses.rcnn_cls_loss(x, torch.from_numpy(G["cls_labels"]).to(dev))
+    np.testing.assert_allclose(float(loss.detach()), float(G["cls_loss"]), rtol=2e-6)
+    loss.backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), G["cls_grad"], rtol=2e-5, atol=1e-9)
+    # ignored RoIs (label -1, CLS_SCORE_TYPE cls): out of the sum, the count and the gradient
+    lab = torch.from_numpy(G["cls_labels"]).to(dev).clone()
+    lab[0, 5:25] = -1
+    x2 = x.detach().clone().requires_grad_(True)
+    l2 = losses.rcnn_cls_loss(x2, lab)
+    keep = (lab.reshape(-1) >= 0)
+    want = torch.nn.functional.binary_cross_entropy(torch.sigmoid(x2.detach().reshape(-1)[keep]), lab.reshape(-1)[keep])
+    np.testing.assert_allclose(float(l2.detach()), float(want), rtol=1e-5)
+    l2.backward()
+    assert float(x2.grad.reshape(2, -1)[0, 5:25].abs().max()) == 0.0
