@@ -312,9 +312,12 @@ class StaticTrainPipeline(StaticFramePipeline):
     dense head's loss).  Parameter gradients are left in `.grad` (rewritten by every replay)."""
 
     def __init__(self, model, cfg, batch_size, num_points, num_features, loss_fn=None, optimizer=None,
-                 train_voxel_cap=True, capacities=None, device=None):
+                 train_voxel_cap=True, capacities=None, device=None, extra_modules=()):
+        """extra_modules: further nn.Modules whose parameters loss_fn trains (e.g. the BEV backbone
+        and dense head behind the sparse backbone); their gradients are reset with the backbone's."""
         super().__init__(model, cfg, batch_size, num_points, num_features,
                          train_voxel_cap=train_voxel_cap, capacities=capacities, device=device)
+        self.extra_modules = tuple(extra_modules)
         self.loss_fn = loss_fn if loss_fn is not None else (lambda bd: bd["spatial_features"].square().mean())
         self.optimizer = optimizer
         self.loss = None
@@ -345,6 +348,8 @@ class StaticTrainPipeline(StaticFramePipeline):
                 bd = self.vfe(bd)
             bd["rule_plan"] = plan
             self.model.zero_grad(set_to_none=True)      # .grad tensors are (re)created by backward
+            for m in self.extra_modules:
+                m.zero_grad(set_to_none=True)
             spconv.core.DEFERRED_COUNTERS = counters = []
             try:
                 with torch.enable_grad():

@@ -76,3 +76,31 @@ print("first-stage training step, %d frames: %.2f ms/step = %.0f frames/s; loss 
                               (tgt["box_cls_labels"] > 0).sum(1).tolist()))
 print("  stages (ms): voxelize + sparse backbone fwd %.2f | BEV backbone + head fwd %.2f | target assignment + loss %.2f | "
       "backward of everything %.2f" % tuple(st))
+
+
+# ---- the same step without read-backs, replayed as one HIP graph (StaticTrainPipeline; the BEV part
+# and the loss ride along as its loss_fn)
+def head_loss(bd):
+    bd = flow.dense_head(flow.backbone_2d(bd))
+    with torch.no_grad():
+        tg = target_assign.assign_targets([anchors], gt, [1], [0.6], [0.45])
+    return losses.rpn_loss(bd["cls_preds"], bd["box_preds"], bd.get("dir_cls_preds"), tg["box_cls_labels"],
+                           tg["box_reg_targets"], anchors)[0]
+
+
+del loss, parts, tgt
+pipe = gb.StaticTrainPipeline(flow.backbone_3d, K, B, pts.shape[0], 4, loss_fn=head_loss,
+                              extra_modules=(flow.backbone_2d, flow.dense_head))
+pipe.calibrate(pts, bidx)
+pipe.load(pts, bidx)
+pipe.capture()
+for _ in range(3):
+    pipe.replay()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(n):
+    pipe.replay()
+torch.cuda.synchronize()
+dg = (time.perf_counter() - t0) / n
+pipe.check()
+print("  shape-static, one HIP graph: %.2f ms/step = %.0f frames/s; loss %.4f" % (dg * 1e3, B / dg, float(pipe.loss.detach())))
