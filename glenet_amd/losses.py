@@ -5,8 +5,13 @@ of VoxelRCNNKLLabelIoUHead.get_box_reg_layer_loss, lines 96-138
 On the device the whole expression -- ResidualCoder.encode_torch of the ground truth against the RoI
 moved to the origin, code-weighted smooth-L1, the variance terms, the foreground-normalised sum -- and
 both gradients are ONE kernel (csrc/glx_loss.hip) and no host read-back (the reference reads
-`fg_sum` and four tb_dict scalars back every step).  `kl_reg_loss_torch` is the same arithmetic in
-tensor ops, statement by statement like the reference; it is what runs for CPU tensors."""
+`fg_sum` and four tb_dict scalars back every step).
+
+The `*_torch` functions are statement-by-statement tensor-op mirrors of the reference.  They are NOT a
+fallback: the public functions (`kl_reg_loss`, `corner_loss`, `canonical_gt_of_rois`,
+`rcnn_cls_loss`, `rpn_loss`) take device tensors only and raise otherwise.  The mirrors exist for the
+CPU tests (pinned against fixtures generated from the reference's own code) and as the
+"reference formulation" leg of tools/loss_bench.py."""
 import ctypes
 
 import torch
@@ -70,9 +75,7 @@ def kl_reg_loss(rcnn_reg, rcnn_reg_std, rois, gt_of_rois, gt_uncertainty, reg_va
     """rcnn_reg, rcnn_reg_std (R,7); rois (B,N,7) or (R,7); gt_of_rois in the RoI frame; gt_uncertainty
     = label variances; reg_valid_mask (R) -> (loss, parts) with parts['src'|'square'|'log'|'fg']
     (device scalars: no read-back)."""
-    if not rcnn_reg.is_cuda:
-        return kl_reg_loss_torch(rcnn_reg, rcnn_reg_std, rois, gt_of_rois, gt_uncertainty, reg_valid_mask,
-                                 code_weights, beta, weight)
+    _lib.check_cuda(rcnn_reg.contiguous())
     r = rcnn_reg.shape[0]
     fg = (reg_valid_mask.reshape(-1) > 0).float()
     loss, parts = _KLRegLoss.apply(rcnn_reg.reshape(r, 7), rcnn_reg_std.reshape(r, 7), rois.reshape(r, 7),
@@ -137,8 +140,7 @@ class _CornerLoss(torch.autograd.Function):
 def corner_loss(rcnn_reg, rois, gt_of_rois_src, reg_valid_mask, weight=1.0):
     """Mean corner loss over the foreground RoIs (0 when there are none, where the reference skips
     the term); device tensors: one kernel, no read-back of the foreground count."""
-    if not rcnn_reg.is_cuda:
-        return corner_loss_torch(rcnn_reg, rois, gt_of_rois_src, reg_valid_mask, weight)
+    _lib.check_cuda(rcnn_reg.contiguous())
     r = rcnn_reg.shape[0]
     fg = (reg_valid_mask.reshape(-1) > 0).float()
     return _CornerLoss.apply(rcnn_reg.reshape(r, 7), rois.reshape(r, 7), gt_of_rois_src.reshape(r, 7), fg,
@@ -169,8 +171,6 @@ def canonical_gt_of_rois_torch(rois, gt_of_rois):
 
 def canonical_gt_of_rois(rois, gt_of_rois):
     """-> gt_of_rois in the RoI frame, same shape; one kernel on the device."""
-    if not rois.is_cuda:
-        return canonical_gt_of_rois_torch(rois, gt_of_rois)
     r = rois.shape[0] * rois.shape[1]
     a, g = rois.contiguous().float(), gt_of_rois.contiguous().float()
     _lib.check_cuda(a, g)
@@ -250,12 +250,14 @@ class _RcnnClsLoss(torch.autograd.Function):
         return (g * g_loss).reshape(ctx.shape), None, None
 
 
+def rcnn_cls_loss_torch(rcnn_cls, rcnn_cls_labels, weight=1.0):
+    """The reference's statements (roi_head_template.py:253-264) in tensor ops."""
+    flat, lab = rcnn_cls.view(-1), rcnn_cls_labels.view(-1)
+    bl = torch.nn.functional.binary_cross_entropy(torch.sigmoid(flat), lab.float().clamp(min=0), reduction="none")
+    valid = (lab >= 0).float()
+    return (bl * valid).sum() / torch.clamp(valid.sum(), min=1.0) * weight
+
+
 def rcnn_cls_loss(rcnn_cls, rcnn_cls_labels, weight=1.0):
-    """get_box_cls_layer_loss with CLS_LOSS = BinaryCrossEntropy; CPU tensors take the reference's
-    tensor-op formula."""
-    if not rcnn_cls.is_cuda:
-        flat, lab = rcnn_cls.view(-1), rcnn_cls_labels.view(-1)
-        bl = torch.nn.functional.binary_cross_entropy(torch.sigmoid(flat), lab.float().clamp(min=0), reduction="none")
-        valid = (lab >= 0).float()
-        return (bl * valid).sum() / torch.clamp(valid.sum(), min=1.0) * weight
+    """get_box_cls_layer_loss with CLS_LOSS = BinaryCrossEntropy (device tensors)."""
     return _RcnnClsLoss.apply(rcnn_cls, rcnn_cls_labels, float(weight))

@@ -30,9 +30,11 @@ def _check(loss, parts, reg, std, rtol):
 
 def test_kl_reg_loss_tensor_ops_match_reference_golden():
     reg, std, rois, gt, unc, valid = _inputs("cpu")
-    loss, parts = losses.kl_reg_loss(reg, std, rois, gt, unc, valid, code_weights=G["code_weights"].tolist(),
-                                     beta=float(G["beta"]))
+    loss, parts = losses.kl_reg_loss_torch(reg, std, rois, gt, unc, valid, code_weights=G["code_weights"].tolist(),
+                                           beta=float(G["beta"]))
     _check(loss, parts, reg, std, 1e-6)
+    with pytest.raises(Exception):          # the public entry points take device tensors only: no CPU fallback
+        losses.kl_reg_loss(reg, std, rois, gt, unc, valid)
 
 
 @pytest.mark.gpu
@@ -52,7 +54,7 @@ def test_kl_reg_loss_kernel_matches_reference_golden(dev):
 
 def test_corner_loss_tensor_ops_match_reference_golden():
     reg, _, rois, _, _, valid = _inputs("cpu")
-    loss = losses.corner_loss(reg, rois, torch.from_numpy(G["gt_of_rois_src"]), valid)
+    loss = losses.corner_loss_torch(reg, rois, torch.from_numpy(G["gt_of_rois_src"]), valid)
     np.testing.assert_allclose(float(loss.detach()), float(G["loss_corner"]), rtol=1e-5)
     loss.backward()
     np.testing.assert_allclose(reg.grad.numpy(), G["grad_reg_corner"], rtol=1e-4, atol=1e-7)
@@ -84,7 +86,7 @@ def _canon_close(got, want):
 
 
 def test_canonical_gt_tensor_ops_match_reference_golden():
-    got = losses.canonical_gt_of_rois(torch.from_numpy(G["canon_rois"]), torch.from_numpy(G["canon_gt"]))
+    got = losses.canonical_gt_of_rois_torch(torch.from_numpy(G["canon_rois"]), torch.from_numpy(G["canon_gt"]))
     _canon_close(got.numpy(), G["canon_out"])
 
 
@@ -97,7 +99,7 @@ def test_canonical_gt_kernel_matches_reference_golden(dev):
 
 def test_rcnn_cls_loss_tensor_ops_match_reference_golden():
     x = torch.from_numpy(G["cls_logits"]).requires_grad_(True)
-    loss = losses.rcnn_cls_loss(x, torch.from_numpy(G["cls_labels"]))
+    loss = losses.rcnn_cls_loss_torch(x, torch.from_numpy(G["cls_labels"]))
     np.testing.assert_allclose(float(loss.detach()), float(G["cls_loss"]), rtol=1e-6)
     loss.backward()
     np.testing.assert_allclose(x.grad.numpy(), G["cls_grad"], rtol=1e-5, atol=1e-9)
