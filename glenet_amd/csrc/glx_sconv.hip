@@ -57,6 +57,7 @@ struct SconvEpilogue {
   long long* trace;    // NULL, or (blocks, 4 + 8*NW) int64: selects the TRACE build (tools/sconv_tiles.py)
   int xcd_group;       // GEMM kernel: tiles per XCD-local group (0 = identity block -> tile map)
   int out_ld;          // row pitch of `out` in floats (0 = COUT): a launch may own a column slice of wider rows
+  const int* tile_map; // NULL, or block -> tile permutation balancing the work per CU (glx_sconv_tile_map)
 };
 
 // Block b runs on XCD b mod 8.  Deal the tiles to the XCDs in groups of `g` consecutive tiles:
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
     const int qn = nb >> 3, rm = nb & 7;
     tile = x * qn + (x < rm ? x : rm) + i;
   }
+  if (TR == 64 && ep.tile_map) tile = ep.tile_map[blockIdx.x];   // maps are built for 64-row tiles
   const int row0 = tile * TR;
   // Chunk c of offset k runs on wave (c + k + rot) mod NW.  rot differs per block: co-resident
   // blocks start together and walk the offsets in step, so without it the chunk-0 waves of all
@@ -580,7 +582,8 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int row0 = sc_xcd_tile(blockIdx.x, gridDim.x, ep.xcd_group & 0xFF) * TR;
+  const int row0 = ((TR == 64 && ep.tile_map) ? ep.tile_map[blockIdx.x]
+                                              : sc_xcd_tile(blockIdx.x, gridDim.x, ep.xcd_group & 0xFF)) * TR;
   const int grp = wave / T::WPG;
   const int tile0 = (wave % T::WPG) * T::TPW;
   // TRACE build: tph = issue loads | multiply | barrier 1 | wait + stage store | barrier 2 (cycles)
@@ -1151,7 +1154,7 @@ extern "C" int glx_sconv_forward_generic(const float* in, int N_in, const float*
   GLX_REQUIRE(in && W && nbr && out && K > 0 && Cin > 0 && Cout > 0,
               "glx_sconv_forward_generic: bad arguments");
   long long total = (long long)N_out * Cout;
-  SconvEpilogue ep{bias, nullptr, nullptr, 0, nullptr, nullptr, 0, 0};
+  SconvEpilogue ep{bias, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, nullptr};
   hipLaunchKernelGGL(k_sconv_generic, dim3(glx_divup(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, in, W, ep, nbr, N_out, K, Cin, Cout, out);
   GLX_LAUNCH_CHECK();
@@ -1457,6 +1460,158 @@ extern "C" int glx_sconv_pack_weights(const float* W, int K, int Cin, int Cout, 
   return glx_sconv_pack_weights_view(W, K, Cin, Cout, 0, 0, Wp, stream);
 }
 
+// ------------------------------------------------------------------ work-balanced block -> tile map
+// The hardware deals block b to XCD b mod 8 and, with an idle chip, block b + 256 to the CU of block b
+// (verified with the TRACE build: CU(b) == CU(b + 256) for every block).  All tiles of a layer are
+// resident at once (3 blocks per CU), so the kernel lasts as long as its most loaded CU; with the
+// identity map that CU carries 1.3-1.5x the mean number of MFMA chunks (LiDAR density varies along
+// the cell order).  glx_sconv_tile_map computes the chunks of every 64-row tile from the rule
+// table and deals the tiles longest-first, round by round (256 CUs per round), each round's tiles in
+// descending order onto the CUs in ascending order of what they already carry.
+#define TM_MAX 4096   // tiles (one block sorts them in LDS)
+
+__global__ void k_tile_work(const int* __restrict__ nbr, const int* __restrict__ tile_order, int N_out,
+                            int K, const int* __restrict__ n_live, int ntiles, int* __restrict__ work) {
+  if (n_live) N_out = min(N_out, *n_live);
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (tile >= ntiles) return;
+  const int p = tile * 64 + lane;
+  const int row = p < N_out ? (tile_order ? tile_order[p] : p) : -1;
+  const int* np = nbr + (long long)(row < 0 ? 0 : row) * K;
+  int nb[SC_MAXK];
+#pragma unroll
+  for (int k = 0; k < SC_MAXK; ++k) nb[k] = np[k < K ? k : 0];      // branch-free: all loads in flight
+  int chunks = 0;
+#pragma unroll
+  for (int k = 0; k < SC_MAXK; ++k) {
+    const bool v = k < K && row >= 0 && nb[k] >= 0;
+    chunks += (__popcll(__ballot(v)) + 15) >> 4;
+  }
+  if (lane == 0) work[tile] = chunks;
+}
+
+// One block.  Tiles are ordered by descending work with a counting sort (a 64-row tile has at most
+// 4 chunks per offset: work <= 4 K <= 108; the order among equal-work tiles comes from LDS atomics and
+// may differ between runs -- the conv results do not depend on the map).  Round 0 serves the CUs that
+// will get one block fewer first (the heaviest tiles stay alone), every later round deals its tiles,
+// heaviest first, to the CUs in ascending order of what they already carry: the same max/mean as a
+// full longest-first greedy on the LiDAR layers (1.11-1.14 instead of 1.31-1.50 for the identity map).
+__global__ __launch_bounds__(1024) void k_tile_assign(const int* __restrict__ work, int ntiles,
+                                                      int* __restrict__ tile_map) {
+  __shared__ int s_work[TM_MAX];
+  __shared__ int s_sorted[TM_MAX];
+  __shared__ int s_bin[16][128];                      // one histogram per wave: 1/16 of the atomic contention
+  __shared__ __attribute__((aligned(16))) int s_tot[128];
+  __shared__ __attribute__((aligned(16))) int s_load[256];
+  __shared__ int s_cu_sorted[256];
+  const int wave = threadIdx.x >> 6;
+  for (int e = threadIdx.x; e < 16 * 128; e += blockDim.x) (&s_bin[0][0])[e] = 0;
+  if (threadIdx.x < 256) s_load[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < ntiles; i += blockDim.x) {
+    const int w = min(work[i], 127);
+    s_work[i] = w;
+    atomicAdd(&s_bin[wave][w], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {                            // bin totals, then per-wave starts inside the bin
+    int t = 0;
+    for (int v = 0; v < 16; ++v) { const int c = s_bin[v][threadIdx.x]; s_bin[v][threadIdx.x] = t; t += c; }
+    s_tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {                            // start of bin w in descending order of work:
+    // suffix sum over the 128 totals with wave scans (two waves of 64 bins)
+    const int lane = threadIdx.x & 63;
+    int x = s_tot[threadIdx.x];
+    int incl = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_down(incl, o, 64);
+      if (lane + o < 64) incl += y;
+    }                                                  // incl = sum of bins lane..63 of this half
+    int b = incl - x;                                  // bins above this one inside the half
+    if (threadIdx.x < 64) {                            // lower half: add the whole upper half
+      int up = 0;
+      for (int v = 64; v < 128; v += 4) {
+        const int4 t4 = *reinterpret_cast<const int4*>(&s_tot[v]);
+        up += t4.x + t4.y + t4.z + t4.w;
+      }
+      b += up;
+    }
+    for (int v = 0; v < 16; ++v) s_bin[v][threadIdx.x] += b;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ntiles; i += blockDim.x) s_sorted[atomicAdd(&s_bin[wave][s_work[i]], 1)] = i;
+  __syncthreads();
+  const int m_last = ntiles - (ntiles - 1) / 256 * 256;   // CUs 0..m_last-1 get a block in the last round
+  for (int r0 = 0; r0 < ntiles; r0 += 256) {
+    const int m = min(256, ntiles - r0);
+    if (r0 == 0) {
+      if (threadIdx.x < 256) {
+        const int pos = threadIdx.x;                  // order: m_last..255, then 0..m_last-1
+        s_cu_sorted[pos] = pos < 256 - m_last ? m_last + pos : pos - (256 - m_last);
+      }
+    } else {
+      // rank of CU `cu` by (load, id) among CUs 0..m-1: four lanes per CU, 64 candidates each
+      const int cu = threadIdx.x >> 2, part = threadIdx.x & 3;
+      const int l = s_load[cu];
+      int rank = 0;
+#pragma unroll 4
+      for (int c = part * 64; c < part * 64 + 64; c += 4) {
+        const int4 v = *reinterpret_cast<const int4*>(&s_load[c]);
+        rank += (c + 0 < m) && (v.x < l || (v.x == l && c + 0 < cu));
+        rank += (c + 1 < m) && (v.y < l || (v.y == l && c + 1 < cu));
+        rank += (c + 2 < m) && (v.z < l || (v.z == l && c + 2 < cu));
+        rank += (c + 3 < m) && (v.w < l || (v.w == l && c + 3 < cu));
+      }
+      rank += __shfl_xor(rank, 1, 64);
+      rank += __shfl_xor(rank, 2, 64);
+      if (part == 0 && cu < m) s_cu_sorted[rank] = cu;
+    }
+    __syncthreads();
+    if (threadIdx.x < m) {
+      const int cu = s_cu_sorted[threadIdx.x];        // round's heaviest tile -> first CU of the order
+      const int tile = s_sorted[r0 + threadIdx.x];
+      tile_map[r0 + cu] = tile;
+      s_load[cu] += s_work[tile];
+    }
+    __syncthreads();
+  }
+}
+
+// block -> tile map for the 64-row tile kernels of one rule table; tile_map: int32[ceil(N_out/64)]
+extern "C" size_t glx_sconv_tile_map_workspace_bytes(int N_out) {
+  return glx_align((size_t)glx_divup(N_out > 0 ? N_out : 1, 64) * sizeof(int)) + 256;
+}
+extern "C" int glx_sconv_tile_map(const int32_t* nbr, const int32_t* tile_order, int N_out, int K,
+                                  const int32_t* n_out_live, int32_t* tile_map, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  if (N_out <= 0) return GLX_OK;
+  GLX_REQUIRE(nbr && tile_map && K > 0 && K <= SC_MAXK, "glx_sconv_tile_map: bad arguments");
+  const int ntiles = glx_divup(N_out, 64);
+  GLX_REQUIRE(ntiles <= TM_MAX, "glx_sconv_tile_map: %d tiles exceed %d", ntiles, TM_MAX);
+  const size_t need = glx_sconv_tile_map_workspace_bytes(N_out) - 256;
+  if (!workspace || workspace_bytes < need) {
+    glx_set_error("glx_sconv_tile_map: workspace %zu < %zu bytes", workspace_bytes, need);
+    return GLX_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_tile_work, dim3(glx_divup(ntiles, 4)), dim3(256), 0, st, nbr, tile_order, N_out, K,
+                     n_out_live, ntiles, (int*)workspace);
+  hipLaunchKernelGGL(k_tile_assign, dim3(1), dim3(1024), 0, st, (const int*)workspace, ntiles, tile_map);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// the map applies to the NEXT glx_sconv_forward call only (like glx_profile_next_sconv)
+static const int* g_next_tile_map = nullptr;
+extern "C" int glx_sconv_next_tile_map(const int32_t* tile_map) {
+  g_next_tile_map = tile_map;
+  return GLX_OK;
+}
+
 extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, const float* Wp,
                                  const float* bias, const float* scale, const float* shift,
                                  int relu, const int32_t* nbr, const int32_t* tile_order,
@@ -1466,7 +1621,8 @@ extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, cons
   GLX_REQUIRE(K > 0 && Cin > 0 && Cout > 0 && N_out >= 0, "glx_sconv_forward: bad sizes");
   if (N_out == 0) return GLX_OK;
   GLX_REQUIRE(in && (W || Wp) && nbr && out, "glx_sconv_forward: null pointer");
-  SconvEpilogue ep{bias, scale, shift, relu, n_out_live, g_sconv_trace, g_sconv_xcd_group, 0};
+  SconvEpilogue ep{bias, scale, shift, relu, n_out_live, g_sconv_trace, g_sconv_xcd_group, 0, g_next_tile_map};
+  g_next_tile_map = nullptr;
   if (!mfma_supported(Cin, Cout, K)) {
     GLX_REQUIRE(W, "glx_sconv_forward: raw weights required for channels (%d,%d)", Cin, Cout);
     long long total = (long long)N_out * Cout;
@@ -1504,7 +1660,7 @@ extern "C" int glx_sconv_forward_rb(const float* in, const float* Wp, const floa
   GLX_REQUIRE(in && Wp && book && out, "glx_sconv_forward_rb: null pointer");
   GLX_REQUIRE(mfma_supported(Cin, Cout, K) && Cin >= 16,
               "glx_sconv_forward_rb: channels (%d,%d) not supported", Cin, Cout);
-  SconvEpilogue ep{bias, scale, shift, relu, n_out_live, nullptr, 0, 0};
+  SconvEpilogue ep{bias, scale, shift, relu, n_out_live, nullptr, 0, 0, nullptr};
   hipStream_t st = (hipStream_t)stream;
   return sc_dispatch(Cin, Cout, [&](auto ci, auto co) {
     constexpr int CI = decltype(ci)::value, CO = decltype(co)::value;

@@ -30,7 +30,7 @@ from torch.autograd import Function
 from torch.nn import init
 
 from .. import _lib
-from .._lib import call, query, size_arg, workspace
+from .._lib import call, call_nostream, query, size_arg, workspace
 
 
 def _triple(v):
@@ -108,6 +108,7 @@ class RuleSet:
         self.count_in = self.count_out = None   # shape-static mode: live rows (device int32[1])
         self.ready = None        # event recorded after the build when it ran on another stream
         self._book = None
+        self._tile_maps = {}     # rule table (data_ptr) -> work-balanced block -> tile map
 
     @property
     def pair_count(self):
@@ -116,6 +117,23 @@ class RuleSet:
             n = self.N_out if self.count_out is None else min(self.N_out, int(self.count_out.item()))
             self._pairs = int((self.nbr[:n] >= 0).sum().item()) if n else 0
         return self._pairs
+
+    def tile_map(self, nbr=None, order=None, n_out=None, n_live=None):
+        """Work-balanced block -> tile permutation of a rule table of this set (default: the
+        forward table) for the 64-row tile kernels (glx_sconv_tile_map); built once, shared by
+        every conv that walks the table."""
+        if nbr is None:
+            nbr, order, n_out, n_live = self.nbr, self.tile_order_out, self.N_out, self.count_out
+        if not USE_TILE_MAP or n_out < TILE_MAP_MIN_ROWS or n_out > 64 * 4096:
+            return None
+        key = nbr.data_ptr()
+        m = self._tile_maps.get(key)
+        if m is None:
+            m = torch.empty((n_out + 63) // 64, dtype=torch.int32, device=nbr.device)
+            ws = workspace.get(query("glx_sconv_tile_map_workspace_bytes", n_out), nbr.device)
+            call("glx_sconv_tile_map", nbr, order, n_out, self.K, n_live, m, ws, size_arg(ws.numel()))
+            self._tile_maps[key] = m
+        return m
 
     def book(self):
         """Rulebook of the forward table (glx_rulebook_build): compacted pair lists per 64-row
@@ -231,6 +249,8 @@ def plan_rules(indices, spatial_shape, batch_size, convs, index=None, count=None
                                       out_capacity=capacities.get(key)))
             x.indice_dict[key] = rs
         new_work = rs.ready is None
+        if new_work and conv.subm and conv.in_channels * conv.out_channels >= TILE_MAP_MIN_WEIGHTS:
+            rs.tile_map()      # on the plan stream too, before the event (see TILE_MAP_MIN_WEIGHTS)
         if USE_RULEBOOK and rulebook_eligible(conv.in_channels, conv.out_channels, rs.K) and rs._book is None:
             rs.book()          # built here (plan stream), before the event the convs wait on
             new_work = True
@@ -319,6 +339,11 @@ def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rule
         call("glx_sconv_forward_rb", features, packed, bias, scale, shift, 1 if relu else 0, book,
              tile_order, n_out, K, cin, cout, out, n_live)
         return out
+    if rules is not None and packed is not None and (rules.subm or rules._tile_maps) \
+            and cin * cout >= TILE_MAP_MIN_WEIGHTS:
+        tmap = rules.tile_map(nbr, tile_order, n_out, n_live)
+        if tmap is not None:
+            call_nostream("glx_sconv_next_tile_map", tmap)
     call("glx_sconv_forward", features, features.shape[0], weight_kio, packed, bias, scale, shift,
          1 if relu else 0, nbr, tile_order, n_out, K, cin, cout, out, n_live, ws,
          size_arg(ws.numel()))
@@ -659,6 +684,14 @@ def ctypes_float(v):
 
 
 USE_FUSED_TRAIN_BN = os.environ.get("GLX_FUSED_BN", "1") != "0"
+# work-balanced block -> tile maps for the sparse-conv kernels (RuleSet.tile_map); off with GLX_TILE_MAP=0
+USE_TILE_MAP = os.environ.get("GLX_TILE_MAP", "1") != "0"
+TILE_MAP_MIN_ROWS = 64 * 256       # fewer tiles than CUs: nothing to balance
+# building a map costs two small launches (~8 us): worth it for the rule tables of submanifold stacks
+# (2-3 convs share one) with at least 32x32 weights per offset -- on the KITTI batch that is
+# subm2..subm4, which save 13 / 19 / 7 us per frame; the thin first stack and the single-use strided
+# tables would save 1-5 us
+TILE_MAP_MIN_WEIGHTS = 32 * 32
 # stream for the weight-gradient kernels of SparseConvFunction.backward (None = the current one).
 # Set by StaticTrainPipeline around its backward pass; the setter waits for it afterwards.
 WGRAD_STREAM = None

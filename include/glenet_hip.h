@@ -121,6 +121,17 @@ size_t glx_sconv_workspace_bytes(int K, int Cin, int Cout);
 /* Bytes of the MFMA-fragment-ordered copy of W (0 when (Cin,Cout) has no MFMA kernel, i.e.
  * channels outside {16,32,64,128} or K > 27: those run the scalar kernel on raw W). */
 size_t glx_sconv_packed_bytes(int K, int Cin, int Cout);
+/* Work-balanced block -> tile map of a rule table for the 64-row tile kernels: tile_map
+ * (int32[ceil(N_out/64)]) is a permutation of the tiles such that the blocks the hardware places on
+ * one CU (b, b+256, b+512 ...) carry similar numbers of 16-pair MFMA chunks.  Results do not depend
+ * on it (tiles are independent).  glx_sconv_next_tile_map(map) applies a map to the next
+ * glx_sconv_forward call only (NULL = built-in map).  Built once per rule table, shared by the
+ * convs of an indice_key. */
+size_t glx_sconv_tile_map_workspace_bytes(int N_out);
+int glx_sconv_tile_map(const int32_t* nbr, const int32_t* tile_order, int N_out, int K,
+                       const int32_t* n_out_live, int32_t* tile_map, void* workspace,
+                       size_t workspace_bytes, void* stream);
+int glx_sconv_next_tile_map(const int32_t* tile_map);
 /* Re-order W (K,Cin,Cout) into Wp (glx_sconv_packed_bytes); do it once per weight update. */
 int glx_sconv_pack_weights(const float* W, int K, int Cin, int Cout, float* Wp, void* stream);
 /* Same for the ADJOINT conv, straight from the forward weights: (Cin, Cout) are the dimensions of

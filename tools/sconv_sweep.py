@@ -90,6 +90,25 @@ for f, w, nbr, order, n_out, rules in calls:
         except Exception as ex:  # variant does not fit LDS
             row.append(float("nan"))
     _lib.call_nostream("glx_sconv_set_variant", -1)
+    if os.environ.get("TILE_MAP"):
+        # the default kernel with the work-balanced block -> tile map of this rule table
+        nt = (n_out + 63) // 64
+        tmap = torch.empty(nt, dtype=torch.int32, device=dev)
+        wsb = _lib.query("glx_sconv_tile_map_workspace_bytes", n_out)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _lib.call("glx_sconv_tile_map", nbr, order, n_out, Kk, None, tmap, ws, _lib.size_arg(wsb))
+        assert sorted(tmap.cpu().tolist()) == list(range(nt))
+        ts = []
+        for it in range(12):
+            s, e = ev(), ev()
+            _lib.call_nostream("glx_sconv_next_tile_map", tmap)
+            _lib.call_nostream("glx_profile_next_sconv", s, e)
+            got = orig(f, w, None, nbr, order, n_out, packed=packed)
+            ms = ctypes.c_float()
+            _lib.call_nostream("glx_event_elapsed_ms", s, e, ctypes.byref(ms))
+            ts.append(ms.value * 1e3)
+        assert torch.equal(got, ref_out)
+        row.append(float(np.median(ts[2:])))
     best = np.nanmin(row)
     alg = R * (cin + 2 * cout) * 4 + R * 8 + Kk * cin * cout * 4
     print(("(%d,%d,%d,%d)" % (cin, cout, n_out, R)).ljust(34) + "".join(("%.1f" % t).rjust(9) for t in row)

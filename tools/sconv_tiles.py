@@ -67,6 +67,45 @@ for f, w, nbr, order, n_out, rules in calls:
     se = (hw >> 13) & 0x7
     cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
     ch = t[:, 3]
+    if os.environ.get("MAPPING"):
+        # how the hardware deals blocks to CUs: is block b + 256 on the CU of block b ?
+        same = np.mean([cuid[b] == cuid[b + 256] for b in range(nblk - 256)])
+        same8 = np.mean([xcc[b] == b % 8 for b in range(nblk)])
+        print("  block -> CU: xcc == b %% 8 for %.2f of the blocks; CU(b) == CU(b+256) for %.2f; first 16 CU ids %s"
+              % (same8, same, cuid[:16].tolist()))
+        # what a perfectly balanced assignment of the same tiles could reach
+        order_ = np.argsort(-ch)
+        load = np.zeros(256)
+        for tix in order_:
+            load[np.argmin(load)] += ch[tix]
+        print("  chunks per CU now max/mean %.2f; greedy longest-first assignment max/mean %.2f"
+              % (np.bincount(cuid, weights=ch).max() / (ch.sum() / 256), load.max() / (ch.sum() / 256)))
+        for name, rev in (("snake (alternate direction per round)", lambda r: r % 2 == 1),
+                          ("snake, last round by current load", None)):
+            sl = np.zeros(256)
+            for r0 in range(0, nblk, 256):
+                tiles_r = order_[r0:r0 + 256]
+                m = len(tiles_r)
+                if rev is None and r0 + 256 >= nblk and r0 > 0:
+                    cus = np.argsort(sl[:m], kind="stable")
+                elif (rev or (lambda r: r % 2 == 1))(r0 // 256):
+                    cus = np.arange(m)[::-1]
+                else:
+                    cus = np.arange(m)
+                sl[cus] += ch[tiles_r]
+            print("  %s: max/mean %.2f" % (name, sl.max() / (ch.sum() / 256)))
+        # longest-first by rounds, CUs that get one block fewer served first in round 0
+        sl = np.zeros(256)
+        m_last = nblk - (nblk - 1) // 256 * 256
+        for r0 in range(0, nblk, 256):
+            tiles_r = order_[r0:r0 + 256]
+            m = len(tiles_r)
+            if r0 == 0:
+                cus = np.concatenate([np.arange(m_last, 256), np.arange(0, m_last)])[:m]
+            else:
+                cus = np.argsort(sl[:m], kind="stable")
+            sl[cus] += ch[tiles_r]
+        print("  rounds, short CUs first then by load: max/mean %.2f" % (sl.max() / (ch.sum() / 256)))
     print("layer (%d,%d) N=%d K=%d blocks=%d  span %.1f us  chunks total %d (mean %.1f, max %d)"
           % (cin, cout, n_out, Kk, nblk, en.max(), ch.sum(), ch.mean(), ch.max()))
     print("  block start: p50 %.1f p90 %.1f max %.1f us | duration: mean %.1f p50 %.1f p90 %.1f max %.1f us"
