@@ -249,7 +249,8 @@ def plan_rules(indices, spatial_shape, batch_size, convs, index=None, count=None
                                       out_capacity=capacities.get(key)))
             x.indice_dict[key] = rs
         new_work = rs.ready is None
-        if new_work and conv.subm and conv.in_channels * conv.out_channels >= TILE_MAP_MIN_WEIGHTS:
+        if new_work and (conv.subm or not TILE_MAP_SUBM_ONLY) \
+                and conv.in_channels * conv.out_channels >= TILE_MAP_MIN_WEIGHTS:
             rs.tile_map()      # on the plan stream too, before the event (see TILE_MAP_MIN_WEIGHTS)
         if USE_RULEBOOK and rulebook_eligible(conv.in_channels, conv.out_channels, rs.K) and rs._book is None:
             rs.book()          # built here (plan stream), before the event the convs wait on
@@ -691,7 +692,8 @@ TILE_MAP_MIN_ROWS = 64 * 256       # fewer tiles than CUs: nothing to balance
 # (2-3 convs share one) with at least 32x32 weights per offset -- on the KITTI batch that is
 # subm2..subm4, which save 13 / 19 / 7 us per frame; the thin first stack and the single-use strided
 # tables would save 1-5 us
-TILE_MAP_MIN_WEIGHTS = 32 * 32
+TILE_MAP_MIN_WEIGHTS = int(os.environ.get("GLX_TILE_MAP_MIN_WEIGHTS", 32 * 32))
+TILE_MAP_SUBM_ONLY = os.environ.get("GLX_TILE_MAP_ALL", "0") == "0"
 # stream for the weight-gradient kernels of SparseConvFunction.backward (None = the current one).
 # Set by StaticTrainPipeline around its backward pass; the setter waits for it afterwards.
 WGRAD_STREAM = None
