@@ -1736,9 +1736,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_partial(
 }
 
 __global__ void k_wgrad_reduce(const float* __restrict__ slabs, int nchunks, long long nel_total,
-                               float* __restrict__ dW) {
+                               float* __restrict__ dW, int nel_k = 0, int center = -1, int nchunks_center = 0) {
   long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nel_total) return;
+  if (center >= 0 && (int)(e / nel_k) == center) nchunks = nchunks_center;   // the centre offset has more slices
   // fixed summation order (deterministic), eight slab loads in flight at a time: a thread's loop is
   // a chain of dependent L2 reads otherwise (16 us for the 75 slabs of a 16x16 layer)
   float s = 0.f;
@@ -1766,6 +1767,12 @@ __global__ void k_wgrad_reduce(const float* __restrict__ slabs, int nchunks, lon
 #define WGM_BATCH 256
 #define WGM_TRIP 8      // MFMA steps whose operand reads are issued together
 
+struct WgradGrid {
+  int slices;        // row slices of an ordinary offset
+  int center;        // heavy (centre) offset or -1
+  int slices_center, rps_center;
+};
+
 template <int CIN, int COUT>
 struct WgradCfg {
   static constexpr int CINP = CIN < 16 ? 16 : CIN;       // Cin 4 / 8 ride in a zero-padded 16-row tile
@@ -1778,7 +1785,8 @@ struct WgradCfg {
 template <int CIN, int COUT>
 __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_mfma(
     const float* __restrict__ in, const float* __restrict__ gout, const int* __restrict__ nbr,
-    int N_out, int K, int rows_per_slice, float* __restrict__ slabs, const int* __restrict__ n_live) {
+    int N_out, int K, int rows_per_slice, float* __restrict__ slabs, const int* __restrict__ n_live,
+    WgradGrid wg) {
   if (n_live) N_out = min(N_out, *n_live);   // shape-static set: rows past the live count are undefined
   using T = WgradCfg<CIN, COUT>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1790,8 +1798,23 @@ __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_mfma(
   int* s_wc = s_pj + LIST;                                         // 4 wave counts + total
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, kk = lane >> 4;
-  const int k = blockIdx.y;
-  const int j_lo = blockIdx.x * rows_per_slice;
+  // block -> (offset k, row slice): uniform slices, or -- on a submanifold table, whose centre
+  // offset pairs EVERY row (3-4x the pairs of an average offset) -- wg.heavy_factor times as many,
+  // shorter slices for the centre so that its blocks do not outlast all the others
+  int k, slice;
+  if (wg.center < 0) {
+    k = blockIdx.x / wg.slices;
+    slice = blockIdx.x - k * wg.slices;
+  } else if ((int)blockIdx.x < (K - 1) * wg.slices) {
+    const int ko = blockIdx.x / wg.slices;
+    slice = blockIdx.x - ko * wg.slices;
+    k = ko < wg.center ? ko : ko + 1;
+  } else {
+    k = wg.center;
+    slice = blockIdx.x - (K - 1) * wg.slices;
+    rows_per_slice = wg.rps_center;
+  }
+  const int j_lo = slice * rows_per_slice;
   const int j_hi = min(N_out, j_lo + rows_per_slice);
 
   f32x4 acc[T::TPW];
@@ -1913,7 +1936,7 @@ __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_mfma(
   if (have > 0) panel(0, have);
   if (staged) multiply_staged();
   // ---- slab of this block: dW[k] partial, (Cin, Cout) row-major
-  float* dst = slabs + ((long long)blockIdx.x * K + k) * (CIN * COUT);
+  float* dst = slabs + ((long long)slice * K + k) * (CIN * COUT);
 #pragma unroll
   for (int u = 0; u < T::TPW; ++u) {
     const int t = wave + 4 * u;
@@ -1939,16 +1962,18 @@ static int wgrad_slices(int K, int Cin, int Cout) {
   return s < 1 ? 1 : (s > 512 ? 512 : s);
 }
 
+#define WGM_CENTER_FACTOR 4
 extern "C" size_t glx_sconv_wgrad_workspace_bytes(int N_out, int K, int Cin, int Cout) {
   (void)N_out;
-  int chunks = wgrad_slices(K, Cin, Cout) > WG_CHUNKS ? wgrad_slices(K, Cin, Cout) : WG_CHUNKS;
+  int chunks = wgrad_slices(K, Cin, Cout) * WGM_CENTER_FACTOR;
+  chunks = chunks > WG_CHUNKS ? chunks : WG_CHUNKS;
   return glx_align((size_t)chunks * K * Cin * Cout * sizeof(float)) + 256;
 }
 
 extern "C" int glx_sconv_wgrad(const float* in, int N_in, const float* grad_out,
                                const int32_t* nbr, int N_out, int K, int Cin, int Cout, float* dW,
-                               const int32_t* n_out_live, void* workspace, size_t workspace_bytes,
-                               void* stream) {
+                               const int32_t* n_out_live, int submanifold, void* workspace,
+                               size_t workspace_bytes, void* stream) {
   (void)N_in;
   GLX_REQUIRE(dW && (N_out == 0 || (in && grad_out && nbr)), "glx_sconv_wgrad: null pointer");
   GLX_REQUIRE(Cin * Cout <= 64 * WG_THREADS, "glx_sconv_wgrad: Cin*Cout=%d too large", Cin * Cout);
@@ -1965,10 +1990,26 @@ extern "C" int glx_sconv_wgrad(const float* in, int N_in, const float* grad_out,
   }
   auto okc = [](int c) { return c == 16 || c == 32 || c == 64 || c == 128; };
   if ((okc(Cin) || Cin == 4 || Cin == 8) && okc(Cout) && !getenv("GLX_WGRAD_SCALAR")) {
-    const int S = wgrad_slices(K, Cin, Cout);
-    int rps = glx_divup(N_out, S);
+    // submanifold table with a centre offset: the resident-block budget S*K is split so that the
+    // centre gets WGM_CENTER_FACTOR times the slices of the others
+    // (measured: 29 -> 23 us for 4x16 / 16x16, where a block is one short latency chain; the wide
+    //  layers are throughput-bound and lose 5-15 % to the extra blocks, so they keep uniform slices)
+    const bool heavy = submanifold && (K & 1) && K >= 9 && Cin * Cout <= 512;
+    const int budget = wgrad_slices(K, Cin, Cout) * K;
+    const int S = heavy ? budget / (K - 1 + WGM_CENTER_FACTOR) : wgrad_slices(K, Cin, Cout);
+    int rps = glx_divup(N_out, S > 0 ? S : 1);
     rps = (rps + WGM_BATCH - 1) / WGM_BATCH * WGM_BATCH;
     const int slices = glx_divup(N_out, rps);
+    WgradGrid wg{slices, -1, 0, 0};
+    int nblocks = slices * K;
+    if (heavy) {
+      int rps_c = glx_divup(N_out, slices * WGM_CENTER_FACTOR);
+      rps_c = (rps_c + WGM_BATCH - 1) / WGM_BATCH * WGM_BATCH;
+      wg.center = K / 2;
+      wg.rps_center = rps_c;
+      wg.slices_center = glx_divup(N_out, rps_c);
+      nblocks = slices * (K - 1) + wg.slices_center;
+    }
     int rc = sc_dispatch(Cin, Cout, [&](auto ci, auto co) {
       constexpr int CI = decltype(ci)::value, CO = decltype(co)::value;
       {
@@ -1980,14 +2021,15 @@ extern "C" int glx_sconv_wgrad(const float* in, int N_in, const float* grad_out,
                                       (int)T::lds_bytes));
           attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3(slices, K), dim3(WGM_THREADS), T::lds_bytes, st, in, grad_out,
-                           nbr, N_out, K, rps, (float*)workspace, n_out_live);
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WGM_THREADS), T::lds_bytes, st, in, grad_out,
+                           nbr, N_out, K, rps, (float*)workspace, n_out_live, wg);
       }
       return GLX_OK;
     });
     if (rc != GLX_OK) return rc;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(glx_divup(nel_total, 256)), dim3(256), 0, st,
-                       (const float*)workspace, slices, nel_total, dW);
+                       (const float*)workspace, slices, nel_total, dW, Cin * Cout, wg.center,
+                       wg.slices_center);
     GLX_LAUNCH_CHECK();
     return GLX_OK;
   }
@@ -1997,7 +2039,7 @@ extern "C" int glx_sconv_wgrad(const float* in, int N_in, const float* grad_out,
                      (Cin + Cout) * sizeof(float), st, in, grad_out, nbr, N_out, K, Cin, Cout,
                      rows_per_chunk, (float*)workspace);
   hipLaunchKernelGGL(k_wgrad_reduce, dim3(glx_divup(nel_total, 256)), dim3(256), 0, st,
-                     (const float*)workspace, WG_CHUNKS, nel_total, dW);
+                     (const float*)workspace, WG_CHUNKS, nel_total, dW, 0, -1, 0);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

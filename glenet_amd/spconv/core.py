@@ -409,7 +409,7 @@ class SparseConvFunction(Function):
                 wsb = query("glx_sconv_wgrad_workspace_bytes", n_fwd_out, K, cin, cout)
                 ws = workspace.get(wsb, w.device)
                 call("glx_sconv_wgrad", features, features.shape[0], grad_out, fwd_nbr, n_fwd_out, K,
-                     cin, cout, g_w, live_fwd, ws, size_arg(ws.numel()))
+                     cin, cout, g_w, live_fwd, 1 if (rules.subm and not inverse) else 0, ws, size_arg(ws.numel()))
         if ctx.needs_input_grad[0]:
             # input gradient = the same kernels on the adjoint weights (Cout -> Cin, taps flipped on
             # a submanifold set), packed from the forward weights in one launch

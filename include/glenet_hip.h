@@ -179,7 +179,9 @@ int glx_sconv_transpose_weights(const float* W, int K, int Cin, int Cout, float*
 size_t glx_sconv_wgrad_workspace_bytes(int N_out, int K, int Cin, int Cout);
 int glx_sconv_wgrad(const float* in, int N_in, const float* grad_out, const int32_t* nbr,
                     int N_out, int K, int Cin, int Cout, float* dW, const int32_t* n_out_live,
-                    void* workspace, size_t workspace_bytes, void* stream);
+                    int submanifold, void* workspace, size_t workspace_bytes, void* stream);
+/* submanifold != 0: nbr is a submanifold table (its centre offset K/2 pairs every row): the centre
+ * gets shorter row slices so that its blocks do not outlast the others. */
 
 /* SparseConvTensor.dense(): out (B, C, D, H, W) must be zero-filled by the caller.
  * Replaces: spconv dense() (height_compression.py:21). */
