@@ -392,3 +392,48 @@ def test_training_graph_with_optimizer_follows_eager_training(dev):
         got.append(float(pipe.loss.detach()))
     pipe.check()
     np.testing.assert_allclose(got, want[2:], rtol=1e-4)
+
+
+def test_tile_maps_do_not_change_results(dev):
+    """Work-balanced block -> tile maps (RuleSet.tile_map) at the bench size, where they switch on:
+    every map is a permutation of the tiles, and the backbone output -- exact-shape path and the
+    shape-static path with device row counts -- is bit-identical with and without them."""
+    from glenet_amd.spconv import core
+    torch.manual_seed(0)
+    grid = oracle.grid_size_of(K["point_cloud_range"], K["voxel_size"])
+    B = 4
+    frames = [synth.kitti_frame(i)[0] for i in range(B)]
+    pts = torch.from_numpy(np.concatenate(frames)).to(dev)
+    bidx = torch.from_numpy(np.concatenate([np.full(len(f), i, np.int32) for i, f in enumerate(frames)])).to(dev)
+    model = gb.VoxelBackBone8x(4, grid).to(dev).eval()
+    _condition(model)
+
+    def run(static):
+        with torch.no_grad():
+            if static:
+                pipe = gb.StaticFramePipeline(model, K, B, pts.shape[0], 4)
+                pipe.calibrate(pts, bidx)
+                pipe.load(pts, bidx)
+                bd = pipe.enqueue()
+                torch.cuda.synchronize()
+                pipe.check()
+            else:
+                bd = gb.HeightCompression()(model(gb.MeanVFE()(gb.voxelize_batch(pts, bidx, B, K))))
+        return bd
+
+    assert core.USE_TILE_MAP
+    with_maps = run(False)
+    maps = [m for rs in with_maps["multi_scale_3d_features"]["x_conv4"].indice_dict.values() for m in rs._tile_maps.values()]
+    assert len(maps) >= 3
+    for m in maps:
+        assert sorted(m.cpu().tolist()) == list(range(m.numel()))
+        assert not torch.equal(m.cpu(), torch.arange(m.numel(), dtype=torch.int32))
+    static_maps = run(True)
+    core.USE_TILE_MAP = False
+    try:
+        plain, static_plain = run(False), run(True)
+    finally:
+        core.USE_TILE_MAP = True
+    assert torch.equal(with_maps["spatial_features"], plain["spatial_features"])
+    assert torch.equal(static_maps["spatial_features"], static_plain["spatial_features"])
+    assert torch.equal(static_maps["spatial_features"], plain["spatial_features"])
