@@ -125,8 +125,9 @@ size_t glx_sconv_packed_bytes(int K, int Cin, int Cout);
  * (int32[ceil(N_out/64)]) is a permutation of the tiles such that the blocks the hardware places on
  * one CU (b, b+256, b+512 ...) carry similar numbers of 16-pair MFMA chunks.  Results do not depend
  * on it (tiles are independent).  glx_sconv_next_tile_map(map) applies a map to the next
- * glx_sconv_forward call only (NULL = built-in map).  Built once per rule table, shared by the
- * convs of an indice_key. */
+ * glx_sconv_forward call only (NULL = built-in map; process-global like glx_profile_next_sconv: the
+ * caller issues the two calls back to back from one thread).  Built once per rule table, shared by
+ * the convs of an indice_key. */
 size_t glx_sconv_tile_map_workspace_bytes(int N_out);
 int glx_sconv_tile_map(const int32_t* nbr, const int32_t* tile_order, int N_out, int K,
                        const int32_t* n_out_live, int32_t* tile_map, void* workspace,
