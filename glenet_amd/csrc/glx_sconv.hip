@@ -1618,11 +1618,12 @@ extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, cons
                                  int N_out, int K, int Cin, int Cout, float* out,
                                  const int32_t* n_out_live, void* workspace,
                                  size_t workspace_bytes, void* stream) {
+  const int* tile_map = g_next_tile_map;   // consumed by THIS call whatever happens below
+  g_next_tile_map = nullptr;
   GLX_REQUIRE(K > 0 && Cin > 0 && Cout > 0 && N_out >= 0, "glx_sconv_forward: bad sizes");
   if (N_out == 0) return GLX_OK;
   GLX_REQUIRE(in && (W || Wp) && nbr && out, "glx_sconv_forward: null pointer");
-  SconvEpilogue ep{bias, scale, shift, relu, n_out_live, g_sconv_trace, g_sconv_xcd_group, 0, g_next_tile_map};
-  g_next_tile_map = nullptr;
+  SconvEpilogue ep{bias, scale, shift, relu, n_out_live, g_sconv_trace, g_sconv_xcd_group, 0, tile_map};
   if (!mfma_supported(Cin, Cout, K)) {
     GLX_REQUIRE(W, "glx_sconv_forward: raw weights required for channels (%d,%d)", Cin, Cout);
     long long total = (long long)N_out * Cout;
