@@ -330,7 +330,11 @@ def main():
                                      "static": "shape-static frame, launches enqueued from Python",
                                      "dynamic": "exact shapes, host read-backs"}[args.mode],
                                parallelism="dp%d (frames shard, no data-path collective)" % world),
-                   roofline=roof, fwd_bwd=fwd_bwd)
+                   roofline=roof, fwd_bwd=fwd_bwd,
+                   baseline_metric="BASELINE.json: 'LiDAR frames/sec (fwd+bwd) on KITTI-shaped clouds at "
+                                   "1/2/4/8 MI355X; sparse-conv HBM GB/s' -- `value` is that metric on "
+                                   "configs[1] (which is forward-only by its own wording), the fwd+bwd rate "
+                                   "of the same backbone is in `fwd_bwd`, the sparse-conv GB/s in `roofline`")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames_np, model)
         print(json.dumps(out), flush=True)
