@@ -106,6 +106,16 @@ for f, w, nbr, order, n_out, rules in calls:
                 cus = np.argsort(sl[:m], kind="stable")
             sl[cus] += ch[tiles_r]
         print("  rounds, short CUs first then by load: max/mean %.2f" % (sl.max() / (ch.sum() / 256)))
+        # cheapest variant: identity for all rounds but the last, which is dealt by load
+        sl = np.zeros(256)
+        last0 = (nblk - 1) // 256 * 256
+        for b_ in range(last0):
+            sl[b_ % 256] += ch[b_]
+        tl = np.arange(last0, nblk)
+        tl = tl[np.argsort(-ch[tl], kind="stable")]
+        cus = np.argsort(sl[:len(tl)], kind="stable")
+        sl[cus] += ch[tl]
+        print("  identity + last round dealt by load: max/mean %.2f" % (sl.max() / (ch.sum() / 256)))
     print("layer (%d,%d) N=%d K=%d blocks=%d  span %.1f us  chunks total %d (mean %.1f, max %d)"
           % (cin, cout, n_out, Kk, nblk, en.max(), ch.sum(), ch.mean(), ch.max()))
     print("  block start: p50 %.1f p90 %.1f max %.1f us | duration: mean %.1f p50 %.1f p90 %.1f max %.1f us"
