@@ -309,3 +309,17 @@ def test_mean_vfe_and_range_mask_match_reference_golden():
     assert (g["vfe_num"] == 0).any()
     m = data_pipeline.mask_points_by_range(torch.from_numpy(g["mask_points"]), [0, -40.0, -3, 70.4, 40.0, 1])
     assert np.array_equal(m.numpy(), g["mask_out"]) and g["mask_out"][:40].any() and not g["mask_out"].all()
+
+
+@pytest.mark.parametrize("norm", [False, True])
+def test_target_assignment_oracle_matches_reference_golden(norm):
+    """oracle.assign (numpy restatement) == the reference's AxisAlignedTargetAssigner run on the same
+    inputs (tests/golden/target_assign_ref.npz): labels bit-identical, targets 1e-6, weights exact."""
+    from oracle import assign
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "target_assign_ref.npz"))
+    lab, tgt, w = assign.assign_targets([g["anchors_car"], g["anchors_cyc"]], g["gt"], [1, 3], [0.6, 0.5],
+                                        [0.45, 0.35], norm=norm)
+    tag = "norm" if norm else "plain"
+    assert np.array_equal(lab, g["labels_" + tag])
+    np.testing.assert_allclose(tgt, g["targets_" + tag], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(w, g["weights_" + tag], rtol=1e-7, atol=0)
