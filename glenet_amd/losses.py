@@ -261,3 +261,53 @@ def rcnn_cls_loss_torch(rcnn_cls, rcnn_cls_labels, weight=1.0):
 def rcnn_cls_loss(rcnn_cls, rcnn_cls_labels, weight=1.0):
     """get_box_cls_layer_loss with CLS_LOSS = BinaryCrossEntropy (device tensors)."""
     return _RcnnClsLoss.apply(rcnn_cls, rcnn_cls_labels, float(weight))
+
+
+def rpn_loss_torch(cls_preds, box_preds, dir_preds, box_cls_labels, box_reg_targets, anchors, code_weights=(1.0,) * 7,
+                   cls_weight=1.0, loc_weight=2.0, dir_weight=0.2, dir_offset=0.78539, alpha=0.25, beta=1.0 / 9.0):
+    """AnchorHeadTemplate.get_loss (anchor_head_template.py:108-232) in tensor ops, statement by
+    statement (test / baseline mirror, any device)."""
+    import numpy as np
+    B, N = box_cls_labels.shape
+    labels = box_cls_labels.clone().long()
+    num_class = cls_preds.reshape(B, N, -1).shape[-1]
+    cared, positives, negatives = labels >= 0, labels > 0, labels == 0
+    cls_weights = (negatives * 1.0 + 1.0 * positives).float()
+    reg_weights = positives.float()
+    if num_class == 1:
+        labels[positives] = 1
+    pos_normalizer = positives.sum(1, keepdim=True).float()
+    reg_weights = reg_weights / torch.clamp(pos_normalizer, min=1.0)
+    cls_weights = cls_weights / torch.clamp(pos_normalizer, min=1.0)
+    cls_targets = labels * cared.type_as(labels)
+    one_hot = torch.zeros(B, N, num_class + 1, dtype=cls_preds.dtype, device=cls_preds.device)
+    one_hot.scatter_(-1, cls_targets.unsqueeze(-1), 1.0)
+    one_hot = one_hot[..., 1:]
+    x = cls_preds.reshape(B, N, num_class)
+    ps = torch.sigmoid(x)
+    alpha_w = one_hot * alpha + (1 - one_hot) * (1 - alpha)
+    pt = one_hot * (1.0 - ps) + (1.0 - one_hot) * ps
+    bce = torch.clamp(x, min=0) - x * one_hot + torch.log1p(torch.exp(-torch.abs(x)))
+    cls_loss = (alpha_w * torch.pow(pt, 2.0) * bce * cls_weights.unsqueeze(-1)).sum() / B * cls_weight
+    bp, tg = box_preds.reshape(B, N, 7), box_reg_targets.reshape(B, N, 7)
+    sin_p = torch.sin(bp[..., 6:7]) * torch.cos(tg[..., 6:7])
+    sin_t = torch.cos(bp[..., 6:7]) * torch.sin(tg[..., 6:7])
+    bp_s, tg_s = torch.cat([bp[..., :6], sin_p], -1), torch.cat([tg[..., :6], sin_t], -1)
+    tg_s = torch.where(torch.isnan(tg_s), bp_s, tg_s)
+    diff = (bp_s - tg_s) * torch.as_tensor(code_weights, dtype=bp.dtype, device=bp.device).view(1, 1, -1)
+    n = torch.abs(diff)
+    loc = torch.where(n < beta, 0.5 * n ** 2 / beta, n - 0.5 * beta) * reg_weights.unsqueeze(-1)
+    loc_loss = loc.sum() / B * loc_weight
+    dir_loss = loc_loss * 0.0
+    if dir_preds is not None:
+        an = anchors.reshape(1, -1, anchors.shape[-1])[..., :7].to(bp.dtype)
+        rot_gt = tg[..., 6] + an[..., 6]
+        v = rot_gt - dir_offset
+        off = v - torch.floor(v / (2 * np.pi) + 0) * (2 * np.pi)
+        bins = torch.clamp(torch.floor(off / (2 * np.pi / 2)).long(), min=0, max=1)
+        w = positives.type_as(bp)
+        w = w / torch.clamp(w.sum(-1, keepdim=True), min=1.0)
+        ce = torch.nn.functional.cross_entropy(dir_preds.reshape(B, N, 2).permute(0, 2, 1), bins, reduction="none")
+        dir_loss = (ce * w).sum() / B * dir_weight
+    total = cls_loss + loc_loss + dir_loss
+    return total, {"rpn_loss_cls": cls_loss.detach(), "rpn_loss_loc": loc_loss.detach(), "rpn_loss_dir": dir_loss.detach()}

@@ -323,3 +323,22 @@ def test_target_assignment_oracle_matches_reference_golden(norm):
     assert np.array_equal(lab, g["labels_" + tag])
     np.testing.assert_allclose(tgt, g["targets_" + tag], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(w, g["weights_" + tag], rtol=1e-7, atol=0)
+
+
+def test_dense_head_loss_mirror_matches_reference_golden():
+    """losses.rpn_loss_torch (tensor-op mirror) == the reference's AnchorHeadTemplate.get_loss called
+    unmodified (fixture: make_golden.py assign): loss parts and the gradients of the three maps."""
+    import torch
+    from glenet_amd import losses
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "target_assign_ref.npz"))
+    cls = torch.from_numpy(g["rpn_cls_preds"]).requires_grad_(True)
+    box = torch.from_numpy(g["rpn_box_preds"]).requires_grad_(True)
+    dr = torch.from_numpy(g["rpn_dir_preds"]).requires_grad_(True)
+    loss, parts = losses.rpn_loss_torch(cls, box, dr, torch.from_numpy(g["rpn_labels"]), torch.from_numpy(g["rpn_targets"]),
+                                        torch.from_numpy(g["anchors_car"]))
+    np.testing.assert_allclose(float(loss.detach()), float(g["rpn_loss"]), rtol=1e-5)
+    for k in ("rpn_loss_cls", "rpn_loss_loc", "rpn_loss_dir"):
+        np.testing.assert_allclose(float(parts[k]), float(g[k]), rtol=1e-5, atol=1e-7)
+    loss.backward()
+    for t, k in ((cls, "rpn_grad_cls"), (box, "rpn_grad_box"), (dr, "rpn_grad_dir")):
+        np.testing.assert_allclose(t.grad.numpy(), g[k], rtol=1e-4, atol=1e-6 * max(1e-3, np.abs(g[k]).max()))
