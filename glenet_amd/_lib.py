@@ -37,7 +37,8 @@ def load():
                  "glx_sconv_wgrad_workspace_bytes", "glx_voxelize_hard_workspace_bytes",
                  "glx_voxelize_dynamic_workspace_bytes", "glx_nms_workspace_bytes",
                  "glx_roiaware_pool3d_workspace_bytes", "glx_roipoint_pool3d_workspace_bytes",
-                 "glx_assign_targets_workspace_bytes", "glx_rpn_loss_workspace_bytes"):
+                 "glx_assign_targets_workspace_bytes", "glx_rpn_loss_workspace_bytes",
+                 "glx_group_points_grad_workspace_bytes"):
         if hasattr(lib, name):
             getattr(lib, name).restype = c_size_t
     lib.glx_index_words.restype = c_int64

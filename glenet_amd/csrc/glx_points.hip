@@ -2,6 +2,8 @@
 // voxel query, ball query, grouping.  Arithmetic restates the reference CUDA kernels cited at
 // each function (fp32, contraction off); the parallel decomposition is ours.
 #include "glx_common.h"
+#include "glx_fill.h"
+#include "glx_scan.h"
 
 // ------------------------------------------------------------------ inside test
 // check_pt_in_box3d, pcdet/ops/roiaware_pool3d/src/roiaware_pool3d_kernel.cu:23-36
@@ -534,6 +536,156 @@ extern "C" int glx_group_points_grad(int B, int M, int C, int N, int nsample, co
   hipLaunchKernelGGL(k_group_points_grad, dim3(glx_divup(M, waves)), dim3(64 * waves),
                      per_wave * waves, (hipStream_t)stream, B, M, C, nsample, grad_out, idx,
                      idx_batch_cnt, features_batch_cnt, grad_features);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// Gather form of the same gradient.  The atomic scatter above collapses on the RoI-grid pooling of
+// Voxel-RCNN: 100+ RoIs per frame sit on the same few objects, every voxel row there receives
+// thousands of contributions and the memory-side atomic unit serialises them (20.8 ms for 86 400
+// grid points x 16 x 32 channels = 44 M atomic adds; the atomic-rate table of MI355X_MICROARCH.md has
+// the same collapse for one hot row).  Here the (grid point, slot) references are bucketed by feature
+// row first -- a count, an exclusive scan and a fill, 2 x M*ns integer atomics instead of M*ns*C
+// float ones -- and each row then sums its references itself: a wave per row, lanes = channels x
+// reference slots, no float atomic at all.  (The order of a row's references comes from integer
+// atomics, so sums may differ in the last bits between runs, as with the atomic scatter.)
+// count / fill: the 64 references of a wave (4 grid points x 16 slots) name few distinct rows (unused
+// slots repeat the first hit, neighbouring grid points share voxels), so equal rows are combined
+// inside the wave first -- one integer atomic per distinct row and wave instead of one per
+// reference (the per-reference version spent 7 / 12 ms in these two kernels on the hot rows).
+__global__ void k_gp_count(int B, int M, int ns, const int* __restrict__ idx, const int* __restrict__ idx_cnt,
+                           const int* __restrict__ feat_cnt, int* __restrict__ cnt) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = t < (long long)M * ns;
+  int row = -1;
+  if (valid) {
+    int start;
+    batch_of((int)(t / ns), idx_cnt, B, start, feat_cnt);
+    row = start + idx[t];
+  }
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(valid);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int r = __shfl(row, leader, 64);
+    const unsigned long long same = __ballot(valid && row == r);
+    if (lane == leader) atomicAdd(&cnt[r], __popcll(same));
+    todo &= ~same;
+  }
+}
+
+__global__ void k_gp_fill(int B, int M, int ns, const int* __restrict__ idx, const int* __restrict__ idx_cnt,
+                          const int* __restrict__ feat_cnt, const int* __restrict__ offs,
+                          int* __restrict__ cursor, int* __restrict__ refs) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = t < (long long)M * ns;
+  int row = -1;
+  if (valid) {
+    int start;
+    batch_of((int)(t / ns), idx_cnt, B, start, feat_cnt);
+    row = start + idx[t];
+  }
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(valid);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int r = __shfl(row, leader, 64);
+    const unsigned long long same = __ballot(valid && row == r);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&cursor[r], __popcll(same));
+    base = __shfl(base, leader, 64);
+    if (valid && row == r)
+      refs[offs[r] + base + __popcll(same & ((1ull << lane) - 1ull))] = (int)t;   // reference = m * ns + s
+    todo &= ~same;
+  }
+}
+
+// One wave per CHUNK of 64 consecutive references (they are sorted by row): uniform work per wave
+// whatever the distribution -- a wave per row would leave the hot rows (tens of thousands of
+// references) to a single wave.  Inside a chunk the references of one row are summed in registers
+// (lane = channel x reference slot) and flushed with one atomic add per (row, channel); a row that
+// spans k chunks receives k adds instead of one per reference.
+#define GP_CHUNK 64
+__global__ __launch_bounds__(256) void k_gp_gather(int N, int C, int ns, long long T,
+                                                   const float* __restrict__ grad_out,
+                                                   const int* __restrict__ offs, const int* __restrict__ refs,
+                                                   float* __restrict__ grad_features) {
+  const int lane = threadIdx.x & 63;
+  const long long p0 = ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * GP_CHUNK;
+  if (p0 >= T) return;
+  const long long p1 = p0 + GP_CHUNK < T ? p0 + GP_CHUNK : T;
+  const int CL = (C < 64 && (C & (C - 1)) == 0) ? C : 64;   // channels covered by one pass of the wave
+  const int J = 64 / CL;                                     // references in flight per pass
+  const int c0 = lane % CL, j = lane / CL;
+  int lo = 0, hi = N;                                        // row of reference p0: last row with offs[row] <= p0
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((long long)offs[mid] <= p0) lo = mid; else hi = mid;
+  }
+  int row = lo;
+  long long e0 = p0;
+  while (e0 < p1) {
+    while ((long long)offs[row + 1] <= e0) ++row;            // skip rows without references
+    const long long e1 = (long long)offs[row + 1] < p1 ? (long long)offs[row + 1] : p1;
+    for (int cb = 0; cb < C; cb += CL) {
+      const int c = cb + c0;
+      float acc = 0.f;
+      if (c < C && j < J) {
+        for (long long e = e0 + j; e < e1; e += J) {
+          const int r = refs[e];
+          const int m = r / ns, sl = r - m * ns;
+          acc += grad_out[((long long)m * C + c) * ns + sl];
+        }
+      }
+      for (int d = CL; d < 64; d <<= 1) acc += __shfl_xor(acc, d, 64);
+      if (j == 0 && c < C) atomicAdd(grad_features + (long long)row * C + c, acc);
+    }
+    e0 = e1;
+  }
+}
+
+extern "C" size_t glx_group_points_grad_workspace_bytes(int M, int N, int nsample) {
+  return glx_align((size_t)(N + 1) * 4) * 3 + glx_align((size_t)M * nsample * 4) +
+         glx_scan_workspace_bytes(N + 1) + 256;
+}
+
+extern "C" int glx_group_points_grad_gather(int B, int M, int C, int N, int nsample, const float* grad_out,
+                                            const int32_t* idx, const int32_t* idx_batch_cnt,
+                                            const int32_t* features_batch_cnt, float* grad_features,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
+  if (N <= 0 || C <= 0) return GLX_OK;
+  GLX_REQUIRE(grad_features && (M == 0 || (grad_out && idx && idx_batch_cnt && features_batch_cnt)),
+              "glx_group_points_grad_gather: null");
+  const size_t need = glx_group_points_grad_workspace_bytes(M, N, nsample) - 256;
+  if (!workspace || workspace_bytes < need) {
+    glx_set_error("glx_group_points_grad_gather: workspace %zu < %zu bytes", workspace_bytes, need);
+    return GLX_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const size_t rowb = glx_align((size_t)(N + 1) * 4);
+  int* cnt = (int*)workspace;
+  int* cursor = (int*)((char*)workspace + rowb);
+  int* offs = (int*)((char*)workspace + 2 * rowb);
+  int* refs = (int*)((char*)workspace + 3 * rowb);
+  void* scan_ws = (char*)refs + glx_align((size_t)M * nsample * 4);
+  GlxFillJob job{cnt, 2 * rowb, 0};                           // counts and cursors
+  int rc = glx_fill_multi(&job, 1, st);
+  if (rc != GLX_OK) return rc;
+  const long long total = (long long)M * nsample;
+  if (total > 0)
+    hipLaunchKernelGGL(k_gp_count, dim3((unsigned)glx_divup(total, 256)), dim3(256), 0, st, B, M, nsample, idx,
+                       idx_batch_cnt, features_batch_cnt, cnt);
+  rc = glx_exclusive_scan(IntArray{cnt}, (long long)N, offs, offs + N, scan_ws, glx_scan_workspace_bytes(N + 1), st);
+  if (rc != GLX_OK) return rc;
+  if (total > 0)
+    hipLaunchKernelGGL(k_gp_fill, dim3((unsigned)glx_divup(total, 256)), dim3(256), 0, st, B, M, nsample, idx,
+                       idx_batch_cnt, features_batch_cnt, (const int*)offs, cursor, refs);
+  GlxFillJob zj{grad_features, (size_t)N * C * sizeof(float), 0};
+  rc = glx_fill_multi(&zj, 1, st);
+  if (rc != GLX_OK) return rc;
+  if (total > 0)
+    hipLaunchKernelGGL(k_gp_gather, dim3((unsigned)glx_divup(glx_divup(total, (long long)GP_CHUNK), 4LL)), dim3(256),
+                       0, st, N, C, nsample, total, grad_out, (const int*)offs, (const int*)refs, grad_features);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

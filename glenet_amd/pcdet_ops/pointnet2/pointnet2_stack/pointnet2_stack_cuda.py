@@ -43,6 +43,16 @@ def group_points_grad_wrapper(B, M, C, N, nsample, grad_out, idx, idx_batch_cnt,
     return 1
 
 
+def group_points_grad_gather_wrapper(B, M, C, N, nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt,
+                                     grad_features):
+    """Gather form of group_points_grad_wrapper (no float atomics; grad_features fully written)."""
+    _lib.check_cuda(grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features)
+    ws = _lib.workspace.get(_lib.query("glx_group_points_grad_workspace_bytes", M, N, nsample), grad_out.device)
+    call("glx_group_points_grad_gather", B, M, C, N, nsample, grad_out, idx, idx_batch_cnt,
+         features_batch_cnt, grad_features, ws, _lib.size_arg(ws.numel()))
+    return 1
+
+
 def stack_farthest_point_sampling_wrapper(xyz, temp, xyz_batch_cnt, idxs, num_sampled_points):
     """sampling.cpp:40-60: xyz (N,3), temp (N) filled with 1e10, idxs (sum m) int32 out."""
     _lib.check_cuda(xyz, temp, xyz_batch_cnt, idxs, num_sampled_points)

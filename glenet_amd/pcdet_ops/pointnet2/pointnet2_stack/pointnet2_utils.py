@@ -35,6 +35,9 @@ class BallQuery(Function):
 ball_query = BallQuery.apply
 
 
+GATHER_MIN_REFS_PER_ROW = 4     # above this many (grid point, slot) references per feature row: gather backward
+
+
 class GroupingOperation(Function):
     @staticmethod
     def forward(ctx, features, features_batch_cnt, idx, idx_batch_cnt):
@@ -58,6 +61,13 @@ class GroupingOperation(Function):
     def backward(ctx, grad_out):
         b, n, idx, features_batch_cnt, idx_batch_cnt = ctx.for_backwards
         m, c, nsample = grad_out.size()
+        if m * nsample >= GATHER_MIN_REFS_PER_ROW * max(n, 1):
+            # many references per feature row (RoI-grid pooling): the atomic scatter serialises on the
+            # hot rows, the gather form does not (csrc/glx_points.hip, k_gp_gather)
+            grad_features = torch.empty((n, c), dtype=torch.float32, device=grad_out.device)
+            pointnet2.group_points_grad_gather_wrapper(b, m, c, n, nsample, grad_out.contiguous(), idx,
+                                                       idx_batch_cnt, features_batch_cnt, grad_features)
+            return grad_features, None, None, None
         grad_features = torch.zeros((n, c), dtype=torch.float32, device=grad_out.device)
         pointnet2.group_points_grad_wrapper(b, m, c, n, nsample, grad_out.contiguous(), idx,
                                             idx_batch_cnt, features_batch_cnt, grad_features)

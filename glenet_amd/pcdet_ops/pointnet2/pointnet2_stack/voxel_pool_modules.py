@@ -48,6 +48,9 @@ class NeighborVoxelSAModuleMSG(nn.Module):
         coords_bzyx = new_coords[:, [0, 3, 2, 1]].contiguous()      # voxel_pool_modules.py:84
         if self._fusable(features):
             return self._forward_fused(xyz, new_xyz, coords_bzyx, features, voxel2point_indices)
+        if self.USE_ROW_MAJOR and features.is_cuda and self.pool_method == 'max_pool':
+            return self._forward_rows(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, coords_bzyx, features,
+                                      voxel2point_indices)
         outs = []
         for grouper, mlp_in, mlp_pos, mlp_out in zip(self.groupers, self.mlps_in, self.mlps_pos,
                                                      self.mlps_out):
@@ -120,3 +123,50 @@ class NeighborVoxelSAModuleMSG(nn.Module):
                                              xyz, new_xyz, idx, None, w_pos, b_pos, w_out, b_out, o)
             outs.append(o)
         return out if len(widths) == 1 else torch.cat(outs, dim=1)
+
+    # ---- training path, row-major: the same arithmetic with the 1x1 convolutions written as matrix
+    # products on (rows, channels) tensors and the BatchNorms applied to rows.  The reference's
+    # (1, C, M, ns) Conv2d / Conv1d formulation sends MIOpen into its worst case on this stack: the
+    # weight gradient of a 3 -> 32 channel 1x1 conv over 1.4 M positions ran 40-50 ms per scale
+    # (naive / batched-GEMM wrw solvers); as a GEMM it is microseconds.  Parameters, running
+    # statistics and results are those of the module path (tested), which stays available
+    # (USE_ROW_MAJOR = False) as the statement-by-statement mirror of voxel_pool_modules.py:88-108.
+    USE_ROW_MAJOR = True
+    SPLITK_MIN_ROWS = 1 << 16
+
+    @staticmethod
+    def _conv_bn_rows(seq, x2d):
+        """Sequential(Conv(k=1, bias=False), BatchNorm[, ReLU]) on a (rows, C_in) tensor."""
+        conv, bn = seq[0], seq[1]
+        w = conv.weight.reshape(conv.out_channels, conv.in_channels)
+        rows = x2d.shape[0]
+        if rows >= NeighborVoxelSAModuleMSG.SPLITK_MIN_ROWS and rows % 128 == 0 and conv.bias is None:
+            # tall-skinny product (1.4 M rows x 3 -> 32): as 128 batched products, so that the weight
+            # gradient autograd derives is a batched GEMM + a sum over the batch (split-K) instead of
+            # one (32 x 3) GEMM with K = 1.4 M, which hipBLASLt runs on a single tile for 2.6 ms
+            y = torch.bmm(x2d.view(128, rows // 128, -1), w.t().unsqueeze(0).expand(128, -1, -1)).view(rows, -1)
+        else:
+            y = F.linear(x2d, w, conv.bias)
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        use_batch = bn.training or not bn.track_running_stats
+        y = F.batch_norm(y, bn.running_mean if bn.track_running_stats else None,
+                         bn.running_var if bn.track_running_stats else None, bn.weight, bn.bias, use_batch,
+                         bn.momentum if bn.momentum is not None else 0.1, bn.eps)
+        return F.relu(y) if len(seq) > 2 else y
+
+    def _forward_rows(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, coords_bzyx, features,
+                      voxel2point_indices):
+        outs = []
+        m = new_xyz.shape[0]
+        for grouper, mlp_in, mlp_pos, mlp_out in zip(self.groupers, self.mlps_in, self.mlps_pos, self.mlps_out):
+            feats = self._conv_bn_rows(mlp_in, features)                                 # (N, c_mid)
+            g_feat, g_xyz, empty = grouper(coords_bzyx, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, feats,
+                                           voxel2point_indices)                          # (M,c,ns), (M,3,ns)
+            keep = (~empty).to(g_feat.dtype).view(m, 1, 1)
+            rel = (g_xyz - new_xyz.unsqueeze(-1)) * keep
+            ns = rel.shape[-1]
+            pos = self._conv_bn_rows(mlp_pos, rel.permute(0, 2, 1).reshape(m * ns, 3))   # (M*ns, c_mid)
+            x = F.relu((g_feat * keep).permute(0, 2, 1) + pos.view(m, ns, -1))           # (M, ns, c_mid)
+            outs.append(self._conv_bn_rows(mlp_out, x.max(dim=1)[0]))                    # (M, c_out)
+        return torch.cat(outs, dim=1)

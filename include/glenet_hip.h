@@ -353,6 +353,14 @@ int glx_group_points(int B, int M, int C, int nsample, const float* features,
 int glx_group_points_grad(int B, int M, int C, int N, int nsample, const float* grad_out,
                           const int32_t* idx, const int32_t* idx_batch_cnt,
                           const int32_t* features_batch_cnt, float* grad_features, void* stream);
+/* Same gradient in gather form (every feature row sums its own references; no float atomics):
+ * the right choice when many grid points share few rows (RoI-grid pooling).  grad_features (N,C) is
+ * written completely (rows without references get 0); workspace >= the query below. */
+size_t glx_group_points_grad_workspace_bytes(int M, int N, int nsample);
+int glx_group_points_grad_gather(int B, int M, int C, int N, int nsample, const float* grad_out,
+                                 const int32_t* idx, const int32_t* idx_batch_cnt,
+                                 const int32_t* features_batch_cnt, float* grad_features,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* RoI-grid pooling aggregation of one scale after its voxel query, inference: out[m,:] =
  * relu(Wout . max_s relu(feats[idx[m,s],:] + Wpos . (xyz[idx[m,s]] - new_xyz[m]) + bpos) + bout);

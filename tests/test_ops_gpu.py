@@ -529,3 +529,60 @@ def test_fused_pointnet_feat_matches_torch_modules(dev, cin, P, B, widths):
     np.testing.assert_allclose(fused.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
     # the module falls back to the torch path when gradients are needed
     assert m(x.requires_grad_(True)).requires_grad
+
+
+def test_group_points_gather_backward_matches_atomic_scatter(dev):
+    """The gather form of the grouping gradient (no float atomics; chosen when many grid points share
+    few rows) == the oracle's scatter, incl. rows nobody references (0), a frame without queries and
+    channel counts that are not a power of two."""
+    rng = np.random.default_rng(17)
+    for C in (32, 3, 48):
+        cnt = np.array([300, 50, 200], np.int32)
+        ncnt = np.array([4000, 0, 2500], np.int32)
+        ns = 16
+        idx = np.concatenate([rng.integers(0, max(int(c * 0.3), 1), (m, ns)) for c, m in zip(cnt, ncnt)]).astype(np.int32)
+        g = rng.normal(size=(int(ncnt.sum()), C, ns)).astype(np.float32)
+        want = oracle.group_points_grad(g, idx, ncnt, cnt, int(cnt.sum()))
+        feats = T(rng.normal(size=(int(cnt.sum()), C)).astype(np.float32), dev).requires_grad_(True)
+        assert int(ncnt.sum()) * ns >= pointnet2_utils.GATHER_MIN_REFS_PER_ROW * int(cnt.sum())
+        out = pointnet2_utils.grouping_operation(feats, T(cnt, dev), T(idx, dev), T(ncnt, dev))
+        out.backward(T(g, dev))
+        np.testing.assert_allclose(feats.grad.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
+        assert float(feats.grad[cnt[0]:cnt[0] + cnt[1]].abs().max()) == 0.0      # the frame without queries
+
+
+def test_roi_grid_pool_row_major_training_path_equals_conv_formulation(dev):
+    """Training-mode NeighborVoxelSAModuleMSG: the row-major path (1x1 convs as matrix products,
+    BatchNorm on rows) == the module's conv formulation that mirrors voxel_pool_modules.py:88-108 --
+    outputs, input / parameter gradients and the BatchNorm running statistics."""
+    import copy
+    rng = np.random.default_rng(41)
+    B, Z, Y, X = 2, 5, 24, 20
+    idx, xyz, cnt = _voxel_scene(rng, B, Z, Y, X, 0.08)
+    feats = rng.normal(size=(len(idx), 16)).astype(np.float32)
+    M = 2 * 304                                   # M * 16 rows divisible by 128: the split-K product runs too
+    qc_xyz = np.stack([np.repeat(np.arange(B), M // B), rng.integers(0, X, M), rng.integers(0, Y, M),
+                       rng.integers(0, Z, M)], 1).astype(np.int32)
+    q = ((qc_xyz[:, 1:4] + rng.random((M, 3))) * np.array([0.1, 0.1, 0.2])).astype(np.float32)
+    torch.manual_seed(3)
+    a = voxel_pool_modules.NeighborVoxelSAModuleMSG(query_ranges=[[1, 1, 1], [2, 2, 2]], radii=[0.25, 0.4],
+                                                    nsamples=[16, 8], mlps=[[16, 32, 32], [16, 16, 24]]).to(dev).train()
+    b = copy.deepcopy(a)
+    b.USE_ROW_MAJOR = False
+    voxel_pool_modules.NeighborVoxelSAModuleMSG.SPLITK_MIN_ROWS = 1024
+    st = sp.SparseConvTensor(T(feats, dev), T(idx, dev), [Z, Y, X], B)
+    outs = []
+    for mod in (a, b):
+        f = T(feats, dev).requires_grad_(True)
+        out = mod(T(xyz, dev), T(cnt, dev), T(q, dev), torch.tensor([M // B] * B, dtype=torch.int32, device=dev),
+                  T(qc_xyz, dev), f, st)
+        (out * torch.linspace(0.5, 1.5, out.shape[1], device=dev)).square().mean().backward()
+        outs.append((out.detach(), f.grad))
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy(), rtol=1e-3, atol=1e-6)
+    for (n, p), (_, q2) in zip(a.named_parameters(), b.named_parameters()):
+        np.testing.assert_allclose(p.grad.cpu().numpy(), q2.grad.cpu().numpy(), rtol=2e-3,
+                                   atol=2e-5 * max(1e-3, float(q2.grad.abs().max())), err_msg=n)
+    for (n, u), (_, v) in zip(a.named_buffers(), b.named_buffers()):
+        np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=n)
+    voxel_pool_modules.NeighborVoxelSAModuleMSG.SPLITK_MIN_ROWS = 1 << 16

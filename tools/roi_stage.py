@@ -17,6 +17,31 @@ pts = torch.from_numpy(np.concatenate(frames)).to(dev)
 bidx = torch.from_numpy(np.concatenate([np.full(len(f), i, np.int32) for i, f in enumerate(frames)])).to(dev)
 torch.manual_seed(0)
 flow = det.VoxelRCNNFlow(K).to(dev).eval()
+if os.environ.get("ROI_TRAIN"):
+    # training path of the stage (tensor ops + group_points autograd), forward + backward
+    with torch.no_grad():
+        bd = flow(pts, bidx, B)
+        rois = bd["rois"][:, :128].contiguous()
+    flow.roi_pool.train()
+    flow.roi_fc.train()
+
+    def tstage():
+        for p in list(flow.roi_pool.parameters()) + list(flow.roi_fc.parameters()):
+            p.grad = None
+        pooled = flow.roi_pool(rois, bd["multi_scale_3d_features"], bd["multi_scale_3d_strides"], B)
+        c, r = flow.roi_fc(pooled)
+        (c.square().mean() + r.square().mean()).backward()
+
+    for _ in range(3):
+        tstage()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        tstage()
+    torch.cuda.synchronize()
+    print("RoI-grid pool + FC, TRAINING path fwd+bwd: %.2f ms (%d RoIs x 216 grid points, 3 scales)"
+          % ((time.perf_counter() - t0) / 10 * 1e3, rois.shape[0] * rois.shape[1]))
+    sys.exit(0)
 with torch.no_grad():
     bd = flow(pts, bidx, B)
     rois = bd["rois"]

@@ -104,3 +104,91 @@ torch.cuda.synchronize()
 dg = (time.perf_counter() - t0) / n
 pipe.check()
 print("  shape-static, one HIP graph: %.2f ms/step = %.0f frames/s; loss %.4f" % (dg * 1e3, B / dg, float(pipe.loss.detach())))
+
+
+# ---- the whole two-stage training step (config 3's shape on one GPU): + proposals (NMS 9000 -> 512), RoI
+# targets, RoI-grid pooling in training mode (autograd through group_points), FC towers, the three
+# RoI-head losses.  RoI sampling is deterministic here (the 128 best-scoring proposals per frame,
+# each matched to its best ground truth by 3-D IoU) where the reference samples at random.
+from glenet_amd.pcdet_ops.iou3d_nms import iou3d_nms_utils  # noqa: E402
+std_layer = torch.nn.Linear(256, 7).to(dev)
+torch.nn.init.normal_(std_layer.weight, std=0.001)
+roi_params = [p for m in (flow.roi_pool, flow.roi_fc, std_layer) for p in m.parameters()]
+R = 128
+ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+
+
+def full_step(timed=False):
+    for p in params + roi_params:
+        p.grad = None
+    if timed:
+        ev2[0].record()
+    bd = gb.voxelize_batch(pts, bidx, B, K, train=True)
+    bd = flow.map_to_bev(flow.backbone_3d(flow.vfe(bd)))
+    bd = flow.dense_head(flow.backbone_2d(bd))
+    if timed:
+        ev2[1].record()
+    with torch.no_grad():
+        tgt = target_assign.assign_targets([anchors], gt, [1], [0.6], [0.45])
+        cls, boxes = det.predicted_boxes(bd["cls_preds"], bd["box_preds"], bd.get("dir_cls_preds"), anchors)
+        rois, _, _ = det.proposal_layer(boxes, cls, 9000, 512, 0.8)
+        rois = rois[:, :R].contiguous()
+        # an untrained head proposes nothing near the ground truth: the first slots take jittered ground-truth
+        # boxes (what a trained first stage delivers) so that the regression / corner terms have foreground
+        for b in range(B):
+            n = min(int((gt[b, :, 7] > 0).sum()), R // 2)
+            jit = torch.tensor([0.2, -0.15, 0.05, 0.1, -0.05, 0.03, 0.08], device=dev)
+            rois[b, :n, :7] = gt[b, :n, :7] + jit
+        gt_of = torch.zeros(B, R, 8, device=dev)
+        iou = torch.zeros(B, R, device=dev)
+        for b in range(B):
+            n = int((gt[b, :, 7] > 0).sum())
+            m = iou3d_nms_utils.boxes_iou3d_gpu(rois[b, :, :7].contiguous(), gt[b, :n, :7].contiguous())
+            iou[b], arg = m.max(1)
+            gt_of[b] = gt[b, arg]
+        reg_valid = (iou > 0.55).long().view(-1)
+        cls_lab = ((iou - 0.25) / 0.5).clamp(0, 1).view(-1)
+        gt_ct = losses.canonical_gt_of_rois(rois, gt_of)
+        unc = torch.full((B * R, 7), 0.05, device=dev)
+    rpn, _ = losses.rpn_loss(bd["cls_preds"], bd["box_preds"], bd.get("dir_cls_preds"), tgt["box_cls_labels"],
+                             tgt["box_reg_targets"], anchors)
+    if timed:
+        ev2[2].record()
+    pooled = flow.roi_pool(rois, bd["multi_scale_3d_features"], bd["multi_scale_3d_strides"], B)
+    shared = flow.roi_fc.shared_fc_layer(pooled.reshape(pooled.shape[0], -1))
+    reg_feat = flow.roi_fc.reg_fc_layers(shared)
+    rcnn_reg, rcnn_std = flow.roi_fc.reg_pred_layer(reg_feat), std_layer(reg_feat)
+    rcnn_cls = flow.roi_fc.cls_pred_layer(flow.roi_fc.cls_fc_layers(shared))
+    if timed:
+        ev2[3].record()
+    l_cls = losses.rcnn_cls_loss(rcnn_cls, cls_lab)
+    l_kl, _ = losses.kl_reg_loss(rcnn_reg, rcnn_std, rois, gt_ct[..., :7], unc, reg_valid)
+    l_cor = losses.corner_loss(rcnn_reg, rois, gt_of[..., :7], reg_valid)
+    total = rpn + l_cls + l_kl + l_cor
+    if timed:
+        ev2[4].record()
+    total.backward()
+    if timed:
+        ev2[5].record()
+    return total, (rpn, l_cls, l_kl, l_cor), int(reg_valid.sum())
+
+
+for _ in range(3):
+    total, terms, nfg = full_step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    full_step()
+torch.cuda.synchronize()
+df = (time.perf_counter() - t0) / 10
+st2 = []
+for _ in range(3):
+    full_step(True)
+    torch.cuda.synchronize()
+    st2.append([ev2[i].elapsed_time(ev2[i + 1]) for i in range(5)])
+st2 = np.mean(st2, 0)
+print("two-stage training step, %d frames x %d RoIs: %.2f ms/step = %.0f frames/s; loss %.4f = rpn %.4f + rcnn cls %.4f "
+      "+ KL reg %.4f + corner %.4f; %d foreground RoIs" % ((B, R, df * 1e3, B / df, float(total.detach()))
+                                                          + tuple(float(t.detach()) for t in terms) + (nfg,)))
+print("  stages (ms): first stage fwd %.2f | targets + proposals + RoI targets + rpn loss %.2f | RoI-grid pool + FC "
+      "(training path) %.2f | RoI losses %.2f | backward %.2f" % tuple(st2))
