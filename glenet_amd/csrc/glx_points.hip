@@ -553,15 +553,22 @@ extern "C" int glx_group_points_grad(int B, int M, int C, int N, int nsample, co
 // slots repeat the first hit, neighbouring grid points share voxels), so equal rows are combined
 // inside the wave first -- one integer atomic per distinct row and wave instead of one per
 // reference (the per-reference version spent 7 / 12 ms in these two kernels on the hot rows).
+// idx_cnt == NULL: idx holds GLOBAL rows as the voxel query leaves them (idx[m,0] < 0 = empty ball,
+// whose slots reference nothing); else per-frame rows as grouping_operation takes them.
 __global__ void k_gp_count(int B, int M, int ns, const int* __restrict__ idx, const int* __restrict__ idx_cnt,
                            const int* __restrict__ feat_cnt, int* __restrict__ cnt) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = t < (long long)M * ns;
+  bool valid = t < (long long)M * ns;
   int row = -1;
   if (valid) {
-    int start;
-    batch_of((int)(t / ns), idx_cnt, B, start, feat_cnt);
-    row = start + idx[t];
+    if (idx_cnt) {
+      int start;
+      batch_of((int)(t / ns), idx_cnt, B, start, feat_cnt);
+      row = start + idx[t];
+    } else {
+      valid = idx[t / ns * ns] >= 0;
+      row = idx[t];
+    }
   }
   const int lane = threadIdx.x & 63;
   unsigned long long todo = __ballot(valid);
@@ -578,12 +585,17 @@ __global__ void k_gp_fill(int B, int M, int ns, const int* __restrict__ idx, con
                           const int* __restrict__ feat_cnt, const int* __restrict__ offs,
                           int* __restrict__ cursor, int* __restrict__ refs) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = t < (long long)M * ns;
+  bool valid = t < (long long)M * ns;
   int row = -1;
   if (valid) {
-    int start;
-    batch_of((int)(t / ns), idx_cnt, B, start, feat_cnt);
-    row = start + idx[t];
+    if (idx_cnt) {
+      int start;
+      batch_of((int)(t / ns), idx_cnt, B, start, feat_cnt);
+      row = start + idx[t];
+    } else {
+      valid = idx[t / ns * ns] >= 0;
+      row = idx[t];
+    }
   }
   const int lane = threadIdx.x & 63;
   unsigned long long todo = __ballot(valid);
@@ -606,12 +618,13 @@ __global__ void k_gp_fill(int B, int M, int ns, const int* __restrict__ idx, con
 // (lane = channel x reference slot) and flushed with one atomic add per (row, channel); a row that
 // spans k chunks receives k adds instead of one per reference.
 #define GP_CHUNK 64
-__global__ __launch_bounds__(256) void k_gp_gather(int N, int C, int ns, long long T,
+__global__ __launch_bounds__(256) void k_gp_gather(int N, int C, int ns, int rows_layout,
                                                    const float* __restrict__ grad_out,
                                                    const int* __restrict__ offs, const int* __restrict__ refs,
                                                    float* __restrict__ grad_features) {
   const int lane = threadIdx.x & 63;
   const long long p0 = ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * GP_CHUNK;
+  const long long T = offs[N];                 // references actually bucketed (empty balls hold none)
   if (p0 >= T) return;
   const long long p1 = p0 + GP_CHUNK < T ? p0 + GP_CHUNK : T;
   const int CL = (C < 64 && (C & (C - 1)) == 0) ? C : 64;   // channels covered by one pass of the wave
@@ -633,8 +646,12 @@ __global__ __launch_bounds__(256) void k_gp_gather(int N, int C, int ns, long lo
       if (c < C && j < J) {
         for (long long e = e0 + j; e < e1; e += J) {
           const int r = refs[e];
-          const int m = r / ns, sl = r - m * ns;
-          acc += grad_out[((long long)m * C + c) * ns + sl];
+          if (rows_layout) {                    // grad_out (M, ns, C): a reference's channels are contiguous
+            acc += grad_out[(long long)r * C + c];
+          } else {                              // grad_out (M, C, ns) as grouping_operation produces it
+            const int m = r / ns, sl = r - m * ns;
+            acc += grad_out[((long long)m * C + c) * ns + sl];
+          }
         }
       }
       for (int d = CL; d < 64; d <<= 1) acc += __shfl_xor(acc, d, 64);
@@ -649,13 +666,12 @@ extern "C" size_t glx_group_points_grad_workspace_bytes(int M, int N, int nsampl
          glx_scan_workspace_bytes(N + 1) + 256;
 }
 
-extern "C" int glx_group_points_grad_gather(int B, int M, int C, int N, int nsample, const float* grad_out,
-                                            const int32_t* idx, const int32_t* idx_batch_cnt,
-                                            const int32_t* features_batch_cnt, float* grad_features,
-                                            void* workspace, size_t workspace_bytes, void* stream) {
+static int gp_grad_gather_impl(int B, int M, int C, int N, int nsample, const float* grad_out,
+                               const int32_t* idx, const int32_t* idx_batch_cnt,
+                               const int32_t* features_batch_cnt, float* grad_features, int rows_layout,
+                               void* workspace, size_t workspace_bytes, void* stream) {
   if (N <= 0 || C <= 0) return GLX_OK;
-  GLX_REQUIRE(grad_features && (M == 0 || (grad_out && idx && idx_batch_cnt && features_batch_cnt)),
-              "glx_group_points_grad_gather: null");
+  GLX_REQUIRE(grad_features && (M == 0 || (grad_out && idx)), "glx_group_points_grad_gather: null");
   const size_t need = glx_group_points_grad_workspace_bytes(M, N, nsample) - 256;
   if (!workspace || workspace_bytes < need) {
     glx_set_error("glx_group_points_grad_gather: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -685,9 +701,52 @@ extern "C" int glx_group_points_grad_gather(int B, int M, int C, int N, int nsam
   if (rc != GLX_OK) return rc;
   if (total > 0)
     hipLaunchKernelGGL(k_gp_gather, dim3((unsigned)glx_divup(glx_divup(total, (long long)GP_CHUNK), 4LL)), dim3(256),
-                       0, st, N, C, nsample, total, grad_out, (const int*)offs, (const int*)refs, grad_features);
+                       0, st, N, C, nsample, rows_layout, grad_out, (const int*)offs, (const int*)refs,
+                       grad_features);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
+}
+
+extern "C" int glx_group_points_grad_gather(int B, int M, int C, int N, int nsample, const float* grad_out,
+                                            const int32_t* idx, const int32_t* idx_batch_cnt,
+                                            const int32_t* features_batch_cnt, float* grad_features,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(M == 0 || (idx_batch_cnt && features_batch_cnt), "glx_group_points_grad_gather: null counts");
+  return gp_grad_gather_impl(B, M, C, N, nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt,
+                             grad_features, 0, workspace, workspace_bytes, stream);
+}
+
+// ------------------------------------------------------------------ row-major grouping
+// out[m, s, :] = features[idx[m, s], :] with idx GLOBAL rows as the voxel query leaves them
+// (idx[m,0] < 0: empty ball -> zeros): the (M, ns, C) layout keeps a neighbour's channels contiguous
+// (128-byte row reads and writes; the reference's (M, C, ns) layout transposes on the way out and
+// again in the gradient).  Gradient: the gather form above on contiguous rows.
+__global__ void k_group_rows(const float* __restrict__ feats, const int* __restrict__ idx, long long total,
+                             int C, int ns, float* __restrict__ out) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const long long ms = e / C;
+  const int c = (int)(e - ms * C);
+  const long long m = ms / ns;
+  out[e] = idx[m * ns] < 0 ? 0.f : feats[(long long)idx[ms] * C + c];
+}
+
+extern "C" int glx_group_rows(const float* features, const int32_t* idx, int M, int nsample, int C,
+                              float* out, void* stream) {
+  const long long total = (long long)M * nsample * C;
+  if (total <= 0) return GLX_OK;
+  GLX_REQUIRE(features && idx && out, "glx_group_rows: null pointer");
+  hipLaunchKernelGGL(k_group_rows, dim3((unsigned)glx_divup(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     features, idx, total, C, nsample, out);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+extern "C" int glx_group_rows_grad(const float* grad_out, const int32_t* idx, int M, int nsample, int C, int N,
+                                   float* grad_features, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  return gp_grad_gather_impl(1, M, C, N, nsample, grad_out, idx, nullptr, nullptr, grad_features, 1, workspace,
+                             workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------ (boxes x points) mask

@@ -53,6 +53,24 @@ def group_points_grad_gather_wrapper(B, M, C, N, nsample, grad_out, idx, idx_bat
     return 1
 
 
+def group_rows_wrapper(features, idx, out):
+    """Row-major grouping on the voxel query's raw output: features (N,C), idx (M,ns) GLOBAL rows with
+    idx[m,0] < 0 for an empty ball, out (M,ns,C) (zeros for empty balls)."""
+    _lib.check_cuda(features, idx, out)
+    call("glx_group_rows", features, idx, idx.shape[0], idx.shape[1], features.shape[1], out)
+    return 1
+
+
+def group_rows_grad_wrapper(grad_out, idx, grad_features):
+    """Gradient of group_rows_wrapper: grad_out (M,ns,C) -> grad_features (N,C), gather form."""
+    _lib.check_cuda(grad_out, idx, grad_features)
+    m, ns = idx.shape
+    n, c = grad_features.shape
+    ws = _lib.workspace.get(_lib.query("glx_group_points_grad_workspace_bytes", m, n, ns), grad_out.device)
+    call("glx_group_rows_grad", grad_out, idx, m, ns, c, n, grad_features, ws, _lib.size_arg(ws.numel()))
+    return 1
+
+
 def stack_farthest_point_sampling_wrapper(xyz, temp, xyz_batch_cnt, idxs, num_sampled_points):
     """sampling.cpp:40-60: xyz (N,3), temp (N) filled with 1e10, idxs (sum m) int32 out."""
     _lib.check_cuda(xyz, temp, xyz_batch_cnt, idxs, num_sampled_points)

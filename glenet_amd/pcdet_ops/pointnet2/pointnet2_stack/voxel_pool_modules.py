@@ -15,6 +15,31 @@ def _conv_bn(cin, cout, dims, relu=False):
     return nn.Sequential(conv, bn, nn.ReLU()) if relu else nn.Sequential(conv, bn)
 
 
+class GroupRows(torch.autograd.Function):
+    """out[m, s, :] = features[idx[m, s], :] on the voxel query's raw (M, ns) global rows (zeros for an
+    empty ball): the (M, ns, C) layout of the row-major training path (csrc/glx_points.hip,
+    k_group_rows; gradient = the gather form on contiguous rows)."""
+
+    @staticmethod
+    def forward(ctx, features, idx):
+        from . import pointnet2_stack_cuda as pointnet2
+        features = features.contiguous()
+        out = torch.empty((idx.shape[0], idx.shape[1], features.shape[1]), dtype=features.dtype,
+                          device=features.device)
+        pointnet2.group_rows_wrapper(features, idx, out)
+        ctx.save_for_backward(idx)
+        ctx.n = features.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import pointnet2_stack_cuda as pointnet2
+        idx, = ctx.saved_tensors
+        grad = torch.empty((ctx.n, grad_out.shape[2]), dtype=grad_out.dtype, device=grad_out.device)
+        pointnet2.group_rows_grad_wrapper(grad_out.contiguous(), idx, grad)
+        return grad, None
+
+
 class NeighborVoxelSAModuleMSG(nn.Module):
     def __init__(self, *, query_ranges, radii, nsamples, mlps, use_xyz=True, pool_method='max_pool'):
         super().__init__()
@@ -159,14 +184,17 @@ class NeighborVoxelSAModuleMSG(nn.Module):
                       voxel2point_indices):
         outs = []
         m = new_xyz.shape[0]
+        xyz, new_xyz = xyz.contiguous(), new_xyz.contiguous()
         for grouper, mlp_in, mlp_pos, mlp_out in zip(self.groupers, self.mlps_in, self.mlps_pos, self.mlps_out):
             feats = self._conv_bn_rows(mlp_in, features)                                 # (N, c_mid)
-            g_feat, g_xyz, empty = grouper(coords_bzyx, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, feats,
-                                           voxel2point_indices)                          # (M,c,ns), (M,3,ns)
-            keep = (~empty).to(g_feat.dtype).view(m, 1, 1)
-            rel = (g_xyz - new_xyz.unsqueeze(-1)) * keep
-            ns = rel.shape[-1]
-            pos = self._conv_bn_rows(mlp_pos, rel.permute(0, 2, 1).reshape(m * ns, 3))   # (M*ns, c_mid)
-            x = F.relu((g_feat * keep).permute(0, 2, 1) + pos.view(m, ns, -1))           # (M, ns, c_mid)
+            ns = grouper.nsample
+            idx = voxel_query_utils.voxel_query_raw(grouper.max_range, grouper.radius, ns, xyz, new_xyz,
+                                                    coords_bzyx, voxel2point_indices)    # (M, ns) global rows
+            keep = (idx[:, :1] >= 0).to(feats.dtype).view(m, 1, 1)
+            g_feat = GroupRows.apply(feats, idx)                                         # (M, ns, c_mid)
+            with torch.no_grad():
+                rel = (GroupRows.apply(xyz, idx) - new_xyz.view(m, 1, 3)) * keep         # (M, ns, 3)
+            pos = self._conv_bn_rows(mlp_pos, rel.view(m * ns, 3))                       # (M*ns, c_mid)
+            x = F.relu(g_feat + pos.view(m, ns, -1))                                     # (M, ns, c_mid)
             outs.append(self._conv_bn_rows(mlp_out, x.max(dim=1)[0]))                    # (M, c_out)
         return torch.cat(outs, dim=1)

@@ -357,6 +357,13 @@ int glx_group_points_grad(int B, int M, int C, int N, int nsample, const float* 
  * the right choice when many grid points share few rows (RoI-grid pooling).  grad_features (N,C) is
  * written completely (rows without references get 0); workspace >= the query below. */
 size_t glx_group_points_grad_workspace_bytes(int M, int N, int nsample);
+/* Row-major grouping on the voxel query's own output: idx (M,nsample) GLOBAL rows, idx[m,0] < 0 =
+ * empty ball; out (M, nsample, C) = features[idx] (zeros for an empty ball).  glx_group_rows_grad:
+ * grad_out (M, nsample, C) -> grad_features (N, C), gather form, same workspace query. */
+int glx_group_rows(const float* features, const int32_t* idx, int M, int nsample, int C, float* out,
+                   void* stream);
+int glx_group_rows_grad(const float* grad_out, const int32_t* idx, int M, int nsample, int C, int N,
+                        float* grad_features, void* workspace, size_t workspace_bytes, void* stream);
 int glx_group_points_grad_gather(int B, int M, int C, int N, int nsample, const float* grad_out,
                                  const int32_t* idx, const int32_t* idx_batch_cnt,
                                  const int32_t* features_batch_cnt, float* grad_features,

@@ -586,3 +586,26 @@ def test_roi_grid_pool_row_major_training_path_equals_conv_formulation(dev):
     for (n, u), (_, v) in zip(a.named_buffers(), b.named_buffers()):
         np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=n)
     voxel_pool_modules.NeighborVoxelSAModuleMSG.SPLITK_MIN_ROWS = 1 << 16
+
+
+def test_group_rows_and_gradient_match_indexing(dev):
+    """GroupRows (row-major grouping on raw query rows): out == features[idx] with empty balls zeroed
+    (bit-exact: copies), gradient == index_add of the incoming rows (gather form, fp32 sum order
+    differs -> rtol 1e-5).  C = 32 (feature width) and C = 3 (coordinates, non-power-of-two)."""
+    rng = np.random.default_rng(5)
+    for n, m, ns, c in ((700, 300, 16, 32), (50, 129, 8, 3), (4000, 64, 16, 16)):
+        feats = rng.normal(size=(n, c)).astype(np.float32)
+        idx = rng.integers(0, n, (m, ns)).astype(np.int32)
+        empty = rng.random(m) < 0.3
+        idx[empty, 0] = -1
+        idx[empty, 1:] = rng.integers(-5, n, (int(empty.sum()), ns - 1))        # unspecified slots
+        f = T(feats, dev).requires_grad_(True)
+        out = voxel_pool_modules.GroupRows.apply(f, T(idx, dev))
+        want = feats[np.where(empty[:, None], 0, idx)] * (~empty)[:, None, None]
+        assert np.array_equal(out.detach().cpu().numpy(), want.astype(np.float32))
+        g = rng.normal(size=(m, ns, c)).astype(np.float32)
+        out.backward(T(g, dev))
+        ref = np.zeros((n, c), np.float64)
+        live = ~empty
+        np.add.at(ref, idx[live].reshape(-1), g[live].reshape(-1, c).astype(np.float64))
+        np.testing.assert_allclose(f.grad.cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
