@@ -92,6 +92,10 @@ def size_arg(n):
     return c_size_t(int(n))
 
 
+def double_arg(x):
+    return ctypes.c_double(float(x))
+
+
 def check_cuda(*tensors):
     for t in tensors:
         if t is None:

@@ -684,3 +684,180 @@ extern "C" int glx_nms_vote(float* boxes, float* scores, const float* variance, 
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
+
+// ------------------------------------------------------------------ RoI targets (training)
+// ProposalTargetLayer (pcdet/models/roi_heads/target_assigner/proposal_target_layer.py:13-239) for the
+// whole batch in two launches and no host round trip; the reference loops over frames and classes
+// in Python with an (R, G) IoU matrix, masks, nonzero() and host-side random draws for each.
+//
+// k_roi_match: a wave per RoI, a lane per ground truth of its frame (trailing all-zero rows trimmed as
+// :98-102), 3-D IoU exactly as boxes_iou3d_gpu composes it (BEV overlap x height overlap / clamped
+// union volume, iou3d_nms_utils.py:88-121), running maximum with the smallest index on ties
+// (torch.max).  same_class: only ground truths of the RoI's label compete (:209-238); a RoI without
+// one keeps overlap 0 and assignment 0.
+#define ROI_MAX_GT 256
+__global__ __launch_bounds__(256) void k_roi_match(const float* __restrict__ rois, const int64_t* __restrict__ roi_labels,
+                                                   int R, int roi_ld, const float* __restrict__ gt, int G, int gt_ld,
+                                                   int same_class, float* __restrict__ max_overlaps,
+                                                   int* __restrict__ assignment, int* __restrict__ n_gt_out) {
+  __shared__ PBox s_gt[ROI_MAX_GT];
+  __shared__ float s_lo[ROI_MAX_GT], s_hi[ROI_MAX_GT], s_vol[ROI_MAX_GT];
+  __shared__ int s_label[ROI_MAX_GT];
+  __shared__ int s_n;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  gt += (long long)b * G * gt_ld;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  for (int g = tid; g < G; g += blockDim.x) {
+    const float* bx = gt + (long long)g * gt_ld;
+    float sum = 0.f;
+    for (int c = 0; c < gt_ld; ++c) sum += bx[c];
+    if (sum != 0.f) atomicMax(&s_n, g + 1);
+    PBox p;
+    p.cx = bx[0]; p.cy = bx[1];
+    p.hx = bx[3] / 2; p.hy = bx[4] / 2;
+    p.c = f_cos(bx[6]); p.s = f_sin(bx[6]);
+    p.rad = sqrtf(p.hx * p.hx + p.hy * p.hy);
+    p.area = bx[3] * bx[4];
+    s_gt[g] = p;
+    s_lo[g] = bx[2] - bx[5] / 2;
+    s_hi[g] = bx[2] + bx[5] / 2;
+    s_vol[g] = bx[3] * bx[4] * bx[5];
+    s_label[g] = (int)(long long)bx[gt_ld - 1];
+  }
+  __syncthreads();
+  const int n = s_n;
+  if (tid == 0 && blockIdx.x == 0) n_gt_out[b] = n;
+  const int r = blockIdx.x * (blockDim.x >> 6) + (tid >> 6);      // a wave per RoI, lane = ground truth
+  if (r >= R) return;
+  const int lane = tid & 63;
+  const float* bx = rois + ((long long)b * R + r) * roi_ld;
+  PBox A;
+  A.cx = bx[0]; A.cy = bx[1];
+  A.hx = bx[3] / 2; A.hy = bx[4] / 2;
+  A.c = f_cos(bx[6]); A.s = f_sin(bx[6]);
+  A.rad = sqrtf(A.hx * A.hx + A.hy * A.hy);
+  A.area = bx[3] * bx[4];
+  const float lo = bx[2] - bx[5] / 2, hi = bx[2] + bx[5] / 2, vol = bx[3] * bx[4] * bx[5];
+  const int label = (int)roi_labels[(long long)b * R + r];
+  float best = -1.f;
+  int arg = 0x7fffffff;
+  for (int g = lane; g < n; g += 64) {
+    if (same_class && s_label[g] != label) continue;
+    float bev = 0.f;
+    if (!pbox_far(A, s_gt[g])) bev = box_overlap<false>(rbox_from(A), rbox_from(s_gt[g]));
+    const float h = fmaxf(mn(hi, s_hi[g]) - mx(lo, s_lo[g]), 0.f);
+    const float inter = bev * h;
+    const float v = inter / fmaxf(vol + s_vol[g] - inter, 1e-6f);
+    if (v > best) { best = v; arg = g; }                           // ascending g within a lane: first maximum
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {                              // maximum, smallest index on ties
+    const float ob = __shfl_xor(best, d, 64);
+    const int oa = __shfl_xor(arg, d, 64);
+    if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+  }
+  if (lane == 0) {
+    max_overlaps[(long long)b * R + r] = best < 0.f ? 0.f : best;
+    assignment[(long long)b * R + r] = best < 0.f ? 0 : arg;
+  }
+}
+
+// k_roi_sample: one block per frame.  Categories by overlap (:128-137): foreground >= fg_thresh,
+// easy background < bg_lo, hard background in between; lists in ascending RoI order (= nonzero()).
+// The random draws come in as uniform numbers so that the caller owns the generator:
+//   key (B, R)  -- foreground RoIs are taken in ascending key order (a uniform random subset and order:
+//                  the reference's permutation, :147-148);
+//   pick (B, P) -- slot q draws list[floor(pick[q] * len(list))] with replacement (torch.randint, :186-207;
+//                  the all-foreground case :158-162).
+// Emits the sampled RoI index and its ground-truth index (-1: the frame has none -> zero row, :103).
+struct RoiSampleCfg {
+  int P, fg_per_image;
+  float fg_thresh, bg_lo, reg_fg;
+  double hard_ratio;
+};
+
+__global__ __launch_bounds__(256) void k_roi_sample(const float* __restrict__ max_overlaps, const int* __restrict__ assignment,
+                                                    const int* __restrict__ n_gt, const float* __restrict__ key,
+                                                    const float* __restrict__ pick, int R, RoiSampleCfg cfg,
+                                                    int* __restrict__ sampled, int* __restrict__ sampled_gt) {
+  extern __shared__ int s_mem[];
+  int* s_list[3] = {s_mem, s_mem + R, s_mem + 2 * R};          // fg, hard, easy
+  __shared__ int s_cnt[3][257];
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  max_overlaps += (long long)b * R;
+  key += (long long)b * R;
+  pick += (long long)b * cfg.P;
+  const int per = (R + nt - 1) / nt, r0 = tid * per, r1 = min(R, r0 + per);
+  auto category = [&](float v) { return v >= cfg.fg_thresh ? 0 : (v < cfg.bg_lo ? 2 : 1); };
+  int c3[3] = {0, 0, 0};
+  for (int r = r0; r < r1; ++r) ++c3[category(max_overlaps[r])];
+  for (int k = 0; k < 3; ++k) s_cnt[k][tid] = c3[k];
+  __syncthreads();
+  if (tid < 3) {                                               // exclusive scan over the threads' chunks
+    int run = 0;
+    for (int t = 0; t < nt; ++t) { const int v = s_cnt[tid][t]; s_cnt[tid][t] = run; run += v; }
+    s_cnt[tid][256] = run;
+  }
+  __syncthreads();
+  int w3[3] = {s_cnt[0][tid], s_cnt[1][tid], s_cnt[2][tid]};
+  for (int r = r0; r < r1; ++r) { const int k = category(max_overlaps[r]); s_list[k][w3[k]++] = r; }
+  __syncthreads();
+  const int nfg = s_cnt[0][256], nhard = s_cnt[1][256], neasy = s_cnt[2][256], nbg = nhard + neasy;
+  const int P = cfg.P;
+  int* out = sampled + (long long)b * P;
+  int take = 0;
+  if (nfg > 0 && nbg > 0) {
+    take = min(cfg.fg_per_image, nfg);
+    for (int i = tid; i < nfg; i += nt) {                      // rank of every foreground RoI by (key, index)
+      const int ri = s_list[0][i];
+      const float ki = key[ri];
+      int rank = 0;
+      for (int j = 0; j < nfg; ++j) {
+        const int rj = s_list[0][j];
+        const float kj = key[rj];
+        rank += (kj < ki || (kj == ki && rj < ri)) ? 1 : 0;
+      }
+      if (rank < take) out[rank] = ri;
+    }
+  } else if (nfg > 0) {                                        // only foreground: P draws with replacement
+    for (int q = tid; q < P; q += nt) out[q] = s_list[0][min((int)(pick[q] * (float)nfg), nfg - 1)];
+    take = P;
+  }
+  const int nslots = P - take;
+  if (nslots > 0 && nbg > 0) {
+    int hard_num;
+    if (nhard > 0 && neasy > 0) hard_num = min((int)((double)nslots * cfg.hard_ratio), nhard);
+    else hard_num = nhard > 0 ? nslots : 0;
+    for (int q = tid; q < nslots; q += nt) {
+      const bool hard = q < hard_num;
+      const int len = hard ? nhard : neasy;
+      out[take + q] = s_list[hard ? 1 : 2][min((int)(pick[take + q] * (float)len), len - 1)];
+    }
+  }
+  __syncthreads();
+  const int n = n_gt[b];
+  for (int q = tid; q < P; q += nt)
+    sampled_gt[(long long)b * P + q] = n > 0 ? assignment[(long long)b * R + out[q]] : -1;
+}
+
+extern "C" int glx_roi_targets(const float* rois, const int64_t* roi_labels, int B, int R, int roi_ld,
+                               const float* gt_boxes, int G, int gt_ld, int same_class, const float* key,
+                               const float* pick, int P, int fg_per_image, float fg_thresh, float bg_lo,
+                               float reg_fg, double hard_ratio, float* max_overlaps, int32_t* assignment,
+                               int32_t* n_gt, int32_t* sampled, int32_t* sampled_gt, void* stream) {
+  if (B <= 0 || P <= 0) return GLX_OK;
+  GLX_REQUIRE(rois && roi_labels && gt_boxes && key && pick && max_overlaps && assignment && n_gt && sampled &&
+              sampled_gt, "glx_roi_targets: null pointer");
+  GLX_REQUIRE(R > 0 && R <= 8192, "glx_roi_targets: %d RoIs per frame (1..8192)", R);
+  GLX_REQUIRE(G > 0 && G <= ROI_MAX_GT, "glx_roi_targets: %d ground-truth rows per frame (1..%d)", G, ROI_MAX_GT);
+  GLX_REQUIRE(roi_ld >= 7 && gt_ld >= 8, "glx_roi_targets: rois need >= 7 columns, ground truths >= 8");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_roi_match, dim3(glx_divup(R, 4), B), dim3(256), 0, st, rois, roi_labels, R, roi_ld, gt_boxes, G,
+                     gt_ld, same_class, max_overlaps, assignment, n_gt);
+  RoiSampleCfg cfg{P, fg_per_image, fg_thresh, bg_lo, reg_fg, hard_ratio};
+  hipLaunchKernelGGL(k_roi_sample, dim3(B), dim3(256), (size_t)3 * R * sizeof(int), st, (const float*)max_overlaps,
+                     (const int*)assignment, (const int*)n_gt, key, pick, R, cfg, sampled, sampled_gt);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

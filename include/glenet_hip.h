@@ -533,6 +533,19 @@ int glx_pointnet_feat_small(const float* points, int B, int Cin, int P, int C1, 
                             const float* W1, const float* b1, const float* W2, const float* b2,
                             const float* W3, const float* b3, float* out, void* stream);
 
+/* RoI targets of the second stage for a whole batch, two launches, no host round trip
+ * (replaces ProposalTargetLayer.sample_rois_for_rcnn + subsample_rois + get_max_iou_with_same_class,
+ * pcdet/models/roi_heads/target_assigner/proposal_target_layer.py:65-239).
+ * rois (B,R,roi_ld>=7), roi_labels (B,R) int64, gt_boxes (B,G,gt_ld>=8) zero-padded with the class id in
+ * the last column.  key (B,R) and pick (B,P) are uniform [0,1) numbers supplied by the caller (foreground
+ * order / draws with replacement).  Outputs: max_overlaps (B,R), assignment (B,R) ground-truth index,
+ * n_gt (B) trimmed count, sampled (B,P) RoI index, sampled_gt (B,P) ground-truth index or -1. */
+int glx_roi_targets(const float* rois, const int64_t* roi_labels, int B, int R, int roi_ld,
+                    const float* gt_boxes, int G, int gt_ld, int same_class, const float* key,
+                    const float* pick, int P, int fg_per_image, float fg_thresh, float bg_lo, float reg_fg,
+                    double hard_ratio, float* max_overlaps, int32_t* assignment, int32_t* n_gt,
+                    int32_t* sampled, int32_t* sampled_gt, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

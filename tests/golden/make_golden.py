@@ -611,8 +611,107 @@ def make_target_assign_ref():
           "dont-care", (lab < 0).sum(1))
 
 
+def make_roi_targets_ref():
+    """roi_targets_ref.npz: the reference's ProposalTargetLayer (imported unmodified from
+    pcdet/models/roi_heads/target_assigner/proposal_target_layer.py) run on CPU, 4 frames x 96 RoIs ->
+    32 samples: a frame with foreground and both backgrounds, a frame without ground truth, a frame
+    whose RoIs are all foreground (the draws-with-replacement branch) and a frame with interior
+    padding; with SAMPLE_ROI_BY_EACH_CLASS on and off, CLS_SCORE_TYPE roi_iou and cls.
+    Stand-ins, disclosed: (1) `iou3d_nms_utils.boxes_iou3d_gpu` needs the CUDA extension, which cannot
+    be built here -- the layer is given oracle.boxes_iou3d instead (itself pinned bit-exact to the
+    reference's rotated-overlap routines, see iou3d_ref.npz); the golden therefore pins the layer's own
+    logic (trimming, per-class matching, categories, counts, gathers, label formulas) on top of that IoU.
+    (2) the config object is a dict with attribute access (easydict is not installed).  (3) the
+    extension modules iou3d_nms_utils imports are empty placeholders.  The layer's random draws are not
+    replayed: every subsample_rois call is logged (its overlaps in, its sampled indices out) and the
+    parity test feeds our sampler the uniform numbers that reproduce exactly those draws."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import oracle
+    for name, path in (("pcdet", "pcdet"), ("pcdet.utils", "pcdet/utils"), ("pcdet.ops", "pcdet/ops"),
+                       ("pcdet.ops.iou3d_nms", "pcdet/ops/iou3d_nms"), ("pcdet.models", "pcdet/models"),
+                       ("pcdet.models.roi_heads", "pcdet/models/roi_heads"),
+                       ("pcdet.models.roi_heads.target_assigner", "pcdet/models/roi_heads/target_assigner")):
+        m = sys.modules.get(name)
+        if m is None or not hasattr(m, "__path__"):
+            m = types.ModuleType(name)
+            sys.modules[name] = m
+        m.__path__ = [os.path.join(REF, path)]
+    sys.modules.setdefault("SharedArray", types.ModuleType("SharedArray"))
+    for ext in ("pcdet.ops.roiaware_pool3d.roiaware_pool3d_cuda", "pcdet.ops.iou3d_nms.iou3d_nms_cuda"):
+        sys.modules.setdefault(ext, types.ModuleType(ext))
+    ptl = importlib.import_module("pcdet.models.roi_heads.target_assigner.proposal_target_layer")
+    ptl.iou3d_nms_utils.boxes_iou3d_gpu = lambda a, b: torch.from_numpy(
+        oracle.boxes_iou3d(a[:, :7].numpy().astype(np.float32), b[:, :7].numpy().astype(np.float32)))
+
+    class Cfg(dict):
+        __getattr__ = dict.__getitem__
+
+    rng = np.random.default_rng(77)
+    B, R, G, P = 4, 96, 12, 32
+
+    def boxes(n):
+        return np.concatenate([rng.uniform([0, -20, -2], [50, 20, 0], (n, 3)), rng.uniform([3, 1.4, 1.3], [4.5, 1.9, 1.8], (n, 3)),
+                               rng.uniform(-3.1, 3.1, (n, 1))], 1).astype(np.float32)
+
+    gt = np.zeros((B, G, 8), np.float32)
+    n_gt = [7, 0, 4, 9]
+    for b, n in enumerate(n_gt):
+        gt[b, :n, :7] = boxes(n)
+        gt[b, :n, 7] = rng.integers(1, 4, n)
+    gt[3, 2] = 0                                       # interior padding row: stays a (zero-IoU) candidate
+    rois = np.zeros((B, R, 7), np.float32)
+    labels = np.zeros((B, R), np.int64)
+    for b in range(B):
+        rois[b] = boxes(R)
+        labels[b] = rng.integers(1, 4, R)
+        n = n_gt[b]
+        if n:
+            src = rng.integers(0, n, R)
+            jitter = rng.normal(0, 1, (R, 7)).astype(np.float32) * np.array([0.5, 0.3, 0.1, 0.2, 0.1, 0.1, 0.15], np.float32)
+            near = rng.random(R) < (1.0 if b == 2 else 0.6)
+            scale = 0.1 if b == 2 else 1.0            # frame 2: every RoI hugs a ground truth -> all foreground
+            rois[b][near] = (gt[b, src, :7] + jitter * scale)[near]
+            labels[b][near] = np.where(rng.random(R) < (1.0 if b == 2 else 0.8), gt[b, src, 7], labels[b])[near]
+    scores = rng.random((B, R)).astype(np.float32)
+    unc = rng.uniform(0.01, 0.5, (B, G, 7)).astype(np.float32)
+    out = dict(rois=rois, roi_labels=labels, roi_scores=scores, gt_boxes=gt, gt_uncertaintys=unc)
+    np.random.seed(5)
+    torch.manual_seed(5)
+    # the reference cannot take gt_uncertaintys together with a frame without ground truth (it indexes an
+    # empty tensor, :124): that input runs on frames 0, 2, 3 only
+    for tag, each, kind, frames in (("each_iou", True, "roi_iou", [0, 1, 2, 3]), ("all_cls", False, "cls", [0, 1, 2, 3]),
+                                    ("unc", True, "roi_iou", [0, 2, 3])):
+        cfg = Cfg(ROI_PER_IMAGE=P, FG_RATIO=0.5, SAMPLE_ROI_BY_EACH_CLASS=each, CLS_SCORE_TYPE=kind, CLS_FG_THRESH=0.75,
+                  CLS_BG_THRESH=0.25, CLS_BG_THRESH_LO=0.1, HARD_BG_RATIO=0.8, REG_FG_THRESH=0.55)
+        layer = ptl.ProposalTargetLayer(cfg)
+        log = []
+        inner = layer.subsample_rois
+
+        def logged(max_overlaps, inner=inner, log=log):
+            s = inner(max_overlaps=max_overlaps)
+            log.append((max_overlaps.numpy().copy(), s.numpy().copy()))
+            return s
+        layer.subsample_rois = logged
+        bd = dict(batch_size=len(frames), rois=torch.from_numpy(rois[frames]), roi_scores=torch.from_numpy(scores[frames]),
+                  roi_labels=torch.from_numpy(labels[frames]), gt_boxes=torch.from_numpy(gt[frames]))
+        if tag == "unc":
+            bd["gt_uncertaintys"] = torch.from_numpy(unc[frames])
+        td = layer.forward(bd)
+        out[tag + "_max_overlaps"] = np.stack([l[0] for l in log])
+        out[tag + "_sampled"] = np.stack([l[1] for l in log])
+        for k, v in td.items():
+            if v is not None:
+                out[tag + "_" + k] = v.numpy()
+        mo = out[tag + "_max_overlaps"]
+        print(tag, "fg/hard/easy per frame", [(int((m >= 0.55).sum()), int(((m < 0.55) & (m >= 0.1)).sum()), int((m < 0.1).sum()))
+                                              for m in mo])
+    np.savez_compressed(os.path.join(HERE, "roi_targets_ref.npz"), **out)
+
+
 if __name__ == "__main__":
-    only = sys.argv[1:] or ["iou3d", "nms", "dense", "glue", "kl", "assign"]
+    only = sys.argv[1:] or ["iou3d", "nms", "dense", "glue", "kl", "assign", "roitgt"]
+    if "roitgt" in only:
+        make_roi_targets_ref()
     if "assign" in only:
         make_target_assign_ref()
     if "kl" in only:

@@ -107,14 +107,17 @@ print("  shape-static, one HIP graph: %.2f ms/step = %.0f frames/s; loss %.4f" %
 
 
 # ---- the whole two-stage training step (config 3's shape on one GPU): + proposals (NMS 9000 -> 512), RoI
-# targets, RoI-grid pooling in training mode (autograd through group_points), FC towers, the three
-# RoI-head losses.  RoI sampling is deterministic here (the 128 best-scoring proposals per frame,
-# each matched to its best ground truth by 3-D IoU) where the reference samples at random.
-from glenet_amd.pcdet_ops.iou3d_nms import iou3d_nms_utils  # noqa: E402
+# targets (roi_targets.ProposalTargetLayer: 512 proposals -> 128 samples per frame, GLENet_VR.yaml:141-153),
+# RoI-grid pooling in training mode, FC towers, the three RoI-head losses.
 std_layer = torch.nn.Linear(256, 7).to(dev)
 torch.nn.init.normal_(std_layer.weight, std=0.001)
 roi_params = [p for m in (flow.roi_pool, flow.roi_fc, std_layer) for p in m.parameters()]
 R = 128
+from glenet_amd import roi_targets  # noqa: E402
+target_layer = roi_targets.ProposalTargetLayer(dict(ROI_PER_IMAGE=R, FG_RATIO=0.5, SAMPLE_ROI_BY_EACH_CLASS=True,
+                                                    CLS_SCORE_TYPE="roi_iou", CLS_FG_THRESH=0.75, CLS_BG_THRESH=0.25,
+                                                    CLS_BG_THRESH_LO=0.1, HARD_BG_RATIO=0.8, REG_FG_THRESH=0.55))
+jit = torch.tensor([0.2, -0.15, 0.05, 0.1, -0.05, 0.03, 0.08], device=dev)
 ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
 
 
@@ -131,23 +134,16 @@ def full_step(timed=False):
     with torch.no_grad():
         tgt = target_assign.assign_targets([anchors], gt, [1], [0.6], [0.45])
         cls, boxes = det.predicted_boxes(bd["cls_preds"], bd["box_preds"], bd.get("dir_cls_preds"), anchors)
-        rois, _, _ = det.proposal_layer(boxes, cls, 9000, 512, 0.8)
-        rois = rois[:, :R].contiguous()
+        rois, roi_scores, roi_labels = det.proposal_layer(boxes, cls, 9000, 512, 0.8)
         # an untrained head proposes nothing near the ground truth: the first slots take jittered ground-truth
         # boxes (what a trained first stage delivers) so that the regression / corner terms have foreground
-        for b in range(B):
-            n = min(int((gt[b, :, 7] > 0).sum()), R // 2)
-            jit = torch.tensor([0.2, -0.15, 0.05, 0.1, -0.05, 0.03, 0.08], device=dev)
-            rois[b, :n, :7] = gt[b, :n, :7] + jit
-        gt_of = torch.zeros(B, R, 8, device=dev)
-        iou = torch.zeros(B, R, device=dev)
-        for b in range(B):
-            n = int((gt[b, :, 7] > 0).sum())
-            m = iou3d_nms_utils.boxes_iou3d_gpu(rois[b, :, :7].contiguous(), gt[b, :n, :7].contiguous())
-            iou[b], arg = m.max(1)
-            gt_of[b] = gt[b, arg]
-        reg_valid = (iou > 0.55).long().view(-1)
-        cls_lab = ((iou - 0.25) / 0.5).clamp(0, 1).view(-1)
+        has = (gt[:, :, 7:8] > 0)
+        ng = gt.shape[1]
+        rois[:, :ng, :7] = torch.where(has, gt[:, :, :7] + jit, rois[:, :ng, :7])
+        roi_labels[:, :ng] = torch.where(has[..., 0], gt[:, :, 7].long(), roi_labels[:, :ng])
+        td = target_layer({"rois": rois, "roi_scores": roi_scores, "roi_labels": roi_labels, "gt_boxes": gt})
+        rois, gt_of = td["rois"].contiguous(), td["gt_of_rois"]
+        reg_valid, cls_lab = td["reg_valid_mask"].view(-1), td["rcnn_cls_labels"].view(-1)
         gt_ct = losses.canonical_gt_of_rois(rois, gt_of)
         unc = torch.full((B * R, 7), 0.05, device=dev)
     rpn, _ = losses.rpn_loss(bd["cls_preds"], bd["box_preds"], bd.get("dir_cls_preds"), tgt["box_cls_labels"],
