@@ -609,3 +609,17 @@ def test_group_rows_and_gradient_match_indexing(dev):
         live = ~empty
         np.add.at(ref, idx[live].reshape(-1), g[live].reshape(-1, c).astype(np.float64))
         np.testing.assert_allclose(f.grad.cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_group_rows_edge_cases(dev):
+    """No query rows, and queries that are all empty balls: zeros out, zero gradient (no reference is
+    bucketed, the gather has nothing to read)."""
+    feats = torch.randn(40, 8, device=dev, requires_grad=True)
+    out = voxel_pool_modules.GroupRows.apply(feats, torch.zeros((0, 4), dtype=torch.int32, device=dev))
+    assert out.shape == (0, 4, 8)
+    idx = torch.full((33, 4), -1, dtype=torch.int32, device=dev)
+    idx[:, 1:] = 7                                                  # unspecified slots of empty balls
+    out = voxel_pool_modules.GroupRows.apply(feats, idx)
+    assert float(out.abs().max()) == 0.0
+    out.backward(torch.ones_like(out))
+    assert float(feats.grad.abs().max()) == 0.0

@@ -135,3 +135,15 @@ def test_device_roi_sampler_default_draws_have_the_reference_composition(dev):
         got = cat[s[b]]
         assert (got[:take] == 0).all() and len(set(s[b][:take].tolist())) == take
         assert (got[take:take + hard_num] == 1).all() and (got[take + hard_num:] == 2).all()
+
+
+@pytest.mark.gpu
+def test_device_roi_targets_reject_host_tensors_and_oversized_inputs(dev):
+    """No CPU path: host tensors raise; more ground-truth rows than the kernel's LDS table raise."""
+    from glenet_amd import roi_targets, _lib
+    layer = roi_targets.ProposalTargetLayer(dict(BASE, SAMPLE_ROI_BY_EACH_CLASS=True, CLS_SCORE_TYPE="roi_iou"))
+    with pytest.raises(_lib.GlxError):
+        layer.match_and_sample(torch.zeros(1, 8, 7), torch.ones(1, 8, dtype=torch.long), torch.zeros(1, 4, 8))
+    with pytest.raises(_lib.GlxError):
+        layer.match_and_sample(torch.zeros(1, 8, 7, device=dev), torch.ones(1, 8, dtype=torch.long, device=dev),
+                               torch.zeros(1, 300, 8, device=dev))
