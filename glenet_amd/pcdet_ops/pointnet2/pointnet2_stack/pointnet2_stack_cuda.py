@@ -71,6 +71,19 @@ def group_rows_grad_wrapper(grad_out, idx, grad_features):
     return 1
 
 
+def relu_add_max_wrapper(a, b, out, arg):
+    """out (M,C), arg (M,C) int32 = max / argmax over s of relu(a + b), a and b (M,ns,C) row-major."""
+    _lib.check_cuda(a, b, out, arg)
+    call("glx_relu_add_max", a, b, a.shape[0], a.shape[1], a.shape[2], out, arg)
+    return 1
+
+
+def relu_add_max_grad_wrapper(grad_out, out, arg, nsample, grad_in):
+    _lib.check_cuda(grad_out, out, arg, grad_in)
+    call("glx_relu_add_max_grad", grad_out, out, arg, out.shape[0], nsample, out.shape[1], grad_in)
+    return 1
+
+
 def stack_farthest_point_sampling_wrapper(xyz, temp, xyz_batch_cnt, idxs, num_sampled_points):
     """sampling.cpp:40-60: xyz (N,3), temp (N) filled with 1e10, idxs (sum m) int32 out."""
     _lib.check_cuda(xyz, temp, xyz_batch_cnt, idxs, num_sampled_points)

@@ -40,6 +40,30 @@ class GroupRows(torch.autograd.Function):
         return grad, None
 
 
+class ReluAddMax(torch.autograd.Function):
+    """max over the neighbours of relu(a + b) on (M, ns, C) rows in one pass; one gradient tensor for
+    both inputs (csrc/glx_points.hip, k_relu_add_max)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        from . import pointnet2_stack_cuda as pointnet2
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty((a.shape[0], a.shape[2]), dtype=a.dtype, device=a.device)
+        arg = torch.empty((a.shape[0], a.shape[2]), dtype=torch.int32, device=a.device)
+        pointnet2.relu_add_max_wrapper(a, b, out, arg)
+        ctx.save_for_backward(out, arg)
+        ctx.ns = a.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import pointnet2_stack_cuda as pointnet2
+        out, arg = ctx.saved_tensors
+        grad = torch.empty((out.shape[0], ctx.ns, out.shape[1]), dtype=out.dtype, device=out.device)
+        pointnet2.relu_add_max_grad_wrapper(grad_out.contiguous(), out, arg, ctx.ns, grad)
+        return grad, grad
+
+
 class NeighborVoxelSAModuleMSG(nn.Module):
     def __init__(self, *, query_ranges, radii, nsamples, mlps, use_xyz=True, pool_method='max_pool'):
         super().__init__()
@@ -195,6 +219,10 @@ class NeighborVoxelSAModuleMSG(nn.Module):
             with torch.no_grad():
                 rel = (GroupRows.apply(xyz, idx) - new_xyz.view(m, 1, 3)) * keep         # (M, ns, 3)
             pos = self._conv_bn_rows(mlp_pos, rel.view(m * ns, 3))                       # (M*ns, c_mid)
-            x = F.relu(g_feat + pos.view(m, ns, -1))                                     # (M, ns, c_mid)
-            outs.append(self._conv_bn_rows(mlp_out, x.max(dim=1)[0]))                    # (M, c_out)
+            if self.pool_method == 'max_pool' and m > 0:
+                pooled = ReluAddMax.apply(g_feat, pos.view(m, ns, -1))                   # (M, c_mid)
+            else:
+                x = F.relu(g_feat + pos.view(m, ns, -1))                                 # (M, ns, c_mid)
+                pooled = x.max(dim=1)[0] if self.pool_method == 'max_pool' else x.mean(dim=1)
+            outs.append(self._conv_bn_rows(mlp_out, pooled))                             # (M, c_out)
         return torch.cat(outs, dim=1)

@@ -533,6 +533,15 @@ int glx_pointnet_feat_small(const float* points, int B, int Cin, int P, int C1, 
                             const float* W1, const float* b1, const float* W2, const float* b2,
                             const float* W3, const float* b3, float* out, void* stream);
 
+/* out[m,c] = max_s relu(a[m,s,c] + b[m,s,c]) on row-major (M, nsample, C) tensors, arg = winning slot
+ * (first on ties) -- add + ReLU + max_pool of the RoI-grid pooling MLP in training
+ * (pcdet/ops/pointnet2/pointnet2_stack/voxel_pool_modules.py:96-104) in one pass.  _grad: grad_in
+ * (M, nsample, C) = grad_out at the winning slot where out > 0, else 0 (the gradient of both a and b). */
+int glx_relu_add_max(const float* a, const float* b, int M, int nsample, int C, float* out, int32_t* arg,
+                     void* stream);
+int glx_relu_add_max_grad(const float* grad_out, const float* out, const int32_t* arg, int M, int nsample,
+                          int C, float* grad_in, void* stream);
+
 /* RoI targets of the second stage for a whole batch, two launches, no host round trip
  * (replaces ProposalTargetLayer.sample_rois_for_rcnn + subsample_rois + get_max_iou_with_same_class,
  * pcdet/models/roi_heads/target_assigner/proposal_target_layer.py:65-239).

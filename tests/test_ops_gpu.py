@@ -620,6 +620,26 @@ def test_group_rows_edge_cases(dev):
     idx = torch.full((33, 4), -1, dtype=torch.int32, device=dev)
     idx[:, 1:] = 7                                                  # unspecified slots of empty balls
     out = voxel_pool_modules.GroupRows.apply(feats, idx)
-    assert float(out.abs().max()) == 0.0
+    assert float(out.detach().abs().max()) == 0.0
     out.backward(torch.ones_like(out))
     assert float(feats.grad.abs().max()) == 0.0
+
+
+def test_relu_add_max_matches_tensor_ops(dev):
+    """ReluAddMax == relu(a + b).max(dim=1)[0], forward bit-exact, gradients of both inputs equal to
+    autograd's (random data: no ties; rows that are negative everywhere give max 0 and no gradient)."""
+    torch.manual_seed(2)
+    for m, ns, c in ((300, 16, 32), (17, 8, 24), (1, 1, 3)):
+        a = torch.randn(m, ns, c, device=dev)
+        a[::7] -= 10.0                                              # all-negative rows
+        b = torch.randn(m, ns, c, device=dev)
+        a1, b1 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        a2, b2 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        out = voxel_pool_modules.ReluAddMax.apply(a1, b1)
+        ref = torch.relu(a2 + b2).max(dim=1)[0]
+        assert torch.equal(out, ref)
+        w = torch.randn_like(ref)
+        (out * w).sum().backward()
+        (ref * w).sum().backward()
+        assert torch.equal(a1.grad, a2.grad) and torch.equal(b1.grad, b2.grad)
+        assert float(a1.grad[::7].abs().max()) == 0.0
