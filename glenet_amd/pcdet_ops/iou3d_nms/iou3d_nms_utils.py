@@ -78,12 +78,12 @@ def nms_func_device(boxes, scores, iou_threshold, score_threshold=0, variance=No
     scores = scores.float().contiguous().clone()
     _lib.check_cuda(boxes, scores)
     n = boxes.shape[0]
-    ious = boxes_iou_bev(boxes, boxes)
+    ious_t = boxes_iou_bev(boxes, boxes).t().contiguous()      # the voting block reads rows of the transpose
     var, stride = None, 0
     if variance is not None:
         var = variance.float().contiguous()
         stride = var.shape[1]
-    call("glx_nms_vote", boxes, scores, var, stride, ious, n, float(iou_threshold), float(score_threshold))
+    call("glx_nms_vote", boxes, scores, var, stride, ious_t, n, float(iou_threshold), float(score_threshold))
     return scores, boxes
 
 

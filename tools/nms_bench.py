@@ -38,3 +38,14 @@ for n, thr in ((9000, 0.8), (2048, 0.7), (4096, 0.1)):
     if n <= 4096:
         t2 = timeit(lambda: iou3d_nms_utils.boxes_iou_bev(bs, bs))
         print("    pairwise BEV IoU %d x %d: %8.1f us" % (n, n, t2))
+
+# GLENet's variance-voting NMS (nms_func / new_nms_gpu, iou3d_nms_utils.py:200-273) at the sizes the
+# single-stage models feed it (GLENet_S/C: every anchor above SCORE_THRESH, up to NMS_PRE_MAXSIZE 4096;
+# two-stage: <= 100 RoIs).  Device time of IoU matrix + voting loop, no read-back.
+for n in (100, 1000, 4096):
+    boxes = torch.from_numpy(synth.random_boxes(rng, n, xy_range=35.0, near_dup=0.7)).to(dev)
+    scores = torch.rand(n, device=dev) * 0.9 + 0.1
+    var = torch.rand(n, 7, device=dev) * 0.2 + 0.01
+    t = timeit(lambda: iou3d_nms_utils.nms_func_device(boxes, scores, 0.1, 0.0, var), n=5)
+    s, _ = iou3d_nms_utils.nms_func_device(boxes, scores, 0.1, 0.0, var)
+    print("variance-voting nms %5d boxes thr 0.1: %9.1f us (IoU matrix + voting block), %d kept" % (n, t, int((s > 0).sum())))
