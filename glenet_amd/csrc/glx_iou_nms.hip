@@ -568,8 +568,10 @@ extern "C" int glx_nms(const float* boxes_sorted, int N, float thresh, int norma
 // access on a round's critical path is one coalesced row of the TRANSPOSED IoU matrix.
 __global__ __launch_bounds__(VOTE_THREADS) void k_nms_vote(
     float* __restrict__ boxes, float* __restrict__ scores, const float* __restrict__ variance,
-    int var_stride, const float* __restrict__ iousT, int N, float iou_thr, float score_thr) {
+    int var_stride, const float* __restrict__ iousT, int N, float iou_thr, float score_thr,
+    float* __restrict__ scratch) {
   __shared__ float s_best[VOTE_WAVES], s_head[VOTE_WAVES];
+  bool tail = false;
   __shared__ int s_bi[VOTE_WAVES];
   __shared__ float s_part[VOTE_WAVES][16];
   __shared__ float s_new[7];
@@ -619,6 +621,16 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_nms_vote(
     }
     const int idx = bi;
     if (idx == 0x7fffffff) break;   // undone_mask.sum() == 0
+    if (best == 0.f && score_thr <= 0.f) {
+      // Every undone box has score 0 (suppressed boxes stay "undone" under a threshold of 0): from here
+      // on the reference visits them in index order, each round votes box j from the still-undone
+      // boxes i >= j -- all untouched originals -- and changes no score.  The rounds are independent:
+      // they run in parallel in k_nms_vote_tail instead of one after the other (4096 boxes: ~3900 rounds).
+      bool odd = false;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) odd |= undone[u] && sc[u] != 0.f;
+      if (!__syncthreads_or(odd)) { tail = true; break; }
+    }
 
     float iouv[PER];
 #pragma unroll
@@ -723,6 +735,14 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_nms_vote(
         }
     }
   }
+  if (variance) {                       // hand the independent rounds to k_nms_vote_tail
+    int* flags = (int*)(scratch + (long long)N * 7);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int i = t + u * VOTE_THREADS;
+      if (i < N) flags[i] = (tail && undone[u]) ? 1 : 0;
+    }
+  }
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
     const int i = t + u * VOTE_THREADS;
@@ -730,16 +750,80 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_nms_vote(
   }
 }
 
+// The independent rounds of the zero-score tail (see k_nms_vote): a wave per flagged box j votes it from
+// the flagged boxes i >= j, all of them untouched originals; results go to scratch and are copied
+// over the boxes by k_nms_vote_copy once every wave has read what it needs.
+__global__ __launch_bounds__(256) void k_nms_vote_tail(const float* __restrict__ boxes,
+                                                       const float* __restrict__ variance, int var_stride,
+                                                       const float* __restrict__ iousT, int N, float iou_thr,
+                                                       float* __restrict__ scratch) {
+  const int* flags = (const int*)(scratch + (long long)N * 7);
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (j >= N || !flags[j]) return;
+  const float PI_3_2 = (float)(3.14159265358979323846 * 3 / 2);
+  const float PI_2x = (float)(3.14159265358979323846 * 2);
+  const float PI_4 = (float)(3.14159265358979323846 / 4);
+  const float top_h = boxes[(long long)j * 7 + 6];
+  float acc[14];
+#pragma unroll
+  for (int c = 0; c < 14; ++c) acc[c] = 0.f;
+  for (int i = (j & ~63) + lane; i < N; i += 64) {
+    if (i < j || !flags[i]) continue;
+    const float iou = iousT[(long long)j * N + i];
+    if (!(iou > iou_thr)) continue;
+    float bx[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) bx[c] = boxes[(long long)i * 7 + c];
+    if (fabsf(bx[6] - top_h) >= PI_3_2) bx[6] = top_h > 0.f ? bx[6] + PI_2x : bx[6] - PI_2x;
+    const float d = 1.f - iou;
+    const float p = expf(-1.f * (d * d) / 0.05f);
+    const bool far = fabsf(bx[6] - top_h) >= PI_4;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+      float w = p / variance[(long long)i * var_stride + c];
+      if (c == 6 && far) w = 0.f;
+      acc[c] += w;
+      acc[7 + c] += w * bx[c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 14; ++c) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc[c] += __shfl_xor(acc[c], d, 64);
+  }
+  if (lane < 7) {
+    float tp = acc[0], tb = acc[7];
+#pragma unroll
+    for (int c = 1; c < 7; ++c)
+      if (lane == c) { tp = acc[c]; tb = acc[7 + c]; }
+    scratch[(long long)j * 7 + lane] = tb / tp;
+  }
+}
+
+__global__ void k_nms_vote_copy(float* __restrict__ boxes, const float* __restrict__ scratch, int N) {
+  const int* flags = (const int*)(scratch + (long long)N * 7);
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < N * 7 && flags[e / 7]) boxes[e] = scratch[e];
+}
+
 extern "C" int glx_nms_vote(float* boxes, float* scores, const float* variance, int var_stride,
                             const float* ious_t, int N, float iou_thr, float score_thr,
-                            void* stream) {
+                            float* scratch, void* stream) {
   if (N == 0) return GLX_OK;
   GLX_REQUIRE(boxes && scores && ious_t, "glx_nms_vote: null pointer");
   GLX_REQUIRE(N <= 4 * VOTE_THREADS, "glx_nms_vote: N=%d exceeds %d (NMS_PRE_MAXSIZE)", N,
               4 * VOTE_THREADS);
   GLX_REQUIRE(!variance || var_stride >= 7, "glx_nms_vote: variance needs >= 7 columns");
+  GLX_REQUIRE(!variance || scratch, "glx_nms_vote: voting needs the N*8-float scratch buffer");
   hipLaunchKernelGGL(k_nms_vote, dim3(1), dim3(VOTE_THREADS), 0, (hipStream_t)stream, boxes,
-                     scores, variance, var_stride, ious_t, N, iou_thr, score_thr);
+                     scores, variance, var_stride, ious_t, N, iou_thr, score_thr, scratch);
+  if (variance) {
+    hipLaunchKernelGGL(k_nms_vote_tail, dim3(glx_divup(N, 4)), dim3(256), 0, (hipStream_t)stream, (const float*)boxes,
+                       variance, var_stride, ious_t, N, iou_thr, scratch);
+    hipLaunchKernelGGL(k_nms_vote_copy, dim3(glx_divup(N * 7, 256)), dim3(256), 0, (hipStream_t)stream, boxes,
+                       (const float*)scratch, N);
+  }
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

@@ -83,7 +83,9 @@ def nms_func_device(boxes, scores, iou_threshold, score_threshold=0, variance=No
     if variance is not None:
         var = variance.float().contiguous()
         stride = var.shape[1]
-    call("glx_nms_vote", boxes, scores, var, stride, ious_t, n, float(iou_threshold), float(score_threshold))
+    scratch = torch.empty((n, 8), dtype=torch.float32, device=boxes.device) if var is not None else None
+    call("glx_nms_vote", boxes, scores, var, stride, ious_t, n, float(iou_threshold), float(score_threshold),
+         scratch)
     return scores, boxes
 
 

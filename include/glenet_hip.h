@@ -290,9 +290,10 @@ int glx_nms_batch(const float* boxes_sorted, int frames, int N, float thresh, in
  * on the device.  boxes (N,7) and scores (N) are updated in place; variance (N, var_stride>=7)
  * may be NULL; ious_t (N,N) = TRANSPOSED BEV IoU matrix of the ORIGINAL boxes (ious_t[j][i] =
  * IoU(box i, box j): a round reads the chosen box's column of the reference's matrix, i.e. one
- * contiguous row here); N <= 4096. */
+ * contiguous row here); scratch: N*8 floats (required with variance); N <= 4096. */
 int glx_nms_vote(float* boxes, float* scores, const float* variance, int var_stride,
-                 const float* ious, int N, float iou_thr, float score_thr, void* stream);
+                 const float* ious_t, int N, float iou_thr, float score_thr, float* scratch,
+                 void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Point / box operators.

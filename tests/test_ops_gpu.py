@@ -158,14 +158,17 @@ def test_variance_voting_nms_vs_reference_golden(dev, case):
     np.testing.assert_allclose(new_boxes, g["c%d_new_boxes" % case], rtol=1e-4, atol=1e-4)
 
 
-def test_variance_voting_nms_larger_vs_oracle(dev):
+@pytest.mark.parametrize("sthr", [0.1, 0.0])
+def test_variance_voting_nms_larger_vs_oracle(dev, sthr):
+    """sthr 0.0 is what class_agnostic_nms passes: suppressed boxes stay in the loop with score 0 and
+    are voted too (the parallel tail of the device path); the whole new_boxes array is compared."""
     rng = np.random.default_rng(3)
     n = 1500
     boxes = synth.random_boxes(rng, n, xy_range=30.0, near_dup=0.7)
     scores = (rng.permutation(n).astype(np.float32) + 1) / n
     var = rng.uniform(0.01, 0.3, (n, 7)).astype(np.float32)
-    rk, rb = oracle.new_nms_gpu(boxes, scores, 0.1, 0.1, var)
-    keep, _, nb = iou3d_nms_utils.new_nms_gpu(T(boxes, dev), T(scores, dev), 0.1, score_threshold=0.1,
+    rk, rb = oracle.new_nms_gpu(boxes, scores, 0.1, sthr, var)
+    keep, _, nb = iou3d_nms_utils.new_nms_gpu(T(boxes, dev), T(scores, dev), 0.1, score_threshold=sthr,
                                               variance=T(var, dev))
     assert np.array_equal(np.asarray(keep), rk)
     np.testing.assert_allclose(nb, rb, rtol=1e-4, atol=1e-4)
