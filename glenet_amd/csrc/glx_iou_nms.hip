@@ -561,15 +561,18 @@ extern "C" int glx_nms(const float* boxes_sorted, int N, float thresh, int norma
 // are visited too), so the round cost is the whole cost: 4096 boxes took 70 ms with tree reductions
 // (~180 barriers per round).  Sum order: deterministic, differs from numpy's pairwise sum like any
 // fp32 reduction (tolerance 1e-4 on the voted boxes, tests/test_ops_gpu.py).
-#define VOTE_WAVES (VOTE_THREADS / 64)
 
 // State in registers: a thread owns boxes t, t+1024, ... -- their scores (only the owner ever changes a
 // score), coordinates and variances; the voted box reaches its owner through LDS.  The only memory
 // access on a round's critical path is one coalesced row of the TRANSPOSED IoU matrix.
-__global__ __launch_bounds__(VOTE_THREADS) void k_nms_vote(
+// THREADS: 1024 for up to 4096 boxes, 256 for up to 1024 (4 waves: cheaper barriers and folds -- the
+// two-stage models vote <= 100 RoIs per frame).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_nms_vote(
     float* __restrict__ boxes, float* __restrict__ scores, const float* __restrict__ variance,
     int var_stride, const float* __restrict__ iousT, int N, float iou_thr, float score_thr,
     float* __restrict__ scratch) {
+  constexpr int VOTE_WAVES = THREADS / 64;
   __shared__ float s_best[VOTE_WAVES], s_head[VOTE_WAVES];
   bool tail = false;
   __shared__ int s_bi[VOTE_WAVES];
@@ -579,12 +582,12 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_nms_vote(
   const float PI_3_2 = (float)(3.14159265358979323846 * 3 / 2);
   const float PI_2x = (float)(3.14159265358979323846 * 2);
   const float PI_4 = (float)(3.14159265358979323846 / 4);
-  constexpr int PER = 4;   // N <= 4096
+  constexpr int PER = 4;   // N <= 4 * THREADS
   bool undone[PER];
   float sc[PER], bxr[PER][7], vr[PER][7];
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
-    const int i = t + u * VOTE_THREADS;
+    const int i = t + u * THREADS;
     sc[u] = i < N ? scores[i] : 0.f;
     undone[u] = i < N && sc[u] >= score_thr;
 #pragma unroll
@@ -599,7 +602,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_nms_vote(
     int bi = 0x7fffffff;
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int i = t + u * VOTE_THREADS;
+      const int i = t + u * THREADS;
       if (undone[u] && (bi == 0x7fffffff || sc[u] > best || (sc[u] == best && i < bi))) {
         best = sc[u]; bi = i; head = bxr[u][6];
       }
@@ -635,7 +638,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_nms_vote(
     float iouv[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int i = t + u * VOTE_THREADS;
+      const int i = t + u * THREADS;
       iouv[u] = undone[u] ? iousT[(long long)idx * N + i] : 0.f;        // == ious[i][idx]
     }
     if (variance) {
@@ -718,7 +721,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_nms_vote(
     // undone[idx] = False; scores[undone] *= (iou < thr); undone[scores < score_thr] = False
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int i = t + u * VOTE_THREADS;
+      const int i = t + u * THREADS;
       if (i == idx) undone[u] = false;
       if (undone[u]) {
         sc[u] = sc[u] * ((iouv[u] < iou_thr) ? 1.f : 0.f);
@@ -726,10 +729,10 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_nms_vote(
       }
     }
     __syncthreads();                                                     // (3)
-    if (variance && (idx & (VOTE_THREADS - 1)) == t) {                   // the owner takes the voted box
+    if (variance && (idx % THREADS) == t) {                   // the owner takes the voted box
 #pragma unroll
       for (int u = 0; u < PER; ++u)
-        if ((idx >> 10) == u) {
+        if ((idx / THREADS) == u) {
 #pragma unroll
           for (int c = 0; c < 7; ++c) bxr[u][c] = s_new[c];
         }
@@ -739,13 +742,13 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_nms_vote(
     int* flags = (int*)(scratch + (long long)N * 7);
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int i = t + u * VOTE_THREADS;
+      const int i = t + u * THREADS;
       if (i < N) flags[i] = (tail && undone[u]) ? 1 : 0;
     }
   }
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
-    const int i = t + u * VOTE_THREADS;
+    const int i = t + u * THREADS;
     if (i < N) scores[i] = sc[u];
   }
 }
@@ -816,8 +819,12 @@ extern "C" int glx_nms_vote(float* boxes, float* scores, const float* variance, 
               4 * VOTE_THREADS);
   GLX_REQUIRE(!variance || var_stride >= 7, "glx_nms_vote: variance needs >= 7 columns");
   GLX_REQUIRE(!variance || scratch, "glx_nms_vote: voting needs the N*8-float scratch buffer");
-  hipLaunchKernelGGL(k_nms_vote, dim3(1), dim3(VOTE_THREADS), 0, (hipStream_t)stream, boxes,
-                     scores, variance, var_stride, ious_t, N, iou_thr, score_thr, scratch);
+  if (N <= 1024)
+    hipLaunchKernelGGL(k_nms_vote<256>, dim3(1), dim3(256), 0, (hipStream_t)stream, boxes, scores, variance,
+                       var_stride, ious_t, N, iou_thr, score_thr, scratch);
+  else
+    hipLaunchKernelGGL(k_nms_vote<VOTE_THREADS>, dim3(1), dim3(VOTE_THREADS), 0, (hipStream_t)stream, boxes,
+                       scores, variance, var_stride, ious_t, N, iou_thr, score_thr, scratch);
   if (variance) {
     hipLaunchKernelGGL(k_nms_vote_tail, dim3(glx_divup(N, 4)), dim3(256), 0, (hipStream_t)stream, (const float*)boxes,
                        variance, var_stride, ious_t, N, iou_thr, scratch);
