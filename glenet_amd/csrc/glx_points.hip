@@ -411,11 +411,16 @@ __device__ __forceinline__ int batch_of(int pt, const int* cnt, int B, int& star
   return bs;
 }
 
-__global__ void k_ball_query(int B, int M, float radius2, int nsample,
-                             const float* __restrict__ new_xyz, const int* __restrict__ new_cnt,
-                             const float* __restrict__ xyz, const int* __restrict__ xyz_cnt,
-                             int* __restrict__ idx) {
-  int pt = blockIdx.x * blockDim.x + threadIdx.x;
+// A wave per query: the lanes test 64 points at a time, a ballot keeps the hits in index order (the first
+// nsample points inside the radius, remaining slots = the first hit, idx[m,0] = -1 for an empty ball:
+// ball_query_gpu.cu:16-67).  The reference's thread-per-query scan leaves 2048 x B queries on 128
+// waves, each walking 16 K points one by one (2.07 ms at 4 x 2048 x 16384; this form: see tools/ops_time.py).
+__global__ __launch_bounds__(256) void k_ball_query(int B, int M, float radius2, int nsample,
+                                                    const float* __restrict__ new_xyz, const int* __restrict__ new_cnt,
+                                                    const float* __restrict__ xyz, const int* __restrict__ xyz_cnt,
+                                                    int* __restrict__ idx) {
+  const int lane = threadIdx.x & 63;
+  const int pt = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (pt >= M) return;
   int start;
   int bs = batch_of(pt, new_cnt, B, start, xyz_cnt);
@@ -423,19 +428,29 @@ __global__ void k_ball_query(int B, int M, float radius2, int nsample,
   const float nx = new_xyz[(long long)pt * 3], ny = new_xyz[(long long)pt * 3 + 1],
               nz = new_xyz[(long long)pt * 3 + 2];
   int* o = idx + (long long)pt * nsample;
-  int n = xyz_cnt[bs], cnt = 0;
-  for (int k = 0; k < n; ++k) {
-    float x = X[(long long)k * 3], y = X[(long long)k * 3 + 1], z = X[(long long)k * 3 + 2];
-    float d2 = (nx - x) * (nx - x) + (ny - y) * (ny - y) + (nz - z) * (nz - z);
-    if (d2 < radius2) {
-      if (cnt == 0)
-        for (int l = 0; l < nsample; ++l) o[l] = k;
-      o[cnt] = k;
-      ++cnt;
-      if (cnt >= nsample) break;
+  const int n = xyz_cnt[bs];
+  int cnt = 0, first = -1;
+  for (int k0 = 0; k0 < n && cnt < nsample; k0 += 64) {
+    const int k = k0 + lane;
+    bool in = false;
+    if (k < n) {
+      float x = X[(long long)k * 3], y = X[(long long)k * 3 + 1], z = X[(long long)k * 3 + 2];
+      float d2 = (nx - x) * (nx - x) + (ny - y) * (ny - y) + (nz - z) * (nz - z);
+      in = d2 < radius2;
+    }
+    const unsigned long long hits = __ballot(in);
+    if (hits) {
+      if (first < 0) first = k0 + __ffsll((long long)hits) - 1;
+      const int pos = cnt + __popcll(hits & ((1ull << lane) - 1ull));
+      if (in && pos < nsample) o[pos] = k;
+      cnt += __popcll(hits);
     }
   }
-  if (cnt == 0) o[0] = -1;
+  if (first < 0) {
+    if (lane == 0) o[0] = -1;
+  } else {
+    for (int l = (cnt < nsample ? cnt : nsample) + lane; l < nsample; l += 64) o[l] = first;
+  }
 }
 
 extern "C" int glx_ball_query(int B, int M, float radius, int nsample, const float* new_xyz,
@@ -443,7 +458,7 @@ extern "C" int glx_ball_query(int B, int M, float radius, int nsample, const flo
                               const int32_t* xyz_batch_cnt, int32_t* idx, void* stream) {
   if (M == 0) return GLX_OK;
   GLX_REQUIRE(new_xyz && new_xyz_batch_cnt && xyz && xyz_batch_cnt && idx, "glx_ball_query: null");
-  hipLaunchKernelGGL(k_ball_query, dim3(glx_divup(M, 256)), dim3(256), 0, (hipStream_t)stream, B,
+  hipLaunchKernelGGL(k_ball_query, dim3(glx_divup(M, 4)), dim3(256), 0, (hipStream_t)stream, B,
                      M, radius * radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt,
                      idx);
   GLX_LAUNCH_CHECK();
@@ -804,9 +819,9 @@ __global__ __launch_bounds__(FPS_THREADS) void k_stack_fps(
     int B, const float* __restrict__ xyz, const int* __restrict__ xyz_batch_cnt,
     float* __restrict__ temp, const int* __restrict__ num_sampled, int* __restrict__ idxs) {
   __shared__ float s_v[FPS_THREADS / 64];
-  __shared__ int s_t[FPS_THREADS / 64], s_i[FPS_THREADS / 64];
+  __shared__ int s_i[FPS_THREADS / 64];
+  __shared__ float s_x[FPS_THREADS / 64], s_y[FPS_THREADS / 64], s_z[FPS_THREADS / 64];
   __shared__ float s_pt[3];
-  __shared__ int s_old;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   long long start = 0, ostart = 0;
   for (int k = 0; k < b; ++k) { start += xyz_batch_cnt[k]; ostart += num_sampled[k]; }
@@ -851,25 +866,37 @@ __global__ __launch_bounds__(FPS_THREADS) void k_stack_fps(
         if (d2 > best.v) { best.v = d2; best.i = k; }
       }
     }
+    // wave maximum of the value alone (6 cross-lane steps), then the lowest lane that holds it -- lower
+    // lane = lower thread, the tie rule -- publishes index and coordinates from its registers
+    float vmax = best.v;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      FpsBest other{__shfl_xor(best.v, o, 64), __shfl_xor(best.t, o, 64), __shfl_xor(best.i, o, 64)};
-      best = fps_pick(best, other);
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    const int win = __ffsll((long long)__ballot(best.v == vmax)) - 1;
+    if (lane == win) {
+      float cx, cy, cz;
+      if (REGS) {
+        const int jw = best.i / FPS_THREADS;
+        cx = px[0]; cy = py[0]; cz = pz[0];
+#pragma unroll
+        for (int j = 1; j < FPS_DPT; ++j)
+          if (jw == j) { cx = px[j]; cy = py[j]; cz = pz[j]; }
+      } else {
+        cx = X[best.i * 3]; cy = X[best.i * 3 + 1]; cz = X[best.i * 3 + 2];
+      }
+      s_v[wave] = best.v; s_i[wave] = best.i;
+      s_x[wave] = cx; s_y[wave] = cy; s_z[wave] = cz;
     }
-    if (lane == 0) { s_v[wave] = best.v; s_t[wave] = best.t; s_i[wave] = best.i; }
     __syncthreads();
     if (wave == 0) {
-      FpsBest w = lane < FPS_THREADS / 64 ? FpsBest{s_v[lane], s_t[lane], s_i[lane]}
-                                          : FpsBest{-3.f, 1 << 30, 0};
+      float wv = lane < FPS_THREADS / 64 ? s_v[lane] : -3.f;
+      float wmax = wv;
 #pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        FpsBest other{__shfl_xor(w.v, o, 64), __shfl_xor(w.t, o, 64), __shfl_xor(w.i, o, 64)};
-        w = fps_pick(w, other);
-      }
-      if (lane == 0) {
-        s_old = w.i;
-        O[s] = w.i + (int)start;
-        s_pt[0] = X[w.i * 3]; s_pt[1] = X[w.i * 3 + 1]; s_pt[2] = X[w.i * 3 + 2];
+      for (int o = 8; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+      wmax = __shfl(wmax, 0, 64);
+      const int win2 = __ffsll((long long)__ballot(lane < FPS_THREADS / 64 && wv == wmax)) - 1;   // lower wave = lower threads
+      if (lane == win2) {
+        O[s] = s_i[lane] + (int)start;
+        s_pt[0] = s_x[lane]; s_pt[1] = s_y[lane]; s_pt[2] = s_z[lane];
       }
     }
     __syncthreads();

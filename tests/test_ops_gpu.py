@@ -291,8 +291,10 @@ def test_ball_query_and_grouping(dev):
     assert np.array_equal(out.detach().cpu().numpy(), ref)
     g = rng.normal(size=ref.shape).astype(np.float32)
     out.backward(T(g, dev))
+    # row 0 of a frame collects every slot of every empty ball (hundreds of terms, |sum of |terms|| ~ 1e3):
+    # fp32 accumulation order (float atomics) moves its entries by ~1e-5 absolute
     np.testing.assert_allclose(f.grad.cpu().numpy(), oracle.group_points_grad(g, idx, ncnt, cnt, cnt.sum()),
-                               rtol=1e-5, atol=1e-5)
+                               rtol=1e-5, atol=2e-4)
     # QueryAndGroup module: relative xyz + features, empty balls zeroed
     qg = pointnet2_utils.QueryAndGroup(0.45, 16, use_xyz=True)
     nf, _ = qg(T(xyz, dev), T(cnt, dev), T(q, dev), T(ncnt, dev), T(feat, dev))
