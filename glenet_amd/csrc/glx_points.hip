@@ -938,7 +938,8 @@ __global__ __launch_bounds__(TNN_THREADS) void k_three_nn(
   const bool act = q < nu;
   const float* up = unknown + (ustart + (act ? q : 0)) * 3;
   const float ux = up[0], uy = up[1], uz = up[2];
-  double b1 = 1e40, b2 = 1e40, b3 = 1e40;
+  // the reference's running minima start at 1e40 in double = above every float: +inf in float decides alike
+  float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
   int i1 = 0, i2 = 0, i3 = 0;
   const float* Kp = known + kstart * 3;
   for (int t0 = 0; t0 < nk; t0 += TNN_TILE) {
@@ -947,6 +948,7 @@ __global__ __launch_bounds__(TNN_THREADS) void k_three_nn(
     for (int e = threadIdx.x; e < tn * 3; e += TNN_THREADS) s_k[e] = Kp[(long long)t0 * 3 + e];
     __syncthreads();
     if (act) {
+#pragma unroll 8
       for (int k = 0; k < tn; ++k) {
         float x = s_k[k * 3], y = s_k[k * 3 + 1], z = s_k[k * 3 + 2];
         float d = (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
@@ -959,7 +961,7 @@ __global__ __launch_bounds__(TNN_THREADS) void k_three_nn(
   if (act) {
     float* dp = dist2 + (ustart + q) * 3;
     int* ip = idx + (ustart + q) * 3;
-    dp[0] = (float)b1; dp[1] = (float)b2; dp[2] = (float)b3;
+    dp[0] = b1; dp[1] = b2; dp[2] = b3;
     ip[0] = i1 + (int)kstart; ip[1] = i2 + (int)kstart; ip[2] = i3 + (int)kstart;
   }
 }
