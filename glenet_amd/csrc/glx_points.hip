@@ -923,6 +923,7 @@ extern "C" int glx_stack_fps(const float* xyz, const int32_t* xyz_batch_cnt, int
 // the frame's known points stream through LDS in tiles shared by the 256 queries of the block.
 #define TNN_THREADS 256
 #define TNN_TILE 1024
+#define TNN_SPLIT 8
 
 __global__ __launch_bounds__(TNN_THREADS) void k_three_nn(
     int B, const float* __restrict__ unknown, const int* __restrict__ unknown_batch_cnt,
@@ -933,8 +934,11 @@ __global__ __launch_bounds__(TNN_THREADS) void k_three_nn(
   long long ustart = 0, kstart = 0;
   for (int k = 0; k < b; ++k) { ustart += unknown_batch_cnt[k]; kstart += known_batch_cnt[k]; }
   const int nu = unknown_batch_cnt[b], nk = known_batch_cnt[b];
-  if ((long long)blockIdx.x * TNN_THREADS >= nu) return;   // block-uniform
-  const int q = blockIdx.x * TNN_THREADS + threadIdx.x;
+  // TNN_SPLIT lanes per query, each scanning every TNN_SPLIT-th known point: 8x the waves of a thread per
+  // query (65 K queries were 1024 waves = one per SIMD, nothing to hide the LDS latency behind)
+  if ((long long)blockIdx.x * (TNN_THREADS / TNN_SPLIT) >= nu) return;   // block-uniform
+  const int q = blockIdx.x * (TNN_THREADS / TNN_SPLIT) + threadIdx.x / TNN_SPLIT;
+  const int sub = threadIdx.x % TNN_SPLIT;
   const bool act = q < nu;
   const float* up = unknown + (ustart + (act ? q : 0)) * 3;
   const float ux = up[0], uy = up[1], uz = up[2];
@@ -948,8 +952,8 @@ __global__ __launch_bounds__(TNN_THREADS) void k_three_nn(
     for (int e = threadIdx.x; e < tn * 3; e += TNN_THREADS) s_k[e] = Kp[(long long)t0 * 3 + e];
     __syncthreads();
     if (act) {
-#pragma unroll 8
-      for (int k = 0; k < tn; ++k) {
+#pragma unroll 4
+      for (int k = sub; k < tn; k += TNN_SPLIT) {
         float x = s_k[k * 3], y = s_k[k * 3 + 1], z = s_k[k * 3 + 2];
         float d = (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
         if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = t0 + k; }
@@ -958,11 +962,28 @@ __global__ __launch_bounds__(TNN_THREADS) void k_three_nn(
       }
     }
   }
-  if (act) {
+  // merge the TNN_SPLIT sorted triples: three rounds of "smallest head by (distance, index)" -- the order
+  // the reference's strict comparisons produce (equal distances fill the slots in index order)
+  float od[3];
+  int oi[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    float hd = b1;
+    int hi = i1;
+#pragma unroll
+    for (int o = TNN_SPLIT / 2; o > 0; o >>= 1) {
+      const float xd = __shfl_xor(hd, o, 64);
+      const int xi = __shfl_xor(hi, o, 64);
+      if (xd < hd || (xd == hd && xi < hi)) { hd = xd; hi = xi; }
+    }
+    od[r] = hd; oi[r] = hi;
+    if (b1 == hd && i1 == hi) { b1 = b2; i1 = i2; b2 = b3; i2 = i3; b3 = INFINITY; i3 = 0; }
+  }
+  if (act && sub == 0) {
     float* dp = dist2 + (ustart + q) * 3;
     int* ip = idx + (ustart + q) * 3;
-    dp[0] = b1; dp[1] = b2; dp[2] = b3;
-    ip[0] = i1 + (int)kstart; ip[1] = i2 + (int)kstart; ip[2] = i3 + (int)kstart;
+    dp[0] = od[0]; dp[1] = od[1]; dp[2] = od[2];
+    ip[0] = oi[0] + (int)kstart; ip[1] = oi[1] + (int)kstart; ip[2] = oi[2] + (int)kstart;
   }
 }
 
@@ -973,7 +994,7 @@ extern "C" int glx_three_nn(int B, int N, int max_queries_per_frame, const float
   GLX_REQUIRE(unknown && unknown_batch_cnt && known && known_batch_cnt && dist2 && idx,
               "glx_three_nn: null pointer");
   const int per = max_queries_per_frame > 0 ? max_queries_per_frame : N;
-  hipLaunchKernelGGL(k_three_nn, dim3(glx_divup(per, TNN_THREADS), B), dim3(TNN_THREADS), 0,
+  hipLaunchKernelGGL(k_three_nn, dim3(glx_divup(per, TNN_THREADS / TNN_SPLIT), B), dim3(TNN_THREADS), 0,
                      (hipStream_t)stream, B, unknown, unknown_batch_cnt, known, known_batch_cnt,
                      dist2, idx);
   GLX_LAUNCH_CHECK();
