@@ -211,34 +211,38 @@ __global__ void k_roipoint_pool(int B, int Np, int M, int C, int S, const float*
                                 const float* __restrict__ boxes, const float* __restrict__ feat,
                                 float* __restrict__ pooled, int* __restrict__ empty_flag) {
   extern __shared__ int s_idx[];   // S
-  const int m = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
-  BoxT bx;
-  bx.load(boxes + ((long long)b * M + m) * 7);
+  __shared__ int s_cnt;
+  const int m = blockIdx.x, b = blockIdx.y, lane = threadIdx.x & 63;
   const float* X = xyz + (long long)b * Np * 3;
-  int cnt = 0;
-  for (int base = 0; base < Np && cnt < S; base += 64) {
-    int k = base + lane;
-    bool in = false;
-    if (k < Np) {
-      float lx, ly;
-      in = bx.contains(X[(long long)k * 3], X[(long long)k * 3 + 1], X[(long long)k * 3 + 2],
-                       PIB_MARGIN, lx, ly);
+  if (threadIdx.x < 64) {          // the ordered scan is one wave's work; the gather below is the block's
+    BoxT bx;
+    bx.load(boxes + ((long long)b * M + m) * 7);
+    int cnt = 0;
+    for (int base = 0; base < Np && cnt < S; base += 64) {
+      int k = base + lane;
+      bool in = false;
+      if (k < Np) {
+        float lx, ly;
+        in = bx.contains(X[(long long)k * 3], X[(long long)k * 3 + 1], X[(long long)k * 3 + 2],
+                         PIB_MARGIN, lx, ly);
+      }
+      unsigned long long bal = __ballot(in);
+      int pos = cnt + __popcll(bal & ((1ull << lane) - 1ull));
+      if (in && pos < S) s_idx[pos] = k;
+      cnt += __popcll(bal);
     }
-    unsigned long long bal = __ballot(in);
-    int pos = cnt + __popcll(bal & ((1ull << lane) - 1ull));
-    if (in && pos < S) s_idx[pos] = k;
-    cnt += __popcll(bal);
+    if (lane == 0) s_cnt = cnt;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  __syncthreads();
+  int cnt = s_cnt;
   if (cnt == 0) {
-    if (lane == 0) empty_flag[(long long)b * M + m] = 1;
+    if (threadIdx.x == 0) empty_flag[(long long)b * M + m] = 1;
     return;
   }
   if (cnt > S) cnt = S;
   const int W = 3 + C;
   float* dst = pooled + ((long long)b * M + m) * S * W;
-  for (int e = lane; e < S * W; e += 64) {
+  for (int e = threadIdx.x; e < S * W; e += blockDim.x) {
     int s = e / W, j = e - s * W;
     int src = s_idx[s < cnt ? s : s % cnt];
     dst[e] = j < 3 ? X[(long long)src * 3 + j] : feat[((long long)b * Np + src) * C + (j - 3)];
@@ -252,7 +256,7 @@ extern "C" int glx_roipoint_pool3d(const float* xyz, const float* boxes3d, const
   GLX_REQUIRE(xyz && boxes3d && pooled && empty_flag && (C == 0 || pts_feature),
               "glx_roipoint_pool3d: null pointer");
   GLX_REQUIRE(S > 0 && (size_t)S * 4 <= 64 * 1024, "glx_roipoint_pool3d: bad sample count %d", S);
-  hipLaunchKernelGGL(k_roipoint_pool, dim3(M, B), dim3(64), S * sizeof(int), (hipStream_t)stream,
+  hipLaunchKernelGGL(k_roipoint_pool, dim3(M, B), dim3(256), S * sizeof(int), (hipStream_t)stream,
                      B, Np, M, C, S, xyz, boxes3d, pts_feature, pooled, empty_flag);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
