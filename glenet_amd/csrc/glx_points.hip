@@ -136,12 +136,12 @@ __global__ void k_roiaware_pool(int N, int C, int maxpts, int nvox, int method,
       float f = feat[(long long)lst[k] * C + c];
       if (f > mv) { mv = f; am = lst[k]; }
     }
-    if (am != -1) pooled[t] = mv;
+    pooled[t] = am != -1 ? mv : 0.f;          // every element written: the caller need not zero-fill 180 MB
     argmax[t] = am;
   } else {
     float s = 0.f;
     for (int k = 1; k <= total; ++k) s += feat[(long long)lst[k] * C + c];
-    if (total > 0) pooled[t] = s / total;
+    pooled[t] = total > 0 ? s / total : 0.f;
   }
 }
 

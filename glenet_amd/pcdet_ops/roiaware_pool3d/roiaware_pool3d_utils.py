@@ -39,10 +39,12 @@ class RoIAwarePool3dFunction(Function):
         ox, oy, oz = (out_size,) * 3 if isinstance(out_size, int) else tuple(out_size)
         shape = (rois.shape[0], ox, oy, oz)
         c = pts_feature.shape[-1]
-        pooled = pts_feature.new_zeros(shape + (c,))
-        argmax = pts_feature.new_zeros(shape + (c,), dtype=torch.int)
-        lists = pts_feature.new_zeros(shape + (max_pts_each_voxel,), dtype=torch.int)
         method = _METHODS[pool_method]
+        # the kernels write every element of `pooled` and (max pooling) `argmax`: no zero fill of those
+        # 2 x 180 MB at PartA2's sizes; avg pooling leaves argmax at the reference's zeros
+        pooled = pts_feature.new_empty(shape + (c,))
+        argmax = (pts_feature.new_empty if method == 0 else pts_feature.new_zeros)(shape + (c,), dtype=torch.int)
+        lists = pts_feature.new_zeros(shape + (max_pts_each_voxel,), dtype=torch.int)
         roiaware_pool3d_cuda.forward(rois.contiguous(), pts.contiguous(), pts_feature.contiguous(),
                                      argmax, lists, pooled, method)
         ctx.roiaware_pool3d_for_backward = (lists, argmax, method, pts.shape[0], c)

@@ -310,8 +310,10 @@ int glx_points_in_boxes(const float* boxes, const float* pts, int B, int T, int 
 int glx_points_in_boxes_mask(const float* boxes, int N, const float* pts, int P, float margin,
                              int32_t* out, void* stream);
 
-/* RoI-aware pooling.  argmax (N,ox,oy,oz,C) i32, pts_idx_of_voxels (N,ox,oy,oz,max_pts) i32 and
- * pooled (N,ox,oy,oz,C) must arrive zero-filled; pool_method 0 = max, 1 = avg.
+/* RoI-aware pooling.  pts_idx_of_voxels (N,ox,oy,oz,max_pts) i32 must arrive zero-filled (the reference's
+ * buffer contents: count, then point indices, then zeros).  pooled (N,ox,oy,oz,C) is written in full (0 for
+ * an empty voxel); argmax (N,ox,oy,oz,C) i32 is written in full by max pooling (-1 for an empty voxel)
+ * and left untouched by avg pooling (the reference leaves its zeros).  pool_method 0 = max, 1 = avg.
  * Replaces: roiaware_pool3d_cuda.forward / backward (roiaware_pool3d.cpp:29-98). */
 int glx_roiaware_pool3d_forward(const float* rois, int N, const float* pts, int P,
                                 const float* pts_feature, int C, int ox, int oy, int oz,
