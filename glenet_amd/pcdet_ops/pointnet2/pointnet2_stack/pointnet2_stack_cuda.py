@@ -84,10 +84,12 @@ def relu_add_max_grad_wrapper(grad_out, out, arg, nsample, grad_in):
     return 1
 
 
-def stack_farthest_point_sampling_wrapper(xyz, temp, xyz_batch_cnt, idxs, num_sampled_points):
-    """sampling.cpp:40-60: xyz (N,3), temp (N) filled with 1e10, idxs (sum m) int32 out."""
+def stack_farthest_point_sampling_wrapper(xyz, temp, xyz_batch_cnt, idxs, num_sampled_points, max_points=None):
+    """sampling.cpp:40-60: xyz (N,3), temp (N) filled with 1e10, idxs (sum m) int32 out.
+    max_points: largest frame (points), if the caller knows it -- frames of up to 16 384 points run with
+    points and running distances in registers; without it only the total N can vouch for that."""
     _lib.check_cuda(xyz, temp, xyz_batch_cnt, idxs, num_sampled_points)
-    n = xyz.shape[0]
+    n = xyz.shape[0] if max_points is None else int(max_points)
     call("glx_stack_fps", xyz, xyz_batch_cnt, xyz_batch_cnt.shape[0], n if n <= 16384 else 0,
          num_sampled_points, temp, idxs)
     return 1

@@ -108,8 +108,12 @@ class StackFarthestPointSampling(Function):
             npoint = torch.tensor(npoint if isinstance(npoint, list) else [npoint] * B, device=xyz.device)
         npoint = npoint.int().contiguous()
         temp = torch.full((xyz.shape[0],), 1e10, dtype=torch.float32, device=xyz.device)
-        out = torch.empty(int(npoint.sum().item()), dtype=torch.int32, device=xyz.device)
-        pointnet2.stack_farthest_point_sampling_wrapper(xyz, temp, _int(xyz_batch_cnt), out, npoint)
+        cnt = _int(xyz_batch_cnt)
+        # one read-back for both host-side numbers: the output length and the largest frame (which picks
+        # the register-resident kernel)
+        total, largest = torch.stack([npoint.sum(), cnt.max().to(npoint.dtype)]).tolist()
+        out = torch.empty(int(total), dtype=torch.int32, device=xyz.device)
+        pointnet2.stack_farthest_point_sampling_wrapper(xyz, temp, cnt, out, npoint, max_points=int(largest))
         ctx.mark_non_differentiable(out)
         return out
 
