@@ -1,0 +1,346 @@
+"""GLENet-VR (Voxel-RCNN with the KL / label-uncertainty RoI head): the composed training step named by
+BASELINE config 3 -- voxelize + sparse backbone + BEV head + proposals (NMS 9000 -> 512) + RoI targets +
+RoI-grid pooling + FC towers + {dense-head, RoI classification, KL regression, corner} losses, forward and
+backward (+ gradient clipping and the AdamW update) -- as a product pipeline.
+
+Our counterpart of the callers (never present at run time):
+  tools/train_utils/train_utils.py:11-110            train_one_epoch: forward, loss.backward(), clip_grad_norm_, step
+  pcdet/models/detectors/voxel_rcnn.py               module order + get_training_loss = loss_rpn + loss_rcnn
+  pcdet/models/roi_heads/voxelrcnn_kl_label_iou_head.py:10-180   the head (reg_std branch, forward, KL loss)
+  pcdet/models/roi_heads/voxelrcnn_head.py:8-191     FC towers, roi_grid_pool
+  pcdet/models/roi_heads/roi_head_template.py:51-286 proposal_layer, assign_targets, get_loss
+  tools/cfgs/kitti_models/GLENet_VR.yaml             every constant below
+
+Module and parameter names equal the reference's (vfe, backbone_3d, map_to_bev_module, backbone_2d,
+dense_head, roi_head.{roi_grid_pool_layers, shared_fc_layer, cls_fc_layers, cls_pred_layer, reg_fc_layers,
+reg_pred_layer, reg_std_layer, reg_std_bn, reg_std_fc1, reg_std_bn1, reg_std_fc2}), so a GLENet-VR
+checkpoint's keys map one to one (glenet_amd.checkpoint).
+
+Two ways to run the same step:
+  * GLENetVR.training_step(...)       exact shapes (host read-backs size the sparse tensors), eager launches;
+  * StaticTrainStep                   shape-static, no host synchronisation anywhere, recorded once into a HIP
+                                      graph and replayed with one call per step (two with a gradient exchange
+                                      between backward and the optimizer at world size > 1).
+Both produce the same loss terms and gradients (tests/test_train_step_gpu.py)."""
+import math
+
+import torch
+from torch import nn
+
+from . import backbone as gb
+from . import dense_path as dp
+from . import detector as det
+from . import losses, roi_grid as rg, roi_targets, target_assign
+
+# GLENet_VR.yaml
+ROI_HEAD_CFG = dict(
+    POOL={n: dict(mlps=[[32, 32]], query_ranges=[[4, 4, 4]], radii=[r], nsamples=[16])
+          for n, r in (("x_conv2", 0.4), ("x_conv3", 0.8), ("x_conv4", 1.6))},                # :117-139
+    GRID_SIZE=6, SHARED_FC=(256, 256), CLS_FC=(256, 256), REG_FC=(256, 256), DP_RATIO=0.3,      # :95-100
+    NMS_TRAIN=(9000, 512, 0.8), NMS_TEST=(2048, 100, 0.7),                                      # :101-115
+    TARGET=dict(ROI_PER_IMAGE=128, FG_RATIO=0.5, SAMPLE_ROI_BY_EACH_CLASS=True, CLS_SCORE_TYPE="roi_iou",
+                CLS_FG_THRESH=0.75, CLS_BG_THRESH=0.25, CLS_BG_THRESH_LO=0.1, HARD_BG_RATIO=0.8,
+                REG_FG_THRESH=0.55),                                                            # :140-153
+    LOSS_WEIGHTS=dict(rcnn_cls_weight=1.0, rcnn_reg_weight=1.0, rcnn_corner_weight=1.0,
+                      code_weights=[1.0] * 7))                                                  # :155-166
+DENSE_HEAD_CFG = dict(anchor_sizes=[[3.9, 1.6, 1.56]], anchor_rotations=[0, 1.57], anchor_bottom_heights=[-1.78],
+                      matched_threshold=0.6, unmatched_threshold=0.45,                          # :63-73
+                      cls_weight=1.0, loc_weight=2.0, dir_weight=0.2, code_weights=[1.0] * 7)   # :84-90
+OPTIM_CFG = dict(LR=0.01, WEIGHT_DECAY=0.01, BETAS=(0.9, 0.99), GRAD_NORM_CLIP=10.0,            # :185-203
+                 MOMS=(0.95, 0.85), PCT_START=0.4, DIV_FACTOR=10)
+
+
+class VoxelRCNNKLHead(rg.RoIGridPool):
+    """VoxelRCNNKLLabelIoUHead: RoI-grid pooling + shared / cls / reg FC towers + the log-variance branch
+    `reg_std_layer` and the small tower on top of it whose sigmoid output rescales the classification score
+    (voxelrcnn_kl_label_iou_head.py:10-37, forward :38-92)."""
+
+    def __init__(self, backbone_channels, voxel_size, point_cloud_range, cfg=None, num_class=1, code_size=7):
+        cfg = cfg or ROI_HEAD_CFG
+        super().__init__(backbone_channels, cfg["POOL"], cfg["GRID_SIZE"], voxel_size, point_cloud_range)
+        self.cfg, self.num_class, self.code_size = cfg, num_class, code_size
+        pre = cfg["GRID_SIZE"] ** 3 * self.num_features
+        self.shared_fc_layer, pre = dp._fc_tower(pre, cfg["SHARED_FC"], cfg["DP_RATIO"])
+        self.cls_fc_layers, c = dp._fc_tower(pre, cfg["CLS_FC"], cfg["DP_RATIO"])
+        self.cls_pred_layer = nn.Linear(c, num_class, bias=True)
+        self.reg_fc_layers, c = dp._fc_tower(pre, cfg["REG_FC"], cfg["DP_RATIO"])
+        self.reg_pred_layer = nn.Linear(c, code_size * num_class, bias=True)
+        self.reg_std_layer = nn.Linear(c, code_size * num_class, bias=True)
+        self.reg_std_bn = nn.BatchNorm1d(code_size * num_class)
+        self.reg_std_fc1 = nn.Linear(code_size * num_class, 64, bias=True)
+        self.reg_std_bn1 = nn.BatchNorm1d(64)
+        self.reg_std_fc2 = nn.Linear(64, 1, bias=True)
+        self.init_weights()
+
+    def init_weights(self):
+        """voxelrcnn_head.py:81-93 + voxelrcnn_kl_label_iou_head.py:30-36."""
+        for tower in (self.shared_fc_layer, self.cls_fc_layers, self.reg_fc_layers):
+            for m in tower.modules():
+                if isinstance(m, nn.Linear):
+                    nn.init.xavier_normal_(m.weight)
+        nn.init.normal_(self.cls_pred_layer.weight, 0, 0.01)
+        nn.init.constant_(self.cls_pred_layer.bias, 0)
+        nn.init.normal_(self.reg_pred_layer.weight, mean=0, std=0.001)
+        nn.init.constant_(self.reg_pred_layer.bias, 0)
+        for m in (self.reg_std_layer, self.reg_std_fc1, self.reg_std_fc2):
+            nn.init.normal_(m.weight, mean=0, std=0.0001)
+            nn.init.constant_(m.bias, 0)
+
+    def heads(self, pooled):
+        """pooled (R, G^3, C) -> rcnn_cls (R,1) [the rescaled logit], rcnn_reg (R,7), rcnn_reg_std (R,7)."""
+        x = pooled.reshape(pooled.shape[0], -1)
+        shared = self.shared_fc_layer(x)
+        ori_cls = self.cls_pred_layer(self.cls_fc_layers(shared))
+        reg_feat = self.reg_fc_layers(shared)
+        rcnn_reg = self.reg_pred_layer(reg_feat)
+        rcnn_reg_std = self.reg_std_layer(reg_feat)
+        s = torch.relu(self.reg_std_bn(rcnn_reg_std.clone()))
+        s = torch.relu(self.reg_std_bn1(self.reg_std_fc1(s)))
+        s = torch.sigmoid(self.reg_std_fc2(s))
+        p = torch.sigmoid(ori_cls) * s                                                   # :73-75 ("ad hoc")
+        rcnn_cls = torch.log((p + 1e-6) / (1 - p + 1e-6))
+        return rcnn_cls, rcnn_reg, rcnn_reg_std
+
+    def forward(self, rois, multi_scale_3d_features, multi_scale_3d_strides, batch_size):
+        pooled = super().forward(rois, multi_scale_3d_features, multi_scale_3d_strides, batch_size)
+        return self.heads(pooled)
+
+
+class GLENetVR(nn.Module):
+    """Detector3DTemplate module order of GLENet_VR.yaml."""
+
+    def __init__(self, cfg, num_point_features=4, roi_cfg=None, head_cfg=None):
+        super().__init__()
+        self.cfg = cfg
+        self.roi_cfg, self.head_cfg = roi_cfg or ROI_HEAD_CFG, head_cfg or DENSE_HEAD_CFG
+        grid = gb.gv.grid_size_of(cfg["point_cloud_range"], cfg["voxel_size"])
+        self.vfe = gb.MeanVFE()
+        self.backbone_3d = gb.VoxelBackBone8x(num_point_features, grid)
+        self.map_to_bev_module = gb.HeightCompression()
+        self.backbone_2d = dp.BEVBackbone(256)
+        self.dense_head = dp.AnchorHead(self.backbone_2d.num_bev_features, num_class=1, num_anchors_per_location=2)
+        self.roi_head = VoxelRCNNKLHead(self.backbone_3d.backbone_channels, cfg["voxel_size"],
+                                        cfg["point_cloud_range"], self.roi_cfg)
+        self.target_layer = roi_targets.ProposalTargetLayer(self.roi_cfg["TARGET"])
+        self.feature_map = (grid[0] // 8, grid[1] // 8)
+        self._anchors = None
+        self.fixed_draws = None      # tests: (key (B,R), pick (B,P)) uniform numbers for the RoI sampler
+        self.last = None
+
+    def anchors(self, device):
+        if self._anchors is None or self._anchors.device != device:
+            h = self.head_cfg
+            self._anchors = det.generate_anchors(self.cfg["point_cloud_range"], self.feature_map, h["anchor_sizes"],
+                                                 h["anchor_rotations"], h["anchor_bottom_heights"], device=device)
+        return self._anchors
+
+    # ------------------------------------------------------------------ stages
+    def first_stage(self, bd):
+        """voxel features + coordinates -> sparse backbone -> BEV map (the part StaticTrainPipeline records)."""
+        return self.map_to_bev_module(self.backbone_3d(self.vfe(bd)))
+
+    def second_stage_losses(self, bd, gt_boxes, gt_uncertaintys, seed_rois_with_gt=None):
+        """Everything behind the BEV map of a training step: BEV backbone + anchor head, anchor targets +
+        dense-head loss, proposals, RoI targets, RoI-grid pooling, FC towers, the three RoI-head losses.
+        gt_boxes (B,G,8) zero-padded [x,y,z,dx,dy,dz,ry,class]; gt_uncertaintys (B,G,7) label variances.
+        seed_rois_with_gt: optional (7,) offset -- the first G proposal slots of every frame are overwritten
+        with ground truth + offset (what a trained first stage delivers; an untrained one proposes nothing
+        near the ground truth, which would leave the regression / corner terms without foreground).
+        Returns (loss, parts) with device scalars; free of host synchronisation on shape-static inputs."""
+        B = gt_boxes.shape[0]
+        h, r = self.head_cfg, self.roi_cfg
+        bd = self.dense_head(self.backbone_2d(bd))
+        anchors = self.anchors(gt_boxes.device)
+        with torch.no_grad():
+            tgt = target_assign.assign_targets([anchors], gt_boxes, [1], [h["matched_threshold"]],
+                                               [h["unmatched_threshold"]])
+            cls, boxes = det.predicted_boxes(bd["cls_preds"], bd["box_preds"], bd.get("dir_cls_preds"), anchors)
+            rois, roi_scores, roi_labels = det.proposal_layer(boxes, cls, *r["NMS_TRAIN"])
+            if seed_rois_with_gt is not None:
+                has = gt_boxes[:, :, 7:8] > 0
+                ng = gt_boxes.shape[1]
+                rois[:, :ng, :7] = torch.where(has, gt_boxes[:, :, :7] + seed_rois_with_gt, rois[:, :ng, :7])
+                roi_labels[:, :ng] = torch.where(has[..., 0], gt_boxes[:, :, 7].long(), roi_labels[:, :ng])
+            key, pick = self.fixed_draws if self.fixed_draws is not None else (None, None)
+            td = self.target_layer({"rois": rois, "roi_scores": roi_scores, "roi_labels": roi_labels,
+                                    "gt_boxes": gt_boxes, "gt_uncertaintys": gt_uncertaintys}, key, pick)
+            rois_s = td["rois"].contiguous()
+            gt_src = td["gt_of_rois"]                                                    # roi_head_template.py:137
+            gt_ct = losses.canonical_gt_of_rois(rois_s, gt_src)                          # :140-159
+            reg_valid, cls_lab = td["reg_valid_mask"].view(-1), td["rcnn_cls_labels"].view(-1)
+            unc = td["gt_uncertaintys_of_rois"].reshape(-1, 7)
+        rpn, rpn_parts = losses.rpn_loss(bd["cls_preds"], bd["box_preds"], bd.get("dir_cls_preds"),
+                                         tgt["box_cls_labels"], tgt["box_reg_targets"], anchors,
+                                         code_weights=h["code_weights"], cls_weight=h["cls_weight"],
+                                         loc_weight=h["loc_weight"], dir_weight=h["dir_weight"])
+        rcnn_cls, rcnn_reg, rcnn_std = self.roi_head(rois_s, bd["multi_scale_3d_features"],
+                                                     bd["multi_scale_3d_strides"], B)
+        w = r["LOSS_WEIGHTS"]
+        l_cls = losses.rcnn_cls_loss(rcnn_cls, cls_lab, weight=w["rcnn_cls_weight"])
+        l_kl, kl_parts = losses.kl_reg_loss(rcnn_reg, rcnn_std, rois_s, gt_ct[..., :7], unc, reg_valid,
+                                            code_weights=w["code_weights"], weight=w["rcnn_reg_weight"])
+        l_cor = losses.corner_loss(rcnn_reg, rois_s, gt_src[..., :7], reg_valid, weight=w["rcnn_corner_weight"])
+        loss = rpn + l_cls + l_kl + l_cor                                                # voxel_rcnn.py get_training_loss
+        parts = dict(loss_rpn=rpn.detach(), rcnn_loss_cls=l_cls.detach(), rcnn_loss_reg=l_kl.detach(),
+                     rcnn_loss_corner=l_cor.detach(), fg_rois=kl_parts["fg"], **rpn_parts)
+        # detached views for inspection / tests (a live autograd graph of an earlier step must not survive into
+        # the next capture, see StaticTrainPipeline.enqueue)
+        self.last = dict(rois=rois_s, rcnn_cls=rcnn_cls.detach(), rcnn_reg=rcnn_reg.detach(),
+                         rcnn_reg_std=rcnn_std.detach(), targets=td, proposals=rois, gt_of_rois_ct=gt_ct,
+                         anchor_targets=tgt, cls_preds=bd["cls_preds"].detach(), box_preds=bd["box_preds"].detach(),
+                         dir_cls_preds=bd["dir_cls_preds"].detach() if "dir_cls_preds" in bd else None)
+        return loss, parts
+
+    def training_step(self, points, batch_idx, batch_size, gt_boxes, gt_uncertaintys, seed_rois_with_gt=None):
+        """Exact-shape forward of one training step (host read-backs size the sparse tensors)."""
+        bd = gb.voxelize_batch(points, batch_idx, batch_size, self.cfg, train=True)
+        bd = self.first_stage(bd)
+        return self.second_stage_losses(bd, gt_boxes, gt_uncertaintys, seed_rois_with_gt)
+
+    @torch.no_grad()
+    def forward(self, points, batch_idx, batch_size):
+        """Inference data flow up to the refined boxes (voxelrcnn_kl_label_iou_head.py:77-85)."""
+        bd = gb.voxelize_batch(points, batch_idx, batch_size, self.cfg, train=False)
+        bd = self.dense_head(self.backbone_2d(self.first_stage(bd)))
+        cls, boxes = det.predicted_boxes(bd["cls_preds"], bd["box_preds"], bd.get("dir_cls_preds"),
+                                         self.anchors(points.device))
+        rois, roi_scores, roi_labels = det.proposal_layer(boxes, cls, *self.roi_cfg["NMS_TEST"])
+        rcnn_cls, rcnn_reg, rcnn_std = self.roi_head(rois, bd["multi_scale_3d_features"],
+                                                     bd["multi_scale_3d_strides"], batch_size)
+        bd.update(rois=rois, roi_scores=roi_scores, roi_labels=roi_labels,
+                  batch_cls_preds=rcnn_cls.view(batch_size, -1, rcnn_cls.shape[-1]),
+                  batch_box_preds=det.refine_boxes(rois, rcnn_reg),
+                  batch_box_std_preds=rcnn_std.view(batch_size, -1, rcnn_std.shape[-1]),
+                  cls_preds_normalized=False)
+        return bd
+
+
+def onecycle(step, total_steps, lr_max=OPTIM_CFG["LR"], moms=OPTIM_CFG["MOMS"], div_factor=OPTIM_CFG["DIV_FACTOR"],
+             pct_start=OPTIM_CFG["PCT_START"]):
+    """fastai-style one-cycle schedule of the reference (tools/train_utils/optimization/learning_schedules_fastai.py
+    OneCycle: cosine annealing lr_max/div -> lr_max over pct_start, then -> lr_max/div/1e4; momentum mirrored)."""
+    a = int(total_steps * pct_start)
+    low = lr_max / div_factor
+
+    def cos(s, e, p):
+        return e + (s - e) / 2 * (math.cos(math.pi * p) + 1)
+    if step < a:
+        p = step / max(a, 1)
+        return cos(low, lr_max, p), cos(moms[0], moms[1], p)
+    p = (step - a) / max(total_steps - a, 1)
+    return cos(lr_max, low / 1e4, p), cos(moms[1], moms[0], p)
+
+
+class StaticTrainStep(gb.StaticTrainPipeline):
+    """The whole GLENet-VR training step as one shape-static launch sequence: the sparse front end of
+    StaticTrainPipeline (voxelize, rule tables on a second stream, backbone, dense()) with
+    GLENetVR.second_stage_losses as its loss, backward of everything, then gradient-norm clipping and AdamW
+    (`torch.optim.AdamW(capturable=True)`: step count and learning rate live on the device).
+
+    capture(split=False): one HIP graph per step.  capture(split=True): two graphs -- forward + backward, and
+    clip + update -- so that a gradient exchange (glenet_amd.dist.GradBucket, one flat RCCL all-reduce) runs
+    between them: step() = replay fwd/bwd, exchange, replay update.
+    Ground truth is part of the static input: gt_boxes (B, G, 8) / gt_uncertaintys (B, G, 7), zero rows = padding."""
+
+    def __init__(self, model, batch_size, num_points, num_features=4, max_gt=32, optimizer=None, lr=None,
+                 seed_rois_with_gt=None, grad_clip=OPTIM_CFG["GRAD_NORM_CLIP"], capacities=None, device=None):
+        dev = device if device is not None else next(model.parameters()).device
+        self.net = model
+        self.gt_boxes = torch.zeros((batch_size, max_gt, 8), dtype=torch.float32, device=dev)
+        self.gt_unc = torch.zeros((batch_size, max_gt, 7), dtype=torch.float32, device=dev)
+        self.seed = (torch.as_tensor(seed_rois_with_gt, dtype=torch.float32, device=dev)
+                     if seed_rois_with_gt is not None else None)
+        self.parts = None
+        self.grad_clip = grad_clip
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        if optimizer is None:
+            optimizer = torch.optim.AdamW(self.params, lr=torch.tensor(lr if lr is not None else OPTIM_CFG["LR"],
+                                                                       dtype=torch.float32, device=dev),
+                                          betas=OPTIM_CFG["BETAS"], weight_decay=OPTIM_CFG["WEIGHT_DECAY"],
+                                          capturable=True, foreach=True)
+        self.step_optimizer = optimizer
+        self.exchange = None           # callable run between backward and the update (gradient all-reduce)
+        self.update_graph = None
+        self.grad_norm = None
+        super().__init__(model.backbone_3d, model.cfg, batch_size, num_points, num_features,
+                         loss_fn=self._loss, optimizer=None, capacities=capacities, device=dev,
+                         extra_modules=(model.backbone_2d, model.dense_head, model.roi_head))
+        self.hc = model.map_to_bev_module
+        self.split = False
+
+    def _loss(self, bd):
+        loss, self.parts = self.net.second_stage_losses(bd, self.gt_boxes, self.gt_unc, self.seed)
+        return loss
+
+    def load(self, points, batch_idx, gt_boxes=None, gt_uncertaintys=None):
+        super().load(points, batch_idx)
+        if gt_boxes is not None:
+            g = gt_boxes.shape[1]
+            if g > self.gt_boxes.shape[1]:
+                raise ValueError("batch has %d ground-truth rows, pipeline was sized for %d" % (g, self.gt_boxes.shape[1]))
+            self.gt_boxes.zero_()
+            self.gt_boxes[:, :g].copy_(gt_boxes, non_blocking=True)
+            self.gt_unc.zero_()
+            if gt_uncertaintys is not None:
+                self.gt_unc[:, :g].copy_(gt_uncertaintys, non_blocking=True)
+
+    def set_lr(self, lr, momentum=None):
+        """One-cycle schedule hook: the learning rate is a device scalar the recorded update reads."""
+        for g in self.step_optimizer.param_groups:
+            if torch.is_tensor(g["lr"]):
+                g["lr"].fill_(lr)
+            else:
+                g["lr"] = lr
+
+    def update(self):
+        """clip_grad_norm_ (train_utils.py:38) + optimizer step; no read-back (the norm stays on the device)."""
+        if self.grad_clip:
+            self.grad_norm = torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip, foreach=True)
+        self.step_optimizer.step()
+
+    def enqueue(self):
+        bd = super().enqueue()
+        if not self.split:
+            if self.exchange is not None:
+                self.exchange()
+            self.update()
+        return bd
+
+    def capture(self, warmup=2, split=False):
+        """split=False: fwd + bwd + clip + update in one graph.  split=True: the update is its own graph and
+        step() runs `exchange` between the two."""
+        self.split = bool(split)
+        if not split and self.exchange is not None:
+            raise ValueError("a gradient exchange needs capture(split=True)")
+        super().capture(warmup)
+        if split:
+            dev = self.points.device
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                self.update()                              # warm-up of the optimizer state (lazy init)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.update_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.update_graph, stream=side):
+                self.update()
+        return self
+
+    def last_rois_shape(self):
+        return tuple(self.net.last["rois"].shape)
+
+    def step(self):
+        """One training step on the loaded batch."""
+        if self.graph is None:
+            self.enqueue()
+            if self.split:
+                if self.exchange is not None:
+                    self.exchange()
+                self.update()
+            return self.loss
+        self.replay()
+        if self.split:
+            if self.exchange is not None:
+                self.exchange()
+            self.update_graph.replay()
+        return self.loss

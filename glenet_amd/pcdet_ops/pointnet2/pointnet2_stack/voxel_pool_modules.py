@@ -196,6 +196,12 @@ class NeighborVoxelSAModuleMSG(nn.Module):
             y = torch.bmm(x2d.view(128, rows // 128, -1), w.t().unsqueeze(0).expand(128, -1, -1)).view(rows, -1)
         else:
             y = F.linear(x2d, w, conv.bias)
+        return NeighborVoxelSAModuleMSG._bn_rows(seq, y)
+
+    @staticmethod
+    def _bn_rows(seq, y):
+        """The BatchNorm (+ ReLU) of Sequential(Conv, BatchNorm[, ReLU]) on (rows, C) tensors."""
+        bn = seq[1]
         if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
             bn.num_batches_tracked += 1
         use_batch = bn.training or not bn.track_running_stats

@@ -7,6 +7,7 @@ and step (generate_voxel2pinds, 189 MB at x_conv2) is not built -- the query wal
 tensor's cell index (glx_voxel_query_index); per-batch counts are computed without a Python loop.
 """
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .pcdet_ops.pointnet2.pointnet2_stack import voxel_pool_modules
@@ -19,6 +20,19 @@ def get_voxel_centers(voxel_coords, downsample_times, voxel_size, point_cloud_ra
     size = torch.tensor(voxel_size, device=xyz.device).float() * downsample_times
     origin = torch.tensor(point_cloud_range[0:3], device=xyz.device).float()
     return (xyz + 0.5) * size + origin
+
+
+def _voxel_centers_capturable(voxel_coords, downsample_times, voxel_size, point_cloud_range):
+    """get_voxel_centers without host->device copies (no index lists, no torch.tensor(...) of the python
+    constants), so that it can be recorded into a HIP graph; same float32 arithmetic step by step: the
+    scaled voxel size is the float32 product the tensor expression forms, applied as a scalar."""
+    import numpy as np
+    c = voxel_coords
+    cols = []
+    for i, col in enumerate((2, 1, 0)):
+        size = float(np.float32(voxel_size[i]) * np.float32(downsample_times))
+        cols.append((c[:, col].float() + 0.5) * size + float(np.float32(point_cloud_range[i])))
+    return torch.stack(cols, dim=1)
 
 
 def rotate_points_along_z(points, angle):
@@ -77,6 +91,8 @@ class RoIGridPool(nn.Module):
         B = batch_size
         if self._fusable(rois, multi_scale_3d_features):
             return self._forward_fused(rois, multi_scale_3d_features, multi_scale_3d_strides, B)
+        if self._trainable_rows(rois, multi_scale_3d_features):
+            return self._forward_rows(rois, multi_scale_3d_features, multi_scale_3d_strides, B)
         grid_xyz, _ = global_grid_points_of_roi(rois, self.grid_size)           # (B*R, G^3, 3)
         grid_xyz = grid_xyz.reshape(B, -1, 3)
         coords1 = self.grid_coords(grid_xyz)                                      # (B, R*G^3, 3) float
@@ -98,6 +114,85 @@ class RoIGridPool(nn.Module):
                         voxel2point_indices=st)
             pooled.append(out.view(-1, self.grid_size ** 3, out.shape[-1]))
         return torch.cat(pooled, dim=-1)
+
+    # ---- training path (autograd), free of host synchronisation: what a shape-static training step
+    # (glenet_amd.glenet_vr.StaticTrainStep) records into its HIP graph.  Same arithmetic as the generic
+    # path above (NeighborVoxelSAModuleMSG._forward_rows); the differences are the grid-point kernel, the
+    # query through the cell index with centres rebuilt from the indices (no xyz / count / coordinate
+    # tensors, no bincount) and the live-row handling of mlps_in: a shape-static sparse tensor carries
+    # undefined rows past `count`, so the statistics of its BatchNorm run over the live rows only
+    # (fused kernels, csrc/glx_bn.hip) and the rows past them are selected away (torch.where, not a
+    # multiplication: they may hold NaN) on both sides of the 1x1 conv, forward and backward.
+    USE_ROWS = True
+
+    def _trainable_rows(self, rois, tensors):
+        if not (self.USE_ROWS and rois.is_cuda and rois.dtype == torch.float32):
+            return False
+        for layer, name in zip(self.roi_grid_pool_layers, self.sources):
+            st = tensors[name]
+            if layer.pool_method != "max_pool" or (st.count is not None and st._index is None):
+                return False
+        return True
+
+    @staticmethod
+    def _mlp_in_rows(layer, seq, st):
+        from .spconv import core
+        conv, bn = seq[0], seq[1]
+        w = conv.weight.reshape(conv.out_channels, conv.in_channels)
+        x = st.features
+        live = None
+        if st.count is not None:
+            live = (torch.arange(x.shape[0], device=x.device) < st.count).view(-1, 1)
+            x = torch.where(live, x, x.new_zeros(()))
+        y = F.linear(x, w, conv.bias)
+        if core.can_fuse_train_bn(bn, y):
+            if live is not None:
+                y = torch.where(live, y, y.new_zeros(()))        # its backward cleans the gradient rows
+            y = core.fused_train_bn(bn, y, False, st.count)
+            return F.relu(y) if len(seq) > 2 else y
+        if live is not None and bn.training:
+            raise NotImplementedError("shape-static training needs the fused BatchNorm kernels")
+        return layer._bn_rows(seq, y)
+
+    def _forward_rows(self, rois, tensors, strides, B):
+        import ctypes
+        from . import _lib
+        GroupRows, ReluAddMax = voxel_pool_modules.GroupRows, voxel_pool_modules.ReluAddMax
+        f3 = ctypes.c_float * 3
+        rmin, vsz = f3(*self.point_cloud_range[0:3]), f3(*self.voxel_size)
+        rois2 = rois.detach().reshape(-1, rois.shape[-1]).contiguous()
+        n, g3 = rois2.shape[0], self.grid_size ** 3
+        m = n * g3
+        dev = rois.device
+        grid_xyz = torch.empty((m, 3), dtype=torch.float32, device=dev)
+        coords = torch.empty((m, 4), dtype=torch.int32, device=dev)
+        _lib.call("glx_roi_grid_points", rois2, n, rois2.shape[1], n // B, self.grid_size, rmin, vsz,
+                  grid_xyz, coords)
+        outs = []
+        for layer, name in zip(self.roi_grid_pool_layers, self.sources):
+            st = tensors[name]
+            index = st._ensure_index()
+            z, y, x = st.spatial_shape
+            ind = st.indices.contiguous()
+            stride = int(strides[name])
+            with torch.no_grad():
+                xyz = _voxel_centers_capturable(ind[:, 1:4], stride, self.voxel_size, self.point_cloud_range)
+            for grouper, mlp_in, mlp_pos, mlp_out in zip(layer.groupers, layer.mlps_in, layer.mlps_pos,
+                                                         layer.mlps_out):
+                feats = self._mlp_in_rows(layer, mlp_in, st)                       # (N, c_mid)
+                ns = grouper.nsample
+                idx = torch.empty((m, ns), dtype=torch.int32, device=dev)
+                zr, yr, xr = grouper.max_range
+                _lib.call("glx_roi_grid_query", m, z, y, x, ns, float(grouper.radius), zr, yr, xr, grid_xyz,
+                          coords, stride, ind, rmin, vsz, index.bitmap, index.prefix, index.rank_to_row, idx)
+                g_feat = GroupRows.apply(feats, idx)                               # (M, ns, c_mid)
+                with torch.no_grad():
+                    keep = (idx[:, :1] >= 0).to(feats.dtype).view(m, 1, 1)
+                    rel = (GroupRows.apply(xyz, idx) - grid_xyz.view(m, 1, 3)) * keep
+                pos = layer._conv_bn_rows(mlp_pos, rel.view(m * ns, 3))           # (M*ns, c_mid)
+                pooled = ReluAddMax.apply(g_feat, pos.view(m, ns, -1))            # (M, c_mid)
+                outs.append(layer._conv_bn_rows(mlp_out, pooled))                 # (M, c_out)
+        return torch.cat(outs, dim=1).view(n, g3, -1)
 
     # ---- inference fast path: 1 + 3 launches per scale (csrc/glx_points.hip) -- grid points and
     # their voxel coordinates in one kernel, then per scale mlp_in (one GEMM), the voxel query and

@@ -78,6 +78,13 @@ def kitti_frame(frame_id, num_points=20000, num_boxes=15):
     return out, boxes.astype(np.float32)
 
 
+def gt_uncertainty(frame_id, num_boxes=15):
+    """(K,7) label variances of a frame's boxes, U(0.01, 0.2) (the `gt_uncertaintys` GLENet's
+    CVAE stage writes next to the ground truth)."""
+    rng = np.random.default_rng(7000 + frame_id)
+    return rng.uniform(0.01, 0.2, (num_boxes, 7)).astype(np.float32)
+
+
 def waymo_frame(frame_id, num_points=180000, num_boxes=60):
     """(P,5) float32 [x,y,z,intensity,elongation]; Waymo-shaped range, full 360 degrees."""
     rng = np.random.default_rng(5000 + frame_id)

@@ -167,3 +167,16 @@ def test_box_decode_matches_reference_golden():
     np.testing.assert_allclose(boxes.numpy(), g["head_boxes"], rtol=0, atol=1e-6)
     ref = det.refine_boxes(torch.from_numpy(g["roi_rois"]), torch.from_numpy(g["roi_reg"]))
     np.testing.assert_allclose(ref.numpy(), g["roi_boxes"], rtol=1e-6, atol=1e-5)
+
+
+def test_capturable_voxel_centres_equal_the_reference_formulation_cpu():
+    """roi_grid._voxel_centers_capturable (no host->device copies, recordable into a HIP graph) is bit-equal to
+    get_voxel_centers (pinned by the reference golden in test_dense_path_cpu.py) at every stride."""
+    from glenet_amd import roi_grid as rg
+    g = torch.Generator().manual_seed(0)
+    for cfg in (synth.KITTI, synth.WAYMO):
+        c = torch.randint(0, 1600, (4000, 3), dtype=torch.int32, generator=g)
+        for stride in (1, 2, 4, 8):
+            a = rg.get_voxel_centers(c, stride, cfg["voxel_size"], cfg["point_cloud_range"])
+            b = rg._voxel_centers_capturable(c, stride, cfg["voxel_size"], cfg["point_cloud_range"])
+            assert torch.equal(a, b)

@@ -1,0 +1,225 @@
+"""BASELINE config 3 as a product path: the composed GLENet-VR training step (glenet_amd.glenet_vr).
+
+What pins it: every piece of the step is pinned on its own against the reference's code (tests/golden: anchor
+targets + dense-head loss, RoI targets, KL / corner / classification losses, box decoding, NMS keep lists) or
+against the oracle (voxelizer, sparse convs, voxel query, grouping).  These tests pin the COMPOSITION:
+  * the step's loss equals the sum of the reference-formulation losses (`*_torch` mirrors, themselves pinned by
+    the goldens in tests/test_losses.py / test_target_assign_gpu.py) evaluated on the step's own tensors;
+  * proposals equal the per-frame loop of RoIHeadTemplate.proposal_layer;
+  * the shape-static step (eager and replayed as a HIP graph) reproduces the exact-shape step: loss terms and
+    every parameter gradient;
+  * a replayed training run follows an eager AdamW loop;
+  * at the full config-3 per-GPU size (4 x 20 000 points, 9000 -> 512 proposals, 128 RoIs / frame) the graph
+    cycles through different batches within its calibrated capacities."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from glenet_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(dev, ids, num_points, max_gt=16):
+    frames = [synth.kitti_frame(i, num_points=num_points) for i in ids]
+    pts = torch.from_numpy(np.concatenate([f[0] for f in frames])).to(dev)
+    bidx = torch.from_numpy(np.concatenate([np.full(len(f[0]), i, np.int32) for i, f in enumerate(frames)])).to(dev)
+    gt = torch.zeros(len(ids), max_gt, 8, device=dev)
+    unc = torch.zeros(len(ids), max_gt, 7, device=dev)
+    for i, (fid, f) in enumerate(zip(ids, frames)):
+        k = len(f[1])
+        gt[i, :k, :7] = torch.from_numpy(f[1]).to(dev)
+        gt[i, :k, 7] = 1
+        unc[i, :k] = torch.from_numpy(synth.gt_uncertainty(fid, k)).to(dev)
+    return pts, bidx, gt, unc
+
+
+def _small_model(dev, dp_ratio=0.0):
+    from glenet_amd import glenet_vr as gvr
+    cfg = copy.deepcopy(gvr.ROI_HEAD_CFG)
+    cfg.update(NMS_TRAIN=(1024, 128, 0.8), DP_RATIO=dp_ratio)
+    cfg["TARGET"] = dict(cfg["TARGET"], ROI_PER_IMAGE=32)
+    torch.manual_seed(0)
+    torch.backends.cudnn.benchmark = True
+    return gvr.GLENetVR(synth.KITTI, roi_cfg=cfg).to(dev).train()
+
+
+JIT = [0.2, -0.15, 0.05, 0.1, -0.05, 0.03, 0.08]
+
+
+def _grads(model):
+    return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+def test_composed_losses_equal_the_reference_formulations(dev):
+    from glenet_amd import detector as det, losses
+    model = _small_model(dev)
+    pts, bidx, gt, unc = _batch(dev, [50, 51], 6000)
+    seed = torch.tensor(JIT, device=dev)
+    loss, parts = model.training_step(pts, bidx, 2, gt, unc, seed_rois_with_gt=seed)
+    last = model.last
+    assert int(parts["fg_rois"]) > 0 and torch.isfinite(loss)
+    # proposals: the batched device path == the per-frame loop of the reference's proposal_layer
+    anchors = model.anchors(dev)
+    with torch.no_grad():
+        cls, boxes = det.predicted_boxes(last["cls_preds"], last["box_preds"], last["dir_cls_preds"], anchors)
+        det.BATCHED_PROPOSALS = False
+        try:
+            rois_loop, _, _ = det.proposal_layer(boxes, cls, *model.roi_cfg["NMS_TRAIN"])
+        finally:
+            det.BATCHED_PROPOSALS = True
+    ng = gt.shape[1]
+    assert torch.equal(last["proposals"][:, ng:], rois_loop[:, ng:])         # slots behind the seeded ones
+    # the four loss terms in the reference's tensor-op formulation, on the step's own tensors
+    at = last["anchor_targets"]
+    rpn, _ = losses.rpn_loss_torch(last["cls_preds"], last["box_preds"], last["dir_cls_preds"], at["box_cls_labels"],
+                                   at["box_reg_targets"], anchors)
+    td = last["targets"]
+    rois = last["rois"]
+    gt_ct = losses.canonical_gt_of_rois_torch(rois, td["gt_of_rois"])
+    np.testing.assert_allclose(last["gt_of_rois_ct"].cpu().numpy(), gt_ct.cpu().numpy(), atol=2e-5)
+    valid = td["reg_valid_mask"].view(-1)
+    l_cls = losses.rcnn_cls_loss_torch(last["rcnn_cls"], td["rcnn_cls_labels"])
+    l_kl, _ = losses.kl_reg_loss_torch(last["rcnn_reg"], last["rcnn_reg_std"], rois, gt_ct[..., :7].reshape(-1, 7),
+                                       td["gt_uncertaintys_of_rois"].reshape(-1, 7), valid)
+    l_cor = losses.corner_loss_torch(last["rcnn_reg"], rois, td["gt_of_rois"][..., :7], valid)
+    for name, want in (("loss_rpn", rpn), ("rcnn_loss_cls", l_cls), ("rcnn_loss_reg", l_kl), ("rcnn_loss_corner", l_cor)):
+        np.testing.assert_allclose(float(parts[name]), float(want), rtol=2e-4, atol=1e-5, err_msg=name)
+    np.testing.assert_allclose(float(loss), float(rpn + l_cls + l_kl + l_cor), rtol=2e-4)
+    loss.backward()
+    g = _grads(model)
+    assert len(g) == sum(1 for p in model.parameters() if p.requires_grad)
+    assert all(torch.isfinite(v).all() for v in g.values())
+
+
+def test_static_step_and_graph_reproduce_the_exact_shape_step(dev):
+    from glenet_amd import glenet_vr as gvr
+    model = _small_model(dev)
+    B = 2
+    pts, bidx, gt, unc = _batch(dev, [52, 53], 6000)
+    R, P = model.roi_cfg["NMS_TRAIN"][1], model.roi_cfg["TARGET"]["ROI_PER_IMAGE"]
+    gen = torch.Generator(device=dev).manual_seed(3)
+    model.fixed_draws = (torch.rand((B, R), device=dev, generator=gen), torch.rand((B, P), device=dev, generator=gen))
+    seed = torch.tensor(JIT, device=dev)
+    state0 = copy.deepcopy(model.state_dict())
+    model.zero_grad(set_to_none=True)
+    loss, parts = model.training_step(pts, bidx, B, gt, unc, seed_rois_with_gt=seed)
+    loss.backward()
+    want_g, want_parts = _grads(model), {k: float(v) for k, v in parts.items()}
+    del loss, parts
+    model.last = None
+
+    def check(pipe, what):
+        got = {k: float(v) for k, v in pipe.parts.items()}
+        for k, v in want_parts.items():
+            np.testing.assert_allclose(got[k], v, rtol=2e-4, atol=1e-6, err_msg="%s: %s" % (what, k))
+        g = _grads(model)
+        assert g.keys() == want_g.keys()
+        for k, v in want_g.items():
+            scale = float(v.abs().max()) + 1e-12
+            assert float((g[k] - v).abs().max()) <= 2e-3 * scale + 1e-7, "%s: grad of %s" % (what, k)
+
+    model.load_state_dict(state0)                 # same BatchNorm running statistics as the exact-shape run saw
+    pipe = gvr.StaticTrainStep(model, B, pts.shape[0] + 700, max_gt=gt.shape[1], lr=0.0, seed_rois_with_gt=JIT,
+                               grad_clip=None)
+    pipe.calibrate(pts, bidx)
+    pipe.load(pts, bidx, gt, unc)
+    pipe.step()
+    torch.cuda.synchronize()
+    pipe.check()
+    check(pipe, "shape-static eager")
+    pipe.capture()
+    for _ in range(2):
+        pipe.step()
+    torch.cuda.synchronize()
+    pipe.check()
+    check(pipe, "HIP graph replay")
+
+
+def test_replayed_training_follows_an_eager_adamw_loop(dev):
+    from glenet_amd import glenet_vr as gvr
+    model = _small_model(dev)
+    ref = copy.deepcopy(model)
+    B = 2
+    pts, bidx, gt, unc = _batch(dev, [54, 55], 6000)
+    R, P = model.roi_cfg["NMS_TRAIN"][1], model.roi_cfg["TARGET"]["ROI_PER_IMAGE"]
+    gen = torch.Generator(device=dev).manual_seed(4)
+    draws = (torch.rand((B, R), device=dev, generator=gen), torch.rand((B, P), device=dev, generator=gen))
+    model.fixed_draws = ref.fixed_draws = draws
+    seed = torch.tensor(JIT, device=dev)
+    lr = 1e-3
+    opt = torch.optim.AdamW(ref.parameters(), lr=lr, betas=gvr.OPTIM_CFG["BETAS"],
+                            weight_decay=gvr.OPTIM_CFG["WEIGHT_DECAY"])
+    steps, warm = 4, 3                                  # capture() itself takes `warm` optimizer steps
+    want = []
+    for _ in range(warm + steps):
+        opt.zero_grad(set_to_none=True)
+        loss, _ = ref.training_step(pts, bidx, B, gt, unc, seed_rois_with_gt=seed)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), gvr.OPTIM_CFG["GRAD_NORM_CLIP"])
+        opt.step()
+        want.append(float(loss))
+        del loss
+    pipe = gvr.StaticTrainStep(model, B, pts.shape[0] + 700, max_gt=gt.shape[1], lr=lr, seed_rois_with_gt=JIT)
+    pipe.calibrate(pts, bidx)
+    pipe.load(pts, bidx, gt, unc)
+    pipe.capture(warmup=2)                              # 2 warm-up steps + the capture pass (which does not execute)
+    got = []
+    for _ in range(steps + 1):
+        pipe.step()
+        got.append(float(pipe.loss))
+    pipe.check()
+    np.testing.assert_allclose(got, want[2:2 + len(got)], rtol=5e-3)
+    assert got[-1] < got[0]
+
+
+def test_split_capture_runs_the_exchange_between_backward_and_update(dev):
+    from glenet_amd import glenet_vr as gvr
+    model = _small_model(dev)
+    B = 2
+    pts, bidx, gt, unc = _batch(dev, [56, 57], 6000)
+    pipe = gvr.StaticTrainStep(model, B, pts.shape[0] + 700, max_gt=gt.shape[1], lr=1e-3, seed_rois_with_gt=JIT)
+    seen = []
+    w = model.roi_head.reg_pred_layer.weight
+
+    def exchange():        # stands in for the flat all-reduce: sees this step's gradients, before the update
+        seen.append((float(w.grad.abs().sum()), w.detach().clone()))
+    pipe.exchange = exchange
+    pipe.calibrate(pts, bidx)
+    pipe.load(pts, bidx, gt, unc)
+    pipe.capture(split=True)
+    before = w.detach().clone()
+    pipe.step()
+    torch.cuda.synchronize()
+    assert len(seen) >= 1 and seen[-1][0] > 0
+    assert torch.equal(seen[-1][1], before)            # update had not run when the exchange looked
+    assert not torch.equal(w.detach(), before)         # and ran afterwards
+    pipe.check()
+
+
+def test_full_size_step_cycles_batches_inside_one_graph(dev):
+    """Config 3 per GPU: 4 frames x 20 000 points, NMS 9000 -> 512, 128 RoIs per frame, dropout on; the
+    recorded step is replayed over different batches (capacities calibrated on the first with headroom)."""
+    from glenet_amd import glenet_vr as gvr
+    torch.manual_seed(0)
+    torch.backends.cudnn.benchmark = True
+    model = gvr.GLENetVR(synth.KITTI).to(dev).train()
+    B = 4
+    batches = [_batch(dev, list(range(1000 + 4 * j, 1004 + 4 * j)), 20000) for j in range(3)]
+    pipe = gvr.StaticTrainStep(model, B, 80000, max_gt=16, lr=1e-3, seed_rois_with_gt=JIT)
+    pipe.calibrate(batches[0][0], batches[0][1], headroom=1.5)
+    pipe.load(*batches[0])
+    pipe.capture()
+    seen = []
+    for j in (0, 1, 2, 0, 1, 2):
+        pipe.load(*batches[j])
+        pipe.step()
+        torch.cuda.synchronize()
+        pipe.check()
+        seen.append((float(pipe.loss), int(pipe.parts["fg_rois"])))
+    assert all(np.isfinite(l) and fg > 0 for l, fg in seen), seen
+    assert len({round(l, 4) for l, _ in seen[:3]}) == 3          # different batches, different losses
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    assert pipe.last_rois_shape() == (B, 128, 7)
