@@ -1,44 +1,70 @@
 #!/usr/bin/env python
-"""bench.py -- headline benchmark of the hot path (contract: see task brief / DESIGN.md section 5).
+"""bench.py -- headline benchmark of the hot path (contract: task brief).
 
-Workload at N=1 = BASELINE.json configs[1]: GLENet-VR SECOND sparse backbone
-(VoxelBackBone8x as written in the reference: 8 SubMConv3d + 4 SparseConv3d), forward only,
-batch 4 synthetic KITTI-shaped frames per GPU.  One step = one pass of the hot path over one
-batch whose points are already resident in HBM:
-    hard voxelize (4 frames) -> MeanVFE -> rule tables -> 12 sparse convs (+BN/ReLU) -> dense().
-Default --mode graph: the frame is shape-static (buffers at capacity, live row counts stay on the
-device: glenet_amd.backbone.StaticFramePipeline), so its ~120 launches need no host read-back
-and are recorded once into a HIP graph; a step = copy the batch into the graph's input buffers
-+ one graph launch.  --mode static enqueues the same launches from Python each step; --mode
-dynamic is the exact-shape path the spconv mirror uses by default (host read-backs size every
-tensor).  All three compute identical results (tests/test_backbone_gpu.py).
-N > 1: one process per GPU (torch.distributed, RCCL), every rank runs its own 4 frames
-(weak scaling, frames shard with no data-path collective in a forward pass); the timed
-region is bracketed by barrier + synchronize and the max over ranks is reported.
+Headline workload = BASELINE.json configs[2], one GPU's share: the GLENet-VR Voxel-RCNN training step
+(glenet_amd.glenet_vr) on 4 synthetic KITTI-shaped frames per GPU --
+    hard voxelize -> MeanVFE -> rule tables -> 12 sparse convs (training-mode BatchNorm) -> dense()
+    -> BEV backbone + anchor head -> anchor targets + dense-head loss -> proposals (NMS 9000 -> 512)
+    -> RoI targets (128 / frame) -> RoI-grid pooling (3 scales) -> FC towers -> cls + KL + corner losses
+    -> backward of everything -> [N > 1: one flat RCCL all-reduce of the gradients]
+    -> gradient-norm clipping + AdamW
+-- forward + backward + update, nothing skipped.  A step = copy the next batch (8 distinct batches per rank,
+resident in HBM, cycled) into the step's static input buffers + one HIP-graph replay (two replays around the
+all-reduce at N > 1).  `value` = frames of all ranks / max-over-ranks time of exactly K steps.
+
+Sub-measurements in the same line (never `value`):
+  config1   BASELINE configs[1]: VoxelBackBone8x forward only, batch 4 (two frame pipelines in flight)
+  roofline  the sparse-conv instantiation with the most device time in config1's launches, kernel-only
+            durations from HIP events on the launch stream
+  stages    per-stage milliseconds of the training step (one event-bracketed eager pass of the same launches)
+  cpu_baseline  the CPU oracle on the host cores (rank 0, N = 1 only)
+
+`--gpus N` with N > 1 and no torchrun environment: this process only starts N children (one per GPU, before
+anything touches a GPU) and forwards rank 0's JSON line.  Under torchrun the environment decides.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from glenet_amd import backbone as gb  # noqa: E402
-from glenet_amd import dist as gdist  # noqa: E402
-from glenet_amd import synth  # noqa: E402
-from glenet_amd.spconv import core as spcore  # noqa: E402
-
-HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak
 FRAMES_PER_GPU = 4
+BATCH_POOL = 8               # distinct batches per rank; rank 0 at N = 1: frames 0..31 = seeds 1000..1031
+METRIC = "LiDAR frames/sec (fwd+bwd) on KITTI-shaped clouds at 1/2/4/8 MI355X; sparse-conv HBM GB/s"
+ROI_SEED_OFFSET = [0.2, -0.15, 0.05, 0.1, -0.05, 0.03, 0.08]
 
 
+# --------------------------------------------------------------------------------- launcher
+def spawn_ranks(args, argv, script=None):
+    """`bench.py --gpus N` without a torchrun environment: start N rank processes of this script (one
+    device each), before this process has made any GPU call; their rank 0 prints the JSON line."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   GLX_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# --------------------------------------------------------------------------------- roofline helpers
 def kernel_name(cin, cout, K):
     """Name of the kernel glx_sconv_forward dispatches to (launch_mfma in csrc/glx_sconv.hip)."""
     ok = {16, 32, 64, 128}
@@ -50,20 +76,25 @@ def kernel_name(cin, cout, K):
 
 
 def alg_bytes(R, K, cin, cout):
-    """gather read Cin, scatter read-modify-write 2*Cout, two int32
+    """SURVEY.md 8(d), the contract figure: gather read Cin, scatter read-modify-write 2*Cout, two int32
     indices per rule, weights once."""
     return R * (cin + 2 * cout) * 4 + R * 8 + K * cin * cout * 4
 
 
+def min_bytes(R, K, cin, cout, n_in, n_out):
+    """SURVEY.md 8(d), the compulsory lower bound: every input and output row once."""
+    return (n_in * cin + n_out * cout) * 4 + R * 8 + K * cin * cout * 4
+
+
 class ConvProfiler:
-    """Kernel-only duration of every sparse-conv launch: the launcher brackets the kernel
-    with two HIP events (hipExtLaunchKernelGGL start/stop) on the stream it is launched on."""
+    """Kernel-only duration of every sparse-conv launch: the launcher brackets the kernel with two HIP
+    events (hipExtLaunchKernelGGL start/stop) on the stream it is launched on."""
 
     def __init__(self):
         import ctypes
         from glenet_amd import _lib
         self._lib, self._ct = _lib, ctypes
-        self.records = []      # (name, start_evt, stop_evt, rules, K, cin, cout)
+        self.records = []
         self.enabled = False
         self._pool = []
 
@@ -80,17 +111,28 @@ class ConvProfiler:
             return
         s, e = self._event(), self._event()
         self._lib.call_nostream("glx_profile_next_sconv", s, e)
-        self.records.append((name, s, e, rules, K, cin, cout))
+        self.records.append((name, s, e, rules, K, cin, cout, tag))
 
     def summary(self):
         per = {}
         ms = self._ct.c_float()
-        for name, s, e, rules, K, cin, cout in self.records:
+        live = {}
+        for name, s, e, rules, K, cin, cout, tag in self.records:
             self._lib.call_nostream("glx_event_elapsed_ms", s, e, self._ct.byref(ms))
-            d = per.setdefault(name, dict(ms=0.0, launches=0, bytes=0))
+            if id(rules) not in live:
+                n_in = rules.N_in if rules.count_in is None else min(rules.N_in, int(rules.count_in.item()))
+                n_out = rules.N_out if rules.count_out is None else min(rules.N_out, int(rules.count_out.item()))
+                live[id(rules)] = (n_in, n_out)
+            n_in, n_out = live[id(rules)]
+            if tag == "dgrad":
+                n_in, n_out = n_out, n_in
+            R = rules.pair_count
+            d = per.setdefault(name, dict(ms=0.0, launches=0, bytes=0, bytes_min=0, flops=0))
             d["ms"] += ms.value
             d["launches"] += 1
-            d["bytes"] += alg_bytes(rules.pair_count, K, cin, cout)
+            d["bytes"] += alg_bytes(R, K, cin, cout)
+            d["bytes_min"] += min_bytes(R, K, cin, cout, n_in, n_out)
+            d["flops"] += 2 * R * cin * cout
             self._pool += [s, e]
         self.records = []
         return per
@@ -105,238 +147,265 @@ def load_traffic():
     return {}
 
 
-def cpu_baseline(frames_np, model, batches=6):
-    """The CPU oracle (oracle/, a scalar C port) over the same workload: `batches` batches of
-    synthetic frames (the bench batch first, then further seeds), ~10-15 s of CPU work."""
-    import oracle
-    from oracle import backbone as ob
-    K = synth.KITTI
-    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-    nf = len(frames_np)
-    sets = [frames_np] + [[synth.kitti_frame(100 + j * nf + i)[0] for i in range(nf)] for j in range(1, batches)]
-    t0 = time.perf_counter()
-    for frames in sets:
-        v, c, n = oracle.voxelize_hard_batch(frames, K["voxel_size"], K["point_cloud_range"],
-                                             K["max_points"], K["max_voxels_train"])
-        f = oracle.mean_vfe(v, n)
-        taps = ob.backbone_forward(sd, f, c, model.sparse_shape)
-        o = taps["out"]
-        oracle.dense(o.features, o.indices, nf, o.shape)
-    dt = time.perf_counter() - t0
-    return dict(value=round(nf * len(sets) / dt, 3), unit="frames/s", cores=1, kind="port",
-                sample="%d batches of %d synthetic KITTI-shaped frames (the same workload), one pass "
-                       "each, %.1f s; host has %d cores" % (len(sets), nf, dt, os.cpu_count()))
+def roofline_of(per, prof_steps):
+    """The contract object for the dominant sparse-conv kernel + the table of all of them."""
+    if not per:
+        return None
+    dom = max(per, key=lambda k: per[k]["ms"])
+    d = per[dom]
+    traffic = load_traffic().get(dom)
+    sec = d["ms"] * 1e-3
+    alg_gbs = d["bytes"] / sec / 1e9
+    tflops = d["flops"] / sec / 1e12
+    hbm_frac_alg = alg_gbs / HBM_PEAK_GBS
+    mfma_frac = tflops / MFMA_F32_PEAK_TFLOPS
+    n = d["launches"]
+    bmin = d["bytes_min"] / n
+    # which roof binds: the kernel is output-stationary, so what reaches HBM is close to bytes_min (the PMC
+    # traffic says how close), not the contract's per-rule figure; compare the time each roof would need
+    t_hbm = (traffic if traffic else bmin) / (HBM_PEAK_GBS * 1e9)
+    t_mfma = d["flops"] / n / (MFMA_F32_PEAK_TFLOPS * 1e12)
+    bound = "mfma" if t_mfma >= t_hbm else "hbm"
+    roof = dict(bound=bound, kernel=dom,
+                achieved=round(tflops if bound == "mfma" else alg_gbs, 2),
+                peak=MFMA_F32_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS,
+                unit="TFLOP/s" if bound == "mfma" else "GB/s",
+                frac=round(mfma_frac if bound == "mfma" else hbm_frac_alg, 4),
+                traffic=traffic,
+                avg_launch_us=round(d["ms"] * 1e3 / n, 2), launches=n,
+                duration_source="HIP events around the kernel (hipExtLaunchKernelGGL) in an eager pass of the "
+                                "same launches, one frame in flight; the graph-replayed headline keeps two "
+                                "frames in flight, where rocprofv3 reads ~5 % longer per launch",
+                flops_per_launch=int(d["flops"] / n), mfma_frac=round(mfma_frac, 4),
+                hbm=dict(achieved_algorithmic_GBps=round(alg_gbs, 1), frac_algorithmic=round(hbm_frac_alg, 4),
+                         alg_bytes_per_launch=int(d["bytes"] / n), bytes_min_per_launch=int(bmin),
+                         traffic_over_bytes_min=round(traffic / bmin, 3) if traffic else None,
+                         traffic_GBps=round(traffic / (sec / n) / 1e9, 1) if traffic else None,
+                         traffic_frac_of_peak=round(traffic / (sec / n) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
+                floor_us=dict(mfma=round(t_mfma * 1e6, 2), hbm=round(t_hbm * 1e6, 2)))
+    tot_b = sum(v["bytes"] for v in per.values())
+    tot_ms = sum(v["ms"] for v in per.values())
+    roof["all_sparse_conv"] = dict(
+        achieved_algorithmic_GBps=round(tot_b / (tot_ms * 1e-3) / 1e9, 1),
+        frac_algorithmic=round(tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        ms_per_step=round(tot_ms / prof_steps, 4),
+        per_kernel={k: dict(GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                            TFLOPs=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                            us_per_launch=round(v["ms"] * 1e3 / v["launches"], 2),
+                            launches_per_step=v["launches"] // prof_steps)
+                    for k, v in sorted(per.items())})
+    return roof
 
 
+# --------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=("graph", "static", "dynamic"), default="graph")
-    ap.add_argument("--no-roofline", action="store_true", help="skip the event-bracketed second pass")
-    ap.add_argument("--no-train", action="store_true", help="skip the fwd+bwd side measurement")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="graph mode: number of frame pipelines replayed round-robin on their own "
-                         "HIP streams (consecutive batches overlap on the GPU)")
-    ap.add_argument("--serial-plan", action="store_true",
-                    help="build the rule tables on the main stream (no overlap with the convolutions)")
+    ap.add_argument("--mode", choices=("graph", "static"), default="graph",
+                    help="graph: the step replayed as HIP graph(s); static: the same launches enqueued from Python")
+    ap.add_argument("--no-config1", action="store_true", help="skip the configs[1] forward-only sub-measurement")
+    ap.add_argument("--no-stages", action="store_true", help="skip the per-stage timing pass")
+    ap.add_argument("--fwd-steps", type=int, default=200)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+
+    import numpy as np
+    import torch
+
+    from glenet_amd import backbone as gb
+    from glenet_amd import dist as gdist
+    from glenet_amd import glenet_vr as gvr
+    from glenet_amd import synth
+    from glenet_amd.spconv import core as spcore
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     rank, local_rank, world = gdist.env_world()
-    # one process per GPU; GLX_DIST_BACKEND=gloo + fewer GPUs than ranks is a plumbing test mode
-    # (ranks share a device, collectives on the host) -- never used for reported numbers
+    # one process per GPU; GLX_DIST_BACKEND=gloo with fewer GPUs than ranks is a plumbing test mode (ranks
+    # share a device, collectives on the host) -- never used for reported numbers
     backend = os.environ.get("GLX_DIST_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit("bench.py: %d ranks but %d GPUs visible (one process per GPU)" % (world, ndev))
+    dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     gdist.init(backend, device=dev)
+    ranks_seen = gdist.reduce_sum_int(1, dev)          # the collective saw this many ranks
 
     K = synth.KITTI
-    frame_ids = gdist.frames_for_rank(rank, world, FRAMES_PER_GPU)
-    frames_np = [synth.kitti_frame(i)[0] for i in frame_ids]
-    pts = torch.from_numpy(np.concatenate(frames_np)).to(dev)
-    bidx = torch.from_numpy(np.concatenate(
-        [np.full(len(f), i, np.int32) for i, f in enumerate(frames_np)])).to(dev)
+    torch.backends.cudnn.benchmark = True              # MIOpen find mode during warm-up, before capture
+
+    def make_batch(frame_ids, max_gt=16):
+        frames = [synth.kitti_frame(i) for i in frame_ids]
+        pts = torch.from_numpy(np.concatenate([f[0] for f in frames])).to(dev)
+        bidx = torch.from_numpy(np.concatenate([np.full(len(f[0]), i, np.int32)
+                                                for i, f in enumerate(frames)])).to(dev)
+        gt = torch.zeros(len(frames), max_gt, 8, device=dev)
+        unc = torch.zeros(len(frames), max_gt, 7, device=dev)
+        for i, (fid, f) in enumerate(zip(frame_ids, frames)):
+            k = len(f[1])
+            gt[i, :k, :7] = torch.from_numpy(f[1]).to(dev)
+            gt[i, :k, 7] = 1
+            unc[i, :k] = torch.from_numpy(synth.gt_uncertainty(fid, k)).to(dev)
+        return pts, bidx, gt, unc, [f[0] for f in frames]
+
+    # batch j of rank r: frames (j * world + r) * 4 .. + 3  (rank 0 of 1: frames 0..31 = seeds 1000..1031)
+    pool = [make_batch(gdist.frames_for_rank(j * world + rank, BATCH_POOL * world, FRAMES_PER_GPU))
+            for j in range(BATCH_POOL)]
+    npts = max(b[0].shape[0] for b in pool)
 
     torch.manual_seed(0)
-    grid = gb.gv.grid_size_of(K["point_cloud_range"], K["voxel_size"])
-    model = gb.VoxelBackBone8x(K["num_features"], grid).to(dev).eval()
-    vfe, hc = gb.MeanVFE(), gb.HeightCompression()
-    nstreams = max(1, args.streams) if args.mode == "graph" else 1
-    pipes = []
-    for _ in range(nstreams):
-        p_ = gb.StaticFramePipeline(model, K, FRAMES_PER_GPU, pts.shape[0], K["num_features"])
-        p_.calibrate(pts, bidx)   # output-set capacities of the strided convs, 1.3x this workload
-        p_.overlap_plan = not args.serial_plan
-        pipes.append(p_)
-    pipe = pipes[0]
-    streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
-    turn = [0]
-
-    def dynamic_step():
-        with torch.no_grad():
-            bd = gb.voxelize_batch(pts, bidx, FRAMES_PER_GPU, K, train=True)
-            bd = vfe(bd)
-            bd["rule_plan"] = model.plan(bd["voxel_coords"], FRAMES_PER_GPU, index=bd["voxel_index"])
-            return hc(model(bd))
-
-    def static_step():
-        pipe.load(pts, bidx)
-        return pipe.enqueue()
-
-    def graph_step():
-        """Batch i goes to pipeline i mod S on stream i mod S: consecutive batches overlap."""
-        i = turn[0] % nstreams
-        turn[0] += 1
-        with torch.cuda.stream(streams[i]):
-            pipes[i].load(pts, bidx)
-            return pipes[i].replay()
-
+    model = gvr.GLENetVR(K).to(dev).train()
+    n_params = sum(p.numel() for p in model.parameters())
+    total_steps = 3712 // (FRAMES_PER_GPU * world) * 80          # GLENet_VR.yaml:185-186 on KITTI train
+    pipe = gvr.StaticTrainStep(model, FRAMES_PER_GPU, npts, K["num_features"], max_gt=16,
+                               seed_rois_with_gt=ROI_SEED_OFFSET)
+    caps = {}
+    for b in pool:       # output-set capacities of the strided convs: 1.3x the largest of the pool
+        for k, v in pipe.calibrate(b[0], b[1]).items():
+            caps[k] = max(caps.get(k, 0), v)
+    pipe.capacities = caps
+    bucket = None
+    if world > 1:        # data-parallel: one flat all-reduce of all gradients between backward and update
+        bucket = gdist.GradBucket(pipe.params)
+        pipe.exchange = bucket.allreduce_
+    pipe.load(*pool[0][:4])
     if args.mode == "graph":
-        for p_ in pipes:
-            p_.load(pts, bidx)
-            p_.capture()
-    step = dict(graph=graph_step, static=static_step, dynamic=dynamic_step)[args.mode]
+        pipe.capture(split=world > 1)
+    else:
+        pipe.split = world > 1
+    it = [0]
 
-    def run(fn, steps):
-        out = None
-        for _ in range(steps):
-            out = fn()
-        return out
+    def train_step():
+        j = it[0]
+        it[0] += 1
+        lr, _mom = gvr.onecycle(j, total_steps)
+        pipe.set_lr(lr)
+        pipe.load(*pool[j % BATCH_POOL][:4])
+        pipe.step()
 
-    run(step, args.warmup)
+    for _ in range(args.warmup):
+        train_step()
     torch.cuda.synchronize(dev)
+    pipe.check()
 
     # ---- headline: exactly K steps between two fences, nothing else in the region
     gdist.fence(dev)
     t0 = time.perf_counter()
-    bd = run(step, args.steps)
+    for _ in range(args.steps):
+        train_step()
     gdist.fence(dev)
     dt = gdist.reduce_max(time.perf_counter() - t0, dev)
-    if args.mode != "dynamic":
-        for p_ in pipes:   # capacities held, voxelizer index valid (one read-back, after the clock)
-            p_.check()
+    pipe.check()          # capacities held over every batch of the pool (one read-back, after the clock)
+    loss_end = float(pipe.loss.detach())
+    parts_end = {k: round(float(v), 5) for k, v in pipe.parts.items()}
 
-    # ---- roofline: K more steps of the same launches, each sparse-conv kernel bracketed by HIP
-    # events on its stream (hipExtLaunchKernelGGL start/stop = kernel-only time).  Kept out of the
-    # headline loop: event-bracketed launches cannot live in a graph and serialise the queue.
-    per = {}
-    if not args.no_roofline:
+    # ---- per-stage milliseconds: one event-bracketed eager pass of the same launches per pool batch
+    stages = None
+    if not args.no_stages:
+        marks = []
+
+        def mark(name):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((name, ev))
+        acc = {}
+        for j in range(min(4, BATCH_POOL)):
+            marks.clear()
+            pipe.load(*pool[j][:4])
+            pipe.mark = model.mark = mark
+            mark("start")
+            pipe.enqueue_eager_marked()
+            torch.cuda.synchronize(dev)
+            for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+                acc.setdefault(n1, []).append(e0.elapsed_time(e1))
+        pipe.mark = model.mark = None
+        stages = {k: round(float(np.mean(v)), 3) for k, v in acc.items()}
+        stages["note"] = ("ms between stage marks in an eager (not graph-replayed) pass, rule tables and weight "
+                          "gradients on their side stream; the sum exceeds ms_per_step by the launch gaps a graph removes")
+
+    # ---- configs[1]: sparse backbone forward only (eval mode, BN folded), two frame pipelines in flight
+    config1 = roof = None
+    if not args.no_config1:
+        bb = gb.VoxelBackBone8x(K["num_features"], gb.gv.grid_size_of(K["point_cloud_range"], K["voxel_size"])).to(dev)
+        bb.load_state_dict(model.backbone_3d.state_dict())
+        bb.eval()
+        pts0, bidx0 = pool[0][0], pool[0][1]
+        fpipes = []
+        for _ in range(2):
+            p_ = gb.StaticFramePipeline(bb, K, FRAMES_PER_GPU, npts, K["num_features"])
+            p_.capacities = dict(caps)
+            p_.load(pts0, bidx0)
+            p_.capture()
+            fpipes.append(p_)
+        streams = [torch.cuda.Stream(dev) for _ in fpipes]
+        turn = [0]
+
+        def fwd_step():
+            i = turn[0] % len(fpipes)
+            b = pool[(turn[0] // 1) % BATCH_POOL]
+            turn[0] += 1
+            with torch.cuda.stream(streams[i]):
+                fpipes[i].load(b[0], b[1])
+                return fpipes[i].replay()
+        for _ in range(20):
+            fwd_step()
+        gdist.fence(dev)
+        t1 = time.perf_counter()
+        for _ in range(args.fwd_steps):
+            fwd_step()
+        gdist.fence(dev)
+        dtf = gdist.reduce_max(time.perf_counter() - t1, dev)
+        for p_ in fpipes:
+            p_.check()
+        config1 = dict(workload="configs[1]: VoxelBackBone8x (8 SubMConv3d + 4 SparseConv3d, spconv_backbone.py:77-117) "
+                                "forward only, eval-mode BatchNorm folded, batch 4, %d batches cycled" % BATCH_POOL,
+                       frames_per_s=round(FRAMES_PER_GPU * world * args.fwd_steps / dtf, 1),
+                       ms_per_step=round(dtf / args.fwd_steps * 1e3, 4), steps=args.fwd_steps)
+        # roofline pass: the same launches, eager, each sparse-conv kernel bracketed by HIP events
         prof = ConvProfiler()
         spcore._profile_hook = prof
         prof.enabled = True
-        run(dynamic_step if args.mode == "dynamic" else static_step, min(args.steps, 50))
+        prof_steps = 24
+        for s in range(prof_steps):
+            fpipes[0].load(pool[s % BATCH_POOL][0], pool[s % BATCH_POOL][1])
+            fpipes[0].enqueue()
         torch.cuda.synchronize(dev)
         prof.enabled = False
         spcore._profile_hook = None
-        per = prof.summary()
-    prof_steps = min(args.steps, 50)
-
-    # ---- side measurement (not `value`): forward + backward of the same backbone in training
-    # mode (BatchNorm batch statistics, autograd through the sparse convs: dgrad = the forward
-    # kernels on transposed weights, wgrad = k_wgrad_mfma), loss = mean(out^2), gradients of every
-    # parameter; shape-static step replayed as one HIP graph (StaticTrainPipeline) unless
-    # --mode dynamic asks for the exact-shape path with its host read-backs
-    fwd_bwd = None
-    if not args.no_train:
-        tmodel = gb.VoxelBackBone8x(K["num_features"], grid).to(dev).train()
-        tmodel.load_state_dict(model.state_dict())
-        if args.mode == "dynamic":
-            def train_step():
-                bd_ = gb.voxelize_batch(pts, bidx, FRAMES_PER_GPU, K, train=True)
-                bd_ = hc(tmodel(vfe(bd_)))
-                tmodel.zero_grad(set_to_none=True)
-                bd_["spatial_features"].square().mean().backward()
-            tnote = "exact-shape path (host read-backs)"
-        else:
-            tpipe = gb.StaticTrainPipeline(tmodel, K, FRAMES_PER_GPU, pts.shape[0], K["num_features"])
-            tpipe.calibrate(pts, bidx)
-            tpipe.load(pts, bidx)
-            if args.mode == "graph":
-                tpipe.capture()
-                train_step = tpipe.replay
-                tnote = "shape-static step replayed as one HIP graph"
-            else:
-                train_step = tpipe.enqueue
-                tnote = "shape-static step, eager launches"
-
-        if world > 1:       # data-parallel training: one flat RCCL all-reduce of the gradients per step
-            bucket = gdist.GradBucket(tmodel.parameters())
-            local_step = train_step
-
-            def train_step():
-                local_step()
-                bucket.allreduce_()
-            tnote += ", + one flat all-reduce of all gradients (RCCL)"
-
-        run(train_step, 6)
-        gdist.fence(dev)
-        t1 = time.perf_counter()
-        run(train_step, 20)
-        gdist.fence(dev)
-        dtt = gdist.reduce_max(time.perf_counter() - t1, dev)
-        if args.mode != "dynamic":
-            tpipe.check()
-        fwd_bwd = dict(frames_per_s=round(FRAMES_PER_GPU * world * 20 / dtt, 1),
-                       ms_per_step=round(dtt / 20 * 1e3, 3), steps=20,
-                       note="training-mode backbone fwd+bwd, " + tnote + ", not the headline workload")
-
-    frames_total = FRAMES_PER_GPU * world * args.steps
-    dom = max(per, key=lambda k: per[k]["ms"]) if per else None
-    traffic = load_traffic()
-    roof = None
-    if dom:
-        d = per[dom]
-        achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-        roof = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
-                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                    traffic=traffic.get(dom),
-                    alg_bytes_per_launch=int(d["bytes"] / d["launches"]),
-                    avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2),
-                    launches=d["launches"])
-        tot_b = sum(v["bytes"] for v in per.values())
-        tot_ms = sum(v["ms"] for v in per.values())
-        roof["all_sparse_conv"] = dict(
-            achieved=round(tot_b / (tot_ms * 1e-3) / 1e9, 1),
-            frac=round(tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            ms_per_step=round(tot_ms / prof_steps, 4),
-            per_kernel={k: dict(GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
-                                us_per_launch=round(v["ms"] * 1e3 / v["launches"], 2),
-                                launches_per_step=v["launches"] // prof_steps)
-                        for k, v in sorted(per.items())})
+        roof = roofline_of(prof.summary(), prof_steps)
 
     if rank == 0:
-        st = bd["encoded_spconv_tensor"]
-        n_in = bd["voxel_index"].count.item() if args.mode != "dynamic" else bd["voxel_coords"].shape[0]
-        n_out = st.count.item() if st.count is not None else st.indices.shape[0]
-        out = dict(metric="LiDAR frames/sec (sparse backbone fwd) on KITTI-shaped clouds",
-                   value=round(frames_total / dt, 2), unit="frames/s", n_gpus=world,
-                   steps=args.steps, warmup=args.warmup,
-                   ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True,
-                   scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload="configs[1]: VoxelBackBone8x (8 SubMConv3d + 4 SparseConv3d "
-                                        "as in spconv_backbone.py:77-117) fwd-only, batch 4 "
-                                        "KITTI-shaped frames/GPU, 20000 pts/frame, voxel "
-                                        "0.05x0.05x0.1 m; step = voxelize + MeanVFE + rule tables + "
-                                        "12 sparse convs + dense()",
-                               frames_per_gpu=FRAMES_PER_GPU, points_per_frame=20000,
-                               voxels_in=int(n_in), voxels_out=int(n_out),
-                               mode={"graph": "shape-static frame replayed as one HIP graph, %d frame "
-                                              "pipeline(s) on their own streams" % nstreams,
-                                     "static": "shape-static frame, launches enqueued from Python",
-                                     "dynamic": "exact shapes, host read-backs"}[args.mode],
-                               parallelism="dp%d (frames shard, no data-path collective)" % world),
-                   roofline=roof, fwd_bwd=fwd_bwd,
-                   baseline_metric="BASELINE.json: 'LiDAR frames/sec (fwd+bwd) on KITTI-shaped clouds at "
-                                   "1/2/4/8 MI355X; sparse-conv HBM GB/s' -- `value` is that metric on "
-                                   "configs[1] (which is forward-only by its own wording), the fwd+bwd rate "
-                                   "of the same backbone is in `fwd_bwd`, the sparse-conv GB/s in `roofline`")
+        st = pipe.out["encoded_spconv_tensor"]
+        out = dict(metric=METRIC, value=round(FRAMES_PER_GPU * world * args.steps / dt, 2), unit="frames/s",
+                   n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True, scaling="weak",
+                   vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload="configs[2] per-GPU share: GLENet-VR Voxel-RCNN full train step (voxelize + sparse "
+                                        "backbone + BEV head + NMS 9000->512 + RoI targets 128/frame + RoI-grid pool + "
+                                        "FC + rpn/cls/KL/corner losses, fwd + bwd + grad clip + AdamW), batch "
+                                        "%d = %d frames/GPU x %d GPU(s), 20000 pts/frame, %d distinct batches cycled"
+                                        % (FRAMES_PER_GPU * world, FRAMES_PER_GPU, world, BATCH_POOL),
+                               frames_per_gpu=FRAMES_PER_GPU, points_per_frame=20000, parameters=n_params,
+                               voxels_in=int(pipe.out["voxel_index"].count.item()), voxels_out=int(st.count.item()),
+                               proposal_seeding="first 15 proposal slots per frame = ground truth + fixed offset "
+                                                "(stands in for a trained first stage; random-init weights)",
+                               mode={"graph": "shape-static step replayed as %d HIP graph(s)" % (2 if world > 1 else 1),
+                                     "static": "shape-static step, launches enqueued from Python"}[args.mode],
+                               parallelism="dp%d: frames shard; one flat RCCL all-reduce of %.1f MB gradients per step"
+                                           % (world, n_params * 4 / 1e6) if world > 1 else "dp1 (single GPU, no collective)",
+                               ranks_seen_by_collective=ranks_seen),
+                   loss=dict(last=round(loss_end, 5), parts=parts_end),
+                   stages_ms=stages, config1=config1, roofline=roof)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames_np, model)
+            from oracle import baseline as cpu_base           # bench's cpu_baseline leg: the checker, timed
+            out["cpu_baseline"] = cpu_base.config3_composite([b[4] for b in pool[:1]], model, K)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -322,6 +322,7 @@ class StaticTrainPipeline(StaticFramePipeline):
         self.optimizer = optimizer
         self.loss = None
         self.overlap_wgrad = True
+        self.mark = None            # optional callable(stage_name): bench.py records an event per stage
 
     def enqueue(self):
         from ._lib import workspace
@@ -346,6 +347,8 @@ class StaticTrainPipeline(StaticFramePipeline):
                     plan = self.model.plan(bd["voxel_coords"], self.B, index=bd["voxel_index"],
                                            capacities=self.capacities)
                 bd = self.vfe(bd)
+            if self.mark:
+                self.mark("voxelize + MeanVFE")
             bd["rule_plan"] = plan
             self.model.zero_grad(set_to_none=True)      # .grad tensors are (re)created by backward
             for m in self.extra_modules:
@@ -354,6 +357,8 @@ class StaticTrainPipeline(StaticFramePipeline):
             try:
                 with torch.enable_grad():
                     bd = self.hc(self.model(bd))
+                    if self.mark:
+                        self.mark("sparse backbone fwd + dense()")
                     loss = self.loss_fn(bd)
             finally:
                 spconv.core.DEFERRED_COUNTERS = None
@@ -369,6 +374,8 @@ class StaticTrainPipeline(StaticFramePipeline):
                 spconv.core.WGRAD_STREAM = None
             if self.overlap_wgrad:
                 cur.wait_stream(self.plan_stream)
+            if self.mark:
+                self.mark("backward")
             if self.optimizer is not None:
                 self.optimizer.step()
         self.out, self.loss = bd, loss

@@ -126,6 +126,7 @@ class GLENetVR(nn.Module):
         self._anchors = None
         self.fixed_draws = None      # tests: (key (B,R), pick (B,P)) uniform numbers for the RoI sampler
         self.last = None
+        self.mark = None             # optional callable(stage_name), see StaticTrainPipeline.mark
 
     def anchors(self, device):
         if self._anchors is None or self._anchors.device != device:
@@ -149,7 +150,9 @@ class GLENetVR(nn.Module):
         Returns (loss, parts) with device scalars; free of host synchronisation on shape-static inputs."""
         B = gt_boxes.shape[0]
         h, r = self.head_cfg, self.roi_cfg
+        mark = self.mark or (lambda name: None)
         bd = self.dense_head(self.backbone_2d(bd))
+        mark("BEV backbone + anchor head fwd")
         anchors = self.anchors(gt_boxes.device)
         with torch.no_grad():
             tgt = target_assign.assign_targets([anchors], gt_boxes, [1], [h["matched_threshold"]],
@@ -173,14 +176,17 @@ class GLENetVR(nn.Module):
                                          tgt["box_cls_labels"], tgt["box_reg_targets"], anchors,
                                          code_weights=h["code_weights"], cls_weight=h["cls_weight"],
                                          loc_weight=h["loc_weight"], dir_weight=h["dir_weight"])
+        mark("anchor targets + proposals (NMS) + RoI targets + dense-head loss")
         rcnn_cls, rcnn_reg, rcnn_std = self.roi_head(rois_s, bd["multi_scale_3d_features"],
                                                      bd["multi_scale_3d_strides"], B)
+        mark("RoI-grid pooling + FC towers fwd")
         w = r["LOSS_WEIGHTS"]
         l_cls = losses.rcnn_cls_loss(rcnn_cls, cls_lab, weight=w["rcnn_cls_weight"])
         l_kl, kl_parts = losses.kl_reg_loss(rcnn_reg, rcnn_std, rois_s, gt_ct[..., :7], unc, reg_valid,
                                             code_weights=w["code_weights"], weight=w["rcnn_reg_weight"])
         l_cor = losses.corner_loss(rcnn_reg, rois_s, gt_src[..., :7], reg_valid, weight=w["rcnn_corner_weight"])
         loss = rpn + l_cls + l_kl + l_cor                                                # voxel_rcnn.py get_training_loss
+        mark("RoI-head losses")
         parts = dict(loss_rpn=rpn.detach(), rcnn_loss_cls=l_cls.detach(), rcnn_loss_reg=l_kl.detach(),
                      rcnn_loss_corner=l_cor.detach(), fg_rois=kl_parts["fg"], **rpn_parts)
         # detached views for inspection / tests (a live autograd graph of an earlier step must not survive into
@@ -297,6 +303,8 @@ class StaticTrainStep(gb.StaticTrainPipeline):
         if self.grad_clip:
             self.grad_norm = torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip, foreach=True)
         self.step_optimizer.step()
+        if self.mark:
+            self.mark("grad clip + AdamW")
 
     def enqueue(self):
         bd = super().enqueue()
@@ -325,6 +333,14 @@ class StaticTrainStep(gb.StaticTrainPipeline):
             with torch.cuda.graph(self.update_graph, stream=side):
                 self.update()
         return self
+
+    def enqueue_eager_marked(self):
+        """One eager pass of the step's launches with `mark` called at the stage boundaries (bench.py)."""
+        self.enqueue()
+        if self.split:
+            if self.exchange is not None:
+                self.exchange()
+            self.update()
 
     def last_rois_shape(self):
         return tuple(self.net.last["rois"].shape)

@@ -1,0 +1,154 @@
+"""CPU baseline of bench.py (TEST INFRASTRUCTURE: imported only by bench.py's `cpu_baseline` leg and tests/).
+
+BASELINE.md section 3, config 3: the reference's CPU path for a whole training step does not exist (spconv and
+the pcdet/ops extensions are GPU code), so the CPU figure is a COMPOSITE of the components the oracle restates,
+timed on this host's cores, plus the dense layers on torch-CPU -- a lower bound on a CPU step (no BatchNorm /
+loss / optimizer time, RoI-grid MLPs not included):
+
+  voxelize + MeanVFE | 12 sparse convs fwd | their input + weight gradients | dense() | BEV backbone + anchor
+  head fwd+bwd (torch) | rotated NMS of 9000 proposals | voxel query + grouping of 4 x 128 x 216 grid points on
+  3 scales | RoI FC towers fwd+bwd (torch)
+
+Two legs: all host cores (OpenMP in oracle/glenet_oracle.c via orc_set_threads, torch.set_num_threads) and one
+core (sparse-backbone forward only, the figure round 1 reported)."""
+import os
+import time
+
+import numpy as np
+
+import oracle
+from oracle import backbone as ob
+
+
+def _t(fn, *a, **k):
+    t0 = time.perf_counter()
+    r = fn(*a, **k)
+    return r, time.perf_counter() - t0
+
+
+def _backbone_fwd_bwd(sd, frames, K, sparse_shape, backward=True):
+    """-> (seconds dict, taps) for one batch of frames on the oracle."""
+    sec = {}
+    (v, c, n), sec["voxelize"] = _t(oracle.voxelize_hard_batch, frames, K["voxel_size"], K["point_cloud_range"],
+                                   K["max_points"], K["max_voxels_train"])
+    f, dt = _t(oracle.mean_vfe, v, n)
+    sec["voxelize"] += dt
+    stats = []
+    t0 = time.perf_counter()
+    taps = ob.backbone_forward(sd, f, c, sparse_shape, stats=stats)
+    sec["sparse_fwd"] = time.perf_counter() - t0
+    sec["rules"] = sum(s["t_rules"] for s in stats)
+    if backward:
+        # input + weight gradient of every conv: same rule tables, unit upstream gradient
+        rules, st = {}, ob.State(f, c, [int(s) for s in sparse_shape])
+        t_b = 0.0
+        for name, kind, ks, stride, pad, key in ob.PLAIN:
+            w = np.asarray(sd[name + ".weight"], np.float32)
+            w = w.reshape(-1, w.shape[-2], w.shape[-1])
+            if key not in rules:
+                rules[key] = oracle.build_rules(st.indices, st.shape, ks, stride, pad, subm=(kind == "subm"))
+            r = rules[key]
+            g = np.ones((len(r.out_indices), w.shape[2]), np.float32)
+            _, dt = _t(oracle.sconv_backward, st.features if st.features.shape[1] == w.shape[1]
+                       else np.ones((len(st.indices), w.shape[1]), np.float32), w, g, r)
+            t_b += dt
+            st = ob.State(np.ones((len(r.out_indices), w.shape[2]), np.float32), r.out_indices, r.out_shape)
+        sec["sparse_bwd"] = t_b
+    o = taps["out"]
+    _, sec["dense"] = _t(oracle.dense, o.features, o.indices, len(frames), o.shape)
+    return sec, taps
+
+
+def config3_composite(frame_batches, model, K, threads=None, rois_per_frame=128, grid=6):
+    """frame_batches: list of batches, each a list of (P,4) float32 frames (the bench's own frames).
+    model: the GLENetVR the bench runs (its state dict and dense modules are copied to the CPU).
+    -> the `cpu_baseline` object of the bench line."""
+    import copy
+
+    import torch
+    cores = os.cpu_count() or 1
+    threads = int(threads or cores)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.backbone_3d.state_dict().items()}
+    sparse_shape = model.backbone_3d.sparse_shape
+    frames = frame_batches[0]
+    nf = len(frames)
+    t_all = time.perf_counter()
+
+    # ---- one core: sparse backbone forward (voxelize + 12 convs + dense), one batch
+    oracle.lib().orc_set_threads(1)
+    s1, _ = _backbone_fwd_bwd(sd, frames, K, sparse_shape, backward=False)
+    one_core = nf / (s1["voxelize"] + s1["sparse_fwd"] + s1["dense"])
+
+    # ---- all cores
+    oracle.lib().orc_set_threads(threads)
+    torch_threads = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        sec, taps = _backbone_fwd_bwd(sd, frames, K, sparse_shape, backward=True)
+        mt_fwd = nf / (sec["voxelize"] + sec["sparse_fwd"] + sec["dense"])
+        # dense BEV backbone + anchor head, fwd + bwd, ONE frame (x nf)
+        bev = copy.deepcopy(model.backbone_2d).cpu().float().train()
+        head = copy.deepcopy(model.dense_head).cpu().float().train()
+        o = taps["out"]
+        x = torch.from_numpy(oracle.dense(o.features, o.indices, nf, o.shape)[:1]).reshape(1, -1, o.shape[1], o.shape[2])
+        x.requires_grad_(True)
+
+        def bev_step():
+            d = head(bev({"spatial_features": x}))
+            (d["cls_preds"].square().mean() + d["box_preds"].square().mean()).backward()
+        bev_step()
+        _, dt = _t(bev_step)
+        sec["bev_head_fwd_bwd"] = dt * nf
+        # rotated NMS 9000 -> (no cap in the reference's host sweep), ONE frame (x nf)
+        rng = np.random.default_rng(3000)
+        from glenet_amd import synth
+        boxes = synth.random_boxes(rng, 9000, xy_range=70.0, near_dup=0.5)
+        _, dt = _t(oracle.nms_sorted, boxes, 0.8)
+        sec["nms_9000"] = dt * nf
+        # RoI-grid pooling queries: voxel_query + grouping (features and xyz) on the three scales
+        m = nf * rois_per_frame * grid ** 3
+        t_q = 0.0
+        for name, stride, radius in (("x_conv2", 2, 0.4), ("x_conv3", 4, 0.8), ("x_conv4", 8, 1.6)):
+            st = taps[name]
+            vs = np.asarray(K["voxel_size"], np.float32) * stride
+            xyz = ((st.indices[:, [3, 2, 1]].astype(np.float32) + 0.5) * vs
+                   + np.asarray(K["point_cloud_range"][:3], np.float32)).astype(np.float32)
+            pick = rng.integers(0, len(xyz), m)
+            new_xyz = (xyz[pick] + rng.normal(0, 0.3, (m, 3))).astype(np.float32)
+            coords = np.concatenate([st.indices[pick, :1], np.floor(
+                (new_xyz[:, [2, 1, 0]] - np.asarray(K["point_cloud_range"][:3], np.float32)[[2, 1, 0]])
+                / vs[[2, 1, 0]]).astype(np.int32)], 1).astype(np.int32)
+            t0 = time.perf_counter()
+            vmap = oracle.generate_voxel2pinds(st.indices, nf, st.shape)
+            idx, empty = oracle.voxel_query((4, 4, 4), radius, 16, xyz, new_xyz, coords, vmap)
+            cnt = np.bincount(st.indices[:, 0], minlength=nf).astype(np.int32)
+            starts = np.cumsum(cnt) - cnt
+            local = (idx.reshape(nf, -1, 16) - starts.reshape(nf, 1, 1)).reshape(-1, 16).astype(np.int32)
+            local[empty] = 0
+            qcnt = np.full(nf, m // nf, np.int32)
+            oracle.group_points(st.features[:, :32].copy(), cnt, local, qcnt)
+            oracle.group_points(xyz, cnt, local, qcnt)
+            t_q += time.perf_counter() - t0
+        sec["voxel_query_group"] = t_q
+        # RoI FC towers fwd + bwd (512 RoIs)
+        fc = torch.nn.Sequential(copy.deepcopy(model.roi_head.shared_fc_layer), copy.deepcopy(model.roi_head.reg_fc_layers)
+                                 ).cpu().float().train()
+        xin = torch.randn(nf * rois_per_frame, fc[0][0].in_features)
+
+        def fc_step():
+            fc(xin).square().mean().backward()
+        fc_step()
+        _, sec["roi_fc_fwd_bwd"] = _t(fc_step)
+    finally:
+        oracle.lib().orc_set_threads(1)
+        torch.set_num_threads(torch_threads)
+    step = sum(v for k, v in sec.items() if k != "rules")
+    return dict(value=round(nf / step, 3), unit="frames/s", cores=threads, kind="port",
+                sample="composite of the config-3 step's components on ONE batch of %d frames of the bench pool "
+                       "(NMS and the BEV head timed on 1 frame and scaled), %d threads (OpenMP oracle + torch-CPU): "
+                       "lower bound on a CPU step (no BatchNorm / loss / optimizer / RoI-grid MLP time); %.1f s of CPU "
+                       "work in all; host has %d cores" % (nf, threads, time.perf_counter() - t_all, cores),
+                seconds_per_step={k: round(v, 4) for k, v in sec.items()},
+                sparse_backbone_fwd=dict(one_core_frames_per_s=round(one_core, 3),
+                                         all_cores_frames_per_s=round(mt_fwd, 3), cores=threads,
+                                         note="voxelize + MeanVFE + 12 sparse convs + dense(), the configs[1] workload"))

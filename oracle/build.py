@@ -16,7 +16,7 @@ REF_DIR = os.path.join(HERE, "_ref")
 def build(force=False):
     os.makedirs(OUT_DIR, exist_ok=True)
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
-        cmd = ["gcc", "-O2", "-ffp-contract=off", "-fvisibility=hidden", "-shared", "-fPIC",
+        cmd = ["gcc", "-O2", "-ffp-contract=off", "-fvisibility=hidden", "-shared", "-fPIC", "-fopenmp",
                "-std=c11", "-Wall", "-o", LIB, SRC, "-lm"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

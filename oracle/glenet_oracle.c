@@ -28,6 +28,15 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
+/* Threads for the CPU-baseline timing legs of bench.py (OpenMP; default 1 = the plain serial loops every
+ * test checks against).  With n > 1 the loops below whose iterations are independent run in parallel --
+ * same arithmetic per element, same results; the one exception is the weight gradient of
+ * orc_sconv_backward, which then sums per-thread partial slabs (order of the fp32 additions differs). */
+static int orc_nthreads = 1;
+ORC_API void orc_set_threads(int n) { orc_nthreads = n > 1 ? n : 1; }
+ORC_API int orc_get_threads(void) { return orc_nthreads; }
+#define ORC_PAR_FOR _Pragma("omp parallel for schedule(static) if(orc_nthreads > 1) num_threads(orc_nthreads)")
+
 /* ======================================================================== voxelization */
 
 /* Hard voxelization.  Restates spconv's CPU generator (points_to_voxel_3d_np /
@@ -234,7 +243,9 @@ ORC_API void orc_sconv_forward(const float* in, const float* W, const float* bia
     for (int c = 0; c < Cout; ++c) out[(size_t)j * Cout + c] = bias ? bias[c] : 0.f;
   for (int k = 0; k < K; ++k) {
     const float* Wk = W + (size_t)k * Cin * Cout;
-    for (int p = 0; p < n_pairs[k]; ++p) {
+    const int np_k = n_pairs[k];
+    ORC_PAR_FOR   /* the outputs of one offset are distinct rows */
+    for (int p = 0; p < np_k; ++p) {
       const float* x = in + (size_t)pairs_in[(size_t)k * ld + p] * Cin;
       float* y = out + (size_t)pairs_out[(size_t)k * ld + p] * Cout;
       for (int ci = 0; ci < Cin; ++ci) {
@@ -253,6 +264,38 @@ ORC_API void orc_sconv_backward(const float* in, const float* W, const float* do
                                 int Cout, float* din, float* dW) {
   memset(din, 0, (size_t)N_in * Cin * sizeof(float));
   memset(dW, 0, (size_t)K * Cin * Cout * sizeof(float));
+  if (orc_nthreads > 1) { /* baseline timing only: inputs of one offset are distinct rows; dW in per-thread slabs */
+    for (int k = 0; k < K; ++k) {
+      const float* Wk = W + (size_t)k * Cin * Cout;
+      float* dWk = dW + (size_t)k * Cin * Cout;
+      const int np_k = n_pairs[k];
+      _Pragma("omp parallel num_threads(orc_nthreads)")
+      {
+        float* part = (float*)calloc((size_t)Cin * Cout, sizeof(float));
+        _Pragma("omp for schedule(static)")
+        for (int p = 0; p < np_k; ++p) {
+          int i = pairs_in[(size_t)k * ld + p], j = pairs_out[(size_t)k * ld + p];
+          const float* x = in + (size_t)i * Cin;
+          const float* g = dout + (size_t)j * Cout;
+          float* dx = din + (size_t)i * Cin;
+          for (int ci = 0; ci < Cin; ++ci) {
+            const float* w = Wk + (size_t)ci * Cout;
+            float* dw = part + (size_t)ci * Cout;
+            float acc = 0.f, xv = x[ci];
+            for (int co = 0; co < Cout; ++co) {
+              acc += g[co] * w[co];
+              dw[co] += xv * g[co];
+            }
+            dx[ci] += acc;
+          }
+        }
+        _Pragma("omp critical")
+        for (int e = 0; e < Cin * Cout; ++e) dWk[e] += part[e];
+        free(part);
+      }
+    }
+    return;
+  }
   for (int k = 0; k < K; ++k) {
     const float* Wk = W + (size_t)k * Cin * Cout;
     float* dWk = dW + (size_t)k * Cin * Cout;
@@ -464,10 +507,14 @@ ORC_API int orc_nms(const float* boxes, int N, float thresh, int normal, int64_t
     keep[num++] = i;
     /* row i of the mask, computed lazily: bit j set iff j > i and iou(i,j) > thresh */
     memset(row, 0, col_blocks * sizeof(uint64_t));
-    for (int j = i + 1; j < N; ++j) {
-      float v = normal ? iou_normal(boxes + i * 7, boxes + j * 7)
-                       : iou_bev_nms(boxes + i * 7, boxes + j * 7);
-      if (v > thresh) row[j / 64] |= 1ULL << (j % 64);
+    ORC_PAR_FOR   /* one 64-column word per iteration: words are written by one thread each */
+    for (int jw = nblock; jw < col_blocks; ++jw) {
+      int j0 = jw * 64 > i + 1 ? jw * 64 : i + 1, j1 = (jw + 1) * 64 < N ? (jw + 1) * 64 : N;
+      for (int j = j0; j < j1; ++j) {
+        float v = normal ? iou_normal(boxes + i * 7, boxes + j * 7)
+                         : iou_bev_nms(boxes + i * 7, boxes + j * 7);
+        if (v > thresh) row[jw] |= 1ULL << (j % 64);
+      }
     }
     for (int j = nblock; j < col_blocks; ++j) remv[j] |= row[j];
   }
@@ -721,6 +768,7 @@ ORC_API void orc_voxel_query(int M, int R1, int R2, int R3, int nsample, float r
                              const float* xyz, const int32_t* new_coords,
                              const int32_t* point_indices, int32_t* idx) {
   float radius2 = radius * radius;
+  ORC_PAR_FOR
   for (int pt = 0; pt < M; ++pt) {
     const float* q = new_xyz + (size_t)pt * 3;
     const int32_t* nc = new_coords + (size_t)pt * 4;
@@ -792,6 +840,7 @@ ORC_API void orc_ball_query(int B, int M, float radius, int nsample, const float
 ORC_API void orc_group_points(int B, int M, int C, int nsample, const float* features,
                               const int32_t* features_batch_cnt, const int32_t* idx,
                               const int32_t* idx_batch_cnt, float* out) {
+  ORC_PAR_FOR
   for (int pt = 0; pt < M; ++pt) {
     int bs = 0, pc = idx_batch_cnt[0];
     for (int k = 1; k < B; k++) {

@@ -110,3 +110,81 @@ def test_two_rank_gradient_bucket_allreduce():
     for x, y, u, v in zip(l0, l1, a0, a1):
         np.testing.assert_allclose(u, (x + y) / 2, rtol=1e-6, atol=1e-7)
         assert np.array_equal(u, v)
+
+
+def test_bench_launcher_starts_one_rank_per_gpu(tmp_path):
+    """`bench.py --gpus N` outside torchrun: N child processes with the torchrun environment variables
+    (the driver's calling convention for N = 1 passes --gpus too; N > 1 must not silently run one rank)."""
+    import argparse
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    script = tmp_path / "rank.py"
+    script.write_text("import os, json, sys\n"
+                      "d = {k: os.environ[k] for k in ('RANK','LOCAL_RANK','WORLD_SIZE','MASTER_ADDR','MASTER_PORT')}\n"
+                      "d['argv'] = sys.argv[1:]\n"
+                      "open(os.path.join(%r, 'rank%%s.json' %% d['RANK']), 'w').write(json.dumps(d))\n"
+                      "sys.exit(3 if d['RANK'] == '1' and '--fail' in sys.argv else 0)\n" % str(tmp_path))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    rc = bench.spawn_ranks(argparse.Namespace(gpus=3), ["--gpus", "3", "--steps", "5"], script=str(script))
+    assert rc == 0
+    got = [json.loads((tmp_path / ("rank%d.json" % r)).read_text()) for r in range(3)]
+    assert [g["RANK"] for g in got] == ["0", "1", "2"] and all(g["WORLD_SIZE"] == "3" for g in got)
+    assert len({g["MASTER_PORT"] for g in got}) == 1 and all(g["MASTER_ADDR"] == "127.0.0.1" for g in got)
+    assert got[0]["argv"] == ["--gpus", "3", "--steps", "5"]
+    assert bench.spawn_ranks(argparse.Namespace(gpus=2), ["--fail"], script=str(script)) == 3
+
+
+def _model_grad_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from glenet_amd import dist as gdist, glenet_vr as gvr, synth
+    gdist.init(backend="gloo")
+    torch.manual_seed(0)
+    model = gvr.GLENetVR(synth.KITTI)                   # parameters only: no kernel runs on the CPU
+    params = [p for p in model.parameters() if p.requires_grad]
+    g = torch.Generator().manual_seed(100 + rank)
+    for i, p in enumerate(params):
+        if i % 7 != 3:                                   # some gradients missing, as after a partial backward
+            p.grad = torch.randn(p.shape, generator=g)
+    local = [None if p.grad is None else p.grad.clone() for p in params]
+    bucket = gdist.GradBucket(params)
+    addr = [None if p.grad is None else p.grad.data_ptr() for p in params]
+    bucket.allreduce_()
+    same_addr = all(a is None or a == p.grad.data_ptr() for a, p in zip(addr, params))
+    sums = [float(p.grad.double().sum()) for p in params]
+    probe = params[10].grad.flatten()[:5].tolist()
+    q.put((rank, len(params), bucket.flat.numel(), same_addr, sums, probe,
+           [None if x is None else float(x.double().sum()) for x in local]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_bucket_over_the_glenet_vr_parameter_list():
+    """The flat all-reduce of the data-parallel step on the real model's parameters (143 parameter tensors, 7.6 M
+    values): every rank ends with the mean, written INTO the existing .grad tensors (a replayed update graph
+    reads those addresses)."""
+    import numpy as np
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_model_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    (_, n0, flat0, same0, s0, pr0, l0), (_, n1, flat1, same1, s1, pr1, l1) = res
+    assert n0 == n1 > 100 and flat0 == flat1 > 7_000_000
+    assert same0 and same1
+    assert pr0 == pr1
+    for a, b, x, y in zip(s0, s1, l0, l1):
+        assert a == b
+        want = ((x or 0.0) + (y or 0.0)) / 2
+        np.testing.assert_allclose(a, want, rtol=1e-4, atol=1e-3)

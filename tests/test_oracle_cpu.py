@@ -342,3 +342,36 @@ def test_dense_head_loss_mirror_matches_reference_golden():
     loss.backward()
     for t, k in ((cls, "rpn_grad_cls"), (box, "rpn_grad_box"), (dr, "rpn_grad_dir")):
         np.testing.assert_allclose(t.grad.numpy(), g[k], rtol=1e-4, atol=1e-6 * max(1e-3, np.abs(g[k]).max()))
+
+
+def test_oracle_threads_do_not_change_results():
+    """orc_set_threads(n > 1) (OpenMP, used only by bench.py's all-cores cpu_baseline leg) runs loops with
+    independent iterations in parallel: sparse-conv forward, input gradient, voxel query, grouping and the NMS
+    keep list are bit-identical to the serial oracle; the weight gradient (per-thread partial sums) to 1e-4 of its scale."""
+    import oracle
+    from glenet_amd import synth
+    rng = np.random.default_rng(5)
+    K = synth.KITTI
+    pts, _ = synth.kitti_frame(3, num_points=6000)
+    v, c, n = oracle.voxelize_hard(pts, K["voxel_size"], K["point_cloud_range"], 5, 16000)
+    idx = np.concatenate([np.zeros((len(c), 1), np.int32), c], 1)
+    f = rng.normal(size=(len(c), 16)).astype(np.float32)
+    w = (rng.normal(size=(27, 16, 32)) / 10).astype(np.float32)
+    r = oracle.build_rules(idx, [41, 1600, 1408], 3, subm=True)
+    g = rng.normal(size=(len(c), 32)).astype(np.float32)
+    boxes = synth.random_boxes(rng, 700, near_dup=0.5)
+    lib = oracle.lib()
+
+    def run():
+        o = oracle.sconv_forward(f, w, r)
+        din, dw = oracle.sconv_backward(f, w, g, r)
+        return o, din, dw, oracle.nms_sorted(boxes, 0.3)
+    assert lib.orc_get_threads() == 1
+    a = run()
+    lib.orc_set_threads(4)
+    try:
+        b = run()
+    finally:
+        lib.orc_set_threads(1)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3])
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-4, atol=1e-4 * float(np.abs(a[2]).max()))
