@@ -226,6 +226,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     rank, local_rank, world = gdist.env_world()
+    t_start = time.perf_counter()
+
+    def progress(msg):
+        if rank == 0:
+            print("[bench %6.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
     # one process per GPU; GLX_DIST_BACKEND=gloo with fewer GPUs than ranks is a plumbing test mode (ranks
     # share a device, collectives on the host) -- never used for reported numbers
     backend = os.environ.get("GLX_DIST_BACKEND", "nccl")
@@ -276,6 +281,7 @@ def main():
         bucket = gdist.GradBucket(pipe.params)
         pipe.exchange = bucket.allreduce_
     pipe.load(*pool[0][:4])
+    progress("model + %d batches resident, capacities calibrated; capturing the step" % BATCH_POOL)
     if args.mode == "graph":
         pipe.capture(split=world > 1)
     else:
@@ -290,10 +296,12 @@ def main():
         pipe.load(*pool[j % BATCH_POOL][:4])
         pipe.step()
 
+    progress("captured; warm-up")
     for _ in range(args.warmup):
         train_step()
     torch.cuda.synchronize(dev)
     pipe.check()
+    progress("timing %d steps" % args.steps)
 
     # ---- headline: exactly K steps between two fences, nothing else in the region
     gdist.fence(dev)
@@ -306,6 +314,7 @@ def main():
     loss_end = float(pipe.loss.detach())
     parts_end = {k: round(float(v), 5) for k, v in pipe.parts.items()}
 
+    progress("headline done: %.2f ms/step" % (dt / args.steps * 1e3))
     # ---- per-stage milliseconds: one event-bracketed eager pass of the same launches per pool batch
     stages = None
     if not args.no_stages:
@@ -330,6 +339,7 @@ def main():
         stages["note"] = ("ms between stage marks in an eager (not graph-replayed) pass, rule tables and weight "
                           "gradients on their side stream; the sum exceeds ms_per_step by the launch gaps a graph removes")
 
+    progress("stages done")
     # ---- configs[1]: sparse backbone forward only (eval mode, BN folded), two frame pipelines in flight
     config1 = roof = None
     if not args.no_config1:
@@ -403,6 +413,7 @@ def main():
                                ranks_seen_by_collective=ranks_seen),
                    loss=dict(last=round(loss_end, 5), parts=parts_end),
                    stages_ms=stages, config1=config1, roofline=roof)
+        progress("config1 + roofline done")
         if world == 1 and not args.no_cpu_baseline:
             from oracle import baseline as cpu_base           # bench's cpu_baseline leg: the checker, timed
             out["cpu_baseline"] = cpu_base.config3_composite([b[4] for b in pool[:1]], model, K)

@@ -16,8 +16,35 @@ import time
 
 import numpy as np
 
-import oracle
-from oracle import backbone as ob
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")     # read by libgomp when liboracle.so loads: idle threads sleep
+import oracle  # noqa: E402
+from oracle import backbone as ob  # noqa: E402
+
+MAX_THREADS = 64     # the rule-pair loops of one kernel offset are ~10^4 iterations: more threads only add fork/join time
+
+
+def usable_cores():
+    """Cores this process may actually use: the affinity mask, cut by a cgroup CPU quota if one is set
+    (os.cpu_count() reports the machine, not the container)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, q // int(f.read())))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
 
 
 def _t(fn, *a, **k):
@@ -66,8 +93,8 @@ def config3_composite(frame_batches, model, K, threads=None, rois_per_frame=128,
     import copy
 
     import torch
-    cores = os.cpu_count() or 1
-    threads = int(threads or cores)
+    cores = usable_cores()
+    threads = int(threads or min(cores, MAX_THREADS))
     sd = {k: v.detach().cpu().numpy() for k, v in model.backbone_3d.state_dict().items()}
     sparse_shape = model.backbone_3d.sparse_shape
     frames = frame_batches[0]
@@ -147,7 +174,8 @@ def config3_composite(frame_batches, model, K, threads=None, rois_per_frame=128,
                 sample="composite of the config-3 step's components on ONE batch of %d frames of the bench pool "
                        "(NMS and the BEV head timed on 1 frame and scaled), %d threads (OpenMP oracle + torch-CPU): "
                        "lower bound on a CPU step (no BatchNorm / loss / optimizer / RoI-grid MLP time); %.1f s of CPU "
-                       "work in all; host has %d cores" % (nf, threads, time.perf_counter() - t_all, cores),
+                       "work in all; %d usable cores (os.cpu_count %d)" % (nf, threads, time.perf_counter() - t_all, cores,
+                                                                           os.cpu_count() or 0),
                 seconds_per_step={k: round(v, 4) for k, v in sec.items()},
                 sparse_backbone_fwd=dict(one_core_frames_per_s=round(one_core, 3),
                                          all_cores_frames_per_s=round(mt_fwd, 3), cores=threads,

@@ -42,7 +42,7 @@ def _small_model(dev, dp_ratio=0.0):
     cfg.update(NMS_TRAIN=(1024, 128, 0.8), DP_RATIO=dp_ratio)
     cfg["TARGET"] = dict(cfg["TARGET"], ROI_PER_IMAGE=32)
     torch.manual_seed(0)
-    torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.benchmark = False        # MIOpen immediate mode: no minutes of find per process in tests
     return gvr.GLENetVR(synth.KITTI, roi_cfg=cfg).to(dev).train()
 
 
@@ -204,7 +204,7 @@ def test_full_size_step_cycles_batches_inside_one_graph(dev):
     recorded step is replayed over different batches (capacities calibrated on the first with headroom)."""
     from glenet_amd import glenet_vr as gvr
     torch.manual_seed(0)
-    torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.benchmark = False
     model = gvr.GLENetVR(synth.KITTI).to(dev).train()
     B = 4
     batches = [_batch(dev, list(range(1000 + 4 * j, 1004 + 4 * j)), 20000) for j in range(3)]
