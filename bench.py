@@ -276,10 +276,8 @@ def main():
         for k, v in pipe.calibrate(b[0], b[1]).items():
             caps[k] = max(caps.get(k, 0), v)
     pipe.capacities = caps
-    bucket = None
-    if world > 1:        # data-parallel: one flat all-reduce of all gradients between backward and update
-        bucket = gdist.GradBucket(pipe.params)
-        pipe.exchange = bucket.allreduce_
+    if world > 1:        # data-parallel: one all-reduce on the flat gradient buffer between backward and update
+        pipe.data_parallel()
     pipe.load(*pool[0][:4])
     progress("model + %d batches resident, capacities calibrated; capturing the step" % BATCH_POOL)
     if args.mode == "graph":
@@ -291,8 +289,8 @@ def main():
     def train_step():
         j = it[0]
         it[0] += 1
-        lr, _mom = gvr.onecycle(j, total_steps)
-        pipe.set_lr(lr)
+        lr, mom = gvr.onecycle(j, total_steps)
+        pipe.set_lr(lr, mom)
         pipe.load(*pool[j % BATCH_POOL][:4])
         pipe.step()
 

@@ -1,0 +1,131 @@
+// Gradient-norm clipping + AdamW over ONE flat fp32 parameter buffer: the update of the training step
+// (tools/train_utils/train_utils.py:38-39: clip_grad_norm_(model.parameters(), GRAD_NORM_CLIP) then
+// optimizer.step(); optimiser = adam_onecycle, tools/train_utils/optimization/__init__.py:29-53: Adam with
+// true weight decay, betas (0.9, 0.99), learning rate and beta1 driven by the one-cycle schedule).
+// torch.optim.AdamW(capturable, foreach) spends ~300 launches per step on the model's 143 parameter tensors
+// (1.1 ms of a 24 ms step); with parameters, gradients and both moments in flat buffers the update is two
+// launches that move 7 x 4 bytes per element once (HBM-bound, ~210 MB for GLENet-VR).
+//   k_gradnorm_partial : per-block fp64 sums of g^2 in a fixed order (deterministic); block 0 bumps the step
+//   k_adamw            : every block folds the partials in the same order -> the same clip coefficient, then
+//                        the elementwise update with torch.optim.AdamW's arithmetic (fp32, one rounding per op)
+#include "glx_common.h"
+
+typedef float of32x4 __attribute__((ext_vector_type(4)));
+
+#define OPT_THREADS 256
+#define OPT_MAX_BLOCKS 1024
+
+__global__ __launch_bounds__(OPT_THREADS) void k_gradnorm_partial(const float* __restrict__ g, long long n,
+                                                                  double* __restrict__ partial,
+                                                                  int* __restrict__ step) {
+  const long long n4 = n >> 2;
+  double s = 0;
+  for (long long e = (long long)blockIdx.x * OPT_THREADS + threadIdx.x; e < n4; e += (long long)gridDim.x * OPT_THREADS) {
+    of32x4 v = reinterpret_cast<const of32x4*>(g)[e];
+    s += (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    float v = g[(n4 << 2) + threadIdx.x];
+    s += (double)v * v;
+  }
+  __shared__ double red[OPT_THREADS];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = OPT_THREADS / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = red[0];
+    if (blockIdx.x == 0 && step) *step += 1;
+  }
+}
+
+// hyper[0] = learning rate, hyper[1] = beta1 (device scalars: the one-cycle schedule writes them, a recorded
+// HIP graph reads them).  max_norm <= 0: no clipping (the norm is still reported).
+__global__ __launch_bounds__(OPT_THREADS) void k_adamw(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v, long long n,
+                                                       const float* __restrict__ hyper, float beta2, float eps,
+                                                       float wd, float max_norm, const int* __restrict__ step,
+                                                       const double* __restrict__ partial, int nparts,
+                                                       float* __restrict__ norm_out) {
+  __shared__ float s_coef;
+  if (threadIdx.x == 0) {
+    double s = 0;
+    for (int i = 0; i < nparts; ++i) s += partial[i];
+    const float total = (float)sqrt(s);
+    float coef = 1.f;
+    if (max_norm > 0.f) {                       // clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
+      coef = max_norm / (total + 1e-6f);
+      coef = coef > 1.f ? 1.f : coef;
+    }
+    s_coef = coef;
+    if (blockIdx.x == 0 && norm_out) *norm_out = total;
+  }
+  __syncthreads();
+  const float coef = s_coef;
+  const float lr = hyper[0], b1 = hyper[1];
+  const int t = *step;
+  // torch.optim.adam._single_tensor_adam (capturable branch) in fp32
+  const float bc1 = 1.f - powf(b1, (float)t), bc2 = 1.f - powf(beta2, (float)t);
+  const float step_size = lr / bc1;
+  const float bc2_sqrt = sqrtf(bc2);
+  const float decay = 1.f - lr * wd;
+  const long long n4 = n >> 2;
+  for (long long e = (long long)blockIdx.x * OPT_THREADS + threadIdx.x; e < n4; e += (long long)gridDim.x * OPT_THREADS) {
+    of32x4 pv = reinterpret_cast<of32x4*>(p)[e], gv = reinterpret_cast<const of32x4*>(g)[e];
+    of32x4 mv = reinterpret_cast<of32x4*>(m)[e], vv = reinterpret_cast<of32x4*>(v)[e];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float gi = gv[i] * coef;
+      pv[i] *= decay;
+      mv[i] = mv[i] + (gi - mv[i]) * (1.f - b1);              // exp_avg.lerp_(grad, 1 - beta1)
+      vv[i] = vv[i] * beta2 + (1.f - beta2) * gi * gi;        // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+      const float denom = sqrtf(vv[i]) / bc2_sqrt + eps;
+      pv[i] -= step_size * (mv[i] / denom);
+    }
+    reinterpret_cast<of32x4*>(p)[e] = pv;
+    reinterpret_cast<of32x4*>(m)[e] = mv;
+    reinterpret_cast<of32x4*>(v)[e] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long e = (n4 << 2) + threadIdx.x;
+    const float gi = g[e] * coef;
+    float pe = p[e] * decay;
+    const float me = m[e] + (gi - m[e]) * (1.f - b1);
+    const float ve = v[e] * beta2 + (1.f - beta2) * gi * gi;
+    pe -= step_size * (me / (sqrtf(ve) / bc2_sqrt + eps));
+    p[e] = pe; m[e] = me; v[e] = ve;
+  }
+}
+
+static int opt_blocks(long long n) {
+  long long b = (n / 4 + OPT_THREADS * 8 - 1) / (OPT_THREADS * 8);
+  return (int)(b < 1 ? 1 : (b > OPT_MAX_BLOCKS ? OPT_MAX_BLOCKS : b));
+}
+
+extern "C" size_t glx_adamw_workspace_bytes(void) { return OPT_MAX_BLOCKS * sizeof(double) + 256; }
+
+extern "C" int glx_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                   int64_t n, const float* hyper, float beta2, float eps, float weight_decay,
+                                   float max_norm, int32_t* step, float* norm_out, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(n >= 0 && (n == 0 || (params && grads && exp_avg && exp_avg_sq)) && hyper && step,
+              "glx_adamw_clip_step: null pointer");
+  GLX_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+              "glx_adamw_clip_step: buffers must be 16-byte aligned");
+  if (!workspace || workspace_bytes < glx_adamw_workspace_bytes() - 256) {
+    glx_set_error("glx_adamw_clip_step: workspace %zu < %zu bytes", workspace_bytes, glx_adamw_workspace_bytes() - 256);
+    return GLX_EWORKSPACE;
+  }
+  if (n == 0) return GLX_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = opt_blocks(n);
+  hipLaunchKernelGGL(k_gradnorm_partial, dim3(blocks), dim3(OPT_THREADS), 0, st, grads, (long long)n,
+                     (double*)workspace, step);
+  hipLaunchKernelGGL(k_adamw, dim3(blocks), dim3(OPT_THREADS), 0, st, params, grads, exp_avg, exp_avg_sq,
+                     (long long)n, hyper, beta2, eps, weight_decay, max_norm, (const int*)step,
+                     (const double*)workspace, blocks, norm_out);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

@@ -250,6 +250,9 @@ class StaticTrainStep(gb.StaticTrainPipeline):
 
     def __init__(self, model, batch_size, num_points, num_features=4, max_gt=32, optimizer=None, lr=None,
                  seed_rois_with_gt=None, grad_clip=OPTIM_CFG["GRAD_NORM_CLIP"], capacities=None, device=None):
+        """optimizer: None -> glenet_amd.optim.FlatAdamW (parameters re-pointed into one flat buffer, clip +
+        update = two launches); or a torch optimizer built with capturable=True (clip_grad_norm_ + step())."""
+        from .optim import FlatAdamW
         dev = device if device is not None else next(model.parameters()).device
         self.net = model
         self.gt_boxes = torch.zeros((batch_size, max_gt, 8), dtype=torch.float32, device=dev)
@@ -260,11 +263,10 @@ class StaticTrainStep(gb.StaticTrainPipeline):
         self.grad_clip = grad_clip
         self.params = [p for p in model.parameters() if p.requires_grad]
         if optimizer is None:
-            optimizer = torch.optim.AdamW(self.params, lr=torch.tensor(lr if lr is not None else OPTIM_CFG["LR"],
-                                                                       dtype=torch.float32, device=dev),
-                                          betas=OPTIM_CFG["BETAS"], weight_decay=OPTIM_CFG["WEIGHT_DECAY"],
-                                          capturable=True, foreach=True)
+            optimizer = FlatAdamW(self.params, lr=lr if lr is not None else OPTIM_CFG["LR"], betas=OPTIM_CFG["BETAS"],
+                                  weight_decay=OPTIM_CFG["WEIGHT_DECAY"], max_norm=grad_clip)
         self.step_optimizer = optimizer
+        self.flat = isinstance(optimizer, FlatAdamW)
         self.exchange = None           # callable run between backward and the update (gradient all-reduce)
         self.update_graph = None
         self.grad_norm = None
@@ -291,23 +293,42 @@ class StaticTrainStep(gb.StaticTrainPipeline):
                 self.gt_unc[:, :g].copy_(gt_uncertaintys, non_blocking=True)
 
     def set_lr(self, lr, momentum=None):
-        """One-cycle schedule hook: the learning rate is a device scalar the recorded update reads."""
+        """One-cycle schedule hook: learning rate (and beta1) are device scalars the recorded update reads."""
+        if self.flat:
+            self.step_optimizer.set_lr(lr, momentum)
+            return
         for g in self.step_optimizer.param_groups:
             if torch.is_tensor(g["lr"]):
                 g["lr"].fill_(lr)
             else:
                 g["lr"] = lr
 
+    def data_parallel(self):
+        """Install the gradient exchange of the data-parallel step (tools/train.py:144-145 wraps the model in
+        DistributedDataParallel): one flat all-reduce between backward and the update."""
+        if self.flat:
+            self.exchange = self.step_optimizer.allreduce_
+        else:
+            from .dist import GradBucket
+            self.exchange = GradBucket(self.params).allreduce_
+        return self
+
     def update(self):
         """clip_grad_norm_ (train_utils.py:38) + optimizer step; no read-back (the norm stays on the device)."""
-        if self.grad_clip:
-            self.grad_norm = torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip, foreach=True)
-        self.step_optimizer.step()
+        if self.flat:
+            self.step_optimizer.step(packed=True)
+            self.grad_norm = self.step_optimizer.grad_norm
+        else:
+            if self.grad_clip:
+                self.grad_norm = torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip, foreach=True)
+            self.step_optimizer.step()
         if self.mark:
             self.mark("grad clip + AdamW")
 
     def enqueue(self):
         bd = super().enqueue()
+        if self.flat:
+            self.step_optimizer.pack_grads()          # part of the forward + backward graph
         if not self.split:
             if self.exchange is not None:
                 self.exchange()

@@ -1,0 +1,113 @@
+"""Update of the training step on flat buffers: gradient-norm clipping + AdamW as two launches
+(csrc/glx_optim.hip) and the gradient exchange of the data-parallel step on the same flat gradient buffer.
+
+Our counterpart of tools/train_utils/train_utils.py:38-39 (`clip_grad_norm_(model.parameters(), GRAD_NORM_CLIP)`,
+`optimizer.step()`) with the `adam_onecycle` optimiser (tools/train_utils/optimization/__init__.py:29-53: Adam with
+true weight decay, betas (0.9, 0.99); OneCycle drives the learning rate and beta1).
+
+Layout: every parameter becomes a view into ONE flat fp32 buffer (`p.data` is re-pointed once, at construction;
+16-byte aligned slices), gradients are gathered into a flat buffer of the same layout after backward (a multi-tensor
+copy), both moments are flat.  Consequences:
+  * the update is two launches moving 7 x 4 B per element once instead of ~300 launches of per-tensor ops;
+  * the data-parallel exchange is one all-reduce ON the flat gradient buffer: no pack / unpack copies;
+  * learning rate, beta1 and the step count are device scalars, so a recorded HIP graph replays the update.
+The kernel writes parameters through raw pointers: torch's version counters do not move.  Whatever caches derived
+tensors by version (packed sparse-conv weights, folded BatchNorms) must not be used in training mode -- the sparse
+convs re-pack inside the step when gradients are enabled (spconv.core.SparseConvolution._packed_weight)."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class FlatAdamW:
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_norm=None):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatAdamW: no trainable parameters")
+        dev = self.params[0].device
+        _lib.check_cuda(*[p.data for p in self.params])
+        if any(p.dtype != torch.float32 for p in self.params):
+            raise ValueError("FlatAdamW: fp32 parameters only")
+        self.offsets, n = [], 0
+        for p in self.params:                       # 16-byte aligned slices
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        self.n = n
+        self.flat_param = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad_views = []
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                view = self.flat_param[o:o + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                self.grad_views.append(self.flat_grad[o:o + p.numel()].view_as(p))
+        self.hyper = torch.tensor([float(lr), float(betas[0])], dtype=torch.float32, device=dev)
+        self.beta2, self.eps, self.weight_decay = float(betas[1]), float(eps), float(weight_decay)
+        self.max_norm = float(max_norm) if max_norm else 0.0
+        self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._ws = torch.empty(_lib.query("glx_adamw_workspace_bytes"), dtype=torch.uint8, device=dev)
+        self._zeros = None
+
+    def set_lr(self, lr, beta1=None):
+        """Device scalars the (recorded) update reads; two fills, no synchronisation."""
+        self.hyper[0:1].fill_(float(lr))
+        if beta1 is not None:
+            self.hyper[1:2].fill_(float(beta1))
+
+    def pack_grads(self):
+        """Gather the .grad tensors into the flat gradient buffer (a parameter without a gradient contributes
+        zeros, as an optimizer that skips it would leave it -- except for weight decay, which torch skips too
+        for such parameters; the training step gives every parameter a gradient)."""
+        have = [(v, p.grad) for v, p in zip(self.grad_views, self.params) if p.grad is not None]
+        if len(have) != len(self.params):
+            for v, p in zip(self.grad_views, self.params):
+                if p.grad is None:
+                    v.zero_()
+        if have:
+            torch._foreach_copy_([h[0] for h in have], [h[1] for h in have])
+        return self.flat_grad
+
+    def allreduce_(self, average=True):
+        """Data-parallel exchange: one all-reduce on the flat gradient buffer (RCCL; gloo for the CPU-side
+        plumbing tests goes through a host copy)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        buf = self.flat_grad
+        if dist.get_backend() == "gloo" and buf.is_cuda:
+            host = buf.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            buf.copy_(host)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        if average:
+            buf.div_(dist.get_world_size())
+
+    def step(self, packed=False):
+        """clip + AdamW.  packed=True: flat_grad already holds this step's (exchanged) gradients."""
+        if not packed:
+            self.pack_grads()
+        _lib.call("glx_adamw_clip_step", self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq,
+                  ctypes.c_int64(self.n), self.hyper, ctypes.c_float(self.beta2), ctypes.c_float(self.eps),
+                  ctypes.c_float(self.weight_decay), ctypes.c_float(self.max_norm), self.step_count, self.grad_norm,
+                  self._ws, _lib.size_arg(self._ws.numel()))
+
+    def bump_versions(self):
+        """Tell torch the parameters changed (eager loops that rely on version-keyed caches)."""
+        torch.autograd.graph.increment_version(self.params)
+
+    def state_dict(self):
+        return dict(exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(), step=self.step_count.clone(),
+                    hyper=self.hyper.clone())
+
+    def load_state_dict(self, sd):
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count.copy_(sd["step"])
+        self.hyper.copy_(sd["hyper"])

@@ -556,6 +556,13 @@ class SparseConvolution(SparseModule):
     def _packed_weight(self, w):
         """Packed copy of the weights, refreshed when the parameter changes (optimizer step,
         load_state_dict, .to())."""
+        if torch.is_grad_enabled() and self.weight.requires_grad:
+            # training: pack inside the step, every step.  The weights change between steps without the
+            # version counter moving (a fused optimizer writes through raw pointers; a replayed HIP graph
+            # runs no Python at all), so a version-keyed cache would feed the forward stale weights while
+            # the backward packs the adjoint from the live ones.
+            with torch.no_grad():
+                return pack_weights(w.detach().contiguous())
         tag = (self.weight._version, self.weight.data_ptr(), self.weight.device)
         cache = self.__dict__.get("_packed_cache")
         if cache is None or cache[0] != tag:

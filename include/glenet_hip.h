@@ -498,6 +498,22 @@ int glx_bn_relu_backward(const float* x, const float* dy, const float* y, int N,
                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Update of the training step on flat fp32 buffers: gradient-norm clipping + AdamW in two launches.
+ * params / grads / exp_avg / exp_avg_sq: n floats each, 16-byte aligned; hyper: DEVICE float[2] =
+ * { learning rate, beta1 } (written by the one-cycle schedule, read by a recorded HIP graph); step: DEVICE
+ * int32 counter, incremented by the call; max_norm <= 0 disables clipping; norm_out (device float, may be
+ * NULL) receives the total gradient norm before clipping.  Arithmetic of torch.optim.AdamW (decoupled
+ * weight decay, bias corrections from `step`) after torch.nn.utils.clip_grad_norm_.
+ * Replaces: tools/train_utils/train_utils.py:38-39 (clip_grad_norm_ + optimizer.step()) with the
+ * adam_onecycle optimiser of tools/train_utils/optimization/__init__.py:29-53.
+ * ------------------------------------------------------------------------------------ */
+size_t glx_adamw_workspace_bytes(void);
+int glx_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                        const float* hyper, float beta2, float eps, float weight_decay, float max_norm,
+                        int32_t* step, float* norm_out, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------
  * PV-RCNN set-abstraction operators (same extension module in the reference).
  * ------------------------------------------------------------------------------------ */
 

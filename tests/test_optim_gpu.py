@@ -1,0 +1,75 @@
+"""glenet_amd.optim.FlatAdamW (csrc/glx_optim.hip: gradient-norm clipping + AdamW on flat buffers, two launches)
+against the plain PyTorch fp32 reference of the same update: torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW
+(the arithmetic of tools/train_utils/train_utils.py:38-39 with the adam_onecycle optimiser)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(dev):
+    torch.manual_seed(0)
+    shapes = [(64, 33), (7,), (3, 3, 3, 16, 32), (1,), (256, 20736 // 64), (5, 5)]
+    a = [torch.nn.Parameter(torch.randn(s, device=dev) * 0.3) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    return a, b
+
+
+@pytest.mark.parametrize("max_norm", [10.0, 0.5, None])
+def test_flat_adamw_matches_torch(dev, max_norm):
+    from glenet_amd.optim import FlatAdamW
+    ours, ref = _models(dev)
+    opt = FlatAdamW(ours, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01, max_norm=max_norm)
+    topt = torch.optim.AdamW(ref, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)
+    assert all(p.data_ptr() >= opt.flat_param.data_ptr() for p in ours)          # parameters live in the flat buffer
+    g = torch.Generator(device=dev).manual_seed(1)
+    for it in range(6):
+        lr, b1 = 3e-3 * (1 + it), 0.9 - 0.01 * it                                   # a moving schedule
+        opt.set_lr(lr, b1)
+        for grp in topt.param_groups:
+            grp["lr"], grp["betas"] = lr, (b1, 0.99)
+        for p, q in zip(ours, ref):
+            gr = torch.randn(p.shape, device=dev, generator=g) * (3.0 if it % 2 else 0.05)
+            p.grad, q.grad = gr.clone(), gr.clone()
+        want_norm = torch.nn.utils.clip_grad_norm_(ref, max_norm) if max_norm else None
+        topt.step()
+        opt.step()
+        if max_norm:
+            np.testing.assert_allclose(float(opt.grad_norm), float(want_norm), rtol=1e-6)
+        for p, q in zip(ours, ref):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-5, atol=2e-7)
+    assert int(opt.step_count) == 6
+
+
+def test_flat_adamw_replays_in_a_graph_and_handles_missing_grads(dev):
+    from glenet_amd.optim import FlatAdamW
+    ours, ref = _models(dev)
+    opt = FlatAdamW(ours, lr=1e-2, betas=(0.9, 0.99), weight_decay=0.0, max_norm=1.0)
+    topt = torch.optim.AdamW(ref, lr=1e-2, betas=(0.9, 0.99), weight_decay=0.0)
+    grads = [torch.randn(p.shape, device=dev) for p in ours]
+    grads[1] = None                                     # a parameter the step did not reach
+    for p, q, gr in zip(ours, ref, grads):
+        p.grad = None if gr is None else gr.clone()
+        q.grad = None if gr is None else gr.clone()
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        opt.step()                                      # warm-up (step 1)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        opt.step()
+    for _ in range(3):
+        graph.replay()                                  # steps 2..4 (same gradients)
+    torch.cuda.synchronize(dev)
+    for _ in range(4):
+        for q, gr in zip(ref, grads):
+            q.grad = None if gr is None else gr.clone()
+        torch.nn.utils.clip_grad_norm_([q for q in ref if q.grad is not None], 1.0)
+        topt.step()
+    assert int(opt.step_count) == 4
+    for i, (p, q) in enumerate(zip(ours, ref)):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=5e-5, atol=5e-7,
+                                   err_msg="parameter %d" % i)
