@@ -15,6 +15,23 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=o
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 
 
+HOST_SRC = os.path.join(CSRC, "host", "glx_host.cpp")
+HOST_LIB = os.path.join(CSRC, "libglenet_host.so")
+HOST_FLAGS = ["-O2", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall"]
+
+
+def build_host(force=False):
+    """libglenet_host.so: the host-memory entry points (include/glenet_host.h), g++ only -- it must not link
+    the HIP runtime (forked DataLoader workers call it)."""
+    hdr = os.path.join(HERE, "..", "include", "glenet_host.h")
+    if force or _stale(HOST_LIB, [HOST_SRC, hdr]):
+        r = subprocess.run([os.environ.get("CXX", "g++")] + HOST_FLAGS + ["-o", HOST_LIB, HOST_SRC],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("g++ failed on glx_host.cpp:\n%s\n%s" % (r.stdout, r.stderr))
+    return HOST_LIB
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -51,6 +68,7 @@ def build(force=False, verbose=False):
             list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    build_host(force)
     return LIB
 
 

@@ -27,14 +27,15 @@ def boxes_iou_bev_gpu(boxes_a, boxes_b, ans_iou):
 
 
 def boxes_iou_bev_cpu(boxes_a, boxes_b, ans_iou):
-    """The reference's CPU entry point (iou3d_cpu.cpp:232-252).  Host tensors in/out; the
-    arithmetic still runs on the GPU (there is no CPU code path in this build), so unlike the
-    reference it must not be called from forked DataLoader workers."""
-    dev = torch.device("cuda", torch.cuda.current_device())
-    a, b = boxes_a.float().contiguous().to(dev), boxes_b.float().contiguous().to(dev)
-    out = torch.zeros((a.shape[0], b.shape[0]), dtype=torch.float32, device=dev)
-    boxes_iou_bev_gpu(a, b, out)
-    ans_iou.copy_(out.cpu())
+    """The reference's CPU entry point (iou3d_cpu.cpp:232-252): host tensors in and out, host arithmetic
+    (libglenet_host.so, plain C++): stateless and free of any GPU runtime call, so the forked DataLoader
+    workers that call it through boxes_bev_iou_cpu (database_sampler.py:246-247) may do so."""
+    from ... import _host
+    if boxes_a.is_cuda or boxes_b.is_cuda or ans_iou.is_cuda:
+        raise _lib.GlxError("boxes_iou_bev_cpu takes host tensors (use boxes_iou_bev_gpu for device tensors)")
+    out = _host.boxes_iou_bev(boxes_a.detach().float().contiguous().numpy(),
+                              boxes_b.detach().float().contiguous().numpy())
+    ans_iou.copy_(torch.from_numpy(out).view_as(ans_iou))
     return 1
 
 

@@ -30,11 +30,11 @@ def points_in_boxes_gpu(boxes, pts, box_idx_of_points):
 
 
 def points_in_boxes_cpu(boxes, pts, pts_indices):
-    """Host tensors in/out like the reference's CPU routine (MARGIN 1e-2); computed on the GPU,
-    so not for forked DataLoader workers."""
-    dev = torch.device("cuda", torch.cuda.current_device())
-    b, p = boxes.float().contiguous().to(dev), pts.float().contiguous().to(dev)
-    out = torch.zeros((b.shape[0], p.shape[0]), dtype=torch.int32, device=dev)
-    call("glx_points_in_boxes_mask", b, b.shape[0], p, p.shape[0], 1e-2, out)
-    pts_indices.copy_(out.cpu())
+    """roiaware_pool3d.cpp:143-168: host tensors in and out, host arithmetic (libglenet_host.so; MARGIN 1e-2),
+    no GPU runtime call -- callable from forked DataLoader workers (box_utils.py:86, augmentor_utils.py)."""
+    from ... import _host
+    if boxes.is_cuda or pts.is_cuda or pts_indices.is_cuda:
+        raise _lib.GlxError("points_in_boxes_cpu takes host tensors (use points_in_boxes_gpu for device tensors)")
+    out = _host.points_in_boxes(boxes.detach().float().contiguous().numpy(), pts.detach().float().contiguous().numpy())
+    pts_indices.copy_(torch.from_numpy(out).view_as(pts_indices))
     return 1

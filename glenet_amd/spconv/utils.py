@@ -1,10 +1,11 @@
 """`spconv.utils` voxel generators with the constructor/generate signatures the reference
-calls (pcdet/datasets/processor/data_processor.py:15-60).  numpy in, numpy out, computed on the
-GPU by glenet_amd.voxelize.hard_voxelize (no CPU path)."""
+calls (pcdet/datasets/processor/data_processor.py:15-60).  numpy in, numpy out, HOST arithmetic
+(libglenet_host.so through glenet_amd._host): the reference builds these inside Dataset objects and
+calls them from forked DataLoader workers, so they must not touch the GPU runtime.  (The device
+voxelizer of the training pipeline is glenet_amd.voxelize.hard_voxelize / data_pipeline.)"""
 import numpy as np
-import torch
 
-from ..voxelize import hard_voxelize
+from .. import _host
 
 
 class _TV:
@@ -29,14 +30,11 @@ class VoxelGeneratorV2:
         self._point_cloud_range = [float(v) for v in point_cloud_range]
         self._max_num_points = int(max_num_points)
         self._max_voxels = int(max_voxels)
-        self.device = torch.device("cuda", torch.cuda.current_device())
 
     def generate(self, points, max_voxels=None):
-        pts = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32)).to(self.device)
-        v, c, n, _ = hard_voxelize(pts, self._voxel_size, self._point_cloud_range,
-                                   self._max_num_points, max_voxels or self._max_voxels)[:4]
-        return {"voxels": v.cpu().numpy(), "coordinates": c[:, 1:].cpu().numpy(),
-                "num_points_per_voxel": n.cpu().numpy()}
+        v, c, n = _host.voxelize_hard(np.asarray(points), self._voxel_size, self._point_cloud_range,
+                                      self._max_num_points, max_voxels or self._max_voxels)
+        return {"voxels": v, "coordinates": c, "num_points_per_voxel": n}
 
     @property
     def voxel_size(self):
