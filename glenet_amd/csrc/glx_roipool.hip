@@ -1,0 +1,301 @@
+// RoI-grid pooling, training path: the position branch of NeighborVoxelSAModuleMSG fused with the add + ReLU +
+// max-pool over the neighbours (pcdet/ops/pointnet2/pointnet2_stack/voxel_pool_modules.py:88-108:
+//   grouped_xyz - new_xyz -> mlps_pos = Conv2d(3, C, 1, bias=False) + BatchNorm2d(C)   [training-mode statistics]
+//   relu(grouped_features + position_features) -> max over nsample).
+// The reference materialises four (M, C, ns) tensors per scale for it (grouped features, positions, sum, ReLU;
+// M = 4 x 128 x 216 grid points, ns = 16, C = 32: 226 MB each) and BatchNorm makes four more passes over the
+// position tensor forward and backward; on this device that was 10.8 ms of a 24 ms training step.  None of
+// those tensors is needed:
+//   * the convolution is linear in rel = xyz[idx] - new_xyz, so the batch statistics of its output follow from
+//     the first and second moments of rel (9 numbers): mean_c = w_c . E[rel], var_c = w_c^T Cov[rel] w_c.  One
+//     reduction over the (m, s) pairs gives them (fp64, fixed order); BatchNorm then folds into the conv:
+//     pos_c(rel) = (a_c w_c) . rel + b_c with a_c = gamma_c / sqrt(var_c + eps), b_c = beta_c - a_c mean_c;
+//   * forward = one pass: per grid point, lanes = channels, the 16 neighbour rows are gathered (a neighbour's C
+//     channels are one contiguous row), v = relu(feat + pos_c(rel)), running max and its slot;
+//   * backward: the gradient lives at the winning slot only (one (m, c) entry each).  Into the features it is an
+//     atomic add per (m, c); for BatchNorm and the conv weight
+//         dbeta_c  = sum dz,  dgamma_c = sum dz * xhat,
+//         dW_c     = a_c ( sum dz * rel  -  dbeta_c/n * S1  -  dgamma_c/n * (S2 w_c - mean_c S1) / sigma_c )
+//     with S1 = sum rel, S2 = sum rel rel^T over all n = M * ns rows (the dense "minus the means" part of the
+//     BatchNorm gradient only ever meets rel through those two sums) -- per-channel sums of 5 numbers over the
+//     winners, one kernel.
+// Empty balls (idx[m,0] < 0) count as ns rows of rel = 0 and feature 0, exactly as the reference's masked tensors.
+#include "glx_common.h"
+#include "glx_fill.h"
+
+#define RP_THREADS 256
+#define RP_MAX_BLOCKS 1024
+#define RP_MAXC 64
+
+// `save` (6 * C floats, forward -> backward): mean[C], invstd[C], folded weights Wp[C][3], folded bias bp[C]
+
+// ---- moments of rel over all (m, s): partial[block][9] = S1 (3), S2 (xx, xy, xz, yy, yz, zz)
+__global__ __launch_bounds__(RP_THREADS) void k_rp_moments(const int* __restrict__ idx, const float* __restrict__ xyz,
+                                                           const float* __restrict__ new_xyz, int M, int ns,
+                                                           double* __restrict__ partial) {
+  double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int m = blockIdx.x * RP_THREADS + threadIdx.x; m < M; m += gridDim.x * RP_THREADS) {
+    const int* row = idx + (long long)m * ns;
+    if (row[0] < 0) continue;
+    const float qx = new_xyz[(long long)m * 3], qy = new_xyz[(long long)m * 3 + 1], qz = new_xyz[(long long)m * 3 + 2];
+    for (int k = 0; k < ns; ++k) {
+      const long long r = row[k];
+      const float x = xyz[r * 3] - qx, y = xyz[r * 3 + 1] - qy, z = xyz[r * 3 + 2] - qz;
+      s[0] += x; s[1] += y; s[2] += z;
+      s[3] += (double)x * x; s[4] += (double)x * y; s[5] += (double)x * z;
+      s[6] += (double)y * y; s[7] += (double)y * z; s[8] += (double)z * z;
+    }
+  }
+  __shared__ double red[RP_THREADS];
+  for (int q = 0; q < 9; ++q) {
+    red[threadIdx.x] = s[q];
+    __syncthreads();
+    for (int o = RP_THREADS / 2; o > 0; o >>= 1) {
+      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(long long)blockIdx.x * 9 + q] = red[0];
+    __syncthreads();
+  }
+}
+
+// one block of C threads: statistics -> folded affine map, saved mean / invstd, running estimates
+__global__ void k_rp_finalize_fwd(const double* __restrict__ partial, int nparts, double n, const float* __restrict__ w,
+                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                  float momentum, int training, float* __restrict__ running_mean,
+                                  float* __restrict__ running_var, int C, float* __restrict__ save,
+                                  double* __restrict__ moments) {
+  __shared__ double S[9];
+  if (threadIdx.x < 9) {
+    double a = 0;
+    if (training)
+      for (int b = 0; b < nparts; ++b) a += partial[(long long)b * 9 + threadIdx.x];
+    S[threadIdx.x] = a;
+    moments[threadIdx.x] = a;
+  }
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  const double w0 = w[c * 3], w1 = w[c * 3 + 1], w2 = w[c * 3 + 2];
+  double mean, var;
+  if (training) {
+    const double mx = S[0] / n, my = S[1] / n, mz = S[2] / n;
+    const double cxx = S[3] / n - mx * mx, cxy = S[4] / n - mx * my, cxz = S[5] / n - mx * mz;
+    const double cyy = S[6] / n - my * my, cyz = S[7] / n - my * mz, czz = S[8] / n - mz * mz;
+    mean = w0 * mx + w1 * my + w2 * mz;
+    var = w0 * w0 * cxx + w1 * w1 * cyy + w2 * w2 * czz + 2 * (w0 * w1 * cxy + w0 * w2 * cxz + w1 * w2 * cyz);
+    if (var < 0) var = 0;
+    if (running_mean) {      // nn.BatchNorm: the running estimate takes the unbiased variance
+      const double unb = n > 1 ? var * n / (n - 1) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  } else {
+    mean = running_mean[c];
+    var = running_var[c];
+  }
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float a = (gamma ? gamma[c] : 1.f) * invstd;
+  save[c] = (float)mean;
+  save[C + c] = invstd;
+  save[2 * C + c * 3] = a * w[c * 3];
+  save[2 * C + c * 3 + 1] = a * w[c * 3 + 1];
+  save[2 * C + c * 3 + 2] = a * w[c * 3 + 2];
+  save[5 * C + c] = (beta ? beta[c] : 0.f) - (float)mean * a;
+}
+
+// forward: lanes = channels; a wave covers 64 / C grid points per pass
+template <int C>
+__global__ __launch_bounds__(RP_THREADS) void k_rp_forward(const float* __restrict__ feats, const float* __restrict__ xyz,
+                                                           const float* __restrict__ new_xyz, const int* __restrict__ idx,
+                                                           int M, int ns, const float* __restrict__ save,
+                                                           float* __restrict__ pooled, unsigned char* __restrict__ arg) {
+  constexpr int PPB = RP_THREADS / C;          // grid points per block pass
+  const int c = threadIdx.x % C, sub = threadIdx.x / C;
+  const float wx = save[2 * C + c * 3], wy = save[2 * C + c * 3 + 1], wz = save[2 * C + c * 3 + 2], b = save[5 * C + c];
+  for (long long m = (long long)blockIdx.x * PPB + sub; m < M; m += (long long)gridDim.x * PPB) {
+    const int* row = idx + m * ns;
+    float best = -1.f;
+    int bi = 0;
+    if (row[0] < 0) {
+      best = fmaxf(b, 0.f);                    // every slot holds feature 0 and rel 0
+    } else {
+      const float qx = new_xyz[m * 3], qy = new_xyz[m * 3 + 1], qz = new_xyz[m * 3 + 2];
+      for (int s0 = 0; s0 < ns; s0 += 8) {     // 8 row gathers in flight
+        float f[8], x[8], y[8], z[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const long long r = row[s0 + j < ns ? s0 + j : 0];
+          f[j] = feats[r * C + c];
+          x[j] = xyz[r * 3]; y[j] = xyz[r * 3 + 1]; z[j] = xyz[r * 3 + 2];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (s0 + j >= ns) break;
+          const float p = (x[j] - qx) * wx + (y[j] - qy) * wy + (z[j] - qz) * wz + b;
+          const float v = fmaxf(f[j] + p, 0.f);
+          if (v > best) { best = v; bi = s0 + j; }
+        }
+      }
+    }
+    pooled[m * C + c] = best;
+    arg[m * C + c] = (unsigned char)bi;
+  }
+}
+
+// backward: feature gradient by atomic adds at the winning slots + per-channel sums
+// partial[block][c][5] = sum dz, sum dz*xhat, sum dz*rel (3)
+template <int C>
+__global__ __launch_bounds__(RP_THREADS) void k_rp_backward(const float* __restrict__ dpooled,
+                                                            const float* __restrict__ pooled,
+                                                            const unsigned char* __restrict__ arg,
+                                                            const int* __restrict__ idx, const float* __restrict__ xyz,
+                                                            const float* __restrict__ new_xyz, int M, int ns,
+                                                            const float* __restrict__ w, const float* __restrict__ save,
+                                                            float* __restrict__ dfeats, double* __restrict__ partial) {
+  constexpr int PPB = RP_THREADS / C;
+  const int c = threadIdx.x % C, sub = threadIdx.x / C;
+  const float w0 = w[c * 3], w1 = w[c * 3 + 1], w2 = w[c * 3 + 2];
+  const float mean = save[c], invstd = save[C + c];
+  double s[5] = {0, 0, 0, 0, 0};
+  for (long long m = (long long)blockIdx.x * PPB + sub; m < M; m += (long long)gridDim.x * PPB) {
+    const float g = pooled[m * C + c] > 0.f ? dpooled[m * C + c] : 0.f;
+    if (g == 0.f) continue;
+    const int* row = idx + m * ns;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (row[0] >= 0) {
+      const long long r = row[arg[m * C + c]];
+      x = xyz[r * 3] - new_xyz[m * 3];
+      y = xyz[r * 3 + 1] - new_xyz[m * 3 + 1];
+      z = xyz[r * 3 + 2] - new_xyz[m * 3 + 2];
+      atomicAdd(dfeats + r * C + c, g);
+    }
+    const float xh = (x * w0 + y * w1 + z * w2 - mean) * invstd;
+    s[0] += g;
+    s[1] += (double)g * xh;
+    s[2] += (double)g * x;
+    s[3] += (double)g * y;
+    s[4] += (double)g * z;
+  }
+  __shared__ double red[RP_THREADS];
+  for (int q = 0; q < 5; ++q) {
+    red[threadIdx.x] = s[q];
+    __syncthreads();
+    if (sub == 0) {
+      double a = 0;
+      for (int k = 0; k < PPB; ++k) a += red[k * C + c];
+      partial[((long long)blockIdx.x * C + c) * 5 + q] = a;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void k_rp_finalize_bwd(const double* __restrict__ partial, int nparts, double n, const double* __restrict__ moments,
+                                  const float* __restrict__ w, const float* __restrict__ gamma,
+                                  const float* __restrict__ save, int training, int C, float* __restrict__ dW,
+                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  double s[5] = {0, 0, 0, 0, 0};
+  for (int b = 0; b < nparts; ++b)
+    for (int q = 0; q < 5; ++q) s[q] += partial[((long long)b * C + c) * 5 + q];
+  const double mean = save[c], invstd = save[C + c];
+  const double a = (gamma ? gamma[c] : 1.f) * invstd;
+  if (dbeta) dbeta[c] = (float)s[0];
+  if (dgamma) dgamma[c] = (float)s[1];
+  double d[3] = {s[2], s[3], s[4]};
+  if (training) {
+    const double w0 = w[c * 3], w1 = w[c * 3 + 1], w2 = w[c * 3 + 2];
+    const double* S = moments;
+    const double yx[3] = {S[3] * w0 + S[4] * w1 + S[5] * w2 - mean * S[0],      // sum y * rel - mean * sum rel
+                          S[4] * w0 + S[6] * w1 + S[7] * w2 - mean * S[1],
+                          S[5] * w0 + S[7] * w1 + S[8] * w2 - mean * S[2]};
+    for (int k = 0; k < 3; ++k) d[k] -= s[0] / n * S[k] + s[1] / n * invstd * yx[k];
+  }
+  for (int k = 0; k < 3; ++k) dW[c * 3 + k] = (float)(a * d[k]);
+}
+
+static bool rp_channels_ok(int C) { return C == 16 || C == 32 || C == 64; }
+static int rp_blocks(int M, int C) {
+  const int ppb = RP_THREADS / C;
+  long long b = ((long long)M + ppb * 4 - 1) / (ppb * 4);
+  return (int)(b < 1 ? 1 : (b > RP_MAX_BLOCKS ? RP_MAX_BLOCKS : b));
+}
+static size_t rp_partial_bytes(int C) { return glx_align((size_t)RP_MAX_BLOCKS * (C * 5 > 9 ? C * 5 : 9) * sizeof(double)); }
+
+extern "C" size_t glx_pos_pool_workspace_bytes(int C) { return rp_partial_bytes(C) + 256; }
+extern "C" int glx_pos_pool_save_floats(int C) { return 6 * C; }
+
+extern "C" int glx_pos_pool_forward(const float* feats, int N, int C, const float* xyz, const float* new_xyz,
+                                    const int32_t* idx, int M, int nsample, const float* w_pos, const float* gamma,
+                                    const float* beta, float* running_mean, float* running_var, float momentum,
+                                    float eps, int training, float* pooled, uint8_t* arg, float* save,
+                                    double* moments, void* workspace, size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(rp_channels_ok(C), "glx_pos_pool_forward: C=%d (16, 32 or 64)", C);
+  GLX_REQUIRE(nsample > 0 && nsample <= 255, "glx_pos_pool_forward: nsample=%d", nsample);
+  GLX_REQUIRE(w_pos && save && moments && (M == 0 || (feats && xyz && new_xyz && idx && pooled && arg)) &&
+                  (training || (running_mean && running_var)),
+              "glx_pos_pool_forward: null pointer");
+  if (!workspace || workspace_bytes < glx_pos_pool_workspace_bytes(C) - 256) {
+    glx_set_error("glx_pos_pool_forward: workspace %zu < %zu bytes", workspace_bytes, glx_pos_pool_workspace_bytes(C) - 256);
+    return GLX_EWORKSPACE;
+  }
+  (void)N;
+  hipStream_t st = (hipStream_t)stream;
+  int nb = (M + RP_THREADS - 1) / RP_THREADS;
+  nb = nb < 1 ? 1 : (nb > RP_MAX_BLOCKS ? RP_MAX_BLOCKS : nb);
+  if (training && M > 0)
+    hipLaunchKernelGGL(k_rp_moments, dim3(nb), dim3(RP_THREADS), 0, st, idx, xyz, new_xyz, M, nsample, (double*)workspace);
+  hipLaunchKernelGGL(k_rp_finalize_fwd, dim3(1), dim3(64), 0, st, (const double*)workspace, M > 0 ? nb : 0,
+                     (double)M * nsample, w_pos, gamma, beta, eps, momentum, training, running_mean, running_var, C, save,
+                     moments);
+  if (M > 0) {
+    const int blocks = rp_blocks(M, C);
+    if (C == 16)
+      hipLaunchKernelGGL((k_rp_forward<16>), dim3(blocks), dim3(RP_THREADS), 0, st, feats, xyz, new_xyz, idx, M, nsample,
+                         (const float*)save, pooled, arg);
+    else if (C == 32)
+      hipLaunchKernelGGL((k_rp_forward<32>), dim3(blocks), dim3(RP_THREADS), 0, st, feats, xyz, new_xyz, idx, M, nsample,
+                         (const float*)save, pooled, arg);
+    else
+      hipLaunchKernelGGL((k_rp_forward<64>), dim3(blocks), dim3(RP_THREADS), 0, st, feats, xyz, new_xyz, idx, M, nsample,
+                         (const float*)save, pooled, arg);
+  }
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+extern "C" int glx_pos_pool_backward(const float* dpooled, const float* pooled, const uint8_t* arg, const int32_t* idx,
+                                     const float* xyz, const float* new_xyz, int M, int nsample, int C, int N,
+                                     const float* w_pos, const float* gamma, const float* save, const double* moments,
+                                     int training, float* dfeats, float* dW, float* dgamma, float* dbeta,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(rp_channels_ok(C), "glx_pos_pool_backward: C=%d (16, 32 or 64)", C);
+  GLX_REQUIRE(w_pos && save && moments && dW && (N == 0 || dfeats) &&
+                  (M == 0 || (dpooled && pooled && arg && idx && xyz && new_xyz)),
+              "glx_pos_pool_backward: null pointer");
+  if (!workspace || workspace_bytes < glx_pos_pool_workspace_bytes(C) - 256) {
+    glx_set_error("glx_pos_pool_backward: workspace %zu < %zu bytes", workspace_bytes, glx_pos_pool_workspace_bytes(C) - 256);
+    return GLX_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  GlxFillJob zj{dfeats, (size_t)N * C * sizeof(float), 0};
+  int rc = glx_fill_multi(&zj, 1, st);
+  if (rc != GLX_OK) return rc;
+  const int blocks = M > 0 ? rp_blocks(M, C) : 0;
+  if (M > 0) {
+    if (C == 16)
+      hipLaunchKernelGGL((k_rp_backward<16>), dim3(blocks), dim3(RP_THREADS), 0, st, dpooled, pooled, arg, idx, xyz, new_xyz,
+                         M, nsample, w_pos, save, dfeats, (double*)workspace);
+    else if (C == 32)
+      hipLaunchKernelGGL((k_rp_backward<32>), dim3(blocks), dim3(RP_THREADS), 0, st, dpooled, pooled, arg, idx, xyz, new_xyz,
+                         M, nsample, w_pos, save, dfeats, (double*)workspace);
+    else
+      hipLaunchKernelGGL((k_rp_backward<64>), dim3(blocks), dim3(RP_THREADS), 0, st, dpooled, pooled, arg, idx, xyz, new_xyz,
+                         M, nsample, w_pos, save, dfeats, (double*)workspace);
+  }
+  hipLaunchKernelGGL(k_rp_finalize_bwd, dim3(1), dim3(64), 0, st, (const double*)workspace, blocks, (double)M * nsample,
+                     moments, w_pos, gamma, save, training, C, dW, dgamma, dbeta);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

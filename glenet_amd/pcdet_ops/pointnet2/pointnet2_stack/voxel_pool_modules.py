@@ -64,6 +64,68 @@ class ReluAddMax(torch.autograd.Function):
         return grad, grad
 
 
+class PosPool(torch.autograd.Function):
+    """max_s relu(feats[idx[m,s]] + BatchNorm(Conv1x1(xyz[idx[m,s]] - new_xyz[m]))) in one pass forward and one
+    backward (csrc/glx_roipool.hip): the position branch + add + ReLU + max-pool of forward() below without any
+    (M, nsample, C) tensor; BatchNorm statistics from the moments of the offsets."""
+
+    @staticmethod
+    def forward(ctx, feats, w_pos, gamma, beta, bn, idx, xyz, new_xyz):
+        import ctypes
+        from .... import _lib
+        feats, w, xyz, new_xyz, idx = (feats.contiguous().float(), w_pos.reshape(w_pos.shape[0], 3).contiguous().float(),
+                                       xyz.contiguous().float(), new_xyz.contiguous().float(), idx.contiguous())
+        _lib.check_cuda(feats, w, xyz, new_xyz, idx)
+        (n, c), (m, ns) = feats.shape, idx.shape
+        dev = feats.device
+        training = bn.training or not bn.track_running_stats
+        pooled = torch.empty((m, c), dtype=torch.float32, device=dev)
+        arg = torch.empty((m, c), dtype=torch.uint8, device=dev)
+        save = torch.empty(_lib.query("glx_pos_pool_save_floats", c), dtype=torch.float32, device=dev)
+        moments = torch.empty(9, dtype=torch.float64, device=dev)
+        ws = _lib.workspace.get(_lib.query("glx_pos_pool_workspace_bytes", c), dev)
+        rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+        _lib.call("glx_pos_pool_forward", feats, n, c, xyz, new_xyz, idx, m, ns, w, gamma, beta, rm, rv,
+                  ctypes.c_float(bn.momentum if bn.momentum is not None else 0.1), ctypes.c_float(bn.eps),
+                  1 if training else 0, pooled, arg, save, moments, ws, _lib.size_arg(ws.numel()))
+        ctx.save_for_backward(feats, w, gamma, pooled, arg, idx, xyz, new_xyz, save, moments)
+        ctx.training, ctx.wshape = training, w_pos.shape
+        ctx.mark_non_differentiable(arg)
+        return pooled, arg
+
+    @staticmethod
+    def backward(ctx, dpooled, _darg):
+        from .... import _lib
+        feats, w, gamma, pooled, arg, idx, xyz, new_xyz, save, moments = ctx.saved_tensors
+        (n, c), (m, ns) = feats.shape, idx.shape
+        dev = feats.device
+        dfeats = torch.empty_like(feats)
+        dw = torch.empty((c, 3), dtype=torch.float32, device=dev)
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+        ws = _lib.workspace.get(_lib.query("glx_pos_pool_workspace_bytes", c), dev)
+        _lib.call("glx_pos_pool_backward", dpooled.contiguous().float(), pooled, arg, idx, xyz, new_xyz, m, ns, c, n, w,
+                  gamma, save, moments, 1 if ctx.training else 0, dfeats, dw, dgamma, dbeta, ws,
+                  _lib.size_arg(ws.numel()))
+        return (dfeats, dw.view(ctx.wshape), dgamma if gamma is not None else None,
+                dbeta if gamma is not None else None, None, None, None, None)
+
+
+def pos_pool(feats, mlp_pos, idx, xyz, new_xyz):
+    """mlp_pos = Sequential(Conv2d(3, C, 1, bias=False), BatchNorm2d(C)) -> pooled (M, C)."""
+    conv, bn = mlp_pos[0], mlp_pos[1]
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return PosPool.apply(feats, conv.weight, bn.weight, bn.bias, bn, idx, xyz, new_xyz)[0]
+
+
+def pos_pool_supported(feats, mlp_pos):
+    conv, bn = mlp_pos[0], mlp_pos[1]
+    return (feats.is_cuda and feats.dtype == torch.float32 and len(mlp_pos) == 2 and conv.bias is None
+            and conv.in_channels == 3 and conv.out_channels in (16, 32, 64) and conv.out_channels == feats.shape[1]
+            and isinstance(bn, (nn.BatchNorm1d, nn.BatchNorm2d)))
+
+
 class NeighborVoxelSAModuleMSG(nn.Module):
     def __init__(self, *, query_ranges, radii, nsamples, mlps, use_xyz=True, pool_method='max_pool'):
         super().__init__()

@@ -124,6 +124,7 @@ class RoIGridPool(nn.Module):
     # (fused kernels, csrc/glx_bn.hip) and the rows past them are selected away (torch.where, not a
     # multiplication: they may hold NaN) on both sides of the 1x1 conv, forward and backward.
     USE_ROWS = True
+    USE_POS_POOL = True
 
     def _trainable_rows(self, rois, tensors):
         if not (self.USE_ROWS and rois.is_cuda and rois.dtype == torch.float32):
@@ -185,12 +186,16 @@ class RoIGridPool(nn.Module):
                 zr, yr, xr = grouper.max_range
                 _lib.call("glx_roi_grid_query", m, z, y, x, ns, float(grouper.radius), zr, yr, xr, grid_xyz,
                           coords, stride, ind, rmin, vsz, index.bitmap, index.prefix, index.rank_to_row, idx)
-                g_feat = GroupRows.apply(feats, idx)                               # (M, ns, c_mid)
-                with torch.no_grad():
-                    keep = (idx[:, :1] >= 0).to(feats.dtype).view(m, 1, 1)
-                    rel = (GroupRows.apply(xyz, idx) - grid_xyz.view(m, 1, 3)) * keep
-                pos = layer._conv_bn_rows(mlp_pos, rel.view(m * ns, 3))           # (M*ns, c_mid)
-                pooled = ReluAddMax.apply(g_feat, pos.view(m, ns, -1))            # (M, c_mid)
+                if self.USE_POS_POOL and voxel_pool_modules.pos_pool_supported(feats, mlp_pos):
+                    # position MLP + add + ReLU + max-pool fused: no (M, ns, C) tensor (csrc/glx_roipool.hip)
+                    pooled = voxel_pool_modules.pos_pool(feats, mlp_pos, idx, xyz, grid_xyz)
+                else:
+                    g_feat = GroupRows.apply(feats, idx)                           # (M, ns, c_mid)
+                    with torch.no_grad():
+                        keep = (idx[:, :1] >= 0).to(feats.dtype).view(m, 1, 1)
+                        rel = (GroupRows.apply(xyz, idx) - grid_xyz.view(m, 1, 3)) * keep
+                    pos = layer._conv_bn_rows(mlp_pos, rel.view(m * ns, 3))       # (M*ns, c_mid)
+                    pooled = ReluAddMax.apply(g_feat, pos.view(m, ns, -1))        # (M, c_mid)
                 outs.append(layer._conv_bn_rows(mlp_out, pooled))                 # (M, c_out)
         return torch.cat(outs, dim=1).view(n, g3, -1)
 

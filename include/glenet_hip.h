@@ -498,6 +498,35 @@ int glx_bn_relu_backward(const float* x, const float* dy, const float* y, int N,
                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * RoI-grid pooling, training path: position MLP (Conv2d(3, C, 1, bias=False) + BatchNorm2d(C), training-mode
+ * statistics or running ones) + add + ReLU + max over the neighbours, fused -- no (M, nsample, C) tensor exists.
+ *   feats (N, C) row-major (the mlps_in output), xyz (N, 3) voxel centres, new_xyz (M, 3) grid points,
+ *   idx (M, nsample) GLOBAL rows as glx_voxel_query_index / glx_roi_grid_query leave them (idx[m,0] < 0: empty
+ *   ball = nsample rows of feature 0 and offset 0), w_pos (C, 3), gamma / beta (C) or NULL, C in {16, 32, 64}.
+ *   pooled (M, C) = max_s relu(feats[idx[m,s]] + BN(w_pos . (xyz[idx[m,s]] - new_xyz[m]))), arg (M, C) uint8 = the
+ *   winning slot (first on ties).  save (glx_pos_pool_save_floats(C) floats) and moments (9 doubles) carry the
+ *   statistics to the backward call.  training != 0: batch statistics over all M * nsample rows (computed from
+ *   the moments of the offsets, fp64), running_mean / running_var updated with `momentum` (unbiased variance);
+ *   training == 0: the running estimates normalise.
+ *   backward: dfeats (N, C) (zero-filled by the call, atomic adds at the winning slots), dW (C, 3), dgamma,
+ *   dbeta (C) -- the exact gradients of the unfused formulation.
+ * Replaces: NeighborVoxelSAModuleMSG.forward lines 91-104 (pcdet/ops/pointnet2/pointnet2_stack/
+ * voxel_pool_modules.py) in training: grouping_operation x 2, mlps_pos, add, ReLU, max_pool2d and their autograd.
+ * ------------------------------------------------------------------------------------ */
+size_t glx_pos_pool_workspace_bytes(int C);
+int glx_pos_pool_save_floats(int C);
+int glx_pos_pool_forward(const float* feats, int N, int C, const float* xyz, const float* new_xyz,
+                         const int32_t* idx, int M, int nsample, const float* w_pos, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                         int training, float* pooled, uint8_t* arg, float* save, double* moments,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int glx_pos_pool_backward(const float* dpooled, const float* pooled, const uint8_t* arg, const int32_t* idx,
+                          const float* xyz, const float* new_xyz, int M, int nsample, int C, int N,
+                          const float* w_pos, const float* gamma, const float* save, const double* moments,
+                          int training, float* dfeats, float* dW, float* dgamma, float* dbeta, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Update of the training step on flat fp32 buffers: gradient-norm clipping + AdamW in two launches.
  * params / grads / exp_avg / exp_avg_sq: n floats each, 16-byte aligned; hyper: DEVICE float[2] =
  * { learning rate, beta1 } (written by the one-cycle schedule, read by a recorded HIP graph); step: DEVICE

@@ -648,3 +648,113 @@ def test_relu_add_max_matches_tensor_ops(dev):
         (ref * w).sum().backward()
         assert torch.equal(a1.grad, a2.grad) and torch.equal(b1.grad, b2.grad)
         assert float(a1.grad[::7].abs().max()) == 0.0
+
+
+def _roi_scene(dev, rng, channels=8, mid=32):
+    from glenet_amd import roi_grid as rg
+    B, vs, pcr = 2, [0.1, 0.1, 0.2], [0.0, 0.0, 0.0, 4.0, 4.8, 2.0]
+    shapes = {"x_conv1": (10, 48, 40), "x_conv2": (5, 24, 20)}
+    strides = {"x_conv1": 1, "x_conv2": 2}
+    feats = {}
+    for name, (Z, Y, X) in shapes.items():
+        idx, _, _ = _voxel_scene(rng, B, Z, Y, X, 0.12)
+        feats[name] = (idx, rng.normal(size=(len(idx), channels)).astype(np.float32), [Z, Y, X])
+    cfg = {n: dict(mlps=[[mid, mid]], query_ranges=[[2, 2, 2]], radii=[0.3 * strides[n]], nsamples=[16]) for n in shapes}
+    torch.manual_seed(4)
+    pool = rg.RoIGridPool({n: channels for n in shapes}, cfg, 3, vs, pcr).to(dev)
+    for m in pool.modules():                      # non-trivial affine parameters
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    rois = np.concatenate([rng.uniform([0.5, 0.5, 0.4], [3.5, 4.3, 1.6], (B, 6, 3)), rng.uniform(0.4, 1.2, (B, 6, 3)),
+                           rng.uniform(-3, 3, (B, 6, 1))], -1).astype(np.float32)
+    rois[1, 5, :3] = [30.0, 30.0, 5.0]            # an RoI outside the scene: empty balls
+    return pool, feats, strides, rois, B
+
+
+def _run_pool(pool, feats, strides, rois, B, dev, pad_rows=0):
+    tensors, leaves = {}, {}
+    for name, (idx, f, shape) in feats.items():
+        leaf = T(f, dev).requires_grad_(True)
+        leaves[name] = leaf
+        if pad_rows:      # shape-static form: capacity rows with garbage behind the live count
+            n = len(idx)
+            fp = torch.cat([leaf, torch.full((pad_rows, f.shape[1]), float("nan"), device=dev)])
+            ip = torch.cat([T(idx, dev), torch.zeros((pad_rows, 4), dtype=torch.int32, device=dev)])
+            st0 = sp.SparseConvTensor(leaf.detach(), T(idx, dev), shape, B)
+            index = st0._ensure_index()
+            cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+            st = sp.SparseConvTensor(fp, ip, shape, B, count=cnt)
+            st._index = sp.core.CellIndex(index.grid, index.bitmap, index.flags, index.prefix, index.rank_to_row,
+                                          index.row_to_rank, n + pad_rows, count=cnt, unique=cnt)
+            tensors[name] = st
+        else:
+            tensors[name] = sp.SparseConvTensor(leaf, T(idx, dev), shape, B)
+    out = pool(T(rois, dev), tensors, strides, B)
+    w = torch.linspace(0.5, 1.5, out.shape[-1], device=dev)
+    pool.zero_grad(set_to_none=True)
+    ((out * w).square().mean() + out.mean()).backward()
+    return (out.detach(), {k: v.grad.clone() for k, v in leaves.items()},
+            {n: p.grad.clone() for n, p in pool.named_parameters()},
+            {n: b.clone() for n, b in pool.named_buffers()})
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_fused_position_pool_equals_the_unfused_training_path(dev, training):
+    """PosPool (csrc/glx_roipool.hip: position conv + BatchNorm from the moments of the offsets + add + ReLU + max,
+    no (M, ns, C) tensor) == the row-major formulation with torch's BatchNorm on the materialised tensors:
+    outputs, gradients of the sparse features, of every parameter, and the running statistics; batch statistics
+    (training) and running statistics (eval with gradients)."""
+    import copy
+    rng = np.random.default_rng(77)
+    pool, feats, strides, rois, B = _roi_scene(dev, rng)
+    pool.train(training)
+    state = copy.deepcopy(pool.state_dict())
+    res = []
+    for fused in (True, False):
+        pool.load_state_dict(state)
+        pool.USE_POS_POOL = fused
+        res.append(_run_pool(pool, feats, strides, rois, B, dev))
+    pool.USE_POS_POOL = True
+    (o1, g1, p1, b1), (o2, g2, p2, b2) = res
+    assert float(o1.abs().max()) > 0 and float((o1[-1] - o1[-2]).abs().max()) > 0
+    np.testing.assert_allclose(o1.cpu().numpy(), o2.cpu().numpy(), rtol=2e-4, atol=2e-5)
+    for k in g1:
+        np.testing.assert_allclose(g1[k].cpu().numpy(), g2[k].cpu().numpy(), rtol=2e-3, atol=2e-6 + 2e-4 * float(g2[k].abs().max()))
+    for k in p1:
+        np.testing.assert_allclose(p1[k].cpu().numpy(), p2[k].cpu().numpy(), rtol=5e-3,
+                                   atol=1e-6 + 5e-4 * float(p2[k].abs().max()), err_msg=k)
+    for k in b1:
+        np.testing.assert_allclose(b1[k].cpu().numpy(), b2[k].cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+def test_roi_grid_training_path_on_shape_static_tensors(dev):
+    """The sync-free training path (grid-point kernel + index query + live-row handling of mlps_in) on
+    capacity-sized sparse tensors whose padding rows hold NaN == the exact-shape tensors, and == the generic
+    module path (voxel centres / coordinates / counts built with tensor ops as voxelrcnn_head.py:106-191 does)."""
+    import copy
+    rng = np.random.default_rng(78)
+    pool, feats, strides, rois, B = _roi_scene(dev, rng)
+    pool.train()
+    state = copy.deepcopy(pool.state_dict())
+    exact = _run_pool(pool, feats, strides, rois, B, dev)
+    pool.load_state_dict(state)
+    static = _run_pool(pool, feats, strides, rois, B, dev, pad_rows=37)
+    pool.load_state_dict(state)
+    pool.USE_ROWS = False
+    try:
+        generic = _run_pool(pool, feats, strides, rois, B, dev)
+    finally:
+        pool.USE_ROWS = True
+    for other, tol in ((static, 1e-5), (generic, 2e-4)):
+        np.testing.assert_allclose(exact[0].cpu().numpy(), other[0].cpu().numpy(), rtol=tol, atol=tol)
+        for k in exact[1]:
+            n = exact[1][k].shape[0]
+            np.testing.assert_allclose(exact[1][k].cpu().numpy(), other[1][k][:n].cpu().numpy(), rtol=5e-3,
+                                       atol=1e-6 + 5e-4 * float(exact[1][k].abs().max()))
+        for k in exact[2]:
+            np.testing.assert_allclose(exact[2][k].cpu().numpy(), other[2][k].cpu().numpy(), rtol=5e-3,
+                                       atol=1e-6 + 5e-4 * float(exact[2][k].abs().max()), err_msg=k)
+        for k in exact[3]:
+            np.testing.assert_allclose(exact[3][k].cpu().numpy(), other[3][k].cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
+    assert torch.isfinite(static[0]).all()
