@@ -685,7 +685,7 @@ def _run_pool(pool, feats, strides, rois, B, dev, pad_rows=0):
             index = st0._ensure_index()
             cnt = torch.tensor([n], dtype=torch.int32, device=dev)
             st = sp.SparseConvTensor(fp, ip, shape, B, count=cnt)
-            st._index = sp.core.CellIndex(index.grid, index.bitmap, index.flags, index.prefix, index.rank_to_row,
+            st._index = sp.CellIndex(index.grid, index.bitmap, index.flags, index.prefix, index.rank_to_row,
                                           index.row_to_rank, n + pad_rows, count=cnt, unique=cnt)
             tensors[name] = st
         else:
