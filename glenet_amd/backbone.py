@@ -208,7 +208,8 @@ class StaticFramePipeline:
         with torch.no_grad():
             bd = voxelize_batch(points, batch_idx, self.B, self.cfg, train=self.train_cap)
             plan = self.model.plan(bd["voxel_coords"], self.B, index=bd["voxel_index"])
-        self.capacities = {key: int(rs.N_out * headroom) + 64 for key, rs in plan.items()
+        # multiples of 128 rows: row-wise products on these tensors can then be split along K (roi_grid)
+        self.capacities = {key: (int(rs.N_out * headroom) + 64 + 127) // 128 * 128 for key, rs in plan.items()
                            if not rs.subm}
         return self.capacities
 

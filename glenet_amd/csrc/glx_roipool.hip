@@ -24,7 +24,7 @@
 #include "glx_fill.h"
 
 #define RP_THREADS 256
-#define RP_MAX_BLOCKS 1024
+#define RP_MAX_BLOCKS 512
 #define RP_MAXC 64
 
 // `save` (6 * C floats, forward -> backward): mean[C], invstd[C], folded weights Wp[C][3], folded bias bp[C]
@@ -59,21 +59,41 @@ __global__ __launch_bounds__(RP_THREADS) void k_rp_moments(const int* __restrict
   }
 }
 
-// one block of C threads: statistics -> folded affine map, saved mean / invstd, running estimates
-__global__ void k_rp_finalize_fwd(const double* __restrict__ partial, int nparts, double n, const float* __restrict__ w,
-                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                  float momentum, int training, float* __restrict__ running_mean,
-                                  float* __restrict__ running_var, int C, float* __restrict__ save,
-                                  double* __restrict__ moments) {
-  __shared__ double S[9];
-  if (threadIdx.x < 9) {
-    double a = 0;
-    if (training)
-      for (int b = 0; b < nparts; ++b) a += partial[(long long)b * 9 + threadIdx.x];
-    S[threadIdx.x] = a;
-    moments[threadIdx.x] = a;
+// Column sums of partial[nparts][Q] (Q <= RP_FIN_THREADS) by one block: thread (col, g) adds parts g, g + G, ...
+// in a fixed order, the G groups are combined in LDS -> tot[col].  (A serial loop over 1024 partials per thread
+// made the one-block finalize kernels the slowest launches of the stage: 263 us.)
+#define RP_FIN_THREADS 1024
+__device__ __forceinline__ void rp_column_sums(const double* __restrict__ partial, int nparts, int Q, double* s_grp,
+                                               double* tot) {
+  const int G = RP_FIN_THREADS / Q;
+  const int col = threadIdx.x % Q, g = threadIdx.x / Q;
+  double a = 0;
+  if (g < G)
+    for (int b = g; b < nparts; b += G) a += partial[(long long)b * Q + col];
+  if (g < G) s_grp[g * Q + col] = a;
+  __syncthreads();
+  if (g == 0) {
+    for (int k = 1; k < G; ++k) a += s_grp[k * Q + col];
+    tot[col] = a;
   }
   __syncthreads();
+}
+
+// one block: statistics -> folded affine map, saved mean / invstd, running estimates
+__global__ __launch_bounds__(RP_FIN_THREADS) void k_rp_finalize_fwd(
+    const double* __restrict__ partial, int nparts, double n, const float* __restrict__ w,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum, int training,
+    float* __restrict__ running_mean, float* __restrict__ running_var, int C, float* __restrict__ save,
+    double* __restrict__ moments) {
+  __shared__ double s_grp[RP_FIN_THREADS];
+  __shared__ double S[9];
+  if (training) {
+    rp_column_sums(partial, nparts, 9, s_grp, S);
+  } else {
+    if (threadIdx.x < 9) S[threadIdx.x] = 0;
+    __syncthreads();
+  }
+  if (threadIdx.x < 9) moments[threadIdx.x] = S[threadIdx.x];
   const int c = threadIdx.x;
   if (c >= C) return;
   const double w0 = w[c * 3], w1 = w[c * 3 + 1], w2 = w[c * 3 + 2];
@@ -184,21 +204,23 @@ __global__ __launch_bounds__(RP_THREADS) void k_rp_backward(const float* __restr
     if (sub == 0) {
       double a = 0;
       for (int k = 0; k < PPB; ++k) a += red[k * C + c];
-      partial[((long long)blockIdx.x * C + c) * 5 + q] = a;
+      partial[((long long)blockIdx.x * 5 + q) * C + c] = a;
     }
     __syncthreads();
   }
 }
 
-__global__ void k_rp_finalize_bwd(const double* __restrict__ partial, int nparts, double n, const double* __restrict__ moments,
-                                  const float* __restrict__ w, const float* __restrict__ gamma,
-                                  const float* __restrict__ save, int training, int C, float* __restrict__ dW,
-                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
+__global__ __launch_bounds__(RP_FIN_THREADS) void k_rp_finalize_bwd(
+    const double* __restrict__ partial, int nparts, double n, const double* __restrict__ moments,
+    const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ save, int training,
+    int C, float* __restrict__ dW, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double s_grp[RP_FIN_THREADS];
+  __shared__ double tot[RP_MAXC * 5];
+  rp_column_sums(partial, nparts, 5 * C, s_grp, tot);       // tot[q * C + c]
   const int c = threadIdx.x;
   if (c >= C) return;
-  double s[5] = {0, 0, 0, 0, 0};
-  for (int b = 0; b < nparts; ++b)
-    for (int q = 0; q < 5; ++q) s[q] += partial[((long long)b * C + c) * 5 + q];
+  double s[5];
+  for (int q = 0; q < 5; ++q) s[q] = tot[q * C + c];
   const double mean = save[c], invstd = save[C + c];
   const double a = (gamma ? gamma[c] : 1.f) * invstd;
   if (dbeta) dbeta[c] = (float)s[0];
@@ -246,7 +268,7 @@ extern "C" int glx_pos_pool_forward(const float* feats, int N, int C, const floa
   nb = nb < 1 ? 1 : (nb > RP_MAX_BLOCKS ? RP_MAX_BLOCKS : nb);
   if (training && M > 0)
     hipLaunchKernelGGL(k_rp_moments, dim3(nb), dim3(RP_THREADS), 0, st, idx, xyz, new_xyz, M, nsample, (double*)workspace);
-  hipLaunchKernelGGL(k_rp_finalize_fwd, dim3(1), dim3(64), 0, st, (const double*)workspace, M > 0 ? nb : 0,
+  hipLaunchKernelGGL(k_rp_finalize_fwd, dim3(1), dim3(RP_FIN_THREADS), 0, st, (const double*)workspace, M > 0 ? nb : 0,
                      (double)M * nsample, w_pos, gamma, beta, eps, momentum, training, running_mean, running_var, C, save,
                      moments);
   if (M > 0) {
@@ -294,7 +316,7 @@ extern "C" int glx_pos_pool_backward(const float* dpooled, const float* pooled, 
       hipLaunchKernelGGL((k_rp_backward<64>), dim3(blocks), dim3(RP_THREADS), 0, st, dpooled, pooled, arg, idx, xyz, new_xyz,
                          M, nsample, w_pos, save, dfeats, (double*)workspace);
   }
-  hipLaunchKernelGGL(k_rp_finalize_bwd, dim3(1), dim3(64), 0, st, (const double*)workspace, blocks, (double)M * nsample,
+  hipLaunchKernelGGL(k_rp_finalize_bwd, dim3(1), dim3(RP_FIN_THREADS), 0, st, (const double*)workspace, blocks, (double)M * nsample,
                      moments, w_pos, gamma, save, training, C, dW, dgamma, dbeta);
   GLX_LAUNCH_CHECK();
   return GLX_OK;

@@ -243,21 +243,25 @@ class NeighborVoxelSAModuleMSG(nn.Module):
     # statistics and results are those of the module path (tested), which stays available
     # (USE_ROW_MAJOR = False) as the statement-by-statement mirror of voxel_pool_modules.py:88-108.
     USE_ROW_MAJOR = True
-    SPLITK_MIN_ROWS = 1 << 16
+    SPLITK_MIN_ROWS = 1 << 13
+
+    @staticmethod
+    def _linear_rows(x2d, w, bias=None):
+        """x2d (rows, C_in) @ w^T.  Tall-skinny products (tens of thousands of rows x <= 64 channels) run as 128
+        batched products, so that the weight gradient autograd derives is a batched GEMM + a sum over the batch
+        (split-K) instead of one (C_out x C_in) GEMM with K = rows, which hipBLASLt runs on a single 32x32 tile
+        (300 us for 60 k rows; 2.6 ms for the 1.4 M rows of the position conv before it was fused away)."""
+        rows = x2d.shape[0]
+        if rows >= NeighborVoxelSAModuleMSG.SPLITK_MIN_ROWS and rows % 128 == 0 and bias is None:
+            return torch.bmm(x2d.view(128, rows // 128, -1), w.t().unsqueeze(0).expand(128, -1, -1)).view(rows, -1)
+        return F.linear(x2d, w, bias)
 
     @staticmethod
     def _conv_bn_rows(seq, x2d):
         """Sequential(Conv(k=1, bias=False), BatchNorm[, ReLU]) on a (rows, C_in) tensor."""
-        conv, bn = seq[0], seq[1]
+        conv = seq[0]
         w = conv.weight.reshape(conv.out_channels, conv.in_channels)
-        rows = x2d.shape[0]
-        if rows >= NeighborVoxelSAModuleMSG.SPLITK_MIN_ROWS and rows % 128 == 0 and conv.bias is None:
-            # tall-skinny product (1.4 M rows x 3 -> 32): as 128 batched products, so that the weight
-            # gradient autograd derives is a batched GEMM + a sum over the batch (split-K) instead of
-            # one (32 x 3) GEMM with K = 1.4 M, which hipBLASLt runs on a single tile for 2.6 ms
-            y = torch.bmm(x2d.view(128, rows // 128, -1), w.t().unsqueeze(0).expand(128, -1, -1)).view(rows, -1)
-        else:
-            y = F.linear(x2d, w, conv.bias)
+        y = NeighborVoxelSAModuleMSG._linear_rows(x2d, w, conv.bias)
         return NeighborVoxelSAModuleMSG._bn_rows(seq, y)
 
     @staticmethod

@@ -145,7 +145,7 @@ class RoIGridPool(nn.Module):
         if st.count is not None:
             live = (torch.arange(x.shape[0], device=x.device) < st.count).view(-1, 1)
             x = torch.where(live, x, x.new_zeros(()))
-        y = F.linear(x, w, conv.bias)
+        y = layer._linear_rows(x, w, conv.bias)
         if core.can_fuse_train_bn(bn, y):
             if live is not None:
                 y = torch.where(live, y, y.new_zeros(()))        # its backward cleans the gradient rows

@@ -590,7 +590,7 @@ def test_roi_grid_pool_row_major_training_path_equals_conv_formulation(dev):
                                    atol=2e-5 * max(1e-3, float(q2.grad.abs().max())), err_msg=n)
     for (n, u), (_, v) in zip(a.named_buffers(), b.named_buffers()):
         np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=n)
-    voxel_pool_modules.NeighborVoxelSAModuleMSG.SPLITK_MIN_ROWS = 1 << 16
+    voxel_pool_modules.NeighborVoxelSAModuleMSG.SPLITK_MIN_ROWS = 1 << 13
 
 
 def test_group_rows_and_gradient_match_indexing(dev):
