@@ -1,6 +1,6 @@
 """Drop-in for `pcdet.ops.pointnet2.pointnet2_stack.pointnet2_stack_cuda`
-(pointnet2_stack/src/pointnet2_api.cpp:12-31): the entry points on GLENet's path.  FPS,
-three_nn / three_interpolate and vector-pool (PV-RCNN(++) only) are the next tier."""
+(pointnet2_stack/src/pointnet2_api.cpp:12-31): every export of the module -- the entry points on GLENet's
+path and the PV-RCNN(++) set-abstraction family (FPS, three_nn / three_interpolate, vector pool)."""
 from .... import _lib
 from ...._lib import call
 
@@ -125,17 +125,58 @@ def three_interpolate_grad_wrapper(grad_out, idx, weight, grad_features):
     call("glx_three_interpolate_grad", idx.shape[0], grad_out.shape[1], grad_out, idx, weight, grad_features)
 
 
-def _next_tier(name):
-    def f(*a, **k):
-        raise NotImplementedError("%s: PV-RCNN(++) operator, not on GLENet's hot path "
-                                  "(SURVEY.md 8f rank 2); not built yet" % name)
-    return f
+def _vp_ws(m, device):
+    return _lib.workspace.get(_lib.query("glx_vector_pool_workspace_bytes", m), device)
 
 
-for _n in ("query_stacked_local_neighbor_idxs_wrapper_stack",
-           "query_three_nn_by_stacked_local_idxs_wrapper_stack", "vector_pool_wrapper",
-           "vector_pool_grad_wrapper"):
-    globals()[_n] = _next_tier(_n)
+def query_stacked_local_neighbor_idxs_wrapper_stack(support_xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt,
+                                                    stack_neighbor_idxs, start_len, cumsum, avg_length_of_neighbor_idxs,
+                                                    max_neighbour_distance, nsample, neighbor_type):
+    """vector_pool.cpp:34-72: fills stack_neighbor_idxs / start_len (M,2) / cumsum (1,) in place."""
+    _lib.check_cuda(support_xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, stack_neighbor_idxs, start_len, cumsum)
+    m = new_xyz.shape[0]
+    ws = _vp_ws(m, new_xyz.device)
+    call("glx_query_stacked_local_neighbor_idxs", support_xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt,
+         xyz_batch_cnt.shape[0], m, stack_neighbor_idxs, start_len, cumsum, int(avg_length_of_neighbor_idxs),
+         float(max_neighbour_distance), int(nsample), int(neighbor_type), ws, _lib.size_arg(ws.numel()))
+    return 0
+
+
+def query_three_nn_by_stacked_local_idxs_wrapper_stack(support_xyz, new_xyz, new_xyz_grid_centers, new_xyz_grid_idxs,
+                                                       new_xyz_grid_dist2, stack_neighbor_idxs, start_len, M,
+                                                       num_total_grids):
+    """vector_pool.cpp:75-112."""
+    _lib.check_cuda(support_xyz, new_xyz_grid_centers, new_xyz_grid_idxs, new_xyz_grid_dist2, stack_neighbor_idxs,
+                    start_len)
+    call("glx_query_three_nn_by_stacked_local_idxs", support_xyz, new_xyz_grid_centers, new_xyz_grid_idxs,
+         new_xyz_grid_dist2, stack_neighbor_idxs, start_len, int(M), int(num_total_grids))
+    return 0
+
+
+def vector_pool_wrapper(support_xyz, xyz_batch_cnt, support_features, new_xyz, new_xyz_batch_cnt, new_features,
+                        new_local_xyz, point_cnt_of_grid, grouped_idxs, num_grid_x, num_grid_y, num_grid_z,
+                        max_neighbour_distance, use_xyz, num_max_sum_points, nsample, neighbor_type, pooling_type):
+    """vector_pool.cpp:115-170 -> cum_sum (python int, as the reference's cudaMemcpy returns it)."""
+    import torch
+    _lib.check_cuda(support_xyz, xyz_batch_cnt, support_features, new_xyz, new_xyz_batch_cnt, new_features,
+                    new_local_xyz, point_cnt_of_grid, grouped_idxs)
+    m = new_xyz.shape[0]
+    cum = torch.zeros(1, dtype=torch.int32, device=new_xyz.device)
+    ws = _vp_ws(m, new_xyz.device)
+    call("glx_vector_pool", support_xyz, support_features, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt,
+         xyz_batch_cnt.shape[0], m, support_features.shape[1], new_features.shape[1], int(num_grid_x), int(num_grid_y),
+         int(num_grid_z), float(max_neighbour_distance), 1 if use_xyz else 0, int(num_max_sum_points), int(nsample),
+         int(neighbor_type), int(pooling_type), new_features, new_local_xyz, point_cnt_of_grid, grouped_idxs, cum, ws,
+         _lib.size_arg(ws.numel()))
+    return int(cum.item())
+
+
+def vector_pool_grad_wrapper(grad_new_features, point_cnt_of_grid, grouped_idxs, grad_support_features):
+    """vector_pool.cpp:173-200."""
+    _lib.check_cuda(grad_new_features, point_cnt_of_grid, grouped_idxs, grad_support_features)
+    call("glx_vector_pool_grad", grad_new_features, point_cnt_of_grid, grouped_idxs, grouped_idxs.shape[0],
+         grad_support_features.shape[1], grad_new_features.shape[1], point_cnt_of_grid.shape[1], grad_support_features)
+    return 0
 
 
 def voxel_pool_agg_wrapper(M, nsample, Cm, Co, feats, xyz, new_xyz, idx, empty, w_pos, b_pos, w_out,

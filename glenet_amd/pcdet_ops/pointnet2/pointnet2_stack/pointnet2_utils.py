@@ -188,3 +188,97 @@ class ThreeInterpolate(Function):
 
 
 three_interpolate = ThreeInterpolate.apply
+
+
+class ThreeNNForVectorPoolByTwoStep(Function):
+    """pointnet2_utils.py:306-352: local neighbour lists (with the host retry loop that grows the buffer), then
+    the three nearest list members of every grid centre -> (dist (M,G,3), idx (M,G,3) int32, avg_length tensor)."""
+
+    @staticmethod
+    def forward(ctx, support_xyz, xyz_batch_cnt, new_xyz, new_xyz_grid_centers, new_xyz_batch_cnt,
+                max_neighbour_distance, nsample, neighbor_type, avg_length_of_neighbor_idxs, num_total_grids,
+                neighbor_distance_multiplier):
+        num_new_xyz = new_xyz.shape[0]
+        new_xyz_grid_dist2 = new_xyz_grid_centers.new_zeros(new_xyz_grid_centers.shape)
+        new_xyz_grid_idxs = new_xyz_grid_centers.new_zeros(new_xyz_grid_centers.shape).int().fill_(-1)
+        while True:
+            num_max_sum_points = avg_length_of_neighbor_idxs * num_new_xyz
+            stack_neighbor_idxs = new_xyz_grid_idxs.new_zeros(max(num_max_sum_points, 1))
+            start_len = new_xyz_grid_idxs.new_zeros(num_new_xyz, 2).int()
+            cumsum = new_xyz_grid_idxs.new_zeros(1)
+            pointnet2.query_stacked_local_neighbor_idxs_wrapper_stack(
+                support_xyz.contiguous(), _int(xyz_batch_cnt).contiguous(), new_xyz.contiguous(),
+                _int(new_xyz_batch_cnt).contiguous(), stack_neighbor_idxs, start_len, cumsum,
+                avg_length_of_neighbor_idxs, max_neighbour_distance * neighbor_distance_multiplier, nsample,
+                neighbor_type)
+            total = int(cumsum[0].item())
+            avg_length_of_neighbor_idxs = total // num_new_xyz + int(total % num_new_xyz > 0)
+            if total <= num_max_sum_points:
+                break
+        stack_neighbor_idxs = stack_neighbor_idxs[:max(total, 1)]
+        pointnet2.query_three_nn_by_stacked_local_idxs_wrapper_stack(
+            support_xyz.contiguous(), new_xyz.contiguous(), new_xyz_grid_centers.contiguous(), new_xyz_grid_idxs,
+            new_xyz_grid_dist2, stack_neighbor_idxs.contiguous(), start_len, num_new_xyz, num_total_grids)
+        return torch.sqrt(new_xyz_grid_dist2), new_xyz_grid_idxs, torch.tensor(avg_length_of_neighbor_idxs)
+
+    @staticmethod
+    def backward(ctx, *a):
+        return (None,) * 11
+
+
+three_nn_for_vector_pool_by_two_step = ThreeNNForVectorPoolByTwoStep.apply
+
+
+class VectorPoolWithVoxelQuery(Function):
+    """pointnet2_utils.py:358-448: sub-voxel average (pooling_type 0) / first-point (1) pooling of the support
+    features around every new point -> (new_features (M, G * c_each), new_local_xyz (M, 3G),
+    num_mean_points_per_grid, point_cnt_of_grid); gradient w.r.t. support_features."""
+
+    @staticmethod
+    def forward(ctx, support_xyz, xyz_batch_cnt, support_features, new_xyz, new_xyz_batch_cnt, num_grid_x, num_grid_y,
+                num_grid_z, max_neighbour_distance, num_c_out_each_grid, use_xyz, num_mean_points_per_grid=100,
+                nsample=-1, neighbor_type=0, pooling_type=0):
+        for t in (support_xyz, support_features, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt):
+            assert t.is_contiguous()
+        num_total_grids = num_grid_x * num_grid_y * num_grid_z
+        num_c_out = num_c_out_each_grid * num_total_grids
+        N, num_c_in = support_features.shape
+        M = new_xyz.shape[0]
+        assert num_c_in % num_c_out_each_grid == 0, \
+            'the input channels (%d) should be an integral multiple of num_c_out_each_grid(%d)' % (num_c_in, num_c_out_each_grid)
+        xbc, nbc = _int(xyz_batch_cnt), _int(new_xyz_batch_cnt)
+        while True:
+            new_features = support_features.new_zeros((M, num_c_out))
+            new_local_xyz = support_features.new_zeros((M, 3 * num_total_grids))
+            point_cnt_of_grid = xbc.new_zeros((M, num_total_grids))
+            num_max_sum_points = num_mean_points_per_grid * M
+            grouped_idxs = xbc.new_zeros((max(num_max_sum_points, 1), 3))
+            num_cum_sum = pointnet2.vector_pool_wrapper(
+                support_xyz, xbc, support_features, new_xyz, nbc, new_features, new_local_xyz, point_cnt_of_grid,
+                grouped_idxs, num_grid_x, num_grid_y, num_grid_z, max_neighbour_distance, use_xyz, num_max_sum_points,
+                nsample, neighbor_type, pooling_type)
+            num_mean_points_per_grid = num_cum_sum // M + int(num_cum_sum % M > 0)
+            if num_cum_sum <= num_max_sum_points:
+                break
+        grouped_idxs = grouped_idxs[:num_cum_sum]
+        normalizer = torch.clamp_min(point_cnt_of_grid[:, :, None].float(), min=1e-6)
+        new_features = (new_features.view(-1, num_total_grids, num_c_out_each_grid) / normalizer).view(-1, num_c_out)
+        if use_xyz:
+            new_local_xyz = (new_local_xyz.view(-1, num_total_grids, 3) / normalizer).view(-1, num_total_grids * 3)
+        num_mean_points_per_grid = torch.Tensor([num_mean_points_per_grid]).int()
+        nsample = torch.Tensor([nsample]).int()
+        ctx.vector_pool_for_backward = (point_cnt_of_grid, grouped_idxs, N, num_c_in)
+        ctx.mark_non_differentiable(new_local_xyz, num_mean_points_per_grid, nsample, point_cnt_of_grid)
+        return new_features, new_local_xyz, num_mean_points_per_grid, point_cnt_of_grid
+
+    @staticmethod
+    def backward(ctx, grad_new_features, grad_local_xyz, grad_num_cum_sum, grad_point_cnt_of_grid):
+        point_cnt_of_grid, grouped_idxs, N, num_c_in = ctx.vector_pool_for_backward
+        grad_support_features = grad_new_features.new_zeros((N, num_c_in))
+        if grouped_idxs.shape[0] > 0:
+            pointnet2.vector_pool_grad_wrapper(grad_new_features.contiguous(), point_cnt_of_grid,
+                                               grouped_idxs.contiguous(), grad_support_features)
+        return (None, None, grad_support_features) + (None,) * 12
+
+
+vector_pool_with_voxel_query_op = VectorPoolWithVoxelQuery.apply

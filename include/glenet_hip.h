@@ -498,6 +498,47 @@ int glx_bn_relu_backward(const float* x, const float* dy, const float* y, int N,
                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * VectorPool family of PV-RCNN++.  Output slots are laid out in ascending new-point order
+ * (the reference's atomicAdd hands them out in a run-dependent order); everything else follows the sequential
+ * scan over a frame's support points of the CUDA kernels.  workspace: glx_vector_pool_workspace_bytes(M).
+ *   glx_query_stacked_local_neighbor_idxs: per new point the first min(nsample, 1000) support points inside the
+ *     ball (neighbor_type 1) or cube of half-width max_dist, GLOBAL indices; start_len (M,2) [offset, length],
+ *     cumsum (device int) = total; segments beyond avg_length * M are dropped / truncated (the caller retries).
+ *     Replaces query_stacked_local_neighbor_idxs_wrapper_stack (vector_pool.cpp:34-72, vector_pool_gpu.cu:122-233).
+ *   glx_query_three_nn_by_stacked_local_idxs: three nearest list members per grid centre -> idx / squared distance
+ *     (M, G, 3); idx -1 and 1e40 (inf in float) for an empty list.  Replaces
+ *     query_three_nn_by_stacked_local_idxs_wrapper_stack (vector_pool.cpp:75-112, vector_pool_gpu.cu:19-119).
+ *   glx_vector_pool: sums of the support features (channel i folded onto i % (C_out / G)) and of the offsets per
+ *     sub-voxel of the local cube, point counts, and one row [support idx, new idx, sub-voxel] per pooled point;
+ *     pooling_type 0 = every point (avg after the caller's division), 1 = the first point per sub-voxel.  Outputs
+ *     arrive zero-filled.  cum_sum (device int) = rows needed; when it exceeds num_max_sum_points NOTHING is
+ *     written (the caller's retry loop re-allocates; this call synchronises the stream once to know).
+ *     Replaces vector_pool_wrapper (vector_pool.cpp:115-170, vector_pool_gpu.cu:243-430).
+ *   glx_vector_pool_grad: grad_support[s, c] += grad_new[p, g * cg + c % cg] / max(count[p, g], 1) per row
+ *     (float atomics); grad_support arrives zero-filled.  Replaces vector_pool_grad_wrapper
+ *     (vector_pool.cpp:173-200, vector_pool_gpu.cu:433-480).
+ * ------------------------------------------------------------------------------------ */
+size_t glx_vector_pool_workspace_bytes(int M);
+int glx_query_stacked_local_neighbor_idxs(const float* support_xyz, const int32_t* xyz_batch_cnt,
+                                          const float* new_xyz, const int32_t* new_xyz_batch_cnt, int B, int M,
+                                          int32_t* stack_neighbor_idxs, int32_t* start_len, int32_t* cumsum,
+                                          int avg_length, float max_dist, int nsample, int neighbor_type,
+                                          void* workspace, size_t workspace_bytes, void* stream);
+int glx_query_three_nn_by_stacked_local_idxs(const float* support_xyz, const float* new_xyz_grid_centers,
+                                             int32_t* new_xyz_grid_idxs, float* new_xyz_grid_dist2,
+                                             const int32_t* stack_neighbor_idxs, const int32_t* start_len, int M,
+                                             int num_total_grids, void* stream);
+int glx_vector_pool(const float* support_xyz, const float* support_features, const int32_t* xyz_batch_cnt,
+                    const float* new_xyz, const int32_t* new_xyz_batch_cnt, int B, int M, int num_c_in,
+                    int num_c_out, int num_grid_x, int num_grid_y, int num_grid_z, float max_dist, int use_xyz,
+                    int num_max_sum_points, int nsample, int neighbor_type, int pooling_type, float* new_features,
+                    float* new_local_xyz, int32_t* point_cnt_of_grid, int32_t* grouped_idxs, int32_t* cum_sum,
+                    void* workspace, size_t workspace_bytes, void* stream);
+int glx_vector_pool_grad(const float* grad_new_features, const int32_t* point_cnt_of_grid,
+                         const int32_t* grouped_idxs, int num_idxs, int num_c_in, int num_c_out,
+                         int num_total_grids, float* grad_support_features, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * RoI-grid pooling, training path: position MLP (Conv2d(3, C, 1, bias=False) + BatchNorm2d(C), training-mode
  * statistics or running ones) + add + ReLU + max over the neighbours, fused -- no (M, nsample, C) tensor exists.
  *   feats (N, C) row-major (the mlps_in output), xyz (N, 3) voxel centres, new_xyz (M, 3) grid points,

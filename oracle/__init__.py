@@ -474,3 +474,81 @@ def three_interpolate_grad(grad_out, idx, weight, M):
     g = np.zeros((int(M), grad_out.shape[1]), np.float32)
     lib().orc_three_interpolate_grad(len(idx), grad_out.shape[1], _f(grad_out), _i(idx), _f(weight), _f(g))
     return g
+
+
+# ------------------------------------------------------------------------------ vector pool (PV-RCNN++)
+def query_stacked_local_neighbor_idxs(support_xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, avg_length,
+                                      max_dist, nsample, neighbor_type):
+    """One call of query_stacked_local_neighbor_idxs_wrapper_stack -> (stack_neighbor_idxs (avg*M,), start_len (M,2),
+    cumsum).  Segment order = ascending new-point index (see glenet_oracle.c)."""
+    sx, nx = _f32(support_xyz), _f32(new_xyz)
+    xbc, nbc = _i32(xyz_batch_cnt), _i32(new_xyz_batch_cnt)
+    m = len(nx)
+    stack = np.zeros(max(avg_length * m, 1), np.int32)
+    start_len = np.zeros((m, 2), np.int32)
+    cum = lib().orc_query_stacked_local_neighbor_idxs(_f(sx), _i(xbc), _f(nx), _i(nbc), len(xbc), m, _i(stack),
+                                                      _i(start_len), int(avg_length), ctypes.c_float(max_dist),
+                                                      int(nsample), int(neighbor_type))
+    return stack, start_len, int(cum)
+
+
+def three_nn_for_vector_pool_by_two_step(support_xyz, xyz_batch_cnt, new_xyz, new_xyz_grid_centers, new_xyz_batch_cnt,
+                                         max_neighbour_distance, nsample, neighbor_type, avg_length, num_total_grids,
+                                         neighbor_distance_multiplier):
+    """ThreeNNForVectorPoolByTwoStep.forward, pointnet2_utils.py:306-352 (the host retry loop included)
+    -> (dist (M,G,3), idx (M,G,3), avg_length)."""
+    m = len(new_xyz)
+    while True:
+        stack, start_len, cum = query_stacked_local_neighbor_idxs(
+            support_xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, avg_length,
+            max_neighbour_distance * neighbor_distance_multiplier, nsample, neighbor_type)
+        max_sum = avg_length * m
+        avg_length = cum // m + int(cum % m > 0)
+        if cum <= max_sum:
+            break
+    centers = _f32(new_xyz_grid_centers)
+    d2 = np.zeros(centers.shape, np.float32)
+    idx = np.full(centers.shape, -1, np.int32)
+    stack = np.ascontiguousarray(stack[:cum])
+    lib().orc_query_three_nn_by_stacked_local_idxs(_f(_f32(support_xyz)), _f(centers), _i(idx), _f(d2), _i(stack),
+                                                   _i(start_len), m, int(num_total_grids))
+    with np.errstate(invalid="ignore"):
+        return np.sqrt(d2), idx, avg_length
+
+
+def vector_pool(support_xyz, xyz_batch_cnt, support_features, new_xyz, new_xyz_batch_cnt, num_grid, max_dist,
+                num_c_out_each_grid, use_xyz, num_mean_points_per_grid=100, nsample=-1, neighbor_type=0, pooling_type=0):
+    """VectorPoolWithVoxelQuery.forward, pointnet2_utils.py:360-431 -> (new_features, new_local_xyz,
+    num_mean_points_per_grid, point_cnt_of_grid, grouped_idxs)."""
+    sx, sf, nx = _f32(support_xyz), _f32(support_features), _f32(new_xyz)
+    xbc, nbc = _i32(xyz_batch_cnt), _i32(new_xyz_batch_cnt)
+    gx, gy, gz = num_grid
+    G = gx * gy * gz
+    c_out = num_c_out_each_grid * G
+    m, c_in = len(nx), sf.shape[1]
+    while True:
+        nf = np.zeros((m, c_out), np.float32)
+        nl = np.zeros((m, 3 * G), np.float32)
+        pc = np.zeros((m, G), np.int32)
+        max_sum = num_mean_points_per_grid * m
+        gi = np.zeros((max(max_sum, 1), 3), np.int32)
+        cum = lib().orc_vector_pool(_f(sx), _f(sf), _i(xbc), _f(nx), _i(nbc), len(xbc), m, c_in, c_out, gx, gy, gz,
+                                    ctypes.c_float(max_dist), 1 if use_xyz else 0, int(max_sum), int(nsample),
+                                    int(neighbor_type), int(pooling_type), _f(nf), _f(nl), _i(pc), _i(gi))
+        num_mean_points_per_grid = cum // m + int(cum % m > 0)
+        if cum <= max_sum:
+            break
+    gi = gi[:cum]
+    norm = np.clip(pc[:, :, None].astype(np.float32), 1e-6, None)
+    nf = (nf.reshape(-1, G, num_c_out_each_grid) / norm).reshape(-1, c_out)
+    if use_xyz:
+        nl = (nl.reshape(-1, G, 3) / norm).reshape(-1, G * 3)
+    return nf, nl, num_mean_points_per_grid, pc, gi
+
+
+def vector_pool_grad(grad_new_features, point_cnt_of_grid, grouped_idxs, N, num_c_in):
+    g = _f32(grad_new_features)
+    pc, gi = _i32(point_cnt_of_grid), _i32(grouped_idxs)
+    out = np.zeros((int(N), int(num_c_in)), np.float32)
+    lib().orc_vector_pool_grad(_f(g), _i(pc), _i(gi), len(gi), int(num_c_in), g.shape[1], pc.shape[1], _f(out))
+    return out

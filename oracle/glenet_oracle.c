@@ -970,3 +970,159 @@ ORC_API void orc_three_interpolate_grad(int N, int C, const float* grad_out, con
       for (int j = 0; j < 3; ++j)
         grad_features[(size_t)idx[p * 3 + j] * C + c] += grad_out[(size_t)p * C + c] * weight[p * 3 + j];
 }
+
+/* ------------------------------------------------------------------------------------------
+ * VectorPool family of PV-RCNN++: pointnet2_stack/src/vector_pool_gpu.cu.
+ * The CUDA kernels hand out buffer slots with atomicAdd, so the ORDER of the per-point segments
+ * (start offsets, rows of grouped_idxs) is implementation-defined upstream; this restatement -- and the
+ * HIP build -- define it as ascending new-point index (one of the orders the reference can produce).
+ * Everything else (which neighbours, their order inside a point's segment, pooled sums) is fixed by the
+ * sequential scan over k of each kernel thread.
+ * ------------------------------------------------------------------------------------------ */
+
+static int orc_frame_of(int pt, const int32_t* cnt, int B) {
+  int bs = 0, pc = cnt[0];
+  for (int k = 1; k < B; k++) {
+    if (pt < pc) break;
+    pc += cnt[k];
+    bs = k;
+  }
+  return bs;
+}
+
+static int orc_in_range(float lx, float ly, float lz, float dist, int neighbor_type) {
+  if (neighbor_type == 1) return !(lx * lx + ly * ly + lz * lz > dist * dist);
+  return !((fabs(lx) > dist) | (fabs(ly) > dist) | (fabs(lz) > dist));
+}
+
+/* query_stacked_local_neighbor_idxs_kernel, vector_pool_gpu.cu:122-200.  Returns the total (cumsum).
+ * A point keeps at most 1000 neighbours (the kernel's temp_idxs) and stops at nsample when nsample > 0;
+ * segments beyond avg_length * M are dropped / truncated exactly as lines 191-199 do. */
+ORC_API int orc_query_stacked_local_neighbor_idxs(const float* support_xyz, const int32_t* xyz_batch_cnt,
+                                                  const float* new_xyz, const int32_t* new_xyz_batch_cnt,
+                                                  int B, int M, int32_t* stack_neighbor_idxs, int32_t* start_len,
+                                                  int avg_length, float max_dist, int nsample, int neighbor_type) {
+  int cumsum = 0;
+  int max_thresh = avg_length * M;
+  int* temp = (int*)malloc(1000 * sizeof(int));
+  for (int pt = 0; pt < M; ++pt) {
+    int bs = orc_frame_of(pt, new_xyz_batch_cnt, B);
+    int start = 0;
+    for (int k = 0; k < bs; k++) start += xyz_batch_cnt[k];
+    const float* X = support_xyz + (size_t)start * 3;
+    const float* q = new_xyz + (size_t)pt * 3;
+    int n = xyz_batch_cnt[bs], cnt = 0;
+    for (int k = 0; k < n; ++k) {
+      float lx = X[k * 3] - q[0], ly = X[k * 3 + 1] - q[1], lz = X[k * 3 + 2] - q[2];
+      if (!orc_in_range(lx, ly, lz, max_dist, neighbor_type)) continue;
+      if (cnt < 1000) temp[cnt] = k; else break;
+      cnt++;
+      if (nsample > 0 && cnt >= nsample) break;
+    }
+    start_len[pt * 2] = cumsum;
+    start_len[pt * 2 + 1] = cnt;
+    int s0 = cumsum;
+    cumsum += cnt;
+    if (s0 >= max_thresh) continue;
+    int w = cnt;
+    if (s0 + w >= max_thresh) w = max_thresh - s0;
+    for (int k = 0; k < w; ++k) stack_neighbor_idxs[s0 + k] = temp[k] + start;
+  }
+  free(temp);
+  return cumsum;
+}
+
+/* query_three_nn_by_stacked_local_idxs_kernel, vector_pool_gpu.cu:19-85 */
+ORC_API void orc_query_three_nn_by_stacked_local_idxs(const float* support_xyz, const float* grid_centers,
+                                                      int32_t* grid_idxs, float* grid_dist2,
+                                                      const int32_t* stack_neighbor_idxs, const int32_t* start_len,
+                                                      int M, int num_total_grids) {
+  for (int pt = 0; pt < M; ++pt)
+    for (int g = 0; g < num_total_grids; ++g) {
+      const float* c = grid_centers + ((size_t)pt * num_total_grids + g) * 3;
+      const int32_t* nb = stack_neighbor_idxs + start_len[pt * 2];
+      int len = start_len[pt * 2 + 1];
+      double b1 = 1e40, b2 = 1e40, b3 = 1e40;
+      int i1 = -1, i2 = -1, i3 = -1;
+      for (int k = 0; k < len; ++k) {
+        int j = nb[k];
+        float x = support_xyz[(size_t)j * 3], y = support_xyz[(size_t)j * 3 + 1], z = support_xyz[(size_t)j * 3 + 2];
+        float d = (c[0] - x) * (c[0] - x) + (c[1] - y) * (c[1] - y) + (c[2] - z) * (c[2] - z);
+        if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = j; }
+        else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = j; }
+        else if (d < b3) { b3 = d; i3 = j; }
+      }
+      if (i2 == -1) { i2 = i1; b2 = b1; }
+      if (i3 == -1) { i3 = i1; b3 = b1; }
+      size_t o = ((size_t)pt * num_total_grids + g) * 3;
+      grid_dist2[o] = (float)b1; grid_dist2[o + 1] = (float)b2; grid_dist2[o + 2] = (float)b3;
+      grid_idxs[o] = i1; grid_idxs[o + 1] = i2; grid_idxs[o + 2] = i3;
+    }
+}
+
+/* vector_pool_kernel_stack, vector_pool_gpu.cu:243-375.  Outputs arrive zero-filled; returns cum_sum.
+ * Rows of grouped_idxs beyond num_max_sum_points are counted, not stored (and, as in the kernel, such a
+ * hit does not advance sample_cnt). */
+ORC_API int orc_vector_pool(const float* support_xyz, const float* support_features, const int32_t* xyz_batch_cnt,
+                            const float* new_xyz, const int32_t* new_xyz_batch_cnt, int B, int M, int num_c_in,
+                            int num_c_out, int gx, int gy, int gz, float max_dist, int use_xyz,
+                            int num_max_sum_points, int nsample, int neighbor_type, int pooling_type,
+                            float* new_features, float* new_local_xyz, int32_t* point_cnt_of_grid,
+                            int32_t* grouped_idxs) {
+  int G = gx * gy * gz, cg = num_c_out / G;
+  float sx = max_dist * 2 / gx, sy = max_dist * 2 / gy, sz = max_dist * 2 / gz;
+  int cum = 0;
+  for (int pt = 0; pt < M; ++pt) {
+    int bs = orc_frame_of(pt, new_xyz_batch_cnt, B);
+    int start = 0;
+    for (int k = 0; k < bs; k++) start += xyz_batch_cnt[k];
+    const float* X = support_xyz + (size_t)start * 3;
+    const float* F = support_features + (size_t)start * num_c_in;
+    const float* q = new_xyz + (size_t)pt * 3;
+    float* nf = new_features + (size_t)pt * num_c_out;
+    float* nl = new_local_xyz + (size_t)pt * 3 * G;
+    int32_t* pc = point_cnt_of_grid + (size_t)pt * G;
+    int n = xyz_batch_cnt[bs], sample_cnt = 0;
+    for (int k = 0; k < n; ++k) {
+      float lx = X[k * 3] - q[0], ly = X[k * 3 + 1] - q[1], lz = X[k * 3 + 2] - q[2];
+      if (!orc_in_range(lx, ly, lz, max_dist, neighbor_type)) continue;
+      int ix = (int)floorf((lx + max_dist) / sx), iy = (int)floorf((ly + max_dist) / sy);
+      int iz = (int)floorf((lz + max_dist) / sz);
+      int g = ix * gy * gz + iy * gz + iz;
+      g = g < 0 ? 0 : (g > G - 1 ? G - 1 : g);
+      if (pooling_type == 0) {
+        pc[g]++;
+        for (int i = 0; i < num_c_in; ++i) nf[g * cg + i % cg] += F[(size_t)k * num_c_in + i];
+        if (use_xyz) { nl[g * 3] += lx; nl[g * 3 + 1] += ly; nl[g * 3 + 2] += lz; }
+      } else {
+        if (pc[g] != 0) continue;
+        pc[g]++;
+        for (int i = 0; i < num_c_in; ++i) nf[g * cg + i % cg] = F[(size_t)k * num_c_in + i];
+        if (use_xyz) { nl[g * 3] = lx; nl[g * 3 + 1] = ly; nl[g * 3 + 2] = lz; }
+      }
+      int cnt = cum++;
+      if (cnt >= num_max_sum_points) continue;
+      grouped_idxs[cnt * 3] = start + k;
+      grouped_idxs[cnt * 3 + 1] = pt;
+      grouped_idxs[cnt * 3 + 2] = g;
+      sample_cnt++;
+      if (pooling_type == 0) { if (nsample > 0 && sample_cnt >= nsample) break; }
+      else if ((nsample > 0 && sample_cnt >= nsample) || sample_cnt >= G) break;
+    }
+  }
+  return cum;
+}
+
+/* vector_pool_grad_kernel_stack, vector_pool_gpu.cu:433-460; grad_support_features zero-filled by the caller */
+ORC_API void orc_vector_pool_grad(const float* grad_new_features, const int32_t* point_cnt_of_grid,
+                                  const int32_t* grouped_idxs, int num_idxs, int num_c_in, int num_c_out,
+                                  int num_total_grids, float* grad_support_features) {
+  int cg = num_c_out / num_total_grids;
+  for (int e = 0; e < num_idxs; ++e) {
+    int s = grouped_idxs[e * 3], p = grouped_idxs[e * 3 + 1], g = grouped_idxs[e * 3 + 2];
+    int tot = point_cnt_of_grid[(size_t)p * num_total_grids + g];
+    float w = 1 / fmaxf((float)tot, 1.0);
+    for (int c = 0; c < num_c_in; ++c)
+      grad_support_features[(size_t)s * num_c_in + c] += grad_new_features[(size_t)p * num_c_out + g * cg + c % cg] * w;
+  }
+}

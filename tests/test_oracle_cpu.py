@@ -375,3 +375,49 @@ def test_oracle_threads_do_not_change_results():
         lib.orc_set_threads(1)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3])
     np.testing.assert_allclose(a[2], b[2], rtol=1e-4, atol=1e-4 * float(np.abs(a[2]).max()))
+
+
+def test_vector_pool_oracle_vs_independent_numpy_formulation():
+    """The restatement of vector_pool_gpu.cu (parity unpinned by the reference: GPU-only code, no tests) against
+    an independent vectorised formulation: sub-voxel membership by masks, folded channel sums, three nearest by a
+    stable argsort over the local neighbour list; gradient by np.add.at."""
+    import oracle
+    rng = np.random.default_rng(0)
+    n, m = [700, 500], [40, 30]
+    sx = rng.uniform(0, 4, (sum(n), 3)).astype(np.float32)
+    sf = rng.normal(size=(sum(n), 8)).astype(np.float32)
+    nx = rng.uniform(0.5, 3.5, (sum(m), 3)).astype(np.float32)
+    r = np.float32(0.6)
+    nf, nl, mean, pc, gi = oracle.vector_pool(sx, n, sf, nx, m, (2, 2, 2), 0.6, 4, True, num_mean_points_per_grid=2)
+    assert mean == -(-len(gi) // sum(m)) and len(gi) == pc.sum()
+    for p in (0, 5, 41, 69):
+        b = 0 if p < m[0] else 1
+        s0 = 0 if b == 0 else n[0]
+        X, F = sx[s0:s0 + n[b]], sf[s0:s0 + n[b]]
+        l = X - nx[p]
+        ok = ~((np.abs(l) > r).any(1))
+        cell = np.floor((l + r) / (r * 2 / 2)).astype(int)
+        g = np.clip(cell[:, 0] * 4 + cell[:, 1] * 2 + cell[:, 2], 0, 7)
+        for gg in range(8):
+            sel = ok & (g == gg)
+            assert pc[p, gg] == sel.sum()
+            want = (F[sel][:, :4] + F[sel][:, 4:]).sum(0) / max(sel.sum(), 1e-6)
+            np.testing.assert_allclose(nf[p, gg * 4:gg * 4 + 4], want, atol=1e-5)
+            if sel.sum():
+                np.testing.assert_allclose(nl[p, gg * 3:gg * 3 + 3], l[sel].sum(0) / sel.sum(), atol=1e-5)
+        rows = gi[gi[:, 1] == p]
+        assert np.array_equal(rows[:, 0], s0 + np.nonzero(ok)[0]) and np.array_equal(rows[:, 2], g[ok])
+    grad = oracle.vector_pool_grad(np.ones_like(nf), pc, gi, sum(n), 8)
+    ref = np.zeros_like(grad)
+    np.add.at(ref, gi[:, 0], (1.0 / np.maximum(pc[gi[:, 1], gi[:, 2]], 1))[:, None])
+    np.testing.assert_allclose(grad, ref, rtol=1e-6)
+    centers = (nx[:, None, :] + rng.uniform(-0.3, 0.3, (sum(m), 8, 3))).astype(np.float32)
+    d, idx, _ = oracle.three_nn_for_vector_pool_by_two_step(sx, n, nx, centers, m, 0.6, -1, 0, 3, 8, 2.0)
+    for p, gcell in ((3, 2), (50, 7)):
+        b = 0 if p < m[0] else 1
+        s0 = 0 if b == 0 else n[0]
+        X = sx[s0:s0 + n[b]]
+        cand = np.nonzero(~((np.abs(X - nx[p]) > np.float32(1.2)).any(1)))[0][:1000]
+        dd = ((centers[p, gcell] - X[cand]) ** 2).sum(1)
+        o = np.argsort(dd, kind="stable")[:3]
+        assert np.array_equal(idx[p, gcell], s0 + cand[o])
