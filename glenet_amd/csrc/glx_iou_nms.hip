@@ -913,8 +913,8 @@ __global__ __launch_bounds__(256) void k_roi_match(const float* __restrict__ roi
   }
 }
 
-// k_roi_sample: one block per frame.  Categories by overlap (:128-137): foreground >= fg_thresh,
-// easy background < bg_lo, hard background in between; lists in ascending RoI order (= nonzero()).
+// k_roi_sample: one block per frame.  Lists by overlap (:128-137): foreground >= fg_thresh, easy background
+// < bg_lo, hard background in [bg_lo, REG_FG_THRESH); each in ascending RoI order (= nonzero()).
 // The random draws come in as uniform numbers so that the caller owns the generator:
 //   key (B, R)  -- foreground RoIs are taken in ascending key order (a uniform random subset and order:
 //                  the reference's permutation, :147-148);
@@ -939,9 +939,16 @@ __global__ __launch_bounds__(256) void k_roi_sample(const float* __restrict__ ma
   key += (long long)b * R;
   pick += (long long)b * cfg.P;
   const int per = (R + nt - 1) / nt, r0 = tid * per, r1 = min(R, r0 + per);
-  auto category = [&](float v) { return v >= cfg.fg_thresh ? 0 : (v < cfg.bg_lo ? 2 : 1); };
+  // three independent predicates, as the reference's three nonzero() calls (:128-137): with CLS_FG_THRESH <
+  // REG_FG_THRESH an RoI in [fg_thresh, REG_FG) is foreground AND hard background; a NaN overlap is in no list
+  auto member = [&](float v, int k) {
+    return k == 0 ? v >= cfg.fg_thresh : (k == 2 ? v < cfg.bg_lo : (v < cfg.reg_fg && v >= cfg.bg_lo));
+  };
   int c3[3] = {0, 0, 0};
-  for (int r = r0; r < r1; ++r) ++c3[category(max_overlaps[r])];
+  for (int r = r0; r < r1; ++r) {
+    const float v = max_overlaps[r];
+    for (int k = 0; k < 3; ++k) c3[k] += member(v, k) ? 1 : 0;
+  }
   for (int k = 0; k < 3; ++k) s_cnt[k][tid] = c3[k];
   __syncthreads();
   if (tid < 3) {                                               // exclusive scan over the threads' chunks
@@ -951,7 +958,11 @@ __global__ __launch_bounds__(256) void k_roi_sample(const float* __restrict__ ma
   }
   __syncthreads();
   int w3[3] = {s_cnt[0][tid], s_cnt[1][tid], s_cnt[2][tid]};
-  for (int r = r0; r < r1; ++r) { const int k = category(max_overlaps[r]); s_list[k][w3[k]++] = r; }
+  for (int r = r0; r < r1; ++r) {
+    const float v = max_overlaps[r];
+    for (int k = 0; k < 3; ++k)
+      if (member(v, k)) s_list[k][w3[k]++] = r;
+  }
   __syncthreads();
   const int nfg = s_cnt[0][256], nhard = s_cnt[1][256], neasy = s_cnt[2][256], nbg = nhard + neasy;
   const int P = cfg.P;
@@ -1006,6 +1017,12 @@ extern "C" int glx_roi_targets(const float* rois, const int64_t* roi_labels, int
   hipLaunchKernelGGL(k_roi_match, dim3(glx_divup(R, 4), B), dim3(256), 0, st, rois, roi_labels, R, roi_ld, gt_boxes, G,
                      gt_ld, same_class, max_overlaps, assignment, n_gt);
   RoiSampleCfg cfg{P, fg_per_image, fg_thresh, bg_lo, reg_fg, hard_ratio};
+  static bool lds_opt_in = false;              // 3 * R ints of dynamic LDS: 96 KB at the largest R
+  if (!lds_opt_in) {
+    GLX_HIP(hipFuncSetAttribute((const void*)k_roi_sample, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                3 * 8192 * (int)sizeof(int)));
+    lds_opt_in = true;
+  }
   hipLaunchKernelGGL(k_roi_sample, dim3(B), dim3(256), (size_t)3 * R * sizeof(int), st, (const float*)max_overlaps,
                      (const int*)assignment, (const int*)n_gt, key, pick, R, cfg, sampled, sampled_gt);
   GLX_LAUNCH_CHECK();

@@ -12,6 +12,12 @@ struct BoxT {
   float cx, cy, cz, dx, dy, dz, cosa, sina;
   __device__ void load(const float* b) {
     cx = b[0]; cy = b[1]; cz = b[2]; dx = b[3]; dy = b[4]; dz = b[5];
+    // The reference calls the float overloads (lidar_to_local_coords, roiaware_pool3d_kernel.cu:23-27; cosf / sinf of
+    // glibc in roiaware_pool3d.cpp:119-123).  Evaluating in double and rounding once gives the correctly rounded
+    // float, which is what glibc's float routines return and what the CPU oracle / libglenet_host.so therefore hold;
+    // the device's own cosf / sinf (ocml) are ~1 ulp routines and would flip boundary points against those.  A CUDA
+    // build of the reference (libdevice float trig) can differ from either by an ulp of the rotation: points within
+    // ~1e-6 m of a box face may be classified differently -- the parity tests place their boundary cases 1e-3 apart.
     cosa = (float)cos((double)(-b[6]));
     sina = (float)sin((double)(-b[6]));
   }
@@ -834,8 +840,11 @@ __global__ __launch_bounds__(FPS_THREADS) void k_stack_fps(
   int* O = idxs + ostart;
   const int n = xyz_batch_cnt[b], m = num_sampled[b];
   if (m <= 0 || n <= 0) return;
+  // the register-resident form holds FPS_THREADS * FPS_DPT points: a frame with more (the host's max_points hint
+  // was stale or too small) takes the global-memory loop instead of silently ignoring its tail
+  const bool regs = REGS && n <= FPS_THREADS * FPS_DPT;
   float px[FPS_DPT], py[FPS_DPT], pz[FPS_DPT], pt[FPS_DPT];
-  if (REGS) {
+  if (regs) {
 #pragma unroll
     for (int j = 0; j < FPS_DPT; ++j) {
       int k = tid + j * FPS_THREADS;
@@ -852,7 +861,7 @@ __global__ __launch_bounds__(FPS_THREADS) void k_stack_fps(
   for (int s = 1; s < m; ++s) {
     const float x1 = s_pt[0], y1 = s_pt[1], z1 = s_pt[2];
     FpsBest best{-1.f, tid, 0};
-    if (REGS) {
+    if (regs) {
 #pragma unroll
       for (int j = 0; j < FPS_DPT; ++j) {
         float dx = px[j] - x1, dy = py[j] - y1, dz = pz[j] - z1;
@@ -878,7 +887,7 @@ __global__ __launch_bounds__(FPS_THREADS) void k_stack_fps(
     const int win = __ffsll((long long)__ballot(best.v == vmax)) - 1;
     if (lane == win) {
       float cx, cy, cz;
-      if (REGS) {
+      if (regs) {
         const int jw = best.i / FPS_THREADS;
         cx = px[0]; cy = py[0]; cz = pz[0];
 #pragma unroll

@@ -848,280 +848,6 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
   }
 }
 
-// ==================================================================== rulebook + streaming GEMM
-// Rulebook of a rule set: the per-(64-row tile, offset) compacted pair lists that k_sconv_gemm /
-// k_sconv_mfma rebuild with ballots in every launch, built ONCE per rule set (2-3 convs share it):
-//   cnt   (tiles, 32)      u8   pairs per offset
-//   pslot (tiles, K, 64)   u8   output slot of pair p
-//   pin   (tiles, K, 64)   i32  input row of pair p
-#define RB_TR 64
-
-static inline size_t rb_off_pslot(int tiles) { return glx_align((size_t)tiles * 32); }
-static inline size_t rb_off_pin(int tiles, int K) {
-  return rb_off_pslot(tiles) + glx_align((size_t)tiles * K * RB_TR);
-}
-
-__global__ __launch_bounds__(256) void k_rulebook(const int* __restrict__ nbr,
-                                                  const int* __restrict__ tile_order, int N_out,
-                                                  int K, const int* __restrict__ n_live,
-                                                  unsigned char* __restrict__ cnt,
-                                                  unsigned char* __restrict__ pslot,
-                                                  int* __restrict__ pin) {
-  if (n_live) N_out = min(N_out, *n_live);
-  const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int prow = tile * RB_TR + lane;
-  const int lrow = (prow < N_out) ? (tile_order ? tile_order[prow] : prow) : -1;
-  const int* np = nbr + (long long)(lrow < 0 ? 0 : lrow) * K;
-  for (int k = wave; k < 32; k += 4) {
-    bool v = false;
-    int nb = -1;
-    if (k < K && lrow >= 0) {
-      nb = np[k];
-      v = nb >= 0;
-    }
-    const unsigned long long bal = __ballot(v);
-    if (v) {
-      const int pos = __popcll(bal & ((1ull << lane) - 1ull));
-      pin[((long long)tile * K + k) * RB_TR + pos] = nb;
-      pslot[((long long)tile * K + k) * RB_TR + pos] = (unsigned char)lane;
-    }
-    if (lane == 0) cnt[(long long)tile * 32 + k] = (unsigned char)__popcll(bal);
-  }
-}
-
-extern "C" size_t glx_rulebook_bytes(int N_out, int K) {
-  int tiles = glx_divup(N_out > 0 ? N_out : 1, RB_TR);
-  return rb_off_pin(tiles, K) + glx_align((size_t)tiles * K * RB_TR * sizeof(int));
-}
-
-extern "C" int glx_rulebook_build(const int32_t* nbr, const int32_t* tile_order, int N_out, int K,
-                                  const int32_t* n_live, void* book, size_t book_bytes,
-                                  void* stream) {
-  if (N_out <= 0) return GLX_OK;
-  GLX_REQUIRE(nbr && book && K > 0 && K <= SC_MAXK, "glx_rulebook_build: bad arguments");
-  if (book_bytes < glx_rulebook_bytes(N_out, K)) {
-    glx_set_error("glx_rulebook_build: book %zu < %zu bytes", book_bytes, glx_rulebook_bytes(N_out, K));
-    return GLX_EWORKSPACE;
-  }
-  const int tiles = glx_divup(N_out, RB_TR);
-  unsigned char* b = (unsigned char*)book;
-  hipLaunchKernelGGL(k_rulebook, dim3(tiles), dim3(256), 0, (hipStream_t)stream, nbr, tile_order,
-                     N_out, K, n_live, b, b + rb_off_pslot(tiles), (int*)(b + rb_off_pin(tiles, K)));
-  GLX_LAUNCH_CHECK();
-  return GLX_OK;
-}
-
-// Streaming variant of the block implicit GEMM on top of a rulebook.  Differences to k_sconv_gemm:
-//   * no rule compaction in the kernel: the tile's pair lists are copied from the rulebook;
-//   * W never touches LDS: every MFMA wave reads the 16 x Cin fragment of ITS column tile straight
-//     from L2 into registers one step ahead (the split image is already in fragment order), so the
-//     weight image needs neither LDS space nor barriers;
-//   * the freed LDS double-buffers the pair panel: ONE barrier per step.
-// Measured (round 1): 79 us on the 64->64 / 48 k-row layer against 74 us for k_sconv_gemm, a little
-// ahead on 32->64 and 64->128 -- so it is opt-in (GLX_SCONV_RULEBOOK=1), not the default.  Why it
-// does not win: vmcnt counts a wave's loads IN ORDER, so a wave that mixes slow row gathers (L2
-// misses) with fast W fragment loads stalls its multiply on the older gather whatever the
-// prefetch distance D.  NP > 0 gives the gathers to NP extra waves with their own counters
-// (wave specialisation); with 2 of them the gather issue becomes the bottleneck (97 us), with 4
-// only 2 blocks fit a CU (104 us).
-template <int CIN, int COUT, int NW_, int WPG_, int NP_ = 2>
-struct SconvRb {
-  using S = SconvSplitCfg<CIN, COUT>;
-  static constexpr int CQ = CIN / 4, NT = COUT / 16;
-  static constexpr int TR = RB_TR, NW = NW_, WPG = WPG_, NP = NP_;
-  static constexpr int THREADS = (NW + NP) * 64;
-  static constexpr int PTHREADS = NP > 0 ? NP * 64 : THREADS;   // NP = 0: every wave does both jobs
-  static constexpr int G = NW / WPG, TPW = NT / WPG;
-  static constexpr int AP = 16 * G;
-  static constexpr int A_LD = CIN + (CIN >= 16 ? 4 : 0);
-  static constexpr int SEGS = CIN / 4;
-  static constexpr int A_SEG = AP * SEGS;
-  static constexpr int GPT = (A_SEG + PTHREADS - 1) / PTHREADS;   // gather segments per producer thread
-  static constexpr int WF4 = CQ >= 4 ? CQ / 4 : 1;          // f32x4 per tile fragment per lane
-  static constexpr int ACC_LD = COUT + 4;
-  static constexpr int MAXSTEPS = (SC_MAXK * ((TR + AP - 1) / AP) + 3) & ~3;   // keeps LDS regions 16-B aligned
-  static constexpr size_t lds_bytes = (size_t)TR * ACC_LD * 4 + 2 * (size_t)AP * A_LD * 4 +
-                                      (size_t)SC_MAXK * TR * 5 + TR * 4 + MAXSTEPS * 4 + 128;
-  static_assert(NW % WPG == 0 && NT % WPG == 0 && CQ % 4 == 0, "bad split");
-};
-
-template <int CIN, int COUT, int NW_, int WPG_, int NP_>
-__global__ __launch_bounds__((NW_ + NP_) * 64) void k_sconv_rb(
-    const float* __restrict__ in, const float* __restrict__ Wp, SconvEpilogue ep,
-    const unsigned char* __restrict__ rb_cnt, const unsigned char* __restrict__ rb_pslot,
-    const int* __restrict__ rb_pin, const int* __restrict__ tile_order, int N_out, int K,
-    float* __restrict__ out) {
-  if (ep.n_live) N_out = min(N_out, *ep.n_live);
-  using T = SconvRb<CIN, COUT, NW_, WPG_, NP_>;
-  using S = SconvSplitCfg<CIN, COUT>;
-  constexpr int TR = T::TR, ACC_LD = T::ACC_LD, CQ = T::CQ, THREADS = T::THREADS;
-  constexpr int PTHREADS = T::PTHREADS;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_acc = smem;                                        // TR * ACC_LD
-  float* s_a = s_acc + TR * ACC_LD;                           // 2 * AP * A_LD
-  int* s_pin = reinterpret_cast<int*>(s_a + 2 * T::AP * T::A_LD);   // K * TR
-  int* s_rows = s_pin + SC_MAXK * TR;                         // TR
-  int* s_step = s_rows + TR;                                  // MAXSTEPS: k | pb << 8 | n << 16
-  int* s_nsteps = s_step + T::MAXSTEPS;                       // 1 (+ pad)
-  unsigned char* s_pslot = reinterpret_cast<unsigned char*>(s_nsteps + 32);   // K * TR
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int tile = blockIdx.x;
-  const int row0 = tile * TR;
-  const bool producer = T::NP > 0 && wave >= T::NW;   // wave-uniform role (NP = 0: unified waves)
-  const int ptid = T::NP > 0 ? tid - T::NW * 64 : tid;   // gather thread index
-  const int grp = wave / T::WPG;
-  const int tile0 = (wave % T::WPG) * T::TPW;
-
-  // ---- tile rows, zero accumulators, pair lists from the rulebook, step list
-  if (tid < TR) {
-    int p = row0 + tid;
-    s_rows[tid] = (p < N_out) ? (tile_order ? tile_order[p] : p) : -1;
-  }
-  for (int i = tid; i < TR * ACC_LD / 4; i += THREADS)
-    reinterpret_cast<f32x4*>(s_acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  {
-    const int4* src = reinterpret_cast<const int4*>(rb_pin + (long long)tile * K * TR);
-    for (int i = tid; i < K * TR / 4; i += THREADS) reinterpret_cast<int4*>(s_pin)[i] = src[i];
-    const int4* ssrc = reinterpret_cast<const int4*>(rb_pslot + (long long)tile * K * TR);
-    for (int i = tid; i < K * TR / 16; i += THREADS) reinterpret_cast<int4*>(s_pslot)[i] = ssrc[i];
-  }
-  if (wave == 0) {   // step list: lane k owns offset k, positions from a wave prefix sum
-    const int c = lane < K ? (int)rb_cnt[(long long)tile * 32 + lane] : 0;
-    const int nk = (c + T::AP - 1) / T::AP;
-    int inc = nk;
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
-      int t = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += t;
-    }
-    int pos = inc - nk;
-    for (int pb = 0; pb < c; pb += T::AP) s_step[pos++] = lane | (pb << 8) | (min(T::AP, c - pb) << 16);
-    if (lane == 31) *s_nsteps = inc;
-  }
-  __syncthreads();
-  const int nsteps = *s_nsteps;
-
-  constexpr int D = 4;   // gather prefetch distance in steps (even): rows are L2 misses, ~2 us away
-  f32x4 areg[D][T::GPT];
-  f32x4 wreg[2][T::TPW][T::WF4];
-#define RB_GATHER(ST, AREG)                                                                 \
-  {                                                                                         \
-    const int st_ = s_step[(ST) < nsteps ? (ST) : nsteps - 1];                              \
-    const int k_ = st_ & 31, pb_ = (st_ >> 8) & 255, n_ = st_ >> 16;                        \
-    _Pragma("unroll") for (int i_ = 0; i_ < T::GPT; ++i_) {                                 \
-      int e_ = ptid + i_ * PTHREADS;                                                        \
-      int pair_ = e_ / T::SEGS, seg_ = e_ - pair_ * T::SEGS;                                \
-      int irow_ = 0;                                                                        \
-      if (pair_ < n_) irow_ = s_pin[k_ * TR + pb_ + pair_];                                 \
-      AREG[i_] = *reinterpret_cast<const f32x4*>(in + (long long)irow_ * CIN + seg_ * 4);   \
-    }                                                                                       \
-  }
-#define RB_STORE(AREG, BUF)                                                                 \
-  {                                                                                         \
-    float* dst_ = s_a + (BUF) * T::AP * T::A_LD;                                            \
-    _Pragma("unroll") for (int i_ = 0; i_ < T::GPT; ++i_) {                                 \
-      int e_ = ptid + i_ * PTHREADS;                                                        \
-      int pair_ = e_ / T::SEGS, seg_ = e_ - pair_ * T::SEGS;                                \
-      if (T::A_SEG % PTHREADS == 0 || e_ < T::A_SEG)                                        \
-        *reinterpret_cast<f32x4*>(dst_ + pair_ * T::A_LD + seg_ * 4) = AREG[i_];            \
-    }                                                                                       \
-  }
-#define RB_LOADW(ST, WREG)                                                                  \
-  {                                                                                         \
-    const int st_ = s_step[(ST) < nsteps ? (ST) : nsteps - 1];                              \
-    const float* wsrc_ = Wp + (size_t)(st_ & 31) * S::IMG;                                  \
-    _Pragma("unroll") for (int tt_ = 0; tt_ < T::TPW; ++tt_) {                              \
-      const float* wp_ = wsrc_ + S::idx(tile0 + tt_, q, 0, r);                              \
-      _Pragma("unroll") for (int t4_ = 0; t4_ < T::WF4; ++t4_)                              \
-        WREG[tt_][t4_] = *reinterpret_cast<const f32x4*>(wp_ + 64 * t4_);                   \
-    }                                                                                       \
-  }
-  // multiply the wave's chunk of panel BUF (step ST) by its column tiles, accumulate
-#define RB_COMPUTE(ST, BUF, WREG)                                                           \
-  {                                                                                         \
-    const int st_ = s_step[ST];                                                             \
-    const int k_ = st_ & 31, pb_ = (st_ >> 8) & 255, n_ = st_ >> 16;                        \
-    if (grp * 16 < n_) {                                                                    \
-      const float* arow_ = s_a + (BUF) * T::AP * T::A_LD + (grp * 16 + r) * T::A_LD + q * CQ; \
-      float Am_[CQ];                                                                        \
-      _Pragma("unroll") for (int i_ = 0; i_ < CQ / 4; ++i_) {                               \
-        f32x4 v_ = *reinterpret_cast<const f32x4*>(arow_ + 4 * i_);                         \
-        Am_[4 * i_] = v_[0]; Am_[4 * i_ + 1] = v_[1]; Am_[4 * i_ + 2] = v_[2]; Am_[4 * i_ + 3] = v_[3]; \
-      }                                                                                     \
-      f32x4 acc_[T::TPW];                                                                   \
-      _Pragma("unroll") for (int tt_ = 0; tt_ < T::TPW; ++tt_) {                            \
-        acc_[tt_] = f32x4{0.f, 0.f, 0.f, 0.f};                                              \
-        _Pragma("unroll") for (int t4_ = 0; t4_ < T::WF4; ++t4_)                            \
-          _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_)                                  \
-            acc_[tt_] = __builtin_amdgcn_mfma_f32_16x16x4f32(WREG[tt_][t4_][e_], Am_[4 * t4_ + e_], acc_[tt_], 0, 0, 0); \
-      }                                                                                     \
-      if (grp * 16 + r < n_) {                                                              \
-        float* dst_ = s_acc + (int)s_pslot[k_ * TR + pb_ + grp * 16 + r] * ACC_LD + tile0 * 16 + 4 * q; \
-        _Pragma("unroll") for (int tt_ = 0; tt_ < T::TPW; ++tt_) {                          \
-          f32x4 v_ = *reinterpret_cast<f32x4*>(dst_ + tt_ * 16);                            \
-          v_ += acc_[tt_];                                                                  \
-          *reinterpret_cast<f32x4*>(dst_ + tt_ * 16) = v_;                                  \
-        }                                                                                   \
-      }                                                                                     \
-    }                                                                                       \
-  }
-
-  if (nsteps > 0) {
-    if (producer || T::NP == 0) {
-      // prologue: panels 0..D-1 requested, panel 0 into LDS
-#pragma unroll
-      for (int d = 0; d < D; ++d) RB_GATHER(d, areg[d]);
-      RB_STORE(areg[0], 0);
-    }
-    if (!producer) RB_LOADW(0, wreg[0]);
-    __syncthreads();
-    for (int s = 0; s < nsteps; s += D) {
-#pragma unroll
-      for (int d = 0; d < D; ++d) {
-        if (s + d >= nsteps) break;
-        // step s+d: panel buffer d%2, W registers d%2
-        if constexpr (T::NP == 0) {
-          RB_GATHER(s + d + D, areg[d]);
-          RB_LOADW(s + d + 1, wreg[(d + 1) & 1]);
-          RB_COMPUTE(s + d, d & 1, wreg[d & 1]);
-          RB_STORE(areg[(d + 1) % D], (d + 1) & 1);
-        } else if (producer) {
-          RB_GATHER(s + d + D, areg[d]);              // areg[d] (panel s+d) was stored a step ago
-          RB_STORE(areg[(d + 1) % D], (d + 1) & 1);   // panel s+d+1, requested D-1 steps ago
-        } else {
-          RB_LOADW(s + d + 1, wreg[(d + 1) & 1]);
-          RB_COMPUTE(s + d, d & 1, wreg[d & 1]);
-        }
-        __syncthreads();
-      }
-    }
-  }
-#undef RB_GATHER
-#undef RB_STORE
-#undef RB_LOADW
-#undef RB_COMPUTE
-  __syncthreads();
-
-  // ---- epilogue: coalesced row stores with the fused pointwise tail
-  constexpr int C4 = COUT / 4;
-  for (int i = tid; i < TR * C4; i += THREADS) {
-    int rr = i / C4, c4 = i - rr * C4;
-    int orow = s_rows[rr];
-    if (orow < 0) continue;
-    f32x4 v = *reinterpret_cast<const f32x4*>(s_acc + rr * ACC_LD + 4 * c4);
-    const int co = 4 * c4;
-    if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + co);
-    if (ep.scale) v *= *reinterpret_cast<const f32x4*>(ep.scale + co);
-    if (ep.shift) v += *reinterpret_cast<const f32x4*>(ep.shift + co);
-    if (ep.relu) {
-      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-    }
-    *reinterpret_cast<f32x4*>(out + (long long)orow * COUT + 4 * c4) = v;
-  }
-}
-
 // ------------------------------------------------------------------ generic scalar kernel
 __global__ void k_sconv_generic(const float* __restrict__ in, const float* __restrict__ W,
                                 SconvEpilogue ep, const int* __restrict__ nbr, int N_out, int K,
@@ -1347,42 +1073,6 @@ static int launch_gemm(const float* in, const float* Wp, const SconvEpilogue& ep
     } else {
       hipLaunchKernelGGL(kern, dim3(nblocks), dim3(T::THREADS), lds, st, in, Wsplit, ep, nbr,
                          tile_order, N_out, K, out);
-    }
-    GLX_LAUNCH_CHECK();
-    return GLX_OK;
-  }
-}
-
-template <int CI, int CO, int NW, int WPG_REQ, int NP = 0>
-static int launch_rb(const float* in, const float* Wp, const SconvEpilogue& ep, const void* book,
-                     const int32_t* tile_order, int N_out, int K, float* out, hipStream_t st) {
-  if constexpr (CI < 16) {
-    glx_set_error("rulebook sparse conv needs Cin >= 16");
-    return GLX_EINVAL;
-  } else {
-    constexpr int WPG = WPG_REQ < CO / 16 ? WPG_REQ : CO / 16;
-    using T = SconvRb<CI, CO, NW, WPG, NP>;
-    static_assert(T::lds_bytes <= 160 * 1024, "rulebook tile exceeds LDS");
-    static bool attr_set = false;
-    auto kern = k_sconv_rb<CI, CO, NW, WPG, NP>;
-    const size_t lds = T::lds_bytes;
-    if (!attr_set) {
-      GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds));
-      attr_set = true;
-    }
-    const int tiles = glx_divup(N_out, RB_TR);
-    const unsigned char* b = (const unsigned char*)book;
-    const float* Wsplit = Wp + (size_t)K * SconvCfg<CI, CO>::IMG;
-    if (g_prof_start && g_prof_stop) {
-      hipExtLaunchKernelGGL(kern, dim3(tiles), dim3(T::THREADS), lds, st, g_prof_start, g_prof_stop,
-                            0, in, Wsplit, ep, b, b + rb_off_pslot(tiles),
-                            (const int*)(b + rb_off_pin(tiles, K)), tile_order, N_out, K, out);
-      g_prof_start = g_prof_stop = nullptr;
-    } else {
-      hipLaunchKernelGGL(kern, dim3(tiles), dim3(T::THREADS), lds, st, in, Wsplit, ep, b,
-                         b + rb_off_pslot(tiles), (const int*)(b + rb_off_pin(tiles, K)), tile_order,
-                         N_out, K, out);
     }
     GLX_LAUNCH_CHECK();
     return GLX_OK;
@@ -1646,28 +1336,6 @@ extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, cons
   return sc_dispatch(Cin, Cout, [&](auto ci, auto co) {
     return launch_mfma<decltype(ci)::value, decltype(co)::value>(in, Wp, ep, nbr, tile_order,
                                                                  N_out, K, out, st);
-  });
-}
-
-// glx_sconv_forward on a prebuilt rulebook (glx_rulebook_build on the same nbr / tile_order /
-// N_out): packed weights required, Cin in {16,32,64,128}, Cout in {16,...,128}.
-extern "C" int glx_sconv_forward_rb(const float* in, const float* Wp, const float* bias,
-                                    const float* scale, const float* shift, int relu,
-                                    const void* book, const int32_t* tile_order, int N_out, int K,
-                                    int Cin, int Cout, float* out, const int32_t* n_out_live,
-                                    void* stream) {
-  GLX_REQUIRE(K > 0 && K <= SC_MAXK && N_out >= 0, "glx_sconv_forward_rb: bad sizes");
-  if (N_out == 0) return GLX_OK;
-  GLX_REQUIRE(in && Wp && book && out, "glx_sconv_forward_rb: null pointer");
-  GLX_REQUIRE(mfma_supported(Cin, Cout, K) && Cin >= 16,
-              "glx_sconv_forward_rb: channels (%d,%d) not supported", Cin, Cout);
-  SconvEpilogue ep{bias, scale, shift, relu, n_out_live, nullptr, 0, 0, nullptr};
-  hipStream_t st = (hipStream_t)stream;
-  return sc_dispatch(Cin, Cout, [&](auto ci, auto co) {
-    constexpr int CI = decltype(ci)::value, CO = decltype(co)::value;
-    if (g_sconv_variant == 41)   // 4 MFMA waves + 2 gather-only waves (wave specialisation)
-      return launch_rb<CI, CO, 4, 4, 2>(in, Wp, ep, book, tile_order, N_out, K, out, st);
-    return launch_rb<CI, CO, 8, 4, 0>(in, Wp, ep, book, tile_order, N_out, K, out, st);
   });
 }
 

@@ -107,7 +107,6 @@ class RuleSet:
         self._pairs = None
         self.count_in = self.count_out = None   # shape-static mode: live rows (device int32[1])
         self.ready = None        # event recorded after the build when it ran on another stream
-        self._book = None
         self._tile_maps = {}     # rule table (data_ptr) -> work-balanced block -> tile map
 
     @property
@@ -134,16 +133,6 @@ class RuleSet:
             call("glx_sconv_tile_map", nbr, order, n_out, self.K, n_live, m, ws, size_arg(ws.numel()))
             self._tile_maps[key] = m
         return m
-
-    def book(self):
-        """Rulebook of the forward table (glx_rulebook_build): compacted pair lists per 64-row
-        tile and offset, built once and shared by every conv that uses this rule set."""
-        if self._book is None and self.N_out > 0:
-            nbytes = query("glx_rulebook_bytes", self.N_out, self.K)
-            self._book = torch.empty(nbytes, dtype=torch.uint8, device=self.nbr.device)
-            call("glx_rulebook_build", self.nbr, self.tile_order_out, self.N_out, self.K,
-                 self.count_out, self._book, size_arg(nbytes))
-        return self._book
 
     def inverse_table(self):
         if self.nbr_in is None:
@@ -252,9 +241,6 @@ def plan_rules(indices, spatial_shape, batch_size, convs, index=None, count=None
         if new_work and (conv.subm or not TILE_MAP_SUBM_ONLY) \
                 and conv.in_channels * conv.out_channels >= TILE_MAP_MIN_WEIGHTS:
             rs.tile_map()      # on the plan stream too, before the event (see TILE_MAP_MIN_WEIGHTS)
-        if USE_RULEBOOK and rulebook_eligible(conv.in_channels, conv.out_channels, rs.K) and rs._book is None:
-            rs.book()          # built here (plan stream), before the event the convs wait on
-            new_work = True
         if events and new_work:
             rs.ready = torch.cuda.Event()
             rs.ready.record()
@@ -313,19 +299,9 @@ def _cin_padding(cin):
     return 0 if target is None else target - cin
 
 
-USE_RULEBOOK = os.environ.get("GLX_SCONV_RULEBOOK", "0") == "1"   # opt-in: see k_sconv_rb
-
-
-def rulebook_eligible(cin, cout, K):
-    """Layers that run the rulebook kernel (k_sconv_rb): the wide ones, where the per-launch
-    rule compaction and the LDS weight staging of the block kernels cost the most."""
-    return cout >= 64 and cin >= 16 and cin in _MFMA_CIN and K <= 27
-
-
 def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rules=None, tag="fwd",
-           scale=None, shift=None, relu=False, n_live=None, book=None, dims=None):
+           scale=None, shift=None, relu=False, n_live=None, dims=None):
     """out[j] = relu?((sum_k features[nbr[j,k]] @ weight_kio[k] + bias) * scale + shift).
-    book: rulebook of (nbr, tile_order, n_out) -> the streaming rulebook kernel.
     weight_kio may be None when `packed` and dims = (K, Cin, Cout) are given."""
     K, cin, cout = dims if dims is not None else weight_kio.shape
     out = torch.empty((n_out, cout), dtype=torch.float32, device=features.device)
@@ -336,10 +312,6 @@ def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rule
     ws = workspace.get(256, features.device)
     if _profile_hook is not None:
         _profile_hook(tag, K, cin, cout, n_out, rules)
-    if book is not None and packed is not None:
-        call("glx_sconv_forward_rb", features, packed, bias, scale, shift, 1 if relu else 0, book,
-             tile_order, n_out, K, cin, cout, out, n_live)
-        return out
     if rules is not None and packed is not None and (rules.subm or rules._tile_maps) \
             and cin * cout >= TILE_MAP_MIN_WEIGHTS:
         tmap = rules.tile_map(nbr, tile_order, n_out, n_live)
@@ -363,10 +335,8 @@ class SparseConvFunction(Function):
             nbr, order, n_out = rules.inverse_table(), rules.tile_order_in, rules.N_in
         else:
             nbr, order, n_out = rules.nbr, rules.tile_order_out, rules.N_out
-        book = rules.book() if (USE_RULEBOOK and not inverse
-                                and rulebook_eligible(w.shape[1], w.shape[2], w.shape[0])) else None
         out = _sconv(features, w, bias, nbr, order, n_out, packed=packed, rules=rules,
-                     n_live=rules.count_in if inverse else rules.count_out, book=book)
+                     n_live=rules.count_in if inverse else rules.count_out)
         ctx.rules, ctx.inverse, ctx.side_ok = rules, inverse, side_ok
         ctx.save_for_backward(features, w)
         ctx.has_bias = bias is not None
@@ -616,9 +586,7 @@ class SparseConvolution(SparseModule):
             feats = _sconv(x_features.contiguous().float(), w.detach().contiguous(), self.bias, nbr,
                            order, n_out, packed=self._packed_weight(w), rules=rs, scale=scale,
                            shift=shift, relu=fused_relu,
-                           n_live=rs.count_in if self.inverse else rs.count_out,
-                           book=rs.book() if (USE_RULEBOOK and not self.inverse and rulebook_eligible(
-                               w.shape[1], w.shape[2], K)) else None)
+                           n_live=rs.count_in if self.inverse else rs.count_out)
         else:
             # side_ok: the weight gradient may run on WGRAD_STREAM only when nothing but views
             # separates it from the parameter (a padded weight's backward copies on the main stream)

@@ -150,20 +150,6 @@ int glx_sconv_forward(const float* in, int N_in, const float* W, const float* Wp
                       const int32_t* nbr, const int32_t* tile_order, int N_out, int K, int Cin,
                       int Cout, float* out, const int32_t* n_out_live, void* workspace,
                       size_t workspace_bytes, void* stream);
-/* Rulebook of a rule set: per 64-row output tile and kernel offset, the compacted list of rule
- * pairs (input row, output slot) + counts -- what the conv kernels otherwise rebuild with wave
- * ballots in every launch.  Build once per (nbr, tile_order, N_out); the 2-3 convolutions that
- * share an indice_key reuse it. */
-size_t glx_rulebook_bytes(int N_out, int K);
-int glx_rulebook_build(const int32_t* nbr, const int32_t* tile_order, int N_out, int K,
-                       const int32_t* n_live, void* book, size_t book_bytes, void* stream);
-/* glx_sconv_forward on a rulebook: W streams from L2 straight into the MFMA waves' registers, the
- * pair panels are double-buffered in LDS, one barrier per step.  Wp = packed weights (required),
- * Cin >= 16. */
-int glx_sconv_forward_rb(const float* in, const float* Wp, const float* bias, const float* scale,
-                         const float* shift, int relu, const void* book, const int32_t* tile_order,
-                         int N_out, int K, int Cin, int Cout, float* out, const int32_t* n_out_live,
-                         void* stream);
 /* Bracket the NEXT glx_sconv_forward MFMA launch of this host thread with two HIP events
  * (hipExtLaunchKernelGGL start/stop): kernel-only duration for bench.py's roofline. */
 int glx_profile_next_sconv(void* start_event, void* stop_event);

@@ -119,6 +119,25 @@ def test_device_roi_targets_match_oracle_on_random_scenes(dev, each):
 
 
 @pytest.mark.gpu
+def test_device_roi_sampler_with_overlapping_foreground_and_hard_background(dev):
+    """CLS_FG_THRESH < REG_FG_THRESH: RoIs with an overlap in [CLS_FG, REG_FG) are in the foreground list AND in the
+    hard-background list (three independent nonzero() calls, proposal_target_layer.py:128-137); a ROI_PER_IMAGE /
+    proposal count that needs more than 64 KB of LDS for the three lists runs too."""
+    rng = np.random.default_rng(9)
+    cfg = dict(BASE, ROI_PER_IMAGE=64, SAMPLE_ROI_BY_EACH_CLASS=False, CLS_SCORE_TYPE="cls", CLS_FG_THRESH=0.4,
+               REG_FG_THRESH=0.7)
+    rois, labels, scores, gt = _scene(rng, 3, 6000, 30, [20, 30, 5], [0.5, 0.8, 0.3])
+    key, pick = rng.random((3, 6000)).astype(np.float32), rng.random((3, 64)).astype(np.float32)
+    o = ort.roi_targets(rois, labels, scores, gt, cfg, key, pick)
+    td, mo, s = _device_forward(dev, cfg, rois, labels, scores, gt, key, pick)
+    assert np.array_equal(s, o["sampled"])
+    both = (o["max_overlaps"] >= 0.4) & (o["max_overlaps"] < 0.7)
+    assert both.sum() > 0
+    bg_slots = o["sampled"][:, 32:]
+    assert np.take_along_axis(both, bg_slots, 1).sum() > 0          # such RoIs were drawn as hard background
+
+
+@pytest.mark.gpu
 def test_device_roi_sampler_default_draws_have_the_reference_composition(dev):
     """With the built-in generator: foreground slots hold min(64, #fg) DISTINCT foreground RoIs, then
     min(int(bg * 0.8), #hard) hard-background draws, then easy ones (proposal_target_layer.py:139-193)."""

@@ -262,24 +262,6 @@ def test_conv_with_five_input_channels_is_padded_not_scalar(dev):
     np.testing.assert_allclose(conv.weight.grad.reshape(27, 5, 16).cpu().numpy(), dw, rtol=1e-3, atol=2e-3)
 
 
-@pytest.mark.parametrize("cin,cout", [(64, 64), (32, 64), (64, 128), (16, 64)])
-def test_rulebook_kernel_matches_default(dev, cin, cout):
-    """k_sconv_rb (opt-in streaming kernel on a prebuilt rulebook) is bit-identical to the default
-    kernel: same pair lists, same summation order."""
-    rng = np.random.default_rng(41 + cin + cout)
-    shape = (9, 30, 26)
-    idx, f = _rand_sparse(rng, 2, *shape, 0.12, cin)
-    x = _gpu_tensor(idx, f, shape, 2, dev)
-    rs = sp.build_subm_rules(x, (3, 3, 3))
-    w = torch.from_numpy((rng.normal(size=(27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)).to(dev)
-    bias = torch.from_numpy(rng.normal(size=cout).astype(np.float32)).to(dev)
-    packed = sp.pack_weights(w)
-    a = sp._sconv(x.features, w, bias, rs.nbr, rs.tile_order_out, rs.N_out, packed=packed, relu=True)
-    b = sp._sconv(x.features, w, bias, rs.nbr, rs.tile_order_out, rs.N_out, packed=packed, relu=True,
-                  book=rs.book())
-    assert torch.equal(a, b)
-
-
 def test_dense_and_empty(dev):
     rng = np.random.default_rng(3)
     shape = (2, 20, 18)

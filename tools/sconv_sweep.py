@@ -55,20 +55,6 @@ for f, w, nbr, order, n_out, rules in calls:
     packed = sp.pack_weights(w)
     R = rules.pair_count
     row = []
-    rb_us = None
-    if sp.rulebook_eligible(cin, cout, Kk) and rules is not None and nbr.data_ptr() == rules.nbr.data_ptr():
-        book = rules.book()
-        _lib.call_nostream("glx_sconv_set_variant", int(os.environ.get("RB_VARIANT", "-1")))
-        ts = []
-        for it in range(12):
-            s_, e_ = ev(), ev()
-            _lib.call_nostream("glx_profile_next_sconv", s_, e_)
-            orig(f, w, None, nbr, order, n_out, packed=packed, book=book)
-            ms = ctypes.c_float()
-            _lib.call_nostream("glx_event_elapsed_ms", s_, e_, ctypes.byref(ms))
-            ts.append(ms.value * 1e3)
-        rb_us = float(np.median(ts[2:]))
-        _lib.call_nostream("glx_sconv_set_variant", -1)
     _lib.call_nostream("glx_sconv_set_variant", -1)
     ref_out = orig(f, w, None, nbr, order, n_out, packed=packed)
     for v in variants:
@@ -112,4 +98,4 @@ for f, w, nbr, order, n_out, rules in calls:
     best = np.nanmin(row)
     alg = R * (cin + 2 * cout) * 4 + R * 8 + Kk * cin * cout * 4
     print(("(%d,%d,%d,%d)" % (cin, cout, n_out, R)).ljust(34) + "".join(("%.1f" % t).rjust(9) for t in row)
-          + "   %.0f" % (alg / best / 1e3) + ("   rulebook kernel %.1f us" % rb_us if rb_us else ""))
+          + "   %.0f" % (alg / best / 1e3))
