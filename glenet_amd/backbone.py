@@ -194,6 +194,7 @@ class StaticFramePipeline:
         self.batch_idx = torch.full((int(num_points),), self.B, dtype=torch.int32, device=dev)
         self.vfe, self.hc = MeanVFE(), HeightCompression()
         self.graph = None
+        self._tag = None
         self.out = None
         self.max_in_flight = 4
         self._inflight = deque()
@@ -262,7 +263,23 @@ class StaticFramePipeline:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=side):
             self.enqueue()
+        self._tag = self._weights_tag()
         return self
+
+    def _tagged_modules(self):
+        return (self.model,)
+
+    def _weights_tag(self):
+        """Inference graphs read packed weights / folded BatchNorms that are cached by tensor version outside the
+        graph: a load_state_dict() or an in-place edit after capture() would leave the replays on the old copies.
+        The sum of the version counters (they only grow) tells; replay() then records the frame again."""
+        tag = 0
+        for m in self._tagged_modules():
+            for t in m.parameters():
+                tag += t._version
+            for t in m.buffers():
+                tag += t._version
+        return tag
 
     def replay(self):
         """Launch the recorded frame.  At most `max_in_flight` frames are queued: the host waits
@@ -270,6 +287,9 @@ class StaticFramePipeline:
         deeper hipGraph queues also proved unreliable on ROCm 7.2)."""
         if len(self._inflight) >= self.max_in_flight:
             self._inflight.popleft().synchronize()
+        if self._tag is not None and self._weights_tag() != self._tag:
+            torch.cuda.current_stream(self.points.device).synchronize()
+            self.capture()                     # weights changed since the capture: record again
         self.graph.replay()
         ev = torch.cuda.Event()
         ev.record()
@@ -324,6 +344,9 @@ class StaticTrainPipeline(StaticFramePipeline):
         self.loss = None
         self.overlap_wgrad = True
         self.mark = None            # optional callable(stage_name): bench.py records an event per stage
+
+    def _weights_tag(self):
+        return None      # training steps pack weights inside the step (spconv.core._packed_weight): nothing cached
 
     def enqueue(self):
         from ._lib import workspace

@@ -202,6 +202,9 @@ class StaticDetectorPipeline(gb.StaticFramePipeline):
                          train_voxel_cap=False, capacities=capacities, device=device)
         self.flow = flow
 
+    def _tagged_modules(self):
+        return (self.flow,)
+
     def enqueue(self):
         from ._lib import workspace
         bd = super().enqueue()

@@ -437,3 +437,52 @@ def test_tile_maps_do_not_change_results(dev):
     assert torch.equal(with_maps["spatial_features"], plain["spatial_features"])
     assert torch.equal(static_maps["spatial_features"], static_plain["spatial_features"])
     assert torch.equal(static_maps["spatial_features"], plain["spatial_features"])
+
+
+def test_graphs_follow_weight_changes_made_outside_them(dev):
+    """packed sparse-conv weights and folded BatchNorms are caches keyed by tensor version.
+    (1) A training graph captured WITHOUT an optimizer, then an eager parameter update between replays: the next
+    replay must compute with the new weights in forward AND backward (weights are packed inside the step).
+    (2) An inference graph, then load_state_dict(): the next replay records the frame again (version tag)."""
+    torch.manual_seed(0)
+    frames = [synth.kitti_frame(30 + i, num_points=6000)[0] for i in range(2)]
+    pts = torch.from_numpy(np.concatenate(frames)).to(dev)
+    bidx = torch.from_numpy(np.concatenate([np.full(len(f), i, np.int32) for i, f in enumerate(frames)])).to(dev)
+    grid = gb.gv.grid_size_of(K["point_cloud_range"], K["voxel_size"])
+    model = gb.VoxelBackBone8x(4, grid).to(dev).train()
+    pipe = gb.StaticTrainPipeline(model, K, 2, pts.shape[0], 4)
+    pipe.calibrate(pts, bidx)
+    pipe.load(pts, bidx)
+    pipe.capture()
+    pipe.replay()
+    torch.cuda.synchronize()
+    loss0 = float(pipe.loss)
+    with torch.no_grad():                               # an eager "optimizer step" outside the graph
+        for p in model.parameters():
+            if p.dim() == 5:
+                p.mul_(1.5)
+    pipe.replay()
+    torch.cuda.synchronize()
+    loss1 = float(pipe.loss)
+    g_graph = {n: p.grad.clone() for n, p in model.named_parameters()}
+    pipe.graph = None
+    pipe.enqueue()                                      # the same step, eager launches, same weights
+    torch.cuda.synchronize()
+    assert abs(float(pipe.loss) - loss1) <= 1e-6 * abs(loss1) and abs(loss1 - loss0) > 1e-3 * abs(loss0)
+    for n, p in model.named_parameters():
+        assert torch.allclose(p.grad, g_graph[n], rtol=1e-5, atol=1e-7), n
+    # ---- inference
+    model.eval()
+    ipipe = gb.StaticFramePipeline(model, K, 2, pts.shape[0], 4)
+    ipipe.calibrate(pts, bidx)
+    ipipe.load(pts, bidx)
+    ipipe.capture()
+    a = ipipe.replay()["spatial_features"].clone()
+    other = gb.VoxelBackBone8x(4, grid).to(dev).eval()
+    model.load_state_dict(other.state_dict())
+    b = ipipe.replay()["spatial_features"].clone()
+    with torch.no_grad():
+        bd = gb.voxelize_batch(pts, bidx, 2, K, train=True)
+        want = gb.HeightCompression()(model(gb.MeanVFE()(bd)))["spatial_features"]
+    torch.cuda.synchronize()
+    assert not torch.allclose(a, b) and torch.allclose(b, want, rtol=1e-5, atol=1e-6)
