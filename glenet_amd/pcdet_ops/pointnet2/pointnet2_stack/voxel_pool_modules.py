@@ -268,6 +268,11 @@ class NeighborVoxelSAModuleMSG(nn.Module):
     def _bn_rows(seq, y):
         """The BatchNorm (+ ReLU) of Sequential(Conv, BatchNorm[, ReLU]) on (rows, C) tensors."""
         bn = seq[1]
+        from ....spconv import core
+        if y.is_cuda and core.can_fuse_train_bn(bn, y):
+            # two launches forward, two backward on the (rows, C) matrix (csrc/glx_bn.hip) instead of torch's
+            # statistics / transform / reduce / elementwise kernels + a separate ReLU
+            return core.fused_train_bn(bn, y, len(seq) > 2, None)
         if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
             bn.num_batches_tracked += 1
         use_batch = bn.training or not bn.track_running_stats

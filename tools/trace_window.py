@@ -14,6 +14,7 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--marker", default="k_kl_reg_loss")
 ap.add_argument("--top", type=int, default=70)
 ap.add_argument("--out")
+ap.add_argument("--seq", help="also write the launches of the LAST step in time order (start us, duration us, name)")
 args = ap.parse_args()
 
 rows = []
@@ -50,6 +51,12 @@ for k, (c, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:args.top]:
     lines.append("| `%s` | %.1f | %.1f | %.1f | %.1f |" % (k, c / args.steps, us / args.steps, us / c, 100 * us / tot))
 txt = "\n".join(lines)
 print(txt)
+if args.seq:
+    last = rows[marks[-2] + 1:marks[-1] + 1]
+    t0 = last[0][0]
+    with open(args.seq, "w") as f:
+        for s_, e_, n_ in last:
+            f.write("%10.1f %8.1f  %s\n" % ((s_ - t0) / 1e3, (e_ - s_) / 1e3, short(n_)))
 if args.out:
     with open(args.out, "w") as f:
         f.write(txt + "\n")
