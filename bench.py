@@ -209,6 +209,8 @@ def main():
     ap.add_argument("--no-config1", action="store_true", help="skip the configs[1] forward-only sub-measurement")
     ap.add_argument("--no-stages", action="store_true", help="skip the per-stage timing pass")
     ap.add_argument("--fwd-steps", type=int, default=200)
+    ap.add_argument("--bev-layout", choices=("nhwc", "nchw"), default="nhwc",
+                    help="memory layout of the BEV map and the 2-D backbone's activations")
     ap.add_argument("--miopen-find", choices=("on", "off"), default="off",
                     help="off: MIOpen's immediate-mode heuristics pick the dense-conv kernels (seconds); on: its find "
                          "mode (torch.backends.cudnn.benchmark) times candidates during warm-up -- four minutes on a "
@@ -270,7 +272,7 @@ def main():
     npts = max(b[0].shape[0] for b in pool)
 
     torch.manual_seed(0)
-    model = gvr.GLENetVR(K).to(dev).train()
+    model = gvr.GLENetVR(K, bev_channels_last=args.bev_layout == "nhwc").to(dev).train()
     n_params = sum(p.numel() for p in model.parameters())
     total_steps = 3712 // (FRAMES_PER_GPU * world) * 80          # GLENet_VR.yaml:185-186 on KITTI train
     pipe = gvr.StaticTrainStep(model, FRAMES_PER_GPU, npts, K["num_features"], max_gt=16,

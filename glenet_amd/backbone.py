@@ -152,7 +152,13 @@ class MeanVFE(nn.Module):
 class HeightCompression(nn.Module):
     """height_compression.py:10-26: dense() then fold depth into channels."""
 
+    channels_last = False       # True: the BEV map is produced in channels-last memory (SparseConvTensor.dense_bev)
+
     def forward(self, batch_dict):
+        if self.channels_last:
+            batch_dict["spatial_features"] = batch_dict["encoded_spconv_tensor"].dense_bev()
+            batch_dict["spatial_features_stride"] = batch_dict["encoded_spconv_tensor_stride"]
+            return batch_dict
         dense = batch_dict["encoded_spconv_tensor"].dense()
         n, c, d, h, w = dense.shape
         batch_dict["spatial_features"] = dense.view(n, c * d, h, w)

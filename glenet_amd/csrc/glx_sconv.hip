@@ -1875,3 +1875,68 @@ extern "C" int glx_dense_from_index(const float* features, int N, int C, const u
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
+
+
+// dense() for the 2-D BEV backbone in channels-last memory: out (B, H, W, C * D) with channel index c * D + z --
+// the tensor HeightCompression's view (B, C * D, H, W) describes (height_compression.py:21-25), laid out NHWC so
+// that MIOpen's NHWC implicit-GEMM kernels take it without transposes.  One wave per 64 x 4 output channels of a
+// pixel: 16-byte coalesced stores; the D cells of the pixel are looked up through the cell index.
+__global__ __launch_bounds__(256) void k_dense_from_index_nhwc(const float* __restrict__ f, int N, int C,
+                                                               const unsigned long long* __restrict__ bitmap,
+                                                               const int* __restrict__ prefix,
+                                                               const int* __restrict__ rank_to_row, GlxGrid g,
+                                                               float* __restrict__ out) {
+  const int CD = C * g.D, q4 = CD >> 2;                      // CD % 4 == 0
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)g.B * g.H * g.W * q4) return;
+  const int j0 = (int)(t % q4) * 4;
+  long long pix = t / q4;
+  const int x = (int)(pix % g.W);
+  pix /= g.W;
+  const int y = (int)(pix % g.H), b = (int)(pix / g.H);
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int j = j0 + e, c = j / g.D, z = j - c * g.D;
+    int rk = glx_rank_lookup(bitmap, prefix, g.lin(b, z, y, x));
+    if (rk >= 0 && rank_to_row) rk = rank_to_row[rk];
+    if (rk >= 0 && rk < N) v[e] = f[(long long)rk * C + c];
+  }
+  reinterpret_cast<f32x4*>(out)[t] = v;
+}
+
+extern "C" int glx_dense_from_index_nhwc(const float* features, int N, int C, const uint64_t* bitmap,
+                                         const int32_t* prefix, const int32_t* rank_to_row, int B, int D, int H,
+                                         int W, float* out, void* stream) {
+  GLX_REQUIRE(features && bitmap && prefix && out && C > 0 && B > 0 && D > 0 && H > 0 && W > 0 && (C * D) % 4 == 0,
+              "glx_dense_from_index_nhwc: bad arguments (C * D must be a multiple of 4)");
+  GlxGrid g{B, D, H, W};
+  const long long total = (long long)B * H * W * (C * D / 4);
+  hipLaunchKernelGGL(k_dense_from_index_nhwc, dim3((unsigned)glx_divup(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     features, N, C, (const unsigned long long*)bitmap, (const int*)prefix, rank_to_row, g, out);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+__global__ void k_dense_gather_nhwc(const float* __restrict__ gd, const int4* __restrict__ idx, int N, int C, int B,
+                                    int D, int H, int W, float* __restrict__ out, const int* __restrict__ n_live) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_live) N = min(N, *n_live);
+  if (t >= (long long)N * C) return;
+  const int row = (int)(t / C), c = (int)(t - (long long)row * C);
+  const int4 p = idx[row];
+  if ((unsigned)p.x >= (unsigned)B || (unsigned)p.y >= (unsigned)D || (unsigned)p.z >= (unsigned)H ||
+      (unsigned)p.w >= (unsigned)W) { out[t] = 0.f; return; }
+  out[t] = gd[(((long long)p.x * H + p.z) * W + p.w) * ((long long)C * D) + (long long)c * D + p.y];
+}
+
+extern "C" int glx_dense_gather_nhwc(const float* grad_dense, const int32_t* indices, int N, int C, int B, int D,
+                                     int H, int W, float* grad_features, const int32_t* n_live, void* stream) {
+  if (N == 0) return GLX_OK;
+  GLX_REQUIRE(grad_dense && indices && grad_features && C > 0, "glx_dense_gather_nhwc: bad arguments");
+  const long long total = (long long)N * C;
+  hipLaunchKernelGGL(k_dense_gather_nhwc, dim3((unsigned)glx_divup(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     grad_dense, (const int4*)indices, N, C, B, D, H, W, grad_features, n_live);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

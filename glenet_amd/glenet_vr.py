@@ -109,7 +109,9 @@ class VoxelRCNNKLHead(rg.RoIGridPool):
 class GLENetVR(nn.Module):
     """Detector3DTemplate module order of GLENet_VR.yaml."""
 
-    def __init__(self, cfg, num_point_features=4, roi_cfg=None, head_cfg=None):
+    def __init__(self, cfg, num_point_features=4, roi_cfg=None, head_cfg=None, bev_channels_last=True):
+        """bev_channels_last: the BEV map leaves dense() in channels-last memory and the 2-D backbone runs NHWC
+        (MIOpen's implicit-GEMM kernels without their NCHW<->NHWC transposes); values are layout-independent."""
         super().__init__()
         self.cfg = cfg
         self.roi_cfg, self.head_cfg = roi_cfg or ROI_HEAD_CFG, head_cfg or DENSE_HEAD_CFG
@@ -117,6 +119,7 @@ class GLENetVR(nn.Module):
         self.vfe = gb.MeanVFE()
         self.backbone_3d = gb.VoxelBackBone8x(num_point_features, grid)
         self.map_to_bev_module = gb.HeightCompression()
+        self.map_to_bev_module.channels_last = bool(bev_channels_last)
         self.backbone_2d = dp.BEVBackbone(256)
         self.dense_head = dp.AnchorHead(self.backbone_2d.num_bev_features, num_class=1, num_anchors_per_location=2)
         self.roi_head = VoxelRCNNKLHead(self.backbone_3d.backbone_channels, cfg["voxel_size"],

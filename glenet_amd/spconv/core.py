@@ -448,6 +448,19 @@ class SparseConvTensor:
         """(B, C, D, H, W) dense tensor (height_compression.py:21-23)."""
         return DenseFunction.apply(self.features, self, channels_first)
 
+    def dense_bev(self):
+        """HeightCompression's tensor in one step: logical shape (B, C * D, H, W) (= dense().view(B, C * D, H, W),
+        height_compression.py:21-25) held in channels-last memory (B, H, W, C * D), the layout MIOpen's NHWC
+        convolution kernels read without transposing.  Needs the cell index (falls back to dense() otherwise)."""
+        idx = self._index
+        c = self.features.shape[1]
+        if (idx is None or self.features.shape[0] == 0 or (c * self.spatial_shape[0]) % 4
+                or not (self.count is None or idx.count is self.count)):
+            d = self.dense()
+            n, c_, dd, h, w = d.shape
+            return d.view(n, c_ * dd, h, w)
+        return DenseBevFunction.apply(self.features, self)
+
 
 class DenseFunction(Function):
     @staticmethod
@@ -479,6 +492,30 @@ class DenseFunction(Function):
         gf = torch.empty((n, c), dtype=torch.float32, device=g.device)
         call("glx_dense_gather", g, st.indices, n, c, st.batch_size, d, h, w, gf, st.count)
         return gf, None, None
+
+
+class DenseBevFunction(Function):
+    @staticmethod
+    def forward(ctx, features, st):
+        f = features.contiguous().float()
+        _lib.check_cuda(f, st.indices)
+        n, c = f.shape
+        d, h, w = st.spatial_shape
+        idx = st._index
+        out = torch.empty((st.batch_size, h, w, c * d), dtype=torch.float32, device=f.device)
+        call("glx_dense_from_index_nhwc", f, n, c, idx.bitmap, idx.prefix, idx.rank_to_row, st.batch_size, d, h, w, out)
+        ctx.st = st
+        return out.permute(0, 3, 1, 2)              # logical NCHW, channels-last strides
+
+    @staticmethod
+    def backward(ctx, g):
+        st = ctx.st
+        g = g.permute(0, 2, 3, 1).contiguous().float()      # a view when the gradient is channels-last too
+        n, c = st.indices.shape[0], st.features.shape[1]
+        d, h, w = st.spatial_shape
+        gf = torch.empty((n, c), dtype=torch.float32, device=g.device)
+        call("glx_dense_gather_nhwc", g, st.indices, n, c, st.batch_size, d, h, w, gf, st.count)
+        return gf, None
 
 
 class SparseModule(nn.Module):

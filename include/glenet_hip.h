@@ -187,6 +187,13 @@ int glx_dense_gather(const float* grad_dense, const int32_t* indices, int N, int
 int glx_dense_from_index(const float* features, int N, int C, const uint64_t* bitmap,
                          const int32_t* prefix, const int32_t* rank_to_row, int B, int D, int H,
                          int W, float* out, void* stream);
+/* The same tensor as HeightCompression's view (B, C * D, H, W) of dense() (height_compression.py:21-25), written
+ * in channels-last memory: out (B, H, W, C * D), channel index c * D + z, C * D a multiple of 4.  glx_dense_gather_nhwc
+ * is its adjoint (grad_features[row, c] = grad[b, y, x, c * D + z]), honouring n_live like glx_dense_gather. */
+int glx_dense_from_index_nhwc(const float* features, int N, int C, const uint64_t* bitmap, const int32_t* prefix,
+                              const int32_t* rank_to_row, int B, int D, int H, int W, float* out, void* stream);
+int glx_dense_gather_nhwc(const float* grad_dense, const int32_t* indices, int N, int C, int B, int D, int H, int W,
+                          float* grad_features, const int32_t* n_live, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Voxelization.

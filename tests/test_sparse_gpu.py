@@ -303,3 +303,25 @@ def test_fused_train_batchnorm_matches_torch(dev, C, relu, N):
     np.testing.assert_allclose(xf.grad.cpu().numpy(), xr.grad.cpu().numpy(), rtol=1e-3, atol=2e-5)
     np.testing.assert_allclose(bn.weight.grad.cpu().numpy(), bn_ref.weight.grad.cpu().numpy(), rtol=1e-4, atol=1e-3)
     np.testing.assert_allclose(bn.bias.grad.cpu().numpy(), bn_ref.bias.grad.cpu().numpy(), rtol=1e-4, atol=1e-3)
+
+
+def test_dense_bev_channels_last_equals_dense_view(dev):
+    """SparseConvTensor.dense_bev() (channels-last memory, one pass through the cell index) holds exactly the values
+    of dense().view(B, C*D, H, W) (height_compression.py:21-25), and its adjoint equals dense()'s."""
+    rng = np.random.default_rng(8)
+    B, D, H, W, C = 3, 2, 20, 24, 16
+    cells = rng.choice(B * D * H * W, 700, replace=False)
+    idx = np.stack(np.unravel_index(cells, (B, D, H, W)), 1).astype(np.int32)
+    feats = rng.normal(size=(len(idx), C)).astype(np.float32)
+    outs = []
+    for bev in (False, True):
+        f = torch.from_numpy(feats).to(dev).requires_grad_(True)
+        st = sp.SparseConvTensor(f, torch.from_numpy(idx).to(dev), [D, H, W], B)
+        st._ensure_index()
+        y = st.dense_bev() if bev else st.dense().view(B, C * D, H, W)
+        w = torch.linspace(0.1, 2.0, C * D * H * W * B, device=dev).view(B, C * D, H, W)
+        (y * w).sum().backward()
+        outs.append((y.detach(), f.grad.clone()))
+    assert outs[1][0].shape == (B, C * D, H, W) and outs[1][0].is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][0].abs().sum()) > 0
