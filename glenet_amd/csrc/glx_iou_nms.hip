@@ -399,6 +399,168 @@ __global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxe
   if (tid < 64 && r * 64 + tid < N) maskT[(long long)c * N + r * 64 + tid] = s_bits[tid];
 }
 
+// ---- broad phase for large box sets.  The tiles above test all N^2 / 2 pairs against the far-apart rule
+// (40 M pairs for 9000 proposals: 0.67 ms for the 4 frames of a training batch, nearly all of it on pairs that
+// are metres apart).  Boxes are score-sorted, so tiles have no spatial coherence; a uniform BEV grid has:
+// cell size >= the largest box diameter + the far-apart slack, so every pair that survives the far-apart test
+// lies in the same or a neighbouring cell.  k_nms_bins (one block per frame): extent and largest radius, cell
+// of every box, counting sort by cell in LDS.  k_nms_pairs (a wave per box): the boxes of the 3 x 3 cells
+// around it, lanes = candidates, only pairs (i, j > i); survivors of the far-apart test get the exact
+// rotated overlap and hits are OR-ed into the (zero-filled) matrix.  Same predicate, same bits as k_nms_mask.
+#define NMS_GRID 64                      // cells per axis (at most)
+#define NMS_BIN_THREADS 1024
+struct NmsGrid {
+  float x0, y0, inv;                     // cell = floor((c - origin) * inv)
+  int gx, gy;
+};
+
+__global__ __launch_bounds__(NMS_BIN_THREADS) void k_nms_bins(const PBox* __restrict__ pb, int N,
+                                                              NmsGrid* __restrict__ grids, int* __restrict__ cell_off,
+                                                              int* __restrict__ order) {
+  const int f = blockIdx.x, tid = threadIdx.x;
+  pb += (long long)f * N;
+  cell_off += (long long)f * (NMS_GRID * NMS_GRID + 1);
+  order += (long long)f * N;
+  __shared__ float s_red[5][NMS_BIN_THREADS / 64];
+  __shared__ NmsGrid s_g;
+  __shared__ int s_cnt[NMS_GRID * NMS_GRID + 1];
+  float mnx = 3.0e38f, mny = 3.0e38f, mxx = -3.0e38f, mxy = -3.0e38f, mxr = 0.f;
+  for (int i = tid; i < N; i += NMS_BIN_THREADS) {
+    const PBox p = pb[i];
+    if (!(p.cx == p.cx) || !(p.cy == p.cy)) continue;     // NaN boxes overlap nothing: they go to cell 0
+    mnx = fminf(mnx, p.cx); mxx = fmaxf(mxx, p.cx);
+    mny = fminf(mny, p.cy); mxy = fmaxf(mxy, p.cy);
+    if (p.rad == p.rad) mxr = fmaxf(mxr, p.rad);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    mnx = fminf(mnx, __shfl_xor(mnx, o, 64)); mny = fminf(mny, __shfl_xor(mny, o, 64));
+    mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, o, 64));
+    mxr = fmaxf(mxr, __shfl_xor(mxr, o, 64));
+  }
+  if ((tid & 63) == 0) {
+    const int w = tid >> 6;
+    s_red[0][w] = mnx; s_red[1][w] = mny; s_red[2][w] = mxx; s_red[3][w] = mxy; s_red[4][w] = mxr;
+  }
+  for (int c = tid; c <= NMS_GRID * NMS_GRID; c += NMS_BIN_THREADS) s_cnt[c] = 0;
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < NMS_BIN_THREADS / 64; ++w) {
+      s_red[0][0] = fminf(s_red[0][0], s_red[0][w]); s_red[1][0] = fminf(s_red[1][0], s_red[1][w]);
+      s_red[2][0] = fmaxf(s_red[2][0], s_red[2][w]); s_red[3][0] = fmaxf(s_red[3][0], s_red[3][w]);
+      s_red[4][0] = fmaxf(s_red[4][0], s_red[4][w]);
+    }
+    NmsGrid g;
+    g.x0 = s_red[0][0]; g.y0 = s_red[1][0];
+    const float ex = fmaxf(s_red[2][0] - g.x0, 0.f), ey = fmaxf(s_red[3][0] - g.y0, 0.f);
+    // a pair passes the far-apart test only if its centres are within 2 * max radius + 0.05: one cell apart
+    float cell = 2.f * s_red[4][0] + 0.06f;
+    cell = fmaxf(cell, fmaxf(ex, ey) / (float)NMS_GRID * 1.0001f + 1e-6f);
+    if (!(cell < 3.0e38f)) cell = 3.0e38f;                 // infinite radius: one cell
+    g.inv = 1.f / cell;
+    g.gx = min(NMS_GRID, (int)(ex * g.inv) + 1);
+    g.gy = min(NMS_GRID, (int)(ey * g.inv) + 1);
+    s_g = g;
+    grids[f] = g;
+  }
+  __syncthreads();
+  const NmsGrid g = s_g;
+  auto cell_of = [&](const PBox& p) {
+    if (!(p.cx == p.cx) || !(p.cy == p.cy)) return 0;
+    const int ix = min(g.gx - 1, max(0, (int)((p.cx - g.x0) * g.inv)));
+    const int iy = min(g.gy - 1, max(0, (int)((p.cy - g.y0) * g.inv)));
+    return iy * g.gx + ix;
+  };
+  for (int i = tid; i < N; i += NMS_BIN_THREADS) atomicAdd(&s_cnt[cell_of(pb[i])], 1);
+  __syncthreads();
+  {                                                        // exclusive scan of the <= 4096 counts, 4 cells per thread
+    const int nc = g.gx * g.gy, c0 = tid * 4;
+    int v[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[q] = c0 + q < nc ? s_cnt[c0 + q] : 0; sum += v[q]; }
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if ((tid & 63) >= o) inc += t; }
+    __shared__ int s_wave[NMS_BIN_THREADS / 64];
+    if ((tid & 63) == 63) s_wave[tid >> 6] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (tid >> 6); ++w) base += s_wave[w];
+    int run = base + inc - sum;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (c0 + q < nc) { s_cnt[c0 + q] = run; cell_off[c0 + q] = run; }
+      run += v[q];
+    }
+    if (tid == NMS_BIN_THREADS - 1) cell_off[nc] = N;
+  }
+  __syncthreads();
+  for (int i = tid; i < N; i += NMS_BIN_THREADS) order[atomicAdd(&s_cnt[cell_of(pb[i])], 1)] = i;
+}
+
+__global__ __launch_bounds__(256) void k_nms_pairs(const PBox* __restrict__ pb, int N, float thresh, int col_blocks,
+                                                   const NmsGrid* __restrict__ grids, const int* __restrict__ cell_off,
+                                                   const int* __restrict__ order,
+                                                   unsigned long long* __restrict__ maskT) {
+  const int f = blockIdx.y, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= N) return;
+  pb += (long long)f * N;
+  cell_off += (long long)f * (NMS_GRID * NMS_GRID + 1);
+  order += (long long)f * N;
+  maskT += (long long)f * N * col_blocks;
+  const NmsGrid g = grids[f];
+  const PBox A = pb[i];
+  if (!(A.cx == A.cx) || !(A.cy == A.cy)) return;
+  const int ix = min(g.gx - 1, max(0, (int)((A.cx - g.x0) * g.inv)));
+  const int iy = min(g.gy - 1, max(0, (int)((A.cy - g.y0) * g.inv)));
+  // survivors of the far-apart test are queued per wave and evaluated 64 at a time, a lane per pair: the rotated
+  // overlap is ~600 branchy flops, run on the few passing lanes of a candidate batch it would idle the others
+  __shared__ int s_q[4][128];
+  int* q = s_q[threadIdx.x >> 6];
+  int qn = 0;
+  auto flush = [&](int n) {                                // evaluate q[0..n), n <= 64
+    if (lane < n) {
+      const int j = q[lane];
+      const PBox B = pb[j];
+      const float sgm = box_overlap<false>(rbox_from(A), rbox_from(B));
+      if (sgm / fmaxf(A.area + B.area - sgm, IOU_EPS) > thresh)
+        atomicOr(&maskT[(long long)(j >> 6) * N + i], 1ull << (j & 63));
+    }
+  };
+  for (int dy = -1; dy <= 1; ++dy) {
+    const int cy = iy + dy;
+    if (cy < 0 || cy >= g.gy) continue;
+    const int c0 = cy * g.gx + max(ix - 1, 0), c1 = cy * g.gx + min(ix + 1, g.gx - 1);
+    const int e0 = cell_off[c0], e1 = cell_off[c1 + 1];    // the (up to) three cells of a row are contiguous
+    for (int eb = e0; eb < e1; eb += 64) {                 // wave-uniform trip count
+      const int e = eb + lane;
+      int j = -1;
+      bool pass = false;
+      if (e < e1) {
+        j = order[e];
+        pass = j > i && !pbox_far(A, pb[j]);
+      }
+      const unsigned long long bal = __ballot(pass);
+      if (pass) q[qn + __popcll(bal & ((1ull << lane) - 1ull))] = j;
+      qn += __popcll(bal);
+      if (qn >= 64) {
+        flush(64);
+        const int moved = lane + 64 < qn ? q[lane + 64] : 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane + 64 < qn) q[lane] = moved;
+        qn -= 64;
+      }
+    }
+  }
+  flush(qn);
+}
+
+static size_t nms_grid_bytes(int N) {
+  return glx_align(sizeof(NmsGrid)) + glx_align((size_t)(NMS_GRID * NMS_GRID + 1) * sizeof(int)) +
+         glx_align((size_t)(N > 0 ? N : 1) * sizeof(int));
+}
+#define NMS_BROAD_MIN 1024               // below this the tiles are few and the dense matrix is cheaper
+
 // Greedy sweep of the matrix, 64 boxes per step (host loop of iou3d_nms.cpp:119-132), one block of
 // 256 threads.  The removed-word of column block b is evaluated ON DEMAND: OR over the boxes kept
 // so far of maskT[b][box] -- all threads gather from one contiguous column block (L2-friendly) and
@@ -487,8 +649,8 @@ static size_t nms_mask_bytes(int N) {
   size_t cb = (size_t)((N + 63) / 64);
   return glx_align((size_t)(N > 0 ? N : 1) * cb * 8);
 }
-extern "C" size_t glx_nms_workspace_bytes(int N) {   // suppression matrix + prepared boxes
-  return nms_mask_bytes(N) + glx_align((size_t)(N > 0 ? N : 1) * sizeof(PBox)) + 256;
+extern "C" size_t glx_nms_workspace_bytes(int N) {   // suppression matrix + prepared boxes + broad-phase grid
+  return nms_mask_bytes(N) + glx_align((size_t)(N > 0 ? N : 1) * sizeof(PBox)) + nms_grid_bytes(N) + 256;
 }
 
 // Batched form: `frames` independent box lists of N boxes each (boxes (F,N,7), keep (F,N),
@@ -507,8 +669,8 @@ extern "C" int glx_nms_batch(const float* boxes_sorted, int frames, int N, float
   }
   GLX_REQUIRE(boxes_sorted, "glx_nms: null boxes");
   int col_blocks = (N + 63) / 64;
-  const size_t mask_b = nms_mask_bytes(N), pb_b = glx_align((size_t)N * sizeof(PBox));
-  size_t need = (size_t)frames * (mask_b + pb_b);
+  const size_t mask_b = nms_mask_bytes(N), pb_b = glx_align((size_t)N * sizeof(PBox)), grid_b = nms_grid_bytes(N);
+  size_t need = (size_t)frames * (mask_b + pb_b + grid_b);
   if (!workspace || workspace_bytes < need) {
     glx_set_error("glx_nms: workspace %zu < %zu bytes", workspace_bytes, need);
     return GLX_EWORKSPACE;
@@ -525,8 +687,22 @@ extern "C" int glx_nms_batch(const float* boxes_sorted, int frames, int N, float
   } else {
     hipLaunchKernelGGL(k_nms_prepare, dim3(glx_divup(N, 256), frames), dim3(256), 0, st, boxes_sorted,
                        N, pb);
-    hipLaunchKernelGGL((k_nms_mask<false>), dim3(ntiles, frames), dim3(256), 0, st, boxes_sorted,
-                       (const PBox*)pb, N, thresh, col_blocks, mask);
+    if (N >= NMS_BROAD_MIN && thresh >= 0.f) {     // thresh < 0 suppresses disjoint boxes too: every pair counts
+      char* gbase = (char*)workspace + (size_t)frames * (mask_b + pb_b);
+      NmsGrid* grids = (NmsGrid*)gbase;
+      int* cell_off = (int*)(gbase + glx_align((size_t)frames * sizeof(NmsGrid)));
+      int* order = cell_off + (size_t)frames * (NMS_GRID * NMS_GRID + 1);
+      GlxFillJob zj{mask, (size_t)frames * (size_t)N * col_blocks * 8, 0};
+      int rc = glx_fill_multi(&zj, 1, st);
+      if (rc != GLX_OK) return rc;
+      hipLaunchKernelGGL(k_nms_bins, dim3(frames), dim3(NMS_BIN_THREADS), 0, st, (const PBox*)pb, N, grids, cell_off,
+                         order);
+      hipLaunchKernelGGL(k_nms_pairs, dim3(glx_divup(N, 4), frames), dim3(256), 0, st, (const PBox*)pb, N, thresh,
+                         col_blocks, (const NmsGrid*)grids, (const int*)cell_off, (const int*)order, mask);
+    } else {
+      hipLaunchKernelGGL((k_nms_mask<false>), dim3(ntiles, frames), dim3(256), 0, st, boxes_sorted,
+                         (const PBox*)pb, N, thresh, col_blocks, mask);
+    }
   }
   GLX_REQUIRE((size_t)N * 4 <= 150 * 1024, "glx_nms: N = %d exceeds the %d boxes the sweep keeps in LDS", N,
               150 * 1024 / 4);
