@@ -173,9 +173,11 @@ def roofline_of(per, prof_steps):
                 frac=round(mfma_frac if bound == "mfma" else hbm_frac_alg, 4),
                 traffic=traffic,
                 avg_launch_us=round(d["ms"] * 1e3 / n, 2), launches=n,
-                duration_source="HIP events around the kernel (hipExtLaunchKernelGGL) in an eager pass of the "
-                                "same launches, one frame in flight; the graph-replayed headline keeps two "
-                                "frames in flight, where rocprofv3 reads ~5 % longer per launch",
+                duration_source="HIP events around the kernel (hipExtLaunchKernelGGL) in an eager pass of configs[1]'s "
+                                "launches, one frame in flight -- `bench.py --roofline-only` runs exactly this pass, "
+                                "its rocprofv3 --kernel-trace --stats summary is profiles/r02_roofline_kernel_stats.csv; "
+                                "a full run's rocprof average of the same kernel also covers the training step's "
+                                "forward / input-gradient launches and the two-frames-in-flight replays (~10 % longer)",
                 flops_per_launch=int(d["flops"] / n), mfma_frac=round(mfma_frac, 4),
                 hbm=dict(achieved_algorithmic_GBps=round(alg_gbs, 1), frac_algorithmic=round(hbm_frac_alg, 4),
                          alg_bytes_per_launch=int(d["bytes"] / n), bytes_min_per_launch=int(bmin),
@@ -209,6 +211,11 @@ def main():
     ap.add_argument("--no-config1", action="store_true", help="skip the configs[1] forward-only sub-measurement")
     ap.add_argument("--no-stages", action="store_true", help="skip the per-stage timing pass")
     ap.add_argument("--fwd-steps", type=int, default=200)
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="run only the event-bracketed eager pass of configs[1]'s launches (the `roofline` object): the "
+                         "command to put under rocprofv3 --kernel-trace --stats when its per-kernel averages are to "
+                         "be compared with the HIP-event figures (a full run mixes in the training step's launches "
+                         "and the two-frames-in-flight replays of the same kernels)")
     ap.add_argument("--bev-layout", choices=("nhwc", "nchw"), default="nhwc",
                     help="memory layout of the BEV map and the 2-D backbone's activations")
     ap.add_argument("--miopen-find", choices=("on", "off"), default="off",
@@ -286,7 +293,10 @@ def main():
         pipe.data_parallel()
     pipe.load(*pool[0][:4])
     progress("model + %d batches resident, capacities calibrated; capturing the step" % BATCH_POOL)
-    if args.mode == "graph":
+    if args.roofline_only:
+        args.steps = args.warmup = 0
+        args.no_stages = True
+    elif args.mode == "graph":
         pipe.capture(split=world > 1)
     else:
         pipe.split = world > 1
@@ -304,7 +314,8 @@ def main():
     for _ in range(args.warmup):
         train_step()
     torch.cuda.synchronize(dev)
-    pipe.check()
+    if args.warmup > 0:
+        pipe.check()
     progress("timing %d steps" % args.steps)
 
     # ---- headline: exactly K steps between two fences, nothing else in the region
@@ -314,11 +325,14 @@ def main():
         train_step()
     gdist.fence(dev)
     dt = gdist.reduce_max(time.perf_counter() - t0, dev)
-    pipe.check()          # capacities held over every batch of the pool (one read-back, after the clock)
-    loss_end = float(pipe.loss.detach())
-    parts_end = {k: round(float(v), 5) for k, v in pipe.parts.items()}
+    if args.steps > 0:
+        pipe.check()      # capacities held over every batch of the pool (one read-back, after the clock)
+        loss_end = float(pipe.loss.detach())
+        parts_end = {k: round(float(v), 5) for k, v in pipe.parts.items()}
+    else:
+        loss_end, parts_end = None, None
 
-    progress("headline done: %.2f ms/step" % (dt / args.steps * 1e3))
+    progress("headline done: %.2f ms/step" % (dt / max(args.steps, 1) * 1e3))
     # ---- per-stage milliseconds: one event-bracketed eager pass of the same launches per pool batch
     stages = None
     if not args.no_stages:
@@ -352,11 +366,12 @@ def main():
         bb.eval()
         pts0, bidx0 = pool[0][0], pool[0][1]
         fpipes = []
-        for _ in range(2):
+        for _ in range(1 if args.roofline_only else 2):
             p_ = gb.StaticFramePipeline(bb, K, FRAMES_PER_GPU, npts, K["num_features"])
             p_.capacities = dict(caps)
             p_.load(pts0, bidx0)
-            p_.capture()
+            if not args.roofline_only:
+                p_.capture()
             fpipes.append(p_)
         streams = [torch.cuda.Stream(dev) for _ in fpipes]
         turn = [0]
@@ -368,25 +383,28 @@ def main():
             with torch.cuda.stream(streams[i]):
                 fpipes[i].load(b[0], b[1])
                 return fpipes[i].replay()
-        for _ in range(20):
+        if args.roofline_only:
+            args.fwd_steps = 0
+        for _ in range(20 if args.fwd_steps else 0):
             fwd_step()
         gdist.fence(dev)
         t1 = time.perf_counter()
         for _ in range(args.fwd_steps):
             fwd_step()
         gdist.fence(dev)
-        dtf = gdist.reduce_max(time.perf_counter() - t1, dev)
+        dtf = max(gdist.reduce_max(time.perf_counter() - t1, dev), 1e-9)
         for p_ in fpipes:
-            p_.check()
+            if args.fwd_steps:
+                p_.check()
         config1 = dict(workload="configs[1]: VoxelBackBone8x (8 SubMConv3d + 4 SparseConv3d, spconv_backbone.py:77-117) "
                                 "forward only, eval-mode BatchNorm folded, batch 4, %d batches cycled" % BATCH_POOL,
                        frames_per_s=round(FRAMES_PER_GPU * world * args.fwd_steps / dtf, 1),
-                       ms_per_step=round(dtf / args.fwd_steps * 1e3, 4), steps=args.fwd_steps)
+                       ms_per_step=round(dtf / max(args.fwd_steps, 1) * 1e3, 4), steps=args.fwd_steps)
         # roofline pass: the same launches, eager, each sparse-conv kernel bracketed by HIP events
         prof = ConvProfiler()
         spcore._profile_hook = prof
         prof.enabled = True
-        prof_steps = 24
+        prof_steps = 48 if args.roofline_only else 24
         for s in range(prof_steps):
             fpipes[0].load(pool[s % BATCH_POOL][0], pool[s % BATCH_POOL][1])
             fpipes[0].enqueue()
@@ -396,10 +414,14 @@ def main():
         roof = roofline_of(prof.summary(), prof_steps)
 
     if rank == 0:
+        if args.roofline_only:
+            print(json.dumps(dict(metric=METRIC, value=None, unit="frames/s", n_gpus=world, roofline_only=True,
+                                  dtype="f32", data="synthetic", roofline=roof)), flush=True)
+            return
         st = pipe.out["encoded_spconv_tensor"]
         out = dict(metric=METRIC, value=round(FRAMES_PER_GPU * world * args.steps / dt, 2), unit="frames/s",
                    n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True, scaling="weak",
+                   ms_per_step=round(dt / max(args.steps, 1) * 1e3, 4), higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="f32", data="synthetic",
                    config=dict(workload="configs[2] per-GPU share: GLENet-VR Voxel-RCNN full train step (voxelize + sparse "
                                         "backbone + BEV head + NMS 9000->512 + RoI targets 128/frame + RoI-grid pool + "
