@@ -63,12 +63,32 @@ class BEVBackbone(nn.Module):
         for i, blk in enumerate(self.blocks):
             x = self._run_block(blk, x)
             data_dict["spatial_features_%dx" % int(x0.shape[2] / x.shape[2])] = x
-            ups.append(self.deblocks[i](x) if len(self.deblocks) > 0 else x)
+            ups.append(self._run_block(self.deblocks[i], x) if len(self.deblocks) > 0 else x)
         x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
         if len(self.deblocks) > len(self.blocks):
-            x = self.deblocks[-1](x)
+            x = self._run_block(self.deblocks[-1], x)
         data_dict["spatial_features_2d"] = x
         return data_dict
+
+    @staticmethod
+    def _fused_bn_relu(bn, x, relu):
+        """Training-mode BatchNorm2d (+ ReLU) on a channels-last map through the fused row kernels of the sparse
+        backbone (csrc/glx_bn.hip): a channels-last (B, C, H, W) tensor IS a row-major (B*H*W, C) matrix.  Four
+        launches forward + backward instead of MIOpen's six NHWC kernels + two ReLU passes; same statistics
+        semantics as nn.BatchNorm2d (tests/test_sparse_gpu.py::test_fused_train_batchnorm_matches_torch)."""
+        from .spconv import core
+        b, c, h, w = x.shape
+        rows = x.permute(0, 2, 3, 1).reshape(b * h * w, c)            # a view of channels-last memory
+        y = core.fused_train_bn(bn, rows, relu, None)
+        return y.view(b, h, w, c).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def _can_fuse_bn(bn, x):
+        from .spconv import core
+        return (isinstance(bn, nn.BatchNorm2d) and bn.training and x.is_cuda and x.dim() == 4
+                and x.is_contiguous(memory_format=torch.channels_last) and torch.is_grad_enabled()
+                and core.USE_FUSED_TRAIN_BN and bn.affine and bn.momentum is not None
+                and bn.num_features % 4 == 0 and bn.num_features <= 512 and 1024 % bn.num_features == 0)
 
     @staticmethod
     def _run_block(blk, x):
@@ -85,6 +105,11 @@ class BEVBackbone(nn.Module):
                 c = mods[i + 1]
                 x = F.conv2d(x, c.weight, c.bias, c.stride, 1, c.dilation, c.groups)
                 i += 2
+                continue
+            if BEVBackbone._can_fuse_bn(m, x):
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = BEVBackbone._fused_bn_relu(m, x, relu)
+                i += 2 if relu else 1
                 continue
             x = m(x)
             i += 1

@@ -155,3 +155,42 @@ def test_waymo_shaped_full_size_shard(dev):
     torch.cuda.synchronize()
     pipe.check()
     np.testing.assert_allclose(out["spatial_features"].cpu().numpy(), dense.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_bev_backbone_training_nhwc_fused_bn_equals_torch_path(dev):
+    """BEVBackbone in training mode on a channels-last map: ZeroPad2d + conv folded into one padded conv and
+    BatchNorm2d + ReLU on the fused row kernels == the plain nn.Sequential modules on the same NCHW data: output,
+    input gradient, every parameter gradient, running statistics."""
+    import copy
+    from glenet_amd.spconv import core
+    torch.manual_seed(3)
+    a = dp.BEVBackbone(16, (2, 2), (1, 2), (32, 64), (1, 2), (32, 32)).to(dev).train()
+    for m in a.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    b = copy.deepcopy(a)
+    x0 = torch.randn(3, 16, 24, 20, device=dev) * (torch.rand(3, 1, 24, 20, device=dev) < 0.3)
+    res = []
+    for mod, fused in ((a, True), (b, False)):
+        x = (x0.contiguous(memory_format=torch.channels_last) if fused else x0.clone()).requires_grad_(True)
+        if fused:
+            assert dp.BEVBackbone._can_fuse_bn(mod.blocks[0][2], mod.blocks[0][1](torch.nn.functional.pad(x, (1, 1, 1, 1))))
+            y = mod({"spatial_features": x})["spatial_features_2d"]
+        else:
+            h, ups = x, []
+            for i, blk in enumerate(mod.blocks):          # the reference's statement sequence (base_bev_backbone.py:88-104)
+                h = blk(h)
+                ups.append(mod.deblocks[i](h))
+            y = torch.cat(ups, dim=1)
+        (y * torch.linspace(0.5, 1.5, y.shape[1], device=dev).view(1, -1, 1, 1)).square().mean().backward()
+        res.append((y.detach(), x.grad.clone(), {n: p.grad.clone() for n, p in mod.named_parameters()},
+                    {n: t.clone() for n, t in mod.named_buffers()}))
+    (y1, g1, p1, b1), (y2, g2, p2, b2) = res
+    np.testing.assert_allclose(y1.cpu().numpy(), y2.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(g1.cpu().numpy(), g2.cpu().numpy(), rtol=1e-3, atol=1e-7 + 1e-4 * float(g2.abs().max()))
+    for k in p1:
+        np.testing.assert_allclose(p1[k].cpu().numpy(), p2[k].cpu().numpy(), rtol=2e-3,
+                                   atol=1e-7 + 2e-4 * float(p2[k].abs().max()), err_msg=k)
+    for k in b1:
+        np.testing.assert_allclose(b1[k].cpu().numpy(), b2[k].cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
