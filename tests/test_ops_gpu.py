@@ -259,7 +259,10 @@ def test_voxel_query_dense_and_index(dev):
                    rng.integers(0, X, M)], 1).astype(np.int32)
     qc[:, 1] = np.clip(qc[:, 1], 0, Z - 1)
     q = ((qc[:, [3, 2, 1]] + rng.random((M, 3))) * np.array([0.1, 0.1, 0.2])).astype(np.float32)
-    for rng_, radius, ns in [((4, 4, 4), 0.4, 16), ((1, 2, 2), 0.25, 4), ((0, 1, 1), 0.05, 8)]:
+    # x windows of 9 / 5 / 3 cells (row-wise bitmap scan), 31 cells (widest row-wise case, rows crossing
+    # bitmap words and the grid border) and 35 cells (per-cell scan)
+    for rng_, radius, ns in [((4, 4, 4), 0.4, 16), ((1, 2, 2), 0.25, 4), ((0, 1, 1), 0.05, 8),
+                             ((1, 1, 15), 0.9, 12), ((1, 0, 17), 1.2, 20)]:
         ref, ref_e = oracle.voxel_query(rng_, radius, ns, xyz, q, qc, v2p)
         got, got_e = voxel_query_utils.voxel_query(rng_, radius, ns, T(xyz, dev), T(q, dev), T(qc, dev), T(v2p, dev))
         assert np.array_equal(got.cpu().numpy(), ref) and np.array_equal(got_e.cpu().numpy(), ref_e)
