@@ -323,6 +323,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         train_step()
+    t_enq = time.perf_counter() - t0      # host time to enqueue the K steps (the device runs behind it)
     gdist.fence(dev)
     dt = gdist.reduce_max(time.perf_counter() - t0, dev)
     if args.steps > 0:
@@ -436,7 +437,8 @@ def main():
                                      "static": "shape-static step, launches enqueued from Python"}[args.mode],
                                parallelism="dp%d: frames shard; one flat RCCL all-reduce of %.1f MB gradients per step"
                                            % (world, n_params * 4 / 1e6) if world > 1 else "dp1 (single GPU, no collective)",
-                               ranks_seen_by_collective=ranks_seen),
+                               ranks_seen_by_collective=ranks_seen,
+                               host_enqueue_ms_per_step=round(t_enq / max(args.steps, 1) * 1e3, 4)),
                    loss=dict(last=round(loss_end, 5), parts=parts_end),
                    stages_ms=stages, config1=config1, roofline=roof)
         progress("config1 + roofline done")

@@ -227,6 +227,158 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_backward_apply(
   }
 }
 
+// ------------------------------------------------------------------ short matrices: one launch
+// The RoI head's FC towers normalise (512, 256) matrices: the three-launch scheme above (and torch's five
+// forward / three backward kernels) is pure launch latency there.  A block owns 16 channels over ALL rows:
+// column statistics (fp64, fixed order: 16 row lanes per wave by shuffles, then the 4 waves in LDS), the
+// finalize and the transform in one kernel; x is read a second time from L2 for the transform.
+#define BN_SMALL_N 4096
+#define BN_SMALL_CQ 4    // float4 columns = 16 channels per block
+
+// sum of v over the threads of the block that share `q` (= threadIdx.x % 4); every thread gets the result
+__device__ __forceinline__ void bn_small_reduce(double (&s0)[4], double (&s1)[4], double (*s_part)[BN_SMALL_CQ][8]) {
+#pragma unroll
+  for (int off = BN_SMALL_CQ; off < 64; off <<= 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s0[i] += __shfl_xor(s0[i], off, 64);
+      s1[i] += __shfl_xor(s1[i], off, 64);
+    }
+  }
+  const int q = threadIdx.x % BN_SMALL_CQ, wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) < BN_SMALL_CQ) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s_part[wave][q][i] = s0[i]; s_part[wave][q][4 + i] = s1[i]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    s0[i] = s_part[0][q][i];
+    s1[i] = s_part[0][q][4 + i];
+    for (int w = 1; w < BN_THREADS / 64; ++w) { s0[i] += s_part[w][q][i]; s1[i] += s_part[w][q][4 + i]; }
+  }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void k_bn_small_forward(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float eps, float momentum, int relu, int N, int C, const int* __restrict__ n_live,
+    float* __restrict__ y, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+    float* __restrict__ running_mean, float* __restrict__ running_var) {
+  __shared__ double s_part[BN_THREADS / 64][BN_SMALL_CQ][8];
+  int n = N;
+  if (n_live) n = min(N, *n_live);
+  const int q = threadIdx.x % BN_SMALL_CQ, rl = threadIdx.x / BN_SMALL_CQ;
+  const int c0 = (blockIdx.x * BN_SMALL_CQ + q) * 4;
+  const bool cok = c0 < C;
+  constexpr int RL = BN_THREADS / BN_SMALL_CQ;
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  if (cok) {
+    for (int r = rl; r < n; r += RL) {
+      const bf32x4 v = *reinterpret_cast<const bf32x4*>(x + (long long)r * C + c0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s0[i] += (double)v[i]; s1[i] += (double)v[i] * (double)v[i]; }
+    }
+  }
+  bn_small_reduce(s0, s1, s_part);
+  if (!cok) return;
+  float sc[4], sh[4];
+  const double cnt = n > 0 ? (double)n : 1.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double m = s0[i] / cnt;
+    double var = s1[i] / cnt - m * m;
+    if (var < 0) var = 0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float gm = gamma ? gamma[c0 + i] : 1.f, bt = beta ? beta[c0 + i] : 0.f;
+    sc[i] = is * gm;
+    sh[i] = bt - (float)m * is * gm;
+    if (rl == 0) {
+      save_mean[c0 + i] = (float)m;
+      save_invstd[c0 + i] = is;
+      if (running_mean) {
+        const double unb = n > 1 ? var * cnt / (cnt - 1.0) : var;
+        running_mean[c0 + i] = (1.f - momentum) * running_mean[c0 + i] + momentum * (float)m;
+        running_var[c0 + i] = (1.f - momentum) * running_var[c0 + i] + momentum * (float)unb;
+      }
+    }
+  }
+  for (int r = rl; r < n; r += RL) {
+    bf32x4 v = *reinterpret_cast<const bf32x4*>(x + (long long)r * C + c0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float t = v[i] * sc[i] + sh[i];
+      v[i] = relu ? fmaxf(t, 0.f) : t;
+    }
+    *reinterpret_cast<bf32x4*>(y + (long long)r * C + c0) = v;
+  }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void k_bn_small_backward(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+    int relu, int N, int C, const int* __restrict__ n_live, float* __restrict__ dx,
+    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double s_part[BN_THREADS / 64][BN_SMALL_CQ][8];
+  int n = N;
+  if (n_live) n = min(N, *n_live);
+  const int q = threadIdx.x % BN_SMALL_CQ, rl = threadIdx.x / BN_SMALL_CQ;
+  const int c0 = (blockIdx.x * BN_SMALL_CQ + q) * 4;
+  const bool cok = c0 < C;
+  constexpr int RL = BN_THREADS / BN_SMALL_CQ;
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  bf32x4 mu = bf32x4{0, 0, 0, 0}, is = mu;
+  if (cok) {
+    mu = *reinterpret_cast<const bf32x4*>(mean + c0);
+    is = *reinterpret_cast<const bf32x4*>(invstd + c0);
+    for (int r = rl; r < n; r += RL) {
+      const long long o = (long long)r * C + c0;
+      const bf32x4 xv = *reinterpret_cast<const bf32x4*>(x + o);
+      bf32x4 g = *reinterpret_cast<const bf32x4*>(dy + o);
+      if (relu) {
+        const bf32x4 yv = *reinterpret_cast<const bf32x4*>(y + o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = yv[i] > 0.f ? g[i] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s0[i] += (double)g[i];
+        s1[i] += (double)g[i] * (double)((xv[i] - mu[i]) * is[i]);
+      }
+    }
+  }
+  bn_small_reduce(s0, s1, s_part);
+  if (!cok) return;
+  const double cnt = n > 0 ? (double)n : 1.0;
+  float a[4], b[4], cc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = (gamma ? gamma[c0 + i] : 1.f) * is[i];
+    b[i] = (float)(s0[i] / cnt);
+    cc[i] = (float)(s1[i] / cnt);
+    if (rl == 0) {
+      if (dgamma) dgamma[c0 + i] = (float)s1[i];
+      if (dbeta) dbeta[c0 + i] = (float)s0[i];
+    }
+  }
+  for (int r = rl; r < n; r += RL) {
+    const long long o = (long long)r * C + c0;
+    const bf32x4 xv = *reinterpret_cast<const bf32x4*>(x + o);
+    bf32x4 g = *reinterpret_cast<const bf32x4*>(dy + o);
+    if (relu) {
+      const bf32x4 yv = *reinterpret_cast<const bf32x4*>(y + o);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g[i] = yv[i] > 0.f ? g[i] : 0.f;
+    }
+    bf32x4 ov;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float xh = (xv[i] - mu[i]) * is[i];
+      ov[i] = a[i] * (g[i] - b[i] - xh * cc[i]);
+    }
+    *reinterpret_cast<bf32x4*>(dx + o) = ov;
+  }
+}
+
 static bool bn_channels_ok(int C) { return C >= 4 && C <= BN_MAXC && (C & 3) == 0 && BN_THREADS % (C >> 2) == 0; }
 
 // workspace: slab partials (fp64) + 3*C coefficient floats
@@ -248,6 +400,13 @@ extern "C" int glx_bn_relu_train_forward(const float* x, int N, int C, const flo
   }
   if (N <= 0) return GLX_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (N <= BN_SMALL_N) {
+    hipLaunchKernelGGL(k_bn_small_forward, dim3(glx_divup(C, 4 * BN_SMALL_CQ)), dim3(BN_THREADS), 0, st, x,
+                       gamma, beta, eps, momentum, relu, N, C, n_live, y, save_mean, save_invstd,
+                       running_mean, running_var);
+    GLX_LAUNCH_CHECK();
+    return GLX_OK;
+  }
   const int slabs = glx_divup(N, 8) > BN_SLABS ? BN_SLABS : glx_divup(N, 8);
   hipLaunchKernelGGL((k_bn_partial<false>), dim3(slabs), dim3(BN_THREADS), 0, st, x, nullptr, nullptr,
                      nullptr, nullptr, 0, N, C, n_live, (double*)workspace);
@@ -278,6 +437,12 @@ extern "C" int glx_bn_relu_backward(const float* x, const float* dy, const float
   }
   if (N <= 0) return GLX_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (N <= BN_SMALL_N) {
+    hipLaunchKernelGGL(k_bn_small_backward, dim3(glx_divup(C, 4 * BN_SMALL_CQ)), dim3(BN_THREADS), 0, st, x,
+                       dy, y, gamma, save_mean, save_invstd, relu, N, C, n_live, dx, dgamma, dbeta);
+    GLX_LAUNCH_CHECK();
+    return GLX_OK;
+  }
   const int slabs = glx_divup(N, 8) > BN_SLABS ? BN_SLABS : glx_divup(N, 8);
   hipLaunchKernelGGL((k_bn_partial<true>), dim3(slabs), dim3(BN_THREADS), 0, st, x, dy, y, save_mean,
                      save_invstd, relu, N, C, n_live, (double*)workspace);

@@ -1346,6 +1346,25 @@ static VoxelCentres make_centres(const int32_t* indices, const float* range_min,
                       voxel_size[2] * (float)stride, range_min[0], range_min[1], range_min[2]};
 }
 
+__global__ __launch_bounds__(256) void k_voxel_centres(VoxelCentres cen, int N, float* __restrict__ xyz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float x, y, z;
+  glx_voxel_centre(cen, i, x, y, z);
+  xyz[3 * (long long)i] = x, xyz[3 * (long long)i + 1] = y, xyz[3 * (long long)i + 2] = z;
+}
+
+extern "C" int glx_voxel_centers(const int32_t* indices, int N, int stride, const float* range_min,
+                                 const float* voxel_size, float* xyz, void* stream) {
+  if (N <= 0) return GLX_OK;
+  GLX_REQUIRE(indices && range_min && voxel_size && xyz, "glx_voxel_centers: null pointer");
+  GLX_REQUIRE(stride >= 1, "glx_voxel_centers: stride must be >= 1");
+  hipLaunchKernelGGL(k_voxel_centres, dim3(glx_divup(N, 256)), dim3(256), 0, (hipStream_t)stream,
+                     make_centres(indices, range_min, voxel_size, stride), N, xyz);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
 extern "C" int glx_roi_grid_query(int M, int Z, int Y, int X, int nsample, float radius, int z_range,
                                   int y_range, int x_range, const float* grid_xyz,
                                   const int32_t* coords, int stride, const int32_t* indices,

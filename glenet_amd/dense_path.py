@@ -197,6 +197,37 @@ class SplitKLinear(nn.Linear):
         return super().forward(x)
 
 
+def bn_relu(bn, x):
+    """relu(bn(x)) for (N, C) activations; a training-mode BatchNorm1d the fused kernels cover runs as ONE launch
+    forward and one backward (csrc/glx_bn.hip -- the short-matrix kernels for the few hundred RoI rows) instead of
+    torch's five + three."""
+    from .spconv import core
+    if x.dim() == 2 and torch.is_grad_enabled() and core.can_fuse_train_bn(bn, x):
+        return core.fused_train_bn(bn, x, True)
+    return torch.relu(bn(x))
+
+
+class FCTower(nn.Sequential):
+    """Linear -> BatchNorm1d -> ReLU (-> Dropout) stack of the RoI head (voxelrcnn_head.py:40-66); module indices,
+    hence parameter names, are nn.Sequential's.  Training: each BatchNorm1d + ReLU pair is one fused launch."""
+
+    def forward(self, x):
+        from .spconv import core
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if (isinstance(m, nn.BatchNorm1d) and x.dim() == 2 and torch.is_grad_enabled()
+                    and core.can_fuse_train_bn(m, x)):
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = core.fused_train_bn(m, x, relu)
+                i += 2 if relu else 1
+                continue
+            x = m(x)
+            i += 1
+        return x
+
+
 def _fc_tower(cin, widths, dp_ratio):
     layers = []
     for k, w in enumerate(widths):
@@ -204,7 +235,7 @@ def _fc_tower(cin, widths, dp_ratio):
         cin = w
         if k != len(widths) - 1 and dp_ratio > 0:
             layers.append(nn.Dropout(dp_ratio))
-    return nn.Sequential(*layers), cin
+    return FCTower(*layers), cin
 
 
 class RoIFCStack(nn.Module):

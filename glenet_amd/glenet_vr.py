@@ -95,7 +95,7 @@ class VoxelRCNNKLHead(rg.RoIGridPool):
         rcnn_reg = self.reg_pred_layer(reg_feat)
         rcnn_reg_std = self.reg_std_layer(reg_feat)
         s = torch.relu(self.reg_std_bn(rcnn_reg_std.clone()))
-        s = torch.relu(self.reg_std_bn1(self.reg_std_fc1(s)))
+        s = dp.bn_relu(self.reg_std_bn1, self.reg_std_fc1(s))
         s = torch.sigmoid(self.reg_std_fc2(s))
         p = torch.sigmoid(ori_cls) * s                                                   # :73-75 ("ad hoc")
         rcnn_cls = torch.log((p + 1e-6) / (1 - p + 1e-6))
@@ -125,6 +125,9 @@ class GLENetVR(nn.Module):
         self.roi_head = VoxelRCNNKLHead(self.backbone_3d.backbone_channels, cfg["voxel_size"],
                                         cfg["point_cloud_range"], self.roi_cfg)
         self.target_layer = roi_targets.ProposalTargetLayer(self.roi_cfg["TARGET"])
+        if bev_channels_last:        # the 2-D convolutions' weights live in the layout the NHWC kernels read
+            self.backbone_2d.to(memory_format=torch.channels_last)
+            self.dense_head.to(memory_format=torch.channels_last)
         self.feature_map = (grid[0] // 8, grid[1] // 8)
         self._anchors = None
         self.fixed_draws = None      # tests: (key (B,R), pick (B,P)) uniform numbers for the RoI sampler

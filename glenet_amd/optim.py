@@ -27,7 +27,8 @@ class FlatAdamW:
         if not self.params:
             raise ValueError("FlatAdamW: no trainable parameters")
         dev = self.params[0].device
-        _lib.check_cuda(*[p.data for p in self.params])
+        if any(not p.is_cuda for p in self.params):
+            raise _lib.GlxError("FlatAdamW: parameters must be device tensors (HIP); there is no CPU path")
         if any(p.dtype != torch.float32 for p in self.params):
             raise ValueError("FlatAdamW: fp32 parameters only")
         self.offsets, n = [], 0
@@ -42,10 +43,10 @@ class FlatAdamW:
         self.grad_views = []
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
-                view = self.flat_param[o:o + p.numel()].view_as(p)
+                view = self._view(self.flat_param, o, p)
                 view.copy_(p.data)
                 p.data = view
-                self.grad_views.append(self.flat_grad[o:o + p.numel()].view_as(p))
+                self.grad_views.append(self._view(self.flat_grad, o, p))
         self.hyper = torch.tensor([float(lr), float(betas[0])], dtype=torch.float32, device=dev)
         self.beta2, self.eps, self.weight_decay = float(betas[1]), float(eps), float(weight_decay)
         self.max_norm = float(max_norm) if max_norm else 0.0
@@ -53,6 +54,18 @@ class FlatAdamW:
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._ws = torch.empty(_lib.query("glx_adamw_workspace_bytes"), dtype=torch.uint8, device=dev)
         self._zeros = None
+
+    @staticmethod
+    def _view(flat, offset, p):
+        """The slice of `flat` seen with the parameter's own strides: a dense parameter keeps its memory format
+        (channels-last convolution weights stay channels-last, so MIOpen's NHWC kernels take them -- and hand back
+        their gradients -- without a layout copy per call); anything else becomes row-major."""
+        t = p.data
+        keeps = ((t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+                 or (t.dim() == 5 and t.is_contiguous(memory_format=torch.channels_last_3d)))
+        if t.is_contiguous() or not keeps:
+            return flat[offset:offset + p.numel()].view_as(p)
+        return torch.as_strided(flat, p.shape, p.stride(), offset)
 
     def set_lr(self, lr, beta1=None):
         """Device scalars the (recorded) update reads; two fills, no synchronisation."""

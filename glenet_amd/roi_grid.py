@@ -176,8 +176,8 @@ class RoIGridPool(nn.Module):
             z, y, x = st.spatial_shape
             ind = st.indices.contiguous()
             stride = int(strides[name])
-            with torch.no_grad():
-                xyz = _voxel_centers_capturable(ind[:, 1:4], stride, self.voxel_size, self.point_cloud_range)
+            xyz = torch.empty((ind.shape[0], 3), dtype=torch.float32, device=dev)           # get_voxel_centers
+            _lib.call("glx_voxel_centers", ind, ind.shape[0], stride, rmin, vsz, xyz)
             for grouper, mlp_in, mlp_pos, mlp_out in zip(layer.groupers, layer.mlps_in, layer.mlps_pos,
                                                          layer.mlps_out):
                 feats = self._mlp_in_rows(layer, mlp_in, st)                       # (N, c_mid)

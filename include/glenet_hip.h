@@ -392,7 +392,12 @@ int glx_voxel_pool_agg(const float* feats, const float* xyz, const float* new_xy
  *   centres are rebuilt from the sparse tensor's indices (N,4) [b,z,y,x] as get_voxel_centers
  *   does ((i + 0.5) * voxel*stride + range_min).  Output as glx_voxel_query_index.
  * glx_roi_grid_agg: glx_voxel_pool_agg with the same on-the-fly centres, writing its Co columns
- *   into a wider row-major output (row pitch out_stride floats; pass out + column offset). */
+ *   into a wider row-major output (row pitch out_stride floats; pass out + column offset).
+ * glx_voxel_centers: get_voxel_centers (pcdet/utils/common_utils.py:66-82) of a sparse tensor's indices
+ *   (N,4) [b,z,y,x] at downsample factor `stride` -> xyz (N,3), rounded step by step as the tensor
+ *   expression does; one launch (the training path of the RoI-grid pooling keeps the centres tensor). */
+int glx_voxel_centers(const int32_t* indices, int N, int stride, const float* range_min,
+                      const float* voxel_size, float* xyz, void* stream);
 int glx_roi_grid_points(const float* rois, int n_rois, int cols, int rois_per_frame, int grid_size,
                         const float* range_min, const float* voxel_size, float* grid_xyz,
                         int32_t* coords, void* stream);

@@ -180,3 +180,21 @@ def test_capturable_voxel_centres_equal_the_reference_formulation_cpu():
             a = rg.get_voxel_centers(c, stride, cfg["voxel_size"], cfg["point_cloud_range"])
             b = rg._voxel_centers_capturable(c, stride, cfg["voxel_size"], cfg["point_cloud_range"])
             assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_voxel_centres_kernel_equals_the_reference_formulation(dev):
+    """glx_voxel_centers (one launch, recordable into a HIP graph) is bit-equal to get_voxel_centers
+    (common_utils.py:66-82, pinned by the reference golden in test_dense_path_cpu.py) at every stride."""
+    import ctypes
+    from glenet_amd import _lib, roi_grid as rg
+    g = torch.Generator().manual_seed(1)
+    f3 = ctypes.c_float * 3
+    for cfg in (synth.KITTI, synth.WAYMO):
+        ind = torch.randint(0, 1600, (5003, 4), dtype=torch.int32, generator=g)
+        for stride in (1, 2, 4, 8):
+            want = rg.get_voxel_centers(ind[:, 1:4], stride, cfg["voxel_size"], cfg["point_cloud_range"])
+            got = torch.full((len(ind), 3), float("nan"), device=dev)
+            _lib.call("glx_voxel_centers", ind.to(dev), len(ind), stride, f3(*cfg["point_cloud_range"][:3]),
+                      f3(*cfg["voxel_size"]), got)
+            assert torch.equal(got.cpu(), want)

@@ -12,6 +12,9 @@ def _models(dev):
     torch.manual_seed(0)
     shapes = [(64, 33), (7,), (3, 3, 3, 16, 32), (1,), (256, 20736 // 64), (5, 5)]
     a = [torch.nn.Parameter(torch.randn(s, device=dev) * 0.3) for s in shapes]
+    # convolution weights kept in channels-last memory (GLENetVR's 2-D backbone): the flat views keep the strides
+    a += [torch.nn.Parameter((torch.randn(s, device=dev) * 0.3).contiguous(memory_format=torch.channels_last))
+          for s in [(32, 16, 3, 3), (8, 16, 1, 1)]]
     b = [torch.nn.Parameter(p.detach().clone()) for p in a]
     return a, b
 
@@ -23,6 +26,8 @@ def test_flat_adamw_matches_torch(dev, max_norm):
     opt = FlatAdamW(ours, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01, max_norm=max_norm)
     topt = torch.optim.AdamW(ref, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)
     assert all(p.data_ptr() >= opt.flat_param.data_ptr() for p in ours)          # parameters live in the flat buffer
+    assert ours[6].is_contiguous(memory_format=torch.channels_last) and not ours[6].is_contiguous()
+    assert opt.grad_views[6].stride() == ours[6].stride()
     g = torch.Generator(device=dev).manual_seed(1)
     for it in range(6):
         lr, b1 = 3e-3 * (1 + it), 0.9 - 0.01 * it                                   # a moving schedule

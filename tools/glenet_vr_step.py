@@ -95,3 +95,19 @@ pipe.check()
 print("HIP graph%s: %.2f ms/step = %.0f frames/s; loss %.4f; parts %s" % (
     " (split: fwd+bwd | update)" if args.split else "", dt * 1e3, B / dt, float(pipe.loss),
     {k: round(float(v), 4) for k, v in pipe.parts.items()}))
+
+# host cost of handing one step to the device: replay() called on an idle device returns after the enqueue, the
+# device finishes later -- if the two are close, the step is bound by the host's graph launch, not by the kernels
+enq, tot = [], []
+for j in range(10):
+    pipe.load(*batches[j % len(batches)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pipe.step()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    enq.append((t1 - t0) * 1e3)
+    tot.append((t2 - t0) * 1e3)
+print("one replay on an idle device: host enqueue %.2f ms (min %.2f), enqueue -> device idle %.2f ms (min %.2f)"
+      % (sum(enq) / len(enq), min(enq), sum(tot) / len(tot), min(tot)))

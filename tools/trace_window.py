@@ -15,6 +15,7 @@ ap.add_argument("--marker", default="k_kl_reg_loss")
 ap.add_argument("--top", type=int, default=70)
 ap.add_argument("--out")
 ap.add_argument("--seq", help="also write the launches of the LAST step in time order (start us, duration us, name)")
+ap.add_argument("--seq-name-chars", type=int, default=0, help="--seq: raw kernel names cut to this many characters")
 args = ap.parse_args()
 
 rows = []
@@ -56,7 +57,8 @@ if args.seq:
     t0 = last[0][0]
     with open(args.seq, "w") as f:
         for s_, e_, n_ in last:
-            f.write("%10.1f %8.1f  %s\n" % ((s_ - t0) / 1e3, (e_ - s_) / 1e3, short(n_)))
+            f.write("%10.1f %8.1f  %s\n" % ((s_ - t0) / 1e3, (e_ - s_) / 1e3,
+                                            n_[:args.seq_name_chars] if args.seq_name_chars else short(n_)))
 if args.out:
     with open(args.out, "w") as f:
         f.write(txt + "\n")
