@@ -1204,3 +1204,68 @@ extern "C" int glx_roi_targets(const float* rois, const int64_t* roi_labels, int
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
+
+// ------------------------------------------------------------------ RoI targets: the sampled rows
+// ProposalTargetLayer.forward after the sampling (proposal_target_layer.py:13-63): the sampled RoIs and their
+// matched ground truths gathered, regression mask and classification labels derived from the IoUs -- two dozen
+// gather / where / compare launches as tensor ops, one block row here.  A frame without ground truth
+// (sampled_gt < 0) gets zero rows.  roi_iou labels keep the tensor expression's rounding: the division by the
+// Python scalar (fg - bg) is ATen's multiplication by the float reciprocal.
+__global__ __launch_bounds__(256) void k_roi_target_gather(
+    const float* __restrict__ rois, const long long* __restrict__ roi_labels,
+    const float* __restrict__ roi_scores, int R, int ld, const float* __restrict__ gt_boxes, int G, int gld,
+    const float* __restrict__ gt_unc, int ud, const float* __restrict__ max_overlaps,
+    const int* __restrict__ sampled, const int* __restrict__ sampled_gt, int P, int total, float reg_fg,
+    float cls_fg, float cls_bg, float cls_inv_span, int score_type, float* __restrict__ o_rois, float* __restrict__ o_gt,
+    float* __restrict__ o_iou, float* __restrict__ o_scores, long long* __restrict__ o_labels,
+    float* __restrict__ o_unc, long long* __restrict__ o_valid, void* __restrict__ o_cls) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int b = i / P;
+  const int s = sampled[i], g = sampled_gt[i];
+  const float* r = rois + ((long long)b * R + s) * ld;
+  for (int c = 0; c < ld; ++c) o_rois[(long long)i * ld + c] = r[c];
+  const float* gb = gt_boxes + ((long long)b * G + (g < 0 ? 0 : g)) * gld;
+  for (int c = 0; c < gld; ++c) o_gt[(long long)i * gld + c] = g < 0 ? 0.f : gb[c];
+  if (gt_unc) {
+    const float* u = gt_unc + ((long long)b * G + (g < 0 ? 0 : g)) * ud;
+    for (int c = 0; c < ud; ++c) o_unc[(long long)i * ud + c] = g < 0 ? 0.f : u[c];
+  }
+  const float iou = max_overlaps[(long long)b * R + s];
+  o_iou[i] = iou;
+  if (roi_scores) o_scores[i] = roi_scores[(long long)b * R + s];
+  o_labels[i] = roi_labels[(long long)b * R + s];
+  o_valid[i] = iou > reg_fg ? 1 : 0;
+  if (score_type == 0) {
+    long long lab = iou > cls_fg ? 1 : 0;
+    if (iou > cls_bg && iou < cls_fg) lab = -1;
+    ((long long*)o_cls)[i] = lab;
+  } else {
+    const bool fg = iou > cls_fg, bg = iou < cls_bg;
+    ((float*)o_cls)[i] = (fg || bg) ? (fg ? 1.f : 0.f) : __fmul_rn(__fsub_rn(iou, cls_bg), cls_inv_span);
+  }
+}
+
+extern "C" int glx_roi_target_gather(const float* rois, const int64_t* roi_labels, const float* roi_scores,
+                                     int B, int R, int roi_ld, const float* gt_boxes, int G, int gt_ld,
+                                     const float* gt_unc, int unc_ld, const float* max_overlaps,
+                                     const int32_t* sampled, const int32_t* sampled_gt, int P, float reg_fg,
+                                     float cls_fg, float cls_bg, float cls_inv_span, int score_type, float* out_rois,
+                                     float* out_gt, float* out_iou, float* out_scores, int64_t* out_labels,
+                                     float* out_unc, int64_t* out_reg_valid, void* out_cls_labels,
+                                     void* stream) {
+  if (B <= 0 || P <= 0) return GLX_OK;
+  GLX_REQUIRE(rois && roi_labels && gt_boxes && max_overlaps && sampled && sampled_gt && out_rois && out_gt &&
+              out_iou && out_labels && out_reg_valid && out_cls_labels, "glx_roi_target_gather: null pointer");
+  GLX_REQUIRE(!roi_scores || out_scores, "glx_roi_target_gather: scores without an output");
+  GLX_REQUIRE(!gt_unc || out_unc, "glx_roi_target_gather: uncertainties without an output");
+  GLX_REQUIRE(score_type == 0 || score_type == 1, "glx_roi_target_gather: score_type 0 (cls) or 1 (roi_iou)");
+  const int total = B * P;
+  hipLaunchKernelGGL(k_roi_target_gather, dim3(glx_divup(total, 256)), dim3(256), 0, (hipStream_t)stream, rois,
+                     (const long long*)roi_labels, roi_scores, R, roi_ld, gt_boxes, G, gt_ld, gt_unc, unc_ld,
+                     max_overlaps, sampled, sampled_gt, P, total, reg_fg, cls_fg, cls_bg, cls_inv_span, score_type, out_rois,
+                     out_gt, out_iou, out_scores, (long long*)out_labels, out_unc, (long long*)out_reg_valid,
+                     out_cls_labels);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

@@ -642,3 +642,105 @@ extern "C" int glx_rcnn_cls_loss(const float* rcnn_cls, const float* rcnn_cls_la
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
+
+// ------------------------------------------------------------------ GLENet's score rescaling + classification loss
+// VoxelRCNNKLLabelIoUHead.forward (voxelrcnn_kl_label_iou_head.py:70-76): the classification logit is rescaled by the
+// predicted localisation certainty before it is used, p = sigmoid(ori_cls) * sigmoid(std_logit),
+// rcnn_cls = log((p + 1e-6) / (1 - p + 1e-6)) -- nine elementwise launches forward and fourteen backward as tensor
+// ops.  Here the rescaling, the BinaryCrossEntropy loss above and the chain rule down to the two logits are ONE
+// block: rcnn_cls (R) is written for the callers that read it, grad_ori / grad_std hold d loss / d logit.
+__global__ __launch_bounds__(KL_THREADS) void k_cls_rescale_loss(
+    const float* __restrict__ ori_cls, const float* __restrict__ std_logit,
+    const float* __restrict__ labels, int R, float weight, float* __restrict__ rcnn_cls,
+    float* __restrict__ out, float* __restrict__ grad_ori, float* __restrict__ grad_std) {
+  __shared__ double red[KL_THREADS];
+  double c = 0;
+  if (labels)
+    for (int i = threadIdx.x; i < R; i += KL_THREADS) c += labels[i] >= 0.f ? 1.0 : 0.0;
+  const double nv = labels ? kl_block_sum(c, red) : 0.0;
+  const float scale = weight / (float)(nv > 1.0 ? nv : 1.0);
+  double acc = 0;
+  for (int i = threadIdx.x; i < R; i += KL_THREADS) {
+    const float sa = 1.f / (1.f + expf(-ori_cls[i])), sb = 1.f / (1.f + expf(-std_logit[i]));
+    const float pr = sa * sb;
+    const float num = pr + 1e-6f, den = (1.f - pr) + 1e-6f;
+    const float z = logf(num / den);
+    rcnn_cls[i] = z;
+    if (!labels) continue;
+    const float y = labels[i];
+    const float p = 1.f / (1.f + expf(-z));
+    const float m = y >= 0.f ? 1.f : 0.f;
+    const float l = -(y * fmaxf(logf(p), -100.f) + (1.f - y) * fmaxf(logf(1.f - p), -100.f));
+    acc += (double)(l * m);
+    const float gz = m * (p - y) / fmaxf((1.f - p) * p, 1e-12f) * (p * (1.f - p)) * scale;   // d loss / d rcnn_cls
+    const float gp = gz * (1.f / num + 1.f / den);                                            // d rcnn_cls / d pr
+    if (grad_ori) grad_ori[i] = gp * sb * sa * (1.f - sa);
+    if (grad_std) grad_std[i] = gp * sa * sb * (1.f - sb);
+  }
+  if (!labels) return;
+  const double total = kl_block_sum(acc, red);
+  if (threadIdx.x == 0) { out[0] = (float)total * scale; out[1] = (float)nv; }
+}
+
+extern "C" int glx_cls_rescale_loss(const float* ori_cls, const float* std_logit,
+                                    const float* rcnn_cls_labels, int R, float weight, float* rcnn_cls,
+                                    float* out2, float* grad_ori, float* grad_std, void* stream) {
+  GLX_REQUIRE(R == 0 || (ori_cls && std_logit && rcnn_cls), "glx_cls_rescale_loss: null pointer");
+  GLX_REQUIRE(!rcnn_cls_labels || out2, "glx_cls_rescale_loss: labels without an output for the loss");
+  hipLaunchKernelGGL(k_cls_rescale_loss, dim3(1), dim3(KL_THREADS), 0, (hipStream_t)stream, ori_cls,
+                     std_logit, rcnn_cls_labels, R, weight, rcnn_cls, out2, grad_ori, grad_std);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// ------------------------------------------------------------------ anchor head: predicted boxes
+// AnchorHeadTemplate.generate_predicted_boxes (anchor_head_template.py:222-271): ResidualCoder.decode_torch
+// (box_coder_utils.py:44-69) of every anchor's residuals and the heading put into the predicted direction bin
+// (limit_period of common_utils.py:35-38) -- thirty elementwise launches as tensor ops.  The arithmetic keeps the
+// tensor expression's rounding: products and sums are rounded separately (no fused multiply-add), a division by a
+// Python scalar is ATen's multiplication by the float reciprocal.
+__global__ __launch_bounds__(256) void k_predicted_boxes(
+    const float* __restrict__ box_preds, const float* __restrict__ dir_preds,
+    const float* __restrict__ anchors, long long total, int A, int ndir, float dir_offset,
+    float dir_limit_offset, float* __restrict__ boxes) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const float* a = anchors + (i % A) * 7;
+  const float* e = box_preds + i * 7;
+  float* o = boxes + i * 7;
+  const float diag = sqrtf(__fadd_rn(__fmul_rn(a[3], a[3]), __fmul_rn(a[4], a[4])));
+  o[0] = __fadd_rn(__fmul_rn(e[0], diag), a[0]);
+  o[1] = __fadd_rn(__fmul_rn(e[1], diag), a[1]);
+  o[2] = __fadd_rn(__fmul_rn(e[2], a[5]), a[2]);
+  o[3] = __fmul_rn(expf(e[3]), a[3]);
+  o[4] = __fmul_rn(expf(e[4]), a[4]);
+  o[5] = __fmul_rn(expf(e[5]), a[5]);
+  float r = __fadd_rn(e[6], a[6]);
+  if (dir_preds) {
+    const float* d = dir_preds + i * ndir;
+    int label = 0;
+    float best = d[0];
+    for (int k = 1; k < ndir; ++k)
+      if (d[k] > best) { best = d[k]; label = k; }
+    const float period = (float)(2.0 * 3.14159265358979323846 / ndir);
+    const float inv_period = 1.f / period;
+    const float val = __fsub_rn(r, dir_offset);
+    const float rot = __fsub_rn(val, __fmul_rn(floorf(__fadd_rn(__fmul_rn(val, inv_period), dir_limit_offset)), period));
+    r = __fadd_rn(__fadd_rn(rot, dir_offset), __fmul_rn(period, (float)label));
+  }
+  o[6] = r;
+}
+
+extern "C" int glx_predicted_boxes(const float* box_preds, const float* dir_preds, const float* anchors,
+                                   int B, int A, int num_dir_bins, float dir_offset,
+                                   float dir_limit_offset, float* boxes, void* stream) {
+  if (B <= 0 || A <= 0) return GLX_OK;
+  GLX_REQUIRE(box_preds && anchors && boxes, "glx_predicted_boxes: null pointer");
+  GLX_REQUIRE(!dir_preds || num_dir_bins >= 1, "glx_predicted_boxes: direction bins");
+  const long long total = (long long)B * A;
+  hipLaunchKernelGGL(k_predicted_boxes, dim3((unsigned)glx_divup(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, box_preds, dir_preds, anchors, total, A, num_dir_bins, dir_offset,
+                     dir_limit_offset, boxes);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

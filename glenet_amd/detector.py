@@ -62,12 +62,27 @@ def decode_boxes(enc, anchors):
     return torch.cat(out, dim=-1)
 
 
+FUSED_PREDICTED_BOXES = True
+
+
 def predicted_boxes(cls_preds, box_preds, dir_cls_preds, anchors, dir_offset=0.78539, dir_limit_offset=0.0,
                     num_dir_bins=2):
     """Head maps (B,H,W,A*c) + anchors (.., 7) -> batch_cls_preds (B,N,cls), batch_box_preds (B,N,7)."""
     B = cls_preds.shape[0]
     anc = anchors.reshape(1, -1, anchors.shape[-1])
     n = anc.shape[1]
+    if (FUSED_PREDICTED_BOXES and box_preds.is_cuda and not torch.is_grad_enabled() and anc.shape[-1] == 7
+            and box_preds.dtype == torch.float32 and box_preds.numel() == B * n * 7):
+        # one launch instead of ~30 elementwise ones, same rounding (csrc/glx_loss.hip: k_predicted_boxes)
+        import ctypes
+        from . import _lib
+        bp = box_preds.reshape(B, n, 7).contiguous()
+        dirp = dir_cls_preds.reshape(B, n, -1).contiguous().float() if dir_cls_preds is not None else None
+        boxes = torch.empty((B, n, 7), dtype=torch.float32, device=bp.device)
+        _lib.call("glx_predicted_boxes", bp, dirp, anc.reshape(n, 7).contiguous().float(), B, n,
+                  num_dir_bins if dirp is None else dirp.shape[-1], ctypes.c_float(dir_offset),
+                  ctypes.c_float(dir_limit_offset), boxes)
+        return cls_preds.reshape(B, n, -1).float(), boxes
     boxes = decode_boxes(box_preds.reshape(B, n, -1), anc.expand(B, n, anc.shape[-1]))
     if dir_cls_preds is not None:
         labels = dir_cls_preds.reshape(B, n, -1).max(dim=-1)[1]

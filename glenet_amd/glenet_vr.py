@@ -86,8 +86,10 @@ class VoxelRCNNKLHead(rg.RoIGridPool):
             nn.init.normal_(m.weight, mean=0, std=0.0001)
             nn.init.constant_(m.bias, 0)
 
-    def heads(self, pooled):
-        """pooled (R, G^3, C) -> rcnn_cls (R,1) [the rescaled logit], rcnn_reg (R,7), rcnn_reg_std (R,7)."""
+    def heads(self, pooled, raw=False):
+        """pooled (R, G^3, C) -> rcnn_cls (R,1) [the rescaled logit], rcnn_reg (R,7), rcnn_reg_std (R,7).
+        raw=True: (ori_cls, std_logit, rcnn_reg, rcnn_reg_std) -- the two logits of the rescaling, for the caller
+        that fuses it with the classification loss (losses.cls_rescale_loss)."""
         x = pooled.reshape(pooled.shape[0], -1)
         shared = self.shared_fc_layer(x)
         ori_cls = self.cls_pred_layer(self.cls_fc_layers(shared))
@@ -96,14 +98,18 @@ class VoxelRCNNKLHead(rg.RoIGridPool):
         rcnn_reg_std = self.reg_std_layer(reg_feat)
         s = torch.relu(self.reg_std_bn(rcnn_reg_std.clone()))
         s = dp.bn_relu(self.reg_std_bn1, self.reg_std_fc1(s))
-        s = torch.sigmoid(self.reg_std_fc2(s))
-        p = torch.sigmoid(ori_cls) * s                                                   # :73-75 ("ad hoc")
-        rcnn_cls = torch.log((p + 1e-6) / (1 - p + 1e-6))
+        std_logit = self.reg_std_fc2(s)
+        if raw:
+            return ori_cls, std_logit, rcnn_reg, rcnn_reg_std
+        if ori_cls.is_cuda and not torch.is_grad_enabled():
+            rcnn_cls = losses.cls_rescale(ori_cls, std_logit)                            # one launch
+        else:
+            rcnn_cls = losses.cls_rescale_torch(ori_cls, std_logit)                      # :73-75 ("ad hoc")
         return rcnn_cls, rcnn_reg, rcnn_reg_std
 
-    def forward(self, rois, multi_scale_3d_features, multi_scale_3d_strides, batch_size):
+    def forward(self, rois, multi_scale_3d_features, multi_scale_3d_strides, batch_size, raw=False):
         pooled = super().forward(rois, multi_scale_3d_features, multi_scale_3d_strides, batch_size)
-        return self.heads(pooled)
+        return self.heads(pooled, raw)
 
 
 class GLENetVR(nn.Module):
@@ -183,11 +189,15 @@ class GLENetVR(nn.Module):
                                          code_weights=h["code_weights"], cls_weight=h["cls_weight"],
                                          loc_weight=h["loc_weight"], dir_weight=h["dir_weight"])
         mark("anchor targets + proposals (NMS) + RoI targets + dense-head loss")
-        rcnn_cls, rcnn_reg, rcnn_std = self.roi_head(rois_s, bd["multi_scale_3d_features"],
-                                                     bd["multi_scale_3d_strides"], B)
+        ori_cls, std_logit, rcnn_reg, rcnn_std = self.roi_head(rois_s, bd["multi_scale_3d_features"],
+                                                               bd["multi_scale_3d_strides"], B, raw=True)
         mark("RoI-grid pooling + FC towers fwd")
         w = r["LOSS_WEIGHTS"]
-        l_cls = losses.rcnn_cls_loss(rcnn_cls, cls_lab, weight=w["rcnn_cls_weight"])
+        if ori_cls.is_cuda:      # score rescaling + classification loss + their backward: one launch
+            l_cls, rcnn_cls = losses.cls_rescale_loss(ori_cls, std_logit, cls_lab, weight=w["rcnn_cls_weight"])
+        else:
+            rcnn_cls = losses.cls_rescale_torch(ori_cls, std_logit)
+            l_cls = losses.rcnn_cls_loss_torch(rcnn_cls, cls_lab, weight=w["rcnn_cls_weight"])
         l_kl, kl_parts = losses.kl_reg_loss(rcnn_reg, rcnn_std, rois_s, gt_ct[..., :7], unc, reg_valid,
                                             code_weights=w["code_weights"], weight=w["rcnn_reg_weight"])
         l_cor = losses.corner_loss(rcnn_reg, rois_s, gt_src[..., :7], reg_valid, weight=w["rcnn_corner_weight"])
@@ -332,7 +342,11 @@ class StaticTrainStep(gb.StaticTrainPipeline):
             self.mark("grad clip + AdamW")
 
     def enqueue(self):
-        bd = super().enqueue()
+        losses.UNIT_ROOT_GRAD = True      # the step's root scalar is the unweighted sum of the loss terms
+        try:
+            bd = super().enqueue()
+        finally:
+            losses.UNIT_ROOT_GRAD = False
         if self.flat:
             self.step_optimizer.pack_grads()          # part of the forward + backward graph
         if not self.split:

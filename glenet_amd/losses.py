@@ -51,6 +51,17 @@ def kl_reg_loss_torch(rcnn_reg, rcnn_reg_std, rois, gt_of_rois, gt_uncertainty, 
     return l_src + l_sq + l_log, {"src": l_src.detach(), "square": l_sq.detach(), "log": l_log.detach()}
 
 
+# The loss kernels hand back d loss / d input; backward() scales it by the incoming gradient of the scalar.  A caller
+# whose root scalar is the plain sum of these terms (GLENetVR.second_stage_losses under StaticTrainStep: voxel_rcnn.py
+# get_training_loss adds them unweighted, and loss.backward() seeds the sum with 1) sets UNIT_ROOT_GRAD for its backward
+# pass: the incoming gradient IS 1.0, and seven multiplications by it (three of them over the BEV head maps) are skipped.
+UNIT_ROOT_GRAD = False
+
+
+def _scaled(g, g_loss):
+    return g if UNIT_ROOT_GRAD else g * g_loss
+
+
 class _KLRegLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rcnn_reg, rcnn_reg_std, rois, gt_of_rois, gt_uncertainty, fg, code_weights, beta, weight):
@@ -67,7 +78,7 @@ class _KLRegLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_parts):
         g_reg, g_std = ctx.saved_tensors
-        return g_reg * g_loss, g_std * g_loss, None, None, None, None, None, None, None
+        return _scaled(g_reg, g_loss), _scaled(g_std, g_loss), None, None, None, None, None, None, None
 
 
 def kl_reg_loss(rcnn_reg, rcnn_reg_std, rois, gt_of_rois, gt_uncertainty, reg_valid_mask, code_weights=None,
@@ -134,7 +145,7 @@ class _CornerLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss):
         (g_reg,) = ctx.saved_tensors
-        return g_reg * g_loss, None, None, None, None
+        return _scaled(g_reg, g_loss), None, None, None, None
 
 
 def corner_loss(rcnn_reg, rois, gt_of_rois_src, reg_valid_mask, weight=1.0):
@@ -210,8 +221,8 @@ class _RpnLoss(torch.autograd.Function):
     def backward(ctx, g_loss, _g_parts):
         g_cls, g_box, g_dir = ctx.saved_tensors
         s = ctx.shapes
-        return ((g_cls * g_loss).reshape(s[0]), (g_box * g_loss).reshape(s[1]),
-                (g_dir * g_loss).reshape(s[2]) if ctx.has_dir else None, None, None, None, None)
+        return (_scaled(g_cls, g_loss).reshape(s[0]), _scaled(g_box, g_loss).reshape(s[1]),
+                _scaled(g_dir, g_loss).reshape(s[2]) if ctx.has_dir else None, None, None, None, None)
 
 
 def rpn_loss(cls_preds, box_preds, dir_preds, box_cls_labels, box_reg_targets, anchors, code_weights=(1.0,) * 7,
@@ -247,7 +258,50 @@ class _RcnnClsLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss):
         (g,) = ctx.saved_tensors
-        return (g * g_loss).reshape(ctx.shape), None, None
+        return _scaled(g, g_loss).reshape(ctx.shape), None, None
+
+
+class _ClsRescaleLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ori_cls, std_logit, labels, weight):
+        a, b = ori_cls.reshape(-1).contiguous().float(), std_logit.reshape(-1).contiguous().float()
+        y = labels.reshape(-1).contiguous().float()
+        _lib.check_cuda(a, b, y)
+        out = torch.empty(2, dtype=torch.float32, device=a.device)
+        z, ga, gb = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+        _lib.call("glx_cls_rescale_loss", a, b, y, a.shape[0], ctypes.c_float(weight), z, out, ga, gb)
+        ctx.save_for_backward(ga, gb)
+        ctx.shapes = (ori_cls.shape, std_logit.shape)
+        z = z.reshape(ori_cls.shape)
+        ctx.mark_non_differentiable(z)
+        return out[0], z
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_z):
+        ga, gb = ctx.saved_tensors
+        return _scaled(ga, g_loss).reshape(ctx.shapes[0]), _scaled(gb, g_loss).reshape(ctx.shapes[1]), None, None
+
+
+def cls_rescale_torch(ori_cls, std_logit):
+    """voxelrcnn_kl_label_iou_head.py:70-76 in tensor ops: the logit of sigmoid(ori_cls) * sigmoid(std_logit)."""
+    p = torch.sigmoid(ori_cls) * torch.sigmoid(std_logit)
+    return torch.log((p + 1e-6) / (1 - p + 1e-6))
+
+
+def cls_rescale(ori_cls, std_logit):
+    """The same as one launch, for callers without autograd (inference)."""
+    a, b = ori_cls.reshape(-1).contiguous().float(), std_logit.reshape(-1).contiguous().float()
+    _lib.check_cuda(a, b)
+    z = torch.empty_like(a)
+    _lib.call("glx_cls_rescale_loss", a, b, None, a.shape[0], ctypes.c_float(1.0), z, None, None, None)
+    return z.reshape(ori_cls.shape)
+
+
+def cls_rescale_loss(ori_cls, std_logit, rcnn_cls_labels, weight=1.0):
+    """GLENet's score rescaling + get_box_cls_layer_loss + the chain rule to both logits in one launch:
+    -> (loss, rcnn_cls); rcnn_cls (the rescaled logit, shape of ori_cls) carries no autograd history -- the
+    gradient flows through the loss."""
+    return _ClsRescaleLoss.apply(ori_cls, std_logit, rcnn_cls_labels, float(weight))
 
 
 def rcnn_cls_loss_torch(rcnn_cls, rcnn_cls_labels, weight=1.0):

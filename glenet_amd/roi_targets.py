@@ -21,6 +21,9 @@ def _get(cfg, name, default=None):
     return getattr(cfg, name, default)
 
 
+FUSED_GATHER = True      # False: the tensor-op statements of the reference's forward (tests compare the two)
+
+
 class ProposalTargetLayer(torch.nn.Module):
     def __init__(self, roi_sampler_cfg):
         super().__init__()
@@ -57,12 +60,45 @@ class ProposalTargetLayer(torch.nn.Module):
              max_overlaps, assignment, n_gt, sampled, sampled_gt)
         return max_overlaps, assignment, sampled, sampled_gt
 
+    def _gather_fused(self, batch_dict, max_overlaps, sampled, sampled_gt):
+        """Everything behind the sampling in one launch (csrc/glx_iou_nms.hip: k_roi_target_gather)."""
+        cfg = self.roi_sampler_cfg
+        rois, gt = batch_dict["rois"].contiguous().float(), batch_dict["gt_boxes"].contiguous().float()
+        labels = batch_dict["roi_labels"].contiguous().long()
+        scores = batch_dict["roi_scores"].contiguous().float() if "roi_scores" in batch_dict else None
+        unc = batch_dict["gt_uncertaintys"].contiguous().float() if "gt_uncertaintys" in batch_dict else None
+        B, R, ld = rois.shape
+        G, gld = gt.shape[1:]
+        P = sampled.shape[1]
+        dev = rois.device
+        kind = 0 if _get(cfg, "CLS_SCORE_TYPE") == "cls" else 1
+        bg_t, fg_t = float(_get(cfg, "CLS_BG_THRESH")), float(_get(cfg, "CLS_FG_THRESH"))
+        o_rois = torch.empty((B, P, ld), dtype=torch.float32, device=dev)
+        o_gt = torch.empty((B, P, gld), dtype=torch.float32, device=dev)
+        o_iou = torch.empty((B, P), dtype=torch.float32, device=dev)
+        o_scores = torch.empty((B, P), dtype=torch.float32, device=dev) if scores is not None else None
+        o_labels = torch.empty((B, P), dtype=torch.int64, device=dev)
+        o_unc = torch.empty((B, P, unc.shape[-1]), dtype=torch.float32, device=dev) if unc is not None else None
+        o_valid = torch.empty((B, P), dtype=torch.int64, device=dev)
+        o_cls = torch.empty((B, P), dtype=torch.int64 if kind == 0 else torch.float32, device=dev)
+        inv_span = float(np.float32(1.0) / np.float32(fg_t - bg_t)) if fg_t != bg_t else 0.0
+        call("glx_roi_target_gather", rois, labels, scores, B, R, ld, gt, G, gld, unc,
+             unc.shape[-1] if unc is not None else 0, max_overlaps, sampled, sampled_gt, P,
+             float(_get(cfg, "REG_FG_THRESH")), fg_t, bg_t, inv_span, kind, o_rois, o_gt, o_iou, o_scores, o_labels,
+             o_unc, o_valid, o_cls)
+        out = {"rois": o_rois, "gt_of_rois": o_gt, "gt_iou_of_rois": o_iou, "roi_labels": o_labels,
+               "reg_valid_mask": o_valid, "rcnn_cls_labels": o_cls, "gt_uncertaintys_of_rois": o_unc}
+        out["roi_scores"] = o_scores if o_scores is not None else None
+        return out
+
     def forward(self, batch_dict, key=None, pick=None):
         """Same keys in and out as the reference's forward (:13-63)."""
         cfg = self.roi_sampler_cfg
         rois, gt_boxes = batch_dict["rois"], batch_dict["gt_boxes"]
         max_overlaps, _, sampled, sampled_gt = self.match_and_sample(rois, batch_dict["roi_labels"], gt_boxes,
                                                                      key, pick)
+        if FUSED_GATHER and _get(cfg, "CLS_SCORE_TYPE") in ("cls", "roi_iou"):
+            return self._gather_fused(batch_dict, max_overlaps, sampled, sampled_gt)
         s = sampled.long()
         g = sampled_gt.long()
         has_gt = (g >= 0).unsqueeze(-1)

@@ -476,6 +476,24 @@ int glx_rpn_loss(const float* cls_preds, const float* box_preds, const float* di
 int glx_rcnn_cls_loss(const float* rcnn_cls, const float* rcnn_cls_labels, int R, float weight,
                       float* out2, float* grad, void* stream);
 
+/* GLENet's score rescaling fused with that loss: rcnn_cls = log((p + 1e-6) / (1 - p + 1e-6)),
+ * p = sigmoid(ori_cls) * sigmoid(std_logit) (R each), then glx_rcnn_cls_loss on rcnn_cls and the chain rule back to
+ * the two logits: rcnn_cls (R) out, out2 = { loss * weight, #valid }, grad_ori / grad_std (R) or NULL.
+ * rcnn_cls_labels NULL: the rescaling only (inference), out2 and the gradients untouched.
+ * Replaces: voxelrcnn_kl_label_iou_head.py:70-76 + roi_head_template.py:246-272 (23 elementwise launches). */
+int glx_cls_rescale_loss(const float* ori_cls, const float* std_logit, const float* rcnn_cls_labels,
+                         int R, float weight, float* rcnn_cls, float* out2, float* grad_ori,
+                         float* grad_std, void* stream);
+
+/* Predicted boxes of the anchor head: box_preds (B, A, 7) residuals, dir_preds (B, A, num_dir_bins) or NULL,
+ * anchors (A, 7) -> boxes (B, A, 7): ResidualCoder.decode_torch + the heading moved into the predicted
+ * direction bin, with the rounding of the tensor expression.
+ * Replaces: AnchorHeadTemplate.generate_predicted_boxes (pcdet/models/dense_heads/anchor_head_template.py:222-271),
+ * box_coder_utils.py:44-69, common_utils.limit_period (pcdet/utils/common_utils.py:35-38). */
+int glx_predicted_boxes(const float* box_preds, const float* dir_preds, const float* anchors, int B, int A,
+                        int num_dir_bins, float dir_offset, float dir_limit_offset, float* boxes,
+                        void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Training-mode BatchNorm1d (+ ReLU) over sparse-tensor features x (N, C), C a multiple of 4 that
  * divides 1024 (16 ... 512).  Semantics of nn.BatchNorm1d(eps, momentum) followed by nn.ReLU as
@@ -643,6 +661,20 @@ int glx_roi_targets(const float* rois, const int64_t* roi_labels, int B, int R, 
                     const float* pick, int P, int fg_per_image, float fg_thresh, float bg_lo, float reg_fg,
                     double hard_ratio, float* max_overlaps, int32_t* assignment, int32_t* n_gt,
                     int32_t* sampled, int32_t* sampled_gt, void* stream);
+
+/* The rest of ProposalTargetLayer.forward (proposal_target_layer.py:13-63) in one launch: rows of the sampled RoIs
+ * (B,P,roi_ld), their ground truths (B,P,gt_ld) and label variances gt_unc (B,G,unc_ld) or NULL -- zero rows for
+ * a frame without ground truth (sampled_gt < 0) --, IoU / score / label of each, reg_valid (int64) = IoU >
+ * reg_fg, classification labels: score_type 0 ("cls") int64 {1, 0, -1 between the thresholds}, 1 ("roi_iou")
+ * float {1 above cls_fg, 0 below cls_bg, (iou - bg) * cls_inv_span between; cls_inv_span = 1 / (fg - bg) as the
+ * caller's float}.  roi_scores may be NULL. */
+int glx_roi_target_gather(const float* rois, const int64_t* roi_labels, const float* roi_scores, int B, int R,
+                          int roi_ld, const float* gt_boxes, int G, int gt_ld, const float* gt_unc,
+                          int unc_ld, const float* max_overlaps, const int32_t* sampled,
+                          const int32_t* sampled_gt, int P, float reg_fg, float cls_fg, float cls_bg,
+                          float cls_inv_span, int score_type, float* out_rois, float* out_gt, float* out_iou, float* out_scores,
+                          int64_t* out_labels, float* out_unc, int64_t* out_reg_valid, void* out_cls_labels,
+                          void* stream);
 
 #ifdef __cplusplus
 }

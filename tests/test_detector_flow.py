@@ -198,3 +198,33 @@ def test_voxel_centres_kernel_equals_the_reference_formulation(dev):
             _lib.call("glx_voxel_centers", ind.to(dev), len(ind), stride, f3(*cfg["point_cloud_range"][:3]),
                       f3(*cfg["voxel_size"]), got)
             assert torch.equal(got.cpu(), want)
+
+
+@pytest.mark.gpu
+def test_predicted_boxes_kernel_matches_reference_golden_and_tensor_ops(dev):
+    """glx_predicted_boxes (decode + direction bin in one launch) against the golden generated by the reference's
+    AnchorHeadTemplate.generate_predicted_boxes, and bit for bit against the tensor-op formulation on the device
+    (same rounding by construction) at the KITTI head size, without and with the direction classifier."""
+    g = _glue()
+    anchors = torch.from_numpy(g["anchors_car"]).to(dev)
+    cls = torch.zeros(2, 25, 22, 2, device=dev)
+    with torch.no_grad():
+        _, boxes = det.predicted_boxes(cls, torch.from_numpy(g["head_box_preds"]).to(dev),
+                                       torch.from_numpy(g["head_dir_preds"]).to(dev), anchors)
+    np.testing.assert_allclose(boxes.cpu().numpy(), g["head_boxes"], rtol=0, atol=1e-6)
+    gen = torch.Generator().manual_seed(2)
+    a = det.generate_anchors([0, -40, -3, 70.4, 40, 1], (200, 176), [[3.9, 1.6, 1.56]], [0, 1.57], [-1.78]).to(dev)
+    n = a.reshape(-1, 7).shape[0]
+    bp = (torch.randn(2, n, 7, generator=gen) * 0.6).to(dev)
+    dirp = torch.randn(2, n, 2, generator=gen).to(dev)
+    dirp[0, :100, 1] = dirp[0, :100, 0]                           # ties -> bin 0, as torch's max
+    cls = torch.zeros(2, n, 1, device=dev)
+    for d in (None, dirp):
+        with torch.no_grad():
+            _, got = det.predicted_boxes(cls, bp, d, a)
+            det.FUSED_PREDICTED_BOXES = False
+            try:
+                _, want = det.predicted_boxes(cls, bp, d, a)
+            finally:
+                det.FUSED_PREDICTED_BOXES = True
+        assert torch.equal(got, want)

@@ -122,3 +122,44 @@ def test_rcnn_cls_loss_kernel_matches_reference_golden(dev):
     np.testing.assert_allclose(float(l2.detach()), float(want), rtol=1e-5)
     l2.backward()
     assert float(x2.grad.reshape(2, -1)[0, 5:25].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_fused_score_rescaling_and_cls_loss_match_the_tensor_formulation(dev):
+    """glx_cls_rescale_loss (rescaling of voxelrcnn_kl_label_iou_head.py:70-76 + get_box_cls_layer_loss + chain rule,
+    one launch) vs the tensor ops: cls_rescale_torch feeding rcnn_cls_loss_torch (pinned by the reference golden
+    above) under autograd -- value, the rescaled logit, and the gradients of both logits."""
+    g = torch.Generator().manual_seed(5)
+    R = 1000
+    a = (torch.randn(R, 1, generator=g) * 3).to(dev)
+    b = (torch.randn(R, 1, generator=g) * 2 + 1).to(dev)
+    a[:4, 0] = torch.tensor([40.0, -40.0, 12.0, -12.0])           # saturated logits: the 1e-6 guards at work
+    b[:4, 0] = torch.tensor([40.0, 40.0, -30.0, 30.0])
+    lab = torch.rand(R, generator=g).to(dev)
+    lab[10:60] = -1.0                                             # ignored RoIs
+    lab[60:90] = 0.0
+    lab[90:120] = 1.0
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    zr = losses.cls_rescale_torch(ar, br)
+    want = losses.rcnn_cls_loss_torch(zr, lab, weight=1.5)
+    (want * 0.7).backward()
+    af, bf = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    got, z = losses.cls_rescale_loss(af, bf, lab, weight=1.5)
+    assert z.shape == a.shape and not z.requires_grad
+    (got * 0.7).backward()
+    np.testing.assert_allclose(float(got.detach()), float(want.detach()), rtol=1e-5)
+    np.testing.assert_allclose(z.cpu().numpy(), zr.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    scale = float(ar.grad.abs().max())
+    np.testing.assert_allclose(af.grad.cpu().numpy(), ar.grad.cpu().numpy(), rtol=2e-4, atol=1e-6 * scale)
+    np.testing.assert_allclose(bf.grad.cpu().numpy(), br.grad.cpu().numpy(), rtol=2e-4, atol=1e-6 * scale)
+    assert float(af.grad[10:60].abs().max()) == 0.0
+    # the rescaling alone (inference) and the unit-gradient shortcut of the training step
+    np.testing.assert_allclose(losses.cls_rescale(a, b).cpu().numpy(), z.cpu().numpy(), rtol=0, atol=0)
+    a2, b2 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    losses.UNIT_ROOT_GRAD = True
+    try:
+        l2, _ = losses.cls_rescale_loss(a2, b2, lab, weight=1.5)
+        l2.backward()
+    finally:
+        losses.UNIT_ROOT_GRAD = False
+    np.testing.assert_allclose(a2.grad.cpu().numpy() * 0.7, af.grad.cpu().numpy(), rtol=1e-6, atol=1e-12)

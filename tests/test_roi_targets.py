@@ -166,3 +166,27 @@ def test_device_roi_targets_reject_host_tensors_and_oversized_inputs(dev):
     with pytest.raises(_lib.GlxError):
         layer.match_and_sample(torch.zeros(1, 8, 7, device=dev), torch.ones(1, 8, dtype=torch.long, device=dev),
                                torch.zeros(1, 300, 8, device=dev))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["roi_iou", "cls"])
+def test_fused_target_gather_equals_the_tensor_statements(dev, kind):
+    """glx_roi_target_gather (one launch) == the gather / where / compare statements of the reference's forward
+    (proposal_target_layer.py:13-63) as tensor ops, bit for bit, including a frame without ground truth."""
+    from glenet_amd import roi_targets
+    rng = np.random.default_rng(21)
+    rois, labels, scores, gt = _scene(rng, 3, 300, 12, [7, 0, 12], [0.5, 0.3, 0.7])
+    unc = rng.random((3, 12, 7)).astype(np.float32)
+    cfg = dict(BASE, CLS_SCORE_TYPE=kind)
+    key, pick = rng.random((3, 300)).astype(np.float32), rng.random((3, BASE["ROI_PER_IMAGE"])).astype(np.float32)
+    got, _, _ = _device_forward(dev, cfg, rois, labels, scores, gt, key, pick, unc)
+    roi_targets.FUSED_GATHER = False
+    try:
+        want, _, _ = _device_forward(dev, cfg, rois, labels, scores, gt, key, pick, unc)
+    finally:
+        roi_targets.FUSED_GATHER = True
+    assert got.keys() == want.keys()
+    for k in want:
+        assert got[k].dtype == want[k].dtype and got[k].shape == want[k].shape, k
+        assert torch.equal(got[k], want[k]), k
+    assert float(got["gt_of_rois"][1].abs().max()) == 0.0 and float(got["gt_of_rois"][0].abs().max()) > 0

@@ -171,12 +171,12 @@ def test_replayed_training_follows_an_eager_adamw_loop(dev):
         pipe.step()
         got.append(float(pipe.loss))
     pipe.check()
-    # Same weights, same batch: the first replayed loss is the eager one.  After that the two runs are separate
-    # trajectories: the float atomics of the backward pass reorder sums by ~1e-7, Adam's m / sqrt(v) turns the sign
-    # of every noise-level gradient element into a full +-lr update, and the losses drift apart by up to ~1 % per
-    # step at this size (run to run, on either path) -- so the later steps get a tolerance a wrong update (no clip,
-    # stale gradients, a skipped parameter group: >= 10 % within 3 steps here) would still break.
-    np.testing.assert_allclose(got[0], want[2], rtol=1e-3)
+    # The two runs are separate trajectories from the first update on: the float atomics of the backward pass reorder
+    # sums by ~1e-7, Adam's m / sqrt(v) turns the sign of every noise-level gradient element into a full +-lr update,
+    # and the losses drift apart -- 0.2 % after the two warm-up updates, up to ~1 % per step after that at this size
+    # (run to run, on either path; the eager loop alone varies by 5e-5 at its third step).  The tolerances are what a
+    # wrong update (no clip, stale gradients, a skipped parameter group: >= 10 % within 3 steps here) still breaks.
+    np.testing.assert_allclose(got[0], want[2], rtol=5e-3)
     np.testing.assert_allclose(got, want[2:2 + len(got)], rtol=3e-2)
     assert got[-1] < got[0]
 
