@@ -64,6 +64,34 @@ def test_roi_fc_stack_and_anchor_head_shapes():
     assert d["dir_cls_preds"].shape == (1, 10, 8, 12)
 
 
+def test_anchor_head_fused_convolution_equals_the_three_heads():
+    """Training: conv_cls / conv_box / conv_dir_cls run as one convolution over the concatenated filters
+    (AnchorHead._forward_fused) -- same outputs and the same gradients of every parameter and of the input as the
+    three separate heads (anchor_head_single.py:41-58)."""
+    torch.manual_seed(3)
+    head = dp.AnchorHead(64, num_class=1, num_anchors_per_location=2).train()
+    x = torch.randn(2, 64, 12, 9)
+    res = []
+    for fused in (True, False):
+        head.FUSE_HEADS = fused
+        head.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        d = head({"spatial_features_2d": xi})
+        assert d["cls_preds"].shape == (2, 12, 9, 2) and d["box_preds"].shape == (2, 12, 9, 14)
+        assert d["dir_cls_preds"].shape == (2, 12, 9, 4) and d["box_preds"].is_contiguous()
+        loss = (d["cls_preds"] * 1.3).sum() + (d["box_preds"] ** 2).sum() + d["dir_cls_preds"].sin().sum()
+        loss.backward()
+        res.append(([d[k].detach() for k in ("cls_preds", "box_preds", "dir_cls_preds")], xi.grad,
+                    {n: p.grad.clone() for n, p in head.named_parameters()}))
+    head.FUSE_HEADS = True
+    for a, b in zip(res[0][0], res[1][0]):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(res[0][1].numpy(), res[1][1].numpy(), rtol=1e-4, atol=1e-6)
+    assert res[0][2].keys() == res[1][2].keys() and len(res[0][2]) == 6
+    for n in res[0][2]:
+        np.testing.assert_allclose(res[0][2][n].numpy(), res[1][2][n].numpy(), rtol=1e-4, atol=1e-5, err_msg=n)
+
+
 def test_roi_grid_geometry_matches_reference_helpers():
     # the module under test needs no GPU for its geometry; import lazily (the package pulls torch ops)
     from glenet_amd import roi_grid as rg
