@@ -7,6 +7,7 @@
 // so bitwise reproducible) + a one-block finalize + one fused normalise/affine/ReLU pass; backward
 // = column sums of dz and dz*xhat + finalize + one fused dx pass.  HBM-bound (x is read twice).
 #include "glx_common.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 typedef float bf32x4 __attribute__((ext_vector_type(4)));
 
@@ -19,11 +20,10 @@ typedef float bf32x4 __attribute__((ext_vector_type(4)));
 //   forward : a = x,  b = x                         -> sum x, sum x^2
 //   backward: a = dz, b = xhat = (x - mean)*invstd  -> sum dz, sum dz*xhat   (dz = dy * [y > 0])
 template <bool BWD>
-__global__ __launch_bounds__(BN_THREADS) void k_bn_partial(
+__device__ __forceinline__ void bn_slab_sums(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ invstd, int relu, int N, int C,
-    const int* __restrict__ n_live, double* __restrict__ partial) {
-  if (n_live) N = min(N, *n_live);
+    double (&a0)[4], double (&a1)[4]) {
   const int c4n = C >> 2;                       // float4 columns
   const int col = threadIdx.x % c4n, rlane = threadIdx.x / c4n;
   const int rstep = BN_THREADS / c4n;           // rows covered per pass by the block
@@ -78,8 +78,9 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_partial(
 #pragma unroll
   for (int i = 0; i < 4; ++i) { red[0][threadIdx.x][i] = s0[i]; red[1][threadIdx.x][i] = s1[i]; }
   __syncthreads();
-  if (threadIdx.x < c4n) {
-    double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a0[i] = a1[i] = 0;
+  if (threadIdx.x < c4n) {       // these threads return the slab's sums of float4 column threadIdx.x
     for (int l = 0; l < rstep; ++l) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -87,6 +88,18 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_partial(
         a1[i] += red[1][l * c4n + threadIdx.x][i];
       }
     }
+  }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(BN_THREADS) void k_bn_partial(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+    const float* __restrict__ mean, const float* __restrict__ invstd, int relu, int N, int C,
+    const int* __restrict__ n_live, double* __restrict__ partial) {
+  if (n_live) N = min(N, *n_live);
+  double a0[4], a1[4];
+  bn_slab_sums<BWD>(x, dy, y, mean, invstd, relu, N, C, a0, a1);
+  if (threadIdx.x < (C >> 2)) {
     double* p = partial + (size_t)blockIdx.x * 2 * C;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { p[4 * threadIdx.x + i] = a0[i]; p[C + 4 * threadIdx.x + i] = a1[i]; }
@@ -226,6 +239,91 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_backward_apply(
     reinterpret_cast<bf32x4*>(dx)[e] = o;
   }
 }
+
+// ------------------------------------------------------------------ statistics + finalize in one launch
+// The one-block finalize kernels above are launch latency (8.8 us each, 64 of them in a GLENet-VR training step,
+// for a few hundred flops).  With a persistent accumulator the statistics kernel finishes the job itself: every
+// block adds its slab sums to one of BN_SETS accumulator sets with fp64 atomics (16 sets: at most 16 blocks
+// queue on an address), takes a ticket, and the block that draws the last ticket sums the sets -- exchanging them
+// for zero, so the state is clean for the next call -- and does the finalize.
+// Ordering without fences (a release fence writes the XCD's whole dirty L2 back -- the conv output that was just
+// produced -- and made an earlier version of this slower than the separate kernel): the atomics execute at the
+// device-coherent level and RETURN their old value; a block consumes the returns (s_waitcnt) before its ticket
+// atomic is issued, so whoever sees the last ticket finds every contribution in place.  The sums of a set arrive in
+// a run-dependent order: the fp64 totals can differ by an ulp of 2^-52 between runs, their float roundings
+// practically never -- callers that need the fixed-order guarantee pass state = NULL (three launches).
+#define BN_SETS 16
+struct BnState {
+  double acc[BN_SETS][2 * BN_MAXC];
+  unsigned ticket;
+};
+
+struct BnFinalize {
+  const float* gamma; const float* beta; float eps, momentum;          // forward
+  float* coef; float* save_mean; float* save_invstd; float* running_mean; float* running_var;
+  const float* invstd; float* dgamma; float* dbeta;                     // backward
+};
+
+__device__ __forceinline__ double bn_take(double* p) {                  // read and clear
+  return __longlong_as_double((long long)__hip_atomic_exchange(reinterpret_cast<unsigned long long*>(p), 0ull,
+                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(BN_THREADS) void k_bn_stats(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+    const float* __restrict__ mean, const float* __restrict__ invstd, int relu, int N, int C,
+    const int* __restrict__ n_live, BnState* __restrict__ st, BnFinalize f) {
+  __shared__ int s_last;
+  if (n_live) N = min(N, *n_live);
+  double a0[4], a1[4];
+  bn_slab_sums<BWD>(x, dy, y, mean, invstd, relu, N, C, a0, a1);
+  if (threadIdx.x < (C >> 2)) {
+    double* acc = st->acc[blockIdx.x % BN_SETS];
+    double seen = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      seen += unsafeAtomicAdd(acc + 4 * threadIdx.x + i, a0[i]);
+      seen += unsafeAtomicAdd(acc + BN_MAXC + 4 * threadIdx.x + i, a1[i]);
+    }
+    asm volatile("" ::"v"(seen) : "memory");                           // the atomics have returned: they are done
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_last = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  const double cnt = N > 0 ? (double)N : 1.0;
+  for (int c = threadIdx.x; c < C; c += BN_THREADS) {
+    double s = 0, ss = 0;
+    for (int k = 0; k < BN_SETS; ++k) { s += bn_take(&st->acc[k][c]); ss += bn_take(&st->acc[k][BN_MAXC + c]); }
+    if (!BWD) {
+      const double m = s / cnt;
+      double var = ss / cnt - m * m;
+      if (var < 0) var = 0;
+      const float is = (float)(1.0 / sqrt(var + (double)f.eps));
+      const float gm = f.gamma ? f.gamma[c] : 1.f, bt = f.beta ? f.beta[c] : 0.f;
+      f.coef[c] = is * gm;
+      f.coef[C + c] = bt - (float)m * is * gm;
+      f.save_mean[c] = (float)m;
+      f.save_invstd[c] = is;
+      if (f.running_mean) {
+        const double unb = N > 1 ? var * cnt / (cnt - 1.0) : var;
+        f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)m;
+        f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unb;
+      }
+    } else {
+      f.coef[c] = (f.gamma ? f.gamma[c] : 1.f) * f.invstd[c];
+      f.coef[C + c] = (float)(s / cnt);
+      f.coef[2 * C + c] = (float)(ss / cnt);
+      if (f.dgamma) f.dgamma[c] = (float)ss;
+      if (f.dbeta) f.dbeta[c] = (float)s;
+    }
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+extern "C" size_t glx_bn_state_bytes(void) { return glx_align(sizeof(BnState)); }
 
 // ------------------------------------------------------------------ short matrices: one launch
 // The RoI head's FC towers normalise (512, 256) matrices: the three-launch scheme above (and torch's five
@@ -390,7 +488,7 @@ extern "C" int glx_bn_relu_train_forward(const float* x, int N, int C, const flo
                                          float* running_mean, float* running_var, float* y,
                                          float* save_mean, float* save_invstd,
                                          const int32_t* n_live, void* workspace,
-                                         size_t workspace_bytes, void* stream) {
+                                         size_t workspace_bytes, void* state, void* stream) {
   GLX_REQUIRE(bn_channels_ok(C), "glx_bn_relu_train_forward: C=%d must be a multiple of 4 dividing 1024, <= 512", C);
   GLX_REQUIRE(y && save_mean && save_invstd && (N == 0 || x), "glx_bn_relu_train_forward: null pointer");
   if (!workspace || workspace_bytes < glx_bn_workspace_bytes(C) - 256) {
@@ -408,14 +506,21 @@ extern "C" int glx_bn_relu_train_forward(const float* x, int N, int C, const flo
     return GLX_OK;
   }
   const int slabs = glx_divup(N, 8) > BN_SLABS ? BN_SLABS : glx_divup(N, 8);
-  hipLaunchKernelGGL((k_bn_partial<false>), dim3(slabs), dim3(BN_THREADS), 0, st, x, nullptr, nullptr,
-                     nullptr, nullptr, 0, N, C, n_live, (double*)workspace);
   const int want = glx_divup((long long)N * C / 4, BN_THREADS * 4);
   const int blocks = want > 512 ? 512 : want;
   float* coef = (float*)((char*)workspace + bn_coef_offset(C));
-  hipLaunchKernelGGL(k_bn_finalize_fwd, dim3(1), dim3(BN_FIN_THREADS), 0, st, (const double*)workspace,
-                     slabs, gamma, beta, eps, momentum, N, C, n_live, coef, save_mean, save_invstd,
-                     running_mean, running_var);
+  if (state) {
+    BnFinalize f{gamma, beta, eps, momentum, coef, save_mean, save_invstd, running_mean, running_var,
+                 nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL((k_bn_stats<false>), dim3(slabs), dim3(BN_THREADS), 0, st, x, nullptr, nullptr,
+                       nullptr, nullptr, 0, N, C, n_live, (BnState*)state, f);
+  } else {
+    hipLaunchKernelGGL((k_bn_partial<false>), dim3(slabs), dim3(BN_THREADS), 0, st, x, nullptr, nullptr,
+                       nullptr, nullptr, 0, N, C, n_live, (double*)workspace);
+    hipLaunchKernelGGL(k_bn_finalize_fwd, dim3(1), dim3(BN_FIN_THREADS), 0, st, (const double*)workspace,
+                       slabs, gamma, beta, eps, momentum, N, C, n_live, coef, save_mean, save_invstd,
+                       running_mean, running_var);
+  }
   hipLaunchKernelGGL(k_bn_forward_apply, dim3(blocks < 1 ? 1 : blocks), dim3(BN_THREADS), 0, st, x,
                      (const float*)coef, relu, N, C, n_live, y);
   GLX_LAUNCH_CHECK();
@@ -426,7 +531,7 @@ extern "C" int glx_bn_relu_backward(const float* x, const float* dy, const float
                                     const float* gamma, const float* save_mean,
                                     const float* save_invstd, int relu, float* dx, float* dgamma,
                                     float* dbeta, const int32_t* n_live, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
+                                    size_t workspace_bytes, void* state, void* stream) {
   GLX_REQUIRE(bn_channels_ok(C), "glx_bn_relu_backward: C=%d not supported", C);
   GLX_REQUIRE(save_mean && save_invstd && (N == 0 || (x && dy && dx)) && (!relu || y || N == 0),
               "glx_bn_relu_backward: null pointer");
@@ -444,13 +549,19 @@ extern "C" int glx_bn_relu_backward(const float* x, const float* dy, const float
     return GLX_OK;
   }
   const int slabs = glx_divup(N, 8) > BN_SLABS ? BN_SLABS : glx_divup(N, 8);
-  hipLaunchKernelGGL((k_bn_partial<true>), dim3(slabs), dim3(BN_THREADS), 0, st, x, dy, y, save_mean,
-                     save_invstd, relu, N, C, n_live, (double*)workspace);
   const int want = glx_divup((long long)N * C / 4, BN_THREADS * 4);
   const int blocks = want > 512 ? 512 : want;
   float* coef = (float*)((char*)workspace + bn_coef_offset(C));
-  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(1), dim3(BN_FIN_THREADS), 0, st, (const double*)workspace,
-                     slabs, gamma, save_invstd, N, C, n_live, coef, dgamma, dbeta);
+  if (state) {
+    BnFinalize f{gamma, nullptr, 0.f, 0.f, coef, nullptr, nullptr, nullptr, nullptr, save_invstd, dgamma, dbeta};
+    hipLaunchKernelGGL((k_bn_stats<true>), dim3(slabs), dim3(BN_THREADS), 0, st, x, dy, y, save_mean,
+                       save_invstd, relu, N, C, n_live, (BnState*)state, f);
+  } else {
+    hipLaunchKernelGGL((k_bn_partial<true>), dim3(slabs), dim3(BN_THREADS), 0, st, x, dy, y, save_mean,
+                       save_invstd, relu, N, C, n_live, (double*)workspace);
+    hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(1), dim3(BN_FIN_THREADS), 0, st, (const double*)workspace,
+                       slabs, gamma, save_invstd, N, C, n_live, coef, dgamma, dbeta);
+  }
   hipLaunchKernelGGL(k_bn_backward_apply, dim3(blocks < 1 ? 1 : blocks), dim3(BN_THREADS), 0, st, x,
                      dy, y, (const float*)coef, save_mean, save_invstd, relu, N, C, n_live, dx);
   GLX_LAUNCH_CHECK();

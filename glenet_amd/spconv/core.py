@@ -658,6 +658,23 @@ def _bn_affine(bn):
     return cache[1], cache[2]
 
 
+# accumulators of the statistics kernels (csrc/glx_bn.hip: k_bn_stats): zero-filled once, self-cleaning, one per
+# (device, stream) -- launches that share a buffer must be ordered by their stream.  GLX_BN_STATE=0: the fixed-order
+# three-launch scheme.
+USE_BN_STATE = os.environ.get("GLX_BN_STATE", "1") != "0"
+_BN_STATES = {}
+
+
+def _bn_state(device):
+    if not USE_BN_STATE:
+        return None
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    st = _BN_STATES.get(key)
+    if st is None:
+        st = _BN_STATES[key] = torch.zeros(query("glx_bn_state_bytes"), dtype=torch.uint8, device=device)
+    return st
+
+
 class FusedBNReLU(Function):
     """Training-mode BatchNorm1d (+ReLU) on (N, C) features in two launches forward and two
     backward (csrc/glx_bn.hip); numerics of nn.BatchNorm1d(eps, momentum) + nn.ReLU."""
@@ -671,7 +688,8 @@ class FusedBNReLU(Function):
         invstd = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = workspace.get(query("glx_bn_workspace_bytes", C), x.device)
         call("glx_bn_relu_train_forward", x, N, C, weight, bias, ctypes_float(eps), ctypes_float(momentum),
-             1 if relu else 0, running_mean, running_var, y, mean, invstd, count, ws, size_arg(ws.numel()))
+             1 if relu else 0, running_mean, running_var, y, mean, invstd, count, ws, size_arg(ws.numel()),
+             _bn_state(x.device))
         ctx.save_for_backward(x, y, weight, mean, invstd)
         ctx.relu, ctx.count = relu, count
         return y
@@ -686,7 +704,7 @@ class FusedBNReLU(Function):
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = workspace.get(query("glx_bn_workspace_bytes", C), x.device)
         call("glx_bn_relu_backward", x, dy, y, N, C, weight, mean, invstd, 1 if ctx.relu else 0, dx,
-             dgamma, dbeta, ctx.count, ws, size_arg(ws.numel()))
+             dgamma, dbeta, ctx.count, ws, size_arg(ws.numel()), _bn_state(x.device))
         return dx, (dgamma if weight is not None else None), (dbeta if weight is not None else None), \
             None, None, None, None, None, None
 

@@ -499,19 +499,26 @@ int glx_predicted_boxes(const float* box_preds, const float* dir_preds, const fl
  * divides 1024 (16 ... 512).  Semantics of nn.BatchNorm1d(eps, momentum) followed by nn.ReLU as
  * the backbone applies them after every sparse conv (spconv_backbone.py:21-25,73): batch
  * statistics (biased variance) normalise, the running estimates take the unbiased variance.
- * Deterministic (fixed reduction order, fp64 partial sums).  relu = 0 gives plain BatchNorm.
+ * relu = 0 gives plain BatchNorm.  fp64 column sums.
+ * state: NULL, or a device buffer of glx_bn_state_bytes() that the caller zero-fills ONCE and then only hands to
+ *   these two functions, one buffer per stream.  NULL: statistics, a one-block finalize and the transform are three
+ *   launches and the reduction order is fixed (bitwise reproducible).  With a state buffer the statistics kernel
+ *   accumulates with fp64 atomics and its last block finalizes (two launches; the buffer is left zeroed again);
+ *   the order of the fp64 additions then varies between runs (differences of one fp64 ulp before the rounding to
+ *   float).  Matrices of at most 4096 rows always take a single launch with a fixed order.
  * ------------------------------------------------------------------------------------ */
 size_t glx_bn_workspace_bytes(int C);
+size_t glx_bn_state_bytes(void);
 int glx_bn_relu_train_forward(const float* x, int N, int C, const float* gamma, const float* beta,
                               float eps, float momentum, int relu, float* running_mean,
                               float* running_var, float* y, float* save_mean, float* save_invstd,
                               const int32_t* n_live, void* workspace, size_t workspace_bytes,
-                              void* stream);
+                              void* state, void* stream);
 /* dx (N,C), dgamma (C), dbeta (C) from dy and the forward's x, y (needed when relu), mean, invstd. */
 int glx_bn_relu_backward(const float* x, const float* dy, const float* y, int N, int C,
                          const float* gamma, const float* save_mean, const float* save_invstd,
                          int relu, float* dx, float* dgamma, float* dbeta, const int32_t* n_live,
-                         void* workspace, size_t workspace_bytes, void* stream);
+                         void* workspace, size_t workspace_bytes, void* state, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * VectorPool family of PV-RCNN++.  Output slots are laid out in ascending new-point order

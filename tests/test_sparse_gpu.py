@@ -278,9 +278,17 @@ def test_dense_and_empty(dev):
 
 @pytest.mark.parametrize("C,relu,N", [(16, True, 5000), (64, True, 48000), (128, False, 777), (32, True, 2),
                                       (256, True, 512), (8, True, 4096), (8, False, 4097)])   # N <= 4096: the one-launch kernels
-def test_fused_train_batchnorm_matches_torch(dev, C, relu, N):
+@pytest.mark.parametrize("state", [True, False])
+def test_fused_train_batchnorm_matches_torch(dev, C, relu, N, state, monkeypatch):
     """glx_bn_relu_train_forward / _backward vs nn.BatchNorm1d (+ nn.ReLU) in training mode:
-    outputs, running statistics, input and affine gradients."""
+    outputs, running statistics, input and affine gradients.  state: statistics + finalize in one launch through
+    the persistent accumulators (run twice: the accumulators are left clean) / the fixed-order three launches."""
+    monkeypatch.setattr(sp, "USE_BN_STATE", state)
+    for _ in range(2 if state else 1):
+        _check_fused_train_batchnorm(dev, C, relu, N)
+
+
+def _check_fused_train_batchnorm(dev, C, relu, N):
     torch.manual_seed(C + N)
     x = (torch.randn(N, C, device=dev) * 2 + 0.5)
     bn_ref = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).to(dev).train()
