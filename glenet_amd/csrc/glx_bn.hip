@@ -11,6 +11,14 @@
 
 typedef float bf32x4 __attribute__((ext_vector_type(4)));
 
+// y = x * scale + shift, written ONE way everywhere: the backward kernels re-derive the ReLU mask (y > 0) from x
+// instead of reading y back (a third of their traffic), which only works if they round exactly like the forward.
+__device__ __forceinline__ float bn_scale(float invstd, float gamma) { return __fmul_rn(invstd, gamma); }
+__device__ __forceinline__ float bn_shift(float beta, float mean, float invstd, float gamma) {
+  return __fsub_rn(beta, __fmul_rn(__fmul_rn(mean, invstd), gamma));
+}
+__device__ __forceinline__ float bn_affine(float x, float scale, float shift) { return __fmaf_rn(x, scale, shift); }
+
 #define BN_THREADS 256
 #define BN_MAXC 512
 #define BN_SLABS 256   // row slabs = blocks of the statistics kernels (one per CU)
@@ -22,8 +30,8 @@ typedef float bf32x4 __attribute__((ext_vector_type(4)));
 template <bool BWD>
 __device__ __forceinline__ void bn_slab_sums(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
-    const float* __restrict__ mean, const float* __restrict__ invstd, int relu, int N, int C,
-    double (&a0)[4], double (&a1)[4]) {
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, int relu, int N, int C, double (&a0)[4], double (&a1)[4]) {
   const int c4n = C >> 2;                       // float4 columns
   const int col = threadIdx.x % c4n, rlane = threadIdx.x / c4n;
   const int rstep = BN_THREADS / c4n;           // rows covered per pass by the block
@@ -31,9 +39,19 @@ __device__ __forceinline__ void bn_slab_sums(
   const int r0 = blockIdx.x * rows_per_slab, r1 = min(N, r0 + rows_per_slab);
   double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
   bf32x4 mu = bf32x4{0, 0, 0, 0}, is = mu;
+  float sc[4] = {0, 0, 0, 0}, sh[4] = {0, 0, 0, 0};
+  const bool remask = BWD && relu && !y;        // ReLU mask from x (y not read)
   if (BWD) {
     mu = *reinterpret_cast<const bf32x4*>(mean + 4 * col);
     is = *reinterpret_cast<const bf32x4*>(invstd + 4 * col);
+    if (remask) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float gm = gamma ? gamma[4 * col + i] : 1.f, bt = beta ? beta[4 * col + i] : 0.f;
+        sc[i] = bn_scale(is[i], gm);
+        sh[i] = bn_shift(bt, mu[i], is[i], gm);
+      }
+    }
   }
   if (rlane < rstep) {
     // 4 rows per trip with all their loads issued first: a slab is ~190 rows over 16 row lanes,
@@ -47,14 +65,17 @@ __device__ __forceinline__ void bn_slab_sums(
         xv[j] = *reinterpret_cast<const bf32x4*>(x + o);
         if (BWD) {
           g[j] = *reinterpret_cast<const bf32x4*>(dy + o);
-          if (relu) yv[j] = *reinterpret_cast<const bf32x4*>(y + o);
+          if (relu && !remask) yv[j] = *reinterpret_cast<const bf32x4*>(y + o);
         }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (r + j * rstep >= r1) break;
         if (BWD) {
-          if (relu) {
+          if (remask) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[j][i] = bn_affine(xv[j][i], sc[i], sh[i]) > 0.f ? g[j][i] : 0.f;
+          } else if (relu) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) g[j][i] = yv[j][i] > 0.f ? g[j][i] : 0.f;
           }
@@ -94,11 +115,12 @@ __device__ __forceinline__ void bn_slab_sums(
 template <bool BWD>
 __global__ __launch_bounds__(BN_THREADS) void k_bn_partial(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
-    const float* __restrict__ mean, const float* __restrict__ invstd, int relu, int N, int C,
-    const int* __restrict__ n_live, double* __restrict__ partial) {
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, int relu, int N, int C, const int* __restrict__ n_live,
+    double* __restrict__ partial) {
   if (n_live) N = min(N, *n_live);
   double a0[4], a1[4];
-  bn_slab_sums<BWD>(x, dy, y, mean, invstd, relu, N, C, a0, a1);
+  bn_slab_sums<BWD>(x, dy, y, mean, invstd, gamma, beta, relu, N, C, a0, a1);
   if (threadIdx.x < (C >> 2)) {
     double* p = partial + (size_t)blockIdx.x * 2 * C;
 #pragma unroll
@@ -145,8 +167,8 @@ __global__ __launch_bounds__(BN_FIN_THREADS) void k_bn_finalize_fwd(
       if (var < 0) var = 0;
       const float is = (float)(1.0 / sqrt(var + (double)eps));
       const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
-      coef[c] = is * gm;
-      coef[C + c] = bt - (float)m * is * gm;
+      coef[c] = bn_scale(is, gm);
+      coef[C + c] = bn_shift(bt, (float)m, is, gm);
       save_mean[c] = (float)m;
       save_invstd[c] = is;
       if (running_mean) {   // nn.BatchNorm semantics: unbiased variance in the running estimate
@@ -174,7 +196,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_forward_apply(
     bf32x4 v = reinterpret_cast<const bf32x4*>(x)[e];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float t = v[i] * s_scale[c + i] + s_shift[c + i];
+      float t = bn_affine(v[i], s_scale[c + i], s_shift[c + i]);
       v[i] = relu ? fmaxf(t, 0.f) : t;
     }
     reinterpret_cast<bf32x4*>(y)[e] = v;
@@ -209,13 +231,19 @@ __global__ __launch_bounds__(BN_FIN_THREADS) void k_bn_finalize_bwd(
 __global__ __launch_bounds__(BN_THREADS) void k_bn_backward_apply(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
     const float* __restrict__ coef, const float* __restrict__ mean, const float* __restrict__ invstd,
-    int relu, int N, int C, const int* __restrict__ n_live, float* __restrict__ dx) {
-  __shared__ float s_a[BN_MAXC], s_b[BN_MAXC], s_c[BN_MAXC], s_mu[BN_MAXC], s_is[BN_MAXC];
+    const float* __restrict__ gamma, const float* __restrict__ beta, int relu, int N, int C,
+    const int* __restrict__ n_live, float* __restrict__ dx) {
+  __shared__ float s_a[BN_MAXC], s_b[BN_MAXC], s_c[BN_MAXC], s_mu[BN_MAXC], s_is[BN_MAXC], s_sc[BN_MAXC],
+      s_sh[BN_MAXC];
   int n = N;
   if (n_live) n = min(N, *n_live);
+  const bool remask = relu && !y;
   for (int c = threadIdx.x; c < C; c += BN_THREADS) {
     s_a[c] = coef[c]; s_b[c] = coef[C + c]; s_c[c] = coef[2 * C + c];
     s_mu[c] = mean[c]; s_is[c] = invstd[c];
+    const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    s_sc[c] = bn_scale(s_is[c], gm);
+    s_sh[c] = bn_shift(bt, s_mu[c], s_is[c], gm);
   }
   __syncthreads();
   const long long total4 = (long long)n * C / 4;
@@ -225,7 +253,10 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_backward_apply(
     const int c = (int)(e % c4n) * 4;
     bf32x4 xv = reinterpret_cast<const bf32x4*>(x)[e];
     bf32x4 g = reinterpret_cast<const bf32x4*>(dy)[e];
-    if (relu) {
+    if (remask) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g[i] = bn_affine(xv[i], s_sc[c + i], s_sh[c + i]) > 0.f ? g[i] : 0.f;
+    } else if (relu) {
       bf32x4 yv = reinterpret_cast<const bf32x4*>(y)[e];
 #pragma unroll
       for (int i = 0; i < 4; ++i) g[i] = yv[i] > 0.f ? g[i] : 0.f;
@@ -277,7 +308,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_stats(
   __shared__ int s_last;
   if (n_live) N = min(N, *n_live);
   double a0[4], a1[4];
-  bn_slab_sums<BWD>(x, dy, y, mean, invstd, relu, N, C, a0, a1);
+  bn_slab_sums<BWD>(x, dy, y, mean, invstd, f.gamma, f.beta, relu, N, C, a0, a1);
   if (threadIdx.x < (C >> 2)) {
     double* acc = st->acc[blockIdx.x % BN_SETS];
     double seen = 0;
@@ -303,8 +334,8 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_stats(
       if (var < 0) var = 0;
       const float is = (float)(1.0 / sqrt(var + (double)f.eps));
       const float gm = f.gamma ? f.gamma[c] : 1.f, bt = f.beta ? f.beta[c] : 0.f;
-      f.coef[c] = is * gm;
-      f.coef[C + c] = bt - (float)m * is * gm;
+      f.coef[c] = bn_scale(is, gm);
+      f.coef[C + c] = bn_shift(bt, (float)m, is, gm);
       f.save_mean[c] = (float)m;
       f.save_invstd[c] = is;
       if (f.running_mean) {
@@ -388,8 +419,8 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_small_forward(
     if (var < 0) var = 0;
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     const float gm = gamma ? gamma[c0 + i] : 1.f, bt = beta ? beta[c0 + i] : 0.f;
-    sc[i] = is * gm;
-    sh[i] = bt - (float)m * is * gm;
+    sc[i] = bn_scale(is, gm);
+    sh[i] = bn_shift(bt, (float)m, is, gm);
     if (rl == 0) {
       save_mean[c0 + i] = (float)m;
       save_invstd[c0 + i] = is;
@@ -404,7 +435,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_small_forward(
     bf32x4 v = *reinterpret_cast<const bf32x4*>(x + (long long)r * C + c0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float t = v[i] * sc[i] + sh[i];
+      const float t = bn_affine(v[i], sc[i], sh[i]);
       v[i] = relu ? fmaxf(t, 0.f) : t;
     }
     *reinterpret_cast<bf32x4*>(y + (long long)r * C + c0) = v;
@@ -413,9 +444,9 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_small_forward(
 
 __global__ __launch_bounds__(BN_THREADS) void k_bn_small_backward(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
-    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
-    int relu, int N, int C, const int* __restrict__ n_live, float* __restrict__ dx,
-    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+    const float* __restrict__ invstd, int relu, int N, int C, const int* __restrict__ n_live,
+    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   __shared__ double s_part[BN_THREADS / 64][BN_SMALL_CQ][8];
   int n = N;
   if (n_live) n = min(N, *n_live);
@@ -425,14 +456,25 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_small_backward(
   constexpr int RL = BN_THREADS / BN_SMALL_CQ;
   double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
   bf32x4 mu = bf32x4{0, 0, 0, 0}, is = mu;
+  float sc[4] = {0, 0, 0, 0}, sh[4] = {0, 0, 0, 0};
+  const bool remask = relu && !y;
   if (cok) {
     mu = *reinterpret_cast<const bf32x4*>(mean + c0);
     is = *reinterpret_cast<const bf32x4*>(invstd + c0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float gm = gamma ? gamma[c0 + i] : 1.f, bt = beta ? beta[c0 + i] : 0.f;
+      sc[i] = bn_scale(is[i], gm);
+      sh[i] = bn_shift(bt, mu[i], is[i], gm);
+    }
     for (int r = rl; r < n; r += RL) {
       const long long o = (long long)r * C + c0;
       const bf32x4 xv = *reinterpret_cast<const bf32x4*>(x + o);
       bf32x4 g = *reinterpret_cast<const bf32x4*>(dy + o);
-      if (relu) {
+      if (remask) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = bn_affine(xv[i], sc[i], sh[i]) > 0.f ? g[i] : 0.f;
+      } else if (relu) {
         const bf32x4 yv = *reinterpret_cast<const bf32x4*>(y + o);
 #pragma unroll
         for (int i = 0; i < 4; ++i) g[i] = yv[i] > 0.f ? g[i] : 0.f;
@@ -462,7 +504,10 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_small_backward(
     const long long o = (long long)r * C + c0;
     const bf32x4 xv = *reinterpret_cast<const bf32x4*>(x + o);
     bf32x4 g = *reinterpret_cast<const bf32x4*>(dy + o);
-    if (relu) {
+    if (remask) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g[i] = bn_affine(xv[i], sc[i], sh[i]) > 0.f ? g[i] : 0.f;
+    } else if (relu) {
       const bf32x4 yv = *reinterpret_cast<const bf32x4*>(y + o);
 #pragma unroll
       for (int i = 0; i < 4; ++i) g[i] = yv[i] > 0.f ? g[i] : 0.f;
@@ -516,7 +561,7 @@ extern "C" int glx_bn_relu_train_forward(const float* x, int N, int C, const flo
                        nullptr, nullptr, 0, N, C, n_live, (BnState*)state, f);
   } else {
     hipLaunchKernelGGL((k_bn_partial<false>), dim3(slabs), dim3(BN_THREADS), 0, st, x, nullptr, nullptr,
-                       nullptr, nullptr, 0, N, C, n_live, (double*)workspace);
+                       nullptr, nullptr, nullptr, nullptr, 0, N, C, n_live, (double*)workspace);
     hipLaunchKernelGGL(k_bn_finalize_fwd, dim3(1), dim3(BN_FIN_THREADS), 0, st, (const double*)workspace,
                        slabs, gamma, beta, eps, momentum, N, C, n_live, coef, save_mean, save_invstd,
                        running_mean, running_var);
@@ -528,13 +573,12 @@ extern "C" int glx_bn_relu_train_forward(const float* x, int N, int C, const flo
 }
 
 extern "C" int glx_bn_relu_backward(const float* x, const float* dy, const float* y, int N, int C,
-                                    const float* gamma, const float* save_mean,
+                                    const float* gamma, const float* beta, const float* save_mean,
                                     const float* save_invstd, int relu, float* dx, float* dgamma,
                                     float* dbeta, const int32_t* n_live, void* workspace,
                                     size_t workspace_bytes, void* state, void* stream) {
   GLX_REQUIRE(bn_channels_ok(C), "glx_bn_relu_backward: C=%d not supported", C);
-  GLX_REQUIRE(save_mean && save_invstd && (N == 0 || (x && dy && dx)) && (!relu || y || N == 0),
-              "glx_bn_relu_backward: null pointer");
+  GLX_REQUIRE(save_mean && save_invstd && (N == 0 || (x && dy && dx)), "glx_bn_relu_backward: null pointer");
   if (!workspace || workspace_bytes < glx_bn_workspace_bytes(C) - 256) {
     glx_set_error("glx_bn_relu_backward: workspace %zu < %zu bytes", workspace_bytes,
                   glx_bn_workspace_bytes(C) - 256);
@@ -544,7 +588,7 @@ extern "C" int glx_bn_relu_backward(const float* x, const float* dy, const float
   hipStream_t st = (hipStream_t)stream;
   if (N <= BN_SMALL_N) {
     hipLaunchKernelGGL(k_bn_small_backward, dim3(glx_divup(C, 4 * BN_SMALL_CQ)), dim3(BN_THREADS), 0, st, x,
-                       dy, y, gamma, save_mean, save_invstd, relu, N, C, n_live, dx, dgamma, dbeta);
+                       dy, y, gamma, beta, save_mean, save_invstd, relu, N, C, n_live, dx, dgamma, dbeta);
     GLX_LAUNCH_CHECK();
     return GLX_OK;
   }
@@ -553,17 +597,17 @@ extern "C" int glx_bn_relu_backward(const float* x, const float* dy, const float
   const int blocks = want > 512 ? 512 : want;
   float* coef = (float*)((char*)workspace + bn_coef_offset(C));
   if (state) {
-    BnFinalize f{gamma, nullptr, 0.f, 0.f, coef, nullptr, nullptr, nullptr, nullptr, save_invstd, dgamma, dbeta};
+    BnFinalize f{gamma, beta, 0.f, 0.f, coef, nullptr, nullptr, nullptr, nullptr, save_invstd, dgamma, dbeta};
     hipLaunchKernelGGL((k_bn_stats<true>), dim3(slabs), dim3(BN_THREADS), 0, st, x, dy, y, save_mean,
                        save_invstd, relu, N, C, n_live, (BnState*)state, f);
   } else {
     hipLaunchKernelGGL((k_bn_partial<true>), dim3(slabs), dim3(BN_THREADS), 0, st, x, dy, y, save_mean,
-                       save_invstd, relu, N, C, n_live, (double*)workspace);
+                       save_invstd, gamma, beta, relu, N, C, n_live, (double*)workspace);
     hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(1), dim3(BN_FIN_THREADS), 0, st, (const double*)workspace,
                        slabs, gamma, save_invstd, N, C, n_live, coef, dgamma, dbeta);
   }
   hipLaunchKernelGGL(k_bn_backward_apply, dim3(blocks < 1 ? 1 : blocks), dim3(BN_THREADS), 0, st, x,
-                     dy, y, (const float*)coef, save_mean, save_invstd, relu, N, C, n_live, dx);
+                     dy, y, (const float*)coef, save_mean, save_invstd, gamma, beta, relu, N, C, n_live, dx);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

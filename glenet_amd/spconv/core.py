@@ -690,20 +690,20 @@ class FusedBNReLU(Function):
         call("glx_bn_relu_train_forward", x, N, C, weight, bias, ctypes_float(eps), ctypes_float(momentum),
              1 if relu else 0, running_mean, running_var, y, mean, invstd, count, ws, size_arg(ws.numel()),
              _bn_state(x.device))
-        ctx.save_for_backward(x, y, weight, mean, invstd)
+        ctx.save_for_backward(x, weight, bias, mean, invstd)          # not y: backward re-derives the ReLU mask from x
         ctx.relu, ctx.count = relu, count
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, weight, mean, invstd = ctx.saved_tensors
+        x, weight, bias, mean, invstd = ctx.saved_tensors
         dy = dy.contiguous().float()
         N, C = x.shape
         dx = torch.empty_like(x)
         dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = workspace.get(query("glx_bn_workspace_bytes", C), x.device)
-        call("glx_bn_relu_backward", x, dy, y, N, C, weight, mean, invstd, 1 if ctx.relu else 0, dx,
+        call("glx_bn_relu_backward", x, dy, None, N, C, weight, bias, mean, invstd, 1 if ctx.relu else 0, dx,
              dgamma, dbeta, ctx.count, ws, size_arg(ws.numel()), _bn_state(x.device))
         return dx, (dgamma if weight is not None else None), (dbeta if weight is not None else None), \
             None, None, None, None, None, None

@@ -514,9 +514,11 @@ int glx_bn_relu_train_forward(const float* x, int N, int C, const float* gamma, 
                               float* running_var, float* y, float* save_mean, float* save_invstd,
                               const int32_t* n_live, void* workspace, size_t workspace_bytes,
                               void* state, void* stream);
-/* dx (N,C), dgamma (C), dbeta (C) from dy and the forward's x, y (needed when relu), mean, invstd. */
+/* dx (N,C), dgamma (C), dbeta (C) from dy and the forward's x, mean, invstd.  The ReLU mask: from the forward's
+ * output y, or -- y = NULL -- re-derived from x with gamma / beta (the forward's own rounding, so it is the same
+ * mask; a third less traffic).  beta is only read in that case. */
 int glx_bn_relu_backward(const float* x, const float* dy, const float* y, int N, int C,
-                         const float* gamma, const float* save_mean, const float* save_invstd,
+                         const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                          int relu, float* dx, float* dgamma, float* dbeta, const int32_t* n_live,
                          void* workspace, size_t workspace_bytes, void* state, void* stream);
 
