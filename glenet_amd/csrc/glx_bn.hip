@@ -21,7 +21,22 @@ __device__ __forceinline__ float bn_affine(float x, float scale, float shift) { 
 
 #define BN_THREADS 256
 #define BN_MAXC 512
-#define BN_SLABS 256   // row slabs = blocks of the statistics kernels (one per CU)
+#define BN_SLABS 256   // row slabs = blocks of the statistics kernels (one per CU) on the fixed-order path
+// with a state buffer the slab count is free, but more blocks did not pay: measured on the training step (caps of the
+// statistics / transform grids 256/512: 12.97 ms, 512/1024: 13.05, 1024/2048: 13.17, 2048/4096: 13.26 -- more blocks queue
+// on the accumulator atomics); env GLX_BN_STATS_BLOCKS / GLX_BN_APPLY_BLOCKS override the caps
+static int bn_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static int bn_stats_slabs(int N, int C) {
+  static const int cap = bn_env("GLX_BN_STATS_BLOCKS", 256);
+  const long long want = ((long long)N * C * 4 + 32767) / 32768;
+  const int lo = glx_divup(N, 8) > BN_SLABS ? BN_SLABS : glx_divup(N, 8);
+  return want <= lo ? lo : (want > cap ? cap : (int)want);
+}
+static int bn_apply_blocks(int N, int C) {
+  static const int cap = bn_env("GLX_BN_APPLY_BLOCKS", 512);
+  const int want = glx_divup((long long)N * C / 4, BN_THREADS * 4);
+  return want > cap ? cap : (want < 1 ? 1 : want);
+}
 #define BN_FIN_THREADS 1024   // the one-block finalize kernels: 1024 / C slab groups per channel
 
 // partial[slab][2][C] (fp64): column sums of (a, a*b) over the slab's rows.
@@ -325,9 +340,19 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_stats(
   __syncthreads();
   if (!s_last) return;
   const double cnt = N > 0 ? (double)N : 1.0;
-  for (int c = threadIdx.x; c < C; c += BN_THREADS) {
+  // all 256 threads fetch: thread (c, g) takes sets g, g + G, ...; the G groups are combined in LDS
+  __shared__ double s_fin[BN_THREADS][2];
+  const int CB = C < BN_THREADS ? C : BN_THREADS, G = BN_THREADS / CB;
+  for (int cb = 0; cb < C; cb += CB) {
+    const int c = cb + threadIdx.x % CB, g = threadIdx.x / CB;
     double s = 0, ss = 0;
-    for (int k = 0; k < BN_SETS; ++k) { s += bn_take(&st->acc[k][c]); ss += bn_take(&st->acc[k][BN_MAXC + c]); }
+    for (int k = g; k < BN_SETS; k += G) { s += bn_take(&st->acc[k][c]); ss += bn_take(&st->acc[k][BN_MAXC + c]); }
+    __syncthreads();
+    s_fin[threadIdx.x][0] = s;
+    s_fin[threadIdx.x][1] = ss;
+    __syncthreads();
+    if (g != 0) continue;
+    for (int k = 1; k < G && k < BN_SETS; ++k) { s += s_fin[k * CB + c - cb][0]; ss += s_fin[k * CB + c - cb][1]; }
     if (!BWD) {
       const double m = s / cnt;
       double var = ss / cnt - m * m;
@@ -550,9 +575,8 @@ extern "C" int glx_bn_relu_train_forward(const float* x, int N, int C, const flo
     GLX_LAUNCH_CHECK();
     return GLX_OK;
   }
-  const int slabs = glx_divup(N, 8) > BN_SLABS ? BN_SLABS : glx_divup(N, 8);
-  const int want = glx_divup((long long)N * C / 4, BN_THREADS * 4);
-  const int blocks = want > 512 ? 512 : want;
+  const int slabs = state ? bn_stats_slabs(N, C) : (glx_divup(N, 8) > BN_SLABS ? BN_SLABS : glx_divup(N, 8));
+  const int blocks = bn_apply_blocks(N, C);
   float* coef = (float*)((char*)workspace + bn_coef_offset(C));
   if (state) {
     BnFinalize f{gamma, beta, eps, momentum, coef, save_mean, save_invstd, running_mean, running_var,
@@ -592,9 +616,8 @@ extern "C" int glx_bn_relu_backward(const float* x, const float* dy, const float
     GLX_LAUNCH_CHECK();
     return GLX_OK;
   }
-  const int slabs = glx_divup(N, 8) > BN_SLABS ? BN_SLABS : glx_divup(N, 8);
-  const int want = glx_divup((long long)N * C / 4, BN_THREADS * 4);
-  const int blocks = want > 512 ? 512 : want;
+  const int slabs = state ? bn_stats_slabs(N, C) : (glx_divup(N, 8) > BN_SLABS ? BN_SLABS : glx_divup(N, 8));
+  const int blocks = bn_apply_blocks(N, C);
   float* coef = (float*)((char*)workspace + bn_coef_offset(C));
   if (state) {
     BnFinalize f{gamma, beta, 0.f, 0.f, coef, nullptr, nullptr, nullptr, nullptr, save_invstd, dgamma, dbeta};
