@@ -38,3 +38,41 @@ def boxes_aligned_iou3d_gpu(boxes_a, boxes_b, box_mode='wlh', rect=False, need_b
     area_a = (boxes_a[:, w_col] * boxes_a[:, l_col]).view(-1, 1)
     area_b = (boxes_b[:, w_col] * boxes_b[:, l_col]).view(-1, 1)
     return iou3d, bev / (area_a + area_b - bev).clamp(min=1e-7)
+
+
+def boxes3d_to_bev_3d_torch(boxes3d, box_mode='wlh', rect=False):
+    """(N,7) centre boxes -> (N,7) [x1, y1, z1, x2, y2, z2, ry] (iou3d_utils.py:109-131); LiDAR frame: z is the
+    box centre; rectified camera frame: the plane is (x, z) and y is the box bottom."""
+    w_col, l_col, h_col = (box_mode.index(ch) + 3 for ch in 'wlh')
+    half_w, half_l, height = boxes3d[:, w_col] / 2., boxes3d[:, l_col] / 2., boxes3d[:, h_col]
+    if rect:
+        cu, cv, cw = boxes3d[:, 0], boxes3d[:, 2], boxes3d[:, 1]
+        lo = [cu - half_l, cv - half_w, cw - height]
+        hi = [cu + half_l, cv + half_w, cw]
+    else:
+        cu, cv, cw = boxes3d[:, 0], boxes3d[:, 1], boxes3d[:, 2]
+        lo = [cu - half_w, cv - half_l, cw - height / 2.]
+        hi = [cu + half_w, cv + half_l, cw + height / 2.]
+    return torch.stack(lo + hi + [boxes3d[:, 6]], dim=1)
+
+
+def _nms(entry, boxes, scores, thresh):
+    order = scores.sort(0, descending=True)[1]
+    keep = torch.zeros(boxes.shape[0], dtype=torch.int64)             # host tensor, as iou3d_utils.py:402 builds it
+    n = entry(boxes[order].contiguous(), keep, thresh)
+    return order[keep[:n].to(order.device)].contiguous()
+
+
+def nms_gpu(boxes, scores, thresh, box_mode='wlh'):
+    """Rotated-BEV NMS on (N,7) centre boxes (iou3d_utils.py:389-406; the reference converts with rect=True)."""
+    return _nms(iou3d_cuda.nms_gpu, boxes3d_to_bev_torch(boxes, box_mode, rect=True), scores, thresh)
+
+
+def nms_3d_gpu(boxes, scores, thresh, box_mode='wlh'):
+    """3-D IoU NMS on (N,7) centre boxes (iou3d_utils.py:408-424)."""
+    return _nms(iou3d_cuda.nms_3d_gpu, boxes3d_to_bev_3d_torch(boxes, box_mode, rect=False), scores, thresh)
+
+
+def nms_normal_gpu(boxes, scores, thresh):
+    """Axis-aligned NMS on (N,5) [x1,y1,x2,y2,ry] (iou3d_utils.py:426-442)."""
+    return _nms(iou3d_cuda.nms_normal_gpu, boxes, scores, thresh)

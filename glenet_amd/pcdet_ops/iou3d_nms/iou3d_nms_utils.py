@@ -100,3 +100,57 @@ def new_nms_gpu(boxes, scores, iou_threshold, pre_maxsize=None, score_threshold=
     keep = (new_scores > 0).nonzero()[0]
     keep = keep[new_scores[keep].argsort()[::-1]]
     return keep, None, new_boxes
+
+
+def softnms(boxes, scores, iou_threshold, soft_sigma, score_threshold, soft_mode="gaussian", variance=None):
+    """Soft-NMS with optional variance voting (iou3d_nms_utils.py:313-356), updating `boxes` and `scores` in place
+    as the reference does.  The reference recomputes one IoU column per iteration on the device and reads the
+    arg-max back each time; every IoU it forms is between ORIGINAL boxes (a box is rewritten by the vote only when
+    it leaves the candidate set), so here the (N, N) matrix is computed once on the device and the inherently
+    sequential sweep runs on the host in float32."""
+    assert soft_mode in ("linear", "gaussian")
+    n = boxes.shape[0]
+    if n == 0:
+        return scores, boxes
+    iou = boxes_iou_bev(boxes[:, :7].float().contiguous(), boxes[:, :7].float().contiguous()).cpu().numpy()
+    b = boxes.detach().float().cpu().numpy().copy()
+    s = scores.detach().float().cpu().numpy().copy()
+    var = variance.detach().float().cpu().numpy() if variance is not None else None
+    orig = b.copy()
+    undone = s >= np.float32(score_threshold)
+    while undone.sum() > 1:
+        cand = undone.nonzero()[0]
+        idx = int(cand[s[cand].argmax()])
+        undone[idx] = False
+        others = undone.nonzero()[0]
+        ious = iou[others, idx]
+        if var is not None:
+            m = ious > np.float32(iou_threshold)
+            klbox = np.concatenate([orig[others[m], :6], orig[idx:idx + 1, :6]], 0)
+            klvar = np.concatenate([var[others[m], :6], var[idx:idx + 1, :6]], 0)
+            w = np.exp(np.float32(-1.0) * (np.float32(1.0) - ious[m]) ** 2 / np.float32(0.05)).astype(np.float32)
+            w = np.concatenate([w, np.ones(1, np.float32)])[:, None] / klvar
+            w = w / w.sum(0)
+            b[idx, :6] = (w * klbox).sum(0)
+        if soft_mode == "linear":
+            scale = np.where(ious >= np.float32(soft_sigma), np.float32(1.0) - ious, np.float32(1.0)).astype(np.float32)
+        else:
+            scale = np.exp(-ious ** 2 / np.float32(soft_sigma)).astype(np.float32)
+        s[others] *= scale
+        undone[s < np.float32(score_threshold)] = False
+    boxes.copy_(torch.from_numpy(b).to(boxes.device, boxes.dtype))
+    scores.copy_(torch.from_numpy(s).to(scores.device, scores.dtype))
+    return scores, boxes
+
+
+def softnms_gpu(boxes, scores, iou_threshold, score_threshold=0.1, soft_mode='gaussian', variance=None,
+                soft_sigma=0.3, **kwargs):
+    """iou3d_nms_utils.py:292-302 -> (keep, None, new_boxes): indices whose decayed score stays above the
+    threshold, by descending score."""
+    assert soft_mode in ("linear", "gaussian")
+    assert boxes.shape[-1] == 7
+    new_scores, new_boxes = softnms(boxes, scores, iou_threshold, soft_sigma, score_threshold, soft_mode,
+                                    variance=variance)
+    keep = (new_scores > score_threshold).nonzero(as_tuple=False).view(-1)
+    keep = keep[new_scores[keep].argsort(descending=True)]
+    return keep, None, new_boxes

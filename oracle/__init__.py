@@ -326,6 +326,88 @@ def iou3d_boxes_aligned_overlap_bev(a, b):
     return out
 
 
+def iou3d_boxes_iou3d(a, b):
+    """iou_3d of the older library for (N,7) x (M,7) [x1,y1,z1,x2,y2,z2,ry] boxes, iou3d_kernel.cu:256-268 /
+    iou3d_cpu.cpp:305-337: BEV overlap of the (x1,y1,x2,y2,ry) rectangles times the height overlap (EPS 1e-8
+    floor; a floor-sized overlap counts as none) over the union of the volumes."""
+    a, b = _f32(a), _f32(b)
+    eps = np.float32(1e-8)
+    bev = iou3d_boxes_overlap_bev(a[:, [0, 1, 3, 4, 6]], b[:, [0, 1, 3, 4, 6]])
+    va = ((a[:, 3] - a[:, 0]) * (a[:, 4] - a[:, 1]) * (a[:, 5] - a[:, 2])).reshape(-1, 1)
+    vb = ((b[:, 3] - b[:, 0]) * (b[:, 4] - b[:, 1]) * (b[:, 5] - b[:, 2])).reshape(1, -1)
+    dh = np.maximum(np.minimum(a[:, 5].reshape(-1, 1), b[:, 5].reshape(1, -1))
+                    - np.maximum(a[:, 2].reshape(-1, 1), b[:, 2].reshape(1, -1)), eps)
+    vo = bev * dh
+    out = vo / np.maximum(va + vb - vo, eps)
+    out[dh == eps] = 0
+    return out.astype(np.float32)
+
+
+def iou3d_nms_sorted(boxes_sorted, thresh, kind="bev"):
+    """nms_gpu / nms_3d_gpu / nms_normal_gpu of the older library on boxes in score order (iou3d.cpp:120-262: the
+    mask kernels mark IoU > thresh, the host loop keeps a box unless an earlier kept one marked it).
+    kind: 'bev' (N,5) rotated, '3d' (N,7) [x1,y1,z1,x2,y2,z2,ry], 'normal' (N,5) axis-aligned
+    (iou3d_kernel.cu:411-422)."""
+    b = _f32(boxes_sorted)
+    if kind == "bev":
+        iou = iou3d_boxes_iou_bev(b, b)
+    elif kind == "3d":
+        iou = iou3d_boxes_iou3d(b, b)
+    else:
+        w = np.maximum(np.minimum(b[:, None, 2], b[None, :, 2]) - np.maximum(b[:, None, 0], b[None, :, 0]), 0)
+        h = np.maximum(np.minimum(b[:, None, 3], b[None, :, 3]) - np.maximum(b[:, None, 1], b[None, :, 1]), 0)
+        area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+        iou = (w * h) / np.maximum(area[:, None] + area[None, :] - w * h, np.float32(1e-8))
+    removed = np.zeros(len(b), bool)
+    keep = []
+    for i in range(len(b)):
+        if removed[i]:
+            continue
+        keep.append(i)
+        removed[i + 1:] |= iou[i, i + 1:] > np.float32(thresh)
+    return np.asarray(keep, np.int64)
+
+
+def softnms(boxes, scores, iou_threshold, soft_sigma, score_threshold, soft_mode="gaussian", variance=None):
+    """iou3d_nms_utils.py:313-356 restated statement by statement (float32, host loops; small cases only): the IoU
+    column of the current top box is recomputed every iteration from the CURRENT boxes, as the reference does."""
+    boxes = np.array(boxes, np.float32, copy=True)
+    scores = np.array(scores, np.float32, copy=True)
+    variance = None if variance is None else np.asarray(variance, np.float32)
+    undone = scores >= np.float32(score_threshold)                                   # :316
+    while undone.sum() > 1:                                                          # :317
+        idx = undone.nonzero()[0][scores[undone].argmax()]                           # :318-319
+        top = boxes[idx:idx + 1].copy()
+        undone[idx] = False                                                          # :321
+        rest = boxes[undone]
+        ious = boxes_iou_bev(rest[:, :7], top[:, :7]).reshape(-1)                    # :324
+        if variance is not None:                                                     # :326-342
+            m = ious > np.float32(iou_threshold)
+            klbox = np.concatenate([rest[m], top], 0)
+            klvar = np.concatenate([variance[undone][m][:, :6], variance[idx:idx + 1, :6]], 0)
+            w = np.exp(np.float32(-1) * (np.float32(1) - ious[m]) ** 2 / np.float32(0.05)).astype(np.float32)
+            w = np.concatenate([w, np.ones(1, np.float32)])[:, None]
+            w = w / klvar
+            w = w / w.sum(0)
+            boxes[idx, :6] = (w * klbox[:, :6]).sum(0)
+        if soft_mode == "linear":                                                    # :304-311
+            scale = np.ones_like(ious)
+            scale[ious >= np.float32(soft_sigma)] = 1 - ious[ious >= np.float32(soft_sigma)]
+        else:
+            scale = np.exp(-ious ** 2 / np.float32(soft_sigma)).astype(np.float32)
+        scores[undone] *= scale                                                      # :352
+        undone[scores < np.float32(score_threshold)] = False                         # :353
+    return scores, boxes
+
+
+def softnms_gpu(boxes, scores, iou_threshold, score_threshold=0.1, soft_mode="gaussian", variance=None, soft_sigma=0.3):
+    """iou3d_nms_utils.py:292-302."""
+    new_scores, new_boxes = softnms(boxes, scores, iou_threshold, soft_sigma, score_threshold, soft_mode, variance)
+    keep = (new_scores > np.float32(score_threshold)).nonzero()[0]
+    keep = keep[np.argsort(-new_scores[keep], kind="stable")]
+    return keep, new_boxes
+
+
 # ------------------------------------------------------------------------------ point ops
 def points_in_boxes_cpu(points, boxes):
     """roiaware_pool3d_utils.points_in_boxes_cpu: (N boxes, P points) int32."""

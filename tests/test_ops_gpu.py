@@ -761,3 +761,71 @@ def test_roi_grid_training_path_on_shape_static_tensors(dev):
         for k in exact[3]:
             np.testing.assert_allclose(exact[3][k].cpu().numpy(), other[3][k].cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
     assert torch.isfinite(static[0]).all()
+
+
+# ------------------------------------------------------------------ the iou3d library's remaining exports, soft-NMS
+def _corner_boxes(rng, n):
+    c = synth.random_boxes(rng, n, xy_range=12.0, near_dup=0.6)                      # [x,y,z,dx,dy,dz,ry]
+    lo = c[:, :3] - c[:, 3:6] / 2
+    hi = c[:, :3] + c[:, 3:6] / 2
+    return np.concatenate([lo, hi, c[:, 6:7]], 1).astype(np.float32)                 # [x1,y1,z1,x2,y2,z2,ry]
+
+
+def test_iou3d_library_iou3d_and_nms_exports(dev):
+    """boxes_iou3d_{gpu,cpu}, nms_gpu, nms_3d_gpu, nms_normal_gpu of pcdet.ops.iou3d.iou3d_cuda (iou3d.cpp:98-266)
+    against the oracle's restatement (its rotated overlap is pinned by the reference-built iou3d_cpu fixture)."""
+    rng = np.random.default_rng(31)
+    a, b = _corner_boxes(rng, 180), _corner_boxes(rng, 75)
+    b[:30] = a[:30] + rng.normal(0, 0.08, (30, 7)).astype(np.float32)
+    a[5, 5] = a[5, 2]                                                                 # a flat box: zero height overlap
+    ref = oracle.iou3d_boxes_iou3d(a, b)
+    got = torch.zeros(len(a), len(b), device=dev)
+    iou3d_cuda.boxes_iou3d_gpu(T(a, dev), T(b, dev), got)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=2e-6)
+    assert (ref > 0.2).sum() > 20 and float(got[5].abs().max()) == 0.0
+    got_cpu = torch.zeros(len(a), len(b))
+    iou3d_cuda.boxes_iou3d_cpu(torch.from_numpy(a), torch.from_numpy(b), got_cpu)
+    np.testing.assert_allclose(got_cpu.numpy(), ref, rtol=1e-5, atol=2e-6)
+    # NMS entry points: boxes in score order, host int64 keep, count returned
+    n = 400
+    c = _corner_boxes(rng, n)
+    for kind, entry, boxes in (("bev", iou3d_cuda.nms_gpu, c[:, [0, 1, 3, 4, 6]]), ("3d", iou3d_cuda.nms_3d_gpu, c),
+                               ("normal", iou3d_cuda.nms_normal_gpu, c[:, [0, 1, 3, 4, 6]])):
+        boxes = np.ascontiguousarray(boxes)
+        want = oracle.iou3d_nms_sorted(boxes, 0.3, kind)
+        keep = torch.zeros(n, dtype=torch.int64)
+        num = entry(T(boxes, dev), keep, 0.3)
+        assert num == len(want) and 0 < num < n, kind
+        assert np.array_equal(keep[:num].numpy(), want), kind
+    # the wrappers of iou3d_utils (centre boxes + scores)
+    centre = synth.random_boxes(rng, 300, xy_range=10.0, near_dup=0.6)
+    scores = (rng.permutation(300).astype(np.float32) + 1) / 300
+    order = np.argsort(-scores, kind="stable")
+    want = order[oracle.iou3d_nms_sorted(iou3d_utils.boxes3d_to_bev_3d_torch(torch.from_numpy(centre)).numpy()[order],
+                                         0.25, "3d")]
+    got = iou3d_utils.nms_3d_gpu(T(centre, dev), T(scores, dev), 0.25)
+    assert np.array_equal(got.cpu().numpy(), want)
+    got = iou3d_utils.nms_normal_gpu(T(np.ascontiguousarray(c[:300, [0, 1, 3, 4, 6]]), dev), T(scores, dev), 0.25)
+    want = order[oracle.iou3d_nms_sorted(np.ascontiguousarray(c[:300, [0, 1, 3, 4, 6]])[order], 0.25, "normal")]
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert iou3d_utils.nms_gpu(T(centre, dev), T(scores, dev), 0.25).numel() > 0
+
+
+@pytest.mark.parametrize("mode,with_var", [("gaussian", True), ("gaussian", False), ("linear", True)])
+def test_softnms_vs_oracle(dev, mode, with_var):
+    """softnms_gpu (iou3d_nms_utils.py:292-356: score decay by IoU with the current top box, optional variance
+    voting of its first six coordinates) against the statement-by-statement restatement."""
+    rng = np.random.default_rng(41)
+    n = 160
+    boxes = synth.random_boxes(rng, n, xy_range=9.0, near_dup=0.7)
+    scores = (rng.permutation(n).astype(np.float32) + 1) / n
+    var = (rng.random((n, 7)).astype(np.float32) * 0.5 + 0.05) if with_var else None
+    keep_ref, boxes_ref = oracle.softnms_gpu(boxes, scores, 0.5, score_threshold=0.1, soft_mode=mode, variance=var)
+    tb, ts = T(boxes, dev), T(scores, dev)
+    keep, _, new_boxes = iou3d_nms_utils.softnms_gpu(tb, ts, 0.5, score_threshold=0.1, soft_mode=mode,
+                                                    variance=None if var is None else T(var, dev))
+    assert np.array_equal(keep.cpu().numpy(), keep_ref) and 0 < len(keep_ref) < n
+    np.testing.assert_allclose(new_boxes.cpu().numpy(), boxes_ref, rtol=1e-5, atol=1e-5)
+    assert new_boxes.data_ptr() == tb.data_ptr()                                      # in place, like the reference
+    if with_var:
+        assert np.abs(boxes_ref[:, :6] - boxes[:, :6]).max() > 1e-3                   # the vote moved boxes
