@@ -286,6 +286,12 @@ def test_fused_train_batchnorm_matches_torch(dev, C, relu, N, state, monkeypatch
     monkeypatch.setattr(sp, "USE_BN_STATE", state)
     for _ in range(2 if state else 1):
         _check_fused_train_batchnorm(dev, C, relu, N)
+    torch.cuda.synchronize()
+    for st in sp._BN_STATES.values():            # BnState of csrc/glx_bn.hip: 16 accumulator sets of 2 x 512 doubles | ticket
+        words = st.view(torch.int32)
+        acc_words = 16 * 2 * 512 * 2
+        assert int(words[:acc_words].abs().max()) == 0, "accumulators left dirty"
+        assert int(words[acc_words]) == 0, "ticket not reset"
 
 
 def _check_fused_train_batchnorm(dev, C, relu, N):
