@@ -141,17 +141,28 @@ __global__ __launch_bounds__(RP_THREADS) void k_rp_forward(const float* __restri
       best = fmaxf(b, 0.f);                    // every slot holds feature 0 and rel 0
     } else {
       const float qx = new_xyz[m * 3], qy = new_xyz[m * 3 + 1], qz = new_xyz[m * 3 + 2];
-      for (int s0 = 0; s0 < ns; s0 += 8) {     // 8 row gathers in flight
+      // The query pads a ball with fewer than ns voxels by repeating its first hit (voxel_query_gpu.cu:75-86); the
+      // repeats can never win the strict `>` below, so the scan stops at the first of them -- on LiDAR surfaces a
+      // ball holds 4-6 voxels of 16, which is most of this kernel's gather traffic.
+      const int r0 = row[0];
+      bool more = true;
+      for (int s0 = 0; s0 < ns && more; s0 += 8) {     // 8 row gathers in flight
         float f[8], x[8], y[8], z[8];
+        int live = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const long long r = row[s0 + j < ns ? s0 + j : 0];
-          f[j] = feats[r * C + c];
-          x[j] = xyz[r * 3]; y[j] = xyz[r * 3 + 1]; z[j] = xyz[r * 3 + 2];
+          const int r = s0 + j < ns ? row[s0 + j] : r0;
+          const bool ok = more && s0 + j < ns && (s0 + j == 0 || r != r0);
+          more = ok;                             // wave-uniform per grid point: all lanes of a point read the same row
+          if (ok) {
+            f[j] = feats[(long long)r * C + c];
+            x[j] = xyz[(long long)r * 3]; y[j] = xyz[(long long)r * 3 + 1]; z[j] = xyz[(long long)r * 3 + 2];
+            live = j + 1;
+          }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          if (s0 + j >= ns) break;
+          if (j >= live) break;
           const float p = (x[j] - qx) * wx + (y[j] - qy) * wy + (z[j] - qz) * wz + b;
           const float v = fmaxf(f[j] + p, 0.f);
           if (v > best) { best = v; bi = s0 + j; }
