@@ -46,7 +46,8 @@ template <bool BWD>
 __device__ __forceinline__ void bn_slab_sums(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-    const float* __restrict__ beta, int relu, int N, int C, double (&a0)[4], double (&a1)[4]) {
+    const float* __restrict__ beta, int relu, int N, int C, long long dy_pitch, double (&a0)[4],
+    double (&a1)[4]) {
   const int c4n = C >> 2;                       // float4 columns
   const int col = threadIdx.x % c4n, rlane = threadIdx.x / c4n;
   const int rstep = BN_THREADS / c4n;           // rows covered per pass by the block
@@ -79,7 +80,7 @@ __device__ __forceinline__ void bn_slab_sums(
         const long long o = (long long)(rr < r1 ? rr : r) * C + 4 * col;
         xv[j] = *reinterpret_cast<const bf32x4*>(x + o);
         if (BWD) {
-          g[j] = *reinterpret_cast<const bf32x4*>(dy + o);
+          g[j] = *reinterpret_cast<const bf32x4*>(dy + (long long)(rr < r1 ? rr : r) * dy_pitch + 4 * col);
           if (relu && !remask) yv[j] = *reinterpret_cast<const bf32x4*>(y + o);
         }
       }
@@ -131,11 +132,11 @@ template <bool BWD>
 __global__ __launch_bounds__(BN_THREADS) void k_bn_partial(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-    const float* __restrict__ beta, int relu, int N, int C, const int* __restrict__ n_live,
-    double* __restrict__ partial) {
+    const float* __restrict__ beta, int relu, int N, int C, long long dy_pitch,
+    const int* __restrict__ n_live, double* __restrict__ partial) {
   if (n_live) N = min(N, *n_live);
   double a0[4], a1[4];
-  bn_slab_sums<BWD>(x, dy, y, mean, invstd, gamma, beta, relu, N, C, a0, a1);
+  bn_slab_sums<BWD>(x, dy, y, mean, invstd, gamma, beta, relu, N, C, dy_pitch, a0, a1);
   if (threadIdx.x < (C >> 2)) {
     double* p = partial + (size_t)blockIdx.x * 2 * C;
 #pragma unroll
@@ -195,26 +196,26 @@ __global__ __launch_bounds__(BN_FIN_THREADS) void k_bn_finalize_fwd(
   }
 }
 
+// The transform kernels: a thread keeps ONE float4 column (its four coefficients live in registers) and strides over
+// the rows -- no index division, no LDS lookups per element; memory order is that of the flat loop (a block covers
+// BN_THREADS / (C/4) consecutive rows per trip).
 __global__ __launch_bounds__(BN_THREADS) void k_bn_forward_apply(
     const float* __restrict__ x, const float* __restrict__ coef, int relu, int N, int C,
-    const int* __restrict__ n_live, float* __restrict__ y) {
-  __shared__ float s_scale[BN_MAXC], s_shift[BN_MAXC];
+    const int* __restrict__ n_live, float* __restrict__ y, long long y_pitch) {
   int n = N;
   if (n_live) n = min(N, *n_live);
-  for (int c = threadIdx.x; c < C; c += BN_THREADS) { s_scale[c] = coef[c]; s_shift[c] = coef[C + c]; }
-  __syncthreads();
-  const long long total4 = (long long)n * C / 4;
   const int c4n = C >> 2;
-  for (long long e = (long long)blockIdx.x * BN_THREADS + threadIdx.x; e < total4;
-       e += (long long)gridDim.x * BN_THREADS) {
-    const int c = (int)(e % c4n) * 4;
-    bf32x4 v = reinterpret_cast<const bf32x4*>(x)[e];
+  const int col = threadIdx.x % c4n, rl = threadIdx.x / c4n, rpb = BN_THREADS / c4n;
+  const bf32x4 sc = *reinterpret_cast<const bf32x4*>(coef + 4 * col);
+  const bf32x4 sh = *reinterpret_cast<const bf32x4*>(coef + C + 4 * col);
+  for (int r = blockIdx.x * rpb + rl; r < n; r += gridDim.x * rpb) {
+    bf32x4 v = *reinterpret_cast<const bf32x4*>(x + (long long)r * C + 4 * col);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float t = bn_affine(v[i], s_scale[c + i], s_shift[c + i]);
+      const float t = bn_affine(v[i], sc[i], sh[i]);
       v[i] = relu ? fmaxf(t, 0.f) : t;
     }
-    reinterpret_cast<bf32x4*>(y)[e] = v;
+    *reinterpret_cast<bf32x4*>(y + (long long)r * y_pitch + 4 * col) = v;
   }
 }
 
@@ -247,42 +248,43 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_backward_apply(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
     const float* __restrict__ coef, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int relu, int N, int C,
-    const int* __restrict__ n_live, float* __restrict__ dx) {
-  __shared__ float s_a[BN_MAXC], s_b[BN_MAXC], s_c[BN_MAXC], s_mu[BN_MAXC], s_is[BN_MAXC], s_sc[BN_MAXC],
-      s_sh[BN_MAXC];
+    long long dy_pitch, const int* __restrict__ n_live, float* __restrict__ dx) {
   int n = N;
   if (n_live) n = min(N, *n_live);
   const bool remask = relu && !y;
-  for (int c = threadIdx.x; c < C; c += BN_THREADS) {
-    s_a[c] = coef[c]; s_b[c] = coef[C + c]; s_c[c] = coef[2 * C + c];
-    s_mu[c] = mean[c]; s_is[c] = invstd[c];
-    const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
-    s_sc[c] = bn_scale(s_is[c], gm);
-    s_sh[c] = bn_shift(bt, s_mu[c], s_is[c], gm);
-  }
-  __syncthreads();
-  const long long total4 = (long long)n * C / 4;
   const int c4n = C >> 2;
-  for (long long e = (long long)blockIdx.x * BN_THREADS + threadIdx.x; e < total4;
-       e += (long long)gridDim.x * BN_THREADS) {
-    const int c = (int)(e % c4n) * 4;
-    bf32x4 xv = reinterpret_cast<const bf32x4*>(x)[e];
-    bf32x4 g = reinterpret_cast<const bf32x4*>(dy)[e];
+  const int col = threadIdx.x % c4n, rl = threadIdx.x / c4n, rpb = BN_THREADS / c4n;
+  const bf32x4 a = *reinterpret_cast<const bf32x4*>(coef + 4 * col);
+  const bf32x4 b = *reinterpret_cast<const bf32x4*>(coef + C + 4 * col);
+  const bf32x4 cc = *reinterpret_cast<const bf32x4*>(coef + 2 * C + 4 * col);
+  const bf32x4 mu = *reinterpret_cast<const bf32x4*>(mean + 4 * col);
+  const bf32x4 is = *reinterpret_cast<const bf32x4*>(invstd + 4 * col);
+  float sc[4], sh[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float gm = gamma ? gamma[4 * col + i] : 1.f, bt = beta ? beta[4 * col + i] : 0.f;
+    sc[i] = bn_scale(is[i], gm);
+    sh[i] = bn_shift(bt, mu[i], is[i], gm);
+  }
+  for (int r = blockIdx.x * rpb + rl; r < n; r += gridDim.x * rpb) {
+    const long long o = (long long)r * C + 4 * col;
+    const bf32x4 xv = *reinterpret_cast<const bf32x4*>(x + o);
+    bf32x4 g = *reinterpret_cast<const bf32x4*>(dy + (long long)r * dy_pitch + 4 * col);
     if (remask) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) g[i] = bn_affine(xv[i], s_sc[c + i], s_sh[c + i]) > 0.f ? g[i] : 0.f;
+      for (int i = 0; i < 4; ++i) g[i] = bn_affine(xv[i], sc[i], sh[i]) > 0.f ? g[i] : 0.f;
     } else if (relu) {
-      bf32x4 yv = reinterpret_cast<const bf32x4*>(y)[e];
+      const bf32x4 yv = *reinterpret_cast<const bf32x4*>(y + o);
 #pragma unroll
       for (int i = 0; i < 4; ++i) g[i] = yv[i] > 0.f ? g[i] : 0.f;
     }
-    bf32x4 o;
+    bf32x4 ov;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float xh = (xv[i] - s_mu[c + i]) * s_is[c + i];
-      o[i] = s_a[c + i] * (g[i] - s_b[c + i] - xh * s_c[c + i]);
+      const float xh = (xv[i] - mu[i]) * is[i];
+      ov[i] = a[i] * (g[i] - b[i] - xh * cc[i]);
     }
-    reinterpret_cast<bf32x4*>(dx)[e] = o;
+    *reinterpret_cast<bf32x4*>(dx + o) = ov;
   }
 }
 
@@ -319,11 +321,11 @@ template <bool BWD>
 __global__ __launch_bounds__(BN_THREADS) void k_bn_stats(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ invstd, int relu, int N, int C,
-    const int* __restrict__ n_live, BnState* __restrict__ st, BnFinalize f) {
+    long long dy_pitch, const int* __restrict__ n_live, BnState* __restrict__ st, BnFinalize f) {
   __shared__ int s_last;
   if (n_live) N = min(N, *n_live);
   double a0[4], a1[4];
-  bn_slab_sums<BWD>(x, dy, y, mean, invstd, f.gamma, f.beta, relu, N, C, a0, a1);
+  bn_slab_sums<BWD>(x, dy, y, mean, invstd, f.gamma, f.beta, relu, N, C, dy_pitch, a0, a1);
   if (threadIdx.x < (C >> 2)) {
     double* acc = st->acc[blockIdx.x % BN_SETS];
     double seen = 0;
@@ -416,7 +418,7 @@ __device__ __forceinline__ void bn_small_reduce(double (&s0)[4], double (&s1)[4]
 __global__ __launch_bounds__(BN_THREADS) void k_bn_small_forward(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     float eps, float momentum, int relu, int N, int C, const int* __restrict__ n_live,
-    float* __restrict__ y, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+    float* __restrict__ y, long long y_pitch, float* __restrict__ save_mean, float* __restrict__ save_invstd,
     float* __restrict__ running_mean, float* __restrict__ running_var) {
   __shared__ double s_part[BN_THREADS / 64][BN_SMALL_CQ][8];
   int n = N;
@@ -463,15 +465,16 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_small_forward(
       const float t = bn_affine(v[i], sc[i], sh[i]);
       v[i] = relu ? fmaxf(t, 0.f) : t;
     }
-    *reinterpret_cast<bf32x4*>(y + (long long)r * C + c0) = v;
+    *reinterpret_cast<bf32x4*>(y + (long long)r * y_pitch + c0) = v;
   }
 }
 
 __global__ __launch_bounds__(BN_THREADS) void k_bn_small_backward(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
-    const float* __restrict__ invstd, int relu, int N, int C, const int* __restrict__ n_live,
-    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const float* __restrict__ invstd, int relu, int N, int C, long long dy_pitch,
+    const int* __restrict__ n_live, float* __restrict__ dx, float* __restrict__ dgamma,
+    float* __restrict__ dbeta) {
   __shared__ double s_part[BN_THREADS / 64][BN_SMALL_CQ][8];
   int n = N;
   if (n_live) n = min(N, *n_live);
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_small_backward(
     for (int r = rl; r < n; r += RL) {
       const long long o = (long long)r * C + c0;
       const bf32x4 xv = *reinterpret_cast<const bf32x4*>(x + o);
-      bf32x4 g = *reinterpret_cast<const bf32x4*>(dy + o);
+      bf32x4 g = *reinterpret_cast<const bf32x4*>(dy + (long long)r * dy_pitch + c0);
       if (remask) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) g[i] = bn_affine(xv[i], sc[i], sh[i]) > 0.f ? g[i] : 0.f;
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_small_backward(
   for (int r = rl; r < n; r += RL) {
     const long long o = (long long)r * C + c0;
     const bf32x4 xv = *reinterpret_cast<const bf32x4*>(x + o);
-    bf32x4 g = *reinterpret_cast<const bf32x4*>(dy + o);
+    bf32x4 g = *reinterpret_cast<const bf32x4*>(dy + (long long)r * dy_pitch + c0);
     if (remask) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) g[i] = bn_affine(xv[i], sc[i], sh[i]) > 0.f ? g[i] : 0.f;
@@ -558,9 +561,12 @@ extern "C" int glx_bn_relu_train_forward(const float* x, int N, int C, const flo
                                          float* running_mean, float* running_var, float* y,
                                          float* save_mean, float* save_invstd,
                                          const int32_t* n_live, void* workspace,
-                                         size_t workspace_bytes, void* state, void* stream) {
+                                         size_t workspace_bytes, void* state, int y_stride,
+                                         void* stream) {
   GLX_REQUIRE(bn_channels_ok(C), "glx_bn_relu_train_forward: C=%d must be a multiple of 4 dividing 1024, <= 512", C);
   GLX_REQUIRE(y && save_mean && save_invstd && (N == 0 || x), "glx_bn_relu_train_forward: null pointer");
+  GLX_REQUIRE(y_stride == 0 || (y_stride >= C && (y_stride & 3) == 0), "glx_bn_relu_train_forward: y_stride %d", y_stride);
+  const long long y_pitch = y_stride ? y_stride : C;
   if (!workspace || workspace_bytes < glx_bn_workspace_bytes(C) - 256) {
     glx_set_error("glx_bn_relu_train_forward: workspace %zu < %zu bytes", workspace_bytes,
                   glx_bn_workspace_bytes(C) - 256);
@@ -570,7 +576,7 @@ extern "C" int glx_bn_relu_train_forward(const float* x, int N, int C, const flo
   hipStream_t st = (hipStream_t)stream;
   if (N <= BN_SMALL_N) {
     hipLaunchKernelGGL(k_bn_small_forward, dim3(glx_divup(C, 4 * BN_SMALL_CQ)), dim3(BN_THREADS), 0, st, x,
-                       gamma, beta, eps, momentum, relu, N, C, n_live, y, save_mean, save_invstd,
+                       gamma, beta, eps, momentum, relu, N, C, n_live, y, y_pitch, save_mean, save_invstd,
                        running_mean, running_var);
     GLX_LAUNCH_CHECK();
     return GLX_OK;
@@ -582,16 +588,16 @@ extern "C" int glx_bn_relu_train_forward(const float* x, int N, int C, const flo
     BnFinalize f{gamma, beta, eps, momentum, coef, save_mean, save_invstd, running_mean, running_var,
                  nullptr, nullptr, nullptr};
     hipLaunchKernelGGL((k_bn_stats<false>), dim3(slabs), dim3(BN_THREADS), 0, st, x, nullptr, nullptr,
-                       nullptr, nullptr, 0, N, C, n_live, (BnState*)state, f);
+                       nullptr, nullptr, 0, N, C, (long long)C, n_live, (BnState*)state, f);
   } else {
     hipLaunchKernelGGL((k_bn_partial<false>), dim3(slabs), dim3(BN_THREADS), 0, st, x, nullptr, nullptr,
-                       nullptr, nullptr, nullptr, nullptr, 0, N, C, n_live, (double*)workspace);
+                       nullptr, nullptr, nullptr, nullptr, 0, N, C, (long long)C, n_live, (double*)workspace);
     hipLaunchKernelGGL(k_bn_finalize_fwd, dim3(1), dim3(BN_FIN_THREADS), 0, st, (const double*)workspace,
                        slabs, gamma, beta, eps, momentum, N, C, n_live, coef, save_mean, save_invstd,
                        running_mean, running_var);
   }
   hipLaunchKernelGGL(k_bn_forward_apply, dim3(blocks < 1 ? 1 : blocks), dim3(BN_THREADS), 0, st, x,
-                     (const float*)coef, relu, N, C, n_live, y);
+                     (const float*)coef, relu, N, C, n_live, y, y_pitch);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
@@ -600,9 +606,11 @@ extern "C" int glx_bn_relu_backward(const float* x, const float* dy, const float
                                     const float* gamma, const float* beta, const float* save_mean,
                                     const float* save_invstd, int relu, float* dx, float* dgamma,
                                     float* dbeta, const int32_t* n_live, void* workspace,
-                                    size_t workspace_bytes, void* state, void* stream) {
+                                    size_t workspace_bytes, void* state, int dy_stride, void* stream) {
   GLX_REQUIRE(bn_channels_ok(C), "glx_bn_relu_backward: C=%d not supported", C);
   GLX_REQUIRE(save_mean && save_invstd && (N == 0 || (x && dy && dx)), "glx_bn_relu_backward: null pointer");
+  GLX_REQUIRE(dy_stride == 0 || (dy_stride >= C && (dy_stride & 3) == 0), "glx_bn_relu_backward: dy_stride %d", dy_stride);
+  const long long dy_pitch = dy_stride ? dy_stride : C;
   if (!workspace || workspace_bytes < glx_bn_workspace_bytes(C) - 256) {
     glx_set_error("glx_bn_relu_backward: workspace %zu < %zu bytes", workspace_bytes,
                   glx_bn_workspace_bytes(C) - 256);
@@ -612,7 +620,7 @@ extern "C" int glx_bn_relu_backward(const float* x, const float* dy, const float
   hipStream_t st = (hipStream_t)stream;
   if (N <= BN_SMALL_N) {
     hipLaunchKernelGGL(k_bn_small_backward, dim3(glx_divup(C, 4 * BN_SMALL_CQ)), dim3(BN_THREADS), 0, st, x,
-                       dy, y, gamma, beta, save_mean, save_invstd, relu, N, C, n_live, dx, dgamma, dbeta);
+                       dy, y, gamma, beta, save_mean, save_invstd, relu, N, C, dy_pitch, n_live, dx, dgamma, dbeta);
     GLX_LAUNCH_CHECK();
     return GLX_OK;
   }
@@ -622,15 +630,15 @@ extern "C" int glx_bn_relu_backward(const float* x, const float* dy, const float
   if (state) {
     BnFinalize f{gamma, beta, 0.f, 0.f, coef, nullptr, nullptr, nullptr, nullptr, save_invstd, dgamma, dbeta};
     hipLaunchKernelGGL((k_bn_stats<true>), dim3(slabs), dim3(BN_THREADS), 0, st, x, dy, y, save_mean,
-                       save_invstd, relu, N, C, n_live, (BnState*)state, f);
+                       save_invstd, relu, N, C, dy_pitch, n_live, (BnState*)state, f);
   } else {
     hipLaunchKernelGGL((k_bn_partial<true>), dim3(slabs), dim3(BN_THREADS), 0, st, x, dy, y, save_mean,
-                       save_invstd, gamma, beta, relu, N, C, n_live, (double*)workspace);
+                       save_invstd, gamma, beta, relu, N, C, dy_pitch, n_live, (double*)workspace);
     hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(1), dim3(BN_FIN_THREADS), 0, st, (const double*)workspace,
                        slabs, gamma, save_invstd, N, C, n_live, coef, dgamma, dbeta);
   }
   hipLaunchKernelGGL(k_bn_backward_apply, dim3(blocks < 1 ? 1 : blocks), dim3(BN_THREADS), 0, st, x,
-                     dy, y, (const float*)coef, save_mean, save_invstd, gamma, beta, relu, N, C, n_live, dx);
+                     dy, y, (const float*)coef, save_mean, save_invstd, gamma, beta, relu, N, C, dy_pitch, n_live, dx);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

@@ -15,6 +15,7 @@ modules is pinned by tests/golden/dense_path_ref.npz (state dicts + outputs prod
 reference code on CPU, see tests/golden/make_golden.py).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -57,14 +58,44 @@ class BEVBackbone(nn.Module):
             self.deblocks.append(nn.Sequential(nn.ConvTranspose2d(c, c, u, stride=u, bias=False), _bn2d(c),
                                                nn.ReLU()))
 
+    def _ups_fused(self, raw):
+        """torch.cat of the upsampled maps (:100-104) with each deblock's BatchNorm2d + ReLU writing its channel
+        block of the concatenated channels-last map directly (no 144 MB copy forward, no slice copies backward);
+        raw: the deblocks' convolution outputs.  None when the fused kernels do not cover the case."""
+        from .spconv import core
+        if len(raw) < 2 or len(self.deblocks) != len(raw):
+            return None
+        bns = []
+        for blk, u in zip(self.deblocks, raw):
+            mods = list(blk)
+            if not (len(mods) == 3 and isinstance(mods[2], nn.ReLU) and self._can_fuse_bn(mods[1], u)
+                    and u.shape[0] == raw[0].shape[0] and u.shape[2:] == raw[0].shape[2:]):
+                return None
+            bns.append(mods[1])
+        b, _, h, w = raw[0].shape
+        rows = [u.permute(0, 2, 3, 1).reshape(b * h * w, u.shape[1]) for u in raw]
+        y = core.fused_train_bn_cat(bns, rows, True)
+        return y.view(b, h, w, y.shape[1]).permute(0, 3, 1, 2)
+
+    FUSE_UPS_CAT = os.environ.get("GLX_BEV_CAT_FUSE", "1") != "0"
+
     def forward(self, data_dict):
         x0 = data_dict["spatial_features"]
-        x, ups = x0, []
+        x, ups, raw = x0, [], []
+        fuse = self.FUSE_UPS_CAT and len(self.deblocks) == len(self.blocks) and len(self.blocks) > 1
         for i, blk in enumerate(self.blocks):
             x = self._run_block(blk, x)
             data_dict["spatial_features_%dx" % int(x0.shape[2] / x.shape[2])] = x
-            ups.append(self._run_block(self.deblocks[i], x) if len(self.deblocks) > 0 else x)
-        x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
+            if fuse:
+                raw.append(self.deblocks[i][0](x))          # the deblock's (transposed) convolution only
+            else:
+                ups.append(self._run_block(self.deblocks[i], x) if len(self.deblocks) > 0 else x)
+        if fuse:
+            x = self._ups_fused(raw)
+            if x is None:                                   # not covered: BatchNorm + ReLU per map, then concatenate
+                ups = [self._run_block(nn.Sequential(*list(self.deblocks[i])[1:]), u) for i, u in enumerate(raw)]
+        if not fuse or x is None:
+            x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
         if len(self.deblocks) > len(self.blocks):
             x = self._run_block(self.deblocks[-1], x)
         data_dict["spatial_features_2d"] = x

@@ -689,7 +689,7 @@ class FusedBNReLU(Function):
         ws = workspace.get(query("glx_bn_workspace_bytes", C), x.device)
         call("glx_bn_relu_train_forward", x, N, C, weight, bias, ctypes_float(eps), ctypes_float(momentum),
              1 if relu else 0, running_mean, running_var, y, mean, invstd, count, ws, size_arg(ws.numel()),
-             _bn_state(x.device))
+             _bn_state(x.device), 0)
         ctx.save_for_backward(x, weight, bias, mean, invstd)          # not y: backward re-derives the ReLU mask from x
         ctx.relu, ctx.count = relu, count
         return y
@@ -704,9 +704,73 @@ class FusedBNReLU(Function):
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = workspace.get(query("glx_bn_workspace_bytes", C), x.device)
         call("glx_bn_relu_backward", x, dy, None, N, C, weight, bias, mean, invstd, 1 if ctx.relu else 0, dx,
-             dgamma, dbeta, ctx.count, ws, size_arg(ws.numel()), _bn_state(x.device))
+             dgamma, dbeta, ctx.count, ws, size_arg(ws.numel()), _bn_state(x.device), 0)
         return dx, (dgamma if weight is not None else None), (dbeta if weight is not None else None), \
             None, None, None, None, None, None
+
+
+class FusedBNReLUCat(Function):
+    """torch.cat([relu(bn_i(x_i)) for i], dim=1) of (N, C_i) matrices without the concatenation copy: every
+    BatchNorm's transform writes its column block of the (N, sum C_i) result (y_stride of glx_bn_relu_train_forward),
+    backward reads its block of the incoming gradient in place (dy_stride) -- BaseBEVBackbone's concatenation of the
+    upsampled maps (base_bev_backbone.py:100-104) on channels-last memory, 144 MB at the KITTI size.
+    args: relu, then per part x, weight, bias, running_mean, running_var, momentum, eps."""
+
+    @staticmethod
+    def forward(ctx, relu, *args):
+        parts = [args[i:i + 7] for i in range(0, len(args), 7)]
+        xs = [p[0].contiguous().float() for p in parts]
+        N = xs[0].shape[0]
+        widths = [x.shape[1] for x in xs]
+        total = sum(widths)
+        out = torch.empty((N, total), dtype=torch.float32, device=xs[0].device)
+        saved, col = [], 0
+        for x, (_, w, b, rm, rv, momentum, eps), C in zip(xs, parts, widths):
+            mean = torch.empty(C, dtype=torch.float32, device=x.device)
+            invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+            ws = workspace.get(query("glx_bn_workspace_bytes", C), x.device)
+            call("glx_bn_relu_train_forward", x, N, C, w, b, ctypes_float(eps), ctypes_float(momentum),
+                 1 if relu else 0, rm, rv, out[:, col:], mean, invstd, None, ws, size_arg(ws.numel()),
+                 _bn_state(x.device), total)
+            saved += [x, w, b, mean, invstd]
+            col += C
+        ctx.save_for_backward(*saved)
+        ctx.relu, ctx.widths = relu, widths
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous().float()
+        total = dout.shape[1]
+        grads, col = [None], 0
+        for i, C in enumerate(ctx.widths):
+            x, w, b, mean, invstd = ctx.saved_tensors[5 * i:5 * i + 5]
+            N = x.shape[0]
+            dx = torch.empty_like(x)
+            dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+            dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+            ws = workspace.get(query("glx_bn_workspace_bytes", C), x.device)
+            call("glx_bn_relu_backward", x, dout[:, col:], None, N, C, w, b, mean, invstd, 1 if ctx.relu else 0, dx,
+                 dgamma, dbeta, None, ws, size_arg(ws.numel()), _bn_state(x.device), total)
+            grads += [dx, dgamma, dbeta, None, None, None, None]
+            col += C
+        return tuple(grads)
+
+
+def fused_train_bn_cat(bns, features, relu):
+    """relu(bn_i(features_i)) concatenated along the columns (FusedBNReLUCat); every bn as fused_train_bn takes it."""
+    args = []
+    for bn, f in zip(bns, features):
+        rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+        args += [f, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps]
+    out = FusedBNReLUCat.apply(relu, *args)
+    for bn in bns:
+        if bn.track_running_stats and bn.num_batches_tracked is not None:
+            if DEFERRED_COUNTERS is not None:
+                DEFERRED_COUNTERS.append(bn.num_batches_tracked)
+            else:
+                bn.num_batches_tracked += 1
+    return out
 
 
 def ctypes_float(v):

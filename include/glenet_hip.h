@@ -506,6 +506,10 @@ int glx_predicted_boxes(const float* box_preds, const float* dir_preds, const fl
  *   accumulates with fp64 atomics and its last block finalizes (two launches; the buffer is left zeroed again);
  *   the order of the fp64 additions then varies between runs (differences of one fp64 ulp before the rounding to
  *   float).  Matrices of at most 4096 rows always take a single launch with a fixed order.
+ * y_stride / dy_stride: floats between consecutive rows of y (forward) / dy (backward); 0 = C.  A wider stride
+ *   writes the result into -- reads the gradient from -- a column block of a wider row-major matrix: the
+ *   concatenation of several normalised maps along the channels (BaseBEVBackbone's `torch.cat(ups, dim=1)`,
+ *   base_bev_backbone.py:100-104, on channels-last maps) then costs no copy in either direction.
  * ------------------------------------------------------------------------------------ */
 size_t glx_bn_workspace_bytes(int C);
 size_t glx_bn_state_bytes(void);
@@ -513,14 +517,14 @@ int glx_bn_relu_train_forward(const float* x, int N, int C, const float* gamma, 
                               float eps, float momentum, int relu, float* running_mean,
                               float* running_var, float* y, float* save_mean, float* save_invstd,
                               const int32_t* n_live, void* workspace, size_t workspace_bytes,
-                              void* state, void* stream);
+                              void* state, int y_stride, void* stream);
 /* dx (N,C), dgamma (C), dbeta (C) from dy and the forward's x, mean, invstd.  The ReLU mask: from the forward's
  * output y, or -- y = NULL -- re-derived from x with gamma / beta (the forward's own rounding, so it is the same
  * mask; a third less traffic).  beta is only read in that case. */
 int glx_bn_relu_backward(const float* x, const float* dy, const float* y, int N, int C,
                          const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                          int relu, float* dx, float* dgamma, float* dbeta, const int32_t* n_live,
-                         void* workspace, size_t workspace_bytes, void* state, void* stream);
+                         void* workspace, size_t workspace_bytes, void* state, int dy_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * VectorPool family of PV-RCNN++.  Output slots are laid out in ascending new-point order

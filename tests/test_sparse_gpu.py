@@ -340,3 +340,33 @@ def test_dense_bev_channels_last_equals_dense_view(dev):
     assert outs[1][0].shape == (B, C * D, H, W) and outs[1][0].is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert float(outs[0][0].abs().sum()) > 0
+
+
+def test_bev_backbone_concatenation_without_the_copy(dev):
+    """BEVBackbone in training on a channels-last map: the deblocks' BatchNorm2d + ReLU writing straight into the
+    concatenated map (y_stride / dy_stride of the fused BatchNorm kernels) == BatchNorm + ReLU per map followed by
+    torch.cat(ups, dim=1) (base_bev_backbone.py:100-104): output, input gradient, every parameter gradient and the
+    running statistics."""
+    import copy
+    from glenet_amd import dense_path as dp
+    torch.manual_seed(5)
+    torch.backends.cudnn.benchmark = False
+    ref = dp.BEVBackbone(32, layer_nums=(1, 1), num_filters=(16, 32), num_upsample_filters=(32, 64)).to(dev).train()
+    ref = ref.to(memory_format=torch.channels_last)
+    net = copy.deepcopy(ref)
+    x = torch.randn(2, 32, 24, 20, device=dev).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for m, fuse in ((net, True), (ref, False)):
+        m.FUSE_UPS_CAT = fuse
+        xi = x.clone().requires_grad_(True)
+        y = m({"spatial_features": xi})["spatial_features_2d"]
+        assert y.shape == (2, 96, 24, 20) and y.is_contiguous(memory_format=torch.channels_last)
+        (y * torch.linspace(0.5, 1.5, 96, device=dev).view(1, -1, 1, 1)).sum().backward()
+        outs.append((y.detach(), xi.grad, m))
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy(), rtol=1e-3, atol=1e-5)
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        scale = float(q.grad.abs().max()) + 1e-12
+        assert float((p.grad - q.grad).abs().max()) <= 1e-3 * scale, n
+    for (n, p), (_, q) in zip(net.named_buffers(), ref.named_buffers()):
+        np.testing.assert_allclose(p.cpu().numpy(), q.cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=n)
