@@ -1269,3 +1269,182 @@ extern "C" int glx_roi_target_gather(const float* rois, const int64_t* roi_label
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
+
+// ------------------------------------------------------------------ top-K of the proposal scores, sorted
+// RoIHeadTemplate.proposal_layer (roi_head_template.py:81-88): `torch.topk(scores, k = NMS_PRE_MAXSIZE)` of the
+// 70 400 anchor scores of a frame, 9 000 kept in descending order for the NMS.  torch runs it as a multi-block radix
+// select plus a segmented sort -- 45 launches, 0.23 ms of launch latency in a training step.  Here one block per
+// frame does the whole thing in LDS: (1) 8-bit MSB radix select of the K-th largest key; (2) ordered compaction of
+// the keys above it, plus as many of the keys equal to it as are still needed, lowest index first; (3) a stable LSD
+// radix sort (4-bit digits, 8 passes) of the K survivors.  Ties: lower index first (torch leaves the order of
+// equal scores unspecified); keys are the floats' bit patterns, so NaN sorts above +inf as in torch.
+#define TK_THREADS 1024
+#define TK_MAXK 10240
+#define TK_E ((TK_MAXK + TK_THREADS - 1) / TK_THREADS)      // survivors per thread in the sort, at most
+
+__device__ __forceinline__ unsigned tk_key(float v) {       // ascending key <=> descending score
+  const unsigned u = __float_as_uint(v);
+  return ~((u & 0x80000000u) ? ~u : (u | 0x80000000u));
+}
+__device__ __forceinline__ float tk_unkey(unsigned d) {
+  const unsigned a = ~d;
+  return __uint_as_float((a & 0x80000000u) ? (a & 0x7fffffffu) : ~a);
+}
+
+__global__ __launch_bounds__(TK_THREADS) void k_topk_desc(const float* __restrict__ scores, int A, int K, int Kp,
+                                                          float* __restrict__ top,
+                                                          long long* __restrict__ order) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tk_smem[];
+  unsigned* keys0 = reinterpret_cast<unsigned*>(tk_smem);                  // Kp
+  unsigned* idx0 = keys0 + Kp;                                             // Kp
+  unsigned short* perm_a = reinterpret_cast<unsigned short*>(idx0 + Kp);   // Kp
+  unsigned short* perm_b = perm_a + Kp;                                    // Kp
+  unsigned short* cnt = perm_b + Kp;                                       // 16 * TK_THREADS
+  __shared__ unsigned s_hist[256];
+  __shared__ unsigned s_bin, s_rem;
+  __shared__ unsigned s_wlt[TK_THREADS / 64], s_weq[TK_THREADS / 64], s_wsum[TK_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* s = scores + (size_t)blockIdx.x * A;
+  const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+
+  // (1) the K-th smallest key, one byte at a time
+  unsigned prefix = 0, mask = 0;
+  unsigned remaining = (unsigned)K;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    if (tid < 256) s_hist[tid] = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < A; i0 += TK_THREADS) {
+      const int i = i0 + tid;
+      const unsigned d = i < A ? tk_key(s[i]) : 0u;
+      const bool in = i < A && (d & mask) == prefix;
+      const unsigned dg = (d >> shift) & 255u;
+      // scores of one frame share their high bytes: lanes that agree with the wave's first digit are added as one
+      const unsigned long long act = __ballot(in);
+      if (act) {
+        const int first = __ffsll((long long)act) - 1;
+        const unsigned lead = __shfl(dg, first, 64);
+        const unsigned long long same = __ballot(in && dg == lead);
+        const bool bulk = __popcll(same) >= 16;
+        if (bulk && lane == first) atomicAdd(&s_hist[lead], (unsigned)__popcll(same));
+        if (in && !(bulk && dg == lead)) atomicAdd(&s_hist[dg], 1u);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned cum = 0;
+      int b = 0;
+      for (; b < 255; ++b) {
+        if (cum + s_hist[b] >= remaining) break;
+        cum += s_hist[b];
+      }
+      s_bin = (unsigned)b;
+      s_rem = remaining - cum;
+    }
+    __syncthreads();
+    prefix |= s_bin << shift;
+    mask |= 255u << shift;
+    remaining = s_rem;
+    __syncthreads();
+  }
+  const unsigned kth = prefix;                   // keys < kth all survive, `remaining` of the keys == kth do
+
+  // (2) ordered compaction: a wave owns a contiguous slice of the frame
+  const int per = ((A + TK_THREADS / 64 - 1) / (TK_THREADS / 64) + 63) / 64 * 64;
+  const int lo = wave * per, hi = min(A, lo + per);
+  unsigned n_lt = 0, n_eq = 0;
+  for (int i0 = lo; i0 < hi; i0 += 64) {
+    const int i = i0 + lane;
+    const unsigned d = i < hi ? tk_key(s[i]) : ~0u;
+    n_lt += (unsigned)__popcll(__ballot(i < hi && d < kth));
+    n_eq += (unsigned)__popcll(__ballot(i < hi && d == kth));
+  }
+  if (lane == 0) { s_wlt[wave] = n_lt; s_weq[wave] = n_eq; }
+  __syncthreads();
+  unsigned lt_run = 0, eq_run = 0;
+  for (int w = 0; w < wave; ++w) { lt_run += s_wlt[w]; eq_run += s_weq[w]; }
+  for (int i0 = lo; i0 < hi; i0 += 64) {
+    const int i = i0 + lane;
+    const unsigned d = i < hi ? tk_key(s[i]) : ~0u;
+    const bool isl = i < hi && d < kth, ise = i < hi && d == kth;
+    const unsigned long long bl = __ballot(isl), be = __ballot(ise);
+    const unsigned lt_before = lt_run + (unsigned)__popcll(bl & lt_mask);
+    const unsigned eq_before = eq_run + (unsigned)__popcll(be & lt_mask);
+    int pos = -1;
+    if (isl) pos = (int)(lt_before + min(eq_before, remaining));
+    else if (ise && eq_before < remaining) pos = (int)(lt_before + eq_before);
+    if (pos >= 0) { keys0[pos] = d; idx0[pos] = (unsigned)i; perm_a[pos] = (unsigned short)pos; }
+    lt_run += (unsigned)__popcll(bl);
+    eq_run += (unsigned)__popcll(be);
+  }
+  __syncthreads();
+
+  // (3) stable LSD radix sort of the K survivors through a permutation (keys stay where they are)
+  const int E = (K + TK_THREADS - 1) / TK_THREADS;
+  unsigned short* pin = perm_a;
+  unsigned short* pout = perm_b;
+  for (int shift = 0; shift < 32; shift += 4) {
+    unsigned long long packed = 0;               // 16 counters of 4 bits: a thread holds at most TK_E = 10 keys
+    for (int e = 0; e < E; ++e) {
+      const int p = tid * E + e;
+      if (p < K) packed += 1ull << (4 * ((keys0[pin[p]] >> shift) & 15u));
+    }
+#pragma unroll
+    for (int dg = 0; dg < 16; ++dg) cnt[dg * TK_THREADS + tid] = (unsigned short)((packed >> (4 * dg)) & 15u);
+    __syncthreads();
+    // exclusive scan of the 16 x 1024 counters in (digit, thread) order: thread t owns entries [16 t, 16 t + 16)
+    unsigned loc[16], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { loc[j] = cnt[tid * 16 + j]; sum += loc[j]; }
+    unsigned inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned v = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += v;
+    }
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    unsigned base = inc - sum;
+    for (int w = 0; w < wave; ++w) base += s_wsum[w];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { cnt[tid * 16 + j] = (unsigned short)base; base += loc[j]; }
+    __syncthreads();
+    for (int e = 0; e < E; ++e) {
+      const int p = tid * E + e;
+      if (p < K) {
+        const unsigned short slot = pin[p];
+        const unsigned dg = (keys0[slot] >> shift) & 15u;
+        const unsigned short pos = cnt[dg * TK_THREADS + tid];
+        cnt[dg * TK_THREADS + tid] = pos + 1;
+        pout[pos] = slot;
+      }
+    }
+    __syncthreads();
+    unsigned short* t = pin; pin = pout; pout = t;
+  }
+  for (int p = tid; p < K; p += TK_THREADS) {
+    const unsigned short slot = pin[p];
+    top[(size_t)blockIdx.x * K + p] = tk_unkey(keys0[slot]);
+    order[(size_t)blockIdx.x * K + p] = (long long)idx0[slot];
+  }
+}
+
+extern "C" int glx_topk_max_k(void) { return TK_MAXK; }
+
+extern "C" int glx_topk_desc(const float* scores, int frames, int A, int K, float* top, int64_t* order,
+                             void* stream) {
+  if (frames <= 0 || K <= 0) return GLX_OK;
+  GLX_REQUIRE(scores && top && order, "glx_topk_desc: null pointer");
+  GLX_REQUIRE(K <= A && K <= TK_MAXK, "glx_topk_desc: K = %d (1..min(A = %d, %d))", K, A, TK_MAXK);
+  const int Kp = (K + 63) / 64 * 64;
+  const size_t lds = (size_t)Kp * 8 + (size_t)Kp * 4 + (size_t)16 * TK_THREADS * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GLX_HIP(hipFuncSetAttribute((const void*)k_topk_desc, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((size_t)TK_MAXK * 12 + 16 * TK_THREADS * 2)));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_topk_desc, dim3(frames), dim3(TK_THREADS), lds, (hipStream_t)stream, scores, A, K, Kp, top,
+                     (long long*)order);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

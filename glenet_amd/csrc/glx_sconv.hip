@@ -1096,6 +1096,9 @@ static int launch_mfma(const float* in, const float* Wp, const SconvEpilogue& ep
     case 31: return launch_gemm<CI, CO, 64, 4, 2>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
     case 32: return launch_gemm<CI, CO, 64, 4, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
     case 33: return launch_gemm<CI, CO, 128, 8, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
+    case 34: return launch_gemm<CI, CO, 32, 8, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
+    case 35: return launch_gemm<CI, CO, 32, 4, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
+    case 36: return launch_gemm<CI, CO, 48, 8, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
     default: break;
   }
 #undef SC_GO

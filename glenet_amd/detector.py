@@ -11,6 +11,8 @@ kernels in the order and with the shapes the reference drives them; it is not a 
   VoxelRCNNFlow         Detector3DTemplate module order for GLENet_VR.yaml: MeanVFE -> VoxelBackBone8x
                         -> HeightCompression -> BaseBEVBackbone -> AnchorHeadSingle -> VoxelRCNNHead
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -119,6 +121,24 @@ def proposal_layer(batch_box_preds, batch_cls_preds, nms_pre_maxsize, nms_post_m
 BATCHED_PROPOSALS = True
 
 
+FUSED_TOPK = os.environ.get("GLX_TOPK", "1") != "0"
+
+
+def topk_desc(scores, k):
+    """torch.topk(scores, k, dim=1) of (B, A) scores, sorted: one launch per call on the device (csrc/glx_iou_nms.hip:
+    k_topk_desc -- radix select + stable radix sort in LDS, one block per frame; equal scores by ascending index)
+    where torch runs ~45 launches; torch itself for host tensors or k beyond the kernel's LDS budget."""
+    from . import _lib
+    if not (FUSED_TOPK and scores.is_cuda and scores.dim() == 2 and scores.dtype == torch.float32
+            and 0 < k <= min(scores.shape[1], _lib.query("glx_topk_max_k"))):
+        return torch.topk(scores, k=k, dim=1)
+    s = scores.contiguous()
+    top = torch.empty((s.shape[0], k), dtype=torch.float32, device=s.device)
+    order = torch.empty((s.shape[0], k), dtype=torch.int64, device=s.device)
+    _lib.call("glx_topk_desc", s, s.shape[0], s.shape[1], k, top, order)
+    return top, order
+
+
 def _proposal_layer_batched(batch_box_preds, scores_all, nms_pre_maxsize, nms_post_maxsize, nms_thresh):
     """Same result as the per-frame loop above without its host round trips: batched class-max and
     top-k (already in descending order, so the NMS wrapper's own sort is the identity), ONE batched
@@ -128,7 +148,7 @@ def _proposal_layer_batched(batch_box_preds, scores_all, nms_pre_maxsize, nms_po
     B, A, C = batch_box_preds.shape
     s, lab = scores_all.max(dim=2)                                              # (B, A)
     k = min(nms_pre_maxsize, A)
-    top, order = torch.topk(s, k=k, dim=1)
+    top, order = topk_desc(s, k)
     cand = torch.gather(batch_box_preds, 1, order.unsqueeze(-1).expand(B, k, C))
     keep, num = iou3d_nms_cuda.nms_device_batch(cand[..., 0:7].contiguous(), nms_thresh,
                                                 max_keep=nms_post_maxsize)

@@ -689,6 +689,14 @@ int glx_roi_target_gather(const float* rois, const int64_t* roi_labels, const fl
                           int64_t* out_labels, float* out_unc, int64_t* out_reg_valid, void* out_cls_labels,
                           void* stream);
 
+/* The K largest of each frame's A scores in descending order (scores (frames, A) -> top (frames, K), order
+ * (frames, K) int64 indices into the frame), equal scores by ascending index; one launch, one block per frame.
+ * K <= min(A, glx_topk_max_k()).
+ * Replaces: torch.topk(scores, k=NMS_PRE_MAXSIZE) of RoIHeadTemplate.proposal_layer
+ * (pcdet/models/roi_heads/roi_head_template.py:81-88). */
+int glx_topk_max_k(void);
+int glx_topk_desc(const float* scores, int frames, int A, int K, float* top, int64_t* order, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -228,3 +228,28 @@ def test_predicted_boxes_kernel_matches_reference_golden_and_tensor_ops(dev):
             finally:
                 det.FUSED_PREDICTED_BOXES = True
         assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("A,K", [(70400, 9000), (70400, 1024), (5000, 4096), (300, 300), (64, 1), (10240, 10240)])
+def test_topk_kernel_matches_a_stable_sort(dev, A, K):
+    """detector.topk_desc (glx_topk_desc: one block per frame, radix select + stable LSD radix sort in LDS) against
+    numpy's stable sort of the negated scores: values, indices, ties by ascending index -- on smooth scores (shared
+    high bytes, as sigmoid outputs of one frame have), on heavy ties, with infinities and negative values."""
+    rng = np.random.default_rng(A + K)
+    B = 4
+    s = np.empty((B, A), np.float32)
+    s[0] = 1 / (1 + np.exp(-rng.normal(-4.6, 0.3, A)))                    # proposal scores of an untrained head
+    s[1] = np.round(rng.random(A) * 50) / 50                              # ~51 distinct values: ties everywhere
+    s[2] = rng.normal(0, 3, A)                                            # both signs
+    s[3] = 0.25                                                           # all equal
+    if A > 100:
+        s[2, 7], s[2, 11], s[2, 13] = np.inf, -np.inf, -0.0
+    from glenet_amd import detector as det
+    top, order = det.topk_desc(torch.from_numpy(s).to(dev), K)
+    assert top.shape == (B, K) and order.dtype == torch.int64
+    want = np.stack([np.argsort(-s[b], kind="stable")[:K] for b in range(B)])
+    assert np.array_equal(order.cpu().numpy(), want)
+    assert np.array_equal(top.cpu().numpy(), np.take_along_axis(s, want, 1))
+    ttop, _ = torch.topk(torch.from_numpy(s).to(dev), K, dim=1)
+    assert torch.equal(ttop, top)
