@@ -70,12 +70,14 @@ __device__ __forceinline__ void bn_slab_sums(
     }
   }
   if (rlane < rstep) {
-    // 4 rows per trip with all their loads issued first: a slab is ~190 rows over 16 row lanes,
-    // and one dependent 16-byte load per trip left the kernel latency-bound (14 us for 12 MB)
-    for (int r = r0 + rlane; r < r1; r += 4 * rstep) {
-      bf32x4 xv[4], g[4], yv[4];
+    // U rows per trip with all their loads issued first: a slab is ~190 rows over 16 row lanes, and one dependent
+    // 16-byte load per trip left the kernel latency-bound (14 us for 12 MB).  The forward pass has one stream (x)
+    // where backward has two: 8 rows keep as many loads in flight.
+    constexpr int U = BWD ? 4 : 8;
+    for (int r = r0 + rlane; r < r1; r += U * rstep) {
+      bf32x4 xv[U], g[U], yv[U];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < U; ++j) {
         const int rr = r + j * rstep;
         const long long o = (long long)(rr < r1 ? rr : r) * C + 4 * col;
         xv[j] = *reinterpret_cast<const bf32x4*>(x + o);
@@ -85,7 +87,7 @@ __device__ __forceinline__ void bn_slab_sums(
         }
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < U; ++j) {
         if (r + j * rstep >= r1) break;
         if (BWD) {
           if (remask) {
