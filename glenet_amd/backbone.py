@@ -9,6 +9,8 @@ glenet_amd.dropin; this module is what bench.py and the tests drive.
 from collections import deque
 from functools import partial
 
+import os
+
 import torch
 from torch import nn
 
@@ -327,6 +329,9 @@ class StaticFramePipeline:
         return st.features[:n], st.indices[:n]
 
 
+PREPACK_WEIGHTS = os.environ.get("GLX_PREPACK", "1") != "0"
+
+
 class StaticTrainPipeline(StaticFramePipeline):
     """Forward + backward (+ optimizer step) of the sparse backbone as one shape-static launch
     sequence / HIP graph.  The autograd Functions take the device row counts of the shape-static
@@ -384,12 +389,17 @@ class StaticTrainPipeline(StaticFramePipeline):
             for m in self.extra_modules:
                 m.zero_grad(set_to_none=True)
             spconv.core.DEFERRED_COUNTERS = counters = []
+            if PREPACK_WEIGHTS:        # every layer's forward + adjoint weight image in one launch
+                spconv.core.prepack([m for m in self.model.modules() if isinstance(m, spconv.core.SparseConvolution)])
             try:
                 with torch.enable_grad():
                     bd = self.hc(self.model(bd))
                     if self.mark:
                         self.mark("sparse backbone fwd + dense()")
                     loss = self.loss_fn(bd)
+            except BaseException:
+                spconv.core.STEP_PACKS = None
+                raise
             finally:
                 spconv.core.DEFERRED_COUNTERS = None
             if counters:
@@ -402,6 +412,7 @@ class StaticTrainPipeline(StaticFramePipeline):
                 loss.backward()
             finally:
                 spconv.core.WGRAD_STREAM = None
+                spconv.core.STEP_PACKS = None
             if self.overlap_wgrad:
                 cur.wait_stream(self.plan_stream)
             if self.mark:

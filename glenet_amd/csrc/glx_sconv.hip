@@ -90,11 +90,10 @@ struct SconvSplitCfg {
 // conv this one is the adjoint of (read transposed), bit 1 = kernel taps reversed (the input
 // gradient of a submanifold conv walks the same rule table with flipped taps).
 template <int CIN, int COUT>
-__global__ void k_pack_weights(const float* __restrict__ W, int K, float* __restrict__ Wp,
-                               float* __restrict__ Wsplit, int view, int src_cout, int co_off) {
+__device__ __forceinline__ void sc_pack_elem(int e, const float* __restrict__ W, int K, float* __restrict__ Wp,
+                                             float* __restrict__ Wsplit, int view, int src_cout, int co_off) {
   using C = SconvCfg<CIN, COUT>;
   using S = SconvSplitCfg<CIN, COUT>;
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
   // padding dwords of the first image (bank spread between its (h,q) blocks): zeroed here instead
   // of by a fill launch in front of every pack
   if (C::QPAD > 0 && e < K * C::IMG && (e % C::QSTRIDE) >= C::QSTRIDE - C::QPAD) Wp[e] = 0.f;
@@ -111,6 +110,12 @@ __global__ void k_pack_weights(const float* __restrict__ W, int K, float* __rest
   int h = ct / C::NC, c = ct % C::NC;
   Wp[(size_t)k * C::IMG + (h * 4 + q) * C::QSTRIDE + (t * 16 + n) * C::NC + c] = w;
   Wsplit[(size_t)k * S::IMG + S::idx(ct, ci / S::CQ, ci % S::CQ, n)] = w;
+}
+
+template <int CIN, int COUT>
+__global__ void k_pack_weights(const float* __restrict__ W, int K, float* __restrict__ Wp,
+                               float* __restrict__ Wsplit, int view, int src_cout, int co_off) {
+  sc_pack_elem<CIN, COUT>(blockIdx.x * blockDim.x + threadIdx.x, W, K, Wp, Wsplit, view, src_cout, co_off);
 }
 
 // Tile geometry: TR output rows per block, NW waves per block, NBUF LDS weight buffers, WPG waves
@@ -1151,6 +1156,89 @@ extern "C" int glx_sconv_pack_weights_view(const float* W, int K, int Cin, int C
 extern "C" int glx_sconv_pack_weights(const float* W, int K, int Cin, int Cout, float* Wp,
                                       void* stream) {
   return glx_sconv_pack_weights_view(W, K, Cin, Cout, 0, 0, Wp, stream);
+}
+
+// All weight images of a training step in ONE launch: a VoxelBackBone8x step packs 12 forward and 11 adjoint images,
+// 24 launches of ~5 us; blockIdx.y selects the job, a switch the layout.
+#define SC_PACK_MAX_JOBS 40
+struct ScPackJob {
+  const float* W;
+  float* Wp;
+  float* Wsplit;
+  int K, cfg, view, src_cout, co_off, cover;
+};
+struct ScPackJobs { ScPackJob j[SC_PACK_MAX_JOBS]; };
+
+#define SC_PACK_CONFIGS(X) \
+  X(0, 4, 16) X(1, 4, 32) X(2, 8, 16) X(3, 8, 32) X(4, 16, 16) X(5, 16, 32) X(6, 16, 64) X(7, 16, 128) \
+  X(8, 32, 16) X(9, 32, 32) X(10, 32, 64) X(11, 32, 128) X(12, 64, 16) X(13, 64, 32) X(14, 64, 64) \
+  X(15, 64, 128) X(16, 128, 16) X(17, 128, 32) X(18, 128, 64) X(19, 128, 128)
+
+__global__ __launch_bounds__(256) void k_pack_weights_multi(ScPackJobs jobs) {
+  const ScPackJob jb = jobs.j[blockIdx.y];
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= jb.cover) return;
+  switch (jb.cfg) {
+#define SC_PACK_CASE(ID, A, B) \
+    case ID: sc_pack_elem<A, B>(e, jb.W, jb.K, jb.Wp, jb.Wsplit, jb.view, jb.src_cout, jb.co_off); break;
+    SC_PACK_CONFIGS(SC_PACK_CASE)
+#undef SC_PACK_CASE
+    default: break;
+  }
+}
+
+static int sc_pack_cfg(int Cin, int Cout) {
+#define SC_PACK_ID(ID, A, B) if (Cin == A && Cout == B) return ID;
+  SC_PACK_CONFIGS(SC_PACK_ID)
+#undef SC_PACK_ID
+  return -1;
+}
+
+template <int CI, int CO>
+static int sc_pack_jobs(const float* W, int K, float* Wp, int view, ScPackJob* out) {
+  using C = SconvCfg<CI, CO>;
+  const int nel = K * CI * CO, cover = K * C::IMG > nel ? K * C::IMG : nel;
+  int n = 0;
+  out[n++] = ScPackJob{W, Wp, Wp + (size_t)K * C::IMG, K, sc_pack_cfg(CI, CO), view, CO, 0, cover};
+  if constexpr (sc_column_halves<CI, CO>()) {
+    using CH = SconvCfg<CI, CO / 2>;
+    const size_t half = (size_t)K * img_bytes<CI, CO / 2>() / sizeof(float);
+    float* base = Wp + (size_t)K * img_bytes<CI, CO>() / sizeof(float);
+    const int nh = K * CI * (CO / 2), ch = K * CH::IMG > nh ? K * CH::IMG : nh;
+    for (int h = 0; h < 2; ++h)
+      out[n++] = ScPackJob{W, base + h * half, base + h * half + (size_t)K * CH::IMG, K, sc_pack_cfg(CI, CO / 2),
+                           view, CO, h * (CO / 2), ch};
+  }
+  return n;
+}
+
+extern "C" int glx_sconv_pack_weights_multi(int n, const float* const* W, const int32_t* K, const int32_t* Cin,
+                                            const int32_t* Cout, const int32_t* transposed,
+                                            const int32_t* flip_taps, float* const* Wp, void* stream) {
+  if (n <= 0) return GLX_OK;
+  GLX_REQUIRE(W && K && Cin && Cout && transposed && flip_taps && Wp, "glx_sconv_pack_weights_multi: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  int done = 0;
+  while (done < n) {                                   // SC_PACK_MAX_JOBS images per launch
+    ScPackJobs jobs;
+    int nj = 0, max_cover = 0;
+    for (; done < n; ++done) {
+      GLX_REQUIRE(W[done] && Wp[done], "glx_sconv_pack_weights_multi: null pointer in job %d", done);
+      GLX_REQUIRE(mfma_supported(Cin[done], Cout[done], K[done]),
+                  "glx_sconv_pack_weights_multi: no MFMA kernel for (K=%d, Cin=%d, Cout=%d)", K[done], Cin[done],
+                  Cout[done]);
+      if (nj + 3 > SC_PACK_MAX_JOBS) break;
+      const int view = (transposed[done] ? 1 : 0) | (flip_taps[done] ? 2 : 0);
+      const int i = done;
+      nj += sc_dispatch(Cin[i], Cout[i], [&](auto ci, auto co) {
+        return sc_pack_jobs<decltype(ci)::value, decltype(co)::value>(W[i], K[i], Wp[i], view, jobs.j + nj);
+      });
+    }
+    for (int j = 0; j < nj; ++j) max_cover = jobs.j[j].cover > max_cover ? jobs.j[j].cover : max_cover;
+    hipLaunchKernelGGL(k_pack_weights_multi, dim3(glx_divup(max_cover, 256), nj), dim3(256), 0, st, jobs);
+  }
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
 }
 
 // ------------------------------------------------------------------ work-balanced block -> tile map

@@ -273,10 +273,50 @@ def check_static(indice_dict, index=None):
 _profile_hook = None   # bench.py installs a callable(tag, K, cin, cout, n_out, rules), run before the launch
 
 
+# Weight images packed ahead for the current training step by prepack(): {(data_ptr, adjoint, flip): packed}; a
+# StaticTrainPipeline fills it at the top of the step with ONE launch and clears it at the end (None = no step open).
+STEP_PACKS = None
+
+
+def prepack(convs):
+    """Pack the forward and the input-gradient (adjoint) weight image of every SparseConvolution in `convs` with one
+    launch (glx_sconv_pack_weights_multi) and park them in STEP_PACKS for pack_weights() to hand out -- the 24 pack
+    launches of a VoxelBackBone8x training step become one.  The caller resets STEP_PACKS = None after the step:
+    the images are only valid while the weights do not change."""
+    global STEP_PACKS
+    import ctypes
+    jobs = []
+    for m in convs:
+        w = m.weight.detach()
+        if m.inverse or _cin_padding(m.in_channels) or not (w.is_cuda and w.is_contiguous() and w.dtype == torch.float32):
+            continue
+        wk = w.view(-1, w.shape[-2], w.shape[-1])
+        K, cin, cout = wk.shape
+        flip = bool(m.subm and not m.inverse)
+        for adjoint, fl, ci, co in ((False, False, cin, cout), (True, flip, cout, cin)):
+            nbytes = query("glx_sconv_packed_bytes", K, ci, co)
+            if nbytes:
+                jobs.append((wk, K, ci, co, adjoint, fl, torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)))
+    STEP_PACKS = {}
+    if not jobs:
+        return
+    n = len(jobs)
+    ptrs = (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in jobs])
+    outs = (ctypes.c_void_p * n)(*[j[6].data_ptr() for j in jobs])
+    ints = [(ctypes.c_int32 * n)(*[int(j[i]) for j in jobs]) for i in (1, 2, 3, 4, 5)]
+    call("glx_sconv_pack_weights_multi", n, ptrs, ints[0], ints[1], ints[2], ints[3], ints[4], outs)
+    for j in jobs:
+        STEP_PACKS[(j[0].data_ptr(), j[4], j[5])] = j[6]
+
+
 def pack_weights(weight_kio, adjoint=False, flip=False):
     """MFMA-fragment-ordered copy of (K, Cin, Cout) weights, or None when the channel counts
     run on the scalar kernel.  adjoint: pack the weights of the input-gradient conv (Cout -> Cin)
     straight from the forward weights, with the taps reversed when flip (submanifold)."""
+    if STEP_PACKS is not None:
+        hit = STEP_PACKS.get((weight_kio.data_ptr(), bool(adjoint), bool(flip)))
+        if hit is not None:
+            return hit
     K, cin, cout = weight_kio.shape
     if adjoint:
         cin, cout = cout, cin

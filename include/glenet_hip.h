@@ -141,6 +141,12 @@ int glx_sconv_pack_weights(const float* W, int K, int Cin, int Cout, float* Wp, 
  * submanifold conv on its own rule table).  One launch instead of flip + transpose + copy + pack. */
 int glx_sconv_pack_weights_view(const float* W, int K, int Cin, int Cout, int transposed,
                                 int flip_taps, float* Wp, void* stream);
+/* n weight images in one launch (a training step packs every layer's forward and adjoint image: 24 launches
+ * otherwise); arrays of length n on the HOST, job i as glx_sconv_pack_weights_view(W[i], K[i], Cin[i], Cout[i],
+ * transposed[i], flip_taps[i], Wp[i]). */
+int glx_sconv_pack_weights_multi(int n, const float* const* W, const int32_t* K, const int32_t* Cin,
+                                 const int32_t* Cout, const int32_t* transposed, const int32_t* flip_taps,
+                                 float* const* Wp, void* stream);
 /* W: raw weights (may be NULL when Wp is given); Wp: packed weights or NULL (then W is packed
  * into `workspace`, >= glx_sconv_workspace_bytes).  Fused pointwise tail on the output tile:
  * y = relu?((acc + bias) * scale + shift); bias/scale/shift are (Cout) or NULL -- this is how
