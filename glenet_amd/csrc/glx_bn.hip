@@ -219,6 +219,10 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_forward_apply(
     }
     *reinterpret_cast<bf32x4*>(y + (long long)r * y_pitch + 4 * col) = v;
   }
+  // rows past the live count of a capacity-sized matrix: zeros, so that nothing downstream (a GEMM's weight
+  // gradient multiplies them by zero gradients) ever meets the NaN an uninitialised row may hold
+  for (int r = n + blockIdx.x * rpb + rl; r < N; r += gridDim.x * rpb)
+    *reinterpret_cast<bf32x4*>(y + (long long)r * y_pitch + 4 * col) = bf32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 // one block: dgamma / dbeta and the coefficients of dx = a * (dz - b - xhat * cc)
@@ -288,6 +292,8 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_backward_apply(
     }
     *reinterpret_cast<bf32x4*>(dx + o) = ov;
   }
+  for (int r = n + blockIdx.x * rpb + rl; r < N; r += gridDim.x * rpb)      // dead rows: zero gradient
+    *reinterpret_cast<bf32x4*>(dx + (long long)r * C + 4 * col) = bf32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 // ------------------------------------------------------------------ statistics + finalize in one launch
@@ -469,6 +475,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_small_forward(
     }
     *reinterpret_cast<bf32x4*>(y + (long long)r * y_pitch + c0) = v;
   }
+  for (int r = n + rl; r < N; r += RL) *reinterpret_cast<bf32x4*>(y + (long long)r * y_pitch + c0) = bf32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 __global__ __launch_bounds__(BN_THREADS) void k_bn_small_backward(
@@ -550,6 +557,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_small_backward(
     }
     *reinterpret_cast<bf32x4*>(dx + o) = ov;
   }
+  for (int r = n + rl; r < N; r += RL) *reinterpret_cast<bf32x4*>(dx + (long long)r * C + c0) = bf32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 static bool bn_channels_ok(int C) { return C >= 4 && C <= BN_MAXC && (C & 3) == 0 && BN_THREADS % (C >> 2) == 0; }

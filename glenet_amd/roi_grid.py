@@ -142,7 +142,9 @@ class RoIGridPool(nn.Module):
         w = conv.weight.reshape(conv.out_channels, conv.in_channels)
         x = st.features
         live = None
-        if st.count is not None:
+        # rows past `count`: a tensor that left the fused BatchNorm kernels carries zeros there (and gets zero
+        # gradients back, see glx_bn_relu_*), anything else may hold NaN and is masked on both sides of the conv
+        if st.count is not None and not getattr(st, "clean_rows", False):
             live = (torch.arange(x.shape[0], device=x.device) < st.count).view(-1, 1)
             x = torch.where(live, x, x.new_zeros(()))
         y = layer._linear_rows(x, w, conv.bias)
@@ -151,7 +153,7 @@ class RoIGridPool(nn.Module):
                 y = torch.where(live, y, y.new_zeros(()))        # its backward cleans the gradient rows
             y = core.fused_train_bn(bn, y, False, st.count)
             return F.relu(y) if len(seq) > 2 else y
-        if live is not None and bn.training:
+        if st.count is not None and bn.training:
             raise NotImplementedError("shape-static training needs the fused BatchNorm kernels")
         return layer._bn_rows(seq, y)
 

@@ -925,6 +925,7 @@ class SparseSequential(SparseModule):
                     and x.indices.shape[0] > 1 and can_fuse_train_bn(m, x.features)):
                 relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
                 x = x.replace_feature(fused_train_bn(m, x.features, relu, x.count))
+                x.clean_rows = True        # the kernels wrote zeros into the rows past `count`
                 i += 2 if relu else 1
                 continue
             if is_spconv_module(m):

@@ -505,7 +505,8 @@ int glx_predicted_boxes(const float* box_preds, const float* dir_preds, const fl
  * divides 1024 (16 ... 512).  Semantics of nn.BatchNorm1d(eps, momentum) followed by nn.ReLU as
  * the backbone applies them after every sparse conv (spconv_backbone.py:21-25,73): batch
  * statistics (biased variance) normalise, the running estimates take the unbiased variance.
- * relu = 0 gives plain BatchNorm.  fp64 column sums.
+ * relu = 0 gives plain BatchNorm.  fp64 column sums.  n_live (device int32, or NULL): statistics and transform
+ * cover the first min(N, *n_live) rows of a capacity-sized matrix; the rows past them are written as ZEROS in y / dx.
  * state: NULL, or a device buffer of glx_bn_state_bytes() that the caller zero-fills ONCE and then only hands to
  *   these two functions, one buffer per stream.  NULL: statistics, a one-block finalize and the transform are three
  *   launches and the reduction order is fixed (bitwise reproducible).  With a state buffer the statistics kernel
