@@ -35,6 +35,9 @@ def assign_targets(all_anchors, gt_boxes_with_classes, anchor_class_ids, matched
         labels.append(lab.view(B, *fmap, -1))
         targets.append(tgt.view(B, *fmap, -1, 7))
         weights.append(w.view(B, *fmap, -1))
+    if len(labels) == 1:          # one anchor class (GLENet-VR's Car model): nothing to interleave, no copies
+        return {"box_cls_labels": labels[0].view(B, -1), "box_reg_targets": targets[0].view(B, -1, 7),
+                "reg_weights": weights[0].view(B, -1)}
     return {"box_cls_labels": torch.cat(labels, dim=-1).view(B, -1),
             "box_reg_targets": torch.cat(targets, dim=-2).view(B, -1, 7),
             "reg_weights": torch.cat(weights, dim=-1).view(B, -1)}
