@@ -738,7 +738,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
       }
       if (has_next) {
         GM_LOAD_A(kn, pbn, cntn);
-        if (new_w) GM_LOAD_W(kn);
+        if (new_w && !(TRACE && (ep.xcd_group & 0x400))) GM_LOAD_W(kn);   // 0x400: ablate the weight image reloads
       }
       if constexpr (TRACE) c1 = clock64();
       // ---- multiply this wave's chunk of the current panel by its column tiles
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
       __syncthreads();   // everyone is done reading the panel and the weight image
       if constexpr (TRACE) c3 = clock64();
       GM_STORE_A();
-      if (new_w) GM_STORE_W();
+      if (new_w && !(TRACE && (ep.xcd_group & 0x400))) GM_STORE_W();
       if constexpr (TRACE) {
         __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) lgkmcnt(0): stores issued and landed
         c4 = clock64();
