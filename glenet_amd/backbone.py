@@ -227,10 +227,46 @@ class StaticFramePipeline:
         n = points.shape[0]
         if n > self.points.shape[0]:
             raise ValueError("batch has %d points, pipeline was sized for %d" % (n, self.points.shape[0]))
+        if self._load_fused(points, batch_idx, ()):
+            return
         self.points[:n].copy_(points, non_blocking=True)
         self.batch_idx[:n].copy_(batch_idx, non_blocking=True)
         if n < self.points.shape[0]:
             self.batch_idx[n:].fill_(self.B)
+
+    def _load_fused(self, points, batch_idx, extra):
+        """The copies and padding fills of load() as ONE launch (glx_copy_fill_multi) when every source is a
+        contiguous device tensor of the buffers' dtypes; `extra`: (dst, src or None) pairs of (B, cap, C) buffers whose
+        first src.shape[1] rows per frame come from src, the rest zeros.  False: the caller falls back to tensor ops."""
+        import ctypes
+        from . import _lib
+        dev = self.points.device
+        srcs = [points, batch_idx] + [s for _, s in extra if s is not None]
+        if not all(t.is_cuda and t.device == dev and t.is_contiguous() for t in srcs):
+            return False
+        if points.dtype != self.points.dtype or batch_idx.dtype != self.batch_idx.dtype or points.shape[1:] != self.points.shape[1:]:
+            return False
+        n = points.shape[0]
+        regions = [(self.points.data_ptr(), points.data_ptr(), points.numel(), points.numel(), 0),
+                   (self.batch_idx.data_ptr(), batch_idx.data_ptr(), n, self.batch_idx.numel(), int(self.B))]
+        for dst, src in extra:
+            b, cap, c = dst.shape
+            if src is None:
+                regions.append((dst.data_ptr(), 0, 0, dst.numel(), 0))
+                continue
+            if src.dtype != dst.dtype or src.shape[0] != b or src.shape[2] != c or dst.element_size() != 4:
+                return False
+            g = src.shape[1]
+            for f in range(b):
+                regions.append((dst.data_ptr() + f * cap * c * 4, src.data_ptr() + f * g * c * 4, g * c, cap * c, 0))
+        m = len(regions)
+        if self.points.element_size() != 4 or self.batch_idx.element_size() != 4 or m > 48:
+            return False
+        arr = [(ctypes.c_void_p * m)(*[r[0] for r in regions]), (ctypes.c_void_p * m)(*[r[1] for r in regions]),
+               (ctypes.c_uint32 * m)(*[r[2] for r in regions]), (ctypes.c_uint32 * m)(*[r[3] for r in regions]),
+               (ctypes.c_uint32 * m)(*[r[4] for r in regions])]
+        _lib.call("glx_copy_fill_multi", m, *arr)
+        return True
 
     def enqueue(self):
         """Launch one frame on the current stream; returns the batch_dict (static buffers)."""

@@ -458,3 +458,61 @@ extern "C" int glx_rules_invert(const int32_t* nbr, int N_out, int K, int N_in, 
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
+
+// ------------------------------------------------------------------ several copy-then-fill regions, one launch
+// Loading the next batch into the static input buffers of a recorded step is seven small launches as tensor ops
+// (points, frame ids + their padding value, the zero-padded ground-truth / label-variance blocks of every frame).
+// Region i: dst[i][0 .. copy_words) = src[i][...], dst[i][copy_words .. total_words) = fill[i]; 32-bit words.
+#define GLX_CF_MAX 48
+#define GLX_CF_BLOCK_WORDS 4096   // 256 threads x 16 words
+struct GlxCopyFillArgs {
+  unsigned long long dst[GLX_CF_MAX], src[GLX_CF_MAX];
+  unsigned copy_words[GLX_CF_MAX], total_words[GLX_CF_MAX], fill[GLX_CF_MAX];
+  unsigned first_block[GLX_CF_MAX + 1];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void k_copy_fill_multi(GlxCopyFillArgs a) {
+  int r = 0;
+  for (int i = 1; i < a.n; ++i)
+    if (blockIdx.x >= a.first_block[i]) r = i;
+  unsigned* dst = reinterpret_cast<unsigned*>(a.dst[r]);
+  const unsigned* src = reinterpret_cast<const unsigned*>(a.src[r]);
+  const unsigned nc = a.copy_words[r], nt = a.total_words[r], fv = a.fill[r];
+  const unsigned base = (blockIdx.x - a.first_block[r]) * GLX_CF_BLOCK_WORDS;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const unsigned w = base + i * 256 + threadIdx.x;
+    if (w < nt) dst[w] = w < nc ? src[w] : fv;
+  }
+}
+
+extern "C" int glx_copy_fill_multi(int n, void* const* dst, const void* const* src, const uint32_t* copy_words,
+                                   const uint32_t* total_words, const uint32_t* fill, void* stream) {
+  if (n <= 0) return GLX_OK;
+  GLX_REQUIRE(dst && src && copy_words && total_words && fill, "glx_copy_fill_multi: null pointer");
+  GLX_REQUIRE(n <= GLX_CF_MAX, "glx_copy_fill_multi: %d regions (at most %d)", n, GLX_CF_MAX);
+  GlxCopyFillArgs a;
+  memset(&a, 0, sizeof(a));
+  unsigned blocks = 0;
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    if (total_words[i] == 0) continue;
+    GLX_REQUIRE(dst[i] && (copy_words[i] == 0 || src[i]) && copy_words[i] <= total_words[i],
+                "glx_copy_fill_multi: region %d", i);
+    a.dst[m] = (unsigned long long)dst[i];
+    a.src[m] = (unsigned long long)src[i];
+    a.copy_words[m] = copy_words[i];
+    a.total_words[m] = total_words[i];
+    a.fill[m] = fill[i];
+    a.first_block[m] = blocks;
+    blocks += (total_words[i] + GLX_CF_BLOCK_WORDS - 1) / GLX_CF_BLOCK_WORDS;
+    ++m;
+  }
+  a.n = m;
+  a.first_block[m] = blocks;
+  if (blocks == 0) return GLX_OK;
+  hipLaunchKernelGGL(k_copy_fill_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

@@ -297,6 +297,15 @@ class StaticTrainStep(gb.StaticTrainPipeline):
         return loss
 
     def load(self, points, batch_idx, gt_boxes=None, gt_uncertaintys=None):
+        if gt_boxes is not None:
+            if points.shape[0] > self.points.shape[0]:
+                raise ValueError("batch has %d points, pipeline was sized for %d" % (points.shape[0], self.points.shape[0]))
+            if gt_boxes.shape[1] > self.gt_boxes.shape[1]:
+                raise ValueError("batch has %d ground-truth rows, pipeline was sized for %d"
+                                 % (gt_boxes.shape[1], self.gt_boxes.shape[1]))
+            unc = gt_uncertaintys[:, :, :7] if gt_uncertaintys is not None and gt_uncertaintys.shape[2] == 7 else gt_uncertaintys
+            if self._load_fused(points, batch_idx, ((self.gt_boxes, gt_boxes), (self.gt_unc, unc))):
+                return                       # points, frame ids, ground truth and label variances: one launch
         super().load(points, batch_idx)
         if gt_boxes is not None:
             g = gt_boxes.shape[1]

@@ -696,6 +696,12 @@ int glx_roi_target_gather(const float* rois, const int64_t* roi_labels, const fl
                           int64_t* out_labels, float* out_unc, int64_t* out_reg_valid, void* out_cls_labels,
                           void* stream);
 
+/* n copy-then-fill regions of 32-bit words in one launch (arrays of length n on the HOST): dst[i][0 .. copy_words[i])
+ * = src[i][...] (device to device), dst[i][copy_words[i] .. total_words[i]) = fill[i].  Loads the next batch into the
+ * static input buffers of a recorded step (points, frame ids + padding value, zero-padded ground-truth blocks). */
+int glx_copy_fill_multi(int n, void* const* dst, const void* const* src, const uint32_t* copy_words,
+                        const uint32_t* total_words, const uint32_t* fill, void* stream);
+
 /* The K largest of each frame's A scores in descending order (scores (frames, A) -> top (frames, K), order
  * (frames, K) int64 indices into the frame), equal scores by ascending index; one launch, one block per frame.
  * K <= min(A, glx_topk_max_k()).

@@ -232,3 +232,28 @@ def test_full_size_step_cycles_batches_inside_one_graph(dev):
     assert len({round(l, 4) for l, _ in seen[:3]}) == 3          # different batches, different losses
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     assert pipe.last_rois_shape() == (B, 128, 7)
+
+
+def test_fused_batch_load_equals_the_tensor_op_load(dev):
+    """StaticTrainStep.load through glx_copy_fill_multi (one launch) leaves exactly what the copies / fills it
+    replaces leave: points, frame ids with their padding value, zero-padded ground truth and label variances --
+    for a batch smaller than the buffers, after a larger one."""
+    from glenet_amd import glenet_vr as gvr
+    model = _small_model(dev)
+    big = _batch(dev, [60, 61], 6000, max_gt=16)
+    small = _batch(dev, [62, 63], 3000, max_gt=16)
+    small = (small[0], small[1], small[2][:, :9].contiguous(), small[3][:, :9].contiguous())   # fewer ground-truth rows
+    pipe = gvr.StaticTrainStep(model, 2, big[0].shape[0] + 500, max_gt=16, lr=1e-3, seed_rois_with_gt=JIT)
+    snaps = []
+    for fused in (True, False):
+        if not fused:
+            pipe._load_fused = lambda *a, **k: False
+        pipe.load(*big)
+        pipe.load(*small)
+        torch.cuda.synchronize()
+        n = small[0].shape[0]
+        snaps.append((pipe.points[:n].clone(), pipe.batch_idx.clone(), pipe.gt_boxes.clone(), pipe.gt_unc.clone()))
+    for a, b in zip(*snaps):
+        assert torch.equal(a, b)
+    assert int((snaps[0][1] == 2).sum()) == pipe.batch_idx.numel() - small[0].shape[0]
+    assert float(snaps[0][2][:, 9:].abs().max()) == 0.0 and float(snaps[0][2][:, :9].abs().max()) > 0
