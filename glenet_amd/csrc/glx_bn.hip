@@ -560,6 +560,107 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_small_backward(
   for (int r = n + rl; r < N; r += RL) *reinterpret_cast<bf32x4*>(dx + (long long)r * C + c0) = bf32x4{0.f, 0.f, 0.f, 0.f};
 }
 
+// Any channel count on a short matrix (GLENet's reg_std branch normalises (512, 7)): one block per channel, scalar
+// loads; statistics in fp64 with a fixed-order tree.  Same arithmetic as the kernels above.
+__device__ __forceinline__ void bn_col_reduce(double& s0, double& s1, double (*red)[2]) {
+  red[threadIdx.x][0] = s0;
+  red[threadIdx.x][1] = s1;
+  __syncthreads();
+  for (int off = BN_THREADS / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      red[threadIdx.x][0] += red[threadIdx.x + off][0];
+      red[threadIdx.x][1] += red[threadIdx.x + off][1];
+    }
+    __syncthreads();
+  }
+  s0 = red[0][0];
+  s1 = red[0][1];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(BN_THREADS) void k_bn_column_forward(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    float momentum, int relu, int N, int C, const int* __restrict__ n_live, float* __restrict__ y,
+    long long y_pitch, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+    float* __restrict__ running_mean, float* __restrict__ running_var) {
+  __shared__ double red[BN_THREADS][2];
+  int n = N;
+  if (n_live) n = min(N, *n_live);
+  const int c = blockIdx.x;
+  double s0 = 0, s1 = 0;
+  for (int r = threadIdx.x; r < n; r += BN_THREADS) {
+    const double v = (double)x[(long long)r * C + c];
+    s0 += v;
+    s1 += v * v;
+  }
+  bn_col_reduce(s0, s1, red);
+  const double cnt = n > 0 ? (double)n : 1.0;
+  const double m = s0 / cnt;
+  double var = s1 / cnt - m * m;
+  if (var < 0) var = 0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+  const float sc = bn_scale(is, gm), sh = bn_shift(bt, (float)m, is, gm);
+  if (threadIdx.x == 0) {
+    save_mean[c] = (float)m;
+    save_invstd[c] = is;
+    if (running_mean) {
+      const double unb = n > 1 ? var * cnt / (cnt - 1.0) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  }
+  for (int r = threadIdx.x; r < N; r += BN_THREADS) {
+    float t = 0.f;
+    if (r < n) {
+      t = bn_affine(x[(long long)r * C + c], sc, sh);
+      if (relu) t = fmaxf(t, 0.f);
+    }
+    y[(long long)r * y_pitch + c] = t;
+  }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void k_bn_column_backward(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+    const float* __restrict__ invstd, int relu, int N, int C, long long dy_pitch,
+    const int* __restrict__ n_live, float* __restrict__ dx, float* __restrict__ dgamma,
+    float* __restrict__ dbeta) {
+  __shared__ double red[BN_THREADS][2];
+  int n = N;
+  if (n_live) n = min(N, *n_live);
+  const int c = blockIdx.x;
+  const float mu = mean[c], is = invstd[c];
+  const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+  const float sc = bn_scale(is, gm), sh = bn_shift(bt, mu, is, gm);
+  const bool remask = relu && !y;
+  double s0 = 0, s1 = 0;
+  for (int r = threadIdx.x; r < n; r += BN_THREADS) {
+    const float xv = x[(long long)r * C + c];
+    float g = dy[(long long)r * dy_pitch + c];
+    if (remask ? !(bn_affine(xv, sc, sh) > 0.f) : (relu && !(y[(long long)r * C + c] > 0.f))) g = 0.f;
+    s0 += (double)g;
+    s1 += (double)g * (double)((xv - mu) * is);
+  }
+  bn_col_reduce(s0, s1, red);
+  const double cnt = n > 0 ? (double)n : 1.0;
+  const float a = gm * is, b = (float)(s0 / cnt), cc = (float)(s1 / cnt);
+  if (threadIdx.x == 0) {
+    if (dgamma) dgamma[c] = (float)s1;
+    if (dbeta) dbeta[c] = (float)s0;
+  }
+  for (int r = threadIdx.x; r < N; r += BN_THREADS) {
+    float o = 0.f;
+    if (r < n) {
+      const float xv = x[(long long)r * C + c];
+      float g = dy[(long long)r * dy_pitch + c];
+      if (remask ? !(bn_affine(xv, sc, sh) > 0.f) : (relu && !(y[(long long)r * C + c] > 0.f))) g = 0.f;
+      o = a * (g - b - (xv - mu) * is * cc);
+    }
+    dx[(long long)r * C + c] = o;
+  }
+}
+
 static bool bn_channels_ok(int C) { return C >= 4 && C <= BN_MAXC && (C & 3) == 0 && BN_THREADS % (C >> 2) == 0; }
 
 // workspace: slab partials (fp64) + 3*C coefficient floats
@@ -573,8 +674,19 @@ extern "C" int glx_bn_relu_train_forward(const float* x, int N, int C, const flo
                                          const int32_t* n_live, void* workspace,
                                          size_t workspace_bytes, void* state, int y_stride,
                                          void* stream) {
-  GLX_REQUIRE(bn_channels_ok(C), "glx_bn_relu_train_forward: C=%d must be a multiple of 4 dividing 1024, <= 512", C);
   GLX_REQUIRE(y && save_mean && save_invstd && (N == 0 || x), "glx_bn_relu_train_forward: null pointer");
+  if (!bn_channels_ok(C)) {                      // any width on a short matrix: one block per channel
+    GLX_REQUIRE(C >= 1 && C <= BN_MAXC && N <= BN_SMALL_N,
+                "glx_bn_relu_train_forward: C=%d needs a multiple of 4 dividing 1024 (<= 512), or at most %d rows", C,
+                BN_SMALL_N);
+    GLX_REQUIRE(y_stride == 0 || y_stride >= C, "glx_bn_relu_train_forward: y_stride %d", y_stride);
+    if (N <= 0) return GLX_OK;
+    hipLaunchKernelGGL(k_bn_column_forward, dim3(C), dim3(BN_THREADS), 0, (hipStream_t)stream, x, gamma, beta, eps,
+                       momentum, relu, N, C, n_live, y, (long long)(y_stride ? y_stride : C), save_mean,
+                       save_invstd, running_mean, running_var);
+    GLX_LAUNCH_CHECK();
+    return GLX_OK;
+  }
   GLX_REQUIRE(y_stride == 0 || (y_stride >= C && (y_stride & 3) == 0), "glx_bn_relu_train_forward: y_stride %d", y_stride);
   const long long y_pitch = y_stride ? y_stride : C;
   if (!workspace || workspace_bytes < glx_bn_workspace_bytes(C) - 256) {
@@ -617,8 +729,17 @@ extern "C" int glx_bn_relu_backward(const float* x, const float* dy, const float
                                     const float* save_invstd, int relu, float* dx, float* dgamma,
                                     float* dbeta, const int32_t* n_live, void* workspace,
                                     size_t workspace_bytes, void* state, int dy_stride, void* stream) {
-  GLX_REQUIRE(bn_channels_ok(C), "glx_bn_relu_backward: C=%d not supported", C);
   GLX_REQUIRE(save_mean && save_invstd && (N == 0 || (x && dy && dx)), "glx_bn_relu_backward: null pointer");
+  if (!bn_channels_ok(C)) {
+    GLX_REQUIRE(C >= 1 && C <= BN_MAXC && N <= BN_SMALL_N, "glx_bn_relu_backward: C=%d not supported for %d rows", C, N);
+    GLX_REQUIRE(dy_stride == 0 || dy_stride >= C, "glx_bn_relu_backward: dy_stride %d", dy_stride);
+    if (N <= 0) return GLX_OK;
+    hipLaunchKernelGGL(k_bn_column_backward, dim3(C), dim3(BN_THREADS), 0, (hipStream_t)stream, x, dy, y, gamma, beta,
+                       save_mean, save_invstd, relu, N, C, (long long)(dy_stride ? dy_stride : C), n_live, dx,
+                       dgamma, dbeta);
+    GLX_LAUNCH_CHECK();
+    return GLX_OK;
+  }
   GLX_REQUIRE(dy_stride == 0 || (dy_stride >= C && (dy_stride & 3) == 0), "glx_bn_relu_backward: dy_stride %d", dy_stride);
   const long long dy_pitch = dy_stride ? dy_stride : C;
   if (!workspace || workspace_bytes < glx_bn_workspace_bytes(C) - 256) {

@@ -96,7 +96,7 @@ class VoxelRCNNKLHead(rg.RoIGridPool):
         reg_feat = self.reg_fc_layers(shared)
         rcnn_reg = self.reg_pred_layer(reg_feat)
         rcnn_reg_std = self.reg_std_layer(reg_feat)
-        s = torch.relu(self.reg_std_bn(rcnn_reg_std.clone()))
+        s = dp.bn_relu(self.reg_std_bn, rcnn_reg_std.clone())
         s = dp.bn_relu(self.reg_std_bn1, self.reg_std_fc1(s))
         std_logit = self.reg_std_fc2(s)
         if raw:

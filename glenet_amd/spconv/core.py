@@ -840,7 +840,11 @@ def can_fuse_train_bn(bn, features):
     """Training-mode BatchNorm1d that the fused kernels cover (else nn.BatchNorm1d runs)."""
     c = bn.num_features
     return (USE_FUSED_TRAIN_BN and isinstance(bn, nn.BatchNorm1d) and bn.training and bn.affine and bn.momentum is not None
-            and features.is_cuda and features.shape[0] > 1 and c % 4 == 0 and c <= 512 and 1024 % c == 0)
+            and features.is_cuda and features.shape[0] > 1 and c <= 512
+            and ((c % 4 == 0 and 1024 % c == 0) or features.shape[0] <= BN_SMALL_ROWS))
+
+
+BN_SMALL_ROWS = 4096       # csrc/glx_bn.hip BN_SMALL_N: up to here any channel count runs (one block per channel)
 
 
 def fused_train_bn(bn, features, relu, count=None):

@@ -502,7 +502,7 @@ int glx_predicted_boxes(const float* box_preds, const float* dir_preds, const fl
 
 /* ------------------------------------------------------------------------------------
  * Training-mode BatchNorm1d (+ ReLU) over sparse-tensor features x (N, C), C a multiple of 4 that
- * divides 1024 (16 ... 512).  Semantics of nn.BatchNorm1d(eps, momentum) followed by nn.ReLU as
+ * divides 1024 (16 ... 512) -- or any C <= 512 when N <= 4096 (one block per channel).  Semantics of nn.BatchNorm1d(eps, momentum) followed by nn.ReLU as
  * the backbone applies them after every sparse conv (spconv_backbone.py:21-25,73): batch
  * statistics (biased variance) normalise, the running estimates take the unbiased variance.
  * relu = 0 gives plain BatchNorm.  fp64 column sums.  n_live (device int32, or NULL): statistics and transform

@@ -277,7 +277,8 @@ def test_dense_and_empty(dev):
 
 
 @pytest.mark.parametrize("C,relu,N", [(16, True, 5000), (64, True, 48000), (128, False, 777), (32, True, 2),
-                                      (256, True, 512), (8, True, 4096), (8, False, 4097)])   # N <= 4096: the one-launch kernels
+                                      (256, True, 512), (8, True, 4096), (8, False, 4097),   # N <= 4096: the one-launch kernels
+                                      (7, True, 512), (30, False, 333)])                    # any width there: a block per channel
 @pytest.mark.parametrize("state", [True, False])
 def test_fused_train_batchnorm_matches_torch(dev, C, relu, N, state, monkeypatch):
     """glx_bn_relu_train_forward / _backward vs nn.BatchNorm1d (+ nn.ReLU) in training mode:
