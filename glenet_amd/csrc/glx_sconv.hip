@@ -1996,6 +1996,48 @@ __global__ __launch_bounds__(256) void k_dense_from_index_nhwc(const float* __re
   reinterpret_cast<f32x4*>(out)[t] = v;
 }
 
+// The same map with the dictionary consulted ONCE per cell: a pixel's C * D values come from D cells, but the kernel
+// above looks a cell up for every output element (256 lookups per pixel at 128 x 2, for 2 cells, 92 % of them empty).
+// Here a block first resolves the D cells of each of its pixels into LDS, then streams the rows out -- an empty
+// pixel costs its zero stores and nothing else.  Needs (C * D / 4) to divide 256 and D <= 4.
+#define DENSE_PIX 64   // pixels per block
+__global__ __launch_bounds__(256) void k_dense_from_index_nhwc_cells(const float* __restrict__ f, int N, int C,
+                                                                     const unsigned long long* __restrict__ bitmap,
+                                                                     const int* __restrict__ prefix,
+                                                                     const int* __restrict__ rank_to_row, GlxGrid g,
+                                                                     float* __restrict__ out) {
+  __shared__ int s_row[DENSE_PIX * 4];
+  const int D = g.D, CD = C * D, q4 = CD >> 2, ppi = 256 / q4;        // pixels per pass of the block
+  const long long npix = (long long)g.B * g.H * g.W;
+  const long long pix0 = (long long)blockIdx.x * DENSE_PIX;
+  for (int i = threadIdx.x; i < DENSE_PIX * D; i += 256) {              // D <= 4: all lookups of the block in flight
+    const long long pix = pix0 + i / D;
+    int rk = -1;
+    if (pix < npix) {
+      const int z = i % D, x = (int)(pix % g.W);
+      const long long t = pix / g.W;
+      const int y = (int)(t % g.H), b = (int)(t / g.H);
+      rk = glx_rank_lookup(bitmap, prefix, g.lin(b, z, y, x));
+      if (rk >= 0 && rank_to_row) rk = rank_to_row[rk];
+      if (rk >= N) rk = -1;
+    }
+    s_row[i] = rk;
+  }
+  __syncthreads();
+  const int sub = threadIdx.x / q4, col = threadIdx.x % q4, j0 = col * 4;
+  for (int lp = sub; lp < DENSE_PIX; lp += ppi) {
+    if (pix0 + lp >= npix) break;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = j0 + e, c = j / D, z = j - c * D;
+      const int rk = s_row[lp * D + z];
+      if (rk >= 0) v[e] = f[(long long)rk * C + c];
+    }
+    reinterpret_cast<f32x4*>(out)[(pix0 + lp) * q4 + col] = v;
+  }
+}
+
 extern "C" int glx_dense_from_index_nhwc(const float* features, int N, int C, const uint64_t* bitmap,
                                          const int32_t* prefix, const int32_t* rank_to_row, int B, int D, int H,
                                          int W, float* out, void* stream) {
@@ -2003,8 +2045,16 @@ extern "C" int glx_dense_from_index_nhwc(const float* features, int N, int C, co
               "glx_dense_from_index_nhwc: bad arguments (C * D must be a multiple of 4)");
   GlxGrid g{B, D, H, W};
   const long long total = (long long)B * H * W * (C * D / 4);
-  hipLaunchKernelGGL(k_dense_from_index_nhwc, dim3((unsigned)glx_divup(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                     features, N, C, (const unsigned long long*)bitmap, (const int*)prefix, rank_to_row, g, out);
+  const int q4 = C * D / 4;
+  if (q4 <= 256 && 256 % q4 == 0 && D <= 4) {
+    const long long npix = (long long)B * H * W;
+    hipLaunchKernelGGL(k_dense_from_index_nhwc_cells, dim3((unsigned)glx_divup(npix, DENSE_PIX)), dim3(256), 0,
+                       (hipStream_t)stream, features, N, C, (const unsigned long long*)bitmap, (const int*)prefix,
+                       rank_to_row, g, out);
+  } else {
+    hipLaunchKernelGGL(k_dense_from_index_nhwc, dim3((unsigned)glx_divup(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       features, N, C, (const unsigned long long*)bitmap, (const int*)prefix, rank_to_row, g, out);
+  }
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
