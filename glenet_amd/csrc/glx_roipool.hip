@@ -22,6 +22,8 @@
 // Empty balls (idx[m,0] < 0) count as ns rows of rel = 0 and feature 0, exactly as the reference's masked tensors.
 #include "glx_common.h"
 #include "glx_fill.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+#define RP_SETS 16
 
 #define RP_THREADS 256
 #define RP_MAX_BLOCKS 512
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(RP_THREADS) void k_rp_backward(const float* __restr
     if (sub == 0) {
       double a = 0;
       for (int k = 0; k < PPB; ++k) a += red[k * C + c];
-      partial[((long long)blockIdx.x * 5 + q) * C + c] = a;
+      unsafeAtomicAdd(partial + ((long long)(blockIdx.x % RP_SETS) * 5 + q) * C + c, a);
     }
     __syncthreads();
   }
@@ -312,8 +314,11 @@ extern "C" int glx_pos_pool_backward(const float* dpooled, const float* pooled, 
     return GLX_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  GlxFillJob zj{dfeats, (size_t)N * C * sizeof(float), 0};
-  int rc = glx_fill_multi(&zj, 1, st);
+  // the blocks add their five per-channel sums to one of RP_SETS accumulator sets with fp64 atomics (zeroed by the
+  // launch that zeroes dfeats): the finalize reads 16 rows instead of one per block (512 x 160 doubles: 25 us)
+  GlxFillJob zj[2] = {{dfeats, (size_t)N * C * sizeof(float), 0},
+                      {workspace, (size_t)RP_SETS * 5 * C * sizeof(double), 0}};
+  int rc = glx_fill_multi(zj, 2, st);
   if (rc != GLX_OK) return rc;
   const int blocks = M > 0 ? rp_blocks(M, C) : 0;
   if (M > 0) {
@@ -327,7 +332,8 @@ extern "C" int glx_pos_pool_backward(const float* dpooled, const float* pooled, 
       hipLaunchKernelGGL((k_rp_backward<64>), dim3(blocks), dim3(RP_THREADS), 0, st, dpooled, pooled, arg, idx, xyz, new_xyz,
                          M, nsample, w_pos, save, dfeats, (double*)workspace);
   }
-  hipLaunchKernelGGL(k_rp_finalize_bwd, dim3(1), dim3(RP_FIN_THREADS), 0, st, (const double*)workspace, blocks, (double)M * nsample,
+  hipLaunchKernelGGL(k_rp_finalize_bwd, dim3(1), dim3(RP_FIN_THREADS), 0, st, (const double*)workspace,
+                     blocks > RP_SETS ? RP_SETS : blocks, (double)M * nsample,
                      moments, w_pos, gamma, save, training, C, dW, dgamma, dbeta);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
