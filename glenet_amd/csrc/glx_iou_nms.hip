@@ -191,6 +191,35 @@ __device__ __forceinline__ bool pbox_far(const PBox& a, const PBox& b) {
   return dx * dx + dy * dy > reach * reach;
 }
 
+// NMS only asks whether IoU > thresh.  A rigorous upper bound of the IoU that costs ~40 flops: along the direction u
+// of the centre difference the intersection cannot be longer than the overlap of the two boxes' projection intervals,
+// across it not wider than the narrower box's projection; so inter <= L * W, and IoU <= inter / (Aa + Ab - inter) is
+// increasing in inter.  Pairs whose bound stays below the threshold (0.1 % margin: the exact routine's own rounding is
+// ~1e-6) cannot set a bit of the suppression matrix and skip the ~600-flop rotated overlap -- at thresh 0.8 that is
+// nine of ten pairs that pass the far-apart test.  Box axes: heading rotates (x, y) to (x c - y s, x s + y c).
+__device__ __forceinline__ bool pbox_iou_below(const PBox& a, const PBox& b, float thresh) {
+  float ux = b.cx - a.cx, uy = b.cy - a.cy;
+  const float d2 = ux * ux + uy * uy;
+  float dist = 0.f;
+  if (d2 > 1e-12f) {
+    const float inv = rsqrtf(d2);
+    dist = d2 * inv;
+    ux *= inv; uy *= inv;
+  } else {
+    ux = 1.f; uy = 0.f;
+  }
+  // half extents along u (h) and across it (w): |u . ex| hx + |u . ey| hy with ex = (c, s), ey = (-s, c)
+  const float pa = fabsf(ux * a.c + uy * a.s), qa = fabsf(uy * a.c - ux * a.s);
+  const float pb_ = fabsf(ux * b.c + uy * b.s), qb = fabsf(uy * b.c - ux * b.s);
+  const float ha = pa * a.hx + qa * a.hy, wa = qa * a.hx + pa * a.hy;
+  const float hb = pb_ * b.hx + qb * b.hy, wb = qb * b.hx + pb_ * b.hy;
+  const float L = fminf(fmaxf(ha + hb - dist, 0.f), 2.f * fminf(ha, hb));
+  float inter = L * 2.f * fminf(wa, wb);
+  inter = fminf(inter, fminf(a.area, b.area)) * 1.001f;
+  const float un = a.area + b.area - inter;
+  return un > 0.f && inter < thresh * un;       // bound / union < thresh  (NaN boxes: false -> exact routine decides)
+}
+
 // (N, M) overlap / IoU matrix in the iou3d_nms convention, one block per 64 x 64 tile: the 128 boxes
 // of the tile are prepared once in LDS (trig per box, not per pair), pairs that are exactly zero by
 // the far-apart test are written as 0 straight away, the survivors are queued and evaluated
@@ -377,7 +406,7 @@ __global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxe
       const int rl = wave * 16 + it, i = r * 64 + rl;
       if (i >= N) break;   // wave-uniform
       const PBox A = pb[i];   // uniform address: one broadcast load
-      const bool pass = jok && j > i && (thresh < 0.f || !pbox_far(A, B));
+      const bool pass = jok && j > i && (thresh < 0.f || (!pbox_far(A, B) && !pbox_iou_below(A, B, thresh)));
       const unsigned long long bal = __ballot(pass);
       if (bal) {
         int base = 0;
@@ -538,7 +567,10 @@ __global__ __launch_bounds__(256) void k_nms_pairs(const PBox* __restrict__ pb, 
       bool pass = false;
       if (e < e1) {
         j = order[e];
-        pass = j > i && !pbox_far(A, pb[j]);
+        if (j > i) {
+          const PBox Bc = pb[j];
+          pass = !pbox_far(A, Bc) && !pbox_iou_below(A, Bc, thresh);
+        }
       }
       const unsigned long long bal = __ballot(pass);
       if (pass) q[qn + __popcll(bal & ((1ull << lane) - 1ull))] = j;
