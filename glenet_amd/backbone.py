@@ -6,10 +6,11 @@ VoxelResBackBone8x :191-232; BatchNorm1d eps=1e-3 momentum=0.01 :73), written ta
 The reference modules themselves also run unmodified on glenet_amd.spconv through
 glenet_amd.dropin; this module is what bench.py and the tests drive.
 """
+import contextlib
+import gc
+import os
 from collections import deque
 from functools import partial
-
-import os
 
 import torch
 from torch import nn
@@ -305,7 +306,7 @@ class StaticFramePipeline:
         torch.cuda.synchronize(self.points.device)
         self.check()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side):
+        with torch.cuda.graph(self.graph, stream=side), no_gc():
             self.enqueue()
         self._tag = self._weights_tag()
         return self
@@ -363,6 +364,22 @@ class StaticFramePipeline:
         """Trim a shape-static SparseConvTensor to its live rows (host sync) for inspection."""
         n = int(st.count.item())
         return st.features[:n], st.indices[:n]
+
+
+@contextlib.contextmanager
+def no_gc():
+    """No cyclic garbage collection while a stream is being captured.  A collection that happens to run in the middle
+    of a capture may finalise an OLDER pipeline (pipelines are reference cycles: they only ever die in the collector),
+    and destroying its hipGraphExec / releasing its memory pool is not allowed while another capture is open -- the
+    process aborts (seen once in ~10 runs of the GPU tests, always inside capture()).  torch.cuda.graph collects
+    on entry; with the collector off nothing but reference counts frees objects until the capture has ended."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 PREPACK_WEIGHTS = os.environ.get("GLX_PREPACK", "1") != "0"

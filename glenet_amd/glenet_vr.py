@@ -380,7 +380,7 @@ class StaticTrainStep(gb.StaticTrainPipeline):
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             self.update_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.update_graph, stream=side):
+            with torch.cuda.graph(self.update_graph, stream=side), gb.no_gc():
                 self.update()
         return self
 
