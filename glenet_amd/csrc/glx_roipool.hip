@@ -24,6 +24,7 @@
 #include "glx_fill.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 #define RP_SETS 16
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define RP_THREADS 256
 #define RP_MAX_BLOCKS 512
@@ -127,52 +128,67 @@ __global__ __launch_bounds__(RP_FIN_THREADS) void k_rp_finalize_fwd(
 }
 
 // forward: lanes = channels; a wave covers 64 / C grid points per pass
+// Lanes = (grid point, float4 of channels): C / 4 lanes per point, 64 / (C / 4) points per wave -- with a lane per
+// channel a wave had two points in flight and the kernel was one L2 latency per 2 x 16 rows (0.7 TB/s of gathers).
 template <int C>
 __global__ __launch_bounds__(RP_THREADS) void k_rp_forward(const float* __restrict__ feats, const float* __restrict__ xyz,
                                                            const float* __restrict__ new_xyz, const int* __restrict__ idx,
                                                            int M, int ns, const float* __restrict__ save,
                                                            float* __restrict__ pooled, unsigned char* __restrict__ arg) {
-  constexpr int PPB = RP_THREADS / C;          // grid points per block pass
-  const int c = threadIdx.x % C, sub = threadIdx.x / C;
-  const float wx = save[2 * C + c * 3], wy = save[2 * C + c * 3 + 1], wz = save[2 * C + c * 3 + 2], b = save[5 * C + c];
+  constexpr int Q = C / 4;                     // lanes per grid point
+  constexpr int PPB = RP_THREADS / Q;          // grid points per block pass
+  const int q = threadIdx.x % Q, sub = threadIdx.x / Q;
+  float wx[4], wy[4], wz[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = 4 * q + i;
+    wx[i] = save[2 * C + c * 3]; wy[i] = save[2 * C + c * 3 + 1]; wz[i] = save[2 * C + c * 3 + 2]; b[i] = save[5 * C + c];
+  }
   for (long long m = (long long)blockIdx.x * PPB + sub; m < M; m += (long long)gridDim.x * PPB) {
     const int* row = idx + m * ns;
-    float best = -1.f;
-    int bi = 0;
-    if (row[0] < 0) {
-      best = fmaxf(b, 0.f);                    // every slot holds feature 0 and rel 0
+    float best[4] = {-1.f, -1.f, -1.f, -1.f};
+    int bi[4] = {0, 0, 0, 0};
+    const int r0 = row[0];
+    if (r0 < 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) best[i] = fmaxf(b[i], 0.f);      // every slot holds feature 0 and rel 0
     } else {
       const float qx = new_xyz[m * 3], qy = new_xyz[m * 3 + 1], qz = new_xyz[m * 3 + 2];
       // The query pads a ball with fewer than ns voxels by repeating its first hit (voxel_query_gpu.cu:75-86); the
       // repeats can never win the strict `>` below, so the scan stops at the first of them -- on LiDAR surfaces a
       // ball holds 4-6 voxels of 16, which is most of this kernel's gather traffic.
-      const int r0 = row[0];
       bool more = true;
-      for (int s0 = 0; s0 < ns && more; s0 += 8) {     // 8 row gathers in flight
-        float f[8], x[8], y[8], z[8];
+      for (int s0 = 0; s0 < ns && more; s0 += 4) {     // 4 row gathers in flight per lane
+        f32x4 f[4];
+        float x[4], y[4], z[4];
         int live = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 4; ++j) {
           const int r = s0 + j < ns ? row[s0 + j] : r0;
           const bool ok = more && s0 + j < ns && (s0 + j == 0 || r != r0);
-          more = ok;                             // wave-uniform per grid point: all lanes of a point read the same row
+          more = ok;                             // uniform per grid point: its lanes read the same row
           if (ok) {
-            f[j] = feats[(long long)r * C + c];
+            f[j] = *reinterpret_cast<const f32x4*>(feats + (long long)r * C + 4 * q);
             x[j] = xyz[(long long)r * 3]; y[j] = xyz[(long long)r * 3 + 1]; z[j] = xyz[(long long)r * 3 + 2];
             live = j + 1;
           }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 4; ++j) {
           if (j >= live) break;
-          const float p = (x[j] - qx) * wx + (y[j] - qy) * wy + (z[j] - qz) * wz + b;
-          const float v = fmaxf(f[j] + p, 0.f);
-          if (v > best) { best = v; bi = s0 + j; }
+          const float dx = x[j] - qx, dy = y[j] - qy, dz = z[j] - qz;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float p = dx * wx[i] + dy * wy[i] + dz * wz[i] + b[i];
+            const float v = fmaxf(f[j][i] + p, 0.f);
+            if (v > best[i]) { best[i] = v; bi[i] = s0 + j; }
+          }
         }
       }
     }
-    pooled[m * C + c] = best;
-    arg[m * C + c] = (unsigned char)bi;
+    *reinterpret_cast<f32x4*>(pooled + m * C + 4 * q) = f32x4{best[0], best[1], best[2], best[3]};
+    *reinterpret_cast<uchar4*>(arg + m * C + 4 * q) =
+        make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
   }
 }
 
@@ -285,7 +301,8 @@ extern "C" int glx_pos_pool_forward(const float* feats, int N, int C, const floa
                      (double)M * nsample, w_pos, gamma, beta, eps, momentum, training, running_mean, running_var, C, save,
                      moments);
   if (M > 0) {
-    const int blocks = rp_blocks(M, C);
+    const int ppb_f = RP_THREADS / (C / 4);
+    const int blocks = (int)(((long long)M + ppb_f - 1) / ppb_f > 4096 ? 4096 : ((long long)M + ppb_f - 1) / ppb_f);
     if (C == 16)
       hipLaunchKernelGGL((k_rp_forward<16>), dim3(blocks), dim3(RP_THREADS), 0, st, feats, xyz, new_xyz, idx, M, nsample,
                          (const float*)save, pooled, arg);
