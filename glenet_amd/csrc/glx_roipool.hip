@@ -202,40 +202,106 @@ __global__ __launch_bounds__(RP_THREADS) void k_rp_backward(const float* __restr
                                                             const float* __restrict__ new_xyz, int M, int ns,
                                                             const float* __restrict__ w, const float* __restrict__ save,
                                                             float* __restrict__ dfeats, double* __restrict__ partial) {
-  constexpr int PPB = RP_THREADS / C;
-  const int c = threadIdx.x % C, sub = threadIdx.x / C;
-  const float w0 = w[c * 3], w1 = w[c * 3 + 1], w2 = w[c * 3 + 2];
-  const float mean = save[c], invstd = save[C + c];
-  double s[5] = {0, 0, 0, 0, 0};
-  for (long long m = (long long)blockIdx.x * PPB + sub; m < M; m += (long long)gridDim.x * PPB) {
-    const float g = pooled[m * C + c] > 0.f ? dpooled[m * C + c] : 0.f;
-    if (g == 0.f) continue;
-    const int* row = idx + m * ns;
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (row[0] >= 0) {
-      const long long r = row[arg[m * C + c]];
-      x = xyz[r * 3] - new_xyz[m * 3];
-      y = xyz[r * 3 + 1] - new_xyz[m * 3 + 1];
-      z = xyz[r * 3 + 2] - new_xyz[m * 3 + 2];
-      atomicAdd(dfeats + r * C + c, g);
-    }
-    const float xh = (x * w0 + y * w1 + z * w2 - mean) * invstd;
-    s[0] += g;
-    s[1] += (double)g * xh;
-    s[2] += (double)g * x;
-    s[3] += (double)g * y;
-    s[4] += (double)g * z;
+  // lanes = (grid point, float4 of channels) as in the forward kernel: four winners' rows in flight per lane
+  constexpr int Q = C / 4, PPB = RP_THREADS / Q, PPW = 64 / Q;        // lanes per point, points per block / wave
+  const int q = threadIdx.x % Q, sub = threadIdx.x / Q;
+  float w0[4], w1[4], w2[4], mean[4], invstd[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = 4 * q + i;
+    w0[i] = w[c * 3]; w1[i] = w[c * 3 + 1]; w2[i] = w[c * 3 + 2];
+    mean[i] = save[c]; invstd[i] = save[C + c];
   }
-  __shared__ double red[RP_THREADS];
-  for (int q = 0; q < 5; ++q) {
-    red[threadIdx.x] = s[q];
-    __syncthreads();
-    if (sub == 0) {
-      double a = 0;
-      for (int k = 0; k < PPB; ++k) a += red[k * C + c];
-      unsafeAtomicAdd(partial + ((long long)(blockIdx.x % RP_SETS) * 5 + q) * C + c, a);
+  double s[4][5];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s[i][k] = 0;
+  const int lane = threadIdx.x & 63;
+  for (long long m = (long long)blockIdx.x * PPB + sub; m < M; m += (long long)gridDim.x * PPB) {
+    // all PPW points of this wave's pass exist <=> the last one does (points of a wave are consecutive)
+    const bool wave_full = m - (sub % PPW) + (PPW - 1) < M;
+    const f32x4 pv = *reinterpret_cast<const f32x4*>(pooled + m * C + 4 * q);
+    const f32x4 dv = *reinterpret_cast<const f32x4*>(dpooled + m * C + 4 * q);
+    float g[4];
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { g[i] = pv[i] > 0.f ? dv[i] : 0.f; any |= g[i] != 0.f; }
+    // no `continue` before the shuffles below: the lanes of a wave stay together
+    const int* row = idx + m * ns;
+    const bool filled = any && row[0] >= 0;
+    float x[4] = {0.f, 0.f, 0.f, 0.f}, y[4] = {0.f, 0.f, 0.f, 0.f}, z[4] = {0.f, 0.f, 0.f, 0.f};
+    int r[4] = {-1, -1, -1, -1};
+    if (filled) {
+      const uchar4 av = *reinterpret_cast<const uchar4*>(arg + m * C + 4 * q);
+      const unsigned char a4[4] = {av.x, av.y, av.z, av.w};
+      const float qx = new_xyz[m * 3], qy = new_xyz[m * 3 + 1], qz = new_xyz[m * 3 + 2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = g[i] != 0.f ? row[a4[i]] : -1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (r[i] < 0) continue;
+        x[i] = xyz[(long long)r[i] * 3] - qx;
+        y[i] = xyz[(long long)r[i] * 3 + 1] - qy;
+        z[i] = xyz[(long long)r[i] * 3 + 2] - qz;
+      }
     }
-    __syncthreads();
+    // neighbouring grid points of a RoI mostly crown the same voxel: the points of a wave that share a winner add
+    // their gradients first and send ONE atomic (the feature rows near a box are hot spots of the L2 atomic units)
+    if (wave_full) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float acc = r[i] >= 0 ? g[i] : 0.f;
+        bool leader = r[i] >= 0;
+#pragma unroll
+        for (int off = Q; off < 64; off += Q) {
+          const int src = (lane + off) & 63;
+          const int ro = __shfl(r[i], src, 64);
+          const float go = __shfl(g[i], src, 64);
+          if (r[i] >= 0 && ro == r[i]) {
+            acc += go;
+            if (src < lane) leader = false;
+          }
+        }
+        if (leader) atomicAdd(dfeats + (long long)r[i] * C + 4 * q + i, acc);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (r[i] >= 0) atomicAdd(dfeats + (long long)r[i] * C + 4 * q + i, g[i]);
+    }
+    if (!any) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (g[i] == 0.f) continue;
+      const float xh = (x[i] * w0[i] + y[i] * w1[i] + z[i] * w2[i] - mean[i]) * invstd[i];
+      s[i][0] += g[i];
+      s[i][1] += (double)g[i] * xh;
+      s[i][2] += (double)g[i] * x[i];
+      s[i][3] += (double)g[i] * y[i];
+      s[i][4] += (double)g[i] * z[i];
+    }
+  }
+  // sums over the points of the wave (lanes with the same q) by shuffles, over the 4 waves in LDS
+#pragma unroll
+  for (int off = Q; off < 64; off <<= 1)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) s[i][k] += __shfl_xor(s[i][k], off, 64);
+  __shared__ double red[RP_THREADS / 64][16][4][5];        // [wave][q][i][quantity], Q <= 16
+  const int wave = threadIdx.x >> 6;
+  if (lane < Q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) red[wave][lane][i][k] = s[i][k];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 5 * C; e += RP_THREADS) {       // e = k * C + c
+    const int k = e / C, c = e - k * C;
+    double a = 0;
+    for (int wv = 0; wv < RP_THREADS / 64; ++wv) a += red[wv][c >> 2][c & 3][k];
+    unsafeAtomicAdd(partial + ((long long)(blockIdx.x % RP_SETS) * 5 + k) * C + c, a);
   }
 }
 
@@ -337,7 +403,8 @@ extern "C" int glx_pos_pool_backward(const float* dpooled, const float* pooled, 
                       {workspace, (size_t)RP_SETS * 5 * C * sizeof(double), 0}};
   int rc = glx_fill_multi(zj, 2, st);
   if (rc != GLX_OK) return rc;
-  const int blocks = M > 0 ? rp_blocks(M, C) : 0;
+  const int ppb_b = RP_THREADS / (C / 4);
+  const int blocks = M > 0 ? (int)(((long long)M + ppb_b - 1) / ppb_b > 4096 ? 4096 : ((long long)M + ppb_b - 1) / ppb_b) : 0;
   if (M > 0) {
     if (C == 16)
       hipLaunchKernelGGL((k_rp_backward<16>), dim3(blocks), dim3(RP_THREADS), 0, st, dpooled, pooled, arg, idx, xyz, new_xyz,
