@@ -50,9 +50,18 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adamw(float* __restrict__ p, co
                                                        const double* __restrict__ partial, int nparts,
                                                        float* __restrict__ norm_out) {
   __shared__ float s_coef;
+  __shared__ double s_wave[OPT_THREADS / 64];
+  // every block folds the partials the same way (thread t takes parts t, t + 256, ...; waves by shuffles, then in
+  // order): the same clip coefficient everywhere, and not a 900-step serial chain in front of every block's work
+  double mine = 0;
+  for (int i = threadIdx.x; i < nparts; i += OPT_THREADS) mine += partial[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+  if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = mine;
+  __syncthreads();
   if (threadIdx.x == 0) {
     double s = 0;
-    for (int i = 0; i < nparts; ++i) s += partial[i];
+    for (int i = 0; i < OPT_THREADS / 64; ++i) s += s_wave[i];
     const float total = (float)sqrt(s);
     float coef = 1.f;
     if (max_norm > 0.f) {                       // clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
