@@ -147,6 +147,13 @@ for f, w, nbr, order, n_out, rules in calls:
     if os.environ.get("GEMM"):
         print("  setup before the loop: %.0f cycles; steps per block %.1f; per-step cycles %.0f"
               % (wv[:, :, 6].mean(), wv[:, :, 7].mean(), tot.mean() / max(wv[:, :, 7].mean(), 1)))
+        # clock64 counts shader cycles, the block start / end are 100 MHz wall ticks: cycles of the loop over
+        # its wall time = the clock the CUs ran at (the epilogue after the loop is in the wall time: lower bound)
+        setup_us = wv[:, 0, 6] / 22.0 / 100.0
+        loop_us = np.maximum(dur - setup_us, 1e-3)
+        print("  setup %.1f us of a block's %.1f us; loop cycles / loop wall time = %.2f GHz (p10 %.2f p90 %.2f)"
+              % (setup_us.mean(), dur.mean(), (tot[:, 0] / loop_us / 1e3).mean(),
+                 np.percentile(tot[:, 0] / loop_us / 1e3, 10), np.percentile(tot[:, 0] / loop_us / 1e3, 90)))
         continue
     print("  multiply cycles per chunk (waves with chunks): %.0f = wait for rows %.0f + MFMA loop %.0f + accumulate %.0f"
           % (ph[:, :, 1].sum() / nch, wv[:, :, 6].sum() / nch, wv[:, :, 7].sum() / nch,
