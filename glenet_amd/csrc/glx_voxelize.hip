@@ -237,12 +237,13 @@ extern "C" int glx_voxelize_hard(const float* points, const int32_t* point_batch
                                  int32_t* idx_prefix, int32_t* idx_rank_to_row,
                                  int32_t* idx_n_unique, void* workspace, size_t workspace_bytes,
                                  void* stream) {
-  GLX_REQUIRE(points && vrange && vsize && voxels && coords && num_points && voxel_offset,
+  // an empty cloud (P == 0: no point buffer to speak of) is a valid input: zero voxels, offsets all zero
+  GLX_REQUIRE((points || P == 0) && vrange && vsize && voxels && coords && num_points && voxel_offset,
               "glx_voxelize_hard: null pointer");
   GLX_REQUIRE(P >= 0 && C >= 3 && B >= 1 && gx > 0 && gy > 0 && gz > 0 && max_points > 0 &&
                   max_voxels > 0,
               "glx_voxelize_hard: bad sizes");
-  GLX_REQUIRE(B == 1 || point_batch, "glx_voxelize_hard: point_batch required when B > 1");
+  GLX_REQUIRE(B == 1 || point_batch || P == 0, "glx_voxelize_hard: point_batch required when B > 1");
   HardWs w = hard_ws_layout(workspace, P, B, gx, gy, gz, max_points, max_voxels);
   if (!workspace || workspace_bytes < w.bytes) {
     glx_set_error("glx_voxelize_hard: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
@@ -399,11 +400,11 @@ extern "C" int glx_voxelize_dynamic_mean(const float* points, const int32_t* poi
                                          int gx, int gy, int gz, float* features, int32_t* coords,
                                          int32_t* n_voxels, void* workspace,
                                          size_t workspace_bytes, void* stream) {
-  GLX_REQUIRE(points && vrange && vsize && features && coords && n_voxels,
+  GLX_REQUIRE((points || P == 0) && vrange && vsize && features && coords && n_voxels,
               "glx_voxelize_dynamic_mean: null pointer");
   GLX_REQUIRE(P >= 0 && C >= 3 && B >= 1 && gx > 0 && gy > 0 && gz > 0,
               "glx_voxelize_dynamic_mean: bad sizes");
-  GLX_REQUIRE(B == 1 || point_batch, "glx_voxelize_dynamic_mean: point_batch required when B > 1");
+  GLX_REQUIRE(B == 1 || point_batch || P == 0, "glx_voxelize_dynamic_mean: point_batch required when B > 1");
   DynWs w = dyn_ws_layout(workspace, P, B, gx, gy, gz);
   if (!workspace || workspace_bytes < w.bytes) {
     glx_set_error("glx_voxelize_dynamic_mean: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
@@ -458,8 +459,9 @@ __global__ void k_mean_vfe(const float* __restrict__ voxels, const int* __restri
 
 extern "C" int glx_mean_vfe(const float* voxels, const int32_t* num_points, int Nv, int max_points,
                             int C, float* out, const int32_t* n_live, void* stream) {
-  GLX_REQUIRE(voxels && num_points && out && max_points > 0 && C > 0, "glx_mean_vfe: bad arguments");
-  if (Nv == 0) return GLX_OK;
+  GLX_REQUIRE(Nv >= 0 && max_points > 0 && C > 0, "glx_mean_vfe: bad sizes");
+  if (Nv == 0) return GLX_OK;   // no voxels: the (empty) buffers may be null
+  GLX_REQUIRE(voxels && num_points && out, "glx_mean_vfe: null pointer");
   long long total = (long long)Nv * C;
   hipLaunchKernelGGL(k_mean_vfe, dim3(glx_divup(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      voxels, num_points, Nv, max_points, C, out, n_live);

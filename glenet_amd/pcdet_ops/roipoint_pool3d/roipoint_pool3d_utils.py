@@ -9,7 +9,7 @@ from . import roipoint_pool3d_cuda
 def enlarge_box3d(boxes3d, extra_width=(0, 0, 0)):
     """pcdet/utils/box_utils.py:145-158: grow dx, dy, dz by extra_width."""
     big = boxes3d.clone()
-    big[:, 3:6] += boxes3d.new_tensor(extra_width)[None, :]
+    big[:, 3:6] += boxes3d.new_tensor(extra_width).reshape(1, -1)    # a triple (the configs') or one width for all
     return big
 
 
