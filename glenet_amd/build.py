@@ -13,6 +13,7 @@ LIB = os.path.join(CSRC, "libglenet_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+FLAGS += os.environ.get("GLX_HIPCC_EXTRA", "").split()      # experiments: e.g. -DBN_THREADS=512
 
 
 HOST_SRC = os.path.join(CSRC, "host", "glx_host.cpp")

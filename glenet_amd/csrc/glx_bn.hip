@@ -19,7 +19,12 @@ __device__ __forceinline__ float bn_shift(float beta, float mean, float invstd, 
 }
 __device__ __forceinline__ float bn_affine(float x, float scale, float shift) { return __fmaf_rn(x, scale, shift); }
 
-#define BN_THREADS 256
+// 512 threads: a statistics block keeps 8 (forward) or 2 x 4 (backward) 16-byte loads per thread in flight, 64 KB per CU
+// with one block per CU -- with 256 threads (32 KB per CU) the 72 MB layers read at 3.6-4 TB/s; measured on the training
+// step 11.99 / 11.89 ms at 256 against 11.80 at 512 (-DBN_THREADS=... through GLX_HIPCC_EXTRA to repeat it)
+#ifndef BN_THREADS
+#define BN_THREADS 512
+#endif
 #define BN_MAXC 512
 #define BN_SLABS 256   // row slabs = blocks of the statistics kernels (one per CU) on the fixed-order path
 // with a state buffer the slab count is free, but more blocks did not pay: measured on the training step (caps of the
