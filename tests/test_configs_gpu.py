@@ -6,7 +6,9 @@
   * configs[4]: a Waymo-shaped shard at full size (2 x 180 000 points, VoxelResBackBone8x) through the
     size-independent properties the domain offers: voxel coordinates unique / in range / first-seen order equal
     to the oracle's voxelizer (cheap at this size), every output cell of a strided conv has an active input
-    in its window, the shape-static graph equals the exact-shape path, duplicated frames give duplicated rows."""
+    in its window, the shape-static graph equals the exact-shape path, duplicated frames give duplicated rows.  * configs[1]: the sparse convolutions' VALUES on the full-size active sets (4 x 20 000 points) against torch's dense
+    conv3d on a window, plus linearity and the two adjoint identities.
+"""
 import os
 
 import numpy as np
@@ -194,3 +196,75 @@ def test_bev_backbone_training_nhwc_fused_bn_equals_torch_path(dev):
                                    atol=1e-7 + 2e-4 * float(p2[k].abs().max()), err_msg=k)
     for k in b1:
         np.testing.assert_allclose(b1[k].cpu().numpy(), b2[k].cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+def test_config1_full_size_sparse_conv_values(dev):
+    """configs[1] at its full size (4 frames x 20 000 points): the values of the sparse convolutions on the real active sets,
+    checked without the oracle (it would take minutes here) by what does not depend on the size --
+      * an independent formulation: torch's dense conv3d on a 41 x 128 x 128 window of frame 0, compared at every
+        active output cell whose receptive field lies inside the window (submanifold and strided conv);
+      * linearity in the features;  * <conv(x), g> = <x, dgrad(g)> and <dW, V> = <conv_V(x), g> (fp64 inner products)."""
+    from glenet_amd.spconv import core as sp
+    K = synth.KITTI
+    frames = [synth.kitti_frame(1000 + i)[0] for i in range(4)]
+    pts = torch.from_numpy(np.concatenate(frames)).to(dev)
+    bidx = torch.from_numpy(np.concatenate([np.full(len(f), i, np.int32) for i, f in enumerate(frames)])).to(dev)
+    grid = oracle.grid_size_of(K["point_cloud_range"], K["voxel_size"])
+    with torch.no_grad():
+        bd = gb.MeanVFE()(gb.voxelize_batch(pts, bidx, 4, K))
+    coords = bd["voxel_coords"]
+    shape = [grid[2] + 1, grid[1], grid[0]]
+    assert coords.shape[0] > 50000
+    torch.manual_seed(3)
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    y0, x0, win = 736, 0, 128                                        # window of frame 0 next to the sensor
+    for cin, cout, subm in ((16, 16, True), (16, 32, False), (64, 64, True)):
+        feats = torch.randn((coords.shape[0], cin), generator=gen).to(dev)
+        if subm:
+            conv = sp.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key="p%d" % cin).to(dev)
+        else:
+            conv = sp.SparseConv3d(cin, cout, 3, stride=2, padding=1, bias=False, indice_key="q%d" % cin).to(dev)
+        x = sp.SparseConvTensor(feats.clone().requires_grad_(True), coords, shape, 4)
+        y = conv(x)
+        out_idx = y.indices.long()
+        # ---- dense conv3d on the window
+        c = coords.long()
+        inw = (c[:, 0] == 0) & (c[:, 2] >= y0) & (c[:, 2] < y0 + win) & (c[:, 3] >= x0) & (c[:, 3] < x0 + win)
+        assert int(inw.sum()) > 3000
+        dense = torch.zeros((1, cin, shape[0], win, win), device=dev)
+        ci = c[inw]
+        dense[0, :, ci[:, 1], ci[:, 2] - y0, ci[:, 3] - x0] = feats[inw].t()
+        wt = conv.weight.detach().permute(4, 3, 0, 1, 2).contiguous()
+        s = 1 if subm else 2
+        ref = torch.nn.functional.conv3d(dense, wt, stride=s, padding=1)
+        o = out_idx
+        # output cell (z, y, x) reads inputs s*o - 1 .. s*o + 1: inside the window when 1 <= s*(o - origin/s) <= win - 2
+        oy, ox = o[:, 2] * s - y0, o[:, 3] * s - x0
+        inside = (o[:, 0] == 0) & (oy >= 1) & (oy <= win - 2) & (ox >= 1) & (ox <= win - 2)
+        assert int(inside.sum()) > 1000
+        oi = o[inside]
+        want = ref[0, :, oi[:, 1], (oi[:, 2] * s - y0) // s, (oi[:, 3] * s - x0) // s].t()
+        got = y.features.detach()[inside]
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-4, atol=2e-4)
+        # ---- linearity
+        with torch.no_grad():
+            f2 = torch.randn((coords.shape[0], cin), generator=gen).to(dev)
+            y2 = conv(sp.SparseConvTensor(f2, coords, shape, 4)).features
+            y3 = conv(sp.SparseConvTensor(2.0 * feats - 3.0 * f2, coords, shape, 4)).features
+        np.testing.assert_allclose(y3.cpu().numpy(), (2.0 * y.features.detach() - 3.0 * y2).cpu().numpy(), rtol=1e-4, atol=2e-4)
+        # ---- adjoints (fp64 inner products)
+        g = torch.randn(y.features.shape, generator=gen).to(dev)
+        y.features.backward(g)
+        lhs = float((y.features.detach().double() * g.double()).sum())
+        rhs = float((feats.double() * x.features.grad.double()).sum())
+        assert abs(lhs - rhs) <= 1e-5 * (abs(lhs) + float(y.features.detach().double().abs().mul(g.double().abs()).sum()) * 1e-2), (lhs, rhs)
+        v = torch.randn(conv.weight.shape, generator=gen).to(dev)
+        dwv = float((conv.weight.grad.double() * v.double()).sum())
+        with torch.no_grad():
+            w0 = conv.weight.detach().clone()
+            conv.weight.copy_(v)
+            yv = conv(sp.SparseConvTensor(feats, coords, shape, 4)).features
+            conv.weight.copy_(w0)
+        ref_dwv = float((yv.double() * g.double()).sum())
+        scale = float((yv.double().abs() * g.double().abs()).sum())
+        assert abs(dwv - ref_dwv) <= 1e-5 * scale, (dwv, ref_dwv, scale)
