@@ -6,7 +6,8 @@
   * configs[4]: a Waymo-shaped shard at full size (2 x 180 000 points, VoxelResBackBone8x) through the
     size-independent properties the domain offers: voxel coordinates unique / in range / first-seen order equal
     to the oracle's voxelizer (cheap at this size), every output cell of a strided conv has an active input
-    in its window, the shape-static graph equals the exact-shape path, duplicated frames give duplicated rows.  * configs[1]: the sparse convolutions' VALUES on the full-size active sets (4 x 20 000 points) against torch's dense
+    in its window, the shape-static graph equals the exact-shape path, duplicated frames give duplicated rows.
+  * configs[1]: the sparse convolutions' VALUES on the full-size active sets (4 x 20 000 points) against torch's dense
     conv3d on a window, plus linearity and the two adjoint identities.
 """
 import os
