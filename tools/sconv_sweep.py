@@ -65,6 +65,18 @@ for f, w, nbr, order, n_out, rules in calls:
             if not torch.equal(got, ref_out):
                 print("  !! variant %d differs from the default on %s: max |d| %.3g" % (
                     v, key, float((got - ref_out).abs().max())))
+            if os.environ.get("WALL"):
+                # variants made of several launches: stream time of 20 back-to-back calls (launch gaps included)
+                for rep in range(5):
+                    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    t0.record()
+                    for it in range(20):
+                        orig(f, w, None, nbr, order, n_out, packed=packed)
+                    t1.record()
+                    torch.cuda.synchronize()
+                    ts.append(t0.elapsed_time(t1) * 1e3 / 20)
+                row.append(float(np.median(ts[1:])))
+                continue
             for it in range(12):
                 s, e = ev(), ev()
                 _lib.call_nostream("glx_profile_next_sconv", s, e)
