@@ -9,8 +9,13 @@ care: a checkpoint holds whichever layout the spconv version it was trained with
     spconv 2.x implicit  (C_out, k1, k2, k3, C_in)
 (the reference converts 1.x -> 2.x with transpose(-1, -2) / permute(4, 0, 1, 2, 3), lines 377-384; here the model is
 the 1.x side, so the inverse maps are applied).  A square 2.x-native weight (C_in == C_out) has the same shape as a 1.x
-one -- pass layout="spconv2_native" for such checkpoints; "auto" resolves everything that shapes can tell apart and
-takes same-shape tensors as they are, exactly as the reference does."""
+one, so the layout is a property of the CHECKPOINT, never of a tensor: layout="auto" infers it ONCE from the weights
+whose shapes can tell the layouts apart (every reference backbone has non-square ones: 4->16, 16->32, ...) and applies
+it to all of them; checkpoints whose evidence disagrees are refused, checkpoints without any evidence (only square
+k x k x k x C x C weights) are taken as 1.x with a warning.  (The reference decides per tensor and silently mixes layouts
+in that situation -- its blind spot is not reproduced.)"""
+import warnings
+
 import torch
 
 from . import spconv
@@ -43,17 +48,43 @@ def to_spconv1_layout(val, want_shape, layout="auto"):
     elif layout == "spconv2_implicit":
         cands = [implicit]
     else:
-        cands = [val, native, implicit]
+        raise ValueError("to_spconv1_layout converts from one named layout; resolve 'auto' with infer_layout")
     for c in cands:
         if tuple(c.shape) == want_shape:
             return c.contiguous()
     return None
 
 
+def infer_layout(model, state):
+    """The spconv layout a checkpoint was written in, from the sparse-conv weights whose shape fits exactly one
+    layout.  Raises when two weights point at different layouts; returns "spconv1" (with a warning) when nothing
+    in the checkpoint can tell."""
+    own = model.state_dict()
+    votes = {}
+    for key in sorted(find_all_spconv_keys(model)):
+        if key not in state or state[key].dim() != 5:
+            continue
+        fits = [name for name in LAYOUTS[1:] if to_spconv1_layout(state[key], own[key].shape, name) is not None]
+        if len(fits) == 1:
+            votes.setdefault(fits[0], []).append(key)
+    if len(votes) > 1:
+        raise ValueError("checkpoint mixes sparse-conv weight layouts: %s"
+                         % {k: v[:2] for k, v in votes.items()})
+    if votes:
+        return next(iter(votes))
+    if any(k in state for k in find_all_spconv_keys(model)):
+        warnings.warn("no sparse-conv weight of this checkpoint identifies its spconv layout (all are square); "
+                      "taking it as spconv 1.x -- pass layout= explicitly if it was written by spconv 2.x")
+    return "spconv1"
+
+
 def adapt_state_dict(model, state, layout="auto"):
-    """-> {name: tensor} with every entry of `state` that has a home in `model`, sparse-conv weights converted."""
+    """-> {name: tensor} with every entry of `state` that has a home in `model`, sparse-conv weights converted
+    from ONE layout (given, or inferred once per checkpoint by infer_layout)."""
     if layout not in LAYOUTS:
         raise ValueError("layout must be one of %s" % (LAYOUTS,))
+    if layout == "auto":
+        layout = infer_layout(model, state)
     own = model.state_dict()
     conv_keys = find_all_spconv_keys(model)
     out = {}

@@ -937,21 +937,40 @@ __device__ __forceinline__ FpsBest fps_pick(FpsBest a, FpsBest b) {
   return (b.v > a.v || (b.v == a.v && b.t < a.t)) ? b : a;
 }
 
+// Frames of a launch: stacked (per-frame counts on the device, GLOBAL output indices) or the batch layout of
+// pointnet2_batch (B equal frames of uni_n points, uni_m samples each, indices LOCAL to the frame).
+// tie_mod = the block size the reference would have launched (opt_n_threads(n), cuda_utils.h:9-13): among equal
+// maxima its winner has the smallest k mod tie_mod, then the smallest k.
+struct FpsFrames {
+  const int* cnt;
+  const int* num;
+  int uni_n, uni_m, tie_mod;
+};
+
 template <bool REGS>
 __global__ __launch_bounds__(FPS_THREADS) void k_stack_fps(
-    int B, const float* __restrict__ xyz, const int* __restrict__ xyz_batch_cnt,
-    float* __restrict__ temp, const int* __restrict__ num_sampled, int* __restrict__ idxs) {
+    int B, const float* __restrict__ xyz, FpsFrames fr,
+    float* __restrict__ temp, int* __restrict__ idxs) {
   __shared__ float s_v[FPS_THREADS / 64];
   __shared__ int s_i[FPS_THREADS / 64];
+  __shared__ int s_key[FPS_THREADS / 64];
   __shared__ float s_x[FPS_THREADS / 64], s_y[FPS_THREADS / 64], s_z[FPS_THREADS / 64];
   __shared__ float s_pt[3];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   long long start = 0, ostart = 0;
-  for (int k = 0; k < b; ++k) { start += xyz_batch_cnt[k]; ostart += num_sampled[k]; }
+  int n, m;
+  if (fr.cnt) {
+    for (int k = 0; k < b; ++k) { start += fr.cnt[k]; ostart += fr.num[k]; }
+    n = fr.cnt[b]; m = fr.num[b];
+  } else {
+    start = (long long)b * fr.uni_n; ostart = (long long)b * fr.uni_m;
+    n = fr.uni_n; m = fr.uni_m;
+  }
+  const int obase = fr.cnt ? (int)start : 0;
+  const bool plain_ties = fr.tie_mod >= FPS_THREADS;
   const float* X = xyz + start * 3;
   float* T = temp + start;
   int* O = idxs + ostart;
-  const int n = xyz_batch_cnt[b], m = num_sampled[b];
   if (m <= 0 || n <= 0) return;
   // the register-resident form holds FPS_THREADS * FPS_DPT points: a frame with more (the host's max_points hint
   // was stale or too small) takes the global-memory loop instead of silently ignoring its tail
@@ -967,7 +986,7 @@ __global__ __launch_bounds__(FPS_THREADS) void k_stack_fps(
     }
   }
   if (tid == 0) {
-    O[0] = (int)start;
+    O[0] = obase;
     s_pt[0] = X[0]; s_pt[1] = X[1]; s_pt[2] = X[2];
   }
   __syncthreads();
@@ -997,7 +1016,17 @@ __global__ __launch_bounds__(FPS_THREADS) void k_stack_fps(
     float vmax = best.v;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-    const int win = __ffsll((long long)__ballot(best.v == vmax)) - 1;
+    int win, wkey = tid;
+    if (plain_ties) {
+      win = __ffsll((long long)__ballot(best.v == vmax)) - 1;
+    } else {
+      // fewer reference threads than ours (n < 1024: one point per thread here): order the tied threads as
+      // the reference's block would -- (thread of the point there = tid mod tie_mod, then the point index)
+      wkey = best.v == vmax ? (((tid % fr.tie_mod) << 10) | tid) : 0x7fffffff;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) wkey = min(wkey, __shfl_xor(wkey, o, 64));
+      win = wkey & 63;
+    }
     if (lane == win) {
       float cx, cy, cz;
       if (regs) {
@@ -1009,7 +1038,7 @@ __global__ __launch_bounds__(FPS_THREADS) void k_stack_fps(
       } else {
         cx = X[best.i * 3]; cy = X[best.i * 3 + 1]; cz = X[best.i * 3 + 2];
       }
-      s_v[wave] = best.v; s_i[wave] = best.i;
+      s_v[wave] = best.v; s_i[wave] = best.i; s_key[wave] = wkey;
       s_x[wave] = cx; s_y[wave] = cy; s_z[wave] = cz;
     }
     __syncthreads();
@@ -1019,9 +1048,18 @@ __global__ __launch_bounds__(FPS_THREADS) void k_stack_fps(
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
       wmax = __shfl(wmax, 0, 64);
-      const int win2 = __ffsll((long long)__ballot(lane < FPS_THREADS / 64 && wv == wmax)) - 1;   // lower wave = lower threads
+      int win2;
+      if (plain_ties) {
+        win2 = __ffsll((long long)__ballot(lane < FPS_THREADS / 64 && wv == wmax)) - 1;   // lower wave = lower threads
+      } else {
+        int k2 = (lane < FPS_THREADS / 64 && wv == wmax) ? s_key[lane] : 0x7fffffff;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) k2 = min(k2, __shfl_xor(k2, o, 64));
+        k2 = __shfl(k2, 0, 64);
+        win2 = (k2 & 1023) >> 6;
+      }
       if (lane == win2) {
-        O[s] = s_i[lane] + (int)start;
+        O[s] = s_i[lane] + obase;
         s_pt[0] = s_x[lane]; s_pt[1] = s_y[lane]; s_pt[2] = s_z[lane];
       }
     }
@@ -1034,12 +1072,33 @@ extern "C" int glx_stack_fps(const float* xyz, const int32_t* xyz_batch_cnt, int
   if (B <= 0) return GLX_OK;
   GLX_REQUIRE(xyz && xyz_batch_cnt && num_sampled && temp && idxs, "glx_stack_fps: null pointer");
   hipStream_t st = (hipStream_t)stream;
+  FpsFrames fr{xyz_batch_cnt, num_sampled, 0, 0, FPS_THREADS};
   if (max_points > 0 && max_points <= FPS_THREADS * FPS_DPT) {
-    hipLaunchKernelGGL((k_stack_fps<true>), dim3(B), dim3(FPS_THREADS), 0, st, B, xyz, xyz_batch_cnt,
-                       temp, num_sampled, idxs);
+    hipLaunchKernelGGL((k_stack_fps<true>), dim3(B), dim3(FPS_THREADS), 0, st, B, xyz, fr, temp, idxs);
   } else {
-    hipLaunchKernelGGL((k_stack_fps<false>), dim3(B), dim3(FPS_THREADS), 0, st, B, xyz,
-                       xyz_batch_cnt, temp, num_sampled, idxs);
+    hipLaunchKernelGGL((k_stack_fps<false>), dim3(B), dim3(FPS_THREADS), 0, st, B, xyz, fr, temp, idxs);
+  }
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// farthest_point_sampling_kernel<block_size>, pointnet2_batch/src/sampling_gpu.cu:97-230 (and its twin in
+// pointnet2_stack/src/sampling_gpu.cu:15-185): B frames of N points, idx (B, m) LOCAL indices; the block
+// size the reference picks (largest power of two <= N, at most 1024) only shows in its tie rule.
+extern "C" int glx_batch_fps(int B, int N, int m, const float* xyz, float* temp, int32_t* idx, void* stream) {
+  if (B <= 0 || m <= 0) return GLX_OK;
+  GLX_REQUIRE(xyz && temp && idx, "glx_batch_fps: null pointer");
+  GLX_REQUIRE(N >= 1, "glx_batch_fps: N = %d", N);
+  // opt_n_threads(N), cuda_utils.h:9-13, evaluated the same way (double log ratio, truncated)
+  const int pow_2 = (int)(log((double)N) / log(2.0));
+  int tie = 1 << pow_2;
+  tie = tie > FPS_THREADS ? FPS_THREADS : (tie < 1 ? 1 : tie);
+  hipStream_t st = (hipStream_t)stream;
+  FpsFrames fr{nullptr, nullptr, N, m, tie};
+  if (N <= FPS_THREADS * FPS_DPT) {
+    hipLaunchKernelGGL((k_stack_fps<true>), dim3(B), dim3(FPS_THREADS), 0, st, B, xyz, fr, temp, idx);
+  } else {
+    hipLaunchKernelGGL((k_stack_fps<false>), dim3(B), dim3(FPS_THREADS), 0, st, B, xyz, fr, temp, idx);
   }
   GLX_LAUNCH_CHECK();
   return GLX_OK;
@@ -1053,13 +1112,20 @@ extern "C" int glx_stack_fps(const float* xyz, const int32_t* xyz_batch_cnt, int
 
 __global__ __launch_bounds__(TNN_THREADS) void k_three_nn(
     int B, const float* __restrict__ unknown, const int* __restrict__ unknown_batch_cnt,
-    const float* __restrict__ known, const int* __restrict__ known_batch_cnt,
+    const float* __restrict__ known, const int* __restrict__ known_batch_cnt, int uni_nu, int uni_nk,
     float* __restrict__ dist2, int* __restrict__ idx) {
   __shared__ float s_k[TNN_TILE * 3];
   const int b = blockIdx.y;
   long long ustart = 0, kstart = 0;
-  for (int k = 0; k < b; ++k) { ustart += unknown_batch_cnt[k]; kstart += known_batch_cnt[k]; }
-  const int nu = unknown_batch_cnt[b], nk = known_batch_cnt[b];
+  int nu, nk;
+  if (unknown_batch_cnt) {
+    for (int k = 0; k < b; ++k) { ustart += unknown_batch_cnt[k]; kstart += known_batch_cnt[k]; }
+    nu = unknown_batch_cnt[b]; nk = known_batch_cnt[b];
+  } else {   // batch layout (pointnet2_batch): B equal frames, indices local to the frame
+    ustart = (long long)b * uni_nu; kstart = (long long)b * uni_nk;
+    nu = uni_nu; nk = uni_nk;
+  }
+  const int ibase = unknown_batch_cnt ? (int)kstart : 0;
   // TNN_SPLIT lanes per query, each scanning every TNN_SPLIT-th known point: 8x the waves of a thread per
   // query (65 K queries were 1024 waves = one per SIMD, nothing to hide the LDS latency behind)
   if ((long long)blockIdx.x * (TNN_THREADS / TNN_SPLIT) >= nu) return;   // block-uniform
@@ -1109,7 +1175,7 @@ __global__ __launch_bounds__(TNN_THREADS) void k_three_nn(
     float* dp = dist2 + (ustart + q) * 3;
     int* ip = idx + (ustart + q) * 3;
     dp[0] = od[0]; dp[1] = od[1]; dp[2] = od[2];
-    ip[0] = oi[0] + (int)kstart; ip[1] = oi[1] + (int)kstart; ip[2] = oi[2] + (int)kstart;
+    ip[0] = oi[0] + ibase; ip[1] = oi[1] + ibase; ip[2] = oi[2] + ibase;
   }
 }
 
@@ -1121,7 +1187,21 @@ extern "C" int glx_three_nn(int B, int N, int max_queries_per_frame, const float
               "glx_three_nn: null pointer");
   const int per = max_queries_per_frame > 0 ? max_queries_per_frame : N;
   hipLaunchKernelGGL(k_three_nn, dim3(glx_divup(per, TNN_THREADS / TNN_SPLIT), B), dim3(TNN_THREADS), 0,
-                     (hipStream_t)stream, B, unknown, unknown_batch_cnt, known, known_batch_cnt,
+                     (hipStream_t)stream, B, unknown, unknown_batch_cnt, known, known_batch_cnt, 0, 0,
+                     dist2, idx);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// three_nn_kernel_fast, pointnet2_batch/src/interpolate_gpu.cu:15-60: unknown (B, n, 3), known (B, m, 3) ->
+// dist2 (B, n, 3), idx (B, n, 3) LOCAL to the frame.  With m < 3 the unfilled slots keep the reference's
+// initial values narrowed to float (1e40 -> +inf) and index 0.
+extern "C" int glx_batch_three_nn(int B, int n, int m, const float* unknown, const float* known, float* dist2,
+                                  int32_t* idx, void* stream) {
+  if (n <= 0 || B <= 0) return GLX_OK;
+  GLX_REQUIRE(unknown && known && dist2 && idx, "glx_batch_three_nn: null pointer");
+  hipLaunchKernelGGL(k_three_nn, dim3(glx_divup(n, TNN_THREADS / TNN_SPLIT), B), dim3(TNN_THREADS), 0,
+                     (hipStream_t)stream, B, unknown, (const int*)nullptr, known, (const int*)nullptr, n, m,
                      dist2, idx);
   GLX_LAUNCH_CHECK();
   return GLX_OK;

@@ -21,6 +21,8 @@ _EXT_MODULES = {
     "pcdet.ops.roipoint_pool3d.roipoint_pool3d_cuda": "glenet_amd.pcdet_ops.roipoint_pool3d.roipoint_pool3d_cuda",
     "pcdet.ops.pointnet2.pointnet2_stack.pointnet2_stack_cuda":
         "glenet_amd.pcdet_ops.pointnet2.pointnet2_stack.pointnet2_stack_cuda",
+    "pcdet.ops.pointnet2.pointnet2_batch.pointnet2_batch_cuda":
+        "glenet_amd.pcdet_ops.pointnet2.pointnet2_batch.pointnet2_batch_cuda",
 }
 _SPCONV = {
     "spconv": "glenet_amd.spconv",

@@ -96,15 +96,10 @@ def stack_farthest_point_sampling_wrapper(xyz, temp, xyz_batch_cnt, idxs, num_sa
 
 
 def farthest_point_sampling_wrapper(B, N, m, xyz, temp, idx):
-    """sampling.cpp:24-37 (batched layout): xyz (B,N,3), temp (B,N), idx (B,m) with per-frame
-    LOCAL indices -- the stacked kernel on B equal frames, rebased."""
+    """sampling.cpp:24-37 (batched layout): xyz (B,N,3), temp (B,N) filled with 1e10, idx (B,m) with per-frame
+    LOCAL indices -- the batch front end of the stacked kernel (same entry point as pointnet2_batch_cuda's)."""
     _lib.check_cuda(xyz, temp, idx)
-    import torch
-    cnt = torch.full((B,), N, dtype=torch.int32, device=xyz.device)
-    ms = torch.full((B,), m, dtype=torch.int32, device=xyz.device)
-    flat = torch.empty(B * m, dtype=torch.int32, device=xyz.device)
-    call("glx_stack_fps", xyz.view(-1, 3), cnt, B, N if N <= 16384 else 0, ms, temp.view(-1), flat)
-    idx.copy_(flat.view(B, m) - (torch.arange(B, device=xyz.device, dtype=torch.int32) * N).view(B, 1))
+    call("glx_batch_fps", B, N, m, xyz, temp, idx)
     return 1
 
 

@@ -644,6 +644,50 @@ int glx_three_interpolate_grad(int N, int C, const float* grad_out, const int32_
                                const float* weight, float* grad_features, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * pcdet.ops.pointnet2.pointnet2_batch.pointnet2_batch_cuda (pointnet2_batch/src/pointnet2_api.cpp:10-24):
+ * the batch-layout PointNet++ operators.  B equal frames; xyz (B, N, 3); features CHANNEL-major (B, C, N);
+ * every index is local to its frame.  `pcdet.models` imports this module unconditionally
+ * (backbones_3d/pointnet2_backbone.py:4, roi_heads/pointrcnn_head.py:4).
+ * ------------------------------------------------------------------------------------ */
+
+/* idx (B, m, nsample): first nsample points with d2 < radius^2 in index order, unused slots = first hit; a
+ * ball without hits leaves its row untouched (the caller zero-fills it, pointnet2_utils.py:236).
+ * Replaces: ball_query_wrapper_fast (ball_query.cpp:28-38, ball_query_gpu.cu:15-51). */
+int glx_batch_ball_query(int B, int n, int m, float radius, int nsample, const float* new_xyz,
+                         const float* xyz, int32_t* idx, void* stream);
+/* out (B, C, npoints, nsample) = points[b, c, idx[b, p, s]].
+ * Replaces: group_points_wrapper_fast (group_points.cpp:33-44, group_points_gpu.cu:57-78). */
+int glx_batch_group_points(int B, int C, int n, int npoints, int nsample, const float* points,
+                           const int32_t* idx, float* out, void* stream);
+/* grad_points (B, C, n) += scatter of grad_out (B, C, npoints, nsample); arrives zero-filled.
+ * Replaces: group_points_grad_wrapper_fast (group_points.cpp:20-30, group_points_gpu.cu:14-32). */
+int glx_batch_group_points_grad(int B, int C, int n, int npoints, int nsample, const float* grad_out,
+                                const int32_t* idx, float* grad_points, void* stream);
+/* out (B, C, npoints) = points[b, c, idx[b, p]] and its adjoint.
+ * Replaces: gather_points_wrapper_fast / gather_points_grad_wrapper_fast (sampling.cpp:17-37,
+ * sampling_gpu.cu:14-71). */
+int glx_batch_gather_points(int B, int C, int n, int npoints, const float* points, const int32_t* idx,
+                            float* out, void* stream);
+int glx_batch_gather_points_grad(int B, int C, int n, int npoints, const float* grad_out,
+                                 const int32_t* idx, float* grad_points, void* stream);
+/* idx (B, m) LOCAL indices; temp (B, N) arrives filled with 1e10; the first sample of a frame is its point 0.
+ * Ties follow the block size the reference launches (opt_n_threads(N), cuda_utils.h:9-13).
+ * Replaces: farthest_point_sampling_wrapper (sampling.cpp:40-49, sampling_gpu.cu:97-257) of both the batch
+ * module and pointnet2_stack_cuda (pointnet2_stack/src/sampling.cpp:24-37). */
+int glx_batch_fps(int B, int N, int m, const float* xyz, float* temp, int32_t* idx, void* stream);
+/* dist2 (B, n, 3) squared distances, idx (B, n, 3) LOCAL indices of the 3 nearest of known (B, m, 3).
+ * Replaces: three_nn_wrapper_fast (interpolate.cpp:21-31, interpolate_gpu.cu:15-60). */
+int glx_batch_three_nn(int B, int n, int m, const float* unknown, const float* known, float* dist2,
+                       int32_t* idx, void* stream);
+/* out (B, C, n) = sum_j weight[b,p,j] * points[b, c, idx[b,p,j]], points (B, C, m); grad_points (B, C, m)
+ * arrives zero-filled.  Replaces: three_interpolate_wrapper_fast / three_interpolate_grad_wrapper_fast
+ * (interpolate.cpp:34-61, interpolate_gpu.cu:84-153). */
+int glx_batch_three_interpolate(int B, int C, int m, int n, const float* points, const int32_t* idx,
+                                const float* weight, float* out, void* stream);
+int glx_batch_three_interpolate_grad(int B, int C, int n, int m, const float* grad_out, const int32_t* idx,
+                                     const float* weight, float* grad_points, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * CVAE label-uncertainty generator (BASELINE config 4): the PointNet feature extractor as ONE
  * kernel.  out[b,:] = max_p W3 relu(W2 relu(W1 x[b,:,p] + b1) + b2) + b3 with widths 64/128/512;
  * points (B, Cin<=8, P); (W, b) = Conv1d(k=1) + eval-mode BatchNorm1d folded; W2p / W3p in MFMA

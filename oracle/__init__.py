@@ -558,6 +558,89 @@ def three_interpolate_grad(grad_out, idx, weight, M):
     return g
 
 
+# ------------------------------------------------------------------------------ pointnet2_batch (batch layout)
+def batch_ball_query(radius, nsample, xyz, new_xyz):
+    """BallQuery.forward, pointnet2_batch/pointnet2_utils.py:198-222: xyz (B,N,3), new_xyz (B,m,3) ->
+    idx (B,m,nsample) int32, zero rows for balls without points."""
+    xyz, new_xyz = _f32(xyz), _f32(new_xyz)
+    B, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    idx = np.zeros((B, m, nsample), np.int32)
+    lib().orc_batch_ball_query(B, n, m, ctypes.c_float(radius), nsample, _f(new_xyz), _f(xyz), _i(idx))
+    return idx
+
+
+def batch_farthest_point_sample(xyz, npoint):
+    """FarthestPointSampling.forward, pointnet2_batch/pointnet2_utils.py:10-32 -> (B, npoint) local indices."""
+    xyz = _f32(xyz)
+    B, n, _ = xyz.shape
+    temp = np.full((B, n), 1e10, np.float32)
+    out = np.zeros((B, npoint), np.int32)
+    lib().orc_batch_fps(B, n, int(npoint), _f(xyz), _f(temp), _i(out))
+    return out
+
+
+def batch_three_nn(unknown, known):
+    """ThreeNN.forward, pointnet2_batch/pointnet2_utils.py:76-101 -> (dist = sqrt(dist2) (B,n,3), idx (B,n,3))."""
+    unknown, known = _f32(unknown), _f32(known)
+    B, n, _ = unknown.shape
+    m = known.shape[1]
+    d2 = np.zeros((B, n, 3), np.float32)
+    idx = np.zeros((B, n, 3), np.int32)
+    lib().orc_batch_three_nn(B, n, m, _f(unknown), _f(known), _f(d2), _i(idx))
+    return np.sqrt(d2), idx
+
+
+def batch_group_points(points, idx):
+    """group_points_kernel_fast, pointnet2_batch/src/group_points_gpu.cu:57-78:
+    out[b, c, p, s] = points[b, c, idx[b, p, s]]; with a 2-D idx (B, m) it is gather_points_kernel_fast
+    (sampling_gpu.cu:14-33)."""
+    points, idx = _f32(points), _i32(idx)
+    B, C, _ = points.shape
+    flat = np.take_along_axis(points, np.broadcast_to(idx.reshape(B, 1, -1), (B, C, idx[0].size)).astype(np.int64), 2)
+    return flat.reshape((B, C) + idx.shape[1:])
+
+
+def batch_group_points_grad(grad_out, idx, n):
+    """group_points_grad_kernel_fast (group_points_gpu.cu:14-32) / gather_points_grad_kernel_fast
+    (sampling_gpu.cu:52-71): scatter-add into (B, C, n), sequential order (the GPU's atomics are unordered)."""
+    grad_out, idx = _f32(grad_out), _i32(idx)
+    B, C = grad_out.shape[:2]
+    g = np.zeros((B, C, int(n)), np.float32)
+    go = grad_out.reshape(B, C, -1)
+    ii = idx.reshape(B, -1)
+    for b in range(B):
+        for c in range(C):
+            np.add.at(g[b, c], ii[b], go[b, c])
+    return g
+
+
+def batch_three_interpolate(points, idx, weight):
+    """three_interpolate_kernel_fast, pointnet2_batch/src/interpolate_gpu.cu:84-106: points (B,C,m),
+    idx / weight (B,n,3) -> (B,C,n), the three products summed left to right in float."""
+    points, idx, weight = _f32(points), _i32(idx), _f32(weight)
+    B, C, _ = points.shape
+    out = np.zeros((B, C, idx.shape[1]), np.float32)
+    for b in range(B):
+        p = points[b]
+        acc = weight[b, :, 0][None] * p[:, idx[b, :, 0]]
+        acc = acc + weight[b, :, 1][None] * p[:, idx[b, :, 1]]
+        out[b] = acc + weight[b, :, 2][None] * p[:, idx[b, :, 2]]
+    return out
+
+
+def batch_three_interpolate_grad(grad_out, idx, weight, m):
+    """three_interpolate_grad_kernel_fast, interpolate_gpu.cu:130-153 -> (B, C, m)."""
+    grad_out, idx, weight = _f32(grad_out), _i32(idx), _f32(weight)
+    B, C, _ = grad_out.shape
+    g = np.zeros((B, C, int(m)), np.float32)
+    for b in range(B):
+        for c in range(C):
+            for j in range(3):
+                np.add.at(g[b, c], idx[b, :, j], grad_out[b, c] * weight[b, :, j])
+    return g
+
+
 # ------------------------------------------------------------------------------ vector pool (PV-RCNN++)
 def query_stacked_local_neighbor_idxs(support_xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, avg_length,
                                       max_dist, nsample, neighbor_type):

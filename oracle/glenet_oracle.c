@@ -953,6 +953,99 @@ ORC_API void orc_three_nn(int B, int N, const float* unknown, const int32_t* unk
   }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Batch-layout PointNet++ operators (pcdet/ops/pointnet2/pointnet2_batch/src/): B equal frames, indices
+ * local to the frame.  GPU-only CUDA upstream, no reference test: parity unpinned, restated line by line.
+ * ------------------------------------------------------------------------------------------ */
+
+/* ball_query_kernel_fast, pointnet2_batch/src/ball_query_gpu.cu:15-51: idx (B, m, nsample) arrives as the
+ * caller filled it (zeros, pointnet2_utils.py:236) and a ball without hits leaves its row untouched. */
+ORC_API void orc_batch_ball_query(int B, int n, int m, float radius, int nsample, const float* new_xyz,
+                                  const float* xyz, int32_t* idx) {
+  float radius2 = radius * radius;
+  for (int b = 0; b < B; ++b)
+    for (int pt = 0; pt < m; ++pt) {
+      const float* q = new_xyz + ((size_t)b * m + pt) * 3;
+      const float* X = xyz + (size_t)b * n * 3;
+      int32_t* o = idx + ((size_t)b * m + pt) * nsample;
+      int cnt = 0;
+      for (int k = 0; k < n; ++k) {
+        float x = X[k * 3], y = X[k * 3 + 1], z = X[k * 3 + 2];
+        float d2 = (q[0] - x) * (q[0] - x) + (q[1] - y) * (q[1] - y) + (q[2] - z) * (q[2] - z);
+        if (d2 < radius2) {
+          if (cnt == 0)
+            for (int l = 0; l < nsample; ++l) o[l] = k;
+          o[cnt] = k;
+          ++cnt;
+          if (cnt >= nsample) break;
+        }
+      }
+    }
+}
+
+/* farthest_point_sampling_kernel<block_size>, pointnet2_batch/src/sampling_gpu.cu:97-230 with
+ * block_size = opt_n_threads(n) (cuda_utils.h:9-13: 2^floor(log n / log 2) clamped to [1, 1024]).  Thread t
+ * scans k = t, t + block_size, ... with a strict '>' (first maximum of its sequence), the tree keeps the
+ * LOWER thread on equal values (__update :82-87): among equal maxima the winner has the smallest
+ * k mod block_size, then the smallest k.  idxs (B, m) are LOCAL; temp (B, n) arrives filled with 1e10. */
+ORC_API void orc_batch_fps(int B, int n, int m, const float* xyz, float* temp, int32_t* idxs) {
+  int pow_2 = (int)(log((double)n) / log(2.0));
+  int bs = 1 << pow_2;
+  if (bs > 1024) bs = 1024;
+  if (bs < 1) bs = 1;
+  for (int b = 0; b < B; ++b) {
+    const float* X = xyz + (size_t)b * n * 3;
+    float* T = temp + (size_t)b * n;
+    int32_t* O = idxs + (size_t)b * m;
+    int old = 0;
+    if (m > 0) O[0] = 0;
+    for (int j = 1; j < m; ++j) {
+      float x1 = X[old * 3], y1 = X[old * 3 + 1], z1 = X[old * 3 + 2];
+      float best = -1.f;
+      int besti = 0, bestt = 1 << 30;
+      for (int t = 0; t < bs; ++t) {
+        float tb = -1.f;
+        int ti = 0;
+        for (int k = t; k < n; k += bs) {
+          float x2 = X[k * 3], y2 = X[k * 3 + 1], z2 = X[k * 3 + 2];
+          float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+          float d2 = d < T[k] ? d : T[k];
+          T[k] = d2;
+          if (d2 > tb) { tb = d2; ti = k; }
+        }
+        if (tb > best || (tb == best && t < bestt)) { best = tb; besti = ti; bestt = t; }
+      }
+      old = besti;
+      O[j] = old;
+    }
+  }
+}
+
+/* three_nn_kernel_fast, pointnet2_batch/src/interpolate_gpu.cu:15-60: running minima in double starting at
+ * 1e40, strict '<', ascending k; outputs narrowed to float (1e40 -> +inf when m < 3). */
+ORC_API void orc_batch_three_nn(int B, int n, int m, const float* unknown, const float* known, float* dist2,
+                                int32_t* idx) {
+  for (int b = 0; b < B; ++b)
+    for (int pt = 0; pt < n; ++pt) {
+      const float* u = unknown + ((size_t)b * n + pt) * 3;
+      const float* Kp = known + (size_t)b * m * 3;
+      float ux = u[0], uy = u[1], uz = u[2];
+      double b1 = 1e40, b2 = 1e40, b3 = 1e40;
+      int i1 = 0, i2 = 0, i3 = 0;
+      for (int k = 0; k < m; ++k) {
+        float x = Kp[k * 3], y = Kp[k * 3 + 1], z = Kp[k * 3 + 2];
+        float d = (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
+        if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k; }
+        else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = k; }
+        else if (d < b3) { b3 = d; i3 = k; }
+      }
+      float* dp = dist2 + ((size_t)b * n + pt) * 3;
+      int32_t* ip = idx + ((size_t)b * n + pt) * 3;
+      dp[0] = (float)b1; dp[1] = (float)b2; dp[2] = (float)b3;
+      ip[0] = i1; ip[1] = i2; ip[2] = i3;
+    }
+}
+
 /* three_interpolate_kernel_stack / _grad_, interpolate_gpu.cu:100-160 */
 ORC_API void orc_three_interpolate(int N, int C, const float* features, const int32_t* idx,
                                    const float* weight, float* out) {

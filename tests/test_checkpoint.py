@@ -51,33 +51,69 @@ def test_every_spconv_layout_loads_back_to_the_same_weights(layout, residual):
     assert not missing and set(loaded) == set(src.state_dict())
     for (k, a), (_, b) in zip(src.state_dict().items(), dst.state_dict().items()):
         assert torch.equal(a, b), k
-    # "auto" tells every layout apart that shapes can tell apart; a square 2.x-native weight looks like a 1.x one
-    # (the reference's loader has the same blind spot) -- non-square ones are converted
+    # "auto" resolves the layout ONCE per checkpoint from the non-square weights and applies it to the square
+    # ones too (a per-tensor decision loads square 2.x-native weights untransposed)
+    assert ck.infer_layout(dst, state) == layout
     dst2 = _model(residual, 2)
     ck.load_params(dst2, state, layout="auto")
     for k in keys:
-        a, b = src.state_dict()[k], dst2.state_dict()[k]
-        square = a.shape[3] == a.shape[4]
-        if layout == "spconv2_native" and square:
-            assert torch.equal(b, a.transpose(-1, -2))
-        else:
-            assert torch.equal(a, b), k
+        assert torch.equal(src.state_dict()[k], dst2.state_dict()[k]), k
 
 
-def test_glenet_vr_parameter_names_are_the_reference_ones():
+def test_auto_layout_refuses_mixed_checkpoints_and_warns_without_evidence():
+    src, dst = _model(False, 0), _model(False, 1)
+    keys = ck.find_all_spconv_keys(src)
+    state = _as_layout(src.state_dict(), keys, "spconv2_native")
+    state["conv_out.0.weight"] = src.state_dict()["conv_out.0.weight"].permute(4, 0, 1, 2, 3).contiguous()
+    with pytest.raises(ValueError, match="mixes"):
+        ck.load_params(dst, state)
+    # only square weights in the file: nothing identifies the layout -> 1.x, said aloud
+    square = {k: v for k, v in src.state_dict().items() if k not in keys or v.shape[3] == v.shape[4]}
+    with pytest.warns(UserWarning, match="identifies"):
+        assert ck.infer_layout(dst, square) == "spconv1"
+    with pytest.raises(ValueError):
+        ck.to_spconv1_layout(src.state_dict()["conv_out.0.weight"], (3, 1, 1, 64, 128), "auto")
+
+
+def _ref_keys(tag):
+    import json
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_state_keys.npz"))
+    return {str(k): tuple(json.loads(str(s))) for k, s in zip(z[tag + "_keys"], z[tag + "_shapes"])}, \
+        [str(m) for m in z[tag + "_modules"]]
+
+
+def test_glenet_vr_state_dict_equals_the_reference_networks_key_for_key():
+    """tests/golden/ref_state_keys.npz = every state-dict key + shape of the network the REFERENCE builds from
+    tools/cfgs/kitti_models/GLENet_VR.yaml over our spconv (tools/ref_dropin_check.py --write, run in the build
+    container).  Exact set comparison, shapes included; sparse-conv weights are (k,k,k,Cin,Cout) on both sides
+    because the reference's modules were built on glenet_amd.spconv."""
+    from glenet_amd import glenet_vr as gvr
+    ref, modules = _ref_keys("glenet_vr")
+    assert modules == ["MeanVFE", "VoxelBackBone8x", "HeightCompression", "BaseBEVBackbone", "AnchorHeadSingle",
+                       "VoxelRCNNKLLabelIoUHead"]
+    ours = {k: tuple(v.shape) for k, v in gvr.GLENetVR(synth.KITTI).state_dict().items()}
+    ref.pop("global_step")                     # Detector3DTemplate's step counter (detector3d_template.py:22), not a weight
+    assert set(ours) == set(ref), (sorted(set(ours) - set(ref))[:5], sorted(set(ref) - set(ours))[:5])
+    wrong = {k: (ours[k], ref[k]) for k in ref if ours[k] != ref[k]}
+    assert not wrong, wrong
+    assert len(ref) == 272
+
+
+def test_sparse_backbones_state_dicts_equal_the_reference_ones():
+    """backbone_3d.* keys of the reference's VoxelBackBone8x (GLENet-VR) and VoxelResBackBone8x (Waymo CenterPoint)."""
+    for tag, residual, cin in (("glenet_vr", False, 4), ("waymo_centerpoint_res", True, 5)):
+        ref, _ = _ref_keys(tag)
+        ref = {k[len("backbone_3d."):]: s for k, s in ref.items() if k.startswith("backbone_3d.")}
+        torch.manual_seed(0)
+        grid = gb.gv.grid_size_of(synth.KITTI["point_cloud_range"], synth.KITTI["voxel_size"])
+        ours = {k: tuple(v.shape) for k, v in gb.SparseBackbone8x(cin, grid, residual=residual).state_dict().items()}
+        assert ours == ref, (tag, sorted(set(ours) ^ set(ref))[:6])
+
+
+def test_glenet_vr_loader_reports_foreign_and_misshapen_tensors():
     from glenet_amd import glenet_vr as gvr
     m = gvr.GLENetVR(synth.KITTI)
-    names = set(m.state_dict())
-    for k in ("backbone_3d.conv_input.0.weight", "backbone_3d.conv4.2.1.running_var", "backbone_3d.conv_out.0.weight",
-              "backbone_2d.blocks.0.1.weight", "backbone_2d.blocks.1.16.weight", "backbone_2d.deblocks.1.1.bias",
-              "dense_head.conv_cls.bias", "dense_head.conv_box.weight", "dense_head.conv_dir_cls.weight",
-              "roi_head.roi_grid_pool_layers.0.mlps_in.0.0.weight", "roi_head.roi_grid_pool_layers.2.mlps_pos.0.1.running_mean",
-              "roi_head.roi_grid_pool_layers.1.mlps_out.0.1.weight", "roi_head.shared_fc_layer.0.weight",
-              "roi_head.shared_fc_layer.4.weight", "roi_head.cls_fc_layers.5.running_mean", "roi_head.cls_pred_layer.bias",
-              "roi_head.reg_fc_layers.0.weight", "roi_head.reg_pred_layer.weight", "roi_head.reg_std_layer.weight",
-              "roi_head.reg_std_bn.running_var", "roi_head.reg_std_fc1.bias", "roi_head.reg_std_bn1.weight",
-              "roi_head.reg_std_fc2.weight"):
-        assert k in names, k
     assert tuple(m.state_dict()["roi_head.shared_fc_layer.0.weight"].shape) == (256, 20736)
     assert tuple(m.state_dict()["roi_head.roi_grid_pool_layers.0.mlps_pos.0.0.weight"].shape) == (32, 3, 1, 1)
     # a checkpoint with foreign keys and a wrong-shaped tensor: those are reported, the rest loads

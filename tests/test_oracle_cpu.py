@@ -61,9 +61,15 @@ def test_rotated_iou_known_answers():
     assert abs(oracle.boxes_iou_bev(b0, b0)[0, 0] - 1.0) < 1e-5
     b1 = np.array([[0.5, 0, 0, 2, 2, 1, 0]], np.float32)
     assert abs(oracle.boxes_iou_bev(b0, b1)[0, 0] - 0.6) < 1e-6
+    # a 2x2 box at the origin and a 2x2 box at (1, 1) turned by 45 degrees: the diamond |x-1|+|y-1| <= sqrt(2) cuts the
+    # triangle (1,1), (1, 1-sqrt(2)), (1-sqrt(2), 1) out of the square -> area 1, IoU 1 / (4 + 4 - 1) = 0.142857
+    v = np.array([[1, 1, 0, 2, 2, 1, np.pi / 4]], np.float32)
+    assert abs(oracle.boxes_iou_bev(b0, v)[0, 0] - 1.0 / 7.0) < 1e-5
+    assert abs(oracle.boxes_overlap_bev(b0, v)[0, 0] - 1.0) < 1e-5
+    # unit boxes whose diamond stays outside the other square: exactly disjoint
     u = np.array([[0.5, 0.5, 0.5, 1, 1, 1, 0]], np.float32)
-    v = np.array([[1.5, 1.5, 1.5, 1, 1, 1, np.pi / 4]], np.float32)
-    assert abs(oracle.boxes_iou_bev(u, v)[0, 0] - 0.1429) < 2e-3 or True
+    w = np.array([[1.5, 1.5, 1.5, 1, 1, 1, np.pi / 4]], np.float32)
+    assert oracle.boxes_iou_bev(u, w)[0, 0] == 0.0
     # symmetry and range on random boxes
     rng = np.random.default_rng(0)
     a = synth.random_boxes(rng, 64)
@@ -295,6 +301,53 @@ def test_set_abstraction_oracle_vs_independent_numpy():
     gf = np.zeros_like(f)
     np.add.at(gf, i.reshape(-1), (g[:, None, :] * w[:, :, None]).reshape(-1, 5))
     np.testing.assert_allclose(oracle.three_interpolate_grad(g, i, w, 300), gf, rtol=1e-5, atol=1e-6)
+
+
+def test_batch_layout_oracle_vs_the_stacked_restatements():
+    """pointnet2_batch restatements cross-checked against the independently written stacked ones on B equal frames
+    (different source files upstream, same semantics up to the empty-ball sentinel, index base and FPS block size)."""
+    rng = np.random.default_rng(11)
+    B, N, m = 3, 1500, 200
+    xyz = rng.uniform(-3, 3, (B, N, 3)).astype(np.float32)
+    new_xyz = rng.uniform(-3, 3, (B, m, 3)).astype(np.float32)
+    new_xyz[1, 0] = 50.0
+    cnt, mcnt = np.full(B, N, np.int32), np.full(B, m, np.int32)
+    bi = oracle.batch_ball_query(0.5, 12, xyz, new_xyz)
+    si, empty = oracle.ball_query(0.5, 12, xyz.reshape(-1, 3), cnt, new_xyz.reshape(-1, 3), mcnt)
+    assert np.array_equal(bi.reshape(-1, 12), si) and empty.reshape(B, m)[1, 0] and (bi[1, 0] == 0).all()
+    # FPS: N >= 1024 -> block size 1024 on both sides
+    bf = oracle.batch_farthest_point_sample(xyz, 64)
+    sf = oracle.stack_farthest_point_sample(xyz.reshape(-1, 3), cnt, 64).reshape(B, 64) - (np.arange(B) * N)[:, None]
+    assert np.array_equal(bf, sf)
+    # N < 1024 with exact ties: the block size opt_n_threads picks (512 for N = 600) decides
+    lat = rng.integers(0, 3, (1, 600, 3)).astype(np.float32)
+    f600 = oracle.batch_farthest_point_sample(lat, 30)[0]
+    d = np.full(600, 1e10, np.float32)
+    sel = [0]
+    for _ in range(29):                                           # independent statement of the tie rule
+        p = lat[0, sel[-1]]
+        d = np.minimum(d, ((lat[0] - p) ** 2).sum(-1).astype(np.float32))
+        tied = np.flatnonzero(d == d.max())
+        sel.append(int(min(tied, key=lambda k: (k % 512, k))))
+    assert list(f600) == sel
+    # three_nn / interpolate / grouping
+    known = rng.uniform(-3, 3, (B, 300, 3)).astype(np.float32)
+    bd, bidx = oracle.batch_three_nn(new_xyz, known)
+    sd, sidx = oracle.three_nn(new_xyz.reshape(-1, 3), mcnt, known.reshape(-1, 3), np.full(B, 300, np.int32))
+    assert np.array_equal(bd.reshape(-1, 3), sd)
+    assert np.array_equal(bidx.reshape(-1, 3) + np.repeat(np.arange(B) * 300, m)[:, None], sidx)
+    feats = rng.normal(size=(B, 6, 300)).astype(np.float32)
+    w = rng.uniform(0, 1, (B, m, 3)).astype(np.float32)
+    bo = oracle.batch_three_interpolate(feats, bidx, w)
+    so = oracle.three_interpolate(feats.transpose(0, 2, 1).reshape(-1, 6), sidx, w.reshape(-1, 3))
+    np.testing.assert_allclose(bo.transpose(0, 2, 1).reshape(-1, 6), so, rtol=1e-6, atol=1e-6)
+    g = oracle.batch_group_points(feats, bi % 300)
+    assert g.shape == (B, 6, m, 12) and g[2, 4, 7, 3] == feats[2, 4, bi[2, 7, 3] % 300]
+    go = rng.normal(size=g.shape).astype(np.float32)
+    gg = oracle.batch_group_points_grad(go, bi % 300, 300)
+    assert abs(float((gg * feats).sum()) - float((go * g).sum())) < 1e-2          # adjoint identity
+    gi = oracle.batch_three_interpolate_grad(bo * 0 + 1, bidx, w, 300)
+    np.testing.assert_allclose(gi.sum(-1), np.broadcast_to(w.sum((1, 2))[:, None], (B, 6)), rtol=1e-4)
 
 
 def test_mean_vfe_and_range_mask_match_reference_golden():
