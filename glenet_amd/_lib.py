@@ -108,6 +108,27 @@ def check_cuda(*tensors):
             raise GlxError("expected a contiguous tensor")
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Weights epoch.  The fused optimizer and the fused training BatchNorm write parameters / running statistics through
+# raw pointers, and a replayed HIP graph runs no Python at all: torch's per-tensor version counters do not move.
+# Every cache of tensors DERIVED from weights (packed sparse-conv images, eval-mode BatchNorm affines, folded
+# BatchNorm + linear / conv weights, the weights tag of recorded inference graphs) therefore keys on
+# (tensor versions, data pointers, weights_epoch()), and whatever updates weights behind torch's back calls
+# bump_weights_epoch(): FlatAdamW.step, the fused training BatchNorm entry points, and the step() / replay() of the
+# recorded training steps.  (train -> eval on the same module ran the first eval's packed weights.)
+_weights_epoch = 0
+
+
+def weights_epoch():
+    return _weights_epoch
+
+
+def bump_weights_epoch():
+    global _weights_epoch
+    _weights_epoch += 1
+    return _weights_epoch
+
+
 class Workspace:
     """Grow-only device scratch buffer per (device, stream): avoids per-call allocation and
     keeps stream-ordered reuse safe."""

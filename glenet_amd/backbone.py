@@ -15,7 +15,7 @@ from functools import partial
 import torch
 from torch import nn
 
-from . import spconv
+from . import _lib, spconv
 from . import voxelize as gv
 
 _norm = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
@@ -324,7 +324,8 @@ class StaticFramePipeline:
                 tag += t._version
             for t in m.buffers():
                 tag += t._version
-        return tag
+        # + the weights epoch: fused optimizer / BatchNorm updates and replayed training graphs move no version counter
+        return (tag, _lib.weights_epoch())
 
     def replay(self):
         """Launch the recorded frame.  At most `max_in_flight` frames are queued: the host waits
@@ -411,6 +412,13 @@ class StaticTrainPipeline(StaticFramePipeline):
 
     def _weights_tag(self):
         return None      # training steps pack weights inside the step (spconv.core._packed_weight): nothing cached
+
+    def replay(self):
+        """A replayed training step updates parameters and running statistics without running any Python: tell the
+        version-keyed caches of everything that shares these weights (eval-mode modules, inference graphs)."""
+        out = super().replay()
+        _lib.bump_weights_epoch()
+        return out
 
     def enqueue(self):
         from ._lib import workspace

@@ -4,21 +4,46 @@
 // Arithmetic restates, operation for operation in fp32 with contraction off:
 //   pcdet/ops/iou3d_nms/src/iou3d_nms_kernel.cu:35-234 (== iou3d_cpu.cpp:59-229)   [NMSCONV]
 //   pcdet/ops/iou3d/src/iou3d_kernel.cu:50-268 (== iou3d/src/iou3d_cpu.cpp:36-253) [OLDCONV]
-// sin/cos/atan2 are evaluated in double and rounded once to float (the CPU reference calls
-// glibc's float routines, which are correctly rounded for all but ~1e-3 of inputs).
+// sin / cos / atan2 are glx_libm.h's: glibc's float routines restated (the CPU reference calls glibc's), verified
+// against the host libm over all finite floats -- so an overlap is the reference's CPU value bit for bit.
 // NMS: the reference computes the full N x ceil(N/64) suppression matrix, copies it to the
 // host and sweeps it serially (iou3d_nms.cpp:90-136).  Here only the upper triangle is
 // computed and the sweep runs on the device in one wave, 64 boxes per step.
 #include "glx_common.h"
 #include "glx_fill.h"
+#include "glx_libm.h"
 
 struct P2 {
   float x, y;
 };
 
-__device__ __forceinline__ float f_cos(float a) { return (float)cos((double)a); }
-__device__ __forceinline__ float f_sin(float a) { return (float)sin((double)a); }
-__device__ __forceinline__ float f_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
+__device__ __forceinline__ float f_cos(float a) { return glxm::cosf_(a); }
+__device__ __forceinline__ float f_sin(float a) { return glxm::sinf_(a); }
+__device__ __forceinline__ float f_atan2(float y, float x) { return glxm::atan2f_(y, x); }
+
+// Test hook: the routines above applied elementwise (fn 0 sinf, 1 cosf, 2 atanf, 3 atan2f(x, y)) so that
+// tests/test_libm_gpu.py can compare the DEVICE build with the host libm bit for bit.
+__global__ void k_libm_eval(int fn, const float* __restrict__ x, const float* __restrict__ y, long long n,
+                            float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = x[i];
+  float r;
+  if (fn == 0) r = glxm::sinf_(a);
+  else if (fn == 1) r = glxm::cosf_(a);
+  else if (fn == 2) r = glxm::atanf_(a);
+  else r = glxm::atan2f_(a, y[i]);
+  out[i] = r;
+}
+
+extern "C" int glx_libm_eval(int fn, const float* x, const float* y, int64_t n, float* out, void* stream) {
+  if (n <= 0) return GLX_OK;
+  GLX_REQUIRE(fn >= 0 && fn <= 3 && x && out && (fn != 3 || y), "glx_libm_eval: bad arguments");
+  hipLaunchKernelGGL(k_libm_eval, dim3(glx_divup(n, 256)), dim3(256), 0, (hipStream_t)stream, fn, x, y,
+                     (long long)n, out);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
 
 __device__ __forceinline__ float cross2(P2 a, P2 b) { return a.x * b.y - a.y * b.x; }
 __device__ __forceinline__ float cross3(P2 p1, P2 p2, P2 p0) {
@@ -194,10 +219,17 @@ __device__ __forceinline__ bool pbox_far(const PBox& a, const PBox& b) {
 // NMS only asks whether IoU > thresh.  A rigorous upper bound of the IoU that costs ~40 flops: along the direction u
 // of the centre difference the intersection cannot be longer than the overlap of the two boxes' projection intervals,
 // across it not wider than the narrower box's projection; so inter <= L * W, and IoU <= inter / (Aa + Ab - inter) is
-// increasing in inter.  Pairs whose bound stays below the threshold (0.1 % margin: the exact routine's own rounding is
-// ~1e-6) cannot set a bit of the suppression matrix and skip the ~600-flop rotated overlap -- at thresh 0.8 that is
+// increasing in inter.  What has to be bounded is the area the exact routine COMPUTES, not the true intersection: its
+// polygon also takes corners that lie up to MARGIN = 1e-2 outside the other box (the inside test of
+// iou3d_nms_kernel.cu:51-61), so for small or thin boxes it exceeds the true intersection by far more than a rounding
+// error.  Every vertex it can use -- true edge crossings, corners of b inside a grown by the margin, corners
+// of a inside b grown by the margin -- lies in (a grown) n (b grown), a convex set that contains the polygon; the bound
+// is therefore taken on the boxes GROWN by the margin on every side, while the union keeps the true areas, exactly as
+// the reference's `sa + sb - s` does.  Pairs whose bound stays below the threshold (0.1 % on top for the bound's own
+// rounding) cannot set a bit of the suppression matrix and skip the ~600-flop rotated overlap -- at thresh 0.8 that is
 // nine of ten pairs that pass the far-apart test.  Box axes: heading rotates (x, y) to (x c - y s, x s + y c).
 __device__ __forceinline__ bool pbox_iou_below(const PBox& a, const PBox& b, float thresh) {
+  const float MARGIN = 1e-2f;
   float ux = b.cx - a.cx, uy = b.cy - a.cy;
   const float d2 = ux * ux + uy * uy;
   float dist = 0.f;
@@ -208,14 +240,15 @@ __device__ __forceinline__ bool pbox_iou_below(const PBox& a, const PBox& b, flo
   } else {
     ux = 1.f; uy = 0.f;
   }
+  const float ahx = a.hx + MARGIN, ahy = a.hy + MARGIN, bhx = b.hx + MARGIN, bhy = b.hy + MARGIN;
   // half extents along u (h) and across it (w): |u . ex| hx + |u . ey| hy with ex = (c, s), ey = (-s, c)
   const float pa = fabsf(ux * a.c + uy * a.s), qa = fabsf(uy * a.c - ux * a.s);
   const float pb_ = fabsf(ux * b.c + uy * b.s), qb = fabsf(uy * b.c - ux * b.s);
-  const float ha = pa * a.hx + qa * a.hy, wa = qa * a.hx + pa * a.hy;
-  const float hb = pb_ * b.hx + qb * b.hy, wb = qb * b.hx + pb_ * b.hy;
+  const float ha = pa * ahx + qa * ahy, wa = qa * ahx + pa * ahy;
+  const float hb = pb_ * bhx + qb * bhy, wb = qb * bhx + pb_ * bhy;
   const float L = fminf(fmaxf(ha + hb - dist, 0.f), 2.f * fminf(ha, hb));
   float inter = L * 2.f * fminf(wa, wb);
-  inter = fminf(inter, fminf(a.area, b.area)) * 1.001f;
+  inter = fminf(inter, 4.f * fminf(ahx * ahy, bhx * bhy)) * 1.001f;
   const float un = a.area + b.area - inter;
   return un > 0.f && inter < thresh * un;       // bound / union < thresh  (NaN boxes: false -> exact routine decides)
 }

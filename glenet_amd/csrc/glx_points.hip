@@ -4,6 +4,7 @@
 #include "glx_common.h"
 #include "glx_fill.h"
 #include "glx_scan.h"
+#include "glx_libm.h"
 
 // ------------------------------------------------------------------ inside test
 // check_pt_in_box3d, pcdet/ops/roiaware_pool3d/src/roiaware_pool3d_kernel.cu:23-36
@@ -13,13 +14,13 @@ struct BoxT {
   __device__ void load(const float* b) {
     cx = b[0]; cy = b[1]; cz = b[2]; dx = b[3]; dy = b[4]; dz = b[5];
     // The reference calls the float overloads (lidar_to_local_coords, roiaware_pool3d_kernel.cu:23-27; cosf / sinf of
-    // glibc in roiaware_pool3d.cpp:119-123).  Evaluating in double and rounding once gives the correctly rounded
-    // float, which is what glibc's float routines return and what the CPU oracle / libglenet_host.so therefore hold;
-    // the device's own cosf / sinf (ocml) are ~1 ulp routines and would flip boundary points against those.  A CUDA
-    // build of the reference (libdevice float trig) can differ from either by an ulp of the rotation: points within
-    // ~1e-6 m of a box face may be classified differently -- the parity tests place their boundary cases 1e-3 apart.
-    cosa = (float)cos((double)(-b[6]));
-    sina = (float)sin((double)(-b[6]));
+    // glibc in roiaware_pool3d.cpp:119-123).  glx_libm.h returns glibc's bits (verified over all finite floats), which
+    // is what the CPU oracle / libglenet_host.so hold; the device's own cosf / sinf (ocml) are different ~1 ulp
+    // routines and would flip boundary points against those.  A CUDA build of the reference (libdevice float trig)
+    // can differ from either by an ulp of the rotation: points within ~1e-6 m of a box face may be classified
+    // differently there.
+    cosa = glxm::cosf_(-b[6]);
+    sina = glxm::sinf_(-b[6]);
   }
   __device__ __forceinline__ int contains(float x, float y, float z, float margin, float& lx,
                                           float& ly) const {

@@ -894,8 +894,10 @@ extern "C" int glx_sconv_forward_generic(const float* in, int N_in, const float*
 
 // ------------------------------------------------------------------ dispatch
 static bool mfma_supported(int Cin, int Cout, int K) {
+  // == the cases of sc_dispatch below: the thin inputs (4 / 8 channels) exist for 16 / 32 output columns only
   auto okc = [](int c) { return c == 16 || c == 32 || c == 64 || c == 128; };
-  return (okc(Cin) || Cin == 4 || Cin == 8) && okc(Cout) && K <= SC_MAXK;
+  const bool thin = (Cin == 4 || Cin == 8) && (Cout == 16 || Cout == 32);
+  return ((okc(Cin) && okc(Cout)) || thin) && K <= SC_MAXK;
 }
 
 template <int CIN, int COUT>
@@ -1230,9 +1232,11 @@ extern "C" int glx_sconv_pack_weights_multi(int n, const float* const* W, const 
       if (nj + 3 > SC_PACK_MAX_JOBS) break;
       const int view = (transposed[done] ? 1 : 0) | (flip_taps[done] ? 2 : 0);
       const int i = done;
-      nj += sc_dispatch(Cin[i], Cout[i], [&](auto ci, auto co) {
+      const int added = sc_dispatch(Cin[i], Cout[i], [&](auto ci, auto co) {
         return sc_pack_jobs<decltype(ci)::value, decltype(co)::value>(W[i], K[i], Wp[i], view, jobs.j + nj);
       });
+      if (added < 0) return added;                     // no kernel for these channels: the error is set, nothing launched
+      nj += added;
     }
     for (int j = 0; j < nj; ++j) max_cover = jobs.j[j].cover > max_cover ? jobs.j[j].cover : max_cover;
     hipLaunchKernelGGL(k_pack_weights_multi, dim3(glx_divup(max_cover, 256), nj), dim3(256), 0, st, jobs);

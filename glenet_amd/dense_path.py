@@ -22,6 +22,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import _lib
+
 
 def _bn2d(c):
     return nn.BatchNorm2d(c, eps=1e-3, momentum=0.01)      # base_bev_backbone.py:37
@@ -326,7 +328,7 @@ class RoIFCStack(nn.Module):
                  if isinstance(seq[i], nn.Linear)]
         tensors = [t for lin, bn in pairs for t in (lin.weight, bn.weight, bn.bias, bn.running_mean,
                                                     bn.running_var)]
-        tag = tuple((t._version, t.data_ptr()) for t in tensors)
+        tag = tuple((t._version, t.data_ptr()) for t in tensors) + (_lib.weights_epoch(),)
         cache = self.__dict__.get("_glx_folded")
         if cache is None or cache[0] != tag:
             with torch.no_grad():
@@ -408,7 +410,7 @@ class PointFeat(nn.Module):
                    for t in (m.weight, m.bias)] + [self.bn1.running_mean, self.bn1.running_var,
                                                    self.bn2.running_mean, self.bn2.running_var,
                                                    self.bn3.running_mean, self.bn3.running_var]
-        tag = tuple((t._version, t.data_ptr()) for t in tensors)
+        tag = tuple((t._version, t.data_ptr()) for t in tensors) + (_lib.weights_epoch(),)
         cache = self.__dict__.get("_glx_packed")
         if cache is None or cache[0] != tag:
             with torch.no_grad():

@@ -409,4 +409,5 @@ class StaticTrainStep(gb.StaticTrainPipeline):
             if self.exchange is not None:
                 self.exchange()
             self.update_graph.replay()
+            gb._lib.bump_weights_epoch()
         return self.loss

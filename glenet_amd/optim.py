@@ -11,9 +11,11 @@ copy), both moments are flat.  Consequences:
   * the update is two launches moving 7 x 4 B per element once instead of ~300 launches of per-tensor ops;
   * the data-parallel exchange is one all-reduce ON the flat gradient buffer: no pack / unpack copies;
   * learning rate, beta1 and the step count are device scalars, so a recorded HIP graph replays the update.
-The kernel writes parameters through raw pointers: torch's version counters do not move.  Whatever caches derived
-tensors by version (packed sparse-conv weights, folded BatchNorms) must not be used in training mode -- the sparse
-convs re-pack inside the step when gradients are enabled (spconv.core.SparseConvolution._packed_weight)."""
+The kernel writes parameters through raw pointers: torch's version counters do not move.  Caches of tensors derived
+from weights (packed sparse-conv images, folded BatchNorms, recorded inference graphs) key on
+`_lib.weights_epoch()` as well, which step() -- and the step() of a recorded training step, whose replay runs no
+Python -- advances; in training mode the sparse convs re-pack inside the step anyway
+(spconv.core.SparseConvolution._packed_weight)."""
 import ctypes
 
 import torch
@@ -110,6 +112,7 @@ class FlatAdamW:
                   ctypes.c_int64(self.n), self.hyper, ctypes.c_float(self.beta2), ctypes.c_float(self.eps),
                   ctypes.c_float(self.weight_decay), ctypes.c_float(self.max_norm), self.step_count, self.grad_norm,
                   self._ws, _lib.size_arg(self._ws.numel()))
+        _lib.bump_weights_epoch()          # parameters changed through raw pointers: version-keyed caches are stale
 
     def bump_versions(self):
         """Tell torch the parameters changed (eager loops that rely on version-keyed caches)."""

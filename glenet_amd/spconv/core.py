@@ -610,7 +610,7 @@ class SparseConvolution(SparseModule):
             # the backward packs the adjoint from the live ones.
             with torch.no_grad():
                 return pack_weights(w.detach().contiguous())
-        tag = (self.weight._version, self.weight.data_ptr(), self.weight.device)
+        tag = (self.weight._version, self.weight.data_ptr(), self.weight.device, _lib.weights_epoch())
         cache = self.__dict__.get("_packed_cache")
         if cache is None or cache[0] != tag:
             with torch.no_grad():
@@ -684,7 +684,7 @@ def _bn_affine(bn):
     """Eval-mode BatchNorm1d as y = x * scale + shift (cached until its tensors change)."""
     tag = (bn.weight._version if bn.weight is not None else -1,
            bn.bias._version if bn.bias is not None else -1,
-           bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr())
+           bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr(), _lib.weights_epoch())
     cache = bn.__dict__.get("_glx_affine")
     if cache is None or cache[0] != tag:
         with torch.no_grad():
@@ -730,6 +730,8 @@ class FusedBNReLU(Function):
         call("glx_bn_relu_train_forward", x, N, C, weight, bias, ctypes_float(eps), ctypes_float(momentum),
              1 if relu else 0, running_mean, running_var, y, mean, invstd, count, ws, size_arg(ws.numel()),
              _bn_state(x.device), 0)
+        if running_mean is not None:
+            _lib.bump_weights_epoch()                                 # running statistics moved behind torch's back
         ctx.save_for_backward(x, weight, bias, mean, invstd)          # not y: backward re-derives the ReLU mask from x
         ctx.relu, ctx.count = relu, count
         return y
@@ -772,6 +774,8 @@ class FusedBNReLUCat(Function):
             call("glx_bn_relu_train_forward", x, N, C, w, b, ctypes_float(eps), ctypes_float(momentum),
                  1 if relu else 0, rm, rv, out[:, col:], mean, invstd, None, ws, size_arg(ws.numel()),
                  _bn_state(x.device), total)
+            if rm is not None:
+                _lib.bump_weights_epoch()
             saved += [x, w, b, mean, invstd]
             col += C
         ctx.save_for_backward(*saved)

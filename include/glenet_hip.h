@@ -643,6 +643,11 @@ int glx_three_interpolate(int N, int C, const float* features, const int32_t* id
 int glx_three_interpolate_grad(int N, int C, const float* grad_out, const int32_t* idx,
                                const float* weight, float* grad_features, void* stream);
 
+/* Test hook for csrc/glx_libm.h (the device restatement of glibc's sinf / cosf / atanf / atan2f that the rotated
+ * overlap and the inside tests use in place of iou3d_cpu.cpp's libm calls, :30,:83,:141-142): out[i] = fn(x[i])
+ * with fn 0 = sinf, 1 = cosf, 2 = atanf, or 3 = atan2f(x[i], y[i]). */
+int glx_libm_eval(int fn, const float* x, const float* y, int64_t n, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * pcdet.ops.pointnet2.pointnet2_batch.pointnet2_batch_cuda (pointnet2_batch/src/pointnet2_api.cpp:10-24):
  * the batch-layout PointNet++ operators.  B equal frames; xyz (B, N, 3); features CHANNEL-major (B, C, N);

@@ -233,6 +233,31 @@ def boxes_iou3d(a, b):
     return (ov3d / np.clip(va + vb - ov3d, 1e-6, None)).astype(np.float32)
 
 
+def iou_bev_pairs(boxes, pairs):
+    """IoU(boxes[i], boxes[j]) (row box first, as nms_kernel evaluates it) for pairs (P,2) int32."""
+    boxes, pairs = _f32(boxes), _i32(pairs)
+    out = np.zeros(len(pairs), np.float32)
+    lib().orc_iou_bev_pairs(_f(boxes), _i(pairs), ctypes.c_longlong(len(pairs)), _f(out))
+    return out
+
+
+def nms_from_pairs(n, pairs, suppress):
+    """The host sweep of iou3d_nms.cpp:116-132 on a sparse suppression relation: pairs (P,2) with i < j,
+    suppress (P,) bool = iou(i, j) > thresh.  -> kept indices (ascending)."""
+    pairs = np.asarray(pairs)[np.asarray(suppress, bool)]
+    order = np.argsort(pairs[:, 0], kind="stable")
+    pairs = pairs[order]
+    starts = np.searchsorted(pairs[:, 0], np.arange(n + 1))
+    removed = np.zeros(n, bool)
+    keep = []
+    for i in range(n):
+        if removed[i]:
+            continue
+        keep.append(i)
+        removed[pairs[starts[i]:starts[i + 1], 1]] = True
+    return np.asarray(keep, np.int64)
+
+
 def nms_sorted(boxes_sorted, thresh, normal=False):
     """iou3d_nms_cuda.nms_gpu / nms_normal_gpu on boxes already sorted by score."""
     boxes_sorted = _f32(boxes_sorted)
@@ -556,6 +581,16 @@ def three_interpolate_grad(grad_out, idx, weight, M):
     g = np.zeros((int(M), grad_out.shape[1]), np.float32)
     lib().orc_three_interpolate_grad(len(idx), grad_out.shape[1], _f(grad_out), _i(idx), _f(weight), _f(g))
     return g
+
+
+def libm_eval(fn, x, y=None):
+    """sinf / cosf / atanf / atan2f of the host libm on float32 arrays (fn = "sin" | "cos" | "atan" | "atan2")."""
+    code = {"sin": 0, "cos": 1, "atan": 2, "atan2": 3}[fn]
+    x = _f32(x).ravel()
+    y = _f32(y).ravel() if y is not None else x
+    out = np.empty_like(x)
+    lib().orc_libm_eval(code, _f(x), _f(y), ctypes.c_longlong(x.size), _f(out))
+    return out
 
 
 # ------------------------------------------------------------------------------ pointnet2_batch (batch layout)

@@ -482,6 +482,14 @@ ORC_API void orc_boxes_iou_bev(const float* a, int N, const float* b, int M, flo
     for (int j = 0; j < M; ++j) out[(size_t)i * M + j] = iou_bev_nms(a + i * 7, b + j * 7);
 }
 
+/* IoU of listed pairs (a = boxes[pairs[2p]], b = boxes[pairs[2p+1]]): the census of tools/nms_census.py evaluates
+ * the candidate pairs of 9000-box frames (everything else is provably 0) instead of all 81 M. */
+ORC_API void orc_iou_bev_pairs(const float* boxes, const int32_t* pairs, long long P, float* out) {
+  ORC_PAR_FOR
+  for (long long p = 0; p < P; ++p)
+    out[p] = iou_bev_nms(boxes + (size_t)pairs[2 * p] * 7, boxes + (size_t)pairs[2 * p + 1] * 7);
+}
+
 /* iou_normal, iou3d_nms_kernel.cu:314-325 */
 static float iou_normal(const float* a, const float* b) {
   float left = fmaxf(a[0] - a[3] / 2, b[0] - b[3] / 2), right = fminf(a[0] + a[3] / 2, b[0] + b[3] / 2);
@@ -951,6 +959,14 @@ ORC_API void orc_three_nn(int B, int N, const float* unknown, const int32_t* unk
     dist2[pt * 3] = (float)b1; dist2[pt * 3 + 1] = (float)b2; dist2[pt * 3 + 2] = (float)b3;
     idx[pt * 3] = i1 + start; idx[pt * 3 + 1] = i2 + start; idx[pt * 3 + 2] = i3 + start;
   }
+}
+
+/* The host C library's float routines, elementwise (fn 0 sinf, 1 cosf, 2 atanf, 3 atan2f(x, y)): what
+ * iou3d_cpu.cpp's cos / sin / atan2 calls resolve to.  Checker for the device restatement in csrc/glx_libm.h. */
+ORC_API void orc_libm_eval(int fn, const float* x, const float* y, long long n, float* out) {
+  ORC_PAR_FOR
+  for (long long i = 0; i < n; ++i)
+    out[i] = fn == 0 ? sinf(x[i]) : fn == 1 ? cosf(x[i]) : fn == 2 ? atanf(x[i]) : atan2f(x[i], y[i]);
 }
 
 /* ------------------------------------------------------------------------------------------

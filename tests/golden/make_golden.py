@@ -19,6 +19,8 @@ committed, this script is committed, nothing of the reference is copied.
                          suppression strictness, output ordering) given the oracle's IoU matrix;
                          the IoU arithmetic itself is pinned by iou3d_ref.npz (shared helpers).
   limit_period / boxes3d_to_bev_torch outputs of the reference are stored alongside.
+  nms_pred_ref.npz   the IoU that decides nms_gpu pinned to the reference's compiled iou3d_cpu.cpp through a
+                     cross-library identity on dyadic boxes (see make_nms_predicate_ref()).
   detector_glue_ref.npz  box coder, anchor generator and the two generate_predicted_boxes statement
                      sequences of the detection heads (see make_detector_glue_ref()).
   target_assign_ref.npz  the reference's AxisAlignedTargetAssigner on a reduced feature map, two
@@ -89,6 +91,56 @@ def make_iou3d_ref():
         out["%s_overlap" % kind], out["%s_iou" % kind] = ov.numpy(), iou.numpy()
     np.savez_compressed(os.path.join(HERE, "iou3d_ref.npz"), **out)
     print("iou3d_ref.npz", {k: v.shape for k, v in out.items() if k.endswith("iou")})
+
+
+def dyadic_boxes7(rng, n, dup_of=None):
+    """[x,y,z,dx,dy,dz,heading] boxes whose centres / sizes are multiples of 1/16 and 1/8 (so that
+    x -/+ dx/2, (x1+x2)/2 and (x2-x1)/2 are exact in float) with arbitrary float32 headings."""
+    if dup_of is None:
+        c = rng.integers(-160, 161, (n, 2)) / 16.0
+        d = rng.integers(4, 41, (n, 2)) / 8.0
+        h = rng.uniform(-np.pi, np.pi, n)
+    else:                       # jittered copies on the same lattice: IoUs all over (0, 1)
+        src = dup_of[rng.integers(0, len(dup_of), n)]
+        c = src[:, :2] + rng.integers(-12, 13, (n, 2)) / 16.0
+        d = np.clip(src[:, 3:5] + rng.integers(-2, 3, (n, 2)) / 8.0, 0.5, None)
+        h = src[:, 6] + rng.normal(0, 0.2, n)
+    h[::9] = rng.choice([0.0, np.pi / 2, -np.pi / 2, np.pi, np.pi / 4], len(h[::9]))
+    z = np.zeros((n, 1))
+    return np.concatenate([c, z, d, z + 1.5, h[:, None]], 1).astype(np.float32)
+
+
+def make_nms_predicate_ref():
+    """nms_pred_ref.npz: pins the IoU that decides NMS (iou3d_nms convention, iou3d_cpu.cpp:129-234) to
+    REFERENCE-EXECUTED values.  That file cannot be compiled here (it includes cuda.h); the older iou3d library's
+    CPU twin can (oracle/_ref) and the two routines are the same arithmetic under
+        iou3d_nms([x, y, dx, dy, heading])  ==  iou3d([x - dx/2, y - dy/2, x + dx/2, y + dy/2], -heading)
+    whenever (i) the corner / centre conversions are exact -- dyadic inputs -- and (ii) no corner of one box lies
+    within the other box's margin band (1e-5 .. 1e-2 outside an edge), where the two inside tests disagree by
+    design (iou3d_nms/src/iou3d_cpu.cpp:76-86 vs iou3d/src/iou3d_cpu.cpp:56-71).  The rotation is the same
+    statement once cos(-a) = cos(a), sin(-a) = -sin(a) (glibc: exact).  Stored: the 7-float boxes, the 5-float
+    boxes handed to the reference build, its overlaps and IoUs.  The tests apply (ii) as a mask computed in
+    float64 from the inputs."""
+    ref = obuild.build_ref()
+    assert ref is not None, "reference extension not built"
+    rng = np.random.default_rng(20241003)
+    a7 = dyadic_boxes7(rng, 192)
+    b7 = np.concatenate([dyadic_boxes7(rng, 64), dyadic_boxes7(rng, 128, dup_of=a7)])
+
+    def to5(b):
+        return np.stack([b[:, 0] - b[:, 3] / 2, b[:, 1] - b[:, 4] / 2, b[:, 0] + b[:, 3] / 2, b[:, 1] + b[:, 4] / 2,
+                         -b[:, 6]], 1).astype(np.float32)
+    a5, b5 = to5(a7), to5(b7)
+    # (i): the conversion is exact and invertible
+    assert np.array_equal((a5[:, 0] + a5[:, 2]) / 2, a7[:, 0]) and np.array_equal(a5[:, 2] - a5[:, 0], a7[:, 3])
+    assert np.array_equal((b5[:, 1] + b5[:, 3]) / 2, b7[:, 1]) and np.array_equal(b5[:, 3] - b5[:, 1], b7[:, 4])
+    ov = torch.zeros(len(a5), len(b5))
+    iou = torch.zeros(len(a5), len(b5))
+    ref.boxes_overlap_bev_cpu(torch.from_numpy(a5), torch.from_numpy(b5), ov)
+    ref.boxes_iou_bev_cpu(torch.from_numpy(a5), torch.from_numpy(b5), iou)
+    np.savez_compressed(os.path.join(HERE, "nms_pred_ref.npz"), a7=a7, b7=b7, a5=a5, b5=b5, overlap=ov.numpy(),
+                        iou=iou.numpy())
+    print("nms_pred_ref.npz", ov.shape, "pairs with overlap:", int((ov > 0).sum()), "IoU > 0.5:", int((iou > 0.5).sum()))
 
 
 def import_reference_nms_utils():
@@ -709,7 +761,9 @@ def make_roi_targets_ref():
 
 
 if __name__ == "__main__":
-    only = sys.argv[1:] or ["iou3d", "nms", "dense", "glue", "kl", "assign", "roitgt"]
+    only = sys.argv[1:] or ["iou3d", "nms", "dense", "glue", "kl", "assign", "roitgt", "nmspred"]
+    if "nmspred" in only:
+        make_nms_predicate_ref()
     if "roitgt" in only:
         make_roi_targets_ref()
     if "assign" in only:

@@ -54,6 +54,43 @@ def test_limit_period_matches_reference():
     assert np.array_equal(oracle.limit_period(g["limit_period_in"], 0.5, np.pi), g["limit_period_pi"])
 
 
+def test_nms_predicate_iou_pinned_to_reference_build():
+    """The IoU that decides nms_gpu (iou3d_nms convention) against REFERENCE-EXECUTED values: the reference's
+    compiled iou3d/src/iou3d_cpu.cpp run on [x - dx/2, y - dy/2, x + dx/2, y + dy/2, -heading] (fixture
+    nms_pred_ref.npz).  Bit-exact on every pair outside the margin band where the two libraries differ by design."""
+    import nms_pred_util as u
+    g = u.load()
+    safe = u.margin_safe(g["a7"], g["b7"])
+    assert safe.mean() > 0.99 and ((g["overlap"] > 0) & safe).sum() > 2000 and ((g["iou"] > 0.5) & safe).sum() > 50
+    ov, iou = oracle.boxes_overlap_bev(g["a7"], g["b7"]), oracle.boxes_iou_bev(g["a7"], g["b7"])
+    assert np.array_equal(ov.view(np.uint32)[safe], g["overlap"].view(np.uint32)[safe])
+    assert np.array_equal(iou.view(np.uint32)[safe], g["iou"].view(np.uint32)[safe])
+    # the band is real: inside it the two margins do disagree (otherwise the mask would be hiding nothing)
+    assert (ov != g["overlap"])[~safe].sum() > 10
+    # the host library (boxes_iou_bev_cpu's product implementation) holds the same bits
+    from glenet_amd import _host
+    assert np.array_equal(_host.boxes_iou_bev(g["a7"], g["b7"]).view(np.uint32)[safe], g["iou"].view(np.uint32)[safe])
+
+
+def test_device_libm_restatement_matches_the_host_libm(tmp_path):
+    """csrc/glx_libm.h compiles for the host unchanged; tools/libm_check.cpp compares it with libm (quick mode:
+    every 4099th float for sinf / cosf / atanf, 2e6 pairs for atan2f; the exhaustive run is in DESIGN.md)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "libm_check")
+    flags = ["-O2", "-ffp-contract=off", "-fopenmp", "-I", os.path.join(root, "glenet_amd", "csrc")]
+    if "fma" in open("/proc/cpuinfo").read():
+        flags.append("-mfma")                     # hardware fma(); without it libm's software fma gives the same bits
+    r = subprocess.run(["g++"] + flags + [os.path.join(root, "tools", "libm_check.cpp"), "-o", exe, "-lm"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, "quick"], capture_output=True, text=True)
+    rep = json.loads(r.stdout)
+    assert r.returncode == 0 and rep["sinf_diff"] == rep["cosf_diff"] == rep["atanf_diff"] == rep["atan2f_diff"] == 0, rep
+    assert rep["values_1d"] > 1000000
+
+
 # ------------------------------------------------------------------ known answers / properties
 def test_rotated_iou_known_answers():
     """SURVEY.md 8c spot values: identical boxes, half-shift of a 2x2 box, 45 degrees."""
