@@ -199,6 +199,162 @@ def roofline_of(per, prof_steps):
     return roof
 
 
+# --------------------------------------------------------------------------------- other configs, same line
+def _timed(fn, n, dev, warm=3):
+    import torch
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) / n
+
+
+def bench_bev(model, dev, frames=FRAMES_PER_GPU):
+    """north_star's "MFMA utilisation on the BEV head", on the path the step runs: the model's own BEV backbone +
+    anchor head (training mode, channels-last, fused BatchNorm), forward and forward + backward on a
+    (frames, 256, 200, 176) map, as TFLOP/s against the fp32 matrix peak.  Flops = multiply-adds x 2 of the
+    convolutions (BEVBackbone.flops_per_frame + the three 1x1 heads); backward counted as 2x forward."""
+    import torch
+    from glenet_amd import dense_path as dp
+    x = torch.randn(frames, 256, 200, 176, device=dev).to(memory_format=torch.channels_last).requires_grad_(True)
+    head_flops = 2 * 200 * 176 * 256 * (2 + 14 + 4)
+    flops = frames * (dp.BEVBackbone.flops_per_frame(200, 176) + head_flops)
+
+    def fwd():
+        with torch.no_grad():
+            model.dense_head(model.backbone_2d({"spatial_features": x}))
+
+    def fwd_bwd():
+        bd = model.dense_head(model.backbone_2d({"spatial_features": x}))
+        (bd["cls_preds"].sum() + bd["box_preds"].sum() + bd["dir_cls_preds"].sum()).backward()
+        x.grad = None
+        model.backbone_2d.zero_grad(set_to_none=True)
+        model.dense_head.zero_grad(set_to_none=True)
+    state = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k or "num_batches" in k}
+    ms_f = _timed(fwd, 10, dev)
+    ms_fb = _timed(fwd_bwd, 10, dev)
+    model.load_state_dict(state, strict=False)          # the timing passes moved the running statistics
+    return dict(workload="BEV backbone (12 conv3x3 + 2 deconv) + anchor head on (%d,256,200,176), fp32, channels-last, "
+                         "training-mode BatchNorm included in the time" % frames,
+                gflop_fwd=round(flops / 1e9, 1), fwd_ms=round(ms_f, 3), fwd_bwd_ms=round(ms_fb, 3),
+                fwd_TFLOPs=round(flops / ms_f / 1e9, 1), fwd_bwd_TFLOPs=round(3 * flops / ms_fb / 1e9, 1),
+                frac_of_fp32_mfma_peak=dict(fwd=round(flops / ms_f / 1e9 / MFMA_F32_PEAK_TFLOPS, 3),
+                                            fwd_bwd=round(3 * flops / ms_fb / 1e9 / MFMA_F32_PEAK_TFLOPS, 3)),
+                kernels="MIOpen implicit-GEMM / Winograd fp32 (vendor) + csrc/glx_bn.hip; per-kernel MFMA-busy counters: "
+                        "profiles/r03_bev_mfma.md")
+
+
+def bench_config3(dev, objects=4096, points=512, samples=30):
+    """BASELINE configs[3]: the CVAE on 4096 object crops x 512 points -- (i) the inference sampler, 30 latent samples
+    per object (fused MFMA PointNet kernel, csrc/glx_pointnet.hip), (ii) one TRAINING step forward + backward + clip +
+    AdamW (glenet_amd.cvae_train.CVAETrainStep: row GEMMs + fused training BatchNorm, one HIP graph)."""
+    import torch
+    from glenet_amd import cvae_train as ct
+    from glenet_amd import dense_path as dp
+    from glenet_amd import synth
+    torch.manual_seed(1)
+    pts, box8, box7 = (torch.from_numpy(a).to(dev) for a in synth.cvae_objects(objects, 2000, points, with_labels=True))
+    model = dp.CVAE(4, 8).to(dev)
+    per_obj = ct.CVAETrainStep.flops_per_object(points)
+    model.eval()
+    gen = torch.Generator(device=dev).manual_seed(7)
+    eps = torch.randn((samples, objects, 8), device=dev, generator=gen)
+
+    def sample_all():
+        with torch.no_grad():
+            for s_ in range(samples):
+                model.sample(pts, eps[s_])
+    ms_s = _timed(sample_all, 3, dev, warm=1)
+    # the sampler runs ONE large extractor (prior) + the narrow one per pass
+    sample_flops = objects * (2 * points * (4 * 64 + 64 * 128 + 128 * 512) + 2 * points * (4 * 8 + 8 * 8 + 8 * 8))
+    step = ct.CVAETrainStep(model, objects, points)
+    step.load(pts, box8, box7)
+    step.capture()
+    ms_t = _timed(step.step, 10, dev, warm=2)
+    loss = float(step.loss)
+    return dict(workload="configs[3]: cvae_uncertainty CVAE, %d object crops x %d points, fp32" % (objects, points),
+                sampler=dict(samples_per_object=samples, ms_all_samples=round(ms_s, 2), ms_per_sample=round(ms_s / samples, 3),
+                             objects_per_s=round(objects / (ms_s * 1e-3), 1),
+                             TFLOPs=round(samples * sample_flops / ms_s / 1e9, 1),
+                             frac_of_fp32_mfma_peak=round(samples * sample_flops / ms_s / 1e9 / MFMA_F32_PEAK_TFLOPS, 3)),
+                train_step=dict(what="forward (posterior + prior encoders, decoder) + losses + backward + clip 10 + AdamW, "
+                                     "one HIP graph", ms_per_step=round(ms_t, 2),
+                                objects_per_s=round(objects / (ms_t * 1e-3), 1), loss=round(loss, 4),
+                                gflop_per_step=round(3 * objects * per_obj / 1e9, 1),
+                                TFLOPs=round(3 * objects * per_obj / ms_t / 1e9, 1),
+                                frac_of_fp32_mfma_peak=round(3 * objects * per_obj / ms_t / 1e9 / MFMA_F32_PEAK_TFLOPS, 3)))
+
+
+def bench_config4(dev, frames=2, steps=60):
+    """BASELINE configs[4], one GPU's share: 2 Waymo-shaped frames (180 000 points, 5 features, 0.1 x 0.1 x 0.15 m
+    voxels) through VoxelResBackBone8x (17 SubM + 4 strided convs), forward, shape-static graph, two frames in flight;
+    plus the event-timed sparse-conv kernels of one eager pass (both roofline fractions of the dominant one)."""
+    import numpy as np
+    import torch
+    from glenet_amd import backbone as gb
+    from glenet_amd import synth
+    from glenet_amd.spconv import core as spcore
+    W = synth.WAYMO
+    fr = [synth.waymo_frame(i)[0] for i in range(frames)]
+    pts = torch.from_numpy(np.concatenate(fr)).to(dev)
+    bidx = torch.from_numpy(np.concatenate([np.full(len(f), i, np.int32) for i, f in enumerate(fr)])).to(dev)
+    torch.manual_seed(0)
+    model = gb.VoxelResBackBone8x(W["num_features"], gb.gv.grid_size_of(W["point_cloud_range"], W["voxel_size"])).to(dev).eval()
+    pipes = []
+    for _ in range(2):
+        p_ = gb.StaticFramePipeline(model, W, frames, pts.shape[0], W["num_features"], train_voxel_cap=False)
+        p_.calibrate(pts, bidx)
+        p_.load(pts, bidx)
+        p_.capture()
+        pipes.append(p_)
+    streams = [torch.cuda.Stream(dev) for _ in pipes]
+    turn = [0]
+
+    def one():
+        i = turn[0] % 2
+        turn[0] += 1
+        with torch.cuda.stream(streams[i]):
+            pipes[i].load(pts, bidx)
+            pipes[i].replay()
+    for _ in range(6):
+        one()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    for p_ in pipes:
+        p_.check()
+    prof = ConvProfiler()
+    spcore._profile_hook = prof
+    prof.enabled = True
+    for _ in range(6):
+        pipes[0].enqueue()
+    torch.cuda.synchronize(dev)
+    prof.enabled = False
+    spcore._profile_hook = None
+    roof = roofline_of(prof.summary(), 6)
+    st = pipes[0].out["encoded_spconv_tensor"]
+    out = dict(workload="configs[4] per-GPU share: %d Waymo-shaped frames x 180000 points, VoxelResBackBone8x forward "
+                        "(voxelize + MeanVFE + 21 sparse convs + dense()), eval-mode BatchNorm folded" % frames,
+               frames_per_s=round(frames / dt, 1), ms_per_step=round(dt * 1e3, 3), steps=steps,
+               voxels_in=int(pipes[0].out["voxel_index"].count.item()), voxels_out=int(st.count.item()))
+    if roof:
+        out["dominant_kernel"] = dict(kernel=roof["kernel"], avg_launch_us=roof["avg_launch_us"], launches=roof["launches"],
+                                      mfma_frac=roof["mfma_frac"], hbm_frac_algorithmic=roof["hbm"]["frac_algorithmic"],
+                                      TFLOPs=round(roof["mfma_frac"] * MFMA_F32_PEAK_TFLOPS, 2),
+                                      alg_GBps=roof["hbm"]["achieved_algorithmic_GBps"])
+        out["all_sparse_conv"] = {k: roof["all_sparse_conv"][k] for k in ("achieved_algorithmic_GBps", "frac_algorithmic",
+                                                                          "ms_per_step")}
+    return out
+
+
 # --------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -211,6 +367,8 @@ def main():
     ap.add_argument("--no-config1", action="store_true", help="skip the configs[1] forward-only sub-measurement")
     ap.add_argument("--no-stages", action="store_true", help="skip the per-stage timing pass")
     ap.add_argument("--fwd-steps", type=int, default=200)
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the configs[3] (CVAE), configs[4] (Waymo shard) and BEV-head sub-measurements")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the event-bracketed eager pass of configs[1]'s launches (the `roofline` object): the "
                          "command to put under rocprofv3 --kernel-trace --stats when its per-kernel averages are to "
@@ -333,6 +491,17 @@ def main():
     else:
         loss_end, parts_end = None, None
 
+    # host cost of a step without back-pressure: replay() lets at most `max_in_flight` (4) steps queue up and then waits
+    # for the oldest one, so over K steps the loop above spends ~(K - 4) / K of the DEVICE time inside that wait --
+    # that is what t_enq shows.  From an idle queue, 3 steps (fewer than the bound) are pure enqueue cost.
+    t_host = None
+    if args.steps > 0:
+        torch.cuda.synchronize(dev)
+        th = time.perf_counter()
+        for _ in range(3):
+            train_step()
+        t_host = (time.perf_counter() - th) / 3
+        torch.cuda.synchronize(dev)
     progress("headline done: %.2f ms/step" % (dt / max(args.steps, 1) * 1e3))
     # ---- per-stage milliseconds: one event-bracketed eager pass of the same launches per pool batch
     stages = None
@@ -438,10 +607,24 @@ def main():
                                parallelism="dp%d: frames shard; one flat RCCL all-reduce of %.1f MB gradients per step"
                                            % (world, n_params * 4 / 1e6) if world > 1 else "dp1 (single GPU, no collective)",
                                ranks_seen_by_collective=ranks_seen,
-                               host_enqueue_ms_per_step=round(t_enq / max(args.steps, 1) * 1e3, 4)),
+                               host_enqueue_ms_per_step=round(t_host * 1e3, 4) if t_host is not None else None,
+                               host_loop_ms_per_step=round(t_enq / max(args.steps, 1) * 1e3, 4),
+                               host_note="host_enqueue = set_lr (2 fills) + load (1 launch) + graph replay(s) measured on 3 "
+                                         "steps from an idle queue; host_loop = the timed loop's host time per step, which "
+                                         "includes waiting for step i-4 (at most 4 steps are kept in flight)"),
                    loss=dict(last=round(loss_end, 5), parts=parts_end),
                    stages_ms=stages, config1=config1, roofline=roof)
         progress("config1 + roofline done")
+        if world == 1 and not args.no_extra:
+            out["bev"] = bench_bev(model, dev)
+            progress("bev done")
+            del pipe
+            torch.cuda.empty_cache()
+            out["config3"] = bench_config3(dev)
+            progress("config3 done")
+            torch.cuda.empty_cache()
+            out["config4"] = bench_config4(dev)
+            progress("config4 done")
         if world == 1 and not args.no_cpu_baseline:
             from oracle import baseline as cpu_base           # bench's cpu_baseline leg: the checker, timed
             out["cpu_baseline"] = cpu_base.config3_composite([b[4] for b in pool[:1]], model, K)

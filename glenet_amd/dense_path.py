@@ -384,10 +384,33 @@ class PointFeat(nn.Module):
     def forward(self, x):                       # x (B, pts_dim, P)
         if self._fusable(x):
             return self._forward_fused(x)
+        if self._rows_trainable(x):
+            return self._forward_train_rows(x)
         x = F.relu(self.bn1(self.conv1(x)))
         x = F.relu(self.bn2(self.conv2(x)))
         x = self.bn3(self.conv3(x))
         return x.max(dim=2)[0]
+
+    # ---- training on the device: points as rows.  Conv1d(k=1) on (B, C, P) is a GEMM on the (B*P, C) row matrix and
+    # BatchNorm1d over (B, C, P) is BatchNorm over those rows: the (B, C, P) layout makes MIOpen run batched
+    # strided GEMMs and four-pass NCL BatchNorms; as rows every layer is ONE hipBLASLt GEMM (MFMA) + the fused
+    # statistics / transform kernels of csrc/glx_bn.hip (two launches forward, two backward, ReLU included), and the
+    # final max over the points of an object is a reduction over P consecutive rows.
+    def _rows_trainable(self, x):
+        from .spconv import core
+        ok = lambda c: c % 4 == 0 and c <= 512 and 1024 % c == 0                                # noqa: E731
+        return (x.is_cuda and self.training and torch.is_grad_enabled() and x.dtype == torch.float32
+                and core.USE_FUSED_TRAIN_BN and all(ok(m.num_features) and m.affine and m.momentum is not None
+                                                    for m in (self.bn1, self.bn2, self.bn3)))
+
+    def _forward_train_rows(self, x):
+        from .spconv import core
+        b, cin, p = x.shape
+        rows = x.transpose(1, 2).reshape(b * p, cin)
+        h = core.fused_train_bn(self.bn1, F.linear(rows, self.conv1.weight[:, :, 0], self.conv1.bias), True, None)
+        h = core.fused_train_bn(self.bn2, F.linear(h, self.conv2.weight[:, :, 0], self.conv2.bias), True, None)
+        h = core.fused_train_bn(self.bn3, F.linear(h, self.conv3.weight[:, :, 0], self.conv3.bias), False, None)
+        return h.view(b, p, -1).amax(dim=1)
 
     # ---- eval-mode fast path: one hand-written MFMA kernel for the whole extractor
     def _fusable(self, x):
@@ -524,3 +547,59 @@ class CVAE(nn.Module):
         prior, mu_x, logvar_x = self.x_encoder(points)
         kl = torch.distributions.kl.kl_divergence(post, prior)
         return post, prior, kl, (mu_xy, logvar_xy, mu_x, logvar_x)
+
+    # ---- training step (cvae_uncertainty/model.py:205-240, 267-370; train_utils/train_utils.py:50-72)
+    LOSS_WEIGHTS = dict(latent_weight=10.0, loc_weight=10.0, dir_weight=0.002, code_weights=(1.0,) * 7)   # cfgs/exp20.yaml
+
+    def training_losses(self, points, gt_boxes_input, gt_boxes, eps_post=None, loss_weights=None):
+        """The training branch of Generator.forward + get_training_loss.
+        points (B, C, P), gt_boxes_input (B, 8) (the posterior's condition), gt_boxes (B, 7) (regression labels),
+        eps_post (B, latent) = the noise of the posterior's reparametrisation (drawn here when None; the reference also
+        draws one for the prior, model.py:222, and never uses it).
+        -> (reg_loss_post, lattent_loss, regular_loss), parts -- the tuple train_one_epoch sums (after scaling the
+        latent term by its annealing factor, train_utils.py:57-59); parts = device scalars named like the tb_dict."""
+        w = dict(self.LOSS_WEIGHTS, **(loss_weights or {}))
+        post, mu_xy, logvar_xy = self.xy_encoder(points, gt_boxes_input)
+        prior, _, _ = self.x_encoder(points)
+        latent = torch.distributions.kl.kl_divergence(post, prior).mean() * w["latent_weight"]
+        if eps_post is None:
+            eps_post = torch.randn_like(mu_xy)
+        pred = self.obj_encoder(points, self.reparametrize(mu_xy, logvar_xy, eps_post))
+        reg, parts = cvae_reg_loss(pred, gt_boxes, w, self.dir_offset, self.num_dir_bins)
+        regular = 1e-4 * (l2_regularisation(self.xy_encoder) + l2_regularisation(self.x_encoder)
+                          + l2_regularisation(self.obj_encoder))
+        parts = dict(parts, box_pred_post=pred)
+        return (reg, latent, regular), parts
+
+
+def l2_regularisation(module):
+    """Sum of the 2-norms of a module's parameter tensors (model.py:20-28) -- one fused norm launch."""
+    return torch.stack(torch._foreach_norm([p for p in module.parameters()], 2)).sum()
+
+
+def cvae_direction_target(labels, dir_offset, num_bins):
+    """Bin of the label heading (Generator.get_direction_target, model.py:278-294), as class indices."""
+    offset_rot = limit_period(labels[..., 6] - dir_offset, 0, 2 * np.pi)
+    return torch.clamp(torch.floor(offset_rot / (2 * np.pi / num_bins)).long(), min=0, max=num_bins - 1)
+
+
+def cvae_reg_loss(box_preds, labels, weights, dir_offset, num_bins, beta=1.0 / 9.0):
+    """Generator.reg_loss (model.py:296-345): code-weighted smooth-L1 (beta 1/9, loss_utils.py:74-141) on the seven box
+    terms with the sin-difference heading encoding, summed over the batch and divided by it, plus the direction
+    cross-entropy.  The reference hands WeightedCrossEntropyLoss a (B, 1, 2) weight tensor of ones where it expects
+    (B, 1) (model.py:334-335): the (B, 1) losses broadcast to (B, B, 2), so `.sum() / batch_size` is TWICE the summed
+    cross-entropy -- restated as such, it is part of the trained objective."""
+    b = box_preds.shape[0]
+    pred, tgt = box_preds[:, :7], labels[:, :7]
+    sin_p = torch.sin(pred[:, 6:7]) * torch.cos(tgt[:, 6:7])
+    sin_t = torch.cos(pred[:, 6:7]) * torch.sin(tgt[:, 6:7])
+    pred = torch.cat([pred[:, :6], sin_p], dim=1)
+    tgt = torch.cat([tgt[:, :6], sin_t], dim=1)
+    tgt = torch.where(torch.isnan(tgt), pred, tgt)
+    cw = torch.as_tensor(weights["code_weights"], dtype=pred.dtype, device=pred.device)
+    n = torch.abs((pred - tgt) * cw)
+    loc = torch.where(n < beta, 0.5 * n ** 2 / beta, n - 0.5 * beta).sum() / b * weights["loc_weight"]
+    dir_t = cvae_direction_target(labels, dir_offset, num_bins)
+    ce = F.cross_entropy(box_preds[:, -num_bins:], dir_t, reduction="none")
+    dir_loss = (2.0 * ce.sum()) * weights["dir_weight"]
+    return loc + dir_loss, {"loss_loc": loc, "loss_dir": dir_loss, "loss_reg": loc + dir_loss}

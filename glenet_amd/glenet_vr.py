@@ -364,12 +364,45 @@ class StaticTrainStep(gb.StaticTrainPipeline):
             self.update()
         return bd
 
-    def capture(self, warmup=2, split=False):
+    def _training_state(self):
+        """Every tensor a step mutates besides gradients: parameters, optimizer moments / step count / schedule
+        scalars, BatchNorm running statistics and batch counters."""
+        opt = self.step_optimizer
+        if self.flat:
+            ts = [opt.flat_param, opt.exp_avg, opt.exp_avg_sq, opt.step_count, opt.hyper]
+        else:
+            ts = list(self.params) + [v for st in opt.state.values() for v in st.values() if torch.is_tensor(v)]
+        return ts + [b for b in self.net.buffers()]
+
+    def capture(self, warmup=2, split=False, keep_state=True):
         """split=False: fwd + bwd + clip + update in one graph.  split=True: the update is its own graph and
-        step() runs `exchange` between the two."""
+        step() runs `exchange` between the two.
+        keep_state (default): the warm-up passes and the capture itself run REAL steps on the loaded batch (that is
+        how the allocator pool and the lazily created optimizer state get sized) -- their effect on parameters, Adam
+        moments, the step count (bias correction), BatchNorm running statistics and num_batches_tracked is undone
+        afterwards by copying a snapshot back in place (pointers recorded in the graph stay valid), so the first
+        step() after capture() is training step 1 at the schedule's first learning rate."""
         self.split = bool(split)
         if not split and self.exchange is not None:
             raise ValueError("a gradient exchange needs capture(split=True)")
+        before = self._training_state() if keep_state else []
+        snap = [t.detach().clone() for t in before]
+        try:
+            self._capture(warmup, split)
+        finally:
+            if keep_state:
+                torch.cuda.synchronize(self.points.device)
+                known = {id(t) for t in before}
+                with torch.no_grad():
+                    for t, s in zip(before, snap):
+                        t.copy_(s)
+                    for t in self._training_state():      # optimizer state a torch optimizer created during warm-up
+                        if id(t) not in known:
+                            t.zero_()
+                gb._lib.bump_weights_epoch()
+        return self
+
+    def _capture(self, warmup, split):
         super().capture(warmup)
         if split:
             dev = self.points.device

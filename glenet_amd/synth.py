@@ -140,3 +140,33 @@ def random_boxes(rng, n, xy_range=40.0, near_dup=0.3):
         b[dst, 3:6] *= rng.uniform(0.9, 1.1, (ndup, 3)).astype(np.float32)
         b[dst, 6] += rng.normal(0, 0.1, ndup).astype(np.float32)
     return b
+
+
+def cvae_objects(n, seed=2000, num_points=512, with_labels=False):
+    """Synthetic CVAE crops (BASELINE configs[3]): per object `num_points` samples (with replacement) of a
+    car-box surface in object coordinates (points relative to the box centre, box turned by a random yaw), normalised
+    as the reference dataset does -- (x - mean) / diag, (y - mean) / diag, (z - mean) / 1.56 with
+    diag = sqrt(3.9^2 + 1.6^2), transposed to (4, P) (cvae_uncertainty/dataset.py:360-397) -- plus an intensity.
+    with_labels: also gt_boxes (n, 7) = [-mean / diag, -mean / diag, -mean / 1.56, log(dx / 3.9), log(dy / 1.6),
+    log(dz / 1.56), yaw] and gt_boxes_input (n, 8) = the same with the yaw as (sin, cos) (dataset.py:406-424)."""
+    rng = np.random.default_rng(seed)
+    size = np.array([3.9, 1.6, 1.56]) * rng.uniform(0.9, 1.1, (n, 1, 3))
+    face = rng.integers(0, 3, (n, num_points))
+    p = rng.uniform(-0.5, 0.5, (n, num_points, 3))
+    sign = rng.choice([-0.5, 0.5], (n, num_points))
+    for a in range(3):
+        p[..., a] = np.where(face == a, sign, p[..., a])
+    p = p * size
+    yaw = rng.uniform(-np.pi, np.pi, (n, 1))
+    c, s = np.cos(yaw), np.sin(yaw)
+    x, y = p[..., 0] * c - p[..., 1] * s, p[..., 0] * s + p[..., 1] * c
+    diag = np.sqrt(3.9 ** 2 + 1.6 ** 2)
+    mx, my, mz = x.mean(1, keepdims=True), y.mean(1, keepdims=True), p[..., 2].mean(1, keepdims=True)
+    pts = np.stack([(x - mx) / diag, (y - my) / diag, (p[..., 2] - mz) / 1.56, rng.uniform(0, 1, (n, num_points))], 1)
+    pts = pts.astype(np.float32)                               # (n, 4, P)
+    if not with_labels:
+        return pts
+    box7 = np.concatenate([-mx / diag, -my / diag, -mz / 1.56, np.log(size[:, 0, 0:1] / 3.9), np.log(size[:, 0, 1:2] / 1.6),
+                           np.log(size[:, 0, 2:3] / 1.56), yaw], 1).astype(np.float32)
+    box8 = np.concatenate([box7[:, :6], np.sin(box7[:, 6:7]), np.cos(box7[:, 6:7])], 1).astype(np.float32)
+    return pts, box8, box7

@@ -19,6 +19,8 @@ committed, this script is committed, nothing of the reference is copied.
                          suppression strictness, output ordering) given the oracle's IoU matrix;
                          the IoU arithmetic itself is pinned by iou3d_ref.npz (shared helpers).
   limit_period / boxes3d_to_bev_torch outputs of the reference are stored alongside.
+  cvae_train_ref.npz the training branch of the CVAE Generator with its loss terms and gradients
+                     (make_cvae_train_ref(), run as `make_golden.py cvaetrain`).
   nms_pred_ref.npz   the IoU that decides nms_gpu pinned to the reference's compiled iou3d_cpu.cpp through a
                      cross-library identity on dyadic boxes (see make_nms_predicate_ref()).
   detector_glue_ref.npz  box coder, anchor generator and the two generate_predicted_boxes statement
@@ -141,6 +143,73 @@ def make_nms_predicate_ref():
     np.savez_compressed(os.path.join(HERE, "nms_pred_ref.npz"), a7=a7, b7=b7, a5=a5, b5=b5, overlap=ov.numpy(),
                         iou=iou.numpy())
     print("nms_pred_ref.npz", ov.shape, "pairs with overlap:", int((ov > 0).sum()), "IoU > 0.5:", int((iou > 0.5).sum()))
+
+
+def make_cvae_train_ref():
+    """cvae_train_ref.npz: the TRAINING branch of the reference's Generator (cvae_uncertainty/model.py:200-240) and its
+    get_training_loss / reg_loss / direction target (:267-370) run unmodified on CPU in train() mode (batch-statistic
+    BatchNorm), with the three loss terms, the tb_dict entries and d(reg + latent + regular)/d(every parameter) from
+    the reference's autograd, plus the BatchNorm running statistics after the step.
+    Run in its own process (`make_golden.py cvaetrain`).  Imports: glenet_amd.dropin.install() serves the compiled
+    extension names, so `pcdet.utils.loss_utils` is the reference's REAL file (WeightedSmoothL1Loss,
+    WeightedCrossEntropyLoss).  Disclosed placeholders: uninstalled third-party packages (torchvision, SharedArray,
+    numba, ... : see tools/ref_dropin_check.py); `.cuda()` is a no-op (loss_utils.py:96 moves code_weights);
+    Generator.reparametrize allocates torch.cuda.FloatTensor noise -> the same statement
+    `eps.mul(std).add_(mu)`, std = logvar.mul(0.5).exp_(), with stored eps (two draws per step: posterior, prior)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ref_dropin_check as rdc
+    placeholders = rdc.prepare_imports()
+    if "torchvision" not in sys.modules:
+        try:
+            import torchvision  # noqa: F401
+        except ModuleNotFoundError:
+            sys.modules["torchvision"] = rdc._Placeholder("torchvision")
+            sys.modules["torchvision.models"] = rdc._Placeholder("torchvision.models")
+            placeholders.append("torchvision")
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, os.path.join(REF, "cvae_uncertainty"))
+    cvae = importlib.import_module("model")
+    mcfg = rdc.EasyDict(LATENT_DIM=8, DIR_OFFSET=0.78539, DIR_LIMIT_OFFSET=0.0, NUM_DIR_BINS=2,
+                        LOSS_CONFIG=dict(LOSS_WEIGHTS={"latent_weight": 10, "loc_weight": 10.0, "dir_weight": 0.002,
+                                                       "code_weights": [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]}))
+    gen = torch.Generator().manual_seed(4321)
+    torch.manual_seed(3)
+    g = cvae.Generator(mcfg, 4, 1)
+    torch.Tensor.cuda = real_cuda
+    g.train()
+    _randomise_bn(g, gen)
+    B, P = 24, 96
+    pts = torch.randn(B, 4, P, generator=gen) * 0.4
+    cond = torch.randn(B, 8, generator=gen) * 0.3
+    labels = torch.randn(B, 7, generator=gen) * 0.3
+    labels[:, 6] = torch.rand(B, generator=gen) * 6.28 - 3.14
+    labels[0, 6], labels[1, 6] = 0.78539, 0.78539 + np.pi                  # bin boundaries of the direction target
+    eps = [torch.randn(B, 8, generator=gen), torch.randn(B, 8, generator=gen)]
+    draws = iter(eps)
+
+    def reparametrize(mu, logvar):
+        std = logvar.mul(0.5).exp_()
+        return next(draws).clone().mul(std).add_(mu)
+    g.reparametrize = reparametrize
+    state0 = {k: v.detach().clone() for k, v in g.state_dict().items()}
+    (reg, lat, regular), tb, _ = g({"points": pts, "gt_boxes_input": cond, "gt_boxes": labels})
+    loss = reg + lat + regular
+    loss.backward()
+    out = {"cvae/%s" % k: v.numpy() for k, v in state0.items() if "global_step" not in k}
+    out.update(points=pts.numpy(), cond=cond.numpy(), labels=labels.numpy(), eps_post=eps[0].numpy(),
+               eps_prior=eps[1].numpy(), reg_loss_post=reg.detach().numpy(), lattent_loss=lat.detach().numpy(),
+               regular_loss=regular.detach().numpy(), box_pred_post=g.box_pred_post.detach().numpy(),
+               dir_targets=g.get_direction_target(labels, dir_offset=mcfg.DIR_OFFSET, num_bins=2).numpy())
+    for k, v in tb.items():
+        out["tb/" + k] = np.float32(v)
+    for k, p_ in g.named_parameters():
+        out["grad/" + k] = p_.grad.numpy()
+    for k, v in g.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            out["after/" + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "cvae_train_ref.npz"), **out)
+    print("cvae_train_ref.npz", float(reg), float(lat), float(regular), tb, "placeholders:", placeholders)
 
 
 def import_reference_nms_utils():
@@ -764,6 +833,8 @@ if __name__ == "__main__":
     only = sys.argv[1:] or ["iou3d", "nms", "dense", "glue", "kl", "assign", "roitgt", "nmspred"]
     if "nmspred" in only:
         make_nms_predicate_ref()
+    if "cvaetrain" in sys.argv[1:]:          # own process only: it installs the drop-in and imports all of pcdet
+        make_cvae_train_ref()
     if "roitgt" in only:
         make_roi_targets_ref()
     if "assign" in only:

@@ -486,3 +486,54 @@ def test_graphs_follow_weight_changes_made_outside_them(dev):
         want = gb.HeightCompression()(model(gb.MeanVFE()(bd)))["spatial_features"]
     torch.cuda.synchronize()
     assert not torch.allclose(a, b) and torch.allclose(b, want, rtol=1e-5, atol=1e-6)
+
+
+def test_eval_after_fused_training_steps_sees_the_new_weights(dev):
+    """FlatAdamW and the fused training BatchNorm update parameters / running statistics through
+    raw pointers, and a replayed training graph runs no Python -- no tensor version moves.  eval -> train steps ->
+    eval on the SAME module (and an inference graph sharing it) must compute with the updated weights: every
+    derived-tensor cache also keys on glenet_amd._lib.weights_epoch()."""
+    import copy
+    from glenet_amd import _lib
+    from glenet_amd.optim import FlatAdamW
+    torch.manual_seed(0)
+    frames = [synth.kitti_frame(40 + i, num_points=6000)[0] for i in range(2)]
+    pts = torch.from_numpy(np.concatenate(frames)).to(dev)
+    bidx = torch.from_numpy(np.concatenate([np.full(len(f), i, np.int32) for i, f in enumerate(frames)])).to(dev)
+    grid = gb.gv.grid_size_of(K["point_cloud_range"], K["voxel_size"])
+    model = gb.VoxelBackBone8x(4, grid).to(dev)
+
+    def evaluate(m):
+        m.eval()
+        with torch.no_grad():
+            bd = gb.voxelize_batch(pts, bidx, 2, K, train=True)
+            return gb.HeightCompression()(m(gb.MeanVFE()(bd)))["spatial_features"].clone()
+
+    y0 = evaluate(model)                                   # fills the packed-weight and BatchNorm-affine caches
+    ipipe = gb.StaticFramePipeline(model, K, 2, pts.shape[0], 4)
+    ipipe.calibrate(pts, bidx)
+    ipipe.load(pts, bidx)
+    ipipe.capture()
+    assert torch.equal(ipipe.replay()["spatial_features"], y0)
+    # ---- training steps as one replayed graph with the fused optimizer inside
+    model.train()
+    opt = FlatAdamW(model.parameters(), lr=5e-3)
+    versions = [p._version for p in model.parameters()] + [b._version for b in model.buffers()]
+    pipe = gb.StaticTrainPipeline(model, K, 2, pts.shape[0], 4, optimizer=opt)
+    pipe.calibrate(pts, bidx)
+    pipe.load(pts, bidx)
+    pipe.capture()
+    e0 = _lib.weights_epoch()
+    for _ in range(3):
+        pipe.replay()
+    torch.cuda.synchronize()
+    assert _lib.weights_epoch() >= e0 + 3
+    # ---- eval again: same module object, same tensors, versions of the PARAMETERS untouched by the replays
+    y1 = evaluate(model)
+    fresh = gb.VoxelBackBone8x(4, grid).to(dev)
+    fresh.load_state_dict(copy.deepcopy(model.state_dict()))
+    y_ref = evaluate(fresh)                                # caches built from scratch on the current weights
+    assert torch.equal(y1, y_ref)
+    assert float((y1 - y0).abs().max()) > 1e-3
+    assert torch.equal(ipipe.replay()["spatial_features"], y_ref)     # the inference graph recorded itself again
+    assert [p._version for p in model.parameters()] == versions[:len(list(model.parameters()))]

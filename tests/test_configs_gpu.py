@@ -56,23 +56,7 @@ def test_cvae_golden_on_device_fused_extractor(dev):
 
 
 def _cvae_objects(n, seed=2000):
-    """512 samples (with replacement) of a car-box surface per object, normalised as the
-    reference dataset does (cvae_uncertainty/dataset.py:364-366,383-397)."""
-    rng = np.random.default_rng(seed)
-    size = np.array([3.9, 1.6, 1.56]) * rng.uniform(0.9, 1.1, (n, 1, 3))
-    face = rng.integers(0, 3, (n, 512))
-    p = rng.uniform(-0.5, 0.5, (n, 512, 3))
-    sign = rng.choice([-0.5, 0.5], (n, 512))
-    for a in range(3):
-        p[..., a] = np.where(face == a, sign, p[..., a])
-    p = p * size
-    yaw = rng.uniform(-np.pi, np.pi, (n, 1))
-    c, s = np.cos(yaw), np.sin(yaw)
-    x, y = p[..., 0] * c - p[..., 1] * s, p[..., 0] * s + p[..., 1] * c
-    diag = np.sqrt(3.9 ** 2 + 1.6 ** 2)
-    pts = np.stack([(x - x.mean(1, keepdims=True)) / diag, (y - y.mean(1, keepdims=True)) / diag,
-                    (p[..., 2] - p[..., 2].mean(1, keepdims=True)) / 1.56, rng.uniform(0, 1, (n, 512))], 1)
-    return pts.astype(np.float32)                              # (n, 4, 512)
+    return synth.cvae_objects(n, seed)                         # (n, 4, 512), SURVEY 8d
 
 
 def test_cvae_config4_full_size_30_samples(dev):
@@ -99,6 +83,68 @@ def test_cvae_config4_full_size_30_samples(dev):
     assert float((got[[0, 17, 29], :512, :6] - want[..., :6]).abs().max()) < 2e-4
     np.testing.assert_allclose(alone.cpu().numpy(), got[3, 100:101].cpu().numpy(), rtol=1e-5, atol=1e-5)
     assert float(got.std(0)[:, :6].mean()) > 0                                    # the 30 samples differ
+
+
+def test_cvae_training_step_matches_reference_golden_on_device(dev):
+    """The training branch on the device (row GEMMs + fused training BatchNorm) against the reference-generated
+    golden of tests/test_dense_path_cpu.py: loss terms, decoder output, every gradient, running statistics."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cvae_train_ref.npz"))
+    m = dp.CVAE(4, 8)
+    m.load_state_dict({k[len("cvae/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("cvae/")}, strict=True)
+    m = m.to(dev).train()
+    T = lambda k: torch.from_numpy(g[k]).to(dev)                                          # noqa: E731
+    assert m.x_encoder.fe._rows_trainable(T("points"))
+    (reg, lat, regular), parts = m.training_losses(T("points"), T("cond"), T("labels"), eps_post=T("eps_post"))
+    np.testing.assert_allclose(parts["box_pred_post"].detach().cpu().numpy(), g["box_pred_post"], rtol=1e-4, atol=1e-5)
+    for got, key in ((reg, "reg_loss_post"), (lat, "lattent_loss"), (regular, "regular_loss")):
+        np.testing.assert_allclose(float(got.detach()), float(g[key]), rtol=2e-5)
+    (reg + lat + regular).backward()
+    for name, p in m.named_parameters():
+        want = g["grad/" + name]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), want, rtol=2e-3, atol=1e-4 * (np.abs(want).max() + 1e-12), err_msg=name)
+    for k, v in m.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            np.testing.assert_allclose(v.cpu().numpy(), g["after/" + k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+def test_cvae_train_step_graph_follows_an_eager_loop(dev):
+    """CVAETrainStep (one HIP graph: forward, backward, clip 10, AdamW on flat buffers) against zero_grad / backward /
+    clip_grad_norm_ / torch.optim.AdamW on a copy of the model run through the unfused (B, C, P) modules."""
+    import copy
+    from glenet_amd import cvae_train as ct
+    torch.manual_seed(0)
+    B, P = 256, 128
+    pts, box8, box7 = (torch.from_numpy(a).to(dev) for a in synth.cvae_objects(B, 5, P, with_labels=True))
+    model = dp.CVAE(4, 8).to(dev).train()
+    ref = copy.deepcopy(model)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    eps = [torch.randn((B, 8), device=dev, generator=gen) for _ in range(4)]
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-3, betas=ct.OPTIM_CFG["BETAS"], weight_decay=ct.OPTIM_CFG["WEIGHT_DECAY"])
+    rows = dp.PointFeat._rows_trainable
+    dp.PointFeat._rows_trainable = lambda self, x: False
+    want = []
+    try:
+        for e in eps:
+            opt.zero_grad(set_to_none=True)
+            (reg, lat, regular), _ = ref.training_losses(pts, box8, box7, eps_post=e)
+            loss = reg + lat + regular
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(ref.parameters(), ct.OPTIM_CFG["GRAD_NORM_CLIP"])
+            opt.step()
+            want.append(float(loss))
+    finally:
+        dp.PointFeat._rows_trainable = rows
+    step = ct.CVAETrainStep(model, B, P, lr=1e-3)
+    step.load(pts, box8, box7, eps[0])
+    step.capture()
+    got = []
+    for e in eps:
+        step.load(pts, box8, box7, e)
+        step.step()
+        got.append(float(step.loss))
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-4)                  # same weights: capture() restored them
+    np.testing.assert_allclose(got, want, rtol=2e-2)
+    assert int(step.optimizer.step_count) == 4
 
 
 def test_waymo_shaped_full_size_shard(dev):

@@ -109,3 +109,31 @@ def test_roi_grid_geometry_matches_reference_helpers():
     np.testing.assert_allclose(local[0, 1].numpy(), [-1.0, -0.5, 0.375])     # z index runs fastest
     np.testing.assert_allclose(local[0, 4].numpy(), [1.0, -0.5, -0.375])
     np.testing.assert_allclose(glob[0, 0].numpy(), [0.0, 1.5, 0.125])
+
+
+def test_cvae_training_losses_and_gradients_match_reference_golden():
+    """cvae_train_ref.npz = the reference Generator's training branch + get_training_loss + autograd on CPU
+    (tests/golden/make_golden.py:make_cvae_train_ref).  Our CVAE.training_losses loads its state dict by name and
+    reproduces the three loss terms, the tb_dict parts, the decoder output, every parameter gradient and the
+    BatchNorm running statistics after the step."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cvae_train_ref.npz"))
+    m = dp.CVAE(4, 8).train()
+    sd = {k[len("cvae/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("cvae/")}
+    m.load_state_dict(sd, strict=True)
+    T = lambda k: torch.from_numpy(g[k])                                                   # noqa: E731
+    (reg, lat, regular), parts = m.training_losses(T("points"), T("cond"), T("labels"), eps_post=T("eps_post"))
+    np.testing.assert_allclose(parts["box_pred_post"].detach().numpy(), g["box_pred_post"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(float(reg), float(g["reg_loss_post"]), rtol=1e-5)
+    np.testing.assert_allclose(float(lat), float(g["lattent_loss"]), rtol=1e-5)
+    np.testing.assert_allclose(float(regular), float(g["regular_loss"]), rtol=1e-5)
+    for k in ("loss_loc", "loss_dir", "loss_reg"):
+        np.testing.assert_allclose(float(parts[k]), float(g["tb/%s_post" % k]), rtol=1e-5)
+    assert np.array_equal(dp.cvae_direction_target(T("labels"), 0.78539, 2).numpy(), g["dir_targets"].argmax(-1))
+    (reg + lat + regular).backward()
+    for name, p in m.named_parameters():
+        want = g["grad/" + name]
+        scale = np.abs(want).max() + 1e-12
+        np.testing.assert_allclose(p.grad.numpy(), want, rtol=1e-4, atol=2e-5 * scale, err_msg=name)
+    for k, v in m.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            np.testing.assert_allclose(v.numpy(), g["after/" + k], rtol=1e-5, atol=1e-6, err_msg=k)
