@@ -409,6 +409,7 @@ class StaticTrainPipeline(StaticFramePipeline):
         self.loss = None
         self.overlap_wgrad = True
         self.mark = None            # optional callable(stage_name): bench.py records an event per stage
+        self.data_step = None       # optional data_pipeline.DeviceDataProcessor: mask + shuffle inside the step
 
     def _weights_tag(self):
         return None      # training steps pack weights inside the step (spconv.core._packed_weight): nothing cached
@@ -431,7 +432,12 @@ class StaticTrainPipeline(StaticFramePipeline):
         self.out = self.loss = None
         with workspace.scoped(id(self)):
             with torch.no_grad():
-                bd = voxelize_batch(self.points, self.batch_idx, self.B, self.cfg, train=self.train_cap,
+                pts, bidx = self.points, self.batch_idx
+                if self.data_step is not None:      # range mask + per-frame shuffle on the device
+                    pts, bidx = self.data_step.static_step(pts, bidx, self.B)
+                    if self.mark:
+                        self.mark("device data step (range mask + shuffle)")
+                bd = voxelize_batch(pts, bidx, self.B, self.cfg, train=self.train_cap,
                                     static=True)
                 cur = torch.cuda.current_stream(dev)
                 if self.overlap_plan:

@@ -15,17 +15,19 @@ typedef float of32x4 __attribute__((ext_vector_type(4)));
 #define OPT_THREADS 256
 #define OPT_MAX_BLOCKS 1024
 
+// grad_scale: the gradient that is clipped and applied is g * grad_scale, each element rounded to float first -- the
+// 1 / world_size of a data-parallel SUM all-reduce folded into the update (it was a separate pass over the buffer).
 __global__ __launch_bounds__(OPT_THREADS) void k_gradnorm_partial(const float* __restrict__ g, long long n,
-                                                                  double* __restrict__ partial,
+                                                                  float grad_scale, double* __restrict__ partial,
                                                                   int* __restrict__ step) {
   const long long n4 = n >> 2;
   double s = 0;
   for (long long e = (long long)blockIdx.x * OPT_THREADS + threadIdx.x; e < n4; e += (long long)gridDim.x * OPT_THREADS) {
-    of32x4 v = reinterpret_cast<const of32x4*>(g)[e];
+    of32x4 v = reinterpret_cast<const of32x4*>(g)[e] * grad_scale;
     s += (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-    float v = g[(n4 << 2) + threadIdx.x];
+    float v = g[(n4 << 2) + threadIdx.x] * grad_scale;
     s += (double)v * v;
   }
   __shared__ double red[OPT_THREADS];
@@ -46,7 +48,8 @@ __global__ __launch_bounds__(OPT_THREADS) void k_gradnorm_partial(const float* _
 __global__ __launch_bounds__(OPT_THREADS) void k_adamw(float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ m, float* __restrict__ v, long long n,
                                                        const float* __restrict__ hyper, float beta2, float eps,
-                                                       float wd, float max_norm, const int* __restrict__ step,
+                                                       float wd, float max_norm, float grad_scale,
+                                                       const int* __restrict__ step,
                                                        const double* __restrict__ partial, int nparts,
                                                        float* __restrict__ norm_out) {
   __shared__ float s_coef;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adamw(float* __restrict__ p, co
     of32x4 mv = reinterpret_cast<of32x4*>(m)[e], vv = reinterpret_cast<of32x4*>(v)[e];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float gi = gv[i] * coef;
+      const float gi = (gv[i] * grad_scale) * coef;
       pv[i] *= decay;
       mv[i] = mv[i] + (gi - mv[i]) * (1.f - b1);              // exp_avg.lerp_(grad, 1 - beta1)
       vv[i] = vv[i] * beta2 + (1.f - beta2) * gi * gi;        // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adamw(float* __restrict__ p, co
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const long long e = (n4 << 2) + threadIdx.x;
-    const float gi = g[e] * coef;
+    const float gi = (g[e] * grad_scale) * coef;
     float pe = p[e] * decay;
     const float me = m[e] + (gi - m[e]) * (1.f - b1);
     const float ve = v[e] * beta2 + (1.f - beta2) * gi * gi;
@@ -115,10 +118,23 @@ static int opt_blocks(long long n) {
 
 extern "C" size_t glx_adamw_workspace_bytes(void) { return OPT_MAX_BLOCKS * sizeof(double) + 256; }
 
+extern "C" int glx_adamw_clip_step_scaled(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                          int64_t n, const float* hyper, float beta2, float eps, float weight_decay,
+                                          float max_norm, float grad_scale, int32_t* step, float* norm_out,
+                                          void* workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int glx_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                    int64_t n, const float* hyper, float beta2, float eps, float weight_decay,
                                    float max_norm, int32_t* step, float* norm_out, void* workspace,
                                    size_t workspace_bytes, void* stream) {
+  return glx_adamw_clip_step_scaled(params, grads, exp_avg, exp_avg_sq, n, hyper, beta2, eps, weight_decay, max_norm,
+                                    1.0f, step, norm_out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int glx_adamw_clip_step_scaled(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                          int64_t n, const float* hyper, float beta2, float eps, float weight_decay,
+                                          float max_norm, float grad_scale, int32_t* step, float* norm_out,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
   GLX_REQUIRE(n >= 0 && (n == 0 || (params && grads && exp_avg && exp_avg_sq)) && hyper && step,
               "glx_adamw_clip_step: null pointer");
   GLX_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
@@ -130,10 +146,10 @@ extern "C" int glx_adamw_clip_step(float* params, const float* grads, float* exp
   if (n == 0) return GLX_OK;
   hipStream_t st = (hipStream_t)stream;
   const int blocks = opt_blocks(n);
-  hipLaunchKernelGGL(k_gradnorm_partial, dim3(blocks), dim3(OPT_THREADS), 0, st, grads, (long long)n,
+  hipLaunchKernelGGL(k_gradnorm_partial, dim3(blocks), dim3(OPT_THREADS), 0, st, grads, (long long)n, grad_scale,
                      (double*)workspace, step);
   hipLaunchKernelGGL(k_adamw, dim3(blocks), dim3(OPT_THREADS), 0, st, params, grads, exp_avg, exp_avg_sq,
-                     (long long)n, hyper, beta2, eps, weight_decay, max_norm, (const int*)step,
+                     (long long)n, hyper, beta2, eps, weight_decay, max_norm, grad_scale, (const int*)step,
                      (const double*)workspace, blocks, norm_out);
   GLX_LAUNCH_CHECK();
   return GLX_OK;

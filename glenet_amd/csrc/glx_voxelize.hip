@@ -391,6 +391,55 @@ static DynWs dyn_ws_layout(void* base, int P, int B, int gx, int gy, int gz) {
   return w;
 }
 
+// ------------------------------------------------------------------ device data step
+// DataProcessor.mask_points_and_boxes_outside_range + shuffle_points (data_processor.py:78-105) on the stacked,
+// capacity-sized point buffer of a shape-static step, without boolean indexing (variable shapes, a host read-back):
+// every point gets the 64-bit key (frame id or B when masked / padding) << 32 | random 32 bits; one sort of the keys
+// IS the per-frame random permutation with the dropped points moved behind the last frame (frame id B = padding for
+// the voxelizer), and k_permute_points gathers the rows.  x / y closed interval as common_utils.py:60-63.
+__global__ void k_shuffle_keys(const float* __restrict__ pts, const int* __restrict__ batch, int P, int C, int B,
+                               float x0, float y0, float x1, float y1, const uint32_t* __restrict__ rnd,
+                               long long* __restrict__ keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const float x = pts[(long long)i * C], y = pts[(long long)i * C + 1];
+  const int b = batch ? batch[i] : 0;
+  const bool keep = b >= 0 && b < B && x >= x0 && x <= x1 && y >= y0 && y <= y1;
+  keys[i] = ((long long)(keep ? b : B) << 32) | (long long)rnd[i];
+}
+
+extern "C" int glx_shuffle_keys(const float* points, const int32_t* point_batch, int P, int C, int B,
+                                const float* range_xy, const uint32_t* random_bits, int64_t* keys, void* stream) {
+  if (P <= 0) return GLX_OK;
+  GLX_REQUIRE(points && range_xy && random_bits && keys && C >= 2, "glx_shuffle_keys: bad arguments");
+  hipLaunchKernelGGL(k_shuffle_keys, dim3(glx_divup(P, 256)), dim3(256), 0, (hipStream_t)stream, points, point_batch,
+                     P, C, B, range_xy[0], range_xy[1], range_xy[2], range_xy[3], random_bits, (long long*)keys);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+__global__ void k_permute_points(const float* __restrict__ pts, const long long* __restrict__ order,
+                                 const long long* __restrict__ sorted_keys, long long total, int C,
+                                 float* __restrict__ out, int* __restrict__ out_batch) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const long long i = t / C;
+  const int c = (int)(t - i * C);
+  out[t] = pts[order[i] * C + c];
+  if (c == 0) out_batch[i] = (int)(sorted_keys[i] >> 32);
+}
+
+extern "C" int glx_permute_points(const float* points, const int64_t* order, const int64_t* sorted_keys, int P, int C,
+                                  float* out_points, int32_t* out_batch, void* stream) {
+  if (P <= 0) return GLX_OK;
+  GLX_REQUIRE(points && order && sorted_keys && out_points && out_batch, "glx_permute_points: null pointer");
+  const long long total = (long long)P * C;
+  hipLaunchKernelGGL(k_permute_points, dim3(glx_divup(total, 256)), dim3(256), 0, (hipStream_t)stream, points,
+                     (const long long*)order, (const long long*)sorted_keys, total, C, out_points, out_batch);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
 extern "C" size_t glx_voxelize_dynamic_workspace_bytes(int P, int B, int gx, int gy, int gz) {
   return dyn_ws_layout(nullptr, P, B, gx, gy, gz).bytes + 256;
 }

@@ -480,7 +480,9 @@ class LatentEncoder(nn.Module):
         if cond is not None:
             h = torch.cat([h, cond], dim=1)
         mu, logvar = self.fc1(h), self.fc2(h)
-        dist = torch.distributions.Independent(torch.distributions.Normal(mu, torch.exp(logvar) + 3e-22), 1)
+        # validate_args=False: the argument checks read a device boolean back (not capturable, and a sync per call)
+        dist = torch.distributions.Independent(
+            torch.distributions.Normal(mu, torch.exp(logvar) + 3e-22, validate_args=False), 1, validate_args=False)
         return dist, mu, logvar
 
 
@@ -583,6 +585,18 @@ def cvae_direction_target(labels, dir_offset, num_bins):
     return torch.clamp(torch.floor(offset_rot / (2 * np.pi / num_bins)).long(), min=0, max=num_bins - 1)
 
 
+_CW_CACHE = {}
+
+
+def _code_weights(values, device):
+    """Device copy of the code weights, made once per (values, device): a host-to-device copy inside a recorded step
+    is not capturable (the first, eager call of a step fills the cache)."""
+    key = (values, str(device))
+    if key not in _CW_CACHE:
+        _CW_CACHE[key] = torch.tensor(values, dtype=torch.float32, device=device)
+    return _CW_CACHE[key]
+
+
 def cvae_reg_loss(box_preds, labels, weights, dir_offset, num_bins, beta=1.0 / 9.0):
     """Generator.reg_loss (model.py:296-345): code-weighted smooth-L1 (beta 1/9, loss_utils.py:74-141) on the seven box
     terms with the sin-difference heading encoding, summed over the batch and divided by it, plus the direction
@@ -596,7 +610,7 @@ def cvae_reg_loss(box_preds, labels, weights, dir_offset, num_bins, beta=1.0 / 9
     pred = torch.cat([pred[:, :6], sin_p], dim=1)
     tgt = torch.cat([tgt[:, :6], sin_t], dim=1)
     tgt = torch.where(torch.isnan(tgt), pred, tgt)
-    cw = torch.as_tensor(weights["code_weights"], dtype=pred.dtype, device=pred.device)
+    cw = _code_weights(tuple(weights["code_weights"]), pred.device)
     n = torch.abs((pred - tgt) * cw)
     loc = torch.where(n < beta, 0.5 * n ** 2 / beta, n - 0.5 * beta).sum() / b * weights["loc_weight"]
     dir_t = cvae_direction_target(labels, dir_offset, num_bins)

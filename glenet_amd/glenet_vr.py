@@ -331,8 +331,24 @@ class StaticTrainStep(gb.StaticTrainPipeline):
     def data_parallel(self):
         """Install the gradient exchange of the data-parallel step (tools/train.py:144-145 wraps the model in
         DistributedDataParallel): one flat all-reduce between backward and the update."""
+        import torch.distributed as dist
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         if self.flat:
             self.exchange = self.step_optimizer.allreduce_
+            # SUM all-reduce; the 1 / world of DDP's average is an argument of the update kernel (set BEFORE capture:
+            # a recorded update graph keeps the value it was recorded with)
+            self.step_optimizer.grad_scale = 1.0 / world
+            # every rank starts from rank 0's parameters, optimizer state and BatchNorm buffers (DDP's constructor
+            # broadcast, tools/train.py:144-145)
+            self.step_optimizer.broadcast_state_(0)
+            if world > 1:
+                for b in self.net.buffers():
+                    if dist.get_backend() == "gloo" and b.is_cuda:
+                        host = b.cpu()
+                        dist.broadcast(host, 0)
+                        b.copy_(host)
+                    else:
+                        dist.broadcast(b, 0)
         else:
             from .dist import GradBucket
             self.exchange = GradBucket(self.params).allreduce_

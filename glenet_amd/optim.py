@@ -54,6 +54,7 @@ class FlatAdamW:
         self.max_norm = float(max_norm) if max_norm else 0.0
         self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.grad_scale = 1.0          # the update reads grads * grad_scale: 1 / world_size after a SUM all-reduce
         self._ws = torch.empty(_lib.query("glx_adamw_workspace_bytes"), dtype=torch.uint8, device=dev)
         self._zeros = None
 
@@ -89,11 +90,13 @@ class FlatAdamW:
         return self.flat_grad
 
     def allreduce_(self, average=True):
-        """Data-parallel exchange: one all-reduce on the flat gradient buffer (RCCL; gloo for the CPU-side
-        plumbing tests goes through a host copy)."""
+        """Data-parallel exchange: one SUM all-reduce on the flat gradient buffer (RCCL; gloo for the CPU-side
+        plumbing tests goes through a host copy).  average: the 1 / world_size of DistributedDataParallel is folded
+        into the update (`grad_scale`, read by glx_adamw_clip_step_scaled) instead of a pass over the buffer."""
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
+        self.grad_scale = 1.0 / dist.get_world_size() if average else 1.0
         buf = self.flat_grad
         if dist.get_backend() == "gloo" and buf.is_cuda:
             host = buf.cpu()
@@ -101,17 +104,31 @@ class FlatAdamW:
             buf.copy_(host)
         else:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        if average:
-            buf.div_(dist.get_world_size())
+
+    def broadcast_state_(self, src=0):
+        """Every rank starts from rank `src`'s parameters, moments and step count (DistributedDataParallel
+        broadcasts the module state at construction, tools/train.py:144-145; without it ranks that were seeded or
+        restored differently would average gradients of different models)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        for buf in (self.flat_param, self.exp_avg, self.exp_avg_sq, self.step_count, self.hyper):
+            if dist.get_backend() == "gloo" and buf.is_cuda:
+                host = buf.cpu()
+                dist.broadcast(host, src)
+                buf.copy_(host)
+            else:
+                dist.broadcast(buf, src)
+        _lib.bump_weights_epoch()
 
     def step(self, packed=False):
         """clip + AdamW.  packed=True: flat_grad already holds this step's (exchanged) gradients."""
         if not packed:
             self.pack_grads()
-        _lib.call("glx_adamw_clip_step", self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq,
+        _lib.call("glx_adamw_clip_step_scaled", self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq,
                   ctypes.c_int64(self.n), self.hyper, ctypes.c_float(self.beta2), ctypes.c_float(self.eps),
-                  ctypes.c_float(self.weight_decay), ctypes.c_float(self.max_norm), self.step_count, self.grad_norm,
-                  self._ws, _lib.size_arg(self._ws.numel()))
+                  ctypes.c_float(self.weight_decay), ctypes.c_float(self.max_norm), ctypes.c_float(self.grad_scale),
+                  self.step_count, self.grad_norm, self._ws, _lib.size_arg(self._ws.numel()))
         _lib.bump_weights_epoch()          # parameters changed through raw pointers: version-keyed caches are stale
 
     def bump_versions(self):

@@ -233,6 +233,17 @@ int glx_voxelize_hard(const float* points, const int32_t* point_batch, int P, in
                       int32_t* idx_prefix, int32_t* idx_rank_to_row, int32_t* idx_n_unique,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* Device data step in front of the voxelizer: DataProcessor.mask_points_and_boxes_outside_range +
+ * shuffle_points (pcdet/datasets/processor/data_processor.py:78-105, common_utils.py:60-63) on a capacity-sized
+ * stacked buffer, shape-static (capturable).  glx_shuffle_keys: keys[i] = (frame id, or B for a point outside the
+ * closed x / y range {x0, y0, x1, y1} (HOST array) or a padding row) << 32 | random_bits[i].  Sorting the keys
+ * ascending gives `order`; glx_permute_points writes out_points[i] = points[order[i]] and out_batch[i] = high word of
+ * sorted_keys[i]: every frame randomly permuted, dropped points last with frame id B (padding for glx_voxelize_hard). */
+int glx_shuffle_keys(const float* points, const int32_t* point_batch, int P, int C, int B, const float* range_xy,
+                     const uint32_t* random_bits, int64_t* keys, void* stream);
+int glx_permute_points(const float* points, const int64_t* order, const int64_t* sorted_keys, int P, int C,
+                       float* out_points, int32_t* out_batch, void* stream);
+
 /* Dynamic voxelization + per-voxel mean, semantics of DynamicMeanVFE.forward
  * (pcdet/models/backbones_3d/vfe/dynamic_mean_vfe.py:53-72): voxels enumerate in ascending
  * key b*XYZ + x*YZ + y*Z + z; features = mean over ALL points of the cell (columns 0..C-1).
@@ -618,6 +629,13 @@ int glx_adamw_clip_step(float* params, const float* grads, float* exp_avg, float
                         const float* hyper, float beta2, float eps, float weight_decay, float max_norm,
                         int32_t* step, float* norm_out, void* workspace, size_t workspace_bytes,
                         void* stream);
+/* Same with the gradient taken as grads * grad_scale (each element rounded to float, then norm / clip / update):
+ * grad_scale = 1 / world_size turns the SUM all-reduce of the data-parallel step into DistributedDataParallel's
+ * average (tools/train.py:144-145) without a separate pass over the 30 MB buffer. */
+int glx_adamw_clip_step_scaled(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                               const float* hyper, float beta2, float eps, float weight_decay, float max_norm,
+                               float grad_scale, int32_t* step, float* norm_out, void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * PV-RCNN set-abstraction operators (same extension module in the reference).

@@ -222,6 +222,80 @@ def test_device_data_processor_matches_oracle_on_the_same_point_order(dev):
     assert np.array_equal(bd["voxels"].cpu().numpy(), v) and np.array_equal(bd["voxel_num_points"].cpu().numpy(), n)
 
 
+def test_static_device_data_step_inside_a_recorded_training_step(dev):
+    """SURVEY 8f rank 1 as a capturable stage: range mask + per-frame shuffle on capacity-sized buffers (no boolean
+    indexing, no read-back), then the voxelizer -- (i) the reference recipe on the SAME permutation: numpy mask
+    (common_utils.py:60-63), `points[shuffle_idx]` (data_processor.py:95-105) with the permutation the device drew,
+    the oracle's hard voxelizer -> identical voxels; (ii) inside a recorded StaticTrainPipeline the replays draw a new
+    permutation every time and the step's own voxels still equal the oracle on that replay's order."""
+    from glenet_amd import data_pipeline as dpl
+    frames = [synth.kitti_frame(70 + i, num_points=6000)[0] for i in range(2)]
+    frames[0][:40, 0] = -5.0                                       # outside the x range
+    frames[1][:25, 1] = 41.0                                       # outside the y range
+    frames[1][25, 1] = 40.0                                        # ON the closed boundary: kept
+    pts = np.concatenate(frames)
+    bid = np.concatenate([np.full(len(f), i, np.int32) for i, f in enumerate(frames)])
+    cap = len(pts) + 300                                           # padding rows: frame id == batch size
+    P = torch.zeros((cap, 4), device=dev)
+    Bx = torch.full((cap,), 2, dtype=torch.int32, device=dev)
+    P[:len(pts)] = torch.from_numpy(pts).to(dev)
+    Bx[:len(pts)] = torch.from_numpy(bid).to(dev)
+    rng = K["point_cloud_range"]
+
+    def reference(order):
+        """the reference's recipe per frame with the device's permutation"""
+        order = order.cpu().numpy()
+        out = []
+        for f in range(2):
+            src = frames[f]
+            keep = (src[:, 0] >= rng[0]) & (src[:, 0] <= rng[3]) & (src[:, 1] >= rng[1]) & (src[:, 1] <= rng[4])
+            kept_rows = np.flatnonzero(keep) + (0 if f == 0 else len(frames[0]))
+            mine = [r for r in order if (r < len(pts)) and bid[r] == f and keep[r - (0 if f == 0 else len(frames[0]))]]
+            assert sorted(mine) == sorted(kept_rows.tolist())          # a permutation of exactly the kept points
+            masked = src[keep]
+            pos = {r: i for i, r in enumerate(kept_rows)}
+            shuffle_idx = np.array([pos[r] for r in mine])            # what np.random.permutation would have returned
+            out.append(masked[shuffle_idx])
+        return out
+
+    op, ob_, order = dpl.mask_and_shuffle_static(P, Bx, 2, rng)
+    b = ob_.cpu().numpy()
+    nkeep = int((b < 2).sum())
+    assert (np.diff(b) >= 0).all() and (b[nkeep:] == 2).all() and nkeep == len(pts) - 65
+    ref_frames = reference(order[:nkeep])
+    assert np.array_equal(op.cpu().numpy()[:nkeep], np.concatenate(ref_frames))
+    assert not np.array_equal(ref_frames[0][:200], frames[0][40:240])                  # shuffled
+    v, c, n = oracle.voxelize_hard_batch(ref_frames, K["voxel_size"], rng, 5, 16000)
+    bd = gb.voxelize_batch(op, ob_, 2, K, train=True, static=True)
+    nv = int(bd["voxel_index"].count.item())
+    assert nv == len(c) and np.array_equal(bd["voxel_coords"].cpu().numpy()[:nv], c)
+    assert np.array_equal(bd["voxels"].cpu().numpy()[:nv], v)
+    # without shuffling only the mask acts: the order inside a frame is kept
+    proc = dpl.DeviceDataProcessor(K, shuffle=False)
+    kp, kb = proc.static_step(P, Bx, 2)
+    keep_np = (pts[:, 0] >= rng[0]) & (pts[:, 0] <= rng[3]) & (pts[:, 1] >= rng[1]) & (pts[:, 1] <= rng[4])
+    assert np.array_equal(kp.cpu().numpy()[:nkeep], pts[keep_np]) and np.array_equal(kb.cpu().numpy()[:nkeep], bid[keep_np])
+    # ---- inside a recorded training step
+    grid = gb.gv.grid_size_of(K["point_cloud_range"], K["voxel_size"])
+    torch.manual_seed(0)
+    model = gb.VoxelBackBone8x(4, grid).to(dev).train()
+    pipe = gb.StaticTrainPipeline(model, K, 2, cap, 4)
+    pipe.data_step = dpl.DeviceDataProcessor(K, shuffle=True)
+    pipe.calibrate(torch.from_numpy(pts).to(dev), torch.from_numpy(bid).to(dev))
+    pipe.load(torch.from_numpy(pts).to(dev), torch.from_numpy(bid).to(dev))
+    pipe.capture()
+    seen = []
+    for _ in range(2):
+        pipe.replay()
+        torch.cuda.synchronize()
+        pipe.check()
+        nv2 = int(pipe.out["voxel_index"].count.item())
+        assert abs(nv2 - nv) <= 0.02 * nv                            # same cells up to the max_points truncation order
+        seen.append(pipe.out["voxels"][:nv2].clone())
+        assert np.isfinite(float(pipe.loss))
+    assert seen[0].shape != seen[1].shape or not torch.equal(seen[0], seen[1])   # a fresh permutation per replay
+
+
 def test_waymo_shaped_residual_backbone_matches_oracle(dev):
     """Config-5 shape: 5 point features (zero-padded to 8 input channels on the MFMA path), Waymo
     grid [41,1504,1504], VoxelResBackBone8x (biased residual blocks), one frame of 30 k points."""

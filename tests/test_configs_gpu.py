@@ -99,9 +99,13 @@ def test_cvae_training_step_matches_reference_golden_on_device(dev):
     for got, key in ((reg, "reg_loss_post"), (lat, "lattent_loss"), (regular, "regular_loss")):
         np.testing.assert_allclose(float(got.detach()), float(g[key]), rtol=2e-5)
     (reg + lat + regular).backward()
+    # biases in front of a BatchNorm have an analytically zero gradient (the mean subtraction removes them): what the
+    # reference stores there is summation noise of ~1e-5, so the absolute floor follows the model's gradient scale
+    top = max(float(np.abs(g[k]).max()) for k in g.files if k.startswith("grad/"))
     for name, p in m.named_parameters():
         want = g["grad/" + name]
-        np.testing.assert_allclose(p.grad.cpu().numpy(), want, rtol=2e-3, atol=1e-4 * (np.abs(want).max() + 1e-12), err_msg=name)
+        atol = 2e-4 * max(float(np.abs(want).max()), 1e-3 * top)
+        np.testing.assert_allclose(p.grad.cpu().numpy(), want, rtol=2e-3, atol=atol, err_msg=name)
     for k, v in m.state_dict().items():
         if "running_" in k or "num_batches" in k:
             np.testing.assert_allclose(v.cpu().numpy(), g["after/" + k], rtol=1e-4, atol=1e-6, err_msg=k)

@@ -1,0 +1,47 @@
+"""Multi-GPU step equivalence without an 8-GPU box: two ranks x 2 frames, one flat all-reduce
+between the forward + backward graph and the update graph, against ONE process that averages the two batches'
+gradients and applies the same update.  The ranks share this box's GPU and the collective runs over gloo (plumbing;
+the arithmetic -- SUM all-reduce, 1 / world folded into glx_adamw_clip_step_scaled, broadcast of rank 0's state at
+start-up -- is what the RCCL path executes)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_make_the_update_of_one_rank_on_both_batches(dev):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dp_step_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    res = sorted((json.loads(line[len("DPRESULT "):]) for so, _ in outs for line in so.splitlines()
+                  if line.startswith("DPRESULT ")), key=lambda d: d["rank"])
+    assert [d["rank"] for d in res] == [0, 1]
+    for d in res:
+        assert d["ranks_equal"], d                       # rank 1 started from other weights: broadcast + same update
+        assert d["grad_scale"] == 0.5 and d["step_count"] == 1
+        assert d["grads_differ_between_batches"] > 1e-3 * d["grad_max_abs"]          # the ranks really had different data
+        # the averaged gradient the update consumed == the mean of the two batches' gradients (float atomics in the
+        # backward reorder sums by ~1e-7 relative)
+        assert d["grad_err_max"] <= 2e-4 * d["grad_max_abs"], d
+        assert d["grad_err_over_1e4"] <= d["n"] * 1e-5, d
+        # Adam's first step moves every element by ~lr * sign(g): a noise-level gradient element whose sign differs
+        # moves the other way (2 lr); everything else agrees to rounding
+        assert d["param_err_max"] <= 2.5 * d["lr"], d
+        assert d["param_err_mean"] <= 2e-3 * d["lr"], d
