@@ -272,7 +272,9 @@ def bench_config3(dev, objects=4096, points=512, samples=30):
     ms_s = _timed(sample_all, 3, dev, warm=1)
     # the sampler runs ONE large extractor (prior) + the narrow one per pass
     sample_flops = objects * (2 * points * (4 * 64 + 64 * 128 + 128 * 512) + 2 * points * (4 * 8 + 8 * 8 + 8 * 8))
-    step = ct.CVAETrainStep(model, objects, points)
+    # learning rate of the one-cycle schedule's first step (LR / DIV_FACTOR, cfgs/exp20.yaml): random-init weights
+    # diverge at the peak rate (tools/cvae_train_probe.py)
+    step = ct.CVAETrainStep(model, objects, points, lr=ct.OPTIM_CFG["LR"] / 10)
     step.load(pts, box8, box7)
     step.capture()
     ms_t = _timed(step.step, 10, dev, warm=2)

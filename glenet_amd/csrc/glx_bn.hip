@@ -7,17 +7,9 @@
 // so bitwise reproducible) + a one-block finalize + one fused normalise/affine/ReLU pass; backward
 // = column sums of dz and dz*xhat + finalize + one fused dx pass.  HBM-bound (x is read twice).
 #include "glx_common.h"
-#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+#include "glx_bn_state.h"
 
 typedef float bf32x4 __attribute__((ext_vector_type(4)));
-
-// y = x * scale + shift, written ONE way everywhere: the backward kernels re-derive the ReLU mask (y > 0) from x
-// instead of reading y back (a third of their traffic), which only works if they round exactly like the forward.
-__device__ __forceinline__ float bn_scale(float invstd, float gamma) { return __fmul_rn(invstd, gamma); }
-__device__ __forceinline__ float bn_shift(float beta, float mean, float invstd, float gamma) {
-  return __fsub_rn(beta, __fmul_rn(__fmul_rn(mean, invstd), gamma));
-}
-__device__ __forceinline__ float bn_affine(float x, float scale, float shift) { return __fmaf_rn(x, scale, shift); }
 
 // 512 threads: a statistics block keeps 8 (forward) or 2 x 4 (backward) 16-byte loads per thread in flight, 64 KB per CU
 // with one block per CU -- with 256 threads (32 KB per CU) the 72 MB layers read at 3.6-4 TB/s; measured on the training
@@ -25,7 +17,6 @@ __device__ __forceinline__ float bn_affine(float x, float scale, float shift) { 
 #ifndef BN_THREADS
 #define BN_THREADS 512
 #endif
-#define BN_MAXC 512
 #define BN_SLABS 256   // row slabs = blocks of the statistics kernels (one per CU) on the fixed-order path
 // with a state buffer the slab count is free, but more blocks did not pay: measured on the training step (caps of the
 // statistics / transform grids 256/512: 12.97 ms, 512/1024: 13.05, 1024/2048: 13.17, 2048/4096: 13.26 -- more blocks queue
@@ -313,22 +304,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_backward_apply(
 // atomic is issued, so whoever sees the last ticket finds every contribution in place.  The sums of a set arrive in
 // a run-dependent order: the fp64 totals can differ by an ulp of 2^-52 between runs, their float roundings
 // practically never -- callers that need the fixed-order guarantee pass state = NULL (three launches).
-#define BN_SETS 16
-struct BnState {
-  double acc[BN_SETS][2 * BN_MAXC];
-  unsigned ticket;
-};
-
-struct BnFinalize {
-  const float* gamma; const float* beta; float eps, momentum;          // forward
-  float* coef; float* save_mean; float* save_invstd; float* running_mean; float* running_var;
-  const float* invstd; float* dgamma; float* dbeta;                     // backward
-};
-
-__device__ __forceinline__ double bn_take(double* p) {                  // read and clear
-  return __longlong_as_double((long long)__hip_atomic_exchange(reinterpret_cast<unsigned long long*>(p), 0ull,
-                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
+// (BnState, BnFinalize, bn_contribute, bn_finalize_sets: glx_bn_state.h, shared with the sparse-conv epilogue)
 
 template <bool BWD>
 __global__ __launch_bounds__(BN_THREADS) void k_bn_stats(
@@ -339,59 +315,9 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_stats(
   if (n_live) N = min(N, *n_live);
   double a0[4], a1[4];
   bn_slab_sums<BWD>(x, dy, y, mean, invstd, f.gamma, f.beta, relu, N, C, dy_pitch, a0, a1);
-  if (threadIdx.x < (C >> 2)) {
-    double* acc = st->acc[blockIdx.x % BN_SETS];
-    double seen = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      seen += unsafeAtomicAdd(acc + 4 * threadIdx.x + i, a0[i]);
-      seen += unsafeAtomicAdd(acc + BN_MAXC + 4 * threadIdx.x + i, a1[i]);
-    }
-    asm volatile("" ::"v"(seen) : "memory");                           // the atomics have returned: they are done
-  }
-  __syncthreads();
-  if (threadIdx.x == 0)
-    s_last = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-  __syncthreads();
-  if (!s_last) return;
-  const double cnt = N > 0 ? (double)N : 1.0;
-  // all 256 threads fetch: thread (c, g) takes sets g, g + G, ...; the G groups are combined in LDS
+  if (!bn_contribute(st, C, a0, a1, gridDim.x, &s_last)) return;
   __shared__ double s_fin[BN_THREADS][2];
-  const int CB = C < BN_THREADS ? C : BN_THREADS, G = BN_THREADS / CB;
-  for (int cb = 0; cb < C; cb += CB) {
-    const int c = cb + threadIdx.x % CB, g = threadIdx.x / CB;
-    double s = 0, ss = 0;
-    for (int k = g; k < BN_SETS; k += G) { s += bn_take(&st->acc[k][c]); ss += bn_take(&st->acc[k][BN_MAXC + c]); }
-    __syncthreads();
-    s_fin[threadIdx.x][0] = s;
-    s_fin[threadIdx.x][1] = ss;
-    __syncthreads();
-    if (g != 0) continue;
-    for (int k = 1; k < G && k < BN_SETS; ++k) { s += s_fin[k * CB + c - cb][0]; ss += s_fin[k * CB + c - cb][1]; }
-    if (!BWD) {
-      const double m = s / cnt;
-      double var = ss / cnt - m * m;
-      if (var < 0) var = 0;
-      const float is = (float)(1.0 / sqrt(var + (double)f.eps));
-      const float gm = f.gamma ? f.gamma[c] : 1.f, bt = f.beta ? f.beta[c] : 0.f;
-      f.coef[c] = bn_scale(is, gm);
-      f.coef[C + c] = bn_shift(bt, (float)m, is, gm);
-      f.save_mean[c] = (float)m;
-      f.save_invstd[c] = is;
-      if (f.running_mean) {
-        const double unb = N > 1 ? var * cnt / (cnt - 1.0) : var;
-        f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)m;
-        f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unb;
-      }
-    } else {
-      f.coef[c] = (f.gamma ? f.gamma[c] : 1.f) * f.invstd[c];
-      f.coef[C + c] = (float)(s / cnt);
-      f.coef[2 * C + c] = (float)(ss / cnt);
-      if (f.dgamma) f.dgamma[c] = (float)ss;
-      if (f.dbeta) f.dbeta[c] = (float)s;
-    }
-  }
-  if (threadIdx.x == 0) __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bn_finalize_sets<BWD, BN_THREADS>(st, f, C, N, s_fin);
 }
 
 extern "C" size_t glx_bn_state_bytes(void) { return glx_align(sizeof(BnState)); }
@@ -725,6 +651,21 @@ extern "C" int glx_bn_relu_train_forward(const float* x, int N, int C, const flo
   }
   hipLaunchKernelGGL(k_bn_forward_apply, dim3(blocks < 1 ? 1 : blocks), dim3(BN_THREADS), 0, st, x,
                      (const float*)coef, relu, N, C, n_live, y, y_pitch);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// The transform alone, for statistics that were taken elsewhere (the sparse conv's epilogue,
+// glx_sconv_next_bn_stats): y = relu?(x * coef[c] + coef[C + c]) on the live rows, zeros on the rest.
+extern "C" int glx_bn_apply_forward(const float* x, const float* coef, int relu, int N, int C, const int32_t* n_live,
+                                    float* y, int y_stride, void* stream) {
+  GLX_REQUIRE(coef && y && (N == 0 || x), "glx_bn_apply_forward: null pointer");
+  GLX_REQUIRE(bn_channels_ok(C), "glx_bn_apply_forward: C=%d needs a multiple of 4 dividing 1024 (<= 512)", C);
+  GLX_REQUIRE(y_stride == 0 || (y_stride >= C && (y_stride & 3) == 0), "glx_bn_apply_forward: y_stride %d", y_stride);
+  if (N <= 0) return GLX_OK;
+  const int blocks = bn_apply_blocks(N, C);
+  hipLaunchKernelGGL(k_bn_forward_apply, dim3(blocks < 1 ? 1 : blocks), dim3(BN_THREADS), 0, (hipStream_t)stream, x,
+                     coef, relu, N, C, n_live, y, (long long)(y_stride ? y_stride : C));
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

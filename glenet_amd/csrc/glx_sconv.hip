@@ -19,6 +19,7 @@
 
 #include "glx_common.h"
 #include "glx_fill.h"
+#include "glx_bn_state.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -58,7 +59,74 @@ struct SconvEpilogue {
   int xcd_group;       // GEMM kernel: tiles per XCD-local group (0 = identity block -> tile map)
   int out_ld;          // row pitch of `out` in floats (0 = COUT): a launch may own a column slice of wider rows
   const int* tile_map; // NULL, or block -> tile permutation balancing the work per CU (glx_sconv_tile_map)
+  // training-mode BatchNorm behind this conv: per-channel sum / sum of squares of the OUTPUT rows are accumulated
+  // here, in the epilogue, while the tile is still in LDS, and the block that draws the last ticket finalizes
+  // (scale / shift, saved mean / invstd, running statistics) -- the layer's statistics kernel (a pass over the
+  // output + an 11 us dependent tail, csrc/glx_bn.hip) disappears.  NULL = no statistics.
+  BnState* bn_state;
+  BnFinalize bn;
 };
+
+// The common epilogue: coalesced row stores with the fused pointwise tail, + the BatchNorm statistics above.
+// smem: the kernel's dynamic LDS, free once the accumulator tile has been read (>= 16.5 KB for 512 threads).
+template <int COUT, int TR, int THREADS, int ACC_LD>
+__device__ __forceinline__ void sc_epilogue(float* smem, const float* s_acc, const int* s_rows, const SconvEpilogue& ep,
+                                            float* __restrict__ out, int ld, int n_live_rows) {
+  constexpr int C4 = COUT / 4;
+  static_assert(THREADS % C4 == 0 && 64 % C4 == 0 || C4 % 64 == 0, "a thread keeps one float4 column");
+  const int tid = threadIdx.x;
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  for (int i = tid; i < TR * C4; i += THREADS) {
+    int rr = i / C4, c4 = i - rr * C4;
+    int orow = s_rows[rr];
+    if (orow < 0) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(s_acc + rr * ACC_LD + 4 * c4);
+    const int co = 4 * c4;
+    if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + co);
+    if (ep.scale) v *= *reinterpret_cast<const f32x4*>(ep.scale + co);
+    if (ep.shift) v += *reinterpret_cast<const f32x4*>(ep.shift + co);
+    if (ep.relu) {
+      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(out + (long long)orow * ld + 4 * c4) = v;
+    if (ep.bn_state) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s0[e] += (double)v[e]; s1[e] += (double)v[e] * (double)v[e]; }
+    }
+  }
+  if (!ep.bn_state) return;          // kernel-uniform
+  // lanes of a wave that share a float4 column (lane % C4), then the waves through LDS
+  if constexpr (C4 < 64) {
+#pragma unroll
+    for (int o = C4; o < 64; o <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s0[e] += __shfl_xor(s0[e], o, 64); s1[e] += __shfl_xor(s1[e], o, 64); }
+    }
+  }
+  __syncthreads();                   // every thread is done reading the accumulator tile
+  constexpr int NWV = THREADS / 64;
+  double* s_part = reinterpret_cast<double*>(smem);                       // [NWV][C4][8]
+  double(*s_fin)[2] = reinterpret_cast<double(*)[2]>(smem + NWV * C4 * 16);   // [THREADS][2]
+  int* s_last = reinterpret_cast<int*>(smem + NWV * C4 * 16 + THREADS * 4);
+  const int lane = tid & 63, wave = tid >> 6;
+  if (lane < C4) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s_part[(wave * C4 + lane) * 8 + e] = s0[e];
+      s_part[(wave * C4 + lane) * 8 + 4 + e] = s1[e];
+    }
+  }
+  __syncthreads();
+  double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+  if (tid < C4) {
+    for (int w = 0; w < NWV; ++w) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a0[e] += s_part[(w * C4 + tid) * 8 + e]; a1[e] += s_part[(w * C4 + tid) * 8 + 4 + e]; }
+    }
+  }
+  if (!bn_contribute(ep.bn_state, COUT, a0, a1, gridDim.x, s_last)) return;
+  bn_finalize_sets<false, THREADS>(ep.bn_state, ep.bn, COUT, n_live_rows, s_fin);
+}
 
 // Block b runs on XCD b mod 8.  Deal the tiles to the XCDs in groups of `g` consecutive tiles:
 // neighbouring tiles (which share neighbour rows) meet in one L2, while every XCD still gets
@@ -496,22 +564,8 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
 #undef SC_STAGE_LOAD
 #undef SC_STAGE_STORE
 
-  // ---- epilogue: coalesced row stores with the fused pointwise tail
-  constexpr int C4 = COUT / 4;
-  for (int i = tid; i < TR * C4; i += SC_THREADS) {
-    int rr = i / C4, c4 = i - rr * C4;
-    int orow = s_rows[rr];
-    if (orow < 0) continue;
-    f32x4 v = *reinterpret_cast<const f32x4*>(s_acc + rr * ACC_LD + 4 * c4);
-    const int co = 4 * c4;
-    if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + co);
-    if (ep.scale) v *= *reinterpret_cast<const f32x4*>(ep.scale + co);
-    if (ep.shift) v += *reinterpret_cast<const f32x4*>(ep.shift + co);
-    if (ep.relu) {
-      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-    }
-    *reinterpret_cast<f32x4*>(out + (long long)orow * COUT + 4 * c4) = v;
-  }
+  // ---- epilogue: coalesced row stores with the fused pointwise tail (+ BatchNorm statistics)
+  sc_epilogue<COUT, TR, SC_THREADS, ACC_LD>(smem, s_acc, s_rows, ep, out, COUT, N_out);
   if constexpr (TRACE) {
     __syncthreads();
     constexpr int REC = 4 + 8 * T::NW;   // int64 per block
@@ -816,22 +870,8 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
 #undef GM_STORE_A
   __syncthreads();
 
-  // ---- epilogue: coalesced row stores with the fused pointwise tail
-  constexpr int C4 = COUT / 4;
-  for (int i = tid; i < TR * C4; i += THREADS) {
-    int rr = i / C4, c4 = i - rr * C4;
-    int orow = s_rows[rr];
-    if (orow < 0) continue;
-    f32x4 v = *reinterpret_cast<const f32x4*>(s_acc + rr * ACC_LD + 4 * c4);
-    const int co = 4 * c4;
-    if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + co);
-    if (ep.scale) v *= *reinterpret_cast<const f32x4*>(ep.scale + co);
-    if (ep.shift) v += *reinterpret_cast<const f32x4*>(ep.shift + co);
-    if (ep.relu) {
-      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-    }
-    *reinterpret_cast<f32x4*>(out + (long long)orow * (ep.out_ld ? ep.out_ld : COUT) + 4 * c4) = v;
-  }
+  // ---- epilogue: coalesced row stores with the fused pointwise tail (+ BatchNorm statistics)
+  sc_epilogue<COUT, TR, THREADS, ACC_LD>(smem, s_acc, s_rows, ep, out, ep.out_ld ? ep.out_ld : COUT, N_out);
   if constexpr (TRACE) {
     __syncthreads();
     constexpr int REC = 4 + 8 * T::NW;
@@ -1050,21 +1090,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm2(
 #undef G2_STORE_A
   __syncthreads();
 
-  constexpr int C4 = COUT / 4;
-  for (int i = tid; i < TR * C4; i += THREADS) {
-    int rr = i / C4, c4 = i - rr * C4;
-    int orow = s_rows[rr];
-    if (orow < 0) continue;
-    f32x4 v = *reinterpret_cast<const f32x4*>(s_acc + rr * ACC_LD + 4 * c4);
-    const int co = 4 * c4;
-    if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + co);
-    if (ep.scale) v *= *reinterpret_cast<const f32x4*>(ep.scale + co);
-    if (ep.shift) v += *reinterpret_cast<const f32x4*>(ep.shift + co);
-    if (ep.relu) {
-      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-    }
-    *reinterpret_cast<f32x4*>(out + (long long)orow * (ep.out_ld ? ep.out_ld : COUT) + 4 * c4) = v;
-  }
+  sc_epilogue<COUT, TR, THREADS, ACC_LD>(smem, s_acc, s_rows, ep, out, ep.out_ld ? ep.out_ld : COUT, N_out);
 }
 
 // ------------------------------------------------------------------ generic scalar kernel
@@ -1099,7 +1125,7 @@ extern "C" int glx_sconv_forward_generic(const float* in, int N_in, const float*
   GLX_REQUIRE(in && W && nbr && out && K > 0 && Cin > 0 && Cout > 0,
               "glx_sconv_forward_generic: bad arguments");
   long long total = (long long)N_out * Cout;
-  SconvEpilogue ep{bias, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, nullptr};
+  SconvEpilogue ep{bias, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, BnFinalize{}};
   hipLaunchKernelGGL(k_sconv_generic, dim3(glx_divup(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, in, W, ep, nbr, N_out, K, Cin, Cout, out);
   GLX_LAUNCH_CHECK();
@@ -1287,7 +1313,7 @@ static int launch_gemm(const float* in, const float* Wp, const SconvEpilogue& ep
         glx_set_error("sparse conv GEMM trace build exists for <64,64,64,8> only");
         return GLX_EINVAL;
       }
-    } else if (g_prof_start && g_prof_stop) {
+    } else if (g_prof_start || g_prof_stop) {   // one of them alone: a launch of a multi-launch conv (column halves)
       hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(T::THREADS), lds, st, g_prof_start,
                             g_prof_stop, 0, in, Wsplit, ep, nbr, tile_order, N_out, K, out);
       g_prof_start = g_prof_stop = nullptr;
@@ -1367,7 +1393,11 @@ static int launch_mfma(const float* in, const float* Wp, const SconvEpilogue& ep
     // two launches of the (CI, CO/2) kernel, each writing its column half of the CO-wide rows
     const float* base = Wp + (size_t)K * img_bytes<CI, CO>() / sizeof(float);
     const size_t half = (size_t)K * img_bytes<CI, CO / 2>() / sizeof(float);
+    // profiling events bracket the PAIR of launches: start on the first, stop on the second
+    const hipEvent_t pstart = g_prof_start, pstop = g_prof_stop;
     for (int h = 0; h < 2; ++h) {
+      g_prof_start = h == 0 ? pstart : nullptr;
+      g_prof_stop = h == 1 ? pstop : nullptr;
       SconvEpilogue eh = ep;
       const int off = h * (CO / 2);
       eh.bias = ep.bias ? ep.bias + off : nullptr;
@@ -1646,6 +1676,21 @@ extern "C" int glx_sconv_next_tile_map(const int32_t* tile_map) {
   return GLX_OK;
 }
 
+// BatchNorm statistics in the epilogue of the NEXT glx_sconv_forward call on this host thread (consumed by it):
+// state = glx_bn_state_bytes() zero-initialised device bytes shared by all calls of a stream; coef (2 * Cout):
+// scale | shift for glx_bn_apply_forward; save_mean / save_invstd (Cout) for the backward pass; running_* may be NULL.
+static thread_local BnState* g_next_bn_state = nullptr;
+static thread_local BnFinalize g_next_bn = {};
+extern "C" int glx_sconv_next_bn_stats(void* state, const float* gamma, const float* beta, float eps, float momentum,
+                                       float* coef, float* save_mean, float* save_invstd, float* running_mean,
+                                       float* running_var) {
+  GLX_REQUIRE(state && coef && save_mean && save_invstd, "glx_sconv_next_bn_stats: null pointer");
+  g_next_bn_state = (BnState*)state;
+  g_next_bn = BnFinalize{gamma, beta, eps, momentum, coef, save_mean, save_invstd, running_mean, running_var,
+                         nullptr, nullptr, nullptr};
+  return GLX_OK;
+}
+
 extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, const float* Wp,
                                  const float* bias, const float* scale, const float* shift,
                                  int relu, const int32_t* nbr, const int32_t* tile_order,
@@ -1654,10 +1699,16 @@ extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, cons
                                  size_t workspace_bytes, void* stream) {
   const int* tile_map = g_next_tile_map;   // consumed by THIS call whatever happens below
   g_next_tile_map = nullptr;
+  BnState* bn_state = g_next_bn_state;
+  g_next_bn_state = nullptr;
   GLX_REQUIRE(K > 0 && Cin > 0 && Cout > 0 && N_out >= 0, "glx_sconv_forward: bad sizes");
+  GLX_REQUIRE(!bn_state || (N_out > 0 && mfma_supported(Cin, Cout, K) && !(Cin >= 128 && Cout >= 128)),
+              "glx_sconv_forward: BatchNorm statistics in the epilogue need an MFMA tile kernel in one launch "
+              "(N_out %d, channels %d -> %d)", N_out, Cin, Cout);
   if (N_out == 0) return GLX_OK;
   GLX_REQUIRE(in && (W || Wp) && nbr && out, "glx_sconv_forward: null pointer");
-  SconvEpilogue ep{bias, scale, shift, relu, n_out_live, g_sconv_trace, g_sconv_xcd_group, 0, tile_map};
+  SconvEpilogue ep{bias, scale, shift, relu, n_out_live, g_sconv_trace, g_sconv_xcd_group, 0, tile_map, bn_state,
+                   g_next_bn};
   if (!mfma_supported(Cin, Cout, K)) {
     GLX_REQUIRE(W, "glx_sconv_forward: raw weights required for channels (%d,%d)", Cin, Cout);
     long long total = (long long)N_out * Cout;

@@ -14,6 +14,7 @@ Every module is table-driven (one builder, several shapes).  Parity with the ref
 modules is pinned by tests/golden/dense_path_ref.npz (state dicts + outputs produced by the
 reference code on CPU, see tests/golden/make_golden.py).
 """
+import contextlib
 import math
 import os
 
@@ -23,6 +24,81 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
+
+
+class _ConvSplitBackward(torch.autograd.Function):
+    """F.conv2d / F.conv_transpose2d whose backward issues the two gradients as SEPARATE library calls: the input
+    gradient on the current stream (it feeds the chain conv <- BatchNorm <- conv <- ...), the weight (+ bias)
+    gradient on spconv.core.WGRAD_STREAM when a training step has set it -- a leaf of the backward pass, exactly like
+    the sparse convs' weight gradients.  torch's own node computes both on one stream, back to back; here MIOpen's
+    weight-gradient kernels (with their zero fills) run beside the next layer's BatchNorm backward, whose statistics
+    kernels are short dependent chains that leave the chip mostly idle.  Same library kernels, same values."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, padding, dilation, transposed, output_padding, groups):
+        ctx.cfg = (tuple(stride), tuple(padding), tuple(dilation), bool(transposed), tuple(output_padding), int(groups))
+        ctx.save_for_backward(x, w)
+        ctx.bias_sizes = [int(bias.shape[0])] if bias is not None else None
+        return torch.ops.aten.convolution(x, w, bias, *ctx.cfg)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .spconv import core
+        x, w = ctx.saved_tensors
+        stride, padding, dilation, transposed, output_padding, groups = ctx.cfg
+        gx = gw = gb = None
+        want_w = ctx.needs_input_grad[1] or (ctx.bias_sizes is not None and ctx.needs_input_grad[2])
+        if want_w:
+            side = core.WGRAD_STREAM
+            if side is not None:
+                cur = torch.cuda.current_stream(x.device)
+                side.wait_stream(cur)
+                for t in (x, gy, w):
+                    t.record_stream(side)
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                _, gw, gb = torch.ops.aten.convolution_backward(
+                    gy, x, w, ctx.bias_sizes, stride, padding, dilation, transposed, output_padding, groups,
+                    [False, bool(ctx.needs_input_grad[1]), ctx.bias_sizes is not None and bool(ctx.needs_input_grad[2])])
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(gy, x, w, None, stride, padding, dilation, transposed,
+                                                     output_padding, groups, [True, False, False])[0]
+        return gx, gw, gb, None, None, None, None, None, None
+
+
+SPLIT_CONV_BACKWARD = os.environ.get("GLX_SPLIT_CONV_BWD", "1") != "0"
+
+
+def _pair(v):
+    return (int(v), int(v)) if isinstance(v, int) else tuple(int(a) for a in v)
+
+
+def _leaf(t):
+    return t is None or t.is_leaf
+
+
+def conv2d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1):
+    """F.conv2d; in a training step on the device its backward splits over two streams (_ConvSplitBackward).
+    Only for LEAF weights: their gradient goes straight to AccumulateGrad (no kernel) and is first read after the
+    step has joined the side stream; a derived weight (the anchor head's concatenated filters) hands its gradient to
+    another autograd node, which would run on the main stream without waiting for the side stream."""
+    if (SPLIT_CONV_BACKWARD and x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
+            and _leaf(w) and _leaf(bias)):
+        return _ConvSplitBackward.apply(x, w, bias, _pair(stride), _pair(padding), _pair(dilation), False, (0, 0), groups)
+    return F.conv2d(x, w, bias, stride, padding, dilation, groups)
+
+
+def conv_module(m, x):
+    """nn.Conv2d / nn.ConvTranspose2d forward through the split-backward node when it applies."""
+    if (SPLIT_CONV_BACKWARD and x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or m.weight.requires_grad)
+            and getattr(m, "padding_mode", "zeros") == "zeros" and not isinstance(m.padding, str)
+            and _leaf(m.weight) and _leaf(m.bias)):
+        if isinstance(m, nn.ConvTranspose2d):
+            return _ConvSplitBackward.apply(x, m.weight, m.bias, _pair(m.stride), _pair(m.padding), _pair(m.dilation),
+                                            True, _pair(m.output_padding), m.groups)
+        if isinstance(m, nn.Conv2d):
+            return _ConvSplitBackward.apply(x, m.weight, m.bias, _pair(m.stride), _pair(m.padding), _pair(m.dilation),
+                                            False, (0, 0), m.groups)
+    return m(x)
 
 
 def _bn2d(c):
@@ -89,7 +165,7 @@ class BEVBackbone(nn.Module):
             x = self._run_block(blk, x)
             data_dict["spatial_features_%dx" % int(x0.shape[2] / x.shape[2])] = x
             if fuse:
-                raw.append(self.deblocks[i][0](x))          # the deblock's (transposed) convolution only
+                raw.append(conv_module(self.deblocks[i][0], x))   # the deblock's (transposed) convolution only
             else:
                 ups.append(self._run_block(self.deblocks[i], x) if len(self.deblocks) > 0 else x)
         if fuse:
@@ -136,7 +212,7 @@ class BEVBackbone(nn.Module):
                     and isinstance(mods[i + 1], nn.Conv2d) and mods[i + 1].padding == (0, 0)
                     and mods[i + 1].kernel_size == (3, 3) and mods[i + 1].dilation == (1, 1)):
                 c = mods[i + 1]
-                x = F.conv2d(x, c.weight, c.bias, c.stride, 1, c.dilation, c.groups)
+                x = conv2d(x, c.weight, c.bias, c.stride, 1, c.dilation, c.groups)
                 i += 2
                 continue
             if BEVBackbone._can_fuse_bn(m, x):
@@ -144,7 +220,7 @@ class BEVBackbone(nn.Module):
                 x = BEVBackbone._fused_bn_relu(m, x, relu)
                 i += 2 if relu else 1
                 continue
-            x = m(x)
+            x = conv_module(m, x) if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) else m(x)
             i += 1
         return x
 
@@ -185,7 +261,7 @@ class AnchorHead(nn.Module):
         convs = [self.conv_cls, self.conv_box] + ([self.conv_dir_cls] if self.conv_dir_cls is not None else [])
         w = torch.cat([c.weight for c in convs], dim=0)
         b = torch.cat([c.bias for c in convs], dim=0)
-        y = F.conv2d(x, w, b).permute(0, 2, 3, 1)                                         # (B,H,W,sum Cout)
+        y = conv2d(x, w, b).permute(0, 2, 3, 1)                                           # (B,H,W,sum Cout)
         parts = y.split([c.out_channels for c in convs], dim=-1)
         data_dict["cls_preds"] = parts[0].contiguous()
         data_dict["box_preds"] = parts[1].contiguous()

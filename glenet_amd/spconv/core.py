@@ -340,12 +340,15 @@ def _cin_padding(cin):
 
 
 def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rules=None, tag="fwd",
-           scale=None, shift=None, relu=False, n_live=None, dims=None):
+           scale=None, shift=None, relu=False, n_live=None, dims=None, bn=None):
     """out[j] = relu?((sum_k features[nbr[j,k]] @ weight_kio[k] + bias) * scale + shift).
-    weight_kio may be None when `packed` and dims = (K, Cin, Cout) are given."""
+    weight_kio may be None when `packed` and dims = (K, Cin, Cout) are given.
+    bn: a training-mode BatchNorm1d that follows the conv -- its batch statistics are taken in the kernel's epilogue
+    (glx_sconv_next_bn_stats) and the call returns (out, coef, save_mean, save_invstd)."""
     K, cin, cout = dims if dims is not None else weight_kio.shape
     out = torch.empty((n_out, cout), dtype=torch.float32, device=features.device)
     if n_out == 0:
+        assert bn is None
         return out
     if packed is None:
         packed = pack_weights(weight_kio)
@@ -357,9 +360,19 @@ def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rule
         tmap = rules.tile_map(nbr, tile_order, n_out, n_live)
         if tmap is not None:
             call_nostream("glx_sconv_next_tile_map", tmap)
+    stats = None
+    if bn is not None:
+        stats = tuple(torch.empty(n, dtype=torch.float32, device=features.device) for n in (2 * cout, cout, cout))
+        rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+        call_nostream("glx_sconv_next_bn_stats", _bn_state(features.device), bn.weight, bn.bias, ctypes_float(bn.eps),
+                      ctypes_float(bn.momentum), stats[0], stats[1], stats[2], rm, rv)
     call("glx_sconv_forward", features, features.shape[0], weight_kio, packed, bias, scale, shift,
          1 if relu else 0, nbr, tile_order, n_out, K, cin, cout, out, n_live, ws,
          size_arg(ws.numel()))
+    if bn is not None:
+        if bn.track_running_stats:
+            _lib.bump_weights_epoch()          # running statistics moved behind torch's back
+        return (out,) + stats
     return out
 
 
@@ -367,7 +380,9 @@ class SparseConvFunction(Function):
     """features (N_in, Cin), weight (K, Cin, Cout), bias (Cout)|None -> (N_out, Cout)."""
 
     @staticmethod
-    def forward(ctx, features, weight, bias, rules, inverse, packed=None, side_ok=False):
+    def forward(ctx, features, weight, bias, rules, inverse, packed=None, side_ok=False, bn=None):
+        """bn: the training-mode BatchNorm1d behind the conv: its statistics ride in the kernel's epilogue and the
+        call returns (out, coef, save_mean, save_invstd) for FusedBNApply (the last three non-differentiable)."""
         features = features.contiguous().float()
         w = weight.contiguous()
         _lib.check_cuda(features, w)
@@ -376,14 +391,16 @@ class SparseConvFunction(Function):
         else:
             nbr, order, n_out = rules.nbr, rules.tile_order_out, rules.N_out
         out = _sconv(features, w, bias, nbr, order, n_out, packed=packed, rules=rules,
-                     n_live=rules.count_in if inverse else rules.count_out)
+                     n_live=rules.count_in if inverse else rules.count_out, bn=bn)
         ctx.rules, ctx.inverse, ctx.side_ok = rules, inverse, side_ok
         ctx.save_for_backward(features, w)
         ctx.has_bias = bias is not None
+        if bn is not None:
+            ctx.mark_non_differentiable(*out[1:])
         return out
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, *_stats_grads):
         features, w = ctx.saved_tensors
         rules, inverse = ctx.rules, ctx.inverse
         grad_out = grad_out.contiguous().float()
@@ -437,7 +454,7 @@ class SparseConvFunction(Function):
             else:   # rows past the live count are undefined (possibly NaN): select, do not multiply
                 live = torch.arange(grad_out.shape[0], device=grad_out.device) < live_fwd
                 g_b = torch.where(live[:, None], grad_out, grad_out.new_zeros(())).sum(0)
-        return g_feat, g_w, g_b, None, None, None, None
+        return g_feat, g_w, g_b, None, None, None, None, None
 
 
 class SparseConvTensor:
@@ -640,9 +657,11 @@ class SparseConvolution(SparseModule):
             x.indice_dict[key] = rs
         return rs
 
-    def forward(self, x, fused_bn=None, fused_relu=False):
+    def forward(self, x, fused_bn=None, fused_relu=False, train_bn=None, train_relu=False):
         """fused_bn / fused_relu: inference-only folding of the eval-mode BatchNorm1d (+ReLU)
-        that follows this conv into the kernel's epilogue (see SparseSequential)."""
+        that follows this conv into the kernel's epilogue (see SparseSequential).
+        train_bn / train_relu: the TRAINING-mode BatchNorm1d (+ReLU) behind the conv: statistics in the conv's
+        epilogue, then one transform launch (FusedBNApply)."""
         assert isinstance(x, SparseConvTensor)
         K = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
         w = self.weight.reshape(K, self.in_channels, self.out_channels)
@@ -667,8 +686,19 @@ class SparseConvolution(SparseModule):
         else:
             # side_ok: the weight gradient may run on WGRAD_STREAM only when nothing but views
             # separates it from the parameter (a padded weight's backward copies on the main stream)
-            feats = SparseConvFunction.apply(x_features, w, self.bias, rs, self.inverse,
-                                             self._packed_weight(w), not pad)
+            if train_bn is not None:
+                feats, coef, mean, invstd = SparseConvFunction.apply(x_features, w, self.bias, rs, self.inverse,
+                                                                     self._packed_weight(w), not pad, train_bn)
+                feats = FusedBNApply.apply(feats, coef, mean, invstd, train_bn.weight, train_bn.bias, train_relu,
+                                           rs.count_in if self.inverse else rs.count_out)
+                if train_bn.track_running_stats and train_bn.num_batches_tracked is not None:
+                    if DEFERRED_COUNTERS is not None:
+                        DEFERRED_COUNTERS.append(train_bn.num_batches_tracked)
+                    else:
+                        train_bn.num_batches_tracked += 1
+            else:
+                feats = SparseConvFunction.apply(x_features, w, self.bias, rs, self.inverse,
+                                                 self._packed_weight(w), not pad)
         if self.inverse:
             out = SparseConvTensor(feats, rs.in_indices, rs.in_spatial_shape, x.batch_size,
                                    x.grid, x.voxel_num, x.indice_dict, x.benchmark, rs.count_in)
@@ -749,6 +779,38 @@ class FusedBNReLU(Function):
              dgamma, dbeta, ctx.count, ws, size_arg(ws.numel()), _bn_state(x.device), 0)
         return dx, (dgamma if weight is not None else None), (dbeta if weight is not None else None), \
             None, None, None, None, None, None
+
+
+class FusedBNApply(Function):
+    """The transform half of FusedBNReLU for statistics that were taken in the producing sparse conv's epilogue
+    (SparseConvFunction with bn=...): y = relu?(x * scale + shift), one launch; backward = FusedBNReLU's."""
+
+    @staticmethod
+    def forward(ctx, x, coef, mean, invstd, weight, bias, relu, count=None):
+        N, C = x.shape
+        y = torch.empty_like(x)
+        call("glx_bn_apply_forward", x, coef, 1 if relu else 0, N, C, count, y, 0)
+        ctx.save_for_backward(x, weight, bias, mean, invstd)
+        ctx.relu, ctx.count = relu, count
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx, dgamma, dbeta = FusedBNReLU.backward(ctx, dy)[:3]
+        return dx, None, None, None, dgamma, dbeta, None, None
+
+
+def conv_bn_fusable(conv, bn, x):
+    """A sparse conv whose training-mode BatchNorm statistics can ride in its epilogue (csrc/glx_sconv.hip
+    sc_epilogue): MFMA tile kernel in one launch, channel counts the fused BatchNorm kernels cover."""
+    cin, cout = conv.in_channels + _cin_padding(conv.in_channels), conv.out_channels
+    return (FUSE_BN_STATS_IN_CONV and USE_BN_STATE and torch.is_grad_enabled() and can_fuse_train_bn(bn, x.features)
+            and bn.num_features == cout and cout in (16, 32, 64, 128) and cin in (4, 8, 16, 32, 64, 128)
+            and not (cin >= 128 and cout >= 128) and not (cin in (4, 8) and cout > 32)
+            and x.features.is_cuda and x.indices.shape[0] > 1)
+
+
+FUSE_BN_STATS_IN_CONV = os.environ.get("GLX_BN_IN_CONV", "1") != "0"
 
 
 class FusedBNReLUCat(Function):
@@ -927,6 +989,13 @@ class SparseSequential(SparseModule):
                     and isinstance(x, SparseConvTensor)):
                 relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
                 x = m(x, fused_bn=mods[i + 1], fused_relu=relu)
+                i += 3 if relu else 2
+                continue
+            if (isinstance(m, SparseConvolution) and i + 1 < len(mods) and isinstance(x, SparseConvTensor)
+                    and isinstance(mods[i + 1], nn.BatchNorm1d) and conv_bn_fusable(m, mods[i + 1], x)):
+                relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                x = m(x, train_bn=mods[i + 1], train_relu=relu)
+                x.clean_rows = True        # the transform wrote zeros into the rows past `count`
                 i += 3 if relu else 2
                 continue
             if (isinstance(x, SparseConvTensor) and isinstance(m, nn.BatchNorm1d)

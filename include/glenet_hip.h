@@ -159,6 +159,15 @@ int glx_sconv_forward(const float* in, int N_in, const float* W, const float* Wp
 /* Bracket the NEXT glx_sconv_forward MFMA launch of this host thread with two HIP events
  * (hipExtLaunchKernelGGL start/stop): kernel-only duration for bench.py's roofline. */
 int glx_profile_next_sconv(void* start_event, void* stop_event);
+/* Training-mode BatchNorm behind a sparse conv (spconv_backbone.py:21-25: SubMConv3d / SparseConv3d -> BatchNorm1d ->
+ * ReLU): the per-channel statistics of the conv's output are taken in the epilogue of the NEXT glx_sconv_forward call
+ * of this host thread (MFMA tile kernels, one launch) and finalized by the last block -- coef (2 * Cout floats) =
+ * scale | shift for glx_bn_apply_forward, save_mean / save_invstd (Cout) for glx_bn_relu_backward, running statistics
+ * updated with nn.BatchNorm1d's semantics (NULL: not tracked).  state: glx_bn_state_bytes() device bytes, zero-filled
+ * once, shared by the calls of a stream. */
+int glx_sconv_next_bn_stats(void* state, const float* gamma, const float* beta, float eps, float momentum,
+                            float* coef, float* save_mean, float* save_invstd, float* running_mean,
+                            float* running_var);
 /* Reference-quality scalar kernel (any channel count); used for tiny Cin and as a
  * device-side cross-check of the MFMA kernel. */
 int glx_sconv_forward_generic(const float* in, int N_in, const float* W, const float* bias,
@@ -536,6 +545,10 @@ int glx_bn_relu_train_forward(const float* x, int N, int C, const float* gamma, 
                               float* running_var, float* y, float* save_mean, float* save_invstd,
                               const int32_t* n_live, void* workspace, size_t workspace_bytes,
                               void* state, int y_stride, void* stream);
+/* The transform of glx_bn_relu_train_forward alone, for statistics taken in a sparse conv's epilogue
+ * (glx_sconv_next_bn_stats): y = relu?(x * coef[c] + coef[C + c]) on the live rows, zeros on the rows past them. */
+int glx_bn_apply_forward(const float* x, const float* coef, int relu, int N, int C, const int32_t* n_live,
+                         float* y, int y_stride, void* stream);
 /* dx (N,C), dgamma (C), dbeta (C) from dy and the forward's x, mean, invstd.  The ReLU mask: from the forward's
  * output y, or -- y = NULL -- re-derived from x with gamma / beta (the forward's own rounding, so it is the same
  * mask; a third less traffic).  beta is only read in that case. */

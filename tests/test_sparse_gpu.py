@@ -371,3 +371,49 @@ def test_bev_backbone_concatenation_without_the_copy(dev):
         assert float((p.grad - q.grad).abs().max()) <= 1e-3 * scale, n
     for (n, p), (_, q) in zip(net.named_buffers(), ref.named_buffers()):
         np.testing.assert_allclose(p.cpu().numpy(), q.cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=n)
+
+
+@pytest.mark.parametrize("cin,cout,subm,n_pts", [(4, 16, True, 9000), (16, 32, False, 9000), (64, 64, True, 30000),
+                                                (32, 64, False, 30000), (64, 128, False, 12000)])
+def test_batchnorm_statistics_in_the_conv_epilogue(dev, cin, cout, subm, n_pts, monkeypatch):
+    """SparseSequential(conv, BatchNorm1d, ReLU) in training mode: the per-channel statistics taken in the sparse conv's
+    epilogue (glx_sconv_next_bn_stats -> sc_epilogue -> last-block finalize) + the transform launch == the conv
+    followed by the separate fused BatchNorm (k_bn_stats + transform): output, running statistics, every gradient.
+    Also with a shape-static row count (rows past `count` excluded from the statistics, zeroed in the output)."""
+    rng = np.random.default_rng(cin + cout)
+    coords = np.unique(rng.integers(0, [2, 20, 90, 90], (n_pts, 4)), axis=0).astype(np.int32)
+    shape = [21, 96, 96]
+    feats = rng.normal(size=(len(coords), cin)).astype(np.float32)
+
+    def build():
+        torch.manual_seed(3)
+        conv = (sp.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key="a") if subm else
+                sp.SparseConv3d(cin, cout, 3, stride=2, padding=1, bias=False, indice_key="b"))
+        bn = torch.nn.BatchNorm1d(cout, eps=1e-3, momentum=0.01)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(cout) + 0.5)
+            bn.bias.copy_(torch.randn(cout) * 0.2)
+        return sp.SparseSequential(conv, bn, torch.nn.ReLU()).to(dev).train()
+
+    def run(fused):
+        monkeypatch.setattr(sp, "FUSE_BN_STATS_IN_CONV", fused)
+        m = build()
+        f = T(feats, dev).requires_grad_(True)
+        x = sp.SparseConvTensor(f, T(coords, dev), shape, 2)
+        y = m(x)
+        g = torch.from_numpy(np.random.default_rng(1).normal(size=tuple(y.features.shape)).astype(np.float32)).to(dev)
+        y.features.backward(g)
+        torch.cuda.synchronize()
+        return (y.features.detach(), f.grad, m[0].weight.grad, m[1].weight.grad, m[1].bias.grad,
+                m[1].running_mean.clone(), m[1].running_var.clone(), int(m[1].num_batches_tracked))
+    a, b = run(True), run(False)
+    assert a[7] == b[7] == 1
+    names = ("output", "input grad", "weight grad", "gamma grad", "beta grad", "running mean", "running var")
+    for name, u, v in zip(names, a[:7], b[:7]):
+        scale = float(v.abs().max()) + 1e-12
+        assert float((u - v).abs().max()) <= 2e-5 * scale + 1e-7, name
+    assert float(a[0].abs().max()) > 0.1
+    torch.cuda.synchronize()
+    for st in sp._BN_STATES.values():                      # accumulators clean, ticket reset
+        words = st.view(torch.int32)
+        assert int(words[:16 * 2 * 512 * 2].abs().max()) == 0 and int(words[16 * 2 * 512 * 2]) == 0

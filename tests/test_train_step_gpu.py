@@ -261,3 +261,44 @@ def test_fused_batch_load_equals_the_tensor_op_load(dev):
         assert torch.equal(a, b)
     assert int((snaps[0][1] == 2).sum()) == pipe.batch_idx.numel() - small[0].shape[0]
     assert float(snaps[0][2][:, 9:].abs().max()) == 0.0 and float(snaps[0][2][:, :9].abs().max()) > 0
+
+
+def test_split_backward_convolutions_give_the_library_gradients(dev):
+    """dense_path._ConvSplitBackward (input gradient on the main stream, weight gradient on the step's side stream) ==
+    torch's own conv2d / conv_transpose2d backward, channels-last, with and without the side stream set."""
+    from glenet_amd import dense_path as dp
+    from glenet_amd.spconv import core
+    torch.manual_seed(0)
+    x = torch.randn(2, 16, 40, 36, device=dev).to(memory_format=torch.channels_last)
+    cases = [(torch.nn.Conv2d(16, 32, 3, stride=2, padding=1, bias=False), None),
+             (torch.nn.Conv2d(16, 8, 1, bias=True), None),
+             (torch.nn.ConvTranspose2d(16, 24, 2, stride=2, bias=False), None)]
+    side = torch.cuda.Stream(dev)
+    for m, _ in cases:
+        m = m.to(dev).to(memory_format=torch.channels_last)
+        for use_side in (False, True):
+            xa = x.clone().requires_grad_(True)
+            xb = x.clone().requires_grad_(True)
+            m.zero_grad(set_to_none=True)
+            ya = m(xa)
+            g = torch.randn_like(ya)
+            ya.backward(g)
+            want = (xa.grad.clone(), m.weight.grad.clone(), None if m.bias is None else m.bias.grad.clone())
+            m.zero_grad(set_to_none=True)
+            yb = dp.conv_module(m, xb)
+            assert type(yb.grad_fn).__name__.startswith("_ConvSplitBackward")
+            core.WGRAD_STREAM = side if use_side else None
+            try:
+                yb.backward(g)
+            finally:
+                core.WGRAD_STREAM = None
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize()
+            assert torch.equal(ya, yb)
+            np.testing.assert_allclose(xb.grad.cpu().numpy(), want[0].cpu().numpy(), rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(m.weight.grad.cpu().numpy(), want[1].cpu().numpy(), rtol=1e-4, atol=1e-4)
+            if want[2] is not None:
+                np.testing.assert_allclose(m.bias.grad.cpu().numpy(), want[2].cpu().numpy(), rtol=1e-4, atol=1e-4)
+    # a derived (non-leaf) weight keeps torch's node: its gradient feeds another node on the main stream
+    w = torch.cat([cases[1][0].weight, cases[1][0].weight], 0)
+    assert not type(dp.conv2d(x.requires_grad_(True), w).grad_fn).__name__.startswith("_ConvSplitBackward")
