@@ -40,7 +40,7 @@ def load():
                  "glx_assign_targets_workspace_bytes", "glx_rpn_loss_workspace_bytes",
                  "glx_group_points_grad_workspace_bytes", "glx_adamw_workspace_bytes", "glx_bn_workspace_bytes",
                  "glx_pos_pool_workspace_bytes", "glx_vector_pool_workspace_bytes",
-                 "glx_sconv_tile_map_workspace_bytes", "glx_sconv_packed_bytes"):
+                 "glx_sconv_tile_map_workspace_bytes", "glx_sconv_packed_bytes", "glx_mask_shuffle_workspace_bytes"):
         if hasattr(lib, name):
             getattr(lib, name).restype = c_size_t
     lib.glx_index_words.restype = c_int64
@@ -127,6 +127,26 @@ def bump_weights_epoch():
     global _weights_epoch
     _weights_epoch += 1
     return _weights_epoch
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# hipGraphExec objects are never destroyed while the process lives (ROCm 7.2 workaround).  Destroying the exec of a
+# graph with parallel branches leaves the runtime with a dangling hip::Stream: a LATER hipGraphLaunch of another graph
+# segfaults in hip::Graph::UpdateStreams <- hip::GraphExec::Run (rocgdb backtrace: profiles/r03_graph_exec_destroy_
+# crash.txt; reproduced by tests/test_backbone_gpu.py + tests/test_train_step_gpu.py in one process, gone with this
+# list).  A pipeline that records itself again (weights changed) retires its old graph here instead of dropping it;
+# the cost is that graph's private memory pool until exit -- 288 GB of HBM make that the cheaper side of the trade.
+# GLX_KEEP_GRAPH_EXECS=0 restores normal lifetimes.
+KEEP_GRAPH_EXECS = os.environ.get("GLX_KEEP_GRAPH_EXECS", "1") != "0"
+_graph_execs = []
+
+
+def new_graph():
+    """torch.cuda.CUDAGraph() whose exec outlives its owner (see above)."""
+    g = torch.cuda.CUDAGraph()
+    if KEEP_GRAPH_EXECS:
+        _graph_execs.append(g)
+    return g
 
 
 class Workspace:

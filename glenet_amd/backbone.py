@@ -305,7 +305,7 @@ class StaticFramePipeline:
         torch.cuda.current_stream(self.points.device).wait_stream(side)
         torch.cuda.synchronize(self.points.device)
         self.check()
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = _lib.new_graph()
         with torch.cuda.graph(self.graph, stream=side), no_gc():
             self.enqueue()
         self._tag = self._weights_tag()

@@ -393,49 +393,133 @@ static DynWs dyn_ws_layout(void* base, int P, int B, int gx, int gy, int gz) {
 
 // ------------------------------------------------------------------ device data step
 // DataProcessor.mask_points_and_boxes_outside_range + shuffle_points (data_processor.py:78-105) on the stacked,
-// capacity-sized point buffer of a shape-static step, without boolean indexing (variable shapes, a host read-back):
-// every point gets the 64-bit key (frame id or B when masked / padding) << 32 | random 32 bits; one sort of the keys
-// IS the per-frame random permutation with the dropped points moved behind the last frame (frame id B = padding for
-// the voxelizer), and k_permute_points gathers the rows.  x / y closed interval as common_utils.py:60-63.
-__global__ void k_shuffle_keys(const float* __restrict__ pts, const int* __restrict__ batch, int P, int C, int B,
-                               float x0, float y0, float x1, float y1, const uint32_t* __restrict__ rnd,
-                               long long* __restrict__ keys) {
+// capacity-sized point buffer of a shape-static step: no boolean indexing (variable shapes, a host read-back), no
+// sort and no library call (rocPRIM's sort puts memset nodes into a captured graph, which ROCm 7.2 replays
+// unreliably -- DESIGN 3a).  Four launches:
+//   scan (2)    excl[i] = kept points before row i (keep = frame id valid and x / y inside the CLOSED range,
+//               common_utils.py:60-63), total kept
+//   frames      frame f's first row by binary search in the non-decreasing frame ids -> kept offsets ko[0..B];
+//               the step's permutation key = seed ^ f(call counter), counter += 1
+//   scatter     kept row i of frame f with in-frame rank r goes to ko[f] + perm_f(r): a keyed BIJECTION of
+//               [0, n_f) -- a 6-round Feistel network on the next even power of two with cycle walking -- i.e. a
+//               pseudo-random permutation of the frame's kept points, evaluated independently per point.
+//               Rows behind the kept ones get frame id B (padding for glx_voxelize_hard) and zeros.
+struct DsKeep {
+  const float* pts; const int* batch; int C, B; float x0, y0, x1, y1;
+  __device__ int operator()(long long i) const {
+    const int b = batch ? batch[i] : 0;
+    const float x = pts[i * C], y = pts[i * C + 1];
+    return (b >= 0 && b < B && x >= x0 && x <= x1 && y >= y0 && y <= y1) ? 1 : 0;
+  }
+};
+
+__device__ __forceinline__ unsigned ds_mix(unsigned x) {        // a 32-bit finaliser (murmur3)
+  x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+  return x;
+}
+
+// bijection of [0, n): Feistel rounds on 2 * half_bits bits, walked until the value falls below n
+__device__ __forceinline__ unsigned ds_perm(unsigned r, unsigned n, unsigned long long key) {
+  if (n <= 1) return 0;
+  int bits = 32 - __clz(n - 1);
+  bits += bits & 1;
+  if (bits < 2) bits = 2;
+  const int hb = bits >> 1;
+  const unsigned hmask = (1u << hb) - 1u;
+  unsigned v = r;
+  do {
+    unsigned L = v >> hb, R = v & hmask;
+#pragma unroll
+    for (int round = 0; round < 6; ++round) {
+      const unsigned k = (unsigned)(key >> ((round & 1) * 32)) + 0x9E3779B9u * (unsigned)(round + 1);
+      const unsigned F = ds_mix(R ^ k) & hmask;
+      const unsigned t = L ^ F;
+      L = R; R = t;
+    }
+    v = (L << hb) | R;
+  } while (v >= n);
+  return v;
+}
+
+__global__ void k_ds_frames(const int* __restrict__ batch, const int* __restrict__ excl,
+                            const int* __restrict__ n_kept, int P, int B, int* __restrict__ ko,
+                            unsigned long long* __restrict__ counter, unsigned long long* __restrict__ key) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f <= B) {
+    // first row whose frame id is >= f (ids non-decreasing; padding rows carry B)
+    int lo = 0, hi = P;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((batch ? batch[mid] : 0) < f) lo = mid + 1; else hi = mid;
+    }
+    ko[f] = (f == B || lo >= P) ? *n_kept : excl[lo];
+  }
+  if (f == 0) {
+    const unsigned long long c = counter[1];
+    // splitmix64 of (seed, call number): a fresh key every call, reproducible from the seed
+    unsigned long long z = counter[0] + 0x9E3779B97F4A7C15ull * (c + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    *key = z ^ (z >> 31);
+    counter[1] = c + 1;
+  }
+}
+
+__global__ void k_ds_scatter(DsKeep keep, const int* __restrict__ excl, const int* __restrict__ ko,
+                             const int* __restrict__ n_kept, const unsigned long long* __restrict__ key, int P,
+                             int shuffle, float* __restrict__ out, int* __restrict__ out_batch,
+                             int* __restrict__ order) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
-  const float x = pts[(long long)i * C], y = pts[(long long)i * C + 1];
-  const int b = batch ? batch[i] : 0;
-  const bool keep = b >= 0 && b < B && x >= x0 && x <= x1 && y >= y0 && y <= y1;
-  keys[i] = ((long long)(keep ? b : B) << 32) | (long long)rnd[i];
+  const int C = keep.C;
+  if (i >= *n_kept) {                                   // the tail of the output: padding rows
+    out_batch[i] = keep.B;
+    if (order) order[i] = -1;
+    for (int c = 0; c < C; ++c) out[(long long)i * C + c] = 0.f;
+  }
+  if (!keep(i)) return;
+  const int f = keep.batch ? keep.batch[i] : 0;
+  const unsigned r = (unsigned)(excl[i] - ko[f]), n = (unsigned)(ko[f + 1] - ko[f]);
+  const unsigned long long k = *key ^ (0xD1B54A32D192ED03ull * (unsigned long long)(f + 1));
+  const int dest = ko[f] + (int)(shuffle ? ds_perm(r, n, k) : r);
+  for (int c = 0; c < C; ++c) out[(long long)dest * C + c] = keep.pts[(long long)i * C + c];
+  out_batch[dest] = f;
+  if (order) order[dest] = i;
 }
 
-extern "C" int glx_shuffle_keys(const float* points, const int32_t* point_batch, int P, int C, int B,
-                                const float* range_xy, const uint32_t* random_bits, int64_t* keys, void* stream) {
+extern "C" size_t glx_mask_shuffle_workspace_bytes(int P, int B) {
+  return glx_align((size_t)(P > 0 ? P : 1) * sizeof(int)) + glx_align((size_t)(B + 2) * sizeof(int)) +
+         glx_scan_workspace_bytes(P > 0 ? P : 1) + 512;
+}
+
+extern "C" int glx_mask_shuffle(const float* points, const int32_t* point_batch, int P, int C, int B,
+                                const float* range_xy, int shuffle, uint64_t* seed_and_calls, float* out_points,
+                                int32_t* out_batch, int32_t* order, void* workspace, size_t workspace_bytes,
+                                void* stream) {
   if (P <= 0) return GLX_OK;
-  GLX_REQUIRE(points && range_xy && random_bits && keys && C >= 2, "glx_shuffle_keys: bad arguments");
-  hipLaunchKernelGGL(k_shuffle_keys, dim3(glx_divup(P, 256)), dim3(256), 0, (hipStream_t)stream, points, point_batch,
-                     P, C, B, range_xy[0], range_xy[1], range_xy[2], range_xy[3], random_bits, (long long*)keys);
-  GLX_LAUNCH_CHECK();
-  return GLX_OK;
-}
-
-__global__ void k_permute_points(const float* __restrict__ pts, const long long* __restrict__ order,
-                                 const long long* __restrict__ sorted_keys, long long total, int C,
-                                 float* __restrict__ out, int* __restrict__ out_batch) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= total) return;
-  const long long i = t / C;
-  const int c = (int)(t - i * C);
-  out[t] = pts[order[i] * C + c];
-  if (c == 0) out_batch[i] = (int)(sorted_keys[i] >> 32);
-}
-
-extern "C" int glx_permute_points(const float* points, const int64_t* order, const int64_t* sorted_keys, int P, int C,
-                                  float* out_points, int32_t* out_batch, void* stream) {
-  if (P <= 0) return GLX_OK;
-  GLX_REQUIRE(points && order && sorted_keys && out_points && out_batch, "glx_permute_points: null pointer");
-  const long long total = (long long)P * C;
-  hipLaunchKernelGGL(k_permute_points, dim3(glx_divup(total, 256)), dim3(256), 0, (hipStream_t)stream, points,
-                     (const long long*)order, (const long long*)sorted_keys, total, C, out_points, out_batch);
+  GLX_REQUIRE(points && range_xy && seed_and_calls && out_points && out_batch && C >= 2 && B >= 1,
+              "glx_mask_shuffle: bad arguments");
+  GLX_REQUIRE(out_points != points, "glx_mask_shuffle: in-place operation is not supported");
+  if (!workspace || workspace_bytes < glx_mask_shuffle_workspace_bytes(P, B) - 256) {
+    glx_set_error("glx_mask_shuffle: workspace %zu < %zu bytes", workspace_bytes, glx_mask_shuffle_workspace_bytes(P, B));
+    return GLX_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  char* w = (char*)workspace;
+  int* excl = (int*)w; w += glx_align((size_t)P * sizeof(int));
+  int* ko = (int*)w; w += glx_align((size_t)(B + 2) * sizeof(int));     // ko[0..B], then n_kept
+  int* n_kept = ko + B + 1;
+  unsigned long long* key = (unsigned long long*)w; w += 256;
+  void* scan_ws = w;
+  const size_t scan_bytes = glx_scan_workspace_bytes(P);
+  DsKeep keep{points, point_batch, C, B, range_xy[0], range_xy[1], range_xy[2], range_xy[3]};
+  int rc = glx_exclusive_scan(keep, P, excl, n_kept, scan_ws, scan_bytes, st);
+  if (rc != GLX_OK) return rc;
+  hipLaunchKernelGGL(k_ds_frames, dim3(glx_divup(B + 1, 64)), dim3(64), 0, st, point_batch, (const int*)excl,
+                     (const int*)n_kept, P, B, ko, (unsigned long long*)seed_and_calls, key);
+  hipLaunchKernelGGL(k_ds_scatter, dim3(glx_divup(P, 256)), dim3(256), 0, st, keep, (const int*)excl, (const int*)ko,
+                     (const int*)n_kept, (const unsigned long long*)key, P, shuffle ? 1 : 0, out_points, out_batch,
+                     order);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

@@ -72,7 +72,7 @@ class CVAETrainStep:
                 self.enqueue()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = _lib.new_graph()
         with torch.cuda.graph(self.graph, stream=side), no_gc():
             self.enqueue()
         torch.cuda.synchronize(dev)

@@ -25,24 +25,22 @@ def shuffle_points(points, batch_idx, batch_size, generator=None):
     return points[order], batch_idx[order]
 
 
-def mask_and_shuffle_static(points, batch_idx, batch_size, limit_range, random_bits=None):
+def mask_and_shuffle_static(points, batch_idx, batch_size, limit_range, state, shuffle=True):
     """The same two operations on a CAPACITY-sized stacked buffer without changing its shape or reading anything
-    back (capturable in a HIP graph): rows outside the x / y range (and padding rows, frame id == batch_size) get
-    frame id `batch_size` and move behind the last frame; the rows of every frame are randomly permuted.
-    -> (points, batch_idx, order): order[i] = source row of output row i (int64), for tests and for gathering
-    per-point side data the same way."""
+    back (capturable in a HIP graph; csrc/glx_voxelize.hip: glx_mask_shuffle): rows outside the x / y range (and
+    padding rows, frame id == batch_size) are dropped, the kept rows of every frame are written in a keyed
+    pseudo-random order, the rest of the buffer becomes padding.  state: device int64[2] = (seed, calls so far).
+    -> (points, batch_idx, order): order[i] = source row of output row i (int32, -1 for padding)."""
     import ctypes
     from . import _lib
-    _lib.check_cuda(points, batch_idx)
+    _lib.check_cuda(points, batch_idx, state)
     p, c = points.shape
-    if random_bits is None:
-        random_bits = torch.empty(p, dtype=torch.int32, device=points.device).random_()      # torch's graph-safe Philox
-    keys = torch.empty(p, dtype=torch.int64, device=points.device)
-    rng = (ctypes.c_float * 4)(float(limit_range[0]), float(limit_range[1]), float(limit_range[3]), float(limit_range[4]))
-    _lib.call("glx_shuffle_keys", points, batch_idx, p, c, int(batch_size), rng, random_bits, keys)
-    skeys, order = torch.sort(keys)                                    # rocPRIM radix sort: no read-back
     out_p, out_b = torch.empty_like(points), torch.empty_like(batch_idx)
-    _lib.call("glx_permute_points", points, order, skeys, p, c, out_p, out_b)
+    order = torch.empty(p, dtype=torch.int32, device=points.device)
+    ws = _lib.workspace.get(_lib.query("glx_mask_shuffle_workspace_bytes", p, int(batch_size)), points.device)
+    rng = (ctypes.c_float * 4)(float(limit_range[0]), float(limit_range[1]), float(limit_range[3]), float(limit_range[4]))
+    _lib.call("glx_mask_shuffle", points, batch_idx, p, c, int(batch_size), rng, 1 if shuffle else 0, state, out_p, out_b,
+              order, ws, _lib.size_arg(ws.numel()))
     return out_p, out_b, order
 
 
@@ -51,15 +49,16 @@ class DeviceDataProcessor:
         self.cfg, self.training, self.shuffle = cfg, training, shuffle
         self.generator = None
         self.seed = seed
+        self._state = None          # device (seed, call counter) of the static step's keyed permutation
 
     def static_step(self, points, batch_idx, batch_size):
         """mask + shuffle on capacity-sized buffers (see mask_and_shuffle_static); voxelization stays with the caller
         (StaticTrainPipeline runs it right after, inside the same recorded step)."""
-        if not self.shuffle:
-            # the row number as the low key word: the order inside a frame is kept, only the mask acts
-            idx = torch.arange(points.shape[0], dtype=torch.int32, device=points.device)
-            return mask_and_shuffle_static(points, batch_idx, batch_size, self.cfg["point_cloud_range"], idx)[:2]
-        return mask_and_shuffle_static(points, batch_idx, batch_size, self.cfg["point_cloud_range"])[:2]
+        if self._state is None or self._state.device != points.device:
+            self._state = torch.tensor([self.seed if self.seed is not None else 0x5EED, 0], dtype=torch.int64,
+                                       device=points.device)
+        return mask_and_shuffle_static(points, batch_idx, batch_size, self.cfg["point_cloud_range"], self._state,
+                                       self.shuffle)[:2]
 
     def __call__(self, points, batch_idx, batch_size, static=False):
         if self.seed is not None and self.generator is None:

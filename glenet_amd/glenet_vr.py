@@ -428,7 +428,7 @@ class StaticTrainStep(gb.StaticTrainPipeline):
                 self.update()                              # warm-up of the optimizer state (lazy init)
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
-            self.update_graph = torch.cuda.CUDAGraph()
+            self.update_graph = gb._lib.new_graph()
             with torch.cuda.graph(self.update_graph, stream=side), gb.no_gc():
                 self.update()
         return self

@@ -244,14 +244,16 @@ int glx_voxelize_hard(const float* points, const int32_t* point_batch, int P, in
 
 /* Device data step in front of the voxelizer: DataProcessor.mask_points_and_boxes_outside_range +
  * shuffle_points (pcdet/datasets/processor/data_processor.py:78-105, common_utils.py:60-63) on a capacity-sized
- * stacked buffer, shape-static (capturable).  glx_shuffle_keys: keys[i] = (frame id, or B for a point outside the
- * closed x / y range {x0, y0, x1, y1} (HOST array) or a padding row) << 32 | random_bits[i].  Sorting the keys
- * ascending gives `order`; glx_permute_points writes out_points[i] = points[order[i]] and out_batch[i] = high word of
- * sorted_keys[i]: every frame randomly permuted, dropped points last with frame id B (padding for glx_voxelize_hard). */
-int glx_shuffle_keys(const float* points, const int32_t* point_batch, int P, int C, int B, const float* range_xy,
-                     const uint32_t* random_bits, int64_t* keys, void* stream);
-int glx_permute_points(const float* points, const int64_t* order, const int64_t* sorted_keys, int P, int C,
-                       float* out_points, int32_t* out_batch, void* stream);
+ * stacked buffer, shape-static and free of library calls (capturable).  point_batch: non-decreasing frame ids, B =
+ * padding.  A point is kept when its frame id is valid and x / y lie in the CLOSED range range_xy = {x0, y0, x1, y1}
+ * (HOST array).  Output: the kept points of frame 0, then frame 1, ... each frame in a pseudo-random order (shuffle
+ * != 0: a keyed bijection of the frame's kept points, new for every call -- seed_and_calls = DEVICE uint64[2] {seed,
+ * number of calls so far}, the call increments the second; shuffle == 0: the original order), then rows with frame id
+ * B and zeros.  order (P, optional): source row of every output row, -1 for padding.  Not in place. */
+size_t glx_mask_shuffle_workspace_bytes(int P, int B);
+int glx_mask_shuffle(const float* points, const int32_t* point_batch, int P, int C, int B, const float* range_xy,
+                     int shuffle, uint64_t* seed_and_calls, float* out_points, int32_t* out_batch, int32_t* order,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* Dynamic voxelization + per-voxel mean, semantics of DynamicMeanVFE.forward
  * (pcdet/models/backbones_3d/vfe/dynamic_mean_vfe.py:53-72): voxels enumerate in ascending

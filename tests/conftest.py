@@ -20,3 +20,4 @@ def dev():
     from glenet_amd import _lib
     _lib.load()  # fail loudly if the HIP library was not built
     return torch.device("cuda", 0)
+

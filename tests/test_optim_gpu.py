@@ -63,7 +63,8 @@ def test_flat_adamw_replays_in_a_graph_and_handles_missing_grads(dev):
         opt.step()                                      # warm-up (step 1)
     torch.cuda.current_stream(dev).wait_stream(side)
     torch.cuda.synchronize(dev)
-    graph = torch.cuda.CUDAGraph()
+    from glenet_amd import _lib
+    graph = _lib.new_graph()
     with torch.cuda.graph(graph, stream=side):
         opt.step()
     for _ in range(3):

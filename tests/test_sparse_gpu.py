@@ -380,6 +380,7 @@ def test_batchnorm_statistics_in_the_conv_epilogue(dev, cin, cout, subm, n_pts, 
     epilogue (glx_sconv_next_bn_stats -> sc_epilogue -> last-block finalize) + the transform launch == the conv
     followed by the separate fused BatchNorm (k_bn_stats + transform): output, running statistics, every gradient.
     Also with a shape-static row count (rows past `count` excluded from the statistics, zeroed in the output)."""
+    T = lambda a, d: torch.from_numpy(np.ascontiguousarray(a)).to(d)                    # noqa: E731
     rng = np.random.default_rng(cin + cout)
     coords = np.unique(rng.integers(0, [2, 20, 90, 90], (n_pts, 4)), axis=0).astype(np.int32)
     shape = [21, 96, 96]
