@@ -810,7 +810,12 @@ def conv_bn_fusable(conv, bn, x):
             and x.features.is_cuda and x.indices.shape[0] > 1)
 
 
-FUSE_BN_STATS_IN_CONV = os.environ.get("GLX_BN_IN_CONV", "1") != "0"
+# Off by default: measured on the GLENet-VR training step (three alternating runs on one box) 11.79 / 11.77 / 11.68 ms
+# with the statistics in the conv epilogue against 11.67 / 11.68 / 11.68 ms with the separate statistics kernel -- the
+# 12 saved launches (a 3 us pass over 12 MB + an 11 us dependent tail each) cost the convs as much: three times the
+# blocks queue on the fp64 accumulator atomics (753 tiles against 256 slabs) and the last-block finalize now sits at
+# the end of the conv instead of overlapping the next launch's ramp-up.  Kept (tested) behind GLX_BN_IN_CONV=1.
+FUSE_BN_STATS_IN_CONV = os.environ.get("GLX_BN_IN_CONV", "0") != "0"
 
 
 class FusedBNReLUCat(Function):
