@@ -252,7 +252,8 @@ def bench_bev(model, dev, frames=FRAMES_PER_GPU):
 def bench_config3(dev, objects=4096, points=512, samples=30):
     """BASELINE configs[3]: the CVAE on 4096 object crops x 512 points -- (i) the inference sampler, 30 latent samples
     per object (fused MFMA PointNet kernel, csrc/glx_pointnet.hip), (ii) one TRAINING step forward + backward + clip +
-    AdamW (glenet_amd.cvae_train.CVAETrainStep: row GEMMs + fused training BatchNorm, one HIP graph)."""
+    AdamW (glenet_amd.cvae_train.CVAETrainStep, one HIP graph; at this size -- 2.1 M point rows -- the extractors run
+    as the reference's (B, C, P) Conv1d + BatchNorm1d modules on MIOpen / hipBLASLt, see PointFeat.ROWS_MAX)."""
     import torch
     from glenet_amd import cvae_train as ct
     from glenet_amd import dense_path as dp
@@ -284,8 +285,9 @@ def bench_config3(dev, objects=4096, points=512, samples=30):
                              objects_per_s=round(objects / (ms_s * 1e-3), 1),
                              TFLOPs=round(samples * sample_flops / ms_s / 1e9, 1),
                              frac_of_fp32_mfma_peak=round(samples * sample_flops / ms_s / 1e9 / MFMA_F32_PEAK_TFLOPS, 3)),
-                train_step=dict(what="forward (posterior + prior encoders, decoder) + losses + backward + clip 10 + AdamW, "
-                                     "one HIP graph", ms_per_step=round(ms_t, 2),
+                train_step=dict(what="forward (posterior + prior encoders, decoder) + losses + backward + clip 10 + AdamW "
+                                     "(flat buffers), one HIP graph, lr = the one-cycle schedule's first step",
+                                ms_per_step=round(ms_t, 2),
                                 objects_per_s=round(objects / (ms_t * 1e-3), 1), loss=round(loss, 4),
                                 gflop_per_step=round(3 * objects * per_obj / 1e9, 1),
                                 TFLOPs=round(3 * objects * per_obj / ms_t / 1e9, 1),

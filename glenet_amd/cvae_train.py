@@ -3,8 +3,9 @@
 Our counterpart of cvae_uncertainty/train_utils/train_utils.py:50-72 -- zero_grad, Generator.forward (training
 branch), `loss = reg_loss_post + anneal * lattent_loss + regular_loss`, backward, clip_grad_norm_(10), adam_onecycle
 step (cfgs/exp20.yaml: lr 0.003, weight decay 0.01, betas (0.9, 0.99)) -- on glenet_amd.dense_path.CVAE:
-PointNet extractors as row GEMMs (hipBLASLt, MFMA) + fused training BatchNorm (csrc/glx_bn.hip), the update as
-glx_adamw_clip_step on flat buffers.  Shapes are static (B objects x P points), nothing reads back, so the step is
+PointNet extractors as row GEMMs (hipBLASLt, MFMA) + fused training BatchNorm (csrc/glx_bn.hip) up to
+PointFeat.ROWS_MAX point rows (the reference's (B, C, P) modules beyond), the update as glx_adamw_clip_step on flat
+buffers.  Shapes are static (B objects x P points), nothing reads back, so the step is
 captured into ONE HIP graph; learning rate, beta1 and the annealing factor of the latent term are device scalars."""
 import torch
 

@@ -19,3 +19,17 @@ for lr in (3e-4, 3e-3):
         step.enqueue()
         out.append([round(float(t), 4) for t in step.terms] + [round(float(step.optimizer.grad_norm), 3)])
     print("lr", lr, out, flush=True)
+
+# the same at the schedule's first lr as ONE recorded graph (what bench.py times), after an eval-mode sampler pass
+torch.manual_seed(1)
+model = dp.CVAE(4, 8).to(dev).eval()
+with torch.no_grad():
+    model.sample(pts)
+step = ct.CVAETrainStep(model, 4096, 512, lr=3e-4)
+step.load(pts, box8, box7)
+step.capture()
+out = []
+for i in range(14):
+    step.step()
+    out.append([round(float(t), 4) for t in step.terms] + [round(float(step.optimizer.grad_norm), 3)])
+print("graph lr 3e-4", out, flush=True)
