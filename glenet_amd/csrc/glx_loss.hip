@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void k_assign_labels(
     const float* __restrict__ anchors, int N, const float* __restrict__ gt, int M, int gt_cols, int cls,
     float matched, float unmatched, const int* __restrict__ n_valid, const float* __restrict__ amax,
     const int* __restrict__ aarg, const int* __restrict__ gmax, int* __restrict__ labels,
-    float* __restrict__ targets, int* __restrict__ num_examples) {
+    float* __restrict__ targets, int* __restrict__ num_examples, int* __restrict__ unc_gt) {
   const int b = blockIdx.y;
   __shared__ AlignedBev s_g[TA_MAXGT];
   __shared__ int s_ok[TA_MAXGT];
@@ -366,9 +366,14 @@ __global__ __launch_bounds__(256) void k_assign_labels(
     } else {
       const AlignedBev a = aligned_bev(an);
       bool forced = false;
+      int jf = -1;
       for (int j = 0; j < nv; ++j)
-        if (s_ok[j] && bev_iou(a, s_g[j]) == s_gm[j]) forced = true;
+        if (s_ok[j] && bev_iou(a, s_g[j]) == s_gm[j]) { forced = true; jf = j; }
       lab = (forced || best >= matched) ? cls : (best < unmatched ? 0 : -1);
+      // WeightedAxisAlignedTargetAssigner (weighted_axis_aligned_target_assigner.py:166-173): the label uncertainty an
+      // anchor carries is that of the ground truth that FORCED it (the last one in index order, as the indexed
+      // assignment on the host resolves duplicates), overwritten by the arg-max ground truth when over the threshold
+      if (unc_gt) unc_gt[(long long)b * N + i] = lab > 0 ? (best >= matched ? arg : jf) : -1;
       if (lab > 0) {                                         // ResidualCoder.encode_torch(gt[arg], anchor)
         const float* g = gt + ((long long)b * M + arg) * gt_cols;
         const float dxa = fmaxf(an[3], 1e-5f), dya = fmaxf(an[4], 1e-5f), dza = fmaxf(an[5], 1e-5f);
@@ -379,6 +384,7 @@ __global__ __launch_bounds__(256) void k_assign_labels(
         t[6] = g[6] - an[6];
       }
     }
+    if (unc_gt && arg < 0) unc_gt[(long long)b * N + i] = -1;
     labels[(long long)b * N + i] = lab;
 #pragma unroll
     for (int k = 0; k < 7; ++k) targets[((long long)b * N + i) * 7 + k] = t[k];
@@ -403,11 +409,29 @@ extern "C" size_t glx_assign_targets_workspace_bytes(int B, int N) {
   return glx_align((size_t)B * N * 8) + glx_align((size_t)B * (TA_MAXGT + 2) * 4) + 256;
 }
 
+extern "C" int glx_assign_targets_ex(const float* anchors, int N, const float* gt_boxes, int B, int M,
+                                     int gt_cols, int class_id, float matched_threshold,
+                                     float unmatched_threshold, int norm_by_num_examples,
+                                     int32_t* box_cls_labels, float* box_reg_targets, float* reg_weights,
+                                     int32_t* uncertainty_gt_index, void* workspace, size_t workspace_bytes,
+                                     void* stream);
+
 extern "C" int glx_assign_targets(const float* anchors, int N, const float* gt_boxes, int B, int M,
                                   int gt_cols, int class_id, float matched_threshold,
                                   float unmatched_threshold, int norm_by_num_examples,
                                   int32_t* box_cls_labels, float* box_reg_targets, float* reg_weights,
                                   void* workspace, size_t workspace_bytes, void* stream) {
+  return glx_assign_targets_ex(anchors, N, gt_boxes, B, M, gt_cols, class_id, matched_threshold, unmatched_threshold,
+                               norm_by_num_examples, box_cls_labels, box_reg_targets, reg_weights, nullptr, workspace,
+                               workspace_bytes, stream);
+}
+
+extern "C" int glx_assign_targets_ex(const float* anchors, int N, const float* gt_boxes, int B, int M,
+                                     int gt_cols, int class_id, float matched_threshold,
+                                     float unmatched_threshold, int norm_by_num_examples,
+                                     int32_t* box_cls_labels, float* box_reg_targets, float* reg_weights,
+                                     int32_t* uncertainty_gt_index, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
   if (B <= 0 || N <= 0) return GLX_OK;
   GLX_REQUIRE(anchors && gt_boxes && box_cls_labels && box_reg_targets && reg_weights,
               "glx_assign_targets: null pointer");
@@ -431,7 +455,8 @@ extern "C" int glx_assign_targets(const float* anchors, int N, const float* gt_b
                      (const int*)n_valid, amax, aarg, gmax);
   hipLaunchKernelGGL(k_assign_labels, grid, dim3(256), 0, st, anchors, N, gt_boxes, M, gt_cols, class_id,
                      matched_threshold, unmatched_threshold, (const int*)n_valid, (const float*)amax,
-                     (const int*)aarg, (const int*)gmax, box_cls_labels, box_reg_targets, num_examples);
+                     (const int*)aarg, (const int*)gmax, box_cls_labels, box_reg_targets, num_examples,
+                     uncertainty_gt_index);
   hipLaunchKernelGGL(k_assign_weights, grid, dim3(256), 0, st, (const int*)box_cls_labels, N,
                      (const int*)num_examples, norm_by_num_examples, reg_weights);
   GLX_LAUNCH_CHECK();

@@ -365,3 +365,87 @@ def rpn_loss_torch(cls_preds, box_preds, dir_preds, box_cls_labels, box_reg_targ
         dir_loss = (ce * w).sum() / B * dir_weight
     total = cls_loss + loc_loss + dir_loss
     return total, {"rpn_loss_cls": cls_loss.detach(), "rpn_loss_loc": loc_loss.detach(), "rpn_loss_dir": dir_loss.detach()}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Single-stage GLENet heads (GLENet-S: AnchorHeadKLLabel, GLENet-C: AnchorHeadKLLabelIoU;
+# pcdet/models/dense_heads/anchor_head_kl_label.py).  Tensor-op product code on device tensors (every step is a
+# bandwidth-bound map over the (B, A, 7) anchor tensors; the rotated aligned IoU of the IoU branch is the
+# glx_iou3d_boxes_aligned_overlap_bev kernel through pcdet_ops.iou3d.iou3d_utils.boxes_aligned_iou3d_gpu).
+def _sin_difference(a, b, dim=6):
+    """AnchorHeadTemplate.add_sin_difference (anchor_head_template.py:176-184)."""
+    sa = torch.sin(a[..., dim:dim + 1]) * torch.cos(b[..., dim:dim + 1])
+    sb = torch.cos(a[..., dim:dim + 1]) * torch.sin(b[..., dim:dim + 1])
+    return (torch.cat([a[..., :dim], sa, a[..., dim + 1:]], dim=-1),
+            torch.cat([b[..., :dim], sb, b[..., dim + 1:]], dim=-1))
+
+
+def rpn_kl_box_loss(box_preds, box_std_preds, box_reg_targets, box_cls_labels, label_uncertainty, loc_weight=2.0,
+                    code_weights=(1.0,) * 7, beta=1.0 / 9.0):
+    """AnchorHeadKLLabel.get_box_reg_layer_loss without its direction term (anchor_head_kl_label.py:128-228): the
+    KL divergence between the predicted Gaussian (mean box_preds, log-variance box_std_preds) and the label
+    distribution (variance = the CVAE's label uncertainty the target assigner attached to every positive anchor),
+        exp(-s) * smoothL1 + exp(log var_label - s) * w - 0.5 (log var_label - s) * w,   w = [positive] / #positives,
+    summed over anchors, divided by the batch size.  box_* (B, H, W, A_loc * 7) or (B, A, 7); label_uncertainty
+    (B, A, 7).  -> (loss, parts).  The log-variance is clamped at -50 in place upstream (a detached floor here)."""
+    b = box_preds.shape[0]
+    box_preds = box_preds.reshape(b, -1, 7)
+    std = box_std_preds.reshape(b, -1, 7)
+    std = torch.where(std < -50, torch.full_like(std, -50.0).detach(), std)
+    positives = box_cls_labels > 0
+    w = positives.float()
+    w = w / torch.clamp(positives.sum(1, keepdim=True).float(), min=1.0)
+    label_var_log = torch.log(label_uncertainty.reshape(b, -1, 7) + 1e-10)
+    p_sin, t_sin = _sin_difference(box_preds, box_reg_targets.reshape(b, -1, 7))
+    t_sin = torch.where(torch.isnan(t_sin), p_sin, t_sin)
+    cw = _code_weights_t(tuple(code_weights), box_preds.device)
+    n = torch.abs((p_sin - t_sin) * cw)
+    l1 = torch.where(n < beta, 0.5 * n ** 2 / beta, n - 0.5 * beta) * w.unsqueeze(-1)
+    src = (torch.exp(-std) * l1).sum() / b
+    square = (torch.exp(label_var_log - std) * w.unsqueeze(-1)).sum() / b
+    log = (-0.5 * (label_var_log - std) * w.unsqueeze(-1)).sum() / b
+    loss = (src + square + log) * loc_weight
+    return loss, {"rpn_loss_loc": loss.detach(), "rpn_loss_loc_src": (src * loc_weight).detach(),
+                  "rpn_loss_loc_square": (square * loc_weight).detach(), "rpn_loss_loc_log": (log * loc_weight).detach()}
+
+
+_CW_T = {}
+
+
+def _code_weights_t(values, device):
+    key = (values, str(device))
+    if key not in _CW_T:
+        _CW_T[key] = torch.tensor(values, dtype=torch.float32, device=device)
+    return _CW_T[key]
+
+
+def decode_residual(box_encodings, anchors):
+    """ResidualCoder.decode_torch (box_coder_utils.py:46-71), 7 code channels."""
+    xa, ya, za, dxa, dya, dza, ra = torch.split(anchors, 1, dim=-1)
+    xt, yt, zt, dxt, dyt, dzt, rt = torch.split(box_encodings, 1, dim=-1)
+    diagonal = torch.sqrt(dxa ** 2 + dya ** 2)
+    return torch.cat([xt * diagonal + xa, yt * diagonal + ya, zt * dza + za, torch.exp(dxt) * dxa, torch.exp(dyt) * dya,
+                      torch.exp(dzt) * dza, rt + ra], dim=-1)
+
+
+def rpn_iou_loss(iou_preds, box_preds, box_reg_targets, box_cls_labels, anchors, aligned_iou3d=None, beta=1.0 / 9.0):
+    """AnchorHeadKLLabelIoU.get_box_iou_layer_loss (anchor_head_kl_label.py:392-434): on the positive anchors, the
+    predicted IoU (one logit per anchor) regressed with smooth-L1 towards 2 * IoU3D(decoded prediction, decoded
+    target) - 1 (the aligned rotated IoU of pcdet.ops.iou3d, detached), weighted by 1 / #positives of the frame,
+    summed and divided by the batch size.  aligned_iou3d(a, b) -> (n, 1): defaults to the device kernel."""
+    if aligned_iou3d is None:
+        from .pcdet_ops.iou3d.iou3d_utils import boxes_aligned_iou3d_gpu as aligned_iou3d
+    b = iou_preds.shape[0]
+    positives = box_cls_labels > 0
+    w = positives.float()
+    w = w / torch.clamp(positives.sum(1, keepdim=True).float(), min=1.0)
+    mask = w > 0
+    a = anchors.reshape(1, -1, 7).expand(b, -1, -1)
+    pred_boxes = decode_residual(box_preds.reshape(b, -1, 7), a)
+    gt_boxes = decode_residual(box_reg_targets.reshape(b, -1, 7), a)
+    target = aligned_iou3d(pred_boxes[mask].detach().contiguous(), gt_boxes[mask].detach().contiguous()).detach()
+    target = 2 * target - 1
+    diff = torch.abs(iou_preds.reshape(b, -1, 1).float()[mask] - target)
+    l1 = torch.where(diff < beta, 0.5 * diff ** 2 / beta, diff - 0.5 * beta) * w[mask].unsqueeze(-1)
+    loss = l1.sum() / b
+    return loss, {"rpn_loss_iou": loss.detach()}

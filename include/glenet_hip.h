@@ -490,6 +490,16 @@ int glx_assign_targets(const float* anchors, int N, const float* gt_boxes, int B
  * Replaces: AnchorHeadTemplate.get_cls_layer_loss / get_box_reg_layer_loss / get_loss
  * (pcdet/models/dense_heads/anchor_head_template.py:108-232) with SigmoidFocalClassificationLoss,
  * WeightedSmoothL1Loss and WeightedCrossEntropyLoss (pcdet/utils/loss_utils.py:7-207). */
+/* Same with uncertainty_gt_index (B, N) int32 (or NULL): for every positive anchor the row of the frame's ground truth
+ * whose label uncertainty it carries -- WeightedAxisAlignedTargetAssigner (GLENet-S / -C,
+ * weighted_axis_aligned_target_assigner.py:145-173): the ground truth that forced the match, overwritten by the
+ * arg-max ground truth when the overlap is over the matched threshold; -1 for the other anchors. */
+int glx_assign_targets_ex(const float* anchors, int N, const float* gt_boxes, int B, int M, int gt_cols,
+                          int class_id, float matched_threshold, float unmatched_threshold,
+                          int norm_by_num_examples, int32_t* box_cls_labels, float* box_reg_targets,
+                          float* reg_weights, int32_t* uncertainty_gt_index, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 size_t glx_rpn_loss_workspace_bytes(int B, int A);
 int glx_rpn_loss(const float* cls_preds, const float* box_preds, const float* dir_preds,
                  const int32_t* box_cls_labels, const float* box_reg_targets, const float* anchors,

@@ -19,6 +19,8 @@ committed, this script is committed, nothing of the reference is copied.
                          suppression strictness, output ordering) given the oracle's IoU matrix;
                          the IoU arithmetic itself is pinned by iou3d_ref.npz (shared helpers).
   limit_period / boxes3d_to_bev_torch outputs of the reference are stored alongside.
+  kl_label_head_ref.npz  GLENet-S / -C dense head: weighted target assignment, KL box regression and IoU-prediction
+                     losses with gradients (make_kl_label_head_ref(), run as `make_golden.py klhead`).
   cvae_train_ref.npz the training branch of the CVAE Generator with its loss terms and gradients
                      (make_cvae_train_ref(), run as `make_golden.py cvaetrain`).
   nms_pred_ref.npz   the IoU that decides nms_gpu pinned to the reference's compiled iou3d_cpu.cpp through a
@@ -210,6 +212,92 @@ def make_cvae_train_ref():
             out["after/" + k] = v.numpy()
     np.savez_compressed(os.path.join(HERE, "cvae_train_ref.npz"), **out)
     print("cvae_train_ref.npz", float(reg), float(lat), float(regular), tb, "placeholders:", placeholders)
+
+
+def make_kl_label_head_ref():
+    """kl_label_head_ref.npz: the dense head of the single-stage GLENet models (GLENet-C: AnchorHeadKLLabelIoU with
+    the WeightedAxisAlignedTargetAssigner; pcdet/models/dense_heads/anchor_head_kl_label.py,
+    target_assigner/weighted_axis_aligned_target_assigner.py) built by the reference from tools/cfgs/kitti_models/
+    GLENet_C.yaml on a reduced grid (44 x 40 locations x 2 rotations = 3520 anchors) and run UNMODIFIED on CPU:
+    assign_targets(gt_boxes, gt_uncertaintys), get_box_reg_layer_loss(), get_box_iou_layer_loss(), autograd gradients
+    of their sum w.r.t. the four prediction maps.  Own process (`make_golden.py klhead`).  Disclosed stand-ins:
+    third-party placeholders and the `.cuda()` no-op of tools/ref_dropin_check.py; `boxes_aligned_iou3d_gpu` (the CUDA
+    extension) -> the same wrapper statements (iou3d_utils.py:332-387: the reference's own boxes3d_to_bev_torch,
+    height overlap, clamp 1e-7) around the oracle's aligned BEV overlap, which tests/golden/iou3d_ref.npz pins to the
+    reference's compiled iou3d_cpu.cpp."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ref_dropin_check as rdc
+    rdc.prepare_imports()
+    from pcdet.config import cfg_from_yaml_file
+    cwd = os.getcwd()
+    os.chdir(os.path.join(REF, "tools"))
+    try:
+        cfg = cfg_from_yaml_file("cfgs/kitti_models/GLENet_C.yaml", rdc.EasyDict())
+    finally:
+        os.chdir(cwd)
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import pcdet.models.dense_heads.anchor_head_kl_label as mod
+    from pcdet.ops.iou3d.iou3d_utils import boxes3d_to_bev_torch
+
+    def aligned_iou3d_cpu(a, b, box_mode="wlh", rect=False, need_bev=False):
+        a_bev = boxes3d_to_bev_torch(a.detach(), box_mode, rect).numpy()
+        b_bev = boxes3d_to_bev_torch(b.detach(), box_mode, rect).numpy()
+        ov = torch.from_numpy(oracle.iou3d_boxes_aligned_overlap_bev(a_bev, b_bev)).view(-1, 1)
+        hmin = torch.max(a[:, 2] - a[:, 5] / 2, b[:, 2] - b[:, 5] / 2).view(-1, 1)
+        hmax = torch.min(a[:, 2] + a[:, 5] / 2, b[:, 2] + b[:, 5] / 2).view(-1, 1)
+        o3 = ov * torch.clamp(hmax - hmin, min=0)
+        va, vb = (a[:, 3] * a[:, 4] * a[:, 5]).view(-1, 1), (b[:, 3] * b[:, 4] * b[:, 5]).view(-1, 1)
+        return o3 / torch.clamp(va + vb - o3, min=1e-7)
+    mod.boxes_aligned_iou3d_gpu = aligned_iou3d_cpu
+    pcr = np.array([0, -8.0, -3, 17.6, 8.0, 1], np.float32)
+    head = mod.AnchorHeadKLLabelIoU(model_cfg=cfg.MODEL.DENSE_HEAD, input_channels=16, num_class=1, class_names=["Car"],
+                                    grid_size=np.array([352, 320, 40]), point_cloud_range=pcr,
+                                    predict_boxes_when_training=False)
+    gen = torch.Generator().manual_seed(99)
+    B, H, W = 3, 40, 44
+    rng = np.random.default_rng(5)
+    gt = np.zeros((B, 6, 8), np.float32)
+    unc = np.zeros((B, 6, 7), np.float32)
+    for bi, k in enumerate((4, 0, 2)):                     # a frame without ground truth too
+        gt[bi, :k, 0] = rng.uniform(2, 15, k); gt[bi, :k, 1] = rng.uniform(-6, 6, k); gt[bi, :k, 2] = rng.uniform(-1.2, -0.6, k)
+        gt[bi, :k, 3:6] = np.array([3.9, 1.6, 1.56]) * rng.uniform(0.85, 1.15, (k, 3))
+        gt[bi, :k, 6] = rng.uniform(-np.pi, np.pi, k); gt[bi, :k, 7] = 1
+        unc[bi, :k] = rng.uniform(0.01, 0.2, (k, 7))
+    maps = {"cls_preds": torch.randn(B, H, W, 2, generator=gen) * 0.5, "box_preds": torch.randn(B, H, W, 14, generator=gen) * 0.2,
+            "box_std_preds": torch.randn(B, H, W, 14, generator=gen) * 0.5 - 1.0, "iou_preds": torch.randn(B, H, W, 2, generator=gen) * 0.3,
+            "dir_cls_preds": torch.randn(B, H, W, 4, generator=gen) * 0.5}
+    maps["box_std_preds"][0, 0, 0, :3] = -60.0            # exercises the clamp at -50
+    for v in maps.values():
+        v.requires_grad_(True)
+    # the head edits box_std_preds in place (it is a conv output there): hand it non-leaf copies, read the leaves' gradients
+    head.forward_ret_dict = {k: v * 1.0 for k, v in maps.items()}
+    tgt = head.assign_targets(gt_boxes=torch.from_numpy(gt), gt_uncertaintys=torch.from_numpy(unc))
+    head.forward_ret_dict.update(tgt)
+    box_loss, tb_box = head.get_box_reg_layer_loss()
+    iou_loss, tb_iou = head.get_box_iou_layer_loss()
+    (box_loss + iou_loss).backward()
+    torch.Tensor.cuda = real_cuda
+    anchors = torch.cat(head.anchors, dim=-3) if isinstance(head.anchors, list) else head.anchors
+    out = dict(gt_boxes=gt, gt_uncertaintys=unc, anchors=anchors.reshape(-1, 7).numpy(),
+               anchors_grid=np.array(head.anchors[0].shape), box_cls_labels=tgt["box_cls_labels"].numpy(),
+               box_reg_targets=tgt["box_reg_targets"].numpy(), reg_weights=tgt["reg_weights"].numpy(),
+               box_loss=box_loss.detach().numpy(), iou_loss=iou_loss.detach().numpy(),
+               matched_threshold=np.float32(cfg.MODEL.DENSE_HEAD.ANCHOR_GENERATOR_CONFIG[0]["matched_threshold"]),
+               unmatched_threshold=np.float32(cfg.MODEL.DENSE_HEAD.ANCHOR_GENERATOR_CONFIG[0]["unmatched_threshold"]),
+               loc_weight=np.float32(cfg.MODEL.DENSE_HEAD.LOSS_CONFIG.LOSS_WEIGHTS["loc_weight"]),
+               dir_weight=np.float32(cfg.MODEL.DENSE_HEAD.LOSS_CONFIG.LOSS_WEIGHTS["dir_weight"]),
+               code_weights=np.array(cfg.MODEL.DENSE_HEAD.LOSS_CONFIG.LOSS_WEIGHTS["code_weights"], np.float32),
+               dir_offset=np.float32(cfg.MODEL.DENSE_HEAD.DIR_OFFSET))
+    for k, v in maps.items():
+        out["in/" + k] = v.detach().numpy()
+        if v.grad is not None:
+            out["grad/" + k] = v.grad.numpy()
+    for k, v in {**tb_box, **tb_iou}.items():
+        out["tb/" + k] = np.float32(v)
+    np.savez_compressed(os.path.join(HERE, "kl_label_head_ref.npz"), **out)
+    print("kl_label_head_ref.npz", float(box_loss), float(iou_loss), {k: round(float(v), 5) for k, v in {**tb_box, **tb_iou}.items()},
+          "positives per frame", (tgt["box_cls_labels"] > 0).sum(1).tolist())
 
 
 def import_reference_nms_utils():
@@ -833,6 +921,8 @@ if __name__ == "__main__":
     only = sys.argv[1:] or ["iou3d", "nms", "dense", "glue", "kl", "assign", "roitgt", "nmspred"]
     if "nmspred" in only:
         make_nms_predicate_ref()
+    if "klhead" in sys.argv[1:]:             # own process as well
+        make_kl_label_head_ref()
     if "cvaetrain" in sys.argv[1:]:          # own process only: it installs the drop-in and imports all of pcdet
         make_cvae_train_ref()
     if "roitgt" in only:
