@@ -371,6 +371,11 @@ def main():
     ap.add_argument("--no-config1", action="store_true", help="skip the configs[1] forward-only sub-measurement")
     ap.add_argument("--no-stages", action="store_true", help="skip the per-stage timing pass")
     ap.add_argument("--fwd-steps", type=int, default=200)
+    ap.add_argument("--device-data-step", action="store_true",
+                    help="put the capturable device data step (range mask + per-frame shuffle, SURVEY 8f rank 1: "
+                         "glx_mask_shuffle) in front of the voxelizer INSIDE the recorded step; it shows up as its own "
+                         "stages_ms entry.  Off by default: the reference does this work in DataLoader workers, outside "
+                         "the step the metric times")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the configs[3] (CVAE), configs[4] (Waymo shard) and BEV-head sub-measurements")
     ap.add_argument("--roofline-only", action="store_true",
@@ -451,6 +456,9 @@ def main():
         for k, v in pipe.calibrate(b[0], b[1]).items():
             caps[k] = max(caps.get(k, 0), v)
     pipe.capacities = caps
+    if args.device_data_step:
+        from glenet_amd.data_pipeline import DeviceDataProcessor
+        pipe.data_step = DeviceDataProcessor(K, training=True, shuffle=True, seed=1000 + rank)
     if world > 1:        # data-parallel: one all-reduce on the flat gradient buffer between backward and update
         pipe.data_parallel()
     pipe.load(*pool[0][:4])
@@ -611,6 +619,7 @@ def main():
                                parallelism="dp%d: frames shard; one flat RCCL all-reduce of %.1f MB gradients per step"
                                            % (world, n_params * 4 / 1e6) if world > 1 else "dp1 (single GPU, no collective)",
                                ranks_seen_by_collective=ranks_seen,
+                               device_data_step=bool(args.device_data_step),
                                host_enqueue_ms_per_step=round(t_host * 1e3, 4) if t_host is not None else None,
                                host_loop_ms_per_step=round(t_enq / max(args.steps, 1) * 1e3, 4),
                                host_note="host_enqueue = set_lr (2 fills) + load (1 launch) + graph replay(s) measured on 3 "
