@@ -1,0 +1,86 @@
+"""3x3 / stride-1 / pad-1 convolutions of the BEV backbone on our own kernels (csrc/glx_conv2d.hip).
+
+BaseBEVBackbone's blocks (pcdet/models/backbones_2d/base_bev_backbone.py:30-49) are 47 % of the training step and all
+fp32 3x3 convolutions; the fp32 MFMA of CDNA4 is 1/16 of its bf16 rate, so the kernels here compute the fp32 products as
+six bf16 products of three-way split operands with fp32 accumulation (fp32 accuracy, 6/16 of the matrix time).
+`conv3x3(x, weight)` is `F.conv2d(x, weight, None, 1, 1)` for channels-last maps; its backward runs the same kernel on
+the flipped pack for the input gradient and leaves the weight gradient on the step's weight-gradient stream."""
+import contextlib
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import call, query
+
+
+def supported(x, weight, stride, padding, dilation, groups, bias):
+    """The layers these kernels cover: 3x3, stride 1, zero padding 1, no bias, channel counts that tile."""
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and bias is None
+            and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
+            and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[0] % 64 == 0 and weight.shape[1] % 64 == 0
+            and x.shape[1] == weight.shape[1] and x.is_contiguous(memory_format=torch.channels_last))
+
+
+_packs = {}
+
+
+def packs(weight):
+    """(fwd, bwd) piece images of a (Cout, Cin, 3, 3) weight; rebuilt when the weights epoch or the tensor's version
+    moves (one launch writes both)."""
+    key = (weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()))
+    tag = (_lib.weights_epoch(), weight._version)
+    hit = _packs.get(key)
+    if hit is not None and hit[0] == tag and not torch.cuda.is_current_stream_capturing():
+        return hit[1], hit[2]
+    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    if hit is not None:
+        fwd, bwd = hit[1], hit[2]          # same storage every step: a recorded step rewrites it in place
+    else:
+        n = query("glx_conv3x3_packed_bytes", cin, cout)
+        fwd = torch.empty(n, dtype=torch.uint8, device=weight.device)
+        bwd = torch.empty(n, dtype=torch.uint8, device=weight.device)
+    s = weight.stride()
+    ll = ctypes.c_longlong
+    call("glx_conv3x3_pack", weight.detach(), ll(s[0]), ll(s[1]), ll(s[2]), ll(s[3]), cin, cout, fwd, bwd)
+    _packs[key] = (tag, fwd, bwd)
+    return fwd, bwd
+
+
+def _run(x, pack, cout):
+    b, c, h, w = x.shape
+    y = torch.empty((b, cout, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    call("glx_conv3x3_forward", x, b, h, w, c, pack, cout, y)
+    return y
+
+
+class _Conv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        fwd, bwd = packs(weight)
+        ctx.save_for_backward(x, weight)
+        ctx.bwd_pack = bwd
+        return _run(x.detach(), fwd, int(weight.shape[0]))
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .spconv import core
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        gx = gw = None
+        if ctx.needs_input_grad[1]:
+            side = core.WGRAD_STREAM
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream(x.device))
+                for t in (x, gy, weight):
+                    t.record_stream(side)
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                gw = torch.ops.aten.convolution_backward(gy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                         [False, True, False])[1]
+        if ctx.needs_input_grad[0]:
+            gx = _run(gy, ctx.bwd_pack, int(weight.shape[1]))
+        return gx, gw
+
+
+def conv3x3(x, weight):
+    return _Conv3x3.apply(x, weight)

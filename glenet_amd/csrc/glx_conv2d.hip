@@ -1,0 +1,238 @@
+// glx_conv2d.hip -- the 3x3 / stride 1 / pad 1 convolutions of the BEV backbone (SURVEY 8a row a21;
+// pcdet/models/backbones_2d/base_bev_backbone.py:30-49) on channels-last fp32 maps.
+//
+// CDNA4 has no reduced-precision fp32 matrix mode and its fp32 MFMA (v_mfma_f32_16x16x4_f32, 256 flop / cycle / CU)
+// runs at 1/16 of the bf16 rate (v_mfma_f32_16x16x32_bf16, 4096 flop / cycle / CU).  These kernels therefore compute
+// the fp32 products ON THE BF16 PIPE, exactly enough: an fp32 value is the sum of three bf16 pieces
+//     x = x1 + x2 + x3,  x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)      (8 + 8 + 8 significand bits),
+// a product x * w is the sum of nine piece products, and the six with i + j <= 4 carry everything above 2^-23 |x w|
+// (the dropped three are below one fp32 rounding of the product).  Six bf16 MFMAs with fp32 accumulation replace eight
+// fp32 MFMAs of the same tile at a quarter of their cycles each: 6 / 16 of the matrix time at fp32 accuracy (piece
+// products are exact in fp32; the accumulation is the fp32 accumulation of the matrix pipe, as in the fp32 form).
+//
+// Implicit GEMM, output stationary: a block of 4 waves owns an 8 x 16 pixel tile x 64 output channels; wave w the tile
+// rows 2w, 2w+1 (two 16-pixel operand tiles) x four 16-channel tiles = 8 accumulators.  K runs over (32-channel chunk
+// of Cin) x (9 taps).  Per chunk the 10 x 18 halo of the tile is loaded once (fp32, coalesced 128-byte pieces), split
+// into its three bf16 planes in registers and kept in LDS (80-byte pixel rows: the 16-lane ds_read_b128 of an operand
+// covers all 64 banks); a tap is then only a shifted read of that image.  The weights are pre-split per step by
+// k_conv3x3_pack into [tap][chunk][plane][Cout][32] bf16, so that a block's 64 x 32 slice of a plane is 4 KB
+// contiguous; slices go L2 -> registers -> LDS one tap ahead (two buffers, one barrier per tap).  The input gradient
+// is the same kernel on the flipped, transposed pack (written by the same pack launch).
+#include "glx_common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define CV_TH 8
+#define CV_TW 16
+#define CV_HW (CV_TW + 2)
+#define CV_HP ((CV_TH + 2) * CV_HW)      // 180 halo pixels
+#define CV_ROW 80                        // bytes per LDS row of a plane: 32 bf16 + 16 (bank spread)
+#define CV_APLANE (CV_HP * CV_ROW)       // 14 400
+#define CV_BN 64                         // output channels per block
+#define CV_WPLANE (CV_BN * CV_ROW)       // 5 120
+#define CV_WBUF (3 * CV_WPLANE)          // 15 360
+#define CV_LDS (3 * CV_APLANE + 2 * CV_WBUF)   // 73 920: two blocks per CU
+#define CV_ALOADS ((CV_HP * 8 + 255) / 256)    // 16-byte pieces of the halo per thread (6)
+
+__device__ __forceinline__ void cv_split(float x, __bf16& a, __bf16& b, __bf16& c) {
+  a = (__bf16)x;
+  float r = x - (float)a;
+  b = (__bf16)r;
+  r = r - (float)b;
+  c = (__bf16)r;
+}
+
+// W (Cout, Cin, 3, 3) with element strides (s_co, s_ci, s_kh, s_kw) ->
+//   fwd [tap][Cin/32][3][Cout][32]   (the conv itself)
+//   bwd [tap'][Cout/32][3][Cin][32]  (its input gradient: a conv Cout -> Cin with W'[ci][co][kh'][kw'] = W[co][ci][2-kh'][2-kw'])
+__global__ void k_conv3x3_pack(const float* __restrict__ W, long long s_co, long long s_ci, long long s_kh,
+                               long long s_kw, int Cin, int Cout, uint16_t* __restrict__ fwd,
+                               uint16_t* __restrict__ bwd) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= Cout * Cin * 9) return;
+  const int ci = e % Cin, co = (e / Cin) % Cout, tap = e / (Cin * Cout);
+  const int kh = tap / 3, kw = tap % 3;
+  const float w = W[co * s_co + ci * s_ci + kh * s_kh + kw * s_kw];
+  __bf16 p[3];
+  cv_split(w, p[0], p[1], p[2]);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const uint16_t bits = __builtin_bit_cast(uint16_t, p[q]);
+    if (fwd) fwd[((((size_t)tap * (Cin / 32) + ci / 32) * 3 + q) * Cout + co) * 32 + (ci & 31)] = bits;
+    if (bwd) bwd[((((size_t)(8 - tap) * (Cout / 32) + co / 32) * 3 + q) * Cin + ci) * 32 + (co & 31)] = bits;
+  }
+}
+
+struct ConvArgs {
+  const float* x;        // (B, H, W, Cin)
+  const uint16_t* wp;    // packed pieces
+  float* y;              // (B, H, W, Cout)
+  int B, H, W, Cin, Cout, tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;
+  char* sW = smem + 3 * CV_APLANE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const int tile = blockIdx.x;
+  const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
+  const int x0 = tx * CV_TW, y0 = ty * CV_TH, n0 = blockIdx.y * CV_BN;
+  const int nch = a.Cin >> 5;
+
+  // the thread's pieces of the halo: element offsets into x (without the chunk), -1 outside the map
+  long long aoff[CV_ALOADS];
+  int adst[CV_ALOADS];
+#pragma unroll
+  for (int i = 0; i < CV_ALOADS; ++i) {
+    const int e = tid + i * 256;
+    const int hp = e >> 3, seg = e & 7;
+    const int gy = y0 - 1 + hp / CV_HW, gx = x0 - 1 + hp % CV_HW;
+    const bool ok = e < CV_HP * 8 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    aoff[i] = ok ? (((long long)b * a.H + gy) * a.W + gx) * a.Cin + seg * 4 : -1;
+    adst[i] = e < CV_HP * 8 ? hp * CV_ROW + seg * 8 : -1;
+  }
+  // the thread's 16-byte piece of each plane of a weight slice
+  const size_t wslice = (size_t)a.Cout * 32;                       // bf16 elements per plane of a (tap, chunk)
+  const uint16_t* wsrc = a.wp + (size_t)n0 * 32 + tid * 8;
+  const int wdst = (tid >> 2) * CV_ROW + (tid & 3) * 16;
+
+  f32x4 areg[CV_ALOADS];
+  uint4 wreg0, wreg1, wreg2;
+#define CV_LOAD_A(CH)                                                                                   \
+  _Pragma("unroll") for (int i_ = 0; i_ < CV_ALOADS; ++i_)                                              \
+    areg[i_] = aoff[i_] >= 0 ? *reinterpret_cast<const f32x4*>(a.x + aoff[i_] + (CH) * 32) : f32x4{0.f, 0.f, 0.f, 0.f};
+#define CV_LOAD_W(TAP, CH)                                                                              \
+  {                                                                                                     \
+    const uint16_t* s_ = wsrc + ((size_t)(TAP) * nch + (CH)) * 3 * wslice;                              \
+    wreg0 = *reinterpret_cast<const uint4*>(s_);                                                        \
+    wreg1 = *reinterpret_cast<const uint4*>(s_ + wslice);                                               \
+    wreg2 = *reinterpret_cast<const uint4*>(s_ + 2 * wslice);                                           \
+  }
+#define CV_STORE_W(BUF)                                                                                 \
+  {                                                                                                     \
+    char* d_ = sW + (BUF) * CV_WBUF + wdst;                                                             \
+    *reinterpret_cast<uint4*>(d_) = wreg0;                                                              \
+    *reinterpret_cast<uint4*>(d_ + CV_WPLANE) = wreg1;                                                  \
+    *reinterpret_cast<uint4*>(d_ + 2 * CV_WPLANE) = wreg2;                                              \
+  }
+#define CV_STORE_A()                                                                                    \
+  _Pragma("unroll") for (int i_ = 0; i_ < CV_ALOADS; ++i_) {                                            \
+    if (adst[i_] >= 0) {                                                                                \
+      bf16x4 p0_, p1_, p2_;                                                                             \
+      _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                \
+        __bf16 u_, v_, w_;                                                                              \
+        cv_split(areg[i_][j_], u_, v_, w_);                                                             \
+        p0_[j_] = u_; p1_[j_] = v_; p2_[j_] = w_;                                                       \
+      }                                                                                                 \
+      *reinterpret_cast<bf16x4*>(sA + adst[i_]) = p0_;                                                  \
+      *reinterpret_cast<bf16x4*>(sA + CV_APLANE + adst[i_]) = p1_;                                      \
+      *reinterpret_cast<bf16x4*>(sA + 2 * CV_APLANE + adst[i_]) = p2_;                                  \
+    }                                                                                                   \
+  }
+
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  CV_LOAD_A(0);
+  CV_LOAD_W(0, 0);
+  const char* aBase = sA + kq * 16;
+  const char* wBase = sW + r * CV_ROW + kq * 16;
+  for (int ch = 0; ch < nch; ++ch) {
+    // the barrier that ended the previous chunk's last tap freed the halo image and weight buffer 0
+    CV_STORE_A();
+    CV_STORE_W(0);
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int cur = tap & 1;
+      if (tap < 8) {
+        CV_LOAD_W(tap + 1, ch);
+      } else if (ch + 1 < nch) {
+        CV_LOAD_W(0, ch + 1);
+      }
+      if (tap == 6 && ch + 1 < nch) { CV_LOAD_A(ch + 1); }
+      const int dy = tap / 3, dx = tap % 3;
+      bf16x8 xa[2][3], wa[4][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int hp = (2 * wave + i + dy) * CV_HW + r + dx;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) xa[i][q] = *reinterpret_cast<const bf16x8*>(aBase + q * CV_APLANE + hp * CV_ROW);
+      }
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          wa[n][q] = *reinterpret_cast<const bf16x8*>(wBase + cur * CV_WBUF + q * CV_WPLANE + n * 16 * CV_ROW);
+      // smallest terms first; rows of the product = output channels (a lane ends up with 4 consecutive channels)
+#define CV_TERM(QW, QX)                                                                     \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                             \
+    _Pragma("unroll") for (int n = 0; n < 4; ++n)                                           \
+      acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[n][QW], xa[i][QX], acc[i][n], 0, 0, 0);
+      CV_TERM(2, 0)
+      CV_TERM(0, 2)
+      CV_TERM(1, 1)
+      CV_TERM(1, 0)
+      CV_TERM(0, 1)
+      CV_TERM(0, 0)
+      if (tap < 8) { CV_STORE_W(cur ^ 1); }
+      __syncthreads();
+    }
+  }
+#undef CV_TERM
+
+  // ---- epilogue: lane (r, kq) of accumulator (i, n) = pixel (row 2*wave + i, column r), channels n0 + 16 n + 4 kq ..
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int py = y0 + 2 * wave + i, px = x0 + r;
+    if (py < a.H && px < a.W) {
+      float* dst = a.y + (((long long)b * a.H + py) * a.W + px) * a.Cout + n0 + 4 * kq;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(dst + 16 * n) = acc[i][n];
+    }
+  }
+}
+
+extern "C" size_t glx_conv3x3_packed_bytes(int Cin, int Cout) {
+  return glx_align((size_t)9 * 3 * Cin * Cout * sizeof(uint16_t));
+}
+
+extern "C" int glx_conv3x3_pack(const float* W, long long s_co, long long s_ci, long long s_kh, long long s_kw,
+                                int Cin, int Cout, void* fwd, void* bwd, void* stream) {
+  GLX_REQUIRE(Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0,
+              "glx_conv3x3_pack: channels must be multiples of 32 (got %d -> %d)", Cin, Cout);
+  GLX_REQUIRE(fwd == nullptr || Cout % CV_BN == 0, "glx_conv3x3_pack: forward pack needs Cout %% 64 == 0 (got %d)", Cout);
+  GLX_REQUIRE(bwd == nullptr || Cin % CV_BN == 0, "glx_conv3x3_pack: gradient pack needs Cin %% 64 == 0 (got %d)", Cin);
+  const int n = Cin * Cout * 9;
+  hipLaunchKernelGGL(k_conv3x3_pack, dim3(glx_divup(n, 256)), dim3(256), 0, (hipStream_t)stream, W, s_co, s_ci, s_kh,
+                     s_kw, Cin, Cout, (uint16_t*)fwd, (uint16_t*)bwd);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+extern "C" int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin, const void* packed, int Cout,
+                                   float* y, void* stream) {
+  GLX_REQUIRE(B > 0 && H > 0 && W > 0, "glx_conv3x3_forward: empty map (%d, %d, %d)", B, H, W);
+  GLX_REQUIRE(Cin % 32 == 0 && Cout % CV_BN == 0, "glx_conv3x3_forward: needs Cin %% 32 == 0 and Cout %% 64 == 0 (got %d -> %d)",
+              Cin, Cout);
+  GLX_REQUIRE((long long)B * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 40), "glx_conv3x3_forward: map too large");
+  static bool attr_set = false;
+  if (!attr_set) {
+    GLX_HIP(hipFuncSetAttribute((const void*)k_conv3x3, hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS));
+    attr_set = true;
+  }
+  ConvArgs a;
+  a.x = x; a.wp = (const uint16_t*)packed; a.y = y;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.tiles_x = glx_divup(W, CV_TW); a.tiles_y = glx_divup(H, CV_TH);
+  hipLaunchKernelGGL(k_conv3x3, dim3(a.tiles_x * a.tiles_y * B, Cout / CV_BN), dim3(256), CV_LDS, (hipStream_t)stream, a);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

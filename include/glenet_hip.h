@@ -802,6 +802,23 @@ int glx_copy_fill_multi(int n, void* const* dst, const void* const* src, const u
 int glx_topk_max_k(void);
 int glx_topk_desc(const float* scores, int frames, int A, int K, float* top, int64_t* order, void* stream);
 
+/* ---- dense 3x3 convolutions of the BEV backbone (stride 1, zero padding 1, channels-last fp32 maps) ----------------
+ * Replaces, for the 3x3 / stride-1 layers: nn.Conv2d(c, c, 3, padding=1, bias=False) and ZeroPad2d(1) + Conv2d(.., 3)
+ * of BaseBEVBackbone (pcdet/models/backbones_2d/base_bev_backbone.py:30-49), which the reference runs through cuDNN.
+ * fp32 in, fp32 out; the products run on the bf16 matrix pipe with every operand split into three bf16 pieces
+ * (six MFMAs per fp32-equivalent product tile, fp32 accumulation): results agree with an fp32 convolution to
+ * fp32 rounding (csrc/glx_conv2d.hip).
+ * glx_conv3x3_pack: W (Cout, Cin, 3, 3) with ELEMENT strides (s_co, s_ci, s_kh, s_kw) -> `fwd` (the pieces laid out
+ * for the convolution Cin -> Cout; needs Cout % 64 == 0) and / or `bwd` (for its input gradient, the convolution
+ * Cout -> Cin of the output gradient with flipped taps; needs Cin % 64 == 0); either may be NULL; both channel counts
+ * multiples of 32; each glx_conv3x3_packed_bytes(Cin, Cout) bytes.  Once per weight update.
+ * glx_conv3x3_forward: x (B, H, W, Cin) -> y (B, H, W, Cout), `packed` = the pack whose input channels are Cin. */
+size_t glx_conv3x3_packed_bytes(int Cin, int Cout);
+int glx_conv3x3_pack(const float* W, long long s_co, long long s_ci, long long s_kh, long long s_kw, int Cin, int Cout,
+                     void* fwd, void* bwd, void* stream);
+int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin, const void* packed, int Cout, float* y,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif
