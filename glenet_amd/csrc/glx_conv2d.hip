@@ -69,19 +69,37 @@ struct ConvArgs {
   const float* x;        // (B, H, W, Cin)
   const uint16_t* wp;    // packed pieces
   float* y;              // (B, H, W, Cout)
-  int B, H, W, Cin, Cout, tiles_x, tiles_y;
+  int B, H, W, Cin, Cout, tiles_x, tiles_y, nblk, ntiles;   // nblk = Cout / 64; ntiles = B * tiles_y * tiles_x * nblk
 };
 
+struct ConvTile {
+  int b, y0, x0, n0;
+};
+
+__device__ __forceinline__ ConvTile cv_tile(const ConvArgs& a, int t) {
+  ConvTile c;
+  c.n0 = (t % a.nblk) * CV_BN;            // the channel blocks of one pixel tile run side by side (shared halo in L2)
+  t /= a.nblk;
+  c.x0 = (t % a.tiles_x) * CV_TW;
+  t /= a.tiles_x;
+  c.y0 = (t % a.tiles_y) * CV_TH;
+  c.b = t / a.tiles_y;
+  return c;
+}
+
+// Persistent blocks (two per CU): block i takes the tiles i, i + grid, ...; the first halo chunk and weight slice of
+// the NEXT tile are requested during the last taps of the current one, so a tile's only exposed latency is LDS.
+template <int ABL>
 __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;
   char* sW = smem + 3 * CV_APLANE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kq = lane >> 4;
-  const int tile = blockIdx.x;
-  const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
-  const int x0 = tx * CV_TW, y0 = ty * CV_TH, n0 = blockIdx.y * CV_BN;
   const int nch = a.Cin >> 5;
+  int tile = blockIdx.x;
+  if (tile >= a.ntiles) return;
+  ConvTile ct = cv_tile(a, tile);
 
   // the thread's pieces of the halo: element offsets into x (without the chunk), -1 outside the map
   long long aoff[CV_ALOADS];
@@ -89,15 +107,19 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
 #pragma unroll
   for (int i = 0; i < CV_ALOADS; ++i) {
     const int e = tid + i * 256;
-    const int hp = e >> 3, seg = e & 7;
-    const int gy = y0 - 1 + hp / CV_HW, gx = x0 - 1 + hp % CV_HW;
-    const bool ok = e < CV_HP * 8 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    aoff[i] = ok ? (((long long)b * a.H + gy) * a.W + gx) * a.Cin + seg * 4 : -1;
-    adst[i] = e < CV_HP * 8 ? hp * CV_ROW + seg * 8 : -1;
+    adst[i] = e < CV_HP * 8 ? (e >> 3) * CV_ROW + (e & 7) * 8 : -1;
+  }
+#define CV_HALO(T)                                                                                      \
+  _Pragma("unroll") for (int i_ = 0; i_ < CV_ALOADS; ++i_) {                                            \
+    const int e_ = tid + i_ * 256;                                                                      \
+    const int hp_ = e_ >> 3, seg_ = e_ & 7;                                                             \
+    const int gy_ = (T).y0 - 1 + hp_ / CV_HW, gx_ = (T).x0 - 1 + hp_ % CV_HW;                           \
+    const bool ok_ = e_ < CV_HP * 8 && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W;                  \
+    aoff[i_] = ok_ ? (((long long)(T).b * a.H + gy_) * a.W + gx_) * a.Cin + seg_ * 4 : -1;              \
   }
   // the thread's 16-byte piece of each plane of a weight slice
   const size_t wslice = (size_t)a.Cout * 32;                       // bf16 elements per plane of a (tap, chunk)
-  const uint16_t* wsrc = a.wp + (size_t)n0 * 32 + tid * 8;
+  const uint16_t* wsrc = a.wp + (size_t)ct.n0 * 32 + tid * 8;
   const int wdst = (tid >> 2) * CV_ROW + (tid & 3) * 16;
 
   f32x4 areg[CV_ALOADS];
@@ -105,9 +127,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
 #define CV_LOAD_A(CH)                                                                                   \
   _Pragma("unroll") for (int i_ = 0; i_ < CV_ALOADS; ++i_)                                              \
     areg[i_] = aoff[i_] >= 0 ? *reinterpret_cast<const f32x4*>(a.x + aoff[i_] + (CH) * 32) : f32x4{0.f, 0.f, 0.f, 0.f};
-#define CV_LOAD_W(TAP, CH)                                                                              \
+#define CV_LOAD_W(SRC, TAP, CH)                                                                         \
   {                                                                                                     \
-    const uint16_t* s_ = wsrc + ((size_t)(TAP) * nch + (CH)) * 3 * wslice;                              \
+    const uint16_t* s_ = (SRC) + ((size_t)(TAP) * nch + (CH)) * 3 * wslice;                             \
     wreg0 = *reinterpret_cast<const uint4*>(s_);                                                        \
     wreg1 = *reinterpret_cast<const uint4*>(s_ + wslice);                                               \
     wreg2 = *reinterpret_cast<const uint4*>(s_ + 2 * wslice);                                           \
@@ -134,69 +156,105 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
     }                                                                                                   \
   }
 
-  f32x4 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int n = 0; n < 4; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+  CV_HALO(ct);
   CV_LOAD_A(0);
-  CV_LOAD_W(0, 0);
+  CV_LOAD_W(wsrc, 0, 0);
   const char* aBase = sA + kq * 16;
   const char* wBase = sW + r * CV_ROW + kq * 16;
-  for (int ch = 0; ch < nch; ++ch) {
-    // the barrier that ended the previous chunk's last tap freed the halo image and weight buffer 0
-    CV_STORE_A();
-    CV_STORE_W(0);
-    __syncthreads();
+  while (true) {
+    f32x4 acc[2][4];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int cur = tap & 1;
-      if (tap < 8) {
-        CV_LOAD_W(tap + 1, ch);
-      } else if (ch + 1 < nch) {
-        CV_LOAD_W(0, ch + 1);
-      }
-      if (tap == 6 && ch + 1 < nch) { CV_LOAD_A(ch + 1); }
-      const int dy = tap / 3, dx = tap % 3;
-      bf16x8 xa[2][3], wa[4][3];
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int hp = (2 * wave + i + dy) * CV_HW + r + dx;
+      for (int n = 0; n < 4; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int next = tile + gridDim.x;
+    const bool has_next = next < a.ntiles;
+    ConvTile nt = ct;
+    const uint16_t* wnext = wsrc;
+    if (has_next) {
+      nt = cv_tile(a, next);
+      wnext = a.wp + (size_t)nt.n0 * 32 + tid * 8;
+    }
+    for (int ch = 0; ch < nch; ++ch) {
+      // the barrier that ended the previous last tap freed the halo image and weight buffer 0
+      CV_STORE_A();
+      CV_STORE_W(0);
+      __syncthreads();
+      const bool last = ch + 1 == nch;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) xa[i][q] = *reinterpret_cast<const bf16x8*>(aBase + q * CV_APLANE + hp * CV_ROW);
-      }
+      for (int tap = 0; tap < 9; ++tap) {
+        const int cur = tap & 1;
+        if (tap < 8) {
+          CV_LOAD_W(wsrc, tap + 1, ch);
+        } else if (!last) {
+          CV_LOAD_W(wsrc, 0, ch + 1);
+        } else if (has_next) {
+          CV_LOAD_W(wnext, 0, 0);
+        }
+        if (tap == 6) {
+          if (!last) {
+            CV_LOAD_A(ch + 1);
+          } else if (has_next) {
+            CV_HALO(nt);
+            CV_LOAD_A(0);
+          }
+        }
+        const int dy = tap / 3, dx = tap % 3;
+        bf16x8 xa[2][3], wa[4][3];
+        if (ABL & 1) {   // experiment: operands from registers (no LDS reads)
 #pragma unroll
-      for (int n = 0; n < 4; ++n)
+          for (int q = 0; q < 3; ++q) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
-          wa[n][q] = *reinterpret_cast<const bf16x8*>(wBase + cur * CV_WBUF + q * CV_WPLANE + n * 16 * CV_ROW);
-      // smallest terms first; rows of the product = output channels (a lane ends up with 4 consecutive channels)
+            for (int i = 0; i < 2; ++i) xa[i][q] = __builtin_bit_cast(bf16x8, wreg0);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) wa[n][q] = __builtin_bit_cast(bf16x8, wreg1);
+          }
+        } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int hp = (2 * wave + i + dy) * CV_HW + r + dx;
+#pragma unroll
+          for (int q = 0; q < 3; ++q) xa[i][q] = *reinterpret_cast<const bf16x8*>(aBase + q * CV_APLANE + hp * CV_ROW);
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            wa[n][q] = *reinterpret_cast<const bf16x8*>(wBase + cur * CV_WBUF + q * CV_WPLANE + n * 16 * CV_ROW);
+        }
+        // smallest terms first; rows of the product = output channels (a lane ends up with 4 consecutive channels)
 #define CV_TERM(QW, QX)                                                                     \
   _Pragma("unroll") for (int i = 0; i < 2; ++i)                                             \
     _Pragma("unroll") for (int n = 0; n < 4; ++n)                                           \
       acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[n][QW], xa[i][QX], acc[i][n], 0, 0, 0);
-      CV_TERM(2, 0)
-      CV_TERM(0, 2)
-      CV_TERM(1, 1)
-      CV_TERM(1, 0)
-      CV_TERM(0, 1)
-      CV_TERM(0, 0)
-      if (tap < 8) { CV_STORE_W(cur ^ 1); }
-      __syncthreads();
+        if (!(ABL & 2)) {   // experiment 2: one term of six
+          CV_TERM(2, 0)
+          CV_TERM(0, 2)
+          CV_TERM(1, 1)
+          CV_TERM(1, 0)
+          CV_TERM(0, 1)
+        }
+        CV_TERM(0, 0)
+        if (tap < 8) { CV_STORE_W(cur ^ 1); }
+        if (!(ABL & 4)) __syncthreads();   // experiment 4: no barrier
+      }
     }
-  }
 #undef CV_TERM
 
-  // ---- epilogue: lane (r, kq) of accumulator (i, n) = pixel (row 2*wave + i, column r), channels n0 + 16 n + 4 kq ..
+    // ---- epilogue: lane (r, kq) of accumulator (i, n) = pixel (row 2*wave + i, column r), channels n0 + 16 n + 4 kq ..
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int py = y0 + 2 * wave + i, px = x0 + r;
-    if (py < a.H && px < a.W) {
-      float* dst = a.y + (((long long)b * a.H + py) * a.W + px) * a.Cout + n0 + 4 * kq;
+    for (int i = 0; i < 2; ++i) {
+      const int py = ct.y0 + 2 * wave + i, px = ct.x0 + r;
+      if (py < a.H && px < a.W) {
+        float* dst = a.y + (((long long)ct.b * a.H + py) * a.W + px) * a.Cout + ct.n0 + 4 * kq;
 #pragma unroll
-      for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(dst + 16 * n) = acc[i][n];
+        for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(dst + 16 * n) = acc[i][n];
+      }
     }
+    if (!has_next) break;
+    tile = next;
+    ct = nt;
+    wsrc = wnext;
   }
 }
 
@@ -217,22 +275,49 @@ extern "C" int glx_conv3x3_pack(const float* W, long long s_co, long long s_ci, 
   return GLX_OK;
 }
 
+static int g_conv_grid = 0;     // experiments: blocks per launch (0 = two per CU)
+static int g_conv_ablate = 0;   // experiments: timing-only builds of the loop (wrong results), see k_conv3x3
+extern "C" int glx_conv3x3_set_grid(int blocks, int ablate) {
+  g_conv_grid = blocks;
+  g_conv_ablate = ablate;
+  return GLX_OK;
+}
+
 extern "C" int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin, const void* packed, int Cout,
                                    float* y, void* stream) {
   GLX_REQUIRE(B > 0 && H > 0 && W > 0, "glx_conv3x3_forward: empty map (%d, %d, %d)", B, H, W);
   GLX_REQUIRE(Cin % 32 == 0 && Cout % CV_BN == 0, "glx_conv3x3_forward: needs Cin %% 32 == 0 and Cout %% 64 == 0 (got %d -> %d)",
               Cin, Cout);
   GLX_REQUIRE((long long)B * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 40), "glx_conv3x3_forward: map too large");
-  static bool attr_set = false;
-  if (!attr_set) {
-    GLX_HIP(hipFuncSetAttribute((const void*)k_conv3x3, hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS));
-    attr_set = true;
+  void (*kern)(ConvArgs) = k_conv3x3<0>;
+  switch (g_conv_ablate) {
+    case 1: kern = k_conv3x3<1>; break;
+    case 2: kern = k_conv3x3<2>; break;
+    case 4: kern = k_conv3x3<4>; break;
+    case 5: kern = k_conv3x3<5>; break;
+    case 6: kern = k_conv3x3<6>; break;
+    default: break;
+  }
+  static bool attr_set[8] = {};
+  if (!attr_set[g_conv_ablate & 7]) {
+    GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS));
+    attr_set[g_conv_ablate & 7] = true;
   }
   ConvArgs a;
   a.x = x; a.wp = (const uint16_t*)packed; a.y = y;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.tiles_x = glx_divup(W, CV_TW); a.tiles_y = glx_divup(H, CV_TH);
-  hipLaunchKernelGGL(k_conv3x3, dim3(a.tiles_x * a.tiles_y * B, Cout / CV_BN), dim3(256), CV_LDS, (hipStream_t)stream, a);
+  a.nblk = Cout / CV_BN;
+  a.ntiles = a.tiles_x * a.tiles_y * B * a.nblk;
+  static int slots = 0;
+  if (!slots) {
+    int dev = 0, cus = 0;
+    GLX_HIP(hipGetDevice(&dev));
+    GLX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    slots = 2 * (cus > 0 ? cus : 256);
+  }
+  const int grid = g_conv_grid > 0 ? g_conv_grid : (a.ntiles < slots ? a.ntiles : slots);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), CV_LDS, (hipStream_t)stream, a);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

@@ -24,6 +24,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
+from . import conv2d as own_conv
 
 
 class _ConvSplitBackward(torch.autograd.Function):
@@ -66,6 +67,7 @@ class _ConvSplitBackward(torch.autograd.Function):
 
 
 SPLIT_CONV_BACKWARD = os.environ.get("GLX_SPLIT_CONV_BWD", "1") != "0"
+OWN_CONV3X3 = os.environ.get("GLX_OWN_CONV3X3", "1") != "0"     # 3x3 / stride 1 layers on csrc/glx_conv2d.hip
 
 
 def _pair(v):
@@ -80,7 +82,12 @@ def conv2d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1):
     """F.conv2d; in a training step on the device its backward splits over two streams (_ConvSplitBackward).
     Only for LEAF weights: their gradient goes straight to AccumulateGrad (no kernel) and is first read after the
     step has joined the side stream; a derived weight (the anchor head's concatenated filters) hands its gradient to
-    another autograd node, which would run on the main stream without waiting for the side stream."""
+    another autograd node, which would run on the main stream without waiting for the side stream.
+    The 3x3 / stride-1 / pad-1 layers without bias on channels-last maps (every block layer of the BEV backbone but
+    the strided one) run on our own kernels (glenet_amd.conv2d), same rule for the weight gradient's stream."""
+    if OWN_CONV3X3 and (_leaf(w) or not torch.is_grad_enabled()) and own_conv.supported(
+            x, w, _pair(stride), _pair(padding), _pair(dilation), groups, bias):
+        return own_conv.conv3x3(x, w)
     if (SPLIT_CONV_BACKWARD and x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
             and _leaf(w) and _leaf(bias)):
         return _ConvSplitBackward.apply(x, w, bias, _pair(stride), _pair(padding), _pair(dilation), False, (0, 0), groups)
@@ -88,7 +95,10 @@ def conv2d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1):
 
 
 def conv_module(m, x):
-    """nn.Conv2d / nn.ConvTranspose2d forward through the split-backward node when it applies."""
+    """nn.Conv2d / nn.ConvTranspose2d forward through our own kernels or the split-backward node when they apply."""
+    if (isinstance(m, nn.Conv2d) and not isinstance(m.padding, str) and getattr(m, "padding_mode", "zeros") == "zeros"
+            and OWN_CONV3X3 and x.is_cuda):
+        return conv2d(x, m.weight, m.bias, m.stride, m.padding, m.dilation, m.groups)
     if (SPLIT_CONV_BACKWARD and x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or m.weight.requires_grad)
             and getattr(m, "padding_mode", "zeros") == "zeros" and not isinstance(m.padding, str)
             and _leaf(m.weight) and _leaf(m.bias)):

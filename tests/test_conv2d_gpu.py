@@ -1,0 +1,112 @@
+"""glenet_amd.conv2d (csrc/glx_conv2d.hip): the 3x3 / stride-1 / pad-1 convolutions of the BEV backbone
+(pcdet/models/backbones_2d/base_bev_backbone.py:30-49) computed as six bf16 matrix products of three-way split fp32
+operands.  Checked against an fp64 convolution (tolerance: a few fp32 roundings of the largest output, and never more
+than a small multiple of the library's own fp32 error), exactly on integer data, and through autograd."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(1, 64, 64, 8, 16), (2, 64, 128, 19, 37), (1, 128, 64, 25, 88), (3, 256, 64, 9, 17), (1, 64, 256, 33, 16),
+          (2, 128, 128, 100, 88)]
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv3x3_matches_fp64_convolution(dev, shape):
+    from glenet_amd import conv2d as c2
+    b, cin, cout, h, w = shape
+    g = torch.Generator(device=dev).manual_seed(sum(shape))
+    x = _cl(torch.randn(b, cin, h, w, device=dev, generator=g))
+    wt = torch.randn(cout, cin, 3, 3, device=dev, generator=g) / (3 * cin ** 0.5)
+    y = c2.conv3x3(x, wt)
+    assert y.shape == (b, cout, h, w) and y.is_contiguous(memory_format=torch.channels_last)
+    ref = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    lib = F.conv2d(x, wt, None, 1, 1)
+    scale = ref.abs().max()
+    err, err_lib = (y.double() - ref).abs().max() / scale, (lib.double() - ref).abs().max() / scale
+    assert err < 4e-6 and err < 4 * err_lib + 1e-6, (float(err), float(err_lib))
+
+
+def test_conv3x3_is_exact_on_integer_data_with_asymmetric_filters(dev):
+    """Small integers are exact in every bf16 piece and every partial sum: any operand-layout or tap-order mistake
+    shows as a wrong integer.  Filters differ in every (tap, cin, cout), inputs in every pixel and channel."""
+    from glenet_amd import conv2d as c2
+    b, cin, cout, h, w = 2, 64, 128, 13, 21
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = _cl(torch.randint(-8, 9, (b, cin, h, w), device=dev, generator=g).float())
+    wt = torch.randint(-4, 5, (cout, cin, 3, 3), device=dev, generator=g).float()
+    y = c2.conv3x3(x, wt)
+    ref = F.conv2d(x.double().cpu(), wt.double().cpu(), None, 1, 1)
+    assert torch.equal(y.double().cpu(), ref)
+    gy = _cl(torch.randint(-8, 9, (b, cout, h, w), device=dev, generator=g).float())
+    fwd, bwd = c2.packs(wt)
+    gx = c2._run(gy, bwd, cin)
+    gref = F.conv_transpose2d(gy.double().cpu(), wt.double().cpu(), None, 1, 1)
+    assert torch.equal(gx.double().cpu(), gref)
+
+
+def test_split_products_carry_full_fp32_significands(dev):
+    """One tap, one input channel live: every output is a single product x * w of two full-significand fp32 numbers;
+    the six piece products must reproduce it to 2^-22 (the dropped piece products are below 2^-23 of it)."""
+    from glenet_amd import conv2d as c2
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.zeros(1, 64, 8, 16, device=dev)
+    x[:, 5] = torch.rand(1, 8, 16, device=dev, generator=g) + 1.0
+    wt = torch.zeros(64, 64, 3, 3, device=dev)
+    wt[:, 5, 1, 1] = torch.rand(64, device=dev, generator=g) + 1.0
+    y = c2.conv3x3(_cl(x), wt)
+    ref = x[:, 5:6].double() * wt[:, 5, 1, 1].double().view(1, 64, 1, 1)
+    assert ((y.double() - ref).abs() / ref.abs()).max() < 2.0 ** -22
+
+
+def test_conv3x3_gradients_and_pack_refresh(dev):
+    from glenet_amd import _lib, conv2d as c2
+    b, cin, cout, h, w = 2, 64, 64, 24, 40
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = _cl(torch.randn(b, cin, h, w, device=dev, generator=g)).requires_grad_(True)
+    wt = torch.nn.Parameter(_cl(torch.randn(cout, cin, 3, 3, device=dev, generator=g) / 24))     # channels-last filters
+    gy = _cl(torch.randn(b, cout, h, w, device=dev, generator=g))
+    y = c2.conv3x3(x, wt)
+    y.backward(gy)
+    xd, wd = x.detach().double().requires_grad_(True), wt.detach().double().requires_grad_(True)
+    F.conv2d(xd, wd, None, 1, 1).backward(gy.double())
+    assert (x.grad.double() - xd.grad).abs().max() < 4e-6 * xd.grad.abs().max()
+    assert (wt.grad.double() - wd.grad).abs().max() < 2e-5 * wd.grad.abs().max()
+    # an in-place weight update (optimizer step through raw pointers) must reach the packed pieces
+    with torch.no_grad():
+        wt.mul_(-2.0)
+    _lib.bump_weights_epoch()
+    y2 = c2.conv3x3(x.detach(), wt)
+    assert torch.allclose(y2, -2.0 * y.detach(), rtol=1e-5, atol=1e-5 * float(y.abs().max()))
+
+
+def test_bev_backbone_runs_its_block_layers_on_the_own_kernels(dev, monkeypatch):
+    """The training-mode BEV backbone with the own 3x3 kernels against the same module on the library's."""
+    from glenet_amd import dense_path as dp
+    torch.manual_seed(0)
+    m = dp.BEVBackbone(64, layer_nums=(1, 1), num_filters=(64, 128)).to(dev).to(memory_format=torch.channels_last).train()
+    x = _cl(torch.randn(2, 64, 24, 32, device=dev))
+    calls = []
+    real = dp.own_conv.conv3x3
+    monkeypatch.setattr(dp.own_conv, "conv3x3", lambda a, b: (calls.append(tuple(b.shape)), real(a, b))[1])
+    outs = []
+    for own in (True, False):
+        monkeypatch.setattr(dp, "OWN_CONV3X3", own)
+        for p in m.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        y = m({"spatial_features": xi})["spatial_features_2d"]
+        y.square().mean().backward()
+        torch.cuda.synchronize()
+        outs.append((y.detach(), xi.grad, [p.grad.clone() for p in m.parameters()]))
+    assert calls == [(64, 64, 3, 3), (64, 64, 3, 3), (128, 128, 3, 3)]      # the strided 64 -> 128 layer stays on MIOpen
+    (y0, gx0, gp0), (y1, gx1, gp1) = outs
+    assert torch.allclose(y0, y1, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(gx0, gx1, rtol=1e-3, atol=1e-5 * float(gx1.abs().max()) + 1e-9)
+    for a, b_ in zip(gp0, gp1):
+        assert torch.allclose(a, b_, rtol=1e-3, atol=2e-5 * float(b_.abs().max()) + 1e-9)
