@@ -54,6 +54,30 @@ def _run(x, pack, cout):
     return y
 
 
+_wgrad_ws = {}
+
+
+def wgrad(x, gy, weight):
+    """dW of conv3x3 for a weight of `weight`'s shape and strides (a fresh tensor).  The workspace is this function's
+    own (one per device and size): weight gradients of a step run one after another on ONE stream."""
+    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    b, _, h, w = x.shape
+    n = query("glx_conv3x3_wgrad_workspace_bytes", cin, cout)
+    key = (x.device.index, n)
+    ws = _wgrad_ws.get(key)
+    if ws is None:
+        ws = _wgrad_ws[key] = torch.empty(n, dtype=torch.uint8, device=x.device)
+    gw = torch.empty_like(weight)
+    s = gw.stride()
+    ll = ctypes.c_longlong
+    call("glx_conv3x3_wgrad", x, gy, b, h, w, cin, cout, gw, ll(s[0]), ll(s[1]), ll(s[2]), ll(s[3]), ws,
+         _lib.size_arg(n))
+    return gw
+
+
+OWN_WGRAD = True
+
+
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
@@ -75,8 +99,11 @@ class _Conv3x3(torch.autograd.Function):
                 for t in (x, gy, weight):
                     t.record_stream(side)
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-                gw = torch.ops.aten.convolution_backward(gy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
-                                                         [False, True, False])[1]
+                if OWN_WGRAD:
+                    gw = wgrad(x, gy, weight)
+                else:
+                    gw = torch.ops.aten.convolution_backward(gy, x, weight, None, (1, 1), (1, 1), (1, 1), False,
+                                                             (0, 0), 1, [False, True, False])[1]
         if ctx.needs_input_grad[0]:
             gx = _run(gy, ctx.bwd_pack, int(weight.shape[1]))
         return gx, gw

@@ -258,6 +258,236 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[co][ci][dy][dx] = sum over pixels p of gy[p][co] * x[p + (dy-1, dx-1)][ci]: per tap a (Cout x pixels) x (pixels x
+// Cin) product whose K index is the PIXEL, the strided index of a channels-last map.  A block owns a 64-channel block
+// of Cout x a 32-channel block of Cin (all nine taps: 18 accumulator tiles per wave) and walks pixel tiles:
+//   * gy (rows = co, one 16-channel tile per wave) is needed in ONE alignment only: every lane loads its 8 pixels x 4
+//     k-steps straight from global memory (16 lanes = 64 contiguous bytes) one tile ahead, splits them in registers;
+//   * x is needed in nine alignments: its halo is staged as in the forward kernel ([pixel][32 ci] rows, three planes)
+//     and read with ds_read_b64_tr_b16, the transposing LDS read (a 16-lane group reads 4 pixels x 16 channels and
+//     every lane receives ITS channel's 4 pixels).  64-byte pixel rows whose two 32-byte halves swap on odd 8-pixel
+//     column groups make the reads of a 32-lane half (2 x 4 pixels, 8 columns apart) cover all 64 banks once.
+// Every block ends with its partial sums (72 KB) in the workspace; k_conv3x3_wgrad_reduce adds the blocks of a
+// (Cout block, Cin block) quadrant and writes dW through the weight's strides.
+typedef __attribute__((ext_vector_type(4))) short i16x4;
+#define WG_XPLANE (CV_HP * 64)          // 11 520
+#define WG_LDS (3 * WG_XPLANE)          // 34 560
+#define WG_PART (9 * 2 * 4 * 256)       // floats per block partial
+
+struct WgradArgs {
+  const float* x;     // (B, H, W, Cin)
+  const float* gy;    // (B, H, W, Cout)
+  float* ws;          // (blocks, WG_PART)
+  int B, H, W, Cin, Cout, tiles_x, tiles_y, ntiles, nq_ci, nq, P;
+};
+
+__device__ __forceinline__ bf16x8 wg_join(i16x4 lo, i16x4 hi) {
+  typedef __attribute__((ext_vector_type(8))) short i16x8;
+  i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, kq = lane >> 4;
+  // blocks 8j .. 8j+7 land on the eight XCDs: the quadrants of one pixel-tile sequence share an XCD (gy, x in its L2)
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int q = j % a.nq, p = (j / a.nq) * 8 + xcd;
+  const int ib = q % a.nq_ci, cb = q / a.nq_ci;
+
+  int adst[CV_ALOADS];
+#pragma unroll
+  for (int i = 0; i < CV_ALOADS; ++i) {
+    const int e = tid + i * 256;
+    const int hp = e >> 3, seg = e & 7, hx = hp % CV_HW;
+    adst[i] = e < CV_HP * 8 ? hp * 64 + (((seg >> 2) ^ ((hx >> 3) & 1)) << 5) + (seg & 3) * 8 : -1;
+  }
+  f32x4 areg[CV_ALOADS];     // x halo of the next tile
+  float greg[4][8];          // gy of the next tile: k-step s, pixel 8 (kq & 1) + jj of tile row 2 s + (kq >> 1)
+#define WG_LOAD(T)                                                                                        \
+  {                                                                                                       \
+    int t_ = (T);                                                                                         \
+    const int x0_ = (t_ % a.tiles_x) * CV_TW;                                                             \
+    t_ /= a.tiles_x;                                                                                      \
+    const int y0_ = (t_ % a.tiles_y) * CV_TH, b_ = t_ / a.tiles_y;                                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < CV_ALOADS; ++i_) {                                            \
+      const int e_ = tid + i_ * 256;                                                                      \
+      const int hp_ = e_ >> 3, seg_ = e_ & 7;                                                             \
+      const int gy_ = y0_ - 1 + hp_ / CV_HW, gx_ = x0_ - 1 + hp_ % CV_HW;                                 \
+      const bool ok_ = e_ < CV_HP * 8 && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W;                  \
+      areg[i_] = ok_ ? *reinterpret_cast<const f32x4*>(a.x + (((long long)b_ * a.H + gy_) * a.W + gx_) * a.Cin + \
+                                                       ib * 32 + seg_ * 4)                                 \
+                     : f32x4{0.f, 0.f, 0.f, 0.f};                                                         \
+    }                                                                                                     \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                    \
+      const int py_ = y0_ + 2 * s_ + (kq >> 1);                                                           \
+      const float* g_ = a.gy + (((long long)b_ * a.H + py_) * a.W + x0_ + 8 * (kq & 1)) * a.Cout + cb * 64 + \
+                        wave * 16 + c;                                                                    \
+      _Pragma("unroll") for (int jj_ = 0; jj_ < 8; ++jj_)                                                 \
+        greg[s_][jj_] = (py_ < a.H && x0_ + 8 * (kq & 1) + jj_ < a.W) ? g_[(long long)jj_ * a.Cout] : 0.f; \
+    }                                                                                                     \
+  }
+
+  f32x4 acc[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // lane's part of a transposed read: pixel column 8 (kq & 1) + 4 h + qq + dx of the halo, 4 channels at pp
+  const int qq = (lane & 15) >> 2, pp = lane & 3;
+  int rbase[2][3];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int hx = 8 * (kq & 1) + 4 * h + qq + dx;
+      rbase[h][dx] = ((kq >> 1) * CV_HW + hx) * 64 + (((hx >> 3) & 1) << 5) + pp * 8;
+    }
+
+  int tile = p;
+  if (tile < a.ntiles) { WG_LOAD(tile); }
+  while (tile < a.ntiles) {
+    // ---- this tile's gy pieces (registers) and x halo image (LDS)
+    bf16x8 ga[4][3];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        __bf16 u, v, w;
+        cv_split(greg[s][jj], u, v, w);
+        ga[s][0][jj] = u; ga[s][1][jj] = v; ga[s][2][jj] = w;
+      }
+    __syncthreads();          // the previous tile's reads of the image are done
+#pragma unroll
+    for (int i = 0; i < CV_ALOADS; ++i) {
+      if (adst[i] >= 0) {
+        bf16x4 p0, p1, p2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          __bf16 u, v, w;
+          cv_split(areg[i][e], u, v, w);
+          p0[e] = u; p1[e] = v; p2[e] = w;
+        }
+        *reinterpret_cast<bf16x4*>(smem + adst[i]) = p0;
+        *reinterpret_cast<bf16x4*>(smem + WG_XPLANE + adst[i]) = p1;
+        *reinterpret_cast<bf16x4*>(smem + 2 * WG_XPLANE + adst[i]) = p2;
+      }
+    }
+    __syncthreads();
+    const int next = tile + a.P;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s == 3 && next < a.ntiles) { WG_LOAD(next); }     // ga[0..2] are dead: their registers take the loads
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          bf16x8 xb[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            const int off = pl * WG_XPLANE + (2 * s + dy) * CV_HW * 64;
+            typedef i16x4 __attribute__((address_space(3))) * lds_p;
+            i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(smem + off + (rbase[0][dx] ^ (n << 5))));
+            i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(smem + off + (rbase[1][dx] ^ (n << 5))));
+            xb[pl] = wg_join(lo, hi);
+          }
+          f32x4 v = acc[tap][n];
+          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[s][2], xb[0], v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[s][0], xb[2], v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[s][1], xb[1], v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[s][1], xb[0], v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[s][0], xb[1], v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[s][0], xb[0], v, 0, 0, 0);
+          acc[tap][n] = v;
+        }
+      }
+    }
+    tile = next;
+  }
+#undef WG_LOAD
+  // ---- the block's partial sums: element ((tap * 2 + n) * 4 + reg) * 256 + tid
+  float* dst = a.ws + (size_t)(q * a.P + p) * WG_PART + tid;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) dst[((tap * 2 + n) * 4 + rg) * 256] = acc[tap][n][rg];
+}
+
+// 64 partial elements x 4 segments of the quadrant's blocks per 256 threads; dW through the weight's strides
+__global__ __launch_bounds__(256) void k_conv3x3_wgrad_reduce(const float* __restrict__ ws, int P, int nq_ci,
+                                                              float* __restrict__ dW, long long s_co, long long s_ci,
+                                                              long long s_kh, long long s_kw) {
+  __shared__ float part[4][64];
+  const int q = blockIdx.y, el = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
+  const float* src = ws + (size_t)q * P * WG_PART + e;
+  float sum = 0.f;
+  int pb = seg;
+  for (; pb + 28 < P; pb += 32) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(pb + 4 * u) * WG_PART];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += v[u];
+  }
+  for (; pb < P; pb += 4) sum += src[(size_t)pb * WG_PART];
+  part[seg][el] = sum;
+  __syncthreads();
+  if (seg == 0) {
+    sum = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+    const int tap = e >> 11, n = (e >> 10) & 1, rg = (e >> 8) & 3, t = e & 255;
+    const int wave = t >> 6, lane = t & 63;
+    const int ib = q % nq_ci, cb = q / nq_ci;
+    const int co = cb * 64 + wave * 16 + 4 * (lane >> 4) + rg, ci = ib * 32 + n * 16 + (lane & 15);
+    dW[co * s_co + ci * s_ci + (tap / 3) * s_kh + (tap % 3) * s_kw] = sum;
+  }
+}
+
+static int wgrad_blocks(int Cin, int Cout, int* P_out) {
+  const int nq = (Cin / 32) * (Cout / 64);
+  int slots = 512;
+  int P = slots / nq;
+  P = P / 8 * 8;
+  if (P < 8) P = 8;
+  *P_out = P;
+  return nq * P;
+}
+
+extern "C" size_t glx_conv3x3_wgrad_workspace_bytes(int Cin, int Cout) {
+  int P = 0;
+  const int blocks = wgrad_blocks(Cin, Cout, &P);
+  return glx_align((size_t)blocks * WG_PART * sizeof(float));
+}
+
+extern "C" int glx_conv3x3_wgrad(const float* x, const float* gy, int B, int H, int W, int Cin, int Cout, float* dW,
+                                 long long s_co, long long s_ci, long long s_kh, long long s_kw, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(B > 0 && H > 0 && W > 0, "glx_conv3x3_wgrad: empty map (%d, %d, %d)", B, H, W);
+  GLX_REQUIRE(Cin % 32 == 0 && Cout % CV_BN == 0, "glx_conv3x3_wgrad: needs Cin %% 32 == 0 and Cout %% 64 == 0 (got %d -> %d)",
+              Cin, Cout);
+  GLX_REQUIRE(workspace_bytes >= glx_conv3x3_wgrad_workspace_bytes(Cin, Cout), "glx_conv3x3_wgrad: workspace too small");
+  WgradArgs a;
+  a.x = x; a.gy = gy; a.ws = (float*)workspace;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.tiles_x = glx_divup(W, CV_TW); a.tiles_y = glx_divup(H, CV_TH);
+  a.ntiles = a.tiles_x * a.tiles_y * B;
+  a.nq_ci = Cin / 32;
+  a.nq = a.nq_ci * (Cout / CV_BN);
+  const int blocks = wgrad_blocks(Cin, Cout, &a.P);
+  hipLaunchKernelGGL(k_conv3x3_wgrad, dim3(blocks), dim3(256), WG_LDS, (hipStream_t)stream, a);
+  GLX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_conv3x3_wgrad_reduce, dim3(WG_PART / 64, a.nq), dim3(256), 0, (hipStream_t)stream, a.ws, a.P,
+                     a.nq_ci, dW, s_co, s_ci, s_kh, s_kw);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
 extern "C" size_t glx_conv3x3_packed_bytes(int Cin, int Cout) {
   return glx_align((size_t)9 * 3 * Cin * Cout * sizeof(uint16_t));
 }

@@ -818,6 +818,16 @@ int glx_conv3x3_pack(const float* W, long long s_co, long long s_ci, long long s
                      void* fwd, void* bwd, void* stream);
 int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin, const void* packed, int Cout, float* y,
                         void* stream);
+/* The weight gradient of the same convolution: dW (Cout, Cin, 3, 3), written through ELEMENT strides (s_co, s_ci,
+ * s_kh, s_kw) (torch keeps the BEV filters in channels-last memory), = sum over pixels of gy (B, H, W, Cout) times
+ * the shifted x (B, H, W, Cin); same split-bf16 arithmetic.  Two launches (block partial sums into the workspace,
+ * then their sum); dW is overwritten, not accumulated into.  Replaces cuDNN's backward-filter call for these layers. */
+size_t glx_conv3x3_wgrad_workspace_bytes(int Cin, int Cout);
+int glx_conv3x3_wgrad(const float* x, const float* gy, int B, int H, int W, int Cin, int Cout, float* dW,
+                      long long s_co, long long s_ci, long long s_kh, long long s_kw, void* workspace,
+                      size_t workspace_bytes, void* stream);
+/* Experiments only: blocks per launch of glx_conv3x3_forward (0 = two per CU) and timing-only ablations of its loop. */
+int glx_conv3x3_set_grid(int blocks, int ablate);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,14 @@ def one(b, cin, cout, h, w, time=False):
                                                [True, False, False])[0]
     gs = gref.abs().max().item()
     g_own, g_lib = (gx.double() - gref).abs().max().item() / gs, (glib.double() - gref).abs().max().item() / gs
+    gw = c2.wgrad(x, gy, wt)
+    wref = torch.ops.aten.convolution_backward(gy.double(), x.double(), wt.double(), None, (1, 1), (1, 1), (1, 1), False,
+                                               (0, 0), 1, [False, True, False])[1]
+    wlib = torch.ops.aten.convolution_backward(gy, x, wt, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                               [False, True, False])[1]
+    ws_ = wref.abs().max().item()
+    w_own, w_lib = (gw.double() - wref).abs().max().item() / ws_, (wlib.double() - wref).abs().max().item() / ws_
+    print("   wgrad err own %.2e lib %.2e" % (w_own, w_lib), flush=True)
     line = "(%d,%d->%d,%dx%d) fwd err own %.2e lib %.2e | dgrad err own %.2e lib %.2e" % (b, cin, cout, h, w, e_own, e_lib,
                                                                                       g_own, g_lib)
     if time:
@@ -46,10 +54,14 @@ def one(b, cin, cout, h, w, time=False):
         t_gown = t(lambda: c2._run(gy, bwd, cin))
         t_glib = t(lambda: torch.ops.aten.convolution_backward(gy, x, wt, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
                                                                [True, False, False]))
+        t_wown = t(lambda: c2.wgrad(x, gy, wt))
+        t_wlib = t(lambda: torch.ops.aten.convolution_backward(gy, x, wt, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                               [False, True, False]))
+        line += " | wgrad %.1f us lib %.1f us" % (t_wown, t_wlib)
         line += " | fwd %.1f us (%.0f TF) lib %.1f us | dgrad %.1f us lib %.1f us" % (
             t_own, flop / t_own / 1e6, t_lib, t_gown, t_glib)
     print(line, flush=True)
-    assert e_own < 4 * max(e_lib, 1e-7) + 1e-6 and g_own < 4 * max(g_lib, 1e-7) + 1e-6
+    assert e_own < 4 * max(e_lib, 1e-7) + 1e-6 and g_own < 4 * max(g_lib, 1e-7) + 1e-6 and w_own < 4 * max(w_lib, 1e-7) + 2e-6
 
 
 if __name__ == "__main__":
