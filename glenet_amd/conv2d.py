@@ -22,6 +22,11 @@ def supported(x, weight, stride, padding, dilation, groups, bias):
             and x.shape[1] == weight.shape[1] and x.is_contiguous(memory_format=torch.channels_last))
 
 
+def bn_state_available():
+    from .spconv import core
+    return core.USE_BN_STATE
+
+
 _packs = {}
 
 
@@ -47,10 +52,23 @@ def packs(weight):
     return fwd, bwd
 
 
-def _run(x, pack, cout):
+def _run(x, pack, cout, bn=None):
+    """bn: a training-mode BatchNorm2d that follows the conv -- its batch statistics are taken in the kernel's epilogue
+    (glx_conv3x3_next_bn_stats) and the call returns (y, coef, save_mean, save_invstd)."""
     b, c, h, w = x.shape
     y = torch.empty((b, cout, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    stats = None
+    if bn is not None:
+        from .spconv import core
+        stats = tuple(torch.empty(n, dtype=torch.float32, device=x.device) for n in (2 * cout, cout, cout))
+        rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+        _lib.call_nostream("glx_conv3x3_next_bn_stats", core._bn_state(x.device), bn.weight, bn.bias,
+                           ctypes.c_float(bn.eps), ctypes.c_float(bn.momentum), stats[0], stats[1], stats[2], rm, rv)
     call("glx_conv3x3_forward", x, b, h, w, c, pack, cout, y)
+    if bn is not None:
+        if bn.track_running_stats:
+            _lib.bump_weights_epoch()          # running statistics moved behind torch's back
+        return (y,) + stats
     return y
 
 
@@ -80,16 +98,22 @@ OWN_WGRAD = True
 
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, bn=None):
         fwd, bwd = packs(weight)
         ctx.save_for_backward(x, weight)
         ctx.bwd_pack = bwd
-        return _run(x.detach(), fwd, int(weight.shape[0]))
+        out = _run(x.detach(), fwd, int(weight.shape[0]), bn)
+        if bn is not None:
+            ctx.mark_non_differentiable(*out[1:])
+            ctx.set_materialize_grads(False)       # no zero tensors (3 fill launches) for the statistics' "gradients"
+        return out
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, *_):
         from .spconv import core
         x, weight = ctx.saved_tensors
+        if gy is None:
+            return None, None, None
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx = gw = None
         if ctx.needs_input_grad[1]:
@@ -106,8 +130,24 @@ class _Conv3x3(torch.autograd.Function):
                                                              (0, 0), 1, [False, True, False])[1]
         if ctx.needs_input_grad[0]:
             gx = _run(gy, ctx.bwd_pack, int(weight.shape[1]))
-        return gx, gw
+        return gx, gw, None
 
 
 def conv3x3(x, weight):
     return _Conv3x3.apply(x, weight)
+
+
+def conv3x3_bn(x, weight, bn, relu):
+    """relu?(bn(conv3x3(x, weight))) for a training-mode nn.BatchNorm2d: statistics in the conv's epilogue, the
+    transform (and the whole backward of the BatchNorm) on the fused row kernels of csrc/glx_bn.hip."""
+    from .spconv import core
+    y, coef, mean, invstd = _Conv3x3.apply(x, weight, bn)
+    b, c, h, w = y.shape
+    rows = y.permute(0, 2, 3, 1).reshape(b * h * w, c)              # a view of channels-last memory
+    out = core.FusedBNApply.apply(rows, coef, mean, invstd, bn.weight, bn.bias, relu)
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        if core.DEFERRED_COUNTERS is not None:
+            core.DEFERRED_COUNTERS.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked += 1
+    return out.view(b, h, w, c).permute(0, 3, 1, 2)

@@ -19,6 +19,7 @@
 // contiguous; slices go L2 -> registers -> LDS one tap ahead (two buffers, one barrier per tap).  The input gradient
 // is the same kernel on the flipped, transposed pack (written by the same pack launch).
 #include "glx_common.h"
+#include "glx_bn_state.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -70,6 +71,8 @@ struct ConvArgs {
   const uint16_t* wp;    // packed pieces
   float* y;              // (B, H, W, Cout)
   int B, H, W, Cin, Cout, tiles_x, tiles_y, nblk, ntiles;   // nblk = Cout / 64; ntiles = B * tiles_y * tiles_x * nblk
+  BnState* bn_state;     // STATS: training-mode BatchNorm statistics of y taken in the epilogue
+  BnFinalize bn;
 };
 
 struct ConvTile {
@@ -89,7 +92,10 @@ __device__ __forceinline__ ConvTile cv_tile(const ConvArgs& a, int t) {
 
 // Persistent blocks (two per CU): block i takes the tiles i, i + grid, ...; the first halo chunk and weight slice of
 // the NEXT tile are requested during the last taps of the current one, so a tile's only exposed latency is LDS.
-template <int ABL>
+// STATS: per-channel sum and sum of squares of the block's outputs ride along (per lane in fp32 over its <= 6 pixels,
+// in fp64 from there: 16 lanes by shuffles, 4 waves in LDS, one set of accumulator atomics per block, last block
+// finalizes as k_bn_stats does); the launch has a multiple of nblk blocks, so a block keeps its channel block.
+template <int ABL, bool STATS>
 __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;
@@ -155,6 +161,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
       *reinterpret_cast<bf16x4*>(sA + 2 * CV_APLANE + adst[i_]) = p2_;                                  \
     }                                                                                                   \
   }
+
+  float ssum[4][4], ssq[4][4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ssum[n][g] = ssq[n][g] = 0.f;
+  const int stats_n0 = ct.n0;
 
   CV_HALO(ct);
   CV_LOAD_A(0);
@@ -249,12 +262,54 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
         float* dst = a.y + (((long long)ct.b * a.H + py) * a.W + px) * a.Cout + ct.n0 + 4 * kq;
 #pragma unroll
         for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(dst + 16 * n) = acc[i][n];
+        if (STATS) {
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              ssum[n][g] += acc[i][n][g];
+              ssq[n][g] += acc[i][n][g] * acc[i][n][g];
+            }
+        }
       }
     }
     if (!has_next) break;
     tile = next;
     ct = nt;
     wsrc = wnext;
+  }
+  if (STATS) {
+    double* red = reinterpret_cast<double*>(smem);          // [wave][moment][64 channels]
+    __shared__ int s_last;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        double d0 = (double)ssum[n][g], d1 = (double)ssq[n][g];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+          d0 += __shfl_xor(d0, m);
+          d1 += __shfl_xor(d1, m);
+        }
+        if (r == 0) {
+          red[(wave * 2 + 0) * 64 + 16 * n + 4 * kq + g] = d0;
+          red[(wave * 2 + 1) * 64 + 16 * n + 4 * kq + g] = d1;
+        }
+      }
+    __syncthreads();
+    if (tid < 128) {
+      const int ch = tid & 63, mom = tid >> 6;
+      const double v = (red[(0 * 2 + mom) * 64 + ch] + red[(1 * 2 + mom) * 64 + ch]) +
+                       (red[(2 * 2 + mom) * 64 + ch] + red[(3 * 2 + mom) * 64 + ch]);
+      double seen = unsafeAtomicAdd(a.bn_state->acc[blockIdx.x % BN_SETS] + mom * BN_MAXC + stats_n0 + ch, v);
+      asm volatile("" ::"v"(seen) : "memory");                // the atomic has returned: it is done
+    }
+    __syncthreads();
+    if (tid == 0)
+      s_last = __hip_atomic_fetch_add(&a.bn_state->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+               gridDim.x - 1;
+    __syncthreads();
+    if (s_last) bn_finalize_sets<false, 256>(a.bn_state, a.bn, a.Cout, a.B * a.H * a.W, reinterpret_cast<double(*)[2]>(smem));
   }
 }
 
@@ -513,25 +568,47 @@ extern "C" int glx_conv3x3_set_grid(int blocks, int ablate) {
   return GLX_OK;
 }
 
+// Training-mode BatchNorm behind the NEXT glx_conv3x3_forward call of this host thread (same contract as
+// glx_sconv_next_bn_stats).
+static thread_local BnState* g_conv_next_bn_state = nullptr;
+static thread_local BnFinalize g_conv_next_bn = {};
+extern "C" int glx_conv3x3_next_bn_stats(void* state, const float* gamma, const float* beta, float eps, float momentum,
+                                         float* coef, float* save_mean, float* save_invstd, float* running_mean,
+                                         float* running_var) {
+  GLX_REQUIRE(state && coef && save_mean && save_invstd, "glx_conv3x3_next_bn_stats: null pointer");
+  g_conv_next_bn_state = (BnState*)state;
+  g_conv_next_bn = BnFinalize{gamma, beta, eps, momentum, coef, save_mean, save_invstd, running_mean, running_var,
+                              nullptr, nullptr, nullptr};
+  return GLX_OK;
+}
+
 extern "C" int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin, const void* packed, int Cout,
                                    float* y, void* stream) {
   GLX_REQUIRE(B > 0 && H > 0 && W > 0, "glx_conv3x3_forward: empty map (%d, %d, %d)", B, H, W);
   GLX_REQUIRE(Cin % 32 == 0 && Cout % CV_BN == 0, "glx_conv3x3_forward: needs Cin %% 32 == 0 and Cout %% 64 == 0 (got %d -> %d)",
               Cin, Cout);
   GLX_REQUIRE((long long)B * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 40), "glx_conv3x3_forward: map too large");
-  void (*kern)(ConvArgs) = k_conv3x3<0>;
-  switch (g_conv_ablate) {
-    case 1: kern = k_conv3x3<1>; break;
-    case 2: kern = k_conv3x3<2>; break;
-    case 4: kern = k_conv3x3<4>; break;
-    case 5: kern = k_conv3x3<5>; break;
-    case 6: kern = k_conv3x3<6>; break;
-    default: break;
+  BnState* bn_state = g_conv_next_bn_state;      // consumed by THIS call whatever happens below
+  g_conv_next_bn_state = nullptr;
+  GLX_REQUIRE(!bn_state || Cout <= BN_MAXC, "glx_conv3x3_forward: BatchNorm statistics for at most %d channels", BN_MAXC);
+  void (*kern)(ConvArgs) = bn_state ? k_conv3x3<0, true> : k_conv3x3<0, false>;
+  int slot = bn_state ? 7 : 0;
+  if (!bn_state) {
+    switch (g_conv_ablate) {
+      case 1: kern = k_conv3x3<1, false>; break;
+      case 2: kern = k_conv3x3<2, false>; break;
+      case 4: kern = k_conv3x3<4, false>; break;
+      case 5: kern = k_conv3x3<5, false>; break;
+      case 6: kern = k_conv3x3<6, false>; break;
+      default: break;
+    }
+    slot = g_conv_ablate & 7;
+    if (slot == 7) slot = 0;
   }
   static bool attr_set[8] = {};
-  if (!attr_set[g_conv_ablate & 7]) {
+  if (!attr_set[slot]) {
     GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS));
-    attr_set[g_conv_ablate & 7] = true;
+    attr_set[slot] = true;
   }
   ConvArgs a;
   a.x = x; a.wp = (const uint16_t*)packed; a.y = y;
@@ -546,7 +623,10 @@ extern "C" int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin,
     GLX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     slots = 2 * (cus > 0 ? cus : 256);
   }
-  const int grid = g_conv_grid > 0 ? g_conv_grid : (a.ntiles < slots ? a.ntiles : slots);
+  a.bn_state = bn_state;
+  a.bn = g_conv_next_bn;
+  int grid = g_conv_grid > 0 ? g_conv_grid : (a.ntiles < slots ? a.ntiles : slots);
+  if (bn_state) grid = grid / a.nblk * a.nblk;   // every block keeps one channel block (ntiles is a multiple of nblk)
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), CV_LDS, (hipStream_t)stream, a);
   GLX_LAUNCH_CHECK();
   return GLX_OK;

@@ -68,6 +68,7 @@ class _ConvSplitBackward(torch.autograd.Function):
 
 SPLIT_CONV_BACKWARD = os.environ.get("GLX_SPLIT_CONV_BWD", "1") != "0"
 OWN_CONV3X3 = os.environ.get("GLX_OWN_CONV3X3", "1") != "0"     # 3x3 / stride 1 layers on csrc/glx_conv2d.hip
+FUSE_BN_IN_CONV3X3 = os.environ.get("GLX_CONV3X3_BN", "1") != "0"    # ... with the next BatchNorm's statistics in the epilogue
 
 
 def _pair(v):
@@ -202,12 +203,16 @@ class BEVBackbone(nn.Module):
         return y.view(b, h, w, c).permute(0, 3, 1, 2)
 
     @staticmethod
-    def _can_fuse_bn(bn, x):
+    def _bn_fusable(bn):
         from .spconv import core
-        return (isinstance(bn, nn.BatchNorm2d) and bn.training and x.is_cuda and x.dim() == 4
-                and x.is_contiguous(memory_format=torch.channels_last) and torch.is_grad_enabled()
+        return (isinstance(bn, nn.BatchNorm2d) and bn.training and torch.is_grad_enabled()
                 and core.USE_FUSED_TRAIN_BN and bn.affine and bn.momentum is not None
                 and bn.num_features % 4 == 0 and bn.num_features <= 512 and 1024 % bn.num_features == 0)
+
+    @staticmethod
+    def _can_fuse_bn(bn, x):
+        return (BEVBackbone._bn_fusable(bn) and x.is_cuda and x.dim() == 4
+                and x.is_contiguous(memory_format=torch.channels_last))
 
     @staticmethod
     def _run_block(blk, x):
@@ -218,19 +223,34 @@ class BEVBackbone(nn.Module):
         i = 0
         while i < len(mods):
             m = mods[i]
+            conv, step = None, 1
             if (isinstance(m, nn.ZeroPad2d) and tuple(m.padding) == (1, 1, 1, 1) and i + 1 < len(mods)
                     and isinstance(mods[i + 1], nn.Conv2d) and mods[i + 1].padding == (0, 0)
                     and mods[i + 1].kernel_size == (3, 3) and mods[i + 1].dilation == (1, 1)):
-                c = mods[i + 1]
-                x = conv2d(x, c.weight, c.bias, c.stride, 1, c.dilation, c.groups)
-                i += 2
+                conv, pad, step = mods[i + 1], (1, 1), 2
+            elif isinstance(m, nn.Conv2d) and not isinstance(m.padding, str) and m.padding_mode == "zeros":
+                conv, pad = m, _pair(m.padding)
+            if conv is not None:
+                # Conv2d -> BatchNorm2d (-> ReLU) on the own 3x3 kernels: the statistics ride in the conv's epilogue
+                j = i + step
+                bn = mods[j] if j < len(mods) else None
+                if (FUSE_BN_IN_CONV3X3 and OWN_CONV3X3 and _leaf(conv.weight) and BEVBackbone._bn_fusable(bn)
+                        and own_conv.bn_state_available()
+                        and x.is_cuda and bn.num_features == conv.out_channels and own_conv.supported(
+                            x, conv.weight, _pair(conv.stride), pad, _pair(conv.dilation), conv.groups, conv.bias)):
+                    relu = j + 1 < len(mods) and isinstance(mods[j + 1], nn.ReLU)
+                    x = own_conv.conv3x3_bn(x, conv.weight, bn, relu)
+                    i = j + (2 if relu else 1)
+                    continue
+                x = conv2d(x, conv.weight, conv.bias, conv.stride, pad, conv.dilation, conv.groups)
+                i += step
                 continue
             if BEVBackbone._can_fuse_bn(m, x):
                 relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
                 x = BEVBackbone._fused_bn_relu(m, x, relu)
                 i += 2 if relu else 1
                 continue
-            x = conv_module(m, x) if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) else m(x)
+            x = conv_module(m, x) if isinstance(m, nn.ConvTranspose2d) else m(x)
             i += 1
         return x
 

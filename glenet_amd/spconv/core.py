@@ -397,6 +397,7 @@ class SparseConvFunction(Function):
         ctx.has_bias = bias is not None
         if bn is not None:
             ctx.mark_non_differentiable(*out[1:])
+            ctx.set_materialize_grads(False)       # no zero tensors (3 fill launches) for the statistics' "gradients"
         return out
 
     @staticmethod
@@ -810,12 +811,11 @@ def conv_bn_fusable(conv, bn, x):
             and x.features.is_cuda and x.indices.shape[0] > 1)
 
 
-# Off by default: measured on the GLENet-VR training step (three alternating runs on one box) 11.79 / 11.77 / 11.68 ms
-# with the statistics in the conv epilogue against 11.67 / 11.68 / 11.68 ms with the separate statistics kernel -- the
-# 12 saved launches (a 3 us pass over 12 MB + an 11 us dependent tail each) cost the convs as much: three times the
-# blocks queue on the fp64 accumulator atomics (753 tiles against 256 slabs) and the last-block finalize now sits at
-# the end of the conv instead of overlapping the next launch's ramp-up.  Kept (tested) behind GLX_BN_IN_CONV=1.
-FUSE_BN_STATS_IN_CONV = os.environ.get("GLX_BN_IN_CONV", "0") != "0"
+# On by default since round 3's second measurement: 10.18 ms per GLENet-VR training step with the statistics in the conv
+# epilogue against 10.29 without (two alternating runs on one box).  The first measurement (11.79 / 11.77 / 11.68 against
+# 11.67 / 11.68 / 11.68 ms) had autograd materialising zero "gradients" for the three statistics outputs of every conv --
+# 36 fill launches per step that ate the 12 saved statistics launches; set_materialize_grads(False) removed them.
+FUSE_BN_STATS_IN_CONV = os.environ.get("GLX_BN_IN_CONV", "1") != "0"
 
 
 class FusedBNReLUCat(Function):

@@ -818,6 +818,12 @@ int glx_conv3x3_pack(const float* W, long long s_co, long long s_ci, long long s
                      void* fwd, void* bwd, void* stream);
 int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin, const void* packed, int Cout, float* y,
                         void* stream);
+/* Training-mode BatchNorm2d behind the convolution (base_bev_backbone.py:37-49: Conv2d -> BatchNorm2d -> ReLU): the
+ * per-channel statistics of y are taken in the epilogue of the NEXT glx_conv3x3_forward call of this host thread and
+ * finalized by its last block; arguments and semantics as glx_sconv_next_bn_stats (coef feeds glx_bn_apply_forward). */
+int glx_conv3x3_next_bn_stats(void* state, const float* gamma, const float* beta, float eps, float momentum,
+                              float* coef, float* save_mean, float* save_invstd, float* running_mean,
+                              float* running_var);
 /* The weight gradient of the same convolution: dW (Cout, Cin, 3, 3), written through ELEMENT strides (s_co, s_ci,
  * s_kh, s_kw) (torch keeps the BEV filters in channels-last memory), = sum over pixels of gy (B, H, W, Cout) times
  * the shifted x (B, H, W, Cin); same split-bf16 arithmetic.  Two launches (block partial sums into the workspace,

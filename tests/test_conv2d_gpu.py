@@ -92,8 +92,9 @@ def test_bev_backbone_runs_its_block_layers_on_the_own_kernels(dev, monkeypatch)
     m = dp.BEVBackbone(64, layer_nums=(1, 1), num_filters=(64, 128)).to(dev).to(memory_format=torch.channels_last).train()
     x = _cl(torch.randn(2, 64, 24, 32, device=dev))
     calls = []
-    real = dp.own_conv.conv3x3
+    real, real_bn = dp.own_conv.conv3x3, dp.own_conv.conv3x3_bn
     monkeypatch.setattr(dp.own_conv, "conv3x3", lambda a, b: (calls.append(tuple(b.shape)), real(a, b))[1])
+    monkeypatch.setattr(dp.own_conv, "conv3x3_bn", lambda a, b, *r: (calls.append(tuple(b.shape)), real_bn(a, b, *r))[1])
     outs = []
     for own in (True, False):
         monkeypatch.setattr(dp, "OWN_CONV3X3", own)
@@ -110,3 +111,35 @@ def test_bev_backbone_runs_its_block_layers_on_the_own_kernels(dev, monkeypatch)
     assert torch.allclose(gx0, gx1, rtol=1e-3, atol=1e-5 * float(gx1.abs().max()) + 1e-9)
     for a, b_ in zip(gp0, gp1):
         assert torch.allclose(a, b_, rtol=1e-3, atol=2e-5 * float(b_.abs().max()) + 1e-9)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 24, 40), (3, 64, 128, 17, 33), (1, 128, 128, 100, 88)])
+def test_batchnorm_statistics_in_the_conv_epilogue(dev, shape):
+    """conv3x3_bn (statistics in the epilogue, last block finalizes) against conv3x3 + the separate fused BatchNorm:
+    output, running statistics and every gradient."""
+    from glenet_amd import conv2d as c2, dense_path as dp
+    b, cin, cout, h, w = shape
+    g = torch.Generator(device=dev).manual_seed(sum(shape))
+    x0 = _cl(torch.randn(b, cin, h, w, device=dev, generator=g))
+    w0 = torch.randn(cout, cin, 3, 3, device=dev, generator=g) / (3 * cin ** 0.5)
+    gy = _cl(torch.randn(b, cout, h, w, device=dev, generator=g))
+    res = []
+    for fused in (True, False):
+        bn = torch.nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, cout))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, cout))
+        x, wt = x0.clone().requires_grad_(True), torch.nn.Parameter(w0.clone())
+        for _ in range(2):                                      # twice: the accumulator sets must come back clean
+            for t in (x, wt, bn.weight, bn.bias):
+                t.grad = None
+            if fused:
+                y = c2.conv3x3_bn(x, wt, bn, True)
+            else:
+                y = dp.BEVBackbone._fused_bn_relu(bn, c2.conv3x3(x, wt), True)
+            y.backward(gy)
+        torch.cuda.synchronize()
+        res.append([y.detach(), x.grad, wt.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(),
+                    bn.running_var.clone(), bn.num_batches_tracked.clone().float()])
+    for a, b_ in zip(*res):
+        assert torch.allclose(a, b_, rtol=1e-4, atol=2e-5 * float(b_.abs().max()) + 1e-12), float((a - b_).abs().max())

@@ -54,6 +54,9 @@ def one(b, cin, cout, h, w, time=False):
         t_gown = t(lambda: c2._run(gy, bwd, cin))
         t_glib = t(lambda: torch.ops.aten.convolution_backward(gy, x, wt, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
                                                                [True, False, False]))
+        bn = torch.nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01).to(dev).train()
+        t_bn = t(lambda: c2._run(x, fwd, cout, bn))
+        line += " | fwd+stats %.1f us" % t_bn
         t_wown = t(lambda: c2.wgrad(x, gy, wt))
         t_wlib = t(lambda: torch.ops.aten.convolution_backward(gy, x, wt, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
                                                                [False, True, False]))
