@@ -156,8 +156,14 @@ class HeightCompression(nn.Module):
     """height_compression.py:10-26: dense() then fold depth into channels."""
 
     channels_last = False       # True: the BEV map is produced in channels-last memory (SparseConvTensor.dense_bev)
+    defer = False               # True: no map here -- the consumer (dense_path.BEVBackbone) runs its first layer on the
+                                # sparse tensor, or builds the map itself when it cannot
 
     def forward(self, batch_dict):
+        if self.defer and self.channels_last:
+            batch_dict["spatial_features"] = None
+            batch_dict["spatial_features_stride"] = batch_dict["encoded_spconv_tensor_stride"]
+            return batch_dict
         if self.channels_last:
             batch_dict["spatial_features"] = batch_dict["encoded_spconv_tensor"].dense_bev()
             batch_dict["spatial_features_stride"] = batch_dict["encoded_spconv_tensor_stride"]

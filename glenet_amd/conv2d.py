@@ -56,6 +56,9 @@ def _run(x, pack, cout, bn=None):
     """bn: a training-mode BatchNorm2d that follows the conv -- its batch statistics are taken in the kernel's epilogue
     (glx_conv3x3_next_bn_stats) and the call returns (y, coef, save_mean, save_invstd)."""
     b, c, h, w = x.shape
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise _lib.GlxError("conv3x3 expects a float32 channels-last device map, got %s strides %s on %s"
+                            % (x.dtype, tuple(x.stride()), x.device))
     y = torch.empty((b, cout, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     stats = None
     if bn is not None:

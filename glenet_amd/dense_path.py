@@ -68,6 +68,7 @@ class _ConvSplitBackward(torch.autograd.Function):
 
 SPLIT_CONV_BACKWARD = os.environ.get("GLX_SPLIT_CONV_BWD", "1") != "0"
 OWN_CONV3X3 = os.environ.get("GLX_OWN_CONV3X3", "1") != "0"     # 3x3 / stride 1 layers on csrc/glx_conv2d.hip
+SPARSE_FIRST_BEV_LAYER = os.environ.get("GLX_BEV_SPARSE_FIRST", "1") != "0"   # see BEVBackbone._first_layer_sparse
 FUSE_BN_IN_CONV3X3 = os.environ.get("GLX_CONV3X3_BN", "1") != "0"    # ... with the next BatchNorm's statistics in the epilogue
 
 
@@ -168,13 +169,52 @@ class BEVBackbone(nn.Module):
 
     FUSE_UPS_CAT = os.environ.get("GLX_BEV_CAT_FUSE", "1") != "0"
 
+    def _first_layer_sparse(self, st):
+        """blocks[0]'s ZeroPad2d(1) + Conv2d(C * D -> c, 3) applied to the SPARSE tensor the BEV map is the dense
+        image of (HeightCompression left it to us): with the depth folded into channels (channel c * D + z,
+        height_compression.py:21-25) the 3x3 convolution over (y, x) IS a sparse convolution with kernel (D, 3, 3),
+        stride (D, 1, 1), padding (0, 1, 1) -- the same sums without the zeros.  ~16 % of the BEV cells of a KITTI
+        frame are occupied: a ninth to a sixth of the dense layer's products in forward, input gradient (needed at
+        the occupied cells only) and weight gradient, and the 144 MB dense map is never built.  Returns the conv's
+        output as a channels-last (B, c, H, W) map, or None when the layer is not of that form."""
+        from .spconv import core
+        mods = list(self.blocks[0])
+        if not (SPARSE_FIRST_BEV_LAYER and len(mods) >= 2 and isinstance(mods[0], nn.ZeroPad2d)
+                and tuple(mods[0].padding) == (1, 1, 1, 1) and isinstance(mods[1], nn.Conv2d)):
+            return None
+        conv = mods[1]
+        c, d = int(st.features.shape[1]), int(st.spatial_shape[0])
+        if not (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.dilation == (1, 1)
+                and conv.groups == 1 and conv.bias is None and conv.in_channels == c * d and st.features.is_cuda
+                and 9 * d <= 27 and c in (16, 32, 64, 128) and conv.out_channels in (16, 32, 64, 128)
+                and st.features.shape[0] > 0 and st._index is not None):
+            return None
+        cout = conv.out_channels
+        # (cout, c * D + z, ky, kx) -> (z, ky, kx, c, cout): views up to the final reshape
+        w = conv.weight.permute(2, 3, 1, 0).unflatten(2, (c, d)).permute(3, 0, 1, 2, 4).reshape(9 * d, c, cout)
+        rs = core.build_strided_rules(st, (d, 3, 3), (d, 1, 1), (0, 1, 1))
+        feats = core.SparseConvFunction.apply(st.features, w, None, rs, False, None, False)
+        out = core.SparseConvTensor(feats, rs.out_indices, rs.out_spatial_shape, st.batch_size, st.grid, st.voxel_num,
+                                    st.indice_dict, st.benchmark, rs.count_out)
+        out._index = rs.out_index
+        return out.dense_bev()
+
     def forward(self, data_dict):
-        x0 = data_dict["spatial_features"]
+        x0 = data_dict.get("spatial_features")
+        first = None
+        if x0 is None:                                  # HeightCompression(defer=True): the map is ours to make
+            st = data_dict["encoded_spconv_tensor"]
+            first = self._first_layer_sparse(st) if torch.is_grad_enabled() else None
+            if first is None:
+                x0 = data_dict["spatial_features"] = st.dense_bev()
+            h0 = int(st.spatial_shape[1])
+        else:
+            h0 = int(x0.shape[2])
         x, ups, raw = x0, [], []
         fuse = self.FUSE_UPS_CAT and len(self.deblocks) == len(self.blocks) and len(self.blocks) > 1
         for i, blk in enumerate(self.blocks):
-            x = self._run_block(blk, x)
-            data_dict["spatial_features_%dx" % int(x0.shape[2] / x.shape[2])] = x
+            x = self._run_block(blk, first, 2) if (i == 0 and first is not None) else self._run_block(blk, x)
+            data_dict["spatial_features_%dx" % int(h0 / x.shape[2])] = x
             if fuse:
                 raw.append(conv_module(self.deblocks[i][0], x))   # the deblock's (transposed) convolution only
             else:
@@ -215,12 +255,12 @@ class BEVBackbone(nn.Module):
                 and x.is_contiguous(memory_format=torch.channels_last))
 
     @staticmethod
-    def _run_block(blk, x):
+    def _run_block(blk, x, start=0):
         """nn.Sequential semantics with ZeroPad2d(1) + Conv2d(k=3, padding=0) run as ONE convolution with
         padding=1: the same sums over the same zeros, without materialising the padded copy of the input (77 us
         forward + 55 us backward for the 144 MB BEV map) -- module list and parameter names stay the reference's."""
         mods = list(blk)
-        i = 0
+        i = start
         while i < len(mods):
             m = mods[i]
             conv, step = None, 1

@@ -126,6 +126,8 @@ class GLENetVR(nn.Module):
         self.backbone_3d = gb.VoxelBackBone8x(num_point_features, grid)
         self.map_to_bev_module = gb.HeightCompression()
         self.map_to_bev_module.channels_last = bool(bev_channels_last)
+        # the BEV backbone takes the sparse tensor itself (first layer as a sparse conv, dense_path.BEVBackbone)
+        self.map_to_bev_module.defer = bool(bev_channels_last) and dp.SPARSE_FIRST_BEV_LAYER
         self.backbone_2d = dp.BEVBackbone(256)
         self.dense_head = dp.AnchorHead(self.backbone_2d.num_bev_features, num_class=1, num_anchors_per_location=2)
         self.roi_head = VoxelRCNNKLHead(self.backbone_3d.backbone_channels, cfg["voxel_size"],

@@ -143,3 +143,35 @@ def test_batchnorm_statistics_in_the_conv_epilogue(dev, shape):
                     bn.running_var.clone(), bn.num_batches_tracked.clone().float()])
     for a, b_ in zip(*res):
         assert torch.allclose(a, b_, rtol=1e-4, atol=2e-5 * float(b_.abs().max()) + 1e-12), float((a - b_).abs().max())
+
+
+def test_first_bev_layer_on_the_sparse_tensor_equals_the_dense_layer(dev, monkeypatch):
+    """BEVBackbone fed the sparse tensor (HeightCompression(defer=True)) against the same module fed its dense image:
+    the first layer as a sparse conv with kernel (D, 3, 3) is the ZeroPad2d + Conv2d of the dense map."""
+    from glenet_amd import dense_path as dp
+    from glenet_amd.spconv import core as sp
+    torch.manual_seed(1)
+    B, D, H, W, C = 2, 2, 40, 48, 64
+    m = dp.BEVBackbone(C * D, layer_nums=(1, 1), num_filters=(64, 128)).to(dev).to(memory_format=torch.channels_last).train()
+    act = (torch.rand(B, 1, H, W, device=dev) < 0.15) & (torch.rand(B, D, H, W, device=dev) < 0.6)
+    act[1, :, 20:] = False                                           # an empty half frame
+    idx = act.nonzero().int().contiguous()
+    feats0 = torch.randn(idx.shape[0], C, device=dev)
+    res = []
+    for sparse in (True, False):
+        for p in m.parameters():
+            p.grad = None
+        feats = feats0.clone().requires_grad_(True)
+        st = sp.SparseConvTensor(feats, idx, [D, H, W], B)
+        st._ensure_index()
+        bd = {"encoded_spconv_tensor": st, "spatial_features": None if sparse else st.dense_bev()}
+        if sparse:
+            assert m._first_layer_sparse(st) is not None
+        out = m(bd)
+        assert ("spatial_features" not in bd or bd["spatial_features"] is None) == sparse      # the dense map was never built
+        y = out["spatial_features_2d"]
+        (y.square().mean() + out["spatial_features_1x"].mean()).backward()
+        torch.cuda.synchronize()
+        res.append([y.detach(), out["spatial_features_1x"].detach(), feats.grad] + [p.grad.clone() for p in m.parameters()])
+    for a, b_ in zip(*res):
+        assert torch.allclose(a, b_, rtol=1e-3, atol=2e-5 * float(b_.abs().max()) + 1e-9), float((a - b_).abs().max())
