@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (2.4 GHz; loops on random data hold 1.5-1.95 GHz)
 FRAMES_PER_GPU = 4
 BATCH_POOL = 8               # distinct batches per rank; rank 0 at N = 1: frames 0..31 = seeds 1000..1031
 METRIC = "LiDAR frames/sec (fwd+bwd) on KITTI-shaped clouds at 1/2/4/8 MI355X; sparse-conv HBM GB/s"
@@ -239,14 +240,34 @@ def bench_bev(model, dev, frames=FRAMES_PER_GPU):
     ms_f = _timed(fwd, 10, dev)
     ms_fb = _timed(fwd_bwd, 10, dev)
     model.load_state_dict(state, strict=False)          # the timing passes moved the running statistics
+    # the own 3x3 kernels alone (csrc/glx_conv2d.hip), on the block layers' shapes: fp32-equivalent TFLOP/s (2 x
+    # multiply-adds of the fp32 convolution) and the share of the bf16 pipe the six piece products per tile occupy
+    from glenet_amd import conv2d as c2
+    layers = {}
+    for cin, cout, h, w in ((64, 64, 200, 176), (128, 128, 100, 88)):
+        xi = torch.randn(frames, cin, h, w, device=dev).contiguous(memory_format=torch.channels_last)
+        gy = torch.randn(frames, cout, h, w, device=dev).contiguous(memory_format=torch.channels_last)
+        wt = torch.randn(cout, cin, 3, 3, device=dev) / (3 * cin ** 0.5)
+        pf, pb = c2.packs(wt)
+        fl = 2.0 * frames * h * w * 9 * cin * cout
+        t = {"forward": _timed(lambda: c2._run(xi, pf, cout), 20, dev), "input_grad": _timed(lambda: c2._run(gy, pb, cin), 20, dev),
+             "weight_grad": _timed(lambda: c2.wgrad(xi, gy, wt), 20, dev)}
+        layers["%d->%d@%dx%d" % (cin, cout, h, w)] = {
+            k: dict(us=round(v * 1e3, 1), TFLOPs_fp32_equivalent=round(fl / v / 1e9, 1),
+                    frac_of_fp32_mfma_peak=round(fl / v / 1e9 / MFMA_F32_PEAK_TFLOPS, 3),
+                    frac_of_bf16_pipe=round(6 * fl / v / 1e9 / MFMA_BF16_PEAK_TFLOPS, 3)) for k, v in t.items()}
     return dict(workload="BEV backbone (12 conv3x3 + 2 deconv) + anchor head on (%d,256,200,176), fp32, channels-last, "
-                         "training-mode BatchNorm included in the time" % frames,
+                         "training-mode BatchNorm included in the time; dense input (in the training step the first "
+                         "layer runs on the sparse tensor instead, dense_path.BEVBackbone._first_layer_sparse)" % frames,
+                conv3x3=layers,
                 gflop_fwd=round(flops / 1e9, 1), fwd_ms=round(ms_f, 3), fwd_bwd_ms=round(ms_fb, 3),
                 fwd_TFLOPs=round(flops / ms_f / 1e9, 1), fwd_bwd_TFLOPs=round(3 * flops / ms_fb / 1e9, 1),
                 frac_of_fp32_mfma_peak=dict(fwd=round(flops / ms_f / 1e9 / MFMA_F32_PEAK_TFLOPS, 3),
                                             fwd_bwd=round(3 * flops / ms_fb / 1e9 / MFMA_F32_PEAK_TFLOPS, 3)),
-                kernels="MIOpen implicit-GEMM / Winograd fp32 (vendor) + csrc/glx_bn.hip; per-kernel MFMA-busy counters: "
-                        "profiles/r03_bev_mfma.md")
+                kernels="3x3 / stride-1 layers (11 of 12: forward, input and weight gradient): csrc/glx_conv2d.hip, fp32 "
+                        "products as six bf16 MFMAs of three-way split operands, fp32 accumulation; the strided layer, "
+                        "the two deconvolutions and the head: MIOpen fp32 (vendor); BatchNorm: csrc/glx_bn.hip with the "
+                        "forward statistics in the conv epilogue")
 
 
 def bench_config3(dev, objects=4096, points=512, samples=30):

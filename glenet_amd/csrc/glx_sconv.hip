@@ -798,6 +798,49 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
       // ---- multiply this wave's chunk of the current panel by its column tiles
       const int pbase = pb + grp * 16;
       if constexpr (TRACE) { my_chunks += pbase < cnt; ++n_steps; }
+      if (TRACE && (ep.xcd_group & 0x800) && pbase < cnt) {
+        // 0x800: TIMING stand-in (wrong values) for a split-bf16 multiply: 1.5 x the operand bytes from LDS, 12 bf16
+        // MFMAs (2 k-steps x 6 piece products, 16 cycles each) per column tile instead of 16 fp32 MFMAs (32 cycles)
+        typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+        const float* arow = s_a + (grp * 16 + r) * T::A_LD + q * CQ;
+        const float* arow2 = s_a + (grp * 16 + (r ^ 1)) * T::A_LD + q * CQ;
+        bf16x8_t Af[6];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Af[i] = *reinterpret_cast<const bf16x8_t*>(arow + 4 * (i % (CQ / 4 > 0 ? CQ / 4 : 1)));
+        Af[4] = *reinterpret_cast<const bf16x8_t*>(arow2);
+        Af[5] = *reinterpret_cast<const bf16x8_t*>(arow2 + 4);
+        f32x4 acc[T::TPW];
+#pragma unroll
+        for (int tt = 0; tt < T::TPW; ++tt) {
+          acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const float* wp = s_w + S::idx(tile0 + tt, q, 0, r);
+          const float* wp2 = s_w + S::idx(tile0 + tt, q ^ 1, 0, r);
+          bf16x8_t Wf[6];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) Wf[i] = *reinterpret_cast<const bf16x8_t*>(wp + 64 * (i % (CQ / 4 > 0 ? CQ / 4 : 1)));
+          Wf[4] = *reinterpret_cast<const bf16x8_t*>(wp2);
+          Wf[5] = *reinterpret_cast<const bf16x8_t*>(wp2 + 64);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[3 * ks + 2], Af[3 * ks + 0], acc[tt], 0, 0, 0);
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[3 * ks + 0], Af[3 * ks + 2], acc[tt], 0, 0, 0);
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[3 * ks + 1], Af[3 * ks + 1], acc[tt], 0, 0, 0);
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[3 * ks + 1], Af[3 * ks + 0], acc[tt], 0, 0, 0);
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[3 * ks + 0], Af[3 * ks + 1], acc[tt], 0, 0, 0);
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[3 * ks + 0], Af[3 * ks + 0], acc[tt], 0, 0, 0);
+          }
+        }
+        const int p = pbase + r;
+        if (p < cnt) {
+          float* dst = s_acc + (int)s_pslot[k * TR + p] * ACC_LD + tile0 * 16 + 4 * q;
+#pragma unroll
+          for (int tt = 0; tt < T::TPW; ++tt) {
+            f32x4 v = *reinterpret_cast<f32x4*>(dst + tt * 16);
+            v += acc[tt];
+            *reinterpret_cast<f32x4*>(dst + tt * 16) = v;
+          }
+        }
+      } else
       if (pbase < cnt && !(TRACE && (ep.xcd_group & 0x100))) {   // wave-uniform (0x100: ablate the multiply)
         const float* arow = s_a + (grp * 16 + r) * T::A_LD + q * CQ;
         float Am[CQ];
@@ -1294,7 +1337,7 @@ static int launch_gemm(const float* in, const float* Wp, const SconvEpilogue& ep
   } else {
     static bool attr_set = false;
     auto kern = k_sconv_gemm<CI, CO, TR, NW, WPG>;
-    const size_t lds = T::lds_bytes;
+    const size_t lds = T::lds_bytes + (size_t)((ep.xcd_group >> 16) & 0xFF) * 1024;   // bits 16-23: experiments, KB of padding
     if (!attr_set) {
       GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
