@@ -109,7 +109,7 @@ class SparseBackbone8x(nn.Module):
         (voxelize_batch(..., static=True)) the plan itself is free of host syncs too."""
         count = index.count if index is not None else None
         return spconv.core.plan_rules(voxel_coords.int(), self.sparse_shape, batch_size,
-                                      self.sparse_convs(), index=index, count=count,
+                                      list(self.sparse_convs()) + list(self.extra_plan), index=index, count=count,
                                       capacities=capacities, events=events)
 
     def forward(self, batch_dict):
@@ -133,6 +133,10 @@ class SparseBackbone8x(nn.Module):
     def sparse_convs(self):
         return [m for m in self.modules() if isinstance(m, spconv.SparseConvolution)]
 
+    # geometry of sparse convs BEHIND the stack whose rule tables plan() should build with the others
+    # (spconv.core.PlannedConv; the BEV backbone's first layer, dense_path.BEVBackbone._first_layer_sparse)
+    extra_plan = ()
+
 
 def VoxelBackBone8x(input_channels, grid_size, **kw):
     return SparseBackbone8x(input_channels, grid_size, residual=False, **kw)
@@ -150,6 +154,11 @@ class MeanVFE(nn.Module):
         batch_dict["voxel_features"] = gv.mean_vfe(batch_dict["voxels"], batch_dict["voxel_num_points"],
                                                    count=index.count if index is not None else None)
         return batch_dict
+
+
+def _reset_conv_packs():
+    from . import conv2d as own_conv
+    own_conv.STEP_PACKS = None
 
 
 class HeightCompression(nn.Module):
@@ -464,6 +473,10 @@ class StaticTrainPipeline(StaticFramePipeline):
             spconv.core.DEFERRED_COUNTERS = counters = []
             if PREPACK_WEIGHTS:        # every layer's forward + adjoint weight image in one launch
                 spconv.core.prepack([m for m in self.model.modules() if isinstance(m, spconv.core.SparseConvolution)])
+                from . import conv2d as own_conv       # ... and the BEV backbone's 3x3 filters (split-bf16 pieces) in another
+                own_conv.prepack([m.weight for em in self.extra_modules for m in em.modules()
+                                  if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1)
+                                  and m.bias is None])
             try:
                 with torch.enable_grad():
                     bd = self.hc(self.model(bd))
@@ -472,6 +485,7 @@ class StaticTrainPipeline(StaticFramePipeline):
                     loss = self.loss_fn(bd)
             except BaseException:
                 spconv.core.STEP_PACKS = None
+                _reset_conv_packs()
                 raise
             finally:
                 spconv.core.DEFERRED_COUNTERS = None
@@ -486,6 +500,7 @@ class StaticTrainPipeline(StaticFramePipeline):
             finally:
                 spconv.core.WGRAD_STREAM = None
                 spconv.core.STEP_PACKS = None
+                _reset_conv_packs()
             if self.overlap_wgrad:
                 cur.wait_stream(self.plan_stream)
             if self.mark:

@@ -7,6 +7,7 @@ six bf16 products of three-way split operands with fp32 accumulation (fp32 accur
 the flipped pack for the input gradient and leaves the weight gradient on the step's weight-gradient stream."""
 import contextlib
 import ctypes
+import weakref
 
 import torch
 
@@ -28,14 +29,51 @@ def bn_state_available():
 
 
 _packs = {}
+# Piece images packed ahead for the current training step by prepack(): {weight data_ptr: (fwd, bwd)}; the caller
+# resets it to None after the step (the images are valid only while the weights do not change).
+STEP_PACKS = None
+
+
+def prepack(weights):
+    """Both piece images of every (Cout, Cin, 3, 3) weight in `weights` with ONE launch (glx_conv3x3_pack_multi),
+    parked in STEP_PACKS for packs() to hand out."""
+    global STEP_PACKS
+    STEP_PACKS = {}
+    jobs = []
+    for w in weights:
+        w = w.detach()
+        cout, cin = int(w.shape[0]), int(w.shape[1])
+        if not (w.is_cuda and w.dtype == torch.float32 and tuple(w.shape[2:]) == (3, 3) and cout % 64 == 0 and cin % 64 == 0):
+            continue
+        n = query("glx_conv3x3_packed_bytes", cin, cout)
+        jobs.append((w, cin, cout, torch.empty(n, dtype=torch.uint8, device=w.device),
+                     torch.empty(n, dtype=torch.uint8, device=w.device)))
+    if not jobs:
+        return
+    n = len(jobs)
+    ptrs = (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in jobs])
+    strides = (ctypes.c_longlong * (4 * n))(*[int(v) for j in jobs for v in j[0].stride()])
+    cins = (ctypes.c_int32 * n)(*[j[1] for j in jobs])
+    couts = (ctypes.c_int32 * n)(*[j[2] for j in jobs])
+    fwd = (ctypes.c_void_p * n)(*[j[3].data_ptr() for j in jobs])
+    bwd = (ctypes.c_void_p * n)(*[j[4].data_ptr() for j in jobs])
+    call("glx_conv3x3_pack_multi", n, ptrs, strides, cins, couts, fwd, bwd)
+    for j in jobs:
+        STEP_PACKS[(j[0].data_ptr(), tuple(j[0].stride()))] = (j[3], j[4])
 
 
 def packs(weight):
     """(fwd, bwd) piece images of a (Cout, Cin, 3, 3) weight; rebuilt when the weights epoch or the tensor's version
     moves (one launch writes both)."""
+    if STEP_PACKS is not None:
+        hit = STEP_PACKS.get((weight.data_ptr(), tuple(weight.stride())))
+        if hit is not None:
+            return hit
     key = (weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()))
     tag = (_lib.weights_epoch(), weight._version)
     hit = _packs.get(key)
+    if hit is not None and hit[3]() is not weight:
+        hit = None                         # another tensor that happens to live where a freed weight did
     if hit is not None and hit[0] == tag and not torch.cuda.is_current_stream_capturing():
         return hit[1], hit[2]
     cout, cin = int(weight.shape[0]), int(weight.shape[1])
@@ -48,7 +86,7 @@ def packs(weight):
     s = weight.stride()
     ll = ctypes.c_longlong
     call("glx_conv3x3_pack", weight.detach(), ll(s[0]), ll(s[1]), ll(s[2]), ll(s[3]), cin, cout, fwd, bwd)
-    _packs[key] = (tag, fwd, bwd)
+    _packs[key] = (tag, fwd, bwd, weakref.ref(weight))
     return fwd, bwd
 
 

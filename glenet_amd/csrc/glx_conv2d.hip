@@ -48,21 +48,31 @@ __device__ __forceinline__ void cv_split(float x, __bf16& a, __bf16& b, __bf16& 
 // W (Cout, Cin, 3, 3) with element strides (s_co, s_ci, s_kh, s_kw) ->
 //   fwd [tap][Cin/32][3][Cout][32]   (the conv itself)
 //   bwd [tap'][Cout/32][3][Cin][32]  (its input gradient: a conv Cout -> Cin with W'[ci][co][kh'][kw'] = W[co][ci][2-kh'][2-kw'])
-__global__ void k_conv3x3_pack(const float* __restrict__ W, long long s_co, long long s_ci, long long s_kh,
-                               long long s_kw, int Cin, int Cout, uint16_t* __restrict__ fwd,
-                               uint16_t* __restrict__ bwd) {
+struct ConvPackJob {
+  const float* W;
+  long long s_co, s_ci, s_kh, s_kw;
+  int Cin, Cout;
+  uint16_t* fwd;
+  uint16_t* bwd;
+};
+#define CV_PACK_MAX_JOBS 16
+struct ConvPackJobs { ConvPackJob j[CV_PACK_MAX_JOBS]; };
+
+__global__ void k_conv3x3_pack(ConvPackJobs jobs) {      // blockIdx.y = job
+  const ConvPackJob jb = jobs.j[blockIdx.y];
+  const int Cin = jb.Cin, Cout = jb.Cout;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= Cout * Cin * 9) return;
   const int ci = e % Cin, co = (e / Cin) % Cout, tap = e / (Cin * Cout);
   const int kh = tap / 3, kw = tap % 3;
-  const float w = W[co * s_co + ci * s_ci + kh * s_kh + kw * s_kw];
+  const float w = jb.W[co * jb.s_co + ci * jb.s_ci + kh * jb.s_kh + kw * jb.s_kw];
   __bf16 p[3];
   cv_split(w, p[0], p[1], p[2]);
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     const uint16_t bits = __builtin_bit_cast(uint16_t, p[q]);
-    if (fwd) fwd[((((size_t)tap * (Cin / 32) + ci / 32) * 3 + q) * Cout + co) * 32 + (ci & 31)] = bits;
-    if (bwd) bwd[((((size_t)(8 - tap) * (Cout / 32) + co / 32) * 3 + q) * Cin + ci) * 32 + (co & 31)] = bits;
+    if (jb.fwd) jb.fwd[((((size_t)tap * (Cin / 32) + ci / 32) * 3 + q) * Cout + co) * 32 + (ci & 31)] = bits;
+    if (jb.bwd) jb.bwd[((((size_t)(8 - tap) * (Cout / 32) + co / 32) * 3 + q) * Cin + ci) * 32 + (co & 31)] = bits;
   }
 }
 
@@ -547,15 +557,43 @@ extern "C" size_t glx_conv3x3_packed_bytes(int Cin, int Cout) {
   return glx_align((size_t)9 * 3 * Cin * Cout * sizeof(uint16_t));
 }
 
-extern "C" int glx_conv3x3_pack(const float* W, long long s_co, long long s_ci, long long s_kh, long long s_kw,
-                                int Cin, int Cout, void* fwd, void* bwd, void* stream) {
+static int conv_pack_check(int Cin, int Cout, const void* fwd, const void* bwd) {
   GLX_REQUIRE(Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0,
               "glx_conv3x3_pack: channels must be multiples of 32 (got %d -> %d)", Cin, Cout);
   GLX_REQUIRE(fwd == nullptr || Cout % CV_BN == 0, "glx_conv3x3_pack: forward pack needs Cout %% 64 == 0 (got %d)", Cout);
   GLX_REQUIRE(bwd == nullptr || Cin % CV_BN == 0, "glx_conv3x3_pack: gradient pack needs Cin %% 64 == 0 (got %d)", Cin);
-  const int n = Cin * Cout * 9;
-  hipLaunchKernelGGL(k_conv3x3_pack, dim3(glx_divup(n, 256)), dim3(256), 0, (hipStream_t)stream, W, s_co, s_ci, s_kh,
-                     s_kw, Cin, Cout, (uint16_t*)fwd, (uint16_t*)bwd);
+  return GLX_OK;
+}
+
+extern "C" int glx_conv3x3_pack(const float* W, long long s_co, long long s_ci, long long s_kh, long long s_kw,
+                                int Cin, int Cout, void* fwd, void* bwd, void* stream) {
+  const int rc = conv_pack_check(Cin, Cout, fwd, bwd);
+  if (rc != GLX_OK) return rc;
+  ConvPackJobs jobs;
+  jobs.j[0] = ConvPackJob{W, s_co, s_ci, s_kh, s_kw, Cin, Cout, (uint16_t*)fwd, (uint16_t*)bwd};
+  hipLaunchKernelGGL(k_conv3x3_pack, dim3(glx_divup(Cin * Cout * 9, 256), 1), dim3(256), 0, (hipStream_t)stream, jobs);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// n weights in one launch (CV_PACK_MAX_JOBS per launch); arrays of length n on the HOST, strides[4 * i ..] = s_co, s_ci,
+// s_kh, s_kw of weight i
+extern "C" int glx_conv3x3_pack_multi(int n, const float* const* W, const long long* strides, const int32_t* Cin,
+                                      const int32_t* Cout, void* const* fwd, void* const* bwd, void* stream) {
+  if (n <= 0) return GLX_OK;
+  GLX_REQUIRE(W && strides && Cin && Cout && fwd && bwd, "glx_conv3x3_pack_multi: null pointer");
+  for (int done = 0; done < n;) {
+    ConvPackJobs jobs;
+    int nj = 0, cover = 0;
+    for (; done < n && nj < CV_PACK_MAX_JOBS; ++done, ++nj) {
+      const int rc = conv_pack_check(Cin[done], Cout[done], fwd[done], bwd[done]);
+      if (rc != GLX_OK) return rc;
+      jobs.j[nj] = ConvPackJob{W[done], strides[4 * done], strides[4 * done + 1], strides[4 * done + 2], strides[4 * done + 3],
+                               Cin[done], Cout[done], (uint16_t*)fwd[done], (uint16_t*)bwd[done]};
+      cover = Cin[done] * Cout[done] * 9 > cover ? Cin[done] * Cout[done] * 9 : cover;
+    }
+    hipLaunchKernelGGL(k_conv3x3_pack, dim3(glx_divup(cover, 256), nj), dim3(256), 0, (hipStream_t)stream, jobs);
+  }
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

@@ -68,6 +68,7 @@ class _ConvSplitBackward(torch.autograd.Function):
 
 SPLIT_CONV_BACKWARD = os.environ.get("GLX_SPLIT_CONV_BWD", "1") != "0"
 OWN_CONV3X3 = os.environ.get("GLX_OWN_CONV3X3", "1") != "0"     # 3x3 / stride 1 layers on csrc/glx_conv2d.hip
+BEV_FIRST_KEY = "bev_first"      # indice_key of the first BEV layer's rule table (spconv.core.PlannedConv)
 SPARSE_FIRST_BEV_LAYER = os.environ.get("GLX_BEV_SPARSE_FIRST", "1") != "0"   # see BEVBackbone._first_layer_sparse
 FUSE_BN_IN_CONV3X3 = os.environ.get("GLX_CONV3X3_BN", "1") != "0"    # ... with the next BatchNorm's statistics in the epilogue
 
@@ -192,7 +193,14 @@ class BEVBackbone(nn.Module):
         cout = conv.out_channels
         # (cout, c * D + z, ky, kx) -> (z, ky, kx, c, cout): views up to the final reshape
         w = conv.weight.permute(2, 3, 1, 0).unflatten(2, (c, d)).permute(3, 0, 1, 2, 4).reshape(9 * d, c, cout)
-        rs = core.build_strided_rules(st, (d, 3, 3), (d, 1, 1), (0, 1, 1))
+        geom = ((d, 3, 3), (d, 1, 1), (0, 1, 1))
+        rs = st.indice_dict.get(BEV_FIRST_KEY) if st.indice_dict is not None else None
+        if rs is not None and (tuple(tuple(g) for g in rs.geom[1:]) != geom or rs.in_indices is not st.indices):
+            rs = None
+        if rs is None:                                  # not planned with the backbone's tables: build it here
+            rs = core.build_strided_rules(st, *geom)
+        elif rs.ready is not None:                      # built on the plan stream
+            torch.cuda.current_stream(st.features.device).wait_event(rs.ready)
         feats = core.SparseConvFunction.apply(st.features, w, None, rs, False, None, False)
         out = core.SparseConvTensor(feats, rs.out_indices, rs.out_spatial_shape, st.batch_size, st.grid, st.voxel_num,
                                     st.indice_dict, st.benchmark, rs.count_out)

@@ -129,6 +129,10 @@ class GLENetVR(nn.Module):
         # the BEV backbone takes the sparse tensor itself (first layer as a sparse conv, dense_path.BEVBackbone)
         self.map_to_bev_module.defer = bool(bev_channels_last) and dp.SPARSE_FIRST_BEV_LAYER
         self.backbone_2d = dp.BEVBackbone(256)
+        if self.map_to_bev_module.defer:     # its rule table is planned with the sparse backbone's
+            d = 256 // self.backbone_3d.num_point_features
+            self.backbone_3d.extra_plan = (gb.spconv.core.PlannedConv(dp.BEV_FIRST_KEY, (d, 3, 3), (d, 1, 1), (0, 1, 1),
+                                                                       self.backbone_3d.num_point_features, 64),)
         self.dense_head = dp.AnchorHead(self.backbone_2d.num_bev_features, num_class=1, num_anchors_per_location=2)
         self.roi_head = VoxelRCNNKLHead(self.backbone_3d.backbone_channels, cfg["voxel_size"],
                                         cfg["point_cloud_range"], self.roi_cfg)

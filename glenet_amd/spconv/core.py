@@ -214,6 +214,17 @@ def build_strided_rules(x, ksize, stride, padding, dilation=(1, 1, 1), out_capac
     return rs
 
 
+class PlannedConv:
+    """Geometry of a strided sparse convolution that is not a module of the stack, for plan_rules(): its rule table is
+    built with the stack's (on the plan stream) and found under `indice_key` in the tensors' indice_dict."""
+    subm = inverse = False
+    dilation = (1, 1, 1)
+
+    def __init__(self, indice_key, kernel_size, stride, padding, in_channels, out_channels):
+        self.indice_key, self.kernel_size, self.stride, self.padding = indice_key, tuple(kernel_size), tuple(stride), tuple(padding)
+        self.in_channels, self.out_channels = in_channels, out_channels
+
+
 def plan_rules(indices, spatial_shape, batch_size, convs, index=None, count=None,
                capacities=None, events=False):
     """Rule tables of a whole conv stack (modules in execution order) from coordinates only:

@@ -816,6 +816,9 @@ int glx_topk_desc(const float* scores, int frames, int A, int K, float* top, int
 size_t glx_conv3x3_packed_bytes(int Cin, int Cout);
 int glx_conv3x3_pack(const float* W, long long s_co, long long s_ci, long long s_kh, long long s_kw, int Cin, int Cout,
                      void* fwd, void* bwd, void* stream);
+/* The same for n weights in one launch: arrays of length n on the HOST; strides[4 i ..] = s_co, s_ci, s_kh, s_kw. */
+int glx_conv3x3_pack_multi(int n, const float* const* W, const long long* strides, const int32_t* Cin,
+                           const int32_t* Cout, void* const* fwd, void* const* bwd, void* stream);
 int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin, const void* packed, int Cout, float* y,
                         void* stream);
 /* Training-mode BatchNorm2d behind the convolution (base_bev_backbone.py:37-49: Conv2d -> BatchNorm2d -> ReLU): the

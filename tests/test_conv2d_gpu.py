@@ -175,3 +175,16 @@ def test_first_bev_layer_on_the_sparse_tensor_equals_the_dense_layer(dev, monkey
         res.append([y.detach(), out["spatial_features_1x"].detach(), feats.grad] + [p.grad.clone() for p in m.parameters()])
     for a, b_ in zip(*res):
         assert torch.allclose(a, b_, rtol=1e-3, atol=2e-5 * float(b_.abs().max()) + 1e-9), float((a - b_).abs().max())
+
+
+def test_pack_cache_is_not_fooled_by_a_new_weight_at_a_freed_address(dev):
+    """Two weights of one shape created one after the other usually share an address: the second must get its own pieces."""
+    from glenet_amd import conv2d as c2
+    x = _cl(torch.randn(1, 64, 16, 16, device=dev))
+    outs = []
+    for seed in (1, 2):
+        wt = torch.randn(64, 64, 3, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(seed)) / 24
+        outs.append((c2.conv3x3(x, wt), F.conv2d(x, wt, None, 1, 1)))
+        del wt
+    for y, ref in outs:
+        assert torch.allclose(y, ref, rtol=1e-4, atol=1e-5)

@@ -61,9 +61,9 @@ if args.seq:
     last = rows[marks[-2] + 1:marks[-1] + 1]
     t0 = last[0][0]
     with open(args.seq, "w") as f:
-        for s_, e_, n_, *_ in last:
-            f.write("%10.1f %8.1f  %s\n" % ((s_ - t0) / 1e3, (e_ - s_) / 1e3,
-                                            n_[:args.seq_name_chars] if args.seq_name_chars else short(n_)))
+        for s_, e_, n_, g_, w_, q_ in last:
+            f.write("%10.1f %8.1f  q%-3s %s\n" % ((s_ - t0) / 1e3, (e_ - s_) / 1e3, q_,
+                                                  n_[:args.seq_name_chars] if args.seq_name_chars else short(n_)))
 if args.out:
     with open(args.out, "w") as f:
         f.write(txt + "\n")
