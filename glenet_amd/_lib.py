@@ -41,7 +41,8 @@ def load():
                  "glx_group_points_grad_workspace_bytes", "glx_adamw_workspace_bytes", "glx_bn_workspace_bytes",
                  "glx_pos_pool_workspace_bytes", "glx_vector_pool_workspace_bytes",
                  "glx_sconv_tile_map_workspace_bytes", "glx_sconv_packed_bytes", "glx_mask_shuffle_workspace_bytes",
-                 "glx_conv3x3_packed_bytes", "glx_conv3x3_wgrad_workspace_bytes"):
+                 "glx_conv3x3_packed_bytes", "glx_conv3x3_wgrad_workspace_bytes",
+                 "glx_deconv_packed_bytes", "glx_deconv_wgrad_workspace_bytes"):
         if hasattr(lib, name):
             getattr(lib, name).restype = c_size_t
     lib.glx_index_words.restype = c_int64

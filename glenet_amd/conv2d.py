@@ -192,3 +192,75 @@ def conv3x3_bn(x, weight, bn, relu):
         else:
             bn.num_batches_tracked += 1
     return out.view(b, h, w, c).permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------------------------------------ transposed convolutions
+def deconv_supported(x, weight, stride, padding, output_padding, dilation, groups, bias):
+    """ConvTranspose2d(c, cu, u, stride=u, bias=False), u in {1, 2} (BaseBEVBackbone's deblocks) on channels-last maps."""
+    u = int(weight.shape[2])
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and bias is None
+            and u in (1, 2) and int(weight.shape[3]) == u and tuple(stride) == (u, u) and tuple(padding) == (0, 0)
+            and tuple(output_padding) == (0, 0) and tuple(dilation) == (1, 1) and groups == 1
+            and weight.shape[0] % 64 == 0 and weight.shape[1] % 64 == 0 and x.shape[1] == weight.shape[0]
+            and x.shape[3] % 8 == 0 and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def _deconv_packs(weight):
+    """(fwd, bwd) piece images of a (Cin, Cout, u, u) weight, packed at every call (two per training step)."""
+    cin, cout, u = int(weight.shape[0]), int(weight.shape[1]), int(weight.shape[2])
+    n = query("glx_deconv_packed_bytes", cin, cout, u)
+    fwd = torch.empty(n, dtype=torch.uint8, device=weight.device)
+    bwd = torch.empty(n, dtype=torch.uint8, device=weight.device)
+    s = weight.stride()
+    ll = ctypes.c_longlong
+    call("glx_deconv_pack", weight.detach(), ll(s[0]), ll(s[1]), ll(s[2]), ll(s[3]), cin, cout, u, fwd, bwd)
+    return fwd, bwd
+
+
+class _Deconv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        cin, cout, u = int(weight.shape[0]), int(weight.shape[1]), int(weight.shape[2])
+        fwd, bwd = _deconv_packs(weight)
+        b, _, h, w = x.shape
+        x = x.detach()
+        y = torch.empty((b, cout, h * u, w * u), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        call("glx_deconv_forward", x, b, h, w, cin, fwd, cout, u, y)
+        ctx.save_for_backward(x, weight)
+        ctx.bwd_pack = bwd
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .spconv import core
+        x, weight = ctx.saved_tensors
+        cin, cout, u = int(weight.shape[0]), int(weight.shape[1]), int(weight.shape[2])
+        b, _, h, w = x.shape
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        gx = gw = None
+        if ctx.needs_input_grad[1]:
+            side = core.WGRAD_STREAM
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream(x.device))
+                for t in (x, gy, weight):
+                    t.record_stream(side)
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                n = query("glx_deconv_wgrad_workspace_bytes", cin, cout, u)
+                key = (x.device.index, "deconv", n)
+                ws = _wgrad_ws.get(key)
+                if ws is None:
+                    ws = _wgrad_ws[key] = torch.empty(n, dtype=torch.uint8, device=x.device)
+                gw = torch.empty_like(weight)
+                s = gw.stride()
+                ll = ctypes.c_longlong
+                call("glx_deconv_wgrad", x, gy, b, h, w, cin, cout, u, gw, ll(s[0]), ll(s[1]), ll(s[2]), ll(s[3]), ws,
+                     _lib.size_arg(n))
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((b, cin, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+            call("glx_deconv_input_grad", gy, b, h, w, cin, ctx.bwd_pack, cout, u, gx)
+        return gx, gw
+
+
+def deconv(x, weight):
+    """F.conv_transpose2d(x, weight, None, stride=u) for a (Cin, Cout, u, u) weight, u in {1, 2}."""
+    return _Deconv.apply(x, weight)

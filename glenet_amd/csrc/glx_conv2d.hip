@@ -20,10 +20,7 @@
 // is the same kernel on the flipped, transposed pack (written by the same pack launch).
 #include "glx_common.h"
 #include "glx_bn_state.h"
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
+#include "glx_bf16x3.h"
 
 #define CV_TH 8
 #define CV_TW 16
@@ -36,14 +33,6 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define CV_WBUF (3 * CV_WPLANE)          // 15 360
 #define CV_LDS (3 * CV_APLANE + 2 * CV_WBUF)   // 73 920: two blocks per CU
 #define CV_ALOADS ((CV_HP * 8 + 255) / 256)    // 16-byte pieces of the halo per thread (6)
-
-__device__ __forceinline__ void cv_split(float x, __bf16& a, __bf16& b, __bf16& c) {
-  a = (__bf16)x;
-  float r = x - (float)a;
-  b = (__bf16)r;
-  r = r - (float)b;
-  c = (__bf16)r;
-}
 
 // W (Cout, Cin, 3, 3) with element strides (s_co, s_ci, s_kh, s_kw) ->
 //   fwd [tap][Cin/32][3][Cout][32]   (the conv itself)
@@ -335,7 +324,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
 //     column groups make the reads of a 32-lane half (2 x 4 pixels, 8 columns apart) cover all 64 banks once.
 // Every block ends with its partial sums (72 KB) in the workspace; k_conv3x3_wgrad_reduce adds the blocks of a
 // (Cout block, Cin block) quadrant and writes dW through the weight's strides.
-typedef __attribute__((ext_vector_type(4))) short i16x4;
 #define WG_XPLANE (CV_HP * 64)          // 11 520
 #define WG_LDS (3 * WG_XPLANE)          // 34 560
 #define WG_PART (9 * 2 * 4 * 256)       // floats per block partial
@@ -346,12 +334,6 @@ struct WgradArgs {
   float* ws;          // (blocks, WG_PART)
   int B, H, W, Cin, Cout, tiles_x, tiles_y, ntiles, nq_ci, nq, P;
 };
-
-__device__ __forceinline__ bf16x8 wg_join(i16x4 lo, i16x4 hi) {
-  typedef __attribute__((ext_vector_type(8))) short i16x8;
-  i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, v);
-}
 
 __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];

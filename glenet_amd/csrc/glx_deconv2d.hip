@@ -1,0 +1,405 @@
+// glx_deconv2d.hip -- the transposed convolutions of the BEV backbone's upsampling branch (SURVEY 8a row a21;
+// pcdet/models/backbones_2d/base_bev_backbone.py:51-66: ConvTranspose2d(c, cu, u, stride=u), u = 1 or 2) on
+// channels-last fp32 maps, with the split-bf16 arithmetic of glx_conv2d.hip (fp32 products as six bf16 MFMAs).
+//
+// With kernel = stride = u a transposed convolution has no overlapping taps: output pixel (u y + dy, u x + dx) is
+// x[y][x] times the (Cin x Cout) slice W[:, :, dy, dx].  On the COARSE grid (the input's) that is
+//   forward         y[(u y + dy, u x + dx)][co] = sum_ci        x[(y, x)][ci]              W[ci][co][dy][dx]
+//   input gradient  gx[(y, x)][ci]              = sum_(dy,dx,co) gy[(u y + dy, u x + dx)][co] W[ci][co][dy][dx]
+//   weight gradient dW[ci][co][dy][dx]          = sum_(y,x)     x[(y, x)][ci]              gy[(u y + dy, u x + dx)][co]
+// i.e. pixel-row GEMMs whose rows are gathered from / scattered to a strided pixel set.  k_pconv runs the first two:
+// 128 consecutive coarse pixels x 64 output channels per block, K = (input tap) x (32-channel chunk); the rows of a step
+// are loaded one step ahead (fp32, 128-byte pieces), split into three bf16 planes in LDS (80-byte rows), the weight
+// slices stream L2 -> registers -> LDS as in k_conv3x3.  k_pconv_wgrad runs the third like k_conv3x3_wgrad: gy (one
+// alignment per tap) straight into registers, the x tile through the transposing LDS read, block partials + a reduce.
+#include "glx_common.h"
+#include "glx_bf16x3.h"
+
+#define PC_TM 128                        // coarse pixels per block
+#define PC_ROW 80
+#define PC_APLANE (PC_TM * PC_ROW)       // 10 240
+#define PC_BN 64
+#define PC_WPLANE (PC_BN * PC_ROW)       // 5 120
+#define PC_WBUF (3 * PC_WPLANE)
+#define PC_LDS (3 * PC_APLANE + 2 * PC_WBUF)   // 61 440: two blocks per CU
+
+// W (Cin, Cout, u, u) with element strides ->
+//   fwd [ntap = (dy, dx)][chunk of Cin][3][Cout][32]             (rows x, K = Cin, columns Cout, one slice per output tap)
+//   bwd [ktap = (dy, dx)][chunk of Cout][3][Cin][32]             (rows gy at the tap's pixels, K = Cout per tap, columns Cin)
+__global__ void k_pconv_pack(const float* __restrict__ W, long long s_ci, long long s_co, long long s_kh, long long s_kw,
+                             int Cin, int Cout, int u, uint16_t* __restrict__ fwd, uint16_t* __restrict__ bwd) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= Cin * Cout * u * u) return;
+  const int co = e % Cout, ci = (e / Cout) % Cin, tap = e / (Cin * Cout);
+  const float w = W[ci * s_ci + co * s_co + (tap / u) * s_kh + (tap % u) * s_kw];
+  __bf16 p[3];
+  cv_split(w, p[0], p[1], p[2]);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const uint16_t bits = __builtin_bit_cast(uint16_t, p[q]);
+    if (fwd) fwd[((((size_t)tap * (Cin / 32) + ci / 32) * 3 + q) * Cout + co) * 32 + (ci & 31)] = bits;
+    if (bwd) bwd[((((size_t)tap * (Cout / 32) + co / 32) * 3 + q) * Cin + ci) * 32 + (co & 31)] = bits;
+  }
+}
+
+struct PconvArgs {
+  const float* x;       // rows gathered from here: (B, Hc * ui, Wc * ui, Ck)
+  const uint16_t* wp;   // [ntaps][ktaps][Ck / 32][3][N][32]
+  float* y;             // rows scattered to here: (B, Hc * uo, Wc * uo, N)
+  int B, Hc, Wc;        // the coarse grid
+  int Ck, N;            // channels per input tap, output channels
+  int ui, uo;           // pixel stride of the input / output map relative to the coarse grid (one of them is 1)
+  int ktaps, ntaps;     // ui * ui, uo * uo
+  int M, mtiles, nblk, nunits;
+};
+
+__global__ __launch_bounds__(256, 2) void k_pconv(PconvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;
+  char* sW = smem + 3 * PC_APLANE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const int nch = a.Ck >> 5, nsteps = a.ktaps * nch;
+  const size_t wslice = (size_t)a.N * 32;
+  const int wdst = (tid >> 2) * PC_ROW + (tid & 3) * 16;
+  const int hw = a.Hc * a.Wc;
+
+  for (int unit = blockIdx.x; unit < a.nunits; unit += gridDim.x) {
+    // unit -> (pixel tile, output tap, channel block): the taps and channel blocks of a tile run side by side
+    int t = unit;
+    const int n0 = (t % a.nblk) * PC_BN;
+    t /= a.nblk;
+    const int ntap = t % a.ntaps;
+    const int m0 = (t / a.ntaps) * PC_TM;
+    const uint16_t* wsrc = a.wp + ((size_t)ntap * nsteps * 3) * wslice + (size_t)n0 * 32 + tid * 8;
+
+    // the thread's four 16-byte pieces of a step's rows: pixel m0 + (e >> 3), channels 4 (e & 7) ..
+    long long abase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256, m = m0 + (e >> 3);
+      if (m < a.M) {
+        const int b = m / hw, rem = m - b * hw, y = rem / a.Wc, x = rem - y * a.Wc;
+        abase[i] = (((long long)b * a.Hc * a.ui + (long long)y * a.ui) * (a.Wc * a.ui) + (long long)x * a.ui) * a.Ck + (e & 7) * 4;
+      } else {
+        abase[i] = -1;
+      }
+    }
+    f32x4 areg[4];
+    uint4 wreg0, wreg1, wreg2;
+#define PC_LOAD(STEP)                                                                                          \
+  {                                                                                                            \
+    const int kt_ = (STEP) / nch, ch_ = (STEP) - kt_ * nch;                                                    \
+    const long long off_ = ((long long)(kt_ / a.ui) * (a.Wc * a.ui) + (kt_ % a.ui)) * a.Ck + ch_ * 32;         \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                           \
+      areg[i_] = abase[i_] >= 0 ? *reinterpret_cast<const f32x4*>(a.x + abase[i_] + off_) : f32x4{0.f, 0.f, 0.f, 0.f}; \
+    const uint16_t* s_ = wsrc + (size_t)(STEP) * 3 * wslice;                                                   \
+    wreg0 = *reinterpret_cast<const uint4*>(s_);                                                               \
+    wreg1 = *reinterpret_cast<const uint4*>(s_ + wslice);                                                      \
+    wreg2 = *reinterpret_cast<const uint4*>(s_ + 2 * wslice);                                                  \
+  }
+#define PC_STORE(BUF)                                                                                          \
+  {                                                                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                         \
+      const int e_ = tid + i_ * 256;                                                                           \
+      char* d_ = sA + (e_ >> 3) * PC_ROW + (e_ & 7) * 8;                                                       \
+      bf16x4 p0_, p1_, p2_;                                                                                    \
+      _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                       \
+        __bf16 u_, v_, w_;                                                                                     \
+        cv_split(areg[i_][j_], u_, v_, w_);                                                                    \
+        p0_[j_] = u_; p1_[j_] = v_; p2_[j_] = w_;                                                              \
+      }                                                                                                        \
+      *reinterpret_cast<bf16x4*>(d_) = p0_;                                                                    \
+      *reinterpret_cast<bf16x4*>(d_ + PC_APLANE) = p1_;                                                        \
+      *reinterpret_cast<bf16x4*>(d_ + 2 * PC_APLANE) = p2_;                                                    \
+    }                                                                                                          \
+    char* w_ = sW + (BUF) * PC_WBUF + wdst;                                                                    \
+    *reinterpret_cast<uint4*>(w_) = wreg0;                                                                     \
+    *reinterpret_cast<uint4*>(w_ + PC_WPLANE) = wreg1;                                                         \
+    *reinterpret_cast<uint4*>(w_ + 2 * PC_WPLANE) = wreg2;                                                     \
+  }
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    PC_LOAD(0);
+    __syncthreads();                      // the previous unit's reads of the images are done
+    PC_STORE(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+      const int cur = s & 1;
+      if (s + 1 < nsteps) { PC_LOAD(s + 1); }
+      bf16x8 xa[2][3], wa[4][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          xa[i][q] = *reinterpret_cast<const bf16x8*>(sA + q * PC_APLANE + ((2 * wave + i) * 16 + r) * PC_ROW + kq * 16);
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          wa[n][q] = *reinterpret_cast<const bf16x8*>(sW + cur * PC_WBUF + q * PC_WPLANE + (n * 16 + r) * PC_ROW + kq * 16);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) BF3_MFMA6(acc[i][n], wa[n], xa[i]);
+      if (s + 1 < nsteps) {
+        __syncthreads();                  // everyone has read the row image
+        PC_STORE(cur ^ 1);
+        __syncthreads();
+      }
+    }
+#undef PC_LOAD
+#undef PC_STORE
+    // lane (r, kq) of accumulator (i, n) = coarse pixel m0 + (2 wave + i) * 16 + r, channels n0 + 16 n + 4 kq ..
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + (2 * wave + i) * 16 + r;
+      if (m < a.M) {
+        const int b = m / hw, rem = m - b * hw, y = rem / a.Wc, x = rem - y * a.Wc;
+        float* dst = a.y + ((((long long)b * a.Hc + y) * a.uo + ntap / a.uo) * (a.Wc * a.uo) + (long long)x * a.uo + ntap % a.uo) * a.N +
+                     n0 + 4 * kq;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(dst + 16 * n) = acc[i][n];
+      }
+    }
+  }
+}
+
+extern "C" size_t glx_deconv_packed_bytes(int Cin, int Cout, int u) {
+  return glx_align((size_t)u * u * 3 * Cin * Cout * sizeof(uint16_t));
+}
+
+extern "C" int glx_deconv_pack(const float* W, long long s_ci, long long s_co, long long s_kh, long long s_kw, int Cin,
+                               int Cout, int u, void* fwd, void* bwd, void* stream) {
+  GLX_REQUIRE((u == 1 || u == 2) && Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 64 == 0,
+              "glx_deconv_pack: kernel = stride in {1, 2}, channels multiples of 64 (got u=%d, %d -> %d)", u, Cin, Cout);
+  hipLaunchKernelGGL(k_pconv_pack, dim3(glx_divup(Cin * Cout * u * u, 256)), dim3(256), 0, (hipStream_t)stream, W, s_ci, s_co,
+                     s_kh, s_kw, Cin, Cout, u, (uint16_t*)fwd, (uint16_t*)bwd);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+static int pconv_launch(const float* x, const void* packed, float* y, int B, int Hc, int Wc, int Ck, int N, int ui, int uo,
+                        hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    GLX_HIP(hipFuncSetAttribute((const void*)k_pconv, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));
+    attr_set = true;
+  }
+  PconvArgs a;
+  a.x = x; a.wp = (const uint16_t*)packed; a.y = y;
+  a.B = B; a.Hc = Hc; a.Wc = Wc; a.Ck = Ck; a.N = N; a.ui = ui; a.uo = uo;
+  a.ktaps = ui * ui; a.ntaps = uo * uo;
+  a.M = B * Hc * Wc;
+  a.mtiles = glx_divup(a.M, PC_TM);
+  a.nblk = N / PC_BN;
+  a.nunits = a.mtiles * a.ntaps * a.nblk;
+  static int slots = 0;
+  if (!slots) {
+    int dev = 0, cus = 0;
+    GLX_HIP(hipGetDevice(&dev));
+    GLX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    slots = 2 * (cus > 0 ? cus : 256);
+  }
+  hipLaunchKernelGGL(k_pconv, dim3(a.nunits < slots ? a.nunits : slots), dim3(256), PC_LDS, st, a);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+extern "C" int glx_deconv_forward(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, int u,
+                                  float* y, void* stream) {
+  GLX_REQUIRE(B > 0 && H > 0 && W > 0 && (u == 1 || u == 2) && Cin % 64 == 0 && Cout % 64 == 0,
+              "glx_deconv_forward: bad sizes (%d, %d, %d), u=%d, %d -> %d", B, H, W, u, Cin, Cout);
+  return pconv_launch(x, packed_fwd, y, B, H, W, Cin, Cout, 1, u, (hipStream_t)stream);
+}
+
+extern "C" int glx_deconv_input_grad(const float* gy, int B, int H, int W, int Cin, const void* packed_bwd, int Cout, int u,
+                                     float* gx, void* stream) {
+  GLX_REQUIRE(B > 0 && H > 0 && W > 0 && (u == 1 || u == 2) && Cin % 64 == 0 && Cout % 64 == 0,
+              "glx_deconv_input_grad: bad sizes (%d, %d, %d), u=%d, %d -> %d", B, H, W, u, Cin, Cout);
+  return pconv_launch(gy, packed_bwd, gx, B, H, W, Cout, Cin, u, 1, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+#define PW_XPLANE (PC_TM * 64)           // 8 192: [pixel][32 ci] bf16, the two 32-byte halves swapped on odd 8-pixel groups
+#define PW_LDS (3 * PW_XPLANE)
+
+struct PwgradArgs {
+  const float* x;     // (B, Hc, Wc, Cin)
+  const float* gy;    // (B, Hc * u, Wc * u, Cout)
+  float* ws;          // (blocks, taps * 2 * 4 * 256)
+  int B, Hc, Wc, Cin, Cout, u, taps, M, mtiles, nq_ci, nq, P;
+};
+
+// A block owns (64 Cout x 32 Cin x u*u taps) over its coarse-pixel tiles; wave = one 16-channel tile of Cout.
+// Needs Wc % 8 == 0 (a lane's 8 consecutive coarse pixels share a row).
+template <int TAPS>
+__global__ __launch_bounds__(256, 2) void k_pconv_wgrad(PwgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, kq = lane >> 4;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int q = j % a.nq, p = (j / a.nq) * 8 + xcd;
+  const int ib = q % a.nq_ci, cb = q / a.nq_ci;
+  const int hw = a.Hc * a.Wc, u = a.u;
+  const long long gyrow = (long long)a.Wc * u * a.Cout;        // floats per fine row
+
+  f32x4 acc[TAPS][2];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int qq = (lane & 15) >> 2, pp = lane & 3;
+  int rbase[2];           // lane's part of a transposing read of k-step 0: pixel 8 kq + 4 h + qq, 4 channels at pp
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int px = 8 * kq + 4 * h + qq;
+    rbase[h] = px * 64 + (((px >> 3) & 1) << 5) + pp * 8;
+  }
+
+  for (int tile = p; tile < a.mtiles; tile += a.P) {
+    const int m0 = tile * PC_TM;
+    // ---- x tile -> LDS (three planes)
+    f32x4 areg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256, m = m0 + (e >> 3);
+      areg[i] = m < a.M ? *reinterpret_cast<const f32x4*>(a.x + (long long)m * a.Cin + ib * 32 + (e & 7) * 4)
+                        : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // the lane's gy pixels: k-step s -> coarse pixels m0 + 32 s + 8 kq + jj, jj = 0..7 (one row: Wc % 8 == 0)
+    long long gbase[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int m = m0 + 32 * s + 8 * kq;
+      if (m < a.M) {
+        const int b = m / hw, rem = m - b * hw, y = rem / a.Wc, x = rem - y * a.Wc;
+        gbase[s] = ((long long)b * a.Hc + y) * u * gyrow + (long long)x * u * a.Cout + cb * 64 + wave * 16 + c;
+      } else {
+        gbase[s] = -1;
+      }
+    }
+    __syncthreads();          // the previous tile's reads of the image are done
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256, px = e >> 3, seg = e & 7;
+      char* d = smem + px * 64 + (((seg >> 2) ^ ((px >> 3) & 1)) << 5) + (seg & 3) * 8;
+      bf16x4 p0, p1, p2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        __bf16 uu, vv, ww;
+        cv_split(areg[i][k], uu, vv, ww);
+        p0[k] = uu; p1[k] = vv; p2[k] = ww;
+      }
+      *reinterpret_cast<bf16x4*>(d) = p0;
+      *reinterpret_cast<bf16x4*>(d + PW_XPLANE) = p1;
+      *reinterpret_cast<bf16x4*>(d + 2 * PW_XPLANE) = p2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const long long toff = (long long)(t / u) * gyrow + (long long)(t % u) * a.Cout;
+      bf16x8 ga[4][3];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const float g = gbase[s] >= 0 ? a.gy[gbase[s] + toff + (long long)jj * u * a.Cout] : 0.f;
+          __bf16 uu, vv, ww;
+          cv_split(g, uu, vv, ww);
+          ga[s][0][jj] = uu; ga[s][1][jj] = vv; ga[s][2][jj] = ww;
+        }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          bf16x8 xb[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            typedef i16x4 __attribute__((address_space(3))) * lds_p;
+            const int off = pl * PW_XPLANE + s * 32 * 64;
+            i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(smem + off + (rbase[0] ^ (n << 5))));
+            i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(smem + off + (rbase[1] ^ (n << 5))));
+            xb[pl] = wg_join(lo, hi);
+          }
+          BF3_MFMA6(acc[t][n], ga[s], xb);
+        }
+    }
+  }
+  // ---- the block's partial sums: element ((tap * 2 + n) * 4 + reg) * 256 + tid
+  float* dst = a.ws + (size_t)(q * a.P + p) * (TAPS * 2 * 4 * 256) + tid;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) dst[((t * 2 + n) * 4 + rg) * 256] = acc[t][n][rg];
+}
+
+// 64 partial elements x 4 segments of the quadrant's blocks per 256 threads; dW (Cin, Cout, u, u) through its strides
+__global__ __launch_bounds__(256) void k_pconv_wgrad_reduce(const float* __restrict__ ws, int P, int nq_ci, int part, int u,
+                                                            float* __restrict__ dW, long long s_ci, long long s_co,
+                                                            long long s_kh, long long s_kw) {
+  __shared__ float psum[4][64];
+  const int q = blockIdx.y, el = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
+  const float* src = ws + (size_t)q * P * part + e;
+  float sum = 0.f;
+  for (int pb = seg; pb < P; pb += 4) sum += src[(size_t)pb * part];
+  psum[seg][el] = sum;
+  __syncthreads();
+  if (seg == 0) {
+    sum = (psum[0][el] + psum[1][el]) + (psum[2][el] + psum[3][el]);
+    const int tap = e >> 11, n = (e >> 10) & 1, rg = (e >> 8) & 3, t = e & 255;
+    const int wave = t >> 6, lane = t & 63;
+    const int ib = q % nq_ci, cb = q / nq_ci;
+    const int co = cb * 64 + wave * 16 + 4 * (lane >> 4) + rg, ci = ib * 32 + n * 16 + (lane & 15);
+    dW[ci * s_ci + co * s_co + (tap / u) * s_kh + (tap % u) * s_kw] = sum;
+  }
+}
+
+static int pwgrad_blocks(int Cin, int Cout, int* P_out) {
+  const int nq = (Cin / 32) * (Cout / 64);
+  int P = 512 / nq / 8 * 8;
+  if (P < 8) P = 8;
+  *P_out = P;
+  return nq * P;
+}
+
+extern "C" size_t glx_deconv_wgrad_workspace_bytes(int Cin, int Cout, int u) {
+  int P = 0;
+  return glx_align((size_t)pwgrad_blocks(Cin, Cout, &P) * u * u * 2 * 4 * 256 * sizeof(float));
+}
+
+extern "C" int glx_deconv_wgrad(const float* x, const float* gy, int B, int H, int W, int Cin, int Cout, int u, float* dW,
+                                long long s_ci, long long s_co, long long s_kh, long long s_kw, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(B > 0 && H > 0 && W > 0 && (u == 1 || u == 2) && Cin % 64 == 0 && Cout % 64 == 0 && W % 8 == 0,
+              "glx_deconv_wgrad: bad sizes (%d, %d, %d), u=%d, %d -> %d (needs W %% 8 == 0)", B, H, W, u, Cin, Cout);
+  GLX_REQUIRE(workspace_bytes >= glx_deconv_wgrad_workspace_bytes(Cin, Cout, u), "glx_deconv_wgrad: workspace too small");
+  PwgradArgs a;
+  a.x = x; a.gy = gy; a.ws = (float*)workspace;
+  a.B = B; a.Hc = H; a.Wc = W; a.Cin = Cin; a.Cout = Cout; a.u = u; a.taps = u * u;
+  a.M = B * H * W;
+  a.mtiles = glx_divup(a.M, PC_TM);
+  a.nq_ci = Cin / 32;
+  a.nq = a.nq_ci * (Cout / 64);
+  const int blocks = pwgrad_blocks(Cin, Cout, &a.P);
+  hipStream_t st = (hipStream_t)stream;
+  if (u == 1)
+    hipLaunchKernelGGL(k_pconv_wgrad<1>, dim3(blocks), dim3(256), PW_LDS, st, a);
+  else
+    hipLaunchKernelGGL(k_pconv_wgrad<4>, dim3(blocks), dim3(256), PW_LDS, st, a);
+  GLX_LAUNCH_CHECK();
+  const int part = a.taps * 2 * 4 * 256;
+  hipLaunchKernelGGL(k_pconv_wgrad_reduce, dim3(part / 64, a.nq), dim3(256), 0, st, a.ws, a.P, a.nq_ci, part, u, dW, s_ci,
+                     s_co, s_kh, s_kw);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

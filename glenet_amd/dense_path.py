@@ -68,6 +68,7 @@ class _ConvSplitBackward(torch.autograd.Function):
 
 SPLIT_CONV_BACKWARD = os.environ.get("GLX_SPLIT_CONV_BWD", "1") != "0"
 OWN_CONV3X3 = os.environ.get("GLX_OWN_CONV3X3", "1") != "0"     # 3x3 / stride 1 layers on csrc/glx_conv2d.hip
+OWN_DECONV = os.environ.get("GLX_OWN_DECONV", "1") != "0"       # the deblocks' transposed convolutions on csrc/glx_deconv2d.hip
 BEV_FIRST_KEY = "bev_first"      # indice_key of the first BEV layer's rule table (spconv.core.PlannedConv)
 SPARSE_FIRST_BEV_LAYER = os.environ.get("GLX_BEV_SPARSE_FIRST", "1") != "0"   # see BEVBackbone._first_layer_sparse
 FUSE_BN_IN_CONV3X3 = os.environ.get("GLX_CONV3X3_BN", "1") != "0"    # ... with the next BatchNorm's statistics in the epilogue
@@ -102,6 +103,9 @@ def conv_module(m, x):
     if (isinstance(m, nn.Conv2d) and not isinstance(m.padding, str) and getattr(m, "padding_mode", "zeros") == "zeros"
             and OWN_CONV3X3 and x.is_cuda):
         return conv2d(x, m.weight, m.bias, m.stride, m.padding, m.dilation, m.groups)
+    if (isinstance(m, nn.ConvTranspose2d) and OWN_DECONV and x.is_cuda and _leaf(m.weight) and own_conv.deconv_supported(
+            x, m.weight, _pair(m.stride), _pair(m.padding), _pair(m.output_padding), _pair(m.dilation), m.groups, m.bias)):
+        return own_conv.deconv(x, m.weight)
     if (SPLIT_CONV_BACKWARD and x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or m.weight.requires_grad)
             and getattr(m, "padding_mode", "zeros") == "zeros" and not isinstance(m.padding, str)
             and _leaf(m.weight) and _leaf(m.bias)):

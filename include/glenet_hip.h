@@ -835,6 +835,23 @@ size_t glx_conv3x3_wgrad_workspace_bytes(int Cin, int Cout);
 int glx_conv3x3_wgrad(const float* x, const float* gy, int B, int H, int W, int Cin, int Cout, float* dW,
                       long long s_co, long long s_ci, long long s_kh, long long s_kw, void* workspace,
                       size_t workspace_bytes, void* stream);
+/* ---- transposed convolutions with kernel = stride = u in {1, 2}, no padding (BaseBEVBackbone's deblocks,
+ * base_bev_backbone.py:51-66: ConvTranspose2d(c, cu, u, stride=u, bias=False)), channels-last fp32 maps, same split-bf16
+ * arithmetic (csrc/glx_deconv2d.hip).  W (Cin, Cout, u, u) with ELEMENT strides (s_ci, s_co, s_kh, s_kw); channel counts
+ * multiples of 64.  glx_deconv_pack writes the piece images for the forward (`fwd`) and / or the input gradient (`bwd`),
+ * glx_deconv_packed_bytes(Cin, Cout, u) bytes each.  x (B, H, W, Cin) -> y (B, u H, u W, Cout); gy -> gx likewise;
+ * glx_deconv_wgrad overwrites dW (needs W % 8 == 0).  Replaces cuDNN's three calls for these layers. */
+size_t glx_deconv_packed_bytes(int Cin, int Cout, int u);
+int glx_deconv_pack(const float* W, long long s_ci, long long s_co, long long s_kh, long long s_kw, int Cin, int Cout,
+                    int u, void* fwd, void* bwd, void* stream);
+int glx_deconv_forward(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, int u, float* y,
+                       void* stream);
+int glx_deconv_input_grad(const float* gy, int B, int H, int W, int Cin, const void* packed_bwd, int Cout, int u,
+                          float* gx, void* stream);
+size_t glx_deconv_wgrad_workspace_bytes(int Cin, int Cout, int u);
+int glx_deconv_wgrad(const float* x, const float* gy, int B, int H, int W, int Cin, int Cout, int u, float* dW,
+                     long long s_ci, long long s_co, long long s_kh, long long s_kw, void* workspace,
+                     size_t workspace_bytes, void* stream);
 /* Experiments only: blocks per launch of glx_conv3x3_forward (0 = two per CU) and timing-only ablations of its loop. */
 int glx_conv3x3_set_grid(int blocks, int ablate);
 

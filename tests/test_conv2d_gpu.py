@@ -188,3 +188,26 @@ def test_pack_cache_is_not_fooled_by_a_new_weight_at_a_freed_address(dev):
         del wt
     for y, ref in outs:
         assert torch.allclose(y, ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 128, 1, 24, 40), (2, 128, 128, 2, 13, 24), (1, 128, 64, 2, 50, 88), (3, 64, 64, 1, 7, 8)])
+def test_transposed_convolutions_match_fp64(dev, shape):
+    """ConvTranspose2d(c, cu, u, stride=u) on the own kernels: forward, input gradient and weight gradient against fp64,
+    and exactly on integer data (asymmetric filters)."""
+    from glenet_amd import conv2d as c2
+    b, cin, cout, u, h, w = shape
+    g = torch.Generator(device=dev).manual_seed(sum(shape))
+    x = _cl(torch.randn(b, cin, h, w, device=dev, generator=g)).requires_grad_(True)
+    wt = torch.nn.Parameter(torch.randn(cin, cout, u, u, device=dev, generator=g) / cin ** 0.5)
+    gy = _cl(torch.randn(b, cout, h * u, w * u, device=dev, generator=g))
+    y = c2.deconv(x, wt)
+    assert y.shape == (b, cout, h * u, w * u) and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(gy)
+    xd, wd = x.detach().double().requires_grad_(True), wt.detach().double().requires_grad_(True)
+    ref = F.conv_transpose2d(xd, wd, None, stride=u)
+    ref.backward(gy.double())
+    for a, r, tol in ((y, ref, 4e-6), (x.grad, xd.grad, 4e-6), (wt.grad, wd.grad, 2e-5)):
+        assert (a.double() - r).abs().max() < tol * r.abs().max(), (float((a.double() - r).abs().max()), float(r.abs().max()))
+    xi = _cl(torch.randint(-8, 9, (b, cin, h, w), device=dev, generator=g).float())
+    wi = torch.randint(-4, 5, (cin, cout, u, u), device=dev, generator=g).float()
+    assert torch.equal(c2.deconv(xi, wi).double().cpu(), F.conv_transpose2d(xi.double().cpu(), wi.double().cpu(), None, stride=u))
