@@ -72,6 +72,7 @@ struct ConvArgs {
   int B, H, W, Cin, Cout, tiles_x, tiles_y, nblk, ntiles;   // nblk = Cout / 64; ntiles = B * tiles_y * tiles_x * nblk
   BnState* bn_state;     // STATS: training-mode BatchNorm statistics of y taken in the epilogue
   BnFinalize bn;
+  long long* stamps;     // diagnostics (glx_conv3x3_set_stamps): per block, shader-clock and 100 MHz-clock ticks of its lifetime
 };
 
 struct ConvTile {
@@ -105,22 +106,22 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
   int tile = blockIdx.x;
   if (tile >= a.ntiles) return;
   ConvTile ct = cv_tile(a, tile);
+  long long stamp_c = 0, stamp_r = 0;
+  if (a.stamps) {
+    stamp_c = __builtin_amdgcn_s_memtime();
+    stamp_r = __builtin_amdgcn_s_memrealtime();
+  }
 
   // the thread's pieces of the halo: element offsets into x (without the chunk), -1 outside the map
-  long long aoff[CV_ALOADS];
-  int adst[CV_ALOADS];
-#pragma unroll
-  for (int i = 0; i < CV_ALOADS; ++i) {
-    const int e = tid + i * 256;
-    adst[i] = e < CV_HP * 8 ? (e >> 3) * CV_ROW + (e & 7) * 8 : -1;
-  }
+  int aoff[CV_ALOADS];                 // (the entry point checks that the map has fewer than 2^31 elements)
+  const int adst0 = (tid >> 3) * CV_ROW + (tid & 7) * 8;      // piece i of the thread: halo pixel (tid >> 3) + 32 i
 #define CV_HALO(T)                                                                                      \
   _Pragma("unroll") for (int i_ = 0; i_ < CV_ALOADS; ++i_) {                                            \
     const int e_ = tid + i_ * 256;                                                                      \
     const int hp_ = e_ >> 3, seg_ = e_ & 7;                                                             \
     const int gy_ = (T).y0 - 1 + hp_ / CV_HW, gx_ = (T).x0 - 1 + hp_ % CV_HW;                           \
     const bool ok_ = e_ < CV_HP * 8 && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W;                  \
-    aoff[i_] = ok_ ? (((long long)(T).b * a.H + gy_) * a.W + gx_) * a.Cin + seg_ * 4 : -1;              \
+    aoff[i_] = ok_ ? (((T).b * a.H + gy_) * a.W + gx_) * a.Cin + seg_ * 4 : -1;                         \
   }
   // the thread's 16-byte piece of each plane of a weight slice
   const size_t wslice = (size_t)a.Cout * 32;                       // bf16 elements per plane of a (tap, chunk)
@@ -148,16 +149,17 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
   }
 #define CV_STORE_A()                                                                                    \
   _Pragma("unroll") for (int i_ = 0; i_ < CV_ALOADS; ++i_) {                                            \
-    if (adst[i_] >= 0) {                                                                                \
+    if (tid + i_ * 256 < CV_HP * 8) {                                                                   \
+      char* d_ = sA + adst0 + i_ * 32 * CV_ROW;                                                         \
       bf16x4 p0_, p1_, p2_;                                                                             \
       _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                \
         __bf16 u_, v_, w_;                                                                              \
         cv_split(areg[i_][j_], u_, v_, w_);                                                             \
         p0_[j_] = u_; p1_[j_] = v_; p2_[j_] = w_;                                                       \
       }                                                                                                 \
-      *reinterpret_cast<bf16x4*>(sA + adst[i_]) = p0_;                                                  \
-      *reinterpret_cast<bf16x4*>(sA + CV_APLANE + adst[i_]) = p1_;                                      \
-      *reinterpret_cast<bf16x4*>(sA + 2 * CV_APLANE + adst[i_]) = p2_;                                  \
+      *reinterpret_cast<bf16x4*>(d_) = p0_;                                                             \
+      *reinterpret_cast<bf16x4*>(d_ + CV_APLANE) = p1_;                                                 \
+      *reinterpret_cast<bf16x4*>(d_ + 2 * CV_APLANE) = p2_;                                             \
     }                                                                                                   \
   }
 
@@ -234,6 +236,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
           for (int q = 0; q < 3; ++q)
             wa[n][q] = *reinterpret_cast<const bf16x8*>(wBase + cur * CV_WBUF + q * CV_WPLANE + n * 16 * CV_ROW);
         }
+        // all 18 operand reads are issued before the first product (the scheduler otherwise feeds them in just in
+        // time, an exposed LDS latency every few MFMAs: ~250 waits per tile)
+        __builtin_amdgcn_sched_barrier(0);
         // smallest terms first; rows of the product = output channels (a lane ends up with 4 consecutive channels)
 #define CV_TERM(QW, QX)                                                                     \
   _Pragma("unroll") for (int i = 0; i < 2; ++i)                                             \
@@ -247,6 +252,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
           CV_TERM(0, 1)
         }
         CV_TERM(0, 0)
+        __builtin_amdgcn_sched_barrier(0);
         if (tap < 8) { CV_STORE_W(cur ^ 1); }
         if (!(ABL & 4)) __syncthreads();   // experiment 4: no barrier
       }
@@ -276,6 +282,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
     tile = next;
     ct = nt;
     wsrc = wnext;
+  }
+  if (a.stamps && tid == 0) {
+    a.stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - stamp_c;
+    a.stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r;
   }
   if (STATS) {
     double* red = reinterpret_cast<double*>(smem);          // [wave][moment][64 channels]
@@ -309,6 +319,154 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
                gridDim.x - 1;
     __syncthreads();
     if (s_last) bn_finalize_sets<false, 256>(a.bn_state, a.bn, a.Cout, a.B * a.H * a.W, reinterpret_cast<double(*)[2]>(smem));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ forward, second form
+// Same tile (8 x 16 pixels x 64 channels, 4 waves), other split: wave w owns ONE 16-channel tile for all eight pixel
+// rows.  Its weight fragments (3 planes x 16 bytes per lane per step) then belong to it alone and come straight from
+// L2 into the MFMA operand registers, one step ahead -- no weight image in LDS, no barrier per tap: the halo image only
+// changes per 32-channel chunk, so a block synchronises twice per NINE taps instead of once per tap, and with 43 KB of
+// LDS three blocks share a CU.  The price is 24 instead of 6 row-operand reads per wave and step (every wave reads the
+// whole tile): 96 instead of 72 LDS reads per block and step, none of them weights.
+#define CV2_LDS (3 * CV_APLANE)          // 43 200: three blocks per CU
+
+template <bool STATS>
+__global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const int nch = a.Cin >> 5;
+  int tile = blockIdx.x;
+  if (tile >= a.ntiles) return;
+  ConvTile ct = cv_tile(a, tile);
+
+  int aoff[CV_ALOADS];
+  const int adst0 = (tid >> 3) * CV_ROW + (tid & 7) * 8;
+  const size_t wslice = (size_t)a.Cout * 32;
+  // the lane's 16 bytes of a plane of a weight slice: channel n0 + 16 wave + r, k = 8 kq ..
+  const uint16_t* wsrc = a.wp + (size_t)(ct.n0 + 16 * wave + r) * 32 + kq * 8;
+  f32x4 areg[CV_ALOADS];
+  bf16x8 wcur[3], wnxt[3];
+#define V2_LOAD_W(DST, SRC, TAP, CH)                                                                    \
+  {                                                                                                     \
+    const uint16_t* s_ = (SRC) + ((size_t)(TAP) * nch + (CH)) * 3 * wslice;                             \
+    DST[0] = *reinterpret_cast<const bf16x8*>(s_);                                                      \
+    DST[1] = *reinterpret_cast<const bf16x8*>(s_ + wslice);                                             \
+    DST[2] = *reinterpret_cast<const bf16x8*>(s_ + 2 * wslice);                                         \
+  }
+  float ssum[4], ssq[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) ssum[g] = ssq[g] = 0.f;
+  const int stats_n0 = ct.n0;
+
+  CV_HALO(ct);
+  CV_LOAD_A(0);
+  V2_LOAD_W(wnxt, wsrc, 0, 0);
+  const char* aBase = sA + kq * 16;
+  while (true) {
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int next = tile + gridDim.x;
+    const bool has_next = next < a.ntiles;
+    ConvTile nt = ct;
+    const uint16_t* wnext_src = wsrc;
+    if (has_next) {
+      nt = cv_tile(a, next);
+      wnext_src = a.wp + (size_t)(nt.n0 + 16 * wave + r) * 32 + kq * 8;
+    }
+    for (int ch = 0; ch < nch; ++ch) {
+      __syncthreads();                    // everyone is done reading the previous halo image
+      CV_STORE_A();
+      __syncthreads();
+      const bool last = ch + 1 == nch;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) wcur[q] = wnxt[q];
+        if (tap < 8) {
+          V2_LOAD_W(wnxt, wsrc, tap + 1, ch);
+        } else if (!last) {
+          V2_LOAD_W(wnxt, wsrc, 0, ch + 1);
+        } else if (has_next) {
+          V2_LOAD_W(wnxt, wnext_src, 0, 0);
+        }
+        if (tap == 6) {
+          if (!last) {
+            CV_LOAD_A(ch + 1);
+          } else if (has_next) {
+            CV_HALO(nt);
+            CV_LOAD_A(0);
+          }
+        }
+        const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+        for (int part = 0; part < 4; ++part) {     // two pixel rows at a time: 6 operand reads, 12 products
+          bf16x8 xa[2][3];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int hp = (2 * part + i + dy) * CV_HW + r + dx;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) xa[i][q] = *reinterpret_cast<const bf16x8*>(aBase + q * CV_APLANE + hp * CV_ROW);
+          }
+          __builtin_amdgcn_sched_barrier(0);       // this part's reads, then its products: keeps the scheduler from
+#pragma unroll
+          for (int i = 0; i < 2; ++i) BF3_MFMA6(acc[2 * part + i], wcur, xa[i]);
+          __builtin_amdgcn_sched_barrier(0);       // hoisting later parts' operands (170-register budget, 3 waves / SIMD)
+        }
+      }
+    }
+    // ---- epilogue: accumulator i = pixel row i, column r; channels n0 + 16 wave + 4 kq ..
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int py = ct.y0 + i, px = ct.x0 + r;
+      if (py < a.H && px < a.W) {
+        *reinterpret_cast<f32x4*>(a.y + (((long long)ct.b * a.H + py) * a.W + px) * a.Cout + ct.n0 + 16 * wave + 4 * kq) = acc[i];
+        if (STATS) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            ssum[g] += acc[i][g];
+            ssq[g] += acc[i][g] * acc[i][g];
+          }
+        }
+      }
+    }
+    if (!has_next) break;
+    tile = next;
+    ct = nt;
+    wsrc = wnext_src;
+  }
+#undef V2_LOAD_W
+  if (STATS) {
+    double* red = reinterpret_cast<double*>(smem);          // [moment][64 channels]
+    __shared__ int s_last2;
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      double d0 = (double)ssum[g], d1 = (double)ssq[g];
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) {
+        d0 += __shfl_xor(d0, m);
+        d1 += __shfl_xor(d1, m);
+      }
+      if (r == 0) {
+        red[16 * wave + 4 * kq + g] = d0;
+        red[64 + 16 * wave + 4 * kq + g] = d1;
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int ch = tid & 63, mom = tid >> 6;
+      double seen = unsafeAtomicAdd(a.bn_state->acc[blockIdx.x % BN_SETS] + mom * BN_MAXC + stats_n0 + ch, red[mom * 64 + ch]);
+      asm volatile("" ::"v"(seen) : "memory");
+    }
+    __syncthreads();
+    if (tid == 0)
+      s_last2 = __hip_atomic_fetch_add(&a.bn_state->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (s_last2) bn_finalize_sets<false, 256>(a.bn_state, a.bn, a.Cout, a.B * a.H * a.W, reinterpret_cast<double(*)[2]>(smem));
   }
 }
 
@@ -580,11 +738,23 @@ extern "C" int glx_conv3x3_pack_multi(int n, const float* const* W, const long l
   return GLX_OK;
 }
 
+static int env_conv_form() {
+  const char* e = getenv("GLX_CONV3X3_FORM");
+  return e ? atoi(e) : 2;
+}
+static int g_conv_form = env_conv_form();   // 1: weight image in LDS (k_conv3x3), 2: weight fragments in registers (k_conv3x3_v2)
 static int g_conv_grid = 0;     // experiments: blocks per launch (0 = two per CU)
 static int g_conv_ablate = 0;   // experiments: timing-only builds of the loop (wrong results), see k_conv3x3
 extern "C" int glx_conv3x3_set_grid(int blocks, int ablate) {
   g_conv_grid = blocks;
-  g_conv_ablate = ablate;
+  g_conv_ablate = ablate & 0xFF;
+  if (ablate >> 8) g_conv_form = ablate >> 8;      // bits 8..: 1 or 2 = the kernel form
+  return GLX_OK;
+}
+
+static long long* g_conv_stamps = nullptr;   // diagnostics: 2 x int64 per block of the following glx_conv3x3_forward launches
+extern "C" int glx_conv3x3_set_stamps(void* stamps) {
+  g_conv_stamps = (long long*)stamps;
   return GLX_OK;
 }
 
@@ -607,13 +777,18 @@ extern "C" int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin,
   GLX_REQUIRE(B > 0 && H > 0 && W > 0, "glx_conv3x3_forward: empty map (%d, %d, %d)", B, H, W);
   GLX_REQUIRE(Cin % 32 == 0 && Cout % CV_BN == 0, "glx_conv3x3_forward: needs Cin %% 32 == 0 and Cout %% 64 == 0 (got %d -> %d)",
               Cin, Cout);
-  GLX_REQUIRE((long long)B * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 40), "glx_conv3x3_forward: map too large");
+  GLX_REQUIRE((long long)B * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31), "glx_conv3x3_forward: map too large (2^31 elements)");
   BnState* bn_state = g_conv_next_bn_state;      // consumed by THIS call whatever happens below
   g_conv_next_bn_state = nullptr;
   GLX_REQUIRE(!bn_state || Cout <= BN_MAXC, "glx_conv3x3_forward: BatchNorm statistics for at most %d channels", BN_MAXC);
   void (*kern)(ConvArgs) = bn_state ? k_conv3x3<0, true> : k_conv3x3<0, false>;
   int slot = bn_state ? 7 : 0;
-  if (!bn_state) {
+  const bool v2 = g_conv_form == 2 && g_conv_ablate == 0;
+  if (v2) {
+    kern = bn_state ? k_conv3x3_v2<true> : k_conv3x3_v2<false>;
+    slot = bn_state ? 6 : 5;      // (slots 5, 6 are ablations nobody selects together with the second form)
+  }
+  if (!bn_state && !v2) {
     switch (g_conv_ablate) {
       case 1: kern = k_conv3x3<1, false>; break;
       case 2: kern = k_conv3x3<2, false>; break;
@@ -627,7 +802,7 @@ extern "C" int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin,
   }
   static bool attr_set[8] = {};
   if (!attr_set[slot]) {
-    GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS));
+    GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, v2 ? CV2_LDS : CV_LDS));
     attr_set[slot] = true;
   }
   ConvArgs a;
@@ -641,13 +816,15 @@ extern "C" int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin,
     int dev = 0, cus = 0;
     GLX_HIP(hipGetDevice(&dev));
     GLX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    slots = 2 * (cus > 0 ? cus : 256);
+    slots = cus > 0 ? cus : 256;
   }
   a.bn_state = bn_state;
   a.bn = g_conv_next_bn;
-  int grid = g_conv_grid > 0 ? g_conv_grid : (a.ntiles < slots ? a.ntiles : slots);
+  a.stamps = g_conv_stamps;
+  const int resident = slots * (v2 ? 3 : 2);
+  int grid = g_conv_grid > 0 ? g_conv_grid : (a.ntiles < resident ? a.ntiles : resident);
   if (bn_state) grid = grid / a.nblk * a.nblk;   // every block keeps one channel block (ntiles is a multiple of nblk)
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), CV_LDS, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), v2 ? CV2_LDS : CV_LDS, (hipStream_t)stream, a);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

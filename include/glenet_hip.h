@@ -854,6 +854,9 @@ int glx_deconv_wgrad(const float* x, const float* gy, int B, int H, int W, int C
                      size_t workspace_bytes, void* stream);
 /* Experiments only: blocks per launch of glx_conv3x3_forward (0 = two per CU) and timing-only ablations of its loop. */
 int glx_conv3x3_set_grid(int blocks, int ablate);
+/* Diagnostics: the following glx_conv3x3_forward launches write, per block, the shader-clock ticks (s_memtime) and the
+ * 100 MHz ticks (s_memrealtime) of its lifetime to stamps[2 * block ..] (NULL: off): their ratio is the clock the chip holds. */
+int glx_conv3x3_set_stamps(void* stamps);
 
 #ifdef __cplusplus
 }

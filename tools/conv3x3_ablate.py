@@ -31,3 +31,24 @@ for (b, cin, cout, h, w) in ((4, 64, 64, 200, 176), (4, 256, 64, 200, 176), (4, 
         out.append("g%d/a%d %.1f" % (grid, abl, t(lambda: c2._run(x, fwd, cout))))
     lib.glx_conv3x3_set_grid(0, 0)
     print((b, cin, cout, h, w), " ".join(out), flush=True)
+    # the clock the chip holds inside the kernel: shader-clock ticks / 100 MHz ticks per block, after 0.5 s of back-to-back launches
+    import ctypes, time
+    stamps = torch.zeros(2 * 512, dtype=torch.int64, device=dev)
+    t0 = time.time()
+    while time.time() - t0 < 0.5:
+        for _ in range(50):
+            c2._run(x, fwd, cout)
+        torch.cuda.synchronize()
+    for abl in (0, 5):
+        lib.glx_conv3x3_set_grid(0, abl)
+        lib.glx_conv3x3_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
+        for _ in range(20):
+            c2._run(x, fwd, cout)
+        torch.cuda.synchronize()
+        lib.glx_conv3x3_set_stamps(None)
+        st = stamps.view(-1, 2).cpu().double()
+        st = st[st[:, 1] > 0]
+        ghz = (st[:, 0] / st[:, 1] * 0.1)
+        print("   ablate %d: in-kernel clock median %.2f GHz (p10 %.2f, p90 %.2f); block lifetime median %.1f us"
+              % (abl, ghz.median(), ghz.quantile(0.1), ghz.quantile(0.9), (st[:, 1] / 100).median()), flush=True)
+    lib.glx_conv3x3_set_grid(0, 0)

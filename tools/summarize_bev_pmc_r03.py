@@ -40,11 +40,17 @@ mfma_ns = sum(a["ns"] for _, a in mfma_rows)
 dense = lambda n: n.startswith(("igemm_", "ck::", "_ZN2ck", "miopen", "Cijk_", "naive_conv"))      # noqa: E731
 d_ns = sum(a["ns"] for n, a in rows if dense(n) and not n.startswith("Cijk_"))
 d_busy = sum(a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) for n, a in rows if dense(n) and not n.startswith("Cijk_"))
-md = ["# GLENet-VR training step: matrix-pipe utilisation per kernel (the BEV head's MIOpen kernels and the rest)", "",
+own = lambda n: n.startswith(("k_conv3x3", "k_pconv"))      # noqa: E731
+o_ns = sum(a["ns"] for n, a in rows if own(n))
+o_busy = sum(a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) for n, a in rows if own(n))
+md = ["# GLENet-VR training step: matrix-pipe utilisation per kernel (the BEV head's kernels and the rest)", "",
       "`bash tools/pmc_bev_r03.sh` (rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA"
       " SQ_WAVES -- python3 bench.py --mode static --steps 6 --warmup 4 ...): the step's own launches (eager, so that"
       " counters attribute per dispatch), 4 frames (BEV map 4 x 256 x 200 x 176, channels-last fp32), last 3 steps.",
-      "", "MIOpen's convolution kernels (BEV backbone + anchor head, forward + backward): %.2f ms per step, matrix pipe busy"
+      "", "The own split-bf16 convolution kernels (csrc/glx_conv2d.hip, glx_deconv2d.hip: `k_conv3x3*`, `k_pconv*`): %.2f ms per"
+      " step, matrix pipe busy **%.2f** of their SIMD-cycles (bf16 MFMAs; six per fp32-equivalent product tile)."
+      % (o_ns / 1e6 / ITERS, o_busy / max(o_ns * GHZ * SIMDS, 1)),
+      "", "MIOpen's convolution kernels (what is left on the vendor library: strided layer, head): %.2f ms per step, matrix pipe busy"
       " **%.2f** of their SIMD-cycles." % (d_ns / 1e6 / ITERS, d_busy / max(d_ns * GHZ * SIMDS, 1)),
       "", "MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (kernel time x %.1f GHz x %d SIMDs) (MI355X_MICROARCH.md,"
       " cycle-constants table; the clock under this load is lower than 2.4 GHz, so the true pipe occupancy is higher than"
