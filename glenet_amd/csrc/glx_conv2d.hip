@@ -70,6 +70,7 @@ struct ConvArgs {
   const uint16_t* wp;    // packed pieces
   float* y;              // (B, H, W, Cout)
   int B, H, W, Cin, Cout, tiles_x, tiles_y, nblk, ntiles;   // nblk = Cout / 64; ntiles = B * tiles_y * tiles_x * nblk
+  int th;                // pixel rows per tile (CV_TH; the second form picks 6, 7 or 8 per launch)
   BnState* bn_state;     // STATS: training-mode BatchNorm statistics of y taken in the epilogue
   BnFinalize bn;
   long long* stamps;     // diagnostics (glx_conv3x3_set_stamps): per block, shader-clock and 100 MHz-clock ticks of its lifetime
@@ -85,7 +86,7 @@ __device__ __forceinline__ ConvTile cv_tile(const ConvArgs& a, int t) {
   t /= a.nblk;
   c.x0 = (t % a.tiles_x) * CV_TW;
   t /= a.tiles_x;
-  c.y0 = (t % a.tiles_y) * CV_TH;
+  c.y0 = (t % a.tiles_y) * a.th;
   c.b = t / a.tiles_y;
   return c;
 }
@@ -329,10 +330,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
 // changes per 32-channel chunk, so a block synchronises twice per NINE taps instead of once per tap, and with 43 KB of
 // LDS three blocks share a CU.  The price is 24 instead of 6 row-operand reads per wave and step (every wave reads the
 // whole tile): 96 instead of 72 LDS reads per block and step, none of them weights.
-#define CV2_LDS (3 * CV_APLANE)          // 43 200: three blocks per CU
+// TH = pixel rows per tile (accumulators per wave), picked per launch so that the tile count fits the resident blocks:
+// 200 rows as 34 tiles of 6 give 1496 tiles = 1.95 rounds of 768 blocks (8 rows: 1100 tiles = 1.43, a second round
+// with 43 % of the blocks); 100 rows as 15 tiles of 7 give one round of 720.
 
-template <bool STATS>
+template <bool STATS, int TH>
 __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
+  constexpr int HP = (TH + 2) * CV_HW, NL = (HP * 8 + 255) / 256, PLANE = HP * CV_ROW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -342,13 +346,39 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
   if (tile >= a.ntiles) return;
   ConvTile ct = cv_tile(a, tile);
 
-  int aoff[CV_ALOADS];
+  int aoff[NL];
   const int adst0 = (tid >> 3) * CV_ROW + (tid & 7) * 8;
   const size_t wslice = (size_t)a.Cout * 32;
   // the lane's 16 bytes of a plane of a weight slice: channel n0 + 16 wave + r, k = 8 kq ..
   const uint16_t* wsrc = a.wp + (size_t)(ct.n0 + 16 * wave + r) * 32 + kq * 8;
-  f32x4 areg[CV_ALOADS];
+  f32x4 areg[NL];
   bf16x8 wcur[3], wnxt[3];
+#define V2_HALO(T)                                                                                      \
+  _Pragma("unroll") for (int i_ = 0; i_ < NL; ++i_) {                                                   \
+    const int e_ = tid + i_ * 256;                                                                      \
+    const int hp_ = e_ >> 3, seg_ = e_ & 7;                                                             \
+    const int gy_ = (T).y0 - 1 + hp_ / CV_HW, gx_ = (T).x0 - 1 + hp_ % CV_HW;                           \
+    const bool ok_ = e_ < HP * 8 && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W;                      \
+    aoff[i_] = ok_ ? (((T).b * a.H + gy_) * a.W + gx_) * a.Cin + seg_ * 4 : -1;                         \
+  }
+#define V2_LOAD_A(CH)                                                                                   \
+  _Pragma("unroll") for (int i_ = 0; i_ < NL; ++i_)                                                     \
+    areg[i_] = aoff[i_] >= 0 ? *reinterpret_cast<const f32x4*>(a.x + aoff[i_] + (CH) * 32) : f32x4{0.f, 0.f, 0.f, 0.f};
+#define V2_STORE_A()                                                                                    \
+  _Pragma("unroll") for (int i_ = 0; i_ < NL; ++i_) {                                                   \
+    if (tid + i_ * 256 < HP * 8) {                                                                      \
+      char* d_ = sA + adst0 + i_ * 32 * CV_ROW;                                                         \
+      bf16x4 p0_, p1_, p2_;                                                                             \
+      _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                \
+        __bf16 u_, v_, w_;                                                                              \
+        cv_split(areg[i_][j_], u_, v_, w_);                                                             \
+        p0_[j_] = u_; p1_[j_] = v_; p2_[j_] = w_;                                                       \
+      }                                                                                                 \
+      *reinterpret_cast<bf16x4*>(d_) = p0_;                                                             \
+      *reinterpret_cast<bf16x4*>(d_ + PLANE) = p1_;                                                     \
+      *reinterpret_cast<bf16x4*>(d_ + 2 * PLANE) = p2_;                                                 \
+    }                                                                                                   \
+  }
 #define V2_LOAD_W(DST, SRC, TAP, CH)                                                                    \
   {                                                                                                     \
     const uint16_t* s_ = (SRC) + ((size_t)(TAP) * nch + (CH)) * 3 * wslice;                             \
@@ -361,14 +391,14 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
   for (int g = 0; g < 4; ++g) ssum[g] = ssq[g] = 0.f;
   const int stats_n0 = ct.n0;
 
-  CV_HALO(ct);
-  CV_LOAD_A(0);
+  V2_HALO(ct);
+  V2_LOAD_A(0);
   V2_LOAD_W(wnxt, wsrc, 0, 0);
   const char* aBase = sA + kq * 16;
   while (true) {
-    f32x4 acc[8];
+    f32x4 acc[TH];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < TH; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int next = tile + gridDim.x;
     const bool has_next = next < a.ntiles;
     ConvTile nt = ct;
@@ -379,7 +409,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
     }
     for (int ch = 0; ch < nch; ++ch) {
       __syncthreads();                    // everyone is done reading the previous halo image
-      CV_STORE_A();
+      V2_STORE_A();
       __syncthreads();
       const bool last = ch + 1 == nch;
 #pragma unroll
@@ -395,32 +425,35 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
         }
         if (tap == 6) {
           if (!last) {
-            CV_LOAD_A(ch + 1);
+            V2_LOAD_A(ch + 1);
           } else if (has_next) {
-            CV_HALO(nt);
-            CV_LOAD_A(0);
+            V2_HALO(nt);
+            V2_LOAD_A(0);
           }
         }
         const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
-        for (int part = 0; part < 4; ++part) {     // two pixel rows at a time: 6 operand reads, 12 products
+        for (int part = 0; part < (TH + 1) / 2; ++part) {     // two pixel rows at a time: 6 operand reads, 12 products
           bf16x8 xa[2][3];
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            const int hp = (2 * part + i + dy) * CV_HW + r + dx;
+            if (2 * part + i < TH) {
+              const int hp = (2 * part + i + dy) * CV_HW + r + dx;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) xa[i][q] = *reinterpret_cast<const bf16x8*>(aBase + q * CV_APLANE + hp * CV_ROW);
+              for (int q = 0; q < 3; ++q) xa[i][q] = *reinterpret_cast<const bf16x8*>(aBase + q * PLANE + hp * CV_ROW);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);       // this part's reads, then its products: keeps the scheduler from
 #pragma unroll
-          for (int i = 0; i < 2; ++i) BF3_MFMA6(acc[2 * part + i], wcur, xa[i]);
+          for (int i = 0; i < 2; ++i)
+            if (2 * part + i < TH) BF3_MFMA6(acc[2 * part + i], wcur, xa[i]);
           __builtin_amdgcn_sched_barrier(0);       // hoisting later parts' operands (170-register budget, 3 waves / SIMD)
         }
       }
     }
     // ---- epilogue: accumulator i = pixel row i, column r; channels n0 + 16 wave + 4 kq ..
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < TH; ++i) {
       const int py = ct.y0 + i, px = ct.x0 + r;
       if (py < a.H && px < a.W) {
         *reinterpret_cast<f32x4*>(a.y + (((long long)ct.b * a.H + py) * a.W + px) * a.Cout + ct.n0 + 16 * wave + 4 * kq) = acc[i];
@@ -439,6 +472,9 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
     wsrc = wnext_src;
   }
 #undef V2_LOAD_W
+#undef V2_HALO
+#undef V2_LOAD_A
+#undef V2_STORE_A
   if (STATS) {
     double* red = reinterpret_cast<double*>(smem);          // [moment][64 channels]
     __shared__ int s_last2;
@@ -743,12 +779,24 @@ static int env_conv_form() {
   return e ? atoi(e) : 2;
 }
 static int g_conv_form = env_conv_form();   // 1: weight image in LDS (k_conv3x3), 2: weight fragments in registers (k_conv3x3_v2)
+static int conv_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cus = n;
+  }
+  return cus;
+}
+static int g_conv_th = 0;       // experiments: rows per tile of the second form (0 = chosen per launch)
 static int g_conv_grid = 0;     // experiments: blocks per launch (0 = two per CU)
 static int g_conv_ablate = 0;   // experiments: timing-only builds of the loop (wrong results), see k_conv3x3
 extern "C" int glx_conv3x3_set_grid(int blocks, int ablate) {
   g_conv_grid = blocks;
   g_conv_ablate = ablate & 0xFF;
-  if (ablate >> 8) g_conv_form = ablate >> 8;      // bits 8..: 1 or 2 = the kernel form
+  if ((ablate >> 8) & 0xF) g_conv_form = (ablate >> 8) & 0xF;      // bits 8-11: 1 or 2 = the kernel form
+  g_conv_th = (ablate >> 12) & 0xF;                                // bits 12-15: rows per tile of the second form
   return GLX_OK;
 }
 
@@ -784,9 +832,20 @@ extern "C" int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin,
   void (*kern)(ConvArgs) = bn_state ? k_conv3x3<0, true> : k_conv3x3<0, false>;
   int slot = bn_state ? 7 : 0;
   const bool v2 = g_conv_form == 2 && g_conv_ablate == 0;
+  int th = CV_TH;
   if (v2) {
-    kern = bn_state ? k_conv3x3_v2<true> : k_conv3x3_v2<false>;
-    slot = bn_state ? 6 : 5;      // (slots 5, 6 are ablations nobody selects together with the second form)
+    // rows per tile: the fewest (rounds of the resident blocks) x (rows + a fixed cost per tile)
+    const int resident = 3 * conv_cus();
+    long long best = -1;
+    for (int t = 8; t >= 6; --t) {
+      const long long units = (long long)glx_divup(W, CV_TW) * glx_divup(H, t) * B * (Cout / CV_BN);
+      const long long cost = ((units + resident - 1) / resident) * (2 * t + 3);
+      if (best < 0 || cost < best) { best = cost; th = t; }
+    }
+    if (g_conv_th >= 6 && g_conv_th <= 8) th = g_conv_th;
+    if (th == 8) kern = bn_state ? k_conv3x3_v2<true, 8> : k_conv3x3_v2<false, 8>;
+    else if (th == 7) kern = bn_state ? k_conv3x3_v2<true, 7> : k_conv3x3_v2<false, 7>;
+    else kern = bn_state ? k_conv3x3_v2<true, 6> : k_conv3x3_v2<false, 6>;
   }
   if (!bn_state && !v2) {
     switch (g_conv_ablate) {
@@ -800,15 +859,21 @@ extern "C" int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin,
     slot = g_conv_ablate & 7;
     if (slot == 7) slot = 0;
   }
-  static bool attr_set[8] = {};
-  if (!attr_set[slot]) {
-    GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, v2 ? CV2_LDS : CV_LDS));
-    attr_set[slot] = true;
+  const int lds_bytes = v2 ? 3 * (th + 2) * CV_HW * CV_ROW : CV_LDS;
+  if (v2) {
+    GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+  } else {
+    static bool attr_set[8] = {};
+    if (!attr_set[slot]) {
+      GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+      attr_set[slot] = true;
+    }
   }
   ConvArgs a;
   a.x = x; a.wp = (const uint16_t*)packed; a.y = y;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-  a.tiles_x = glx_divup(W, CV_TW); a.tiles_y = glx_divup(H, CV_TH);
+  a.th = th;
+  a.tiles_x = glx_divup(W, CV_TW); a.tiles_y = glx_divup(H, th);
   a.nblk = Cout / CV_BN;
   a.ntiles = a.tiles_x * a.tiles_y * B * a.nblk;
   static int slots = 0;
@@ -824,7 +889,7 @@ extern "C" int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin,
   const int resident = slots * (v2 ? 3 : 2);
   int grid = g_conv_grid > 0 ? g_conv_grid : (a.ntiles < resident ? a.ntiles : resident);
   if (bn_state) grid = grid / a.nblk * a.nblk;   // every block keeps one channel block (ntiles is a multiple of nblk)
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), v2 ? CV2_LDS : CV_LDS, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, a);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

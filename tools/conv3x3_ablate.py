@@ -26,10 +26,12 @@ for (b, cin, cout, h, w) in ((4, 64, 64, 200, 176), (4, 256, 64, 200, 176), (4, 
     wt = torch.randn(cout, cin, 3, 3, device=dev) / 30
     fwd, bwd = c2.packs(wt)
     out = []
-    for grid, abl in ((0, 0), (0, 1), (0, 2), (0, 4), (0, 5), (0, 6), (256, 0), (768, 0)):
+    # first form (weight image in LDS) with its ablations, then the second form by rows per tile
+    for grid, abl in ((0, 0x100), (0, 0x101), (0, 0x102), (0, 0x104), (0, 0x105), (0, 0x106), (256, 0x100), (768, 0x100),
+                      (0, 0x200), (0, 0x8200), (0, 0x7200), (0, 0x6200)):
         lib.glx_conv3x3_set_grid(grid, abl)
-        out.append("g%d/a%d %.1f" % (grid, abl, t(lambda: c2._run(x, fwd, cout))))
-    lib.glx_conv3x3_set_grid(0, 0)
+        out.append("g%d/%x %.1f" % (grid, abl, t(lambda: c2._run(x, fwd, cout))))
+    lib.glx_conv3x3_set_grid(0, 0x200)
     print((b, cin, cout, h, w), " ".join(out), flush=True)
     # the clock the chip holds inside the kernel: shader-clock ticks / 100 MHz ticks per block, after 0.5 s of back-to-back launches
     import ctypes, time
@@ -39,16 +41,18 @@ for (b, cin, cout, h, w) in ((4, 64, 64, 200, 176), (4, 256, 64, 200, 176), (4, 
         for _ in range(50):
             c2._run(x, fwd, cout)
         torch.cuda.synchronize()
-    for abl in (0, 5):
+    for abl in (0x100, 0x105, 0x200):
         lib.glx_conv3x3_set_grid(0, abl)
         lib.glx_conv3x3_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
         for _ in range(20):
             c2._run(x, fwd, cout)
         torch.cuda.synchronize()
         lib.glx_conv3x3_set_stamps(None)
+        if abl == 0x200:
+            continue                       # (the second form carries no stamps)
         st = stamps.view(-1, 2).cpu().double()
         st = st[st[:, 1] > 0]
         ghz = (st[:, 0] / st[:, 1] * 0.1)
-        print("   ablate %d: in-kernel clock median %.2f GHz (p10 %.2f, p90 %.2f); block lifetime median %.1f us"
+        print("   form/ablate %x: in-kernel clock median %.2f GHz (p10 %.2f, p90 %.2f); block lifetime median %.1f us"
               % (abl, ghz.median(), ghz.quantile(0.1), ghz.quantile(0.9), (st[:, 1] / 100).median()), flush=True)
-    lib.glx_conv3x3_set_grid(0, 0)
+    lib.glx_conv3x3_set_grid(0, 0x200)
