@@ -789,7 +789,11 @@ static int conv_cus() {
   }
   return cus;
 }
-static int g_conv_th = 0;       // experiments: rows per tile of the second form (0 = chosen per launch)
+static int env_conv_th() {
+  const char* e = getenv("GLX_CONV3X3_TH");
+  return e ? atoi(e) : 0;
+}
+static int g_conv_th = env_conv_th();       // experiments: rows per tile of the second form (0 = chosen per launch)
 static int g_conv_grid = 0;     // experiments: blocks per launch (0 = two per CU)
 static int g_conv_ablate = 0;   // experiments: timing-only builds of the loop (wrong results), see k_conv3x3
 extern "C" int glx_conv3x3_set_grid(int blocks, int ablate) {
@@ -837,7 +841,7 @@ extern "C" int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin,
     // rows per tile: the fewest (rounds of the resident blocks) x (rows + a fixed cost per tile)
     const int resident = 3 * conv_cus();
     long long best = -1;
-    for (int t = 8; t >= 6; --t) {
+    for (int t = 8; t >= 7; --t) {
       const long long units = (long long)glx_divup(W, CV_TW) * glx_divup(H, t) * B * (Cout / CV_BN);
       const long long cost = ((units + resident - 1) / resident) * (2 * t + 3);
       if (best < 0 || cost < best) { best = cost; th = t; }

@@ -49,7 +49,17 @@ def main():
     pipe.data_parallel()                    # broadcast from rank 0 + grad_scale = 1 / world
     pipe.load(*batches[rank])
     pipe.capture(split=True)
-    pipe.step()
+    g_local = None
+    if os.environ.get("GLX_DP_DEBUG"):             # the step taken apart: this rank's gradient before the exchange
+        from glenet_amd import _lib
+        pipe.replay()
+        torch.cuda.synchronize()
+        g_local = pipe.step_optimizer.flat_grad.detach().clone()
+        pipe.exchange()
+        pipe.update_graph.replay()
+        _lib.bump_weights_epoch()
+    else:
+        pipe.step()
     torch.cuda.synchronize()
     pipe.check()
     opt = pipe.step_optimizer
@@ -82,6 +92,20 @@ def main():
                param_err_max=float(dp_.max()), param_err_mean=float(dp_.mean()),
                grads_differ_between_batches=float((grads[0] - grads[1]).abs().max()), lr=lr,
                step_count=int(opt.step_count))
+    if g_local is not None:
+        e_loc = float((g_local - grads[rank]).abs().max())
+        print("DPDEBUG rank %d: own recorded gradient vs own eager gradient of the same batch: %.3e (scale %.3e)"
+              % (rank, e_loc, float(grads[rank].abs().max())), flush=True)
+    if os.environ.get("GLX_DP_DEBUG"):             # which parameters carry the deviation
+        off = 0
+        worst = []
+        for name, prm in model.named_parameters():
+            n = prm.numel()
+            e = float(dg[off:off + n].max()) if n else 0.0
+            worst.append((e, name, n))
+            off += n
+        for e, name, n in sorted(worst, reverse=True)[:8]:
+            print("DPDEBUG rank %d %-60s n=%d err %.3e" % (rank, name, n, e), flush=True)
     print("DPRESULT " + json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()
