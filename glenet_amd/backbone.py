@@ -475,7 +475,7 @@ class StaticTrainPipeline(StaticFramePipeline):
                 spconv.core.prepack([m for m in self.model.modules() if isinstance(m, spconv.core.SparseConvolution)])
                 from . import conv2d as own_conv       # ... and the BEV backbone's 3x3 filters (split-bf16 pieces) in another
                 own_conv.prepack([m.weight for em in self.extra_modules for m in em.modules()
-                                  if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1)
+                                  if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.stride in ((1, 1), (2, 2))
                                   and m.bias is None])
             try:
                 with torch.enable_grad():

@@ -50,6 +50,7 @@ struct PconvArgs {
   int Ck, N;            // channels per input tap, output channels
   int ui, uo;           // pixel stride of the input / output map relative to the coarse grid (one of them is 1)
   int ktaps, ntaps;     // ui * ui, uo * uo
+  int k3;               // 1: the input taps are a 3 x 3 window with zero padding 1 around (ui y, ui x) (strided convolution)
   int M, mtiles, nblk, nunits;
 };
 
@@ -75,14 +76,18 @@ __global__ __launch_bounds__(256, 2) void k_pconv(PconvArgs a) {
 
     // the thread's four 16-byte pieces of a step's rows: pixel m0 + (e >> 3), channels 4 (e & 7) ..
     long long abase[4];
+    int iy0[4], ix0[4];       // k3: the window's centre in the input map
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = tid + i * 256, m = m0 + (e >> 3);
       if (m < a.M) {
         const int b = m / hw, rem = m - b * hw, y = rem / a.Wc, x = rem - y * a.Wc;
         abase[i] = (((long long)b * a.Hc * a.ui + (long long)y * a.ui) * (a.Wc * a.ui) + (long long)x * a.ui) * a.Ck + (e & 7) * 4;
+        iy0[i] = y * a.ui;
+        ix0[i] = x * a.ui;
       } else {
         abase[i] = -1;
+        iy0[i] = ix0[i] = 0;
       }
     }
     f32x4 areg[4];
@@ -90,9 +95,13 @@ __global__ __launch_bounds__(256, 2) void k_pconv(PconvArgs a) {
 #define PC_LOAD(STEP)                                                                                          \
   {                                                                                                            \
     const int kt_ = (STEP) / nch, ch_ = (STEP) - kt_ * nch;                                                    \
-    const long long off_ = ((long long)(kt_ / a.ui) * (a.Wc * a.ui) + (kt_ % a.ui)) * a.Ck + ch_ * 32;         \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                           \
-      areg[i_] = abase[i_] >= 0 ? *reinterpret_cast<const f32x4*>(a.x + abase[i_] + off_) : f32x4{0.f, 0.f, 0.f, 0.f}; \
+    const int dy_ = a.k3 ? kt_ / 3 - 1 : kt_ / a.ui, dx_ = a.k3 ? kt_ % 3 - 1 : kt_ % a.ui;                    \
+    const long long off_ = ((long long)dy_ * (a.Wc * a.ui) + dx_) * a.Ck + ch_ * 32;                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                         \
+      const bool ok_ = abase[i_] >= 0 && (!a.k3 || ((unsigned)(iy0[i_] + dy_) < (unsigned)(a.Hc * a.ui) &&     \
+                                                    (unsigned)(ix0[i_] + dx_) < (unsigned)(a.Wc * a.ui)));     \
+      areg[i_] = ok_ ? *reinterpret_cast<const f32x4*>(a.x + abase[i_] + off_) : f32x4{0.f, 0.f, 0.f, 0.f};    \
+    }                                                                                                          \
     const uint16_t* s_ = wsrc + (size_t)(STEP) * 3 * wslice;                                                   \
     wreg0 = *reinterpret_cast<const uint4*>(s_);                                                               \
     wreg1 = *reinterpret_cast<const uint4*>(s_ + wslice);                                                      \
@@ -185,7 +194,7 @@ extern "C" int glx_deconv_pack(const float* W, long long s_ci, long long s_co, l
 }
 
 static int pconv_launch(const float* x, const void* packed, float* y, int B, int Hc, int Wc, int Ck, int N, int ui, int uo,
-                        hipStream_t st) {
+                        hipStream_t st, int k3 = 0) {
   static bool attr_set = false;
   if (!attr_set) {
     GLX_HIP(hipFuncSetAttribute((const void*)k_pconv, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));
@@ -194,7 +203,8 @@ static int pconv_launch(const float* x, const void* packed, float* y, int B, int
   PconvArgs a;
   a.x = x; a.wp = (const uint16_t*)packed; a.y = y;
   a.B = B; a.Hc = Hc; a.Wc = Wc; a.Ck = Ck; a.N = N; a.ui = ui; a.uo = uo;
-  a.ktaps = ui * ui; a.ntaps = uo * uo;
+  a.ktaps = k3 ? 9 : ui * ui; a.ntaps = uo * uo;
+  a.k3 = k3;
   a.M = B * Hc * Wc;
   a.mtiles = glx_divup(a.M, PC_TM);
   a.nblk = N / PC_BN;
@@ -402,4 +412,16 @@ extern "C" int glx_deconv_wgrad(const float* x, const float* gy, int B, int H, i
                      s_co, s_kh, s_kw);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
+}
+
+// The strided 3x3 convolution of the second BEV block (base_bev_backbone.py:33-36: ZeroPad2d(1) + Conv2d(c, 2c, 3, stride 2)):
+// FORWARD only, on k_pconv with a 3 x 3 window of input taps around (2 y, 2 x) and the piece image glx_conv3x3_pack writes
+// for the stride-1 layers ([tap][chunk][plane][Cout][32] is what k_pconv reads for nine input taps and one output tap).
+// x (B, H, W, Cin), H and W even -> y (B, H / 2, W / 2, Cout).  Bit-reproducible, which the vendor kernel for this layer is
+// not (split-K atomics in a FORWARD pass: every ReLU mask behind it can flip from run to run).
+extern "C" int glx_conv3x3s2_forward(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, float* y,
+                                     void* stream) {
+  GLX_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cin % 32 == 0 && Cout % 64 == 0,
+              "glx_conv3x3s2_forward: bad sizes (%d, %d, %d), %d -> %d (even maps, Cin %% 32, Cout %% 64)", B, H, W, Cin, Cout);
+  return pconv_launch(x, packed_fwd, y, B, H / 2, W / 2, Cin, Cout, 2, 1, (hipStream_t)stream, 1);
 }

@@ -66,6 +66,47 @@ class _ConvSplitBackward(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None, None, None
 
 
+class _OwnStridedForward(torch.autograd.Function):
+    """ZeroPad2d(1) + Conv2d(c, 2c, 3, stride 2) of the second BEV block: forward on csrc/glx_deconv2d.hip
+    (glx_conv3x3s2_forward, the split-bf16 arithmetic of the stride-1 layers), backward the library's two calls as in
+    _ConvSplitBackward.  The point is reproducibility more than speed: MIOpen's forward kernel for this layer sums
+    split-K slices with float atomics, so that every activation behind it -- and with it the ReLU masks of the whole
+    second block -- changes in the last bit from run to run (tools/forward_determinism.py); an element of a
+    pre-activation that sits at zero then takes or drops its whole gradient at random, and two passes over one batch
+    differ by up to 1 % in every weight gradient upstream (tools/step_repeat.py)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        from ._lib import call
+        b, c, h, wd = x.shape
+        cout = int(w.shape[0])
+        fwd, _ = own_conv.packs(w)
+        xd = x.detach()
+        y = torch.empty((b, cout, h // 2, wd // 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        call("glx_conv3x3s2_forward", xd, b, h, wd, c, fwd, cout, y)
+        ctx.cfg = ((2, 2), (1, 1), (1, 1), False, (0, 0), 1)
+        ctx.bias_sizes = None
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        # (x, w, bias, ...) of _ConvSplitBackward: needs_input_grad has two entries here, the helper reads [0], [1] and [2]
+        class _Shim:
+            saved_tensors = ctx.saved_tensors
+            cfg, bias_sizes = ctx.cfg, None
+            needs_input_grad = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], False)
+        return _ConvSplitBackward.backward(_Shim, gy.contiguous(memory_format=torch.channels_last))[:2]
+
+
+def _own_strided_ok(x, w, stride, padding, dilation, groups, bias):
+    return (OWN_STRIDED_FORWARD and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and bias is None and groups == 1
+            and tuple(w.shape[2:]) == (3, 3) and tuple(stride) == (2, 2) and tuple(padding) == (1, 1)
+            and tuple(dilation) == (1, 1) and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0 and x.shape[1] == w.shape[1]
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.is_contiguous(memory_format=torch.channels_last))
+
+
+OWN_STRIDED_FORWARD = os.environ.get("GLX_OWN_S2_FWD", "1") != "0"
 SPLIT_CONV_BACKWARD = os.environ.get("GLX_SPLIT_CONV_BWD", "1") != "0"
 OWN_CONV3X3 = os.environ.get("GLX_OWN_CONV3X3", "1") != "0"     # 3x3 / stride 1 layers on csrc/glx_conv2d.hip
 OWN_DECONV = os.environ.get("GLX_OWN_DECONV", "1") != "0"       # the deblocks' transposed convolutions on csrc/glx_deconv2d.hip
@@ -92,6 +133,8 @@ def conv2d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1):
     if OWN_CONV3X3 and (_leaf(w) or not torch.is_grad_enabled()) and own_conv.supported(
             x, w, _pair(stride), _pair(padding), _pair(dilation), groups, bias):
         return own_conv.conv3x3(x, w)
+    if OWN_CONV3X3 and _leaf(w) and _own_strided_ok(x, w, _pair(stride), _pair(padding), _pair(dilation), groups, bias):
+        return _OwnStridedForward.apply(x, w)
     if (SPLIT_CONV_BACKWARD and x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
             and _leaf(w) and _leaf(bias)):
         return _ConvSplitBackward.apply(x, w, bias, _pair(stride), _pair(padding), _pair(dilation), False, (0, 0), groups)

@@ -848,6 +848,11 @@ int glx_deconv_forward(const float* x, int B, int H, int W, int Cin, const void*
                        void* stream);
 int glx_deconv_input_grad(const float* gy, int B, int H, int W, int Cin, const void* packed_bwd, int Cout, int u,
                           float* gx, void* stream);
+/* Forward of the strided layer (ZeroPad2d(1) + Conv2d(c, 2c, 3, stride 2), base_bev_backbone.py:33-36) on the same kernel:
+ * x (B, H, W, Cin) with even H, W -> y (B, H/2, W/2, Cout); `packed_fwd` = the forward image of glx_conv3x3_pack.
+ * Bit-reproducible (the vendor's forward kernel for this layer sums split-K slices with atomics). */
+int glx_conv3x3s2_forward(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, float* y,
+                          void* stream);
 size_t glx_deconv_wgrad_workspace_bytes(int Cin, int Cout, int u);
 int glx_deconv_wgrad(const float* x, const float* gy, int B, int H, int W, int Cin, int Cout, int u, float* dW,
                      long long s_ci, long long s_co, long long s_kh, long long s_kw, void* workspace,

@@ -211,3 +211,27 @@ def test_transposed_convolutions_match_fp64(dev, shape):
     xi = _cl(torch.randint(-8, 9, (b, cin, h, w), device=dev, generator=g).float())
     wi = torch.randint(-4, 5, (cin, cout, u, u), device=dev, generator=g).float()
     assert torch.equal(c2.deconv(xi, wi).double().cpu(), F.conv_transpose2d(xi.double().cpu(), wi.double().cpu(), None, stride=u))
+
+
+def test_strided_block_convolution_forward_is_exact_and_reproducible(dev):
+    """Conv2d(64, 128, 3, stride 2, padding 1) forward on the own kernel: integers exactly, random data to fp32 rounding,
+    the same bits on every run; gradients (the library's) as F.conv2d's."""
+    from glenet_amd import dense_path as dp
+    g = torch.Generator(device=dev).manual_seed(9)
+    xi = _cl(torch.randint(-8, 9, (2, 64, 24, 40), device=dev, generator=g).float())
+    wi = torch.nn.Parameter(torch.randint(-4, 5, (128, 64, 3, 3), device=dev, generator=g).float())
+    assert dp._own_strided_ok(xi, wi, (2, 2), (1, 1), (1, 1), 1, None)
+    y = dp.conv2d(xi, wi, None, 2, 1)
+    assert torch.equal(y.double().cpu(), F.conv2d(xi.double().cpu(), wi.detach().double().cpu(), None, 2, 1))
+    x = _cl(torch.randn(2, 64, 50, 44, device=dev, generator=g)).requires_grad_(True)
+    wt = torch.nn.Parameter(_cl(torch.randn(128, 64, 3, 3, device=dev, generator=g) / 24))
+    y = dp.conv2d(x, wt, None, 2, 1)
+    assert all(torch.equal(dp.conv2d(x, wt, None, 2, 1), y) for _ in range(5))
+    gy = _cl(torch.randn_like(y))
+    y.backward(gy)
+    xd, wd = x.detach().double().requires_grad_(True), wt.detach().double().requires_grad_(True)
+    ref = F.conv2d(xd, wd, None, 2, 1)
+    ref.backward(gy.double())
+    assert (y.double() - ref).abs().max() < 4e-6 * ref.abs().max()
+    assert (x.grad.double() - xd.grad).abs().max() < 2e-5 * xd.grad.abs().max()
+    assert (wt.grad.double() - wd.grad).abs().max() < 2e-5 * wd.grad.abs().max()
