@@ -312,6 +312,11 @@ class StaticFramePipeline:
 
     def capture(self, warmup=2):
         """Warm up (one-time packing / attribute calls must not land in the graph), then record."""
+        # Drop dead autograd graphs that only a reference cycle keeps alive: as long as one of them lives, the parameters'
+        # AccumulateGrad nodes keep the stream they were created under (the default stream of an earlier eager pass), the
+        # recorded backward then makes THAT stream wait on a capturing event -- and capture_end() fails with "capturing
+        # stream has unjoined work", or not, depending on when the collector last ran.
+        gc.collect()
         side = torch.cuda.Stream(self.points.device)
         side.wait_stream(torch.cuda.current_stream(self.points.device))
         with torch.cuda.stream(side):
@@ -320,6 +325,7 @@ class StaticFramePipeline:
         torch.cuda.current_stream(self.points.device).wait_stream(side)
         torch.cuda.synchronize(self.points.device)
         self.check()
+        gc.collect()
         self.graph = _lib.new_graph()
         with torch.cuda.graph(self.graph, stream=side), no_gc():
             self.enqueue()

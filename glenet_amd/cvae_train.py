@@ -62,6 +62,8 @@ class CVAETrainStep:
     def capture(self, warmup=2):
         """Record the step.  Warm-up passes are real steps on the loaded batch; parameters, moments, step count and
         BatchNorm statistics are restored afterwards (as glenet_vr.StaticTrainStep.capture does)."""
+        import gc
+        gc.collect()                 # see backbone.StaticFramePipeline.capture: dead graphs pin AccumulateGrad streams
         opt = self.optimizer
         state = [opt.flat_param, opt.exp_avg, opt.exp_avg_sq, opt.step_count, opt.hyper] + list(self.model.buffers())
         snap = [t.detach().clone() for t in state]

@@ -17,6 +17,7 @@ reference code on CPU, see tests/golden/make_golden.py).
 import contextlib
 import math
 import os
+import types
 
 import numpy as np
 import torch
@@ -91,12 +92,12 @@ class _OwnStridedForward(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        # (x, w, bias, ...) of _ConvSplitBackward: needs_input_grad has two entries here, the helper reads [0], [1] and [2]
-        class _Shim:
-            saved_tensors = ctx.saved_tensors
-            cfg, bias_sizes = ctx.cfg, None
-            needs_input_grad = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], False)
-        return _ConvSplitBackward.backward(_Shim, gy.contiguous(memory_format=torch.channels_last))[:2]
+        # (x, w, bias, ...) of _ConvSplitBackward: needs_input_grad has two entries here, the helper reads [0], [1] and [2].
+        # A plain namespace, not a class: a class object sits in a reference cycle and would keep the saved activation --
+        # and the whole graph above it -- alive until the collector runs.
+        shim = types.SimpleNamespace(saved_tensors=ctx.saved_tensors, cfg=ctx.cfg, bias_sizes=None,
+                                     needs_input_grad=(ctx.needs_input_grad[0], ctx.needs_input_grad[1], False))
+        return _ConvSplitBackward.backward(shim, gy.contiguous(memory_format=torch.channels_last))[:2]
 
 
 def _own_strided_ok(x, w, stride, padding, dilation, groups, bias):
