@@ -752,3 +752,61 @@ def vector_pool_grad(grad_new_features, point_cnt_of_grid, grouped_idxs, N, num_
     out = np.zeros((int(N), int(num_c_in)), np.float32)
     lib().orc_vector_pool_grad(_f(g), _i(pc), _i(gi), len(gi), int(num_c_in), g.shape[1], pc.shape[1], _f(out))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Dense convolutions of the BEV backbone (pcdet/models/backbones_2d/base_bev_backbone.py:30-66): plain fp64 restatements of
+# nn.Conv2d(k=3, padding=1, stride 1 or 2) and nn.ConvTranspose2d(k = stride = u) on channels-first arrays, and the
+# split-bf16 arithmetic the device kernels compute fp32 products with (csrc/glx_bf16x3.h), restated on the host.
+def conv2d_3x3(x, w, stride=1):
+    """x (B, Cin, H, W), w (Cout, Cin, 3, 3), zero padding 1 -> (B, Cout, H', W') in fp64 (torch.nn.functional.conv2d's
+    definition: y[b, o, i, j] = sum_{c, p, q} x[b, c, s i + p - 1, s j + q - 1] w[o, c, p, q])."""
+    x, w = np.asarray(x, np.float64), np.asarray(w, np.float64)
+    b, cin, h, wd = x.shape
+    ho, wo = (h + 2 - 3) // stride + 1, (wd + 2 - 3) // stride + 1
+    xp = np.zeros((b, cin, h + 2, wd + 2))
+    xp[:, :, 1:-1, 1:-1] = x
+    y = np.zeros((b, w.shape[0], ho, wo))
+    for p in range(3):
+        for q in range(3):
+            patch = xp[:, :, p:p + stride * (ho - 1) + 1:stride, q:q + stride * (wo - 1) + 1:stride]
+            y += np.einsum("bchw,oc->bohw", patch, w[:, :, p, q])
+    return y
+
+
+def conv_transpose2d(x, w, u):
+    """x (B, Cin, H, W), w (Cin, Cout, u, u), stride u, no padding -> (B, Cout, u H, u W) in fp64:
+    y[b, o, u i + p, u j + q] = sum_c x[b, c, i, j] w[c, o, p, q]."""
+    x, w = np.asarray(x, np.float64), np.asarray(w, np.float64)
+    b, cin, h, wd = x.shape
+    y = np.zeros((b, w.shape[1], u * h, u * wd))
+    for p in range(u):
+        for q in range(u):
+            y[:, :, p::u, q::u] = np.einsum("bchw,co->bohw", x, w[:, :, p, q])
+    return y
+
+
+def bf16_round(x):
+    """float32 -> nearest bfloat16 (ties to even), returned as float32 (v_cvt_pk_bf16_f32's rounding)."""
+    u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return (r & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
+
+
+def bf16x3_split(x):
+    """The three bf16 pieces of an fp32 array (cv_split in csrc/glx_bf16x3.h): x1 = bf16(x), x2 = bf16(x - x1),
+    x3 = bf16(x - x1 - x2), each returned as float32."""
+    x = np.asarray(x, np.float32)
+    a = bf16_round(x)
+    r = (x - a).astype(np.float32)
+    b = bf16_round(r)
+    c = bf16_round((r - b).astype(np.float32))
+    return a, b, c
+
+
+def bf16x3_product(x, w):
+    """x * w as the device computes it: the six piece products with i + j <= 4, each exact, summed in fp64 here (the
+    device accumulates them in fp32 inside the matrix pipe)."""
+    xs, ws = bf16x3_split(x), bf16x3_split(w)
+    terms = ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0))
+    return sum(ws[i].astype(np.float64) * xs[j].astype(np.float64) for i, j in terms)

@@ -235,3 +235,28 @@ def test_strided_block_convolution_forward_is_exact_and_reproducible(dev):
     assert (y.double() - ref).abs().max() < 4e-6 * ref.abs().max()
     assert (x.grad.double() - xd.grad).abs().max() < 2e-5 * xd.grad.abs().max()
     assert (wt.grad.double() - wd.grad).abs().max() < 2e-5 * wd.grad.abs().max()
+
+
+def test_dense_kernels_against_the_oracle(dev):
+    """The three dense entry points against oracle/'s fp64 restatements (the checker the rest of the path is pinned to),
+    on maps that do not divide into tiles."""
+    import numpy as np
+    import oracle
+    from glenet_amd import conv2d as c2, dense_path as dp
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((2, 64, 11, 19)).astype(np.float32)
+    w = (rng.standard_normal((64, 64, 3, 3)) / 24).astype(np.float32)
+    y = c2.conv3x3(_cl(torch.from_numpy(x).to(dev)), torch.from_numpy(w).to(dev)).cpu().numpy()
+    ref = oracle.conv2d_3x3(x, w)
+    assert np.abs(y - ref).max() < 4e-6 * np.abs(ref).max()
+    x2 = rng.standard_normal((2, 64, 12, 20)).astype(np.float32)
+    w2 = (rng.standard_normal((128, 64, 3, 3)) / 24).astype(np.float32)
+    y2 = dp.conv2d(_cl(torch.from_numpy(x2).to(dev)), torch.nn.Parameter(torch.from_numpy(w2).to(dev)), None, 2, 1)
+    ref2 = oracle.conv2d_3x3(x2, w2, 2)
+    assert np.abs(y2.detach().cpu().numpy() - ref2).max() < 4e-6 * np.abs(ref2).max()
+    for u in (1, 2):
+        x3 = rng.standard_normal((2, 64, 5, 8)).astype(np.float32)
+        w3 = (rng.standard_normal((64, 128, u, u)) / 8).astype(np.float32)
+        y3 = c2.deconv(_cl(torch.from_numpy(x3).to(dev)), torch.from_numpy(w3).to(dev)).cpu().numpy()
+        ref3 = oracle.conv_transpose2d(x3, w3, u)
+        assert np.abs(y3 - ref3).max() < 4e-6 * np.abs(ref3).max()

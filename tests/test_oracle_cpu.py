@@ -511,3 +511,37 @@ def test_vector_pool_oracle_vs_independent_numpy_formulation():
         dd = ((centers[p, gcell] - X[cand]) ** 2).sum(1)
         o = np.argsort(dd, kind="stable")[:3]
         assert np.array_equal(idx[p, gcell], s0 + cand[o])
+
+
+def test_split_bf16_pieces_carry_an_fp32_product():
+    """The arithmetic of csrc/glx_bf16x3.h restated on the host: three bf16 pieces reproduce an fp32 number to its last
+    bit or so, their piece products are exact in fp32, and the six products with i + j <= 4 give x * w to 2^-22."""
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(200000) * np.exp(rng.uniform(-30, 30, 200000))).astype(np.float32)
+    w = (rng.standard_normal(200000) * np.exp(rng.uniform(-10, 10, 200000))).astype(np.float32)
+    a, b, c = oracle.bf16x3_split(x)
+    for piece in (a, b, c):                                  # every piece IS a bfloat16: the low 16 bits are zero
+        assert not np.any(piece.view(np.uint32) & 0xFFFF)
+    rec = a.astype(np.float64) + b.astype(np.float64) + c.astype(np.float64)
+    assert np.max(np.abs(rec - x.astype(np.float64)) / np.abs(x.astype(np.float64))) <= 2.0 ** -24
+    exact = x.astype(np.float64) * w.astype(np.float64)
+    got = oracle.bf16x3_product(x, w)
+    assert np.max(np.abs(got - exact) / np.abs(exact)) < 2.0 ** -22
+    # a two-piece split (three products) would stop at 2^-15: the third piece is what buys fp32
+    two = (oracle.bf16x3_split(w)[0].astype(np.float64) * (a.astype(np.float64) + b) + oracle.bf16x3_split(w)[1].astype(np.float64) * a)
+    assert np.max(np.abs(two - exact) / np.abs(exact)) > 2.0 ** -18
+
+
+def test_dense_convolution_restatements_match_torch():
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 5, 9, 12))
+    w = rng.standard_normal((7, 5, 3, 3))
+    for s in (1, 2):
+        ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), None, s, 1).numpy()
+        np.testing.assert_allclose(oracle.conv2d_3x3(x, w, s), ref, rtol=1e-12, atol=1e-12)
+    for u in (1, 2):
+        wt = rng.standard_normal((5, 4, u, u))
+        ref = F.conv_transpose2d(torch.from_numpy(x), torch.from_numpy(wt), None, stride=u).numpy()
+        np.testing.assert_allclose(oracle.conv_transpose2d(x, wt, u), ref, rtol=1e-12, atol=1e-12)
