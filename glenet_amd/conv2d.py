@@ -264,3 +264,51 @@ class _Deconv(torch.autograd.Function):
 def deconv(x, weight):
     """F.conv_transpose2d(x, weight, None, stride=u) for a (Cin, Cout, u, u) weight, u in {1, 2}."""
     return _Deconv.apply(x, weight)
+
+
+# ------------------------------------------------------------------------------------------------ inference (folded BatchNorm)
+_deconv_pack_cache = {}
+
+
+def _deconv_packs_cached(weight):
+    key = (weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()))
+    tag = (_lib.weights_epoch(), weight._version)
+    hit = _deconv_pack_cache.get(key)
+    if hit is not None and hit[3]() is weight and hit[0] == tag and not torch.cuda.is_current_stream_capturing():
+        return hit[1], hit[2]
+    fwd, bwd = _deconv_packs(weight)
+    _deconv_pack_cache[key] = (tag, fwd, bwd, weakref.ref(weight))
+    return fwd, bwd
+
+
+def conv3x3_affine(x, weight, scale, shift, relu):
+    """relu?(conv3x3(x, weight) * scale[c] + shift[c]) in one launch (no autograd): an eval-mode BatchNorm2d folded into
+    the convolution's epilogue."""
+    fwd, _ = packs(weight)
+    _lib.call_nostream("glx_conv3x3_next_epilogue", scale, shift, 1 if relu else 0)
+    return _run(x, fwd, int(weight.shape[0]))
+
+
+def conv3x3s2_affine(x, weight, scale, shift, relu):
+    """The same for the strided layer (3x3, stride 2, zero padding 1; even maps)."""
+    fwd, _ = packs(weight)
+    b, c, h, w = x.shape
+    cout = int(weight.shape[0])
+    y = torch.empty((b, cout, h // 2, w // 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    _lib.call_nostream("glx_pconv_next_epilogue", scale, shift, 1 if relu else 0, 0, 0)
+    call("glx_conv3x3s2_forward", x, b, h, w, c, fwd, cout, y)
+    return y
+
+
+def deconv_affine(x, weight, scale, shift, relu, out=None, channel_offset=0):
+    """relu?(conv_transpose2d(x, weight, stride=u) * scale[c] + shift[c]); with `out` (a channels-last (B, Ctot, uH, uW)
+    map) the result goes straight into channels [channel_offset, channel_offset + Cout) of it."""
+    cin, cout, u = int(weight.shape[0]), int(weight.shape[1]), int(weight.shape[2])
+    fwd, _ = _deconv_packs_cached(weight)
+    b, _, h, w = x.shape
+    if out is None:
+        out = torch.empty((b, cout, h * u, w * u), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    ldc = int(out.shape[1])
+    _lib.call_nostream("glx_pconv_next_epilogue", scale, shift, 1 if relu else 0, ldc if ldc != cout else 0, int(channel_offset))
+    call("glx_deconv_forward", x, b, h, w, cin, fwd, cout, u, out)
+    return out

@@ -74,6 +74,9 @@ struct ConvArgs {
   BnState* bn_state;     // STATS: training-mode BatchNorm statistics of y taken in the epilogue
   BnFinalize bn;
   long long* stamps;     // diagnostics (glx_conv3x3_set_stamps): per block, shader-clock and 100 MHz-clock ticks of its lifetime
+  const float* epi_scale;   // inference epilogue (glx_conv3x3_next_epilogue): y = relu?(conv * scale[c] + shift[c]), second form
+  const float* epi_shift;
+  int epi_relu;
 };
 
 struct ConvTile {
@@ -456,7 +459,17 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
     for (int i = 0; i < TH; ++i) {
       const int py = ct.y0 + i, px = ct.x0 + r;
       if (py < a.H && px < a.W) {
-        *reinterpret_cast<f32x4*>(a.y + (((long long)ct.b * a.H + py) * a.W + px) * a.Cout + ct.n0 + 16 * wave + 4 * kq) = acc[i];
+        f32x4 v = acc[i];
+        if (!STATS && a.epi_scale) {           // folded eval-mode BatchNorm (+ ReLU)
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(a.epi_scale + ct.n0 + 16 * wave + 4 * kq);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(a.epi_shift + ct.n0 + 16 * wave + 4 * kq);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float t = __fmaf_rn(v[g], sc[g], sh[g]);
+            v[g] = a.epi_relu ? fmaxf(t, 0.f) : t;
+          }
+        }
+        *reinterpret_cast<f32x4*>(a.y + (((long long)ct.b * a.H + py) * a.W + px) * a.Cout + ct.n0 + 16 * wave + 4 * kq) = v;
         if (STATS) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -804,6 +817,19 @@ extern "C" int glx_conv3x3_set_grid(int blocks, int ablate) {
   return GLX_OK;
 }
 
+// y = relu?(conv * scale[c] + shift[c]) in the epilogue of the NEXT glx_conv3x3_forward call of this host thread (an
+// eval-mode BatchNorm folded behind the convolution; scale, shift: Cout floats on the device)
+static thread_local const float* g_conv_next_epi_scale = nullptr;
+static thread_local const float* g_conv_next_epi_shift = nullptr;
+static thread_local int g_conv_next_epi_relu = 0;
+extern "C" int glx_conv3x3_next_epilogue(const float* scale, const float* shift, int relu) {
+  GLX_REQUIRE(scale && shift, "glx_conv3x3_next_epilogue: null pointer");
+  g_conv_next_epi_scale = scale;
+  g_conv_next_epi_shift = shift;
+  g_conv_next_epi_relu = relu;
+  return GLX_OK;
+}
+
 static long long* g_conv_stamps = nullptr;   // diagnostics: 2 x int64 per block of the following glx_conv3x3_forward launches
 extern "C" int glx_conv3x3_set_stamps(void* stamps) {
   g_conv_stamps = (long long*)stamps;
@@ -832,10 +858,15 @@ extern "C" int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin,
   GLX_REQUIRE((long long)B * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31), "glx_conv3x3_forward: map too large (2^31 elements)");
   BnState* bn_state = g_conv_next_bn_state;      // consumed by THIS call whatever happens below
   g_conv_next_bn_state = nullptr;
+  const float* epi_scale = g_conv_next_epi_scale;
+  const float* epi_shift = g_conv_next_epi_shift;
+  const int epi_relu = g_conv_next_epi_relu;
+  g_conv_next_epi_scale = g_conv_next_epi_shift = nullptr;
+  GLX_REQUIRE(!(bn_state && epi_scale), "glx_conv3x3_forward: statistics and an inference epilogue in one call");
   GLX_REQUIRE(!bn_state || Cout <= BN_MAXC, "glx_conv3x3_forward: BatchNorm statistics for at most %d channels", BN_MAXC);
   void (*kern)(ConvArgs) = bn_state ? k_conv3x3<0, true> : k_conv3x3<0, false>;
   int slot = bn_state ? 7 : 0;
-  const bool v2 = g_conv_form == 2 && g_conv_ablate == 0;
+  const bool v2 = (g_conv_form == 2 && g_conv_ablate == 0) || epi_scale;      // the epilogue lives in the second form
   int th = CV_TH;
   if (v2) {
     // rows per tile: the fewest (rounds of the resident blocks) x (rows + a fixed cost per tile)
@@ -890,6 +921,9 @@ extern "C" int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin,
   a.bn_state = bn_state;
   a.bn = g_conv_next_bn;
   a.stamps = g_conv_stamps;
+  a.epi_scale = epi_scale;
+  a.epi_shift = epi_shift;
+  a.epi_relu = epi_relu;
   const int resident = slots * (v2 ? 3 : 2);
   int grid = g_conv_grid > 0 ? g_conv_grid : (a.ntiles < resident ? a.ntiles : resident);
   if (bn_state) grid = grid / a.nblk * a.nblk;   // every block keeps one channel block (ntiles is a multiple of nblk)

@@ -52,6 +52,10 @@ struct PconvArgs {
   int ktaps, ntaps;     // ui * ui, uo * uo
   int k3;               // 1: the input taps are a 3 x 3 window with zero padding 1 around (ui y, ui x) (strided convolution)
   int M, mtiles, nblk, nunits;
+  const float* epi_scale;   // inference epilogue (glx_pconv_next_epilogue): y = relu?(acc * scale[c] + shift[c])
+  const float* epi_shift;
+  int epi_relu;
+  int ldc, coff;        // floats between output pixels (>= N) and the first output channel's offset inside a pixel
 };
 
 __global__ __launch_bounds__(256, 2) void k_pconv(PconvArgs a) {
@@ -170,10 +174,22 @@ __global__ __launch_bounds__(256, 2) void k_pconv(PconvArgs a) {
       const int m = m0 + (2 * wave + i) * 16 + r;
       if (m < a.M) {
         const int b = m / hw, rem = m - b * hw, y = rem / a.Wc, x = rem - y * a.Wc;
-        float* dst = a.y + ((((long long)b * a.Hc + y) * a.uo + ntap / a.uo) * (a.Wc * a.uo) + (long long)x * a.uo + ntap % a.uo) * a.N +
-                     n0 + 4 * kq;
+        float* dst = a.y + ((((long long)b * a.Hc + y) * a.uo + ntap / a.uo) * (a.Wc * a.uo) + (long long)x * a.uo + ntap % a.uo) * a.ldc +
+                     a.coff + n0 + 4 * kq;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(dst + 16 * n) = acc[i][n];
+        for (int n = 0; n < 4; ++n) {
+          f32x4 v = acc[i][n];
+          if (a.epi_scale) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.epi_scale + n0 + 16 * n + 4 * kq);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(a.epi_shift + n0 + 16 * n + 4 * kq);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const float t = __fmaf_rn(v[g], sc[g], sh[g]);
+              v[g] = a.epi_relu ? fmaxf(t, 0.f) : t;
+            }
+          }
+          *reinterpret_cast<f32x4*>(dst + 16 * n) = v;
+        }
       }
     }
   }
@@ -193,8 +209,26 @@ extern "C" int glx_deconv_pack(const float* W, long long s_ci, long long s_co, l
   return GLX_OK;
 }
 
+// Epilogue and output placement of the NEXT glx_deconv_forward / glx_conv3x3s2_forward call of this host thread:
+// y = relu?(acc * scale[c] + shift[c]) (a folded eval-mode BatchNorm), written with `ldc` floats between pixels starting at
+// channel `coff` of each pixel -- a deblock's result straight into its slice of the concatenated map
+// (base_bev_backbone.py:100-104).  ldc = 0: dense (ldc = Cout, coff = 0); scale = NULL: no transform.
+static thread_local const float* g_pc_next_scale = nullptr;
+static thread_local const float* g_pc_next_shift = nullptr;
+static thread_local int g_pc_next_relu = 0, g_pc_next_ldc = 0, g_pc_next_coff = 0;
+extern "C" int glx_pconv_next_epilogue(const float* scale, const float* shift, int relu, int ldc, int coff) {
+  GLX_REQUIRE((scale == nullptr) == (shift == nullptr) && ldc >= 0 && coff >= 0 && (ldc & 3) == 0 && (coff & 3) == 0,
+              "glx_pconv_next_epilogue: bad arguments (ldc %d, coff %d)", ldc, coff);
+  g_pc_next_scale = scale;
+  g_pc_next_shift = shift;
+  g_pc_next_relu = relu;
+  g_pc_next_ldc = ldc;
+  g_pc_next_coff = coff;
+  return GLX_OK;
+}
+
 static int pconv_launch(const float* x, const void* packed, float* y, int B, int Hc, int Wc, int Ck, int N, int ui, int uo,
-                        hipStream_t st, int k3 = 0) {
+                        hipStream_t st, int k3 = 0, bool take_epilogue = false) {
   static bool attr_set = false;
   if (!attr_set) {
     GLX_HIP(hipFuncSetAttribute((const void*)k_pconv, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));
@@ -205,6 +239,15 @@ static int pconv_launch(const float* x, const void* packed, float* y, int B, int
   a.B = B; a.Hc = Hc; a.Wc = Wc; a.Ck = Ck; a.N = N; a.ui = ui; a.uo = uo;
   a.ktaps = k3 ? 9 : ui * ui; a.ntaps = uo * uo;
   a.k3 = k3;
+  a.epi_scale = a.epi_shift = nullptr;
+  a.epi_relu = 0; a.ldc = N; a.coff = 0;
+  if (take_epilogue) {
+    a.epi_scale = g_pc_next_scale; a.epi_shift = g_pc_next_shift; a.epi_relu = g_pc_next_relu;
+    if (g_pc_next_ldc) { a.ldc = g_pc_next_ldc; a.coff = g_pc_next_coff; }
+    g_pc_next_scale = g_pc_next_shift = nullptr;
+    g_pc_next_ldc = g_pc_next_coff = 0;
+    GLX_REQUIRE(a.ldc >= a.coff + N, "glx_pconv: output slice [%d, %d) does not fit a pixel of %d floats", a.coff, a.coff + N, a.ldc);
+  }
   a.M = B * Hc * Wc;
   a.mtiles = glx_divup(a.M, PC_TM);
   a.nblk = N / PC_BN;
@@ -225,7 +268,7 @@ extern "C" int glx_deconv_forward(const float* x, int B, int H, int W, int Cin, 
                                   float* y, void* stream) {
   GLX_REQUIRE(B > 0 && H > 0 && W > 0 && (u == 1 || u == 2) && Cin % 64 == 0 && Cout % 64 == 0,
               "glx_deconv_forward: bad sizes (%d, %d, %d), u=%d, %d -> %d", B, H, W, u, Cin, Cout);
-  return pconv_launch(x, packed_fwd, y, B, H, W, Cin, Cout, 1, u, (hipStream_t)stream);
+  return pconv_launch(x, packed_fwd, y, B, H, W, Cin, Cout, 1, u, (hipStream_t)stream, 0, true);
 }
 
 extern "C" int glx_deconv_input_grad(const float* gy, int B, int H, int W, int Cin, const void* packed_bwd, int Cout, int u,
@@ -423,5 +466,5 @@ extern "C" int glx_conv3x3s2_forward(const float* x, int B, int H, int W, int Ci
                                      void* stream) {
   GLX_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cin % 32 == 0 && Cout % 64 == 0,
               "glx_conv3x3s2_forward: bad sizes (%d, %d, %d), %d -> %d (even maps, Cin %% 32, Cout %% 64)", B, H, W, Cin, Cout);
-  return pconv_launch(x, packed_fwd, y, B, H / 2, W / 2, Cin, Cout, 2, 1, (hipStream_t)stream, 1);
+  return pconv_launch(x, packed_fwd, y, B, H / 2, W / 2, Cin, Cout, 2, 1, (hipStream_t)stream, 1, true);
 }

@@ -255,7 +255,123 @@ class BEVBackbone(nn.Module):
         out._index = rs.out_index
         return out.dense_bev()
 
+    # ---- inference: every eval-mode BatchNorm2d (+ ReLU) folded into the epilogue of the convolution in front of it,
+    # the deblocks write their slices of the concatenated map, the first layer runs on the sparse tensor
+    FUSE_EVAL = os.environ.get("GLX_BEV_EVAL_FUSE", "1") != "0"
+
+    def _eval_plan(self, data_dict):
+        """[(kind, conv, bn)] per block + the deblocks, or None when the module is not of the reference's form."""
+        if not (self.FUSE_EVAL and OWN_CONV3X3 and OWN_DECONV and not self.training and not torch.is_grad_enabled()
+                and len(self.deblocks) == len(self.blocks)):
+            return None
+        plan = []
+        for blk, up in zip(self.blocks, self.deblocks):
+            mods, layers = list(blk), []
+            if not (len(mods) >= 4 and (len(mods) - 1) % 3 == 0 and isinstance(mods[0], nn.ZeroPad2d)
+                    and tuple(mods[0].padding) == (1, 1, 1, 1)):
+                return None
+            for k in range(1, len(mods), 3):
+                conv, bn, act = mods[k], mods[k + 1], mods[k + 2]
+                first = k == 1
+                if not (isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d) and isinstance(act, nn.ReLU)
+                        and conv.kernel_size == (3, 3) and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1)
+                        and conv.padding == ((0, 0) if first else (1, 1)) and bn.track_running_stats
+                        and conv.stride in (((1, 1), (2, 2)) if first else ((1, 1),))
+                        and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0 and conv.weight.is_cuda):
+                    return None
+                layers.append((conv, bn))
+            um = list(up)
+            if not (len(um) == 3 and isinstance(um[0], nn.ConvTranspose2d) and isinstance(um[1], nn.BatchNorm2d)
+                    and isinstance(um[2], nn.ReLU) and um[0].bias is None and um[0].kernel_size == um[0].stride
+                    and um[0].kernel_size in ((1, 1), (2, 2)) and um[0].padding == (0, 0) and um[0].output_padding == (0, 0)
+                    and um[0].groups == 1 and um[0].in_channels % 64 == 0 and um[0].out_channels % 64 == 0
+                    and um[1].track_running_stats):
+                return None
+            plan.append((layers, um[0], um[1]))
+        return plan
+
+    def _forward_eval(self, data_dict, plan):
+        from .spconv import core
+        x = data_dict.get("spatial_features")
+        st = data_dict.get("encoded_spconv_tensor")
+        ups = []
+        for i, (layers, upconv, upbn) in enumerate(plan):
+            for k, (conv, bn) in enumerate(layers):
+                scale, shift = core._bn_affine(bn)
+                if i == 0 and k == 0 and x is None:
+                    x = self._first_layer_sparse_eval(st, conv, scale, shift)
+                    if x is None:
+                        x = data_dict["spatial_features"] = st.dense_bev()
+                    else:
+                        continue
+                if conv.stride == (2, 2):
+                    if x.shape[2] % 2 or x.shape[3] % 2:
+                        return None
+                    x = own_conv.conv3x3s2_affine(x, conv.weight, scale, shift, True)
+                else:
+                    x = own_conv.conv3x3_affine(x, conv.weight, scale, shift, True)
+            ups.append((x, upconv, upbn))
+        h0 = int(st.spatial_shape[1]) if data_dict.get("spatial_features") is None else int(data_dict["spatial_features"].shape[2])
+        for x, _, _ in ups:
+            data_dict["spatial_features_%dx" % int(h0 / x.shape[2])] = x
+        sizes = {(x.shape[2] * int(u.stride[0]), x.shape[3] * int(u.stride[1])) for x, u, _ in ups}
+        if len(sizes) != 1:
+            return None
+        (ho, wo), = sizes
+        b = ups[0][0].shape[0]
+        total = sum(u.out_channels for _, u, _ in ups)
+        cat = torch.empty((b, total, ho, wo), dtype=torch.float32, device=ups[0][0].device, memory_format=torch.channels_last)
+        off = 0
+        for x, upconv, upbn in ups:
+            scale, shift = core._bn_affine(upbn)
+            own_conv.deconv_affine(x, upconv.weight, scale, shift, True, out=cat, channel_offset=off)
+            off += upconv.out_channels
+        data_dict["spatial_features_2d"] = cat
+        return data_dict
+
+    def _first_layer_sparse_eval(self, st, conv, scale, shift):
+        """Inference twin of _first_layer_sparse: the sparse conv, the dense image of its result, then the folded
+        BatchNorm + ReLU on the dense map (cells without an occupied neighbour hold relu(shift), not zero)."""
+        from .spconv import core
+        if st is None or not SPARSE_FIRST_BEV_LAYER:
+            return None
+        c, d = int(st.features.shape[1]), int(st.spatial_shape[0])
+        if not (conv.stride == (1, 1) and conv.in_channels == c * d and 9 * d <= 27 and c in (16, 32, 64, 128)
+                and conv.out_channels in (16, 32, 64, 128) and st.features.shape[0] > 0 and st._index is not None):
+            return None
+        cout = conv.out_channels
+        w = conv.weight.detach().permute(2, 3, 1, 0).unflatten(2, (c, d)).permute(3, 0, 1, 2, 4).reshape(9 * d, c, cout).contiguous()
+        geom = ((d, 3, 3), (d, 1, 1), (0, 1, 1))
+        rs = st.indice_dict.get(BEV_FIRST_KEY) if st.indice_dict is not None else None
+        if rs is not None and (tuple(tuple(g) for g in rs.geom[1:]) != geom or rs.in_indices is not st.indices):
+            rs = None
+        if rs is None:
+            rs = core.build_strided_rules(st, *geom)
+        elif rs.ready is not None:
+            torch.cuda.current_stream(st.features.device).wait_event(rs.ready)
+        feats = core._sconv(st.features.contiguous().float(), w, None, rs.nbr, rs.tile_order_out, rs.N_out, rules=rs,
+                            n_live=rs.count_out)
+        out = core.SparseConvTensor(feats, rs.out_indices, rs.out_spatial_shape, st.batch_size, st.grid, st.voxel_num,
+                                    st.indice_dict, st.benchmark, rs.count_out)
+        out._index = rs.out_index
+        raw = out.dense_bev()
+        b, ch, h, wd = raw.shape
+        rows = raw.permute(0, 2, 3, 1).reshape(b * h * wd, ch)
+        y = torch.empty_like(rows)
+        _lib.call("glx_bn_apply_forward", rows, torch.cat([scale, shift]), 1, b * h * wd, ch, None, y, 0)
+        return y.view(b, h, wd, ch).permute(0, 3, 1, 2)
+
     def forward(self, data_dict):
+        plan = self._eval_plan(data_dict)
+        if plan is not None:
+            x_in = data_dict.get("spatial_features")
+            if x_in is None or (x_in.is_cuda and x_in.is_contiguous(memory_format=torch.channels_last)):
+                keys = set(data_dict.keys())
+                out = self._forward_eval(data_dict, plan)
+                if out is not None:
+                    return out
+                for k in set(data_dict.keys()) - keys:          # a shape the fused path does not cover: module by module
+                    del data_dict[k]
         x0 = data_dict.get("spatial_features")
         first = None
         if x0 is None:                                  # HeightCompression(defer=True): the map is ours to make

@@ -190,7 +190,14 @@ class VoxelRCNNFlow(nn.Module):
         self.vfe = gb.MeanVFE()
         self.backbone_3d = gb.VoxelBackBone8x(num_point_features, grid)
         self.map_to_bev = gb.HeightCompression()
-        self.backbone_2d = dp.BEVBackbone(256)
+        # channels-last BEV map, left to the BEV backbone (first layer on the sparse tensor, dense_path.BEVBackbone)
+        self.map_to_bev.channels_last = True
+        self.map_to_bev.defer = dp.SPARSE_FIRST_BEV_LAYER
+        self.backbone_2d = dp.BEVBackbone(256).to(memory_format=torch.channels_last)
+        if self.map_to_bev.defer:
+            d = 256 // self.backbone_3d.num_point_features
+            self.backbone_3d.extra_plan = (gb.spconv.core.PlannedConv(dp.BEV_FIRST_KEY, (d, 3, 3), (d, 1, 1), (0, 1, 1),
+                                                                       self.backbone_3d.num_point_features, 64),)
         self.dense_head = dp.AnchorHead(self.backbone_2d.num_bev_features, num_class=1,
                                         num_anchors_per_location=2)
         self.roi_pool = rg.RoIGridPool(self.backbone_3d.backbone_channels, self.POOL, 6, cfg["voxel_size"],
@@ -215,7 +222,7 @@ class VoxelRCNNFlow(nn.Module):
         FC refinement.  Free of host synchronisation in eval mode on the device."""
         bd = self.dense_head(self.backbone_2d(bd))
         cls, boxes = predicted_boxes(bd["cls_preds"], bd["box_preds"], bd.get("dir_cls_preds"),
-                                     self.anchors(bd["spatial_features"].device))
+                                     self.anchors(bd["spatial_features_2d"].device))
         rois, roi_scores, roi_labels = proposal_layer(boxes, cls, *self.nms)
         pooled = self.roi_pool(rois, bd["multi_scale_3d_features"], bd["multi_scale_3d_strides"], batch_size)
         rcnn_cls, rcnn_reg = self.roi_fc(pooled)

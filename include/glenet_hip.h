@@ -827,6 +827,9 @@ int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin, const void
 int glx_conv3x3_next_bn_stats(void* state, const float* gamma, const float* beta, float eps, float momentum,
                               float* coef, float* save_mean, float* save_invstd, float* running_mean,
                               float* running_var);
+/* Inference: y = relu?(conv * scale[c] + shift[c]) in the epilogue of the NEXT glx_conv3x3_forward call of this host
+ * thread -- the eval-mode BatchNorm2d (+ ReLU) behind the convolution folded into it (scale, shift: Cout device floats). */
+int glx_conv3x3_next_epilogue(const float* scale, const float* shift, int relu);
 /* The weight gradient of the same convolution: dW (Cout, Cin, 3, 3), written through ELEMENT strides (s_co, s_ci,
  * s_kh, s_kw) (torch keeps the BEV filters in channels-last memory), = sum over pixels of gy (B, H, W, Cout) times
  * the shifted x (B, H, W, Cin); same split-bf16 arithmetic.  Two launches (block partial sums into the workspace,
@@ -853,6 +856,11 @@ int glx_deconv_input_grad(const float* gy, int B, int H, int W, int Cin, const v
  * Bit-reproducible (the vendor's forward kernel for this layer sums split-K slices with atomics). */
 int glx_conv3x3s2_forward(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, float* y,
                           void* stream);
+/* Inference: epilogue and placement of the NEXT glx_deconv_forward / glx_conv3x3s2_forward call of this host thread:
+ * y = relu?(acc * scale[c] + shift[c]) (scale = shift = NULL: none), written with `ldc` floats between output pixels from
+ * channel `coff` of a pixel on (ldc = 0: dense) -- a deblock's map straight into its slice of the concatenated map
+ * (base_bev_backbone.py:100-104: torch.cat(ups, dim=1) on channels-last memory costs no copy). */
+int glx_pconv_next_epilogue(const float* scale, const float* shift, int relu, int ldc, int coff);
 size_t glx_deconv_wgrad_workspace_bytes(int Cin, int Cout, int u);
 int glx_deconv_wgrad(const float* x, const float* gy, int B, int H, int W, int Cin, int Cout, int u, float* dW,
                      long long s_ci, long long s_co, long long s_kh, long long s_kw, void* workspace,

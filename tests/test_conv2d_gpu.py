@@ -260,3 +260,38 @@ def test_dense_kernels_against_the_oracle(dev):
         y3 = c2.deconv(_cl(torch.from_numpy(x3).to(dev)), torch.from_numpy(w3).to(dev)).cpu().numpy()
         ref3 = oracle.conv_transpose2d(x3, w3, u)
         assert np.abs(y3 - ref3).max() < 4e-6 * np.abs(ref3).max()
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_eval_mode_bev_backbone_with_folded_batchnorm_equals_the_modules(dev, sparse, monkeypatch):
+    """Inference: BatchNorm + ReLU in the convolutions' epilogues, deblocks writing their slices of the concatenated map,
+    the first layer on the sparse tensor -- against the same module run layer by layer."""
+    from glenet_amd import dense_path as dp
+    from glenet_amd.spconv import core as sp
+    torch.manual_seed(2)
+    B, D, H, W, C = 2, 2, 40, 48, 128
+    m = dp.BEVBackbone(C * D).to(dev).to(memory_format=torch.channels_last)
+    with torch.no_grad():                                  # non-trivial running statistics and affine parameters
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.uniform_(-0.2, 0.2)
+                mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.uniform_(-0.3, 0.3)
+    m.eval()
+    act = (torch.rand(B, 1, H, W, device=dev) < 0.15) & (torch.rand(B, D, H, W, device=dev) < 0.6)
+    idx = act.nonzero().int().contiguous()
+    feats = torch.randn(idx.shape[0], C, device=dev)
+    outs = []
+    with torch.no_grad():
+        for fuse in (True, False):
+            monkeypatch.setattr(dp.BEVBackbone, "FUSE_EVAL", fuse)
+            st = sp.SparseConvTensor(feats, idx, [D, H, W], B)
+            st._ensure_index()
+            bd = {"encoded_spconv_tensor": st, "spatial_features": None if sparse else st.dense_bev()}
+            assert (m._eval_plan(bd) is not None) == fuse
+            out = m(bd)
+            outs.append((out["spatial_features_2d"], out["spatial_features_1x"], out["spatial_features_2x"]))
+    for a, b_ in zip(*outs):
+        assert a.shape == b_.shape
+        assert torch.allclose(a, b_, rtol=1e-4, atol=2e-5 * float(b_.abs().max())), float((a - b_).abs().max())

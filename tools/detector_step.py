@@ -55,7 +55,7 @@ with torch.no_grad():
     dt = (time.perf_counter() - t0) / n
 st = np.mean([stage_times() for _ in range(5)], axis=0)
 print("two-stage inference flow, %d frames: %.2f ms/step = %.0f frames/s (eager, exact shapes)" % (B, dt * 1e3, B / dt))
-print("  stages (ms): voxelize+sparse backbone+dense %.2f | BEV backbone+head (MIOpen fp32) %.2f | "
+print("  stages (ms): voxelize+sparse backbone+dense %.2f | BEV backbone+head %.2f | "
       "decode+top-k+NMS %.2f | RoI-grid pool+FC %.2f" % tuple(st))
 
 pipe = det.StaticDetectorPipeline(flow, B, pts.shape[0])
