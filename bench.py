@@ -270,6 +270,34 @@ def bench_bev(model, dev, frames=FRAMES_PER_GPU):
                         "forward statistics in the conv epilogue")
 
 
+def bench_inference(dev, frames=FRAMES_PER_GPU, steps=50):
+    """The two-stage INFERENCE flow of the same detector (glenet_amd.detector.VoxelRCNNFlow: voxelize -> sparse backbone ->
+    BEV backbone + anchor head -> decode + top-k + NMS 2048 -> 100 -> RoI-grid pooling -> FC refinement), eval mode, random
+    weights, `frames` synthetic KITTI-shaped frames: eager with exact shapes and as one shape-static HIP graph."""
+    import numpy as np
+    import torch
+    from glenet_amd import detector as det
+    from glenet_amd import synth
+    K = synth.KITTI
+    fr = [synth.kitti_frame(2000 + i)[0] for i in range(frames)]
+    pts = torch.from_numpy(np.concatenate(fr)).to(dev)
+    bidx = torch.from_numpy(np.concatenate([np.full(len(f), i, np.int32) for i, f in enumerate(fr)])).to(dev)
+    torch.manual_seed(0)
+    flow = det.VoxelRCNNFlow(K).to(dev).eval()
+    with torch.no_grad():
+        ms_e = _timed(lambda: flow(pts, bidx, frames), steps, dev, warm=5)
+    pipe = det.StaticDetectorPipeline(flow, frames, pts.shape[0])
+    pipe.calibrate(pts, bidx)
+    pipe.load(pts, bidx)
+    pipe.capture()
+    ms_g = _timed(pipe.replay, steps, dev, warm=5)
+    pipe.check()
+    return dict(workload="two-stage inference flow (VoxelRCNNFlow), %d frames x 20 000 points, eval mode: BatchNorm folded into "
+                         "the sparse and dense convolutions' epilogues, NMS 2048 -> 100 proposals per frame" % frames,
+                eager_ms_per_step=round(ms_e, 3), eager_frames_per_s=round(frames / ms_e * 1e3, 1),
+                graph_ms_per_step=round(ms_g, 3), graph_frames_per_s=round(frames / ms_g * 1e3, 1))
+
+
 def bench_config3(dev, objects=4096, points=512, samples=30):
     """BASELINE configs[3]: the CVAE on 4096 object crops x 512 points -- (i) the inference sampler, 30 latent samples
     per object (fused MFMA PointNet kernel, csrc/glx_pointnet.hip), (ii) one TRAINING step forward + backward + clip +
@@ -653,6 +681,9 @@ def main():
             out["bev"] = bench_bev(model, dev)
             progress("bev done")
             del pipe
+            torch.cuda.empty_cache()
+            out["inference"] = bench_inference(dev)
+            progress("inference flow done")
             torch.cuda.empty_cache()
             out["config3"] = bench_config3(dev)
             progress("config3 done")
