@@ -896,7 +896,11 @@ extern "C" int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin,
   }
   const int lds_bytes = v2 ? 3 * (th + 2) * CV_HW * CV_ROW : CV_LDS;
   if (v2) {
-    GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    static bool v2_set[2][9] = {};
+    if (!v2_set[bn_state ? 1 : 0][th]) {
+      GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+      v2_set[bn_state ? 1 : 0][th] = true;
+    }
   } else {
     static bool attr_set[8] = {};
     if (!attr_set[slot]) {
