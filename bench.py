@@ -669,6 +669,11 @@ def main():
                                            % (world, n_params * 4 / 1e6) if world > 1 else "dp1 (single GPU, no collective)",
                                ranks_seen_by_collective=ranks_seen,
                                device_data_step=bool(args.device_data_step),
+                               arithmetic="fp32 tensors and fp32 accumulation everywhere; the BEV backbone's convolutions form "
+                                          "their fp32 products on the bf16 matrix pipe from three-way split operands (six "
+                                          "MFMAs per product tile, products exact to 2^-22: error against an fp64 convolution "
+                                          "equal to the vendor's fp32 kernels', tests/test_conv2d_gpu.py, "
+                                          "tests/test_oracle_cpu.py::test_split_bf16_pieces_carry_an_fp32_product)",
                                host_enqueue_ms_per_step=round(t_host * 1e3, 4) if t_host is not None else None,
                                host_loop_ms_per_step=round(t_enq / max(args.steps, 1) * 1e3, 4),
                                host_note="host_enqueue = set_lr (2 fills) + load (1 launch) + graph replay(s) measured on 3 "
