@@ -333,9 +333,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
 // changes per 32-channel chunk, so a block synchronises twice per NINE taps instead of once per tap, and with 43 KB of
 // LDS three blocks share a CU.  The price is 24 instead of 6 row-operand reads per wave and step (every wave reads the
 // whole tile): 96 instead of 72 LDS reads per block and step, none of them weights.
-// TH = pixel rows per tile (accumulators per wave), picked per launch so that the tile count fits the resident blocks:
-// 200 rows as 34 tiles of 6 give 1496 tiles = 1.95 rounds of 768 blocks (8 rows: 1100 tiles = 1.43, a second round
-// with 43 % of the blocks); 100 rows as 15 tiles of 7 give one round of 720.
+// TH = pixel rows per tile (accumulators per wave), 7 or 8, picked per launch so that the tile count fits whole rounds of
+// the 768 resident blocks: 200 rows x 176 columns x 4 frames are 1100 tiles of 8 rows (1.43 rounds: a second round with
+// 43 % of the blocks) or 1276 of 7 (1.66); 100 x 88 x 4 with two channel blocks are 720 units of 7 rows, one round.
+// (Six rows measured the same as seven and are instantiated for experiments only: GLX_CONV3X3_TH=6.)
 
 template <bool STATS, int TH>
 __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
