@@ -361,7 +361,13 @@ class BEVBackbone(nn.Module):
         _lib.call("glx_bn_apply_forward", rows, torch.cat([scale, shift]), 1, b * h * wd, ch, None, y, 0)
         return y.view(b, h, wd, ch).permute(0, 3, 1, 2)
 
+    convert_input = False      # dropin.accelerate(): an NCHW `spatial_features` map is converted to channels-last on entry
+
     def forward(self, data_dict):
+        x_in = data_dict.get("spatial_features")
+        if (self.convert_input and x_in is not None and x_in.is_cuda and x_in.dim() == 4
+                and not x_in.is_contiguous(memory_format=torch.channels_last)):
+            data_dict["spatial_features"] = x_in.contiguous(memory_format=torch.channels_last)
         plan = self._eval_plan(data_dict)
         if plan is not None:
             x_in = data_dict.get("spatial_features")

@@ -72,3 +72,28 @@ def install(spconv=True, ops=True, overwrite=False):
         sys.modules["cumm.tensorview"] = cumm.tensorview
         done += ["cumm", "cumm.tensorview"]
     return done
+
+
+def accelerate(model, channels_last=True):
+    """Put the reference's BEV backbones on the own dense kernels: every `BaseBEVBackbone` in `model`
+    (pcdet/models/backbones_2d/base_bev_backbone.py:6-112 -- `blocks`, `deblocks`, `forward(data_dict)`) is re-classed to
+    glenet_amd.dense_path.BEVBackbone, which keeps the module lists, parameter names and data_dict keys and runs the 3x3
+    / strided / transposed convolutions on csrc/glx_conv2d.hip + glx_deconv2d.hip (fp32 products on the bf16 matrix
+    pipe), training-mode BatchNorm on csrc/glx_bn.hip with the statistics in the conv epilogues, eval-mode BatchNorm
+    folded into the epilogues.  channels_last: filters are moved to channels-last memory and the incoming
+    `spatial_features` map is converted on entry (one copy); everything downstream sees logical NCHW tensors as before.
+    Returns the names of the modules it changed.  Nothing else of the reference is touched; on CPU tensors the module
+    runs its layers one by one exactly as the reference does."""
+    import torch
+    from . import dense_path as dp
+    changed = []
+    for name, m in model.named_modules():
+        if type(m).__name__ == "BaseBEVBackbone" and not isinstance(m, dp.BEVBackbone) \
+                and isinstance(getattr(m, "blocks", None), torch.nn.ModuleList) \
+                and isinstance(getattr(m, "deblocks", None), torch.nn.ModuleList):
+            m.__class__ = dp.BEVBackbone
+            if channels_last:
+                m.to(memory_format=torch.channels_last)
+                m.convert_input = True
+            changed.append(name)
+    return changed

@@ -295,3 +295,43 @@ def test_eval_mode_bev_backbone_with_folded_batchnorm_equals_the_modules(dev, sp
     for a, b_ in zip(*outs):
         assert a.shape == b_.shape
         assert torch.allclose(a, b_, rtol=1e-4, atol=2e-5 * float(b_.abs().max())), float((a - b_).abs().max())
+
+
+def test_dropin_accelerate_reclasses_a_reference_shaped_backbone(dev):
+    """dropin.accelerate() on a module with the reference's BaseBEVBackbone layout (same attribute names, an NCHW input
+    map): the own kernels run, outputs and gradients equal the module's plain layer-by-layer forward."""
+    import types
+    from glenet_amd import dense_path as dp, dropin
+
+    class BaseBEVBackbone(torch.nn.Module):                  # the reference's class name and attribute layout
+        def __init__(self):
+            super().__init__()
+            src = dp.BEVBackbone(64, layer_nums=(1, 1), num_filters=(64, 128))
+            self.blocks, self.deblocks, self.num_bev_features = src.blocks, src.deblocks, src.num_bev_features
+
+        def forward(self, data_dict):                        # base_bev_backbone.py:81-112
+            x, ups = data_dict["spatial_features"], []
+            for i in range(len(self.blocks)):
+                x = self.blocks[i](x)
+                ups.append(self.deblocks[i](x))
+            data_dict["spatial_features_2d"] = torch.cat(ups, dim=1)
+            return data_dict
+
+    torch.manual_seed(3)
+    m = BaseBEVBackbone().to(dev).train()
+    x = torch.randn(2, 64, 24, 32, device=dev)               # NCHW, as HeightCompression delivers it
+    xa = x.clone().requires_grad_(True)
+    ya = m({"spatial_features": xa})["spatial_features_2d"]
+    ya.square().mean().backward()
+    ga = [p.grad.clone() for p in m.parameters()]
+    for p in m.parameters():
+        p.grad = None
+    assert dropin.accelerate(types.SimpleNamespace(named_modules=lambda: [("backbone_2d", m)])) == ["backbone_2d"]
+    assert isinstance(m, dp.BEVBackbone)
+    xb = x.clone().requires_grad_(True)
+    yb = m({"spatial_features": xb})["spatial_features_2d"]
+    yb.square().mean().backward()
+    assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(xa.grad, xb.grad, rtol=1e-3, atol=1e-5 * float(xa.grad.abs().max()))
+    for a, p in zip(ga, m.parameters()):
+        assert torch.allclose(a, p.grad, rtol=1e-3, atol=2e-5 * float(a.abs().max()) + 1e-9)

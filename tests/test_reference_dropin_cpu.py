@@ -30,6 +30,9 @@ def test_unmodified_reference_imports_and_builds_on_the_dropin(tmp_path):
                              "VoxelRCNNKLLabelIoUHead"]
     assert vr["spconv_weight_keys"] == 12 and vr["layout_conversion_by_reference_loader"].startswith("ok")
     assert rep["networks"]["waymo_centerpoint_res"]["spconv_weight_keys"] == 21
+    acc = vr["accelerate"]                      # dropin.accelerate(): the reference's BEV backbone on our dense kernels
+    assert acc["modules"] == ["backbone_2d"] and acc["class"] == "glenet_amd.dense_path.BEVBackbone"
+    assert acc["max_abs_diff_cpu"] < 1e-5
     assert rep["networks"]["glenet_c"]["modules"][-1] == "AnchorHeadKLLabelIoU"
     assert rep["data_processor_voxels"] > 10000
     # the committed fixture is what this run produces

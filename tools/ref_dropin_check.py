@@ -214,6 +214,28 @@ def check_data_processor(cfg, report):
     report["data_processor_voxels"] = int(len(c))
 
 
+def check_accelerate(net):
+    """glenet_amd.dropin.accelerate() on the reference's own network: its BaseBEVBackbone is re-classed to our BEVBackbone,
+    the state-dict keys stay, and (on CPU, where both run torch's kernels layer by layer) the output stays."""
+    import torch
+    from glenet_amd import dropin
+    bev = [m for m in net.modules() if type(m).__name__ == "BaseBEVBackbone"][0]
+    keys = list(net.state_dict().keys())
+    x = torch.randn(1, bev.blocks[0][1].in_channels, 16, 24)
+    was = bev.training
+    bev.eval()
+    with torch.no_grad():
+        want = bev({"spatial_features": x})["spatial_features_2d"].clone()
+    changed = dropin.accelerate(net)
+    with torch.no_grad():
+        got = bev({"spatial_features": x})["spatial_features_2d"]
+    bev.train(was)
+    assert type(bev).__module__ == "glenet_amd.dense_path" and list(net.state_dict().keys()) == keys
+    err = float((got - want).abs().max())
+    assert err < 1e-5, err
+    return {"modules": changed, "class": type(bev).__module__ + "." + type(bev).__name__, "max_abs_diff_cpu": err}
+
+
 def main(write=False):
     import numpy as np
     import torch  # noqa: F401
@@ -235,6 +257,8 @@ def main(write=False):
                                   "parameters": int(sum(p.numel() for p in net.parameters()))}
         if tag in ("glenet_vr", "waymo_centerpoint_res"):
             check_spconv_side(net, report["networks"][tag])
+        if tag == "glenet_vr":
+            report["networks"][tag]["accelerate"] = check_accelerate(net)
     check_data_processor(first_cfg, report)
     # the import name every reference file sees is ours
     import pcdet.ops.pointnet2.pointnet2_batch.pointnet2_utils as pb
