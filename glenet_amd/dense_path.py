@@ -507,8 +507,19 @@ class AnchorHead(nn.Module):
 
     def _forward_fused(self, data_dict, x):
         convs = [self.conv_cls, self.conv_box] + ([self.conv_dir_cls] if self.conv_dir_cls is not None else [])
-        w = torch.cat([c.weight for c in convs], dim=0)
-        b = torch.cat([c.bias for c in convs], dim=0)
+        if torch.is_grad_enabled():
+            w = torch.cat([c.weight for c in convs], dim=0)
+            b = torch.cat([c.bias for c in convs], dim=0)
+        else:                                   # inference: the concatenated filters are cached until the weights move
+            tag = (_lib.weights_epoch(),) + tuple(c.weight._version for c in convs) + tuple(c.bias._version for c in convs)
+            hit = self.__dict__.get("_glx_fused_heads")
+            if hit is None or hit[0] != tag or hit[1].device != x.device:
+                w = torch.cat([c.weight.detach() for c in convs], dim=0)
+                if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
+                    w = w.contiguous(memory_format=torch.channels_last)
+                hit = (tag, w, torch.cat([c.bias.detach() for c in convs], dim=0))
+                self.__dict__["_glx_fused_heads"] = hit
+            w, b = hit[1], hit[2]
         y = conv2d(x, w, b).permute(0, 2, 3, 1)                                           # (B,H,W,sum Cout)
         parts = y.split([c.out_channels for c in convs], dim=-1)
         data_dict["cls_preds"] = parts[0].contiguous()
@@ -519,7 +530,8 @@ class AnchorHead(nn.Module):
 
     def forward(self, data_dict):
         x = data_dict["spatial_features_2d"]
-        if (self.FUSE_HEADS and torch.is_grad_enabled() and self.conv_cls.bias is not None
+        if (self.FUSE_HEADS and self.conv_cls.bias is not None and self.conv_box.bias is not None
+                and (self.conv_dir_cls is None or self.conv_dir_cls.bias is not None)
                 and all(c.kernel_size == (1, 1) for c in (self.conv_cls, self.conv_box))):
             return self._forward_fused(data_dict, x)
         data_dict["cls_preds"] = self.conv_cls(x).permute(0, 2, 3, 1).contiguous()      # (B,H,W,A*cls)
