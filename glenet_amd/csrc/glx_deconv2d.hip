@@ -195,6 +195,129 @@ __global__ __launch_bounds__(256, 2) void k_pconv(PconvArgs a) {
   }
 }
 
+// Second form, as k_conv3x3_v2: wave w owns ONE 16-channel tile for all 128 pixels of the block, its weight fragments
+// (3 planes x 16 bytes per lane per step) come straight from L2 into the MFMA operands one step ahead -- no weight image
+// in LDS; the row image alone (31 KB) lets three blocks share a CU.
+#define PC2_LDS (3 * PC_APLANE)
+
+__global__ __launch_bounds__(256, 3) void k_pconv_v2(PconvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const int nch = a.Ck >> 5, nsteps = a.ktaps * nch;
+  const size_t wslice = (size_t)a.N * 32;
+  const int hw = a.Hc * a.Wc;
+
+  for (int unit = blockIdx.x; unit < a.nunits; unit += gridDim.x) {
+    int t = unit;
+    const int n0 = (t % a.nblk) * PC_BN;
+    t /= a.nblk;
+    const int ntap = t % a.ntaps;
+    const int m0 = (t / a.ntaps) * PC_TM;
+    const uint16_t* wsrc = a.wp + ((size_t)ntap * nsteps * 3) * wslice + (size_t)(n0 + 16 * wave + r) * 32 + kq * 8;
+
+    long long abase[4];
+    int iy0[4], ix0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256, m = m0 + (e >> 3);
+      if (m < a.M) {
+        const int b = m / hw, rem = m - b * hw, y = rem / a.Wc, x = rem - y * a.Wc;
+        abase[i] = (((long long)b * a.Hc * a.ui + (long long)y * a.ui) * (a.Wc * a.ui) + (long long)x * a.ui) * a.Ck + (e & 7) * 4;
+        iy0[i] = y * a.ui;
+        ix0[i] = x * a.ui;
+      } else {
+        abase[i] = -1;
+        iy0[i] = ix0[i] = 0;
+      }
+    }
+    f32x4 areg[4];
+    bf16x8 wcur[3], wnxt[3];
+#define PC2_LOAD(STEP)                                                                                         \
+  {                                                                                                            \
+    const int kt_ = (STEP) / nch, ch_ = (STEP) - kt_ * nch;                                                    \
+    const int dy_ = a.k3 ? kt_ / 3 - 1 : kt_ / a.ui, dx_ = a.k3 ? kt_ % 3 - 1 : kt_ % a.ui;                    \
+    const long long off_ = ((long long)dy_ * (a.Wc * a.ui) + dx_) * a.Ck + ch_ * 32;                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                         \
+      const bool ok_ = abase[i_] >= 0 && (!a.k3 || ((unsigned)(iy0[i_] + dy_) < (unsigned)(a.Hc * a.ui) &&     \
+                                                    (unsigned)(ix0[i_] + dx_) < (unsigned)(a.Wc * a.ui)));     \
+      areg[i_] = ok_ ? *reinterpret_cast<const f32x4*>(a.x + abase[i_] + off_) : f32x4{0.f, 0.f, 0.f, 0.f};    \
+    }                                                                                                          \
+    const uint16_t* s_ = wsrc + (size_t)(STEP) * 3 * wslice;                                                   \
+    wnxt[0] = *reinterpret_cast<const bf16x8*>(s_);                                                            \
+    wnxt[1] = *reinterpret_cast<const bf16x8*>(s_ + wslice);                                                   \
+    wnxt[2] = *reinterpret_cast<const bf16x8*>(s_ + 2 * wslice);                                               \
+  }
+#define PC2_STORE()                                                                                            \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                           \
+    const int e_ = tid + i_ * 256;                                                                             \
+    char* d_ = sA + (e_ >> 3) * PC_ROW + (e_ & 7) * 8;                                                         \
+    bf16x4 p0_, p1_, p2_;                                                                                      \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                         \
+      __bf16 u_, v_, w_;                                                                                       \
+      cv_split(areg[i_][j_], u_, v_, w_);                                                                      \
+      p0_[j_] = u_; p1_[j_] = v_; p2_[j_] = w_;                                                                \
+    }                                                                                                          \
+    *reinterpret_cast<bf16x4*>(d_) = p0_;                                                                      \
+    *reinterpret_cast<bf16x4*>(d_ + PC_APLANE) = p1_;                                                          \
+    *reinterpret_cast<bf16x4*>(d_ + 2 * PC_APLANE) = p2_;                                                      \
+  }
+
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    PC2_LOAD(0);
+    for (int s = 0; s < nsteps; ++s) {
+      __syncthreads();                  // everyone has read the previous row image
+      PC2_STORE();
+#pragma unroll
+      for (int q = 0; q < 3; ++q) wcur[q] = wnxt[q];
+      __syncthreads();
+      if (s + 1 < nsteps) { PC2_LOAD(s + 1); }
+#pragma unroll
+      for (int part = 0; part < 4; ++part) {
+        bf16x8 xa[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            xa[i][q] = *reinterpret_cast<const bf16x8*>(sA + q * PC_APLANE + ((2 * part + i) * 16 + r) * PC_ROW + kq * 16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) BF3_MFMA6(acc[2 * part + i], wcur, xa[i]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#undef PC2_LOAD
+#undef PC2_STORE
+    // accumulator i = coarse pixel m0 + 16 i + r; channels n0 + 16 wave + 4 kq ..
+    const int ch0 = n0 + 16 * wave + 4 * kq;
+    f32x4 sc = f32x4{1.f, 1.f, 1.f, 1.f}, sh = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.epi_scale) {
+      sc = *reinterpret_cast<const f32x4*>(a.epi_scale + ch0);
+      sh = *reinterpret_cast<const f32x4*>(a.epi_shift + ch0);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + 16 * i + r;
+      if (m < a.M) {
+        const int b = m / hw, rem = m - b * hw, y = rem / a.Wc, x = rem - y * a.Wc;
+        f32x4 v = acc[i];
+        if (a.epi_scale) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float tt = __fmaf_rn(v[g], sc[g], sh[g]);
+            v[g] = a.epi_relu ? fmaxf(tt, 0.f) : tt;
+          }
+        }
+        *reinterpret_cast<f32x4*>(a.y + ((((long long)b * a.Hc + y) * a.uo + ntap / a.uo) * (a.Wc * a.uo) + (long long)x * a.uo +
+                                          ntap % a.uo) * a.ldc + a.coff + ch0) = v;
+      }
+    }
+  }
+}
+
 extern "C" size_t glx_deconv_packed_bytes(int Cin, int Cout, int u) {
   return glx_align((size_t)u * u * 3 * Cin * Cout * sizeof(uint16_t));
 }
@@ -229,6 +352,7 @@ extern "C" int glx_pconv_next_epilogue(const float* scale, const float* shift, i
 
 static int pconv_launch(const float* x, const void* packed, float* y, int B, int Hc, int Wc, int Ck, int N, int ui, int uo,
                         hipStream_t st, int k3 = 0, bool take_epilogue = false) {
+  static const int form = getenv("GLX_PCONV_FORM") ? atoi(getenv("GLX_PCONV_FORM")) : 2;
   static bool attr_set = false;
   if (!attr_set) {
     GLX_HIP(hipFuncSetAttribute((const void*)k_pconv, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));
@@ -259,7 +383,12 @@ static int pconv_launch(const float* x, const void* packed, float* y, int B, int
     GLX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     slots = 2 * (cus > 0 ? cus : 256);
   }
-  hipLaunchKernelGGL(k_pconv, dim3(a.nunits < slots ? a.nunits : slots), dim3(256), PC_LDS, st, a);
+  if (form == 2) {
+    const int resident = slots / 2 * 3;
+    hipLaunchKernelGGL(k_pconv_v2, dim3(a.nunits < resident ? a.nunits : resident), dim3(256), PC2_LDS, st, a);
+  } else {
+    hipLaunchKernelGGL(k_pconv, dim3(a.nunits < slots ? a.nunits : slots), dim3(256), PC_LDS, st, a);
+  }
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
