@@ -523,9 +523,11 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
 // ------------------------------------------------------------------------------------------------ weight gradient
 // dW[co][ci][dy][dx] = sum over pixels p of gy[p][co] * x[p + (dy-1, dx-1)][ci]: per tap a (Cout x pixels) x (pixels x
 // Cin) product whose K index is the PIXEL, the strided index of a channels-last map.  A block owns a 64-channel block
-// of Cout x a 32-channel block of Cin (all nine taps: 18 accumulator tiles per wave) and walks pixel tiles:
-//   * gy (rows = co, one 16-channel tile per wave) is needed in ONE alignment only: every lane loads its 8 pixels x 4
-//     k-steps straight from global memory (16 lanes = 64 contiguous bytes) one tile ahead, splits them in registers;
+// of Cout x a 32-channel block of Cin (all nine taps); a wave owns TWO 16-channel tiles of Cout x ONE of Cin (18
+// accumulator tiles: every x fragment read from LDS feeds two tiles -- with one tile of Cout x two of Cin the LDS reads
+// took as long as the MFMAs) and walks pixel tiles:
+//   * gy (rows = co) is needed in ONE alignment only: every lane loads its 8 pixels of the two tiles straight from
+//     global memory (16 lanes = 64 contiguous bytes) one k-step ahead and splits them in registers;
 //   * x is needed in nine alignments: its halo is staged as in the forward kernel ([pixel][32 ci] rows, three planes)
 //     and read with ds_read_b64_tr_b16, the transposing LDS read (a 16-lane group reads 4 pixels x 16 channels and
 //     every lane receives ITS channel's 4 pixels).  64-byte pixel rows whose two 32-byte halves swap on odd 8-pixel
@@ -543,6 +545,7 @@ struct WgradArgs {
   int B, H, W, Cin, Cout, tiles_x, tiles_y, ntiles, nq_ci, nq, P;
 };
 
+template <bool PIPE>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -560,8 +563,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
     adst[i] = e < CV_HP * 8 ? hp * 64 + (((seg >> 2) ^ ((hx >> 3) & 1)) << 5) + (seg & 3) * 8 : -1;
   }
   f32x4 areg[CV_ALOADS];     // x halo of the next tile
-  float greg[4][8];          // gy of the next tile: k-step s, pixel 8 (kq & 1) + jj of tile row 2 s + (kq >> 1)
-#define WG_LOAD(T)                                                                                        \
+  float graw[2][8];          // gy of the next k-step: channel tile 2 cp + a2, pixel 8 (kq & 1) + jj of tile row 2 s + (kq >> 1)
+  const int cp = wave >> 1, nn = wave & 1;
+#define WG_LOADX(T)                                                                                       \
   {                                                                                                       \
     int t_ = (T);                                                                                         \
     const int x0_ = (t_ % a.tiles_x) * CV_TW;                                                             \
@@ -576,16 +580,21 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
                                                        ib * 32 + seg_ * 4)                                 \
                      : f32x4{0.f, 0.f, 0.f, 0.f};                                                         \
     }                                                                                                     \
-    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                    \
-      const int py_ = y0_ + 2 * s_ + (kq >> 1);                                                           \
-      const float* g_ = a.gy + (((long long)b_ * a.H + py_) * a.W + x0_ + 8 * (kq & 1)) * a.Cout + cb * 64 + \
-                        wave * 16 + c;                                                                    \
+  }
+#define WG_LOADG(T, S)                                                                                    \
+  {                                                                                                       \
+    int t_ = (T);                                                                                         \
+    const int x0_ = (t_ % a.tiles_x) * CV_TW;                                                             \
+    t_ /= a.tiles_x;                                                                                      \
+    const int y0_ = (t_ % a.tiles_y) * CV_TH, b_ = t_ / a.tiles_y;                                        \
+    const int py_ = y0_ + 2 * (S) + (kq >> 1), px_ = x0_ + 8 * (kq & 1);                                  \
+    const float* g_ = a.gy + (((long long)b_ * a.H + py_) * a.W + px_) * a.Cout + cb * 64 + cp * 32 + c;  \
+    _Pragma("unroll") for (int a2_ = 0; a2_ < 2; ++a2_)                                                   \
       _Pragma("unroll") for (int jj_ = 0; jj_ < 8; ++jj_)                                                 \
-        greg[s_][jj_] = (py_ < a.H && x0_ + 8 * (kq & 1) + jj_ < a.W) ? g_[(long long)jj_ * a.Cout] : 0.f; \
-    }                                                                                                     \
+        graw[a2_][jj_] = (py_ < a.H && px_ + jj_ < a.W) ? g_[(long long)jj_ * a.Cout + a2_ * 16] : 0.f;    \
   }
 
-  f32x4 acc[9][2];
+  f32x4 acc[9][2];           // [tap][channel tile of the pair]
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -599,22 +608,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
       const int hx = 8 * (kq & 1) + 4 * h + qq + dx;
-      rbase[h][dx] = ((kq >> 1) * CV_HW + hx) * 64 + (((hx >> 3) & 1) << 5) + pp * 8;
+      rbase[h][dx] = (((kq >> 1) * CV_HW + hx) * 64 + (((hx >> 3) & 1) << 5) + pp * 8) ^ (nn << 5);
     }
 
   int tile = p;
-  if (tile < a.ntiles) { WG_LOAD(tile); }
+  if (tile < a.ntiles) {
+    WG_LOADX(tile);
+    WG_LOADG(tile, 0);
+  }
   while (tile < a.ntiles) {
-    // ---- this tile's gy pieces (registers) and x halo image (LDS)
-    bf16x8 ga[4][3];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
-        __bf16 u, v, w;
-        cv_split(greg[s][jj], u, v, w);
-        ga[s][0][jj] = u; ga[s][1][jj] = v; ga[s][2][jj] = w;
-      }
     __syncthreads();          // the previous tile's reads of the image are done
 #pragma unroll
     for (int i = 0; i < CV_ALOADS; ++i) {
@@ -635,36 +637,55 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
     const int next = tile + a.P;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      if (s == 3 && next < a.ntiles) { WG_LOAD(next); }     // ga[0..2] are dead: their registers take the loads
+      // this k-step's gy pieces (two channel tiles), then the next k-step's loads into the registers they leave
+      bf16x8 ga[2][3];
+#pragma unroll
+      for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          __bf16 u, v, w;
+          cv_split(graw[a2][jj], u, v, w);
+          ga[a2][0][jj] = u; ga[a2][1][jj] = v; ga[a2][2][jj] = w;
+        }
+      if (s < 3) {
+        WG_LOADG(tile, s + 1);
+      } else if (next < a.ntiles) {
+        WG_LOADG(next, 0);
+      }
+      if (s == 2 && next < a.ntiles) { WG_LOADX(next); }
+#define WG_READX(XB, TAP)                                                                                  \
+  _Pragma("unroll") for (int pl_ = 0; pl_ < 3; ++pl_) {                                                    \
+    const int off_ = pl_ * WG_XPLANE + (2 * s + (TAP) / 3) * CV_HW * 64;                                   \
+    typedef i16x4 __attribute__((address_space(3))) * lds_p;                                               \
+    i16x4 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(smem + off_ + rbase[0][(TAP) % 3]));       \
+    i16x4 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(smem + off_ + rbase[1][(TAP) % 3]));       \
+    XB[pl_] = wg_join(lo_, hi_);                                                                           \
+  }
+      bf16x8 xb[2][3];
+      if (PIPE) { WG_READX(xb[0], 0); }
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3, dx = tap % 3;
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-          bf16x8 xb[3];
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) {
-            const int off = pl * WG_XPLANE + (2 * s + dy) * CV_HW * 64;
-            typedef i16x4 __attribute__((address_space(3))) * lds_p;
-            i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(smem + off + (rbase[0][dx] ^ (n << 5))));
-            i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(smem + off + (rbase[1][dx] ^ (n << 5))));
-            xb[pl] = wg_join(lo, hi);
-          }
-          f32x4 v = acc[tap][n];
-          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[s][2], xb[0], v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[s][0], xb[2], v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[s][1], xb[1], v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[s][1], xb[0], v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[s][0], xb[1], v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[s][0], xb[0], v, 0, 0, 0);
-          acc[tap][n] = v;
+        if (PIPE) {
+          if (tap < 8) { WG_READX(xb[(tap + 1) & 1], tap + 1); }
+        } else {
+          WG_READX(xb[tap & 1], tap);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2) {
+          f32x4 v = acc[tap][a2];
+          BF3_MFMA6(v, ga[a2], xb[tap & 1]);
+          acc[tap][a2] = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
+#undef WG_READX
     }
     tile = next;
   }
-#undef WG_LOAD
-  // ---- the block's partial sums: element ((tap * 2 + n) * 4 + reg) * 256 + tid
+#undef WG_LOADX
+#undef WG_LOADG
+  // ---- the block's partial sums: element ((tap * 2 + a2) * 4 + reg) * 256 + tid
   float* dst = a.ws + (size_t)(q * a.P + p) * WG_PART + tid;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
@@ -696,10 +717,10 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad_reduce(const float* __res
   __syncthreads();
   if (seg == 0) {
     sum = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
-    const int tap = e >> 11, n = (e >> 10) & 1, rg = (e >> 8) & 3, t = e & 255;
+    const int tap = e >> 11, a2 = (e >> 10) & 1, rg = (e >> 8) & 3, t = e & 255;
     const int wave = t >> 6, lane = t & 63;
     const int ib = q % nq_ci, cb = q / nq_ci;
-    const int co = cb * 64 + wave * 16 + 4 * (lane >> 4) + rg, ci = ib * 32 + n * 16 + (lane & 15);
+    const int co = cb * 64 + (wave >> 1) * 32 + a2 * 16 + 4 * (lane >> 4) + rg, ci = ib * 32 + (wave & 1) * 16 + (lane & 15);
     dW[co * s_co + ci * s_ci + (tap / 3) * s_kh + (tap % 3) * s_kw] = sum;
   }
 }
@@ -735,7 +756,11 @@ extern "C" int glx_conv3x3_wgrad(const float* x, const float* gy, int B, int H, 
   a.nq_ci = Cin / 32;
   a.nq = a.nq_ci * (Cout / CV_BN);
   const int blocks = wgrad_blocks(Cin, Cout, &a.P);
-  hipLaunchKernelGGL(k_conv3x3_wgrad, dim3(blocks), dim3(256), WG_LDS, (hipStream_t)stream, a);
+  static const bool pipe = getenv("GLX_WGRAD_PIPE") ? atoi(getenv("GLX_WGRAD_PIPE")) != 0 : true;
+  if (pipe)
+    hipLaunchKernelGGL(k_conv3x3_wgrad<true>, dim3(blocks), dim3(256), WG_LDS, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(k_conv3x3_wgrad<false>, dim3(blocks), dim3(256), WG_LDS, (hipStream_t)stream, a);
   GLX_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_conv3x3_wgrad_reduce, dim3(WG_PART / 64, a.nq), dim3(256), 0, (hipStream_t)stream, a.ws, a.P,
                      a.nq_ci, dW, s_co, s_ci, s_kh, s_kw);
