@@ -564,29 +564,42 @@ def main():
         t_host = (time.perf_counter() - th) / 3
         torch.cuda.synchronize(dev)
     progress("headline done: %.2f ms/step" % (dt / max(args.steps, 1) * 1e3))
-    # ---- per-stage milliseconds: one event-bracketed eager pass of the same launches per pool batch
+    # ---- per-stage milliseconds INSIDE graph replays: the step is recorded once more with a one-thread stamp launch
+    # (glx_stamp: the device's 100 MHz wall clock) at every stage boundary of the main stream, replayed over the batch
+    # pool, and the differences of the stamps are averaged.  (Events would split the graph, the profiler's per-kernel
+    # signals stretch it by ~1 ms; a stamp costs one 2-3 us launch.)
     stages = None
-    if not args.no_stages:
-        marks = []
+    if not args.no_stages and args.mode == "graph" and pipe.graph is not None:
+        stamps = torch.zeros(64, dtype=torch.int64, device=dev)
+        names = []
 
         def mark(name):
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-            marks.append((name, ev))
+            if name == "start":
+                names.clear()
+            gb._lib.call("glx_stamp", stamps, len(names))
+            names.append(name)
+        pipe.mark = model.mark = mark
+        torch.cuda.synchronize(dev)
+        pipe.capture(split=world > 1)
         acc = {}
-        for j in range(min(4, BATCH_POOL)):
-            marks.clear()
-            pipe.load(*pool[j][:4])
-            pipe.mark = model.mark = mark
-            mark("start")
-            pipe.enqueue_eager_marked()
+        for j in range(3 * BATCH_POOL):
+            pipe.load(*pool[j % BATCH_POOL][:4])
+            pipe.step()
+            if j % 3 != 2:
+                continue              # read the stamps of a replay that ran right behind two others (clocks up)
             torch.cuda.synchronize(dev)
-            for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
-                acc.setdefault(n1, []).append(e0.elapsed_time(e1))
+            t = stamps[:len(names)].tolist()
+            for n1, t1 in zip(names[1:], t[1:]):
+                acc.setdefault(n1, []).append((t1 - t[0]) * 1e-5)
         pipe.mark = model.mark = None
         stages = {k: round(float(np.mean(v)), 3) for k, v in acc.items()}
-        stages["note"] = ("ms between stage marks in an eager (not graph-replayed) pass, rule tables and weight "
-                          "gradients on their side stream; the sum exceeds ms_per_step by the launch gaps a graph removes")
+        stages["note"] = ("ms from the step's first launch to one-thread stamp launches (100 MHz device clock) recorded "
+                          "at the stage boundaries, inside graph replays of a second recording of the same step; a stamp "
+                          "is ordered on the stream its stage runs on: the RoI stages (proposals ... RoI-head losses) run "
+                          "on their own stream beside the anchor targets, the dense-head loss and the first two backward "
+                          "stages; rule tables and weight gradients run on a third")
+        torch.cuda.synchronize(dev)
+        pipe.capture(split=world > 1)          # the recording without stamps again
 
     progress("stages done")
     # ---- configs[1]: sparse backbone forward only (eval mode, BN folded), two frame pipelines in flight

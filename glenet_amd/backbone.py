@@ -451,6 +451,8 @@ class StaticTrainPipeline(StaticFramePipeline):
         # the capture down (a segfault in hipStreamEndCapture on ROCm 7.2).  Callers that keep
         # their own reference to an earlier loss / batch_dict must drop it before capture().
         self.out = self.loss = None
+        if self.mark:
+            self.mark("start")
         with workspace.scoped(id(self)):
             with torch.no_grad():
                 pts, bidx = self.points, self.batch_idx
@@ -509,6 +511,8 @@ class StaticTrainPipeline(StaticFramePipeline):
                 _reset_conv_packs()
             if self.overlap_wgrad:
                 cur.wait_stream(self.plan_stream)
+            if not torch.is_tensor(loss):      # a staged backward (glenet_vr.StagedLoss): its scalar exists now
+                loss = loss.detach()
             if self.mark:
                 self.mark("backward")
             if self.optimizer is not None:

@@ -154,3 +154,16 @@ extern "C" int glx_adamw_clip_step_scaled(float* params, const float* grads, flo
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ stage stamps
+// One-thread launch that stores the constant 100 MHz wall clock (s_memrealtime) into stamps[slot].  Recorded into a
+// captured step at its stage boundaries it times the stages INSIDE graph replays, where events and the profiler's
+// per-kernel signals would change what is measured (bench.py `stages_ms`).
+__global__ void k_stamp(unsigned long long* stamps, int slot) { stamps[slot] = wall_clock64(); }
+
+extern "C" int glx_stamp(unsigned long long* stamps, int slot, void* stream) {
+  GLX_REQUIRE(stamps != nullptr && slot >= 0, "glx_stamp: bad arguments");
+  hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, (hipStream_t)stream, stamps, slot);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

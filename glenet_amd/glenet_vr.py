@@ -22,7 +22,9 @@ Two ways to run the same step:
                                       graph and replayed with one call per step (two with a gradient exchange
                                       between backward and the optimizer at world size > 1).
 Both produce the same loss terms and gradients (tests/test_train_step_gpu.py)."""
+import contextlib
 import math
+import os
 
 import torch
 from torch import nn
@@ -112,6 +114,48 @@ class VoxelRCNNKLHead(rg.RoIGridPool):
         return self.heads(pooled, raw)
 
 
+OVERLAP_ROI = os.environ.get("GLX_OVERLAP_ROI", "1") != "0"
+
+
+class StagedLoss:
+    """The scalar of a training step whose backward() runs as three partial passes instead of one, so that the RoI
+    branch (proposals, RoI targets, RoI-grid pooling, FC towers, RoI losses and their backward: ~350 short launches
+    that never fill the chip) runs on a stream of its own BESIDE the dense-head loss and the BEV backbone's backward --
+    the two meet again at the sparse backbone's feature tensors:
+      A (RoI stream)   d roi_loss / d (x_conv features the RoI grid pools from -- handed over as detached leaves --,
+                       RoI-head parameters)
+      B (main stream)  d rpn_loss / d (BEV input = the sparse backbone's output -- a detached leaf too --, 2-D parameters)
+      C (main stream, after the join)  the sparse backbone's backward from those feature tensors' gradients.
+    One backward() from the summed scalar would compute the same gradients but the autograd engine's root gradient
+    lives on the caller's stream: the RoI branch would wait for whatever the main stream has queued.  The reference
+    has no counterpart (one stream, loss.backward(), tools/train_utils/train_utils.py:47-52).
+    `value` (the detached sum) exists after backward()."""
+
+    def __init__(self, rpn, roi, roi_stream, cuts):
+        """cuts: (tensor of the sparse front end, its detached leaf copy a branch was given) pairs."""
+        self.rpn, self.roi, self.roi_stream, self.cuts = rpn, roi, roi_stream, cuts
+        self.value = None
+
+    def backward(self):
+        dev = self.rpn.device
+        main = torch.cuda.current_stream(dev)
+        with torch.cuda.stream(self.roi_stream):      # A: caller stream = RoI stream, nothing of the main stream is
+            torch.autograd.backward(self.roi)         # waited for; ends at the detached leaves
+        torch.autograd.backward(self.rpn)             # B: ends at the BEV input's detached leaf
+        main.wait_stream(self.roi_stream)             # join
+        roots, grads = [], []
+        for orig, leaf in self.cuts:
+            if leaf.grad is not None:
+                roots.append(orig)
+                grads.append(leaf.grad)
+        self.value = self.rpn.detach() + self.roi.detach()
+        self.rpn = self.roi = self.cuts = None
+        torch.autograd.backward(roots, grads)         # C
+
+    def detach(self):
+        return self.value
+
+
 class GLENetVR(nn.Module):
     """Detector3DTemplate module order of GLENet_VR.yaml."""
 
@@ -145,6 +189,8 @@ class GLENetVR(nn.Module):
         self.fixed_draws = None      # tests: (key (B,R), pick (B,P)) uniform numbers for the RoI sampler
         self.last = None
         self.mark = None             # optional callable(stage_name), see StaticTrainPipeline.mark
+        self.overlap_roi = False     # StaticTrainStep: RoI branch on its own stream, backward in stages (StagedLoss)
+        self._roi_streams = {}
 
     def anchors(self, device):
         if self._anchors is None or self._anchors.device != device:
@@ -169,46 +215,87 @@ class GLENetVR(nn.Module):
         B = gt_boxes.shape[0]
         h, r = self.head_cfg, self.roi_cfg
         mark = self.mark or (lambda name: None)
+        enc = bd.get("encoded_spconv_tensor")
+        overlap = bool(self.overlap_roi) and gt_boxes.is_cuda and torch.is_grad_enabled()
+        cuts = []
+        if overlap:          # cut the autograd graph in front of the BEV backbone (StagedLoss)
+            sf = bd.get("spatial_features")
+            if torch.is_tensor(sf) and sf.requires_grad:
+                bd["spatial_features"] = sf.detach().requires_grad_(True)
+                cuts.append((sf, bd["spatial_features"]))
+            elif enc is not None and enc.features.requires_grad:
+                bd["encoded_spconv_tensor"] = enc.replace_feature(enc.features.detach().requires_grad_(True))
+                cuts.append((enc.features, bd["encoded_spconv_tensor"].features))
+            else:
+                overlap = False
         bd = self.dense_head(self.backbone_2d(bd))
         mark("BEV backbone + anchor head fwd")
+        if self.mark:        # two boundaries inside backward(): gradient hooks run on the stream of the backward pass
+            def stamp_when_grad_arrives(t, name):
+                if t is not None and t.requires_grad:
+                    t.register_hook(lambda g: mark(name))
+            stamp_when_grad_arrives(bd.get("spatial_features_2d"), "backward: losses, RoI head, anchor head")
+            stamp_when_grad_arrives(cuts[0][1] if cuts else getattr(enc, "features", None), "backward: BEV backbone")
         anchors = self.anchors(gt_boxes.device)
+        dev = gt_boxes.device
+        if overlap:      # fork: the RoI branch needs the head's predictions and the sparse backbone's features only
+            main = torch.cuda.current_stream(dev)
+            if dev not in self._roi_streams:
+                self._roi_streams[dev] = torch.cuda.Stream(dev)
+            roi_stream = self._roi_streams[dev]
+            roi_stream.wait_stream(main)
+        with (torch.cuda.stream(roi_stream) if overlap else contextlib.nullcontext()):
+            with torch.no_grad():
+                cls, boxes = det.predicted_boxes(bd["cls_preds"], bd["box_preds"], bd.get("dir_cls_preds"), anchors)
+                rois, roi_scores, roi_labels = det.proposal_layer(boxes, cls, *r["NMS_TRAIN"])
+                if seed_rois_with_gt is not None:
+                    has = gt_boxes[:, :, 7:8] > 0
+                    ng = gt_boxes.shape[1]
+                    rois[:, :ng, :7] = torch.where(has, gt_boxes[:, :, :7] + seed_rois_with_gt, rois[:, :ng, :7])
+                    roi_labels[:, :ng] = torch.where(has[..., 0], gt_boxes[:, :, 7].long(), roi_labels[:, :ng])
+                key, pick = self.fixed_draws if self.fixed_draws is not None else (None, None)
+                td = self.target_layer({"rois": rois, "roi_scores": roi_scores, "roi_labels": roi_labels,
+                                        "gt_boxes": gt_boxes, "gt_uncertaintys": gt_uncertaintys}, key, pick)
+                rois_s = td["rois"].contiguous()
+                gt_src = td["gt_of_rois"]                                                    # roi_head_template.py:137
+                gt_ct = losses.canonical_gt_of_rois(rois_s, gt_src)                          # :140-159
+                reg_valid, cls_lab = td["reg_valid_mask"].view(-1), td["rcnn_cls_labels"].view(-1)
+                unc = td["gt_uncertaintys_of_rois"].reshape(-1, 7)
+            if not overlap:
+                mark("proposals (NMS) + RoI targets")
+            msf = bd["multi_scale_3d_features"]
+            if overlap:      # ... and at the feature tensors the RoI grid pools from
+                msf = dict(msf)
+                for k, st in msf.items():
+                    f = getattr(st, "features", None)
+                    if torch.is_tensor(f) and f.requires_grad:
+                        msf[k] = st.replace_feature(f.detach().requires_grad_(True))
+                        cuts.append((f, msf[k].features))
+            ori_cls, std_logit, rcnn_reg, rcnn_std = self.roi_head(rois_s, msf, bd["multi_scale_3d_strides"], B, raw=True)
+            mark("RoI-grid pooling + FC towers fwd")
+            w = r["LOSS_WEIGHTS"]
+            if ori_cls.is_cuda:      # score rescaling + classification loss + their backward: one launch
+                l_cls, rcnn_cls = losses.cls_rescale_loss(ori_cls, std_logit, cls_lab, weight=w["rcnn_cls_weight"])
+            else:
+                rcnn_cls = losses.cls_rescale_torch(ori_cls, std_logit)
+                l_cls = losses.rcnn_cls_loss_torch(rcnn_cls, cls_lab, weight=w["rcnn_cls_weight"])
+            l_kl, kl_parts = losses.kl_reg_loss(rcnn_reg, rcnn_std, rois_s, gt_ct[..., :7], unc, reg_valid,
+                                                code_weights=w["code_weights"], weight=w["rcnn_reg_weight"])
+            l_cor = losses.corner_loss(rcnn_reg, rois_s, gt_src[..., :7], reg_valid, weight=w["rcnn_corner_weight"])
+            roi_loss = l_cls + l_kl + l_cor
+            mark("RoI-head losses")
         with torch.no_grad():
             tgt = target_assign.assign_targets([anchors], gt_boxes, [1], [h["matched_threshold"]],
                                                [h["unmatched_threshold"]])
-            cls, boxes = det.predicted_boxes(bd["cls_preds"], bd["box_preds"], bd.get("dir_cls_preds"), anchors)
-            rois, roi_scores, roi_labels = det.proposal_layer(boxes, cls, *r["NMS_TRAIN"])
-            if seed_rois_with_gt is not None:
-                has = gt_boxes[:, :, 7:8] > 0
-                ng = gt_boxes.shape[1]
-                rois[:, :ng, :7] = torch.where(has, gt_boxes[:, :, :7] + seed_rois_with_gt, rois[:, :ng, :7])
-                roi_labels[:, :ng] = torch.where(has[..., 0], gt_boxes[:, :, 7].long(), roi_labels[:, :ng])
-            key, pick = self.fixed_draws if self.fixed_draws is not None else (None, None)
-            td = self.target_layer({"rois": rois, "roi_scores": roi_scores, "roi_labels": roi_labels,
-                                    "gt_boxes": gt_boxes, "gt_uncertaintys": gt_uncertaintys}, key, pick)
-            rois_s = td["rois"].contiguous()
-            gt_src = td["gt_of_rois"]                                                    # roi_head_template.py:137
-            gt_ct = losses.canonical_gt_of_rois(rois_s, gt_src)                          # :140-159
-            reg_valid, cls_lab = td["reg_valid_mask"].view(-1), td["rcnn_cls_labels"].view(-1)
-            unc = td["gt_uncertaintys_of_rois"].reshape(-1, 7)
         rpn, rpn_parts = losses.rpn_loss(bd["cls_preds"], bd["box_preds"], bd.get("dir_cls_preds"),
                                          tgt["box_cls_labels"], tgt["box_reg_targets"], anchors,
                                          code_weights=h["code_weights"], cls_weight=h["cls_weight"],
                                          loc_weight=h["loc_weight"], dir_weight=h["dir_weight"])
-        mark("anchor targets + proposals (NMS) + RoI targets + dense-head loss")
-        ori_cls, std_logit, rcnn_reg, rcnn_std = self.roi_head(rois_s, bd["multi_scale_3d_features"],
-                                                               bd["multi_scale_3d_strides"], B, raw=True)
-        mark("RoI-grid pooling + FC towers fwd")
-        w = r["LOSS_WEIGHTS"]
-        if ori_cls.is_cuda:      # score rescaling + classification loss + their backward: one launch
-            l_cls, rcnn_cls = losses.cls_rescale_loss(ori_cls, std_logit, cls_lab, weight=w["rcnn_cls_weight"])
+        mark("anchor targets + dense-head loss")
+        if overlap:
+            loss = StagedLoss(rpn, roi_loss, roi_stream, cuts)
         else:
-            rcnn_cls = losses.cls_rescale_torch(ori_cls, std_logit)
-            l_cls = losses.rcnn_cls_loss_torch(rcnn_cls, cls_lab, weight=w["rcnn_cls_weight"])
-        l_kl, kl_parts = losses.kl_reg_loss(rcnn_reg, rcnn_std, rois_s, gt_ct[..., :7], unc, reg_valid,
-                                            code_weights=w["code_weights"], weight=w["rcnn_reg_weight"])
-        l_cor = losses.corner_loss(rcnn_reg, rois_s, gt_src[..., :7], reg_valid, weight=w["rcnn_corner_weight"])
-        loss = rpn + l_cls + l_kl + l_cor                                                # voxel_rcnn.py get_training_loss
-        mark("RoI-head losses")
+            loss = rpn + roi_loss                                                        # voxel_rcnn.py get_training_loss
         parts = dict(loss_rpn=rpn.detach(), rcnn_loss_cls=l_cls.detach(), rcnn_loss_reg=l_kl.detach(),
                      rcnn_loss_corner=l_cor.detach(), fg_rois=kl_parts["fg"], **rpn_parts)
         # detached views for inspection / tests (a live autograd graph of an earlier step must not survive into
@@ -297,6 +384,7 @@ class StaticTrainStep(gb.StaticTrainPipeline):
                          extra_modules=(model.backbone_2d, model.dense_head, model.roi_head))
         self.hc = model.map_to_bev_module
         self.split = False
+        model.overlap_roi = OVERLAP_ROI and torch.device(dev).type == "cuda"
 
     def _loss(self, bd):
         loss, self.parts = self.net.second_stage_losses(bd, self.gt_boxes, self.gt_unc, self.seed)

@@ -874,6 +874,12 @@ int glx_conv3x3_set_grid(int blocks, int ablate);
  * 100 MHz ticks (s_memrealtime) of its lifetime to stamps[2 * block ..] (NULL: off): their ratio is the clock the chip holds. */
 int glx_conv3x3_set_stamps(void* stamps);
 
+/* Stage stamps: a one-thread launch on `stream` that stores the device's constant 100 MHz wall clock into
+ * stamps[slot] (10 ns per tick).  Recorded into a captured training step at its stage boundaries
+ * (StaticTrainPipeline.mark) it times the stages inside graph replays; the reference has no counterpart (it times
+ * stages with host clocks around the calls, tools/train_utils/train_utils.py:18-90). */
+int glx_stamp(unsigned long long* stamps, int slot, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
