@@ -131,16 +131,18 @@ class StagedLoss:
     has no counterpart (one stream, loss.backward(), tools/train_utils/train_utils.py:47-52).
     `value` (the detached sum) exists after backward()."""
 
-    def __init__(self, rpn, roi, roi_stream, cuts):
+    def __init__(self, rpn, roi, roi_stream, cuts, mark=None):
         """cuts: (tensor of the sparse front end, its detached leaf copy a branch was given) pairs."""
         self.rpn, self.roi, self.roi_stream, self.cuts = rpn, roi, roi_stream, cuts
-        self.value = None
+        self.value, self.mark = None, mark
 
     def backward(self):
         dev = self.rpn.device
         main = torch.cuda.current_stream(dev)
         with torch.cuda.stream(self.roi_stream):      # A: caller stream = RoI stream, nothing of the main stream is
             torch.autograd.backward(self.roi)         # waited for; ends at the detached leaves
+            if self.mark:
+                self.mark("backward: RoI head (RoI stream)")
         torch.autograd.backward(self.rpn)             # B: ends at the BEV input's detached leaf
         main.wait_stream(self.roi_stream)             # join
         roots, grads = [], []
@@ -235,14 +237,16 @@ class GLENetVR(nn.Module):
                 if t is not None and t.requires_grad:
                     t.register_hook(lambda g: mark(name))
             stamp_when_grad_arrives(bd.get("spatial_features_2d"), "backward: losses, RoI head, anchor head")
+            stamp_when_grad_arrives(bd.get("spatial_features_1x"), "backward: BEV deblocks + block 2")
             stamp_when_grad_arrives(cuts[0][1] if cuts else getattr(enc, "features", None), "backward: BEV backbone")
         anchors = self.anchors(gt_boxes.device)
         dev = gt_boxes.device
         if overlap:      # fork: the RoI branch needs the head's predictions and the sparse backbone's features only
             main = torch.cuda.current_stream(dev)
-            if dev not in self._roi_streams:
-                self._roi_streams[dev] = torch.cuda.Stream(dev)
-            roi_stream = self._roi_streams[dev]
+            key = dev.index if dev.index is not None else torch.cuda.current_device()
+            if key not in self._roi_streams:
+                self._roi_streams[key] = torch.cuda.Stream(dev)
+            roi_stream = self._roi_streams[key]
             roi_stream.wait_stream(main)
         with (torch.cuda.stream(roi_stream) if overlap else contextlib.nullcontext()):
             with torch.no_grad():
@@ -261,8 +265,7 @@ class GLENetVR(nn.Module):
                 gt_ct = losses.canonical_gt_of_rois(rois_s, gt_src)                          # :140-159
                 reg_valid, cls_lab = td["reg_valid_mask"].view(-1), td["rcnn_cls_labels"].view(-1)
                 unc = td["gt_uncertaintys_of_rois"].reshape(-1, 7)
-            if not overlap:
-                mark("proposals (NMS) + RoI targets")
+            mark("proposals (NMS) + RoI targets")
             msf = bd["multi_scale_3d_features"]
             if overlap:      # ... and at the feature tensors the RoI grid pools from
                 msf = dict(msf)
@@ -293,7 +296,7 @@ class GLENetVR(nn.Module):
                                          loc_weight=h["loc_weight"], dir_weight=h["dir_weight"])
         mark("anchor targets + dense-head loss")
         if overlap:
-            loss = StagedLoss(rpn, roi_loss, roi_stream, cuts)
+            loss = StagedLoss(rpn, roi_loss, roi_stream, cuts, self.mark)
         else:
             loss = rpn + roi_loss                                                        # voxel_rcnn.py get_training_loss
         parts = dict(loss_rpn=rpn.detach(), rcnn_loss_cls=l_cls.detach(), rcnn_loss_reg=l_kl.detach(),
