@@ -225,7 +225,7 @@ class StaticFramePipeline:
         # rule tables depend on coordinates only: they are built on a second stream and overlap
         # the convolutions of the levels above them (parallel branches of the HIP graph)
         self.plan_stream = torch.cuda.Stream(dev)
-        self.overlap_plan = True
+        self.overlap_plan = os.environ.get("GLX_OVERLAP_PLAN", "1") != "0"
 
     def calibrate(self, points, batch_idx, headroom=1.3):
         """Size the strided convs' output sets from a representative batch: one pass of the exact
@@ -428,7 +428,7 @@ class StaticTrainPipeline(StaticFramePipeline):
         self.loss_fn = loss_fn if loss_fn is not None else (lambda bd: bd["spatial_features"].square().mean())
         self.optimizer = optimizer
         self.loss = None
-        self.overlap_wgrad = True
+        self.overlap_wgrad = os.environ.get("GLX_OVERLAP_WGRAD", "1") != "0"
         self.mark = None            # optional callable(stage_name): bench.py records an event per stage
         self.data_step = None       # optional data_pipeline.DeviceDataProcessor: mask + shuffle inside the step
 

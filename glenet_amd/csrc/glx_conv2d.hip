@@ -833,7 +833,16 @@ static int env_conv_th() {
   return e ? atoi(e) : 0;
 }
 static int g_conv_th = env_conv_th();       // experiments: rows per tile of the second form (0 = chosen per launch)
-static int g_conv_grid = 0;     // experiments: blocks per launch (0 = two per CU)
+static int g_conv_grid = 0;     // experiments: blocks per launch (0 = as many as are meant to be resident)
+// Blocks per CU of the second form's persistent grid (GLX_CONV3X3_BLOCKS_PER_CU, 1..3).  Three fit (168 registers
+// each) and fill every SIMD's register file: no other kernel can start a wave while such a kernel runs.  Two per CU run
+// the BEV layers within a few per cent of that and leave room for the kernels of a parallel graph branch
+// (tools/conv_side_load.py: 600 small launches beside 40 convolutions, 3.28 -> 2.42 ms); inside the training step the
+// two settings measured the same (7.79 / 7.83 ms), so the default stays three.
+static int conv_per_cu() {
+  static const int v = getenv("GLX_CONV3X3_BLOCKS_PER_CU") ? atoi(getenv("GLX_CONV3X3_BLOCKS_PER_CU")) : 3;
+  return v >= 1 && v <= 3 ? v : 3;
+}
 static int g_conv_ablate = 0;   // experiments: timing-only builds of the loop (wrong results), see k_conv3x3
 extern "C" int glx_conv3x3_set_grid(int blocks, int ablate) {
   g_conv_grid = blocks;
@@ -896,7 +905,7 @@ extern "C" int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin,
   int th = CV_TH;
   if (v2) {
     // rows per tile: the fewest (rounds of the resident blocks) x (rows + a fixed cost per tile)
-    const int resident = 3 * conv_cus();
+    const int resident = conv_per_cu() * conv_cus();
     long long best = -1;
     for (int t = 8; t >= 7; --t) {
       const long long units = (long long)glx_divup(W, CV_TW) * glx_divup(H, t) * B * (Cout / CV_BN);
@@ -954,7 +963,7 @@ extern "C" int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin,
   a.epi_scale = epi_scale;
   a.epi_shift = epi_shift;
   a.epi_relu = epi_relu;
-  const int resident = slots * (v2 ? 3 : 2);
+  const int resident = slots * (v2 ? conv_per_cu() : 2);
   int grid = g_conv_grid > 0 ? g_conv_grid : (a.ntiles < resident ? a.ntiles : resident);
   if (bn_state) grid = grid / a.nblk * a.nblk;   // every block keeps one channel block (ntiles is a multiple of nblk)
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, a);

@@ -139,11 +139,19 @@ class StagedLoss:
     def backward(self):
         dev = self.rpn.device
         main = torch.cuda.current_stream(dev)
-        with torch.cuda.stream(self.roi_stream):      # A: caller stream = RoI stream, nothing of the main stream is
-            torch.autograd.backward(self.roi)         # waited for; ends at the detached leaves
-            if self.mark:
-                self.mark("backward: RoI head (RoI stream)")
-        torch.autograd.backward(self.rpn)             # B: ends at the BEV input's detached leaf
+        core = gb.spconv.core
+        # While the RoI branch is in flight the convolutions' weight gradients stay on the main stream: with a third
+        # branch (the weight-gradient stream) in the recorded graph the RoI branch and the BEV backward were executed
+        # one after the other (measured with the stage stamps, ROCm 7.2's graph executor); two branches do overlap.
+        wgrad_stream, core.WGRAD_STREAM = core.WGRAD_STREAM, None
+        try:
+            with torch.cuda.stream(self.roi_stream):      # A: caller stream = RoI stream, nothing of the main stream
+                torch.autograd.backward(self.roi)         # is waited for; ends at the detached leaves
+                if self.mark:
+                    self.mark("backward: RoI head (RoI stream)")
+            torch.autograd.backward(self.rpn)             # B: ends at the BEV input's detached leaf
+        finally:
+            core.WGRAD_STREAM = wgrad_stream
         main.wait_stream(self.roi_stream)             # join
         roots, grads = [], []
         for orig, leaf in self.cuts:
@@ -245,6 +253,7 @@ class GLENetVR(nn.Module):
             main = torch.cuda.current_stream(dev)
             key = dev.index if dev.index is not None else torch.cuda.current_device()
             if key not in self._roi_streams:
+                # default priority: a high-priority stream (like GPU_MAX_HW_QUEUES > 4) doubled the step time
                 self._roi_streams[key] = torch.cuda.Stream(dev)
             roi_stream = self._roi_streams[key]
             roi_stream.wait_stream(main)

@@ -78,3 +78,11 @@ print("one graph: 40 convolutions                           %.3f ms" % graph_ms(
 print("one graph: 600 small kernels                         %.3f ms" % graph_ms(0, 600))
 print("one graph: both, small kernels on a forked stream    %.3f ms" % graph_ms(40, 600))
 print("one graph: both on one stream                        %.3f ms" % graph_ms(40, 600, fork=False))
+
+# ---- with room left on every CU: 512 (two per CU) and 256 convolution blocks instead of the resident 768
+from glenet_amd import _lib  # noqa: E402
+for blocks in (512, 256):
+    _lib.call_nostream("glx_conv3x3_set_grid", blocks, 0)
+    print("%d conv blocks: 40 convolutions %.3f ms, with 600 small kernels on a forked stream %.3f ms"
+          % (blocks, graph_ms(40, 0), graph_ms(40, 600)))
+_lib.call_nostream("glx_conv3x3_set_grid", 0, 0)
