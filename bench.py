@@ -265,9 +265,10 @@ def bench_bev(model, dev, frames=FRAMES_PER_GPU):
                 frac_of_fp32_mfma_peak=dict(fwd=round(flops / ms_f / 1e9 / MFMA_F32_PEAK_TFLOPS, 3),
                                             fwd_bwd=round(3 * flops / ms_fb / 1e9 / MFMA_F32_PEAK_TFLOPS, 3)),
                 kernels="3x3 / stride-1 layers (11 of 12: forward, input and weight gradient): csrc/glx_conv2d.hip, fp32 "
-                        "products as six bf16 MFMAs of three-way split operands, fp32 accumulation; the strided layer, "
-                        "the two deconvolutions and the head: MIOpen fp32 (vendor); BatchNorm: csrc/glx_bn.hip with the "
-                        "forward statistics in the conv epilogue")
+                        "products as six bf16 MFMAs of three-way split operands, fp32 accumulation; the two transposed "
+                        "convolutions (forward, both gradients) and the strided layer's forward: csrc/glx_deconv2d.hip, "
+                        "same arithmetic; the strided layer's gradients and the 1x1 head: MIOpen fp32 (vendor); "
+                        "BatchNorm: csrc/glx_bn.hip with the forward statistics in the conv epilogue")
 
 
 def bench_inference(dev, frames=FRAMES_PER_GPU, steps=50):

@@ -1574,3 +1574,35 @@ extern "C" int glx_topk_desc(const float* scores, int frames, int A, int K, floa
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ proposals
+// The tail of the proposal layer (pcdet/models/roi_heads/roi_head_template.py:63-126) as one launch: slot j of frame
+// b takes candidate keep[b][j] of the top-k list when j < num[b], zeros otherwise; the label comes through the top-k
+// order from the per-anchor class index.  Replaces arange / compare / where / three gathers / three masks / add.
+__global__ void k_gather_proposals(const float* __restrict__ cand, const float* __restrict__ top,
+                                   const int64_t* __restrict__ lab, const int64_t* __restrict__ order,
+                                   const int64_t* __restrict__ keep, const int* __restrict__ num, int F, int A, int K,
+                                   int keep_stride, int P, int C, float* __restrict__ rois, float* __restrict__ scores,
+                                   int64_t* __restrict__ labels) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F * P) return;
+  const int b = i / P, j = i - b * P;
+  const bool valid = j < num[b] && j < keep_stride;
+  const long long sel = valid ? keep[(size_t)b * keep_stride + j] : 0;
+  const float* src = cand + ((size_t)b * K + sel) * C;
+  float* dst = rois + (size_t)i * C;
+  for (int c = 0; c < C; ++c) dst[c] = valid ? src[c] : 0.f;
+  scores[i] = valid ? top[(size_t)b * K + sel] : 0.f;
+  labels[i] = (valid ? lab[(size_t)b * A + order[(size_t)b * K + sel]] : 0) + 1;
+}
+
+extern "C" int glx_gather_proposals(const float* cand, const float* top, const int64_t* lab, const int64_t* order,
+                                    const int64_t* keep, const int* num, int F, int A, int K, int keep_stride, int P,
+                                    int C, float* rois, float* scores, int64_t* labels, void* stream) {
+  GLX_REQUIRE(F >= 0 && A > 0 && K > 0 && P > 0 && C > 0 && keep_stride > 0, "glx_gather_proposals: bad sizes");
+  if (F == 0) return GLX_OK;
+  hipLaunchKernelGGL(k_gather_proposals, dim3(glx_divup(F * P, 256)), dim3(256), 0, (hipStream_t)stream, cand, top, lab,
+                     order, keep, num, F, A, K, keep_stride, P, C, rois, scores, labels);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

@@ -153,6 +153,16 @@ def _proposal_layer_batched(batch_box_preds, scores_all, nms_pre_maxsize, nms_po
     keep, num = iou3d_nms_cuda.nms_device_batch(cand[..., 0:7].contiguous(), nms_thresh,
                                                 max_keep=nms_post_maxsize)
     p = nms_post_maxsize
+    if (cand.dtype == torch.float32 and top.dtype == torch.float32 and lab.dtype == torch.int64
+            and order.dtype == torch.int64 and num.dtype == torch.int32):
+        from . import _lib
+        cand, top, lab, order = cand.contiguous(), top.contiguous(), lab.contiguous(), order.contiguous()
+        rois = torch.empty((B, p, C), dtype=torch.float32, device=cand.device)
+        scores = torch.empty((B, p), dtype=torch.float32, device=cand.device)
+        labels = torch.empty((B, p), dtype=torch.int64, device=cand.device)
+        _lib.call("glx_gather_proposals", cand, top, lab, order, keep, num, B, A, k, keep.shape[1], p, C,
+                  rois, scores, labels)
+        return rois, scores, labels
     if keep.shape[1] < p:
         keep = torch.nn.functional.pad(keep, (0, p - keep.shape[1]))
     slot = torch.arange(p, device=keep.device)

@@ -874,6 +874,15 @@ int glx_conv3x3_set_grid(int blocks, int ablate);
  * 100 MHz ticks (s_memrealtime) of its lifetime to stamps[2 * block ..] (NULL: off): their ratio is the clock the chip holds. */
 int glx_conv3x3_set_stamps(void* stamps);
 
+/* Tail of the proposal layer (pcdet/models/roi_heads/roi_head_template.py:63-126: selected = keep[:NMS_POST_MAXSIZE],
+ * rois / roi_scores / roi_labels rows, zero rows behind the survivors) in one launch.  cand (F, K, C) top-k candidates,
+ * top (F, K) their scores, lab (F, A) class index per anchor, order (F, K) anchor index of every candidate,
+ * keep (F, keep_stride) / num (F): the NMS keep list and its length.  Outputs rois (F, P, C), scores (F, P),
+ * labels (F, P) = class + 1 (1 in empty slots, as the reference's `roi_labels + 1` on its zero-initialised rows). */
+int glx_gather_proposals(const float* cand, const float* top, const int64_t* lab, const int64_t* order,
+                         const int64_t* keep, const int* num, int F, int A, int K, int keep_stride, int P, int C,
+                         float* rois, float* scores, int64_t* labels, void* stream);
+
 /* Stage stamps: a one-thread launch on `stream` that stores the device's constant 100 MHz wall clock into
  * stamps[slot] (10 ns per tick).  Recorded into a captured training step at its stage boundaries
  * (StaticTrainPipeline.mark) it times the stages inside graph replays; the reference has no counterpart (it times
