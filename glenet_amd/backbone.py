@@ -99,6 +99,7 @@ class SparseBackbone8x(nn.Module):
         self.conv_out = _conv_bn_relu(cfg["out_in"], 128, (3, 1, 1), "spconv_down2", kind="spconv",
                                       stride=(2, 1, 1), padding=last_pad)
         self.num_point_features = 128
+        self.stage_cuts = False      # set by a training step whose loss runs the staged backward
         self.backbone_channels = {"x_conv1": 16, "x_conv2": 32, "x_conv3": 64,
                                   "x_conv4": cfg["stages"][-1][1]}
 
@@ -122,9 +123,22 @@ class SparseBackbone8x(nn.Module):
         x = self.conv_input(x)
         c1 = self.conv1(x)
         c2 = self.conv2(c1)
-        c3 = self.conv3(c2)
-        c4 = self.conv4(c3)
+        cuts = {}
+        if self.stage_cuts and torch.is_grad_enabled() and c2.features.is_cuda and c2.features.requires_grad:
+            # staged backward (glenet_vr.StagedLoss): conv3 / conv4 read detached leaf copies of x_conv2 / x_conv3, so the
+            # backward of the levels above a cut can run before the RoI branch has delivered the gradients of the
+            # levels below it; batch_dict["stage_cuts"][name] = (the level's feature tensor, the leaf the next block read)
+            def cut(name, st):
+                leaf = st.replace_feature(st.features.detach().requires_grad_(True))
+                cuts[name] = (st.features, leaf.features)
+                return leaf
+            c3 = self.conv3(cut("x_conv2", c2))
+            c4 = self.conv4(cut("x_conv3", c3))
+        else:
+            c3 = self.conv3(c2)
+            c4 = self.conv4(c3)
         out = self.conv_out(c4)
+        batch_dict["stage_cuts"] = cuts
         batch_dict.update(encoded_spconv_tensor=out, encoded_spconv_tensor_stride=8,
                           multi_scale_3d_features=dict(x_conv1=c1, x_conv2=c2, x_conv3=c3, x_conv4=c4),
                           multi_scale_3d_strides=dict(x_conv1=1, x_conv2=2, x_conv3=4, x_conv4=8))

@@ -115,6 +115,7 @@ class VoxelRCNNKLHead(rg.RoIGridPool):
 
 
 OVERLAP_ROI = os.environ.get("GLX_OVERLAP_ROI", "1") != "0"
+STAGE_CUTS = os.environ.get("GLX_STAGE_CUTS", "1") != "0"
 
 
 class StagedLoss:
@@ -131,15 +132,25 @@ class StagedLoss:
     has no counterpart (one stream, loss.backward(), tools/train_utils/train_utils.py:47-52).
     `value` (the detached sum) exists after backward()."""
 
-    def __init__(self, rpn, roi, roi_stream, cuts, mark=None):
-        """cuts: (tensor of the sparse front end, its detached leaf copy a branch was given) pairs."""
-        self.rpn, self.roi, self.roi_stream, self.cuts = rpn, roi, roi_stream, cuts
+    def __init__(self, rpn, roi, roi_stream, bev_cut, roi_cuts, stage_cuts, mark=None):
+        """bev_cut: (sparse backbone's output features, the detached leaf the BEV backbone read);
+        roi_cuts {level: (x_conv features, the leaf the RoI head read)};
+        stage_cuts {level: (x_conv features, the leaf the backbone's next block read)} (SparseBackbone8x.stage_cuts)."""
+        self.rpn, self.roi, self.roi_stream = rpn, roi, roi_stream
+        self.bev_cut, self.roi_cuts, self.stage_cuts = bev_cut, roi_cuts, stage_cuts
         self.value, self.mark = None, mark
+
+    LEVELS = ("x_conv4", "x_conv3", "x_conv2", "x_conv1")       # the order their gradients leave the RoI branch
 
     def backward(self):
         dev = self.rpn.device
         main = torch.cuda.current_stream(dev)
         core = gb.spconv.core
+        # an event per level on the RoI stream, recorded when that level's gradient has arrived at its leaf
+        ready = {}
+        for name, (_, leaf) in self.roi_cuts.items():
+            ready[name] = ev = torch.cuda.Event()
+            leaf.register_post_accumulate_grad_hook(lambda t, ev=ev: ev.record(torch.cuda.current_stream(t.device)))
         # While the RoI branch is in flight the convolutions' weight gradients stay on the main stream: with a third
         # branch (the weight-gradient stream) in the recorded graph the RoI branch and the BEV backward were executed
         # one after the other (measured with the stage stamps, ROCm 7.2's graph executor); two branches do overlap.
@@ -150,17 +161,38 @@ class StagedLoss:
                 if self.mark:
                     self.mark("backward: RoI head (RoI stream)")
             torch.autograd.backward(self.rpn)             # B: ends at the BEV input's detached leaf
+            # C: the sparse backbone, level by level: the levels above a stage cut run as soon as THEIR RoI gradients are
+            # there (x_conv4's leave the RoI branch first, x_conv2's last)
+            roots, grads = [self.bev_cut[0]], [self.bev_cut[1].grad]
+            self.bev_cut[1].grad = None
+            for name in self.LEVELS + tuple(n for n in self.roi_cuts if n not in self.LEVELS):
+                if name in self.stage_cuts:
+                    torch.autograd.backward(roots, grads)
+                    if self.mark:
+                        self.mark("backward: sparse backbone above " + name)
+                    feat, leaf = self.stage_cuts[name]
+                    roots, grads = [feat], [leaf.grad]
+                    leaf.grad = None
+                if name in self.roi_cuts:
+                    feat, leaf = self.roi_cuts[name]
+                    if leaf.grad is None:
+                        continue
+                    main.wait_event(ready[name])
+                    same = [i for i, t in enumerate(roots) if t is feat]
+                    if same:
+                        grads[same[0]] = grads[same[0]] + leaf.grad
+                    else:
+                        roots.append(feat)
+                        grads.append(leaf.grad)
+                    leaf.grad = None
+            main.wait_stream(self.roi_stream)             # join (parameter gradients of the RoI head)
+            self.value = self.rpn.detach() + self.roi.detach()
+            self.rpn = self.roi = self.bev_cut = self.roi_cuts = self.stage_cuts = None
+            core.WGRAD_STREAM = wgrad_stream              # free again: the RoI branch has been joined
+            keep = [(t, g) for t, g in zip(roots, grads) if g is not None]
+            torch.autograd.backward([t for t, _ in keep], [g for _, g in keep])
         finally:
             core.WGRAD_STREAM = wgrad_stream
-        main.wait_stream(self.roi_stream)             # join
-        roots, grads = [], []
-        for orig, leaf in self.cuts:
-            if leaf.grad is not None:
-                roots.append(orig)
-                grads.append(leaf.grad)
-        self.value = self.rpn.detach() + self.roi.detach()
-        self.rpn = self.roi = self.cuts = None
-        torch.autograd.backward(roots, grads)         # C
 
     def detach(self):
         return self.value
@@ -227,17 +259,19 @@ class GLENetVR(nn.Module):
         mark = self.mark or (lambda name: None)
         enc = bd.get("encoded_spconv_tensor")
         overlap = bool(self.overlap_roi) and gt_boxes.is_cuda and torch.is_grad_enabled()
-        cuts = []
+        bev_cut, roi_cuts = None, {}
         if overlap:          # cut the autograd graph in front of the BEV backbone (StagedLoss)
             sf = bd.get("spatial_features")
             if torch.is_tensor(sf) and sf.requires_grad:
                 bd["spatial_features"] = sf.detach().requires_grad_(True)
-                cuts.append((sf, bd["spatial_features"]))
+                bev_cut = (sf, bd["spatial_features"])
             elif enc is not None and enc.features.requires_grad:
                 bd["encoded_spconv_tensor"] = enc.replace_feature(enc.features.detach().requires_grad_(True))
-                cuts.append((enc.features, bd["encoded_spconv_tensor"].features))
+                bev_cut = (enc.features, bd["encoded_spconv_tensor"].features)
             else:
                 overlap = False
+        if bd.get("stage_cuts") and not overlap:
+            raise RuntimeError("the sparse backbone cut its autograd graph for a staged backward that will not run")
         bd = self.dense_head(self.backbone_2d(bd))
         mark("BEV backbone + anchor head fwd")
         if self.mark:        # two boundaries inside backward(): gradient hooks run on the stream of the backward pass
@@ -246,7 +280,7 @@ class GLENetVR(nn.Module):
                     t.register_hook(lambda g: mark(name))
             stamp_when_grad_arrives(bd.get("spatial_features_2d"), "backward: losses, RoI head, anchor head")
             stamp_when_grad_arrives(bd.get("spatial_features_1x"), "backward: BEV deblocks + block 2")
-            stamp_when_grad_arrives(cuts[0][1] if cuts else getattr(enc, "features", None), "backward: BEV backbone")
+            stamp_when_grad_arrives(bev_cut[1] if bev_cut else getattr(enc, "features", None), "backward: BEV backbone")
         anchors = self.anchors(gt_boxes.device)
         dev = gt_boxes.device
         if overlap:      # fork: the RoI branch needs the head's predictions and the sparse backbone's features only
@@ -282,7 +316,7 @@ class GLENetVR(nn.Module):
                     f = getattr(st, "features", None)
                     if torch.is_tensor(f) and f.requires_grad:
                         msf[k] = st.replace_feature(f.detach().requires_grad_(True))
-                        cuts.append((f, msf[k].features))
+                        roi_cuts[k] = (f, msf[k].features)
             ori_cls, std_logit, rcnn_reg, rcnn_std = self.roi_head(rois_s, msf, bd["multi_scale_3d_strides"], B, raw=True)
             mark("RoI-grid pooling + FC towers fwd")
             w = r["LOSS_WEIGHTS"]
@@ -305,7 +339,7 @@ class GLENetVR(nn.Module):
                                          loc_weight=h["loc_weight"], dir_weight=h["dir_weight"])
         mark("anchor targets + dense-head loss")
         if overlap:
-            loss = StagedLoss(rpn, roi_loss, roi_stream, cuts, self.mark)
+            loss = StagedLoss(rpn, roi_loss, roi_stream, bev_cut, roi_cuts, bd.get("stage_cuts") or {}, self.mark)
         else:
             loss = rpn + roi_loss                                                        # voxel_rcnn.py get_training_loss
         parts = dict(loss_rpn=rpn.detach(), rcnn_loss_cls=l_cls.detach(), rcnn_loss_reg=l_kl.detach(),
@@ -397,6 +431,7 @@ class StaticTrainStep(gb.StaticTrainPipeline):
         self.hc = model.map_to_bev_module
         self.split = False
         model.overlap_roi = OVERLAP_ROI and torch.device(dev).type == "cuda"
+        model.backbone_3d.stage_cuts = model.overlap_roi and STAGE_CUTS
 
     def _loss(self, bd):
         loss, self.parts = self.net.second_stage_losses(bd, self.gt_boxes, self.gt_unc, self.seed)
