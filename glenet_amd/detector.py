@@ -230,12 +230,19 @@ class VoxelRCNNFlow(nn.Module):
     def second_stage(self, bd, batch_size):
         """Everything after map_to_bev: BEV backbone + anchor head, proposals, RoI-grid pooling,
         FC refinement.  Free of host synchronisation in eval mode on the device."""
-        bd = self.dense_head(self.backbone_2d(bd))
+        mark = getattr(self, "mark", None) or (lambda name: None)      # optional callable(stage_name), as in GLENetVR
+        bd = self.backbone_2d(bd)
+        mark("BEV backbone")
+        bd = self.dense_head(bd)
+        mark("anchor head")
         cls, boxes = predicted_boxes(bd["cls_preds"], bd["box_preds"], bd.get("dir_cls_preds"),
                                      self.anchors(bd["spatial_features_2d"].device))
         rois, roi_scores, roi_labels = proposal_layer(boxes, cls, *self.nms)
+        mark("decode + top-k + NMS")
         pooled = self.roi_pool(rois, bd["multi_scale_3d_features"], bd["multi_scale_3d_strides"], batch_size)
+        mark("RoI-grid pooling")
         rcnn_cls, rcnn_reg = self.roi_fc(pooled)
+        mark("FC towers")
         bd.update(rois=rois, roi_scores=roi_scores, roi_labels=roi_labels,
                   batch_cls_preds=rcnn_cls.view(batch_size, -1, rcnn_cls.shape[-1]),
                   batch_box_preds=refine_boxes(rois, rcnn_reg))
@@ -253,6 +260,9 @@ class StaticDetectorPipeline(gb.StaticFramePipeline):
         super().__init__(flow.backbone_3d, flow.cfg, batch_size, num_points, num_features,
                          train_voxel_cap=False, capacities=capacities, device=device)
         self.flow = flow
+        # the flow's own HeightCompression (channels-last, deferred to the BEV backbone's sparse first layer): with the
+        # base class's default one the BEV backbone received an NCHW map and ran on the vendor's kernels
+        self.hc = flow.map_to_bev
 
     def _tagged_modules(self):
         return (self.flow,)

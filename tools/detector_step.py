@@ -76,3 +76,43 @@ with torch.no_grad():
 ok = torch.equal(ref["rois"], pipe.out["rois"]) and torch.allclose(ref["batch_box_preds"], pipe.out["batch_box_preds"],
                                                                     rtol=1e-4, atol=1e-4)
 print("  as one HIP graph (shape-static): %.2f ms/step = %.0f frames/s; matches the eager flow: %s" % (dg * 1e3, B / dg, ok))
+
+# ---- where the recorded flow spends its time: the same frame recorded once more with stamp launches (glx_stamp)
+from glenet_amd import _lib, backbone as gb  # noqa: E402
+stamps = torch.zeros(16, dtype=torch.int64, device=dev)
+names = []
+
+
+def stamp(name):
+    _lib.call("glx_stamp", stamps, len(names))
+    names.append(name)
+
+
+class _Stamped(det.StaticDetectorPipeline):
+    def enqueue(self):
+        names.clear()
+        stamp("start")
+        bd = gb.StaticFramePipeline.enqueue(self)
+        stamp("voxelize + sparse backbone + dense")
+        with torch.no_grad(), _lib.workspace.scoped(id(self)):
+            self.flow.__dict__["mark"] = stamp
+            try:
+                bd = self.flow.second_stage(bd, self.B)
+            finally:
+                self.flow.__dict__.pop("mark", None)
+        self.out = bd
+        return bd
+
+
+try:
+    sp = _Stamped(flow, B, pts.shape[0], capacities=pipe.capacities)
+    sp.load(pts, bidx)
+    sp.capture()
+    for _ in range(3):
+        sp.replay()
+    torch.cuda.synchronize()
+    t = stamps[:len(names)].tolist()
+    print("  recorded flow, stamps (ms since start): " + " | ".join("%s %.2f" % (n_, (t1 - t[0]) * 1e-5)
+                                                                  for n_, t1 in zip(names[1:], t[1:])))
+except Exception as e:      # the stamped variant pokes at the flow's modules; the numbers above do not depend on it
+    print("  (stamped recording not available: %r)" % (e,))
