@@ -8,7 +8,7 @@ python - <<'PY'
 import json
 b = json.load(open("gpurun_out/final/bench.json"))
 r = b["roofline"]
-print("value %.1f %s  ms/step %.4f | %s frac %.4f traffic %s | all convs frac %.4f %.4f ms | cpu %s | fwd_bwd %s"
-      % (b["value"], b["unit"], b["ms_per_step"], r["kernel"], r["frac"], r["traffic"], r["all_sparse_conv"]["frac"],
-         r["all_sparse_conv"]["ms_per_step"], b["cpu_baseline"]["value"], b["fwd_bwd"]["frames_per_s"]))
+print("value %.1f %s  ms/step %.4f | %s frac %.4f traffic %s | all convs %.4f ms | cpu %s | inference %s / %s ms"
+      % (b["value"], b["unit"], b["ms_per_step"], r["kernel"], r["frac"], r["traffic"], r["all_sparse_conv"]["ms_per_step"],
+         b["cpu_baseline"]["value"], b["inference"]["eager_ms_per_step"], b["inference"]["graph_ms_per_step"]))
 PY
