@@ -316,6 +316,8 @@ class GLENetVR(nn.Module):
                     f = getattr(st, "features", None)
                     if torch.is_tensor(f) and f.requires_grad:
                         msf[k] = st.replace_feature(f.detach().requires_grad_(True))
+                        if getattr(st, "clean_rows", False):      # same values: still zeros past `count`
+                            msf[k].clean_rows = True
                         roi_cuts[k] = (f, msf[k].features)
             ori_cls, std_logit, rcnn_reg, rcnn_std = self.roi_head(rois_s, msf, bd["multi_scale_3d_strides"], B, raw=True)
             mark("RoI-grid pooling + FC towers fwd")
