@@ -117,7 +117,11 @@ def pos_pool(feats, mlp_pos, idx, xyz, new_xyz):
     """mlp_pos = Sequential(Conv2d(3, C, 1, bias=False), BatchNorm2d(C)) -> pooled (M, C)."""
     conv, bn = mlp_pos[0], mlp_pos[1]
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+        from ....spconv import core
+        if core.DEFERRED_COUNTERS is not None:       # a training step adds 1 to all its counters in one launch
+            core.DEFERRED_COUNTERS.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked += 1
     return PosPool.apply(feats, conv.weight, bn.weight, bn.bias, bn, idx, xyz, new_xyz)[0]
 
 
