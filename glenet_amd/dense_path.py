@@ -567,15 +567,41 @@ class _SplitKLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = gy @ w
         if ctx.needs_input_grad[1]:
-            rows = x.shape[0]
-            chunks = next((c for c in (16, 8, 4, 2) if rows % c == 0 and rows // c >= 16), 0) \
-                if w.shape[0] * w.shape[1] <= 256 * 1024 else 0
-            if chunks:
-                gw = torch.bmm(gy.view(chunks, rows // chunks, -1).transpose(1, 2),
-                               x.view(chunks, rows // chunks, -1)).sum(0)
+            if DEFERRED_FC_WGRADS is not None and w.is_leaf:
+                # a leaf of the backward pass: a staged training step computes it later, on the main stream's idle time,
+                # instead of on the RoI branch (its critical path) -- see run_deferred_fc_wgrads
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(x.device))
+                DEFERRED_FC_WGRADS.append((x, gy, w, ev, _SplitKLinearFn.weight_grad))
             else:
-                gw = gy.t() @ x
+                gw = _SplitKLinearFn.weight_grad(x, gy, w)
         return gx, gw
+
+    @staticmethod
+    def weight_grad(x, gy, w):
+        rows = x.shape[0]
+        chunks = next((c for c in (16, 8, 4, 2) if rows % c == 0 and rows // c >= 16), 0) \
+            if w.shape[0] * w.shape[1] <= 256 * 1024 else 0
+        if chunks:
+            return torch.bmm(gy.view(chunks, rows // chunks, -1).transpose(1, 2),
+                             x.view(chunks, rows // chunks, -1)).sum(0)
+        return gy.t() @ x
+
+
+DEFERRED_FC_WGRADS = None     # a list while a staged backward collects the FC towers' weight-gradient jobs
+
+
+def run_deferred_fc_wgrads(jobs):
+    """The weight gradients _SplitKLinearFn.backward left out, on the current stream (which waits for the event each
+    job recorded where its gy became available); written into the parameters' .grad like AccumulateGrad would."""
+    cur = torch.cuda.current_stream()
+    with torch.no_grad():
+        for x, gy, w, ev, weight_grad in jobs:
+            cur.wait_event(ev)
+            x.record_stream(cur)
+            gy.record_stream(cur)
+            gw = weight_grad(x, gy, w)
+            w.grad = gw if w.grad is None else w.grad + gw
 
 
 class SplitKLinear(nn.Linear):

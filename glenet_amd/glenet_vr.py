@@ -116,6 +116,7 @@ class VoxelRCNNKLHead(rg.RoIGridPool):
 
 OVERLAP_ROI = os.environ.get("GLX_OVERLAP_ROI", "1") != "0"
 STAGE_CUTS = os.environ.get("GLX_STAGE_CUTS", "1") != "0"
+DEFER_FC_WGRADS = os.environ.get("GLX_DEFER_FC_WGRADS", "1") != "0"
 
 
 class StagedLoss:
@@ -156,11 +157,17 @@ class StagedLoss:
         # one after the other (measured with the stage stamps, ROCm 7.2's graph executor); two branches do overlap.
         wgrad_stream, core.WGRAD_STREAM = core.WGRAD_STREAM, None
         try:
+            fc_jobs = dp.DEFERRED_FC_WGRADS = [] if DEFER_FC_WGRADS else None
             with torch.cuda.stream(self.roi_stream):      # A: caller stream = RoI stream, nothing of the main stream
-                torch.autograd.backward(self.roi)         # is waited for; ends at the detached leaves
+                try:
+                    torch.autograd.backward(self.roi)     # is waited for; ends at the detached leaves
+                finally:
+                    dp.DEFERRED_FC_WGRADS = None
                 if self.mark:
                     self.mark("backward: RoI head (RoI stream)")
             torch.autograd.backward(self.rpn)             # B: ends at the BEV input's detached leaf
+            if fc_jobs:      # the FC towers' weight gradients: in the main stream's wait for the RoI gradients
+                dp.run_deferred_fc_wgrads(fc_jobs)
             # C: the sparse backbone, level by level: the levels above a stage cut run as soon as THEIR RoI gradients are
             # there (x_conv4's leave the RoI branch first, x_conv2's last)
             roots, grads = [self.bev_cut[0]], [self.bev_cut[1].grad]
