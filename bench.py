@@ -570,7 +570,7 @@ def main():
     # pool, and the differences of the stamps are averaged.  (Events would split the graph, the profiler's per-kernel
     # signals stretch it by ~1 ms; a stamp costs one 2-3 us launch.)
     stages = None
-    if not args.no_stages and args.mode == "graph" and pipe.graph is not None:
+    if not args.no_stages and args.mode == "graph" and pipe.graph is not None and world == 1:      # an N = 1 diagnostic
         stamps = torch.zeros(64, dtype=torch.int64, device=dev)
         names = []
 
