@@ -285,7 +285,8 @@ class GLENetVR(nn.Module):
             def stamp_when_grad_arrives(t, name):
                 if t is not None and t.requires_grad:
                     t.register_hook(lambda g: mark(name))
-            stamp_when_grad_arrives(bd.get("spatial_features_2d"), "backward: losses, RoI head, anchor head")
+            stamp_when_grad_arrives(bd.get("spatial_features_2d"), "backward: dense-head loss, anchor head" if overlap
+                                    else "backward: losses, RoI head, anchor head")
             stamp_when_grad_arrives(bd.get("spatial_features_1x"), "backward: BEV deblocks + block 2")
             stamp_when_grad_arrives(bev_cut[1] if bev_cut else getattr(enc, "features", None), "backward: BEV backbone")
         anchors = self.anchors(gt_boxes.device)
