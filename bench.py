@@ -601,6 +601,9 @@ def main():
                           "stages; rule tables and weight gradients run on a third")
         torch.cuda.synchronize(dev)
         pipe.capture(split=world > 1)          # the recording without stamps again
+        pipe.load(*pool[0][:4])
+        pipe.step()                            # ... and its buffers filled (the config block below reads row counts)
+        torch.cuda.synchronize(dev)
 
     progress("stages done")
     # ---- configs[1]: sparse backbone forward only (eval mode, BN folded), two frame pipelines in flight
