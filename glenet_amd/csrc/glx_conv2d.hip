@@ -727,7 +727,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad_reduce(const float* __res
 
 static int wgrad_blocks(int Cin, int Cout, int* P_out) {
   const int nq = (Cin / 32) * (Cout / 64);
-  int slots = 512;
+  static const int env_slots = getenv("GLX_CONV3X3_WGRAD_SLOTS") ? atoi(getenv("GLX_CONV3X3_WGRAD_SLOTS")) : 512;
+  int slots = env_slots >= 64 && env_slots <= 1024 ? env_slots : 512;      // blocks per launch (two per CU)
   int P = slots / nq;
   P = P / 8 * 8;
   if (P < 8) P = 8;
