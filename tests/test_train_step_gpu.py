@@ -124,12 +124,17 @@ def test_static_step_and_graph_reproduce_the_exact_shape_step(dev):
     model.load_state_dict(state0)                 # same BatchNorm running statistics as the exact-shape run saw
     pipe = gvr.StaticTrainStep(model, B, pts.shape[0] + 700, max_gt=gt.shape[1], lr=0.0, seed_rois_with_gt=JIT,
                                grad_clip=None)
+    # what runs below is the staged backward: RoI branch on its own stream, sparse backward level by level
+    assert model.overlap_roi and model.backbone_3d.stage_cuts
     pipe.calibrate(pts, bidx)
     pipe.load(pts, bidx, gt, unc)
     pipe.step()
     torch.cuda.synchronize()
     pipe.check()
     check(pipe, "shape-static eager")
+    assert torch.is_tensor(pipe.loss) and not pipe.loss.requires_grad
+    total = sum(want_parts[k] for k in ("loss_rpn", "rcnn_loss_cls", "rcnn_loss_reg", "rcnn_loss_corner"))
+    np.testing.assert_allclose(float(pipe.loss), total, rtol=2e-4)
     pipe.capture()
     for _ in range(2):
         pipe.step()
@@ -324,3 +329,39 @@ def test_split_backward_convolutions_give_the_library_gradients(dev):
     # a derived (non-leaf) weight keeps torch's node: its gradient feeds another node on the main stream
     w = torch.cat([cases[1][0].weight, cases[1][0].weight], 0)
     assert not type(dp.conv2d(x.requires_grad_(True), w).grad_fn).__name__.startswith("_ConvSplitBackward")
+
+
+def test_stage_stamps_inside_a_recorded_step_are_ordered(dev):
+    """glx_stamp launches recorded at the stage boundaries (StaticTrainPipeline.mark) give increasing device-clock
+    values along the main stream of a replayed step, and the staged step marks its RoI-stream stages too."""
+    from glenet_amd import _lib, glenet_vr as gvr
+    model = _small_model(dev)
+    B = 2
+    pts, bidx, gt, unc = _batch(dev, [54, 55], 6000)
+    pipe = gvr.StaticTrainStep(model, B, pts.shape[0] + 700, max_gt=gt.shape[1], lr=1e-4, seed_rois_with_gt=JIT)
+    pipe.calibrate(pts, bidx)
+    pipe.load(pts, bidx, gt, unc)
+    stamps = torch.zeros(32, dtype=torch.int64, device=dev)
+    names = []
+
+    def mark(name):
+        if name == "start":
+            names.clear()
+        _lib.call("glx_stamp", stamps, len(names))
+        names.append(name)
+    pipe.mark = model.mark = mark
+    try:
+        pipe.capture()
+        for _ in range(2):
+            pipe.step()
+        torch.cuda.synchronize()
+    finally:
+        pipe.mark = model.mark = None
+    t = dict(zip(names, stamps[:len(names)].tolist()))
+    assert "backward: RoI head (RoI stream)" in t and "RoI-head losses" in t
+    main = ["start", "voxelize + MeanVFE", "sparse backbone fwd + dense()", "BEV backbone + anchor head fwd",
+            "anchor targets + dense-head loss", "backward: BEV backbone", "backward", "grad clip + AdamW"]
+    seq = [t[n] for n in main]
+    assert all(b > a for a, b in zip(seq[:-1], seq[1:])), list(zip(main, seq))
+    assert 0 < (seq[-1] - seq[0]) * 1e-5 < 1000.0          # 100 MHz ticks: a step of this size takes milliseconds
+    assert t["RoI-head losses"] < t["backward: RoI head (RoI stream)"] <= t["backward"]
