@@ -253,3 +253,29 @@ def test_topk_kernel_matches_a_stable_sort(dev, A, K):
     assert np.array_equal(top.cpu().numpy(), np.take_along_axis(s, want, 1))
     ttop, _ = torch.topk(torch.from_numpy(s).to(dev), K, dim=1)
     assert torch.equal(ttop, top)
+
+
+@pytest.mark.gpu
+def test_gather_proposals_kernel_equals_the_tensor_expression(dev):
+    """glx_gather_proposals (the proposal layer's tail in one launch) == arange / where / gather / mask on the same
+    keep lists, incl. frames with fewer survivors than slots and an empty frame (roi_head_template.py:106-126)."""
+    from glenet_amd import _lib
+    g = torch.Generator(device=dev).manual_seed(5)
+    F, A, K, P, C = 3, 500, 200, 64, 7
+    cand = torch.randn((F, K, C), device=dev, generator=g)
+    top = torch.rand((F, K), device=dev, generator=g)
+    lab = torch.randint(0, 3, (F, A), device=dev, generator=g)
+    order = torch.stack([torch.randperm(A, device=dev, generator=g)[:K] for _ in range(F)])
+    keep = torch.stack([torch.randperm(K, device=dev, generator=g) for _ in range(F)])
+    num = torch.tensor([P + 10, 17, 0], dtype=torch.int32, device=dev)
+    rois = torch.empty((F, P, C), device=dev)
+    scores = torch.empty((F, P), device=dev)
+    labels = torch.empty((F, P), dtype=torch.int64, device=dev)
+    _lib.call("glx_gather_proposals", cand, top, lab, order, keep, num, F, A, K, K, P, C, rois, scores, labels)
+    valid = torch.arange(P, device=dev)[None, :] < num[:, None]
+    sel = torch.where(valid, keep[:, :P], torch.zeros_like(keep[:, :P]))
+    want_rois = torch.gather(cand, 1, sel.unsqueeze(-1).expand(F, P, C)) * valid.unsqueeze(-1)
+    want_scores = torch.gather(top, 1, sel) * valid
+    want_labels = torch.gather(torch.gather(lab, 1, order), 1, sel) * valid + 1
+    assert torch.equal(rois, want_rois) and torch.equal(scores, want_scores) and torch.equal(labels, want_labels)
+    assert float(rois[2].abs().max()) == 0.0 and int(labels[2].max()) == 1
