@@ -110,6 +110,9 @@ def test_static_detector_pipeline_and_graph_match_the_eager_flow(dev):
     with torch.no_grad():
         want = flow(pts, bidx, B)
     pipe = det.StaticDetectorPipeline(flow, B, pts.shape[0] + 500)
+    # the recorded flow hands the BEV backbone what the eager flow does (channels-last, deferred to the sparse first layer):
+    # with the base class's own HeightCompression the map arrived NCHW and the backbone ran on the vendor's kernels
+    assert pipe.hc is flow.map_to_bev
     pipe.calibrate(pts, bidx)
     pipe.load(pts, bidx)
     got = pipe.enqueue()
