@@ -111,8 +111,8 @@ class ConvProfiler:
         if not self.enabled or name == "k_sconv_generic":
             return
         s, e = self._event(), self._event()
-        self._lib.call_nostream("glx_profile_next_sconv", s, e)
         self.records.append((name, s, e, rules, K, cin, cout, tag))
+        return s, e              # handed to THIS launch as glx_sconv_opts.profile_start / profile_stop
 
     def summary(self):
         per = {}

@@ -100,6 +100,42 @@ def double_arg(x):
     return ctypes.c_double(float(x))
 
 
+# ---- per-call option structs of the *_ex entry points (include/glenet_hip.h: glx_bn_stats, glx_epilogue,
+# glx_sconv_opts, glx_conv_opts): explicit arguments, no "next call" state anywhere
+def _p(t):
+    return None if t is None else (t.data_ptr() if isinstance(t, torch.Tensor) else t)
+
+
+class BnStats(ctypes.Structure):
+    _fields_ = [("state", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("momentum", c_float),
+                ("coef", c_void_p), ("save_mean", c_void_p), ("save_invstd", c_void_p), ("running_mean", c_void_p),
+                ("running_var", c_void_p)]
+
+
+class Epilogue(ctypes.Structure):
+    _fields_ = [("scale", c_void_p), ("shift", c_void_p), ("relu", c_int), ("ldc", c_int), ("coff", c_int)]
+
+
+class SconvOpts(ctypes.Structure):
+    _fields_ = [("tile_map", c_void_p), ("bn", ctypes.POINTER(BnStats)), ("profile_start", c_void_p),
+                ("profile_stop", c_void_p)]
+
+
+class ConvOpts(ctypes.Structure):
+    _fields_ = [("bn", ctypes.POINTER(BnStats)), ("epilogue", ctypes.POINTER(Epilogue))]
+
+
+def bn_stats(state, bn, coef, save_mean, save_invstd):
+    """glx_bn_stats of a training-mode torch BatchNorm module (statistics of the convolution in front of it)."""
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    return BnStats(_p(state), _p(bn.weight), _p(bn.bias), float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1),
+                   _p(coef), _p(save_mean), _p(save_invstd), _p(rm), _p(rv))
+
+
+def epilogue(scale, shift, relu, ldc=0, coff=0):
+    return Epilogue(_p(scale), _p(shift), 1 if relu else 0, int(ldc), int(coff))
+
+
 def check_cuda(*tensors):
     for t in tensors:
         if t is None:
@@ -118,17 +154,42 @@ def check_cuda(*tensors):
 # (tensor versions, data pointers, weights_epoch()), and whatever updates weights behind torch's back calls
 # bump_weights_epoch(): FlatAdamW.step, the fused training BatchNorm entry points, and the step() / replay() of the
 # recorded training steps.  (train -> eval on the same module ran the first eval's packed weights.)
-_weights_epoch = 0
+# The epoch is SCOPED to the tensors it protects (a process-global epoch made an eval pipeline re-record itself
+# whenever ANY model trained): a writer names the tensors it wrote -- each then carries its own `_glx_epoch` -- and a reader
+# asks for the epoch of the tensors its cache derives from.  A writer that cannot name them bumps the global part, which
+# every reader includes (the conservative behaviour of before).
+_weights_epoch = 0          # global part
+_epoch_counter = 0
 
 
-def weights_epoch():
-    return _weights_epoch
+def weights_epoch(*tensors):
+    """Epoch of the caches derived from `tensors` (None entries ignored): the global part + the newest per-tensor stamp."""
+    e = _weights_epoch
+    for t in tensors:
+        if t is not None:
+            te = t.__dict__.get("_glx_epoch", 0)
+            if te > e:
+                e = te
+    return e
 
 
-def bump_weights_epoch():
-    global _weights_epoch
-    _weights_epoch += 1
-    return _weights_epoch
+def tensors_epoch_sum(tensors):
+    """Sum of the per-tensor stamps (they only grow): the tag of a cache that derives from many tensors."""
+    return sum(t.__dict__.get("_glx_epoch", 0) for t in tensors)
+
+
+def bump_weights_epoch(tensors=None):
+    """tensors: the parameters / buffers that were written behind torch's back (their stamps move, nobody else's caches
+    are invalidated); None: unknown -- everything is stale."""
+    global _weights_epoch, _epoch_counter
+    _epoch_counter += 1
+    if tensors is None:
+        _weights_epoch = _epoch_counter
+    else:
+        for t in tensors:
+            if t is not None:
+                t.__dict__["_glx_epoch"] = _epoch_counter
+    return _epoch_counter
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -340,8 +340,13 @@ class StaticFramePipeline:
         torch.cuda.synchronize(self.points.device)
         self.check()
         gc.collect()
+        # A pipeline that records itself AGAIN (its weights changed) retires the old exec (never destroyed, _lib.new_graph)
+        # but records into the old graph's private memory pool: the retired graph is never launched again and its
+        # buffers die with the old `out`, so repeated re-captures do not grow the pool.
+        retired = self.graph
+        pool = retired.pool() if (retired is not None and REUSE_GRAPH_POOL) else None
         self.graph = _lib.new_graph()
-        with torch.cuda.graph(self.graph, stream=side), no_gc():
+        with torch.cuda.graph(self.graph, stream=side, pool=pool), no_gc():
             self.enqueue()
         self._tag = self._weights_tag()
         return self
@@ -353,14 +358,17 @@ class StaticFramePipeline:
         """Inference graphs read packed weights / folded BatchNorms that are cached by tensor version outside the
         graph: a load_state_dict() or an in-place edit after capture() would leave the replays on the old copies.
         The sum of the version counters (they only grow) tells; replay() then records the frame again."""
-        tag = 0
+        tag = stamps = 0
         for m in self._tagged_modules():
             for t in m.parameters():
                 tag += t._version
+                stamps += t.__dict__.get("_glx_epoch", 0)
             for t in m.buffers():
                 tag += t._version
-        # + the weights epoch: fused optimizer / BatchNorm updates and replayed training graphs move no version counter
-        return (tag, _lib.weights_epoch())
+                stamps += t.__dict__.get("_glx_epoch", 0)
+        # + the weights epoch of THESE tensors: fused optimizer / BatchNorm updates and replayed training graphs move no
+        # version counter.  Scoped (ADVICE r3): training an unrelated model leaves this pipeline's tag alone.
+        return (tag, stamps, _lib.weights_epoch())
 
     def replay(self):
         """Launch the recorded frame.  At most `max_in_flight` frames are queued: the host waits
@@ -400,6 +408,9 @@ class StaticFramePipeline:
         """Trim a shape-static SparseConvTensor to its live rows (host sync) for inspection."""
         n = int(st.count.item())
         return st.features[:n], st.indices[:n]
+
+
+REUSE_GRAPH_POOL = os.environ.get("GLX_REUSE_GRAPH_POOL", "1") != "0"
 
 
 @contextlib.contextmanager
@@ -453,8 +464,18 @@ class StaticTrainPipeline(StaticFramePipeline):
         """A replayed training step updates parameters and running statistics without running any Python: tell the
         version-keyed caches of everything that shares these weights (eval-mode modules, inference graphs)."""
         out = super().replay()
-        _lib.bump_weights_epoch()
+        _lib.bump_weights_epoch(self._written_tensors())
         return out
+
+    def _written_tensors(self):
+        """Everything a replayed step writes behind torch's back: parameters (a recorded optimizer) and BatchNorm
+        running statistics of the modules the step runs."""
+        hit = self.__dict__.get("_glx_written")
+        if hit is None:
+            mods = (self.model,) + tuple(self.extra_modules)
+            hit = [t for m in mods for t in list(m.parameters()) + list(m.buffers())]
+            self.__dict__["_glx_written"] = hit
+        return hit
 
     def enqueue(self):
         from ._lib import workspace

@@ -20,7 +20,10 @@ def supported(x, weight, stride, padding, dilation, groups, bias):
     return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and bias is None
             and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
             and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[0] % 64 == 0 and weight.shape[1] % 64 == 0
-            and x.shape[1] == weight.shape[1] and x.is_contiguous(memory_format=torch.channels_last))
+            and x.shape[1] == weight.shape[1] and x.is_contiguous(memory_format=torch.channels_last)
+            # the kernels index a map with 32-bit element offsets (GLX_REQUIRE in glx_conv3x3_forward): larger batches
+            # take the caller's fallback instead of an error
+            and x.shape[0] * x.shape[2] * x.shape[3] * max(int(weight.shape[0]), int(weight.shape[1])) < (1 << 31))
 
 
 def bn_state_available():
@@ -70,7 +73,7 @@ def packs(weight):
         if hit is not None:
             return hit
     key = (weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()))
-    tag = (_lib.weights_epoch(), weight._version)
+    tag = (_lib.weights_epoch(weight), weight._version)
     hit = _packs.get(key)
     if hit is not None and hit[3]() is not weight:
         hit = None                         # another tensor that happens to live where a freed weight did
@@ -90,42 +93,38 @@ def packs(weight):
     return fwd, bwd
 
 
-def _run(x, pack, cout, bn=None):
+def _run(x, pack, cout, bn=None, epi=None):
     """bn: a training-mode BatchNorm2d that follows the conv -- its batch statistics are taken in the kernel's epilogue
-    (glx_conv3x3_next_bn_stats) and the call returns (y, coef, save_mean, save_invstd)."""
+    (glx_conv_opts.bn) and the call returns (y, coef, save_mean, save_invstd).  epi: an _lib.Epilogue (inference)."""
     b, c, h, w = x.shape
     if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)):
         raise _lib.GlxError("conv3x3 expects a float32 channels-last device map, got %s strides %s on %s"
                             % (x.dtype, tuple(x.stride()), x.device))
     y = torch.empty((b, cout, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    stats = None
+    stats = opts = None
     if bn is not None:
         from .spconv import core
         stats = tuple(torch.empty(n, dtype=torch.float32, device=x.device) for n in (2 * cout, cout, cout))
-        rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-        _lib.call_nostream("glx_conv3x3_next_bn_stats", core._bn_state(x.device), bn.weight, bn.bias,
-                           ctypes.c_float(bn.eps), ctypes.c_float(bn.momentum), stats[0], stats[1], stats[2], rm, rv)
-    call("glx_conv3x3_forward", x, b, h, w, c, pack, cout, y)
+        st = _lib.bn_stats(core._bn_state(x.device), bn, *stats)
+        opts = _lib.ConvOpts(ctypes.pointer(st), None)
+    elif epi is not None:
+        opts = _lib.ConvOpts(None, ctypes.pointer(epi))
+    call("glx_conv3x3_forward_ex", x, b, h, w, c, pack, cout, y, ctypes.byref(opts) if opts is not None else None)
     if bn is not None:
         if bn.track_running_stats:
-            _lib.bump_weights_epoch()          # running statistics moved behind torch's back
+            _lib.bump_weights_epoch((bn.running_mean, bn.running_var))     # moved behind torch's back
         return (y,) + stats
     return y
 
 
-_wgrad_ws = {}
-
-
 def wgrad(x, gy, weight):
-    """dW of conv3x3 for a weight of `weight`'s shape and strides (a fresh tensor).  The workspace is this function's
-    own (one per device and size): weight gradients of a step run one after another on ONE stream."""
+    """dW of conv3x3 for a weight of `weight`'s shape and strides (a fresh tensor).  The split-K workspace is the
+    (device, CURRENT stream, pipeline scope) buffer of _lib.workspace: weight gradients launched on different streams
+    (the staged backward moves them between the main and the side stream; two pipelines) never share it."""
     cout, cin = int(weight.shape[0]), int(weight.shape[1])
     b, _, h, w = x.shape
     n = query("glx_conv3x3_wgrad_workspace_bytes", cin, cout)
-    key = (x.device.index, n)
-    ws = _wgrad_ws.get(key)
-    if ws is None:
-        ws = _wgrad_ws[key] = torch.empty(n, dtype=torch.uint8, device=x.device)
+    ws = _lib.workspace.get(n, x.device)
     gw = torch.empty_like(weight)
     s = gw.stride()
     ll = ctypes.c_longlong
@@ -246,10 +245,7 @@ class _Deconv(torch.autograd.Function):
                     t.record_stream(side)
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
                 n = query("glx_deconv_wgrad_workspace_bytes", cin, cout, u)
-                key = (x.device.index, "deconv", n)
-                ws = _wgrad_ws.get(key)
-                if ws is None:
-                    ws = _wgrad_ws[key] = torch.empty(n, dtype=torch.uint8, device=x.device)
+                ws = _lib.workspace.get(n, x.device)          # per (device, current stream): see wgrad()
                 gw = torch.empty_like(weight)
                 s = gw.stride()
                 ll = ctypes.c_longlong
@@ -272,7 +268,7 @@ _deconv_pack_cache = {}
 
 def _deconv_packs_cached(weight):
     key = (weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()))
-    tag = (_lib.weights_epoch(), weight._version)
+    tag = (_lib.weights_epoch(weight), weight._version)
     hit = _deconv_pack_cache.get(key)
     if hit is not None and hit[3]() is weight and hit[0] == tag and not torch.cuda.is_current_stream_capturing():
         return hit[1], hit[2]
@@ -285,8 +281,7 @@ def conv3x3_affine(x, weight, scale, shift, relu):
     """relu?(conv3x3(x, weight) * scale[c] + shift[c]) in one launch (no autograd): an eval-mode BatchNorm2d folded into
     the convolution's epilogue."""
     fwd, _ = packs(weight)
-    _lib.call_nostream("glx_conv3x3_next_epilogue", scale, shift, 1 if relu else 0)
-    return _run(x, fwd, int(weight.shape[0]))
+    return _run(x, fwd, int(weight.shape[0]), epi=_lib.epilogue(scale, shift, relu))
 
 
 def conv3x3s2_affine(x, weight, scale, shift, relu):
@@ -295,8 +290,7 @@ def conv3x3s2_affine(x, weight, scale, shift, relu):
     b, c, h, w = x.shape
     cout = int(weight.shape[0])
     y = torch.empty((b, cout, h // 2, w // 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    _lib.call_nostream("glx_pconv_next_epilogue", scale, shift, 1 if relu else 0, 0, 0)
-    call("glx_conv3x3s2_forward", x, b, h, w, c, fwd, cout, y)
+    call("glx_conv3x3s2_forward_ex", x, b, h, w, c, fwd, cout, y, ctypes.byref(_lib.epilogue(scale, shift, relu)))
     return y
 
 
@@ -309,6 +303,6 @@ def deconv_affine(x, weight, scale, shift, relu, out=None, channel_offset=0):
     if out is None:
         out = torch.empty((b, cout, h * u, w * u), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     ldc = int(out.shape[1])
-    _lib.call_nostream("glx_pconv_next_epilogue", scale, shift, 1 if relu else 0, ldc if ldc != cout else 0, int(channel_offset))
-    call("glx_deconv_forward", x, b, h, w, cin, fwd, cout, u, out)
+    epi = _lib.epilogue(scale, shift, relu, ldc if ldc != cout else 0, channel_offset)
+    call("glx_deconv_forward_ex", x, b, h, w, cin, fwd, cout, u, out, ctypes.byref(epi))
     return out

@@ -656,7 +656,7 @@ extern "C" int glx_bn_relu_train_forward(const float* x, int N, int C, const flo
 }
 
 // The transform alone, for statistics that were taken elsewhere (the sparse conv's epilogue,
-// glx_sconv_next_bn_stats): y = relu?(x * coef[c] + coef[C + c]) on the live rows, zeros on the rest.
+// glx_sconv_opts.bn): y = relu?(x * coef[c] + coef[C + c]) on the live rows, zeros on the rest.
 extern "C" int glx_bn_apply_forward(const float* x, const float* coef, int relu, int N, int C, const int32_t* n_live,
                                     float* y, int y_stride, void* stream) {
   GLX_REQUIRE(coef && y && (N == 0 || x), "glx_bn_apply_forward: null pointer");

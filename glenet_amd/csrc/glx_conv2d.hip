@@ -74,7 +74,7 @@ struct ConvArgs {
   BnState* bn_state;     // STATS: training-mode BatchNorm statistics of y taken in the epilogue
   BnFinalize bn;
   long long* stamps;     // diagnostics (glx_conv3x3_set_stamps): per block, shader-clock and 100 MHz-clock ticks of its lifetime
-  const float* epi_scale;   // inference epilogue (glx_conv3x3_next_epilogue): y = relu?(conv * scale[c] + shift[c]), second form
+  const float* epi_scale;   // inference epilogue (glx_conv_opts.epilogue): y = relu?(conv * scale[c] + shift[c]), second form
   const float* epi_shift;
   int epi_relu;
 };
@@ -853,51 +853,35 @@ extern "C" int glx_conv3x3_set_grid(int blocks, int ablate) {
   return GLX_OK;
 }
 
-// y = relu?(conv * scale[c] + shift[c]) in the epilogue of the NEXT glx_conv3x3_forward call of this host thread (an
-// eval-mode BatchNorm folded behind the convolution; scale, shift: Cout floats on the device)
-static thread_local const float* g_conv_next_epi_scale = nullptr;
-static thread_local const float* g_conv_next_epi_shift = nullptr;
-static thread_local int g_conv_next_epi_relu = 0;
-extern "C" int glx_conv3x3_next_epilogue(const float* scale, const float* shift, int relu) {
-  GLX_REQUIRE(scale && shift, "glx_conv3x3_next_epilogue: null pointer");
-  g_conv_next_epi_scale = scale;
-  g_conv_next_epi_shift = shift;
-  g_conv_next_epi_relu = relu;
-  return GLX_OK;
-}
-
 static long long* g_conv_stamps = nullptr;   // diagnostics: 2 x int64 per block of the following glx_conv3x3_forward launches
 extern "C" int glx_conv3x3_set_stamps(void* stamps) {
   g_conv_stamps = (long long*)stamps;
   return GLX_OK;
 }
 
-// Training-mode BatchNorm behind the NEXT glx_conv3x3_forward call of this host thread (same contract as
-// glx_sconv_next_bn_stats).
-static thread_local BnState* g_conv_next_bn_state = nullptr;
-static thread_local BnFinalize g_conv_next_bn = {};
-extern "C" int glx_conv3x3_next_bn_stats(void* state, const float* gamma, const float* beta, float eps, float momentum,
-                                         float* coef, float* save_mean, float* save_invstd, float* running_mean,
-                                         float* running_var) {
-  GLX_REQUIRE(state && coef && save_mean && save_invstd, "glx_conv3x3_next_bn_stats: null pointer");
-  g_conv_next_bn_state = (BnState*)state;
-  g_conv_next_bn = BnFinalize{gamma, beta, eps, momentum, coef, save_mean, save_invstd, running_mean, running_var,
-                              nullptr, nullptr, nullptr};
-  return GLX_OK;
-}
-
-extern "C" int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin, const void* packed, int Cout,
-                                   float* y, void* stream) {
+// opts->bn: training-mode BatchNorm statistics of y in the epilogue (same contract as glx_sconv_forward_ex); opts->epilogue:
+// y = relu?(conv * scale[c] + shift[c]), an eval-mode BatchNorm folded behind the convolution (scale, shift: Cout device
+// floats).  Explicit arguments: nothing is carried between calls.
+extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int Cin, const void* packed, int Cout,
+                                      float* y, const glx_conv_opts* opts, void* stream) {
+  const glx_bn_stats* bnp = opts ? opts->bn : nullptr;
+  const glx_epilogue* epi = opts ? opts->epilogue : nullptr;
+  BnState* bn_state = bnp ? (BnState*)bnp->state : nullptr;
+  BnFinalize bn_fin = {};
+  if (bnp) {
+    GLX_REQUIRE(bnp->state && bnp->coef && bnp->save_mean && bnp->save_invstd, "glx_conv3x3_forward_ex: BatchNorm statistics: null pointer");
+    bn_fin = BnFinalize{bnp->gamma, bnp->beta, bnp->eps, bnp->momentum, bnp->coef, bnp->save_mean, bnp->save_invstd,
+                        bnp->running_mean, bnp->running_var, nullptr, nullptr, nullptr};
+  }
+  const float* epi_scale = epi ? epi->scale : nullptr;
+  const float* epi_shift = epi ? epi->shift : nullptr;
+  const int epi_relu = epi ? epi->relu : 0;
+  GLX_REQUIRE(!epi || (epi->scale && epi->shift && epi->ldc == 0 && epi->coff == 0),
+              "glx_conv3x3_forward_ex: the epilogue needs scale and shift, dense placement");
   GLX_REQUIRE(B > 0 && H > 0 && W > 0, "glx_conv3x3_forward: empty map (%d, %d, %d)", B, H, W);
   GLX_REQUIRE(Cin % 32 == 0 && Cout % CV_BN == 0, "glx_conv3x3_forward: needs Cin %% 32 == 0 and Cout %% 64 == 0 (got %d -> %d)",
               Cin, Cout);
   GLX_REQUIRE((long long)B * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31), "glx_conv3x3_forward: map too large (2^31 elements)");
-  BnState* bn_state = g_conv_next_bn_state;      // consumed by THIS call whatever happens below
-  g_conv_next_bn_state = nullptr;
-  const float* epi_scale = g_conv_next_epi_scale;
-  const float* epi_shift = g_conv_next_epi_shift;
-  const int epi_relu = g_conv_next_epi_relu;
-  g_conv_next_epi_scale = g_conv_next_epi_shift = nullptr;
   GLX_REQUIRE(!(bn_state && epi_scale), "glx_conv3x3_forward: statistics and an inference epilogue in one call");
   GLX_REQUIRE(!bn_state || Cout <= BN_MAXC, "glx_conv3x3_forward: BatchNorm statistics for at most %d channels", BN_MAXC);
   void (*kern)(ConvArgs) = bn_state ? k_conv3x3<0, true> : k_conv3x3<0, false>;
@@ -959,7 +943,7 @@ extern "C" int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin,
     slots = cus > 0 ? cus : 256;
   }
   a.bn_state = bn_state;
-  a.bn = g_conv_next_bn;
+  a.bn = bn_fin;
   a.stamps = g_conv_stamps;
   a.epi_scale = epi_scale;
   a.epi_shift = epi_shift;
@@ -970,4 +954,9 @@ extern "C" int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin,
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, a);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
+}
+
+extern "C" int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin, const void* packed, int Cout,
+                                   float* y, void* stream) {
+  return glx_conv3x3_forward_ex(x, B, H, W, Cin, packed, Cout, y, nullptr, stream);
 }

@@ -52,7 +52,7 @@ struct PconvArgs {
   int ktaps, ntaps;     // ui * ui, uo * uo
   int k3;               // 1: the input taps are a 3 x 3 window with zero padding 1 around (ui y, ui x) (strided convolution)
   int M, mtiles, nblk, nunits;
-  const float* epi_scale;   // inference epilogue (glx_pconv_next_epilogue): y = relu?(acc * scale[c] + shift[c])
+  const float* epi_scale;   // inference epilogue (glx_epilogue): y = relu?(acc * scale[c] + shift[c])
   const float* epi_shift;
   int epi_relu;
   int ldc, coff;        // floats between output pixels (>= N) and the first output channel's offset inside a pixel
@@ -336,22 +336,12 @@ extern "C" int glx_deconv_pack(const float* W, long long s_ci, long long s_co, l
 // y = relu?(acc * scale[c] + shift[c]) (a folded eval-mode BatchNorm), written with `ldc` floats between pixels starting at
 // channel `coff` of each pixel -- a deblock's result straight into its slice of the concatenated map
 // (base_bev_backbone.py:100-104).  ldc = 0: dense (ldc = Cout, coff = 0); scale = NULL: no transform.
-static thread_local const float* g_pc_next_scale = nullptr;
-static thread_local const float* g_pc_next_shift = nullptr;
-static thread_local int g_pc_next_relu = 0, g_pc_next_ldc = 0, g_pc_next_coff = 0;
-extern "C" int glx_pconv_next_epilogue(const float* scale, const float* shift, int relu, int ldc, int coff) {
-  GLX_REQUIRE((scale == nullptr) == (shift == nullptr) && ldc >= 0 && coff >= 0 && (ldc & 3) == 0 && (coff & 3) == 0,
-              "glx_pconv_next_epilogue: bad arguments (ldc %d, coff %d)", ldc, coff);
-  g_pc_next_scale = scale;
-  g_pc_next_shift = shift;
-  g_pc_next_relu = relu;
-  g_pc_next_ldc = ldc;
-  g_pc_next_coff = coff;
-  return GLX_OK;
-}
-
+// (glx_epilogue, an explicit argument of glx_deconv_forward_ex / glx_conv3x3s2_forward_ex)
 static int pconv_launch(const float* x, const void* packed, float* y, int B, int Hc, int Wc, int Ck, int N, int ui, int uo,
-                        hipStream_t st, int k3 = 0, bool take_epilogue = false) {
+                        hipStream_t st, int k3 = 0, const glx_epilogue* epi = nullptr) {
+  GLX_REQUIRE(!epi || ((epi->scale == nullptr) == (epi->shift == nullptr) && epi->ldc >= 0 && epi->coff >= 0 &&
+                       (epi->ldc & 3) == 0 && (epi->coff & 3) == 0),
+              "glx_pconv: bad epilogue (ldc %d, coff %d)", epi ? epi->ldc : 0, epi ? epi->coff : 0);
   static const int form = getenv("GLX_PCONV_FORM") ? atoi(getenv("GLX_PCONV_FORM")) : 2;
   static bool attr_set = false;
   if (!attr_set) {
@@ -365,11 +355,9 @@ static int pconv_launch(const float* x, const void* packed, float* y, int B, int
   a.k3 = k3;
   a.epi_scale = a.epi_shift = nullptr;
   a.epi_relu = 0; a.ldc = N; a.coff = 0;
-  if (take_epilogue) {
-    a.epi_scale = g_pc_next_scale; a.epi_shift = g_pc_next_shift; a.epi_relu = g_pc_next_relu;
-    if (g_pc_next_ldc) { a.ldc = g_pc_next_ldc; a.coff = g_pc_next_coff; }
-    g_pc_next_scale = g_pc_next_shift = nullptr;
-    g_pc_next_ldc = g_pc_next_coff = 0;
+  if (epi) {
+    a.epi_scale = epi->scale; a.epi_shift = epi->shift; a.epi_relu = epi->relu;
+    if (epi->ldc) { a.ldc = epi->ldc; a.coff = epi->coff; }
     GLX_REQUIRE(a.ldc >= a.coff + N, "glx_pconv: output slice [%d, %d) does not fit a pixel of %d floats", a.coff, a.coff + N, a.ldc);
   }
   a.M = B * Hc * Wc;
@@ -393,11 +381,15 @@ static int pconv_launch(const float* x, const void* packed, float* y, int B, int
   return GLX_OK;
 }
 
-extern "C" int glx_deconv_forward(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, int u,
-                                  float* y, void* stream) {
+extern "C" int glx_deconv_forward_ex(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, int u,
+                                     float* y, const glx_epilogue* epilogue, void* stream) {
   GLX_REQUIRE(B > 0 && H > 0 && W > 0 && (u == 1 || u == 2) && Cin % 64 == 0 && Cout % 64 == 0,
               "glx_deconv_forward: bad sizes (%d, %d, %d), u=%d, %d -> %d", B, H, W, u, Cin, Cout);
-  return pconv_launch(x, packed_fwd, y, B, H, W, Cin, Cout, 1, u, (hipStream_t)stream, 0, true);
+  return pconv_launch(x, packed_fwd, y, B, H, W, Cin, Cout, 1, u, (hipStream_t)stream, 0, epilogue);
+}
+extern "C" int glx_deconv_forward(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, int u,
+                                  float* y, void* stream) {
+  return glx_deconv_forward_ex(x, B, H, W, Cin, packed_fwd, Cout, u, y, nullptr, stream);
 }
 
 extern "C" int glx_deconv_input_grad(const float* gy, int B, int H, int W, int Cin, const void* packed_bwd, int Cout, int u,
@@ -591,9 +583,13 @@ extern "C" int glx_deconv_wgrad(const float* x, const float* gy, int B, int H, i
 // for the stride-1 layers ([tap][chunk][plane][Cout][32] is what k_pconv reads for nine input taps and one output tap).
 // x (B, H, W, Cin), H and W even -> y (B, H / 2, W / 2, Cout).  Bit-reproducible, which the vendor kernel for this layer is
 // not (split-K atomics in a FORWARD pass: every ReLU mask behind it can flip from run to run).
-extern "C" int glx_conv3x3s2_forward(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, float* y,
-                                     void* stream) {
+extern "C" int glx_conv3x3s2_forward_ex(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout,
+                                        float* y, const glx_epilogue* epilogue, void* stream) {
   GLX_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cin % 32 == 0 && Cout % 64 == 0,
               "glx_conv3x3s2_forward: bad sizes (%d, %d, %d), %d -> %d (even maps, Cin %% 32, Cout %% 64)", B, H, W, Cin, Cout);
-  return pconv_launch(x, packed_fwd, y, B, H / 2, W / 2, Cin, Cout, 2, 1, (hipStream_t)stream, 1, true);
+  return pconv_launch(x, packed_fwd, y, B, H / 2, W / 2, Cin, Cout, 2, 1, (hipStream_t)stream, 1, epilogue);
+}
+extern "C" int glx_conv3x3s2_forward(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, float* y,
+                                     void* stream) {
+  return glx_conv3x3s2_forward_ex(x, B, H, W, Cin, packed_fwd, Cout, y, nullptr, stream);
 }

@@ -20,7 +20,7 @@ void glx_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* glx_last_error(void) { return g_err; }
-extern "C" int glx_abi_version(void) { return 6; }
+extern "C" int glx_abi_version(void) { return 7; }
 
 // ---------------------------------------------------------------- timing events (bench)
 extern "C" int glx_event_create(void** event) {

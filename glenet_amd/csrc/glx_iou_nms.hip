@@ -259,7 +259,13 @@ __device__ __forceinline__ bool pbox_iou_below(const PBox& a, const PBox& b, flo
 // densely (a thread per surviving pair) -- same two-phase scheme as k_nms_mask.
 __global__ __launch_bounds__(256) void k_pairwise_tile(const float* __restrict__ a, int N,
                                                        const float* __restrict__ b, int M, int mode,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, long long si, long long sj,
+                                                       long long a_frame, long long b_frame, long long out_frame,
+                                                       const int* __restrict__ counts) {
+  // blockIdx.z = frame of a batch of independent box lists (strides in elements); counts: live boxes per frame
+  // (rows and columns past it are left untouched)
+  a += a_frame * blockIdx.z; b += b_frame * blockIdx.z; out += out_frame * blockIdx.z;
+  if (counts) { N = min(N, counts[blockIdx.z]); M = min(M, counts[blockIdx.z]); }
   __shared__ PBox s_row[64], s_col[64];
   __shared__ unsigned short s_q[64 * 64];
   __shared__ int s_n;
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(256) void k_pairwise_tile(const float* __restrict__
     if (i >= N) break;   // wave-uniform
     const PBox A = s_row[rl];
     const bool pass = jok && !pbox_far(A, B);
-    if (jok && !pass) out[(long long)i * M + j] = 0.f;
+    if (jok && !pass) out[(long long)i * si + (long long)j * sj] = 0.f;
     const unsigned long long bal = __ballot(pass);
     if (bal) {
       int base = 0;
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(256) void k_pairwise_tile(const float* __restrict__
     const PBox A = s_row[rl], Bq = s_col[cl];
     float v = box_overlap<false>(rbox_from(A), rbox_from(Bq));
     if (mode == 1) v = v / fmaxf(A.area + Bq.area - v, IOU_EPS);
-    out[(long long)(i0 + rl) * M + j0 + cl] = v;
+    out[(long long)(i0 + rl) * si + (long long)(j0 + cl) * sj] = v;
   }
 }
 
@@ -341,7 +347,23 @@ extern "C" int glx_boxes_overlap_bev(const float* boxes_a, int N, const float* b
   if (N == 0 || M == 0) return GLX_OK;
   GLX_REQUIRE(boxes_a && boxes_b && out, "glx_boxes_overlap_bev: null pointer");
   hipLaunchKernelGGL(k_pairwise_tile, dim3(glx_divup(M, 64), glx_divup(N, 64)), dim3(256), 0,
-                     (hipStream_t)stream, boxes_a, N, boxes_b, M, iou ? 1 : 0, out);
+                     (hipStream_t)stream, boxes_a, N, boxes_b, M, iou ? 1 : 0, out, (long long)M, 1ll, 0ll, 0ll, 0ll,
+                     (const int*)nullptr);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// `frames` independent lists of N boxes (frames, N, 7): out (frames, N, N) with out[f][j][i] = IoU(box i, box j) when
+// transposed (what glx_nms_vote_batch reads), out[f][i][j] otherwise.  counts (frames) int32 device or NULL: only the
+// leading counts[f] boxes of a frame are live, the rest of its matrix is not written.
+extern "C" int glx_boxes_iou_bev_self_batch(const float* boxes, int frames, int N, const int32_t* counts, int transposed,
+                                            float* out, void* stream) {
+  if (frames <= 0 || N <= 0) return GLX_OK;
+  GLX_REQUIRE(boxes && out, "glx_boxes_iou_bev_self_batch: null pointer");
+  GLX_REQUIRE(frames <= 65535, "glx_boxes_iou_bev_self_batch: %d frames", frames);
+  hipLaunchKernelGGL(k_pairwise_tile, dim3(glx_divup(N, 64), glx_divup(N, 64), frames), dim3(256), 0, (hipStream_t)stream,
+                     boxes, N, boxes, N, 1, out, transposed ? 1ll : (long long)N, transposed ? (long long)N : 1ll,
+                     (long long)N * 7, (long long)N * 7, (long long)N * N, counts);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
@@ -828,7 +850,16 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_nms_vote(
     float* __restrict__ boxes, float* __restrict__ scores, const float* __restrict__ variance,
     int var_stride, const float* __restrict__ iousT, int N, float iou_thr, float score_thr,
-    float* __restrict__ scratch) {
+    float* __restrict__ scratch, const int* __restrict__ counts) {
+  // blockIdx.x = frame; N = row pitch of every per-frame array; counts[frame] (<= N) live boxes when given
+  const int P = N;
+  {
+    const long long f = blockIdx.x;
+    boxes += f * P * 7; scores += f * P; iousT += f * P * P;
+    if (variance) variance += f * P * var_stride;
+    if (scratch) scratch += f * P * 8;
+    if (counts) N = min(P, counts[f]);
+  }
   constexpr int VOTE_WAVES = THREADS / 64;
   __shared__ float s_best[VOTE_WAVES], s_head[VOTE_WAVES];
   bool tail = false;
@@ -896,7 +927,7 @@ __global__ __launch_bounds__(THREADS) void k_nms_vote(
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int i = t + u * THREADS;
-      iouv[u] = undone[u] ? iousT[(long long)idx * N + i] : 0.f;        // == ious[i][idx]
+      iouv[u] = undone[u] ? iousT[(long long)idx * P + i] : 0.f;        // == ious[i][idx]
     }
     if (variance) {
       const float top_h = head;
@@ -996,7 +1027,7 @@ __global__ __launch_bounds__(THREADS) void k_nms_vote(
     }
   }
   if (variance) {                       // hand the independent rounds to k_nms_vote_tail
-    int* flags = (int*)(scratch + (long long)N * 7);
+    int* flags = (int*)(scratch + (long long)P * 7);
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int i = t + u * THREADS;
@@ -1016,8 +1047,14 @@ __global__ __launch_bounds__(THREADS) void k_nms_vote(
 __global__ __launch_bounds__(256) void k_nms_vote_tail(const float* __restrict__ boxes,
                                                        const float* __restrict__ variance, int var_stride,
                                                        const float* __restrict__ iousT, int N, float iou_thr,
-                                                       float* __restrict__ scratch) {
-  const int* flags = (const int*)(scratch + (long long)N * 7);
+                                                       float* __restrict__ scratch, const int* __restrict__ counts) {
+  const int P = N;
+  {
+    const long long f = blockIdx.y;
+    boxes += f * P * 7; iousT += f * P * P; variance += f * P * var_stride; scratch += f * P * 8;
+    if (counts) N = min(P, counts[f]);
+  }
+  const int* flags = (const int*)(scratch + (long long)P * 7);
   const int lane = threadIdx.x & 63;
   const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (j >= N || !flags[j]) return;
@@ -1030,7 +1067,7 @@ __global__ __launch_bounds__(256) void k_nms_vote_tail(const float* __restrict__
   for (int c = 0; c < 14; ++c) acc[c] = 0.f;
   for (int i = (j & ~63) + lane; i < N; i += 64) {
     if (i < j || !flags[i]) continue;
-    const float iou = iousT[(long long)j * N + i];
+    const float iou = iousT[(long long)j * P + i];
     if (!(iou > iou_thr)) continue;
     float bx[7];
 #pragma unroll
@@ -1061,33 +1098,147 @@ __global__ __launch_bounds__(256) void k_nms_vote_tail(const float* __restrict__
   }
 }
 
-__global__ void k_nms_vote_copy(float* __restrict__ boxes, const float* __restrict__ scratch, int N) {
-  const int* flags = (const int*)(scratch + (long long)N * 7);
+__global__ void k_nms_vote_copy(float* __restrict__ boxes, const float* __restrict__ scratch, int N,
+                                const int* __restrict__ counts) {
+  const int P = N;
+  boxes += (long long)blockIdx.y * P * 7; scratch += (long long)blockIdx.y * P * 8;
+  if (counts) N = min(P, counts[blockIdx.y]);
+  const int* flags = (const int*)(scratch + (long long)P * 7);
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < N * 7 && flags[e / 7]) boxes[e] = scratch[e];
+}
+
+extern "C" int glx_nms_vote_batch(float* boxes, float* scores, const float* variance, int var_stride,
+                                  const float* ious_t, int frames, int N, const int32_t* counts, float iou_thr,
+                                  float score_thr, float* scratch, void* stream) {
+  if (N == 0 || frames == 0) return GLX_OK;
+  GLX_REQUIRE(boxes && scores && ious_t, "glx_nms_vote: null pointer");
+  GLX_REQUIRE(N <= 4 * VOTE_THREADS, "glx_nms_vote: N=%d exceeds %d (NMS_PRE_MAXSIZE)", N,
+              4 * VOTE_THREADS);
+  GLX_REQUIRE(frames > 0 && frames <= 65535, "glx_nms_vote: %d frames", frames);
+  GLX_REQUIRE(!variance || var_stride >= 7, "glx_nms_vote: variance needs >= 7 columns");
+  GLX_REQUIRE(!variance || scratch, "glx_nms_vote: voting needs the N*8-float scratch buffer");
+  if (N <= 1024)
+    hipLaunchKernelGGL(k_nms_vote<256>, dim3(frames), dim3(256), 0, (hipStream_t)stream, boxes, scores, variance,
+                       var_stride, ious_t, N, iou_thr, score_thr, scratch, counts);
+  else
+    hipLaunchKernelGGL(k_nms_vote<VOTE_THREADS>, dim3(frames), dim3(VOTE_THREADS), 0, (hipStream_t)stream, boxes,
+                       scores, variance, var_stride, ious_t, N, iou_thr, score_thr, scratch, counts);
+  if (variance) {
+    hipLaunchKernelGGL(k_nms_vote_tail, dim3(glx_divup(N, 4), frames), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)boxes, variance, var_stride, ious_t, N, iou_thr, scratch, counts);
+    hipLaunchKernelGGL(k_nms_vote_copy, dim3(glx_divup(N * 7, 256), frames), dim3(256), 0, (hipStream_t)stream, boxes,
+                       (const float*)scratch, N, counts);
+  }
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
 }
 
 extern "C" int glx_nms_vote(float* boxes, float* scores, const float* variance, int var_stride,
                             const float* ious_t, int N, float iou_thr, float score_thr,
                             float* scratch, void* stream) {
-  if (N == 0) return GLX_OK;
-  GLX_REQUIRE(boxes && scores && ious_t, "glx_nms_vote: null pointer");
-  GLX_REQUIRE(N <= 4 * VOTE_THREADS, "glx_nms_vote: N=%d exceeds %d (NMS_PRE_MAXSIZE)", N,
-              4 * VOTE_THREADS);
-  GLX_REQUIRE(!variance || var_stride >= 7, "glx_nms_vote: variance needs >= 7 columns");
-  GLX_REQUIRE(!variance || scratch, "glx_nms_vote: voting needs the N*8-float scratch buffer");
-  if (N <= 1024)
-    hipLaunchKernelGGL(k_nms_vote<256>, dim3(1), dim3(256), 0, (hipStream_t)stream, boxes, scores, variance,
-                       var_stride, ious_t, N, iou_thr, score_thr, scratch);
-  else
-    hipLaunchKernelGGL(k_nms_vote<VOTE_THREADS>, dim3(1), dim3(VOTE_THREADS), 0, (hipStream_t)stream, boxes,
-                       scores, variance, var_stride, ious_t, N, iou_thr, score_thr, scratch);
-  if (variance) {
-    hipLaunchKernelGGL(k_nms_vote_tail, dim3(glx_divup(N, 4)), dim3(256), 0, (hipStream_t)stream, (const float*)boxes,
-                       variance, var_stride, ious_t, N, iou_thr, scratch);
-    hipLaunchKernelGGL(k_nms_vote_copy, dim3(glx_divup(N * 7, 256)), dim3(256), 0, (hipStream_t)stream, boxes,
-                       (const float*)scratch, N);
+  return glx_nms_vote_batch(boxes, scores, variance, var_stride, ious_t, 1, N, nullptr, iou_thr, score_thr, scratch,
+                            stream);
+}
+
+// ------------------------------------------------------------------ inference post-processing
+// The two ends of Detector3DTemplate.post_processing + class_agnostic_nms (pcdet/models/detectors/detector3d_template.py:
+// 179-317, pcdet/models/model_utils/model_nms_utils.py:6-62) around the top-k and the voting NMS, one launch each.
+
+// k_det_candidates: a thread per (frame, top-k slot).  order[f][j] = index of the j-th best score of the frame among
+// the boxes that passed SCORE_THRESH (slots >= counts[f] are padding): gathers the box with its heading wrapped to
+// [-pi, pi) (new_nms_gpu, iou3d_nms_utils.py:212-214: limit_period(offset 0.5, period 2 pi)) and exp(log-variance).
+__global__ void k_det_candidates(const float* __restrict__ box_preds, const float* __restrict__ std_preds, int ld_box,
+                                 int ld_std, const int64_t* __restrict__ order, const int* __restrict__ counts, int F,
+                                 int R, int K, float* __restrict__ cand, float* __restrict__ var) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F * K) return;
+  const int f = i / K, j = i - f * K;
+  const bool live = j < counts[f];
+  const long long src = (long long)f * R + (live ? order[i] : 0);
+  float* c = cand + (long long)i * 7;
+  for (int k = 0; k < 7; ++k) c[k] = live ? box_preds[src * ld_box + k] : 0.f;
+  if (live) {
+    const float period = (float)(3.14159265358979323846 * 2);
+    c[6] = c[6] - floorf(c[6] / period + 0.5f) * period;
   }
+  if (var) {
+    float* v = var + (long long)i * 7;
+    for (int k = 0; k < 7; ++k) v[k] = live ? expf(std_preds[src * ld_std + k]) : 1.f;
+  }
+}
+
+extern "C" int glx_det_candidates(const float* box_preds, const float* std_preds, int ld_box, int ld_std,
+                                  const int64_t* order, const int32_t* counts, int F, int R, int K, float* cand,
+                                  float* var, void* stream) {
+  if (F <= 0 || K <= 0) return GLX_OK;
+  GLX_REQUIRE(box_preds && order && counts && cand, "glx_det_candidates: null pointer");
+  GLX_REQUIRE(ld_box >= 7 && (!var || (std_preds && ld_std >= 7)), "glx_det_candidates: boxes / variances need >= 7 columns");
+  hipLaunchKernelGGL(k_det_candidates, dim3(glx_divup(F * K, 256)), dim3(256), 0, (hipStream_t)stream, box_preds,
+                     std_preds, ld_box, ld_std, order, counts, F, R, K, cand, var);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// k_det_gather: one block per frame.  Survivors of the voting NMS are the slots whose score is still > 0
+// (iou3d_nms_utils.py:219-220), in slot order = descending score; the first `P` of them (NMS_POST_MAXSIZE) whose ORIGINAL
+// score also exceeds post_thr (POST_SCORE_THRESH, detector3d_template.py:295-300; scores descend along the keep list, so
+// that mask is a prefix) are written with the voted box, the original score, the label of the source box and its index.
+__global__ __launch_bounds__(256) void k_det_gather(const float* __restrict__ new_scores, const float* __restrict__ top,
+                                                    const float* __restrict__ cand, const int64_t* __restrict__ order,
+                                                    const int64_t* __restrict__ labels, const int* __restrict__ counts,
+                                                    int R, int K, int P, float post_thr, int use_post,
+                                                    float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                    int64_t* __restrict__ out_labels, int64_t* __restrict__ out_index,
+                                                    int* __restrict__ out_num) {
+  __shared__ int s_wave[4];
+  __shared__ int s_base, s_cnt;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = min(K, counts[f]);
+  if (tid == 0) { s_base = 0; s_cnt = 0; }
+  for (int e = tid; e < P * 7; e += 256) out_boxes[(long long)f * P * 7 + e] = 0.f;
+  for (int e = tid; e < P; e += 256) {
+    out_scores[(long long)f * P + e] = 0.f;
+    out_labels[(long long)f * P + e] = 0;
+    out_index[(long long)f * P + e] = -1;
+  }
+  __syncthreads();
+  for (int j0 = 0; j0 < n; j0 += 256) {
+    const int j = j0 + tid;
+    const long long g = (long long)f * K + j;
+    const bool alive = j < n && new_scores[g] > 0.f;
+    const bool pass = alive && (!use_post || top[g] > post_thr);
+    const unsigned long long bal = __ballot(alive);
+    if (lane == 0) s_wave[wave] = __popcll(bal);
+    __syncthreads();
+    int before = s_base;
+    for (int w = 0; w < wave; ++w) before += s_wave[w];
+    const int slot = before + __popcll(bal & ((1ull << lane) - 1ull));
+    if (pass && slot < P) {
+      const long long o = (long long)f * P + slot;
+      for (int k = 0; k < 7; ++k) out_boxes[o * 7 + k] = cand[g * 7 + k];
+      out_scores[o] = top[g];
+      out_labels[o] = labels ? labels[(long long)f * R + order[g]] : 1;
+      out_index[o] = order[g];
+      atomicAdd(&s_cnt, 1);
+    }
+    __syncthreads();
+    if (tid == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+  }
+  if (tid == 0) out_num[f] = s_cnt;      // the written slots are the prefix [0, s_cnt): scores descend along the survivors
+}
+
+extern "C" int glx_det_gather(const float* new_scores, const float* top, const float* cand, const int64_t* order,
+                              const int64_t* labels, const int32_t* counts, int F, int R, int K, int P, float post_thr,
+                              int use_post, float* out_boxes, float* out_scores, int64_t* out_labels,
+                              int64_t* out_index, int32_t* out_num, void* stream) {
+  if (F <= 0) return GLX_OK;
+  GLX_REQUIRE(new_scores && top && cand && order && counts && out_boxes && out_scores && out_labels && out_index && out_num,
+              "glx_det_gather: null pointer");
+  GLX_REQUIRE(K > 0 && P > 0 && R > 0, "glx_det_gather: bad sizes");
+  hipLaunchKernelGGL(k_det_gather, dim3(F), dim3(256), 0, (hipStream_t)stream, new_scores, top, cand, order, labels, counts,
+                     R, K, P, post_thr, use_post, out_boxes, out_scores, out_labels, out_index, out_num);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

@@ -366,14 +366,14 @@ __global__ __launch_bounds__(256) void k_assign_labels(
     } else {
       const AlignedBev a = aligned_bev(an);
       bool forced = false;
-      int jf = -1;
       for (int j = 0; j < nv; ++j)
-        if (s_ok[j] && bev_iou(a, s_g[j]) == s_gm[j]) { forced = true; jf = j; }
+        if (s_ok[j] && bev_iou(a, s_g[j]) == s_gm[j]) forced = true;
       lab = (forced || best >= matched) ? cls : (best < unmatched ? 0 : -1);
-      // WeightedAxisAlignedTargetAssigner (weighted_axis_aligned_target_assigner.py:166-173): the label uncertainty an
-      // anchor carries is that of the ground truth that FORCED it (the last one in index order, as the indexed
-      // assignment on the host resolves duplicates), overwritten by the arg-max ground truth when over the threshold
-      if (unc_gt) unc_gt[(long long)b * N + i] = lab > 0 ? (best >= matched ? arg : jf) : -1;
+      // WeightedAxisAlignedTargetAssigner (weighted_axis_aligned_target_assigner.py:166-173): a positive anchor carries
+      // the label uncertainty of ITS arg-max ground truth in both branches -- gt_inds_force =
+      // anchor_to_gt_argmax[anchors_with_max_overlap] for the anchors a ground truth forced, anchor_to_gt_argmax[pos_inds]
+      // for those over the threshold -- i.e. of the box its regression targets are encoded from.
+      if (unc_gt) unc_gt[(long long)b * N + i] = lab > 0 ? arg : -1;
       if (lab > 0) {                                         // ResidualCoder.encode_torch(gt[arg], anchor)
         const float* g = gt + ((long long)b * M + arg) * gt_cols;
         const float dxa = fmaxf(an[3], 1e-5f), dya = fmaxf(an[4], 1e-5f), dza = fmaxf(an[5], 1e-5f);

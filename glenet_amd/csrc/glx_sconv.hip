@@ -1222,14 +1222,15 @@ extern "C" size_t glx_sconv_workspace_bytes(int K, int Cin, int Cout) {
   return glx_align(packed_bytes(K, Cin, Cout)) + 256;
 }
 
-// optional per-launch timing: the next sparse-conv launch on this host thread is bracketed by
-// these two HIP events (hipExtLaunchKernelGGL start/stop = exactly the kernel's execution).
+// optional per-launch timing (glx_sconv_opts.profile_start / profile_stop): the MFMA launch of the glx_sconv_forward_ex
+// call that is RUNNING on this host thread is bracketed by these two HIP events (hipExtLaunchKernelGGL start/stop =
+// exactly the kernel's execution).  Set on entry of that call and cleared on its exit (ProfScope): never carried from
+// one API call to another.
 static thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
-extern "C" int glx_profile_next_sconv(void* start_event, void* stop_event) {
-  g_prof_start = (hipEvent_t)start_event;
-  g_prof_stop = (hipEvent_t)stop_event;
-  return GLX_OK;
-}
+struct ProfScope {
+  ProfScope(void* a, void* b) { g_prof_start = (hipEvent_t)a; g_prof_stop = (hipEvent_t)b; }
+  ~ProfScope() { g_prof_start = g_prof_stop = nullptr; }
+};
 
 template <int CI, int CO>
 static int pack_weights(const float* W, int K, float* Wp, int view, hipStream_t st) {
@@ -1712,38 +1713,27 @@ extern "C" int glx_sconv_tile_map(const int32_t* nbr, const int32_t* tile_order,
   return GLX_OK;
 }
 
-// the map applies to the NEXT glx_sconv_forward call only (like glx_profile_next_sconv)
-static const int* g_next_tile_map = nullptr;
-extern "C" int glx_sconv_next_tile_map(const int32_t* tile_map) {
-  g_next_tile_map = tile_map;
-  return GLX_OK;
-}
-
-// BatchNorm statistics in the epilogue of the NEXT glx_sconv_forward call on this host thread (consumed by it):
-// state = glx_bn_state_bytes() zero-initialised device bytes shared by all calls of a stream; coef (2 * Cout):
-// scale | shift for glx_bn_apply_forward; save_mean / save_invstd (Cout) for the backward pass; running_* may be NULL.
-static thread_local BnState* g_next_bn_state = nullptr;
-static thread_local BnFinalize g_next_bn = {};
-extern "C" int glx_sconv_next_bn_stats(void* state, const float* gamma, const float* beta, float eps, float momentum,
-                                       float* coef, float* save_mean, float* save_invstd, float* running_mean,
-                                       float* running_var) {
-  GLX_REQUIRE(state && coef && save_mean && save_invstd, "glx_sconv_next_bn_stats: null pointer");
-  g_next_bn_state = (BnState*)state;
-  g_next_bn = BnFinalize{gamma, beta, eps, momentum, coef, save_mean, save_invstd, running_mean, running_var,
-                         nullptr, nullptr, nullptr};
-  return GLX_OK;
-}
-
-extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, const float* Wp,
-                                 const float* bias, const float* scale, const float* shift,
-                                 int relu, const int32_t* nbr, const int32_t* tile_order,
-                                 int N_out, int K, int Cin, int Cout, float* out,
-                                 const int32_t* n_out_live, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
-  const int* tile_map = g_next_tile_map;   // consumed by THIS call whatever happens below
-  g_next_tile_map = nullptr;
-  BnState* bn_state = g_next_bn_state;
-  g_next_bn_state = nullptr;
+// glx_sconv_forward_ex: the per-call options are ARGUMENTS (include/glenet_hip.h: glx_sconv_opts) -- the tile map of the
+// rule table, the training-mode BatchNorm whose statistics are taken in the epilogue (state = glx_bn_state_bytes()
+// zero-initialised device bytes shared by the calls of a stream; coef (2 * Cout): scale | shift for glx_bn_apply_forward;
+// save_mean / save_invstd (Cout) for the backward pass; running_* may be NULL), the profiling events.  Nothing is carried
+// from one call to the next and two host threads driving two streams cannot cross wires.
+extern "C" int glx_sconv_forward_ex(const float* in, int N_in, const float* W, const float* Wp,
+                                    const float* bias, const float* scale, const float* shift,
+                                    int relu, const int32_t* nbr, const int32_t* tile_order,
+                                    int N_out, int K, int Cin, int Cout, float* out,
+                                    const int32_t* n_out_live, void* workspace,
+                                    size_t workspace_bytes, const glx_sconv_opts* opts, void* stream) {
+  const int* tile_map = opts ? opts->tile_map : nullptr;
+  const glx_bn_stats* bnp = opts ? opts->bn : nullptr;
+  BnState* bn_state = bnp ? (BnState*)bnp->state : nullptr;
+  BnFinalize bn_fin = {};
+  if (bnp) {
+    GLX_REQUIRE(bnp->state && bnp->coef && bnp->save_mean && bnp->save_invstd, "glx_sconv_forward_ex: BatchNorm statistics: null pointer");
+    bn_fin = BnFinalize{bnp->gamma, bnp->beta, bnp->eps, bnp->momentum, bnp->coef, bnp->save_mean, bnp->save_invstd,
+                        bnp->running_mean, bnp->running_var, nullptr, nullptr, nullptr};
+  }
+  ProfScope prof(opts ? opts->profile_start : nullptr, opts ? opts->profile_stop : nullptr);
   GLX_REQUIRE(K > 0 && Cin > 0 && Cout > 0 && N_out >= 0, "glx_sconv_forward: bad sizes");
   GLX_REQUIRE(!bn_state || (N_out > 0 && mfma_supported(Cin, Cout, K) && !(Cin >= 128 && Cout >= 128)),
               "glx_sconv_forward: BatchNorm statistics in the epilogue need an MFMA tile kernel in one launch "
@@ -1751,7 +1741,7 @@ extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, cons
   if (N_out == 0) return GLX_OK;
   GLX_REQUIRE(in && (W || Wp) && nbr && out, "glx_sconv_forward: null pointer");
   SconvEpilogue ep{bias, scale, shift, relu, n_out_live, g_sconv_trace, g_sconv_xcd_group, 0, tile_map, bn_state,
-                   g_next_bn};
+                   bn_fin};
   if (!mfma_supported(Cin, Cout, K)) {
     GLX_REQUIRE(W, "glx_sconv_forward: raw weights required for channels (%d,%d)", Cin, Cout);
     long long total = (long long)N_out * Cout;
@@ -1775,6 +1765,16 @@ extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, cons
     return launch_mfma<decltype(ci)::value, decltype(co)::value>(in, Wp, ep, nbr, tile_order,
                                                                  N_out, K, out, st);
   });
+}
+
+extern "C" int glx_sconv_forward(const float* in, int N_in, const float* W, const float* Wp,
+                                 const float* bias, const float* scale, const float* shift,
+                                 int relu, const int32_t* nbr, const int32_t* tile_order,
+                                 int N_out, int K, int Cin, int Cout, float* out,
+                                 const int32_t* n_out_live, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  return glx_sconv_forward_ex(in, N_in, W, Wp, bias, scale, shift, relu, nbr, tile_order, N_out, K, Cin, Cout, out,
+                              n_out_live, workspace, workspace_bytes, nullptr, stream);
 }
 
 // ------------------------------------------------------------------ weight transpose

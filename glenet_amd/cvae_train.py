@@ -82,14 +82,15 @@ class CVAETrainStep:
         with torch.no_grad():
             for t, s in zip(state, snap):
                 t.copy_(s)
-        _lib.bump_weights_epoch()
+        self._written = list(self.model.parameters()) + list(self.model.buffers())
+        _lib.bump_weights_epoch(self._written)
         return self
 
     def step(self):
         if self.graph is None:
             return self.enqueue()
         self.graph.replay()
-        _lib.bump_weights_epoch()
+        _lib.bump_weights_epoch(self._written)       # parameters and running statistics of THIS model moved
         return self.loss
 
     @staticmethod

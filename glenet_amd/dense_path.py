@@ -511,7 +511,8 @@ class AnchorHead(nn.Module):
             w = torch.cat([c.weight for c in convs], dim=0)
             b = torch.cat([c.bias for c in convs], dim=0)
         else:                                   # inference: the concatenated filters are cached until the weights move
-            tag = (_lib.weights_epoch(),) + tuple(c.weight._version for c in convs) + tuple(c.bias._version for c in convs)
+            tag = ((_lib.weights_epoch(*[c.weight for c in convs], *[c.bias for c in convs]),)
+                   + tuple(c.weight._version for c in convs) + tuple(c.bias._version for c in convs))
             hit = self.__dict__.get("_glx_fused_heads")
             if hit is None or hit[0] != tag or hit[1].device != x.device:
                 w = torch.cat([c.weight.detach() for c in convs], dim=0)
@@ -690,7 +691,7 @@ class RoIFCStack(nn.Module):
                  if isinstance(seq[i], nn.Linear)]
         tensors = [t for lin, bn in pairs for t in (lin.weight, bn.weight, bn.bias, bn.running_mean,
                                                     bn.running_var)]
-        tag = tuple((t._version, t.data_ptr()) for t in tensors) + (_lib.weights_epoch(),)
+        tag = tuple((t._version, t.data_ptr()) for t in tensors) + (_lib.weights_epoch(*tensors),)
         cache = self.__dict__.get("_glx_folded")
         if cache is None or cache[0] != tag:
             with torch.no_grad():
@@ -821,7 +822,7 @@ class PointFeat(nn.Module):
                    for t in (m.weight, m.bias)] + [self.bn1.running_mean, self.bn1.running_var,
                                                    self.bn2.running_mean, self.bn2.running_var,
                                                    self.bn3.running_mean, self.bn3.running_var]
-        tag = tuple((t._version, t.data_ptr()) for t in tensors) + (_lib.weights_epoch(),)
+        tag = tuple((t._version, t.data_ptr()) for t in tensors) + (_lib.weights_epoch(*tensors),)
         cache = self.__dict__.get("_glx_packed")
         if cache is None or cache[0] != tag:
             with torch.no_grad():

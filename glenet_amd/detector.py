@@ -186,6 +186,75 @@ def refine_boxes(rois, box_preds):
     return boxes.view(B, R, -1)
 
 
+# GLENet_VR.yaml:168-181 (GLENet_S / GLENet_C use the same keys with their own values)
+POST_PROCESSING_CFG = dict(SCORE_THRESH=0.3, POST_SCORE_THRESH=0.81, NMS_THRESH=0.1, NMS_PRE_MAXSIZE=4096,
+                           NMS_POST_MAXSIZE=500)
+
+
+def post_processing(batch_cls_preds, batch_box_preds, batch_box_std_preds=None, roi_labels=None, cfg=None,
+                    normalized=False):
+    """Detector3DTemplate.post_processing with NMS_TYPE new_nms_gpu (pcdet/models/detectors/detector3d_template.py:179-317
+    -> model_nms_utils.class_agnostic_nms :6-62 -> iou3d_nms_utils.new_nms_gpu / nms_func :200-273) for the whole batch on
+    the device, shape-static, without a host loop or read-back: sigmoid + class max, SCORE_THRESH mask, top-k
+    (NMS_PRE_MAXSIZE), heading wrap, variance = exp(log-variance), the greedy variance-voting NMS (every frame its own
+    block), NMS_POST_MAXSIZE, POST_SCORE_THRESH.  The reference runs this per frame on the host in numpy.
+
+    batch_cls_preds (B,R,C) logits (or scores when `normalized`), batch_box_preds (B,R,7+), batch_box_std_preds (B,R,7)
+    log-variances or None (plain greedy NMS with the >= strictness of nms_func), roi_labels (B,R) 1-based or None
+    (-> class arg-max + 1).  Returns pred_boxes (B,P,7), pred_scores (B,P), pred_labels (B,P), pred_index (B,P) source
+    box (-1 = padding) and num (B,) int32 on the device, P = NMS_POST_MAXSIZE; rows past num[b] are zero.
+    Equal scores: lower index first (torch.topk leaves that order unspecified in the reference)."""
+    from . import _lib
+    cfg = dict(POST_PROCESSING_CFG, **(cfg or {}))
+    B, R, C = batch_cls_preds.shape
+    _lib.check_cuda(batch_cls_preds, batch_box_preds, batch_box_std_preds, roi_labels)
+    scores_all = batch_cls_preds.float() if normalized else torch.sigmoid(batch_cls_preds.float())
+    scores, arg = scores_all.max(dim=-1)                                         # (B, R)
+    labels = roi_labels.long().contiguous() if roi_labels is not None else (arg + 1).contiguous()
+    thr = cfg.get("SCORE_THRESH")
+    if thr is not None:
+        passed = scores >= thr
+        counts = passed.sum(dim=1, dtype=torch.int32)
+        masked = torch.where(passed, scores, scores.new_full((), -1.0))
+    else:
+        counts = torch.full((B,), R, dtype=torch.int32, device=scores.device)
+        masked = scores
+    K = min(int(cfg["NMS_PRE_MAXSIZE"]), R)
+    top, order = topk_desc(masked.contiguous(), K)
+    counts = counts.clamp(max=K).contiguous()
+    boxes = batch_box_preds.float().contiguous()
+    std = batch_box_std_preds.float().contiguous() if batch_box_std_preds is not None else None
+    dev = boxes.device
+    cand = torch.empty((B, K, 7), dtype=torch.float32, device=dev)
+    var = torch.empty((B, K, 7), dtype=torch.float32, device=dev) if std is not None else None
+    _lib.call("glx_det_candidates", boxes, std, boxes.shape[-1], std.shape[-1] if std is not None else 0,
+              order.contiguous(), counts, B, R, K, cand, var)
+    ious_t = torch.empty((B, K, K), dtype=torch.float32, device=dev)
+    _lib.call("glx_boxes_iou_bev_self_batch", cand, B, K, counts, 1, ious_t)
+    new_scores = top.clone()
+    scratch = torch.empty((B, K, 8), dtype=torch.float32, device=dev) if var is not None else None
+    _lib.call("glx_nms_vote_batch", cand, new_scores, var, 7, ious_t, B, K, counts, float(cfg["NMS_THRESH"]), 0.0, scratch)
+    P = int(cfg["NMS_POST_MAXSIZE"])
+    out_boxes = torch.empty((B, P, 7), dtype=torch.float32, device=dev)
+    out_scores = torch.empty((B, P), dtype=torch.float32, device=dev)
+    out_labels = torch.empty((B, P), dtype=torch.int64, device=dev)
+    out_index = torch.empty((B, P), dtype=torch.int64, device=dev)
+    num = torch.empty((B,), dtype=torch.int32, device=dev)
+    post = cfg.get("POST_SCORE_THRESH")
+    _lib.call("glx_det_gather", new_scores, top, cand, order, labels, counts, B, R, K, P,
+              float(post) if post is not None else 0.0, 1 if post is not None else 0, out_boxes, out_scores, out_labels,
+              out_index, num)
+    return dict(pred_boxes=out_boxes, pred_scores=out_scores, pred_labels=out_labels, pred_index=out_index, num=num)
+
+
+def pred_dicts(post):
+    """The reference's list of per-frame dicts (detector3d_template.py:311-316) from post_processing's static output:
+    ONE read-back of `num`, then slices."""
+    n = post["num"].tolist()
+    return [{"pred_boxes": post["pred_boxes"][b, :k], "pred_scores": post["pred_scores"][b, :k],
+             "pred_labels": post["pred_labels"][b, :k]} for b, k in enumerate(n)]
+
+
 class VoxelRCNNFlow(nn.Module):
     """GLENet-VR inference data flow on one batch of stacked device points."""
 

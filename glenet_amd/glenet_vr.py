@@ -93,9 +93,23 @@ class VoxelRCNNKLHead(rg.RoIGridPool):
         raw=True: (ori_cls, std_logit, rcnn_reg, rcnn_reg_std) -- the two logits of the rescaling, for the caller
         that fuses it with the classification loss (losses.cls_rescale_loss)."""
         x = pooled.reshape(pooled.shape[0], -1)
-        shared = self.shared_fc_layer(x)
-        ori_cls = self.cls_pred_layer(self.cls_fc_layers(shared))
-        reg_feat = self.reg_fc_layers(shared)
+        if x.is_cuda and not self.training and not torch.is_grad_enabled() and x.dtype == torch.float32 and self.USE_FOLDED:
+            # inference: eval-mode BatchNorm folded into each Linear and the 20736-wide first layer split along K
+            # (dense_path.RoIFCStack's folded path -- the towers carry the same attribute names)
+            shared_w, cls_w, reg_w = dp.RoIFCStack._folded(self)
+            h = x.contiguous()
+            for w, b in shared_w:
+                h = dp.RoIFCStack._affine_relu(h, w, b)
+            c = reg_feat = h
+            for w, b in cls_w:
+                c = dp.RoIFCStack._affine_relu(c, w, b)
+            for w, b in reg_w:
+                reg_feat = dp.RoIFCStack._affine_relu(reg_feat, w, b)
+            ori_cls = self.cls_pred_layer(c)
+        else:
+            shared = self.shared_fc_layer(x)
+            ori_cls = self.cls_pred_layer(self.cls_fc_layers(shared))
+            reg_feat = self.reg_fc_layers(shared)
         rcnn_reg = self.reg_pred_layer(reg_feat)
         rcnn_reg_std = self.reg_std_layer(reg_feat)
         s = dp.bn_relu(self.reg_std_bn, rcnn_reg_std.clone())
@@ -109,8 +123,13 @@ class VoxelRCNNKLHead(rg.RoIGridPool):
             rcnn_cls = losses.cls_rescale_torch(ori_cls, std_logit)                      # :73-75 ("ad hoc")
         return rcnn_cls, rcnn_reg, rcnn_reg_std
 
+    keep_pooled = False       # tests: leave the pooled features of the last forward in `last_pooled`
+    USE_FOLDED = True         # inference: BatchNorm folded into the FC towers
+
     def forward(self, rois, multi_scale_3d_features, multi_scale_3d_strides, batch_size, raw=False):
         pooled = super().forward(rois, multi_scale_3d_features, multi_scale_3d_strides, batch_size)
+        if self.keep_pooled:
+            self.last_pooled = pooled.detach()
         return self.heads(pooled, raw)
 
 
@@ -236,6 +255,7 @@ class GLENetVR(nn.Module):
         self.feature_map = (grid[0] // 8, grid[1] // 8)
         self._anchors = None
         self.fixed_draws = None      # tests: (key (B,R), pick (B,P)) uniform numbers for the RoI sampler
+        self.fixed_proposals = None  # tests: (rois (B,R,7), roi_scores (B,R), roi_labels (B,R)) in place of the own proposals
         self.last = None
         self.mark = None             # optional callable(stage_name), see StaticTrainPipeline.mark
         self.overlap_roi = False     # StaticTrainStep: RoI branch on its own stream, backward in stages (StagedLoss)
@@ -303,6 +323,9 @@ class GLENetVR(nn.Module):
             with torch.no_grad():
                 cls, boxes = det.predicted_boxes(bd["cls_preds"], bd["box_preds"], bd.get("dir_cls_preds"), anchors)
                 rois, roi_scores, roi_labels = det.proposal_layer(boxes, cls, *r["NMS_TRAIN"])
+                own_proposals = (rois, roi_scores, roi_labels)
+                if self.fixed_proposals is not None:     # what RoIHeadTemplate.proposal_layer does when `rois` is given
+                    rois, roi_scores, roi_labels = self.fixed_proposals                  # (roi_head_template.py:69-70)
                 if seed_rois_with_gt is not None:
                     has = gt_boxes[:, :, 7:8] > 0
                     ng = gt_boxes.shape[1]
@@ -357,7 +380,8 @@ class GLENetVR(nn.Module):
         # detached views for inspection / tests (a live autograd graph of an earlier step must not survive into
         # the next capture, see StaticTrainPipeline.enqueue)
         self.last = dict(rois=rois_s, rcnn_cls=rcnn_cls.detach(), rcnn_reg=rcnn_reg.detach(),
-                         rcnn_reg_std=rcnn_std.detach(), targets=td, proposals=rois, gt_of_rois_ct=gt_ct,
+                         rcnn_reg_std=rcnn_std.detach(), targets=td, proposals=rois, own_proposals=own_proposals,
+                         batch_cls_preds=cls, batch_box_preds=boxes, gt_of_rois_ct=gt_ct,
                          anchor_targets=tgt, cls_preds=bd["cls_preds"].detach(), box_preds=bd["box_preds"].detach(),
                          dir_cls_preds=bd["dir_cls_preds"].detach() if "dir_cls_preds" in bd else None)
         return loss, parts
@@ -368,21 +392,51 @@ class GLENetVR(nn.Module):
         bd = self.first_stage(bd)
         return self.second_stage_losses(bd, gt_boxes, gt_uncertaintys, seed_rois_with_gt)
 
+    @property
+    def map_to_bev(self):            # the name detector.StaticDetectorPipeline reads
+        return self.map_to_bev_module
+
     @torch.no_grad()
-    def forward(self, points, batch_idx, batch_size):
-        """Inference data flow up to the refined boxes (voxelrcnn_kl_label_iou_head.py:77-85)."""
-        bd = gb.voxelize_batch(points, batch_idx, batch_size, self.cfg, train=False)
-        bd = self.dense_head(self.backbone_2d(self.first_stage(bd)))
+    def second_stage(self, bd, batch_size, post_cfg=None, post=True):
+        """Everything of the inference pass behind the BEV map: BEV backbone + anchor head, proposals (NMS_TEST), RoI-grid
+        pooling, FC towers with the score rescaling, box refinement (voxelrcnn_kl_label_iou_head.py:38-85) and -- post --
+        Detector3DTemplate.post_processing on the device (det.post_processing).  Free of host synchronisation."""
+        mark = self.mark or (lambda name: None)
+        bd = self.dense_head(self.backbone_2d(bd))
+        mark("BEV backbone + anchor head")
         cls, boxes = det.predicted_boxes(bd["cls_preds"], bd["box_preds"], bd.get("dir_cls_preds"),
-                                         self.anchors(points.device))
+                                         self.anchors(bd["cls_preds"].device))
         rois, roi_scores, roi_labels = det.proposal_layer(boxes, cls, *self.roi_cfg["NMS_TEST"])
+        mark("decode + top-k + NMS")
         rcnn_cls, rcnn_reg, rcnn_std = self.roi_head(rois, bd["multi_scale_3d_features"],
                                                      bd["multi_scale_3d_strides"], batch_size)
+        mark("RoI-grid pooling + FC towers")
         bd.update(rois=rois, roi_scores=roi_scores, roi_labels=roi_labels,
                   batch_cls_preds=rcnn_cls.view(batch_size, -1, rcnn_cls.shape[-1]),
                   batch_box_preds=det.refine_boxes(rois, rcnn_reg),
                   batch_box_std_preds=rcnn_std.view(batch_size, -1, rcnn_std.shape[-1]),
-                  cls_preds_normalized=False)
+                  cls_preds_normalized=False, has_class_labels=True)
+        if post:
+            bd["post"] = det.post_processing(bd["batch_cls_preds"], bd["batch_box_preds"], bd["batch_box_std_preds"],
+                                             bd["roi_labels"], post_cfg)
+            mark("post-processing (variance-voting NMS)")
+        return bd
+
+    @torch.no_grad()
+    def forward(self, points, batch_idx, batch_size):
+        """Inference data flow up to the refined boxes (voxelrcnn_kl_label_iou_head.py:77-85)."""
+        bd = gb.voxelize_batch(points, batch_idx, batch_size, self.cfg, train=False)
+        return self.second_stage(self.first_stage(bd), batch_size, post=False)
+
+    @torch.no_grad()
+    def predict(self, points, batch_idx, batch_size, post_cfg=None):
+        """forward + Detector3DTemplate.post_processing (score threshold, top-k, variance-voting NMS with
+        variance = exp(batch_box_std_preds), post max size, POST_SCORE_THRESH) on the device:
+        bd["post"] = {pred_boxes (B,P,7), pred_scores, pred_labels, pred_index, num}; det.pred_dicts(bd["post"]) gives the
+        reference's list of per-frame dicts (one read-back)."""
+        bd = self.forward(points, batch_idx, batch_size)
+        bd["post"] = det.post_processing(bd["batch_cls_preds"], bd["batch_box_preds"], bd["batch_box_std_preds"],
+                                         bd["roi_labels"], post_cfg)
         return bd
 
 
@@ -440,8 +494,11 @@ class StaticTrainStep(gb.StaticTrainPipeline):
                          extra_modules=(model.backbone_2d, model.dense_head, model.roi_head))
         self.hc = model.map_to_bev_module
         self.split = False
-        model.overlap_roi = OVERLAP_ROI and torch.device(dev).type == "cuda"
-        model.backbone_3d.stage_cuts = model.overlap_roi and STAGE_CUTS
+        # the staged backward (RoI branch on its own stream, StagedLoss) is a property of THIS pipeline's launch
+        # sequence: the model's flags are set around enqueue() only, so the model's eager API (training_losses ->
+        # a tensor with .backward()) is what it was before a pipeline was built on it
+        self.overlap_roi = OVERLAP_ROI and torch.device(dev).type == "cuda"
+        self.stage_cuts = self.overlap_roi and STAGE_CUTS
 
     def _loss(self, bd):
         loss, self.parts = self.net.second_stage_losses(bd, self.gt_boxes, self.gt_unc, self.seed)
@@ -519,10 +576,14 @@ class StaticTrainStep(gb.StaticTrainPipeline):
 
     def enqueue(self):
         losses.UNIT_ROOT_GRAD = True      # the step's root scalar is the unweighted sum of the loss terms
+        net = self.net
+        was = (net.overlap_roi, net.backbone_3d.stage_cuts)
+        net.overlap_roi, net.backbone_3d.stage_cuts = self.overlap_roi, self.stage_cuts
         try:
             bd = super().enqueue()
         finally:
             losses.UNIT_ROOT_GRAD = False
+            net.overlap_roi, net.backbone_3d.stage_cuts = was
         if self.flat:
             self.step_optimizer.pack_grads()          # part of the forward + backward graph
         if not self.split:
@@ -566,7 +627,7 @@ class StaticTrainStep(gb.StaticTrainPipeline):
                     for t in self._training_state():      # optimizer state a torch optimizer created during warm-up
                         if id(t) not in known:
                             t.zero_()
-                gb._lib.bump_weights_epoch()
+                gb._lib.bump_weights_epoch(self._written_tensors())
         return self
 
     def _capture(self, warmup, split):
@@ -609,5 +670,5 @@ class StaticTrainStep(gb.StaticTrainPipeline):
             if self.exchange is not None:
                 self.exchange()
             self.update_graph.replay()
-            gb._lib.bump_weights_epoch()
+            gb._lib.bump_weights_epoch(self._written_tensors())
         return self.loss

@@ -119,7 +119,7 @@ class FlatAdamW:
                 buf.copy_(host)
             else:
                 dist.broadcast(buf, src)
-        _lib.bump_weights_epoch()
+        _lib.bump_weights_epoch(self.params)
 
     def step(self, packed=False):
         """clip + AdamW.  packed=True: flat_grad already holds this step's (exchanged) gradients."""
@@ -129,7 +129,7 @@ class FlatAdamW:
                   ctypes.c_int64(self.n), self.hyper, ctypes.c_float(self.beta2), ctypes.c_float(self.eps),
                   ctypes.c_float(self.weight_decay), ctypes.c_float(self.max_norm), ctypes.c_float(self.grad_scale),
                   self.step_count, self.grad_norm, self._ws, _lib.size_arg(self._ws.numel()))
-        _lib.bump_weights_epoch()          # parameters changed through raw pointers: version-keyed caches are stale
+        _lib.bump_weights_epoch(self.params)      # changed through raw pointers: version-keyed caches of THESE are stale
 
     def bump_versions(self):
         """Tell torch the parameters changed (eager loops that rely on version-keyed caches)."""

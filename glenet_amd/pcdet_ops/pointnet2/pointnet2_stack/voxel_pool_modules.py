@@ -89,7 +89,7 @@ class PosPool(torch.autograd.Function):
                   ctypes.c_float(bn.momentum if bn.momentum is not None else 0.1), ctypes.c_float(bn.eps),
                   1 if training else 0, pooled, arg, save, moments, ws, _lib.size_arg(ws.numel()))
         if training and rm is not None:
-            _lib.bump_weights_epoch()                     # running statistics updated through raw pointers
+            _lib.bump_weights_epoch((rm, rv))             # running statistics updated through raw pointers
         ctx.save_for_backward(feats, w, gamma, pooled, arg, idx, xyz, new_xyz, save, moments)
         ctx.training, ctx.wshape = training, w_pos.shape
         ctx.mark_non_differentiable(arg)
@@ -215,7 +215,7 @@ class NeighborVoxelSAModuleMSG(nn.Module):
         tensors += [t for m in mods if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d))
                     for t in (m.running_mean, m.running_var)]
         from .... import _lib
-        tag = tuple((t._version, t.data_ptr()) for t in tensors) + (_lib.weights_epoch(),)
+        tag = tuple((t._version, t.data_ptr()) for t in tensors) + (_lib.weights_epoch(*tensors),)
         cache = self.__dict__.get("_glx_folded")
         if cache is None or cache[0] != tag:
             with torch.no_grad():

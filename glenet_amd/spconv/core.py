@@ -20,6 +20,7 @@ whole frame runs without host synchronisation and can be captured in a HIP graph
 `check_static()` verifies afterwards that no capacity was exceeded.
 """
 import contextlib
+import ctypes
 import math
 import os
 from collections import OrderedDict
@@ -281,7 +282,7 @@ def check_static(indice_dict, index=None):
                                    % (key, n, rs.N_out))
 
 
-_profile_hook = None   # bench.py installs a callable(tag, K, cin, cout, n_out, rules), run before the launch
+_profile_hook = None   # bench.py installs a callable(tag, K, cin, cout, n_out, rules) -> (start, stop) HIP events or None
 
 
 # Weight images packed ahead for the current training step by prepack(): {(data_ptr, adjoint, flip): packed}; a
@@ -355,7 +356,7 @@ def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rule
     """out[j] = relu?((sum_k features[nbr[j,k]] @ weight_kio[k] + bias) * scale + shift).
     weight_kio may be None when `packed` and dims = (K, Cin, Cout) are given.
     bn: a training-mode BatchNorm1d that follows the conv -- its batch statistics are taken in the kernel's epilogue
-    (glx_sconv_next_bn_stats) and the call returns (out, coef, save_mean, save_invstd)."""
+    (glx_sconv_opts.bn) and the call returns (out, coef, save_mean, save_invstd)."""
     K, cin, cout = dims if dims is not None else weight_kio.shape
     out = torch.empty((n_out, cout), dtype=torch.float32, device=features.device)
     if n_out == 0:
@@ -364,25 +365,29 @@ def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rule
     if packed is None:
         packed = pack_weights(weight_kio)
     ws = workspace.get(256, features.device)
+    opts = None           # per-call options travel as an argument (glx_sconv_opts): tile map, BatchNorm statistics, events
     if _profile_hook is not None:
-        _profile_hook(tag, K, cin, cout, n_out, rules)
+        events = _profile_hook(tag, K, cin, cout, n_out, rules)       # (start, stop) HIP events or None
+        if events is not None:
+            opts = _lib.SconvOpts(None, None, events[0], events[1])
     if rules is not None and packed is not None and (rules.subm or rules._tile_maps) \
             and cin * cout >= TILE_MAP_MIN_WEIGHTS:
         tmap = rules.tile_map(nbr, tile_order, n_out, n_live)
         if tmap is not None:
-            call_nostream("glx_sconv_next_tile_map", tmap)
+            opts = opts or _lib.SconvOpts()
+            opts.tile_map = tmap.data_ptr()
     stats = None
     if bn is not None:
         stats = tuple(torch.empty(n, dtype=torch.float32, device=features.device) for n in (2 * cout, cout, cout))
-        rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-        call_nostream("glx_sconv_next_bn_stats", _bn_state(features.device), bn.weight, bn.bias, ctypes_float(bn.eps),
-                      ctypes_float(bn.momentum), stats[0], stats[1], stats[2], rm, rv)
-    call("glx_sconv_forward", features, features.shape[0], weight_kio, packed, bias, scale, shift,
+        st = _lib.bn_stats(_bn_state(features.device), bn, *stats)
+        opts = opts or _lib.SconvOpts()
+        opts.bn = ctypes.pointer(st)
+    call("glx_sconv_forward_ex", features, features.shape[0], weight_kio, packed, bias, scale, shift,
          1 if relu else 0, nbr, tile_order, n_out, K, cin, cout, out, n_live, ws,
-         size_arg(ws.numel()))
+         size_arg(ws.numel()), ctypes.byref(opts) if opts is not None else None)
     if bn is not None:
         if bn.track_running_stats:
-            _lib.bump_weights_epoch()          # running statistics moved behind torch's back
+            _lib.bump_weights_epoch((bn.running_mean, bn.running_var))     # moved behind torch's back
         return (out,) + stats
     return out
 
@@ -639,7 +644,7 @@ class SparseConvolution(SparseModule):
             # the backward packs the adjoint from the live ones.
             with torch.no_grad():
                 return pack_weights(w.detach().contiguous())
-        tag = (self.weight._version, self.weight.data_ptr(), self.weight.device, _lib.weights_epoch())
+        tag = (self.weight._version, self.weight.data_ptr(), self.weight.device, _lib.weights_epoch(self.weight))
         cache = self.__dict__.get("_packed_cache")
         if cache is None or cache[0] != tag:
             with torch.no_grad():
@@ -726,7 +731,8 @@ def _bn_affine(bn):
     """Eval-mode BatchNorm1d as y = x * scale + shift (cached until its tensors change)."""
     tag = (bn.weight._version if bn.weight is not None else -1,
            bn.bias._version if bn.bias is not None else -1,
-           bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr(), _lib.weights_epoch())
+           bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr(),
+           _lib.weights_epoch(bn.weight, bn.bias, bn.running_mean, bn.running_var))
     cache = bn.__dict__.get("_glx_affine")
     if cache is None or cache[0] != tag:
         with torch.no_grad():
@@ -773,7 +779,7 @@ class FusedBNReLU(Function):
              1 if relu else 0, running_mean, running_var, y, mean, invstd, count, ws, size_arg(ws.numel()),
              _bn_state(x.device), 0)
         if running_mean is not None:
-            _lib.bump_weights_epoch()                                 # running statistics moved behind torch's back
+            _lib.bump_weights_epoch((running_mean, running_var))      # running statistics moved behind torch's back
         ctx.save_for_backward(x, weight, bias, mean, invstd)          # not y: backward re-derives the ReLU mask from x
         ctx.relu, ctx.count = relu, count
         return y
@@ -853,7 +859,7 @@ class FusedBNReLUCat(Function):
                  1 if relu else 0, rm, rv, out[:, col:], mean, invstd, None, ws, size_arg(ws.numel()),
                  _bn_state(x.device), total)
             if rm is not None:
-                _lib.bump_weights_epoch()
+                _lib.bump_weights_epoch((rm, rv))
             saved += [x, w, b, mean, invstd]
             col += C
         ctx.save_for_backward(*saved)

@@ -43,6 +43,47 @@ const char* glx_last_error(void);
 /* Library ABI version (bumped on any signature change). */
 int glx_abi_version(void);
 
+/* ---- per-call options: explicit ARGUMENTS of the *_ex entry points (NULL = none).  There is no "applies to the next
+ * call" state anywhere in this ABI: two host threads driving two streams share nothing. ----
+ *
+ * glx_bn_stats: a TRAINING-mode BatchNorm behind a convolution (spconv_backbone.py:21-25: conv -> BatchNorm1d -> ReLU;
+ * base_bev_backbone.py:37-49: Conv2d -> BatchNorm2d -> ReLU).  The per-channel statistics of the convolution's output are
+ * taken in its epilogue (one launch) and finalized by the last block: coef (2 * Cout floats) = scale | shift for
+ * glx_bn_apply_forward, save_mean / save_invstd (Cout) for glx_bn_relu_backward, running statistics updated with
+ * nn.BatchNorm's semantics (NULL: not tracked).  state: glx_bn_state_bytes() device bytes, zero-filled once, shared by
+ * the calls of ONE stream.
+ * glx_epilogue: an inference epilogue y = relu?(acc * scale[c] + shift[c]) (scale = shift = NULL: none) -- an eval-mode
+ * BatchNorm (+ ReLU) folded behind the convolution -- and, for the deconv / strided entry points, the placement of the
+ * result: `ldc` floats between output pixels, from channel `coff` of a pixel on (ldc = 0: dense). */
+typedef struct glx_bn_stats {
+  void* state;
+  const float* gamma;
+  const float* beta;
+  float eps, momentum;
+  float* coef;
+  float* save_mean;
+  float* save_invstd;
+  float* running_mean;
+  float* running_var;
+} glx_bn_stats;
+typedef struct glx_epilogue {
+  const float* scale;
+  const float* shift;
+  int relu, ldc, coff;
+} glx_epilogue;
+/* tile_map: glx_sconv_tile_map of the rule table (NULL = built-in map); profile_start / profile_stop: two HIP events
+ * that bracket the MFMA launch of the call (hipExtLaunchKernelGGL: kernel-only duration for bench.py's roofline). */
+typedef struct glx_sconv_opts {
+  const int32_t* tile_map;
+  const glx_bn_stats* bn;
+  void* profile_start;
+  void* profile_stop;
+} glx_sconv_opts;
+typedef struct glx_conv_opts {
+  const glx_bn_stats* bn;
+  const glx_epilogue* epilogue;
+} glx_conv_opts;
+
 /* HIP events for kernel-only timing (bench.py); glx_event_elapsed_ms blocks until `stop`. */
 int glx_event_create(void** event);
 int glx_event_destroy(void* event);
@@ -124,15 +165,12 @@ size_t glx_sconv_packed_bytes(int K, int Cin, int Cout);
 /* Work-balanced block -> tile map of a rule table for the 64-row tile kernels: tile_map
  * (int32[ceil(N_out/64)]) is a permutation of the tiles such that the blocks the hardware places on
  * one CU (b, b+256, b+512 ...) carry similar numbers of 16-pair MFMA chunks.  Results do not depend
- * on it (tiles are independent).  glx_sconv_next_tile_map(map) applies a map to the next
- * glx_sconv_forward call only (NULL = built-in map; process-global like glx_profile_next_sconv: the
- * caller issues the two calls back to back from one thread).  Built once per rule table, shared by
- * the convs of an indice_key. */
+ * on it (tiles are independent).  Handed to a convolution as glx_sconv_opts.tile_map.  Built once per rule table,
+ * shared by the convs of an indice_key. */
 size_t glx_sconv_tile_map_workspace_bytes(int N_out);
 int glx_sconv_tile_map(const int32_t* nbr, const int32_t* tile_order, int N_out, int K,
                        const int32_t* n_out_live, int32_t* tile_map, void* workspace,
                        size_t workspace_bytes, void* stream);
-int glx_sconv_next_tile_map(const int32_t* tile_map);
 /* Re-order W (K,Cin,Cout) into Wp (glx_sconv_packed_bytes); do it once per weight update. */
 int glx_sconv_pack_weights(const float* W, int K, int Cin, int Cout, float* Wp, void* stream);
 /* Same for the ADJOINT conv, straight from the forward weights: (Cin, Cout) are the dimensions of
@@ -156,18 +194,13 @@ int glx_sconv_forward(const float* in, int N_in, const float* W, const float* Wp
                       const int32_t* nbr, const int32_t* tile_order, int N_out, int K, int Cin,
                       int Cout, float* out, const int32_t* n_out_live, void* workspace,
                       size_t workspace_bytes, void* stream);
-/* Bracket the NEXT glx_sconv_forward MFMA launch of this host thread with two HIP events
- * (hipExtLaunchKernelGGL start/stop): kernel-only duration for bench.py's roofline. */
-int glx_profile_next_sconv(void* start_event, void* stop_event);
-/* Training-mode BatchNorm behind a sparse conv (spconv_backbone.py:21-25: SubMConv3d / SparseConv3d -> BatchNorm1d ->
- * ReLU): the per-channel statistics of the conv's output are taken in the epilogue of the NEXT glx_sconv_forward call
- * of this host thread (MFMA tile kernels, one launch) and finalized by the last block -- coef (2 * Cout floats) =
- * scale | shift for glx_bn_apply_forward, save_mean / save_invstd (Cout) for glx_bn_relu_backward, running statistics
- * updated with nn.BatchNorm1d's semantics (NULL: not tracked).  state: glx_bn_state_bytes() device bytes, zero-filled
- * once, shared by the calls of a stream. */
-int glx_sconv_next_bn_stats(void* state, const float* gamma, const float* beta, float eps, float momentum,
-                            float* coef, float* save_mean, float* save_invstd, float* running_mean,
-                            float* running_var);
+/* The same with per-call options (tile map of the rule table, training-mode BatchNorm statistics in the epilogue -- MFMA
+ * tile kernels, one launch --, profiling events): see glx_sconv_opts above. */
+int glx_sconv_forward_ex(const float* in, int N_in, const float* W, const float* Wp,
+                         const float* bias, const float* scale, const float* shift, int relu,
+                         const int32_t* nbr, const int32_t* tile_order, int N_out, int K, int Cin,
+                         int Cout, float* out, const int32_t* n_out_live, void* workspace,
+                         size_t workspace_bytes, const glx_sconv_opts* opts, void* stream);
 /* Reference-quality scalar kernel (any channel count); used for tiny Cin and as a
  * device-side cross-check of the MFMA kernel. */
 int glx_sconv_forward_generic(const float* in, int N_in, const float* W, const float* bias,
@@ -315,6 +348,33 @@ int glx_nms_batch(const float* boxes_sorted, int frames, int N, float thresh, in
 int glx_nms_vote(float* boxes, float* scores, const float* variance, int var_stride,
                  const float* ious_t, int N, float iou_thr, float score_thr, float* scratch,
                  void* stream);
+/* `frames` independent lists in one launch sequence (the per-frame loop of Detector3DTemplate.post_processing,
+ * pcdet/models/detectors/detector3d_template.py:196-309): boxes (frames,N,7), scores (frames,N), variance
+ * (frames,N,var_stride), ious_t (frames,N,N), scratch (frames,N*8); counts (frames) int32 DEVICE or NULL = live boxes
+ * per frame (<= N, the rest of a frame's rows is padding and is neither read nor written). */
+int glx_nms_vote_batch(float* boxes, float* scores, const float* variance, int var_stride,
+                       const float* ious_t, int frames, int N, const int32_t* counts, float iou_thr,
+                       float score_thr, float* scratch, void* stream);
+/* boxes (frames,N,7) -> out (frames,N,N) BEV IoU of every frame's boxes with themselves; transposed != 0:
+ * out[f][j][i] = IoU(box i, box j) (the layout glx_nms_vote reads), else out[f][i][j]; counts as above.
+ * Replaces: boxes_bev_iou_cpu(boxes, boxes) of nms_func (iou3d_nms_utils.py:235) per frame. */
+int glx_boxes_iou_bev_self_batch(const float* boxes, int frames, int N, const int32_t* counts, int transposed,
+                                 float* out, void* stream);
+/* Inference post-processing around the top-k and the voting NMS (detector3d_template.py:179-317,
+ * model_nms_utils.py:6-62).  glx_det_candidates: order (F,K) int64 = top-k indices into a frame's R boxes, counts (F)
+ * = boxes that passed SCORE_THRESH; writes cand (F,K,7) with the heading wrapped to [-pi,pi) (iou3d_nms_utils.py:
+ * 212-214) and var (F,K,7) = exp(std_preds) (model_nms_utils.py:18; var/std_preds may be NULL), padding slots zero / one.
+ * glx_det_gather: new_scores (F,K) after glx_nms_vote_batch, top (F,K) the scores before it, cand the voted boxes;
+ * survivors (new score > 0) in slot order, first P, original score > post_thr when use_post -> out_boxes (F,P,7),
+ * out_scores (F,P), out_labels (F,P) = labels[f][source] (labels (F,R) int64 or NULL -> 1), out_index (F,P) source box
+ * or -1, out_num (F) int32. */
+int glx_det_candidates(const float* box_preds, const float* std_preds, int ld_box, int ld_std,
+                       const int64_t* order, const int32_t* counts, int F, int R, int K, float* cand,
+                       float* var, void* stream);
+int glx_det_gather(const float* new_scores, const float* top, const float* cand, const int64_t* order,
+                   const int64_t* labels, const int32_t* counts, int F, int R, int K, int P, float post_thr,
+                   int use_post, float* out_boxes, float* out_scores, int64_t* out_labels,
+                   int64_t* out_index, int32_t* out_num, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Point / box operators.
@@ -558,7 +618,7 @@ int glx_bn_relu_train_forward(const float* x, int N, int C, const float* gamma, 
                               const int32_t* n_live, void* workspace, size_t workspace_bytes,
                               void* state, int y_stride, void* stream);
 /* The transform of glx_bn_relu_train_forward alone, for statistics taken in a sparse conv's epilogue
- * (glx_sconv_next_bn_stats): y = relu?(x * coef[c] + coef[C + c]) on the live rows, zeros on the rows past them. */
+ * (glx_sconv_opts.bn): y = relu?(x * coef[c] + coef[C + c]) on the live rows, zeros on the rows past them. */
 int glx_bn_apply_forward(const float* x, const float* coef, int relu, int N, int C, const int32_t* n_live,
                          float* y, int y_stride, void* stream);
 /* dx (N,C), dgamma (C), dbeta (C) from dy and the forward's x, mean, invstd.  The ReLU mask: from the forward's
@@ -821,15 +881,11 @@ int glx_conv3x3_pack_multi(int n, const float* const* W, const long long* stride
                            const int32_t* Cout, void* const* fwd, void* const* bwd, void* stream);
 int glx_conv3x3_forward(const float* x, int B, int H, int W, int Cin, const void* packed, int Cout, float* y,
                         void* stream);
-/* Training-mode BatchNorm2d behind the convolution (base_bev_backbone.py:37-49: Conv2d -> BatchNorm2d -> ReLU): the
- * per-channel statistics of y are taken in the epilogue of the NEXT glx_conv3x3_forward call of this host thread and
- * finalized by its last block; arguments and semantics as glx_sconv_next_bn_stats (coef feeds glx_bn_apply_forward). */
-int glx_conv3x3_next_bn_stats(void* state, const float* gamma, const float* beta, float eps, float momentum,
-                              float* coef, float* save_mean, float* save_invstd, float* running_mean,
-                              float* running_var);
-/* Inference: y = relu?(conv * scale[c] + shift[c]) in the epilogue of the NEXT glx_conv3x3_forward call of this host
- * thread -- the eval-mode BatchNorm2d (+ ReLU) behind the convolution folded into it (scale, shift: Cout device floats). */
-int glx_conv3x3_next_epilogue(const float* scale, const float* shift, int relu);
+/* With per-call options (glx_conv_opts): opts->bn = the training-mode BatchNorm2d behind the convolution
+ * (base_bev_backbone.py:37-49), statistics of y in the epilogue; opts->epilogue = the eval-mode BatchNorm2d (+ ReLU) folded
+ * into it, y = relu?(conv * scale[c] + shift[c]) (ldc / coff must be 0 here).  At most one of the two. */
+int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int Cin, const void* packed, int Cout, float* y,
+                           const glx_conv_opts* opts, void* stream);
 /* The weight gradient of the same convolution: dW (Cout, Cin, 3, 3), written through ELEMENT strides (s_co, s_ci,
  * s_kh, s_kw) (torch keeps the BEV filters in channels-last memory), = sum over pixels of gy (B, H, W, Cout) times
  * the shifted x (B, H, W, Cin); same split-bf16 arithmetic.  Two launches (block partial sums into the workspace,
@@ -856,11 +912,14 @@ int glx_deconv_input_grad(const float* gy, int B, int H, int W, int Cin, const v
  * Bit-reproducible (the vendor's forward kernel for this layer sums split-K slices with atomics). */
 int glx_conv3x3s2_forward(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, float* y,
                           void* stream);
-/* Inference: epilogue and placement of the NEXT glx_deconv_forward / glx_conv3x3s2_forward call of this host thread:
- * y = relu?(acc * scale[c] + shift[c]) (scale = shift = NULL: none), written with `ldc` floats between output pixels from
- * channel `coff` of a pixel on (ldc = 0: dense) -- a deblock's map straight into its slice of the concatenated map
- * (base_bev_backbone.py:100-104: torch.cat(ups, dim=1) on channels-last memory costs no copy). */
-int glx_pconv_next_epilogue(const float* scale, const float* shift, int relu, int ldc, int coff);
+/* Inference: the two calls above with an epilogue and a placement (glx_epilogue): y = relu?(acc * scale[c] + shift[c])
+ * (scale = shift = NULL: none), written with `ldc` floats between output pixels from channel `coff` of a pixel on
+ * (ldc = 0: dense) -- a deblock's map straight into its slice of the concatenated map (base_bev_backbone.py:100-104:
+ * torch.cat(ups, dim=1) on channels-last memory costs no copy). */
+int glx_deconv_forward_ex(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, int u, float* y,
+                          const glx_epilogue* epilogue, void* stream);
+int glx_conv3x3s2_forward_ex(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, float* y,
+                             const glx_epilogue* epilogue, void* stream);
 size_t glx_deconv_wgrad_workspace_bytes(int Cin, int Cout, int u);
 int glx_deconv_wgrad(const float* x, const float* gy, int B, int H, int W, int Cin, int Cout, int u, float* dW,
                      long long s_ci, long long s_co, long long s_kh, long long s_kw, void* workspace,

@@ -329,6 +329,35 @@ def new_nms_gpu(boxes, scores, iou_threshold, score_threshold=0, variance=None):
     return keep, new_boxes
 
 
+def post_processing(cls_preds, box_preds, box_std_preds=None, labels=None, score_thresh=0.3, post_score_thresh=0.81,
+                    nms_thresh=0.1, nms_pre_maxsize=4096, nms_post_maxsize=500, normalized=False):
+    """ONE frame of Detector3DTemplate.post_processing with NMS_TYPE new_nms_gpu (pcdet/models/detectors/
+    detector3d_template.py:196-316) -> model_nms_utils.class_agnostic_nms (:6-62) -> new_nms_gpu above, restated in numpy:
+    cls_preds (R,C) logits, box_preds (R,7), box_std_preds (R,7) log-variances or None, labels (R,) 1-based or None.
+    Returns (boxes (n,7), scores (n,), labels (n,), source index (n,)).  torch.topk's order among equal scores is
+    unspecified in the reference; here lower index first (stable)."""
+    cls = np.asarray(cls_preds, np.float32)
+    if not normalized:                                                         # :213-214 torch.sigmoid in float32
+        cls = (np.float32(1) / (np.float32(1) + np.exp(-cls, dtype=np.float32))).astype(np.float32)
+    scores, arg = cls.max(1), cls.argmax(1)                                    # :258
+    lab = np.asarray(labels) if labels is not None else arg + 1                # :259-263
+    box = np.asarray(box_preds, np.float32)
+    mask = scores >= np.float32(score_thresh) if score_thresh is not None else np.ones(len(scores), bool)   # nms_utils :12-15
+    s, bx = scores[mask], box[mask]
+    var = np.exp(np.asarray(box_std_preds, np.float32))[mask] if box_std_preds is not None else None        # :18-21
+    if len(s) == 0:
+        return np.zeros((0, 7), np.float32), s, lab[:0], np.zeros(0, np.int64)
+    order = np.argsort(-s, kind="stable")[:min(nms_pre_maxsize, len(s))]      # :26 topk
+    keep, new_boxes = new_nms_gpu(bx[order, :7], s[order], nms_thresh, 0, var[order] if var is not None else None)
+    keep = keep[:nms_post_maxsize]                                             # :45-46
+    sel = np.nonzero(mask)[0][order[keep]]                                     # :58-60
+    out_boxes, out_scores, out_labels = new_boxes[keep], scores[sel], lab[sel]
+    if post_score_thresh is not None:                                          # detector3d_template.py:295-300
+        m = out_scores > np.float32(post_score_thresh)
+        out_boxes, out_scores, out_labels, sel = out_boxes[m], out_scores[m], out_labels[m], sel[m]
+    return out_boxes, out_scores, out_labels, sel
+
+
 # ---- iou3d (older) library, [x1,y1,x2,y2,ry] boxes
 def iou3d_boxes_overlap_bev(a, b):
     a, b = _f32(a), _f32(b)

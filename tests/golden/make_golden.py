@@ -35,6 +35,7 @@ committed, this script is committed, nothing of the reference is copied.
                      and which placeholders stand in for uninstalled / CUDA-only imports.
 """
 import importlib
+import json
 import os
 import sys
 import types
@@ -917,12 +918,331 @@ def make_roi_targets_ref():
     np.savez_compressed(os.path.join(HERE, "roi_targets_ref.npz"), **out)
 
 
+
+REFSTEP_RANGE = [0.0, -8.0, -3.0, 17.6, 8.0, 1.0]
+
+
+def _refstep_frame(seed, num_points, num_boxes):
+    """A reduced-range LiDAR-shaped frame: beams over the ground plane and `num_boxes` cars whose headings are within a
+    few degrees of an anchor rotation and whose centres sit at the anchors' height, so that an untrained first stage
+    (proposals = anchors + small residuals) still produces foreground RoIs.  The beams' elevations space the ground rings
+    evenly (0.25 m) and the azimuth covers the whole reduced range, so that no RoI of the range is far from every point:
+    RoIs whose 216 grid points are ALL empty leave the RoI head with one and the same score -- ties between different,
+    overlapping boxes, whose order torch.topk leaves unspecified."""
+    rng = np.random.default_rng(seed)
+    elev = -np.arctan(1.73 / np.linspace(1.0, 25.0, 96))
+    az = np.deg2rad(np.arange(-100.0, 100.0, 0.5))
+    el = np.repeat(elev[:, None], len(az), 1)
+    azj = az[None, :] + np.deg2rad(rng.uniform(-0.04, 0.04, el.shape))
+    d = np.stack([np.cos(el) * np.cos(azj), np.cos(el) * np.sin(azj), np.sin(el)], -1).reshape(-1, 3)
+    boxes = synth.make_boxes(rng, num_boxes, (4, 15), (-6, 6), -1.73)
+    boxes[:, 6] = rng.choice([0.0, np.pi / 2], num_boxes) + rng.normal(0, 0.04, num_boxes)
+    boxes[:, 3:6] = np.array([3.9, 1.6, 1.56]) * rng.uniform(0.96, 1.04, (num_boxes, 3))
+    boxes[:, 2] = -1.0 + rng.normal(0, 0.03, num_boxes)
+    with np.errstate(divide="ignore"):
+        tg = np.where(d[:, 2] < 0, -1.73 / d[:, 2], np.inf)
+    # ground AND car hits of every ray (no shadows behind the cars: they would be regions without any point, see above)
+    tb = synth._ray_box_hits(d, boxes)
+    d2 = np.concatenate([d[np.isfinite(tg) & (tg < 40)], d[np.isfinite(tb)]])
+    t = np.concatenate([tg[np.isfinite(tg) & (tg < 40)], tb[np.isfinite(tb)]])
+    pts = d2 * (t + rng.normal(0, 0.02, len(t)))[:, None]
+    r = REFSTEP_RANGE
+    ins = ((pts[:, 0] >= r[0]) & (pts[:, 0] < r[3]) & (pts[:, 1] >= r[1]) & (pts[:, 1] < r[4]) & (pts[:, 2] >= r[2])
+           & (pts[:, 2] < r[5]))
+    pts = pts[ins]
+    pts = pts[rng.permutation(len(pts))[:num_points]]
+    return np.concatenate([pts, rng.uniform(0, 1, (len(pts), 1))], 1).astype(np.float32), boxes.astype(np.float32)
+
+
+class _Tied(Exception):
+    pass
+
+
+def make_ref_step(frame_seed=40):
+    """ref_step.npz: ONE training step (forward, get_training_loss, backward) and ONE inference pass (forward,
+    post_processing) of the reference's OWN GLENet-VR network -- `build_network` on tools/cfgs/kitti_models/GLENet_VR.yaml,
+    classes VoxelRCNN, MeanVFE, VoxelBackBone8x, HeightCompression, BaseBEVBackbone, AnchorHeadSingle (+
+    AxisAlignedTargetAssigner, ResidualCoder, its losses), VoxelRCNNKLLabelIoUHead (+ proposal_layer /
+    class_agnostic_nms, ProposalTargetLayer, roi_grid_pool, NeighborVoxelSAModuleMSG / VoxelQueryAndGrouping, the KL /
+    corner losses) and Detector3DTemplate.post_processing (new_nms_gpu: variance voting), all imported UNMODIFIED from
+    /root/reference -- executed on CPU in this container on two synthetic frames, with every stage of `batch_dict`
+    stored.  tests/test_reference_step_gpu.py runs glenet_amd.glenet_vr.GLENetVR on the same input and parameters.
+    Run in its own process: `python tests/golden/make_golden.py refstep`.
+
+    What stands in for what cannot exist here, disclosed in full:
+      * the compiled modules (spconv, the six pcdet.ops extensions) -> oracle/refshim.py: CPU modules with the same
+        signatures whose arithmetic is the ORACLE's (oracle/glenet_oracle.c: rule tables, sparse convolution forward /
+        backward, rotated IoU, NMS sweep, voxel query, grouping).  So this fixture pins the reference's Python --
+        module composition, grid-point order, coordinate floor-divisions, the [0,3,2,1] reorder, top-k / padding,
+        target sampling, canonical transformation, loss formulas, score rescaling, variance voting -- on top of the
+        operator semantics the per-operator tests pin; it cannot pin spconv's own arithmetic (source absent).
+      * uninstalled third-party imports -> empty placeholders (tools/ref_dropin_check.py: SharedArray, numba, skimage,
+        easydict restated); `.cuda()` / torch.cuda.{Int,Float}Tensor -> host twins (oracle.refshim.cpu_placeholders).
+      * configuration VALUES changed: POINT_CLOUD_RANGE -> [0,-8,-3,17.6,8,1] (grid 352 x 320 x 40, BEV map 44 x 40) so
+        that the step runs in seconds on CPU.  Everything else is GLENet_VR.yaml.
+      * parameters: tests/golden/refstep_params.py (seeded numpy; digest stored) instead of the constructors' draws.
+      * exactly equal float32 scores (about every second frame has a pair among its 3520 anchors) are left by
+        torch.topk / sort in an unspecified order: the frames are the first seed pair whose tied anchors cannot suppress
+        one another (so the kept SET does not depend on that order; the tests compare runs of equal score as sets) and whose
+        100 final RoI scores per frame are distinct.
+      * random draws inside the step: every ProposalTargetLayer.subsample_rois call is logged (overlaps in, sampled
+        indices out) and
+        the three nn.Dropout modules of the RoI towers multiply by stored Bernoulli(0.7) masks / 0.7
+        (what torch's dropout computes) -- the test replays both."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, HERE)
+    import ref_dropin_check as rdc
+    import refstep_params as rp
+    from oracle import refshim
+    placeholders = rdc.prepare_imports(install=refshim.install)
+
+    def edit(cfg):
+        cfg.DATA_CONFIG.POINT_CLOUD_RANGE = list(REFSTEP_RANGE)
+    cfg, ds, net = rdc.build_reference_network("cfgs/kitti_models/GLENet_VR.yaml", 4, edit)
+    assert [type(m).__name__ for m in net.module_list] == ["MeanVFE", "VoxelBackBone8x", "HeightCompression",
+                                                           "BaseBEVBackbone", "AnchorHeadSingle", "VoxelRCNNKLLabelIoUHead"]
+    spec = [(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in net.state_dict().items()]
+    params = rp.make_params(spec)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    out = {"seed": np.int64(rp.SEED), "point_cloud_range": np.array(REFSTEP_RANGE, np.float32),
+           "param_names": np.array([s[0] for s in spec]), "param_shapes": np.array([json.dumps(list(s[1])) for s in spec]),
+           "param_dtypes": np.array([s[2] for s in spec]),
+           "param_digest": np.array([rp.digest(params)[s[0]] for s in spec], np.float64),
+           "placeholders": np.array(placeholders)}
+
+    # ---- input: two frames, voxelized by the oracle's hard voxelizer (the data processor's contract)
+    B, G = 2, 8
+    vsize = [0.05, 0.05, 0.1]
+    pts_all, bidx, vox, coords, nums = [], [], [], [], []
+    gt = np.zeros((B, G, 8), np.float32)
+    unc = np.zeros((B, G, 7), np.float32)
+    urng = np.random.default_rng(9)
+    for b, (npts, nbox) in enumerate(((4500, 6), (3500, 5))):
+        p, bx = _refstep_frame(frame_seed + b, npts, nbox)
+        v, c, n = oracle.voxelize_hard(p, vsize, REFSTEP_RANGE, 5, 16000)
+        pts_all.append(p)
+        bidx.append(np.full(len(p), b, np.int32))
+        vox.append(v)
+        nums.append(n)
+        coords.append(np.concatenate([np.full((len(c), 1), b, np.int32), c], 1))
+        gt[b, :nbox, :7], gt[b, :nbox, 7] = bx, 1
+        unc[b, :nbox] = urng.uniform(0.01, 0.2, (nbox, 7))
+    out.update(points=np.concatenate(pts_all), batch_idx=np.concatenate(bidx), voxels=np.concatenate(vox),
+               voxel_num_points=np.concatenate(nums), voxel_coords=np.concatenate(coords), gt_boxes=gt, gt_uncertaintys=unc)
+
+    def batch():
+        # load_data_to_gpu (pcdet/models/__init__.py:22-34): every array becomes float32
+        return dict(batch_size=B, voxels=torch.from_numpy(out["voxels"]).float(),
+                    voxel_num_points=torch.from_numpy(out["voxel_num_points"]).float(),
+                    voxel_coords=torch.from_numpy(out["voxel_coords"]).float(), gt_boxes=torch.from_numpy(gt.copy()),
+                    gt_uncertaintys=torch.from_numpy(unc.copy()))
+
+    def f32(t):
+        return t.detach().numpy().astype(np.float32).copy()
+
+    # cheap pre-check of the seed pair: the first stage alone, in both modes.  Two of a frame's 3520 float32 anchor scores
+    # collide in about every second frame and torch.topk / sort leave equal scores in an unspecified order -- harmless as
+    # long as the tied boxes cannot suppress one another (BEV IoU below the NMS threshold: the kept SET does not depend on
+    # their order; the tests compare runs of equal score as sets) and no tie straddles the top-k cut.  Anything else: next seed.
+    for mode, (pre, _, thr) in ((True, (9000, 512, 0.8)), (False, (2048, 100, 0.7))):
+        net.train(mode)
+        bd = batch()
+        with refshim.cpu_placeholders(), torch.no_grad():
+            for m in net.module_list[:5]:
+                bd = m(bd)
+        sc = torch.sigmoid(bd["batch_cls_preds"][..., 0]).numpy()
+        bx = bd["batch_box_preds"].numpy()
+        for b in range(B):
+            u, cnt = np.unique(sc[b], return_counts=True)
+            srt = np.sort(sc[b])[::-1]
+            if pre < len(srt) and srt[pre - 1] == srt[pre]:
+                raise _Tied("%s frame %d: a tie straddles the top-%d cut" % ("train" if mode else "eval", b, pre))
+            for v in u[cnt > 1]:
+                grp = np.ascontiguousarray(bx[b][sc[b] == v])
+                iou = oracle.boxes_iou_bev(grp, grp)
+                np.fill_diagonal(iou, 0)
+                if iou.max() > thr - 0.1:
+                    raise _Tied("%s frame %d: tied anchors overlap by %.3f" % ("train" if mode else "eval", b, iou.max()))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+
+    def store_sparse(tag, pre, st, step):
+        out["%s_%s_indices" % (tag, pre)] = st.indices.numpy().astype(np.int16)
+        feats = f32(st.features)
+        out["%s_%s_rows" % (tag, pre)] = rp.sample_rows(feats, step)
+        out["%s_%s_colsum" % (tag, pre)] = feats.astype(np.float64).sum(0)
+        out["%s_%s_step" % (tag, pre)] = np.int64(step)
+
+    def store_map(tag, name, t):
+        a = f32(t)                                                   # (B, C, H, W)
+        out["%s_%s_chansum" % (tag, name)] = a.astype(np.float64).sum((2, 3))
+        out["%s_%s_sample" % (tag, name)] = a[:, ::8, ::3, ::3].copy()
+
+    roi = net.roi_head
+    # ---- the random draws of the step, logged / pinned
+    sub_log = []
+    inner = roi.proposal_target_layer.subsample_rois
+
+    def logged(max_overlaps):
+        s = inner(max_overlaps=max_overlaps)
+        sub_log.append((max_overlaps.numpy().copy(), s.numpy().copy()))
+        return s
+    roi.proposal_target_layer.subsample_rois = logged
+    drops = [(n, m) for n, m in roi.named_modules() if isinstance(m, torch.nn.Dropout)]
+    assert [n for n, _ in drops] == ["shared_fc_layer.3", "cls_fc_layers.3", "reg_fc_layers.3"]
+    mgen = torch.Generator().manual_seed(11)
+    masks = {}
+
+    def pinned(name, m):
+        def fwd(x):
+            if not m.training:
+                return x
+            if name not in masks:
+                masks[name] = torch.rand(x.shape, generator=mgen) < (1.0 - m.p)
+            return x * (masks[name].float() / (1.0 - m.p))
+        return fwd
+    for n, m in drops:
+        m.forward = pinned(n, m)
+    # what proposal_layer hands to the sampler, and what roi_grid_pool returns
+    seen = {}
+    ptl_fwd = roi.proposal_target_layer.forward
+
+    def ptl_logged(batch_dict):
+        seen["rois"], seen["roi_scores"], seen["roi_labels"] = (f32(batch_dict["rois"]), f32(batch_dict["roi_scores"]),
+                                                                batch_dict["roi_labels"].numpy().copy())
+        return ptl_fwd(batch_dict)
+    roi.proposal_target_layer.forward = ptl_logged
+    pool_fwd = roi.roi_grid_pool
+
+    def pool_logged(batch_dict):
+        seen["pooled"] = pool_fwd(batch_dict)
+        return seen["pooled"]
+    roi.roi_grid_pool = pool_logged
+
+    def common_stages(tag, bd):
+        out[tag + "_voxel_features"] = f32(bd["voxel_features"])
+        for k, st in bd["multi_scale_3d_features"].items():
+            store_sparse(tag, k, st, 8)
+        store_sparse(tag, "encoded", bd["encoded_spconv_tensor"], 4)
+        store_map(tag, "spatial_features", bd["spatial_features"])
+        store_map(tag, "spatial_features_2d", bd["spatial_features_2d"])
+        out[tag + "_pooled_rows"] = rp.sample_rows(f32(seen["pooled"]), 32)
+        out[tag + "_pooled_roisum"] = f32(seen["pooled"]).astype(np.float64).sum((1, 2))
+        out[tag + "_pooled_chansum"] = f32(seen["pooled"]).astype(np.float64).sum((0, 1))
+
+    # ------------------------------------------------------------------ training step
+    net.train()
+    np.random.seed(3)
+    torch.manual_seed(3)
+    bd = batch()
+    with refshim.cpu_placeholders():
+        ret, tb, _ = net(bd)
+        ret["loss"].backward()
+    common_stages("train", bd)
+    dh = net.dense_head.forward_ret_dict
+    for k in ("cls_preds", "box_preds", "dir_cls_preds", "box_cls_labels", "box_reg_targets", "reg_weights"):
+        out["train_" + k] = dh[k].detach().numpy().copy()
+    out["train_batch_cls_preds"], out["train_batch_box_preds"] = f32(bd["batch_cls_preds"]), f32(bd["batch_box_preds"])
+    for k in ("rois", "roi_scores", "roi_labels"):
+        out["train_proposal_" + k] = seen[k]
+    fr = roi.forward_ret_dict
+    for k in ("rois", "gt_of_rois", "gt_of_rois_src", "gt_iou_of_rois", "roi_scores", "roi_labels", "reg_valid_mask",
+              "rcnn_cls_labels", "gt_uncertaintys_of_rois", "rcnn_cls", "rcnn_reg", "rcnn_reg_std"):
+        out["train_" + k] = fr[k].detach().numpy().copy()
+    out["train_max_overlaps"] = np.stack([l[0] for l in sub_log])
+    out["train_sampled"] = np.stack([l[1] for l in sub_log])
+    for n, _ in drops:
+        out["train_dropout_" + n.replace(".", "_")] = np.packbits(masks[n].numpy())
+    out["train_loss"] = np.float64(ret["loss"].item())
+    out["train_tb_keys"] = np.array(sorted(tb))
+    out["train_tb_vals"] = np.array([tb[k] for k in sorted(tb)], np.float64)
+    grads = {k: p.grad for k, p in net.named_parameters()}
+    assert all(g is not None for g in grads.values())
+    out["train_grad_names"] = np.array(list(grads))
+    out["train_grad_digest"] = np.array([(float(g.double().sum()), float((g.double() ** 2).sum())) for g in grads.values()])
+    out["train_grad_samples"] = np.stack([np.pad(rp.grad_sample(g.numpy()), (0, 256 - len(rp.grad_sample(g.numpy()))))
+                                          for g in grads.values()]).astype(np.float32)
+    sd = net.state_dict()
+    out["train_bn_after"] = np.concatenate([sd[k].numpy().reshape(-1) for k in sd
+                                            if k.endswith("running_mean") or k.endswith("running_var")]).astype(np.float32)
+    fgn = int((fr["reg_valid_mask"] > 0).sum())
+    print("train: loss %.6f" % ret["loss"].item(), {k: round(v, 5) for k, v in tb.items()})
+    print("train: proposals kept per frame", [(int((seen["rois"][b].any(1)).sum())) for b in range(B)], "fg RoIs", fgn,
+          "max_overlaps fg/hard/easy", [(int((m >= 0.55).sum()), int(((m < 0.55) & (m >= 0.1)).sum()), int((m < 0.1).sum()))
+                                        for m in out["train_max_overlaps"]])
+    # ------------------------------------------------------------------ inference pass
+    # Parameters as loaded; the BatchNorm running statistics are CALIBRATED first -- one training-mode forward with
+    # momentum 1 (running = batch statistics), stored in the fixture -- as they are in any network that is evaluated:
+    # with arbitrary running statistics every RoI leaves the towers with nearly the same activations and the final scores
+    # sit in a band of 0.1, on one side of both score thresholds.
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    net.zero_grad()
+    bns = [m for m in net.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    saved = [m.momentum for m in bns]
+    for m in bns:
+        m.momentum = 1.0
+    net.train()
+    with refshim.cpu_placeholders(), torch.no_grad():
+        net(batch())
+    for m, mom in zip(bns, saved):
+        m.momentum = mom
+    sd = net.state_dict()
+    bn_keys = [k for k in sd if k.endswith("running_mean") or k.endswith("running_var")]
+    out["eval_bn_keys"] = np.array(bn_keys)
+    out["eval_bn_buffers"] = np.concatenate([sd[k].numpy().reshape(-1) for k in bn_keys]).astype(np.float32)
+    net.eval()
+    bd = batch()
+    rpn = {}
+    hook = net.dense_head.register_forward_hook(lambda m, i, o: rpn.update(cls=f32(o["batch_cls_preds"]),
+                                                                        box=f32(o["batch_box_preds"])))
+    with refshim.cpu_placeholders(), torch.no_grad():
+        pred_dicts, recall = net(bd)
+    hook.remove()
+    out["eval_rpn_batch_cls_preds"], out["eval_rpn_batch_box_preds"] = rpn["cls"], rpn["box"]
+    common_stages("eval", bd)
+    for k in ("cls_preds", "box_preds", "dir_cls_preds"):
+        out["eval_" + k] = net.dense_head.forward_ret_dict[k].detach().numpy().copy()
+    for k in ("rois", "roi_scores", "roi_labels", "batch_cls_preds", "batch_box_preds", "batch_box_std_preds"):
+        out["eval_" + k] = bd[k].detach().numpy().copy()
+    for b, pdict in enumerate(pred_dicts):
+        out["eval_pred_boxes_%d" % b] = np.asarray(pdict["pred_boxes"], np.float32).reshape(-1, 7)
+        out["eval_pred_scores_%d" % b] = pdict["pred_scores"].numpy().astype(np.float32)
+        out["eval_pred_labels_%d" % b] = pdict["pred_labels"].numpy().astype(np.int64)
+    out["eval_recall_keys"] = np.array(sorted(recall))
+    out["eval_recall_vals"] = np.array([recall[k] for k in sorted(recall)], np.float64)
+    sc = torch.sigmoid(torch.from_numpy(out["eval_batch_cls_preds"][..., 0])).numpy()
+    for b in range(B):
+        # the refined scores of a frame: distinct, except for rows that are identical altogether (the zero RoIs that pad
+        # a frame with fewer than NMS_POST_MAXSIZE proposals all come out of the head with one score and one box)
+        rows = np.concatenate([sc[b][:, None], out["eval_batch_box_preds"][b], out["eval_batch_box_std_preds"][b]], 1)
+        if len(np.unique(sc[b])) != len(np.unique(rows, axis=0)) and os.environ.get("REFSTEP_DEBUG"):
+            u, cnt = np.unique(sc[b], return_counts=True)
+            for v in u[cnt > 1][:4]:
+                m = sc[b] == v
+                print("tie", v, np.nonzero(m)[0], out["eval_batch_cls_preds"][b][m, 0], out["eval_rois"][b][m][:, :3],
+                      out["eval_batch_box_std_preds"][b][m][:, :2])
+        if len(np.unique(sc[b])) != len(np.unique(rows, axis=0)):
+            raise _Tied("eval frame %d: tied RoI-head scores" % b)
+    print("eval: RoIs per frame", [(int(out["eval_rois"][b].any(1).sum())) for b in range(B)], "final score quantiles",
+          np.quantile(sc, [0, 0.25, 0.5, 0.75, 1]).round(3), ">=0.3:", int((sc >= 0.3).sum()), ">0.81:", int((sc > 0.81).sum()),
+          "predictions", [len(p["pred_scores"]) for p in pred_dicts], "recall", dict(recall))
+    np.savez_compressed(os.path.join(HERE, "ref_step.npz"), **out)
+    print("ref_step.npz %.2f MB, %d arrays" % (os.path.getsize(os.path.join(HERE, "ref_step.npz")) / 1e6, len(out)))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:] or ["iou3d", "nms", "dense", "glue", "kl", "assign", "roitgt", "nmspred"]
     if "nmspred" in only:
         make_nms_predicate_ref()
     if "klhead" in sys.argv[1:]:             # own process as well
         make_kl_label_head_ref()
+    if "refstep" in sys.argv[1:]:            # own process only: installs the oracle-backed stand-ins, imports all of pcdet
+        for fs in range(40, 400, 10):          # first pair of frames without exact score ties (see the docstring)
+            try:
+                make_ref_step(fs)
+                break
+            except _Tied as e:
+                print("frame seed", fs, "->", e)
+        sys.exit(0)
     if "cvaetrain" in sys.argv[1:]:          # own process only: it installs the drop-in and imports all of pcdet
         make_cvae_train_ref()
     if "roitgt" in only:

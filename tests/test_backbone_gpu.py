@@ -622,11 +622,21 @@ def test_eval_after_fused_training_steps_sees_the_new_weights(dev):
     pipe.calibrate(pts, bidx)
     pipe.load(pts, bidx)
     pipe.capture()
-    e0 = _lib.weights_epoch()
+    e0, g0 = _lib.weights_epoch(*model.parameters()), _lib.weights_epoch()
+    # an unrelated model that never trains: its inference graph must NOT record itself again (the epoch is
+    # scoped to the tensors that were written, not process-global)
+    other = gb.VoxelBackBone8x(4, grid).to(dev).eval()
+    opipe = gb.StaticFramePipeline(other, K, 2, pts.shape[0], 4)
+    opipe.calibrate(pts, bidx)
+    opipe.load(pts, bidx)
+    opipe.capture()
+    other_graph, other_tag = opipe.graph, opipe._weights_tag()
     for _ in range(3):
         pipe.replay()
     torch.cuda.synchronize()
-    assert _lib.weights_epoch() >= e0 + 3
+    assert _lib.weights_epoch(*model.parameters()) >= e0 + 3 and _lib.weights_epoch() == g0
+    opipe.replay()
+    assert opipe.graph is other_graph and opipe._weights_tag() == other_tag
     # ---- eval again: same module object, same tensors, versions of the PARAMETERS untouched by the replays
     y1 = evaluate(model)
     fresh = gb.VoxelBackBone8x(4, grid).to(dev)
@@ -636,4 +646,4 @@ def test_eval_after_fused_training_steps_sees_the_new_weights(dev):
     assert float((y1 - y0).abs().max()) > 1e-3
     assert torch.equal(ipipe.replay()["spatial_features"], y_ref)     # the inference graph recorded itself again
     assert [p._version for p in model.parameters()] == versions[:len(list(model.parameters()))]
-    _drop_graphs(pipe, ipipe)
+    _drop_graphs(pipe, ipipe, opipe)

@@ -1,0 +1,296 @@
+"""glenet_amd.glenet_vr.GLENetVR on the device against ONE training step and ONE inference pass of the reference's OWN
+GLENet-VR classes (tests/golden/ref_step.npz, written by tests/golden/make_golden.py refstep: VoxelRCNN.forward /
+get_training_loss / backward and forward / post_processing, executed on CPU over the oracle-backed stand-ins of
+oracle/refshim.py).  Same points, same parameters (regenerated from the stored seed, digest checked), the reference's
+random draws replayed (RoI sampler, dropout masks).  Stage by stage:
+
+  bit-exact   voxel coordinates / point lists, sparse index sets of every level, anchor labels, proposals (top-k order,
+              NMS keep lists, padding) and detections given the reference's head outputs, sampled RoIs and targets
+  <= 1e-4     (of the tensor's scale) every float stage: sparse features, BEV maps, head maps, pooled features, RoI outputs
+  <= 2e-4     every loss term;   <= 1e-3 of scale: parameter gradients;   BatchNorm running statistics 1e-4
+
+Discrete decisions that depend on floats computed by different arithmetic (CPU MKL / oracle vs the device kernels) are
+tested with the reference's floats handed in, so that a 1e-7 difference cannot flip an order; the free-running flow is
+compared beside it with the flips counted."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import roi_targets as ort
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import refstep_params as rp  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(HERE, "golden", "ref_step.npz"))
+B = 2
+LEVELS = ("x_conv1", "x_conv2", "x_conv3", "x_conv4")
+
+
+def T(key, dev):
+    return torch.from_numpy(np.ascontiguousarray(G[key])).to(dev)
+
+
+def close(got, want, tol=1e-4, what=""):
+    """max |got - want| <= tol * max |want| (+ a float32 floor)."""
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = float(np.abs(want).max()) + 1e-12
+    err = float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max())
+    assert err <= tol * scale + 1e-7, "%s: max error %.3e vs scale %.3e (tol %.1e)" % (what, err, scale, tol)
+
+
+@pytest.fixture(scope="module")
+def net(dev):
+    from glenet_amd import glenet_vr as gvr, synth
+    cfg = dict(synth.KITTI, point_cloud_range=[float(v) for v in G["point_cloud_range"]])
+    torch.manual_seed(0)
+    model = gvr.GLENetVR(cfg).to(dev)
+    spec = list(zip(G["param_names"].tolist(), [json.loads(s) for s in G["param_shapes"]], G["param_dtypes"].tolist()))
+    sd = model.state_dict()
+    # the reference network's state dict, key for key and shape for shape
+    assert list(sd.keys()) == [s[0] for s in spec]
+    assert [list(v.shape) for v in sd.values()] == [list(s[1]) for s in spec]
+    params = rp.make_params(spec, int(G["seed"]))
+    d = rp.digest(params)
+    np.testing.assert_allclose(np.array([d[s[0]] for s in spec]), G["param_digest"], rtol=1e-12)
+    state = {k: torch.from_numpy(v) for k, v in params.items()}
+    model.load_state_dict(state)
+    model.roi_head.keep_pooled = True
+    return model, cfg, state
+
+
+def _points(dev):
+    return T("points", dev), T("batch_idx", dev)
+
+
+def _check_sparse(tag, name, st, tol=1e-4):
+    idx = st.indices.cpu().numpy()
+    want_idx = G["%s_%s_indices" % (tag, name)].astype(np.int32)
+    assert np.array_equal(idx, want_idx), "%s %s: sparse index set / row order" % (tag, name)
+    f = st.features.detach().cpu().numpy()
+    step = int(G["%s_%s_step" % (tag, name)])
+    scale = float(np.abs(G["%s_%s_rows" % (tag, name)]).max())
+    assert float(np.abs(f[::step] - G["%s_%s_rows" % (tag, name)]).max()) <= tol * scale, (tag, name)
+    cs = G["%s_%s_colsum" % (tag, name)]
+    assert float(np.abs(f.astype(np.float64).sum(0) - cs).max()) <= tol * (float(np.abs(f).astype(np.float64).sum(0).max()) + 1e-9)
+
+
+def _check_map(tag, name, t, tol=1e-4):
+    a = t.detach().float().cpu().numpy()
+    want = G["%s_%s_sample" % (tag, name)]
+    close(a[:, ::8, ::3, ::3], want, tol, "%s %s" % (tag, name))
+    cs = G["%s_%s_chansum" % (tag, name)]
+    assert float(np.abs(a.astype(np.float64).sum((2, 3)) - cs).max()) <= tol * float(np.abs(a).astype(np.float64).sum((2, 3)).max())
+
+
+def _first_stage(model, cfg, dev, train):
+    """voxelize -> MeanVFE -> sparse backbone -> (deferred) BEV map, with the stage checks both passes share."""
+    from glenet_amd import backbone as gb
+    tag = "train" if train else "eval"
+    pts, bidx = _points(dev)
+    bd = gb.voxelize_batch(pts, bidx, B, cfg, train=train)
+    n = G["voxel_coords"].shape[0]
+    assert bd["voxel_coords"].shape[0] == n
+    assert np.array_equal(bd["voxel_coords"].cpu().numpy(), G["voxel_coords"])                  # bit-exact
+    assert np.array_equal(bd["voxels"].cpu().numpy(), G["voxels"])
+    assert np.array_equal(bd["voxel_num_points"].cpu().numpy(), G["voxel_num_points"])
+    bd = model.first_stage(bd)
+    assert np.array_equal(bd["voxel_features"].cpu().numpy(), G[tag + "_voxel_features"])       # MeanVFE: exact
+    for k in LEVELS:
+        _check_sparse(tag, k, bd["multi_scale_3d_features"][k])
+    enc = bd["encoded_spconv_tensor"]
+    _check_sparse(tag, "encoded", enc)
+    dense = enc.dense()                                                                         # height_compression.py:21-23
+    _check_map(tag, "spatial_features", dense.view(dense.shape[0], -1, dense.shape[3], dense.shape[4]))
+    return bd
+
+
+def _pin_dropout(model, dev):
+    """The three nn.Dropout modules of the RoI towers multiply by the masks the reference's run drew."""
+    for name, m in model.roi_head.named_modules():
+        if isinstance(m, torch.nn.Dropout):
+            key = "train_dropout_" + name.replace(".", "_")
+            bits = np.unpackbits(G[key])[:256 * 256].reshape(256, 256).astype(np.float32)
+            mask = torch.from_numpy(bits).to(dev) / (1.0 - m.p)
+            m.forward = (lambda mask, m: lambda x: x * mask if m.training else x)(mask, m)
+
+
+def test_training_step_equals_the_references_own_classes(dev, net):
+    from glenet_amd import detector as det, glenet_vr as gvr
+    model, cfg, state = net
+    model.load_state_dict(state)
+    model.train()
+    model.zero_grad(set_to_none=True)
+    _pin_dropout(model, dev)
+    bd = _first_stage(model, cfg, dev, train=True)
+    gt, unc = T("gt_boxes", dev), T("gt_uncertaintys", dev)
+    # the reference's random draws, replayed through the sampler's uniform-number interface
+    kp = [ort.uniforms_for(G["train_max_overlaps"][b], G["train_sampled"][b], gvr.ROI_HEAD_CFG["TARGET"]) for b in range(B)]
+    model.fixed_draws = (torch.from_numpy(np.stack([k for k, _ in kp])).to(dev),
+                         torch.from_numpy(np.stack([p for _, p in kp])).to(dev))
+    model.fixed_proposals = (T("train_proposal_rois", dev), T("train_proposal_roi_scores", dev),
+                             T("train_proposal_roi_labels", dev))
+    try:
+        loss, parts = model.second_stage_losses(bd, gt, unc)
+    finally:
+        model.fixed_draws = model.fixed_proposals = None
+    last = model.last
+    # ---- dense head (base_bev_backbone.py:81-112, anchor_head_single.py:41-58)
+    _check_map("train", "spatial_features_2d", bd["spatial_features_2d"])
+    for k in ("cls_preds", "box_preds", "dir_cls_preds"):
+        close(last[k], G["train_" + k], 1e-4, k)
+    close(last["batch_box_preds"], G["train_batch_box_preds"], 1e-4, "decoded first-stage boxes")
+    # ---- anchor targets (axis_aligned_target_assigner.py): labels exact
+    at = last["anchor_targets"]
+    assert np.array_equal(at["box_cls_labels"].cpu().numpy(), G["train_box_cls_labels"])
+    close(at["box_reg_targets"], G["train_box_reg_targets"], 1e-5, "box_reg_targets")
+    assert int((G["train_box_cls_labels"] > 0).sum()) > 10
+    # ---- the free-running proposals: same set up to the few flips a 1e-7 score / box difference allows
+    own = last["own_proposals"][0].cpu().numpy()
+    same = float(np.mean([np.array_equal(own[b, j], G["train_proposal_rois"][b, j]) or
+                          np.abs(own[b, j] - G["train_proposal_rois"][b, j]).max() < 1e-4
+                          for b in range(B) for j in range(own.shape[1])]))
+    assert same > 0.9, "only %.3f of the free-running proposals sit where the reference's do" % same
+    # ---- RoI targets with the replayed draws (proposal_target_layer.py:13-123, roi_head_template.py:130-159): exact gathers
+    td = last["targets"]
+    assert np.array_equal(td["rois"].cpu().numpy(), G["train_rois"])
+    assert np.array_equal(td["roi_labels"].cpu().numpy(), G["train_roi_labels"])
+    assert np.array_equal(td["gt_of_rois"].cpu().numpy(), G["train_gt_of_rois_src"])
+    assert np.array_equal(td["reg_valid_mask"].cpu().numpy(), G["train_reg_valid_mask"])
+    assert np.array_equal(td["gt_uncertaintys_of_rois"].cpu().numpy(), G["train_gt_uncertaintys_of_rois"])
+    np.testing.assert_allclose(td["gt_iou_of_rois"].cpu().numpy(), G["train_gt_iou_of_rois"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(td["rcnn_cls_labels"].cpu().numpy(), G["train_rcnn_cls_labels"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(last["gt_of_rois_ct"].cpu().numpy()[..., :7], G["train_gt_of_rois"][..., :7], rtol=1e-5, atol=2e-5)
+    # ---- RoI-grid pooling (voxelrcnn_head.py:106-191, voxel_pool_modules.py:70-130) and the FC towers
+    pooled = model.roi_head.last_pooled.reshape(B * 128, 216, -1).cpu().numpy()
+    scale = float(np.abs(G["train_pooled_rows"]).max())
+    assert float(np.abs(pooled[::32] - G["train_pooled_rows"]).max()) <= 1e-4 * scale
+    np.testing.assert_allclose(pooled.astype(np.float64).sum((1, 2)), G["train_pooled_roisum"], rtol=2e-4,
+                               atol=1e-4 * float(np.abs(G["train_pooled_roisum"]).max()))
+    close(last["rcnn_reg"], G["train_rcnn_reg"], 2e-4, "rcnn_reg")
+    close(last["rcnn_reg_std"], G["train_rcnn_reg_std"], 2e-4, "rcnn_reg_std")
+    close(last["rcnn_cls"], G["train_rcnn_cls"], 2e-4, "rcnn_cls")
+    # ---- every loss term (voxel_rcnn.py:25-35, anchor_head_template.py, voxelrcnn_kl_label_iou_head.py:93-180)
+    tb = dict(zip(G["train_tb_keys"].tolist(), G["train_tb_vals"].tolist()))
+    got = {k: float(v) for k, v in parts.items()}
+    for ours, theirs in (("loss_rpn", "rpn_loss"), ("rpn_loss_cls", "rpn_loss_cls"), ("rpn_loss_loc", "rpn_loss_loc"),
+                         ("rpn_loss_dir", "rpn_loss_dir"), ("rcnn_loss_cls", "rcnn_loss_cls"),
+                         ("rcnn_loss_reg", "rcnn_loss_reg"), ("rcnn_loss_corner", "rcnn_loss_corner")):
+        np.testing.assert_allclose(got[ours], tb[theirs], rtol=2e-4, err_msg=ours)
+    np.testing.assert_allclose(float(loss), float(G["train_loss"]), rtol=2e-4)
+    assert torch.is_tensor(loss) and loss.requires_grad
+    # ---- backward: every parameter's gradient
+    loss.backward()
+    names = G["train_grad_names"].tolist()
+    grads = dict(model.named_parameters())
+    assert list(grads) == names
+    worst = ("", 0.0)
+    for i, k in enumerate(names):
+        g = grads[k].grad
+        assert g is not None, k
+        g = g.detach().float().cpu().numpy()
+        s2 = float(G["train_grad_digest"][i, 1])
+        scale = np.sqrt(s2 / g.size) + 1e-12                                  # rms of the reference's gradient
+        samp = rp.grad_sample(g)
+        want = G["train_grad_samples"][i, :len(samp)]
+        peak = float(np.abs(want).max()) + 1e-12
+        err = float(np.abs(samp - want).max())
+        rel = err / max(peak, scale)
+        if rel > worst[1]:
+            worst = (k, rel)
+        assert err <= 1e-3 * max(peak, scale) + 1e-7, "gradient of %s: %.3e vs peak %.3e" % (k, err, peak)
+        np.testing.assert_allclose(np.sqrt(float((g.astype(np.float64) ** 2).sum())), np.sqrt(s2), rtol=2e-3, atol=1e-7,
+                                   err_msg="norm of the gradient of " + k)
+    print("largest relative gradient error: %s %.2e" % worst)
+    # ---- BatchNorm running statistics after the step
+    sd = model.state_dict()
+    after = np.concatenate([sd[k].cpu().numpy().reshape(-1) for k in sd if k.endswith("running_mean") or k.endswith("running_var")])
+    close(after, G["train_bn_after"], 1e-4, "running statistics")
+    model.zero_grad(set_to_none=True)
+    model.last = None
+
+
+def test_proposal_layer_is_bit_exact_given_the_references_head_outputs(dev, net):
+    """sigmoid + top-k + NMS + padding on the reference's own decoded boxes and logits: the RoI list, its order, scores
+    and labels are identical (train: 9000 -> 512 at 0.8; test: 2048 -> 100 at 0.7; roi_head_template.py:52-128)."""
+    from glenet_amd import detector as det, glenet_vr as gvr
+    for tag, cls, box, cfgkey, want in (
+            ("train", "train_batch_cls_preds", "train_batch_box_preds", "NMS_TRAIN",
+             ("train_proposal_rois", "train_proposal_roi_scores", "train_proposal_roi_labels")),
+            ("eval", "eval_rpn_batch_cls_preds", "eval_rpn_batch_box_preds", "NMS_TEST",
+             ("eval_rois", "eval_roi_scores", "eval_roi_labels"))):
+        with torch.no_grad():
+            rois, scores, labels = det.proposal_layer(T(box, dev), T(cls, dev), *gvr.ROI_HEAD_CFG[cfgkey])
+        rois, scores = rois.cpu().numpy(), scores.cpu().numpy()
+        for b in range(B):       # rows of exactly equal score: an unspecified order in the reference, compared as sets
+            pg, pw = rp.canon_ties(G[want[1]][b], rois[b]), rp.canon_ties(G[want[1]][b], G[want[0]][b])
+            assert np.array_equal(rois[b][pg], G[want[0]][b][pw]), (tag, b)
+            np.testing.assert_allclose(scores[b][pg], G[want[1]][b][pw], rtol=0, atol=1.2e-7)     # sigmoid: one ulp
+        assert np.array_equal(labels.cpu().numpy(), G[want[2]]), tag
+    # the head maps -> decoded boxes step (anchor_head_template.py:233-279) on the reference's maps
+    model, cfg, _ = net
+    with torch.no_grad():
+        cls, boxes = det.predicted_boxes(T("eval_cls_preds", dev), T("eval_box_preds", dev), T("eval_dir_cls_preds", dev),
+                                         model.anchors(dev))
+    assert np.array_equal(cls.cpu().numpy(), G["eval_rpn_batch_cls_preds"])
+    np.testing.assert_allclose(boxes.cpu().numpy(), G["eval_rpn_batch_box_preds"], rtol=1e-6, atol=1e-5)
+
+
+def test_inference_pass_equals_the_references_own_classes(dev, net):
+    from glenet_amd import detector as det
+    model, cfg, state = net
+    model.load_state_dict(state)
+    # the calibrated BatchNorm running statistics the reference's inference pass ran with (stored in the fixture)
+    sd, off = model.state_dict(), 0
+    for k in G["eval_bn_keys"].tolist():
+        n = sd[k].numel()
+        sd[k].copy_(torch.from_numpy(G["eval_bn_buffers"][off:off + n]).view(sd[k].shape))
+        off += n
+    assert off == len(G["eval_bn_buffers"])
+    model.eval()
+    bd = _first_stage(model, cfg, dev, train=False)
+    with torch.no_grad():
+        bd = model.dense_head(model.backbone_2d(bd))
+        _check_map("eval", "spatial_features_2d", bd["spatial_features_2d"])
+        for k in ("cls_preds", "box_preds", "dir_cls_preds"):
+            close(bd[k], G["eval_" + k], 1e-4, k)
+        # RoI head on the reference's RoIs (voxelrcnn_kl_label_iou_head.py:38-92)
+        rois = T("eval_rois", dev)
+        rcnn_cls, rcnn_reg, rcnn_std = model.roi_head(rois, bd["multi_scale_3d_features"], bd["multi_scale_3d_strides"], B)
+        pooled = model.roi_head.last_pooled.reshape(B * 100, 216, -1).cpu().numpy()
+        scale = float(np.abs(G["eval_pooled_rows"]).max())
+        assert float(np.abs(pooled[::32] - G["eval_pooled_rows"]).max()) <= 1e-4 * scale
+        close(rcnn_cls.view(B, -1, 1), G["eval_batch_cls_preds"], 2e-4, "batch_cls_preds")
+        close(rcnn_std.view(B, -1, 7), G["eval_batch_box_std_preds"], 2e-4, "batch_box_std_preds")
+        close(det.refine_boxes(rois, rcnn_reg), G["eval_batch_box_preds"], 1e-4, "batch_box_preds")
+        # post_processing on the reference's RoI-head outputs: detections, their order, scores and labels identical
+        post = det.post_processing(T("eval_batch_cls_preds", dev), T("eval_batch_box_preds", dev),
+                                   T("eval_batch_box_std_preds", dev), T("eval_roi_labels", dev))
+        pd = det.pred_dicts(post)
+        for b in range(B):
+            want_s = G["eval_pred_scores_%d" % b]
+            assert pd[b]["pred_scores"].shape[0] == len(want_s), "frame %d: %d detections, reference %d" % (
+                b, pd[b]["pred_scores"].shape[0], len(want_s))
+            np.testing.assert_allclose(pd[b]["pred_scores"].cpu().numpy(), want_s, rtol=0, atol=1.2e-7)
+            assert np.array_equal(pd[b]["pred_labels"].cpu().numpy(), G["eval_pred_labels_%d" % b])
+            np.testing.assert_allclose(pd[b]["pred_boxes"].cpu().numpy(), G["eval_pred_boxes_%d" % b], rtol=1e-4, atol=1e-4)
+        assert sum(len(G["eval_pred_scores_%d" % b]) for b in range(B)) >= 4
+        # the free-running flow end to end: the same detections up to the flips float differences allow
+        pts, bidx = _points(dev)
+        out = model.predict(pts, bidx, B)
+        free = det.pred_dicts(out["post"])
+        hit = tot = 0
+        for b in range(B):
+            want = G["eval_pred_boxes_%d" % b]
+            got = free[b]["pred_boxes"].cpu().numpy()
+            tot += len(want)
+            for w in want:
+                hit += int(len(got) > 0 and float(np.abs(got - w).max(1).min()) < 2e-3)
+        assert hit >= 0.8 * tot, "free-running inference reproduces %d of %d reference detections" % (hit, tot)

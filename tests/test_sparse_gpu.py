@@ -377,7 +377,7 @@ def test_bev_backbone_concatenation_without_the_copy(dev):
                                                 (32, 64, False, 30000), (64, 128, False, 12000)])
 def test_batchnorm_statistics_in_the_conv_epilogue(dev, cin, cout, subm, n_pts, monkeypatch):
     """SparseSequential(conv, BatchNorm1d, ReLU) in training mode: the per-channel statistics taken in the sparse conv's
-    epilogue (glx_sconv_next_bn_stats -> sc_epilogue -> last-block finalize) + the transform launch == the conv
+    epilogue (glx_sconv_opts.bn -> sc_epilogue -> last-block finalize) + the transform launch == the conv
     followed by the separate fused BatchNorm (k_bn_stats + transform): output, running statistics, every gradient.
     Also with a shape-static row count (rows past `count` excluded from the statistics, zeroed in the output)."""
     T = lambda a, d: torch.from_numpy(np.ascontiguousarray(a)).to(d)                    # noqa: E731

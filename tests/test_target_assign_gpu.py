@@ -110,3 +110,29 @@ def test_dense_head_loss_kernel_vs_mirror_at_full_size(dev):
         w = y.grad.cpu().numpy()
         np.testing.assert_allclose(x.grad.cpu().numpy(), w, rtol=1e-4, atol=1e-6 * max(1e-3, np.abs(w).max()))
     assert int((tgt["box_cls_labels"][2] > 0).sum()) == 0          # the frame without ground truth
+
+
+def test_forced_anchor_carries_the_uncertainty_of_its_argmax_ground_truth(dev):
+    """weighted_axis_aligned_target_assigner.py:166-169: `gt_inds_force = anchor_to_gt_argmax[anchors_with_max_overlap]`,
+    `reg_weights[anchors_with_max_overlap] = gt_uncertaintys[gt_inds_force]` -- an anchor that ground truth B forces
+    positive (it is B's best anchor) but whose own arg-max is ground truth A takes A's label uncertainty, the box its
+    regression targets are encoded from (it used to take B's)."""
+    def box(x, y):
+        return [x, y, -1.0, 3.9, 1.6, 1.56, 0.0]
+    # anchor 1 overlaps A (y 0) by 0.56 and B (y 1) by 0.49: arg-max A, below the 0.6 threshold, and nobody overlaps B more
+    anchors = torch.tensor([box(10, 0.1), box(10, 0.45), box(30, 5.0)], device=dev).view(1, 1, 3, 1, 1, 7)
+    gt = torch.zeros((1, 4, 8), device=dev)
+    gt[0, 0, :7], gt[0, 1, :7] = torch.tensor(box(10, 0.0)), torch.tensor(box(10, 1.0))
+    gt[0, :2, 7] = 1
+    unc = torch.zeros((1, 4, 7), device=dev)
+    unc[0, 0], unc[0, 1] = 0.11, 0.77
+    out = target_assign.assign_targets([anchors], gt, [1], [0.6], [0.45], gt_uncertaintys=unc)
+    lab = out["box_cls_labels"].cpu().numpy()[0]
+    lu = out["label_uncertainty"].cpu().numpy()[0]
+    assert lab.tolist() == [1, 1, 0]
+    np.testing.assert_array_equal(lu[0], np.full(7, 0.11, np.float32))      # over the threshold: arg-max A
+    np.testing.assert_array_equal(lu[1], np.full(7, 0.11, np.float32))      # forced by B, arg-max A -> A's
+    np.testing.assert_array_equal(lu[2], np.zeros(7, np.float32))
+    # its regression targets are A's too: dy = (0 - 0.45) / diag
+    want = (0.0 - 0.45) / np.sqrt(3.9 ** 2 + 1.6 ** 2)
+    np.testing.assert_allclose(out["box_reg_targets"].cpu().numpy()[0, 1, 1], want, rtol=1e-6)

@@ -124,8 +124,10 @@ def test_static_step_and_graph_reproduce_the_exact_shape_step(dev):
     model.load_state_dict(state0)                 # same BatchNorm running statistics as the exact-shape run saw
     pipe = gvr.StaticTrainStep(model, B, pts.shape[0] + 700, max_gt=gt.shape[1], lr=0.0, seed_rois_with_gt=JIT,
                                grad_clip=None)
-    # what runs below is the staged backward: RoI branch on its own stream, sparse backward level by level
-    assert model.overlap_roi and model.backbone_3d.stage_cuts
+    # what runs below is the staged backward: RoI branch on its own stream, sparse backward level by level -- a property
+    # of the pipeline's own launch sequence; building a pipeline leaves the model's eager API alone
+    assert pipe.overlap_roi and pipe.stage_cuts
+    assert not model.overlap_roi and not model.backbone_3d.stage_cuts
     pipe.calibrate(pts, bidx)
     pipe.load(pts, bidx, gt, unc)
     pipe.step()
@@ -141,6 +143,13 @@ def test_static_step_and_graph_reproduce_the_exact_shape_step(dev):
     torch.cuda.synchronize()
     pipe.check()
     check(pipe, "HIP graph replay")
+    # ... and afterwards an eager call still returns a plain tensor loss
+    assert not model.overlap_roi and not model.backbone_3d.stage_cuts
+    model.zero_grad(set_to_none=True)
+    loss, _ = model.training_step(pts, bidx, B, gt, unc, seed_rois_with_gt=seed)
+    assert torch.is_tensor(loss) and loss.requires_grad
+    del loss
+    model.last = None
 
 
 def test_replayed_training_follows_an_eager_adamw_loop(dev):

@@ -86,12 +86,16 @@ class EasyDict(dict):
             self[k] = v
 
 
-def prepare_imports():
-    """Steps 1-2.  Returns the list of placeholder names that were needed."""
+def prepare_imports(install=None):
+    """Steps 1-2.  Returns the list of placeholder names that were needed.
+    install: callable that registers the extension / spconv module names (default glenet_amd.dropin.install; the
+    whole-step golden passes oracle.refshim.install -- the CPU stand-ins backed by the oracle)."""
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
-    import glenet_amd.dropin as dropin
-    dropin.install()
+    if install is None:
+        import glenet_amd.dropin as dropin
+        install = dropin.install
+    install()
     pk = types.ModuleType("pcdet")
     pk.__path__ = [os.path.join(REF, "pcdet")]
     sys.modules["pcdet"] = pk
@@ -138,8 +142,9 @@ class _FakeDataset:
         self.depth_downsample_factor = None
 
 
-def build_reference_network(cfg_rel, num_point_features):
-    """Step 3: the reference's own config loader and network builder."""
+def build_reference_network(cfg_rel, num_point_features, edit=None):
+    """Step 3: the reference's own config loader and network builder.  edit(cfg): optional change of config VALUES
+    (a reduced point-cloud range for the whole-step golden) between loading and building."""
     import torch
     from pcdet.config import cfg_from_yaml_file
     from pcdet.models import build_network
@@ -149,6 +154,8 @@ def build_reference_network(cfg_rel, num_point_features):
         cfg = cfg_from_yaml_file(cfg_rel, EasyDict())
     finally:
         os.chdir(cwd)
+    if edit is not None:
+        edit(cfg)
     ds = _FakeDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, num_point_features)
     real_cuda = torch.Tensor.cuda
     torch.Tensor.cuda = lambda self, *a, **k: self

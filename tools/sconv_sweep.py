@@ -79,8 +79,9 @@ for f, w, nbr, order, n_out, rules in calls:
                 continue
             for it in range(12):
                 s, e = ev(), ev()
-                _lib.call_nostream("glx_profile_next_sconv", s, e)
+                sp._profile_hook = lambda *a, s=s, e=e: (s, e)       # -> glx_sconv_opts.profile_start / _stop
                 orig(f, w, None, nbr, order, n_out, packed=packed)
+                sp._profile_hook = None
                 ms = ctypes.c_float()
                 _lib.call_nostream("glx_event_elapsed_ms", s, e, ctypes.byref(ms))
                 ts.append(ms.value * 1e3)
@@ -99,9 +100,10 @@ for f, w, nbr, order, n_out, rules in calls:
         ts = []
         for it in range(12):
             s, e = ev(), ev()
-            _lib.call_nostream("glx_sconv_next_tile_map", tmap)
-            _lib.call_nostream("glx_profile_next_sconv", s, e)
-            got = orig(f, w, None, nbr, order, n_out, packed=packed)
+            sp._profile_hook = lambda *a, s=s, e=e: (s, e)
+            rules = type("R", (), dict(subm=True, _tile_maps=True, tile_map=lambda self, *a: tmap))()
+            got = orig(f, w, None, nbr, order, n_out, packed=packed, rules=rules)     # -> glx_sconv_opts.tile_map
+            sp._profile_hook = None
             ms = ctypes.c_float()
             _lib.call_nostream("glx_event_elapsed_ms", s, e, ctypes.byref(ms))
             ts.append(ms.value * 1e3)
