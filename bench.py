@@ -271,32 +271,83 @@ def bench_bev(model, dev, frames=FRAMES_PER_GPU):
                         "BatchNorm: csrc/glx_bn.hip with the forward statistics in the conv epilogue")
 
 
-def bench_inference(dev, frames=FRAMES_PER_GPU, steps=50):
-    """The two-stage INFERENCE flow of the same detector (glenet_amd.detector.VoxelRCNNFlow: voxelize -> sparse backbone ->
-    BEV backbone + anchor head -> decode + top-k + NMS 2048 -> 100 -> RoI-grid pooling -> FC refinement), eval mode, random
-    weights, `frames` synthetic KITTI-shaped frames: eager with exact shapes and as one shape-static HIP graph."""
+def bench_inference(dev, frames=FRAMES_PER_GPU, steps=50, cpu=True):
+    """The two-stage INFERENCE pass of GLENet-VR (glenet_amd.glenet_vr.GLENetVR.second_stage behind the sparse front end:
+    voxelize -> sparse backbone -> BEV backbone + anchor head -> decode + top-k + NMS 2048 -> 100 -> RoI-grid pooling -> FC
+    towers with the log-variance branch and the score rescaling -> box refinement -> POST-PROCESSING on the device: score
+    threshold, top-k, variance-voting NMS (variance = exp(batch_box_std_preds)), post max size, POST_SCORE_THRESH --
+    Detector3DTemplate.post_processing, detector3d_template.py:179-317), eval mode, random weights, `frames` synthetic
+    KITTI-shaped frames: eager with exact shapes and as one shape-static HIP graph; the post-processing alone beside it."""
     import numpy as np
     import torch
     from glenet_amd import detector as det
+    from glenet_amd import glenet_vr as gvr
     from glenet_amd import synth
     K = synth.KITTI
     fr = [synth.kitti_frame(2000 + i)[0] for i in range(frames)]
     pts = torch.from_numpy(np.concatenate(fr)).to(dev)
     bidx = torch.from_numpy(np.concatenate([np.full(len(f), i, np.int32) for i, f in enumerate(fr)])).to(dev)
     torch.manual_seed(0)
-    flow = det.VoxelRCNNFlow(K).to(dev).eval()
+    flow = gvr.GLENetVR(K).to(dev).eval()
     with torch.no_grad():
-        ms_e = _timed(lambda: flow(pts, bidx, frames), steps, dev, warm=5)
+        ms_e = _timed(lambda: flow.predict(pts, bidx, frames), steps, dev, warm=5)
+        out = flow.predict(pts, bidx, frames)
+        args = (out["batch_cls_preds"], out["batch_box_preds"], out["batch_box_std_preds"], out["roi_labels"])
+        # an untrained head scores every RoI about alike: thresholds off, so that all 100 RoIs of a frame enter the voting NMS
+        cfg_all = dict(SCORE_THRESH=0.0, POST_SCORE_THRESH=None)
+        ms_post = _timed(lambda: det.post_processing(*args, cfg_all), steps, dev, warm=5)
     pipe = det.StaticDetectorPipeline(flow, frames, pts.shape[0])
     pipe.calibrate(pts, bidx)
     pipe.load(pts, bidx)
     pipe.capture()
     ms_g = _timed(pipe.replay, steps, dev, warm=5)
     pipe.check()
-    return dict(workload="two-stage inference flow (VoxelRCNNFlow), %d frames x 20 000 points, eval mode: BatchNorm folded into "
-                         "the sparse and dense convolutions' epilogues, NMS 2048 -> 100 proposals per frame" % frames,
+    return dict(workload="GLENet-VR inference pass incl. post-processing (GLENetVR.predict), %d frames x 20 000 points, eval "
+                         "mode: BatchNorm folded into the sparse and dense convolutions' epilogues and the FC towers, NMS 2048 "
+                         "-> 100 proposals per frame, variance-voting NMS of the refined boxes on the device" % frames,
                 eager_ms_per_step=round(ms_e, 3), eager_frames_per_s=round(frames / ms_e * 1e3, 1),
-                graph_ms_per_step=round(ms_g, 3), graph_frames_per_s=round(frames / ms_g * 1e3, 1))
+                graph_ms_per_step=round(ms_g, 3), graph_frames_per_s=round(frames / ms_g * 1e3, 1),
+                post_processing_ms=round(ms_post, 4),
+                post_processing_note="det.post_processing alone on the pass's own outputs, thresholds off (all %d x 100 RoIs "
+                                     "enter the voting NMS); it is inside both figures above" % frames,
+                new_nms_4096=bench_new_nms(dev, frames, cpu=cpu))
+
+
+def bench_new_nms(dev, frames=FRAMES_PER_GPU, n=4096, steps=20, cpu=True):
+    """GLENet's variance-voting NMS at NMS_PRE_MAXSIZE = 4096 candidates per frame -- what the single-stage GLENet-S / -C
+    hand to new_nms_gpu (GLENet_S.yaml:93-106; SURVEY a11: on the reference's host path up to 16.8 M rotated IoUs + the
+    greedy loop on ONE CPU thread per frame, its dominant inference cost): det.post_processing on `frames` frames of 6000
+    random boxes (60 % jittered duplicates), SCORE_THRESH 0.1, NMS_THRESH 0.01, beside the CPU oracle's restatement of the
+    same routine on one frame (the checker, timed: numpy loop + the C IoU matrix, one thread)."""
+    import time
+    import numpy as np
+    import torch
+    from glenet_amd import detector as det
+    from glenet_amd import synth
+    rng = np.random.default_rng(11)
+    R = 6000
+    boxes = np.stack([synth.random_boxes(rng, R, xy_range=60.0, near_dup=0.6) for _ in range(frames)]).astype(np.float32)
+    scores = rng.uniform(0.05, 0.99, (frames, R)).astype(np.float32)
+    logits = np.log(scores / (1 - scores)).astype(np.float32)[..., None]
+    std = rng.normal(-2.0, 0.7, (frames, R, 7)).astype(np.float32)
+    cfg = dict(SCORE_THRESH=0.1, POST_SCORE_THRESH=None, NMS_THRESH=0.01, NMS_PRE_MAXSIZE=n, NMS_POST_MAXSIZE=500)
+    t = [torch.from_numpy(a).to(dev) for a in (logits, boxes, std)]
+    with torch.no_grad():
+        ms = _timed(lambda: det.post_processing(*t, None, cfg), steps, dev, warm=3)
+        post = det.post_processing(*t, None, cfg)
+        sig = torch.sigmoid(t[0][0]).cpu().numpy()
+    out = dict(candidates_per_frame=n, frames=frames, device_ms=round(ms, 3), device_ms_per_frame=round(ms / frames, 3),
+               kept_frame0=int(post["num"][0]))
+    if cpu:      # a cpu_baseline leg: the oracle is the checker, timed beside the device path, never part of it
+        import oracle
+        t0 = time.perf_counter()
+        wb, ws, wl, wsel = oracle.post_processing(sig, boxes[0], std[0], None, normalized=True, score_thresh=0.1,
+                                                  post_score_thresh=None, nms_thresh=0.01, nms_pre_maxsize=n,
+                                                  nms_post_maxsize=500)
+        out["cpu_oracle_ms_per_frame"] = round((time.perf_counter() - t0) * 1e3, 1)
+        out["keep_list_equals_oracle"] = bool(int(post["num"][0]) == len(ws) and
+                                              np.array_equal(post["pred_index"][0, :len(ws)].cpu().numpy(), wsel))
+    return out
 
 
 def bench_config3(dev, objects=4096, points=512, samples=30):
@@ -704,7 +755,7 @@ def main():
             progress("bev done")
             del pipe
             torch.cuda.empty_cache()
-            out["inference"] = bench_inference(dev)
+            out["inference"] = bench_inference(dev, cpu=not args.no_cpu_baseline)
             progress("inference flow done")
             torch.cuda.empty_cache()
             out["config3"] = bench_config3(dev)
