@@ -64,6 +64,17 @@ def reduce_sum_int(value, device=None):
     return int(t.item())
 
 
+def gather_floats(values, device=None):
+    """[[values of rank 0], [values of rank 1], ...] on every rank (diagnostics: per-rank step time, exchange time)."""
+    vals = [float(v) for v in values]
+    if not (dist.is_available() and dist.is_initialized()):
+        return [vals]
+    t = torch.tensor(vals, dtype=torch.float64, device=_coll_device(device))
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.tolist() for o in out]
+
+
 def job_throughput(units_this_rank, seconds_this_rank, device=None):
     """Whole-job units/s = (sum of units over ranks) / (max time over ranks)."""
     return reduce_sum_int(units_this_rank, device) / reduce_max(seconds_this_rank, device)

@@ -381,7 +381,7 @@ class GLENetVR(nn.Module):
         # the next capture, see StaticTrainPipeline.enqueue)
         self.last = dict(rois=rois_s, rcnn_cls=rcnn_cls.detach(), rcnn_reg=rcnn_reg.detach(),
                          rcnn_reg_std=rcnn_std.detach(), targets=td, proposals=rois, own_proposals=own_proposals,
-                         batch_cls_preds=cls, batch_box_preds=boxes, gt_of_rois_ct=gt_ct,
+                         batch_cls_preds=cls.detach(), batch_box_preds=boxes.detach(), gt_of_rois_ct=gt_ct,
                          anchor_targets=tgt, cls_preds=bd["cls_preds"].detach(), box_preds=bd["box_preds"].detach(),
                          dir_cls_preds=bd["dir_cls_preds"].detach() if "dir_cls_preds" in bd else None)
         return loss, parts

@@ -6,6 +6,8 @@ Differences by design: the dense (B,Z,Y,X) int32 voxel->point map the reference 
 and step (generate_voxel2pinds, 189 MB at x_conv2) is not built -- the query walks the sparse
 tensor's cell index (glx_voxel_query_index); per-batch counts are computed without a Python loop.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -172,7 +174,18 @@ class RoIGridPool(nn.Module):
         _lib.call("glx_roi_grid_points", rois2, n, rois2.shape[1], n // B, self.grid_size, rmin, vsz,
                   grid_xyz, coords)
         outs = []
-        for layer, name in zip(self.roi_grid_pool_layers, self.sources):
+        # The scales are independent chains of ~11 short launches each (mlp_in GEMM + BatchNorm, centres, query, moments,
+        # aggregation, mlp_out GEMM + BatchNorm), none of which fills the chip: with SCALE_STREAMS they run side by side
+        # on streams of their own (forked behind the grid points, joined in front of the concatenation; autograd runs
+        # each chain's backward on the stream its forward ran on), so the RoI branch -- the critical path of the training
+        # step -- waits for the longest of the three instead of their sum.
+        cur = torch.cuda.current_stream(dev)
+        side = self._scale_streams(dev, len(self.sources) - 1) if (self.SCALE_STREAMS and len(self.sources) > 1) else []
+        for k, (layer, name) in enumerate(zip(self.roi_grid_pool_layers, self.sources)):
+          stream = side[k - 1] if (side and k > 0) else cur
+          if stream is not cur:
+              stream.wait_stream(cur)
+          with torch.cuda.stream(stream):
             st = tensors[name]
             index = st._ensure_index()
             z, y, x = st.spatial_shape
@@ -199,7 +212,24 @@ class RoIGridPool(nn.Module):
                     pos = layer._conv_bn_rows(mlp_pos, rel.view(m * ns, 3))       # (M*ns, c_mid)
                     pooled = ReluAddMax.apply(g_feat, pos.view(m, ns, -1))        # (M, c_mid)
                 outs.append(layer._conv_bn_rows(mlp_out, pooled))                 # (M, c_out)
+                if stream is not cur:
+                    outs[-1].record_stream(cur)
+        for sd in side:
+            cur.wait_stream(sd)
         return torch.cat(outs, dim=1).view(n, g3, -1)
+
+    # Opt-in experiment (GLX_ROI_SCALE_STREAMS=1), OFF by default: eager launches and the shape-static eager step are
+    # correct with it, but RECORDING the step with the two extra branches ends in a segmentation fault inside
+    # hipStreamEndCapture on ROCm 7.2 (round 4, tests/test_train_step_gpu.py; the same failure mode as an unjoined
+    # branch, although every chain is joined in forward and autograd joins its backward).
+    SCALE_STREAMS = os.environ.get("GLX_ROI_SCALE_STREAMS", "0") == "1"
+
+    def _scale_streams(self, dev, n):
+        key = (dev.index if dev.index is not None else torch.cuda.current_device())
+        pool = self.__dict__.setdefault("_glx_scale_streams", {})
+        if key not in pool or len(pool[key]) < n:
+            pool[key] = [torch.cuda.Stream(dev) for _ in range(n)]
+        return pool[key][:n]
 
     # ---- inference fast path: 1 + 3 launches per scale (csrc/glx_points.hip) -- grid points and
     # their voxel coordinates in one kernel, then per scale mlp_in (one GEMM), the voxel query and

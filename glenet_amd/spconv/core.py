@@ -124,7 +124,7 @@ class RuleSet:
         every conv that walks the table."""
         if nbr is None:
             nbr, order, n_out, n_live = self.nbr, self.tile_order_out, self.N_out, self.count_out
-        if not USE_TILE_MAP or n_out < TILE_MAP_MIN_ROWS or n_out > 64 * 4096:
+        if not USE_TILE_MAP or n_out < TILE_MAP_MIN_ROWS or n_out > 64 * 16384:     # beyond: the kernels' built-in map
             return None
         key = nbr.data_ptr()
         m = self._tile_maps.get(key)

@@ -647,3 +647,25 @@ def test_eval_after_fused_training_steps_sees_the_new_weights(dev):
     assert torch.equal(ipipe.replay()["spatial_features"], y_ref)     # the inference graph recorded itself again
     assert [p._version for p in model.parameters()] == versions[:len(list(model.parameters()))]
     _drop_graphs(pipe, ipipe, opipe)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ntiles", [6000, 16384, 17000])
+def test_tile_map_of_large_rule_tables(dev, ntiles):
+    """glx_sconv_tile_map beyond the 4096 tiles of round 3 (max_voxels Waymo x batch > 2 exceeded it and the
+    entry point failed): up to 16384 tiles (1 M output rows) one block sorts them in dynamic LDS -- a permutation of the
+    tiles that differs from the identity --, beyond that the identity map; never an error."""
+    from glenet_amd import _lib
+    n_out, Kk = ntiles * 64, 27
+    g = torch.Generator(device=dev).manual_seed(ntiles)
+    nbr = torch.randint(0, n_out, (n_out, Kk), device=dev, dtype=torch.int32, generator=g)
+    # uneven work: the share of present neighbours grows along the rows
+    drop = torch.rand((n_out, Kk), device=dev, generator=g) > torch.linspace(0.05, 0.9, n_out, device=dev)[:, None]
+    nbr = torch.where(drop, torch.full_like(nbr, -1), nbr).contiguous()
+    tmap = torch.full((ntiles,), -7, dtype=torch.int32, device=dev)
+    wsb = _lib.query("glx_sconv_tile_map_workspace_bytes", n_out)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _lib.call("glx_sconv_tile_map", nbr, None, n_out, Kk, None, tmap, ws, _lib.size_arg(wsb))
+    got = tmap.cpu().numpy()
+    assert np.array_equal(np.sort(got), np.arange(ntiles))
+    assert np.array_equal(got, np.arange(ntiles)) == (ntiles > 16384)

@@ -375,9 +375,11 @@ def test_roi_grid_pool_fused_aggregation_matches_module_path(dev, mlps):
 
 
 def test_roi_grid_pool_harness_vs_reference_formulation(dev):
-    """glenet_amd.roi_grid.RoIGridPool == the reference's roi_grid_pool data flow restated with
-    its own pieces: dense voxel->point map per scale, grid coords by float floor division, per-batch
-    counts (voxelrcnn_head.py:106-191), on two scales of a synthetic scene."""
+    """REGRESSION test (the parity of this stage against the reference's OWN VoxelRCNNHead.roi_grid_pool /
+    NeighborVoxelSAModuleMSG, executed, is tests/test_reference_step_gpu.py: pooled features of a training step and an
+    inference pass): glenet_amd.roi_grid.RoIGridPool == that data flow re-typed here with its own pieces -- dense
+    voxel->point map per scale, grid coords by float floor division, per-batch counts (voxelrcnn_head.py:106-191) -- on
+    two scales of a synthetic scene with other shapes than the golden's."""
     from glenet_amd import roi_grid as rg
     rng = np.random.default_rng(21)
     B, vs, pcr = 2, [0.1, 0.1, 0.2], [0.0, 0.0, 0.0, 4.0, 4.8, 2.0]

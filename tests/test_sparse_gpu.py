@@ -418,3 +418,37 @@ def test_batchnorm_statistics_in_the_conv_epilogue(dev, cin, cout, subm, n_pts, 
     for st in sp._BN_STATES.values():                      # accumulators clean, ticket reset
         words = st.view(torch.int32)
         assert int(words[:16 * 2 * 512 * 2].abs().max()) == 0 and int(words[16 * 2 * 512 * 2]) == 0
+
+
+@pytest.mark.parametrize("cin,cmid,cout", [(16, 32, 16), (32, 64, 32)])
+def test_sparse_inverse_conv_vs_oracle(dev, cin, cmid, cout):
+    """spconv.SparseInverseConv3d (the name spconv_backbone.py:17 imports; used by pcdet/models/backbones_3d/
+    spconv_unet.py's decoder): the strided conv's rule table walked backwards -- output rows = the forward conv's INPUT
+    set, out[i] = sum over (k, i, j) of in[j] @ W[k] -- against the oracle's pair lists with the roles swapped; forward
+    values, index set restored, and the gradients of input and weight."""
+    rng = np.random.default_rng(5)
+    shape = (9, 24, 22)
+    idx, f = _rand_sparse(rng, 2, *shape, 0.06, cin)
+    x = _gpu_tensor(idx, f, shape, 2, dev)
+    down = sp.SparseConv3d(cin, cmid, 3, stride=2, padding=1, bias=False, indice_key="spconv2").to(dev)
+    up = sp.SparseInverseConv3d(cmid, cout, 3, indice_key="spconv2", bias=False).to(dev)
+    x.features.requires_grad_(True)
+    mid = down(x)
+    y = up(mid)
+    assert np.array_equal(y.indices.cpu().numpy(), idx) and list(y.spatial_shape) == list(shape)
+    r = oracle.build_rules(idx, shape, 3, 2, 1, subm=False)
+    w1 = down.weight.detach().cpu().numpy().reshape(27, cin, cmid)
+    w2 = up.weight.detach().cpu().numpy().reshape(27, cmid, cout)
+    m_ref = oracle.sconv_forward(f, w1, r)
+    swapped = oracle.Rules(r.pairs_out, r.pairs_in, r.n_pairs, idx, list(shape), len(r.out_indices))
+    y_ref = oracle.sconv_forward(m_ref, w2, swapped)
+    np.testing.assert_allclose(mid.features.detach().cpu().numpy(), m_ref, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(y.features.detach().cpu().numpy(), y_ref, rtol=1e-4, atol=1e-4)
+    g = rng.normal(size=y_ref.shape).astype(np.float32)
+    y.features.backward(torch.from_numpy(g).to(dev))
+    dmid, dw2 = oracle.sconv_backward(m_ref, w2, g, swapped)
+    dx, dw1 = oracle.sconv_backward(f, w1, dmid, r)
+    for got, want, name in ((up.weight.grad.reshape(27, cmid, cout), dw2, "dW up"), (down.weight.grad.reshape(27, cin, cmid), dw1, "dW down"),
+                            (x.features.grad, dx, "dx")):
+        got = got.cpu().numpy()
+        assert np.abs(got - want).max() <= 2e-4 * (np.abs(want).max() + 1e-12), name

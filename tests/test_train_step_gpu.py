@@ -54,6 +54,10 @@ def _grads(model):
 
 
 def test_composed_losses_equal_the_reference_formulations(dev):
+    """REGRESSION test at the full KITTI range: the fused device paths of the composed step against the tensor-statement
+    formulations re-typed in glenet_amd (batched proposals == per-frame loop, fused losses == torch statements).  That these
+    formulations ARE the reference's is pinned elsewhere: tests/test_reference_step_gpu.py runs the same model against a
+    training step of the reference's own VoxelRCNN / VoxelRCNNKLLabelIoUHead classes (tests/golden/ref_step.npz)."""
     from glenet_amd import detector as det, losses
     model = _small_model(dev)
     pts, bidx, gt, unc = _batch(dev, [50, 51], 6000)
