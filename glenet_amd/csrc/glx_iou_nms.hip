@@ -1141,6 +1141,32 @@ extern "C" int glx_nms_vote(float* boxes, float* scores, const float* variance, 
                             stream);
 }
 
+// Stand-in for a trained first stage (bench.py, tests): the first G proposal slots of every frame take the frame's ground
+// truth + a fixed offset wherever a ground-truth row is live (class > 0) -- eleven elementwise launches as tensor
+// statements (compare, add, two where, casts, copies), one here.
+__global__ void k_seed_rois(float* __restrict__ rois, int64_t* __restrict__ labels, const float* __restrict__ gt,
+                            const float* __restrict__ offset, int B, int R, int ld, int G, int gld) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * G) return;
+  const int b = i / G, g = i - b * G;
+  const float* q = gt + ((long long)b * G + g) * gld;
+  if (!(q[7] > 0.f)) return;
+  float* r = rois + ((long long)b * R + g) * ld;
+  for (int k = 0; k < 7; ++k) r[k] = q[k] + offset[k];
+  labels[(long long)b * R + g] = (int64_t)q[7];
+}
+
+extern "C" int glx_seed_rois(float* rois, int64_t* roi_labels, const float* gt_boxes, const float* offset7, int B, int R,
+                             int roi_ld, int G, int gt_ld, void* stream) {
+  if (B <= 0 || G <= 0) return GLX_OK;
+  GLX_REQUIRE(rois && roi_labels && gt_boxes && offset7, "glx_seed_rois: null pointer");
+  GLX_REQUIRE(G <= R && roi_ld >= 7 && gt_ld >= 8, "glx_seed_rois: %d ground-truth rows for %d RoI slots", G, R);
+  hipLaunchKernelGGL(k_seed_rois, dim3(glx_divup(B * G, 256)), dim3(256), 0, (hipStream_t)stream, rois, roi_labels, gt_boxes,
+                     offset7, B, R, roi_ld, G, gt_ld);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
 // ------------------------------------------------------------------ inference post-processing
 // The two ends of Detector3DTemplate.post_processing + class_agnostic_nms (pcdet/models/detectors/detector3d_template.py:
 // 179-317, pcdet/models/model_utils/model_nms_utils.py:6-62) around the top-k and the voting NMS, one launch each.

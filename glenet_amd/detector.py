@@ -139,6 +139,17 @@ def topk_desc(scores, k):
     return top, order
 
 
+_ZEROS_I64 = {}
+
+
+def _zeros_i64(b, a, device):
+    """A cached, never written (b, a) int64 zero tensor (the class index of a one-class head)."""
+    key = (b, a, device.type, device.index)
+    if key not in _ZEROS_I64:
+        _ZEROS_I64[key] = torch.zeros((b, a), dtype=torch.int64, device=device)
+    return _ZEROS_I64[key]
+
+
 def _proposal_layer_batched(batch_box_preds, scores_all, nms_pre_maxsize, nms_post_maxsize, nms_thresh):
     """Same result as the per-frame loop above without its host round trips: batched class-max and
     top-k (already in descending order, so the NMS wrapper's own sort is the identity), ONE batched
@@ -146,7 +157,10 @@ def _proposal_layer_batched(batch_box_preds, scores_all, nms_pre_maxsize, nms_po
     place of the variable-length slice."""
     from .pcdet_ops.iou3d_nms import iou3d_nms_cuda
     B, A, C = batch_box_preds.shape
-    s, lab = scores_all.max(dim=2)                                              # (B, A)
+    if scores_all.shape[2] == 1:             # one class: the class maximum is the score itself, its arg-max 0 (no launches)
+        s, lab = scores_all.reshape(B, A), _zeros_i64(B, A, scores_all.device)
+    else:
+        s, lab = scores_all.max(dim=2)                                          # (B, A)
     k = min(nms_pre_maxsize, A)
     top, order = topk_desc(s, k)
     cand = torch.gather(batch_box_preds, 1, order.unsqueeze(-1).expand(B, k, C))

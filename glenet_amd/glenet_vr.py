@@ -327,10 +327,15 @@ class GLENetVR(nn.Module):
                 if self.fixed_proposals is not None:     # what RoIHeadTemplate.proposal_layer does when `rois` is given
                     rois, roi_scores, roi_labels = self.fixed_proposals                  # (roi_head_template.py:69-70)
                 if seed_rois_with_gt is not None:
-                    has = gt_boxes[:, :, 7:8] > 0
                     ng = gt_boxes.shape[1]
-                    rois[:, :ng, :7] = torch.where(has, gt_boxes[:, :, :7] + seed_rois_with_gt, rois[:, :ng, :7])
-                    roi_labels[:, :ng] = torch.where(has[..., 0], gt_boxes[:, :, 7].long(), roi_labels[:, :ng])
+                    if (rois.is_cuda and rois.is_contiguous() and roi_labels.is_contiguous() and gt_boxes.is_contiguous()
+                            and rois.dtype == torch.float32 and roi_labels.dtype == torch.int64 and ng <= rois.shape[1]):
+                        gb._lib.call("glx_seed_rois", rois, roi_labels, gt_boxes, seed_rois_with_gt.contiguous().float(),
+                                     B, rois.shape[1], rois.shape[2], ng, gt_boxes.shape[2])          # one launch
+                    else:
+                        has = gt_boxes[:, :, 7:8] > 0
+                        rois[:, :ng, :7] = torch.where(has, gt_boxes[:, :, :7] + seed_rois_with_gt, rois[:, :ng, :7])
+                        roi_labels[:, :ng] = torch.where(has[..., 0], gt_boxes[:, :, 7].long(), roi_labels[:, :ng])
                 key, pick = self.fixed_draws if self.fixed_draws is not None else (None, None)
                 td = self.target_layer({"rois": rois, "roi_scores": roi_scores, "roi_labels": roi_labels,
                                         "gt_boxes": gt_boxes, "gt_uncertaintys": gt_uncertaintys}, key, pick)

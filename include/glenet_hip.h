@@ -348,6 +348,11 @@ int glx_nms_batch(const float* boxes_sorted, int frames, int N, float thresh, in
 int glx_nms_vote(float* boxes, float* scores, const float* variance, int var_stride,
                  const float* ious_t, int N, float iou_thr, float score_thr, float* scratch,
                  void* stream);
+/* Test / bench helper, no reference counterpart: rois (B,R,ld >= 7) and roi_labels (B,R) int64 -- slot g < G of frame b
+ * takes gt_boxes[b][g][0:7] + offset7 and the row's class wherever gt_boxes[b][g][7] > 0 (gt_boxes (B,G,gld >= 8)): what a
+ * trained first stage delivers (a random-init one proposes nothing near the ground truth). */
+int glx_seed_rois(float* rois, int64_t* roi_labels, const float* gt_boxes, const float* offset7, int B, int R,
+                  int roi_ld, int G, int gt_ld, void* stream);
 /* `frames` independent lists in one launch sequence (the per-frame loop of Detector3DTemplate.post_processing,
  * pcdet/models/detectors/detector3d_template.py:196-309): boxes (frames,N,7), scores (frames,N), variance
  * (frames,N,var_stride), ious_t (frames,N,N), scratch (frames,N*8); counts (frames) int32 DEVICE or NULL = live boxes

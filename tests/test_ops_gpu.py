@@ -836,3 +836,23 @@ def test_softnms_vs_oracle(dev, mode, with_var):
     assert new_boxes.data_ptr() == tb.data_ptr()                                      # in place, like the reference
     if with_var:
         assert np.abs(boxes_ref[:, :6] - boxes[:, :6]).max() > 1e-3                   # the vote moved boxes
+
+
+def test_seed_rois_kernel_equals_the_tensor_statements(dev):
+    """glx_seed_rois (bench / test helper: ground truth + offset into the first proposal slots) == the torch.where
+    statements it replaces, rows without a live ground truth untouched."""
+    from glenet_amd import _lib
+    g = torch.Generator(device=dev).manual_seed(5)
+    B, R, G = 3, 40, 9
+    rois = torch.rand((B, R, 7), device=dev, generator=g)
+    labels = torch.randint(1, 4, (B, R), device=dev, generator=g)
+    gt = torch.rand((B, G, 8), device=dev, generator=g)
+    gt[..., 7] = torch.randint(0, 3, (B, G), device=dev, generator=g).float()
+    gt[1] = 0
+    off = torch.tensor([0.3, -0.2, 0.05, 0.1, 0.0, -0.1, 0.07], device=dev)
+    want_r, want_l = rois.clone(), labels.clone()
+    has = gt[:, :, 7:8] > 0
+    want_r[:, :G, :7] = torch.where(has, gt[:, :, :7] + off, want_r[:, :G, :7])
+    want_l[:, :G] = torch.where(has[..., 0], gt[:, :, 7].long(), want_l[:, :G])
+    _lib.call("glx_seed_rois", rois, labels, gt, off, B, R, 7, G, 8)
+    assert torch.equal(rois, want_r) and torch.equal(labels, want_l)
