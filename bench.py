@@ -350,6 +350,57 @@ def bench_new_nms(dev, frames=FRAMES_PER_GPU, n=4096, steps=20, cpu=True):
     return out
 
 
+def bench_dropin(state, K, pool, dev, steps=12):
+    """what the fast paths are worth to a network in the REFERENCE'S module layout.  The same training
+    step (state-dict-identical GLENet-VR, same batches, exact shapes, eager launches, torch.optim.AdamW + clip_grad_norm_ as
+    tools/train_utils/train_utils.py drives it) timed twice: (i) under glenet_amd.dropin.reference_layout() -- the call
+    sequence the reference's own Python makes through install() alone: vendor 2-D convolutions + torch BatchNorm on an NCHW
+    map built by dense(), per-frame proposal loop with read-backs, RoI-grid pooling through VoxelQueryAndGrouping /
+    grouping_operation and Conv1d / Conv2d modules -- and (ii) with the fused / batched paths dropin.accelerate() switches
+    on.  Both beside the headline (the shape-static recorded step)."""
+    import contextlib
+    import time
+    import torch
+    from glenet_amd import dropin
+    from glenet_amd import glenet_vr as gvr
+    seed = torch.tensor(ROI_SEED_OFFSET, dtype=torch.float32, device=dev)
+
+    def run(layout):
+        with (dropin.reference_layout() if layout else contextlib.nullcontext()):
+            torch.manual_seed(0)
+            m = gvr.GLENetVR(K, bev_channels_last=not layout).to(dev).train()
+            m.load_state_dict(state)
+            opt = torch.optim.AdamW(m.parameters(), lr=1e-3, betas=gvr.OPTIM_CFG["BETAS"], weight_decay=gvr.OPTIM_CFG["WEIGHT_DECAY"])
+
+            def step(b):
+                opt.zero_grad(set_to_none=True)
+                loss, _ = m.training_step(b[0], b[1], FRAMES_PER_GPU, b[2], b[3], seed_rois_with_gt=seed)
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(m.parameters(), gvr.OPTIM_CFG["GRAD_NORM_CLIP"])
+                opt.step()
+                m.last = None
+            for j in range(3):
+                step(pool[j % len(pool)])
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for j in range(steps):
+                step(pool[j % len(pool)])
+            torch.cuda.synchronize(dev)
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            del m, opt
+            torch.cuda.empty_cache()
+            return ms
+    ref_ms = run(True)
+    acc_ms = run(False)
+    return dict(dropin_step_ms=round(ref_ms, 3), dropin_step_frames_per_s=round(FRAMES_PER_GPU / ref_ms * 1e3, 1),
+                dropin_accelerated_step_ms=round(acc_ms, 3),
+                dropin_accelerated_frames_per_s=round(FRAMES_PER_GPU / acc_ms * 1e3, 1), steps=steps,
+                note="eager exact-shape training steps (host read-backs size the sparse tensors; torch.optim.AdamW): "
+                     "dropin_step = reference module layout through the drop-in's operators only (glenet_amd.dropin."
+                     "reference_layout); dropin_accelerated_step = the same with the fused / batched paths that "
+                     "dropin.accelerate() switches on; the headline is the shape-static step replayed as one HIP graph")
+
+
 def bench_config3(dev, objects=4096, points=512, samples=30):
     """BASELINE configs[3]: the CVAE on 4096 object crops x 512 points -- (i) the inference sampler, 30 latent samples
     per object (fused MFMA PointNet kernel, csrc/glx_pointnet.hip), (ii) one TRAINING step forward + backward + clip +
@@ -796,8 +847,14 @@ def main():
         if world == 1 and not args.no_extra:
             out["bev"] = bench_bev(model, dev)
             progress("bev done")
+            state = {k: v.detach().clone() for k, v in model.state_dict().items()}
             del pipe
             torch.cuda.empty_cache()
+            out["dropin"] = bench_dropin(state, K, pool, dev)
+            out["dropin"]["ratio_dropin_step_over_headline"] = round(out["dropin"]["dropin_step_ms"] / out["ms_per_step"], 2)
+            out["dropin"]["ratio_accelerated_over_headline"] = round(out["dropin"]["dropin_accelerated_step_ms"] / out["ms_per_step"], 2)
+            del state
+            progress("drop-in layout steps done")
             out["inference"] = bench_inference(dev, cpu=not args.no_cpu_baseline)
             progress("inference flow done")
             torch.cuda.empty_cache()
