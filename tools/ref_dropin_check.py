@@ -240,9 +240,9 @@ def check_accelerate(net):
     assert type(bev).__module__ == "glenet_amd.dense_path" and list(net.state_dict().keys()) == keys
     # round 4: the reference's own HeightCompression, NeighborVoxelSAModuleMSG x 3 and ProposalTargetLayer instances are
     # re-classed, VoxelRCNNHead.roi_grid_pool / RoIHeadTemplate.proposal_layer are bound to the device paths
-    want = {"backbone_2d", "map_to_bev_module", "roi_head.proposal_target_layer", "roi_head.roi_grid_pool",
-            "roi_head.proposal_layer"} | {"roi_head.roi_grid_pool_layers.%d" % i for i in range(3)}
-    assert want <= set(changed), sorted(want - set(changed))
+    expect = {"backbone_2d", "map_to_bev_module", "roi_head.proposal_target_layer", "roi_head.roi_grid_pool",
+              "roi_head.proposal_layer"} | {"roi_head.roi_grid_pool_layers.%d" % i for i in range(3)}
+    assert expect <= set(changed), sorted(expect - set(changed))
     assert type(net.map_to_bev_module).__module__ == "glenet_amd.backbone" and net.map_to_bev_module.defer
     assert type(net.roi_head.proposal_target_layer).__module__ == "glenet_amd.roi_targets"
     assert net.roi_head.__dict__["_glx_pool"].grid_size == 6 and net.roi_head.__dict__["_glx_pool"].num_features == 96
