@@ -31,7 +31,12 @@ def test_unmodified_reference_imports_and_builds_on_the_dropin(tmp_path):
     assert vr["spconv_weight_keys"] == 12 and vr["layout_conversion_by_reference_loader"].startswith("ok")
     assert rep["networks"]["waymo_centerpoint_res"]["spconv_weight_keys"] == 21
     acc = vr["accelerate"]                      # dropin.accelerate(): the reference's BEV backbone on our dense kernels
-    assert acc["modules"] == ["backbone_2d"] and acc["class"] == "glenet_amd.dense_path.BEVBackbone"
+    # round 4: accelerate() also re-classes the reference's HeightCompression, its three NeighborVoxelSAModuleMSG layers and
+    # its ProposalTargetLayer, and binds the head's roi_grid_pool / proposal_layer to the device paths
+    assert acc["modules"] == ["backbone_2d", "map_to_bev_module", "roi_head.proposal_target_layer",
+                              "roi_head.roi_grid_pool_layers.0", "roi_head.roi_grid_pool_layers.1",
+                              "roi_head.roi_grid_pool_layers.2", "roi_head.roi_grid_pool", "roi_head.proposal_layer"]
+    assert acc["class"] == "glenet_amd.dense_path.BEVBackbone"
     assert acc["max_abs_diff_cpu"] < 1e-5
     assert rep["networks"]["glenet_c"]["modules"][-1] == "AnchorHeadKLLabelIoU"
     assert rep["data_processor_voxels"] > 10000
