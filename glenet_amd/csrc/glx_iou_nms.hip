@@ -498,11 +498,15 @@ struct NmsGrid {
   int gx, gy;
 };
 
-__global__ __launch_bounds__(NMS_BIN_THREADS) void k_nms_bins(const PBox* __restrict__ pb, int N,
+// pb_stride: boxes per frame in `pb` (>= N: a launch may cover the leading N boxes of longer lists); done / max_keep: a frame
+// whose earlier pass over a prefix already kept max_keep boxes is skipped (see glx_nms_batch).
+__global__ __launch_bounds__(NMS_BIN_THREADS) void k_nms_bins(const PBox* __restrict__ pb, int N, int pb_stride,
                                                               NmsGrid* __restrict__ grids, int* __restrict__ cell_off,
-                                                              int* __restrict__ order) {
+                                                              int* __restrict__ order, const int* __restrict__ done,
+                                                              int max_keep) {
   const int f = blockIdx.x, tid = threadIdx.x;
-  pb += (long long)f * N;
+  if (done && done[f] >= max_keep) return;
+  pb += (long long)f * pb_stride;
   cell_off += (long long)f * (NMS_GRID * NMS_GRID + 1);
   order += (long long)f * N;
   __shared__ float s_red[5][NMS_BIN_THREADS / 64];
@@ -581,14 +585,16 @@ __global__ __launch_bounds__(NMS_BIN_THREADS) void k_nms_bins(const PBox* __rest
   for (int i = tid; i < N; i += NMS_BIN_THREADS) order[atomicAdd(&s_cnt[cell_of(pb[i])], 1)] = i;
 }
 
-__global__ __launch_bounds__(256) void k_nms_pairs(const PBox* __restrict__ pb, int N, float thresh, int col_blocks,
-                                                   const NmsGrid* __restrict__ grids, const int* __restrict__ cell_off,
-                                                   const int* __restrict__ order,
-                                                   unsigned long long* __restrict__ maskT) {
+__global__ __launch_bounds__(256) void k_nms_pairs(const PBox* __restrict__ pb, int N, int pb_stride, float thresh,
+                                                   int col_blocks, const NmsGrid* __restrict__ grids,
+                                                   const int* __restrict__ cell_off, const int* __restrict__ order,
+                                                   unsigned long long* __restrict__ maskT, const int* __restrict__ done,
+                                                   int max_keep) {
   const int f = blockIdx.y, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= N) return;
-  pb += (long long)f * N;
+  if (done && done[f] >= max_keep) return;
+  pb += (long long)f * pb_stride;
   cell_off += (long long)f * (NMS_GRID * NMS_GRID + 1);
   order += (long long)f * N;
   maskT += (long long)f * N * col_blocks;
@@ -663,6 +669,7 @@ static size_t nms_grid_bytes(int N) {
          glx_align((size_t)(N > 0 ? N : 1) * sizeof(int));
 }
 #define NMS_BROAD_MIN 1024               // below this the tiles are few and the dense matrix is cheaper
+#define NMS_PREFIX 2048                  // leading boxes of the first pass of the early-terminating NMS (glx_nms_batch)
 
 // Greedy sweep of the matrix, 64 boxes per step (host loop of iou3d_nms.cpp:119-132), one block of
 // 256 threads.  The removed-word of column block b is evaluated ON DEMAND: OR over the boxes kept
@@ -672,10 +679,11 @@ static size_t nms_grid_bytes(int N) {
 #define SWEEP_THREADS 1024
 __global__ __launch_bounds__(SWEEP_THREADS) void k_nms_sweep(
     const unsigned long long* __restrict__ maskT, int N, int col_blocks,
-    long long* __restrict__ keep, int* __restrict__ num_out, int max_keep) {
+    long long* __restrict__ keep, int keep_stride, int* __restrict__ num_out, int max_keep, int skip_if_done) {
   maskT += (long long)blockIdx.x * N * col_blocks;               // blockIdx.x = frame
-  keep += (long long)blockIdx.x * N;
+  keep += (long long)blockIdx.x * keep_stride;
   num_out += blockIdx.x;
+  if (skip_if_done && *num_out >= max_keep) return;              // the pass over the prefix has the whole answer already
   extern __shared__ int s_keep[];   // kept boxes so far (the gather list of every later step)
   __shared__ unsigned long long s_part[SWEEP_THREADS / 64];
   __shared__ int s_num;
@@ -748,6 +756,15 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_nms_sweep(
   if (tid == 0) *num_out = s_num;
 }
 
+// zero the suppression matrices of the frames that still need the full pass
+__global__ void k_nms_zero_unless_done(unsigned long long* __restrict__ mask, long long words_per_frame,
+                                       const int* __restrict__ done, int max_keep) {
+  if (done[blockIdx.y] >= max_keep) return;
+  unsigned long long* m = mask + (long long)blockIdx.y * words_per_frame;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < words_per_frame; e += (long long)gridDim.x * blockDim.x)
+    m[e] = 0ull;
+}
+
 static size_t nms_mask_bytes(int N) {
   size_t cb = (size_t)((N + 63) / 64);
   return glx_align((size_t)(N > 0 ? N : 1) * cb * 8);
@@ -795,13 +812,49 @@ extern "C" int glx_nms_batch(const float* boxes_sorted, int frames, int N, float
       NmsGrid* grids = (NmsGrid*)gbase;
       int* cell_off = (int*)(gbase + glx_align((size_t)frames * sizeof(NmsGrid)));
       int* order = cell_off + (size_t)frames * (NMS_GRID * NMS_GRID + 1);
-      GlxFillJob zj{mask, (size_t)frames * (size_t)N * col_blocks * 8, 0};
-      int rc = glx_fill_multi(&zj, 1, st);
-      if (rc != GLX_OK) return rc;
-      hipLaunchKernelGGL(k_nms_bins, dim3(frames), dim3(NMS_BIN_THREADS), 0, st, (const PBox*)pb, N, grids, cell_off,
-                         order);
-      hipLaunchKernelGGL(k_nms_pairs, dim3(glx_divup(N, 4), frames), dim3(256), 0, st, (const PBox*)pb, N, thresh,
-                         col_blocks, (const NmsGrid*)grids, (const int*)cell_off, (const int*)order, mask);
+      // Early termination (max_keep > 0, long lists).  The greedy decision for box i depends on boxes before i only, so
+      // the keep list of the leading N1 boxes is a PREFIX of the full list; when it already holds max_keep boxes -- the
+      // caller wants no more: keep[:NMS_POST_MAXSIZE] of class_agnostic_nms -- the full pass has nothing to add.  Score-
+      // sorted proposal lists end their first 512 survivors early (the bulk of 9000 candidates are background boxes that
+      // rarely suppress one another at 0.8), so: a pass over the first NMS_PREFIX boxes, then the full pass whose every
+      // kernel returns at once for a frame that is done (device-side flag: no read-back, capturable).  Same keep list,
+      // bit for bit, either way; 40 M candidate pairs per frame shrink to 2 M when the prefix suffices.
+      const bool two_stage = max_keep > 0 && N >= 2 * NMS_PREFIX && max_keep <= NMS_PREFIX;
+      static bool sweep_attr = false;
+      if (!sweep_attr) {
+        GLX_HIP(hipFuncSetAttribute((const void*)k_nms_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        sweep_attr = true;
+      }
+      GLX_REQUIRE((size_t)N * 4 <= 150 * 1024, "glx_nms: N = %d exceeds the %d boxes the sweep keeps in LDS", N,
+                  150 * 1024 / 4);
+      if (two_stage) {
+        const int N1 = NMS_PREFIX, cb1 = (N1 + 63) / 64;
+        GlxFillJob zj{mask, (size_t)frames * (size_t)N1 * cb1 * 8, 0};
+        int rc = glx_fill_multi(&zj, 1, st);
+        if (rc != GLX_OK) return rc;
+        hipLaunchKernelGGL(k_nms_bins, dim3(frames), dim3(NMS_BIN_THREADS), 0, st, (const PBox*)pb, N1, N, grids, cell_off,
+                           order, (const int*)nullptr, 0);
+        hipLaunchKernelGGL(k_nms_pairs, dim3(glx_divup(N1, 4), frames), dim3(256), 0, st, (const PBox*)pb, N1, N, thresh,
+                           cb1, (const NmsGrid*)grids, (const int*)cell_off, (const int*)order, mask, (const int*)nullptr, 0);
+        hipLaunchKernelGGL(k_nms_sweep, dim3(frames), dim3(SWEEP_THREADS), (size_t)N1 * 4, st,
+                           (const unsigned long long*)mask, N1, cb1, (long long*)keep, N, num_out, max_keep, 0);
+        hipLaunchKernelGGL(k_nms_zero_unless_done, dim3(256, frames), dim3(256), 0, st, mask, (long long)N * col_blocks,
+                           (const int*)num_out, max_keep);
+      } else {
+        GlxFillJob zj{mask, (size_t)frames * (size_t)N * col_blocks * 8, 0};
+        int rc = glx_fill_multi(&zj, 1, st);
+        if (rc != GLX_OK) return rc;
+      }
+      const int* done = two_stage ? (const int*)num_out : (const int*)nullptr;
+      hipLaunchKernelGGL(k_nms_bins, dim3(frames), dim3(NMS_BIN_THREADS), 0, st, (const PBox*)pb, N, N, grids, cell_off,
+                         order, done, max_keep);
+      hipLaunchKernelGGL(k_nms_pairs, dim3(glx_divup(N, 4), frames), dim3(256), 0, st, (const PBox*)pb, N, N, thresh,
+                         col_blocks, (const NmsGrid*)grids, (const int*)cell_off, (const int*)order, mask, done, max_keep);
+      hipLaunchKernelGGL(k_nms_sweep, dim3(frames), dim3(SWEEP_THREADS), (size_t)N * 4, st,
+                         (const unsigned long long*)mask, N, col_blocks, (long long*)keep, N, num_out,
+                         max_keep > 0 ? max_keep : 0x7fffffff, two_stage ? 1 : 0);
+      GLX_LAUNCH_CHECK();
+      return GLX_OK;
     } else {
       hipLaunchKernelGGL((k_nms_mask<false>), dim3(ntiles, frames), dim3(256), 0, st, boxes_sorted,
                          (const PBox*)pb, N, thresh, col_blocks, mask);
@@ -816,8 +869,8 @@ extern "C" int glx_nms_batch(const float* boxes_sorted, int frames, int N, float
     sweep_attr = true;
   }
   hipLaunchKernelGGL(k_nms_sweep, dim3(frames), dim3(SWEEP_THREADS), (size_t)N * 4, st,
-                     (const unsigned long long*)mask, N, col_blocks, (long long*)keep, num_out,
-                     max_keep > 0 ? max_keep : 0x7fffffff);
+                     (const unsigned long long*)mask, N, col_blocks, (long long*)keep, N, num_out,
+                     max_keep > 0 ? max_keep : 0x7fffffff, 0);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

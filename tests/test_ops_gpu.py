@@ -856,3 +856,35 @@ def test_seed_rois_kernel_equals_the_tensor_statements(dev):
     want_l[:, :G] = torch.where(has[..., 0], gt[:, :, 7].long(), want_l[:, :G])
     _lib.call("glx_seed_rois", rois, labels, gt, off, B, R, 7, G, 8)
     assert torch.equal(rois, want_r) and torch.equal(labels, want_l)
+
+
+def test_nms_early_termination_gives_the_full_sweeps_prefix(dev):
+    """glx_nms_batch with max_keep on long lists (round 4): a pass over the first 2048 boxes, then the full pass whose
+    kernels return at once for frames that already hold max_keep survivors.  Three kinds of frame in one batch -- (0) spread
+    boxes: the prefix suffices; (1) 9000 boxes drawn around 300 clusters: fewer than 512 survive at all, the full pass
+    runs; (2) a list whose first 2048 boxes are near-duplicates of 200 boxes and whose tail is spread: the 512th survivor
+    lies behind the prefix -- every frame's keep[:min(num, 512)] equals the full sweep's and the oracle's."""
+    from glenet_amd.pcdet_ops.iou3d_nms import iou3d_nms_cuda
+    rng = np.random.default_rng(17)
+    n, thr, cap = 9000, 0.8, 512
+
+    def clustered(k, m, jitter):
+        base = synth.random_boxes(rng, k, xy_range=70.0, near_dup=0.0)
+        b = base[rng.integers(0, k, m)].copy()
+        b[:, :2] += rng.normal(0, jitter, (m, 2)).astype(np.float32)
+        b[:, 6] += rng.normal(0, 0.02, m).astype(np.float32)
+        return b
+    f0 = synth.random_boxes(rng, n, xy_range=70.0, near_dup=0.1)
+    f1 = clustered(300, n, 0.03)
+    f2 = np.concatenate([clustered(200, 2048, 0.03), synth.random_boxes(rng, n - 2048, xy_range=70.0, near_dup=0.1)])
+    boxes = np.stack([f0, f1, f2]).astype(np.float32)
+    full_k, full_n = iou3d_nms_cuda.nms_device_batch(T(boxes, dev), thr)
+    cut_k, cut_n = iou3d_nms_cuda.nms_device_batch(T(boxes, dev), thr, max_keep=cap)
+    full_k, full_n, cut_k, cut_n = (t.cpu().numpy() for t in (full_k, full_n, cut_k, cut_n))
+    for f in range(3):
+        want = oracle.nms_sorted(boxes[f], thr)
+        assert full_n[f] == len(want) and np.array_equal(full_k[f, :full_n[f]], want)
+        m = min(cap, len(want))
+        assert cut_n[f] >= m and np.array_equal(cut_k[f, :m], np.asarray(want[:m])), f
+    # the three frames are the three cases
+    assert full_k[0, cap - 1] < 2048 and full_n[1] < cap and full_k[2, cap - 1] >= 2048
