@@ -126,8 +126,8 @@ class VoxelRCNNKLHead(rg.RoIGridPool):
     keep_pooled = False       # tests: leave the pooled features of the last forward in `last_pooled`
     USE_FOLDED = True         # inference: BatchNorm folded into the FC towers
 
-    def forward(self, rois, multi_scale_3d_features, multi_scale_3d_strides, batch_size, raw=False):
-        pooled = super().forward(rois, multi_scale_3d_features, multi_scale_3d_strides, batch_size)
+    def forward(self, rois, multi_scale_3d_features, multi_scale_3d_strides, batch_size, raw=False, pre=None):
+        pooled = super().forward(rois, multi_scale_3d_features, multi_scale_3d_strides, batch_size, pre)
         if self.keep_pooled:
             self.last_pooled = pooled.detach()
         return self.heads(pooled, raw)
@@ -136,6 +136,11 @@ class VoxelRCNNKLHead(rg.RoIGridPool):
 OVERLAP_ROI = os.environ.get("GLX_OVERLAP_ROI", "1") != "0"
 STAGE_CUTS = os.environ.get("GLX_STAGE_CUTS", "1") != "0"
 DEFER_FC_WGRADS = os.environ.get("GLX_DEFER_FC_WGRADS", "1") != "0"
+# First MLP of the three pooling scales on the RoI stream BESIDE the BEV forward (it needs the sparse backbone's output only).
+# Measured in round 4, alternating runs on one box: 7.22 / 7.23 ms per step with it against 7.03 / 7.02 without -- the nine
+# short launches compete with the BEV convolutions that produce the proposals' inputs, and the RoI branch starts later than
+# it gains.  Off by default (GLX_EARLY_MLP_IN=1).
+EARLY_MLP_IN = os.environ.get("GLX_EARLY_MLP_IN", "0") == "1"
 
 
 class StagedLoss:
@@ -299,6 +304,30 @@ class GLENetVR(nn.Module):
                 overlap = False
         if bd.get("stage_cuts") and not overlap:
             raise RuntimeError("the sparse backbone cut its autograd graph for a staged backward that will not run")
+        dev = gt_boxes.device
+        msf, pre = bd["multi_scale_3d_features"], None
+        if overlap:
+            # fork #1, in front of the BEV backbone: the RoI stream cuts the autograd graph at the feature tensors the RoI
+            # grid pools from and runs the first MLP of every pooling scale (it needs the sparse backbone's output only)
+            # WHILE the main stream computes the head maps the proposals need
+            main = torch.cuda.current_stream(dev)
+            key = dev.index if dev.index is not None else torch.cuda.current_device()
+            if key not in self._roi_streams:
+                # default priority: a high-priority stream (like GPU_MAX_HW_QUEUES > 4) doubled the step time
+                self._roi_streams[key] = torch.cuda.Stream(dev)
+            roi_stream = self._roi_streams[key]
+            roi_stream.wait_stream(main)
+            with torch.cuda.stream(roi_stream):
+                msf = dict(msf)
+                for k, st in msf.items():
+                    f = getattr(st, "features", None)
+                    if torch.is_tensor(f) and f.requires_grad:
+                        msf[k] = st.replace_feature(f.detach().requires_grad_(True))
+                        if getattr(st, "clean_rows", False):      # same values: still zeros past `count`
+                            msf[k].clean_rows = True
+                        roi_cuts[k] = (f, msf[k].features)
+                if EARLY_MLP_IN:
+                    pre = self.roi_head.mlp_in_features({n: msf[n] for n in self.roi_head.sources})
         bd = self.dense_head(self.backbone_2d(bd))
         mark("BEV backbone + anchor head fwd")
         if self.mark:        # two boundaries inside backward(): gradient hooks run on the stream of the backward pass
@@ -310,14 +339,7 @@ class GLENetVR(nn.Module):
             stamp_when_grad_arrives(bd.get("spatial_features_1x"), "backward: BEV deblocks + block 2")
             stamp_when_grad_arrives(bev_cut[1] if bev_cut else getattr(enc, "features", None), "backward: BEV backbone")
         anchors = self.anchors(gt_boxes.device)
-        dev = gt_boxes.device
-        if overlap:      # fork: the RoI branch needs the head's predictions and the sparse backbone's features only
-            main = torch.cuda.current_stream(dev)
-            key = dev.index if dev.index is not None else torch.cuda.current_device()
-            if key not in self._roi_streams:
-                # default priority: a high-priority stream (like GPU_MAX_HW_QUEUES > 4) doubled the step time
-                self._roi_streams[key] = torch.cuda.Stream(dev)
-            roi_stream = self._roi_streams[key]
+        if overlap:      # fork #2: the rest of the RoI branch needs the head's predictions
             roi_stream.wait_stream(main)
         with (torch.cuda.stream(roi_stream) if overlap else contextlib.nullcontext()):
             with torch.no_grad():
@@ -345,17 +367,8 @@ class GLENetVR(nn.Module):
                 reg_valid, cls_lab = td["reg_valid_mask"].view(-1), td["rcnn_cls_labels"].view(-1)
                 unc = td["gt_uncertaintys_of_rois"].reshape(-1, 7)
             mark("proposals (NMS) + RoI targets")
-            msf = bd["multi_scale_3d_features"]
-            if overlap:      # ... and at the feature tensors the RoI grid pools from
-                msf = dict(msf)
-                for k, st in msf.items():
-                    f = getattr(st, "features", None)
-                    if torch.is_tensor(f) and f.requires_grad:
-                        msf[k] = st.replace_feature(f.detach().requires_grad_(True))
-                        if getattr(st, "clean_rows", False):      # same values: still zeros past `count`
-                            msf[k].clean_rows = True
-                        roi_cuts[k] = (f, msf[k].features)
-            ori_cls, std_logit, rcnn_reg, rcnn_std = self.roi_head(rois_s, msf, bd["multi_scale_3d_strides"], B, raw=True)
+            ori_cls, std_logit, rcnn_reg, rcnn_std = self.roi_head(rois_s, msf, bd["multi_scale_3d_strides"], B, raw=True,
+                                                                  pre=pre)
             mark("RoI-grid pooling + FC towers fwd")
             w = r["LOSS_WEIGHTS"]
             if ori_cls.is_cuda:      # score rescaling + classification loss + their backward: one launch

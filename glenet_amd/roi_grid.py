@@ -88,13 +88,14 @@ class RoIGridPool(nn.Module):
         r, v = self.point_cloud_range, self.voxel_size
         return torch.stack([(roi_grid_xyz[..., i] - r[i]) // v[i] for i in range(3)], dim=-1)
 
-    def forward(self, rois, multi_scale_3d_features, multi_scale_3d_strides, batch_size):
-        """rois (B, R, 7+) -> (B*R, G^3, sum C_out)."""
+    def forward(self, rois, multi_scale_3d_features, multi_scale_3d_strides, batch_size, pre=None):
+        """rois (B, R, 7+) -> (B*R, G^3, sum C_out).  pre: the result of mlp_in_features() on the same tensors (training
+        path only): the first MLP of every scale computed ahead of the proposals."""
         B = batch_size
         if self._fusable(rois, multi_scale_3d_features):
             return self._forward_fused(rois, multi_scale_3d_features, multi_scale_3d_strides, B)
         if self._trainable_rows(rois, multi_scale_3d_features):
-            return self._forward_rows(rois, multi_scale_3d_features, multi_scale_3d_strides, B)
+            return self._forward_rows(rois, multi_scale_3d_features, multi_scale_3d_strides, B, pre)
         grid_xyz, _ = global_grid_points_of_roi(rois, self.grid_size)           # (B*R, G^3, 3)
         grid_xyz = grid_xyz.reshape(B, -1, 3)
         coords1 = self.grid_coords(grid_xyz)                                      # (B, R*G^3, 3) float
@@ -159,7 +160,22 @@ class RoIGridPool(nn.Module):
             raise NotImplementedError("shape-static training needs the fused BatchNorm kernels")
         return layer._bn_rows(seq, y)
 
-    def _forward_rows(self, rois, tensors, strides, B):
+    def mlp_in_features(self, tensors):
+        """The first MLP (1x1 conv + BatchNorm) of every pooling scale on the sparse tensors' features: it depends on the
+        backbone's output only, not on the RoIs, so a training step runs it on the RoI stream WHILE the BEV backbone
+        computes the proposals' inputs (glenet_vr.GLENetVR.second_stage_losses) -- nine launches off the RoI branch's
+        critical path.  None when the row-major training path does not apply."""
+        probe = next(iter(tensors.values())).features
+        if not (self.USE_ROWS and probe.is_cuda and probe.dtype == torch.float32 and torch.is_grad_enabled()):
+            return None
+        for layer, name in zip(self.roi_grid_pool_layers, self.sources):
+            st = tensors[name]
+            if layer.pool_method != "max_pool" or (st.count is not None and st._index is None):
+                return None
+        return {name: [self._mlp_in_rows(layer, mlp_in, tensors[name]) for mlp_in in layer.mlps_in]
+                for layer, name in zip(self.roi_grid_pool_layers, self.sources)}
+
+    def _forward_rows(self, rois, tensors, strides, B, pre=None):
         import ctypes
         from . import _lib
         GroupRows, ReluAddMax = voxel_pool_modules.GroupRows, voxel_pool_modules.ReluAddMax
@@ -193,9 +209,9 @@ class RoIGridPool(nn.Module):
             stride = int(strides[name])
             xyz = torch.empty((ind.shape[0], 3), dtype=torch.float32, device=dev)           # get_voxel_centers
             _lib.call("glx_voxel_centers", ind, ind.shape[0], stride, rmin, vsz, xyz)
-            for grouper, mlp_in, mlp_pos, mlp_out in zip(layer.groupers, layer.mlps_in, layer.mlps_pos,
-                                                         layer.mlps_out):
-                feats = self._mlp_in_rows(layer, mlp_in, st)                       # (N, c_mid)
+            for j, (grouper, mlp_in, mlp_pos, mlp_out) in enumerate(zip(layer.groupers, layer.mlps_in, layer.mlps_pos,
+                                                                        layer.mlps_out)):
+                feats = pre[name][j] if pre is not None else self._mlp_in_rows(layer, mlp_in, st)   # (N, c_mid)
                 ns = grouper.nsample
                 idx = torch.empty((m, ns), dtype=torch.int32, device=dev)
                 zr, yr, xr = grouper.max_range
