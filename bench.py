@@ -413,8 +413,8 @@ def bench_dropin(state, K, pool, dev, steps=12):
 def bench_config3(dev, objects=4096, points=512, samples=30):
     """BASELINE configs[3]: the CVAE on 4096 object crops x 512 points -- (i) the inference sampler, 30 latent samples
     per object (fused MFMA PointNet kernel, csrc/glx_pointnet.hip), (ii) one TRAINING step forward + backward + clip +
-    AdamW (glenet_amd.cvae_train.CVAETrainStep, one HIP graph; at this size -- 2.1 M point rows -- the extractors run
-    as the reference's (B, C, P) Conv1d + BatchNorm1d modules on MIOpen / hipBLASLt, see PointFeat.ROWS_MAX)."""
+    AdamW (glenet_amd.cvae_train.CVAETrainStep, one HIP graph; the extractors run on the 2.1 M point rows as row GEMMs +
+    the fused training BatchNorm, PointFeat._forward_train_rows)."""
     import torch
     from glenet_amd import cvae_train as ct
     from glenet_amd import dense_path as dp

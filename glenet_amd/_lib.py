@@ -204,12 +204,79 @@ KEEP_GRAPH_EXECS = os.environ.get("GLX_KEEP_GRAPH_EXECS", "1") != "0"
 _graph_execs = []
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Memset nodes.  On ROCm 7.2 a hipMemsetAsync RECORDED into a graph fills its buffer with the requested value on the first
+# launch of the graph and with a stale 16-byte pattern (host pointers by the look of them) on every later launch
+# (tools/graph_memset_repro.py, 40 lines, torch + ctypes only; profiles/r04_graph_memset_repro.txt).  Whatever zeroes scratch
+# memory with a memset in front of a kernel is therefore wrong from the second replay on -- this is what turned the recorded
+# CVAE training step's gradients into NaN (torch's multi-block reductions zero their semaphores that way,
+# tools/graph_reduce_repro.py).  Own kernels never use memsets (glx_fill_multi is a kernel); library calls inside a recorded
+# step may.  AUDIT_GRAPHS (default on): graphs are created with keep_graph=True and `audit_graph` counts the node types of
+# what was recorded; pipelines call it after capture and report / refuse memset nodes (see backbone.StaticFramePipeline).
+AUDIT_GRAPHS = os.environ.get("GLX_AUDIT_GRAPHS", "1") != "0"
+_HIP_NODE_TYPES = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event", 7: "event_record",
+                   8: "ext_semaphore_signal", 9: "ext_semaphore_wait", 10: "mem_alloc", 11: "mem_free", 12: "memcpy_from_symbol",
+                   13: "memcpy_to_symbol"}
+
+
+class _MemsetParams(ctypes.Structure):
+    _fields_ = [("dst", c_void_p), ("elementSize", ctypes.c_uint), ("height", c_size_t), ("pitch", c_size_t),
+                ("value", ctypes.c_uint), ("width", c_size_t)]
+
+
 def new_graph():
-    """torch.cuda.CUDAGraph() whose exec outlives its owner (see above)."""
-    g = torch.cuda.CUDAGraph()
+    """torch.cuda.CUDAGraph() whose exec outlives its owner (see above); with AUDIT_GRAPHS the hipGraph_t is kept so that
+    audit_graph() can look at what was recorded."""
+    try:
+        g = torch.cuda.CUDAGraph(keep_graph=True) if AUDIT_GRAPHS else torch.cuda.CUDAGraph()
+    except TypeError:                                   # a torch without keep_graph
+        g = torch.cuda.CUDAGraph()
     if KEEP_GRAPH_EXECS:
         _graph_execs.append(g)
     return g
+
+
+def finish_graph(graph):
+    """Call right after a capture into a graph from new_graph(): replaces the memset nodes of what was recorded by fill-kernel
+    nodes (ROCm 7.2 replays memset nodes with a stale pattern, csrc/glx_graph.hip) and instantiates the graph.  Returns the
+    number of memset nodes replaced (None: the raw graph is not available, nothing was changed)."""
+    try:
+        raw = graph.raw_cuda_graph()
+    except Exception:
+        return None
+    n = c_int(0)
+    call_nostream("glx_graph_replace_memsets", c_void_p(raw), ctypes.byref(n))
+    graph.instantiate()
+    return n.value
+
+
+def audit_graph(graph):
+    """{node type: count} of a captured torch.cuda.CUDAGraph created by new_graph(), plus "memset_bytes": the sizes of its
+    memset nodes; None when the raw graph is not available (AUDIT_GRAPHS off)."""
+    try:
+        raw = graph.raw_cuda_graph()
+    except Exception:
+        return None
+    hip = ctypes.CDLL("libamdhip64.so")
+    n = c_size_t(0)
+    if hip.hipGraphGetNodes(c_void_p(raw), None, ctypes.byref(n)) != 0 or n.value == 0:
+        return {} if n.value == 0 else None
+    nodes = (c_void_p * n.value)()
+    if hip.hipGraphGetNodes(c_void_p(raw), nodes, ctypes.byref(n)) != 0:
+        return None
+    out, sizes = {}, []
+    for node in nodes:
+        t = ctypes.c_int(-1)
+        hip.hipGraphNodeGetType(c_void_p(node), ctypes.byref(t))
+        name = _HIP_NODE_TYPES.get(t.value, "type_%d" % t.value)
+        out[name] = out.get(name, 0) + 1
+        if name == "memset":
+            p = _MemsetParams()
+            if hip.hipGraphMemsetNodeGetParams(c_void_p(node), ctypes.byref(p)) == 0:
+                sizes.append(int(p.width) * max(int(p.height), 1) * max(int(p.elementSize), 1) if p.height > 1 else int(p.width) * max(int(p.elementSize), 1))
+    if sizes:
+        out["memset_bytes"] = sorted(sizes)
+    return out
 
 
 class Workspace:

@@ -348,6 +348,7 @@ class StaticFramePipeline:
         self.graph = _lib.new_graph()
         with torch.cuda.graph(self.graph, stream=side, pool=pool), no_gc():
             self.enqueue()
+        self.memsets_replaced = _lib.finish_graph(self.graph)       # ROCm 7.2: memset nodes replay a stale pattern
         self._tag = self._weights_tag()
         return self
 

@@ -78,6 +78,7 @@ class CVAETrainStep:
         self.graph = _lib.new_graph()
         with torch.cuda.graph(self.graph, stream=side), no_gc():
             self.enqueue()
+        self.memsets_replaced = _lib.finish_graph(self.graph)       # ROCm 7.2: memset nodes replay a stale pattern
         torch.cuda.synchronize(dev)
         with torch.no_grad():
             for t, s in zip(state, snap):

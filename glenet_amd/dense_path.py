@@ -762,13 +762,10 @@ class PointFeat(nn.Module):
     def _rows_trainable(self, x):
         from .spconv import core
         ok = lambda c: c % 4 == 0 and c <= 512 and 1024 % c == 0                                # noqa: E731
-        # beyond ROWS_MAX rows the extractor stays on the reference's (B, C, P) modules: at BASELINE configs[3]'s
-        # 4096 x 512 = 2.1 M rows the RECORDED step returned NaN gradients from its third replay on (and, with an
-        # index-based max in place of amax, a GPU memory fault) whichever BatchNorm (ours / torch's) and GEMM form
-        # (F.linear / batched) ran on the rows, for the wide extractors (4.3 GB matrices) and for the narrow one alone
-        # (67 MB) -- eager launches of the very same ops were fine, as was the (B, C, P) form recorded.  Unexplained
-        # (tools/cvae_nan_probe2.py holds the bisection; DESIGN.md section 3, "CVAE training step"); the row form is
-        # pinned by tests up to 32 K rows and not used where it was seen to fail.
+        # ROWS_MAX: a switch back to the reference's (B, C, P) modules for very tall inputs.  Rounds 2-3 kept the row form
+        # below 1 M rows because the RECORDED step returned NaN gradients at configs[3]'s 2.1 M rows; that was ROCm 7.2
+        # replaying recorded memset nodes (torch's reductions zero their semaphores with one) with a stale pattern, which
+        # _lib.finish_graph now removes from every recorded step (csrc/glx_graph.hip).
         if x.shape[0] * x.shape[2] > self.ROWS_MAX:
             return False
         return (x.is_cuda and self.training and torch.is_grad_enabled() and x.dtype == torch.float32
@@ -776,15 +773,13 @@ class PointFeat(nn.Module):
                                                     for m in (self.bn1, self.bn2, self.bn3)))
 
     ROW_CHUNKS = 128
-    ROWS_MAX = 1 << 20
+    ROWS_MAX = int(os.environ.get("GLX_CVAE_ROWS_MAX", 1 << 22))
 
     @classmethod
     def _rows_linear(cls, x2d, conv):
         """x2d (rows, C_in) @ W^T + b as ROW_CHUNKS batched products when the matrix is tall: the weight gradient
         autograd derives is then a batched GEMM + a sum over the batch (split-K) instead of ONE (C_out x C_in) GEMM
-        with K = rows -- at 2.1 M rows the library's own choice for that shape is both slow and, replayed inside a HIP
-        graph, returned NaN gradients (tools/cvae_nan_probe2.py: eager fine, torch BatchNorm on the same rows not
-        fine, the batched form fine -- so not our kernels; recorded in DESIGN.md section 3)."""
+        with K = rows, for which the library's own choice at 2.1 M rows is slow."""
         w, rows = conv.weight[:, :, 0], x2d.shape[0]
         s_ = cls.ROW_CHUNKS
         if rows % s_ == 0 and rows // s_ >= 64:

@@ -661,6 +661,7 @@ class StaticTrainStep(gb.StaticTrainPipeline):
             self.update_graph = gb._lib.new_graph()
             with torch.cuda.graph(self.update_graph, stream=side), gb.no_gc():
                 self.update()
+            gb._lib.finish_graph(self.update_graph)
         return self
 
     def enqueue_eager_marked(self):

@@ -84,6 +84,12 @@ typedef struct glx_conv_opts {
   const glx_epilogue* epilogue;
 } glx_conv_opts;
 
+/* ROCm 7.2 workaround (csrc/glx_graph.hip): a hipMemsetAsync recorded into a HIP graph is replayed with a stale pattern from
+ * the graph's second launch on (tools/graph_memset_repro.py).  Replaces every memset node of a CAPTURED, not yet instantiated
+ * hipGraph_t by a kernel node doing the same fill (same dependencies and dependents); *n_replaced (host, may be NULL) =
+ * how many.  No reference counterpart: the reference records no graphs. */
+int glx_graph_replace_memsets(void* graph, int* n_replaced);
+
 /* HIP events for kernel-only timing (bench.py); glx_event_elapsed_ms blocks until `stop`. */
 int glx_event_create(void** event);
 int glx_event_destroy(void* event);
