@@ -103,7 +103,7 @@ class SparseBackbone8x(nn.Module):
         self.backbone_channels = {"x_conv1": 16, "x_conv2": 32, "x_conv3": 64,
                                   "x_conv4": cfg["stages"][-1][1]}
 
-    def plan(self, voxel_coords, batch_size, index=None, capacities=None, events=False):
+    def plan(self, voxel_coords, batch_size, index=None, capacities=None, events=False, pair_lists=False):
         """Build every rule table of the backbone from the coordinates alone (they do not depend
         on features), so the convolutions afterwards run back to back without host syncs.
         Returns the indice_dict to pass as batch_dict["rule_plan"].  With a shape-static index
@@ -111,7 +111,7 @@ class SparseBackbone8x(nn.Module):
         count = index.count if index is not None else None
         return spconv.core.plan_rules(voxel_coords.int(), self.sparse_shape, batch_size,
                                       list(self.sparse_convs()) + list(self.extra_plan), index=index, count=count,
-                                      capacities=capacities, events=events)
+                                      capacities=capacities, events=events, pair_lists=pair_lists)
 
     def forward(self, batch_dict):
         index = batch_dict.get("voxel_index")
@@ -503,10 +503,10 @@ class StaticTrainPipeline(StaticFramePipeline):
                     self.plan_stream.wait_stream(cur)
                     with torch.cuda.stream(self.plan_stream):
                         plan = self.model.plan(bd["voxel_coords"], self.B, index=bd["voxel_index"],
-                                               capacities=self.capacities, events=True)
+                                               capacities=self.capacities, events=True, pair_lists=True)
                 else:
                     plan = self.model.plan(bd["voxel_coords"], self.B, index=bd["voxel_index"],
-                                           capacities=self.capacities)
+                                           capacities=self.capacities, pair_lists=True)
                 bd = self.vfe(bd)
             if self.mark:
                 self.mark("voxelize + MeanVFE")

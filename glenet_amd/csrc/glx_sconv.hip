@@ -2345,6 +2345,359 @@ __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_mfma(
   }
 }
 
+// ------------------------------------------------------------------ weight gradient over per-offset PAIR LISTS
+// What the (slice, k) grid above costs on the wide layers was measured in round 4 with a (row slab, offset group) variant
+// and its ablations (tools/wgrad_sweep.py, profiles/r04_wgrad.md): scanning the K-strided column of the rule table and
+// compacting it in every block is 23 us of a 76 us call, the gathers 9, the multiply 34 (its fp32-MFMA floor is 26), the slab
+// sums 10 -- and the parts ADD UP, because a block that owns rows x offset holds one or two panels of pairs and never
+// reaches a steady state, while the centre offset of a submanifold table carries 3-4 x the pairs of any other.
+// Here the rule table is turned into what the contraction actually runs over, once per table and shared by the
+// convolutions that walk it: per offset the list of (input row, output row) pairs in ascending output-row order
+// (k_pairs_count / k_pairs_emit -- spconv's own "indice pairs").  The weight gradient then splits every offset's list into
+// chunks of CH pairs, CH chosen ON THE DEVICE from the table's pair count so that the chunks fill the chip once
+// (<= WGP_CHUNKS + K of them): a block takes a chunk, copies its <= 1024 index pairs into LDS with one coalesced read, and
+// streams panels of 32 pairs through a double-buffered LDS stage -- rows gathered two panels ahead into registers, one
+// barrier per panel, dW[k] (Cin x Cout) in the MFMA accumulators for the whole chunk.  One slab per chunk, summed per
+// offset in chunk order by k_wgrad_pairs_reduce: fixed summation order, bitwise reproducible.
+#define WGP_CHUNKS 720                  // target number of chunks (3 resident blocks per CU x 256 CUs, minus the K ragged tails)
+#define WGP_MAXCH 1024                  // pairs per chunk at most (the LDS index lists)
+#define WGP_MINCH 128
+#define WGP_PANEL 32
+#define WGP_ROWS 256                    // rows per block of the list builders
+
+struct PairMeta {                       // head of a pair-list buffer (device)
+  int poff[SC_MAXK + 1];                // start of offset k's list in pair_in / pair_out
+  int coff[SC_MAXK + 1];                // first chunk of offset k
+  int ch;                               // pairs per chunk
+  int pad[7];
+};
+
+static size_t pair_lists_layout(int N_out, int K, size_t* off_cnt, size_t* off_in, size_t* off_out) {
+  const size_t nb = (size_t)glx_divup(N_out > 0 ? N_out : 1, WGP_ROWS);
+  size_t o = glx_align(sizeof(PairMeta));
+  *off_cnt = o; o += glx_align((size_t)K * nb * sizeof(int));
+  *off_in = o;  o += glx_align((size_t)(N_out > 0 ? N_out : 1) * K * sizeof(int));
+  *off_out = o; o += glx_align((size_t)(N_out > 0 ? N_out : 1) * K * sizeof(int));
+  return o;
+}
+
+extern "C" size_t glx_pair_lists_bytes(int N_out, int K) {
+  size_t a, b, c;
+  return pair_lists_layout(N_out, K, &a, &b, &c);
+}
+
+// The rule entries of rows [row0, row0 + 256) transposed into LDS: s_t[k * 256 + r] (rows past n are -1).
+__device__ __forceinline__ void pairs_load_block(const int* __restrict__ nbr, int n, int K, int row0, int* s_t) {
+  const long long base = (long long)row0 * K;
+  const int total = min(WGP_ROWS, n - row0) * K;
+  for (int e = threadIdx.x; e < WGP_ROWS * K; e += WGP_ROWS) {
+    const int r = e / K, k = e - r * K;
+    s_t[k * WGP_ROWS + r] = e < total ? nbr[base + e] : -1;
+  }
+}
+
+__global__ __launch_bounds__(WGP_ROWS) void k_pairs_count(const int* __restrict__ nbr, int N_out, int K,
+                                                          const int* __restrict__ n_live, int* __restrict__ blkcnt) {
+  const int n = n_live ? min(N_out, *n_live) : N_out;
+  const int nb = gridDim.x, b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ int s_t[SC_MAXK * WGP_ROWS];
+  if (b * WGP_ROWS >= n) {                                   // past the live rows: no pairs
+    if ((int)threadIdx.x < K) blkcnt[threadIdx.x * nb + b] = 0;
+    return;
+  }
+  pairs_load_block(nbr, n, K, b * WGP_ROWS, s_t);
+  __syncthreads();
+  for (int k = wave; k < K; k += WGP_ROWS / 64) {
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < WGP_ROWS / 64; ++q) c += __popcll(__ballot(s_t[k * WGP_ROWS + q * 64 + lane] >= 0));
+    if (lane == 0) blkcnt[k * nb + b] = c;
+  }
+}
+
+__global__ __launch_bounds__(WGP_ROWS) void k_pairs_emit(const int* __restrict__ nbr, int N_out, int K,
+                                                         const int* __restrict__ n_live, const int* __restrict__ blkcnt,
+                                                         PairMeta* __restrict__ meta, int* __restrict__ pair_in,
+                                                         int* __restrict__ pair_out) {
+  const int n = n_live ? min(N_out, *n_live) : N_out;
+  const int nb = gridDim.x, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ int s_t[SC_MAXK * WGP_ROWS];
+  __shared__ int s_tot[SC_MAXK + 1], s_mine[SC_MAXK], s_off[SC_MAXK + 1];
+  // totals of every offset and this block's start inside each list: every block sums the (K x nb) counts on its own --
+  // a few thousand L2-resident ints -- which saves a scan launch between the two passes
+  for (int k = wave; k < K; k += WGP_ROWS / 64) {
+    int tot = 0, mine = 0;
+    for (int i = lane; i < nb; i += 64) {
+      const int c = blkcnt[k * nb + i];
+      tot += c;
+      mine += i < b ? c : 0;
+    }
+    tot = glx_wave_sum(tot);
+    mine = glx_wave_sum(mine);
+    if (lane == 0) { s_tot[k] = tot; s_mine[k] = mine; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int k = 0; k < K; ++k) { s_off[k] = run; run += s_tot[k]; }
+    s_off[K] = run;
+    if (b == 0) {
+      int ch = ((run + WGP_CHUNKS - 1) / WGP_CHUNKS + WGP_PANEL - 1) / WGP_PANEL * WGP_PANEL;
+      ch = max(WGP_MINCH, min(WGP_MAXCH, ch));
+      int crun = 0;
+      for (int k = 0; k < K; ++k) { meta->poff[k] = s_off[k]; meta->coff[k] = crun; crun += (s_tot[k] + ch - 1) / ch; }
+      for (int k = K; k <= SC_MAXK; ++k) { meta->poff[k] = run; meta->coff[k] = crun; }
+      meta->ch = ch;
+    }
+  }
+  if (b * WGP_ROWS >= n) return;
+  pairs_load_block(nbr, n, K, b * WGP_ROWS, s_t);
+  __syncthreads();
+  for (int k = wave; k < K; k += WGP_ROWS / 64) {
+    int pos = s_off[k] + s_mine[k];
+#pragma unroll
+    for (int q = 0; q < WGP_ROWS / 64; ++q) {
+      const int r = q * 64 + lane;
+      const int i = s_t[k * WGP_ROWS + r];
+      const unsigned long long bal = __ballot(i >= 0);
+      if (i >= 0) {
+        const int p = pos + __popcll(bal & ((1ull << lane) - 1ull));
+        pair_in[p] = i;
+        pair_out[p] = b * WGP_ROWS + r;
+      }
+      pos += __popcll(bal);
+    }
+  }
+}
+
+extern "C" int glx_pair_lists_build(const int32_t* nbr, int N_out, int K, const int32_t* n_live, void* lists,
+                                    size_t lists_bytes, void* stream) {
+  GLX_REQUIRE(lists && (N_out == 0 || nbr), "glx_pair_lists_build: null pointer");
+  GLX_REQUIRE(K >= 1 && K <= SC_MAXK, "glx_pair_lists_build: K=%d", K);
+  size_t oc, oi, oo;
+  const size_t need = pair_lists_layout(N_out, K, &oc, &oi, &oo);
+  GLX_REQUIRE(lists_bytes >= need, "glx_pair_lists_build: buffer %zu < %zu bytes", lists_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  char* base = (char*)lists;
+  const int nb = glx_divup(N_out > 0 ? N_out : 1, WGP_ROWS);
+  hipLaunchKernelGGL(k_pairs_count, dim3(nb), dim3(WGP_ROWS), 0, st, nbr, N_out, K, n_live, (int*)(base + oc));
+  hipLaunchKernelGGL(k_pairs_emit, dim3(nb), dim3(WGP_ROWS), 0, st, nbr, N_out, K, n_live, (const int*)(base + oc),
+                     (PairMeta*)base, (int*)(base + oi), (int*)(base + oo));
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+template <int CIN, int COUT>
+struct WgradPairsCfg {
+  using C = WgradCfg<CIN, COUT>;
+  static constexpr int A_LD = C::A_LD, B_LD = C::B_LD;
+  static constexpr size_t lds_bytes = (size_t)2 * WGP_PANEL * (A_LD + B_LD) * 4 + (size_t)WGP_MAXCH * 8 + sizeof(PairMeta) + 64;
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(WGM_THREADS) void k_wgrad_pairs(
+    const float* __restrict__ in, const float* __restrict__ gout, const PairMeta* __restrict__ meta,
+    const int* __restrict__ pair_in, const int* __restrict__ pair_out, int K, float* __restrict__ slabs) {
+  using T = WgradCfg<CIN, COUT>;
+  constexpr int A_LD = T::A_LD, B_LD = T::B_LD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_a = smem;                                           // 2 x WGP_PANEL * A_LD   (input rows)
+  float* s_b = s_a + 2 * WGP_PANEL * A_LD;                     // 2 x WGP_PANEL * B_LD   (grad rows)
+  int* s_pi = reinterpret_cast<int*>(s_b + 2 * WGP_PANEL * B_LD);   // WGP_MAXCH input rows of the chunk's pairs
+  int* s_pj = s_pi + WGP_MAXCH;                                     // WGP_MAXCH output rows
+  PairMeta* s_meta = reinterpret_cast<PairMeta*>(s_pj + WGP_MAXCH);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, kk = lane >> 4;
+  for (int e = tid; e < (int)(sizeof(PairMeta) / 4); e += WGM_THREADS)
+    reinterpret_cast<int*>(s_meta)[e] = reinterpret_cast<const int*>(meta)[e];
+  if constexpr (T::CINP != CIN) {                              // the padding channels stay zero for the whole kernel
+    for (int e = tid; e < 2 * WGP_PANEL * A_LD; e += WGM_THREADS) s_a[e] = 0.f;
+  }
+  __syncthreads();
+  const int n_chunks = s_meta->coff[K], CH = s_meta->ch;
+
+  constexpr int SEG_A = CIN / 4, SEG_B = COUT / 4;
+  constexpr int RA = (WGP_PANEL * SEG_A + WGM_THREADS - 1) / WGM_THREADS;
+  constexpr int RB = (WGP_PANEL * SEG_B + WGM_THREADS - 1) / WGM_THREADS;
+  f32x4 acc[T::TPW];
+  // one panel = 8 MFMA steps of 4 pairs; all its operand reads are issued before the first MFMA (see k_wgrad_mfma)
+  auto multiply = [&](int buf) {
+    const float* pa = s_a + buf * WGP_PANEL * A_LD;
+    const float* pb = s_b + buf * WGP_PANEL * B_LD;
+    float av[8][T::TPW], bv[8][T::TPW];
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4) {
+      const float* ar = pa + (4 * s4 + kk) * A_LD + n;
+      const float* br = pb + (4 * s4 + kk) * B_LD + n;
+#pragma unroll
+      for (int u = 0; u < T::TPW; ++u) {
+        const int t = wave + 4 * u;
+        av[s4][u] = bv[s4][u] = 0.f;
+        if (T::TILES % 4 == 0 || t < T::TILES) {
+          const int mi = t / T::NI, ni = t - mi * T::NI;
+          av[s4][u] = ar[mi * 16];
+          if (4 % T::NI != 0 || u == 0) bv[s4][u] = br[ni * 16];   // NI | 4: every tile of a wave shares ni
+          else bv[s4][u] = bv[s4][0];
+        }
+      }
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4) {
+#pragma unroll
+      for (int u = 0; u < T::TPW; ++u) {
+        const int t = wave + 4 * u;
+        if (T::TILES % 4 == 0 || t < T::TILES)
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4][u], bv[s4][u], acc[u], 0, 0, 0);
+      }
+    }
+  };
+  // rows of panel p (pairs [32 p, 32 p + 32) of the chunk's np pairs) -> registers.  Branch-free: a pair past the chunk's
+  // end reads the chunk's first pair and is zeroed when it is staged -- with conditional loads the compiler cannot count
+  // the loads in flight and waits for ALL of them (vmcnt(0)) where only the older register set is needed
+  auto gather = [&](int p, int np, f32x4 (&ra)[RA], f32x4 (&rb)[RB]) {
+#pragma unroll
+    for (int it = 0; it < RA; ++it) {
+      const int e = tid + it * WGM_THREADS, pr = e / SEG_A, sg = e - pr * SEG_A;
+      const int q = p * WGP_PANEL + pr;
+      ra[it] = *reinterpret_cast<const f32x4*>(in + (long long)s_pi[(pr < WGP_PANEL && q < np) ? q : 0] * CIN + sg * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < RB; ++it) {
+      const int e = tid + it * WGM_THREADS, pr = e / SEG_B, sg = e - pr * SEG_B;
+      const int q = p * WGP_PANEL + pr;
+      rb[it] = *reinterpret_cast<const f32x4*>(gout + (long long)s_pj[(pr < WGP_PANEL && q < np) ? q : 0] * COUT + sg * 4);
+    }
+  };
+  auto stage = [&](int buf, int p, int np, const f32x4 (&ra)[RA], const f32x4 (&rb)[RB]) {
+    float* pa = s_a + buf * WGP_PANEL * A_LD;
+    float* pb = s_b + buf * WGP_PANEL * B_LD;
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < RA; ++it) {
+      const int e = tid + it * WGM_THREADS, pr = e / SEG_A, sg = e - pr * SEG_A;
+      if (pr < WGP_PANEL) *reinterpret_cast<f32x4*>(pa + pr * A_LD + sg * 4) = p * WGP_PANEL + pr < np ? ra[it] : zero;
+    }
+#pragma unroll
+    for (int it = 0; it < RB; ++it) {
+      const int e = tid + it * WGM_THREADS, pr = e / SEG_B, sg = e - pr * SEG_B;
+      if (pr < WGP_PANEL) *reinterpret_cast<f32x4*>(pb + pr * B_LD + sg * 4) = p * WGP_PANEL + pr < np ? rb[it] : zero;
+    }
+  };
+
+#pragma unroll 1
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    int k = 0;
+    while (s_meta->coff[k + 1] <= c) ++k;                      // block-uniform: <= K steps
+    const int p_lo = s_meta->poff[k] + (c - s_meta->coff[k]) * CH;
+    const int np = min(CH, s_meta->poff[k + 1] - p_lo);        // >= 1 by construction of coff
+    __syncthreads();                                           // the previous chunk's lists and panels are done with
+    for (int e = tid; e < np; e += WGM_THREADS) {
+      s_pi[e] = pair_in[p_lo + e];
+      s_pj[e] = pair_out[p_lo + e];
+    }
+#pragma unroll
+    for (int u = 0; u < T::TPW; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const int npan = (np + WGP_PANEL - 1) / WGP_PANEL;
+    f32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];
+    gather(0, np, ra0, rb0);
+    gather(1, np, ra1, rb1);
+    stage(0, 0, np, ra0, rb0);
+    __syncthreads();
+    // panel p is in LDS buffer p & 1, panel p + 1 in flight in one register set; the other set takes panel p + 2
+#pragma unroll 1
+    for (int p = 0; p < npan; p += 2) {
+      gather(p + 2, np, ra0, rb0);
+      multiply(0);
+      stage(1, p + 1, np, ra1, rb1);
+      __syncthreads();
+      if (p + 1 >= npan) break;
+      gather(p + 3, np, ra1, rb1);
+      multiply(1);
+      stage(0, p + 2, np, ra0, rb0);
+      __syncthreads();
+    }
+    float* dst = slabs + (long long)c * (CIN * COUT);          // this chunk's partial dW[k], (Cin, Cout) row-major
+#pragma unroll
+    for (int u = 0; u < T::TPW; ++u) {
+      const int t = wave + 4 * u;
+      if (T::TILES % 4 == 0 || t < T::TILES) {
+        const int mi = t / T::NI, ni = t - mi * T::NI;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (T::CINP == CIN || mi * 16 + 4 * kk + e < CIN)
+            dst[(mi * 16 + 4 * kk + e) * COUT + ni * 16 + n] = acc[u][e];
+      }
+    }
+  }
+}
+
+// dW[k][e] = sum of the slabs of offset k's chunks, in chunk order (an offset without pairs has no chunk: zero).
+__global__ void k_wgrad_pairs_reduce(const float* __restrict__ slabs, const PairMeta* __restrict__ meta, int nel,
+                                     float* __restrict__ dW) {
+  const int k = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nel) return;
+  const int c0 = meta->coff[k], c1 = meta->coff[k + 1];
+  float s = 0.f;
+  int c = c0;
+  for (; c + 8 <= c1; c += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = slabs[(long long)(c + u) * nel + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; c < c1; ++c) s += slabs[(long long)c * nel + e];
+  dW[(long long)k * nel + e] = s;
+}
+
+extern "C" size_t glx_sconv_wgrad_pairs_workspace_bytes(int N_out, int K, int Cin, int Cout) {
+  // chunks <= pairs / CH + K with CH >= max(WGP_MINCH, pairs / WGP_CHUNKS), capped at WGP_MAXCH for very large tables
+  const long long cap = (long long)(N_out > 0 ? N_out : 1) * K;
+  long long chunks = WGP_CHUNKS + K;
+  if (cap / WGP_MAXCH + K > chunks) chunks = cap / WGP_MAXCH + K;
+  return glx_align((size_t)chunks * Cin * Cout * sizeof(float)) + 256;
+}
+
+extern "C" int glx_sconv_wgrad_pairs(const float* in, const float* grad_out, const void* lists, int N_out, int K,
+                                     int Cin, int Cout, float* dW, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  GLX_REQUIRE(dW && lists && workspace && (N_out == 0 || (in && grad_out)), "glx_sconv_wgrad_pairs: null pointer");
+  GLX_REQUIRE(K >= 1 && K <= SC_MAXK, "glx_sconv_wgrad_pairs: K=%d", K);
+  const size_t need = glx_sconv_wgrad_pairs_workspace_bytes(N_out, K, Cin, Cout) - 256;
+  if (workspace_bytes < need) {
+    glx_set_error("glx_sconv_wgrad_pairs: workspace %zu < %zu bytes", workspace_bytes, need);
+    return GLX_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  size_t oc, oi, oo;
+  pair_lists_layout(N_out, K, &oc, &oi, &oo);
+  const char* base = (const char*)lists;
+  const long long cap = (long long)(N_out > 0 ? N_out : 1) * K;
+  long long grid = WGP_CHUNKS + K;
+  if (cap / WGP_MINCH + K < grid) grid = cap / WGP_MINCH + K;
+  int rc = sc_dispatch(Cin, Cout, [&](auto ci, auto co) {
+    constexpr int CI = decltype(ci)::value, CO = decltype(co)::value;
+    using T = WgradPairsCfg<CI, CO>;
+    auto kern = k_wgrad_pairs<CI, CO>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::lds_bytes));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WGM_THREADS), T::lds_bytes, st, in, grad_out,
+                       (const PairMeta*)base, (const int*)(base + oi), (const int*)(base + oo), K, (float*)workspace);
+    return GLX_OK;
+  });
+  if (rc != GLX_OK) return rc;
+  const int nel = Cin * Cout;
+  hipLaunchKernelGGL(k_wgrad_pairs_reduce, dim3(glx_divup(nel, 256), K), dim3(256), 0, st, (const float*)workspace,
+                     (const PairMeta*)base, nel, dW);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
 // Row slices of the weight-gradient grid: as many blocks as are resident at once (LDS-limited
 // blocks per CU x 256 CUs) divided by the K offsets -- a block's work is a serial chain of row
 // batches, so the kernel takes as long as one block, and a partial second wave of blocks doubles it.

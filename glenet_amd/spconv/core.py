@@ -109,6 +109,7 @@ class RuleSet:
         self.count_in = self.count_out = None   # shape-static mode: live rows (device int32[1])
         self.ready = None        # event recorded after the build when it ran on another stream
         self._tile_maps = {}     # rule table (data_ptr) -> work-balanced block -> tile map
+        self._pair_lists = {}    # rule table (data_ptr) -> per-offset pair lists (glx_pair_lists_build)
 
     @property
     def pair_count(self):
@@ -134,6 +135,27 @@ class RuleSet:
             call("glx_sconv_tile_map", nbr, order, n_out, self.K, n_live, m, ws, size_arg(ws.numel()))
             self._tile_maps[key] = m
         return m
+
+    def pair_lists(self, nbr, n_out, n_live):
+        """Per-offset (input row, output row) pair lists of a rule table of this set -- what the weight gradient contracts
+        over (spconv's indice pairs); built on first use (two launches on the caller's stream), shared by every
+        convolution that walks the table."""
+        key = nbr.data_ptr()
+        cur = torch.cuda.current_stream(nbr.device)
+        hit = self._pair_lists.get(key)
+        if hit is None:
+            nbytes = query("glx_pair_lists_bytes", n_out, self.K)
+            pl = torch.empty(nbytes, dtype=torch.uint8, device=nbr.device)
+            call("glx_pair_lists_build", nbr, n_out, self.K, n_live, pl, size_arg(nbytes))
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self._pair_lists[key] = (pl, cur, ev)
+            return pl
+        pl, built_on, ev = hit
+        if built_on != cur:          # built by a weight gradient on another stream of this step
+            cur.wait_event(ev)
+            pl.record_stream(cur)
+        return pl
 
     def inverse_table(self):
         if self.nbr_in is None:
@@ -227,13 +249,15 @@ class PlannedConv:
 
 
 def plan_rules(indices, spatial_shape, batch_size, convs, index=None, count=None,
-               capacities=None, events=False):
+               capacities=None, events=False, pair_lists=False):
     """Rule tables of a whole conv stack (modules in execution order) from coordinates only:
     returns {indice_key: RuleSet}.  Keys are required (they are how convs find their table).
     count: live rows of `indices` on the device (shape-static mode, no host sync at all);
     capacities: optional {indice_key: rows} for the output sets of the strided convs;
     events: record an event after each rule set (RuleSet.ready) -- for plans built on a side
-    stream while the convolutions of the previous levels run on the main one."""
+    stream while the convolutions of the previous levels run on the main one;
+    pair_lists: a training step's plan -- the per-offset pair lists the weight gradients contract over
+    (RuleSet.pair_lists) are built behind the LAST rule table, so that no convolution of the forward pass waits for them."""
     x = SparseConvTensor(None, indices, spatial_shape, batch_size, count=count)
     x._index = index
     capacities = capacities or {}
@@ -261,6 +285,10 @@ def plan_rules(indices, spatial_shape, batch_size, convs, index=None, count=None
                                    indice_dict=x.indice_dict, count=rs.count_out)
             nxt._index = rs.out_index
             x = nxt
+    if pair_lists and USE_PAIR_LISTS:
+        for rs in x.indice_dict.values():
+            if rs.nbr is not None and rs.N_out > 0:
+                rs.pair_lists(rs.nbr, rs.N_out, rs.count_out)
     return x.indice_dict
 
 
@@ -450,10 +478,17 @@ class SparseConvFunction(Function):
                     t.record_stream(side)
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
                 g_w = torch.empty_like(w)
-                wsb = query("glx_sconv_wgrad_workspace_bytes", n_fwd_out, K, cin, cout)
-                ws = workspace.get(wsb, w.device)
-                call("glx_sconv_wgrad", features, features.shape[0], grad_out, fwd_nbr, n_fwd_out, K,
-                     cin, cout, g_w, live_fwd, 1 if (rules.subm and not inverse) else 0, ws, size_arg(ws.numel()))
+                if USE_PAIR_LISTS and n_fwd_out > 0 and query("glx_sconv_packed_bytes", K, cin, cout):
+                    pl = rules.pair_lists(fwd_nbr, n_fwd_out, live_fwd)
+                    wsb = query("glx_sconv_wgrad_pairs_workspace_bytes", n_fwd_out, K, cin, cout)
+                    ws = workspace.get(wsb, w.device)
+                    call("glx_sconv_wgrad_pairs", features, grad_out, pl, n_fwd_out, K, cin, cout, g_w, ws,
+                         size_arg(ws.numel()))
+                else:
+                    wsb = query("glx_sconv_wgrad_workspace_bytes", n_fwd_out, K, cin, cout)
+                    ws = workspace.get(wsb, w.device)
+                    call("glx_sconv_wgrad", features, features.shape[0], grad_out, fwd_nbr, n_fwd_out, K,
+                         cin, cout, g_w, live_fwd, 1 if (rules.subm and not inverse) else 0, ws, size_arg(ws.numel()))
         if ctx.needs_input_grad[0]:
             # input gradient = the same kernels on the adjoint weights (Cout -> Cin, taps flipped on
             # a submanifold set), packed from the forward weights in one launch
@@ -909,6 +944,7 @@ def ctypes_float(v):
 USE_FUSED_TRAIN_BN = os.environ.get("GLX_FUSED_BN", "1") != "0"
 # work-balanced block -> tile maps for the sparse-conv kernels (RuleSet.tile_map); off with GLX_TILE_MAP=0
 USE_TILE_MAP = os.environ.get("GLX_TILE_MAP", "1") != "0"
+USE_PAIR_LISTS = os.environ.get("GLX_PAIR_LISTS", "1") != "0"      # weight gradients over per-offset pair lists
 TILE_MAP_MIN_ROWS = 64 * 256       # fewer tiles than CUs: nothing to balance
 # building a map costs two small launches (~8 us): worth it for the rule tables of submanifold stacks
 # (2-3 convs share one) with at least 32x32 weights per offset -- on the KITTI batch that is

@@ -224,6 +224,21 @@ int glx_sconv_wgrad(const float* in, int N_in, const float* grad_out, const int3
 /* submanifold != 0: nbr is a submanifold table (its centre offset K/2 pairs every row): the centre
  * gets shorter row slices so that its blocks do not outlast the others. */
 
+/* Per-offset pair lists of a rule table -- spconv's "indice pairs" (the (K, 2, N) indice_pairs + indice_pair_num that
+ * spconv.ops.get_indice_pairs returns and the reference's convs carry in indice_dict, spconv_backbone.py:77-117): for every
+ * offset k the (input row, output row) pairs with nbr[j, k] >= 0 in ascending j.  Built once per table (two launches), shared
+ * by every weight gradient over it.  `lists` is an opaque device buffer of glx_pair_lists_bytes(N_out, K) bytes; rows
+ * >= *n_live (device, may be NULL) are ignored. */
+size_t glx_pair_lists_bytes(int N_out, int K);
+int glx_pair_lists_build(const int32_t* nbr, int N_out, int K, const int32_t* n_live, void* lists,
+                         size_t lists_bytes, void* stream);
+/* Weight gradient (as glx_sconv_wgrad) over pair lists: every offset's list is cut into equal chunks sized on the device
+ * from the table's pair count, a block per chunk, slabs summed per offset in chunk order (bitwise reproducible).
+ * N_out / K: the values the lists were built with. */
+size_t glx_sconv_wgrad_pairs_workspace_bytes(int N_out, int K, int Cin, int Cout);
+int glx_sconv_wgrad_pairs(const float* in, const float* grad_out, const void* lists, int N_out, int K,
+                          int Cin, int Cout, float* dW, void* workspace, size_t workspace_bytes, void* stream);
+
 /* SparseConvTensor.dense(): out (B, C, D, H, W) must be zero-filled by the caller.
  * Replaces: spconv dense() (height_compression.py:21). */
 int glx_dense_scatter(const float* features, const int32_t* indices, int N, int C, int B,
