@@ -239,6 +239,86 @@ def test_conv_backward_conv_out_geometry(dev):
     np.testing.assert_allclose(conv.weight.grad.reshape(3, 64, 128).cpu().numpy(), dw, rtol=1e-3, atol=2e-3)
 
 
+def _pair_lists_of(nbr, n_out, K, n_live, dev):
+    from glenet_amd import _lib
+    nbytes = _lib.query("glx_pair_lists_bytes", n_out, K)
+    pl = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    live = None if n_live is None else torch.tensor([n_live], dtype=torch.int32, device=dev)
+    _lib.call("glx_pair_lists_build", nbr, n_out, K, live, pl, _lib.size_arg(nbytes))
+    meta = pl[:4 * 57].view(torch.int32).cpu().numpy()         # poff[28], coff[28], ch
+    nb = (max(n_out, 1) + 255) // 256
+    align = lambda b: (b + 255) // 256 * 256                    # noqa: E731
+    o_in = align(4 * 64) + align(4 * K * nb)
+    o_out = o_in + align(4 * max(n_out, 1) * K)
+    total = int(meta[K])
+    pin = pl[o_in:o_in + 4 * total].view(torch.int32).cpu().numpy()
+    pout = pl[o_out:o_out + 4 * total].view(torch.int32).cpu().numpy()
+    return pl, meta, pin, pout
+
+
+@pytest.mark.parametrize("n_out,K,n_live,density", [(5000, 27, None, 0.2), (1031, 27, 700, 0.3), (300, 3, None, 0.5),
+                                                    (70000, 27, 65000, 0.15), (257, 27, 0, 0.2), (4000, 27, None, 0.0)])
+def test_pair_lists_equal_the_rule_table_offset_by_offset(dev, n_out, K, n_live, density):
+    """glx_pair_lists_build: per offset the (input row, output row) pairs of the rule table in ascending output row --
+    spconv's indice pairs -- bit-exact against numpy, rows past *n_live ignored, offsets without pairs empty, and the
+    chunking the weight gradient reads from the same buffer: CH a multiple of 32 in [128, 1024], chunk offsets = running
+    ceil(count / CH)."""
+    rng = np.random.default_rng(n_out + K)
+    nbr = np.where(rng.random((n_out, K)) < density, rng.integers(0, 90000, (n_out, K)), -1).astype(np.int32)
+    if K == 27:
+        nbr[:, 5] = -1                                          # an offset without a single pair
+    pl, meta, pin, pout = _pair_lists_of(torch.from_numpy(nbr).to(dev), n_out, K, n_live, dev)
+    n = n_out if n_live is None else min(n_out, n_live)
+    ch = int(meta[56])
+    assert ch % 32 == 0 and 128 <= ch <= 1024
+    run = crun = 0
+    for k in range(K):
+        rows = np.nonzero(nbr[:n, k] >= 0)[0]
+        assert meta[k] == run and meta[28 + k] == crun
+        assert np.array_equal(pout[run:run + len(rows)], rows.astype(np.int32))
+        assert np.array_equal(pin[run:run + len(rows)], nbr[rows, k])
+        run += len(rows)
+        crun += -(-len(rows) // ch)
+    assert meta[K] == run and meta[28 + K] == crun and crun <= 720 + K
+
+
+@pytest.mark.parametrize("cin,cout,n_out,K,n_live", [(64, 64, 9000, 27, None), (16, 32, 3000, 27, 2500), (4, 16, 2000, 27, None),
+                                                       (64, 128, 700, 3, None), (128, 128, 1500, 27, None), (32, 32, 40, 27, None)])
+def test_weight_gradient_over_pair_lists_and_over_row_slices_equal_the_fp64_contraction(dev, cin, cout, n_out, K, n_live):
+    """glx_sconv_wgrad_pairs (chunks of per-offset pair lists) and glx_sconv_wgrad (row slices) against
+    dW[k] = sum_j in[nbr[j, k]]^T gout[j] in fp64: 2e-6 of the gradient's scale each; two runs of either are bitwise equal
+    (fixed summation order)."""
+    from glenet_amd import _lib
+    rng = np.random.default_rng(cin * cout + n_out)
+    n_in = n_out + 17
+    nbr_np = np.where(rng.random((n_out, K)) < 0.25, rng.integers(0, n_in, (n_out, K)), -1).astype(np.int32)
+    x = rng.normal(size=(n_in, cin)).astype(np.float32)
+    g = rng.normal(size=(n_out, cout)).astype(np.float32)
+    n = n_out if n_live is None else n_live
+    want = np.zeros((K, cin, cout))
+    for k in range(K):
+        rows = np.nonzero(nbr_np[:n, k] >= 0)[0]
+        want[k] = x[nbr_np[rows, k]].astype(np.float64).T @ g[rows].astype(np.float64)
+    nbr, xt, gt = (torch.from_numpy(a).to(dev) for a in (nbr_np, x, g))
+    live = None if n_live is None else torch.tensor([n_live], dtype=torch.int32, device=dev)
+    pl = _pair_lists_of(nbr, n_out, K, n_live, dev)[0]
+    outs = []
+    for rep in range(2):
+        dw = torch.full((K, cin, cout), float("nan"), device=dev)
+        wsb = _lib.query("glx_sconv_wgrad_pairs_workspace_bytes", n_out, K, cin, cout)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _lib.call("glx_sconv_wgrad_pairs", xt, gt, pl, n_out, K, cin, cout, dw, ws, _lib.size_arg(wsb))
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1])
+    dw2 = torch.full((K, cin, cout), float("nan"), device=dev)
+    wsb = _lib.query("glx_sconv_wgrad_workspace_bytes", n_out, K, cin, cout)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _lib.call("glx_sconv_wgrad", xt, n_in, gt, nbr, n_out, K, cin, cout, dw2, live, 0, ws, _lib.size_arg(wsb))
+    scale = np.abs(want).max() + 1e-30
+    for got in (outs[0], dw2):
+        assert np.abs(got.cpu().numpy().astype(np.float64) - want).max() <= 2e-6 * scale
+
+
 def test_conv_with_five_input_channels_is_padded_not_scalar(dev):
     """Waymo point features (C = 5): forward and both gradients equal the oracle."""
     rng = np.random.default_rng(31)
