@@ -262,3 +262,256 @@ extern "C" int glx_pointnet_feat_small(const float* points, int B, int Cin, int 
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ training twin, layer 3
+// Training-mode  out[b, :] = max_p BatchNorm3(W3 h2[b, p, :] + b3)  of PointNetfeat (point_net.py:22-28: conv3 + bn3, no
+// ReLU, max over the points) WITHOUT the (B x P x 512) tensor: 4.3 GB at BASELINE configs[3]'s 4096 x 512 points, which the
+// module-by-module path writes once and re-reads eight times per step.  BatchNorm3 is a per-channel affine map of the
+// conv output y, so  max_p bn3(y) = scale * (scale >= 0 ? max_p y : min_p y) + shift:  one pass over h2 that keeps, per
+// (object, channel), max / min of y with the points they occur at and the sums of y and y^2 (the batch statistics),
+// is the whole forward.  Backward (glx_pointmax_scatter / glx_pointmax_wsum + 128 x 128 algebra on the host side,
+// dense_path.PointMaxBN): with  dy[r, c] = a_c g^[r, c] - b_c - c_c y[r, c]  (g^ = the gradient at the extreme point of its
+// (object, channel), zero elsewhere; a, b, c from the BatchNorm backward's two sums, which only involve the extreme
+// values) and y = h2 W3^T,
+//     dh2 = dy W3   = (rows of W3 scattered to the extreme points) - v - h2 (W3^T diag(c) W3),
+//     dW3 = dy^T h2 = a * (g-weighted sums of the extreme points' h2 rows) - b (x) sum_r h2 - diag(c) W3 (h2^T h2),
+// i.e. the 512-wide layer's backward costs two 128 x 128 products per row instead of two 128 x 512 ones.
+// Kernel layout = layer 3 of k_pointnet_feat: one block (4 waves) per object, 128 points per pass, v_mfma_f32_16x16x4_f32
+// with the point tile as the B operand (read from h2 in global memory: lane (j, q) holds channels 16 t2 + 4 q + e of point
+// j), W3 streamed through two 8 KB LDS slabs in fragment order.
+#define PM_STAT 6                      // running per-wave arrays in LDS: max, min, argmax, argmin, sum, sum of squares
+
+__global__ __launch_bounds__(PN_THREADS) void k_pointmax_fwd(
+    const float* __restrict__ h2, int P, const float* __restrict__ W3p, float* __restrict__ vmax, float* __restrict__ vmin,
+    int* __restrict__ amax, int* __restrict__ amin, float* __restrict__ s1, float* __restrict__ s2) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_w3 = smem;                                  // 2 slabs
+  float* s_st = s_w3 + 2 * PN_SLAB;                    // PM_STAT x 4 waves x 512
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const long long obj = blockIdx.x;
+  float* w_max = s_st + (0 * 4 + wave) * PN_C3;
+  float* w_min = s_st + (1 * 4 + wave) * PN_C3;
+  int* w_amax = reinterpret_cast<int*>(s_st + (2 * 4 + wave) * PN_C3);
+  int* w_amin = reinterpret_cast<int*>(s_st + (3 * 4 + wave) * PN_C3);
+  float* w_s1 = s_st + (4 * 4 + wave) * PN_C3;
+  float* w_s2 = s_st + (5 * 4 + wave) * PN_C3;
+  for (int e = tid; e < 4 * PN_C3; e += PN_THREADS) {
+    s_st[e] = -FLT_MAX;
+    s_st[4 * PN_C3 + e] = FLT_MAX;
+    reinterpret_cast<int*>(s_st)[8 * PN_C3 + e] = 0;
+    reinterpret_cast<int*>(s_st)[12 * PN_C3 + e] = 0;
+    s_st[16 * PN_C3 + e] = 0.f;
+    s_st[20 * PN_C3 + e] = 0.f;
+  }
+  pf32x4 slab[2];
+  slab[0] = reinterpret_cast<const pf32x4*>(W3p)[tid];
+  slab[1] = reinterpret_cast<const pf32x4*>(W3p)[tid + PN_THREADS];
+  reinterpret_cast<pf32x4*>(s_w3)[tid] = slab[0];
+  reinterpret_cast<pf32x4*>(s_w3)[tid + PN_THREADS] = slab[1];
+  __syncthreads();
+
+  const float* ho = h2 + obj * (long long)P * PN_C2;
+  for (int p0 = 0; p0 < P; p0 += PN_PTS) {
+    float hreg[2][32];
+    bool live[2];
+    int pidx[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      const int p = p0 + wave * 32 + pt * 16 + j;
+      live[pt] = p < P;
+      pidx[pt] = p;
+      const float* row = ho + (long long)(live[pt] ? p : 0) * PN_C2 + 4 * q;
+#pragma unroll
+      for (int t2 = 0; t2 < 8; ++t2) {
+        const pf32x4 v = *reinterpret_cast<const pf32x4*>(row + 16 * t2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hreg[pt][t2 * 4 + e] = live[pt] ? v[e] : 0.f;
+      }
+    }
+    for (int t3 = 0; t3 < 32; ++t3) {
+      const int nxt = (t3 + 1) & 31;
+      const pf32x4* src = reinterpret_cast<const pf32x4*>(W3p + (size_t)nxt * PN_SLAB);
+      slab[0] = src[tid];
+      slab[1] = src[tid + PN_THREADS];
+      const float* sw = s_w3 + (t3 & 1) * PN_SLAB;
+      pf32x4 acc0 = pf32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+      for (int t2 = 0; t2 < 8; ++t2) {
+        const pf32x4 a = *reinterpret_cast<const pf32x4*>(sw + (t2 * 64 + lane) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], hreg[0][t2 * 4 + e], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], hreg[1][t2 * 4 + e], acc1, 0, 0, 0);
+        }
+      }
+      // the 32 points of this wave, channel 16 t3 + 4 q + e: extremes with their points (ties: the lower point index),
+      // sum and sum of squares; 16-lane butterflies over j, then into the wave's running values
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float mx = live[0] ? acc0[e] : -FLT_MAX, mn = live[0] ? acc0[e] : FLT_MAX;
+        int ix = pidx[0], in_ = pidx[0];
+        if (live[1]) {
+          if (acc1[e] > mx) { mx = acc1[e]; ix = pidx[1]; }
+          if (acc1[e] < mn) { mn = acc1[e]; in_ = pidx[1]; }
+        }
+        float a1 = (live[0] ? acc0[e] : 0.f) + (live[1] ? acc1[e] : 0.f);
+        float a2 = (live[0] ? acc0[e] * acc0[e] : 0.f) + (live[1] ? acc1[e] * acc1[e] : 0.f);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          const float omx = __shfl_xor(mx, o, 64), omn = __shfl_xor(mn, o, 64);
+          const int oix = __shfl_xor(ix, o, 64), oin = __shfl_xor(in_, o, 64);
+          if (omx > mx || (omx == mx && oix < ix)) { mx = omx; ix = oix; }
+          if (omn < mn || (omn == mn && oin < in_)) { mn = omn; in_ = oin; }
+          a1 += __shfl_xor(a1, o, 64);
+          a2 += __shfl_xor(a2, o, 64);
+        }
+        if (j == 0) {
+          const int c = 16 * t3 + 4 * q + e;
+          if (mx > w_max[c]) { w_max[c] = mx; w_amax[c] = ix; }      // earlier passes hold lower point indices: ties keep them
+          if (mn < w_min[c]) { w_min[c] = mn; w_amin[c] = in_; }
+          w_s1[c] += a1;
+          w_s2[c] += a2;
+        }
+      }
+      float* dw = s_w3 + ((t3 + 1) & 1) * PN_SLAB;
+      reinterpret_cast<pf32x4*>(dw)[tid] = slab[0];
+      reinterpret_cast<pf32x4*>(dw)[tid + PN_THREADS] = slab[1];
+      __syncthreads();
+    }
+  }
+  // ---- the 4 waves' values (a wave holds points 32 w .. 32 w + 31 of every pass: ties go to the lower index)
+  for (int c = tid; c < PN_C3; c += PN_THREADS) {
+    float mx = -FLT_MAX, mn = FLT_MAX, a1 = 0.f, a2 = 0.f;
+    int ix = 0, in_ = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float vmx = s_st[(0 * 4 + w) * PN_C3 + c], vmn = s_st[(1 * 4 + w) * PN_C3 + c];
+      const int vix = reinterpret_cast<const int*>(s_st)[(2 * 4 + w) * PN_C3 + c];
+      const int vin = reinterpret_cast<const int*>(s_st)[(3 * 4 + w) * PN_C3 + c];
+      if (vmx > mx || (vmx == mx && vix < ix)) { mx = vmx; ix = vix; }
+      if (vmn < mn || (vmn == mn && vin < in_)) { mn = vmn; in_ = vin; }
+      a1 += s_st[(4 * 4 + w) * PN_C3 + c];
+      a2 += s_st[(5 * 4 + w) * PN_C3 + c];
+    }
+    const long long o = obj * PN_C3 + c;
+    vmax[o] = mx; vmin[o] = mn; amax[o] = ix; amin[o] = in_; s1[o] = a1; s2[o] = a2;
+  }
+}
+
+extern "C" int glx_pointmax_forward(const float* h2, int B, int P, const float* W3p, float* vmax, float* vmin,
+                                    int32_t* amax, int32_t* amin, float* s1, float* s2, void* stream) {
+  if (B <= 0) return GLX_OK;
+  GLX_REQUIRE(h2 && W3p && vmax && vmin && amax && amin && s1 && s2, "glx_pointmax_forward: null pointer");
+  GLX_REQUIRE(P >= 1, "glx_pointmax_forward: P >= 1");
+  const size_t lds = (size_t)(2 * PN_SLAB + PM_STAT * 4 * PN_C3) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GLX_HIP(hipFuncSetAttribute((const void*)k_pointmax_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_pointmax_fwd, dim3(B), dim3(PN_THREADS), lds, (hipStream_t)stream, h2, P, W3p, vmax, vmin,
+                     (int*)amax, (int*)amin, s1, s2);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// dh2s[b * P + p, :] = sum over the channels c whose extreme point in object b is p of coef[b, c] * W3[c, :]  (zero rows
+// for the other points; `init` (128 floats or NULL) is what every row starts from): the part of  dy W3  that comes from
+// the max's gradient.  One block per object; a wave takes
+// every fourth point and walks the channels in ascending order (ballots over the object's 512 extreme points in LDS):
+// every row is written exactly once, no atomics, fixed summation order.
+__global__ __launch_bounds__(PN_THREADS) void k_pointmax_scatter(const int* __restrict__ arg, const float* __restrict__ coef,
+                                                                 const float* __restrict__ W3, const float* __restrict__ init,
+                                                                 int P, float* __restrict__ dh2) {
+  __shared__ int s_arg[PN_C3];
+  __shared__ float s_coef[PN_C3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long obj = blockIdx.x;
+  for (int c = tid; c < PN_C3; c += PN_THREADS) {
+    s_arg[c] = arg[obj * PN_C3 + c];
+    s_coef[c] = coef[obj * PN_C3 + c];
+  }
+  __syncthreads();
+  for (int p = wave; p < P; p += PN_THREADS / 64) {
+    float a0 = init ? init[lane] : 0.f, a1 = init ? init[64 + lane] : 0.f;   // channels k = lane and lane + 64 of the row
+#pragma unroll 1
+    for (int c0 = 0; c0 < PN_C3; c0 += 64) {
+      unsigned long long hit = __ballot(s_arg[c0 + lane] == p && s_coef[c0 + lane] != 0.f);
+      while (hit) {
+        const int c = c0 + __ffsll((long long)hit) - 1;
+        hit &= hit - 1;
+        const float w = s_coef[c];
+        a0 = fmaf(w, W3[(long long)c * PN_C2 + lane], a0);
+        a1 = fmaf(w, W3[(long long)c * PN_C2 + 64 + lane], a1);
+      }
+    }
+    float* row = dh2 + (obj * P + p) * PN_C2;
+    row[lane] = a0;
+    row[64 + lane] = a1;
+  }
+}
+
+extern "C" int glx_pointmax_scatter(const int32_t* arg, const float* coef, const float* W3, const float* init, int B, int P,
+                                    float* dh2, void* stream) {
+  if (B <= 0) return GLX_OK;
+  GLX_REQUIRE(arg && coef && W3 && dh2 && P >= 1, "glx_pointmax_scatter: null pointer");
+  hipLaunchKernelGGL(k_pointmax_scatter, dim3(B), dim3(PN_THREADS), 0, (hipStream_t)stream, (const int*)arg, coef, W3, init, P, dh2);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// T[c, :] = sum_b g[b, c] * h2[b * P + arg[b, c], :]   (512 x 128): the max's part of the weight gradient.  A wave per
+// (channel, slice of the objects), 8 row gathers in flight; slices are summed in order by the second kernel.
+#define PMW_SLICES 8
+__global__ __launch_bounds__(PN_THREADS) void k_pointmax_wsum(const float* __restrict__ g, const int* __restrict__ arg,
+                                                              const float* __restrict__ h2, int B, int P,
+                                                              float* __restrict__ part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * (PN_THREADS / 64) + wave, sl = blockIdx.y;
+  const int per = (B + PMW_SLICES - 1) / PMW_SLICES, b0 = sl * per, b1 = min(B, b0 + per);
+  float a0 = 0.f, a1 = 0.f;
+  for (int b = b0; b < b1; b += 8) {
+    float w[8], x0[8], x1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int bb = min(b + u, b1 - 1);
+      const long long o = (long long)bb * PN_C3 + c;
+      w[u] = b + u < b1 ? g[o] : 0.f;
+      const float* row = h2 + ((long long)bb * P + arg[o]) * PN_C2;
+      x0[u] = row[lane];
+      x1[u] = row[64 + lane];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a0 = fmaf(w[u], x0[u], a0);
+      a1 = fmaf(w[u], x1[u], a1);
+    }
+  }
+  float* dst = part + ((long long)sl * PN_C3 + c) * PN_C2;
+  dst[lane] = a0;
+  dst[64 + lane] = a1;
+}
+
+__global__ void k_pointmax_wsum_reduce(const float* __restrict__ part, float* __restrict__ T) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= PN_C3 * PN_C2) return;
+  float s = 0.f;
+#pragma unroll
+  for (int sl = 0; sl < PMW_SLICES; ++sl) s += part[(long long)sl * PN_C3 * PN_C2 + e];
+  T[e] = s;
+}
+
+extern "C" size_t glx_pointmax_wsum_workspace_bytes(void) { return (size_t)PMW_SLICES * PN_C3 * PN_C2 * sizeof(float); }
+
+extern "C" int glx_pointmax_wsum(const float* g, const int32_t* arg, const float* h2, int B, int P, float* T,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(g && arg && h2 && T && workspace && B >= 1 && P >= 1, "glx_pointmax_wsum: null pointer / empty batch");
+  GLX_REQUIRE(workspace_bytes >= glx_pointmax_wsum_workspace_bytes(), "glx_pointmax_wsum: workspace too small");
+  hipLaunchKernelGGL(k_pointmax_wsum, dim3(PN_C3 / (PN_THREADS / 64), PMW_SLICES), dim3(PN_THREADS), 0, (hipStream_t)stream, g,
+                     (const int*)arg, h2, B, P, (float*)workspace);
+  hipLaunchKernelGGL(k_pointmax_wsum_reduce, dim3(PN_C3 * PN_C2 / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, T);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

@@ -772,6 +772,7 @@ class PointFeat(nn.Module):
                 and core.USE_FUSED_TRAIN_BN and all(ok(m.num_features) and m.affine and m.momentum is not None
                                                     for m in (self.bn1, self.bn2, self.bn3)))
 
+    USE_POINTMAX = os.environ.get("GLX_CVAE_POINTMAX", "1") != "0"
     ROW_CHUNKS = 128
     ROWS_MAX = int(os.environ.get("GLX_CVAE_ROWS_MAX", 1 << 22))
 
@@ -793,6 +794,9 @@ class PointFeat(nn.Module):
         rows = x.transpose(1, 2).reshape(b * p, cin)
         h = core.fused_train_bn(self.bn1, self._rows_linear(rows, self.conv1), True, None)
         h = core.fused_train_bn(self.bn2, self._rows_linear(h, self.conv2), True, None)
+        if self.USE_POINTMAX and h.shape[1] == 128 and self.conv3.out_channels == 512 and self.bn3.affine:
+            # the 512-wide layer + BatchNorm + max over the points without the (B, P, 512) tensor
+            return PointMaxBN.apply(h, self.conv3.weight[:, :, 0], self.conv3.bias, self.bn3.weight, self.bn3.bias, self.bn3, b, p)
         h = core.fused_train_bn(self.bn3, self._rows_linear(h, self.conv3), False, None)
         return h.view(b, p, -1).amax(dim=1)
 
@@ -847,6 +851,74 @@ class PointFeat(nn.Module):
             call("glx_pointnet_feat_small", x, B, cin, P, self.conv1.out_channels, self.conv2.out_channels,
                  c3, w1, b1, w2p, b2, w3p, b3, out)
         return out
+
+
+class PointMaxBN(torch.autograd.Function):
+    """out[b, :] = max_p BatchNorm1d(W3 h2[b, p, :] + b3) in training mode (point_net.py:22-28: conv3 + bn3 + max over the
+    points) without the (B, P, 512) tensor -- csrc/glx_pointnet.hip, "training twin, layer 3".  h2 (B * P, 128) rows;
+    weight (512, 128); returns (B, 512).  Running statistics of `bn` are updated as nn.BatchNorm1d does."""
+
+    @staticmethod
+    def forward(ctx, h2, weight, bias, gamma, beta, bn, B, P):
+        from ._lib import call
+        dev = h2.device
+        h2 = h2.contiguous()
+        W3 = weight.contiguous()
+        w3p = W3.view(32, 16, 8, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
+        vmax, vmin, s1, s2 = (torch.empty((B, 512), dtype=torch.float32, device=dev) for _ in range(4))
+        amax, amin = (torch.empty((B, 512), dtype=torch.int32, device=dev) for _ in range(2))
+        call("glx_pointmax_forward", h2, B, P, w3p, vmax, vmin, amax, amin, s1, s2)
+        R = B * P
+        mean_nb = s1.double().sum(0) / R                        # batch mean of y without the bias
+        var = (s2.double().sum(0) / R - mean_nb * mean_nb).clamp_min_(0.0)
+        invstd = torch.rsqrt(var + bn.eps).float()
+        mean_nb = mean_nb.float()
+        scale = gamma * invstd
+        sel = scale >= 0
+        ext = torch.where(sel, vmax, vmin)
+        arg = torch.where(sel, amax, amin)
+        out = (ext - mean_nb) * scale + beta
+        if bn.track_running_stats:
+            with torch.no_grad():
+                m = bn.momentum
+                bn.running_mean.mul_(1 - m).add_(mean_nb + (bias if bias is not None else 0), alpha=m)
+                bn.running_var.mul_(1 - m).add_(var.float() * (R / max(R - 1, 1)), alpha=m)
+                bn.num_batches_tracked.add_(1)
+        ctx.save_for_backward(h2, W3, ext, arg, mean_nb, invstd, scale)
+        ctx.dims = (B, P, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from ._lib import call, query, size_arg
+        h2, W3, ext, arg, mean_nb, invstd, scale = ctx.saved_tensors
+        B, P, has_bias = ctx.dims
+        R = B * P
+        g = g.contiguous()
+        xhat = (ext - mean_nb) * invstd
+        dbeta = g.sum(0)
+        dgamma = (g * xhat).sum(0)
+        # dy[r, c] = a_c g^[r, c] - bvec_c - cvec_c (y[r, c] - mean_c):  BatchNorm backward with the max's sparse gradient g^
+        bvec = scale * dbeta / R
+        cvec = scale * invstd * dgamma / R
+        d_h2 = d_w = None
+        if ctx.needs_input_grad[0]:
+            v = (bvec - cvec * mean_nb) @ W3                                    # (128)
+            M = W3.t() @ (cvec[:, None] * W3)                                   # (128, 128)
+            d_h2 = torch.empty_like(h2)
+            call("glx_pointmax_scatter", arg, (g * scale).contiguous(), W3, (-v).contiguous(), B, P, d_h2)
+            d_h2.addmm_(h2, M, alpha=-1.0)
+        if ctx.needs_input_grad[1]:
+            T = torch.empty_like(W3)
+            ws = torch.empty(query("glx_pointmax_wsum_workspace_bytes"), dtype=torch.uint8, device=h2.device)
+            call("glx_pointmax_wsum", g, arg, h2, B, P, T, ws, size_arg(ws.numel()))
+            S = 128 if R % 128 == 0 and R >= 128 * 256 else 1
+            hc = h2.view(S, R // S, 128)
+            G2 = torch.bmm(hc.transpose(1, 2), hc).sum(0)                       # h2^T h2
+            H1 = h2.sum(0)
+            d_w = scale[:, None] * T - bvec[:, None] * H1[None] - cvec[:, None] * (W3 @ G2 - mean_nb[:, None] * H1[None])
+        d_b = torch.zeros_like(dbeta) if has_bias else None                     # sum_r dy = 0 exactly (the BatchNorm removes it)
+        return d_h2, d_w, d_b, dgamma, dbeta, None, None, None
 
 
 class LatentEncoder(nn.Module):

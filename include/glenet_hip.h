@@ -838,6 +838,22 @@ int glx_pointnet_feat_small(const float* points, int B, int Cin, int P, int C1, 
                             const float* W1, const float* b1, const float* W2, const float* b2,
                             const float* W3, const float* b3, float* out, void* stream);
 
+/* Training twin of the extractor's last layer (cvae_uncertainty/point_net.py:22-28: conv3 + bn3, max over the points;
+ * model.py:200-243 trains through it): the (B x P x 512) tensor is never built.  h2 (B * P, 128) row-major = the second
+ * layer's output, W3p = the (512, 128) weight in the fragment order of glx_pointnet_feat.
+ * glx_pointmax_forward: per (object, channel) max / min of y = W3 h2 over the object's points, the point indices they occur
+ * at (ties: the lower index) and the sums of y and y^2 (BatchNorm's batch statistics); all outputs (B, 512).
+ * glx_pointmax_scatter: dh2 (B * P, 128) = rows of W3 (512, 128) row-major scattered to arg[b, c] with weights coef[b, c]
+ * on top of the row `init` (128 floats, may be NULL = zeros); every row is written, deterministic.
+ * glx_pointmax_wsum: T (512, 128) = sum_b g[b, c] * h2[b * P + arg[b, c], :]. */
+int glx_pointmax_forward(const float* h2, int B, int P, const float* W3p, float* vmax, float* vmin, int32_t* amax,
+                         int32_t* amin, float* s1, float* s2, void* stream);
+int glx_pointmax_scatter(const int32_t* arg, const float* coef, const float* W3, const float* init, int B, int P, float* dh2,
+                         void* stream);
+size_t glx_pointmax_wsum_workspace_bytes(void);
+int glx_pointmax_wsum(const float* g, const int32_t* arg, const float* h2, int B, int P, float* T, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 /* out[m,c] = max_s relu(a[m,s,c] + b[m,s,c]) on row-major (M, nsample, C) tensors, arg = winning slot
  * (first on ties) -- add + ReLU + max_pool of the RoI-grid pooling MLP in training
  * (pcdet/ops/pointnet2/pointnet2_stack/voxel_pool_modules.py:96-104) in one pass.  _grad: grad_in

@@ -111,6 +111,38 @@ def test_cvae_training_step_matches_reference_golden_on_device(dev):
             np.testing.assert_allclose(v.cpu().numpy(), g["after/" + k], rtol=1e-4, atol=1e-6, err_msg=k)
 
 
+@pytest.mark.parametrize("B,P,neg", [(6, 100, False), (16, 512, True), (3, 130, True)])
+def test_point_max_batchnorm_without_the_wide_tensor_equals_the_modules(dev, B, P, neg):
+    """dense_path.PointMaxBN (csrc/glx_pointnet.hip: max / min / arg / moments in one pass over h2, backward through
+    128 x 128 algebra) against Conv1d(128, 512, 1) + BatchNorm1d(512) in training mode + max over the points run by torch
+    on the (B, 512, P) tensor (point_net.py:22-28): output, running statistics, gradients of input and parameters; negative
+    BatchNorm weights take the min branch; P not a multiple of the 128-point pass."""
+    torch.manual_seed(B * P)
+    conv, bn = torch.nn.Conv1d(128, 512, 1).to(dev), torch.nn.BatchNorm1d(512).to(dev).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(512, device=dev) if neg else torch.rand(512, device=dev) + 0.5)
+        bn.bias.copy_(torch.randn(512, device=dev))
+    bn2 = torch.nn.BatchNorm1d(512).to(dev).train()
+    bn2.load_state_dict(bn.state_dict())
+    h = torch.relu(torch.randn(B * P, 128, device=dev) + 0.3).requires_grad_(True)
+    gout = torch.randn(B, 512, device=dev)
+    want = bn(conv(h.view(B, P, 128).transpose(1, 2))).amax(dim=2)
+    want.backward(gout)
+    ref = [t.grad.clone() for t in (h, conv.weight, conv.bias, bn.weight, bn.bias)]
+    for t in (h, conv.weight, conv.bias, bn.weight, bn.bias):
+        t.grad = None
+    got = dp.PointMaxBN.apply(h, conv.weight[:, :, 0], conv.bias, bn2.weight, bn2.bias, bn2, B, P)
+    got.backward(gout)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().cpu().numpy(), rtol=2e-4, atol=2e-4)
+    for k in ("running_mean", "running_var", "num_batches_tracked"):
+        np.testing.assert_allclose(getattr(bn2, k).cpu().numpy(), getattr(bn, k).cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+    for name, a, b in zip(("h2", "conv.weight", "conv.bias", "bn.weight", "bn.bias"),
+                          (h.grad, conv.weight.grad[:, :, 0], conv.bias.grad, bn2.weight.grad, bn2.bias.grad),
+                          (ref[0], ref[1][:, :, 0], ref[2], ref[3], ref[4])):
+        scale = float(b.abs().max()) if name != "conv.bias" else float(ref[1].abs().max())   # the bias gradient is 0 + noise
+        assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-6, (name, float((a - b).abs().max()), scale)
+
+
 def test_cvae_train_step_graph_follows_an_eager_loop(dev):
     """CVAETrainStep (one HIP graph: forward, backward, clip 10, AdamW on flat buffers) against zero_grad / backward /
     clip_grad_norm_ / torch.optim.AdamW on a copy of the model run through the unfused (B, C, P) modules."""
