@@ -314,19 +314,16 @@ __global__ __launch_bounds__(PN_THREADS) void k_pointmax_fwd(
   const float* ho = h2 + obj * (long long)P * PN_C2;
   for (int p0 = 0; p0 < P; p0 += PN_PTS) {
     float hreg[2][32];
-    bool live[2];
-    int pidx[2];
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
       const int p = p0 + wave * 32 + pt * 16 + j;
-      live[pt] = p < P;
-      pidx[pt] = p;
-      const float* row = ho + (long long)(live[pt] ? p : 0) * PN_C2 + 4 * q;
+      const bool live = p < P;
+      const float* row = ho + (long long)(live ? p : 0) * PN_C2 + 4 * q;
 #pragma unroll
       for (int t2 = 0; t2 < 8; ++t2) {
         const pf32x4 v = *reinterpret_cast<const pf32x4*>(row + 16 * t2);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) hreg[pt][t2 * 4 + e] = live[pt] ? v[e] : 0.f;
+        for (int e = 0; e < 4; ++e) hreg[pt][t2 * 4 + e] = live ? v[e] : 0.f;
       }
     }
     for (int t3 = 0; t3 < 32; ++t3) {
@@ -335,30 +332,41 @@ __global__ __launch_bounds__(PN_THREADS) void k_pointmax_fwd(
       slab[0] = src[tid];
       slab[1] = src[tid + PN_THREADS];
       const float* sw = s_w3 + (t3 & 1) * PN_SLAB;
+      // operands swapped against k_pointnet_feat (point tile = A, weights = B): D comes out TRANSPOSED, rows = the 16 points
+      // of the tile (4 q + e), columns = channels 16 t3 + j -- the reduction over points is then mostly inside a lane
+      // (8 values: 2 tiles x 4 rows) and two exchanges across the lane's quad group, instead of four 16-lane butterflies
+      // per channel row (profiles/r04_cvae.md)
       pf32x4 acc0 = pf32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
       for (int t2 = 0; t2 < 8; ++t2) {
         const pf32x4 a = *reinterpret_cast<const pf32x4*>(sw + (t2 * 64 + lane) * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], hreg[0][t2 * 4 + e], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], hreg[1][t2 * 4 + e], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(hreg[0][t2 * 4 + e], a[e], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(hreg[1][t2 * 4 + e], a[e], acc1, 0, 0, 0);
         }
       }
-      // the 32 points of this wave, channel 16 t3 + 4 q + e: extremes with their points (ties: the lower point index),
-      // sum and sum of squares; 16-lane butterflies over j, then into the wave's running values
+      {
+        // this lane: channel 16 t3 + j, points pbase + 4 q + e (tile 0) and + 16 (tile 1), ascending in (tile, e)
+        const int pb = p0 + wave * 32 + 4 * q;
+        float mx = -FLT_MAX, mn = FLT_MAX, a1 = 0.f, a2 = 0.f;
+        int ix = 0, in_ = 0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float mx = live[0] ? acc0[e] : -FLT_MAX, mn = live[0] ? acc0[e] : FLT_MAX;
-        int ix = pidx[0], in_ = pidx[0];
-        if (live[1]) {
-          if (acc1[e] > mx) { mx = acc1[e]; ix = pidx[1]; }
-          if (acc1[e] < mn) { mn = acc1[e]; in_ = pidx[1]; }
+        for (int pt = 0; pt < 2; ++pt) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int p = pb + 16 * pt + e;
+            const float v = pt ? acc1[e] : acc0[e];
+            if (p < P) {
+              if (v > mx) { mx = v; ix = p; }
+              if (v < mn) { mn = v; in_ = p; }
+              a1 += v;
+              a2 += v * v;
+            }
+          }
         }
-        float a1 = (live[0] ? acc0[e] : 0.f) + (live[1] ? acc1[e] : 0.f);
-        float a2 = (live[0] ? acc0[e] * acc0[e] : 0.f) + (live[1] ? acc1[e] * acc1[e] : 0.f);
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
+        for (int o = 16; o < 64; o <<= 1) {            // the four lanes (q) of a channel
           const float omx = __shfl_xor(mx, o, 64), omn = __shfl_xor(mn, o, 64);
           const int oix = __shfl_xor(ix, o, 64), oin = __shfl_xor(in_, o, 64);
           if (omx > mx || (omx == mx && oix < ix)) { mx = omx; ix = oix; }
@@ -366,8 +374,8 @@ __global__ __launch_bounds__(PN_THREADS) void k_pointmax_fwd(
           a1 += __shfl_xor(a1, o, 64);
           a2 += __shfl_xor(a2, o, 64);
         }
-        if (j == 0) {
-          const int c = 16 * t3 + 4 * q + e;
+        if (q == 0) {
+          const int c = 16 * t3 + j;
           if (mx > w_max[c]) { w_max[c] = mx; w_amax[c] = ix; }      // earlier passes hold lower point indices: ties keep them
           if (mn < w_min[c]) { w_min[c] = mn; w_amin[c] = in_; }
           w_s1[c] += a1;
