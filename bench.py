@@ -414,7 +414,8 @@ def bench_config3(dev, objects=4096, points=512, samples=30):
     """BASELINE configs[3]: the CVAE on 4096 object crops x 512 points -- (i) the inference sampler, 30 latent samples
     per object (fused MFMA PointNet kernel, csrc/glx_pointnet.hip), (ii) one TRAINING step forward + backward + clip +
     AdamW (glenet_amd.cvae_train.CVAETrainStep, one HIP graph; the extractors run on the 2.1 M point rows as row GEMMs +
-    the fused training BatchNorm, PointFeat._forward_train_rows)."""
+    the fused training BatchNorm, their 128 -> 512 layer + BatchNorm + max without the (B, P, 512) tensor:
+    PointFeat._forward_train_rows, dense_path.PointMaxBN)."""
     import torch
     from glenet_amd import cvae_train as ct
     from glenet_amd import dense_path as dp
@@ -423,6 +424,10 @@ def bench_config3(dev, objects=4096, points=512, samples=30):
     pts, box8, box7 = (torch.from_numpy(a).to(dev) for a in synth.cvae_objects(objects, 2000, points, with_labels=True))
     model = dp.CVAE(4, 8).to(dev)
     per_obj = ct.CVAETrainStep.flops_per_object(points)
+    # flops the step executes per object: the two large extractors' 4 -> 64 -> 128 layers forward + both gradients, the
+    # 128 -> 512 layer forward + (h2^T h2 and h2 M: two 128 x 128 products per point) backward; the narrow extractor in full
+    executed = 2 * (3 * 2 * points * (4 * 64 + 64 * 128) + 2 * points * 128 * 512 + 2 * 2 * points * 128 * 128) \
+        + 3 * 2 * points * (4 * 8 + 8 * 8 + 8 * 8)
     model.eval()
     gen = torch.Generator(device=dev).manual_seed(7)
     eps = torch.randn((samples, objects, 8), device=dev, generator=gen)
@@ -452,7 +457,13 @@ def bench_config3(dev, objects=4096, points=512, samples=30):
                                 objects_per_s=round(objects / (ms_t * 1e-3), 1), loss=round(loss, 4),
                                 gflop_per_step=round(3 * objects * per_obj / 1e9, 1),
                                 TFLOPs=round(3 * objects * per_obj / ms_t / 1e9, 1),
-                                frac_of_fp32_mfma_peak=round(3 * objects * per_obj / ms_t / 1e9 / MFMA_F32_PEAK_TFLOPS, 3)))
+                                frac_of_fp32_mfma_peak=round(3 * objects * per_obj / ms_t / 1e9 / MFMA_F32_PEAK_TFLOPS, 3),
+                                flop_note="gflop_per_step / TFLOPs / frac are the module-by-module count (3 x the forward GEMMs: "
+                                          "what the reference's autograd executes); the 128 -> 512 layer's backward here is two "
+                                          "128 x 128 products per row instead of two 128 x 512 ones (dense_path.PointMaxBN, exact "
+                                          "algebra), see executed_*",
+                                executed_gflop_per_step=round(objects * executed / 1e9, 1),
+                                executed_TFLOPs=round(objects * executed / ms_t / 1e9, 1)))
 
 
 def bench_config4(dev, frames=2, steps=60):

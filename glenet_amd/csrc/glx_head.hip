@@ -1,0 +1,313 @@
+// The anchor head's 1x1 convolutions (pcdet/models/dense_heads/anchor_head_single.py:19-37: conv_cls, conv_box,
+// conv_dir_cls on the (B, 256, H, W) BEV map) as ONE pass per direction over the channels-last map.  The map is 144 MB at
+// the KITTI size and the three heads have 2 + 14 + 4 output channels: the work is reading (forward, weight gradient) or
+// writing (input gradient) the map once.  Through the vendor's convolution the training step paid a concatenation of the
+// three filters, a zero fill, the convolution, a bias pass, three `.contiguous()` copies forward and the same in reverse
+// plus two fills backward (0.3 ms, 20 launches); here: one launch forward writing the three prediction tensors, one for
+// the input gradient, two for the filter / bias gradients.
+// All three kernels are exact-fp32 v_mfma_f32_16x16x4_f32 GEMMs with M = pixels; the concatenated filters (<= 32 rows,
+// zero padded) sit in LDS.
+#include "glx_common.h"
+
+typedef float hf32x4 __attribute__((ext_vector_type(4)));
+
+#define HD_THREADS 256
+#define HD_MAXO 32                       // output channels of the three heads together, at most
+#define HD_PIX 64                        // pixels per block and pass (4 waves x 16)
+
+struct HeadOut {
+  float* p[3];                           // cls / box / dir predictions (M, n[k]) row-major (dir may have n = 0)
+  int n[3];
+};
+struct HeadGrad {
+  const float* p[3];
+  int n[3];
+};
+
+// concatenated filters into LDS, row o = output channel (zero rows above the total), row stride C + 4
+__device__ __forceinline__ void hd_load_w(const float* const* W, const int* n, int C, float* s_w) {
+  const int ld = C + 4;
+  for (int e = threadIdx.x; e < HD_MAXO * (C / 4); e += HD_THREADS) {
+    const int o = e / (C / 4), c4 = e - o * (C / 4);
+    hf32x4 v = hf32x4{0.f, 0.f, 0.f, 0.f};
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (o >= base && o < base + n[k]) v = *reinterpret_cast<const hf32x4*>(W[k] + (long long)(o - base) * C + 4 * c4);
+      base += n[k];
+    }
+    *reinterpret_cast<hf32x4*>(s_w + o * ld + 4 * c4) = v;
+  }
+}
+
+struct HeadW {
+  const float* w[3];
+  const float* b[3];
+  int n[3];
+};
+
+// out[m, o] = sum_c x[m, c] W[o, c] + b[o].  A = the pixel tile (lane (i, kq): pixel i, channels 16 t + 4 kq + e), B = W^T.
+__global__ __launch_bounds__(HD_THREADS) void k_head_fwd(const float* __restrict__ x, long long M, int C, HeadW hw, HeadOut out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_w = smem;                                    // HD_MAXO x (C + 4)
+  const int ld = C + 4;
+  hd_load_w(hw.w, hw.n, C, s_w);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int total = hw.n[0] + hw.n[1] + hw.n[2];
+  for (long long m0 = (long long)blockIdx.x * HD_PIX; m0 < M; m0 += (long long)gridDim.x * HD_PIX) {
+    const long long m = m0 + wave * 16 + i;
+    const float* row = x + (m < M ? m : M - 1) * C + 4 * kq;
+    hf32x4 acc0 = hf32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    for (int t0 = 0; t0 < C / 16; t0 += 8) {           // 8 channel groups of 16 at a time: 8 row loads in flight
+      hf32x4 xa[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xa[u] = t0 + u < C / 16 ? *reinterpret_cast<const hf32x4*>(row + 16 * (t0 + u)) : hf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (t0 + u < C / 16) {
+          const hf32x4 w0 = *reinterpret_cast<const hf32x4*>(s_w + i * ld + 16 * (t0 + u) + 4 * kq);
+          const hf32x4 w1 = *reinterpret_cast<const hf32x4*>(s_w + (16 + i) * ld + 16 * (t0 + u) + 4 * kq);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][e], w0[e], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][e], w1[e], acc1, 0, 0, 0);
+          }
+        }
+      }
+    }
+    // D: rows = pixels 4 kq + e of the wave's 16, columns = output channels i (acc0) and 16 + i (acc1)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int o = 16 * half + i;
+      if (o >= total) continue;
+      int k = 0, oo = o;
+      if (oo >= hw.n[0]) { oo -= hw.n[0]; k = 1; if (oo >= hw.n[1]) { oo -= hw.n[1]; k = 2; } }
+      const float bias = hw.b[k] ? hw.b[k][oo] : 0.f;
+      float* dst = out.p[k];
+      const int nk = out.n[k];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const long long mm = m0 + wave * 16 + 4 * kq + e;
+        if (mm < M) dst[mm * nk + oo] = (half ? acc1[e] : acc0[e]) + bias;
+      }
+    }
+  }
+}
+
+// gx[m, c] = sum_o g[m, o] W[o, c]:  A = the gradient tile (pixels x 32 output channels), B = W (32 x C), a wave owns a
+// quarter of the C columns of the block's 64 pixels... no: a wave owns 16 pixels and walks all column tiles.
+__global__ __launch_bounds__(HD_THREADS) void k_head_dgrad(HeadGrad g, long long M, int C, HeadW hw, float* __restrict__ gx) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_w = smem;                                    // HD_MAXO x (C + 4)
+  const int ld = C + 4;
+  hd_load_w(hw.w, hw.n, C, s_w);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  for (long long m0 = (long long)blockIdx.x * HD_PIX; m0 < M; m0 += (long long)gridDim.x * HD_PIX) {
+    const long long m = m0 + wave * 16 + i;
+    // A operand: lane (i, kq) holds g[pixel i][o = 4 s + kq] for the 8 steps s
+    float ga[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int o = 4 * s + kq;
+      float v = 0.f;
+      if (m < M) {
+        if (o < g.n[0]) v = g.p[0][m * g.n[0] + o];
+        else if (o < g.n[0] + g.n[1]) v = g.p[1][m * g.n[1] + (o - g.n[0])];
+        else if (o < g.n[0] + g.n[1] + g.n[2]) v = g.p[2][m * g.n[2] + (o - g.n[0] - g.n[1])];
+      }
+      ga[s] = v;
+    }
+    for (int t = 0; t < C / 16; ++t) {
+      hf32x4 acc = hf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const float wv = s_w[(4 * s + kq) * ld + 16 * t + i];      // B[kq][j = i]: W[o = 4 s + kq][c = 16 t + i]
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], wv, acc, 0, 0, 0);
+      }
+      // D rows = pixels 4 kq + e, column = channel 16 t + i
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const long long mm = m0 + wave * 16 + 4 * kq + e;
+        if (mm < M) gx[mm * C + 16 * t + i] = acc[e];
+      }
+    }
+  }
+}
+
+// gW[o, c] = sum_m g[m, o] x[m, c], gb[o] = sum_m g[m, o]: contraction over pixels.  A = g^T (lane (i, kq): output channel
+// i (+16), pixel 4 s + kq), B = x (lane (j, kq): pixel 4 s + kq, channel 16 t + j).  A wave owns C / 64 column tiles... a block
+// of 4 waves covers C = 256 with 4 column tiles per wave; partial sums per block go to the workspace, k_head_wreduce adds
+// them in block order (fixed summation order).
+#define HD_WBLOCKS 512
+__global__ __launch_bounds__(HD_THREADS) void k_head_wgrad(HeadGrad g, const float* __restrict__ x, long long M, int C,
+                                                           float* __restrict__ part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int tpw = C / 64;                               // column tiles per wave (C = 256: 4)
+  hf32x4 acc[2][8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[h][u] = hf32x4{0.f, 0.f, 0.f, 0.f};
+  float gsum0 = 0.f, gsum1 = 0.f;
+  const long long per = (M + gridDim.x - 1) / gridDim.x;
+  const long long lo = (long long)blockIdx.x * per, hi = lo + per < M ? lo + per : M;
+  auto gval = [&](long long m, int o) {
+    if (m >= hi) return 0.f;
+    if (o < g.n[0]) return g.p[0][m * g.n[0] + o];
+    if (o < g.n[0] + g.n[1]) return g.p[1][m * g.n[1] + (o - g.n[0])];
+    if (o < g.n[0] + g.n[1] + g.n[2]) return g.p[2][m * g.n[2] + (o - g.n[0] - g.n[1])];
+    return 0.f;
+  };
+  for (long long m0 = lo; m0 < hi; m0 += 16) {          // 4 steps of 4 pixels
+    float a0[4], a1[4], xb[4][8];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const long long m = m0 + 4 * s + kq;
+      a0[s] = gval(m, i);
+      a1[s] = gval(m, 16 + i);
+      const float* row = x + (m < hi ? m : hi - 1) * C + 16 * (wave * tpw) + i;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xb[s][u] = (u < tpw && m < hi) ? row[16 * u] : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      gsum0 += a0[s];
+      gsum1 += a1[s];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (u < tpw) {
+          acc[0][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], xb[s][u], acc[0][u], 0, 0, 0);
+          acc[1][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], xb[s][u], acc[1][u], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D rows = output channels 4 kq + e (+16), columns = channels 16 (wave tpw + u) + i
+  float* dst = part + (long long)blockIdx.x * (HD_MAXO * (C + 1));
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (u < tpw)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[(16 * h + 4 * kq + e) * (C + 1) + 16 * (wave * tpw + u) + i] = acc[h][u][e];
+  // bias gradient: lanes (i, kq) hold the sums over the pixels 4 s + kq of their kq
+  gsum0 += __shfl_xor(gsum0, 16, 64); gsum0 += __shfl_xor(gsum0, 32, 64);
+  gsum1 += __shfl_xor(gsum1, 16, 64); gsum1 += __shfl_xor(gsum1, 32, 64);
+  if (wave == 0 && kq == 0) {
+    dst[i * (C + 1) + C] = gsum0;
+    dst[(16 + i) * (C + 1) + C] = gsum1;
+  }
+}
+
+struct HeadWOut {
+  float* w[3];
+  float* b[3];
+  int n[3];
+};
+__global__ void k_head_wreduce(const float* __restrict__ part, int nblocks, int C, HeadWOut out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = out.n[0] + out.n[1] + out.n[2];
+  if (e >= total * (C + 1)) return;
+  const int o = e / (C + 1), c = e - o * (C + 1);
+  float s = 0.f;
+  int b = 0;
+  for (; b + 8 <= nblocks; b += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(long long)(b + u) * (HD_MAXO * (C + 1)) + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; b < nblocks; ++b) s += part[(long long)b * (HD_MAXO * (C + 1)) + e];
+  int k = 0, oo = o;
+  if (oo >= out.n[0]) { oo -= out.n[0]; k = 1; if (oo >= out.n[1]) { oo -= out.n[1]; k = 2; } }
+  if (c < C) { if (out.w[k]) out.w[k][(long long)oo * C + c] = s; }
+  else if (out.b[k]) out.b[k][oo] = s;
+}
+
+static int head_check(long long M, int C, const int32_t* n, const char* who) {
+  GLX_REQUIRE(M >= 1 && C >= 64 && C % 64 == 0 && C <= 512, "%s: needs M >= 1 and C a multiple of 64 up to 512 (got %lld, %d)", who, M, C);
+  GLX_REQUIRE(n[0] >= 1 && n[1] >= 0 && n[2] >= 0 && n[0] + n[1] + n[2] <= HD_MAXO, "%s: %d + %d + %d output channels (1..%d)",
+              who, n[0], n[1], n[2], HD_MAXO);
+  return GLX_OK;
+}
+
+static int head_lds_attr(const void* kern, size_t lds) {
+  GLX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return GLX_OK;
+}
+
+extern "C" int glx_head1x1_forward(const float* x, int64_t M, int C, const float* const* W, const float* const* bias,
+                                   const int32_t* n, float* const* out, void* stream) {
+  GLX_REQUIRE(x && W && n && out, "glx_head1x1_forward: null pointer");
+  int rc = head_check(M, C, n, "glx_head1x1_forward");
+  if (rc != GLX_OK) return rc;
+  HeadW hw; HeadOut ho;
+  for (int k = 0; k < 3; ++k) {
+    hw.w[k] = W[k]; hw.b[k] = bias ? bias[k] : nullptr; hw.n[k] = n[k];
+    ho.p[k] = out[k]; ho.n[k] = n[k];
+    GLX_REQUIRE(n[k] == 0 || (W[k] && out[k]), "glx_head1x1_forward: head %d has no weights / output", k);
+  }
+  const size_t lds = (size_t)HD_MAXO * (C + 4) * 4;
+  rc = head_lds_attr((const void*)k_head_fwd, lds);
+  if (rc != GLX_OK) return rc;
+  long long blocks = (M + HD_PIX - 1) / HD_PIX;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_head_fwd, dim3((unsigned)blocks), dim3(HD_THREADS), lds, (hipStream_t)stream, x, (long long)M, C, hw, ho);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+extern "C" int glx_head1x1_input_grad(const float* const* grad, int64_t M, int C, const float* const* W, const int32_t* n,
+                                      float* gx, void* stream) {
+  GLX_REQUIRE(grad && W && n && gx, "glx_head1x1_input_grad: null pointer");
+  int rc = head_check(M, C, n, "glx_head1x1_input_grad");
+  if (rc != GLX_OK) return rc;
+  HeadW hw; HeadGrad hg;
+  for (int k = 0; k < 3; ++k) {
+    hw.w[k] = W[k]; hw.b[k] = nullptr; hw.n[k] = n[k];
+    hg.p[k] = grad[k]; hg.n[k] = n[k];
+    GLX_REQUIRE(n[k] == 0 || (W[k] && grad[k]), "glx_head1x1_input_grad: head %d has no weights / gradient", k);
+  }
+  const size_t lds = (size_t)HD_MAXO * (C + 4) * 4;
+  rc = head_lds_attr((const void*)k_head_dgrad, lds);
+  if (rc != GLX_OK) return rc;
+  long long blocks = (M + HD_PIX - 1) / HD_PIX;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_head_dgrad, dim3((unsigned)blocks), dim3(HD_THREADS), lds, (hipStream_t)stream, hg, (long long)M, C, hw, gx);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+extern "C" size_t glx_head1x1_wgrad_workspace_bytes(int C) { return (size_t)HD_WBLOCKS * HD_MAXO * (C + 1) * sizeof(float); }
+
+extern "C" int glx_head1x1_weight_grad(const float* const* grad, const float* x, int64_t M, int C, const int32_t* n,
+                                       float* const* gW, float* const* gb, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+  GLX_REQUIRE(grad && x && n && gW && workspace, "glx_head1x1_weight_grad: null pointer");
+  int rc = head_check(M, C, n, "glx_head1x1_weight_grad");
+  if (rc != GLX_OK) return rc;
+  GLX_REQUIRE(C <= 512 && C / 64 <= 8, "glx_head1x1_weight_grad: C = %d", C);
+  GLX_REQUIRE(workspace_bytes >= glx_head1x1_wgrad_workspace_bytes(C), "glx_head1x1_weight_grad: workspace too small");
+  HeadGrad hg; HeadWOut wo;
+  for (int k = 0; k < 3; ++k) {
+    hg.p[k] = grad[k]; hg.n[k] = n[k];
+    wo.w[k] = gW[k]; wo.b[k] = gb ? gb[k] : nullptr; wo.n[k] = n[k];
+    GLX_REQUIRE(n[k] == 0 || grad[k], "glx_head1x1_weight_grad: head %d has no gradient", k);
+  }
+  long long blocks = (M + 63) / 64;
+  if (blocks > HD_WBLOCKS) blocks = HD_WBLOCKS;
+  hipLaunchKernelGGL(k_head_wgrad, dim3((unsigned)blocks), dim3(HD_THREADS), 0, (hipStream_t)stream, hg, x, (long long)M, C,
+                     (float*)workspace);
+  const int total = n[0] + n[1] + n[2];
+  hipLaunchKernelGGL(k_head_wreduce, dim3(glx_divup((long long)total * (C + 1), 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, (int)blocks, C, wo);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

@@ -485,6 +485,61 @@ class BEVBackbone(nn.Module):
         return total
 
 
+class _Head1x1(torch.autograd.Function):
+    """The anchor head's 1x1 convolutions + permute(0, 2, 3, 1).contiguous() on a channels-last map as one launch per
+    direction (csrc/glx_head.hip): x (B, C, H, W) channels-last, (weight (n, C, 1, 1), bias (n)) per head ->
+    (B, H, W, n) predictions per head."""
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        import ctypes
+        from ._lib import call
+        ws, bs = wb[0::2], wb[1::2]
+        b, c, h, w = x.shape
+        M = b * h * w
+        outs = [torch.empty((b, h, w, wt.shape[0]), dtype=torch.float32, device=x.device) for wt in ws]
+        P3, I3 = ctypes.c_void_p * 3, ctypes.c_int32 * 3
+        pad = lambda seq: list(seq) + [None] * (3 - len(seq))                                   # noqa: E731
+        ptr = lambda seq: P3(*[t.data_ptr() if t is not None else None for t in pad(seq)])      # noqa: E731
+        ctx.n = I3(*[int(wt.shape[0]) for wt in ws] + [0] * (3 - len(ws)))
+        ws2 = [wt.detach().reshape(wt.shape[0], c).contiguous() for wt in ws]
+        call("glx_head1x1_forward", x, ctypes.c_int64(M), c, ptr(ws2), ptr([t.detach() for t in bs]), ctx.n, ptr(outs))
+        ctx.save_for_backward(x, *ws2)
+        ctx.shape = (b, c, h, w, M)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        import ctypes
+        from ._lib import call, query, size_arg
+        from .spconv import core
+        x, ws2 = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        b, c, h, w, M = ctx.shape
+        P3 = ctypes.c_void_p * 3
+        pad = lambda seq: list(seq) + [None] * (3 - len(seq))                                   # noqa: E731
+        ptr = lambda seq: P3(*[t.data_ptr() if t is not None else None for t in pad(seq)])      # noqa: E731
+        gs = [g.contiguous() for g in grads]
+        gx = None
+        gws = [torch.empty((wt.shape[0], c, 1, 1), dtype=torch.float32, device=x.device) for wt in ws2]
+        gbs = [torch.empty(wt.shape[0], dtype=torch.float32, device=x.device) for wt in ws2]
+        side = core.WGRAD_STREAM
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            for t in [x] + gs + gws + gbs:
+                t.record_stream(side)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            nb = query("glx_head1x1_wgrad_workspace_bytes", c)
+            wsp = _lib.workspace.get(nb, x.device)
+            call("glx_head1x1_weight_grad", ptr(gs), x, ctypes.c_int64(M), c, ctx.n, ptr(gws), ptr(gbs), wsp, size_arg(nb))
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((b, c, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+            call("glx_head1x1_input_grad", ptr(gs), ctypes.c_int64(M), c, ptr(list(ws2)), ctx.n, gx)
+        out = [gx]
+        for gw_, gb_ in zip(gws, gbs):
+            out += [gw_, gb_]
+        return tuple(out)
+
+
 class AnchorHead(nn.Module):
     """conv_cls / conv_box / conv_dir_cls, 1x1, with AnchorHeadSingle's bias init (:60-62)."""
 
@@ -529,8 +584,25 @@ class AnchorHead(nn.Module):
             data_dict["dir_cls_preds"] = parts[2].contiguous()
         return data_dict
 
+    OWN_HEAD = os.environ.get("GLX_OWN_HEAD", "1") != "0"
+
+    def _own(self, x):
+        convs = [self.conv_cls, self.conv_box] + ([self.conv_dir_cls] if self.conv_dir_cls is not None else [])
+        return (self.OWN_HEAD and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+                and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] % 64 == 0 and 64 <= x.shape[1] <= 512
+                and all(c.kernel_size == (1, 1) and c.stride == (1, 1) and c.padding == (0, 0) and c.groups == 1
+                        and c.bias is not None for c in convs)
+                and sum(c.out_channels for c in convs) <= 32)
+
     def forward(self, data_dict):
         x = data_dict["spatial_features_2d"]
+        if self._own(x):
+            convs = [self.conv_cls, self.conv_box] + ([self.conv_dir_cls] if self.conv_dir_cls is not None else [])
+            outs = _Head1x1.apply(x, *[t for c in convs for t in (c.weight, c.bias)])
+            data_dict["cls_preds"], data_dict["box_preds"] = outs[0], outs[1]
+            if self.conv_dir_cls is not None:
+                data_dict["dir_cls_preds"] = outs[2]
+            return data_dict
         if (self.FUSE_HEADS and self.conv_cls.bias is not None and self.conv_box.bias is not None
                 and (self.conv_dir_cls is None or self.conv_dir_cls.bias is not None)
                 and all(c.kernel_size == (1, 1) for c in (self.conv_cls, self.conv_box))):

@@ -838,6 +838,19 @@ int glx_pointnet_feat_small(const float* points, int B, int Cin, int P, int C1, 
                             const float* W1, const float* b1, const float* W2, const float* b2,
                             const float* W3, const float* b3, float* out, void* stream);
 
+/* The anchor head's three 1x1 convolutions (pcdet/models/dense_heads/anchor_head_single.py:19-37, 52-75: conv_cls, conv_box,
+ * conv_dir_cls on spatial_features_2d, each followed by permute(0, 2, 3, 1).contiguous()) in one pass per direction over the
+ * channels-last map x (M = B * H * W pixels, C channels, C a multiple of 64 up to 512).  W[k] (n[k], C) row-major, bias[k]
+ * (n[k]) or NULL, out[k] / grad[k] (M, n[k]) row-major = the permuted predictions; n[0] + n[1] + n[2] <= 32, n[2] may be 0.
+ * W / bias / n / out / grad / gW / gb are HOST arrays of three device pointers (ints). */
+int glx_head1x1_forward(const float* x, int64_t M, int C, const float* const* W, const float* const* bias,
+                        const int32_t* n, float* const* out, void* stream);
+int glx_head1x1_input_grad(const float* const* grad, int64_t M, int C, const float* const* W, const int32_t* n, float* gx,
+                           void* stream);
+size_t glx_head1x1_wgrad_workspace_bytes(int C);
+int glx_head1x1_weight_grad(const float* const* grad, const float* x, int64_t M, int C, const int32_t* n, float* const* gW,
+                            float* const* gb, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Training twin of the extractor's last layer (cvae_uncertainty/point_net.py:22-28: conv3 + bn3, max over the points;
  * model.py:200-243 trains through it): the (B x P x 512) tensor is never built.  h2 (B * P, 128) row-major = the second
  * layer's output, W3p = the (512, 128) weight in the fragment order of glx_pointnet_feat.

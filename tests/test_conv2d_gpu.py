@@ -335,3 +335,41 @@ def test_dropin_accelerate_reclasses_a_reference_shaped_backbone(dev):
     assert torch.allclose(xa.grad, xb.grad, rtol=1e-3, atol=1e-5 * float(xa.grad.abs().max()))
     for a, p in zip(ga, m.parameters()):
         assert torch.allclose(a, p.grad, rtol=1e-3, atol=2e-5 * float(a.abs().max()) + 1e-9)
+
+
+@pytest.mark.parametrize("B,H,W,C,dirs", [(2, 25, 22, 256, 4), (1, 7, 9, 64, 0), (4, 200, 176, 256, 4)])
+def test_anchor_head_1x1_convolutions_in_one_pass_equal_the_modules(dev, B, H, W, C, dirs):
+    """dense_path._Head1x1 (csrc/glx_head.hip: conv_cls, conv_box, conv_dir_cls + permute(0, 2, 3, 1).contiguous() of
+    anchor_head_single.py:52-75 as one launch per direction over the channels-last map) against the three nn.Conv2d
+    modules: predictions, input gradient, filter and bias gradients (fp32 MFMA: 2e-6 of each tensor's scale; the gradients
+    of the filters sum 140 800 pixels at the full size: 2e-5)."""
+    from glenet_amd import dense_path as dp
+    torch.manual_seed(C + H)
+    head = dp.AnchorHead(C, num_class=1, num_anchors_per_location=2, code_size=7, num_dir_bins=2 if dirs else 0).to(dev)
+    with torch.no_grad():
+        for p in head.parameters():
+            p.copy_(torch.randn_like(p) * 0.1)
+    x = torch.randn(B, C, H, W, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    names = ["cls_preds", "box_preds"] + (["dir_cls_preds"] if dirs else [])
+    gouts = None
+    res = {}
+    for own in (False, True):
+        dp.AnchorHead.OWN_HEAD, fuse = own, dp.AnchorHead.FUSE_HEADS
+        dp.AnchorHead.FUSE_HEADS = False
+        try:
+            x.grad = None
+            head.zero_grad(set_to_none=True)
+            out = head({"spatial_features_2d": x})
+            if gouts is None:
+                gouts = [torch.randn_like(out[k]) for k in names]
+            torch.autograd.backward([out[k] for k in names], gouts)
+            res[own] = ([out[k].detach().clone() for k in names], x.grad.clone(),
+                        {n: p.grad.clone() for n, p in head.named_parameters()})
+        finally:
+            dp.AnchorHead.OWN_HEAD, dp.AnchorHead.FUSE_HEADS = True, fuse
+    for a, b in zip(res[True][0], res[False][0]):
+        assert a.shape == b.shape and a.is_contiguous()
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-7
+    assert float((res[True][1] - res[False][1]).abs().max()) <= 2e-6 * float(res[False][1].abs().max()) + 1e-7
+    for n, g in res[False][2].items():
+        assert float((res[True][2][n] - g).abs().max()) <= 2e-5 * float(g.abs().max()) + 1e-6, n
