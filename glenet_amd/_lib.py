@@ -124,7 +124,7 @@ class SconvOpts(ctypes.Structure):
 
 
 class ConvOpts(ctypes.Structure):
-    _fields_ = [("bn", ctypes.POINTER(BnStats)), ("epilogue", ctypes.POINTER(Epilogue))]
+    _fields_ = [("bn", ctypes.POINTER(BnStats)), ("epilogue", ctypes.POINTER(Epilogue)), ("prologue", ctypes.POINTER(Epilogue))]
 
 
 def bn_stats(state, bn, coef, save_mean, save_invstd):

@@ -93,22 +93,29 @@ def packs(weight):
     return fwd, bwd
 
 
-def _run(x, pack, cout, bn=None, epi=None):
+def _run(x, pack, cout, bn=None, epi=None, pre=None):
     """bn: a training-mode BatchNorm2d that follows the conv -- its batch statistics are taken in the kernel's epilogue
-    (glx_conv_opts.bn) and the call returns (y, coef, save_mean, save_invstd).  epi: an _lib.Epilogue (inference)."""
+    (glx_conv_opts.bn) and the call returns (y, coef, save_mean, save_invstd).  epi: an _lib.Epilogue (inference).
+    pre: (coef (2 * Cin: scale, shift), relu) -- the input is transformed on load (glx_conv_opts.prologue)."""
     b, c, h, w = x.shape
     if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)):
         raise _lib.GlxError("conv3x3 expects a float32 channels-last device map, got %s strides %s on %s"
                             % (x.dtype, tuple(x.stride()), x.device))
     y = torch.empty((b, cout, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     stats = opts = None
+    prologue = None
+    if pre is not None:
+        coef, relu = pre
+        prologue = ctypes.pointer(_lib.epilogue(coef[:c], coef[c:], relu))
     if bn is not None:
         from .spconv import core
         stats = tuple(torch.empty(n, dtype=torch.float32, device=x.device) for n in (2 * cout, cout, cout))
         st = _lib.bn_stats(core._bn_state(x.device), bn, *stats)
-        opts = _lib.ConvOpts(ctypes.pointer(st), None)
+        opts = _lib.ConvOpts(ctypes.pointer(st), None, prologue)
     elif epi is not None:
-        opts = _lib.ConvOpts(None, ctypes.pointer(epi))
+        opts = _lib.ConvOpts(None, ctypes.pointer(epi), prologue)
+    elif prologue is not None:
+        opts = _lib.ConvOpts(None, None, prologue)
     call("glx_conv3x3_forward_ex", x, b, h, w, c, pack, cout, y, ctypes.byref(opts) if opts is not None else None)
     if bn is not None:
         if bn.track_running_stats:
@@ -117,8 +124,9 @@ def _run(x, pack, cout, bn=None, epi=None):
     return y
 
 
-def wgrad(x, gy, weight):
-    """dW of conv3x3 for a weight of `weight`'s shape and strides (a fresh tensor).  The split-K workspace is the
+def wgrad(x, gy, weight, pre=None):
+    """dW of conv3x3 for a weight of `weight`'s shape and strides (a fresh tensor); pre as in _run (the input is
+    transformed on load).  The split-K workspace is the
     (device, CURRENT stream, pipeline scope) buffer of _lib.workspace: weight gradients launched on different streams
     (the staged backward moves them between the main and the side stream; two pipelines) never share it."""
     cout, cin = int(weight.shape[0]), int(weight.shape[1])
@@ -128,7 +136,11 @@ def wgrad(x, gy, weight):
     gw = torch.empty_like(weight)
     s = gw.stride()
     ll = ctypes.c_longlong
-    call("glx_conv3x3_wgrad", x, gy, b, h, w, cin, cout, gw, ll(s[0]), ll(s[1]), ll(s[2]), ll(s[3]), ws,
+    prologue = None
+    if pre is not None:
+        coef, relu = pre
+        prologue = ctypes.byref(_lib.epilogue(coef[:cin], coef[cin:], relu))
+    call("glx_conv3x3_wgrad_ex", x, gy, b, h, w, cin, cout, gw, ll(s[0]), ll(s[1]), ll(s[2]), ll(s[3]), prologue, ws,
          _lib.size_arg(n))
     return gw
 
@@ -173,24 +185,93 @@ class _Conv3x3(torch.autograd.Function):
         return gx, gw, None
 
 
+class _ConvPre3x3(torch.autograd.Function):
+    """conv3x3(relu(bn_prev(y_prev)), weight) (+ the statistics of `bn` in the epilogue) WITHOUT the normalised map: the
+    convolution and its weight gradient transform y_prev on load (glx_conv_opts.prologue, coef_prev = the scale / shift the
+    previous convolution's epilogue left), and this node's backward carries the previous BatchNorm's backward
+    (glx_bn_relu_backward on y_prev and the input gradient): one pass over the map less per layer forward.
+    Inputs (y_prev, coef_prev, mean_prev, invstd_prev, gamma_prev, beta_prev, weight, bn) -> (y, coef, mean, invstd)."""
+
+    @staticmethod
+    def forward(ctx, y_prev, coef_prev, mean_prev, invstd_prev, gamma_prev, beta_prev, weight, bn):
+        fwd, bwd = packs(weight)
+        ctx.save_for_backward(y_prev, coef_prev, mean_prev, invstd_prev, gamma_prev, beta_prev, weight)
+        ctx.bwd_pack = bwd
+        out = _run(y_prev.detach(), fwd, int(weight.shape[0]), bn, pre=(coef_prev, True))
+        ctx.mark_non_differentiable(*out[1:])
+        ctx.set_materialize_grads(False)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy, *_):
+        from .spconv import core
+        y_prev, coef_prev, mean_prev, invstd_prev, gamma_prev, beta_prev, weight = ctx.saved_tensors
+        if gy is None:
+            return (None,) * 8
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        gw = None
+        if ctx.needs_input_grad[6]:
+            side = core.WGRAD_STREAM
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream(y_prev.device))
+                for t in (y_prev, gy, weight, coef_prev):
+                    t.record_stream(side)
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                gw = wgrad(y_prev, gy, weight, pre=(coef_prev, True))
+        gh = _run(gy, ctx.bwd_pack, int(weight.shape[1]))                  # gradient of relu(bn_prev(y_prev))
+        b, c, h, w = y_prev.shape
+        n = b * h * w
+        rows = y_prev.permute(0, 2, 3, 1).reshape(n, c)
+        grows = gh.permute(0, 2, 3, 1).reshape(n, c)
+        dx = torch.empty_like(rows)
+        dgamma = torch.empty(c, dtype=torch.float32, device=rows.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=rows.device)
+        ws = core.workspace.get(query("glx_bn_workspace_bytes", c), rows.device)
+        call("glx_bn_relu_backward", rows, grows, None, n, c, gamma_prev, beta_prev, mean_prev, invstd_prev, 1, dx,
+             dgamma, dbeta, None, ws, _lib.size_arg(ws.numel()), core._bn_state(rows.device), 0)
+        return dx.view(b, h, w, c).permute(0, 3, 1, 2), None, None, None, dgamma, dbeta, gw, None
+
+
 def conv3x3(x, weight):
     return _Conv3x3.apply(x, weight)
 
 
-def conv3x3_bn(x, weight, bn, relu):
-    """relu?(bn(conv3x3(x, weight))) for a training-mode nn.BatchNorm2d: statistics in the conv's epilogue, the
-    transform (and the whole backward of the BatchNorm) on the fused row kernels of csrc/glx_bn.hip."""
+def _count_batch(bn):
     from .spconv import core
-    y, coef, mean, invstd = _Conv3x3.apply(x, weight, bn)
-    b, c, h, w = y.shape
-    rows = y.permute(0, 2, 3, 1).reshape(b * h * w, c)              # a view of channels-last memory
-    out = core.FusedBNApply.apply(rows, coef, mean, invstd, bn.weight, bn.bias, relu)
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         if core.DEFERRED_COUNTERS is not None:
             core.DEFERRED_COUNTERS.append(bn.num_batches_tracked)
         else:
             bn.num_batches_tracked += 1
+
+
+def conv3x3_bn_raw(x, weight, bn, pending=None):
+    """The convolution in front of a training-mode BatchNorm2d with the statistics in its epilogue, the transform NOT
+    applied: returns (y, coef, mean, invstd, bn) for bn_apply() or for the next layer's conv3x3_bn_raw(pending=...), which
+    then reads y through the transform (x is ignored)."""
+    if pending is not None:
+        y_prev, coef_prev, mean_prev, invstd_prev, bn_prev = pending
+        out = _ConvPre3x3.apply(y_prev, coef_prev, mean_prev, invstd_prev, bn_prev.weight, bn_prev.bias, weight, bn)
+    else:
+        out = _Conv3x3.apply(x, weight, bn)
+    _count_batch(bn)
+    return out + (bn,)
+
+
+def bn_apply(pending, relu):
+    """relu?(bn(y)) of a conv3x3_bn_raw() result as a map (csrc/glx_bn.hip row kernels)."""
+    from .spconv import core
+    y, coef, mean, invstd, bn = pending
+    b, c, h, w = y.shape
+    rows = y.permute(0, 2, 3, 1).reshape(b * h * w, c)              # a view of channels-last memory
+    out = core.FusedBNApply.apply(rows, coef, mean, invstd, bn.weight, bn.bias, relu)
     return out.view(b, h, w, c).permute(0, 3, 1, 2)
+
+
+def conv3x3_bn(x, weight, bn, relu):
+    """relu?(bn(conv3x3(x, weight))) for a training-mode nn.BatchNorm2d: statistics in the conv's epilogue, the
+    transform (and the whole backward of the BatchNorm) on the fused row kernels of csrc/glx_bn.hip."""
+    return bn_apply(conv3x3_bn_raw(x, weight, bn), relu)
 
 
 # ------------------------------------------------------------------------------------------------ transposed convolutions

@@ -77,6 +77,9 @@ struct ConvArgs {
   const float* epi_scale;   // inference epilogue (glx_conv_opts.epilogue): y = relu?(conv * scale[c] + shift[c]), second form
   const float* epi_shift;
   int epi_relu;
+  const float* pre_scale;   // input transform on load (glx_conv_opts.prologue): x' = relu?(x * scale[c] + shift[c]) at the pixels
+  const float* pre_shift;   // of the map (the zero padding stays zero) -- the BatchNorm (+ ReLU) of the layer in front, second form
+  int pre_relu;
 };
 
 struct ConvTile {
@@ -338,11 +341,21 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
 // 43 % of the blocks) or 1276 of 7 (1.66); 100 x 88 x 4 with two channel blocks are 720 units of 7 rows, one round.
 // (Six rows measured the same as seven and are instantiated for experiments only: GLX_CONV3X3_TH=6.)
 
-template <bool STATS, int TH>
+// PRE: the input is transformed on load (a.pre_scale / a.pre_shift, staged in LDS behind the halo planes: the kernel sits
+// at its 168-register budget, eight more live registers for the coefficients spilled 27 more -- as a template parameter the
+// plain kernels compile as before).
+template <bool STATS, int TH, bool PRE = false>
 __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
   constexpr int HP = (TH + 2) * CV_HW, NL = (HP * 8 + 255) / 256, PLANE = HP * CV_ROW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;
+  float* s_pre = reinterpret_cast<float*>(smem + 3 * PLANE);      // PRE: scale[Cin], shift[Cin]
+  if constexpr (PRE) {
+    for (int e = threadIdx.x; e < a.Cin; e += 256) {
+      s_pre[e] = a.pre_scale[e];
+      s_pre[a.Cin + e] = a.pre_shift[e];
+    }
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kq = lane >> 4;
   const int nch = a.Cin >> 5;
@@ -373,6 +386,14 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
     if (tid + i_ * 256 < HP * 8) {                                                                      \
       char* d_ = sA + adst0 + i_ * 32 * CV_ROW;                                                         \
       bf16x4 p0_, p1_, p2_;                                                                             \
+      if (PRE && aoff[i_] >= 0) {                                                                       \
+        const f32x4 sc_ = *reinterpret_cast<const f32x4*>(s_pre + pre_ch * 32 + (tid & 7) * 4);         \
+        const f32x4 sh_ = *reinterpret_cast<const f32x4*>(s_pre + a.Cin + pre_ch * 32 + (tid & 7) * 4); \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                              \
+          const float t_ = __fmaf_rn(areg[i_][j_], sc_[j_], sh_[j_]);                                   \
+          areg[i_][j_] = a.pre_relu ? fmaxf(t_, 0.f) : t_;                                              \
+        }                                                                                               \
+      }                                                                                                 \
       _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                \
         __bf16 u_, v_, w_;                                                                              \
         cv_split(areg[i_][j_], u_, v_, w_);                                                             \
@@ -413,6 +434,8 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
     }
     for (int ch = 0; ch < nch; ++ch) {
       __syncthreads();                    // everyone is done reading the previous halo image
+      const int pre_ch = ch;              // the thread's four channels of the staged chunk: 32 ch + 4 (tid & 7) ..
+      (void)pre_ch;
       V2_STORE_A();
       __syncthreads();
       const bool last = ch + 1 == nch;
@@ -543,6 +566,9 @@ struct WgradArgs {
   const float* gy;    // (B, H, W, Cout)
   float* ws;          // (blocks, WG_PART)
   int B, H, W, Cin, Cout, tiles_x, tiles_y, ntiles, nq_ci, nq, P;
+  const float* pre_scale;   // x' = relu?(x * scale[c] + shift[c]) on load (the BatchNorm + ReLU in front of the layer), or NULL
+  const float* pre_shift;
+  int pre_relu;
 };
 
 template <bool PIPE>
@@ -563,6 +589,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
     adst[i] = e < CV_HP * 8 ? hp * 64 + (((seg >> 2) ^ ((hx >> 3) & 1)) << 5) + (seg & 3) * 8 : -1;
   }
   f32x4 areg[CV_ALOADS];     // x halo of the next tile
+  unsigned aok = 0;          // which of them are pixels of the map (the zero padding is not transformed)
+  f32x4 pre_sc = f32x4{1.f, 1.f, 1.f, 1.f}, pre_sh = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (a.pre_scale) {         // the thread's four channels: 32 ib + 4 (tid & 7) ..
+    pre_sc = *reinterpret_cast<const f32x4*>(a.pre_scale + ib * 32 + (tid & 7) * 4);
+    pre_sh = *reinterpret_cast<const f32x4*>(a.pre_shift + ib * 32 + (tid & 7) * 4);
+  }
   float graw[2][8];          // gy of the next k-step: channel tile 2 cp + a2, pixel 8 (kq & 1) + jj of tile row 2 s + (kq >> 1)
   const int cp = wave >> 1, nn = wave & 1;
 #define WG_LOADX(T)                                                                                       \
@@ -576,6 +608,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
       const int hp_ = e_ >> 3, seg_ = e_ & 7;                                                             \
       const int gy_ = y0_ - 1 + hp_ / CV_HW, gx_ = x0_ - 1 + hp_ % CV_HW;                                 \
       const bool ok_ = e_ < CV_HP * 8 && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W;                  \
+      aok = ok_ ? (aok | (1u << i_)) : (aok & ~(1u << i_));                                               \
       areg[i_] = ok_ ? *reinterpret_cast<const f32x4*>(a.x + (((long long)b_ * a.H + gy_) * a.W + gx_) * a.Cin + \
                                                        ib * 32 + seg_ * 4)                                 \
                      : f32x4{0.f, 0.f, 0.f, 0.f};                                                         \
@@ -622,6 +655,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
     for (int i = 0; i < CV_ALOADS; ++i) {
       if (adst[i] >= 0) {
         bf16x4 p0, p1, p2;
+        if (a.pre_scale && ((aok >> i) & 1u)) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = __fmaf_rn(areg[i][e], pre_sc[e], pre_sh[e]);
+            areg[i][e] = a.pre_relu ? fmaxf(t, 0.f) : t;
+          }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           __bf16 u, v, w;
@@ -742,15 +782,29 @@ extern "C" size_t glx_conv3x3_wgrad_workspace_bytes(int Cin, int Cout) {
   return glx_align((size_t)blocks * WG_PART * sizeof(float));
 }
 
+extern "C" int glx_conv3x3_wgrad_ex(const float* x, const float* gy, int B, int H, int W, int Cin, int Cout, float* dW,
+                                    long long s_co, long long s_ci, long long s_kh, long long s_kw, const glx_epilogue* pre,
+                                    void* workspace, size_t workspace_bytes, void* stream);
 extern "C" int glx_conv3x3_wgrad(const float* x, const float* gy, int B, int H, int W, int Cin, int Cout, float* dW,
                                  long long s_co, long long s_ci, long long s_kh, long long s_kw, void* workspace,
                                  size_t workspace_bytes, void* stream) {
+  return glx_conv3x3_wgrad_ex(x, gy, B, H, W, Cin, Cout, dW, s_co, s_ci, s_kh, s_kw, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int glx_conv3x3_wgrad_ex(const float* x, const float* gy, int B, int H, int W, int Cin, int Cout, float* dW,
+                                    long long s_co, long long s_ci, long long s_kh, long long s_kw, const glx_epilogue* pre,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(!pre || (pre->scale && pre->shift && pre->ldc == 0 && pre->coff == 0),
+              "glx_conv3x3_wgrad_ex: the prologue needs scale and shift (Cin floats each)");
   GLX_REQUIRE(B > 0 && H > 0 && W > 0, "glx_conv3x3_wgrad: empty map (%d, %d, %d)", B, H, W);
   GLX_REQUIRE(Cin % 32 == 0 && Cout % CV_BN == 0, "glx_conv3x3_wgrad: needs Cin %% 32 == 0 and Cout %% 64 == 0 (got %d -> %d)",
               Cin, Cout);
   GLX_REQUIRE(workspace_bytes >= glx_conv3x3_wgrad_workspace_bytes(Cin, Cout), "glx_conv3x3_wgrad: workspace too small");
   WgradArgs a;
   a.x = x; a.gy = gy; a.ws = (float*)workspace;
+  a.pre_scale = pre ? pre->scale : nullptr;
+  a.pre_shift = pre ? pre->shift : nullptr;
+  a.pre_relu = pre ? pre->relu : 0;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.tiles_x = glx_divup(W, CV_TW); a.tiles_y = glx_divup(H, CV_TH);
   a.ntiles = a.tiles_x * a.tiles_y * B;
@@ -866,6 +920,7 @@ extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int C
                                       float* y, const glx_conv_opts* opts, void* stream) {
   const glx_bn_stats* bnp = opts ? opts->bn : nullptr;
   const glx_epilogue* epi = opts ? opts->epilogue : nullptr;
+  const glx_epilogue* pre = opts ? opts->prologue : nullptr;
   BnState* bn_state = bnp ? (BnState*)bnp->state : nullptr;
   BnFinalize bn_fin = {};
   if (bnp) {
@@ -886,7 +941,9 @@ extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int C
   GLX_REQUIRE(!bn_state || Cout <= BN_MAXC, "glx_conv3x3_forward: BatchNorm statistics for at most %d channels", BN_MAXC);
   void (*kern)(ConvArgs) = bn_state ? k_conv3x3<0, true> : k_conv3x3<0, false>;
   int slot = bn_state ? 7 : 0;
-  const bool v2 = (g_conv_form == 2 && g_conv_ablate == 0) || epi_scale;      // the epilogue lives in the second form
+  GLX_REQUIRE(!pre || (pre->scale && pre->shift && pre->ldc == 0 && pre->coff == 0),
+              "glx_conv3x3_forward_ex: the prologue needs scale and shift (Cin floats each)");
+  const bool v2 = (g_conv_form == 2 && g_conv_ablate == 0) || epi_scale || pre;   // epilogue / prologue live in the second form
   int th = CV_TH;
   if (v2) {
     // rows per tile: the fewest (rounds of the resident blocks) x (rows + a fixed cost per tile)
@@ -898,7 +955,11 @@ extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int C
       if (best < 0 || cost < best) { best = cost; th = t; }
     }
     if (g_conv_th >= 6 && g_conv_th <= 8) th = g_conv_th;
-    if (th == 8) kern = bn_state ? k_conv3x3_v2<true, 8> : k_conv3x3_v2<false, 8>;
+    if (pre) {
+      if (th == 8) kern = bn_state ? k_conv3x3_v2<true, 8, true> : k_conv3x3_v2<false, 8, true>;
+      else if (th == 7) kern = bn_state ? k_conv3x3_v2<true, 7, true> : k_conv3x3_v2<false, 7, true>;
+      else kern = bn_state ? k_conv3x3_v2<true, 6, true> : k_conv3x3_v2<false, 6, true>;
+    } else if (th == 8) kern = bn_state ? k_conv3x3_v2<true, 8> : k_conv3x3_v2<false, 8>;
     else if (th == 7) kern = bn_state ? k_conv3x3_v2<true, 7> : k_conv3x3_v2<false, 7>;
     else kern = bn_state ? k_conv3x3_v2<true, 6> : k_conv3x3_v2<false, 6>;
   }
@@ -914,12 +975,13 @@ extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int C
     slot = g_conv_ablate & 7;
     if (slot == 7) slot = 0;
   }
-  const int lds_bytes = v2 ? 3 * (th + 2) * CV_HW * CV_ROW : CV_LDS;
+  const int lds_bytes = v2 ? 3 * (th + 2) * CV_HW * CV_ROW + (pre ? 2 * Cin * (int)sizeof(float) : 0) : CV_LDS;
   if (v2) {
-    static bool v2_set[2][9] = {};
-    if (!v2_set[bn_state ? 1 : 0][th]) {
+    static int v2_set[2][2][9] = {};      // largest dynamic LDS size registered per instantiation
+    int& reg = v2_set[pre ? 1 : 0][bn_state ? 1 : 0][th];
+    if (reg < lds_bytes) {
       GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-      v2_set[bn_state ? 1 : 0][th] = true;
+      reg = lds_bytes;
     }
   } else {
     static bool attr_set[8] = {};
@@ -948,6 +1010,9 @@ extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int C
   a.epi_scale = epi_scale;
   a.epi_shift = epi_shift;
   a.epi_relu = epi_relu;
+  a.pre_scale = pre ? pre->scale : nullptr;
+  a.pre_shift = pre ? pre->shift : nullptr;
+  a.pre_relu = pre ? pre->relu : 0;
   const int resident = slots * (v2 ? conv_per_cu() : 2);
   int grid = g_conv_grid > 0 ? g_conv_grid : (a.ntiles < resident ? a.ntiles : resident);
   if (bn_state) grid = grid / a.nblk * a.nblk;   // every block keeps one channel block (ntiles is a multiple of nblk)

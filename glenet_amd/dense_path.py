@@ -114,6 +114,10 @@ OWN_DECONV = os.environ.get("GLX_OWN_DECONV", "1") != "0"       # the deblocks' 
 BEV_FIRST_KEY = "bev_first"      # indice_key of the first BEV layer's rule table (spconv.core.PlannedConv)
 SPARSE_FIRST_BEV_LAYER = os.environ.get("GLX_BEV_SPARSE_FIRST", "1") != "0"   # see BEVBackbone._first_layer_sparse
 FUSE_BN_IN_CONV3X3 = os.environ.get("GLX_CONV3X3_BN", "1") != "0"    # ... with the next BatchNorm's statistics in the epilogue
+# ... and a layer's BatchNorm + ReLU applied ON LOAD by the next 3x3 layer of the block (forward and weight gradient read the
+# raw convolution output through scale / shift; the next layer's backward carries this BatchNorm's backward): the normalised
+# map of the inner layers of a block is never written (base_bev_backbone.py:36-49)
+BN_ON_LOAD = os.environ.get("GLX_CONV3X3_BN_ON_LOAD", "1") != "0"
 
 
 def _pair(v):
@@ -433,15 +437,29 @@ class BEVBackbone(nn.Module):
                 and x.is_contiguous(memory_format=torch.channels_last))
 
     @staticmethod
+    def _own_bn_conv(conv, bn, x):
+        """conv: a 3x3 / stride-1 / pad-1 Conv2d on the own kernels whose training-mode BatchNorm `bn` rides in its epilogue
+        -- the layers that can read their input through the previous layer's BatchNorm + ReLU."""
+        return (FUSE_BN_IN_CONV3X3 and OWN_CONV3X3 and not isinstance(conv.padding, str) and conv.padding_mode == "zeros"
+                and _pair(conv.padding) == (1, 1) and _pair(conv.stride) == (1, 1) and conv.kernel_size == (3, 3)
+                and _leaf(conv.weight) and BEVBackbone._bn_fusable(bn) and own_conv.bn_state_available() and x.is_cuda
+                and bn.num_features == conv.out_channels and conv.in_channels == x.shape[1]
+                and own_conv.supported(x, conv.weight, (1, 1), (1, 1), _pair(conv.dilation), conv.groups, conv.bias))
+
+    @staticmethod
     def _run_block(blk, x, start=0):
         """nn.Sequential semantics with ZeroPad2d(1) + Conv2d(k=3, padding=0) run as ONE convolution with
         padding=1: the same sums over the same zeros, without materialising the padded copy of the input (77 us
         forward + 55 us backward for the 144 MB BEV map) -- module list and parameter names stay the reference's."""
         mods = list(blk)
         i = start
+        pending = None        # (y, coef, mean, invstd, bn) of a conv whose BatchNorm + ReLU the NEXT conv applies on load
         while i < len(mods):
             m = mods[i]
             conv, step = None, 1
+            if pending is not None and not (isinstance(m, nn.Conv2d) and i + 1 < len(mods)
+                                            and BEVBackbone._own_bn_conv(m, mods[i + 1], x)):
+                x, pending = own_conv.bn_apply(pending, True), None         # not the layer that was expected: materialise
             if (isinstance(m, nn.ZeroPad2d) and tuple(m.padding) == (1, 1, 1, 1) and i + 1 < len(mods)
                     and isinstance(mods[i + 1], nn.Conv2d) and mods[i + 1].padding == (0, 0)
                     and mods[i + 1].kernel_size == (3, 3) and mods[i + 1].dilation == (1, 1)):
@@ -457,8 +475,16 @@ class BEVBackbone(nn.Module):
                         and x.is_cuda and bn.num_features == conv.out_channels and own_conv.supported(
                             x, conv.weight, _pair(conv.stride), pad, _pair(conv.dilation), conv.groups, conv.bias)):
                     relu = j + 1 < len(mods) and isinstance(mods[j + 1], nn.ReLU)
-                    x = own_conv.conv3x3_bn(x, conv.weight, bn, relu)
-                    i = j + (2 if relu else 1)
+                    raw = own_conv.conv3x3_bn_raw(x, conv.weight, bn, pending)
+                    pending = None
+                    nxt = j + (2 if relu else 1)
+                    # BatchNorm + ReLU of this layer on load in the next own convolution of the block (no normalised map)
+                    if (BN_ON_LOAD and relu and nxt + 1 < len(mods) and isinstance(mods[nxt], nn.Conv2d)
+                            and BEVBackbone._own_bn_conv(mods[nxt], mods[nxt + 1], raw[0])):
+                        pending, x = raw, raw[0]
+                    else:
+                        x = own_conv.bn_apply(raw, relu)
+                    i = nxt
                     continue
                 x = conv2d(x, conv.weight, conv.bias, conv.stride, pad, conv.dilation, conv.groups)
                 i += step
@@ -470,6 +496,8 @@ class BEVBackbone(nn.Module):
                 continue
             x = conv_module(m, x) if isinstance(m, nn.ConvTranspose2d) else m(x)
             i += 1
+        if pending is not None:
+            x = own_conv.bn_apply(pending, True)
         return x
 
     @staticmethod

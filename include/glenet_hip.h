@@ -82,6 +82,10 @@ typedef struct glx_sconv_opts {
 typedef struct glx_conv_opts {
   const glx_bn_stats* bn;
   const glx_epilogue* epilogue;
+  /* glx_conv3x3_forward_ex only: transform of the INPUT on load, x' = relu?(x * scale[c] + shift[c]) at the pixels of the map
+   * (the zero padding stays zero; scale, shift: Cin device floats, ldc = coff = 0) -- the training-mode BatchNorm (+ ReLU) of
+   * the layer in front applied without writing the normalised map (base_bev_backbone.py:36-49).  NULL: none. */
+  const glx_epilogue* prologue;
 } glx_conv_opts;
 
 /* ROCm 7.2 workaround (csrc/glx_graph.hip): a hipMemsetAsync recorded into a HIP graph is replayed with a stale pattern from
@@ -949,6 +953,10 @@ size_t glx_conv3x3_wgrad_workspace_bytes(int Cin, int Cout);
 int glx_conv3x3_wgrad(const float* x, const float* gy, int B, int H, int W, int Cin, int Cout, float* dW,
                       long long s_co, long long s_ci, long long s_kh, long long s_kw, void* workspace,
                       size_t workspace_bytes, void* stream);
+/* The same for an input that is transformed on load (`pre` as glx_conv_opts.prologue; NULL = glx_conv3x3_wgrad). */
+int glx_conv3x3_wgrad_ex(const float* x, const float* gy, int B, int H, int W, int Cin, int Cout, float* dW,
+                         long long s_co, long long s_ci, long long s_kh, long long s_kw, const glx_epilogue* pre,
+                         void* workspace, size_t workspace_bytes, void* stream);
 /* ---- transposed convolutions with kernel = stride = u in {1, 2}, no padding (BaseBEVBackbone's deblocks,
  * base_bev_backbone.py:51-66: ConvTranspose2d(c, cu, u, stride=u, bias=False)), channels-last fp32 maps, same split-bf16
  * arithmetic (csrc/glx_deconv2d.hip).  W (Cin, Cout, u, u) with ELEMENT strides (s_ci, s_co, s_kh, s_kw); channel counts

@@ -92,9 +92,9 @@ def test_bev_backbone_runs_its_block_layers_on_the_own_kernels(dev, monkeypatch)
     m = dp.BEVBackbone(64, layer_nums=(1, 1), num_filters=(64, 128)).to(dev).to(memory_format=torch.channels_last).train()
     x = _cl(torch.randn(2, 64, 24, 32, device=dev))
     calls = []
-    real, real_bn = dp.own_conv.conv3x3, dp.own_conv.conv3x3_bn
+    real, real_bn = dp.own_conv.conv3x3, dp.own_conv.conv3x3_bn_raw
     monkeypatch.setattr(dp.own_conv, "conv3x3", lambda a, b: (calls.append(tuple(b.shape)), real(a, b))[1])
-    monkeypatch.setattr(dp.own_conv, "conv3x3_bn", lambda a, b, *r: (calls.append(tuple(b.shape)), real_bn(a, b, *r))[1])
+    monkeypatch.setattr(dp.own_conv, "conv3x3_bn_raw", lambda a, b, *r: (calls.append(tuple(b.shape)), real_bn(a, b, *r))[1])
     outs = []
     for own in (True, False):
         monkeypatch.setattr(dp, "OWN_CONV3X3", own)
@@ -373,3 +373,42 @@ def test_anchor_head_1x1_convolutions_in_one_pass_equal_the_modules(dev, B, H, W
     assert float((res[True][1] - res[False][1]).abs().max()) <= 2e-6 * float(res[False][1].abs().max()) + 1e-7
     for n, g in res[False][2].items():
         assert float((res[True][2][n] - g).abs().max()) <= 2e-5 * float(g.abs().max()) + 1e-6, n
+
+
+def test_batchnorm_on_load_in_the_next_convolution_equals_the_materialised_map(dev):
+    """dense_path.BN_ON_LOAD: the inner layers of a BEV block read the previous layer's raw convolution output through its
+    BatchNorm + ReLU (glx_conv_opts.prologue in forward and weight gradient; the BatchNorm's backward rides in the next
+    layer's node) -- output, running statistics and every gradient against the same block with the normalised maps
+    written (base_bev_backbone.py:36-49), both on the own kernels: bitwise-equal products, so 1e-6 of scale."""
+    import copy
+    from glenet_amd import dense_path as dp
+    torch.manual_seed(3)
+    bev = dp.BEVBackbone(64, layer_nums=(3, 2), layer_strides=(1, 2), num_filters=(64, 128), upsample_strides=(1, 2),
+                         num_upsample_filters=(128, 128)).to(dev).train()
+    with torch.no_grad():
+        for m in bev.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(torch.rand_like(m.weight) + 0.5)
+                m.bias.copy_(torch.randn_like(m.bias) * 0.3)
+    ref = copy.deepcopy(bev)
+    x = _cl(torch.randn(2, 64, 40, 48, device=dev))
+    g = None
+    outs = {}
+    for on, net in ((True, bev), (False, ref)):
+        dp.BN_ON_LOAD = on
+        try:
+            xi = x.clone().requires_grad_(True)
+            y = net({"spatial_features": xi})["spatial_features_2d"]
+            if g is None:
+                g = torch.randn_like(y)
+            y.backward(g)
+            outs[on] = (y.detach(), xi.grad, net)
+        finally:
+            dp.BN_ON_LOAD = True
+    (ya, ga, na), (yb, gb_, nb) = outs[True], outs[False]
+    assert float((ya - yb).abs().max()) <= 1e-6 * float(yb.abs().max())
+    assert float((ga - gb_).abs().max()) <= 1e-5 * float(gb_.abs().max())
+    for (n1, p1), (n2, p2) in zip(na.named_parameters(), nb.named_parameters()):
+        assert float((p1.grad - p2.grad).abs().max()) <= 1e-5 * float(p2.grad.abs().max()) + 1e-8, n1
+    for (n1, b1), (n2, b2) in zip(na.named_buffers(), nb.named_buffers()):
+        assert torch.allclose(b1.float(), b2.float(), rtol=1e-6, atol=1e-7), n1
