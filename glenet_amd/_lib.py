@@ -123,8 +123,14 @@ class SconvOpts(ctypes.Structure):
                 ("profile_stop", c_void_p)]
 
 
+class BnBwdStats(ctypes.Structure):
+    _fields_ = [("state", c_void_p), ("y", c_void_p), ("coef_fwd", c_void_p), ("mean", c_void_p), ("invstd", c_void_p),
+                ("gamma", c_void_p), ("coef", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p)]
+
+
 class ConvOpts(ctypes.Structure):
-    _fields_ = [("bn", ctypes.POINTER(BnStats)), ("epilogue", ctypes.POINTER(Epilogue)), ("prologue", ctypes.POINTER(Epilogue))]
+    _fields_ = [("bn", ctypes.POINTER(BnStats)), ("epilogue", ctypes.POINTER(Epilogue)), ("prologue", ctypes.POINTER(Epilogue)),
+                ("bn_bwd", ctypes.POINTER(BnBwdStats))]
 
 
 def bn_stats(state, bn, coef, save_mean, save_invstd):

@@ -7,6 +7,7 @@ six bf16 products of three-way split operands with fp32 accumulation (fp32 accur
 the flipped pack for the input gradient and leaves the weight gradient on the step's weight-gradient stream."""
 import contextlib
 import ctypes
+import os
 import weakref
 
 import torch
@@ -93,10 +94,13 @@ def packs(weight):
     return fwd, bwd
 
 
-def _run(x, pack, cout, bn=None, epi=None, pre=None):
+def _run(x, pack, cout, bn=None, epi=None, pre=None, bwd=None):
     """bn: a training-mode BatchNorm2d that follows the conv -- its batch statistics are taken in the kernel's epilogue
     (glx_conv_opts.bn) and the call returns (y, coef, save_mean, save_invstd).  epi: an _lib.Epilogue (inference).
-    pre: (coef (2 * Cin: scale, shift), relu) -- the input is transformed on load (glx_conv_opts.prologue)."""
+    pre: (coef (2 * Cin: scale, shift), relu) -- the input is transformed on load (glx_conv_opts.prologue).
+    bwd: (y_prev, coef_prev, mean, invstd, gamma) -- the call is an input-gradient convolution whose output is the gradient of
+    relu(bn(y_prev)): the epilogue masks it and takes the BatchNorm backward's sums (glx_conv_opts.bn_bwd); returns
+    (dz, coef (3 C), dgamma, dbeta)."""
     b, c, h, w = x.shape
     if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)):
         raise _lib.GlxError("conv3x3 expects a float32 channels-last device map, got %s strides %s on %s"
@@ -116,10 +120,18 @@ def _run(x, pack, cout, bn=None, epi=None, pre=None):
         opts = _lib.ConvOpts(None, ctypes.pointer(epi), prologue)
     elif prologue is not None:
         opts = _lib.ConvOpts(None, None, prologue)
+    if bwd is not None:
+        from .spconv import core
+        y_prev, coef_prev, mean, invstd, gamma = bwd
+        stats = tuple(torch.empty(n, dtype=torch.float32, device=x.device) for n in (3 * cout, cout, cout))
+        st = _lib.BnBwdStats(*[_lib._p(t) for t in (core._bn_state(x.device), y_prev, coef_prev, mean, invstd, gamma) + stats])
+        opts = _lib.ConvOpts(None, None, None, ctypes.pointer(st))
     call("glx_conv3x3_forward_ex", x, b, h, w, c, pack, cout, y, ctypes.byref(opts) if opts is not None else None)
     if bn is not None:
         if bn.track_running_stats:
             _lib.bump_weights_epoch((bn.running_mean, bn.running_var))     # moved behind torch's back
+        return (y,) + stats
+    if bwd is not None:
         return (y,) + stats
     return y
 
@@ -146,6 +158,7 @@ def wgrad(x, gy, weight, pre=None):
 
 
 OWN_WGRAD = True
+BN_BWD_IN_DGRAD = os.environ.get("GLX_CONV3X3_BN_BWD", "1") != "0"     # _ConvPre3x3: BatchNorm backward sums in the dgrad epilogue
 
 
 class _Conv3x3(torch.autograd.Function):
@@ -218,17 +231,24 @@ class _ConvPre3x3(torch.autograd.Function):
                     t.record_stream(side)
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
                 gw = wgrad(y_prev, gy, weight, pre=(coef_prev, True))
-        gh = _run(gy, ctx.bwd_pack, int(weight.shape[1]))                  # gradient of relu(bn_prev(y_prev))
         b, c, h, w = y_prev.shape
         n = b * h * w
         rows = y_prev.permute(0, 2, 3, 1).reshape(n, c)
-        grows = gh.permute(0, 2, 3, 1).reshape(n, c)
         dx = torch.empty_like(rows)
-        dgamma = torch.empty(c, dtype=torch.float32, device=rows.device)
-        dbeta = torch.empty(c, dtype=torch.float32, device=rows.device)
-        ws = core.workspace.get(query("glx_bn_workspace_bytes", c), rows.device)
-        call("glx_bn_relu_backward", rows, grows, None, n, c, gamma_prev, beta_prev, mean_prev, invstd_prev, 1, dx,
-             dgamma, dbeta, None, ws, _lib.size_arg(ws.numel()), core._bn_state(rows.device), 0)
+        if BN_BWD_IN_DGRAD:
+            # the input-gradient convolution masks its output with the ReLU and takes the BatchNorm backward's sums in its
+            # epilogue (no statistics pass over the two maps); what is left is the transform
+            dz, coef3, dgamma, dbeta = _run(gy, ctx.bwd_pack, int(weight.shape[1]),
+                                            bwd=(y_prev, coef_prev, mean_prev, invstd_prev, gamma_prev))
+            call("glx_bn_backward_apply", rows, dz.permute(0, 2, 3, 1).reshape(n, c), coef3, mean_prev, invstd_prev, n, c, dx)
+        else:
+            gh = _run(gy, ctx.bwd_pack, int(weight.shape[1]))              # gradient of relu(bn_prev(y_prev))
+            grows = gh.permute(0, 2, 3, 1).reshape(n, c)
+            dgamma = torch.empty(c, dtype=torch.float32, device=rows.device)
+            dbeta = torch.empty(c, dtype=torch.float32, device=rows.device)
+            ws = core.workspace.get(query("glx_bn_workspace_bytes", c), rows.device)
+            call("glx_bn_relu_backward", rows, grows, None, n, c, gamma_prev, beta_prev, mean_prev, invstd_prev, 1, dx,
+                 dgamma, dbeta, None, ws, _lib.size_arg(ws.numel()), core._bn_state(rows.device), 0)
         return dx.view(b, h, w, c).permute(0, 3, 1, 2), None, None, None, dgamma, dbeta, gw, None
 
 

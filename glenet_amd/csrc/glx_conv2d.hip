@@ -80,6 +80,13 @@ struct ConvArgs {
   const float* pre_scale;   // input transform on load (glx_conv_opts.prologue): x' = relu?(x * scale[c] + shift[c]) at the pixels
   const float* pre_shift;   // of the map (the zero padding stays zero) -- the BatchNorm (+ ReLU) of the layer in front, second form
   int pre_relu;
+  // BWD (glx_conv_opts.bn_bwd; the launch is the INPUT-GRADIENT convolution of a layer whose input was relu(bn(y_prev))):
+  // the epilogue masks the gradient with the ReLU (re-derived from y_prev * scale + shift), writes dz and takes the two sums
+  // of the BatchNorm backward (sum dz, sum dz * xhat) -- bn_state / bn then finalize them (coef (3 C), dgamma, dbeta)
+  const float* bwd_y;       // (B, H, W, Cout) raw output of the convolution in front of that BatchNorm
+  const float* bwd_coef;    // scale[Cout], shift[Cout]
+  const float* bwd_mean;
+  const float* bwd_invstd;
 };
 
 struct ConvTile {
@@ -344,8 +351,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
 // PRE: the input is transformed on load (a.pre_scale / a.pre_shift, staged in LDS behind the halo planes: the kernel sits
 // at its 168-register budget, eight more live registers for the coefficients spilled 27 more -- as a template parameter the
 // plain kernels compile as before).
-template <bool STATS, int TH, bool PRE = false>
+template <bool STATS, int TH, bool PRE = false, bool BWD = false>
 __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
+  static_assert(!(BWD && (STATS || PRE)), "BWD is a mode of the plain input-gradient launch");
   constexpr int HP = (TH + 2) * CV_HW, NL = (HP * 8 + 255) / 256, PLANE = HP * CV_ROW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;
@@ -354,6 +362,14 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
     for (int e = threadIdx.x; e < a.Cin; e += 256) {
       s_pre[e] = a.pre_scale[e];
       s_pre[a.Cin + e] = a.pre_shift[e];
+    }
+  }
+  if constexpr (BWD) {                                             // scale, shift, mean, invstd of the BatchNorm: 4 x Cout
+    for (int e = threadIdx.x; e < a.Cout; e += 256) {
+      s_pre[e] = a.bwd_coef[e];
+      s_pre[a.Cout + e] = a.bwd_coef[a.Cout + e];
+      s_pre[2 * a.Cout + e] = a.bwd_mean[e];
+      s_pre[3 * a.Cout + e] = a.bwd_invstd[e];
     }
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -493,7 +509,22 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
             v[g] = a.epi_relu ? fmaxf(t, 0.f) : t;
           }
         }
-        *reinterpret_cast<f32x4*>(a.y + (((long long)ct.b * a.H + py) * a.W + px) * a.Cout + ct.n0 + 16 * wave + 4 * kq) = v;
+        const long long o_ = (((long long)ct.b * a.H + py) * a.W + px) * a.Cout + ct.n0 + 16 * wave + 4 * kq;
+        if constexpr (BWD) {
+          const int cb = ct.n0 + 16 * wave + 4 * kq;
+          const f32x4 yv = *reinterpret_cast<const f32x4*>(a.bwd_y + o_);
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(s_pre + cb), sh = *reinterpret_cast<const f32x4*>(s_pre + a.Cout + cb);
+          const f32x4 mu = *reinterpret_cast<const f32x4*>(s_pre + 2 * a.Cout + cb);
+          const f32x4 is = *reinterpret_cast<const f32x4*>(s_pre + 3 * a.Cout + cb);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float dz = bn_affine(yv[g], sc[g], sh[g]) > 0.f ? v[g] : 0.f;
+            v[g] = dz;
+            ssum[g] += dz;
+            ssq[g] += dz * ((yv[g] - mu[g]) * is[g]);
+          }
+        }
+        *reinterpret_cast<f32x4*>(a.y + o_) = v;
         if (STATS) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -512,7 +543,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
 #undef V2_HALO
 #undef V2_LOAD_A
 #undef V2_STORE_A
-  if (STATS) {
+  if (STATS || BWD) {
     double* red = reinterpret_cast<double*>(smem);          // [moment][64 channels]
     __shared__ int s_last2;
     __syncthreads();
@@ -539,7 +570,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
     if (tid == 0)
       s_last2 = __hip_atomic_fetch_add(&a.bn_state->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
-    if (s_last2) bn_finalize_sets<false, 256>(a.bn_state, a.bn, a.Cout, a.B * a.H * a.W, reinterpret_cast<double(*)[2]>(smem));
+    if (s_last2) bn_finalize_sets<BWD, 256>(a.bn_state, a.bn, a.Cout, a.B * a.H * a.W, reinterpret_cast<double(*)[2]>(smem));
   }
 }
 
@@ -921,6 +952,7 @@ extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int C
   const glx_bn_stats* bnp = opts ? opts->bn : nullptr;
   const glx_epilogue* epi = opts ? opts->epilogue : nullptr;
   const glx_epilogue* pre = opts ? opts->prologue : nullptr;
+  const glx_bn_bwd_stats* bwd = opts ? opts->bn_bwd : nullptr;
   BnState* bn_state = bnp ? (BnState*)bnp->state : nullptr;
   BnFinalize bn_fin = {};
   if (bnp) {
@@ -943,7 +975,14 @@ extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int C
   int slot = bn_state ? 7 : 0;
   GLX_REQUIRE(!pre || (pre->scale && pre->shift && pre->ldc == 0 && pre->coff == 0),
               "glx_conv3x3_forward_ex: the prologue needs scale and shift (Cin floats each)");
-  const bool v2 = (g_conv_form == 2 && g_conv_ablate == 0) || epi_scale || pre;   // epilogue / prologue live in the second form
+  if (bwd) {
+    GLX_REQUIRE(!bnp && !epi && !pre, "glx_conv3x3_forward_ex: bn_bwd excludes the other options");
+    GLX_REQUIRE(bwd->state && bwd->y && bwd->coef_fwd && bwd->mean && bwd->invstd && bwd->coef, "glx_conv3x3_forward_ex: bn_bwd: null pointer");
+    GLX_REQUIRE(Cout <= BN_MAXC, "glx_conv3x3_forward_ex: bn_bwd for at most %d channels", BN_MAXC);
+    bn_state = (BnState*)bwd->state;
+    bn_fin = BnFinalize{bwd->gamma, nullptr, 0.f, 0.f, bwd->coef, nullptr, nullptr, nullptr, nullptr, bwd->invstd, bwd->dgamma, bwd->dbeta};
+  }
+  const bool v2 = (g_conv_form == 2 && g_conv_ablate == 0) || epi_scale || pre || bwd;   // epilogue / prologue / bn_bwd live in the second form
   int th = CV_TH;
   if (v2) {
     // rows per tile: the fewest (rounds of the resident blocks) x (rows + a fixed cost per tile)
@@ -955,7 +994,9 @@ extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int C
       if (best < 0 || cost < best) { best = cost; th = t; }
     }
     if (g_conv_th >= 6 && g_conv_th <= 8) th = g_conv_th;
-    if (pre) {
+    if (bwd) {
+      kern = th == 8 ? k_conv3x3_v2<false, 8, false, true> : th == 7 ? k_conv3x3_v2<false, 7, false, true> : k_conv3x3_v2<false, 6, false, true>;
+    } else if (pre) {
       if (th == 8) kern = bn_state ? k_conv3x3_v2<true, 8, true> : k_conv3x3_v2<false, 8, true>;
       else if (th == 7) kern = bn_state ? k_conv3x3_v2<true, 7, true> : k_conv3x3_v2<false, 7, true>;
       else kern = bn_state ? k_conv3x3_v2<true, 6, true> : k_conv3x3_v2<false, 6, true>;
@@ -975,10 +1016,11 @@ extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int C
     slot = g_conv_ablate & 7;
     if (slot == 7) slot = 0;
   }
-  const int lds_bytes = v2 ? 3 * (th + 2) * CV_HW * CV_ROW + (pre ? 2 * Cin * (int)sizeof(float) : 0) : CV_LDS;
+  const int lds_bytes = v2 ? 3 * (th + 2) * CV_HW * CV_ROW + (pre ? 2 * Cin * (int)sizeof(float) : 0) +
+                                 (bwd ? 4 * Cout * (int)sizeof(float) : 0) : CV_LDS;
   if (v2) {
-    static int v2_set[2][2][9] = {};      // largest dynamic LDS size registered per instantiation
-    int& reg = v2_set[pre ? 1 : 0][bn_state ? 1 : 0][th];
+    static int v2_set[3][2][9] = {};      // largest dynamic LDS size registered per instantiation
+    int& reg = v2_set[bwd ? 2 : pre ? 1 : 0][(bn_state && !bwd) ? 1 : 0][th];
     if (reg < lds_bytes) {
       GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
       reg = lds_bytes;
@@ -1013,6 +1055,10 @@ extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int C
   a.pre_scale = pre ? pre->scale : nullptr;
   a.pre_shift = pre ? pre->shift : nullptr;
   a.pre_relu = pre ? pre->relu : 0;
+  a.bwd_y = bwd ? bwd->y : nullptr;
+  a.bwd_coef = bwd ? bwd->coef_fwd : nullptr;
+  a.bwd_mean = bwd ? bwd->mean : nullptr;
+  a.bwd_invstd = bwd ? bwd->invstd : nullptr;
   const int resident = slots * (v2 ? conv_per_cu() : 2);
   int grid = g_conv_grid > 0 ? g_conv_grid : (a.ntiles < resident ? a.ntiles : resident);
   if (bn_state) grid = grid / a.nblk * a.nblk;   // every block keeps one channel block (ntiles is a multiple of nblk)

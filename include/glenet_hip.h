@@ -79,6 +79,23 @@ typedef struct glx_sconv_opts {
   void* profile_start;
   void* profile_stop;
 } glx_sconv_opts;
+/* Backward statistics of a BatchNorm (+ ReLU) in the epilogue of the INPUT-GRADIENT convolution that produces the gradient
+ * of its output (glx_conv3x3_forward_ex on the adjoint filters): the epilogue masks the gradient with the ReLU (re-derived
+ * from y * scale + shift), writes dz, and takes sum dz and sum dz * xhat per channel; the last block writes coef (3 C floats:
+ * a = gamma * invstd, b = mean dz, cc = mean dz * xhat -- what glx_bn_backward_apply reads), dgamma and dbeta.
+ * y: the raw output (B, H, W, C) of the convolution in front of the BatchNorm; coef_fwd: its scale[C], shift[C];
+ * mean / invstd: the saved batch statistics; state: as glx_bn_stats. */
+typedef struct glx_bn_bwd_stats {
+  void* state;
+  const float* y;
+  const float* coef_fwd;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  float* coef;
+  float* dgamma;
+  float* dbeta;
+} glx_bn_bwd_stats;
 typedef struct glx_conv_opts {
   const glx_bn_stats* bn;
   const glx_epilogue* epilogue;
@@ -86,6 +103,8 @@ typedef struct glx_conv_opts {
    * (the zero padding stays zero; scale, shift: Cin device floats, ldc = coff = 0) -- the training-mode BatchNorm (+ ReLU) of
    * the layer in front applied without writing the normalised map (base_bev_backbone.py:36-49).  NULL: none. */
   const glx_epilogue* prologue;
+  /* glx_conv3x3_forward_ex only, excludes the three above: see glx_bn_bwd_stats.  NULL: none. */
+  const glx_bn_bwd_stats* bn_bwd;
 } glx_conv_opts;
 
 /* ROCm 7.2 workaround (csrc/glx_graph.hip): a hipMemsetAsync recorded into a HIP graph is replayed with a stale pattern from
@@ -658,6 +677,11 @@ int glx_bn_relu_backward(const float* x, const float* dy, const float* y, int N,
                          const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                          int relu, float* dx, float* dgamma, float* dbeta, const int32_t* n_live,
                          void* workspace, size_t workspace_bytes, void* state, int dy_stride, void* stream);
+/* The transform half of glx_bn_relu_backward for sums that were taken elsewhere (glx_bn_bwd_stats):
+ * dx = a * (dz - b - xhat * cc) with coef = (a, b, cc) (3 C floats), xhat = (x - mean) * invstd; dz already carries the
+ * ReLU mask.  x, dz, dx (N, C) row-major. */
+int glx_bn_backward_apply(const float* x, const float* dz, const float* coef, const float* mean, const float* invstd,
+                          int N, int C, float* dx, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * VectorPool family of PV-RCNN++.  Output slots are laid out in ascending new-point order
