@@ -13,9 +13,32 @@
 
 __global__ void k_graph_fill(unsigned char* __restrict__ dst, unsigned value, unsigned elem, unsigned long long width,
                              unsigned long long height, unsigned long long pitch) {
+  const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long nthreads = (unsigned long long)gridDim.x * blockDim.x;
+  if (height <= 1) {
+    // one row of width * elem bytes: 16-byte stores over the aligned middle (library memsets are tens of MB -- the
+    // vendor convolutions zero their outputs with them), single elements at the ragged ends
+    const unsigned word = elem == 4 ? value : elem == 2 ? (value & 0xFFFFu) * 0x10001u : (value & 0xFFu) * 0x01010101u;
+    const unsigned long long bytes = width * elem;
+    const unsigned long long head = ((16 - ((unsigned long long)dst & 15)) & 15) < bytes ? ((16 - ((unsigned long long)dst & 15)) & 15) : bytes;
+    const unsigned long long nvec = (bytes - head) / 16, tail0 = head + nvec * 16;
+    uint4* v = reinterpret_cast<uint4*>(dst + head);
+    for (unsigned long long i = tid; i < nvec; i += nthreads) v[i] = make_uint4(word, word, word, word);
+    // head and tail: whole elements (dst is elem-aligned, so head and tail0 are multiples of elem)
+    for (unsigned long long b = tid * elem; b < head; b += nthreads * elem) {
+      if (elem == 4) *reinterpret_cast<unsigned*>(dst + b) = value;
+      else if (elem == 2) *reinterpret_cast<unsigned short*>(dst + b) = (unsigned short)value;
+      else dst[b] = (unsigned char)value;
+    }
+    for (unsigned long long b = tail0 + tid * elem; b < bytes; b += nthreads * elem) {
+      if (elem == 4) *reinterpret_cast<unsigned*>(dst + b) = value;
+      else if (elem == 2) *reinterpret_cast<unsigned short*>(dst + b) = (unsigned short)value;
+      else dst[b] = (unsigned char)value;
+    }
+    return;
+  }
   const unsigned long long n = width * height;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (unsigned long long)gridDim.x * blockDim.x) {
+  for (unsigned long long i = tid; i < n; i += nthreads) {
     const unsigned long long row = i / width, col = i - row * width;
     unsigned char* p = dst + row * pitch + col * elem;
     if (elem == 4) *reinterpret_cast<unsigned*>(p) = value;
@@ -53,7 +76,7 @@ extern "C" int glx_graph_replace_memsets(void* graph_, int* n_replaced) {
     void* args[] = {&dst, &value, &elem, &width, &height, &pitch};
     hipKernelNodeParams kp = {};
     kp.func = (void*)k_graph_fill;
-    const unsigned long long total = width * height;
+    const unsigned long long total = height > 1 ? width * height : (width * elem + 15) / 16 + 32;
     unsigned blocks = (unsigned)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     if (blocks == 0) blocks = 1;

@@ -70,3 +70,33 @@ def test_recorded_steps_contain_no_memset_nodes(dev):
         torch.cuda.synchronize()
         assert abs(float(step.loss) - loss) <= 1e-5 * abs(loss)
         assert float((step.optimizer.flat_grad - want).abs().max()) <= 1e-4 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("kind,offset,count", [("D8", 0, 1 << 20), ("D8", 3, 1000003), ("D8", 5, 7), ("D16", 2, 50001), ("D32", 4, 123457),
+                                               ("D32", 0, 9 << 20), ("D8", 1, 36 << 20)])
+def test_fill_nodes_write_what_the_memset_would(dev, kind, offset, count):
+    """The kernel node that replaces a recorded memset (k_graph_fill: 16-byte stores over the aligned middle, elements at the
+    ragged ends) fills exactly the requested bytes -- unaligned starts, odd lengths, 1 / 2 / 4-byte elements -- on every
+    replay and touches nothing around them."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    esz = {"D8": 1, "D16": 2, "D32": 4}[kind]
+    fn = getattr(hip, "hipMemset%sAsync" % kind)
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int if kind == "D32" else (ctypes.c_ushort if kind == "D16" else ctypes.c_ubyte),
+                   ctypes.c_size_t, ctypes.c_void_p]
+    value = {"D8": 0xA5, "D16": 0xBEEF, "D32": 0x12345678}[kind]
+    buf = torch.zeros(offset + count * esz + 64, dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream(dev)
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g, stream=side):
+        rc = fn(ctypes.c_void_p(buf.data_ptr() + offset), value, count, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        assert rc == 0
+    assert _lib.finish_graph(g) == 1
+    want = torch.full((offset + count * esz + 64,), 0x11, dtype=torch.uint8)
+    pat = torch.tensor([(value >> (8 * i)) & 0xFF for i in range(esz)], dtype=torch.uint8)
+    want[offset:offset + count * esz] = pat.repeat(count)
+    for _ in range(2):
+        buf.fill_(0x11)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(buf.cpu(), want)
