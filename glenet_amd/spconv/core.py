@@ -285,7 +285,7 @@ def plan_rules(indices, spatial_shape, batch_size, convs, index=None, count=None
                                    indice_dict=x.indice_dict, count=rs.count_out)
             nxt._index = rs.out_index
             x = nxt
-    if pair_lists and USE_PAIR_LISTS:
+    if pair_lists and USE_PAIR_LISTS and PAIR_LISTS_IN_PLAN:
         for rs in x.indice_dict.values():
             if rs.nbr is not None and rs.N_out > 0:
                 rs.pair_lists(rs.nbr, rs.N_out, rs.count_out)
@@ -945,6 +945,7 @@ USE_FUSED_TRAIN_BN = os.environ.get("GLX_FUSED_BN", "1") != "0"
 # work-balanced block -> tile maps for the sparse-conv kernels (RuleSet.tile_map); off with GLX_TILE_MAP=0
 USE_TILE_MAP = os.environ.get("GLX_TILE_MAP", "1") != "0"
 USE_PAIR_LISTS = os.environ.get("GLX_PAIR_LISTS", "1") != "0"      # weight gradients over per-offset pair lists
+PAIR_LISTS_IN_PLAN = os.environ.get("GLX_PAIR_LISTS_IN_PLAN", "1") != "0"   # built behind the rule tables (0: by the first weight gradient)
 TILE_MAP_MIN_ROWS = 64 * 256       # fewer tiles than CUs: nothing to balance
 # building a map costs two small launches (~8 us): worth it for the rule tables of submanifold stacks
 # (2-3 convs share one) with at least 32x32 weights per offset -- on the KITTI batch that is
