@@ -1606,6 +1606,61 @@ __device__ __forceinline__ float tk_unkey(unsigned d) {
   return __uint_as_float((a & 0x80000000u) ? (a & 0x7fffffffu) : ~a);
 }
 
+// Step (3) of the top-K kernels: stable LSD radix sort (4-bit digits, 8 passes) of the K survivors in keys0 / idx0 through a
+// permutation (keys stay where they are); writes `top` / `order` of frame `frame`.  All TK_THREADS threads of the block.
+__device__ __forceinline__ void tk_sort_and_write(unsigned* keys0, unsigned* idx0, unsigned short* perm_a, unsigned short* perm_b,
+                                                  unsigned short* cnt, unsigned* s_wsum, int K, int frame,
+                                                  float* __restrict__ top, long long* __restrict__ order) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int E = (K + TK_THREADS - 1) / TK_THREADS;
+  unsigned short* pin = perm_a;
+  unsigned short* pout = perm_b;
+  for (int shift = 0; shift < 32; shift += 4) {
+    unsigned long long packed = 0;               // 16 counters of 4 bits: a thread holds at most TK_E = 10 keys
+    for (int e = 0; e < E; ++e) {
+      const int p = tid * E + e;
+      if (p < K) packed += 1ull << (4 * ((keys0[pin[p]] >> shift) & 15u));
+    }
+#pragma unroll
+    for (int dg = 0; dg < 16; ++dg) cnt[dg * TK_THREADS + tid] = (unsigned short)((packed >> (4 * dg)) & 15u);
+    __syncthreads();
+    // exclusive scan of the 16 x 1024 counters in (digit, thread) order: thread t owns entries [16 t, 16 t + 16)
+    unsigned loc[16], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { loc[j] = cnt[tid * 16 + j]; sum += loc[j]; }
+    unsigned inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned v = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += v;
+    }
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    unsigned base = inc - sum;
+    for (int w = 0; w < wave; ++w) base += s_wsum[w];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { cnt[tid * 16 + j] = (unsigned short)base; base += loc[j]; }
+    __syncthreads();
+    for (int e = 0; e < E; ++e) {
+      const int p = tid * E + e;
+      if (p < K) {
+        const unsigned short slot = pin[p];
+        const unsigned dg = (keys0[slot] >> shift) & 15u;
+        const unsigned short pos = cnt[dg * TK_THREADS + tid];
+        cnt[dg * TK_THREADS + tid] = pos + 1;
+        pout[pos] = slot;
+      }
+    }
+    __syncthreads();
+    unsigned short* t = pin; pin = pout; pout = t;
+  }
+  for (int p = tid; p < K; p += TK_THREADS) {
+    const unsigned short slot = pin[p];
+    top[(size_t)frame * K + p] = tk_unkey(keys0[slot]);
+    order[(size_t)frame * K + p] = (long long)idx0[slot];
+  }
+}
+
 __global__ __launch_bounds__(TK_THREADS) void k_topk_desc(const float* __restrict__ scores, int A, int K, int Kp,
                                                           float* __restrict__ top,
                                                           long long* __restrict__ order) {
@@ -1734,54 +1789,202 @@ __global__ __launch_bounds__(TK_THREADS) void k_topk_desc(const float* __restric
   }
   __syncthreads();
 
-  // (3) stable LSD radix sort of the K survivors through a permutation (keys stay where they are)
-  const int E = (K + TK_THREADS - 1) / TK_THREADS;
-  unsigned short* pin = perm_a;
-  unsigned short* pout = perm_b;
-  for (int shift = 0; shift < 32; shift += 4) {
-    unsigned long long packed = 0;               // 16 counters of 4 bits: a thread holds at most TK_E = 10 keys
-    for (int e = 0; e < E; ++e) {
-      const int p = tid * E + e;
-      if (p < K) packed += 1ull << (4 * ((keys0[pin[p]] >> shift) & 15u));
+  tk_sort_and_write(keys0, idx0, perm_a, perm_b, cnt, s_wsum, K, (int)blockIdx.x, top, order);
+}
+
+// ---- the same result from many blocks per frame.  One block streaming a 70 400-score frame six times is what the
+// single-launch kernel above spends 60 of its 124 us on; here TKM_NB blocks of a frame each keep a 1 / TKM_NB slice of the
+// scores IN REGISTERS and cooperate through global memory: per radix pass a block histograms its slice in LDS, adds the
+// non-empty bins to the frame's global histogram and waits at a per-frame barrier (a counter the blocks spin on -- frames x
+// TKM_NB blocks are a fraction of the chip, all resident); every block then finds the bin on its own.  After four passes
+// the blocks exchange their (below, equal) counts and write their survivors in index order to the frame's unsorted list;
+// k_topk_sort (one block per frame, the LDS radix sort above) finishes and ZEROES the workspace for the next call --
+// the workspace must be zero when the first call starts (glx_topk_workspace_bytes of zeros, owned by ONE stream).
+#define TKM_NB 32
+#define TKM_THREADS 256
+#define TKM_E 16                                   // scores per thread at most: A <= TKM_NB * TKM_THREADS * TKM_E = 131 072
+struct TkFrameWs {
+  unsigned hist[4][256];
+  unsigned cnt[TKM_NB][2];
+  unsigned bar[8];
+};
+
+__device__ __forceinline__ void tkm_barrier(unsigned* counter) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < TKM_NB) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(TKM_THREADS) void k_topk_select(const float* __restrict__ scores, int A, int K,
+                                                             TkFrameWs* __restrict__ ws, unsigned* __restrict__ keys_out,
+                                                             unsigned* __restrict__ idx_out) {
+  const int f = blockIdx.x / TKM_NB, b = blockIdx.x - f * TKM_NB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  TkFrameWs* w = ws + f;
+  __shared__ unsigned s_hist[256];
+  __shared__ unsigned s_bin, s_rem;
+  __shared__ unsigned s_w[TKM_THREADS / 64][2];
+  // the block's slice, a contiguous run per thread (index order = thread order, then element order)
+  const int per_blk = ((A + TKM_NB - 1) / TKM_NB + TKM_THREADS - 1) / TKM_THREADS * TKM_THREADS;
+  const int E = per_blk / TKM_THREADS;                               // <= TKM_E (checked by the host)
+  const int i0 = b * per_blk + tid * E;
+  const float* s = scores + (size_t)f * A;
+  unsigned key[TKM_E];
+#pragma unroll
+  for (int e = 0; e < TKM_E; ++e) {
+    const int i = i0 + e;
+    key[e] = (e < E && i < A) ? tk_key(s[i]) : 0xFFFFFFFFu;          // the largest key: never among the K smallest ...
+  }
+  // ... unless the frame really holds NaN-free 0xFFFFFFFF keys, which tk_key never produces for a float
+  unsigned prefix = 0, mask = 0, remaining = (unsigned)K;
+#pragma unroll 1
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (tid < 256) s_hist[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < TKM_E; ++e) {
+      const int i = i0 + e;
+      if (e < E && i < A && (key[e] & mask) == prefix) atomicAdd(&s_hist[(key[e] >> shift) & 255u], 1u);
     }
-#pragma unroll
-    for (int dg = 0; dg < 16; ++dg) cnt[dg * TK_THREADS + tid] = (unsigned short)((packed >> (4 * dg)) & 15u);
     __syncthreads();
-    // exclusive scan of the 16 x 1024 counters in (digit, thread) order: thread t owns entries [16 t, 16 t + 16)
-    unsigned loc[16], sum = 0;
+    if (tid < 256 && s_hist[tid]) atomicAdd(&w->hist[pass][tid], s_hist[tid]);
+    tkm_barrier(&w->bar[pass]);
+    if (wave == 0) {                               // the bin where the running count reaches `remaining`: 4 bins per lane
+      unsigned c[4], sum = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { loc[j] = cnt[tid * 16 + j]; sum += loc[j]; }
-    unsigned inc = sum;
+      for (int j = 0; j < 4; ++j) {
+        c[j] = __hip_atomic_load(&w->hist[pass][lane * 4 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sum += c[j];
+      }
+      unsigned inc = sum;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const unsigned v = __shfl_up(inc, off, 64);
-      if (lane >= off) inc += v;
-    }
-    if (lane == 63) s_wsum[wave] = inc;
-    __syncthreads();
-    unsigned base = inc - sum;
-    for (int w = 0; w < wave; ++w) base += s_wsum[w];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) { cnt[tid * 16 + j] = (unsigned short)base; base += loc[j]; }
-    __syncthreads();
-    for (int e = 0; e < E; ++e) {
-      const int p = tid * E + e;
-      if (p < K) {
-        const unsigned short slot = pin[p];
-        const unsigned dg = (keys0[slot] >> shift) & 15u;
-        const unsigned short pos = cnt[dg * TK_THREADS + tid];
-        cnt[dg * TK_THREADS + tid] = pos + 1;
-        pout[pos] = slot;
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned u = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += u;
+      }
+      const unsigned long long hit = __ballot(inc >= remaining);
+      const int owner = hit ? __ffsll((long long)hit) - 1 : 63;
+      if (lane == owner) {
+        unsigned cum = inc - sum;
+        int j = 0;
+        for (; j < 3; ++j) {
+          if (cum + c[j] >= remaining) break;
+          cum += c[j];
+        }
+        s_bin = (unsigned)(lane * 4 + j);
+        s_rem = remaining - cum;
       }
     }
     __syncthreads();
-    unsigned short* t = pin; pin = pout; pout = t;
+    prefix |= s_bin << shift;
+    mask |= 255u << shift;
+    remaining = s_rem;
+    __syncthreads();
   }
+  const unsigned kth = prefix;                   // keys < kth all survive, `remaining` of the keys == kth do (lowest index first)
+  // ---- counts of the block, exchanged; position of every survivor in the frame's index order
+  unsigned my_lt = 0, my_eq = 0;
+#pragma unroll
+  for (int e = 0; e < TKM_E; ++e) {
+    const int i = i0 + e;
+    if (e < E && i < A) { my_lt += key[e] < kth; my_eq += key[e] == kth; }
+  }
+  unsigned inc_lt = my_lt, inc_eq = my_eq;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned u = __shfl_up(inc_lt, off, 64), v = __shfl_up(inc_eq, off, 64);
+    if (lane >= off) { inc_lt += u; inc_eq += v; }
+  }
+  if (lane == 63) { s_w[wave][0] = inc_lt; s_w[wave][1] = inc_eq; }
+  __syncthreads();
+  unsigned lt_run = inc_lt - my_lt, eq_run = inc_eq - my_eq, blk_lt = 0, blk_eq = 0;
+#pragma unroll
+  for (int ww = 0; ww < TKM_THREADS / 64; ++ww) {
+    if (ww < wave) { lt_run += s_w[ww][0]; eq_run += s_w[ww][1]; }
+    blk_lt += s_w[ww][0];
+    blk_eq += s_w[ww][1];
+  }
+  if (tid == 0) {
+    __hip_atomic_store(&w->cnt[b][0], blk_lt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&w->cnt[b][1], blk_eq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  tkm_barrier(&w->bar[4]);
+  for (int bb = 0; bb < b; ++bb) {               // block-uniform: <= 31 pairs of loads
+    lt_run += __hip_atomic_load(&w->cnt[bb][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    eq_run += __hip_atomic_load(&w->cnt[bb][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#pragma unroll
+  for (int e = 0; e < TKM_E; ++e) {
+    const int i = i0 + e;
+    if (!(e < E && i < A)) continue;
+    const bool isl = key[e] < kth, ise = key[e] == kth;
+    int pos = -1;
+    if (isl) pos = (int)(lt_run + min(eq_run, remaining));
+    else if (ise && eq_run < remaining) pos = (int)(lt_run + eq_run);
+    if (pos >= 0) { keys_out[(size_t)f * K + pos] = key[e]; idx_out[(size_t)f * K + pos] = (unsigned)i; }
+    lt_run += isl;
+    eq_run += ise;
+  }
+}
+
+__global__ __launch_bounds__(TK_THREADS) void k_topk_sort(const unsigned* __restrict__ keys_in, const unsigned* __restrict__ idx_in,
+                                                          int K, int Kp, TkFrameWs* __restrict__ ws, float* __restrict__ top,
+                                                          long long* __restrict__ order) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tk_smem[];
+  unsigned* keys0 = reinterpret_cast<unsigned*>(tk_smem);                  // Kp
+  unsigned* idx0 = keys0 + Kp;                                             // Kp
+  unsigned short* perm_a = reinterpret_cast<unsigned short*>(idx0 + Kp);   // Kp
+  unsigned short* perm_b = perm_a + Kp;                                    // Kp
+  unsigned short* cnt = perm_b + Kp;                                       // 16 * TK_THREADS
+  __shared__ unsigned s_wsum[TK_THREADS / 64];
+  const int f = blockIdx.x, tid = threadIdx.x;
   for (int p = tid; p < K; p += TK_THREADS) {
-    const unsigned short slot = pin[p];
-    top[(size_t)blockIdx.x * K + p] = tk_unkey(keys0[slot]);
-    order[(size_t)blockIdx.x * K + p] = (long long)idx0[slot];
+    keys0[p] = keys_in[(size_t)f * K + p];
+    idx0[p] = idx_in[(size_t)f * K + p];
+    perm_a[p] = (unsigned short)p;
   }
+  // the select kernel is done with this frame's workspace: clean for the next call
+  for (int e = tid; e < (int)(sizeof(TkFrameWs) / 4); e += TK_THREADS) reinterpret_cast<unsigned*>(ws + f)[e] = 0u;
+  __syncthreads();
+  tk_sort_and_write(keys0, idx0, perm_a, perm_b, cnt, s_wsum, K, f, top, order);
+}
+
+extern "C" size_t glx_topk_workspace_bytes(int frames, int K) {
+  return glx_align((size_t)(frames > 0 ? frames : 1) * sizeof(TkFrameWs)) + 2 * glx_align((size_t)(frames > 0 ? frames : 1) * K * 4);
+}
+
+// The multi-block form: `workspace` = glx_topk_workspace_bytes(frames, K) bytes that were ZERO before the first call and are
+// only ever touched by these calls (they leave it zero), used by one stream at a time.
+extern "C" int glx_topk_desc_ws(const float* scores, int frames, int A, int K, float* top, int64_t* order, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  if (frames <= 0 || K <= 0) return GLX_OK;
+  GLX_REQUIRE(scores && top && order && workspace, "glx_topk_desc_ws: null pointer");
+  GLX_REQUIRE(K <= A && K <= TK_MAXK, "glx_topk_desc_ws: K = %d (1..min(A = %d, %d))", K, A, TK_MAXK);
+  GLX_REQUIRE(A <= TKM_NB * TKM_THREADS * TKM_E, "glx_topk_desc_ws: A = %d (<= %d)", A, TKM_NB * TKM_THREADS * TKM_E);
+  GLX_REQUIRE(frames * TKM_NB <= 512, "glx_topk_desc_ws: %d frames (the cooperating blocks must all be resident)", frames);
+  GLX_REQUIRE(workspace_bytes >= glx_topk_workspace_bytes(frames, K), "glx_topk_desc_ws: workspace too small");
+  char* base = (char*)workspace;
+  TkFrameWs* ws = (TkFrameWs*)base;
+  unsigned* keys = (unsigned*)(base + glx_align((size_t)frames * sizeof(TkFrameWs)));
+  unsigned* idx = (unsigned*)((char*)keys + glx_align((size_t)frames * K * 4));
+  const int Kp = (K + 63) / 64 * 64;
+  const size_t lds = (size_t)Kp * 8 + (size_t)Kp * 4 + (size_t)16 * TK_THREADS * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GLX_HIP(hipFuncSetAttribute((const void*)k_topk_sort, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((size_t)TK_MAXK * 12 + 16 * TK_THREADS * 2)));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_topk_select, dim3(frames * TKM_NB), dim3(TKM_THREADS), 0, (hipStream_t)stream, scores, A, K, ws, keys, idx);
+  hipLaunchKernelGGL(k_topk_sort, dim3(frames), dim3(TK_THREADS), lds, (hipStream_t)stream, (const unsigned*)keys,
+                     (const unsigned*)idx, K, Kp, ws, top, (long long*)order);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
 }
 
 extern "C" int glx_topk_max_k(void) { return TK_MAXK; }

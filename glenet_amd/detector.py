@@ -135,8 +135,21 @@ def topk_desc(scores, k):
     s = scores.contiguous()
     top = torch.empty((s.shape[0], k), dtype=torch.float32, device=s.device)
     order = torch.empty((s.shape[0], k), dtype=torch.int64, device=s.device)
-    _lib.call("glx_topk_desc", s, s.shape[0], s.shape[1], k, top, order)
+    if MULTI_BLOCK_TOPK and s.shape[0] <= 16 and 4096 <= s.shape[1] <= 131072:
+        # 32 cooperating blocks per frame + a per-frame sort; the zero-initialised workspace belongs to (device, stream)
+        key = (s.device.index, torch.cuda.current_stream(s.device).cuda_stream, s.shape[0], k)
+        ws = _TOPK_WS.get(key)
+        if ws is None:
+            ws = _TOPK_WS[key] = torch.zeros(_lib.query("glx_topk_workspace_bytes", s.shape[0], k), dtype=torch.uint8,
+                                             device=s.device)
+        _lib.call("glx_topk_desc_ws", s, s.shape[0], s.shape[1], k, top, order, ws, _lib.size_arg(ws.numel()))
+    else:
+        _lib.call("glx_topk_desc", s, s.shape[0], s.shape[1], k, top, order)
     return top, order
+
+
+MULTI_BLOCK_TOPK = os.environ.get("GLX_TOPK_MULTI", "1") != "0"
+_TOPK_WS = {}
 
 
 _ZEROS_I64 = {}

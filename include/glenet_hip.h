@@ -944,6 +944,12 @@ int glx_copy_fill_multi(int n, void* const* dst, const void* const* src, const u
  * (pcdet/models/roi_heads/roi_head_template.py:81-88). */
 int glx_topk_max_k(void);
 int glx_topk_desc(const float* scores, int frames, int A, int K, float* top, int64_t* order, void* stream);
+/* The same result from TKM_NB = 32 cooperating blocks per frame + a per-frame sort (two launches): `workspace` =
+ * glx_topk_workspace_bytes(frames, K) bytes that were ZERO before the first call and are touched by these calls only (they
+ * leave it zero); one stream at a time.  A <= 131 072, frames <= 16. */
+size_t glx_topk_workspace_bytes(int frames, int K);
+int glx_topk_desc_ws(const float* scores, int frames, int A, int K, float* top, int64_t* order, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 /* ---- dense 3x3 convolutions of the BEV backbone (stride 1, zero padding 1, channels-last fp32 maps) ----------------
  * Replaces, for the 3x3 / stride-1 layers: nn.Conv2d(c, c, 3, padding=1, bias=False) and ZeroPad2d(1) + Conv2d(.., 3)

@@ -236,9 +236,11 @@ def test_predicted_boxes_kernel_matches_reference_golden_and_tensor_ops(dev):
 @pytest.mark.gpu
 @pytest.mark.parametrize("A,K", [(70400, 9000), (70400, 1024), (5000, 4096), (300, 300), (64, 1), (10240, 10240)])
 def test_topk_kernel_matches_a_stable_sort(dev, A, K):
-    """detector.topk_desc (glx_topk_desc: one block per frame, radix select + stable LSD radix sort in LDS) against
+    """detector.topk_desc (glx_topk_desc: one block per frame, radix select + stable LSD radix sort in LDS; from 4096
+    scores per frame on glx_topk_desc_ws: 32 cooperating blocks per frame select, one block per frame sorts) against
     numpy's stable sort of the negated scores: values, indices, ties by ascending index -- on smooth scores (shared
-    high bytes, as sigmoid outputs of one frame have), on heavy ties, with infinities and negative values."""
+    high bytes, as sigmoid outputs of one frame have), on heavy ties, with infinities and negative values; a second call
+    on other scores finds the cooperative kernels' workspace clean."""
     rng = np.random.default_rng(A + K)
     B = 4
     s = np.empty((B, A), np.float32)
@@ -256,6 +258,10 @@ def test_topk_kernel_matches_a_stable_sort(dev, A, K):
     assert np.array_equal(top.cpu().numpy(), np.take_along_axis(s, want, 1))
     ttop, _ = torch.topk(torch.from_numpy(s).to(dev), K, dim=1)
     assert torch.equal(ttop, top)
+    s2 = np.ascontiguousarray(s[::-1, ::-1])
+    top2, order2 = det.topk_desc(torch.from_numpy(s2).to(dev), K)
+    want2 = np.stack([np.argsort(-s2[b], kind="stable")[:K] for b in range(B)])
+    assert np.array_equal(order2.cpu().numpy(), want2)
 
 
 @pytest.mark.gpu
