@@ -118,14 +118,14 @@ class Epilogue(ctypes.Structure):
     _fields_ = [("scale", c_void_p), ("shift", c_void_p), ("relu", c_int), ("ldc", c_int), ("coff", c_int)]
 
 
-class SconvOpts(ctypes.Structure):
-    _fields_ = [("tile_map", c_void_p), ("bn", ctypes.POINTER(BnStats)), ("profile_start", c_void_p),
-                ("profile_stop", c_void_p)]
-
-
 class BnBwdStats(ctypes.Structure):
     _fields_ = [("state", c_void_p), ("y", c_void_p), ("coef_fwd", c_void_p), ("mean", c_void_p), ("invstd", c_void_p),
                 ("gamma", c_void_p), ("coef", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p)]
+
+
+class SconvOpts(ctypes.Structure):
+    _fields_ = [("tile_map", c_void_p), ("bn", ctypes.POINTER(BnStats)), ("profile_start", c_void_p),
+                ("profile_stop", c_void_p), ("bn_bwd", ctypes.POINTER(BnBwdStats))]
 
 
 class ConvOpts(ctypes.Structure):

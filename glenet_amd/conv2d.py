@@ -240,7 +240,7 @@ class _ConvPre3x3(torch.autograd.Function):
             # epilogue (no statistics pass over the two maps); what is left is the transform
             dz, coef3, dgamma, dbeta = _run(gy, ctx.bwd_pack, int(weight.shape[1]),
                                             bwd=(y_prev, coef_prev, mean_prev, invstd_prev, gamma_prev))
-            call("glx_bn_backward_apply", rows, dz.permute(0, 2, 3, 1).reshape(n, c), coef3, mean_prev, invstd_prev, n, c, dx)
+            call("glx_bn_backward_apply", rows, dz.permute(0, 2, 3, 1).reshape(n, c), coef3, mean_prev, invstd_prev, n, c, None, dx)
         else:
             gh = _run(gy, ctx.bwd_pack, int(weight.shape[1]))              # gradient of relu(bn_prev(y_prev))
             grows = gh.permute(0, 2, 3, 1).reshape(n, c)

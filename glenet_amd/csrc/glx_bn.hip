@@ -721,14 +721,14 @@ extern "C" int glx_bn_relu_backward(const float* x, const float* dy, const float
 }
 
 extern "C" int glx_bn_backward_apply(const float* x, const float* dz, const float* coef, const float* mean, const float* invstd,
-                                     int N, int C, float* dx, void* stream) {
+                                     int N, int C, const int32_t* n_live, float* dx, void* stream) {
   GLX_REQUIRE(coef && mean && invstd && (N == 0 || (x && dz && dx)), "glx_bn_backward_apply: null pointer");
   GLX_REQUIRE(bn_channels_ok(C), "glx_bn_backward_apply: C=%d needs a multiple of 4 dividing 1024 (<= 512)", C);
   if (N <= 0) return GLX_OK;
   const int blocks = bn_apply_blocks(N, C);
   hipLaunchKernelGGL(k_bn_backward_apply, dim3(blocks < 1 ? 1 : blocks), dim3(BN_THREADS), 0, (hipStream_t)stream, x, dz,
                      (const float*)nullptr, coef, mean, invstd, (const float*)nullptr, (const float*)nullptr, 0, N, C,
-                     (long long)C, (const int*)nullptr, dx);
+                     (long long)C, (const int*)n_live, dx);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

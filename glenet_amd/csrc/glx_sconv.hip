@@ -66,6 +66,13 @@ struct SconvEpilogue {
   // output + an 11 us dependent tail, csrc/glx_bn.hip) disappears.  NULL = no statistics.
   BnState* bn_state;
   BnFinalize bn;
+  // bwd_y != NULL (glx_sconv_opts.bn_bwd): the launch is the INPUT-GRADIENT convolution of a layer whose input was
+  // relu(bn(y)), y = bwd_y (N_out, COUT): the epilogue masks the gradient with the ReLU (re-derived from y * scale + shift),
+  // writes dz and accumulates sum dz / sum dz * xhat in bn_state; the last block finalizes with bn (backward form)
+  const float* bwd_y;
+  const float* bwd_coef;   // scale[COUT], shift[COUT]
+  const float* bwd_mean;
+  const float* bwd_invstd;
 };
 
 // The common epilogue: coalesced row stores with the fused pointwise tail, + the BatchNorm statistics above.
@@ -77,12 +84,32 @@ __device__ __forceinline__ void sc_epilogue(float* smem, const float* s_acc, con
   static_assert(THREADS % C4 == 0 && 64 % C4 == 0 || C4 % 64 == 0, "a thread keeps one float4 column");
   const int tid = threadIdx.x;
   double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  f32x4 b_sc = f32x4{0.f, 0.f, 0.f, 0.f}, b_sh = b_sc, b_mu = b_sc, b_is = b_sc;
+  if (ep.bwd_y) {                     // a thread keeps one float4 column: tid % C4 (THREADS % C4 == 0)
+    const int cc = 4 * (tid % C4);
+    b_sc = *reinterpret_cast<const f32x4*>(ep.bwd_coef + cc);
+    b_sh = *reinterpret_cast<const f32x4*>(ep.bwd_coef + COUT + cc);
+    b_mu = *reinterpret_cast<const f32x4*>(ep.bwd_mean + cc);
+    b_is = *reinterpret_cast<const f32x4*>(ep.bwd_invstd + cc);
+  }
   for (int i = tid; i < TR * C4; i += THREADS) {
     int rr = i / C4, c4 = i - rr * C4;
     int orow = s_rows[rr];
     if (orow < 0) continue;
     f32x4 v = *reinterpret_cast<const f32x4*>(s_acc + rr * ACC_LD + 4 * c4);
     const int co = 4 * c4;
+    if (ep.bwd_y) {
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(ep.bwd_y + (long long)orow * COUT + 4 * c4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dz = bn_affine(yv[e], b_sc[e], b_sh[e]) > 0.f ? v[e] : 0.f;
+        v[e] = dz;
+        s0[e] += (double)dz;
+        s1[e] += (double)dz * (double)((yv[e] - b_mu[e]) * b_is[e]);
+      }
+      *reinterpret_cast<f32x4*>(out + (long long)orow * ld + 4 * c4) = v;
+      continue;
+    }
     if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + co);
     if (ep.scale) v *= *reinterpret_cast<const f32x4*>(ep.scale + co);
     if (ep.shift) v += *reinterpret_cast<const f32x4*>(ep.shift + co);
@@ -126,7 +153,8 @@ __device__ __forceinline__ void sc_epilogue(float* smem, const float* s_acc, con
     }
   }
   if (!bn_contribute(ep.bn_state, COUT, a0, a1, gridDim.x, s_last)) return;
-  bn_finalize_sets<false, THREADS>(ep.bn_state, ep.bn, COUT, n_live_rows, s_fin);
+  if (ep.bwd_y) bn_finalize_sets<true, THREADS>(ep.bn_state, ep.bn, COUT, n_live_rows, s_fin);
+  else bn_finalize_sets<false, THREADS>(ep.bn_state, ep.bn, COUT, n_live_rows, s_fin);
 }
 
 // Block b runs on XCD b mod 8.  Deal the tiles to the XCDs in groups of `g` consecutive tiles:
@@ -2021,6 +2049,13 @@ extern "C" int glx_sconv_forward_ex(const float* in, int N_in, const float* W, c
     bn_fin = BnFinalize{bnp->gamma, bnp->beta, bnp->eps, bnp->momentum, bnp->coef, bnp->save_mean, bnp->save_invstd,
                         bnp->running_mean, bnp->running_var, nullptr, nullptr, nullptr};
   }
+  const glx_bn_bwd_stats* bwd = opts ? opts->bn_bwd : nullptr;
+  if (bwd) {
+    GLX_REQUIRE(!bnp && !bias && !scale && !shift && !relu, "glx_sconv_forward_ex: bn_bwd excludes the forward epilogue options");
+    GLX_REQUIRE(bwd->state && bwd->y && bwd->coef_fwd && bwd->mean && bwd->invstd && bwd->coef, "glx_sconv_forward_ex: bn_bwd: null pointer");
+    bn_state = (BnState*)bwd->state;
+    bn_fin = BnFinalize{bwd->gamma, nullptr, 0.f, 0.f, bwd->coef, nullptr, nullptr, nullptr, nullptr, bwd->invstd, bwd->dgamma, bwd->dbeta};
+  }
   ProfScope prof(opts ? opts->profile_start : nullptr, opts ? opts->profile_stop : nullptr);
   GLX_REQUIRE(K > 0 && Cin > 0 && Cout > 0 && N_out >= 0, "glx_sconv_forward: bad sizes");
   GLX_REQUIRE(!bn_state || (N_out > 0 && mfma_supported(Cin, Cout, K) && !(Cin >= 128 && Cout >= 128)),
@@ -2029,7 +2064,8 @@ extern "C" int glx_sconv_forward_ex(const float* in, int N_in, const float* W, c
   if (N_out == 0) return GLX_OK;
   GLX_REQUIRE(in && (W || Wp) && nbr && out, "glx_sconv_forward: null pointer");
   SconvEpilogue ep{bias, scale, shift, relu, n_out_live, g_sconv_trace, g_sconv_xcd_group, 0, tile_map, bn_state,
-                   bn_fin};
+                   bn_fin, bwd ? bwd->y : nullptr, bwd ? bwd->coef_fwd : nullptr, bwd ? bwd->mean : nullptr,
+                   bwd ? bwd->invstd : nullptr};
   if (!mfma_supported(Cin, Cout, K)) {
     GLX_REQUIRE(W, "glx_sconv_forward: raw weights required for channels (%d,%d)", Cin, Cout);
     long long total = (long long)N_out * Cout;

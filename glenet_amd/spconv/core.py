@@ -21,6 +21,7 @@ whole frame runs without host synchronisation and can be captured in a HIP graph
 """
 import contextlib
 import ctypes
+import weakref
 import math
 import os
 from collections import OrderedDict
@@ -380,11 +381,14 @@ def _cin_padding(cin):
 
 
 def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rules=None, tag="fwd",
-           scale=None, shift=None, relu=False, n_live=None, dims=None, bn=None):
+           scale=None, shift=None, relu=False, n_live=None, dims=None, bn=None, bwd_bn=None):
     """out[j] = relu?((sum_k features[nbr[j,k]] @ weight_kio[k] + bias) * scale + shift).
     weight_kio may be None when `packed` and dims = (K, Cin, Cout) are given.
     bn: a training-mode BatchNorm1d that follows the conv -- its batch statistics are taken in the kernel's epilogue
-    (glx_sconv_opts.bn) and the call returns (out, coef, save_mean, save_invstd)."""
+    (glx_sconv_opts.bn) and the call returns (out, coef, save_mean, save_invstd).
+    bwd_bn: (y, coef, mean, invstd, gamma) -- the call is an input-gradient convolution whose output is the gradient of
+    relu(bn(y)): the epilogue masks it with the ReLU and takes the BatchNorm backward's two sums (glx_sconv_opts.bn_bwd);
+    returns (dz, coef3 (3 * cout), dgamma, dbeta)."""
     K, cin, cout = dims if dims is not None else weight_kio.shape
     out = torch.empty((n_out, cout), dtype=torch.float32, device=features.device)
     if n_out == 0:
@@ -410,6 +414,13 @@ def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rule
         st = _lib.bn_stats(_bn_state(features.device), bn, *stats)
         opts = opts or _lib.SconvOpts()
         opts.bn = ctypes.pointer(st)
+    if bwd_bn is not None:
+        y_prev, coef_prev, mean_prev, invstd_prev, gamma_prev = bwd_bn
+        stats = tuple(torch.empty(n, dtype=torch.float32, device=features.device) for n in (3 * cout, cout, cout))
+        stb = _lib.BnBwdStats(*[_lib._p(t) for t in (_bn_state(features.device), y_prev, coef_prev, mean_prev, invstd_prev,
+                                                     gamma_prev) + stats])
+        opts = opts or _lib.SconvOpts()
+        opts.bn_bwd = ctypes.pointer(stb)
     call("glx_sconv_forward_ex", features, features.shape[0], weight_kio, packed, bias, scale, shift,
          1 if relu else 0, nbr, tile_order, n_out, K, cin, cout, out, n_live, ws,
          size_arg(ws.numel()), ctypes.byref(opts) if opts is not None else None)
@@ -417,16 +428,29 @@ def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rule
         if bn.track_running_stats:
             _lib.bump_weights_epoch((bn.running_mean, bn.running_var))     # moved behind torch's back
         return (out,) + stats
+    if bwd_bn is not None:
+        return (out,) + stats
     return out
+
+
+# The BatchNorm backward's statistics pass of an inner layer rides in the epilogue of the NEXT convolution's input-gradient
+# launch (glx_sconv_opts.bn_bwd): FusedBNApply.forward leaves a link {y, coef, mean, invstd, gamma, out} on the tensor it
+# returns; the SparseConvFunction that consumes exactly that tensor runs its input gradient with the link (ReLU mask, dz,
+# sum dz, sum dz xhat, finalize) and parks (dz, coef3, dgamma, dbeta) on it; FusedBNApply.backward, handed that very dz,
+# only applies the transform.  Any other gradient (several consumers: autograd hands over a sum) takes the full path --
+# the mask is idempotent, so an already masked contribution inside the sum is still right.
+BN_BWD_IN_DGRAD = os.environ.get("GLX_SCONV_BN_BWD", "1") != "0"
 
 
 class SparseConvFunction(Function):
     """features (N_in, Cin), weight (K, Cin, Cout), bias (Cout)|None -> (N_out, Cout)."""
 
     @staticmethod
-    def forward(ctx, features, weight, bias, rules, inverse, packed=None, side_ok=False, bn=None):
+    def forward(ctx, features, weight, bias, rules, inverse, packed=None, side_ok=False, bn=None, in_link=None):
         """bn: the training-mode BatchNorm1d behind the conv: its statistics ride in the kernel's epilogue and the
-        call returns (out, coef, save_mean, save_invstd) for FusedBNApply (the last three non-differentiable)."""
+        call returns (out, coef, save_mean, save_invstd) for FusedBNApply (the last three non-differentiable).
+        in_link: the link FusedBNApply left on `features` (see BN_BWD_IN_DGRAD)."""
+        ctx.in_link = in_link if (in_link is not None and in_link.get("out") is not None and in_link["out"]() is features) else None
         features = features.contiguous().float()
         w = weight.contiguous()
         _lib.check_cuda(features, w)
@@ -493,7 +517,15 @@ class SparseConvFunction(Function):
             # input gradient = the same kernels on the adjoint weights (Cout -> Cin, taps flipped on
             # a submanifold set), packed from the forward weights in one launch
             wp_t = pack_weights(w, adjoint=True, flip=flip)
-            if wp_t is not None:
+            link = ctx.in_link
+            if (wp_t is not None and link is not None and BN_BWD_IN_DGRAD and USE_BN_STATE and link["y"].shape == (n_bwd_out, cin)
+                    and cin in (16, 32, 64, 128) and not (cin >= 128 and cout >= 128)):
+                g_feat, coef3, dgamma, dbeta = _sconv(grad_out, None, None, bwd_nbr, bwd_order, n_bwd_out, packed=wp_t,
+                                                      rules=rules, tag="dgrad", n_live=live_bwd, dims=(K, cout, cin),
+                                                      bwd_bn=(link["y"], link["coef"], link["mean"], link["invstd"],
+                                                              link["gamma"]))
+                link["result"] = (g_feat, coef3, dgamma, dbeta)
+            elif wp_t is not None:
                 g_feat = _sconv(grad_out, None, None, bwd_nbr, bwd_order, n_bwd_out, packed=wp_t, rules=rules,
                                 tag="dgrad", n_live=live_bwd, dims=(K, cout, cin))
             else:       # channel counts of the scalar kernel: materialise the adjoint weights
@@ -506,7 +538,7 @@ class SparseConvFunction(Function):
             else:   # rows past the live count are undefined (possibly NaN): select, do not multiply
                 live = torch.arange(grad_out.shape[0], device=grad_out.device) < live_fwd
                 g_b = torch.where(live[:, None], grad_out, grad_out.new_zeros(())).sum(0)
-        return g_feat, g_w, g_b, None, None, None, None, None
+        return g_feat, g_w, g_b, None, None, None, None, None, None
 
 
 class SparseConvTensor:
@@ -725,6 +757,7 @@ class SparseConvolution(SparseModule):
         rs = self._rules(x)
         if rs.ready is not None:       # built on another stream: order this stream after it
             torch.cuda.current_stream(x.indices.device).wait_event(rs.ready)
+        out_link = None
         if fused_bn is not None or fused_relu:
             scale, shift = _bn_affine(fused_bn) if fused_bn is not None else (None, None)
             if self.inverse:
@@ -738,19 +771,23 @@ class SparseConvolution(SparseModule):
         else:
             # side_ok: the weight gradient may run on WGRAD_STREAM only when nothing but views
             # separates it from the parameter (a padded weight's backward copies on the main stream)
+            in_link = getattr(x, "_bn_link", None) if not pad else None
             if train_bn is not None:
                 feats, coef, mean, invstd = SparseConvFunction.apply(x_features, w, self.bias, rs, self.inverse,
-                                                                     self._packed_weight(w), not pad, train_bn)
+                                                                     self._packed_weight(w), not pad, train_bn, in_link)
+                # relu only: the epilogue re-derives the ReLU mask; a BatchNorm without ReLU keeps the full backward
+                out_link = {} if (BN_BWD_IN_DGRAD and train_relu and train_bn.affine) else None
                 feats = FusedBNApply.apply(feats, coef, mean, invstd, train_bn.weight, train_bn.bias, train_relu,
-                                           rs.count_in if self.inverse else rs.count_out)
+                                           rs.count_in if self.inverse else rs.count_out, out_link)
                 if train_bn.track_running_stats and train_bn.num_batches_tracked is not None:
                     if DEFERRED_COUNTERS is not None:
                         DEFERRED_COUNTERS.append(train_bn.num_batches_tracked)
                     else:
                         train_bn.num_batches_tracked += 1
             else:
+                out_link = None
                 feats = SparseConvFunction.apply(x_features, w, self.bias, rs, self.inverse,
-                                                 self._packed_weight(w), not pad)
+                                                 self._packed_weight(w), not pad, None, in_link)
         if self.inverse:
             out = SparseConvTensor(feats, rs.in_indices, rs.in_spatial_shape, x.batch_size,
                                    x.grid, x.voxel_num, x.indice_dict, x.benchmark, rs.count_in)
@@ -759,6 +796,8 @@ class SparseConvolution(SparseModule):
             out = SparseConvTensor(feats, rs.out_indices, rs.out_spatial_shape, x.batch_size,
                                    x.grid, x.voxel_num, x.indice_dict, x.benchmark, rs.count_out)
             out._index = rs.out_index
+        if out_link is not None:
+            out._bn_link = out_link
         return out
 
 
@@ -839,18 +878,36 @@ class FusedBNApply(Function):
     (SparseConvFunction with bn=...): y = relu?(x * scale + shift), one launch; backward = FusedBNReLU's."""
 
     @staticmethod
-    def forward(ctx, x, coef, mean, invstd, weight, bias, relu, count=None):
+    def forward(ctx, x, coef, mean, invstd, weight, bias, relu, count=None, link=None):
         N, C = x.shape
         y = torch.empty_like(x)
         call("glx_bn_apply_forward", x, coef, 1 if relu else 0, N, C, count, y, 0)
         ctx.save_for_backward(x, weight, bias, mean, invstd)
         ctx.relu, ctx.count = relu, count
+        ctx.link = link
+        if link is not None:
+            # `out` weakly: the output's grad_fn is this node, whose ctx holds the link -- a strong reference closes a cycle
+            # through C++ that Python's collector cannot see, and a step's autograd graph that outlives the step tears
+            # the next capture down (see StaticTrainPipeline.enqueue)
+            link.update(y=x, coef=coef, mean=mean, invstd=invstd, gamma=weight, out=weakref.ref(y), result=None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        link = ctx.link
+        res = link.get("result") if link is not None else None
+        if res is not None and res[0] is dy:
+            # the convolution that consumed this tensor masked its input gradient and took the two sums in its epilogue
+            x, weight, bias, mean, invstd = ctx.saved_tensors
+            dz, coef3, dgamma, dbeta = res
+            link["result"] = None
+            dx = torch.empty_like(x)
+            call("glx_bn_backward_apply", x, dz, coef3, mean, invstd, x.shape[0], x.shape[1], ctx.count, dx)
+            return dx, None, None, None, dgamma, dbeta, None, None, None
+        if link is not None:
+            link["result"] = None
         dx, dgamma, dbeta = FusedBNReLU.backward(ctx, dy)[:3]
-        return dx, None, None, None, dgamma, dbeta, None, None
+        return dx, None, None, None, dgamma, dbeta, None, None, None
 
 
 def conv_bn_fusable(conv, bn, x):

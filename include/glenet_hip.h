@@ -71,16 +71,8 @@ typedef struct glx_epilogue {
   const float* shift;
   int relu, ldc, coff;
 } glx_epilogue;
-/* tile_map: glx_sconv_tile_map of the rule table (NULL = built-in map); profile_start / profile_stop: two HIP events
- * that bracket the MFMA launch of the call (hipExtLaunchKernelGGL: kernel-only duration for bench.py's roofline). */
-typedef struct glx_sconv_opts {
-  const int32_t* tile_map;
-  const glx_bn_stats* bn;
-  void* profile_start;
-  void* profile_stop;
-} glx_sconv_opts;
 /* Backward statistics of a BatchNorm (+ ReLU) in the epilogue of the INPUT-GRADIENT convolution that produces the gradient
- * of its output (glx_conv3x3_forward_ex on the adjoint filters): the epilogue masks the gradient with the ReLU (re-derived
+ * of its output (glx_conv3x3_forward_ex / glx_sconv_forward_ex on the adjoint filters; for the sparse form y has the rows of the gradient): the epilogue masks the gradient with the ReLU (re-derived
  * from y * scale + shift), writes dz, and takes sum dz and sum dz * xhat per channel; the last block writes coef (3 C floats:
  * a = gamma * invstd, b = mean dz, cc = mean dz * xhat -- what glx_bn_backward_apply reads), dgamma and dbeta.
  * y: the raw output (B, H, W, C) of the convolution in front of the BatchNorm; coef_fwd: its scale[C], shift[C];
@@ -96,6 +88,15 @@ typedef struct glx_bn_bwd_stats {
   float* dgamma;
   float* dbeta;
 } glx_bn_bwd_stats;
+/* tile_map: glx_sconv_tile_map of the rule table (NULL = built-in map); profile_start / profile_stop: two HIP events
+ * that bracket the MFMA launch of the call (hipExtLaunchKernelGGL: kernel-only duration for bench.py's roofline). */
+typedef struct glx_sconv_opts {
+  const int32_t* tile_map;
+  const glx_bn_stats* bn;
+  void* profile_start;
+  void* profile_stop;
+  const glx_bn_bwd_stats* bn_bwd;   /* see glx_bn_bwd_stats; excludes bn and the bias / scale / shift / relu arguments.  NULL: none */
+} glx_sconv_opts;
 typedef struct glx_conv_opts {
   const glx_bn_stats* bn;
   const glx_epilogue* epilogue;
@@ -679,9 +680,9 @@ int glx_bn_relu_backward(const float* x, const float* dy, const float* y, int N,
                          void* workspace, size_t workspace_bytes, void* state, int dy_stride, void* stream);
 /* The transform half of glx_bn_relu_backward for sums that were taken elsewhere (glx_bn_bwd_stats):
  * dx = a * (dz - b - xhat * cc) with coef = (a, b, cc) (3 C floats), xhat = (x - mean) * invstd; dz already carries the
- * ReLU mask.  x, dz, dx (N, C) row-major. */
+ * ReLU mask.  x, dz, dx (N, C) row-major; rows >= *n_live (device, may be NULL) get zeros. */
 int glx_bn_backward_apply(const float* x, const float* dz, const float* coef, const float* mean, const float* invstd,
-                          int N, int C, float* dx, void* stream);
+                          int N, int C, const int32_t* n_live, float* dx, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * VectorPool family of PV-RCNN++.  Output slots are laid out in ascending new-point order
