@@ -2399,7 +2399,7 @@ __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_mfma(
 #define WGP_MAXCH 1024                  // pairs per chunk at most (the LDS index lists)
 #define WGP_MINCH 128
 #define WGP_PANEL 32
-#define WGP_ROWS 256                    // rows per block of the list builders
+#define WGP_ROWS 512                    // rows per block of the list builders
 
 struct PairMeta {                       // head of a pair-list buffer (device)
   int poff[SC_MAXK + 1];                // start of offset k's list in pair_in / pair_out

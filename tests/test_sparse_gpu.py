@@ -246,7 +246,7 @@ def _pair_lists_of(nbr, n_out, K, n_live, dev):
     live = None if n_live is None else torch.tensor([n_live], dtype=torch.int32, device=dev)
     _lib.call("glx_pair_lists_build", nbr, n_out, K, live, pl, _lib.size_arg(nbytes))
     meta = pl[:4 * 57].view(torch.int32).cpu().numpy()         # poff[28], coff[28], ch
-    nb = (max(n_out, 1) + 255) // 256
+    nb = (max(n_out, 1) + 511) // 512                       # WGP_ROWS rows per block of the builders
     align = lambda b: (b + 255) // 256 * 256                    # noqa: E731
     o_in = align(4 * 64) + align(4 * K * nb)
     o_out = o_in + align(4 * max(n_out, 1) * K)
