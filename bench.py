@@ -256,10 +256,37 @@ def bench_bev(model, dev, frames=FRAMES_PER_GPU):
             k: dict(us=round(v * 1e3, 1), TFLOPs_fp32_equivalent=round(fl / v / 1e9, 1),
                     frac_of_fp32_mfma_peak=round(fl / v / 1e9 / MFMA_F32_PEAK_TFLOPS, 3),
                     frac_of_bf16_pipe=round(6 * fl / v / 1e9 / MFMA_BF16_PEAK_TFLOPS, 3)) for k, v in t.items()}
+    # how close to an fp64 convolution the three kernel forms are, next to the vendor's fp32 kernels on the same data
+    # (tests/test_conv2d_gpu.py asserts err <= 4 err_lib + 1e-6 of scale; here the measured numbers): one frame of the
+    # 128 -> 128 shape, max |difference| / max |fp64 result|
+    import torch.nn.functional as F
+    xe = torch.randn(1, 128, 100, 88, device=dev).contiguous(memory_format=torch.channels_last)
+    ge = torch.randn(1, 128, 100, 88, device=dev).contiguous(memory_format=torch.channels_last)
+    we = torch.randn(128, 128, 3, 3, device=dev) / (3 * 128 ** 0.5)
+    pfe, pbe = c2.packs(we)
+    xd, gd, wd = xe.double(), ge.double(), we.double()
+    ref = {"forward": F.conv2d(xd, wd, None, 1, 1),
+           "input_grad": torch.ops.aten.convolution_backward(gd, xd, wd, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                            [True, False, False])[0],
+           "weight_grad": torch.ops.aten.convolution_backward(gd, xd, wd, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                             [False, True, False])[1]}
+    lib = {"forward": F.conv2d(xe, we, None, 1, 1),
+           "input_grad": torch.ops.aten.convolution_backward(ge, xe, we, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                            [True, False, False])[0],
+           "weight_grad": torch.ops.aten.convolution_backward(ge, xe, we, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                             [False, True, False])[1]}
+    own = {"forward": c2._run(xe, pfe, 128), "input_grad": c2._run(ge, pbe, 128), "weight_grad": c2.wgrad(xe, ge, we)}
+    accuracy = {}
+    for k in ref:
+        sc = float(ref[k].abs().max())
+        e_own, e_lib = float((own[k].double() - ref[k]).abs().max()) / sc, float((lib[k].double() - ref[k]).abs().max()) / sc
+        accuracy[k] = dict(err=float("%.3g" % e_own), err_vendor_fp32=float("%.3g" % e_lib), ratio=round(e_own / max(e_lib, 1e-30), 2))
     return dict(workload="BEV backbone (12 conv3x3 + 2 deconv) + anchor head on (%d,256,200,176), fp32, channels-last, "
                          "training-mode BatchNorm included in the time; dense input (in the training step the first "
                          "layer runs on the sparse tensor instead, dense_path.BEVBackbone._first_layer_sparse)" % frames,
                 conv3x3=layers,
+                conv3x3_error_vs_fp64=dict(shape="(1, 128, 100, 88) -> 128, max |d| / max |fp64|; vendor = MIOpen's fp32 kernels on "
+                                                 "the same data", **accuracy),
                 gflop_fwd=round(flops / 1e9, 1), fwd_ms=round(ms_f, 3), fwd_bwd_ms=round(ms_fb, 3),
                 fwd_TFLOPs=round(flops / ms_f / 1e9, 1), fwd_bwd_TFLOPs=round(3 * flops / ms_fb / 1e9, 1),
                 frac_of_fp32_mfma_peak=dict(fwd=round(flops / ms_f / 1e9 / MFMA_F32_PEAK_TFLOPS, 3),
@@ -267,8 +294,9 @@ def bench_bev(model, dev, frames=FRAMES_PER_GPU):
                 kernels="3x3 / stride-1 layers (11 of 12: forward, input and weight gradient): csrc/glx_conv2d.hip, fp32 "
                         "products as six bf16 MFMAs of three-way split operands, fp32 accumulation; the two transposed "
                         "convolutions (forward, both gradients) and the strided layer's forward: csrc/glx_deconv2d.hip, "
-                        "same arithmetic; the strided layer's gradients and the 1x1 head: MIOpen fp32 (vendor); "
-                        "BatchNorm: csrc/glx_bn.hip with the forward statistics in the conv epilogue")
+                        "same arithmetic; the strided layer's gradients: MIOpen fp32 (vendor); the 1x1 anchor head: csrc/glx_head.hip "
+                        "(fp32 MFMA); BatchNorm: csrc/glx_bn.hip -- forward statistics in the conv epilogue, the transform applied "
+                        "on load by the next 3x3 layer, backward sums in the input-gradient epilogue")
 
 
 def bench_inference(dev, frames=FRAMES_PER_GPU, steps=50, cpu=True):

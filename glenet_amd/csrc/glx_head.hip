@@ -210,21 +210,18 @@ struct HeadWOut {
   float* b[3];
   int n[3];
 };
+// a wave per element: lane l adds the partials of blocks l, l + 64, ... (in that order), then a butterfly -- a fixed
+// summation order, 64 loads in flight per element instead of one thread walking 512 slabs
 __global__ void k_head_wreduce(const float* __restrict__ part, int nblocks, int C, HeadWOut out) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int total = out.n[0] + out.n[1] + out.n[2];
   if (e >= total * (C + 1)) return;
   const int o = e / (C + 1), c = e - o * (C + 1);
   float s = 0.f;
-  int b = 0;
-  for (; b + 8 <= nblocks; b += 8) {
-    float v[8];
+  for (int b = lane; b < nblocks; b += 64) s += part[(long long)b * (HD_MAXO * (C + 1)) + e];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = part[(long long)(b + u) * (HD_MAXO * (C + 1)) + e];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
-  }
-  for (; b < nblocks; ++b) s += part[(long long)b * (HD_MAXO * (C + 1)) + e];
+  for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
+  if (lane) return;
   int k = 0, oo = o;
   if (oo >= out.n[0]) { oo -= out.n[0]; k = 1; if (oo >= out.n[1]) { oo -= out.n[1]; k = 2; } }
   if (c < C) { if (out.w[k]) out.w[k][(long long)oo * C + c] = s; }
@@ -306,7 +303,7 @@ extern "C" int glx_head1x1_weight_grad(const float* const* grad, const float* x,
   hipLaunchKernelGGL(k_head_wgrad, dim3((unsigned)blocks), dim3(HD_THREADS), 0, (hipStream_t)stream, hg, x, (long long)M, C,
                      (float*)workspace);
   const int total = n[0] + n[1] + n[2];
-  hipLaunchKernelGGL(k_head_wreduce, dim3(glx_divup((long long)total * (C + 1), 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_head_wreduce, dim3(glx_divup((long long)total * (C + 1), 4)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)workspace, (int)blocks, C, wo);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
