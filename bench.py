@@ -27,6 +27,8 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+
+os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "2")      # before the HIP runtime initialises: see glenet_amd/__init__.py
 import socket
 import subprocess
 import sys
