@@ -143,6 +143,9 @@ DEFER_FC_WGRADS = os.environ.get("GLX_DEFER_FC_WGRADS", "1") != "0"
 EARLY_MLP_IN = os.environ.get("GLX_EARLY_MLP_IN", "0") == "1"
 
 
+WGRAD_STREAM_DURING_ROI = os.environ.get("GLX_WGRAD_DURING_ROI", "0") == "1"     # experiment: see StagedLoss.backward
+
+
 class StagedLoss:
     """The scalar of a training step whose backward() runs as three partial passes instead of one, so that the RoI
     branch (proposals, RoI targets, RoI-grid pooling, FC towers, RoI losses and their backward: ~350 short launches
@@ -179,7 +182,9 @@ class StagedLoss:
         # While the RoI branch is in flight the convolutions' weight gradients stay on the main stream: with a third
         # branch (the weight-gradient stream) in the recorded graph the RoI branch and the BEV backward were executed
         # one after the other (measured with the stage stamps, ROCm 7.2's graph executor); two branches do overlap.
-        wgrad_stream, core.WGRAD_STREAM = core.WGRAD_STREAM, None
+        wgrad_stream = core.WGRAD_STREAM
+        if not WGRAD_STREAM_DURING_ROI:      # measured again with two executor queues: 8.0 ms against 6.44
+            core.WGRAD_STREAM = None
         try:
             fc_jobs = dp.DEFERRED_FC_WGRADS = [] if DEFER_FC_WGRADS else None
             with torch.cuda.stream(self.roi_stream):      # A: caller stream = RoI stream, nothing of the main stream

@@ -1,12 +1,16 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python bench.py --no-config1 --no-cpu-baseline --no-extra > gpurun_out/b_def.json 2> gpurun_out/b_def.err; python - <<'PY'
+run() { tag=$1; shift; env "$@" timeout 600 python bench.py --no-config1 --no-cpu-baseline --no-extra > gpurun_out/b_$tag.json 2> gpurun_out/b_$tag.err; python - <<PY
 import json
-d=json.loads(open("gpurun_out/b_def.json").read().strip().splitlines()[-1])
-print("default", d["value"], d["ms_per_step"])
+try:
+    d=json.loads(open("gpurun_out/b_$tag.json").read().strip().splitlines()[-1])
+    s=d["stages_ms"]
+    print("$tag", d["value"], d["ms_per_step"], "head", s["BEV backbone + anchor head fwd"], "roi_bwd_end", s["backward: RoI head (RoI stream)"], "bev_bwd_end", s["backward: BEV backbone"], "bwd", s["backward"])
+except Exception as e:
+    print("$tag failed", e)
 PY
-DEBUG_HIP_FORCE_GRAPH_QUEUES=4 timeout 600 python bench.py --no-config1 --no-cpu-baseline --no-extra > gpurun_out/b_q4.json 2> gpurun_out/b_q4.err; python - <<'PY'
-import json
-d=json.loads(open("gpurun_out/b_q4.json").read().strip().splitlines()[-1])
-print("q4", d["value"], d["ms_per_step"])
-PY
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+}
+run base A=1
+run wgroi GLX_WGRAD_DURING_ROI=1
+run wgroi_q3 GLX_WGRAD_DURING_ROI=1 DEBUG_HIP_FORCE_GRAPH_QUEUES=3
+run scales GLX_ROI_SCALE_STREAMS=1
+run base2 A=1
