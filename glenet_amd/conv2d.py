@@ -319,20 +319,34 @@ def _deconv_packs(weight):
 
 class _Deconv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, bn=None):
+        """bn: the training-mode BatchNorm2d behind the transposed convolution -- its statistics ride in the kernel's
+        epilogue (glx_deconv_forward_bn) and the call returns (y, coef, save_mean, save_invstd)."""
         cin, cout, u = int(weight.shape[0]), int(weight.shape[1]), int(weight.shape[2])
         fwd, bwd = _deconv_packs(weight)
         b, _, h, w = x.shape
         x = x.detach()
         y = torch.empty((b, cout, h * u, w * u), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-        call("glx_deconv_forward", x, b, h, w, cin, fwd, cout, u, y)
         ctx.save_for_backward(x, weight)
         ctx.bwd_pack = bwd
-        return y
+        if bn is None:
+            call("glx_deconv_forward", x, b, h, w, cin, fwd, cout, u, y)
+            return y
+        from .spconv import core
+        stats = tuple(torch.empty(n, dtype=torch.float32, device=x.device) for n in (2 * cout, cout, cout))
+        st = _lib.bn_stats(core._bn_state(x.device), bn, *stats)
+        call("glx_deconv_forward_bn", x, b, h, w, cin, fwd, cout, u, y, ctypes.byref(st))
+        if bn.track_running_stats:
+            _lib.bump_weights_epoch((bn.running_mean, bn.running_var))
+        ctx.mark_non_differentiable(*stats)
+        ctx.set_materialize_grads(False)
+        return (y,) + stats
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, *_):
         from .spconv import core
+        if gy is None:
+            return None, None, None
         x, weight = ctx.saved_tensors
         cin, cout, u = int(weight.shape[0]), int(weight.shape[1]), int(weight.shape[2])
         b, _, h, w = x.shape
@@ -355,7 +369,15 @@ class _Deconv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.empty((b, cin, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
             call("glx_deconv_input_grad", gy, b, h, w, cin, ctx.bwd_pack, cout, u, gx)
-        return gx, gw
+        return gx, gw, None
+
+
+def deconv_bn_raw(x, weight, bn):
+    """ConvTranspose2d in front of a training-mode BatchNorm2d with the statistics in its epilogue, the transform not
+    applied: (y, coef, mean, invstd) for spconv.core.FusedBNApplyCat."""
+    out = _Deconv.apply(x, weight, bn)
+    _count_batch(bn)
+    return out
 
 
 def deconv(x, weight):

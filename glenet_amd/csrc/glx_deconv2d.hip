@@ -14,6 +14,7 @@
 // alignment per tap) straight into registers, the x tile through the transposing LDS read, block partials + a reduce.
 #include "glx_common.h"
 #include "glx_bf16x3.h"
+#include "glx_bn_state.h"
 
 #define PC_TM 128                        // coarse pixels per block
 #define PC_ROW 80
@@ -56,6 +57,8 @@ struct PconvArgs {
   const float* epi_shift;
   int epi_relu;
   int ldc, coff;        // floats between output pixels (>= N) and the first output channel's offset inside a pixel
+  BnState* bn_state;    // second form, STATS: training-mode BatchNorm statistics of y taken in the epilogue (as k_conv3x3_v2)
+  BnFinalize bn;
 };
 
 __global__ __launch_bounds__(256, 2) void k_pconv(PconvArgs a) {
@@ -200,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void k_pconv(PconvArgs a) {
 // in LDS; the row image alone (31 KB) lets three blocks share a CU.
 #define PC2_LDS (3 * PC_APLANE)
 
+template <bool STATS>
 __global__ __launch_bounds__(256, 3) void k_pconv_v2(PconvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;
@@ -208,6 +212,9 @@ __global__ __launch_bounds__(256, 3) void k_pconv_v2(PconvArgs a) {
   const int nch = a.Ck >> 5, nsteps = a.ktaps * nch;
   const size_t wslice = (size_t)a.N * 32;
   const int hw = a.Hc * a.Wc;
+  // STATS: the grid is a multiple of nblk, so every unit of this block has the same channel block
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  const int stats_n0 = ((int)blockIdx.x % a.nblk) * PC_BN;
 
   for (int unit = blockIdx.x; unit < a.nunits; unit += gridDim.x) {
     int t = unit;
@@ -313,8 +320,44 @@ __global__ __launch_bounds__(256, 3) void k_pconv_v2(PconvArgs a) {
         }
         *reinterpret_cast<f32x4*>(a.y + ((((long long)b * a.Hc + y) * a.uo + ntap / a.uo) * (a.Wc * a.uo) + (long long)x * a.uo +
                                           ntap % a.uo) * a.ldc + a.coff + ch0) = v;
+        if (STATS) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            ssum[g] += v[g];
+            ssq[g] += v[g] * v[g];
+          }
+        }
       }
     }
+  }
+  if (STATS) {                                            // as k_conv3x3_v2: block sums -> accumulator set -> ticket -> finalize
+    double* red = reinterpret_cast<double*>(smem);        // [moment][64 channels]
+    __shared__ int s_last;
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      double d0 = (double)ssum[g], d1 = (double)ssq[g];
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) {
+        d0 += __shfl_xor(d0, m);
+        d1 += __shfl_xor(d1, m);
+      }
+      if (r == 0) {
+        red[16 * wave + 4 * kq + g] = d0;
+        red[64 + 16 * wave + 4 * kq + g] = d1;
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int ch = tid & 63, mom = tid >> 6;
+      double seen = unsafeAtomicAdd(a.bn_state->acc[blockIdx.x % BN_SETS] + mom * BN_MAXC + stats_n0 + ch, red[mom * 64 + ch]);
+      asm volatile("" ::"v"(seen) : "memory");
+    }
+    __syncthreads();
+    if (tid == 0)
+      s_last = __hip_atomic_fetch_add(&a.bn_state->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (s_last) bn_finalize_sets<false, 256>(a.bn_state, a.bn, a.N, a.M * a.ntaps, reinterpret_cast<double(*)[2]>(smem));
   }
 }
 
@@ -338,7 +381,9 @@ extern "C" int glx_deconv_pack(const float* W, long long s_ci, long long s_co, l
 // (base_bev_backbone.py:100-104).  ldc = 0: dense (ldc = Cout, coff = 0); scale = NULL: no transform.
 // (glx_epilogue, an explicit argument of glx_deconv_forward_ex / glx_conv3x3s2_forward_ex)
 static int pconv_launch(const float* x, const void* packed, float* y, int B, int Hc, int Wc, int Ck, int N, int ui, int uo,
-                        hipStream_t st, int k3 = 0, const glx_epilogue* epi = nullptr) {
+                        hipStream_t st, int k3 = 0, const glx_epilogue* epi = nullptr, const glx_bn_stats* bnp = nullptr) {
+  GLX_REQUIRE(!bnp || (!epi && bnp->state && bnp->coef && bnp->save_mean && bnp->save_invstd && N <= BN_MAXC),
+              "glx_pconv: BatchNorm statistics: null pointer, more than %d channels, or combined with an epilogue", BN_MAXC);
   GLX_REQUIRE(!epi || ((epi->scale == nullptr) == (epi->shift == nullptr) && epi->ldc >= 0 && epi->coff >= 0 &&
                        (epi->ldc & 3) == 0 && (epi->coff & 3) == 0),
               "glx_pconv: bad epilogue (ldc %d, coff %d)", epi ? epi->ldc : 0, epi ? epi->coff : 0);
@@ -355,6 +400,11 @@ static int pconv_launch(const float* x, const void* packed, float* y, int B, int
   a.k3 = k3;
   a.epi_scale = a.epi_shift = nullptr;
   a.epi_relu = 0; a.ldc = N; a.coff = 0;
+  a.bn_state = bnp ? (BnState*)bnp->state : nullptr;
+  a.bn = BnFinalize{};
+  if (bnp)
+    a.bn = BnFinalize{bnp->gamma, bnp->beta, bnp->eps, bnp->momentum, bnp->coef, bnp->save_mean, bnp->save_invstd,
+                      bnp->running_mean, bnp->running_var, nullptr, nullptr, nullptr};
   if (epi) {
     a.epi_scale = epi->scale; a.epi_shift = epi->shift; a.epi_relu = epi->relu;
     if (epi->ldc) { a.ldc = epi->ldc; a.coff = epi->coff; }
@@ -371,9 +421,15 @@ static int pconv_launch(const float* x, const void* packed, float* y, int B, int
     GLX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     slots = 2 * (cus > 0 ? cus : 256);
   }
-  if (form == 2) {
+  if (form == 2 || bnp) {
     const int resident = slots / 2 * 3;
-    hipLaunchKernelGGL(k_pconv_v2, dim3(a.nunits < resident ? a.nunits : resident), dim3(256), PC2_LDS, st, a);
+    int grid = a.nunits < resident ? a.nunits : resident;
+    if (bnp) {
+      grid = grid / a.nblk * a.nblk;                      // every block keeps one channel block (nunits is a multiple of nblk)
+      hipLaunchKernelGGL(k_pconv_v2<true>, dim3(grid), dim3(256), PC2_LDS, st, a);
+    } else {
+      hipLaunchKernelGGL(k_pconv_v2<false>, dim3(grid), dim3(256), PC2_LDS, st, a);
+    }
   } else {
     hipLaunchKernelGGL(k_pconv, dim3(a.nunits < slots ? a.nunits : slots), dim3(256), PC_LDS, st, a);
   }
@@ -390,6 +446,13 @@ extern "C" int glx_deconv_forward_ex(const float* x, int B, int H, int W, int Ci
 extern "C" int glx_deconv_forward(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, int u,
                                   float* y, void* stream) {
   return glx_deconv_forward_ex(x, B, H, W, Cin, packed_fwd, Cout, u, y, nullptr, stream);
+}
+// ... with the training-mode BatchNorm statistics of y taken in the epilogue (contract of glx_bn_stats / glx_conv_opts.bn)
+extern "C" int glx_deconv_forward_bn(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, int u,
+                                     float* y, const glx_bn_stats* bn, void* stream) {
+  GLX_REQUIRE(B > 0 && H > 0 && W > 0 && (u == 1 || u == 2) && Cin % 64 == 0 && Cout % 64 == 0,
+              "glx_deconv_forward_bn: bad sizes (%d, %d, %d), u=%d, %d -> %d", B, H, W, u, Cin, Cout);
+  return pconv_launch(x, packed_fwd, y, B, H, W, Cin, Cout, 1, u, (hipStream_t)stream, 0, nullptr, bn);
 }
 
 extern "C" int glx_deconv_input_grad(const float* gy, int B, int H, int W, int Cin, const void* packed_bwd, int Cout, int u,

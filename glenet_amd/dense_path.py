@@ -118,6 +118,7 @@ FUSE_BN_IN_CONV3X3 = os.environ.get("GLX_CONV3X3_BN", "1") != "0"    # ... with 
 # raw convolution output through scale / shift; the next layer's backward carries this BatchNorm's backward): the normalised
 # map of the inner layers of a block is never written (base_bev_backbone.py:36-49)
 BN_ON_LOAD = os.environ.get("GLX_CONV3X3_BN_ON_LOAD", "1") != "0"
+DECONV_BN_STATS = os.environ.get("GLX_DECONV_BN_STATS", "1") != "0"   # deblocks: BatchNorm statistics in the deconv's epilogue
 
 
 def _pair(v):
@@ -208,16 +209,26 @@ class BEVBackbone(nn.Module):
         from .spconv import core
         if len(raw) < 2 or len(self.deblocks) != len(raw):
             return None
+        with_stats = [isinstance(u, tuple) for u in raw]
+        maps = [u[0] if t else u for u, t in zip(raw, with_stats)]
         bns = []
-        for blk, u in zip(self.deblocks, raw):
+        for blk, u in zip(self.deblocks, maps):
             mods = list(blk)
             if not (len(mods) == 3 and isinstance(mods[2], nn.ReLU) and self._can_fuse_bn(mods[1], u)
-                    and u.shape[0] == raw[0].shape[0] and u.shape[2:] == raw[0].shape[2:]):
+                    and u.shape[0] == maps[0].shape[0] and u.shape[2:] == maps[0].shape[2:]):
                 return None
             bns.append(mods[1])
-        b, _, h, w = raw[0].shape
-        rows = [u.permute(0, 2, 3, 1).reshape(b * h * w, u.shape[1]) for u in raw]
-        y = core.fused_train_bn_cat(bns, rows, True)
+        b, _, h, w = maps[0].shape
+        rows = [u.permute(0, 2, 3, 1).reshape(b * h * w, u.shape[1]) for u in maps]
+        if all(with_stats):       # the transposed convolutions took the statistics: one transform launch per part
+            args = []
+            for r_, u, bn in zip(rows, raw, bns):
+                args += [r_, u[1], u[2], u[3], bn.weight, bn.bias]
+            y = core.FusedBNApplyCat.apply(True, *args)
+        elif any(with_stats):
+            return None
+        else:
+            y = core.fused_train_bn_cat(bns, rows, True)
         return y.view(b, h, w, y.shape[1]).permute(0, 3, 1, 2)
 
     FUSE_UPS_CAT = os.environ.get("GLX_BEV_CAT_FUSE", "1") != "0"
@@ -398,13 +409,27 @@ class BEVBackbone(nn.Module):
             x = self._run_block(blk, first, 2) if (i == 0 and first is not None) else self._run_block(blk, x)
             data_dict["spatial_features_%dx" % int(h0 / x.shape[2])] = x
             if fuse:
+                up, ubn = self.deblocks[i][0], (self.deblocks[i][1] if len(self.deblocks[i]) > 1 else None)
+                if (DECONV_BN_STATS and OWN_DECONV and isinstance(up, nn.ConvTranspose2d) and self._bn_fusable(ubn)
+                        and own_conv.bn_state_available() and ubn.num_features == up.out_channels and _leaf(up.weight)
+                        and own_conv.deconv_supported(x, up.weight, _pair(up.stride), _pair(up.padding),
+                                                      _pair(up.output_padding), _pair(up.dilation), up.groups, up.bias)):
+                    raw.append(own_conv.deconv_bn_raw(x, up.weight, ubn))      # (y, coef, mean, invstd): statistics in the epilogue
+                    continue
                 raw.append(conv_module(self.deblocks[i][0], x))   # the deblock's (transposed) convolution only
             else:
                 ups.append(self._run_block(self.deblocks[i], x) if len(self.deblocks) > 0 else x)
         if fuse:
             x = self._ups_fused(raw)
             if x is None:                                   # not covered: BatchNorm + ReLU per map, then concatenate
-                ups = [self._run_block(nn.Sequential(*list(self.deblocks[i])[1:]), u) for i, u in enumerate(raw)]
+                ups = []
+                for i, u in enumerate(raw):
+                    mods = list(self.deblocks[i])
+                    if isinstance(u, tuple):                # statistics already taken (and counted) by the deconv
+                        y = own_conv.bn_apply(u + (mods[1],), len(mods) > 2 and isinstance(mods[2], nn.ReLU))
+                        ups.append(self._run_block(nn.Sequential(*mods[3:]), y) if len(mods) > 3 else y)
+                    else:
+                        ups.append(self._run_block(nn.Sequential(*mods[1:]), u))
         if not fuse or x is None:
             x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
         if len(self.deblocks) > len(self.blocks):

@@ -977,6 +977,37 @@ class FusedBNReLUCat(Function):
         return tuple(grads)
 
 
+class FusedBNApplyCat(Function):
+    """FusedBNReLUCat for parts whose statistics were taken elsewhere (a transposed convolution's epilogue,
+    conv2d.deconv_bn_raw): every part's transform writes its column block of the concatenated result (one launch per part,
+    no statistics pass); backward = FusedBNReLUCat's.  args: relu, then per part x, coef, mean, invstd, weight, bias."""
+
+    @staticmethod
+    def forward(ctx, relu, *args):
+        parts = [args[i:i + 6] for i in range(0, len(args), 6)]
+        N = parts[0][0].shape[0]
+        widths = [p[0].shape[1] for p in parts]
+        total = sum(widths)
+        out = torch.empty((N, total), dtype=torch.float32, device=parts[0][0].device)
+        saved, col = [], 0
+        for (x, coef, mean, invstd, w, b), C in zip(parts, widths):
+            call("glx_bn_apply_forward", x, coef, 1 if relu else 0, N, C, None, out[:, col:], total)
+            saved += [x, w, b, mean, invstd]
+            col += C
+        ctx.save_for_backward(*saved)
+        ctx.relu, ctx.widths = relu, widths
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = FusedBNReLUCat.backward(ctx, dout)           # (None, then per part dx, dgamma, dbeta, 4 x None)
+        grads = [None]
+        for i in range(len(ctx.widths)):
+            dx, dgamma, dbeta = g[1 + 7 * i:4 + 7 * i]
+            grads += [dx, None, None, None, dgamma, dbeta]
+        return tuple(grads)
+
+
 def fused_train_bn_cat(bns, features, relu):
     """relu(bn_i(features_i)) concatenated along the columns (FusedBNReLUCat); every bn as fused_train_bn takes it."""
     args = []

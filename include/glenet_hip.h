@@ -1012,6 +1012,11 @@ int glx_conv3x3s2_forward(const float* x, int B, int H, int W, int Cin, const vo
  * torch.cat(ups, dim=1) on channels-last memory costs no copy). */
 int glx_deconv_forward_ex(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, int u, float* y,
                           const glx_epilogue* epilogue, void* stream);
+/* The same with the training-mode BatchNorm statistics of y taken in the kernel's epilogue (glx_bn_stats as in
+ * glx_conv_opts.bn: coef / saved mean / invstd for glx_bn_apply_forward and glx_bn_relu_backward, running statistics
+ * updated) -- the BatchNorm2d behind a deblock's ConvTranspose2d (base_bev_backbone.py:51-66). */
+int glx_deconv_forward_bn(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, int u, float* y,
+                          const glx_bn_stats* bn, void* stream);
 int glx_conv3x3s2_forward_ex(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, float* y,
                              const glx_epilogue* epilogue, void* stream);
 size_t glx_deconv_wgrad_workspace_bytes(int Cin, int Cout, int u);

@@ -412,3 +412,35 @@ def test_batchnorm_on_load_in_the_next_convolution_equals_the_materialised_map(d
         assert float((p1.grad - p2.grad).abs().max()) <= 1e-5 * float(p2.grad.abs().max()) + 1e-8, n1
     for (n1, b1), (n2, b2) in zip(na.named_buffers(), nb.named_buffers()):
         assert torch.allclose(b1.float(), b2.float(), rtol=1e-6, atol=1e-7), n1
+
+
+def test_deblock_batchnorm_statistics_in_the_transposed_convolutions_epilogue(dev):
+    """dense_path.DECONV_BN_STATS: the deblocks' ConvTranspose2d kernels take their BatchNorm's batch statistics in the epilogue
+    (glx_deconv_forward_bn) and spconv.core.FusedBNApplyCat only transforms into the concatenated map -- against the same
+    backbone with the statistics pass (base_bev_backbone.py:51-66, 100-104): output, running statistics, every gradient."""
+    import copy
+    from glenet_amd import dense_path as dp
+    torch.manual_seed(5)
+    bev = dp.BEVBackbone(64, layer_nums=(1, 1), layer_strides=(1, 2), num_filters=(64, 128), upsample_strides=(1, 2),
+                         num_upsample_filters=(128, 128)).to(dev).train()
+    ref = copy.deepcopy(bev)
+    x = _cl(torch.randn(3, 64, 24, 40, device=dev))
+    g, outs = None, {}
+    for on, net in ((True, bev), (False, ref)):
+        dp.DECONV_BN_STATS = on
+        try:
+            xi = x.clone().requires_grad_(True)
+            y = net({"spatial_features": xi})["spatial_features_2d"]
+            if g is None:
+                g = torch.randn_like(y)
+            y.backward(g)
+            outs[on] = (y.detach(), xi.grad, net)
+        finally:
+            dp.DECONV_BN_STATS = True
+    (ya, ga, na), (yb, gb_, nb) = outs[True], outs[False]
+    assert float((ya - yb).abs().max()) <= 2e-6 * float(yb.abs().max())
+    assert float((ga - gb_).abs().max()) <= 1e-5 * float(gb_.abs().max())
+    for (n1, p1), (n2, p2) in zip(na.named_parameters(), nb.named_parameters()):
+        assert float((p1.grad - p2.grad).abs().max()) <= 1e-5 * float(p2.grad.abs().max()) + 1e-8, n1
+    for (n1, b1), (n2, b2) in zip(na.named_buffers(), nb.named_buffers()):
+        assert torch.allclose(b1.float(), b2.float(), rtol=1e-5, atol=1e-7), n1
