@@ -22,6 +22,7 @@
 // Empty balls (idx[m,0] < 0) count as ns rows of rel = 0 and feature 0, exactly as the reference's masked tensors.
 #include "glx_common.h"
 #include "glx_fill.h"
+#include "glx_bn_state.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 #define RP_SETS 16
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -130,14 +131,33 @@ __global__ __launch_bounds__(RP_FIN_THREADS) void k_rp_finalize_fwd(
 // forward: lanes = channels; a wave covers 64 / C grid points per pass
 // Lanes = (grid point, float4 of channels): C / 4 lanes per point, 64 / (C / 4) points per wave -- with a lane per
 // channel a wave had two points in flight and the kernel was one L2 latency per 2 x 16 rows (0.7 TB/s of gathers).
-template <int C>
+// OUT: the layer's output MLP rides along (voxel_pool_modules.py:105-108: mlps_out = Conv1d(C, C, 1, bias=False) +
+// BatchNorm1d + ReLU on the pooled features): y_out[m, :] = W_out pooled[m, :] is formed from the point's pooled row while
+// it is still in the lanes' registers (Q lanes per point exchange their float4s), and the BatchNorm's batch statistics of
+// y_out are accumulated on the way (BnState: block sums -> accumulator set -> ticket -> the last block finalizes) -- the
+// GEMM launch and the statistics pass over (M, C) disappear from the RoI branch's forward chain.
+struct RpOut {
+  const float* w_out;      // (C, C) row-major: y[co] = sum_c w_out[co][c] * pooled[c]
+  float* y_out;            // (M, C)
+  BnState* bn_state;
+  BnFinalize bn;
+};
+
+template <int C, bool OUT = false>
 __global__ __launch_bounds__(RP_THREADS) void k_rp_forward(const float* __restrict__ feats, const float* __restrict__ xyz,
                                                            const float* __restrict__ new_xyz, const int* __restrict__ idx,
                                                            int M, int ns, const float* __restrict__ save,
-                                                           float* __restrict__ pooled, unsigned char* __restrict__ arg) {
+                                                           float* __restrict__ pooled, unsigned char* __restrict__ arg,
+                                                           RpOut ro) {
   constexpr int Q = C / 4;                     // lanes per grid point
   constexpr int PPB = RP_THREADS / Q;          // grid points per block pass
   const int q = threadIdx.x % Q, sub = threadIdx.x / Q;
+  __shared__ float s_wout[OUT ? C * (C + 4) : 1];      // row co at co * (C + 4): the 4 rows of a lane in different banks
+  float osum[4] = {0.f, 0.f, 0.f, 0.f}, osq[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (OUT) {
+    for (int e = threadIdx.x; e < C * C; e += RP_THREADS) s_wout[(e / C) * (C + 4) + (e % C)] = ro.w_out[e];
+    __syncthreads();
+  }
   float wx[4], wy[4], wz[4], b[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -189,6 +209,53 @@ __global__ __launch_bounds__(RP_THREADS) void k_rp_forward(const float* __restri
     *reinterpret_cast<f32x4*>(pooled + m * C + 4 * q) = f32x4{best[0], best[1], best[2], best[3]};
     *reinterpret_cast<uchar4*>(arg + m * C + 4 * q) =
         make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
+    if constexpr (OUT) {
+      // the point's pooled row from its Q lanes (lane base + qq holds channels 4 qq ..), this lane's four outputs
+      const int lane = threadIdx.x & 63, base = lane - q;
+      float y[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int qq = 0; qq < Q; ++qq) {
+        float p[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i] = __shfl(best[i], base + qq, 64);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(s_wout + (4 * q + o) * (C + 4) + 4 * qq);
+          y[o] = fmaf(wv[0], p[0], y[o]);
+          y[o] = fmaf(wv[1], p[1], y[o]);
+          y[o] = fmaf(wv[2], p[2], y[o]);
+          y[o] = fmaf(wv[3], p[3], y[o]);
+        }
+      }
+      *reinterpret_cast<f32x4*>(ro.y_out + m * C + 4 * q) = f32x4{y[0], y[1], y[2], y[3]};
+#pragma unroll
+      for (int o = 0; o < 4; ++o) { osum[o] += y[o]; osq[o] += y[o] * y[o]; }
+    }
+  }
+  if constexpr (OUT) {
+    // per-channel sums of the block: lanes with the same q, then the waves; fp64 from here on
+    double d0[4], d1[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) { d0[o] = (double)osum[o]; d1[o] = (double)osq[o]; }
+#pragma unroll
+    for (int off = Q; off < 64; off <<= 1)
+#pragma unroll
+      for (int o = 0; o < 4; ++o) { d0[o] += __shfl_xor(d0[o], off, 64); d1[o] += __shfl_xor(d1[o], off, 64); }
+    __shared__ double s_red[RP_THREADS / 64][2][C];
+    __shared__ int s_last;
+    __shared__ double s_fin[RP_THREADS][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < Q)
+#pragma unroll
+      for (int o = 0; o < 4; ++o) { s_red[wave][0][4 * lane + o] = d0[o]; s_red[wave][1][4 * lane + o] = d1[o]; }
+    __syncthreads();
+    double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+    if ((int)threadIdx.x < Q)
+      for (int w = 0; w < RP_THREADS / 64; ++w)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) { a0[o] += s_red[w][0][4 * threadIdx.x + o]; a1[o] += s_red[w][1][4 * threadIdx.x + o]; }
+    if (!bn_contribute(ro.bn_state, C, a0, a1, gridDim.x, &s_last)) return;
+    bn_finalize_sets<false, RP_THREADS>(ro.bn_state, ro.bn, C, M, s_fin);
   }
 }
 
@@ -343,12 +410,39 @@ static size_t rp_partial_bytes(int C) { return glx_align((size_t)RP_MAX_BLOCKS *
 extern "C" size_t glx_pos_pool_workspace_bytes(int C) { return rp_partial_bytes(C) + 256; }
 extern "C" int glx_pos_pool_save_floats(int C) { return 6 * C; }
 
+extern "C" int glx_pos_pool_forward_out(const float* feats, int N, int C, const float* xyz, const float* new_xyz,
+                                        const int32_t* idx, int M, int nsample, const float* w_pos, const float* gamma,
+                                        const float* beta, float* running_mean, float* running_var, float momentum,
+                                        float eps, int training, float* pooled, uint8_t* arg, float* save,
+                                        double* moments, const float* w_out, float* y_out, const glx_bn_stats* bn_out,
+                                        void* workspace, size_t workspace_bytes, void* stream);
 extern "C" int glx_pos_pool_forward(const float* feats, int N, int C, const float* xyz, const float* new_xyz,
                                     const int32_t* idx, int M, int nsample, const float* w_pos, const float* gamma,
                                     const float* beta, float* running_mean, float* running_var, float momentum,
                                     float eps, int training, float* pooled, uint8_t* arg, float* save,
                                     double* moments, void* workspace, size_t workspace_bytes, void* stream) {
+  return glx_pos_pool_forward_out(feats, N, C, xyz, new_xyz, idx, M, nsample, w_pos, gamma, beta, running_mean, running_var,
+                                  momentum, eps, training, pooled, arg, save, moments, nullptr, nullptr, nullptr, workspace,
+                                  workspace_bytes, stream);
+}
+
+// ... with the output MLP of the layer: y_out (M, C) = pooled @ w_out^T (w_out (C, C) row-major) and the training-mode
+// BatchNorm statistics of y_out in the same launch (bn_out as glx_conv_opts.bn; all three NULL = glx_pos_pool_forward)
+extern "C" int glx_pos_pool_forward_out(const float* feats, int N, int C, const float* xyz, const float* new_xyz,
+                                        const int32_t* idx, int M, int nsample, const float* w_pos, const float* gamma,
+                                        const float* beta, float* running_mean, float* running_var, float momentum,
+                                        float eps, int training, float* pooled, uint8_t* arg, float* save,
+                                        double* moments, const float* w_out, float* y_out, const glx_bn_stats* bn_out,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
   GLX_REQUIRE(rp_channels_ok(C), "glx_pos_pool_forward: C=%d (16, 32 or 64)", C);
+  GLX_REQUIRE((w_out == nullptr) == (y_out == nullptr) && (w_out == nullptr) == (bn_out == nullptr),
+              "glx_pos_pool_forward_out: w_out, y_out and bn_out come together");
+  GLX_REQUIRE(!bn_out || (C <= 32 && M > 0 && bn_out->state && bn_out->coef && bn_out->save_mean && bn_out->save_invstd),
+              "glx_pos_pool_forward_out: the output MLP needs C <= 32, M > 0 and the statistics' buffers");
+  RpOut ro{w_out, y_out, bn_out ? (BnState*)bn_out->state : nullptr, BnFinalize{}};
+  if (bn_out)
+    ro.bn = BnFinalize{bn_out->gamma, bn_out->beta, bn_out->eps, bn_out->momentum, bn_out->coef, bn_out->save_mean,
+                       bn_out->save_invstd, bn_out->running_mean, bn_out->running_var, nullptr, nullptr, nullptr};
   GLX_REQUIRE(nsample > 0 && nsample <= 255, "glx_pos_pool_forward: nsample=%d", nsample);
   GLX_REQUIRE(w_pos && save && moments && (M == 0 || (feats && xyz && new_xyz && idx && pooled && arg)) &&
                   (training || (running_mean && running_var)),
@@ -369,15 +463,21 @@ extern "C" int glx_pos_pool_forward(const float* feats, int N, int C, const floa
   if (M > 0) {
     const int ppb_f = RP_THREADS / (C / 4);
     const int blocks = (int)(((long long)M + ppb_f - 1) / ppb_f > 4096 ? 4096 : ((long long)M + ppb_f - 1) / ppb_f);
-    if (C == 16)
+    if (C == 16 && w_out)
+      hipLaunchKernelGGL((k_rp_forward<16, true>), dim3(blocks), dim3(RP_THREADS), 0, st, feats, xyz, new_xyz, idx, M, nsample,
+                         (const float*)save, pooled, arg, ro);
+    else if (C == 32 && w_out)
+      hipLaunchKernelGGL((k_rp_forward<32, true>), dim3(blocks), dim3(RP_THREADS), 0, st, feats, xyz, new_xyz, idx, M, nsample,
+                         (const float*)save, pooled, arg, ro);
+    else if (C == 16)
       hipLaunchKernelGGL((k_rp_forward<16>), dim3(blocks), dim3(RP_THREADS), 0, st, feats, xyz, new_xyz, idx, M, nsample,
-                         (const float*)save, pooled, arg);
+                         (const float*)save, pooled, arg, ro);
     else if (C == 32)
       hipLaunchKernelGGL((k_rp_forward<32>), dim3(blocks), dim3(RP_THREADS), 0, st, feats, xyz, new_xyz, idx, M, nsample,
-                         (const float*)save, pooled, arg);
+                         (const float*)save, pooled, arg, ro);
     else
       hipLaunchKernelGGL((k_rp_forward<64>), dim3(blocks), dim3(RP_THREADS), 0, st, feats, xyz, new_xyz, idx, M, nsample,
-                         (const float*)save, pooled, arg);
+                         (const float*)save, pooled, arg, ro);
   }
   GLX_LAUNCH_CHECK();
   return GLX_OK;

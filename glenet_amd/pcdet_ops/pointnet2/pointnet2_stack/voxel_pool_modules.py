@@ -2,6 +2,8 @@
 abstraction of Voxel-RCNN (called from voxelrcnn_head.py:106-191).  Same constructor keywords,
 submodule names (groupers / mlps_in / mlps_pos / mlps_out, so checkpoints load) and forward
 signature; the query + grouping run on glenet_amd kernels."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -70,7 +72,10 @@ class PosPool(torch.autograd.Function):
     (M, nsample, C) tensor; BatchNorm statistics from the moments of the offsets."""
 
     @staticmethod
-    def forward(ctx, feats, w_pos, gamma, beta, bn, idx, xyz, new_xyz):
+    def forward(ctx, feats, w_pos, gamma, beta, bn, idx, xyz, new_xyz, w_out=None, bn_out=None):
+        """w_out (C, C) / bn_out: the layer's output MLP (mlps_out's Conv1d weight and its training-mode BatchNorm1d) --
+        y_out = pooled @ w_out^T and the BatchNorm's batch statistics are formed in the pooling launch
+        (glx_pos_pool_forward_out); returns (pooled, arg, y_out, coef, mean, invstd) then."""
         import ctypes
         from .... import _lib
         feats, w, xyz, new_xyz, idx = (feats.contiguous().float(), w_pos.reshape(w_pos.shape[0], 3).contiguous().float(),
@@ -85,22 +90,55 @@ class PosPool(torch.autograd.Function):
         moments = torch.empty(9, dtype=torch.float64, device=dev)
         ws = _lib.workspace.get(_lib.query("glx_pos_pool_workspace_bytes", c), dev)
         rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-        _lib.call("glx_pos_pool_forward", feats, n, c, xyz, new_xyz, idx, m, ns, w, gamma, beta, rm, rv,
-                  ctypes.c_float(bn.momentum if bn.momentum is not None else 0.1), ctypes.c_float(bn.eps),
-                  1 if training else 0, pooled, arg, save, moments, ws, _lib.size_arg(ws.numel()))
+        extra = ()
+        if w_out is not None:
+            from ....spconv import core
+            wo = w_out.detach().reshape(c, c).contiguous().float()
+            y_out = torch.empty((m, c), dtype=torch.float32, device=dev)
+            stats = tuple(torch.empty(k, dtype=torch.float32, device=dev) for k in (2 * c, c, c))
+            st = _lib.bn_stats(core._bn_state(dev), bn_out, *stats)
+            _lib.call("glx_pos_pool_forward_out", feats, n, c, xyz, new_xyz, idx, m, ns, w, gamma, beta, rm, rv,
+                      ctypes.c_float(bn.momentum if bn.momentum is not None else 0.1), ctypes.c_float(bn.eps),
+                      1 if training else 0, pooled, arg, save, moments, wo, y_out, ctypes.byref(st), ws,
+                      _lib.size_arg(ws.numel()))
+            if bn_out.track_running_stats:
+                _lib.bump_weights_epoch((bn_out.running_mean, bn_out.running_var))
+            extra = (y_out,) + stats
+            ctx.wo = wo
+        else:
+            _lib.call("glx_pos_pool_forward", feats, n, c, xyz, new_xyz, idx, m, ns, w, gamma, beta, rm, rv,
+                      ctypes.c_float(bn.momentum if bn.momentum is not None else 0.1), ctypes.c_float(bn.eps),
+                      1 if training else 0, pooled, arg, save, moments, ws, _lib.size_arg(ws.numel()))
+            ctx.wo = None
         if training and rm is not None:
             _lib.bump_weights_epoch((rm, rv))             # running statistics updated through raw pointers
         ctx.save_for_backward(feats, w, gamma, pooled, arg, idx, xyz, new_xyz, save, moments)
         ctx.training, ctx.wshape = training, w_pos.shape
-        ctx.mark_non_differentiable(arg)
-        return pooled, arg
+        ctx.wo_shape = w_out.shape if w_out is not None else None
+        if extra:
+            ctx.mark_non_differentiable(arg, *extra[1:])
+            ctx.set_materialize_grads(False)
+        else:
+            ctx.mark_non_differentiable(arg)
+        return (pooled, arg) + extra
 
     @staticmethod
-    def backward(ctx, dpooled, _darg):
+    def backward(ctx, dpooled, _darg, dy_out=None, *_stats):
         from .... import _lib
         feats, w, gamma, pooled, arg, idx, xyz, new_xyz, save, moments = ctx.saved_tensors
         (n, c), (m, ns) = feats.shape, idx.shape
         dev = feats.device
+        d_wo = None
+        if ctx.wo is not None and dy_out is not None:
+            # the output MLP's two gradients: into the pooled rows, and the (C, C) filter -- rows in 128 batched products
+            # so that the contraction over M rows is a batched GEMM + a sum, not one 32 x 32 tile with K = M
+            dy_out = dy_out.contiguous().float()
+            g = dy_out @ ctx.wo
+            dpooled = g if dpooled is None else dpooled.contiguous().float() + g
+            s_ = 128 if (m % 128 == 0 and m >= 128 * 64) else 1
+            d_wo = torch.bmm(dy_out.view(s_, m // s_, c).transpose(1, 2), pooled.view(s_, m // s_, c)).sum(0).view(ctx.wo_shape)
+        elif dpooled is None:
+            dpooled = torch.zeros_like(pooled)
         dfeats = torch.empty_like(feats)
         dw = torch.empty((c, 3), dtype=torch.float32, device=dev)
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
@@ -110,19 +148,54 @@ class PosPool(torch.autograd.Function):
                   gamma, save, moments, 1 if ctx.training else 0, dfeats, dw, dgamma, dbeta, ws,
                   _lib.size_arg(ws.numel()))
         return (dfeats, dw.view(ctx.wshape), dgamma if gamma is not None else None,
-                dbeta if gamma is not None else None, None, None, None, None)
+                dbeta if gamma is not None else None, None, None, None, None, d_wo, None)
 
 
-def pos_pool(feats, mlp_pos, idx, xyz, new_xyz):
-    """mlp_pos = Sequential(Conv2d(3, C, 1, bias=False), BatchNorm2d(C)) -> pooled (M, C)."""
-    conv, bn = mlp_pos[0], mlp_pos[1]
+def _count(bn):
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         from ....spconv import core
         if core.DEFERRED_COUNTERS is not None:       # a training step adds 1 to all its counters in one launch
             core.DEFERRED_COUNTERS.append(bn.num_batches_tracked)
         else:
             bn.num_batches_tracked += 1
+
+
+def pos_pool(feats, mlp_pos, idx, xyz, new_xyz):
+    """mlp_pos = Sequential(Conv2d(3, C, 1, bias=False), BatchNorm2d(C)) -> pooled (M, C)."""
+    conv, bn = mlp_pos[0], mlp_pos[1]
+    _count(bn)
     return PosPool.apply(feats, conv.weight, bn.weight, bn.bias, bn, idx, xyz, new_xyz)[0]
+
+
+# Off by default: measured on the GLENet-VR step (A/B on one box) 6.475 ms with it against 6.419 without -- the exchange of
+# the pooled row between a point's lanes and the statistics tail (atomics, ticket, last-block finalize) cost the pooling
+# launch more than the GEMM and the statistics pass they replace (14 + 13 us per scale).  Kept for the record and its test.
+POS_POOL_OUT = os.environ.get("GLX_POS_POOL_OUT", "0") != "0"
+
+
+def pos_pool_out_supported(feats, mlp_pos, mlp_out):
+    """The pooling launch can carry the layer's output MLP: Sequential(Conv1d(C, C, 1, bias=False), BatchNorm1d(C), ReLU)
+    in training mode with C <= 32 (csrc/glx_roipool.hip k_rp_forward<C, true>)."""
+    from ....spconv import core
+    if not (POS_POOL_OUT and torch.is_grad_enabled() and pos_pool_supported(feats, mlp_pos) and len(mlp_out) == 3):
+        return False
+    conv, bn, act = mlp_out[0], mlp_out[1], mlp_out[2]
+    c = feats.shape[1]
+    return (isinstance(conv, nn.Conv1d) and conv.kernel_size == (1,) and conv.bias is None and conv.in_channels == c
+            and conv.out_channels == c and c <= 32 and isinstance(bn, nn.BatchNorm1d) and isinstance(act, nn.ReLU)
+            and bn.training and bn.affine and core.USE_BN_STATE and core.USE_FUSED_TRAIN_BN and bn.momentum is not None)
+
+
+def pos_pool_out(feats, mlp_pos, mlp_out, idx, xyz, new_xyz):
+    """relu(bn_out(conv_out(pos_pool(...)))) (M, C): pooling, the output convolution and the BatchNorm statistics in one
+    launch, the transform in a second (spconv.core.FusedBNApply)."""
+    from ....spconv import core
+    conv, bn = mlp_pos[0], mlp_pos[1]
+    _count(bn)
+    _count(mlp_out[1])
+    _, _, y, coef, mean, invstd = PosPool.apply(feats, conv.weight, bn.weight, bn.bias, bn, idx, xyz, new_xyz,
+                                                mlp_out[0].weight, mlp_out[1])
+    return core.FusedBNApply.apply(y, coef, mean, invstd, mlp_out[1].weight, mlp_out[1].bias, True)
 
 
 def pos_pool_supported(feats, mlp_pos):

@@ -217,6 +217,12 @@ class RoIGridPool(nn.Module):
                 zr, yr, xr = grouper.max_range
                 _lib.call("glx_roi_grid_query", m, z, y, x, ns, float(grouper.radius), zr, yr, xr, grid_xyz,
                           coords, stride, ind, rmin, vsz, index.bitmap, index.prefix, index.rank_to_row, idx)
+                if self.USE_POS_POOL and voxel_pool_modules.pos_pool_out_supported(feats, mlp_pos, mlp_out):
+                    # ... and the output MLP's convolution + BatchNorm statistics in the same launch
+                    outs.append(voxel_pool_modules.pos_pool_out(feats, mlp_pos, mlp_out, idx, xyz, grid_xyz))
+                    if stream is not cur:
+                        outs[-1].record_stream(cur)
+                    continue
                 if self.USE_POS_POOL and voxel_pool_modules.pos_pool_supported(feats, mlp_pos):
                     # position MLP + add + ReLU + max-pool fused: no (M, ns, C) tensor (csrc/glx_roipool.hip)
                     pooled = voxel_pool_modules.pos_pool(feats, mlp_pos, idx, xyz, grid_xyz)

@@ -748,6 +748,15 @@ int glx_pos_pool_forward(const float* feats, int N, int C, const float* xyz, con
                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                          int training, float* pooled, uint8_t* arg, float* save, double* moments,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the layer's output MLP (voxel_pool_modules.py:105-108, mlps_out = Conv1d(C, C, 1, bias=False) + BatchNorm1d +
+ * ReLU): y_out (M, C) = pooled @ w_out^T (w_out (C, C) row-major) formed in the pooling launch, with the training-mode
+ * BatchNorm statistics of y_out taken on the way (bn_out: glx_bn_stats as in glx_conv_opts.bn; the transform is
+ * glx_bn_apply_forward).  C <= 32, M > 0.  w_out = y_out = bn_out = NULL: glx_pos_pool_forward. */
+int glx_pos_pool_forward_out(const float* feats, int N, int C, const float* xyz, const float* new_xyz, const int32_t* idx,
+                             int M, int nsample, const float* w_pos, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float momentum, float eps, int training,
+                             float* pooled, uint8_t* arg, float* save, double* moments, const float* w_out, float* y_out,
+                             const glx_bn_stats* bn_out, void* workspace, size_t workspace_bytes, void* stream);
 int glx_pos_pool_backward(const float* dpooled, const float* pooled, const uint8_t* arg, const int32_t* idx,
                           const float* xyz, const float* new_xyz, int M, int nsample, int C, int N,
                           const float* w_pos, const float* gamma, const float* save, const double* moments,

@@ -738,6 +738,38 @@ def test_fused_position_pool_equals_the_unfused_training_path(dev, training):
         np.testing.assert_allclose(b1[k].cpu().numpy(), b2[k].cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
 
 
+def test_position_pool_with_the_output_mlp_in_the_same_launch(dev):
+    """glx_pos_pool_forward_out (k_rp_forward<C, true>: the layer's output Conv1d and its BatchNorm's batch statistics formed
+    while a point's pooled row is in registers) against the pooling launch + GEMM + statistics pass: outputs, gradients of
+    the sparse features and of every parameter, running statistics (voxel_pool_modules.py:105-108)."""
+    import copy
+    from glenet_amd.pcdet_ops.pointnet2.pointnet2_stack import voxel_pool_modules as vpm
+    rng = np.random.default_rng(79)
+    pool, feats, strides, rois, B = _roi_scene(dev, rng)
+    pool.train()
+    state = copy.deepcopy(pool.state_dict())
+    res, used = [], []
+    orig, was = vpm.pos_pool_out, vpm.POS_POOL_OUT
+    vpm.pos_pool_out = lambda *a: (used.append(1), orig(*a))[1]
+    try:
+        for on in (True, False):
+            pool.load_state_dict(state)
+            vpm.POS_POOL_OUT = on
+            res.append(_run_pool(pool, feats, strides, rois, B, dev))
+    finally:
+        vpm.POS_POOL_OUT, vpm.pos_pool_out = was, orig
+    assert len(used) == len(pool.roi_grid_pool_layers)              # every scale took the fused launch, once
+    (o1, g1, p1, b1), (o2, g2, p2, b2) = res
+    np.testing.assert_allclose(o1.cpu().numpy(), o2.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    for k in g1:
+        np.testing.assert_allclose(g1[k].cpu().numpy(), g2[k].cpu().numpy(), rtol=1e-3, atol=1e-6 + 1e-4 * float(g2[k].abs().max()))
+    for k in p1:
+        np.testing.assert_allclose(p1[k].cpu().numpy(), p2[k].cpu().numpy(), rtol=1e-3,
+                                   atol=1e-6 + 1e-4 * float(p2[k].abs().max()), err_msg=k)
+    for k in b1:
+        np.testing.assert_allclose(b1[k].cpu().numpy(), b2[k].cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
+
+
 def test_roi_grid_training_path_on_shape_static_tensors(dev):
     """The sync-free training path (grid-point kernel + index query + live-row handling of mlps_in) on
     capacity-sized sparse tensors whose padding rows hold NaN == the exact-shape tensors, and == the generic
