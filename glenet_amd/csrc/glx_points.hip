@@ -28,7 +28,7 @@ struct BoxT {
     float sx = x - cx, sy = y - cy;
     lx = sx * cosa + sy * (-sina);
     ly = sx * sina + sy * cosa;
-    return (fabsf(lx) < dx / 2.0 + margin) & (fabsf(ly) < dy / 2.0 + margin);
+    return (int)(fabsf(lx) < dx / 2.0 + margin) & (int)(fabsf(ly) < dy / 2.0 + margin);   // branch-free, as the reference's
   }
 };
 

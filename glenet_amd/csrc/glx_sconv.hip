@@ -81,7 +81,7 @@ template <int COUT, int TR, int THREADS, int ACC_LD>
 __device__ __forceinline__ void sc_epilogue(float* smem, const float* s_acc, const int* s_rows, const SconvEpilogue& ep,
                                             float* __restrict__ out, int ld, int n_live_rows) {
   constexpr int C4 = COUT / 4;
-  static_assert(THREADS % C4 == 0 && 64 % C4 == 0 || C4 % 64 == 0, "a thread keeps one float4 column");
+  static_assert((THREADS % C4 == 0 && 64 % C4 == 0) || C4 % 64 == 0, "a thread keeps one float4 column");
   const int tid = threadIdx.x;
   double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
   f32x4 b_sc = f32x4{0.f, 0.f, 0.f, 0.f}, b_sh = b_sc, b_mu = b_sc, b_is = b_sc;

@@ -30,7 +30,7 @@ __device__ __forceinline__ int vp_frame(int pt, const int* __restrict__ new_cnt,
 
 __device__ __forceinline__ bool vp_in_range(float lx, float ly, float lz, float dist, int neighbor_type) {
   if (neighbor_type == 1) return !(lx * lx + ly * ly + lz * lz > dist * dist);
-  return !((fabsf(lx) > dist) | (fabsf(ly) > dist) | (fabsf(lz) > dist));
+  return !((int)(fabsf(lx) > dist) | (int)(fabsf(ly) > dist) | (int)(fabsf(lz) > dist));
 }
 
 // ---- local neighbour lists (vector_pool_gpu.cu:122-200).  EMIT = false: counts[pt]; true: the lists.
