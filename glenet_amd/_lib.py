@@ -44,7 +44,7 @@ def load():
                  "glx_conv3x3_packed_bytes", "glx_conv3x3_wgrad_workspace_bytes",
                  "glx_deconv_packed_bytes", "glx_deconv_wgrad_workspace_bytes", "glx_pair_lists_bytes",
                  "glx_sconv_wgrad_pairs_workspace_bytes", "glx_pointmax_wsum_workspace_bytes",
-                 "glx_head1x1_wgrad_workspace_bytes", "glx_topk_workspace_bytes"):
+                 "glx_head1x1_wgrad_workspace_bytes", "glx_topk_workspace_bytes", "glx_fc_tower_scratch_bytes"):
         if hasattr(lib, name):
             getattr(lib, name).restype = c_size_t
     lib.glx_index_words.restype = c_int64
@@ -131,6 +131,30 @@ class SconvOpts(ctypes.Structure):
 class ConvOpts(ctypes.Structure):
     _fields_ = [("bn", ctypes.POINTER(BnStats)), ("epilogue", ctypes.POINTER(Epilogue)), ("prologue", ctypes.POINTER(Epilogue)),
                 ("bn_bwd", ctypes.POINTER(BnBwdStats))]
+
+
+class FcBn(ctypes.Structure):
+    _fields_ = [("gamma", c_void_p), ("beta", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p),
+                ("save_mean", c_void_p), ("save_invstd", c_void_p), ("eps", c_float), ("momentum", c_float)]
+
+
+class FcTower(ctypes.Structure):
+    """glx_fc_tower (include/glenet_hip.h)."""
+    _fields_ = [("R", c_int), ("drop_p", c_float), ("drop_u", c_void_p), ("z0", c_void_p), ("w", c_void_p * 6), ("bn", FcBn * 6),
+                ("z", c_void_p * 6), ("h", c_void_p * 6), ("w_cls", c_void_p), ("b_cls", c_void_p), ("w_reg", c_void_p),
+                ("b_reg", c_void_p), ("w_std", c_void_p), ("b_std", c_void_p), ("bn_s7", FcBn), ("w_fc1", c_void_p),
+                ("b_fc1", c_void_p), ("bn_s64", FcBn), ("w_fc2", c_void_p), ("b_fc2", c_void_p), ("ori_cls", c_void_p),
+                ("rcnn_reg", c_void_p), ("rcnn_reg_std", c_void_p), ("std_logit", c_void_p), ("scratch", c_void_p),
+                ("barrier", c_void_p), ("cooperative", c_int)]
+
+
+class FcTowerGrads(ctypes.Structure):
+    """glx_fc_tower_grads (include/glenet_hip.h)."""
+    _fields_ = [("g_cls", c_void_p), ("g_logit", c_void_p), ("g_reg", c_void_p), ("g_std", c_void_p), ("dz", c_void_p * 6),
+                ("dgamma", c_void_p * 6), ("dbeta", c_void_p * 6), ("dw_cls", c_void_p), ("db_cls", c_void_p),
+                ("dw_reg", c_void_p), ("db_reg", c_void_p), ("dw_std", c_void_p), ("db_std", c_void_p), ("dgamma7", c_void_p),
+                ("dbeta7", c_void_p), ("dw_fc1", c_void_p), ("db_fc1", c_void_p), ("dgamma64", c_void_p), ("dbeta64", c_void_p),
+                ("dw_fc2", c_void_p), ("db_fc2", c_void_p), ("scratch", c_void_p)]
 
 
 def bn_stats(state, bn, coef, save_mean, save_invstd):

@@ -15,6 +15,7 @@ modules is pinned by tests/golden/dense_path_ref.npz (state dicts + outputs prod
 reference code on CPU, see tests/golden/make_golden.py).
 """
 import contextlib
+import ctypes
 import math
 import os
 import types
@@ -696,9 +697,7 @@ class _SplitKLinearFn(torch.autograd.Function):
             if DEFERRED_FC_WGRADS is not None and w.is_leaf:
                 # a leaf of the backward pass: a staged training step computes it later, on the main stream's idle time,
                 # instead of on the RoI branch (its critical path) -- see run_deferred_fc_wgrads
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(x.device))
-                DEFERRED_FC_WGRADS.append((x, gy, w, ev, _SplitKLinearFn.weight_grad))
+                DEFERRED_FC_WGRADS.append((x, gy, w, _deferred_event(x.device), _SplitKLinearFn.weight_grad))
             else:
                 gw = _SplitKLinearFn.weight_grad(x, gy, w)
         return gx, gw
@@ -715,6 +714,15 @@ class _SplitKLinearFn(torch.autograd.Function):
 
 
 DEFERRED_FC_WGRADS = None     # a list while a staged backward collects the FC towers' weight-gradient jobs
+DEFERRED_FC_SAME_STREAM = False   # the collector will run the jobs on the stream that creates them: no events
+
+
+def _deferred_event(device):
+    if DEFERRED_FC_SAME_STREAM:
+        return None
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    return ev
 
 
 def run_deferred_fc_wgrads(jobs):
@@ -723,9 +731,10 @@ def run_deferred_fc_wgrads(jobs):
     cur = torch.cuda.current_stream()
     with torch.no_grad():
         for x, gy, w, ev, weight_grad in jobs:
-            cur.wait_event(ev)
-            x.record_stream(cur)
-            gy.record_stream(cur)
+            if ev is not None:
+                cur.wait_event(ev)
+                x.record_stream(cur)
+                gy.record_stream(cur)
             gw = weight_grad(x, gy, w)
             w.grad = gw if w.grad is None else w.grad + gw
 
@@ -769,6 +778,216 @@ class FCTower(nn.Sequential):
             x = m(x)
             i += 1
         return x
+
+
+# ---- the towers behind the first Linear as one launch per direction (csrc/glx_fctower.hip)
+FC_TOWER_FUSED = os.environ.get("GLX_FC_TOWER", "1") != "0"
+FC_TOWER_COOPERATIVE = os.environ.get("GLX_FC_TOWER_COOP", "1") != "0"     # 0: one launch per phase (5 forward, 4 backward)
+_FCT_BARRIER = {}
+
+
+def _fct_barrier(device):
+    """The grid barrier's counters: zero once, every launch leaves them zero (one per device and stream: launches on one
+    stream are ordered, two streams must not share them)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    b = _FCT_BARRIER.get(key)
+    if b is None:
+        b = _FCT_BARRIER[key] = torch.zeros(32, dtype=torch.int32, device=device)
+    return b
+
+
+def _fc_bn(bn, mean, invstd):
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    return _lib.FcBn(_lib._p(bn.weight), _lib._p(bn.bias), _lib._p(rm), _lib._p(rv), _lib._p(mean), _lib._p(invstd), float(bn.eps),
+                     float(bn.momentum))
+
+
+def fc_tower_layers(head):
+    """(Linear, BatchNorm1d) of layers 0..5 of a VoxelRCNNKLHead-shaped module, or None when the towers are not the
+    Linear(bias=False) + BatchNorm1d + ReLU (+ Dropout behind the first layer) x 2 stacks of width 256 the kernel covers."""
+    pairs, ps = [], set()
+    for seq in (head.shared_fc_layer, head.cls_fc_layers, head.reg_fc_layers):
+        mods = list(seq)
+        kinds = [type(m) for m in mods]
+        with_drop = len(mods) == 7
+        want = [nn.Linear, nn.BatchNorm1d, nn.ReLU] + ([nn.Dropout] if with_drop else []) + [nn.Linear, nn.BatchNorm1d, nn.ReLU]
+        if len(kinds) != len(want) or not all(issubclass(k, w) for k, w in zip(kinds, want)):
+            return None
+        ps.add(float(mods[3].p) if with_drop else 0.0)
+        b = 4 if with_drop else 3
+        for lin, bn in ((mods[0], mods[1]), (mods[b], mods[b + 1])):
+            if lin.bias is not None:
+                return None
+            pairs.append((lin, bn))
+    if len(ps) != 1 or any(l.out_features != 256 for l, _ in pairs) or any(l.in_features != 256 for l, _ in pairs[1:]):
+        return None
+    return pairs
+
+
+def fc_tower_usable(head, x):
+    """Training-mode heads() of a VoxelRCNNKLHead on the fused kernels: every BatchNorm in training mode with affine
+    parameters and a momentum, 7 box codes, one class, the rows a multiple of 16 up to 1024."""
+    if not (FC_TOWER_FUSED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and torch.is_grad_enabled() and head.training):
+        return False
+    if x.shape[0] % 16 or not 16 <= x.shape[0] <= 1024:
+        return False
+    pairs = head.__dict__.get("_glx_fct_pairs", 0)
+    if pairs == 0:
+        pairs = head.__dict__["_glx_fct_pairs"] = fc_tower_layers(head)
+    if pairs is None:
+        return False
+    bns = [bn for _, bn in pairs] + [head.reg_std_bn, head.reg_std_bn1]
+    if not all(bn.training and bn.affine and bn.momentum is not None for bn in bns):
+        return False
+    return (head.cls_pred_layer.out_features == 1 and head.reg_pred_layer.out_features == 7
+            and head.reg_std_layer.out_features == 7 and head.reg_std_fc1.out_features == 64 and head.reg_std_fc2.out_features == 1)
+
+
+class FCTowersFn(torch.autograd.Function):
+    """(ori_cls (R,1), std_logit (R,1), rcnn_reg (R,7), rcnn_reg_std (R,7)) of VoxelRCNNKLHead.heads in training mode:
+    the first Linear as the split-K library product, everything behind it in glx_fc_tower_forward; backward =
+    glx_fc_tower_backward + the Linear weight gradients (deferred like _SplitKLinearFn's when a staged step collects
+    them) + the pooled features' gradient."""
+
+    @staticmethod
+    def forward(ctx, head, drop_p, x, w0, *params):
+        pairs = head._glx_fct_pairs
+        R, dev = x.shape[0], x.device
+        with torch.no_grad():
+            z0 = _SplitKLinearFn.forward(_NoCtx(), x, w0)
+        f32 = dict(dtype=torch.float32, device=dev)
+        u = None
+        if drop_p > 0:
+            # fixed_dropout_draws: (3, R, 256) uniforms for layers 0 / 2 / 4 instead of fresh ones (tests replaying a reference run)
+            u = getattr(head, "fixed_dropout_draws", None)
+            u = torch.rand((3, R, 256), **f32) if u is None else u.to(**f32).contiguous()
+        zh = torch.empty((11, R, 256), **f32)                 # z[1..5], h[0..5]
+        stats = torch.empty((12, 256), **f32)
+        small = torch.empty((2, 7 + 64), **f32)
+        dense = torch.empty((2, R), **f32)                    # ori_cls, std_logit
+        reg = torch.empty((2, R, 7), **f32)                   # rcnn_reg, rcnn_reg_std
+        scratch = _lib.workspace.get(_lib.query("glx_fc_tower_scratch_bytes", R), dev)
+        t = _lib.FcTower()
+        t.R, t.drop_p, t.drop_u, t.z0 = R, float(drop_p), _lib._p(u), z0.data_ptr()
+        for l, (lin, bn) in enumerate(pairs):
+            t.w[l] = lin.weight.data_ptr() if l else None
+            t.bn[l] = _fc_bn(bn, stats[2 * l], stats[2 * l + 1])
+            t.z[l] = zh[l - 1].data_ptr() if l else None
+            t.h[l] = zh[5 + l].data_ptr()
+        t.w_cls, t.b_cls = head.cls_pred_layer.weight.data_ptr(), head.cls_pred_layer.bias.data_ptr()
+        t.w_reg, t.b_reg = head.reg_pred_layer.weight.data_ptr(), head.reg_pred_layer.bias.data_ptr()
+        t.w_std, t.b_std = head.reg_std_layer.weight.data_ptr(), head.reg_std_layer.bias.data_ptr()
+        t.bn_s7 = _fc_bn(head.reg_std_bn, small[0, :7], small[1, :7])
+        t.w_fc1, t.b_fc1 = head.reg_std_fc1.weight.data_ptr(), head.reg_std_fc1.bias.data_ptr()
+        t.bn_s64 = _fc_bn(head.reg_std_bn1, small[0, 7:], small[1, 7:])
+        t.w_fc2, t.b_fc2 = head.reg_std_fc2.weight.data_ptr(), head.reg_std_fc2.bias.data_ptr()
+        t.ori_cls, t.std_logit = dense[0].data_ptr(), dense[1].data_ptr()
+        t.rcnn_reg, t.rcnn_reg_std = reg[0].data_ptr(), reg[1].data_ptr()
+        t.scratch, t.barrier = scratch.data_ptr(), _fct_barrier(dev).data_ptr()
+        t.cooperative = 1 if FC_TOWER_COOPERATIVE else 0
+        _lib.call("glx_fc_tower_forward", ctypes.byref(t))
+        from .spconv import core
+        written = []
+        for bn in [b for _, b in pairs] + [head.reg_std_bn, head.reg_std_bn1]:
+            if bn.track_running_stats:
+                written += [bn.running_mean, bn.running_var]
+                if bn.num_batches_tracked is not None:
+                    if core.DEFERRED_COUNTERS is not None:
+                        core.DEFERRED_COUNTERS.append(bn.num_batches_tracked)
+                    else:
+                        bn.num_batches_tracked += 1
+        if written:
+            _lib.bump_weights_epoch(written)
+        ctx.head, ctx.drop_p = head, drop_p
+        ctx.keep = (x, w0, z0, u, zh, stats, small, reg, dense)
+        ctx.n_params = len(params)
+        return dense[0].view(R, 1), dense[1].view(R, 1), reg[0], reg[1]
+
+    @staticmethod
+    def backward(ctx, g_cls, g_logit, g_reg, g_std):
+        head, drop_p = ctx.head, ctx.drop_p
+        x, w0, z0, u, zh, stats, small, reg, dense = ctx.keep
+        pairs = head._glx_fct_pairs
+        R, dev = x.shape[0], x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        cont = lambda g_: None if g_ is None else g_.contiguous().float()
+        g_cls, g_logit, g_reg, g_std = cont(g_cls), cont(g_logit), cont(g_reg), cont(g_std)
+        scratch = _lib.workspace.get(_lib.query("glx_fc_tower_scratch_bytes", R), dev)
+        t = _lib.FcTower()
+        t.R, t.drop_p, t.drop_u, t.z0 = R, float(drop_p), _lib._p(u), z0.data_ptr()
+        for l, (lin, bn) in enumerate(pairs):
+            t.w[l] = lin.weight.data_ptr() if l else None
+            t.bn[l] = _fc_bn(bn, stats[2 * l], stats[2 * l + 1])
+            t.z[l] = zh[l - 1].data_ptr() if l else None
+            t.h[l] = zh[5 + l].data_ptr()
+        t.w_cls, t.b_cls = head.cls_pred_layer.weight.data_ptr(), head.cls_pred_layer.bias.data_ptr()
+        t.w_reg, t.b_reg = head.reg_pred_layer.weight.data_ptr(), head.reg_pred_layer.bias.data_ptr()
+        t.w_std, t.b_std = head.reg_std_layer.weight.data_ptr(), head.reg_std_layer.bias.data_ptr()
+        t.bn_s7 = _fc_bn(head.reg_std_bn, small[0, :7], small[1, :7])
+        t.w_fc1, t.b_fc1 = head.reg_std_fc1.weight.data_ptr(), head.reg_std_fc1.bias.data_ptr()
+        t.bn_s64 = _fc_bn(head.reg_std_bn1, small[0, 7:], small[1, 7:])
+        t.w_fc2, t.b_fc2 = head.reg_std_fc2.weight.data_ptr(), head.reg_std_fc2.bias.data_ptr()
+        t.ori_cls, t.std_logit = dense[0].data_ptr(), dense[1].data_ptr()
+        t.rcnn_reg, t.rcnn_reg_std = reg[0].data_ptr(), reg[1].data_ptr()
+        t.scratch, t.barrier = scratch.data_ptr(), _fct_barrier(dev).data_ptr()
+        t.cooperative = 1 if FC_TOWER_COOPERATIVE else 0
+        dz = torch.empty((6, R, 256), **f32)
+        dgb = torch.empty((12, 256), **f32)
+        dw_cls, db_cls = torch.empty((1, 256), **f32), torch.empty(1, **f32)
+        dw_rs, db_rs = torch.empty((2, 7, 256), **f32), torch.empty((2, 7), **f32)
+        d7, d64 = torch.empty((2, 7), **f32), torch.empty((2, 64), **f32)
+        dw_fc1, db_fc1 = torch.empty((64, 7), **f32), torch.empty(64, **f32)
+        dw_fc2, db_fc2 = torch.empty((1, 64), **f32), torch.empty(1, **f32)
+        g = _lib.FcTowerGrads()
+        g.g_cls, g.g_logit, g.g_reg, g.g_std = _lib._p(g_cls), _lib._p(g_logit), _lib._p(g_reg), _lib._p(g_std)
+        for l in range(6):
+            g.dz[l], g.dgamma[l], g.dbeta[l] = dz[l].data_ptr(), dgb[2 * l].data_ptr(), dgb[2 * l + 1].data_ptr()
+        g.dw_cls, g.db_cls = dw_cls.data_ptr(), db_cls.data_ptr()
+        g.dw_reg, g.db_reg, g.dw_std, g.db_std = dw_rs[0].data_ptr(), db_rs[0].data_ptr(), dw_rs[1].data_ptr(), db_rs[1].data_ptr()
+        g.dgamma7, g.dbeta7, g.dgamma64, g.dbeta64 = d7[0].data_ptr(), d7[1].data_ptr(), d64[0].data_ptr(), d64[1].data_ptr()
+        g.dw_fc1, g.db_fc1, g.dw_fc2, g.db_fc2 = dw_fc1.data_ptr(), db_fc1.data_ptr(), dw_fc2.data_ptr(), db_fc2.data_ptr()
+        g.scratch = scratch.data_ptr()
+        _lib.call("glx_fc_tower_backward", ctypes.byref(t), ctypes.byref(g))
+        gx = dz[0] @ w0 if ctx.needs_input_grad[2] else None
+        # the Linear weight gradients: leaves, deferred when a staged step collects them
+        ins = [x] + [zh[5 + l] for l in range(5)]              # layer l's input: pooled, h0, h1, h2, h1, h4
+        ins[4] = zh[5 + 1]
+        wgrads = []
+        for l in range(6):
+            w = w0 if l == 0 else pairs[l][0].weight
+            if DEFERRED_FC_WGRADS is not None and w.is_leaf:
+                DEFERRED_FC_WGRADS.append((ins[l], dz[l], w, _deferred_event(dev), _SplitKLinearFn.weight_grad))
+                wgrads.append(None)
+            else:
+                wgrads.append(_SplitKLinearFn.weight_grad(ins[l], dz[l], w))
+        grads = [None, None, gx, wgrads[0]]
+        for l in range(6):
+            if l:
+                grads.append(wgrads[l])
+            grads += [dgb[2 * l], dgb[2 * l + 1]]
+        grads += [dw_cls, db_cls, dw_rs[0], db_rs[0], dw_rs[1], db_rs[1], d7[0], d7[1], dw_fc1, db_fc1, d64[0], d64[1], dw_fc2, db_fc2]
+        assert len(grads) == 4 + ctx.n_params, (len(grads), ctx.n_params)
+        return tuple(grads)
+
+
+class _NoCtx:
+    def save_for_backward(self, *a):
+        pass
+
+
+def fc_towers(head, x):
+    """heads() of a VoxelRCNNKLHead-shaped module on the fused kernels (fc_tower_usable says when)."""
+    pairs = head._glx_fct_pairs
+    drops = [m for m in head.shared_fc_layer if isinstance(m, nn.Dropout)]
+    drop_p = float(drops[0].p) if drops else 0.0
+    params = [pairs[0][1].weight, pairs[0][1].bias]
+    for lin, bn in pairs[1:]:
+        params += [lin.weight, bn.weight, bn.bias]
+    params += [head.cls_pred_layer.weight, head.cls_pred_layer.bias, head.reg_pred_layer.weight, head.reg_pred_layer.bias,
+               head.reg_std_layer.weight, head.reg_std_layer.bias, head.reg_std_bn.weight, head.reg_std_bn.bias,
+               head.reg_std_fc1.weight, head.reg_std_fc1.bias, head.reg_std_bn1.weight, head.reg_std_bn1.bias,
+               head.reg_std_fc2.weight, head.reg_std_fc2.bias]
+    return FCTowersFn.apply(head, drop_p, x.contiguous(), pairs[0][0].weight, *params)
 
 
 def _fc_tower(cin, widths, dp_ratio):

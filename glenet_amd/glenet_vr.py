@@ -106,6 +106,12 @@ class VoxelRCNNKLHead(rg.RoIGridPool):
             for w, b in reg_w:
                 reg_feat = dp.RoIFCStack._affine_relu(reg_feat, w, b)
             ori_cls = self.cls_pred_layer(c)
+        elif dp.fc_tower_usable(self, x):
+            # training: the towers behind the first Linear as one launch per direction (csrc/glx_fctower.hip)
+            ori_cls, std_logit, rcnn_reg, rcnn_reg_std = dp.fc_towers(self, x)
+            if raw:
+                return ori_cls, std_logit, rcnn_reg, rcnn_reg_std
+            return losses.cls_rescale_torch(ori_cls, std_logit), rcnn_reg, rcnn_reg_std
         else:
             shared = self.shared_fc_layer(x)
             ori_cls = self.cls_pred_layer(self.cls_fc_layers(shared))
@@ -136,6 +142,7 @@ class VoxelRCNNKLHead(rg.RoIGridPool):
 OVERLAP_ROI = os.environ.get("GLX_OVERLAP_ROI", "1") != "0"
 STAGE_CUTS = os.environ.get("GLX_STAGE_CUTS", "1") != "0"
 DEFER_FC_WGRADS = os.environ.get("GLX_DEFER_FC_WGRADS", "1") != "0"
+FC_WGRADS_BEHIND_ROI = os.environ.get("GLX_FC_WGRADS_BEHIND_ROI", "1") != "0"      # see StagedLoss.backward
 # First MLP of the three pooling scales on the RoI stream BESIDE the BEV forward (it needs the sparse backbone's output only).
 # Measured in round 4, alternating runs on one box: 7.22 / 7.23 ms per step with it against 7.03 / 7.02 without -- the nine
 # short launches compete with the BEV convolutions that produce the proposals' inputs, and the RoI branch starts later than
@@ -187,15 +194,22 @@ class StagedLoss:
             core.WGRAD_STREAM = None
         try:
             fc_jobs = dp.DEFERRED_FC_WGRADS = [] if DEFER_FC_WGRADS else None
+            dp.DEFERRED_FC_SAME_STREAM = FC_WGRADS_BEHIND_ROI
             with torch.cuda.stream(self.roi_stream):      # A: caller stream = RoI stream, nothing of the main stream
                 try:
                     torch.autograd.backward(self.roi)     # is waited for; ends at the detached leaves
                 finally:
                     dp.DEFERRED_FC_WGRADS = None
+                    dp.DEFERRED_FC_SAME_STREAM = False
                 if self.mark:
                     self.mark("backward: RoI head (RoI stream)")
+                if fc_jobs and FC_WGRADS_BEHIND_ROI:
+                    # the FC towers' weight gradients behind the x_conv gradients on the RoI stream: with the fused towers
+                    # (csrc/glx_fctower.hip) the RoI branch ends ~0.25 ms before the main stream asks for its last gradient
+                    dp.run_deferred_fc_wgrads(fc_jobs)
+                    fc_jobs = None
             torch.autograd.backward(self.rpn)             # B: ends at the BEV input's detached leaf
-            if fc_jobs:      # the FC towers' weight gradients: in the main stream's wait for the RoI gradients
+            if fc_jobs:      # ... or in the main stream's wait for the RoI gradients (what paid while the RoI branch was longer)
                 dp.run_deferred_fc_wgrads(fc_jobs)
             # C: the sparse backbone, level by level: the levels above a stage cut run as soon as THEIR RoI gradients are
             # there (x_conv4's leave the RoI branch first, x_conv2's last)

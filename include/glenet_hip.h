@@ -1041,6 +1041,60 @@ int glx_conv3x3_set_grid(int blocks, int ablate);
  * 100 MHz ticks (s_memrealtime) of its lifetime to stamps[2 * block ..] (NULL: off): their ratio is the clock the chip holds. */
 int glx_conv3x3_set_stamps(void* stamps);
 
+/* The RoI head's FC towers behind the first Linear, training mode, one launch per direction
+ * (pcdet/models/roi_heads/voxelrcnn_kl_label_iou_head.py:38-92: shared_fc_layer[second Linear on] -> cls_fc_layers ->
+ * cls_pred_layer and reg_fc_layers -> reg_pred_layer / reg_std_layer -> reg_std_bn -> reg_std_fc1 -> reg_std_bn1 ->
+ * reg_std_fc2; the towers are voxelrcnn_head.py:40-66: Linear(bias=False) + BatchNorm1d + ReLU (+ Dropout behind the first
+ * layer of a tower)).  Layers are numbered 0 (the 20 736 -> 256 Linear, computed by the caller: z0), 1 (second shared
+ * layer), 2-3 (cls tower), 4-5 (reg tower); all are 256 wide.  Every BatchNorm runs on batch statistics over the R rows
+ * (biased variance to normalise, running statistics updated with the unbiased one and `momentum`), dropout keeps an element
+ * of layers 0 / 2 / 4 when its uniform draw is >= drop_p and scales it by 1 / (1 - drop_p) (nn.Dropout's arithmetic on
+ * caller-supplied draws).  All tensors fp32, row-major, contiguous. */
+typedef struct glx_fc_bn {
+  const float* gamma; const float* beta;       /* (C) */
+  float* running_mean; float* running_var;     /* (C), or both NULL */
+  float* save_mean; float* save_invstd;        /* (C): written by the forward, read by the backward */
+  float eps, momentum;
+} glx_fc_bn;
+
+typedef struct glx_fc_tower {
+  int R;                                       /* rows (RoIs): a multiple of 16 in 16..1024 */
+  float drop_p;                                /* dropout probability, 0 = none (then drop_u is NULL) */
+  const float* drop_u;                         /* (3, R, 256) uniform draws for layers 0, 2, 4 */
+  const float* z0;                             /* (R, 256) = pooled features x W0^T */
+  const float* w[6];                           /* w[1..5] (256 out, 256 in); w[0] unused */
+  glx_fc_bn bn[6];
+  float* z[6];                                 /* z[1..5] (R, 256): Linear outputs, written by the forward; z[0] unused */
+  float* h[6];                                 /* h[0..5] (R, 256): layer outputs, written by the forward */
+  const float* w_cls; const float* b_cls;      /* cls_pred_layer (1, 256), (1) */
+  const float* w_reg; const float* b_reg;      /* reg_pred_layer (7, 256), (7) */
+  const float* w_std; const float* b_std;      /* reg_std_layer (7, 256), (7) */
+  glx_fc_bn bn_s7;                             /* reg_std_bn (7) */
+  const float* w_fc1; const float* b_fc1;      /* reg_std_fc1 (64, 7), (64) */
+  glx_fc_bn bn_s64;                            /* reg_std_bn1 (64) */
+  const float* w_fc2; const float* b_fc2;      /* reg_std_fc2 (1, 64), (1) */
+  float* ori_cls; float* rcnn_reg; float* rcnn_reg_std; float* std_logit;   /* (R), (R, 7), (R, 7), (R): forward outputs */
+  float* scratch;                              /* glx_fc_tower_scratch_bytes(R) */
+  unsigned* barrier;                           /* 128 bytes, zero before the first launch; every launch leaves them zero */
+  int cooperative;                             /* 1: ONE launch of 32 co-resident blocks with grid barriers; 0: a launch per phase */
+} glx_fc_tower;
+
+typedef struct glx_fc_tower_grads {
+  const float* g_cls; const float* g_logit; const float* g_reg; const float* g_std;   /* dL/d(ori_cls, std_logit, rcnn_reg,
+                                                                                         rcnn_reg_std); NULL = zero */
+  float* dz[6];                                /* (R, 256): dL/d(Linear output of layer l); dz[0] = dL/dz0 */
+  float* dgamma[6]; float* dbeta[6];           /* (256) */
+  float* dw_cls; float* db_cls; float* dw_reg; float* db_reg; float* dw_std; float* db_std;
+  float* dgamma7; float* dbeta7; float* dw_fc1; float* db_fc1; float* dgamma64; float* dbeta64; float* dw_fc2; float* db_fc2;
+  float* scratch;                              /* glx_fc_tower_scratch_bytes(R) */
+} glx_fc_tower_grads;
+
+size_t glx_fc_tower_scratch_bytes(int R);
+int glx_fc_tower_forward(const glx_fc_tower* t, void* stream);
+/* `t` as the forward left it (z, h, save_mean / save_invstd, rcnn_reg_std, drop_u).  The Linear weight gradients
+ * dW_l = dz[l]^T h[l-1] (dW_0 = dz[0]^T pooled) and the pooled features' gradient dz[0] W0 are GEMMs left to the caller. */
+int glx_fc_tower_backward(const glx_fc_tower* t, const glx_fc_tower_grads* g, void* stream);
+
 /* Tail of the proposal layer (pcdet/models/roi_heads/roi_head_template.py:63-126: selected = keep[:NMS_POST_MAXSIZE],
  * rois / roi_scores / roi_labels rows, zero rows behind the survivors) in one launch.  cand (F, K, C) top-k candidates,
  * top (F, K) their scores, lab (F, A) class index per anchor, order (F, K) anchor index of every candidate,

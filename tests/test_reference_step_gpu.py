@@ -117,12 +117,16 @@ def _first_stage(model, cfg, dev, train):
 
 def _pin_dropout(model, dev):
     """The three nn.Dropout modules of the RoI towers multiply by the masks the reference's run drew."""
+    draws = {}
     for name, m in model.roi_head.named_modules():
         if isinstance(m, torch.nn.Dropout):
             key = "train_dropout_" + name.replace(".", "_")
             bits = np.unpackbits(G[key])[:256 * 256].reshape(256, 256).astype(np.float32)
             mask = torch.from_numpy(bits).to(dev) / (1.0 - m.p)
             m.forward = (lambda mask, m: lambda x: x * mask if m.training else x)(mask, m)
+            draws[name.split(".")[0]] = torch.from_numpy(bits).to(dev)          # kept <=> draw 1.0 >= p
+    # the fused towers (csrc/glx_fctower.hip) take uniform draws instead of going through the nn.Dropout modules
+    model.roi_head.fixed_dropout_draws = torch.stack([draws[k] for k in ("shared_fc_layer", "cls_fc_layers", "reg_fc_layers")])
 
 
 def test_training_step_equals_the_references_own_classes(dev, net):
