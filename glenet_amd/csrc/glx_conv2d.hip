@@ -19,6 +19,7 @@
 // contiguous; slices go L2 -> registers -> LDS one tap ahead (two buffers, one barrier per tap).  The input gradient
 // is the same kernel on the flipped, transposed pack (written by the same pack launch).
 #include "glx_common.h"
+#include <stdlib.h>
 #include "glx_bn_state.h"
 #include "glx_bf16x3.h"
 
@@ -848,8 +849,21 @@ extern "C" int glx_conv3x3_wgrad_ex(const float* x, const float* gy, int B, int 
   else
     hipLaunchKernelGGL(k_conv3x3_wgrad<false>, dim3(blocks), dim3(256), WG_LDS, (hipStream_t)stream, a);
   GLX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_conv3x3_wgrad_reduce, dim3(WG_PART / 64, a.nq), dim3(256), 0, (hipStream_t)stream, a.ws, a.P,
-                     a.nq_ci, dW, s_co, s_ci, s_kh, s_kw);
+  if (!dW) return GLX_OK;                            // the blocks' partial sums only: glx_conv3x3_wgrad_reduce finishes later
+  return glx_conv3x3_wgrad_reduce(Cin, Cout, dW, s_co, s_ci, s_kh, s_kw, workspace, workspace_bytes, stream);
+}
+
+extern "C" int glx_conv3x3_wgrad_reduce(int Cin, int Cout, float* dW, long long s_co, long long s_ci, long long s_kh,
+                                        long long s_kw, const void* workspace, size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(dW && workspace, "glx_conv3x3_wgrad_reduce: null pointer");
+  GLX_REQUIRE(Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % CV_BN == 0,
+              "glx_conv3x3_wgrad_reduce: needs Cin %% 32 == 0 and Cout %% 64 == 0 (got %d -> %d)", Cin, Cout);
+  GLX_REQUIRE(workspace_bytes >= glx_conv3x3_wgrad_workspace_bytes(Cin, Cout), "glx_conv3x3_wgrad_reduce: workspace too small");
+  int P = 0;
+  wgrad_blocks(Cin, Cout, &P);
+  const int nq_ci = Cin / 32, nq = nq_ci * (Cout / CV_BN);
+  hipLaunchKernelGGL(k_conv3x3_wgrad_reduce, dim3(WG_PART / 64, nq), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, P,
+                     nq_ci, dW, s_co, s_ci, s_kh, s_kw);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

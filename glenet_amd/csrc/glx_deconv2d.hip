@@ -13,6 +13,7 @@
 // slices stream L2 -> registers -> LDS as in k_conv3x3.  k_pconv_wgrad runs the third like k_conv3x3_wgrad: gy (one
 // alignment per tap) straight into registers, the x tile through the transposing LDS read, block partials + a reduce.
 #include "glx_common.h"
+#include <stdlib.h>
 #include "glx_bf16x3.h"
 #include "glx_bn_state.h"
 

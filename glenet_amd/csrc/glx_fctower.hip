@@ -144,6 +144,38 @@ __device__ __forceinline__ ft4 fct_tile(const float* __restrict__ X, int tile, c
   return acc;
 }
 
+// The same with the first half of the NEXT tile of this wave (tile + 8) loaded behind the first half's multiplies: xa holds
+// the first half of `tile` on entry (fct_tile_prime for the wave's first tile) and of tile + 8 on return.
+__device__ __forceinline__ void fct_tile_prime(const float* __restrict__ X, int tile, int ntiles, ft4 (&xa)[8]) {
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const float* xp = X + (tile < ntiles ? tile : ntiles - 1) * (16 * FCT_W) + r * FCT_W + 4 * q;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) xa[s] = *reinterpret_cast<const ft4*>(xp + 16 * s);
+}
+
+__device__ __forceinline__ ft4 fct_tile_pf(const float* __restrict__ X, int tile, int ntiles, const float* s_w, ft4 (&xa)[8], ft4 acc) {
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const float* xp = X + tile * (16 * FCT_W) + r * FCT_W + 4 * q;
+  const float* wl = s_w + r * FCT_WLD + 4 * q;
+  ft4 xb[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) xb[s] = *reinterpret_cast<const ft4*>(xp + 128 + 16 * s);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const ft4 wv = *reinterpret_cast<const ft4*>(wl + 16 * s);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e], xa[s][e], acc, 0, 0, 0);
+  }
+  fct_tile_prime(X, tile + FCT_WAVES, ntiles, xa);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const ft4 wv = *reinterpret_cast<const ft4*>(wl + 128 + 16 * s);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e], xb[s][e], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
 // Training-mode BatchNorm1d + ReLU (+ dropout) of a slab whose Linear output produce(tile) delivers tile by tile: pass 1
 // stores z and sums it, passes 2 and 3 read the block's own z back (L2) for the centred second moment and the transform.
 // zbuf: where z lives afterwards (produce's values are stored there unless `stored` says they already are).
@@ -266,11 +298,18 @@ __device__ __forceinline__ ft4 fct_outer(const float* A, int lda, int acol0, int
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
   ft4 acc = ft4{0.f, 0.f, 0.f, 0.f};
   const int steps = R >> 2;
-  for (int ks = wave; ks < steps; ks += FCT_WAVES) {
-    const int row = 4 * ks + q;
-    const float av = r < avalid ? A[(size_t)row * lda + acol0 + r] : 0.f;
-    const float bv = r < bvalid ? B[(size_t)row * ldb + bcol0 + r] : 0.f;
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+  // 8 k-steps (this wave's rows 4 ks + q) per batch: their 16 loads are in flight together
+  for (int k0 = wave; k0 < steps; k0 += 8 * FCT_WAVES) {
+    float av[8], bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int ks = k0 + u * FCT_WAVES;
+      const int row = ks < steps ? 4 * ks + q : 0;
+      av[u] = (r < avalid && ks < steps) ? A[(size_t)row * lda + acol0 + (r < avalid ? r : 0)] : 0.f;
+      bv[u] = (r < bvalid && ks < steps) ? B[(size_t)row * ldb + bcol0 + (r < bvalid ? r : 0)] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
   }
   __syncthreads();                                   // s_part may still be read from an earlier call
   *reinterpret_cast<ft4*>(s_part + wave * 256 + lane * 4) = acc;
@@ -343,8 +382,10 @@ __device__ __forceinline__ void fct_fwd_layer(const glx_fc_tower& p, FctSmem& sm
   const float* du = (DROP >= 0 && p.drop_u) ? p.drop_u + (size_t)DROP * p.R * FCT_W : nullptr;
   const ft4 zero4 = ft4{0.f, 0.f, 0.f, 0.f};
   fct_stage_w<0>(p.w[L], nullptr, cb, sm.w);
-  fct_bn_fwd([&](int tile) { return fct_tile(X, tile, sm.w, zero4); }, false, p.R, cb, p.bn[L], du, p.drop_p, p.z[L], p.h[L], sm.red,
-             flip);
+  ft4 xa[8];
+  fct_tile_prime(X, threadIdx.x >> 6, p.R >> 4, xa);
+  fct_bn_fwd([&](int tile) { return fct_tile_pf(X, tile, p.R >> 4, sm.w, xa, zero4); }, false, p.R, cb, p.bn[L], du, p.drop_p, p.z[L],
+             p.h[L], sm.red, flip);
 }
 
 // backward through layer L's Linear into layer L - 1... : dL/dh[LB] = dz[L] W_L (+ dz[L2] W_L2), then BatchNorm / ReLU / dropout
@@ -358,11 +399,14 @@ __device__ __forceinline__ void fct_bwd_layer(const glx_fc_tower& p, const glx_f
   const ft4 zero4 = ft4{0.f, 0.f, 0.f, 0.f};
   fct_stage_w<1>(p.w[L], nullptr, cb, sm.w);
   if constexpr (L2 >= 0) fct_stage_w<1>(p.w[L2 >= 0 ? L2 : 0], nullptr, cb, sm.w2);
+  ft4 xa[8], xa2[L2 >= 0 ? 8 : 1];
+  fct_tile_prime(Xa, threadIdx.x >> 6, p.R >> 4, xa);
+  if constexpr (L2 >= 0) fct_tile_prime(Xb, threadIdx.x >> 6, p.R >> 4, xa2);
   fct_bn_bwd([&](int tile) {
-    ft4 a4 = fct_tile(Xa, tile, sm.w, zero4);
+    ft4 a4 = fct_tile_pf(Xa, tile, p.R >> 4, sm.w, xa, zero4);
     if constexpr (L2 >= 0) {
-      __builtin_amdgcn_sched_barrier(0);             // the second product's 16 loads stay behind the first's multiplies
-      a4 = fct_tile(Xb, tile, sm.w2, a4);
+      __builtin_amdgcn_sched_barrier(0);             // the second product's loads stay behind the first's multiplies
+      a4 = fct_tile_pf(Xb, tile, p.R >> 4, sm.w2, xa2, a4);
     }
     return a4;
   }, p.R, cb, p.bn[LB], z, du, p.drop_p, g.dz[LB], g.dgamma[LB], g.dbeta[LB], sm.red, flip);
@@ -490,6 +534,7 @@ __device__ __forceinline__ void fct_fwd_phase(const glx_fc_tower& p, FctSmem& sm
       // statistics of t: thread (part, j) over the rows part, part + 8, ...
       const int j = tid & 63, part = tid >> 6;
       float s = 0.f;
+#pragma unroll 8
       for (int row = part; row < R; row += FCT_WAVES) s += T[row * FCT_NH + j];
       sm.part[part * 64 + j] = s;
       __syncthreads();
@@ -499,6 +544,7 @@ __device__ __forceinline__ void fct_fwd_phase(const glx_fc_tower& p, FctSmem& sm
       mean64 *= invR;
       __syncthreads();
       s = 0.f;
+#pragma unroll 8
       for (int row = part; row < R; row += FCT_WAVES) { const float d = T[row * FCT_NH + j] - mean64; s += d * d; }
       sm.part[part * 64 + j] = s;
       __syncthreads();
@@ -620,7 +666,7 @@ __device__ __forceinline__ void fct_bwd_phase(const glx_fc_tower& p, const glx_f
         const int j = tid & 63, part = tid >> 6;
         {
           float a = 0.f, b = 0.f, c = 0.f;
-#pragma unroll 2
+#pragma unroll 8
           for (int row = part; row < R; row += FCT_WAVES) {
             const float xh = (T[row * FCT_NH + j] - sm.m64[j]) * sm.is64[j];
             const float pre = xh * sm.g64[j] + sm.be64[j];
@@ -646,7 +692,7 @@ __device__ __forceinline__ void fct_bwd_phase(const glx_fc_tower& p, const glx_f
         __syncthreads();
         {
           float sdt = 0.f;
-#pragma unroll 2
+#pragma unroll 8
           for (int row = part; row < R; row += FCT_WAVES) {
             const float xh = (T[row * FCT_NH + j] - sm.m64[j]) * sm.is64[j];
             const float pre = xh * sm.g64[j] + sm.be64[j];

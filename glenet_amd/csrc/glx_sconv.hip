@@ -2699,7 +2699,7 @@ extern "C" size_t glx_sconv_wgrad_pairs_workspace_bytes(int N_out, int K, int Ci
 extern "C" int glx_sconv_wgrad_pairs(const float* in, const float* grad_out, const void* lists, int N_out, int K,
                                      int Cin, int Cout, float* dW, void* workspace, size_t workspace_bytes,
                                      void* stream) {
-  GLX_REQUIRE(dW && lists && workspace && (N_out == 0 || (in && grad_out)), "glx_sconv_wgrad_pairs: null pointer");
+  GLX_REQUIRE(lists && workspace && (N_out == 0 || (in && grad_out)), "glx_sconv_wgrad_pairs: null pointer");
   GLX_REQUIRE(K >= 1 && K <= SC_MAXK, "glx_sconv_wgrad_pairs: K=%d", K);
   const size_t need = glx_sconv_wgrad_pairs_workspace_bytes(N_out, K, Cin, Cout) - 256;
   if (workspace_bytes < need) {
@@ -2727,9 +2727,23 @@ extern "C" int glx_sconv_wgrad_pairs(const float* in, const float* grad_out, con
     return GLX_OK;
   });
   if (rc != GLX_OK) return rc;
+  GLX_LAUNCH_CHECK();
+  if (!dW) return GLX_OK;                            // the chunk products only: glx_sconv_wgrad_pairs_reduce finishes later
+  return glx_sconv_wgrad_pairs_reduce(lists, N_out, K, Cin, Cout, dW, workspace, workspace_bytes, stream);
+}
+
+extern "C" int glx_sconv_wgrad_pairs_reduce(const void* lists, int N_out, int K, int Cin, int Cout, float* dW,
+                                            const void* workspace, size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(dW && lists && workspace, "glx_sconv_wgrad_pairs_reduce: null pointer");
+  GLX_REQUIRE(K >= 1 && K <= SC_MAXK, "glx_sconv_wgrad_pairs_reduce: K=%d", K);
+  const size_t need = glx_sconv_wgrad_pairs_workspace_bytes(N_out, K, Cin, Cout) - 256;
+  if (workspace_bytes < need) {
+    glx_set_error("glx_sconv_wgrad_pairs_reduce: workspace %zu < %zu bytes", workspace_bytes, need);
+    return GLX_EWORKSPACE;
+  }
   const int nel = Cin * Cout;
-  hipLaunchKernelGGL(k_wgrad_pairs_reduce, dim3(glx_divup(nel, 256), K), dim3(256), 0, st, (const float*)workspace,
-                     (const PairMeta*)base, nel, dW);
+  hipLaunchKernelGGL(k_wgrad_pairs_reduce, dim3(glx_divup(nel, 256), K), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, (const PairMeta*)lists, nel, dW);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

@@ -446,11 +446,13 @@ class SparseConvFunction(Function):
     """features (N_in, Cin), weight (K, Cin, Cout), bias (Cout)|None -> (N_out, Cout)."""
 
     @staticmethod
-    def forward(ctx, features, weight, bias, rules, inverse, packed=None, side_ok=False, bn=None, in_link=None):
+    def forward(ctx, features, weight, bias, rules, inverse, packed=None, side_ok=False, bn=None, in_link=None, leaf=None):
         """bn: the training-mode BatchNorm1d behind the conv: its statistics ride in the kernel's epilogue and the
         call returns (out, coef, save_mean, save_invstd) for FusedBNApply (the last three non-differentiable).
         in_link: the link FusedBNApply left on `features` (see BN_BWD_IN_DGRAD)."""
         ctx.in_link = in_link if (in_link is not None and in_link.get("out") is not None and in_link["out"]() is features) else None
+        # leaf: the parameter `weight` is a plain view of (None: it is not) -- what a deferred weight-gradient sum writes to
+        ctx.leaf = leaf if (leaf is not None and leaf.is_leaf and leaf.requires_grad and leaf.numel() == weight.numel()) else None
         features = features.contiguous().float()
         w = weight.contiguous()
         _lib.check_cuda(features, w)
@@ -501,14 +503,32 @@ class SparseConvFunction(Function):
                 for t in (features, grad_out, fwd_nbr):
                     t.record_stream(side)
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-                g_w = torch.empty_like(w)
-                if USE_PAIR_LISTS and n_fwd_out > 0 and query("glx_sconv_packed_bytes", K, cin, cout):
+                pairs = USE_PAIR_LISTS and n_fwd_out > 0 and query("glx_sconv_packed_bytes", K, cin, cout)
+                if pairs and _lib.DEFERRED_REDUCES is not None and ctx.leaf is not None:
+                    # the chunk products now (a workspace of this layer's own), their sum later on another stream: no
+                    # gradient returned, the job stores the parameter's .grad (_lib.run_deferred_reduces)
+                    pl = rules.pair_lists(fwd_nbr, n_fwd_out, live_fwd)
+                    wsb = query("glx_sconv_wgrad_pairs_workspace_bytes", n_fwd_out, K, cin, cout)
+                    ws = torch.empty(wsb, dtype=torch.uint8, device=w.device)
+                    call("glx_sconv_wgrad_pairs", features, grad_out, pl, n_fwd_out, K, cin, cout, None, ws, size_arg(wsb))
+
+                    def run(stream, ws=ws, pl=pl, leaf=ctx.leaf, dims=(n_fwd_out, K, cin, cout), wsb=wsb):
+                        ws.record_stream(stream)
+                        pl.record_stream(stream)
+                        gw = torch.empty(dims[1:], dtype=torch.float32, device=ws.device)
+                        call("glx_sconv_wgrad_pairs_reduce", pl, dims[0], dims[1], dims[2], dims[3], gw, ws, size_arg(wsb))
+                        gw = gw.view_as(leaf)
+                        leaf.grad = gw if leaf.grad is None else leaf.grad + gw
+                    _lib.defer_reduce(w.device, run)
+                elif pairs:
+                    g_w = torch.empty_like(w)
                     pl = rules.pair_lists(fwd_nbr, n_fwd_out, live_fwd)
                     wsb = query("glx_sconv_wgrad_pairs_workspace_bytes", n_fwd_out, K, cin, cout)
                     ws = workspace.get(wsb, w.device)
                     call("glx_sconv_wgrad_pairs", features, grad_out, pl, n_fwd_out, K, cin, cout, g_w, ws,
                          size_arg(ws.numel()))
                 else:
+                    g_w = torch.empty_like(w)
                     wsb = query("glx_sconv_wgrad_workspace_bytes", n_fwd_out, K, cin, cout)
                     ws = workspace.get(wsb, w.device)
                     call("glx_sconv_wgrad", features, features.shape[0], grad_out, fwd_nbr, n_fwd_out, K,
@@ -538,7 +558,7 @@ class SparseConvFunction(Function):
             else:   # rows past the live count are undefined (possibly NaN): select, do not multiply
                 live = torch.arange(grad_out.shape[0], device=grad_out.device) < live_fwd
                 g_b = torch.where(live[:, None], grad_out, grad_out.new_zeros(())).sum(0)
-        return g_feat, g_w, g_b, None, None, None, None, None, None
+        return g_feat, g_w, g_b, None, None, None, None, None, None, None
 
 
 class SparseConvTensor:
@@ -774,7 +794,8 @@ class SparseConvolution(SparseModule):
             in_link = getattr(x, "_bn_link", None) if not pad else None
             if train_bn is not None:
                 feats, coef, mean, invstd = SparseConvFunction.apply(x_features, w, self.bias, rs, self.inverse,
-                                                                     self._packed_weight(w), not pad, train_bn, in_link)
+                                                                     self._packed_weight(w), not pad, train_bn, in_link,
+                                                                     None if pad else self.weight)
                 # relu only: the epilogue re-derives the ReLU mask; a BatchNorm without ReLU keeps the full backward
                 out_link = {} if (BN_BWD_IN_DGRAD and train_relu and train_bn.affine) else None
                 feats = FusedBNApply.apply(feats, coef, mean, invstd, train_bn.weight, train_bn.bias, train_relu,
@@ -787,7 +808,7 @@ class SparseConvolution(SparseModule):
             else:
                 out_link = None
                 feats = SparseConvFunction.apply(x_features, w, self.bias, rs, self.inverse,
-                                                 self._packed_weight(w), not pad, None, in_link)
+                                                 self._packed_weight(w), not pad, None, in_link, None if pad else self.weight)
         if self.inverse:
             out = SparseConvTensor(feats, rs.in_indices, rs.in_spatial_shape, x.batch_size,
                                    x.grid, x.voxel_num, x.indice_dict, x.benchmark, rs.count_in)

@@ -262,6 +262,11 @@ int glx_pair_lists_build(const int32_t* nbr, int N_out, int K, const int32_t* n_
 size_t glx_sconv_wgrad_pairs_workspace_bytes(int N_out, int K, int Cin, int Cout);
 int glx_sconv_wgrad_pairs(const float* in, const float* grad_out, const void* lists, int N_out, int K,
                           int Cin, int Cout, float* dW, void* workspace, size_t workspace_bytes, void* stream);
+/* The two launches apart: glx_sconv_wgrad_pairs with dW == NULL leaves the chunk products in `workspace` (which the caller
+ * then keeps), glx_sconv_wgrad_pairs_reduce sums them into dW -- a leaf of the backward pass that a training step can run
+ * later on another stream (the sum is a pass over memory, the products fill the matrix pipe: they overlap). */
+int glx_sconv_wgrad_pairs_reduce(const void* lists, int N_out, int K, int Cin, int Cout, float* dW, const void* workspace,
+                                 size_t workspace_bytes, void* stream);
 
 /* SparseConvTensor.dense(): out (B, C, D, H, W) must be zero-filled by the caller.
  * Replaces: spconv dense() (height_compression.py:21). */
@@ -997,6 +1002,10 @@ int glx_conv3x3_wgrad(const float* x, const float* gy, int B, int H, int W, int 
 int glx_conv3x3_wgrad_ex(const float* x, const float* gy, int B, int H, int W, int Cin, int Cout, float* dW,
                          long long s_co, long long s_ci, long long s_kh, long long s_kw, const glx_epilogue* pre,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* The two launches apart (as glx_sconv_wgrad_pairs_reduce): glx_conv3x3_wgrad_ex with dW == NULL leaves the blocks' partial
+ * sums in `workspace`, glx_conv3x3_wgrad_reduce adds them into dW (strides as above). */
+int glx_conv3x3_wgrad_reduce(int Cin, int Cout, float* dW, long long s_co, long long s_ci, long long s_kh, long long s_kw,
+                             const void* workspace, size_t workspace_bytes, void* stream);
 /* ---- transposed convolutions with kernel = stride = u in {1, 2}, no padding (BaseBEVBackbone's deblocks,
  * base_bev_backbone.py:51-66: ConvTranspose2d(c, cu, u, stride=u, bias=False)), channels-last fp32 maps, same split-bf16
  * arithmetic (csrc/glx_deconv2d.hip).  W (Cin, Cout, u, u) with ELEMENT strides (s_ci, s_co, s_kh, s_kw); channel counts
