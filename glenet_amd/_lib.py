@@ -125,7 +125,7 @@ class BnBwdStats(ctypes.Structure):
 
 class SconvOpts(ctypes.Structure):
     _fields_ = [("tile_map", c_void_p), ("bn", ctypes.POINTER(BnStats)), ("profile_start", c_void_p),
-                ("profile_stop", c_void_p), ("bn_bwd", ctypes.POINTER(BnBwdStats))]
+                ("profile_stop", c_void_p), ("bn_bwd", ctypes.POINTER(BnBwdStats)), ("prologue", ctypes.POINTER(Epilogue))]
 
 
 class ConvOpts(ctypes.Structure):

@@ -76,6 +76,7 @@ class SparseBackbone8x(nn.Module):
         self.sparse_shape = [gz + 1, gy, gx]                       # spconv_backbone.py:75
         self.residual = residual
         self.conv_input = _conv_bn_relu(input_channels, cfg["stem"], 3, "subm1", padding=1)
+        self.conv_input.leave_pending = True       # its only reader is conv1's first convolution (spconv.core.BN_ON_LOAD)
 
         def body(c, key):
             if residual:

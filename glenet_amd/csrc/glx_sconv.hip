@@ -73,6 +73,10 @@ struct SconvEpilogue {
   const float* bwd_coef;   // scale[COUT], shift[COUT]
   const float* bwd_mean;
   const float* bwd_invstd;
+  // pre_scale != NULL (glx_sconv_opts.prologue): the INPUT rows are transformed on load, x' = max(x * scale[c] + shift[c], 0)
+  // -- the training-mode BatchNorm + ReLU of the layer in front applied without writing the normalised features
+  const float* pre_scale;
+  const float* pre_shift;
 };
 
 // The common epilogue: coalesced row stores with the fused pointwise tail, + the BatchNorm statistics above.
@@ -258,7 +262,7 @@ struct SconvTile {
   static constexpr int ACC_LD = COUT + 4;
   static constexpr int LW = (TR + 63) / 64;                     // waves that own row slots
   static constexpr size_t lds_bytes = (size_t)TR * ACC_LD * 4 + (size_t)SC_MAXK * TR * 5 +
-                                      (TR + 32 + 32 * LW) * 4 + 64 + (size_t)NBUF * IMGW * 4;
+                                      (TR + 32 + 32 * LW) * 4 + 64 + (size_t)NBUF * IMGW * 4 + (size_t)CIN * 8;
   static_assert(LW <= NW, "row-slot waves exceed block");
   static_assert(TR <= 256, "row slots are stored as bytes");
   static_assert(NW % WPG == 0 && C::NT % WPG == 0 && (G & (G - 1)) == 0, "bad column split");
@@ -301,7 +305,8 @@ __device__ __forceinline__ void sc_compute(const float* s_w, float* s_acc,
                                            const unsigned char* s_pslot, int k, int cnt, int grp,
                                            int tile0, int r, int q, int rot,
                                            const float (&A)[T::MAXC][SconvCfg<CIN, COUT>::CQ],
-                                           const bool (&valid)[T::MAXC], long long* tsub = nullptr) {
+                                           const bool (&valid)[T::MAXC], const float* pre = nullptr,
+                                           long long* tsub = nullptr) {
   using C = SconvCfg<CIN, COUT>;
   using S = SconvSplitCfg<CIN, COUT>;
 #pragma unroll
@@ -315,8 +320,14 @@ __device__ __forceinline__ void sc_compute(const float* s_w, float* s_acc,
       u1 = clock64();
     }
     float Am[C::CQ];
+    if (pre) {                 // wave-uniform: the input transform of the prologue on the lane's channels q * CQ + i
 #pragma unroll
-    for (int i = 0; i < C::CQ; ++i) Am[i] = valid[j] ? A[j][i] : 0.f;
+      for (int i = 0; i < C::CQ; ++i)
+        Am[i] = valid[j] ? fmaxf(bn_affine(A[j][i], pre[q * C::CQ + i], pre[CIN + q * C::CQ + i]), 0.f) : 0.f;
+    } else {
+#pragma unroll
+      for (int i = 0; i < C::CQ; ++i) Am[i] = valid[j] ? A[j][i] : 0.f;
+    }
     if constexpr (T::WPG > 1) {
       // column split: this wave owns tiles tile0 .. tile0+TPW-1 of the chunk; one dependent
       // accumulator chain per tile (SrcC forwarding keeps a chain at the full MFMA rate)
@@ -436,10 +447,15 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
   int* s_cnt = s_rows + TR;                                   // 32
   int* s_wcnt = s_cnt + 32;                                   // LW * 32
   unsigned char* s_pslot = reinterpret_cast<unsigned char*>(s_wcnt + LW * 32);  // SC_MAXK * TR
+  float* s_pre = reinterpret_cast<float*>(s_pslot + SC_MAXK * TR + 64);         // 2 * CIN: scale | shift of the prologue
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
+  if (ep.pre_scale) {          // visible to everybody behind the compaction's barrier
+    for (int e = tid; e < CIN; e += SC_THREADS) { s_pre[e] = ep.pre_scale[e]; s_pre[CIN + e] = ep.pre_shift[e]; }
+  }
+  const float* pre = ep.pre_scale ? s_pre : nullptr;
   // XCD-aware tile mapping: workgroups are dealt round-robin to the 8 XCDs (block b runs on XCD
   // b mod 8), each with a private L2.  Rows are in cell order, so a CONTIGUOUS range of tiles
   // per XCD keeps the neighbour rows that adjacent tiles share in one L2 instead of eight.
@@ -590,7 +606,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
     sc_gather<CIN, COUT, T>(in, s_pin, kn_, cntn_, grp, r, q, rot, NXT, VNXT);                   \
     if constexpr (TRACE) c1_ = clock64();                                                   \
     sc_compute<CIN, COUT, T, TRACE>(s_w + (NBUF == 2 ? buf : 0) * IMGW, s_acc, s_pslot, k,   \
-                                    cnt, grp, tile0, r, q, rot, CUR, VCUR, tsub);            \
+                                    cnt, grp, tile0, r, q, rot, CUR, VCUR, pre, tsub);       \
     if constexpr (TRACE) c2_ = clock64();                                                   \
     if (NBUF == 1) __syncthreads();                                                         \
     if constexpr (TRACE) c3_ = clock64();                                                   \
@@ -667,7 +683,7 @@ struct SconvGemm {
   static constexpr int LW = (TR + 63) / 64;
   static constexpr size_t lds_bytes = (size_t)TR * ACC_LD * 4 + (size_t)S::IMG * 4 +
                                       (size_t)AP * A_LD * 4 + (size_t)SC_MAXK * TR * 5 +
-                                      (TR + 32 + 32 * LW) * 4 + 64;
+                                      (TR + 32 + 32 * LW) * 4 + 64 + (size_t)CIN * 8;
   static_assert(NW % WPG == 0 && NT % WPG == 0, "bad column split");
   static_assert(LW <= NW && TR <= 256, "bad tile");
 };
@@ -690,10 +706,15 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
   int* s_cnt = s_rows + TR;                                   // 32
   int* s_wcnt = s_cnt + 32;                                   // LW * 32
   unsigned char* s_pslot = reinterpret_cast<unsigned char*>(s_wcnt + LW * 32);  // SC_MAXK * TR
+  float* s_pre = reinterpret_cast<float*>(s_pslot + SC_MAXK * TR + 64);         // 2 * CIN: scale | shift of the prologue
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
+  const bool pre = ep.pre_scale != nullptr;
+  if (pre) {                   // visible to everybody behind the compaction's barrier
+    for (int e = tid; e < CIN; e += THREADS) { s_pre[e] = ep.pre_scale[e]; s_pre[CIN + e] = ep.pre_shift[e]; }
+  }
   const int row0 = ((TR == 64 && ep.tile_map) ? ep.tile_map[blockIdx.x]
                                               : sc_xcd_tile(blockIdx.x, gridDim.x, ep.xcd_group & 0xFF)) * TR;
   const int grp = wave / T::WPG;
@@ -811,8 +832,14 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
     _Pragma("unroll") for (int i_ = 0; i_ < T::GPT; ++i_) {                                 \
       int e_ = tid + i_ * THREADS;                                                          \
       int pair_ = e_ / T::SEGS, seg_ = e_ - pair_ * T::SEGS;                                \
+      f32x4 v_ = areg[i_];                                                                  \
+      if (pre) {             /* the prologue: BatchNorm + ReLU of the layer in front on the row segment's channels */ \
+        const f32x4 sc_ = *reinterpret_cast<const f32x4*>(s_pre + seg_ * 4);                \
+        const f32x4 sh_ = *reinterpret_cast<const f32x4*>(s_pre + CIN + seg_ * 4);          \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) v_[c_] = fmaxf(bn_affine(v_[c_], sc_[c_], sh_[c_]), 0.f); \
+      }                                                                                     \
       if (T::A_SEG % THREADS == 0 || e_ < T::A_SEG)                                         \
-        *reinterpret_cast<f32x4*>(s_a + pair_ * T::A_LD + seg_ * 4) = areg[i_];             \
+        *reinterpret_cast<f32x4*>(s_a + pair_ * T::A_LD + seg_ * 4) = v_;                   \
     }                                                                                       \
   }
 
@@ -2063,9 +2090,16 @@ extern "C" int glx_sconv_forward_ex(const float* in, int N_in, const float* W, c
               "(N_out %d, channels %d -> %d)", N_out, Cin, Cout);
   if (N_out == 0) return GLX_OK;
   GLX_REQUIRE(in && (W || Wp) && nbr && out, "glx_sconv_forward: null pointer");
+  const glx_epilogue* prol = opts ? opts->prologue : nullptr;
+  if (prol) {
+    GLX_REQUIRE(prol->scale && prol->shift && prol->relu && prol->ldc == 0 && prol->coff == 0,
+                "glx_sconv_forward_ex: the prologue is x' = relu(x * scale + shift) with Cin floats each");
+    GLX_REQUIRE(mfma_supported(Cin, Cout, K) && Cin >= 16 && !(Cin >= 128 && Cout >= 128) && g_sconv_variant < 0 && !g_sconv_trace,
+                "glx_sconv_forward_ex: the prologue needs a default MFMA tile kernel in one launch (channels %d -> %d)", Cin, Cout);
+  }
   SconvEpilogue ep{bias, scale, shift, relu, n_out_live, g_sconv_trace, g_sconv_xcd_group, 0, tile_map, bn_state,
                    bn_fin, bwd ? bwd->y : nullptr, bwd ? bwd->coef_fwd : nullptr, bwd ? bwd->mean : nullptr,
-                   bwd ? bwd->invstd : nullptr};
+                   bwd ? bwd->invstd : nullptr, prol ? prol->scale : nullptr, prol ? prol->shift : nullptr};
   if (!mfma_supported(Cin, Cout, K)) {
     GLX_REQUIRE(W, "glx_sconv_forward: raw weights required for channels (%d,%d)", Cin, Cout);
     long long total = (long long)N_out * Cout;
@@ -2527,13 +2561,15 @@ template <int CIN, int COUT>
 struct WgradPairsCfg {
   using C = WgradCfg<CIN, COUT>;
   static constexpr int A_LD = C::A_LD, B_LD = C::B_LD;
-  static constexpr size_t lds_bytes = (size_t)2 * WGP_PANEL * (A_LD + B_LD) * 4 + (size_t)WGP_MAXCH * 8 + sizeof(PairMeta) + 64;
+  static constexpr size_t lds_bytes = (size_t)2 * WGP_PANEL * (A_LD + B_LD) * 4 + (size_t)WGP_MAXCH * 8 + sizeof(PairMeta) + 64 +
+                                      (size_t)CIN * 8;
 };
 
 template <int CIN, int COUT>
 __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_pairs(
     const float* __restrict__ in, const float* __restrict__ gout, const PairMeta* __restrict__ meta,
-    const int* __restrict__ pair_in, const int* __restrict__ pair_out, int K, float* __restrict__ slabs) {
+    const int* __restrict__ pair_in, const int* __restrict__ pair_out, int K, float* __restrict__ slabs,
+    const float* __restrict__ pre_scale, const float* __restrict__ pre_shift) {
   using T = WgradCfg<CIN, COUT>;
   constexpr int A_LD = T::A_LD, B_LD = T::B_LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -2542,8 +2578,13 @@ __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_pairs(
   int* s_pi = reinterpret_cast<int*>(s_b + 2 * WGP_PANEL * B_LD);   // WGP_MAXCH input rows of the chunk's pairs
   int* s_pj = s_pi + WGP_MAXCH;                                     // WGP_MAXCH output rows
   PairMeta* s_meta = reinterpret_cast<PairMeta*>(s_pj + WGP_MAXCH);
+  float* s_pre = reinterpret_cast<float*>(s_meta + 1) + 16;         // 2 * CIN: scale | shift of the input transform
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, kk = lane >> 4;
+  const bool pre = pre_scale != nullptr;      // the input rows are relu(x * scale + shift) (glx_sconv_opts.prologue's twin)
+  if (pre) {
+    for (int e = tid; e < CIN; e += WGM_THREADS) { s_pre[e] = pre_scale[e]; s_pre[CIN + e] = pre_shift[e]; }
+  }
   for (int e = tid; e < (int)(sizeof(PairMeta) / 4); e += WGM_THREADS)
     reinterpret_cast<int*>(s_meta)[e] = reinterpret_cast<const int*>(meta)[e];
   if constexpr (T::CINP != CIN) {                              // the padding channels stay zero for the whole kernel
@@ -2611,7 +2652,13 @@ __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_pairs(
 #pragma unroll
     for (int it = 0; it < RA; ++it) {
       const int e = tid + it * WGM_THREADS, pr = e / SEG_A, sg = e - pr * SEG_A;
-      if (pr < WGP_PANEL) *reinterpret_cast<f32x4*>(pa + pr * A_LD + sg * 4) = p * WGP_PANEL + pr < np ? ra[it] : zero;
+      f32x4 v = ra[it];
+      if (pre) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(s_pre + sg * 4), sh = *reinterpret_cast<const f32x4*>(s_pre + CIN + sg * 4);
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) v[c4] = fmaxf(bn_affine(v[c4], sc[c4], sh[c4]), 0.f);
+      }
+      if (pr < WGP_PANEL) *reinterpret_cast<f32x4*>(pa + pr * A_LD + sg * 4) = p * WGP_PANEL + pr < np ? v : zero;
     }
 #pragma unroll
     for (int it = 0; it < RB; ++it) {
@@ -2671,21 +2718,26 @@ __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_pairs(
 // dW[k][e] = sum of the slabs of offset k's chunks, in chunk order (an offset without pairs has no chunk: zero).
 __global__ void k_wgrad_pairs_reduce(const float* __restrict__ slabs, const PairMeta* __restrict__ meta, int nel,
                                      float* __restrict__ dW) {
+  // four elements per thread, 16 chunks' loads in flight per batch (the ragged last batch predicated, not serial: a
+  // dependent load per leftover chunk was half of this kernel's time); summation in chunk order as before
   const int k = blockIdx.y;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (e >= nel) return;
   const int c0 = meta->coff[k], c1 = meta->coff[k + 1];
-  float s = 0.f;
-  int c = c0;
-  for (; c + 8 <= c1; c += 8) {
-    float v[8];
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c = c0; c < c1; c += 16) {
+    f32x4 v[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = slabs[(long long)(c + u) * nel + e];
+    for (int u = 0; u < 16; ++u) {
+      const int cc = c + u < c1 ? c + u : c1 - 1;
+      v[u] = *reinterpret_cast<const f32x4*>(slabs + (long long)cc * nel + e);
+    }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
+    for (int u = 0; u < 16; ++u) {
+      if (c + u < c1) s += v[u];
+    }
   }
-  for (; c < c1; ++c) s += slabs[(long long)c * nel + e];
-  dW[(long long)k * nel + e] = s;
+  *reinterpret_cast<f32x4*>(dW + (long long)k * nel + e) = s;
 }
 
 extern "C" size_t glx_sconv_wgrad_pairs_workspace_bytes(int N_out, int K, int Cin, int Cout) {
@@ -2699,6 +2751,14 @@ extern "C" size_t glx_sconv_wgrad_pairs_workspace_bytes(int N_out, int K, int Ci
 extern "C" int glx_sconv_wgrad_pairs(const float* in, const float* grad_out, const void* lists, int N_out, int K,
                                      int Cin, int Cout, float* dW, void* workspace, size_t workspace_bytes,
                                      void* stream) {
+  return glx_sconv_wgrad_pairs_ex(in, grad_out, lists, N_out, K, Cin, Cout, dW, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int glx_sconv_wgrad_pairs_ex(const float* in, const float* grad_out, const void* lists, int N_out, int K,
+                                        int Cin, int Cout, float* dW, const glx_epilogue* pre, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(!pre || (pre->scale && pre->shift && pre->relu && pre->ldc == 0 && pre->coff == 0 && Cin >= 16),
+              "glx_sconv_wgrad_pairs_ex: the input transform is relu(x * scale + shift), Cin floats each, Cin >= 16");
   GLX_REQUIRE(lists && workspace && (N_out == 0 || (in && grad_out)), "glx_sconv_wgrad_pairs: null pointer");
   GLX_REQUIRE(K >= 1 && K <= SC_MAXK, "glx_sconv_wgrad_pairs: K=%d", K);
   const size_t need = glx_sconv_wgrad_pairs_workspace_bytes(N_out, K, Cin, Cout) - 256;
@@ -2723,7 +2783,8 @@ extern "C" int glx_sconv_wgrad_pairs(const float* in, const float* grad_out, con
       attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WGM_THREADS), T::lds_bytes, st, in, grad_out,
-                       (const PairMeta*)base, (const int*)(base + oi), (const int*)(base + oo), K, (float*)workspace);
+                       (const PairMeta*)base, (const int*)(base + oi), (const int*)(base + oo), K, (float*)workspace,
+                       pre ? pre->scale : (const float*)nullptr, pre ? pre->shift : (const float*)nullptr);
     return GLX_OK;
   });
   if (rc != GLX_OK) return rc;
@@ -2742,7 +2803,7 @@ extern "C" int glx_sconv_wgrad_pairs_reduce(const void* lists, int N_out, int K,
     return GLX_EWORKSPACE;
   }
   const int nel = Cin * Cout;
-  hipLaunchKernelGGL(k_wgrad_pairs_reduce, dim3(glx_divup(nel, 256), K), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_wgrad_pairs_reduce, dim3(glx_divup(nel, 4 * 256), K), dim3(256), 0, (hipStream_t)stream,
                      (const float*)workspace, (const PairMeta*)lists, nel, dW);
   GLX_LAUNCH_CHECK();
   return GLX_OK;

@@ -381,14 +381,15 @@ def _cin_padding(cin):
 
 
 def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rules=None, tag="fwd",
-           scale=None, shift=None, relu=False, n_live=None, dims=None, bn=None, bwd_bn=None):
+           scale=None, shift=None, relu=False, n_live=None, dims=None, bn=None, bwd_bn=None, pre=None):
     """out[j] = relu?((sum_k features[nbr[j,k]] @ weight_kio[k] + bias) * scale + shift).
     weight_kio may be None when `packed` and dims = (K, Cin, Cout) are given.
     bn: a training-mode BatchNorm1d that follows the conv -- its batch statistics are taken in the kernel's epilogue
     (glx_sconv_opts.bn) and the call returns (out, coef, save_mean, save_invstd).
     bwd_bn: (y, coef, mean, invstd, gamma) -- the call is an input-gradient convolution whose output is the gradient of
     relu(bn(y)): the epilogue masks it with the ReLU and takes the BatchNorm backward's two sums (glx_sconv_opts.bn_bwd);
-    returns (dz, coef3 (3 * cout), dgamma, dbeta)."""
+    returns (dz, coef3 (3 * cout), dgamma, dbeta).
+    pre: coef (2 * cin: scale | shift) -- the input rows are relu(features * scale + shift) on load (glx_sconv_opts.prologue)."""
     K, cin, cout = dims if dims is not None else weight_kio.shape
     out = torch.empty((n_out, cout), dtype=torch.float32, device=features.device)
     if n_out == 0:
@@ -421,6 +422,10 @@ def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rule
                                                      gamma_prev) + stats])
         opts = opts or _lib.SconvOpts()
         opts.bn_bwd = ctypes.pointer(stb)
+    if pre is not None:
+        pro = _lib.epilogue(pre[:cin], pre[cin:], True)
+        opts = opts or _lib.SconvOpts()
+        opts.prologue = ctypes.pointer(pro)
     call("glx_sconv_forward_ex", features, features.shape[0], weight_kio, packed, bias, scale, shift,
          1 if relu else 0, nbr, tile_order, n_out, K, cin, cout, out, n_live, ws,
          size_arg(ws.numel()), ctypes.byref(opts) if opts is not None else None)
@@ -442,14 +447,45 @@ def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rule
 BN_BWD_IN_DGRAD = os.environ.get("GLX_SCONV_BN_BWD", "1") != "0"
 
 
+def _pre_arg(pre, cin):
+    """glx_epilogue* of an input transform (coef = scale | shift) or NULL."""
+    if pre is None:
+        return None
+    return ctypes.byref(_lib.epilogue(pre[0][:cin], pre[0][cin:], True))
+
+
+# Inner layers of the sparse backbone's blocks: relu(bn(y)) of a convolution is not written at all when the consumer is the
+# next convolution -- it transforms y on load (glx_sconv_opts.prologue), its weight gradient does the same
+# (glx_sconv_wgrad_pairs_ex) and its backward carries the BatchNorm's.  The producer leaves a `_pending` transform on its
+# SparseConvTensor; anything else that reads `.features` materialises it (FusedBNApply) then.  GLX_SCONV_BN_ON_LOAD=0: off.
+BN_ON_LOAD = os.environ.get("GLX_SCONV_BN_ON_LOAD", "1") != "0"
+
+
+class PendingBN:
+    """relu(bn(raw)) not yet computed: raw (N, C) = the convolution's output, coef / mean / invstd from its epilogue."""
+
+    def __init__(self, raw, coef, mean, invstd, bn, count, link):
+        self.raw, self.coef, self.mean, self.invstd, self.bn, self.count, self.link = raw, coef, mean, invstd, bn, count, link
+
+    def materialise(self):
+        return FusedBNApply.apply(self.raw, self.coef, self.mean, self.invstd, self.bn.weight, self.bn.bias, True, self.count,
+                                  self.link)
+
+
 class SparseConvFunction(Function):
     """features (N_in, Cin), weight (K, Cin, Cout), bias (Cout)|None -> (N_out, Cout)."""
 
     @staticmethod
-    def forward(ctx, features, weight, bias, rules, inverse, packed=None, side_ok=False, bn=None, in_link=None, leaf=None):
+    def forward(ctx, features, weight, bias, rules, inverse, packed=None, side_ok=False, bn=None, in_link=None, leaf=None,
+                pre_coef=None, pre_mean=None, pre_invstd=None, pre_gamma=None, pre_beta=None, pre_count=None):
         """bn: the training-mode BatchNorm1d behind the conv: its statistics ride in the kernel's epilogue and the
         call returns (out, coef, save_mean, save_invstd) for FusedBNApply (the last three non-differentiable).
-        in_link: the link FusedBNApply left on `features` (see BN_BWD_IN_DGRAD)."""
+        in_link: the link FusedBNApply left on `features` (see BN_BWD_IN_DGRAD).
+        pre_*: `features` is the RAW output y of the convolution in front and this convolution reads relu(bn(y)) by
+        transforming the rows on load (pre_coef = scale | shift its epilogue left, BN_ON_LOAD); this node's backward then
+        carries that BatchNorm's backward: it returns d/dy and the gradients of pre_gamma / pre_beta."""
+        ctx.pre = pre_coef is not None
+        ctx.pre_count = pre_count
         ctx.in_link = in_link if (in_link is not None and in_link.get("out") is not None and in_link["out"]() is features) else None
         # leaf: the parameter `weight` is a plain view of (None: it is not) -- what a deferred weight-gradient sum writes to
         ctx.leaf = leaf if (leaf is not None and leaf.is_leaf and leaf.requires_grad and leaf.numel() == weight.numel()) else None
@@ -461,9 +497,12 @@ class SparseConvFunction(Function):
         else:
             nbr, order, n_out = rules.nbr, rules.tile_order_out, rules.N_out
         out = _sconv(features, w, bias, nbr, order, n_out, packed=packed, rules=rules,
-                     n_live=rules.count_in if inverse else rules.count_out, bn=bn)
+                     n_live=rules.count_in if inverse else rules.count_out, bn=bn, pre=pre_coef)
         ctx.rules, ctx.inverse, ctx.side_ok = rules, inverse, side_ok
-        ctx.save_for_backward(features, w)
+        if ctx.pre:
+            ctx.save_for_backward(features, w, pre_coef, pre_mean, pre_invstd, pre_gamma)
+        else:
+            ctx.save_for_backward(features, w)
         ctx.has_bias = bias is not None
         if bn is not None:
             ctx.mark_non_differentiable(*out[1:])
@@ -472,7 +511,9 @@ class SparseConvFunction(Function):
 
     @staticmethod
     def backward(ctx, grad_out, *_stats_grads):
-        features, w = ctx.saved_tensors
+        features, w = ctx.saved_tensors[:2]
+        pre = ctx.saved_tensors[2:] if ctx.pre else None        # (coef, mean, invstd, gamma) of the BatchNorm in front
+        g_pre_gamma = g_pre_beta = None
         rules, inverse = ctx.rules, ctx.inverse
         grad_out = grad_out.contiguous().float()
         K, cin, cout = w.shape
@@ -510,7 +551,8 @@ class SparseConvFunction(Function):
                     pl = rules.pair_lists(fwd_nbr, n_fwd_out, live_fwd)
                     wsb = query("glx_sconv_wgrad_pairs_workspace_bytes", n_fwd_out, K, cin, cout)
                     ws = torch.empty(wsb, dtype=torch.uint8, device=w.device)
-                    call("glx_sconv_wgrad_pairs", features, grad_out, pl, n_fwd_out, K, cin, cout, None, ws, size_arg(wsb))
+                    call("glx_sconv_wgrad_pairs_ex", features, grad_out, pl, n_fwd_out, K, cin, cout, None, _pre_arg(pre, cin), ws,
+                         size_arg(wsb))
 
                     def run(stream, ws=ws, pl=pl, leaf=ctx.leaf, dims=(n_fwd_out, K, cin, cout), wsb=wsb):
                         ws.record_stream(stream)
@@ -525,9 +567,10 @@ class SparseConvFunction(Function):
                     pl = rules.pair_lists(fwd_nbr, n_fwd_out, live_fwd)
                     wsb = query("glx_sconv_wgrad_pairs_workspace_bytes", n_fwd_out, K, cin, cout)
                     ws = workspace.get(wsb, w.device)
-                    call("glx_sconv_wgrad_pairs", features, grad_out, pl, n_fwd_out, K, cin, cout, g_w, ws,
+                    call("glx_sconv_wgrad_pairs_ex", features, grad_out, pl, n_fwd_out, K, cin, cout, g_w, _pre_arg(pre, cin), ws,
                          size_arg(ws.numel()))
                 else:
+                    assert pre is None, "the input transform on load needs the pair-list weight gradient"
                     g_w = torch.empty_like(w)
                     wsb = query("glx_sconv_wgrad_workspace_bytes", n_fwd_out, K, cin, cout)
                     ws = workspace.get(wsb, w.device)
@@ -538,7 +581,16 @@ class SparseConvFunction(Function):
             # a submanifold set), packed from the forward weights in one launch
             wp_t = pack_weights(w, adjoint=True, flip=flip)
             link = ctx.in_link
-            if (wp_t is not None and link is not None and BN_BWD_IN_DGRAD and USE_BN_STATE and link["y"].shape == (n_bwd_out, cin)
+            if pre is not None:
+                # the input was relu(bn(features)): the input-gradient launch masks with the ReLU and takes the BatchNorm
+                # backward's sums in its epilogue, one transform launch turns that into d/d(features)
+                coef_p, mean_p, invstd_p, gamma_p = pre
+                dz, coef3, g_pre_gamma, g_pre_beta = _sconv(grad_out, None, None, bwd_nbr, bwd_order, n_bwd_out, packed=wp_t,
+                                                            rules=rules, tag="dgrad", n_live=live_bwd, dims=(K, cout, cin),
+                                                            bwd_bn=(features, coef_p, mean_p, invstd_p, gamma_p))
+                g_feat = torch.empty_like(features)
+                call("glx_bn_backward_apply", features, dz, coef3, mean_p, invstd_p, features.shape[0], cin, ctx.pre_count, g_feat)
+            elif (wp_t is not None and link is not None and BN_BWD_IN_DGRAD and USE_BN_STATE and link["y"].shape == (n_bwd_out, cin)
                     and cin in (16, 32, 64, 128) and not (cin >= 128 and cout >= 128)):
                 g_feat, coef3, dgamma, dbeta = _sconv(grad_out, None, None, bwd_nbr, bwd_order, n_bwd_out, packed=wp_t,
                                                       rules=rules, tag="dgrad", n_live=live_bwd, dims=(K, cout, cin),
@@ -558,12 +610,13 @@ class SparseConvFunction(Function):
             else:   # rows past the live count are undefined (possibly NaN): select, do not multiply
                 live = torch.arange(grad_out.shape[0], device=grad_out.device) < live_fwd
                 g_b = torch.where(live[:, None], grad_out, grad_out.new_zeros(())).sum(0)
-        return g_feat, g_w, g_b, None, None, None, None, None, None, None
+        return g_feat, g_w, g_b, None, None, None, None, None, None, None, None, None, None, g_pre_gamma, g_pre_beta, None
 
 
 class SparseConvTensor:
     def __init__(self, features, indices, spatial_shape, batch_size, grid=None, voxel_num=None,
                  indice_dict=None, benchmark=False, count=None):
+        self._pending = None    # PendingBN: `features` = relu(bn(raw)) is computed when somebody reads it (BN_ON_LOAD)
         self.features = features
         self.count = count      # shape-static mode: device int32[1] live rows (None = all rows)
         if indices.dtype != torch.int32:
@@ -576,6 +629,24 @@ class SparseConvTensor:
         self.voxel_num = voxel_num
         self.benchmark = benchmark
         self._index = None
+
+    @property
+    def features(self):
+        if self._features is None and self._pending is not None:
+            self._features = self._pending.materialise()
+            if self._pending.link is not None:
+                self._bn_link = self._pending.link
+            self._pending = None
+        return self._features
+
+    @features.setter
+    def features(self, value):
+        self._features = value
+        self._pending = None
+
+    def features_meta(self):
+        """A tensor with the features' shape / dtype / device (the raw rows while the transform is pending)."""
+        return self._features if self._features is not None else self._pending.raw
 
     # -- spconv 2.x API used by pcdet/utils/spconv_utils.py:28-34
     def replace_feature(self, new_features):
@@ -769,8 +840,16 @@ class SparseConvolution(SparseModule):
         assert isinstance(x, SparseConvTensor)
         K = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
         w = self.weight.reshape(K, self.in_channels, self.out_channels)
-        x_features = x.features
         pad = _cin_padding(self.in_channels)
+        # the producer left relu(bn(raw)) pending: take the raw rows and transform them on load when this launch can
+        pend = x._pending if (x._features is None and not pad and fused_bn is None and not fused_relu
+                              and x.indices.shape[0] > 1) else None
+        if pend is not None and not (BN_ON_LOAD and BN_BWD_IN_DGRAD and USE_BN_STATE and USE_PAIR_LISTS and torch.is_grad_enabled()
+                                     and self.in_channels in (16, 32, 64, 128) and self.out_channels in (16, 32, 64, 128)
+                                     and not (self.in_channels >= 128 and self.out_channels >= 128)
+                                     and query("glx_sconv_packed_bytes", K, self.in_channels, self.out_channels)):
+            pend = None
+        x_features = pend.raw if pend is not None else x.features
         if pad:
             w = torch.nn.functional.pad(w, (0, 0, 0, pad))
             x_features = torch.nn.functional.pad(x_features, (0, pad))
@@ -791,15 +870,22 @@ class SparseConvolution(SparseModule):
         else:
             # side_ok: the weight gradient may run on WGRAD_STREAM only when nothing but views
             # separates it from the parameter (a padded weight's backward copies on the main stream)
-            in_link = getattr(x, "_bn_link", None) if not pad else None
+            in_link = getattr(x, "_bn_link", None) if (not pad and pend is None) else None
+            pre_args = (None,) * 6 if pend is None else (pend.coef, pend.mean, pend.invstd, pend.bn.weight, pend.bn.bias, pend.count)
+            pending_out = None
             if train_bn is not None:
                 feats, coef, mean, invstd = SparseConvFunction.apply(x_features, w, self.bias, rs, self.inverse,
                                                                      self._packed_weight(w), not pad, train_bn, in_link,
-                                                                     None if pad else self.weight)
+                                                                     None if pad else self.weight, *pre_args)
                 # relu only: the epilogue re-derives the ReLU mask; a BatchNorm without ReLU keeps the full backward
                 out_link = {} if (BN_BWD_IN_DGRAD and train_relu and train_bn.affine) else None
-                feats = FusedBNApply.apply(feats, coef, mean, invstd, train_bn.weight, train_bn.bias, train_relu,
-                                           rs.count_in if self.inverse else rs.count_out, out_link)
+                cnt = rs.count_in if self.inverse else rs.count_out
+                if BN_ON_LOAD and out_link is not None and self.out_channels in (16, 32, 64, 128):
+                    pending_out = PendingBN(feats, coef, mean, invstd, train_bn, cnt, out_link)      # whoever reads it first
+                    feats, out_link = None, None
+                else:
+                    feats = FusedBNApply.apply(feats, coef, mean, invstd, train_bn.weight, train_bn.bias, train_relu, cnt,
+                                               out_link)
                 if train_bn.track_running_stats and train_bn.num_batches_tracked is not None:
                     if DEFERRED_COUNTERS is not None:
                         DEFERRED_COUNTERS.append(train_bn.num_batches_tracked)
@@ -808,7 +894,8 @@ class SparseConvolution(SparseModule):
             else:
                 out_link = None
                 feats = SparseConvFunction.apply(x_features, w, self.bias, rs, self.inverse,
-                                                 self._packed_weight(w), not pad, None, in_link, None if pad else self.weight)
+                                                 self._packed_weight(w), not pad, None, in_link, None if pad else self.weight,
+                                                 *pre_args)
         if self.inverse:
             out = SparseConvTensor(feats, rs.in_indices, rs.in_spatial_shape, x.batch_size,
                                    x.grid, x.voxel_num, x.indice_dict, x.benchmark, rs.count_in)
@@ -819,6 +906,8 @@ class SparseConvolution(SparseModule):
             out._index = rs.out_index
         if out_link is not None:
             out._bn_link = out_link
+        if not (fused_bn is not None or fused_relu) and pending_out is not None:
+            out._pending = pending_out
         return out
 
 
@@ -935,10 +1024,10 @@ def conv_bn_fusable(conv, bn, x):
     """A sparse conv whose training-mode BatchNorm statistics can ride in its epilogue (csrc/glx_sconv.hip
     sc_epilogue): MFMA tile kernel in one launch, channel counts the fused BatchNorm kernels cover."""
     cin, cout = conv.in_channels + _cin_padding(conv.in_channels), conv.out_channels
-    return (FUSE_BN_STATS_IN_CONV and USE_BN_STATE and torch.is_grad_enabled() and can_fuse_train_bn(bn, x.features)
+    return (FUSE_BN_STATS_IN_CONV and USE_BN_STATE and torch.is_grad_enabled() and can_fuse_train_bn(bn, x.features_meta())
             and bn.num_features == cout and cout in (16, 32, 64, 128) and cin in (4, 8, 16, 32, 64, 128)
             and not (cin >= 128 and cout >= 128) and not (cin in (4, 8) and cout > 32)
-            and x.features.is_cuda and x.indices.shape[0] > 1)
+            and x.features_meta().is_cuda and x.indices.shape[0] > 1)
 
 
 # On by default since round 3's second measurement: 10.18 ms per GLENet-VR training step with the statistics in the conv
@@ -1148,7 +1237,24 @@ class SparseSequential(SparseModule):
     def add(self, module, name=None):
         self.add_module(name if name is not None else str(len(self._modules)), module)
 
+    # A pending relu(bn(raw)) (BN_ON_LOAD) leaves the OUTERMOST SparseSequential materialised -- on the stream and at the place
+    # in the launch order where the module ran (a lazy first read on another stream would put the transform, and with it the
+    # BatchNorm's backward, on that stream) -- unless the container says its consumer is the next container's convolution.
+    leave_pending = False
+    _depth = 0
+
     def forward(self, x):
+        SparseSequential._depth += 1
+        try:
+            x = self._forward(x)
+        finally:
+            SparseSequential._depth -= 1
+        if (SparseSequential._depth == 0 and not self.leave_pending and isinstance(x, SparseConvTensor)
+                and x._features is None and x._pending is not None):
+            x.features                                   # materialise here
+        return x
+
+    def _forward(self, x):
         mods = list(self._modules.values())
         i = 0
         while i < len(mods):

@@ -96,6 +96,10 @@ typedef struct glx_sconv_opts {
   void* profile_start;
   void* profile_stop;
   const glx_bn_bwd_stats* bn_bwd;   /* see glx_bn_bwd_stats; excludes bn and the bias / scale / shift / relu arguments.  NULL: none */
+  /* transform of the INPUT rows on load, x' = relu(x * scale[c] + shift[c]) (scale, shift: Cin device floats, relu = 1, ldc =
+   * coff = 0): the training-mode BatchNorm1d + ReLU of the layer in front (spconv_backbone.py:21-25 post_act_block) applied
+   * without writing the normalised features; MFMA tile kernels with Cin >= 16 in one launch.  NULL: none. */
+  const glx_epilogue* prologue;
 } glx_sconv_opts;
 typedef struct glx_conv_opts {
   const glx_bn_stats* bn;
@@ -262,6 +266,9 @@ int glx_pair_lists_build(const int32_t* nbr, int N_out, int K, const int32_t* n_
 size_t glx_sconv_wgrad_pairs_workspace_bytes(int N_out, int K, int Cin, int Cout);
 int glx_sconv_wgrad_pairs(const float* in, const float* grad_out, const void* lists, int N_out, int K,
                           int Cin, int Cout, float* dW, void* workspace, size_t workspace_bytes, void* stream);
+/* The same for input rows that are transformed on load (`pre` as glx_sconv_opts.prologue; NULL = glx_sconv_wgrad_pairs). */
+int glx_sconv_wgrad_pairs_ex(const float* in, const float* grad_out, const void* lists, int N_out, int K, int Cin, int Cout,
+                             float* dW, const glx_epilogue* pre, void* workspace, size_t workspace_bytes, void* stream);
 /* The two launches apart: glx_sconv_wgrad_pairs with dW == NULL leaves the chunk products in `workspace` (which the caller
  * then keeps), glx_sconv_wgrad_pairs_reduce sums them into dW -- a leaf of the backward pass that a training step can run
  * later on another stream (the sum is a pass over memory, the products fill the matrix pipe: they overlap). */

@@ -669,3 +669,48 @@ def test_tile_map_of_large_rule_tables(dev, ntiles):
     got = tmap.cpu().numpy()
     assert np.array_equal(np.sort(got), np.arange(ntiles))
     assert np.array_equal(got, np.arange(ntiles)) == (ntiles > 16384)
+
+
+def test_batchnorm_on_load_in_the_next_sparse_convolution_changes_nothing(dev):
+    """Inner layers of the blocks (spconv_backbone.py:77-117 post_act_block chains): relu(bn(y)) is not written when the
+    next convolution consumes it -- that convolution and its weight gradient transform y on load
+    (glx_sconv_opts.prologue, glx_sconv_wgrad_pairs_ex) and its backward carries the BatchNorm's.  Same arithmetic: the
+    outputs and the running statistics equal the materialising path bit for bit, the gradients to rounding (a layer whose
+    BatchNorm backward took the two-launch statistics path there takes the epilogue sums here), and the launches that
+    would write the inner activations are gone."""
+    from glenet_amd.spconv import core
+    grid = oracle.grid_size_of(K["point_cloud_range"], K["voxel_size"])
+    pts, bidx = _frames_on(dev, 2, num_points=12000)
+
+    def run(on_load):
+        torch.manual_seed(3)
+        model = gb.VoxelBackBone8x(4, grid).to(dev).train()
+        _condition(model)
+        core.BN_ON_LOAD = on_load
+        applied = []
+        real = core.FusedBNApply.apply
+        core.FusedBNApply.apply = staticmethod(lambda *a, **k: (applied.append(1), real(*a, **k))[1])
+        try:
+            bd = model(gb.MeanVFE()(gb.voxelize_batch(pts, bidx, 2, K)))
+            out = bd["encoded_spconv_tensor"].features
+            feats = [bd["multi_scale_3d_features"][k].features for k in ("x_conv1", "x_conv2", "x_conv3", "x_conv4")]
+            g = torch.Generator(dev).manual_seed(1)
+            loss = sum((f * torch.randn(f.shape, device=dev, generator=g)).sum() for f in feats + [out])
+            loss.backward()
+        finally:
+            core.FusedBNApply.apply = real
+            core.BN_ON_LOAD = True
+        grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+        bufs = {n: b.clone() for n, b in model.named_buffers()}
+        return [out] + feats, grads, bufs, len(applied)
+
+    outs1, grads1, bufs1, n1 = run(True)
+    outs0, grads0, bufs0, n0 = run(False)
+    assert n0 == 12 and n1 == 5, (n0, n1)           # the block outputs (x_conv1..4, conv_out) are still written
+    for a, b in zip(outs1, outs0):
+        assert torch.equal(a, b)
+    for n in grads0:
+        scale = float(grads0[n].abs().max()) + 1e-12
+        assert float((grads1[n] - grads0[n]).abs().max()) <= 2e-5 * scale, n
+    for n in bufs0:
+        assert torch.equal(bufs1[n], bufs0[n]), n
