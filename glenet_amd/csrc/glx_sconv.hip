@@ -300,7 +300,7 @@ __device__ __forceinline__ void sc_gather(const float* __restrict__ in, const in
 }
 
 // MFMA the wave's chunks of offset k against the staged W[k] and add into the LDS tile
-template <int CIN, int COUT, class T, bool TRACE = false>
+template <int CIN, int COUT, class T, bool TRACE = false, bool PRE = false>
 __device__ __forceinline__ void sc_compute(const float* s_w, float* s_acc,
                                            const unsigned char* s_pslot, int k, int cnt, int grp,
                                            int tile0, int r, int q, int rot,
@@ -320,7 +320,7 @@ __device__ __forceinline__ void sc_compute(const float* s_w, float* s_acc,
       u1 = clock64();
     }
     float Am[C::CQ];
-    if (pre) {                 // wave-uniform: the input transform of the prologue on the lane's channels q * CQ + i
+    if constexpr (PRE) {       // the input transform of the prologue on the lane's channels q * CQ + i
 #pragma unroll
       for (int i = 0; i < C::CQ; ++i)
         Am[i] = valid[j] ? fmaxf(bn_affine(A[j][i], pre[q * C::CQ + i], pre[CIN + q * C::CQ + i]), 0.f) : 0.f;
@@ -428,7 +428,7 @@ __device__ __forceinline__ void sc_compute(const float* s_w, float* s_acc,
 // order: bitwise reproducible, no global atomics.  W[k+1] is parked in registers (NBUF = 1) or
 // streams into a second LDS buffer (NBUF = 2) and the next offset's input rows are gathered into
 // registers while offset k multiplies.
-template <int CIN, int COUT, int TR_, int NW_, int NBUF_, int WPG_ = 1, bool TRACE = false>
+template <int CIN, int COUT, int TR_, int NW_, int NBUF_, int WPG_ = 1, bool TRACE = false, bool PRE = false>
 __global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
     const float* __restrict__ in, const float* __restrict__ Wp, SconvEpilogue ep,
     const int* __restrict__ nbr, const int* __restrict__ tile_order, int N_out, int K,
@@ -452,10 +452,10 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  if (ep.pre_scale) {          // visible to everybody behind the compaction's barrier
+  if constexpr (PRE) {         // visible to everybody behind the compaction's barrier
     for (int e = tid; e < CIN; e += SC_THREADS) { s_pre[e] = ep.pre_scale[e]; s_pre[CIN + e] = ep.pre_shift[e]; }
   }
-  const float* pre = ep.pre_scale ? s_pre : nullptr;
+  const float* pre = PRE ? s_pre : nullptr;
   // XCD-aware tile mapping: workgroups are dealt round-robin to the 8 XCDs (block b runs on XCD
   // b mod 8), each with a private L2.  Rows are in cell order, so a CONTIGUOUS range of tiles
   // per XCD keeps the neighbour rows that adjacent tiles share in one L2 instead of eight.
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
     SC_STAGE_LOAD(kn_);                                                                     \
     sc_gather<CIN, COUT, T>(in, s_pin, kn_, cntn_, grp, r, q, rot, NXT, VNXT);                   \
     if constexpr (TRACE) c1_ = clock64();                                                   \
-    sc_compute<CIN, COUT, T, TRACE>(s_w + (NBUF == 2 ? buf : 0) * IMGW, s_acc, s_pslot, k,   \
+    sc_compute<CIN, COUT, T, TRACE, PRE>(s_w + (NBUF == 2 ? buf : 0) * IMGW, s_acc, s_pslot, k,   \
                                     cnt, grp, tile0, r, q, rot, CUR, VCUR, pre, tsub);       \
     if constexpr (TRACE) c2_ = clock64();                                                   \
     if (NBUF == 1) __syncthreads();                                                         \
@@ -688,7 +688,7 @@ struct SconvGemm {
   static_assert(LW <= NW && TR <= 256, "bad tile");
 };
 
-template <int CIN, int COUT, int TR_, int NW_, int WPG_, bool TRACE = false>
+template <int CIN, int COUT, int TR_, int NW_, int WPG_, bool TRACE = false, bool PRE = false>
 __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
     const float* __restrict__ in, const float* __restrict__ Wp, SconvEpilogue ep,
     const int* __restrict__ nbr, const int* __restrict__ tile_order, int N_out, int K,
@@ -711,8 +711,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const bool pre = ep.pre_scale != nullptr;
-  if (pre) {                   // visible to everybody behind the compaction's barrier
+  if constexpr (PRE) {         // visible to everybody behind the compaction's barrier
     for (int e = tid; e < CIN; e += THREADS) { s_pre[e] = ep.pre_scale[e]; s_pre[CIN + e] = ep.pre_shift[e]; }
   }
   const int row0 = ((TR == 64 && ep.tile_map) ? ep.tile_map[blockIdx.x]
@@ -833,7 +832,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
       int e_ = tid + i_ * THREADS;                                                          \
       int pair_ = e_ / T::SEGS, seg_ = e_ - pair_ * T::SEGS;                                \
       f32x4 v_ = areg[i_];                                                                  \
-      if (pre) {             /* the prologue: BatchNorm + ReLU of the layer in front on the row segment's channels */ \
+      if constexpr (PRE) {   /* the prologue: BatchNorm + ReLU of the layer in front on the row segment's channels */ \
         const f32x4 sc_ = *reinterpret_cast<const f32x4*>(s_pre + seg_ * 4);                \
         const f32x4 sh_ = *reinterpret_cast<const f32x4*>(s_pre + CIN + seg_ * 4);          \
         _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) v_[c_] = fmaxf(bn_affine(v_[c_], sc_[c_], sh_[c_]), 0.f); \
@@ -1583,11 +1582,14 @@ static int launch_tile(const float* in, const float* Wp, const SconvEpilogue& ep
     return GLX_EINVAL;
   } else {
     static bool attr_set = false;   // one per instantiation
-    auto kern = k_sconv_mfma<CI, CO, TR, NW, NBUF, WPG>;
+    constexpr bool HAS_PRE = CI >= 16 && TR == 64 && NBUF == 1;      // the instantiations glx_sconv_opts.prologue reaches
+    auto kern = ep.pre_scale ? k_sconv_mfma<CI, CO, TR, NW, NBUF, WPG, false, HAS_PRE> : k_sconv_mfma<CI, CO, TR, NW, NBUF, WPG>;
     const size_t lds = T::lds_bytes;
     if (!attr_set) {
-      GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds));
+      GLX_HIP(hipFuncSetAttribute((const void*)k_sconv_mfma<CI, CO, TR, NW, NBUF, WPG>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      GLX_HIP(hipFuncSetAttribute((const void*)k_sconv_mfma<CI, CO, TR, NW, NBUF, WPG, false, HAS_PRE>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr_set = true;
     }
     int nblocks = glx_divup(N_out, TR);
@@ -1627,11 +1629,14 @@ static int launch_gemm(const float* in, const float* Wp, const SconvEpilogue& ep
     return GLX_EINVAL;
   } else {
     static bool attr_set = false;
-    auto kern = k_sconv_gemm<CI, CO, TR, NW, WPG>;
+    constexpr bool HAS_PRE = CI >= 16 && TR == 64;                   // the instantiations glx_sconv_opts.prologue reaches
+    auto kern = ep.pre_scale ? k_sconv_gemm<CI, CO, TR, NW, WPG, false, HAS_PRE> : k_sconv_gemm<CI, CO, TR, NW, WPG>;
     const size_t lds = T::lds_bytes + (size_t)((ep.xcd_group >> 16) & 0xFF) * 1024;   // bits 16-23: experiments, KB of padding
     if (!attr_set) {
-      GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+      GLX_HIP(hipFuncSetAttribute((const void*)k_sconv_gemm<CI, CO, TR, NW, WPG>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
+      GLX_HIP(hipFuncSetAttribute((const void*)k_sconv_gemm<CI, CO, TR, NW, WPG, false, HAS_PRE>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr_set = true;
     }
     const float* Wsplit = Wp + (size_t)K * SconvCfg<CI, CO>::IMG;   // second image of the packed buffer
