@@ -133,29 +133,6 @@ class ConvOpts(ctypes.Structure):
                 ("bn_bwd", ctypes.POINTER(BnBwdStats))]
 
 
-# ---- weight gradients in two halves (glx_conv3x3_wgrad_reduce, glx_sconv_wgrad_pairs_reduce): while a staged training step
-# sets DEFERRED_REDUCES to a list, the convolutions' backward launches only the partial products (into a workspace of its own)
-# and leaves the sum -- a pass over memory at the end of a dependency chain -- as a job the step runs on a stream that is idle
-DEFERRED_REDUCES = None
-
-
-def defer_reduce(device, run):
-    """run(stream): launches the sum on the (then current) stream and stores the parameter's .grad."""
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(device))
-    DEFERRED_REDUCES.append((ev, run))
-
-
-def run_deferred_reduces(jobs, stream):
-    """The jobs collected so far, on `stream` (NOT the stream their events were recorded on: ROCm 7.2's stream capture
-    crashes in hipStreamEndCapture on an event recorded and waited for on one stream); the list is emptied."""
-    with torch.no_grad(), torch.cuda.stream(stream):
-        for ev, run in jobs:
-            stream.wait_event(ev)
-            run(stream)
-    del jobs[:]
-
-
 class FcBn(ctypes.Structure):
     _fields_ = [("gamma", c_void_p), ("beta", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p),
                 ("save_mean", c_void_p), ("save_invstd", c_void_p), ("eps", c_float), ("momentum", c_float)]

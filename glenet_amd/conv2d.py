@@ -149,22 +149,6 @@ def wgrad(x, gy, weight, pre=None):
     if pre is not None:
         coef, relu = pre
         prologue = ctypes.byref(_lib.epilogue(coef[:cin], coef[cin:], relu))
-    if _lib.DEFERRED_REDUCES is not None and weight.is_leaf:
-        # the blocks' partial sums now (a workspace of this layer's own), their sum later on another stream: returns None
-        # and the job stores weight.grad (_lib.run_deferred_reduces)
-        ws = torch.empty(n, dtype=torch.uint8, device=x.device)
-        s = weight.stride()
-        call("glx_conv3x3_wgrad_ex", x, gy, b, h, w, cin, cout, None, ll(s[0]), ll(s[1]), ll(s[2]), ll(s[3]), prologue, ws,
-             _lib.size_arg(n))
-
-        def run(stream, ws=ws, weight=weight, n=n, cin=cin, cout=cout):
-            ws.record_stream(stream)
-            gw = torch.empty_like(weight)
-            s = gw.stride()
-            call("glx_conv3x3_wgrad_reduce", cin, cout, gw, ll(s[0]), ll(s[1]), ll(s[2]), ll(s[3]), ws, _lib.size_arg(n))
-            weight.grad = gw if weight.grad is None else weight.grad + gw
-        _lib.defer_reduce(x.device, run)
-        return None
     ws = _lib.workspace.get(n, x.device)
     gw = torch.empty_like(weight)
     s = gw.stride()

@@ -142,7 +142,6 @@ class VoxelRCNNKLHead(rg.RoIGridPool):
 OVERLAP_ROI = os.environ.get("GLX_OVERLAP_ROI", "1") != "0"
 STAGE_CUTS = os.environ.get("GLX_STAGE_CUTS", "1") != "0"
 DEFER_FC_WGRADS = os.environ.get("GLX_DEFER_FC_WGRADS", "1") != "0"
-DEFER_WGRAD_SUMS = int(os.environ.get("GLX_DEFER_WGRAD_SUMS", "0"))     # 1: on the RoI stream, 2: on the weight-gradient stream (StagedLoss.backward)
 FC_WGRADS_BEHIND_ROI = os.environ.get("GLX_FC_WGRADS_BEHIND_ROI", "1") != "0"      # see StagedLoss.backward
 # First MLP of the three pooling scales on the RoI stream BESIDE the BEV forward (it needs the sparse backbone's output only).
 # Measured in round 4, alternating runs on one box: 7.22 / 7.23 ms per step with it against 7.03 / 7.02 without -- the nine
@@ -193,13 +192,6 @@ class StagedLoss:
         wgrad_stream = core.WGRAD_STREAM
         if not WGRAD_STREAM_DURING_ROI:      # measured again with two executor queues: 8.0 ms against 6.44
             core.WGRAD_STREAM = None
-        # The convolutions' weight gradients end in a sum over partial products (a pass over memory: 8-10 us each, 23 of them
-        # between the input gradients of the main stream's chain; without them the step is 0.21 ms shorter).  Deferred to
-        # the RoI stream (1) or the weight-gradient stream (2) they were measured 0.19 ms SLOWER than inline (6.47 against
-        # 6.28): the executor runs them at the end of the branch they are on and the final join waits -- off by default.
-        lib = gb._lib
-        jobs = lib.DEFERRED_REDUCES = [] if (DEFER_WGRAD_SUMS and wgrad_stream is not None) else None
-        sum_stream = wgrad_stream if DEFER_WGRAD_SUMS == 2 else self.roi_stream
         try:
             fc_jobs = dp.DEFERRED_FC_WGRADS = [] if DEFER_FC_WGRADS else None
             dp.DEFERRED_FC_SAME_STREAM = FC_WGRADS_BEHIND_ROI
@@ -217,8 +209,6 @@ class StagedLoss:
                     dp.run_deferred_fc_wgrads(fc_jobs)
                     fc_jobs = None
             torch.autograd.backward(self.rpn)             # B: ends at the BEV input's detached leaf
-            if jobs:
-                lib.run_deferred_reduces(jobs, sum_stream)
             if fc_jobs:      # ... or in the main stream's wait for the RoI gradients (what paid while the RoI branch was longer)
                 dp.run_deferred_fc_wgrads(fc_jobs)
             # C: the sparse backbone, level by level: the levels above a stage cut run as soon as THEIR RoI gradients are
@@ -228,8 +218,6 @@ class StagedLoss:
             for name in self.LEVELS + tuple(n for n in self.roi_cuts if n not in self.LEVELS):
                 if name in self.stage_cuts:
                     torch.autograd.backward(roots, grads)
-                    if jobs:
-                        lib.run_deferred_reduces(jobs, sum_stream)
                     if self.mark:
                         self.mark("backward: sparse backbone above " + name)
                     feat, leaf = self.stage_cuts[name]
@@ -247,23 +235,14 @@ class StagedLoss:
                         roots.append(feat)
                         grads.append(leaf.grad)
                     leaf.grad = None
-            roi_stream = self.roi_stream
-            if jobs is None:
-                main.wait_stream(roi_stream)              # join (parameter gradients of the RoI head)
+            main.wait_stream(self.roi_stream)             # join (parameter gradients of the RoI head)
             self.value = self.rpn.detach() + self.roi.detach()
             self.rpn = self.roi = self.bev_cut = self.roi_cuts = self.stage_cuts = None
-            # free again: the RoI branch has been joined (with deferred sums the RoI stream stays the one side stream:
-            # the last levels' weight gradients go there too, their sums inline)
-            lib.DEFERRED_REDUCES = None
-            core.WGRAD_STREAM = wgrad_stream if jobs is None else sum_stream
+            core.WGRAD_STREAM = wgrad_stream              # free again: the RoI branch has been joined
             keep = [(t, g) for t, g in zip(roots, grads) if g is not None]
             torch.autograd.backward([t for t, _ in keep], [g for _, g in keep])
-            if jobs is not None:
-                main.wait_stream(roi_stream)              # join: the RoI head's gradients, the deferred sums, the last levels
-                main.wait_stream(sum_stream)
         finally:
             core.WGRAD_STREAM = wgrad_stream
-            lib.DEFERRED_REDUCES = None
 
     def detach(self):
         return self.value

@@ -545,24 +545,7 @@ class SparseConvFunction(Function):
                     t.record_stream(side)
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
                 pairs = USE_PAIR_LISTS and n_fwd_out > 0 and query("glx_sconv_packed_bytes", K, cin, cout)
-                if pairs and _lib.DEFERRED_REDUCES is not None and ctx.leaf is not None:
-                    # the chunk products now (a workspace of this layer's own), their sum later on another stream: no
-                    # gradient returned, the job stores the parameter's .grad (_lib.run_deferred_reduces)
-                    pl = rules.pair_lists(fwd_nbr, n_fwd_out, live_fwd)
-                    wsb = query("glx_sconv_wgrad_pairs_workspace_bytes", n_fwd_out, K, cin, cout)
-                    ws = torch.empty(wsb, dtype=torch.uint8, device=w.device)
-                    call("glx_sconv_wgrad_pairs_ex", features, grad_out, pl, n_fwd_out, K, cin, cout, None, _pre_arg(pre, cin), ws,
-                         size_arg(wsb))
-
-                    def run(stream, ws=ws, pl=pl, leaf=ctx.leaf, dims=(n_fwd_out, K, cin, cout), wsb=wsb):
-                        ws.record_stream(stream)
-                        pl.record_stream(stream)
-                        gw = torch.empty(dims[1:], dtype=torch.float32, device=ws.device)
-                        call("glx_sconv_wgrad_pairs_reduce", pl, dims[0], dims[1], dims[2], dims[3], gw, ws, size_arg(wsb))
-                        gw = gw.view_as(leaf)
-                        leaf.grad = gw if leaf.grad is None else leaf.grad + gw
-                    _lib.defer_reduce(w.device, run)
-                elif pairs:
+                if pairs:
                     g_w = torch.empty_like(w)
                     pl = rules.pair_lists(fwd_nbr, n_fwd_out, live_fwd)
                     wsb = query("glx_sconv_wgrad_pairs_workspace_bytes", n_fwd_out, K, cin, cout)

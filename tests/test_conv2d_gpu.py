@@ -85,6 +85,31 @@ def test_conv3x3_gradients_and_pack_refresh(dev):
     assert torch.allclose(y2, -2.0 * y.detach(), rtol=1e-5, atol=1e-5 * float(y.abs().max()))
 
 
+def test_conv3x3_weight_gradient_in_two_halves(dev):
+    """glx_conv3x3_wgrad_ex with dW = NULL (the blocks' partial sums only) + glx_conv3x3_wgrad_reduce on another stream give
+    the bits of the one-call form."""
+    import ctypes
+    from glenet_amd import _lib, conv2d as c2
+    b, cin, cout, h, w = 2, 64, 128, 20, 36
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = _cl(torch.randn(b, cin, h, w, device=dev, generator=g))
+    wt = _cl(torch.randn(cout, cin, 3, 3, device=dev, generator=g) / 24)
+    gy = _cl(torch.randn(b, cout, h, w, device=dev, generator=g))
+    whole = c2.wgrad(x, gy, wt)
+    n = _lib.query("glx_conv3x3_wgrad_workspace_bytes", cin, cout)
+    ws = torch.empty(n, dtype=torch.uint8, device=dev)
+    gw = torch.full_like(wt, float("nan"))
+    s, ll = gw.stride(), ctypes.c_longlong
+    _lib.call("glx_conv3x3_wgrad_ex", x, gy, b, h, w, cin, cout, None, ll(s[0]), ll(s[1]), ll(s[2]), ll(s[3]), None, ws,
+              _lib.size_arg(n))
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        _lib.call("glx_conv3x3_wgrad_reduce", cin, cout, gw, ll(s[0]), ll(s[1]), ll(s[2]), ll(s[3]), ws, _lib.size_arg(n))
+    torch.cuda.current_stream(dev).wait_stream(side)
+    assert torch.equal(gw, whole)
+
+
 def test_bev_backbone_runs_its_block_layers_on_the_own_kernels(dev, monkeypatch):
     """The training-mode BEV backbone with the own 3x3 kernels against the same module on the library's."""
     from glenet_amd import dense_path as dp

@@ -319,6 +319,45 @@ def test_weight_gradient_over_pair_lists_and_over_row_slices_equal_the_fp64_cont
         assert np.abs(got.cpu().numpy().astype(np.float64) - want).max() <= 2e-6 * scale
 
 
+@pytest.mark.parametrize("cin,cout,n_out,K", [(64, 64, 5000, 27), (32, 32, 900, 27), (16, 16, 3000, 27)])
+def test_weight_gradient_in_two_halves_and_with_the_input_transform(dev, cin, cout, n_out, K):
+    """glx_sconv_wgrad_pairs with dW = NULL + glx_sconv_wgrad_pairs_reduce give the bits of the one-call form; with an input
+    transform (glx_sconv_wgrad_pairs_ex: relu(x * scale + shift) on load) the result is the bits of the same call on the
+    transformed rows."""
+    import ctypes
+    from glenet_amd import _lib
+    rng = np.random.default_rng(cin + n_out)
+    n_in = n_out + 5
+    nbr_np = np.where(rng.random((n_out, K)) < 0.3, rng.integers(0, n_in, (n_out, K)), -1).astype(np.int32)
+    nbr = torch.from_numpy(nbr_np).to(dev)
+    x = torch.from_numpy(rng.normal(size=(n_in, cin)).astype(np.float32)).to(dev)
+    g = torch.from_numpy(rng.normal(size=(n_out, cout)).astype(np.float32)).to(dev)
+    pl = _pair_lists_of(nbr, n_out, K, None, dev)[0]
+    wsb = _lib.query("glx_sconv_wgrad_pairs_workspace_bytes", n_out, K, cin, cout)
+
+    def run(xin, pre=None, halves=False):
+        dw = torch.full((K, cin, cout), float("nan"), device=dev)
+        ws = torch.zeros(wsb, dtype=torch.uint8, device=dev)
+        if halves:
+            _lib.call("glx_sconv_wgrad_pairs_ex", xin, g, pl, n_out, K, cin, cout, None, pre, ws, _lib.size_arg(wsb))
+            _lib.call("glx_sconv_wgrad_pairs_reduce", pl, n_out, K, cin, cout, dw, ws, _lib.size_arg(wsb))
+        else:
+            _lib.call("glx_sconv_wgrad_pairs_ex", xin, g, pl, n_out, K, cin, cout, dw, pre, ws, _lib.size_arg(wsb))
+        return dw
+
+    whole = run(x)
+    assert torch.isfinite(whole).all()
+    assert torch.equal(run(x, halves=True), whole)
+    scale = torch.from_numpy((rng.random(cin) + 0.5).astype(np.float32)).to(dev)
+    shift = torch.from_numpy((rng.normal(size=cin) * 0.3).astype(np.float32)).to(dev)
+    pre = ctypes.byref(_lib.epilogue(scale, shift, True))
+    xt = torch.empty_like(x)                                         # the transform kernel's own arithmetic (one fused multiply-add)
+    _lib.call("glx_bn_apply_forward", x, torch.cat([scale, shift]), 1, n_in, cin, None, xt, 0)
+    want = run(xt)
+    assert torch.equal(run(x, pre), want)
+    assert torch.equal(run(x, pre, halves=True), want)
+
+
 def test_conv_with_five_input_channels_is_padded_not_scalar(dev):
     """Waymo point features (C = 5): forward and both gradients equal the oracle."""
     rng = np.random.default_rng(31)
