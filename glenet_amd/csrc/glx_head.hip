@@ -40,6 +40,16 @@ __device__ __forceinline__ void hd_load_w(const float* const* W, const int* n, i
   }
 }
 
+// The map the head reads: one (M, C) matrix, or two column parts x[0] (M, c0) | x[1] (M, C - c0) (c0 a multiple of 16) that
+// are transformed on load, x' = max(x * scale + shift, 0) with coef[p] = scale | shift of part p -- the deblocks' raw
+// transposed-convolution outputs with their training-mode BatchNorm + ReLU applied here instead of being written as the
+// concatenated map first (base_bev_backbone.py:100-104).
+struct HeadIn {
+  const float* x[2];
+  const float* coef[2];
+  int c0;
+};
+
 struct HeadW {
   const float* w[3];
   const float* b[3];
@@ -47,23 +57,49 @@ struct HeadW {
 };
 
 // out[m, o] = sum_c x[m, c] W[o, c] + b[o].  A = the pixel tile (lane (i, kq): pixel i, channels 16 t + 4 kq + e), B = W^T.
-__global__ __launch_bounds__(HD_THREADS) void k_head_fwd(const float* __restrict__ x, long long M, int C, HeadW hw, HeadOut out) {
+__global__ __launch_bounds__(HD_THREADS) void k_head_fwd(HeadIn in, long long M, int C, HeadW hw, HeadOut out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_w = smem;                                    // HD_MAXO x (C + 4)
   const int ld = C + 4;
+  float* s_coef = s_w + HD_MAXO * ld;                   // scale[C] | shift[C] in the concatenated channel order
   hd_load_w(hw.w, hw.n, C, s_w);
+  const bool pre = in.coef[0] != nullptr;
+  const int c0 = in.c0, c1 = C - in.c0;
+  if (pre) {
+    for (int c = threadIdx.x; c < C; c += HD_THREADS) {
+      const bool a = c < c0;
+      s_coef[c] = a ? in.coef[0][c] : in.coef[1][c - c0];
+      s_coef[C + c] = a ? in.coef[0][c0 + c] : in.coef[1][c1 + c - c0];
+    }
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int total = hw.n[0] + hw.n[1] + hw.n[2];
   for (long long m0 = (long long)blockIdx.x * HD_PIX; m0 < M; m0 += (long long)gridDim.x * HD_PIX) {
     const long long m = m0 + wave * 16 + i;
-    const float* row = x + (m < M ? m : M - 1) * C + 4 * kq;
+    const long long mc = m < M ? m : M - 1;
+    const float* row0 = in.x[0] + mc * c0 + 4 * kq;
+    const float* row1 = in.x[1] ? in.x[1] + mc * c1 + 4 * kq - c0 : row0;      // indexed with the concatenated channel
     hf32x4 acc0 = hf32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     for (int t0 = 0; t0 < C / 16; t0 += 8) {           // 8 channel groups of 16 at a time: 8 row loads in flight
       hf32x4 xa[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) xa[u] = t0 + u < C / 16 ? *reinterpret_cast<const hf32x4*>(row + 16 * (t0 + u)) : hf32x4{0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < 8; ++u) {
+        const int ch = 16 * (t0 + u);
+        xa[u] = t0 + u < C / 16 ? *reinterpret_cast<const hf32x4*>((ch < c0 ? row0 : row1) + ch) : hf32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (pre) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (t0 + u < C / 16) {
+            const hf32x4 sc = *reinterpret_cast<const hf32x4*>(s_coef + 16 * (t0 + u) + 4 * kq);
+            const hf32x4 sh = *reinterpret_cast<const hf32x4*>(s_coef + C + 16 * (t0 + u) + 4 * kq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xa[u][e] = fmaxf(__fmaf_rn(xa[u][e], sc[e], sh[e]), 0.f);
+          }
+        }
+      }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         if (t0 + u < C / 16) {
@@ -143,11 +179,22 @@ __global__ __launch_bounds__(HD_THREADS) void k_head_dgrad(HeadGrad g, long long
 // of 4 waves covers C = 256 with 4 column tiles per wave; partial sums per block go to the workspace, k_head_wreduce adds
 // them in block order (fixed summation order).
 #define HD_WBLOCKS 512
-__global__ __launch_bounds__(HD_THREADS) void k_head_wgrad(HeadGrad g, const float* __restrict__ x, long long M, int C,
-                                                           float* __restrict__ part) {
+__global__ __launch_bounds__(HD_THREADS) void k_head_wgrad(HeadGrad g, HeadIn in, long long M, int C, float* __restrict__ part) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int tpw = C / 64;                               // column tiles per wave (C = 256: 4)
+  const bool pre = in.coef[0] != nullptr;
+  const int c0 = in.c0, c1 = C - in.c0;
+  float psc[8], psh[8];                                 // the input transform of this lane's channels 16 (wave tpw + u) + i
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int c = 16 * (wave * tpw + u) + i;
+    psc[u] = 1.f; psh[u] = 0.f;
+    if (pre && u < tpw) {
+      psc[u] = c < c0 ? in.coef[0][c] : in.coef[1][c - c0];
+      psh[u] = c < c0 ? in.coef[0][c0 + c] : in.coef[1][c1 + c - c0];
+    }
+  }
   hf32x4 acc[2][8];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
@@ -170,9 +217,16 @@ __global__ __launch_bounds__(HD_THREADS) void k_head_wgrad(HeadGrad g, const flo
       const long long m = m0 + 4 * s + kq;
       a0[s] = gval(m, i);
       a1[s] = gval(m, 16 + i);
-      const float* row = x + (m < hi ? m : hi - 1) * C + 16 * (wave * tpw) + i;
+      const long long mc = m < hi ? m : hi - 1;
+      const float* row0 = in.x[0] + mc * c0 + i;
+      const float* row1 = in.x[1] ? in.x[1] + mc * c1 + i - c0 : row0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) xb[s][u] = (u < tpw && m < hi) ? row[16 * u] : 0.f;
+      for (int u = 0; u < 8; ++u) {
+        const int ch = 16 * (wave * tpw + u);
+        float v = (u < tpw && m < hi) ? (ch < c0 ? row0 : row1)[ch] : 0.f;
+        if (pre && u < tpw && m < hi) v = fmaxf(__fmaf_rn(v, psc[u], psh[u]), 0.f);
+        xb[s][u] = v;
+      }
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -240,10 +294,33 @@ static int head_lds_attr(const void* kern, size_t lds) {
   return GLX_OK;
 }
 
+static int head_in(const float* x0, const float* x1, int c0, const float* coef0, const float* coef1, int C, HeadIn* in,
+                   const char* who) {
+  GLX_REQUIRE(x0, "%s: null map", who);
+  if (!x1) {
+    GLX_REQUIRE(!coef0 && !coef1, "%s: the input transform needs the two-part form", who);
+    *in = HeadIn{{x0, nullptr}, {nullptr, nullptr}, C};
+    return GLX_OK;
+  }
+  GLX_REQUIRE(c0 > 0 && c0 < C && c0 % 16 == 0, "%s: the first part has %d of %d channels (a multiple of 16 inside)", who, c0, C);
+  GLX_REQUIRE((coef0 == nullptr) == (coef1 == nullptr), "%s: both parts or neither are transformed", who);
+  *in = HeadIn{{x0, x1}, {coef0, coef1}, c0};
+  return GLX_OK;
+}
+
 extern "C" int glx_head1x1_forward(const float* x, int64_t M, int C, const float* const* W, const float* const* bias,
                                    const int32_t* n, float* const* out, void* stream) {
-  GLX_REQUIRE(x && W && n && out, "glx_head1x1_forward: null pointer");
+  return glx_head1x1_forward_parts(x, nullptr, C, nullptr, nullptr, M, C, W, bias, n, out, stream);
+}
+
+extern "C" int glx_head1x1_forward_parts(const float* x0, const float* x1, int c0, const float* coef0, const float* coef1,
+                                         int64_t M, int C, const float* const* W, const float* const* bias, const int32_t* n,
+                                         float* const* out, void* stream) {
+  GLX_REQUIRE(x0 && W && n && out, "glx_head1x1_forward: null pointer");
   int rc = head_check(M, C, n, "glx_head1x1_forward");
+  if (rc != GLX_OK) return rc;
+  HeadIn in;
+  rc = head_in(x0, x1, c0, coef0, coef1, C, &in, "glx_head1x1_forward");
   if (rc != GLX_OK) return rc;
   HeadW hw; HeadOut ho;
   for (int k = 0; k < 3; ++k) {
@@ -251,12 +328,12 @@ extern "C" int glx_head1x1_forward(const float* x, int64_t M, int C, const float
     ho.p[k] = out[k]; ho.n[k] = n[k];
     GLX_REQUIRE(n[k] == 0 || (W[k] && out[k]), "glx_head1x1_forward: head %d has no weights / output", k);
   }
-  const size_t lds = (size_t)HD_MAXO * (C + 4) * 4;
+  const size_t lds = (size_t)HD_MAXO * (C + 4) * 4 + (size_t)2 * C * 4;
   rc = head_lds_attr((const void*)k_head_fwd, lds);
   if (rc != GLX_OK) return rc;
   long long blocks = (M + HD_PIX - 1) / HD_PIX;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_head_fwd, dim3((unsigned)blocks), dim3(HD_THREADS), lds, (hipStream_t)stream, x, (long long)M, C, hw, ho);
+  hipLaunchKernelGGL(k_head_fwd, dim3((unsigned)blocks), dim3(HD_THREADS), lds, (hipStream_t)stream, in, (long long)M, C, hw, ho);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
@@ -287,8 +364,18 @@ extern "C" size_t glx_head1x1_wgrad_workspace_bytes(int C) { return (size_t)HD_W
 extern "C" int glx_head1x1_weight_grad(const float* const* grad, const float* x, int64_t M, int C, const int32_t* n,
                                        float* const* gW, float* const* gb, void* workspace, size_t workspace_bytes,
                                        void* stream) {
-  GLX_REQUIRE(grad && x && n && gW && workspace, "glx_head1x1_weight_grad: null pointer");
+  return glx_head1x1_weight_grad_parts(grad, x, nullptr, C, nullptr, nullptr, M, C, n, gW, gb, workspace, workspace_bytes, stream);
+}
+
+extern "C" int glx_head1x1_weight_grad_parts(const float* const* grad, const float* x0, const float* x1, int c0,
+                                             const float* coef0, const float* coef1, int64_t M, int C, const int32_t* n,
+                                             float* const* gW, float* const* gb, void* workspace, size_t workspace_bytes,
+                                             void* stream) {
+  GLX_REQUIRE(grad && x0 && n && gW && workspace, "glx_head1x1_weight_grad: null pointer");
   int rc = head_check(M, C, n, "glx_head1x1_weight_grad");
+  if (rc != GLX_OK) return rc;
+  HeadIn in;
+  rc = head_in(x0, x1, c0, coef0, coef1, C, &in, "glx_head1x1_weight_grad");
   if (rc != GLX_OK) return rc;
   GLX_REQUIRE(C <= 512 && C / 64 <= 8, "glx_head1x1_weight_grad: C = %d", C);
   GLX_REQUIRE(workspace_bytes >= glx_head1x1_wgrad_workspace_bytes(C), "glx_head1x1_weight_grad: workspace too small");
@@ -300,7 +387,7 @@ extern "C" int glx_head1x1_weight_grad(const float* const* grad, const float* x,
   }
   long long blocks = (M + 63) / 64;
   if (blocks > HD_WBLOCKS) blocks = HD_WBLOCKS;
-  hipLaunchKernelGGL(k_head_wgrad, dim3((unsigned)blocks), dim3(HD_THREADS), 0, (hipStream_t)stream, hg, x, (long long)M, C,
+  hipLaunchKernelGGL(k_head_wgrad, dim3((unsigned)blocks), dim3(HD_THREADS), 0, (hipStream_t)stream, hg, in, (long long)M, C,
                      (float*)workspace);
   const int total = n[0] + n[1] + n[2];
   hipLaunchKernelGGL(k_head_wreduce, dim3(glx_divup((long long)total * (C + 1), 4)), dim3(256), 0, (hipStream_t)stream,

@@ -119,6 +119,7 @@ FUSE_BN_IN_CONV3X3 = os.environ.get("GLX_CONV3X3_BN", "1") != "0"    # ... with 
 # raw convolution output through scale / shift; the next layer's backward carries this BatchNorm's backward): the normalised
 # map of the inner layers of a block is never written (base_bev_backbone.py:36-49)
 BN_ON_LOAD = os.environ.get("GLX_CONV3X3_BN_ON_LOAD", "1") != "0"
+HEAD_BN_ON_LOAD = os.environ.get("GLX_HEAD_BN_ON_LOAD", "1") != "0"    # deblocks' BatchNorm + ReLU applied by the anchor head's kernels
 DECONV_BN_STATS = os.environ.get("GLX_DECONV_BN_STATS", "1") != "0"   # deblocks: BatchNorm statistics in the deconv's epilogue
 
 
@@ -203,10 +204,24 @@ class BEVBackbone(nn.Module):
             self.deblocks.append(nn.Sequential(nn.ConvTranspose2d(c, c, u, stride=u, bias=False), _bn2d(c),
                                                nn.ReLU()))
 
+    head_on_load = False      # GLENetVR: leave the concatenation to the anchor head (_Head1x1Parts) in training steps
+
+    @staticmethod
+    def concat_parts(parts):
+        """The concatenated map of `spatial_features_2d_parts` (what _ups_fused would have returned)."""
+        from .spconv import core
+        args = []
+        for rows, coef, mean, invstd, bn in parts["parts"]:
+            args += [rows, coef, mean, invstd, bn.weight, bn.bias]
+        b, h, w = parts["shape"]
+        y = core.FusedBNApplyCat.apply(True, *args)
+        return y.view(b, h, w, y.shape[1]).permute(0, 3, 1, 2)
+
     def _ups_fused(self, raw):
         """torch.cat of the upsampled maps (:100-104) with each deblock's BatchNorm2d + ReLU writing its channel
         block of the concatenated channels-last map directly (no 144 MB copy forward, no slice copies backward);
-        raw: the deblocks' convolution outputs.  None when the fused kernels do not cover the case."""
+        raw: the deblocks' convolution outputs.  None when the fused kernels do not cover the case.  With head_on_load
+        (two parts, statistics taken by the transposed convolutions) the parts themselves are returned as a dict."""
         from .spconv import core
         if len(raw) < 2 or len(self.deblocks) != len(raw):
             return None
@@ -221,6 +236,9 @@ class BEVBackbone(nn.Module):
             bns.append(mods[1])
         b, _, h, w = maps[0].shape
         rows = [u.permute(0, 2, 3, 1).reshape(b * h * w, u.shape[1]) for u in maps]
+        if all(with_stats) and self.head_on_load and len(raw) == 2 and torch.is_grad_enabled() and HEAD_BN_ON_LOAD \
+                and len(self.deblocks) == len(self.blocks):
+            return dict(shape=(b, h, w), parts=[(r_.contiguous(), u[1], u[2], u[3], bn) for r_, u, bn in zip(rows, raw, bns)])
         if all(with_stats):       # the transposed convolutions took the statistics: one transform launch per part
             args = []
             for r_, u, bn in zip(rows, raw, bns):
@@ -422,6 +440,10 @@ class BEVBackbone(nn.Module):
                 ups.append(self._run_block(self.deblocks[i], x) if len(self.deblocks) > 0 else x)
         if fuse:
             x = self._ups_fused(raw)
+            if isinstance(x, dict):                         # the anchor head reads the parts (head_on_load)
+                data_dict["spatial_features_2d"] = None
+                data_dict["spatial_features_2d_parts"] = x
+                return data_dict
             if x is None:                                   # not covered: BatchNorm + ReLU per map, then concatenate
                 ups = []
                 for i, u in enumerate(raw):
@@ -594,6 +616,75 @@ class _Head1x1(torch.autograd.Function):
         return tuple(out)
 
 
+class _Head1x1Parts(torch.autograd.Function):
+    """_Head1x1 reading the map as the two deblocks' RAW outputs r_p (M, c_p) and applying their training-mode BatchNorm +
+    ReLU on load (coef_p = scale | shift from the transposed convolution's epilogue, glx_head1x1_forward_parts): the
+    concatenated 144 MB map is neither written nor read back.  backward: the weight gradient transforms on load too, the
+    input gradient (M, C) goes through both BatchNorms' backward here (what FusedBNApplyCat.backward did)."""
+
+    @staticmethod
+    def forward(ctx, shape, r0, coef0, mean0, invstd0, g0, b0, r1, coef1, mean1, invstd1, g1, b1, *wb):
+        import ctypes
+        from ._lib import call
+        ws, bs = wb[0::2], wb[1::2]
+        b, h, w = shape
+        M, c0, c1 = b * h * w, r0.shape[1], r1.shape[1]
+        C = c0 + c1
+        outs = [torch.empty((b, h, w, wt.shape[0]), dtype=torch.float32, device=r0.device) for wt in ws]
+        P3, I3 = ctypes.c_void_p * 3, ctypes.c_int32 * 3
+        pad = lambda seq: list(seq) + [None] * (3 - len(seq))                                   # noqa: E731
+        ptr = lambda seq: P3(*[t.data_ptr() if t is not None else None for t in pad(seq)])      # noqa: E731
+        ctx.n = I3(*[int(wt.shape[0]) for wt in ws] + [0] * (3 - len(ws)))
+        ws2 = [wt.detach().reshape(wt.shape[0], C).contiguous() for wt in ws]
+        call("glx_head1x1_forward_parts", r0, r1, c0, coef0, coef1, ctypes.c_int64(M), C, ptr(ws2), ptr([t.detach() for t in bs]),
+             ctx.n, ptr(outs))
+        ctx.save_for_backward(r0, coef0, mean0, invstd0, g0, b0, r1, coef1, mean1, invstd1, g1, b1, *ws2)
+        ctx.dims = (M, c0, c1)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        import ctypes
+        from ._lib import call, query, size_arg
+        from .spconv import core
+        r0, coef0, mean0, invstd0, g0, b0, r1, coef1, mean1, invstd1, g1, b1 = ctx.saved_tensors[:12]
+        ws2 = ctx.saved_tensors[12:]
+        M, c0, c1 = ctx.dims
+        C, dev = c0 + c1, r0.device
+        P3 = ctypes.c_void_p * 3
+        pad = lambda seq: list(seq) + [None] * (3 - len(seq))                                   # noqa: E731
+        ptr = lambda seq: P3(*[t.data_ptr() if t is not None else None for t in pad(seq)])      # noqa: E731
+        gs = [g.contiguous() for g in grads]
+        gws = [torch.empty((wt.shape[0], C, 1, 1), dtype=torch.float32, device=dev) for wt in ws2]
+        gbs = [torch.empty(wt.shape[0], dtype=torch.float32, device=dev) for wt in ws2]
+        side = core.WGRAD_STREAM
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(dev))
+            for t in [r0, r1, coef0, coef1] + gs + gws + gbs:
+                t.record_stream(side)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            nb = query("glx_head1x1_wgrad_workspace_bytes", C)
+            wsp = _lib.workspace.get(nb, dev)
+            call("glx_head1x1_weight_grad_parts", ptr(gs), r0, r1, c0, coef0, coef1, ctypes.c_int64(M), C, ctx.n, ptr(gws),
+                 ptr(gbs), wsp, size_arg(nb))
+        gx = torch.empty((M, C), dtype=torch.float32, device=dev)
+        call("glx_head1x1_input_grad", ptr(gs), ctypes.c_int64(M), C, ptr(list(ws2)), ctx.n, gx)
+        out = [None]
+        col = 0
+        for r_, mean, invstd, gam, bet, c in ((r0, mean0, invstd0, g0, b0, c0), (r1, mean1, invstd1, g1, b1, c1)):
+            dx = torch.empty_like(r_)
+            dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+            dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+            wsb = core.workspace.get(query("glx_bn_workspace_bytes", c), dev)
+            call("glx_bn_relu_backward", r_, gx[:, col:], None, M, c, gam, bet, mean, invstd, 1, dx, dgamma, dbeta, None, wsb,
+                 size_arg(wsb.numel()), core._bn_state(dev), C)
+            out += [dx, None, None, None, dgamma, dbeta]
+            col += c
+        for gw_, gb_ in zip(gws, gbs):
+            out += [gw_, gb_]
+        return tuple(out)
+
+
 class AnchorHead(nn.Module):
     """conv_cls / conv_box / conv_dir_cls, 1x1, with AnchorHeadSingle's bias init (:60-62)."""
 
@@ -648,8 +739,31 @@ class AnchorHead(nn.Module):
                         and c.bias is not None for c in convs)
                 and sum(c.out_channels for c in convs) <= 32)
 
+    def _own_parts(self, parts):
+        convs = [self.conv_cls, self.conv_box] + ([self.conv_dir_cls] if self.conv_dir_cls is not None else [])
+        rows = [p[0] for p in parts["parts"]]
+        c = sum(r.shape[1] for r in rows)
+        return (self.OWN_HEAD and len(rows) == 2 and rows[0].is_cuda and c % 64 == 0 and 64 <= c <= 512
+                and rows[0].shape[1] % 16 == 0 and all(r.is_contiguous() and r.dtype == torch.float32 for r in rows)
+                and all(cv.kernel_size == (1, 1) and cv.stride == (1, 1) and cv.padding == (0, 0) and cv.groups == 1
+                        and cv.bias is not None and cv.in_channels == c for cv in convs)
+                and sum(cv.out_channels for cv in convs) <= 32)
+
     def forward(self, data_dict):
-        x = data_dict["spatial_features_2d"]
+        x = data_dict.get("spatial_features_2d")
+        parts = data_dict.get("spatial_features_2d_parts") if x is None else None
+        if parts is not None and self._own_parts(parts):
+            convs = [self.conv_cls, self.conv_box] + ([self.conv_dir_cls] if self.conv_dir_cls is not None else [])
+            args = []
+            for rows, coef, mean, invstd, bn in parts["parts"]:
+                args += [rows, coef, mean, invstd, bn.weight, bn.bias]
+            outs = _Head1x1Parts.apply(parts["shape"], *args, *[t for c in convs for t in (c.weight, c.bias)])
+            data_dict["cls_preds"], data_dict["box_preds"] = outs[0], outs[1]
+            if self.conv_dir_cls is not None:
+                data_dict["dir_cls_preds"] = outs[2]
+            return data_dict
+        if x is None:                       # the parts were left for us but this head cannot take them: concatenate after all
+            x = data_dict["spatial_features_2d"] = BEVBackbone.concat_parts(parts)
         if self._own(x):
             convs = [self.conv_cls, self.conv_box] + ([self.conv_dir_cls] if self.conv_dir_cls is not None else [])
             outs = _Head1x1.apply(x, *[t for c in convs for t in (c.weight, c.bias)])

@@ -265,6 +265,7 @@ class GLENetVR(nn.Module):
         # the BEV backbone takes the sparse tensor itself (first layer as a sparse conv, dense_path.BEVBackbone)
         self.map_to_bev_module.defer = bool(bev_channels_last) and dp.SPARSE_FIRST_BEV_LAYER
         self.backbone_2d = dp.BEVBackbone(256)
+        self.backbone_2d.head_on_load = bool(bev_channels_last)      # its reader is self.dense_head (dense_path._Head1x1Parts)
         if self.map_to_bev_module.defer:     # its rule table is planned with the sparse backbone's
             d = 256 // self.backbone_3d.num_point_features
             self.backbone_3d.extra_plan = (gb.spconv.core.PlannedConv(dp.BEV_FIRST_KEY, (d, 3, 3), (d, 1, 1), (0, 1, 1),
@@ -353,7 +354,10 @@ class GLENetVR(nn.Module):
             def stamp_when_grad_arrives(t, name):
                 if t is not None and t.requires_grad:
                     t.register_hook(lambda g: mark(name))
-            stamp_when_grad_arrives(bd.get("spatial_features_2d"), "backward: dense-head loss, anchor head" if overlap
+            head_in = bd.get("spatial_features_2d")
+            if head_in is None and bd.get("spatial_features_2d_parts"):       # the head read the deblocks' raw outputs
+                head_in = bd["spatial_features_2d_parts"]["parts"][0][0]
+            stamp_when_grad_arrives(head_in, "backward: dense-head loss, anchor head" if overlap
                                     else "backward: losses, RoI head, anchor head")
             stamp_when_grad_arrives(bd.get("spatial_features_1x"), "backward: BEV deblocks + block 2")
             stamp_when_grad_arrives(bev_cut[1] if bev_cut else getattr(enc, "features", None), "backward: BEV backbone")

@@ -897,6 +897,15 @@ int glx_head1x1_forward(const float* x, int64_t M, int C, const float* const* W,
                         const int32_t* n, float* const* out, void* stream);
 int glx_head1x1_input_grad(const float* const* grad, int64_t M, int C, const float* const* W, const int32_t* n, float* gx,
                            void* stream);
+/* The same two for a map given as two column parts x0 (M, c0) | x1 (M, C - c0) (c0 a multiple of 16) that are transformed on
+ * load, x' = relu(x * scale + shift) with coef_p = scale | shift of part p (2 * its width floats; both NULL: no transform) --
+ * BaseBEVBackbone's deblock outputs with their training-mode BatchNorm + ReLU (base_bev_backbone.py:51-66, 100-104) read
+ * without the concatenated map having been written. */
+int glx_head1x1_forward_parts(const float* x0, const float* x1, int c0, const float* coef0, const float* coef1, int64_t M, int C,
+                              const float* const* W, const float* const* bias, const int32_t* n, float* const* out, void* stream);
+int glx_head1x1_weight_grad_parts(const float* const* grad, const float* x0, const float* x1, int c0, const float* coef0,
+                                  const float* coef1, int64_t M, int C, const int32_t* n, float* const* gW, float* const* gb,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 size_t glx_head1x1_wgrad_workspace_bytes(int C);
 int glx_head1x1_weight_grad(const float* const* grad, const float* x, int64_t M, int C, const int32_t* n, float* const* gW,
                             float* const* gb, void* workspace, size_t workspace_bytes, void* stream);

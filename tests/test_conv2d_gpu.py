@@ -469,3 +469,37 @@ def test_deblock_batchnorm_statistics_in_the_transposed_convolutions_epilogue(de
         assert float((p1.grad - p2.grad).abs().max()) <= 1e-5 * float(p2.grad.abs().max()) + 1e-8, n1
     for (n1, b1), (n2, b2) in zip(na.named_buffers(), nb.named_buffers()):
         assert torch.allclose(b1.float(), b2.float(), rtol=1e-5, atol=1e-7), n1
+
+
+def test_anchor_head_reads_the_deblocks_through_their_batchnorm(dev):
+    """BEVBackbone.head_on_load: the deblocks' raw outputs go to the anchor head, whose kernels apply BatchNorm + ReLU on load
+    (glx_head1x1_forward_parts / _weight_grad_parts) -- the concatenated map (base_bev_backbone.py:100-104) is never written.
+    Against the same modules with the map: predictions bit for bit, every gradient and running statistic."""
+    import copy
+    from glenet_amd import dense_path as dp
+    torch.manual_seed(7)
+    bev = dp.BEVBackbone(64, layer_nums=(1, 1), layer_strides=(1, 2), num_filters=(64, 128), upsample_strides=(1, 2),
+                         num_upsample_filters=(128, 128)).to(dev).train()
+    head = dp.AnchorHead(256, num_class=1, num_anchors_per_location=2).to(dev).train()
+    nets = {True: (bev, head), False: (copy.deepcopy(bev), copy.deepcopy(head))}
+    x = _cl(torch.randn(3, 64, 24, 48, device=dev))       # widths 48 / 24: both deblocks on the own kernels
+    gs, outs = None, {}
+    for on, (b_, h_) in nets.items():
+        b_.head_on_load = on
+        xi = x.clone().requires_grad_(True)
+        bd = h_(b_({"spatial_features": xi}))
+        assert (bd["spatial_features_2d"] is None) == on
+        preds = [bd["cls_preds"], bd["box_preds"], bd["dir_cls_preds"]]
+        if gs is None:
+            gs = [torch.randn_like(p) for p in preds]
+        torch.autograd.backward(preds, gs)
+        outs[on] = ([p.detach() for p in preds], xi.grad)
+    for a, b in zip(outs[True][0], outs[False][0]):
+        assert torch.equal(a, b)
+    ga, gb_ = outs[True][1], outs[False][1]
+    assert float((ga - gb_).abs().max()) <= 1e-5 * float(gb_.abs().max())
+    for mod in (0, 1):
+        for (n1, p1), (n2, p2) in zip(nets[True][mod].named_parameters(), nets[False][mod].named_parameters()):
+            assert float((p1.grad - p2.grad).abs().max()) <= 1e-5 * float(p2.grad.abs().max()) + 1e-8, n1
+        for (n1, b1), (n2, b2) in zip(nets[True][mod].named_buffers(), nets[False][mod].named_buffers()):
+            assert torch.equal(b1, b2), n1
