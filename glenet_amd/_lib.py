@@ -111,7 +111,7 @@ def _p(t):
 class BnStats(ctypes.Structure):
     _fields_ = [("state", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("momentum", c_float),
                 ("coef", c_void_p), ("save_mean", c_void_p), ("save_invstd", c_void_p), ("running_mean", c_void_p),
-                ("running_var", c_void_p)]
+                ("running_var", c_void_p), ("count", ctypes.c_int64)]
 
 
 class Epilogue(ctypes.Structure):
@@ -157,11 +157,11 @@ class FcTowerGrads(ctypes.Structure):
                 ("dw_fc2", c_void_p), ("db_fc2", c_void_p), ("scratch", c_void_p)]
 
 
-def bn_stats(state, bn, coef, save_mean, save_invstd):
+def bn_stats(state, bn, coef, save_mean, save_invstd, count=0):
     """glx_bn_stats of a training-mode torch BatchNorm module (statistics of the convolution in front of it)."""
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     return BnStats(_p(state), _p(bn.weight), _p(bn.bias), float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1),
-                   _p(coef), _p(save_mean), _p(save_invstd), _p(rm), _p(rv))
+                   _p(coef), _p(save_mean), _p(save_invstd), _p(rm), _p(rv), int(count))
 
 
 def epilogue(scale, shift, relu, ldc=0, coff=0):

@@ -17,6 +17,8 @@ struct BnFinalize {
   const float* gamma; const float* beta; float eps, momentum;          // forward
   float* coef; float* save_mean; float* save_invstd; float* running_mean; float* running_var;
   const float* invstd; float* dgamma; float* dbeta;                     // backward
+  long long count;      // > 0: the number of elements per channel the sums stand for (rows that are all zero are not summed:
+                        // the first BEV layer as a sparse convolution, whose BatchNorm2d counts every pixel); 0: the rows
 };
 
 // y = x * scale + shift, written ONE way everywhere: the backward kernels re-derive the ReLU mask (y > 0) from x
@@ -57,6 +59,7 @@ __device__ __forceinline__ bool bn_contribute(BnState* st, int C, const double (
 // The last block: sum the sets (exchanging them for zero), finalize.  s_fin: THREADS x 2 doubles of shared memory.
 template <bool BWD, int THREADS>
 __device__ __forceinline__ void bn_finalize_sets(BnState* st, const BnFinalize& f, int C, int N, double (*s_fin)[2]) {
+  if (f.count > 0) N = (int)(f.count < 2147483647LL ? f.count : 2147483647LL);
   const double cnt = N > 0 ? (double)N : 1.0;
   const int CB = C < THREADS ? C : THREADS, G = THREADS / CB;
   for (int cb = 0; cb < C; cb += CB) {

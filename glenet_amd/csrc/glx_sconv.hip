@@ -2079,7 +2079,7 @@ extern "C" int glx_sconv_forward_ex(const float* in, int N_in, const float* W, c
   if (bnp) {
     GLX_REQUIRE(bnp->state && bnp->coef && bnp->save_mean && bnp->save_invstd, "glx_sconv_forward_ex: BatchNorm statistics: null pointer");
     bn_fin = BnFinalize{bnp->gamma, bnp->beta, bnp->eps, bnp->momentum, bnp->coef, bnp->save_mean, bnp->save_invstd,
-                        bnp->running_mean, bnp->running_var, nullptr, nullptr, nullptr};
+                        bnp->running_mean, bnp->running_var, nullptr, nullptr, nullptr, (long long)bnp->count};
   }
   const glx_bn_bwd_stats* bwd = opts ? opts->bn_bwd : nullptr;
   if (bwd) {

@@ -119,6 +119,7 @@ FUSE_BN_IN_CONV3X3 = os.environ.get("GLX_CONV3X3_BN", "1") != "0"    # ... with 
 # raw convolution output through scale / shift; the next layer's backward carries this BatchNorm's backward): the normalised
 # map of the inner layers of a block is never written (base_bev_backbone.py:36-49)
 BN_ON_LOAD = os.environ.get("GLX_CONV3X3_BN_ON_LOAD", "1") != "0"
+FIRST_LAYER_BN_STATS = os.environ.get("GLX_BEV_FIRST_BN_STATS", "1") != "0"   # first BEV layer (sparse): statistics in its epilogue
 HEAD_BN_ON_LOAD = os.environ.get("GLX_HEAD_BN_ON_LOAD", "1") != "0"    # deblocks' BatchNorm + ReLU applied by the anchor head's kernels
 DECONV_BN_STATS = os.environ.get("GLX_DECONV_BN_STATS", "1") != "0"   # deblocks: BatchNorm statistics in the deconv's epilogue
 
@@ -283,11 +284,23 @@ class BEVBackbone(nn.Module):
             rs = core.build_strided_rules(st, *geom)
         elif rs.ready is not None:                      # built on the plan stream
             torch.cuda.current_stream(st.features.device).wait_event(rs.ready)
-        feats = core.SparseConvFunction.apply(st.features, w, None, rs, False, None, False)
+        bn = mods[2] if len(mods) > 3 and isinstance(mods[3], nn.ReLU) else None
+        stats = None
+        if (FIRST_LAYER_BN_STATS and bn is not None and self._bn_fusable(bn) and bn.num_features == cout and core.USE_BN_STATE
+                and core.FUSE_BN_STATS_IN_CONV and torch.is_grad_enabled() and not (c >= 128 and cout >= 128)
+                and rs.out_spatial_shape[0] == 1):
+            # the layer's BatchNorm2d counts every pixel of the dense map; the cells the sparse convolution does not store
+            # are zeros: the statistics are the rows' sums over B * H * W elements -- taken in the convolution's epilogue
+            pixels = int(st.batch_size) * int(rs.out_spatial_shape[1]) * int(rs.out_spatial_shape[2])
+            feats, *stats = core.SparseConvFunction.apply(st.features, w, None, rs, False, None, False, (bn, pixels))
+            own_conv._count_batch(bn)
+        else:
+            feats = core.SparseConvFunction.apply(st.features, w, None, rs, False, None, False)
         out = core.SparseConvTensor(feats, rs.out_indices, rs.out_spatial_shape, st.batch_size, st.grid, st.voxel_num,
                                     st.indice_dict, st.benchmark, rs.count_out)
         out._index = rs.out_index
-        return out.dense_bev()
+        dense = out.dense_bev()
+        return dense if stats is None else (dense,) + tuple(stats) + (bn,)
 
     # ---- inference: every eval-mode BatchNorm2d (+ ReLU) folded into the epilogue of the convolution in front of it,
     # the deblocks write their slices of the concatenated map, the first layer runs on the sparse tensor
@@ -425,7 +438,10 @@ class BEVBackbone(nn.Module):
         x, ups, raw = x0, [], []
         fuse = self.FUSE_UPS_CAT and len(self.deblocks) == len(self.blocks) and len(self.blocks) > 1
         for i, blk in enumerate(self.blocks):
-            x = self._run_block(blk, first, 2) if (i == 0 and first is not None) else self._run_block(blk, x)
+            if i == 0 and isinstance(first, tuple):       # the first layer's statistics are taken: its BatchNorm + ReLU is pending
+                x = self._run_block(blk, first[0], 4, pending=first)
+            else:
+                x = self._run_block(blk, first, 2) if (i == 0 and first is not None) else self._run_block(blk, x)
             data_dict["spatial_features_%dx" % int(h0 / x.shape[2])] = x
             if fuse:
                 up, ubn = self.deblocks[i][0], (self.deblocks[i][1] if len(self.deblocks[i]) > 1 else None)
@@ -495,13 +511,13 @@ class BEVBackbone(nn.Module):
                 and own_conv.supported(x, conv.weight, (1, 1), (1, 1), _pair(conv.dilation), conv.groups, conv.bias))
 
     @staticmethod
-    def _run_block(blk, x, start=0):
+    def _run_block(blk, x, start=0, pending=None):
         """nn.Sequential semantics with ZeroPad2d(1) + Conv2d(k=3, padding=0) run as ONE convolution with
         padding=1: the same sums over the same zeros, without materialising the padded copy of the input (77 us
         forward + 55 us backward for the 144 MB BEV map) -- module list and parameter names stay the reference's."""
         mods = list(blk)
         i = start
-        pending = None        # (y, coef, mean, invstd, bn) of a conv whose BatchNorm + ReLU the NEXT conv applies on load
+        # pending: (y, coef, mean, invstd, bn) of a conv whose BatchNorm + ReLU the NEXT conv applies on load
         while i < len(mods):
             m = mods[i]
             conv, step = None, 1

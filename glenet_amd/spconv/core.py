@@ -410,9 +410,12 @@ def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rule
             opts = opts or _lib.SconvOpts()
             opts.tile_map = tmap.data_ptr()
     stats = None
+    bn_count = 0
+    if isinstance(bn, tuple):       # (module, elements per channel): statistics over more than the rows (zeros not stored)
+        bn, bn_count = bn
     if bn is not None:
         stats = tuple(torch.empty(n, dtype=torch.float32, device=features.device) for n in (2 * cout, cout, cout))
-        st = _lib.bn_stats(_bn_state(features.device), bn, *stats)
+        st = _lib.bn_stats(_bn_state(features.device), bn, *stats, count=bn_count)
         opts = opts or _lib.SconvOpts()
         opts.bn = ctypes.pointer(st)
     if bwd_bn is not None:

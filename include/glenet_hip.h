@@ -65,6 +65,9 @@ typedef struct glx_bn_stats {
   float* save_invstd;
   float* running_mean;
   float* running_var;
+  int64_t count;   /* glx_sconv_forward_ex only: > 0 = elements per channel the statistics stand for when that is more than the
+                    * output rows (the rest are zeros nobody stores: BaseBEVBackbone's first layer run as a sparse convolution,
+                    * whose BatchNorm2d counts every pixel of the dense map); 0: the live output rows */
 } glx_bn_stats;
 typedef struct glx_epilogue {
   const float* scale;
