@@ -653,6 +653,13 @@ extern "C" int glx_conv3x3s2_forward_ex(const float* x, int B, int H, int W, int
               "glx_conv3x3s2_forward: bad sizes (%d, %d, %d), %d -> %d (even maps, Cin %% 32, Cout %% 64)", B, H, W, Cin, Cout);
   return pconv_launch(x, packed_fwd, y, B, H / 2, W / 2, Cin, Cout, 2, 1, (hipStream_t)stream, 1, epilogue);
 }
+// ... with the training-mode BatchNorm statistics of y taken in the epilogue (contract of glx_bn_stats / glx_conv_opts.bn)
+extern "C" int glx_conv3x3s2_forward_bn(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout,
+                                        float* y, const glx_bn_stats* bn, void* stream) {
+  GLX_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cin % 32 == 0 && Cout % 64 == 0 && bn,
+              "glx_conv3x3s2_forward_bn: bad sizes (%d, %d, %d), %d -> %d (even maps, Cin %% 32, Cout %% 64)", B, H, W, Cin, Cout);
+  return pconv_launch(x, packed_fwd, y, B, H / 2, W / 2, Cin, Cout, 2, 1, (hipStream_t)stream, 1, nullptr, bn);
+}
 extern "C" int glx_conv3x3s2_forward(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, float* y,
                                      void* stream) {
   return glx_conv3x3s2_forward_ex(x, B, H, W, Cin, packed_fwd, Cout, y, nullptr, stream);

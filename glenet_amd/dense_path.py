@@ -78,27 +78,42 @@ class _OwnStridedForward(torch.autograd.Function):
     differ by up to 1 % in every weight gradient upstream (tools/step_repeat.py)."""
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, bn=None):
+        """bn: the training-mode BatchNorm2d behind the layer -- statistics in the kernel's epilogue
+        (glx_conv3x3s2_forward_bn), returns (y, coef, save_mean, save_invstd)."""
+        import ctypes
         from ._lib import call
         b, c, h, wd = x.shape
         cout = int(w.shape[0])
         fwd, _ = own_conv.packs(w)
         xd = x.detach()
         y = torch.empty((b, cout, h // 2, wd // 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-        call("glx_conv3x3s2_forward", xd, b, h, wd, c, fwd, cout, y)
         ctx.cfg = ((2, 2), (1, 1), (1, 1), False, (0, 0), 1)
         ctx.bias_sizes = None
         ctx.save_for_backward(x, w)
-        return y
+        if bn is None:
+            call("glx_conv3x3s2_forward", xd, b, h, wd, c, fwd, cout, y)
+            return y
+        from .spconv import core
+        stats = tuple(torch.empty(n, dtype=torch.float32, device=x.device) for n in (2 * cout, cout, cout))
+        st = _lib.bn_stats(core._bn_state(x.device), bn, *stats)
+        call("glx_conv3x3s2_forward_bn", xd, b, h, wd, c, fwd, cout, y, ctypes.byref(st))
+        if bn.track_running_stats:
+            _lib.bump_weights_epoch((bn.running_mean, bn.running_var))
+        ctx.mark_non_differentiable(*stats)
+        ctx.set_materialize_grads(False)
+        return (y,) + stats
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, *_):
+        if gy is None:
+            return None, None, None
         # (x, w, bias, ...) of _ConvSplitBackward: needs_input_grad has two entries here, the helper reads [0], [1] and [2].
         # A plain namespace, not a class: a class object sits in a reference cycle and would keep the saved activation --
         # and the whole graph above it -- alive until the collector runs.
         shim = types.SimpleNamespace(saved_tensors=ctx.saved_tensors, cfg=ctx.cfg, bias_sizes=None,
                                      needs_input_grad=(ctx.needs_input_grad[0], ctx.needs_input_grad[1], False))
-        return _ConvSplitBackward.backward(shim, gy.contiguous(memory_format=torch.channels_last))[:2]
+        return _ConvSplitBackward.backward(shim, gy.contiguous(memory_format=torch.channels_last))[:2] + (None,)
 
 
 def _own_strided_ok(x, w, stride, padding, dilation, groups, bias):
@@ -119,6 +134,7 @@ FUSE_BN_IN_CONV3X3 = os.environ.get("GLX_CONV3X3_BN", "1") != "0"    # ... with 
 # raw convolution output through scale / shift; the next layer's backward carries this BatchNorm's backward): the normalised
 # map of the inner layers of a block is never written (base_bev_backbone.py:36-49)
 BN_ON_LOAD = os.environ.get("GLX_CONV3X3_BN_ON_LOAD", "1") != "0"
+STRIDED_BN_STATS = os.environ.get("GLX_BEV_S2_BN_STATS", "1") != "0"          # a block's strided layer: statistics in its epilogue
 FIRST_LAYER_BN_STATS = os.environ.get("GLX_BEV_FIRST_BN_STATS", "1") != "0"   # first BEV layer (sparse): statistics in its epilogue
 HEAD_BN_ON_LOAD = os.environ.get("GLX_HEAD_BN_ON_LOAD", "1") != "0"    # deblocks' BatchNorm + ReLU applied by the anchor head's kernels
 DECONV_BN_STATS = os.environ.get("GLX_DECONV_BN_STATS", "1") != "0"   # deblocks: BatchNorm statistics in the deconv's epilogue
@@ -549,6 +565,22 @@ class BEVBackbone(nn.Module):
                     else:
                         x = own_conv.bn_apply(raw, relu)
                     i = nxt
+                    continue
+                if (STRIDED_BN_STATS and BN_ON_LOAD and torch.is_grad_enabled() and _leaf(conv.weight) and BEVBackbone._bn_fusable(bn)
+                        and own_conv.bn_state_available() and bn.num_features == conv.out_channels
+                        and _own_strided_ok(x, conv.weight, _pair(conv.stride), pad, _pair(conv.dilation), conv.groups, conv.bias)
+                        and j + 2 < len(mods) and isinstance(mods[j + 1], nn.ReLU) and isinstance(mods[j + 2], nn.Conv2d)
+                        and j + 3 < len(mods)):
+                    # the strided layer of a block: statistics in its epilogue, BatchNorm + ReLU on load in the next layer
+                    raw = _OwnStridedForward.apply(x, conv.weight, bn)
+                    if BEVBackbone._own_bn_conv(mods[j + 2], mods[j + 3], raw[0]):
+                        own_conv._count_batch(bn)
+                        pending, x = raw + (bn,), raw[0]
+                        i = j + 2
+                        continue
+                    own_conv._count_batch(bn)
+                    x = own_conv.bn_apply(raw + (bn,), True)
+                    i = j + 2
                     continue
                 x = conv2d(x, conv.weight, conv.bias, conv.stride, pad, conv.dilation, conv.groups)
                 i += step

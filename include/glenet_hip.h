@@ -1054,6 +1054,9 @@ int glx_deconv_forward_ex(const float* x, int B, int H, int W, int Cin, const vo
  * updated) -- the BatchNorm2d behind a deblock's ConvTranspose2d (base_bev_backbone.py:51-66). */
 int glx_deconv_forward_bn(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, int u, float* y,
                           const glx_bn_stats* bn, void* stream);
+/* ... with the training-mode BatchNorm statistics of y in the epilogue (glx_bn_stats as for glx_conv3x3_forward_ex). */
+int glx_conv3x3s2_forward_bn(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, float* y,
+                             const glx_bn_stats* bn, void* stream);
 int glx_conv3x3s2_forward_ex(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, float* y,
                              const glx_epilogue* epilogue, void* stream);
 size_t glx_deconv_wgrad_workspace_bytes(int Cin, int Cout, int u);
