@@ -8,6 +8,7 @@
 // All three kernels are exact-fp32 v_mfma_f32_16x16x4_f32 GEMMs with M = pixels; the concatenated filters (<= 32 rows,
 // zero padded) sit in LDS.
 #include "glx_common.h"
+#include "glx_bn_state.h"
 
 typedef float hf32x4 __attribute__((ext_vector_type(4)));
 
@@ -172,6 +173,127 @@ __global__ __launch_bounds__(HD_THREADS) void k_head_dgrad(HeadGrad g, long long
       }
     }
   }
+}
+
+// The input gradient for a head that read its map through two BatchNorm + ReLU transforms (HeadIn with coefficients): the
+// gradient of the transformed map is masked with the ReLU (re-derived from the raw value, like every BatchNorm backward here),
+// written per part as dz, and its two BatchNorm-backward sums per channel -- sum dz, sum dz * xhat -- are taken on the way
+// (block sums -> the stream's BnState accumulators -> the last block writes gamma * invstd | mean dz | mean dz xhat for
+// glx_bn_backward_apply, and dgamma / dbeta): the two statistics passes over the 144 MB map (31 + 43 us) are gone.  C = 256.
+struct HeadBnBwd {
+  const float* y[2];       // raw parts (M, c_p)
+  const float* coef[2];    // forward scale | shift
+  const float* mean[2];
+  const float* invstd[2];
+  const float* gamma[2];
+  float* dz[2];            // (M, c_p) masked gradients
+  float* coef3[2];         // 3 * c_p
+  float* dgamma[2];
+  float* dbeta[2];
+  BnState* state;
+  int c0;
+};
+
+__global__ __launch_bounds__(HD_THREADS) void k_head_dgrad_bn(HeadGrad g, long long M, HeadW hw, HeadBnBwd bb) {
+  constexpr int C = 256, NT = C / 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_w = smem;                                    // HD_MAXO x (C + 4)
+  const int ld = C + 4;
+  float* s_par = s_w + HD_MAXO * ld;                    // scale | shift | mean | invstd, C each (concatenated channel order)
+  float* s_sum = s_par + 4 * C;                         // 4 waves x C x 2
+  __shared__ int s_last;
+  hd_load_w(hw.w, hw.n, C, s_w);
+  const int c0 = bb.c0, c1 = C - bb.c0;
+  for (int c = threadIdx.x; c < C; c += HD_THREADS) {
+    const int p = c < c0 ? 0 : 1, cc = c - (p ? c0 : 0), cp = p ? c1 : c0;
+    s_par[c] = bb.coef[p][cc];
+    s_par[C + c] = bb.coef[p][cp + cc];
+    s_par[2 * C + c] = bb.mean[p][cc];
+    s_par[3 * C + c] = bb.invstd[p][cc];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  for (int e = threadIdx.x; e < 4 * C * 2; e += HD_THREADS) s_sum[e] = 0.f;     // per wave and channel: owned by one lane
+  __syncthreads();
+  for (long long m0 = (long long)blockIdx.x * HD_PIX; m0 < M; m0 += (long long)gridDim.x * HD_PIX) {
+    const long long m = m0 + wave * 16 + i;
+    float ga[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int o = 4 * s + kq;
+      float v = 0.f;
+      if (m < M) {
+        if (o < g.n[0]) v = g.p[0][m * g.n[0] + o];
+        else if (o < g.n[0] + g.n[1]) v = g.p[1][m * g.n[1] + (o - g.n[0])];
+        else if (o < g.n[0] + g.n[1] + g.n[2]) v = g.p[2][m * g.n[2] + (o - g.n[0] - g.n[1])];
+      }
+      ga[s] = v;
+    }
+#pragma unroll 2
+    for (int t = 0; t < NT; ++t) {
+      const int c = 16 * t + i;
+      const int p = 16 * t < c0 ? 0 : 1, cc = c - (p ? c0 : 0), cp = p ? c1 : c0;
+      const float* yp = bb.y[p];
+      float yv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const long long mm = m0 + wave * 16 + 4 * kq + e;
+        yv[e] = yp[(mm < M ? mm : M - 1) * cp + cc];
+      }
+      hf32x4 acc = hf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const float wv = s_w[(4 * s + kq) * ld + c];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], wv, acc, 0, 0, 0);
+      }
+      const float sc = s_par[c], sh = s_par[C + c], mu = s_par[2 * C + c], is = s_par[3 * C + c];
+      float* dzp = bb.dz[p];
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const long long mm = m0 + wave * 16 + 4 * kq + e;
+        if (mm < M) {
+          const float gv = bn_affine(yv[e], sc, sh) > 0.f ? acc[e] : 0.f;
+          dzp[mm * cp + cc] = gv;
+          t1 += gv;
+          t2 += gv * ((yv[e] - mu) * is);
+        }
+      }
+      t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
+      t2 += __shfl_xor(t2, 16, 64); t2 += __shfl_xor(t2, 32, 64);
+      if (kq == 0) {
+        s_sum[(wave * C + c) * 2] += t1;
+        s_sum[(wave * C + c) * 2 + 1] += t2;
+      }
+    }
+  }
+  __syncthreads();
+  double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+  if (threadIdx.x < C / 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        a0[j] += (double)s_sum[(w * C + 4 * threadIdx.x + j) * 2];
+        a1[j] += (double)s_sum[(w * C + 4 * threadIdx.x + j) * 2 + 1];
+      }
+  }
+  if (!bn_contribute(bb.state, C, a0, a1, gridDim.x, &s_last)) return;
+  // the last block: the sets' totals (exchanged for zero), the coefficients of the transform, dgamma / dbeta
+  const double cnt = (double)M;
+  for (int c = threadIdx.x; c < C; c += HD_THREADS) {
+    double s = 0, ss = 0;
+    for (int k = 0; k < BN_SETS; ++k) { s += bn_take(&bb.state->acc[k][c]); ss += bn_take(&bb.state->acc[k][BN_MAXC + c]); }
+    const int p = c < c0 ? 0 : 1, cc = c - (p ? c0 : 0), cp = p ? c1 : c0;
+    bb.coef3[p][cc] = (bb.gamma[p] ? bb.gamma[p][cc] : 1.f) * bb.invstd[p][cc];
+    bb.coef3[p][cp + cc] = (float)(s / cnt);
+    bb.coef3[p][2 * cp + cc] = (float)(ss / cnt);
+    bb.dgamma[p][cc] = (float)ss;
+    bb.dbeta[p][cc] = (float)s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&bb.state->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // gW[o, c] = sum_m g[m, o] x[m, c], gb[o] = sum_m g[m, o]: contraction over pixels.  A = g^T (lane (i, kq): output channel
@@ -355,6 +477,41 @@ extern "C" int glx_head1x1_input_grad(const float* const* grad, int64_t M, int C
   long long blocks = (M + HD_PIX - 1) / HD_PIX;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(k_head_dgrad, dim3((unsigned)blocks), dim3(HD_THREADS), lds, (hipStream_t)stream, hg, (long long)M, C, hw, gx);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+extern "C" int glx_head1x1_input_grad_bn(const float* const* grad, int64_t M, int C, const float* const* W, const int32_t* n,
+                                         const float* y0, const float* y1, int c0, const glx_bn_bwd_stats* bn0,
+                                         const glx_bn_bwd_stats* bn1, float* dz0, float* dz1, void* stream) {
+  GLX_REQUIRE(grad && W && n && y0 && y1 && bn0 && bn1 && dz0 && dz1, "glx_head1x1_input_grad_bn: null pointer");
+  GLX_REQUIRE(C == 256 && c0 > 0 && c0 < C && c0 % 16 == 0, "glx_head1x1_input_grad_bn: C = %d (256), first part %d", C, c0);
+  int rc = head_check(M, C, n, "glx_head1x1_input_grad_bn");
+  if (rc != GLX_OK) return rc;
+  GLX_REQUIRE(M < 2147483647LL / 4, "glx_head1x1_input_grad_bn: %lld pixels", (long long)M);
+  const glx_bn_bwd_stats* b[2] = {bn0, bn1};
+  HeadBnBwd bb;
+  bb.y[0] = y0; bb.y[1] = y1; bb.dz[0] = dz0; bb.dz[1] = dz1; bb.c0 = c0;
+  for (int p = 0; p < 2; ++p) {
+    GLX_REQUIRE(b[p]->state && b[p]->coef_fwd && b[p]->mean && b[p]->invstd && b[p]->coef && b[p]->dgamma && b[p]->dbeta,
+                "glx_head1x1_input_grad_bn: part %d: null pointer", p);
+    GLX_REQUIRE(b[p]->state == bn0->state, "glx_head1x1_input_grad_bn: the parts share the stream's accumulator");
+    bb.coef[p] = b[p]->coef_fwd; bb.mean[p] = b[p]->mean; bb.invstd[p] = b[p]->invstd; bb.gamma[p] = b[p]->gamma;
+    bb.coef3[p] = b[p]->coef; bb.dgamma[p] = b[p]->dgamma; bb.dbeta[p] = b[p]->dbeta;
+  }
+  bb.state = (BnState*)bn0->state;
+  HeadW hw; HeadGrad hg;
+  for (int k = 0; k < 3; ++k) {
+    hw.w[k] = W[k]; hw.b[k] = nullptr; hw.n[k] = n[k];
+    hg.p[k] = grad[k]; hg.n[k] = n[k];
+    GLX_REQUIRE(n[k] == 0 || (W[k] && grad[k]), "glx_head1x1_input_grad_bn: head %d has no weights / gradient", k);
+  }
+  const size_t lds = (size_t)HD_MAXO * (C + 4) * 4 + (size_t)4 * C * 4 + (size_t)4 * C * 2 * 4;
+  rc = head_lds_attr((const void*)k_head_dgrad_bn, lds);
+  if (rc != GLX_OK) return rc;
+  long long blocks = (M + HD_PIX - 1) / HD_PIX;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_head_dgrad_bn, dim3((unsigned)blocks), dim3(HD_THREADS), lds, (hipStream_t)stream, hg, (long long)M, hw, bb);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

@@ -136,6 +136,7 @@ FUSE_BN_IN_CONV3X3 = os.environ.get("GLX_CONV3X3_BN", "1") != "0"    # ... with 
 BN_ON_LOAD = os.environ.get("GLX_CONV3X3_BN_ON_LOAD", "1") != "0"
 STRIDED_BN_STATS = os.environ.get("GLX_BEV_S2_BN_STATS", "1") != "0"          # a block's strided layer: statistics in its epilogue
 FIRST_LAYER_BN_STATS = os.environ.get("GLX_BEV_FIRST_BN_STATS", "1") != "0"   # first BEV layer (sparse): statistics in its epilogue
+HEAD_DGRAD_BN = os.environ.get("GLX_HEAD_DGRAD_BN", "1") != "0"        # ... and their backward sums in the head's input gradient
 HEAD_BN_ON_LOAD = os.environ.get("GLX_HEAD_BN_ON_LOAD", "1") != "0"    # deblocks' BatchNorm + ReLU applied by the anchor head's kernels
 DECONV_BN_STATS = os.environ.get("GLX_DECONV_BN_STATS", "1") != "0"   # deblocks: BatchNorm statistics in the deconv's epilogue
 
@@ -715,19 +716,40 @@ class _Head1x1Parts(torch.autograd.Function):
             wsp = _lib.workspace.get(nb, dev)
             call("glx_head1x1_weight_grad_parts", ptr(gs), r0, r1, c0, coef0, coef1, ctypes.c_int64(M), C, ctx.n, ptr(gws),
                  ptr(gbs), wsp, size_arg(nb))
-        gx = torch.empty((M, C), dtype=torch.float32, device=dev)
-        call("glx_head1x1_input_grad", ptr(gs), ctypes.c_int64(M), C, ptr(list(ws2)), ctx.n, gx)
         out = [None]
-        col = 0
-        for r_, mean, invstd, gam, bet, c in ((r0, mean0, invstd0, g0, b0, c0), (r1, mean1, invstd1, g1, b1, c1)):
-            dx = torch.empty_like(r_)
-            dgamma = torch.empty(c, dtype=torch.float32, device=dev)
-            dbeta = torch.empty(c, dtype=torch.float32, device=dev)
-            wsb = core.workspace.get(query("glx_bn_workspace_bytes", c), dev)
-            call("glx_bn_relu_backward", r_, gx[:, col:], None, M, c, gam, bet, mean, invstd, 1, dx, dgamma, dbeta, None, wsb,
-                 size_arg(wsb.numel()), core._bn_state(dev), C)
-            out += [dx, None, None, None, dgamma, dbeta]
-            col += c
+        parts = ((r0, coef0, mean0, invstd0, g0, b0, c0), (r1, coef1, mean1, invstd1, g1, b1, c1))
+        if HEAD_DGRAD_BN and C == 256 and core.USE_BN_STATE:
+            # the input-gradient launch masks with the two ReLUs and takes both BatchNorm backwards' sums (no statistics pass
+            # over the 144 MB map); what is left per part is the transform
+            state = core._bn_state(dev)
+            dzs, bns, res = [], [], []
+            for r_, coef, mean, invstd, gam, bet, c in parts:
+                dz = torch.empty_like(r_)
+                coef3 = torch.empty(3 * c, dtype=torch.float32, device=dev)
+                dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+                dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+                bns.append(_lib.BnBwdStats(*[_lib._p(t) for t in (state, None, coef, mean, invstd, gam, coef3, dgamma, dbeta)]))
+                dzs.append(dz)
+                res.append((coef3, dgamma, dbeta))
+            call("glx_head1x1_input_grad_bn", ptr(gs), ctypes.c_int64(M), C, ptr(list(ws2)), ctx.n, r0, r1, c0,
+                 ctypes.byref(bns[0]), ctypes.byref(bns[1]), dzs[0], dzs[1])
+            for (r_, coef, mean, invstd, gam, bet, c), dz, (coef3, dgamma, dbeta) in zip(parts, dzs, res):
+                dx = torch.empty_like(r_)
+                call("glx_bn_backward_apply", r_, dz, coef3, mean, invstd, M, c, None, dx)
+                out += [dx, None, None, None, dgamma, dbeta]
+        else:
+            gx = torch.empty((M, C), dtype=torch.float32, device=dev)
+            call("glx_head1x1_input_grad", ptr(gs), ctypes.c_int64(M), C, ptr(list(ws2)), ctx.n, gx)
+            col = 0
+            for r_, coef, mean, invstd, gam, bet, c in parts:
+                dx = torch.empty_like(r_)
+                dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+                dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+                wsb = core.workspace.get(query("glx_bn_workspace_bytes", c), dev)
+                call("glx_bn_relu_backward", r_, gx[:, col:], None, M, c, gam, bet, mean, invstd, 1, dx, dgamma, dbeta, None, wsb,
+                     size_arg(wsb.numel()), core._bn_state(dev), C)
+                out += [dx, None, None, None, dgamma, dbeta]
+                col += c
         for gw_, gb_ in zip(gws, gbs):
             out += [gw_, gb_]
         return tuple(out)

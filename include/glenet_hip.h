@@ -909,6 +909,13 @@ int glx_head1x1_forward_parts(const float* x0, const float* x1, int c0, const fl
 int glx_head1x1_weight_grad_parts(const float* const* grad, const float* x0, const float* x1, int c0, const float* coef0,
                                   const float* coef1, int64_t M, int C, const int32_t* n, float* const* gW, float* const* gb,
                                   void* workspace, size_t workspace_bytes, void* stream);
+/* The input gradient of glx_head1x1_forward_parts WITH the two BatchNorm + ReLU transforms' backward sums: dz_p (M, c_p) = the
+ * gradient of part p's transformed map masked with its ReLU; bn_p (glx_bn_bwd_stats: y unused, coef_fwd = the forward scale |
+ * shift, mean, invstd, gamma; outputs coef (3 * c_p) for glx_bn_backward_apply, dgamma, dbeta; both parts name the same
+ * `state`).  C = 256.  Replaces glx_head1x1_input_grad + the statistics launch of each part's BatchNorm backward. */
+int glx_head1x1_input_grad_bn(const float* const* grad, int64_t M, int C, const float* const* W, const int32_t* n, const float* y0,
+                              const float* y1, int c0, const glx_bn_bwd_stats* bn0, const glx_bn_bwd_stats* bn1, float* dz0,
+                              float* dz1, void* stream);
 size_t glx_head1x1_wgrad_workspace_bytes(int C);
 int glx_head1x1_weight_grad(const float* const* grad, const float* x, int64_t M, int C, const int32_t* n, float* const* gW,
                             float* const* gb, void* workspace, size_t workspace_bytes, void* stream);
