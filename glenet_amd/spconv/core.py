@@ -159,11 +159,22 @@ class RuleSet:
         return pl
 
     def inverse_table(self):
+        """The table of the transposed rules (input row -> output rows): what the input gradient of a strided convolution
+        walks.  Built on first use on the caller's stream -- a training plan builds it ahead, on the plan stream
+        (plan_rules(pair_lists=True)): two launches per table that sat in the backward chain of the main stream."""
+        cur = torch.cuda.current_stream(self.nbr.device)
         if self.nbr_in is None:
             dev = self.nbr.device
             self.nbr_in = torch.empty((max(self.N_in, 1), self.K), dtype=torch.int32, device=dev)
             call("glx_rules_invert", self.nbr, self.N_out, self.K, self.N_in, self.nbr_in,
                  self.count_out)
+            self._nbr_in_built = (cur, torch.cuda.Event())
+            self._nbr_in_built[1].record(cur)
+            return self.nbr_in
+        built = getattr(self, "_nbr_in_built", None)
+        if built is not None and built[0] != cur:
+            cur.wait_event(built[1])
+            self.nbr_in.record_stream(cur)
         return self.nbr_in
 
 
@@ -290,6 +301,10 @@ def plan_rules(indices, spatial_shape, batch_size, convs, index=None, count=None
         for rs in x.indice_dict.values():
             if rs.nbr is not None and rs.N_out > 0:
                 rs.pair_lists(rs.nbr, rs.N_out, rs.count_out)
+    if pair_lists and INVERSE_TABLES_IN_PLAN:          # a training plan: the strided tables' transposes, for the input gradients
+        for rs in x.indice_dict.values():
+            if rs.nbr is not None and not rs.subm and rs.N_out > 0 and rs.N_in > 0:
+                rs.inverse_table()
     return x.indice_dict
 
 
@@ -1129,6 +1144,7 @@ USE_FUSED_TRAIN_BN = os.environ.get("GLX_FUSED_BN", "1") != "0"
 # work-balanced block -> tile maps for the sparse-conv kernels (RuleSet.tile_map); off with GLX_TILE_MAP=0
 USE_TILE_MAP = os.environ.get("GLX_TILE_MAP", "1") != "0"
 USE_PAIR_LISTS = os.environ.get("GLX_PAIR_LISTS", "1") != "0"      # weight gradients over per-offset pair lists
+INVERSE_TABLES_IN_PLAN = os.environ.get("GLX_INVERSE_TABLES_IN_PLAN", "1") != "0"
 PAIR_LISTS_IN_PLAN = os.environ.get("GLX_PAIR_LISTS_IN_PLAN", "1") != "0"   # built behind the rule tables (0: by the first weight gradient)
 TILE_MAP_MIN_ROWS = 64 * 256       # fewer tiles than CUs: nothing to balance
 # building a map costs two small launches (~8 us): worth it for the rule tables of submanifold stacks
