@@ -9,6 +9,7 @@
 // zero padded) sit in LDS.
 #include "glx_common.h"
 #include "glx_bn_state.h"
+#include <stdlib.h>
 
 typedef float hf32x4 __attribute__((ext_vector_type(4)));
 
@@ -49,6 +50,7 @@ struct HeadIn {
   const float* x[2];
   const float* coef[2];
   int c0;
+  int quad;      // k_head_wgrad, C = 256: a lane's four column tiles as one 16-byte load (GLX_HEAD_WGRAD_QUAD=0: off)
 };
 
 struct HeadW {
@@ -232,39 +234,42 @@ __global__ __launch_bounds__(HD_THREADS) void k_head_dgrad_bn(HeadGrad g, long l
     }
 #pragma unroll 2
     for (int t = 0; t < NT; ++t) {
-      const int c = 16 * t + i;
+      // operands swapped against k_head_dgrad: D rows = channels 16 t + 4 kq + e, column = pixel i -- a lane holds FOUR
+      // CONSECUTIVE CHANNELS of one pixel, so the raw map is read and dz written with 16-byte accesses
+      const int c = 16 * t + 4 * kq;
       const int p = 16 * t < c0 ? 0 : 1, cc = c - (p ? c0 : 0), cp = p ? c1 : c0;
-      const float* yp = bb.y[p];
-      float yv[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const long long mm = m0 + wave * 16 + 4 * kq + e;
-        yv[e] = yp[(mm < M ? mm : M - 1) * cp + cc];
-      }
+      const long long mc = m < M ? m : M - 1;
+      const hf32x4 yv = *reinterpret_cast<const hf32x4*>(bb.y[p] + mc * cp + cc);
       hf32x4 acc = hf32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        const float wv = s_w[(4 * s + kq) * ld + c];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], wv, acc, 0, 0, 0);
+        const float wv = s_w[(4 * s + kq) * ld + 16 * t + i];      // A[m = channel 16 t + i][k = o = 4 s + kq]
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, ga[s], acc, 0, 0, 0);
       }
-      const float sc = s_par[c], sh = s_par[C + c], mu = s_par[2 * C + c], is = s_par[3 * C + c];
-      float* dzp = bb.dz[p];
-      float t1 = 0.f, t2 = 0.f;
+      const hf32x4 sc = *reinterpret_cast<const hf32x4*>(s_par + c), sh = *reinterpret_cast<const hf32x4*>(s_par + C + c);
+      const hf32x4 mu = *reinterpret_cast<const hf32x4*>(s_par + 2 * C + c), is = *reinterpret_cast<const hf32x4*>(s_par + 3 * C + c);
+      hf32x4 gv, gx2;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const long long mm = m0 + wave * 16 + 4 * kq + e;
-        if (mm < M) {
-          const float gv = bn_affine(yv[e], sc, sh) > 0.f ? acc[e] : 0.f;
-          dzp[mm * cp + cc] = gv;
-          t1 += gv;
-          t2 += gv * ((yv[e] - mu) * is);
+        gv[e] = (m < M && bn_affine(yv[e], sc[e], sh[e]) > 0.f) ? acc[e] : 0.f;
+        gx2[e] = gv[e] * ((yv[e] - mu[e]) * is[e]);
+      }
+      if (m < M) *reinterpret_cast<hf32x4*>(bb.dz[p] + m * cp + cc) = gv;
+      // sums over the wave's 16 pixels (the lanes i of a kq group)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int x = 1; x < 16; x <<= 1) {
+          gv[e] += __shfl_xor(gv[e], x, 64);
+          gx2[e] += __shfl_xor(gx2[e], x, 64);
         }
       }
-      t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
-      t2 += __shfl_xor(t2, 16, 64); t2 += __shfl_xor(t2, 32, 64);
-      if (kq == 0) {
-        s_sum[(wave * C + c) * 2] += t1;
-        s_sum[(wave * C + c) * 2 + 1] += t2;
+      if (i == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s_sum[(wave * C + c + e) * 2] += gv[e];
+          s_sum[(wave * C + c + e) * 2 + 1] += gx2[e];
+        }
       }
     }
   }
@@ -308,9 +313,12 @@ __global__ __launch_bounds__(HD_THREADS) void k_head_wgrad(HeadGrad g, HeadIn in
   const bool pre = in.coef[0] != nullptr;
   const int c0 = in.c0, c1 = C - in.c0;
   float psc[8], psh[8];                                 // the input transform of this lane's channels 16 (wave tpw + u) + i
+  // C = 256 (four column tiles per wave): tile u of lane i is channel 64 wave + 4 i + u, so that a lane's four tiles are ONE
+  // 16-byte load of the pixel's row (16 lanes = 256 contiguous bytes); other widths: channel 16 (wave tpw + u) + i
+  const bool quad = tpw == 4 && in.quad;
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
-    const int c = 16 * (wave * tpw + u) + i;
+    const int c = quad ? 64 * wave + 4 * i + u : 16 * (wave * tpw + u) + i;
     psc[u] = 1.f; psh[u] = 0.f;
     if (pre && u < tpw) {
       psc[u] = c < c0 ? in.coef[0][c] : in.coef[1][c - c0];
@@ -340,14 +348,26 @@ __global__ __launch_bounds__(HD_THREADS) void k_head_wgrad(HeadGrad g, HeadIn in
       a0[s] = gval(m, i);
       a1[s] = gval(m, 16 + i);
       const long long mc = m < hi ? m : hi - 1;
-      const float* row0 = in.x[0] + mc * c0 + i;
-      const float* row1 = in.x[1] ? in.x[1] + mc * c1 + i - c0 : row0;
+      if (quad) {
+        const int ch = 64 * wave + 4 * i;
+        const float* src = ch < c0 ? in.x[0] + mc * c0 + ch : in.x[1] + mc * c1 + ch - c0;
+        const hf32x4 v4 = *reinterpret_cast<const hf32x4*>(src);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int ch = 16 * (wave * tpw + u);
-        float v = (u < tpw && m < hi) ? (ch < c0 ? row0 : row1)[ch] : 0.f;
-        if (pre && u < tpw && m < hi) v = fmaxf(__fmaf_rn(v, psc[u], psh[u]), 0.f);
-        xb[s][u] = v;
+        for (int u = 0; u < 8; ++u) {
+          float v = (u < 4 && m < hi) ? v4[u & 3] : 0.f;
+          if (pre && u < 4 && m < hi) v = fmaxf(__fmaf_rn(v, psc[u], psh[u]), 0.f);
+          xb[s][u] = v;
+        }
+      } else {
+        const float* row0 = in.x[0] + mc * c0 + i;
+        const float* row1 = in.x[1] ? in.x[1] + mc * c1 + i - c0 : row0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int ch = 16 * (wave * tpw + u);
+          float v = (u < tpw && m < hi) ? (ch < c0 ? row0 : row1)[ch] : 0.f;
+          if (pre && u < tpw && m < hi) v = fmaxf(__fmaf_rn(v, psc[u], psh[u]), 0.f);
+          xb[s][u] = v;
+        }
       }
     }
 #pragma unroll
@@ -371,7 +391,8 @@ __global__ __launch_bounds__(HD_THREADS) void k_head_wgrad(HeadGrad g, HeadIn in
     for (int u = 0; u < 8; ++u)
       if (u < tpw)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dst[(16 * h + 4 * kq + e) * (C + 1) + 16 * (wave * tpw + u) + i] = acc[h][u][e];
+        for (int e = 0; e < 4; ++e)
+          dst[(16 * h + 4 * kq + e) * (C + 1) + (quad ? 64 * wave + 4 * i + u : 16 * (wave * tpw + u) + i)] = acc[h][u][e];
   // bias gradient: lanes (i, kq) hold the sums over the pixels 4 s + kq of their kq
   gsum0 += __shfl_xor(gsum0, 16, 64); gsum0 += __shfl_xor(gsum0, 32, 64);
   gsum1 += __shfl_xor(gsum1, 16, 64); gsum1 += __shfl_xor(gsum1, 32, 64);
@@ -421,12 +442,13 @@ static int head_in(const float* x0, const float* x1, int c0, const float* coef0,
   GLX_REQUIRE(x0, "%s: null map", who);
   if (!x1) {
     GLX_REQUIRE(!coef0 && !coef1, "%s: the input transform needs the two-part form", who);
-    *in = HeadIn{{x0, nullptr}, {nullptr, nullptr}, C};
+    *in = HeadIn{{x0, nullptr}, {nullptr, nullptr}, C, 0};
     return GLX_OK;
   }
   GLX_REQUIRE(c0 > 0 && c0 < C && c0 % 16 == 0, "%s: the first part has %d of %d channels (a multiple of 16 inside)", who, c0, C);
   GLX_REQUIRE((coef0 == nullptr) == (coef1 == nullptr), "%s: both parts or neither are transformed", who);
-  *in = HeadIn{{x0, x1}, {coef0, coef1}, c0};
+  static const int quad = getenv("GLX_HEAD_WGRAD_QUAD") ? atoi(getenv("GLX_HEAD_WGRAD_QUAD")) : 1;
+  *in = HeadIn{{x0, x1}, {coef0, coef1}, c0, quad};
   return GLX_OK;
 }
 
