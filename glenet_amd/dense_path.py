@@ -887,17 +887,21 @@ class _SplitKLinearFn(torch.autograd.Function):
         return gx, gw
 
     @staticmethod
-    def weight_grad(x, gy, w):
+    def weight_grad(x, gy, w, out=None):
+        """out: where to write the gradient (the optimizer's flat-buffer view of w: no gather copy afterwards)."""
         rows = x.shape[0]
         chunks = next((c for c in (16, 8, 4, 2) if rows % c == 0 and rows // c >= 16), 0) \
             if w.shape[0] * w.shape[1] <= 256 * 1024 else 0
+        if out is not None and not (out.shape == w.shape and out.is_contiguous() and out.dtype == torch.float32):
+            out = None
         if chunks:
-            return torch.bmm(gy.view(chunks, rows // chunks, -1).transpose(1, 2),
-                             x.view(chunks, rows // chunks, -1)).sum(0)
-        return gy.t() @ x
+            parts = torch.bmm(gy.view(chunks, rows // chunks, -1).transpose(1, 2), x.view(chunks, rows // chunks, -1))
+            return parts.sum(0) if out is None else torch.sum(parts, 0, out=out)
+        return gy.t() @ x if out is None else torch.mm(gy.t(), x, out=out)
 
 
 DEFERRED_FC_WGRADS = None     # a list while a staged backward collects the FC towers' weight-gradient jobs
+GRADS_IN_PLACE = os.environ.get("GLX_GRADS_IN_PLACE", "1") != "0"      # FC weight gradients straight into the optimizer's buffer
 DEFERRED_FC_SAME_STREAM = False   # the collector will run the jobs on the stream that creates them: no events
 
 
@@ -919,7 +923,8 @@ def run_deferred_fc_wgrads(jobs):
                 cur.wait_event(ev)
                 x.record_stream(cur)
                 gy.record_stream(cur)
-            gw = weight_grad(x, gy, w)
+            view = getattr(w, "_glx_grad_view", None) if (w.grad is None and GRADS_IN_PLACE) else None
+            gw = weight_grad(x, gy, w, view) if view is not None else weight_grad(x, gy, w)
             w.grad = gw if w.grad is None else w.grad + gw
 
 

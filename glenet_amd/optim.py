@@ -49,6 +49,7 @@ class FlatAdamW:
                 view.copy_(p.data)
                 p.data = view
                 self.grad_views.append(self._view(self.flat_grad, o, p))
+                p._glx_grad_view = self.grad_views[-1]      # producers that can write a gradient in place (pack_grads skips it)
         self.hyper = torch.tensor([float(lr), float(betas[0])], dtype=torch.float32, device=dev)
         self.beta2, self.eps, self.weight_decay = float(betas[1]), float(eps), float(weight_decay)
         self.max_norm = float(max_norm) if max_norm else 0.0
@@ -80,7 +81,10 @@ class FlatAdamW:
         """Gather the .grad tensors into the flat gradient buffer (a parameter without a gradient contributes
         zeros, as an optimizer that skips it would leave it -- except for weight decay, which torch skips too
         for such parameters; the training step gives every parameter a gradient)."""
-        have = [(v, p.grad) for v, p in zip(self.grad_views, self.params) if p.grad is not None]
+        # (a gradient that was computed INTO its view -- dense_path.run_deferred_fc_wgrads does that for the 21 MB first RoI
+        # Linear, 70 % of this copy -- needs none)
+        have = [(v, p.grad) for v, p in zip(self.grad_views, self.params)
+                if p.grad is not None and not (p.grad.data_ptr() == v.data_ptr() and p.grad.stride() == v.stride())]
         if len(have) != len(self.params):
             for v, p in zip(self.grad_views, self.params):
                 if p.grad is None:
