@@ -284,11 +284,12 @@ class BEVBackbone(nn.Module):
                 and tuple(mods[0].padding) == (1, 1, 1, 1) and isinstance(mods[1], nn.Conv2d)):
             return None
         conv = mods[1]
-        c, d = int(st.features.shape[1]), int(st.spatial_shape[0])
+        meta = st.features_meta()
+        c, d = int(meta.shape[1]), int(st.spatial_shape[0])
         if not (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.dilation == (1, 1)
-                and conv.groups == 1 and conv.bias is None and conv.in_channels == c * d and st.features.is_cuda
+                and conv.groups == 1 and conv.bias is None and conv.in_channels == c * d and meta.is_cuda
                 and 9 * d <= 27 and c in (16, 32, 64, 128) and conv.out_channels in (16, 32, 64, 128)
-                and st.features.shape[0] > 0 and st._index is not None):
+                and meta.shape[0] > 0 and st._index is not None):
             return None
         cout = conv.out_channels
         # (cout, c * D + z, ky, kx) -> (z, ky, kx, c, cout): views up to the final reshape
@@ -303,16 +304,22 @@ class BEVBackbone(nn.Module):
             torch.cuda.current_stream(st.features.device).wait_event(rs.ready)
         bn = mods[2] if len(mods) > 3 and isinstance(mods[3], nn.ReLU) else None
         stats = None
+        # the producer (conv_out) may have left relu(bn(raw)) pending: take the raw rows, transform on load
+        pend = st._pending if (st._features is None and core.BN_ON_LOAD and core.BN_BWD_IN_DGRAD and core.USE_BN_STATE
+                               and core.USE_PAIR_LISTS and torch.is_grad_enabled() and not (c >= 128 and cout >= 128)
+                               and _lib.query("glx_sconv_packed_bytes", 9 * d, c, cout)) else None
+        x_in = pend.raw if pend is not None else st.features
+        pre_args = (None,) * 6 if pend is None else (pend.coef, pend.mean, pend.invstd, pend.bn.weight, pend.bn.bias, pend.count)
         if (FIRST_LAYER_BN_STATS and bn is not None and self._bn_fusable(bn) and bn.num_features == cout and core.USE_BN_STATE
                 and core.FUSE_BN_STATS_IN_CONV and torch.is_grad_enabled() and not (c >= 128 and cout >= 128)
                 and rs.out_spatial_shape[0] == 1):
             # the layer's BatchNorm2d counts every pixel of the dense map; the cells the sparse convolution does not store
             # are zeros: the statistics are the rows' sums over B * H * W elements -- taken in the convolution's epilogue
             pixels = int(st.batch_size) * int(rs.out_spatial_shape[1]) * int(rs.out_spatial_shape[2])
-            feats, *stats = core.SparseConvFunction.apply(st.features, w, None, rs, False, None, False, (bn, pixels))
+            feats, *stats = core.SparseConvFunction.apply(x_in, w, None, rs, False, None, False, (bn, pixels), None, None, *pre_args)
             own_conv._count_batch(bn)
         else:
-            feats = core.SparseConvFunction.apply(st.features, w, None, rs, False, None, False)
+            feats = core.SparseConvFunction.apply(x_in, w, None, rs, False, None, False, None, None, None, *pre_args)
         out = core.SparseConvTensor(feats, rs.out_indices, rs.out_spatial_shape, st.batch_size, st.grid, st.voxel_num,
                                     st.indice_dict, st.benchmark, rs.count_out)
         out._index = rs.out_index

@@ -266,6 +266,8 @@ class GLENetVR(nn.Module):
         self.map_to_bev_module.defer = bool(bev_channels_last) and dp.SPARSE_FIRST_BEV_LAYER
         self.backbone_2d = dp.BEVBackbone(256)
         self.backbone_2d.head_on_load = bool(bev_channels_last)      # its reader is self.dense_head (dense_path._Head1x1Parts)
+        # conv_out's only reader is the BEV backbone's first layer (a sparse convolution): BatchNorm + ReLU on load there
+        self.backbone_3d.conv_out.leave_pending = bool(self.map_to_bev_module.defer) and os.environ.get("GLX_CONV_OUT_ON_LOAD", "1") != "0"
         if self.map_to_bev_module.defer:     # its rule table is planned with the sparse backbone's
             d = 256 // self.backbone_3d.num_point_features
             self.backbone_3d.extra_plan = (gb.spconv.core.PlannedConv(dp.BEV_FIRST_KEY, (d, 3, 3), (d, 1, 1), (0, 1, 1),
@@ -317,6 +319,15 @@ class GLENetVR(nn.Module):
             if torch.is_tensor(sf) and sf.requires_grad:
                 bd["spatial_features"] = sf.detach().requires_grad_(True)
                 bev_cut = (sf, bd["spatial_features"])
+            elif enc is not None and enc._features is None and enc._pending is not None and enc._pending.raw.requires_grad:
+                # conv_out left its BatchNorm + ReLU to its reader (the BEV backbone's first layer, a sparse convolution that
+                # transforms on load): the cut goes through the RAW rows
+                pend = enc._pending
+                raw_leaf = pend.raw.detach().requires_grad_(True)
+                cut = enc.replace_feature(None)
+                cut._pending = gb.spconv.core.PendingBN(raw_leaf, pend.coef, pend.mean, pend.invstd, pend.bn, pend.count, None)
+                bd["encoded_spconv_tensor"] = cut
+                bev_cut = (pend.raw, raw_leaf)
             elif enc is not None and enc.features.requires_grad:
                 bd["encoded_spconv_tensor"] = enc.replace_feature(enc.features.detach().requires_grad_(True))
                 bev_cut = (enc.features, bd["encoded_spconv_tensor"].features)
