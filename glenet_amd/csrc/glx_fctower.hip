@@ -457,30 +457,40 @@ __device__ __forceinline__ void fct_fwd_phase(const glx_fc_tower& p, FctSmem& sm
         const int c = 4 * q + i;
         bias[i] = c < FCT_NS ? p.b_reg[c] : (c < 2 * FCT_NS ? p.b_std[c - FCT_NS] : 0.f);
       }
+      // the wave's (up to 8) row tiles stay in registers through the BatchNorm of the variance branch's first layer
       float v[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-      for (int tile = wave; tile < ntiles; tile += FCT_WAVES) {
-        const ft4 o = fct_tile(p.h[5], tile, sm.w, zero4);
-        const int row = tile * 16 + r;
+      ft4 vals[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int c = 4 * q + i;
-          const float val = o[i] + bias[i];
-          if (c < FCT_NS) p.rcnn_reg[row * FCT_NS + c] = val;
-          else if (c < 2 * FCT_NS) { p.rcnn_reg_std[row * FCT_NS + c - FCT_NS] = val; v[i] += val; }
+      for (int t = 0; t < 8; ++t) {
+        const int tile = wave + FCT_WAVES * t;
+        vals[t] = zero4;
+        if (tile < ntiles) {
+          const ft4 o = fct_tile(p.h[5], tile, sm.w, zero4);
+          const int row = tile * 16 + r;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int c = 4 * q + i;
+            const float val = o[i] + bias[i];
+            vals[t][i] = val;
+            if (c < FCT_NS) p.rcnn_reg[row * FCT_NS + c] = val;
+            else if (c < 2 * FCT_NS) { p.rcnn_reg_std[row * FCT_NS + c - FCT_NS] = val; v[i] += val; }
+          }
         }
+        __builtin_amdgcn_sched_barrier(0);           // one tile's 16 loads at a time
       }
       const float invR = 1.f / (float)R;
       fct_colsum(v, sm.red, flip);
       float mean[4], istd[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) { mean[i] = v[i] * invR; v[i] = 0.f; }
-#pragma unroll 1
-      for (int tile = wave; tile < ntiles; tile += FCT_WAVES) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int c = 4 * q + i - FCT_NS;
-          if (c >= 0 && c < FCT_NS) { const float d = p.rcnn_reg_std[(tile * 16 + r) * FCT_NS + c] - mean[i]; v[i] += d * d; }
+      for (int t = 0; t < 8; ++t) {
+        if (wave + FCT_WAVES * t < ntiles) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int c = 4 * q + i - FCT_NS;
+            if (c >= 0 && c < FCT_NS) { const float d = vals[t][i] - mean[i]; v[i] += d * d; }
+          }
         }
       }
       fct_colsum(v, sm.red, flip);
@@ -499,43 +509,33 @@ __device__ __forceinline__ void fct_fwd_phase(const glx_fc_tower& p, FctSmem& sm
           }
         }
       }
-#pragma unroll 1
-      for (int tile = wave; tile < ntiles; tile += FCT_WAVES) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int c = 4 * q + i - FCT_NS;
-          if (c >= 0 && c < FCT_NS) {
-            const int row = tile * 16 + r;
-            s_dyn[row * 8 + c] = fmaxf(((p.rcnn_reg_std[row * FCT_NS + c] - mean[i]) * istd[i]) * sm.g7[c] + sm.be7[c], 0.f);
+      for (int t = 0; t < 8; ++t) {
+        const int tile = wave + FCT_WAVES * t;
+        if (tile < ntiles) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int c = 4 * q + i - FCT_NS;
+            if (c >= 0 && c < FCT_NS)
+              s_dyn[(tile * 16 + r) * 8 + c] = fmaxf(((vals[t][i] - mean[i]) * istd[i]) * sm.g7[c] + sm.be7[c], 0.f);
           }
         }
       }
       __syncthreads();
-      // t = s1 W_fc1^T + b (R, 64) -> scratch, a thread per row
-      float* T = p.scratch;
-      for (int row = tid; row < R; row += FCT_THREADS) {
-        float s1[FCT_NS];
-#pragma unroll
-        for (int o = 0; o < FCT_NS; ++o) s1[o] = s_dyn[row * 8 + o];
-#pragma unroll 1
-        for (int j4 = 0; j4 < FCT_NH; j4 += 4) {
-          ft4 tv;
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            float s = sm.b1[j4 + jj];
-#pragma unroll
-            for (int o = 0; o < FCT_NS; ++o) s += s1[o] * sm.wf1[(j4 + jj) * 8 + o];
-            tv[jj] = s;
-          }
-          *reinterpret_cast<ft4*>(T + row * FCT_NH + j4) = tv;
-        }
-      }
-      __syncthreads();
-      // statistics of t: thread (part, j) over the rows part, part + 8, ...
+      // t = s1 W_fc1^T + b (R, 64) is seven multiply-adds per element: recomputed from s1 (LDS) wherever it is needed instead
+      // of making a round trip through memory.  Statistics: thread (part, j) over the rows part, part + 8, ...
       const int j = tid & 63, part = tid >> 6;
+      float wj[FCT_NS];
+#pragma unroll
+      for (int o = 0; o < FCT_NS; ++o) wj[o] = sm.wf1[j * 8 + o];
+      const float bj = sm.b1[j];
+      auto tval = [&](int row) {
+        const ft4 a = *reinterpret_cast<const ft4*>(s_dyn + row * 8), b = *reinterpret_cast<const ft4*>(s_dyn + row * 8 + 4);
+        return bj + a[0] * wj[0] + a[1] * wj[1] + a[2] * wj[2] + a[3] * wj[3] + b[0] * wj[4] + b[1] * wj[5] + b[2] * wj[6];
+      };
       float s = 0.f;
-#pragma unroll 8
-      for (int row = part; row < R; row += FCT_WAVES) s += T[row * FCT_NH + j];
+#pragma unroll 4
+      for (int row = part; row < R; row += FCT_WAVES) s += tval(row);
       sm.part[part * 64 + j] = s;
       __syncthreads();
       float mean64 = 0.f;
@@ -544,8 +544,8 @@ __device__ __forceinline__ void fct_fwd_phase(const glx_fc_tower& p, FctSmem& sm
       mean64 *= invR;
       __syncthreads();
       s = 0.f;
-#pragma unroll 8
-      for (int row = part; row < R; row += FCT_WAVES) { const float d = T[row * FCT_NH + j] - mean64; s += d * d; }
+#pragma unroll 4
+      for (int row = part; row < R; row += FCT_WAVES) { const float d = tval(row) - mean64; s += d * d; }
       sm.part[part * 64 + j] = s;
       __syncthreads();
       if (tid < FCT_NH) {
@@ -565,17 +565,18 @@ __device__ __forceinline__ void fct_fwd_phase(const glx_fc_tower& p, FctSmem& sm
         }
       }
       __syncthreads();
+      // std_logit[row] = sum_j relu(bn64(t[row][j])) w_fc2[j] + b: a thread per row walks the 64 columns (parameters from
+      // LDS, broadcast reads) -- a wave per row with a shuffle reduction was a chain of dependent cross-lane hops per row
       const float b2 = p.b_fc2[0];
       for (int row = tid; row < R; row += FCT_THREADS) {
+        const ft4 a4 = *reinterpret_cast<const ft4*>(s_dyn + row * 8), b4 = *reinterpret_cast<const ft4*>(s_dyn + row * 8 + 4);
         float o = b2;
-#pragma unroll 1
-        for (int j4 = 0; j4 < FCT_NH; j4 += 4) {
-          const ft4 tv = *reinterpret_cast<const ft4*>(T + row * FCT_NH + j4);
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            const int jx = j4 + jj;
-            o += fmaxf(((tv[jj] - sm.m64[jx]) * sm.is64[jx]) * sm.g64[jx] + sm.be64[jx], 0.f) * sm.wf2[jx];
-          }
+#pragma unroll 4
+        for (int jx = 0; jx < FCT_NH; ++jx) {
+          const ft4 w0 = *reinterpret_cast<const ft4*>(sm.wf1 + jx * 8), w1 = *reinterpret_cast<const ft4*>(sm.wf1 + jx * 8 + 4);
+          const float t = sm.b1[jx] + a4[0] * w0[0] + a4[1] * w0[1] + a4[2] * w0[2] + a4[3] * w0[3] + b4[0] * w1[0] + b4[1] * w1[1] +
+                          b4[2] * w1[2];
+          o += fmaxf(((t - sm.m64[jx]) * sm.is64[jx]) * sm.g64[jx] + sm.be64[jx], 0.f) * sm.wf2[jx];
         }
         p.std_logit[row] = o;
       }
@@ -637,41 +638,44 @@ __device__ __forceinline__ void fct_bwd_phase(const glx_fc_tower& p, const glx_f
         // ---- variance branch backward (every block of the group computes it: no barrier in front of the regression
         // tower), then dL/dh5 = g_reg W_reg + d_std W_std
         fct_load_small(p, sm, true);
-        float* T = g.scratch + (size_t)(blk & 15) * R * (FCT_NH + 8);    // (R, 64) t, then dt
-        float* S1 = T + (size_t)R * FCT_NH;                               // (R, 8)
+        // roles inside the group (every block computes the branch; the parameter gradients are spread so that no block
+        // carries all the extra work): block 0 writes the BatchNorm / fc2 / bias gradients, blocks 1-4 one 16-row tile of
+        // dW_fc1 each (block 1 also db_fc1) -- those four put dt in memory, a slice of the scratch each
+        const int fc1_tile = (blk & 15) - 1;
+        const bool fc1 = fc1_tile >= 0 && fc1_tile < 4;
+        float* T = g.scratch + (size_t)(fc1 ? fc1_tile : 0) * R * FCT_NH;      // (R, 64): dt
+        float* s_s1 = s_g + R * 16;                            // (R, 8) s1 = relu(bn7(rcnn_reg_std)), LDS
+        float* s_gl = s_s1 + R * 8;                            // (R) dL/d std_logit
         __syncthreads();
         for (int row = tid; row < R; row += FCT_THREADS) {
-          float s1[FCT_NS];
 #pragma unroll
           for (int o = 0; o < FCT_NS; ++o) {
             const float xh = (p.rcnn_reg_std[row * FCT_NS + o] - sm.m7[o]) * sm.is7[o];
-            s1[o] = fmaxf(xh * sm.g7[o] + sm.be7[o], 0.f);
-            S1[row * 8 + o] = s1[o];
+            s_s1[row * 8 + o] = fmaxf(xh * sm.g7[o] + sm.be7[o], 0.f);
           }
-          S1[row * 8 + 7] = 0.f;
-#pragma unroll 1
-          for (int j4 = 0; j4 < FCT_NH; j4 += 4) {
-            ft4 tv;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              float s = sm.b1[j4 + jj];
-#pragma unroll
-              for (int o = 0; o < FCT_NS; ++o) s += s1[o] * sm.wf1[(j4 + jj) * 8 + o];
-              tv[jj] = s;
-            }
-            *reinterpret_cast<ft4*>(T + row * FCT_NH + j4) = tv;
-          }
+          s_s1[row * 8 + 7] = 0.f;
+          s_gl[row] = g.g_logit ? g.g_logit[row] : 0.f;
         }
         __syncthreads();
+        // t = s1 W_fc1^T + b is seven multiply-adds per element: recomputed from s1 (LDS) wherever it is needed.
+        // Column sums of the bn64 backward: thread (part, j) over the rows part, part + 8, ...
         const int j = tid & 63, part = tid >> 6;
+        float wj[FCT_NS];
+#pragma unroll
+        for (int o = 0; o < FCT_NS; ++o) wj[o] = sm.wf1[j * 8 + o];
+        const float bj = sm.b1[j], m64j = sm.m64[j], is64j = sm.is64[j], g64j = sm.g64[j], be64j = sm.be64[j], wf2j = sm.wf2[j];
+        auto tval = [&](int row) {
+          const ft4 a = *reinterpret_cast<const ft4*>(s_s1 + row * 8), b = *reinterpret_cast<const ft4*>(s_s1 + row * 8 + 4);
+          return bj + a[0] * wj[0] + a[1] * wj[1] + a[2] * wj[2] + a[3] * wj[3] + b[0] * wj[4] + b[1] * wj[5] + b[2] * wj[6];
+        };
         {
           float a = 0.f, b = 0.f, c = 0.f;
-#pragma unroll 8
+#pragma unroll 4
           for (int row = part; row < R; row += FCT_WAVES) {
-            const float xh = (T[row * FCT_NH + j] - sm.m64[j]) * sm.is64[j];
-            const float pre = xh * sm.g64[j] + sm.be64[j];
-            const float gl = g.g_logit ? g.g_logit[row] : 0.f;
-            const float gq = pre > 0.f ? gl * sm.wf2[j] : 0.f;
+            const float xh = (tval(row) - m64j) * is64j;
+            const float pre = xh * g64j + be64j;
+            const float gl = s_gl[row];
+            const float gq = pre > 0.f ? gl * wf2j : 0.f;
             a += gq;
             b += gq * xh;
             c += gl * fmaxf(pre, 0.f);
@@ -690,44 +694,47 @@ __device__ __forceinline__ void fct_bwd_phase(const glx_fc_tower& p, const glx_f
           if (writer) { g.dbeta64[j] = a; g.dgamma64[j] = b; g.dw_fc2[j] = c; }
         }
         __syncthreads();
-        {
+        const float A64j = sm.A64[j] * invR, B64j = sm.B64[j] * invR;
+        if (fc1) {               // dt to memory (dW_fc1 contracts it with s1 below) and its column sums (db_fc1)
           float sdt = 0.f;
-#pragma unroll 8
+#pragma unroll 4
           for (int row = part; row < R; row += FCT_WAVES) {
-            const float xh = (T[row * FCT_NH + j] - sm.m64[j]) * sm.is64[j];
-            const float pre = xh * sm.g64[j] + sm.be64[j];
-            const float gl = g.g_logit ? g.g_logit[row] : 0.f;
-            const float gq = pre > 0.f ? gl * sm.wf2[j] : 0.f;
-            const float dt = sm.g64[j] * sm.is64[j] * (gq - sm.A64[j] * invR - xh * (sm.B64[j] * invR));
+            const float xh = (tval(row) - m64j) * is64j;
+            const float gq = (xh * g64j + be64j > 0.f) ? s_gl[row] * wf2j : 0.f;
+            const float dt = g64j * is64j * (gq - A64j - xh * B64j);
             T[row * FCT_NH + j] = dt;
             sdt += dt;
           }
           sm.part[part * 64 + j] = sdt;
-        }
-        __syncthreads();
-        if (writer && tid < FCT_NH) {
-          float s = 0.f;
+          __syncthreads();
+          if (tid < FCT_NH && fc1_tile == 0) {
+            float sd = 0.f;
 #pragma unroll
-          for (int w = 0; w < FCT_WAVES; ++w) s += sm.part[w * 64 + j];
-          g.db_fc1[j] = s;
+            for (int w = 0; w < FCT_WAVES; ++w) sd += sm.part[w * 64 + j];
+            g.db_fc1[j] = sd;
+          }
         }
-        // a thread per row: ds1 = dt W_fc1, through bn7 + ReLU (masked gradient and xhat parked in s_g until the sums are known)
+        // a thread per row: ds1 = dt W_fc1 (dt recomputed column by column), through bn7 + ReLU (masked gradient and xhat
+        // parked in s_g until the sums are known)
         float v14[14];
 #pragma unroll
         for (int i = 0; i < 14; ++i) v14[i] = 0.f;
 #pragma unroll 1
         for (int row = tid; row < R; row += FCT_THREADS) {
-          float ds1[FCT_NS];
+          float s1[FCT_NS], ds1[FCT_NS];
 #pragma unroll
-          for (int o = 0; o < FCT_NS; ++o) ds1[o] = 0.f;
-#pragma unroll 1
-          for (int j4 = 0; j4 < FCT_NH; j4 += 4) {
-            const ft4 dt = *reinterpret_cast<const ft4*>(T + row * FCT_NH + j4);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-#pragma unroll
-              for (int o = 0; o < FCT_NS; ++o) ds1[o] += dt[jj] * sm.wf1[(j4 + jj) * 8 + o];
-            }
+          for (int o = 0; o < FCT_NS; ++o) { s1[o] = s_s1[row * 8 + o]; ds1[o] = 0.f; }
+          const float gl = s_gl[row];
+#pragma unroll 2
+          for (int jx = 0; jx < FCT_NH; ++jx) {
+            const ft4 w0 = *reinterpret_cast<const ft4*>(sm.wf1 + jx * 8), w1 = *reinterpret_cast<const ft4*>(sm.wf1 + jx * 8 + 4);
+            float t = sm.b1[jx] + s1[0] * w0[0] + s1[1] * w0[1] + s1[2] * w0[2] + s1[3] * w0[3] + s1[4] * w1[0] + s1[5] * w1[1] +
+                      s1[6] * w1[2];
+            const float xh = (t - sm.m64[jx]) * sm.is64[jx];
+            const float gq = (xh * sm.g64[jx] + sm.be64[jx] > 0.f) ? gl * sm.wf2[jx] : 0.f;
+            const float dt = sm.g64[jx] * sm.is64[jx] * (gq - sm.A64[jx] * invR - xh * (sm.B64[jx] * invR));
+            ds1[0] += dt * w0[0]; ds1[1] += dt * w0[1]; ds1[2] += dt * w0[2]; ds1[3] += dt * w0[3];
+            ds1[4] += dt * w1[0]; ds1[5] += dt * w1[1]; ds1[6] += dt * w1[2];
           }
 #pragma unroll
           for (int o = 0; o < FCT_NS; ++o) {
@@ -754,15 +761,16 @@ __device__ __forceinline__ void fct_bwd_phase(const glx_fc_tower& p, const glx_f
           s_g[row * 16 + 15] = 0.f;
         }
         __syncthreads();
-        if (writer) {
-          // dW_fc1[j][o] = sum_rows dt[row][j] s1[row][o] (four 16-row tiles of j), the prediction layers' bias gradients
-          for (int mt = 0; mt < 4; ++mt) {
-            const ft4 d = fct_outer(T, FCT_NH, 16 * mt, 16, S1, 8, 0, FCT_NS, R, sm.part);
-            if (r < FCT_NS) {
+        if (fc1) {
+          // dW_fc1[j][o] = sum_rows dt[row][j] s1[row][o]: this block's 16-row tile of j
+          const int mt = fc1_tile;
+          const ft4 d = fct_outer(T, FCT_NH, 16 * mt, 16, s_s1, 8, 0, FCT_NS, R, sm.part);
+          if (r < FCT_NS) {
 #pragma unroll
-              for (int i = 0; i < 4; ++i) g.dw_fc1[(16 * mt + 4 * q + i) * FCT_NS + r] = d[i];
-            }
+            for (int i = 0; i < 4; ++i) g.dw_fc1[(16 * mt + 4 * q + i) * FCT_NS + r] = d[i];
           }
+        }
+        if (writer) {            // the prediction layers' bias gradients, db_fc2
           float v[1] = {0.f};
           for (int row = tid; row < R; row += FCT_THREADS) v[0] += g.g_logit ? g.g_logit[row] : 0.f;
           fct_block_sum<1>(v, sm.sbuf, sm.A7 + 14);
@@ -880,11 +888,11 @@ static int fct_launch_fwd(const glx_fc_tower& t, hipStream_t st) {
 }
 
 static int fct_launch_bwd(const glx_fc_tower& t, const glx_fc_tower_grads& g, hipStream_t st) {
-  const size_t lds = (size_t)t.R * 16 * sizeof(float);
+  const size_t lds = (size_t)t.R * 25 * sizeof(float);          // per row: 16 output gradients, 8 s1, dL/d std_logit
   static bool attr_set = false;
   if (!attr_set) {
-    GLX_HIP(hipFuncSetAttribute((const void*)k_fct_backward<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    GLX_HIP(hipFuncSetAttribute((const void*)k_fct_backward<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    GLX_HIP(hipFuncSetAttribute((const void*)k_fct_backward<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    GLX_HIP(hipFuncSetAttribute((const void*)k_fct_backward<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     attr_set = true;
   }
   if (t.cooperative) {
