@@ -133,6 +133,13 @@ class ConvOpts(ctypes.Structure):
                 ("bn_bwd", ctypes.POINTER(BnBwdStats))]
 
 
+class RoiQuery(ctypes.Structure):
+    """glx_roi_query (include/glenet_hip.h)."""
+    _fields_ = [("Z", c_int), ("Y", c_int), ("X", c_int), ("nsample", c_int), ("z_range", c_int), ("y_range", c_int),
+                ("x_range", c_int), ("stride", c_int), ("radius", c_float), ("indices", c_void_p), ("bitmap", c_void_p),
+                ("prefix", c_void_p), ("rank_to_row", c_void_p), ("idx", c_void_p)]
+
+
 class FcBn(ctypes.Structure):
     _fields_ = [("gamma", c_void_p), ("beta", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p),
                 ("save_mean", c_void_p), ("save_invstd", c_void_p), ("eps", c_float), ("momentum", c_float)]

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void k_voxel_query(
 constexpr int VQ_ROW_MAX_WX = 32;
 
 template <bool CEN>
-__global__ __launch_bounds__(256) void k_voxel_query_rows(
+__device__ __forceinline__ void vq_rows_body(
     int M, int R1, int R2, int R3, int nsample, float radius2, int zr, int yr, int xr,
     const float* __restrict__ new_xyz, const float* __restrict__ xyz, const int* __restrict__ new_coords,
     const unsigned long long* __restrict__ bitmap, const int* __restrict__ prefix,
@@ -480,6 +480,37 @@ __global__ __launch_bounds__(256) void k_voxel_query_rows(
   } else {
     for (int l = cnt + g; l < nsample; l += G) o[l] = first;
   }
+}
+
+template <bool CEN>
+__global__ __launch_bounds__(256) void k_voxel_query_rows(
+    int M, int R1, int R2, int R3, int nsample, float radius2, int zr, int yr, int xr,
+    const float* __restrict__ new_xyz, const float* __restrict__ xyz, const int* __restrict__ new_coords,
+    const unsigned long long* __restrict__ bitmap, const int* __restrict__ prefix,
+    const int* __restrict__ rank_to_row, int* __restrict__ idx, VoxelCentres cen, int coord_stride) {
+  vq_rows_body<CEN>(M, R1, R2, R3, nsample, radius2, zr, yr, xr, new_xyz, xyz, new_coords, bitmap, prefix, rank_to_row, idx, cen,
+                    coord_stride);
+}
+
+// The RoI grid's queries of several feature scales (same grid points, each scale its own tensor) in ONE launch:
+// blockIdx.y = scale.  The scales' launches were a serial chain of 43-46 us each on the RoI branch.
+#define VQ_MAX_SCALES 4
+struct VqScale {
+  int R1, R2, R3, nsample, zr, yr, xr, stride;
+  float radius2;
+  const unsigned long long* bitmap;
+  const int* prefix;
+  const int* rank_to_row;
+  int* idx;
+  VoxelCentres cen;
+};
+struct VqScales { VqScale s[VQ_MAX_SCALES]; };
+
+__global__ __launch_bounds__(256) void k_voxel_query_rows_multi(int M, const float* __restrict__ new_xyz,
+                                                                const int* __restrict__ new_coords, VqScales q) {
+  const VqScale& a = q.s[blockIdx.y];
+  vq_rows_body<true>(M, a.R1, a.R2, a.R3, a.nsample, a.radius2, a.zr, a.yr, a.xr, new_xyz, nullptr, new_coords, a.bitmap,
+                     a.prefix, a.rank_to_row, a.idx, a.cen, a.stride);
 }
 
 extern "C" int glx_voxel_query(int M, int Z, int Y, int X, int nsample, float radius, int z_range,
@@ -1468,6 +1499,28 @@ extern "C" int glx_roi_grid_query(int M, int Z, int Y, int X, int nsample, float
                        x_range, grid_xyz, (const float*)nullptr, coords, (const int*)nullptr,
                        (const unsigned long long*)bitmap, (const int*)prefix, rank_to_row, idx,
                        make_centres(indices, range_min, voxel_size, stride), stride);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+extern "C" int glx_roi_grid_query_multi(int n_scales, const glx_roi_query* scales, int M, const float* grid_xyz,
+                                        const int32_t* coords, const float* range_min, const float* voxel_size,
+                                        void* stream) {
+  if (M == 0 || n_scales == 0) return GLX_OK;
+  GLX_REQUIRE(scales && grid_xyz && coords && range_min && voxel_size, "glx_roi_grid_query_multi: null pointer");
+  GLX_REQUIRE(n_scales >= 1 && n_scales <= VQ_MAX_SCALES, "glx_roi_grid_query_multi: %d scales (1..%d)", n_scales, VQ_MAX_SCALES);
+  VqScales q;
+  for (int k = 0; k < n_scales; ++k) {
+    const glx_roi_query& a = scales[k];
+    GLX_REQUIRE(a.indices && a.bitmap && a.prefix && a.idx && a.stride >= 1 && a.nsample >= 1,
+                "glx_roi_grid_query_multi: scale %d: null pointer / bad stride or nsample", k);
+    GLX_REQUIRE(2 * a.x_range + 1 <= VQ_ROW_MAX_WX, "glx_roi_grid_query_multi: scale %d: x range %d", k, a.x_range);
+    q.s[k] = VqScale{a.Z, a.Y, a.X, a.nsample, a.z_range, a.y_range, a.x_range, a.stride, a.radius * a.radius,
+                     (const unsigned long long*)a.bitmap, (const int*)a.prefix, (const int*)a.rank_to_row, (int*)a.idx,
+                     make_centres(a.indices, range_min, voxel_size, a.stride)};
+  }
+  hipLaunchKernelGGL(k_voxel_query_rows_multi, dim3(glx_divup(M, 32), n_scales), dim3(256), 0, (hipStream_t)stream, M, grid_xyz,
+                     coords, q);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

@@ -559,6 +559,16 @@ int glx_roi_grid_query(int M, int Z, int Y, int X, int nsample, float radius, in
                        int stride, const int32_t* indices, const float* range_min,
                        const float* voxel_size, const uint64_t* bitmap, const int32_t* prefix,
                        const int32_t* rank_to_row, int32_t* idx, void* stream);
+/* The same query for several feature scales in one launch (same grid points / coords; Z, Y, X, ranges, stride, tensors and
+ * output per scale; x_range <= 15): RoIGridPool's three scales (voxelrcnn_head.py:106-191) were a serial chain. */
+typedef struct glx_roi_query {
+  int Z, Y, X, nsample, z_range, y_range, x_range, stride;
+  float radius;
+  const int32_t* indices; const uint64_t* bitmap; const int32_t* prefix; const int32_t* rank_to_row;
+  int32_t* idx;
+} glx_roi_query;
+int glx_roi_grid_query_multi(int n_scales, const glx_roi_query* scales, int M, const float* grid_xyz, const int32_t* coords,
+                             const float* range_min, const float* voxel_size, void* stream);
 int glx_roi_grid_agg(const float* feats, const int32_t* indices, int stride, const float* range_min,
                      const float* voxel_size, const float* grid_xyz, const int32_t* idx, int M,
                      int nsample, int Cm, int Co, const float* Wpos, const float* bpos,

@@ -800,6 +800,18 @@ def test_roi_grid_training_path_on_shape_static_tensors(dev):
         for k in exact[3]:
             np.testing.assert_allclose(exact[3][k].cpu().numpy(), other[3][k].cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
     assert torch.isfinite(static[0]).all()
+    # the scales' neighbour queries as ONE launch (glx_roi_grid_query_multi) == a launch per scale, bit for bit
+    pool.load_state_dict(state)
+    was = pool.GROUPED_QUERY
+    pool.GROUPED_QUERY = not was
+    try:
+        other = _run_pool(pool, feats, strides, rois, B, dev)
+    finally:
+        pool.GROUPED_QUERY = was
+    assert torch.equal(exact[0], other[0])
+    for k in exact[1]:
+        np.testing.assert_allclose(exact[1][k].cpu().numpy(), other[1][k].cpu().numpy(), rtol=1e-4,
+                                   atol=1e-6 + 1e-5 * float(exact[1][k].abs().max()), err_msg=k)
 
 
 # ------------------------------------------------------------------ the iou3d library's remaining exports, soft-NMS
