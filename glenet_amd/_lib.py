@@ -140,6 +140,16 @@ class RoiQuery(ctypes.Structure):
                 ("prefix", c_void_p), ("rank_to_row", c_void_p), ("idx", c_void_p)]
 
 
+class RoiHeadLossesArgs(ctypes.Structure):
+    """glx_roi_head_losses_args (include/glenet_hip.h)."""
+    _fields_ = [("ori_cls", c_void_p), ("std_logit", c_void_p), ("cls_labels", c_void_p), ("rcnn_reg", c_void_p),
+                ("rcnn_reg_std", c_void_p), ("rois", c_void_p), ("gt_ct", c_void_p), ("gt_ct_ld", c_int),
+                ("gt_src", c_void_p), ("gt_src_ld", c_int), ("label_var", c_void_p), ("reg_valid", c_void_p), ("R", c_int),
+                ("code_weights", c_float * 7), ("beta", c_float), ("w_cls", c_float), ("w_reg", c_float),
+                ("w_corner", c_float), ("rcnn_cls", c_void_p), ("out", c_void_p), ("grad_ori", c_void_p),
+                ("grad_std_logit", c_void_p), ("grad_reg", c_void_p), ("grad_reg_std", c_void_p)]
+
+
 class FcBn(ctypes.Structure):
     _fields_ = [("gamma", c_void_p), ("beta", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p),
                 ("save_mean", c_void_p), ("save_invstd", c_void_p), ("eps", c_float), ("momentum", c_float)]

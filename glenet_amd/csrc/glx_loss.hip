@@ -14,11 +14,12 @@
 
 #define KL_THREADS 256
 
-__device__ __forceinline__ double kl_block_sum(double v, double* red) {
+template <int NT>
+__device__ __forceinline__ double blk_sum(double v, double* red) {
   const int t = threadIdx.x;
   red[t] = v;
   __syncthreads();
-  for (int s = KL_THREADS / 2; s > 0; s >>= 1) {
+  for (int s = NT / 2; s > 0; s >>= 1) {
     if (t < s) red[t] += red[t + s];
     __syncthreads();
   }
@@ -26,24 +27,28 @@ __device__ __forceinline__ double kl_block_sum(double v, double* red) {
   __syncthreads();
   return r;
 }
+__device__ __forceinline__ double kl_block_sum(double v, double* red) { return blk_sum<KL_THREADS>(v, red); }
 
 struct KlCodeWeights { float w[7]; };
 
-__global__ __launch_bounds__(KL_THREADS) void k_kl_reg_loss(
+// One block of NT threads; the bodies below are shared by the stand-alone kernels (NT = KL_THREADS, float masks, dense
+// 7-column rows) and by k_roi_head_losses (all three RoI-head terms in one launch, int64 mask, strided ground-truth rows).
+// `fg`: > 0 = foreground (float or int64).  Returns the loss (every thread).
+template <int NT, class M>
+__device__ __forceinline__ float kl_reg_body(
     const float* __restrict__ reg, const float* __restrict__ reg_std, const float* __restrict__ rois,
-    const float* __restrict__ gt, const float* __restrict__ label_var, const float* __restrict__ fg,
-    int R, KlCodeWeights cw, float beta, float weight, float* __restrict__ out,
-    float* __restrict__ grad_reg, float* __restrict__ grad_std) {
-  __shared__ double red[KL_THREADS];
+    const float* __restrict__ gt, int gt_ld, const float* __restrict__ label_var, const M* __restrict__ fg,
+    int R, const KlCodeWeights& cw, float beta, float weight, float* __restrict__ out,
+    float* __restrict__ grad_reg, float* __restrict__ grad_std, double* red) {
   double c = 0;
-  for (int i = threadIdx.x; i < R; i += KL_THREADS) c += fg[i] > 0.f ? 1.0 : 0.0;
-  const double nfg = kl_block_sum(c, red);
+  for (int i = threadIdx.x; i < R; i += NT) c += fg[i] > 0 ? 1.0 : 0.0;
+  const double nfg = blk_sum<NT>(c, red);
   const float scale = weight / (float)(nfg > 1.0 ? nfg : 1.0);
   double s_src = 0, s_sq = 0, s_log = 0;
-  for (int e = threadIdx.x; e < R * 7; e += KL_THREADS) {
+  for (int e = threadIdx.x; e < R * 7; e += NT) {
     const int i = e / 7, k = e - i * 7;
     const float* a = rois + (long long)i * 7;
-    const float* g = gt + (long long)i * 7;
+    const float* g = gt + (long long)i * gt_ld;
     const float dxa = fmaxf(a[3], 1e-5f), dya = fmaxf(a[4], 1e-5f), dza = fmaxf(a[5], 1e-5f);
     float t;
     if (k < 2) t = g[k] / sqrtf(dxa * dxa + dya * dya);            // anchor centre is the origin
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(KL_THREADS) void k_kl_reg_loss(
     const bool clamped = sraw < -50.f;
     const float s = clamped ? -50.f : sraw;
     const float lv = logf(label_var[e] + 1e-10f);
-    const float m = fg[i] > 0.f ? 1.f : 0.f;
+    const float m = fg[i] > 0 ? 1.f : 0.f;
     const float es = expf(-s), sq = expf(lv - s);
     s_src += (double)(es * src * m);
     s_sq += (double)(sq * m);
@@ -69,14 +74,26 @@ __global__ __launch_bounds__(KL_THREADS) void k_kl_reg_loss(
     if (grad_reg) grad_reg[e] = m * es * dsrc * cw.w[k] * scale;
     if (grad_std) grad_std[e] = clamped ? 0.f : m * (-es * src - sq + 0.5f) * scale;
   }
-  const double a_src = kl_block_sum(s_src, red), a_sq = kl_block_sum(s_sq, red), a_log = kl_block_sum(s_log, red);
+  const double a_src = blk_sum<NT>(s_src, red), a_sq = blk_sum<NT>(s_sq, red), a_log = blk_sum<NT>(s_log, red);
+  const float o1 = (float)a_src * scale, o2 = (float)a_sq * scale, o3 = (float)a_log * scale;
+  const float total = o1 + o2 + o3;
   if (threadIdx.x == 0) {
-    out[1] = (float)a_src * scale;
-    out[2] = (float)a_sq * scale;
-    out[3] = (float)a_log * scale;
-    out[0] = out[1] + out[2] + out[3];
+    out[1] = o1;
+    out[2] = o2;
+    out[3] = o3;
+    out[0] = total;
     out[4] = (float)nfg;
   }
+  return total;
+}
+
+__global__ __launch_bounds__(KL_THREADS) void k_kl_reg_loss(
+    const float* __restrict__ reg, const float* __restrict__ reg_std, const float* __restrict__ rois,
+    const float* __restrict__ gt, const float* __restrict__ label_var, const float* __restrict__ fg,
+    int R, KlCodeWeights cw, float beta, float weight, float* __restrict__ out,
+    float* __restrict__ grad_reg, float* __restrict__ grad_std) {
+  __shared__ double red[KL_THREADS];
+  kl_reg_body<KL_THREADS>(reg, reg_std, rois, gt, 7, label_var, fg, R, cw, beta, weight, out, grad_reg, grad_std, red);
 }
 
 extern "C" int glx_kl_reg_loss(const float* rcnn_reg, const float* rcnn_reg_std, const float* rois,
@@ -119,22 +136,22 @@ __device__ __forceinline__ void corner_of(int j, float dx, float dy, float dz, f
   z = dz * tz + cz;
 }
 
-__global__ __launch_bounds__(KL_THREADS) void k_corner_loss(
-    const float* __restrict__ reg, const float* __restrict__ rois, const float* __restrict__ gt,
-    const float* __restrict__ fg, int R, float weight, float* __restrict__ out,
-    float* __restrict__ grad_reg) {
-  __shared__ double red[KL_THREADS];
+// ACC: the row gradients are ADDED to what grad_reg holds (the KL term's, written by this block before a barrier).
+template <int NT, bool ACC, class M>
+__device__ __forceinline__ float corner_loss_body(
+    const float* __restrict__ reg, const float* __restrict__ rois, const float* __restrict__ gt, int gt_ld,
+    const M* __restrict__ fg, int R, float weight, float* __restrict__ out, float* __restrict__ grad_reg, double* red) {
   double c = 0;
-  for (int i = threadIdx.x; i < R; i += KL_THREADS) c += fg[i] > 0.f ? 1.0 : 0.0;
-  const double nfg = kl_block_sum(c, red);
+  for (int i = threadIdx.x; i < R; i += NT) c += fg[i] > 0 ? 1.0 : 0.0;
+  const double nfg = blk_sum<NT>(c, red);
   const float scale = nfg > 0.0 ? weight / (float)nfg : 0.f;
   double acc = 0;
-  for (int i = threadIdx.x; i < R; i += KL_THREADS) {
+  for (int i = threadIdx.x; i < R; i += NT) {
     float g7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (fg[i] > 0.f) {
+    if (fg[i] > 0) {
       const float* a = rois + (long long)i * 7;
       const float* r = reg + (long long)i * 7;
-      const float* q = gt + (long long)i * 7;
+      const float* q = gt + (long long)i * gt_ld;
       const float dxa = a[3], dya = a[4], dza = a[5], ra = a[6];
       const float diag = sqrtf(dxa * dxa + dya * dya);
       const float xl = r[0] * diag, yl = r[1] * diag, zl = r[2] * dza;
@@ -176,14 +193,27 @@ __global__ __launch_bounds__(KL_THREADS) void k_corner_loss(
     }
     if (grad_reg) {
 #pragma unroll
-      for (int k = 0; k < 7; ++k) grad_reg[(long long)i * 7 + k] = g7[k];
+      for (int k = 0; k < 7; ++k) {
+        if constexpr (ACC) grad_reg[(long long)i * 7 + k] += g7[k];
+        else grad_reg[(long long)i * 7 + k] = g7[k];
+      }
     }
   }
-  const double total = kl_block_sum(acc, red);
+  const double total = blk_sum<NT>(acc, red);
+  const float loss = (float)total * scale;
   if (threadIdx.x == 0) {
-    out[0] = (float)total * scale;
+    out[0] = loss;
     out[1] = (float)nfg;
   }
+  return loss;
+}
+
+__global__ __launch_bounds__(KL_THREADS) void k_corner_loss(
+    const float* __restrict__ reg, const float* __restrict__ rois, const float* __restrict__ gt,
+    const float* __restrict__ fg, int R, float weight, float* __restrict__ out,
+    float* __restrict__ grad_reg) {
+  __shared__ double red[KL_THREADS];
+  corner_loss_body<KL_THREADS, false>(reg, rois, gt, 7, fg, R, weight, out, grad_reg, red);
 }
 
 extern "C" int glx_corner_loss(const float* rcnn_reg, const float* rois, const float* gt_of_rois_src,
@@ -674,18 +704,18 @@ extern "C" int glx_rcnn_cls_loss(const float* rcnn_cls, const float* rcnn_cls_la
 // rcnn_cls = log((p + 1e-6) / (1 - p + 1e-6)) -- nine elementwise launches forward and fourteen backward as tensor
 // ops.  Here the rescaling, the BinaryCrossEntropy loss above and the chain rule down to the two logits are ONE
 // block: rcnn_cls (R) is written for the callers that read it, grad_ori / grad_std hold d loss / d logit.
-__global__ __launch_bounds__(KL_THREADS) void k_cls_rescale_loss(
+template <int NT>
+__device__ __forceinline__ float cls_rescale_body(
     const float* __restrict__ ori_cls, const float* __restrict__ std_logit,
     const float* __restrict__ labels, int R, float weight, float* __restrict__ rcnn_cls,
-    float* __restrict__ out, float* __restrict__ grad_ori, float* __restrict__ grad_std) {
-  __shared__ double red[KL_THREADS];
+    float* __restrict__ out, float* __restrict__ grad_ori, float* __restrict__ grad_std, double* red) {
   double c = 0;
   if (labels)
-    for (int i = threadIdx.x; i < R; i += KL_THREADS) c += labels[i] >= 0.f ? 1.0 : 0.0;
-  const double nv = labels ? kl_block_sum(c, red) : 0.0;
+    for (int i = threadIdx.x; i < R; i += NT) c += labels[i] >= 0.f ? 1.0 : 0.0;
+  const double nv = labels ? blk_sum<NT>(c, red) : 0.0;
   const float scale = weight / (float)(nv > 1.0 ? nv : 1.0);
   double acc = 0;
-  for (int i = threadIdx.x; i < R; i += KL_THREADS) {
+  for (int i = threadIdx.x; i < R; i += NT) {
     const float sa = 1.f / (1.f + expf(-ori_cls[i])), sb = 1.f / (1.f + expf(-std_logit[i]));
     const float pr = sa * sb;
     const float num = pr + 1e-6f, den = (1.f - pr) + 1e-6f;
@@ -702,9 +732,49 @@ __global__ __launch_bounds__(KL_THREADS) void k_cls_rescale_loss(
     if (grad_ori) grad_ori[i] = gp * sb * sa * (1.f - sa);
     if (grad_std) grad_std[i] = gp * sa * sb * (1.f - sb);
   }
-  if (!labels) return;
-  const double total = kl_block_sum(acc, red);
-  if (threadIdx.x == 0) { out[0] = (float)total * scale; out[1] = (float)nv; }
+  if (!labels) return 0.f;
+  const double total = blk_sum<NT>(acc, red);
+  const float loss = (float)total * scale;
+  if (threadIdx.x == 0) { out[0] = loss; out[1] = (float)nv; }
+  return loss;
+}
+
+__global__ __launch_bounds__(KL_THREADS) void k_cls_rescale_loss(
+    const float* __restrict__ ori_cls, const float* __restrict__ std_logit,
+    const float* __restrict__ labels, int R, float weight, float* __restrict__ rcnn_cls,
+    float* __restrict__ out, float* __restrict__ grad_ori, float* __restrict__ grad_std) {
+  __shared__ double red[KL_THREADS];
+  cls_rescale_body<KL_THREADS>(ori_cls, std_logit, labels, R, weight, rcnn_cls, out, grad_ori, grad_std, red);
+}
+
+// ------------------------------------------------------------------ the three RoI-head terms in ONE launch
+// VoxelRCNNKLLabelIoUHead.get_loss (roi_head_template.py get_loss -> voxelrcnn_kl_label_iou_head.py:93-172 + the
+// classification term, roi_head_template.py:246-272) behind GLENet's score rescaling: the three blocks above ran as
+// three launches with seven tensor launches between them (mask compare / cast, slices of the 8-column ground-truth
+// rows, the sum of the terms) and autograd added the two gradients of rcnn_reg in another.  Here one block of 1024
+// threads runs the three bodies back to back: ground-truth rows through their stride, the int64 mask as it is,
+// d loss / d rcnn_reg = KL term + corner term, out9[10] = { total, cls, #valid, KL, src, square, log, #fg, corner, #fg }.
+#define RHL_THREADS 1024
+struct RoiHeadLossArgs {
+  const float *ori_cls, *std_logit, *cls_labels, *rcnn_reg, *rcnn_reg_std, *rois, *gt_ct, *gt_src, *label_var;
+  const long long* reg_valid;
+  int R, gt_ct_ld, gt_src_ld;
+  KlCodeWeights cw;
+  float beta, w_cls, w_reg, w_corner;
+  float *rcnn_cls, *out9, *grad_ori, *grad_std_logit, *grad_reg, *grad_reg_std;
+};
+
+__global__ __launch_bounds__(RHL_THREADS) void k_roi_head_losses(RoiHeadLossArgs a) {
+  __shared__ double red[RHL_THREADS];
+  const float l_cls = cls_rescale_body<RHL_THREADS>(a.ori_cls, a.std_logit, a.cls_labels, a.R, a.w_cls, a.rcnn_cls, a.out9 + 1,
+                                                    a.grad_ori, a.grad_std_logit, red);
+  const float l_kl = kl_reg_body<RHL_THREADS>(a.rcnn_reg, a.rcnn_reg_std, a.rois, a.gt_ct, a.gt_ct_ld, a.label_var, a.reg_valid,
+                                              a.R, a.cw, a.beta, a.w_reg, a.out9 + 3, a.grad_reg, a.grad_reg_std, red);
+  __threadfence_block();          // the KL term's rows of grad_reg, written by other threads of this block
+  __syncthreads();
+  const float l_cor = corner_loss_body<RHL_THREADS, true>(a.rcnn_reg, a.rois, a.gt_src, a.gt_src_ld, a.reg_valid, a.R,
+                                                          a.w_corner, a.out9 + 8, a.grad_reg, red);
+  if (threadIdx.x == 0) a.out9[0] = (l_cls + l_kl) + l_cor;
 }
 
 extern "C" int glx_cls_rescale_loss(const float* ori_cls, const float* std_logit,
@@ -714,6 +784,28 @@ extern "C" int glx_cls_rescale_loss(const float* ori_cls, const float* std_logit
   GLX_REQUIRE(!rcnn_cls_labels || out2, "glx_cls_rescale_loss: labels without an output for the loss");
   hipLaunchKernelGGL(k_cls_rescale_loss, dim3(1), dim3(KL_THREADS), 0, (hipStream_t)stream, ori_cls,
                      std_logit, rcnn_cls_labels, R, weight, rcnn_cls, out2, grad_ori, grad_std);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+extern "C" int glx_roi_head_losses(const glx_roi_head_losses_args* args, void* stream) {
+  GLX_REQUIRE(args && args->out, "glx_roi_head_losses: null arguments / output");
+  const glx_roi_head_losses_args& g = *args;
+  GLX_REQUIRE(g.R == 0 || (g.ori_cls && g.std_logit && g.cls_labels && g.rcnn_reg && g.rcnn_reg_std && g.rois && g.gt_ct &&
+                           g.gt_src && g.label_var && g.reg_valid && g.rcnn_cls),
+              "glx_roi_head_losses: null pointer");
+  GLX_REQUIRE(g.gt_ct_ld >= 7 && g.gt_src_ld >= 7, "glx_roi_head_losses: ground-truth rows need >= 7 columns (%d, %d)",
+              g.gt_ct_ld, g.gt_src_ld);
+  RoiHeadLossArgs a;
+  a.ori_cls = g.ori_cls; a.std_logit = g.std_logit; a.cls_labels = g.cls_labels; a.rcnn_reg = g.rcnn_reg;
+  a.rcnn_reg_std = g.rcnn_reg_std; a.rois = g.rois; a.gt_ct = g.gt_ct; a.gt_src = g.gt_src; a.label_var = g.label_var;
+  a.reg_valid = (const long long*)g.reg_valid;
+  a.R = g.R; a.gt_ct_ld = g.gt_ct_ld; a.gt_src_ld = g.gt_src_ld;
+  for (int k = 0; k < 7; ++k) a.cw.w[k] = g.code_weights[k];
+  a.beta = g.beta; a.w_cls = g.w_cls; a.w_reg = g.w_reg; a.w_corner = g.w_corner;
+  a.rcnn_cls = g.rcnn_cls; a.out9 = g.out; a.grad_ori = g.grad_ori; a.grad_std_logit = g.grad_std_logit;
+  a.grad_reg = g.grad_reg; a.grad_reg_std = g.grad_reg_std;
+  hipLaunchKernelGGL(k_roi_head_losses, dim3(1), dim3(RHL_THREADS), 0, (hipStream_t)stream, a);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

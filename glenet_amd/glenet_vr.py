@@ -148,6 +148,8 @@ FC_WGRADS_BEHIND_ROI = os.environ.get("GLX_FC_WGRADS_BEHIND_ROI", "1") != "0"   
 # short launches compete with the BEV convolutions that produce the proposals' inputs, and the RoI branch starts later than
 # it gains.  Off by default (GLX_EARLY_MLP_IN=1).
 EARLY_MLP_IN = os.environ.get("GLX_EARLY_MLP_IN", "0") == "1"
+# the RoI head's three loss terms as one launch / one autograd node (losses.roi_head_losses); 0 = the three entry points
+ROI_LOSSES_ONE_LAUNCH = os.environ.get("GLX_ROI_LOSSES_ONE_LAUNCH", "1") != "0"
 
 
 WGRAD_STREAM_DURING_ROI = os.environ.get("GLX_WGRAD_DURING_ROI", "0") == "1"     # experiment: see StagedLoss.backward
@@ -405,15 +407,24 @@ class GLENetVR(nn.Module):
                                                                   pre=pre)
             mark("RoI-grid pooling + FC towers fwd")
             w = r["LOSS_WEIGHTS"]
-            if ori_cls.is_cuda:      # score rescaling + classification loss + their backward: one launch
-                l_cls, rcnn_cls = losses.cls_rescale_loss(ori_cls, std_logit, cls_lab, weight=w["rcnn_cls_weight"])
+            if ROI_LOSSES_ONE_LAUNCH and losses.roi_head_losses_supported(ori_cls, rcnn_reg, cls_lab, rois_s, gt_ct, gt_src, unc,
+                                                                           reg_valid):
+                # the three terms, their sum and both gradients of rcnn_reg in ONE launch / one autograd node
+                roi_loss, kl_parts, rcnn_cls = losses.roi_head_losses(
+                    ori_cls, std_logit, rcnn_reg, rcnn_std, cls_lab, rois_s, gt_ct, gt_src, unc, reg_valid,
+                    code_weights=w["code_weights"], w_cls=w["rcnn_cls_weight"], w_reg=w["rcnn_reg_weight"],
+                    w_corner=w["rcnn_corner_weight"])
+                l_cls, l_kl, l_cor = kl_parts["cls"], kl_parts["kl"], kl_parts["corner"]
             else:
-                rcnn_cls = losses.cls_rescale_torch(ori_cls, std_logit)
-                l_cls = losses.rcnn_cls_loss_torch(rcnn_cls, cls_lab, weight=w["rcnn_cls_weight"])
-            l_kl, kl_parts = losses.kl_reg_loss(rcnn_reg, rcnn_std, rois_s, gt_ct[..., :7], unc, reg_valid,
-                                                code_weights=w["code_weights"], weight=w["rcnn_reg_weight"])
-            l_cor = losses.corner_loss(rcnn_reg, rois_s, gt_src[..., :7], reg_valid, weight=w["rcnn_corner_weight"])
-            roi_loss = l_cls + l_kl + l_cor
+                if ori_cls.is_cuda:      # score rescaling + classification loss + their backward: one launch
+                    l_cls, rcnn_cls = losses.cls_rescale_loss(ori_cls, std_logit, cls_lab, weight=w["rcnn_cls_weight"])
+                else:
+                    rcnn_cls = losses.cls_rescale_torch(ori_cls, std_logit)
+                    l_cls = losses.rcnn_cls_loss_torch(rcnn_cls, cls_lab, weight=w["rcnn_cls_weight"])
+                l_kl, kl_parts = losses.kl_reg_loss(rcnn_reg, rcnn_std, rois_s, gt_ct[..., :7], unc, reg_valid,
+                                                    code_weights=w["code_weights"], weight=w["rcnn_reg_weight"])
+                l_cor = losses.corner_loss(rcnn_reg, rois_s, gt_src[..., :7], reg_valid, weight=w["rcnn_corner_weight"])
+                roi_loss = l_cls + l_kl + l_cor
             mark("RoI-head losses")
         with torch.no_grad():
             tgt = target_assign.assign_targets([anchors], gt_boxes, [1], [h["matched_threshold"]],

@@ -282,6 +282,67 @@ class _ClsRescaleLoss(torch.autograd.Function):
         return _scaled(ga, g_loss).reshape(ctx.shapes[0]), _scaled(gb, g_loss).reshape(ctx.shapes[1]), None, None
 
 
+class _RoiHeadLosses(torch.autograd.Function):
+    """The RoI head's three terms as one launch (glx_roi_head_losses): see roi_head_losses."""
+
+    @staticmethod
+    def forward(ctx, ori_cls, std_logit, rcnn_reg, rcnn_reg_std, cls_labels, rois, gt_ct, gt_src, label_var, reg_valid, cfg):
+        r = rcnn_reg.shape[0]
+        a, b = ori_cls.reshape(-1).contiguous().float(), std_logit.reshape(-1).contiguous().float()
+        reg, std = rcnn_reg.reshape(r, 7).contiguous().float(), rcnn_reg_std.reshape(r, 7).contiguous().float()
+        _lib.check_cuda(a, b, reg, std, cls_labels, rois, gt_ct, gt_src, label_var, reg_valid)
+        dev = a.device
+        out = torch.empty(10, dtype=torch.float32, device=dev)
+        z, ga, gb = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+        g_reg, g_std = torch.empty_like(reg), torch.empty_like(std)
+        t = _lib.RoiHeadLossesArgs()
+        t.ori_cls, t.std_logit, t.cls_labels = a.data_ptr(), b.data_ptr(), cls_labels.data_ptr()
+        t.rcnn_reg, t.rcnn_reg_std, t.rois = reg.data_ptr(), std.data_ptr(), rois.data_ptr()
+        t.gt_ct, t.gt_ct_ld, t.gt_src, t.gt_src_ld = gt_ct.data_ptr(), gt_ct.shape[-1], gt_src.data_ptr(), gt_src.shape[-1]
+        t.label_var, t.reg_valid, t.R = label_var.data_ptr(), reg_valid.data_ptr(), r
+        cw = cfg["code_weights"]
+        for k in range(7):
+            t.code_weights[k] = float(cw[k]) if cw is not None else 1.0
+        t.beta, t.w_cls, t.w_reg, t.w_corner = cfg["beta"], cfg["w_cls"], cfg["w_reg"], cfg["w_corner"]
+        t.rcnn_cls, t.out = z.data_ptr(), out.data_ptr()
+        t.grad_ori, t.grad_std_logit, t.grad_reg, t.grad_reg_std = ga.data_ptr(), gb.data_ptr(), g_reg.data_ptr(), g_std.data_ptr()
+        _lib.call("glx_roi_head_losses", ctypes.byref(t))
+        ctx.save_for_backward(ga, gb, g_reg, g_std)
+        ctx.shapes = (ori_cls.shape, std_logit.shape, rcnn_reg.shape, rcnn_reg_std.shape)
+        z = z.reshape(ori_cls.shape)
+        parts = out[1:]
+        ctx.mark_non_differentiable(z, parts)
+        return out[0], parts, z
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_parts, _g_z):
+        s = ctx.shapes
+        return tuple(_scaled(g, g_loss).reshape(sh) for g, sh in zip(ctx.saved_tensors, s)) + (None,) * 7
+
+
+def roi_head_losses_supported(ori_cls, rcnn_reg, cls_labels, rois, gt_ct, gt_src, label_var, reg_valid):
+    """The one-launch form takes the target layer's tensors as they are: float32 soft labels, contiguous (.., >= 7)
+    ground-truth rows, an int64 mask."""
+    ok = ori_cls.is_cuda and ori_cls.dtype == torch.float32 and rcnn_reg.dtype == torch.float32
+    for t, dt in ((cls_labels, torch.float32), (rois, torch.float32), (gt_ct, torch.float32), (gt_src, torch.float32),
+                  (label_var, torch.float32), (reg_valid, torch.int64)):
+        ok = ok and t.is_cuda and t.dtype == dt and t.is_contiguous()
+    return bool(ok and rois.shape[-1] == 7 and gt_ct.shape[-1] >= 7 and gt_src.shape[-1] >= 7 and label_var.shape[-1] == 7)
+
+
+def roi_head_losses(ori_cls, std_logit, rcnn_reg, rcnn_reg_std, cls_labels, rois, gt_ct, gt_src, label_var, reg_valid,
+                    code_weights=None, beta=1.0 / 9.0, w_cls=1.0, w_reg=1.0, w_corner=1.0):
+    """cls_rescale_loss + kl_reg_loss + corner_loss (the same arithmetic) as ONE launch and one autograd node:
+    -> (loss, parts, rcnn_cls); parts = device scalars {cls, kl, src, square, log, fg, corner}; gt_ct / gt_src: the
+    (.., >= 7)-column target rows as the target layer leaves them, reg_valid its int64 mask (no compare / cast / slice
+    launches), d loss / d rcnn_reg = KL + corner gradient (no accumulation launch in backward)."""
+    cfg = dict(code_weights=code_weights, beta=float(beta), w_cls=float(w_cls), w_reg=float(w_reg), w_corner=float(w_corner))
+    loss, p, z = _RoiHeadLosses.apply(ori_cls, std_logit, rcnn_reg, rcnn_reg_std, cls_labels.reshape(-1), rois, gt_ct, gt_src,
+                                      label_var, reg_valid.reshape(-1), cfg)
+    p = p.detach()
+    return loss, {"cls": p[0], "kl": p[2], "src": p[3], "square": p[4], "log": p[5], "fg": p[6], "corner": p[7]}, z
+
+
 def cls_rescale_torch(ori_cls, std_logit):
     """voxelrcnn_kl_label_iou_head.py:70-76 in tensor ops: the logit of sigmoid(ori_cls) * sigmoid(std_logit)."""
     p = torch.sigmoid(ori_cls) * torch.sigmoid(std_logit)

@@ -658,6 +658,33 @@ int glx_cls_rescale_loss(const float* ori_cls, const float* std_logit, const flo
                          int R, float weight, float* rcnn_cls, float* out2, float* grad_ori,
                          float* grad_std, void* stream);
 
+/* The three RoI-head loss terms of a training step in ONE launch: GLENet's score rescaling + classification term
+ * (glx_cls_rescale_loss), the KL regression term (glx_kl_reg_loss) and the corner term (glx_corner_loss) -- the same
+ * arithmetic, one block.  Ground-truth rows through a row stride (the (R, 8) target rows as they are), the int64
+ * reg_valid_mask as it is, d loss / d rcnn_reg = KL + corner gradient.
+ * out (device float[10]) = { cls + KL + corner, cls, #valid, KL, src, square, log, #foreground, corner, #foreground };
+ * gradients (d total / d input) or NULL.
+ * Replaces: RoIHeadTemplate.get_loss (pcdet/models/roi_heads/roi_head_template.py:246-272 + 274-291) over
+ * voxelrcnn_kl_label_iou_head.py:70-76, 93-172. */
+typedef struct glx_roi_head_losses_args {
+  const float* ori_cls; const float* std_logit;      /* (R) logits of the two towers */
+  const float* cls_labels;                           /* (R) soft IoU labels, < 0 = ignored */
+  const float* rcnn_reg; const float* rcnn_reg_std;  /* (R, 7) */
+  const float* rois;                                 /* (R, 7) LiDAR frame */
+  const float* gt_ct; int gt_ct_ld;                  /* matched ground truth in the RoI frame, row stride >= 7 floats */
+  const float* gt_src; int gt_src_ld;                /* ... in the LiDAR frame */
+  const float* label_var;                            /* (R, 7) label variances */
+  const int64_t* reg_valid;                          /* (R) > 0 = foreground */
+  int R;
+  float code_weights[7];
+  float beta, w_cls, w_reg, w_corner;
+  float* rcnn_cls;                                   /* (R) out: the rescaled logit */
+  float* out;                                        /* float[10] */
+  float* grad_ori; float* grad_std_logit;            /* (R) or NULL */
+  float* grad_reg; float* grad_reg_std;              /* (R, 7) or NULL */
+} glx_roi_head_losses_args;
+int glx_roi_head_losses(const glx_roi_head_losses_args* args, void* stream);
+
 /* Predicted boxes of the anchor head: box_preds (B, A, 7) residuals, dir_preds (B, A, num_dir_bins) or NULL,
  * anchors (A, 7) -> boxes (B, A, 7): ResidualCoder.decode_torch + the heading moved into the predicted
  * direction bin, with the rounding of the tensor expression.

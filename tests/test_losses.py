@@ -165,6 +165,51 @@ def test_fused_score_rescaling_and_cls_loss_match_the_tensor_formulation(dev):
     np.testing.assert_allclose(a2.grad.cpu().numpy() * 0.7, af.grad.cpu().numpy(), rtol=1e-6, atol=1e-12)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("no_fg", [False, True])
+def test_roi_head_losses_one_launch_equals_the_three_entry_points(dev, no_fg):
+    """glx_roi_head_losses (the three RoI-head terms, their sum and d loss / d rcnn_reg = KL + corner in one launch,
+    8-column ground-truth rows through their stride, int64 mask) vs cls_rescale_loss + kl_reg_loss + corner_loss --
+    each pinned by the reference goldens above -- on the golden fixture's rows: values 2e-6, gradients 1e-5."""
+    reg0, std0, rois, gt, unc, valid = _inputs(dev)
+    R = reg0.shape[0]
+    g = torch.Generator().manual_seed(11)
+    a0 = (torch.randn(R, 1, generator=g) * 3).to(dev)
+    b0 = (torch.randn(R, 1, generator=g) * 2 + 1).to(dev)
+    lab = torch.rand(R, generator=g).to(dev)
+    lab[::5] = -1.0
+    gt_src = torch.from_numpy(G["gt_of_rois_src"]).to(dev)
+    pad = lambda t: torch.cat([t.reshape(R, 7), torch.full((R, 1), 3.0, device=dev)], 1).contiguous()   # noqa: E731  + class column
+    gt8, src8 = pad(gt), pad(gt_src)
+    valid = (torch.zeros_like(valid) if no_fg else valid).long().contiguous()
+    cw, beta = G["code_weights"].tolist(), float(G["beta"])
+    leaves = lambda: [t.detach().clone().requires_grad_(True) for t in (a0, b0, reg0, std0)]   # noqa: E731
+    a, b, reg, std = leaves()
+    l_cls, z = losses.cls_rescale_loss(a, b, lab, weight=1.5)
+    l_kl, kp = losses.kl_reg_loss(reg, std, rois, gt, unc, valid, code_weights=cw, beta=beta, weight=0.8)
+    l_cor = losses.corner_loss(reg, rois, gt_src, valid, weight=1.2)
+    want = l_cls + l_kl + l_cor
+    (want * 0.7).backward()
+    af, bf, regf, stdf = leaves()
+    assert losses.roi_head_losses_supported(af, regf, lab, rois, gt8, src8, unc, valid)
+    got, parts, zf = losses.roi_head_losses(af, bf, regf, stdf, lab, rois, gt8, src8, unc, valid, code_weights=cw, beta=beta,
+                                            w_cls=1.5, w_reg=0.8, w_corner=1.2)
+    assert zf.shape == a0.shape and not zf.requires_grad and torch.equal(zf, z)
+    (got * 0.7).backward()
+    np.testing.assert_allclose(float(got.detach()), float(want.detach()), rtol=2e-6)
+    for k, w in (("cls", l_cls), ("kl", l_kl), ("corner", l_cor), ("src", kp["src"]), ("square", kp["square"]),
+                 ("log", kp["log"]), ("fg", kp["fg"])):
+        np.testing.assert_allclose(float(parts[k]), float(w.detach()), rtol=2e-6, atol=1e-7, err_msg=k)
+    for gf, gw, name in ((af, a, "ori"), (bf, b, "std logit"), (regf, reg, "reg"), (stdf, std, "reg std")):
+        scale = float(gw.grad.abs().max())
+        np.testing.assert_allclose(gf.grad.cpu().numpy(), gw.grad.cpu().numpy(), rtol=1e-5, atol=1e-7 + 1e-6 * scale,
+                                   err_msg=name)
+    if no_fg:
+        assert float(regf.grad.abs().max()) == 0.0 and float(parts["corner"]) == 0.0 and float(parts["kl"]) == 0.0
+    else:
+        assert float(parts["corner"]) > 0 and float(regf.grad.abs().max()) > 0
+
+
 def _kl_head_golden():
     import os
     return np.load(os.path.join(os.path.dirname(__file__), "golden", "kl_label_head_ref.npz"))
