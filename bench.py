@@ -605,6 +605,16 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args, sys.argv[1:]))
 
+    # stdout carries ONE line, the JSON.  Libraries write there too (RCCL prints its version banner to the C stdout at
+    # communicator creation and flushes it at exit -- BEHIND the JSON line, measured with GLX_BENCH_FORCE_DP=1): from here
+    # on descriptor 1 is stderr for everybody, and the JSON goes to the saved original.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     import numpy as np
     import torch
 
@@ -631,7 +641,10 @@ def main():
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    gdist.init(backend, device=dev)
+    # GLX_BENCH_FORCE_DP=1: the data-parallel step (two graphs, RCCL all-reduce on the flat gradient buffer, scaled update)
+    # with whatever world size there is -- on ONE GPU the N > 1 code path over real RCCL; a plumbing mode like the gloo one
+    dp = world > 1 or os.environ.get("GLX_BENCH_FORCE_DP") == "1"
+    gdist.init(backend, device=dev, force=dp)
     ranks_seen = gdist.reduce_sum_int(1, dev)          # the collective saw this many ranks
 
     K = synth.KITTI
@@ -670,17 +683,19 @@ def main():
     if args.device_data_step:
         from glenet_amd.data_pipeline import DeviceDataProcessor
         pipe.data_step = DeviceDataProcessor(K, training=True, shuffle=True, seed=1000 + rank)
-    if world > 1:        # data-parallel: one all-reduce on the flat gradient buffer between backward and update
+    if dp:               # data-parallel: one all-reduce on the flat gradient buffer between backward and update
         pipe.data_parallel()
+        if world == 1:
+            pipe.step_optimizer.exchange_alone = True      # the collective runs although it has nobody to talk to
     pipe.load(*pool[0][:4])
     progress("model + %d batches resident, capacities calibrated; capturing the step" % BATCH_POOL)
     if args.roofline_only:
         args.steps = args.warmup = 0
         args.no_stages = True
     elif args.mode == "graph":
-        pipe.capture(split=world > 1)
+        pipe.capture(split=dp)
     else:
-        pipe.split = world > 1
+        pipe.split = dp
     it = [0]
 
     def train_step():
@@ -730,7 +745,7 @@ def main():
     # ---- N > 1 diagnostics (outside the timed region): per-rank step time, the gradient exchange alone (events around
     # the all-reduce on the stream it runs on, the two graphs of a step replayed around it) and per-rank host enqueue cost
     per_rank = None
-    if world > 1 and args.steps > 0:
+    if dp and args.steps > 0:
         ex_ms = None
         if getattr(pipe, "exchange", None) is not None and pipe.graph is not None and pipe.update_graph is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -754,7 +769,7 @@ def main():
     # pool, and the differences of the stamps are averaged.  (Events would split the graph, the profiler's per-kernel
     # signals stretch it by ~1 ms; a stamp costs one 2-3 us launch.)
     stages = None
-    if not args.no_stages and args.mode == "graph" and pipe.graph is not None and world == 1:      # an N = 1 diagnostic
+    if not args.no_stages and args.mode == "graph" and pipe.graph is not None and not dp:      # an N = 1 diagnostic
         stamps = torch.zeros(64, dtype=torch.int64, device=dev)
         names = []
 
@@ -765,7 +780,7 @@ def main():
             names.append(name)
         pipe.mark = model.mark = mark
         torch.cuda.synchronize(dev)
-        pipe.capture(split=world > 1)
+        pipe.capture(split=dp)
         acc = {}
         for j in range(3 * BATCH_POOL):
             pipe.load(*pool[j % BATCH_POOL][:4])
@@ -784,7 +799,7 @@ def main():
                           "on their own stream beside the anchor targets, the dense-head loss and the first two backward "
                           "stages; rule tables and weight gradients run on a third")
         torch.cuda.synchronize(dev)
-        pipe.capture(split=world > 1)          # the recording without stamps again
+        pipe.capture(split=dp)          # the recording without stamps again
         pipe.load(*pool[0][:4])
         pipe.step()                            # ... and its buffers filled (the config block below reads row counts)
         torch.cuda.synchronize(dev)
@@ -847,8 +862,8 @@ def main():
 
     if rank == 0:
         if args.roofline_only:
-            print(json.dumps(dict(metric=METRIC, value=None, unit="frames/s", n_gpus=world, roofline_only=True,
-                                  dtype="f32", data="synthetic", roofline=roof)), flush=True)
+            emit(dict(metric=METRIC, value=None, unit="frames/s", n_gpus=world, roofline_only=True,
+                      dtype="f32", data="synthetic", roofline=roof))
             return
         st = pipe.out["encoded_spconv_tensor"]
         out = dict(metric=METRIC, value=round(FRAMES_PER_GPU * world * args.steps / dt, 2), unit="frames/s",
@@ -865,10 +880,10 @@ def main():
                                voxels_in=int(pipe.out["voxel_index"].count.item()), voxels_out=int(st.count.item()),
                                proposal_seeding="first 15 proposal slots per frame = ground truth + fixed offset "
                                                 "(stands in for a trained first stage; random-init weights)",
-                               mode={"graph": "shape-static step replayed as %d HIP graph(s)" % (2 if world > 1 else 1),
+                               mode={"graph": "shape-static step replayed as %d HIP graph(s)" % (2 if dp else 1),
                                      "static": "shape-static step, launches enqueued from Python"}[args.mode],
                                parallelism="dp%d: frames shard; one flat RCCL all-reduce of %.1f MB gradients per step"
-                                           % (world, n_params * 4 / 1e6) if world > 1 else "dp1 (single GPU, no collective)",
+                                           % (world, n_params * 4 / 1e6) if dp else "dp1 (single GPU, no collective)",
                                ranks_seen_by_collective=ranks_seen,
                                device_data_step=bool(args.device_data_step),
                                arithmetic="fp32 tensors and fp32 accumulation everywhere; the BEV backbone's convolutions form "
@@ -894,7 +909,7 @@ def main():
                                         "waiting for the slowest rank's backward); host_enqueue: set_lr + load + replay + "
                                         "all_reduce + replay from an idle queue")
         progress("config1 + roofline done")
-        if world == 1 and not args.no_extra:
+        if not dp and not args.no_extra:
             out["bev"] = bench_bev(model, dev)
             progress("bev done")
             state = {k: v.detach().clone() for k, v in model.state_dict().items()}
@@ -913,11 +928,11 @@ def main():
             torch.cuda.empty_cache()
             out["config4"] = bench_config4(dev)
             progress("config4 done")
-        if world == 1 and not args.no_cpu_baseline:
+        if not dp and not args.no_cpu_baseline:
             from oracle import baseline as cpu_base           # bench's cpu_baseline leg: the checker, timed
             out["cpu_baseline"] = cpu_base.config3_composite([b[4] for b in pool[:1]], model, K)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        emit(out)
+    if dp:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

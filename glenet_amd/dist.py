@@ -14,10 +14,13 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend="nccl", device=None):
+def init(backend="nccl", device=None, force=False):
+    """force: initialise the process group for a single process too (bench.py's GLX_BENCH_FORCE_DP plumbing mode: the
+    N > 1 code path over real RCCL on one GPU)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29653")
         kw = {"device_id": device} if (device is not None and backend == "nccl") else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world

@@ -98,7 +98,9 @@ class FlatAdamW:
         plumbing tests goes through a host copy).  average: the 1 / world_size of DistributedDataParallel is folded
         into the update (`grad_scale`, read by glx_adamw_clip_step_scaled) instead of a pass over the buffer."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        if dist.get_world_size() == 1 and not getattr(self, "exchange_alone", False):
             return
         self.grad_scale = 1.0 / dist.get_world_size() if average else 1.0
         buf = self.flat_grad
