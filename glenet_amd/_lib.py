@@ -94,6 +94,23 @@ def query(name, *args):
     return int(getattr(lib, name)(*[_arg(a) for a in args]))
 
 
+CONV_GRADS_IN_PLACE = os.environ.get("GLX_CONV_GRADS_IN_PLACE", "1") != "0"
+
+
+def grad_buffer(param, shape=None):
+    """Where a weight-gradient kernel writes d loss / d `param`: a fresh alias of the optimizer's flat gradient buffer
+    (FlatAdamW leaves `param._glx_grad_view`) when the parameter has no gradient yet -- autograd's AccumulateGrad takes the
+    tensor as it is (no other owner, the parameter's layout), `FlatAdamW.pack_grads` finds it in place and copies nothing --
+    else a new tensor.  shape: the kernel's view of the weight (same element order), default the parameter's."""
+    view = getattr(param, "_glx_grad_view", None) if (CONV_GRADS_IN_PLACE and param is not None) else None
+    if (view is not None and param.grad is None and view.shape == param.shape and view.stride() == param.stride()
+            and view.dtype == param.dtype and (shape is None or view.is_contiguous())):
+        g = view.detach()       # the parameter's own strides (channels-last filters keep theirs): the kernels write through them
+        return g if shape is None else g.view(shape)
+    like = param if shape is None else param.reshape(shape)
+    return torch.empty_like(like, memory_format=torch.contiguous_format) if shape is not None else torch.empty_like(like)
+
+
 def size_arg(n):
     return c_size_t(int(n))
 

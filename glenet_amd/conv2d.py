@@ -150,7 +150,7 @@ def wgrad(x, gy, weight, pre=None):
         coef, relu = pre
         prologue = ctypes.byref(_lib.epilogue(coef[:cin], coef[cin:], relu))
     ws = _lib.workspace.get(n, x.device)
-    gw = torch.empty_like(weight)
+    gw = _lib.grad_buffer(weight)       # the optimizer's flat gradient buffer when the step has one (no gather copy)
     s = gw.stride()
     call("glx_conv3x3_wgrad_ex", x, gy, b, h, w, cin, cout, gw, ll(s[0]), ll(s[1]), ll(s[2]), ll(s[3]), prologue, ws,
          _lib.size_arg(n))

@@ -564,7 +564,8 @@ class SparseConvFunction(Function):
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
                 pairs = USE_PAIR_LISTS and n_fwd_out > 0 and query("glx_sconv_packed_bytes", K, cin, cout)
                 if pairs:
-                    g_w = torch.empty_like(w)
+                    # written where the optimizer reads it when the parameter is a plain view of `w` (no gather copy)
+                    g_w = _lib.grad_buffer(ctx.leaf, w.shape) if ctx.leaf is not None else torch.empty_like(w)
                     pl = rules.pair_lists(fwd_nbr, n_fwd_out, live_fwd)
                     wsb = query("glx_sconv_wgrad_pairs_workspace_bytes", n_fwd_out, K, cin, cout)
                     ws = workspace.get(wsb, w.device)

@@ -139,6 +139,13 @@ def test_static_step_and_graph_reproduce_the_exact_shape_step(dev):
     pipe.check()
     check(pipe, "shape-static eager")
     assert torch.is_tensor(pipe.loss) and not pipe.loss.requires_grad
+    # the 3x3 / sparse convolutions' and the FC layers' weight gradients were written straight into the optimizer's flat
+    # gradient buffer (_lib.grad_buffer): their .grad IS the buffer's view, pack_grads has nothing to gather for them
+    in_place = [n for n, p in model.named_parameters() if p.grad is not None and getattr(p, "_glx_grad_view", None) is not None
+                and p.grad.data_ptr() == p._glx_grad_view.data_ptr() and p.grad.stride() == p._glx_grad_view.stride()]
+    assert sum(n.startswith("backbone_3d") for n in in_place) >= 4, in_place
+    assert sum(n.startswith("backbone_2d") for n in in_place) >= 4, in_place
+    assert sum(n.startswith("roi_head") for n in in_place) >= 1, in_place
     total = sum(want_parts[k] for k in ("loss_rpn", "rcnn_loss_cls", "rcnn_loss_reg", "rcnn_loss_corner"))
     np.testing.assert_allclose(float(pipe.loss), total, rtol=2e-4)
     pipe.capture()
