@@ -65,7 +65,14 @@ def _arg(a):
     return a
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """The current torch stream of the current device as a hipStream_t (every entry point's last argument).  The raw getter
+    skips building a torch.cuda.Stream object per call: 925 of them per eager training step were 0.5 ms of host time."""
+    if _raw_stream is not None:
+        return c_void_p(_raw_stream(torch.cuda.current_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -1,7 +1,7 @@
 """Per-step kernel table from a rocprofv3 --kernel-trace CSV: keeps the launches between the (N+1)-th last and
 the last occurrence of a once-per-step marker kernel (so warm-up, MIOpen's find-mode trials and the sub-measurements
 of bench.py do not pollute it) and aggregates by kernel name.
-usage: python tools/trace_window.py <kernel_trace.csv> [--steps 10] [--marker k_kl_reg_loss] [--top 70] [--out file.md]"""
+usage: python tools/trace_window.py <kernel_trace.csv> [--steps 10] [--marker k_roi_head_losses] [--top 70] [--out file.md]"""
 import argparse
 import collections
 import csv
@@ -11,7 +11,7 @@ import sys
 ap = argparse.ArgumentParser()
 ap.add_argument("trace")
 ap.add_argument("--steps", type=int, default=10)
-ap.add_argument("--marker", default="k_kl_reg_loss")
+ap.add_argument("--marker", default="k_roi_head_losses")
 ap.add_argument("--top", type=int, default=70)
 ap.add_argument("--out")
 ap.add_argument("--seq", help="also write the launches of the LAST step in time order (start us, duration us, name)")
