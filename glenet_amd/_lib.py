@@ -102,6 +102,11 @@ def query(name, *args):
 
 
 CONV_GRADS_IN_PLACE = os.environ.get("GLX_CONV_GRADS_IN_PLACE", "1") != "0"
+_grad_generation = [0]      # bumped by FlatAdamW.pack_grads: one lending of a parameter's gradient view per optimizer step
+
+
+def next_grad_generation():
+    _grad_generation[0] += 1
 
 
 def grad_buffer(param, shape=None):
@@ -110,8 +115,12 @@ def grad_buffer(param, shape=None):
     tensor as it is (no other owner, the parameter's layout), `FlatAdamW.pack_grads` finds it in place and copies nothing --
     else a new tensor.  shape: the kernel's view of the weight (same element order), default the parameter's."""
     view = getattr(param, "_glx_grad_view", None) if (CONV_GRADS_IN_PLACE and param is not None) else None
-    if (view is not None and param.grad is None and view.shape == param.shape and view.stride() == param.stride()
+    # lent ONCE per optimizer step: a weight that two layers share gets two gradients in one backward pass, the second of
+    # which must not land on the first (autograd adds it to .grad, which is then the view: still no gather)
+    if (view is not None and param.grad is None and getattr(param, "_glx_grad_lent", -1) != _grad_generation[0]
+            and view.shape == param.shape and view.stride() == param.stride()
             and view.dtype == param.dtype and (shape is None or view.is_contiguous())):
+        param._glx_grad_lent = _grad_generation[0]
         g = view.detach()       # the parameter's own strides (channels-last filters keep theirs): the kernels write through them
         return g if shape is None else g.view(shape)
     like = param if shape is None else param.reshape(shape)

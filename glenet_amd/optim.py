@@ -91,6 +91,7 @@ class FlatAdamW:
                     v.zero_()
         if have:
             torch._foreach_copy_([h[0] for h in have], [h[1] for h in have])
+        _lib.next_grad_generation()       # the views may be lent to the next backward pass (_lib.grad_buffer)
         return self.flat_grad
 
     def allreduce_(self, average=True):

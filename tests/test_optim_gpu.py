@@ -79,3 +79,36 @@ def test_flat_adamw_replays_in_a_graph_and_handles_missing_grads(dev):
     for i, (p, q) in enumerate(zip(ours, ref)):
         np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=5e-5, atol=5e-7,
                                    err_msg="parameter %d" % i)
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_conv_weight_gradient_lands_in_the_flat_buffer(dev, shared):
+    """_lib.grad_buffer: the own 3x3 convolution writes dW straight into FlatAdamW's gradient view (the parameter's .grad
+    IS the view: pack_grads has nothing to gather), every step anew.  The view is lent ONCE per optimizer step: a weight
+    that two layers share gets its second gradient in a tensor of its own, the engine sums the two, and the flat buffer
+    ends with that sum through the gather."""
+    from glenet_amd import conv2d
+    from glenet_amd.optim import FlatAdamW
+    torch.manual_seed(3)
+    w0 = (torch.randn(64, 64, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+    w1 = (torch.randn(64, 64, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+    x = torch.randn(2, 64, 24, 16, device=dev).contiguous(memory_format=torch.channels_last)
+
+    def loss(a, b):
+        return conv2d.conv3x3(torch.relu(conv2d.conv3x3(x, a)), b).square().mean()
+    pa, pb = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(w1.clone())
+    loss(pa, pa if shared else pb).backward()
+    want = pa.grad.clone()
+    oa, ob = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(w1.clone())
+    opt = FlatAdamW([oa, ob], lr=0.0, weight_decay=0.0, max_norm=None)
+    view = oa._glx_grad_view
+    assert view.stride() == oa.stride() and not view.is_contiguous()
+    for step in range(2):
+        oa.grad = ob.grad = None
+        loss(oa, oa if shared else ob).backward()
+        np.testing.assert_allclose(oa.grad.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-8)
+        if not shared:
+            assert oa.grad.data_ptr() == view.data_ptr() and oa.grad.stride() == view.stride(), step
+            assert ob.grad.data_ptr() == ob._glx_grad_view.data_ptr(), step
+        opt.pack_grads()
+        np.testing.assert_allclose(view.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-8)
