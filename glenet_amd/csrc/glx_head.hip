@@ -301,6 +301,149 @@ __global__ __launch_bounds__(HD_THREADS) void k_head_dgrad_bn(HeadGrad g, long l
   if (threadIdx.x == 0) __hip_atomic_store(&bb.state->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Second form of k_head_dgrad_bn (c0 a multiple of 64): a WAVE owns 64 channels (four column tiles) of the block's 64
+// pixels instead of 16 pixels x all channels.  What that buys: the filter operands of its tiles live in registers (no LDS
+// read per MFMA), the BatchNorm-backward sums stay in per-lane registers over all passes and are reduced across lanes
+// ONCE at the end (the first form spent 32 cross-lane steps per 16-channel group and pass, as many issue cycles as its
+// MFMAs), and eight 16-byte loads of the raw map per lane are in flight before the first product is needed (the first
+// form had two).  The gradient rows of the 64 pixels (80 bytes each) are read by every wave (L2 hits).
+__global__ __launch_bounds__(HD_THREADS) void k_head_dgrad_bn2(HeadGrad g, long long M, HeadW hw, HeadBnBwd bb) {
+  constexpr int C = 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_w = smem;                                    // HD_MAXO x (C + 4)
+  const int ld = C + 4;
+  float* s_par = s_w + HD_MAXO * ld;                    // scale | shift | mean | invstd, C each (concatenated channel order)
+  float* s_sum = s_par + 4 * C;                         // C x 2
+  float* s_g = s_sum + 2 * C;                           // HD_PIX x 33: the pass's gradient rows (zero beyond the heads' total)
+  __shared__ int s_last;
+  hd_load_w(hw.w, hw.n, C, s_w);
+  const int c0 = bb.c0, c1 = C - bb.c0;
+  for (int c = threadIdx.x; c < C; c += HD_THREADS) {
+    const int p = c < c0 ? 0 : 1, cc = c - (p ? c0 : 0), cp = p ? c1 : c0;
+    s_par[c] = bb.coef[p][cc];
+    s_par[C + c] = bb.coef[p][cp + cc];
+    s_par[2 * C + c] = bb.mean[p][cc];
+    s_par[3 * C + c] = bb.invstd[p][cc];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int cw = 64 * wave;                             // the wave's first channel (concatenated order)
+  const int p = cw < c0 ? 0 : 1, cp = p ? c1 : c0;      // its part, wave-uniform (c0 % 64 == 0)
+  const int cpart = cw - (p ? c0 : 0);                  // first channel inside the part
+  const float* __restrict__ yp = bb.y[p];
+  float* __restrict__ dzp = bb.dz[p];
+  float sg[4][4], sx[4][4];                             // per lane: sum dz, sum dz * xhat of channel cw + 16 tl + 4 kq + e
+#pragma unroll
+  for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sg[tl][e] = 0.f; sx[tl][e] = 0.f; }
+  const int n0 = g.n[0], n1 = g.n[1], n2 = g.n[2];
+  for (long long m0 = (long long)blockIdx.x * HD_PIX; m0 < M; m0 += (long long)gridDim.x * HD_PIX) {
+    {   // the pass's gradient rows into LDS: thread = (pixel, eight output channels)
+      const int px = threadIdx.x >> 2, o0 = (threadIdx.x & 3) * 8;
+      const long long m = m0 + px;
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int o = o0 + u;
+        v[u] = 0.f;
+        if (m < M) {
+          if (o < n0) v[u] = g.p[0][m * n0 + o];
+          else if (o < n0 + n1) v[u] = g.p[1][m * n1 + (o - n0)];
+          else if (o < n0 + n1 + n2) v[u] = g.p[2][m * n2 + (o - n0 - n1)];
+        }
+      }
+      __syncthreads();          // the previous pass has read its rows
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s_g[px * 33 + o0 + u] = v[u];
+      __syncthreads();
+    }
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {          // two pixel groups of 16 at a time: 8 loads of the raw map in flight per lane
+      hf32x4 yv[2][4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const long long m = m0 + 16 * (2 * h + q) + i;
+        const long long mc = m < M ? m : M - 1;
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) yv[q][tl] = *reinterpret_cast<const hf32x4*>(yp + mc * cp + cpart + 16 * tl + 4 * kq);
+      }
+      float ga[2][8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) ga[q][s] = s_g[(16 * (2 * h + q) + i) * 33 + 4 * s + kq];
+      int lo = 0;
+      asm volatile("" : "+v"(lo));         // an opaque 0: the LDS reads below stay inside the loop (hoisted, the per-channel
+                                           // coefficients and filter columns of all four tiles were 96 live registers)
+#pragma unroll
+      for (int tl = 0; tl < 4; ++tl) {
+        const int c = cw + 16 * tl + 4 * kq + lo;
+        const hf32x4 sc = *reinterpret_cast<const hf32x4*>(s_par + c), sh = *reinterpret_cast<const hf32x4*>(s_par + C + c);
+        const hf32x4 mu = *reinterpret_cast<const hf32x4*>(s_par + 2 * C + c), is = *reinterpret_cast<const hf32x4*>(s_par + 3 * C + c);
+        float wv[8];                                      // A[m = channel cw + 16 tl + i][k = o = 4 s + kq]
+#pragma unroll
+        for (int s = 0; s < 8; ++s) wv[s] = s_w[(4 * s + kq) * ld + cw + 16 * tl + i + lo];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const long long m = m0 + 16 * (2 * h + q) + i;
+          hf32x4 acc = hf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], ga[q][s], acc, 0, 0, 0);
+          hf32x4 gv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float y = yv[q][tl][e];
+            gv[e] = (m < M && bn_affine(y, sc[e], sh[e]) > 0.f) ? acc[e] : 0.f;
+            sg[tl][e] += gv[e];
+            sx[tl][e] += gv[e] * ((y - mu[e]) * is[e]);
+          }
+          if (m < M) *reinterpret_cast<hf32x4*>(dzp + m * cp + cpart + 16 * tl + 4 * kq) = gv;
+        }
+      }
+    }
+  }
+  // sums over the lanes i of a kq group, once
+#pragma unroll
+  for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int x = 1; x < 16; x <<= 1) {
+        sg[tl][e] += __shfl_xor(sg[tl][e], x, 64);
+        sx[tl][e] += __shfl_xor(sx[tl][e], x, 64);
+      }
+      if (i == 0) {
+        s_sum[(cw + 16 * tl + 4 * kq + e) * 2] = sg[tl][e];
+        s_sum[(cw + 16 * tl + 4 * kq + e) * 2 + 1] = sx[tl][e];
+      }
+    }
+  __syncthreads();
+  double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+  if (threadIdx.x < C / 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a0[j] = (double)s_sum[(4 * threadIdx.x + j) * 2];
+      a1[j] = (double)s_sum[(4 * threadIdx.x + j) * 2 + 1];
+    }
+  }
+  if (!bn_contribute(bb.state, C, a0, a1, gridDim.x, &s_last)) return;
+  const double cnt = (double)M;
+  for (int c = threadIdx.x; c < C; c += HD_THREADS) {
+    double s = 0, ss = 0;
+    for (int k = 0; k < BN_SETS; ++k) { s += bn_take(&bb.state->acc[k][c]); ss += bn_take(&bb.state->acc[k][BN_MAXC + c]); }
+    const int pp = c < c0 ? 0 : 1, cc = c - (pp ? c0 : 0), cq = pp ? c1 : c0;
+    bb.coef3[pp][cc] = (bb.gamma[pp] ? bb.gamma[pp][cc] : 1.f) * bb.invstd[pp][cc];
+    bb.coef3[pp][cq + cc] = (float)(s / cnt);
+    bb.coef3[pp][2 * cq + cc] = (float)(ss / cnt);
+    bb.dgamma[pp][cc] = (float)ss;
+    bb.dbeta[pp][cc] = (float)s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&bb.state->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // gW[o, c] = sum_m g[m, o] x[m, c], gb[o] = sum_m g[m, o]: contraction over pixels.  A = g^T (lane (i, kq): output channel
 // i (+16), pixel 4 s + kq), B = x (lane (j, kq): pixel 4 s + kq, channel 16 t + j).  A wave owns C / 64 column tiles... a block
 // of 4 waves covers C = 256 with 4 column tiles per wave; partial sums per block go to the workspace, k_head_wreduce adds
@@ -476,7 +619,8 @@ extern "C" int glx_head1x1_forward_parts(const float* x0, const float* x1, int c
   rc = head_lds_attr((const void*)k_head_fwd, lds);
   if (rc != GLX_OK) return rc;
   long long blocks = (M + HD_PIX - 1) / HD_PIX;
-  if (blocks > 2048) blocks = 2048;
+  static const int fwd_blocks = getenv("GLX_HEAD_FWD_BLOCKS") ? atoi(getenv("GLX_HEAD_FWD_BLOCKS")) : 1024;    // the resident count (four 35 KB blocks per CU): 44.6 us; 512: 50.2, 768: 46.4, 1536: 51.5, 2048: 49.1
+  if (blocks > fwd_blocks) blocks = fwd_blocks;
   hipLaunchKernelGGL(k_head_fwd, dim3((unsigned)blocks), dim3(HD_THREADS), lds, (hipStream_t)stream, in, (long long)M, C, hw, ho);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
@@ -528,10 +672,24 @@ extern "C" int glx_head1x1_input_grad_bn(const float* const* grad, int64_t M, in
     hg.p[k] = grad[k]; hg.n[k] = n[k];
     GLX_REQUIRE(n[k] == 0 || (W[k] && grad[k]), "glx_head1x1_input_grad_bn: head %d has no weights / gradient", k);
   }
+  long long blocks = (M + HD_PIX - 1) / HD_PIX;
+  // measured (round 4): alone 74 us against the first form's 109; inside the recorded step the head's backward stage takes
+  // 0.31 ms either way (the weight gradient reads the same 144 MB beside it on the weight-gradient stream, the RoI branch's
+  // proposal kernels on a third) and the step is 6.085 against 6.074 ms over six alternating pairs: opt-in
+  static const int v2 = getenv("GLX_HEAD_DGRAD_V2") ? atoi(getenv("GLX_HEAD_DGRAD_V2")) : 0;
+  static const int v2_blocks = getenv("GLX_HEAD_DGRAD_BLOCKS") ? atoi(getenv("GLX_HEAD_DGRAD_BLOCKS")) : 512;   // two resident blocks per CU: 74 us; 768: 97, 1024: 87, 2048: 108 (per-block filter image + atomics)
+  if (v2 && c0 % 64 == 0) {       // a wave owns 64 channels: weights and sums in registers, 16 loads in flight
+    const size_t lds2 = (size_t)HD_MAXO * (C + 4) * 4 + (size_t)4 * C * 4 + (size_t)C * 2 * 4 + (size_t)HD_PIX * 33 * 4;
+    rc = head_lds_attr((const void*)k_head_dgrad_bn2, lds2);
+    if (rc != GLX_OK) return rc;
+    if (blocks > v2_blocks) blocks = v2_blocks;
+    hipLaunchKernelGGL(k_head_dgrad_bn2, dim3((unsigned)blocks), dim3(HD_THREADS), lds2, (hipStream_t)stream, hg, (long long)M, hw, bb);
+    GLX_LAUNCH_CHECK();
+    return GLX_OK;
+  }
   const size_t lds = (size_t)HD_MAXO * (C + 4) * 4 + (size_t)4 * C * 4 + (size_t)4 * C * 2 * 4;
   rc = head_lds_attr((const void*)k_head_dgrad_bn, lds);
   if (rc != GLX_OK) return rc;
-  long long blocks = (M + HD_PIX - 1) / HD_PIX;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(k_head_dgrad_bn, dim3((unsigned)blocks), dim3(HD_THREADS), lds, (hipStream_t)stream, hg, (long long)M, hw, bb);
   GLX_LAUNCH_CHECK();
