@@ -650,7 +650,14 @@ extern "C" int glx_head1x1_input_grad(const float* const* grad, int64_t M, int C
 extern "C" int glx_head1x1_input_grad_bn(const float* const* grad, int64_t M, int C, const float* const* W, const int32_t* n,
                                          const float* y0, const float* y1, int c0, const glx_bn_bwd_stats* bn0,
                                          const glx_bn_bwd_stats* bn1, float* dz0, float* dz1, void* stream) {
+  return glx_head1x1_input_grad_bn_form(grad, M, C, W, n, y0, y1, c0, bn0, bn1, dz0, dz1, 0, stream);
+}
+
+extern "C" int glx_head1x1_input_grad_bn_form(const float* const* grad, int64_t M, int C, const float* const* W, const int32_t* n,
+                                              const float* y0, const float* y1, int c0, const glx_bn_bwd_stats* bn0,
+                                              const glx_bn_bwd_stats* bn1, float* dz0, float* dz1, int form, void* stream) {
   GLX_REQUIRE(grad && W && n && y0 && y1 && bn0 && bn1 && dz0 && dz1, "glx_head1x1_input_grad_bn: null pointer");
+  GLX_REQUIRE(form == 0 || form == 1, "glx_head1x1_input_grad_bn_form: form %d (0: a wave owns 16 pixels, 1: 64 channels)", form);
   GLX_REQUIRE(C == 256 && c0 > 0 && c0 < C && c0 % 16 == 0, "glx_head1x1_input_grad_bn: C = %d (256), first part %d", C, c0);
   int rc = head_check(M, C, n, "glx_head1x1_input_grad_bn");
   if (rc != GLX_OK) return rc;
@@ -673,10 +680,10 @@ extern "C" int glx_head1x1_input_grad_bn(const float* const* grad, int64_t M, in
     GLX_REQUIRE(n[k] == 0 || (W[k] && grad[k]), "glx_head1x1_input_grad_bn: head %d has no weights / gradient", k);
   }
   long long blocks = (M + HD_PIX - 1) / HD_PIX;
-  // measured (round 4): alone 74 us against the first form's 109; inside the recorded step the head's backward stage takes
+  // form 1 measured (round 4): alone 74 us against form 0's 109; inside the recorded step the head's backward stage takes
   // 0.31 ms either way (the weight gradient reads the same 144 MB beside it on the weight-gradient stream, the RoI branch's
-  // proposal kernels on a third) and the step is 6.085 against 6.074 ms over six alternating pairs: opt-in
-  static const int v2 = getenv("GLX_HEAD_DGRAD_V2") ? atoi(getenv("GLX_HEAD_DGRAD_V2")) : 0;
+  // proposal kernels on a third) and the step is 6.085 against 6.074 ms over six alternating pairs: the caller's choice
+  const int v2 = form;
   static const int v2_blocks = getenv("GLX_HEAD_DGRAD_BLOCKS") ? atoi(getenv("GLX_HEAD_DGRAD_BLOCKS")) : 512;   // two resident blocks per CU: 74 us; 768: 97, 1024: 87, 2048: 108 (per-block filter image + atomics)
   if (v2 && c0 % 64 == 0) {       // a wave owns 64 channels: weights and sums in registers, 16 loads in flight
     const size_t lds2 = (size_t)HD_MAXO * (C + 4) * 4 + (size_t)4 * C * 4 + (size_t)C * 2 * 4 + (size_t)HD_PIX * 33 * 4;

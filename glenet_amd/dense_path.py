@@ -137,6 +137,9 @@ BN_ON_LOAD = os.environ.get("GLX_CONV3X3_BN_ON_LOAD", "1") != "0"
 STRIDED_BN_STATS = os.environ.get("GLX_BEV_S2_BN_STATS", "1") != "0"          # a block's strided layer: statistics in its epilogue
 FIRST_LAYER_BN_STATS = os.environ.get("GLX_BEV_FIRST_BN_STATS", "1") != "0"   # first BEV layer (sparse): statistics in its epilogue
 HEAD_DGRAD_BN = os.environ.get("GLX_HEAD_DGRAD_BN", "1") != "0"        # ... and their backward sums in the head's input gradient
+# kernel form of that launch (glx_head1x1_input_grad_bn_form): 1 = a wave owns 64 channels -- 74 us against 109 alone, no
+# difference on the recorded step (DESIGN 9.22 viii)
+HEAD_DGRAD_FORM = int(os.environ.get("GLX_HEAD_DGRAD_V2", "0"))
 HEAD_BN_ON_LOAD = os.environ.get("GLX_HEAD_BN_ON_LOAD", "1") != "0"    # deblocks' BatchNorm + ReLU applied by the anchor head's kernels
 DECONV_BN_STATS = os.environ.get("GLX_DECONV_BN_STATS", "1") != "0"   # deblocks: BatchNorm statistics in the deconv's epilogue
 
@@ -738,8 +741,8 @@ class _Head1x1Parts(torch.autograd.Function):
                 bns.append(_lib.BnBwdStats(*[_lib._p(t) for t in (state, None, coef, mean, invstd, gam, coef3, dgamma, dbeta)]))
                 dzs.append(dz)
                 res.append((coef3, dgamma, dbeta))
-            call("glx_head1x1_input_grad_bn", ptr(gs), ctypes.c_int64(M), C, ptr(list(ws2)), ctx.n, r0, r1, c0,
-                 ctypes.byref(bns[0]), ctypes.byref(bns[1]), dzs[0], dzs[1])
+            call("glx_head1x1_input_grad_bn_form", ptr(gs), ctypes.c_int64(M), C, ptr(list(ws2)), ctx.n, r0, r1, c0,
+                 ctypes.byref(bns[0]), ctypes.byref(bns[1]), dzs[0], dzs[1], int(HEAD_DGRAD_FORM))
             for (r_, coef, mean, invstd, gam, bet, c), dz, (coef3, dgamma, dbeta) in zip(parts, dzs, res):
                 dx = torch.empty_like(r_)
                 call("glx_bn_backward_apply", r_, dz, coef3, mean, invstd, M, c, None, dx)

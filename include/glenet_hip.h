@@ -953,6 +953,12 @@ int glx_head1x1_weight_grad_parts(const float* const* grad, const float* x0, con
 int glx_head1x1_input_grad_bn(const float* const* grad, int64_t M, int C, const float* const* W, const int32_t* n, const float* y0,
                               const float* y1, int c0, const glx_bn_bwd_stats* bn0, const glx_bn_bwd_stats* bn1, float* dz0,
                               float* dz1, void* stream);
+/* The same with the kernel form chosen by the caller: 0 = a wave owns 16 pixels x all channels, 1 = a wave owns 64 channels of
+ * the block's 64 pixels (needs c0 % 64 == 0, else form 0 runs): 74 us against 109 alone on the 144 MB map, no difference inside
+ * the recorded training step (DESIGN 9.22 viii). */
+int glx_head1x1_input_grad_bn_form(const float* const* grad, int64_t M, int C, const float* const* W, const int32_t* n,
+                                   const float* y0, const float* y1, int c0, const glx_bn_bwd_stats* bn0,
+                                   const glx_bn_bwd_stats* bn1, float* dz0, float* dz1, int form, void* stream);
 size_t glx_head1x1_wgrad_workspace_bytes(int C);
 int glx_head1x1_weight_grad(const float* const* grad, const float* x, int64_t M, int C, const int32_t* n, float* const* gW,
                             float* const* gb, void* workspace, size_t workspace_bytes, void* stream);

@@ -471,12 +471,15 @@ def test_deblock_batchnorm_statistics_in_the_transposed_convolutions_epilogue(de
         assert torch.allclose(b1.float(), b2.float(), rtol=1e-5, atol=1e-7), n1
 
 
-def test_anchor_head_reads_the_deblocks_through_their_batchnorm(dev):
-    """BEVBackbone.head_on_load: the deblocks' raw outputs go to the anchor head, whose kernels apply BatchNorm + ReLU on load
+@pytest.mark.parametrize("form", [0, 1])
+def test_anchor_head_reads_the_deblocks_through_their_batchnorm(dev, form, monkeypatch):
+    """(form: the two kernel forms of the head's input gradient with the BatchNorm-backward sums.)
+    BEVBackbone.head_on_load: the deblocks' raw outputs go to the anchor head, whose kernels apply BatchNorm + ReLU on load
     (glx_head1x1_forward_parts / _weight_grad_parts) -- the concatenated map (base_bev_backbone.py:100-104) is never written.
     Against the same modules with the map: predictions bit for bit, every gradient and running statistic."""
     import copy
     from glenet_amd import dense_path as dp
+    monkeypatch.setattr(dp, "HEAD_DGRAD_FORM", form)
     torch.manual_seed(7)
     bev = dp.BEVBackbone(64, layer_nums=(1, 1), layer_strides=(1, 2), num_filters=(64, 128), upsample_strides=(1, 2),
                          num_upsample_filters=(128, 128)).to(dev).train()
