@@ -45,3 +45,28 @@ def test_two_ranks_make_the_update_of_one_rank_on_both_batches(dev):
         # moves the other way (2 lr); everything else agrees to rounding
         assert d["param_err_max"] <= 2.5 * d["lr"], d
         assert d["param_err_mean"] <= 2e-3 * d["lr"], d
+
+
+def test_bench_data_parallel_step_over_rccl_prints_one_json_line(dev):
+    """GLX_BENCH_FORCE_DP=1: bench.py's N > 1 code path -- process group over RCCL (`nccl`) with `device_id`, two graphs,
+    the flat SUM all-reduce between them, the scaled update, the per-rank diagnostics -- with a world of one process on
+    this box's GPU; and what a launcher reads: stdout holds exactly ONE line, the JSON (RCCL's version banner, which the
+    C library flushes at exit, goes to stderr with everything else)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, GLX_BENCH_FORCE_DP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GLX_DIST_BACKEND"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-config1",
+                        "--no-extra", "--no-cpu-baseline", "--no-stages"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["unit"] == "frames/s"
+    assert "2 HIP graph(s)" in d["config"]["mode"] and d["config"]["ranks_seen_by_collective"] == 1
+    assert d["per_rank"]["exchange_ms"][0] >= 0.0            # events around the RCCL all-reduce
