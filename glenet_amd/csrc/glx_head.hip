@@ -697,7 +697,8 @@ extern "C" int glx_head1x1_input_grad_bn_form(const float* const* grad, int64_t 
   const size_t lds = (size_t)HD_MAXO * (C + 4) * 4 + (size_t)4 * C * 4 + (size_t)4 * C * 2 * 4;
   rc = head_lds_attr((const void*)k_head_dgrad_bn, lds);
   if (rc != GLX_OK) return rc;
-  if (blocks > 2048) blocks = 2048;
+  static const int v1_blocks = getenv("GLX_HEAD_DGRAD_BLOCKS0") ? atoi(getenv("GLX_HEAD_DGRAD_BLOCKS0")) : 2048;
+  if (blocks > v1_blocks) blocks = v1_blocks;
   hipLaunchKernelGGL(k_head_dgrad_bn, dim3((unsigned)blocks), dim3(HD_THREADS), lds, (hipStream_t)stream, hg, (long long)M, hw, bb);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
