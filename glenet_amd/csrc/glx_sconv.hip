@@ -934,6 +934,9 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
           for (int i = 0; i < CQ; ++i) Am[i] = arow[i];
         }
         f32x4 acc[T::TPW];
+#ifdef GLX_SCONV_SETPRIO      // measured at the end of round 4 (-DGLX_SCONV_SETPRIO): 54.7-55.4 us against 51.8-52.9: off
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int tt = 0; tt < T::TPW; ++tt) {
           acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -952,6 +955,9 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
               acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t], Am[t], acc[tt], 0, 0, 0);
           }
         }
+#ifdef GLX_SCONV_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         const int p = pbase + r;
         if (p < cnt && !(TRACE && (ep.xcd_group & 0x200))) {   // 0x200: ablate the accumulate
           float* dst = s_acc + (int)s_pslot[k * TR + p] * ACC_LD + tile0 * 16 + 4 * q;
