@@ -27,8 +27,6 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
-
-os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "2")      # before the HIP runtime initialises: see glenet_amd/__init__.py
 import socket
 import subprocess
 import sys
@@ -98,6 +96,7 @@ class ConvProfiler:
         from glenet_amd import _lib
         self._lib, self._ct = _lib, ctypes
         self.records = []
+        self.wgrad_records = []
         self.enabled = False
         self._pool = []
 
@@ -115,6 +114,29 @@ class ConvProfiler:
         s, e = self._event(), self._event()
         self.records.append((name, s, e, rules, K, cin, cout, tag))
         return s, e              # handed to THIS launch as glx_sconv_opts.profile_start / profile_stop
+
+    def wgrad(self, K, cin, cout, rules):
+        """torch events (current stream) around one weight gradient over pair lists (k_wgrad_pairs + its slab sum)."""
+        if not self.enabled:
+            return None
+        import torch
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.wgrad_records.append((s, e, rules, K, cin, cout))
+        return s, e
+
+    def wgrad_summary(self):
+        """Per (cin, cout): time, launches, flops (2 R Cin Cout) and the bytes the contraction has to move: both operand
+        rows of every pair once, the pair's two indices, dW written once."""
+        per = {}
+        for s, e, rules, K, cin, cout in self.wgrad_records:
+            R = rules.pair_count
+            d = per.setdefault("k_wgrad_pairs<%d,%d>" % (cin, cout), dict(ms=0.0, launches=0, bytes=0, flops=0))
+            d["ms"] += s.elapsed_time(e)
+            d["launches"] += 1
+            d["bytes"] += R * (cin + cout) * 4 + R * 8 + K * cin * cout * 4
+            d["flops"] += 2 * R * cin * cout
+        self.wgrad_records = []
+        return per
 
     def summary(self):
         per = {}
@@ -558,6 +580,127 @@ def bench_config4(dev, frames=2, steps=60):
                                       alg_GBps=roof["hbm"]["achieved_algorithmic_GBps"])
         out["all_sparse_conv"] = {k: roof["all_sparse_conv"][k] for k in ("achieved_algorithmic_GBps", "frac_algorithmic",
                                                                           "ms_per_step")}
+    for p_ in pipes:
+        p_.graph = None
+        p_.out = None
+    del pipes
+    torch.cuda.empty_cache()
+    out["train"] = bench_config4_train(dev, pts, bidx, frames, steps)
+    return out
+
+
+def bench_config4_train(dev, pts, bidx, frames, steps=60):
+    """configs[4] as the metric states it (fwd + bwd): the same shard through VoxelResBackBone8x in TRAINING mode --
+    voxelize + MeanVFE + rule tables + pair lists + 21 sparse convs with batch-statistics BatchNorm + dense() + a stand-in
+    loss on the BEV map + backward (input and weight gradients of every conv, BatchNorm backward) -- one recorded HIP graph,
+    one step in flight; then one profiled eager pass: HIP-event time of every forward / input-gradient launch and of every
+    weight gradient, both roofline fractions of the dominant kernel of each kind, and the rule-table build's share."""
+    import torch
+    from glenet_amd import backbone as gb
+    from glenet_amd import synth
+    from glenet_amd.spconv import core as spcore
+    W = synth.WAYMO
+    torch.manual_seed(0)
+    model = gb.VoxelResBackBone8x(W["num_features"], gb.gv.grid_size_of(W["point_cloud_range"], W["voxel_size"])).to(dev).train()
+    pipe = gb.StaticTrainPipeline(model, W, frames, pts.shape[0], W["num_features"])
+    pipe.calibrate(pts, bidx)
+    pipe.load(pts, bidx)
+    pipe.capture()
+
+    def one():
+        pipe.load(pts, bidx)
+        pipe.replay()
+    ms = _timed(one, steps, dev, warm=5)
+    pipe.check()
+    loss = float(pipe.loss.detach())
+    # stages of one eager pass (events on the step's stream; the plan runs on its own stream beside the forward pass)
+    marks = []
+
+    def mark(name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        marks.append((name, e))
+    pipe.mark = mark
+    prof = ConvProfiler()
+    spcore._profile_hook = prof
+    n_prof = 4
+    overlap = pipe.overlap_wgrad
+    pipe.overlap_wgrad = False          # weight gradients inline: their events bracket nothing else
+    try:
+        pipe.enqueue()
+        torch.cuda.synchronize(dev)
+        prof.enabled = True
+        marks.clear()
+        for _ in range(n_prof):
+            pipe.enqueue()
+        torch.cuda.synchronize(dev)
+    finally:
+        prof.enabled = False
+        spcore._profile_hook = None
+        pipe.mark = None
+        pipe.overlap_wgrad = overlap
+    per = prof.summary()
+    wg = prof.wgrad_summary()
+    fwd = {k: v for k, v in per.items()}
+    roof = roofline_of(fwd, n_prof)
+    # rule-table build alone: the plan (9 tables + tile maps + pair lists + transposes) on an idle device
+    with torch.no_grad():
+        bd = gb.voxelize_batch(pipe.points, pipe.batch_idx, frames, W, train=True, static=True)
+
+        def plan():
+            pipe.model.plan(bd["voxel_coords"], frames, index=bd["voxel_index"], capacities=pipe.capacities, pair_lists=True)
+        from glenet_amd._lib import workspace
+        with workspace.scoped(id(pipe)):
+            plan_ms = _timed(plan, 10, dev, warm=2)
+
+            def plan_fwd():
+                pipe.model.plan(bd["voxel_coords"], frames, index=bd["voxel_index"], capacities=pipe.capacities)
+            plan_fwd_ms = _timed(plan_fwd, 10, dev, warm=2)
+    stage = {}
+    per_pass = len(marks) // n_prof
+    for i in range(n_prof):
+        chunk = marks[i * per_pass:(i + 1) * per_pass]
+        for (n0, e0), (n1, e1) in zip(chunk[:-1], chunk[1:]):
+            stage[n1] = stage.get(n1, 0.0) + e0.elapsed_time(e1) / n_prof
+    out = dict(workload="configs[4] per-GPU share, fwd + bwd: %d Waymo-shaped frames x 180000 points, VoxelResBackBone8x in "
+                        "training mode (batch-statistics BatchNorm), loss = mean(BEV map^2), every input / weight / "
+                        "BatchNorm gradient; one HIP graph" % frames,
+               fwd_bwd_ms=round(ms, 3), frames_per_s=round(frames / (ms * 1e-3), 1), steps=steps, loss=round(loss, 6),
+               eager_stages_ms={k: round(v, 3) for k, v in stage.items()},
+               rule_tables=dict(build_ms_alone=round(plan_ms, 3), forward_tables_only_ms=round(plan_fwd_ms, 3),
+                                share_of_step=round(plan_ms / ms, 3),
+                                note="9 rule tables + tile maps (+ per-offset pair lists and the strided tables' "
+                                     "transposes for the backward) from coordinates alone, timed on an idle device; in "
+                                     "the step they run on a second stream beside the forward convolutions"))
+    if roof:
+        out["dominant_forward_kernel"] = dict(kernel=roof["kernel"], avg_launch_us=roof["avg_launch_us"],
+                                              launches_per_step=roof["launches"] // n_prof,
+                                              mfma_frac=roof["mfma_frac"], hbm_frac_algorithmic=roof["hbm"]["frac_algorithmic"],
+                                              TFLOPs=round(roof["mfma_frac"] * MFMA_F32_PEAK_TFLOPS, 2),
+                                              alg_GBps=roof["hbm"]["achieved_algorithmic_GBps"],
+                                              note="forward AND input-gradient launches (the same kernel on adjoint weights)")
+        out["forward_and_dgrad_kernels"] = roof["all_sparse_conv"]
+    if wg:
+        tot = sum(v["ms"] for v in wg.values())
+        dom = max(wg, key=lambda k: wg[k]["ms"])
+        d = wg[dom]
+        sec = d["ms"] * 1e-3
+        out["dominant_wgrad_kernel"] = dict(kernel=dom, avg_call_us=round(d["ms"] * 1e3 / d["launches"], 2),
+                                            calls_per_step=d["launches"] // n_prof,
+                                            TFLOPs=round(d["flops"] / sec / 1e12, 2),
+                                            mfma_frac=round(d["flops"] / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                            alg_GBps=round(d["bytes"] / sec / 1e9, 1),
+                                            hbm_frac_algorithmic=round(d["bytes"] / sec / 1e9 / HBM_PEAK_GBS, 4),
+                                            note="torch events around k_wgrad_pairs + k_wgrad_pairs_reduce of one call; "
+                                                 "bytes = both operand rows of every pair + 2 indices + dW once")
+        out["wgrad_kernels"] = dict(ms_per_step=round(tot / n_prof, 4),
+                                    per_kernel={k: dict(us_per_call=round(v["ms"] * 1e3 / v["launches"], 2),
+                                                        calls_per_step=v["launches"] // n_prof,
+                                                        TFLOPs=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                                        mfma_frac=round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4))
+                                                for k, v in sorted(wg.items())})
+    pipe.graph = None
+    pipe.out = pipe.loss = None
     return out
 
 
@@ -588,6 +731,12 @@ def main():
                          "command to put under rocprofv3 --kernel-trace --stats when its per-kernel averages are to "
                          "be compared with the HIP-event figures (a full run mixes in the training step's launches "
                          "and the two-frames-in-flight replays of the same kernels)")
+    ap.add_argument("--graph-queues", type=int, default=2,
+                    help="HIP-graph executor queues (glenet_amd.runtime.configure_graph_executor: the process-wide "
+                         "DEBUG_HIP_FORCE_GRAPH_QUEUES switch, set before the first GPU call and echoed in config); "
+                         "0 = leave the runtime's default (4): +0.2 ms on the headline step")
+    ap.add_argument("--config4-only", action="store_true",
+                    help="run only the configs[4] sub-measurement (Waymo-shaped shard, forward and fwd + bwd) and print it")
     ap.add_argument("--bev-layout", choices=("nhwc", "nchw"), default="nhwc",
                     help="memory layout of the BEV map and the 2-D backbone's activations")
     ap.add_argument("--miopen-find", choices=("on", "off"), default="off",
@@ -595,6 +744,8 @@ def main():
                          "mode (torch.backends.cudnn.benchmark) times candidates during warm-up -- four minutes on a "
                          "fresh box for the same step time (measured: 18.6 ms either way)")
     args = ap.parse_args()
+    from glenet_amd import runtime as glx_runtime
+    glx_runtime.configure_graph_executor(args.graph_queues if args.graph_queues > 0 else None)
     # frames/s over >= 50 timed steps after >= 10 warm-up steps.  A shorter request (the driver's --steps 20
     # --warmup 5 times 0.15 s of a 7 ms step) is raised to that; "steps" / "warmup" in the line are what was timed, the
     # requested values ride along as steps_requested / warmup_requested.
@@ -647,6 +798,9 @@ def main():
     gdist.init(backend, device=dev, force=dp)
     ranks_seen = gdist.reduce_sum_int(1, dev)          # the collective saw this many ranks
 
+    if args.config4_only:
+        emit(dict(config4=bench_config4(dev)))
+        return
     K = synth.KITTI
     torch.backends.cudnn.benchmark = args.miopen_find == "on"   # MIOpen find mode during warm-up, before capture
 
@@ -886,6 +1040,7 @@ def main():
                                            % (world, n_params * 4 / 1e6) if dp else "dp1 (single GPU, no collective)",
                                ranks_seen_by_collective=ranks_seen,
                                device_data_step=bool(args.device_data_step),
+                               graph_executor_queues=glx_runtime.graph_executor_queues(),
                                arithmetic="fp32 tensors and fp32 accumulation everywhere; the BEV backbone's convolutions form "
                                           "their fp32 products on the bf16 matrix pipe from three-way split operands (six "
                                           "MFMAs per product tile, products exact to 2^-22: error against an fp64 convolution "

@@ -293,8 +293,9 @@ _graph_execs = []
 # memory with a memset in front of a kernel is therefore wrong from the second replay on -- this is what turned the recorded
 # CVAE training step's gradients into NaN (torch's multi-block reductions zero their semaphores that way,
 # tools/graph_reduce_repro.py).  Own kernels never use memsets (glx_fill_multi is a kernel); library calls inside a recorded
-# step may.  AUDIT_GRAPHS (default on): graphs are created with keep_graph=True and `audit_graph` counts the node types of
-# what was recorded; pipelines call it after capture and report / refuse memset nodes (see backbone.StaticFramePipeline).
+# step may.  Every recorded pipeline therefore ends its capture with finish_graph() (below), which replaces the memset nodes
+# by fill-kernel nodes and RAISES when it cannot (the pipelines store the count as `memsets_replaced`).  AUDIT_GRAPHS only
+# gates the diagnostic `audit_graph` (node-type census of what was recorded).
 AUDIT_GRAPHS = os.environ.get("GLX_AUDIT_GRAPHS", "1") != "0"
 _HIP_NODE_TYPES = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event", 7: "event_record",
                    8: "ext_semaphore_signal", 9: "ext_semaphore_wait", 10: "mem_alloc", 11: "mem_free", 12: "memcpy_from_symbol",
@@ -306,25 +307,58 @@ class _MemsetParams(ctypes.Structure):
                 ("value", ctypes.c_uint), ("width", c_size_t)]
 
 
+MAX_RETIRED_GRAPHS = int(os.environ.get("GLX_MAX_RETIRED_GRAPHS", "256"))
+_retired_warned = [False]
+
+
 def new_graph():
-    """torch.cuda.CUDAGraph() whose exec outlives its owner (see above); with AUDIT_GRAPHS the hipGraph_t is kept so that
-    audit_graph() can look at what was recorded."""
+    """torch.cuda.CUDAGraph() whose exec outlives its owner (see above).  The hipGraph_t is ALWAYS kept (keep_graph=True):
+    finish_graph() needs it for the memset surgery, which is a correctness fix and not a diagnostic -- it does not hang on
+    GLX_AUDIT_GRAPHS.  A torch without keep_graph cannot run recorded pipelines on this runtime: that raises here."""
     try:
-        g = torch.cuda.CUDAGraph(keep_graph=True) if AUDIT_GRAPHS else torch.cuda.CUDAGraph()
-    except TypeError:                                   # a torch without keep_graph
-        g = torch.cuda.CUDAGraph()
+        g = torch.cuda.CUDAGraph(keep_graph=True)
+    except TypeError as e:                              # a torch without keep_graph
+        raise GlxError("torch.cuda.CUDAGraph(keep_graph=True) is not available in this torch: recorded pipelines need the "
+                       "raw hipGraph_t to replace memset nodes (ROCm 7.2 replays them with a stale pattern -> NaN "
+                       "gradients from the second replay on).  Run the pipelines eagerly (enqueue()/step() without "
+                       "capture()) or set GLX_ALLOW_UNFIXED_MEMSETS=1 to record anyway.") from e
     if KEEP_GRAPH_EXECS:
         _graph_execs.append(g)
+        if len(_graph_execs) > MAX_RETIRED_GRAPHS and not _retired_warned[0]:
+            _retired_warned[0] = True
+            import warnings
+            warnings.warn("%d recorded graphs are being kept alive (ROCm 7.2: destroying a hipGraphExec can crash a later "
+                          "launch, profiles/r03_graph_exec_destroy_crash.txt).  Each retired exec holds host memory and its "
+                          "kernel-argument buffers; pipelines reuse the retired graph's memory pool, so device memory does "
+                          "not grow with it (tests/test_graph_memset_gpu.py::test_recaptures_do_not_grow_reserved_memory). "
+                          "Re-recording this often usually means weights change between replays of an inference "
+                          "pipeline: record once per evaluation phase." % len(_graph_execs), RuntimeWarning, stacklevel=2)
     return g
 
 
+def retired_graph_count():
+    """Graphs created through new_graph() and kept alive for the life of the process."""
+    return len(_graph_execs)
+
+
+ALLOW_UNFIXED_MEMSETS = os.environ.get("GLX_ALLOW_UNFIXED_MEMSETS", "0") == "1"
+
+
 def finish_graph(graph):
-    """Call right after a capture into a graph from new_graph(): replaces the memset nodes of what was recorded by fill-kernel
-    nodes (ROCm 7.2 replays memset nodes with a stale pattern, csrc/glx_graph.hip) and instantiates the graph.  Returns the
-    number of memset nodes replaced (None: the raw graph is not available, nothing was changed)."""
+    """Call right after a capture into a graph from new_graph(): replaces the memset nodes of what was recorded (child
+    graphs included) by fill-kernel nodes (ROCm 7.2 replays memset nodes with a stale pattern, csrc/glx_graph.hip) and
+    instantiates the graph.  Returns the number of memset nodes replaced.  Raises GlxError when the raw graph cannot be
+    had (the recorded step would be wrong from its second replay on) unless GLX_ALLOW_UNFIXED_MEMSETS=1, in which case
+    it warns, leaves the graph as torch instantiated it, and returns None."""
     try:
         raw = graph.raw_cuda_graph()
-    except Exception:
+    except Exception as e:
+        if not ALLOW_UNFIXED_MEMSETS:
+            raise GlxError("finish_graph: the raw hipGraph_t of the recorded step is not available (%s: %s); memset nodes "
+                           "would replay a stale pattern on ROCm 7.2.  Create graphs with _lib.new_graph(), or set "
+                           "GLX_ALLOW_UNFIXED_MEMSETS=1 to accept the recorded graph as it is." % (type(e).__name__, e)) from e
+        import warnings
+        warnings.warn("finish_graph: raw graph not available, memset nodes (if any) left in place", RuntimeWarning, stacklevel=2)
         return None
     n = c_int(0)
     call_nostream("glx_graph_replace_memsets", c_void_p(raw), ctypes.byref(n))

@@ -39,6 +39,27 @@ void glx_set_error(const char* fmt, ...);
     }                                                                        \
   } while (0)
 
+// Kernels whose blocks meet at a spin barrier in global memory are only correct when ALL blocks of the launch are resident at
+// once.  This asks the runtime (per call: the answer depends on the current device and on the dynamic LDS of the call) how
+// many blocks of `func` fit per CU and whether `nblocks` fit the device -- half the device, in fact: such a launch runs beside
+// other streams' kernels by design, so it may only claim a fraction of the chip.  Any runtime error counts as "no".
+static inline bool glx_blocks_coresident(const void* func, int threads, size_t dyn_lds, int nblocks) {
+  int dev = 0, cus = 0, lds_max = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+  if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return false;
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, func) != hipSuccess) return false;
+  if (fa.sharedSizeBytes + dyn_lds > (size_t)lds_max) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, func, threads, dyn_lds) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return per_cu >= 1 && (long long)per_cu * cus >= 2LL * nblocks;
+}
+
+// Upper bound on the polls of a spin barrier (each poll is an agent-scope load behind an s_sleep: ~1 us): a launch whose
+// partner blocks never arrive gives up after a few seconds, raises the error word next to the counter and runs on (its
+// results are garbage, the host sees the word) instead of hanging the GPU.
+#define GLX_SPIN_LIMIT (1u << 22)
+
 static inline int glx_divup(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline size_t glx_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 

@@ -46,7 +46,14 @@ __device__ __forceinline__ void fct_grid_barrier(unsigned* counter, unsigned tar
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    unsigned polls = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++polls > GLX_SPIN_LIMIT) {          // the partner blocks are not resident: give up loudly instead of hanging
+        __hip_atomic_store(counter + 24, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -873,7 +880,9 @@ static int fct_launch_fwd(const glx_fc_tower& t, hipStream_t st) {
     GLX_HIP(hipFuncSetAttribute((const void*)k_fct_forward<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 1024));
     attr_set = true;
   }
-  if (t.cooperative) {
+  // the one-launch form spins at grid barriers: only when the runtime confirms that all FCT_NB blocks are resident together
+  // (a smaller partition, a CU mask or less LDS per CU: the per-phase launches below need no such guarantee)
+  if (t.cooperative && glx_blocks_coresident((const void*)k_fct_forward<-1>, FCT_THREADS, lds, FCT_NB)) {
     hipLaunchKernelGGL(k_fct_forward<-1>, dim3(FCT_NB), dim3(FCT_THREADS), lds, st, t);
     GLX_LAUNCH_CHECK();
   } else {
@@ -895,7 +904,7 @@ static int fct_launch_bwd(const glx_fc_tower& t, const glx_fc_tower_grads& g, hi
     GLX_HIP(hipFuncSetAttribute((const void*)k_fct_backward<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     attr_set = true;
   }
-  if (t.cooperative) {
+  if (t.cooperative && glx_blocks_coresident((const void*)k_fct_backward<-1>, FCT_THREADS, lds, FCT_NB)) {
     hipLaunchKernelGGL(k_fct_backward<-1>, dim3(FCT_NB), dim3(FCT_THREADS), lds, st, t, g);
     GLX_LAUNCH_CHECK();
   } else {
@@ -905,6 +914,34 @@ static int fct_launch_bwd(const glx_fc_tower& t, const glx_fc_tower_grads& g, hi
     hipLaunchKernelGGL(k_fct_backward<3>, dim3(16), dim3(FCT_THREADS), (size_t)0, st, t, g);
     GLX_LAUNCH_CHECK();
   }
+  return GLX_OK;
+}
+
+// 1 when the launches of a tower of R rows can run on the current device at all (the LDS the phases ask for fits a block);
+// *cooperative (may be NULL) = 1 when the one-launch forms with grid barriers will be used, 0 = one launch per phase.
+extern "C" int glx_fc_tower_supported(int R, int* cooperative) {
+  int dev = 0, lds_max = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess)
+    return 0;
+  hipFuncAttributes ff, fb;
+  if (hipFuncGetAttributes(&ff, (const void*)k_fct_forward<4>) != hipSuccess) return 0;
+  if (hipFuncGetAttributes(&fb, (const void*)k_fct_backward<0>) != hipSuccess) return 0;
+  const size_t lf = (size_t)R * 8 * sizeof(float), lb = (size_t)R * 25 * sizeof(float);
+  if (ff.sharedSizeBytes + lf > (size_t)lds_max || fb.sharedSizeBytes + lb > (size_t)lds_max) return 0;
+  if (cooperative)
+    *cooperative = glx_blocks_coresident((const void*)k_fct_forward<-1>, FCT_THREADS, lf, FCT_NB) &&
+                   glx_blocks_coresident((const void*)k_fct_backward<-1>, FCT_THREADS, lb, FCT_NB);
+  return 1;
+}
+
+// The error word of a barrier buffer (`barrier` of glx_fc_tower: 32 x u32): nonzero after a launch gave up waiting for its
+// partner blocks (GLX_SPIN_LIMIT).  Host-synchronising read; clears the word.
+extern "C" int glx_fc_tower_barrier_status(void* barrier, int* gave_up) {
+  GLX_REQUIRE(barrier && gave_up, "glx_fc_tower_barrier_status: null pointer");
+  unsigned w = 0;
+  GLX_HIP(hipMemcpy(&w, (unsigned*)barrier + 24, sizeof(w), hipMemcpyDeviceToHost));
+  *gave_up = (int)w;
+  if (w) GLX_HIP(hipMemset((unsigned*)barrier + 24, 0, sizeof(w)));
   return GLX_OK;
 }
 

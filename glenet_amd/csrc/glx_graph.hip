@@ -47,19 +47,26 @@ __global__ void k_graph_fill(unsigned char* __restrict__ dst, unsigned value, un
   }
 }
 
-// graph: a hipGraph_t (torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()) that has not been instantiated yet.
-// n_replaced (host int, may be NULL) receives the number of memset nodes that were replaced.
-extern "C" int glx_graph_replace_memsets(void* graph_, int* n_replaced) {
-  hipGraph_t graph = (hipGraph_t)graph_;
-  GLX_REQUIRE(graph, "glx_graph_replace_memsets: null graph");
+// Replaces the memset nodes of ONE graph level; child-graph nodes (hipGraphNodeTypeGraph: a library that records a
+// sub-graph of its own) are visited recursively -- their embedded graphs replay through the same executor path.
+static int replace_memsets_in(hipGraph_t graph, int depth, int* done) {
+  GLX_REQUIRE(depth < 8, "glx_graph_replace_memsets: child graphs nested deeper than 8 levels");
   size_t n = 0;
   GLX_HIP(hipGraphGetNodes(graph, nullptr, &n));
   std::vector<hipGraphNode_t> nodes(n);
   if (n) GLX_HIP(hipGraphGetNodes(graph, nodes.data(), &n));
-  int done = 0;
   for (size_t i = 0; i < n; ++i) {
     hipGraphNodeType type;
     GLX_HIP(hipGraphNodeGetType(nodes[i], &type));
+    if (type == hipGraphNodeTypeGraph) {
+      hipGraph_t child = nullptr;
+      GLX_HIP(hipGraphChildGraphNodeGetGraph(nodes[i], &child));
+      if (child) {
+        const int rc = replace_memsets_in(child, depth + 1, done);
+        if (rc != GLX_OK) return rc;
+      }
+      continue;
+    }
     if (type != hipGraphNodeTypeMemset) continue;
     hipMemsetParams mp;
     GLX_HIP(hipGraphMemsetNodeGetParams(nodes[i], &mp));
@@ -89,8 +96,18 @@ extern "C" int glx_graph_replace_memsets(void* graph_, int* n_replaced) {
     GLX_HIP(hipGraphAddKernelNode(&fill, graph, nd ? deps.data() : nullptr, nd, &kp));
     for (size_t k = 0; k < nt; ++k) GLX_HIP(hipGraphAddDependencies(graph, &fill, &outs[k], 1));
     GLX_HIP(hipGraphDestroyNode(nodes[i]));
-    ++done;
+    ++*done;
   }
-  if (n_replaced) *n_replaced = done;
   return GLX_OK;
+}
+
+// graph: a hipGraph_t (torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()) that has not been instantiated yet.
+// n_replaced (host int, may be NULL) receives the number of memset nodes that were replaced, child graphs included.
+extern "C" int glx_graph_replace_memsets(void* graph_, int* n_replaced) {
+  hipGraph_t graph = (hipGraph_t)graph_;
+  GLX_REQUIRE(graph, "glx_graph_replace_memsets: null graph");
+  int done = 0;
+  const int rc = replace_memsets_in(graph, 0, &done);
+  if (n_replaced) *n_replaced = done;
+  return rc;
 }

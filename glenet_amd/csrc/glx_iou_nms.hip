@@ -1814,7 +1814,11 @@ __device__ __forceinline__ void tkm_barrier(unsigned* counter) {
   if (threadIdx.x == 0) {
     __threadfence();
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < TKM_NB) __builtin_amdgcn_s_sleep(2);
+    unsigned polls = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < TKM_NB) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++polls > GLX_SPIN_LIMIT) break;     // partner blocks not resident (the entry point checks): do not hang the GPU
+    }
   }
   __syncthreads();
 }
@@ -1968,6 +1972,10 @@ extern "C" int glx_topk_desc_ws(const float* scores, int frames, int A, int K, f
   GLX_REQUIRE(A <= TKM_NB * TKM_THREADS * TKM_E, "glx_topk_desc_ws: A = %d (<= %d)", A, TKM_NB * TKM_THREADS * TKM_E);
   GLX_REQUIRE(frames * TKM_NB <= 512, "glx_topk_desc_ws: %d frames (the cooperating blocks must all be resident)", frames);
   GLX_REQUIRE(workspace_bytes >= glx_topk_workspace_bytes(frames, K), "glx_topk_desc_ws: workspace too small");
+  // the cooperating blocks spin on a per-frame counter: without the runtime's word that they are all resident together
+  // (smaller partition, CU mask) the single-block form does the same job
+  if (!glx_blocks_coresident((const void*)k_topk_select, TKM_THREADS, 0, frames * TKM_NB))
+    return glx_topk_desc(scores, frames, A, K, top, order, stream);
   char* base = (char*)workspace;
   TkFrameWs* ws = (TkFrameWs*)base;
   unsigned* keys = (unsigned*)(base + glx_align((size_t)frames * sizeof(TkFrameWs)));

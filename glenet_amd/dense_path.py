@@ -982,17 +982,45 @@ class FCTower(nn.Sequential):
 # ---- the towers behind the first Linear as one launch per direction (csrc/glx_fctower.hip)
 FC_TOWER_FUSED = os.environ.get("GLX_FC_TOWER", "1") != "0"
 FC_TOWER_COOPERATIVE = os.environ.get("GLX_FC_TOWER_COOP", "1") != "0"     # 0: one launch per phase (5 forward, 4 backward)
-_FCT_BARRIER = {}
+_FCT_SUPPORT = {}
 
 
-def _fct_barrier(device):
-    """The grid barrier's counters: zero once, every launch leaves them zero (one per device and stream: launches on one
-    stream are ordered, two streams must not share them)."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    b = _FCT_BARRIER.get(key)
+def _fct_barrier(head, device):
+    """The grid barrier's counters of ONE head module on ONE stream: zero once, every launch leaves them zero.  Owned by the
+    module (not a process-global cache): the graph of a pipeline and an eager step of another model never share them.
+    Allocated OUTSIDE stream capture only -- a buffer born inside a capture would live in the graph's private pool while
+    this cache kept handing it out; the pipelines' warm-up pass creates it before they record."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    owned = head.__dict__.setdefault("_glx_fct_barriers", {})
+    b = owned.get(key)
     if b is None:
-        b = _FCT_BARRIER[key] = torch.zeros(32, dtype=torch.int32, device=device)
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("fc tower: the grid-barrier counters of this head do not exist yet on the capturing stream; "
+                               "run one eager (warm-up) pass on that stream before recording it")
+        b = owned[key] = torch.zeros(32, dtype=torch.int32, device=device)
     return b
+
+
+def fc_tower_support(device, rows):
+    """(supported, cooperative) of glx_fc_tower_supported on `device`, cached per (device, rows)."""
+    key = (device.index, int(rows))
+    hit = _FCT_SUPPORT.get(key)
+    if hit is None:
+        coop = ctypes.c_int(0)
+        with torch.cuda.device(device):
+            ok = _lib.load().glx_fc_tower_supported(int(rows), ctypes.byref(coop))
+        hit = _FCT_SUPPORT[key] = (bool(ok), bool(coop.value))
+    return hit
+
+
+def fc_tower_barrier_gave_up(head):
+    """True when a one-launch tower of `head` gave up at a grid barrier since the last call (host sync; diagnostics)."""
+    bad = False
+    for b in head.__dict__.get("_glx_fct_barriers", {}).values():
+        flag = ctypes.c_int(0)
+        _lib.call_nostream("glx_fc_tower_barrier_status", b, ctypes.byref(flag))
+        bad = bad or bool(flag.value)
+    return bad
 
 
 def _fc_bn(bn, mean, invstd):
@@ -1029,6 +1057,8 @@ def fc_tower_usable(head, x):
     if not (FC_TOWER_FUSED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and torch.is_grad_enabled() and head.training):
         return False
     if x.shape[0] % 16 or not 16 <= x.shape[0] <= 1024:
+        return False
+    if not fc_tower_support(x.device, x.shape[0])[0]:       # the phases' LDS does not fit this device: module-by-module path
         return False
     pairs = head.__dict__.get("_glx_fct_pairs", 0)
     if pairs == 0:
@@ -1082,7 +1112,7 @@ class FCTowersFn(torch.autograd.Function):
         t.w_fc2, t.b_fc2 = head.reg_std_fc2.weight.data_ptr(), head.reg_std_fc2.bias.data_ptr()
         t.ori_cls, t.std_logit = dense[0].data_ptr(), dense[1].data_ptr()
         t.rcnn_reg, t.rcnn_reg_std = reg[0].data_ptr(), reg[1].data_ptr()
-        t.scratch, t.barrier = scratch.data_ptr(), _fct_barrier(dev).data_ptr()
+        t.scratch, t.barrier = scratch.data_ptr(), _fct_barrier(head, dev).data_ptr()
         t.cooperative = 1 if FC_TOWER_COOPERATIVE else 0
         _lib.call("glx_fc_tower_forward", ctypes.byref(t))
         from .spconv import core
@@ -1128,7 +1158,7 @@ class FCTowersFn(torch.autograd.Function):
         t.w_fc2, t.b_fc2 = head.reg_std_fc2.weight.data_ptr(), head.reg_std_fc2.bias.data_ptr()
         t.ori_cls, t.std_logit = dense[0].data_ptr(), dense[1].data_ptr()
         t.rcnn_reg, t.rcnn_reg_std = reg[0].data_ptr(), reg[1].data_ptr()
-        t.scratch, t.barrier = scratch.data_ptr(), _fct_barrier(dev).data_ptr()
+        t.scratch, t.barrier = scratch.data_ptr(), _fct_barrier(head, dev).data_ptr()
         t.cooperative = 1 if FC_TOWER_COOPERATIVE else 0
         dz = torch.empty((6, R, 256), **f32)
         dgb = torch.empty((12, 256), **f32)

@@ -139,9 +139,14 @@ def topk_desc(scores, k):
         # 32 cooperating blocks per frame + a per-frame sort; the zero-initialised workspace belongs to (device, stream)
         key = (s.device.index, torch.cuda.current_stream(s.device).cuda_stream, s.shape[0], k)
         ws = _TOPK_WS.get(key)
-        if ws is None:
+        if ws is None and torch.cuda.is_current_stream_capturing():
+            ws = False       # never allocate a cached buffer inside a capture (it would live in the graph's private pool)
+        elif ws is None:
             ws = _TOPK_WS[key] = torch.zeros(_lib.query("glx_topk_workspace_bytes", s.shape[0], k), dtype=torch.uint8,
                                              device=s.device)
+        if ws is False:
+            _lib.call("glx_topk_desc", s, s.shape[0], s.shape[1], k, top, order)
+            return top, order
         _lib.call("glx_topk_desc_ws", s, s.shape[0], s.shape[1], k, top, order, ws, _lib.size_arg(ws.numel()))
     else:
         _lib.call("glx_topk_desc", s, s.shape[0], s.shape[1], k, top, order)

@@ -694,6 +694,8 @@ class StaticTrainStep(gb.StaticTrainPipeline):
         return self
 
     def _capture(self, warmup, split):
+        from . import runtime
+        runtime.note_capture()          # one diagnostic if the executor setting of the published step time is not in effect
         super().capture(warmup)
         if split:
             dev = self.points.device
@@ -706,7 +708,7 @@ class StaticTrainStep(gb.StaticTrainPipeline):
             self.update_graph = gb._lib.new_graph()
             with torch.cuda.graph(self.update_graph, stream=side), gb.no_gc():
                 self.update()
-            gb._lib.finish_graph(self.update_graph)
+            self.update_memsets_replaced = gb._lib.finish_graph(self.update_graph)   # raises if it cannot repair
         return self
 
     def enqueue_eager_marked(self):

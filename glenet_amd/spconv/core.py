@@ -569,8 +569,14 @@ class SparseConvFunction(Function):
                     pl = rules.pair_lists(fwd_nbr, n_fwd_out, live_fwd)
                     wsb = query("glx_sconv_wgrad_pairs_workspace_bytes", n_fwd_out, K, cin, cout)
                     ws = workspace.get(wsb, w.device)
+                    # bench.py's profiler: torch events around the weight gradient's two launches (pairs + slab sum)
+                    wev = _profile_hook.wgrad(K, cin, cout, rules) if hasattr(_profile_hook, "wgrad") else None
+                    if wev is not None:
+                        wev[0].record()
                     call("glx_sconv_wgrad_pairs_ex", features, grad_out, pl, n_fwd_out, K, cin, cout, g_w, _pre_arg(pre, cin), ws,
                          size_arg(ws.numel()))
+                    if wev is not None:
+                        wev[1].record()
                 else:
                     assert pre is None, "the input transform on load needs the pair-list weight gradient"
                     g_w = torch.empty_like(w)

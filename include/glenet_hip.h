@@ -1156,8 +1156,11 @@ typedef struct glx_fc_tower {
   const float* w_fc2; const float* b_fc2;      /* reg_std_fc2 (1, 64), (1) */
   float* ori_cls; float* rcnn_reg; float* rcnn_reg_std; float* std_logit;   /* (R), (R, 7), (R, 7), (R): forward outputs */
   float* scratch;                              /* glx_fc_tower_scratch_bytes(R) */
-  unsigned* barrier;                           /* 128 bytes, zero before the first launch; every launch leaves them zero */
-  int cooperative;                             /* 1: ONE launch of 32 co-resident blocks with grid barriers; 0: a launch per phase */
+  unsigned* barrier;                           /* 128 bytes, zero before the first launch; every launch leaves them zero.  Owned
+                                                  by ONE tower descriptor / stream at a time; word 24 = error word (below) */
+  int cooperative;                             /* 1: ONE launch of 32 co-resident blocks with grid barriers WHEN the runtime
+                                                  confirms that they are resident together on the current device (else, and
+                                                  with 0, a launch per phase: no residency assumption) */
 } glx_fc_tower;
 
 typedef struct glx_fc_tower_grads {
@@ -1171,6 +1174,13 @@ typedef struct glx_fc_tower_grads {
 } glx_fc_tower_grads;
 
 size_t glx_fc_tower_scratch_bytes(int R);
+/* 1 when a tower of R rows can run on the current device at all (the phases' LDS fits a block), else 0 -- the caller then
+ * keeps the module-by-module path (voxelrcnn_kl_label_iou_head.py:38-92 on library GEMMs).  *cooperative (may be NULL):
+ * whether the one-launch forms will be used (occupancy x CUs >= 2 x 32 blocks for both directions). */
+int glx_fc_tower_supported(int R, int* cooperative);
+/* *gave_up != 0: a one-launch form stopped waiting at a grid barrier (its partner blocks never arrived within ~4 M polls) --
+ * the results of that launch are invalid.  Host-synchronising; clears the word. */
+int glx_fc_tower_barrier_status(void* barrier, int* gave_up);
 int glx_fc_tower_forward(const glx_fc_tower* t, void* stream);
 /* `t` as the forward left it (z, h, save_mean / save_invstd, rcnn_reg_std, drop_u).  The Linear weight gradients
  * dW_l = dz[l]^T h[l-1] (dW_0 = dz[0]^T pooled) and the pooled features' gradient dz[0] W0 are GEMMs left to the caller. */

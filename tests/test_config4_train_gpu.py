@@ -1,0 +1,267 @@
+"""BASELINE configs[4] as the metric states it (fwd + bwd): the Waymo-shaped shard through VoxelResBackBone8x in TRAINING mode.
+
+Reference: pcdet/models/backbones_3d/spconv_backbone.py:30-63 (SparseBasicBlock), :183-260 (VoxelResBackBone8x),
+tools/cfgs/waymo_models/centerpoint.yaml:12-13.  Reduced sizes are checked against the CPU oracle's gather-GEMM-scatter
+backward (oracle.sconv_backward) and an fp64 evaluation of the whole residual block over the oracle's rule table; the full
+2 x 180 000-point shard is checked through size-independent properties (pair lists == rule tables, tile maps beyond 4096
+tiles, recorded graph == eager pass, finite gradients everywhere).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from glenet_amd import backbone as gb
+from glenet_amd import synth
+from glenet_amd.spconv import core as sp
+
+pytestmark = pytest.mark.gpu
+W = synth.WAYMO
+
+
+def _level_cells(frame_seed, npts, shift, shape):
+    """Active cells of a Waymo-shaped frame at a coarser level: voxel coordinates >> shift, unique, ascending."""
+    pts = synth.waymo_frame(frame_seed, num_points=npts)[0]
+    _, c, _ = oracle.voxelize_hard(pts, W["voxel_size"], W["point_cloud_range"], 5, 150000)
+    cc = (c.astype(np.int64) >> shift)
+    cc = cc[(cc[:, 0] < shape[0]) & (cc[:, 1] < shape[1]) & (cc[:, 2] < shape[2])]
+    cc = np.unique(cc, axis=0)
+    return np.concatenate([np.zeros((len(cc), 1), np.int64), cc], 1).astype(np.int32)
+
+
+def _fp64_block(f, nbr, p, g, eps=1e-3):
+    """SparseBasicBlock in fp64 on the CPU over the oracle's rule table, training-mode BatchNorm (biased batch variance):
+    relu(bn2(conv2(relu(bn1(conv1(x))))) + x); returns the output and the gradients of sum(out * g)."""
+    t = {k: torch.from_numpy(np.asarray(v, np.float64)).requires_grad_(True) for k, v in p.items()}
+    x = torch.from_numpy(f.astype(np.float64)).requires_grad_(True)
+    idx = torch.from_numpy(nbr.astype(np.int64))
+    ok = (idx >= 0)
+
+    def conv(h, w, b):
+        out = torch.zeros((idx.shape[0], w.shape[2]), dtype=torch.float64)
+        for k in range(idx.shape[1]):
+            rows = ok[:, k].nonzero()[:, 0]
+            if len(rows):
+                out = out.index_add(0, rows, h[idx[rows, k]] @ w[k])
+        return out + b
+
+    def bn(h, gamma, beta):
+        m = h.mean(0)
+        v = ((h - m) ** 2).mean(0)
+        return (h - m) / torch.sqrt(v + eps) * gamma + beta
+
+    h = torch.relu(bn(conv(x, t["w1"], t["b1"]), t["g1"], t["be1"]))
+    h = bn(conv(h, t["w2"], t["b2"]), t["g2"], t["be2"])
+    out = torch.relu(h + x)
+    (out * torch.from_numpy(g.astype(np.float64))).sum().backward()
+    grads = {k: v.grad.numpy() for k, v in t.items()}
+    grads["x"] = x.grad.numpy()
+    return out.detach().numpy(), grads
+
+
+@pytest.mark.parametrize("C,shift,shape", [(64, 2, (11, 376, 376)), (128, 3, (6, 188, 188))])
+def test_residual_block_training_backward_matches_fp64(dev, C, shift, shape):
+    """One SparseBasicBlock of VoxelResBackBone8x's third / fourth stage (C = 64 / 128, biased SubM convs, training-mode
+    BatchNorm) on the active set a Waymo-shaped frame leaves at that level: output, input gradient, both weight gradients,
+    bias and BatchNorm gradients against the fp64 evaluation; the single convolutions against oracle.sconv_backward."""
+    rng = np.random.default_rng(C)
+    idx = _level_cells(31, 60000, shift, shape)
+    n = len(idx)
+    assert n > 3000
+    f = rng.normal(size=(n, C)).astype(np.float32)
+    g = rng.normal(size=(n, C)).astype(np.float32)
+    rules = oracle.build_rules(idx, shape, 3, subm=True)
+    nbr = rules.nbr_table()
+    p = dict(w1=rng.normal(size=(27, C, C)) / np.sqrt(27 * C), b1=rng.normal(size=C) * 0.1,
+             g1=rng.uniform(0.5, 1.5, C), be1=rng.normal(size=C) * 0.2,
+             w2=rng.normal(size=(27, C, C)) / np.sqrt(27 * C), b2=rng.normal(size=C) * 0.1,
+             g2=rng.uniform(0.5, 1.5, C), be2=rng.normal(size=C) * 0.2)
+    p = {k: v.astype(np.float32) for k, v in p.items()}
+    want, wg = _fp64_block(f, nbr, p, g)
+
+    blk = gb.ResidualBlock(C, "res").to(dev).train()
+    with torch.no_grad():
+        blk.conv1.weight.copy_(torch.from_numpy(p["w1"]).reshape(3, 3, 3, C, C))
+        blk.conv2.weight.copy_(torch.from_numpy(p["w2"]).reshape(3, 3, 3, C, C))
+        blk.conv1.bias.copy_(torch.from_numpy(p["b1"]))
+        blk.conv2.bias.copy_(torch.from_numpy(p["b2"]))
+        blk.bn1.weight.copy_(torch.from_numpy(p["g1"]))
+        blk.bn1.bias.copy_(torch.from_numpy(p["be1"]))
+        blk.bn2.weight.copy_(torch.from_numpy(p["g2"]))
+        blk.bn2.bias.copy_(torch.from_numpy(p["be2"]))
+    xf = torch.from_numpy(f).to(dev).requires_grad_(True)
+    x = sp.SparseConvTensor(xf, torch.from_numpy(idx).to(dev), list(shape), 1)
+    out = blk(x)
+    out.features.backward(torch.from_numpy(g).to(dev))
+    got = out.features.detach().cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+
+    def close(a, b, name):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        scale = np.abs(b).max()
+        err = np.abs(a - b).max()
+        assert err <= 2e-4 * scale + 1e-6, "%s: max error %.3g against scale %.3g" % (name, err, scale)
+
+    close(xf.grad.cpu().numpy(), wg["x"], "d input")
+    close(blk.conv1.weight.grad.reshape(27, C, C).cpu().numpy(), wg["w1"], "d conv1.weight")
+    close(blk.conv2.weight.grad.reshape(27, C, C).cpu().numpy(), wg["w2"], "d conv2.weight")
+    close(blk.bn1.weight.grad.cpu().numpy(), wg["g1"], "d bn1.weight")
+    close(blk.bn1.bias.grad.cpu().numpy(), wg["be1"], "d bn1.bias")
+    close(blk.bn2.weight.grad.cpu().numpy(), wg["g2"], "d bn2.weight")
+    close(blk.bn2.bias.grad.cpu().numpy(), wg["be2"], "d bn2.bias")
+    # a bias in front of a training BatchNorm has an exactly-zero gradient: both sides return rounding noise
+    assert np.abs(blk.conv1.bias.grad.cpu().numpy()).max() <= 1e-3 * np.abs(g).sum(0).max()
+    assert np.abs(wg["b1"]).max() <= 1e-9 * np.abs(g).sum(0).max()
+
+    # the single convolution against the oracle's own backward (fp32 gather-GEMM-scatter)
+    conv = sp.SubMConv3d(C, C, 3, padding=1, bias=False, indice_key="one").to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(p["w1"]).reshape(3, 3, 3, C, C))
+    din, dw = oracle.sconv_backward(f, p["w1"], g, rules)
+    x1 = torch.from_numpy(f).to(dev).requires_grad_(True)
+    y = conv(sp.SparseConvTensor(x1, torch.from_numpy(idx).to(dev), list(shape), 1))
+    np.testing.assert_allclose(y.features.detach().cpu().numpy(), oracle.sconv_forward(f, p["w1"], rules), rtol=1e-4, atol=1e-4)
+    y.features.backward(torch.from_numpy(g).to(dev))
+    close(x1.grad.cpu().numpy(), din, "conv d input")
+    close(conv.weight.grad.reshape(27, C, C).cpu().numpy(), dw, "conv d weight")
+
+
+def test_strided_64_to_128_backward_matches_oracle(dev):
+    """VoxelResBackBone8x's conv4 entry: SparseConv3d 64 -> 128, k 3, s 2, pad (0, 1, 1) (spconv_backbone.py:219-224) on a
+    Waymo-shaped level-3 active set: output set, values, input gradient over the inverse table, weight gradient."""
+    rng = np.random.default_rng(9)
+    shape = (11, 376, 376)
+    idx = _level_cells(33, 50000, 2, shape)
+    n = len(idx)
+    f = rng.normal(size=(n, 64)).astype(np.float32)
+    w = (rng.normal(size=(27, 64, 128)) / np.sqrt(27 * 64)).astype(np.float32)
+    rules = oracle.build_rules(idx, shape, 3, 2, (0, 1, 1), subm=False)
+    g = rng.normal(size=(len(rules.out_indices), 128)).astype(np.float32)
+    din, dw = oracle.sconv_backward(f, w, g, rules)
+    conv = sp.SparseConv3d(64, 128, 3, stride=2, padding=(0, 1, 1), bias=False, indice_key="sp4").to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(w).reshape(3, 3, 3, 64, 128))
+    xf = torch.from_numpy(f).to(dev).requires_grad_(True)
+    y = conv(sp.SparseConvTensor(xf, torch.from_numpy(idx).to(dev), list(shape), 1))
+    assert np.array_equal(y.indices.cpu().numpy(), rules.out_indices)
+    np.testing.assert_allclose(y.features.detach().cpu().numpy(), oracle.sconv_forward(f, w, rules), rtol=1e-4, atol=1e-4)
+    y.features.backward(torch.from_numpy(g).to(dev))
+    np.testing.assert_allclose(xf.grad.cpu().numpy(), din, rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(conv.weight.grad.reshape(27, 64, 128).cpu().numpy(), dw, rtol=1e-3, atol=2e-3)
+
+
+class _PairMeta(ctypes.Structure):        # head of a pair-list buffer (csrc/glx_sconv.hip PairMeta)
+    _fields_ = [("poff", ctypes.c_int * 28), ("coff", ctypes.c_int * 28), ("ch", ctypes.c_int), ("pad", ctypes.c_int * 7)]
+
+
+def _shard(dev, frames=2):
+    fr = [synth.waymo_frame(40 + i)[0] for i in range(frames)]
+    pts = torch.from_numpy(np.concatenate(fr)).to(dev)
+    bidx = torch.from_numpy(np.concatenate([np.full(len(f), i, np.int32) for i, f in enumerate(fr)])).to(dev)
+    return pts, bidx
+
+
+def test_waymo_shard_training_step_full_size(dev):
+    """configs[4] per GPU, fwd + bwd: 2 frames x 180 000 points through VoxelResBackBone8x in training mode.
+    Full-size properties: (1) every table's per-offset pair lists hold exactly the table's rules, (2) the level-1 tile maps
+    exceed 4096 tiles and are permutations, (3) every parameter gradient is finite and non-trivial, (4) the shape-static
+    recorded graph reproduces the exact-shape eager step (loss, gradients, running statistics), also on a second batch."""
+    torch.manual_seed(2)
+    grid = oracle.grid_size_of(W["point_cloud_range"], W["voxel_size"])
+    model = gb.VoxelResBackBone8x(5, grid).to(dev).train()
+    g = torch.Generator().manual_seed(1)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) * 0.5 + 0.75)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    state0 = {k: v.clone() for k, v in model.state_dict().items()}
+    loss_fn = lambda bd: (bd["spatial_features"] * 3.0).square().mean()   # noqa: E731
+    a = _shard(dev)
+    f1 = synth.waymo_frame(47, num_points=150000)[0]
+    f2 = synth.waymo_frame(48, num_points=170000)[0]
+    b_pts = torch.from_numpy(np.concatenate([f1, f2])).to(dev)
+    b_idx = torch.from_numpy(np.concatenate([np.zeros(len(f1), np.int32), np.ones(len(f2), np.int32)])).to(dev)
+
+    def exact(pts, bidx):
+        model.load_state_dict(state0)
+        model.zero_grad(set_to_none=True)
+        bd = gb.MeanVFE()(gb.voxelize_batch(pts, bidx, 2, W, train=True))
+        plan = model.plan(bd["voxel_coords"], 2, index=bd["voxel_index"], pair_lists=True)
+        bd["rule_plan"] = plan
+        bd = gb.HeightCompression()(model(bd))
+        loss = loss_fn(bd)
+        loss.backward()
+        grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+        stats = {n: b.clone() for n, b in model.named_buffers()}
+        return loss.detach().clone(), grads, stats, plan, bd
+
+    loss_a, grads_a, stats_a, plan, bd = exact(*a)
+    torch.cuda.synchronize()
+    nvox = bd["voxel_coords"].shape[0]
+    assert nvox > 200000 and float(loss_a) > 0
+    # (1) pair lists == rule tables, per offset
+    seen = 0
+    for key, rs in plan.items():
+        for ptr, (pl, _, _) in rs._pair_lists.items():
+            nbr = rs.nbr if ptr == rs.nbr.data_ptr() else rs.nbr_in
+            assert nbr is not None and nbr.data_ptr() == ptr
+            head = pl[:ctypes.sizeof(_PairMeta)].cpu().numpy().tobytes()
+            meta = _PairMeta.from_buffer_copy(head)
+            per_k = (nbr >= 0).sum(0).cpu().numpy()
+            assert np.array_equal(np.diff(np.asarray(meta.poff[:rs.K + 1])), per_k), key
+            assert meta.poff[rs.K] == int(per_k.sum()) == (rs.pair_count if ptr == rs.nbr.data_ptr() else int(per_k.sum()))
+            assert 128 <= meta.ch <= 1024
+            seen += 1
+    assert seen >= 9                                  # conv_input/res1 .. res4 + the four strided tables
+    # (2) tile maps beyond 4096 tiles
+    big = 0
+    for key, rs in plan.items():
+        for ptr, m in rs._tile_maps.items():
+            mm = m.cpu().numpy()
+            assert np.array_equal(np.sort(mm), np.arange(len(mm))), key
+            big = max(big, len(mm))
+    assert big > 4096, big
+    # (3) gradients
+    for n, p in model.named_parameters():
+        gr = grads_a[n]
+        assert torch.isfinite(gr).all(), n
+        if not (n.endswith("conv1.bias") or n.endswith("conv2.bias")):      # biases in front of a BatchNorm: zero + noise
+            assert float(gr.abs().max()) > 0, n
+    del bd, plan
+    loss_b, grads_b, stats_b, _, _ = exact(b_pts, b_idx)
+
+    # (4) shape-static pipeline, eager then recorded
+    pipe = gb.StaticTrainPipeline(model, W, 2, a[0].shape[0], 5, loss_fn=loss_fn)
+    pipe.calibrate(*a)
+
+    def compare(ref_loss, ref_grads, ref_stats):
+        torch.cuda.synchronize()
+        pipe.check()
+        np.testing.assert_allclose(float(pipe.loss.detach()), float(ref_loss), rtol=1e-5)
+        gmax = max(float(v.abs().max()) for v in ref_grads.values())
+        for n, p in model.named_parameters():
+            got, want = p.grad.cpu().numpy(), ref_grads[n].cpu().numpy()
+            assert np.isfinite(got).all(), n
+            np.testing.assert_allclose(got, want, rtol=5e-4, atol=5e-5 * max(gmax * 1e-2, np.abs(want).max()), err_msg=n)
+        for n, b in model.named_buffers():
+            np.testing.assert_allclose(b.cpu().numpy(), ref_stats[n].cpu().numpy(), rtol=1e-5, atol=1e-7, err_msg=n)
+
+    model.load_state_dict(state0)
+    pipe.load(*a)
+    pipe.enqueue()
+    compare(loss_a, grads_a, stats_a)
+    model.load_state_dict(state0)
+    pipe.capture(warmup=1)
+    model.load_state_dict(state0)
+    pipe.load(b_pts, b_idx)
+    pipe.replay()
+    compare(loss_b, grads_b, stats_b)
+    model.load_state_dict(state0)
+    pipe.load(*a)
+    pipe.replay()
+    compare(loss_a, grads_a, stats_a)
+    torch.cuda.synchronize()
+    pipe.graph = None
+    pipe.out = pipe.loss = None

@@ -29,7 +29,9 @@ def test_conv3x3_matches_fp64_convolution(dev, shape):
     lib = F.conv2d(x, wt, None, 1, 1)
     scale = ref.abs().max()
     err, err_lib = (y.double() - ref).abs().max() / scale, (lib.double() - ref).abs().max() / scale
-    assert err < 4e-6 and err < 4 * err_lib + 1e-6, (float(err), float(err_lib))
+    # fp32-class: within 2 x the vendor fp32 kernel's own error against fp64 (bench: bev.conv3x3_error_vs_fp64 measures 1.15 x
+    # forward at the BEV sizes), + a third of one fp32 rounding of the largest output for the max-statistic's jitter
+    assert err < 4e-6 and err < 2 * err_lib + 3e-7, (float(err), float(err_lib))
 
 
 def test_conv3x3_is_exact_on_integer_data_with_asymmetric_filters(dev):
@@ -77,6 +79,15 @@ def test_conv3x3_gradients_and_pack_refresh(dev):
     F.conv2d(xd, wd, None, 1, 1).backward(gy.double())
     assert (x.grad.double() - xd.grad).abs().max() < 4e-6 * xd.grad.abs().max()
     assert (wt.grad.double() - wd.grad).abs().max() < 2e-5 * wd.grad.abs().max()
+    # ... and both within 2 x the vendor fp32 kernels' own error against fp64 (the input gradient is the loosest of the
+    # three: bench measures 1.68 x at the BEV sizes)
+    xl, wl = x.detach().clone().requires_grad_(True), wt.detach().clone().requires_grad_(True)
+    F.conv2d(xl, wl, None, 1, 1).backward(gy)
+    sx, sw = xd.grad.abs().max(), wd.grad.abs().max()
+    ex, ex_lib = (x.grad.double() - xd.grad).abs().max() / sx, (xl.grad.double() - xd.grad).abs().max() / sx
+    ew, ew_lib = (wt.grad.double() - wd.grad).abs().max() / sw, (wl.grad.double() - wd.grad).abs().max() / sw
+    assert ex < 2 * ex_lib + 3e-7, (float(ex), float(ex_lib))
+    assert ew < 2 * ew_lib + 3e-7, (float(ew), float(ew_lib))
     # an in-place weight update (optimizer step through raw pointers) must reach the packed pieces
     with torch.no_grad():
         wt.mul_(-2.0)

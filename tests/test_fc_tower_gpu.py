@@ -114,5 +114,24 @@ def test_fc_towers_leave_the_barrier_clean_and_repeat():
     b = [o.clone() for o in dp.fc_towers(head, x.clone().requires_grad_(True))]
     for u, v in zip(a, b):
         assert torch.equal(u, v)
-    for bar in dp._FCT_BARRIER.values():
+    bars = head.__dict__["_glx_fct_barriers"]           # owned by the module, one per (device, stream)
+    assert len(bars) == 1
+    for bar in bars.values():
         assert int(bar.abs().sum()) == 0
+    assert not dp.fc_tower_barrier_gave_up(head)
+
+
+def test_fc_tower_residency_is_checked_not_assumed(monkeypatch):
+    """the one-launch towers spin at grid barriers across 32 blocks; the entry point asks the runtime whether
+    those blocks are resident together (occupancy x CUs) and otherwise launches per phase.  On a whole MI355X both
+    directions are supported and cooperative; a row count whose LDS request cannot fit a block is reported unsupported
+    (fc_tower_usable then keeps the module path); counters are never allocated inside a stream capture."""
+    from glenet_amd import dense_path as dp
+    dev = torch.device("cuda", 0)
+    assert dp.fc_tower_support(dev, 512) == (True, True)
+    assert dp.fc_tower_support(dev, 1024)[0] is True
+    assert dp.fc_tower_support(dev, 1 << 20)[0] is False          # 100 MB of LDS per block: no device has that
+    head = _Head(256, 0.0).to(dev).train()
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
+    with pytest.raises(RuntimeError, match="warm-up"):
+        dp._fct_barrier(head, dev)

@@ -100,3 +100,94 @@ def test_fill_nodes_write_what_the_memset_would(dev, kind, offset, count):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(buf.cpu(), want)
+
+
+def test_finish_graph_refuses_a_graph_without_its_raw_handle(dev):
+    """finish_graph must not silently leave memset nodes in place.  A graph recorded by torch's default capture
+    (hipGraph_t destroyed at instantiation) cannot be repaired: GlxError, not None."""
+    x = torch.randn(1 << 12, device=dev)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        x.mul(2.0)
+    with pytest.raises(_lib.GlxError):
+        _lib.finish_graph(g)
+    # pipelines create their graphs through new_graph(): always with the raw handle, whatever GLX_AUDIT_GRAPHS says
+    g2 = _lib.new_graph()
+    with torch.cuda.graph(g2, stream=side):
+        y = x.mul(2.0)
+    assert _lib.finish_graph(g2) == 0
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, x * 2.0)
+
+
+def test_memsets_inside_a_child_graph_are_replaced_too(dev):
+    """A memset node inside a child-graph node (a library that records a sub-graph of its own) is found by the recursive walk
+    of glx_graph_replace_memsets and replays the right pattern."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    buf = torch.full((4096,), 0x11, dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream(dev)
+    child = _lib.new_graph()
+    with torch.cuda.graph(child, stream=side):
+        rc = hip.hipMemsetAsync(ctypes.c_void_p(buf.data_ptr() + 256), 0xA5, ctypes.c_size_t(1024),
+                                ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        assert rc == 0
+    parent = ctypes.c_void_p()
+    assert hip.hipGraphCreate(ctypes.byref(parent), 0) == 0
+    node = ctypes.c_void_p()
+    assert hip.hipGraphAddChildGraphNode(ctypes.byref(node), parent, None, ctypes.c_size_t(0),
+                                         ctypes.c_void_p(child.raw_cuda_graph())) == 0
+    n = ctypes.c_int(0)
+    _lib.call_nostream("glx_graph_replace_memsets", parent, ctypes.byref(n))
+    assert n.value == 1
+    ex = ctypes.c_void_p()
+    assert hip.hipGraphInstantiate(ctypes.byref(ex), parent, None, None, ctypes.c_size_t(0)) == 0
+    stream = torch.cuda.Stream(dev)
+    want = torch.full((4096,), 0x11, dtype=torch.uint8)
+    want[256:256 + 1024] = 0xA5
+    for _ in range(3):
+        buf.fill_(0x11)
+        torch.cuda.synchronize()
+        assert hip.hipGraphLaunch(ex, ctypes.c_void_p(stream.cuda_stream)) == 0
+        stream.synchronize()
+        assert torch.equal(buf.cpu(), want)
+    _KEEP.append((ex, parent, child))         # never destroyed (ROCm 7.2: see _lib.KEEP_GRAPH_EXECS)
+
+
+_KEEP = []
+
+
+def test_recaptures_do_not_grow_reserved_memory(dev):
+    """VERDICT r4 hygiene: an inference pipeline that records itself again and again (weights change between evaluations)
+    retires its old hipGraphExec (never destroyed on ROCm 7.2) but records into the retired graph's memory pool: device
+    memory reserved by the allocator stops growing after the first re-captures."""
+    import oracle
+    from glenet_amd import backbone as gb
+    K = synth.KITTI
+    grid = oracle.grid_size_of(K["point_cloud_range"], K["voxel_size"])
+    torch.manual_seed(0)
+    model = gb.SparseBackbone8x(4, grid).eval().to(dev)
+    f = synth.kitti_frame(3, num_points=3000)[0]
+    pts = torch.from_numpy(f).to(dev)
+    bidx = torch.zeros(len(f), dtype=torch.int32, device=dev)
+    pipe = gb.StaticFramePipeline(model, K, 1, pts.shape[0], 4)
+    pipe.calibrate(pts, bidx)
+    pipe.load(pts, bidx)
+    pipe.capture()
+    n0 = _lib.retired_graph_count()
+    seen = []
+    for i in range(50):
+        with torch.no_grad():
+            model.conv_input[0].weight.mul_(1.0)          # a version bump: replay() records the frame again
+        pipe.load(pts, bidx)
+        pipe.replay()
+        torch.cuda.synchronize()
+        seen.append(torch.cuda.memory_reserved(dev))
+    assert _lib.retired_graph_count() == n0 + 50
+    assert seen[-1] == seen[9], "reserved memory grew from %d to %d bytes over 40 re-captures" % (seen[9], seen[-1])
+    torch.cuda.synchronize()
+    pipe.graph = None
+    pipe.out = None
