@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libglenet_hip.so")
+# GLX_HIP_LIB: another build of the same sources (tools/build_variant.sh: kernel experiments A/B'd on one box)
+LIB_PATH = os.environ.get("GLX_HIP_LIB") or os.path.join(_HERE, "csrc", "libglenet_hip.so")
 
 _lib = None
 

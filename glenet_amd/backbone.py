@@ -332,7 +332,12 @@ class StaticFramePipeline:
         # recorded backward then makes THAT stream wait on a capturing event -- and capture_end() fails with "capturing
         # stream has unjoined work", or not, depending on when the collector last ran.
         gc.collect()
-        side = torch.cuda.Stream(self.points.device)
+        # ONE capture stream per pipeline: the caching allocator keeps freed blocks per stream, so a fresh side stream per
+        # (re-)capture would strand the warm-up pass's buffers of every earlier capture (55 MB per re-capture measured on
+        # a small inference pipeline: tests/test_graph_memset_gpu.py::test_recaptures_do_not_grow_reserved_memory)
+        side = self.__dict__.get("_capture_stream")
+        if side is None:
+            side = self._capture_stream = torch.cuda.Stream(self.points.device)
         side.wait_stream(torch.cuda.current_stream(self.points.device))
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):

@@ -27,7 +27,9 @@
 #define CV_TW 16
 #define CV_HW (CV_TW + 2)
 #define CV_HP ((CV_TH + 2) * CV_HW)      // 180 halo pixels
+#ifndef CV_ROW
 #define CV_ROW 80                        // bytes per LDS row of a plane: 32 bf16 + 16 (bank spread)
+#endif
 #define CV_APLANE (CV_HP * CV_ROW)       // 14 400
 #define CV_BN 64                         // output channels per block
 #define CV_WPLANE (CV_BN * CV_ROW)       // 5 120
@@ -352,6 +354,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
 // PRE: the input is transformed on load (a.pre_scale / a.pre_shift, staged in LDS behind the halo planes: the kernel sits
 // at its 168-register budget, eight more live registers for the coefficients spilled 27 more -- as a template parameter the
 // plain kernels compile as before).
+// CV_ABL (compile-time, tools/build_variant.sh -DCV_ABL=n; 0 in the product): TIMING-ONLY ablations of the second form (wrong
+// results): 1 = operand fragments read from LDS once per tile, 2 = weight fragments loaded once per tile, 4 = halo loaded and
+// staged once per tile (no per-chunk loads, splits, stores, barriers), 8 = no barriers, 16 = one piece product of six.
+#ifndef CV_ABL
+#define CV_ABL 0
+#endif
 template <bool STATS, int TH, bool PRE = false, bool BWD = false>
 __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
   static_assert(!(BWD && (STATS || PRE)), "BWD is a mode of the plain input-gradient launch");
@@ -450,16 +458,17 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
       wnext_src = a.wp + (size_t)(nt.n0 + 16 * wave + r) * 32 + kq * 8;
     }
     for (int ch = 0; ch < nch; ++ch) {
-      __syncthreads();                    // everyone is done reading the previous halo image
+      if (!(CV_ABL & 8) && !((CV_ABL & 4) && ch > 0)) __syncthreads();   // everyone is done reading the previous halo image
       const int pre_ch = ch;              // the thread's four channels of the staged chunk: 32 ch + 4 (tid & 7) ..
       (void)pre_ch;
-      V2_STORE_A();
-      __syncthreads();
+      if (!((CV_ABL & 4) && ch > 0)) { V2_STORE_A(); }
+      if (!(CV_ABL & 8) && !((CV_ABL & 4) && ch > 0)) __syncthreads();
       const bool last = ch + 1 == nch;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) wcur[q] = wnxt[q];
+        if (!((CV_ABL & 2) && (ch > 0 || tap > 0))) {
         if (tap < 8) {
           V2_LOAD_W(wnxt, wsrc, tap + 1, ch);
         } else if (!last) {
@@ -467,7 +476,8 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
         } else if (has_next) {
           V2_LOAD_W(wnxt, wnext_src, 0, 0);
         }
-        if (tap == 6) {
+        }
+        if (tap == 6 && !(CV_ABL & 4)) {
           if (!last) {
             V2_LOAD_A(ch + 1);
           } else if (has_next) {
@@ -483,14 +493,22 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
           for (int i = 0; i < 2; ++i) {
             if (2 * part + i < TH) {
               const int hp = (2 * part + i + dy) * CV_HW + r + dx;
+              if ((CV_ABL & 1) && (tap > 0 || ch > 0)) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) xa[i][q] = wcur[(q + i) % 3];
+              } else {
 #pragma unroll
               for (int q = 0; q < 3; ++q) xa[i][q] = *reinterpret_cast<const bf16x8*>(aBase + q * PLANE + hp * CV_ROW);
+              }
             }
           }
           __builtin_amdgcn_sched_barrier(0);       // this part's reads, then its products: keeps the scheduler from
 #pragma unroll
           for (int i = 0; i < 2; ++i)
-            if (2 * part + i < TH) BF3_MFMA6(acc[2 * part + i], wcur, xa[i]);
+            if (2 * part + i < TH) {
+              if (CV_ABL & 16) acc[2 * part + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur[0], xa[i][0], acc[2 * part + i], 0, 0, 0);
+              else BF3_MFMA6(acc[2 * part + i], wcur, xa[i]);
+            }
           __builtin_amdgcn_sched_barrier(0);       // hoisting later parts' operands (170-register budget, 3 waves / SIMD)
         }
       }

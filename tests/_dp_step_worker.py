@@ -1,5 +1,7 @@
-"""Worker of tests/test_dist_gpu.py: one rank of a 2-rank data-parallel GLENet-VR training step.  Both ranks share the
-box's single GPU; the collective runs over gloo (host copies) -- plumbing only, the arithmetic is the RCCL path's."""
+"""Worker of tests/test_dist_gpu.py: one rank of a 2-rank data-parallel GLENet-VR training step.
+GLX_DIST_BACKEND=gloo (default): both ranks share the box's single GPU, the collective runs over gloo (host copies) --
+plumbing only, the arithmetic is the RCCL path's.  GLX_DIST_BACKEND=nccl: one GPU per rank (LOCAL_RANK), the flat gradient
+all-reduce over real RCCL / xGMI -- what tests/test_dist_gpu.py runs when two GPUs are visible."""
 import json
 import os
 import sys
@@ -17,10 +19,13 @@ def main():
     from glenet_amd import dist as gdist
     from glenet_amd import glenet_vr as gvr
     import test_train_step_gpu as helpers
-    rank, _, world = gdist.env_world()
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
-    gdist.init("gloo")
+    rank, local_rank, world = gdist.env_world()
+    backend = os.environ.get("GLX_DIST_BACKEND", "gloo")
+    di = local_rank % torch.cuda.device_count() if backend == "nccl" else 0
+    dev = torch.device("cuda", di)
+    torch.cuda.set_device(di)
+    gdist.init(backend, device=dev)
+    cdev = dev if backend == "nccl" else "cpu"          # where collectives of diagnostics tensors run
     lr = 1e-3
     batches = [helpers._batch(dev, [60, 61], 6000), helpers._batch(dev, [62, 63], 6000)]
     npts = max(b[0].shape[0] for b in batches) + 700
@@ -65,7 +70,7 @@ def main():
     opt = pipe.step_optimizer
     p_dp = opt.flat_param.detach().cpu()
     g_dp = (opt.flat_grad.detach() * opt.grad_scale).cpu()          # what the update consumed
-    lo, hi = p_dp.clone(), p_dp.clone()
+    lo, hi = p_dp.clone().to(cdev), p_dp.clone().to(cdev)
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     ranks_equal = bool(torch.equal(lo, hi))
@@ -91,7 +96,7 @@ def main():
                grad_max_abs=scale, grad_err_max=float(dg.max()), grad_err_over_1e4=int((dg > 1e-4 * scale).sum()),
                param_err_max=float(dp_.max()), param_err_mean=float(dp_.mean()),
                grads_differ_between_batches=float((grads[0] - grads[1]).abs().max()), lr=lr,
-               step_count=int(opt.step_count))
+               step_count=int(opt.step_count), backend=dist.get_backend(), device=di, world=dist.get_world_size())
     if g_local is not None:
         e_loc = float((g_local - grads[rank]).abs().max())
         print("DPDEBUG rank %d: own recorded gradient vs own eager gradient of the same batch: %.3e (scale %.3e)"

@@ -15,15 +15,20 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_ranks_make_the_update_of_one_rank_on_both_batches(dev):
+def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    return port
+
+
+def _two_rank_step(backend):
+    port = _free_port()
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
+                   MASTER_PORT=str(port), GLX_DIST_BACKEND=backend)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dp_step_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -34,6 +39,7 @@ def test_two_ranks_make_the_update_of_one_rank_on_both_batches(dev):
                   if line.startswith("DPRESULT ")), key=lambda d: d["rank"])
     assert [d["rank"] for d in res] == [0, 1]
     for d in res:
+        assert d["backend"] == backend and d["world"] == 2
         assert d["ranks_equal"], d                       # rank 1 started from other weights: broadcast + same update
         assert d["grad_scale"] == 0.5 and d["step_count"] == 1
         assert d["grads_differ_between_batches"] > 1e-3 * d["grad_max_abs"]          # the ranks really had different data
@@ -47,16 +53,56 @@ def test_two_ranks_make_the_update_of_one_rank_on_both_batches(dev):
         assert d["param_err_mean"] <= 2e-3 * d["lr"], d
 
 
+    return res
+
+
+def test_two_ranks_make_the_update_of_one_rank_on_both_batches(dev):
+    _two_rank_step("gloo")
+
+
+def _gpus_visible():
+    import torch
+    return torch.cuda.device_count()          # counting devices does not initialise the runtime
+
+
+def test_two_ranks_over_real_rccl_when_two_gpus_are_visible(dev):
+    """skips itself on a 1-GPU box and runs the day the suite sees two GPUs.  One process per GPU, the
+    flat fp32 SUM all-reduce of the gradient buffer over RCCL (xGMI) between the forward + backward graph and the update
+    graph: both ranks end with bit-identical parameters (rank 1 started from other weights: the broadcast), and the
+    gradient the update consumed is the mean of the two shards' gradients."""
+    if _gpus_visible() < 2:
+        pytest.skip("one GPU visible: the 2-GPU RCCL step runs where the box has two")
+    res = _two_rank_step("nccl")
+    assert sorted(d["device"] for d in res) == [0, 1]
+
+
+def test_bench_two_gpus_over_rccl_when_two_gpus_are_visible(dev):
+    """`python bench.py --gpus 2 --no-extra` as the driver launches it (bench.py spawns one process per GPU before anything
+    touches a GPU): ONE JSON line, n_gpus 2, the collective saw two ranks, per-rank diagnostics of both, weak scaling."""
+    if _gpus_visible() < 2:
+        pytest.skip("one GPU visible: bench.py --gpus 2 runs where the box has two")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GLX_DIST_BACKEND", "GLX_BENCH_FORCE_DP"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2",
+                        "--no-config1", "--no-extra", "--no-cpu-baseline", "--no-stages"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=1200)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["ranks_seen_by_collective"] == 2
+    assert len(d["per_rank"]["ms_per_step"]) == 2 and min(d["per_rank"]["exchange_ms"]) >= 0.0
+
+
 def test_bench_data_parallel_step_over_rccl_prints_one_json_line(dev):
     """GLX_BENCH_FORCE_DP=1: bench.py's N > 1 code path -- process group over RCCL (`nccl`) with `device_id`, two graphs,
     the flat SUM all-reduce between them, the scaled update, the per-rank diagnostics -- with a world of one process on
     this box's GPU; and what a launcher reads: stdout holds exactly ONE line, the JSON (RCCL's version banner, which the
     C library flushes at exit, goes to stderr with everything else)."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, GLX_BENCH_FORCE_DP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env = dict(os.environ, GLX_BENCH_FORCE_DP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GLX_DIST_BACKEND"):
         env.pop(k, None)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
