@@ -417,40 +417,54 @@ def bench_dropin(state, K, pool, dev, steps=12):
     from glenet_amd import glenet_vr as gvr
     seed = torch.tensor(ROI_SEED_OFFSET, dtype=torch.float32, device=dev)
 
-    def run(layout):
+    def run(layout, gemm=True, vary_only=0):
+        """gemm: glenet_amd.dropin.pointwise_as_gemm() in effect (1 x 1 Conv1d / Conv2d as matrix products, stacked BatchNorms
+        on torch's native kernels: no per-voxel-count preparation in the vendor library); vary_only = n: only n new-shape steps."""
         with (dropin.reference_layout() if layout else contextlib.nullcontext()):
-            torch.manual_seed(0)
-            m = gvr.GLENetVR(K, bev_channels_last=not layout).to(dev).train()
-            m.load_state_dict(state)
-            opt = torch.optim.AdamW(m.parameters(), lr=1e-3, betas=gvr.OPTIM_CFG["BETAS"], weight_decay=gvr.OPTIM_CFG["WEIGHT_DECAY"])
+            if gemm:
+                dropin.pointwise_as_gemm()
+            try:
+                torch.manual_seed(0)
+                m = gvr.GLENetVR(K, bev_channels_last=not layout).to(dev).train()
+                m.load_state_dict(state)
+                opt = torch.optim.AdamW(m.parameters(), lr=1e-3, betas=gvr.OPTIM_CFG["BETAS"], weight_decay=gvr.OPTIM_CFG["WEIGHT_DECAY"])
 
-            def step(b):
-                opt.zero_grad(set_to_none=True)
-                loss, _ = m.training_step(b[0], b[1], FRAMES_PER_GPU, b[2], b[3], seed_rois_with_gt=seed)
-                loss.backward()
-                torch.nn.utils.clip_grad_norm_(m.parameters(), gvr.OPTIM_CFG["GRAD_NORM_CLIP"])
-                opt.step()
-                m.last = None
-            def timed(batches, n):
-                for b in batches[:3]:
-                    step(b)
-                torch.cuda.synchronize(dev)
-                t0 = time.perf_counter()
-                for j in range(n):
-                    step(batches[j % len(batches)])
-                torch.cuda.synchronize(dev)
-                return (time.perf_counter() - t0) / n * 1e3
-            same = timed(pool[:1], steps)              # one batch over and over: every library call sees a shape it has seen
-            varying = timed(pool, len(pool))           # the pool's batches in turn: a new voxel count every step
-            del m, opt
-            torch.cuda.empty_cache()
-            return same, varying
+                def step(b):
+                    opt.zero_grad(set_to_none=True)
+                    loss, _ = m.training_step(b[0], b[1], FRAMES_PER_GPU, b[2], b[3], seed_rois_with_gt=seed)
+                    loss.backward()
+                    torch.nn.utils.clip_grad_norm_(m.parameters(), gvr.OPTIM_CFG["GRAD_NORM_CLIP"])
+                    opt.step()
+                    m.last = None
+
+                def timed(batches, n, warm=3):
+                    for b in batches[:warm]:
+                        step(b)
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    for j in range(n):
+                        step(batches[(warm + j) % len(batches)] if warm < len(batches) else batches[j % len(batches)])
+                    torch.cuda.synchronize(dev)
+                    return (time.perf_counter() - t0) / n * 1e3
+                if vary_only:
+                    same, varying = None, timed(pool, vary_only, warm=1)      # batches 1 .. n: voxel counts never seen before
+                else:
+                    same = timed(pool[:1], steps)          # one batch over and over: every library call sees a shape it has seen
+                    varying = timed(pool, len(pool), warm=1)   # the pool's other batches in turn: a new voxel count every step
+                del m, opt
+                torch.cuda.empty_cache()
+                return same, varying
+            finally:
+                if gemm:
+                    dropin.pointwise_as_gemm(False)
     ref_ms, ref_var = run(True)
+    _, ref_var_vendor = run(True, gemm=False, vary_only=3)
     acc_ms, acc_var = run(False)
     return dict(dropin_step_ms=round(ref_ms, 3), dropin_step_frames_per_s=round(FRAMES_PER_GPU / ref_ms * 1e3, 1),
                 dropin_accelerated_step_ms=round(acc_ms, 3),
                 dropin_accelerated_frames_per_s=round(FRAMES_PER_GPU / acc_ms * 1e3, 1), steps=steps,
                 dropin_step_ms_new_shape_every_step=round(ref_var, 3),
+                dropin_step_ms_new_shape_without_pointwise_as_gemm=round(ref_var_vendor, 3),
                 dropin_accelerated_step_ms_new_shape_every_step=round(acc_var, 3),
                 note="eager exact-shape training steps (host read-backs size the sparse tensors; torch.optim.AdamW): "
                      "dropin_step = reference module layout through the drop-in's operators only (glenet_amd.dropin."
@@ -459,7 +473,9 @@ def bench_dropin(state, K, pool, dev, steps=12):
                      "*_ms: one batch repeated (steady state of the kernels); *_new_shape_every_step: the bench pool's 8 "
                      "batches in turn -- in the reference layout the voxel count is a tensor DIMENSION of the 1x1 Conv1d / "
                      "BatchNorm layers of the RoI-grid pooling, and the vendor library selects (and on first sight builds) "
-                     "a kernel per problem size, every step")
+                     "a kernel per problem size, every step: *_without_pointwise_as_gemm (3 steps).  dropin_step* are "
+                     "measured with glenet_amd.dropin.pointwise_as_gemm() in effect (round 5): those 1x1 layers as matrix "
+                     "products and the stacked BatchNorms on torch's native kernels -- nothing to prepare per voxel count")
 
 
 def bench_config3(dev, objects=4096, points=512, samples=30):

@@ -387,6 +387,9 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
   int tile = blockIdx.x;
   if (tile >= a.ntiles) return;
   ConvTile ct = cv_tile(a, tile);
+#ifdef CV_STAGGER          // experiment: the three blocks of a CU (b, b + 256, b + 512) start CV_STAGGER x 1024 cycles apart
+  for (int i_ = 0; i_ < (int)((blockIdx.x >> 8) % 3) * CV_STAGGER; ++i_) __builtin_amdgcn_s_sleep(16);
+#endif
 
   int aoff[NL];
   const int adst0 = (tid >> 3) * CV_ROW + (tid & 7) * 8;

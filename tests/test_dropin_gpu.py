@@ -135,3 +135,51 @@ def test_accelerate_reclasses_reference_layout_modules_and_keeps_results(dev):
         scale = float(b[k].abs().max()) + 1e-9
         assert float((a[k] - b[k]).abs().max()) <= 2e-4 * scale, k
     assert torch.equal(a["rois"], b["rois"])
+
+
+def test_pointwise_as_gemm_equals_the_vendor_layers_and_is_undone(dev):
+    """dropin.pointwise_as_gemm(): 1 x 1 Conv1d / Conv2d modules as matrix products and stacked BatchNorms on torch's native
+    kernels (no per-voxel-count preparation in the vendor library: voxel_pool_modules.py:70-130 feeds them (1, C, M) and
+    (1, C, M, nsample) tensors whose M changes every step) -- outputs, input gradients and parameter gradients equal the
+    vendor path's; 3-tap layers, strided layers and image batches keep the original forward; the switch is undone."""
+    import time
+    torch.manual_seed(0)
+    conv_f = nn.Conv1d.forward
+    c1 = nn.Sequential(nn.Conv1d(16, 32, 1, bias=False), nn.BatchNorm1d(32), nn.ReLU()).to(dev).train()
+    c2 = nn.Sequential(nn.Conv2d(3, 16, 1, bias=True), nn.BatchNorm2d(16)).to(dev).train()
+    c3 = nn.Conv1d(16, 8, 3, padding=1).to(dev)
+    rows = torch.randn(5003, 16, device=dev)
+    x1 = rows.t().unsqueeze(0)                                   # the reference's (1, C, M) view of row-major features: strided
+    x2 = torch.randn(1, 3, 777, 16, device=dev)
+
+    def run():
+        out = []
+        for mod, x in ((c1, x1), (c2, x2), (c3, x1)):
+            for m in mod.modules():
+                if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+                    m.reset_running_stats()
+            xi = x.detach().clone().requires_grad_(True)
+            mod.zero_grad(set_to_none=True)
+            y = mod(xi)
+            (y * y).sum().backward()
+            out.append([y.detach().clone(), xi.grad.clone()] + [p.grad.clone() for p in mod.parameters()]
+                       + [b.clone() for b in mod.buffers() if b.dtype.is_floating_point])
+        return out
+    want = run()
+    assert set(dropin.pointwise_as_gemm()) >= {nn.Conv1d, nn.Conv2d, nn.BatchNorm1d, nn.BatchNorm2d}
+    try:
+        got = run()
+        # a length the library has never seen costs nothing to prepare (the vendor path: ~0.3 s per new problem size)
+        xs = [torch.randn(1, 16, 4001 + 13 * i, device=dev) for i in range(5)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for x in xs:
+            c1(x)
+        torch.cuda.synchronize()
+        assert time.perf_counter() - t0 < 0.25
+    finally:
+        dropin.pointwise_as_gemm(False)
+    assert nn.Conv1d.forward is conv_f
+    for a, b in zip(want, got):
+        for u, v in zip(a, b):
+            assert float((u - v).abs().max()) <= 2e-5 * float(u.abs().max()) + 1e-6
