@@ -18,7 +18,9 @@
 #include "glx_bn_state.h"
 
 #define PC_TM 128                        // coarse pixels per block
-#define PC_ROW 80
+#ifndef PC_ROW
+#define PC_ROW 80                        // (96-byte rows, conflict-free for the 3x3 kernels' operand map, measured no better here: r05)
+#endif
 #define PC_APLANE (PC_TM * PC_ROW)       // 10 240
 #define PC_BN 64
 #define PC_WPLANE (PC_BN * PC_ROW)       // 5 120

@@ -165,7 +165,11 @@ def test_pointwise_as_gemm_equals_the_vendor_layers_and_is_undone(dev):
             out.append([y.detach().clone(), xi.grad.clone()] + [p.grad.clone() for p in mod.parameters()]
                        + [b.clone() for b in mod.buffers() if b.dtype.is_floating_point])
         return out
-    want = run()
+    # the yardstick: torch's native kernels for every layer.  (The vendor's training BatchNorm with running statistics is NOT a
+    # yardstick on these shapes: on the (1, 32, 5003) tensor here it deviates from an fp64 evaluation by 3e-3, torch's native
+    # kernel by 1e-6 -- tools/pointwise_bn_probe.py, round 5.)
+    with torch.backends.cudnn.flags(enabled=False):
+        want = run()
     assert set(dropin.pointwise_as_gemm()) >= {nn.Conv1d, nn.Conv2d, nn.BatchNorm1d, nn.BatchNorm2d}
     try:
         got = run()
