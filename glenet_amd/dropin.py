@@ -196,8 +196,7 @@ def pointwise_as_gemm(enable=True):
     `mlps_in` / `mlps_pos` / `mlps_out`), a new value every training step -- and MIOpen prepares a convolution per problem
     size (measured: 1.04 s per step with a new voxel count against 33 ms with a repeated one); a matrix product has no
     per-shape preparation.  Same arithmetic (fp32 dot products over Cin, bias added afterwards), autograd through torch's
-    matmul.  Everything else -- other kernel sizes, CPU tensors -- takes the original forward.  BatchNorm1d / BatchNorm2d on
-    such stacked tensors (batch dimension 1, or 2-D / 3-D inputs) run torch's native kernels for the same reason.
+    matmul.  Everything else -- other kernel sizes, CPU tensors -- takes the original forward.
     Returns the list of patched classes; pointwise_as_gemm(False) restores the originals."""
     import torch
     import torch.nn.functional as F
@@ -226,25 +225,14 @@ def pointwise_as_gemm(enable=True):
             return y.reshape((b, self.out_channels) + tuple(x.shape[2:]))
         return forward
 
-    def make_bn(orig):
-        # the same per-problem-size preparation exists in the vendor's BatchNorm (4 ms forward + 9 ms backward per new voxel
-        # count measured): tensors in the stacked convention -- batch dimension 1, the rows along the length -- and 2-D / 3-D
-        # BatchNorm1d inputs take torch's native kernels, fixed-shape image batches (the BEV maps) keep the vendor's
-        def forward(self, x):
-            if x.is_cuda and (x.dim() <= 3 or x.shape[0] == 1) and torch.backends.cudnn.enabled:
-                with torch.backends.cudnn.flags(enabled=False):
-                    return orig(self, x)
-            return orig(self, x)
-        return forward
-
     for cls in (nn.Conv1d, nn.Conv2d):
         if cls not in _POINTWISE:
             _POINTWISE[cls] = cls.forward
             cls.forward = make(cls.forward)
-    for cls in (nn.BatchNorm1d, nn.BatchNorm2d):
-        if cls not in _POINTWISE:
-            _POINTWISE[cls] = cls.forward
-            cls.forward = make_bn(cls.forward)
+    # BatchNorm1d / BatchNorm2d on the same stacked tensors stay on the vendor kernels: they, too, prepare per problem size
+    # (4 ms forward + 9 ms backward per new voxel count), but both replacements measured in round 5 cost more than that in
+    # EVERY step on the 200 MB batch-1 tensors of the pooling -- torch's native batch_norm kernel 43 ms per step, var_mean +
+    # addcmul tensor statements 47 ms, against 35 ms (repeated shape) / 46 ms (new shape) with the vendor's.
     return list(_POINTWISE)
 
 

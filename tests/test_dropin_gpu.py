@@ -138,10 +138,10 @@ def test_accelerate_reclasses_reference_layout_modules_and_keeps_results(dev):
 
 
 def test_pointwise_as_gemm_equals_the_vendor_layers_and_is_undone(dev):
-    """dropin.pointwise_as_gemm(): 1 x 1 Conv1d / Conv2d modules as matrix products and stacked BatchNorms on torch's native
-    kernels (no per-voxel-count preparation in the vendor library: voxel_pool_modules.py:70-130 feeds them (1, C, M) and
-    (1, C, M, nsample) tensors whose M changes every step) -- outputs, input gradients and parameter gradients equal the
-    vendor path's; 3-tap layers, strided layers and image batches keep the original forward; the switch is undone."""
+    """dropin.pointwise_as_gemm(): 1 x 1 Conv1d / Conv2d modules as matrix products (no per-voxel-count preparation in the
+    vendor library: voxel_pool_modules.py:70-130 feeds them (1, C, M) and (1, C, M, nsample) tensors whose M changes every
+    step) -- outputs, input gradients and parameter gradients equal the native kernels'; 3-tap layers keep the original
+    forward; the switch is undone."""
     import time
     torch.manual_seed(0)
     conv_f = nn.Conv1d.forward
@@ -170,15 +170,19 @@ def test_pointwise_as_gemm_equals_the_vendor_layers_and_is_undone(dev):
     # kernel by 1e-6 -- tools/pointwise_bn_probe.py, round 5.)
     with torch.backends.cudnn.flags(enabled=False):
         want = run()
-    assert set(dropin.pointwise_as_gemm()) >= {nn.Conv1d, nn.Conv2d, nn.BatchNorm1d, nn.BatchNorm2d}
+        dropin.pointwise_as_gemm()
+        try:
+            got = run()
+        finally:
+            dropin.pointwise_as_gemm(False)
+    assert set(dropin.pointwise_as_gemm()) == {nn.Conv1d, nn.Conv2d}
     try:
-        got = run()
         # a length the library has never seen costs nothing to prepare (the vendor path: ~0.3 s per new problem size)
         xs = [torch.randn(1, 16, 4001 + 13 * i, device=dev) for i in range(5)]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for x in xs:
-            c1(x)
+            c1[0](x)
         torch.cuda.synchronize()
         assert time.perf_counter() - t0 < 0.25
     finally:
