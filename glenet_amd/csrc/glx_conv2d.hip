@@ -1036,6 +1036,10 @@ extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int C
       if (best < 0 || cost < best) { best = cost; th = t; }
     }
     if (g_conv_th >= 6 && g_conv_th <= 8) th = g_conv_th;
+    // the BWD form (input gradient + ReLU mask + BatchNorm-backward sums in the epilogue) runs six rows per tile: at seven the
+    // compiler spills 13 registers of its 168 (at eight, 23); 6.05 -> 6.02 ms per step (three alternating pairs, round 5)
+    static const int th_bwd = getenv("GLX_CONV3X3_TH_BWD") ? atoi(getenv("GLX_CONV3X3_TH_BWD")) : 6;
+    if (bwd && g_conv_th == 0 && th_bwd >= 6 && th_bwd <= 8) th = th_bwd;
     if (bwd) {
       kern = th == 8 ? k_conv3x3_v2<false, 8, false, true> : th == 7 ? k_conv3x3_v2<false, 7, false, true> : k_conv3x3_v2<false, 6, false, true>;
     } else if (pre) {
