@@ -131,7 +131,7 @@ extern "C" int glx_index_build(const int32_t* indices, int N, int B, int D, int 
 __global__ void k_rules_subm(const int4* __restrict__ idx, int N, GlxGrid g,
                              const unsigned long long* __restrict__ bitmap,
                              const int* __restrict__ prefix, const int* __restrict__ rank_to_row,
-                             int kd, int kh, int kw, int* __restrict__ nbr,
+                             int kd, int kh, int kw, int dd, int dh, int dw, int* __restrict__ nbr,
                              int* __restrict__ pair_count, const int* __restrict__ n_live) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   int zy = kd * kh;
@@ -144,11 +144,11 @@ __global__ void k_rules_subm(const int4* __restrict__ idx, int N, GlxGrid g,
     int r = (int)(t - (long long)s * zy);
     int kz = r / kh, ky = r - kz * kh;
     int4 c = idx[j];
-    int z = c.y + kz - kd / 2, y = c.z + ky - kh / 2;
+    int z = c.y + (kz - kd / 2) * dd, y = c.z + (ky - kh / 2) * dh;
     int* dst = nbr + (long long)j * (zy * kw) + (long long)r * kw;
     bool row_ok = (unsigned)z < (unsigned)g.D && (unsigned)y < (unsigned)g.H;
     for (int kx = 0; kx < kw; ++kx) {
-      int x = c.w + kx - kw / 2;
+      int x = c.w + (kx - kw / 2) * dw;
       int v = -1;
       if (row_ok && (unsigned)x < (unsigned)g.W) {
         int rk = glx_rank_lookup(bitmap, prefix, g.lin(c.x, z, y, x));
@@ -171,8 +171,17 @@ extern "C" int glx_rules_subm(const int32_t* indices, int N, int B, int D, int H
                               const uint64_t* bitmap, const int32_t* prefix,
                               const int32_t* rank_to_row, int kd, int kh, int kw, int32_t* nbr,
                               int32_t* pair_count, const int32_t* n_live, void* stream) {
+  return glx_rules_subm_dilated(indices, N, B, D, H, W, bitmap, prefix, rank_to_row, kd, kh, kw, 1, 1, 1, nbr, pair_count,
+                                n_live, stream);
+}
+
+extern "C" int glx_rules_subm_dilated(const int32_t* indices, int N, int B, int D, int H, int W,
+                                      const uint64_t* bitmap, const int32_t* prefix,
+                                      const int32_t* rank_to_row, int kd, int kh, int kw, int dd, int dh, int dw,
+                                      int32_t* nbr, int32_t* pair_count, const int32_t* n_live, void* stream) {
   GLX_REQUIRE(kd > 0 && kh > 0 && kw > 0 && (kd & 1) && (kh & 1) && (kw & 1),
               "glx_rules_subm: kernel size must be odd, got (%d,%d,%d)", kd, kh, kw);
+  GLX_REQUIRE(dd > 0 && dh > 0 && dw > 0, "glx_rules_subm: dilation must be positive, got (%d,%d,%d)", dd, dh, dw);
   if (N == 0) return GLX_OK;
   GLX_REQUIRE(indices && bitmap && prefix && nbr, "glx_rules_subm: null pointer");
   GlxGrid g{B, D, H, W};
@@ -180,7 +189,7 @@ extern "C" int glx_rules_subm(const int32_t* indices, int N, int B, int D, int H
   hipLaunchKernelGGL(k_rules_subm, dim3(glx_divup(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, (const int4*)indices, N, g,
                      (const unsigned long long*)bitmap, (const int*)prefix, rank_to_row, kd, kh,
-                     kw, nbr, pair_count, n_live);
+                     kw, dd, dh, dw, nbr, pair_count, n_live);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
@@ -188,6 +197,7 @@ extern "C" int glx_rules_subm(const int32_t* indices, int N, int B, int D, int H
 // ---------------------------------------------------------------- strided conv
 struct ConvGeom {
   int kd, kh, kw, sd, sh, sw, pd, ph, pw;
+  int dd = 1, dh = 1, dw = 1;     // dilation (spconv's SparseConv3d(dilation=...): input cell = o * s - p + k * d)
 };
 
 // one thread per input row: the outputs that reach input cell c along one axis are
@@ -228,6 +238,38 @@ __global__ void k_outset_mark(const int4* __restrict__ idx, const int* __restric
           oflags[l >> 9] = 1;
         }
       }
+}
+
+// Dilated geometry (any dilation != 1): the outputs an input cell reaches are not a contiguous range -- one test per tap:
+// o = (c + p - k d) / s where that is a non-negative multiple of s inside the output grid.
+__global__ void k_outset_mark_dilated(const int4* __restrict__ idx, const int* __restrict__ in_rank_to_row,
+                                      int N, ConvGeom cg, GlxGrid og,
+                                      unsigned long long* __restrict__ obitmap,
+                                      unsigned char* __restrict__ oflags, const int* __restrict__ n_live) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_live) N = min(N, *n_live);
+  if (s >= N) return;
+  int i = in_rank_to_row ? in_rank_to_row[s] : s;
+  if (i < 0 || i >= N) return;
+  int4 c = idx[i];
+  for (int kz = 0; kz < cg.kd; ++kz) {
+    const int az = c.y + cg.pd - kz * cg.dd;
+    if (az < 0 || az % cg.sd || az / cg.sd >= og.D) continue;
+    for (int ky = 0; ky < cg.kh; ++ky) {
+      const int ay = c.z + cg.ph - ky * cg.dh;
+      if (ay < 0 || ay % cg.sh || ay / cg.sh >= og.H) continue;
+      for (int kx = 0; kx < cg.kw; ++kx) {
+        const int ax = c.w + cg.pw - kx * cg.dw;
+        if (ax < 0 || ax % cg.sw || ax / cg.sw >= og.W) continue;
+        long long l = og.lin(c.x, az / cg.sd, ay / cg.sh, ax / cg.sw);
+        unsigned long long bit = 1ull << (l & 63);
+        if (!(obitmap[l >> 6] & bit)) {
+          atomicOr(&obitmap[l >> 6], bit);
+          oflags[l >> 9] = 1;
+        }
+      }
+    }
+  }
 }
 
 // Variant for the common geometry where every axis range has at most 2 cells: the lanes of a
@@ -292,7 +334,18 @@ extern "C" int glx_outset_build(const int32_t* indices_in, int N_in, int B, int 
                                 uint64_t* out_bitmap, uint8_t* out_chunk_flags,
                                 int32_t* out_prefix, int32_t* n_out, const int32_t* n_in_live,
                                 void* workspace, size_t workspace_bytes, void* stream) {
-  GLX_REQUIRE(kd > 0 && kh > 0 && kw > 0 && sd > 0 && sh > 0 && sw > 0,
+  return glx_outset_build_dilated(indices_in, N_in, B, D, H, W, in_rank_to_row, kd, kh, kw, sd, sh, sw, pd, ph, pw, 1, 1, 1,
+                                  oD, oH, oW, out_bitmap, out_chunk_flags, out_prefix, n_out, n_in_live, workspace,
+                                  workspace_bytes, stream);
+}
+
+extern "C" int glx_outset_build_dilated(const int32_t* indices_in, int N_in, int B, int D, int H, int W,
+                                        const int32_t* in_rank_to_row, int kd, int kh, int kw, int sd,
+                                        int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw,
+                                        int oD, int oH, int oW, uint64_t* out_bitmap, uint8_t* out_chunk_flags,
+                                        int32_t* out_prefix, int32_t* n_out, const int32_t* n_in_live,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(kd > 0 && kh > 0 && kw > 0 && sd > 0 && sh > 0 && sw > 0 && dd > 0 && dh > 0 && dw > 0,
               "glx_outset_build: bad geometry");
   GLX_REQUIRE(oD > 0 && oH > 0 && oW > 0, "glx_outset_build: empty output grid");
   (void)D; (void)H; (void)W;
@@ -306,9 +359,13 @@ extern "C" int glx_outset_build(const int32_t* indices_in, int N_in, int B, int 
     if (rc != GLX_OK) return rc;
   }
   if (N_in > 0) {
-    ConvGeom cg{kd, kh, kw, sd, sh, sw, pd, ph, pw};
+    ConvGeom cg{kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw};
     auto reach = [](int k, int s) { return (k + s - 1) / s; };
-    if (reach(kd, sd) <= 2 && reach(kh, sh) <= 2 && reach(kw, sw) <= 2) {
+    if (dd != 1 || dh != 1 || dw != 1) {
+      hipLaunchKernelGGL(k_outset_mark_dilated, dim3(glx_divup(N_in, 256)), dim3(256), 0, st,
+                         (const int4*)indices_in, in_rank_to_row, N_in, cg, og,
+                         (unsigned long long*)out_bitmap, out_chunk_flags, n_in_live);
+    } else if (reach(kd, sd) <= 2 && reach(kh, sh) <= 2 && reach(kw, sw) <= 2) {
       hipLaunchKernelGGL(k_outset_mark_agg, dim3(glx_divup(N_in, 256)), dim3(256), 0, st,
                          (const int4*)indices_in, in_rank_to_row, N_in, cg, og,
                          (unsigned long long*)out_bitmap, out_chunk_flags, n_in_live);
@@ -388,11 +445,11 @@ __global__ void k_rules_strided(const int4* __restrict__ oidx, int N_out, int N_
     int r = (int)(t - (long long)j * zy);
     int kz = r / cg.kh, ky = r - kz * cg.kh;
     int4 c = oidx[j];
-    int z = c.y * cg.sd - cg.pd + kz, y = c.z * cg.sh - cg.ph + ky;
+    int z = c.y * cg.sd - cg.pd + kz * cg.dd, y = c.z * cg.sh - cg.ph + ky * cg.dh;
     bool row_ok = (unsigned)z < (unsigned)ig.D && (unsigned)y < (unsigned)ig.H;
     int* dst = nbr + (long long)j * (zy * cg.kw) + (long long)r * cg.kw;
     for (int kx = 0; kx < cg.kw; ++kx) {
-      int x = c.w * cg.sw - cg.pw + kx;
+      int x = c.w * cg.sw - cg.pw + kx * cg.dw;
       int v = -1;
       if (row_ok && (unsigned)x < (unsigned)ig.W) {
         int rk = glx_rank_lookup(ibitmap, iprefix, ig.lin(c.x, z, y, x));
@@ -416,10 +473,20 @@ extern "C" int glx_rules_strided(const int32_t* indices_out, int N_out, int N_in
                                  const int32_t* in_rank_to_row, int kd, int kh, int kw, int sd,
                                  int sh, int sw, int pd, int ph, int pw, int32_t* nbr,
                                  int32_t* pair_count, const int32_t* n_out_live, void* stream) {
+  return glx_rules_strided_dilated(indices_out, N_out, N_in, B, D, H, W, in_bitmap, in_prefix, in_rank_to_row, kd, kh, kw,
+                                   sd, sh, sw, pd, ph, pw, 1, 1, 1, nbr, pair_count, n_out_live, stream);
+}
+
+extern "C" int glx_rules_strided_dilated(const int32_t* indices_out, int N_out, int N_in, int B, int D,
+                                         int H, int W, const uint64_t* in_bitmap, const int32_t* in_prefix,
+                                         const int32_t* in_rank_to_row, int kd, int kh, int kw, int sd,
+                                         int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw, int32_t* nbr,
+                                         int32_t* pair_count, const int32_t* n_out_live, void* stream) {
   if (N_out == 0) return GLX_OK;
   GLX_REQUIRE(indices_out && in_bitmap && in_prefix && nbr, "glx_rules_strided: null pointer");
+  GLX_REQUIRE(dd > 0 && dh > 0 && dw > 0, "glx_rules_strided: dilation must be positive");
   GlxGrid ig{B, D, H, W};
-  ConvGeom cg{kd, kh, kw, sd, sh, sw, pd, ph, pw};
+  ConvGeom cg{kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw};
   long long total = (long long)N_out * kd * kh;
   hipLaunchKernelGGL(k_rules_strided, dim3(glx_divup(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, (const int4*)indices_out, N_out, N_in, ig,

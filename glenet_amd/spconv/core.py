@@ -178,20 +178,20 @@ class RuleSet:
         return self.nbr_in
 
 
-def build_subm_rules(x, ksize):
+def build_subm_rules(x, ksize, dilation=(1, 1, 1)):
     idx = x._ensure_index()
     N = x.indices.shape[0]
     K = ksize[0] * ksize[1] * ksize[2]
     rs = RuleSet()
     rs.subm, rs.K, rs.N_in, rs.N_out = True, K, N, N
     rs.nbr = torch.empty((max(N, 1), K), dtype=torch.int32, device=x.indices.device)
-    call("glx_rules_subm", x.indices, N, *idx.grid, idx.bitmap, idx.prefix, idx.rank_to_row,
-         *ksize, rs.nbr, None, x.count)
+    call("glx_rules_subm_dilated", x.indices, N, *idx.grid, idx.bitmap, idx.prefix, idx.rank_to_row,
+         *ksize, *dilation, rs.nbr, None, x.count)
     rs.count_in = rs.count_out = x.count
     rs.tile_order_out = rs.tile_order_in = idx.rank_to_row
     rs.out_indices, rs.out_spatial_shape, rs.out_index = x.indices, list(x.spatial_shape), idx
     rs.in_index, rs.in_indices, rs.in_spatial_shape = idx, x.indices, list(x.spatial_shape)
-    rs.geom = ("subm", ksize)
+    rs.geom = ("subm", ksize) if tuple(dilation) == (1, 1, 1) else ("subm", ksize, tuple(dilation))
     return rs
 
 
@@ -200,14 +200,13 @@ def build_strided_rules(x, ksize, stride, padding, dilation=(1, 1, 1), out_capac
     safe bound N_in * prod(ceil(k/s)) (clipped to the grid); calibrated capacities
     (StaticFramePipeline.calibrate) keep the launches tight, check_static() tells if one was
     exceeded."""
-    if dilation != (1, 1, 1):
-        raise NotImplementedError("dilation != 1 is not used by the reference backbones")
+    dilation = tuple(int(d) for d in dilation)
     idx = x._ensure_index()
     dev = x.indices.device
     B = x.batch_size
     D, H, W = x.spatial_shape
-    out_shape = [(s + 2 * p - (k - 1) - 1) // st + 1
-                 for s, p, k, st in zip((D, H, W), padding, ksize, stride)]
+    out_shape = [(s + 2 * p - d * (k - 1) - 1) // st + 1
+                 for s, p, k, st, d in zip((D, H, W), padding, ksize, stride, dilation)]
     if min(out_shape) <= 0:
         raise ValueError("SparseConv3d output shape %s is empty" % (out_shape,))
     ogrid = (B, *out_shape)
@@ -216,14 +215,14 @@ def build_strided_rules(x, ksize, stride, padding, dilation=(1, 1, 1), out_capac
     wsb = query("glx_index_workspace_bytes", *ogrid)
     ws = workspace.get(wsb, dev)
     N_in = x.indices.shape[0]
-    call("glx_outset_build", x.indices, N_in, B, D, H, W, idx.rank_to_row, *ksize, *stride, *padding,
+    call("glx_outset_build_dilated", x.indices, N_in, B, D, H, W, idx.rank_to_row, *ksize, *stride, *padding, *dilation,
          *out_shape, obitmap, oflags, oprefix, n_out_dev, x.count, ws, size_arg(ws.numel()))
     static = x.count is not None
     if static:
         cells = B * out_shape[0] * out_shape[1] * out_shape[2]
         reach = 1
-        for k, st in zip(ksize, stride):
-            reach *= -(-k // st)
+        for k, st, d in zip(ksize, stride, dilation):
+            reach *= -(-k // st) if d == 1 else k       # dilated taps land on distinct outputs
         N_out = min(int(out_capacity) if out_capacity else N_in * reach, cells)
     else:
         N_out = int(n_out_dev.item())  # host sync: output row count sizes the next tensors
@@ -236,8 +235,8 @@ def build_strided_rules(x, ksize, stride, padding, dilation=(1, 1, 1), out_capac
         rs.count_in, rs.count_out = x.count, n_out_dev
     if N_out > 0:
         call("glx_outset_emit", obitmap, oflags, oprefix, *ogrid, N_out, rs.out_indices)
-        call("glx_rules_strided", rs.out_indices, N_out, N_in, B, D, H, W, idx.bitmap, idx.prefix,
-             idx.rank_to_row, *ksize, *stride, *padding, rs.nbr, None, rs.count_out)
+        call("glx_rules_strided_dilated", rs.out_indices, N_out, N_in, B, D, H, W, idx.bitmap, idx.prefix,
+             idx.rank_to_row, *ksize, *stride, *padding, *dilation, rs.nbr, None, rs.count_out)
     rs.out_spatial_shape = out_shape
     # rows already sorted: rank == row
     rs.out_index = CellIndex(ogrid, obitmap, oflags, oprefix, None, None, N_out,
@@ -245,7 +244,7 @@ def build_strided_rules(x, ksize, stride, padding, dilation=(1, 1, 1), out_capac
     rs.tile_order_out = None
     rs.tile_order_in = idx.rank_to_row
     rs.in_index, rs.in_indices, rs.in_spatial_shape = idx, x.indices, list(x.spatial_shape)
-    rs.geom = ("spconv", ksize, stride, padding)
+    rs.geom = ("spconv", ksize, stride, padding) if dilation == (1, 1, 1) else ("spconv", ksize, stride, padding, dilation)
     return rs
 
 
@@ -281,7 +280,7 @@ def plan_rules(indices, spatial_shape, batch_size, convs, index=None, count=None
             continue
         rs = x.indice_dict.get(key)
         if rs is None:
-            rs = (build_subm_rules(x, conv.kernel_size) if conv.subm else
+            rs = (build_subm_rules(x, conv.kernel_size, conv.dilation) if conv.subm else
                   build_strided_rules(x, conv.kernel_size, conv.stride, conv.padding, conv.dilation,
                                       out_capacity=capacities.get(key)))
             x.indice_dict[key] = rs
@@ -833,7 +832,7 @@ class SparseConvolution(SparseModule):
                                  % (key, rs.N_in, x.indices.shape[0]))
             return rs
         if self.subm:
-            rs = build_subm_rules(x, self.kernel_size)
+            rs = build_subm_rules(x, self.kernel_size, self.dilation)
         else:
             rs = build_strided_rules(x, self.kernel_size, self.stride, self.padding, self.dilation)
         if key is not None:

@@ -159,6 +159,13 @@ int glx_rules_subm(const int32_t* indices, int N, int B, int D, int H, int W,
                    int kd, int kh, int kw, int32_t* nbr, int32_t* pair_count,
                    const int32_t* n_live, void* stream);
 
+/* ... with dilation (dd, dh, dw): neighbour of offset k at cell + (k - K/2) * d (spconv's SubMConv3d(dilation=...);
+ * glx_rules_subm = dilation 1). */
+int glx_rules_subm_dilated(const int32_t* indices, int N, int B, int D, int H, int W,
+                           const uint64_t* bitmap, const int32_t* prefix, const int32_t* rank_to_row,
+                           int kd, int kh, int kw, int dd, int dh, int dw, int32_t* nbr, int32_t* pair_count,
+                           const int32_t* n_live, void* stream);
+
 /* Strided (regular) sparse conv output set: marks every output cell reached by >=1 active
  * input in out_bitmap, scans it, writes n_out (device int32[1]).  Output rows are
  * enumerated in ascending linear (b,z,y,x) order.  Out grid = (B, oD, oH, oW).
@@ -169,6 +176,13 @@ int glx_outset_build(const int32_t* indices_in, int N_in, int B, int D, int H, i
                      uint8_t* out_chunk_flags, int32_t* out_prefix, int32_t* n_out,
                      const int32_t* n_in_live, void* workspace, size_t workspace_bytes,
                      void* stream);
+/* ... with dilation: output o is reached from input cell c through offset k where o * s - p + k * d == c
+ * (spconv's SparseConv3d(dilation=...); the callers compute oD/oH/oW = (size + 2 p - d (k - 1) - 1) / s + 1). */
+int glx_outset_build_dilated(const int32_t* indices_in, int N_in, int B, int D, int H, int W,
+                             const int32_t* in_rank_to_row, int kd, int kh, int kw, int sd, int sh, int sw,
+                             int pd, int ph, int pw, int dd, int dh, int dw, int oD, int oH, int oW,
+                             uint64_t* out_bitmap, uint8_t* out_chunk_flags, int32_t* out_prefix, int32_t* n_out,
+                             const int32_t* n_in_live, void* workspace, size_t workspace_bytes, void* stream);
 /* Decode the set bits of an index into (n,4) indices [b,z,y,x], ascending order; indices_out
  * has room for `capacity` rows, further cells are dropped (compare n_out with the capacity). */
 int glx_outset_emit(const uint64_t* bitmap, const uint8_t* chunk_flags, const int32_t* prefix,
@@ -181,6 +195,12 @@ int glx_rules_strided(const int32_t* indices_out, int N_out, int N_in, int B, in
                       const int32_t* in_rank_to_row, int kd, int kh, int kw, int sd, int sh,
                       int sw, int pd, int ph, int pw, int32_t* nbr, int32_t* pair_count,
                       const int32_t* n_out_live, void* stream);
+/* ... with dilation: nbr[j*K+k] = input row at cell(j)*stride - pad + k*dilation. */
+int glx_rules_strided_dilated(const int32_t* indices_out, int N_out, int N_in, int B, int D, int H, int W,
+                              const uint64_t* in_bitmap, const int32_t* in_prefix,
+                              const int32_t* in_rank_to_row, int kd, int kh, int kw, int sd, int sh,
+                              int sw, int pd, int ph, int pw, int dd, int dh, int dw, int32_t* nbr,
+                              int32_t* pair_count, const int32_t* n_out_live, void* stream);
 /* Input-major inverse: nbr_in[i*K+k] = output row j with nbr[j*K+k]==i, else -1.
  * n_out_live (device int32, may be NULL): live output rows of a shape-static rule set. */
 int glx_rules_invert(const int32_t* nbr, int N_out, int K, int N_in, int32_t* nbr_in,

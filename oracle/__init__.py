@@ -144,29 +144,29 @@ class Rules:
         return t
 
 
-def build_rules(indices, spatial_shape, ksize, stride=1, padding=0, subm=True):
+def build_rules(indices, spatial_shape, ksize, stride=1, padding=0, subm=True, dilation=1):
     indices = _i32(indices)
-    ksize, stride, padding = _triple(ksize), _triple(stride), _triple(padding)
+    ksize, stride, padding, dilation = _triple(ksize), _triple(stride), _triple(padding), _triple(dilation)
     K = ksize[0] * ksize[1] * ksize[2]
     N_in = len(indices)
     shape = [int(s) for s in spatial_shape]
     if subm:
         out_idx, oshape = indices, shape
     else:
-        oshape = [(s + 2 * p - (k - 1) - 1) // st + 1
-                  for s, p, k, st in zip(shape, padding, ksize, stride)]
+        oshape = [(s + 2 * p - d * (k - 1) - 1) // st + 1
+                  for s, p, k, st, d in zip(shape, padding, ksize, stride, dilation)]
         buf = np.zeros((max(N_in, 1) * K, 4), np.int32)
-        n_out = lib().orc_outset_strided(_i(indices), N_in, _ints(shape), _ints(ksize),
-                                         _ints(stride), _ints(padding), _ints(oshape), _i(buf))
+        n_out = lib().orc_outset_strided_dil(_i(indices), N_in, _ints(shape), _ints(ksize),
+                                             _ints(stride), _ints(padding), _ints(dilation), _ints(oshape), _i(buf))
         out_idx = buf[:n_out].copy()
     N_out = len(out_idx)
     ld = max(N_in, N_out, 1)
     pin = np.zeros((K, ld), np.int32)
     pout = np.zeros((K, ld), np.int32)
     npairs = np.zeros((K,), np.int32)
-    lib().orc_build_rules(_i(indices), N_in, _i(_i32(out_idx)), N_out, _ints(shape), _ints(ksize),
-                          _ints(stride), _ints(padding), 1 if subm else 0, _i(pin), _i(pout),
-                          _i(npairs))
+    lib().orc_build_rules_dil(_i(indices), N_in, _i(_i32(out_idx)), N_out, _ints(shape), _ints(ksize),
+                              _ints(stride), _ints(padding), _ints(dilation), 1 if subm else 0, _i(pin), _i(pout),
+                              _i(npairs))
     return Rules(pin, pout, npairs, out_idx, oshape, N_in)
 
 

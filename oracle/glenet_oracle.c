@@ -147,9 +147,19 @@ static int cmp_i64(const void* a, const void* b) {
  * (spconv getIndicePairs / get_indice_pairs, called for spconv_backbone.py:90,97,104,113).
  * spconv leaves the output ORDER implementation-defined; this build defines it as
  * ascending linear (b, z, y, x).  out_indices must hold N_in*K rows; returns N_out. */
+ORC_API int orc_outset_strided_dil(const int32_t* in_idx, int N_in, const int* shape /*D,H,W*/,
+                                   const int* ksize, const int* stride, const int* pad, const int* dil,
+                                   const int* oshape, int32_t* out_indices);
 ORC_API int orc_outset_strided(const int32_t* in_idx, int N_in, const int* shape /*D,H,W*/,
                                const int* ksize, const int* stride, const int* pad,
                                const int* oshape, int32_t* out_indices) {
+  const int one[3] = {1, 1, 1};
+  return orc_outset_strided_dil(in_idx, N_in, shape, ksize, stride, pad, one, oshape, out_indices);
+}
+/* ... with dilation (spconv SparseConv3d(dilation=...)): output o is reached through offset k when o * s - p + k * d == c */
+ORC_API int orc_outset_strided_dil(const int32_t* in_idx, int N_in, const int* shape /*D,H,W*/,
+                                   const int* ksize, const int* stride, const int* pad, const int* dil,
+                                   const int* oshape, int32_t* out_indices) {
   int K = ksize[0] * ksize[1] * ksize[2];
   int64_t* cand = (int64_t*)malloc((size_t)(N_in > 0 ? N_in : 1) * K * sizeof(int64_t));
   size_t nc = 0;
@@ -159,7 +169,7 @@ ORC_API int orc_outset_strided(const int32_t* in_idx, int N_in, const int* shape
     for (int kz = 0; kz < ksize[0]; ++kz)
       for (int ky = 0; ky < ksize[1]; ++ky)
         for (int kx = 0; kx < ksize[2]; ++kx) {
-          int n[3] = {c[1] + pad[0] - kz, c[2] + pad[1] - ky, c[3] + pad[2] - kx};
+          int n[3] = {c[1] + pad[0] - kz * dil[0], c[2] + pad[1] - ky * dil[1], c[3] + pad[2] - kx * dil[2]};
           int ok = 1, o[3];
           for (int d = 0; d < 3; ++d) {
             if (n[d] < 0 || n[d] % stride[d]) { ok = 0; break; }
@@ -191,10 +201,21 @@ ORC_API int orc_outset_strided(const int32_t* in_idx, int N_in, const int* shape
  * subm != 0: output set == input set, neighbour = cell + (k - ksize/2)   (SubMConv3d)
  * subm == 0: input cell = out*stride - pad + k                           (SparseConv3d)
  * Cross-correlation convention, identical to torch.nn.functional.conv3d. */
+ORC_API int orc_build_rules_dil(const int32_t* in_idx, int N_in, const int32_t* out_idx, int N_out,
+                                const int* shape, const int* ksize, const int* stride,
+                                const int* pad, const int* dil, int subm, int32_t* pairs_in, int32_t* pairs_out,
+                                int32_t* n_pairs);
 ORC_API int orc_build_rules(const int32_t* in_idx, int N_in, const int32_t* out_idx, int N_out,
                             const int* shape, const int* ksize, const int* stride,
                             const int* pad, int subm, int32_t* pairs_in, int32_t* pairs_out,
                             int32_t* n_pairs) {
+  const int one[3] = {1, 1, 1};
+  return orc_build_rules_dil(in_idx, N_in, out_idx, N_out, shape, ksize, stride, pad, one, subm, pairs_in, pairs_out, n_pairs);
+}
+ORC_API int orc_build_rules_dil(const int32_t* in_idx, int N_in, const int32_t* out_idx, int N_out,
+                                const int* shape, const int* ksize, const int* stride,
+                                const int* pad, const int* dil, int subm, int32_t* pairs_in, int32_t* pairs_out,
+                                int32_t* n_pairs) {
   int K = ksize[0] * ksize[1] * ksize[2];
   int D = shape[0], H = shape[1], W = shape[2];
   size_t ld = (size_t)(N_in > N_out ? N_in : N_out);
@@ -214,11 +235,12 @@ ORC_API int orc_build_rules(const int32_t* in_idx, int N_in, const int32_t* out_
         for (int kx = 0; kx < ksize[2]; ++kx, ++k) {
           int z, y, x;
           if (subm) {
-            z = o[1] + kz - ksize[0] / 2; y = o[2] + ky - ksize[1] / 2; x = o[3] + kx - ksize[2] / 2;
+            z = o[1] + (kz - ksize[0] / 2) * dil[0]; y = o[2] + (ky - ksize[1] / 2) * dil[1];
+            x = o[3] + (kx - ksize[2] / 2) * dil[2];
           } else {
-            z = o[1] * stride[0] - pad[0] + kz;
-            y = o[2] * stride[1] - pad[1] + ky;
-            x = o[3] * stride[2] - pad[2] + kx;
+            z = o[1] * stride[0] - pad[0] + kz * dil[0];
+            y = o[2] * stride[1] - pad[1] + ky * dil[1];
+            x = o[3] * stride[2] - pad[2] + kx * dil[2];
           }
           if (z < 0 || z >= D || y < 0 || y >= H || x < 0 || x >= W) continue;
           int i = map_get(&m, lin4(o[0], z, y, x, D, H, W));

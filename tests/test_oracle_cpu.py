@@ -149,26 +149,30 @@ def test_sparse_conv_oracle_vs_dense_conv3d():
     dense = torch.zeros(B, cin, D, H, W)
     ti = torch.from_numpy(idx).long()
     dense[ti[:, 0], :, ti[:, 1], ti[:, 2], ti[:, 3]] = torch.from_numpy(f)
-    for ks, st, pd, subm in [((3, 3, 3), 1, 1, True), ((3, 3, 3), 2, 1, False), ((3, 3, 3), 2, (0, 1, 1), False),
-                             ((3, 1, 1), (2, 1, 1), 0, False)]:
+    # (kernel, stride, padding, submanifold, dilation): the reference backbones' geometries, then dilated ones (spconv's
+    # SubMConv3d / SparseConv3d take a dilation; no GLENet config sets it) -- a submanifold conv with dilation d is the dense
+    # conv with padding d * (k // 2) read at the active cells
+    for ks, st, pd, subm, dl in [((3, 3, 3), 1, 1, True, 1), ((3, 3, 3), 2, 1, False, 1), ((3, 3, 3), 2, (0, 1, 1), False, 1),
+                                 ((3, 1, 1), (2, 1, 1), 0, False, 1), ((3, 3, 3), 1, 2, True, 2), ((3, 3, 3), 1, (1, 2, 3), True, (1, 2, 3)),
+                                 ((3, 3, 3), 2, 1, False, 2), ((3, 3, 3), 1, (2, 1, 2), False, (2, 1, 2)), ((3, 1, 3), (1, 1, 2), 1, False, (1, 1, 3))]:
         K = ks[0] * ks[1] * ks[2]
         w = rng.normal(size=(K, cin, cout)).astype(np.float32)
-        r = oracle.build_rules(idx, [D, H, W], ks, st, pd, subm=subm)
+        r = oracle.build_rules(idx, [D, H, W], ks, st, 0 if subm else pd, subm=subm, dilation=dl)
         out = oracle.sconv_forward(f, w, r)
         wt = torch.from_numpy(w).reshape(*ks, cin, cout).permute(4, 3, 0, 1, 2)
-        ref = torch.nn.functional.conv3d(dense, wt, stride=st, padding=pd)
+        ref = torch.nn.functional.conv3d(dense, wt, stride=st, padding=pd, dilation=dl)
         oi = torch.from_numpy(np.asarray(r.out_indices)).long()
         np.testing.assert_allclose(out, ref[oi[:, 0], :, oi[:, 1], oi[:, 2], oi[:, 3]].numpy(), atol=1e-4)
         if not subm:
             occd = torch.nn.functional.conv3d((dense.abs().sum(1, keepdim=True) > 0).float(),
-                                              torch.ones(1, 1, *ks), stride=st, padding=pd) > 0
+                                              torch.ones(1, 1, *ks), stride=st, padding=pd, dilation=dl) > 0
             assert np.array_equal(torch.nonzero(occd[:, 0]).numpy(), r.out_indices)
         # backward against autograd of the dense formulation
         g = rng.normal(size=out.shape).astype(np.float32)
         din, dw = oracle.sconv_backward(f, w, g, r)
         d2 = dense.clone().requires_grad_(True)
         w2 = wt.clone().requires_grad_(True)
-        o2 = torch.nn.functional.conv3d(d2, w2, stride=st, padding=pd)
+        o2 = torch.nn.functional.conv3d(d2, w2, stride=st, padding=pd, dilation=dl)
         o2[oi[:, 0], :, oi[:, 1], oi[:, 2], oi[:, 3]].backward(torch.from_numpy(g))
         np.testing.assert_allclose(din, d2.grad[ti[:, 0], :, ti[:, 1], ti[:, 2], ti[:, 3]].numpy(), atol=1e-4)
         np.testing.assert_allclose(dw, w2.grad.permute(2, 3, 4, 1, 0).reshape(K, cin, cout).numpy(), atol=1e-3)

@@ -127,6 +127,49 @@ def test_strided_rules_bit_exact(dev, ks, st, pd):
     assert (inv >= 0).sum() == ref.R
 
 
+@pytest.mark.parametrize("subm,ks,st,pd,dl", [(True, (3, 3, 3), (1, 1, 1), (0, 0, 0), (2, 2, 2)), (True, (3, 3, 3), (1, 1, 1), (0, 0, 0), (1, 2, 3)),
+                                              (False, (3, 3, 3), (2, 2, 2), (1, 1, 1), (2, 2, 2)),
+                                              (False, (3, 3, 3), (1, 1, 1), (2, 1, 2), (2, 1, 2)),
+                                              (False, (3, 1, 3), (1, 1, 2), (1, 1, 1), (1, 1, 3))])
+def test_dilated_convolutions_match_the_oracle(dev, subm, ks, st, pd, dl):
+    """spconv's SubMConv3d / SparseConv3d take a dilation (no GLENet config sets it; the spconv surface SURVEY 8b lists does):
+    rule tables, output sets and the inverse table bit-exact against the oracle (itself checked against torch's dilated dense
+    conv3d, tests/test_oracle_cpu.py), forward values and both gradients through the modules."""
+    rng = np.random.default_rng(4)
+    shape = (11, 30, 27)
+    cin, cout = 16, 32
+    idx, f = _rand_sparse(rng, 2, *shape, 0.06, cin)
+    ref = oracle.build_rules(idx, shape, ks, st, pd, subm=subm, dilation=dl)
+    x = _gpu_tensor(idx, f, shape, 2, dev)
+    rs = sp.build_subm_rules(x, ks, dl) if subm else sp.build_strided_rules(x, ks, st, pd, dl)
+    assert list(rs.out_spatial_shape) == list(ref.out_shape)
+    assert np.array_equal(rs.out_indices.cpu().numpy(), ref.out_indices)
+    assert np.array_equal(rs.nbr.cpu().numpy(), ref.nbr_table())
+    assert rs.pair_count == ref.R and ref.R > 0
+    if not subm:
+        inv = rs.inverse_table().cpu().numpy()
+        nbr = ref.nbr_table()
+        jj, kk = np.nonzero(nbr >= 0)
+        assert np.array_equal(inv[nbr[jj, kk], kk], jj) and (inv >= 0).sum() == ref.R
+    K = ks[0] * ks[1] * ks[2]
+    w = (rng.normal(size=(K, cin, cout)) / np.sqrt(K * cin)).astype(np.float32)
+    g = rng.normal(size=(len(ref.out_indices), cout)).astype(np.float32)
+    want = oracle.sconv_forward(f, w, ref)
+    din, dw = oracle.sconv_backward(f, w, g, ref)
+    conv = (sp.SubMConv3d(cin, cout, ks, dilation=dl, bias=False) if subm else
+            sp.SparseConv3d(cin, cout, ks, stride=st, padding=pd, dilation=dl, bias=False)).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(w).reshape(*ks, cin, cout))
+    xt = _gpu_tensor(idx, f, shape, 2, dev)
+    xt.features.requires_grad_(True)
+    y = conv(xt)
+    assert np.array_equal(y.indices.cpu().numpy(), ref.out_indices)
+    np.testing.assert_allclose(y.features.detach().cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    y.features.backward(torch.from_numpy(g).to(dev))
+    np.testing.assert_allclose(xt.features.grad.cpu().numpy(), din, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(conv.weight.grad.reshape(K, cin, cout).cpu().numpy(), dw, rtol=1e-3, atol=2e-3)
+
+
 def test_index_rejects_duplicates_and_out_of_range(dev):
     idx = np.array([[0, 1, 1, 1], [0, 1, 1, 1]], np.int32)
     x = _gpu_tensor(idx, np.zeros((2, 4), np.float32), (4, 4, 4), 1, dev)
