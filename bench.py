@@ -418,8 +418,8 @@ def bench_dropin(state, K, pool, dev, steps=12):
     seed = torch.tensor(ROI_SEED_OFFSET, dtype=torch.float32, device=dev)
 
     def run(layout, gemm=True, vary_only=0):
-        """gemm: glenet_amd.dropin.pointwise_as_gemm() in effect (1 x 1 Conv1d / Conv2d as matrix products: no per-voxel-count
-        preparation of a convolution in the vendor library); vary_only = n: only n new-shape steps."""
+        """gemm: glenet_amd.dropin.pointwise_as_gemm() in effect (1 x 1 Conv1d / Conv2d as matrix products, training BatchNorm of
+        stacked tensors on the channel-major kernels: nothing prepared per voxel count); vary_only = n: only n new-shape steps."""
         with (dropin.reference_layout() if layout else contextlib.nullcontext()):
             if gemm:
                 dropin.pointwise_as_gemm()
@@ -475,8 +475,8 @@ def bench_dropin(state, K, pool, dev, steps=12):
                      "BatchNorm layers of the RoI-grid pooling, and the vendor library selects (and on first sight builds) "
                      "a kernel per problem size, every step: *_without_pointwise_as_gemm (3 steps).  dropin_step* are "
                      "measured with glenet_amd.dropin.pointwise_as_gemm() in effect (round 5): those 1x1 layers as matrix "
-                     "products -- no convolution to prepare per voxel count (the vendor BatchNorm's per-size preparation, "
-                     "~11 ms, stays: both replacements measured cost more in every step)")
+                     "products and their training BatchNorms on the channel-major kernels (glx_bn_cm_*) -- nothing is "
+                     "prepared per voxel count")
 
 
 def bench_config3(dev, objects=4096, points=512, samples=30):

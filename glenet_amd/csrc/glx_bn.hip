@@ -732,3 +732,167 @@ extern "C" int glx_bn_backward_apply(const float* x, const float* dz, const floa
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
+
+// ================================================================================================ channel-major form
+// Training-mode BatchNorm of a tensor in the reference's STACKED convention: batch dimension 1, channels next, the rows
+// along the rest -- (1, C, M) and (1, C, M, nsample), what pcdet/ops/pointnet2/pointnet2_stack/voxel_pool_modules.py:70-130
+// feeds its BatchNorm1d / BatchNorm2d layers.  M is the number of active voxels / grid points of the batch, a new value every
+// training step, and the vendor library prepares (on first sight: builds) a BatchNorm kernel per problem size: 0.45 s per new
+// voxel count measured in a fresh process.  A channel's values are contiguous here (x is (C, L) row-major), so the reductions
+// are plain coalesced sums: per (channel, chunk) fp64 partials, every block of the transform re-adds its channel's <= 64
+// partials (fixed order: bitwise reproducible), two launches per direction, nothing depends on L but the grid.
+#define BNCM_THREADS 256
+#define BNCM_CHUNKS 64                   // partials per channel at most
+
+__device__ __forceinline__ double bncm_block_sum(double v, double* s_red) {      // all threads get the block's sum
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  __syncthreads();
+  if (lane == 0) s_red[wave] = v;
+  __syncthreads();
+  return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// part[(c * chunks + k) * 2 ..]: BWD = false: sum x, sum x^2 of chunk k of channel c; BWD = true: sum dy, sum dy * xhat
+template <bool BWD>
+__global__ __launch_bounds__(BNCM_THREADS) void k_bncm_partial(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               long long L, int chunks, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, double* __restrict__ part) {
+  __shared__ double s_red[4];
+  const int c = blockIdx.y, k = blockIdx.x;
+  const long long per = (L + chunks - 1) / chunks, lo = (long long)k * per, hi = min(L, lo + per);
+  const float* xr = x + (long long)c * L;
+  const float* gr = BWD ? dy + (long long)c * L : nullptr;
+  const float mu = BWD ? mean[c] : 0.f, is = BWD ? invstd[c] : 0.f;
+  double a = 0.0, b = 0.0;
+  for (long long i = lo + threadIdx.x; i < hi; i += BNCM_THREADS) {
+    const float v = xr[i];
+    if (BWD) {
+      const float g = gr[i];
+      a += (double)g;
+      b += (double)(g * ((v - mu) * is));
+    } else {
+      a += (double)v;
+      b += (double)v * (double)v;
+    }
+  }
+  a = bncm_block_sum(a, s_red);
+  b = bncm_block_sum(b, s_red);
+  if (threadIdx.x == 0) {
+    part[((long long)c * chunks + k) * 2] = a;
+    part[((long long)c * chunks + k) * 2 + 1] = b;
+  }
+}
+
+__global__ __launch_bounds__(BNCM_THREADS) void k_bncm_forward(const float* __restrict__ x, long long L, int chunks,
+                                                               const double* __restrict__ part, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, float momentum,
+                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                               float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                               float* __restrict__ y) {
+  __shared__ float s_coef[2];
+  const int c = blockIdx.y;
+  if (threadIdx.x == 0) {
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < chunks; ++k) { s += part[((long long)c * chunks + k) * 2]; q += part[((long long)c * chunks + k) * 2 + 1]; }
+    const double mean = s / (double)L;
+    double var = q / (double)L - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    s_coef[0] = g * is;
+    s_coef[1] = bt - (float)mean * g * is;
+    if (blockIdx.x == 0) {
+      save_mean[c] = (float)mean;
+      save_invstd[c] = is;
+      if (running_mean) {        // nn.BatchNorm: running_var takes the UNBIASED batch variance
+        const double unb = L > 1 ? var * (double)L / (double)(L - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+      }
+    }
+  }
+  __syncthreads();
+  const float sc = s_coef[0], sh = s_coef[1];
+  const float* xr = x + (long long)c * L;
+  float* yr = y + (long long)c * L;
+  const long long stride = (long long)gridDim.x * BNCM_THREADS;
+  for (long long i = (long long)blockIdx.x * BNCM_THREADS + threadIdx.x; i < L; i += stride) yr[i] = __fmaf_rn(xr[i], sc, sh);
+}
+
+__global__ __launch_bounds__(BNCM_THREADS) void k_bncm_backward(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                long long L, int chunks, const double* __restrict__ part,
+                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, float* __restrict__ dx,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float s_coef[4];
+  const int c = blockIdx.y;
+  if (threadIdx.x == 0) {
+    double s = 0.0, q = 0.0;     // sum dy, sum dy * xhat
+    for (int k = 0; k < chunks; ++k) { s += part[((long long)c * chunks + k) * 2]; q += part[((long long)c * chunks + k) * 2 + 1]; }
+    const float g = gamma ? gamma[c] : 1.f;
+    s_coef[0] = g * invstd[c];                       // a
+    s_coef[1] = (float)(s / (double)L);              // b = dbeta / n
+    s_coef[2] = (float)(q / (double)L);              // c = dgamma / n
+    if (blockIdx.x == 0) {
+      if (dgamma) dgamma[c] = (float)q;
+      if (dbeta) dbeta[c] = (float)s;
+    }
+  }
+  __syncthreads();
+  const float a = s_coef[0], b = s_coef[1], cc = s_coef[2], mu = mean[c], is = invstd[c];
+  const float* xr = x + (long long)c * L;
+  const float* gr = dy + (long long)c * L;
+  float* dr = dx + (long long)c * L;
+  const long long stride = (long long)gridDim.x * BNCM_THREADS;
+  for (long long i = (long long)blockIdx.x * BNCM_THREADS + threadIdx.x; i < L; i += stride)
+    dr[i] = a * (gr[i] - b - cc * ((xr[i] - mu) * is));
+}
+
+static int bncm_chunks(long long L) {
+  long long k = (L + 8191) / 8192;
+  return (int)(k < 1 ? 1 : k > BNCM_CHUNKS ? BNCM_CHUNKS : k);
+}
+static int bncm_apply_blocks(long long L, int C) {      // ~2048 blocks over all channels, >= 1 per channel
+  long long per = (L + 4 * BNCM_THREADS - 1) / (4 * BNCM_THREADS), cap = 2048 / (C > 0 ? C : 1);
+  if (cap < 1) cap = 1;
+  return (int)(per < 1 ? 1 : per > cap ? cap : per);
+}
+
+extern "C" size_t glx_bn_cm_workspace_bytes(int C) { return glx_align((size_t)(C > 0 ? C : 1) * BNCM_CHUNKS * 2 * sizeof(double)); }
+
+extern "C" int glx_bn_cm_train_forward(const float* x, int C, long long L, const float* gamma, const float* beta, float eps,
+                                       float momentum, float* running_mean, float* running_var, float* y, float* save_mean,
+                                       float* save_invstd, void* workspace, size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(C > 0 && L > 0, "glx_bn_cm_train_forward: empty tensor (C = %d, L = %lld)", C, L);
+  GLX_REQUIRE(x && y && save_mean && save_invstd && workspace, "glx_bn_cm_train_forward: null pointer");
+  GLX_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "glx_bn_cm_train_forward: running statistics: both or none");
+  GLX_REQUIRE(workspace_bytes >= glx_bn_cm_workspace_bytes(C), "glx_bn_cm_train_forward: workspace too small");
+  GLX_REQUIRE(C <= 65535, "glx_bn_cm_train_forward: C = %d", C);
+  hipStream_t st = (hipStream_t)stream;
+  const int chunks = bncm_chunks(L);
+  hipLaunchKernelGGL((k_bncm_partial<false>), dim3(chunks, C), dim3(BNCM_THREADS), 0, st, x, (const float*)nullptr, L, chunks,
+                     (const float*)nullptr, (const float*)nullptr, (double*)workspace);
+  hipLaunchKernelGGL(k_bncm_forward, dim3(bncm_apply_blocks(L, C), C), dim3(BNCM_THREADS), 0, st, x, L, chunks,
+                     (const double*)workspace, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, y);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+extern "C" int glx_bn_cm_backward(const float* x, const float* dy, int C, long long L, const float* gamma, const float* save_mean,
+                                  const float* save_invstd, float* dx, float* dgamma, float* dbeta, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(C > 0 && L > 0, "glx_bn_cm_backward: empty tensor (C = %d, L = %lld)", C, L);
+  GLX_REQUIRE(x && dy && dx && save_mean && save_invstd && workspace, "glx_bn_cm_backward: null pointer");
+  GLX_REQUIRE(workspace_bytes >= glx_bn_cm_workspace_bytes(C), "glx_bn_cm_backward: workspace too small");
+  GLX_REQUIRE(C <= 65535, "glx_bn_cm_backward: C = %d", C);
+  hipStream_t st = (hipStream_t)stream;
+  const int chunks = bncm_chunks(L);
+  hipLaunchKernelGGL((k_bncm_partial<true>), dim3(chunks, C), dim3(BNCM_THREADS), 0, st, x, dy, L, chunks, save_mean, save_invstd,
+                     (double*)workspace);
+  hipLaunchKernelGGL(k_bncm_backward, dim3(bncm_apply_blocks(L, C), C), dim3(BNCM_THREADS), 0, st, x, dy, L, chunks,
+                     (const double*)workspace, gamma, save_mean, save_invstd, dx, dgamma, dbeta);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

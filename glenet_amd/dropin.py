@@ -196,7 +196,9 @@ def pointwise_as_gemm(enable=True):
     `mlps_in` / `mlps_pos` / `mlps_out`), a new value every training step -- and MIOpen prepares a convolution per problem
     size (measured: 1.04 s per step with a new voxel count against 33 ms with a repeated one); a matrix product has no
     per-shape preparation.  Same arithmetic (fp32 dot products over Cin, bias added afterwards), autograd through torch's
-    matmul.  Everything else -- other kernel sizes, CPU tensors -- takes the original forward.
+    matmul.  Everything else -- other kernel sizes, CPU tensors -- takes the original forward.  BatchNorm1d / BatchNorm2d in
+    training mode on such stacked tensors run on this package's channel-major kernels (glx_bn_cm_*: the vendor's BatchNorm
+    builds a kernel per problem size as well); eval mode, image batches and (rows, C) inputs keep the original forward.
     Returns the list of patched classes; pointwise_as_gemm(False) restores the originals."""
     import torch
     import torch.nn.functional as F
@@ -229,10 +231,21 @@ def pointwise_as_gemm(enable=True):
         if cls not in _POINTWISE:
             _POINTWISE[cls] = cls.forward
             cls.forward = make(cls.forward)
-    # BatchNorm1d / BatchNorm2d on the same stacked tensors stay on the vendor kernels: they, too, prepare per problem size
-    # (4 ms forward + 9 ms backward per new voxel count), but both replacements measured in round 5 cost more than that in
-    # EVERY step on the 200 MB batch-1 tensors of the pooling -- torch's native batch_norm kernel 43 ms per step, var_mean +
-    # addcmul tensor statements 47 ms, against 35 ms (repeated shape) / 46 ms (new shape) with the vendor's.
+    def make_bn(orig):
+        # The vendor's BatchNorm prepares per problem size too -- and on first sight BUILDS a kernel: 0.45 s per new voxel count
+        # in a fresh process (round 5's bench: 508 ms per step with only the convolutions patched).  Stacked tensors (batch
+        # dimension 1) in training mode take the channel-major kernels of this package (spconv.core.StackedBN); torch's native
+        # batch_norm kernel (43 ms per step) and tensor statements (47 ms) were measured and are slower on these 200 MB tensors.
+        def forward(self, x):
+            from .spconv import core
+            y = core.stacked_train_bn(self, x) if isinstance(x, torch.Tensor) else None
+            return orig(self, x) if y is None else y
+        return forward
+
+    for cls in (nn.BatchNorm1d, nn.BatchNorm2d):
+        if cls not in _POINTWISE:
+            _POINTWISE[cls] = cls.forward
+            cls.forward = make_bn(cls.forward)
     return list(_POINTWISE)
 
 

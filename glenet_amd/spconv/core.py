@@ -1027,6 +1027,59 @@ class FusedBNApply(Function):
         return dx, None, None, None, dgamma, dbeta, None, None, None
 
 
+class StackedBN(Function):
+    """Training-mode BatchNorm of a STACKED tensor -- batch dimension 1, channels next: (1, C, M) / (1, C, M, nsample), the inputs
+    of the BatchNorm1d / BatchNorm2d layers in voxel_pool_modules.py:70-130 -- on the channel-major kernels
+    (glx_bn_cm_train_forward / _backward, csrc/glx_bn.hip): two launches per direction, nothing prepared per length."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        x = x.contiguous().float()
+        c = x.shape[1]
+        length = x.numel() // c
+        y = torch.empty_like(x)
+        mean = torch.empty(c, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+        ws = workspace.get(query("glx_bn_cm_workspace_bytes", c), x.device)
+        call("glx_bn_cm_train_forward", x, c, ctypes.c_longlong(length), weight, bias, ctypes_float(eps), ctypes_float(momentum),
+             running_mean, running_var, y, mean, invstd, ws, size_arg(ws.numel()))
+        if running_mean is not None:
+            _lib.bump_weights_epoch((running_mean, running_var))
+        ctx.save_for_backward(x, weight, mean, invstd)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, mean, invstd = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        c = x.shape[1]
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device) if weight is not None else None
+        dbeta = torch.empty(c, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        ws = workspace.get(query("glx_bn_cm_workspace_bytes", c), x.device)
+        call("glx_bn_cm_backward", x, dy, c, ctypes.c_longlong(x.numel() // c), weight, mean, invstd, dx, dgamma, dbeta, ws,
+             size_arg(ws.numel()))
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+def stacked_train_bn(bn, x):
+    """nn.BatchNorm1d / BatchNorm2d `bn` in training mode on a stacked (1, C, ...) device tensor; None when the module or the
+    tensor is not what StackedBN covers (the caller then runs the module's own forward)."""
+    if not (bn.training and x.is_cuda and x.dim() >= 3 and x.shape[0] == 1 and x.dtype == torch.float32
+            and x.shape[1] == bn.num_features and x.numel() > 0
+            and (bn.momentum is not None or not bn.track_running_stats) and (bn.weight is None) == (bn.bias is None)):
+        return None
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats and bn.running_mean is not None else (None, None)
+    y = StackedBN.apply(x, bn.weight, bn.bias, rm, rv, float(bn.momentum if bn.momentum is not None else 0.0), float(bn.eps))
+    if rm is not None and bn.num_batches_tracked is not None:
+        if DEFERRED_COUNTERS is not None:
+            DEFERRED_COUNTERS.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked += 1
+    return y
+
+
 def conv_bn_fusable(conv, bn, x):
     """A sparse conv whose training-mode BatchNorm statistics can ride in its epilogue (csrc/glx_sconv.hip
     sc_epilogue): MFMA tile kernel in one launch, channel counts the fused BatchNorm kernels cover."""

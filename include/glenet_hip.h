@@ -732,6 +732,19 @@ int glx_predicted_boxes(const float* box_preds, const float* dir_preds, const fl
  *   concatenation of several normalised maps along the channels (BaseBEVBackbone's `torch.cat(ups, dim=1)`,
  *   base_bev_backbone.py:100-104, on channels-last maps) then costs no copy in either direction.
  * ------------------------------------------------------------------------------------ */
+/* Channel-major form (round 5): training-mode BatchNorm of a tensor in the reference's STACKED convention -- batch dimension 1,
+ * x = (C, L) row-major, L = rows x nsample -- i.e. the (1, C, M) / (1, C, M, nsample) inputs of the BatchNorm1d / BatchNorm2d
+ * layers in pcdet/ops/pointnet2/pointnet2_stack/voxel_pool_modules.py:70-130 (torch.nn.BatchNorm semantics: biased variance to
+ * normalise, running_var updated with the unbiased one and `momentum`; gamma / beta may be NULL = 1 / 0).  Nothing is
+ * prepared per L: the vendor library builds a kernel per problem size, 0.45 s per new voxel count.  workspace =
+ * glx_bn_cm_workspace_bytes(C).  Backward: dx, and dgamma / dbeta where not NULL. */
+size_t glx_bn_cm_workspace_bytes(int C);
+int glx_bn_cm_train_forward(const float* x, int C, long long L, const float* gamma, const float* beta, float eps, float momentum,
+                            float* running_mean, float* running_var, float* y, float* save_mean, float* save_invstd,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int glx_bn_cm_backward(const float* x, const float* dy, int C, long long L, const float* gamma, const float* save_mean,
+                       const float* save_invstd, float* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                       void* stream);
 size_t glx_bn_workspace_bytes(int C);
 size_t glx_bn_state_bytes(void);
 int glx_bn_relu_train_forward(const float* x, int N, int C, const float* gamma, const float* beta,

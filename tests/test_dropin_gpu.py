@@ -138,15 +138,16 @@ def test_accelerate_reclasses_reference_layout_modules_and_keeps_results(dev):
 
 
 def test_pointwise_as_gemm_equals_the_vendor_layers_and_is_undone(dev):
-    """dropin.pointwise_as_gemm(): 1 x 1 Conv1d / Conv2d modules as matrix products (no per-voxel-count preparation in the
-    vendor library: voxel_pool_modules.py:70-130 feeds them (1, C, M) and (1, C, M, nsample) tensors whose M changes every
-    step) -- outputs, input gradients and parameter gradients equal the native kernels'; 3-tap layers keep the original
+    """dropin.pointwise_as_gemm(): 1 x 1 Conv1d / Conv2d modules as matrix products and training-mode BatchNorm1d / 2d of
+    stacked tensors on the channel-major kernels (no per-voxel-count preparation in the vendor library:
+    voxel_pool_modules.py:70-130 feeds them (1, C, M) and (1, C, M, nsample) tensors whose M changes every step) -- outputs,
+    input gradients, parameter gradients and running statistics equal the native kernels'; 3-tap layers keep the original
     forward; the switch is undone."""
     import time
     torch.manual_seed(0)
     conv_f = nn.Conv1d.forward
     c1 = nn.Sequential(nn.Conv1d(16, 32, 1, bias=False), nn.BatchNorm1d(32), nn.ReLU()).to(dev).train()
-    c2 = nn.Sequential(nn.Conv2d(3, 16, 1, bias=True), nn.BatchNorm2d(16)).to(dev).train()
+    c2 = nn.Sequential(nn.Conv2d(3, 16, 1, bias=False), nn.BatchNorm2d(16)).to(dev).train()   # (a bias in front of a BatchNorm has a zero gradient: noise on both sides)
     c3 = nn.Conv1d(16, 8, 3, padding=1).to(dev)
     rows = torch.randn(5003, 16, device=dev)
     x1 = rows.t().unsqueeze(0)                                   # the reference's (1, C, M) view of row-major features: strided
@@ -161,7 +162,9 @@ def test_pointwise_as_gemm_equals_the_vendor_layers_and_is_undone(dev):
             xi = x.detach().clone().requires_grad_(True)
             mod.zero_grad(set_to_none=True)
             y = mod(xi)
-            (y * y).sum().backward()
+            # a fixed random cotangent ((y * y).sum() behind a BatchNorm is all cancellation: its input gradient is noise)
+            gen = torch.Generator(device=dev).manual_seed(7)
+            y.backward(torch.randn(y.shape, device=dev, generator=gen))
             out.append([y.detach().clone(), xi.grad.clone()] + [p.grad.clone() for p in mod.parameters()]
                        + [b.clone() for b in mod.buffers() if b.dtype.is_floating_point])
         return out
@@ -175,14 +178,14 @@ def test_pointwise_as_gemm_equals_the_vendor_layers_and_is_undone(dev):
             got = run()
         finally:
             dropin.pointwise_as_gemm(False)
-    assert set(dropin.pointwise_as_gemm()) == {nn.Conv1d, nn.Conv2d}
+    assert set(dropin.pointwise_as_gemm()) == {nn.Conv1d, nn.Conv2d, nn.BatchNorm1d, nn.BatchNorm2d}
     try:
         # a length the library has never seen costs nothing to prepare (the vendor path: ~0.3 s per new problem size)
         xs = [torch.randn(1, 16, 4001 + 13 * i, device=dev) for i in range(5)]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for x in xs:
-            c1[0](x)
+            c1(x)                    # convolution AND training BatchNorm: nothing is prepared per length
         torch.cuda.synchronize()
         assert time.perf_counter() - t0 < 0.25
     finally:

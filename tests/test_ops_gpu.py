@@ -932,3 +932,59 @@ def test_nms_early_termination_gives_the_full_sweeps_prefix(dev):
         assert cut_n[f] >= m and np.array_equal(cut_k[f, :m], np.asarray(want[:m])), f
     # the three frames are the three cases
     assert full_k[0, cap - 1] < 2048 and full_n[1] < cap and full_k[2, cap - 1] >= 2048
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 5003), (1, 16, 777, 16), (1, 64, 1), (1, 7, 70001)])
+def test_channel_major_batchnorm_matches_fp64(dev, shape):
+    """glx_bn_cm_train_forward / _backward (spconv.core.StackedBN): training-mode BatchNorm of a stacked (1, C, ...) tensor
+    (the BatchNorm1d / 2d inputs of voxel_pool_modules.py:70-130) against an fp64 evaluation of torch.nn.BatchNorm: output,
+    input gradient, gamma / beta gradients, running statistics (unbiased variance), num_batches_tracked; twice in a row
+    (bitwise reproducible: fixed summation order)."""
+    import torch
+    from torch import nn
+    from glenet_amd.spconv import core
+    torch.manual_seed(sum(shape))
+    c = shape[1]
+    cls = nn.BatchNorm1d if len(shape) == 3 else nn.BatchNorm2d
+    bn = cls(c, eps=1e-3, momentum=0.01).to(dev).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+    ref = cls(c, eps=1e-3, momentum=0.01).double().train()
+    ref.load_state_dict({k: v.double().cpu() if v.dtype.is_floating_point else v.cpu() for k, v in bn.state_dict().items()})
+    x = torch.randn(*shape, device=dev) * 2.0 + 0.7
+    g = torch.randn(*shape, device=dev)
+    xd = x.double().cpu().requires_grad_(True)
+    if x.numel() // c > 1:
+        ref(xd).backward(g.double().cpu())
+    outs = []
+    for _ in range(2):
+        x1 = x.clone().requires_grad_(True)
+        bn.zero_grad(set_to_none=True)
+        y = core.stacked_train_bn(bn, x1)
+        assert y is not None and y.shape == x.shape
+        y.backward(g)
+        outs.append((y.detach().clone(), x1.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    if x.numel() // c > 1:
+        yd = torch.nn.functional.batch_norm(x.double().cpu(), None, None, ref.weight.detach(), ref.bias.detach(), True, 0.0, 1e-3)
+        y, dx, dgam, dbet = outs[0]
+        scale = float(yd.abs().max())
+        assert float((y.double().cpu() - yd).abs().max()) <= 2e-6 * scale + 1e-6
+        assert float((dx.double().cpu() - xd.grad).abs().max()) <= 2e-5 * float(xd.grad.abs().max()) + 1e-6
+        assert float((dgam.double().cpu() - ref.weight.grad).abs().max()) <= 2e-5 * float(ref.weight.grad.abs().max()) + 1e-5
+        assert float((dbet.double().cpu() - ref.bias.grad).abs().max()) <= 2e-5 * float(ref.bias.grad.abs().max()) + 1e-5
+        assert int(bn.num_batches_tracked) == 2
+        # two updates of the running statistics with the same batch statistics
+        m1 = ref.running_mean.clone()           # after one reference update from (0, 1)
+        mean = x.double().cpu().transpose(0, 1).reshape(c, -1).mean(1)
+        var = x.double().cpu().transpose(0, 1).reshape(c, -1).var(1, unbiased=True)
+        want_m = 0.99 * (0.99 * 0 + 0.01 * mean) + 0.01 * mean
+        want_v = 0.99 * (0.99 * 1 + 0.01 * var) + 0.01 * var
+        assert float((bn.running_mean.double().cpu() - want_m).abs().max()) <= 1e-6
+        assert float((bn.running_var.double().cpu() - want_v).abs().max()) <= 1e-5
+        assert float((m1 - 0.01 * mean).abs().max()) <= 1e-12
+    # eval mode, image batches and CPU tensors are not this path's
+    assert core.stacked_train_bn(bn.eval(), x) is None
+    assert core.stacked_train_bn(bn.train(), torch.randn(2, c, 5, device=dev) if len(shape) == 3 else torch.randn(2, c, 5, 5, device=dev)) is None
