@@ -107,6 +107,13 @@ CONV_GRADS_IN_PLACE = os.environ.get("GLX_CONV_GRADS_IN_PLACE", "1") != "0"
 _grad_generation = [0]      # bumped by FlatAdamW.pack_grads: one lending of a parameter's gradient view per optimizer step
 
 
+def grad_generation_of(param):
+    """The lending counter that governs `param`'s gradient view: its optimizer's own (`_glx_grad_gen`, a one-element list
+    FlatAdamW shares with its parameters), else the process-wide one."""
+    own = getattr(param, "_glx_grad_gen", None)
+    return own[0] if own is not None else _grad_generation[0]
+
+
 def next_grad_generation():
     _grad_generation[0] += 1
 
@@ -118,11 +125,16 @@ def grad_buffer(param, shape=None):
     else a new tensor.  shape: the kernel's view of the weight (same element order), default the parameter's."""
     view = getattr(param, "_glx_grad_view", None) if (CONV_GRADS_IN_PLACE and param is not None) else None
     # lent ONCE per optimizer step: a weight that two layers share gets two gradients in one backward pass, the second of
-    # which must not land on the first (autograd adds it to .grad, which is then the view: still no gather)
-    if (view is not None and param.grad is None and getattr(param, "_glx_grad_lent", -1) != _grad_generation[0]
+    # which must not land on the first (autograd adds it to .grad, which is then the view: still no gather).  The step counter
+    # is the OWNING optimizer's (FlatAdamW stamps its parameters with its own counter): a second optimizer's pack_grads does
+    # not re-open the lending of this one's views in the middle of an accumulation (ADVICE r4).
+    # NOTE: a gradient obtained through torch.autograd.grad() (no AccumulateGrad) may therefore ALIAS the optimizer's flat
+    # gradient buffer and is overwritten by the next step -- clone it if it has to outlive the step.
+    gen = grad_generation_of(param)
+    if (view is not None and param.grad is None and getattr(param, "_glx_grad_lent", -1) != gen
             and view.shape == param.shape and view.stride() == param.stride()
             and view.dtype == param.dtype and (shape is None or view.is_contiguous())):
-        param._glx_grad_lent = _grad_generation[0]
+        param._glx_grad_lent = gen
         g = view.detach()       # the parameter's own strides (channels-last filters keep theirs): the kernels write through them
         return g if shape is None else g.view(shape)
     like = param if shape is None else param.reshape(shape)

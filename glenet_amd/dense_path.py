@@ -933,7 +933,11 @@ def run_deferred_fc_wgrads(jobs):
                 cur.wait_event(ev)
                 x.record_stream(cur)
                 gy.record_stream(cur)
-            view = getattr(w, "_glx_grad_view", None) if (w.grad is None and GRADS_IN_PLACE) else None
+            gen = _lib.grad_generation_of(w)
+            view = getattr(w, "_glx_grad_view", None) if (w.grad is None and GRADS_IN_PLACE
+                                                          and getattr(w, "_glx_grad_lent", -1) != gen) else None
+            if view is not None:
+                w._glx_grad_lent = gen      # the same once-per-step lending stamp _lib.grad_buffer keeps
             gw = weight_grad(x, gy, w, view) if view is not None else weight_grad(x, gy, w)
             w.grad = gw if w.grad is None else w.grad + gw
 

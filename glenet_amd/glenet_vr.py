@@ -132,8 +132,8 @@ class VoxelRCNNKLHead(rg.RoIGridPool):
     keep_pooled = False       # tests: leave the pooled features of the last forward in `last_pooled`
     USE_FOLDED = True         # inference: BatchNorm folded into the FC towers
 
-    def forward(self, rois, multi_scale_3d_features, multi_scale_3d_strides, batch_size, raw=False, pre=None):
-        pooled = super().forward(rois, multi_scale_3d_features, multi_scale_3d_strides, batch_size, pre)
+    def forward(self, rois, multi_scale_3d_features, multi_scale_3d_strides, batch_size, raw=False):
+        pooled = super().forward(rois, multi_scale_3d_features, multi_scale_3d_strides, batch_size)
         if self.keep_pooled:
             self.last_pooled = pooled.detach()
         return self.heads(pooled, raw)
@@ -143,16 +143,8 @@ OVERLAP_ROI = os.environ.get("GLX_OVERLAP_ROI", "1") != "0"
 STAGE_CUTS = os.environ.get("GLX_STAGE_CUTS", "1") != "0"
 DEFER_FC_WGRADS = os.environ.get("GLX_DEFER_FC_WGRADS", "1") != "0"
 FC_WGRADS_BEHIND_ROI = os.environ.get("GLX_FC_WGRADS_BEHIND_ROI", "1") != "0"      # see StagedLoss.backward
-# First MLP of the three pooling scales on the RoI stream BESIDE the BEV forward (it needs the sparse backbone's output only).
-# Measured in round 4, alternating runs on one box: 7.22 / 7.23 ms per step with it against 7.03 / 7.02 without -- the nine
-# short launches compete with the BEV convolutions that produce the proposals' inputs, and the RoI branch starts later than
-# it gains.  Off by default (GLX_EARLY_MLP_IN=1).
-EARLY_MLP_IN = os.environ.get("GLX_EARLY_MLP_IN", "0") == "1"
 # the RoI head's three loss terms as one launch / one autograd node (losses.roi_head_losses); 0 = the three entry points
 ROI_LOSSES_ONE_LAUNCH = os.environ.get("GLX_ROI_LOSSES_ONE_LAUNCH", "1") != "0"
-
-
-WGRAD_STREAM_DURING_ROI = os.environ.get("GLX_WGRAD_DURING_ROI", "0") == "1"     # experiment: see StagedLoss.backward
 
 
 class StagedLoss:
@@ -192,8 +184,9 @@ class StagedLoss:
         # branch (the weight-gradient stream) in the recorded graph the RoI branch and the BEV backward were executed
         # one after the other (measured with the stage stamps, ROCm 7.2's graph executor); two branches do overlap.
         wgrad_stream = core.WGRAD_STREAM
-        if not WGRAD_STREAM_DURING_ROI:      # measured again with two executor queues: 8.0 ms against 6.44
-            core.WGRAD_STREAM = None
+        # no weight-gradient side stream while the RoI branch is in flight: a third concurrent branch was measured at 8.0 ms
+        # per step against 6.44 (round 4, also with two executor queues)
+        core.WGRAD_STREAM = None
         try:
             fc_jobs = dp.DEFERRED_FC_WGRADS = [] if DEFER_FC_WGRADS else None
             dp.DEFERRED_FC_SAME_STREAM = FC_WGRADS_BEHIND_ROI
@@ -338,11 +331,12 @@ class GLENetVR(nn.Module):
         if bd.get("stage_cuts") and not overlap:
             raise RuntimeError("the sparse backbone cut its autograd graph for a staged backward that will not run")
         dev = gt_boxes.device
-        msf, pre = bd["multi_scale_3d_features"], None
+        msf = bd["multi_scale_3d_features"]
         if overlap:
             # fork #1, in front of the BEV backbone: the RoI stream cuts the autograd graph at the feature tensors the RoI
-            # grid pools from and runs the first MLP of every pooling scale (it needs the sparse backbone's output only)
-            # WHILE the main stream computes the head maps the proposals need
+            # grid pools from.  (Running the pooling scales' first MLP here, beside the BEV forward, was measured in round 4:
+            # 7.22 against 7.03 ms per step -- the nine short launches compete with the convolutions that produce the
+            # proposals' inputs; that branch is gone.)
             main = torch.cuda.current_stream(dev)
             key = dev.index if dev.index is not None else torch.cuda.current_device()
             if key not in self._roi_streams:
@@ -359,8 +353,6 @@ class GLENetVR(nn.Module):
                         if getattr(st, "clean_rows", False):      # same values: still zeros past `count`
                             msf[k].clean_rows = True
                         roi_cuts[k] = (f, msf[k].features)
-                if EARLY_MLP_IN:
-                    pre = self.roi_head.mlp_in_features({n: msf[n] for n in self.roi_head.sources})
         bd = self.dense_head(self.backbone_2d(bd))
         mark("BEV backbone + anchor head fwd")
         if self.mark:        # two boundaries inside backward(): gradient hooks run on the stream of the backward pass
@@ -403,8 +395,7 @@ class GLENetVR(nn.Module):
                 reg_valid, cls_lab = td["reg_valid_mask"].view(-1), td["rcnn_cls_labels"].view(-1)
                 unc = td["gt_uncertaintys_of_rois"].reshape(-1, 7)
             mark("proposals (NMS) + RoI targets")
-            ori_cls, std_logit, rcnn_reg, rcnn_std = self.roi_head(rois_s, msf, bd["multi_scale_3d_strides"], B, raw=True,
-                                                                  pre=pre)
+            ori_cls, std_logit, rcnn_reg, rcnn_std = self.roi_head(rois_s, msf, bd["multi_scale_3d_strides"], B, raw=True)
             mark("RoI-grid pooling + FC towers fwd")
             w = r["LOSS_WEIGHTS"]
             if ROI_LOSSES_ONE_LAUNCH and losses.roi_head_losses_supported(ori_cls, rcnn_reg, cls_lab, rois_s, gt_ct, gt_src, unc,

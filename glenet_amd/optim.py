@@ -43,6 +43,7 @@ class FlatAdamW:
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grad_views = []
+        self._gen = [0]             # this optimizer's lending counter (_lib.grad_buffer): bumped by ITS pack_grads only
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 view = self._view(self.flat_param, o, p)
@@ -50,6 +51,7 @@ class FlatAdamW:
                 p.data = view
                 self.grad_views.append(self._view(self.flat_grad, o, p))
                 p._glx_grad_view = self.grad_views[-1]      # producers that can write a gradient in place (pack_grads skips it)
+                p._glx_grad_gen = self._gen
         self.hyper = torch.tensor([float(lr), float(betas[0])], dtype=torch.float32, device=dev)
         self.beta2, self.eps, self.weight_decay = float(betas[1]), float(eps), float(weight_decay)
         self.max_norm = float(max_norm) if max_norm else 0.0
@@ -83,15 +85,18 @@ class FlatAdamW:
         for such parameters; the training step gives every parameter a gradient)."""
         # (a gradient that was computed INTO its view -- dense_path.run_deferred_fc_wgrads does that for the 21 MB first RoI
         # Linear, 70 % of this copy -- needs none)
-        have = [(v, p.grad) for v, p in zip(self.grad_views, self.params)
-                if p.grad is not None and not (p.grad.data_ptr() == v.data_ptr() and p.grad.stride() == v.stride())]
-        if len(have) != len(self.params):
-            for v, p in zip(self.grad_views, self.params):
-                if p.grad is None:
-                    v.zero_()
+        have, missing = [], []
+        for v, p in zip(self.grad_views, self.params):
+            if p.grad is None:
+                missing.append(v)           # genuinely no gradient this step (in-place gradients are NOT missing)
+            elif not (p.grad.data_ptr() == v.data_ptr() and p.grad.stride() == v.stride()):
+                have.append((v, p.grad))
+        if missing:
+            torch._foreach_zero_(missing)
         if have:
             torch._foreach_copy_([h[0] for h in have], [h[1] for h in have])
-        _lib.next_grad_generation()       # the views may be lent to the next backward pass (_lib.grad_buffer)
+        self._gen[0] += 1                 # the views may be lent to the next backward pass (_lib.grad_buffer)
+        _lib.next_grad_generation()       # (parameters without an owning optimizer follow the process-wide counter)
         return self.flat_grad
 
     def allreduce_(self, average=True):

@@ -88,14 +88,13 @@ class RoIGridPool(nn.Module):
         r, v = self.point_cloud_range, self.voxel_size
         return torch.stack([(roi_grid_xyz[..., i] - r[i]) // v[i] for i in range(3)], dim=-1)
 
-    def forward(self, rois, multi_scale_3d_features, multi_scale_3d_strides, batch_size, pre=None):
-        """rois (B, R, 7+) -> (B*R, G^3, sum C_out).  pre: the result of mlp_in_features() on the same tensors (training
-        path only): the first MLP of every scale computed ahead of the proposals."""
+    def forward(self, rois, multi_scale_3d_features, multi_scale_3d_strides, batch_size):
+        """rois (B, R, 7+) -> (B*R, G^3, sum C_out)."""
         B = batch_size
         if self._fusable(rois, multi_scale_3d_features):
             return self._forward_fused(rois, multi_scale_3d_features, multi_scale_3d_strides, B)
         if self._trainable_rows(rois, multi_scale_3d_features):
-            return self._forward_rows(rois, multi_scale_3d_features, multi_scale_3d_strides, B, pre)
+            return self._forward_rows(rois, multi_scale_3d_features, multi_scale_3d_strides, B)
         grid_xyz, _ = global_grid_points_of_roi(rois, self.grid_size)           # (B*R, G^3, 3)
         grid_xyz = grid_xyz.reshape(B, -1, 3)
         coords1 = self.grid_coords(grid_xyz)                                      # (B, R*G^3, 3) float
@@ -160,22 +159,7 @@ class RoIGridPool(nn.Module):
             raise NotImplementedError("shape-static training needs the fused BatchNorm kernels")
         return layer._bn_rows(seq, y)
 
-    def mlp_in_features(self, tensors):
-        """The first MLP (1x1 conv + BatchNorm) of every pooling scale on the sparse tensors' features: it depends on the
-        backbone's output only, not on the RoIs, so a training step runs it on the RoI stream WHILE the BEV backbone
-        computes the proposals' inputs (glenet_vr.GLENetVR.second_stage_losses) -- nine launches off the RoI branch's
-        critical path.  None when the row-major training path does not apply."""
-        probe = next(iter(tensors.values())).features
-        if not (self.USE_ROWS and probe.is_cuda and probe.dtype == torch.float32 and torch.is_grad_enabled()):
-            return None
-        for layer, name in zip(self.roi_grid_pool_layers, self.sources):
-            st = tensors[name]
-            if layer.pool_method != "max_pool" or (st.count is not None and st._index is None):
-                return None
-        return {name: [self._mlp_in_rows(layer, mlp_in, tensors[name]) for mlp_in in layer.mlps_in]
-                for layer, name in zip(self.roi_grid_pool_layers, self.sources)}
-
-    def _forward_rows(self, rois, tensors, strides, B, pre=None):
+    def _forward_rows(self, rois, tensors, strides, B):
         import ctypes
         from . import _lib
         GroupRows, ReluAddMax = voxel_pool_modules.GroupRows, voxel_pool_modules.ReluAddMax
@@ -190,17 +174,10 @@ class RoIGridPool(nn.Module):
         _lib.call("glx_roi_grid_points", rois2, n, rois2.shape[1], n // B, self.grid_size, rmin, vsz,
                   grid_xyz, coords)
         outs = []
-        # The scales are independent chains of ~11 short launches each (mlp_in GEMM + BatchNorm, centres, query, moments,
-        # aggregation, mlp_out GEMM + BatchNorm), none of which fills the chip: with SCALE_STREAMS they run side by side
-        # on streams of their own (forked behind the grid points, joined in front of the concatenation; autograd runs
-        # each chain's backward on the stream its forward ran on), so the RoI branch -- the critical path of the training
-        # step -- waits for the longest of the three instead of their sum.
-        cur = torch.cuda.current_stream(dev)
-        side = self._scale_streams(dev, len(self.sources) - 1) if (self.SCALE_STREAMS and len(self.sources) > 1) else []
         # the scales' neighbour queries need the grid points and the tensors' cell indices only: ONE launch for all of them
         # (blockIdx.y = scale) instead of a 43-46 us launch per scale down the chain
         queries = {}
-        if self.GROUPED_QUERY and not side:
+        if self.GROUPED_QUERY:
             qs = []
             for k, (layer, name) in enumerate(zip(self.roi_grid_pool_layers, self.sources)):
                 st = tensors[name]
@@ -218,10 +195,6 @@ class RoIGridPool(nn.Module):
                 _lib.call("glx_roi_grid_query_multi", len(qs), arr, m, grid_xyz, coords, rmin, vsz)
                 queries = {(q[0], q[1]): q[2] for q in qs}
         for k, (layer, name) in enumerate(zip(self.roi_grid_pool_layers, self.sources)):
-          stream = side[k - 1] if (side and k > 0) else cur
-          if stream is not cur:
-              stream.wait_stream(cur)
-          with torch.cuda.stream(stream):
             st = tensors[name]
             index = st._ensure_index()
             z, y, x = st.spatial_shape
@@ -231,7 +204,7 @@ class RoIGridPool(nn.Module):
             _lib.call("glx_voxel_centers", ind, ind.shape[0], stride, rmin, vsz, xyz)
             for j, (grouper, mlp_in, mlp_pos, mlp_out) in enumerate(zip(layer.groupers, layer.mlps_in, layer.mlps_pos,
                                                                         layer.mlps_out)):
-                feats = pre[name][j] if pre is not None else self._mlp_in_rows(layer, mlp_in, st)   # (N, c_mid)
+                feats = self._mlp_in_rows(layer, mlp_in, st)   # (N, c_mid)
                 ns = grouper.nsample
                 idx = queries.get((k, j))
                 if idx is None:
@@ -242,8 +215,6 @@ class RoIGridPool(nn.Module):
                 if self.USE_POS_POOL and voxel_pool_modules.pos_pool_out_supported(feats, mlp_pos, mlp_out):
                     # ... and the output MLP's convolution + BatchNorm statistics in the same launch
                     outs.append(voxel_pool_modules.pos_pool_out(feats, mlp_pos, mlp_out, idx, xyz, grid_xyz))
-                    if stream is not cur:
-                        outs[-1].record_stream(cur)
                     continue
                 if self.USE_POS_POOL and voxel_pool_modules.pos_pool_supported(feats, mlp_pos):
                     # position MLP + add + ReLU + max-pool fused: no (M, ns, C) tensor (csrc/glx_roipool.hip)
@@ -256,27 +227,11 @@ class RoIGridPool(nn.Module):
                     pos = layer._conv_bn_rows(mlp_pos, rel.view(m * ns, 3))       # (M*ns, c_mid)
                     pooled = ReluAddMax.apply(g_feat, pos.view(m, ns, -1))        # (M, c_mid)
                 outs.append(layer._conv_bn_rows(mlp_out, pooled))                 # (M, c_out)
-                if stream is not cur:
-                    outs[-1].record_stream(cur)
-        for sd in side:
-            cur.wait_stream(sd)
         return torch.cat(outs, dim=1).view(n, g3, -1)
 
-    # Opt-in experiment (GLX_ROI_SCALE_STREAMS=1), OFF by default: eager launches and the shape-static eager step are
-    # correct with it, but RECORDING the step with the two extra branches ends in a segmentation fault inside
-    # hipStreamEndCapture on ROCm 7.2 (round 4, tests/test_train_step_gpu.py; the same failure mode as an unjoined
-    # branch, although every chain is joined in forward and autograd joins its backward).
-    SCALE_STREAMS = os.environ.get("GLX_ROI_SCALE_STREAMS", "0") == "1"
     # the scales' voxel queries in one launch: built, bit-identical, measured on the step 6.145 / 6.094 ms against 6.086 /
     # 6.078 per scale (the three launches already overlap the towers of the previous scale): off
     GROUPED_QUERY = os.environ.get("GLX_ROI_GROUPED_QUERY", "0") == "1"
-
-    def _scale_streams(self, dev, n):
-        key = (dev.index if dev.index is not None else torch.cuda.current_device())
-        pool = self.__dict__.setdefault("_glx_scale_streams", {})
-        if key not in pool or len(pool[key]) < n:
-            pool[key] = [torch.cuda.Stream(dev) for _ in range(n)]
-        return pool[key][:n]
 
     # ---- inference fast path: 1 + 3 launches per scale (csrc/glx_points.hip) -- grid points and
     # their voxel coordinates in one kernel, then per scale mlp_in (one GEMM), the voxel query and
