@@ -97,6 +97,42 @@ def test_bench_two_gpus_over_rccl_when_two_gpus_are_visible(dev):
     assert len(d["per_rank"]["ms_per_step"]) == 2 and min(d["per_rank"]["exchange_ms"]) >= 0.0
 
 
+def _syncbn(world):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_syncbn_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    res = [json.loads(line[len("SYNCBN "):]) for so, _ in outs for line in so.splitlines() if line.startswith("SYNCBN ")]
+    assert len(res) == world
+    for d in res:
+        assert d["world"] == world and d["rows"] > 100 and d["same_indices"]
+        assert d["out_err"] <= 2e-5 * d["out_scale"] + 1e-6, d
+        assert max(d["grad_err"]) <= 5e-4, d
+        assert d["stats_err"] <= 1e-5, d
+    return res
+
+
+def test_sync_bn_conversion_runs_on_the_module_path(dev):
+    """The reference's --sync_bn (tools/train.py:119-120: nn.SyncBatchNorm.convert_sync_batchnorm) on a stack of this
+    package's spconv classes, process group over RCCL with a world of one: the converted BatchNorms take the module path
+    (no conv + BatchNorm fusion) and reproduce the fused kernels' outputs, gradients and running statistics."""
+    _syncbn(1)
+
+
+def test_sync_bn_statistics_span_the_ranks_when_two_gpus_are_visible(dev):
+    """... and with one GPU per rank the statistics span both ranks' rows: each rank's rows and the summed weight gradients
+    equal one process running the unconverted stack on the union batch.  Skips itself on a 1-GPU box."""
+    if _gpus_visible() < 2:
+        pytest.skip("one GPU visible: cross-rank BatchNorm statistics need two")
+    _syncbn(2)
+
+
 def test_bench_data_parallel_step_over_rccl_prints_one_json_line(dev):
     """GLX_BENCH_FORCE_DP=1: bench.py's N > 1 code path -- process group over RCCL (`nccl`) with `device_id`, two graphs,
     the flat SUM all-reduce between them, the scaled update, the per-rank diagnostics -- with a world of one process on
