@@ -6,7 +6,9 @@
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #define BN_MAXC 512
+#ifndef BN_SETS
 #define BN_SETS 16
+#endif
 
 struct BnState {
   double acc[BN_SETS][2 * BN_MAXC];
