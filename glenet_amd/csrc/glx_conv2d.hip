@@ -363,7 +363,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
 // plain kernels compile as before).
 // CV_ABL (compile-time, tools/build_variant.sh -DCV_ABL=n; 0 in the product): TIMING-ONLY ablations of the second form (wrong
 // results): 1 = operand fragments read from LDS once per tile, 2 = weight fragments loaded once per tile, 4 = halo loaded and
-// staged once per tile (no per-chunk loads, splits, stores, barriers), 8 = no barriers, 16 = one piece product of six.
+// staged once per tile (no per-chunk loads, splits, stores, barriers), 8 = no barriers, 16 = one piece product of six,
+// 32 = the statistics' tail dropped (no atomics / ticket / finalize), 64 = no finalize.
 #ifndef CV_ABL
 #define CV_ABL 0
 #endif
@@ -590,6 +591,10 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
       }
     }
     __syncthreads();
+    if (CV_ABL & 32) {               // timing ablation: the block's sums go nowhere (no atomics, no ticket, no finalize)
+      if (tid < 128 && red[tid] == 12345.678) a.y[0] = 0.f;
+      return;
+    }
     if (tid < 128) {
       const int ch = tid & 63, mom = tid >> 6;
       double seen = unsafeAtomicAdd(a.bn_state->acc[blockIdx.x % BN_SETS] + mom * BN_MAXC + stats_n0 + ch, red[mom * 64 + ch]);
@@ -599,6 +604,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
     if (tid == 0)
       s_last2 = __hip_atomic_fetch_add(&a.bn_state->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
+    if (CV_ABL & 64) return;         // timing ablation: atomics and ticket, no finalize
     if (s_last2) bn_finalize_sets<BWD, 256>(a.bn_state, a.bn, a.Cout, a.B * a.H * a.W, reinterpret_cast<double(*)[2]>(smem));
   }
 }
