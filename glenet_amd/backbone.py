@@ -47,16 +47,25 @@ class ResidualBlock(spconv.SparseModule):
             out = self.conv2(out, fused_bn=self.bn2)
         else:
             core = spconv.core
-            out = self.conv1(x)
-            if core.can_fuse_train_bn(self.bn1, out.features):     # training: fused BN(+ReLU) kernels
-                out = out.replace_feature(core.fused_train_bn(self.bn1, out.features, True, out.count))
+            if core.conv_bn_fusable(self.conv1, self.bn1, x):
+                # training, as SparseSequential runs conv + BatchNorm + ReLU: the statistics ride in conv1's epilogue and conv2
+                # reads relu(bn1(.)) by transforming the raw rows on load (round 5; the 128 -> 128 blocks, whose convolutions
+                # run as two column halves, keep the separate statistics launch below)
+                out = self.conv1(x, train_bn=self.bn1, train_relu=True)
             else:
-                out = out.replace_feature(self.relu(self.bn1(out.features)))
-            out = self.conv2(out)
-            if core.can_fuse_train_bn(self.bn2, out.features):
-                out = out.replace_feature(core.fused_train_bn(self.bn2, out.features, False, out.count))
+                out = self.conv1(x)
+                if core.can_fuse_train_bn(self.bn1, out.features):     # training: fused BN(+ReLU) kernels
+                    out = out.replace_feature(core.fused_train_bn(self.bn1, out.features, True, out.count))
+                else:
+                    out = out.replace_feature(self.relu(self.bn1(out.features)))
+            if core.conv_bn_fusable(self.conv2, self.bn2, out):
+                out = self.conv2(out, train_bn=self.bn2, train_relu=False)
             else:
-                out = out.replace_feature(self.bn2(out.features))
+                out = self.conv2(out)
+                if core.can_fuse_train_bn(self.bn2, out.features):
+                    out = out.replace_feature(core.fused_train_bn(self.bn2, out.features, False, out.count))
+                else:
+                    out = out.replace_feature(self.bn2(out.features))
         return out.replace_feature(self.relu(out.features + x.features))
 
 
