@@ -47,3 +47,11 @@ pr.disable()
 st = pstats.Stats(pr)
 st.sort_stats("cumulative").print_stats(45)
 st.sort_stats("tottime").print_stats(25)
+
+if os.environ.get("ITEM_CALLERS"):
+    pr2 = cProfile.Profile()
+    pr2.enable()
+    step()
+    torch.cuda.synchronize()
+    pr2.disable()
+    pstats.Stats(pr2).print_callers("item")
