@@ -205,6 +205,32 @@ def pos_pool_supported(feats, mlp_pos):
             and isinstance(bn, (nn.BatchNorm1d, nn.BatchNorm2d)))
 
 
+ROWS_LINEAR_FN = os.environ.get("GLX_ROWS_LINEAR_FN", "1") != "0"
+
+
+class _RowsLinearFn(torch.autograd.Function):
+    """x (rows, C_in) @ w^T for tall-skinny products (tens of thousands of rows x <= 64 channels) with the backward written
+    out: dX = dY @ w, dW = sum over 128 row groups of dY_g^T X_g (split-K as a batched product + one sum, in the weight's own
+    layout).  The bmm-with-expanded-weight formulation this replaces left autograd a second bmm, the sum over the expanded
+    dimension AND a transpose copy per call (tools/torch_ops_in_step.py: 12 bmm + 6 sum + 7 copy_ per training step)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        rows = x.shape[0]
+        gx = gy @ w if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw = torch.bmm(gy.view(128, rows // 128, -1).transpose(1, 2), x.view(128, rows // 128, -1)).sum(0)
+        return gx, gw
+
+
 class NeighborVoxelSAModuleMSG(nn.Module):
     def __init__(self, *, query_ranges, radii, nsamples, mlps, use_xyz=True, pool_method='max_pool'):
         super().__init__()
@@ -333,6 +359,8 @@ class NeighborVoxelSAModuleMSG(nn.Module):
         (300 us for 60 k rows; 2.6 ms for the 1.4 M rows of the position conv before it was fused away)."""
         rows = x2d.shape[0]
         if rows >= NeighborVoxelSAModuleMSG.SPLITK_MIN_ROWS and rows % 128 == 0 and bias is None:
+            if ROWS_LINEAR_FN and x2d.is_cuda and x2d.is_contiguous() and x2d.dtype == torch.float32:
+                return _RowsLinearFn.apply(x2d, w)
             return torch.bmm(x2d.view(128, rows // 128, -1), w.t().unsqueeze(0).expand(128, -1, -1)).view(rows, -1)
         return F.linear(x2d, w, bias)
 
