@@ -720,6 +720,22 @@ extern "C" int glx_bn_relu_backward(const float* x, const float* dy, const float
   return GLX_OK;
 }
 
+// The statistics half of glx_bn_relu_backward alone (one launch): dgamma, dbeta and coef3 = (a, b, c) of
+// dx = a (dy [y > 0] - b - c xhat) for a consumer that applies the transform on load (glx_rows_linear_bn_backward).  coef3: 3 C
+// floats of the caller's; state: glx_bn_state_bytes(), required.
+extern "C" int glx_bn_backward_sums(const float* x, const float* dy, int N, int C, const float* gamma, const float* beta,
+                                    const float* save_mean, const float* save_invstd, int relu, float* dgamma, float* dbeta,
+                                    const int32_t* n_live, float* coef3, void* state, void* stream) {
+  GLX_REQUIRE(save_mean && save_invstd && coef3 && state && (N == 0 || (x && dy)), "glx_bn_backward_sums: null pointer");
+  GLX_REQUIRE(bn_channels_ok(C), "glx_bn_backward_sums: C=%d needs a multiple of 4 dividing 1024 (<= 512)", C);
+  const int slabs = bn_stats_slabs(N > 0 ? N : 1, C);
+  BnFinalize f{gamma, beta, 0.f, 0.f, coef3, nullptr, nullptr, nullptr, nullptr, save_invstd, dgamma, dbeta};
+  hipLaunchKernelGGL((k_bn_stats<true>), dim3(slabs), dim3(BN_THREADS), 0, (hipStream_t)stream, x, dy, (const float*)nullptr,
+                     save_mean, save_invstd, relu, N > 0 ? N : 0, C, (long long)C, (const int*)n_live, (BnState*)state, f);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
 extern "C" int glx_bn_backward_apply(const float* x, const float* dz, const float* coef, const float* mean, const float* invstd,
                                      int N, int C, const int32_t* n_live, float* dx, void* stream) {
   GLX_REQUIRE(coef && mean && invstd && (N == 0 || (x && dz && dx)), "glx_bn_backward_apply: null pointer");

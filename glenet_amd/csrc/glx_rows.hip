@@ -1,0 +1,429 @@
+// Conv(kernel 1, no bias) + training-mode BatchNorm (+ ReLU) on (rows, C) matrices: the input and output MLPs of the RoI-grid
+// pool (pcdet/ops/pointnet2/pointnet2_stack/voxel_pool_modules.py:70-130: mlps_in on the scale's voxels, mlps_out on the
+// pooled grid points; Conv1d / Conv2d with a 1 x 1 kernel there) and any other tall-skinny x @ W^T with <= 64 channels.
+//
+// Shape of the work: 20 000 .. 110 000 rows, 16 .. 64 channels in, 16 .. 64 out: a stream of rows through an 8 KB weight
+// matrix -- 28 .. 42 MB of traffic and 0.2 .. 0.9 GFLOP per call, i.e. ~5 us of HBM time and ~5 us of fp32 MFMA time.  The
+// vendor GEMMs spend 17 .. 46 us on each of these products (32 x 32 macro tiles, one launch per product) and leave autograd
+// a second product, a split-K batched product and its sum for the backward: 3 + 5 launches per layer with the BatchNorm's.
+//
+//   forward (1 launch + the transform):  z = x W^T, 16 rows per wave and trip: W (<= 64 x 64) lives in registers as MFMA A
+//     operands, the rows stream through as B operands straight from global memory (16-byte loads), so a lane ends up with
+//     FOUR CONSECUTIVE CHANNELS of one row (16-byte stores).  The BatchNorm statistics (sum z, sum z^2, fp64) are taken from
+//     the accumulators; the block that draws the last ticket turns them into scale / shift, saved mean / invstd and the
+//     running statistics (glx_bn_state.h: the scheme of k_bn_stats and the sparse convolutions' epilogue).
+//   backward (the statistics launch of glx_bn.hip + 2 launches):  dz = a (dy [y > 0] - b - c xhat) is formed ON LOAD from the
+//     3 C coefficients, then  dx = dz W  (k = output channels: the tile as loaded)  and  dW += dz^T x  (k = rows: the tile
+//     transposed through a wave-private LDS patch) from the same registers; per-block partial dW, summed by a second launch in
+//     a fixed order (bitwise reproducible).
+// v_mfma_f32_16x16x4_f32 throughout: exact fp32 products, fp32 accumulation.
+#include "glx_common.h"
+#include "glx_bn_state.h"
+
+typedef float ft4 __attribute__((ext_vector_type(4)));
+
+#define RW_THREADS 256
+#define RW_WAVES 4
+#define RW_MAX_BLOCKS 512          // forward: two blocks per CU
+#define RW_BWD_BLOCKS 256          // backward: one partial weight gradient per block
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int K, int N, bool STATS>
+__global__ __launch_bounds__(RW_THREADS) void k_rows_linear(const float* __restrict__ x, const float* __restrict__ w,
+                                                            float* __restrict__ z, int rows, const int* __restrict__ n_live,
+                                                            BnState* __restrict__ st, BnFinalize f) {
+  constexpr int KS = K / 16, NT = N / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+  int n = rows;
+  if (n_live) n = min(rows, *n_live);
+  ft4 wv[NT][KS];          // A operand: output channel 16 nt + r, input channels 16 s + 4 q + e
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) wv[nt][s] = *reinterpret_cast<const ft4*>(w + (16 * nt + r) * K + 16 * s + 4 * q);
+  double s0[NT][4], s1[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s0[nt][i] = s1[nt][i] = 0;
+  const int ntiles = (n + 15) >> 4, stride = gridDim.x * RW_WAVES;
+  int tile = blockIdx.x * RW_WAVES + wave;
+  ft4 xv[KS];
+  if (tile < ntiles) {
+    const int row = min(tile * 16 + r, n - 1);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xv[s] = *reinterpret_cast<const ft4*>(x + (long long)row * K + 16 * s + 4 * q);
+  }
+  while (tile < ntiles) {
+    const int next = tile + stride;
+    ft4 xn[KS];
+    if (next < ntiles) {
+      const int row = min(next * 16 + r, n - 1);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) xn[s] = *reinterpret_cast<const ft4*>(x + (long long)row * K + 16 * s + 4 * q);
+    }
+    ft4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      acc[nt] = ft4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][s][e], xv[s][e], acc[nt], 0, 0, 0);
+    }
+    const int row = tile * 16 + r;
+    if (row < n) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        *reinterpret_cast<ft4*>(z + (long long)row * N + 16 * nt + 4 * q) = acc[nt];
+        if (STATS) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            s0[nt][i] += (double)acc[nt][i];
+            s1[nt][i] += (double)acc[nt][i] * (double)acc[nt][i];
+          }
+        }
+      }
+    }
+    if (next < ntiles) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) xv[s] = xn[s];
+    }
+    tile = next;
+  }
+  if (!STATS) return;
+  // the 16 row lanes of a channel quad, then the block's four waves: thread t < N / 4 ends up with float4 column t
+  __shared__ double s_red[RW_WAVES][N / 4][2][4];
+  __shared__ int s_last;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        s0[nt][i] += __shfl_xor(s0[nt][i], o, 64);
+        s1[nt][i] += __shfl_xor(s1[nt][i], o, 64);
+      }
+  if (r == 0) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s_red[wave][4 * nt + q][0][i] = s0[nt][i];
+        s_red[wave][4 * nt + q][1][i] = s1[nt][i];
+      }
+  }
+  __syncthreads();
+  double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+  if ((int)threadIdx.x < N / 4) {
+#pragma unroll
+    for (int wv_ = 0; wv_ < RW_WAVES; ++wv_)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a0[i] += s_red[wv_][threadIdx.x][0][i];
+        a1[i] += s_red[wv_][threadIdx.x][1][i];
+      }
+  }
+  if (!bn_contribute(st, N, a0, a1, gridDim.x, &s_last)) return;
+  __shared__ double s_fin[RW_THREADS][2];
+  bn_finalize_sets<false, RW_THREADS>(st, f, N, n, s_fin);
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+struct RowsBwdBn {
+  const float* coef_fwd;   // scale, shift of the forward transform (2 CO): the ReLU mask is re-derived from z
+  const float* coef3;      // a, b, c of dz = a (g - b - c xhat) (3 CO), from the statistics launch
+  const float* mean;
+  const float* invstd;
+  int relu;
+};
+
+// element ((a * NB + b) * 4 + i) * 64 + lane of a block's partial = dW[16 a + 4 (lane >> 4) + i][16 b + (lane & 15)]
+template <int CI, int CO, bool BN>
+__global__ __launch_bounds__(RW_THREADS) void k_rows_linear_bwd(const float* __restrict__ x, const float* __restrict__ z,
+                                                                const float* __restrict__ dy, const float* __restrict__ w,
+                                                                int rows, const int* __restrict__ n_live, RowsBwdBn bn,
+                                                                float* __restrict__ gx, float* __restrict__ part) {
+  constexpr int MT = CI / 16, KS = CO / 16, NA = CO / 16, NB = CI / 16, LD = CO + 16;
+  __shared__ float s_dz[RW_WAVES][16 * LD];
+  __shared__ float s_acc[NA * NB * 4 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+  int n = rows;
+  if (n_live) n = min(rows, *n_live);
+  ft4 wt[MT][KS];          // input gradient, A operand: input channel 16 mt + r, k = output channels 16 s + 4 q + e
+  if (gx) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wt[mt][s][e] = w[(16 * s + 4 * q + e) * CI + 16 * mt + r];
+  }
+  ft4 c_sc[KS], c_sh[KS], c_mu[KS], c_is[KS], c_a[KS], c_b[KS], c_cc[KS];
+  if (BN) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int c = 16 * s + 4 * q;
+      c_sc[s] = *reinterpret_cast<const ft4*>(bn.coef_fwd + c);
+      c_sh[s] = *reinterpret_cast<const ft4*>(bn.coef_fwd + CO + c);
+      c_mu[s] = *reinterpret_cast<const ft4*>(bn.mean + c);
+      c_is[s] = *reinterpret_cast<const ft4*>(bn.invstd + c);
+      c_a[s] = *reinterpret_cast<const ft4*>(bn.coef3 + c);
+      c_b[s] = *reinterpret_cast<const ft4*>(bn.coef3 + CO + c);
+      c_cc[s] = *reinterpret_cast<const ft4*>(bn.coef3 + 2 * CO + c);
+    }
+  }
+  ft4 accw[NA][NB];
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) accw[a][b] = ft4{0.f, 0.f, 0.f, 0.f};
+  float* dzs = s_dz[wave];
+  const int ntiles = (n + 15) >> 4, stride = gridDim.x * RW_WAVES;
+  for (int tile = blockIdx.x * RW_WAVES + wave; tile < ntiles; tile += stride) {
+    const int row0 = tile * 16;
+    // ---- dz of the tile, lane (r, q): row r, channels 16 s + 4 q ..
+    const bool live = row0 + r < n;
+    const long long ro = (long long)min(row0 + r, n - 1) * CO + 4 * q;
+    ft4 dzv[KS], zv[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      dzv[s] = *reinterpret_cast<const ft4*>(dy + ro + 16 * s);
+      if (BN) zv[s] = *reinterpret_cast<const ft4*>(z + ro + 16 * s);
+    }
+    // the rows of x as the weight gradient's B operand: lane (c, k) = x[row 4 s4 + k][16 b + c]
+    float xb[4][NB];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int rr = row0 + 4 * s4 + q;
+      const float* xp = x + (long long)min(rr, n - 1) * CI + r;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float v = xp[16 * b];
+        xb[s4][b] = rr < n ? v : 0.f;          // a dead row may hold anything (0 x NaN = NaN)
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float g = dzv[s][e];
+        if (BN) {
+          if (bn.relu) g = bn_affine(zv[s][e], c_sc[s][e], c_sh[s][e]) > 0.f ? g : 0.f;
+          const float xh = (zv[s][e] - c_mu[s][e]) * c_is[s][e];
+          g = c_a[s][e] * (g - c_b[s][e] - xh * c_cc[s][e]);
+        }
+        dzv[s][e] = live ? g : 0.f;
+      }
+    // ---- input gradient: rows of dz as B operands (k = output channels)
+    if (gx) {
+      ft4 acc[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        acc[mt] = ft4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[mt][s][e], dzv[s][e], acc[mt], 0, 0, 0);
+      }
+      if (live) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<ft4*>(gx + (long long)(row0 + r) * CI + 16 * mt + 4 * q) = acc[mt];
+      }
+    }
+    // ---- weight gradient: the tile transposed through the wave's LDS patch (k = rows)
+    if (part) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) *reinterpret_cast<ft4*>(dzs + r * LD + 16 * s + 4 * q) = dzv[s];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        float da[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) da[a] = dzs[(4 * s4 + q) * LD + 16 * a + r];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+          for (int b = 0; b < NB; ++b) accw[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(da[a], xb[s4][b], accw[a][b], 0, 0, 0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  // rows past the live count: zero gradient
+  if (gx) {
+    const long long e0 = (long long)n * CI, e1 = (long long)rows * CI;
+    for (long long e = e0 + ((long long)blockIdx.x * RW_THREADS + threadIdx.x) * 4; e < e1; e += (long long)gridDim.x * RW_THREADS * 4)
+      *reinterpret_cast<ft4*>(gx + e) = ft4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (!part) return;
+  // ---- the block's partial: waves 1 .. 3 hand theirs to wave 0 through LDS, one after the other (fixed order)
+  for (int wv_ = 1; wv_ < RW_WAVES; ++wv_) {
+    __syncthreads();
+    if (wave == wv_) {
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) s_acc[((a * NB + b) * 4 + i) * 64 + lane] = accw[a][b][i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) accw[a][b][i] += s_acc[((a * NB + b) * 4 + i) * 64 + lane];
+    }
+  }
+  if (wave == 0) {
+    float* dst = part + (size_t)blockIdx.x * (CO * CI);
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[((a * NB + b) * 4 + i) * 64 + lane] = accw[a][b][i];
+  }
+}
+
+// dW[co][ci] = sum over the blocks' partials: a block owns 16 elements, thread (element, group g of 16) adds partials g, g + 16, ..
+// and the groups are combined in a fixed order (bitwise reproducible).  64 .. 256 blocks: the 1 .. 4 MB of partials are read by
+// the whole chip (sixteen blocks of 64 elements with 64 loads in series per thread took 21 us).
+#define RW_RED_EL 16
+__global__ __launch_bounds__(256) void k_rows_wgrad_reduce(const float* __restrict__ part, int nparts, int CI, int CO,
+                                                           float* __restrict__ gw) {
+  __shared__ float s_red[16][RW_RED_EL];
+  const int el = threadIdx.x & (RW_RED_EL - 1), g = threadIdx.x / RW_RED_EL;
+  const int e = blockIdx.x * RW_RED_EL + el, total = CI * CO;
+  float s = 0.f;
+  if (e < total) {
+    const float* p = part + e;
+    int k = g;
+#pragma unroll 1
+    for (; k + 48 < nparts; k += 64) {
+      const float v0 = p[(size_t)k * total], v1 = p[(size_t)(k + 16) * total], v2 = p[(size_t)(k + 32) * total],
+                  v3 = p[(size_t)(k + 48) * total];
+      s = (((s + v0) + v1) + v2) + v3;
+    }
+    for (; k < nparts; k += 16) s += p[(size_t)k * total];
+  }
+  s_red[g][el] = s;
+  __syncthreads();
+  if (g == 0 && e < total) {
+    float v = s_red[0][el];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v += s_red[k][el];
+    const int NB = CI / 16;
+    const int lane = e & 63, i = (e >> 6) & 3, ab = e >> 8;
+    const int a = ab / NB, b = ab % NB;
+    gw[(16 * a + 4 * (lane >> 4) + i) * CI + 16 * b + (lane & 15)] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+static bool rows_dims_ok(int Cin, int Cout) {
+  return (Cin == 16 || Cin == 32 || Cin == 64) && (Cout == 16 || Cout == 32 || Cout == 64);
+}
+
+extern "C" int glx_rows_linear_supported(int Cin, int Cout) { return rows_dims_ok(Cin, Cout) ? 1 : 0; }
+
+extern "C" size_t glx_rows_linear_workspace_bytes(int Cin, int Cout) {
+  return glx_align((size_t)RW_BWD_BLOCKS * (Cin > 0 ? Cin : 1) * (Cout > 0 ? Cout : 1) * sizeof(float));
+}
+
+static int rows_fwd_blocks(int rows) {
+  const int want = glx_divup(glx_divup(rows, 16), RW_WAVES);
+  return want < 1 ? 1 : (want > RW_MAX_BLOCKS ? RW_MAX_BLOCKS : want);
+}
+
+template <int K, int N>
+static void rows_fwd_launch(const float* x, const float* w, float* z, int rows, const int32_t* n_live, BnState* st,
+                            const BnFinalize& f, hipStream_t stream) {
+  const int blocks = rows_fwd_blocks(rows);
+  if (st) hipLaunchKernelGGL((k_rows_linear<K, N, true>), dim3(blocks), dim3(RW_THREADS), 0, stream, x, w, z, rows, (const int*)n_live, st, f);
+  else hipLaunchKernelGGL((k_rows_linear<K, N, false>), dim3(blocks), dim3(RW_THREADS), 0, stream, x, w, z, rows, (const int*)n_live, st, f);
+}
+
+#define RW_DISPATCH(CI_, CO_, CALL)                                                           \
+  switch ((CI_) * 100 + (CO_)) {                                                              \
+    case 1616: CALL(16, 16); break; case 1632: CALL(16, 32); break; case 1664: CALL(16, 64); break; \
+    case 3216: CALL(32, 16); break; case 3232: CALL(32, 32); break; case 3264: CALL(32, 64); break; \
+    case 6416: CALL(64, 16); break; case 6432: CALL(64, 32); break; case 6464: CALL(64, 64); break; \
+    default: break;                                                                           \
+  }
+
+// z (rows, Cout) = x (rows, Cin) @ w^T (w: (Cout, Cin) row-major) on the first min(rows, *n_live) rows (the rest of z is left
+// untouched and never read by the entry points below).  bn_state != NULL: the training-mode BatchNorm statistics of z in the
+// same launch -- coef (scale, shift: 2 Cout floats, what glx_bn_apply_forward takes), save_mean, save_invstd, the running
+// statistics (NULL: not tracked); gamma / beta NULL = 1 / 0.  bn_state: glx_bn_state_bytes() zero-filled once, shared with the
+// other statistics kernels of the stream.  Replaces Conv1d(k = 1, bias = False) + the statistics half of BatchNorm1d
+// (voxel_pool_modules.py:70-130).
+extern "C" int glx_rows_linear_bn_forward(const float* x, int rows, int Cin, const float* w, int Cout, const int32_t* n_live,
+                                          float* z, const float* gamma, const float* beta, float eps, float momentum,
+                                          float* running_mean, float* running_var, float* coef, float* save_mean,
+                                          float* save_invstd, void* bn_state, void* stream) {
+  GLX_REQUIRE(rows_dims_ok(Cin, Cout), "glx_rows_linear_bn_forward: channels %d -> %d (16 / 32 / 64 each)", Cin, Cout);
+  GLX_REQUIRE(w && (rows == 0 || (x && z)), "glx_rows_linear_bn_forward: null pointer");
+  GLX_REQUIRE(!bn_state || (coef && save_mean && save_invstd), "glx_rows_linear_bn_forward: statistics without their outputs");
+  if (rows <= 0) return GLX_OK;
+  BnFinalize f{gamma, beta, eps, momentum, coef, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, nullptr, 0};
+#define RW_FWD(CI_, CO_) rows_fwd_launch<CI_, CO_>(x, w, z, rows, n_live, (BnState*)bn_state, f, (hipStream_t)stream)
+  RW_DISPATCH(Cin, Cout, RW_FWD)
+#undef RW_FWD
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+template <int CI, int CO>
+static void rows_bwd_launch(const float* x, const float* z, const float* dy, const float* w, int rows, const int32_t* n_live,
+                            const RowsBwdBn& bn, float* gx, float* part, int blocks, hipStream_t stream) {
+  if (bn.coef3)
+    hipLaunchKernelGGL((k_rows_linear_bwd<CI, CO, true>), dim3(blocks), dim3(RW_THREADS), 0, stream, x, z, dy, w, rows,
+                       (const int*)n_live, bn, gx, part);
+  else
+    hipLaunchKernelGGL((k_rows_linear_bwd<CI, CO, false>), dim3(blocks), dim3(RW_THREADS), 0, stream, x, z, dy, w, rows,
+                       (const int*)n_live, bn, gx, part);
+}
+
+// The backward of glx_rows_linear_bn_forward (+ glx_bn_apply_forward): dy = the gradient of the TRANSFORMED output; coef3 (from
+// glx_bn_backward_sums) != NULL: the BatchNorm (+ ReLU, mask re-derived from z and coef_fwd) backward is applied to dy on load;
+// coef3 == NULL: dy is the gradient of z itself (plain x @ w^T).  gx (rows, Cin): rows past the live count are zeroed; NULL =
+// not wanted.  gw (Cout, Cin); NULL = not wanted.  workspace: glx_rows_linear_workspace_bytes(Cin, Cout).
+extern "C" int glx_rows_linear_bn_backward(const float* x, const float* z, const float* dy, int rows, int Cin, const float* w,
+                                           int Cout, const int32_t* n_live, const float* coef_fwd, int relu, const float* coef3,
+                                           const float* mean, const float* invstd, float* gx, float* gw, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(rows_dims_ok(Cin, Cout), "glx_rows_linear_bn_backward: channels %d -> %d (16 / 32 / 64 each)", Cin, Cout);
+  GLX_REQUIRE(w && (rows == 0 || (x && dy)), "glx_rows_linear_bn_backward: null pointer");
+  GLX_REQUIRE(!coef3 || (z && coef_fwd && mean && invstd), "glx_rows_linear_bn_backward: BatchNorm backward without z / coefficients");
+  GLX_REQUIRE(!gw || (workspace && workspace_bytes >= glx_rows_linear_workspace_bytes(Cin, Cout)),
+              "glx_rows_linear_bn_backward: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (rows <= 0) {                       // no rows: a zero weight gradient (the sum of no partials)
+    if (gw) {
+      hipLaunchKernelGGL(k_rows_wgrad_reduce, dim3(glx_divup(Cin * Cout, RW_RED_EL)), dim3(256), 0, st, (const float*)workspace, 0, Cin,
+                         Cout, gw);
+      GLX_LAUNCH_CHECK();
+    }
+    return GLX_OK;
+  }
+  const int want = glx_divup(glx_divup(rows, 16), RW_WAVES);
+  const int blocks = want < 1 ? 1 : (want > RW_BWD_BLOCKS ? RW_BWD_BLOCKS : want);
+  RowsBwdBn bn{coef_fwd, coef3, mean, invstd, relu};
+  float* part = gw ? (float*)workspace : nullptr;
+#define RW_BWD(CI_, CO_) rows_bwd_launch<CI_, CO_>(x, z, dy, w, rows, n_live, bn, gx, part, blocks, st)
+  RW_DISPATCH(Cin, Cout, RW_BWD)
+#undef RW_BWD
+  GLX_LAUNCH_CHECK();
+  if (gw) {
+    hipLaunchKernelGGL(k_rows_wgrad_reduce, dim3(glx_divup(Cin * Cout, RW_RED_EL)), dim3(256), 0, st, (const float*)part, blocks, Cin,
+                       Cout, gw);
+    GLX_LAUNCH_CHECK();
+  }
+  return GLX_OK;
+}

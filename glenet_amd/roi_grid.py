@@ -146,6 +146,10 @@ class RoIGridPool(nn.Module):
         live = None
         # rows past `count`: a tensor that left the fused BatchNorm kernels carries zeros there (and gets zero
         # gradients back, see glx_bn_relu_*), anything else may hold NaN and is masked on both sides of the conv
+        clean = st.count is None or getattr(st, "clean_rows", False)
+        if clean and voxel_pool_modules.rows_conv_bn_supported(seq, x):
+            # the product with the BatchNorm statistics in its epilogue, the BatchNorm backward applied on load (csrc/glx_rows.hip)
+            return voxel_pool_modules.rows_conv_bn(seq, x, st.count)
         if st.count is not None and not getattr(st, "clean_rows", False):
             live = (torch.arange(x.shape[0], device=x.device) < st.count).view(-1, 1)
             x = torch.where(live, x, x.new_zeros(()))

@@ -768,6 +768,36 @@ int glx_bn_relu_backward(const float* x, const float* dy, const float* y, int N,
  * ReLU mask.  x, dz, dx (N, C) row-major; rows >= *n_live (device, may be NULL) get zeros. */
 int glx_bn_backward_apply(const float* x, const float* dz, const float* coef, const float* mean, const float* invstd,
                           int N, int C, const int32_t* n_live, float* dx, void* stream);
+/* The statistics half of glx_bn_relu_backward alone (one launch): dgamma, dbeta and coef3 = (a, b, cc) for a consumer that applies
+ * dx = a * (dy [y > 0] - b - xhat * cc) itself on load (glx_rows_linear_bn_backward).  x = the BatchNorm's input, dy = the gradient of
+ * its (ReLU'd) output, both (N, C) row-major; coef3: 3 C floats; state: glx_bn_state_bytes(), zero-filled once (required). */
+int glx_bn_backward_sums(const float* x, const float* dy, int N, int C, const float* gamma, const float* beta,
+                         const float* save_mean, const float* save_invstd, int relu, float* dgamma, float* dbeta,
+                         const int32_t* n_live, float* coef3, void* state, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Conv(kernel 1, bias = False) + training-mode BatchNorm (+ ReLU) on (rows, C) matrices: the input / output MLPs of the RoI-grid
+ * pool (pcdet/ops/pointnet2/pointnet2_stack/voxel_pool_modules.py:70-130, mlps_in / mlps_out: nn.Conv1d / nn.Conv2d with 1 x 1
+ * kernels + BatchNorm in the reference's (1, C, M) layout) -- csrc/glx_rows.hip.  Cin, Cout in {16, 32, 64}
+ * (glx_rows_linear_supported), fp32 MFMA (exact products, fp32 accumulation).
+ *
+ * forward: z (rows, Cout) = x (rows, Cin) @ w^T, w (Cout, Cin) row-major, on the first min(rows, *n_live) rows (n_live: device
+ * int32, may be NULL; the rest of z is left untouched and is not read by the backward).  bn_state != NULL: the BatchNorm statistics
+ * of z are taken in the same launch: coef (scale[Cout], shift[Cout]: what glx_bn_apply_forward takes), save_mean, save_invstd, the
+ * running statistics (NULL: not tracked); gamma / beta NULL = 1 / 0.  bn_state NULL: the plain product.
+ *
+ * backward: dy (rows, Cout) = the gradient of the transformed output when coef3 != NULL (from glx_bn_backward_sums on (z, dy)): the
+ * BatchNorm (+ ReLU: mask re-derived from z and coef_fwd) backward is applied to dy on load; coef3 == NULL: dy is the gradient of z.
+ * gx (rows, Cin) = dz @ w, rows past the live count zeroed (NULL: not wanted); gw (Cout, Cin) = dz^T @ x (NULL: not wanted), per-block
+ * partial sums in `workspace` (glx_rows_linear_workspace_bytes) added in a fixed order by a second launch. */
+int glx_rows_linear_supported(int Cin, int Cout);
+size_t glx_rows_linear_workspace_bytes(int Cin, int Cout);
+int glx_rows_linear_bn_forward(const float* x, int rows, int Cin, const float* w, int Cout, const int32_t* n_live, float* z,
+                               const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                               float* running_var, float* coef, float* save_mean, float* save_invstd, void* bn_state, void* stream);
+int glx_rows_linear_bn_backward(const float* x, const float* z, const float* dy, int rows, int Cin, const float* w, int Cout,
+                                const int32_t* n_live, const float* coef_fwd, int relu, const float* coef3, const float* mean,
+                                const float* invstd, float* gx, float* gw, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * VectorPool family of PV-RCNN++.  Output slots are laid out in ascending new-point order

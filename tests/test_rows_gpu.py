@@ -1,0 +1,142 @@
+"""csrc/glx_rows.hip: Conv(k = 1, bias = False) + training-mode BatchNorm (+ ReLU) on (rows, C) matrices -- the input / output
+MLPs of the RoI-grid pool (pcdet/ops/pointnet2/pointnet2_stack/voxel_pool_modules.py:70-130) -- against an fp64 evaluation of the
+reference's modules (nn.Conv1d + nn.BatchNorm1d + nn.ReLU on the (1, C, M) layout), forward, all four gradients and the running
+statistics; the plain product through the C ABI; live-row counts of shape-static matrices."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+def _modules(cin, cout, relu, seed):
+    torch.manual_seed(seed)
+    conv = nn.Conv1d(cin, cout, 1, bias=False)
+    bn = nn.BatchNorm1d(cout)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.uniform_(-0.2, 0.2)
+        bn.running_var.uniform_(0.5, 1.5)
+    return nn.Sequential(conv, bn, nn.ReLU()) if relu else nn.Sequential(conv, bn)
+
+
+def _reference(seq, x, cot, live):
+    """fp64, the reference's layout: (1, C, M) through Conv1d / BatchNorm1d / ReLU on the live rows."""
+    import copy
+    ref = copy.deepcopy(seq).double().train()
+    xr = x[:live].double().detach().clone().requires_grad_(True)
+    y = ref(xr.t().unsqueeze(0)).squeeze(0).t()
+    (y * cot[:live].double()).sum().backward()
+    return ref, y.detach(), xr.grad
+
+
+@pytest.mark.parametrize("rows,cin,cout,relu,live", [
+    (20011, 32, 32, True, None),
+    (110592, 32, 32, True, None),
+    (61858, 64, 32, False, 50021),
+    (30000, 64, 32, False, None),
+    (4099, 16, 64, True, 4001),
+    (9000, 64, 64, True, None),
+    (2048, 32, 16, False, 37),
+])
+def test_rows_conv_bn_matches_the_reference_modules_in_fp64(dev, rows, cin, cout, relu, live):
+    from glenet_amd.pcdet_ops.pointnet2.pointnet2_stack import voxel_pool_modules as vpm
+    seq = _modules(cin, cout, relu, rows).to(dev).train()
+    g = torch.Generator(device=dev).manual_seed(rows + cin)
+    x = torch.randn(rows, cin, device=dev, generator=g) * 1.5 + 0.3
+    cot = torch.randn(rows, cout, device=dev, generator=g)
+    count = None
+    n = rows
+    if live is not None:
+        n = live
+        x[n:] = 0                                             # the contract: rows past the count are zero
+        count = torch.tensor([n], dtype=torch.int32, device=dev)
+    ref, y_ref, gx_ref = _reference(seq, x, cot, n)
+    x.requires_grad_(True)
+    assert vpm.rows_conv_bn_supported(seq, x)
+    y = vpm.rows_conv_bn(seq, x, count)
+    (y * cot).sum().backward()
+    torch.cuda.synchronize()
+    ys = float(y_ref.abs().max())
+    assert float((y[:n].double() - y_ref).abs().max()) <= 2e-6 * ys + 1e-6
+    if live is not None:
+        assert float(y[n:].abs().max()) == 0.0 and float(x.grad[n:].abs().max()) == 0.0
+    # a ReLU that flips on a rounding-level pre-activation moves one element's gradient: mean error, and the maximum loosely
+    for got, want in ((x.grad[:n], gx_ref), (seq[0].weight.grad, ref[0].weight.grad), (seq[1].weight.grad, ref[1].weight.grad),
+                      (seq[1].bias.grad, ref[1].bias.grad)):
+        sc = float(want.abs().max()) + 1e-30
+        err = (got.double() - want).abs()
+        assert float(err.mean()) <= 2e-6 * sc, (float(err.mean()), sc)
+        assert float(err.max()) <= (2e-3 if relu else 2e-5) * sc, (float(err.max()), sc)
+    assert float((seq[1].running_mean.double() - ref[1].running_mean).abs().max()) <= 1e-6
+    assert float((seq[1].running_var.double() - ref[1].running_var).abs().max()) <= 1e-5 * float(ref[1].running_var.max())
+    assert int(seq[1].num_batches_tracked) == 1
+
+
+def test_rows_conv_bn_equals_the_library_formulation_it_replaces(dev):
+    """The same Sequential through _linear_rows + the fused BatchNorm kernels (GLX_ROWS_CONV_BN=0's path): results agree to fp32
+    rounding, including a live-row count."""
+    from glenet_amd.pcdet_ops.pointnet2.pointnet2_stack import voxel_pool_modules as vpm
+    from glenet_amd.spconv import core
+    import copy
+    rows, cin, cout, n = 40960, 64, 32, 33333
+    seq = _modules(cin, cout, True, 5).to(dev).train()
+    old = copy.deepcopy(seq)
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn(rows, cin, device=dev, generator=g)
+    x[n:] = 0
+    cot = torch.randn(rows, cout, device=dev, generator=g)
+    count = torch.tensor([n], dtype=torch.int32, device=dev)
+    xa = x.clone().requires_grad_(True)
+    ya = vpm.rows_conv_bn(seq, xa, count)
+    (ya * cot).sum().backward()
+    xb = x.clone().requires_grad_(True)
+    w = old[0].weight.reshape(cout, cin)
+    yb = core.fused_train_bn(old[1], vpm.NeighborVoxelSAModuleMSG._linear_rows(xb, w, None), True, count)
+    (yb * cot).sum().backward()
+    torch.cuda.synchronize()
+    assert float((ya - yb).abs().max()) <= 1e-5 * float(yb.abs().max())
+    for a, b in ((xa.grad, xb.grad), (seq[0].weight.grad, old[0].weight.grad), (seq[1].weight.grad, old[1].weight.grad),
+                 (seq[1].bias.grad, old[1].bias.grad)):
+        assert float((a - b).abs().mean()) <= 1e-5 * float(b.abs().max())
+    assert torch.allclose(seq[1].running_var, old[1].running_var, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(16, 32, 32), (33, 16, 16), (70001, 64, 64), (12345, 32, 64)])
+def test_plain_product_through_the_c_abi(dev, rows, cin, cout):
+    """bn_state == NULL / coef3 == NULL: z = x w^T, gx = dy w, gw = dy^T x (fp64 products as the yardstick); twice: the weight
+    gradient's partial sums are added in a fixed order (bitwise equal)."""
+    from glenet_amd import _lib
+    g = torch.Generator(device=dev).manual_seed(rows)
+    x = torch.randn(rows, cin, device=dev, generator=g)
+    w = torch.randn(cout, cin, device=dev, generator=g) / cin ** 0.5
+    dy = torch.randn(rows, cout, device=dev, generator=g)
+    z = torch.empty(rows, cout, device=dev)
+    zero = ctypes.c_float(0.0)
+    _lib.call("glx_rows_linear_bn_forward", x, rows, cin, w, cout, None, z, None, None, zero, zero, None, None, None, None, None, None)
+    ws = torch.empty(_lib.query("glx_rows_linear_workspace_bytes", cin, cout), dtype=torch.uint8, device=dev)
+    outs = []
+    for _ in range(2):
+        gx, gw = torch.empty_like(x), torch.empty_like(w)
+        _lib.call("glx_rows_linear_bn_backward", x, None, dy, rows, cin, w, cout, None, None, 0, None, None, None, gx, gw, ws,
+                  _lib.size_arg(ws.numel()))
+        outs.append((gx, gw))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    xd, wd, dd = x.double(), w.double(), dy.double()
+    for got, want in ((z, xd @ wd.t()), (outs[0][0], dd @ wd), (outs[0][1], dd.t() @ xd)):
+        assert float((got.double() - want).abs().max()) <= 3e-6 * float(want.abs().max())
+
+
+def test_unsupported_widths_are_refused_loudly(dev):
+    from glenet_amd import _lib
+    x = torch.zeros(64, 48, device=dev)
+    w = torch.zeros(32, 48, device=dev)
+    z = torch.zeros(64, 32, device=dev)
+    zero = ctypes.c_float(0.0)
+    assert _lib.query("glx_rows_linear_supported", 48, 32) == 0 and _lib.query("glx_rows_linear_supported", 64, 32) == 1
+    with pytest.raises(_lib.GlxError, match="channels 48 -> 32"):
+        _lib.call("glx_rows_linear_bn_forward", x, 64, 48, w, 32, None, z, None, None, zero, zero, None, None, None, None, None, None)
