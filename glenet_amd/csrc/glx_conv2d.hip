@@ -637,6 +637,11 @@ struct WgradArgs {
   int pre_relu;
 };
 
+// WG_ABL (timing-only builds, wrong results; tools/build_variant.sh): 1 no gy loads, 2 no split of gy, 4 no x halo loads / staging,
+// 8 no LDS operand reads, 16 one MFMA of six, 32 no workgroup barriers
+#ifndef WG_ABL
+#define WG_ABL 0
+#endif
 template <bool PIPE>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -680,7 +685,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
                      : f32x4{0.f, 0.f, 0.f, 0.f};                                                         \
     }                                                                                                     \
   }
-#define WG_LOADG(T, S)                                                                                    \
+#define WG_LOADG_(GR, T, S)                                                                               \
   {                                                                                                       \
     int t_ = (T);                                                                                         \
     const int x0_ = (t_ % a.tiles_x) * CV_TW;                                                             \
@@ -690,8 +695,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
     const float* g_ = a.gy + (((long long)b_ * a.H + py_) * a.W + px_) * a.Cout + cb * 64 + cp * 32 + c;  \
     _Pragma("unroll") for (int a2_ = 0; a2_ < 2; ++a2_)                                                   \
       _Pragma("unroll") for (int jj_ = 0; jj_ < 8; ++jj_)                                                 \
-        graw[a2_][jj_] = (py_ < a.H && px_ + jj_ < a.W) ? g_[(long long)jj_ * a.Cout + a2_ * 16] : 0.f;    \
+        GR[a2_][jj_] = (WG_ABL & 1)   ? (float)(py_ + jj_)                                                 \
+                         : (py_ < a.H && px_ + jj_ < a.W) ? g_[(long long)jj_ * a.Cout + a2_ * 16] : 0.f;  \
   }
+#define WG_LOADG(T, S) WG_LOADG_(graw, T, S)
 
   f32x4 acc[9][2];           // [tap][channel tile of the pair]
 #pragma unroll
@@ -716,10 +723,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
     WG_LOADG(tile, 0);
   }
   while (tile < a.ntiles) {
-    __syncthreads();          // the previous tile's reads of the image are done
+    if (!(WG_ABL & 32)) __syncthreads();          // the previous tile's reads of the image are done
 #pragma unroll
     for (int i = 0; i < CV_ALOADS; ++i) {
-      if (adst[i] >= 0) {
+      if (!(WG_ABL & 4) && adst[i] >= 0) {
         bf16x4 p0, p1, p2;
         if (a.pre_scale && ((aok >> i) & 1u)) {
 #pragma unroll
@@ -739,7 +746,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
         *reinterpret_cast<bf16x4*>(smem + 2 * WG_XPLANE + adst[i]) = p2;
       }
     }
-    __syncthreads();
+    if (!(WG_ABL & 32)) __syncthreads();
     const int next = tile + a.P;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -750,7 +757,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
           __bf16 u, v, w;
-          cv_split(graw[a2][jj], u, v, w);
+          const float gval = graw[a2][jj];
+          if (WG_ABL & 2) {
+            const unsigned bits = __builtin_bit_cast(unsigned, gval);
+            u = __builtin_bit_cast(__bf16, (unsigned short)(bits >> 16));
+            v = __builtin_bit_cast(__bf16, (unsigned short)bits);
+            w = u;
+          } else {
+            cv_split(gval, u, v, w);
+          }
           ga[a2][0][jj] = u; ga[a2][1][jj] = v; ga[a2][2][jj] = w;
         }
       if (s < 3) {
@@ -758,14 +773,18 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
       } else if (next < a.ntiles) {
         WG_LOADG(next, 0);
       }
-      if (s == 2 && next < a.ntiles) { WG_LOADX(next); }
+      if (!(WG_ABL & 4) && s == 2 && next < a.ntiles) { WG_LOADX(next); }
 #define WG_READX(XB, TAP)                                                                                  \
   _Pragma("unroll") for (int pl_ = 0; pl_ < 3; ++pl_) {                                                    \
     const int off_ = pl_ * WG_XPLANE + (2 * s + (TAP) / 3) * CV_HW * 64;                                   \
     typedef i16x4 __attribute__((address_space(3))) * lds_p;                                               \
-    i16x4 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(smem + off_ + rbase[0][(TAP) % 3]));       \
-    i16x4 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(smem + off_ + rbase[1][(TAP) % 3]));       \
-    XB[pl_] = wg_join(lo_, hi_);                                                                           \
+    if (WG_ABL & 8) {                                                                                      \
+      XB[pl_] = __builtin_bit_cast(bf16x8, areg[((TAP) + pl_) % CV_ALOADS]);                               \
+    } else {                                                                                               \
+      i16x4 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(smem + off_ + rbase[0][(TAP) % 3]));     \
+      i16x4 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(smem + off_ + rbase[1][(TAP) % 3]));     \
+      XB[pl_] = wg_join(lo_, hi_);                                                                         \
+    }                                                                                                      \
   }
       bf16x8 xb[2][3];
       if (PIPE) { WG_READX(xb[0], 0); }
@@ -780,7 +799,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
 #pragma unroll
         for (int a2 = 0; a2 < 2; ++a2) {
           f32x4 v = acc[tap][a2];
-          BF3_MFMA6(v, ga[a2], xb[tap & 1]);
+          if (WG_ABL & 16) {
+            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[a2][0], xb[tap & 1][0], v, 0, 0, 0);
+          } else {
+            BF3_MFMA6(v, ga[a2], xb[tap & 1]);
+          }
           acc[tap][a2] = v;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -791,6 +814,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
   }
 #undef WG_LOADX
 #undef WG_LOADG
+#undef WG_LOADG_
   // ---- the block's partial sums: element ((tap * 2 + a2) * 4 + reg) * 256 + tid
   float* dst = a.ws + (size_t)(q * a.P + p) * WG_PART + tid;
 #pragma unroll

@@ -139,7 +139,7 @@ FIRST_LAYER_BN_STATS = os.environ.get("GLX_BEV_FIRST_BN_STATS", "1") != "0"   # 
 HEAD_DGRAD_BN = os.environ.get("GLX_HEAD_DGRAD_BN", "1") != "0"        # ... and their backward sums in the head's input gradient
 # kernel form of that launch (glx_head1x1_input_grad_bn_form): 1 = a wave owns 64 channels -- 74 us against 109 alone, no
 # difference on the recorded step (DESIGN 9.22 viii)
-HEAD_DGRAD_FORM = int(os.environ.get("GLX_HEAD_DGRAD_V2", "0"))
+HEAD_DGRAD_FORM = int(os.environ.get("GLX_HEAD_DGRAD_V2", "1"))
 HEAD_BN_ON_LOAD = os.environ.get("GLX_HEAD_BN_ON_LOAD", "1") != "0"    # deblocks' BatchNorm + ReLU applied by the anchor head's kernels
 DECONV_BN_STATS = os.environ.get("GLX_DECONV_BN_STATS", "1") != "0"   # deblocks: BatchNorm statistics in the deconv's epilogue
 
