@@ -427,3 +427,120 @@ extern "C" int glx_rows_linear_bn_backward(const float* x, const float* z, const
   }
   return GLX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ several small dW = dY^T X
+// The RoI head's FC towers (voxelrcnn_head.py:40-66: five 256 x 256 Linear layers behind the first) leave five weight gradients
+// dW_l (256, 256) = dZ_l^T (256, R) H_(l-1) (R, 256) with R = 512 RoI rows: 67 MFLOP each.  As library products each was a batched
+// split-K GEMM + a sum (ten launches, 17 - 110 us apiece beside the BEV backward); here ONE launch: blockIdx.y = the layer, a block
+// owns a 64 x 64 tile of dW, its four waves take every fourth k-step (k = the R rows, four per step) and meet in LDS (fixed order:
+// bitwise reproducible).  Operands straight from L2 as 16-byte loads: lane (j, q) reads channels 4 j .. 4 j + 3 of row 4 t + q of
+// both matrices, which are the A operands of FOUR interleaved 16-channel tiles {4 m + e} and the B operands of four {4 n + e'}:
+// sixteen MFMAs per pair of loads (a lane = output channel form with 4-byte loads needs twelve loads for eight).
+#define RW_MJ_MAX 8
+struct RowsWgradJobs {
+  const float* x[RW_MJ_MAX];
+  const float* gy[RW_MJ_MAX];
+  float* out[RW_MJ_MAX];
+};
+
+#define RW_MJ_U 4          // k-steps per trip (their loads issued together)
+__global__ __launch_bounds__(256) void k_rows_wgrad_multi(RowsWgradJobs jobs, int rows, int cin, int cout) {
+  __shared__ float s_acc[16 * 4 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+  const int tn = cin / 64, tile = blockIdx.x;
+  const int co0 = (tile / tn) * 64, ci0 = (tile % tn) * 64;
+  const float* __restrict__ gp = jobs.gy[blockIdx.y] + co0 + 4 * j;
+  const float* __restrict__ xp = jobs.x[blockIdx.y] + ci0 + 4 * j;
+  float* __restrict__ out = jobs.out[blockIdx.y];
+  ft4 acc[4][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[e][f] = ft4{0.f, 0.f, 0.f, 0.f};
+  const int nsteps = (rows + 3) >> 2;
+  const ft4 zero = ft4{0.f, 0.f, 0.f, 0.f};
+  ft4 a[RW_MJ_U], b[RW_MJ_U];
+#define RW_MJ_LOAD(A, B, T0)                                                                     \
+  _Pragma("unroll") for (int u_ = 0; u_ < RW_MJ_U; ++u_) {                                       \
+    const int row_ = 4 * ((T0) + 4 * u_) + q;                                                    \
+    const bool ok_ = row_ < rows;                                                                \
+    const long long rc_ = ok_ ? row_ : rows - 1;                                                 \
+    const ft4 av_ = *reinterpret_cast<const ft4*>(gp + rc_ * cout);                              \
+    const ft4 bv_ = *reinterpret_cast<const ft4*>(xp + rc_ * cin);                               \
+    A[u_] = ok_ ? av_ : zero;                                                                    \
+    B[u_] = ok_ ? bv_ : zero;                                                                    \
+  }
+  int t = wave;                                   // this wave's k-steps: t, t + 4, ..
+  if (t < nsteps) { RW_MJ_LOAD(a, b, t); }
+  while (t < nsteps) {
+    const int tnext = t + 4 * RW_MJ_U;
+    ft4 an[RW_MJ_U], bn[RW_MJ_U];
+    if (tnext < nsteps) { RW_MJ_LOAD(an, bn, tnext); }
+#pragma unroll
+    for (int u = 0; u < RW_MJ_U; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b[u][f], acc[e][f], 0, 0, 0);
+    if (tnext < nsteps) {
+#pragma unroll
+      for (int u = 0; u < RW_MJ_U; ++u) { a[u] = an[u]; b[u] = bn[u]; }
+    }
+    t = tnext;
+  }
+#undef RW_MJ_LOAD
+  // rows past the matrix were loaded as zeros (a step past nsteps inside a trip is all zeros too: row_ >= rows)
+  for (int w = 1; w < RW_WAVES; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) s_acc[((e * 4 + f) * 4 + i) * 64 + lane] = acc[e][f][i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[e][f][i] += s_acc[((e * 4 + f) * 4 + i) * 64 + lane];
+    }
+  }
+  if (wave == 0) {
+    // acc[e][f][i] = dW[co0 + 4 (4 q + i) + e][ci0 + 4 j + f]
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ft4 v;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) v[f] = acc[e][f][i];
+        *reinterpret_cast<ft4*>(out + (long long)(co0 + 4 * (4 * q + i) + e) * cin + ci0 + 4 * j) = v;
+      }
+  }
+}
+
+// out_j (cout, cin) = gy_j (rows, cout)^T @ x_j (rows, cin) for j < njobs <= 8 problems of ONE shape, one launch.  cout % 64 == 0,
+// cin % 64 == 0; everything row-major and dense; rows >= 1.  Replaces the weight gradient autograd derives for nn.Linear
+// (voxelrcnn_head.py:40-66's towers) as library GEMMs.
+extern "C" int glx_linear_wgrad_multi(int njobs, const float* const* x, const float* const* gy, float* const* out, int rows,
+                                      int cin, int cout, void* stream) {
+  GLX_REQUIRE(njobs >= 1 && njobs <= RW_MJ_MAX, "glx_linear_wgrad_multi: %d problems (1 .. %d)", njobs, RW_MJ_MAX);
+  GLX_REQUIRE(x && gy && out, "glx_linear_wgrad_multi: null pointer");
+  GLX_REQUIRE(rows >= 1 && cin > 0 && cout > 0 && cin % 64 == 0 && cout % 64 == 0,
+              "glx_linear_wgrad_multi: rows %d, (%d, %d) filters: needs cout %% 64 == 0 and cin %% 64 == 0", rows, cout, cin);
+  RowsWgradJobs jobs;
+  for (int j = 0; j < RW_MJ_MAX; ++j) {
+    const int s = j < njobs ? j : 0;
+    GLX_REQUIRE(x[s] && gy[s] && out[s], "glx_linear_wgrad_multi: null pointer in problem %d", s);
+    jobs.x[j] = x[s]; jobs.gy[j] = gy[s]; jobs.out[j] = out[s];
+  }
+  hipLaunchKernelGGL(k_rows_wgrad_multi, dim3((cout / 64) * (cin / 64), njobs), dim3(256), 0, (hipStream_t)stream, jobs, rows, cin,
+                     cout);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

@@ -923,9 +923,26 @@ def _deferred_event(device):
     return ev
 
 
+FC_WGRADS_GROUPED = os.environ.get("GLX_FC_WGRADS_GROUPED", "1") != "0"   # the towers' 256 x 256 weight gradients in one launch
+
+
+def _grad_target(w):
+    """Where a deferred weight gradient of `w` is written: the optimizer's flat-buffer view when the parameter has no gradient
+    yet this step (lent once per step: the stamp _lib.grad_buffer keeps), else None (a fresh tensor, added)."""
+    gen = _lib.grad_generation_of(w)
+    view = getattr(w, "_glx_grad_view", None) if (w.grad is None and GRADS_IN_PLACE
+                                                  and getattr(w, "_glx_grad_lent", -1) != gen) else None
+    if view is not None:
+        w._glx_grad_lent = gen
+    return view
+
+
 def run_deferred_fc_wgrads(jobs):
     """The weight gradients _SplitKLinearFn.backward left out, on the current stream (which waits for the event each
-    job recorded where its gy became available); written into the parameters' .grad like AccumulateGrad would."""
+    job recorded where its gy became available); written into the parameters' .grad like AccumulateGrad would.  Jobs of one
+    small shape (the towers' five 256 x 256 filters over the same RoI rows) run as ONE launch (csrc/glx_rows.hip,
+    glx_linear_wgrad_multi) instead of a batched library GEMM + a sum each."""
+    import ctypes
     cur = torch.cuda.current_stream()
     with torch.no_grad():
         for x, gy, w, ev, weight_grad in jobs:
@@ -933,11 +950,32 @@ def run_deferred_fc_wgrads(jobs):
                 cur.wait_event(ev)
                 x.record_stream(cur)
                 gy.record_stream(cur)
-            gen = _lib.grad_generation_of(w)
-            view = getattr(w, "_glx_grad_view", None) if (w.grad is None and GRADS_IN_PLACE
-                                                          and getattr(w, "_glx_grad_lent", -1) != gen) else None
-            if view is not None:
-                w._glx_grad_lent = gen      # the same once-per-step lending stamp _lib.grad_buffer keeps
+        groups, rest = {}, []
+        for job in jobs:
+            x, gy, w = job[0], job[1], job[2]
+            small = (FC_WGRADS_GROUPED and w.dim() == 2 and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0
+                     and w.shape[0] * w.shape[1] <= 512 * 512 and x.is_cuda and x.dtype == gy.dtype == w.dtype == torch.float32
+                     and x.is_contiguous() and gy.is_contiguous() and x.shape == (gy.shape[0], w.shape[1])
+                     and gy.shape[1] == w.shape[0] and x.shape[0] >= 1)
+            if small:
+                groups.setdefault((tuple(w.shape), x.shape[0]), []).append(job)
+            else:
+                rest.append(job)
+        for (shape, rows), group in groups.items():
+            for lo in range(0, len(group), 8):
+                part = group[lo:lo + 8]
+                outs = []
+                for x, gy, w, ev, weight_grad in part:
+                    view = _grad_target(w)
+                    outs.append(view if view is not None and view.is_contiguous() and view.shape == w.shape
+                                else torch.empty_like(w, memory_format=torch.contiguous_format))
+                ptrs = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+                _lib.call("glx_linear_wgrad_multi", len(part), ptrs([j[0] for j in part]), ptrs([j[1] for j in part]), ptrs(outs),
+                          rows, shape[1], shape[0])
+                for (x, gy, w, ev, weight_grad), gw in zip(part, outs):
+                    w.grad = gw if w.grad is None else w.grad + gw
+        for x, gy, w, ev, weight_grad in rest:
+            view = _grad_target(w)
             gw = weight_grad(x, gy, w, view) if view is not None else weight_grad(x, gy, w)
             w.grad = gw if w.grad is None else w.grad + gw
 

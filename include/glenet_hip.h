@@ -798,6 +798,12 @@ int glx_rows_linear_bn_forward(const float* x, int rows, int Cin, const float* w
 int glx_rows_linear_bn_backward(const float* x, const float* z, const float* dy, int rows, int Cin, const float* w, int Cout,
                                 const int32_t* n_live, const float* coef_fwd, int relu, const float* coef3, const float* mean,
                                 const float* invstd, float* gx, float* gw, void* workspace, size_t workspace_bytes, void* stream);
+/* out_j (cout, cin) = gy_j (rows, cout)^T @ x_j (rows, cin) for njobs <= 8 problems of one shape in ONE launch (host arrays of
+ * device pointers; cout % 64 == 0, cin % 64 == 0, dense row-major, rows >= 1; fixed summation order): the weight gradients of the
+ * RoI head's 256 x 256 nn.Linear layers (pcdet/models/roi_heads/voxelrcnn_head.py:40-66), which autograd leaves as one library
+ * GEMM + reduction each. */
+int glx_linear_wgrad_multi(int njobs, const float* const* x, const float* const* gy, float* const* out, int rows, int cin, int cout,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------
  * VectorPool family of PV-RCNN++.  Output slots are laid out in ascending new-point order

@@ -140,3 +140,56 @@ def test_unsupported_widths_are_refused_loudly(dev):
     assert _lib.query("glx_rows_linear_supported", 48, 32) == 0 and _lib.query("glx_rows_linear_supported", 64, 32) == 1
     with pytest.raises(_lib.GlxError, match="channels 48 -> 32"):
         _lib.call("glx_rows_linear_bn_forward", x, 64, 48, w, 32, None, z, None, None, zero, zero, None, None, None, None, None, None)
+
+
+@pytest.mark.parametrize("njobs,rows,cin,cout", [(5, 512, 256, 256), (3, 510, 256, 256), (8, 7, 64, 64), (1, 1021, 192, 128)])
+def test_grouped_weight_gradients_of_small_linear_layers(dev, njobs, rows, cin, cout):
+    """glx_linear_wgrad_multi: out_j = gy_j^T x_j for several layers of one shape in one launch (the RoI towers' 256 x 256 filters,
+    voxelrcnn_head.py:40-66) against fp64 products; a second call gives the same bits."""
+    from glenet_amd import _lib
+    g = torch.Generator(device=dev).manual_seed(rows * 7 + njobs)
+    xs = [torch.randn(rows, cin, device=dev, generator=g) for _ in range(njobs)]
+    gys = [torch.randn(rows, cout, device=dev, generator=g) for _ in range(njobs)]
+    ptrs = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    results = []
+    for _ in range(2):
+        outs = [torch.full((cout, cin), float("nan"), device=dev) for _ in range(njobs)]
+        _lib.call("glx_linear_wgrad_multi", njobs, ptrs(xs), ptrs(gys), ptrs(outs), rows, cin, cout)
+        results.append(outs)
+    torch.cuda.synchronize()
+    for j in range(njobs):
+        assert torch.equal(results[0][j], results[1][j])
+        want = gys[j].double().t() @ xs[j].double()
+        assert float((results[0][j].double() - want).abs().max()) <= 3e-6 * float(want.abs().max())
+    with pytest.raises(_lib.GlxError, match="cout % 64"):
+        _lib.call("glx_linear_wgrad_multi", 1, ptrs(xs[:1]), ptrs(gys[:1]), ptrs(results[0][:1]), rows, cin, 48)
+
+
+def test_deferred_tower_weight_gradients_run_grouped_and_match_the_library_products(dev):
+    """dense_path.run_deferred_fc_wgrads: the five (256, 256) jobs of the FC towers in one launch + the long first Linear as before;
+    gradients equal the per-job library products (GLX_FC_WGRADS_GROUPED=0's path), including accumulation into an existing .grad."""
+    from glenet_amd import dense_path as dp
+    g = torch.Generator(device=dev).manual_seed(3)
+    rows = 512
+    shapes = [(256, 1024)] + [(256, 256)] * 5 + [(64, 96), (128, 64)]
+    def make():
+        ws = [torch.nn.Parameter(torch.zeros(s, device=dev)) for s in shapes]
+        ws[2].grad = torch.ones_like(ws[2])                    # one filter already has a gradient: added, not overwritten
+        return ws
+    xs = [torch.randn(rows, s[1], device=dev, generator=g) for s in shapes]
+    gys = [torch.randn(rows, s[0], device=dev, generator=g) for s in shapes]
+    res = []
+    for grouped in (True, False):
+        old = dp.FC_WGRADS_GROUPED
+        dp.FC_WGRADS_GROUPED = grouped
+        try:
+            ws = make()
+            dp.run_deferred_fc_wgrads([(x, gy, w, None, dp._SplitKLinearFn.weight_grad) for x, gy, w in zip(xs, gys, ws)])
+        finally:
+            dp.FC_WGRADS_GROUPED = old
+        res.append([w.grad.clone() for w in ws])
+    torch.cuda.synchronize()
+    for a, b, x, gy in zip(res[0], res[1], xs, gys):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    want = gys[2].double().t() @ xs[2].double() + 1.0
+    assert float((res[0][2].double() - want).abs().max()) <= 3e-6 * float(want.abs().max())
