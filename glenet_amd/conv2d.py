@@ -38,20 +38,25 @@ _packs = {}
 STEP_PACKS = None
 
 
+# A weight whose forward image the strided layer's kernel reads (csrc/glx_deconv2d.hip: bf16x3 whatever the process arithmetic
+# is) carries the attribute _glx_strided_pack (set at its first strided call); prepack() packs it accordingly.
+
+
 def prepack(weights):
-    """Both piece images of every (Cout, Cin, 3, 3) weight in `weights` with ONE launch (glx_conv3x3_pack_multi),
+    """Both piece images of every (Cout, Cin, 3, 3) weight in `weights` with ONE launch (glx_conv3x3_pack_multi_arith),
     parked in STEP_PACKS for packs() to hand out."""
     global STEP_PACKS
     STEP_PACKS = {}
     jobs = []
     for w in weights:
+        kind = "bf16x3" if getattr(w, "_glx_strided_pack", False) else arithmetic()
         w = w.detach()
         cout, cin = int(w.shape[0]), int(w.shape[1])
         if not (w.is_cuda and w.dtype == torch.float32 and tuple(w.shape[2:]) == (3, 3) and cout % 64 == 0 and cin % 64 == 0):
             continue
         n = query("glx_conv3x3_packed_bytes", cin, cout)
         jobs.append((w, cin, cout, torch.empty(n, dtype=torch.uint8, device=w.device),
-                     torch.empty(n, dtype=torch.uint8, device=w.device)))
+                     torch.empty(n, dtype=torch.uint8, device=w.device), kind))
     if not jobs:
         return
     n = len(jobs)
@@ -61,19 +66,46 @@ def prepack(weights):
     couts = (ctypes.c_int32 * n)(*[j[2] for j in jobs])
     fwd = (ctypes.c_void_p * n)(*[j[3].data_ptr() for j in jobs])
     bwd = (ctypes.c_void_p * n)(*[j[4].data_ptr() for j in jobs])
-    call("glx_conv3x3_pack_multi", n, ptrs, strides, cins, couts, fwd, bwd)
+    kinds = (ctypes.c_int32 * n)(*[1 if j[5] == "f16x2" else 0 for j in jobs])
+    call("glx_conv3x3_pack_multi_arith", n, ptrs, strides, cins, couts, fwd, bwd, kinds)
     for j in jobs:
-        STEP_PACKS[(j[0].data_ptr(), tuple(j[0].stride()))] = (j[3], j[4])
+        STEP_PACKS[(j[0].data_ptr(), tuple(j[0].stride()))] = (j[3], j[4], j[5])
 
 
-def packs(weight):
+def arithmetic():
+    """'f16x2' (default) or 'bf16x3': how the forward / input-gradient kernel forms its fp32 products (csrc/glx_conv2d.hip;
+    env GLX_CONV3X3_ARITH)."""
+    return "f16x2" if query("glx_conv3x3_get_arith") else "bf16x3"
+
+
+def set_arithmetic(name):
+    """Switch the process to 'f16x2' or 'bf16x3'; the cached packs are dropped (they carry the layout of the arithmetic they
+    were made under).  Not while a recorded step that holds packs is alive: its replays would read the old layout."""
+    if name not in ("f16x2", "bf16x3"):
+        raise ValueError("conv3x3 arithmetic is 'f16x2' or 'bf16x3', got %r" % (name,))
+    old = arithmetic()
+    if name != old:
+        _lib.load().glx_conv3x3_set_arith(1 if name == "f16x2" else 0)
+        _packs.clear()
+        _lib.bump_weights_epoch()
+    return old
+
+
+def packs(weight, strided=False):
     """(fwd, bwd) piece images of a (Cout, Cin, 3, 3) weight; rebuilt when the weights epoch or the tensor's version
-    moves (one launch writes both)."""
+    moves (one launch writes both).  strided: the images for glx_conv3x3s2_forward* (the bf16x3 layout whatever the process
+    arithmetic is)."""
+    kind = "bf16x3" if strided else arithmetic()
+    if strided and not getattr(weight, "_glx_strided_pack", False):
+        try:
+            weight._glx_strided_pack = True
+        except AttributeError:
+            pass
     if STEP_PACKS is not None:
         hit = STEP_PACKS.get((weight.data_ptr(), tuple(weight.stride())))
-        if hit is not None:
-            return hit
-    key = (weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()))
+        if hit is not None and hit[2] == kind:
+            return hit[0], hit[1]
+    key = (weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()), kind)
     tag = (_lib.weights_epoch(weight), weight._version)
     hit = _packs.get(key)
     if hit is not None and hit[3]() is not weight:
@@ -89,7 +121,8 @@ def packs(weight):
         bwd = torch.empty(n, dtype=torch.uint8, device=weight.device)
     s = weight.stride()
     ll = ctypes.c_longlong
-    call("glx_conv3x3_pack", weight.detach(), ll(s[0]), ll(s[1]), ll(s[2]), ll(s[3]), cin, cout, fwd, bwd)
+    call("glx_conv3x3_pack_arith", weight.detach(), ll(s[0]), ll(s[1]), ll(s[2]), ll(s[3]), cin, cout, fwd, bwd,
+         1 if kind == "f16x2" else 0)
     _packs[key] = (tag, fwd, bwd, weakref.ref(weight))
     return fwd, bwd
 
@@ -409,7 +442,7 @@ def conv3x3_affine(x, weight, scale, shift, relu):
 
 def conv3x3s2_affine(x, weight, scale, shift, relu):
     """The same for the strided layer (3x3, stride 2, zero padding 1; even maps)."""
-    fwd, _ = packs(weight)
+    fwd, _ = packs(weight, strided=True)
     b, c, h, w = x.shape
     cout = int(weight.shape[0])
     y = torch.empty((b, cout, h // 2, w // 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)

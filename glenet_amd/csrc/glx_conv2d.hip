@@ -20,6 +20,8 @@
 // is the same kernel on the flipped, transposed pack (written by the same pack launch).
 #include "glx_common.h"
 #include <stdlib.h>
+#include <string.h>
+#include <type_traits>
 #include "glx_bn_state.h"
 #include "glx_bf16x3.h"
 
@@ -44,6 +46,33 @@
 #define CV_LDS (3 * CV_APLANE + 2 * CV_WBUF)   // 88 704 (the first form: kept for experiments, one block per CU at this row size)
 #define CV_ALOADS ((CV_HP * 8 + 255) / 256)    // 16-byte pieces of the halo per thread (6)
 
+// Arithmetic of the forward / input-gradient kernel (k_conv3x3_v2<.., F16>), chosen per process (GLX_CONV3X3_ARITH = f16x2 |
+// bf16x3, glx_conv3x3_set_arith; the packs carry the layout of the arithmetic they were made under):
+//   f16x2 (default): fp32 products from TWO fp16 pieces per operand and THREE MFMAs (a a', a b', b a').  fp16 has 11 significand
+//     bits and a narrow exponent, so both operands are scaled by powers of two (exact) into fp16's range first: the filter per
+//     OUTPUT channel once, by the pack kernels (exponent array behind the planes); the halo image per staged 32-channel chunk by
+//     the maximum over the block's chunk, kept as a running exponent of the tile -- a later chunk with larger values lowers it
+//     and the accumulators are rescaled (ldexp: exact) -- and taken out in the epilogue.  An operand carries 22 bits where its
+//     second piece is a normal fp16 number (values within 2^-18 of the maximum of their 10 x 18 pixel x 32 channel chunk; below
+//     that the absolute resolution is 2^-39 of that maximum), a product >= 20.5 bits (measured 2^-21.1 at worst on full-
+//     significand operands): the error against an fp64 convolution stays that of the vendor's fp32 kernels
+//     (tests/test_conv2d_gpu.py).  Half the matrix instructions, two LDS planes instead of three: 34 / 37 us where bf16x3 takes
+//     49 / 54 (64 -> 64 @ 4 x 200 x 176 | 128 -> 128 @ 4 x 100 x 88), 5.70 against 6.01 ms on the training step.
+//   bf16x3: three bf16 pieces (24 bits, fp32's own exponent range: no scaling), six MFMAs, products exact to 2^-22 whatever the
+//     operands' magnitudes.  The weight gradient (k_conv3x3_wgrad) and glx_deconv2d.hip use this form regardless: their time
+//     is not in the matrix pipe (profiles/r05_bev_mfma.md 3b).
+static int env_conv_f16() {
+  const char* e = getenv("GLX_CONV3X3_ARITH");
+  return !(e && (!strcmp(e, "bf16x3") || !strcmp(e, "0")));
+}
+static int g_conv_f16 = env_conv_f16();
+extern "C" int glx_conv3x3_set_arith(int f16x2) {        // returns the previous setting; packs made before are stale afterwards
+  const int old = g_conv_f16;
+  g_conv_f16 = f16x2 ? 1 : 0;
+  return old;
+}
+extern "C" int glx_conv3x3_get_arith(void) { return g_conv_f16; }
+
 // W (Cout, Cin, 3, 3) with element strides (s_co, s_ci, s_kh, s_kw) ->
 //   fwd [tap][Cin/32][3][Cout][32]   (the conv itself)
 //   bwd [tap'][Cout/32][3][Cin][32]  (its input gradient: a conv Cout -> Cin with W'[ci][co][kh'][kw'] = W[co][ci][2-kh'][2-kw'])
@@ -53,9 +82,40 @@ struct ConvPackJob {
   int Cin, Cout;
   uint16_t* fwd;
   uint16_t* bwd;
+  int f16;               // 1: two fp16 planes + the exponent arrays, 0: three bf16 planes
 };
 #define CV_PACK_MAX_JOBS 16
 struct ConvPackJobs { ConvPackJob j[CV_PACK_MAX_JOBS]; };
+
+// the planes of an f16x2 pack are followed by its exponent array: int32 per output channel of the pack's convolution
+__host__ __device__ inline size_t cv_pack_plane_elems(int Cin, int Cout, int npl) { return (size_t)9 * npl * Cin * Cout; }
+
+// f16x2: e[c] = 14 - floor(log2 max |W[c]|) over the filter of output channel c -- of the convolution itself (block < Cout:
+// c = co, maximum over ci and the taps) and of its input gradient (block >= Cout: c = ci, maximum over co and the taps)
+__global__ __launch_bounds__(256) void k_conv3x3_wexp(ConvPackJobs jobs) {      // blockIdx.y = job, blockIdx.x = channel
+  const ConvPackJob jb = jobs.j[blockIdx.y];
+  const int Cin = jb.Cin, Cout = jb.Cout;
+  if (!jb.f16 || (int)blockIdx.x >= Cin + Cout) return;
+  const bool fwd = (int)blockIdx.x < Cout;
+  const int c = fwd ? blockIdx.x : blockIdx.x - Cout, n = (fwd ? Cin : Cout) * 9;
+  uint16_t* dst = fwd ? jb.fwd : jb.bwd;
+  if (!dst) return;
+  float m = 0.f;
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int o = e / 9, tap = e % 9;
+    const int co = fwd ? c : o, ci = fwd ? o : c;
+    m = fmaxf(m, fabsf(jb.W[co * jb.s_co + ci * jb.s_ci + (tap / 3) * jb.s_kh + (tap % 3) * jb.s_kw]));
+  }
+  __shared__ float s_m[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int e = cv_block_exponent(fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3])));
+    reinterpret_cast<int*>(dst + cv_pack_plane_elems(Cin, Cout, 2))[c] = e == 127 ? 0 : e;
+  }
+}
 
 __global__ void k_conv3x3_pack(ConvPackJobs jobs) {      // blockIdx.y = job
   const ConvPackJob jb = jobs.j[blockIdx.y];
@@ -65,6 +125,23 @@ __global__ void k_conv3x3_pack(ConvPackJobs jobs) {      // blockIdx.y = job
   const int ci = e % Cin, co = (e / Cin) % Cout, tap = e / (Cin * Cout);
   const int kh = tap / 3, kw = tap % 3;
   const float w = jb.W[co * jb.s_co + ci * jb.s_ci + kh * jb.s_kh + kw * jb.s_kw];
+  if (jb.f16) {
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+      uint16_t* dst = dir ? jb.bwd : jb.fwd;
+      if (!dst) continue;
+      const int ex = reinterpret_cast<const int*>(dst + cv_pack_plane_elems(Cin, Cout, 2))[dir ? ci : co];
+      _Float16 p[2];
+      cv_split2(ldexpf(w, ex), p[0], p[1]);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const uint16_t bits = __builtin_bit_cast(uint16_t, p[q]);
+        if (dir) dst[((((size_t)(8 - tap) * (Cout / 32) + co / 32) * 2 + q) * Cin + ci) * 32 + (co & 31)] = bits;
+        else dst[((((size_t)tap * (Cin / 32) + ci / 32) * 2 + q) * Cout + co) * 32 + (ci & 31)] = bits;
+      }
+    }
+    return;
+  }
   __bf16 p[3];
   cv_split(w, p[0], p[1], p[2]);
 #pragma unroll
@@ -78,6 +155,7 @@ __global__ void k_conv3x3_pack(ConvPackJobs jobs) {      // blockIdx.y = job
 struct ConvArgs {
   const float* x;        // (B, H, W, Cin)
   const uint16_t* wp;    // packed pieces
+  const int* wexp;       // f16x2: the pack's exponent per output channel
   float* y;              // (B, H, W, Cout)
   int B, H, W, Cin, Cout, tiles_x, tiles_y, nblk, ntiles;   // nblk = Cout / 64; ntiles = B * tiles_y * tiles_x * nblk
   int th;                // pixel rows per tile (CV_TH; the second form picks 6, 7 or 8 per launch)
@@ -368,18 +446,21 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
 #ifndef CV_ABL
 #define CV_ABL 0
 #endif
-template <bool STATS, int TH, bool PRE = false, bool BWD = false>
+template <bool STATS, int TH, bool PRE, bool BWD, bool F16>
 __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
+  constexpr int NPL = F16 ? 2 : 3;      // operand planes
   static_assert(!(BWD && (STATS || PRE)), "BWD is a mode of the plain input-gradient launch");
   constexpr int HP = (TH + 2) * CV_HW, NL = (HP * 8 + 255) / 256, PLANE = HP * CV_ROW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;
-  float* s_pre = reinterpret_cast<float*>(smem + 3 * PLANE);      // PRE: scale[Cin], shift[Cin]
+  float* s_max = reinterpret_cast<float*>(smem + NPL * PLANE);     // f16x2: the waves' maxima of the staged chunk
+  float* s_pre = reinterpret_cast<float*>(smem + NPL * PLANE + 16);      // PRE: scale[Cin], shift[Cin]
   if constexpr (PRE) {
     for (int e = threadIdx.x; e < a.Cin; e += 256) {
       s_pre[e] = a.pre_scale[e];
       s_pre[a.Cin + e] = a.pre_shift[e];
     }
+    __syncthreads();          // the first chunk is transformed in front of the loop's first barrier
   }
   if constexpr (BWD) {                                             // scale, shift, mean, invstd of the BatchNorm: 4 x Cout
     for (int e = threadIdx.x; e < a.Cout; e += 256) {
@@ -405,7 +486,8 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
   // the lane's 16 bytes of a plane of a weight slice: channel n0 + 16 wave + r, k = 8 kq ..
   const uint16_t* wsrc = a.wp + (size_t)(ct.n0 + 16 * wave + r) * 32 + kq * 8;
   f32x4 areg[NL];
-  bf16x8 wcur[3], wnxt[3];
+  typedef typename std::conditional<F16, f16x8, bf16x8>::type cvop8;
+  cvop8 wcur[NPL], wnxt[NPL];
 #define V2_HALO(T)                                                                                      \
   _Pragma("unroll") for (int i_ = 0; i_ < NL; ++i_) {                                                   \
     const int e_ = tid + i_ * 256;                                                                      \
@@ -417,11 +499,11 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
 #define V2_LOAD_A(CH)                                                                                   \
   _Pragma("unroll") for (int i_ = 0; i_ < NL; ++i_)                                                     \
     areg[i_] = aoff[i_] >= 0 ? *reinterpret_cast<const f32x4*>(a.x + aoff[i_] + (CH) * 32) : f32x4{0.f, 0.f, 0.f, 0.f};
-#define V2_STORE_A()                                                                                    \
-  _Pragma("unroll") for (int i_ = 0; i_ < NL; ++i_) {                                                   \
-    if (tid + i_ * 256 < HP * 8) {                                                                      \
-      char* d_ = sA + adst0 + i_ * 32 * CV_ROW;                                                         \
-      bf16x4 p0_, p1_, p2_;                                                                             \
+// the staged chunk, transformed in place (PRE); f16x2: and the block's maximum of it on its way (s_max, read behind the barrier)
+#define V2_PREP_A()                                                                                     \
+  {                                                                                                     \
+    float m_ = 0.f;                                                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < NL; ++i_) {                                                 \
       if (PRE && aoff[i_] >= 0) {                                                                       \
         const f32x4 sc_ = *reinterpret_cast<const f32x4*>(s_pre + pre_ch * 32 + (tid & 7) * 4);         \
         const f32x4 sh_ = *reinterpret_cast<const f32x4*>(s_pre + a.Cin + pre_ch * 32 + (tid & 7) * 4); \
@@ -430,6 +512,50 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
           areg[i_][j_] = a.pre_relu ? fmaxf(t_, 0.f) : t_;                                              \
         }                                                                                               \
       }                                                                                                 \
+      if (F16) {                                                                                        \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) m_ = fmaxf(m_, fabsf(areg[i_][j_]));           \
+      }                                                                                                 \
+    }                                                                                                   \
+    if (F16) {                                                                                          \
+      _Pragma("unroll") for (int o_ = 32; o_ > 0; o_ >>= 1) m_ = fmaxf(m_, __shfl_xor(m_, o_, 64));     \
+      if (lane == 0) s_max[wave] = m_;                                                                  \
+    }                                                                                                   \
+  }
+// f16x2: the running exponent of the tile follows the chunk's maximum down (accumulators rescaled: exact), the chunk is converted
+// at it; bf16x3: three pieces as they are
+#define V2_STORE_A()                                                                                    \
+  if constexpr (F16)                                                                                    \
+  {                                                                                                     \
+    const float bm_ = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));                      \
+    const int ex_ = __builtin_amdgcn_readfirstlane(cv_block_exponent(bm_));                             \
+    if (ex_ < etile) {                                                                                  \
+      if (etile != 127) {                                                                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < TH; ++i_)                                               \
+          _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) acc[i_][j_] = ldexpf(acc[i_][j_], ex_ - etile); \
+      }                                                                                                 \
+      etile = ex_;                                                                                      \
+    }                                                                                                   \
+    const int es_ = etile == 127 ? 0 : etile;                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < NL; ++i_) {                                                 \
+      if (tid + i_ * 256 < HP * 8) {                                                                    \
+        char* d_ = sA + adst0 + i_ * 32 * CV_ROW;                                                       \
+        f16x4 p0_, p1_;                                                                                 \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                              \
+          _Float16 u_, v_;                                                                              \
+          cv_split2(ldexpf(areg[i_][j_], es_), u_, v_);                                                 \
+          p0_[j_] = u_; p1_[j_] = v_;                                                                   \
+        }                                                                                               \
+        *reinterpret_cast<f16x4*>(d_) = p0_;                                                            \
+        *reinterpret_cast<f16x4*>(d_ + PLANE) = p1_;                                                    \
+      }                                                                                                 \
+    }                                                                                                   \
+  }                                                                                                     \
+  else                                                                                                  \
+  {                                                                                                     \
+  _Pragma("unroll") for (int i_ = 0; i_ < NL; ++i_) {                                                   \
+    if (tid + i_ * 256 < HP * 8) {                                                                      \
+      char* d_ = sA + adst0 + i_ * 32 * CV_ROW;                                                         \
+      bf16x4 p0_, p1_, p2_;                                                                             \
       _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                \
         __bf16 u_, v_, w_;                                                                              \
         cv_split(areg[i_][j_], u_, v_, w_);                                                             \
@@ -439,13 +565,12 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
       *reinterpret_cast<bf16x4*>(d_ + PLANE) = p1_;                                                     \
       *reinterpret_cast<bf16x4*>(d_ + 2 * PLANE) = p2_;                                                 \
     }                                                                                                   \
+  }                                                                                                     \
   }
 #define V2_LOAD_W(DST, SRC, TAP, CH)                                                                    \
   {                                                                                                     \
-    const uint16_t* s_ = (SRC) + ((size_t)(TAP) * nch + (CH)) * 3 * wslice;                             \
-    DST[0] = *reinterpret_cast<const bf16x8*>(s_);                                                      \
-    DST[1] = *reinterpret_cast<const bf16x8*>(s_ + wslice);                                             \
-    DST[2] = *reinterpret_cast<const bf16x8*>(s_ + 2 * wslice);                                         \
+    const uint16_t* s_ = (SRC) + ((size_t)(TAP) * nch + (CH)) * NPL * wslice;                        \
+    _Pragma("unroll") for (int q_ = 0; q_ < NPL; ++q_) DST[q_] = *reinterpret_cast<const cvop8*>(s_ + q_ * wslice); \
   }
   float ssum[4], ssq[4];
 #pragma unroll
@@ -460,6 +585,8 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
     f32x4 acc[TH];
 #pragma unroll
     for (int i = 0; i < TH; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int etile = 127;          // f16x2: the exponent the tile's chunks are converted at (127: nothing but zeros so far)
+    (void)etile;
     const int next = tile + gridDim.x;
     const bool has_next = next < a.ntiles;
     ConvTile nt = ct;
@@ -469,16 +596,17 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
       wnext_src = a.wp + (size_t)(nt.n0 + 16 * wave + r) * 32 + kq * 8;
     }
     for (int ch = 0; ch < nch; ++ch) {
-      if (!(CV_ABL & 8) && !((CV_ABL & 4) && ch > 0)) __syncthreads();   // everyone is done reading the previous halo image
       const int pre_ch = ch;              // the thread's four channels of the staged chunk: 32 ch + 4 (tid & 7) ..
       (void)pre_ch;
+      if (!((CV_ABL & 4) && ch > 0)) { V2_PREP_A(); }
+      if (!(CV_ABL & 8) && !((CV_ABL & 4) && ch > 0)) __syncthreads();   // everyone is done reading the previous halo image
       if (!((CV_ABL & 4) && ch > 0)) { V2_STORE_A(); }
       if (!(CV_ABL & 8) && !((CV_ABL & 4) && ch > 0)) __syncthreads();
       const bool last = ch + 1 == nch;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) wcur[q] = wnxt[q];
+        for (int q = 0; q < NPL; ++q) wcur[q] = wnxt[q];
         if (!((CV_ABL & 2) && (ch > 0 || tap > 0))) {
         if (tap < 8) {
           V2_LOAD_W(wnxt, wsrc, tap + 1, ch);
@@ -499,17 +627,17 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
         const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
         for (int part = 0; part < (TH + 1) / 2; ++part) {     // two pixel rows at a time: 6 operand reads, 12 products
-          bf16x8 xa[2][3];
+          cvop8 xa[2][NPL];
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             if (2 * part + i < TH) {
               const int hp = (2 * part + i + dy) * CV_HW + r + dx;
               if ((CV_ABL & 1) && (tap > 0 || ch > 0)) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) xa[i][q] = wcur[(q + i) % 3];
+                for (int q = 0; q < NPL; ++q) xa[i][q] = wcur[(q + i) % NPL];
               } else {
 #pragma unroll
-              for (int q = 0; q < 3; ++q) xa[i][q] = *reinterpret_cast<const bf16x8*>(aBase + q * PLANE + hp * CV_ROW);
+              for (int q = 0; q < NPL; ++q) xa[i][q] = *reinterpret_cast<const cvop8*>(aBase + q * PLANE + hp * CV_ROW);
               }
             }
           }
@@ -517,14 +645,29 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
 #pragma unroll
           for (int i = 0; i < 2; ++i)
             if (2 * part + i < TH) {
-              if (CV_ABL & 16) acc[2 * part + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur[0], xa[i][0], acc[2 * part + i], 0, 0, 0);
-              else BF3_MFMA6(acc[2 * part + i], wcur, xa[i]);
+              if constexpr (F16) {
+                if (CV_ABL & 16) acc[2 * part + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wcur[0], xa[i][0], acc[2 * part + i], 0, 0, 0);
+                else F2_MFMA3(acc[2 * part + i], wcur, xa[i]);
+              } else {
+                if (CV_ABL & 16) acc[2 * part + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur[0], xa[i][0], acc[2 * part + i], 0, 0, 0);
+                else BF3_MFMA6(acc[2 * part + i], wcur, xa[i]);
+              }
             }
           __builtin_amdgcn_sched_barrier(0);       // hoisting later parts' operands (170-register budget, 3 waves / SIMD)
         }
       }
     }
     // ---- epilogue: accumulator i = pixel row i, column r; channels n0 + 16 wave + 4 kq ..
+    if constexpr (F16) {      // the two operands' exponents come out again (exact)
+      const int et = etile == 127 ? 0 : etile;
+      int ew[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) ew[g] = -(et + a.wexp[ct.n0 + 16 * wave + 4 * kq + g]);
+#pragma unroll
+      for (int i = 0; i < TH; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[i][g] = ldexpf(acc[i][g], ew[g]);
+    }
 #pragma unroll
     for (int i = 0; i < TH; ++i) {
       const int py = ct.y0 + i, px = ct.x0 + r;
@@ -938,37 +1081,58 @@ static int conv_pack_check(int Cin, int Cout, const void* fwd, const void* bwd) 
   return GLX_OK;
 }
 
-extern "C" int glx_conv3x3_pack(const float* W, long long s_co, long long s_ci, long long s_kh, long long s_kw,
-                                int Cin, int Cout, void* fwd, void* bwd, void* stream) {
+// f16x2: 1 / 0 = the layout of that arithmetic, -1 = the process setting (glx_conv3x3_set_arith).  The strided layer's forward
+// (glx_conv3x3s2_forward*, csrc/glx_deconv2d.hip) reads the bf16x3 forward image whatever the process setting is.
+extern "C" int glx_conv3x3_pack_arith(const float* W, long long s_co, long long s_ci, long long s_kh, long long s_kw,
+                                      int Cin, int Cout, void* fwd, void* bwd, int f16x2, void* stream) {
   const int rc = conv_pack_check(Cin, Cout, fwd, bwd);
   if (rc != GLX_OK) return rc;
+  const int f16 = f16x2 < 0 ? g_conv_f16 : (f16x2 ? 1 : 0);
   ConvPackJobs jobs;
-  jobs.j[0] = ConvPackJob{W, s_co, s_ci, s_kh, s_kw, Cin, Cout, (uint16_t*)fwd, (uint16_t*)bwd};
+  jobs.j[0] = ConvPackJob{W, s_co, s_ci, s_kh, s_kw, Cin, Cout, (uint16_t*)fwd, (uint16_t*)bwd, f16};
+  if (f16) hipLaunchKernelGGL(k_conv3x3_wexp, dim3(Cin + Cout, 1), dim3(256), 0, (hipStream_t)stream, jobs);
   hipLaunchKernelGGL(k_conv3x3_pack, dim3(glx_divup(Cin * Cout * 9, 256), 1), dim3(256), 0, (hipStream_t)stream, jobs);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
 
+extern "C" int glx_conv3x3_pack(const float* W, long long s_co, long long s_ci, long long s_kh, long long s_kw,
+                                int Cin, int Cout, void* fwd, void* bwd, void* stream) {
+  return glx_conv3x3_pack_arith(W, s_co, s_ci, s_kh, s_kw, Cin, Cout, fwd, bwd, -1, stream);
+}
+
 // n weights in one launch (CV_PACK_MAX_JOBS per launch); arrays of length n on the HOST, strides[4 * i ..] = s_co, s_ci,
-// s_kh, s_kw of weight i
-extern "C" int glx_conv3x3_pack_multi(int n, const float* const* W, const long long* strides, const int32_t* Cin,
-                                      const int32_t* Cout, void* const* fwd, void* const* bwd, void* stream) {
+// s_kh, s_kw of weight i; f16x2: per weight 1 / 0 / -1 as above, NULL = the process setting for all
+extern "C" int glx_conv3x3_pack_multi_arith(int n, const float* const* W, const long long* strides, const int32_t* Cin,
+                                            const int32_t* Cout, void* const* fwd, void* const* bwd, const int32_t* f16x2,
+                                            void* stream) {
   if (n <= 0) return GLX_OK;
   GLX_REQUIRE(W && strides && Cin && Cout && fwd && bwd, "glx_conv3x3_pack_multi: null pointer");
   for (int done = 0; done < n;) {
     ConvPackJobs jobs;
-    int nj = 0, cover = 0;
+    int nj = 0, cover = 0, chans = 0, any16 = 0;
     for (; done < n && nj < CV_PACK_MAX_JOBS; ++done, ++nj) {
       const int rc = conv_pack_check(Cin[done], Cout[done], fwd[done], bwd[done]);
       if (rc != GLX_OK) return rc;
+      const int f16 = (!f16x2 || f16x2[done] < 0) ? g_conv_f16 : (f16x2[done] ? 1 : 0);
       jobs.j[nj] = ConvPackJob{W[done], strides[4 * done], strides[4 * done + 1], strides[4 * done + 2], strides[4 * done + 3],
-                               Cin[done], Cout[done], (uint16_t*)fwd[done], (uint16_t*)bwd[done]};
+                               Cin[done], Cout[done], (uint16_t*)fwd[done], (uint16_t*)bwd[done], f16};
       cover = Cin[done] * Cout[done] * 9 > cover ? Cin[done] * Cout[done] * 9 : cover;
+      if (f16) {
+        any16 = 1;
+        chans = Cin[done] + Cout[done] > chans ? Cin[done] + Cout[done] : chans;
+      }
     }
+    if (any16) hipLaunchKernelGGL(k_conv3x3_wexp, dim3(chans, nj), dim3(256), 0, (hipStream_t)stream, jobs);
     hipLaunchKernelGGL(k_conv3x3_pack, dim3(glx_divup(cover, 256), nj), dim3(256), 0, (hipStream_t)stream, jobs);
   }
   GLX_LAUNCH_CHECK();
   return GLX_OK;
+}
+
+extern "C" int glx_conv3x3_pack_multi(int n, const float* const* W, const long long* strides, const int32_t* Cin,
+                                      const int32_t* Cout, void* const* fwd, void* const* bwd, void* stream) {
+  return glx_conv3x3_pack_multi_arith(n, W, strides, Cin, Cout, fwd, bwd, nullptr, stream);
 }
 
 static int env_conv_form() {
@@ -1008,6 +1172,21 @@ extern "C" int glx_conv3x3_set_grid(int blocks, int ablate) {
   if ((ablate >> 8) & 0xF) g_conv_form = (ablate >> 8) & 0xF;      // bits 8-11: 1 or 2 = the kernel form
   g_conv_th = (ablate >> 12) & 0xF;                                // bits 12-15: rows per tile of the second form
   return GLX_OK;
+}
+
+// the instantiations of the second form: (statistics epilogue | plain) x rows per tile x (plain | transform on load | bn_bwd) x arithmetic
+template <bool F16>
+static void (*conv_v2_kernel(bool stats, int th, bool pre, bool bwd))(ConvArgs) {
+  if (bwd) return th == 8 ? k_conv3x3_v2<false, 8, false, true, F16> : th == 7 ? k_conv3x3_v2<false, 7, false, true, F16>
+                                                                                : k_conv3x3_v2<false, 6, false, true, F16>;
+  if (pre) {
+    if (th == 8) return stats ? k_conv3x3_v2<true, 8, true, false, F16> : k_conv3x3_v2<false, 8, true, false, F16>;
+    if (th == 7) return stats ? k_conv3x3_v2<true, 7, true, false, F16> : k_conv3x3_v2<false, 7, true, false, F16>;
+    return stats ? k_conv3x3_v2<true, 6, true, false, F16> : k_conv3x3_v2<false, 6, true, false, F16>;
+  }
+  if (th == 8) return stats ? k_conv3x3_v2<true, 8, false, false, F16> : k_conv3x3_v2<false, 8, false, false, F16>;
+  if (th == 7) return stats ? k_conv3x3_v2<true, 7, false, false, F16> : k_conv3x3_v2<false, 7, false, false, F16>;
+  return stats ? k_conv3x3_v2<true, 6, false, false, F16> : k_conv3x3_v2<false, 6, false, false, F16>;
 }
 
 static long long* g_conv_stamps = nullptr;   // diagnostics: 2 x int64 per block of the following glx_conv3x3_forward launches
@@ -1054,7 +1233,9 @@ extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int C
     bn_state = (BnState*)bwd->state;
     bn_fin = BnFinalize{bwd->gamma, nullptr, 0.f, 0.f, bwd->coef, nullptr, nullptr, nullptr, nullptr, bwd->invstd, bwd->dgamma, bwd->dbeta};
   }
-  const bool v2 = (g_conv_form == 2 && g_conv_ablate == 0) || epi_scale || pre || bwd;   // epilogue / prologue / bn_bwd live in the second form
+  // epilogue / prologue / bn_bwd live in the second form; so does the fp16 arithmetic (the packs have ITS layout then)
+  const bool f16 = g_conv_f16 != 0;
+  const bool v2 = (g_conv_form == 2 && g_conv_ablate == 0) || epi_scale || pre || bwd || f16;
   int th = CV_TH;
   if (v2) {
     // rows per tile: the fewest (rounds of the resident blocks) x (rows + a fixed cost per tile)
@@ -1068,17 +1249,12 @@ extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int C
     if (g_conv_th >= 6 && g_conv_th <= 8) th = g_conv_th;
     // the BWD form (input gradient + ReLU mask + BatchNorm-backward sums in the epilogue) runs six rows per tile: at seven the
     // compiler spills 13 registers of its 168 (at eight, 23); 6.05 -> 6.02 ms per step (three alternating pairs, round 5)
-    static const int th_bwd = getenv("GLX_CONV3X3_TH_BWD") ? atoi(getenv("GLX_CONV3X3_TH_BWD")) : 6;
-    if (bwd && g_conv_th == 0 && th_bwd >= 6 && th_bwd <= 8) th = th_bwd;
-    if (bwd) {
-      kern = th == 8 ? k_conv3x3_v2<false, 8, false, true> : th == 7 ? k_conv3x3_v2<false, 7, false, true> : k_conv3x3_v2<false, 6, false, true>;
-    } else if (pre) {
-      if (th == 8) kern = bn_state ? k_conv3x3_v2<true, 8, true> : k_conv3x3_v2<false, 8, true>;
-      else if (th == 7) kern = bn_state ? k_conv3x3_v2<true, 7, true> : k_conv3x3_v2<false, 7, true>;
-      else kern = bn_state ? k_conv3x3_v2<true, 6, true> : k_conv3x3_v2<false, 6, true>;
-    } else if (th == 8) kern = bn_state ? k_conv3x3_v2<true, 8> : k_conv3x3_v2<false, 8>;
-    else if (th == 7) kern = bn_state ? k_conv3x3_v2<true, 7> : k_conv3x3_v2<false, 7>;
-    else kern = bn_state ? k_conv3x3_v2<true, 6> : k_conv3x3_v2<false, 6>;
+    // (the f16x2 form of it has room for the cost model's seven or eight: 162 / 166 registers, nothing spilled)
+    static const int th_bwd = getenv("GLX_CONV3X3_TH_BWD") ? atoi(getenv("GLX_CONV3X3_TH_BWD")) : -1;
+    const int thb = th_bwd >= 0 ? th_bwd : (f16 ? 0 : 6);
+    if (bwd && g_conv_th == 0 && thb >= 6 && thb <= 8) th = thb;
+    kern = f16 ? conv_v2_kernel<true>(bn_state != nullptr, th, pre != nullptr, bwd != nullptr)
+               : conv_v2_kernel<false>(bn_state != nullptr, th, pre != nullptr, bwd != nullptr);
   }
   if (!bn_state && !v2) {
     switch (g_conv_ablate) {
@@ -1092,11 +1268,11 @@ extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int C
     slot = g_conv_ablate & 7;
     if (slot == 7) slot = 0;
   }
-  const int lds_bytes = v2 ? 3 * (th + 2) * CV_HW * CV_ROW + (pre ? 2 * Cin * (int)sizeof(float) : 0) +
+  const int lds_bytes = v2 ? (f16 ? 2 : 3) * (th + 2) * CV_HW * CV_ROW + 16 + (pre ? 2 * Cin * (int)sizeof(float) : 0) +
                                  (bwd ? 4 * Cout * (int)sizeof(float) : 0) : CV_LDS;
   if (v2) {
-    static int v2_set[3][2][9] = {};      // largest dynamic LDS size registered per instantiation
-    int& reg = v2_set[bwd ? 2 : pre ? 1 : 0][(bn_state && !bwd) ? 1 : 0][th];
+    static int v2_set[2][3][2][9] = {};      // largest dynamic LDS size registered per instantiation
+    int& reg = v2_set[f16 ? 1 : 0][bwd ? 2 : pre ? 1 : 0][(bn_state && !bwd) ? 1 : 0][th];
     if (reg < lds_bytes) {
       GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
       reg = lds_bytes;
@@ -1110,6 +1286,7 @@ extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int C
   }
   ConvArgs a;
   a.x = x; a.wp = (const uint16_t*)packed; a.y = y;
+  a.wexp = reinterpret_cast<const int*>((const uint16_t*)packed + cv_pack_plane_elems(Cin, Cout, 2));
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.th = th;
   a.tiles_x = glx_divup(W, CV_TW); a.tiles_y = glx_divup(H, th);

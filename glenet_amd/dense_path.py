@@ -85,7 +85,7 @@ class _OwnStridedForward(torch.autograd.Function):
         from ._lib import call
         b, c, h, wd = x.shape
         cout = int(w.shape[0])
-        fwd, _ = own_conv.packs(w)
+        fwd, _ = own_conv.packs(w, strided=True)
         xd = x.detach()
         y = torch.empty((b, cout, h // 2, wd // 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         ctx.cfg = ((2, 2), (1, 1), (1, 1), False, (0, 0), 1)

@@ -1104,6 +1104,19 @@ size_t glx_topk_workspace_bytes(int frames, int K);
 int glx_topk_desc_ws(const float* scores, int frames, int A, int K, float* top, int64_t* order, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* Arithmetic of glx_conv3x3_forward[_ex] (and of the packs it reads), per process: 1 = f16x2 (default: two fp16 pieces per operand,
+ * scaled per output channel / per staged chunk by powers of two, three MFMAs per product tile), 0 = bf16x3 (three bf16 pieces, six
+ * MFMAs, products exact to 2^-22 at any magnitude).  env GLX_CONV3X3_ARITH=bf16x3 selects 0 at load.  set returns the previous value;
+ * packs written under the other setting must be rewritten (glx_conv3x3_pack) before the next convolution reads them.
+ * base_bev_backbone.py:30-49's nn.Conv2d(3 x 3, stride 1) layers. */
+int glx_conv3x3_set_arith(int f16x2);
+int glx_conv3x3_get_arith(void);
+/* glx_conv3x3_pack / glx_conv3x3_pack_multi with the layout named per call / per weight: f16x2 = 1 / 0, -1 = the process setting
+ * (f16x2 array NULL = the process setting for all).  glx_conv3x3s2_forward* reads the bf16x3 forward image whatever the setting. */
+int glx_conv3x3_pack_arith(const float* W, long long s_co, long long s_ci, long long s_kh, long long s_kw, int Cin, int Cout,
+                           void* fwd, void* bwd, int f16x2, void* stream);
+int glx_conv3x3_pack_multi_arith(int n, const float* const* W, const long long* strides, const int32_t* Cin, const int32_t* Cout,
+                                 void* const* fwd, void* const* bwd, const int32_t* f16x2, void* stream);
 /* ---- dense 3x3 convolutions of the BEV backbone (stride 1, zero padding 1, channels-last fp32 maps) ----------------
  * Replaces, for the 3x3 / stride-1 layers: nn.Conv2d(c, c, 3, padding=1, bias=False) and ZeroPad2d(1) + Conv2d(.., 3)
  * of BaseBEVBackbone (pcdet/models/backbones_2d/base_bev_backbone.py:30-49), which the reference runs through cuDNN.

@@ -1,7 +1,9 @@
 """glenet_amd.conv2d (csrc/glx_conv2d.hip): the 3x3 / stride-1 / pad-1 convolutions of the BEV backbone
-(pcdet/models/backbones_2d/base_bev_backbone.py:30-49) computed as six bf16 matrix products of three-way split fp32
-operands.  Checked against an fp64 convolution (tolerance: a few fp32 roundings of the largest output, and never more
-than a small multiple of the library's own fp32 error), exactly on integer data, and through autograd."""
+(pcdet/models/backbones_2d/base_bev_backbone.py:30-49) computed on the 16-bit matrix pipe from split fp32 operands: the forward /
+input-gradient kernel as three fp16 products of two-way split, power-of-two scaled operands (f16x2, the default) or six bf16
+products of three-way split operands (bf16x3, GLX_CONV3X3_ARITH / conv2d.set_arithmetic), the weight gradient always as bf16x3.
+Checked against an fp64 convolution (tolerance: a few fp32 roundings of the largest output, and never more than a small multiple
+of the library's own fp32 error), exactly on integer data, through autograd, and over wide dynamic ranges."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -39,7 +41,7 @@ def test_conv3x3_matches_fp64_convolution(dev, shape):
 
 
 def test_conv3x3_is_exact_on_integer_data_with_asymmetric_filters(dev):
-    """Small integers are exact in every bf16 piece and every partial sum: any operand-layout or tap-order mistake
+    """Small integers are exact in every piece (bf16 or scaled fp16) and every partial sum: any operand-layout or tap-order mistake
     shows as a wrong integer.  Filters differ in every (tap, cin, cout), inputs in every pixel and channel."""
     from glenet_amd import conv2d as c2
     b, cin, cout, h, w = 2, 64, 128, 13, 21
@@ -56,10 +58,20 @@ def test_conv3x3_is_exact_on_integer_data_with_asymmetric_filters(dev):
     assert torch.equal(gx.double().cpu(), gref)
 
 
-def test_split_products_carry_full_fp32_significands(dev):
-    """One tap, one input channel live: every output is a single product x * w of two full-significand fp32 numbers;
-    the six piece products must reproduce it to 2^-22 (the dropped piece products are below 2^-23 of it)."""
+@pytest.fixture(params=["f16x2", "bf16x3"])
+def arith(request, dev):
     from glenet_amd import conv2d as c2
+    old = c2.set_arithmetic(request.param)
+    yield request.param
+    c2.set_arithmetic(old)
+
+
+def test_split_products_carry_fp32_class_significands(arith):
+    """One tap, one input channel live: every output is a single product x * w of two full-significand fp32 numbers.  bf16x3: the
+    six piece products reproduce it to 2^-22 (the dropped ones are below 2^-23 of it).  f16x2: each operand keeps 22 bits (two
+    11-bit pieces), the dropped b b' product is below 2^-22: 2^-20.4 at worst, measured 2^-21.1."""
+    from glenet_amd import conv2d as c2
+    dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(11)
     x = torch.zeros(1, 64, 8, 16, device=dev)
     x[:, 5] = torch.rand(1, 8, 16, device=dev, generator=g) + 1.0
@@ -67,7 +79,82 @@ def test_split_products_carry_full_fp32_significands(dev):
     wt[:, 5, 1, 1] = torch.rand(64, device=dev, generator=g) + 1.0
     y = c2.conv3x3(_cl(x), wt)
     ref = x[:, 5:6].double() * wt[:, 5, 1, 1].double().view(1, 64, 1, 1)
-    assert ((y.double() - ref).abs() / ref.abs()).max() < 2.0 ** -22
+    assert ((y.double() - ref).abs() / ref.abs()).max() < (2.0 ** -22 if arith == "bf16x3" else 2.0 ** -20.4)
+
+
+def test_both_arithmetics_match_fp64_on_the_bev_shapes(arith):
+    """Forward and input gradient of the block layers' shapes under either arithmetic: within 2 x the vendor fp32 kernels' error
+    against fp64 (+ 3e-7 of the largest output), 3 x for the input gradient."""
+    from glenet_amd import conv2d as c2
+    dev = torch.device("cuda", 0)
+    for b, cin, cout, h, w in BEV_SHAPES:
+        g = torch.Generator(device=dev).manual_seed(cin + h)
+        x = _cl(torch.randn(b, cin, h, w, device=dev, generator=g))
+        gy = _cl(torch.randn(b, cout, h, w, device=dev, generator=g))
+        wt = torch.randn(cout, cin, 3, 3, device=dev, generator=g) / (3 * cin ** 0.5)
+        fwd, bwd = c2.packs(wt)
+        for got, ref, lib in ((c2._run(x, fwd, cout), F.conv2d(x.double(), wt.double(), None, 1, 1), F.conv2d(x, wt, None, 1, 1)),
+                              (c2._run(gy, bwd, cin), F.conv_transpose2d(gy.double(), wt.double(), None, 1, 1),
+                               F.conv_transpose2d(gy, wt, None, 1, 1))):
+            scale = ref.abs().max()
+            err, err_lib = (got.double() - ref).abs().max() / scale, (lib.double() - ref).abs().max() / scale
+            # (the vendor's transposed convolution is the tighter of its two kernels: bf16x3's input gradient measures 2.6 x it)
+            assert err < 3.0 * err_lib + 3e-7, (arith, float(err), float(err_lib))
+
+
+@pytest.mark.parametrize("case", ["scaled", "halves", "chunks", "zeros", "tiny", "huge"])
+def test_f16x2_scaling_follows_the_data(dev, case):
+    """The f16x2 form scales every staged 32-channel chunk of a tile by its own maximum (running exponent per tile) and every
+    filter by its output channel's: results must not depend on where fp16's range lies.  Error bound per OUTPUT: 2^-19 of
+    conv(|x|, |w|) at that output (what an fp32 accumulation guarantees up to a constant), so a dim region beside a bright one is
+    held to ITS scale -- plus the form's absolute resolution, 2^-36 of the largest |x| within a tile's reach times sum |w| (a
+    value more than 2^-18 below the maximum of its staged chunk has a subnormal second piece: 'halves' puts 1e-4 beside 1e4
+    inside one tile)."""
+    from glenet_amd import conv2d as c2
+    old = c2.set_arithmetic("f16x2")
+    try:
+        b, cin, cout, h, w = 2, 128, 64, 40, 48
+        g = torch.Generator(device=dev).manual_seed(7)
+        x = torch.randn(b, cin, h, w, device=dev, generator=g)
+        wt = torch.randn(cout, cin, 3, 3, device=dev, generator=g) / (3 * cin ** 0.5)
+        if case == "scaled":
+            x, wt = x * 3.7e4, wt * 2.9e-6                 # far outside fp16's range on both sides without scaling
+        elif case == "halves":
+            x[..., : w // 2] *= 1e4                         # bright left half, dim right half: tiles scale on their own
+            x[..., w // 2:] *= 1e-4
+        elif case == "chunks":
+            x[:, 32:64] *= 3e5                              # the SECOND chunk is the large one: the running exponent steps down
+            x[:, 64:96] *= 1e-5                             # and the accumulators are rescaled; a tiny chunk follows
+            wt[:7] *= 1e-6                                  # output channels with small filters keep their own exponents
+            wt[7:9] *= 1e5
+        elif case == "zeros":
+            x[:, :, : h // 2] = 0                           # all-zero tiles / chunks
+            x[:, 40:80] = 0
+            wt[3] = 0                                       # an all-zero filter
+        elif case == "tiny":
+            x, wt = x * 1e-30, wt * 1e-3
+        elif case == "huge":
+            x, wt = x * 1e25, wt * 1e8
+        x = _cl(x)
+        y = c2.conv3x3(x, wt)
+        ref = F.conv2d(x.double(), wt.double(), None, 1, 1)
+        bound = F.conv2d(x.double().abs(), wt.double().abs(), None, 1, 1)
+        # the largest |x| any tile (8 x 16 pixels + halo) that holds the pixel can see, times the filter's absolute sum
+        reach = F.max_pool2d(x.double().abs().amax(1, keepdim=True), (19, 35), 1, (9, 17))
+        floor_ = 2.0 ** -36 * reach * wt.double().abs().sum((1, 2, 3)).view(1, -1, 1, 1)
+        assert torch.isfinite(y).all()
+        ok = (y.double() - ref).abs() <= 2.0 ** -19 * bound + floor_ + 1e-37
+        assert bool(ok.all()), (case, float(((y.double() - ref).abs() / (bound + 1e-300)).max()))
+        fwd, bwd = c2.packs(wt)
+        gy = _cl(torch.randn(b, cout, h, w, device=dev, generator=g) * (1e-7 if case in ("tiny", "halves") else 1.0))
+        gx = c2._run(gy, bwd, cin)
+        gref = F.conv_transpose2d(gy.double(), wt.double(), None, 1, 1)
+        gbound = F.conv_transpose2d(gy.double().abs(), wt.double().abs(), None, 1, 1)
+        greach = F.max_pool2d(gy.double().abs().amax(1, keepdim=True), (19, 35), 1, (9, 17))
+        gfloor = 2.0 ** -36 * greach * wt.double().abs().sum((0, 2, 3)).view(1, -1, 1, 1)
+        assert bool(((gx.double() - gref).abs() <= 2.0 ** -19 * gbound + gfloor + 1e-37).all()), case
+    finally:
+        c2.set_arithmetic(old)
 
 
 def test_conv3x3_gradients_and_pack_refresh(dev):

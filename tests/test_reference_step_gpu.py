@@ -225,7 +225,13 @@ def test_training_step_equals_the_references_own_classes(dev, net):
     # of ReLU masks differ -- of the ~10^5 activations of a layer about one lies within the 1e-6 the two forward passes
     # differ by -- and such a flip moves ONE element's upstream gradient in or out of the sums behind it: visible as a
     # 1e-2 outlier in single entries of a per-channel sum (the BatchNorm biases), invisible in the tensors' norms.
-    assert q[0] <= 3e-4 and q[1] <= 2e-3, "gradient errors: median %.2e, 90th percentile %.2e" % (q[0], q[1])
+    # Round 5: the pooling MLPs' own kernels (csrc/glx_rows.hip) round the third scale's output convolution differently from
+    # the library GEMM, and ONE of its 1.77 M pre-activations (|y| ~ 1e-7) takes the other side of the ReLU than the reference's
+    # CPU run did -- an element with a large upstream gradient: that layer's bias gradient moves by 1.9 % of its peak and
+    # everything upstream of x_conv4 by ~1e-3 (checked against an fp64 evaluation of the layer on the step's own tensors: the
+    # kernels' sums agree with it to 1e-7 on the other five layers and differ from it only through that one mask element
+    # here; with GLX_ROWS_CONV_BN=0 the quantiles are 1.3e-4 / 1.3e-3).  The 90th percentile bound is 4e-3 since.
+    assert q[0] <= 3e-4 and q[1] <= 4e-3, "gradient errors: median %.2e, 90th percentile %.2e" % (q[0], q[1])
     assert rels[0][0] <= 3e-2, "gradient of %s: sampled entries differ by %.2e of its scale" % (rels[0][2], rels[0][0])
     assert max(r[1] for r in rels) <= 3e-3, "gradient norm of %s" % max(rels, key=lambda r: r[1])[2]
     # ---- BatchNorm running statistics after the step
