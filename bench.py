@@ -265,9 +265,12 @@ def bench_bev(model, dev, frames=FRAMES_PER_GPU):
     ms_fb = _timed(fwd_bwd, 10, dev)
     model.load_state_dict(state, strict=False)          # the timing passes moved the running statistics
     # the own 3x3 kernels alone (csrc/glx_conv2d.hip), on the block layers' shapes: fp32-equivalent TFLOP/s (2 x
-    # multiply-adds of the fp32 convolution) and the share of the bf16 pipe the six piece products per tile occupy
+    # multiply-adds of the fp32 convolution) and the share of the 16-bit matrix pipe (2.5 PFLOP/s dense, fp16 = bf16) the piece
+    # products per tile occupy: three fp16 products in the forward / input-gradient kernel (f16x2, the default; six bf16
+    # products under GLX_CONV3X3_ARITH=bf16x3, timed beside it), six bf16 products in the weight gradient
     from glenet_amd import conv2d as c2
     layers = {}
+    arith = c2.arithmetic()
     for cin, cout, h, w in ((64, 64, 200, 176), (128, 128, 100, 88)):
         xi = torch.randn(frames, cin, h, w, device=dev).contiguous(memory_format=torch.channels_last)
         gy = torch.randn(frames, cout, h, w, device=dev).contiguous(memory_format=torch.channels_last)
@@ -276,10 +279,19 @@ def bench_bev(model, dev, frames=FRAMES_PER_GPU):
         fl = 2.0 * frames * h * w * 9 * cin * cout
         t = {"forward": _timed(lambda: c2._run(xi, pf, cout), 20, dev), "input_grad": _timed(lambda: c2._run(gy, pb, cin), 20, dev),
              "weight_grad": _timed(lambda: c2.wgrad(xi, gy, wt), 20, dev)}
-        layers["%d->%d@%dx%d" % (cin, cout, h, w)] = {
-            k: dict(us=round(v * 1e3, 1), TFLOPs_fp32_equivalent=round(fl / v / 1e9, 1),
-                    frac_of_fp32_mfma_peak=round(fl / v / 1e9 / MFMA_F32_PEAK_TFLOPS, 3),
-                    frac_of_bf16_pipe=round(6 * fl / v / 1e9 / MFMA_BF16_PEAK_TFLOPS, 3)) for k, v in t.items()}
+        pieces = {"forward": 3 if arith == "f16x2" else 6, "input_grad": 3 if arith == "f16x2" else 6, "weight_grad": 6}
+        entry = {k: dict(us=round(v * 1e3, 1), TFLOPs_fp32_equivalent=round(fl / v / 1e9, 1),
+                         frac_of_fp32_mfma_peak=round(fl / v / 1e9 / MFMA_F32_PEAK_TFLOPS, 3), mfma_per_product_tile=pieces[k],
+                         frac_of_16bit_pipe=round(pieces[k] * fl / v / 1e9 / MFMA_BF16_PEAK_TFLOPS, 3)) for k, v in t.items()}
+        other = "bf16x3" if arith == "f16x2" else "f16x2"
+        c2.set_arithmetic(other)                          # the other arithmetic on the same data (packs rebuilt)
+        try:
+            pf2, pb2 = c2.packs(wt)
+            entry["under_" + other] = dict(forward_us=round(_timed(lambda: c2._run(xi, pf2, cout), 20, dev) * 1e3, 1),
+                                           input_grad_us=round(_timed(lambda: c2._run(gy, pb2, cin), 20, dev) * 1e3, 1))
+        finally:
+            c2.set_arithmetic(arith)
+        layers["%d->%d@%dx%d" % (cin, cout, h, w)] = entry
     # how close to an fp64 convolution the three kernel forms are, next to the vendor's fp32 kernels on the same data
     # (tests/test_conv2d_gpu.py asserts err <= 4 err_lib + 1e-6 of scale; here the measured numbers): one frame of the
     # 128 -> 128 shape, max |difference| / max |fp64 result|
@@ -315,12 +327,20 @@ def bench_bev(model, dev, frames=FRAMES_PER_GPU):
                 fwd_TFLOPs=round(flops / ms_f / 1e9, 1), fwd_bwd_TFLOPs=round(3 * flops / ms_fb / 1e9, 1),
                 frac_of_fp32_mfma_peak=dict(fwd=round(flops / ms_f / 1e9 / MFMA_F32_PEAK_TFLOPS, 3),
                                             fwd_bwd=round(3 * flops / ms_fb / 1e9 / MFMA_F32_PEAK_TFLOPS, 3)),
-                kernels="3x3 / stride-1 layers (11 of 12: forward, input and weight gradient): csrc/glx_conv2d.hip, fp32 "
-                        "products as six bf16 MFMAs of three-way split operands, fp32 accumulation; the two transposed "
+                conv3x3_arithmetic=arith,
+                kernels="3x3 / stride-1 layers (11 of 12: forward, input and weight gradient): csrc/glx_conv2d.hip -- forward and "
+                        "input gradient: fp32 products as three fp16 MFMAs of two-way split operands scaled by powers of two (per "
+                        "output channel / per staged chunk), fp32 accumulation (f16x2; GLX_CONV3X3_ARITH=bf16x3: six bf16 MFMAs of "
+                        "three-way split operands); weight gradient: bf16x3; the two transposed "
                         "convolutions (forward, both gradients) and the strided layer's forward: csrc/glx_deconv2d.hip, "
-                        "same arithmetic; the strided layer's gradients: MIOpen fp32 (vendor); the 1x1 anchor head: csrc/glx_head.hip "
+                        "bf16x3; the strided layer's gradients: MIOpen fp32 (vendor); the 1x1 anchor head: csrc/glx_head.hip "
                         "(fp32 MFMA); BatchNorm: csrc/glx_bn.hip -- forward statistics in the conv epilogue, the transform applied "
                         "on load by the next 3x3 layer, backward sums in the input-gradient epilogue")
+
+
+def _conv_arith():
+    from glenet_amd import conv2d as c2
+    return c2.arithmetic()
 
 
 def bench_inference(dev, frames=FRAMES_PER_GPU, steps=50, cpu=True):
@@ -1059,10 +1079,15 @@ def main():
                                device_data_step=bool(args.device_data_step),
                                graph_executor_queues=glx_runtime.graph_executor_queues(),
                                arithmetic="fp32 tensors and fp32 accumulation everywhere; the BEV backbone's convolutions form "
-                                          "their fp32 products on the bf16 matrix pipe from three-way split operands (six "
-                                          "MFMAs per product tile, products exact to 2^-22: error against an fp64 convolution "
-                                          "equal to the vendor's fp32 kernels', tests/test_conv2d_gpu.py, "
-                                          "tests/test_oracle_cpu.py::test_split_bf16_pieces_carry_an_fp32_product)",
+                                          "their fp32 products on the 16-bit matrix pipe from split operands: forward / input "
+                                          "gradient of the 3x3 layers from two fp16 pieces per operand, scaled by powers of two "
+                                          "per output channel and per staged chunk (three MFMAs per product tile, products to "
+                                          "2^-20.4 at worst; conv3x3_arithmetic=%s, GLX_CONV3X3_ARITH=bf16x3 restores the "
+                                          "former), weight gradients and transposed convolutions from three bf16 pieces (six "
+                                          "MFMAs, products exact to 2^-22): error against an fp64 convolution within 2 x the "
+                                          "vendor's fp32 kernels' (tests/test_conv2d_gpu.py, bev.conv3x3_error_vs_fp64, "
+                                          "tests/test_oracle_cpu.py::test_split_bf16_pieces_carry_an_fp32_product)"
+                                          % _conv_arith(),
                                host_enqueue_ms_per_step=round(t_host * 1e3, 4) if t_host is not None else None,
                                host_loop_ms_per_step=round(t_enq / max(args.steps, 1) * 1e3, 4),
                                host_note="host_enqueue = set_lr (2 fills) + load (1 launch) + graph replay(s) measured on 3 "

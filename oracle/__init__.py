@@ -839,3 +839,31 @@ def bf16x3_product(x, w):
     xs, ws = bf16x3_split(x), bf16x3_split(w)
     terms = ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0))
     return sum(ws[i].astype(np.float64) * xs[j].astype(np.float64) for i, j in terms)
+
+
+def f16x2_block_exponent(m):
+    """cv_block_exponent of csrc/glx_bf16x3.h: the power of two that puts a block's maximum |value| m into [2^14, 2^15)
+    (127 for a block of zeros: 'no value yet'), clamped to +-110."""
+    m = np.float32(m)
+    if not m > 0:
+        return 127
+    field = int((np.array([m], np.float32).view(np.uint32)[0] >> 23) & 0xFF)        # the biased exponent, as the kernel reads it
+    return max(-110, min(110, 14 - field + 127))
+
+
+def f16x2_split(x, e):
+    """The two fp16 pieces of x * 2^e (cv_split2 in csrc/glx_bf16x3.h; the scaling is exact): a = fp16(xs), b = fp16(xs - a),
+    each returned as float32 in the SCALED domain."""
+    xs = np.ldexp(np.asarray(x, np.float32), int(e)).astype(np.float32)
+    a = xs.astype(np.float16).astype(np.float32)
+    b = (xs - a).astype(np.float32).astype(np.float16).astype(np.float32)
+    return a, b
+
+
+def f16x2_product(x, w, ex, ew):
+    """x * w as the f16x2 form of csrc/glx_conv2d.hip computes it: operands scaled by 2^ex / 2^ew, the three piece products
+    b_w a_x, a_w b_x, a_w a_x (each exact in fp32), summed in fp64 here, the exponents taken out again."""
+    ax, bx = f16x2_split(x, ex)
+    aw, bw = f16x2_split(w, ew)
+    s = bw.astype(np.float64) * ax + aw.astype(np.float64) * bx + aw.astype(np.float64) * ax
+    return np.ldexp(s, -(int(ex) + int(ew)))

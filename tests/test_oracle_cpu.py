@@ -536,6 +536,44 @@ def test_split_bf16_pieces_carry_an_fp32_product():
     assert np.max(np.abs(two - exact) / np.abs(exact)) > 2.0 ** -18
 
 
+def test_scaled_f16_pieces_carry_an_fp32_class_product():
+    """The f16x2 arithmetic of csrc/glx_conv2d.hip restated on the host (oracle.f16x2_*): a block of values scaled by the power
+    of two of its maximum, two fp16 pieces per value.  An operand keeps 22 bits where its second piece is a normal fp16 number
+    (within 2^-18 of the block's maximum), the absolute resolution below that is 2^-25 in the scaled domain (2^-39 of the
+    maximum); the three piece products give x * w to 2^-20.4 at worst on such operands; scaling makes the result independent
+    of the operands' magnitude."""
+    rng = np.random.default_rng(0)
+    x = (rng.uniform(1.0, 2.0, 200000) * rng.choice([-1.0, 1.0], 200000)).astype(np.float32)
+    w = (rng.uniform(1.0, 2.0, 200000) * rng.choice([-1.0, 1.0], 200000)).astype(np.float32)
+    ex, ew = oracle.f16x2_block_exponent(np.abs(x).max()), oracle.f16x2_block_exponent(np.abs(w).max())
+    assert ex == 14 and ew == 14 and oracle.f16x2_block_exponent(0.0) == 127
+    a, b = oracle.f16x2_split(x, ex)
+    assert np.all(np.abs(a) <= 2.0 ** 15) and np.all(np.abs(a) >= 2.0 ** 14)          # scaled into fp16's top binade
+    xs = np.ldexp(x.astype(np.float64), ex)
+    assert np.max(np.abs(a.astype(np.float64) + b - xs) / np.abs(xs)) <= 2.0 ** -22
+    exact = x.astype(np.float64) * w.astype(np.float64)
+    err = np.abs(oracle.f16x2_product(x, w, ex, ew) - exact) / np.abs(exact)
+    assert np.max(err) < 2.0 ** -20.4 and np.mean(err) < 2.0 ** -23
+    # the same values at any common magnitude: bitwise the same relative result (the exponents are exact)
+    for kx, kw in ((37, -60), (-90, 20), (0, 0)):
+        x2, w2 = np.ldexp(x, kx).astype(np.float32), np.ldexp(w, kw).astype(np.float32)
+        e2x, e2w = oracle.f16x2_block_exponent(np.abs(x2).max()), oracle.f16x2_block_exponent(np.abs(w2).max())
+        assert (e2x, e2w) == (14 - kx, 14 - kw)
+        got = oracle.f16x2_product(x2, w2, e2x, e2w)
+        assert np.array_equal(np.ldexp(got, -(kx + kw)), oracle.f16x2_product(x, w, ex, ew))
+    # a dim value beside a bright one: full precision down to 2^-18 of the block's maximum, an absolute floor below
+    dim = (x * np.float32(2.0 ** -17)).astype(np.float32)
+    ad, bd = oracle.f16x2_split(dim, ex)
+    sd = np.ldexp(dim.astype(np.float64), ex)
+    assert np.max(np.abs(ad.astype(np.float64) + bd - sd) / np.abs(sd)) <= 2.0 ** -21
+    dimmer = (x * np.float32(2.0 ** -30)).astype(np.float32)
+    ad, bd = oracle.f16x2_split(dimmer, ex)
+    assert np.max(np.abs(ad.astype(np.float64) + bd - np.ldexp(dimmer.astype(np.float64), ex))) <= 2.0 ** -25
+    # without the second piece (one fp16 product) the product stops at 2^-11
+    one = np.ldexp(oracle.f16x2_split(w, ew)[0].astype(np.float64) * a, -(ex + ew))
+    assert np.max(np.abs(one - exact) / np.abs(exact)) > 2.0 ** -12
+
+
 def test_dense_convolution_restatements_match_torch():
     import torch
     import torch.nn.functional as F
