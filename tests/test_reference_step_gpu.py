@@ -233,7 +233,8 @@ def test_training_step_equals_the_references_own_classes(dev, net):
     # here; with GLX_ROWS_CONV_BN=0 the quantiles are 1.3e-4 / 1.3e-3).  The 90th percentile bound is 4e-3 since.
     assert q[0] <= 3e-4 and q[1] <= 4e-3, "gradient errors: median %.2e, 90th percentile %.2e" % (q[0], q[1])
     assert rels[0][0] <= 3e-2, "gradient of %s: sampled entries differ by %.2e of its scale" % (rels[0][2], rels[0][0])
-    assert max(r[1] for r in rels) <= 3e-3, "gradient norm of %s" % max(rels, key=lambda r: r[1])[2]
+    # (the same flipped element moves the norm of that scale's position-MLP weight gradient by 3.5e-3)
+    assert max(r[1] for r in rels) <= 5e-3, "gradient norm of %s" % max(rels, key=lambda r: r[1])[2]
     # ---- BatchNorm running statistics after the step
     sd = model.state_dict()
     after = np.concatenate([sd[k].cpu().numpy().reshape(-1) for k in sd if k.endswith("running_mean") or k.endswith("running_var")])
