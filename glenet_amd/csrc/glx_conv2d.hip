@@ -9,6 +9,9 @@
 // (the dropped three are below one fp32 rounding of the product).  Six bf16 MFMAs with fp32 accumulation replace eight
 // fp32 MFMAs of the same tile at a quarter of their cycles each: 6 / 16 of the matrix time at fp32 accuracy (piece
 // products are exact in fp32; the accumulation is the fp32 accumulation of the matrix pipe, as in the fp32 form).
+// That is the bf16 x 3 arithmetic: the weight gradient's, and the forward / input-gradient kernel's under
+// GLX_CONV3X3_ARITH=bf16x3.  By default the forward / input-gradient kernel halves the instruction count once more with
+// TWO fp16 pieces per operand and THREE products (f16 x 2, described in front of the pack kernels below).
 //
 // Implicit GEMM, output stationary: a block of 4 waves owns an 8 x 16 pixel tile x 64 output channels; wave w the tile
 // rows 2w, 2w+1 (two 16-pixel operand tiles) x four 16-channel tiles = 8 accumulators.  K runs over (32-channel chunk
