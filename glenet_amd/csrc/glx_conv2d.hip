@@ -971,6 +971,242 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
       for (int rg = 0; rg < 4; ++rg) dst[((tap * 2 + n) * 4 + rg) * 256] = acc[tap][n][rg];
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient, second form
+// The first form's time is in its operand paths, not in the matrix pipe (profiles/r05_bev_mfma.md 3b: one MFMA of six takes the
+// same time; without either operand's global loads it lands at the MFMA floor): gy comes as sixteen 4-byte loads per lane and
+// k-step, one k-step ahead, and is split by EVERY wave that needs it.  Here both operands take the path x always took: the
+// block loads the tile's gy (8 x 16 pixels x 64 channels, 16-byte pieces, a tile ahead) like the x halo, converts each element
+// ONCE and keeps it in LDS in the transposable layout ([pixel][32 channels] rows of 64 bytes, halves swapped on odd 8-pixel
+// column groups); both MFMA operands are ds_read_b64_tr_b16 reads.  Two such images fit beside the halo only with two planes:
+// the arithmetic is f16 x 2 (two fp16 pieces per operand, three products), scaled per TILE by the block's maxima of the staged
+// x halo and gy tile; the accumulators carry a running exponent S = e_x + e_g across the block's tiles -- a tile whose product
+// scale is smaller rescales them (ldexp: exact), a tile whose scale is larger converts its gy at S - e_x instead -- taken out
+// when the partial sums are written.  Same partial-sum layout as the first form (k_conv3x3_wgrad_reduce).
+#define WG2_GIMG (128 * 64)                        // one 32-channel image of the gy tile, one plane
+#define WG2_GPLANE (2 * WG2_GIMG)                  // both channel halves of the block's 64 output channels
+#define WG2_LDS (2 * WG_XPLANE + 2 * WG2_GPLANE + 64)   // 55 872 bytes: two blocks per CU
+#define WG2_GLOADS 8                               // 16-byte pieces of the gy tile per thread
+
+__global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad2(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sX = smem;                                  // [plane][halo pixel][64 B]
+  char* sG = smem + 2 * WG_XPLANE;                  // [plane][channel half][pixel][64 B]
+  float* s_max = reinterpret_cast<float*>(smem + 2 * WG_XPLANE + 2 * WG2_GPLANE);      // [wave][x | gy]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = lane >> 4;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int q = j % a.nq, p = (j / a.nq) * 8 + xcd;
+  const int ib = q % a.nq_ci, cb = q / a.nq_ci;
+  const int cp = wave >> 1, nn = wave & 1;
+
+  int adst[CV_ALOADS], gdst[WG2_GLOADS];
+#pragma unroll
+  for (int i = 0; i < CV_ALOADS; ++i) {
+    const int e = tid + i * 256;
+    const int hp = e >> 3, seg = e & 7, hx = hp % CV_HW;
+    adst[i] = e < CV_HP * 8 ? hp * 64 + (((seg >> 2) ^ ((hx >> 3) & 1)) << 5) + (seg & 3) * 8 : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < WG2_GLOADS; ++i) {
+    const int e = tid + i * 256;                    // pixel e >> 4 of the tile (row-major 8 x 16), channels 4 (e & 15) ..
+    const int px = e >> 4, seg = e & 15, col = px & 15;
+    gdst[i] = (seg >> 3) * WG2_GIMG + px * 64 + ((((seg & 7) >> 2) ^ ((col >> 3) & 1)) << 5) + (seg & 3) * 8;
+  }
+  f32x4 areg[CV_ALOADS], greg[WG2_GLOADS];
+  unsigned aok = 0;
+  f32x4 pre_sc = f32x4{1.f, 1.f, 1.f, 1.f}, pre_sh = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (a.pre_scale) {
+    pre_sc = *reinterpret_cast<const f32x4*>(a.pre_scale + ib * 32 + (tid & 7) * 4);
+    pre_sh = *reinterpret_cast<const f32x4*>(a.pre_shift + ib * 32 + (tid & 7) * 4);
+  }
+#define WG2_TILE(T, X0, Y0, BB)                                                                          \
+  int X0, Y0, BB;                                                                                        \
+  {                                                                                                      \
+    int t_ = (T);                                                                                        \
+    X0 = (t_ % a.tiles_x) * CV_TW;                                                                       \
+    t_ /= a.tiles_x;                                                                                     \
+    Y0 = (t_ % a.tiles_y) * CV_TH;                                                                       \
+    BB = t_ / a.tiles_y;                                                                                 \
+  }
+#define WG2_LOADX(T)                                                                                     \
+  {                                                                                                      \
+    WG2_TILE(T, x0_, y0_, b_)                                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < CV_ALOADS; ++i_) {                                           \
+      const int e_ = tid + i_ * 256;                                                                     \
+      const int hp_ = e_ >> 3, seg_ = e_ & 7;                                                            \
+      const int gy_ = y0_ - 1 + hp_ / CV_HW, gx_ = x0_ - 1 + hp_ % CV_HW;                                \
+      const bool ok_ = e_ < CV_HP * 8 && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W;                 \
+      aok = ok_ ? (aok | (1u << i_)) : (aok & ~(1u << i_));                                              \
+      areg[i_] = ok_ ? *reinterpret_cast<const f32x4*>(a.x + (((long long)b_ * a.H + gy_) * a.W + gx_) * a.Cin + \
+                                                       ib * 32 + seg_ * 4)                                \
+                     : f32x4{0.f, 0.f, 0.f, 0.f};                                                        \
+    }                                                                                                    \
+  }
+#define WG2_LOADG(T)                                                                                     \
+  {                                                                                                      \
+    WG2_TILE(T, x0_, y0_, b_)                                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < WG2_GLOADS; ++i_) {                                          \
+      const int e_ = tid + i_ * 256;                                                                     \
+      const int py_ = y0_ + (e_ >> 8), px_ = x0_ + ((e_ >> 4) & 15), seg_ = e_ & 15;                      \
+      greg[i_] = (py_ < a.H && px_ < a.W)                                                                \
+                     ? *reinterpret_cast<const f32x4*>(a.gy + (((long long)b_ * a.H + py_) * a.W + px_) * a.Cout + \
+                                                       cb * 64 + seg_ * 4)                                \
+                     : f32x4{0.f, 0.f, 0.f, 0.f};                                                        \
+    }                                                                                                    \
+  }
+
+  f32x4 acc[9][2];           // [tap][channel tile of the pair]
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int esum = 254;            // the exponent e_x + e_g the accumulators are scaled by (254: nothing accumulated yet)
+
+  // a lane's part of the transposing reads: pixel column 8 (kq & 1) + 4 h + qq (+ dx in the halo), 4 channels at pp
+  const int qq = (lane & 15) >> 2, pp = lane & 3;
+  int rbase[2][3], gbase[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int hx = 8 * (kq & 1) + 4 * h + qq + dx;
+      rbase[h][dx] = (((kq >> 1) * CV_HW + hx) * 64 + (((hx >> 3) & 1) << 5) + pp * 8) ^ (nn << 5);
+    }
+    const int col = 8 * (kq & 1) + 4 * h + qq;
+    gbase[h] = cp * WG2_GIMG + ((kq >> 1) * 16 + col) * 64 + (((col >> 3) & 1) << 5) + pp * 8;
+  }
+
+  int tile = p;
+  if (tile < a.ntiles) {
+    WG2_LOADX(tile);
+    WG2_LOADG(tile);
+  }
+  while (tile < a.ntiles) {
+    // ---- the staged tile: x transformed in place, the block's maxima of both operands on their way
+    float mx = 0.f, mg = 0.f;
+#pragma unroll
+    for (int i = 0; i < CV_ALOADS; ++i) {
+      if (a.pre_scale && ((aok >> i) & 1u)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = __fmaf_rn(areg[i][e], pre_sc[e], pre_sh[e]);
+          areg[i][e] = a.pre_relu ? fmaxf(t, 0.f) : t;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(areg[i][e]));
+    }
+#pragma unroll
+    for (int i = 0; i < WG2_GLOADS; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mg = fmaxf(mg, fabsf(greg[i][e]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      mg = fmaxf(mg, __shfl_xor(mg, o, 64));
+    }
+    if (lane == 0) { s_max[2 * wave] = mx; s_max[2 * wave + 1] = mg; }
+    __syncthreads();          // the previous tile's reads of the images are done; the maxima are there
+    int ex = __builtin_amdgcn_readfirstlane(cv_block_exponent(fmaxf(fmaxf(s_max[0], s_max[2]), fmaxf(s_max[4], s_max[6]))));
+    int eg = __builtin_amdgcn_readfirstlane(cv_block_exponent(fmaxf(fmaxf(s_max[1], s_max[3]), fmaxf(s_max[5], s_max[7]))));
+    if (ex == 127) ex = 0;    // an operand of zeros: any scale
+    if (eg == 127) eg = 0;
+    if (ex + eg < esum) {
+      if (esum != 254) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][n][e] = ldexpf(acc[t][n][e], ex + eg - esum);
+      }
+      esum = ex + eg;
+    }
+    int egu = esum - ex;      // <= eg: a tile whose own product scale is larger takes the accumulators' scale
+    egu = egu < -120 ? -120 : egu;
+#pragma unroll
+    for (int i = 0; i < CV_ALOADS; ++i) {
+      if (adst[i] >= 0) {
+        f16x4 p0, p1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          _Float16 u, v;
+          cv_split2(ldexpf(areg[i][e], ex), u, v);
+          p0[e] = u; p1[e] = v;
+        }
+        *reinterpret_cast<f16x4*>(sX + adst[i]) = p0;
+        *reinterpret_cast<f16x4*>(sX + WG_XPLANE + adst[i]) = p1;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WG2_GLOADS; ++i) {
+      f16x4 p0, p1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        _Float16 u, v;
+        cv_split2(ldexpf(greg[i][e], egu), u, v);
+        p0[e] = u; p1[e] = v;
+      }
+      *reinterpret_cast<f16x4*>(sG + gdst[i]) = p0;
+      *reinterpret_cast<f16x4*>(sG + WG2_GPLANE + gdst[i]) = p1;
+    }
+    __syncthreads();
+    const int next = tile + a.P;
+    typedef i16x4 __attribute__((address_space(3))) * lds_p;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s == 1 && next < a.ntiles) { WG2_LOADG(next); }
+      if (s == 2 && next < a.ntiles) { WG2_LOADX(next); }
+      // this k-step's gy operands: two channel tiles x two planes
+      f16x8 ga[2][2];
+#pragma unroll
+      for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          const int off = pl * WG2_GPLANE + s * 2048;
+          i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(sG + off + (gbase[0] ^ (a2 << 5))));
+          i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(sG + off + (gbase[1] ^ (a2 << 5))));
+          ga[a2][pl] = __builtin_bit_cast(f16x8, wg_join(lo, hi));
+        }
+#define WG2_READX(XB, TAP)                                                                                 \
+  _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_) {                                                    \
+    const int off_ = pl_ * WG_XPLANE + (2 * s + (TAP) / 3) * CV_HW * 64;                                   \
+    i16x4 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(sX + off_ + rbase[0][(TAP) % 3]));         \
+    i16x4 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(sX + off_ + rbase[1][(TAP) % 3]));         \
+    XB[pl_] = __builtin_bit_cast(f16x8, wg_join(lo_, hi_));                                                \
+  }
+      f16x8 xb[2][2];
+      WG2_READX(xb[0], 0);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap < 8) { WG2_READX(xb[(tap + 1) & 1], tap + 1); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2) {
+          f32x4 v = acc[tap][a2];
+          F2_MFMA3(v, ga[a2], xb[tap & 1]);
+          acc[tap][a2] = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#undef WG2_READX
+    }
+    tile = next;
+  }
+#undef WG2_LOADX
+#undef WG2_LOADG
+#undef WG2_TILE
+  // ---- the block's partial sums (the exponent taken out): element ((tap * 2 + a2) * 4 + reg) * 256 + tid
+  const int eo = esum == 254 ? 0 : -esum;
+  float* dst = a.ws + (size_t)(q * a.P + p) * WG_PART + tid;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[((tap * 2 + n) * 4 + e) * 256] = ldexpf(acc[tap][n][e], eo);
+}
+
 // 64 partial elements x 4 segments of the quadrant's blocks per 256 threads; dW through the weight's strides
 __global__ __launch_bounds__(256) void k_conv3x3_wgrad_reduce(const float* __restrict__ ws, int P, int nq_ci,
                                                               float* __restrict__ dW, long long s_co, long long s_ci,
@@ -1048,7 +1284,10 @@ extern "C" int glx_conv3x3_wgrad_ex(const float* x, const float* gy, int B, int 
   a.nq = a.nq_ci * (Cout / CV_BN);
   const int blocks = wgrad_blocks(Cin, Cout, &a.P);
   static const bool pipe = getenv("GLX_WGRAD_PIPE") ? atoi(getenv("GLX_WGRAD_PIPE")) != 0 : true;
-  if (pipe)
+  static const int form = getenv("GLX_WGRAD_FORM") ? atoi(getenv("GLX_WGRAD_FORM")) : 2;
+  if (form == 2)
+    hipLaunchKernelGGL(k_conv3x3_wgrad2, dim3(blocks), dim3(256), WG2_LDS, (hipStream_t)stream, a);
+  else if (pipe)
     hipLaunchKernelGGL(k_conv3x3_wgrad<true>, dim3(blocks), dim3(256), WG_LDS, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(k_conv3x3_wgrad<false>, dim3(blocks), dim3(256), WG_LDS, (hipStream_t)stream, a);
