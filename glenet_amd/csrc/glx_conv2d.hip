@@ -987,6 +987,17 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
 #define WG2_LDS (2 * WG_XPLANE + 2 * WG2_GPLANE + 64)   // 55 872 bytes: two blocks per CU
 #define WG2_GLOADS 8                               // 16-byte pieces of the gy tile per thread
 
+// k-steps (of four) at which the next tile's gy / x loads are issued; W2_ABL: timing-only builds (1 no global loads after the first
+// tile, 8 operands read from LDS once per tile, 16 one MFMA of three)
+#ifndef W2_SG
+#define W2_SG 1
+#endif
+#ifndef W2_SX
+#define W2_SX 2
+#endif
+#ifndef W2_ABL
+#define W2_ABL 0
+#endif
 __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad2(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sX = smem;                                  // [plane][halo pixel][64 B]
@@ -1155,8 +1166,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad2(WgradArgs a) {
     typedef i16x4 __attribute__((address_space(3))) * lds_p;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      if (s == 1 && next < a.ntiles) { WG2_LOADG(next); }
-      if (s == 2 && next < a.ntiles) { WG2_LOADX(next); }
+      if (!(W2_ABL & 1) && s == W2_SG && next < a.ntiles) { WG2_LOADG(next); }
+      if (!(W2_ABL & 1) && s == W2_SX && next < a.ntiles) { WG2_LOADX(next); }
       // this k-step's gy operands: two channel tiles x two planes
       f16x8 ga[2][2];
 #pragma unroll
@@ -1179,12 +1190,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad2(WgradArgs a) {
       WG2_READX(xb[0], 0);
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        if (tap < 8) { WG2_READX(xb[(tap + 1) & 1], tap + 1); }
+        if (tap < 8 && !(W2_ABL & 8)) { WG2_READX(xb[(tap + 1) & 1], tap + 1); }
+        if (tap < 8 && (W2_ABL & 8)) { xb[(tap + 1) & 1][0] = xb[tap & 1][1]; xb[(tap + 1) & 1][1] = xb[tap & 1][0]; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a2 = 0; a2 < 2; ++a2) {
           f32x4 v = acc[tap][a2];
-          F2_MFMA3(v, ga[a2], xb[tap & 1]);
+          if (W2_ABL & 16) v = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga[a2][0], xb[tap & 1][0], v, 0, 0, 0);
+          else F2_MFMA3(v, ga[a2], xb[tap & 1]);
           acc[tap][a2] = v;
         }
         __builtin_amdgcn_sched_barrier(0);
