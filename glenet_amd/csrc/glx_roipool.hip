@@ -261,7 +261,16 @@ __global__ __launch_bounds__(RP_THREADS) void k_rp_forward(const float* __restri
 
 // backward: feature gradient by atomic adds at the winning slots + per-channel sums
 // partial[block][c][5] = sum dz, sum dz*xhat, sum dz*rel (3)
-template <int C>
+// AGG: the feature gradient is summed per block in LDS first.  The winners of neighbouring grid points are the same few
+// voxels (a RoI's 216 points crown some tens of rows, 512 RoIs sit on the same objects), and float atomics execute at the
+// memory side where adds to one row serialise: without the atomics the launch takes 36 us on every scale, with one global atomic
+// per (point, channel) 114 / 72 / 38 us (x_conv4 / x_conv3 / x_conv2: the coarser the scale the fewer the rows).  A block takes
+// RP_AGG_POINTS CONSECUTIVE points, adds their gradients into a hash table of (row -> C sums) in LDS (ds_add_f32) and sends
+// one global atomic per (occupied slot, channel) at the end, as whole 128-byte rows; a row that finds no slot within eight probes
+// goes to memory directly.
+#define RP_AGG_POINTS 256
+#define RP_AGG_SLOTS 256
+template <int C, bool AGG>
 __global__ __launch_bounds__(RP_THREADS) void k_rp_backward(const float* __restrict__ dpooled,
                                                             const float* __restrict__ pooled,
                                                             const unsigned char* __restrict__ arg,
@@ -285,7 +294,19 @@ __global__ __launch_bounds__(RP_THREADS) void k_rp_backward(const float* __restr
 #pragma unroll
     for (int k = 0; k < 5; ++k) s[i][k] = 0;
   const int lane = threadIdx.x & 63;
-  for (long long m = (long long)blockIdx.x * PPB + sub; m < M; m += (long long)gridDim.x * PPB) {
+  constexpr int NSLOT = AGG ? (C <= 32 ? RP_AGG_SLOTS : RP_AGG_SLOTS / 2) : 1;
+  __shared__ int s_key[NSLOT];
+  __shared__ float s_val[AGG ? NSLOT * C : 1];
+  if (AGG) {
+    for (int e = threadIdx.x; e < NSLOT; e += RP_THREADS) s_key[e] = -1;
+    for (int e = threadIdx.x; e < NSLOT * C; e += RP_THREADS) s_val[e] = 0.f;
+    __syncthreads();
+  }
+  // AGG: a block owns RP_AGG_POINTS consecutive points (passes of PPB); else passes strided over the grid
+  const long long m_lo = AGG ? (long long)blockIdx.x * RP_AGG_POINTS : (long long)blockIdx.x * PPB;
+  const long long m_hi = AGG ? (m_lo + RP_AGG_POINTS < M ? m_lo + RP_AGG_POINTS : (long long)M) : (long long)M;
+  const long long m_step = AGG ? PPB : (long long)gridDim.x * PPB;
+  for (long long m = m_lo + sub; m < m_hi; m += m_step) {
     // all PPW points of this wave's pass exist <=> the last one does (points of a wave are consecutive)
     const bool wave_full = m - (sub % PPW) + (PPW - 1) < M;
     const f32x4 pv = *reinterpret_cast<const f32x4*>(pooled + m * C + 4 * q);
@@ -315,7 +336,25 @@ __global__ __launch_bounds__(RP_THREADS) void k_rp_backward(const float* __restr
     }
     // neighbouring grid points of a RoI mostly crown the same voxel: the points of a wave that share a winner add
     // their gradients first and send ONE atomic (the feature rows near a box are hot spots of the L2 atomic units)
-    if (wave_full) {
+    if (AGG) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (r[i] < 0) continue;
+        unsigned sl = ((unsigned)r[i] * 2654435761u) >> 16 & (NSLOT - 1);
+        bool put = false;
+#pragma unroll 1
+        for (int probe = 0; probe < 8 && !put; ++probe) {
+          const int k = atomicCAS(&s_key[sl], -1, r[i]);
+          if (k == -1 || k == r[i]) {
+            atomicAdd(&s_val[sl * C + 4 * q + i], g[i]);
+            put = true;
+          } else {
+            sl = (sl + 1) & (NSLOT - 1);
+          }
+        }
+        if (!put) atomicAdd(dfeats + (long long)r[i] * C + 4 * q + i, g[i]);
+      }
+    } else if (wave_full) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float acc = r[i] >= 0 ? g[i] : 0.f;
@@ -347,6 +386,14 @@ __global__ __launch_bounds__(RP_THREADS) void k_rp_backward(const float* __restr
       s[i][2] += (double)g[i] * x[i];
       s[i][3] += (double)g[i] * y[i];
       s[i][4] += (double)g[i] * z[i];
+    }
+  }
+  if (AGG) {                 // the block's table -> memory: consecutive threads = the channels of a slot (128-byte rows)
+    __syncthreads();
+    for (int e = threadIdx.x; e < NSLOT * C; e += RP_THREADS) {
+      const int row = s_key[e / C];
+      const float v = s_val[e];
+      if (row >= 0 && v != 0.f) atomicAdd(dfeats + (long long)row * C + (e % C), v);
     }
   }
   // sums over the points of the wave (lanes with the same q) by shuffles, over the 4 waves in LDS
@@ -504,17 +551,22 @@ extern "C" int glx_pos_pool_backward(const float* dpooled, const float* pooled, 
   int rc = glx_fill_multi(zj, 2, st);
   if (rc != GLX_OK) return rc;
   const int ppb_b = RP_THREADS / (C / 4);
-  const int blocks = M > 0 ? (int)(((long long)M + ppb_b - 1) / ppb_b > 4096 ? 4096 : ((long long)M + ppb_b - 1) / ppb_b) : 0;
+  // per launch the table pays where the winners are few (114 -> 57 us on x_conv4's 26 k rows, 72 -> 59 on x_conv3's 42 k, 38 -> 55
+  // on x_conv2's 62 k; 4 frames x 128 RoIs x 216 points each) -- on the training step it pays on every scale: 5.46-5.48 ms with the
+  // table everywhere against 5.52-5.55 with it on the coarsest scale only and 5.59-5.61 without (the serialised adds at the
+  // memory side also hold up the BEV backward that runs beside them).  GLX_RP_BWD_AGG=0: one global atomic per (point, channel)
+  static const bool agg = getenv("GLX_RP_BWD_AGG") ? atoi(getenv("GLX_RP_BWD_AGG")) != 0 : true;
+  const long long want = agg ? ((long long)M + RP_AGG_POINTS - 1) / RP_AGG_POINTS : ((long long)M + ppb_b - 1) / ppb_b;
+  // (the aggregating form needs every point covered by ITS block: no cap on the grid)
+  const int blocks = M > 0 ? (int)(agg ? want : (want > 4096 ? 4096 : want)) : 0;
   if (M > 0) {
-    if (C == 16)
-      hipLaunchKernelGGL((k_rp_backward<16>), dim3(blocks), dim3(RP_THREADS), 0, st, dpooled, pooled, arg, idx, xyz, new_xyz,
-                         M, nsample, w_pos, save, dfeats, (double*)workspace);
-    else if (C == 32)
-      hipLaunchKernelGGL((k_rp_backward<32>), dim3(blocks), dim3(RP_THREADS), 0, st, dpooled, pooled, arg, idx, xyz, new_xyz,
-                         M, nsample, w_pos, save, dfeats, (double*)workspace);
-    else
-      hipLaunchKernelGGL((k_rp_backward<64>), dim3(blocks), dim3(RP_THREADS), 0, st, dpooled, pooled, arg, idx, xyz, new_xyz,
-                         M, nsample, w_pos, save, dfeats, (double*)workspace);
+#define RP_BWD_LAUNCH(C_, A_)                                                                                              \
+  hipLaunchKernelGGL((k_rp_backward<C_, A_>), dim3(blocks), dim3(RP_THREADS), 0, st, dpooled, pooled, arg, idx, xyz, new_xyz, M, \
+                     nsample, w_pos, save, dfeats, (double*)workspace)
+    if (C == 16) { if (agg) RP_BWD_LAUNCH(16, true); else RP_BWD_LAUNCH(16, false); }
+    else if (C == 32) { if (agg) RP_BWD_LAUNCH(32, true); else RP_BWD_LAUNCH(32, false); }
+    else { if (agg) RP_BWD_LAUNCH(64, true); else RP_BWD_LAUNCH(64, false); }
+#undef RP_BWD_LAUNCH
   }
   hipLaunchKernelGGL(k_rp_finalize_bwd, dim3(1), dim3(RP_FIN_THREADS), 0, st, (const double*)workspace,
                      blocks > RP_SETS ? RP_SETS : blocks, (double)M * nsample,
