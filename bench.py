@@ -267,7 +267,7 @@ def bench_bev(model, dev, frames=FRAMES_PER_GPU):
     # the own 3x3 kernels alone (csrc/glx_conv2d.hip), on the block layers' shapes: fp32-equivalent TFLOP/s (2 x
     # multiply-adds of the fp32 convolution) and the share of the 16-bit matrix pipe (2.5 PFLOP/s dense, fp16 = bf16) the piece
     # products per tile occupy: three fp16 products in the forward / input-gradient kernel (f16x2, the default; six bf16
-    # products under GLX_CONV3X3_ARITH=bf16x3, timed beside it), six bf16 products in the weight gradient
+    # products under GLX_CONV3X3_ARITH=bf16x3, timed beside it), three fp16 products in the weight gradient's second form
     from glenet_amd import conv2d as c2
     layers = {}
     arith = c2.arithmetic()
@@ -279,7 +279,8 @@ def bench_bev(model, dev, frames=FRAMES_PER_GPU):
         fl = 2.0 * frames * h * w * 9 * cin * cout
         t = {"forward": _timed(lambda: c2._run(xi, pf, cout), 20, dev), "input_grad": _timed(lambda: c2._run(gy, pb, cin), 20, dev),
              "weight_grad": _timed(lambda: c2.wgrad(xi, gy, wt), 20, dev)}
-        pieces = {"forward": 3 if arith == "f16x2" else 6, "input_grad": 3 if arith == "f16x2" else 6, "weight_grad": 6}
+        wform2 = os.environ.get("GLX_WGRAD_FORM", "2") == "2"        # the weight gradient's second form is f16 x 2 whatever `arith` is
+        pieces = {"forward": 3 if arith == "f16x2" else 6, "input_grad": 3 if arith == "f16x2" else 6, "weight_grad": 3 if wform2 else 6}
         entry = {k: dict(us=round(v * 1e3, 1), TFLOPs_fp32_equivalent=round(fl / v / 1e9, 1),
                          frac_of_fp32_mfma_peak=round(fl / v / 1e9 / MFMA_F32_PEAK_TFLOPS, 3), mfma_per_product_tile=pieces[k],
                          frac_of_16bit_pipe=round(pieces[k] * fl / v / 1e9 / MFMA_BF16_PEAK_TFLOPS, 3)) for k, v in t.items()}
@@ -331,7 +332,8 @@ def bench_bev(model, dev, frames=FRAMES_PER_GPU):
                 kernels="3x3 / stride-1 layers (11 of 12: forward, input and weight gradient): csrc/glx_conv2d.hip -- forward and "
                         "input gradient: fp32 products as three fp16 MFMAs of two-way split operands scaled by powers of two (per "
                         "output channel / per staged chunk), fp32 accumulation (f16x2; GLX_CONV3X3_ARITH=bf16x3: six bf16 MFMAs of "
-                        "three-way split operands); weight gradient: bf16x3; the two transposed "
+                        "three-way split operands); weight gradient: both operands through LDS, f16x2 with a running exponent over the block's "
+                        "tiles (GLX_WGRAD_FORM=1: the first form, bf16x3); the two transposed "
                         "convolutions (forward, both gradients) and the strided layer's forward: csrc/glx_deconv2d.hip, "
                         "bf16x3; the strided layer's gradients: MIOpen fp32 (vendor); the 1x1 anchor head: csrc/glx_head.hip "
                         "(fp32 MFMA); BatchNorm: csrc/glx_bn.hip -- forward statistics in the conv epilogue, the transform applied "
@@ -1083,8 +1085,8 @@ def main():
                                           "gradient of the 3x3 layers from two fp16 pieces per operand, scaled by powers of two "
                                           "per output channel and per staged chunk (three MFMAs per product tile, products to "
                                           "2^-20.4 at worst; conv3x3_arithmetic=%s, GLX_CONV3X3_ARITH=bf16x3 restores the "
-                                          "former), weight gradients and transposed convolutions from three bf16 pieces (six "
-                                          "MFMAs, products exact to 2^-22): error against an fp64 convolution within 2 x the "
+                                          "former), their weight gradient the same way per pixel tile, transposed convolutions from three "
+                                          "bf16 pieces (six MFMAs, products exact to 2^-22): error against an fp64 convolution within 2 x the "
                                           "vendor's fp32 kernels' (tests/test_conv2d_gpu.py, bev.conv3x3_error_vs_fp64, "
                                           "tests/test_oracle_cpu.py::test_split_bf16_pieces_carry_an_fp32_product)"
                                           % _conv_arith(),
