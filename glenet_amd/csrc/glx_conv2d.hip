@@ -1261,6 +1261,19 @@ static int wgrad_blocks(int Cin, int Cout, int* P_out) {
   return nq * P;
 }
 
+// the weight gradient's kernel form: 2 (default) = k_conv3x3_wgrad2 (both operands through LDS, f16 x 2), 1 = k_conv3x3_wgrad
+// (bf16 x 3, gy from global memory per k-step); GLX_WGRAD_FORM at load, glx_conv3x3_set_wgrad_form afterwards (returns the previous)
+static int env_wgrad_form() {
+  const char* e = getenv("GLX_WGRAD_FORM");
+  return e && atoi(e) == 1 ? 1 : 2;
+}
+static int g_wgrad_form = env_wgrad_form();
+extern "C" int glx_conv3x3_set_wgrad_form(int form) {
+  const int old = g_wgrad_form;
+  g_wgrad_form = form == 1 ? 1 : 2;
+  return old;
+}
+
 extern "C" size_t glx_conv3x3_wgrad_workspace_bytes(int Cin, int Cout) {
   int P = 0;
   const int blocks = wgrad_blocks(Cin, Cout, &P);
@@ -1297,8 +1310,7 @@ extern "C" int glx_conv3x3_wgrad_ex(const float* x, const float* gy, int B, int 
   a.nq = a.nq_ci * (Cout / CV_BN);
   const int blocks = wgrad_blocks(Cin, Cout, &a.P);
   static const bool pipe = getenv("GLX_WGRAD_PIPE") ? atoi(getenv("GLX_WGRAD_PIPE")) != 0 : true;
-  static const int form = getenv("GLX_WGRAD_FORM") ? atoi(getenv("GLX_WGRAD_FORM")) : 2;
-  if (form == 2)
+  if (g_wgrad_form == 2)
     hipLaunchKernelGGL(k_conv3x3_wgrad2, dim3(blocks), dim3(256), WG2_LDS, (hipStream_t)stream, a);
   else if (pipe)
     hipLaunchKernelGGL(k_conv3x3_wgrad<true>, dim3(blocks), dim3(256), WG_LDS, (hipStream_t)stream, a);

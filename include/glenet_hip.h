@@ -1111,6 +1111,9 @@ int glx_topk_desc_ws(const float* scores, int frames, int A, int K, float* top, 
  * base_bev_backbone.py:30-49's nn.Conv2d(3 x 3, stride 1) layers. */
 int glx_conv3x3_set_arith(int f16x2);
 int glx_conv3x3_get_arith(void);
+/* Kernel form of glx_conv3x3_wgrad[_ex]: 2 (default) = both operands through LDS, f16x2 with a running exponent over the block's
+ * pixel tiles; 1 = the first form (bf16x3, gy from global memory per k-step).  env GLX_WGRAD_FORM=1 at load; returns the previous. */
+int glx_conv3x3_set_wgrad_form(int form);
 /* glx_conv3x3_pack / glx_conv3x3_pack_multi with the layout named per call / per weight: f16x2 = 1 / 0, -1 = the process setting
  * (f16x2 array NULL = the process setting for all).  glx_conv3x3s2_forward* reads the bf16x3 forward image whatever the setting. */
 int glx_conv3x3_pack_arith(const float* W, long long s_co, long long s_ci, long long s_kh, long long s_kw, int Cin, int Cout,

@@ -187,6 +187,35 @@ def test_conv3x3_gradients_and_pack_refresh(dev):
     assert torch.allclose(y2, -2.0 * y.detach(), rtol=1e-5, atol=1e-5 * float(y.abs().max()))
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 64, 40, 48), (1, 128, 128, 100, 88), (2, 64, 128, 19, 37)])
+def test_both_weight_gradient_forms_match_fp64(dev, shape):
+    """The second form (both operands through LDS, f16x2 with a running exponent over the block's tiles: the default) and the
+    first (bf16x3) against an fp64 weight gradient and the vendor's: within 2 x the vendor fp32 kernel's error + 3e-7 of the
+    largest entry; and with operands spread over many magnitudes across the map (the running exponent steps down and the
+    accumulators are rescaled)."""
+    from glenet_amd import _lib, conv2d as c2
+    b, cin, cout, h, w = shape
+    g = torch.Generator(device=dev).manual_seed(sum(shape))
+    x = _cl(torch.randn(b, cin, h, w, device=dev, generator=g))
+    gy = _cl(torch.randn(b, cout, h, w, device=dev, generator=g))
+    wt = torch.randn(cout, cin, 3, 3, device=dev, generator=g)
+    ramp = torch.logspace(-6, 3, w, device=dev).view(1, 1, 1, w)             # nine orders of magnitude along a row
+    lib_w = torch.ops.aten.convolution_backward
+    for xs, gs in ((x, gy), (x * ramp, gy * ramp.flip(3))):
+        ref = lib_w(gs.double(), xs.double(), wt.double(), None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, [False, True, False])[1]
+        lib = lib_w(gs, xs, wt, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, [False, True, False])[1]
+        sc = ref.abs().max()
+        e_lib = (lib.double() - ref).abs().max() / sc
+        for form in (2, 1):
+            old = _lib.load().glx_conv3x3_set_wgrad_form(form)
+            try:
+                got = c2.wgrad(xs, gs, wt)
+            finally:
+                _lib.load().glx_conv3x3_set_wgrad_form(old)
+            err = (got.double() - ref).abs().max() / sc
+            assert err < 2.0 * e_lib + 3e-7, (form, float(err), float(e_lib))
+
+
 def test_conv3x3_weight_gradient_in_two_halves(dev):
     """glx_conv3x3_wgrad_ex with dW = NULL (the blocks' partial sums only) + glx_conv3x3_wgrad_reduce on another stream give
     the bits of the one-call form."""
