@@ -40,6 +40,6 @@ for cin, cout, h, w, xi, gy, wt, pf, pb in cases:
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / n * 1e3
-        k = 6 if (name == "weight_grad" or c2.arithmetic() == "bf16x3") else 3
+        k = (3 if os.environ.get("GLX_WGRAD_FORM", "2") == "2" else 6) if name == "weight_grad" else (6 if c2.arithmetic() == "bf16x3" else 3)
         print("%d->%d@%dx%d %-12s %7.1f us  %6.1f TFLOP/s fp32-equivalent  %.3f of the 16-bit pipe (%d MFMAs per product, 2.5 PF)"
               % (cin, cout, h, w, name, us, fl / us / 1e6, k * fl / us / 1e6 / 2500.0, k), flush=True)
