@@ -530,6 +530,14 @@ extern "C" int glx_pos_pool_forward_out(const float* feats, int N, int C, const 
   return GLX_OK;
 }
 
+static int g_rp_bwd_agg = getenv("GLX_RP_BWD_AGG") ? (atoi(getenv("GLX_RP_BWD_AGG")) != 0) : 1;
+// 1 (default): the feature gradient through the per-block LDS table; 0: one global atomic per (point, channel).  Returns the previous.
+extern "C" int glx_pos_pool_set_backward_form(int aggregate) {
+  const int old = g_rp_bwd_agg;
+  g_rp_bwd_agg = aggregate ? 1 : 0;
+  return old;
+}
+
 extern "C" int glx_pos_pool_backward(const float* dpooled, const float* pooled, const uint8_t* arg, const int32_t* idx,
                                      const float* xyz, const float* new_xyz, int M, int nsample, int C, int N,
                                      const float* w_pos, const float* gamma, const float* save, const double* moments,
@@ -555,7 +563,7 @@ extern "C" int glx_pos_pool_backward(const float* dpooled, const float* pooled, 
   // on x_conv2's 62 k; 4 frames x 128 RoIs x 216 points each) -- on the training step it pays on every scale: 5.46-5.48 ms with the
   // table everywhere against 5.52-5.55 with it on the coarsest scale only and 5.59-5.61 without (the serialised adds at the
   // memory side also hold up the BEV backward that runs beside them).  GLX_RP_BWD_AGG=0: one global atomic per (point, channel)
-  static const bool agg = getenv("GLX_RP_BWD_AGG") ? atoi(getenv("GLX_RP_BWD_AGG")) != 0 : true;
+  const bool agg = g_rp_bwd_agg != 0;
   const long long want = agg ? ((long long)M + RP_AGG_POINTS - 1) / RP_AGG_POINTS : ((long long)M + ppb_b - 1) / ppb_b;
   // (the aggregating form needs every point covered by ITS block: no cap on the grid)
   const int blocks = M > 0 ? (int)(agg ? want : (want > 4096 ? 4096 : want)) : 0;

@@ -869,6 +869,9 @@ int glx_pos_pool_forward(const float* feats, int N, int C, const float* xyz, con
                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                          int training, float* pooled, uint8_t* arg, float* save, double* moments,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* Form of glx_pos_pool_backward's feature gradient: 1 (default) = summed per block of 256 grid points in an LDS hash table, one global
+ * atomic per (occupied slot, channel); 0 = one global atomic per (point, channel).  env GLX_RP_BWD_AGG at load; returns the previous. */
+int glx_pos_pool_set_backward_form(int aggregate);
 /* The same with the layer's output MLP (voxel_pool_modules.py:105-108, mlps_out = Conv1d(C, C, 1, bias=False) + BatchNorm1d +
  * ReLU): y_out (M, C) = pooled @ w_out^T (w_out (C, C) row-major) formed in the pooling launch, with the training-mode
  * BatchNorm statistics of y_out taken on the way (bn_out: glx_bn_stats as in glx_conv_opts.bn; the transform is

@@ -738,6 +738,33 @@ def test_fused_position_pool_equals_the_unfused_training_path(dev, training):
         np.testing.assert_allclose(b1[k].cpu().numpy(), b2[k].cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
 
 
+def test_position_pool_backward_forms_agree(dev):
+    """glx_pos_pool_backward with the feature gradient summed in the per-block LDS table (default) and with one global atomic per
+    (point, channel): the same gradients up to the order of the float sums."""
+    from glenet_amd import _lib
+    rng = np.random.default_rng(81)
+    pool, feats, strides, rois, B = _roi_scene(dev, rng)
+    pool.train()
+    import copy
+    state = copy.deepcopy(pool.state_dict())
+    res = []
+    for form in (1, 0):
+        pool.load_state_dict(state)
+        old = _lib.load().glx_pos_pool_set_backward_form(form)
+        try:
+            res.append(_run_pool(pool, feats, strides, rois, B, dev))
+        finally:
+            _lib.load().glx_pos_pool_set_backward_form(old)
+    (o1, g1, p1, b1), (o2, g2, p2, b2) = res
+    assert torch.equal(o1, o2)
+    for k in g1:
+        assert float(g1[k].abs().max()) > 0
+        np.testing.assert_allclose(g1[k].cpu().numpy(), g2[k].cpu().numpy(), rtol=1e-4, atol=1e-6 + 1e-5 * float(g2[k].abs().max()))
+    for k in p1:
+        np.testing.assert_allclose(p1[k].cpu().numpy(), p2[k].cpu().numpy(), rtol=1e-3,
+                                   atol=1e-6 + 1e-4 * float(p2[k].abs().max()), err_msg=k)
+
+
 def test_position_pool_with_the_output_mlp_in_the_same_launch(dev):
     """glx_pos_pool_forward_out (k_rp_forward<C, true>: the layer's output Conv1d and its BatchNorm's batch statistics formed
     while a point's pooled row is in registers) against the pooling launch + GEMM + statistics pass: outputs, gradients of
