@@ -172,6 +172,18 @@ def load_traffic():
     return {}
 
 
+def _sconv_arith():
+    from glenet_amd import _lib
+    return "f16x2" if _lib.query("glx_sconv_get_arith") else "fp32"
+
+
+def _has_f16_image(kernel):
+    """k_sconv_gemm<cin,cout>: the channels glx_sconv_set_arith's fp16 image exists for."""
+    import re
+    m = re.match(r"k_sconv_gemm<(\d+),(\d+)>", kernel)
+    return bool(m) and int(m.group(1)) % 32 == 0 and int(m.group(2)) >= 64
+
+
 def roofline_of(per, prof_steps):
     """The contract object for the dominant sparse-conv kernel + the table of all of them."""
     if not per:
@@ -183,17 +195,22 @@ def roofline_of(per, prof_steps):
     alg_gbs = d["bytes"] / sec / 1e9
     tflops = d["flops"] / sec / 1e12
     hbm_frac_alg = alg_gbs / HBM_PEAK_GBS
-    mfma_frac = tflops / MFMA_F32_PEAK_TFLOPS
+    # the block kernel's products: fp32 MFMAs, or (GLX_SCONV_ARITH=f16x2, the default, where the channels have an fp16 image:
+    # Cin % 32 == 0 and Cout >= 64) two scaled fp16 pieces per operand and THREE 16-bit MFMAs per product tile -- its matrix
+    # roof is then a third of the dense 16-bit peak
+    f16 = _sconv_arith() == "f16x2" and _has_f16_image(dom)
+    mfma_peak = MFMA_BF16_PEAK_TFLOPS / 3 if f16 else MFMA_F32_PEAK_TFLOPS
+    mfma_frac = tflops / mfma_peak
     n = d["launches"]
     bmin = d["bytes_min"] / n
     # which roof binds: the kernel is output-stationary, so what reaches HBM is close to bytes_min (the PMC
     # traffic says how close), not the contract's per-rule figure; compare the time each roof would need
     t_hbm = (traffic if traffic else bmin) / (HBM_PEAK_GBS * 1e9)
-    t_mfma = d["flops"] / n / (MFMA_F32_PEAK_TFLOPS * 1e12)
+    t_mfma = d["flops"] / n / (mfma_peak * 1e12)
     bound = "mfma" if t_mfma >= t_hbm else "hbm"
     roof = dict(bound=bound, kernel=dom,
                 achieved=round(tflops if bound == "mfma" else alg_gbs, 2),
-                peak=MFMA_F32_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS,
+                peak=round(mfma_peak, 1) if bound == "mfma" else HBM_PEAK_GBS,
                 unit="TFLOP/s" if bound == "mfma" else "GB/s",
                 frac=round(mfma_frac if bound == "mfma" else hbm_frac_alg, 4),
                 traffic=traffic,
@@ -204,6 +221,10 @@ def roofline_of(per, prof_steps):
                                 "a full run's rocprof average of the same kernel also covers the training step's "
                                 "forward / input-gradient launches and the two-frames-in-flight replays (~10 % longer)",
                 flops_per_launch=int(d["flops"] / n), mfma_frac=round(mfma_frac, 4),
+                arithmetic=("f16x2: two scaled fp16 pieces per operand, three v_mfma_f32_16x16x32_f16 per product tile (>= 20.4 "
+                            "bits per product, fp32 sums); mfma_frac is of a third of the dense 16-bit peak"
+                            if f16 else "fp32: v_mfma_f32_16x16x4_f32, exact products; mfma_frac is of the fp32 matrix peak"),
+                frac_of_fp32_mfma_peak=round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
                 hbm=dict(achieved_algorithmic_GBps=round(alg_gbs, 1), frac_algorithmic=round(hbm_frac_alg, 4),
                          alg_bytes_per_launch=int(d["bytes"] / n), bytes_min_per_launch=int(bmin),
                          traffic_over_bytes_min=round(traffic / bmin, 3) if traffic else None,
@@ -615,7 +636,7 @@ def bench_config4(dev, frames=2, steps=60):
     if roof:
         out["dominant_kernel"] = dict(kernel=roof["kernel"], avg_launch_us=roof["avg_launch_us"], launches=roof["launches"],
                                       mfma_frac=roof["mfma_frac"], hbm_frac_algorithmic=roof["hbm"]["frac_algorithmic"],
-                                      TFLOPs=round(roof["mfma_frac"] * MFMA_F32_PEAK_TFLOPS, 2),
+                                      TFLOPs=round(roof["frac_of_fp32_mfma_peak"] * MFMA_F32_PEAK_TFLOPS, 2), arithmetic=roof["arithmetic"].split(":")[0],
                                       alg_GBps=roof["hbm"]["achieved_algorithmic_GBps"])
         out["all_sparse_conv"] = {k: roof["all_sparse_conv"][k] for k in ("achieved_algorithmic_GBps", "frac_algorithmic",
                                                                           "ms_per_step")}
@@ -715,7 +736,7 @@ def bench_config4_train(dev, pts, bidx, frames, steps=60):
         out["dominant_forward_kernel"] = dict(kernel=roof["kernel"], avg_launch_us=roof["avg_launch_us"],
                                               launches_per_step=roof["launches"] // n_prof,
                                               mfma_frac=roof["mfma_frac"], hbm_frac_algorithmic=roof["hbm"]["frac_algorithmic"],
-                                              TFLOPs=round(roof["mfma_frac"] * MFMA_F32_PEAK_TFLOPS, 2),
+                                              TFLOPs=round(roof["frac_of_fp32_mfma_peak"] * MFMA_F32_PEAK_TFLOPS, 2), arithmetic=roof["arithmetic"].split(":")[0],
                                               alg_GBps=roof["hbm"]["achieved_algorithmic_GBps"],
                                               note="forward AND input-gradient launches (the same kernel on adjoint weights)")
         out["forward_and_dgrad_kernels"] = roof["all_sparse_conv"]
@@ -1088,8 +1109,13 @@ def main():
                                           "former), their weight gradient the same way per pixel tile, transposed convolutions from three "
                                           "bf16 pieces (six MFMAs, products exact to 2^-22): error against an fp64 convolution within 2 x the "
                                           "vendor's fp32 kernels' (tests/test_conv2d_gpu.py, bev.conv3x3_error_vs_fp64, "
-                                          "tests/test_oracle_cpu.py::test_split_bf16_pieces_carry_an_fp32_product)"
-                                          % _conv_arith(),
+                                          "tests/test_oracle_cpu.py::test_split_bf16_pieces_carry_an_fp32_product); the sparse "
+                                          "convolutions with Cin in {32, 64, 128} -> Cout in {64, 128} the same way (sconv_arithmetic=%s: "
+                                          "the packed filter scaled by one power of two, every gathered row by its own; "
+                                          "GLX_SCONV_ARITH=fp32 restores exact fp32 MFMA products; tests/test_sparse_gpu.py), all other "
+                                          "sparse layers and the sparse weight gradient in fp32 MFMAs"
+                                          % (_conv_arith(), _sconv_arith()),
+                               sconv_arithmetic=_sconv_arith(),
                                host_enqueue_ms_per_step=round(t_host * 1e3, 4) if t_host is not None else None,
                                host_loop_ms_per_step=round(t_enq / max(args.steps, 1) * 1e3, 4),
                                host_note="host_enqueue = set_lr (2 fills) + load (1 launch) + graph replay(s) measured on 3 "

@@ -15,6 +15,7 @@
 // Weight gradient: k_wgrad_mfma (offset-stationary).  dense(): k_dense_from_index.
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 #include "glx_common.h"
@@ -201,6 +202,22 @@ struct SconvBf3Cfg {
   }
 };
 
+// Fourth image (k_sconv_gemm<..., F16 = true>): the weights as TWO fp16 planes of w 2^e (e = the filter's exponent: max |w| 2^e
+// in [2^14, 2^15), one per packed filter, kept in the 16 bytes behind the K images), w 2^e = a + b up to 2^-22, in the operand
+// order of v_mfma_f32_16x16x32_f16 with W^T as the row operand: per offset, column tile, 32-channel k-step and plane one 1 KB
+// block of 64 lanes x 8 fp16 -- lane l = (q, r) holds W[k][32 s + 8 q + j][16 tile + r], j = 0..7.  An offset's image has the
+// bytes of the fp32 image (CIN x COUT x 4): the block kernel's LDS budget and its three blocks per CU stay as they are.
+template <int CIN, int COUT>
+struct SconvF2Cfg {
+  static constexpr bool ON = CIN % 32 == 0 && COUT >= 64;
+  static constexpr int KS = CIN / 32, NT = COUT / 16;
+  static constexpr int IMG16 = ON ? CIN * COUT * 2 : 0;          // fp16 elements per offset
+  static constexpr int TAIL = ON ? 16 : 0;                       // bytes behind the K images: the exponent (int32)
+  __host__ __device__ static constexpr size_t idx(int k, int tile, int s, int plane, int lane) {
+    return ((((size_t)k * NT + tile) * KS + s) * 2 + plane) * 512 + (size_t)lane * 8;
+  }
+};
+
 // Both packed images in one launch.  view: bit 0 = the source is the (K, COUT, CIN) weight of the
 // conv this one is the adjoint of (read transposed), bit 1 = kernel taps reversed (the input
 // gradient of a submanifold conv walks the same rule table with flipped taps).
@@ -234,6 +251,38 @@ __device__ __forceinline__ void sc_pack_elem(int e, const float* __restrict__ W,
     Wb[B3::idx(k, ct, 0, s3, lane3) + j3] = p0;
     Wb[B3::idx(k, ct, 1, s3, lane3) + j3] = p1;
     Wb[B3::idx(k, ct, 2, s3, lane3) + j3] = p2;
+  }
+  using F2 = SconvF2Cfg<CIN, COUT>;
+  if constexpr (F2::ON) {              // the two scaled fp16 planes behind those; the exponent was written by k_sconv_wexp
+    _Float16* Wh = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(Wsplit + (size_t)K * S::IMG) + (size_t)K * B3::IMG16 * 2);
+    const int ew = *reinterpret_cast<const int*>(Wh + (size_t)K * F2::IMG16);
+    _Float16 pa, pb;
+    cv_split2(ldexpf(w, ew), pa, pb);
+    const int s2 = ci / 32, lane2 = ((ci % 32) / 8) * 16 + n, j2 = ci % 8;
+    Wh[F2::idx(k, ct, s2, 0, lane2) + j2] = pa;
+    Wh[F2::idx(k, ct, s2, 1, lane2) + j2] = pb;
+  }
+}
+
+// the exponent of a filter's fp16 image: block b takes job b, max |w| over the whole source tensor (the column halves of a
+// 128 -> 128 filter share it); all-zero filters get 0
+struct ScExpJob { const float* W; int* dst; int n; };
+struct ScExpJobs { ScExpJob j[40]; };   // <= SC_PACK_MAX_JOBS
+__global__ __launch_bounds__(1024) void k_sconv_wexp(ScExpJobs jobs) {
+  const ScExpJob jb = jobs.j[blockIdx.x];
+  __shared__ float s_m[16];
+  float m = 0.f;
+  for (int e = threadIdx.x * 4; e < jb.n; e += 4096) {              // n % 4 == 0: channels are multiples of 4
+    const f32x4 v = *reinterpret_cast<const f32x4*>(jb.W + e);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, s_m[w]);
+    const int e = cv_block_exponent(m);
+    *jb.dst = e == 127 ? 0 : e;
   }
 }
 
@@ -656,6 +705,28 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
   }
 }
 
+// max |v| over the SEGS lanes that hold one gathered row (SEGS = 8, 16: within a DPP row; 32: two rows), the same value in all of
+// them.  Hand-written: the compiler's form of fmaxf over update_dpp is four instructions per step (mov_dpp, two canonicalising
+// maxima, a hazard nop); the values are |x|, no NaN handling is wanted here.  s_nop 1 = the two wait states between a VALU write
+// and a DPP read of the same register, which nobody inserts inside an asm statement.
+template <int SEGS>
+__device__ __forceinline__ float sc_row_absmax(const f32x4 v) {
+  float m;
+  asm volatile("v_max3_f32 %0, |%1|, |%2|, |%3|\n\t"
+               "v_max_f32 %0, |%4|, %0\n\t"
+               "s_nop 1\n\t"
+               "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\t"
+               "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\t"
+               "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
+               : "=&v"(m) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+  if constexpr (SEGS >= 16)
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(m));
+  if constexpr (SEGS >= 32) m = fmaxf(m, __shfl_xor(m, 16));
+  return m;
+}
+
 // ==================================================================== block implicit GEMM
 // Same output-stationary scheme as k_sconv_mfma (rule compaction per offset, fp32 accumulator tile
 // in LDS, fixed summation order), organised like a blocked GEMM:
@@ -688,7 +759,7 @@ struct SconvGemm {
   static_assert(LW <= NW && TR <= 256, "bad tile");
 };
 
-template <int CIN, int COUT, int TR_, int NW_, int WPG_, bool TRACE = false, bool PRE = false>
+template <int CIN, int COUT, int TR_, int NW_, int WPG_, bool TRACE = false, bool PRE = false, bool F16 = false>
 __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
     const float* __restrict__ in, const float* __restrict__ Wp, SconvEpilogue ep,
     const int* __restrict__ nbr, const int* __restrict__ tile_order, int N_out, int K,
@@ -706,7 +777,14 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
   int* s_cnt = s_rows + TR;                                   // 32
   int* s_wcnt = s_cnt + 32;                                   // LW * 32
   unsigned char* s_pslot = reinterpret_cast<unsigned char*>(s_wcnt + LW * 32);  // SC_MAXK * TR
+  signed char* s_aexp = reinterpret_cast<signed char*>(s_pslot + SC_MAXK * TR);  // F16: the staged rows' exponents (AP <= 64)
   float* s_pre = reinterpret_cast<float*>(s_pslot + SC_MAXK * TR + 64);         // 2 * CIN: scale | shift of the prologue
+  static_assert(!F16 || (SconvF2Cfg<CIN, COUT>::ON && T::AP <= 64), "no fp16 image for these channels");
+  // F16: the products come from two fp16 pieces per operand and three MFMAs (glx_conv2d.hip has the arithmetic): the filter was
+  // scaled by 2^ew when it was packed, a gathered row is scaled by its own 2^ea when it is staged, and a chunk's sums lose
+  // 2^-(ea + ew) on their way into the accumulator tile
+  int ew = 0;
+  if constexpr (F16) ew = *reinterpret_cast<const int*>(Wp + (size_t)K * S::IMG);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -800,6 +878,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
   // ---- staging registers: next weight image and next panel of gathered rows
   f32x4 wreg[T::SPT];
   f32x4 areg[T::GPT];
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 #define GM_LOAD_W(KK)                                                                       \
   {                                                                                         \
     const f32x4* src_ = reinterpret_cast<const f32x4*>(Wp + (size_t)(KK) * S::IMG);         \
@@ -823,7 +902,33 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
       int p_ = (PB) + pair_;                                                                \
       int irow_ = 0;                                                                        \
       if (p_ < (CNT) && pair_ < T::AP) irow_ = s_pin[(KK) * TR + p_];                       \
+      if (TRACE && (ep.xcd_group & 0x4000)) irow_ = p_ & 7;   /* 0x4000: ablate the gather (eight cache-hot rows) */ \
       areg[i_] = *reinterpret_cast<const f32x4*>(in + (long long)irow_ * CIN + seg_ * 4);   \
+    }                                                                                       \
+  }
+  // F16: a gathered row segment becomes two fp16 pieces (x, y = the four first pieces, z, w = the second ones) of the
+  // row scaled by its own power of two -- the row's maximum over the lanes that hold it (SEGS = CIN / 4 of them)
+  int aex[T::GPT];
+#define GM_SPLIT_A()                                                                        \
+  {                                                                                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < T::GPT; ++i_) {                                 \
+      f32x4 v_ = areg[i_];                                                                  \
+      if constexpr (PRE) {                                                                  \
+        const int seg_ = (tid + i_ * THREADS) % T::SEGS;                                    \
+        const f32x4 sc_ = *reinterpret_cast<const f32x4*>(s_pre + seg_ * 4);                \
+        const f32x4 sh_ = *reinterpret_cast<const f32x4*>(s_pre + CIN + seg_ * 4);          \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) v_[c_] = fmaxf(bn_affine(v_[c_], sc_[c_], sh_[c_]), 0.f); \
+      }                                                                                     \
+      const float m_ = sc_row_absmax<T::SEGS>(v_);                                          \
+      const int ex0_ = cv_block_exponent(m_);                                               \
+      const int ex_ = ex0_ == 127 ? 0 : ex0_;                                               \
+      aex[i_] = ex_;                                                                        \
+      const float s_ = __builtin_bit_cast(float, (unsigned)(ex_ + 127) << 23);              \
+      f16x4 pa_, pb_;                                                                       \
+      _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) { _Float16 a_, b_; cv_split2(v_[c_] * s_, a_, b_); pa_[c_] = a_; pb_[c_] = b_; } \
+      const f32x2_t lo_ = __builtin_bit_cast(f32x2_t, pa_), hi_ = __builtin_bit_cast(f32x2_t, pb_); \
+      areg[i_] = f32x4{lo_[0], lo_[1], hi_[0], hi_[1]};                                     \
+      asm volatile("" : "+v"(areg[i_]));   /* formed HERE (in front of the barrier), not where the store wants it */ \
     }                                                                                       \
   }
 #define GM_STORE_A()                                                                        \
@@ -832,6 +937,14 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
       int e_ = tid + i_ * THREADS;                                                          \
       int pair_ = e_ / T::SEGS, seg_ = e_ - pair_ * T::SEGS;                                \
       f32x4 v_ = areg[i_];                                                                  \
+      if constexpr (F16) {   /* GM_SPLIT_A() has run: plane a in the row's first CIN halves, plane b behind */ \
+        if (T::A_SEG % THREADS == 0 || e_ < T::A_SEG) {                                     \
+          *reinterpret_cast<f32x2_t*>(s_a + pair_ * T::A_LD + seg_ * 2) = f32x2_t{v_[0], v_[1]};           \
+          *reinterpret_cast<f32x2_t*>(s_a + pair_ * T::A_LD + CIN / 2 + seg_ * 2) = f32x2_t{v_[2], v_[3]}; \
+          if (seg_ == 0) s_aexp[pair_] = (signed char)aex[i_];                              \
+        }                                                                                   \
+        continue;                                                                           \
+      }                                                                                     \
       if constexpr (PRE) {   /* the prologue: BatchNorm + ReLU of the layer in front on the row segment's channels */ \
         const f32x4 sc_ = *reinterpret_cast<const f32x4*>(s_pre + seg_ * 4);                \
         const f32x4 sh_ = *reinterpret_cast<const f32x4*>(s_pre + CIN + seg_ * 4);          \
@@ -849,6 +962,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
     GM_LOAD_W(k);
     GM_LOAD_A(k, 0, cnt);
     GM_STORE_W();
+    if constexpr (F16) GM_SPLIT_A();
     GM_STORE_A();
     __syncthreads();
     if constexpr (TRACE) t_loop = wall_clock64();
@@ -920,6 +1034,50 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
           }
         }
       } else
+      if constexpr (F16) { if (pbase < cnt && !(TRACE && (ep.xcd_group & 0x100))) {   // wave-uniform (0x100: ablate the multiply)
+        constexpr int KS = CIN / 32;
+        const _Float16* arow = reinterpret_cast<const _Float16*>(s_a + (grp * 16 + r) * T::A_LD) + q * 8;
+        f16x8 Xa[KS], Xb[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          Xa[ks] = *reinterpret_cast<const f16x8*>(arow + ks * 32);
+          Xb[ks] = *reinterpret_cast<const f16x8*>(arow + CIN + ks * 32);
+        }
+        // where the sums go and what they lose on the way: read for every lane (absent pairs read some slot of the tile and
+        // write nothing), so that these reads and the tile's old values travel under the MFMAs instead of behind them
+        const int p = pbase + r;
+        const int et = -((int)s_aexp[grp * 16 + r] + ew);
+        float* dst = s_acc + ((int)s_pslot[k * TR + p] & (TR - 1)) * ACC_LD + tile0 * 16 + 4 * q;
+        f32x4 old[T::TPW];
+#pragma unroll
+        for (int tt = 0; tt < T::TPW; ++tt) old[tt] = *reinterpret_cast<f32x4*>(dst + tt * 16);
+        f32x4 acc[T::TPW];
+#pragma unroll
+        for (int tt = 0; tt < T::TPW; ++tt) {
+          acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const _Float16* wp = reinterpret_cast<const _Float16*>(s_w) + (size_t)(tile0 + tt) * KS * 1024 + lane * 8;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const f16x8 Wa = *reinterpret_cast<const f16x8*>(wp + ks * 1024);
+            const f16x8 Wb = *reinterpret_cast<const f16x8*>(wp + ks * 1024 + 512);
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wb, Xa[ks], acc[tt], 0, 0, 0);   // smallest first
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xb[ks], acc[tt], 0, 0, 0);
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xa[ks], acc[tt], 0, 0, 0);
+          }
+        }
+        if (TRACE && (ep.xcd_group & 0x200)) {   // 0x200: ablate the accumulate
+          asm volatile("" ::"v"(acc[0]));
+        } else
+        if (p < cnt) {
+#pragma unroll
+          for (int tt = 0; tt < T::TPW; ++tt) {
+            f32x4 v = old[tt];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] += ldexpf(acc[tt][c], et);
+            *reinterpret_cast<f32x4*>(dst + tt * 16) = v;
+          }
+        }
+      } } else
       if (pbase < cnt && !(TRACE && (ep.xcd_group & 0x100))) {   // wave-uniform (0x100: ablate the multiply)
         const float* arow = s_a + (grp * 16 + r) * T::A_LD + q * CQ;
         float Am[CQ];
@@ -976,6 +1134,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
         if constexpr (TRACE) { tph[0] += c1 - c0; tph[1] += c2 - c1; }
         break;
       }
+      if constexpr (F16) if (!(TRACE && (ep.xcd_group & 0x8000))) { GM_SPLIT_A(); __builtin_amdgcn_sched_barrier(0); }   // in front of the barrier, and kept there (0x8000: ablate the split): the conversions overlap the other waves' multiplies
       __syncthreads();   // everyone is done reading the panel and the weight image
       if constexpr (TRACE) c3 = clock64();
       GM_STORE_A();
@@ -996,6 +1155,7 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
 #undef GM_STORE_W
 #undef GM_LOAD_A
 #undef GM_STORE_A
+#undef GM_SPLIT_A
   __syncthreads();
 
   // ---- epilogue: coalesced row stores with the fused pointwise tail (+ BatchNorm statistics)
@@ -1045,13 +1205,13 @@ struct SconvGemm2 {
   static constexpr int WF = TPW * (CQ / 4);                  // f32x4 registers of one weight fragment set
   static constexpr int ACC_LD = COUT + 4;
   static constexpr size_t lds_bytes = (size_t)TR * ACC_LD * 4 + 2 * (size_t)AP * A_LD * 4 +
-                                      (size_t)SC_MAXK * TR * 5 + (TR + 32) * 4 + 64;
+                                      (size_t)SC_MAXK * TR * 5 + (TR + 32) * 4 + 64 + (size_t)CIN * 8;
   static_assert(TR == 64, "one wave spans the tile");
   static_assert(CQ % 4 == 0, "weights-in-registers kernel: CIN >= 16");
   static_assert(NW % WPG == 0 && NT % WPG == 0, "bad column split");
 };
 
-template <int CIN, int COUT, int TR_, int NW_, int WPG_>
+template <int CIN, int COUT, int TR_, int NW_, int WPG_, bool PRE = false, bool F16 = false>
 __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm2(
     const float* __restrict__ in, const float* __restrict__ Wp, SconvEpilogue ep,
     const int* __restrict__ nbr, const int* __restrict__ tile_order, int N_out, int K,
@@ -1067,6 +1227,11 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm2(
   int* s_rows = s_pin + SC_MAXK * TR;                             // TR
   int* s_cnt = s_rows + TR;                                       // 32
   unsigned char* s_pslot = reinterpret_cast<unsigned char*>(s_cnt + 32);   // SC_MAXK * TR
+  signed char* s_aexp = reinterpret_cast<signed char*>(s_pslot + SC_MAXK * TR);   // F16: 2 x AP row exponents (in the 64 spare bytes)
+  float* s_pre = reinterpret_cast<float*>(s_pslot + SC_MAXK * TR + 64);           // PRE: 2 * CIN scale | shift
+  static_assert(!F16 || (SconvF2Cfg<CIN, COUT>::ON && 2 * T::AP <= 64), "no fp16 image for these channels");
+  int ew = 0;                              // F16: see k_sconv_gemm
+  if constexpr (F16) ew = *reinterpret_cast<const int*>(Wp + (size_t)K * S::IMG);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -1074,6 +1239,9 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm2(
   const int row0 = (ep.tile_map ? ep.tile_map[blockIdx.x] : sc_xcd_tile(blockIdx.x, gridDim.x, ep.xcd_group & 0xFF)) * TR;
   const int grp = wave / T::WPG;
   const int tile0 = (wave % T::WPG) * T::TPW;
+  if constexpr (PRE) {         // visible to everybody behind the compaction's barrier
+    for (int e = tid; e < CIN; e += THREADS) { s_pre[e] = ep.pre_scale[e]; s_pre[CIN + e] = ep.pre_shift[e]; }
+  }
 
   // ---- tile rows, zero accumulators, rule compaction: every wave compacts a share of the offsets
   for (int i = tid; i < TR * ACC_LD / 4; i += THREADS)
@@ -1112,7 +1280,13 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm2(
   f32x4 areg[T::GPT];
   // this wave's fragment of offset KK: S::idx(tile, q, 4 * t4, r) = ((tile * 4 + q) * (CQ / 4) + t4) * 64 + r * 4
 #define G2_LOAD_W(KK)                                                                        \
-  {                                                                                          \
+  if constexpr (F16) {   /* SconvF2Cfg::idx: 1 KB per (tile, k-step, plane), a lane's 16 bytes at lane * 16 */ \
+    const float* src_ = Wp + (size_t)(KK) * S::IMG + lane * 4;                               \
+    _Pragma("unroll") for (int tt_ = 0; tt_ < T::TPW; ++tt_) {                               \
+      _Pragma("unroll") for (int u_ = 0; u_ < CQ / 4; ++u_)                                  \
+        wnxt[tt_ * (CQ / 4) + u_] = *reinterpret_cast<const f32x4*>(src_ + ((tile0 + tt_) * (CQ / 4) + u_) * 256); \
+    }                                                                                        \
+  } else {                                                                                   \
     const float* src_ = Wp + (size_t)(KK) * S::IMG + r * 4;                                  \
     _Pragma("unroll") for (int tt_ = 0; tt_ < T::TPW; ++tt_) {                               \
       _Pragma("unroll") for (int t4_ = 0; t4_ < CQ / 4; ++t4_)                               \
@@ -1137,8 +1311,26 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm2(
     _Pragma("unroll") for (int i_ = 0; i_ < T::GPT; ++i_) {                                  \
       int e_ = tid + i_ * THREADS;                                                           \
       int pair_ = e_ / T::SEGS, seg_ = e_ - pair_ * T::SEGS;                                 \
-      if (T::A_SEG % THREADS == 0 || e_ < T::A_SEG)                                          \
-        *reinterpret_cast<f32x4*>(dst_ + pair_ * T::A_LD + seg_ * 4) = areg[i_];             \
+      f32x4 v_ = areg[i_];                                                                   \
+      if constexpr (PRE) {                                                                   \
+        const f32x4 sc_ = *reinterpret_cast<const f32x4*>(s_pre + seg_ * 4);                 \
+        const f32x4 sh_ = *reinterpret_cast<const f32x4*>(s_pre + CIN + seg_ * 4);           \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) v_[c_] = fmaxf(bn_affine(v_[c_], sc_[c_], sh_[c_]), 0.f); \
+      }                                                                                      \
+      if constexpr (F16) {   /* two fp16 pieces of the row scaled by its own power of two (k_sconv_gemm) */ \
+        const float m_ = sc_row_absmax<T::SEGS>(v_);                                         \
+        const int ex0_ = cv_block_exponent(m_);                                              \
+        const int ex_ = ex0_ == 127 ? 0 : ex0_;                                              \
+        const float s_ = __builtin_bit_cast(float, (unsigned)(ex_ + 127) << 23);             \
+        f16x4 pa_, pb_;                                                                      \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) { _Float16 a_, b_; cv_split2(v_[c_] * s_, a_, b_); pa_[c_] = a_; pb_[c_] = b_; } \
+        if (T::A_SEG % THREADS == 0 || e_ < T::A_SEG) {                                      \
+          *reinterpret_cast<f16x4*>(dst_ + pair_ * T::A_LD + seg_ * 2) = pa_;                \
+          *reinterpret_cast<f16x4*>(dst_ + pair_ * T::A_LD + CIN / 2 + seg_ * 2) = pb_;      \
+          if (seg_ == 0) s_aexp[(BUF) * T::AP + pair_] = (signed char)ex_;                   \
+        }                                                                                    \
+      } else if (T::A_SEG % THREADS == 0 || e_ < T::A_SEG)                                   \
+        *reinterpret_cast<f32x4*>(dst_ + pair_ * T::A_LD + seg_ * 4) = v_;                   \
     }                                                                                        \
   }
 
@@ -1167,11 +1359,46 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm2(
         }
       }
       if (has_next) {
-        if (new_w) G2_LOAD_W(kn);            // first: the gathers below must not stand between W and its use
+        if (new_w) { G2_LOAD_W(kn); }        // first: the gathers below must not stand between W and its use
         G2_LOAD_A(kn, pbn, cntn);
       }
       // ---- multiply this wave's chunk of the current panel by its column tile(s)
       const int pbase = pb + grp * 16;
+      if constexpr (F16) { if (pbase < cnt) {   // wave-uniform
+        constexpr int KS = CIN / 32;
+        const _Float16* arow = reinterpret_cast<const _Float16*>(s_a + buf * (T::AP * T::A_LD) + (grp * 16 + r) * T::A_LD) + q * 8;
+        f16x8 Xa[KS], Xb[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          Xa[ks] = *reinterpret_cast<const f16x8*>(arow + ks * 32);
+          Xb[ks] = *reinterpret_cast<const f16x8*>(arow + CIN + ks * 32);
+        }
+        f32x4 acc[T::TPW];
+#pragma unroll
+        for (int tt = 0; tt < T::TPW; ++tt) {
+          acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const f16x8 Wa = __builtin_bit_cast(f16x8, wcur[tt * (CQ / 4) + 2 * ks]);
+            const f16x8 Wb = __builtin_bit_cast(f16x8, wcur[tt * (CQ / 4) + 2 * ks + 1]);
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wb, Xa[ks], acc[tt], 0, 0, 0);
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xb[ks], acc[tt], 0, 0, 0);
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xa[ks], acc[tt], 0, 0, 0);
+          }
+        }
+        const int p = pbase + r;
+        if (p < cnt) {
+          const int et = -((int)s_aexp[buf * T::AP + grp * 16 + r] + ew);
+          float* dst = s_acc + (int)s_pslot[k * TR + p] * ACC_LD + tile0 * 16 + 4 * q;
+#pragma unroll
+          for (int tt = 0; tt < T::TPW; ++tt) {
+            f32x4 v = *reinterpret_cast<f32x4*>(dst + tt * 16);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] += ldexpf(acc[tt][c], et);
+            *reinterpret_cast<f32x4*>(dst + tt * 16) = v;
+          }
+        }
+      } } else
       if (pbase < cnt) {                     // wave-uniform
         const float* arow = s_a + buf * (T::AP * T::A_LD) + (grp * 16 + r) * T::A_LD + q * CQ;
         float Am[CQ];
@@ -1478,9 +1705,18 @@ static bool mfma_supported(int Cin, int Cout, int K) {
 }
 
 template <int CIN, int COUT>
-static size_t img_bytes() {   // both LDS images (whole-chunk and column-split layout) of one offset + the bf16 planes
+static size_t img_bytes() {   // both LDS images (whole-chunk and column-split layout) of one offset + the bf16 and fp16 planes
   return (size_t)(SconvCfg<CIN, COUT>::IMG + SconvSplitCfg<CIN, COUT>::IMG) * sizeof(float) +
-         (size_t)SconvBf3Cfg<CIN, COUT>::IMG16 * 2;
+         (size_t)SconvBf3Cfg<CIN, COUT>::IMG16 * 2 + (size_t)SconvF2Cfg<CIN, COUT>::IMG16 * 2;
+}
+template <int CIN, int COUT>
+static size_t filter_bytes(int K) {   // a packed filter: K offsets of every image, then the fp16 image's exponent
+  return (size_t)K * img_bytes<CIN, COUT>() + SconvF2Cfg<CIN, COUT>::TAIL;
+}
+// where a packed filter keeps its fp16 planes (the exponent sits behind them) -- Wp = start of the packed filter
+template <int CIN, int COUT>
+static float* f2_image(float* Wp, int K) {
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(Wp) + (size_t)K * (img_bytes<CIN, COUT>() - (size_t)SconvF2Cfg<CIN, COUT>::IMG16 * 2));
 }
 // A 128 -> 128 conv runs as two column halves (launch_mfma): its 64 KB weight image per offset would
 // leave ONE 4-wave block per CU.  The packed buffer then also holds the two (128, 64) half images.
@@ -1505,8 +1741,8 @@ static size_t packed_bytes(int K, int Cin, int Cout) {
   size_t b = 0;
   sc_dispatch(Cin, Cout, [&](auto ci, auto co) {
     constexpr int CI = decltype(ci)::value, CO = decltype(co)::value;
-    b = (size_t)K * img_bytes<CI, CO>();
-    if constexpr (sc_column_halves<CI, CO>()) b += 2 * (size_t)K * img_bytes<CI, CO / 2>();
+    b = filter_bytes<CI, CO>(K);
+    if constexpr (sc_column_halves<CI, CO>()) b += 2 * filter_bytes<CI, CO / 2>(K);
     return 0;
   });
   return b;
@@ -1533,12 +1769,23 @@ static int pack_weights(const float* W, int K, float* Wp, int view, hipStream_t 
   using S = SconvSplitCfg<CI, CO>;
   static_assert(S::IMG == CI * CO, "the split image has no padding");
   const int nel = K * CI * CO, cover = K * C::IMG > nel ? K * C::IMG : nel;   // C::IMG >= CI*CO (padding)
+  ScExpJobs ex;
+  int nex = 0;
+  if constexpr (SconvF2Cfg<CI, CO>::ON)
+    ex.j[nex++] = ScExpJob{W, reinterpret_cast<int*>(f2_image<CI, CO>(Wp, K) + (size_t)K * S::IMG), nel};
+  if constexpr (sc_column_halves<CI, CO>()) {
+    const size_t half = filter_bytes<CI, CO / 2>(K) / sizeof(float);
+    float* base = Wp + filter_bytes<CI, CO>(K) / sizeof(float);
+    for (int h = 0; h < 2; ++h)
+      ex.j[nex++] = ScExpJob{W, reinterpret_cast<int*>(f2_image<CI, CO / 2>(base + h * half, K) + (size_t)K * SconvSplitCfg<CI, CO / 2>::IMG), nel};
+  }
+  if (nex) hipLaunchKernelGGL(k_sconv_wexp, dim3(nex), dim3(1024), 0, st, ex);
   hipLaunchKernelGGL((k_pack_weights<CI, CO>), dim3(glx_divup(cover, 256)), dim3(256), 0, st, W, K,
                      Wp, Wp + (size_t)K * C::IMG, view, CO, 0);
   if constexpr (sc_column_halves<CI, CO>()) {
     using CH = SconvCfg<CI, CO / 2>;
-    const size_t half = (size_t)K * img_bytes<CI, CO / 2>() / sizeof(float);
-    float* base = Wp + (size_t)K * img_bytes<CI, CO>() / sizeof(float);
+    const size_t half = filter_bytes<CI, CO / 2>(K) / sizeof(float);
+    float* base = Wp + filter_bytes<CI, CO>(K) / sizeof(float);
     const int nh = K * CI * (CO / 2), ch = K * CH::IMG > nh ? K * CH::IMG : nh;
     for (int h = 0; h < 2; ++h)
       hipLaunchKernelGGL((k_pack_weights<CI, CO / 2>), dim3(glx_divup(ch, 256)), dim3(256), 0, st, W, K,
@@ -1569,6 +1816,19 @@ extern "C" int glx_sconv_set_xcd_group(int g) {
   g_sconv_xcd_group = g;
   return GLX_OK;
 }
+// arithmetic of the block kernel's products (GLX_SCONV_ARITH / glx_sconv_set_arith): 0 = fp32 MFMAs (exact products),
+// 1 = two scaled fp16 pieces per operand and three fp16 MFMAs per product tile (>= 20.4 bits per product); layers whose
+// channels have no fp16 image (CIN % 32, COUT < 64) run the fp32 form either way
+static int env_sconv_f16() {
+  const char* e = getenv("GLX_SCONV_ARITH");
+  return e ? (strcmp(e, "fp32") != 0) : 1;
+}
+static int g_sconv_f16 = env_sconv_f16();
+extern "C" int glx_sconv_set_arith(int f16x2) {
+  g_sconv_f16 = f16x2 != 0;
+  return GLX_OK;
+}
+extern "C" int glx_sconv_get_arith(void) { return g_sconv_f16; }
 extern "C" int glx_sconv_set_variant(int v) {
   g_sconv_variant = v;
   return GLX_OK;
@@ -1623,7 +1883,7 @@ static int launch_tile(const float* in, const float* Wp, const SconvEpilogue& ep
   }
 }
 
-template <int CI, int CO, int TR, int NW, int WPG_REQ>
+template <int CI, int CO, int TR, int NW, int WPG_REQ, bool F16 = false>
 static int launch_gemm(const float* in, const float* Wp, const SconvEpilogue& ep,
                        const int32_t* nbr, const int32_t* tile_order, int N_out, int K, float* out,
                        hipStream_t st) {
@@ -1636,20 +1896,21 @@ static int launch_gemm(const float* in, const float* Wp, const SconvEpilogue& ep
   } else {
     static bool attr_set = false;
     constexpr bool HAS_PRE = CI >= 16 && TR == 64;                   // the instantiations glx_sconv_opts.prologue reaches
-    auto kern = ep.pre_scale ? k_sconv_gemm<CI, CO, TR, NW, WPG, false, HAS_PRE> : k_sconv_gemm<CI, CO, TR, NW, WPG>;
+    auto kern = ep.pre_scale ? k_sconv_gemm<CI, CO, TR, NW, WPG, false, HAS_PRE, F16> : k_sconv_gemm<CI, CO, TR, NW, WPG, false, false, F16>;
     const size_t lds = T::lds_bytes + (size_t)((ep.xcd_group >> 16) & 0xFF) * 1024;   // bits 16-23: experiments, KB of padding
     if (!attr_set) {
-      GLX_HIP(hipFuncSetAttribute((const void*)k_sconv_gemm<CI, CO, TR, NW, WPG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      GLX_HIP(hipFuncSetAttribute((const void*)k_sconv_gemm<CI, CO, TR, NW, WPG, false, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
-      GLX_HIP(hipFuncSetAttribute((const void*)k_sconv_gemm<CI, CO, TR, NW, WPG, false, HAS_PRE>,
+      GLX_HIP(hipFuncSetAttribute((const void*)k_sconv_gemm<CI, CO, TR, NW, WPG, false, HAS_PRE, F16>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr_set = true;
     }
-    const float* Wsplit = Wp + (size_t)K * SconvCfg<CI, CO>::IMG;   // second image of the packed buffer
+    // second image of the packed buffer, or (F16) the fourth with its exponent behind it
+    const float* Wsplit = F16 ? f2_image<CI, CO>(const_cast<float*>(Wp), K) : Wp + (size_t)K * SconvCfg<CI, CO>::IMG;
     int nblocks = glx_divup(N_out, TR);
     if (ep.trace) {
       if constexpr (CI == 64 && CO == 64 && TR == 64 && NW == 8) {
-        auto tkern = k_sconv_gemm<CI, CO, TR, NW, WPG, true>;
+        auto tkern = k_sconv_gemm<CI, CO, TR, NW, WPG, true, false, F16>;
         GLX_HIP(hipFuncSetAttribute((const void*)tkern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
         hipLaunchKernelGGL(tkern, dim3(nblocks), dim3(T::THREADS), lds, st, in, Wsplit, ep, nbr,
@@ -1671,7 +1932,7 @@ static int launch_gemm(const float* in, const float* Wp, const SconvEpilogue& ep
   }
 }
 
-template <int CI, int CO, int TR, int NW, int WPG_REQ>
+template <int CI, int CO, int TR, int NW, int WPG_REQ, bool F16 = false>
 static int launch_gemm2(const float* in, const float* Wp, const SconvEpilogue& ep,
                         const int32_t* nbr, const int32_t* tile_order, int N_out, int K, float* out,
                         hipStream_t st) {
@@ -1682,15 +1943,16 @@ static int launch_gemm2(const float* in, const float* Wp, const SconvEpilogue& e
   } else {
     using T = SconvGemm2<CI, CO, TR, NW, WPG>;
     static bool attr_set = false;
-    auto kern = k_sconv_gemm2<CI, CO, TR, NW, WPG>;
+    auto kern = ep.pre_scale ? k_sconv_gemm2<CI, CO, TR, NW, WPG, true, F16> : k_sconv_gemm2<CI, CO, TR, NW, WPG, false, F16>;
     const size_t lds = T::lds_bytes;
     if (!attr_set) {
-      GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      GLX_HIP(hipFuncSetAttribute((const void*)k_sconv_gemm2<CI, CO, TR, NW, WPG, true, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      GLX_HIP(hipFuncSetAttribute((const void*)k_sconv_gemm2<CI, CO, TR, NW, WPG, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr_set = true;
     }
-    const float* Wsplit = Wp + (size_t)K * SconvCfg<CI, CO>::IMG;
+    const float* Wsplit = F16 ? f2_image<CI, CO>(const_cast<float*>(Wp), K) : Wp + (size_t)K * SconvCfg<CI, CO>::IMG;
     int nblocks = glx_divup(N_out, TR);
-    if (g_prof_start && g_prof_stop) {
+    if (g_prof_start || g_prof_stop) {
       hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(T::THREADS), lds, st, g_prof_start, g_prof_stop, 0, in, Wsplit,
                             ep, nbr, tile_order, N_out, K, out);
       g_prof_start = g_prof_stop = nullptr;
@@ -1757,6 +2019,9 @@ static int launch_mfma(const float* in, const float* Wp, const SconvEpilogue& ep
     case 40: return launch_gemm2<CI, CO, 64, 8, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
     case 41: return launch_gemm2<CI, CO, 64, 4, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
     case 42: return launch_gemm2<CI, CO, 64, 8, 2>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
+    // f16 x 2 multiply with the weights in registers (shapes without the fp16 image keep their default)
+    case 60: if constexpr (SconvF2Cfg<CI, CO>::ON) return launch_gemm2<CI, CO, 64, 8, 4, true>(in, Wp, ep, nbr, tile_order, N_out, K, out, st); break;
+    case 61: if constexpr (SconvF2Cfg<CI, CO>::ON) return launch_gemm2<CI, CO, 64, 4, 4, true>(in, Wp, ep, nbr, tile_order, N_out, K, out, st); break;
     // split-bf16 multiply, weights in registers (shapes without that kernel keep their default)
     case 50: if constexpr (SconvBf3Cfg<CI, CO>::ON) return launch_gemm3<CI, CO, 64, 8, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st); break;
     case 51: if constexpr (SconvBf3Cfg<CI, CO>::ON) return launch_gemm3<CI, CO, 64, 4, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st); break;
@@ -1771,8 +2036,8 @@ static int launch_mfma(const float* in, const float* Wp, const SconvEpilogue& ep
   //               second LDS hop does not pay), 64 rows x 4 waves.
   if constexpr (sc_column_halves<CI, CO>()) {
     // two launches of the (CI, CO/2) kernel, each writing its column half of the CO-wide rows
-    const float* base = Wp + (size_t)K * img_bytes<CI, CO>() / sizeof(float);
-    const size_t half = (size_t)K * img_bytes<CI, CO / 2>() / sizeof(float);
+    const float* base = Wp + filter_bytes<CI, CO>(K) / sizeof(float);
+    const size_t half = filter_bytes<CI, CO / 2>(K) / sizeof(float);
     // profiling events bracket the PAIR of launches: start on the first, stop on the second
     const hipEvent_t pstart = g_prof_start, pstop = g_prof_stop;
     for (int h = 0; h < 2; ++h) {
@@ -1784,13 +2049,18 @@ static int launch_mfma(const float* in, const float* Wp, const SconvEpilogue& ep
       eh.scale = ep.scale ? ep.scale + off : nullptr;
       eh.shift = ep.shift ? ep.shift + off : nullptr;
       eh.out_ld = CO;
-      int rc = launch_gemm<CI, CO / 2, 64, 8, 4>(in, base + h * half, eh, nbr, tile_order, N_out, K, out + off, st);
+      int rc = g_sconv_f16 ? launch_gemm<CI, CO / 2, 64, 8, 4, true>(in, base + h * half, eh, nbr, tile_order, N_out, K, out + off, st)
+                           : launch_gemm<CI, CO / 2, 64, 8, 4>(in, base + h * half, eh, nbr, tile_order, N_out, K, out + off, st);
       if (rc != GLX_OK) return rc;
     }
     return GLX_OK;
   } else if constexpr (CO >= 128) {
+    if constexpr (SconvF2Cfg<CI, CO>::ON)
+      if (g_sconv_f16) return launch_gemm<CI, CO, 64, 4, 4, true>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
     return launch_gemm<CI, CO, 64, 4, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
   } else if constexpr (CO >= 64 && CI >= 16) {
+    if constexpr (SconvF2Cfg<CI, CO>::ON)
+      if (g_sconv_f16) return launch_gemm<CI, CO, 64, 8, 4, true>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
     return launch_gemm<CI, CO, 64, 8, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
   } else {
     return launch_tile<CI, CO, 64, 4, 1>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
@@ -1856,19 +2126,24 @@ static int sc_pack_cfg(int Cin, int Cout) {
 }
 
 template <int CI, int CO>
-static int sc_pack_jobs(const float* W, int K, float* Wp, int view, ScPackJob* out) {
+static int sc_pack_jobs(const float* W, int K, float* Wp, int view, ScPackJob* out, ScExpJob* ex, int* nex) {
   using C = SconvCfg<CI, CO>;
   const int nel = K * CI * CO, cover = K * C::IMG > nel ? K * C::IMG : nel;
   int n = 0;
   out[n++] = ScPackJob{W, Wp, Wp + (size_t)K * C::IMG, K, sc_pack_cfg(CI, CO), view, CO, 0, cover};
+  if constexpr (SconvF2Cfg<CI, CO>::ON)
+    ex[(*nex)++] = ScExpJob{W, reinterpret_cast<int*>(f2_image<CI, CO>(Wp, K) + (size_t)K * SconvSplitCfg<CI, CO>::IMG), nel};
   if constexpr (sc_column_halves<CI, CO>()) {
     using CH = SconvCfg<CI, CO / 2>;
-    const size_t half = (size_t)K * img_bytes<CI, CO / 2>() / sizeof(float);
-    float* base = Wp + (size_t)K * img_bytes<CI, CO>() / sizeof(float);
+    const size_t half = filter_bytes<CI, CO / 2>(K) / sizeof(float);
+    float* base = Wp + filter_bytes<CI, CO>(K) / sizeof(float);
     const int nh = K * CI * (CO / 2), ch = K * CH::IMG > nh ? K * CH::IMG : nh;
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h) {
       out[n++] = ScPackJob{W, base + h * half, base + h * half + (size_t)K * CH::IMG, K, sc_pack_cfg(CI, CO / 2),
                            view, CO, h * (CO / 2), ch};
+      ex[(*nex)++] = ScExpJob{W, reinterpret_cast<int*>(f2_image<CI, CO / 2>(base + h * half, K) +
+                                                       (size_t)K * SconvSplitCfg<CI, CO / 2>::IMG), nel};
+    }
   }
   return n;
 }
@@ -1882,7 +2157,8 @@ extern "C" int glx_sconv_pack_weights_multi(int n, const float* const* W, const 
   int done = 0;
   while (done < n) {                                   // SC_PACK_MAX_JOBS images per launch
     ScPackJobs jobs;
-    int nj = 0, max_cover = 0;
+    ScExpJobs ex;
+    int nj = 0, max_cover = 0, nex = 0;
     for (; done < n; ++done) {
       GLX_REQUIRE(W[done] && Wp[done], "glx_sconv_pack_weights_multi: null pointer in job %d", done);
       GLX_REQUIRE(mfma_supported(Cin[done], Cout[done], K[done]),
@@ -1892,12 +2168,13 @@ extern "C" int glx_sconv_pack_weights_multi(int n, const float* const* W, const 
       const int view = (transposed[done] ? 1 : 0) | (flip_taps[done] ? 2 : 0);
       const int i = done;
       const int added = sc_dispatch(Cin[i], Cout[i], [&](auto ci, auto co) {
-        return sc_pack_jobs<decltype(ci)::value, decltype(co)::value>(W[i], K[i], Wp[i], view, jobs.j + nj);
+        return sc_pack_jobs<decltype(ci)::value, decltype(co)::value>(W[i], K[i], Wp[i], view, jobs.j + nj, ex.j, &nex);
       });
       if (added < 0) return added;                     // no kernel for these channels: the error is set, nothing launched
       nj += added;
     }
     for (int j = 0; j < nj; ++j) max_cover = jobs.j[j].cover > max_cover ? jobs.j[j].cover : max_cover;
+    if (nex) hipLaunchKernelGGL(k_sconv_wexp, dim3(nex), dim3(1024), 0, st, ex);      // the fp16 images' exponents first
     hipLaunchKernelGGL(k_pack_weights_multi, dim3(glx_divup(max_cover, 256), nj), dim3(256), 0, st, jobs);
   }
   GLX_LAUNCH_CHECK();
@@ -2105,7 +2382,7 @@ extern "C" int glx_sconv_forward_ex(const float* in, int N_in, const float* W, c
   if (prol) {
     GLX_REQUIRE(prol->scale && prol->shift && prol->relu && prol->ldc == 0 && prol->coff == 0,
                 "glx_sconv_forward_ex: the prologue is x' = relu(x * scale + shift) with Cin floats each");
-    GLX_REQUIRE(mfma_supported(Cin, Cout, K) && Cin >= 16 && !(Cin >= 128 && Cout >= 128) && g_sconv_variant < 0 && !g_sconv_trace,
+    GLX_REQUIRE(mfma_supported(Cin, Cout, K) && Cin >= 16 && !(Cin >= 128 && Cout >= 128) && (g_sconv_variant < 0 || g_sconv_variant >= 60) && !g_sconv_trace,
                 "glx_sconv_forward_ex: the prologue needs a default MFMA tile kernel in one launch (channels %d -> %d)", Cin, Cout);
   }
   SconvEpilogue ep{bias, scale, shift, relu, n_out_live, g_sconv_trace, g_sconv_xcd_group, 0, tile_map, bn_state,

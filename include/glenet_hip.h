@@ -228,6 +228,13 @@ size_t glx_sconv_tile_map_workspace_bytes(int N_out);
 int glx_sconv_tile_map(const int32_t* nbr, const int32_t* tile_order, int N_out, int K,
                        const int32_t* n_out_live, int32_t* tile_map, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* Arithmetic of the block kernels behind glx_sconv_forward[_ex] for channels Cin in {32, 64, 128} -> Cout in {64, 128} (every other
+ * layer multiplies in fp32 either way), per process: 1 = f16x2 (default: two fp16 pieces per operand -- the packed filter scaled by
+ * one power of two, every gathered row by its own -- and three v_mfma_f32_16x16x32_f16 per product tile, >= 20.4 bits per product,
+ * fp32 sums), 0 = fp32 (v_mfma_f32_16x16x4_f32, exact products).  env GLX_SCONV_ARITH=fp32 selects 0 at load.  A packed filter
+ * holds the images of both, so the switch needs no re-pack.  spconv's SubMConv3d / SparseConv3d (spconv_backbone.py:30-75). */
+int glx_sconv_set_arith(int f16x2);
+int glx_sconv_get_arith(void);
 /* Re-order W (K,Cin,Cout) into Wp (glx_sconv_packed_bytes); do it once per weight update. */
 int glx_sconv_pack_weights(const float* W, int K, int Cin, int Cout, float* Wp, void* stream);
 /* Same for the ADJOINT conv, straight from the forward weights: (Cin, Cout) are the dimensions of

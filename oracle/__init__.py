@@ -867,3 +867,33 @@ def f16x2_product(x, w, ex, ew):
     aw, bw = f16x2_split(w, ew)
     s = bw.astype(np.float64) * ax + aw.astype(np.float64) * bx + aw.astype(np.float64) * ax
     return np.ldexp(s, -(int(ex) + int(ew)))
+
+
+def sconv_forward_f16x2(features, weights, rules, bias=None):
+    """sconv_forward with the products formed the way csrc/glx_sconv.hip's f16x2 block kernel forms them (k_sconv_gemm<..., F16>;
+    reference semantics: spconv's SubMConv3d / SparseConv3d, spconv_backbone.py:30-75): the whole filter scaled by ONE power of two
+    (max |w| into [2^14, 2^15)), every gathered input row by its OWN, two fp16 pieces per operand, the three piece products
+    b_w a_x + a_w b_x + a_w a_x -- exact here (fp64 sums), where the kernel adds them in fp32.  Pure numpy: small cases only."""
+    f = np.asarray(features, np.float32)
+    w = np.asarray(weights, np.float32)
+    K, cin, cout = w.shape
+    ew = f16x2_block_exponent(np.abs(w).max())
+    ew = 0 if ew == 127 else ew
+    aw, bw = f16x2_split(w, ew)
+    aw, bw = aw.astype(np.float64), bw.astype(np.float64)
+    n_out = len(rules.out_indices)
+    rows_e = np.array([f16x2_block_exponent(m) for m in np.abs(f).max(axis=1)], np.int64) if len(f) else np.zeros(0, np.int64)
+    rows_e[rows_e == 127] = 0
+    fs = np.ldexp(f, rows_e[:, None].astype(np.int32)).astype(np.float32)           # exact: a power of two
+    ax = fs.astype(np.float16).astype(np.float32)
+    bx = (fs - ax).astype(np.float32).astype(np.float16).astype(np.float64)
+    ax = ax.astype(np.float64)
+    out = np.zeros((n_out, cout), np.float64)
+    for k in range(K):
+        n = int(rules.n_pairs[k])
+        i, o = rules.pairs_in[k, :n], rules.pairs_out[k, :n]
+        s = ax[i] @ bw[k] + bx[i] @ aw[k] + ax[i] @ aw[k]
+        np.add.at(out, o, np.ldexp(s, (-(rows_e[i] + ew))[:, None].astype(np.int32)))
+    if bias is not None:
+        out += np.asarray(bias, np.float64)
+    return out

@@ -574,6 +574,53 @@ def test_scaled_f16_pieces_carry_an_fp32_class_product():
     assert np.max(np.abs(one - exact) / np.abs(exact)) > 2.0 ** -12
 
 
+def _exact_sconv(f, w, rules):
+    """fp64 sums of the exact products over the rule pairs, and sum |f| |w| (the scale errors are quoted on)."""
+    out = np.zeros((len(rules.out_indices), w.shape[2]), np.float64)
+    mag = np.zeros_like(out)
+    for k in range(w.shape[0]):
+        n = int(rules.n_pairs[k])
+        i, o = rules.pairs_in[k, :n], rules.pairs_out[k, :n]
+        np.add.at(out, o, f[i].astype(np.float64) @ w[k].astype(np.float64))
+        np.add.at(mag, o, np.abs(f[i]).astype(np.float64) @ np.abs(w[k]).astype(np.float64))
+    return out, mag
+
+
+def test_sparse_convolution_from_scaled_f16_pieces_is_an_fp32_class_convolution():
+    """oracle.sconv_forward_f16x2 (the arithmetic of csrc/glx_sconv.hip's f16x2 block kernel: the filter scaled by one power of
+    two, every input row by its own, three piece products) against the exact convolution and beside the fp32 C oracle: rows and
+    filters of any magnitude, rows of zeros, an all-zero filter."""
+    rng = np.random.default_rng(3)
+    shape = (5, 12, 11)
+    idx = np.argwhere(rng.random((2,) + shape) < 0.2).astype(np.int32)
+    rules = oracle.build_rules(idx, shape, 3, subm=True)
+    f0 = rng.normal(size=(len(idx), 32)).astype(np.float32)
+    w0 = (rng.normal(size=(27, 32, 64)) / 30).astype(np.float32)
+    rows = np.exp2(rng.integers(-30, 31, size=(len(idx), 1))).astype(np.float32)
+    chans = np.exp2(rng.integers(-9, 10, size=(1, 32))).astype(np.float32)
+    cases = {"plain": (f0, w0), "rows x 2^[-30, 30]": (f0 * rows, w0), "channels x 2^[-9, 9]": (f0 * chans, w0),
+             "filter x 2^-40": (f0, w0 * np.float32(2.0 ** -40)), "filter x 2^30": (f0, w0 * np.float32(2.0 ** 30))}
+    fz = f0.copy()
+    fz[::3] = 0
+    cases["every third row zero"] = (fz, w0)
+    for name, (f, w) in cases.items():
+        exact, mag = _exact_sconv(f, w, rules)
+        live = mag > 0
+        got = oracle.sconv_forward_f16x2(f, w, rules)
+        err = np.abs(got - exact)[live] / mag[live]
+        assert err.max() <= 2.0 ** -20.4, (name, np.log2(err.max()))
+        # beside the fp32 oracle (exact products, fp32 sums): the same class
+        err32 = np.abs(oracle.sconv_forward(f, w, rules) - exact)[live] / mag[live]
+        assert err.max() <= 4 * err32.max() + 2.0 ** -24, (name, err.max(), err32.max())
+    # scaling a row or the filter by a power of two scales the result bitwise
+    base = oracle.sconv_forward_f16x2(f0, w0, rules)
+    assert np.array_equal(oracle.sconv_forward_f16x2(f0, w0 * np.float32(2.0 ** 30), rules), base * 2.0 ** 30)
+    assert np.array_equal(oracle.sconv_forward_f16x2(f0 * np.float32(2.0 ** -17), w0, rules), base * 2.0 ** -17)
+    assert not oracle.sconv_forward_f16x2(f0, np.zeros_like(w0), rules).any()
+    b = rng.normal(size=64).astype(np.float32)
+    assert np.array_equal(oracle.sconv_forward_f16x2(f0, w0, rules, bias=b), base + b.astype(np.float64))
+
+
 def test_dense_convolution_restatements_match_torch():
     import torch
     import torch.nn.functional as F

@@ -236,6 +236,107 @@ def test_mfma_kernel_matches_generic_kernel_on_device(dev):
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.fixture
+def sconv_arith():
+    """glx_sconv_set_arith for a test, the library's setting restored behind it."""
+    from glenet_amd import _lib
+    old = _lib.query("glx_sconv_get_arith")
+    yield lambda v: _lib.call_nostream("glx_sconv_set_arith", v)
+    _lib.call_nostream("glx_sconv_set_arith", old)
+
+
+def _fp64_rule_conv(f, w, nbr, n_out):
+    """On the device in fp64: out[j] = sum_k f[nbr[j, k]] @ w[k] over the present neighbours, and sum |f| |w|."""
+    fd, wd = f.double(), w.double()
+    out = torch.zeros(n_out, w.shape[2], dtype=torch.float64, device=f.device)
+    mag = torch.zeros_like(out)
+    for k in range(w.shape[0]):
+        i = nbr[:n_out, k].long()
+        rows = fd[i.clamp(min=0)] * (i >= 0)[:, None]
+        out += rows @ wd[k]
+        mag += rows.abs() @ wd[k].abs()
+    return out, mag
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 64), (64, 64), (64, 128), (128, 64), (32, 128), (128, 128)])
+def test_both_arithmetics_of_the_block_kernel_match_fp64(dev, cin, cout, sconv_arith):
+    """glx_sconv_set_arith: fp32 MFMAs | two scaled fp16 pieces per operand and three fp16 MFMAs (the default) on every channel
+    pair that has an fp16 image, against an fp64 evaluation of the rule table: plain inputs, rows and channels that differ by
+    many powers of two, tiny and huge filters, rows of zeros, the BatchNorm + ReLU prologue.  Errors are quoted
+    on sum |f| |w| per output: both arithmetics stay below 2^-19 (measured on the KITTI layers: 2^-20.5 ... 2^-23), and the
+    f16 x 2 form is within 2 x the fp32 form's error + 2^-23 everywhere."""
+    from glenet_amd import _lib
+    assert _lib.query("glx_sconv_get_arith") in (0, 1)
+    rng = np.random.default_rng(cin * 7 + cout)
+    shape = (17, 50, 44)
+    idx, f0 = _rand_sparse(rng, 2, *shape, 0.06, cin)
+    x = _gpu_tensor(idx, f0, shape, 2, dev)
+    rs = sp.build_subm_rules(x, (3, 3, 3))
+    n = rs.N_out
+    g = torch.Generator(device=dev).manual_seed(cin + cout)
+    w0 = torch.randn(27, cin, cout, device=dev, generator=g) / (27 * cin) ** 0.5
+    f0 = x.features
+    rows = torch.exp2(torch.randint(-20, 21, (n, 1), device=dev, generator=g).float())
+    chans = torch.exp2(torch.randint(-12, 13, (1, cin), device=dev, generator=g).float())
+    fz = f0.clone()
+    fz[::3] = 0
+    cases = [("plain", f0, w0, None, None), ("rows x 2^[-20, 20]", f0 * rows, w0, None, None),
+             ("channels x 2^[-12, 12]", f0 * chans, w0, None, None), ("filter x 2^-30", f0, w0 * 2.0 ** -30, None, None),
+             ("filter x 2^25", f0, w0 * 2.0 ** 25, None, None), ("every third row zero", fz, w0, None, None)]
+    if not (cin >= 128 and cout >= 128):                        # the prologue needs a one-launch kernel
+        coef = torch.cat([torch.rand(cin, device=dev, generator=g) + 0.5, torch.randn(cin, device=dev, generator=g) * 0.3])
+        cases.append(("prologue", f0, w0, None, coef))
+    for name, f, w, live, pre in cases:
+        f, w = f.contiguous(), w.contiguous()
+        fin = torch.relu(f * pre[:cin] + pre[cin:]) if pre is not None else f
+        m = n if live is None else live
+        want, mag = _fp64_rule_conv(fin, w, rs.nbr, m)
+        packed = sp.pack_weights(w)
+        n_live = None if live is None else torch.tensor([live], dtype=torch.int32, device=dev)
+        err = {}
+        outs = {}
+        for arith in (0, 1):
+            sconv_arith(arith)
+            out = sp._sconv(f, w, None, rs.nbr, rs.tile_order_out, n, packed=packed, rules=rs, n_live=n_live, pre=pre)
+            ok = mag > 0
+            err[arith] = float(((out[:m].double() - want).abs()[ok] / mag[ok]).max())
+            outs[arith] = out[:m]
+        assert err[0] <= 2.0 ** -19 and err[1] <= 2.0 ** -19, (name, err)
+        assert err[1] <= 2 * err[0] + 2.0 ** -23, (name, err)
+        assert not torch.equal(outs[0], outs[1])                 # two arithmetics, not one: the switch reaches the kernel
+    # an all-zero filter: exponent 0, zeros out
+    sconv_arith(1)
+    wz = torch.zeros_like(w0)
+    assert not sp._sconv(f0, wz, None, rs.nbr, rs.tile_order_out, n, packed=sp.pack_weights(wz), rules=rs).any()
+
+
+def test_f16x2_block_kernel_equals_its_restatement_to_fp32_summation(dev, sconv_arith):
+    """The kernel's f16 x 2 result against oracle.sconv_forward_f16x2 (the same scaling, pieces and piece products, summed in
+    fp64): what is left is the fp32 summation inside the MFMAs and the accumulator tile -- below the fp32 kernel's own distance
+    to the exact convolution + 2^-24, on rows that differ by 2^+-20."""
+    rng = np.random.default_rng(21)
+    shape = (7, 20, 18)
+    idx, f = _rand_sparse(rng, 2, *shape, 0.15, 64)
+    f = (f * np.exp2(rng.integers(-20, 21, size=(len(f), 1)))).astype(np.float32)
+    w = (rng.normal(size=(27, 64, 64)) / 40).astype(np.float32)
+    rules = oracle.build_rules(idx, shape, 3, subm=True)
+    restated = oracle.sconv_forward_f16x2(f, w, rules)
+    x = _gpu_tensor(idx, f, shape, 2, dev)
+    rs = sp.build_subm_rules(x, (3, 3, 3))
+    wt = torch.from_numpy(w).to(dev)
+    want, mag = _fp64_rule_conv(x.features, wt, rs.nbr, rs.N_out)
+    mag = mag.cpu().numpy()
+    got = {}
+    for arith in (0, 1):
+        sconv_arith(arith)
+        got[arith] = sp._sconv(x.features, wt, None, rs.nbr, rs.tile_order_out, rs.N_out).double().cpu().numpy()
+    ok = mag > 0
+    d_restated = (np.abs(got[1] - restated)[ok] / mag[ok]).max()
+    d_fp32 = (np.abs(got[0] - want.cpu().numpy())[ok] / mag[ok]).max()
+    assert d_restated <= d_fp32 + 2.0 ** -24, (d_restated, d_fp32)
+    assert (np.abs(restated - want.cpu().numpy())[ok] / mag[ok]).max() <= 2.0 ** -20.4
+
+
 @pytest.mark.parametrize("cin,cout,subm", [(16, 16, True), (32, 64, False), (64, 64, True), (4, 16, True)])
 def test_conv_backward(dev, cin, cout, subm):
     rng = np.random.default_rng(11 + cin + cout)
