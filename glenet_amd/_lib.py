@@ -141,6 +141,13 @@ def grad_buffer(param, shape=None):
     return torch.empty_like(like, memory_format=torch.contiguous_format) if shape is not None else torch.empty_like(like)
 
 
+def is_lent(param, g):
+    """True when `g` (what grad_buffer returned) is the optimizer's own view of `param`'s gradient: autograd then keeps the tensor
+    as it is and reads nothing, so a kernel may fill it later in the step (deferred weight-gradient sums)."""
+    view = getattr(param, "_glx_grad_view", None) if param is not None else None
+    return view is not None and g.data_ptr() == view.data_ptr() and param.grad is None
+
+
 def size_arg(n):
     return c_size_t(int(n))
 

@@ -445,6 +445,7 @@ def no_gc():
             gc.enable()
 
 
+DEFER_WGRAD_REDUCES = os.environ.get("GLX_DEFER_WGRAD_REDUCES", "1") != "0"    # see StaticTrainStep.step
 PREPACK_WEIGHTS = os.environ.get("GLX_PREPACK", "1") != "0"
 
 
@@ -554,14 +555,24 @@ class StaticTrainPipeline(StaticFramePipeline):
                 cur.wait_stream(self.plan_stream)
             if self.overlap_wgrad:     # weight gradients next to the input-gradient chain
                 spconv.core.WGRAD_STREAM = self.plan_stream
+            # a plain loss: the layers' weight-gradient sums in one launch per kind behind the backward pass (a staged loss --
+            # glenet_vr.StagedLoss -- does the same inside its own backward)
+            from . import conv2d as c2
+            defer = DEFER_WGRAD_REDUCES and torch.is_tensor(loss)
+            sparse_sums = spconv.core.DEFERRED_WGRAD_REDUCES = [] if defer else None
+            bev_sums = c2.DEFERRED_WGRAD_REDUCES = [] if defer else None
             try:
                 loss.backward()
             finally:
                 spconv.core.WGRAD_STREAM = None
                 spconv.core.STEP_PACKS = None
+                spconv.core.DEFERRED_WGRAD_REDUCES = c2.DEFERRED_WGRAD_REDUCES = None
                 _reset_conv_packs()
             if self.overlap_wgrad:
                 cur.wait_stream(self.plan_stream)
+            if defer:
+                c2.run_deferred_wgrad_reduces(bev_sums)
+                spconv.core.run_deferred_wgrad_reduces(sparse_sums)
             if not torch.is_tensor(loss):      # a staged backward (glenet_vr.StagedLoss): its scalar exists now
                 loss = loss.detach()
             if self.mark:

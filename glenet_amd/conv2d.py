@@ -182,12 +182,46 @@ def wgrad(x, gy, weight, pre=None):
     if pre is not None:
         coef, relu = pre
         prologue = ctypes.byref(_lib.epilogue(coef[:cin], coef[cin:], relu))
-    ws = _lib.workspace.get(n, x.device)
     gw = _lib.grad_buffer(weight)       # the optimizer's flat gradient buffer when the step has one (no gather copy)
     s = gw.stride()
+    if DEFERRED_WGRAD_REDUCES is not None and _lib.is_lent(weight, gw):
+        # the blocks' partial sums now, into a buffer of this layer's own; their sum with every other layer's in ONE launch when
+        # the step calls run_deferred_wgrad_reduces() (autograd only keeps `gw`, the optimizer's view, and reads nothing)
+        ws = torch.empty(n, dtype=torch.uint8, device=x.device)
+        call("glx_conv3x3_wgrad_ex", x, gy, b, h, w, cin, cout, None, ll(s[0]), ll(s[1]), ll(s[2]), ll(s[3]), prologue, ws,
+             _lib.size_arg(n))
+        # an ALIAS of gw in the job: AccumulateGrad keeps a gradient as it is only while nobody else holds the tensor object
+        DEFERRED_WGRAD_REDUCES.append((cin, cout, gw.detach(), tuple(s), ws, torch.cuda.current_stream(x.device)))
+        return gw
+    ws = _lib.workspace.get(n, x.device)
     call("glx_conv3x3_wgrad_ex", x, gy, b, h, w, cin, cout, gw, ll(s[0]), ll(s[1]), ll(s[2]), ll(s[3]), prologue, ws,
          _lib.size_arg(n))
     return gw
+
+
+# A training step that sets this to a list gets the 3x3 layers' weight gradients in two parts: each layer's partial sums where the
+# backward pass reaches it, the sums of ALL layers in one launch from run_deferred_wgrad_reduces() (ten ~8 us launches on the
+# step's main chain become one).  None (the default): every weight gradient is complete when its call returns.
+DEFERRED_WGRAD_REDUCES = None
+
+
+def run_deferred_wgrad_reduces(jobs):
+    """Finish the weight gradients `jobs` (the list DEFERRED_WGRAD_REDUCES was) on the current stream, which waits for the
+    streams the partial sums were written on."""
+    if not jobs:
+        return
+    cur = torch.cuda.current_stream(jobs[0][2].device)
+    for st in {j[5] for j in jobs}:
+        if st != cur:
+            cur.wait_stream(st)
+    n = len(jobs)
+    i32 = ctypes.c_int32 * n
+    strides = (ctypes.c_longlong * (4 * n))(*[v for j in jobs for v in j[3]])
+    ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    call("glx_conv3x3_wgrad_reduce_multi", n, i32(*[j[0] for j in jobs]), i32(*[j[1] for j in jobs]), ptrs([j[2] for j in jobs]),
+         strides, ptrs([j[4] for j in jobs]), (ctypes.c_size_t * n)(*[j[4].numel() for j in jobs]))
+    for j in jobs:
+        j[4].record_stream(cur)
 
 
 OWN_WGRAD = True

@@ -1336,6 +1336,71 @@ extern "C" int glx_conv3x3_wgrad_reduce(int Cin, int Cout, float* dW, long long 
   return GLX_OK;
 }
 
+// The partial sums of SEVERAL layers in one launch (a training step defers them to the end of its backward pass): blockIdx.z = job,
+// per element the same sums in the same order as k_conv3x3_wgrad_reduce.
+#define WG_REDUCE_JOBS 16
+struct WgReduceJob { const float* ws; float* dW; long long s_co, s_ci, s_kh, s_kw; int P, nq_ci, nq; };
+struct WgReduceJobs { WgReduceJob j[WG_REDUCE_JOBS]; };
+__global__ __launch_bounds__(256) void k_conv3x3_wgrad_reduce_multi(WgReduceJobs jobs) {
+  __shared__ float part[4][64];
+  const WgReduceJob jb = jobs.j[blockIdx.z];
+  const int q = blockIdx.y, el = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  if (q >= jb.nq) return;                                        // block-uniform
+  const int e = blockIdx.x * 64 + el;
+  const float* src = jb.ws + (size_t)q * jb.P * WG_PART + e;
+  float sum = 0.f;
+  int pb = seg;
+  for (; pb + 28 < jb.P; pb += 32) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(pb + 4 * u) * WG_PART];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += v[u];
+  }
+  for (; pb < jb.P; pb += 4) sum += src[(size_t)pb * WG_PART];
+  part[seg][el] = sum;
+  __syncthreads();
+  if (seg == 0) {
+    sum = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+    const int tap = e >> 11, a2 = (e >> 10) & 1, rg = (e >> 8) & 3, t = e & 255;
+    const int wave = t >> 6, lane = t & 63;
+    const int ib = q % jb.nq_ci, cb = q / jb.nq_ci;
+    const int co = cb * 64 + (wave >> 1) * 32 + a2 * 16 + 4 * (lane >> 4) + rg, ci = ib * 32 + (wave & 1) * 16 + (lane & 15);
+    jb.dW[co * jb.s_co + ci * jb.s_ci + (tap / 3) * jb.s_kh + (tap % 3) * jb.s_kw] = sum;
+  }
+}
+
+extern "C" int glx_conv3x3_wgrad_reduce_multi(int n, const int32_t* Cin, const int32_t* Cout, float* const* dW,
+                                              const long long* strides, const void* const* workspace,
+                                              const size_t* workspace_bytes, void* stream) {
+  if (n <= 0) return GLX_OK;
+  GLX_REQUIRE(Cin && Cout && dW && strides && workspace && workspace_bytes, "glx_conv3x3_wgrad_reduce_multi: null pointer");
+  for (int i = 0; i < n; ++i) {
+    GLX_REQUIRE(dW[i] && workspace[i], "glx_conv3x3_wgrad_reduce_multi: null pointer in job %d", i);
+    GLX_REQUIRE(Cin[i] > 0 && Cout[i] > 0 && Cin[i] % 32 == 0 && Cout[i] % CV_BN == 0,
+                "glx_conv3x3_wgrad_reduce_multi: job %d needs Cin %% 32 == 0 and Cout %% 64 == 0 (got %d -> %d)", i, Cin[i], Cout[i]);
+    GLX_REQUIRE(workspace_bytes[i] >= glx_conv3x3_wgrad_workspace_bytes(Cin[i], Cout[i]),
+                "glx_conv3x3_wgrad_reduce_multi: job %d: workspace too small", i);
+  }
+  for (int done = 0; done < n; done += WG_REDUCE_JOBS) {
+    WgReduceJobs jobs;
+    const int nj = n - done < WG_REDUCE_JOBS ? n - done : WG_REDUCE_JOBS;
+    int max_nq = 0;
+    for (int j = 0; j < nj; ++j) {
+      const int i = done + j;
+      int P = 0;
+      wgrad_blocks(Cin[i], Cout[i], &P);
+      const int nq_ci = Cin[i] / 32, nq = nq_ci * (Cout[i] / CV_BN);
+      jobs.j[j] = WgReduceJob{(const float*)workspace[i], dW[i], strides[4 * i], strides[4 * i + 1], strides[4 * i + 2],
+                              strides[4 * i + 3], P, nq_ci, nq};
+      max_nq = nq > max_nq ? nq : max_nq;
+    }
+    hipLaunchKernelGGL(k_conv3x3_wgrad_reduce_multi, dim3(WG_PART / 64, max_nq, nj), dim3(256), 0, (hipStream_t)stream, jobs);
+  }
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
 extern "C" size_t glx_conv3x3_packed_bytes(int Cin, int Cout) {
   return glx_align((size_t)9 * 3 * Cin * Cout * sizeof(uint16_t));
 }

@@ -3097,6 +3097,64 @@ extern "C" int glx_sconv_wgrad_pairs_reduce(const void* lists, int N_out, int K,
   return GLX_OK;
 }
 
+// The slab sums of SEVERAL layers in one launch (a training step defers them to the end of its backward pass: thirteen ~8 us
+// launches on the main chain become one): blockIdx.z = job, blockIdx.y = offset, the same sums in the same order per element.
+#define WGP_REDUCE_JOBS 32
+struct PairReduceJob { const float* slabs; const PairMeta* meta; float* dW; int nel, K; };
+struct PairReduceJobs { PairReduceJob j[WGP_REDUCE_JOBS]; };
+__global__ void k_wgrad_pairs_reduce_multi(PairReduceJobs jobs) {
+  const PairReduceJob jb = jobs.j[blockIdx.z];
+  const int k = blockIdx.y;
+  const int e = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (k >= jb.K || e >= jb.nel) return;
+  const int c0 = jb.meta->coff[k], c1 = jb.meta->coff[k + 1];
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c = c0; c < c1; c += 16) {
+    f32x4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int cc = c + u < c1 ? c + u : c1 - 1;
+      v[u] = *reinterpret_cast<const f32x4*>(jb.slabs + (long long)cc * jb.nel + e);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (c + u < c1) s += v[u];
+    }
+  }
+  *reinterpret_cast<f32x4*>(jb.dW + (long long)k * jb.nel + e) = s;
+}
+
+extern "C" int glx_sconv_wgrad_pairs_reduce_multi(int n, const void* const* lists, const int32_t* N_out, const int32_t* K,
+                                                  const int32_t* Cin, const int32_t* Cout, float* const* dW,
+                                                  const void* const* workspace, const size_t* workspace_bytes, void* stream) {
+  if (n <= 0) return GLX_OK;
+  GLX_REQUIRE(lists && N_out && K && Cin && Cout && dW && workspace && workspace_bytes, "glx_sconv_wgrad_pairs_reduce_multi: null pointer");
+  for (int i = 0; i < n; ++i) {
+    GLX_REQUIRE(lists[i] && dW[i] && workspace[i], "glx_sconv_wgrad_pairs_reduce_multi: null pointer in job %d", i);
+    GLX_REQUIRE(K[i] >= 1 && K[i] <= SC_MAXK && (Cin[i] * Cout[i]) % 4 == 0, "glx_sconv_wgrad_pairs_reduce_multi: job %d: K=%d, %d -> %d", i,
+                K[i], Cin[i], Cout[i]);
+    const size_t need = glx_sconv_wgrad_pairs_workspace_bytes(N_out[i], K[i], Cin[i], Cout[i]) - 256;
+    if (workspace_bytes[i] < need) {
+      glx_set_error("glx_sconv_wgrad_pairs_reduce_multi: job %d: workspace %zu < %zu bytes", i, workspace_bytes[i], need);
+      return GLX_EWORKSPACE;
+    }
+  }
+  for (int done = 0; done < n; done += WGP_REDUCE_JOBS) {
+    PairReduceJobs jobs;
+    const int nj = n - done < WGP_REDUCE_JOBS ? n - done : WGP_REDUCE_JOBS;
+    int max_nel = 0, max_k = 0;
+    for (int j = 0; j < nj; ++j) {
+      const int i = done + j, nel = Cin[i] * Cout[i];
+      jobs.j[j] = PairReduceJob{(const float*)workspace[i], (const PairMeta*)lists[i], dW[i], nel, K[i]};
+      max_nel = nel > max_nel ? nel : max_nel;
+      max_k = K[i] > max_k ? K[i] : max_k;
+    }
+    hipLaunchKernelGGL(k_wgrad_pairs_reduce_multi, dim3(glx_divup(max_nel, 4 * 256), max_k, nj), dim3(256), 0, (hipStream_t)stream, jobs);
+  }
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
 // Row slices of the weight-gradient grid: as many blocks as are resident at once (LDS-limited
 // blocks per CU x 256 CUs) divided by the K offsets -- a block's work is a serial chain of row
 // batches, so the kernel takes as long as one block, and a partial second wave of blocks doubles it.

@@ -143,6 +143,9 @@ OVERLAP_ROI = os.environ.get("GLX_OVERLAP_ROI", "1") != "0"
 STAGE_CUTS = os.environ.get("GLX_STAGE_CUTS", "1") != "0"
 DEFER_FC_WGRADS = os.environ.get("GLX_DEFER_FC_WGRADS", "1") != "0"
 FC_WGRADS_BEHIND_ROI = os.environ.get("GLX_FC_WGRADS_BEHIND_ROI", "1") != "0"      # see StagedLoss.backward
+# the slab / partial sums of the sparse and the BEV 3x3 weight gradients: one launch each at the end of the backward pass
+# (spconv.core.DEFERRED_WGRAD_REDUCES, conv2d.DEFERRED_WGRAD_REDUCES) instead of one ~8 us launch per layer on the main chain
+DEFER_WGRAD_REDUCES = os.environ.get("GLX_DEFER_WGRAD_REDUCES", "1") != "0"
 # the RoI head's three loss terms as one launch / one autograd node (losses.roi_head_losses); 0 = the three entry points
 ROI_LOSSES_ONE_LAUNCH = os.environ.get("GLX_ROI_LOSSES_ONE_LAUNCH", "1") != "0"
 
@@ -187,6 +190,9 @@ class StagedLoss:
         # no weight-gradient side stream while the RoI branch is in flight: a third concurrent branch was measured at 8.0 ms
         # per step against 6.44 (round 4, also with two executor queues)
         core.WGRAD_STREAM = None
+        from . import conv2d as c2
+        sparse_sums = core.DEFERRED_WGRAD_REDUCES = [] if DEFER_WGRAD_REDUCES else None
+        bev_sums = c2.DEFERRED_WGRAD_REDUCES = [] if DEFER_WGRAD_REDUCES else None
         try:
             fc_jobs = dp.DEFERRED_FC_WGRADS = [] if DEFER_FC_WGRADS else None
             dp.DEFERRED_FC_SAME_STREAM = FC_WGRADS_BEHIND_ROI
@@ -236,8 +242,14 @@ class StagedLoss:
             core.WGRAD_STREAM = wgrad_stream              # free again: the RoI branch has been joined
             keep = [(t, g) for t, g in zip(roots, grads) if g is not None]
             torch.autograd.backward([t for t, _ in keep], [g for _, g in keep])
+            core.DEFERRED_WGRAD_REDUCES = c2.DEFERRED_WGRAD_REDUCES = None
+            if wgrad_stream is not None:
+                main.wait_stream(wgrad_stream)            # products written on the side stream (the last sparse layers)
+            c2.run_deferred_wgrad_reduces(bev_sums)       # every layer's partial sums -> its gradient: two launches
+            core.run_deferred_wgrad_reduces(sparse_sums)
         finally:
             core.WGRAD_STREAM = wgrad_stream
+            core.DEFERRED_WGRAD_REDUCES = c2.DEFERRED_WGRAD_REDUCES = None
 
     def detach(self):
         return self.value

@@ -567,13 +567,20 @@ class SparseConvFunction(Function):
                     g_w = _lib.grad_buffer(ctx.leaf, w.shape) if ctx.leaf is not None else torch.empty_like(w)
                     pl = rules.pair_lists(fwd_nbr, n_fwd_out, live_fwd)
                     wsb = query("glx_sconv_wgrad_pairs_workspace_bytes", n_fwd_out, K, cin, cout)
-                    ws = workspace.get(wsb, w.device)
                     # bench.py's profiler: torch events around the weight gradient's two launches (pairs + slab sum)
                     wev = _profile_hook.wgrad(K, cin, cout, rules) if hasattr(_profile_hook, "wgrad") else None
+                    defer = (DEFERRED_WGRAD_REDUCES is not None and wev is None and ctx.leaf is not None
+                             and _lib.is_lent(ctx.leaf, g_w))
+                    # deferred: the chunk products now, into a buffer of this layer's own; the sums of ALL layers in one
+                    # launch from run_deferred_wgrad_reduces() (autograd keeps `g_w`, the optimizer's view, and reads nothing)
+                    ws = torch.empty(wsb, dtype=torch.uint8, device=w.device) if defer else workspace.get(wsb, w.device)
                     if wev is not None:
                         wev[0].record()
-                    call("glx_sconv_wgrad_pairs_ex", features, grad_out, pl, n_fwd_out, K, cin, cout, g_w, _pre_arg(pre, cin), ws,
-                         size_arg(ws.numel()))
+                    call("glx_sconv_wgrad_pairs_ex", features, grad_out, pl, n_fwd_out, K, cin, cout, None if defer else g_w,
+                         _pre_arg(pre, cin), ws, size_arg(ws.numel()))
+                    if defer:
+                        # an ALIAS of g_w: AccumulateGrad keeps a gradient as it is only while nobody else holds the tensor object
+                        DEFERRED_WGRAD_REDUCES.append((pl, n_fwd_out, K, cin, cout, g_w.detach(), ws, torch.cuda.current_stream(w.device)))
                     if wev is not None:
                         wev[1].record()
                 else:
@@ -1215,6 +1222,29 @@ TILE_MAP_SUBM_ONLY = os.environ.get("GLX_TILE_MAP_ALL", "0") == "0"
 # stream for the weight-gradient kernels of SparseConvFunction.backward (None = the current one).
 # Set by StaticTrainPipeline around its backward pass; the setter waits for it afterwards.
 WGRAD_STREAM = None
+# A training step that sets this to a list gets the sparse layers' weight gradients in two parts: each layer's chunk products where
+# the backward pass reaches it, the sums of ALL layers in one launch from run_deferred_wgrad_reduces() (thirteen ~8 us launches on
+# the step's main chain become one).  None (the default): every weight gradient is complete when its call returns.
+DEFERRED_WGRAD_REDUCES = None
+
+
+def run_deferred_wgrad_reduces(jobs):
+    """Finish the weight gradients `jobs` (the list DEFERRED_WGRAD_REDUCES was) on the current stream, which waits for the
+    streams the chunk products were written on."""
+    if not jobs:
+        return
+    cur = torch.cuda.current_stream(jobs[0][5].device)
+    for st in {j[7] for j in jobs}:
+        if st != cur:
+            cur.wait_stream(st)
+    n = len(jobs)
+    i32 = ctypes.c_int32 * n
+    ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    call("glx_sconv_wgrad_pairs_reduce_multi", n, ptrs([j[0] for j in jobs]), i32(*[j[1] for j in jobs]), i32(*[j[2] for j in jobs]),
+         i32(*[j[3] for j in jobs]), i32(*[j[4] for j in jobs]), ptrs([j[5] for j in jobs]), ptrs([j[6] for j in jobs]),
+         (ctypes.c_size_t * n)(*[j[6].numel() for j in jobs]))
+    for j in jobs:
+        j[6].record_stream(cur)
 # list collecting the num_batches_tracked buffers of the fused BatchNorms of a step, so that the
 # caller bumps them with ONE multi-tensor add instead of a tiny kernel per layer (None = bump at once)
 DEFERRED_COUNTERS = None

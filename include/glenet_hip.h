@@ -304,6 +304,12 @@ int glx_sconv_wgrad_pairs_ex(const float* in, const float* grad_out, const void*
  * later on another stream (the sum is a pass over memory, the products fill the matrix pipe: they overlap). */
 int glx_sconv_wgrad_pairs_reduce(const void* lists, int N_out, int K, int Cin, int Cout, float* dW, const void* workspace,
                                  size_t workspace_bytes, void* stream);
+/* The sums of n layers in ONE launch (arrays of n: a training step keeps every layer's chunk products in a buffer of its own and
+ * runs the sums at the end of its backward pass -- thirteen ~8 us launches on the step's main chain become one).  Per element the
+ * same sums in the same order as glx_sconv_wgrad_pairs_reduce.  spconv's SparseConvolution weight gradient (ops.py indice_conv_backward). */
+int glx_sconv_wgrad_pairs_reduce_multi(int n, const void* const* lists, const int32_t* N_out, const int32_t* K, const int32_t* Cin,
+                                       const int32_t* Cout, float* const* dW, const void* const* workspace,
+                                       const size_t* workspace_bytes, void* stream);
 
 /* SparseConvTensor.dense(): out (B, C, D, H, W) must be zero-filled by the caller.
  * Replaces: spconv dense() (height_compression.py:21). */
@@ -1170,6 +1176,10 @@ int glx_conv3x3_wgrad_ex(const float* x, const float* gy, int B, int H, int W, i
  * sums in `workspace`, glx_conv3x3_wgrad_reduce adds them into dW (strides as above). */
 int glx_conv3x3_wgrad_reduce(int Cin, int Cout, float* dW, long long s_co, long long s_ci, long long s_kh, long long s_kw,
                              const void* workspace, size_t workspace_bytes, void* stream);
+/* The partial sums of n layers in ONE launch (arrays of n; strides = 4 per layer: s_co, s_ci, s_kh, s_kw): the same sums in the
+ * same order as glx_conv3x3_wgrad_reduce.  nn.Conv2d's weight gradient (base_bev_backbone.py:30-49's 3 x 3 layers). */
+int glx_conv3x3_wgrad_reduce_multi(int n, const int32_t* Cin, const int32_t* Cout, float* const* dW, const long long* strides,
+                                   const void* const* workspace, const size_t* workspace_bytes, void* stream);
 /* ---- transposed convolutions with kernel = stride = u in {1, 2}, no padding (BaseBEVBackbone's deblocks,
  * base_bev_backbone.py:51-66: ConvTranspose2d(c, cu, u, stride=u, bias=False)), channels-last fp32 maps, same split-bf16
  * arithmetic (csrc/glx_deconv2d.hip).  W (Cin, Cout, u, u) with ELEMENT strides (s_ci, s_co, s_kh, s_kw); channel counts

@@ -637,3 +637,35 @@ def test_anchor_head_reads_the_deblocks_through_their_batchnorm(dev, form, monke
             assert float((p1.grad - p2.grad).abs().max()) <= 1e-5 * float(p2.grad.abs().max()) + 1e-8, n1
         for (n1, b1), (n2, b2) in zip(nets[True][mod].named_buffers(), nets[False][mod].named_buffers()):
             assert torch.equal(b1, b2), n1
+
+
+def test_partial_sums_of_several_layers_in_one_launch(dev):
+    """glx_conv3x3_wgrad_reduce_multi: the blocks' partial sums of layers of different widths (dW = NULL calls, each into a buffer
+    of its own), added by ONE launch into strided (channels-last) filters -- the bits of the per-layer calls."""
+    import ctypes
+    from glenet_amd import _lib
+    ll = ctypes.c_longlong
+    g = torch.Generator(device=dev).manual_seed(0)
+    jobs = []
+    for cin, cout, h, w in ((128, 128, 40, 36), (128, 256, 24, 20), (256, 256, 20, 18), (64, 64, 33, 17), (32, 64, 9, 50)):
+        x = torch.randn(2, cin, h, w, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+        gy = torch.randn(2, cout, h, w, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+        n = _lib.query("glx_conv3x3_wgrad_workspace_bytes", cin, cout)
+        want = torch.full((cout, cin, 3, 3), float("nan"), device=dev).contiguous(memory_format=torch.channels_last)
+        s = want.stride()
+        ws = torch.empty(n, dtype=torch.uint8, device=dev)
+        _lib.call("glx_conv3x3_wgrad_ex", x, gy, 2, h, w, cin, cout, want, ll(s[0]), ll(s[1]), ll(s[2]), ll(s[3]), None, ws, _lib.size_arg(n))
+        own = torch.empty(n, dtype=torch.uint8, device=dev)
+        _lib.call("glx_conv3x3_wgrad_ex", x, gy, 2, h, w, cin, cout, None, ll(s[0]), ll(s[1]), ll(s[2]), ll(s[3]), None, own, _lib.size_arg(n))
+        jobs.append((cin, cout, torch.full_like(want, float("nan")), tuple(s), own, want))
+    n = len(jobs)
+    i32 = ctypes.c_int32 * n
+    ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    _lib.call("glx_conv3x3_wgrad_reduce_multi", n, i32(*[j[0] for j in jobs]), i32(*[j[1] for j in jobs]), ptrs([j[2] for j in jobs]),
+              (ll * (4 * n))(*[v for j in jobs for v in j[3]]), ptrs([j[4] for j in jobs]), (ctypes.c_size_t * n)(*[j[4].numel() for j in jobs]))
+    torch.cuda.synchronize()
+    for j in jobs:
+        assert torch.equal(j[2], j[5]), j[:2]
+    with pytest.raises(_lib.GlxError, match="job 1 needs Cin"):
+        _lib.call("glx_conv3x3_wgrad_reduce_multi", 2, (ctypes.c_int32 * 2)(64, 48), (ctypes.c_int32 * 2)(64, 64), ptrs([j[2] for j in jobs][:2] + [jobs[0][2]] * (n - 2)),
+                  (ll * 8)(*([1] * 8)), ptrs([j[4] for j in jobs]), (ctypes.c_size_t * 2)(1 << 30, 1 << 30))

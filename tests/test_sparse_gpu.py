@@ -502,6 +502,43 @@ def test_weight_gradient_in_two_halves_and_with_the_input_transform(dev, cin, co
     assert torch.equal(run(x, pre, halves=True), want)
 
 
+def test_slab_sums_of_several_layers_in_one_launch(dev):
+    """glx_sconv_wgrad_pairs_reduce_multi: the chunk products of layers of different shapes (dW = NULL calls, each into a buffer
+    of its own), summed by ONE launch -- the bits of the per-layer calls; a job with too small a workspace is refused loudly."""
+    import ctypes
+    from glenet_amd import _lib
+    rng = np.random.default_rng(5)
+    jobs = []
+    for cin, cout, n_out, K in ((64, 64, 4000, 27), (16, 32, 1500, 27), (128, 64, 900, 8), (4, 16, 700, 27), (32, 32, 2500, 3)):
+        n_in = n_out + 3
+        nbr = torch.from_numpy(np.where(rng.random((n_out, K)) < 0.3, rng.integers(0, n_in, (n_out, K)), -1).astype(np.int32)).to(dev)
+        x = torch.from_numpy(rng.normal(size=(n_in, cin)).astype(np.float32)).to(dev)
+        g = torch.from_numpy(rng.normal(size=(n_out, cout)).astype(np.float32)).to(dev)
+        pl = _pair_lists_of(nbr, n_out, K, None, dev)[0]
+        wsb = _lib.query("glx_sconv_wgrad_pairs_workspace_bytes", n_out, K, cin, cout)
+        want = torch.full((K, cin, cout), float("nan"), device=dev)
+        ws = torch.zeros(wsb, dtype=torch.uint8, device=dev)
+        _lib.call("glx_sconv_wgrad_pairs_ex", x, g, pl, n_out, K, cin, cout, want, None, ws, _lib.size_arg(wsb))
+        own = torch.zeros(wsb, dtype=torch.uint8, device=dev)
+        _lib.call("glx_sconv_wgrad_pairs_ex", x, g, pl, n_out, K, cin, cout, None, None, own, _lib.size_arg(wsb))
+        jobs.append((pl, n_out, K, cin, cout, torch.full((K, cin, cout), float("nan"), device=dev), own, want))
+    n = len(jobs)
+    i32 = ctypes.c_int32 * n
+    ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+
+    def multi(sizes):
+        _lib.call("glx_sconv_wgrad_pairs_reduce_multi", n, ptrs([j[0] for j in jobs]), i32(*[j[1] for j in jobs]),
+                  i32(*[j[2] for j in jobs]), i32(*[j[3] for j in jobs]), i32(*[j[4] for j in jobs]), ptrs([j[5] for j in jobs]),
+                  ptrs([j[6] for j in jobs]), (ctypes.c_size_t * n)(*sizes))
+
+    multi([j[6].numel() for j in jobs])
+    torch.cuda.synchronize()
+    for j in jobs:
+        assert torch.equal(j[5], j[7]), j[1:5]
+    with pytest.raises(_lib.GlxError, match="job 2: workspace"):
+        multi([j[6].numel() if i != 2 else 1024 for i, j in enumerate(jobs)])
+
+
 def test_conv_with_five_input_channels_is_padded_not_scalar(dev):
     """Waymo point features (C = 5): forward and both gradients equal the oracle."""
     rng = np.random.default_rng(31)
