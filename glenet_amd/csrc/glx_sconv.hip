@@ -708,13 +708,13 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_mfma(
 // max |v| over the SEGS lanes that hold one gathered row (SEGS = 8, 16: within a DPP row; 32: two rows), the same value in all of
 // them.  Hand-written: the compiler's form of fmaxf over update_dpp is four instructions per step (mov_dpp, two canonicalising
 // maxima, a hazard nop); the values are |x|, no NaN handling is wanted here.  s_nop 1 = the two wait states between a VALU write
-// and a DPP read of the same register, which nobody inserts inside an asm statement.
+// and a DPP read of the same register, which nobody inserts inside an asm statement (the first one is longer: see there).
 template <int SEGS>
 __device__ __forceinline__ float sc_row_absmax(const f32x4 v) {
   float m;
   asm volatile("v_max3_f32 %0, |%1|, |%2|, |%3|\n\t"
                "v_max_f32 %0, |%4|, %0\n\t"
-               "s_nop 1\n\t"
+               "s_nop 2\n\t"      // 2 + 3 states: also the five a DPP needs behind a write of EXEC, should one end just in front
                "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                "s_nop 1\n\t"
                "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
