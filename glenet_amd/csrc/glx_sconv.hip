@@ -203,7 +203,8 @@ struct SconvBf3Cfg {
 };
 
 // Fourth image (k_sconv_gemm<..., F16 = true>): the weights as TWO fp16 planes of w 2^e (e = the filter's exponent: max |w| 2^e
-// in [2^14, 2^15), one per packed filter, kept in the 16 bytes behind the K images), w 2^e = a + b up to 2^-22, in the operand
+// in [2^14, 2^15), one per packed filter, kept in the 64 bytes behind the K images: int e, pad, then the SC_WEXP_PARTS partial
+// maxima k_sconv_wexp left for the pack kernel), w 2^e = a + b up to 2^-22, in the operand
 // order of v_mfma_f32_16x16x32_f16 with W^T as the row operand: per offset, column tile, 32-channel k-step and plane one 1 KB
 // block of 64 lanes x 8 fp16 -- lane l = (q, r) holds W[k][32 s + 8 q + j][16 tile + r], j = 0..7.  An offset's image has the
 // bytes of the fp32 image (CIN x COUT x 4): the block kernel's LDS budget and its three blocks per CU stay as they are.
@@ -212,7 +213,7 @@ struct SconvF2Cfg {
   static constexpr bool ON = CIN % 32 == 0 && COUT >= 64;
   static constexpr int KS = CIN / 32, NT = COUT / 16;
   static constexpr int IMG16 = ON ? CIN * COUT * 2 : 0;          // fp16 elements per offset
-  static constexpr int TAIL = ON ? 16 : 0;                       // bytes behind the K images: the exponent (int32)
+  static constexpr int TAIL = ON ? 64 : 0;                       // bytes behind the K images: the exponent (int32) + partial maxima
   __host__ __device__ static constexpr size_t idx(int k, int tile, int s, int plane, int lane) {
     return ((((size_t)k * NT + tile) * KS + s) * 2 + plane) * 512 + (size_t)lane * 8;
   }
@@ -253,9 +254,15 @@ __device__ __forceinline__ void sc_pack_elem(int e, const float* __restrict__ W,
     Wb[B3::idx(k, ct, 2, s3, lane3) + j3] = p2;
   }
   using F2 = SconvF2Cfg<CIN, COUT>;
-  if constexpr (F2::ON) {              // the two scaled fp16 planes behind those; the exponent was written by k_sconv_wexp
+  if constexpr (F2::ON) {              // the two scaled fp16 planes behind those; max |w| was taken by k_sconv_wexp
     _Float16* Wh = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(Wsplit + (size_t)K * S::IMG) + (size_t)K * B3::IMG16 * 2);
-    const int ew = *reinterpret_cast<const int*>(Wh + (size_t)K * F2::IMG16);
+    // the filter's exponent from the partial maxima of k_sconv_wexp (every thread for itself: two 16-byte reads of a cached
+    // line); the filter's first element leaves it where the convolution kernels read it
+    int* tail = reinterpret_cast<int*>(Wh + (size_t)K * F2::IMG16);
+    const f32x4 m0 = *reinterpret_cast<const f32x4*>(tail + 4), m1 = *reinterpret_cast<const f32x4*>(tail + 8);
+    const int e127 = cv_block_exponent(fmaxf(fmaxf(fmaxf(m0[0], m0[1]), fmaxf(m0[2], m0[3])), fmaxf(fmaxf(m1[0], m1[1]), fmaxf(m1[2], m1[3]))));
+    const int ew = e127 == 127 ? 0 : e127;             // an all-zero filter: any scale
+    if (e == 0) tail[0] = ew;
     _Float16 pa, pb;
     cv_split2(ldexpf(w, ew), pa, pb);
     const int s2 = ci / 32, lane2 = ((ci % 32) / 8) * 16 + n, j2 = ci % 8;
@@ -264,26 +271,32 @@ __device__ __forceinline__ void sc_pack_elem(int e, const float* __restrict__ W,
   }
 }
 
-// the exponent of a filter's fp16 image: block b takes job b, max |w| over the whole source tensor (the column halves of a
-// 128 -> 128 filter share it); all-zero filters get 0
-struct ScExpJob { const float* W; int* dst; int n; };
+// max |w| of a filter for its fp16 image's exponent: blockIdx.x = job, blockIdx.y = one of SC_WEXP_PARTS slices of the WHOLE source
+// tensor (the column halves of a 128 -> 128 filter share it); a slice's maximum goes to the packed filter's tail, the pack kernel
+// that follows turns the eight of them into the exponent.  (One block per job took 15 us of the step's first 100.)
+#define SC_WEXP_PARTS 8
+struct ScExpJob { const float* W; float* dst; int n; };
 struct ScExpJobs { ScExpJob j[40]; };   // <= SC_PACK_MAX_JOBS
-__global__ __launch_bounds__(1024) void k_sconv_wexp(ScExpJobs jobs) {
+__global__ __launch_bounds__(256) void k_sconv_wexp(ScExpJobs jobs) {
   const ScExpJob jb = jobs.j[blockIdx.x];
-  __shared__ float s_m[16];
-  float m = 0.f;
-  for (int e = threadIdx.x * 4; e < jb.n; e += 4096) {              // n % 4 == 0: channels are multiples of 4
-    const f32x4 v = *reinterpret_cast<const f32x4*>(jb.W + e);
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  __shared__ float s_m[4];
+  const int n4 = jb.n / 4;                                           // channels are multiples of 4
+  const int per = (n4 + SC_WEXP_PARTS - 1) / SC_WEXP_PARTS;
+  const int lo = blockIdx.y * per, hi = min(n4, lo + per);
+  float m[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int e = lo + (int)threadIdx.x; e < hi; e += 4 * 256) {        // four independent loads in flight per thread
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = e + u * 256;
+      const f32x4 v = reinterpret_cast<const f32x4*>(jb.W)[i < hi ? i : lo];
+      m[u] = fmaxf(fmaxf(m[u], fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
   }
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  float mm = lo < hi ? fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3])) : 0.f;
+  for (int o = 32; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mm;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < 16; ++w) m = fmaxf(m, s_m[w]);
-    const int e = cv_block_exponent(m);
-    *jb.dst = e == 127 ? 0 : e;
-  }
+  if (threadIdx.x == 0) jb.dst[4 + blockIdx.y] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
 }
 
 template <int CIN, int COUT>
@@ -1772,14 +1785,14 @@ static int pack_weights(const float* W, int K, float* Wp, int view, hipStream_t 
   ScExpJobs ex;
   int nex = 0;
   if constexpr (SconvF2Cfg<CI, CO>::ON)
-    ex.j[nex++] = ScExpJob{W, reinterpret_cast<int*>(f2_image<CI, CO>(Wp, K) + (size_t)K * S::IMG), nel};
+    ex.j[nex++] = ScExpJob{W, f2_image<CI, CO>(Wp, K) + (size_t)K * S::IMG, nel};
   if constexpr (sc_column_halves<CI, CO>()) {
     const size_t half = filter_bytes<CI, CO / 2>(K) / sizeof(float);
     float* base = Wp + filter_bytes<CI, CO>(K) / sizeof(float);
     for (int h = 0; h < 2; ++h)
-      ex.j[nex++] = ScExpJob{W, reinterpret_cast<int*>(f2_image<CI, CO / 2>(base + h * half, K) + (size_t)K * SconvSplitCfg<CI, CO / 2>::IMG), nel};
+      ex.j[nex++] = ScExpJob{W, f2_image<CI, CO / 2>(base + h * half, K) + (size_t)K * SconvSplitCfg<CI, CO / 2>::IMG, nel};
   }
-  if (nex) hipLaunchKernelGGL(k_sconv_wexp, dim3(nex), dim3(1024), 0, st, ex);
+  if (nex) hipLaunchKernelGGL(k_sconv_wexp, dim3(nex, SC_WEXP_PARTS), dim3(256), 0, st, ex);
   hipLaunchKernelGGL((k_pack_weights<CI, CO>), dim3(glx_divup(cover, 256)), dim3(256), 0, st, W, K,
                      Wp, Wp + (size_t)K * C::IMG, view, CO, 0);
   if constexpr (sc_column_halves<CI, CO>()) {
@@ -2132,7 +2145,7 @@ static int sc_pack_jobs(const float* W, int K, float* Wp, int view, ScPackJob* o
   int n = 0;
   out[n++] = ScPackJob{W, Wp, Wp + (size_t)K * C::IMG, K, sc_pack_cfg(CI, CO), view, CO, 0, cover};
   if constexpr (SconvF2Cfg<CI, CO>::ON)
-    ex[(*nex)++] = ScExpJob{W, reinterpret_cast<int*>(f2_image<CI, CO>(Wp, K) + (size_t)K * SconvSplitCfg<CI, CO>::IMG), nel};
+    ex[(*nex)++] = ScExpJob{W, f2_image<CI, CO>(Wp, K) + (size_t)K * SconvSplitCfg<CI, CO>::IMG, nel};
   if constexpr (sc_column_halves<CI, CO>()) {
     using CH = SconvCfg<CI, CO / 2>;
     const size_t half = filter_bytes<CI, CO / 2>(K) / sizeof(float);
@@ -2141,8 +2154,7 @@ static int sc_pack_jobs(const float* W, int K, float* Wp, int view, ScPackJob* o
     for (int h = 0; h < 2; ++h) {
       out[n++] = ScPackJob{W, base + h * half, base + h * half + (size_t)K * CH::IMG, K, sc_pack_cfg(CI, CO / 2),
                            view, CO, h * (CO / 2), ch};
-      ex[(*nex)++] = ScExpJob{W, reinterpret_cast<int*>(f2_image<CI, CO / 2>(base + h * half, K) +
-                                                       (size_t)K * SconvSplitCfg<CI, CO / 2>::IMG), nel};
+      ex[(*nex)++] = ScExpJob{W, f2_image<CI, CO / 2>(base + h * half, K) + (size_t)K * SconvSplitCfg<CI, CO / 2>::IMG, nel};
     }
   }
   return n;
@@ -2174,7 +2186,7 @@ extern "C" int glx_sconv_pack_weights_multi(int n, const float* const* W, const 
       nj += added;
     }
     for (int j = 0; j < nj; ++j) max_cover = jobs.j[j].cover > max_cover ? jobs.j[j].cover : max_cover;
-    if (nex) hipLaunchKernelGGL(k_sconv_wexp, dim3(nex), dim3(1024), 0, st, ex);      // the fp16 images' exponents first
+    if (nex) hipLaunchKernelGGL(k_sconv_wexp, dim3(nex, SC_WEXP_PARTS), dim3(256), 0, st, ex);      // max |w| of the fp16 images first
     hipLaunchKernelGGL(k_pack_weights_multi, dim3(glx_divup(max_cover, 256), nj), dim3(256), 0, st, jobs);
   }
   GLX_LAUNCH_CHECK();
