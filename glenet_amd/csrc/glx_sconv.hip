@@ -2729,7 +2729,9 @@ __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_mfma(
 // streams panels of 32 pairs through a double-buffered LDS stage -- rows gathered two panels ahead into registers, one
 // barrier per panel, dW[k] (Cin x Cout) in the MFMA accumulators for the whole chunk.  One slab per chunk, summed per
 // offset in chunk order by k_wgrad_pairs_reduce: fixed summation order, bitwise reproducible.
+#ifndef WGP_CHUNKS                      // (-DWGP_CHUNKS=480 / 1000 measured at the end of round 5: 5.25 / 5.29 against 5.24 ms per step)
 #define WGP_CHUNKS 720                  // target number of chunks (3 resident blocks per CU x 256 CUs, minus the K ragged tails)
+#endif
 #define WGP_MAXCH 1024                  // pairs per chunk at most (the LDS index lists)
 #define WGP_MINCH 128
 #define WGP_PANEL 32
