@@ -8,11 +8,13 @@
 // scatter-add disappears).  A block owns TR output rows, compacts their rule pairs per kernel
 // offset (wave ballots) so the matrix pipe only multiplies real rules, multiplies 16-pair chunks
 // by W[k] (LDS, MFMA-fragment order) with v_mfma_f32_16x16x4_f32 (exact fp32, bitwise an fmaf
-// chain) and sums into an fp32 accumulator tile in LDS; bias / BatchNorm / ReLU ride in the
-// epilogue.  Two kernels share that scheme:
-//   k_sconv_mfma   whole-chunk (or column-split) waves gather their rows into registers;
-//   k_sconv_gemm   all threads gather the next pair panel into LDS, chunks split over 4 waves.
-// Weight gradient: k_wgrad_mfma (offset-stationary).  dense(): k_dense_from_index.
+// chain) -- or, in the block kernel where the channels allow it (glx_sconv_set_arith, the default), with three
+// v_mfma_f32_16x16x32_f16 on two scaled fp16 pieces per operand (SconvF2Cfg) -- and sums into an fp32 accumulator tile in
+// LDS; bias / BatchNorm / ReLU ride in the epilogue.  The kernels that share that scheme:
+//   k_sconv_mfma   whole-chunk (or column-split) waves gather their rows into registers (thin layers);
+//   k_sconv_gemm   all threads gather the next pair panel into LDS, chunks split over 4 waves (Cout >= 64; fp32 or f16 x 2);
+//   k_sconv_gemm2  the same with the filter fragments in registers and a second row panel (sweep variants 40-42, 60-61).
+// Weight gradient: k_wgrad_pairs over per-offset pair lists (k_wgrad_mfma: row slices).  dense(): k_dense_from_index.
 #include <hip/hip_ext.h>
 #include <stdlib.h>
 #include <string.h>
@@ -188,21 +190,7 @@ struct SconvSplitCfg {
   }
 };
 
-// Third image (k_sconv_gemm3): the weights split into THREE bf16 planes (w = w0 + w1 + w2 up to 2^-24 |w|) in the operand
-// order of v_mfma_f32_16x16x32_bf16 with W^T as the row operand: per offset, column tile, plane and 32-channel k-step one
-// 1 KB block of 64 lanes x 8 bf16 -- lane l = (q, r) holds W[k][32 s + 8 q + j][16 tile + r], j = 0..7 -- so that a wave
-// loads the fragment of ITS column tile straight from L2 into registers with one 16-byte load per (plane, k-step).
-template <int CIN, int COUT>
-struct SconvBf3Cfg {
-  static constexpr bool ON = (CIN == 32 || CIN == 64) && (COUT == 64 || COUT == 128);
-  static constexpr int KS = CIN / 32, NT = COUT / 16;
-  static constexpr int IMG16 = ON ? CIN * COUT * 3 : 0;          // bf16 elements per offset
-  __host__ __device__ static constexpr size_t idx(int k, int tile, int plane, int s, int lane) {
-    return ((((size_t)k * NT + tile) * 3 + plane) * KS + s) * 512 + (size_t)lane * 8;
-  }
-};
-
-// Fourth image (k_sconv_gemm<..., F16 = true>): the weights as TWO fp16 planes of w 2^e (e = the filter's exponent: max |w| 2^e
+// Third image (k_sconv_gemm<..., F16 = true>): the weights as TWO fp16 planes of w 2^e (e = the filter's exponent: max |w| 2^e
 // in [2^14, 2^15), one per packed filter, kept in the 64 bytes behind the K images: int e, pad, then the SC_WEXP_PARTS partial
 // maxima k_sconv_wexp left for the pack kernel), w 2^e = a + b up to 2^-22, in the operand
 // order of v_mfma_f32_16x16x32_f16 with W^T as the row operand: per offset, column tile, 32-channel k-step and plane one 1 KB
@@ -243,19 +231,9 @@ __device__ __forceinline__ void sc_pack_elem(int e, const float* __restrict__ W,
   int h = ct / C::NC, c = ct % C::NC;
   Wp[(size_t)k * C::IMG + (h * 4 + q) * C::QSTRIDE + (t * 16 + n) * C::NC + c] = w;
   Wsplit[(size_t)k * S::IMG + S::idx(ct, ci / S::CQ, ci % S::CQ, n)] = w;
-  using B3 = SconvBf3Cfg<CIN, COUT>;
-  if constexpr (B3::ON) {              // the three bf16 planes, behind the two fp32 images of the packed buffer
-    __bf16* Wb = reinterpret_cast<__bf16*>(Wsplit + (size_t)K * S::IMG);
-    __bf16 p0, p1, p2;
-    cv_split(w, p0, p1, p2);
-    const int s3 = ci / 32, lane3 = ((ci % 32) / 8) * 16 + n, j3 = ci % 8;
-    Wb[B3::idx(k, ct, 0, s3, lane3) + j3] = p0;
-    Wb[B3::idx(k, ct, 1, s3, lane3) + j3] = p1;
-    Wb[B3::idx(k, ct, 2, s3, lane3) + j3] = p2;
-  }
   using F2 = SconvF2Cfg<CIN, COUT>;
-  if constexpr (F2::ON) {              // the two scaled fp16 planes behind those; max |w| was taken by k_sconv_wexp
-    _Float16* Wh = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(Wsplit + (size_t)K * S::IMG) + (size_t)K * B3::IMG16 * 2);
+  if constexpr (F2::ON) {              // the two scaled fp16 planes behind the two fp32 images; max |w| was taken by k_sconv_wexp
+    _Float16* Wh = reinterpret_cast<_Float16*>(Wsplit + (size_t)K * S::IMG);
     // the filter's exponent from the partial maxima of k_sconv_wexp (every thread for itself: two 16-byte reads of a cached
     // line); the filter's first element leaves it where the convolution kernels read it
     int* tail = reinterpret_cast<int*>(Wh + (size_t)K * F2::IMG16);
@@ -1004,49 +982,6 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
       // ---- multiply this wave's chunk of the current panel by its column tiles
       const int pbase = pb + grp * 16;
       if constexpr (TRACE) { my_chunks += pbase < cnt; ++n_steps; }
-      if (TRACE && (ep.xcd_group & 0x800) && pbase < cnt) {
-        // 0x800: TIMING stand-in (wrong values) for a split-bf16 multiply: 1.5 x the operand bytes from LDS, 12 bf16
-        // MFMAs (2 k-steps x 6 piece products, 16 cycles each) per column tile instead of 16 fp32 MFMAs (32 cycles)
-        typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-        const float* arow = s_a + (grp * 16 + r) * T::A_LD + q * CQ;
-        const float* arow2 = s_a + (grp * 16 + (r ^ 1)) * T::A_LD + q * CQ;
-        bf16x8_t Af[6];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Af[i] = *reinterpret_cast<const bf16x8_t*>(arow + 4 * (i % (CQ / 4 > 0 ? CQ / 4 : 1)));
-        Af[4] = *reinterpret_cast<const bf16x8_t*>(arow2);
-        Af[5] = *reinterpret_cast<const bf16x8_t*>(arow2 + 4);
-        f32x4 acc[T::TPW];
-#pragma unroll
-        for (int tt = 0; tt < T::TPW; ++tt) {
-          acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-          const float* wp = s_w + S::idx(tile0 + tt, q, 0, r);
-          const float* wp2 = s_w + S::idx(tile0 + tt, q ^ 1, 0, r);
-          bf16x8_t Wf[6];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) Wf[i] = *reinterpret_cast<const bf16x8_t*>(wp + 64 * (i % (CQ / 4 > 0 ? CQ / 4 : 1)));
-          Wf[4] = *reinterpret_cast<const bf16x8_t*>(wp2);
-          Wf[5] = *reinterpret_cast<const bf16x8_t*>(wp2 + 64);
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[3 * ks + 2], Af[3 * ks + 0], acc[tt], 0, 0, 0);
-            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[3 * ks + 0], Af[3 * ks + 2], acc[tt], 0, 0, 0);
-            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[3 * ks + 1], Af[3 * ks + 1], acc[tt], 0, 0, 0);
-            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[3 * ks + 1], Af[3 * ks + 0], acc[tt], 0, 0, 0);
-            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[3 * ks + 0], Af[3 * ks + 1], acc[tt], 0, 0, 0);
-            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[3 * ks + 0], Af[3 * ks + 0], acc[tt], 0, 0, 0);
-          }
-        }
-        const int p = pbase + r;
-        if (p < cnt) {
-          float* dst = s_acc + (int)s_pslot[k * TR + p] * ACC_LD + tile0 * 16 + 4 * q;
-#pragma unroll
-          for (int tt = 0; tt < T::TPW; ++tt) {
-            f32x4 v = *reinterpret_cast<f32x4*>(dst + tt * 16);
-            v += acc[tt];
-            *reinterpret_cast<f32x4*>(dst + tt * 16) = v;
-          }
-        }
-      } else
       if constexpr (F16) { if (pbase < cnt && !(TRACE && (ep.xcd_group & 0x100))) {   // wave-uniform (0x100: ablate the multiply)
         constexpr int KS = CIN / 32;
         const _Float16* arow = reinterpret_cast<const _Float16*>(s_a + (grp * 16 + r) * T::A_LD) + q * 8;
@@ -1461,215 +1396,6 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm2(
   sc_epilogue<COUT, TR, THREADS, ACC_LD>(smem, s_acc, s_rows, ep, out, ep.out_ld ? ep.out_ld : COUT, N_out);
 }
 
-// ------------------------------------------------------------------ GEMM kernel, fp32 products on the bf16 matrix pipe
-// k_sconv_gemm2's organisation (64-row tile, rule compaction, 16 G-pair row panels gathered by all threads, a chunk split
-// over WPG waves by column tile, the wave's weight fragment in registers one offset ahead, two row panels in LDS, ONE
-// barrier per step) with the multiply of glx_conv2d.hip: every fp32 operand is the sum of three bf16 pieces and a
-// product is the six piece products with i + j <= 2 on v_mfma_f32_16x16x32_bf16, fp32 accumulation -- exact to 2^-22 per
-// product, i.e. fp32-class results, at 12 MFMAs of 16 cycles per (16-pair chunk, column tile) for CIN = 64 where the
-// fp32 MFMA path issues 16 of 32 cycles.  The weights are split at pack time (SconvBf3Cfg), the gathered rows by the
-// thread that stages them into LDS (once per row, not once per column tile): a panel is three bf16 planes of
-// (pairs, CIN + 8) -- 144-byte rows, so that the 16 lanes of a k-group read their 16-byte fragments from 16 distinct
-// bank groups.  LDS: 17 KB accumulator tile + 2 x 3 x 4.6 KB panels + 9 KB pair lists = 54 KB, three blocks per CU.
-template <int CIN, int COUT, int TR_, int NW_, int WPG_>
-struct SconvGemm3 {
-  using B3 = SconvBf3Cfg<CIN, COUT>;
-  static constexpr int NT = COUT / 16, KS = CIN / 32;
-  static constexpr int TR = TR_, NW = NW_, WPG = WPG_, THREADS = NW * 64;
-  static constexpr int G = NW / WPG, TPW = NT / WPG;
-  static constexpr int AP = 16 * G;
-  static constexpr int A_LDB = CIN + 8;                       // bf16 per panel row
-  static constexpr int PLANE = AP * A_LDB;                    // bf16 per plane of a panel
-  static constexpr int SEGS = CIN / 4;
-  static constexpr int A_SEG = AP * SEGS;
-  static constexpr int GPT = (A_SEG + THREADS - 1) / THREADS;
-  static constexpr int ACC_LD = COUT + 4;
-  static constexpr size_t lds_bytes = (size_t)TR * ACC_LD * 4 + 2 * 3 * (size_t)PLANE * 2 +
-                                      (size_t)SC_MAXK * TR * 5 + (TR + 32) * 4 + 64;
-  static_assert(TR == 64, "one wave spans the tile");
-  static_assert(NW % WPG == 0 && NT % WPG == 0, "bad column split");
-};
-
-// __launch_bounds__' second argument (waves per SIMD): three 8-wave blocks per CU = 6 -- the compiler then keeps the
-// kernel within 80 VGPRs (it takes 85 when left alone, which costs the third block); four 4-wave blocks = 4.
-template <int CIN, int COUT, int TR_, int NW_, int WPG_>
-__global__ __launch_bounds__(NW_ * 64, (COUT / 16 / WPG_ == 1 ? (NW_ == 8 ? 6 : 4) : 1)) void k_sconv_gemm3(
-    const float* __restrict__ in, const __bf16* __restrict__ Wb, SconvEpilogue ep,
-    const int* __restrict__ nbr, const int* __restrict__ tile_order, int N_out, int K,
-    float* __restrict__ out) {
-  if (ep.n_live) N_out = min(N_out, *ep.n_live);
-  using T = SconvGemm3<CIN, COUT, TR_, NW_, WPG_>;
-  using B3 = SconvBf3Cfg<CIN, COUT>;
-  constexpr int TR = T::TR, ACC_LD = T::ACC_LD, THREADS = T::THREADS, KS = T::KS;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_acc = smem;                                                    // TR * ACC_LD
-  __bf16* s_a = reinterpret_cast<__bf16*>(s_acc + TR * ACC_LD);           // 2 buffers x 3 planes x PLANE
-  int* s_pin = reinterpret_cast<int*>(s_a + 2 * 3 * T::PLANE);            // SC_MAXK * TR
-  int* s_rows = s_pin + SC_MAXK * TR;                                     // TR
-  int* s_cnt = s_rows + TR;                                               // 32
-  unsigned char* s_pslot = reinterpret_cast<unsigned char*>(s_cnt + 32);  // SC_MAXK * TR
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int row0 = (ep.tile_map ? ep.tile_map[blockIdx.x] : sc_xcd_tile(blockIdx.x, gridDim.x, ep.xcd_group & 0xFF)) * TR;
-  const int grp = wave / T::WPG;
-  const int tile0 = (wave % T::WPG) * T::TPW;
-
-  // ---- tile rows, zero accumulators, rule compaction: every wave compacts a share of the offsets
-  for (int i = tid; i < TR * ACC_LD / 4; i += THREADS)
-    reinterpret_cast<f32x4*>(s_acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  {
-    const int prow = row0 + lane;
-    const int lrow = (prow < N_out) ? (tile_order ? tile_order[prow] : prow) : -1;
-    const int* np = nbr + (long long)(lrow < 0 ? 0 : lrow) * K;
-    constexpr int KPW = (SC_MAXK + T::NW - 1) / T::NW;
-    int nbv[KPW];
-#pragma unroll
-    for (int u = 0; u < KPW; ++u) {
-      const int k = wave + u * T::NW;
-      nbv[u] = np[k < K ? k : 0];
-    }
-    if (wave == 0) s_rows[lane] = lrow;
-#pragma unroll
-    for (int u = 0; u < KPW; ++u) {
-      const int k = wave + u * T::NW;
-      if (k < SC_MAXK) {
-        const bool v = k < K && lrow >= 0 && nbv[u] >= 0;
-        const unsigned long long bal = __ballot(v);
-        if (v) {
-          const int pos = k * TR + __popcll(bal & ((1ull << lane) - 1ull));
-          s_pin[pos] = nbv[u];
-          s_pslot[pos] = (unsigned char)lane;
-        }
-        if (lane == 0) s_cnt[k] = __popcll(bal);
-      }
-    }
-    __syncthreads();
-  }
-  const unsigned mask = (unsigned)__ballot(lane < K && lane < SC_MAXK && s_cnt[lane < SC_MAXK ? lane : 0] > 0);
-
-  bf16x8 wcur[T::TPW][KS][3], wnxt[T::TPW][KS][3];
-  f32x4 areg[T::GPT];
-#define G3_LOAD_W(KK)                                                                        \
-  {                                                                                          \
-    _Pragma("unroll") for (int tt_ = 0; tt_ < T::TPW; ++tt_) {                               \
-      _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) {                                     \
-        _Pragma("unroll") for (int s_ = 0; s_ < KS; ++s_)                                    \
-          wnxt[tt_][s_][p_] = *reinterpret_cast<const bf16x8*>(Wb + B3::idx((KK), tile0 + tt_, p_, s_, lane)); \
-      }                                                                                      \
-    }                                                                                        \
-  }
-#define G3_TAKE_W()                                                                          \
-  {                                                                                          \
-    _Pragma("unroll") for (int tt_ = 0; tt_ < T::TPW; ++tt_) {                               \
-      _Pragma("unroll") for (int s_ = 0; s_ < KS; ++s_) {                                    \
-        _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) wcur[tt_][s_][p_] = wnxt[tt_][s_][p_]; \
-      }                                                                                      \
-    }                                                                                        \
-  }
-#define G3_LOAD_A(KK, PB, CNT)                                                               \
-  {                                                                                          \
-    _Pragma("unroll") for (int i_ = 0; i_ < T::GPT; ++i_) {                                  \
-      int e_ = tid + i_ * THREADS;                                                           \
-      int pair_ = e_ / T::SEGS, seg_ = e_ - pair_ * T::SEGS;                                 \
-      int p_ = (PB) + pair_;                                                                 \
-      int irow_ = 0;                                                                         \
-      if (p_ < (CNT) && pair_ < T::AP) irow_ = s_pin[(KK) * TR + p_];                        \
-      areg[i_] = *reinterpret_cast<const f32x4*>(in + (long long)irow_ * CIN + seg_ * 4);    \
-    }                                                                                        \
-  }
-  // the staging thread splits its four floats into the three planes (8-byte stores)
-#define G3_STORE_A(BUF)                                                                      \
-  {                                                                                          \
-    __bf16* dst_ = s_a + (BUF) * (3 * T::PLANE);                                             \
-    _Pragma("unroll") for (int i_ = 0; i_ < T::GPT; ++i_) {                                  \
-      int e_ = tid + i_ * THREADS;                                                           \
-      int pair_ = e_ / T::SEGS, seg_ = e_ - pair_ * T::SEGS;                                 \
-      if (T::A_SEG % THREADS == 0 || e_ < T::A_SEG) {                                        \
-        bf16x4 h0_, h1_, h2_;                                                                \
-        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                   \
-          __bf16 a_, b_, c3_;                                                                \
-          cv_split(areg[i_][c_], a_, b_, c3_);                                               \
-          h0_[c_] = a_; h1_[c_] = b_; h2_[c_] = c3_;                                         \
-        }                                                                                    \
-        __bf16* row_ = dst_ + pair_ * T::A_LDB + seg_ * 4;                                   \
-        *reinterpret_cast<bf16x4*>(row_) = h0_;                                              \
-        *reinterpret_cast<bf16x4*>(row_ + T::PLANE) = h1_;                                   \
-        *reinterpret_cast<bf16x4*>(row_ + 2 * T::PLANE) = h2_;                               \
-      }                                                                                      \
-    }                                                                                        \
-  }
-
-  if (mask) {
-    int k = __builtin_ctz(mask);
-    unsigned rem = mask & (mask - 1);
-    int cnt = s_cnt[k], pb = 0, buf = 0;
-    G3_LOAD_W(k);
-    G3_LOAD_A(k, 0, cnt);
-    G3_TAKE_W();
-    G3_STORE_A(0);
-    __syncthreads();
-    while (true) {
-      bool has_next = true, new_w = false;
-      int kn = k, pbn = pb + T::AP, cntn = cnt;
-      if (pbn >= cnt) {
-        if (rem) {
-          kn = __builtin_ctz(rem);
-          rem &= rem - 1;
-          pbn = 0;
-          cntn = s_cnt[kn];
-          new_w = true;
-        } else {
-          has_next = false;
-        }
-      }
-      if (has_next) {
-        if (new_w) G3_LOAD_W(kn);            // first: the gathers below must not stand between W and its use (vmcnt is in order)
-        G3_LOAD_A(kn, pbn, cntn);
-      }
-      // ---- multiply this wave's chunk of the current panel by its column tile(s)
-      const int pbase = pb + grp * 16;
-      if (pbase < cnt) {                     // wave-uniform
-        const __bf16* arow = s_a + buf * (3 * T::PLANE) + (grp * 16 + r) * T::A_LDB + 8 * q;
-        f32x4 acc[T::TPW];
-#pragma unroll
-        for (int tt = 0; tt < T::TPW; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          bf16x8 Af[3];
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) Af[pl] = *reinterpret_cast<const bf16x8*>(arow + pl * T::PLANE + 32 * s);
-#pragma unroll
-          for (int tt = 0; tt < T::TPW; ++tt) BF3_MFMA6(acc[tt], wcur[tt][s], Af);
-        }
-        const int p = pbase + r;
-        if (p < cnt) {
-          float* dst = s_acc + (int)s_pslot[k * TR + p] * ACC_LD + tile0 * 16 + 4 * q;
-#pragma unroll
-          for (int tt = 0; tt < T::TPW; ++tt) {
-            f32x4 v = *reinterpret_cast<f32x4*>(dst + tt * 16);
-            v += acc[tt];
-            *reinterpret_cast<f32x4*>(dst + tt * 16) = v;
-          }
-        }
-      }
-      if (!has_next) break;
-      G3_STORE_A(buf ^ 1);                   // the other buffer: last read one barrier ago
-      if (new_w) G3_TAKE_W();
-      __syncthreads();
-      k = kn; pb = pbn; cnt = cntn; buf ^= 1;
-    }
-  }
-#undef G3_LOAD_W
-#undef G3_TAKE_W
-#undef G3_LOAD_A
-#undef G3_STORE_A
-  __syncthreads();
-
-  sc_epilogue<COUT, TR, THREADS, ACC_LD>(smem, s_acc, s_rows, ep, out, ep.out_ld ? ep.out_ld : COUT, N_out);
-}
-
 // ------------------------------------------------------------------ generic scalar kernel
 __global__ void k_sconv_generic(const float* __restrict__ in, const float* __restrict__ W,
                                 SconvEpilogue ep, const int* __restrict__ nbr, int N_out, int K,
@@ -1718,9 +1444,9 @@ static bool mfma_supported(int Cin, int Cout, int K) {
 }
 
 template <int CIN, int COUT>
-static size_t img_bytes() {   // both LDS images (whole-chunk and column-split layout) of one offset + the bf16 and fp16 planes
+static size_t img_bytes() {   // both LDS images (whole-chunk and column-split layout) of one offset + the fp16 planes
   return (size_t)(SconvCfg<CIN, COUT>::IMG + SconvSplitCfg<CIN, COUT>::IMG) * sizeof(float) +
-         (size_t)SconvBf3Cfg<CIN, COUT>::IMG16 * 2 + (size_t)SconvF2Cfg<CIN, COUT>::IMG16 * 2;
+         (size_t)SconvF2Cfg<CIN, COUT>::IMG16 * 2;
 }
 template <int CIN, int COUT>
 static size_t filter_bytes(int K) {   // a packed filter: K offsets of every image, then the fp16 image's exponent
@@ -1978,37 +1704,6 @@ static int launch_gemm2(const float* in, const float* Wp, const SconvEpilogue& e
   }
 }
 
-template <int CI, int CO, int TR, int NW, int WPG_REQ>
-static int launch_gemm3(const float* in, const float* Wp, const SconvEpilogue& ep,
-                        const int32_t* nbr, const int32_t* tile_order, int N_out, int K, float* out,
-                        hipStream_t st) {
-  constexpr int WPG = WPG_REQ < CO / 16 ? WPG_REQ : CO / 16;
-  if constexpr (!SconvBf3Cfg<CI, CO>::ON || TR != 64) {
-    glx_set_error("sparse conv GEMM3 (split-bf16) tile: channels (32|64) -> (64|128), 64-row tiles (%d,%d,TR=%d)", CI, CO, TR);
-    return GLX_EINVAL;
-  } else {
-    using T = SconvGemm3<CI, CO, TR, NW, WPG>;
-    static bool attr_set = false;
-    auto kern = k_sconv_gemm3<CI, CO, TR, NW, WPG>;
-    const size_t lds = T::lds_bytes;
-    if (!attr_set) {
-      GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
-    }
-    const __bf16* Wb = reinterpret_cast<const __bf16*>(Wp + (size_t)K * (SconvCfg<CI, CO>::IMG + SconvSplitCfg<CI, CO>::IMG));
-    int nblocks = glx_divup(N_out, TR);
-    if (g_prof_start && g_prof_stop) {
-      hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(T::THREADS), lds, st, g_prof_start, g_prof_stop, 0, in, Wb,
-                            ep, nbr, tile_order, N_out, K, out);
-      g_prof_start = g_prof_stop = nullptr;
-    } else {
-      hipLaunchKernelGGL(kern, dim3(nblocks), dim3(T::THREADS), lds, st, in, Wb, ep, nbr, tile_order, N_out, K, out);
-    }
-    GLX_LAUNCH_CHECK();
-    return GLX_OK;
-  }
-}
-
 template <int CI, int CO>
 static int launch_mfma(const float* in, const float* Wp, const SconvEpilogue& ep,
                        const int32_t* nbr, const int32_t* tile_order, int N_out, int K, float* out,
@@ -2035,10 +1730,6 @@ static int launch_mfma(const float* in, const float* Wp, const SconvEpilogue& ep
     // f16 x 2 multiply with the weights in registers (shapes without the fp16 image keep their default)
     case 60: if constexpr (SconvF2Cfg<CI, CO>::ON) return launch_gemm2<CI, CO, 64, 8, 4, true>(in, Wp, ep, nbr, tile_order, N_out, K, out, st); break;
     case 61: if constexpr (SconvF2Cfg<CI, CO>::ON) return launch_gemm2<CI, CO, 64, 4, 4, true>(in, Wp, ep, nbr, tile_order, N_out, K, out, st); break;
-    // split-bf16 multiply, weights in registers (shapes without that kernel keep their default)
-    case 50: if constexpr (SconvBf3Cfg<CI, CO>::ON) return launch_gemm3<CI, CO, 64, 8, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st); break;
-    case 51: if constexpr (SconvBf3Cfg<CI, CO>::ON) return launch_gemm3<CI, CO, 64, 4, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st); break;
-    case 52: if constexpr (SconvBf3Cfg<CI, CO>::ON) return launch_gemm3<CI, CO, 64, 8, 2>(in, Wp, ep, nbr, tile_order, N_out, K, out, st); break;
     default: break;
   }
 #undef SC_GO
