@@ -177,6 +177,14 @@ def _sconv_arith():
     return "f16x2" if _lib.query("glx_sconv_get_arith") else "fp32"
 
 
+def _wgrad_arith(kernel):
+    """k_wgrad_pairs<cin,cout> -> the arithmetic glx_sconv_wgrad_pairs runs for it."""
+    import re
+    from glenet_amd import _lib
+    m = re.match(r"k_wgrad_pairs<(\d+),(\d+)>", kernel)
+    return "f16x2" if m and _lib.query("glx_sconv_wgrad_arith", int(m.group(1)), int(m.group(2))) else "fp32"
+
+
 def _has_f16_image(kernel):
     """k_sconv_gemm<cin,cout>: the channels glx_sconv_set_arith's fp16 image exists for."""
     import re
@@ -749,6 +757,7 @@ def bench_config4_train(dev, pts, bidx, frames, steps=60):
                                             calls_per_step=d["launches"] // n_prof,
                                             TFLOPs=round(d["flops"] / sec / 1e12, 2),
                                             mfma_frac=round(d["flops"] / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                            arithmetic=_wgrad_arith(dom) + " (mfma_frac: TFLOP/s over the fp32 matrix peak)",
                                             alg_GBps=round(d["bytes"] / sec / 1e9, 1),
                                             hbm_frac_algorithmic=round(d["bytes"] / sec / 1e9 / HBM_PEAK_GBS, 4),
                                             note="torch events around k_wgrad_pairs + k_wgrad_pairs_reduce of one call; "

@@ -2708,6 +2708,260 @@ __global__ __launch_bounds__(WGM_THREADS) void k_wgrad_pairs(
   }
 }
 
+// ------------------------------------------------------------------ the same contraction from two scaled fp16 pieces
+// k_wgrad_pairs with the f16 x 2 arithmetic of the block kernel (Cin, Cout multiples of 32): a panel is 32 pairs = ONE k-step of
+// v_mfma_f32_16x16x32_f16, both operands staged as two fp16 planes in pair-major rows of 64 bytes per 32-channel image and read
+// back transposed (ds_read_b64_tr_b16: a lane gets ITS channel at four pairs), three MFMAs per 16 x 16 tile of dW[k] instead of
+// eight fp32 ones of twice the cycles.  The pairs are the contraction index, so a panel has ONE exponent per operand (the
+// block's maximum over the 32 rows, two barriers per panel), and the accumulators carry a running exponent over the chunk's
+// panels exactly as k_conv3x3_wgrad2's do over its pixel tiles (glx_conv2d.hip).  Row gathers two panels ahead in two register
+// sets; index lists, chunking, slab layout and the slab sums are k_wgrad_pairs's.  It pays where the tiles per gathered row are
+// many (wide layers: the narrow ones are bound by their row gathers either way), see sc_wgrad_f16_pays().
+template <int CIN, int COUT>
+struct WgradPairsF16Cfg {
+  static constexpr bool ON = CIN % 32 == 0 && COUT % 32 == 0;
+  static constexpr int MI = CIN / 16, NI = COUT / 16;
+  static constexpr int MW = MI >= 4 ? MI / 4 : 1;              // x tiles of a wave
+  static constexpr int NW = MI >= 4 ? NI : NI / (4 / MI);      // gy tiles of a wave
+  static constexpr int XPLANE = (CIN / 32) * 2048, GPLANE = (COUT / 32) * 2048;      // bytes of one fp16 plane of a panel
+  static constexpr size_t lds_bytes = (size_t)2 * (XPLANE + GPLANE) + (size_t)WGP_MAXCH * 8 + sizeof(PairMeta) + 64 + (size_t)CIN * 8 + 64;
+};
+
+// max of a non-negative value over the wave, in every lane: the 16-lane rows by DPP, the four rows through readlane
+__device__ __forceinline__ float sc_wave_max(float m) {
+  asm volatile("s_nop 2\n\t"
+               "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\t"
+               "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\t"
+               "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\t"
+               "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+               : "+v"(m));
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(WGM_THREADS) void k_wgrad_pairs_f16(
+    const float* __restrict__ in, const float* __restrict__ gout, const PairMeta* __restrict__ meta,
+    const int* __restrict__ pair_in, const int* __restrict__ pair_out, int K, float* __restrict__ slabs,
+    const float* __restrict__ pre_scale, const float* __restrict__ pre_shift) {
+  using T = WgradPairsF16Cfg<CIN, COUT>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* sX = reinterpret_cast<char*>(smem);                        // [plane][32-channel image][pair][64 B]
+  char* sG = sX + 2 * T::XPLANE;
+  int* s_pi = reinterpret_cast<int*>(sG + 2 * T::GPLANE);          // WGP_MAXCH input rows of the chunk's pairs
+  int* s_pj = s_pi + WGP_MAXCH;                                    // WGP_MAXCH output rows
+  PairMeta* s_meta = reinterpret_cast<PairMeta*>(s_pj + WGP_MAXCH);
+  float* s_pre = reinterpret_cast<float*>(s_meta + 1) + 16;        // 2 * CIN: scale | shift of the input transform
+  float* s_max = s_pre + 2 * CIN;                                  // [wave][x | gy]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, kq = lane >> 4;
+  const bool pre = pre_scale != nullptr;
+  if (pre) {
+    for (int e = tid; e < CIN; e += WGM_THREADS) { s_pre[e] = pre_scale[e]; s_pre[CIN + e] = pre_shift[e]; }
+  }
+  for (int e = tid; e < (int)(sizeof(PairMeta) / 4); e += WGM_THREADS)
+    reinterpret_cast<int*>(s_meta)[e] = reinterpret_cast<const int*>(meta)[e];
+  __syncthreads();
+  const int n_chunks = s_meta->coff[K], CH = s_meta->ch;
+
+  constexpr int SEG_A = CIN / 4, SEG_B = COUT / 4;
+  constexpr int RA = WGP_PANEL * SEG_A / WGM_THREADS, RB = WGP_PANEL * SEG_B / WGM_THREADS;      // CIN / 32, COUT / 32
+  static_assert(WGP_PANEL == 32 && WGM_THREADS == 256, "one panel = one 32-wide k-step, four waves");
+  // where a thread's 4-channel piece of pair pr goes: image sg >> 3, 16-channel half ((sg & 7) >> 2) ^ bit 3 of the pair (bank
+  // spread of the transposing reads), 8 bytes at (sg & 3) * 8
+  auto piece = [](int pr, int sg) { return (sg >> 3) * 2048 + pr * 64 + (((((sg & 7) >> 2) ^ ((pr >> 3) & 1))) << 5) + (sg & 3) * 8; };
+  // a lane's part of the transposing reads of a 16-channel tile t (image t >> 1, half t & 1): pairs 8 kq + 4 h + qq, 4 channels at pp
+  const int qq = n >> 2, pp = n & 3;
+  auto tr_addr = [&](int t, int h) {
+    const int pr = 8 * kq + 4 * h + qq;
+    return (t >> 1) * 2048 + pr * 64 + ((((t & 1) ^ ((pr >> 3) & 1))) << 5) + pp * 8;
+  };
+  // this wave's tiles: MI >= 4: x tiles wave + 4 i, every gy tile; MI == 2: x tile wave & 1, a half of the gy tiles
+  const int mi0 = T::MI >= 4 ? wave : (wave & 1);
+  const int ni0 = T::MI >= 4 ? 0 : (wave >> 1) * T::NW;
+
+  auto gather = [&](int p, int np, f32x4 (&ra)[RA], f32x4 (&rb)[RB]) {
+#pragma unroll
+    for (int it = 0; it < RA; ++it) {
+      const int e = tid + it * WGM_THREADS, pr = e / SEG_A, sg = e - pr * SEG_A;
+      const int q = p * WGP_PANEL + pr;
+      ra[it] = *reinterpret_cast<const f32x4*>(in + (long long)s_pi[q < np ? q : 0] * CIN + sg * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < RB; ++it) {
+      const int e = tid + it * WGM_THREADS, pr = e / SEG_B, sg = e - pr * SEG_B;
+      const int q = p * WGP_PANEL + pr;
+      rb[it] = *reinterpret_cast<const f32x4*>(gout + (long long)s_pj[q < np ? q : 0] * COUT + sg * 4);
+    }
+  };
+
+  f32x4 acc[T::MW][T::NW];
+  int esum = 254;            // the exponent e_x + e_g the accumulators are scaled by (254: nothing accumulated yet)
+  typedef i16x4 __attribute__((address_space(3))) * lds_p;
+  // panel p (in the register set) -> LDS
+  auto panel = [&](int p, int np, f32x4 (&ra)[RA], f32x4 (&rb)[RB]) {
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mx = 0.f, mg = 0.f;
+#pragma unroll
+    for (int it = 0; it < RA; ++it) {
+      const int e = tid + it * WGM_THREADS, pr = e / SEG_A, sg = e - pr * SEG_A;
+      f32x4 v = ra[it];
+      if (pre) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(s_pre + sg * 4), sh = *reinterpret_cast<const f32x4*>(s_pre + CIN + sg * 4);
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) v[c4] = fmaxf(bn_affine(v[c4], sc[c4], sh[c4]), 0.f);
+      }
+      ra[it] = v = p * WGP_PANEL + pr < np ? v : zero;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) mx = fmaxf(mx, fabsf(v[c4]));
+    }
+#pragma unroll
+    for (int it = 0; it < RB; ++it) {
+      const int e = tid + it * WGM_THREADS, pr = e / SEG_B;
+      const f32x4 v = rb[it] = p * WGP_PANEL + pr < np ? rb[it] : zero;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) mg = fmaxf(mg, fabsf(v[c4]));
+    }
+    mx = sc_wave_max(mx);
+    mg = sc_wave_max(mg);
+    if (lane == 0) { s_max[2 * wave] = mx; s_max[2 * wave + 1] = mg; }
+    __syncthreads();          // the previous panel's reads of the images are done; the maxima are there
+    const f32x4 m03 = *reinterpret_cast<const f32x4*>(s_max), m47 = *reinterpret_cast<const f32x4*>(s_max + 4);
+    int ex = __builtin_amdgcn_readfirstlane(cv_block_exponent(fmaxf(fmaxf(m03[0], m03[2]), fmaxf(m47[0], m47[2]))));
+    int eg = __builtin_amdgcn_readfirstlane(cv_block_exponent(fmaxf(fmaxf(m03[1], m03[3]), fmaxf(m47[1], m47[3]))));
+    if (ex == 127) ex = 0;    // an operand of zeros: any scale
+    if (eg == 127) eg = 0;
+    if (ex + eg < esum) {      // block-uniform
+      if (esum != 254) {
+#pragma unroll
+        for (int i = 0; i < T::MW; ++i)
+#pragma unroll
+          for (int j = 0; j < T::NW; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = ldexpf(acc[i][j][e], ex + eg - esum);
+      }
+      esum = ex + eg;
+    }
+    int egu = esum - ex;      // <= eg: a panel whose own product scale is larger takes the accumulators' scale
+    egu = egu < -120 ? -120 : egu;
+    const float sx = __builtin_bit_cast(float, (unsigned)(ex + 127) << 23);       // exact powers of two, |e| <= 120
+    const float sg_ = __builtin_bit_cast(float, (unsigned)(egu + 127) << 23);
+#pragma unroll
+    for (int it = 0; it < RA; ++it) {
+      const int e = tid + it * WGM_THREADS, pr = e / SEG_A, sg = e - pr * SEG_A;
+      f16x4 p0, p1;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        _Float16 u, v;
+        cv_split2(ra[it][c4] * sx, u, v);
+        p0[c4] = u; p1[c4] = v;
+      }
+      *reinterpret_cast<f16x4*>(sX + piece(pr, sg)) = p0;
+      *reinterpret_cast<f16x4*>(sX + T::XPLANE + piece(pr, sg)) = p1;
+    }
+#pragma unroll
+    for (int it = 0; it < RB; ++it) {
+      const int e = tid + it * WGM_THREADS, pr = e / SEG_B, sg = e - pr * SEG_B;
+      f16x4 p0, p1;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        _Float16 u, v;
+        cv_split2(rb[it][c4] * sg_, u, v);
+        p0[c4] = u; p1[c4] = v;
+      }
+      *reinterpret_cast<f16x4*>(sG + piece(pr, sg)) = p0;
+      *reinterpret_cast<f16x4*>(sG + T::GPLANE + piece(pr, sg)) = p1;
+    }
+    __syncthreads();
+  };
+  auto multiply = [&]() {
+    f16x8 xa[T::MW][2];
+#pragma unroll
+    for (int i = 0; i < T::MW; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        const int t = mi0 + 4 * i;
+        i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(sX + pl * T::XPLANE + tr_addr(t, 0)));
+        i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(sX + pl * T::XPLANE + tr_addr(t, 1)));
+        xa[i][pl] = __builtin_bit_cast(f16x8, wg_join(lo, hi));
+      }
+#pragma unroll
+    for (int j = 0; j < T::NW; ++j) {
+      f16x8 gb[2];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(sG + pl * T::GPLANE + tr_addr(ni0 + j, 0)));
+        i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(sG + pl * T::GPLANE + tr_addr(ni0 + j, 1)));
+        gb[pl] = __builtin_bit_cast(f16x8, wg_join(lo, hi));
+      }
+#pragma unroll
+      for (int i = 0; i < T::MW; ++i) F2_MFMA3(acc[i][j], xa[i], gb);
+    }
+  };
+
+#pragma unroll 1
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    int k = 0;
+    while (s_meta->coff[k + 1] <= c) ++k;                      // block-uniform: <= K steps
+    const int p_lo = s_meta->poff[k] + (c - s_meta->coff[k]) * CH;
+    const int np = min(CH, s_meta->poff[k + 1] - p_lo);        // >= 1 by construction of coff
+    __syncthreads();                                           // the previous chunk's lists and panels are done with
+    for (int e = tid; e < np; e += WGM_THREADS) {
+      s_pi[e] = pair_in[p_lo + e];
+      s_pj[e] = pair_out[p_lo + e];
+    }
+#pragma unroll
+    for (int i = 0; i < T::MW; ++i)
+#pragma unroll
+      for (int j = 0; j < T::NW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    esum = 254;
+    __syncthreads();
+    const int npan = (np + WGP_PANEL - 1) / WGP_PANEL;
+    f32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];
+    gather(0, np, ra0, rb0);
+    gather(1, np, ra1, rb1);
+    // panel p in one register set, panel p + 1 in flight in the other; a set is free again once its panel is staged
+#pragma unroll 1
+    for (int p = 0; p < npan; p += 2) {
+      panel(p, np, ra0, rb0);
+      gather(p + 2, np, ra0, rb0);
+      multiply();
+      if (p + 1 >= npan) break;
+      panel(p + 1, np, ra1, rb1);
+      gather(p + 3, np, ra1, rb1);
+      multiply();
+    }
+    float* dst = slabs + (long long)c * (CIN * COUT);          // this chunk's partial dW[k], (Cin, Cout) row-major
+    const int eo = esum == 254 ? 0 : -esum;
+#pragma unroll
+    for (int i = 0; i < T::MW; ++i)
+#pragma unroll
+      for (int j = 0; j < T::NW; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          dst[((mi0 + 4 * i) * 16 + 4 * kq + e) * COUT + (ni0 + j) * 16 + n] = ldexpf(acc[i][j][e], eo);
+  }
+}
+
+// where the f16 x 2 form of the weight gradient is the faster one (measured per shape, profiles/r05_summary.md)
+static int env_wgrad_f16() {
+  const char* e = getenv("GLX_SCONV_WGRAD_F16");      // 0 never, 1 where it pays (default), 2 wherever the kernel exists
+  return e ? atoi(e) : 1;
+}
+static int g_wgrad_f16 = env_wgrad_f16();
+// measured against the fp32 form: (128, 128) 301 / 407 us, (64, 128) 92 / 127, (64, 64) 150 / 167 at Waymo size; at KITTI size
+// (64, 128) 15.6 / 26, (64, 64) 31.5 / 33.2, (128, 64) 72 / 70, (32, 64) 17.8 / 17, (32, 32) 33.7 / 24: the narrow layers are bound
+// by their row gathers either way and only pay for the conversions
+static bool sc_wgrad_f16_pays(int Cin, int Cout) {
+  return g_wgrad_f16 >= 2 || (g_wgrad_f16 == 1 && Cin >= 64 && Cout >= 64 && !(Cin >= 128 && Cout < 128));
+}
+
 // dW[k][e] = sum of the slabs of offset k's chunks, in chunk order (an offset without pairs has no chunk: zero).
 __global__ void k_wgrad_pairs_reduce(const float* __restrict__ slabs, const PairMeta* __restrict__ meta, int nel,
                                      float* __restrict__ dW) {
@@ -2747,6 +3001,11 @@ extern "C" int glx_sconv_wgrad_pairs(const float* in, const float* grad_out, con
   return glx_sconv_wgrad_pairs_ex(in, grad_out, lists, N_out, K, Cin, Cout, dW, nullptr, workspace, workspace_bytes, stream);
 }
 
+extern "C" int glx_sconv_wgrad_arith(int Cin, int Cout) {      // 1: glx_sconv_wgrad_pairs runs its f16 x 2 form for these channels
+  if (!g_sconv_f16 || Cin % 32 || Cout % 32 || !mfma_supported(Cin, Cout, 1)) return 0;
+  return sc_wgrad_f16_pays(Cin, Cout) ? 1 : 0;
+}
+
 extern "C" int glx_sconv_wgrad_pairs_ex(const float* in, const float* grad_out, const void* lists, int N_out, int K,
                                         int Cin, int Cout, float* dW, const glx_epilogue* pre, void* workspace,
                                         size_t workspace_bytes, void* stream) {
@@ -2768,6 +3027,21 @@ extern "C" int glx_sconv_wgrad_pairs_ex(const float* in, const float* grad_out, 
   if (cap / WGP_MINCH + K < grid) grid = cap / WGP_MINCH + K;
   int rc = sc_dispatch(Cin, Cout, [&](auto ci, auto co) {
     constexpr int CI = decltype(ci)::value, CO = decltype(co)::value;
+    if constexpr (WgradPairsF16Cfg<CI, CO>::ON) {
+      if (g_sconv_f16 && sc_wgrad_f16_pays(CI, CO)) {    // the block kernels' arithmetic switch covers their weight gradient
+        using F = WgradPairsF16Cfg<CI, CO>;
+        auto kern = k_wgrad_pairs_f16<CI, CO>;
+        static bool attr_set16 = false;
+        if (!attr_set16) {
+          GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F::lds_bytes));
+          attr_set16 = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WGM_THREADS), F::lds_bytes, st, in, grad_out,
+                           (const PairMeta*)base, (const int*)(base + oi), (const int*)(base + oo), K, (float*)workspace,
+                           pre ? pre->scale : (const float*)nullptr, pre ? pre->shift : (const float*)nullptr);
+        return GLX_OK;
+      }
+    }
     using T = WgradPairsCfg<CI, CO>;
     auto kern = k_wgrad_pairs<CI, CO>;
     static bool attr_set = false;

@@ -296,6 +296,11 @@ int glx_pair_lists_build(const int32_t* nbr, int N_out, int K, const int32_t* n_
 size_t glx_sconv_wgrad_pairs_workspace_bytes(int N_out, int K, int Cin, int Cout);
 int glx_sconv_wgrad_pairs(const float* in, const float* grad_out, const void* lists, int N_out, int K,
                           int Cin, int Cout, float* dW, void* workspace, size_t workspace_bytes, void* stream);
+/* The arithmetic glx_sconv_wgrad_pairs[_ex] uses for these channels: 1 = the f16 x 2 form (glx_sconv_set_arith's arithmetic with
+ * the pairs as contraction index: a 32-pair panel scaled by the block's two maxima, running exponent over a chunk; taken where it
+ * measured faster -- Cin >= 64 and Cout >= 64 except 128 -> 64; env GLX_SCONV_WGRAD_F16=0 never, 2 wherever Cin, Cout are
+ * multiples of 32), 0 = fp32 MFMAs. */
+int glx_sconv_wgrad_arith(int Cin, int Cout);
 /* The same for input rows that are transformed on load (`pre` as glx_sconv_opts.prologue; NULL = glx_sconv_wgrad_pairs). */
 int glx_sconv_wgrad_pairs_ex(const float* in, const float* grad_out, const void* lists, int N_out, int K, int Cin, int Cout,
                              float* dW, const glx_epilogue* pre, void* workspace, size_t workspace_bytes, void* stream);

@@ -530,6 +530,43 @@ def test_weight_gradient_in_two_halves_and_with_the_input_transform(dev, cin, co
     assert torch.equal(run(x, pre, halves=True), want)
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 128), (128, 128)])
+def test_weight_gradient_from_scaled_f16_pieces_matches_fp64(dev, cin, cout, sconv_arith):
+    """glx_sconv_wgrad_pairs runs its f16 x 2 form for these channels (glx_sconv_wgrad_arith; a 32-pair panel is one k-step, scaled
+    by the block's two maxima, running exponent over a chunk): against dW[k] = sum_j x[nbr[j, k]]^T g[j] in fp64, with rows of both
+    operands that differ by up to 2^16, rows of zeros and a chunk whose first panels are tiny -- the error, quoted on
+    sum |x|^T |g|, stays below 2^-18 and within 4 x the fp32 form's + 2^-22 (glx_sconv_set_arith(0) selects that form)."""
+    from glenet_amd import _lib
+    assert _lib.query("glx_sconv_wgrad_arith", cin, cout) == 1 and _lib.query("glx_sconv_wgrad_arith", 32, 32) == 0
+    rng = np.random.default_rng(cin + cout)
+    n_out, K = 6000, 27
+    n_in = n_out + 11
+    nbr_np = np.where(rng.random((n_out, K)) < 0.25, rng.integers(0, n_in, (n_out, K)), -1).astype(np.int32)
+    x = rng.normal(size=(n_in, cin)).astype(np.float32) * np.exp2(rng.integers(-8, 9, size=(n_in, 1))).astype(np.float32)
+    g = rng.normal(size=(n_out, cout)).astype(np.float32) * np.exp2(rng.integers(-8, 9, size=(n_out, 1))).astype(np.float32)
+    x[::7] = 0
+    g[:200] *= np.float32(2.0 ** -30)                     # the first panels of every offset's first chunk: far below the rest
+    xt, gt, nbr = (torch.from_numpy(a).to(dev) for a in (x, g, nbr_np))
+    want = torch.zeros(K, cin, cout, dtype=torch.float64, device=dev)
+    mag = torch.zeros_like(want)
+    for k in range(K):
+        rows = torch.nonzero(nbr[:, k] >= 0)[:, 0]
+        xi, gi = xt[nbr[rows, k].long()].double(), gt[rows].double()
+        want[k] = xi.t() @ gi
+        mag[k] = xi.abs().t() @ gi.abs()
+    pl = _pair_lists_of(nbr, n_out, K, None, dev)[0]
+    wsb = _lib.query("glx_sconv_wgrad_pairs_workspace_bytes", n_out, K, cin, cout)
+    err = {}
+    for arith in (0, 1):
+        sconv_arith(arith)
+        assert _lib.query("glx_sconv_wgrad_arith", cin, cout) == arith
+        dw = torch.full((K, cin, cout), float("nan"), device=dev)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _lib.call("glx_sconv_wgrad_pairs", xt, gt, pl, n_out, K, cin, cout, dw, ws, _lib.size_arg(wsb))
+        err[arith] = float(((dw.double() - want).abs() / mag).max())
+    assert err[1] <= 2.0 ** -18 and err[1] <= 4 * err[0] + 2.0 ** -22, err
+
+
 def test_slab_sums_of_several_layers_in_one_launch(dev):
     """glx_sconv_wgrad_pairs_reduce_multi: the chunk products of layers of different shapes (dW = NULL calls, each into a buffer
     of its own), summed by ONE launch -- the bits of the per-layer calls; a job with too small a workspace is refused loudly."""
