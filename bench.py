@@ -1121,8 +1121,13 @@ def main():
                                           "tests/test_oracle_cpu.py::test_split_bf16_pieces_carry_an_fp32_product); the sparse "
                                           "convolutions with Cin in {32, 64, 128} -> Cout in {64, 128} the same way (sconv_arithmetic=%s: "
                                           "the packed filter scaled by one power of two, every gathered row by its own; "
-                                          "GLX_SCONV_ARITH=fp32 restores exact fp32 MFMA products; tests/test_sparse_gpu.py), all other "
-                                          "sparse layers and the sparse weight gradient in fp32 MFMAs"
+                                          "GLX_SCONV_ARITH=fp32 restores exact fp32 MFMA products; tests/test_sparse_gpu.py), the sparse "
+                                          "weight gradient of the layers with Cin >= 64 and Cout >= 64 except 128 -> 64 the same "
+                                          "way per 32-pair panel (glx_sconv_wgrad_arith per shape; GLX_SCONV_WGRAD_F16=0 restores "
+                                          "fp32 MFMAs), all other sparse layers and weight gradients in exact fp32 MFMAs.  The "
+                                          "default is therefore NOT component-wise fp32: products carry >= 20.4 bits relative to "
+                                          "the row / chunk maximum (norm-wise at or below the fp32 kernels' error against fp64); the "
+                                          "strict_arithmetic object of this line times the same step with exact fp32 products"
                                           % (_conv_arith(), _sconv_arith()),
                                sconv_arithmetic=_sconv_arith(),
                                host_enqueue_ms_per_step=round(t_host * 1e3, 4) if t_host is not None else None,

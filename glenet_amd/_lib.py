@@ -145,7 +145,26 @@ def is_lent(param, g):
     """True when `g` (what grad_buffer returned) is the optimizer's own view of `param`'s gradient: autograd then keeps the tensor
     as it is and reads nothing, so a kernel may fill it later in the step (deferred weight-gradient sums)."""
     view = getattr(param, "_glx_grad_view", None) if param is not None else None
-    return view is not None and g.data_ptr() == view.data_ptr() and param.grad is None
+    if view is None or g.data_ptr() != view.data_ptr() or param.grad is not None:
+        return False
+    # AccumulateGrad steals the tensor untouched only in the plain case: no double backward (create_graph reads the gradient),
+    # no tensor / post-accumulate hooks on the leaf (a DDP reducer is one) -- otherwise the gradient is complete when its call
+    # returns (ADVICE r5)
+    if torch.is_grad_enabled() or getattr(param, "_backward_hooks", None) or getattr(param, "_post_accumulate_grad_hooks", None):
+        return False
+    return True
+
+
+def settle_lent_grad(param, view):
+    """After a deferred weight-gradient sum has filled `view` (the optimizer's lent view of `param`'s gradient): `param.grad`
+    must BE that memory.  If autograd cloned the gradient at accumulate time (it then holds what the view held before the sum),
+    the finished sum is copied over the clone; a gradient that is missing altogether is an error."""
+    view = getattr(param, "_glx_grad_view", view)      # the parameter's own shape / strides (a kernel's view may be reshaped)
+    g = param.grad
+    if g is None:
+        raise GlxError("deferred weight-gradient sum: the parameter has no .grad after the backward pass")
+    if g.data_ptr() != view.data_ptr() or g.stride() != view.stride():
+        g.copy_(view)
 
 
 def size_arg(n):
@@ -332,6 +351,9 @@ MAX_RETIRED_GRAPHS = int(os.environ.get("GLX_MAX_RETIRED_GRAPHS", "256"))
 _retired_warned = [False]
 
 
+ALLOW_UNFIXED_MEMSETS = os.environ.get("GLX_ALLOW_UNFIXED_MEMSETS", "0") == "1"
+
+
 def new_graph():
     """torch.cuda.CUDAGraph() whose exec outlives its owner (see above).  The hipGraph_t is ALWAYS kept (keep_graph=True):
     finish_graph() needs it for the memset surgery, which is a correctness fix and not a diagnostic -- it does not hang on
@@ -339,10 +361,15 @@ def new_graph():
     try:
         g = torch.cuda.CUDAGraph(keep_graph=True)
     except TypeError as e:                              # a torch without keep_graph
-        raise GlxError("torch.cuda.CUDAGraph(keep_graph=True) is not available in this torch: recorded pipelines need the "
+        if not ALLOW_UNFIXED_MEMSETS:
+            raise GlxError("torch.cuda.CUDAGraph(keep_graph=True) is not available in this torch: recorded pipelines need the "
                        "raw hipGraph_t to replace memset nodes (ROCm 7.2 replays them with a stale pattern -> NaN "
                        "gradients from the second replay on).  Run the pipelines eagerly (enqueue()/step() without "
                        "capture()) or set GLX_ALLOW_UNFIXED_MEMSETS=1 to record anyway.") from e
+        import warnings
+        warnings.warn("GLX_ALLOW_UNFIXED_MEMSETS=1: recording without the raw hipGraph_t -- memset nodes stay as they are "
+                      "(ROCm 7.2 replays them with a stale pattern)", RuntimeWarning, stacklevel=2)
+        g = torch.cuda.CUDAGraph()
     if KEEP_GRAPH_EXECS:
         _graph_execs.append(g)
         if len(_graph_execs) > MAX_RETIRED_GRAPHS and not _retired_warned[0]:
@@ -362,7 +389,6 @@ def retired_graph_count():
     return len(_graph_execs)
 
 
-ALLOW_UNFIXED_MEMSETS = os.environ.get("GLX_ALLOW_UNFIXED_MEMSETS", "0") == "1"
 
 
 def finish_graph(graph):

@@ -191,7 +191,7 @@ def wgrad(x, gy, weight, pre=None):
         call("glx_conv3x3_wgrad_ex", x, gy, b, h, w, cin, cout, None, ll(s[0]), ll(s[1]), ll(s[2]), ll(s[3]), prologue, ws,
              _lib.size_arg(n))
         # an ALIAS of gw in the job: AccumulateGrad keeps a gradient as it is only while nobody else holds the tensor object
-        DEFERRED_WGRAD_REDUCES.append((cin, cout, gw.detach(), tuple(s), ws, torch.cuda.current_stream(x.device)))
+        DEFERRED_WGRAD_REDUCES.append((cin, cout, gw.detach(), tuple(s), ws, torch.cuda.current_stream(x.device), weight))
         return gw
     ws = _lib.workspace.get(n, x.device)
     call("glx_conv3x3_wgrad_ex", x, gy, b, h, w, cin, cout, gw, ll(s[0]), ll(s[1]), ll(s[2]), ll(s[3]), prologue, ws,
@@ -222,6 +222,7 @@ def run_deferred_wgrad_reduces(jobs):
          strides, ptrs([j[4] for j in jobs]), (ctypes.c_size_t * n)(*[j[4].numel() for j in jobs]))
     for j in jobs:
         j[4].record_stream(cur)
+        _lib.settle_lent_grad(j[6], j[2])      # param.grad IS the filled view, or gets its contents
 
 
 OWN_WGRAD = True

@@ -18,10 +18,15 @@ def configure_graph_executor(queues=2):
     does, and echoes the value in its `config`), not something `import glenet_amd` does.  Call it before anything
     touches the GPU.  Returns the value in effect (a string) or None when the runtime's default holds.
 
+    It must be the FIRST GPU-related call of the process: `torch.cuda.is_available()` already initialises HIP on ROCm while
+    `torch.cuda.is_initialized()` stays False, so a call after it cannot be detected here -- `requested()` says what this
+    module asked for, which equals what is in effect only under that condition.
+
     queues=None leaves the environment alone and only reports."""
     cur = os.environ.get(GRAPH_QUEUES_ENV)
     if queues is None or cur is not None:
         return cur                      # the caller's environment wins
+    _requested[0] = str(int(queues))
     try:
         import torch
         started = torch.cuda.is_initialized()
@@ -35,6 +40,15 @@ def configure_graph_executor(queues=2):
         return None
     os.environ[GRAPH_QUEUES_ENV] = str(int(queues))
     return os.environ[GRAPH_QUEUES_ENV]
+
+
+_requested = [None]
+
+
+def requested():
+    """The value configure_graph_executor() asked for in this process (None: it never set anything).  It is what the runtime
+    uses only if the call came before the first HIP call (see configure_graph_executor)."""
+    return _requested[0]
 
 
 def graph_executor_queues():

@@ -580,7 +580,7 @@ class SparseConvFunction(Function):
                          _pre_arg(pre, cin), ws, size_arg(ws.numel()))
                     if defer:
                         # an ALIAS of g_w: AccumulateGrad keeps a gradient as it is only while nobody else holds the tensor object
-                        DEFERRED_WGRAD_REDUCES.append((pl, n_fwd_out, K, cin, cout, g_w.detach(), ws, torch.cuda.current_stream(w.device)))
+                        DEFERRED_WGRAD_REDUCES.append((pl, n_fwd_out, K, cin, cout, g_w.detach(), ws, torch.cuda.current_stream(w.device), ctx.leaf))
                     if wev is not None:
                         wev[1].record()
                 else:
@@ -1245,6 +1245,9 @@ def run_deferred_wgrad_reduces(jobs):
          (ctypes.c_size_t * n)(*[j[6].numel() for j in jobs]))
     for j in jobs:
         j[6].record_stream(cur)
+        _lib.settle_lent_grad(j[8], j[5])      # param.grad IS the filled view, or gets its contents
+
+
 # list collecting the num_batches_tracked buffers of the fused BatchNorms of a step, so that the
 # caller bumps them with ONE multi-tensor add instead of a tiny kernel per layer (None = bump at once)
 DEFERRED_COUNTERS = None
