@@ -793,6 +793,7 @@ def main():
                          "glx_mask_shuffle) in front of the voxelizer INSIDE the recorded step; it shows up as its own "
                          "stages_ms entry.  Off by default: the reference does this work in DataLoader workers, outside "
                          "the step the metric times")
+    ap.add_argument("--no-strict", action="store_true", help="skip the strict-arithmetic re-recording of the headline step")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the configs[3] (CVAE), configs[4] (Waymo shard) and BEV-head sub-measurements")
     ap.add_argument("--roofline-only", action="store_true",
@@ -1028,6 +1029,48 @@ def main():
         torch.cuda.synchronize(dev)
 
     progress("stages done")
+    # ---- strict arithmetic: the SAME recorded step with exact fp32 products in the sparse block kernel and
+    # its weight gradient (fp32 MFMAs) and the bf16 x 3 forms of the BEV 3x3 kernels (six MFMAs, products exact to 2^-22, no
+    # scaling): component-wise fp32-class arithmetic, timed by the same fences, so the exact-product number is in the driver's line
+    strict = None
+    if not args.no_strict and args.mode == "graph" and pipe.graph is not None and not dp and args.steps > 0:
+        from glenet_amd import conv2d as c2
+        from glenet_amd import _lib as glib
+        torch.cuda.synchronize(dev)
+        old_s = glib.query("glx_sconv_get_arith")
+        old_f = glib.load().glx_conv3x3_set_wgrad_form(1)
+        old_c = c2.set_arithmetic("bf16x3")
+        glib.call_nostream("glx_sconv_set_arith", 0)
+        glib.bump_weights_epoch()
+        try:
+            pipe.capture(split=dp)
+            for _ in range(5):
+                train_step()
+            gdist.fence(dev)
+            ts = time.perf_counter()
+            for _ in range(args.steps):
+                train_step()
+            gdist.fence(dev)
+            dts = time.perf_counter() - ts
+            pipe.check()
+            strict = dict(ms_per_step=round(dts / args.steps * 1e3, 4), frames_per_s=round(FRAMES_PER_GPU * args.steps / dts, 2),
+                          steps=args.steps, loss=round(float(pipe.loss.detach()), 5),
+                          arithmetic="GLX_SCONV_ARITH=fp32 (v_mfma_f32_16x16x4_f32 in every sparse kernel, weight gradients "
+                                     "included) + GLX_CONV3X3_ARITH=bf16x3 + GLX_WGRAD_FORM=1 (three bf16 pieces per operand, "
+                                     "six MFMAs, products exact to 2^-22 component-wise)",
+                          note="the headline step re-recorded under the exact-product arithmetic, same batches, same fences; "
+                               "the headline itself runs the default (f16x2) arithmetic")
+        finally:
+            torch.cuda.synchronize(dev)
+            glib.call_nostream("glx_sconv_set_arith", old_s)
+            c2.set_arithmetic(old_c)
+            glib.load().glx_conv3x3_set_wgrad_form(old_f)
+            glib.bump_weights_epoch()
+        pipe.capture(split=dp)                 # the default arithmetic's recording again (config block + later legs read it)
+        pipe.load(*pool[0][:4])
+        pipe.step()
+        torch.cuda.synchronize(dev)
+        progress("strict arithmetic done: %.2f ms/step" % strict["ms_per_step"])
     # ---- configs[1]: sparse backbone forward only (eval mode, BN folded), two frame pipelines in flight
     config1 = roof = None
     if not args.no_config1:
@@ -1136,7 +1179,7 @@ def main():
                                          "steps from an idle queue; host_loop = the timed loop's host time per step, which "
                                          "includes waiting for step i-4 (at most 4 steps are kept in flight)"),
                    loss=dict(last=round(loss_end, 5), parts=parts_end),
-                   stages_ms=stages, config1=config1, roofline=roof)
+                   stages_ms=stages, strict_arithmetic=strict, config1=config1, roofline=roof)
         if per_rank is not None:
             out["per_rank"] = dict(ms_per_step=[round(r[0], 4) for r in per_rank],
                                    host_enqueue_ms_per_step=[round(r[1], 4) for r in per_rank],
