@@ -508,10 +508,60 @@ def bench_dropin(state, K, pool, dev, steps=12):
             finally:
                 if gemm:
                     dropin.pointwise_as_gemm(False)
+    def recorded():
+        """the reference's loop (model(batch) -> loss.backward() -> clip_grad_norm_ -> optimizer.step(),
+        tools/train_utils/train_utils.py:45-76) around dropin.record(): forward + backward of the network's own parameters as
+        ONE replayed graph, torch.optim.AdamW and the clip outside, a different batch (new voxel count) every step."""
+        import types
+        import numpy as np
+        torch.manual_seed(0)
+        m = gvr.GLENetVR(K).to(dev).train()
+        m.load_state_dict(state)
+        m.model_cfg = GLENET_VR_MODEL_CFG
+        m.dataset = types.SimpleNamespace(point_cloud_range=np.array(K["point_cloud_range"], np.float32), voxel_size=K["voxel_size"],
+                                          point_feature_encoder=types.SimpleNamespace(num_point_features=K["num_features"]))
+        batches = [dict(points=torch.cat([b[1].float()[:, None], b[0]], 1), gt_boxes=b[2], gt_uncertaintys=b[3]) for b in pool]
+        rec = dropin.record(m, batches, seed_rois_with_gt=ROI_SEED_OFFSET)
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-3, betas=gvr.OPTIM_CFG["BETAS"], weight_decay=gvr.OPTIM_CFG["WEIGHT_DECAY"])
+
+        def step(bd):
+            opt.zero_grad(set_to_none=True)
+            ret, _, _ = rec(bd)
+            ret["loss"].mean().backward()
+            torch.nn.utils.clip_grad_norm_(m.parameters(), gvr.OPTIM_CFG["GRAD_NORM_CLIP"])
+            opt.step()
+        for bd in batches[:3]:
+            step(bd)
+        torch.cuda.synchronize(dev)
+        n = 5 * len(batches)
+        t0 = time.perf_counter()
+        for j in range(n):
+            step(batches[j % len(batches)])
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / n * 1e3
+        rec.check()
+        # the graph alone (replay + gradient hand-over, no optimizer): what the caller's update adds
+        t0 = time.perf_counter()
+        for j in range(n):
+            ret, _, _ = rec(batches[j % len(batches)])
+            ret["loss"].backward()
+        torch.cuda.synchronize(dev)
+        ms_graph = (time.perf_counter() - t0) / n * 1e3
+        del rec, opt, m
+        torch.cuda.empty_cache()
+        return ms, ms_graph, n
     ref_ms, ref_var = run(True)
     _, ref_var_vendor = run(True, gemm=False, vary_only=3)
     acc_ms, acc_var = run(False)
-    return dict(dropin_step_ms=round(ref_ms, 3), dropin_step_frames_per_s=round(FRAMES_PER_GPU / ref_ms * 1e3, 1),
+    rec_ms, rec_graph_ms, rec_n = recorded()
+    return dict(dropin_recorded_step_ms=round(rec_ms, 3), dropin_recorded_frames_per_s=round(FRAMES_PER_GPU / rec_ms * 1e3, 1),
+                dropin_recorded_forward_backward_ms=round(rec_graph_ms, 3), dropin_recorded_steps=rec_n,
+                dropin_recorded_note="glenet_amd.dropin.record(network): the reference loop's statements (model(batch) -> "
+                                     "ret['loss'].mean().backward() -> clip_grad_norm_ -> torch.optim.AdamW.step(), "
+                                     "zero_grad(set_to_none=True)) around ONE recorded graph of forward + backward on the network's "
+                                     "own parameters; a different batch (new voxel count) every step; "
+                                     "dropin_recorded_forward_backward_ms = without the caller's clip + optimizer",
+                dropin_step_ms=round(ref_ms, 3), dropin_step_frames_per_s=round(FRAMES_PER_GPU / ref_ms * 1e3, 1),
                 dropin_accelerated_step_ms=round(acc_ms, 3),
                 dropin_accelerated_frames_per_s=round(FRAMES_PER_GPU / acc_ms * 1e3, 1), steps=steps,
                 dropin_step_ms_new_shape_every_step=round(ref_var, 3),
@@ -772,6 +822,39 @@ def bench_config4_train(dev, pts, bidx, frames, steps=60):
     pipe.out = pipe.loss = None
     return out
 
+
+# MODEL of tools/cfgs/kitti_models/GLENet_VR.yaml:32-166 as the reference's cfg_from_yaml_file leaves it (values): what a network
+# built by the reference's build_network carries in `model_cfg`, and what glenet_amd.dropin.record() reads
+GLENET_VR_MODEL_CFG = dict(
+    NAME="VoxelRCNN", VFE=dict(NAME="MeanVFE"), BACKBONE_3D=dict(NAME="VoxelBackBone8x"),
+    MAP_TO_BEV=dict(NAME="HeightCompression", NUM_BEV_FEATURES=256),
+    BACKBONE_2D=dict(NAME="BaseBEVBackbone", LAYER_NUMS=[5, 5], LAYER_STRIDES=[1, 2], NUM_FILTERS=[64, 128],
+                     UPSAMPLE_STRIDES=[1, 2], NUM_UPSAMPLE_FILTERS=[128, 128]),
+    DENSE_HEAD=dict(NAME="AnchorHeadSingle", CLASS_AGNOSTIC=False, USE_DIRECTION_CLASSIFIER=True, DIR_OFFSET=0.78539,
+                    DIR_LIMIT_OFFSET=0.0, NUM_DIR_BINS=2,
+                    ANCHOR_GENERATOR_CONFIG=[dict(class_name="Car", anchor_sizes=[[3.9, 1.6, 1.56]], anchor_rotations=[0, 1.57],
+                                                  anchor_bottom_heights=[-1.78], align_center=False, feature_map_stride=8,
+                                                  matched_threshold=0.6, unmatched_threshold=0.45)],
+                    TARGET_ASSIGNER_CONFIG=dict(NAME="AxisAlignedTargetAssigner", POS_FRACTION=-1.0, SAMPLE_SIZE=512,
+                                                NORM_BY_NUM_EXAMPLES=False, MATCH_HEIGHT=False, BOX_CODER="ResidualCoder"),
+                    LOSS_CONFIG=dict(LOSS_WEIGHTS=dict(cls_weight=1.0, loc_weight=2.0, dir_weight=0.2, code_weights=[1.0] * 7))),
+    ROI_HEAD=dict(NAME="VoxelRCNNKLLabelIoUHead", CLASS_AGNOSTIC=True, SHARED_FC=[256, 256], CLS_FC=[256, 256], REG_FC=[256, 256],
+                  DP_RATIO=0.3,
+                  NMS_CONFIG=dict(TRAIN=dict(NMS_TYPE="nms_gpu", MULTI_CLASSES_NMS=False, NMS_PRE_MAXSIZE=9000,
+                                             NMS_POST_MAXSIZE=512, NMS_THRESH=0.8),
+                                  TEST=dict(NMS_TYPE="nms_gpu", MULTI_CLASSES_NMS=False, NMS_PRE_MAXSIZE=2048,
+                                            NMS_POST_MAXSIZE=100, NMS_THRESH=0.7)),
+                  ROI_GRID_POOL=dict(FEATURES_SOURCE=["x_conv2", "x_conv3", "x_conv4"], PRE_MLP=True, GRID_SIZE=6,
+                                     POOL_LAYERS={n: dict(MLPS=[[32, 32]], QUERY_RANGES=[[4, 4, 4]], POOL_RADIUS=[r], NSAMPLE=[16],
+                                                          POOL_METHOD="max_pool")
+                                                  for n, r in (("x_conv2", 0.4), ("x_conv3", 0.8), ("x_conv4", 1.6))}),
+                  TARGET_CONFIG=dict(BOX_CODER="ResidualCoder", ROI_PER_IMAGE=128, FG_RATIO=0.5, SAMPLE_ROI_BY_EACH_CLASS=True,
+                                     CLS_SCORE_TYPE="roi_iou", CLS_FG_THRESH=0.75, CLS_BG_THRESH=0.25, CLS_BG_THRESH_LO=0.1,
+                                     HARD_BG_RATIO=0.8, REG_FG_THRESH=0.55),
+                  LOSS_CONFIG=dict(CLS_LOSS="BinaryCrossEntropy", REG_LOSS="smooth-l1", CORNER_LOSS_REGULARIZATION=True,
+                                   GRID_3D_IOU_LOSS=False,
+                                   LOSS_WEIGHTS=dict(rcnn_cls_weight=1.0, rcnn_reg_weight=1.0, rcnn_corner_weight=1.0,
+                                                     rcnn_iou3d_weight=1.0, code_weights=[1.0] * 7))))
 
 # --------------------------------------------------------------------------------- main
 MIN_TIMED_STEPS, MIN_WARMUP_STEPS = 50, 10
@@ -1200,6 +1283,7 @@ def main():
             out["dropin"] = bench_dropin(state, K, pool, dev)
             out["dropin"]["ratio_dropin_step_over_headline"] = round(out["dropin"]["dropin_step_ms"] / out["ms_per_step"], 2)
             out["dropin"]["ratio_accelerated_over_headline"] = round(out["dropin"]["dropin_accelerated_step_ms"] / out["ms_per_step"], 2)
+            out["dropin"]["ratio_recorded_over_headline"] = round(out["dropin"]["dropin_recorded_step_ms"] / out["ms_per_step"], 2)
             del state
             progress("drop-in layout steps done")
             out["inference"] = bench_inference(dev, cpu=not args.no_cpu_baseline)

@@ -287,3 +287,280 @@ class reference_layout:
         for obj, name, val in reversed(self.saved):
             setattr(obj, name, val)
         return False
+
+
+# ------------------------------------------------------------------------------------------------ the recorded training step
+def _cfg_get(c, key, default=None):
+    if c is None:
+        return default
+    if isinstance(c, dict):
+        return c.get(key, default)
+    return getattr(c, key, default)
+
+
+def _translate_cfg(model_cfg):
+    """(roi_cfg, head_cfg) for glenet_vr.GLENetVR from the MODEL block of a GLENet-VR configuration as the reference's
+    cfg_from_yaml_file leaves it (tools/cfgs/kitti_models/GLENet_VR.yaml:32-166); raises on anything the recorded step does
+    not implement (another detector / head class, several anchor classes, multi-class NMS, iou3d loss, ...)."""
+    from .glenet_vr import DENSE_HEAD_CFG, ROI_HEAD_CFG
+    g = _cfg_get
+    want = dict(NAME="VoxelRCNN")
+    names = dict(VFE="MeanVFE", BACKBONE_3D="VoxelBackBone8x", MAP_TO_BEV="HeightCompression", BACKBONE_2D="BaseBEVBackbone",
+                 DENSE_HEAD="AnchorHeadSingle", ROI_HEAD="VoxelRCNNKLLabelIoUHead")
+    if g(model_cfg, "NAME") != want["NAME"]:
+        raise NotImplementedError("dropin.record: the recorded step is GLENet-VR's (MODEL.NAME VoxelRCNN), got %r" % g(model_cfg, "NAME"))
+    for block, name in names.items():
+        if g(g(model_cfg, block), "NAME") != name:
+            raise NotImplementedError("dropin.record: MODEL.%s.NAME is %r, the recorded step implements %r"
+                                      % (block, g(g(model_cfg, block), "NAME"), name))
+    b2 = g(model_cfg, "BACKBONE_2D")
+    if (list(g(b2, "LAYER_NUMS")), list(g(b2, "LAYER_STRIDES")), list(g(b2, "NUM_FILTERS")), list(g(b2, "UPSAMPLE_STRIDES")),
+            list(g(b2, "NUM_UPSAMPLE_FILTERS"))) != ([5, 5], [1, 2], [64, 128], [1, 2], [128, 128]):
+        raise NotImplementedError("dropin.record: BACKBONE_2D layout differs from GLENet_VR.yaml:46-52")
+    dh = g(model_cfg, "DENSE_HEAD")
+    ag = list(g(dh, "ANCHOR_GENERATOR_CONFIG"))
+    if len(ag) != 1 or not g(dh, "USE_DIRECTION_CLASSIFIER") or g(dh, "NUM_DIR_BINS") != 2 \
+            or abs(float(g(dh, "DIR_OFFSET")) - 0.78539) > 1e-6 or float(g(dh, "DIR_LIMIT_OFFSET")) != 0.0:
+        raise NotImplementedError("dropin.record: one anchor class with the two-bin direction classifier (GLENet_VR.yaml:54-73)")
+    ta = g(dh, "TARGET_ASSIGNER_CONFIG")
+    if g(ta, "NAME") != "AxisAlignedTargetAssigner" or g(ta, "NORM_BY_NUM_EXAMPLES") or g(ta, "MATCH_HEIGHT") \
+            or float(g(ta, "POS_FRACTION")) >= 0:
+        raise NotImplementedError("dropin.record: AxisAlignedTargetAssigner without sampling (GLENet_VR.yaml:75-81)")
+    a = ag[0]
+    lw = g(g(dh, "LOSS_CONFIG"), "LOSS_WEIGHTS")
+    head_cfg = dict(DENSE_HEAD_CFG, anchor_sizes=[list(map(float, s)) for s in g(a, "anchor_sizes")],
+                    anchor_rotations=[float(v) for v in g(a, "anchor_rotations")],
+                    anchor_bottom_heights=[float(v) for v in g(a, "anchor_bottom_heights")],
+                    matched_threshold=float(g(a, "matched_threshold")), unmatched_threshold=float(g(a, "unmatched_threshold")),
+                    cls_weight=float(g(lw, "cls_weight")), loc_weight=float(g(lw, "loc_weight")),
+                    dir_weight=float(g(lw, "dir_weight")), code_weights=[float(v) for v in g(lw, "code_weights")])
+    if g(a, "align_center") or int(g(a, "feature_map_stride")) != 8:
+        raise NotImplementedError("dropin.record: anchors on the stride-8 map, align_center False")
+    rh = g(model_cfg, "ROI_HEAD")
+    pool = g(rh, "ROI_GRID_POOL")
+    layers = g(pool, "POOL_LAYERS")
+    POOL = {}
+    for src in g(pool, "FEATURES_SOURCE"):
+        lc = g(layers, src)
+        if g(lc, "POOL_METHOD") != "max_pool":
+            raise NotImplementedError("dropin.record: POOL_METHOD max_pool")
+        # (c_mid, c_out) per group: VoxelRCNNHead.__init__ prepends the source's channel count to these lists IN PLACE
+        # (voxelrcnn_head.py:26-28), so a configuration that has built a network carries three entries
+        POOL[src] = dict(mlps=[list(m)[-2:] for m in g(lc, "MLPS")], query_ranges=[list(q) for q in g(lc, "QUERY_RANGES")],
+                         radii=[float(v) for v in g(lc, "POOL_RADIUS")], nsamples=[int(v) for v in g(lc, "NSAMPLE")])
+
+    def nms(c):
+        if g(c, "NMS_TYPE") != "nms_gpu" or g(c, "MULTI_CLASSES_NMS"):
+            raise NotImplementedError("dropin.record: proposals by class-agnostic nms_gpu (GLENet_VR.yaml:101-115)")
+        return (int(g(c, "NMS_PRE_MAXSIZE")), int(g(c, "NMS_POST_MAXSIZE")), float(g(c, "NMS_THRESH")))
+    tc = g(rh, "TARGET_CONFIG")
+    lc = g(rh, "LOSS_CONFIG")
+    if g(lc, "CLS_LOSS") != "BinaryCrossEntropy" or g(lc, "REG_LOSS") != "smooth-l1" or not g(lc, "CORNER_LOSS_REGULARIZATION") \
+            or g(lc, "GRID_3D_IOU_LOSS") or not g(rh, "CLASS_AGNOSTIC"):
+        raise NotImplementedError("dropin.record: the KL head's loss configuration differs from GLENet_VR.yaml:155-166")
+    w = g(lc, "LOSS_WEIGHTS")
+    roi_cfg = dict(ROI_HEAD_CFG, POOL=POOL, GRID_SIZE=int(g(pool, "GRID_SIZE")), SHARED_FC=tuple(g(rh, "SHARED_FC")),
+                   CLS_FC=tuple(g(rh, "CLS_FC")), REG_FC=tuple(g(rh, "REG_FC")), DP_RATIO=float(g(rh, "DP_RATIO")),
+                   NMS_TRAIN=nms(g(g(rh, "NMS_CONFIG"), "TRAIN")), NMS_TEST=nms(g(g(rh, "NMS_CONFIG"), "TEST")),
+                   TARGET={k: g(tc, k) for k in ROI_HEAD_CFG["TARGET"]},
+                   LOSS_WEIGHTS=dict(rcnn_cls_weight=float(g(w, "rcnn_cls_weight")), rcnn_reg_weight=float(g(w, "rcnn_reg_weight")),
+                                     rcnn_corner_weight=float(g(w, "rcnn_corner_weight")),
+                                     code_weights=[float(v) for v in g(w, "code_weights")]))
+    return roi_cfg, head_cfg
+
+
+def _share_state(twin, model):
+    """Make `twin` (a glenet_vr.GLENetVR) hold the SAME Parameter / buffer objects as `model` (the reference-built network):
+    the state-dict keys are equal by construction (tests/golden/ref_state_keys.npz), so every entry is re-pointed by name.
+    Returns the number of shared tensors; raises when a key or shape does not match."""
+    import torch
+    src = dict(model.named_parameters())
+    srcb = {k: v for k, v in model.named_buffers() if k != "global_step"}      # the detector's own step counter
+    mine = dict(twin.named_parameters())                                        # (detector3d_template.py:21, model_func bumps it)
+    mineb = dict(twin.named_buffers())
+    if set(src) != set(mine) or set(srcb) != set(mineb):
+        odd = sorted((set(src) ^ set(mine)) | (set(srcb) ^ set(mineb)))
+        raise ValueError("dropin.record: the network's state differs from GLENet-VR's in %d entries, e.g. %s" % (len(odd), odd[:6]))
+    n = 0
+    for name, p in list(src.items()) + list(srcb.items()):
+        path = name.split(".")
+        mod = twin
+        for part in path[:-1]:
+            mod = getattr(mod, part)
+        table = mod._parameters if path[-1] in mod._parameters else mod._buffers
+        old = table[path[-1]]
+        if old is not None and tuple(old.shape) != tuple(p.shape):
+            raise ValueError("dropin.record: %s is %s here, %s in the network" % (name, tuple(old.shape), tuple(p.shape)))
+        table[path[-1]] = p
+        n += 1
+    assert all(a is b for a, b in zip(twin.parameters(), (dict(model.named_parameters())[k] for k, _ in twin.named_parameters())))
+    return n
+
+
+class RecordedStep:
+    """What dropin.record() returns: a callable with the contract of the reference's network in training mode
+    (pcdet/models/detectors/voxel_rcnn.py:forward: `ret_dict, tb_dict, disp_dict = model(batch_dict)`, consumed by
+    pcdet/models/__init__.py:37-52 model_func and tools/train_utils/train_utils.py:45-76), backed by ONE recorded HIP graph of
+    forward + backward on the network's OWN parameters:
+
+        step = glenet_amd.dropin.record(model, batch_size=4, max_points=..., max_gt=...)
+        for batch in loader:
+            optimizer.zero_grad()                          # either form
+            ret, tb, disp = step(batch)                    # copies the batch into the static inputs, replays the graph
+            ret["loss"].backward()                         # hands every parameter its gradient (views of one flat buffer)
+            clip_grad_norm_(model.parameters(), 10); optimizer.step()          # the caller's, untouched
+
+    The graph runs glenet_amd.glenet_vr.GLENetVR's shape-static step (capacity-padded buffers, live counts on the device, the
+    RoI branch on its own stream, weight gradients written in place) over Parameter objects SHARED with `model`; voxelization
+    happens on the device from batch["points"] (the reference's DataProcessor voxels of the same points are bit-identical,
+    tests/test_sparse_gpu.py).  Gradient accumulation over several calls is not supported (a replay overwrites the flat
+    gradient buffer): call zero_grad() between steps as tools/train.py does."""
+
+    def __init__(self, model, twin, pipe):
+        import torch
+        self.model, self.twin, self.pipe = model, twin, pipe
+        self._anchor = torch.zeros((), device=pipe.points.device, requires_grad=True)
+        self.params = pipe.flat_grads.params
+        self.views = pipe.flat_grads.grad_views
+        self.flat_grad = pipe.flat_grads.flat_grad
+
+    def tensors(self, batch_dict):
+        """(points (P, C), frame ids (P,) int32, gt_boxes (B, G, 8), gt_uncertaintys (B, G, 7) or None) on the device from a
+        collated batch (pcdet/datasets/dataset.py:170-250: `points` (P, 1 + C) with the frame id in column 0)."""
+        import torch
+        dev = self.pipe.points.device
+        pts = torch.as_tensor(batch_dict["points"]).to(dev, non_blocking=True)
+        gt = torch.as_tensor(batch_dict["gt_boxes"]).to(dev, torch.float32, non_blocking=True).contiguous()
+        unc = batch_dict.get("gt_uncertaintys")
+        if unc is not None:
+            unc = torch.as_tensor(unc).to(dev, torch.float32, non_blocking=True)[:, :, :7]
+            unc = torch.where(gt[:, :, 7:8] > 0, unc, torch.zeros_like(unc)).contiguous()      # dataset.py:188 pads with -1
+        return pts[:, 1:].float().contiguous(), pts[:, 0].to(torch.int32).contiguous(), gt, unc
+
+    def load(self, batch_dict):
+        self.pipe.load(*self.tensors(batch_dict))
+
+    def __call__(self, batch_dict):
+        import torch
+        if not (self.model.training and torch.is_grad_enabled()):
+            raise RuntimeError("dropin.record: the recorded step is the TRAINING step; run evaluation through the network itself")
+        self.load(batch_dict)
+        self.pipe.step()
+        loss = _recorded_loss().apply(self._anchor, self.pipe.loss, self)
+        tb = {k: v for k, v in self.pipe.parts.items()}
+        tb["rpn_loss"] = tb.get("loss_rpn")
+        return {"loss": loss}, tb, {}
+
+    def check(self):
+        """One read-back: did the last batch fit the recorded capacities?  Raises (spconv.core.check_static) when a strided
+        output set or the voxel cap overflowed -- that step's gradients are then not the batch's; returns True otherwise."""
+        self.pipe.check()
+        return True
+
+
+def _recorded_loss_class():
+    import torch
+
+    class _RecordedLoss(torch.autograd.Function):
+        """The scalar of a replayed step: backward() hands every parameter its gradient -- the views of the flat buffer the
+        replay has filled -- scaled by the incoming gradient (1 for `loss.backward()`; `loss.mean()` of a scalar is 1 as well)."""
+
+        @staticmethod
+        def forward(ctx, anchor, value, rec):
+            ctx.rec = rec
+            return value.detach().clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            rec = ctx.rec
+            rec.flat_grad.mul_(g)                                   # one launch on the flat buffer (g is a device scalar)
+            for p, v in zip(rec.params, rec.views):
+                if p.grad is None:
+                    p.grad = v
+                elif p.grad.data_ptr() != v.data_ptr():
+                    p.grad.add_(v)
+            return None, None, None
+    return _RecordedLoss
+
+
+_RL = None
+
+
+def _recorded_loss():
+    global _RL
+    if _RL is None:
+        _RL = _recorded_loss_class()
+    return _RL
+
+
+def record(model, batches=None, batch_size=None, max_points=None, max_gt=32, data_cfg=None, capacities=None, warmup=2,
+           seed_rois_with_gt=None, dry_run=False):
+    """Record the training step of a GLENet-VR network built by the REFERENCE'S OWN `build_network` (over install()) as one HIP
+    graph of forward + backward on the network's own parameters, optimizer left to the caller: returns a RecordedStep.
+
+    model        the network (pcdet.models.detectors.VoxelRCNN with the GLENet_VR.yaml module layout); its `model_cfg` and
+                 `dataset` (point_cloud_range, voxel_size) are read, anything the recorded step does not implement raises
+    batches      one collated batch_dict or several (`points` (P, 1 + C), `gt_boxes` (B, G, 8)[, `gt_uncertaintys` (B, G, 7)]):
+                 representative inputs -- the warm-up passes run on the first, the strided output sets' capacities are sized
+                 1.3 x the largest seen (backbone.StaticFramePipeline.calibrate; RecordedStep.check() tells whether a later
+                 batch fitted), batch_size / max_points default to what they show (points + 10 %)
+    max_gt       capacity of the ground-truth rows per frame
+    data_cfg     optional dict(max_points=5, max_voxels_train=16000, num_features=4): DATA_PROCESSOR's voxel settings
+                 (kitti_dataset.yaml:65-72); default: the dataset's own config when the network carries it, else those values
+    dry_run      build the parameter-sharing twin and translate the configuration only (no device, no graph): what
+                 tools/ref_dropin_check.py runs on CPU against the reference's own network
+    What is changed on `model`: the 4-D filters of its BEV backbone and dense head move to channels-last memory (values and
+    keys unchanged, as accelerate() does); nothing else."""
+    import torch
+    from . import glenet_vr as gvr
+    roi_cfg, head_cfg = _translate_cfg(model.model_cfg)
+    ds = getattr(model, "dataset", None)
+    cfg = dict(point_cloud_range=[round(float(v), 5) for v in ds.point_cloud_range],      # the dataset keeps a float32 array
+               voxel_size=[round(float(v), 6) for v in ds.voxel_size],
+               max_points=5, max_voxels_train=16000, max_voxels_test=40000,
+               num_features=int(getattr(getattr(ds, "point_feature_encoder", None), "num_point_features", 4)))
+    dc = getattr(ds, "dataset_cfg", None)
+    for p in (_cfg_get(dc, "DATA_PROCESSOR", None) or []):
+        if _cfg_get(p, "NAME") == "transform_points_to_voxels":
+            cfg["max_points"] = int(_cfg_get(p, "MAX_POINTS_PER_VOXEL"))
+            mv = _cfg_get(p, "MAX_NUMBER_OF_VOXELS")
+            cfg["max_voxels_train"], cfg["max_voxels_test"] = int(_cfg_get(mv, "train")), int(_cfg_get(mv, "test"))
+    cfg.update(data_cfg or {})
+    dev = next(model.parameters()).device
+    with torch.device(dev):
+        twin = gvr.GLENetVR(cfg, cfg["num_features"], roi_cfg=roi_cfg, head_cfg=head_cfg, bev_channels_last=True)
+    if not dry_run:
+        with torch.no_grad():
+            for name in ("backbone_2d", "dense_head"):
+                for p in getattr(model, name).parameters():
+                    if p.dim() == 4:
+                        p.data = p.data.contiguous(memory_format=torch.channels_last)
+    shared = _share_state(twin, model)
+    twin.train(model.training)
+    if dry_run:
+        return dict(shared=shared, roi_cfg=roi_cfg, head_cfg=head_cfg, cfg=cfg, twin=twin)
+    if dev.type != "cuda":
+        raise RuntimeError("dropin.record: the network must live on the GPU (no CPU path)")
+    if isinstance(batches, dict):
+        batches = [batches]
+    batches = list(batches or [])
+    if not batches:
+        raise ValueError("dropin.record: at least one representative batch_dict (the warm-up passes of the recording run on it)")
+    if batch_size is None:
+        batch_size = int(batches[0]["gt_boxes"].shape[0])
+    if max_points is None:
+        max_points = (int(max(len(b["points"]) for b in batches) * 1.1) + 1023) // 1024 * 1024
+    max_gt = max(int(max_gt), max(int(b["gt_boxes"].shape[1]) for b in batches))
+    pipe = gvr.StaticTrainStep(twin, batch_size, max_points, cfg["num_features"], max_gt=max_gt, optimizer="external",
+                               seed_rois_with_gt=seed_rois_with_gt, capacities=capacities, device=dev)
+    rec = RecordedStep(model, twin, pipe)
+    if capacities is None:
+        caps = {}
+        for bd in batches:
+            pts, bidx, _, _ = rec.tensors(bd)
+            for k, v in pipe.calibrate(pts, bidx).items():
+                caps[k] = max(caps.get(k, 0), v)
+        pipe.capacities = caps
+    rec.load(batches[0])
+    pipe.capture(warmup=warmup, split=True)
+    return rec

@@ -537,7 +537,7 @@ class StaticTrainStep(gb.StaticTrainPipeline):
                  seed_rois_with_gt=None, grad_clip=OPTIM_CFG["GRAD_NORM_CLIP"], capacities=None, device=None):
         """optimizer: None -> glenet_amd.optim.FlatAdamW (parameters re-pointed into one flat buffer, clip +
         update = two launches); or a torch optimizer built with capturable=True (clip_grad_norm_ + step())."""
-        from .optim import FlatAdamW
+        from .optim import FlatAdamW, FlatGrads
         dev = device if device is not None else next(model.parameters()).device
         self.net = model
         self.gt_boxes = torch.zeros((batch_size, max_gt, 8), dtype=torch.float32, device=dev)
@@ -547,11 +547,19 @@ class StaticTrainStep(gb.StaticTrainPipeline):
         self.parts = None
         self.grad_clip = grad_clip
         self.params = [p for p in model.parameters() if p.requires_grad]
-        if optimizer is None:
+        # optimizer="external": clip + update belong to the caller (dropin.record): the step ends with every gradient in ONE flat
+        # buffer (FlatGrads: the in-place weight gradients land there directly), nothing of the update is recorded
+        self.external = isinstance(optimizer, str) and optimizer == "external"
+        self.flat_grads = FlatGrads(self.params) if self.external else None
+        if self.external:
+            optimizer = None
+        elif optimizer is None:
             optimizer = FlatAdamW(self.params, lr=lr if lr is not None else OPTIM_CFG["LR"], betas=OPTIM_CFG["BETAS"],
                                   weight_decay=OPTIM_CFG["WEIGHT_DECAY"], max_norm=grad_clip)
         self.step_optimizer = optimizer
         self.flat = isinstance(optimizer, FlatAdamW)
+        if optimizer is None and not self.external:
+            raise ValueError("StaticTrainStep: no optimizer")
         self.exchange = None           # callable run between backward and the update (gradient all-reduce)
         self.update_graph = None
         self.grad_norm = None
@@ -630,6 +638,8 @@ class StaticTrainStep(gb.StaticTrainPipeline):
 
     def update(self):
         """clip_grad_norm_ (train_utils.py:38) + optimizer step; no read-back (the norm stays on the device)."""
+        if self.external:
+            return                         # the caller's clip_grad_norm_ + optimizer.step()
         if self.flat:
             self.step_optimizer.step(packed=True)
             self.grad_norm = self.step_optimizer.grad_norm
@@ -652,6 +662,8 @@ class StaticTrainStep(gb.StaticTrainPipeline):
             net.overlap_roi, net.backbone_3d.stage_cuts = was
         if self.flat:
             self.step_optimizer.pack_grads()          # part of the forward + backward graph
+        elif self.external:
+            self.flat_grads.pack_grads()
         if not self.split:
             if self.exchange is not None:
                 self.exchange()
@@ -662,7 +674,9 @@ class StaticTrainStep(gb.StaticTrainPipeline):
         """Every tensor a step mutates besides gradients: parameters, optimizer moments / step count / schedule
         scalars, BatchNorm running statistics and batch counters."""
         opt = self.step_optimizer
-        if self.flat:
+        if self.external:
+            ts = list(self.params)
+        elif self.flat:
             ts = [opt.flat_param, opt.exp_avg, opt.exp_avg_sq, opt.step_count, opt.hyper]
         else:
             ts = list(self.params) + [v for st in opt.state.values() for v in st.values() if torch.is_tensor(v)]
@@ -700,7 +714,7 @@ class StaticTrainStep(gb.StaticTrainPipeline):
         from . import runtime
         runtime.note_capture()          # one diagnostic if the executor setting of the published step time is not in effect
         super().capture(warmup)
-        if split:
+        if split and not self.external:
             dev = self.points.device
             side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -735,7 +749,7 @@ class StaticTrainStep(gb.StaticTrainPipeline):
                 self.update()
             return self.loss
         self.replay()
-        if self.split:
+        if self.split and not self.external:
             if self.exchange is not None:
                 self.exchange()
             self.update_graph.replay()

@@ -23,6 +23,43 @@ import torch
 from . import _lib
 
 
+class FlatGrads:
+    """The gradient half of FlatAdamW for a step whose optimizer belongs to the CALLER (dropin.record): one flat fp32 gradient
+    buffer, every parameter's slice of it as a view with the parameter's own strides (`grad_views`, lent to the kernels that can
+    write a gradient in place through `p._glx_grad_view`), and pack_grads() gathering whatever backward left in `.grad`.  The
+    parameters themselves are NOT touched (no flat parameter buffer): a torch optimizer steps them as it finds them."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatGrads: no trainable parameters")
+        if any(not p.is_cuda for p in self.params):
+            raise _lib.GlxError("FlatGrads: parameters must be device tensors (HIP); there is no CPU path")
+        dev = self.params[0].device
+        self.offsets, n = [], 0
+        for p in self.params:                       # 16-byte aligned slices
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        self.n = n
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._gen = [0]
+        self.grad_views = []
+        for p, o in zip(self.params, self.offsets):
+            self.grad_views.append(FlatAdamW._view(self.flat_grad, o, p))
+            p._glx_grad_view = self.grad_views[-1]
+            p._glx_grad_gen = self._gen
+
+    def pack_grads(self):
+        return FlatAdamW.pack_grads(self)
+
+    def release(self):
+        """Take the lending marks off the parameters again (the recorder is being dropped)."""
+        for p in self.params:
+            for a in ("_glx_grad_view", "_glx_grad_gen", "_glx_grad_lent"):
+                if hasattr(p, a):
+                    delattr(p, a)
+
+
 class FlatAdamW:
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_norm=None):
         self.params = [p for p in params if p.requires_grad]

@@ -38,6 +38,10 @@ def test_unmodified_reference_imports_and_builds_on_the_dropin(tmp_path):
                               "roi_head.roi_grid_pool_layers.2", "roi_head.roi_grid_pool", "roi_head.proposal_layer"]
     assert acc["class"] == "glenet_amd.dense_path.BEVBackbone"
     assert acc["max_abs_diff_cpu"] < 1e-5
+    # round 6: dropin.record()'s twin shares the reference network's own Parameter / buffer objects key for key, and the
+    # configuration the reference's loader produced translates to the constants of glenet_amd.glenet_vr
+    rec = vr["record"]
+    assert rec["shared_tensors"] == vr["state_keys"] - 1 and rec["voxel_size"] == [0.05, 0.05, 0.1]
     assert rep["networks"]["glenet_c"]["modules"][-1] == "AnchorHeadKLLabelIoU"
     assert rep["data_processor_voxels"] > 10000
     # the committed fixture is what this run produces

@@ -252,6 +252,37 @@ def check_accelerate(net):
     return {"modules": changed, "class": type(bev).__module__ + "." + type(bev).__name__, "max_abs_diff_cpu": err}
 
 
+def check_record(net, ds):
+    """glenet_amd.dropin.record(dry_run=True) on the reference's own GLENet-VR network: the configuration the reference's loader
+    left in `net.model_cfg` translates to exactly the constants of glenet_amd.glenet_vr (GLENet_VR.yaml), and the twin that
+    the recorded step runs holds the network's OWN Parameter and buffer objects under the same state-dict keys."""
+    import torch
+    from glenet_amd import dropin
+    from glenet_amd import glenet_vr as gvr
+    net.dataset = ds
+    rep = dropin.record(net, dry_run=True)
+    assert rep["roi_cfg"] == gvr.ROI_HEAD_CFG, {k: (rep["roi_cfg"][k], gvr.ROI_HEAD_CFG[k]) for k in gvr.ROI_HEAD_CFG if rep["roi_cfg"][k] != gvr.ROI_HEAD_CFG[k]}
+    assert rep["head_cfg"] == gvr.DENSE_HEAD_CFG, (rep["head_cfg"], gvr.DENSE_HEAD_CFG)
+    twin = rep["twin"]
+    mine, theirs = dict(twin.named_parameters()), dict(net.named_parameters())
+    assert list(twin.state_dict().keys()) == [k for k in net.state_dict().keys() if k != "global_step"]
+    assert all(mine[k] is theirs[k] for k in theirs) and len(mine) == len(theirs)
+    bm, bt = dict(twin.named_buffers()), {k: v for k, v in net.named_buffers() if k != "global_step"}
+    assert all(bm[k] is bt[k] for k in bt) and len(bm) == len(bt)
+    with torch.no_grad():                      # one object: a write through the network is seen by the twin
+        p = net.dense_head.conv_cls.bias
+        p.add_(1.0)
+        assert torch.equal(twin.dense_head.conv_cls.bias, p)
+        p.sub_(1.0)
+    bad = dict(net.model_cfg)
+    try:
+        dropin._translate_cfg(EasyDict(dict(net.model_cfg, NAME="PVRCNN")))
+        raise AssertionError("a foreign detector was accepted")
+    except NotImplementedError:
+        pass
+    return {"shared_tensors": rep["shared"], "point_cloud_range": rep["cfg"]["point_cloud_range"], "voxel_size": rep["cfg"]["voxel_size"]}
+
+
 def main(write=False):
     import numpy as np
     import torch  # noqa: F401
@@ -274,6 +305,7 @@ def main(write=False):
         if tag in ("glenet_vr", "waymo_centerpoint_res"):
             check_spconv_side(net, report["networks"][tag])
         if tag == "glenet_vr":
+            report["networks"][tag]["record"] = check_record(net, ds)          # before accelerate() re-classes anything
             report["networks"][tag]["accelerate"] = check_accelerate(net)
     check_data_processor(first_cfg, report)
     # the import name every reference file sees is ours
