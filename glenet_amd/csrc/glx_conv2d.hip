@@ -13,14 +13,14 @@
 // GLX_CONV3X3_ARITH=bf16x3.  By default the forward / input-gradient kernel halves the instruction count once more with
 // TWO fp16 pieces per operand and THREE products (f16 x 2, described in front of the pack kernels below).
 //
-// Implicit GEMM, output stationary: a block of 4 waves owns an 8 x 16 pixel tile x 64 output channels; wave w the tile
-// rows 2w, 2w+1 (two 16-pixel operand tiles) x four 16-channel tiles = 8 accumulators.  K runs over (32-channel chunk
-// of Cin) x (9 taps).  Per chunk the 10 x 18 halo of the tile is loaded once (fp32, coalesced 128-byte pieces), split
-// into its three bf16 planes in registers and kept in LDS (80-byte pixel rows: the 16-lane ds_read_b128 of an operand
-// covers all 64 banks); a tap is then only a shifted read of that image.  The weights are pre-split per step by
-// k_conv3x3_pack into [tap][chunk][plane][Cout][32] bf16, so that a block's 64 x 32 slice of a plane is 4 KB
-// contiguous; slices go L2 -> registers -> LDS one tap ahead (two buffers, one barrier per tap).  The input gradient
-// is the same kernel on the flipped, transposed pack (written by the same pack launch).
+// Implicit GEMM, output stationary: a block of 4 waves owns a TH x 16 pixel tile (TH = 7 or 8 rows, per launch) x 64 output
+// channels; wave w owns ONE 16-channel tile for all pixel rows (TH accumulators).  K runs over (32-channel chunk of Cin) x
+// (9 taps).  Per chunk the (TH + 2) x 18 halo of the tile is loaded once (fp32, coalesced 128-byte pieces), split into its
+// fp16 / bf16 planes in registers and kept in LDS (96-byte pixel rows: the 16-lane ds_read_b128 of an operand is
+// conflict-free); a tap is then only a shifted read of that image.  The weights are pre-split per step by k_conv3x3_pack into
+// [tap][chunk][plane][Cout][32] pieces; a wave's fragments go L2 -> registers one tap ahead (no weight image in LDS, two
+// barriers per nine taps).  The input gradient is the same kernel on the flipped, transposed pack (written by the same pack
+// launch).
 #include "glx_common.h"
 #include <stdlib.h>
 #include <string.h>
@@ -44,9 +44,6 @@
 #endif
 #define CV_APLANE (CV_HP * CV_ROW)       // 17 280
 #define CV_BN 64                         // output channels per block
-#define CV_WPLANE (CV_BN * CV_ROW)       // 6 144
-#define CV_WBUF (3 * CV_WPLANE)          // 18 432
-#define CV_LDS (3 * CV_APLANE + 2 * CV_WBUF)   // 88 704 (the first form: kept for experiments, one block per CU at this row size)
 #define CV_ALOADS ((CV_HP * 8 + 255) / 256)    // 16-byte pieces of the halo per thread (6)
 
 // Arithmetic of the forward / input-gradient kernel (k_conv3x3_v2<.., F16>), chosen per process (GLX_CONV3X3_ARITH = f16x2 |
@@ -170,7 +167,6 @@ struct ConvArgs {
   int th;                // pixel rows per tile (CV_TH; the second form picks 6, 7 or 8 per launch)
   BnState* bn_state;     // STATS: training-mode BatchNorm statistics of y taken in the epilogue
   BnFinalize bn;
-  long long* stamps;     // diagnostics (glx_conv3x3_set_stamps): per block, shader-clock and 100 MHz-clock ticks of its lifetime
   const float* epi_scale;   // inference epilogue (glx_conv_opts.epilogue): y = relu?(conv * scale[c] + shift[c]), second form
   const float* epi_shift;
   int epi_relu;
@@ -201,241 +197,12 @@ __device__ __forceinline__ ConvTile cv_tile(const ConvArgs& a, int t) {
   return c;
 }
 
-// Persistent blocks (two per CU): block i takes the tiles i, i + grid, ...; the first halo chunk and weight slice of
-// the NEXT tile are requested during the last taps of the current one, so a tile's only exposed latency is LDS.
-// STATS: per-channel sum and sum of squares of the block's outputs ride along (per lane in fp32 over its <= 6 pixels,
-// in fp64 from there: 16 lanes by shuffles, 4 waves in LDS, one set of accumulator atomics per block, last block
-// finalizes as k_bn_stats does); the launch has a multiple of nblk blocks, so a block keeps its channel block.
-template <int ABL, bool STATS>
-__global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sA = smem;
-  char* sW = smem + 3 * CV_APLANE;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, kq = lane >> 4;
-  const int nch = a.Cin >> 5;
-  int tile = blockIdx.x;
-  if (tile >= a.ntiles) return;
-  ConvTile ct = cv_tile(a, tile);
-  long long stamp_c = 0, stamp_r = 0;
-  if (a.stamps) {
-    stamp_c = __builtin_amdgcn_s_memtime();
-    stamp_r = __builtin_amdgcn_s_memrealtime();
-  }
-
-  // the thread's pieces of the halo: element offsets into x (without the chunk), -1 outside the map
-  int aoff[CV_ALOADS];                 // (the entry point checks that the map has fewer than 2^31 elements)
-  const int adst0 = (tid >> 3) * CV_ROW + (tid & 7) * 8;      // piece i of the thread: halo pixel (tid >> 3) + 32 i
-#define CV_HALO(T)                                                                                      \
-  _Pragma("unroll") for (int i_ = 0; i_ < CV_ALOADS; ++i_) {                                            \
-    const int e_ = tid + i_ * 256;                                                                      \
-    const int hp_ = e_ >> 3, seg_ = e_ & 7;                                                             \
-    const int gy_ = (T).y0 - 1 + hp_ / CV_HW, gx_ = (T).x0 - 1 + hp_ % CV_HW;                           \
-    const bool ok_ = e_ < CV_HP * 8 && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W;                  \
-    aoff[i_] = ok_ ? (((T).b * a.H + gy_) * a.W + gx_) * a.Cin + seg_ * 4 : -1;                         \
-  }
-  // the thread's 16-byte piece of each plane of a weight slice
-  const size_t wslice = (size_t)a.Cout * 32;                       // bf16 elements per plane of a (tap, chunk)
-  const uint16_t* wsrc = a.wp + (size_t)ct.n0 * 32 + tid * 8;
-  const int wdst = (tid >> 2) * CV_ROW + (tid & 3) * 16;
-
-  f32x4 areg[CV_ALOADS];
-  uint4 wreg0, wreg1, wreg2;
-#define CV_LOAD_A(CH)                                                                                   \
-  _Pragma("unroll") for (int i_ = 0; i_ < CV_ALOADS; ++i_)                                              \
-    areg[i_] = aoff[i_] >= 0 ? *reinterpret_cast<const f32x4*>(a.x + aoff[i_] + (CH) * 32) : f32x4{0.f, 0.f, 0.f, 0.f};
-#define CV_LOAD_W(SRC, TAP, CH)                                                                         \
-  {                                                                                                     \
-    const uint16_t* s_ = (SRC) + ((size_t)(TAP) * nch + (CH)) * 3 * wslice;                             \
-    wreg0 = *reinterpret_cast<const uint4*>(s_);                                                        \
-    wreg1 = *reinterpret_cast<const uint4*>(s_ + wslice);                                               \
-    wreg2 = *reinterpret_cast<const uint4*>(s_ + 2 * wslice);                                           \
-  }
-#define CV_STORE_W(BUF)                                                                                 \
-  {                                                                                                     \
-    char* d_ = sW + (BUF) * CV_WBUF + wdst;                                                             \
-    *reinterpret_cast<uint4*>(d_) = wreg0;                                                              \
-    *reinterpret_cast<uint4*>(d_ + CV_WPLANE) = wreg1;                                                  \
-    *reinterpret_cast<uint4*>(d_ + 2 * CV_WPLANE) = wreg2;                                              \
-  }
-#define CV_STORE_A()                                                                                    \
-  _Pragma("unroll") for (int i_ = 0; i_ < CV_ALOADS; ++i_) {                                            \
-    if (tid + i_ * 256 < CV_HP * 8) {                                                                   \
-      char* d_ = sA + adst0 + i_ * 32 * CV_ROW;                                                         \
-      bf16x4 p0_, p1_, p2_;                                                                             \
-      _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                \
-        __bf16 u_, v_, w_;                                                                              \
-        cv_split(areg[i_][j_], u_, v_, w_);                                                             \
-        p0_[j_] = u_; p1_[j_] = v_; p2_[j_] = w_;                                                       \
-      }                                                                                                 \
-      *reinterpret_cast<bf16x4*>(d_) = p0_;                                                             \
-      *reinterpret_cast<bf16x4*>(d_ + CV_APLANE) = p1_;                                                 \
-      *reinterpret_cast<bf16x4*>(d_ + 2 * CV_APLANE) = p2_;                                             \
-    }                                                                                                   \
-  }
-
-  float ssum[4][4], ssq[4][4];
-#pragma unroll
-  for (int n = 0; n < 4; ++n)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) ssum[n][g] = ssq[n][g] = 0.f;
-  const int stats_n0 = ct.n0;
-
-  CV_HALO(ct);
-  CV_LOAD_A(0);
-  CV_LOAD_W(wsrc, 0, 0);
-  const char* aBase = sA + kq * 16;
-  const char* wBase = sW + r * CV_ROW + kq * 16;
-  while (true) {
-    f32x4 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int n = 0; n < 4; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int next = tile + gridDim.x;
-    const bool has_next = next < a.ntiles;
-    ConvTile nt = ct;
-    const uint16_t* wnext = wsrc;
-    if (has_next) {
-      nt = cv_tile(a, next);
-      wnext = a.wp + (size_t)nt.n0 * 32 + tid * 8;
-    }
-    for (int ch = 0; ch < nch; ++ch) {
-      // the barrier that ended the previous last tap freed the halo image and weight buffer 0
-      CV_STORE_A();
-      CV_STORE_W(0);
-      __syncthreads();
-      const bool last = ch + 1 == nch;
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int cur = tap & 1;
-        if (tap < 8) {
-          CV_LOAD_W(wsrc, tap + 1, ch);
-        } else if (!last) {
-          CV_LOAD_W(wsrc, 0, ch + 1);
-        } else if (has_next) {
-          CV_LOAD_W(wnext, 0, 0);
-        }
-        if (tap == 6) {
-          if (!last) {
-            CV_LOAD_A(ch + 1);
-          } else if (has_next) {
-            CV_HALO(nt);
-            CV_LOAD_A(0);
-          }
-        }
-        const int dy = tap / 3, dx = tap % 3;
-        bf16x8 xa[2][3], wa[4][3];
-        if (ABL & 1) {   // experiment: operands from registers (no LDS reads)
-#pragma unroll
-          for (int q = 0; q < 3; ++q) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) xa[i][q] = __builtin_bit_cast(bf16x8, wreg0);
-#pragma unroll
-            for (int n = 0; n < 4; ++n) wa[n][q] = __builtin_bit_cast(bf16x8, wreg1);
-          }
-        } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int hp = (2 * wave + i + dy) * CV_HW + r + dx;
-#pragma unroll
-          for (int q = 0; q < 3; ++q) xa[i][q] = *reinterpret_cast<const bf16x8*>(aBase + q * CV_APLANE + hp * CV_ROW);
-        }
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-          for (int q = 0; q < 3; ++q)
-            wa[n][q] = *reinterpret_cast<const bf16x8*>(wBase + cur * CV_WBUF + q * CV_WPLANE + n * 16 * CV_ROW);
-        }
-        // all 18 operand reads are issued before the first product (the scheduler otherwise feeds them in just in
-        // time, an exposed LDS latency every few MFMAs: ~250 waits per tile)
-        __builtin_amdgcn_sched_barrier(0);
-        // smallest terms first; rows of the product = output channels (a lane ends up with 4 consecutive channels)
-#define CV_TERM(QW, QX)                                                                     \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                             \
-    _Pragma("unroll") for (int n = 0; n < 4; ++n)                                           \
-      acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[n][QW], xa[i][QX], acc[i][n], 0, 0, 0);
-        if (!(ABL & 2)) {   // experiment 2: one term of six
-          CV_TERM(2, 0)
-          CV_TERM(0, 2)
-          CV_TERM(1, 1)
-          CV_TERM(1, 0)
-          CV_TERM(0, 1)
-        }
-        CV_TERM(0, 0)
-        __builtin_amdgcn_sched_barrier(0);
-        if (tap < 8) { CV_STORE_W(cur ^ 1); }
-        if (!(ABL & 4)) __syncthreads();   // experiment 4: no barrier
-      }
-    }
-#undef CV_TERM
-
-    // ---- epilogue: lane (r, kq) of accumulator (i, n) = pixel (row 2*wave + i, column r), channels n0 + 16 n + 4 kq ..
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int py = ct.y0 + 2 * wave + i, px = ct.x0 + r;
-      if (py < a.H && px < a.W) {
-        float* dst = a.y + (((long long)ct.b * a.H + py) * a.W + px) * a.Cout + ct.n0 + 4 * kq;
-#pragma unroll
-        for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(dst + 16 * n) = acc[i][n];
-        if (STATS) {
-#pragma unroll
-          for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              ssum[n][g] += acc[i][n][g];
-              ssq[n][g] += acc[i][n][g] * acc[i][n][g];
-            }
-        }
-      }
-    }
-    if (!has_next) break;
-    tile = next;
-    ct = nt;
-    wsrc = wnext;
-  }
-  if (a.stamps && tid == 0) {
-    a.stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - stamp_c;
-    a.stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r;
-  }
-  if (STATS) {
-    double* red = reinterpret_cast<double*>(smem);          // [wave][moment][64 channels]
-    __shared__ int s_last;
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        double d0 = (double)ssum[n][g], d1 = (double)ssq[n][g];
-#pragma unroll
-        for (int m = 1; m < 16; m <<= 1) {
-          d0 += __shfl_xor(d0, m);
-          d1 += __shfl_xor(d1, m);
-        }
-        if (r == 0) {
-          red[(wave * 2 + 0) * 64 + 16 * n + 4 * kq + g] = d0;
-          red[(wave * 2 + 1) * 64 + 16 * n + 4 * kq + g] = d1;
-        }
-      }
-    __syncthreads();
-    if (tid < 128) {
-      const int ch = tid & 63, mom = tid >> 6;
-      const double v = (red[(0 * 2 + mom) * 64 + ch] + red[(1 * 2 + mom) * 64 + ch]) +
-                       (red[(2 * 2 + mom) * 64 + ch] + red[(3 * 2 + mom) * 64 + ch]);
-      double seen = unsafeAtomicAdd(a.bn_state->acc[blockIdx.x % BN_SETS] + mom * BN_MAXC + stats_n0 + ch, v);
-      asm volatile("" ::"v"(seen) : "memory");                // the atomic has returned: it is done
-    }
-    __syncthreads();
-    if (tid == 0)
-      s_last = __hip_atomic_fetch_add(&a.bn_state->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-               gridDim.x - 1;
-    __syncthreads();
-    if (s_last) bn_finalize_sets<false, 256>(a.bn_state, a.bn, a.Cout, a.B * a.H * a.W, reinterpret_cast<double(*)[2]>(smem));
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ forward, second form
-// Same tile (8 x 16 pixels x 64 channels, 4 waves), other split: wave w owns ONE 16-channel tile for all eight pixel
-// rows.  Its weight fragments (3 planes x 16 bytes per lane per step) then belong to it alone and come straight from
+// ------------------------------------------------------------------------------------------------ forward
+// (The first form of this kernel -- the tap's weight image staged in LDS, one barrier per tap, two blocks per CU -- was removed in
+// round 6: profiles/LABBOOK_r01_r04.md has its measurements.)
+// Persistent blocks: block i takes the tiles i, i + grid, ...; the first halo chunk and weight slice of the NEXT tile are requested
+// during the last taps of the current one.  Tile = TH x 16 pixels x 64 channels, 4 waves: wave w owns ONE 16-channel tile for all
+// pixel rows.  Its weight fragments (3 planes x 16 bytes per lane per step) then belong to it alone and come straight from
 // L2 into the MFMA operand registers, one step ahead -- no weight image in LDS, no barrier per tap: the halo image only
 // changes per 32-channel chunk, so a block synchronises twice per NINE taps instead of once per tap, and with 43 KB of
 // LDS three blocks share a CU.  The price is 24 instead of 6 row-operand reads per wave and step (every wave reads the
@@ -448,13 +215,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
 // PRE: the input is transformed on load (a.pre_scale / a.pre_shift, staged in LDS behind the halo planes: the kernel sits
 // at its 168-register budget, eight more live registers for the coefficients spilled 27 more -- as a template parameter the
 // plain kernels compile as before).
-// CV_ABL (compile-time, tools/build_variant.sh -DCV_ABL=n; 0 in the product): TIMING-ONLY ablations of the second form (wrong
-// results): 1 = operand fragments read from LDS once per tile, 2 = weight fragments loaded once per tile, 4 = halo loaded and
-// staged once per tile (no per-chunk loads, splits, stores, barriers), 8 = no barriers, 16 = one piece product of six,
-// 32 = the statistics' tail dropped (no atomics / ticket / finalize), 64 = no finalize.
-#ifndef CV_ABL
-#define CV_ABL 0
-#endif
 template <bool STATS, int TH, bool PRE, bool BWD, bool F16>
 __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
   constexpr int NPL = F16 ? 2 : 3;      // operand planes
@@ -485,9 +245,6 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
   int tile = blockIdx.x;
   if (tile >= a.ntiles) return;
   ConvTile ct = cv_tile(a, tile);
-#ifdef CV_STAGGER          // experiment: the three blocks of a CU (b, b + 256, b + 512) start CV_STAGGER x 1024 cycles apart
-  for (int i_ = 0; i_ < (int)((blockIdx.x >> 8) % 3) * CV_STAGGER; ++i_) __builtin_amdgcn_s_sleep(16);
-#endif
 
   int aoff[NL];
   const int adst0 = (tid >> 3) * CV_ROW + (tid & 7) * 8;
@@ -607,16 +364,15 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
     for (int ch = 0; ch < nch; ++ch) {
       const int pre_ch = ch;              // the thread's four channels of the staged chunk: 32 ch + 4 (tid & 7) ..
       (void)pre_ch;
-      if (!((CV_ABL & 4) && ch > 0)) { V2_PREP_A(); }
-      if (!(CV_ABL & 8) && !((CV_ABL & 4) && ch > 0)) __syncthreads();   // everyone is done reading the previous halo image
-      if (!((CV_ABL & 4) && ch > 0)) { V2_STORE_A(); }
-      if (!(CV_ABL & 8) && !((CV_ABL & 4) && ch > 0)) __syncthreads();
+      V2_PREP_A();
+      __syncthreads();   // everyone is done reading the previous halo image
+      V2_STORE_A();
+      __syncthreads();
       const bool last = ch + 1 == nch;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
         for (int q = 0; q < NPL; ++q) wcur[q] = wnxt[q];
-        if (!((CV_ABL & 2) && (ch > 0 || tap > 0))) {
         if (tap < 8) {
           V2_LOAD_W(wnxt, wsrc, tap + 1, ch);
         } else if (!last) {
@@ -624,8 +380,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
         } else if (has_next) {
           V2_LOAD_W(wnxt, wnext_src, 0, 0);
         }
-        }
-        if (tap == 6 && !(CV_ABL & 4)) {
+        if (tap == 6) {
           if (!last) {
             V2_LOAD_A(ch + 1);
           } else if (has_next) {
@@ -641,13 +396,8 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
           for (int i = 0; i < 2; ++i) {
             if (2 * part + i < TH) {
               const int hp = (2 * part + i + dy) * CV_HW + r + dx;
-              if ((CV_ABL & 1) && (tap > 0 || ch > 0)) {
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) xa[i][q] = wcur[(q + i) % NPL];
-              } else {
 #pragma unroll
               for (int q = 0; q < NPL; ++q) xa[i][q] = *reinterpret_cast<const cvop8*>(aBase + q * PLANE + hp * CV_ROW);
-              }
             }
           }
           __builtin_amdgcn_sched_barrier(0);       // this part's reads, then its products: keeps the scheduler from
@@ -655,11 +405,9 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
           for (int i = 0; i < 2; ++i)
             if (2 * part + i < TH) {
               if constexpr (F16) {
-                if (CV_ABL & 16) acc[2 * part + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wcur[0], xa[i][0], acc[2 * part + i], 0, 0, 0);
-                else F2_MFMA3(acc[2 * part + i], wcur, xa[i]);
+                F2_MFMA3(acc[2 * part + i], wcur, xa[i]);
               } else {
-                if (CV_ABL & 16) acc[2 * part + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur[0], xa[i][0], acc[2 * part + i], 0, 0, 0);
-                else BF3_MFMA6(acc[2 * part + i], wcur, xa[i]);
+                BF3_MFMA6(acc[2 * part + i], wcur, xa[i]);
               }
             }
           __builtin_amdgcn_sched_barrier(0);       // hoisting later parts' operands (170-register budget, 3 waves / SIMD)
@@ -743,10 +491,6 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
       }
     }
     __syncthreads();
-    if (CV_ABL & 32) {               // timing ablation: the block's sums go nowhere (no atomics, no ticket, no finalize)
-      if (tid < 128 && red[tid] == 12345.678) a.y[0] = 0.f;
-      return;
-    }
     if (tid < 128) {
       const int ch = tid & 63, mom = tid >> 6;
       double seen = unsafeAtomicAdd(a.bn_state->acc[blockIdx.x % BN_SETS] + mom * BN_MAXC + stats_n0 + ch, red[mom * 64 + ch]);
@@ -756,7 +500,6 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_v2(ConvArgs a) {
     if (tid == 0)
       s_last2 = __hip_atomic_fetch_add(&a.bn_state->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
-    if (CV_ABL & 64) return;         // timing ablation: atomics and ticket, no finalize
     if (s_last2) bn_finalize_sets<BWD, 256>(a.bn_state, a.bn, a.Cout, a.B * a.H * a.W, reinterpret_cast<double(*)[2]>(smem));
   }
 }
@@ -789,11 +532,6 @@ struct WgradArgs {
   int pre_relu;
 };
 
-// WG_ABL (timing-only builds, wrong results; tools/build_variant.sh): 1 no gy loads, 2 no split of gy, 4 no x halo loads / staging,
-// 8 no LDS operand reads, 16 one MFMA of six, 32 no workgroup barriers
-#ifndef WG_ABL
-#define WG_ABL 0
-#endif
 template <bool PIPE>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -847,8 +585,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
     const float* g_ = a.gy + (((long long)b_ * a.H + py_) * a.W + px_) * a.Cout + cb * 64 + cp * 32 + c;  \
     _Pragma("unroll") for (int a2_ = 0; a2_ < 2; ++a2_)                                                   \
       _Pragma("unroll") for (int jj_ = 0; jj_ < 8; ++jj_)                                                 \
-        GR[a2_][jj_] = (WG_ABL & 1)   ? (float)(py_ + jj_)                                                 \
-                         : (py_ < a.H && px_ + jj_ < a.W) ? g_[(long long)jj_ * a.Cout + a2_ * 16] : 0.f;  \
+        GR[a2_][jj_] = (py_ < a.H && px_ + jj_ < a.W) ? g_[(long long)jj_ * a.Cout + a2_ * 16] : 0.f;       \
   }
 #define WG_LOADG(T, S) WG_LOADG_(graw, T, S)
 
@@ -875,10 +612,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
     WG_LOADG(tile, 0);
   }
   while (tile < a.ntiles) {
-    if (!(WG_ABL & 32)) __syncthreads();          // the previous tile's reads of the image are done
+    __syncthreads();          // the previous tile's reads of the image are done
 #pragma unroll
     for (int i = 0; i < CV_ALOADS; ++i) {
-      if (!(WG_ABL & 4) && adst[i] >= 0) {
+      if (adst[i] >= 0) {
         bf16x4 p0, p1, p2;
         if (a.pre_scale && ((aok >> i) & 1u)) {
 #pragma unroll
@@ -898,7 +635,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
         *reinterpret_cast<bf16x4*>(smem + 2 * WG_XPLANE + adst[i]) = p2;
       }
     }
-    if (!(WG_ABL & 32)) __syncthreads();
+    __syncthreads();
     const int next = tile + a.P;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -910,14 +647,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
         for (int jj = 0; jj < 8; ++jj) {
           __bf16 u, v, w;
           const float gval = graw[a2][jj];
-          if (WG_ABL & 2) {
-            const unsigned bits = __builtin_bit_cast(unsigned, gval);
-            u = __builtin_bit_cast(__bf16, (unsigned short)(bits >> 16));
-            v = __builtin_bit_cast(__bf16, (unsigned short)bits);
-            w = u;
-          } else {
-            cv_split(gval, u, v, w);
-          }
+          cv_split(gval, u, v, w);
           ga[a2][0][jj] = u; ga[a2][1][jj] = v; ga[a2][2][jj] = w;
         }
       if (s < 3) {
@@ -925,18 +655,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
       } else if (next < a.ntiles) {
         WG_LOADG(next, 0);
       }
-      if (!(WG_ABL & 4) && s == 2 && next < a.ntiles) { WG_LOADX(next); }
+      if (s == 2 && next < a.ntiles) { WG_LOADX(next); }
 #define WG_READX(XB, TAP)                                                                                  \
   _Pragma("unroll") for (int pl_ = 0; pl_ < 3; ++pl_) {                                                    \
     const int off_ = pl_ * WG_XPLANE + (2 * s + (TAP) / 3) * CV_HW * 64;                                   \
     typedef i16x4 __attribute__((address_space(3))) * lds_p;                                               \
-    if (WG_ABL & 8) {                                                                                      \
-      XB[pl_] = __builtin_bit_cast(bf16x8, areg[((TAP) + pl_) % CV_ALOADS]);                               \
-    } else {                                                                                               \
-      i16x4 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(smem + off_ + rbase[0][(TAP) % 3]));     \
-      i16x4 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(smem + off_ + rbase[1][(TAP) % 3]));     \
-      XB[pl_] = wg_join(lo_, hi_);                                                                         \
-    }                                                                                                      \
+    i16x4 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(smem + off_ + rbase[0][(TAP) % 3]));       \
+    i16x4 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(smem + off_ + rbase[1][(TAP) % 3]));       \
+    XB[pl_] = wg_join(lo_, hi_);                                                                           \
   }
       bf16x8 xb[2][3];
       if (PIPE) { WG_READX(xb[0], 0); }
@@ -951,11 +677,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
 #pragma unroll
         for (int a2 = 0; a2 < 2; ++a2) {
           f32x4 v = acc[tap][a2];
-          if (WG_ABL & 16) {
-            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[a2][0], xb[tap & 1][0], v, 0, 0, 0);
-          } else {
-            BF3_MFMA6(v, ga[a2], xb[tap & 1]);
-          }
+          BF3_MFMA6(v, ga[a2], xb[tap & 1]);
           acc[tap][a2] = v;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -993,16 +715,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(WgradArgs a) {
 #define WG2_LDS (2 * WG_XPLANE + 2 * WG2_GPLANE + 64)   // 55 872 bytes: two blocks per CU
 #define WG2_GLOADS 8                               // 16-byte pieces of the gy tile per thread
 
-// k-steps (of four) at which the next tile's gy / x loads are issued; W2_ABL: timing-only builds (1 no global loads after the first
-// tile, 8 operands read from LDS once per tile, 16 one MFMA of three)
+// k-steps (of four) at which the next tile's gy / x loads are issued
 #ifndef W2_SG
 #define W2_SG 1
 #endif
 #ifndef W2_SX
 #define W2_SX 2
-#endif
-#ifndef W2_ABL
-#define W2_ABL 0
 #endif
 __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad2(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1172,8 +890,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad2(WgradArgs a) {
     typedef i16x4 __attribute__((address_space(3))) * lds_p;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      if (!(W2_ABL & 1) && s == W2_SG && next < a.ntiles) { WG2_LOADG(next); }
-      if (!(W2_ABL & 1) && s == W2_SX && next < a.ntiles) { WG2_LOADX(next); }
+      if (s == W2_SG && next < a.ntiles) { WG2_LOADG(next); }
+      if (s == W2_SX && next < a.ntiles) { WG2_LOADX(next); }
       // this k-step's gy operands: two channel tiles x two planes
       f16x8 ga[2][2];
 #pragma unroll
@@ -1196,14 +914,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad2(WgradArgs a) {
       WG2_READX(xb[0], 0);
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        if (tap < 8 && !(W2_ABL & 8)) { WG2_READX(xb[(tap + 1) & 1], tap + 1); }
-        if (tap < 8 && (W2_ABL & 8)) { xb[(tap + 1) & 1][0] = xb[tap & 1][1]; xb[(tap + 1) & 1][1] = xb[tap & 1][0]; }
+        if (tap < 8) { WG2_READX(xb[(tap + 1) & 1], tap + 1); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a2 = 0; a2 < 2; ++a2) {
           f32x4 v = acc[tap][a2];
-          if (W2_ABL & 16) v = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga[a2][0], xb[tap & 1][0], v, 0, 0, 0);
-          else F2_MFMA3(v, ga[a2], xb[tap & 1]);
+          F2_MFMA3(v, ga[a2], xb[tap & 1]);
           acc[tap][a2] = v;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1475,11 +1191,6 @@ extern "C" int glx_conv3x3_pack_multi(int n, const float* const* W, const long l
   return glx_conv3x3_pack_multi_arith(n, W, strides, Cin, Cout, fwd, bwd, nullptr, stream);
 }
 
-static int env_conv_form() {
-  const char* e = getenv("GLX_CONV3X3_FORM");
-  return e ? atoi(e) : 2;
-}
-static int g_conv_form = env_conv_form();   // 1: weight image in LDS (k_conv3x3), 2: weight fragments in registers (k_conv3x3_v2)
 static int conv_cus() {
   static int cus = 0;
   if (!cus) {
@@ -1490,27 +1201,17 @@ static int conv_cus() {
   }
   return cus;
 }
-static int env_conv_th() {
-  const char* e = getenv("GLX_CONV3X3_TH");
-  return e ? atoi(e) : 0;
-}
-static int g_conv_th = env_conv_th();       // experiments: rows per tile of the second form (0 = chosen per launch)
+static int g_conv_th = 0;       // experiments (glx_conv3x3_set_grid): rows per tile (0 = chosen per launch)
 static int g_conv_grid = 0;     // experiments: blocks per launch (0 = as many as are meant to be resident)
-// Blocks per CU of the second form's persistent grid (GLX_CONV3X3_BLOCKS_PER_CU, 1..3).  Three fit (168 registers
+// Blocks per CU of the persistent grid.  Three fit (168 registers
 // each) and fill every SIMD's register file: no other kernel can start a wave while such a kernel runs.  Two per CU run
 // the BEV layers within a few per cent of that and leave room for the kernels of a parallel graph branch
 // (tools/conv_side_load.py: 600 small launches beside 40 convolutions, 3.28 -> 2.42 ms); inside the training step the
 // two settings measured the same (7.79 / 7.83 ms), so the default stays three.
-static int conv_per_cu() {
-  static const int v = getenv("GLX_CONV3X3_BLOCKS_PER_CU") ? atoi(getenv("GLX_CONV3X3_BLOCKS_PER_CU")) : 3;
-  return v >= 1 && v <= 3 ? v : 3;
-}
-static int g_conv_ablate = 0;   // experiments: timing-only builds of the loop (wrong results), see k_conv3x3
-extern "C" int glx_conv3x3_set_grid(int blocks, int ablate) {
+static int conv_per_cu() { return 3; }
+extern "C" int glx_conv3x3_set_grid(int blocks, int rows_per_tile) {
   g_conv_grid = blocks;
-  g_conv_ablate = ablate & 0xFF;
-  if ((ablate >> 8) & 0xF) g_conv_form = (ablate >> 8) & 0xF;      // bits 8-11: 1 or 2 = the kernel form
-  g_conv_th = (ablate >> 12) & 0xF;                                // bits 12-15: rows per tile of the second form
+  g_conv_th = rows_per_tile >= 6 && rows_per_tile <= 8 ? rows_per_tile : 0;
   return GLX_OK;
 }
 
@@ -1529,11 +1230,6 @@ static void (*conv_v2_kernel(bool stats, int th, bool pre, bool bwd))(ConvArgs) 
   return stats ? k_conv3x3_v2<true, 6, false, false, F16> : k_conv3x3_v2<false, 6, false, false, F16>;
 }
 
-static long long* g_conv_stamps = nullptr;   // diagnostics: 2 x int64 per block of the following glx_conv3x3_forward launches
-extern "C" int glx_conv3x3_set_stamps(void* stamps) {
-  g_conv_stamps = (long long*)stamps;
-  return GLX_OK;
-}
 
 // opts->bn: training-mode BatchNorm statistics of y in the epilogue (same contract as glx_sconv_forward_ex); opts->epilogue:
 // y = relu?(conv * scale[c] + shift[c]), an eval-mode BatchNorm folded behind the convolution (scale, shift: Cout device
@@ -1562,8 +1258,7 @@ extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int C
   GLX_REQUIRE((long long)B * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31), "glx_conv3x3_forward: map too large (2^31 elements)");
   GLX_REQUIRE(!(bn_state && epi_scale), "glx_conv3x3_forward: statistics and an inference epilogue in one call");
   GLX_REQUIRE(!bn_state || Cout <= BN_MAXC, "glx_conv3x3_forward: BatchNorm statistics for at most %d channels", BN_MAXC);
-  void (*kern)(ConvArgs) = bn_state ? k_conv3x3<0, true> : k_conv3x3<0, false>;
-  int slot = bn_state ? 7 : 0;
+  void (*kern)(ConvArgs) = nullptr;
   GLX_REQUIRE(!pre || (pre->scale && pre->shift && pre->ldc == 0 && pre->coff == 0),
               "glx_conv3x3_forward_ex: the prologue needs scale and shift (Cin floats each)");
   if (bwd) {
@@ -1573,11 +1268,9 @@ extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int C
     bn_state = (BnState*)bwd->state;
     bn_fin = BnFinalize{bwd->gamma, nullptr, 0.f, 0.f, bwd->coef, nullptr, nullptr, nullptr, nullptr, bwd->invstd, bwd->dgamma, bwd->dbeta};
   }
-  // epilogue / prologue / bn_bwd live in the second form; so does the fp16 arithmetic (the packs have ITS layout then)
   const bool f16 = g_conv_f16 != 0;
-  const bool v2 = (g_conv_form == 2 && g_conv_ablate == 0) || epi_scale || pre || bwd || f16;
   int th = CV_TH;
-  if (v2) {
+  {
     // rows per tile: the fewest (rounds of the resident blocks) x (rows + a fixed cost per tile)
     const int resident = conv_per_cu() * conv_cus();
     long long best = -1;
@@ -1596,32 +1289,14 @@ extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int C
     kern = f16 ? conv_v2_kernel<true>(bn_state != nullptr, th, pre != nullptr, bwd != nullptr)
                : conv_v2_kernel<false>(bn_state != nullptr, th, pre != nullptr, bwd != nullptr);
   }
-  if (!bn_state && !v2) {
-    switch (g_conv_ablate) {
-      case 1: kern = k_conv3x3<1, false>; break;
-      case 2: kern = k_conv3x3<2, false>; break;
-      case 4: kern = k_conv3x3<4, false>; break;
-      case 5: kern = k_conv3x3<5, false>; break;
-      case 6: kern = k_conv3x3<6, false>; break;
-      default: break;
-    }
-    slot = g_conv_ablate & 7;
-    if (slot == 7) slot = 0;
-  }
-  const int lds_bytes = v2 ? (f16 ? 2 : 3) * (th + 2) * CV_HW * CV_ROW + 16 + (pre ? 2 * Cin * (int)sizeof(float) : 0) +
-                                 (bwd ? 4 * Cout * (int)sizeof(float) : 0) : CV_LDS;
-  if (v2) {
+  const int lds_bytes = (f16 ? 2 : 3) * (th + 2) * CV_HW * CV_ROW + 16 + (pre ? 2 * Cin * (int)sizeof(float) : 0) +
+                        (bwd ? 4 * Cout * (int)sizeof(float) : 0);
+  {
     static int v2_set[2][3][2][9] = {};      // largest dynamic LDS size registered per instantiation
     int& reg = v2_set[f16 ? 1 : 0][bwd ? 2 : pre ? 1 : 0][(bn_state && !bwd) ? 1 : 0][th];
     if (reg < lds_bytes) {
       GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
       reg = lds_bytes;
-    }
-  } else {
-    static bool attr_set[8] = {};
-    if (!attr_set[slot]) {
-      GLX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-      attr_set[slot] = true;
     }
   }
   ConvArgs a;
@@ -1641,7 +1316,6 @@ extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int C
   }
   a.bn_state = bn_state;
   a.bn = bn_fin;
-  a.stamps = g_conv_stamps;
   a.epi_scale = epi_scale;
   a.epi_shift = epi_shift;
   a.epi_relu = epi_relu;
@@ -1652,7 +1326,7 @@ extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int C
   a.bwd_coef = bwd ? bwd->coef_fwd : nullptr;
   a.bwd_mean = bwd ? bwd->mean : nullptr;
   a.bwd_invstd = bwd ? bwd->invstd : nullptr;
-  const int resident = slots * (v2 ? conv_per_cu() : 2);
+  const int resident = slots * conv_per_cu();
   int grid = g_conv_grid > 0 ? g_conv_grid : (a.ntiles < resident ? a.ntiles : resident);
   if (bn_state) grid = grid / a.nblk * a.nblk;   // every block keeps one channel block (ntiles is a multiple of nblk)
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, a);

@@ -13,7 +13,6 @@
 // LDS; bias / BatchNorm / ReLU ride in the epilogue.  The kernels that share that scheme:
 //   k_sconv_mfma   whole-chunk (or column-split) waves gather their rows into registers (thin layers);
 //   k_sconv_gemm   all threads gather the next pair panel into LDS, chunks split over 4 waves (Cout >= 64; fp32 or f16 x 2);
-//   k_sconv_gemm2  the same with the filter fragments in registers and a second row panel (sweep variants 40-42, 60-61).
 // Weight gradient: k_wgrad_pairs over per-offset pair lists (k_wgrad_mfma: row slices).  dense(): k_dense_from_index.
 #include <hip/hip_ext.h>
 #include <stdlib.h>
@@ -1129,273 +1128,6 @@ __global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm(
   }
 }
 
-// ------------------------------------------------------------------ GEMM kernel, weights in registers
-// Same tile, compaction, panel gathers and accumulate as k_sconv_gemm; what changes is where W[k] lives.  There the
-// 16 KB image of an offset goes L2 -> registers -> LDS (all threads) and every MFMA wave reads its 4 KB fragment back
-// per chunk: per 32-pair step 16 KB of LDS stores + 32 KB of LDS operand reads for W next to 8.5 + 32 KB for the rows,
-// and a second barrier so that nobody overwrites the image (or the panel) while it is read.  Here a wave keeps the
-// fragment of ITS column tile(s) in registers (CIN x 16 floats = 16 VGPRs per tile at CIN = 64), loaded straight from
-// the packed split image in L2 (a lane's four 16-byte pieces; 16 lanes = 256 contiguous bytes) ONE offset ahead into
-// a second register set, and the freed 16 KB of LDS hold a second row panel: rows of step s+1 are stored while step
-// s multiplies from the other buffer, so a step has ONE barrier.  Load order per step: W of the next offset first,
-// then the next panel's row gathers -- vmcnt retires in order, so nothing ever waits for a gather in order to use W.
-template <int CIN, int COUT, int TR_, int NW_, int WPG_>
-struct SconvGemm2 {
-  using S = SconvSplitCfg<CIN, COUT>;
-  static constexpr int CQ = CIN / 4, NT = COUT / 16;
-  static constexpr int TR = TR_, NW = NW_, WPG = WPG_, THREADS = NW * 64;
-  static constexpr int G = NW / WPG, TPW = NT / WPG;
-  static constexpr int AP = 16 * G;
-  static constexpr int A_LD = CIN + 4;
-  static constexpr int SEGS = CIN / 4;
-  static constexpr int A_SEG = AP * SEGS;
-  static constexpr int GPT = (A_SEG + THREADS - 1) / THREADS;
-  static constexpr int WF = TPW * (CQ / 4);                  // f32x4 registers of one weight fragment set
-  static constexpr int ACC_LD = COUT + 4;
-  static constexpr size_t lds_bytes = (size_t)TR * ACC_LD * 4 + 2 * (size_t)AP * A_LD * 4 +
-                                      (size_t)SC_MAXK * TR * 5 + (TR + 32) * 4 + 64 + (size_t)CIN * 8;
-  static_assert(TR == 64, "one wave spans the tile");
-  static_assert(CQ % 4 == 0, "weights-in-registers kernel: CIN >= 16");
-  static_assert(NW % WPG == 0 && NT % WPG == 0, "bad column split");
-};
-
-template <int CIN, int COUT, int TR_, int NW_, int WPG_, bool PRE = false, bool F16 = false>
-__global__ __launch_bounds__(NW_ * 64) void k_sconv_gemm2(
-    const float* __restrict__ in, const float* __restrict__ Wp, SconvEpilogue ep,
-    const int* __restrict__ nbr, const int* __restrict__ tile_order, int N_out, int K,
-    float* __restrict__ out) {
-  if (ep.n_live) N_out = min(N_out, *ep.n_live);
-  using T = SconvGemm2<CIN, COUT, TR_, NW_, WPG_>;
-  using S = SconvSplitCfg<CIN, COUT>;
-  constexpr int TR = T::TR, ACC_LD = T::ACC_LD, CQ = T::CQ, THREADS = T::THREADS;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_acc = smem;                                            // TR * ACC_LD
-  float* s_a = s_acc + TR * ACC_LD;                               // 2 * AP * A_LD
-  int* s_pin = reinterpret_cast<int*>(s_a + 2 * T::AP * T::A_LD); // SC_MAXK * TR
-  int* s_rows = s_pin + SC_MAXK * TR;                             // TR
-  int* s_cnt = s_rows + TR;                                       // 32
-  unsigned char* s_pslot = reinterpret_cast<unsigned char*>(s_cnt + 32);   // SC_MAXK * TR
-  signed char* s_aexp = reinterpret_cast<signed char*>(s_pslot + SC_MAXK * TR);   // F16: 2 x AP row exponents (in the 64 spare bytes)
-  float* s_pre = reinterpret_cast<float*>(s_pslot + SC_MAXK * TR + 64);           // PRE: 2 * CIN scale | shift
-  static_assert(!F16 || (SconvF2Cfg<CIN, COUT>::ON && 2 * T::AP <= 64), "no fp16 image for these channels");
-  int ew = 0;                              // F16: see k_sconv_gemm
-  if constexpr (F16) ew = *reinterpret_cast<const int*>(Wp + (size_t)K * S::IMG);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int row0 = (ep.tile_map ? ep.tile_map[blockIdx.x] : sc_xcd_tile(blockIdx.x, gridDim.x, ep.xcd_group & 0xFF)) * TR;
-  const int grp = wave / T::WPG;
-  const int tile0 = (wave % T::WPG) * T::TPW;
-  if constexpr (PRE) {         // visible to everybody behind the compaction's barrier
-    for (int e = tid; e < CIN; e += THREADS) { s_pre[e] = ep.pre_scale[e]; s_pre[CIN + e] = ep.pre_shift[e]; }
-  }
-
-  // ---- tile rows, zero accumulators, rule compaction: every wave compacts a share of the offsets
-  for (int i = tid; i < TR * ACC_LD / 4; i += THREADS)
-    reinterpret_cast<f32x4*>(s_acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  {
-    const int prow = row0 + lane;
-    const int lrow = (prow < N_out) ? (tile_order ? tile_order[prow] : prow) : -1;
-    const int* np = nbr + (long long)(lrow < 0 ? 0 : lrow) * K;
-    constexpr int KPW = (SC_MAXK + T::NW - 1) / T::NW;
-    int nbv[KPW];
-#pragma unroll
-    for (int u = 0; u < KPW; ++u) {
-      const int k = wave + u * T::NW;
-      nbv[u] = np[k < K ? k : 0];
-    }
-    if (wave == 0) s_rows[lane] = lrow;
-#pragma unroll
-    for (int u = 0; u < KPW; ++u) {
-      const int k = wave + u * T::NW;
-      if (k < SC_MAXK) {
-        const bool v = k < K && lrow >= 0 && nbv[u] >= 0;
-        const unsigned long long bal = __ballot(v);
-        if (v) {
-          const int pos = k * TR + __popcll(bal & ((1ull << lane) - 1ull));
-          s_pin[pos] = nbv[u];
-          s_pslot[pos] = (unsigned char)lane;
-        }
-        if (lane == 0) s_cnt[k] = __popcll(bal);
-      }
-    }
-    __syncthreads();
-  }
-  const unsigned mask = (unsigned)__ballot(lane < K && lane < SC_MAXK && s_cnt[lane < SC_MAXK ? lane : 0] > 0);
-
-  f32x4 wcur[T::WF], wnxt[T::WF];
-  f32x4 areg[T::GPT];
-  // this wave's fragment of offset KK: S::idx(tile, q, 4 * t4, r) = ((tile * 4 + q) * (CQ / 4) + t4) * 64 + r * 4
-#define G2_LOAD_W(KK)                                                                        \
-  if constexpr (F16) {   /* SconvF2Cfg::idx: 1 KB per (tile, k-step, plane), a lane's 16 bytes at lane * 16 */ \
-    const float* src_ = Wp + (size_t)(KK) * S::IMG + lane * 4;                               \
-    _Pragma("unroll") for (int tt_ = 0; tt_ < T::TPW; ++tt_) {                               \
-      _Pragma("unroll") for (int u_ = 0; u_ < CQ / 4; ++u_)                                  \
-        wnxt[tt_ * (CQ / 4) + u_] = *reinterpret_cast<const f32x4*>(src_ + ((tile0 + tt_) * (CQ / 4) + u_) * 256); \
-    }                                                                                        \
-  } else {                                                                                   \
-    const float* src_ = Wp + (size_t)(KK) * S::IMG + r * 4;                                  \
-    _Pragma("unroll") for (int tt_ = 0; tt_ < T::TPW; ++tt_) {                               \
-      _Pragma("unroll") for (int t4_ = 0; t4_ < CQ / 4; ++t4_)                               \
-        wnxt[tt_ * (CQ / 4) + t4_] = *reinterpret_cast<const f32x4*>(                        \
-            src_ + (((tile0 + tt_) * 4 + q) * (CQ / 4) + t4_) * 64);                         \
-    }                                                                                        \
-  }
-#define G2_LOAD_A(KK, PB, CNT)                                                               \
-  {                                                                                          \
-    _Pragma("unroll") for (int i_ = 0; i_ < T::GPT; ++i_) {                                  \
-      int e_ = tid + i_ * THREADS;                                                           \
-      int pair_ = e_ / T::SEGS, seg_ = e_ - pair_ * T::SEGS;                                 \
-      int p_ = (PB) + pair_;                                                                 \
-      int irow_ = 0;                                                                         \
-      if (p_ < (CNT) && pair_ < T::AP) irow_ = s_pin[(KK) * TR + p_];                        \
-      areg[i_] = *reinterpret_cast<const f32x4*>(in + (long long)irow_ * CIN + seg_ * 4);    \
-    }                                                                                        \
-  }
-#define G2_STORE_A(BUF)                                                                      \
-  {                                                                                          \
-    float* dst_ = s_a + (BUF) * (T::AP * T::A_LD);                                           \
-    _Pragma("unroll") for (int i_ = 0; i_ < T::GPT; ++i_) {                                  \
-      int e_ = tid + i_ * THREADS;                                                           \
-      int pair_ = e_ / T::SEGS, seg_ = e_ - pair_ * T::SEGS;                                 \
-      f32x4 v_ = areg[i_];                                                                   \
-      if constexpr (PRE) {                                                                   \
-        const f32x4 sc_ = *reinterpret_cast<const f32x4*>(s_pre + seg_ * 4);                 \
-        const f32x4 sh_ = *reinterpret_cast<const f32x4*>(s_pre + CIN + seg_ * 4);           \
-        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) v_[c_] = fmaxf(bn_affine(v_[c_], sc_[c_], sh_[c_]), 0.f); \
-      }                                                                                      \
-      if constexpr (F16) {   /* two fp16 pieces of the row scaled by its own power of two (k_sconv_gemm) */ \
-        const float m_ = sc_row_absmax<T::SEGS>(v_);                                         \
-        const int ex0_ = cv_block_exponent(m_);                                              \
-        const int ex_ = ex0_ == 127 ? 0 : ex0_;                                              \
-        const float s_ = __builtin_bit_cast(float, (unsigned)(ex_ + 127) << 23);             \
-        f16x4 pa_, pb_;                                                                      \
-        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) { _Float16 a_, b_; cv_split2(v_[c_] * s_, a_, b_); pa_[c_] = a_; pb_[c_] = b_; } \
-        if (T::A_SEG % THREADS == 0 || e_ < T::A_SEG) {                                      \
-          *reinterpret_cast<f16x4*>(dst_ + pair_ * T::A_LD + seg_ * 2) = pa_;                \
-          *reinterpret_cast<f16x4*>(dst_ + pair_ * T::A_LD + CIN / 2 + seg_ * 2) = pb_;      \
-          if (seg_ == 0) s_aexp[(BUF) * T::AP + pair_] = (signed char)ex_;                   \
-        }                                                                                    \
-      } else if (T::A_SEG % THREADS == 0 || e_ < T::A_SEG)                                   \
-        *reinterpret_cast<f32x4*>(dst_ + pair_ * T::A_LD + seg_ * 4) = v_;                   \
-    }                                                                                        \
-  }
-
-  if (mask) {
-    int k = __builtin_ctz(mask);
-    unsigned rem = mask & (mask - 1);
-    int cnt = s_cnt[k], pb = 0, buf = 0;
-    G2_LOAD_W(k);
-    G2_LOAD_A(k, 0, cnt);
-#pragma unroll
-    for (int i = 0; i < T::WF; ++i) wcur[i] = wnxt[i];
-    G2_STORE_A(0);
-    __syncthreads();
-    while (true) {
-      bool has_next = true, new_w = false;
-      int kn = k, pbn = pb + T::AP, cntn = cnt;
-      if (pbn >= cnt) {
-        if (rem) {
-          kn = __builtin_ctz(rem);
-          rem &= rem - 1;
-          pbn = 0;
-          cntn = s_cnt[kn];
-          new_w = true;
-        } else {
-          has_next = false;
-        }
-      }
-      if (has_next) {
-        if (new_w) { G2_LOAD_W(kn); }        // first: the gathers below must not stand between W and its use
-        G2_LOAD_A(kn, pbn, cntn);
-      }
-      // ---- multiply this wave's chunk of the current panel by its column tile(s)
-      const int pbase = pb + grp * 16;
-      if constexpr (F16) { if (pbase < cnt) {   // wave-uniform
-        constexpr int KS = CIN / 32;
-        const _Float16* arow = reinterpret_cast<const _Float16*>(s_a + buf * (T::AP * T::A_LD) + (grp * 16 + r) * T::A_LD) + q * 8;
-        f16x8 Xa[KS], Xb[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          Xa[ks] = *reinterpret_cast<const f16x8*>(arow + ks * 32);
-          Xb[ks] = *reinterpret_cast<const f16x8*>(arow + CIN + ks * 32);
-        }
-        f32x4 acc[T::TPW];
-#pragma unroll
-        for (int tt = 0; tt < T::TPW; ++tt) {
-          acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            const f16x8 Wa = __builtin_bit_cast(f16x8, wcur[tt * (CQ / 4) + 2 * ks]);
-            const f16x8 Wb = __builtin_bit_cast(f16x8, wcur[tt * (CQ / 4) + 2 * ks + 1]);
-            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wb, Xa[ks], acc[tt], 0, 0, 0);
-            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xb[ks], acc[tt], 0, 0, 0);
-            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xa[ks], acc[tt], 0, 0, 0);
-          }
-        }
-        const int p = pbase + r;
-        if (p < cnt) {
-          const int et = -((int)s_aexp[buf * T::AP + grp * 16 + r] + ew);
-          float* dst = s_acc + (int)s_pslot[k * TR + p] * ACC_LD + tile0 * 16 + 4 * q;
-#pragma unroll
-          for (int tt = 0; tt < T::TPW; ++tt) {
-            f32x4 v = *reinterpret_cast<f32x4*>(dst + tt * 16);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] += ldexpf(acc[tt][c], et);
-            *reinterpret_cast<f32x4*>(dst + tt * 16) = v;
-          }
-        }
-      } } else
-      if (pbase < cnt) {                     // wave-uniform
-        const float* arow = s_a + buf * (T::AP * T::A_LD) + (grp * 16 + r) * T::A_LD + q * CQ;
-        float Am[CQ];
-#pragma unroll
-        for (int i = 0; i < CQ / 4; ++i) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(arow + 4 * i);
-          Am[4 * i + 0] = v[0]; Am[4 * i + 1] = v[1]; Am[4 * i + 2] = v[2]; Am[4 * i + 3] = v[3];
-        }
-        f32x4 acc[T::TPW];
-#pragma unroll
-        for (int tt = 0; tt < T::TPW; ++tt) {
-          acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int t4 = 0; t4 < CQ / 4; ++t4) {
-            const f32x4 wv = wcur[tt * (CQ / 4) + t4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e], Am[4 * t4 + e], acc[tt], 0, 0, 0);
-          }
-        }
-        const int p = pbase + r;
-        if (p < cnt) {
-          float* dst = s_acc + (int)s_pslot[k * TR + p] * ACC_LD + tile0 * 16 + 4 * q;
-#pragma unroll
-          for (int tt = 0; tt < T::TPW; ++tt) {
-            f32x4 v = *reinterpret_cast<f32x4*>(dst + tt * 16);
-            v += acc[tt];
-            *reinterpret_cast<f32x4*>(dst + tt * 16) = v;
-          }
-        }
-      }
-      if (!has_next) break;
-      G2_STORE_A(buf ^ 1);                   // the other buffer: last read one barrier ago
-      if (new_w) {
-#pragma unroll
-        for (int i = 0; i < T::WF; ++i) wcur[i] = wnxt[i];
-      }
-      __syncthreads();
-      k = kn; pb = pbn; cnt = cntn; buf ^= 1;
-    }
-  }
-#undef G2_LOAD_W
-#undef G2_LOAD_A
-#undef G2_STORE_A
-  __syncthreads();
-
-  sc_epilogue<COUT, TR, THREADS, ACC_LD>(smem, s_acc, s_rows, ep, out, ep.out_ld ? ep.out_ld : COUT, N_out);
-}
-
 // ------------------------------------------------------------------ generic scalar kernel
 __global__ void k_sconv_generic(const float* __restrict__ in, const float* __restrict__ W,
                                 SconvEpilogue ep, const int* __restrict__ nbr, int N_out, int K,
@@ -1534,12 +1266,6 @@ static int pack_weights(const float* W, int K, float* Wp, int view, hipStream_t 
   return GLX_OK;
 }
 
-// experiment knob: glx_sconv_set_variant() or env GLX_SCONV_VARIANT; -1 = default kernel choice
-static int env_variant() {
-  const char* e = getenv("GLX_SCONV_VARIANT");
-  return e ? atoi(e) : -1;
-}
-static int g_sconv_variant = env_variant();
 // profiling aid (tools/sconv_tiles.py): per-block timeline of the block kernel
 static long long* g_sconv_trace = nullptr;
 extern "C" int glx_sconv_set_trace(void* trace) {
@@ -1568,10 +1294,6 @@ extern "C" int glx_sconv_set_arith(int f16x2) {
   return GLX_OK;
 }
 extern "C" int glx_sconv_get_arith(void) { return g_sconv_f16; }
-extern "C" int glx_sconv_set_variant(int v) {
-  g_sconv_variant = v;
-  return GLX_OK;
-}
 
 template <int CI, int CO, int TR, int NW, int NBUF, int WPG_REQ = 1>
 static int launch_tile(const float* in, const float* Wp, const SconvEpilogue& ep,
@@ -1671,68 +1393,10 @@ static int launch_gemm(const float* in, const float* Wp, const SconvEpilogue& ep
   }
 }
 
-template <int CI, int CO, int TR, int NW, int WPG_REQ, bool F16 = false>
-static int launch_gemm2(const float* in, const float* Wp, const SconvEpilogue& ep,
-                        const int32_t* nbr, const int32_t* tile_order, int N_out, int K, float* out,
-                        hipStream_t st) {
-  constexpr int WPG = WPG_REQ < CO / 16 ? WPG_REQ : CO / 16;
-  if constexpr (CI < 16 || TR != 64) {
-    glx_set_error("sparse conv GEMM2 tile: CIN >= 16 and 64-row tiles only (%d,%d,TR=%d)", CI, CO, TR);
-    return GLX_EINVAL;
-  } else {
-    using T = SconvGemm2<CI, CO, TR, NW, WPG>;
-    static bool attr_set = false;
-    auto kern = ep.pre_scale ? k_sconv_gemm2<CI, CO, TR, NW, WPG, true, F16> : k_sconv_gemm2<CI, CO, TR, NW, WPG, false, F16>;
-    const size_t lds = T::lds_bytes;
-    if (!attr_set) {
-      GLX_HIP(hipFuncSetAttribute((const void*)k_sconv_gemm2<CI, CO, TR, NW, WPG, true, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      GLX_HIP(hipFuncSetAttribute((const void*)k_sconv_gemm2<CI, CO, TR, NW, WPG, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
-    }
-    const float* Wsplit = F16 ? f2_image<CI, CO>(const_cast<float*>(Wp), K) : Wp + (size_t)K * SconvCfg<CI, CO>::IMG;
-    int nblocks = glx_divup(N_out, TR);
-    if (g_prof_start || g_prof_stop) {
-      hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(T::THREADS), lds, st, g_prof_start, g_prof_stop, 0, in, Wsplit,
-                            ep, nbr, tile_order, N_out, K, out);
-      g_prof_start = g_prof_stop = nullptr;
-    } else {
-      hipLaunchKernelGGL(kern, dim3(nblocks), dim3(T::THREADS), lds, st, in, Wsplit, ep, nbr, tile_order, N_out, K,
-                         out);
-    }
-    GLX_LAUNCH_CHECK();
-    return GLX_OK;
-  }
-}
-
 template <int CI, int CO>
 static int launch_mfma(const float* in, const float* Wp, const SconvEpilogue& ep,
                        const int32_t* nbr, const int32_t* tile_order, int N_out, int K, float* out,
                        hipStream_t st) {
-#define SC_GO(TR, NW, NBUF) \
-  return launch_tile<CI, CO, TR, NW, NBUF>(in, Wp, ep, nbr, tile_order, N_out, K, out, st)
-  // sweep knob (tools/sconv_sweep.py): the tile shapes that were competitive on some layer;
-  // the many others that were measured and lost are listed in profiles/r01_summary.md
-  switch (g_sconv_variant) {
-    case 2: SC_GO(128, 8, 1);
-    case 5: SC_GO(64, 4, 1);
-    case 6: SC_GO(64, 4, 2);
-    case 23: return launch_tile<CI, CO, 64, 8, 1, 2>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
-    case 30: return launch_gemm<CI, CO, 64, 8, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
-    case 31: return launch_gemm<CI, CO, 64, 4, 2>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
-    case 32: return launch_gemm<CI, CO, 64, 4, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
-    case 33: return launch_gemm<CI, CO, 128, 8, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
-    case 34: return launch_gemm<CI, CO, 32, 8, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
-    case 35: return launch_gemm<CI, CO, 32, 4, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
-    case 36: return launch_gemm<CI, CO, 48, 8, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
-    case 40: return launch_gemm2<CI, CO, 64, 8, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
-    case 41: return launch_gemm2<CI, CO, 64, 4, 4>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
-    case 42: return launch_gemm2<CI, CO, 64, 8, 2>(in, Wp, ep, nbr, tile_order, N_out, K, out, st);
-    // f16 x 2 multiply with the weights in registers (shapes without the fp16 image keep their default)
-    case 60: if constexpr (SconvF2Cfg<CI, CO>::ON) return launch_gemm2<CI, CO, 64, 8, 4, true>(in, Wp, ep, nbr, tile_order, N_out, K, out, st); break;
-    case 61: if constexpr (SconvF2Cfg<CI, CO>::ON) return launch_gemm2<CI, CO, 64, 4, 4, true>(in, Wp, ep, nbr, tile_order, N_out, K, out, st); break;
-    default: break;
-  }
-#undef SC_GO
   // default (measured best per shape on the KITTI-shaped batch, tools/sconv_sweep.py):
   //   Cout >= 64: block implicit GEMM (LDS-staged gathers, column split over 4 waves), 64-row
   //               tiles, 8 waves (4 for Cout = 128: its two 16-column tiles per wave);
@@ -2085,7 +1749,7 @@ extern "C" int glx_sconv_forward_ex(const float* in, int N_in, const float* W, c
   if (prol) {
     GLX_REQUIRE(prol->scale && prol->shift && prol->relu && prol->ldc == 0 && prol->coff == 0,
                 "glx_sconv_forward_ex: the prologue is x' = relu(x * scale + shift) with Cin floats each");
-    GLX_REQUIRE(mfma_supported(Cin, Cout, K) && Cin >= 16 && !(Cin >= 128 && Cout >= 128) && (g_sconv_variant < 0 || g_sconv_variant >= 60) && !g_sconv_trace,
+    GLX_REQUIRE(mfma_supported(Cin, Cout, K) && Cin >= 16 && !(Cin >= 128 && Cout >= 128) && !g_sconv_trace,
                 "glx_sconv_forward_ex: the prologue needs a default MFMA tile kernel in one launch (channels %d -> %d)", Cin, Cout);
   }
   SconvEpilogue ep{bias, scale, shift, relu, n_out_live, g_sconv_trace, g_sconv_xcd_group, 0, tile_map, bn_state,

@@ -1223,14 +1223,9 @@ size_t glx_deconv_wgrad_workspace_bytes(int Cin, int Cout, int u);
 int glx_deconv_wgrad(const float* x, const float* gy, int B, int H, int W, int Cin, int Cout, int u, float* dW,
                      long long s_ci, long long s_co, long long s_kh, long long s_kw, void* workspace,
                      size_t workspace_bytes, void* stream);
-/* Experiments only: blocks per launch of glx_conv3x3_forward (0 = as many as are resident) and, in `ablate`: bits 0-7
- * timing-only ablations of the first form's loop (wrong results), bits 8-11 the kernel form (1 = weight image in LDS,
- * 2 = weight fragments in registers, the default; environment GLX_CONV3X3_FORM), bits 12-15 rows per tile of the second
- * form (0 = chosen per launch; GLX_CONV3X3_TH).  The stamps below are written by the first form only. */
-int glx_conv3x3_set_grid(int blocks, int ablate);
-/* Diagnostics: the following glx_conv3x3_forward launches write, per block, the shader-clock ticks (s_memtime) and the
- * 100 MHz ticks (s_memrealtime) of its lifetime to stamps[2 * block ..] (NULL: off): their ratio is the clock the chip holds. */
-int glx_conv3x3_set_stamps(void* stamps);
+/* Experiments only (tools/conv_side_load.py): blocks per launch of glx_conv3x3_forward (0 = as many as are resident) and rows
+ * per tile (6 / 7 / 8; 0 = chosen per launch by the cost model). */
+int glx_conv3x3_set_grid(int blocks, int rows_per_tile);
 
 /* The RoI head's FC towers behind the first Linear, training mode, one launch per direction
  * (pcdet/models/roi_heads/voxelrcnn_kl_label_iou_head.py:38-92: shared_fc_layer[second Linear on] -> cls_fc_layers ->

@@ -356,34 +356,6 @@ def test_component_wise_accuracy_of_the_two_arithmetics_on_a_dim_channel(dev, dr
         assert err[1] > 4 * err[0], (drop, err)                   # the documented loss is real: not fp32-class on this output
 
 
-@pytest.mark.parametrize("cin,cout", [(64, 64), (32, 64), (64, 128)])
-def test_weights_in_registers_form_of_the_f16x2_kernel_gives_the_same_bits(dev, cin, cout, sconv_arith):
-    """k_sconv_gemm2 under the f16 x 2 arithmetic (GLX_SCONV_VARIANT=60 / 61: filter fragments in registers, a second row panel,
-    one barrier per step; kept as a sweep variant) against the default kernel: the same pieces, products and summation
-    order -- bitwise equal, with and without the BatchNorm + ReLU prologue."""
-    from glenet_amd import _lib
-    rng = np.random.default_rng(cin + 3 * cout)
-    shape = (13, 40, 36)
-    idx, f0 = _rand_sparse(rng, 2, *shape, 0.08, cin)
-    x = _gpu_tensor(idx, f0, shape, 2, dev)
-    rs = sp.build_subm_rules(x, (3, 3, 3))
-    g = torch.Generator(device=dev).manual_seed(cin)
-    w = torch.randn(27, cin, cout, device=dev, generator=g) / (27 * cin) ** 0.5
-    coef = torch.cat([torch.rand(cin, device=dev, generator=g) + 0.5, torch.randn(cin, device=dev, generator=g) * 0.3])
-    packed = sp.pack_weights(w)
-    sconv_arith(1)
-    try:
-        for pre in (None, coef):
-            _lib.call_nostream("glx_sconv_set_variant", -1)
-            want = sp._sconv(x.features, w, None, rs.nbr, rs.tile_order_out, rs.N_out, packed=packed, rules=rs, pre=pre)
-            for v in (60, 61):
-                _lib.call_nostream("glx_sconv_set_variant", v)
-                got = sp._sconv(x.features, w, None, rs.nbr, rs.tile_order_out, rs.N_out, packed=packed, rules=rs, pre=pre)
-                assert torch.equal(got, want), (v, pre is not None)
-    finally:
-        _lib.call_nostream("glx_sconv_set_variant", -1)
-
-
 def test_f16x2_block_kernel_equals_its_restatement_to_fp32_summation(dev, sconv_arith):
     """The kernel's f16 x 2 result against oracle.sconv_forward_f16x2 (the same scaling, pieces and piece products, summed in
     fp64): what is left is the fp32 summation inside the MFMAs and the accumulator tile -- below the fp32 kernel's own distance

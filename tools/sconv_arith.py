@@ -12,6 +12,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from glenet_amd import _lib, backbone as gb, synth  # noqa: E402
 from glenet_amd.spconv import core as sp  # noqa: E402
 
+
+def _set_variant(v):
+    """The tile-shape sweep variants (2-42, 60 / 61) were removed from the product library in round 6 (every one of them measured
+    and rejected: profiles/LABBOOK_r01_r04.md, r05_sconv_bound.md); on a library without the knob only the default runs."""
+    try:
+        fn = _lib.load().glx_sconv_set_variant
+    except AttributeError:
+        if v not in (-1, None):
+            raise SystemExit("this library has no glx_sconv_set_variant: check out a round <= 5 tree for the sweep variants")
+        return
+    fn(int(v))
+
+
+
 K = synth.KITTI
 dev = torch.device("cuda", 0)
 frames = [synth.kitti_frame(i)[0] for i in range(4)]
@@ -92,10 +106,10 @@ for f, w, nbr, order, n_out, rules in calls:
         _lib.call_nostream("glx_sconv_set_arith", 1)
         extra = ""
         for v in [int(x) for x in os.environ.get("VARIANTS", "").split(",") if x]:      # other kernel forms of the f16 x 2 arithmetic
-            _lib.call_nostream("glx_sconv_set_variant", v)
+            _set_variant(v)
             got = orig(fv, wv, None, nbr, order, n_out, packed=packed, rules=rules)
             t = timed(lambda: orig(fv, wv, None, nbr, order, n_out, packed=packed, rules=rules))
-            _lib.call_nostream("glx_sconv_set_variant", -1)
+            _set_variant(-1)
             extra += " | v%d %.1f us, max |d| vs f16x2 %.3g" % (v, t, float((got - res[1]).abs().max() / res[1].abs().max()))
         live = mag > 0
         e = [float(((res[a].double() - want).abs()[live] / mag[live]).max()) for a in (0, 1)]

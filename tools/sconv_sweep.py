@@ -10,6 +10,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from glenet_amd import _lib, backbone as gb, synth  # noqa: E402
 from glenet_amd.spconv import core as sp  # noqa: E402
 
+
+def _set_variant(v):
+    """The tile-shape sweep variants (2-42, 60 / 61) were removed from the product library in round 6 (every one of them measured
+    and rejected: profiles/LABBOOK_r01_r04.md, r05_sconv_bound.md); on a library without the knob only the default runs."""
+    try:
+        fn = _lib.load().glx_sconv_set_variant
+    except AttributeError:
+        if v not in (-1, None):
+            raise SystemExit("this library has no glx_sconv_set_variant: check out a round <= 5 tree for the sweep variants")
+        return
+    fn(int(v))
+
+
 K = synth.KITTI
 dev = torch.device("cuda", 0)
 frames = [synth.kitti_frame(i)[0] for i in range(4)]
@@ -55,10 +68,10 @@ for f, w, nbr, order, n_out, rules in calls:
     seen.add(key)
     packed = sp.pack_weights(w)
     row = []
-    _lib.call_nostream("glx_sconv_set_variant", -1)
+    _set_variant(-1)
     ref_out = orig(f, w, None, nbr, order, n_out, packed=packed)
     for v in variants:
-        _lib.call_nostream("glx_sconv_set_variant", v)
+        _set_variant(v)
         ts = []
         try:
             got = orig(f, w, None, nbr, order, n_out, packed=packed)
@@ -88,7 +101,7 @@ for f, w, nbr, order, n_out, rules in calls:
             row.append(float(np.median(ts[2:])))
         except Exception as ex:  # variant does not fit LDS
             row.append(float("nan"))
-    _lib.call_nostream("glx_sconv_set_variant", -1)
+    _set_variant(-1)
     if os.environ.get("TILE_MAP"):
         # the default kernel with the work-balanced block -> tile map of this rule table
         nt = (n_out + 63) // 64

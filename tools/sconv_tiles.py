@@ -11,6 +11,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from glenet_amd import _lib, backbone as gb, synth  # noqa: E402
 from glenet_amd.spconv import core as sp  # noqa: E402
 
+
+def _set_variant(v):
+    """The tile-shape sweep variants (2-42, 60 / 61) were removed from the product library in round 6 (every one of them measured
+    and rejected: profiles/LABBOOK_r01_r04.md, r05_sconv_bound.md); on a library without the knob only the default runs."""
+    try:
+        fn = _lib.load().glx_sconv_set_variant
+    except AttributeError:
+        if v not in (-1, None):
+            raise SystemExit("this library has no glx_sconv_set_variant: check out a round <= 5 tree for the sweep variants")
+        return
+    fn(int(v))
+
+
+
 K = synth.KITTI
 dev = torch.device("cuda", 0)
 frames = [synth.kitti_frame(i)[0] for i in range(4)]
@@ -37,7 +51,7 @@ sp._sconv = orig
 TR = int(os.environ.get("TR", "64"))
 NW = int(os.environ.get("NW", "4"))
 VARIANT = int(os.environ.get("VARIANT", "-1"))   # e.g. VARIANT=20 NW=8 for the column-split tile
-_lib.call_nostream("glx_sconv_set_variant", VARIANT)
+_set_variant(VARIANT)
 _lib.call_nostream("glx_sconv_set_xcd_group", int(os.environ.get("ABLATE", "0"), 0))   # 0x100 / 0x200: TRACE-build ablations
 seen = set()
 for f, w, nbr, order, n_out, rules in calls:
