@@ -103,7 +103,7 @@ def query(name, *args):
     return int(getattr(lib, name)(*[_arg(a) for a in args]))
 
 
-CONV_GRADS_IN_PLACE = os.environ.get("GLX_CONV_GRADS_IN_PLACE", "1") != "0"
+CONV_GRADS_IN_PLACE = True
 _grad_generation = [0]      # bumped by FlatAdamW.pack_grads: one lending of a parameter's gradient view per optimizer step
 
 

@@ -446,7 +446,7 @@ def no_gc():
 
 
 DEFER_WGRAD_REDUCES = os.environ.get("GLX_DEFER_WGRAD_REDUCES", "1") != "0"    # see StaticTrainStep.step
-PREPACK_WEIGHTS = os.environ.get("GLX_PREPACK", "1") != "0"
+PREPACK_WEIGHTS = True
 
 
 class StaticTrainPipeline(StaticFramePipeline):

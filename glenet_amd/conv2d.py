@@ -226,7 +226,7 @@ def run_deferred_wgrad_reduces(jobs):
 
 
 OWN_WGRAD = True
-BN_BWD_IN_DGRAD = os.environ.get("GLX_CONV3X3_BN_BWD", "1") != "0"     # _ConvPre3x3: BatchNorm backward sums in the dgrad epilogue
+BN_BWD_IN_DGRAD = True     # _ConvPre3x3: BatchNorm backward sums in the dgrad epilogue
 
 
 class _Conv3x3(torch.autograd.Function):

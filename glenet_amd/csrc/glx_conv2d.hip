@@ -976,7 +976,7 @@ static int wgrad_blocks(int Cin, int Cout, int* P_out) {
   const int nq = (Cin / 32) * (Cout / 64);
   // blocks per launch: every block leaves 72 KB of partial sums that the reduce reads back (ten layers: 2 x 377 MB per step at
   // 512 blocks); 384 measured 0.02-0.03 ms per step faster than 512 in three alternating series (256 / 320 / 448 / 768 no better)
-  static const int env_slots = getenv("GLX_CONV3X3_WGRAD_SLOTS") ? atoi(getenv("GLX_CONV3X3_WGRAD_SLOTS")) : 384;
+  static const int env_slots = 384;
   int slots = env_slots >= 64 && env_slots <= 1024 ? env_slots : 384;
   int P = slots / nq;
   P = P / 8 * 8;
@@ -1033,7 +1033,7 @@ extern "C" int glx_conv3x3_wgrad_ex(const float* x, const float* gy, int B, int 
   a.nq_ci = Cin / 32;
   a.nq = a.nq_ci * (Cout / CV_BN);
   const int blocks = wgrad_blocks(Cin, Cout, &a.P);
-  static const bool pipe = getenv("GLX_WGRAD_PIPE") ? atoi(getenv("GLX_WGRAD_PIPE")) != 0 : true;
+  static const bool pipe = true;
   if (g_wgrad_form == 2)
     hipLaunchKernelGGL(k_conv3x3_wgrad2, dim3(blocks), dim3(256), WG2_LDS, (hipStream_t)stream, a);
   else if (pipe)
@@ -1283,7 +1283,7 @@ extern "C" int glx_conv3x3_forward_ex(const float* x, int B, int H, int W, int C
     // the BWD form (input gradient + ReLU mask + BatchNorm-backward sums in the epilogue) runs six rows per tile: at seven the
     // compiler spills 13 registers of its 168 (at eight, 23); 6.05 -> 6.02 ms per step (three alternating pairs, round 5)
     // (the f16x2 form of it has room for the cost model's seven or eight: 162 / 166 registers, nothing spilled)
-    static const int th_bwd = getenv("GLX_CONV3X3_TH_BWD") ? atoi(getenv("GLX_CONV3X3_TH_BWD")) : -1;
+    static const int th_bwd = -1;
     const int thb = th_bwd >= 0 ? th_bwd : (f16 ? 0 : 6);
     if (bwd && g_conv_th == 0 && thb >= 6 && thb <= 8) th = thb;
     kern = f16 ? conv_v2_kernel<true>(bn_state != nullptr, th, pre != nullptr, bwd != nullptr)

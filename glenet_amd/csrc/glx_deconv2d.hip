@@ -390,7 +390,7 @@ static int pconv_launch(const float* x, const void* packed, float* y, int B, int
   GLX_REQUIRE(!epi || ((epi->scale == nullptr) == (epi->shift == nullptr) && epi->ldc >= 0 && epi->coff >= 0 &&
                        (epi->ldc & 3) == 0 && (epi->coff & 3) == 0),
               "glx_pconv: bad epilogue (ldc %d, coff %d)", epi ? epi->ldc : 0, epi ? epi->coff : 0);
-  static const int form = getenv("GLX_PCONV_FORM") ? atoi(getenv("GLX_PCONV_FORM")) : 2;
+  static const int form = 2;
   static bool attr_set = false;
   if (!attr_set) {
     GLX_HIP(hipFuncSetAttribute((const void*)k_pconv, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));

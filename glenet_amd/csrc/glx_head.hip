@@ -590,7 +590,7 @@ static int head_in(const float* x0, const float* x1, int c0, const float* coef0,
   }
   GLX_REQUIRE(c0 > 0 && c0 < C && c0 % 16 == 0, "%s: the first part has %d of %d channels (a multiple of 16 inside)", who, c0, C);
   GLX_REQUIRE((coef0 == nullptr) == (coef1 == nullptr), "%s: both parts or neither are transformed", who);
-  static const int quad = getenv("GLX_HEAD_WGRAD_QUAD") ? atoi(getenv("GLX_HEAD_WGRAD_QUAD")) : 1;
+  static const int quad = 1;
   *in = HeadIn{{x0, x1}, {coef0, coef1}, c0, quad};
   return GLX_OK;
 }
@@ -619,7 +619,7 @@ extern "C" int glx_head1x1_forward_parts(const float* x0, const float* x1, int c
   rc = head_lds_attr((const void*)k_head_fwd, lds);
   if (rc != GLX_OK) return rc;
   long long blocks = (M + HD_PIX - 1) / HD_PIX;
-  static const int fwd_blocks = getenv("GLX_HEAD_FWD_BLOCKS") ? atoi(getenv("GLX_HEAD_FWD_BLOCKS")) : 1024;    // the resident count (four 35 KB blocks per CU): 44.6 us; 512: 50.2, 768: 46.4, 1536: 51.5, 2048: 49.1
+  static const int fwd_blocks = 1024;    // the resident count (four 35 KB blocks per CU): 44.6 us; 512: 50.2, 768: 46.4, 1536: 51.5, 2048: 49.1
   if (blocks > fwd_blocks) blocks = fwd_blocks;
   hipLaunchKernelGGL(k_head_fwd, dim3((unsigned)blocks), dim3(HD_THREADS), lds, (hipStream_t)stream, in, (long long)M, C, hw, ho);
   GLX_LAUNCH_CHECK();
@@ -684,7 +684,7 @@ extern "C" int glx_head1x1_input_grad_bn_form(const float* const* grad, int64_t 
   // 0.31 ms either way (the weight gradient reads the same 144 MB beside it on the weight-gradient stream, the RoI branch's
   // proposal kernels on a third) and the step is 6.085 against 6.074 ms over six alternating pairs: the caller's choice
   const int v2 = form;
-  static const int v2_blocks = getenv("GLX_HEAD_DGRAD_BLOCKS") ? atoi(getenv("GLX_HEAD_DGRAD_BLOCKS")) : 512;   // two resident blocks per CU: 74 us; 768: 97, 1024: 87, 2048: 108 (per-block filter image + atomics)
+  static const int v2_blocks = 512;   // two resident blocks per CU: 74 us; 768: 97, 1024: 87, 2048: 108 (per-block filter image + atomics)
   if (v2 && c0 % 64 == 0) {       // a wave owns 64 channels: weights and sums in registers, 16 loads in flight
     const size_t lds2 = (size_t)HD_MAXO * (C + 4) * 4 + (size_t)4 * C * 4 + (size_t)C * 2 * 4 + (size_t)HD_PIX * 33 * 4;
     rc = head_lds_attr((const void*)k_head_dgrad_bn2, lds2);
@@ -697,7 +697,7 @@ extern "C" int glx_head1x1_input_grad_bn_form(const float* const* grad, int64_t 
   const size_t lds = (size_t)HD_MAXO * (C + 4) * 4 + (size_t)4 * C * 4 + (size_t)4 * C * 2 * 4;
   rc = head_lds_attr((const void*)k_head_dgrad_bn, lds);
   if (rc != GLX_OK) return rc;
-  static const int v1_blocks = getenv("GLX_HEAD_DGRAD_BLOCKS0") ? atoi(getenv("GLX_HEAD_DGRAD_BLOCKS0")) : 2048;
+  static const int v1_blocks = 2048;
   if (blocks > v1_blocks) blocks = v1_blocks;
   hipLaunchKernelGGL(k_head_dgrad_bn, dim3((unsigned)blocks), dim3(HD_THREADS), lds, (hipStream_t)stream, hg, (long long)M, hw, bb);
   GLX_LAUNCH_CHECK();

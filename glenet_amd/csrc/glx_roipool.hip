@@ -530,7 +530,7 @@ extern "C" int glx_pos_pool_forward_out(const float* feats, int N, int C, const 
   return GLX_OK;
 }
 
-static int g_rp_bwd_agg = getenv("GLX_RP_BWD_AGG") ? (atoi(getenv("GLX_RP_BWD_AGG")) != 0) : 1;
+static int g_rp_bwd_agg = 1;
 // 1 (default): the feature gradient through the per-block LDS table; 0: one global atomic per (point, channel).  Returns the previous.
 extern "C" int glx_pos_pool_set_backward_form(int aggregate) {
   const int old = g_rp_bwd_agg;

@@ -1272,11 +1272,7 @@ extern "C" int glx_sconv_set_trace(void* trace) {
   g_sconv_trace = (long long*)trace;
   return GLX_OK;
 }
-static int env_xcd_group() {
-  const char* e = getenv("GLX_SCONV_XCD_GROUP");
-  return e ? atoi(e) : 0;
-}
-static int g_sconv_xcd_group = env_xcd_group();
+static int g_sconv_xcd_group = 0;
 extern "C" int glx_sconv_set_xcd_group(int g) {
   g_sconv_xcd_group = g;
   return GLX_OK;
@@ -2837,7 +2833,7 @@ extern "C" int glx_sconv_wgrad(const float* in, int N_in, const float* grad_out,
     return GLX_EWORKSPACE;
   }
   auto okc = [](int c) { return c == 16 || c == 32 || c == 64 || c == 128; };
-  if ((okc(Cin) || Cin == 4 || Cin == 8) && okc(Cout) && !getenv("GLX_WGRAD_SCALAR")) {
+  if ((okc(Cin) || Cin == 4 || Cin == 8) && okc(Cout)) {
     // submanifold table with a centre offset: the resident-block budget S*K is split so that the
     // centre gets WGM_CENTER_FACTOR times the slices of the others
     // (measured: 29 -> 23 us for 4x16 / 16x16, where a block is one short latency chain; the wide

@@ -123,25 +123,25 @@ def _own_strided_ok(x, w, stride, padding, dilation, groups, bias):
             and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.is_contiguous(memory_format=torch.channels_last))
 
 
-OWN_STRIDED_FORWARD = os.environ.get("GLX_OWN_S2_FWD", "1") != "0"
-SPLIT_CONV_BACKWARD = os.environ.get("GLX_SPLIT_CONV_BWD", "1") != "0"
-OWN_CONV3X3 = os.environ.get("GLX_OWN_CONV3X3", "1") != "0"     # 3x3 / stride 1 layers on csrc/glx_conv2d.hip
-OWN_DECONV = os.environ.get("GLX_OWN_DECONV", "1") != "0"       # the deblocks' transposed convolutions on csrc/glx_deconv2d.hip
+OWN_STRIDED_FORWARD = True
+SPLIT_CONV_BACKWARD = True
+OWN_CONV3X3 = True     # 3x3 / stride 1 layers on csrc/glx_conv2d.hip
+OWN_DECONV = True       # the deblocks' transposed convolutions on csrc/glx_deconv2d.hip
 BEV_FIRST_KEY = "bev_first"      # indice_key of the first BEV layer's rule table (spconv.core.PlannedConv)
-SPARSE_FIRST_BEV_LAYER = os.environ.get("GLX_BEV_SPARSE_FIRST", "1") != "0"   # see BEVBackbone._first_layer_sparse
-FUSE_BN_IN_CONV3X3 = os.environ.get("GLX_CONV3X3_BN", "1") != "0"    # ... with the next BatchNorm's statistics in the epilogue
+SPARSE_FIRST_BEV_LAYER = True   # see BEVBackbone._first_layer_sparse
+FUSE_BN_IN_CONV3X3 = True    # ... with the next BatchNorm's statistics in the epilogue
 # ... and a layer's BatchNorm + ReLU applied ON LOAD by the next 3x3 layer of the block (forward and weight gradient read the
 # raw convolution output through scale / shift; the next layer's backward carries this BatchNorm's backward): the normalised
 # map of the inner layers of a block is never written (base_bev_backbone.py:36-49)
-BN_ON_LOAD = os.environ.get("GLX_CONV3X3_BN_ON_LOAD", "1") != "0"
-STRIDED_BN_STATS = os.environ.get("GLX_BEV_S2_BN_STATS", "1") != "0"          # a block's strided layer: statistics in its epilogue
-FIRST_LAYER_BN_STATS = os.environ.get("GLX_BEV_FIRST_BN_STATS", "1") != "0"   # first BEV layer (sparse): statistics in its epilogue
-HEAD_DGRAD_BN = os.environ.get("GLX_HEAD_DGRAD_BN", "1") != "0"        # ... and their backward sums in the head's input gradient
+BN_ON_LOAD = True
+STRIDED_BN_STATS = True          # a block's strided layer: statistics in its epilogue
+FIRST_LAYER_BN_STATS = True   # first BEV layer (sparse): statistics in its epilogue
+HEAD_DGRAD_BN = True        # ... and their backward sums in the head's input gradient
 # kernel form of that launch (glx_head1x1_input_grad_bn_form): 1 = a wave owns 64 channels -- 74 us against 109 alone, no
 # difference on the recorded step (DESIGN 9.22 viii)
-HEAD_DGRAD_FORM = int(os.environ.get("GLX_HEAD_DGRAD_V2", "1"))
-HEAD_BN_ON_LOAD = os.environ.get("GLX_HEAD_BN_ON_LOAD", "1") != "0"    # deblocks' BatchNorm + ReLU applied by the anchor head's kernels
-DECONV_BN_STATS = os.environ.get("GLX_DECONV_BN_STATS", "1") != "0"   # deblocks: BatchNorm statistics in the deconv's epilogue
+HEAD_DGRAD_FORM = 1
+HEAD_BN_ON_LOAD = True    # deblocks' BatchNorm + ReLU applied by the anchor head's kernels
+DECONV_BN_STATS = True   # deblocks: BatchNorm statistics in the deconv's epilogue
 
 
 def _pair(v):
@@ -271,7 +271,7 @@ class BEVBackbone(nn.Module):
             y = core.fused_train_bn_cat(bns, rows, True)
         return y.view(b, h, w, y.shape[1]).permute(0, 3, 1, 2)
 
-    FUSE_UPS_CAT = os.environ.get("GLX_BEV_CAT_FUSE", "1") != "0"
+    FUSE_UPS_CAT = True
 
     def _first_layer_sparse(self, st):
         """blocks[0]'s ZeroPad2d(1) + Conv2d(C * D -> c, 3) applied to the SPARSE tensor the BEV map is the dense
@@ -331,7 +331,7 @@ class BEVBackbone(nn.Module):
 
     # ---- inference: every eval-mode BatchNorm2d (+ ReLU) folded into the epilogue of the convolution in front of it,
     # the deblocks write their slices of the concatenated map, the first layer runs on the sparse tensor
-    FUSE_EVAL = os.environ.get("GLX_BEV_EVAL_FUSE", "1") != "0"
+    FUSE_EVAL = True
 
     def _eval_plan(self, data_dict):
         """[(kind, conv, bn)] per block + the deblocks, or None when the module is not of the reference's form."""
@@ -809,7 +809,7 @@ class AnchorHead(nn.Module):
             data_dict["dir_cls_preds"] = parts[2].contiguous()
         return data_dict
 
-    OWN_HEAD = os.environ.get("GLX_OWN_HEAD", "1") != "0"
+    OWN_HEAD = True
 
     def _own(self, x):
         convs = [self.conv_cls, self.conv_box] + ([self.conv_dir_cls] if self.conv_dir_cls is not None else [])
@@ -911,7 +911,7 @@ class _SplitKLinearFn(torch.autograd.Function):
 
 
 DEFERRED_FC_WGRADS = None     # a list while a staged backward collects the FC towers' weight-gradient jobs
-GRADS_IN_PLACE = os.environ.get("GLX_GRADS_IN_PLACE", "1") != "0"      # FC weight gradients straight into the optimizer's buffer
+GRADS_IN_PLACE = True      # FC weight gradients straight into the optimizer's buffer
 DEFERRED_FC_SAME_STREAM = False   # the collector will run the jobs on the stream that creates them: no events
 
 
@@ -923,7 +923,7 @@ def _deferred_event(device):
     return ev
 
 
-FC_WGRADS_GROUPED = os.environ.get("GLX_FC_WGRADS_GROUPED", "1") != "0"   # the towers' 256 x 256 weight gradients in one launch
+FC_WGRADS_GROUPED = True   # the towers' 256 x 256 weight gradients in one launch
 
 
 def _grad_target(w):
@@ -1022,8 +1022,8 @@ class FCTower(nn.Sequential):
 
 
 # ---- the towers behind the first Linear as one launch per direction (csrc/glx_fctower.hip)
-FC_TOWER_FUSED = os.environ.get("GLX_FC_TOWER", "1") != "0"
-FC_TOWER_COOPERATIVE = os.environ.get("GLX_FC_TOWER_COOP", "1") != "0"     # 0: one launch per phase (5 forward, 4 backward)
+FC_TOWER_FUSED = True
+FC_TOWER_COOPERATIVE = True     # 0: one launch per phase (5 forward, 4 backward)
 _FCT_SUPPORT = {}
 
 
@@ -1387,9 +1387,9 @@ class PointFeat(nn.Module):
                 and core.USE_FUSED_TRAIN_BN and all(ok(m.num_features) and m.affine and m.momentum is not None
                                                     for m in (self.bn1, self.bn2, self.bn3)))
 
-    USE_POINTMAX = os.environ.get("GLX_CVAE_POINTMAX", "1") != "0"
+    USE_POINTMAX = True
     ROW_CHUNKS = 128
-    ROWS_MAX = int(os.environ.get("GLX_CVAE_ROWS_MAX", 1 << 22))
+    ROWS_MAX = 1 << 22
 
     @classmethod
     def _rows_linear(cls, x2d, conv):

@@ -121,7 +121,7 @@ def proposal_layer(batch_box_preds, batch_cls_preds, nms_pre_maxsize, nms_post_m
 BATCHED_PROPOSALS = True
 
 
-FUSED_TOPK = os.environ.get("GLX_TOPK", "1") != "0"
+FUSED_TOPK = True
 
 
 def topk_desc(scores, k):
@@ -153,7 +153,7 @@ def topk_desc(scores, k):
     return top, order
 
 
-MULTI_BLOCK_TOPK = os.environ.get("GLX_TOPK_MULTI", "1") != "0"
+MULTI_BLOCK_TOPK = True
 _TOPK_WS = {}
 
 

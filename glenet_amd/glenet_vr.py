@@ -141,13 +141,13 @@ class VoxelRCNNKLHead(rg.RoIGridPool):
 
 OVERLAP_ROI = os.environ.get("GLX_OVERLAP_ROI", "1") != "0"
 STAGE_CUTS = os.environ.get("GLX_STAGE_CUTS", "1") != "0"
-DEFER_FC_WGRADS = os.environ.get("GLX_DEFER_FC_WGRADS", "1") != "0"
-FC_WGRADS_BEHIND_ROI = os.environ.get("GLX_FC_WGRADS_BEHIND_ROI", "1") != "0"      # see StagedLoss.backward
+DEFER_FC_WGRADS = True
+FC_WGRADS_BEHIND_ROI = True      # see StagedLoss.backward
 # the slab / partial sums of the sparse and the BEV 3x3 weight gradients: one launch each at the end of the backward pass
 # (spconv.core.DEFERRED_WGRAD_REDUCES, conv2d.DEFERRED_WGRAD_REDUCES) instead of one ~8 us launch per layer on the main chain
 DEFER_WGRAD_REDUCES = os.environ.get("GLX_DEFER_WGRAD_REDUCES", "1") != "0"
 # the RoI head's three loss terms as one launch / one autograd node (losses.roi_head_losses); 0 = the three entry points
-ROI_LOSSES_ONE_LAUNCH = os.environ.get("GLX_ROI_LOSSES_ONE_LAUNCH", "1") != "0"
+ROI_LOSSES_ONE_LAUNCH = True
 
 
 class StagedLoss:
@@ -274,7 +274,7 @@ class GLENetVR(nn.Module):
         self.backbone_2d = dp.BEVBackbone(256)
         self.backbone_2d.head_on_load = bool(bev_channels_last)      # its reader is self.dense_head (dense_path._Head1x1Parts)
         # conv_out's only reader is the BEV backbone's first layer (a sparse convolution): BatchNorm + ReLU on load there
-        self.backbone_3d.conv_out.leave_pending = bool(self.map_to_bev_module.defer) and os.environ.get("GLX_CONV_OUT_ON_LOAD", "1") != "0"
+        self.backbone_3d.conv_out.leave_pending = bool(self.map_to_bev_module.defer) and True
         if self.map_to_bev_module.defer:     # its rule table is planned with the sparse backbone's
             d = 256 // self.backbone_3d.num_point_features
             self.backbone_3d.extra_plan = (gb.spconv.core.PlannedConv(dp.BEV_FIRST_KEY, (d, 3, 3), (d, 1, 1), (0, 1, 1),

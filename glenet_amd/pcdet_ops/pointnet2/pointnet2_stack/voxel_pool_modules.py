@@ -170,7 +170,7 @@ def pos_pool(feats, mlp_pos, idx, xyz, new_xyz):
 # Off by default: measured on the GLENet-VR step (A/B on one box) 6.475 ms with it against 6.419 without -- the exchange of
 # the pooled row between a point's lanes and the statistics tail (atomics, ticket, last-block finalize) cost the pooling
 # launch more than the GEMM and the statistics pass they replace (14 + 13 us per scale).  Kept for the record and its test.
-POS_POOL_OUT = os.environ.get("GLX_POS_POOL_OUT", "0") != "0"
+POS_POOL_OUT = False
 
 
 def pos_pool_out_supported(feats, mlp_pos, mlp_out):
@@ -205,7 +205,7 @@ def pos_pool_supported(feats, mlp_pos):
             and isinstance(bn, (nn.BatchNorm1d, nn.BatchNorm2d)))
 
 
-ROWS_LINEAR_FN = os.environ.get("GLX_ROWS_LINEAR_FN", "1") != "0"
+ROWS_LINEAR_FN = True
 
 
 class _RowsLinearFn(torch.autograd.Function):
@@ -231,7 +231,7 @@ class _RowsLinearFn(torch.autograd.Function):
         return gx, gw
 
 
-ROWS_CONV_BN = os.environ.get("GLX_ROWS_CONV_BN", "1") != "0"
+ROWS_CONV_BN = True
 
 
 class RowsConvBN(torch.autograd.Function):

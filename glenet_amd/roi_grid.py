@@ -235,7 +235,7 @@ class RoIGridPool(nn.Module):
 
     # the scales' voxel queries in one launch: built, bit-identical, measured on the step 6.145 / 6.094 ms against 6.086 /
     # 6.078 per scale (the three launches already overlap the towers of the previous scale): off
-    GROUPED_QUERY = os.environ.get("GLX_ROI_GROUPED_QUERY", "0") == "1"
+    GROUPED_QUERY = False
 
     # ---- inference fast path: 1 + 3 launches per scale (csrc/glx_points.hip) -- grid points and
     # their voxel coordinates in one kernel, then per scale mlp_in (one GEMM), the voxel query and

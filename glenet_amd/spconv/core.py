@@ -461,7 +461,7 @@ def _sconv(features, weight_kio, bias, nbr, tile_order, n_out, packed=None, rule
 # sum dz, sum dz xhat, finalize) and parks (dz, coef3, dgamma, dbeta) on it; FusedBNApply.backward, handed that very dz,
 # only applies the transform.  Any other gradient (several consumers: autograd hands over a sum) takes the full path --
 # the mask is idempotent, so an already masked contribution inside the sum is still right.
-BN_BWD_IN_DGRAD = os.environ.get("GLX_SCONV_BN_BWD", "1") != "0"
+BN_BWD_IN_DGRAD = True
 
 
 def _pre_arg(pre, cin):
@@ -475,7 +475,7 @@ def _pre_arg(pre, cin):
 # next convolution -- it transforms y on load (glx_sconv_opts.prologue), its weight gradient does the same
 # (glx_sconv_wgrad_pairs_ex) and its backward carries the BatchNorm's.  The producer leaves a `_pending` transform on its
 # SparseConvTensor; anything else that reads `.features` materialises it (FusedBNApply) then.  GLX_SCONV_BN_ON_LOAD=0: off.
-BN_ON_LOAD = os.environ.get("GLX_SCONV_BN_ON_LOAD", "1") != "0"
+BN_ON_LOAD = True
 
 
 class PendingBN:
@@ -947,7 +947,7 @@ def _bn_affine(bn):
 # accumulators of the statistics kernels (csrc/glx_bn.hip: k_bn_stats): zero-filled once, self-cleaning, one per
 # (device, stream) -- launches that share a buffer must be ordered by their stream.  GLX_BN_STATE=0: the fixed-order
 # three-launch scheme.
-USE_BN_STATE = os.environ.get("GLX_BN_STATE", "1") != "0"
+USE_BN_STATE = True
 _BN_STATES = {}
 
 
@@ -1101,7 +1101,7 @@ def conv_bn_fusable(conv, bn, x):
 # epilogue against 10.29 without (two alternating runs on one box).  The first measurement (11.79 / 11.77 / 11.68 against
 # 11.67 / 11.68 / 11.68 ms) had autograd materialising zero "gradients" for the three statistics outputs of every conv --
 # 36 fill launches per step that ate the 12 saved statistics launches; set_materialize_grads(False) removed them.
-FUSE_BN_STATS_IN_CONV = os.environ.get("GLX_BN_IN_CONV", "1") != "0"
+FUSE_BN_STATS_IN_CONV = True
 
 
 class FusedBNReLUCat(Function):
@@ -1206,19 +1206,19 @@ def ctypes_float(v):
     return ctypes.c_float(float(v))
 
 
-USE_FUSED_TRAIN_BN = os.environ.get("GLX_FUSED_BN", "1") != "0"
+USE_FUSED_TRAIN_BN = True      # (False: torch's BatchNorm1d layer by layer; exact-shape eager steps only)
 # work-balanced block -> tile maps for the sparse-conv kernels (RuleSet.tile_map); off with GLX_TILE_MAP=0
-USE_TILE_MAP = os.environ.get("GLX_TILE_MAP", "1") != "0"
-USE_PAIR_LISTS = os.environ.get("GLX_PAIR_LISTS", "1") != "0"      # weight gradients over per-offset pair lists
-INVERSE_TABLES_IN_PLAN = os.environ.get("GLX_INVERSE_TABLES_IN_PLAN", "1") != "0"
-PAIR_LISTS_IN_PLAN = os.environ.get("GLX_PAIR_LISTS_IN_PLAN", "1") != "0"   # built behind the rule tables (0: by the first weight gradient)
+USE_TILE_MAP = True
+USE_PAIR_LISTS = True      # weight gradients over per-offset pair lists
+INVERSE_TABLES_IN_PLAN = True
+PAIR_LISTS_IN_PLAN = True   # built behind the rule tables (0: by the first weight gradient)
 TILE_MAP_MIN_ROWS = 64 * 256       # fewer tiles than CUs: nothing to balance
 # building a map costs two small launches (~8 us): worth it for the rule tables of submanifold stacks
 # (2-3 convs share one) with at least 32x32 weights per offset -- on the KITTI batch that is
 # subm2..subm4, which save 13 / 19 / 7 us per frame; the thin first stack and the single-use strided
 # tables would save 1-5 us
-TILE_MAP_MIN_WEIGHTS = int(os.environ.get("GLX_TILE_MAP_MIN_WEIGHTS", 32 * 32))
-TILE_MAP_SUBM_ONLY = os.environ.get("GLX_TILE_MAP_ALL", "0") == "0"
+TILE_MAP_MIN_WEIGHTS = 32 * 32
+TILE_MAP_SUBM_ONLY = True
 # stream for the weight-gradient kernels of SparseConvFunction.backward (None = the current one).
 # Set by StaticTrainPipeline around its backward pass; the setter waits for it afterwards.
 WGRAD_STREAM = None
