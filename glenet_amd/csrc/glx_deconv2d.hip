@@ -666,3 +666,33 @@ extern "C" int glx_conv3x3s2_forward(const float* x, int B, int H, int W, int Ci
                                      void* stream) {
   return glx_conv3x3s2_forward_ex(x, B, H, W, Cin, packed_fwd, Cout, y, nullptr, stream);
 }
+
+// ------------------------------------------------------------------------------------------------ gradients of the strided layer
+// ZeroPad2d(1) + Conv2d(c, 2c, 3, stride 2) (base_bev_backbone.py:33-38) is the stride-1 convolution sampled at the even pixels, so
+// its gradients are the stride-1 kernels' (glx_conv3x3_forward on the flipped pack, glx_conv3x3_wgrad) on the output gradient
+// spread back over the stride-1 map: out (B, 2H, 2W, C) = gy (B, H, W, C) at the even pixels, zero elsewhere.  One pass, 16-byte
+// pieces (C % 4 == 0).
+__global__ __launch_bounds__(256) void k_spread2(const float* __restrict__ gy, float* __restrict__ out, int B, int H, int W, int C) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;         // one 16-byte piece of `out`
+  const int c4 = C >> 2;
+  const long long n = (long long)B * 2 * H * 2 * W * c4;
+  if (e >= n) return;
+  const int c = (int)(e % c4);
+  long long p = e / c4;
+  const int x = (int)(p % (2 * W));
+  p /= 2 * W;
+  const int y = (int)(p % (2 * H));
+  const int b = (int)(p / (2 * H));
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!((x | y) & 1)) v = reinterpret_cast<const float4*>(gy)[(((long long)b * H + (y >> 1)) * W + (x >> 1)) * c4 + c];
+  reinterpret_cast<float4*>(out)[e] = v;
+}
+
+extern "C" int glx_spread_stride2(const float* gy, int B, int H, int W, int C, float* out, void* stream) {
+  GLX_REQUIRE(gy && out, "glx_spread_stride2: null pointer");
+  GLX_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "glx_spread_stride2: (%d, %d, %d, %d), C %% 4", B, H, W, C);
+  const long long n = (long long)B * 2 * H * 2 * W * (C / 4);
+  hipLaunchKernelGGL(k_spread2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gy, out, B, H, W, C);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

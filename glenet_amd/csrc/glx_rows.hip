@@ -544,3 +544,179 @@ extern "C" int glx_linear_wgrad_multi(int njobs, const float* const* x, const fl
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ the wide first Linear
+// VoxelRCNNHead's first shared layer (voxelrcnn_head.py:40-52: Linear(6^3 * 96 = 20 736, 256, bias=False)) on R = 512 RoI rows:
+// 5.4 GFLOP per direction, the last library GEMMs of the training step until round 6.  Exact fp32 products on v_mfma_f32_16x16x4_f32
+// (that instruction takes ONE scalar per lane and operand: any operand layout feeds it, no transposes), operands straight from L2
+// as 16-byte loads, fixed summation order.
+//   forward   y (R, N)  = x (R, K) w (N, K)^T     split along K over gridDim.y slabs -> partial tiles, summed by k_lin_reduce
+//   input gr. gx (R, K) = dz (R, N) w (N, K)      a wave owns 16 rows x 64 columns, the contraction (N = 256) runs in the wave
+//   weight gr. dW (N, K) = dz^T x                 glx_linear_wgrad_multi above (one job)
+// Lane l = (i = l & 15, q = l >> 4).  A 16-byte load along the contraction index gives a lane the scalars of FOUR k-steps
+// (k = k0 + 4 q + s, s = 0..3): both operands of the forward are read that way (rows of x, rows of w), and dz in the input
+// gradient; w in the input gradient is read along its rows' K (four consecutive output columns = four interleaved column
+// tiles), one load per k-step.
+#define LIN_TRIPS 2        // 16-k trips whose loads are issued together (forward)
+__global__ __launch_bounds__(256) void k_lin_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ part,
+                                                 int R, int N, int K, int kslab) {
+  __shared__ float s_acc[16 * 4 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+  const int tn = N / 64, tile = blockIdx.x;
+  const int r0 = (tile / tn) * 64, n0 = (tile % tn) * 64;
+  const int k_begin = blockIdx.y * kslab, k_end = min(K, k_begin + kslab);
+  ft4 acc[4][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[e][f] = ft4{0.f, 0.f, 0.f, 0.f};
+  const ft4 zero = ft4{0.f, 0.f, 0.f, 0.f};
+  const float* __restrict__ xp[4];
+  const float* __restrict__ wp[4];
+  bool xok[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int row = r0 + 16 * e + i;
+    xok[e] = row < R;
+    xp[e] = x + (long long)(xok[e] ? row : R - 1) * K + 4 * q;
+    wp[e] = w + (long long)(n0 + 16 * e + i) * K + 4 * q;
+  }
+  // this wave's trips: k_begin + 16 (wave + 4 t), a trip = 16 consecutive k (four MFMA k-steps)
+  for (int k = k_begin + 16 * wave * LIN_TRIPS; k < k_end; k += 16 * 4 * LIN_TRIPS) {
+    ft4 a[LIN_TRIPS][4], b[LIN_TRIPS][4];
+#pragma unroll
+    for (int u = 0; u < LIN_TRIPS; ++u) {
+      const int kk = k + 16 * u;
+      const bool kok = kk + 4 * q + 3 < k_end;            // K and the slabs are multiples of 16: a trip is whole or absent
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const ft4 av = *reinterpret_cast<const ft4*>(xp[e] + (kok ? kk : k_begin));
+        const ft4 bv = *reinterpret_cast<const ft4*>(wp[e] + (kok ? kk : k_begin));
+        a[u][e] = (kok && xok[e]) ? av : zero;
+        b[u][e] = kok ? bv : zero;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < LIN_TRIPS; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int f = 0; f < 4; ++f) acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e][s], b[u][f][s], acc[e][f], 0, 0, 0);
+  }
+  // the four waves' sums meet in LDS in wave order (bitwise reproducible)
+  for (int wv = 1; wv < 4; ++wv) {
+    __syncthreads();
+    if (wave == wv) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) s_acc[((e * 4 + f) * 4 + t) * 64 + lane] = acc[e][f][t];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[e][f][t] += s_acc[((e * 4 + f) * 4 + t) * 64 + lane];
+    }
+  }
+  if (wave == 0) {
+    // acc[e][f][t] = y[r0 + 16 e + 4 q + t][n0 + 16 f + i] (partial over this slab)
+    float* __restrict__ dst = part + (long long)blockIdx.y * R * N;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = r0 + 16 * e + 4 * q + t;
+        if (row < R) {
+#pragma unroll
+          for (int f = 0; f < 4; ++f) dst[(long long)row * N + n0 + 16 * f + i] = acc[e][f][t];
+        }
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_lin_reduce(const float* __restrict__ part, int slabs, long long n, float* __restrict__ y) {
+  const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= n) return;
+  ft4 s = *reinterpret_cast<const ft4*>(part + e);
+  for (int k = 1; k < slabs; ++k) s += *reinterpret_cast<const ft4*>(part + (long long)k * n + e);
+  *reinterpret_cast<ft4*>(y + e) = s;
+}
+
+__global__ __launch_bounds__(256) void k_lin_dgrad(const float* __restrict__ dz, const float* __restrict__ w, float* __restrict__ gx,
+                                                   int R, int N, int K) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+  const int tk = K / 64, tile = blockIdx.x;
+  const int r0 = (tile / tk) * 64 + 16 * wave, c0 = (tile % tk) * 64;
+  const int row = r0 + i;
+  const bool rok = row < R;
+  const float* __restrict__ ap = dz + (long long)(rok ? row : R - 1) * N + 4 * q;      // dz[row][n0 + 4 q + s]
+  const float* __restrict__ bp = w + c0 + 4 * i;                                       // w[n][c0 + 4 i .. + 3]: column tiles {4 i + f}
+  ft4 acc[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) acc[f] = ft4{0.f, 0.f, 0.f, 0.f};
+  const ft4 zero = ft4{0.f, 0.f, 0.f, 0.f};
+  for (int n0 = 0; n0 < N; n0 += 32) {                       // two trips of 16 n per pass
+    ft4 a[2], b[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const ft4 av = *reinterpret_cast<const ft4*>(ap + n0 + 16 * u);
+      a[u] = rok ? av : zero;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) b[u][s] = *reinterpret_cast<const ft4*>(bp + (long long)(n0 + 16 * u + 4 * q + s) * K);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][s], b[u][s][f], acc[f], 0, 0, 0);
+  }
+  // acc[f][t] = gx[r0 + 4 q + t][c0 + 4 i + f]: a lane's four column tiles are four consecutive floats
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int orow = r0 + 4 * q + t;
+    if (orow < R) *reinterpret_cast<ft4*>(gx + (long long)orow * K + c0 + 4 * i) = ft4{acc[0][t], acc[1][t], acc[2][t], acc[3][t]};
+  }
+}
+
+extern "C" size_t glx_linear_wide_workspace_bytes(int rows, int N, int K) {
+  const int slabs = K >= 4096 ? (K % 27 == 0 && (K / 27) % 16 == 0 ? 27 : 16) : 1;
+  return glx_align((size_t)slabs * rows * N * sizeof(float)) + 256;
+}
+
+// y (rows, N) = x (rows, K) @ w (N, K)^T.  N % 64 == 0, K % 16 == 0; workspace: glx_linear_wide_workspace_bytes.
+extern "C" int glx_linear_wide_forward(const float* x, const float* w, float* y, int rows, int N, int K, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(x && w && y && workspace, "glx_linear_wide_forward: null pointer");
+  GLX_REQUIRE(rows >= 1 && N > 0 && K > 0 && N % 64 == 0 && K % 16 == 0, "glx_linear_wide_forward: rows %d, N %d %% 64, K %d %% 16",
+              rows, N, K);
+  int slabs = K >= 4096 ? (K % 27 == 0 && (K / 27) % 16 == 0 ? 27 : 16) : 1;
+  int kslab = glx_divup(glx_divup(K, slabs), 16) * 16;
+  slabs = glx_divup(K, kslab);
+  GLX_REQUIRE(workspace_bytes >= (size_t)slabs * rows * N * sizeof(float), "glx_linear_wide_forward: workspace %zu bytes", workspace_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_lin_fwd, dim3(glx_divup(rows, 64) * (N / 64), slabs), dim3(256), 0, st, x, w, (float*)workspace, rows, N, K, kslab);
+  GLX_LAUNCH_CHECK();
+  const long long n = (long long)rows * N;
+  hipLaunchKernelGGL(k_lin_reduce, dim3((unsigned)glx_divup(n, 1024)), dim3(256), 0, st, (const float*)workspace, slabs, n, y);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// gx (rows, K) = dz (rows, N) @ w (N, K).  K % 64 == 0, N % 32 == 0.
+extern "C" int glx_linear_wide_input_grad(const float* dz, const float* w, float* gx, int rows, int N, int K, void* stream) {
+  GLX_REQUIRE(dz && w && gx, "glx_linear_wide_input_grad: null pointer");
+  GLX_REQUIRE(rows >= 1 && N > 0 && K > 0 && K % 64 == 0 && N % 32 == 0, "glx_linear_wide_input_grad: rows %d, N %d %% 32, K %d %% 64",
+              rows, N, K);
+  hipLaunchKernelGGL(k_lin_dgrad, dim3(glx_divup(rows, 64) * (K / 64)), dim3(256), 0, (hipStream_t)stream, dz, w, gx, rows, N, K);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

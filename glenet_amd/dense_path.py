@@ -108,6 +108,29 @@ class _OwnStridedForward(torch.autograd.Function):
     def backward(ctx, gy, *_):
         if gy is None:
             return None, None, None
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        if OWN_STRIDED_GRADS and gy.dtype == torch.float32 and w.shape[0] % 64 == 0 and w.shape[1] % 32 == 0:
+            # the layer is the stride-1 convolution sampled at the even pixels: its gradients are the stride-1 kernels' on the
+            # output gradient spread over the stride-1 map (csrc/glx_deconv2d.hip: glx_spread_stride2) -- no library call
+            from ._lib import call
+            from .spconv import core
+            b, cout, ho, wo = gy.shape
+            up = torch.empty((b, cout, 2 * ho, 2 * wo), dtype=torch.float32, device=gy.device, memory_format=torch.channels_last)
+            call("glx_spread_stride2", gy, b, ho, wo, cout, up)
+            gx = gw = None
+            if ctx.needs_input_grad[1]:
+                side = core.WGRAD_STREAM
+                if side is not None:
+                    side.wait_stream(torch.cuda.current_stream(x.device))
+                    for t in (x, up, w):
+                        t.record_stream(side)
+                with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                    gw = own_conv.wgrad(x.detach(), up, w)
+            if ctx.needs_input_grad[0]:
+                _, bwd = own_conv.packs(w)
+                gx = own_conv._run(up, bwd, int(w.shape[1]))
+            return gx, gw, None
         # (x, w, bias, ...) of _ConvSplitBackward: needs_input_grad has two entries here, the helper reads [0], [1] and [2].
         # A plain namespace, not a class: a class object sits in a reference cycle and would keep the saved activation --
         # and the whole graph above it -- alive until the collector runs.
@@ -124,6 +147,11 @@ def _own_strided_ok(x, w, stride, padding, dilation, groups, bias):
 
 
 OWN_STRIDED_FORWARD = True
+# ... and its two gradients on the stride-1 kernels over the spread output gradient (no library call; exact like them).  OFF by
+# default: three of four pixels of the spread map are zeros that the stride-1 kernels multiply all the same -- 5.23 -> 5.28 ms per
+# step against the library's two launches (three alternating runs per arm, profiles/r06_summary.md); set True for a step without
+# a vendor convolution.
+OWN_STRIDED_GRADS = False
 SPLIT_CONV_BACKWARD = True
 OWN_CONV3X3 = True     # 3x3 / stride 1 layers on csrc/glx_conv2d.hip
 OWN_DECONV = True       # the deblocks' transposed convolutions on csrc/glx_deconv2d.hip
@@ -862,6 +890,34 @@ class AnchorHead(nn.Module):
         return data_dict
 
 
+OWN_WIDE_LINEAR = True      # the 20 736-wide first RoI Linear on csrc/glx_rows.hip (exact fp32 MFMA products) instead of library GEMMs
+
+
+def _wide_linear_ok(x, w):
+    """The shapes glx_linear_wide_* / glx_linear_wgrad_multi take: dense fp32 device matrices, a long K, few rows."""
+    return (OWN_WIDE_LINEAR and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 2 and w.dim() == 2
+            and x.is_contiguous() and w.is_contiguous() and x.shape[1] == w.shape[1] and x.shape[1] >= 4096 and x.shape[1] % 64 == 0
+            and w.shape[0] % 64 == 0 and 1 <= x.shape[0] <= 4096)
+
+
+def wide_linear_forward(x, w):
+    rows, k = x.shape
+    n = w.shape[0]
+    y = torch.empty((rows, n), dtype=torch.float32, device=x.device)
+    nb = _lib.query("glx_linear_wide_workspace_bytes", rows, n, k)
+    ws = _lib.workspace.get(nb, x.device)
+    _lib.call("glx_linear_wide_forward", x, w, y, rows, n, k, ws, _lib.size_arg(nb))
+    return y
+
+
+def wide_linear_input_grad(gy, w):
+    rows, n = gy.shape
+    k = w.shape[1]
+    gx = torch.empty((rows, k), dtype=torch.float32, device=gy.device)
+    _lib.call("glx_linear_wide_input_grad", gy, w, gx, rows, n, k)
+    return gx
+
+
 class _SplitKLinearFn(torch.autograd.Function):
     """y = x @ W^T for the RoI FC towers (a few hundred rows) with the products hipBLASLt's heuristics starve split
     along K into batched GEMMs:
@@ -873,6 +929,8 @@ class _SplitKLinearFn(torch.autograd.Function):
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
         k = x.shape[1]
+        if _wide_linear_ok(x, w):
+            return wide_linear_forward(x, w)
         split = next((s_ for s_ in (32, 27, 24, 16, 12, 8) if k % s_ == 0), 0) if (k >= 4096 and x.shape[0] <= 4096) else 0
         if split:
             xs = x.view(x.shape[0], split, k // split).transpose(0, 1)               # (S, R, k/S) view
@@ -886,7 +944,7 @@ class _SplitKLinearFn(torch.autograd.Function):
         gy = gy.contiguous()
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = gy @ w
+            gx = wide_linear_input_grad(gy, w) if _wide_linear_ok(x, w) else gy @ w
         if ctx.needs_input_grad[1]:
             if DEFERRED_FC_WGRADS is not None and w.is_leaf:
                 # a leaf of the backward pass: a staged training step computes it later, on the main stream's idle time,
@@ -904,6 +962,12 @@ class _SplitKLinearFn(torch.autograd.Function):
             if w.shape[0] * w.shape[1] <= 256 * 1024 else 0
         if out is not None and not (out.shape == w.shape and out.is_contiguous() and out.dtype == torch.float32):
             out = None
+        if _wide_linear_ok(x, w) and gy.is_contiguous() and gy.dtype == torch.float32:
+            # dW (N, K) = gy^T x on the towers' weight-gradient kernel (one job): 4 x 324 blocks of 64 x 64
+            dst = out if out is not None else torch.empty_like(w)
+            ptr = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
+            _lib.call("glx_linear_wgrad_multi", 1, ptr(x), ptr(gy), ptr(dst), rows, int(w.shape[1]), int(w.shape[0]))
+            return dst
         if chunks:
             parts = torch.bmm(gy.view(chunks, rows // chunks, -1).transpose(1, 2), x.view(chunks, rows // chunks, -1))
             return parts.sum(0) if out is None else torch.sum(parts, 0, out=out)
@@ -1219,7 +1283,9 @@ class FCTowersFn(torch.autograd.Function):
         g.dw_fc1, g.db_fc1, g.dw_fc2, g.db_fc2 = dw_fc1.data_ptr(), db_fc1.data_ptr(), dw_fc2.data_ptr(), db_fc2.data_ptr()
         g.scratch = scratch.data_ptr()
         _lib.call("glx_fc_tower_backward", ctypes.byref(t), ctypes.byref(g))
-        gx = dz[0] @ w0 if ctx.needs_input_grad[2] else None
+        gx = None
+        if ctx.needs_input_grad[2]:
+            gx = wide_linear_input_grad(dz[0], w0) if _wide_linear_ok(x, w0) else dz[0] @ w0
         # the Linear weight gradients: leaves, deferred when a staged step collects them
         ins = [x] + [zh[5 + l] for l in range(5)]              # layer l's input: pooled, h0, h1, h2, h1, h4
         ins[4] = zh[5 + 1]

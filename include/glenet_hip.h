@@ -822,6 +822,16 @@ int glx_rows_linear_bn_backward(const float* x, const float* z, const float* dy,
  * GEMM + reduction each. */
 int glx_linear_wgrad_multi(int njobs, const float* const* x, const float* const* gy, float* const* out, int rows, int cin, int cout,
                            void* stream);
+/* The wide first Linear of the RoI head (pcdet/models/roi_heads/voxelrcnn_head.py:40-52: nn.Linear(GRID_SIZE^3 * C, 256, bias=False)
+ * on the pooled (rows, 20 736) features), exact fp32 products (v_mfma_f32_16x16x4_f32), fixed summation order:
+ *   glx_linear_wide_forward      y (rows, N) = x (rows, K) @ w (N, K)^T      N % 64 == 0, K % 16 == 0; split along K into slabs whose
+ *                                partial tiles a second launch sums (workspace: glx_linear_wide_workspace_bytes)
+ *   glx_linear_wide_input_grad   gx (rows, K) = dz (rows, N) @ w (N, K)      K % 64 == 0, N % 32 == 0
+ * The weight gradient dz^T x is glx_linear_wgrad_multi with one job.  Replaces autograd's three library GEMMs for that layer. */
+size_t glx_linear_wide_workspace_bytes(int rows, int N, int K);
+int glx_linear_wide_forward(const float* x, const float* w, float* y, int rows, int N, int K, void* workspace, size_t workspace_bytes,
+                            void* stream);
+int glx_linear_wide_input_grad(const float* dz, const float* w, float* gx, int rows, int N, int K, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * VectorPool family of PV-RCNN++.  Output slots are laid out in ascending new-point order
@@ -1219,6 +1229,10 @@ int glx_conv3x3s2_forward_bn(const float* x, int B, int H, int W, int Cin, const
                              const glx_bn_stats* bn, void* stream);
 int glx_conv3x3s2_forward_ex(const float* x, int B, int H, int W, int Cin, const void* packed_fwd, int Cout, float* y,
                              const glx_epilogue* epilogue, void* stream);
+/* out (B, 2H, 2W, C) = gy (B, H, W, C) at the even pixels, zero elsewhere (channels-last, C % 4 == 0): the output gradient of
+ * ZeroPad2d(1) + Conv2d(c, 2c, 3, stride 2) (base_bev_backbone.py:33-38) spread over the stride-1 map, on which the layer's two
+ * gradients are glx_conv3x3_forward (flipped pack) and glx_conv3x3_wgrad -- autograd's two library calls for that layer. */
+int glx_spread_stride2(const float* gy, int B, int H, int W, int C, float* out, void* stream);
 size_t glx_deconv_wgrad_workspace_bytes(int Cin, int Cout, int u);
 int glx_deconv_wgrad(const float* x, const float* gy, int B, int H, int W, int Cin, int Cout, int u, float* dW,
                      long long s_ci, long long s_co, long long s_kh, long long s_kw, void* workspace,

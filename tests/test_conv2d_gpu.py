@@ -261,7 +261,7 @@ def test_bev_backbone_runs_its_block_layers_on_the_own_kernels(dev, monkeypatch)
         y.square().mean().backward()
         torch.cuda.synchronize()
         outs.append((y.detach(), xi.grad, [p.grad.clone() for p in m.parameters()]))
-    assert calls == [(64, 64, 3, 3), (64, 64, 3, 3), (128, 128, 3, 3)]      # the strided 64 -> 128 layer stays on MIOpen
+    assert calls == [(64, 64, 3, 3), (64, 64, 3, 3), (128, 128, 3, 3)]      # (the strided 64 -> 128 layer has its own entry points: glx_conv3x3s2_*)
     (y0, gx0, gp0), (y1, gx1, gp1) = outs
     assert torch.allclose(y0, y1, rtol=1e-4, atol=1e-5)
     assert torch.allclose(gx0, gx1, rtol=1e-3, atol=1e-5 * float(gx1.abs().max()) + 1e-9)
@@ -371,7 +371,8 @@ def test_transposed_convolutions_match_fp64(dev, shape):
 
 def test_strided_block_convolution_forward_is_exact_and_reproducible(dev):
     """Conv2d(64, 128, 3, stride 2, padding 1) forward on the own kernel: integers exactly, random data to fp32 rounding,
-    the same bits on every run; gradients (the library's) as F.conv2d's."""
+    the same bits on every run; both gradients -- the stride-1 kernels on the output gradient spread over the stride-1 map
+    (glx_spread_stride2, round 6: no library call) -- as F.conv2d's in fp64."""
     from glenet_amd import dense_path as dp
     g = torch.Generator(device=dev).manual_seed(9)
     xi = _cl(torch.randint(-8, 9, (2, 64, 24, 40), device=dev, generator=g).float())
@@ -384,13 +385,21 @@ def test_strided_block_convolution_forward_is_exact_and_reproducible(dev):
     y = dp.conv2d(x, wt, None, 2, 1)
     assert all(torch.equal(dp.conv2d(x, wt, None, 2, 1), y) for _ in range(5))
     gy = _cl(torch.randn_like(y))
-    y.backward(gy)
     xd, wd = x.detach().double().requires_grad_(True), wt.detach().double().requires_grad_(True)
     ref = F.conv2d(xd, wd, None, 2, 1)
     ref.backward(gy.double())
     assert (y.double() - ref).abs().max() < 4e-6 * ref.abs().max()
-    assert (x.grad.double() - xd.grad).abs().max() < 2e-5 * xd.grad.abs().max()
-    assert (wt.grad.double() - wd.grad).abs().max() < 2e-5 * wd.grad.abs().max()
+    was = dp.OWN_STRIDED_GRADS
+    try:
+        for own in (False, True):           # the library's two calls (default) | the own kernels on the spread gradient
+            dp.OWN_STRIDED_GRADS = own
+            x.grad = wt.grad = None
+            y = dp.conv2d(x, wt, None, 2, 1)
+            y.backward(gy)
+            assert (x.grad.double() - xd.grad).abs().max() < 2e-5 * xd.grad.abs().max(), own
+            assert (wt.grad.double() - wd.grad).abs().max() < 2e-5 * wd.grad.abs().max(), own
+    finally:
+        dp.OWN_STRIDED_GRADS = was
 
 
 def test_dense_kernels_against_the_oracle(dev):

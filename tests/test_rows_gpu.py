@@ -193,3 +193,41 @@ def test_deferred_tower_weight_gradients_run_grouped_and_match_the_library_produ
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
     want = gys[2].double().t() @ xs[2].double() + 1.0
     assert float((res[0][2].double() - want).abs().max()) <= 3e-6 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("rows,k,n", [(512, 20736, 256), (37, 4160, 64), (130, 4096, 128)])
+def test_wide_first_linear_on_own_kernels_matches_fp64(dev, rows, k, n):
+    """voxelrcnn_head.py:40-52's Linear(20 736, 256, bias=False) on the RoI rows: forward (split along K, fixed-order sum), input
+    gradient and weight gradient on the package's fp32-MFMA kernels (glx_linear_wide_forward / _input_grad, glx_linear_wgrad_multi)
+    against fp64 products -- exact fp32 products, so the error is that of fp32 accumulation; ragged row counts; the autograd
+    function of SplitKLinear takes the same path; two calls give the same bits."""
+    from glenet_amd import dense_path as dp
+    g = torch.Generator(device=dev).manual_seed(rows + k)
+    x = torch.randn(rows, k, device=dev, generator=g)
+    w = torch.randn(n, k, device=dev, generator=g) / k ** 0.5
+    gy = torch.randn(rows, n, device=dev, generator=g)
+    assert dp._wide_linear_ok(x, w)
+    y = dp.wide_linear_forward(x, w)
+    gx = dp.wide_linear_input_grad(gy, w)
+    gw = dp._SplitKLinearFn.weight_grad(x, gy, w)
+    y64, gx64, gw64 = x.double() @ w.double().t(), gy.double() @ w.double(), gy.double().t() @ x.double()
+    for got, want, mag in ((y, y64, x.double().abs() @ w.double().abs().t()), (gx, gx64, gy.double().abs() @ w.double().abs()),
+                           (gw, gw64, gy.double().abs().t() @ x.double().abs())):
+        assert float(((got.double() - want).abs() / mag).max()) <= 2.0 ** -18, (rows, k, n)
+    assert torch.equal(y, dp.wide_linear_forward(x, w)) and torch.equal(gx, dp.wide_linear_input_grad(gy, w))
+    # through autograd
+    xa, wa = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    lin = dp.SplitKLinear(k, n, bias=False).to(dev)
+    with torch.no_grad():
+        lin.weight.copy_(w)
+    out = lin(xa)
+    assert torch.equal(out, y)
+    out.backward(gy)
+    assert torch.equal(xa.grad, gx) and torch.equal(lin.weight.grad, gw)
+    # the library path stays one assignment away
+    dp.OWN_WIDE_LINEAR = False
+    try:
+        ref = dp._SplitKLinearFn.apply(x, w)
+    finally:
+        dp.OWN_WIDE_LINEAR = True
+    assert float((ref - y).abs().max()) <= 1e-4 * float(y.abs().max())
