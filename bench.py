@@ -899,12 +899,11 @@ def main():
     args = ap.parse_args()
     from glenet_amd import runtime as glx_runtime
     glx_runtime.configure_graph_executor(args.graph_queues if args.graph_queues > 0 else None)
-    # frames/s over >= 50 timed steps after >= 10 warm-up steps.  A shorter request (the driver's --steps 20
-    # --warmup 5 times 0.15 s of a 7 ms step) is raised to that; "steps" / "warmup" in the line are what was timed, the
-    # requested values ride along as steps_requested / warmup_requested.
+    # The headline times EXACTLY the K steps asked for after exactly W warm-up steps (the driver's contract; round 6 -- rounds 1-5
+    # raised a shorter request to SURVEY 8(d)'s >= 50 / >= 10 and echoed the request, which the driver flagged as a mismatch).
+    # SURVEY 8(d)'s figure -- frames/s over >= 50 timed steps after >= 10 warm-up steps -- is measured right behind it with the same
+    # fences whenever K < 50 and reported as `survey_8d` (with K >= 50 the headline is that figure).
     steps_requested, warmup_requested = args.steps, args.warmup
-    if not args.roofline_only:
-        args.steps, args.warmup = max(args.steps, MIN_TIMED_STEPS), max(args.warmup, MIN_WARMUP_STEPS)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args, sys.argv[1:]))
@@ -1049,6 +1048,23 @@ def main():
         t_host = (time.perf_counter() - th) / 3
         torch.cuda.synchronize(dev)
     progress("headline done: %.2f ms/step" % (dt / max(args.steps, 1) * 1e3))
+    survey = None
+    if 0 < args.steps < MIN_TIMED_STEPS and not args.roofline_only:
+        for _ in range(max(0, MIN_WARMUP_STEPS - args.warmup)):
+            train_step()
+        gdist.fence(dev)
+        ts = time.perf_counter()
+        for _ in range(MIN_TIMED_STEPS):
+            train_step()
+        gdist.fence(dev)
+        dts = gdist.reduce_max(time.perf_counter() - ts, dev)
+        pipe.check()
+        survey = dict(steps=MIN_TIMED_STEPS, warmup=max(args.warmup, MIN_WARMUP_STEPS) + args.steps,
+                      ms_per_step=round(dts / MIN_TIMED_STEPS * 1e3, 4),
+                      value=round(FRAMES_PER_GPU * world * MIN_TIMED_STEPS / dts, 2), unit="frames/s",
+                      note="SURVEY 8(d): frames/s over >= 50 timed steps after >= 10 warm-up steps, the same fences, right behind "
+                           "the headline's K steps")
+        progress("survey 8(d) region done: %.2f ms/step" % survey["ms_per_step"])
     # ---- N > 1 diagnostics (outside the timed region): per-rank step time, the gradient exchange alone (events around
     # the all-reduce on the stream it runs on, the two graphs of a step replayed around it) and per-rank host enqueue cost
     per_rank = None
@@ -1217,7 +1233,7 @@ def main():
         st = pipe.out["encoded_spconv_tensor"]
         out = dict(metric=METRIC, value=round(FRAMES_PER_GPU * world * args.steps / dt, 2), unit="frames/s",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, steps_requested=steps_requested,
-                   warmup_requested=warmup_requested,
+                   warmup_requested=warmup_requested, survey_8d=survey,
                    ms_per_step=round(dt / max(args.steps, 1) * 1e3, 4), higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="f32", data="synthetic",
                    config=dict(workload="configs[2] per-GPU share: GLENet-VR Voxel-RCNN full train step (voxelize + sparse "
