@@ -446,7 +446,8 @@ class RecordedStep:
             raise RuntimeError("dropin.record: the recorded step is the TRAINING step; run evaluation through the network itself")
         self.load(batch_dict)
         self.pipe.step()
-        loss = _recorded_loss().apply(self._anchor, self.pipe.loss, self)
+        # (the pipeline's scalar: already detached after a staged backward, a consumed autograd graph behind it otherwise)
+        loss = _recorded_loss().apply(self._anchor, self.pipe.loss.detach(), self)
         tb = {k: v for k, v in self.pipe.parts.items()}
         tb["rpn_loss"] = tb.get("loss_rpn")
         return {"loss": loss}, tb, {}
