@@ -547,14 +547,29 @@ def bench_dropin(state, K, pool, dev, steps=12):
             ret["loss"].backward()
         torch.cuda.synchronize(dev)
         ms_graph = (time.perf_counter() - t0) / n * 1e3
-        del rec, opt, m
+        # ... and the eval loop's `pred_dicts, recall_dicts = model(batch_dict)` (tools/eval_utils/eval_utils.py:53-66) around
+        # dropin.record_inference(): the whole pass incl. post-processing as one graph, the per-frame dicts read back every step
+        m.eval()
+        inf = dropin.record_inference(m, [dict(b, batch_size=FRAMES_PER_GPU) for b in batches])
+        for bd in batches[:3]:
+            inf(bd)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for j in range(n):
+            inf(batches[j % len(batches)])
+        torch.cuda.synchronize(dev)
+        ms_inf = (time.perf_counter() - t0) / n * 1e3
+        inf.check()
+        del rec, opt, m, inf
         torch.cuda.empty_cache()
-        return ms, ms_graph, n
+        return ms, ms_graph, n, ms_inf
     ref_ms, ref_var = run(True)
     _, ref_var_vendor = run(True, gemm=False, vary_only=3)
     acc_ms, acc_var = run(False)
-    rec_ms, rec_graph_ms, rec_n = recorded()
-    return dict(dropin_recorded_step_ms=round(rec_ms, 3), dropin_recorded_frames_per_s=round(FRAMES_PER_GPU / rec_ms * 1e3, 1),
+    rec_ms, rec_graph_ms, rec_n, rec_inf_ms = recorded()
+    return dict(dropin_recorded_inference_ms=round(rec_inf_ms, 3),
+                dropin_recorded_inference_frames_per_s=round(FRAMES_PER_GPU / rec_inf_ms * 1e3, 1),
+                dropin_recorded_step_ms=round(rec_ms, 3), dropin_recorded_frames_per_s=round(FRAMES_PER_GPU / rec_ms * 1e3, 1),
                 dropin_recorded_forward_backward_ms=round(rec_graph_ms, 3), dropin_recorded_steps=rec_n,
                 dropin_recorded_note="glenet_amd.dropin.record(network): the reference loop's statements (model(batch) -> "
                                      "ret['loss'].mean().backward() -> clip_grad_norm_ -> torch.optim.AdamW.step(), "
@@ -854,7 +869,10 @@ GLENET_VR_MODEL_CFG = dict(
                   LOSS_CONFIG=dict(CLS_LOSS="BinaryCrossEntropy", REG_LOSS="smooth-l1", CORNER_LOSS_REGULARIZATION=True,
                                    GRID_3D_IOU_LOSS=False,
                                    LOSS_WEIGHTS=dict(rcnn_cls_weight=1.0, rcnn_reg_weight=1.0, rcnn_corner_weight=1.0,
-                                                     rcnn_iou3d_weight=1.0, code_weights=[1.0] * 7))))
+                                                     rcnn_iou3d_weight=1.0, code_weights=[1.0] * 7))),
+    POST_PROCESSING=dict(RECALL_THRESH_LIST=[0.3, 0.5, 0.7], SCORE_THRESH=0.3, POST_SCORE_THRESH=0.81, OUTPUT_RAW_SCORE=False,
+                         EVAL_METRIC="kitti", NMS_CONFIG=dict(MULTI_CLASSES_NMS=False, NMS_TYPE="new_nms_gpu", NMS_THRESH=0.1,
+                                                              NMS_PRE_MAXSIZE=4096, NMS_POST_MAXSIZE=500)))
 
 # --------------------------------------------------------------------------------- main
 MIN_TIMED_STEPS, MIN_WARMUP_STEPS = 50, 10

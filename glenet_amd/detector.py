@@ -361,6 +361,7 @@ class StaticDetectorPipeline(gb.StaticFramePipeline):
         super().__init__(flow.backbone_3d, flow.cfg, batch_size, num_points, num_features,
                          train_voxel_cap=False, capacities=capacities, device=device)
         self.flow = flow
+        self.post_cfg = None          # Detector3DTemplate.post_processing's settings (None: POST_PROCESSING_CFG, GLENet_VR.yaml:168-181)
         # the flow's own HeightCompression (channels-last, deferred to the BEV backbone's sparse first layer): with the
         # base class's default one the BEV backbone received an NCHW map and ran on the vendor's kernels
         self.hc = flow.map_to_bev
@@ -372,7 +373,7 @@ class StaticDetectorPipeline(gb.StaticFramePipeline):
         from ._lib import workspace
         bd = super().enqueue()
         with torch.no_grad(), workspace.scoped(id(self)):
-            bd = self.flow.second_stage(bd, self.B)
+            bd = self.flow.second_stage(bd, self.B, self.post_cfg) if self.post_cfg is not None else self.flow.second_stage(bd, self.B)
         self.out = bd
         return bd
 

@@ -565,3 +565,149 @@ def record(model, batches=None, batch_size=None, max_points=None, max_gt=32, dat
     rec.load(batches[0])
     pipe.capture(warmup=warmup, split=True)
     return rec
+
+
+# ------------------------------------------------------------------------------------------------ the recorded inference pass
+def _translate_post_cfg(model_cfg):
+    """det.post_processing's settings from MODEL.POST_PROCESSING (GLENet_VR.yaml:168-181)."""
+    g = _cfg_get
+    pp = g(model_cfg, "POST_PROCESSING")
+    nms = g(pp, "NMS_CONFIG")
+    if g(nms, "NMS_TYPE") != "new_nms_gpu" or g(nms, "MULTI_CLASSES_NMS") or g(pp, "OUTPUT_RAW_SCORE"):
+        raise NotImplementedError("dropin.record_inference: class-agnostic variance-voting NMS (NMS_TYPE new_nms_gpu) of "
+                                  "normalised scores (GLENet_VR.yaml:168-181)")
+    cfg = dict(SCORE_THRESH=g(pp, "SCORE_THRESH"), POST_SCORE_THRESH=g(pp, "POST_SCORE_THRESH", None),
+               NMS_THRESH=float(g(nms, "NMS_THRESH")), NMS_PRE_MAXSIZE=int(g(nms, "NMS_PRE_MAXSIZE")),
+               NMS_POST_MAXSIZE=int(g(nms, "NMS_POST_MAXSIZE")))
+    return cfg, [float(t) for t in (g(pp, "RECALL_THRESH_LIST") or [])]
+
+
+def recall_counts(box_preds, rois, gt_boxes, thresh_list):
+    """Detector3DTemplate.generate_recall_record's counts (detector3d_template.py:318-362) for a whole batch ON THE DEVICE:
+    box_preds (B, R, 7+) the refined boxes, rois (B, R, 7+) or None, gt_boxes (B, G, 7+) with zero rows behind a frame's last box.
+    Returns an int64 tensor [gt, rcnn_t0, roi_t0, rcnn_t1, roi_t1, ...]: the rows up to a frame's last non-zero row count as ground
+    truth (as the reference's trimming loop leaves them); an all-zero row overlaps nothing, so it is never recalled."""
+    import torch
+    from .pcdet_ops.iou3d_nms import iou3d_nms_utils
+    B, G = gt_boxes.shape[0], gt_boxes.shape[1]
+    nz = gt_boxes.abs().sum(dim=-1) != 0                                          # (B, G)
+    idx = torch.arange(1, G + 1, device=gt_boxes.device)
+    n_gt = (nz * idx).max(dim=1)[0]                                               # last non-zero row + 1 per frame
+    inside = idx[None, :] <= n_gt[:, None]
+    out = [n_gt.sum()]
+    rc, ro = [], []
+    for b in range(B):
+        g = gt_boxes[b, :, 0:7].contiguous()
+        rc.append(iou3d_nms_utils.boxes_iou3d_gpu(box_preds[b, :, 0:7].contiguous(), g).max(dim=0)[0])
+        if rois is not None:
+            ro.append(iou3d_nms_utils.boxes_iou3d_gpu(rois[b, :, 0:7].contiguous(), g).max(dim=0)[0])
+    rc = torch.stack(rc)
+    ro = torch.stack(ro) if ro else None
+    for t in thresh_list:
+        out.append(((rc > t) & inside).sum())
+        out.append(((ro > t) & inside).sum() if ro is not None else torch.zeros((), dtype=torch.int64, device=gt_boxes.device))
+    return torch.stack([o.to(torch.int64) for o in out])
+
+
+def recall_record(box_preds, rois, gt_boxes, thresh_list, recall_dict=None):
+    """The dict Detector3DTemplate.post_processing returns beside pred_dicts, for a batch (one read-back)."""
+    counts = recall_counts(box_preds, rois, gt_boxes, thresh_list).tolist()
+    if not recall_dict:
+        recall_dict = {"gt": 0}
+        for t in thresh_list:
+            recall_dict["roi_%s" % str(t)] = 0
+            recall_dict["rcnn_%s" % str(t)] = 0
+    recall_dict["gt"] += counts[0]
+    for i, t in enumerate(thresh_list):
+        recall_dict["rcnn_%s" % str(t)] += counts[1 + 2 * i]
+        recall_dict["roi_%s" % str(t)] += counts[2 + 2 * i]
+    return recall_dict
+
+
+class RecordedInference:
+    """What dropin.record_inference() returns: a callable with the contract of the reference's network in EVAL mode
+    (pcdet/models/detectors/voxel_rcnn.py:forward: `pred_dicts, recall_dicts = model(batch_dict)`, consumed by
+    tools/eval_utils/eval_utils.py:53-66), backed by one recorded HIP graph of the whole pass -- voxelization, sparse backbone,
+    BEV backbone + anchor head with eval-mode BatchNorm folded, proposals, RoI-grid pooling, FC towers, box refinement and
+    Detector3DTemplate.post_processing's variance-voting NMS on the device -- over the network's own parameters."""
+
+    def __init__(self, model, twin, pipe, thresh_list):
+        self.model, self.twin, self.pipe, self.thresh_list = model, twin, pipe, thresh_list
+
+    def __call__(self, batch_dict):
+        import torch
+        from . import detector as det
+        if self.model.training:
+            raise RuntimeError("dropin.record_inference: the recorded pass is the EVAL pass (model.eval())")
+        dev = self.pipe.points.device
+        pts = torch.as_tensor(batch_dict["points"]).to(dev, non_blocking=True)
+        self.pipe.load(pts[:, 1:].float().contiguous(), pts[:, 0].to(torch.int32).contiguous())
+        out = self.pipe.replay()
+        pred = det.pred_dicts(out["post"])                       # the pass's one read-back
+        recall = {}
+        if "gt_boxes" in batch_dict and self.thresh_list:
+            gt = torch.as_tensor(batch_dict["gt_boxes"]).to(dev, torch.float32)
+            recall = recall_record(out["batch_box_preds"], out["rois"], gt, self.thresh_list)
+        return pred, recall
+
+    def check(self):
+        self.pipe.check()
+        return True
+
+
+def record_inference(model, batches, batch_size=None, max_points=None, data_cfg=None):
+    """The eval-mode counterpart of record(): the inference pass of a reference-built GLENet-VR network as one recorded graph on
+    the network's own parameters (a parameter-sharing twin, the configuration -- NMS_CONFIG.TEST, POST_PROCESSING -- translated
+    from model.model_cfg).  batches: representative collated batch_dicts (`points` (P, 1 + C)); returns a RecordedInference.
+    A change of the weights (load_state_dict, a training step) is noticed by the pipeline's weight tag: the pass re-records."""
+    import torch
+    from . import detector as det
+    from . import glenet_vr as gvr
+    roi_cfg, head_cfg = _translate_cfg(model.model_cfg)
+    post_cfg, thresh = _translate_post_cfg(model.model_cfg)
+    ds = getattr(model, "dataset", None)
+    cfg = dict(point_cloud_range=[round(float(v), 5) for v in ds.point_cloud_range],
+               voxel_size=[round(float(v), 6) for v in ds.voxel_size], max_points=5, max_voxels_train=16000, max_voxels_test=40000,
+               num_features=int(getattr(getattr(ds, "point_feature_encoder", None), "num_point_features", 4)))
+    dc = getattr(ds, "dataset_cfg", None)
+    for p in (_cfg_get(dc, "DATA_PROCESSOR", None) or []):
+        if _cfg_get(p, "NAME") == "transform_points_to_voxels":
+            cfg["max_points"] = int(_cfg_get(p, "MAX_POINTS_PER_VOXEL"))
+            mv = _cfg_get(p, "MAX_NUMBER_OF_VOXELS")
+            cfg["max_voxels_train"], cfg["max_voxels_test"] = int(_cfg_get(mv, "train")), int(_cfg_get(mv, "test"))
+    cfg.update(data_cfg or {})
+    dev = next(model.parameters()).device
+    if dev.type != "cuda":
+        raise RuntimeError("dropin.record_inference: the network must live on the GPU (no CPU path)")
+    with torch.device(dev):
+        twin = gvr.GLENetVR(cfg, cfg["num_features"], roi_cfg=roi_cfg, head_cfg=head_cfg, bev_channels_last=True)
+    with torch.no_grad():
+        for name in ("backbone_2d", "dense_head"):
+            for p in getattr(model, name).parameters():
+                if p.dim() == 4:
+                    p.data = p.data.contiguous(memory_format=torch.channels_last)
+    _share_state(twin, model)
+    twin.eval()
+    if isinstance(batches, dict):
+        batches = [batches]
+    batches = list(batches or [])
+    if not batches:
+        raise ValueError("dropin.record_inference: at least one representative batch_dict")
+    if batch_size is None:
+        batch_size = int(batches[0].get("batch_size") or int(torch.as_tensor(batches[0]["points"])[:, 0].max().item()) + 1)
+    if max_points is None:
+        max_points = (int(max(len(b["points"]) for b in batches) * 1.1) + 1023) // 1024 * 1024
+    pipe = det.StaticDetectorPipeline(twin, batch_size, max_points, cfg["num_features"], device=dev)
+    pipe.post_cfg = post_cfg
+    caps = {}
+    first = None
+    for bd in batches:
+        pts = torch.as_tensor(bd["points"]).to(dev)
+        xyz, bidx = pts[:, 1:].float().contiguous(), pts[:, 0].to(torch.int32).contiguous()
+        first = first if first is not None else (xyz, bidx)
+        for k, v in pipe.calibrate(xyz, bidx).items():
+            caps[k] = max(caps.get(k, 0), v)
+    pipe.capacities = caps
+    pipe.load(*first)
+    pipe.capture()
+    return RecordedInference(model, twin, pipe, thresh)

@@ -24,3 +24,16 @@ def test_translated_configuration_is_the_packages():
         dropin._translate_cfg(multi)
 
 
+
+
+def test_translated_post_processing_is_the_packages():
+    from glenet_amd import detector as det
+    from glenet_amd import dropin
+    full = copy.deepcopy(MODEL_CFG)
+    full["POST_PROCESSING"].update(SCORE_THRESH=0.3, POST_SCORE_THRESH=0.81)
+    cfg, thresh = dropin._translate_post_cfg(full)
+    assert cfg == det.POST_PROCESSING_CFG and thresh == [0.3, 0.5, 0.7]
+    other = copy.deepcopy(full)
+    other["POST_PROCESSING"]["NMS_CONFIG"]["NMS_TYPE"] = "nms_gpu"
+    with pytest.raises(NotImplementedError):
+        dropin._translate_post_cfg(other)

@@ -50,6 +50,10 @@ MODEL_CFG = dict(
                                    GRID_3D_IOU_LOSS=False,
                                    LOSS_WEIGHTS=dict(rcnn_cls_weight=1.0, rcnn_reg_weight=1.0, rcnn_corner_weight=1.0,
                                                      rcnn_iou3d_weight=1.0, code_weights=[1.0] * 7))))
+MODEL_CFG["POST_PROCESSING"] = dict(RECALL_THRESH_LIST=[0.3, 0.5, 0.7], SCORE_THRESH=0.3, POST_SCORE_THRESH=0.4, OUTPUT_RAW_SCORE=False,
+                                   EVAL_METRIC="kitti",
+                                   NMS_CONFIG=dict(MULTI_CLASSES_NMS=False, NMS_TYPE="new_nms_gpu", NMS_THRESH=0.1, NMS_PRE_MAXSIZE=4096,
+                                                   NMS_POST_MAXSIZE=500))
 JIT = [0.2, -0.15, 0.05, 0.1, -0.05, 0.03, 0.08]
 
 
@@ -182,3 +186,61 @@ def test_recorded_step_gives_the_eager_step_s_loss_and_gradients_and_trains_unde
     big = _collated([70, 71], 9000)
     with pytest.raises(ValueError):
         step(big)
+
+
+def test_recorded_inference_pass_returns_the_reference_s_eval_contract(dev):
+    """`pred_dicts, recall_dicts = model(batch_dict)` of the eval loop (tools/eval_utils/eval_utils.py:53-66) from ONE recorded graph
+    on the network's own parameters: the per-frame dicts equal the exact-shape eager pass (GLENetVR.predict with the translated
+    POST_PROCESSING settings), the recall record equals Detector3DTemplate.generate_recall_record's statements evaluated directly,
+    a change of the weights is picked up (the pass re-records), training mode is refused."""
+    from glenet_amd import detector as det
+    from glenet_amd import dropin
+    from glenet_amd.pcdet_ops.iou3d_nms import iou3d_nms_utils
+    net = _network(dev).eval()
+    batches = [_collated([90 + 2 * i, 91 + 2 * i], 6000) for i in range(2)]
+    for b in batches:
+        b["batch_size"] = 2
+    post_cfg, thresh = dropin._translate_post_cfg(MODEL_CFG)
+    assert post_cfg == dict(SCORE_THRESH=0.3, POST_SCORE_THRESH=0.4, NMS_THRESH=0.1, NMS_PRE_MAXSIZE=4096, NMS_POST_MAXSIZE=500)
+    # an untrained head scores everything about alike (sigmoid ~ 0.5): thresholds that let boxes through
+    post_cfg = dict(post_cfg, SCORE_THRESH=0.0, POST_SCORE_THRESH=None)
+    rec = dropin.record_inference(net, batches)
+    rec.pipe.post_cfg = post_cfg
+    rec.pipe.capture()
+    for bd in batches:
+        pred, recall = rec(bd)
+        assert rec.check()
+        pts = torch.as_tensor(bd["points"]).to(dev)
+        with torch.no_grad():
+            want = net.predict(pts[:, 1:].contiguous(), pts[:, 0].int().contiguous(), 2, post_cfg)
+        ref = det.pred_dicts(want["post"])
+        assert len(pred) == len(ref) == 2
+        for a, b in zip(pred, ref):
+            assert a["pred_boxes"].shape == b["pred_boxes"].shape and a["pred_boxes"].shape[0] > 0
+            assert torch.equal(a["pred_labels"], b["pred_labels"])
+            assert torch.allclose(a["pred_scores"], b["pred_scores"], atol=2e-5)
+            assert torch.allclose(a["pred_boxes"], b["pred_boxes"], atol=2e-4)
+        # the recall record: detector3d_template.py:318-362 evaluated directly on the pass's own tensors
+        gt = torch.as_tensor(bd["gt_boxes"]).to(dev)
+        exp = {"gt": 0, **{"%s_%s" % (k, t): 0 for t in thresh for k in ("roi", "rcnn")}}
+        for f in range(2):
+            g = gt[f][gt[f].abs().sum(1) > 0]
+            exp["gt"] += int(g.shape[0])
+            i_rcnn = iou3d_nms_utils.boxes_iou3d_gpu(want["batch_box_preds"][f][:, :7].contiguous(), g[:, :7].contiguous())
+            i_roi = iou3d_nms_utils.boxes_iou3d_gpu(want["rois"][f][:, :7].contiguous(), g[:, :7].contiguous())
+            for t in thresh:
+                exp["rcnn_%s" % t] += int((i_rcnn.max(0)[0] > t).sum())
+                exp["roi_%s" % t] += int((i_roi.max(0)[0] > t).sum())
+        assert recall == exp and recall["gt"] > 0, (recall, exp)
+    # new weights: the recorded pass follows them
+    before = rec(batches[0])[0][0]["pred_scores"].clone()
+    with torch.no_grad():
+        net.dense_head.conv_cls.bias.add_(0.5)
+        net.roi_head.cls_pred_layer.bias.add_(0.7)
+    from glenet_amd import _lib
+    _lib.bump_weights_epoch((net.dense_head.conv_cls.bias, net.roi_head.cls_pred_layer.bias))
+    after = rec(batches[0])[0][0]["pred_scores"]
+    assert after.shape[0] > 0 and (after.shape != before.shape or not torch.allclose(after, before))
+    net.train()
+    with pytest.raises(RuntimeError):
+        rec(batches[0])

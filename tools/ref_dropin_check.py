@@ -274,6 +274,9 @@ def check_record(net, ds):
         p.add_(1.0)
         assert torch.equal(twin.dense_head.conv_cls.bias, p)
         p.sub_(1.0)
+    from glenet_amd import detector as det
+    post_cfg, thresh = dropin._translate_post_cfg(net.model_cfg)             # record_inference()'s settings
+    assert post_cfg == det.POST_PROCESSING_CFG and thresh == [0.3, 0.5, 0.7], (post_cfg, thresh)
     bad = dict(net.model_cfg)
     try:
         dropin._translate_cfg(EasyDict(dict(net.model_cfg, NAME="PVRCNN")))
