@@ -622,6 +622,11 @@ def bench_config3(dev, objects=4096, points=512, samples=30):
             for s_ in range(samples):
                 model.sample(pts, eps[s_])
     ms_s = _timed(sample_all, 3, dev, warm=1)
+    dp.PointFeat.F16X2 = False                  # the same sampler with exact fp32 MFMA products in the wide extractor
+    try:
+        ms_s32 = _timed(sample_all, 3, dev, warm=1)
+    finally:
+        dp.PointFeat.F16X2 = True
     # the sampler runs ONE large extractor (prior) + the narrow one per pass
     sample_flops = objects * (2 * points * (4 * 64 + 64 * 128 + 128 * 512) + 2 * points * (4 * 8 + 8 * 8 + 8 * 8))
     # learning rate of the one-cycle schedule's first step (LR / DIV_FACTOR, cfgs/exp20.yaml): random-init weights
@@ -633,6 +638,9 @@ def bench_config3(dev, objects=4096, points=512, samples=30):
     loss = float(step.loss)
     return dict(workload="configs[3]: cvae_uncertainty CVAE, %d object crops x %d points, fp32" % (objects, points),
                 sampler=dict(samples_per_object=samples, ms_all_samples=round(ms_s, 2), ms_per_sample=round(ms_s / samples, 3),
+                             arithmetic="wide extractor layers 2-3: f16 x 2 products (3 fp16 MFMAs per tile, >= 20.4 bits), "
+                                        "fp32 sums; layer 1 and the narrow extractor fp32",
+                             ms_per_sample_fp32_mfma=round(ms_s32 / samples, 3),
                              objects_per_s=round(objects / (ms_s * 1e-3), 1),
                              TFLOPs=round(samples * sample_flops / ms_s / 1e9, 1),
                              frac_of_fp32_mfma_peak=round(samples * sample_flops / ms_s / 1e9 / MFMA_F32_PEAK_TFLOPS, 3)),

@@ -170,6 +170,260 @@ extern "C" int glx_pointnet_feat(const float* points, int B, int Cin, int P, con
   return GLX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ f16 x 2 form (round 6)
+// The same extractor with layers 2 and 3 on v_mfma_f32_16x16x32_f16: every operand is split into two fp16 pieces of the value
+// scaled by a power of two (the arithmetic of csrc/glx_conv2d.hip / glx_sconv.hip: three MFMAs per product tile -- b_w a_x,
+// a_w b_x, a_w a_x --, >= 20.4 bits per product, fp32 sums), 96 matrix-pipe cycles per 16 x 16 x 64 block instead of 512.
+// The register chaining of the fp32 kernel survives: a 16 x 16 x 32 MFMA wants, per lane (j, q), EIGHT consecutive
+// contraction slots of its point j -- and the contraction index may be enumerated any way both operands agree on, so k-step s
+// takes the lane's own D registers of input tiles 2 s and 2 s + 1 (channels 32 s + 16 h + 4 q + e, slot 4 h + e); the packed
+// weights use the same enumeration (dense_path.PointFeat._packed_f16).  Scales: a weight row (output channel) by its own power of
+// two (ew2 / ew3, host side), a point by the maximum of its activations over the channels (4 lanes of a quad column: two
+// register-half swaps); both come out per product tile (ldexp).  Layer 1 (K <= 8) stays on the VALU in fp32.
+typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void pn_split2(float xs, _Float16& a, _Float16& b) {
+  a = (_Float16)xs;
+  b = (_Float16)(xs - (float)a);
+}
+// the exponent e that puts m = max |x| into [2^14, 2^15); 0 for m == 0
+__device__ __forceinline__ int pn_exponent(float m) {
+  if (!(m > 0.f)) return 0;
+  const int e = 14 - (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xFF) + 127;
+  return e > 110 ? 110 : (e < -110 ? -110 : e);
+}
+// max over the four lanes (j, q = 0..3) that hold one point: lanes 16 apart
+__device__ __forceinline__ float pn_point_max(float m) {
+  const unsigned mu = __builtin_bit_cast(unsigned, m);
+  const auto s16 = __builtin_amdgcn_permlane16_swap(mu, mu, false, false);
+  m = fmaxf(__builtin_bit_cast(float, (unsigned)s16[0]), __builtin_bit_cast(float, (unsigned)s16[1]));
+  const unsigned mv = __builtin_bit_cast(unsigned, m);
+  const auto s32 = __builtin_amdgcn_permlane32_swap(mv, mv, false, false);
+  return fmaxf(__builtin_bit_cast(float, (unsigned)s32[0]), __builtin_bit_cast(float, (unsigned)s32[1]));
+}
+
+#define PNH_SLAB_U4 512          // uint4 per W3 slab: 4 k-steps x 2 planes x 64 lanes (8 KB)
+#define PNH_RING 3               // slabs in LDS: one being read, two on their way
+
+// W3's slabs go L2 -> LDS by DMA (no registers, no ds_write); the compiler does not see these operations, so the kernel counts
+// them itself: every thread issues exactly two per slab, and nothing else of its own is in flight while the ring turns.
+__device__ __forceinline__ unsigned pn_lds_addr(const void* p) {
+  return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ void pn_dma16(const void* base_uniform, unsigned off, unsigned lds_uniform) {
+  // 64 lanes x 16 B from base + off (per lane) -> LDS at lds_uniform + 16 lane
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base_uniform), "s"(lds_uniform)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void pn_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pointnet_feat_f16(
+    const float* __restrict__ pts, int CIN, int P, const float* __restrict__ W1, const float* __restrict__ b1,
+    const uint4* __restrict__ W2h, const int* __restrict__ ew2, const float* __restrict__ b2, const uint4* __restrict__ W3h,
+    const int* __restrict__ ew3, const float* __restrict__ b3, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  uint4* s_w2 = reinterpret_cast<uint4*>(smem);              // 8 t2 x 2 s x 2 planes x 64 lanes          (32 KB)
+  uint4* s_w3 = s_w2 + 8 * 2 * 2 * 64;                       // PNH_RING slabs of PNH_SLAB_U4              (24 KB)
+  float* s_w1 = reinterpret_cast<float*>(s_w3 + PNH_RING * PNH_SLAB_U4);   // 64 * 8
+  float* s_b1 = s_w1 + PN_C1 * PN_MAXCIN;                    // 64
+  float* s_b2 = s_b1 + PN_C1;                                // 128
+  int* s_e2 = reinterpret_cast<int*>(s_b2 + PN_C2);          // 128
+  int* s_e3 = s_e2 + PN_C2;                                  // 512: MINUS the rows' exponents
+  float* s_max = reinterpret_cast<float*>(s_e3 + PN_C3);     // 4 waves * 512
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const long long obj = blockIdx.x;
+
+  // the ring's first two slabs are on their way while the rest of the block's constants are staged
+  const unsigned ring = pn_lds_addr(s_w3);
+  const unsigned my = __builtin_amdgcn_readfirstlane(wave) * 1024u;     // this wave's 1 KB of each half slab
+  const unsigned woff = tid * 16u;
+#define PN_STAGE(slab, buf)                                                                                   \
+  do {                                                                                                        \
+    pn_dma16(W3h, woff + (unsigned)(slab) * (PNH_SLAB_U4 * 16u), ring + (buf) * (PNH_SLAB_U4 * 16u) + my);                      \
+    pn_dma16(W3h, woff + (unsigned)(slab) * (PNH_SLAB_U4 * 16u) + 4096u, ring + (buf) * (PNH_SLAB_U4 * 16u) + 4096u + my);      \
+  } while (0)
+  PN_STAGE(0, 0);
+  PN_STAGE(1, 1);
+  for (int e = tid; e < 8 * 2 * 2 * 64; e += PN_THREADS) s_w2[e] = W2h[e];
+  for (int e = tid; e < PN_C1 * PN_MAXCIN; e += PN_THREADS) {
+    int c = e / PN_MAXCIN, ci = e - c * PN_MAXCIN;
+    s_w1[e] = ci < CIN ? W1[c * CIN + ci] : 0.f;
+  }
+  if (tid < PN_C1) s_b1[tid] = b1[tid];
+  if (tid < PN_C2) { s_b2[tid] = b2[tid]; s_e2[tid] = ew2[tid]; }
+  for (int e = tid; e < PN_C3; e += PN_THREADS) s_e3[e] = -ew3[e];
+  pn_wait_vm<0>();
+  __syncthreads();
+
+  // running maxima of layer 3, TRANSPOSED product (points x channels): lane (j, q) holds channel 16 t3 + j of points 4 q + e,
+  // so the max over the points is a max over registers; the four q meet once, after the last pass
+  float mx[32];
+#pragma unroll
+  for (int t = 0; t < 32; ++t) mx[t] = -FLT_MAX;
+  unsigned cur = 0;                                          // the ring buffer slab t3 of this pass is in
+
+  const float* xo = pts + obj * CIN * (long long)P;
+  for (int p0 = 0; p0 < P; p0 += PN_PTS) {
+    // ---- layer 1 on the VALU (as k_pointnet_feat): h1[pt][t1*4+e] = channel 16 t1 + 4 q + e of point (tile pt, j); a point
+    // past the end repeats the object's last one (a duplicate does not move a maximum: no masks further down)
+    float h1[2][16];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      const int pp = p0 + wave * 32 + pt * 16 + j, p = pp < P ? pp : P - 1;
+      float x[PN_MAXCIN];
+#pragma unroll
+      for (int ci = 0; ci < PN_MAXCIN; ++ci) x[ci] = ci < CIN ? xo[(long long)ci * P + p] : 0.f;
+#pragma unroll
+      for (int t1 = 0; t1 < 4; ++t1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = 16 * t1 + 4 * q + e;
+          float a = s_b1[c];
+#pragma unroll
+          for (int ci = 0; ci < PN_MAXCIN; ++ci) a = fmaf(s_w1[c * PN_MAXCIN + ci], x[ci], a);
+          h1[pt][t1 * 4 + e] = fmaxf(a, 0.f);
+        }
+      }
+    }
+    // ---- h1 -> two fp16 pieces at the point's own power of two; k-step s = input tiles 2 s, 2 s + 1
+    pf16x8 Xa[2][2], Xb[2][2];
+    int ex1[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      float m = 0.f;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) m = fmaxf(m, h1[pt][v]);           // ReLU outputs: no sign
+      ex1[pt] = pn_exponent(pn_point_max(m));
+      const float sc = __builtin_bit_cast(float, (unsigned)(ex1[pt] + 127) << 23);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          _Float16 a, b;
+          pn_split2(h1[pt][(2 * s + (jj >> 2)) * 4 + (jj & 3)] * sc, a, b);
+          Xa[pt][s][jj] = a;
+          Xb[pt][s][jj] = b;
+        }
+    }
+    // ---- layer 2 (channels x points): 8 output tiles x 2 k-steps x 3 products per point tile
+    float h2[2][32];
+#pragma unroll
+    for (int t2 = 0; t2 < 8; ++t2) {
+      pf32x4 acc0 = pf32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const pf16x8 Wa = __builtin_bit_cast(pf16x8, s_w2[((t2 * 2 + s) * 2 + 0) * 64 + lane]);
+        const pf16x8 Wb = __builtin_bit_cast(pf16x8, s_w2[((t2 * 2 + s) * 2 + 1) * 64 + lane]);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wb, Xa[0][s], acc0, 0, 0, 0);     // smallest first
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xb[0][s], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xa[0][s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wb, Xa[1][s], acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xb[1][s], acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xa[1][s], acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 16 * t2 + 4 * q + e;
+        const float bb = s_b2[c];
+        const int ew = s_e2[c];
+        h2[0][t2 * 4 + e] = fmaxf(ldexpf(acc0[e], -(ew + ex1[0])) + bb, 0.f);
+        h2[1][t2 * 4 + e] = fmaxf(ldexpf(acc1[e], -(ew + ex1[1])) + bb, 0.f);
+      }
+    }
+    // ---- h2 -> pieces (4 k-steps)
+    pf16x8 Ya[2][4], Yb[2][4];
+    int nex[2][4];                                   // MINUS the exponents of points 4 q + e of the two tiles
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      float m = 0.f;
+#pragma unroll
+      for (int v = 0; v < 32; ++v) m = fmaxf(m, h2[pt][v]);
+      const int ex2 = pn_exponent(pn_point_max(m));
+      const float sc = __builtin_bit_cast(float, (unsigned)(ex2 + 127) << 23);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) nex[pt][e] = -__shfl(ex2, 4 * q + e, 64);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          _Float16 a, b;
+          pn_split2(h2[pt][(2 * s + (jj >> 2)) * 4 + (jj & 3)] * sc, a, b);
+          Ya[pt][s][jj] = a;
+          Yb[pt][s][jj] = b;
+        }
+    }
+    // ---- layer 3 (points x channels): 32 output tiles, W3's slabs through the ring
+#pragma unroll
+    for (int t3 = 0; t3 < 32; ++t3) {
+      const unsigned nb = cur >= 1 ? cur - 1 : PNH_RING - 1;          // (cur + 2) mod 3: read last in the step before
+      PN_STAGE((t3 + 2) & 31, nb);                                    // slabs 0, 1 of the next pass follow 30, 31
+      const uint4* sw = s_w3 + cur * PNH_SLAB_U4;
+      pf32x4 acc0 = pf32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const pf16x8 Wa = __builtin_bit_cast(pf16x8, sw[(s * 2 + 0) * 64 + lane]);
+        const pf16x8 Wb = __builtin_bit_cast(pf16x8, sw[(s * 2 + 1) * 64 + lane]);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ya[0][s], Wb, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Yb[0][s], Wa, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ya[0][s], Wa, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ya[1][s], Wb, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Yb[1][s], Wa, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ya[1][s], Wa, acc1, 0, 0, 0);
+      }
+      const int nw = s_e3[16 * t3 + j];
+      float v = mx[t3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v = fmaxf(v, ldexpf(acc0[e], nw + nex[0][e]));
+        v = fmaxf(v, ldexpf(acc1[e], nw + nex[1][e]));
+      }
+      mx[t3] = v;
+      cur = cur == PNH_RING - 1 ? 0 : cur + 1;
+      pn_wait_vm<2>();                   // slab t3 + 1 has landed (this thread's part); t3 + 2 may still fly
+      __syncthreads();
+    }
+  }
+  pn_wait_vm<0>();
+#undef PN_STAGE
+#pragma unroll
+  for (int t3 = 0; t3 < 32; ++t3) {
+    const float v = pn_point_max(mx[t3]);
+    if (q == 0) s_max[wave * PN_C3 + 16 * t3 + j] = v;
+  }
+  __syncthreads();
+  for (int c = tid; c < PN_C3; c += PN_THREADS) {
+    float v = fmaxf(fmaxf(s_max[c], s_max[PN_C3 + c]), fmaxf(s_max[2 * PN_C3 + c], s_max[3 * PN_C3 + c]));
+    out[obj * PN_C3 + c] = v + b3[c];
+  }
+}
+
+extern "C" size_t glx_pointnet_feat_f16x2_lds_bytes(void) {
+  return (size_t)(8 * 2 * 2 * 64 + PNH_RING * PNH_SLAB_U4) * 16 + (size_t)(PN_C1 * PN_MAXCIN + PN_C1 + PN_C2 + PN_C2 + PN_C3 + 4 * PN_C3) * 4;
+}
+
+// W2h / W3h: the folded (128, 64) / (512, 128) weights as two fp16 planes of w 2^ew[row] in the kernel's operand order
+// ([output tile][k-step][plane][lane 16 q + m][slot 4 h + e] = W[16 tile + m][32 s + 16 h + 4 q + e]); ew2 / ew3: the rows'
+// exponents (max |w| 2^ew in [2^14, 2^15), 0 for a zero row).
+extern "C" int glx_pointnet_feat_f16x2(const float* points, int B, int Cin, int P, const float* W1, const float* b1,
+                                       const void* W2h, const int32_t* ew2, const float* b2, const void* W3h, const int32_t* ew3,
+                                       const float* b3, float* out, void* stream) {
+  if (B <= 0) return GLX_OK;
+  GLX_REQUIRE(points && W1 && b1 && W2h && ew2 && b2 && W3h && ew3 && b3 && out, "glx_pointnet_feat_f16x2: null pointer");
+  GLX_REQUIRE(Cin >= 1 && Cin <= PN_MAXCIN && P >= 1, "glx_pointnet_feat_f16x2: Cin must be 1..8, P >= 1");
+  const size_t lds = glx_pointnet_feat_f16x2_lds_bytes();
+  static bool attr_set = false;
+  if (!attr_set) {
+    GLX_HIP(hipFuncSetAttribute((const void*)k_pointnet_feat_f16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_pointnet_feat_f16, dim3(B), dim3(PN_THREADS), lds, (hipStream_t)stream, points, Cin, P, W1, b1,
+                     (const uint4*)W2h, ew2, b2, (const uint4*)W3h, ew3, b3, out);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
 // Small variant (all widths <= 16, e.g. the decoder's 4 -> 8 -> 8 -> 8 SimPointNetfeat,
 // point_net.py:31-49): pure VALU, one block per object, a thread per point, the (folded) weights
 // in LDS, max over points by wave butterflies + LDS.  Memory-bound on reading the points once.

@@ -1519,6 +1519,41 @@ class PointFeat(nn.Module):
             self.__dict__["_glx_packed"] = cache
         return cache[1]
 
+    # layers 2 and 3 of the wide extractor as f16 x 2 products (csrc/glx_pointnet.hip "f16 x 2 form"): three fp16 MFMAs per product
+    # tile instead of eight fp32 ones, >= 20.4 bits per product; False: exact fp32 MFMA products (glx_pointnet_feat)
+    F16X2 = True
+
+    @staticmethod
+    def _f16x2_image(w):
+        """(Cout, Cin) fp32 -> (two fp16 planes of w 2^ew[row] in the kernel's operand order, ew (Cout,) int32):
+        [tile][k-step s][plane][lane 16 q + m][slot 4 h + e] = W[16 tile + m][32 s + 16 h + 4 q + e]."""
+        cout, cin = w.shape
+        m = w.abs().amax(dim=1)
+        e = torch.where(m > 0, 14 - torch.floor(torch.log2(m.clamp_min(1e-38))), torch.zeros_like(m))
+        # floor(log2) in floating point can be one off at exact powers of two: settle with the integer test the kernels use
+        scaled = m * torch.exp2(e)
+        e = torch.where(scaled >= 2.0 ** 15, e - 1, torch.where((scaled < 2.0 ** 14) & (m > 0), e + 1, e)).clamp_(-110, 110)
+        ws = w * torch.exp2(e)[:, None]
+        a = ws.half()
+        b = (ws - a.float()).half()
+
+        def order(p):           # (Cout, Cin) -> [tile][s][q][m][h][e] = [tile][s][lane][slot]
+            return p.view(cout // 16, 16, cin // 32, 2, 4, 4).permute(0, 2, 4, 1, 3, 5).contiguous()
+        img = torch.stack([order(a), order(b)], dim=2).contiguous()          # [tile][s][plane][q][m][h][e]
+        return img, e.to(torch.int32).contiguous()
+
+    def _packed_f16(self):
+        tag, packed = self.__dict__["_glx_packed"]
+        hit = self.__dict__.get("_glx_packed_f16")
+        if hit is None or hit[0] != tag:
+            w1, b1, w2p, b2, w3p, b3 = packed
+            with torch.no_grad():
+                w2, _ = self._fold(self.conv2, self.bn2)
+                w3, _ = self._fold(self.conv3, self.bn3)
+                hit = (tag, self._f16x2_image(w2) + self._f16x2_image(w3))
+            self.__dict__["_glx_packed_f16"] = hit
+        return hit[1]
+
     def _forward_fused(self, x):
         from ._lib import call
         x = x.contiguous()
@@ -1526,7 +1561,10 @@ class PointFeat(nn.Module):
         w1, b1, w2p, b2, w3p, b3 = self._packed()
         c3 = self.conv3.out_channels
         out = torch.empty((B, c3), dtype=torch.float32, device=x.device)
-        if c3 == 512:
+        if c3 == 512 and self.F16X2:
+            w2h, e2, w3h, e3 = self._packed_f16()
+            call("glx_pointnet_feat_f16x2", x, B, cin, P, w1, b1, w2h, e2, b2, w3h, e3, b3, out)
+        elif c3 == 512:
             call("glx_pointnet_feat", x, B, cin, P, w1, b1, w2p, b2, w3p, b3, out)
         else:
             call("glx_pointnet_feat_small", x, B, cin, P, self.conv1.out_channels, self.conv2.out_channels,

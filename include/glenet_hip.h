@@ -1024,6 +1024,15 @@ int glx_pointnet_feat(const float* points, int B, int Cin, int P, const float* W
                       float* out, void* stream);
 /* Same function for narrow extractors (all widths <= 16, e.g. SimPointNetfeat 8/8/8,
  * point_net.py:31-49); W1 (C1,Cin), W2 (C2,C1), W3 (C3,C2) row-major, folded like above. */
+/* The same extractor with layers 2 and 3 as f16x2 products (two scaled fp16 pieces per operand, three v_mfma_f32_16x16x32_f16 per
+ * product tile, >= 20.4 bits per product, fp32 sums -- the arithmetic of glx_conv3x3_forward's default).  W2h / W3h: the folded
+ * (128, 64) / (512, 128) weights as two fp16 planes of w 2^ew[row] in the kernel's operand order, [output tile][k-step s][plane]
+ * [lane 16 q + m][slot 4 h + e] = W[16 tile + m][32 s + 16 h + 4 q + e]; ew2 (128) / ew3 (512): the rows' exponents (max |w| 2^ew in
+ * [2^14, 2^15), 0 for a zero row).  cvae_uncertainty/point_net.py:10-28, eval mode. */
+size_t glx_pointnet_feat_f16x2_lds_bytes(void);
+int glx_pointnet_feat_f16x2(const float* points, int B, int Cin, int P, const float* W1, const float* b1, const void* W2h,
+                            const int32_t* ew2, const float* b2, const void* W3h, const int32_t* ew3, const float* b3, float* out,
+                            void* stream);
 int glx_pointnet_feat_small(const float* points, int B, int Cin, int P, int C1, int C2, int C3,
                             const float* W1, const float* b1, const float* W2, const float* b2,
                             const float* W3, const float* b3, float* out, void* stream);

@@ -1,5 +1,6 @@
 """GPU parity of the pcdet.ops mirrors (rotated IoU / NMS / voting NMS, point-box operators,
 queries and grouping) against the CPU oracle and the reference's golden vectors."""
+import copy
 import os
 
 import numpy as np
@@ -517,10 +518,14 @@ def test_three_nn_and_interpolate(dev):
 @pytest.mark.parametrize("cin,P,B,widths", [(4, 512, 9, (64, 128, 512)), (5, 200, 3, (64, 128, 512)),
                                               (4, 128, 1, (64, 128, 512)), (4, 512, 7, (8, 8, 8)),
                                               (5, 300, 2, (16, 8, 12))])
-def test_fused_pointnet_feat_matches_torch_modules(dev, cin, P, B, widths):
-    """glx_pointnet_feat (one MFMA kernel) == the unfused Conv1d/BatchNorm1d/ReLU/max modules in
+@pytest.mark.parametrize("f16x2", [True, False])
+def test_fused_pointnet_feat_matches_torch_modules(dev, cin, P, B, widths, f16x2, monkeypatch):
+    """glx_pointnet_feat / glx_pointnet_feat_f16x2 (one MFMA kernel) == the unfused Conv1d/BatchNorm1d/ReLU/max modules in
     fp32, also when P is not a multiple of the 128-point pass and for 5 point features."""
     from glenet_amd import dense_path as dp
+    if not f16x2 and widths[2] != 512:
+        pytest.skip("the narrow extractor has one form")
+    monkeypatch.setattr(dp.PointFeat, "F16X2", f16x2)
     torch.manual_seed(cin * 100 + P)
     m = dp.PointFeat(cin, widths).to(dev).eval()
     g = torch.Generator().manual_seed(1)
@@ -539,6 +544,52 @@ def test_fused_pointnet_feat_matches_torch_modules(dev, cin, P, B, widths):
     np.testing.assert_allclose(fused.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
     # the module falls back to the torch path when gradients are needed
     assert m(x.requires_grad_(True)).requires_grad
+
+
+def test_pointnet_feat_f16x2_against_fp64_with_wild_scales(dev):
+    """The f16 x 2 form of the wide extractor carries a power of two per weight row and per point: output channels whose
+    folded weights are 2^-12 .. 2^12 apart, an all-zero weight row, points far from the origin next to points at it and
+    objects whose second layer is dead (every activation 0) all come out within 2^-17 of the output's scale of the
+    fp64 result -- the fp32-MFMA form is held to the same bound beside it."""
+    from glenet_amd import dense_path as dp
+    torch.manual_seed(5)
+    B, cin, P = 6, 4, 333
+    m = dp.PointFeat(cin, (64, 128, 512)).to(dev).eval()
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for bn in (m.bn1, m.bn2, m.bn3):
+            bn.running_mean.copy_((torch.randn(bn.num_features, generator=g) * 0.2).to(dev))
+            bn.running_var.copy_((torch.rand(bn.num_features, generator=g) + 0.5).to(dev))
+            bn.weight.copy_((torch.rand(bn.num_features, generator=g) - 0.3).to(dev))
+            bn.bias.copy_((torch.randn(bn.num_features, generator=g) * 0.1).to(dev))
+        m.conv2.weight.mul_(torch.exp2(torch.randint(-12, 13, (128, 1, 1), generator=g).float()).to(dev))
+        m.conv3.weight.mul_(torch.exp2(torch.randint(-12, 13, (512, 1, 1), generator=g).float()).to(dev))
+        m.conv2.weight[9].zero_()
+        m.conv3.weight[77].zero_()
+    x = torch.randn(B, cin, P, device=dev)
+    x[1] *= 300.0                                   # a far object
+    x[2, :, ::2] = 0.0                              # points at the origin between the others
+    x[3] *= 1e-6
+    md = copy.deepcopy(m).double()
+    with torch.no_grad():
+        xd = x.double()
+        z = torch.relu(md.bn1(md.conv1(xd)))
+        z = torch.relu(md.bn2(md.conv2(z)))
+        y = md.bn3(md.conv3(z))
+        ref = y.max(dim=2)[0]
+        scale = y.abs().amax(dim=2)                 # per object and channel: what the sums were made of
+        # the contraction's own scale: |W3| |h2| per object and channel, at its largest over the points
+        w3 = (md.conv3.weight[:, :, 0] * (md.bn3.weight / torch.sqrt(md.bn3.running_var + md.bn3.eps))[:, None]).abs()
+        mag = torch.einsum("oc,bcp->bop", w3, z.abs()).amax(dim=2) + scale
+    for f16x2 in (True, False):
+        dp.PointFeat.F16X2 = f16x2
+        try:
+            with torch.no_grad():
+                got = m(x).double()
+        finally:
+            dp.PointFeat.F16X2 = True
+        err = ((got - ref).abs() / mag.clamp_min(1e-30)).max().item()
+        assert err < 2.0 ** -17, (f16x2, err)
 
 
 def test_group_points_gather_backward_matches_atomic_scatter(dev):
