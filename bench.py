@@ -643,9 +643,14 @@ def bench_config3(dev, objects=4096, points=512, samples=30):
                              ms_per_sample_fp32_mfma=round(ms_s32 / samples, 3),
                              objects_per_s=round(objects / (ms_s * 1e-3), 1),
                              TFLOPs=round(samples * sample_flops / ms_s / 1e9, 1),
-                             frac_of_fp32_mfma_peak=round(samples * sample_flops / ms_s / 1e9 / MFMA_F32_PEAK_TFLOPS, 3)),
+                             frac_of_16bit_pipe=round(3 * samples * sample_flops / ms_s / 1e9 / MFMA_BF16_PEAK_TFLOPS, 3),
+                             note="TFLOPs = the extractors' nominal (fp32-equivalent) flops per second over the whole sampler "
+                                  "(wide + narrow extractor + the decoder's ~35 small launches); frac_of_16bit_pipe counts the "
+                                  "three fp16 MFMAs per product tile against the dense 16-bit matrix peak",
+                             frac_of_fp32_mfma_peak_fp32_form=round(samples * sample_flops / ms_s32 / 1e9 / MFMA_F32_PEAK_TFLOPS, 3)),
                 train_step=dict(what="forward (posterior + prior encoders, decoder) + losses + backward + clip 10 + AdamW "
-                                     "(flat buffers), one HIP graph, lr = the one-cycle schedule's first step",
+                                     "(flat buffers), one HIP graph, lr = the one-cycle schedule's first step; the 128 -> 512 "
+                                     "layer's forward as f16 x 2 products, everything else fp32",
                                 ms_per_step=round(ms_t, 2),
                                 objects_per_s=round(objects / (ms_t * 1e-3), 1), loss=round(loss, 4),
                                 gflop_per_step=round(3 * objects * per_obj / 1e9, 1),

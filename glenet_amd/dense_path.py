@@ -1583,13 +1583,26 @@ class PointMaxBN(torch.autograd.Function):
         dev = h2.device
         h2 = h2.contiguous()
         W3 = weight.contiguous()
-        w3p = W3.view(32, 16, 8, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
-        vmax, vmin, s1, s2 = (torch.empty((B, 512), dtype=torch.float32, device=dev) for _ in range(4))
+        vmax, vmin = (torch.empty((B, 512), dtype=torch.float32, device=dev) for _ in range(2))
         amax, amin = (torch.empty((B, 512), dtype=torch.int32, device=dev) for _ in range(2))
-        call("glx_pointmax_forward", h2, B, P, w3p, vmax, vmin, amax, amin, s1, s2)
         R = B * P
-        mean_nb = s1.double().sum(0) / R                        # batch mean of y without the bias
-        var = (s2.double().sum(0) / R - mean_nb * mean_nb).clamp_min_(0.0)
+        G2 = H1 = None
+        if PointMaxBN.F16X2:
+            # f16 x 2 products; the batch statistics of y = h2 W3^T from the two moments of h2 the backward needs anyway:
+            # sum_r y = W3 (sum_r h2), sum_r y^2 = diag(W3 (h2^T h2) W3^T)
+            w3h, e3 = PointFeat._f16x2_image(W3.detach())
+            call("glx_pointmax_forward_f16x2", h2, B, P, w3h, e3, vmax, vmin, amax, amin)
+            G2d, H1 = PointMaxBN._moments(h2, R)
+            W3d = W3.detach().double()
+            mean_nb = (W3d @ H1.double()) / R
+            var = (((W3d @ G2d) * W3d).sum(1) / R - mean_nb * mean_nb).clamp_min_(0.0)
+            G2 = G2d.float()
+        else:
+            w3p = W3.view(32, 16, 8, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
+            s1, s2 = (torch.empty((B, 512), dtype=torch.float32, device=dev) for _ in range(2))
+            call("glx_pointmax_forward", h2, B, P, w3p, vmax, vmin, amax, amin, s1, s2)
+            mean_nb = s1.double().sum(0) / R                        # batch mean of y without the bias
+            var = (s2.double().sum(0) / R - mean_nb * mean_nb).clamp_min_(0.0)
         invstd = torch.rsqrt(var + bn.eps).float()
         mean_nb = mean_nb.float()
         scale = gamma * invstd
@@ -1604,8 +1617,19 @@ class PointMaxBN(torch.autograd.Function):
                 bn.running_var.mul_(1 - m).add_(var.float() * (R / max(R - 1, 1)), alpha=m)
                 bn.num_batches_tracked.add_(1)
         ctx.save_for_backward(h2, W3, ext, arg, mean_nb, invstd, scale)
+        ctx.moments = (G2, H1)
         ctx.dims = (B, P, bias is not None)
         return out
+
+    # the 128 -> 512 layer as f16 x 2 products (csrc/glx_pointnet.hip, k_pointmax_fwd_f16); False: fp32 MFMA products
+    F16X2 = True
+
+    @staticmethod
+    def _moments(h2, R):
+        """(h2^T h2 in fp64 from fp32 partial products over row chunks, sum_r h2)."""
+        S = 128 if R % 128 == 0 and R >= 128 * 256 else 1
+        hc = h2.view(S, R // S, 128)
+        return torch.bmm(hc.transpose(1, 2), hc).double().sum(0), h2.sum(0)
 
     @staticmethod
     def backward(ctx, g):
@@ -1631,10 +1655,10 @@ class PointMaxBN(torch.autograd.Function):
             T = torch.empty_like(W3)
             ws = torch.empty(query("glx_pointmax_wsum_workspace_bytes"), dtype=torch.uint8, device=h2.device)
             call("glx_pointmax_wsum", g, arg, h2, B, P, T, ws, size_arg(ws.numel()))
-            S = 128 if R % 128 == 0 and R >= 128 * 256 else 1
-            hc = h2.view(S, R // S, 128)
-            G2 = torch.bmm(hc.transpose(1, 2), hc).sum(0)                       # h2^T h2
-            H1 = h2.sum(0)
+            G2, H1 = ctx.moments
+            if G2 is None:
+                G2d, H1 = PointMaxBN._moments(h2, R)                            # h2^T h2, sum_r h2
+                G2 = G2d.float()
             d_w = scale[:, None] * T - bvec[:, None] * H1[None] - cvec[:, None] * (W3 @ G2 - mean_nb[:, None] * H1[None])
         d_b = torch.zeros_like(dbeta) if has_bias else None                     # sum_r dy = 0 exactly (the BatchNorm removes it)
         return d_h2, d_w, d_b, dgamma, dbeta, None, None, None

@@ -111,12 +111,15 @@ def test_cvae_training_step_matches_reference_golden_on_device(dev):
             np.testing.assert_allclose(v.cpu().numpy(), g["after/" + k], rtol=1e-4, atol=1e-6, err_msg=k)
 
 
+@pytest.mark.parametrize("f16x2", [True, False])
 @pytest.mark.parametrize("B,P,neg", [(6, 100, False), (16, 512, True), (3, 130, True)])
-def test_point_max_batchnorm_without_the_wide_tensor_equals_the_modules(dev, B, P, neg):
+def test_point_max_batchnorm_without_the_wide_tensor_equals_the_modules(dev, B, P, neg, f16x2, monkeypatch):
     """dense_path.PointMaxBN (csrc/glx_pointnet.hip: max / min / arg / moments in one pass over h2, backward through
     128 x 128 algebra) against Conv1d(128, 512, 1) + BatchNorm1d(512) in training mode + max over the points run by torch
     on the (B, 512, P) tensor (point_net.py:22-28): output, running statistics, gradients of input and parameters; negative
-    BatchNorm weights take the min branch; P not a multiple of the 128-point pass."""
+    BatchNorm weights take the min branch; P not a multiple of the 128-point pass.  Both arithmetics of the 128 -> 512 product
+    (f16 x 2 with the statistics from the moments of h2; fp32 MFMA with the sums from the pass)."""
+    monkeypatch.setattr(dp.PointMaxBN, "F16X2", f16x2)
     torch.manual_seed(B * P)
     conv, bn = torch.nn.Conv1d(128, 512, 1).to(dev), torch.nn.BatchNorm1d(512).to(dev).train()
     with torch.no_grad():
