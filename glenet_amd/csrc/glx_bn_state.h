@@ -39,10 +39,11 @@ __device__ __forceinline__ double bn_take(double* p) {                  // read 
 // Threads t < C / 4 of a block hold the block's sums (a0 = first moment, a1 = second) of float4 column t: add them to
 // the block's accumulator set, take a ticket; returns true in EVERY thread of the block that drew the last one.
 // `s_last` = one int of shared memory.  All threads of the block must call it.
+// `coff`: the first of the block's C channels (a launch whose blocks own different channel ranges of one BatchNorm).
 __device__ __forceinline__ bool bn_contribute(BnState* st, int C, const double (&a0)[4], const double (&a1)[4],
-                                              unsigned nblocks, int* s_last) {
+                                              unsigned nblocks, int* s_last, int coff = 0) {
   if ((int)threadIdx.x < (C >> 2)) {
-    double* acc = st->acc[blockIdx.x % BN_SETS];
+    double* acc = st->acc[blockIdx.x % BN_SETS] + coff;
     double seen = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -361,10 +361,15 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       PN_STAGE((t3 + 2) & 31, nb);                                    // slabs 0, 1 of the next pass follow 30, 31
       const uint4* sw = s_w3 + cur * PNH_SLAB_U4;
       pf32x4 acc0 = pf32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+      uint4 wf[8];                         // the tile's eight fragments in one go: one LDS round trip per tile, not four
+#pragma unroll
+      for (int f = 0; f < 8; ++f) wf[f] = sw[f * 64 + lane];
+      const int nw = s_e3[16 * t3 + j];
+      asm volatile("" ::: "memory");       // (keeps the reads above the products)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const pf16x8 Wa = __builtin_bit_cast(pf16x8, sw[(s * 2 + 0) * 64 + lane]);
-        const pf16x8 Wb = __builtin_bit_cast(pf16x8, sw[(s * 2 + 1) * 64 + lane]);
+        const pf16x8 Wa = __builtin_bit_cast(pf16x8, wf[s * 2 + 0]);
+        const pf16x8 Wb = __builtin_bit_cast(pf16x8, wf[s * 2 + 1]);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ya[0][s], Wb, acc0, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Yb[0][s], Wa, acc0, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ya[0][s], Wa, acc0, 0, 0, 0);
@@ -372,7 +377,6 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Yb[1][s], Wa, acc1, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ya[1][s], Wa, acc1, 0, 0, 0);
       }
-      const int nw = s_e3[16 * t3 + j];
       float v = mx[t3];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {

@@ -31,9 +31,14 @@ typedef float ft4 __attribute__((ext_vector_type(4)));
 template <int K, int N, bool STATS>
 __global__ __launch_bounds__(RW_THREADS) void k_rows_linear(const float* __restrict__ x, const float* __restrict__ w,
                                                             float* __restrict__ z, int rows, const int* __restrict__ n_live,
-                                                            BnState* __restrict__ st, BnFinalize f) {
+                                                            BnState* __restrict__ st, BnFinalize f, int ldz) {
+  // blockIdx.y: the block's N of the ldz output channels (a 128-wide layer = two column halves of 64: the weights of a half fit
+  // the registers, the BatchNorm is per channel anyway)
   constexpr int KS = K / 16, NT = N / 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+  const int coff = blockIdx.y * N;
+  w += (size_t)coff * K;
+  z += coff;
   int n = rows;
   if (n_live) n = min(rows, *n_live);
   ft4 wv[NT][KS];          // A operand: output channel 16 nt + r, input channels 16 s + 4 q + e
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(RW_THREADS) void k_rows_linear(const float* __restr
     if (row < n) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        *reinterpret_cast<ft4*>(z + (long long)row * N + 16 * nt + 4 * q) = acc[nt];
+        *reinterpret_cast<ft4*>(z + (long long)row * ldz + 16 * nt + 4 * q) = acc[nt];
         if (STATS) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -124,9 +129,9 @@ __global__ __launch_bounds__(RW_THREADS) void k_rows_linear(const float* __restr
         a1[i] += s_red[wv_][threadIdx.x][1][i];
       }
   }
-  if (!bn_contribute(st, N, a0, a1, gridDim.x, &s_last)) return;
+  if (!bn_contribute(st, N, a0, a1, gridDim.x * gridDim.y, &s_last, coff)) return;
   __shared__ double s_fin[RW_THREADS][2];
-  bn_finalize_sets<false, RW_THREADS>(st, f, N, n, s_fin);
+  bn_finalize_sets<false, RW_THREADS>(st, f, ldz, n, s_fin);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -143,8 +148,14 @@ template <int CI, int CO, bool BN>
 __global__ __launch_bounds__(RW_THREADS) void k_rows_linear_bwd(const float* __restrict__ x, const float* __restrict__ z,
                                                                 const float* __restrict__ dy, const float* __restrict__ w,
                                                                 int rows, const int* __restrict__ n_live, RowsBwdBn bn,
-                                                                float* __restrict__ gx, float* __restrict__ part) {
+                                                                float* __restrict__ gx, float* __restrict__ part, int ldo, int coff,
+                                                                int accumulate) {
+  // the launch's CO of the layer's ldo output channels start at `coff` (dy, z, w, the coefficients); accumulate: gx += (the
+  // second half of a 128-wide layer, launched behind the first)
   constexpr int MT = CI / 16, KS = CO / 16, NA = CO / 16, NB = CI / 16, LD = CO + 16;
+  w += (size_t)coff * CI;
+  dy += coff;
+  if (BN) z += coff;
   __shared__ float s_dz[RW_WAVES][16 * LD];
   __shared__ float s_acc[NA * NB * 4 * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
@@ -163,14 +174,14 @@ __global__ __launch_bounds__(RW_THREADS) void k_rows_linear_bwd(const float* __r
   if (BN) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const int c = 16 * s + 4 * q;
+      const int c = coff + 16 * s + 4 * q;
       c_sc[s] = *reinterpret_cast<const ft4*>(bn.coef_fwd + c);
-      c_sh[s] = *reinterpret_cast<const ft4*>(bn.coef_fwd + CO + c);
+      c_sh[s] = *reinterpret_cast<const ft4*>(bn.coef_fwd + ldo + c);
       c_mu[s] = *reinterpret_cast<const ft4*>(bn.mean + c);
       c_is[s] = *reinterpret_cast<const ft4*>(bn.invstd + c);
       c_a[s] = *reinterpret_cast<const ft4*>(bn.coef3 + c);
-      c_b[s] = *reinterpret_cast<const ft4*>(bn.coef3 + CO + c);
-      c_cc[s] = *reinterpret_cast<const ft4*>(bn.coef3 + 2 * CO + c);
+      c_b[s] = *reinterpret_cast<const ft4*>(bn.coef3 + ldo + c);
+      c_cc[s] = *reinterpret_cast<const ft4*>(bn.coef3 + 2 * ldo + c);
     }
   }
   ft4 accw[NA][NB];
@@ -184,7 +195,7 @@ __global__ __launch_bounds__(RW_THREADS) void k_rows_linear_bwd(const float* __r
     const int row0 = tile * 16;
     // ---- dz of the tile, lane (r, q): row r, channels 16 s + 4 q ..
     const bool live = row0 + r < n;
-    const long long ro = (long long)min(row0 + r, n - 1) * CO + 4 * q;
+    const long long ro = (long long)min(row0 + r, n - 1) * ldo + 4 * q;
     ft4 dzv[KS], zv[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -228,7 +239,10 @@ __global__ __launch_bounds__(RW_THREADS) void k_rows_linear_bwd(const float* __r
       }
       if (live) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<ft4*>(gx + (long long)(row0 + r) * CI + 16 * mt + 4 * q) = acc[mt];
+        for (int mt = 0; mt < MT; ++mt) {
+          ft4* dst = reinterpret_cast<ft4*>(gx + (long long)(row0 + r) * CI + 16 * mt + 4 * q);
+          *dst = accumulate ? *dst + acc[mt] : acc[mt];
+        }
       }
     }
     // ---- weight gradient: the tile transposed through the wave's LDS patch (k = rows)
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(RW_THREADS) void k_rows_linear_bwd(const float* __r
     }
   }
   // rows past the live count: zero gradient
-  if (gx) {
+  if (gx && !accumulate) {
     const long long e0 = (long long)n * CI, e1 = (long long)rows * CI;
     for (long long e = e0 + ((long long)blockIdx.x * RW_THREADS + threadIdx.x) * 4; e < e1; e += (long long)gridDim.x * RW_THREADS * 4)
       *reinterpret_cast<ft4*>(gx + e) = ft4{0.f, 0.f, 0.f, 0.f};
@@ -326,14 +340,16 @@ __global__ __launch_bounds__(256) void k_rows_wgrad_reduce(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ host
+// Cout = 128: two column halves of 64 (forward: blockIdx.y; backward: two launches, the second adding its part of dX)
 static bool rows_dims_ok(int Cin, int Cout) {
-  return (Cin == 16 || Cin == 32 || Cin == 64) && (Cout == 16 || Cout == 32 || Cout == 64);
+  return (Cin == 16 || Cin == 32 || Cin == 64) && (Cout == 16 || Cout == 32 || Cout == 64 || Cout == 128);
 }
+static int rows_cols_per_launch(int Cout) { return Cout > 64 ? 64 : Cout; }
 
 extern "C" int glx_rows_linear_supported(int Cin, int Cout) { return rows_dims_ok(Cin, Cout) ? 1 : 0; }
 
 extern "C" size_t glx_rows_linear_workspace_bytes(int Cin, int Cout) {
-  return glx_align((size_t)RW_BWD_BLOCKS * (Cin > 0 ? Cin : 1) * (Cout > 0 ? Cout : 1) * sizeof(float));
+  return glx_align((size_t)RW_BWD_BLOCKS * (Cin > 0 ? Cin : 1) * (Cout > 0 ? rows_cols_per_launch(Cout) : 1) * sizeof(float));
 }
 
 static int rows_fwd_blocks(int rows) {
@@ -343,10 +359,10 @@ static int rows_fwd_blocks(int rows) {
 
 template <int K, int N>
 static void rows_fwd_launch(const float* x, const float* w, float* z, int rows, const int32_t* n_live, BnState* st,
-                            const BnFinalize& f, hipStream_t stream) {
-  const int blocks = rows_fwd_blocks(rows);
-  if (st) hipLaunchKernelGGL((k_rows_linear<K, N, true>), dim3(blocks), dim3(RW_THREADS), 0, stream, x, w, z, rows, (const int*)n_live, st, f);
-  else hipLaunchKernelGGL((k_rows_linear<K, N, false>), dim3(blocks), dim3(RW_THREADS), 0, stream, x, w, z, rows, (const int*)n_live, st, f);
+                            const BnFinalize& f, int Cout, hipStream_t stream) {
+  const dim3 grid(rows_fwd_blocks(rows), Cout / N);
+  if (st) hipLaunchKernelGGL((k_rows_linear<K, N, true>), grid, dim3(RW_THREADS), 0, stream, x, w, z, rows, (const int*)n_live, st, f, Cout);
+  else hipLaunchKernelGGL((k_rows_linear<K, N, false>), grid, dim3(RW_THREADS), 0, stream, x, w, z, rows, (const int*)n_live, st, f, Cout);
 }
 
 #define RW_DISPATCH(CI_, CO_, CALL)                                                           \
@@ -367,13 +383,13 @@ extern "C" int glx_rows_linear_bn_forward(const float* x, int rows, int Cin, con
                                           float* z, const float* gamma, const float* beta, float eps, float momentum,
                                           float* running_mean, float* running_var, float* coef, float* save_mean,
                                           float* save_invstd, void* bn_state, void* stream) {
-  GLX_REQUIRE(rows_dims_ok(Cin, Cout), "glx_rows_linear_bn_forward: channels %d -> %d (16 / 32 / 64 each)", Cin, Cout);
+  GLX_REQUIRE(rows_dims_ok(Cin, Cout), "glx_rows_linear_bn_forward: channels %d -> %d (16 / 32 / 64 in, 16 / 32 / 64 / 128 out)", Cin, Cout);
   GLX_REQUIRE(w && (rows == 0 || (x && z)), "glx_rows_linear_bn_forward: null pointer");
   GLX_REQUIRE(!bn_state || (coef && save_mean && save_invstd), "glx_rows_linear_bn_forward: statistics without their outputs");
   if (rows <= 0) return GLX_OK;
   BnFinalize f{gamma, beta, eps, momentum, coef, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, nullptr, 0};
-#define RW_FWD(CI_, CO_) rows_fwd_launch<CI_, CO_>(x, w, z, rows, n_live, (BnState*)bn_state, f, (hipStream_t)stream)
-  RW_DISPATCH(Cin, Cout, RW_FWD)
+#define RW_FWD(CI_, CO_) rows_fwd_launch<CI_, CO_>(x, w, z, rows, n_live, (BnState*)bn_state, f, Cout, (hipStream_t)stream)
+  RW_DISPATCH(Cin, rows_cols_per_launch(Cout), RW_FWD)
 #undef RW_FWD
   GLX_LAUNCH_CHECK();
   return GLX_OK;
@@ -381,13 +397,13 @@ extern "C" int glx_rows_linear_bn_forward(const float* x, int rows, int Cin, con
 
 template <int CI, int CO>
 static void rows_bwd_launch(const float* x, const float* z, const float* dy, const float* w, int rows, const int32_t* n_live,
-                            const RowsBwdBn& bn, float* gx, float* part, int blocks, hipStream_t stream) {
+                            const RowsBwdBn& bn, float* gx, float* part, int blocks, int Cout, int coff, hipStream_t stream) {
   if (bn.coef3)
     hipLaunchKernelGGL((k_rows_linear_bwd<CI, CO, true>), dim3(blocks), dim3(RW_THREADS), 0, stream, x, z, dy, w, rows,
-                       (const int*)n_live, bn, gx, part);
+                       (const int*)n_live, bn, gx, part, Cout, coff, coff > 0 ? 1 : 0);
   else
     hipLaunchKernelGGL((k_rows_linear_bwd<CI, CO, false>), dim3(blocks), dim3(RW_THREADS), 0, stream, x, z, dy, w, rows,
-                       (const int*)n_live, bn, gx, part);
+                       (const int*)n_live, bn, gx, part, Cout, coff, coff > 0 ? 1 : 0);
 }
 
 // The backward of glx_rows_linear_bn_forward (+ glx_bn_apply_forward): dy = the gradient of the TRANSFORMED output; coef3 (from
@@ -398,7 +414,7 @@ extern "C" int glx_rows_linear_bn_backward(const float* x, const float* z, const
                                            int Cout, const int32_t* n_live, const float* coef_fwd, int relu, const float* coef3,
                                            const float* mean, const float* invstd, float* gx, float* gw, void* workspace,
                                            size_t workspace_bytes, void* stream) {
-  GLX_REQUIRE(rows_dims_ok(Cin, Cout), "glx_rows_linear_bn_backward: channels %d -> %d (16 / 32 / 64 each)", Cin, Cout);
+  GLX_REQUIRE(rows_dims_ok(Cin, Cout), "glx_rows_linear_bn_backward: channels %d -> %d (16 / 32 / 64 in, 16 / 32 / 64 / 128 out)", Cin, Cout);
   GLX_REQUIRE(w && (rows == 0 || (x && dy)), "glx_rows_linear_bn_backward: null pointer");
   GLX_REQUIRE(!coef3 || (z && coef_fwd && mean && invstd), "glx_rows_linear_bn_backward: BatchNorm backward without z / coefficients");
   GLX_REQUIRE(!gw || (workspace && workspace_bytes >= glx_rows_linear_workspace_bytes(Cin, Cout)),
@@ -416,14 +432,17 @@ extern "C" int glx_rows_linear_bn_backward(const float* x, const float* z, const
   const int blocks = want < 1 ? 1 : (want > RW_BWD_BLOCKS ? RW_BWD_BLOCKS : want);
   RowsBwdBn bn{coef_fwd, coef3, mean, invstd, relu};
   float* part = gw ? (float*)workspace : nullptr;
-#define RW_BWD(CI_, CO_) rows_bwd_launch<CI_, CO_>(x, z, dy, w, rows, n_live, bn, gx, part, blocks, st)
-  RW_DISPATCH(Cin, Cout, RW_BWD)
+  const int cols = rows_cols_per_launch(Cout);
+  for (int coff = 0; coff < Cout; coff += cols) {          // (the halves share the workspace: same stream, one after the other)
+#define RW_BWD(CI_, CO_) rows_bwd_launch<CI_, CO_>(x, z, dy, w, rows, n_live, bn, gx, part, blocks, Cout, coff, st)
+    RW_DISPATCH(Cin, cols, RW_BWD)
 #undef RW_BWD
-  GLX_LAUNCH_CHECK();
-  if (gw) {
-    hipLaunchKernelGGL(k_rows_wgrad_reduce, dim3(glx_divup(Cin * Cout, RW_RED_EL)), dim3(256), 0, st, (const float*)part, blocks, Cin,
-                       Cout, gw);
     GLX_LAUNCH_CHECK();
+    if (gw) {
+      hipLaunchKernelGGL(k_rows_wgrad_reduce, dim3(glx_divup(Cin * cols, RW_RED_EL)), dim3(256), 0, st, (const float*)part, blocks, Cin,
+                         cols, gw + (size_t)coff * Cin);
+      GLX_LAUNCH_CHECK();
+    }
   }
   return GLX_OK;
 }

@@ -1458,27 +1458,67 @@ class PointFeat(nn.Module):
     ROWS_MAX = 1 << 22
 
     @classmethod
-    def _rows_linear(cls, x2d, conv):
+    def _rows_linear(cls, x2d, conv, bias=True):
         """x2d (rows, C_in) @ W^T + b as ROW_CHUNKS batched products when the matrix is tall: the weight gradient
         autograd derives is then a batched GEMM + a sum over the batch (split-K) instead of ONE (C_out x C_in) GEMM
         with K = rows, for which the library's own choice at 2.1 M rows is slow."""
         w, rows = conv.weight[:, :, 0], x2d.shape[0]
+        b_ = conv.bias if bias else None
         s_ = cls.ROW_CHUNKS
         if rows % s_ == 0 and rows // s_ >= 64:
             y = torch.bmm(x2d.view(s_, rows // s_, -1), w.t().unsqueeze(0).expand(s_, -1, -1)).view(rows, -1)
-            return y if conv.bias is None else y + conv.bias
-        return F.linear(x2d, w, conv.bias)
+            return y if b_ is None else y + b_
+        return F.linear(x2d, w, b_)
+
+    # A bias in front of a training-mode BatchNorm moves the batch mean and nothing else: the normalised output is the same
+    # function of x W^T, the bias's gradient is the sum of the BatchNorm's input gradient, which is zero.  True: the product
+    # runs without the bias (one elementwise pass over the (rows, C) matrix less, and one column reduction less in the
+    # backward), the running mean gets momentum x bias added, the bias's gradient is an exact zero (the reference's is
+    # rounding noise around it).
+    BIAS_INTO_RUNNING_MEAN = True
+
+    # Layers up to 64 -> 128 channels on csrc/glx_rows.hip (RowsConvBN: the product with the BatchNorm statistics in its
+    # epilogue + the transform forward; the statistics launch + ONE launch that applies the BatchNorm / ReLU backward on load and
+    # forms both gradients backward) instead of library products + separate BatchNorm passes.  The 4 point features of the
+    # first layer are padded to the kernels' 16.
+    OWN_ROW_LAYERS = True
+
+    @classmethod
+    def _rows_layer(cls, x2d, conv, bn, relu):
+        from .spconv import core
+        fold = cls.BIAS_INTO_RUNNING_MEAN and conv.bias is not None and bn.track_running_stats
+        if not fold and conv.bias is not None:
+            return core.fused_train_bn(bn, cls._rows_linear(x2d, conv), relu, None)
+        cout, cin = conv.weight.shape[:2]
+        kin = cin if cin in (16, 32, 64) else (16 if cin < 16 else 0)
+        if cls.OWN_ROW_LAYERS and kin and core.USE_BN_STATE and _lib.query("glx_rows_linear_supported", kin, cout):
+            from .pcdet_ops.pointnet2.pointnet2_stack import voxel_pool_modules as vpm
+            w = conv.weight[:, :, 0]
+            if kin != cin:
+                x2d, w = F.pad(x2d, (0, kin - cin)), F.pad(w, (0, kin - cin))
+            vpm._count(bn)
+            h = vpm.RowsConvBN.apply(x2d, w, bn.weight, bn.bias, bn, relu, None)
+            if conv.bias is not None:
+                h = _ZeroGradOperand.apply(h, conv.bias)
+        else:
+            z = cls._rows_linear(x2d, conv, bias=False)
+            if conv.bias is not None:
+                z = _ZeroGradOperand.apply(z, conv.bias)
+            h = core.fused_train_bn(bn, z, relu, None)
+        if conv.bias is not None:
+            with torch.no_grad():
+                bn.running_mean.add_(conv.bias, alpha=bn.momentum)
+        return h
 
     def _forward_train_rows(self, x):
-        from .spconv import core
         b, cin, p = x.shape
         rows = x.transpose(1, 2).reshape(b * p, cin)
-        h = core.fused_train_bn(self.bn1, self._rows_linear(rows, self.conv1), True, None)
-        h = core.fused_train_bn(self.bn2, self._rows_linear(h, self.conv2), True, None)
+        h = self._rows_layer(rows, self.conv1, self.bn1, True)
+        h = self._rows_layer(h, self.conv2, self.bn2, True)
         if self.USE_POINTMAX and h.shape[1] == 128 and self.conv3.out_channels == 512 and self.bn3.affine:
             # the 512-wide layer + BatchNorm + max over the points without the (B, P, 512) tensor
             return PointMaxBN.apply(h, self.conv3.weight[:, :, 0], self.conv3.bias, self.bn3.weight, self.bn3.bias, self.bn3, b, p)
-        h = core.fused_train_bn(self.bn3, self._rows_linear(h, self.conv3), False, None)
+        h = self._rows_layer(h, self.conv3, self.bn3, False)
         return h.view(b, p, -1).amax(dim=1)
 
     # ---- eval-mode fast path: one hand-written MFMA kernel for the whole extractor
@@ -1570,6 +1610,19 @@ class PointFeat(nn.Module):
             call("glx_pointnet_feat_small", x, B, cin, P, self.conv1.out_channels, self.conv2.out_channels,
                  c3, w1, b1, w2p, b2, w3p, b3, out)
         return out
+
+
+class _ZeroGradOperand(torch.autograd.Function):
+    """z, with `other` tied into the graph at an exactly zero gradient (PointFeat.BIAS_INTO_RUNNING_MEAN)."""
+
+    @staticmethod
+    def forward(ctx, z, other):
+        ctx.save_for_backward(other)
+        return z.view_as(z)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, torch.zeros_like(ctx.saved_tensors[0])
 
 
 class PointMaxBN(torch.autograd.Function):

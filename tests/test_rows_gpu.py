@@ -41,6 +41,8 @@ def _reference(seq, x, cot, live):
     (4099, 16, 64, True, 4001),
     (9000, 64, 64, True, None),
     (2048, 32, 16, False, 37),
+    (50000, 64, 128, True, None),          # two column halves (the CVAE's 64 -> 128 point layer)
+    (7001, 16, 128, False, 6500),
 ])
 def test_rows_conv_bn_matches_the_reference_modules_in_fp64(dev, rows, cin, cout, relu, live):
     from glenet_amd.pcdet_ops.pointnet2.pointnet2_stack import voxel_pool_modules as vpm
@@ -105,7 +107,7 @@ def test_rows_conv_bn_equals_the_library_formulation_it_replaces(dev):
     assert torch.allclose(seq[1].running_var, old[1].running_var, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("rows,cin,cout", [(16, 32, 32), (33, 16, 16), (70001, 64, 64), (12345, 32, 64)])
+@pytest.mark.parametrize("rows,cin,cout", [(16, 32, 32), (33, 16, 16), (70001, 64, 64), (12345, 32, 64), (40003, 64, 128)])
 def test_plain_product_through_the_c_abi(dev, rows, cin, cout):
     """bn_state == NULL / coef3 == NULL: z = x w^T, gx = dy w, gw = dy^T x (fp64 products as the yardstick); twice: the weight
     gradient's partial sums are added in a fixed order (bitwise equal)."""
