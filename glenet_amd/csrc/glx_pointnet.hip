@@ -684,17 +684,19 @@ extern "C" int glx_pointmax_forward(const float* h2, int B, int P, const float* 
 
 // The same pass with f16 x 2 products (the arithmetic and the structure of k_pointnet_feat_f16's layer 3: a point's own power of
 // two, the weight rows' powers of two from the host, three fp16 MFMAs per product tile, W3's slabs by DMA through a ring of
-// three, the product transposed): a lane keeps the running max / min and the points they occur at of ITS channel and its eight
+// three, the product transposed): a lane keeps the running maximum and the point it occurs at of ITS channel and its eight
 // points per pass in registers for all 32 channel tiles; the four lanes of a channel and the four waves meet once, at the end.
-// The sums of y and y^2 are not taken here: they are  W3 (sum_r h2)  and  diag(W3 (h2^T h2) W3^T), two quantities the backward
-// needs anyway (dense_path.PointMaxBN).  Ties go to the lower point index, as in k_pointmax_fwd.
+// ONE extreme per channel: which of max / min the BatchNorm needs is the sign of its weight, known before the launch, so the
+// caller hands in the rows of W3 with that sign and gets max_p (sign y) (dense_path.PointMaxBN) -- half the epilogue and half
+// the running registers of a pass that keeps both.  The sums of y and y^2 are not taken here either: they are  W3 (sum_r h2)
+// and  diag(W3 (h2^T h2) W3^T), two quantities the backward needs anyway.  Ties go to the lower point index.
 __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pointmax_fwd_f16(
-    const float* __restrict__ h2, int P, const uint4* __restrict__ W3h, const int* __restrict__ ew3, float* __restrict__ vmax,
-    float* __restrict__ vmin, int* __restrict__ amax, int* __restrict__ amin) {
+    const float* __restrict__ h2, int P, const uint4* __restrict__ W3h, const int* __restrict__ ew3, float* __restrict__ vext,
+    int* __restrict__ aext) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   uint4* s_w3 = reinterpret_cast<uint4*>(smem);                        // PNH_RING slabs                       (24 KB)
   int* s_e3 = reinterpret_cast<int*>(s_w3 + PNH_RING * PNH_SLAB_U4);   // 512: MINUS the rows' exponents
-  float* s_st = reinterpret_cast<float*>(s_e3 + PN_C3);                // 4 quantities x 4 waves x 512        (32 KB)
+  float* s_st = reinterpret_cast<float*>(s_e3 + PN_C3);                // 2 quantities x 4 waves x 512        (16 KB)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, q = lane >> 4;
   const long long obj = blockIdx.x;
@@ -713,10 +715,12 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   pn_wait_vm<0>();
   __syncthreads();
 
-  float mx[32], mn[32];
-  int ix[32], in_[32];
+  // running maxima in the CHANNEL's scale (y 2^ew[c]: the row's power of two is the same for every point, it comes out once
+  // at the end)
+  float mx[32];
+  int ix[32];
 #pragma unroll
-  for (int t = 0; t < 32; ++t) { mx[t] = -FLT_MAX; mn[t] = FLT_MAX; ix[t] = 0; in_[t] = 0; }
+  for (int t = 0; t < 32; ++t) { mx[t] = -FLT_MAX; ix[t] = 0; }
   unsigned cur = 0;
 
   const float* ho = h2 + obj * (long long)P * PN_C2;
@@ -752,16 +756,25 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
     }
     const int pb = p0 + wave * 32 + 4 * q;       // this lane's points: pb + e (tile 0), pb + 16 + e (tile 1)
+    int pidx[2][4];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const int pp = pb + 16 * pt + e; pidx[pt][e] = pp < P ? pp : P - 1; }
 #pragma unroll
     for (int t3 = 0; t3 < 32; ++t3) {
       const unsigned nb = cur >= 1 ? cur - 1 : PNH_RING - 1;
       PM_STAGE((t3 + 2) & 31, nb);
       const uint4* sw = s_w3 + cur * PNH_SLAB_U4;
       pf32x4 acc0 = pf32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+      uint4 wf[8];
+#pragma unroll
+      for (int f = 0; f < 8; ++f) wf[f] = sw[f * 64 + lane];
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const pf16x8 Wa = __builtin_bit_cast(pf16x8, sw[(s * 2 + 0) * 64 + lane]);
-        const pf16x8 Wb = __builtin_bit_cast(pf16x8, sw[(s * 2 + 1) * 64 + lane]);
+        const pf16x8 Wa = __builtin_bit_cast(pf16x8, wf[s * 2 + 0]);
+        const pf16x8 Wb = __builtin_bit_cast(pf16x8, wf[s * 2 + 1]);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ya[0][s], Wb, acc0, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Yb[0][s], Wa, acc0, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ya[0][s], Wa, acc0, 0, 0, 0);
@@ -769,19 +782,16 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Yb[1][s], Wa, acc1, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ya[1][s], Wa, acc1, 0, 0, 0);
       }
-      const int nw = s_e3[16 * t3 + j];
-      float bmx = mx[t3], bmn = mn[t3];
-      int bix = ix[t3], bin = in_[t3];
+      float bmx = mx[t3];
+      int bix = ix[t3];
 #pragma unroll
       for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int pp = pb + 16 * pt + e, p = pp < P ? pp : P - 1;
-          const float v = ldexpf(pt ? acc1[e] : acc0[e], nw + nex[pt][e]);
-          if (v > bmx) { bmx = v; bix = p; }
-          if (v < bmn) { bmn = v; bin = p; }
+          const float v = ldexpf(pt ? acc1[e] : acc0[e], nex[pt][e]);
+          if (v > bmx) { bmx = v; bix = pidx[pt][e]; }
         }
-      mx[t3] = bmx; mn[t3] = bmn; ix[t3] = bix; in_[t3] = bin;
+      mx[t3] = bmx; ix[t3] = bix;
       cur = cur == PNH_RING - 1 ? 0 : cur + 1;
       pn_wait_vm<2>();
       __syncthreads();
@@ -792,54 +802,51 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   // ---- the four lanes of a channel (16 apart: ascending point blocks), then the four waves
 #pragma unroll
   for (int t3 = 0; t3 < 32; ++t3) {
-    float bmx = mx[t3], bmn = mn[t3];
-    int bix = ix[t3], bin = in_[t3];
+    float bmx = ldexpf(mx[t3], s_e3[16 * t3 + j]);
+    int bix = ix[t3];
 #pragma unroll
     for (int o = 16; o < 64; o <<= 1) {
-      const float omx = __shfl_xor(bmx, o, 64), omn = __shfl_xor(bmn, o, 64);
-      const int oix = __shfl_xor(bix, o, 64), oin = __shfl_xor(bin, o, 64);
+      const float omx = __shfl_xor(bmx, o, 64);
+      const int oix = __shfl_xor(bix, o, 64);
       if (omx > bmx || (omx == bmx && oix < bix)) { bmx = omx; bix = oix; }
-      if (omn < bmn || (omn == bmn && oin < bin)) { bmn = omn; bin = oin; }
     }
     if (q == 0) {
       const int c = 16 * t3 + j;
-      s_st[(0 * 4 + wave) * PN_C3 + c] = bmx;
-      s_st[(1 * 4 + wave) * PN_C3 + c] = bmn;
-      reinterpret_cast<int*>(s_st)[(2 * 4 + wave) * PN_C3 + c] = bix;
-      reinterpret_cast<int*>(s_st)[(3 * 4 + wave) * PN_C3 + c] = bin;
+      s_st[wave * PN_C3 + c] = bmx;
+      reinterpret_cast<int*>(s_st)[(4 + wave) * PN_C3 + c] = bix;
     }
   }
   __syncthreads();
   for (int c = tid; c < PN_C3; c += PN_THREADS) {
-    float bmx = -FLT_MAX, bmn = FLT_MAX;
-    int bix = 0, bin = 0;
+    float bmx = -FLT_MAX;
+    int bix = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      const float vmx = s_st[(0 * 4 + w) * PN_C3 + c], vmn = s_st[(1 * 4 + w) * PN_C3 + c];
-      const int vix = reinterpret_cast<const int*>(s_st)[(2 * 4 + w) * PN_C3 + c];
-      const int vin = reinterpret_cast<const int*>(s_st)[(3 * 4 + w) * PN_C3 + c];
+      const float vmx = s_st[w * PN_C3 + c];
+      const int vix = reinterpret_cast<const int*>(s_st)[(4 + w) * PN_C3 + c];
       if (vmx > bmx || (vmx == bmx && vix < bix)) { bmx = vmx; bix = vix; }
-      if (vmn < bmn || (vmn == bmn && vin < bin)) { bmn = vmn; bin = vin; }
     }
     const long long o = obj * PN_C3 + c;
-    vmax[o] = bmx; vmin[o] = bmn; amax[o] = bix; amin[o] = bin;
+    vext[o] = bmx;
+    aext[o] = bix;
   }
 }
 
-// W3h / ew3: the (512, 128) weight as glx_pointnet_feat_f16x2 takes it (two fp16 planes of w 2^ew[row] in operand order).
-extern "C" int glx_pointmax_forward_f16x2(const float* h2, int B, int P, const void* W3h, const int32_t* ew3, float* vmax,
-                                          float* vmin, int32_t* amax, int32_t* amin, void* stream) {
+// vext[b, c] = max_p y[b, p, c], aext = the (lowest) point it occurs at, for y = h2 W^T with W the (512, 128) weight whose f16 x 2
+// image W3h / ew3 is (as glx_pointnet_feat_f16x2 takes it).  A caller that needs the MINIMUM of a channel hands in that row negated.
+extern "C" int glx_pointmax_forward_f16x2(const float* h2, int B, int P, const void* W3h, const int32_t* ew3, float* vext,
+                                          int32_t* aext, void* stream) {
   if (B <= 0) return GLX_OK;
-  GLX_REQUIRE(h2 && W3h && ew3 && vmax && vmin && amax && amin, "glx_pointmax_forward_f16x2: null pointer");
+  GLX_REQUIRE(h2 && W3h && ew3 && vext && aext, "glx_pointmax_forward_f16x2: null pointer");
   GLX_REQUIRE(P >= 1, "glx_pointmax_forward_f16x2: P >= 1");
-  const size_t lds = (size_t)PNH_RING * PNH_SLAB_U4 * 16 + (size_t)(PN_C3 + 4 * 4 * PN_C3) * 4;
+  const size_t lds = (size_t)PNH_RING * PNH_SLAB_U4 * 16 + (size_t)(PN_C3 + 2 * 4 * PN_C3) * 4;
   static bool attr_set = false;
   if (!attr_set) {
     GLX_HIP(hipFuncSetAttribute((const void*)k_pointmax_fwd_f16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_pointmax_fwd_f16, dim3(B), dim3(PN_THREADS), lds, (hipStream_t)stream, h2, P, (const uint4*)W3h, ew3, vmax,
-                     vmin, (int*)amax, (int*)amin);
+  hipLaunchKernelGGL(k_pointmax_fwd_f16, dim3(B), dim3(PN_THREADS), lds, (hipStream_t)stream, h2, P, (const uint4*)W3h, ew3, vext,
+                     (int*)aext);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

@@ -1643,8 +1643,13 @@ class PointMaxBN(torch.autograd.Function):
         if PointMaxBN.F16X2:
             # f16 x 2 products; the batch statistics of y = h2 W3^T from the two moments of h2 the backward needs anyway:
             # sum_r y = W3 (sum_r h2), sum_r y^2 = diag(W3 (h2^T h2) W3^T)
-            w3h, e3 = PointFeat._f16x2_image(W3.detach())
-            call("glx_pointmax_forward_f16x2", h2, B, P, w3h, e3, vmax, vmin, amax, amin)
+            # one extreme per channel: the BatchNorm's weight decides which (scale = gamma invstd, invstd > 0), so the rows of W3
+            # go in with its sign and the pass returns max_p (sign y)
+            sgn = torch.where(gamma.detach() >= 0, 1.0, -1.0)
+            w3h, e3 = PointFeat._f16x2_image(W3.detach() * sgn[:, None])
+            call("glx_pointmax_forward_f16x2", h2, B, P, w3h, e3, vmax, amax)
+            vmax *= sgn
+            vmin, amin = vmax, amax
             G2d, H1 = PointMaxBN._moments(h2, R)
             W3d = W3.detach().double()
             mean_nb = (W3d @ H1.double()) / R

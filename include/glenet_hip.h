@@ -1082,10 +1082,11 @@ int glx_head1x1_weight_grad(const float* const* grad, const float* x, int64_t M,
  * glx_pointmax_wsum: T (512, 128) = sum_b g[b, c] * h2[b * P + arg[b, c], :]. */
 int glx_pointmax_forward(const float* h2, int B, int P, const float* W3p, float* vmax, float* vmin, int32_t* amax,
                          int32_t* amin, float* s1, float* s2, void* stream);
-/* glx_pointmax_forward with f16 x 2 products (three fp16 MFMAs per product tile, >= 20.4 bits, fp32 sums) and without the two
- * sums (the caller takes them from the moments of h2).  W3h / ew3: the weight as glx_pointnet_feat_f16x2 takes it. */
-int glx_pointmax_forward_f16x2(const float* h2, int B, int P, const void* W3h, const int32_t* ew3, float* vmax, float* vmin,
-                               int32_t* amax, int32_t* amin, void* stream);
+/* glx_pointmax_forward's one-sided twin with f16 x 2 products (three fp16 MFMAs per product tile, >= 20.4 bits, fp32 sums):
+ * vext[b, c] = max_p (h2 W^T)[b, p, c] and the lowest point it occurs at; no sums (the caller takes them from the moments of h2).
+ * W3h / ew3: the weight as glx_pointnet_feat_f16x2 takes it; a channel's MINIMUM = that row handed in negated. */
+int glx_pointmax_forward_f16x2(const float* h2, int B, int P, const void* W3h, const int32_t* ew3, float* vext, int32_t* aext,
+                               void* stream);
 int glx_pointmax_scatter(const int32_t* arg, const float* coef, const float* W3, const float* init, int B, int P, float* dh2,
                          void* stream);
 size_t glx_pointmax_wsum_workspace_bytes(void);
