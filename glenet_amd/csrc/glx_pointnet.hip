@@ -851,6 +851,115 @@ extern "C" int glx_pointmax_forward_f16x2(const float* h2, int B, int P, const v
   return GLX_OK;
 }
 
+// y[r, :] = init + x[r, :] W^T  for a 128 x 128 W on a tall row matrix, f16 x 2 products: the dense part of the 128 -> 512 layer's
+// input gradient (dh2 = ... - v - h2 (W3^T diag(c) W3), dense_path.PointMaxBN.backward), 69 GFLOP at configs[3] that the library ran
+// at half the fp32 matrix peak behind a read-modify-write of the 1 GB result.  The whole weight image (two fp16 planes, operand
+// order: 64 KB) stays in LDS; a wave takes 2 x 16 rows per trip (their own powers of two, as everywhere in this file), the product
+// comes out rows-in-lanes (lane (j, q): channels 16 t + 4 q + e of row j), so the result goes out as 16-byte stores.  Memory-bound:
+// 1 GB in, 1 GB out.
+#define RM_BLOCKS 512
+__global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_rows128_affine_f16(
+    const float* __restrict__ x, long long rows, const uint4* __restrict__ Wh, const int* __restrict__ ew,
+    const float* __restrict__ init, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  uint4* s_w = reinterpret_cast<uint4*>(smem);                         // 8 tiles x 4 k-steps x 2 planes x 64 lanes (64 KB)
+  int* s_e = reinterpret_cast<int*>(s_w + 8 * 4 * 2 * 64);             // 128: MINUS the rows' exponents
+  float* s_i = reinterpret_cast<float*>(s_e + PN_C2);                  // 128: init
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  for (int e = tid; e < 8 * 4 * 2 * 64; e += PN_THREADS) s_w[e] = Wh[e];
+  if (tid < PN_C2) { s_e[tid] = -ew[tid]; s_i[tid] = init ? init[tid] : 0.f; }
+  __syncthreads();
+  const long long ntrips = (rows + 31) >> 5, stride = (long long)gridDim.x * 4;
+  long long trip = (long long)blockIdx.x * 4 + wave;
+  pf32x4 nv[2][8];                         // the next trip's rows, on their way while this one is multiplied
+#define RM_LOAD(T)                                                                       \
+  _Pragma("unroll") for (int pt = 0; pt < 2; ++pt) {                                     \
+    const long long r0_ = (T) * 32 + pt * 16 + j, r_ = r0_ < rows ? r0_ : rows - 1;      \
+    const float* row_ = x + r_ * PN_C2 + 4 * q;                                          \
+    _Pragma("unroll") for (int t = 0; t < 8; ++t) nv[pt][t] = *reinterpret_cast<const pf32x4*>(row_ + 16 * t); \
+  }
+  if (trip < ntrips) { RM_LOAD(trip) }
+  for (; trip < ntrips; trip += stride) {
+    pf16x8 Xa[2][4], Xb[2][4];
+    int nex[2];
+    long long rr[2];
+    pf32x4 v[2][8];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[pt][t] = nv[pt][t];
+    if (trip + stride < ntrips) { RM_LOAD(trip + stride) }
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      rr[pt] = trip * 32 + pt * 16 + j;
+      float m = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[pt][t][e]));
+      const int ex = pn_exponent(pn_point_max(m));
+      nex[pt] = -ex;
+      const float sc = __builtin_bit_cast(float, (unsigned)(ex + 127) << 23);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          _Float16 a, b;
+          pn_split2(v[pt][2 * s + (jj >> 2)][jj & 3] * sc, a, b);
+          Xa[pt][s][jj] = a;
+          Xb[pt][s][jj] = b;
+        }
+    }
+#pragma unroll 1
+    for (int t = 0; t < 8; ++t) {          // (rolled: unrolled, the 64 fragment reads are hoisted and the registers spill)
+      pf32x4 acc0 = pf32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const pf16x8 Wa = __builtin_bit_cast(pf16x8, s_w[((t * 4 + s) * 2 + 0) * 64 + lane]);
+        const pf16x8 Wb = __builtin_bit_cast(pf16x8, s_w[((t * 4 + s) * 2 + 1) * 64 + lane]);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wb, Xa[0][s], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xb[0][s], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xa[0][s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wb, Xa[1][s], acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xb[1][s], acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xa[1][s], acc1, 0, 0, 0);
+      }
+      const int c = 16 * t + 4 * q;
+      pf32x4 o0, o1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o0[e] = s_i[c + e] + ldexpf(acc0[e], s_e[c + e] + nex[0]);
+        o1[e] = s_i[c + e] + ldexpf(acc1[e], s_e[c + e] + nex[1]);
+      }
+      if (rr[0] < rows) *reinterpret_cast<pf32x4*>(y + rr[0] * PN_C2 + c) = o0;
+      if (rr[1] < rows) *reinterpret_cast<pf32x4*>(y + rr[1] * PN_C2 + c) = o1;
+    }
+  }
+}
+
+#undef RM_LOAD
+
+// Wh / ew: the (128 out, 128 in) weight as two fp16 planes of w 2^ew[row] in operand order (dense_path.PointFeat._f16x2_image);
+// init: 128 floats or NULL.  x, y: (rows, 128) fp32, y may not alias x.
+extern "C" int glx_rows128_affine_f16x2(const float* x, long long rows, const void* Wh, const int32_t* ew, const float* init,
+                                        float* y, void* stream) {
+  if (rows <= 0) return GLX_OK;
+  GLX_REQUIRE(x && Wh && ew && y, "glx_rows128_affine_f16x2: null pointer");
+  const size_t lds = (size_t)8 * 4 * 2 * 64 * 16 + (size_t)2 * PN_C2 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GLX_HIP(hipFuncSetAttribute((const void*)k_rows128_affine_f16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const long long want = (((rows + 31) >> 5) + 3) >> 2;
+  const int blocks = (int)(want < RM_BLOCKS ? want : RM_BLOCKS);
+  hipLaunchKernelGGL(k_rows128_affine_f16, dim3(blocks), dim3(PN_THREADS), lds, (hipStream_t)stream, x, rows, (const uint4*)Wh, ew,
+                     init, y);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
 // dh2s[b * P + p, :] = sum over the channels c whose extreme point in object b is p of coef[b, c] * W3[c, :]  (zero rows
 // for the other points; `init` (128 floats or NULL) is what every row starts from): the part of  dy W3  that comes from
 // the max's gradient.  One block per object; a wave takes
@@ -858,7 +967,7 @@ extern "C" int glx_pointmax_forward_f16x2(const float* h2, int B, int P, const v
 // every row is written exactly once, no atomics, fixed summation order.
 __global__ __launch_bounds__(PN_THREADS) void k_pointmax_scatter(const int* __restrict__ arg, const float* __restrict__ coef,
                                                                  const float* __restrict__ W3, const float* __restrict__ init,
-                                                                 int P, float* __restrict__ dh2) {
+                                                                 int P, float* __restrict__ dh2, int accumulate) {
   __shared__ int s_arg[PN_C3];
   __shared__ float s_coef[PN_C3];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -869,31 +978,58 @@ __global__ __launch_bounds__(PN_THREADS) void k_pointmax_scatter(const int* __re
   }
   __syncthreads();
   for (int p = wave; p < P; p += PN_THREADS / 64) {
-    float a0 = init ? init[lane] : 0.f, a1 = init ? init[64 + lane] : 0.f;   // channels k = lane and lane + 64 of the row
-#pragma unroll 1
-    for (int c0 = 0; c0 < PN_C3; c0 += 64) {
-      unsigned long long hit = __ballot(s_arg[c0 + lane] == p && s_coef[c0 + lane] != 0.f);
+    unsigned long long hits[PN_C3 / 64];
+    bool touched = false;
+#pragma unroll
+    for (int k = 0; k < PN_C3 / 64; ++k) {
+      hits[k] = __ballot(s_arg[64 * k + lane] == p && s_coef[64 * k + lane] != 0.f);
+      touched |= hits[k] != 0;
+    }
+    float* row = dh2 + (obj * P + p) * PN_C2;
+    float a0, a1;                          // channels k = lane and lane + 64 of the row
+    if (accumulate) {                      // the rows hold the dense part already: only a row some channel points at moves
+      if (!touched) continue;
+      a0 = row[lane];
+      a1 = row[64 + lane];
+    } else {
+      a0 = init ? init[lane] : 0.f;
+      a1 = init ? init[64 + lane] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < PN_C3 / 64; ++k) {
+      unsigned long long hit = hits[k];
       while (hit) {
-        const int c = c0 + __ffsll((long long)hit) - 1;
+        const int c = 64 * k + __ffsll((long long)hit) - 1;
         hit &= hit - 1;
         const float w = s_coef[c];
         a0 = fmaf(w, W3[(long long)c * PN_C2 + lane], a0);
         a1 = fmaf(w, W3[(long long)c * PN_C2 + 64 + lane], a1);
       }
     }
-    float* row = dh2 + (obj * P + p) * PN_C2;
     row[lane] = a0;
     row[64 + lane] = a1;
   }
 }
 
-extern "C" int glx_pointmax_scatter(const int32_t* arg, const float* coef, const float* W3, const float* init, int B, int P,
-                                    float* dh2, void* stream) {
+static int pointmax_scatter(const int32_t* arg, const float* coef, const float* W3, const float* init, int B, int P, float* dh2,
+                            int accumulate, void* stream) {
   if (B <= 0) return GLX_OK;
   GLX_REQUIRE(arg && coef && W3 && dh2 && P >= 1, "glx_pointmax_scatter: null pointer");
-  hipLaunchKernelGGL(k_pointmax_scatter, dim3(B), dim3(PN_THREADS), 0, (hipStream_t)stream, (const int*)arg, coef, W3, init, P, dh2);
+  hipLaunchKernelGGL(k_pointmax_scatter, dim3(B), dim3(PN_THREADS), 0, (hipStream_t)stream, (const int*)arg, coef, W3, init, P, dh2,
+                     accumulate);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
+}
+
+extern "C" int glx_pointmax_scatter(const int32_t* arg, const float* coef, const float* W3, const float* init, int B, int P,
+                                    float* dh2, void* stream) {
+  return pointmax_scatter(arg, coef, W3, init, B, P, dh2, 0, stream);
+}
+
+// ... added to what dh2 holds (the dense part from glx_rows128_affine_f16x2): rows no channel points at are left alone.
+extern "C" int glx_pointmax_scatter_add(const int32_t* arg, const float* coef, const float* W3, int B, int P, float* dh2,
+                                        void* stream) {
+  return pointmax_scatter(arg, coef, W3, nullptr, B, P, dh2, 1, stream);
 }
 
 // T[c, :] = sum_b g[b, c] * h2[b * P + arg[b, c], :]   (512 x 128): the max's part of the weight gradient.  A wave per

@@ -1567,6 +1567,7 @@ class PointFeat(nn.Module):
     def _f16x2_image(w):
         """(Cout, Cin) fp32 -> (two fp16 planes of w 2^ew[row] in the kernel's operand order, ew (Cout,) int32):
         [tile][k-step s][plane][lane 16 q + m][slot 4 h + e] = W[16 tile + m][32 s + 16 h + 4 q + e]."""
+        w = w.contiguous()
         cout, cin = w.shape
         m = w.abs().amax(dim=1)
         e = torch.where(m > 0, 14 - torch.floor(torch.log2(m.clamp_min(1e-38))), torch.zeros_like(m))
@@ -1707,8 +1708,14 @@ class PointMaxBN(torch.autograd.Function):
             v = (bvec - cvec * mean_nb) @ W3                                    # (128)
             M = W3.t() @ (cvec[:, None] * W3)                                   # (128, 128)
             d_h2 = torch.empty_like(h2)
-            call("glx_pointmax_scatter", arg, (g * scale).contiguous(), W3, (-v).contiguous(), B, P, d_h2)
-            d_h2.addmm_(h2, M, alpha=-1.0)
+            if PointMaxBN.F16X2:
+                # dense part first (f16 x 2 products, one pass: read h2, write d_h2), then the extreme points' rows on top
+                mh, em = PointFeat._f16x2_image(-M.t())
+                call("glx_rows128_affine_f16x2", h2, ctypes.c_longlong(R), mh, em, (-v).contiguous(), d_h2)
+                call("glx_pointmax_scatter_add", arg, (g * scale).contiguous(), W3, B, P, d_h2)
+            else:
+                call("glx_pointmax_scatter", arg, (g * scale).contiguous(), W3, (-v).contiguous(), B, P, d_h2)
+                d_h2.addmm_(h2, M, alpha=-1.0)
         if ctx.needs_input_grad[1]:
             T = torch.empty_like(W3)
             ws = torch.empty(query("glx_pointmax_wsum_workspace_bytes"), dtype=torch.uint8, device=h2.device)

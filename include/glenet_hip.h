@@ -1089,6 +1089,13 @@ int glx_pointmax_forward_f16x2(const float* h2, int B, int P, const void* W3h, c
                                void* stream);
 int glx_pointmax_scatter(const int32_t* arg, const float* coef, const float* W3, const float* init, int B, int P, float* dh2,
                          void* stream);
+/* glx_pointmax_scatter_add: the same sums ADDED to the rows of dh2 some channel points at (the others are left alone).
+ * glx_rows128_affine_f16x2: y (rows, 128) = init (128 or NULL) + x (rows, 128) W^T with f16 x 2 products; Wh / ew: the (128, 128)
+ * weight as two fp16 planes of w 2^ew[row] in MFMA operand order (what glx_pointnet_feat_f16x2 takes for its layers).  Together the
+ * input gradient of the 128 -> 512 layer + BatchNorm + max: dh2 = -v - h2 M, then the extreme points' rows of W3. */
+int glx_pointmax_scatter_add(const int32_t* arg, const float* coef, const float* W3, int B, int P, float* dh2, void* stream);
+int glx_rows128_affine_f16x2(const float* x, long long rows, const void* Wh, const int32_t* ew, const float* init, float* y,
+                             void* stream);
 size_t glx_pointmax_wsum_workspace_bytes(void);
 int glx_pointmax_wsum(const float* g, const int32_t* arg, const float* h2, int B, int P, float* T, void* workspace,
                       size_t workspace_bytes, void* stream);
