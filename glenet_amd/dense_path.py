@@ -1485,23 +1485,43 @@ class PointFeat(nn.Module):
 
     @classmethod
     def _rows_layer(cls, x2d, conv, bn, relu):
+        """relu?(bn(conv(x2d))) on rows; x2d may carry zero columns behind the conv's input channels and the result may carry
+        zero columns behind its output channels (the narrow extractor's 8 channels run as 16: the kernels' tiles)."""
         from .spconv import core
         fold = cls.BIAS_INTO_RUNNING_MEAN and conv.bias is not None and bn.track_running_stats
-        if not fold and conv.bias is not None:
-            return core.fused_train_bn(bn, cls._rows_linear(x2d, conv), relu, None)
         cout, cin = conv.weight.shape[:2]
-        kin = cin if cin in (16, 32, 64) else (16 if cin < 16 else 0)
-        if cls.OWN_ROW_LAYERS and kin and core.USE_BN_STATE and _lib.query("glx_rows_linear_supported", kin, cout):
+        xin = x2d.shape[1]
+        if not fold and conv.bias is not None:
+            return core.fused_train_bn(bn, cls._rows_linear(x2d[:, :cin] if xin != cin else x2d, conv), relu, None)
+        kin = xin if xin in (16, 32, 64) else (16 if xin < 16 else 0)
+        kout = max(cout, 16)
+        if cls.OWN_ROW_LAYERS and kin and core.USE_BN_STATE and bn.track_running_stats \
+                and _lib.query("glx_rows_linear_supported", kin, kout):
             from .pcdet_ops.pointnet2.pointnet2_stack import voxel_pool_modules as vpm
             w = conv.weight[:, :, 0]
-            if kin != cin:
-                x2d, w = F.pad(x2d, (0, kin - cin)), F.pad(w, (0, kin - cin))
+            if kin != cin or kout != cout:
+                w = F.pad(w, (0, kin - cin, 0, kout - cout))
+            if kin != xin:
+                x2d = F.pad(x2d, (0, kin - xin))
             vpm._count(bn)
-            h = vpm.RowsConvBN.apply(x2d, w, bn.weight, bn.bias, bn, relu, None)
+            if kout != cout:
+                # a BatchNorm of kout channels around the module's: weight 1 / bias 0 / mean 0 / variance 1 behind its own, so
+                # the extra columns stay exactly zero; the running statistics go back into the module's buffers afterwards
+                pad = kout - cout
+                proxy = types.SimpleNamespace(
+                    weight=F.pad(bn.weight, (0, pad), value=1.0), bias=F.pad(bn.bias, (0, pad)), eps=bn.eps, momentum=bn.momentum,
+                    track_running_stats=True, running_mean=F.pad(bn.running_mean, (0, pad)),
+                    running_var=F.pad(bn.running_var, (0, pad), value=1.0))
+                h = vpm.RowsConvBN.apply(x2d, w, proxy.weight, proxy.bias, proxy, relu, None)
+                with torch.no_grad():
+                    bn.running_mean.copy_(proxy.running_mean[:cout])
+                    bn.running_var.copy_(proxy.running_var[:cout])
+            else:
+                h = vpm.RowsConvBN.apply(x2d, w, bn.weight, bn.bias, bn, relu, None)
             if conv.bias is not None:
                 h = _ZeroGradOperand.apply(h, conv.bias)
         else:
-            z = cls._rows_linear(x2d, conv, bias=False)
+            z = cls._rows_linear(x2d[:, :cin] if xin != cin else x2d, conv, bias=False)
             if conv.bias is not None:
                 z = _ZeroGradOperand.apply(z, conv.bias)
             h = core.fused_train_bn(bn, z, relu, None)
@@ -1519,7 +1539,7 @@ class PointFeat(nn.Module):
             # the 512-wide layer + BatchNorm + max over the points without the (B, P, 512) tensor
             return PointMaxBN.apply(h, self.conv3.weight[:, :, 0], self.conv3.bias, self.bn3.weight, self.bn3.bias, self.bn3, b, p)
         h = self._rows_layer(h, self.conv3, self.bn3, False)
-        return h.view(b, p, -1).amax(dim=1)
+        return h.view(b, p, -1).amax(dim=1)[:, :self.conv3.out_channels]
 
     # ---- eval-mode fast path: one hand-written MFMA kernel for the whole extractor
     def _fusable(self, x):
