@@ -622,7 +622,7 @@ def bench_config3(dev, objects=4096, points=512, samples=30):
             for s_ in range(samples):
                 model.sample(pts, eps[s_])
     ms_s = _timed(sample_all, 3, dev, warm=1)
-    dp.PointFeat.F16X2 = False                  # the same sampler with exact fp32 MFMA products in the wide extractor
+    dp.PointFeat.F16X2 = False                  # the same sampler with exact fp32 MFMA products in the wide extractor (round 5's path)
     try:
         ms_s32 = _timed(sample_all, 3, dev, warm=1)
     finally:
@@ -644,9 +644,10 @@ def bench_config3(dev, objects=4096, points=512, samples=30):
                              objects_per_s=round(objects / (ms_s * 1e-3), 1),
                              TFLOPs=round(samples * sample_flops / ms_s / 1e9, 1),
                              frac_of_16bit_pipe=round(3 * samples * sample_flops / ms_s / 1e9 / MFMA_BF16_PEAK_TFLOPS, 3),
-                             note="TFLOPs = the extractors' nominal (fp32-equivalent) flops per second over the whole sampler "
-                                  "(wide + narrow extractor + the decoder's ~35 small launches); frac_of_16bit_pipe counts the "
-                                  "three fp16 MFMAs per product tile against the dense 16-bit matrix peak",
+                             note="two launches per sample (both extractors in one kernel, everything behind them in a second); "
+                                  "TFLOPs = the extractors' nominal (fp32-equivalent) flops per second over the whole sampler; "
+                                  "frac_of_16bit_pipe counts the three fp16 MFMAs per product tile against the dense 16-bit matrix "
+                                  "peak; ms_per_sample_fp32_mfma = the module-by-module sampler on the fp32-MFMA extractor kernels",
                              frac_of_fp32_mfma_peak_fp32_form=round(samples * sample_flops / ms_s32 / 1e9 / MFMA_F32_PEAK_TFLOPS, 3)),
                 train_step=dict(what="forward (posterior + prior encoders, decoder) + losses + backward + clip 10 + AdamW "
                                      "(flat buffers), one HIP graph, lr = the one-cycle schedule's first step; the 128 -> 512 "

@@ -218,10 +218,17 @@ __device__ __forceinline__ void pn_dma16(const void* base_uniform, unsigned off,
 template <int N>
 __device__ __forceinline__ void pn_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// NARROW: the decoder's narrow extractor (4 -> 8 -> 8 -> 8, point_net.py:31-49) rides along on the same points: its folded
+// weights (`nw`: W1 (8 x 8, input channels zero-padded), b1, W2, b2, W3, b3 = 216 floats) become MFMA operands (below):
+// 2 x 12 fp32 MFMAs per pass beside the 864 fp16 ones, and a launch less.  (As VALU sums with the weights at uniform addresses the
+// compiler hoisted 216 scalar loads out of the loop and spilled them to lanes: +290 us per launch.)
+#define PNN_W 8
+template <bool NARROW>
 __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pointnet_feat_f16(
     const float* __restrict__ pts, int CIN, int P, const float* __restrict__ W1, const float* __restrict__ b1,
     const uint4* __restrict__ W2h, const int* __restrict__ ew2, const float* __restrict__ b2, const uint4* __restrict__ W3h,
-    const int* __restrict__ ew3, const float* __restrict__ b3, float* __restrict__ out) {
+    const int* __restrict__ ew3, const float* __restrict__ b3, float* __restrict__ out, const float* __restrict__ nw,
+    float* __restrict__ nout) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   uint4* s_w2 = reinterpret_cast<uint4*>(smem);              // 8 t2 x 2 s x 2 planes x 64 lanes          (32 KB)
   uint4* s_w3 = s_w2 + 8 * 2 * 2 * 64;                       // PNH_RING slabs of PNH_SLAB_U4              (24 KB)
@@ -262,6 +269,18 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   float mx[32];
 #pragma unroll
   for (int t = 0; t < 32; ++t) mx[t] = -FLT_MAX;
+  // NARROW: the three 8 x 8 layers as fp32 MFMAs (16 x 16 x 4, exact products) chained in registers like the wide layers: a
+  // lane's D registers e = channels 4 q + e of its point are the B operands of the next layer's steps e (contraction index
+  // 4 kq + e <-> step e, lane group kq), so the weights are per-lane A operands (12 registers, loaded once) and nothing moves
+  // between lanes; channels 8 .. 15 are zero rows.
+  float na[3][4];
+  pf32x4 nmx = pf32x4{-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+  if constexpr (NARROW) {
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) na[l][e] = (j < PNN_W && q < 2) ? nw[72 * l + j * 8 + 4 * q + e] : 0.f;
+  }
   unsigned cur = 0;                                          // the ring buffer slab t3 of this pass is in
 
   const float* xo = pts + obj * CIN * (long long)P;
@@ -275,6 +294,26 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       float x[PN_MAXCIN];
 #pragma unroll
       for (int ci = 0; ci < PN_MAXCIN; ++ci) x[ci] = ci < CIN ? xo[(long long)ci * P + p] : 0.f;
+      if constexpr (NARROW) {
+        pf32x4 d = pf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {          // layer 1: B = the point's inputs 4 q + e (q < 2)
+          const float xb = q == 0 ? x[e] : (q == 1 ? x[4 + e] : 0.f);
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(na[0][e], xb, d, 0, 0, 0);
+        }
+#pragma unroll
+        for (int l = 1; l < 3; ++l) {
+          const pf32x4 bias = (q < 2) ? *reinterpret_cast<const pf32x4*>(nw + 72 * (l - 1) + 64 + 4 * q) : pf32x4{0.f, 0.f, 0.f, 0.f};
+          pf32x4 h;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) h[e] = fmaxf(d[e] + bias[e], 0.f);
+          d = pf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d = __builtin_amdgcn_mfma_f32_16x16x4f32(na[l][e], h[e], d, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) nmx[e] = fmaxf(nmx[e], d[e]);      // (the last layer's bias: added at the end)
+      }
 #pragma unroll
       for (int t1 = 0; t1 < 4; ++t1) {
 #pragma unroll
@@ -401,29 +440,235 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     float v = fmaxf(fmaxf(s_max[c], s_max[PN_C3 + c]), fmaxf(s_max[2 * PN_C3 + c], s_max[3 * PN_C3 + c]));
     out[obj * PN_C3 + c] = v + b3[c];
   }
+  if constexpr (NARROW) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = nmx[e];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));       // the 16 points of the lane group
+      if (j == 0 && q < 2) s_max[wave * PNN_W + 4 * q + e] = v;
+    }
+    __syncthreads();
+    if (tid < PNN_W)
+      nout[obj * PNN_W + tid] = fmaxf(fmaxf(s_max[tid], s_max[PNN_W + tid]), fmaxf(s_max[2 * PNN_W + tid], s_max[3 * PNN_W + tid])) +
+                                nw[144 + 64 + tid];
+  }
 }
 
 extern "C" size_t glx_pointnet_feat_f16x2_lds_bytes(void) {
-  return (size_t)(8 * 2 * 2 * 64 + PNH_RING * PNH_SLAB_U4) * 16 + (size_t)(PN_C1 * PN_MAXCIN + PN_C1 + PN_C2 + PN_C2 + PN_C3 + 4 * PN_C3) * 4;
+  return (size_t)(8 * 2 * 2 * 64 + PNH_RING * PNH_SLAB_U4) * 16 +
+         (size_t)(PN_C1 * PN_MAXCIN + PN_C1 + PN_C2 + PN_C2 + PN_C3 + 4 * PN_C3) * 4;
 }
 
 // W2h / W3h: the folded (128, 64) / (512, 128) weights as two fp16 planes of w 2^ew[row] in the kernel's operand order
 // ([output tile][k-step][plane][lane 16 q + m][slot 4 h + e] = W[16 tile + m][32 s + 16 h + 4 q + e]); ew2 / ew3: the rows'
 // exponents (max |w| 2^ew in [2^14, 2^15), 0 for a zero row).
+extern "C" int glx_pointnet_feat_f16x2_pair(const float* points, int B, int Cin, int P, const float* W1, const float* b1,
+                                            const void* W2h, const int32_t* ew2, const float* b2, const void* W3h,
+                                            const int32_t* ew3, const float* b3, float* out, const float* narrow, float* narrow_out,
+                                            void* stream);
 extern "C" int glx_pointnet_feat_f16x2(const float* points, int B, int Cin, int P, const float* W1, const float* b1,
                                        const void* W2h, const int32_t* ew2, const float* b2, const void* W3h, const int32_t* ew3,
                                        const float* b3, float* out, void* stream) {
   if (B <= 0) return GLX_OK;
   GLX_REQUIRE(points && W1 && b1 && W2h && ew2 && b2 && W3h && ew3 && b3 && out, "glx_pointnet_feat_f16x2: null pointer");
   GLX_REQUIRE(Cin >= 1 && Cin <= PN_MAXCIN && P >= 1, "glx_pointnet_feat_f16x2: Cin must be 1..8, P >= 1");
+  return glx_pointnet_feat_f16x2_pair(points, B, Cin, P, W1, b1, W2h, ew2, b2, W3h, ew3, b3, out, nullptr, nullptr, stream);
+}
+
+// ... and the narrow extractor (widths 8, 8, 8) of the same points in the same launch: narrow = 216 floats (W1 (8 x 8: input
+// channels zero-padded to 8), b1 (8), W2 (8 x 8), b2, W3 (8 x 8), b3; eval-mode BatchNorm folded, no ReLU behind the last layer),
+// narrow_out (B, 8).  narrow == NULL: glx_pointnet_feat_f16x2.
+extern "C" int glx_pointnet_feat_f16x2_pair(const float* points, int B, int Cin, int P, const float* W1, const float* b1,
+                                            const void* W2h, const int32_t* ew2, const float* b2, const void* W3h,
+                                            const int32_t* ew3, const float* b3, float* out, const float* narrow, float* narrow_out,
+                                            void* stream) {
+  if (B <= 0) return GLX_OK;
+  GLX_REQUIRE(points && W1 && b1 && W2h && ew2 && b2 && W3h && ew3 && b3 && out, "glx_pointnet_feat_f16x2: null pointer");
+  GLX_REQUIRE(Cin >= 1 && Cin <= PN_MAXCIN && P >= 1, "glx_pointnet_feat_f16x2: Cin must be 1..8, P >= 1");
+  GLX_REQUIRE(!narrow || narrow_out, "glx_pointnet_feat_f16x2_pair: narrow weights without an output");
   const size_t lds = glx_pointnet_feat_f16x2_lds_bytes();
   static bool attr_set = false;
   if (!attr_set) {
-    GLX_HIP(hipFuncSetAttribute((const void*)k_pointnet_feat_f16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GLX_HIP(hipFuncSetAttribute((const void*)k_pointnet_feat_f16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GLX_HIP(hipFuncSetAttribute((const void*)k_pointnet_feat_f16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_pointnet_feat_f16, dim3(B), dim3(PN_THREADS), lds, (hipStream_t)stream, points, Cin, P, W1, b1,
-                     (const uint4*)W2h, ew2, b2, (const uint4*)W3h, ew3, b3, out);
+  if (narrow)
+    hipLaunchKernelGGL(k_pointnet_feat_f16<true>, dim3(B), dim3(PN_THREADS), lds, (hipStream_t)stream, points, Cin, P, W1, b1,
+                       (const uint4*)W2h, ew2, b2, (const uint4*)W3h, ew3, b3, out, narrow, narrow_out);
+  else
+    hipLaunchKernelGGL(k_pointnet_feat_f16<false>, dim3(B), dim3(PN_THREADS), lds, (hipStream_t)stream, points, Cin, P, W1, b1,
+                       (const uint4*)W2h, ew2, b2, (const uint4*)W3h, ew3, b3, out, (const float*)nullptr, (float*)nullptr);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ the sampler's tail
+// Everything of Generator.forward's eval branch (cvae_uncertainty/model.py:245-265) behind the two extractors, one launch:
+//   (mu, logvar) = fc1 / fc2 of the prior encoder on the 512 features (model.py:33-50), z = eps exp(logvar / 2) + mu (:194-198),
+//   the decoder's fc1 -> bn1 -> ReLU -> fc2 -> bn2 -> ReLU on cat(narrow features, z), its four heads (64 -> 64 -> 3 / 3 / 1 / bins,
+//   model.py:82-142) and the heading taken out of its bin (:257-264).
+// ~35 library / elementwise launches of ~5 us before.  A wave takes CT_G objects (every weight it fetches feeds CT_G sums), a lane
+// is an output channel of the 64-wide layers; activations pass between layers through a wave-private LDS patch.  Weights: `w`, one
+// float buffer (dense_path.CVAE._tail_pack): WL (16 x 512: fc1 | fc2 rows), bL (16), W1T (16 x 64: [input][output], BatchNorm
+// folded), b1 (64), W2T (64 x 64), b2 (64), WhT (4 x 64 x 64: [head][input][output]), bh (4 x 64), Wo ((7 + bins) x 64).
+#define CT_G 4
+#define CT_WAVES 4
+#define CT_KMAX 16
+__global__ __launch_bounds__(64 * CT_WAVES) void k_cvae_tail(const float* __restrict__ f512, const float* __restrict__ f8,
+                                                             const float* __restrict__ eps, const float* __restrict__ w, int B,
+                                                             int bins, float dir_offset, float dir_limit, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float s_f[CT_WAVES][CT_G][512];
+  __shared__ __attribute__((aligned(16))) float s_a[CT_WAVES][CT_G][64], s_b[CT_WAVES][CT_G][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int obj0 = (blockIdx.x * CT_WAVES + wave) * CT_G;
+  if (obj0 >= B) return;
+  const float* WL = w;
+  const float* bL = WL + 16 * 512;
+  const float* W1T = bL + 16;
+  const float* b1 = W1T + 16 * 64;
+  const float* W2T = b1 + 64;
+  const float* b2 = W2T + 64 * 64;
+  const float* WhT = b2 + 64;
+  const float* bh = WhT + 4 * 64 * 64;
+  const float* Wo = bh + 4 * 64;
+  const int kout = 7 + bins;
+#define CT_SYNC()                                            \
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
+  __builtin_amdgcn_wave_barrier();                           \
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront")
+  int ob[CT_G];
+#pragma unroll
+  for (int g = 0; g < CT_G; ++g) ob[g] = obj0 + g < B ? obj0 + g : B - 1;
+#pragma unroll
+  for (int g = 0; g < CT_G; ++g)
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      reinterpret_cast<pf32x4*>(s_f[wave][g])[lane + 64 * e] = reinterpret_cast<const pf32x4*>(f512 + (long long)ob[g] * 512)[lane + 64 * e];
+  CT_SYNC();
+  // ---- the latent Gaussian: lane (k, c) sums inputs 128 c .. of output k (mu: k < 8, logvar: k >= 8)
+  const int k = lane & 15, c = lane >> 4;
+  float lat[CT_G];
+#pragma unroll
+  for (int g = 0; g < CT_G; ++g) lat[g] = 0.f;
+  {
+    const pf32x4* wr = reinterpret_cast<const pf32x4*>(WL + k * 512 + c * 128);
+#pragma unroll 4
+    for (int i = 0; i < 32; ++i) {
+      const pf32x4 wv = wr[i];
+#pragma unroll
+      for (int g = 0; g < CT_G; ++g) {
+        const pf32x4 fv = *reinterpret_cast<const pf32x4*>(&s_f[wave][g][c * 128 + 4 * i]);
+        lat[g] = fmaf(wv[0], fv[0], fmaf(wv[1], fv[1], fmaf(wv[2], fv[2], fmaf(wv[3], fv[3], lat[g]))));
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < CT_G; ++g) {
+    lat[g] += __shfl_xor(lat[g], 16, 64);
+    lat[g] += __shfl_xor(lat[g], 32, 64);
+    lat[g] += bL[k];
+    const float lv = __shfl(lat[g], (lane & 7) + 8, 64);
+    if (lane < 8) {
+      s_a[wave][g][lane] = f8[(long long)ob[g] * 8 + lane];
+      s_a[wave][g][8 + lane] = eps[(long long)ob[g] * 8 + lane] * expf(0.5f * lv) + lat[g];
+    }
+  }
+  CT_SYNC();
+  // ---- decoder trunk: lane = output channel
+  float a[CT_G];
+#pragma unroll
+  for (int g = 0; g < CT_G; ++g) a[g] = b1[lane];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float wv = W1T[i * 64 + lane];
+#pragma unroll
+    for (int g = 0; g < CT_G; ++g) a[g] = fmaf(wv, s_a[wave][g][i], a[g]);
+  }
+#pragma unroll
+  for (int g = 0; g < CT_G; ++g) s_b[wave][g][lane] = fmaxf(a[g], 0.f);
+  CT_SYNC();
+#pragma unroll
+  for (int g = 0; g < CT_G; ++g) a[g] = b2[lane];
+#pragma unroll 8
+  for (int i = 0; i < 64; ++i) {
+    const float wv = W2T[i * 64 + lane];
+#pragma unroll
+    for (int g = 0; g < CT_G; ++g) a[g] = fmaf(wv, s_b[wave][g][i], a[g]);
+  }
+  CT_SYNC();                // (everyone has read s_a's 16 inputs)
+#pragma unroll
+  for (int g = 0; g < CT_G; ++g) s_a[wave][g][lane] = fmaxf(a[g], 0.f);
+  CT_SYNC();
+  // ---- the heads' hidden layers
+  float hid[4][CT_G];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int g = 0; g < CT_G; ++g) hid[t][g] = bh[t * 64 + lane];
+#pragma unroll 4
+  for (int i = 0; i < 64; ++i) {
+    float hv[CT_G];
+#pragma unroll
+    for (int g = 0; g < CT_G; ++g) hv[g] = s_a[wave][g][i];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float wv = WhT[(t * 64 + i) * 64 + lane];
+#pragma unroll
+      for (int g = 0; g < CT_G; ++g) hid[t][g] = fmaf(wv, hv[g], hid[t][g]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int g = 0; g < CT_G; ++g) hid[t][g] = fmaxf(hid[t][g], 0.f);
+  // ---- their output layers (no bias): centre 0..2 <- head 0, size 3..5 <- head 1, heading residual 6 <- head 2, bins <- head 3
+  float pred[CT_KMAX][CT_G];
+#pragma unroll
+  for (int o = 0; o < CT_KMAX; ++o) {
+    if (o < kout) {
+      const int t = o < 3 ? 0 : (o < 6 ? 1 : (o < 7 ? 2 : 3));
+      const float wv = Wo[o * 64 + lane];
+#pragma unroll
+      for (int g = 0; g < CT_G; ++g) {
+        float v = wv * (t == 0 ? hid[0][g] : (t == 1 ? hid[1][g] : (t == 2 ? hid[2][g] : hid[3][g])));
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+        pred[o][g] = v;
+      }
+    }
+  }
+  // ---- the heading out of its bin; lane g writes object g
+  const float period = 6.283185307179586f / (float)bins, inv_period = 1.f / period;
+#pragma unroll
+  for (int g = 0; g < CT_G; ++g) {
+    if (lane == g && obj0 + g < B) {
+      int label = 0;
+      float best = pred[7][g];
+#pragma unroll
+      for (int o = 8; o < CT_KMAX; ++o)
+        if (o < kout && pred[o][g] > best) { best = pred[o][g]; label = o - 7; }
+      const float val = pred[6][g] - dir_offset;
+      const float rot = val - floorf(val * inv_period + dir_limit) * period;
+      float* dst = out + (long long)(obj0 + g) * kout;
+#pragma unroll
+      for (int o = 0; o < CT_KMAX; ++o)
+        if (o < kout) dst[o] = o == 6 ? rot + dir_offset + period * (float)label : pred[o][g];
+    }
+  }
+#undef CT_SYNC
+}
+
+// f512 (B, 512), f8 (B, 8): the two extractors' features; eps (B, 8); w: see above; out (B, 7 + bins), 1 <= bins <= 9.
+extern "C" int glx_cvae_sample_tail(const float* f512, const float* f8, const float* eps, const float* w, int B, int bins,
+                                    float dir_offset, float dir_limit_offset, float* out, void* stream) {
+  if (B <= 0) return GLX_OK;
+  GLX_REQUIRE(f512 && f8 && eps && w && out, "glx_cvae_sample_tail: null pointer");
+  GLX_REQUIRE(bins >= 1 && 7 + bins <= CT_KMAX, "glx_cvae_sample_tail: 1 <= bins <= 9");
+  hipLaunchKernelGGL(k_cvae_tail, dim3(glx_divup(B, CT_WAVES * CT_G)), dim3(64 * CT_WAVES), 0, (hipStream_t)stream, f512, f8, eps, w, B,
+                     bins, dir_offset, dir_limit_offset, out);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

@@ -1814,8 +1814,72 @@ class CVAE(nn.Module):
     def reparametrize(mu, logvar, eps):
         return eps * torch.exp(0.5 * logvar) + mu                              # model.py:194-198
 
+    # eval-mode sampler as two launches: both extractors over the points (glx_pointnet_feat_f16x2_pair), everything behind them
+    # (glx_cvae_sample_tail); False: module by module (the extractors still on their fused kernels)
+    FUSED_SAMPLER = True
+
+    def _sample_fusable(self, points):
+        fe, fn, dec = self.x_encoder.fe, self.obj_encoder.fe, self.obj_encoder
+        wide = (fe.conv1.out_channels, fe.conv2.out_channels, fe.conv3.out_channels) == (64, 128, 512)
+        narrow = (fn.conv1.out_channels, fn.conv2.out_channels, fn.conv3.out_channels) == (8, 8, 8)
+        return (self.FUSED_SAMPLER and PointFeat.F16X2 and points.is_cuda and points.dtype == torch.float32
+                and not self.training and not torch.is_grad_enabled() and wide and narrow and points.shape[1] <= 8
+                and fe.conv1.in_channels == fn.conv1.in_channels == points.shape[1] and self.latent_dim == 8
+                and dec.fc1.out_features == dec.fc2.out_features == 64 and dec.fc1.in_features == 16
+                and 1 <= self.num_dir_bins <= 9 and all(m.track_running_stats for m in (dec.bn1, dec.bn2)))
+
+    def _sample_pack(self):
+        """(the narrow extractor's 216 folded weights, the tail's weight buffer) as glx_pointnet_feat_f16x2_pair /
+        glx_cvae_sample_tail take them; cached until a parameter or running statistic changes."""
+        tensors = list(self.parameters()) + list(self.buffers())
+        tag = tuple((t._version, t.data_ptr()) for t in tensors) + (_lib.weights_epoch(*tensors),)
+        hit = self.__dict__.get("_glx_sample_pack")
+        if hit is None or hit[0] != tag:
+            with torch.no_grad():
+                fn, dec, enc = self.obj_encoder.fe, self.obj_encoder, self.x_encoder
+                w1, b1 = PointFeat._fold(fn.conv1, fn.bn1)
+                w2, b2 = PointFeat._fold(fn.conv2, fn.bn2)
+                w3, b3 = PointFeat._fold(fn.conv3, fn.bn3)
+                narrow = torch.cat([F.pad(w1, (0, 8 - w1.shape[1])).reshape(-1), b1, w2.reshape(-1), b2, w3.reshape(-1), b3])
+
+                def fold_fc(fc, bn):
+                    sc = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                    return fc.weight * sc[:, None], (fc.bias - bn.running_mean) * sc + bn.bias
+                f1w, f1b = fold_fc(dec.fc1, dec.bn1)
+                f2w, f2b = fold_fc(dec.fc2, dec.bn2)
+                heads1 = (dec.fc_ce1, dec.fc_s1, dec.fc_hr1, dec.fc_dir1)
+                heads2 = (dec.fc_ce2, dec.fc_s2, dec.fc_hr2, dec.fc_dir2)
+                tail = torch.cat([torch.cat([enc.fc1.weight, enc.fc2.weight]).reshape(-1), enc.fc1.bias, enc.fc2.bias,
+                                  f1w.t().reshape(-1), f1b, f2w.t().reshape(-1), f2b,
+                                  torch.cat([h.weight.t().reshape(-1) for h in heads1]), torch.cat([h.bias for h in heads1]),
+                                  torch.cat([h.weight for h in heads2]).reshape(-1)]).float().contiguous()
+            hit = (tag, (narrow.float().contiguous(), tail))
+            self.__dict__["_glx_sample_pack"] = hit
+        return hit[1]
+
+    def _sample_fused(self, points, eps):
+        from ._lib import call
+        points = points.contiguous()
+        B, cin, P = points.shape
+        fe = self.x_encoder.fe
+        w1, b1, _, b2, _, b3 = fe._packed()
+        w2h, e2, w3h, e3 = fe._packed_f16()
+        narrow, tail = self._sample_pack()
+        dev = points.device
+        f512 = torch.empty((B, 512), dtype=torch.float32, device=dev)
+        f8 = torch.empty((B, 8), dtype=torch.float32, device=dev)
+        out = torch.empty((B, 7 + self.num_dir_bins), dtype=torch.float32, device=dev)
+        if eps is None:
+            eps = torch.randn((B, 8), dtype=torch.float32, device=dev)
+        call("glx_pointnet_feat_f16x2_pair", points, B, cin, P, w1, b1, w2h, e2, b2, w3h, e3, b3, f512, narrow, f8)
+        call("glx_cvae_sample_tail", f512, f8, eps.contiguous().float(), tail, B, self.num_dir_bins,
+             ctypes.c_float(self.dir_offset), ctypes.c_float(self.dir_limit_offset), out)
+        return out
+
     def sample(self, points, eps=None):
         """points (B, C, P) -> boxes (B, 7 + num_dir_bins) with the heading decoded from its bin."""
+        if self._sample_fusable(points):
+            return self._sample_fused(points, eps)
         _, mu, logvar = self.x_encoder(points)
         if eps is None:
             eps = torch.randn_like(mu)

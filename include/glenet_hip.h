@@ -1033,6 +1033,18 @@ size_t glx_pointnet_feat_f16x2_lds_bytes(void);
 int glx_pointnet_feat_f16x2(const float* points, int B, int Cin, int P, const float* W1, const float* b1, const void* W2h,
                             const int32_t* ew2, const float* b2, const void* W3h, const int32_t* ew3, const float* b3, float* out,
                             void* stream);
+/* ... with the narrow extractor (widths 8, 8, 8; cvae_uncertainty/point_net.py:31-49) of the same points in the same launch:
+ * narrow = 216 floats (W1 (8 x 8, input channels zero-padded), b1, W2, b2, W3, b3; eval-mode BatchNorm folded), narrow_out (B, 8);
+ * narrow == NULL: glx_pointnet_feat_f16x2. */
+int glx_pointnet_feat_f16x2_pair(const float* points, int B, int Cin, int P, const float* W1, const float* b1, const void* W2h,
+                                 const int32_t* ew2, const float* b2, const void* W3h, const int32_t* ew3, const float* b3,
+                                 float* out, const float* narrow, float* narrow_out, void* stream);
+/* The eval branch of Generator.forward behind the extractors (cvae_uncertainty/model.py:245-265) in one launch: prior (mu, logvar)
+ * from f512 (B, 512), z = eps exp(logvar / 2) + mu, the decoder on cat(f8 (B, 8), z), heading decoded from its bin.
+ * w: WL (16 x 512: fc1 | fc2 rows) | bL (16) | W1T (16 x 64, [input][output], BatchNorm folded) | b1 (64) | W2T (64 x 64) | b2 (64) |
+ * WhT (4 x 64 x 64, heads centre / size / heading / bins, [input][output]) | bh (4 x 64) | Wo ((7 + bins) x 64).  out (B, 7 + bins). */
+int glx_cvae_sample_tail(const float* f512, const float* f8, const float* eps, const float* w, int B, int bins, float dir_offset,
+                         float dir_limit_offset, float* out, void* stream);
 int glx_pointnet_feat_small(const float* points, int B, int Cin, int P, int C1, int C2, int C3,
                             const float* W1, const float* b1, const float* W2, const float* b2,
                             const float* W3, const float* b3, float* out, void* stream);

@@ -45,8 +45,16 @@ def test_cvae_golden_on_device_fused_extractor(dev):
     pts, eps = torch.from_numpy(G["cvae_points"]).to(dev), torch.from_numpy(G["cvae_eps"]).to(dev)
     cond = torch.from_numpy(G["cvae_cond"]).to(dev)
     with torch.no_grad():
-        assert m.x_encoder.fe._fusable(pts)                   # the hand-written kernel is the one that runs
+        assert m.x_encoder.fe._fusable(pts) and m._sample_fusable(pts)        # the hand-written kernels are the ones that run
         box = m.sample(pts, eps)
+        dp.CVAE.FUSED_SAMPLER = False                         # module by module behind the extractors' kernels: the same boxes
+        try:
+            box_modules = m.sample(pts, eps)
+        finally:
+            dp.CVAE.FUSED_SAMPLER = True
+        d = (box - box_modules).abs()
+        d[:, 6] = torch.minimum(d[:, 6], (d[:, 6] - np.pi).abs())
+        assert float(d.max()) < 1e-4, float(d.max())
         _, mu, logvar = m.x_encoder(pts)
         _, _, kl, (mu_xy, logvar_xy, _, _) = m.posterior_prior(pts, cond)
     for got, key in ((mu, "cvae_mu_x"), (logvar, "cvae_logvar_x"), (mu_xy, "cvae_mu_xy"), (logvar_xy, "cvae_logvar_xy"),
@@ -70,10 +78,12 @@ def test_cvae_config4_full_size_30_samples(dev):
         got = torch.stack([m.sample(pts, eps[s]) for s in range(30)])            # (30, 4096, 9)
         fused = dp.PointFeat._fusable
         dp.PointFeat._fusable = lambda self, x: False                             # unfused reference path
+        dp.CVAE.FUSED_SAMPLER = False
         try:
             want = torch.stack([m.sample(pts[:512], eps[s, :512]) for s in (0, 17, 29)])
         finally:
             dp.PointFeat._fusable = fused
+            dp.CVAE.FUSED_SAMPLER = True
         alone = m.sample(pts[100:101].contiguous(), eps[3, 100:101])
     assert got.shape == (30, 4096, 9) and torch.isfinite(got).all()
     # the decoded heading jumps by the bin period when the direction logits tie: compare modulo the period

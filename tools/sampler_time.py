@@ -9,6 +9,8 @@ from glenet_amd import dense_path as dp, synth  # noqa: E402
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    if len(sys.argv) > 2 and sys.argv[2] == "modules":        # the decoder module by module behind the extractors' kernels
+        dp.CVAE.FUSED_SAMPLER = False
     dev = torch.device("cuda:0")
     torch.manual_seed(1)
     pts = torch.from_numpy(synth.cvae_objects(4096, 2000, 512, with_labels=True)[0]).to(dev)
