@@ -916,6 +916,10 @@ def main():
                          "command to put under rocprofv3 --kernel-trace --stats when its per-kernel averages are to "
                          "be compared with the HIP-event figures (a full run mixes in the training step's launches "
                          "and the two-frames-in-flight replays of the same kernels)")
+    ap.add_argument("--grad-buckets", type=int, choices=(1, 2), default=1,
+                    help="data-parallel step: 2 = the gradient exchange in two buckets, the first (everything but the sparse "
+                         "backbone) beside the sparse backward (forward + backward recorded as two graphs); 1 = one flat "
+                         "all-reduce behind the backward (default; never measured on more than one GPU)")
     ap.add_argument("--graph-queues", type=int, default=2,
                     help="HIP-graph executor queues (glenet_amd.runtime.configure_graph_executor: the process-wide "
                          "DEBUG_HIP_FORCE_GRAPH_QUEUES switch, set before the first GPU call and echoed in config); "
@@ -979,6 +983,7 @@ def main():
     # GLX_BENCH_FORCE_DP=1: the data-parallel step (two graphs, RCCL all-reduce on the flat gradient buffer, scaled update)
     # with whatever world size there is -- on ONE GPU the N > 1 code path over real RCCL; a plumbing mode like the gloo one
     dp = world > 1 or os.environ.get("GLX_BENCH_FORCE_DP") == "1"
+    buckets = args.grad_buckets if dp else 1
     gdist.init(backend, device=dev, force=dp)
     ranks_seen = gdist.reduce_sum_int(1, dev)          # the collective saw this many ranks
 
@@ -1031,7 +1036,7 @@ def main():
         args.steps = args.warmup = 0
         args.no_stages = True
     elif args.mode == "graph":
-        pipe.capture(split=dp)
+        pipe.capture(split=dp, buckets=buckets)
     else:
         pipe.split = dp
     it = [0]
@@ -1135,7 +1140,7 @@ def main():
             names.append(name)
         pipe.mark = model.mark = mark
         torch.cuda.synchronize(dev)
-        pipe.capture(split=dp)
+        pipe.capture(split=dp, buckets=buckets)
         acc = {}
         for j in range(3 * BATCH_POOL):
             pipe.load(*pool[j % BATCH_POOL][:4])
@@ -1154,7 +1159,7 @@ def main():
                           "on their own stream beside the anchor targets, the dense-head loss and the first two backward "
                           "stages; rule tables and weight gradients run on a third")
         torch.cuda.synchronize(dev)
-        pipe.capture(split=dp)          # the recording without stamps again
+        pipe.capture(split=dp, buckets=buckets)          # the recording without stamps again
         pipe.load(*pool[0][:4])
         pipe.step()                            # ... and its buffers filled (the config block below reads row counts)
         torch.cuda.synchronize(dev)
@@ -1174,7 +1179,7 @@ def main():
         glib.call_nostream("glx_sconv_set_arith", 0)
         glib.bump_weights_epoch()
         try:
-            pipe.capture(split=dp)
+            pipe.capture(split=dp, buckets=buckets)
             for _ in range(5):
                 train_step()
             gdist.fence(dev)
@@ -1197,7 +1202,7 @@ def main():
             c2.set_arithmetic(old_c)
             glib.load().glx_conv3x3_set_wgrad_form(old_f)
             glib.bump_weights_epoch()
-        pipe.capture(split=dp)                 # the default arithmetic's recording again (config block + later legs read it)
+        pipe.capture(split=dp, buckets=buckets)                 # the default arithmetic's recording again (config block + later legs read it)
         pipe.load(*pool[0][:4])
         pipe.step()
         torch.cuda.synchronize(dev)
@@ -1277,10 +1282,13 @@ def main():
                                voxels_in=int(pipe.out["voxel_index"].count.item()), voxels_out=int(st.count.item()),
                                proposal_seeding="first 15 proposal slots per frame = ground truth + fixed offset "
                                                 "(stands in for a trained first stage; random-init weights)",
-                               mode={"graph": "shape-static step replayed as %d HIP graph(s)" % (2 if dp else 1),
+                               mode={"graph": "shape-static step replayed as %d HIP graph(s)" % ((1 + buckets) if dp else 1),
                                      "static": "shape-static step, launches enqueued from Python"}[args.mode],
-                               parallelism="dp%d: frames shard; one flat RCCL all-reduce of %.1f MB gradients per step"
-                                           % (world, n_params * 4 / 1e6) if dp else "dp1 (single GPU, no collective)",
+                               parallelism=("dp%d: frames shard; %s of %.1f MB gradients per step"
+                                            % (world, "one flat RCCL all-reduce" if buckets == 1 else
+                                               "RCCL all-reduce in two buckets (everything but the sparse backbone beside the "
+                                               "sparse backward, then the sparse backbone's)", n_params * 4 / 1e6))
+                               if dp else "dp1 (single GPU, no collective)",
                                ranks_seen_by_collective=ranks_seen,
                                device_data_step=bool(args.device_data_step),
                                graph_executor_queues=glx_runtime.graph_executor_queues(),

@@ -171,6 +171,10 @@ class StagedLoss:
         self.rpn, self.roi, self.roi_stream = rpn, roi, roi_stream
         self.bev_cut, self.roi_cuts, self.stage_cuts = bev_cut, roi_cuts, stage_cuts
         self.value, self.mark = None, mark
+        # optional callable run between B and C, when every gradient but the sparse backbone's is final (the RoI branch joined,
+        # the BEV backbone's weight-gradient sums done): StaticTrainStep's two-bucket gradient exchange starts its first bucket
+        # there.  The price is the overlap of the RoI branch's tail with the upper sparse levels.
+        self.boundary = None
 
     LEVELS = ("x_conv4", "x_conv3", "x_conv2", "x_conv1")       # the order their gradients leave the RoI branch
 
@@ -212,6 +216,15 @@ class StagedLoss:
             torch.autograd.backward(self.rpn)             # B: ends at the BEV input's detached leaf
             if fc_jobs:      # ... or in the main stream's wait for the RoI gradients (what paid while the RoI branch was longer)
                 dp.run_deferred_fc_wgrads(fc_jobs)
+            joined = False
+            if self.boundary is not None:
+                main.wait_stream(self.roi_stream)         # join: the first bucket holds the RoI head's gradients too
+                joined = True
+                c2.DEFERRED_WGRAD_REDUCES = None
+                c2.run_deferred_wgrad_reduces(bev_sums)
+                bev_sums = None
+                self.boundary()                           # (a recorded step ends its first graph here and begins the second)
+                core.WGRAD_STREAM = wgrad_stream
             # C: the sparse backbone, level by level: the levels above a stage cut run as soon as THEIR RoI gradients are
             # there (x_conv4's leave the RoI branch first, x_conv2's last)
             roots, grads = [self.bev_cut[0]], [self.bev_cut[1].grad]
@@ -228,7 +241,8 @@ class StagedLoss:
                     feat, leaf = self.roi_cuts[name]
                     if leaf.grad is None:
                         continue
-                    main.wait_event(ready[name])
+                    if not joined:
+                        main.wait_event(ready[name])
                     same = [i for i, t in enumerate(roots) if t is feat]
                     if same:
                         grads[same[0]] = grads[same[0]] + leaf.grad
@@ -236,7 +250,8 @@ class StagedLoss:
                         roots.append(feat)
                         grads.append(leaf.grad)
                     leaf.grad = None
-            main.wait_stream(self.roi_stream)             # join (parameter gradients of the RoI head)
+            if not joined:
+                main.wait_stream(self.roi_stream)         # join (parameter gradients of the RoI head)
             self.value = self.rpn.detach() + self.roi.detach()
             self.rpn = self.roi = self.bev_cut = self.roi_cuts = self.stage_cuts = None
             core.WGRAD_STREAM = wgrad_stream              # free again: the RoI branch has been joined
@@ -439,6 +454,7 @@ class GLENetVR(nn.Module):
         mark("anchor targets + dense-head loss")
         if overlap:
             loss = StagedLoss(rpn, roi_loss, roi_stream, bev_cut, roi_cuts, bd.get("stage_cuts") or {}, self.mark)
+            loss.boundary = getattr(self, "grad_boundary", None)
         else:
             loss = rpn + roi_loss                                                        # voxel_rcnn.py get_training_loss
         parts = dict(loss_rpn=rpn.detach(), rcnn_loss_cls=l_cls.detach(), rcnn_loss_reg=l_kl.detach(),
@@ -568,6 +584,9 @@ class StaticTrainStep(gb.StaticTrainPipeline):
                          extra_modules=(model.backbone_2d, model.dense_head, model.roi_head))
         self.hc = model.map_to_bev_module
         self.split = False
+        # the gradient exchange in two buckets (capture(split=True, buckets=2)): everything but the sparse backbone's gradients is
+        # final ~1 ms before the step ends -- that bucket's all-reduce runs beside the sparse backward (two recorded graphs)
+        self.buckets, self.graph2, self._bucket_capture, self._bucket_plan = 1, None, None, None
         # the staged backward (RoI branch on its own stream, StagedLoss) is a property of THIS pipeline's launch
         # sequence: the model's flags are set around enqueue() only, so the model's eager API (training_losses ->
         # a tensor with .backward()) is what it was before a pipeline was built on it
@@ -650,17 +669,33 @@ class StaticTrainStep(gb.StaticTrainPipeline):
         if self.mark:
             self.mark("grad clip + AdamW")
 
+    def _bucket_boundary(self):
+        """StagedLoss calls this when every gradient but the sparse backbone's is final: gather that bucket; a capture in
+        progress ends its first graph here and begins the second (same stream, same memory pool)."""
+        self.step_optimizer.pack_grads(only=self._bucket_plan[2], bump=False)
+        st = self._bucket_capture
+        if st is not None and st["phase"] == 1:
+            st["g1"].capture_end()
+            st["g2"].capture_begin(pool=st["g1"].pool())
+            st["phase"] = 2
+
     def enqueue(self):
         losses.UNIT_ROOT_GRAD = True      # the step's root scalar is the unweighted sum of the loss terms
         net = self.net
         was = (net.overlap_roi, net.backbone_3d.stage_cuts)
         net.overlap_roi, net.backbone_3d.stage_cuts = self.overlap_roi, self.stage_cuts
+        bucketed = self.buckets == 2
+        if bucketed:
+            net.grad_boundary = self._bucket_boundary
         try:
             bd = super().enqueue()
         finally:
             losses.UNIT_ROOT_GRAD = False
             net.overlap_roi, net.backbone_3d.stage_cuts = was
-        if self.flat:
+            net.grad_boundary = None
+        if bucketed:
+            self.step_optimizer.pack_grads(only=self._bucket_plan[3])      # the late bucket; the lending generation moves
+        elif self.flat:
             self.step_optimizer.pack_grads()          # part of the forward + backward graph
         elif self.external:
             self.flat_grads.pack_grads()
@@ -682,9 +717,12 @@ class StaticTrainStep(gb.StaticTrainPipeline):
             ts = list(self.params) + [v for st in opt.state.values() for v in st.values() if torch.is_tensor(v)]
         return ts + [b for b in self.net.buffers()]
 
-    def capture(self, warmup=2, split=False, keep_state=True):
+    def capture(self, warmup=2, split=False, keep_state=True, buckets=1):
         """split=False: fwd + bwd + clip + update in one graph.  split=True: the update is its own graph and
-        step() runs `exchange` between the two.
+        step() runs `exchange` between the two.  buckets=2 (with split=True, the flat optimizer and the staged loss):
+        forward + backward are recorded as TWO graphs cut where everything but the sparse backbone's gradients is final;
+        step() starts that bucket's all-reduce behind the first graph, launches the second (the sparse backward) beside it,
+        exchanges the sparse backbone's bucket and waits for both before the update graph.
         keep_state (default): the warm-up passes and the capture itself run REAL steps on the loaded batch (that is
         how the allocator pool and the lazily created optimizer state get sized) -- their effect on parameters, Adam
         moments, the step count (bias correction), BatchNorm running statistics and num_batches_tracked is undone
@@ -693,6 +731,12 @@ class StaticTrainStep(gb.StaticTrainPipeline):
         self.split = bool(split)
         if not split and self.exchange is not None:
             raise ValueError("a gradient exchange needs capture(split=True)")
+        if buckets not in (1, 2):
+            raise ValueError("capture: buckets is 1 or 2")
+        if buckets == 2 and not (split and self.flat and self.overlap_roi and not self.external):
+            raise ValueError("capture(buckets=2) needs split=True, the flat optimizer and the staged loss (overlap_roi)")
+        self.buckets = buckets
+        self._bucket_plan = self.step_optimizer.buckets(list(self.net.backbone_3d.parameters())) if buckets == 2 else None
         before = self._training_state() if keep_state else []
         snap = [t.detach().clone() for t in before]
         try:
@@ -713,7 +757,10 @@ class StaticTrainStep(gb.StaticTrainPipeline):
     def _capture(self, warmup, split):
         from . import runtime
         runtime.note_capture()          # one diagnostic if the executor setting of the published step time is not in effect
-        super().capture(warmup)
+        if self.buckets == 2:
+            self._capture_two_graphs(warmup)
+        else:
+            super().capture(warmup)
         if split and not self.external:
             dev = self.points.device
             side = torch.cuda.Stream(dev)
@@ -727,6 +774,45 @@ class StaticTrainStep(gb.StaticTrainPipeline):
                 self.update()
             self.update_memsets_replaced = gb._lib.finish_graph(self.update_graph)   # raises if it cannot repair
         return self
+
+    def _capture_two_graphs(self, warmup):
+        """StaticFramePipeline.capture with the forward + backward in two graphs (the cut: _bucket_boundary)."""
+        import gc
+        dev = self.points.device
+        gc.collect()
+        side = self.__dict__.get("_capture_stream")
+        if side is None:
+            side = self._capture_stream = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self.enqueue()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.check()
+        gc.collect()
+        retired = self.graph
+        pool = retired.pool() if (retired is not None and gb.REUSE_GRAPH_POOL) else None
+        g1, g2 = gb._lib.new_graph(), gb._lib.new_graph()
+        self._bucket_capture = st = dict(g1=g1, g2=g2, phase=1)
+        torch.cuda.empty_cache()
+        try:
+            with torch.cuda.stream(side), gb.no_gc():
+                if pool is not None:
+                    g1.capture_begin(pool=pool)
+                else:
+                    g1.capture_begin()
+                try:
+                    self.enqueue()
+                finally:
+                    (g2 if st["phase"] == 2 else g1).capture_end()
+        finally:
+            self._bucket_capture = None
+        if st["phase"] != 2:
+            raise RuntimeError("capture(buckets=2): the step never reached the bucket boundary (no staged loss?)")
+        self.graph, self.graph2 = g1, g2
+        self.memsets_replaced = (gb._lib.finish_graph(g1) or 0) + (gb._lib.finish_graph(g2) or 0)
+        self._tag = self._weights_tag()
 
     def enqueue_eager_marked(self):
         """One eager pass of the step's launches with `mark` called at the stage boundaries (bench.py)."""
@@ -749,7 +835,19 @@ class StaticTrainStep(gb.StaticTrainPipeline):
                 self.update()
             return self.loss
         self.replay()
-        if self.split and not self.external:
+        if self.buckets == 2:
+            opt = self.step_optimizer
+            early, late, _, _ = self._bucket_plan
+            exchange = self.exchange is not None
+            pending = opt.allreduce_ranges_(early, async_op=True) if exchange else []     # behind the first graph ...
+            self.graph2.replay()                                                          # ... beside the sparse backward
+            if exchange:
+                opt.allreduce_ranges_([late])
+            for h in pending:
+                h.wait()
+            self.update_graph.replay()
+            gb._lib.bump_weights_epoch(self._written_tensors())
+        elif self.split and not self.external:
             if self.exchange is not None:
                 self.exchange()
             self.update_graph.replay()

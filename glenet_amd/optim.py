@@ -116,14 +116,17 @@ class FlatAdamW:
         if beta1 is not None:
             self.hyper[1:2].fill_(float(beta1))
 
-    def pack_grads(self):
+    def pack_grads(self, only=None, bump=True):
         """Gather the .grad tensors into the flat gradient buffer (a parameter without a gradient contributes
         zeros, as an optimizer that skips it would leave it -- except for weight decay, which torch skips too
-        for such parameters; the training step gives every parameter a gradient)."""
+        for such parameters; the training step gives every parameter a gradient).
+        only: indices into `params` (a bucket of the step's exchange: the rest is packed by a later call);
+        bump=False: more of this step's gradients follow (the lending generation moves with the last call)."""
         # (a gradient that was computed INTO its view -- dense_path.run_deferred_fc_wgrads does that for the 21 MB first RoI
         # Linear, 70 % of this copy -- needs none)
         have, missing = [], []
-        for v, p in zip(self.grad_views, self.params):
+        pairs = zip(self.grad_views, self.params) if only is None else ((self.grad_views[i], self.params[i]) for i in only)
+        for v, p in pairs:
             if p.grad is None:
                 missing.append(v)           # genuinely no gradient this step (in-place gradients are NOT missing)
             elif not (p.grad.data_ptr() == v.data_ptr() and p.grad.stride() == v.stride()):
@@ -132,9 +135,50 @@ class FlatAdamW:
             torch._foreach_zero_(missing)
         if have:
             torch._foreach_copy_([h[0] for h in have], [h[1] for h in have])
-        self._gen[0] += 1                 # the views may be lent to the next backward pass (_lib.grad_buffer)
-        _lib.next_grad_generation()       # (parameters without an owning optimizer follow the process-wide counter)
+        if bump:
+            self._gen[0] += 1             # the views may be lent to the next backward pass (_lib.grad_buffer)
+            _lib.next_grad_generation()   # (parameters without an owning optimizer follow the process-wide counter)
         return self.flat_grad
+
+    def buckets(self, late_params):
+        """The flat buffer as two buckets of a step whose gradients become final in two instalments: `late_params` (one
+        contiguous run of `params`: the sparse backbone, whose backward ends the step) and everything else.
+        -> (early element ranges [(lo, hi), ...], late range (lo, hi), early parameter indices, late parameter indices)."""
+        ids = {id(p) for p in late_params}
+        late = [i for i, p in enumerate(self.params) if id(p) in ids]
+        if not late:
+            raise ValueError("buckets: none of the late parameters belongs to this optimizer")
+        if late != list(range(late[0], late[-1] + 1)):
+            raise ValueError("buckets: the late parameters are not one contiguous run of the flat buffer")
+        lo = self.offsets[late[0]]
+        hi = self.offsets[late[-1] + 1] if late[-1] + 1 < len(self.params) else self.n
+        early = [r for r in ((0, lo), (hi, self.n)) if r[1] > r[0]]
+        keep = set(late)
+        return early, (lo, hi), [i for i in range(len(self.params)) if i not in keep], late
+
+    def allreduce_ranges_(self, ranges, average=True, async_op=False):
+        """SUM all-reduce of element ranges of the flat gradient buffer (a bucket of the exchange).  async_op (RCCL): the
+        collectives are queued behind what the current stream holds and the handles are returned -- wait() on them makes
+        the current stream wait; over gloo with device tensors the exchange goes through host copies and is complete
+        on return."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return []
+        if dist.get_world_size() == 1 and not getattr(self, "exchange_alone", False):
+            return []
+        self.grad_scale = 1.0 / dist.get_world_size() if average else 1.0
+        handles = []
+        for lo, hi in ranges:
+            buf = self.flat_grad[lo:hi]
+            if dist.get_backend() == "gloo" and buf.is_cuda:
+                host = buf.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                buf.copy_(host)
+            elif async_op:
+                handles.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+            else:
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        return handles
 
     def allreduce_(self, average=True):
         """Data-parallel exchange: one SUM all-reduce on the flat gradient buffer (RCCL; gloo for the CPU-side

@@ -53,11 +53,14 @@ def main():
     pipe = gvr.StaticTrainStep(model, 2, npts, max_gt=16, lr=lr, seed_rois_with_gt=helpers.JIT, capacities=caps)
     pipe.data_parallel()                    # broadcast from rank 0 + grad_scale = 1 / world
     pipe.load(*batches[rank])
-    pipe.capture(split=True)
+    buckets = int(os.environ.get("GLX_TEST_GRAD_BUCKETS", "1"))     # 2: the exchange in two buckets, two fwd + bwd graphs
+    pipe.capture(split=True, buckets=buckets)
     g_local = None
     if os.environ.get("GLX_DP_DEBUG"):             # the step taken apart: this rank's gradient before the exchange
         from glenet_amd import _lib
         pipe.replay()
+        if buckets == 2:
+            pipe.graph2.replay()
         torch.cuda.synchronize()
         g_local = pipe.step_optimizer.flat_grad.detach().clone()
         pipe.exchange()
@@ -96,7 +99,8 @@ def main():
                grad_max_abs=scale, grad_err_max=float(dg.max()), grad_err_over_1e4=int((dg > 1e-4 * scale).sum()),
                param_err_max=float(dp_.max()), param_err_mean=float(dp_.mean()),
                grads_differ_between_batches=float((grads[0] - grads[1]).abs().max()), lr=lr,
-               step_count=int(opt.step_count), backend=dist.get_backend(), device=di, world=dist.get_world_size())
+               step_count=int(opt.step_count), backend=dist.get_backend(), device=di, world=dist.get_world_size(),
+               buckets=buckets, graphs=1 + (pipe.graph2 is not None) + (pipe.update_graph is not None))
     if g_local is not None:
         e_loc = float((g_local - grads[rank]).abs().max())
         print("DPDEBUG rank %d: own recorded gradient vs own eager gradient of the same batch: %.3e (scale %.3e)"

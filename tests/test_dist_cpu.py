@@ -188,3 +188,62 @@ def test_gradient_bucket_over_the_glenet_vr_parameter_list():
         assert a == b
         want = ((x or 0.0) + (y or 0.0)) / 2
         np.testing.assert_allclose(a, want, rtol=1e-4, atol=1e-3)
+
+
+def _ranges_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import types
+    import torch
+    import torch.distributed as dist
+    from glenet_amd import dist as gdist
+    from glenet_amd.optim import FlatAdamW
+    gdist.init(backend="gloo")
+    gen = torch.Generator().manual_seed(rank + 1)
+    # the optimizer's bookkeeping without its device buffers: five parameters in one flat buffer, 16-byte aligned slices
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in (6, 10, 3, 8, 5)]
+    offsets, n = [], 0
+    for p in params:
+        offsets.append(n)
+        n += (p.numel() + 3) // 4 * 4
+    flat = torch.randn(n, generator=gen)
+    opt = types.SimpleNamespace(params=params, offsets=offsets, n=n, flat_grad=flat.clone(), grad_scale=1.0)
+    early, late, ei, li = FlatAdamW.buckets(opt, params[1:3])             # the "late" run sits in the middle: two early ranges
+    whole = flat.clone()
+    dist.all_reduce(whole, op=dist.ReduceOp.SUM)
+    handles = FlatAdamW.allreduce_ranges_(opt, early, async_op=True)
+    FlatAdamW.allreduce_ranges_(opt, [late])
+    for h in handles:
+        h.wait()
+    try:
+        FlatAdamW.buckets(opt, [params[0], params[2]])
+        contiguous_checked = False
+    except ValueError:
+        contiguous_checked = True
+    q.put((rank, early, late, ei, li, whole.numpy(), opt.flat_grad.numpy().copy(), opt.grad_scale, contiguous_checked))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_exchange_in_two_buckets_equals_one_flat_all_reduce():
+    """FlatAdamW.buckets / allreduce_ranges_ (the data-parallel step's two-bucket exchange, glenet_vr.StaticTrainStep.capture(
+    buckets=2)): the early ranges (asynchronous handles) + the late range cover the flat buffer exactly once and leave what ONE
+    all-reduce of the whole buffer leaves, bit for bit; 1 / world is folded into grad_scale; a late set that is not one
+    contiguous run is refused."""
+    import numpy as np
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_ranges_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, early, late, ei, li, whole, bucketed, scale, checked in res:
+        assert early == [(0, 8), (24, 40)] and late == (8, 24) and ei == [0, 3, 4] and li == [1, 2]
+        assert np.array_equal(whole, bucketed) and scale == 0.5 and checked
+    assert np.array_equal(res[0][6], res[1][6])

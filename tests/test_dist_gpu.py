@@ -23,12 +23,12 @@ def _free_port():
     return port
 
 
-def _two_rank_step(backend):
+def _two_rank_step(backend, buckets=1):
     port = _free_port()
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), GLX_DIST_BACKEND=backend)
+                   MASTER_PORT=str(port), GLX_DIST_BACKEND=backend, GLX_TEST_GRAD_BUCKETS=str(buckets))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dp_step_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -40,6 +40,7 @@ def _two_rank_step(backend):
     assert [d["rank"] for d in res] == [0, 1]
     for d in res:
         assert d["backend"] == backend and d["world"] == 2
+        assert d["buckets"] == buckets and d["graphs"] == 2 + (buckets == 2)
         assert d["ranks_equal"], d                       # rank 1 started from other weights: broadcast + same update
         assert d["grad_scale"] == 0.5 and d["step_count"] == 1
         assert d["grads_differ_between_batches"] > 1e-3 * d["grad_max_abs"]          # the ranks really had different data
@@ -60,6 +61,13 @@ def test_two_ranks_make_the_update_of_one_rank_on_both_batches(dev):
     _two_rank_step("gloo")
 
 
+def test_two_ranks_with_the_gradient_exchange_in_two_buckets(dev):
+    """capture(split=True, buckets=2) -- forward + backward as two graphs cut where everything but the sparse
+    backbone's gradients is final, that bucket exchanged behind the first graph (beside the sparse backward under RCCL), the sparse
+    backbone's behind the second: the same update as one rank on both batches, to the same bounds as the one-bucket step."""
+    _two_rank_step("gloo", buckets=2)
+
+
 def _gpus_visible():
     import torch
     return torch.cuda.device_count()          # counting devices does not initialise the runtime
@@ -73,6 +81,8 @@ def test_two_ranks_over_real_rccl_when_two_gpus_are_visible(dev):
     if _gpus_visible() < 2:
         pytest.skip("one GPU visible: the 2-GPU RCCL step runs where the box has two")
     res = _two_rank_step("nccl")
+    assert sorted(d["device"] for d in res) == [0, 1]
+    res = _two_rank_step("nccl", buckets=2)              # ... and with the first bucket's all-reduce beside the sparse backward
     assert sorted(d["device"] for d in res) == [0, 1]
 
 
