@@ -41,9 +41,10 @@ def test_two_bucket_recording_is_the_one_graph_step(dev):
             if i == 0:
                 torch.cuda.synchronize()
                 grads = pipe.step_optimizer.flat_grad.detach().clone()
+                params = pipe.step_optimizer.flat_param.detach().clone()
         torch.cuda.synchronize()
         pipe.check()
-        results[buckets] = (losses, grads, pipe.step_optimizer.flat_param.detach().clone(), pipe)
+        results[buckets] = (losses, grads, params, pipe)
     (l1, g1, p1, pipe1), (l2, g2, p2, pipe2) = results[1], results[2]
     early, late, ei, li = pipe2._bucket_plan
     n = pipe2.step_optimizer.n
@@ -51,7 +52,10 @@ def test_two_bucket_recording_is_the_one_graph_step(dev):
     assert late[1] - late[0] > 0 and early                                   # both buckets exist
     scale = float(g1.abs().max())
     assert float((g1 - g2).abs().max()) <= 2e-4 * scale                      # (float atomics reorder sums by ~1e-7 relative)
-    for a, b in zip(l1, l2):
-        assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (l1, l2)
-    # three Adam steps at lr 1e-3: noise-level gradient elements may step the other way (<= 2 lr per step)
-    assert float((p1 - p2).abs().max()) <= 3 * 2.5e-3 and float((p1 - p2).abs().mean()) <= 1e-5
+    # the first step is the same step; from then on two free-running Adam trajectories (noise-level gradient elements step the
+    # other way now and then: the recorded-graph tests of tests/test_train_step_gpu.py see the same)
+    for (a, b), tol in zip(zip(l1, l2), (1e-5, 1e-4, 5e-3)):
+        assert abs(a - b) <= tol * max(1.0, abs(a)), (l1, l2)
+    # the parameters after the FIRST update (Adam's first step moves every element by ~lr sign(g): a noise-level gradient element
+    # whose sign differs moves the other way -- 2 lr --, everything else agrees to rounding: the bounds of tests/test_dist_gpu.py)
+    assert float((p1 - p2).abs().max()) <= 2.5e-3 and float((p1 - p2).abs().mean()) <= 2e-6
