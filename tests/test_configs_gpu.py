@@ -95,9 +95,18 @@ def test_cvae_config4_full_size_30_samples(dev):
     assert float(got.std(0)[:, :6].mean()) > 0                                    # the 30 samples differ
 
 
-def test_cvae_training_step_matches_reference_golden_on_device(dev):
-    """The training branch on the device (row GEMMs + fused training BatchNorm) against the reference-generated
-    golden of tests/test_dense_path_cpu.py: loss terms, decoder output, every gradient, running statistics."""
+@pytest.mark.parametrize("path", ["default", "library_products", "bias_in_the_product", "fp32_wide_layer"])
+def test_cvae_training_step_matches_reference_golden_on_device(dev, path, monkeypatch):
+    """The training branch on the device (row kernels + fused training BatchNorm) against the reference-generated
+    golden of tests/test_dense_path_cpu.py: loss terms, decoder output, every gradient, running statistics -- on the default
+    path and with each of its class-level choices turned off (library products instead of csrc/glx_rows.hip; the conv biases added
+    in the product instead of folded into the running means; the 128 -> 512 layer with fp32 MFMA products)."""
+    if path == "library_products":
+        monkeypatch.setattr(dp.PointFeat, "OWN_ROW_LAYERS", False)
+    elif path == "bias_in_the_product":
+        monkeypatch.setattr(dp.PointFeat, "BIAS_INTO_RUNNING_MEAN", False)
+    elif path == "fp32_wide_layer":
+        monkeypatch.setattr(dp.PointMaxBN, "F16X2", False)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cvae_train_ref.npz"))
     m = dp.CVAE(4, 8)
     m.load_state_dict({k[len("cvae/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("cvae/")}, strict=True)
