@@ -592,6 +592,75 @@ def test_pointnet_feat_f16x2_against_fp64_with_wild_scales(dev):
         assert err < 2.0 ** -17, (f16x2, err)
 
 
+def test_rows128_affine_f16x2_against_fp64(dev):
+    """glx_rows128_affine_f16x2 (the dense part of the 128 -> 512 layer's input gradient): y = init + x W^T on a row count that
+    is not a multiple of the 32-row trip, weight rows 2^-10 .. 2^10 apart, rows of very different magnitudes and an all-zero row:
+    within 2^-17 of the contraction's own scale per element."""
+    import ctypes
+    from glenet_amd import _lib, dense_path as dp
+    g = torch.Generator(device=dev).manual_seed(21)
+    rows = 5003
+    x = torch.randn(rows, 128, device=dev, generator=g) * torch.exp2(torch.randint(-8, 9, (rows, 1), device=dev, generator=g).float())
+    x[17] = 0
+    w = torch.randn(128, 128, device=dev, generator=g) * torch.exp2(torch.randint(-10, 11, (128, 1), device=dev, generator=g).float())
+    init = torch.randn(128, device=dev, generator=g)
+    wh, ew = dp.PointFeat._f16x2_image(w)
+    y = torch.full((rows, 128), float("nan"), device=dev)
+    _lib.call("glx_rows128_affine_f16x2", x, ctypes.c_longlong(rows), wh, ew, init, y)
+    want = init.double() + x.double() @ w.double().t()
+    mag = x.abs().double() @ w.abs().double().t() + init.abs().double()
+    assert torch.isfinite(y).all()
+    assert float(((y.double() - want).abs() / mag.clamp_min(1e-300)).max()) < 2.0 ** -17
+    assert torch.equal(y[17], init)                                       # the zero row: exactly init
+    y2 = torch.empty_like(y)
+    _lib.call("glx_rows128_affine_f16x2", x, ctypes.c_longlong(rows), wh, ew, None, y2)      # init == NULL
+    assert float(((y2.double() - (want - init.double())).abs() / mag).max()) < 2.0 ** -17
+
+
+@pytest.mark.parametrize("bins,cin", [(2, 4), (3, 5)])
+def test_cvae_two_launch_sampler_equals_the_modules(dev, bins, cin):
+    """CVAE.sample's fused path (glx_pointnet_feat_f16x2_pair + glx_cvae_sample_tail) against the same model module by module
+    (eval-mode BatchNorm with non-trivial running statistics, 2 and 3 direction bins, 4 and 5 point features, an object count
+    that is not a multiple of the tail kernel's 16 objects per block): boxes to 1e-4, the heading modulo its bin period; and the
+    narrow extractor riding along in the wide one's launch against its own kernel."""
+    from glenet_amd import _lib, dense_path as dp
+    torch.manual_seed(bins * 10 + cin)
+    m = dp.CVAE(cin, 8, num_dir_bins=bins).to(dev).eval()
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.copy_((torch.randn(mod.num_features, generator=g) * 0.2).to(dev))
+                mod.running_var.copy_((torch.rand(mod.num_features, generator=g) + 0.5).to(dev))
+                mod.weight.copy_((torch.rand(mod.num_features, generator=g) + 0.5).to(dev))
+                mod.bias.copy_((torch.randn(mod.num_features, generator=g) * 0.1).to(dev))
+        B, P = 37, 300
+        pts = torch.randn(B, cin, P, device=dev)
+        eps = torch.randn(B, 8, device=dev)
+        assert m._sample_fusable(pts)
+        got = m.sample(pts, eps)
+        dp.CVAE.FUSED_SAMPLER = False
+        try:
+            want = m.sample(pts, eps)
+        finally:
+            dp.CVAE.FUSED_SAMPLER = True
+        f8_small = m.obj_encoder.fe(pts)                                   # glx_pointnet_feat_small
+        fe = m.x_encoder.fe
+        w1, b1, _, b2, _, b3 = fe._packed()
+        w2h, e2, w3h, e3 = fe._packed_f16()
+        narrow, _ = m._sample_pack()
+        f512, f8 = torch.empty(B, 512, device=dev), torch.empty(B, 8, device=dev)
+        _lib.call("glx_pointnet_feat_f16x2_pair", pts.contiguous(), B, cin, P, w1, b1, w2h, e2, b2, w3h, e3, b3, f512, narrow, f8)
+        f512_alone = fe(pts)                                               # glx_pointnet_feat_f16x2
+    assert got.shape == (B, 7 + bins)
+    d = (got - want).abs()
+    period = 2 * np.pi / bins
+    d[:, 6] = torch.minimum(d[:, 6], (d[:, 6] - period).abs())
+    assert float(d.max()) < 1e-4, float(d.max())
+    np.testing.assert_allclose(f8.cpu().numpy(), f8_small.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(f512.cpu().numpy(), f512_alone.cpu().numpy(), rtol=0, atol=0)     # the same kernel body: bitwise
+
+
 def test_group_points_gather_backward_matches_atomic_scatter(dev):
     """The gather form of the grouping gradient (no float atomics; chosen when many grid points share
     few rows) == the oracle's scatter, incl. rows nobody references (0), a frame without queries and
