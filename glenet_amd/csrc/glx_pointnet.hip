@@ -17,6 +17,7 @@
 #include <float.h>
 
 #include "glx_common.h"
+#include "glx_bf16x3.h"
 
 typedef float pf32x4 __attribute__((ext_vector_type(4)));
 
@@ -1201,6 +1202,153 @@ extern "C" int glx_rows128_affine_f16x2(const float* x, long long rows, const vo
   const int blocks = (int)(want < RM_BLOCKS ? want : RM_BLOCKS);
   hipLaunchKernelGGL(k_rows128_affine_f16, dim3(blocks), dim3(PN_THREADS), lds, (hipStream_t)stream, x, rows, (const uint4*)Wh, ew,
                      init, y);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ moments of a tall (rows, 128) matrix
+// G = x^T x (128 x 128) and h = sum_r x[r, :] in ONE pass over x: the batch statistics of the 128 -> 512 layer's output (sum y = W3 h,
+// sum y^2 = diag(W3 G W3^T)) and two terms of its weight gradient (dense_path.PointMaxBN).  The library's split-K product took 0.49 ms
+// for G at 2.1 M rows and a reduction kernel another 0.15 for h; the pass is 1 GB of reads.  The contraction runs over the ROWS, so
+// no power of two can be taken out per row: three bf16 pieces per value (fp32's own exponent range, products exact to 2^-22), six
+// MFMAs per tile.  A block walks a contiguous range of rows, 32 at a time: the rows land in LDS as fp32, wave w turns channel tiles
+// w and 7 - w into MFMA operand fragments (the A operand of a tile and its B operand are the same registers: lane (i, kg) holds rows
+// 8 kg .. 8 kg + 7 of channel 16 t + i) and leaves them in LDS for the other waves; wave w then owns the tiles (w, >= w) and
+// (7 - w, >= 7 - w) of the upper triangle, nine of the 36 each.  Per-block partial sums in accumulator order; k_rows128_moments_reduce
+// adds them in block order in fp64 and mirrors the triangle.
+#define MO_BLOCKS 256
+#define MO_PITCH 132                       // floats per staged row (16-byte aligned rows; the column reads are two-way conflicted)
+__global__ __launch_bounds__(256) void k_rows128_moments(const float* __restrict__ x, long long rows, float* __restrict__ part,
+                                                         float* __restrict__ hpart) {
+  __shared__ __attribute__((aligned(16))) float s_x[32 * MO_PITCH];
+  __shared__ __attribute__((aligned(16))) uint4 s_f[8 * 3 * 64];          // [tile][piece][lane]: 8 bf16 each
+  __shared__ float s_h[8][128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kg = lane >> 4;
+  const long long nsteps = (rows + 31) >> 5, per = (nsteps + gridDim.x - 1) / gridDim.x;
+  const long long s0 = (long long)blockIdx.x * per, s1 = s0 + per < nsteps ? s0 + per : nsteps;
+  pf32x4 acc[2][8];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[a][t] = pf32x4{0.f, 0.f, 0.f, 0.f};
+  pf32x4 hs = pf32x4{0.f, 0.f, 0.f, 0.f};
+  const int c4 = tid & 31, r0 = tid >> 5;          // this thread's float4 column and its first row of a step (+ 8 u)
+  pf32x4 nv[4];
+#define MO_LOAD(S)                                                                                           \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                            \
+    const long long row_ = (S) * 32 + r0 + 8 * u;                                                            \
+    nv[u] = row_ < rows ? *reinterpret_cast<const pf32x4*>(x + row_ * PN_C2 + 4 * c4) : pf32x4{0.f, 0.f, 0.f, 0.f}; \
+  }
+  if (s0 < s1) { MO_LOAD(s0) }
+  const int mine[2] = {wave, 7 - wave};
+  for (long long st = s0; st < s1; ++st) {
+    pf32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = nv[u];
+    if (st + 1 < s1) { MO_LOAD(st + 1) }
+    __syncthreads();                                     // the previous step's fragments have been read
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      *reinterpret_cast<pf32x4*>(s_x + (r0 + 8 * u) * MO_PITCH + 4 * c4) = v[u];
+      hs += v[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {                        // this wave's two channel tiles -> operand fragments
+      const int t = mine[a];
+      bf16x8 p0, p1, p2;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        __bf16 b0, b1, b2;
+        cv_split(s_x[(8 * kg + r) * MO_PITCH + 16 * t + i], b0, b1, b2);
+        p0[r] = b0; p1[r] = b1; p2[r] = b2;
+      }
+      s_f[(t * 3 + 0) * 64 + lane] = __builtin_bit_cast(uint4, p0);
+      s_f[(t * 3 + 1) * 64 + lane] = __builtin_bit_cast(uint4, p1);
+      s_f[(t * 3 + 2) * 64 + lane] = __builtin_bit_cast(uint4, p2);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int ta = mine[a];
+      bf16x8 fa[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) fa[q] = __builtin_bit_cast(bf16x8, s_f[(ta * 3 + q) * 64 + lane]);
+#pragma unroll
+      for (int tb = 0; tb < 8; ++tb) {
+        if (tb >= ta) {                                  // (uniform in the wave)
+          bf16x8 fb[3];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) fb[q] = __builtin_bit_cast(bf16x8, s_f[(tb * 3 + q) * 64 + lane]);
+          pf32x4 t_ = acc[a][tb];
+          BF3_MFMA6(t_, fa, fb);
+          acc[a][tb] = t_;
+        }
+      }
+    }
+  }
+#undef MO_LOAD
+  // ---- the block's partials: element (((wave * 2 + a) * 8 + tb) * 4 + reg) * 64 + lane = G[16 ta + 4 kg + reg][16 tb + i]
+  float* dst = part + (size_t)blockIdx.x * (PN_C2 * PN_C2);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int tb = 0; tb < 8; ++tb)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) dst[(((wave * 2 + a) * 8 + tb) * 4 + reg) * 64 + lane] = acc[a][tb][reg];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s_h[r0][4 * c4 + e] = hs[e];
+  __syncthreads();
+  if (tid < PN_C2) {
+    float t_ = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t_ += s_h[g][tid];
+    hpart[(size_t)blockIdx.x * PN_C2 + tid] = t_;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_rows128_moments_reduce(const float* __restrict__ part, const float* __restrict__ hpart,
+                                                                int nblocks, double* __restrict__ G, float* __restrict__ h) {
+  const int e = blockIdx.x * 256 + threadIdx.x;           // output element (ci, cj)
+  if (e < PN_C2 * PN_C2) {
+    const int ci = e >> 7, cj = e & 127;
+    const int lo = ci <= cj ? ci : cj, hi = ci <= cj ? cj : ci;      // the upper triangle holds it as (lo, hi)
+    const int ta = lo >> 4, tb = hi >> 4;
+    const int wave = ta < 4 ? ta : 7 - ta, a = ta < 4 ? 0 : 1;
+    const int rl = lo & 15, cl = hi & 15;
+    // inside a diagonal tile (ta == tb) both triangles are computed: (lo, hi) is as good as (hi, lo)
+    const int idx = (((wave * 2 + a) * 8 + tb) * 4 + (rl & 3)) * 64 + 16 * (rl >> 2) + cl;
+    double sum = 0;
+    for (int b = 0; b < nblocks; ++b) sum += (double)part[(size_t)b * (PN_C2 * PN_C2) + idx];
+    G[e] = sum;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < PN_C2) {
+    double sum = 0;
+    for (int b = 0; b < nblocks; ++b) sum += (double)hpart[(size_t)b * PN_C2 + threadIdx.x];
+    h[threadIdx.x] = (float)sum;
+  }
+}
+
+extern "C" size_t glx_rows128_moments_workspace_bytes(void) {
+  return glx_align((size_t)MO_BLOCKS * (PN_C2 * PN_C2 + PN_C2) * sizeof(float));
+}
+
+// G (128 x 128, fp64) = x^T x, h (128, fp32) = the column sums of x (rows, 128); bf16 x 3 products (exact to 2^-22), fp32 sums over a
+// block's rows, fp64 over the blocks in a fixed order (bitwise reproducible).  workspace: glx_rows128_moments_workspace_bytes().
+extern "C" int glx_rows128_moments(const float* x, long long rows, double* G, float* h, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  GLX_REQUIRE(x && G && h && workspace && rows >= 0, "glx_rows128_moments: null pointer");
+  GLX_REQUIRE(workspace_bytes >= glx_rows128_moments_workspace_bytes(), "glx_rows128_moments: workspace too small");
+  const long long nsteps = (rows + 31) >> 5;
+  int blocks = (int)(nsteps < MO_BLOCKS ? nsteps : MO_BLOCKS);
+  if (blocks < 1) blocks = 1;
+  float* part = (float*)workspace;
+  float* hpart = part + (size_t)MO_BLOCKS * PN_C2 * PN_C2;
+  hipLaunchKernelGGL(k_rows128_moments, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, rows, part, hpart);
+  hipLaunchKernelGGL(k_rows128_moments_reduce, dim3(PN_C2 * PN_C2 / 256), dim3(256), 0, (hipStream_t)stream, (const float*)part,
+                     (const float*)hpart, blocks, G, h);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

@@ -1703,9 +1703,21 @@ class PointMaxBN(torch.autograd.Function):
     # the 128 -> 512 layer as f16 x 2 products (csrc/glx_pointnet.hip, k_pointmax_fwd_f16); False: fp32 MFMA products
     F16X2 = True
 
+    # the two moments in one pass of csrc/glx_pointnet.hip's k_rows128_moments (bf16 x 3 products, fixed summation order); False: a
+    # library split-K product + a column reduction
+    OWN_MOMENTS = True
+
     @staticmethod
     def _moments(h2, R):
         """(h2^T h2 in fp64 from fp32 partial products over row chunks, sum_r h2)."""
+        if PointMaxBN.OWN_MOMENTS and h2.is_cuda and h2.dtype == torch.float32 and h2.shape[1] == 128 and h2.is_contiguous():
+            from ._lib import call, query, size_arg, workspace
+            G = torch.empty((128, 128), dtype=torch.float64, device=h2.device)
+            H = torch.empty(128, dtype=torch.float32, device=h2.device)
+            n = query("glx_rows128_moments_workspace_bytes")
+            ws = workspace.get(n, h2.device)
+            call("glx_rows128_moments", h2, ctypes.c_longlong(R), G, H, ws, size_arg(n))
+            return G, H
         S = 128 if R % 128 == 0 and R >= 128 * 256 else 1
         hc = h2.view(S, R // S, 128)
         return torch.bmm(hc.transpose(1, 2), hc).double().sum(0), h2.sum(0)

@@ -1106,6 +1106,11 @@ int glx_pointmax_scatter(const int32_t* arg, const float* coef, const float* W3,
  * weight as two fp16 planes of w 2^ew[row] in MFMA operand order (what glx_pointnet_feat_f16x2 takes for its layers).  Together the
  * input gradient of the 128 -> 512 layer + BatchNorm + max: dh2 = -v - h2 M, then the extreme points' rows of W3. */
 int glx_pointmax_scatter_add(const int32_t* arg, const float* coef, const float* W3, int B, int P, float* dh2, void* stream);
+/* G (128 x 128, fp64, row-major) = x^T x and h (128 floats) = the column sums of x (rows, 128) in one pass: the moments the
+ * 128 -> 512 layer's batch statistics and weight gradient are made of (dense_path.PointMaxBN).  bf16 x 3 products, fp32 sums per
+ * block of rows, fp64 over the blocks in a fixed order.  workspace: glx_rows128_moments_workspace_bytes(). */
+size_t glx_rows128_moments_workspace_bytes(void);
+int glx_rows128_moments(const float* x, long long rows, double* G, float* h, void* workspace, size_t workspace_bytes, void* stream);
 int glx_rows128_affine_f16x2(const float* x, long long rows, const void* Wh, const int32_t* ew, const float* init, float* y,
                              void* stream);
 size_t glx_pointmax_wsum_workspace_bytes(void);

@@ -95,7 +95,7 @@ def test_cvae_config4_full_size_30_samples(dev):
     assert float(got.std(0)[:, :6].mean()) > 0                                    # the 30 samples differ
 
 
-@pytest.mark.parametrize("path", ["default", "library_products", "bias_in_the_product", "fp32_wide_layer"])
+@pytest.mark.parametrize("path", ["default", "library_products", "bias_in_the_product", "fp32_wide_layer", "library_moments"])
 def test_cvae_training_step_matches_reference_golden_on_device(dev, path, monkeypatch):
     """The training branch on the device (row kernels + fused training BatchNorm) against the reference-generated
     golden of tests/test_dense_path_cpu.py: loss terms, decoder output, every gradient, running statistics -- on the default
@@ -107,6 +107,8 @@ def test_cvae_training_step_matches_reference_golden_on_device(dev, path, monkey
         monkeypatch.setattr(dp.PointFeat, "BIAS_INTO_RUNNING_MEAN", False)
     elif path == "fp32_wide_layer":
         monkeypatch.setattr(dp.PointMaxBN, "F16X2", False)
+    elif path == "library_moments":
+        monkeypatch.setattr(dp.PointMaxBN, "OWN_MOMENTS", False)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cvae_train_ref.npz"))
     m = dp.CVAE(4, 8)
     m.load_state_dict({k[len("cvae/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("cvae/")}, strict=True)

@@ -592,6 +592,38 @@ def test_pointnet_feat_f16x2_against_fp64_with_wild_scales(dev):
         assert err < 2.0 ** -17, (f16x2, err)
 
 
+@pytest.mark.parametrize("rows", [70001, 31, 8192 * 256])
+def test_rows128_moments_against_fp64(dev, rows):
+    """glx_rows128_moments: x^T x (fp64 out) and the column sums of a (rows, 128) matrix in one pass, bf16 x 3 products: against
+    fp64 products to 5e-6 of sqrt(G_ii G_jj) (fp32 sums over a block's <= 8192 rows of non-negative values: 2.3e-6 measured at
+    2.1 M rows), symmetric, twice the same bits; row counts that are
+    not a multiple of the 32-row step, fewer rows than one step, and the CVAE's 2.1 M."""
+    import ctypes
+    from glenet_amd import _lib
+    g = torch.Generator(device=dev).manual_seed(rows % 1000)
+    x = torch.relu(torch.randn(rows, 128, device=dev, generator=g) + 0.3) * torch.exp2(torch.randint(-6, 7, (1, 128), device=dev, generator=g).float())
+    n = _lib.query("glx_rows128_moments_workspace_bytes")
+    ws = torch.empty(n, dtype=torch.uint8, device=dev)
+    outs = []
+    for _ in range(2):
+        G = torch.full((128, 128), float("nan"), dtype=torch.float64, device=dev)
+        H = torch.full((128,), float("nan"), device=dev)
+        _lib.call("glx_rows128_moments", x, ctypes.c_longlong(rows), G, H, ws, _lib.size_arg(n))
+        outs.append((G, H))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    G, H = outs[0]
+    want, hw = torch.zeros(128, 128, dtype=torch.float64, device=dev), torch.zeros(128, dtype=torch.float64, device=dev)
+    for lo in range(0, rows, 1 << 18):                     # fp64 in chunks (memory)
+        xd = x[lo:lo + (1 << 18)].double()
+        want += xd.t() @ xd
+        hw += xd.sum(0)
+    dg = want.diagonal().sqrt()
+    assert torch.equal(G, G.t())
+    assert float(((G - want).abs() / (dg[:, None] * dg[None, :]).clamp_min(1e-300)).max()) < 5e-6
+    assert float(((H.double() - hw).abs() / hw.abs().clamp_min(1e-30)).max()) < 5e-6
+
+
 def test_rows128_affine_f16x2_against_fp64(dev):
     """glx_rows128_affine_f16x2 (the dense part of the 128 -> 512 layer's input gradient): y = init + x W^T on a row count that
     is not a multiple of the 32-row trip, weight rows 2^-10 .. 2^10 apart, rows of very different magnitudes and an all-zero row:
