@@ -18,6 +18,7 @@
 
 #include "glx_common.h"
 #include "glx_bf16x3.h"
+#include "glx_bn_state.h"
 
 typedef float pf32x4 __attribute__((ext_vector_type(4)));
 
@@ -1206,6 +1207,163 @@ extern "C" int glx_rows128_affine_f16x2(const float* x, long long rows, const vo
   return GLX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ 64 -> 128 point layer, f16 x 2
+// z (rows, 128) = x (rows, 64) W^T with the training-mode BatchNorm statistics of z in the epilogue: the CVAE's second point layer on
+// 2.1 M rows (cvae_uncertainty/point_net.py:17,24).  The fp32-MFMA row kernel (csrc/glx_rows.hip, two column halves) is bound by its
+// matrix instructions (0.53 ms: 34 GFLOP at 0.4 of the fp32 peak); with f16 x 2 products the pass is its memory traffic (0.5 GB in, 1 GB
+// out).  Structure of k_rows128_affine_f16: the weight image (two fp16 planes in operand order, 32 KB) in LDS, a wave takes 2 x 16
+// rows per trip (their own powers of two), rows prefetched a trip ahead; the sums of z and z^2 stay in fp32 per lane over the wave's
+// trips (<= 64 values each at 2.1 M rows), meet in fp64 at the end and go through the shared accumulator / ticket / last-block
+// finalize of glx_bn_state.h.
+#define RF_BLOCKS 512
+__global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_rows_linear_64_128_f16(
+    const float* __restrict__ x, int rows, const int* __restrict__ n_live, const uint4* __restrict__ Wh, const int* __restrict__ ew,
+    float* __restrict__ z, BnState* __restrict__ st, BnFinalize f) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  uint4* s_w = reinterpret_cast<uint4*>(smem);                         // 8 tiles x 2 k-steps x 2 planes x 64 lanes (32 KB)
+  int* s_e = reinterpret_cast<int*>(s_w + 8 * 2 * 2 * 64);             // 128: MINUS the rows' exponents
+  double* s_red = reinterpret_cast<double*>(s_e + PN_C2);              // [4 waves][32 float4 columns][2 moments][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  int n = rows;
+  if (n_live) n = min(rows, *n_live);
+  for (int e = tid; e < 8 * 2 * 2 * 64; e += PN_THREADS) s_w[e] = Wh[e];
+  if (tid < PN_C2) s_e[tid] = -ew[tid];
+  __syncthreads();
+  // the product TRANSPOSED (rows x channels): lane (j, q) holds channel 16 t + j of rows 4 q + e, so a lane's statistics are ONE
+  // channel's per tile (16 registers instead of 64) and the reduction over rows is mostly inside the lane
+  float s0[8], s1[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) s0[t] = s1[t] = 0.f;
+  const int ntrips = (n + 31) >> 5, stride = gridDim.x * 4;
+  int trip = blockIdx.x * 4 + wave;
+  pf32x4 nv[2][4];
+#define RF_LOAD(T)                                                                       \
+  _Pragma("unroll") for (int pt = 0; pt < 2; ++pt) {                                     \
+    const int r0_ = (T) * 32 + pt * 16 + j, r_ = r0_ < n ? r0_ : n - 1;                  \
+    const float* row_ = x + (long long)r_ * PN_C1 + 4 * q;                               \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) nv[pt][t] = *reinterpret_cast<const pf32x4*>(row_ + 16 * t); \
+  }
+  if (trip < ntrips) { RF_LOAD(trip) }
+  for (; trip < ntrips; trip += stride) {
+    pf16x8 Xa[2][2], Xb[2][2];
+    int nex[2][4];
+    pf32x4 v[2][4];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[pt][t] = nv[pt][t];
+    if (trip + stride < ntrips) { RF_LOAD(trip + stride) }
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      float m = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[pt][t][e]));
+      const int ex = pn_exponent(pn_point_max(m));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) nex[pt][e] = -__shfl(ex, 4 * q + e, 64);
+      const float sc = __builtin_bit_cast(float, (unsigned)(ex + 127) << 23);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          _Float16 a, b;
+          pn_split2(v[pt][2 * s + (jj >> 2)][jj & 3] * sc, a, b);
+          Xa[pt][s][jj] = a;
+          Xb[pt][s][jj] = b;
+        }
+    }
+    const int rb = trip * 32 + 4 * q;             // this lane's rows: rb + e (tile 0), rb + 16 + e (tile 1)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      pf32x4 acc0 = pf32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const pf16x8 Wa = __builtin_bit_cast(pf16x8, s_w[((t * 2 + s) * 2 + 0) * 64 + lane]);
+        const pf16x8 Wb = __builtin_bit_cast(pf16x8, s_w[((t * 2 + s) * 2 + 1) * 64 + lane]);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Xa[0][s], Wb, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Xb[0][s], Wa, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Xa[0][s], Wa, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Xa[1][s], Wb, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Xb[1][s], Wa, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Xa[1][s], Wa, acc1, 0, 0, 0);
+      }
+      const int c = 16 * t + j, nw = s_e[c];
+      float a0_ = 0.f, a1_ = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r0_ = rb + e, r1_ = rb + 16 + e;
+        const float o0 = r0_ < n ? ldexpf(acc0[e], nw + nex[0][e]) : 0.f;
+        const float o1 = r1_ < n ? ldexpf(acc1[e], nw + nex[1][e]) : 0.f;
+        if (r0_ < n) z[(long long)r0_ * PN_C2 + c] = o0;
+        if (r1_ < n) z[(long long)r1_ * PN_C2 + c] = o1;
+        a0_ += o0 + o1;
+        a1_ = fmaf(o0, o0, fmaf(o1, o1, a1_));
+      }
+      s0[t] += a0_;
+      s1[t] += a1_;
+      __builtin_amdgcn_sched_barrier(0);          // (keeps the next tiles' fragment reads from being hoisted: registers)
+    }
+  }
+#undef RF_LOAD
+  if (!st) return;
+  // ---- the four lanes of a channel (16 apart; fp64 from here), then the four waves: thread c4 < 32 ends up with float4 column c4
+  __shared__ int s_last;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    double d0 = (double)s0[t], d1 = (double)s1[t];
+    d0 += __shfl_xor(d0, 16, 64);
+    d1 += __shfl_xor(d1, 16, 64);
+    d0 += __shfl_xor(d0, 32, 64);
+    d1 += __shfl_xor(d1, 32, 64);
+    if (q == 0) {
+      const int c = 16 * t + j;
+      s_red[((wave * 32 + (c >> 2)) * 2 + 0) * 4 + (c & 3)] = d0;
+      s_red[((wave * 32 + (c >> 2)) * 2 + 1) * 4 + (c & 3)] = d1;
+    }
+  }
+  __syncthreads();
+  double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+  if (tid < PN_C2 / 4) {
+#pragma unroll
+    for (int w_ = 0; w_ < 4; ++w_)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a0[e] += s_red[((w_ * 32 + tid) * 2 + 0) * 4 + e];
+        a1[e] += s_red[((w_ * 32 + tid) * 2 + 1) * 4 + e];
+      }
+  }
+  if (!bn_contribute(st, PN_C2, a0, a1, gridDim.x, &s_last)) return;
+  __shared__ double s_fin[PN_THREADS][2];
+  bn_finalize_sets<false, PN_THREADS>(st, f, PN_C2, n, s_fin);
+}
+
+// x (rows, 64), Wh / ew: the (128, 64) weight as two fp16 planes of w 2^ew[row] in operand order (dense_path.PointFeat._f16x2_image);
+// the other arguments as glx_rows_linear_bn_forward's (bn_state == NULL: the product alone).
+extern "C" int glx_rows_linear_bn_forward_64_128_f16x2(const float* x, int rows, const void* Wh, const int32_t* ew, const int32_t* n_live,
+                                                       float* z, const float* gamma, const float* beta, float eps, float momentum,
+                                                       float* running_mean, float* running_var, float* coef, float* save_mean,
+                                                       float* save_invstd, void* bn_state, void* stream) {
+  GLX_REQUIRE(Wh && ew && (rows == 0 || (x && z)), "glx_rows_linear_bn_forward_64_128_f16x2: null pointer");
+  GLX_REQUIRE(!bn_state || (coef && save_mean && save_invstd), "glx_rows_linear_bn_forward_64_128_f16x2: statistics without their outputs");
+  if (rows <= 0) return GLX_OK;
+  BnFinalize f{gamma, beta, eps, momentum, coef, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, nullptr, 0};
+  const size_t lds = (size_t)8 * 2 * 2 * 64 * 16 + (size_t)PN_C2 * 4 + (size_t)4 * 32 * 2 * 4 * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GLX_HIP(hipFuncSetAttribute((const void*)k_rows_linear_64_128_f16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int want = (((rows + 31) >> 5) + 3) >> 2;
+  const int blocks = want < 1 ? 1 : (want > RF_BLOCKS ? RF_BLOCKS : want);
+  hipLaunchKernelGGL(k_rows_linear_64_128_f16, dim3(blocks), dim3(PN_THREADS), lds, (hipStream_t)stream, x, rows, (const int*)n_live,
+                     (const uint4*)Wh, ew, z, (BnState*)bn_state, f);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ moments of a tall (rows, 128) matrix
 // G = x^T x (128 x 128) and h = sum_r x[r, :] in ONE pass over x: the batch statistics of the 128 -> 512 layer's output (sum y = W3 h,
 // sum y^2 = diag(W3 G W3^T)) and two terms of its weight gradient (dense_path.PointMaxBN).  The library's split-K product took 0.49 ms
@@ -1216,7 +1374,7 @@ extern "C" int glx_rows128_affine_f16x2(const float* x, long long rows, const vo
 // 8 kg .. 8 kg + 7 of channel 16 t + i) and leaves them in LDS for the other waves; wave w then owns the tiles (w, >= w) and
 // (7 - w, >= 7 - w) of the upper triangle, nine of the 36 each.  Per-block partial sums in accumulator order; k_rows128_moments_reduce
 // adds them in block order in fp64 and mirrors the triangle.
-#define MO_BLOCKS 256
+#define MO_BLOCKS 768
 #define MO_PITCH 132                       // floats per staged row (16-byte aligned rows; the column reads are two-way conflicted)
 __global__ __launch_bounds__(256) void k_rows128_moments(const float* __restrict__ x, long long rows, float* __restrict__ part,
                                                          float* __restrict__ hpart) {
@@ -1311,7 +1469,12 @@ __global__ __launch_bounds__(256) void k_rows128_moments(const float* __restrict
 
 __global__ __launch_bounds__(256) void k_rows128_moments_reduce(const float* __restrict__ part, const float* __restrict__ hpart,
                                                                 int nblocks, double* __restrict__ G, float* __restrict__ h) {
-  const int e = blockIdx.x * 256 + threadIdx.x;           // output element (ci, cj)
+  // 16 output elements per block, 16 threads per element: thread (el, g) adds the partials of blocks g, g + 16, ..; the groups meet
+  // in LDS in a fixed order (one thread per element walking all the blocks was 256 dependent loads deep)
+  __shared__ double s_g[16][16];
+  const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + el;                     // output element (ci, cj), or (past the matrix) column sum e - 128 * 128
+  double sum = 0;
   if (e < PN_C2 * PN_C2) {
     const int ci = e >> 7, cj = e & 127;
     const int lo = ci <= cj ? ci : cj, hi = ci <= cj ? cj : ci;      // the upper triangle holds it as (lo, hi)
@@ -1320,14 +1483,25 @@ __global__ __launch_bounds__(256) void k_rows128_moments_reduce(const float* __r
     const int rl = lo & 15, cl = hi & 15;
     // inside a diagonal tile (ta == tb) both triangles are computed: (lo, hi) is as good as (hi, lo)
     const int idx = (((wave * 2 + a) * 8 + tb) * 4 + (rl & 3)) * 64 + 16 * (rl >> 2) + cl;
-    double sum = 0;
-    for (int b = 0; b < nblocks; ++b) sum += (double)part[(size_t)b * (PN_C2 * PN_C2) + idx];
-    G[e] = sum;
+    const float* src = part + idx;
+    int b = g;
+    for (; b + 48 < nblocks; b += 64) {
+      const float v0 = src[(size_t)b * (PN_C2 * PN_C2)], v1 = src[(size_t)(b + 16) * (PN_C2 * PN_C2)],
+                  v2 = src[(size_t)(b + 32) * (PN_C2 * PN_C2)], v3 = src[(size_t)(b + 48) * (PN_C2 * PN_C2)];
+      sum = (((sum + (double)v0) + (double)v1) + (double)v2) + (double)v3;
+    }
+    for (; b < nblocks; b += 16) sum += (double)src[(size_t)b * (PN_C2 * PN_C2)];
+  } else if (e < PN_C2 * PN_C2 + PN_C2) {
+    for (int b = g; b < nblocks; b += 16) sum += (double)hpart[(size_t)b * PN_C2 + (e - PN_C2 * PN_C2)];
   }
-  if (blockIdx.x == 0 && threadIdx.x < PN_C2) {
-    double sum = 0;
-    for (int b = 0; b < nblocks; ++b) sum += (double)hpart[(size_t)b * PN_C2 + threadIdx.x];
-    h[threadIdx.x] = (float)sum;
+  s_g[g][el] = sum;
+  __syncthreads();
+  if (g == 0) {
+    double t_ = s_g[0][el];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t_ += s_g[k][el];
+    if (e < PN_C2 * PN_C2) G[e] = t_;
+    else if (e < PN_C2 * PN_C2 + PN_C2) h[e - PN_C2 * PN_C2] = (float)t_;
   }
 }
 
@@ -1347,7 +1521,7 @@ extern "C" int glx_rows128_moments(const float* x, long long rows, double* G, fl
   float* part = (float*)workspace;
   float* hpart = part + (size_t)MO_BLOCKS * PN_C2 * PN_C2;
   hipLaunchKernelGGL(k_rows128_moments, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, rows, part, hpart);
-  hipLaunchKernelGGL(k_rows128_moments_reduce, dim3(PN_C2 * PN_C2 / 256), dim3(256), 0, (hipStream_t)stream, (const float*)part,
+  hipLaunchKernelGGL(k_rows128_moments_reduce, dim3((PN_C2 * PN_C2 + PN_C2) / 16), dim3(256), 0, (hipStream_t)stream, (const float*)part,
                      (const float*)hpart, blocks, G, h);
   GLX_LAUNCH_CHECK();
   return GLX_OK;

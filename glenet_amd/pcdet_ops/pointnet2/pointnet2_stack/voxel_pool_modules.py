@@ -232,6 +232,7 @@ class _RowsLinearFn(torch.autograd.Function):
 
 
 ROWS_CONV_BN = True
+ROWS_64_128_F16X2 = True      # RowsConvBN's 64 -> 128 forward with f16 x 2 products (False: fp32 MFMA, two column halves)
 
 
 class RowsConvBN(torch.autograd.Function):
@@ -258,8 +259,15 @@ class RowsConvBN(torch.autograd.Function):
         mean = torch.empty(cout, dtype=torch.float32, device=dev)
         invstd = torch.empty(cout, dtype=torch.float32, device=dev)
         rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-        _lib.call("glx_rows_linear_bn_forward", x, rows, cin, w, cout, count, z, gamma, beta, ctypes.c_float(bn.eps),
-                  ctypes.c_float(bn.momentum), rm, rv, coef, mean, invstd, core._bn_state(dev))
+        if ROWS_64_128_F16X2 and (cin, cout) == (64, 128):
+            # the CVAE's second point layer: f16 x 2 products (the fp32-MFMA form is matrix-bound there), csrc/glx_pointnet.hip
+            from ....dense_path import PointFeat
+            wh, ew = PointFeat._f16x2_image(w)
+            _lib.call("glx_rows_linear_bn_forward_64_128_f16x2", x, rows, wh, ew, count, z, gamma, beta, ctypes.c_float(bn.eps),
+                      ctypes.c_float(bn.momentum), rm, rv, coef, mean, invstd, core._bn_state(dev))
+        else:
+            _lib.call("glx_rows_linear_bn_forward", x, rows, cin, w, cout, count, z, gamma, beta, ctypes.c_float(bn.eps),
+                      ctypes.c_float(bn.momentum), rm, rv, coef, mean, invstd, core._bn_state(dev))
         _lib.call("glx_bn_apply_forward", z, coef, 1 if relu else 0, rows, cout, count, y, 0)
         if rm is not None:
             _lib.bump_weights_epoch((rm, rv))             # running statistics updated through raw pointers

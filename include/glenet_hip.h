@@ -1106,6 +1106,13 @@ int glx_pointmax_scatter(const int32_t* arg, const float* coef, const float* W3,
  * weight as two fp16 planes of w 2^ew[row] in MFMA operand order (what glx_pointnet_feat_f16x2 takes for its layers).  Together the
  * input gradient of the 128 -> 512 layer + BatchNorm + max: dh2 = -v - h2 M, then the extreme points' rows of W3. */
 int glx_pointmax_scatter_add(const int32_t* arg, const float* coef, const float* W3, int B, int P, float* dh2, void* stream);
+/* glx_rows_linear_bn_forward for the CVAE's 64 -> 128 point layer with f16 x 2 products (memory-bound where the fp32-MFMA form is
+ * matrix-bound): Wh / ew = the (128, 64) weight as two fp16 planes of w 2^ew[row] in MFMA operand order; the BatchNorm arguments
+ * as there (bn_state == NULL: the product alone). */
+int glx_rows_linear_bn_forward_64_128_f16x2(const float* x, int rows, const void* Wh, const int32_t* ew, const int32_t* n_live, float* z,
+                                            const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                            float* running_var, float* coef, float* save_mean, float* save_invstd, void* bn_state,
+                                            void* stream);
 /* G (128 x 128, fp64, row-major) = x^T x and h (128 floats) = the column sums of x (rows, 128) in one pass: the moments the
  * 128 -> 512 layer's batch statistics and weight gradient are made of (dense_path.PointMaxBN).  bf16 x 3 products, fp32 sums per
  * block of rows, fp64 over the blocks in a fixed order.  workspace: glx_rows128_moments_workspace_bytes(). */

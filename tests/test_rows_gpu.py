@@ -41,11 +41,16 @@ def _reference(seq, x, cot, live):
     (4099, 16, 64, True, 4001),
     (9000, 64, 64, True, None),
     (2048, 32, 16, False, 37),
-    (50000, 64, 128, True, None),          # two column halves (the CVAE's 64 -> 128 point layer)
+    (50000, 64, 128, True, None),          # the CVAE's 64 -> 128 point layer (forward f16 x 2 or fp32 column halves)
+    (33333, 64, 128, False, 30011),
     (7001, 16, 128, False, 6500),
 ])
-def test_rows_conv_bn_matches_the_reference_modules_in_fp64(dev, rows, cin, cout, relu, live):
+@pytest.mark.parametrize("f16x2_wide", [True, False])
+def test_rows_conv_bn_matches_the_reference_modules_in_fp64(dev, rows, cin, cout, relu, live, f16x2_wide, monkeypatch):
     from glenet_amd.pcdet_ops.pointnet2.pointnet2_stack import voxel_pool_modules as vpm
+    if not f16x2_wide and (cin, cout) != (64, 128):
+        pytest.skip("the arithmetic choice exists for 64 -> 128 only")
+    monkeypatch.setattr(vpm, "ROWS_64_128_F16X2", f16x2_wide)
     seq = _modules(cin, cout, relu, rows).to(dev).train()
     g = torch.Generator(device=dev).manual_seed(rows + cin)
     x = torch.randn(rows, cin, device=dev, generator=g) * 1.5 + 0.3
