@@ -1364,6 +1364,288 @@ extern "C" int glx_rows_linear_bn_forward_64_128_f16x2(const float* x, int rows,
   return GLX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ 64 -> 128 point layer, backward
+// Backward of z = x W^T (x (rows, 64), W (128, 64)) behind a training-mode BatchNorm (+ ReLU) in ONE pass over the rows, both products
+// on the 16-bit matrix pipe:  dz = A [y > 0] dy + C z + D  is formed on load (the BatchNorm backward folded to three vectors, as
+// csrc/glx_rows.hip's k_rows_linear_bwd forms it from seven),
+//   dX = dz W      contraction over the 128 channels: f16 x 2 with the row's own power of two (k_rows128_affine_f16's arithmetic; the
+//                  weight image W^T in LDS),
+//   dW = dz^T x    contraction over the ROWS: bf16 x 3 (k_rows128_moments' arithmetic): dz and x go through LDS once and come back as
+//                  operand fragments whose eight k values are eight rows.
+// The fp32-MFMA kernel it replaces is bound by its matrix instructions (2 x 0.58 ms at 2.1 M rows as column halves, 1.21 ms as one
+// pass).  A block of four waves takes 64 rows per step as two teams of 32; wave (t, h) owns rows 32 t + 16 h .. + 15 for dX and the
+// output-channel tiles 4 h .. 4 h + 3 of its team's dW.  Per-block partial dW (the two teams added), summed by
+// k_rows_bwd_64_128_reduce in block order.
+#define RB_PITCH 132
+#define RB_BLOCKS 512
+struct RowsBwd128 {
+  const float* coef_fwd;   // scale | shift of the forward transform (2 x 128): the ReLU mask is re-derived from z
+  const float* coef3;      // a | b | c of dz = a (g - b - c xhat) (3 x 128); NULL: dy is the gradient of z itself
+  const float* mean;
+  const float* invstd;
+  int relu;
+};
+
+__global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_rows_bwd_64_128_f16(
+    const float* __restrict__ x, const float* __restrict__ z, const float* __restrict__ dy, const uint4* __restrict__ Wth,
+    const int* __restrict__ ewt, int rows, const int* __restrict__ n_live, RowsBwd128 bn, float* __restrict__ gx,
+    float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  uint4* s_w = reinterpret_cast<uint4*>(smem);                          // W^T image: 4 tiles x 4 k-steps x 2 planes x 64 lanes (16 KB)
+  float* s_dz = reinterpret_cast<float*>(s_w + 4 * 4 * 2 * 64);         // [team][32 rows][RB_PITCH]                       (33 KB)
+  uint4* s_xf = reinterpret_cast<uint4*>(s_dz + 2 * 32 * RB_PITCH);     // [team][x tile 4][piece 3][lane]                  (24 KB)
+  float* s_cf = reinterpret_cast<float*>(s_xf + 2 * 4 * 3 * 64);        // A | C | D | scale | shift, 128 each
+  int* s_e = reinterpret_cast<int*>(s_cf + 5 * PN_C2);                  // 64: MINUS the exponents of W^T's rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, q = lane >> 4, team = wave >> 1, half = wave & 1;
+  int n = rows;
+  if (n_live) n = min(rows, *n_live);
+  for (int e = tid; e < 4 * 4 * 2 * 64; e += PN_THREADS) s_w[e] = Wth[e];
+  if (tid < PN_C1) s_e[tid] = -ewt[tid];
+  const bool BN = bn.coef3 != nullptr;
+  if (tid < PN_C2) {
+    float a = 1.f, cC = 0.f, cD = 0.f, sc = 0.f, sh = 1.f;
+    if (BN) {
+      const float b = bn.coef3[PN_C2 + tid], cc = bn.coef3[2 * PN_C2 + tid], mu = bn.mean[tid], is = bn.invstd[tid];
+      a = bn.coef3[tid];
+      cC = -a * cc * is;
+      cD = a * (cc * is * mu - b);
+      sc = bn.coef_fwd[tid];
+      sh = bn.coef_fwd[PN_C2 + tid];
+    }
+    s_cf[tid] = a; s_cf[PN_C2 + tid] = cC; s_cf[2 * PN_C2 + tid] = cD; s_cf[3 * PN_C2 + tid] = sc; s_cf[4 * PN_C2 + tid] = sh;
+  }
+  __syncthreads();
+  const bool mask = BN && bn.relu;
+  float* dzs = s_dz + team * 32 * RB_PITCH;
+  uint4* xfs = s_xf + team * 4 * 3 * 64;
+  pf32x4 accw[4][4];           // [output-channel tile 4 half + a][input-channel tile b]: dW[16 (4 half + a) + 4 q + e][16 b + j]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) accw[a][b] = pf32x4{0.f, 0.f, 0.f, 0.f};
+  const int nsteps = (n + 63) >> 6;
+  // every global load of a step is issued in one go, one step AHEAD: behind the first barrier of the step before (the registers they
+  // land in are dead there), so they fly during that step's weight-gradient phase and its second barrier
+  pf32x4 dzv[8], zv[8];
+  float xs[2][8];
+#define RB_LOAD(S)                                                                                            \
+  {                                                                                                           \
+    const int tb_ = (S) * 64 + 32 * team, row_ = tb_ + 16 * half + j;                                         \
+    const long long ro_ = (long long)(row_ < n ? row_ : n - 1) * PN_C2 + 4 * q;                               \
+    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) dzv[s_] = *reinterpret_cast<const pf32x4*>(dy + ro_ + 16 * s_); \
+    if (BN) {                                                                                                 \
+      _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) zv[s_] = *reinterpret_cast<const pf32x4*>(z + ro_ + 16 * s_); \
+    }                                                                                                         \
+  }
+  if ((int)blockIdx.x < nsteps) RB_LOAD(blockIdx.x)
+  for (int step = blockIdx.x; step < nsteps; step += gridDim.x) {
+    const int tb0 = step * 64 + 32 * team;               // the team's first row
+    const int row = tb0 + 16 * half + j;
+    const bool live = row < n;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)             // (x: 16 dwords per lane, mostly L2 hits -- the team's other wave reads the same rows)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int rr = tb0 + 8 * q + r;
+        xs[a][r] = x[(long long)(rr < n ? rr : n - 1) * PN_C1 + 16 * (2 * half + a) + j];
+      }
+    // ---- dz of this wave's 16 rows: lane (j, q) = row j, channels 16 s + 4 q ..
+#pragma unroll
+    for (int s_ = 0; s_ < 8; ++s_) {
+      pf32x4 g = dzv[s_];
+      if (BN) {
+        const int c = 16 * s_ + 4 * q;
+        const pf32x4 cA = *reinterpret_cast<const pf32x4*>(s_cf + c), cC = *reinterpret_cast<const pf32x4*>(s_cf + PN_C2 + c);
+        const pf32x4 cD = *reinterpret_cast<const pf32x4*>(s_cf + 2 * PN_C2 + c);
+        const pf32x4 sc = *reinterpret_cast<const pf32x4*>(s_cf + 3 * PN_C2 + c), sh = *reinterpret_cast<const pf32x4*>(s_cf + 4 * PN_C2 + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float gg = g[e];
+          if (mask) gg = bn_affine(zv[s_][e], sc[e], sh[e]) > 0.f ? gg : 0.f;
+          g[e] = fmaf(cA[e], gg, fmaf(cC[e], zv[s_][e], cD[e]));
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = live ? g[e] : 0.f;
+      dzv[s_] = g;
+      *reinterpret_cast<pf32x4*>(dzs + (16 * half + j) * RB_PITCH + 16 * s_ + 4 * q) = g;
+    }
+    // ---- this wave's two tiles of x as operand fragments (lane (i, kg): rows 8 kg .. of channel 16 tile + i), for the team
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int tile = 2 * half + a;
+      bf16x8 p0, p1, p2;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float v = tb0 + 8 * q + r < n ? xs[a][r] : 0.f;
+        __bf16 b0, b1, b2;
+        cv_split(v, b0, b1, b2);
+        p0[r] = b0; p1[r] = b1; p2[r] = b2;
+      }
+      xfs[(tile * 3 + 0) * 64 + lane] = __builtin_bit_cast(uint4, p0);
+      xfs[(tile * 3 + 1) * 64 + lane] = __builtin_bit_cast(uint4, p1);
+      xfs[(tile * 3 + 2) * 64 + lane] = __builtin_bit_cast(uint4, p2);
+    }
+    // ---- dX of the wave's rows: f16 x 2, the row's own power of two
+    if (gx) {
+      float m = 0.f;
+#pragma unroll
+      for (int s_ = 0; s_ < 8; ++s_)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(dzv[s_][e]));
+      const int ex = pn_exponent(pn_point_max(m));
+      const float scl = __builtin_bit_cast(float, (unsigned)(ex + 127) << 23);
+      pf16x8 Xa[4], Xb[4];
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          _Float16 a_, b_;
+          pn_split2(dzv[2 * s_ + (jj >> 2)][jj & 3] * scl, a_, b_);
+          Xa[s_][jj] = a_;
+          Xb[s_][jj] = b_;
+        }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        pf32x4 acc = pf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+          const pf16x8 Wa = __builtin_bit_cast(pf16x8, s_w[((t * 4 + s_) * 2 + 0) * 64 + lane]);
+          const pf16x8 Wb = __builtin_bit_cast(pf16x8, s_w[((t * 4 + s_) * 2 + 1) * 64 + lane]);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wb, Xa[s_], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xb[s_], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xa[s_], acc, 0, 0, 0);
+        }
+        if (live) {
+          const int c = 16 * t + 4 * q;
+          pf32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = ldexpf(acc[e], s_e[c + e] - ex);
+          *reinterpret_cast<pf32x4*>(gx + (long long)row * PN_C1 + c) = o;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();                                      // the teams' dz patches and x fragments are complete
+    if (step + (int)gridDim.x < nsteps) RB_LOAD(step + gridDim.x)
+    // ---- dW: this wave's four output-channel tiles x the four input-channel tiles, k = the team's 32 rows
+    if (part) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        bf16x8 fa[3];
+        {
+          bf16x8 p0, p1, p2;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            __bf16 b0, b1, b2;
+            cv_split(dzs[(8 * q + r) * RB_PITCH + 16 * (4 * half + a) + j], b0, b1, b2);
+            p0[r] = b0; p1[r] = b1; p2[r] = b2;
+          }
+          fa[0] = p0; fa[1] = p1; fa[2] = p2;
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          bf16x8 fb[3];                                    // (re-read per output tile: the registers hold the next step's rows)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) fb[p] = __builtin_bit_cast(bf16x8, xfs[(b * 3 + p) * 64 + lane]);
+          pf32x4 t_ = accw[a][b];
+          BF3_MFMA6(t_, fa, fb);
+          accw[a][b] = t_;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();                                      // before the next step overwrites the patches
+  }
+#undef RB_LOAD
+  if (gx) {                               // rows past the live count: zero gradient
+    const long long e0 = (long long)n * PN_C1, e1 = (long long)rows * PN_C1;
+    for (long long e = e0 + ((long long)blockIdx.x * PN_THREADS + tid) * 4; e < e1; e += (long long)gridDim.x * PN_THREADS * 4)
+      *reinterpret_cast<pf32x4*>(gx + e) = pf32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (!part) return;
+  // ---- the block's partial: team 1 hands its sums to team 0 through LDS (same tiles), team 0 writes
+  float* s_acc = s_dz;                                    // 2 waves x 16 tiles x 4 x 64 floats = 32 KB <= the patches' 33 KB
+  __syncthreads();
+  if (team == 1) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_acc[(((half * 4 + a) * 4 + b) * 4 + e) * 64 + lane] = accw[a][b][e];
+  }
+  __syncthreads();
+  if (team == 0) {
+    float* dst = part + (size_t)blockIdx.x * (PN_C2 * PN_C1);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k_ = (((half * 4 + a) * 4 + b) * 4 + e) * 64 + lane;
+          dst[k_] = accw[a][b][e] + s_acc[k_];
+        }
+  }
+}
+
+// gw[co][ci] = the sum of the blocks' partials in block order (16 threads per element, the groups added in a fixed order);
+// partial element (((half * 4 + a) * 4 + b) * 4 + e) * 64 + lane = dW[16 (4 half + a) + 4 (lane >> 4) + e][16 b + (lane & 15)]
+__global__ __launch_bounds__(256) void k_rows_bwd_64_128_reduce(const float* __restrict__ part, int nblocks, float* __restrict__ gw) {
+  __shared__ float s_g[16][16];
+  const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + el;                     // co * 64 + ci
+  const int co = e >> 6, ci = e & 63;
+  const int ta = co >> 4, half = ta >> 2, a = ta & 3, b = ci >> 4;
+  const int idx = (((half * 4 + a) * 4 + b) * 4 + (co & 3)) * 64 + 16 * ((co & 15) >> 2) + (ci & 15);
+  float sum = 0.f;
+  for (int blk = g; blk < nblocks; blk += 16) sum += part[(size_t)blk * (PN_C2 * PN_C1) + idx];
+  s_g[g][el] = sum;
+  __syncthreads();
+  if (g == 0) {
+    float t_ = s_g[0][el];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t_ += s_g[k][el];
+    gw[e] = t_;
+  }
+}
+
+extern "C" size_t glx_rows_bwd_64_128_workspace_bytes(void) { return glx_align((size_t)RB_BLOCKS * PN_C2 * PN_C1 * sizeof(float)); }
+
+// The backward of glx_rows_linear_bn_forward(_64_128_f16x2) for Cin = 64, Cout = 128, arguments as glx_rows_linear_bn_backward's,
+// with the weight as Wth / ewt = the f16 x 2 image of W^T ((64, 128): dense_path.PointFeat._f16x2_image(w.t())).
+extern "C" int glx_rows_linear_bn_backward_64_128_f16x2(const float* x, const float* z, const float* dy, int rows, const void* Wth,
+                                                        const int32_t* ewt, const int32_t* n_live, const float* coef_fwd, int relu,
+                                                        const float* coef3, const float* mean, const float* invstd, float* gx,
+                                                        float* gw, void* workspace, size_t workspace_bytes, void* stream) {
+  GLX_REQUIRE(Wth && ewt && (rows == 0 || (x && dy)), "glx_rows_linear_bn_backward_64_128_f16x2: null pointer");
+  GLX_REQUIRE(!coef3 || (z && coef_fwd && mean && invstd), "glx_rows_linear_bn_backward_64_128_f16x2: BatchNorm backward without z / coefficients");
+  GLX_REQUIRE(!gw || (workspace && workspace_bytes >= glx_rows_bwd_64_128_workspace_bytes()),
+              "glx_rows_linear_bn_backward_64_128_f16x2: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (rows <= 0) {
+    if (gw) GLX_HIP(hipMemsetAsync(gw, 0, (size_t)PN_C2 * PN_C1 * sizeof(float), st));
+    return GLX_OK;
+  }
+  const size_t lds = (size_t)4 * 4 * 2 * 64 * 16 + (size_t)2 * 32 * RB_PITCH * 4 + (size_t)2 * 4 * 3 * 64 * 16 + (size_t)5 * PN_C2 * 4 + PN_C1 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GLX_HIP(hipFuncSetAttribute((const void*)k_rows_bwd_64_128_f16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int nsteps = (rows + 63) >> 6;
+  const int blocks = nsteps < RB_BLOCKS ? nsteps : RB_BLOCKS;
+  RowsBwd128 bn{coef_fwd, coef3, mean, invstd, relu};
+  hipLaunchKernelGGL(k_rows_bwd_64_128_f16, dim3(blocks), dim3(PN_THREADS), lds, st, x, z, dy, (const uint4*)Wth, ewt, rows,
+                     (const int*)n_live, bn, gx, gw ? (float*)workspace : (float*)nullptr);
+  if (gw)
+    hipLaunchKernelGGL(k_rows_bwd_64_128_reduce, dim3(PN_C2 * PN_C1 / 16), dim3(256), 0, st, (const float*)workspace, blocks, gw);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ moments of a tall (rows, 128) matrix
 // G = x^T x (128 x 128) and h = sum_r x[r, :] in ONE pass over x: the batch statistics of the 128 -> 512 layer's output (sum y = W3 h,
 // sum y^2 = diag(W3 G W3^T)) and two terms of its weight gradient (dense_path.PointMaxBN).  The library's split-K product took 0.49 ms

@@ -232,7 +232,7 @@ class _RowsLinearFn(torch.autograd.Function):
 
 
 ROWS_CONV_BN = True
-ROWS_64_128_F16X2 = True      # RowsConvBN's 64 -> 128 forward with f16 x 2 products (False: fp32 MFMA, two column halves)
+ROWS_64_128_F16X2 = True      # RowsConvBN's 64 -> 128 layer on the 16-bit matrix pipe, forward and backward (False: fp32 MFMA, two column halves)
 
 
 class RowsConvBN(torch.autograd.Function):
@@ -295,9 +295,17 @@ class RowsConvBN(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             # written where the optimizer reads it when the filter is a leaf it owns (no gather copy afterwards)
             gw = _lib.grad_buffer(ctx.leaf, (cout, cin)) if ctx.leaf is not None else torch.empty((cout, cin), dtype=torch.float32, device=dev)
-        ws = _lib.workspace.get(_lib.query("glx_rows_linear_workspace_bytes", cin, cout), dev)
-        _lib.call("glx_rows_linear_bn_backward", x, z, dy, rows, cin, w, cout, ctx.count, coef, 1 if ctx.relu else 0, coef3,
-                  mean, invstd, gx, gw, ws, _lib.size_arg(ws.numel()))
+        if ROWS_64_128_F16X2 and (cin, cout) == (64, 128):
+            # one pass, both products on the 16-bit matrix pipe (csrc/glx_pointnet.hip, k_rows_bwd_64_128_f16)
+            from ....dense_path import PointFeat
+            wth, ewt = PointFeat._f16x2_image(w.t())
+            ws = _lib.workspace.get(_lib.query("glx_rows_bwd_64_128_workspace_bytes"), dev)
+            _lib.call("glx_rows_linear_bn_backward_64_128_f16x2", x, z, dy, rows, wth, ewt, ctx.count, coef, 1 if ctx.relu else 0,
+                      coef3, mean, invstd, gx, gw, ws, _lib.size_arg(ws.numel()))
+        else:
+            ws = _lib.workspace.get(_lib.query("glx_rows_linear_workspace_bytes", cin, cout), dev)
+            _lib.call("glx_rows_linear_bn_backward", x, z, dy, rows, cin, w, cout, ctx.count, coef, 1 if ctx.relu else 0, coef3,
+                      mean, invstd, gx, gw, ws, _lib.size_arg(ws.numel()))
         return (gx, gw.view(ctx.wshape) if gw is not None else None, dgamma if gamma is not None else None,
                 dbeta if gamma is not None else None, None, None, None)
 

@@ -1113,6 +1113,14 @@ int glx_rows_linear_bn_forward_64_128_f16x2(const float* x, int rows, const void
                                             const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                                             float* running_var, float* coef, float* save_mean, float* save_invstd, void* bn_state,
                                             void* stream);
+/* ... and its backward in one pass over the rows (arguments as glx_rows_linear_bn_backward's): dz formed on load, dX = dz W with
+ * f16 x 2 products (Wth / ewt = the image of W^T (64, 128)), dW = dz^T x with bf16 x 3 products (the contraction runs over the rows).
+ * workspace: glx_rows_bwd_64_128_workspace_bytes(). */
+size_t glx_rows_bwd_64_128_workspace_bytes(void);
+int glx_rows_linear_bn_backward_64_128_f16x2(const float* x, const float* z, const float* dy, int rows, const void* Wth,
+                                             const int32_t* ewt, const int32_t* n_live, const float* coef_fwd, int relu,
+                                             const float* coef3, const float* mean, const float* invstd, float* gx, float* gw,
+                                             void* workspace, size_t workspace_bytes, void* stream);
 /* G (128 x 128, fp64, row-major) = x^T x and h (128 floats) = the column sums of x (rows, 128) in one pass: the moments the
  * 128 -> 512 layer's batch statistics and weight gradient are made of (dense_path.PointMaxBN).  bf16 x 3 products, fp32 sums per
  * block of rows, fp64 over the blocks in a fixed order.  workspace: glx_rows128_moments_workspace_bytes(). */
