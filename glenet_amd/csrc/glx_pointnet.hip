@@ -1207,6 +1207,47 @@ extern "C" int glx_rows128_affine_f16x2(const float* x, long long rows, const vo
   return GLX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ the f16 x 2 weight image
+// W (Cout, Cin) (any strides; optionally times a per-row factor and a constant) -> two fp16 planes of w 2^ew[row] in the operand order of
+// the kernels above ([output tile][k-step][plane][lane 16 q + m][slot 4 h + e] = W[16 tile + m][32 s + 16 h + 4 q + e]) + the rows'
+// exponents (max |w| 2^ew in [2^14, 2^15), 0 for a zero row).  One launch; as tensor statements the same image was ~25 launches of
+// ~4.5 us, eight times per CVAE training step.
+__global__ __launch_bounds__(128) void k_f16x2_pack(const float* __restrict__ w, int cout, int cin, long long s_row, long long s_col,
+                                                    const float* __restrict__ row_scale, float scale, _Float16* __restrict__ img,
+                                                    int* __restrict__ ew) {
+  __shared__ float s_m[2];
+  const int r = blockIdx.x, c = threadIdx.x;
+  const float f = scale * (row_scale ? row_scale[r] : 1.f);
+  const float v = c < cin ? w[r * s_row + c * s_col] * f : 0.f;
+  float m = fabsf(v);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  const int e = pn_exponent(fmaxf(s_m[0], s_m[1]));
+  if (c == 0) ew[r] = e;
+  if (c < cin) {
+    const int S = cin >> 5, tile = r >> 4, mm = r & 15;
+    const int s_ = c >> 5, h = (c >> 4) & 1, q = (c >> 2) & 3, ee = c & 3;
+    _Float16 a, b;
+    pn_split2(ldexpf(v, e), a, b);
+    const size_t base = ((size_t)(tile * S + s_) * 2 * 64 + 16 * q + mm) * 8 + 4 * h + ee;
+    img[base] = a;
+    img[base + (size_t)64 * 8] = b;
+  }
+}
+
+// img: Cout x Cin x 2 halfs; ew: Cout int32.  Cout % 16 == 0, Cin % 32 == 0, Cin <= 128.  row_scale: Cout floats or NULL.
+extern "C" int glx_f16x2_pack(const float* w, int cout, int cin, long long stride_row, long long stride_col, const float* row_scale,
+                              float scale, void* img, int32_t* ew, void* stream) {
+  GLX_REQUIRE(w && img && ew, "glx_f16x2_pack: null pointer");
+  GLX_REQUIRE(cout > 0 && cout % 16 == 0 && cin >= 32 && cin % 32 == 0 && cin <= 128, "glx_f16x2_pack: %d x %d (rows %% 16, 32 <= columns <= 128, %% 32)", cout, cin);
+  hipLaunchKernelGGL(k_f16x2_pack, dim3(cout), dim3(128), 0, (hipStream_t)stream, w, cout, cin, stride_row, stride_col, row_scale, scale,
+                     (_Float16*)img, (int*)ew);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ 64 -> 128 point layer, f16 x 2
 // z (rows, 128) = x (rows, 64) W^T with the training-mode BatchNorm statistics of z in the epilogue: the CVAE's second point layer on
 // 2.1 M rows (cvae_uncertainty/point_net.py:17,24).  The fp32-MFMA row kernel (csrc/glx_rows.hip, two column halves) is bound by its

@@ -1584,11 +1584,20 @@ class PointFeat(nn.Module):
     F16X2 = True
 
     @staticmethod
-    def _f16x2_image(w):
-        """(Cout, Cin) fp32 -> (two fp16 planes of w 2^ew[row] in the kernel's operand order, ew (Cout,) int32):
-        [tile][k-step s][plane][lane 16 q + m][slot 4 h + e] = W[16 tile + m][32 s + 16 h + 4 q + e]."""
-        w = w.contiguous()
+    def _f16x2_image(w, row_scale=None, scale=1.0):
+        """(Cout, Cin) fp32 (any strides), times row_scale[row] times scale -> (two fp16 planes of w 2^ew[row] in the kernels'
+        operand order, ew (Cout,) int32): [tile][k-step s][plane][lane 16 q + m][slot 4 h + e] = W[16 tile + m][32 s + 16 h + 4 q + e].
+        One launch on the device (glx_f16x2_pack); the tensor statements below are the same image for host tensors."""
         cout, cin = w.shape
+        if w.is_cuda and w.dtype == torch.float32:
+            img = torch.empty((cout // 16, cin // 32, 2, 4, 16, 2, 4), dtype=torch.float16, device=w.device)
+            ew = torch.empty(cout, dtype=torch.int32, device=w.device)
+            _lib.call("glx_f16x2_pack", w, cout, cin, ctypes.c_longlong(w.stride(0)), ctypes.c_longlong(w.stride(1)),
+                      row_scale, ctypes.c_float(scale), img, ew)
+            return img, ew
+        if row_scale is not None:
+            w = w * row_scale[:, None]
+        w = (w * scale).contiguous()
         m = w.abs().amax(dim=1)
         e = torch.where(m > 0, 14 - torch.floor(torch.log2(m.clamp_min(1e-38))), torch.zeros_like(m))
         # floor(log2) in floating point can be one off at exact powers of two: settle with the integer test the kernels use
@@ -1667,7 +1676,7 @@ class PointMaxBN(torch.autograd.Function):
             # one extreme per channel: the BatchNorm's weight decides which (scale = gamma invstd, invstd > 0), so the rows of W3
             # go in with its sign and the pass returns max_p (sign y)
             sgn = torch.where(gamma.detach() >= 0, 1.0, -1.0)
-            w3h, e3 = PointFeat._f16x2_image(W3.detach() * sgn[:, None])
+            w3h, e3 = PointFeat._f16x2_image(W3.detach(), row_scale=sgn)
             call("glx_pointmax_forward_f16x2", h2, B, P, w3h, e3, vmax, amax)
             vmax *= sgn
             vmin, amin = vmax, amax
@@ -1742,7 +1751,7 @@ class PointMaxBN(torch.autograd.Function):
             d_h2 = torch.empty_like(h2)
             if PointMaxBN.F16X2:
                 # dense part first (f16 x 2 products, one pass: read h2, write d_h2), then the extreme points' rows on top
-                mh, em = PointFeat._f16x2_image(-M.t())
+                mh, em = PointFeat._f16x2_image(M.t(), scale=-1.0)
                 call("glx_rows128_affine_f16x2", h2, ctypes.c_longlong(R), mh, em, (-v).contiguous(), d_h2)
                 call("glx_pointmax_scatter_add", arg, (g * scale).contiguous(), W3, B, P, d_h2)
             else:

@@ -1106,6 +1106,12 @@ int glx_pointmax_scatter(const int32_t* arg, const float* coef, const float* W3,
  * weight as two fp16 planes of w 2^ew[row] in MFMA operand order (what glx_pointnet_feat_f16x2 takes for its layers).  Together the
  * input gradient of the 128 -> 512 layer + BatchNorm + max: dh2 = -v - h2 M, then the extreme points' rows of W3. */
 int glx_pointmax_scatter_add(const int32_t* arg, const float* coef, const float* W3, int B, int P, float* dh2, void* stream);
+/* The f16 x 2 weight image the point kernels take (glx_pointnet_feat_f16x2, glx_pointmax_forward_f16x2, glx_rows128_affine_f16x2,
+ * glx_rows_linear_bn_*_64_128_f16x2): w (Cout, Cin) with element strides (stride_row, stride_col), times row_scale[row] (NULL: 1) times
+ * scale -> two fp16 planes of w 2^ew[row] in MFMA operand order (img: Cout x Cin x 2 halfs) + ew (Cout).  Cout % 16 == 0,
+ * Cin in {32, 64, 96, 128}. */
+int glx_f16x2_pack(const float* w, int cout, int cin, long long stride_row, long long stride_col, const float* row_scale, float scale,
+                   void* img, int32_t* ew, void* stream);
 /* glx_rows_linear_bn_forward for the CVAE's 64 -> 128 point layer with f16 x 2 products (memory-bound where the fp32-MFMA form is
  * matrix-bound): Wh / ew = the (128, 64) weight as two fp16 planes of w 2^ew[row] in MFMA operand order; the BatchNorm arguments
  * as there (bn_state == NULL: the product alone). */

@@ -592,6 +592,26 @@ def test_pointnet_feat_f16x2_against_fp64_with_wild_scales(dev):
         assert err < 2.0 ** -17, (f16x2, err)
 
 
+@pytest.mark.parametrize("cout,cin", [(128, 64), (512, 128), (64, 128), (128, 128)])
+def test_f16x2_pack_kernel_equals_the_tensor_statements(dev, cout, cin):
+    """glx_f16x2_pack (one launch) == the image dense_path.PointFeat._f16x2_image builds with tensor statements on the host, bit for
+    bit: rows 2^-20 .. 2^20 apart, a zero row, an exact power of two as a row's maximum; a transposed (strided) source, a per-row
+    factor and a constant."""
+    from glenet_amd import dense_path as dp
+    g = torch.Generator().manual_seed(cout + cin)
+    w = torch.randn(cout, cin, generator=g) * torch.exp2(torch.randint(-20, 21, (cout, 1), generator=g).float())
+    w[3] = 0
+    w[5] = 0.25 * torch.sign(w[5])
+    for src, rs, sc in ((w, None, 1.0), (w.t().contiguous().t(), torch.where(torch.rand(cout, generator=g) > 0.5, 1.0, -1.0), 1.0),
+                        (w, None, -1.0)):
+        img_h, ew_h = dp.PointFeat._f16x2_image(src, rs, sc)                       # host: tensor statements
+        img_d, ew_d = dp.PointFeat._f16x2_image(src.to(dev) if src.is_contiguous() else src.t().contiguous().to(dev).t(),
+                                                None if rs is None else rs.to(dev), sc)
+        assert img_d.shape == img_h.shape and img_d.dtype == torch.float16
+        assert torch.equal(ew_d.cpu(), ew_h)
+        assert torch.equal(img_d.cpu().view(torch.int16), img_h.view(torch.int16))
+
+
 @pytest.mark.parametrize("rows", [70001, 31, 8192 * 256])
 def test_rows128_moments_against_fp64(dev, rows):
     """glx_rows128_moments: x^T x (fp64 out) and the column sums of a (rows, 128) matrix in one pass, bf16 x 3 products: against
