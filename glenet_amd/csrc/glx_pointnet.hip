@@ -1213,11 +1213,12 @@ extern "C" int glx_rows128_affine_f16x2(const float* x, long long rows, const vo
 // exponents (max |w| 2^ew in [2^14, 2^15), 0 for a zero row).  One launch; as tensor statements the same image was ~25 launches of
 // ~4.5 us, eight times per CVAE training step.
 __global__ __launch_bounds__(128) void k_f16x2_pack(const float* __restrict__ w, int cout, int cin, long long s_row, long long s_col,
-                                                    const float* __restrict__ row_scale, float scale, _Float16* __restrict__ img,
-                                                    int* __restrict__ ew) {
+                                                    const float* __restrict__ row_scale, int sign_only, float scale,
+                                                    _Float16* __restrict__ img, int* __restrict__ ew) {
   __shared__ float s_m[2];
   const int r = blockIdx.x, c = threadIdx.x;
-  const float f = scale * (row_scale ? row_scale[r] : 1.f);
+  const float rs = row_scale ? (sign_only ? (row_scale[r] >= 0.f ? 1.f : -1.f) : row_scale[r]) : 1.f;
+  const float f = scale * rs;
   const float v = c < cin ? w[r * s_row + c * s_col] * f : 0.f;
   float m = fabsf(v);
 #pragma unroll
@@ -1237,13 +1238,14 @@ __global__ __launch_bounds__(128) void k_f16x2_pack(const float* __restrict__ w,
   }
 }
 
-// img: Cout x Cin x 2 halfs; ew: Cout int32.  Cout % 16 == 0, Cin % 32 == 0, Cin <= 128.  row_scale: Cout floats or NULL.
+// img: Cout x Cin x 2 halfs; ew: Cout int32.  Cout % 16 == 0, Cin % 32 == 0, Cin <= 128.  row_scale: Cout floats or NULL
+// (row_scale_sign_only: only its sign is used: +1 for >= 0, -1 otherwise).
 extern "C" int glx_f16x2_pack(const float* w, int cout, int cin, long long stride_row, long long stride_col, const float* row_scale,
-                              float scale, void* img, int32_t* ew, void* stream) {
+                              int row_scale_sign_only, float scale, void* img, int32_t* ew, void* stream) {
   GLX_REQUIRE(w && img && ew, "glx_f16x2_pack: null pointer");
   GLX_REQUIRE(cout > 0 && cout % 16 == 0 && cin >= 32 && cin % 32 == 0 && cin <= 128, "glx_f16x2_pack: %d x %d (rows %% 16, 32 <= columns <= 128, %% 32)", cout, cin);
-  hipLaunchKernelGGL(k_f16x2_pack, dim3(cout), dim3(128), 0, (hipStream_t)stream, w, cout, cin, stride_row, stride_col, row_scale, scale,
-                     (_Float16*)img, (int*)ew);
+  hipLaunchKernelGGL(k_f16x2_pack, dim3(cout), dim3(128), 0, (hipStream_t)stream, w, cout, cin, stride_row, stride_col, row_scale,
+                     row_scale_sign_only, scale, (_Float16*)img, (int*)ew);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
@@ -1857,14 +1859,15 @@ extern "C" int glx_rows128_moments(const float* x, long long rows, double* G, fl
 // every row is written exactly once, no atomics, fixed summation order.
 __global__ __launch_bounds__(PN_THREADS) void k_pointmax_scatter(const int* __restrict__ arg, const float* __restrict__ coef,
                                                                  const float* __restrict__ W3, const float* __restrict__ init,
-                                                                 int P, float* __restrict__ dh2, int accumulate) {
+                                                                 int P, float* __restrict__ dh2, int accumulate,
+                                                                 const float* __restrict__ chan_scale) {
   __shared__ int s_arg[PN_C3];
   __shared__ float s_coef[PN_C3];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long obj = blockIdx.x;
   for (int c = tid; c < PN_C3; c += PN_THREADS) {
     s_arg[c] = arg[obj * PN_C3 + c];
-    s_coef[c] = coef[obj * PN_C3 + c];
+    s_coef[c] = coef[obj * PN_C3 + c] * (chan_scale ? chan_scale[c] : 1.f);
   }
   __syncthreads();
   for (int p = wave; p < P; p += PN_THREADS / 64) {
@@ -1902,11 +1905,11 @@ __global__ __launch_bounds__(PN_THREADS) void k_pointmax_scatter(const int* __re
 }
 
 static int pointmax_scatter(const int32_t* arg, const float* coef, const float* W3, const float* init, int B, int P, float* dh2,
-                            int accumulate, void* stream) {
+                            int accumulate, void* stream, const float* chan_scale = nullptr) {
   if (B <= 0) return GLX_OK;
   GLX_REQUIRE(arg && coef && W3 && dh2 && P >= 1, "glx_pointmax_scatter: null pointer");
   hipLaunchKernelGGL(k_pointmax_scatter, dim3(B), dim3(PN_THREADS), 0, (hipStream_t)stream, (const int*)arg, coef, W3, init, P, dh2,
-                     accumulate);
+                     accumulate, chan_scale);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
@@ -1920,6 +1923,163 @@ extern "C" int glx_pointmax_scatter(const int32_t* arg, const float* coef, const
 extern "C" int glx_pointmax_scatter_add(const int32_t* arg, const float* coef, const float* W3, int B, int P, float* dh2,
                                         void* stream) {
   return pointmax_scatter(arg, coef, W3, nullptr, B, P, dh2, 1, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ the BatchNorm around the max, fused
+// What dense_path.PointMaxBN did with ~40 tensor statements per direction (each a ~4.5 us launch inside the recorded step):
+//   forward   k_pm_stats: per channel c  mean = W3[c] . h / R,  var = W3[c] G W3[c]^T / R - mean^2  in fp64 (G = h2^T h2, h = sum h2),
+//             invstd, scale = gamma invstd, the running statistics (bias folded into the running mean);
+//             k_pm_out: ext = sign(gamma) vext (the pass returned max_p (sign y)), out = (ext - mean) scale + beta;
+//   backward  k_pm_bwd_sums: dbeta = sum_b g, dgamma = sum_b g xhat, bvec = scale dbeta / R, cvec = scale invstd dgamma / R;
+//             k_pm_bwd_mats: v = (bvec - cvec mean) W3 (negated: the dense pass's init), M = W3^T diag(cvec) W3;
+//             k_pm_bwd_dw: dW3 = scale T - bvec (x) h - diag(cvec) (W3 G - mean (x) h).
+__global__ __launch_bounds__(PN_C2) void k_pm_stats(const float* __restrict__ W3, const double* __restrict__ G, const float* __restrict__ h,
+                                                    long long R, const float* __restrict__ gamma, const float* __restrict__ bias, float eps,
+                                                    float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale) {
+  __shared__ double s_w[PN_C2], s_r[2][PN_C2];
+  const int c = blockIdx.x, i = threadIdx.x;
+  s_w[i] = (double)W3[(long long)c * PN_C2 + i];
+  __syncthreads();
+  double t = 0;
+  for (int jj = 0; jj < PN_C2; ++jj) t += G[i * PN_C2 + jj] * s_w[jj];
+  s_r[0][i] = s_w[i] * (double)h[i];
+  s_r[1][i] = s_w[i] * t;
+  __syncthreads();
+  for (int o = PN_C2 / 2; o > 0; o >>= 1) {
+    if (i < o) { s_r[0][i] += s_r[0][i + o]; s_r[1][i] += s_r[1][i + o]; }
+    __syncthreads();
+  }
+  if (i == 0) {
+    const double m = s_r[0][0] / (double)R;
+    double var = s_r[1][0] / (double)R - m * m;
+    if (var < 0) var = 0;
+    const float mf = (float)m, is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = mf;
+    invstd[c] = is;
+    scale[c] = gamma[c] * is;
+    if (running_mean) {
+      const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (mf + (bias ? bias[c] : 0.f));
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pm_out(float* __restrict__ vext, int B, const float* __restrict__ gamma,
+                                                const float* __restrict__ mean, const float* __restrict__ scale,
+                                                const float* __restrict__ beta, float* __restrict__ out) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)B * PN_C3) return;
+  const int c = (int)(e & (PN_C3 - 1));
+  const float ext = gamma[c] >= 0.f ? vext[e] : -vext[e];
+  vext[e] = ext;
+  out[e] = (ext - mean[c]) * scale[c] + beta[c];
+}
+
+// a block takes 4 channels: thread (cl = tid & 3, rb = tid >> 2) sums rows rb, rb + 64, ..
+__global__ __launch_bounds__(256) void k_pm_bwd_sums(const float* __restrict__ g, const float* __restrict__ ext, int B, long long R,
+                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                     const float* __restrict__ scale, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, float* __restrict__ bvec, float* __restrict__ cvec) {
+  __shared__ double s_r[2][256];
+  const int cl = threadIdx.x & 3, rb = threadIdx.x >> 2, c = blockIdx.x * 4 + cl;
+  const float mu = mean[c], is = invstd[c];
+  double a0 = 0, a1 = 0;
+  for (int b = rb; b < B; b += 64) {
+    const float gv = g[(long long)b * PN_C3 + c];
+    a0 += (double)gv;
+    a1 += (double)(gv * ((ext[(long long)b * PN_C3 + c] - mu) * is));
+  }
+  s_r[0][threadIdx.x] = a0;
+  s_r[1][threadIdx.x] = a1;
+  __syncthreads();
+  for (int o = 128; o >= 4; o >>= 1) {
+    if ((int)threadIdx.x < o) { s_r[0][threadIdx.x] += s_r[0][threadIdx.x + o]; s_r[1][threadIdx.x] += s_r[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) {
+    const float db = (float)s_r[0][threadIdx.x], dg = (float)s_r[1][threadIdx.x];
+    dbeta[c] = db;
+    dgamma[c] = dg;
+    bvec[c] = scale[c] * db / (float)R;
+    cvec[c] = scale[c] * is * dg / (float)R;
+  }
+}
+
+// block j < 128: M[j][i] = sum_c W3[c][i] cvec[c] W3[c][j]; block 128: nv[i] = -sum_c (bvec[c] - cvec[c] mean[c]) W3[c][i]
+__global__ __launch_bounds__(PN_C2) void k_pm_bwd_mats(const float* __restrict__ W3, const float* __restrict__ bvec,
+                                                       const float* __restrict__ cvec, const float* __restrict__ mean,
+                                                       float* __restrict__ M, float* __restrict__ nv) {
+  const int jb = blockIdx.x, i = threadIdx.x;
+  float acc = 0.f;
+  if (jb < PN_C2) {
+    for (int c = 0; c < PN_C3; ++c) acc = fmaf(W3[c * PN_C2 + i], cvec[c] * W3[c * PN_C2 + jb], acc);
+    M[jb * PN_C2 + i] = acc;
+  } else {
+    for (int c = 0; c < PN_C3; ++c) acc = fmaf(bvec[c] - cvec[c] * mean[c], W3[c * PN_C2 + i], acc);
+    nv[i] = -acc;
+  }
+}
+
+// block c: dW3[c][k] = scale[c] T[c][k] - bvec[c] h[k] - cvec[c] ((W3 G)[c][k] - mean[c] h[k])
+__global__ __launch_bounds__(PN_C2) void k_pm_bwd_dw(const float* __restrict__ W3, const double* __restrict__ G, const float* __restrict__ h,
+                                                     const float* __restrict__ T, const float* __restrict__ scale,
+                                                     const float* __restrict__ bvec, const float* __restrict__ cvec,
+                                                     const float* __restrict__ mean, float* __restrict__ dW) {
+  __shared__ float s_w[PN_C2];
+  const int c = blockIdx.x, k = threadIdx.x;
+  s_w[k] = W3[c * PN_C2 + k];
+  __syncthreads();
+  float wg = 0.f;
+  for (int i = 0; i < PN_C2; ++i) wg = fmaf(s_w[i], (float)G[i * PN_C2 + k], wg);
+  dW[c * PN_C2 + k] = scale[c] * T[c * PN_C2 + k] - bvec[c] * h[k] - cvec[c] * (wg - mean[c] * h[k]);
+}
+
+// vext (B, 512): what glx_pointmax_forward_f16x2 returned (max_p (sign(gamma) y)), REPLACED by ext = the extreme of y the BatchNorm
+// uses; out (B, 512); mean / invstd / scale: 512 each (saved for the backward); running_*: NULL = not tracked.
+extern "C" int glx_pointmax_bn_forward(const float* W3, const double* G, const float* h, long long R, float* vext, int B,
+                                       const float* gamma, const float* beta, const float* bias, float eps, float momentum,
+                                       float* running_mean, float* running_var, float* mean, float* invstd, float* scale, float* out,
+                                       void* stream) {
+  GLX_REQUIRE(W3 && G && h && vext && gamma && beta && mean && invstd && scale && out && R > 0 && B > 0, "glx_pointmax_bn_forward: bad arguments");
+  GLX_REQUIRE(!running_mean == !running_var, "glx_pointmax_bn_forward: both running statistics or neither");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_pm_stats, dim3(PN_C3), dim3(PN_C2), 0, st, W3, G, h, R, gamma, bias, eps, momentum, running_mean, running_var, mean,
+                     invstd, scale);
+  hipLaunchKernelGGL(k_pm_out, dim3((unsigned)(((long long)B * PN_C3 + 255) / 256)), dim3(256), 0, st, vext, B, gamma, (const float*)mean,
+                     (const float*)scale, beta, out);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// g (B, 512): the gradient of out; ext / mean / invstd / scale: from glx_pointmax_bn_forward.  -> dgamma, dbeta, bvec, cvec (512 each),
+// M (128 x 128) = W3^T diag(cvec) W3 and nv (128) = -(bvec - cvec mean) W3: the dense part of the input gradient is nv - h2 M.
+extern "C" int glx_pointmax_bn_backward_sums(const float* g, const float* ext, int B, long long R, const float* W3, const float* mean,
+                                             const float* invstd, const float* scale, float* dgamma, float* dbeta, float* bvec,
+                                             float* cvec, float* M, float* nv, void* stream) {
+  GLX_REQUIRE(g && ext && W3 && mean && invstd && scale && dgamma && dbeta && bvec && cvec && M && nv && B > 0 && R > 0,
+              "glx_pointmax_bn_backward_sums: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_pm_bwd_sums, dim3(PN_C3 / 4), dim3(256), 0, st, g, ext, B, R, mean, invstd, scale, dgamma, dbeta, bvec, cvec);
+  hipLaunchKernelGGL(k_pm_bwd_mats, dim3(PN_C2 + 1), dim3(PN_C2), 0, st, W3, (const float*)bvec, (const float*)cvec, mean, M, nv);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// dW3 (512, 128) from T (glx_pointmax_wsum of the UNSCALED g), the moments G (fp64) / h and the vectors of the sums call.
+extern "C" int glx_pointmax_bn_backward_weight(const float* W3, const double* G, const float* h, const float* T, const float* scale,
+                                               const float* bvec, const float* cvec, const float* mean, float* dW, void* stream) {
+  GLX_REQUIRE(W3 && G && h && T && scale && bvec && cvec && mean && dW, "glx_pointmax_bn_backward_weight: null pointer");
+  hipLaunchKernelGGL(k_pm_bwd_dw, dim3(PN_C3), dim3(PN_C2), 0, (hipStream_t)stream, W3, G, h, T, scale, bvec, cvec, mean, dW);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// glx_pointmax_scatter_add with the coefficients scaled per channel (coef[b, c] chan_scale[c]): the caller hands in g as it is
+extern "C" int glx_pointmax_scatter_add_scaled(const int32_t* arg, const float* coef, const float* chan_scale, const float* W3, int B, int P,
+                                               float* dh2, void* stream) {
+  return pointmax_scatter(arg, coef, W3, nullptr, B, P, dh2, 1, stream, chan_scale);
 }
 
 // T[c, :] = sum_b g[b, c] * h2[b * P + arg[b, c], :]   (512 x 128): the max's part of the weight gradient.  A wave per

@@ -1584,7 +1584,7 @@ class PointFeat(nn.Module):
     F16X2 = True
 
     @staticmethod
-    def _f16x2_image(w, row_scale=None, scale=1.0):
+    def _f16x2_image(w, row_scale=None, scale=1.0, sign_only=False):
         """(Cout, Cin) fp32 (any strides), times row_scale[row] times scale -> (two fp16 planes of w 2^ew[row] in the kernels'
         operand order, ew (Cout,) int32): [tile][k-step s][plane][lane 16 q + m][slot 4 h + e] = W[16 tile + m][32 s + 16 h + 4 q + e].
         One launch on the device (glx_f16x2_pack); the tensor statements below are the same image for host tensors."""
@@ -1593,10 +1593,10 @@ class PointFeat(nn.Module):
             img = torch.empty((cout // 16, cin // 32, 2, 4, 16, 2, 4), dtype=torch.float16, device=w.device)
             ew = torch.empty(cout, dtype=torch.int32, device=w.device)
             _lib.call("glx_f16x2_pack", w, cout, cin, ctypes.c_longlong(w.stride(0)), ctypes.c_longlong(w.stride(1)),
-                      row_scale, ctypes.c_float(scale), img, ew)
+                      row_scale, 1 if sign_only else 0, ctypes.c_float(scale), img, ew)
             return img, ew
         if row_scale is not None:
-            w = w * row_scale[:, None]
+            w = w * (torch.where(row_scale >= 0, 1.0, -1.0) if sign_only else row_scale)[:, None]
         w = (w * scale).contiguous()
         m = w.abs().amax(dim=1)
         e = torch.where(m > 0, 14 - torch.floor(torch.log2(m.clamp_min(1e-38))), torch.zeros_like(m))
@@ -1675,12 +1675,26 @@ class PointMaxBN(torch.autograd.Function):
             # sum_r y = W3 (sum_r h2), sum_r y^2 = diag(W3 (h2^T h2) W3^T)
             # one extreme per channel: the BatchNorm's weight decides which (scale = gamma invstd, invstd > 0), so the rows of W3
             # go in with its sign and the pass returns max_p (sign y)
-            sgn = torch.where(gamma.detach() >= 0, 1.0, -1.0)
-            w3h, e3 = PointFeat._f16x2_image(W3.detach(), row_scale=sgn)
+            w3h, e3 = PointFeat._f16x2_image(W3.detach(), row_scale=gamma.detach(), sign_only=True)
             call("glx_pointmax_forward_f16x2", h2, B, P, w3h, e3, vmax, amax)
+            G2d, H1 = PointMaxBN._moments(h2, R)
+            if PointMaxBN.FUSED_BN and bn.momentum is not None:
+                # statistics, running statistics, the choice of the extreme and the transform: two launches (~40 tensor statements)
+                mean_nb, invstd, scale = (torch.empty(512, dtype=torch.float32, device=dev) for _ in range(3))
+                out = torch.empty((B, 512), dtype=torch.float32, device=dev)
+                rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+                call("glx_pointmax_bn_forward", W3, G2d, H1, ctypes.c_longlong(R), vmax, B, gamma, beta, bias, ctypes.c_float(bn.eps),
+                     ctypes.c_float(bn.momentum), rm, rv, mean_nb, invstd, scale, out)
+                if bn.track_running_stats:
+                    bn.num_batches_tracked.add_(1)
+                    _lib.bump_weights_epoch((rm, rv))
+                ctx.save_for_backward(h2, W3, vmax, amax, mean_nb, invstd, scale)
+                ctx.moments, ctx.fused = (G2d, H1), True
+                ctx.dims = (B, P, bias is not None)
+                return out
+            sgn = torch.where(gamma.detach() >= 0, 1.0, -1.0)
             vmax *= sgn
             vmin, amin = vmax, amax
-            G2d, H1 = PointMaxBN._moments(h2, R)
             W3d = W3.detach().double()
             mean_nb = (W3d @ H1.double()) / R
             var = (((W3d @ G2d) * W3d).sum(1) / R - mean_nb * mean_nb).clamp_min_(0.0)
@@ -1705,9 +1719,13 @@ class PointMaxBN(torch.autograd.Function):
                 bn.running_var.mul_(1 - m).add_(var.float() * (R / max(R - 1, 1)), alpha=m)
                 bn.num_batches_tracked.add_(1)
         ctx.save_for_backward(h2, W3, ext, arg, mean_nb, invstd, scale)
-        ctx.moments = (G2, H1)
+        ctx.moments, ctx.fused = (G2, H1), False
         ctx.dims = (B, P, bias is not None)
         return out
+
+    # the BatchNorm's own arithmetic around the f16 x 2 pass (statistics from the moments, running statistics, transform; the backward's
+    # sums, vectors and 128 x 128 matrices) as five launches of csrc/glx_pointnet.hip; False: tensor statements
+    FUSED_BN = True
 
     # the 128 -> 512 layer as f16 x 2 products (csrc/glx_pointnet.hip, k_pointmax_fwd_f16); False: fp32 MFMA products
     F16X2 = True
@@ -1738,6 +1756,28 @@ class PointMaxBN(torch.autograd.Function):
         B, P, has_bias = ctx.dims
         R = B * P
         g = g.contiguous()
+        if ctx.fused:
+            dev = h2.device
+            dgamma, dbeta, bvec, cvec = (torch.empty(512, dtype=torch.float32, device=dev) for _ in range(4))
+            M = torch.empty((128, 128), dtype=torch.float32, device=dev)
+            nv = torch.empty(128, dtype=torch.float32, device=dev)
+            call("glx_pointmax_bn_backward_sums", g, ext, B, ctypes.c_longlong(R), W3, mean_nb, invstd, scale, dgamma, dbeta, bvec, cvec,
+                 M, nv)
+            d_h2 = d_w = None
+            if ctx.needs_input_grad[0]:
+                mh, em = PointFeat._f16x2_image(M.t(), scale=-1.0)
+                d_h2 = torch.empty_like(h2)
+                call("glx_rows128_affine_f16x2", h2, ctypes.c_longlong(R), mh, em, nv, d_h2)
+                call("glx_pointmax_scatter_add_scaled", arg, g, scale, W3, B, P, d_h2)
+            if ctx.needs_input_grad[1]:
+                T = torch.empty_like(W3)
+                ws = torch.empty(query("glx_pointmax_wsum_workspace_bytes"), dtype=torch.uint8, device=dev)
+                call("glx_pointmax_wsum", g, arg, h2, B, P, T, ws, size_arg(ws.numel()))
+                G2d, H1 = ctx.moments
+                d_w = torch.empty_like(W3)
+                call("glx_pointmax_bn_backward_weight", W3, G2d, H1, T, scale, bvec, cvec, mean_nb, d_w)
+            d_b = torch.zeros_like(dbeta) if has_bias else None
+            return d_h2, d_w, d_b, dgamma, dbeta, None, None, None
         xhat = (ext - mean_nb) * invstd
         dbeta = g.sum(0)
         dgamma = (g * xhat).sum(0)

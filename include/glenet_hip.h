@@ -1108,10 +1108,11 @@ int glx_pointmax_scatter(const int32_t* arg, const float* coef, const float* W3,
 int glx_pointmax_scatter_add(const int32_t* arg, const float* coef, const float* W3, int B, int P, float* dh2, void* stream);
 /* The f16 x 2 weight image the point kernels take (glx_pointnet_feat_f16x2, glx_pointmax_forward_f16x2, glx_rows128_affine_f16x2,
  * glx_rows_linear_bn_*_64_128_f16x2): w (Cout, Cin) with element strides (stride_row, stride_col), times row_scale[row] (NULL: 1) times
- * scale -> two fp16 planes of w 2^ew[row] in MFMA operand order (img: Cout x Cin x 2 halfs) + ew (Cout).  Cout % 16 == 0,
+ * scale (row_scale_sign_only: +1 / -1 by the sign of row_scale[row]) -> two fp16 planes of w 2^ew[row] in MFMA operand order (img:
+ * Cout x Cin x 2 halfs) + ew (Cout).  Cout % 16 == 0,
  * Cin in {32, 64, 96, 128}. */
-int glx_f16x2_pack(const float* w, int cout, int cin, long long stride_row, long long stride_col, const float* row_scale, float scale,
-                   void* img, int32_t* ew, void* stream);
+int glx_f16x2_pack(const float* w, int cout, int cin, long long stride_row, long long stride_col, const float* row_scale,
+                   int row_scale_sign_only, float scale, void* img, int32_t* ew, void* stream);
 /* glx_rows_linear_bn_forward for the CVAE's 64 -> 128 point layer with f16 x 2 products (memory-bound where the fp32-MFMA form is
  * matrix-bound): Wh / ew = the (128, 64) weight as two fp16 planes of w 2^ew[row] in MFMA operand order; the BatchNorm arguments
  * as there (bn_state == NULL: the product alone). */
@@ -1134,6 +1135,26 @@ size_t glx_rows128_moments_workspace_bytes(void);
 int glx_rows128_moments(const float* x, long long rows, double* G, float* h, void* workspace, size_t workspace_bytes, void* stream);
 int glx_rows128_affine_f16x2(const float* x, long long rows, const void* Wh, const int32_t* ew, const float* init, float* y,
                              void* stream);
+/* The training-mode BatchNorm around the max of the 128 -> 512 layer (cvae_uncertainty/point_net.py:22-28: bn3 + torch.max), as launches
+ * instead of ~40 tensor statements per direction (dense_path.PointMaxBN):
+ * glx_pointmax_bn_forward: batch statistics of y = h2 W3^T from the moments G = h2^T h2 (fp64), h = sum h2 (glx_rows128_moments) in
+ *   fp64, running statistics (the conv bias folded into the running mean), ext = sign(gamma) vext in place, out = (ext - mean) scale +
+ *   beta; mean / invstd / scale (512 each) are what the backward takes.
+ * glx_pointmax_bn_backward_sums: dgamma, dbeta, the vectors bvec / cvec of dy = a g^ - bvec - cvec (y - mean), M = W3^T diag(cvec) W3
+ *   and nv = -(bvec - cvec mean) W3 (the dense part of the input gradient is nv - h2 M: glx_rows128_affine_f16x2).
+ * glx_pointmax_scatter_add_scaled: glx_pointmax_scatter_add with coef[b, c] chan_scale[c].
+ * glx_pointmax_bn_backward_weight: dW3 = scale T - bvec (x) h - diag(cvec) (W3 G - mean (x) h), T from glx_pointmax_wsum on the
+ *   unscaled gradient. */
+int glx_pointmax_bn_forward(const float* W3, const double* G, const float* h, long long R, float* vext, int B, const float* gamma,
+                            const float* beta, const float* bias, float eps, float momentum, float* running_mean, float* running_var,
+                            float* mean, float* invstd, float* scale, float* out, void* stream);
+int glx_pointmax_bn_backward_sums(const float* g, const float* ext, int B, long long R, const float* W3, const float* mean,
+                                  const float* invstd, const float* scale, float* dgamma, float* dbeta, float* bvec, float* cvec,
+                                  float* M, float* nv, void* stream);
+int glx_pointmax_bn_backward_weight(const float* W3, const double* G, const float* h, const float* T, const float* scale,
+                                    const float* bvec, const float* cvec, const float* mean, float* dW, void* stream);
+int glx_pointmax_scatter_add_scaled(const int32_t* arg, const float* coef, const float* chan_scale, const float* W3, int B, int P,
+                                    float* dh2, void* stream);
 size_t glx_pointmax_wsum_workspace_bytes(void);
 int glx_pointmax_wsum(const float* g, const int32_t* arg, const float* h2, int B, int P, float* T, void* workspace,
                       size_t workspace_bytes, void* stream);

@@ -95,7 +95,8 @@ def test_cvae_config4_full_size_30_samples(dev):
     assert float(got.std(0)[:, :6].mean()) > 0                                    # the 30 samples differ
 
 
-@pytest.mark.parametrize("path", ["default", "library_products", "bias_in_the_product", "fp32_wide_layer", "library_moments"])
+@pytest.mark.parametrize("path", ["default", "library_products", "bias_in_the_product", "fp32_wide_layer", "library_moments",
+                                  "batchnorm_as_tensor_statements"])
 def test_cvae_training_step_matches_reference_golden_on_device(dev, path, monkeypatch):
     """The training branch on the device (row kernels + fused training BatchNorm) against the reference-generated
     golden of tests/test_dense_path_cpu.py: loss terms, decoder output, every gradient, running statistics -- on the default
@@ -109,6 +110,8 @@ def test_cvae_training_step_matches_reference_golden_on_device(dev, path, monkey
         monkeypatch.setattr(dp.PointMaxBN, "F16X2", False)
     elif path == "library_moments":
         monkeypatch.setattr(dp.PointMaxBN, "OWN_MOMENTS", False)
+    elif path == "batchnorm_as_tensor_statements":
+        monkeypatch.setattr(dp.PointMaxBN, "FUSED_BN", False)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cvae_train_ref.npz"))
     m = dp.CVAE(4, 8)
     m.load_state_dict({k[len("cvae/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("cvae/")}, strict=True)
@@ -132,7 +135,7 @@ def test_cvae_training_step_matches_reference_golden_on_device(dev, path, monkey
             np.testing.assert_allclose(v.cpu().numpy(), g["after/" + k], rtol=1e-4, atol=1e-6, err_msg=k)
 
 
-@pytest.mark.parametrize("f16x2", [True, False])
+@pytest.mark.parametrize("f16x2", [True, False, "statements"])
 @pytest.mark.parametrize("B,P,neg", [(6, 100, False), (16, 512, True), (3, 130, True)])
 def test_point_max_batchnorm_without_the_wide_tensor_equals_the_modules(dev, B, P, neg, f16x2, monkeypatch):
     """dense_path.PointMaxBN (csrc/glx_pointnet.hip: max / min / arg / moments in one pass over h2, backward through
@@ -140,7 +143,8 @@ def test_point_max_batchnorm_without_the_wide_tensor_equals_the_modules(dev, B, 
     on the (B, 512, P) tensor (point_net.py:22-28): output, running statistics, gradients of input and parameters; negative
     BatchNorm weights take the min branch; P not a multiple of the 128-point pass.  Both arithmetics of the 128 -> 512 product
     (f16 x 2 with the statistics from the moments of h2; fp32 MFMA with the sums from the pass)."""
-    monkeypatch.setattr(dp.PointMaxBN, "F16X2", f16x2)
+    monkeypatch.setattr(dp.PointMaxBN, "F16X2", bool(f16x2))
+    monkeypatch.setattr(dp.PointMaxBN, "FUSED_BN", f16x2 is True)       # "statements": the f16 x 2 pass with the BatchNorm as tensor statements
     torch.manual_seed(B * P)
     conv, bn = torch.nn.Conv1d(128, 512, 1).to(dev), torch.nn.BatchNorm1d(512).to(dev).train()
     with torch.no_grad():
