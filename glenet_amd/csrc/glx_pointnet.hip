@@ -675,6 +675,110 @@ extern "C" int glx_cvae_sample_tail(const float* f512, const float* f8, const fl
   return GLX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ the training losses, two launches
+// Generator.get_training_loss's two data terms (cvae_uncertainty/model.py:296-345 reg_loss; :205-212 + torch.distributions' KL of two
+// diagonal Gaussians with scale = exp(logvar) + 3e-22, model.py:49,77) with their gradients, instead of ~160 elementwise launches of
+// ~4.5 us in the recorded step:
+//   loss_loc = sum_b sum_k smoothL1_beta(cw_k (p'_bk - t'_bk)) / B * loc_weight   (k < 7; heading as sin(p) cos(t) vs cos(p) sin(t);
+//              a NaN target contributes nothing),
+//   loss_dir = 2 sum_b CE(logits_b, bin(t_b6)) * dir_weight    (the factor 2: see dense_path.cvae_reg_loss),
+//   latent   = mean_b sum_j KL(N(mu1, s1) || N(mu2, s2))_bj * latent_weight.
+// One block of 1024 threads walks the objects in a fixed order (B is a few thousand): bitwise reproducible sums.
+struct CvaeLossArgs {
+  const float* pred;      // (B, 7 + bins)
+  const float* labels;    // (B, 7)
+  const float* cw;        // 7 code weights
+  const float* mu1; const float* lv1; const float* mu2; const float* lv2;     // (B, L): posterior, prior
+  float* d_pred; float* d_mu1; float* d_lv1; float* d_mu2; float* d_lv2;      // gradients of the WEIGHTED terms
+  float* out;             // loss_loc, loss_dir, latent
+  int B, bins, L;
+  float beta, loc_weight, dir_weight, latent_weight, dir_offset;
+};
+
+__global__ __launch_bounds__(1024) void k_cvae_losses(CvaeLossArgs a) {
+  __shared__ double s_r[3][1024];
+  const int tid = threadIdx.x, K = 7 + a.bins;
+  double loc = 0, dir = 0, lat = 0;
+  const float period = 6.283185307179586f / (float)a.bins;
+  for (int b = tid; b < a.B; b += 1024) {
+    const float* p = a.pred + (long long)b * K;
+    const float* t = a.labels + (long long)b * 7;
+    float* dp = a.d_pred + (long long)b * K;
+    // ---- location: smooth L1 on the code-weighted differences
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      float pv = p[k], tv = t[k], dd = 1.f;
+      if (k == 6) {
+        const float sp = sinf(p[6]), cp = cosf(p[6]), st = sinf(t[6]), ct = cosf(t[6]);
+        pv = sp * ct;
+        tv = cp * st;
+        dd = cp * ct + sp * st;                           // d (p' - t') / d p6
+      }
+      const bool nan_t = tv != tv;
+      const float x = nan_t ? 0.f : (pv - tv) * a.cw[k];
+      const float n = fabsf(x);
+      loc += (double)(n < a.beta ? 0.5f * n * n / a.beta : n - 0.5f * a.beta);
+      const float dx = n < a.beta ? x / a.beta : (x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f));
+      dp[k] = nan_t ? 0.f : dx * a.cw[k] * dd * (a.loc_weight / (float)a.B);
+    }
+    // ---- direction: cross-entropy against the bin of the label heading
+    {
+      const float v = t[6] - a.dir_offset;
+      const float rot = v - floorf(v * (1.f / 6.283185307179586f)) * 6.283185307179586f;     // limit_period(v, 0, 2 pi)
+      int bin = (int)floorf(rot * (1.f / period));
+      bin = bin < 0 ? 0 : (bin > a.bins - 1 ? a.bins - 1 : bin);
+      float mx = p[7];
+      for (int k = 1; k < a.bins; ++k) mx = fmaxf(mx, p[7 + k]);
+      float se = 0.f;
+      for (int k = 0; k < a.bins; ++k) se += expf(p[7 + k] - mx);
+      const float lse = mx + logf(se);
+      dir += (double)(lse - p[7 + bin]);
+      for (int k = 0; k < a.bins; ++k) dp[7 + k] = (expf(p[7 + k] - lse) - (k == bin ? 1.f : 0.f)) * (2.f * a.dir_weight);
+    }
+    // ---- KL(posterior || prior), scale = exp(logvar) + 3e-22
+    for (int jj = 0; jj < a.L; ++jj) {
+      const long long e = (long long)b * a.L + jj;
+      const float e1 = expf(a.lv1[e]), e2 = expf(a.lv2[e]);
+      const float s1 = e1 + 3e-22f, s2 = e2 + 3e-22f, dm = a.mu1[e] - a.mu2[e];
+      const float vr = (s1 / s2) * (s1 / s2), t1 = (dm / s2) * (dm / s2);
+      lat += (double)(0.5f * (vr + t1 - 1.f - logf(vr)));
+      const float wgt = a.latent_weight / (float)a.B;
+      a.d_mu1[e] = dm / (s2 * s2) * wgt;
+      a.d_mu2[e] = -dm / (s2 * s2) * wgt;
+      a.d_lv1[e] = (s1 / (s2 * s2) - 1.f / s1) * e1 * wgt;
+      a.d_lv2[e] = (-(s1 * s1 + dm * dm) / (s2 * s2 * s2) + 1.f / s2) * e2 * wgt;
+    }
+  }
+  s_r[0][tid] = loc; s_r[1][tid] = dir; s_r[2][tid] = lat;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) { s_r[0][tid] += s_r[0][tid + o]; s_r[1][tid] += s_r[1][tid + o]; s_r[2][tid] += s_r[2][tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    a.out[0] = (float)(s_r[0][0] / (double)a.B * (double)a.loc_weight);
+    a.out[1] = (float)(2.0 * s_r[1][0] * (double)a.dir_weight);
+    a.out[2] = (float)(s_r[2][0] / (double)a.B * (double)a.latent_weight);
+  }
+}
+
+// pred (B, 7 + bins), labels (B, 7), code_weights (7); mu / logvar of the posterior (1) and the prior (2), (B, L) each.
+// out (3): loss_loc, loss_dir, latent (each with its weight applied); d_*: the gradients of those weighted terms (d_pred holds both
+// location and direction terms' columns).  1 <= bins <= 9.
+extern "C" int glx_cvae_losses(const float* pred, const float* labels, const float* code_weights, int B, int bins, float beta,
+                               float loc_weight, float dir_weight, float dir_offset, const float* mu1, const float* logvar1,
+                               const float* mu2, const float* logvar2, int L, float latent_weight, float* out, float* d_pred,
+                               float* d_mu1, float* d_logvar1, float* d_mu2, float* d_logvar2, void* stream) {
+  GLX_REQUIRE(pred && labels && code_weights && mu1 && logvar1 && mu2 && logvar2 && out && d_pred && d_mu1 && d_logvar1 && d_mu2 && d_logvar2,
+              "glx_cvae_losses: null pointer");
+  GLX_REQUIRE(B > 0 && bins >= 1 && bins <= 9 && L >= 1, "glx_cvae_losses: B > 0, 1 <= bins <= 9, L >= 1");
+  CvaeLossArgs a{pred, labels, code_weights, mu1, logvar1, mu2, logvar2, d_pred, d_mu1, d_logvar1, d_mu2, d_logvar2, out, B, bins, L,
+                 beta, loc_weight, dir_weight, latent_weight, dir_offset};
+  hipLaunchKernelGGL(k_cvae_losses, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
 // Small variant (all widths <= 16, e.g. the decoder's 4 -> 8 -> 8 -> 8 SimPointNetfeat,
 // point_net.py:31-49): pure VALU, one block per object, a thread per point, the (folded) weights
 // in LDS, max over points by wave butterflies + LDS.  Memory-bound on reading the points once.

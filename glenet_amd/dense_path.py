@@ -1959,6 +1959,8 @@ class CVAE(nn.Module):
         kl = torch.distributions.kl.kl_divergence(post, prior)
         return post, prior, kl, (mu_xy, logvar_xy, mu_x, logvar_x)
 
+    FUSED_LOSSES = True          # training_losses: the regression / direction / KL terms with their gradients in one launch
+
     # ---- training step (cvae_uncertainty/model.py:205-240, 267-370; train_utils/train_utils.py:50-72)
     LOSS_WEIGHTS = dict(latent_weight=10.0, loc_weight=10.0, dir_weight=0.002, code_weights=(1.0,) * 7)   # cfgs/exp20.yaml
 
@@ -1971,16 +1973,52 @@ class CVAE(nn.Module):
         latent term by its annealing factor, train_utils.py:57-59); parts = device scalars named like the tb_dict."""
         w = dict(self.LOSS_WEIGHTS, **(loss_weights or {}))
         post, mu_xy, logvar_xy = self.xy_encoder(points, gt_boxes_input)
-        prior, _, _ = self.x_encoder(points)
-        latent = torch.distributions.kl.kl_divergence(post, prior).mean() * w["latent_weight"]
+        prior, mu_x, logvar_x = self.x_encoder(points)
         if eps_post is None:
             eps_post = torch.randn_like(mu_xy)
         pred = self.obj_encoder(points, self.reparametrize(mu_xy, logvar_xy, eps_post))
-        reg, parts = cvae_reg_loss(pred, gt_boxes, w, self.dir_offset, self.num_dir_bins)
+        if self.FUSED_LOSSES and pred.is_cuda and pred.dtype == torch.float32 and 1 <= self.num_dir_bins <= 9:
+            # both data terms and their gradients in one launch (csrc/glx_pointnet.hip, k_cvae_losses)
+            loc, dir_loss, latent = CvaeLosses.apply(pred, gt_boxes, mu_xy, logvar_xy, mu_x, logvar_x,
+                                                     _code_weights(tuple(w["code_weights"]), pred.device), float(w["loc_weight"]),
+                                                     float(w["dir_weight"]), float(w["latent_weight"]), float(self.dir_offset),
+                                                     int(self.num_dir_bins))
+            reg = loc + dir_loss
+            parts = {"loss_loc": loc, "loss_dir": dir_loss, "loss_reg": reg}
+        else:
+            latent = torch.distributions.kl.kl_divergence(post, prior).mean() * w["latent_weight"]
+            reg, parts = cvae_reg_loss(pred, gt_boxes, w, self.dir_offset, self.num_dir_bins)
         regular = 1e-4 * (l2_regularisation(self.xy_encoder) + l2_regularisation(self.x_encoder)
                           + l2_regularisation(self.obj_encoder))
         parts = dict(parts, box_pred_post=pred)
         return (reg, latent, regular), parts
+
+
+class CvaeLosses(torch.autograd.Function):
+    """(loss_loc, loss_dir, latent) of cvae_reg_loss + the KL term (weights applied) with the gradients of all five inputs from ONE
+    launch (glx_cvae_losses); backward scales them by the incoming gradients."""
+
+    @staticmethod
+    def forward(ctx, pred, labels, mu1, lv1, mu2, lv2, cw, loc_weight, dir_weight, latent_weight, dir_offset, bins):
+        pred, labels = pred.contiguous(), labels.contiguous().float()
+        B, L = pred.shape[0], mu1.shape[1]
+        dev = pred.device
+        out = torch.empty(3, dtype=torch.float32, device=dev)
+        d_pred = torch.empty_like(pred)
+        d_lat = torch.empty((4, B, L), dtype=torch.float32, device=dev)          # d mu1, d logvar1, d mu2, d logvar2
+        _lib.call("glx_cvae_losses", pred, labels[:, :7].contiguous(), cw, B, bins, ctypes.c_float(1.0 / 9.0), ctypes.c_float(loc_weight),
+                  ctypes.c_float(dir_weight), ctypes.c_float(dir_offset), mu1.contiguous(), lv1.contiguous(), mu2.contiguous(),
+                  lv2.contiguous(), L, ctypes.c_float(latent_weight), out, d_pred, d_lat[0], d_lat[1], d_lat[2], d_lat[3])
+        ctx.save_for_backward(d_pred, d_lat)
+        ctx.bins = bins
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g_loc, g_dir, g_lat):
+        d_pred, d_lat = ctx.saved_tensors
+        gp = torch.cat([g_loc.reshape(1).expand(7), g_dir.reshape(1).expand(ctx.bins)])
+        dl = d_lat * g_lat
+        return d_pred * gp, None, dl[0], dl[1], dl[2], dl[3], None, None, None, None, None, None
 
 
 def l2_regularisation(module):

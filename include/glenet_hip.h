@@ -1039,6 +1039,14 @@ int glx_pointnet_feat_f16x2(const float* points, int B, int Cin, int P, const fl
 int glx_pointnet_feat_f16x2_pair(const float* points, int B, int Cin, int P, const float* W1, const float* b1, const void* W2h,
                                  const int32_t* ew2, const float* b2, const void* W3h, const int32_t* ew3, const float* b3,
                                  float* out, const float* narrow, float* narrow_out, void* stream);
+/* The two data terms of the CVAE's training loss with their gradients in one launch (cvae_uncertainty/model.py:296-345 reg_loss: code-
+ * weighted smooth-L1 with the sin-difference heading + TWICE the direction cross-entropy, see dense_path.cvae_reg_loss; model.py:205-212:
+ * KL(posterior || prior) of diagonal Gaussians with scale = exp(logvar) + 3e-22, mean over the batch).  out (3) = loss_loc, loss_dir,
+ * latent, weights applied; d_* = the gradients of those weighted terms. */
+int glx_cvae_losses(const float* pred, const float* labels, const float* code_weights, int B, int bins, float beta, float loc_weight,
+                    float dir_weight, float dir_offset, const float* mu1, const float* logvar1, const float* mu2, const float* logvar2,
+                    int L, float latent_weight, float* out, float* d_pred, float* d_mu1, float* d_logvar1, float* d_mu2,
+                    float* d_logvar2, void* stream);
 /* The eval branch of Generator.forward behind the extractors (cvae_uncertainty/model.py:245-265) in one launch: prior (mu, logvar)
  * from f512 (B, 512), z = eps exp(logvar / 2) + mu, the decoder on cat(f8 (B, 8), z), heading decoded from its bin.
  * w: WL (16 x 512: fc1 | fc2 rows) | bL (16) | W1T (16 x 64, [input][output], BatchNorm folded) | b1 (64) | W2T (64 x 64) | b2 (64) |

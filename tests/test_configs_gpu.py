@@ -96,7 +96,7 @@ def test_cvae_config4_full_size_30_samples(dev):
 
 
 @pytest.mark.parametrize("path", ["default", "library_products", "bias_in_the_product", "fp32_wide_layer", "library_moments",
-                                  "batchnorm_as_tensor_statements"])
+                                  "batchnorm_as_tensor_statements", "losses_as_tensor_statements"])
 def test_cvae_training_step_matches_reference_golden_on_device(dev, path, monkeypatch):
     """The training branch on the device (row kernels + fused training BatchNorm) against the reference-generated
     golden of tests/test_dense_path_cpu.py: loss terms, decoder output, every gradient, running statistics -- on the default
@@ -112,6 +112,8 @@ def test_cvae_training_step_matches_reference_golden_on_device(dev, path, monkey
         monkeypatch.setattr(dp.PointMaxBN, "OWN_MOMENTS", False)
     elif path == "batchnorm_as_tensor_statements":
         monkeypatch.setattr(dp.PointMaxBN, "FUSED_BN", False)
+    elif path == "losses_as_tensor_statements":
+        monkeypatch.setattr(dp.CVAE, "FUSED_LOSSES", False)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cvae_train_ref.npz"))
     m = dp.CVAE(4, 8)
     m.load_state_dict({k[len("cvae/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("cvae/")}, strict=True)
@@ -169,6 +171,38 @@ def test_point_max_batchnorm_without_the_wide_tensor_equals_the_modules(dev, B, 
                           (ref[0], ref[1][:, :, 0], ref[2], ref[3], ref[4])):
         scale = float(b.abs().max()) if name != "conv.bias" else float(ref[1].abs().max())   # the bias gradient is 0 + noise
         assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-6, (name, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("bins", [2, 3])
+def test_cvae_fused_losses_equal_the_tensor_statements(dev, bins):
+    """glx_cvae_losses (regression + direction + KL terms and their gradients, one launch) against cvae_reg_loss + torch.distributions'
+    KL with autograd: values to 1e-5, every gradient to 1e-5 of its scale; NaN targets, headings on both sides of the bins, large and
+    small residuals (both smooth-L1 branches), non-unit incoming gradients."""
+    g = torch.Generator(device=dev).manual_seed(bins)
+    B, L = 1000, 8
+    pred = (torch.randn(B, 7 + bins, device=dev, generator=g) * 0.5).requires_grad_(True)
+    labels = torch.randn(B, 7, device=dev, generator=g) * 0.5
+    labels[:, 6] = (torch.rand(B, device=dev, generator=g) - 0.5) * 12.0
+    labels[::17, 2] = float("nan")
+    pred.data[::5, :3] += labels[::5, :3].nan_to_num() + 0.01                 # small residuals: the quadratic branch
+    mu1, lv1, mu2, lv2 = ((torch.randn(B, L, device=dev, generator=g) * 0.7).requires_grad_(True) for _ in range(4))
+    w = dict(dp.CVAE.LOSS_WEIGHTS, code_weights=(1.0, 0.8, 1.2, 1.0, 0.5, 1.0, 2.0))
+    cw = dp._code_weights(tuple(w["code_weights"]), dev)
+    loc, dr, lat = dp.CvaeLosses.apply(pred, labels, mu1, lv1, mu2, lv2, cw, float(w["loc_weight"]), float(w["dir_weight"]),
+                                       float(w["latent_weight"]), 0.78539, bins)
+    (1.5 * loc + 0.5 * dr + 0.3 * lat).backward()
+    got = [t.grad.clone() for t in (pred, mu1, lv1, mu2, lv2)]
+    for t in (pred, mu1, lv1, mu2, lv2):
+        t.grad = None
+    mk = lambda m, lv: torch.distributions.Independent(torch.distributions.Normal(m, torch.exp(lv) + 3e-22), 1)       # noqa: E731
+    lat_ref = torch.distributions.kl.kl_divergence(mk(mu1, lv1), mk(mu2, lv2)).mean() * w["latent_weight"]
+    reg_ref, parts = dp.cvae_reg_loss(pred, labels, w, 0.78539, bins)
+    (1.5 * parts["loss_loc"] + 0.5 * parts["loss_dir"] + 0.3 * lat_ref).backward()
+    want = [t.grad for t in (pred, mu1, lv1, mu2, lv2)]
+    for a, b in ((loc, parts["loss_loc"]), (dr, parts["loss_dir"]), (lat, lat_ref)):
+        assert abs(float(a) - float(b)) <= 1e-5 * max(1.0, abs(float(b))), (float(a), float(b))
+    for a, b in zip(got, want):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9
 
 
 def test_cvae_train_step_graph_follows_an_eager_loop(dev):
