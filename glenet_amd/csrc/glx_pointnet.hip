@@ -1043,11 +1043,14 @@ extern "C" int glx_pointmax_forward(const float* h2, int B, int P, const float* 
 // and  diag(W3 (h2^T h2) W3^T), two quantities the backward needs anyway.  Ties go to the lower point index.
 __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pointmax_fwd_f16(
     const float* __restrict__ h2, int P, const uint4* __restrict__ W3h, const int* __restrict__ ew3, float* __restrict__ vext,
-    int* __restrict__ aext) {
+    int* __restrict__ aext, const float* __restrict__ pre) {
+  // pre != NULL: h2 is the RAW output z of the layer in front and the rows are relu(z scale + shift) (pre = scale | shift, 128 each:
+  // its BatchNorm's transform, applied on load -- the transformed matrix is never written)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   uint4* s_w3 = reinterpret_cast<uint4*>(smem);                        // PNH_RING slabs                       (24 KB)
   int* s_e3 = reinterpret_cast<int*>(s_w3 + PNH_RING * PNH_SLAB_U4);   // 512: MINUS the rows' exponents
   float* s_st = reinterpret_cast<float*>(s_e3 + PN_C3);                // 2 quantities x 4 waves x 512        (16 KB)
+  float* s_pre = s_st + 2 * 4 * PN_C3;                                 // 2 x 128
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, q = lane >> 4;
   const long long obj = blockIdx.x;
@@ -1063,6 +1066,7 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   PM_STAGE(0, 0);
   PM_STAGE(1, 1);
   for (int e = tid; e < PN_C3; e += PN_THREADS) s_e3[e] = -ew3[e];
+  if (pre && tid < 2 * PN_C2) s_pre[tid] = pre[tid];
   pn_wait_vm<0>();
   __syncthreads();
 
@@ -1087,6 +1091,15 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       pf32x4 v[8];
 #pragma unroll
       for (int t2 = 0; t2 < 8; ++t2) v[t2] = *reinterpret_cast<const pf32x4*>(row + 16 * t2);
+      if (pre) {
+#pragma unroll
+        for (int t2 = 0; t2 < 8; ++t2) {
+          const pf32x4 sc = *reinterpret_cast<const pf32x4*>(s_pre + 16 * t2 + 4 * q);
+          const pf32x4 sh = *reinterpret_cast<const pf32x4*>(s_pre + PN_C2 + 16 * t2 + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[t2][e] = fmaxf(__fmaf_rn(v[t2][e], sc[e], sh[e]), 0.f);
+        }
+      }
       float m = 0.f;
 #pragma unroll
       for (int t2 = 0; t2 < 8; ++t2)
@@ -1186,18 +1199,18 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 // vext[b, c] = max_p y[b, p, c], aext = the (lowest) point it occurs at, for y = h2 W^T with W the (512, 128) weight whose f16 x 2
 // image W3h / ew3 is (as glx_pointnet_feat_f16x2 takes it).  A caller that needs the MINIMUM of a channel hands in that row negated.
 extern "C" int glx_pointmax_forward_f16x2(const float* h2, int B, int P, const void* W3h, const int32_t* ew3, float* vext,
-                                          int32_t* aext, void* stream) {
+                                          int32_t* aext, const float* pre_coef, void* stream) {
   if (B <= 0) return GLX_OK;
   GLX_REQUIRE(h2 && W3h && ew3 && vext && aext, "glx_pointmax_forward_f16x2: null pointer");
   GLX_REQUIRE(P >= 1, "glx_pointmax_forward_f16x2: P >= 1");
-  const size_t lds = (size_t)PNH_RING * PNH_SLAB_U4 * 16 + (size_t)(PN_C3 + 2 * 4 * PN_C3) * 4;
+  const size_t lds = (size_t)PNH_RING * PNH_SLAB_U4 * 16 + (size_t)(PN_C3 + 2 * 4 * PN_C3 + 2 * PN_C2) * 4;
   static bool attr_set = false;
   if (!attr_set) {
     GLX_HIP(hipFuncSetAttribute((const void*)k_pointmax_fwd_f16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   hipLaunchKernelGGL(k_pointmax_fwd_f16, dim3(B), dim3(PN_THREADS), lds, (hipStream_t)stream, h2, P, (const uint4*)W3h, ew3, vext,
-                     (int*)aext);
+                     (int*)aext, pre_coef);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
@@ -1211,11 +1224,13 @@ extern "C" int glx_pointmax_forward_f16x2(const float* h2, int B, int P, const v
 #define RM_BLOCKS 512
 __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_rows128_affine_f16(
     const float* __restrict__ x, long long rows, const uint4* __restrict__ Wh, const int* __restrict__ ew,
-    const float* __restrict__ init, float* __restrict__ y) {
+    const float* __restrict__ init, float* __restrict__ y, const float* __restrict__ pre) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   uint4* s_w = reinterpret_cast<uint4*>(smem);                         // 8 tiles x 4 k-steps x 2 planes x 64 lanes (64 KB)
   int* s_e = reinterpret_cast<int*>(s_w + 8 * 4 * 2 * 64);             // 128: MINUS the rows' exponents
   float* s_i = reinterpret_cast<float*>(s_e + PN_C2);                  // 128: init
+  float* s_pre = s_i + PN_C2;                                          // pre != NULL: x is relu(x scale + shift) on load (2 x 128)
+  if (pre && threadIdx.x < 2 * PN_C2) s_pre[threadIdx.x] = pre[threadIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, q = lane >> 4;
   for (int e = tid; e < 8 * 4 * 2 * 64; e += PN_THREADS) s_w[e] = Wh[e];
@@ -1239,7 +1254,15 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
-      for (int t = 0; t < 8; ++t) v[pt][t] = nv[pt][t];
+      for (int t = 0; t < 8; ++t) {
+        v[pt][t] = nv[pt][t];
+        if (pre) {
+          const pf32x4 sc = *reinterpret_cast<const pf32x4*>(s_pre + 16 * t + 4 * q);
+          const pf32x4 sh = *reinterpret_cast<const pf32x4*>(s_pre + PN_C2 + 16 * t + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[pt][t][e] = fmaxf(__fmaf_rn(v[pt][t][e], sc[e], sh[e]), 0.f);
+        }
+      }
     if (trip + stride < ntrips) { RM_LOAD(trip + stride) }
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
@@ -1294,10 +1317,10 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 // Wh / ew: the (128 out, 128 in) weight as two fp16 planes of w 2^ew[row] in operand order (dense_path.PointFeat._f16x2_image);
 // init: 128 floats or NULL.  x, y: (rows, 128) fp32, y may not alias x.
 extern "C" int glx_rows128_affine_f16x2(const float* x, long long rows, const void* Wh, const int32_t* ew, const float* init,
-                                        float* y, void* stream) {
+                                        float* y, const float* pre_coef, void* stream) {
   if (rows <= 0) return GLX_OK;
   GLX_REQUIRE(x && Wh && ew && y, "glx_rows128_affine_f16x2: null pointer");
-  const size_t lds = (size_t)8 * 4 * 2 * 64 * 16 + (size_t)2 * PN_C2 * 4;
+  const size_t lds = (size_t)8 * 4 * 2 * 64 * 16 + (size_t)4 * PN_C2 * 4;
   static bool attr_set = false;
   if (!attr_set) {
     GLX_HIP(hipFuncSetAttribute((const void*)k_rows128_affine_f16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1306,7 +1329,7 @@ extern "C" int glx_rows128_affine_f16x2(const float* x, long long rows, const vo
   const long long want = (((rows + 31) >> 5) + 3) >> 2;
   const int blocks = (int)(want < RM_BLOCKS ? want : RM_BLOCKS);
   hipLaunchKernelGGL(k_rows128_affine_f16, dim3(blocks), dim3(PN_THREADS), lds, (hipStream_t)stream, x, rows, (const uint4*)Wh, ew,
-                     init, y);
+                     init, y, pre_coef);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
@@ -1806,7 +1829,7 @@ extern "C" int glx_rows_linear_bn_backward_64_128_f16x2(const float* x, const fl
 #define MO_BLOCKS 768
 #define MO_PITCH 132                       // floats per staged row (16-byte aligned rows; the column reads are two-way conflicted)
 __global__ __launch_bounds__(256) void k_rows128_moments(const float* __restrict__ x, long long rows, float* __restrict__ part,
-                                                         float* __restrict__ hpart) {
+                                                         float* __restrict__ hpart, const float* __restrict__ pre) {
   __shared__ __attribute__((aligned(16))) float s_x[32 * MO_PITCH];
   __shared__ __attribute__((aligned(16))) uint4 s_f[8 * 3 * 64];          // [tile][piece][lane]: 8 bf16 each
   __shared__ float s_h[8][128];
@@ -1821,6 +1844,9 @@ __global__ __launch_bounds__(256) void k_rows128_moments(const float* __restrict
     for (int t = 0; t < 8; ++t) acc[a][t] = pf32x4{0.f, 0.f, 0.f, 0.f};
   pf32x4 hs = pf32x4{0.f, 0.f, 0.f, 0.f};
   const int c4 = tid & 31, r0 = tid >> 5;          // this thread's float4 column and its first row of a step (+ 8 u)
+  // pre != NULL: the moments of relu(x scale + shift) (the transform of the BatchNorm in front, applied on load)
+  const pf32x4 psc = pre ? *reinterpret_cast<const pf32x4*>(pre + 4 * c4) : pf32x4{1.f, 1.f, 1.f, 1.f};
+  const pf32x4 psh = pre ? *reinterpret_cast<const pf32x4*>(pre + PN_C2 + 4 * c4) : pf32x4{0.f, 0.f, 0.f, 0.f};
   pf32x4 nv[4];
 #define MO_LOAD(S)                                                                                           \
   _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                            \
@@ -1832,7 +1858,14 @@ __global__ __launch_bounds__(256) void k_rows128_moments(const float* __restrict
   for (long long st = s0; st < s1; ++st) {
     pf32x4 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = nv[u];
+    for (int u = 0; u < 4; ++u) {
+      v[u] = nv[u];
+      if (pre) {
+        const bool in_ = st * 32 + r0 + 8 * u < rows;     // (a row past the end stays zero)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[u][e] = in_ ? fmaxf(__fmaf_rn(v[u][e], psc[e], psh[e]), 0.f) : 0.f;
+      }
+    }
     if (st + 1 < s1) { MO_LOAD(st + 1) }
     __syncthreads();                                     // the previous step's fragments have been read
 #pragma unroll
@@ -1940,8 +1973,8 @@ extern "C" size_t glx_rows128_moments_workspace_bytes(void) {
 
 // G (128 x 128, fp64) = x^T x, h (128, fp32) = the column sums of x (rows, 128); bf16 x 3 products (exact to 2^-22), fp32 sums over a
 // block's rows, fp64 over the blocks in a fixed order (bitwise reproducible).  workspace: glx_rows128_moments_workspace_bytes().
-extern "C" int glx_rows128_moments(const float* x, long long rows, double* G, float* h, void* workspace, size_t workspace_bytes,
-                                   void* stream) {
+extern "C" int glx_rows128_moments(const float* x, long long rows, double* G, float* h, const float* pre_coef, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
   GLX_REQUIRE(x && G && h && workspace && rows >= 0, "glx_rows128_moments: null pointer");
   GLX_REQUIRE(workspace_bytes >= glx_rows128_moments_workspace_bytes(), "glx_rows128_moments: workspace too small");
   const long long nsteps = (rows + 31) >> 5;
@@ -1949,7 +1982,7 @@ extern "C" int glx_rows128_moments(const float* x, long long rows, double* G, fl
   if (blocks < 1) blocks = 1;
   float* part = (float*)workspace;
   float* hpart = part + (size_t)MO_BLOCKS * PN_C2 * PN_C2;
-  hipLaunchKernelGGL(k_rows128_moments, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, rows, part, hpart);
+  hipLaunchKernelGGL(k_rows128_moments, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, rows, part, hpart, pre_coef);
   hipLaunchKernelGGL(k_rows128_moments_reduce, dim3((PN_C2 * PN_C2 + PN_C2) / 16), dim3(256), 0, (hipStream_t)stream, (const float*)part,
                      (const float*)hpart, blocks, G, h);
   GLX_LAUNCH_CHECK();
@@ -2191,8 +2224,11 @@ extern "C" int glx_pointmax_scatter_add_scaled(const int32_t* arg, const float* 
 #define PMW_SLICES 8
 __global__ __launch_bounds__(PN_THREADS) void k_pointmax_wsum(const float* __restrict__ g, const int* __restrict__ arg,
                                                               const float* __restrict__ h2, int B, int P,
-                                                              float* __restrict__ part) {
+                                                              float* __restrict__ part, const float* __restrict__ pre) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // pre != NULL: the rows are relu(h2 scale + shift) on load
+  const float sc0 = pre ? pre[lane] : 1.f, sc1 = pre ? pre[64 + lane] : 1.f;
+  const float sh0 = pre ? pre[PN_C2 + lane] : 0.f, sh1 = pre ? pre[PN_C2 + 64 + lane] : 0.f;
   const int c = blockIdx.x * (PN_THREADS / 64) + wave, sl = blockIdx.y;
   const int per = (B + PMW_SLICES - 1) / PMW_SLICES, b0 = sl * per, b1 = min(B, b0 + per);
   float a0 = 0.f, a1 = 0.f;
@@ -2206,6 +2242,10 @@ __global__ __launch_bounds__(PN_THREADS) void k_pointmax_wsum(const float* __res
       const float* row = h2 + ((long long)bb * P + arg[o]) * PN_C2;
       x0[u] = row[lane];
       x1[u] = row[64 + lane];
+      if (pre) {
+        x0[u] = fmaxf(__fmaf_rn(x0[u], sc0, sh0), 0.f);
+        x1[u] = fmaxf(__fmaf_rn(x1[u], sc1, sh1), 0.f);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -2229,12 +2269,20 @@ __global__ void k_pointmax_wsum_reduce(const float* __restrict__ part, float* __
 
 extern "C" size_t glx_pointmax_wsum_workspace_bytes(void) { return (size_t)PMW_SLICES * PN_C3 * PN_C2 * sizeof(float); }
 
+extern "C" int glx_pointmax_wsum_pre(const float* g, const int32_t* arg, const float* h2, const float* pre_coef, int B, int P, float* T,
+                                     void* workspace, size_t workspace_bytes, void* stream);
 extern "C" int glx_pointmax_wsum(const float* g, const int32_t* arg, const float* h2, int B, int P, float* T,
                                  void* workspace, size_t workspace_bytes, void* stream) {
+  return glx_pointmax_wsum_pre(g, arg, h2, nullptr, B, P, T, workspace, workspace_bytes, stream);
+}
+
+// ... of the rows relu(h2 scale + shift) (pre_coef = scale | shift, 128 each; NULL: of h2 itself)
+extern "C" int glx_pointmax_wsum_pre(const float* g, const int32_t* arg, const float* h2, const float* pre_coef, int B, int P, float* T,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
   GLX_REQUIRE(g && arg && h2 && T && workspace && B >= 1 && P >= 1, "glx_pointmax_wsum: null pointer / empty batch");
   GLX_REQUIRE(workspace_bytes >= glx_pointmax_wsum_workspace_bytes(), "glx_pointmax_wsum: workspace too small");
   hipLaunchKernelGGL(k_pointmax_wsum, dim3(PN_C3 / (PN_THREADS / 64), PMW_SLICES), dim3(PN_THREADS), 0, (hipStream_t)stream, g,
-                     (const int*)arg, h2, B, P, (float*)workspace);
+                     (const int*)arg, h2, B, P, (float*)workspace, pre_coef);
   hipLaunchKernelGGL(k_pointmax_wsum_reduce, dim3(PN_C3 * PN_C2 / 256), dim3(256), 0, (hipStream_t)stream,
                      (const float*)workspace, T);
   GLX_LAUNCH_CHECK();

@@ -1454,6 +1454,7 @@ class PointFeat(nn.Module):
                                                     for m in (self.bn1, self.bn2, self.bn3)))
 
     USE_POINTMAX = True
+    LAZY_H2 = True              # see _forward_train_rows
     ROW_CHUNKS = 128
     ROWS_MAX = 1 << 22
 
@@ -1484,15 +1485,19 @@ class PointFeat(nn.Module):
     OWN_ROW_LAYERS = True
 
     @classmethod
-    def _rows_layer(cls, x2d, conv, bn, relu):
+    def _rows_layer(cls, x2d, conv, bn, relu, lazy=False):
         """relu?(bn(conv(x2d))) on rows; x2d may carry zero columns behind the conv's input channels and the result may carry
         zero columns behind its output channels (the narrow extractor's 8 channels run as 16: the kernels' tiles)."""
         from .spconv import core
+        """lazy: -> (z, coef) with the transform left to the consumer (RowsConvBN's lazy form), or (h, None) where this layer
+        does not run on the row kernels."""
+        pre = None
         fold = cls.BIAS_INTO_RUNNING_MEAN and conv.bias is not None and bn.track_running_stats
         cout, cin = conv.weight.shape[:2]
         xin = x2d.shape[1]
         if not fold and conv.bias is not None:
-            return core.fused_train_bn(bn, cls._rows_linear(x2d[:, :cin] if xin != cin else x2d, conv), relu, None)
+            h = core.fused_train_bn(bn, cls._rows_linear(x2d[:, :cin] if xin != cin else x2d, conv), relu, None)
+            return (h, None) if lazy else h
         kin = xin if xin in (16, 32, 64) else (16 if xin < 16 else 0)
         kout = max(cout, 16)
         if cls.OWN_ROW_LAYERS and kin and core.USE_BN_STATE and bn.track_running_stats \
@@ -1517,7 +1522,9 @@ class PointFeat(nn.Module):
                     bn.running_mean.copy_(proxy.running_mean[:cout])
                     bn.running_var.copy_(proxy.running_var[:cout])
             else:
-                h = vpm.RowsConvBN.apply(x2d, w, bn.weight, bn.bias, bn, relu, None)
+                h = vpm.RowsConvBN.apply(x2d, w, bn.weight, bn.bias, bn, relu, None, lazy)
+                if lazy:
+                    h, pre = h
             if conv.bias is not None:
                 h = _ZeroGradOperand.apply(h, conv.bias)
         else:
@@ -1528,16 +1535,23 @@ class PointFeat(nn.Module):
         if conv.bias is not None:
             with torch.no_grad():
                 bn.running_mean.add_(conv.bias, alpha=bn.momentum)
-        return h
+        return (h, pre) if lazy else h
 
     def _forward_train_rows(self, x):
         b, cin, p = x.shape
         rows = x.transpose(1, 2).reshape(b * p, cin)
         h = self._rows_layer(rows, self.conv1, self.bn1, True)
-        h = self._rows_layer(h, self.conv2, self.bn2, True)
-        if self.USE_POINTMAX and h.shape[1] == 128 and self.conv3.out_channels == 512 and self.bn3.affine:
+        pointmax = self.USE_POINTMAX and self.conv2.out_channels == 128 and self.conv3.out_channels == 512 and self.bn3.affine
+        # the second layer's BatchNorm + ReLU applied by its consumers on load: h2 (1 GB at configs[3]) is never written
+        lazy = pointmax and self.LAZY_H2 and PointMaxBN.F16X2 and PointMaxBN.FUSED_BN and PointMaxBN.OWN_MOMENTS \
+            and self.bn3.momentum is not None
+        h = self._rows_layer(h, self.conv2, self.bn2, True, lazy=lazy)
+        pre = None
+        if lazy:
+            h, pre = h
+        if pointmax and h.shape[1] == 128:
             # the 512-wide layer + BatchNorm + max over the points without the (B, P, 512) tensor
-            return PointMaxBN.apply(h, self.conv3.weight[:, :, 0], self.conv3.bias, self.bn3.weight, self.bn3.bias, self.bn3, b, p)
+            return PointMaxBN.apply(h, self.conv3.weight[:, :, 0], self.conv3.bias, self.bn3.weight, self.bn3.bias, self.bn3, b, p, pre)
         h = self._rows_layer(h, self.conv3, self.bn3, False)
         return h.view(b, p, -1).amax(dim=1)[:, :self.conv3.out_channels]
 
@@ -1661,10 +1675,18 @@ class PointMaxBN(torch.autograd.Function):
     weight (512, 128); returns (B, 512).  Running statistics of `bn` are updated as nn.BatchNorm1d does."""
 
     @staticmethod
-    def forward(ctx, h2, weight, bias, gamma, beta, bn, B, P):
+    def forward(ctx, h2, weight, bias, gamma, beta, bn, B, P, pre=None):
+        """pre (scale | shift, 256 floats) != None: `h2` is the RAW output z of the layer in front and the rows this layer works on
+        are relu(z scale + shift), formed on load by every kernel that reads them (f16 x 2 path with the fused BatchNorm only); the
+        gradient returned for `h2` is the gradient of those rows."""
         from ._lib import call
         dev = h2.device
         h2 = h2.contiguous()
+        ctx.pre = None
+        if pre is not None and not (PointMaxBN.F16X2 and PointMaxBN.FUSED_BN and PointMaxBN.OWN_MOMENTS and bn.momentum is not None):
+            y = torch.empty_like(h2)                       # a path without the on-load form: materialise the rows after all
+            call("glx_bn_apply_forward", h2, pre, 1, h2.shape[0], h2.shape[1], None, y, 0)
+            h2, pre = y, None
         W3 = weight.contiguous()
         vmax, vmin = (torch.empty((B, 512), dtype=torch.float32, device=dev) for _ in range(2))
         amax, amin = (torch.empty((B, 512), dtype=torch.int32, device=dev) for _ in range(2))
@@ -1676,8 +1698,9 @@ class PointMaxBN(torch.autograd.Function):
             # one extreme per channel: the BatchNorm's weight decides which (scale = gamma invstd, invstd > 0), so the rows of W3
             # go in with its sign and the pass returns max_p (sign y)
             w3h, e3 = PointFeat._f16x2_image(W3.detach(), row_scale=gamma.detach(), sign_only=True)
-            call("glx_pointmax_forward_f16x2", h2, B, P, w3h, e3, vmax, amax)
-            G2d, H1 = PointMaxBN._moments(h2, R)
+            call("glx_pointmax_forward_f16x2", h2, B, P, w3h, e3, vmax, amax, pre)
+            G2d, H1 = PointMaxBN._moments(h2, R, pre)
+            ctx.pre = pre
             if PointMaxBN.FUSED_BN and bn.momentum is not None:
                 # statistics, running statistics, the choice of the extreme and the transform: two launches (~40 tensor statements)
                 mean_nb, invstd, scale = (torch.empty(512, dtype=torch.float32, device=dev) for _ in range(3))
@@ -1735,16 +1758,17 @@ class PointMaxBN(torch.autograd.Function):
     OWN_MOMENTS = True
 
     @staticmethod
-    def _moments(h2, R):
-        """(h2^T h2 in fp64 from fp32 partial products over row chunks, sum_r h2)."""
+    def _moments(h2, R, pre=None):
+        """(h2^T h2 in fp64 from fp32 partial products over row chunks, sum_r h2); pre: of relu(h2 scale + shift)."""
         if PointMaxBN.OWN_MOMENTS and h2.is_cuda and h2.dtype == torch.float32 and h2.shape[1] == 128 and h2.is_contiguous():
             from ._lib import call, query, size_arg, workspace
             G = torch.empty((128, 128), dtype=torch.float64, device=h2.device)
             H = torch.empty(128, dtype=torch.float32, device=h2.device)
             n = query("glx_rows128_moments_workspace_bytes")
             ws = workspace.get(n, h2.device)
-            call("glx_rows128_moments", h2, ctypes.c_longlong(R), G, H, ws, size_arg(n))
+            call("glx_rows128_moments", h2, ctypes.c_longlong(R), G, H, pre, ws, size_arg(n))
             return G, H
+        assert pre is None
         S = 128 if R % 128 == 0 and R >= 128 * 256 else 1
         hc = h2.view(S, R // S, 128)
         return torch.bmm(hc.transpose(1, 2), hc).double().sum(0), h2.sum(0)
@@ -1767,17 +1791,17 @@ class PointMaxBN(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 mh, em = PointFeat._f16x2_image(M.t(), scale=-1.0)
                 d_h2 = torch.empty_like(h2)
-                call("glx_rows128_affine_f16x2", h2, ctypes.c_longlong(R), mh, em, nv, d_h2)
+                call("glx_rows128_affine_f16x2", h2, ctypes.c_longlong(R), mh, em, nv, d_h2, ctx.pre)
                 call("glx_pointmax_scatter_add_scaled", arg, g, scale, W3, B, P, d_h2)
             if ctx.needs_input_grad[1]:
                 T = torch.empty_like(W3)
                 ws = torch.empty(query("glx_pointmax_wsum_workspace_bytes"), dtype=torch.uint8, device=dev)
-                call("glx_pointmax_wsum", g, arg, h2, B, P, T, ws, size_arg(ws.numel()))
+                call("glx_pointmax_wsum_pre", g, arg, h2, ctx.pre, B, P, T, ws, size_arg(ws.numel()))
                 G2d, H1 = ctx.moments
                 d_w = torch.empty_like(W3)
                 call("glx_pointmax_bn_backward_weight", W3, G2d, H1, T, scale, bvec, cvec, mean_nb, d_w)
             d_b = torch.zeros_like(dbeta) if has_bias else None
-            return d_h2, d_w, d_b, dgamma, dbeta, None, None, None
+            return d_h2, d_w, d_b, dgamma, dbeta, None, None, None, None
         xhat = (ext - mean_nb) * invstd
         dbeta = g.sum(0)
         dgamma = (g * xhat).sum(0)
@@ -1792,7 +1816,7 @@ class PointMaxBN(torch.autograd.Function):
             if PointMaxBN.F16X2:
                 # dense part first (f16 x 2 products, one pass: read h2, write d_h2), then the extreme points' rows on top
                 mh, em = PointFeat._f16x2_image(M.t(), scale=-1.0)
-                call("glx_rows128_affine_f16x2", h2, ctypes.c_longlong(R), mh, em, (-v).contiguous(), d_h2)
+                call("glx_rows128_affine_f16x2", h2, ctypes.c_longlong(R), mh, em, (-v).contiguous(), d_h2, None)
                 call("glx_pointmax_scatter_add", arg, (g * scale).contiguous(), W3, B, P, d_h2)
             else:
                 call("glx_pointmax_scatter", arg, (g * scale).contiguous(), W3, (-v).contiguous(), B, P, d_h2)
@@ -1807,7 +1831,7 @@ class PointMaxBN(torch.autograd.Function):
                 G2 = G2d.float()
             d_w = scale[:, None] * T - bvec[:, None] * H1[None] - cvec[:, None] * (W3 @ G2 - mean_nb[:, None] * H1[None])
         d_b = torch.zeros_like(dbeta) if has_bias else None                     # sum_r dy = 0 exactly (the BatchNorm removes it)
-        return d_h2, d_w, d_b, dgamma, dbeta, None, None, None
+        return d_h2, d_w, d_b, dgamma, dbeta, None, None, None, None
 
 
 class LatentEncoder(nn.Module):

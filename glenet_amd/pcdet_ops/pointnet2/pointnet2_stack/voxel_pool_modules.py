@@ -243,7 +243,10 @@ class RowsConvBN(torch.autograd.Function):
     (3 launches).  The library formulation this replaces: 3 launches forward, 5 backward, the products at 17 - 46 us each."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, bn, relu, count):
+    def forward(ctx, x, weight, gamma, beta, bn, relu, count, lazy=False):
+        """lazy: the transform is NOT applied: returns (z, coef) -- the raw product and the BatchNorm's scale | shift -- for a
+        consumer that reads relu?(z scale + shift) on load (dense_path.PointMaxBN); the gradient it hands back for z is taken as the
+        gradient of the TRANSFORMED output, as in the eager form."""
         import ctypes
         from .... import _lib
         from ....spconv import core
@@ -254,7 +257,7 @@ class RowsConvBN(torch.autograd.Function):
         dev = x.device
         w = weight.detach().reshape(cout, cin).contiguous().float()
         z = torch.empty((rows, cout), dtype=torch.float32, device=dev)
-        y = torch.empty((rows, cout), dtype=torch.float32, device=dev)
+        y = None if lazy else torch.empty((rows, cout), dtype=torch.float32, device=dev)
         coef = torch.empty(2 * cout, dtype=torch.float32, device=dev)
         mean = torch.empty(cout, dtype=torch.float32, device=dev)
         invstd = torch.empty(cout, dtype=torch.float32, device=dev)
@@ -268,16 +271,21 @@ class RowsConvBN(torch.autograd.Function):
         else:
             _lib.call("glx_rows_linear_bn_forward", x, rows, cin, w, cout, count, z, gamma, beta, ctypes.c_float(bn.eps),
                       ctypes.c_float(bn.momentum), rm, rv, coef, mean, invstd, core._bn_state(dev))
-        _lib.call("glx_bn_apply_forward", z, coef, 1 if relu else 0, rows, cout, count, y, 0)
+        if not lazy:
+            _lib.call("glx_bn_apply_forward", z, coef, 1 if relu else 0, rows, cout, count, y, 0)
         if rm is not None:
             _lib.bump_weights_epoch((rm, rv))             # running statistics updated through raw pointers
         ctx.save_for_backward(x, w, z, coef, mean, invstd, gamma, beta)
         ctx.relu, ctx.count, ctx.wshape = relu, count, weight.shape
         ctx.leaf = weight if weight.is_leaf else None
+        ctx.lazy = bool(lazy)
+        if lazy:
+            ctx.mark_non_differentiable(coef)
+            return z.view_as(z), coef
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_):
         from .... import _lib
         from ....spconv import core
         x, w, z, coef, mean, invstd, gamma, beta = ctx.saved_tensors
@@ -307,7 +315,7 @@ class RowsConvBN(torch.autograd.Function):
             _lib.call("glx_rows_linear_bn_backward", x, z, dy, rows, cin, w, cout, ctx.count, coef, 1 if ctx.relu else 0, coef3,
                       mean, invstd, gx, gw, ws, _lib.size_arg(ws.numel()))
         return (gx, gw.view(ctx.wshape) if gw is not None else None, dgamma if gamma is not None else None,
-                dbeta if gamma is not None else None, None, None, None)
+                dbeta if gamma is not None else None, None, None, None, None)
 
 
 def rows_conv_bn_supported(seq, x2d):

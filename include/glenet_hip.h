@@ -1104,9 +1104,12 @@ int glx_pointmax_forward(const float* h2, int B, int P, const float* W3p, float*
                          int32_t* amin, float* s1, float* s2, void* stream);
 /* glx_pointmax_forward's one-sided twin with f16 x 2 products (three fp16 MFMAs per product tile, >= 20.4 bits, fp32 sums):
  * vext[b, c] = max_p (h2 W^T)[b, p, c] and the lowest point it occurs at; no sums (the caller takes them from the moments of h2).
- * W3h / ew3: the weight as glx_pointnet_feat_f16x2 takes it; a channel's MINIMUM = that row handed in negated. */
+ * W3h / ew3: the weight as glx_pointnet_feat_f16x2 takes it; a channel's MINIMUM = that row handed in negated.
+ * pre_coef (here and in glx_rows128_moments / glx_rows128_affine_f16x2 / glx_pointmax_wsum_pre; NULL: none): scale | shift, 128 floats each --
+ * the (rows, 128) operand is the RAW output z of the layer in front and its rows are read as relu(z scale + shift): that layer's
+ * BatchNorm + ReLU applied on load, the transformed matrix is never written. */
 int glx_pointmax_forward_f16x2(const float* h2, int B, int P, const void* W3h, const int32_t* ew3, float* vext, int32_t* aext,
-                               void* stream);
+                               const float* pre_coef, void* stream);
 int glx_pointmax_scatter(const int32_t* arg, const float* coef, const float* W3, const float* init, int B, int P, float* dh2,
                          void* stream);
 /* glx_pointmax_scatter_add: the same sums ADDED to the rows of dh2 some channel points at (the others are left alone).
@@ -1140,9 +1143,10 @@ int glx_rows_linear_bn_backward_64_128_f16x2(const float* x, const float* z, con
  * 128 -> 512 layer's batch statistics and weight gradient are made of (dense_path.PointMaxBN).  bf16 x 3 products, fp32 sums per
  * block of rows, fp64 over the blocks in a fixed order.  workspace: glx_rows128_moments_workspace_bytes(). */
 size_t glx_rows128_moments_workspace_bytes(void);
-int glx_rows128_moments(const float* x, long long rows, double* G, float* h, void* workspace, size_t workspace_bytes, void* stream);
+int glx_rows128_moments(const float* x, long long rows, double* G, float* h, const float* pre_coef, void* workspace,
+                        size_t workspace_bytes, void* stream);
 int glx_rows128_affine_f16x2(const float* x, long long rows, const void* Wh, const int32_t* ew, const float* init, float* y,
-                             void* stream);
+                             const float* pre_coef, void* stream);
 /* The training-mode BatchNorm around the max of the 128 -> 512 layer (cvae_uncertainty/point_net.py:22-28: bn3 + torch.max), as launches
  * instead of ~40 tensor statements per direction (dense_path.PointMaxBN):
  * glx_pointmax_bn_forward: batch statistics of y = h2 W3^T from the moments G = h2^T h2 (fp64), h = sum h2 (glx_rows128_moments) in
@@ -1166,6 +1170,8 @@ int glx_pointmax_scatter_add_scaled(const int32_t* arg, const float* coef, const
 size_t glx_pointmax_wsum_workspace_bytes(void);
 int glx_pointmax_wsum(const float* g, const int32_t* arg, const float* h2, int B, int P, float* T, void* workspace,
                       size_t workspace_bytes, void* stream);
+int glx_pointmax_wsum_pre(const float* g, const int32_t* arg, const float* h2, const float* pre_coef, int B, int P, float* T,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* out[m,c] = max_s relu(a[m,s,c] + b[m,s,c]) on row-major (M, nsample, C) tensors, arg = winning slot
  * (first on ties) -- add + ReLU + max_pool of the RoI-grid pooling MLP in training

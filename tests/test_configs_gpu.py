@@ -96,7 +96,7 @@ def test_cvae_config4_full_size_30_samples(dev):
 
 
 @pytest.mark.parametrize("path", ["default", "library_products", "bias_in_the_product", "fp32_wide_layer", "library_moments",
-                                  "batchnorm_as_tensor_statements", "losses_as_tensor_statements"])
+                                  "batchnorm_as_tensor_statements", "losses_as_tensor_statements", "h2_written"])
 def test_cvae_training_step_matches_reference_golden_on_device(dev, path, monkeypatch):
     """The training branch on the device (row kernels + fused training BatchNorm) against the reference-generated
     golden of tests/test_dense_path_cpu.py: loss terms, decoder output, every gradient, running statistics -- on the default
@@ -114,6 +114,8 @@ def test_cvae_training_step_matches_reference_golden_on_device(dev, path, monkey
         monkeypatch.setattr(dp.PointMaxBN, "FUSED_BN", False)
     elif path == "losses_as_tensor_statements":
         monkeypatch.setattr(dp.CVAE, "FUSED_LOSSES", False)
+    elif path == "h2_written":
+        monkeypatch.setattr(dp.PointFeat, "LAZY_H2", False)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cvae_train_ref.npz"))
     m = dp.CVAE(4, 8)
     m.load_state_dict({k[len("cvae/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("cvae/")}, strict=True)

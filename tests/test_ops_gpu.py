@@ -628,7 +628,7 @@ def test_rows128_moments_against_fp64(dev, rows):
     for _ in range(2):
         G = torch.full((128, 128), float("nan"), dtype=torch.float64, device=dev)
         H = torch.full((128,), float("nan"), device=dev)
-        _lib.call("glx_rows128_moments", x, ctypes.c_longlong(rows), G, H, ws, _lib.size_arg(n))
+        _lib.call("glx_rows128_moments", x, ctypes.c_longlong(rows), G, H, None, ws, _lib.size_arg(n))
         outs.append((G, H))
     torch.cuda.synchronize()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
@@ -658,14 +658,14 @@ def test_rows128_affine_f16x2_against_fp64(dev):
     init = torch.randn(128, device=dev, generator=g)
     wh, ew = dp.PointFeat._f16x2_image(w)
     y = torch.full((rows, 128), float("nan"), device=dev)
-    _lib.call("glx_rows128_affine_f16x2", x, ctypes.c_longlong(rows), wh, ew, init, y)
+    _lib.call("glx_rows128_affine_f16x2", x, ctypes.c_longlong(rows), wh, ew, init, y, None)
     want = init.double() + x.double() @ w.double().t()
     mag = x.abs().double() @ w.abs().double().t() + init.abs().double()
     assert torch.isfinite(y).all()
     assert float(((y.double() - want).abs() / mag.clamp_min(1e-300)).max()) < 2.0 ** -17
     assert torch.equal(y[17], init)                                       # the zero row: exactly init
     y2 = torch.empty_like(y)
-    _lib.call("glx_rows128_affine_f16x2", x, ctypes.c_longlong(rows), wh, ew, None, y2)      # init == NULL
+    _lib.call("glx_rows128_affine_f16x2", x, ctypes.c_longlong(rows), wh, ew, None, y2, None)      # init == NULL
     assert float(((y2.double() - (want - init.double())).abs() / mag).max()) < 2.0 ** -17
 
 
