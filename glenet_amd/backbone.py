@@ -30,6 +30,9 @@ def _conv_bn_relu(cin, cout, ksize, key, kind="subm", stride=1, padding=0):
     return spconv.SparseSequential(conv, _norm(cout), nn.ReLU())
 
 
+FUSED_RESIDUAL_TAIL = True      # ResidualBlock (training): relu(bn2(.) + identity) as one launch
+
+
 class ResidualBlock(spconv.SparseModule):
     """SparseBasicBlock (spconv_backbone.py:30-64): two biased SubM convs + identity."""
 
@@ -59,6 +62,9 @@ class ResidualBlock(spconv.SparseModule):
                 else:
                     out = out.replace_feature(self.relu(self.bn1(out.features)))
             if core.conv_bn_fusable(self.conv2, self.bn2, out):
+                if FUSED_RESIDUAL_TAIL and self.bn2.affine:
+                    # bn2's transform, the identity branch and the ReLU in one launch (three; two maps of traffic less)
+                    return self.conv2(out, train_bn=self.bn2, train_relu=False, residual=x.features)
                 out = self.conv2(out, train_bn=self.bn2, train_relu=False)
             else:
                 out = self.conv2(out)

@@ -199,7 +199,8 @@ __global__ __launch_bounds__(BN_FIN_THREADS) void k_bn_finalize_fwd(
 // BN_THREADS / (C/4) consecutive rows per trip).
 __global__ __launch_bounds__(BN_THREADS) void k_bn_forward_apply(
     const float* __restrict__ x, const float* __restrict__ coef, int relu, int N, int C,
-    const int* __restrict__ n_live, float* __restrict__ y, long long y_pitch) {
+    const int* __restrict__ n_live, float* __restrict__ y, long long y_pitch, const float* __restrict__ res) {
+  // res != NULL (N x C, dense): y = relu?(x scale + shift + res) -- the identity branch of a residual block joins here
   int n = N;
   if (n_live) n = min(N, *n_live);
   const int c4n = C >> 2;
@@ -208,9 +209,11 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_forward_apply(
   const bf32x4 sh = *reinterpret_cast<const bf32x4*>(coef + C + 4 * col);
   for (int r = blockIdx.x * rpb + rl; r < n; r += gridDim.x * rpb) {
     bf32x4 v = *reinterpret_cast<const bf32x4*>(x + (long long)r * C + 4 * col);
+    bf32x4 rv = bf32x4{0.f, 0.f, 0.f, 0.f};
+    if (res) rv = *reinterpret_cast<const bf32x4*>(res + (long long)r * C + 4 * col);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float t = bn_affine(v[i], sc[i], sh[i]);
+      const float t = bn_affine(v[i], sc[i], sh[i]) + rv[i];
       v[i] = relu ? fmaxf(t, 0.f) : t;
     }
     *reinterpret_cast<bf32x4*>(y + (long long)r * y_pitch + 4 * col) = v;
@@ -650,7 +653,7 @@ extern "C" int glx_bn_relu_train_forward(const float* x, int N, int C, const flo
                        running_mean, running_var);
   }
   hipLaunchKernelGGL(k_bn_forward_apply, dim3(blocks < 1 ? 1 : blocks), dim3(BN_THREADS), 0, st, x,
-                     (const float*)coef, relu, N, C, n_live, y, y_pitch);
+                     (const float*)coef, relu, N, C, n_live, y, y_pitch, (const float*)nullptr);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
@@ -665,7 +668,21 @@ extern "C" int glx_bn_apply_forward(const float* x, const float* coef, int relu,
   if (N <= 0) return GLX_OK;
   const int blocks = bn_apply_blocks(N, C);
   hipLaunchKernelGGL(k_bn_forward_apply, dim3(blocks < 1 ? 1 : blocks), dim3(BN_THREADS), 0, (hipStream_t)stream, x,
-                     coef, relu, N, C, n_live, y, (long long)(y_stride ? y_stride : C));
+                     coef, relu, N, C, n_live, y, (long long)(y_stride ? y_stride : C), (const float*)nullptr);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+// y = relu?(x * scale + shift + res): the transform with the identity branch of a residual block added (SparseBasicBlock,
+// pcdet/models/backbones_3d/spconv_backbone.py:30-64: out = relu(bn2(conv2(.)) + identity)), one launch instead of three.
+extern "C" int glx_bn_apply_add_forward(const float* x, const float* coef, const float* res, int relu, int N, int C,
+                                        const int32_t* n_live, float* y, void* stream) {
+  GLX_REQUIRE(coef && y && res && (N == 0 || x), "glx_bn_apply_add_forward: null pointer");
+  GLX_REQUIRE(bn_channels_ok(C), "glx_bn_apply_add_forward: C=%d needs a multiple of 4 dividing 1024 (<= 512)", C);
+  if (N <= 0) return GLX_OK;
+  const int blocks = bn_apply_blocks(N, C);
+  hipLaunchKernelGGL(k_bn_forward_apply, dim3(blocks < 1 ? 1 : blocks), dim3(BN_THREADS), 0, (hipStream_t)stream, x,
+                     coef, relu, N, C, n_live, y, (long long)C, res);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

@@ -846,11 +846,12 @@ class SparseConvolution(SparseModule):
             x.indice_dict[key] = rs
         return rs
 
-    def forward(self, x, fused_bn=None, fused_relu=False, train_bn=None, train_relu=False):
+    def forward(self, x, fused_bn=None, fused_relu=False, train_bn=None, train_relu=False, residual=None):
         """fused_bn / fused_relu: inference-only folding of the eval-mode BatchNorm1d (+ReLU)
         that follows this conv into the kernel's epilogue (see SparseSequential).
         train_bn / train_relu: the TRAINING-mode BatchNorm1d (+ReLU) behind the conv: statistics in the conv's
-        epilogue, then one transform launch (FusedBNApply)."""
+        epilogue, then one transform launch (FusedBNApply).  residual (with train_bn): the output is relu(bn(conv(x)) + residual),
+        the tail of a residual block in that same launch (FusedBNApplyAdd)."""
         assert isinstance(x, SparseConvTensor)
         K = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
         w = self.weight.reshape(K, self.in_channels, self.out_channels)
@@ -894,7 +895,10 @@ class SparseConvolution(SparseModule):
                 # relu only: the epilogue re-derives the ReLU mask; a BatchNorm without ReLU keeps the full backward
                 out_link = {} if (BN_BWD_IN_DGRAD and train_relu and train_bn.affine) else None
                 cnt = rs.count_in if self.inverse else rs.count_out
-                if BN_ON_LOAD and out_link is not None and self.out_channels in (16, 32, 64, 128):
+                if residual is not None:
+                    feats = FusedBNApplyAdd.apply(feats, coef, mean, invstd, train_bn.weight, train_bn.bias, residual, cnt)
+                    out_link = None
+                elif BN_ON_LOAD and out_link is not None and self.out_channels in (16, 32, 64, 128):
                     pending_out = PendingBN(feats, coef, mean, invstd, train_bn, cnt, out_link)      # whoever reads it first
                     feats, out_link = None, None
                 else:
@@ -1032,6 +1036,36 @@ class FusedBNApply(Function):
             link["result"] = None
         dx, dgamma, dbeta = FusedBNReLU.backward(ctx, dy)[:3]
         return dx, None, None, None, dgamma, dbeta, None, None, None
+
+
+class FusedBNApplyAdd(Function):
+    """y = relu(bn(x) + res) for statistics taken in the producing conv's epilogue: the tail of a residual block
+    (spconv_backbone.py:30-64) as ONE launch (transform, add and ReLU were three); backward: the ReLU's mask comes from the saved
+    output (the BatchNorm-backward kernels take it: glx_bn_relu_backward's `y`), the identity branch gets the masked gradient."""
+
+    @staticmethod
+    def forward(ctx, x, coef, mean, invstd, weight, bias, res, count=None):
+        N, C = x.shape
+        res = res.contiguous()
+        y = torch.empty_like(x)
+        call("glx_bn_apply_add_forward", x, coef, res, 1, N, C, count, y)
+        ctx.save_for_backward(x, weight, bias, mean, invstd, y)
+        ctx.count = count
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, mean, invstd, y = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        N, C = x.shape
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = workspace.get(query("glx_bn_workspace_bytes", C), x.device)
+        call("glx_bn_relu_backward", x, dy, y, N, C, weight, bias, mean, invstd, 1, dx, dgamma, dbeta, ctx.count, ws,
+             size_arg(ws.numel()), _bn_state(x.device), 0)
+        d_res = torch.ops.aten.threshold_backward(dy, y, 0) if ctx.needs_input_grad[6] else None
+        return dx, None, None, None, dgamma, dbeta, d_res, None
 
 
 class StackedBN(Function):

@@ -774,6 +774,10 @@ int glx_bn_relu_train_forward(const float* x, int N, int C, const float* gamma, 
  * (glx_sconv_opts.bn): y = relu?(x * coef[c] + coef[C + c]) on the live rows, zeros on the rows past them. */
 int glx_bn_apply_forward(const float* x, const float* coef, int relu, int N, int C, const int32_t* n_live,
                          float* y, int y_stride, void* stream);
+/* y = relu?(x * scale + shift + res): glx_bn_apply_forward with the identity branch of a residual block added (SparseBasicBlock,
+ * pcdet/models/backbones_3d/spconv_backbone.py:30-64: relu(bn2(conv2(.)) + identity)); res (N, C) dense.  One launch for three. */
+int glx_bn_apply_add_forward(const float* x, const float* coef, const float* res, int relu, int N, int C, const int32_t* n_live,
+                             float* y, void* stream);
 /* dx (N,C), dgamma (C), dbeta (C) from dy and the forward's x, mean, invstd.  The ReLU mask: from the forward's
  * output y, or -- y = NULL -- re-derived from x with gamma / beta (the forward's own rounding, so it is the same
  * mask; a third less traffic).  beta is only read in that case. */

@@ -61,11 +61,15 @@ def _fp64_block(f, nbr, p, g, eps=1e-3):
     return out.detach().numpy(), grads
 
 
+@pytest.mark.parametrize("fused_tail", [True, False])
 @pytest.mark.parametrize("C,shift,shape", [(64, 2, (11, 376, 376)), (128, 3, (6, 188, 188))])
-def test_residual_block_training_backward_matches_fp64(dev, C, shift, shape):
+def test_residual_block_training_backward_matches_fp64(dev, C, shift, shape, fused_tail, monkeypatch):
     """One SparseBasicBlock of VoxelResBackBone8x's third / fourth stage (C = 64 / 128, biased SubM convs, training-mode
     BatchNorm) on the active set a Waymo-shaped frame leaves at that level: output, input gradient, both weight gradients,
-    bias and BatchNorm gradients against the fp64 evaluation; the single convolutions against oracle.sconv_backward."""
+    bias and BatchNorm gradients against the fp64 evaluation; the single convolutions against oracle.sconv_backward.
+    fused_tail: relu(bn2(.) + identity) as one launch (glx_bn_apply_add_forward) or as transform, add, ReLU."""
+    from glenet_amd import backbone as _gb
+    monkeypatch.setattr(_gb, "FUSED_RESIDUAL_TAIL", fused_tail)
     rng = np.random.default_rng(C)
     idx = _level_cells(31, 60000, shift, shape)
     n = len(idx)
