@@ -1487,10 +1487,10 @@ class PointFeat(nn.Module):
     @classmethod
     def _rows_layer(cls, x2d, conv, bn, relu, lazy=False):
         """relu?(bn(conv(x2d))) on rows; x2d may carry zero columns behind the conv's input channels and the result may carry
-        zero columns behind its output channels (the narrow extractor's 8 channels run as 16: the kernels' tiles)."""
-        from .spconv import core
-        """lazy: -> (z, coef) with the transform left to the consumer (RowsConvBN's lazy form), or (h, None) where this layer
+        zero columns behind its output channels (the narrow extractor's 8 channels run as 16: the kernels' tiles).
+        lazy: -> (z, coef) with the transform left to the consumer (RowsConvBN's lazy form), or (h, None) where this layer
         does not run on the row kernels."""
+        from .spconv import core
         pre = None
         fold = cls.BIAS_INTO_RUNNING_MEAN and conv.bias is not None and bn.track_running_stats
         cout, cin = conv.weight.shape[:2]
