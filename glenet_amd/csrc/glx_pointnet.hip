@@ -183,6 +183,7 @@ extern "C" int glx_pointnet_feat(const float* points, int B, int Cin, int P, con
 // two (ew2 / ew3, host side), a point by the maximum of its activations over the channels (4 lanes of a quad column: two
 // register-half swaps); both come out per product tile (ldexp).  Layer 1 (K <= 8) stays on the VALU in fp32.
 typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
+typedef int pi32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void pn_split2(float xs, _Float16& a, _Float16& b) {
   a = (_Float16)xs;
@@ -216,6 +217,21 @@ __device__ __forceinline__ void pn_dma16(const void* base_uniform, unsigned off,
   // 64 lanes x 16 B from base + off (per lane) -> LDS at lds_uniform + 16 lane
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base_uniform), "s"(lds_uniform)
                : "memory");
+}
+__device__ __forceinline__ void pn_dma4(const void* base_uniform, unsigned off, unsigned lds_uniform) {
+  // 64 lanes x 4 B from base + off (per lane) -> LDS at lds_uniform + 4 lane
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(off), "s"(base_uniform), "s"(lds_uniform)
+               : "memory");
+}
+__device__ __forceinline__ float pn_row_max(float v) {      // the maximum over a row of 16 lanes, in every lane (four DPP steps)
+#define PN_DPP_MAX(ctrl) \
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true)))
+  PN_DPP_MAX(0xB1);      // quad_perm [1, 0, 3, 2]
+  PN_DPP_MAX(0x4E);      // quad_perm [2, 3, 0, 1]
+  PN_DPP_MAX(0x141);     // row_half_mirror
+  PN_DPP_MAX(0x140);     // row_mirror
+#undef PN_DPP_MAX
+  return v;
 }
 template <int N>
 __device__ __forceinline__ void pn_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -458,6 +474,341 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   }
 }
 
+// ------------------------------------------------------------------------------------------------ f16 x 2 form, W3 in registers
+// The same extractor with the roles of layer 3's operands swapped in the memory hierarchy: a block of EIGHT waves stays on a CU and walks
+// over objects, wave w keeps the fragments of W3's channel tiles 4 w .. 4 w + 3 in registers for the whole launch (128 registers, loaded
+// once: no slab ring, no barrier per channel tile) and the POINTS go through LDS in half-passes of 64 -- four waves run layers 1 and 2
+// for 16 points each and leave their two fp16 planes (operand order) + their exponents in one of three LDS buffers, then ALL waves
+// multiply the four point tiles against their own channels.  A fragment read (8 x 1 KB per point tile) feeds 4 x 12 = 48 MFMAs instead
+// of 24: layer 3's LDS traffic halves (the form above shares its time between the matrix pipe and LDS reads, profiles/r06_cvae.md).
+// The two halves of the block alternate as preparers (half-pass t by waves 4 (t & 1) .. + 3), and there is no barrier in the loop: a
+// wave runs  prepare, multiply, multiply  and meets the others through two counts per wave in LDS (see the loop).  The preparing wave
+// has its SIMD's vector issue to itself, so its own latencies show: the points arrive by LDS-DMA one turn ahead, layer 1 and the narrow
+// extractor's first layer take them as fp32 MFMA operands as they lie (k-step i, lane (j, q) = input channel 4 i + q of point j),
+// every LDS round trip fetches a whole channel tile's operands, and the wave runs at raised priority.  A wave owns its channels
+// outright: nothing to combine across waves at an object's end.  Measured (tools/sampler_time.py, 4096 objects x 512 points):
+// 0.65 ms against 0.75 ms for the form above; layer 3 alone is 0.45 ms of it, which is what the matrix pipe sustains on operands
+// with random bits (tools/experiments/mfma_peak.hip: 0.69 of the nominal rate, profiles/r06_mfma_ceiling.md).
+#define PNW_THREADS 512
+#define PNW_NM_RING 4
+#define PNW_BUFS 3
+template <bool NARROW>
+__global__ __launch_bounds__(PNW_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pointnet_feat_f16w(
+    const float* __restrict__ pts, int B, int CIN, int P, const float* __restrict__ W1, const float* __restrict__ b1,
+    const uint4* __restrict__ W2h, const int* __restrict__ ew2, const float* __restrict__ b2, const uint4* __restrict__ W3h,
+    const int* __restrict__ ew3, const float* __restrict__ b3, float* __restrict__ out, const float* __restrict__ nw,
+    float* __restrict__ nout) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  uint4* s_w2 = reinterpret_cast<uint4*>(smem);              // 8 t2 x 2 s x 2 planes x 64 lanes                          (32 KB)
+  uint4* s_y = s_w2 + 8 * 2 * 2 * 64;                        // [buffer 3][point tile 4][k-step 4][plane 2][lane 64]      (96 KB)
+  pf32x4* s_w1f = reinterpret_cast<pf32x4*>(s_y + PNW_BUFS * 4 * 4 * 2 * 64);      // [k-step 2][lane 64]: layer 1's weights as fp32 MFMA fragments
+  float* s_b1 = reinterpret_cast<float*>(s_w1f + 2 * 64);    // 64
+  float* s_b2 = s_b1 + PN_C1;                                // 128
+  int* s_e2 = reinterpret_cast<int*>(s_b2 + PN_C2);          // 128
+  int* s_ex = s_e2 + PN_C2;                                  // [buffer 3][64]: MINUS the exponents of the half-pass's points
+  int* s_pa = s_ex + PNW_BUFS * 64;                          // [wave 8]: half-passes this wave has prepared ...
+  int* s_pb = s_pa + 8;                                      // [wave 8]: ... and half-passes it has multiplied
+  int* s_e3 = s_pb + 8;                                      // 512: MINUS the exponents of layer 3's rows ...
+  float* s_b3 = reinterpret_cast<float*>(s_e3 + PN_C3);      // 512: ... and its biases (an object's end must not wait for HBM)
+  float* s_x = s_b3 + PN_C3;         // [wave 8][2][64]: the wave's next 16 points, channel (4 i + q) of point j
+  pf32x4* s_na = reinterpret_cast<pf32x4*>(s_x + 8 * 2 * 64);     // NARROW: [layer 3][lane 64] weight fragments, [layer 2][lane 64] biases
+  float* s_nm = reinterpret_cast<float*>(s_na + 5 * 64);     // NARROW: [object ring 4][8 waves][8]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, q = lane >> 4, grp = wave >> 2, wt = wave & 3;
+
+  for (int e = tid; e < 8 * 2 * 2 * 64; e += PNW_THREADS) s_w2[e] = W2h[e];
+  if (tid < 2 * 64) {
+    const int i = tid >> 6, ci = 4 * i + q;
+    pf32x4 v;
+#pragma unroll
+    for (int t1 = 0; t1 < 4; ++t1) v[t1] = ci < CIN ? W1[(16 * t1 + j) * CIN + ci] : 0.f;
+    s_w1f[tid] = v;
+  }
+  if (tid < PN_C1) s_b1[tid] = b1[tid];
+  if (tid < PN_C2) { s_b2[tid] = b2[tid]; s_e2[tid] = ew2[tid]; }
+  if (tid < 16) s_pa[tid] = 0;
+  for (int e = tid; e < PN_C3; e += PNW_THREADS) { s_e3[e] = -ew3[e]; s_b3[e] = b3[e]; }
+  // this wave's channels: tiles 4 wave + a, fragments [a][k-step][plane] straight from the packed image
+  pf16x8 Wa[4][4], Wb[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      Wa[a][s] = __builtin_bit_cast(pf16x8, W3h[(((4 * wave + a) * 4 + s) * 2 + 0) * 64 + lane]);
+      Wb[a][s] = __builtin_bit_cast(pf16x8, W3h[(((4 * wave + a) * 4 + s) * 2 + 1) * 64 + lane]);
+    }
+  float mx[4];                                               // lane (j, q): channel 16 (4 wave + a) + j, in the channel's scale
+#pragma unroll
+  for (int a = 0; a < 4; ++a) mx[a] = -FLT_MAX;
+  pf32x4 nmx = pf32x4{-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+  if constexpr (NARROW) {                                    // the narrow extractor's weights as MFMA fragments, zero outside 8 x 8
+    if (tid < 3 * 64) {      // layer 0: [k-step i] = input channel 4 i + q (the staged points' order); layers 1, 2: [e] = channel 4 q + e (D's)
+      const int l = tid >> 6;
+      pf32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int col = l == 0 ? 4 * e + q : 4 * q + e;
+        v[e] = (j < PNN_W && col < PNN_W) ? nw[72 * l + j * 8 + col] : 0.f;
+      }
+      s_na[tid] = v;
+    }
+    if (tid < 2 * 64) {
+      const int l = tid >> 6;
+      s_na[3 * 64 + tid] = (q < 2) ? *reinterpret_cast<const pf32x4*>(nw + 72 * l + 64 + 4 * q) : pf32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __syncthreads();
+
+  const int H = (P + 63) >> 6;                               // half-passes per object
+  const int G = __builtin_amdgcn_readfirstlane((int)gridDim.x);
+  const int nobj = ((int)blockIdx.x < B) ? (B - 1 - (int)blockIdx.x) / G + 1 : 0;
+  const int T = nobj * H;                                    // this block's half-passes, objects one after the other
+
+  // the 16 points this wave prepares in half-pass t, on their way into its corner of LDS (a point past the end repeats the object's
+  // last one, a channel past CIN the last channel: its weights are zero)
+  const unsigned my_x = __builtin_amdgcn_readfirstlane(pn_lds_addr(s_x + wave * 128));
+  auto stage = [&](int k, int hp) {
+    const long long obj = (long long)blockIdx.x + (long long)k * G;
+    const float* xo = pts + obj * CIN * (long long)P;
+    const int pp = hp * 64 + wt * 16 + j, p = pp < P ? pp : P - 1;
+    const int c0 = q < CIN ? q : CIN - 1, c1 = 4 + q < CIN ? 4 + q : CIN - 1;
+    const unsigned long long xa = (unsigned long long)xo;    // (uniform, but the compiler has to be told)
+    xo = reinterpret_cast<const float*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xa >> 32)) << 32) |
+                                        (unsigned)__builtin_amdgcn_readfirstlane((int)xa));
+    pn_dma4(xo, (unsigned)(c0 * P + p) * 4u, my_x);
+    pn_dma4(xo, (unsigned)(c1 * P + p) * 4u, my_x + 256u);
+  };
+  // layers 1 and 2 for this wave's 16 points of half-pass t
+  auto produce = [&](int t, int k, int hp) {
+    const int buf = t % PNW_BUFS;
+    __builtin_amdgcn_s_setprio(3);                           // the block waits for this wave: ahead of the SIMD's other wave
+    pn_wait_vm<0>();
+    // the staged points are MFMA operands as they lie: k-step i of a 16 x 16 x 4 product wants, in lane (j, q), input channel 4 i + q of
+    // point j.  Layer 1 (and the narrow extractor's first layer) on the matrix pipe in fp32: one or two steps per channel tile
+    // instead of eight FMAs per channel on a wave that has the SIMD's vector issue to itself
+    const int KS = CIN > 4 ? 2 : 1;
+    float xb[2];
+    xb[0] = s_x[wave * 128 + lane];
+    xb[1] = s_x[wave * 128 + 64 + lane];
+    if constexpr (NARROW) {
+      if (hp < 2) nmx = pf32x4{-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};      // this wave's first half-pass of the object
+      const pf32x4 n0 = s_na[lane];                          // [0], [1]: the first layer's two k-steps
+      pf32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(n0[0], xb[0], pf32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      if (KS > 1) d = __builtin_amdgcn_mfma_f32_16x16x4f32(n0[1], xb[1], d, 0, 0, 0);
+#pragma unroll
+      for (int l = 1; l < 3; ++l) {
+        const pf32x4 bias = s_na[(2 + l) * 64 + lane];
+        const pf32x4 na = s_na[l * 64 + lane];
+        pf32x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = fmaxf(d[e] + bias[e], 0.f);
+        pf32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(na[0], h[0], pf32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);     // two chains
+        pf32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(na[1], h[1], pf32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(na[2], h[2], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(na[3], h[3], d1, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = d0[e] + d1[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) nmx[e] = fmaxf(nmx[e], d[e]);
+      if (hp + 2 >= H) {                                     // ... and its last: the wave's share of the narrow maxima
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = pn_row_max(nmx[e]);
+          if (j == 0 && q < 2) s_nm[((k & (PNW_NM_RING - 1)) * 8 + wave) * PNN_W + 4 * q + e] = v;
+        }
+      }
+    }
+    float h1[16];
+    {
+      const pf32x4 w0 = s_w1f[lane], w1 = s_w1f[64 + lane];  // k-step i, lane (j, q): W1[16 t1 + j][4 i + q] for t1 = 0 .. 3
+#pragma unroll
+      for (int t1 = 0; t1 < 4; ++t1) {
+        pf32x4 acc = *reinterpret_cast<const pf32x4*>(s_b1 + 16 * t1 + 4 * q);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t1], xb[0], acc, 0, 0, 0);
+        if (KS > 1) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[t1], xb[1], acc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h1[t1 * 4 + e] = fmaxf(acc[e], 0.f);
+      }
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) m = fmaxf(m, h1[v]);
+    const int ex1 = pn_exponent(pn_point_max(m));
+    const float sc1 = __builtin_bit_cast(float, (unsigned)(ex1 + 127) << 23);
+    pf16x8 Xa[2], Xb[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        _Float16 a, b;
+        pn_split2(h1[(2 * s + (jj >> 2)) * 4 + (jj & 3)] * sc1, a, b);
+        Xa[s][jj] = a;
+        Xb[s][jj] = b;
+      }
+    // layer 2, one LDS round trip per channel tile: its four fragments, exponents and biases are in flight together
+    float h2[32];
+#pragma unroll
+    for (int t2 = 0; t2 < 8; ++t2) {
+      uint4 V[2][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) V[s][pl] = s_w2[((t2 * 2 + s) * 2 + pl) * 64 + lane];
+      const pi32x4 e2v = *reinterpret_cast<const pi32x4*>(s_e2 + 16 * t2 + 4 * q);
+      const pf32x4 b2v = *reinterpret_cast<const pf32x4*>(s_b2 + 16 * t2 + 4 * q);
+      __builtin_amdgcn_sched_barrier(0);
+      pf32x4 ac[2];                                          // the two k-steps as independent chains (a wave is alone here)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) ac[s] = pf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 2; ++s) ac[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pf16x8, V[s][1]), Xa[s], ac[s], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) ac[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pf16x8, V[s][0]), Xb[s], ac[s], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) ac[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pf16x8, V[s][0]), Xa[s], ac[s], 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h2[t2 * 4 + e] = fmaxf(ldexpf(ac[0][e] + ac[1][e], -(e2v[e] + ex1)) + b2v[e], 0.f);
+    }
+    m = 0.f;
+#pragma unroll
+    for (int v = 0; v < 32; ++v) m = fmaxf(m, h2[v]);
+    const int ex2 = pn_exponent(pn_point_max(m));
+    const float sc2 = __builtin_bit_cast(float, (unsigned)(ex2 + 127) << 23);
+    if (q == 0) s_ex[buf * 64 + 16 * wt + j] = -ex2;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      pf16x8 ya, yb;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        _Float16 a, b;
+        pn_split2(h2[(2 * s + (jj >> 2)) * 4 + (jj & 3)] * sc2, a, b);
+        ya[jj] = a;
+        yb[jj] = b;
+      }
+      s_y[(((buf * 4 + wt) * 4 + s) * 2 + 0) * 64 + lane] = __builtin_bit_cast(uint4, ya);
+      s_y[(((buf * 4 + wt) * 4 + s) * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, yb);
+    }
+    if (t + 2 < T) {                                         // this wave's next turn
+      int k2 = k, h2p = hp + 2;
+      while (h2p >= H) { h2p -= H; ++k2; }
+      stage(k2, h2p);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the planes and exponents are in LDS before the count says so
+    if (lane == 0) __hip_atomic_store(s_pa + wave, (t >> 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // No barrier in the loop: a wave runs  prepare, multiply, multiply  over and over and meets the others through two counts per wave in
+  // LDS -- half-pass t may be multiplied once its four preparers have counted it, buffer t % 3 may be overwritten once all eight waves
+  // have counted the multiplication of half-pass t - 3.  The two waves of a SIMD are one multiplication apart, so one prepares (vector
+  // and LDS work, a long dependent chain) under the other's MFMAs instead of the block waiting for the slowest preparer.
+  auto count_min = [&](const int* c, int n) {
+    int m = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int i = 1; i < n; ++i) {
+      const int v = __hip_atomic_load(c + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      m = v < m ? v : m;
+    }
+    return __builtin_amdgcn_readfirstlane(m);
+  };
+
+  if (grp < T) stage(grp >= H ? 1 : 0, grp >= H ? 0 : grp);  // group 0 starts with half-pass 0, group 1 with 1
+  if (T > 0 && grp == 0) produce(0, 0, 0);
+  int kc = 0, hc = 0;                                        // half-pass t = object kc of this block, its half-pass hc
+  for (int t = 0; t < T; ++t) {
+    if (t + 1 < T && ((t + 1) & 1) == grp) {
+      if (t + 1 >= PNW_BUFS) {
+        while (count_min(s_pb, 8) < t + 2 - PNW_BUFS) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+      produce(t + 1, hc + 1 == H ? kc + 1 : kc, hc + 1 == H ? 0 : hc + 1);
+    }
+    while (count_min(s_pa + 4 * (t & 1), 4) < (t >> 1) + 1) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- layer 3 (points x channels): the half-pass's four point tiles against this wave's four channel tiles, as 16 steps of 12
+    // MFMAs; a step's two fragments are read one step ahead (an LDS round trip is shorter than 12 MFMAs, and this wave may be the
+    // only one multiplying on its SIMD), a tile's maxima are taken under the next tile's first step
+    const int buf = t % PNW_BUFS;
+    {
+      const uint4* yl = s_y + buf * (4 * 4 * 2 * 64) + lane;
+      uint4 Yn0 = yl[0], Yn1 = yl[64];
+      pf32x4 acc[2][4];
+      pi32x4 nex[2];
+      auto maxima = [&](int h) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          float v = mx[a];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v = fmaxf(v, ldexpf(acc[h][a][e], nex[h][e]));
+          mx[a] = v;
+        }
+      };
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) {
+        nex[pt & 1] = *reinterpret_cast<const pi32x4*>(s_ex + buf * 64 + 16 * pt + 4 * q);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const pf16x8 Ya = __builtin_bit_cast(pf16x8, Yn0), Yb = __builtin_bit_cast(pf16x8, Yn1);
+          if (pt * 4 + s + 1 < 16) {
+            Yn0 = yl[((pt * 4 + s + 1) * 2 + 0) * 64];
+            Yn1 = yl[((pt * 4 + s + 1) * 2 + 1) * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+            acc[pt & 1][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ya, Wb[a][s], s == 0 ? pf32x4{0.f, 0.f, 0.f, 0.f} : acc[pt & 1][a], 0, 0, 0);
+#pragma unroll
+          for (int a = 0; a < 4; ++a) acc[pt & 1][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Yb, Wa[a][s], acc[pt & 1][a], 0, 0, 0);
+#pragma unroll
+          for (int a = 0; a < 4; ++a) acc[pt & 1][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ya, Wa[a][s], acc[pt & 1][a], 0, 0, 0);
+          if (s == 0 && pt > 0) maxima((pt - 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      maxima(1);
+    }
+    const int k = kc;
+    const bool last = hc == H - 1;                           // the object's last half-pass: its features leave
+    if (++hc == H) { hc = 0; ++kc; }
+    if (last) {
+      const long long obj = (long long)blockIdx.x + (long long)k * G;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const float v = pn_point_max(mx[a]);
+        const int c = 16 * (4 * wave + a) + j;
+        if (q == 0) out[obj * PN_C3 + c] = ldexpf(v, s_e3[c]) + s_b3[c];
+        mx[a] = -FLT_MAX;
+      }
+    }
+    if constexpr (NARROW) {                                  // (every preparer of the object has counted its last half-pass by now)
+      if (last && tid < PNN_W) {
+        const long long obj = (long long)blockIdx.x + (long long)k * G;
+        float v = -FLT_MAX;
+#pragma unroll
+        for (int w_ = 0; w_ < 8; ++w_)
+          if (H >= 2 || ((k * H) & 1) == (w_ >> 2)) v = fmaxf(v, s_nm[((k & (PNW_NM_RING - 1)) * 8 + w_) * PNN_W + tid]);
+        nout[obj * PNN_W + tid] = v + nw[144 + 64 + tid];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (the reads of the buffer are behind this wave)
+    if (lane == 0) __hip_atomic_store(s_pb + wave, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+
+static int glx_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+static size_t pointnet_feat_f16w_lds_bytes() {
+  return (size_t)(8 * 2 * 2 * 64 + PNW_BUFS * 4 * 4 * 2 * 64) * 16 +
+         (size_t)(PN_C1 * PN_MAXCIN + PN_C1 + PN_C2 + PN_C2 + PNW_BUFS * 64 + 16 + 2 * PN_C3 + 8 * 2 * 64 + 5 * 64 * 4 + PNW_NM_RING * 8 * PNN_W) * 4;
+}
+
 extern "C" size_t glx_pointnet_feat_f16x2_lds_bytes(void) {
   return (size_t)(8 * 2 * 2 * 64 + PNH_RING * PNH_SLAB_U4) * 16 +
          (size_t)(PN_C1 * PN_MAXCIN + PN_C1 + PN_C2 + PN_C2 + PN_C3 + 4 * PN_C3) * 4;
@@ -466,6 +817,12 @@ extern "C" size_t glx_pointnet_feat_f16x2_lds_bytes(void) {
 // W2h / W3h: the folded (128, 64) / (512, 128) weights as two fp16 planes of w 2^ew[row] in the kernel's operand order
 // ([output tile][k-step][plane][lane 16 q + m][slot 4 h + e] = W[16 tile + m][32 s + 16 h + 4 q + e]); ew2 / ew3: the rows'
 // exponents (max |w| 2^ew in [2^14, 2^15), 0 for a zero row).
+static int g_pointnet_w_stationary = 1;      // 1: k_pointnet_feat_f16w (W3 in registers, points through LDS); 0: k_pointnet_feat_f16
+extern "C" int glx_pointnet_feat_set_form(int w_stationary) {      // returns the previous setting (measurements)
+  const int old = g_pointnet_w_stationary;
+  g_pointnet_w_stationary = w_stationary ? 1 : 0;
+  return old;
+}
 extern "C" int glx_pointnet_feat_f16x2_pair(const float* points, int B, int Cin, int P, const float* W1, const float* b1,
                                             const void* W2h, const int32_t* ew2, const float* b2, const void* W3h,
                                             const int32_t* ew3, const float* b3, float* out, const float* narrow, float* narrow_out,
@@ -496,6 +853,24 @@ extern "C" int glx_pointnet_feat_f16x2_pair(const float* points, int B, int Cin,
     GLX_HIP(hipFuncSetAttribute((const void*)k_pointnet_feat_f16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     GLX_HIP(hipFuncSetAttribute((const void*)k_pointnet_feat_f16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
+  }
+  if (g_pointnet_w_stationary) {
+    const size_t ldw = pointnet_feat_f16w_lds_bytes();
+    static bool attr_w = false;
+    if (!attr_w) {
+      GLX_HIP(hipFuncSetAttribute((const void*)k_pointnet_feat_f16w<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldw));
+      GLX_HIP(hipFuncSetAttribute((const void*)k_pointnet_feat_f16w<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldw));
+      attr_w = true;
+    }
+    const int gw = B < glx_num_cus() ? B : glx_num_cus();          // one block per CU (LDS), each walks over its objects
+    if (narrow)
+      hipLaunchKernelGGL(k_pointnet_feat_f16w<true>, dim3(gw), dim3(PNW_THREADS), ldw, (hipStream_t)stream, points, B, Cin, P, W1, b1,
+                         (const uint4*)W2h, ew2, b2, (const uint4*)W3h, ew3, b3, out, narrow, narrow_out);
+    else
+      hipLaunchKernelGGL(k_pointnet_feat_f16w<false>, dim3(gw), dim3(PNW_THREADS), ldw, (hipStream_t)stream, points, B, Cin, P, W1, b1,
+                         (const uint4*)W2h, ew2, b2, (const uint4*)W3h, ew3, b3, out, (const float*)nullptr, (float*)nullptr);
+    GLX_LAUNCH_CHECK();
+    return GLX_OK;
   }
   if (narrow)
     hipLaunchKernelGGL(k_pointnet_feat_f16<true>, dim3(B), dim3(PN_THREADS), lds, (hipStream_t)stream, points, Cin, P, W1, b1,

@@ -1043,6 +1043,10 @@ int glx_pointnet_feat_f16x2(const float* points, int B, int Cin, int P, const fl
 int glx_pointnet_feat_f16x2_pair(const float* points, int B, int Cin, int P, const float* W1, const float* b1, const void* W2h,
                                  const int32_t* ew2, const float* b2, const void* W3h, const int32_t* ew3, const float* b3,
                                  float* out, const float* narrow, float* narrow_out, void* stream);
+/* Which kernel the f16 x 2 extractor entries launch: 1 (default) keeps W3 in registers and passes the points through LDS (eight waves per
+ * object), 0 streams W3 through an LDS ring (four waves per object).  Same arithmetic, same results bit for bit; returns the previous
+ * setting.  For measurements (tools/sampler_time.py). */
+int glx_pointnet_feat_set_form(int w_stationary);
 /* The two data terms of the CVAE's training loss with their gradients in one launch (cvae_uncertainty/model.py:296-345 reg_loss: code-
  * weighted smooth-L1 with the sin-difference heading + TWICE the direction cross-entropy, see dense_path.cvae_reg_loss; model.py:205-212:
  * KL(posterior || prior) of diagonal Gaussians with scale = exp(logvar) + 3e-22, mean over the batch).  out (3) = loss_loc, loss_dir,

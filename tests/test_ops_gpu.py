@@ -669,6 +669,66 @@ def test_rows128_affine_f16x2_against_fp64(dev):
     assert float(((y2.double() - (want - init.double())).abs() / mag).max()) < 2.0 ** -17
 
 
+@pytest.mark.parametrize("cin,P,B", [(4, 17, 3), (4, 64, 2), (3, 65, 5), (8, 129, 1), (4, 512, 300), (5, 191, 259)])
+def test_pointnet_feat_f16x2_register_resident_form_against_the_streamed_one(dev, cin, P, B):
+    """The two kernels behind glx_pointnet_feat_f16x2(_pair) -- W3 in registers with the points through LDS (the default) and W3
+    streamed through an LDS ring -- on objects of one, two and many half-passes of 64 points (P = 17: one, mostly padding; 65: the
+    second holds one point), fewer objects than CUs and more (a block walks over several objects, 300 and 259 are not multiples of
+    anything), 3 .. 8 point features (8: two k-steps in layer 1), with and without the narrow extractor riding along: against the
+    modules in fp64 to 2^-17 of the contraction's scale, and against each other to the rounding of layer 1 (fp32 MFMA sums in one form,
+    an FMA chain in the other)."""
+    from glenet_amd import _lib, dense_path as dp
+    torch.manual_seed(cin * 1000 + P)
+    m = dp.CVAE(cin, 8).to(dev).eval()
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.copy_((torch.randn(mod.num_features, generator=g) * 0.2).to(dev))
+                mod.running_var.copy_((torch.rand(mod.num_features, generator=g) + 0.5).to(dev))
+                mod.weight.copy_((torch.rand(mod.num_features, generator=g) - 0.3).to(dev))
+                mod.bias.copy_((torch.randn(mod.num_features, generator=g) * 0.1).to(dev))
+        fe = m.x_encoder.fe
+        pts = torch.randn(B, cin, P, device=dev)
+        pts[0] *= 50.0
+        w1, b1, _, b2, _, b3 = fe._packed()
+        w2h, e2, w3h, e3 = fe._packed_f16()
+        narrow, _ = m._sample_pack()
+        out = {}
+        lib = _lib.load()
+        for form in (1, 0):
+            before = lib.glx_pointnet_feat_set_form(form)
+            try:
+                f512, f8 = torch.full((B, 512), 7.0, device=dev), torch.full((B, 8), 7.0, device=dev)
+                _lib.call("glx_pointnet_feat_f16x2_pair", pts, B, cin, P, w1, b1, w2h, e2, b2, w3h, e3, b3, f512, narrow, f8)
+                alone = torch.full((B, 512), 7.0, device=dev)
+                _lib.call("glx_pointnet_feat_f16x2", pts, B, cin, P, w1, b1, w2h, e2, b2, w3h, e3, b3, alone)
+                torch.cuda.synchronize()
+            finally:
+                lib.glx_pointnet_feat_set_form(before)
+            assert torch.equal(alone, f512), form                  # the narrow extractor does not disturb the wide one
+            out[form] = (f512.double(), f8.double())
+        assert before == 1                                          # the register-resident form is the default
+        fd = copy.deepcopy(fe).double()
+        xd = pts.double()
+        z = torch.relu(fd.bn1(fd.conv1(xd)))
+        z = torch.relu(fd.bn2(fd.conv2(z)))
+        y = fd.bn3(fd.conv3(z))
+        ref = y.max(dim=2)[0]
+        w3 = (fd.conv3.weight[:, :, 0] * (fd.bn3.weight / torch.sqrt(fd.bn3.running_var + fd.bn3.eps))[:, None]).abs()
+        mag = torch.einsum("oc,bcp->bop", w3, z.abs()).amax(dim=2) + y.abs().amax(dim=2)
+        nd = copy.deepcopy(m.obj_encoder.fe).double()
+        zn = torch.relu(nd.bn1(nd.conv1(xd)))
+        zn = torch.relu(nd.bn2(nd.conv2(zn)))
+        ref8 = nd.bn3(nd.conv3(zn)).max(dim=2)[0]
+    for form in (1, 0):
+        err = ((out[form][0] - ref).abs() / mag.clamp_min(1e-30)).max().item()
+        assert err < 2.0 ** -17, (form, err)
+        np.testing.assert_allclose(out[form][1].cpu().numpy(), ref8.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    between = ((out[1][0] - out[0][0]).abs() / mag.clamp_min(1e-30)).max().item()
+    assert between < 2.0 ** -19, between
+
+
 @pytest.mark.parametrize("bins,cin", [(2, 4), (3, 5)])
 def test_cvae_two_launch_sampler_equals_the_modules(dev, bins, cin):
     """CVAE.sample's fused path (glx_pointnet_feat_f16x2_pair + glx_cvae_sample_tail) against the same model module by module

@@ -11,6 +11,9 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     if len(sys.argv) > 2 and sys.argv[2] == "modules":        # the decoder module by module behind the extractors' kernels
         dp.CVAE.FUSED_SAMPLER = False
+    if os.environ.get("GLX_POINTNET_FORM"):                   # 0: W3 through the LDS ring, 1: W3 in registers
+        from glenet_amd import _lib
+        _lib.load().glx_pointnet_feat_set_form(int(os.environ["GLX_POINTNET_FORM"]))
     dev = torch.device("cuda:0")
     torch.manual_seed(1)
     pts = torch.from_numpy(synth.cvae_objects(4096, 2000, 512, with_labels=True)[0]).to(dev)
