@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak
+MFMA_F16_SUSTAINED_FRAC = 0.693  # profiles/r06_mfma_ceiling.md: v_mfma_f32_16x16x32_f16 back to back on random operand bits, of nominal
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (2.4 GHz; loops on random data hold 1.5-1.95 GHz)
 FRAMES_PER_GPU = 4
 BATCH_POOL = 8               # distinct batches per rank; rank 0 at N = 1: frames 0..31 = seeds 1000..1031
@@ -233,6 +234,13 @@ def roofline_of(per, prof_steps):
                             "bits per product, fp32 sums); mfma_frac is of a third of the dense 16-bit peak"
                             if f16 else "fp32: v_mfma_f32_16x16x4_f32, exact products; mfma_frac is of the fp32 matrix peak"),
                 frac_of_fp32_mfma_peak=round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
+                # `peak` is the guide's nominal rate.  Measured on this part (tools/experiments/mfma_peak.hip, profiles/
+                # r06_mfma_ceiling.md): back-to-back v_mfma_f32_16x16x32_f16 sustains 0.94-0.98 of it on regular operands and 0.693 of
+                # it on operands with random bits (bf16: 0.73; the fp32 instruction: 0.97), the same for one and two waves per SIMD
+                mfma_sustained=(dict(frac_of_nominal_on_random_operand_bits=MFMA_F16_SUSTAINED_FRAC,
+                                     mfma_frac_of_sustained=round(mfma_frac / MFMA_F16_SUSTAINED_FRAC, 4),
+                                     source="profiles/r06_mfma_ceiling.md (tools/experiments/mfma_peak.hip), not re-measured by this run")
+                                if f16 else None),
                 hbm=dict(achieved_algorithmic_GBps=round(alg_gbs, 1), frac_algorithmic=round(hbm_frac_alg, 4),
                          alg_bytes_per_launch=int(d["bytes"] / n), bytes_min_per_launch=int(bmin),
                          traffic_over_bytes_min=round(traffic / bmin, 3) if traffic else None,

@@ -91,6 +91,57 @@ static void run_step(int waves_per_simd, float* d) {
   printf("layer-3 step pattern, %s operands, point fragments from %s, waves/SIMD %d: %.3f ms  %.1f TFLOP/s  %.3f of 2500\n",
          RANDOM ? "random" : "regular", LDS ? "LDS" : "registers", waves_per_simd, ms, flop / ms * 1e-9, flop / ms * 1e-9 / 2500.0);
 }
+// the other two matrix instructions of the hot path on random operand bits: bf16 (weight gradients, bf16 x 3) and fp32 (rows kernels)
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+template <int KIND>      // 0: v_mfma_f32_16x16x32_bf16, 1: v_mfma_f32_16x16x4_f32
+__global__ __launch_bounds__(512) void k_other(float* out, int iters, int random) {
+  unsigned st = threadIdx.x * 977u + blockIdx.x * 131u + 7u;
+  uint4 A[8], Bv[8];
+  for (int i = 0; i < 8; ++i) {
+    unsigned w[8];
+    for (int c = 0; c < 8; ++c) {
+      const unsigned r = rnd(st), e = rnd(st) >> 9;
+      if (KIND == 0) w[c] = random ? ((r >> 4) & 0x807F807Fu) | ((120u + (e & 15u)) << 7) | ((120u + ((e >> 6) & 15u)) << 23) : 0x3F803F80u;
+      else w[c] = random ? ((r >> 3) & 0x807FFFFFu) | ((120u + (e & 15u)) << 23) : 0x3F800000u;
+    }
+    A[i] = uint4{w[0], w[1], w[2], w[3]};
+    Bv[i] = uint4{w[4], w[5], w[6], w[7]};
+  }
+  f4 acc[4];
+  for (int n = 0; n < 4; ++n) acc[n] = f4{0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        if (KIND == 0)
+          acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, A[i]), __builtin_bit_cast(b8, Bv[(i + n) & 7]), acc[n], 0, 0, 0);
+        else
+          acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, A[i].x), __builtin_bit_cast(float, Bv[(i + n) & 7].y), acc[n], 0, 0, 0);
+      }
+  }
+  float sum = 0.f;
+  for (int n = 0; n < 4; ++n) sum += acc[n][0] + acc[n][1] + acc[n][2] + acc[n][3];
+  if (sum == 12345.678f) out[0] = sum;
+}
+template <int KIND>
+static void run_other(int waves_per_simd, int random, float* d) {
+  const int iters = 20000, blocks = 256, threads = 64 * 4 * waves_per_simd;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(k_other<KIND>, dim3(blocks), dim3(threads), 0, 0, d, 10, random);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(k_other<KIND>, dim3(blocks), dim3(threads), 0, 0, d, iters, random);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double k = KIND == 0 ? 32 : 4, nominal = KIND == 0 ? 2500.0 : 157.3;
+  const double flop = (double)blocks * (threads / 64) * iters * 32.0 * 16 * 16 * k * 2;
+  printf("%s, %s operands, waves/SIMD %d: %.3f ms  %.1f TFLOP/s  %.3f of %.1f\n", KIND == 0 ? "v_mfma_f32_16x16x32_bf16" : "v_mfma_f32_16x16x4_f32",
+         random ? "random" : "regular", waves_per_simd, ms, flop / ms * 1e-9, flop / ms * 1e-9 / nominal, nominal);
+}
 template <int NACC>
 static void run(int waves_per_simd, float* d) {
   const int iters = 20000, blocks = 256, threads = 64 * 4 * waves_per_simd;
@@ -116,6 +167,7 @@ int main() {
     run<8>(1, d); run<8>(2, d);
     run_step<0, 0>(1, d); run_step<0, 0>(2, d); run_step<1, 0>(1, d); run_step<1, 0>(2, d);
     run_step<1, 1>(1, d); run_step<1, 1>(2, d);
+    run_other<0>(2, 0, d); run_other<0>(2, 1, d); run_other<1>(2, 0, d); run_other<1>(2, 1, d);
   }
   return 0;
 }
