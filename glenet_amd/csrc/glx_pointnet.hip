@@ -1571,6 +1571,219 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   }
 }
 
+// The same pass in the organisation of k_pointnet_feat_f16w (W3's fragments resident in the registers of eight waves that walk over
+// objects, the rows through LDS in half-passes of 64, preparers and multipliers meeting through per-wave counts): preparing is light
+// here -- a wave's 16 rows arrive by LDS-DMA one turn ahead (8 KB per wave: with the staging area there is room for two buffers of
+// planes, not three), take the BatchNorm in front on the way, their power of two, and leave as two fp16 planes.  The multiplying side
+// keeps the point index beside each running maximum.  Same results as k_pointmax_fwd_f16 bit for bit (the same products in the
+// same order per accumulator; maxima and ties do not depend on who looks at them).
+#define PMW_BUFS 2
+__global__ __launch_bounds__(PNW_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pointmax_fwd_f16w(
+    const float* __restrict__ h2, int B, int P, const uint4* __restrict__ W3h, const int* __restrict__ ew3, float* __restrict__ vext,
+    int* __restrict__ aext, const float* __restrict__ pre) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  uint4* s_y = reinterpret_cast<uint4*>(smem);               // [buffer 2][point tile 4][k-step 4][plane 2][lane 64]      (64 KB)
+  uint4* s_in = s_y + PMW_BUFS * 4 * 4 * 2 * 64;             // [wave 8][channel tile 8][lane 64]: a wave's next 16 rows    (64 KB)
+  int* s_e3 = reinterpret_cast<int*>(s_in + 8 * 8 * 64);     // 512: MINUS the rows' exponents
+  float* s_pre = reinterpret_cast<float*>(s_e3 + PN_C3);     // 2 x 128
+  int* s_ex = reinterpret_cast<int*>(s_pre + 2 * PN_C2);     // [buffer 2][64]: MINUS the exponents of the half-pass's rows
+  int* s_pa = s_ex + PMW_BUFS * 64;                          // [wave 8]: half-passes prepared, [wave 8]: half-passes multiplied
+  int* s_pb = s_pa + 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, q = lane >> 4, grp = wave >> 2, wt = wave & 3;
+
+  for (int e = tid; e < PN_C3; e += PNW_THREADS) s_e3[e] = -ew3[e];
+  if (pre && tid < 2 * PN_C2) s_pre[tid] = pre[tid];
+  if (tid < 16) s_pa[tid] = 0;
+  pf16x8 Wa[4][4], Wb[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      Wa[a][s] = __builtin_bit_cast(pf16x8, W3h[(((4 * wave + a) * 4 + s) * 2 + 0) * 64 + lane]);
+      Wb[a][s] = __builtin_bit_cast(pf16x8, W3h[(((4 * wave + a) * 4 + s) * 2 + 1) * 64 + lane]);
+    }
+  float mx[4];                                               // lane (j, q): channel 16 (4 wave + a) + j over the points 4 q + e of the tiles
+  int ix[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) { mx[a] = -FLT_MAX; ix[a] = 0; }
+  __syncthreads();
+
+  const int H = (P + 63) >> 6;
+  const int G = __builtin_amdgcn_readfirstlane((int)gridDim.x);
+  const int nobj = ((int)blockIdx.x < B) ? (B - 1 - (int)blockIdx.x) / G + 1 : 0;
+  const int T = nobj * H;
+  const unsigned my_in = __builtin_amdgcn_readfirstlane(pn_lds_addr(s_in + wave * 8 * 64));
+
+  auto stage = [&](int k, int hp) {      // the 16 rows this wave prepares in half-pass hp of object k, on their way into its corner of LDS
+    const long long obj = (long long)blockIdx.x + (long long)k * G;
+    const float* ho = h2 + obj * (long long)P * PN_C2;
+    const unsigned long long xa = (unsigned long long)ho;
+    ho = reinterpret_cast<const float*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xa >> 32)) << 32) |
+                                        (unsigned)__builtin_amdgcn_readfirstlane((int)xa));
+    const int pp = hp * 64 + wt * 16 + j, p = pp < P ? pp : P - 1;
+    const unsigned off = ((unsigned)p * PN_C2 + 4u * q) * 4u;
+#pragma unroll
+    for (int t2 = 0; t2 < 8; ++t2) pn_dma16(ho, off + 64u * t2, my_in + 1024u * t2);
+  };
+  auto produce = [&](int t, int k, int hp) {
+    const int buf = t % PMW_BUFS;
+    __builtin_amdgcn_s_setprio(3);
+    pn_wait_vm<0>();
+    pf32x4 v[8];
+#pragma unroll
+    for (int t2 = 0; t2 < 8; ++t2) v[t2] = __builtin_bit_cast(pf32x4, s_in[(wave * 8 + t2) * 64 + lane]);
+    if (pre) {
+#pragma unroll
+      for (int t2 = 0; t2 < 8; ++t2) {
+        const pf32x4 sc = *reinterpret_cast<const pf32x4*>(s_pre + 16 * t2 + 4 * q);
+        const pf32x4 sh = *reinterpret_cast<const pf32x4*>(s_pre + PN_C2 + 16 * t2 + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[t2][e] = fmaxf(__fmaf_rn(v[t2][e], sc[e], sh[e]), 0.f);
+      }
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int t2 = 0; t2 < 8; ++t2)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[t2][e]));
+    const int ex2 = pn_exponent(pn_point_max(m));
+    const float sc = __builtin_bit_cast(float, (unsigned)(ex2 + 127) << 23);
+    if (q == 0) s_ex[buf * 64 + 16 * wt + j] = -ex2;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      pf16x8 ya, yb;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        _Float16 a, b;
+        pn_split2(v[2 * s + (jj >> 2)][jj & 3] * sc, a, b);
+        ya[jj] = a;
+        yb[jj] = b;
+      }
+      s_y[(((buf * 4 + wt) * 4 + s) * 2 + 0) * 64 + lane] = __builtin_bit_cast(uint4, ya);
+      s_y[(((buf * 4 + wt) * 4 + s) * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, yb);
+    }
+    if (t + 2 < T) {                                         // this wave's next turn (its corner has been read: the values are in registers)
+      int k2 = k, h2p = hp + 2;
+      while (h2p >= H) { h2p -= H; ++k2; }
+      stage(k2, h2p);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(s_pa + wave, (t >> 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto count_min = [&](const int* c, int n) {
+    int m = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int i = 1; i < n; ++i) {
+      const int v = __hip_atomic_load(c + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      m = v < m ? v : m;
+    }
+    return __builtin_amdgcn_readfirstlane(m);
+  };
+
+  if (grp < T) stage(grp >= H ? 1 : 0, grp >= H ? 0 : grp);
+  if (T > 0 && grp == 0) produce(0, 0, 0);
+  int kc = 0, hc = 0;
+  for (int t = 0; t < T; ++t) {
+    if (t + 1 < T && ((t + 1) & 1) == grp) {
+      if (t + 1 >= PMW_BUFS) {
+        while (count_min(s_pb, 8) < t + 2 - PMW_BUFS) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+      produce(t + 1, hc + 1 == H ? kc + 1 : kc, hc + 1 == H ? 0 : hc + 1);
+    }
+    while (count_min(s_pa + 4 * (t & 1), 4) < (t >> 1) + 1) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int buf = t % PMW_BUFS;
+    {
+      const uint4* yl = s_y + buf * (4 * 4 * 2 * 64) + lane;
+      uint4 Yn0 = yl[0], Yn1 = yl[64];
+      pf32x4 acc[2][4];
+      pi32x4 nex[2];
+      auto maxima = [&](int h, int pt) {                     // tile pt's products against the running maxima (ties: the lower point stays)
+        int pidx[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int pp = hc * 64 + pt * 16 + 4 * q + e; pidx[e] = pp < P ? pp : P - 1; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          float bmx = mx[a];
+          int bix = ix[a];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = ldexpf(acc[h][a][e], nex[h][e]);
+            if (v > bmx) { bmx = v; bix = pidx[e]; }
+          }
+          mx[a] = bmx;
+          ix[a] = bix;
+        }
+      };
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) {
+        nex[pt & 1] = *reinterpret_cast<const pi32x4*>(s_ex + buf * 64 + 16 * pt + 4 * q);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const pf16x8 Ya = __builtin_bit_cast(pf16x8, Yn0), Yb = __builtin_bit_cast(pf16x8, Yn1);
+          if (pt * 4 + s + 1 < 16) {
+            Yn0 = yl[((pt * 4 + s + 1) * 2 + 0) * 64];
+            Yn1 = yl[((pt * 4 + s + 1) * 2 + 1) * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+            acc[pt & 1][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ya, Wb[a][s], s == 0 ? pf32x4{0.f, 0.f, 0.f, 0.f} : acc[pt & 1][a], 0, 0, 0);
+#pragma unroll
+          for (int a = 0; a < 4; ++a) acc[pt & 1][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Yb, Wa[a][s], acc[pt & 1][a], 0, 0, 0);
+#pragma unroll
+          for (int a = 0; a < 4; ++a) acc[pt & 1][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ya, Wa[a][s], acc[pt & 1][a], 0, 0, 0);
+          if (s == 0 && pt > 0) maxima((pt - 1) & 1, pt - 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      maxima(1, 3);
+    }
+    const int k = kc;
+    const bool last = hc == H - 1;
+    if (++hc == H) { hc = 0; ++kc; }
+    if (last) {                                              // the object's extremes leave: the four lanes of a channel first
+      const long long obj = (long long)blockIdx.x + (long long)k * G;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int c = 16 * (4 * wave + a) + j;
+        float bmx = ldexpf(mx[a], s_e3[c]);
+        int bix = ix[a];
+        {
+          const unsigned mu = __builtin_bit_cast(unsigned, bmx), iu = (unsigned)bix;
+          const auto sm = __builtin_amdgcn_permlane16_swap(mu, mu, false, false);
+          const auto si = __builtin_amdgcn_permlane16_swap(iu, iu, false, false);
+          const float m0 = __builtin_bit_cast(float, (unsigned)sm[0]), m1 = __builtin_bit_cast(float, (unsigned)sm[1]);
+          const int i0 = (int)si[0], i1 = (int)si[1];
+          const bool first = m0 > m1 || (m0 == m1 && i0 < i1);
+          bmx = first ? m0 : m1;
+          bix = first ? i0 : i1;
+        }
+        {
+          const unsigned mu = __builtin_bit_cast(unsigned, bmx), iu = (unsigned)bix;
+          const auto sm = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+          const auto si = __builtin_amdgcn_permlane32_swap(iu, iu, false, false);
+          const float m0 = __builtin_bit_cast(float, (unsigned)sm[0]), m1 = __builtin_bit_cast(float, (unsigned)sm[1]);
+          const int i0 = (int)si[0], i1 = (int)si[1];
+          const bool first = m0 > m1 || (m0 == m1 && i0 < i1);
+          bmx = first ? m0 : m1;
+          bix = first ? i0 : i1;
+        }
+        if (q == 0) {
+          vext[obj * PN_C3 + c] = bmx;
+          aext[obj * PN_C3 + c] = bix;
+        }
+        mx[a] = -FLT_MAX;
+        ix[a] = 0;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(s_pb + wave, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+
 // vext[b, c] = max_p y[b, p, c], aext = the (lowest) point it occurs at, for y = h2 W^T with W the (512, 128) weight whose f16 x 2
 // image W3h / ew3 is (as glx_pointnet_feat_f16x2 takes it).  A caller that needs the MINIMUM of a channel hands in that row negated.
 extern "C" int glx_pointmax_forward_f16x2(const float* h2, int B, int P, const void* W3h, const int32_t* ew3, float* vext,
@@ -1578,6 +1791,19 @@ extern "C" int glx_pointmax_forward_f16x2(const float* h2, int B, int P, const v
   if (B <= 0) return GLX_OK;
   GLX_REQUIRE(h2 && W3h && ew3 && vext && aext, "glx_pointmax_forward_f16x2: null pointer");
   GLX_REQUIRE(P >= 1, "glx_pointmax_forward_f16x2: P >= 1");
+  if (g_pointnet_w_stationary) {
+    const size_t ldw = (size_t)(PMW_BUFS * 4 * 4 * 2 * 64 + 8 * 8 * 64) * 16 + (size_t)(PN_C3 + 2 * PN_C2 + PMW_BUFS * 64 + 16) * 4;
+    static bool attr_w = false;
+    if (!attr_w) {
+      GLX_HIP(hipFuncSetAttribute((const void*)k_pointmax_fwd_f16w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldw));
+      attr_w = true;
+    }
+    const int gw = B < glx_num_cus() ? B : glx_num_cus();
+    hipLaunchKernelGGL(k_pointmax_fwd_f16w, dim3(gw), dim3(PNW_THREADS), ldw, (hipStream_t)stream, h2, B, P, (const uint4*)W3h, ew3,
+                       vext, (int*)aext, pre_coef);
+    GLX_LAUNCH_CHECK();
+    return GLX_OK;
+  }
   const size_t lds = (size_t)PNH_RING * PNH_SLAB_U4 * 16 + (size_t)(PN_C3 + 2 * 4 * PN_C3 + 2 * PN_C2) * 4;
   static bool attr_set = false;
   if (!attr_set) {

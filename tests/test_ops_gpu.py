@@ -729,6 +729,48 @@ def test_pointnet_feat_f16x2_register_resident_form_against_the_streamed_one(dev
     assert between < 2.0 ** -19, between
 
 
+@pytest.mark.parametrize("P,B,pre", [(17, 3, False), (64, 2, True), (65, 5, True), (512, 300, True), (191, 259, False)])
+def test_pointmax_forward_f16x2_register_resident_form_equals_the_streamed_one(dev, P, B, pre):
+    """The two kernels behind glx_pointmax_forward_f16x2 (W3 in registers with the rows through LDS -- the default --, and W3 streamed
+    through an LDS ring): the same maxima AND the same points bit for bit, on one-, two- and many-half-pass objects, fewer and more
+    objects than CUs, with and without the BatchNorm of the layer in front applied on load, duplicated rows (ties go to the lower
+    point) and a constant object; the maxima against an fp64 product to 2^-17 of the contraction's scale."""
+    from glenet_amd import _lib, dense_path as dp
+    torch.manual_seed(P * 7 + B)
+    h2 = torch.randn(B * P, 128, device=dev)
+    h2[: P] = h2[0]                                    # object 0: every row the same (all ties)
+    if B > 1 and P > 3:
+        h2[P + 3] = h2[P + 1]                          # object 1: a duplicated row
+    w = torch.randn(512, 128, device=dev) * torch.exp2(torch.randint(-6, 7, (512, 1), device=dev).float())
+    w3h, e3 = dp.PointFeat._f16x2_image(w)
+    coef = torch.cat([torch.rand(128, device=dev) + 0.5, torch.randn(128, device=dev) * 0.3]) if pre else None
+    lib = _lib.load()
+    out = {}
+    for form in (1, 0):
+        before = lib.glx_pointnet_feat_set_form(form)
+        try:
+            v = torch.full((B, 512), 3.0, device=dev)
+            a = torch.full((B, 512), -1, device=dev, dtype=torch.int32)
+            _lib.call("glx_pointmax_forward_f16x2", h2, B, P, w3h, e3, v, a, coef)
+            torch.cuda.synchronize()
+        finally:
+            lib.glx_pointnet_feat_set_form(before)
+        out[form] = (v, a)
+    assert torch.equal(out[1][0], out[0][0]) and torch.equal(out[1][1], out[0][1])
+    v, a = out[1]
+    hd = h2.double()
+    if pre:
+        hd = torch.relu(hd * coef[:128].double() + coef[128:].double())
+    y = (hd @ w.double().t()).view(B, P, 512)
+    ref = y.max(dim=1)[0]
+    mag = (hd.abs() @ w.double().abs().t()).view(B, P, 512).amax(dim=1)
+    assert float(((v.double() - ref).abs() / mag.clamp_min(1e-30)).max()) < 2.0 ** -17
+    assert int(a.min()) >= 0 and int(a.max()) < P
+    picked = torch.gather(y, 1, a.long()[:, None, :])[:, 0]          # the value at the reported point is the maximum (to the same bound)
+    assert float(((picked - ref).abs() / mag.clamp_min(1e-30)).max()) < 2.0 ** -16
+    assert int(a[0].max()) == 0                                      # all rows equal: the lowest point
+
+
 @pytest.mark.parametrize("bins,cin", [(2, 4), (3, 5)])
 def test_cvae_two_launch_sampler_equals_the_modules(dev, bins, cin):
     """CVAE.sample's fused path (glx_pointnet_feat_f16x2_pair + glx_cvae_sample_tail) against the same model module by module
