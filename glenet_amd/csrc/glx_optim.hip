@@ -155,6 +155,71 @@ extern "C" int glx_adamw_clip_step_scaled(float* params, const float* grads, flo
   return GLX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ sum of the tensors' 2-norms
+// The regulariser of cvae_uncertainty/model.py:20-28 (`l2_regularisation`: the SUM over a module's parameter tensors of their 2-norms)
+// on a flat parameter buffer whose tensors are the segments segs[i] = (start, length): one block per tensor for the norms (fixed
+// summation order), one block for their sum; and its gradient  coef scale p / |p|  (0 for a zero tensor, as torch's norm backward)
+// added into the flat gradient buffer in one launch -- autograd's form is four elementwise launches per tensor and one more to add
+// the result to the tensor's other gradient.
+__global__ __launch_bounds__(256) void k_seg_norms(const float* __restrict__ p, const long long* __restrict__ segs, float* __restrict__ norms) {
+  __shared__ double red[256];
+  const long long start = segs[2 * blockIdx.x], len = segs[2 * blockIdx.x + 1];
+  double s = 0.0;
+  for (long long i = threadIdx.x; i < len; i += 256) {
+    const double v = (double)p[start + i];
+    s += v * v;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) norms[blockIdx.x] = (float)sqrt(red[0]);
+}
+__global__ void k_seg_norms_sum(const float* __restrict__ norms, int nseg, float scale, float* __restrict__ total) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < nseg; ++i) s += norms[i];          // torch.stack(norms).sum() adds floats too; the order is this one, always
+    total[0] = s * scale;
+  }
+}
+__global__ __launch_bounds__(256) void k_seg_norm_grad(const float* __restrict__ p, const long long* __restrict__ segs, int nseg,
+                                                       const float* __restrict__ norms, const float* __restrict__ coef, float scale,
+                                                       float* __restrict__ grads, long long n) {
+  const float c = (coef ? coef[0] : 1.f) * scale;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    int lo = 0, hi = nseg - 1;                              // the last segment that starts at or before i
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (segs[2 * mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    const long long start = segs[2 * lo], len = segs[2 * lo + 1];
+    if (i < start || i >= start + len) continue;            // alignment padding between tensors
+    const float nm = norms[lo];
+    if (nm > 0.f) grads[i] += c * (p[i] / nm);
+  }
+}
+extern "C" int glx_flat_l2_norms(const float* params, const int64_t* segs, int nseg, float scale, float* norms, float* total,
+                                 void* stream) {
+  if (nseg <= 0) return GLX_OK;
+  GLX_REQUIRE(params && segs && norms && total, "glx_flat_l2_norms: null pointer");
+  hipLaunchKernelGGL(k_seg_norms, dim3(nseg), dim3(256), 0, (hipStream_t)stream, params, (const long long*)segs, norms);
+  hipLaunchKernelGGL(k_seg_norms_sum, dim3(1), dim3(64), 0, (hipStream_t)stream, norms, nseg, scale, total);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+extern "C" int glx_flat_l2_norm_grad_add(const float* params, const int64_t* segs, int nseg, const float* norms, const float* coef,
+                                         float scale, float* grads, int64_t n, void* stream) {
+  if (nseg <= 0 || n <= 0) return GLX_OK;
+  GLX_REQUIRE(params && segs && norms && grads, "glx_flat_l2_norm_grad_add: null pointer");
+  const int blocks = opt_blocks(n);
+  hipLaunchKernelGGL(k_seg_norm_grad, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, (const long long*)segs, nseg, norms,
+                     coef, scale, grads, (long long)n);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ stage stamps
 // One-thread launch that stores the constant 100 MHz wall clock (s_memrealtime) into stamps[slot].  Recorded into a
 // captured step at its stage boundaries it times the stages INSIDE graph replays, where events and the profiler's

@@ -17,6 +17,10 @@ OPTIM_CFG = dict(LR=0.003, WEIGHT_DECAY=0.01, BETAS=(0.9, 0.99), GRAD_NORM_CLIP=
 
 
 class CVAETrainStep:
+    # the weight regulariser (sum of the parameter tensors' 2-norms) and its gradient from the flat buffers: 3 launches instead of
+    # ~330 (four elementwise launches and an accumulation per parameter tensor behind autograd's norm backward)
+    FLAT_REGULARISER = True
+
     def __init__(self, model, batch, num_points, lr=None, grad_clip=OPTIM_CFG["GRAD_NORM_CLIP"], device=None):
         dev = device if device is not None else next(model.parameters()).device
         self.model = model.train()
@@ -32,6 +36,8 @@ class CVAETrainStep:
                                    weight_decay=OPTIM_CFG["WEIGHT_DECAY"], max_norm=grad_clip)
         self.graph = None
         self.loss = self.parts = self.terms = None
+        if self.FLAT_REGULARISER:
+            self.optimizer.after_pack.append(self.optimizer.add_l2_norm_grad)
 
     def load(self, points, gt_boxes_input, gt_boxes, eps=None):
         """Copy one batch into the step's static inputs (eps: the posterior's noise; None = drawn inside the step)."""
@@ -52,9 +58,14 @@ class CVAETrainStep:
         self.model.zero_grad(set_to_none=True)
         if self.draw_eps:
             self.eps.normal_()
-        (reg, lat, regular), parts = self.model.training_losses(self.points, self.cond, self.labels, eps_post=self.eps)
+        flat = self.optimizer if self.FLAT_REGULARISER else None
+        (reg, lat, regular), parts = self.model.training_losses(self.points, self.cond, self.labels, eps_post=self.eps,
+                                                                flat_optimizer=flat)
         loss = reg + lat * self.anneal + regular
-        loss.backward()
+        if flat is None:
+            loss.backward()
+        else:              # the regulariser has no graph: its gradient goes into the flat buffer behind the others (optimizer.after_pack)
+            (reg + lat * self.anneal).backward()
         self.optimizer.step()
         self.loss, self.terms, self.parts = loss.detach(), (reg.detach(), lat.detach(), regular.detach()), parts
         return self.loss

@@ -1988,13 +1988,16 @@ class CVAE(nn.Module):
     # ---- training step (cvae_uncertainty/model.py:205-240, 267-370; train_utils/train_utils.py:50-72)
     LOSS_WEIGHTS = dict(latent_weight=10.0, loc_weight=10.0, dir_weight=0.002, code_weights=(1.0,) * 7)   # cfgs/exp20.yaml
 
-    def training_losses(self, points, gt_boxes_input, gt_boxes, eps_post=None, loss_weights=None):
+    def training_losses(self, points, gt_boxes_input, gt_boxes, eps_post=None, loss_weights=None, flat_optimizer=None):
         """The training branch of Generator.forward + get_training_loss.
         points (B, C, P), gt_boxes_input (B, 8) (the posterior's condition), gt_boxes (B, 7) (regression labels),
         eps_post (B, latent) = the noise of the posterior's reparametrisation (drawn here when None; the reference also
         draws one for the prior, model.py:222, and never uses it).
         -> (reg_loss_post, lattent_loss, regular_loss), parts -- the tuple train_one_epoch sums (after scaling the
-        latent term by its annealing factor, train_utils.py:57-59); parts = device scalars named like the tb_dict."""
+        latent term by its annealing factor, train_utils.py:57-59); parts = device scalars named like the tb_dict.
+        flat_optimizer: an optim.FlatAdamW that owns every parameter -- regular_loss then comes from its flat buffer WITHOUT a
+        graph behind it (two launches), and the caller adds its gradient with `flat_optimizer.add_l2_norm_grad()` after the
+        gradients are packed (cvae_train.CVAETrainStep): the same numbers as autograd's ~5 launches per parameter tensor."""
         w = dict(self.LOSS_WEIGHTS, **(loss_weights or {}))
         post, mu_xy, logvar_xy = self.xy_encoder(points, gt_boxes_input)
         prior, mu_x, logvar_x = self.x_encoder(points)
@@ -2012,8 +2015,12 @@ class CVAE(nn.Module):
         else:
             latent = torch.distributions.kl.kl_divergence(post, prior).mean() * w["latent_weight"]
             reg, parts = cvae_reg_loss(pred, gt_boxes, w, self.dir_offset, self.num_dir_bins)
-        regular = 1e-4 * (l2_regularisation(self.xy_encoder) + l2_regularisation(self.x_encoder)
-                          + l2_regularisation(self.obj_encoder))
+        if flat_optimizer is not None:
+            regular = flat_optimizer.l2_norm_sum(list(self.xy_encoder.parameters()) + list(self.x_encoder.parameters())
+                                                 + list(self.obj_encoder.parameters()), 1e-4)
+        else:
+            regular = 1e-4 * (l2_regularisation(self.xy_encoder) + l2_regularisation(self.x_encoder)
+                              + l2_regularisation(self.obj_encoder))
         parts = dict(parts, box_pred_post=pred)
         return (reg, latent, regular), parts
 

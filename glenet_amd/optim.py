@@ -97,6 +97,7 @@ class FlatAdamW:
         self.grad_scale = 1.0          # the update reads grads * grad_scale: 1 / world_size after a SUM all-reduce
         self._ws = torch.empty(_lib.query("glx_adamw_workspace_bytes"), dtype=torch.uint8, device=dev)
         self._zeros = None
+        self.after_pack = []
 
     @staticmethod
     def _view(flat, offset, p):
@@ -214,10 +215,37 @@ class FlatAdamW:
                 dist.broadcast(buf, src)
         _lib.bump_weights_epoch(self.params)
 
+    def l2_norm_sum(self, params, scale=1.0):
+        """scale * (sum of the 2-norms of `params`, tensors of this optimizer) from the flat parameter buffer, two launches, no
+        autograd (cvae_uncertainty/model.py:20-28); `add_l2_norm_grad` adds the gradient of the last value to flat_grad."""
+        key = tuple(id(p) for p in params)
+        if getattr(self, "_l2_key", None) != key:
+            index = {id(p): i for i, p in enumerate(self.params)}
+            missing = [i for i, p in enumerate(params) if id(p) not in index]
+            if missing:
+                raise ValueError("FlatAdamW.l2_norm_sum: %d tensors are not parameters of this optimizer" % len(missing))
+            order = sorted({index[id(p)] for p in params})
+            segs = [[self.offsets[i], self.params[i].numel()] for i in order]
+            self._l2_segs = torch.tensor(segs, dtype=torch.int64, device=self.flat_param.device)
+            self._l2_norms = torch.zeros(len(segs), dtype=torch.float32, device=self.flat_param.device)
+            self._l2_total = torch.zeros(1, dtype=torch.float32, device=self.flat_param.device)
+            self._l2_key = key
+        self._l2_scale = float(scale)
+        _lib.call("glx_flat_l2_norms", self.flat_param, self._l2_segs, int(self._l2_segs.shape[0]), ctypes.c_float(self._l2_scale),
+                  self._l2_norms, self._l2_total)
+        return self._l2_total[0]
+
+    def add_l2_norm_grad(self, coef=None):
+        """flat_grad += coef * d(l2_norm_sum's last value) / d params (coef: a device scalar, None = 1)."""
+        _lib.call("glx_flat_l2_norm_grad_add", self.flat_param, self._l2_segs, int(self._l2_segs.shape[0]), self._l2_norms, coef,
+                  ctypes.c_float(self._l2_scale), self.flat_grad, ctypes.c_int64(self.n))
+
     def step(self, packed=False):
         """clip + AdamW.  packed=True: flat_grad already holds this step's (exchanged) gradients."""
         if not packed:
             self.pack_grads()
+            for fn in self.after_pack:          # gradient terms that are cheaper to add to the flat buffer than to hand to autograd
+                fn()
         _lib.call("glx_adamw_clip_step_scaled", self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq,
                   ctypes.c_int64(self.n), self.hyper, ctypes.c_float(self.beta2), ctypes.c_float(self.eps),
                   ctypes.c_float(self.weight_decay), ctypes.c_float(self.max_norm), ctypes.c_float(self.grad_scale),

@@ -942,6 +942,16 @@ int glx_adamw_clip_step_scaled(float* params, const float* grads, float* exp_avg
                                float grad_scale, int32_t* step, float* norm_out, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* The CVAE's weight regulariser on a flat parameter buffer (cvae_uncertainty/model.py:20-28 l2_regularisation: the SUM over the
+ * parameter tensors of their 2-norms; train_utils.py:57-59 adds 1e-4 of it to the loss): segs = nseg pairs (start, length) of the
+ * tensors inside params (ascending, disjoint); norms (nseg) <- the tensors' 2-norms, total (1) <- scale * their sum. */
+int glx_flat_l2_norms(const float* params, const int64_t* segs, int nseg, float scale, float* norms, float* total, void* stream);
+/* ... and its gradient added into the flat gradient buffer: grads[i] += coef[0] * scale * params[i] / norms[tensor of i] (nothing for
+ * a zero tensor, as torch's norm backward; coef == NULL: 1) -- the gradient of scale * total, for the loss that added it with the
+ * upstream gradient coef.  n = the length of both buffers. */
+int glx_flat_l2_norm_grad_add(const float* params, const int64_t* segs, int nseg, const float* norms, const float* coef, float scale,
+                              float* grads, int64_t n, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * PV-RCNN set-abstraction operators (same extension module in the reference).
  * ------------------------------------------------------------------------------------ */

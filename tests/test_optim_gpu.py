@@ -47,6 +47,39 @@ def test_flat_adamw_matches_torch(dev, max_norm):
     assert int(opt.step_count) == 6
 
 
+def test_flat_l2_norm_sum_and_its_gradient_equal_autograd(dev):
+    """FlatAdamW.l2_norm_sum / add_l2_norm_grad (csrc/glx_optim.hip: the sum of the parameter tensors' 2-norms from the flat buffer
+    and its gradient added into the flat gradient buffer, three launches) == torch's norms and their autograd gradients: a subset
+    of the tensors, a channels-last tensor, a ZERO tensor (gradient 0, as torch's norm backward), a one-element tensor, with an
+    upstream gradient as a device scalar and on top of gradients that are already in the buffer."""
+    from glenet_amd.optim import FlatAdamW
+    ours, ref = _models(dev)
+    with torch.no_grad():
+        ours[1].zero_()
+        ref[1].zero_()
+    opt = FlatAdamW(ours, lr=1e-3)
+    with torch.no_grad():
+        opt.flat_param[opt.offsets[1]:opt.offsets[1] + 8] = 0          # (the zero tensor and its alignment padding)
+    pick = [0, 1, 3, 4, 6, 7]
+    got = opt.l2_norm_sum([ours[i] for i in pick], 1e-4)
+    want = 1e-4 * torch.stack([ref[i].norm(2) for i in pick]).sum()
+    np.testing.assert_allclose(float(got), float(want.detach()), rtol=2e-6)
+    (2.5 * want).backward()
+    base = torch.randn(opt.n, device=dev) * 1e-5                       # (the size of the term that is added)
+    opt.flat_grad.copy_(base)
+    opt.add_l2_norm_grad(torch.tensor([2.5], device=dev))
+    for i, (v, q) in enumerate(zip(opt.grad_views, ref)):
+        o = opt.offsets[i]
+        b = FlatAdamW._view(base, o, ours[i])
+        if i in pick:
+            np.testing.assert_allclose(v.cpu().numpy(), (b + q.grad).cpu().numpy(), rtol=1e-5, atol=1e-11)
+        else:
+            assert torch.equal(v, b)
+    assert float((opt.grad_views[1] - FlatAdamW._view(base, opt.offsets[1], ours[1])).abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        opt.l2_norm_sum([torch.nn.Parameter(torch.ones(3, device=dev))])
+
+
 def test_flat_adamw_replays_in_a_graph_and_handles_missing_grads(dev):
     from glenet_amd.optim import FlatAdamW
     ours, ref = _models(dev)
