@@ -1537,9 +1537,31 @@ class PointFeat(nn.Module):
                 bn.running_mean.add_(conv.bias, alpha=bn.momentum)
         return (h, pre) if lazy else h
 
+    # one (B P, 16) row matrix of the points for every extractor that runs inside `with PointFeat.shared_rows():` on the same
+    # points tensor (the CVAE's three extractors: the transposition and the zero padding to the row kernels' 16 columns are 0.1 ms
+    # and 170 MB of traffic each)
+    _ROWS_MEMO = None
+
+    @classmethod
+    @contextlib.contextmanager
+    def shared_rows(cls):
+        outer = cls._ROWS_MEMO
+        cls._ROWS_MEMO = {}
+        try:
+            yield
+        finally:
+            cls._ROWS_MEMO = outer
+
     def _forward_train_rows(self, x):
         b, cin, p = x.shape
-        rows = x.transpose(1, 2).reshape(b * p, cin)
+        memo, key = type(self)._ROWS_MEMO, None
+        if memo is not None and not x.requires_grad and cin < 16:
+            key = (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()))
+            rows = memo.get(key)
+            if rows is None:
+                rows = memo[key] = F.pad(x.transpose(1, 2).reshape(b * p, cin), (0, 16 - cin))
+        else:
+            rows = x.transpose(1, 2).reshape(b * p, cin)
         h = self._rows_layer(rows, self.conv1, self.bn1, True)
         pointmax = self.USE_POINTMAX and self.conv2.out_channels == 128 and self.conv3.out_channels == 512 and self.bn3.affine
         # the second layer's BatchNorm + ReLU applied by its consumers on load: h2 (1 GB at configs[3]) is never written
@@ -1999,11 +2021,12 @@ class CVAE(nn.Module):
         graph behind it (two launches), and the caller adds its gradient with `flat_optimizer.add_l2_norm_grad()` after the
         gradients are packed (cvae_train.CVAETrainStep): the same numbers as autograd's ~5 launches per parameter tensor."""
         w = dict(self.LOSS_WEIGHTS, **(loss_weights or {}))
-        post, mu_xy, logvar_xy = self.xy_encoder(points, gt_boxes_input)
-        prior, mu_x, logvar_x = self.x_encoder(points)
-        if eps_post is None:
-            eps_post = torch.randn_like(mu_xy)
-        pred = self.obj_encoder(points, self.reparametrize(mu_xy, logvar_xy, eps_post))
+        with PointFeat.shared_rows():
+            post, mu_xy, logvar_xy = self.xy_encoder(points, gt_boxes_input)
+            prior, mu_x, logvar_x = self.x_encoder(points)
+            if eps_post is None:
+                eps_post = torch.randn_like(mu_xy)
+            pred = self.obj_encoder(points, self.reparametrize(mu_xy, logvar_xy, eps_post))
         if self.FUSED_LOSSES and pred.is_cuda and pred.dtype == torch.float32 and 1 <= self.num_dir_bins <= 9:
             # both data terms and their gradients in one launch (csrc/glx_pointnet.hip, k_cvae_losses)
             loc, dir_loss, latent = CvaeLosses.apply(pred, gt_boxes, mu_xy, logvar_xy, mu_x, logvar_x,
