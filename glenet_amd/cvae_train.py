@@ -36,8 +36,13 @@ class CVAETrainStep:
                                    weight_decay=OPTIM_CFG["WEIGHT_DECAY"], max_norm=grad_clip)
         self.graph = None
         self.loss = self.parts = self.terms = None
-        if self.FLAT_REGULARISER:
-            self.optimizer.after_pack.append(self.optimizer.add_l2_norm_grad)
+        self._regulariser_pending = False       # a flat regulariser value whose gradient has not been added yet
+        self.optimizer.after_pack.append(self._add_regulariser_grad)
+
+    def _add_regulariser_grad(self):
+        if self._regulariser_pending:           # (only behind a step that took the regulariser from the flat buffer)
+            self.optimizer.add_l2_norm_grad()
+            self._regulariser_pending = False
 
     def load(self, points, gt_boxes_input, gt_boxes, eps=None):
         """Copy one batch into the step's static inputs (eps: the posterior's noise; None = drawn inside the step)."""
@@ -66,6 +71,7 @@ class CVAETrainStep:
             loss.backward()
         else:              # the regulariser has no graph: its gradient goes into the flat buffer behind the others (optimizer.after_pack)
             (reg + lat * self.anneal).backward()
+            self._regulariser_pending = True
         self.optimizer.step()
         self.loss, self.terms, self.parts = loss.detach(), (reg.detach(), lat.detach(), regular.detach()), parts
         return self.loss

@@ -247,6 +247,38 @@ def test_cvae_train_step_graph_follows_an_eager_loop(dev):
     assert int(step.optimizer.step_count) == 4
 
 
+def test_cvae_step_regulariser_from_the_flat_buffers_equals_autograds(dev, monkeypatch):
+    """cvae_train.CVAETrainStep with the weight regulariser taken from the optimizer's flat buffers (glx_flat_l2_norms /
+    glx_flat_l2_norm_grad_add, the default) against the same step with it behind autograd: the same loss and, after two eager
+    steps, the same parameters to rounding -- and switching the flag off on a live step does not add a stale gradient."""
+    import copy
+    from glenet_amd import cvae_train as ct
+    torch.manual_seed(3)
+    B, P = 128, 64
+    pts, box8, box7 = (torch.from_numpy(a).to(dev) for a in synth.cvae_objects(B, 7, P, with_labels=True))
+    base = dp.CVAE(4, 8).to(dev).train()
+    eps = torch.randn((B, 8), device=dev)
+    out = {}
+    for flat in (True, False):
+        monkeypatch.setattr(ct.CVAETrainStep, "FLAT_REGULARISER", flat)
+        step = ct.CVAETrainStep(copy.deepcopy(base), B, P, lr=1e-3)
+        step.load(pts, box8, box7, eps)
+        losses = [float(step.enqueue()) for _ in range(2)]
+        if flat:                                   # flag off on the live object: the autograd path, nothing pending behind it
+            monkeypatch.setattr(ct.CVAETrainStep, "FLAT_REGULARISER", False)
+            step.enqueue()
+            assert step._regulariser_pending is False
+            out["third_flat_then_autograd"] = step.optimizer.flat_param.detach().clone()
+        else:
+            step.enqueue()
+            out["third_autograd"] = step.optimizer.flat_param.detach().clone()
+        out[flat] = losses
+        torch.cuda.synchronize()
+    np.testing.assert_allclose(out[True], out[False], rtol=1e-5)
+    a, b = out["third_flat_then_autograd"], out["third_autograd"]
+    assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+
+
 def test_waymo_shaped_full_size_shard(dev):
     """configs[4] per GPU: 2 frames x 180 000 points, 5 features, VoxelResBackBone8x."""
     W = synth.WAYMO
