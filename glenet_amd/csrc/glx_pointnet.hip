@@ -223,6 +223,15 @@ __device__ __forceinline__ void pn_dma4(const void* base_uniform, unsigned off, 
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(off), "s"(base_uniform), "s"(lds_uniform)
                : "memory");
 }
+__device__ __forceinline__ float pn_row_sum(float v) {      // the sum over a row of 16 lanes, in every lane, always in this order
+#define PN_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+  PN_DPP_ADD(0xB1);
+  PN_DPP_ADD(0x4E);
+  PN_DPP_ADD(0x141);
+  PN_DPP_ADD(0x140);
+#undef PN_DPP_ADD
+  return v;
+}
 __device__ __forceinline__ float pn_row_max(float v) {      // the maximum over a row of 16 lanes, in every lane (four DPP steps)
 #define PN_DPP_MAX(ctrl) \
   v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true)))
@@ -1823,41 +1832,50 @@ extern "C" int glx_pointmax_forward_f16x2(const float* h2, int B, int P, const v
 // comes out rows-in-lanes (lane (j, q): channels 16 t + 4 q + e of row j), so the result goes out as 16-byte stores.  Memory-bound:
 // 1 GB in, 1 GB out.
 #define RM_BLOCKS 512
+// SUMS (needs pre): y is a gradient with respect to relu(x scale + shift) and the layer behind x is a BatchNorm: the block's sums over its
+// rows of  dz = [x scale + shift > 0] y  and of  dz x  (x RAW: what that BatchNorm's backward is made of) go to bsum[block][2][128] -- the
+// pass over y and x that would take them afterwards (two reads of a GB each at configs[3]) is not needed.  The raw rows stay in the
+// registers the transformed ones had (the transform is applied where a value is used: twice), and the channel-tile loop is unrolled so
+// that they can be addressed (a load issued inside the loop would return behind the next trip's rows: loads retire in order).
+template <bool SUMS>
 __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_rows128_affine_f16(
     const float* __restrict__ x, long long rows, const uint4* __restrict__ Wh, const int* __restrict__ ew,
-    const float* __restrict__ init, float* __restrict__ y, const float* __restrict__ pre) {
+    const float* __restrict__ init, float* __restrict__ y, const float* __restrict__ pre, float* __restrict__ bsum) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   uint4* s_w = reinterpret_cast<uint4*>(smem);                         // 8 tiles x 4 k-steps x 2 planes x 64 lanes (64 KB)
   int* s_e = reinterpret_cast<int*>(s_w + 8 * 4 * 2 * 64);             // 128: MINUS the rows' exponents
   float* s_i = reinterpret_cast<float*>(s_e + PN_C2);                  // 128: init
   float* s_pre = s_i + PN_C2;                                          // pre != NULL: x is relu(x scale + shift) on load (2 x 128)
+  float* s_sum = s_pre + 2 * PN_C2;                                    // SUMS: [wave 4][2][128]
   if (pre && threadIdx.x < 2 * PN_C2) s_pre[threadIdx.x] = pre[threadIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, q = lane >> 4;
   for (int e = tid; e < 8 * 4 * 2 * 64; e += PN_THREADS) s_w[e] = Wh[e];
   if (tid < PN_C2) { s_e[tid] = -ew[tid]; s_i[tid] = init ? init[tid] : 0.f; }
   __syncthreads();
-  const long long ntrips = (rows + 31) >> 5, stride = (long long)gridDim.x * 4;
+  constexpr int NPT = SUMS ? 1 : 2;        // 16-row tiles per trip (SUMS: one -- the raw rows have to stay in registers beside the pieces)
+  const long long ntrips = (rows + 16 * NPT - 1) / (16 * NPT), stride = (long long)gridDim.x * 4;
   long long trip = (long long)blockIdx.x * 4 + wave;
-  pf32x4 nv[2][8];                         // the next trip's rows, on their way while this one is multiplied
+  pf32x4 nv[NPT][8];                       // the next trip's rows, on their way while this one is multiplied
 #define RM_LOAD(T)                                                                       \
-  _Pragma("unroll") for (int pt = 0; pt < 2; ++pt) {                                     \
-    const long long r0_ = (T) * 32 + pt * 16 + j, r_ = r0_ < rows ? r0_ : rows - 1;      \
+  _Pragma("unroll") for (int pt = 0; pt < NPT; ++pt) {                                   \
+    const long long r0_ = (T) * (16 * NPT) + pt * 16 + j, r_ = r0_ < rows ? r0_ : rows - 1; \
     const float* row_ = x + r_ * PN_C2 + 4 * q;                                          \
     _Pragma("unroll") for (int t = 0; t < 8; ++t) nv[pt][t] = *reinterpret_cast<const pf32x4*>(row_ + 16 * t); \
   }
   if (trip < ntrips) { RM_LOAD(trip) }
+  float bs1[4] = {0.f, 0.f, 0.f, 0.f}, bs2[4] = {0.f, 0.f, 0.f, 0.f};      // SUMS: channels 16 (j & 7) + 4 q + e, over this wave's rows
   for (; trip < ntrips; trip += stride) {
-    pf16x8 Xa[2][4], Xb[2][4];
-    int nex[2];
-    long long rr[2];
-    pf32x4 v[2][8];
+    pf16x8 Xa[NPT][4], Xb[NPT][4];
+    int nex[NPT];
+    long long rr[NPT];
+    pf32x4 v[NPT][8];                      // SUMS: the RAW rows; otherwise the rows as the product takes them
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt)
+    for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         v[pt][t] = nv[pt][t];
-        if (pre) {
+        if (!SUMS && pre) {
           const pf32x4 sc = *reinterpret_cast<const pf32x4*>(s_pre + 16 * t + 4 * q);
           const pf32x4 sh = *reinterpret_cast<const pf32x4*>(s_pre + PN_C2 + 16 * t + 4 * q);
 #pragma unroll
@@ -1865,14 +1883,19 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
       }
     if (trip + stride < ntrips) { RM_LOAD(trip + stride) }
+    // the value the product takes of the raw one (SUMS: transformed where it is used)
+    auto taken = [&](int pt, int t, int e) -> float {
+      if constexpr (SUMS) return fmaxf(__fmaf_rn(v[pt][t][e], s_pre[16 * t + 4 * q + e], s_pre[PN_C2 + 16 * t + 4 * q + e]), 0.f);
+      else return v[pt][t][e];
+    };
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-      rr[pt] = trip * 32 + pt * 16 + j;
+    for (int pt = 0; pt < NPT; ++pt) {
+      rr[pt] = trip * (16 * NPT) + pt * 16 + j;
       float m = 0.f;
 #pragma unroll
       for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[pt][t][e]));
+        for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(taken(pt, t, e)));
       const int ex = pn_exponent(pn_point_max(m));
       nex[pt] = -ex;
       const float sc = __builtin_bit_cast(float, (unsigned)(ex + 127) << 23);
@@ -1881,13 +1904,13 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
           _Float16 a, b;
-          pn_split2(v[pt][2 * s + (jj >> 2)][jj & 3] * sc, a, b);
+          pn_split2(taken(pt, 2 * s + (jj >> 2), jj & 3) * sc, a, b);
           Xa[pt][s][jj] = a;
           Xb[pt][s][jj] = b;
         }
     }
-#pragma unroll 1
-    for (int t = 0; t < 8; ++t) {          // (rolled: unrolled, the 64 fragment reads are hoisted and the registers spill)
+    const bool in0 = rr[0] < rows, in1 = NPT > 1 && rr[NPT - 1] < rows;
+    auto tile = [&](int t, const pf32x4& z0) {
       pf32x4 acc0 = pf32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -1896,20 +1919,59 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wb, Xa[0][s], acc0, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xb[0][s], acc0, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xa[0][s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wb, Xa[1][s], acc1, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xb[1][s], acc1, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xa[1][s], acc1, 0, 0, 0);
+        if constexpr (NPT > 1) {
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wb, Xa[NPT - 1][s], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xb[NPT - 1][s], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wa, Xa[NPT - 1][s], acc1, 0, 0, 0);
+        }
       }
       const int c = 16 * t + 4 * q;
       pf32x4 o0, o1;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         o0[e] = s_i[c + e] + ldexpf(acc0[e], s_e[c + e] + nex[0]);
-        o1[e] = s_i[c + e] + ldexpf(acc1[e], s_e[c + e] + nex[1]);
+        o1[e] = s_i[c + e] + ldexpf(acc1[e], s_e[c + e] + nex[NPT - 1]);
       }
-      if (rr[0] < rows) *reinterpret_cast<pf32x4*>(y + rr[0] * PN_C2 + c) = o0;
-      if (rr[1] < rows) *reinterpret_cast<pf32x4*>(y + rr[1] * PN_C2 + c) = o1;
+      if (in0) *reinterpret_cast<pf32x4*>(y + rr[0] * PN_C2 + c) = o0;
+      if (in1) *reinterpret_cast<pf32x4*>(y + rr[NPT - 1] * PN_C2 + c) = o1;
+      if constexpr (SUMS) {
+        // the ReLU's mask re-derived as every reader of x forms it; the 16 rows of a lane group summed by DPP (fixed order, every
+        // lane of the group then holds the sums), lane j keeps the sums of channel tile j & 7: vector instructions only
+        const pf32x4 sc = *reinterpret_cast<const pf32x4*>(s_pre + c);
+        const pf32x4 sh = *reinterpret_cast<const pf32x4*>(s_pre + PN_C2 + c);
+        const bool mine = (j & 7) == t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d0 = (in0 && __fmaf_rn(z0[e], sc[e], sh[e]) > 0.f) ? o0[e] : 0.f;
+          const float s1 = pn_row_sum(d0), s2 = pn_row_sum(d0 * z0[e]);
+          bs1[e] += mine ? s1 : 0.f;
+          bs2[e] += mine ? s2 : 0.f;
+        }
+      }
+    };
+    if constexpr (SUMS) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        tile(t, v[0][t]);
+        __builtin_amdgcn_sched_barrier(0);   // (or the 64 fragment reads of the eight tiles are hoisted and the registers spill)
+      }
+    } else {
+#pragma unroll 1
+      for (int t = 0; t < 8; ++t) tile(t, v[0][0]);      // (rolled for the same reason; the row argument is not used)
     }
+  }
+  if constexpr (SUMS) {
+    if (j < 8) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s_sum[(wave * 2 + 0) * PN_C2 + 16 * j + 4 * q + e] = bs1[e];
+        s_sum[(wave * 2 + 1) * PN_C2 + 16 * j + 4 * q + e] = bs2[e];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * PN_C2)
+      bsum[(long long)blockIdx.x * 2 * PN_C2 + tid] =
+          ((s_sum[tid] + s_sum[2 * PN_C2 + tid]) + s_sum[4 * PN_C2 + tid]) + s_sum[6 * PN_C2 + tid];
   }
 }
 
@@ -1917,20 +1979,36 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 
 // Wh / ew: the (128 out, 128 in) weight as two fp16 planes of w 2^ew[row] in operand order (dense_path.PointFeat._f16x2_image);
 // init: 128 floats or NULL.  x, y: (rows, 128) fp32, y may not alias x.
+static int rows128_affine_blocks(long long rows, bool sums) {
+  const long long per_trip = sums ? 16 : 32, want = ((rows + per_trip - 1) / per_trip + 3) >> 2;
+  return (int)(want < RM_BLOCKS ? want : RM_BLOCKS);
+}
+extern "C" int glx_rows128_affine_blocks(long long rows) { return rows > 0 ? rows128_affine_blocks(rows, true) : 0; }
+extern "C" int glx_rows128_affine_f16x2_sums(const float* x, long long rows, const void* Wh, const int32_t* ew, const float* init,
+                                             float* y, const float* pre_coef, float* bsum, void* stream);
 extern "C" int glx_rows128_affine_f16x2(const float* x, long long rows, const void* Wh, const int32_t* ew, const float* init,
                                         float* y, const float* pre_coef, void* stream) {
+  return glx_rows128_affine_f16x2_sums(x, rows, Wh, ew, init, y, pre_coef, nullptr, stream);
+}
+extern "C" int glx_rows128_affine_f16x2_sums(const float* x, long long rows, const void* Wh, const int32_t* ew, const float* init,
+                                             float* y, const float* pre_coef, float* bsum, void* stream) {
   if (rows <= 0) return GLX_OK;
   GLX_REQUIRE(x && Wh && ew && y, "glx_rows128_affine_f16x2: null pointer");
-  const size_t lds = (size_t)8 * 4 * 2 * 64 * 16 + (size_t)4 * PN_C2 * 4;
+  GLX_REQUIRE(!bsum || pre_coef, "glx_rows128_affine_f16x2_sums: the sums need the transform in front (pre_coef)");
+  const size_t lds = (size_t)8 * 4 * 2 * 64 * 16 + (size_t)(4 + 8) * PN_C2 * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    GLX_HIP(hipFuncSetAttribute((const void*)k_rows128_affine_f16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GLX_HIP(hipFuncSetAttribute((const void*)k_rows128_affine_f16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GLX_HIP(hipFuncSetAttribute((const void*)k_rows128_affine_f16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  const long long want = (((rows + 31) >> 5) + 3) >> 2;
-  const int blocks = (int)(want < RM_BLOCKS ? want : RM_BLOCKS);
-  hipLaunchKernelGGL(k_rows128_affine_f16, dim3(blocks), dim3(PN_THREADS), lds, (hipStream_t)stream, x, rows, (const uint4*)Wh, ew,
-                     init, y, pre_coef);
+  const int blocks = rows128_affine_blocks(rows, bsum != nullptr);
+  if (bsum)
+    hipLaunchKernelGGL(k_rows128_affine_f16<true>, dim3(blocks), dim3(PN_THREADS), lds, (hipStream_t)stream, x, rows, (const uint4*)Wh,
+                       ew, init, y, pre_coef, bsum);
+  else
+    hipLaunchKernelGGL(k_rows128_affine_f16<false>, dim3(blocks), dim3(PN_THREADS), lds, (hipStream_t)stream, x, rows, (const uint4*)Wh,
+                       ew, init, y, pre_coef, bsum);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
@@ -2598,11 +2676,19 @@ extern "C" int glx_rows128_moments(const float* x, long long rows, double* G, fl
 __global__ __launch_bounds__(PN_THREADS) void k_pointmax_scatter(const int* __restrict__ arg, const float* __restrict__ coef,
                                                                  const float* __restrict__ W3, const float* __restrict__ init,
                                                                  int P, float* __restrict__ dh2, int accumulate,
-                                                                 const float* __restrict__ chan_scale) {
+                                                                 const float* __restrict__ chan_scale, const float* __restrict__ z,
+                                                                 const float* __restrict__ pre, float* __restrict__ bsum) {
+  // bsum != NULL (accumulate mode; z, pre given): dh2 is a gradient with respect to relu(z scale + shift); the object's sums of
+  // [z scale + shift > 0] delta  and of  that times z  over the rows it moves (delta = what this launch adds) go to
+  // bsum[object][2][128] -- the share of the BatchNorm-backward sums that k_rows128_affine_f16's own sums do not contain yet
   __shared__ int s_arg[PN_C3];
   __shared__ float s_coef[PN_C3];
+  __shared__ float s_part[4][4][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long obj = blockIdx.x;
+  float sa1 = 0.f, sa2 = 0.f, sb1 = 0.f, sb2 = 0.f;
+  float sc0 = 0.f, sh0 = 0.f, sc1 = 0.f, sh1 = 0.f;
+  if (bsum) { sc0 = pre[lane]; sc1 = pre[64 + lane]; sh0 = pre[PN_C2 + lane]; sh1 = pre[PN_C2 + 64 + lane]; }
   for (int c = tid; c < PN_C3; c += PN_THREADS) {
     s_arg[c] = arg[obj * PN_C3 + c];
     s_coef[c] = coef[obj * PN_C3 + c] * (chan_scale ? chan_scale[c] : 1.f);
@@ -2618,10 +2704,16 @@ __global__ __launch_bounds__(PN_THREADS) void k_pointmax_scatter(const int* __re
     }
     float* row = dh2 + (obj * P + p) * PN_C2;
     float a0, a1;                          // channels k = lane and lane + 64 of the row
+    float o0 = 0.f, o1 = 0.f, z0 = 0.f, z1 = 0.f;
     if (accumulate) {                      // the rows hold the dense part already: only a row some channel points at moves
       if (!touched) continue;
-      a0 = row[lane];
-      a1 = row[64 + lane];
+      a0 = o0 = row[lane];
+      a1 = o1 = row[64 + lane];
+      if (bsum) {                          // (in the same round trip as the row itself)
+        const float* zr = z + (obj * P + p) * PN_C2;
+        z0 = zr[lane];
+        z1 = zr[64 + lane];
+      }
     } else {
       a0 = init ? init[lane] : 0.f;
       a1 = init ? init[64 + lane] : 0.f;
@@ -2639,15 +2731,70 @@ __global__ __launch_bounds__(PN_THREADS) void k_pointmax_scatter(const int* __re
     }
     row[lane] = a0;
     row[64 + lane] = a1;
+    if (bsum) {
+      if (__fmaf_rn(z0, sc0, sh0) > 0.f) { const float d = a0 - o0; sa1 += d; sa2 += d * z0; }
+      if (__fmaf_rn(z1, sc1, sh1) > 0.f) { const float d = a1 - o1; sb1 += d; sb2 += d * z1; }
+    }
+  }
+  if (bsum) {
+    s_part[wave][0][lane] = sa1; s_part[wave][1][lane] = sb1; s_part[wave][2][lane] = sa2; s_part[wave][3][lane] = sb2;
+    __syncthreads();
+    if (tid < 2 * PN_C2) {        // tid = moment * 128 + channel; channel = 64 half + lane
+      const int k = tid >> 6, l = tid & 63;
+      bsum[obj * 2 * PN_C2 + tid] = ((s_part[0][k][l] + s_part[1][k][l]) + s_part[2][k][l]) + s_part[3][k][l];
+    }
   }
 }
 
+// The BatchNorm backward's vectors from sums that their producers took (k_rows128_affine_f16, k_pointmax_scatter): pa (na, 2, C) and
+// pb (nb, 2, C) hold partial sums of dz (moment 0) and dz z (moment 1, z the BatchNorm's raw input); one block per channel adds them in a
+// fixed order in double and finishes as glx_bn_backward_sums does:  sum dz xhat = invstd (sum dz z - mean sum dz),
+// coef3 = (gamma invstd, sum dz / rows, sum dz xhat / rows), dgamma = sum dz xhat, dbeta = sum dz.
+__global__ __launch_bounds__(256) void k_bn_bwd_from_partials(const float* __restrict__ pa, int na, const float* __restrict__ pb, int nb,
+                                                              int C, double rows, const float* __restrict__ gamma,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ coef3) {
+  __shared__ double red[256];
+  const int c = blockIdx.x, m = threadIdx.x >> 7, t = threadIdx.x & 127;
+  double s = 0.0;
+  for (int i = t; i < na; i += 128) s += (double)pa[((long long)i * 2 + m) * C + c];
+  for (int i = t; i < nb; i += 128) s += (double)pb[((long long)i * 2 + m) * C + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 64; o > 0; o >>= 1) {
+    if (t < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double s1 = red[0], s2z = red[128];
+    const double ss = (double)invstd[c] * (s2z - (double)mean[c] * s1);
+    coef3[c] = (gamma ? gamma[c] : 1.f) * invstd[c];
+    coef3[C + c] = (float)(s1 / rows);
+    coef3[2 * C + c] = (float)(ss / rows);
+    if (dgamma) dgamma[c] = (float)ss;
+    if (dbeta) dbeta[c] = (float)s1;
+  }
+}
+extern "C" int glx_bn_backward_from_partials(const float* pa, int na, const float* pb, int nb, int C, long long rows, const float* gamma,
+                                             const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef3,
+                                             void* stream) {
+  GLX_REQUIRE(C >= 1 && rows >= 1 && mean && invstd && coef3 && (na == 0 || pa) && (nb == 0 || pb),
+              "glx_bn_backward_from_partials: null pointer / empty problem");
+  hipLaunchKernelGGL(k_bn_bwd_from_partials, dim3(C), dim3(256), 0, (hipStream_t)stream, pa, na, pb, nb, C, (double)rows, gamma, mean,
+                     invstd, dgamma, dbeta, coef3);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
 static int pointmax_scatter(const int32_t* arg, const float* coef, const float* W3, const float* init, int B, int P, float* dh2,
-                            int accumulate, void* stream, const float* chan_scale = nullptr) {
+                            int accumulate, void* stream, const float* chan_scale = nullptr, const float* z = nullptr,
+                            const float* pre = nullptr, float* bsum = nullptr) {
   if (B <= 0) return GLX_OK;
   GLX_REQUIRE(arg && coef && W3 && dh2 && P >= 1, "glx_pointmax_scatter: null pointer");
+  GLX_REQUIRE(!bsum || (accumulate && z && pre), "glx_pointmax_scatter: the sums need the accumulating form, z and pre_coef");
   hipLaunchKernelGGL(k_pointmax_scatter, dim3(B), dim3(PN_THREADS), 0, (hipStream_t)stream, (const int*)arg, coef, W3, init, P, dh2,
-                     accumulate, chan_scale);
+                     accumulate, chan_scale, z, pre, bsum);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
@@ -2818,6 +2965,10 @@ extern "C" int glx_pointmax_bn_backward_weight(const float* W3, const double* G,
 extern "C" int glx_pointmax_scatter_add_scaled(const int32_t* arg, const float* coef, const float* chan_scale, const float* W3, int B, int P,
                                                float* dh2, void* stream) {
   return pointmax_scatter(arg, coef, W3, nullptr, B, P, dh2, 1, stream, chan_scale);
+}
+extern "C" int glx_pointmax_scatter_add_scaled_sums(const int32_t* arg, const float* coef, const float* chan_scale, const float* W3, int B,
+                                                    int P, float* dh2, const float* z, const float* pre_coef, float* bsum, void* stream) {
+  return pointmax_scatter(arg, coef, W3, nullptr, B, P, dh2, 1, stream, chan_scale, z, pre_coef, bsum);
 }
 
 // T[c, :] = sum_b g[b, c] * h2[b * P + arg[b, c], :]   (512 x 128): the max's part of the weight gradient.  A wave per

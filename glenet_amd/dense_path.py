@@ -1691,10 +1691,19 @@ class _ZeroGradOperand(torch.autograd.Function):
         return g, torch.zeros_like(ctx.saved_tensors[0])
 
 
+# gradient tensor (data pointer) -> (partial sums of the affine launch, of the scatter launch, data pointer of the raw output they belong
+# to): BatchNorm-backward sums that the producers of a gradient took, for the backward of the lazy row layer in front
+# (pcdet_ops ... voxel_pool_modules.RowsConvBN.backward); one entry, replaced by the next backward pass
+BWD_PARTIALS = {}
+
+
 class PointMaxBN(torch.autograd.Function):
     """out[b, :] = max_p BatchNorm1d(W3 h2[b, p, :] + b3) in training mode (point_net.py:22-28: conv3 + bn3 + max over the
     points) without the (B, P, 512) tensor -- csrc/glx_pointnet.hip, "training twin, layer 3".  h2 (B * P, 128) rows;
     weight (512, 128); returns (B, 512).  Running statistics of `bn` are updated as nn.BatchNorm1d does."""
+
+    # the backward sums of the BatchNorm in front (lazy form: `pre`) taken by the launches that write the gradient (no extra pass)
+    BWD_SUMS_IN_PRODUCERS = True
 
     @staticmethod
     def forward(ctx, h2, weight, bias, gamma, beta, bn, B, P, pre=None):
@@ -1813,8 +1822,19 @@ class PointMaxBN(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 mh, em = PointFeat._f16x2_image(M.t(), scale=-1.0)
                 d_h2 = torch.empty_like(h2)
-                call("glx_rows128_affine_f16x2", h2, ctypes.c_longlong(R), mh, em, nv, d_h2, ctx.pre)
-                call("glx_pointmax_scatter_add_scaled", arg, g, scale, W3, B, P, d_h2)
+                if ctx.pre is not None and PointMaxBN.BWD_SUMS_IN_PRODUCERS:
+                    # h2 is the raw output of the layer in front and d_h2 the gradient behind its BatchNorm + ReLU: the two launches
+                    # that write d_h2 also take that BatchNorm's backward sums; RowsConvBN.backward picks them up (BWD_PARTIALS)
+                    na = int(_lib.load().glx_rows128_affine_blocks(ctypes.c_longlong(R)))
+                    pa = torch.empty((na, 2, 128), dtype=torch.float32, device=dev)
+                    pb = torch.empty((B, 2, 128), dtype=torch.float32, device=dev)
+                    call("glx_rows128_affine_f16x2_sums", h2, ctypes.c_longlong(R), mh, em, nv, d_h2, ctx.pre, pa)
+                    call("glx_pointmax_scatter_add_scaled_sums", arg, g, scale, W3, B, P, d_h2, h2, ctx.pre, pb)
+                    BWD_PARTIALS.clear()
+                    BWD_PARTIALS[d_h2.data_ptr()] = (pa, pb, h2.data_ptr())
+                else:
+                    call("glx_rows128_affine_f16x2", h2, ctypes.c_longlong(R), mh, em, nv, d_h2, ctx.pre)
+                    call("glx_pointmax_scatter_add_scaled", arg, g, scale, W3, B, P, d_h2)
             if ctx.needs_input_grad[1]:
                 T = torch.empty_like(W3)
                 ws = torch.empty(query("glx_pointmax_wsum_workspace_bytes"), dtype=torch.uint8, device=dev)

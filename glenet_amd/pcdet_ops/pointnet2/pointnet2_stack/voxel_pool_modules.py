@@ -4,6 +4,8 @@ submodule names (groupers / mlps_in / mlps_pos / mlps_out, so checkpoints load) 
 signature; the query + grouping run on glenet_amd kernels."""
 import os
 
+import ctypes
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -296,8 +298,16 @@ class RowsConvBN(torch.autograd.Function):
         coef3 = torch.empty(3 * cout, dtype=torch.float32, device=dev)
         dgamma = torch.empty(cout, dtype=torch.float32, device=dev)
         dbeta = torch.empty(cout, dtype=torch.float32, device=dev)
-        _lib.call("glx_bn_backward_sums", z, dy, rows, cout, gamma, beta, mean, invstd, 1 if ctx.relu else 0, dgamma, dbeta,
-                  ctx.count, coef3, core._bn_state(dev))
+        from .... import dense_path
+        taken = dense_path.BWD_PARTIALS.pop(dy.data_ptr(), None)
+        if taken is not None and taken[2] == z.data_ptr() and ctx.relu and ctx.count is None and cout == 128:
+            # the launches that wrote dy took the sums on their way (dense_path.PointMaxBN.backward): no pass over dy and z
+            pa, pb = taken[0], taken[1]
+            _lib.call("glx_bn_backward_from_partials", pa, int(pa.shape[0]), pb, int(pb.shape[0]), cout, ctypes.c_longlong(rows), gamma,
+                      mean, invstd, dgamma, dbeta, coef3)
+        else:
+            _lib.call("glx_bn_backward_sums", z, dy, rows, cout, gamma, beta, mean, invstd, 1 if ctx.relu else 0, dgamma, dbeta,
+                      ctx.count, coef3, core._bn_state(dev))
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gw = None
         if ctx.needs_input_grad[1]:

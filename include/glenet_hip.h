@@ -1185,6 +1185,21 @@ int glx_pointmax_bn_backward_weight(const float* W3, const double* G, const floa
                                     const float* bvec, const float* cvec, const float* mean, float* dW, void* stream);
 int glx_pointmax_scatter_add_scaled(const int32_t* arg, const float* coef, const float* chan_scale, const float* W3, int B, int P,
                                     float* dh2, void* stream);
+/* The BatchNorm-backward sums of the layer in FRONT of the 128 -> 512 layer taken by the two launches that write its output gradient
+ * (cvae_uncertainty/point_net.py:17,24 bn2 behind conv2; autograd would read dh2 and the layer's raw output z once more, 2 GB at
+ * configs[3]).  dh2 is the gradient with respect to relu(z scale + shift) (pre_coef = scale | shift), dz = [z scale + shift > 0] dh2:
+ *   glx_rows128_affine_f16x2_sums: glx_rows128_affine_f16x2 + bsum (glx_rows128_affine_blocks(rows), 2, 128) <- per block the sums of
+ *     dz and dz z over its rows, of the values it writes (x is z here);
+ *   glx_pointmax_scatter_add_scaled_sums: glx_pointmax_scatter_add_scaled + bsum (B, 2, 128) <- per object the same sums of what it ADDS;
+ *   glx_bn_backward_from_partials: pa (na, 2, C) + pb (nb, 2, C) -> what glx_bn_backward_sums hands back (coef3 (3 C) = gamma invstd,
+ *     sum dz / rows, sum dz xhat / rows; dgamma, dbeta), with sum dz xhat = invstd (sum dz z - mean sum dz); fixed summation order. */
+int glx_rows128_affine_blocks(long long rows);
+int glx_rows128_affine_f16x2_sums(const float* x, long long rows, const void* Wh, const int32_t* ew, const float* init, float* y,
+                                  const float* pre_coef, float* bsum, void* stream);
+int glx_pointmax_scatter_add_scaled_sums(const int32_t* arg, const float* coef, const float* chan_scale, const float* W3, int B, int P,
+                                         float* dh2, const float* z, const float* pre_coef, float* bsum, void* stream);
+int glx_bn_backward_from_partials(const float* pa, int na, const float* pb, int nb, int C, long long rows, const float* gamma,
+                                  const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef3, void* stream);
 size_t glx_pointmax_wsum_workspace_bytes(void);
 int glx_pointmax_wsum(const float* g, const int32_t* arg, const float* h2, int B, int P, float* T, void* workspace,
                       size_t workspace_bytes, void* stream);

@@ -96,7 +96,8 @@ def test_cvae_config4_full_size_30_samples(dev):
 
 
 @pytest.mark.parametrize("path", ["default", "library_products", "bias_in_the_product", "fp32_wide_layer", "library_moments",
-                                  "batchnorm_as_tensor_statements", "losses_as_tensor_statements", "h2_written"])
+                                  "batchnorm_as_tensor_statements", "losses_as_tensor_statements", "h2_written",
+                                  "backward_sums_as_a_pass"])
 def test_cvae_training_step_matches_reference_golden_on_device(dev, path, monkeypatch):
     """The training branch on the device (row kernels + fused training BatchNorm) against the reference-generated
     golden of tests/test_dense_path_cpu.py: loss terms, decoder output, every gradient, running statistics -- on the default
@@ -116,6 +117,8 @@ def test_cvae_training_step_matches_reference_golden_on_device(dev, path, monkey
         monkeypatch.setattr(dp.CVAE, "FUSED_LOSSES", False)
     elif path == "h2_written":
         monkeypatch.setattr(dp.PointFeat, "LAZY_H2", False)
+    elif path == "backward_sums_as_a_pass":      # the second layer's BatchNorm-backward sums by glx_bn_backward_sums, not by dh2's producers
+        monkeypatch.setattr(dp.PointMaxBN, "BWD_SUMS_IN_PRODUCERS", False)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cvae_train_ref.npz"))
     m = dp.CVAE(4, 8)
     m.load_state_dict({k[len("cvae/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("cvae/")}, strict=True)
@@ -205,6 +208,57 @@ def test_cvae_fused_losses_equal_the_tensor_statements(dev, bins):
         assert abs(float(a) - float(b)) <= 1e-5 * max(1.0, abs(float(b))), (float(a), float(b))
     for a, b in zip(got, want):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9
+
+
+def test_batchnorm_backward_sums_taken_by_the_gradients_producers(dev):
+    """glx_rows128_affine_f16x2_sums + glx_pointmax_scatter_add_scaled_sums + glx_bn_backward_from_partials against
+    glx_bn_backward_sums on the finished gradient: the same coef3 / dgamma / dbeta to rounding, the gradient itself bit for bit (the sums
+    ride along, they change nothing); rows that no channel points at, objects whose extremes share a row, a channel the ReLU shuts
+    everywhere and a row count that is not a multiple of the kernels' 32."""
+    import ctypes
+    from glenet_amd import _lib
+    from glenet_amd.spconv import core
+    torch.manual_seed(11)
+    B, P = 37, 77
+    R = B * P
+    z = torch.randn(R, 128, device=dev)
+    gamma, beta = torch.rand(128, device=dev) + 0.5, torch.randn(128, device=dev) * 0.3
+    beta[5] = -50.0                                     # channel 5: the ReLU passes nothing
+    mean, var = z.mean(0), z.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    pre = torch.cat([scale, shift]).contiguous()
+    M = torch.randn(128, 128, device=dev) * 0.05
+    mh, em = dp.PointFeat._f16x2_image(M.t(), scale=-1.0)
+    nv = torch.randn(128, device=dev) * 0.1
+    arg = torch.randint(0, P, (B, 512), device=dev, dtype=torch.int32)
+    arg[3] = 7                                          # object 3: every extreme at the same row
+    gext = torch.randn(B, 512, device=dev)
+    cscale = torch.rand(512, device=dev) + 0.5
+    W3 = torch.randn(512, 128, device=dev) * 0.1
+    d_plain = torch.empty_like(z)
+    _lib.call("glx_rows128_affine_f16x2", z, ctypes.c_longlong(R), mh, em, nv, d_plain, pre)
+    _lib.call("glx_pointmax_scatter_add_scaled", arg, gext, cscale, W3, B, P, d_plain)
+    na = int(_lib.load().glx_rows128_affine_blocks(ctypes.c_longlong(R)))
+    pa, pb = torch.full((na, 2, 128), 9.0, device=dev), torch.full((B, 2, 128), 9.0, device=dev)
+    d_sums = torch.empty_like(z)
+    _lib.call("glx_rows128_affine_f16x2_sums", z, ctypes.c_longlong(R), mh, em, nv, d_sums, pre, pa)
+    _lib.call("glx_pointmax_scatter_add_scaled_sums", arg, gext, cscale, W3, B, P, d_sums, z, pre, pb)
+    assert torch.equal(d_plain, d_sums)
+    got = [torch.empty(n, device=dev) for n in (128, 128, 384)]
+    _lib.call("glx_bn_backward_from_partials", pa, na, pb, B, 128, ctypes.c_longlong(R), gamma, mean, invstd, *got)
+    want = [torch.empty(n, device=dev) for n in (128, 128, 384)]
+    _lib.call("glx_bn_backward_sums", z, d_plain, R, 128, gamma, beta, mean, invstd, 1, want[0], want[1], None, want[2],
+              core._bn_state(dev))
+    torch.cuda.synchronize()
+    dz = torch.where(z * scale + shift > 0, d_plain, torch.zeros_like(d_plain)).double()
+    ref_beta, ref_gamma = dz.sum(0), (dz * ((z.double() - mean.double()) * invstd.double())).sum(0)
+    mag = dz.abs().sum(0).clamp_min(1e-30)
+    assert float(got[1][5]) == 0.0 and float(got[0][5]) == 0.0
+    for name, a, b, r in (("dgamma", got[0], want[0], ref_gamma), ("dbeta", got[1], want[1], ref_beta)):
+        assert float(((a.double() - r).abs() / mag).max()) < 2e-6, name           # against fp64
+        assert float(((b.double() - r).abs() / mag).max()) < 2e-6, name
+    np.testing.assert_allclose(got[2].cpu().numpy(), want[2].cpu().numpy(), rtol=1e-4, atol=1e-7)
 
 
 def test_cvae_train_step_graph_follows_an_eager_loop(dev):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-kernel table of the recorded CVAE training step (configs[3], 4096 x 512): gpurun_out/<tag>_cvae_kernels.txt
 R=$GRAFT_REPO_ROOT; TAG=${1:-t}; mkdir -p $R/gpurun_out; cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_cvae_$TAG -o cvae -- python3 $R/tools/cvae_step_run.py > $R/gpurun_out/${TAG}_cvae_trace.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_cvae_$TAG -o cvae -- python3 $R/tools/cvae_step_run.py > $R/gpurun_out/${TAG}_cvae_trace.log 2>&1
 python3 - <<PY
 import csv, collections
 rows = list(csv.DictReader(open("/tmp/p_cvae_$TAG/cvae_kernel_stats.csv")))
