@@ -320,7 +320,12 @@ def bench_bev(model, dev, frames=FRAMES_PER_GPU):
         pieces = {"forward": 3 if arith == "f16x2" else 6, "input_grad": 3 if arith == "f16x2" else 6, "weight_grad": 3 if wform2 else 6}
         entry = {k: dict(us=round(v * 1e3, 1), TFLOPs_fp32_equivalent=round(fl / v / 1e9, 1),
                          frac_of_fp32_mfma_peak=round(fl / v / 1e9 / MFMA_F32_PEAK_TFLOPS, 3), mfma_per_product_tile=pieces[k],
-                         frac_of_16bit_pipe=round(pieces[k] * fl / v / 1e9 / MFMA_BF16_PEAK_TFLOPS, 3)) for k, v in t.items()}
+                         frac_of_16bit_pipe=round(pieces[k] * fl / v / 1e9 / MFMA_BF16_PEAK_TFLOPS, 3),
+                         # ... and of what the pipe sustains on operands with random bits (profiles/r06_mfma_ceiling.md; the bench's
+                         # data is random): the f16 figure for three-MFMA tiles, the bf16 one (0.73) for six-MFMA tiles
+                         frac_of_sustained_16bit_pipe=round(pieces[k] * fl / v / 1e9 / MFMA_BF16_PEAK_TFLOPS
+                                                            / (MFMA_F16_SUSTAINED_FRAC if pieces[k] == 3 else 0.73), 3))
+                 for k, v in t.items()}
         other = "bf16x3" if arith == "f16x2" else "f16x2"
         c2.set_arithmetic(other)                          # the other arithmetic on the same data (packs rebuilt)
         try:
@@ -652,6 +657,8 @@ def bench_config3(dev, objects=4096, points=512, samples=30):
                              objects_per_s=round(objects / (ms_s * 1e-3), 1),
                              TFLOPs=round(samples * sample_flops / ms_s / 1e9, 1),
                              frac_of_16bit_pipe=round(3 * samples * sample_flops / ms_s / 1e9 / MFMA_BF16_PEAK_TFLOPS, 3),
+                             frac_of_sustained_16bit_pipe=round(3 * samples * sample_flops / ms_s / 1e9 / MFMA_BF16_PEAK_TFLOPS
+                                                                / MFMA_F16_SUSTAINED_FRAC, 3),
                              note="two launches per sample (both extractors in one kernel, everything behind them in a second); "
                                   "TFLOPs = the extractors' nominal (fp32-equivalent) flops per second over the whole sampler; "
                                   "frac_of_16bit_pipe counts the three fp16 MFMAs per product tile against the dense 16-bit matrix "
