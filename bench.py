@@ -226,7 +226,7 @@ def roofline_of(per, prof_steps):
                 avg_launch_us=round(d["ms"] * 1e3 / n, 2), launches=n,
                 duration_source="HIP events around the kernel (hipExtLaunchKernelGGL) in an eager pass of configs[1]'s "
                                 "launches, one frame in flight -- `bench.py --roofline-only` runs exactly this pass, "
-                                "its rocprofv3 --kernel-trace --stats summary is profiles/r05v_roofline_kernel_stats.csv (each round keeps its own rNN_roofline_kernel_stats.csv); "
+                                "its rocprofv3 --kernel-trace --stats summary is profiles/r06zz_roofline_kernel_stats.csv (each round keeps its own rNN_roofline_kernel_stats.csv); "
                                 "a full run's rocprof average of the same kernel also covers the training step's "
                                 "forward / input-gradient launches and the two-frames-in-flight replays (~10 % longer)",
                 flops_per_launch=int(d["flops"] / n), mfma_frac=round(mfma_frac, 4),
