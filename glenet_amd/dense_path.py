@@ -1428,6 +1428,10 @@ class PointFeat(nn.Module):
     def forward(self, x):                       # x (B, pts_dim, P)
         if self._fusable(x):
             return self._forward_fused(x)
+        if self._narrow_trainable(x):
+            return NarrowFeatTrain.apply(x, self.conv1.weight, self.conv1.bias, self.bn1.weight, self.bn1.bias, self.conv2.weight,
+                                         self.conv2.bias, self.bn2.weight, self.bn2.bias, self.conv3.weight, self.conv3.bias,
+                                         self.bn3.weight, self.bn3.bias, (self.bn1, self.bn2, self.bn3))
         if self._rows_trainable(x):
             return self._forward_train_rows(x)
         x = F.relu(self.bn1(self.conv1(x)))
@@ -1440,6 +1444,18 @@ class PointFeat(nn.Module):
     # strided GEMMs and four-pass NCL BatchNorms; as rows every layer is ONE hipBLASLt GEMM (MFMA) + the fused
     # statistics / transform kernels of csrc/glx_bn.hip (two launches forward, two backward, ReLU included), and the
     # final max over the points of an object is a reduction over P consecutive rows.
+    # the 8-wide extractor's training pass without intermediate tensors (csrc/glx_narrowfeat.hip): ten launches forward, nine backward,
+    # every pass reads the points only; False: layer by layer on the row kernels (_forward_train_rows)
+    NARROW_FUSED_TRAIN = True
+
+    def _narrow_trainable(self, x):
+        bns = (self.bn1, self.bn2, self.bn3)
+        return (self.NARROW_FUSED_TRAIN and x.is_cuda and self.training and torch.is_grad_enabled() and x.dtype == torch.float32
+                and not x.requires_grad and x.dim() == 3 and x.shape[1] <= 8
+                and self.conv1.out_channels == self.conv2.out_channels == self.conv3.out_channels == 8
+                and all(b.affine and b.momentum is not None and b.track_running_stats and b.eps == bns[0].eps
+                        and b.momentum == bns[0].momentum for b in bns))
+
     def _rows_trainable(self, x):
         from .spconv import core
         ok = lambda c: c % 4 == 0 and c <= 512 and 1024 % c == 0                                # noqa: E731
@@ -1689,6 +1705,52 @@ class _ZeroGradOperand(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g, torch.zeros_like(ctx.saved_tensors[0])
+
+
+class NarrowFeatTrain(torch.autograd.Function):
+    """PointFeat(C, (8, 8, 8)) in training mode on the device without intermediate tensors (csrc/glx_narrowfeat.hip: batch statistics of
+    every BatchNorm from the moments of its input, every pass recomputes the layers in front from the points): x (B, C <= 8, P) -> (B, 8).
+    Running statistics are updated by the launch; the convolutions' biases receive exact zeros (a bias in front of a training BatchNorm
+    only moves the batch mean)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, g3, be3, bns):
+        from .pcdet_ops.pointnet2.pointnet2_stack import voxel_pool_modules as vpm
+        x = x.contiguous()
+        B, C, P = x.shape
+        dev = x.device
+        ws = [w.detach().reshape(8, -1).contiguous().float() for w in (w1, w2, w3)]
+        out = torch.empty((B, 8), dtype=torch.float32, device=dev)
+        arg = torch.empty((B, 8), dtype=torch.int32, device=dev)
+        xh = torch.empty((B, 8), dtype=torch.float32, device=dev)
+        coef = torch.empty((3, 4, 8), dtype=torch.float32, device=dev)
+        wsp = _lib.workspace.get(_lib.query("glx_narrowfeat_workspace_bytes"), dev)
+        for bn in bns:
+            vpm._count(bn)
+        _lib.call("glx_narrowfeat_train_forward", x, B, C, P, ws[0], b1, g1, be1, bns[0].running_mean, bns[0].running_var, ws[1], b2, g2, be2,
+                  bns[1].running_mean, bns[1].running_var, ws[2], b3, g3, be3, bns[2].running_mean, bns[2].running_var,
+                  ctypes.c_float(bns[0].eps), ctypes.c_float(bns[0].momentum), out, arg, xh, coef, wsp, _lib.size_arg(wsp.numel()))
+        _lib.bump_weights_epoch([t for bn in bns for t in (bn.running_mean, bn.running_var)])
+        ctx.save_for_backward(x, ws[0], ws[1], ws[2], coef, arg, xh)
+        ctx.shapes = (w1.shape, w2.shape, w3.shape)
+        ctx.has_bias = (b1 is not None, b2 is not None, b3 is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, w1, w2, w3, coef, arg, xh = ctx.saved_tensors
+        B, C, P = x.shape
+        dev = x.device
+        grads = torch.empty((4, 64), dtype=torch.float32, device=dev)
+        wsp = _lib.workspace.get(_lib.query("glx_narrowfeat_workspace_bytes"), dev)
+        _lib.call("glx_narrowfeat_train_backward", x, B, C, P, w1, w2, w3, coef, gout.contiguous().float(), arg, xh, grads, wsp,
+                  _lib.size_arg(wsp.numel()))
+        dw1 = grads[0].view(8, 8)[:, :C].reshape(ctx.shapes[0])
+        dw2, dw3 = grads[1].view(ctx.shapes[1]), grads[2].view(ctx.shapes[2])
+        v = grads[3]
+        zero = lambda has: torch.zeros(8, dtype=torch.float32, device=dev) if has else None          # noqa: E731
+        return (None, dw1, zero(ctx.has_bias[0]), v[0:8], v[8:16], dw2, zero(ctx.has_bias[1]), v[16:24], v[24:32],
+                dw3, zero(ctx.has_bias[2]), v[32:40], v[40:48], None)
 
 
 # gradient tensor (data pointer) -> (partial sums of the affine launch, of the scatter launch, data pointer of the raw output they belong

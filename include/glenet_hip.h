@@ -942,6 +942,27 @@ int glx_adamw_clip_step_scaled(float* params, const float* grads, float* exp_avg
                                float grad_scale, int32_t* step, float* norm_out, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* The CVAE decoder's small point extractor in TRAINING mode without an intermediate tensor (cvae_uncertainty/point_net.py:31-49
+ * SimPointNetfeat(x = 0.5): Conv1d(C, 8, 1) + BatchNorm1d + ReLU, Conv1d(8, 8, 1) + BatchNorm1d + ReLU, Conv1d(8, 8, 1) + BatchNorm1d, max over
+ * the points; autograd's backward of it).  points (B, C <= 8, P); w1 (8, C), w2, w3 (8, 8) row-major; b*: the convolutions' biases or NULL
+ * (they only move the batch means: running means, zero gradient); gamma / beta: the BatchNorms' affine parameters; rmean / rvar: running
+ * statistics updated with `momentum` (unbiased variance), or NULL.
+ *   forward: out (B, 8) = max_p bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) with BATCH statistics over all B P rows, arg (B, 8) = the
+ *     lowest point it occurs at, xh_ext (B, 8) = the normalised value there, coef (3, 4, 8) = per layer gamma invstd | beta - that * mean |
+ *     mean | invstd of W h (no bias) -- what backward needs again.  Ten launches (three of them one block), every pass reads the points only.
+ *   backward: gout (B, 8) -> grads (4, 64) = dW1 (8 x 8, the first C columns), dW2, dW3, then dgamma1, dbeta1, dgamma2, dbeta2, dgamma3, dbeta3
+ *     (8 each).  Sums: fp32 over a block's rows, double over the blocks, fixed order.
+ * workspace: glx_narrowfeat_workspace_bytes(). */
+size_t glx_narrowfeat_workspace_bytes(void);
+int glx_narrowfeat_train_forward(const float* points, int B, int C, int P, const float* w1, const float* b1, const float* gamma1,
+                                 const float* beta1, float* rmean1, float* rvar1, const float* w2, const float* b2, const float* gamma2,
+                                 const float* beta2, float* rmean2, float* rvar2, const float* w3, const float* b3, const float* gamma3,
+                                 const float* beta3, float* rmean3, float* rvar3, float eps, float momentum, float* out, int32_t* arg,
+                                 float* xh_ext, float* coef, void* workspace, size_t workspace_bytes, void* stream);
+int glx_narrowfeat_train_backward(const float* points, int B, int C, int P, const float* w1, const float* w2, const float* w3,
+                                  const float* coef, const float* gout, const int32_t* arg, const float* xh_ext, float* grads,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+
 /* The CVAE's weight regulariser on a flat parameter buffer (cvae_uncertainty/model.py:20-28 l2_regularisation: the SUM over the
  * parameter tensors of their 2-norms; train_utils.py:57-59 adds 1e-4 of it to the loss): segs = nseg pairs (start, length) of the
  * tensors inside params (ascending, disjoint); norms (nseg) <- the tensors' 2-norms, total (1) <- scale * their sum. */

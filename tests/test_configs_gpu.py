@@ -97,7 +97,7 @@ def test_cvae_config4_full_size_30_samples(dev):
 
 @pytest.mark.parametrize("path", ["default", "library_products", "bias_in_the_product", "fp32_wide_layer", "library_moments",
                                   "batchnorm_as_tensor_statements", "losses_as_tensor_statements", "h2_written",
-                                  "backward_sums_as_a_pass"])
+                                  "backward_sums_as_a_pass", "narrow_extractor_layer_by_layer"])
 def test_cvae_training_step_matches_reference_golden_on_device(dev, path, monkeypatch):
     """The training branch on the device (row kernels + fused training BatchNorm) against the reference-generated
     golden of tests/test_dense_path_cpu.py: loss terms, decoder output, every gradient, running statistics -- on the default
@@ -117,6 +117,8 @@ def test_cvae_training_step_matches_reference_golden_on_device(dev, path, monkey
         monkeypatch.setattr(dp.CVAE, "FUSED_LOSSES", False)
     elif path == "h2_written":
         monkeypatch.setattr(dp.PointFeat, "LAZY_H2", False)
+    elif path == "narrow_extractor_layer_by_layer":      # the decoder's 8-wide extractor on the row kernels, not csrc/glx_narrowfeat.hip
+        monkeypatch.setattr(dp.PointFeat, "NARROW_FUSED_TRAIN", False)
     elif path == "backward_sums_as_a_pass":      # the second layer's BatchNorm-backward sums by glx_bn_backward_sums, not by dh2's producers
         monkeypatch.setattr(dp.PointMaxBN, "BWD_SUMS_IN_PRODUCERS", False)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cvae_train_ref.npz"))
@@ -208,6 +210,47 @@ def test_cvae_fused_losses_equal_the_tensor_statements(dev, bins):
         assert abs(float(a) - float(b)) <= 1e-5 * max(1.0, abs(float(b))), (float(a), float(b))
     for a, b in zip(got, want):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9
+
+
+@pytest.mark.parametrize("cin,B,P", [(4, 37, 77), (5, 3, 300), (8, 600, 16), (3, 1, 1000)])
+def test_narrow_extractor_training_pass_without_intermediates(dev, cin, B, P):
+    """PointFeat(C, (8, 8, 8)) in training mode through csrc/glx_narrowfeat.hip (batch statistics from moments, every pass recomputed
+    from the points) against the same modules in fp64 autograd: the output, every parameter gradient (the convolutions' biases: exact
+    zeros), the running statistics and the batch counters; 3 .. 8 point features, fewer and more objects than the passes' 512 blocks,
+    objects of 16 and 1000 points, duplicated points (ties go to the lower point), a channel the first ReLU shuts."""
+    import copy
+    torch.manual_seed(cin * 31 + B)
+    m = dp.PointFeat(cin, (8, 8, 8)).to(dev).train()
+    with torch.no_grad():
+        for bn in (m.bn1, m.bn2, m.bn3):
+            bn.weight.copy_(torch.rand(8, device=dev) + 0.5)
+            bn.bias.copy_(torch.randn(8, device=dev) * 0.3)
+            bn.running_mean.copy_(torch.randn(8, device=dev) * 0.1)
+            bn.running_var.copy_(torch.rand(8, device=dev) + 0.5)
+        m.bn1.bias[2] = -30.0                          # channel 2 of layer 1: the ReLU passes nothing
+    ref = copy.deepcopy(m).double()
+    x = torch.randn(B, cin, P, device=dev)
+    x[0, :, 1] = x[0, :, 0]                              # a duplicated point
+    gout = torch.randn(B, 8, device=dev)
+    assert m._narrow_trainable(x)
+    out = m(x)
+    (out * gout).sum().backward()
+    yd = ref(x.double())
+    (yd * gout.double()).sum().backward()
+    torch.cuda.synchronize()
+    scale = float(yd.detach().abs().max())
+    assert float((out.double() - yd).abs().max()) < 2e-5 * scale
+    for (name, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        if name.startswith("conv") and name.endswith("bias"):
+            assert float(p.grad.abs().max()) == 0.0, name
+            assert float(q.grad.abs().max()) < 1e-9 * max(1.0, float(gout.abs().sum())), name      # (zero in exact arithmetic)
+            continue
+        tol = 2e-4 * float(q.grad.abs().max()) + 1e-6
+        assert float((p.grad.double() - q.grad).abs().max()) < tol, (name, float((p.grad.double() - q.grad).abs().max()), tol)
+    for bn, bd in ((m.bn1, ref.bn1), (m.bn2, ref.bn2), (m.bn3, ref.bn3)):
+        np.testing.assert_allclose(bn.running_mean.cpu().numpy(), bd.running_mean.float().cpu().numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(bn.running_var.cpu().numpy(), bd.running_var.float().cpu().numpy(), rtol=1e-4, atol=1e-6)
+        assert int(bn.num_batches_tracked) == int(bd.num_batches_tracked) == 1
 
 
 def test_batchnorm_backward_sums_taken_by_the_gradients_producers(dev):
