@@ -665,8 +665,10 @@ def bench_config3(dev, objects=4096, points=512, samples=30):
                                   "peak; ms_per_sample_fp32_mfma = the module-by-module sampler on the fp32-MFMA extractor kernels",
                              frac_of_fp32_mfma_peak_fp32_form=round(samples * sample_flops / ms_s32 / 1e9 / MFMA_F32_PEAK_TFLOPS, 3)),
                 train_step=dict(what="forward (posterior + prior encoders, decoder) + losses + backward + clip 10 + AdamW "
-                                     "(flat buffers), one HIP graph, lr = the one-cycle schedule's first step; the 128 -> 512 "
-                                     "layer's forward as f16 x 2 products, everything else fp32",
+                                     "(flat buffers), one HIP graph, lr = the one-cycle schedule's first step; the 64 -> 128 and "
+                                     "128 -> 512 layers' products as f16 x 2 / bf16 x 3 pieces (>= 20.4 bits, fp32 sums), everything else "
+                                     "fp32; the decoder's 8-wide extractor without intermediate tensors (csrc/glx_narrowfeat.hip), the "
+                                     "weight regulariser from the optimizer's flat buffers",
                                 ms_per_step=round(ms_t, 2),
                                 objects_per_s=round(objects / (ms_t * 1e-3), 1), loss=round(loss, 4),
                                 gflop_per_step=round(3 * objects * per_obj / 1e9, 1),
