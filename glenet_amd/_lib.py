@@ -46,7 +46,7 @@ def load():
                  "glx_deconv_packed_bytes", "glx_deconv_wgrad_workspace_bytes", "glx_pair_lists_bytes",
                  "glx_sconv_wgrad_pairs_workspace_bytes", "glx_pointmax_wsum_workspace_bytes", "glx_rows128_moments_workspace_bytes", "glx_rows_bwd_64_128_workspace_bytes",
                  "glx_head1x1_wgrad_workspace_bytes", "glx_topk_workspace_bytes", "glx_fc_tower_scratch_bytes",
-                 "glx_bn_cm_workspace_bytes", "glx_rows_linear_workspace_bytes", "glx_narrowfeat_workspace_bytes"):
+                 "glx_bn_cm_workspace_bytes", "glx_rows_linear_workspace_bytes", "glx_narrowfeat_workspace_bytes", "glx_point_layer1_workspace_bytes", "glx_flat_l2_workspace_bytes"):
         if hasattr(lib, name):
             getattr(lib, name).restype = c_size_t
     lib.glx_index_words.restype = c_int64

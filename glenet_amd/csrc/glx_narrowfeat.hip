@@ -525,3 +525,216 @@ extern "C" int glx_narrowfeat_train_backward(const float* points, int B, int C, 
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }
+
+// ================================================================================================ the wide extractors' first layer
+// Conv1d(C, 64, 1) + BatchNorm1d + ReLU of PointNetfeat (cvae_uncertainty/point_net.py:10-16) in training mode, in the same manner: the
+// batch statistics of W1 x from the mean and covariance of x (k_narrow_pass<0>'s 44 sums), ONE pass that reads the points and writes
+// h1 = relu(A (W1 x) + Cc) as (B P, 64) rows (the row kernels in front wrote the raw product, read it back for the statistics' transform and
+// wrote h1: 0.38 ms per extractor at configs[3], 0.11 here), and for the backward ONE pass over the gradient of h1 that takes, per
+// channel, sum dq, sum dq xhat and sum dq (x) x (dq = the gradient where the ReLU passes; mask and xhat recomputed from the point): the
+// weight gradient follows from those and the moments of x,
+//   dW[c][i] = A_c (sum dq_c x_i - (dbeta_c / N) sum x_i - (dgamma_c / N) is_c (W_c . M[:, i] - m_c sum x_i)),   M = sum x x^T.
+#define L1_W 64
+#define L1_NV (L1_W * (2 + NF_W))        // per channel: dbeta, dgamma, 8 products with x
+#define L1_BLOCKS 2048                   // of the backward pass (a streaming read: eight blocks per CU)
+
+__global__ void k_l1_coef(const double* __restrict__ T, int B, int C, int P, const float* __restrict__ w, const float* __restrict__ bias,
+                          const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
+                          float* __restrict__ rvar, float eps, float momentum, float* __restrict__ coef) {
+  const int c = threadIdx.x;          // 64 threads
+  const double N = (double)B * (double)P;
+  double mean[NF_W];
+  for (int k = 0; k < C; ++k) mean[k] = T[k] / N;
+  double mu = 0.0, var = 0.0;
+  for (int k = 0; k < C; ++k) mu += (double)w[c * C + k] * mean[k];
+  for (int k = 0; k < C; ++k)
+    for (int l = k; l < C; ++l) {
+      const double cov = T[NF_W + k * NF_W - k * (k - 1) / 2 + (l - k)] / N - mean[k] * mean[l];
+      var += (k == l ? 1.0 : 2.0) * (double)w[c * C + k] * (double)w[c * C + l] * cov;
+    }
+  if (var < 0.0) var = 0.0;
+  const float inv = (float)(1.0 / sqrt(var + (double)eps));
+  const float A = gamma[c] * inv;
+  coef[c] = A;
+  coef[L1_W + c] = beta[c] - A * (float)mu;
+  coef[2 * L1_W + c] = (float)mu;
+  coef[3 * L1_W + c] = inv;
+  if (rmean) {
+    const double unb = N > 1.0 ? var * N / (N - 1.0) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * ((float)mu + (bias ? bias[c] : 0.f));
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+  }
+}
+
+// 16 lanes per row, four channels per lane: a wave instruction writes (reads) four whole rows of h1 (of its gradient)
+template <bool BWD, int CW>      // CW: 4 or 8 point features at most (the loops' trip counts)
+__global__ __launch_bounds__(NF_THREADS) void k_l1_rows(const float* __restrict__ x, int B, int C, int P, const float* __restrict__ w,
+                                                        const float* __restrict__ coef, float* __restrict__ h1,
+                                                        const float* __restrict__ dh1, float* __restrict__ partial) {
+  const int tid = threadIdx.x, cq = tid & 15, slot = tid >> 4;
+  float wr[4][CW], A[4], Cc[4], m[4], is[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = 4 * cq + e;
+#pragma unroll
+    for (int k = 0; k < CW; ++k) wr[e][k] = k < C ? w[c * C + k] : 0.f;
+    A[e] = coef[c]; Cc[e] = coef[L1_W + c]; m[e] = coef[2 * L1_W + c]; is[e] = coef[3 * L1_W + c];
+  }
+  float sb[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f}, sx[4][CW];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int k = 0; k < CW; ++k) sx[e][k] = 0.f;
+  for (long long b = blockIdx.x; b < B; b += gridDim.x)          // a block walks over whole objects (no division per row)
+  for (int p = slot; p < P; p += 16) {
+    const long long r = b * P + p;
+    const float* xo = x + b * C * P + p;
+    float xv[CW];
+#pragma unroll
+    for (int k = 0; k < CW; ++k) xv[k] = k < C ? xo[(long long)k * P] : 0.f;
+    float u[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < CW; ++k) s = fmaf(wr[e][k], xv[k], s);
+      u[e] = s;
+    }
+    if constexpr (!BWD) {
+      float4 o;
+      o.x = fmaxf(fmaf(A[0], u[0], Cc[0]), 0.f);
+      o.y = fmaxf(fmaf(A[1], u[1], Cc[1]), 0.f);
+      o.z = fmaxf(fmaf(A[2], u[2], Cc[2]), 0.f);
+      o.w = fmaxf(fmaf(A[3], u[3], Cc[3]), 0.f);
+      *reinterpret_cast<float4*>(h1 + r * L1_W + 4 * cq) = o;
+    } else {
+      const float4 g4 = *reinterpret_cast<const float4*>(dh1 + r * L1_W + 4 * cq);
+      const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dq = fmaf(A[e], u[e], Cc[e]) > 0.f ? g[e] : 0.f;
+        sb[e] += dq;
+        sg[e] = fmaf(dq, (u[e] - m[e]) * is[e], sg[e]);
+#pragma unroll
+        for (int k = 0; k < CW; ++k) sx[e][k] = fmaf(dq, xv[k], sx[e][k]);
+      }
+    }
+  }
+  if constexpr (BWD) {
+    // the 16 row slots of the block: lanes 16 apart inside a wave (register-half swaps), then the four waves through LDS
+    __shared__ float s_red[NF_THREADS / 64][16][4 * (2 + NF_W)];
+    const int lane = tid & 63, wave = tid >> 6;
+    auto quad = [&](float v) {
+      const unsigned u_ = __builtin_bit_cast(unsigned, v);
+      const auto s16 = __builtin_amdgcn_permlane16_swap(u_, u_, false, false);
+      v = __builtin_bit_cast(float, (unsigned)s16[0]) + __builtin_bit_cast(float, (unsigned)s16[1]);
+      const unsigned w_ = __builtin_bit_cast(unsigned, v);
+      const auto s32 = __builtin_amdgcn_permlane32_swap(w_, w_, false, false);
+      return __builtin_bit_cast(float, (unsigned)s32[0]) + __builtin_bit_cast(float, (unsigned)s32[1]);
+    };
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float vb = quad(sb[e]), vg = quad(sg[e]);
+      if (lane < 16) { s_red[wave][cq][e * (2 + NF_W) + 0] = vb; s_red[wave][cq][e * (2 + NF_W) + 1] = vg; }
+#pragma unroll
+      for (int k = 0; k < NF_W; ++k) {
+        const float vx = k < CW ? quad(sx[e][k < CW ? k : 0]) : 0.f;
+        if (lane < 16) s_red[wave][cq][e * (2 + NF_W) + 2 + k] = vx;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < L1_NV; i += NF_THREADS) {          // i = channel * 10 + j, channel = 4 cq + e
+      const int c = i / (2 + NF_W), jj = i - c * (2 + NF_W);
+      const int q_ = c >> 2, e = c & 3;
+      float t = 0.f;
+      for (int w_ = 0; w_ < NF_THREADS / 64; ++w_) t += s_red[w_][q_][e * (2 + NF_W) + jj];
+      partial[(long long)blockIdx.x * L1_NV + i] = t;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_l1_reduce(const float* __restrict__ partial, int nblocks, double* __restrict__ totals) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) s += (double)partial[(long long)b * L1_NV + blockIdx.x];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = red[0];
+}
+
+// grads: dW (64, C) | dgamma (64) | dbeta (64)
+__global__ void k_l1_emit(const double* __restrict__ S, const double* __restrict__ T, int B, int C, int P, const float* __restrict__ w,
+                          const float* __restrict__ coef, float* __restrict__ grads) {
+  const int c = threadIdx.x;          // 64 threads
+  const double N = (double)B * (double)P;
+  const double db = S[c * (2 + NF_W)], dg = S[c * (2 + NF_W) + 1];
+  const double A = (double)coef[c], m = (double)coef[2 * L1_W + c], is = (double)coef[3 * L1_W + c];
+  for (int i = 0; i < C; ++i) {
+    double wm = 0.0;                  // W_c . M[:, i], M = sum x x^T (upper triangle stored)
+    for (int k = 0; k < C; ++k) {
+      const int lo = k < i ? k : i, hi = k < i ? i : k;
+      wm += (double)w[c * C + k] * T[NF_W + lo * NF_W - lo * (lo - 1) / 2 + (hi - lo)];
+    }
+    const double sxh = is * (wm - m * T[i]);      // sum_r xhat[r, c] x[r, i]
+    grads[c * C + i] = (float)(A * (S[c * (2 + NF_W) + 2 + i] - (db / N) * T[i] - (dg / N) * sxh));
+  }
+  grads[L1_W * C + c] = (float)dg;
+  grads[L1_W * C + L1_W + c] = (float)db;
+}
+
+extern "C" size_t glx_point_layer1_workspace_bytes(void) {
+  return glx_align((size_t)L1_BLOCKS * L1_NV * sizeof(float)) + glx_align((size_t)L1_NV * sizeof(double));
+}
+
+// moments (44 doubles, out): the sums of x and of its products -- backward takes them again; coef (4, 64, out): A | Cc | mean | invstd.
+extern "C" int glx_point_layer1_train_forward(const float* points, int B, int C, int P, const float* w, const float* bias, const float* gamma,
+                                              const float* beta, float* rmean, float* rvar, float eps, float momentum, float* h1,
+                                              float* coef, double* moments, void* workspace, size_t workspace_bytes, void* stream) {
+  if (B <= 0) return GLX_OK;
+  GLX_REQUIRE(points && w && gamma && beta && h1 && coef && moments && workspace, "glx_point_layer1_train_forward: null pointer");
+  GLX_REQUIRE(C >= 1 && C <= NF_W && P >= 1, "glx_point_layer1_train_forward: 1 <= C <= 8 point features, P >= 1 (got %d, %d)", C, P);
+  GLX_REQUIRE(workspace_bytes >= glx_point_layer1_workspace_bytes(), "glx_point_layer1_train_forward: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  NarrowArgs a = {};
+  a.x = points; a.B = B; a.C = C; a.P = P; a.w1 = w; a.w2 = w; a.w3 = w; a.partial = partial;      // (stage 0 reads the points only)
+  const int nb = nf_blocks(B);
+  hipLaunchKernelGGL(k_narrow_pass<0>, dim3(nb), dim3(NF_THREADS), 0, st, a);
+  hipLaunchKernelGGL(k_narrow_reduce, dim3(NF_MOM), dim3(256), 0, st, partial, nb, moments, (float*)nullptr);
+  hipLaunchKernelGGL(k_l1_coef, dim3(1), dim3(L1_W), 0, st, (const double*)moments, B, C, P, w, bias, gamma, beta, rmean, rvar, eps, momentum,
+                     coef);
+  const int rb = B < 4096 ? B : 4096;
+  if (C <= 4)
+    hipLaunchKernelGGL((k_l1_rows<false, 4>), dim3(rb), dim3(NF_THREADS), 0, st, points, B, C, P, w, (const float*)coef, h1,
+                       (const float*)nullptr, (float*)nullptr);
+  else
+    hipLaunchKernelGGL((k_l1_rows<false, 8>), dim3(rb), dim3(NF_THREADS), 0, st, points, B, C, P, w, (const float*)coef, h1,
+                       (const float*)nullptr, (float*)nullptr);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}
+
+extern "C" int glx_point_layer1_train_backward(const float* points, int B, int C, int P, const float* w, const float* coef,
+                                               const double* moments, const float* dh1, float* grads, void* workspace,
+                                               size_t workspace_bytes, void* stream) {
+  if (B <= 0) return GLX_OK;
+  GLX_REQUIRE(points && w && coef && moments && dh1 && grads && workspace, "glx_point_layer1_train_backward: null pointer");
+  GLX_REQUIRE(C >= 1 && C <= NF_W && P >= 1, "glx_point_layer1_train_backward: 1 <= C <= 8 point features, P >= 1 (got %d, %d)", C, P);
+  GLX_REQUIRE(workspace_bytes >= glx_point_layer1_workspace_bytes(), "glx_point_layer1_train_backward: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  double* totals = (double*)((char*)workspace + glx_align((size_t)L1_BLOCKS * L1_NV * sizeof(float)));
+  const int rb = B < L1_BLOCKS ? B : L1_BLOCKS;
+  if (C <= 4)
+    hipLaunchKernelGGL((k_l1_rows<true, 4>), dim3(rb), dim3(NF_THREADS), 0, st, points, B, C, P, w, coef, (float*)nullptr, dh1, partial);
+  else
+    hipLaunchKernelGGL((k_l1_rows<true, 8>), dim3(rb), dim3(NF_THREADS), 0, st, points, B, C, P, w, coef, (float*)nullptr, dh1, partial);
+  hipLaunchKernelGGL(k_l1_reduce, dim3(L1_NV), dim3(256), 0, st, (const float*)partial, rb, totals);
+  hipLaunchKernelGGL(k_l1_emit, dim3(1), dim3(L1_W), 0, st, (const double*)totals, moments, B, C, P, w, coef, grads);
+  GLX_LAUNCH_CHECK();
+  return GLX_OK;
+}

@@ -161,11 +161,13 @@ extern "C" int glx_adamw_clip_step_scaled(float* params, const float* grads, flo
 // summation order), one block for their sum; and its gradient  coef scale p / |p|  (0 for a zero tensor, as torch's norm backward)
 // added into the flat gradient buffer in one launch -- autograd's form is four elementwise launches per tensor and one more to add
 // the result to the tensor's other gradient.
-__global__ __launch_bounds__(256) void k_seg_norms(const float* __restrict__ p, const long long* __restrict__ segs, float* __restrict__ norms) {
+#define SEG_SPLIT 8      // blocks per tensor (the largest tensor sets the launch's length)
+__global__ __launch_bounds__(256) void k_seg_norms(const float* __restrict__ p, const long long* __restrict__ segs, double* __restrict__ part) {
   __shared__ double red[256];
   const long long start = segs[2 * blockIdx.x], len = segs[2 * blockIdx.x + 1];
+  const long long per = (len + SEG_SPLIT - 1) / SEG_SPLIT, lo = per * blockIdx.y, hi = lo + per < len ? lo + per : len;
   double s = 0.0;
-  for (long long i = threadIdx.x; i < len; i += 256) {
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
     const double v = (double)p[start + i];
     s += v * v;
   }
@@ -175,10 +177,16 @@ __global__ __launch_bounds__(256) void k_seg_norms(const float* __restrict__ p, 
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) norms[blockIdx.x] = (float)sqrt(red[0]);
+  if (threadIdx.x == 0) part[blockIdx.x * SEG_SPLIT + blockIdx.y] = red[0];
 }
-__global__ void k_seg_norms_sum(const float* __restrict__ norms, int nseg, float scale, float* __restrict__ total) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
+__global__ void k_seg_norms_sum(const double* __restrict__ part, int nseg, float scale, float* __restrict__ norms, float* __restrict__ total) {
+  for (int i = threadIdx.x; i < nseg; i += blockDim.x) {
+    double s = 0.0;
+    for (int k = 0; k < SEG_SPLIT; ++k) s += part[i * SEG_SPLIT + k];
+    norms[i] = (float)sqrt(s);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
     float s = 0.f;
     for (int i = 0; i < nseg; ++i) s += norms[i];          // torch.stack(norms).sum() adds floats too; the order is this one, always
     total[0] = s * scale;
@@ -200,12 +208,14 @@ __global__ __launch_bounds__(256) void k_seg_norm_grad(const float* __restrict__
     if (nm > 0.f) grads[i] += c * (p[i] / nm);
   }
 }
+extern "C" size_t glx_flat_l2_workspace_bytes(int nseg) { return glx_align((size_t)(nseg > 0 ? nseg : 1) * SEG_SPLIT * sizeof(double)); }
 extern "C" int glx_flat_l2_norms(const float* params, const int64_t* segs, int nseg, float scale, float* norms, float* total,
-                                 void* stream) {
+                                 void* workspace, size_t workspace_bytes, void* stream) {
   if (nseg <= 0) return GLX_OK;
-  GLX_REQUIRE(params && segs && norms && total, "glx_flat_l2_norms: null pointer");
-  hipLaunchKernelGGL(k_seg_norms, dim3(nseg), dim3(256), 0, (hipStream_t)stream, params, (const long long*)segs, norms);
-  hipLaunchKernelGGL(k_seg_norms_sum, dim3(1), dim3(64), 0, (hipStream_t)stream, norms, nseg, scale, total);
+  GLX_REQUIRE(params && segs && norms && total && workspace, "glx_flat_l2_norms: null pointer");
+  GLX_REQUIRE(workspace_bytes >= glx_flat_l2_workspace_bytes(nseg), "glx_flat_l2_norms: workspace too small");
+  hipLaunchKernelGGL(k_seg_norms, dim3(nseg, SEG_SPLIT), dim3(256), 0, (hipStream_t)stream, params, (const long long*)segs, (double*)workspace);
+  hipLaunchKernelGGL(k_seg_norms_sum, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, nseg, scale, norms, total);
   GLX_LAUNCH_CHECK();
   return GLX_OK;
 }

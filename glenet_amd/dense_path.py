@@ -1568,8 +1568,20 @@ class PointFeat(nn.Module):
         finally:
             cls._ROWS_MEMO = outer
 
+    # the first layer (C -> 64) from the points: statistics from the moments of x, one pass that writes h1, one pass over its gradient
+    # (csrc/glx_narrowfeat.hip, second half); False: the row kernels (product, statistics epilogue, transform pass; two backward passes)
+    LAYER1_FROM_POINTS = True
+
+    def _layer1_from_points(self, x):
+        bn = self.bn1
+        return (self.LAYER1_FROM_POINTS and self.conv1.out_channels == 64 and x.shape[1] <= 8 and not x.requires_grad
+                and bn.affine and bn.momentum is not None and bn.track_running_stats)
+
     def _forward_train_rows(self, x):
         b, cin, p = x.shape
+        if self._layer1_from_points(x):
+            h = PointLayer1Train.apply(x, self.conv1.weight, self.conv1.bias, self.bn1.weight, self.bn1.bias, self.bn1)
+            return self._forward_train_rows_tail(h, b, p)
         memo, key = type(self)._ROWS_MEMO, None
         if memo is not None and not x.requires_grad and cin < 16:
             key = (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()))
@@ -1579,6 +1591,9 @@ class PointFeat(nn.Module):
         else:
             rows = x.transpose(1, 2).reshape(b * p, cin)
         h = self._rows_layer(rows, self.conv1, self.bn1, True)
+        return self._forward_train_rows_tail(h, b, p)
+
+    def _forward_train_rows_tail(self, h, b, p):
         pointmax = self.USE_POINTMAX and self.conv2.out_channels == 128 and self.conv3.out_channels == 512 and self.bn3.affine
         # the second layer's BatchNorm + ReLU applied by its consumers on load: h2 (1 GB at configs[3]) is never written
         lazy = pointmax and self.LAZY_H2 and PointMaxBN.F16X2 and PointMaxBN.FUSED_BN and PointMaxBN.OWN_MOMENTS \
@@ -1705,6 +1720,43 @@ class _ZeroGradOperand(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g, torch.zeros_like(ctx.saved_tensors[0])
+
+
+class PointLayer1Train(torch.autograd.Function):
+    """conv1 + bn1 + relu of the wide extractor in training mode, from the points (csrc/glx_narrowfeat.hip): x (B, C <= 8, P) ->
+    h1 (B P, 64) rows.  The running statistics are updated by the launch; the convolution's bias receives exact zeros."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, gamma, beta, bn):
+        from .pcdet_ops.pointnet2.pointnet2_stack import voxel_pool_modules as vpm
+        x = x.contiguous()
+        B, C, P = x.shape
+        dev = x.device
+        w2 = w.detach().reshape(64, C).contiguous().float()
+        h1 = torch.empty((B * P, 64), dtype=torch.float32, device=dev)
+        coef = torch.empty((4, 64), dtype=torch.float32, device=dev)
+        moments = torch.empty(44, dtype=torch.float64, device=dev)
+        wsp = _lib.workspace.get(_lib.query("glx_point_layer1_workspace_bytes"), dev)
+        vpm._count(bn)
+        _lib.call("glx_point_layer1_train_forward", x, B, C, P, w2, bias, gamma, beta, bn.running_mean, bn.running_var,
+                  ctypes.c_float(bn.eps), ctypes.c_float(bn.momentum), h1, coef, moments, wsp, _lib.size_arg(wsp.numel()))
+        _lib.bump_weights_epoch((bn.running_mean, bn.running_var))
+        ctx.save_for_backward(x, w2, coef, moments)
+        ctx.wshape, ctx.has_bias = w.shape, bias is not None
+        return h1
+
+    @staticmethod
+    def backward(ctx, dh1):
+        x, w2, coef, moments = ctx.saved_tensors
+        B, C, P = x.shape
+        dev = x.device
+        grads = torch.empty(64 * C + 128, dtype=torch.float32, device=dev)
+        wsp = _lib.workspace.get(_lib.query("glx_point_layer1_workspace_bytes"), dev)
+        _lib.call("glx_point_layer1_train_backward", x, B, C, P, w2, coef, moments, dh1.contiguous().float(), grads, wsp,
+                  _lib.size_arg(wsp.numel()))
+        dw = grads[:64 * C].view(ctx.wshape)
+        db = torch.zeros(64, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        return None, dw, db, grads[64 * C:64 * C + 64], grads[64 * C + 64:], None
 
 
 class NarrowFeatTrain(torch.autograd.Function):

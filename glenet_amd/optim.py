@@ -229,10 +229,11 @@ class FlatAdamW:
             self._l2_segs = torch.tensor(segs, dtype=torch.int64, device=self.flat_param.device)
             self._l2_norms = torch.zeros(len(segs), dtype=torch.float32, device=self.flat_param.device)
             self._l2_total = torch.zeros(1, dtype=torch.float32, device=self.flat_param.device)
+            self._l2_ws = torch.empty(_lib.query("glx_flat_l2_workspace_bytes", len(segs)), dtype=torch.uint8, device=self.flat_param.device)
             self._l2_key = key
         self._l2_scale = float(scale)
         _lib.call("glx_flat_l2_norms", self.flat_param, self._l2_segs, int(self._l2_segs.shape[0]), ctypes.c_float(self._l2_scale),
-                  self._l2_norms, self._l2_total)
+                  self._l2_norms, self._l2_total, self._l2_ws, _lib.size_arg(self._l2_ws.numel()))
         return self._l2_total[0]
 
     def add_l2_norm_grad(self, coef=None):

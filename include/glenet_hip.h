@@ -963,10 +963,26 @@ int glx_narrowfeat_train_backward(const float* points, int B, int C, int P, cons
                                   const float* coef, const float* gout, const int32_t* arg, const float* xh_ext, float* grads,
                                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* The wide extractors' FIRST layer in training mode, from the points (cvae_uncertainty/point_net.py:10-16 conv1 + bn1 + relu of PointNetfeat;
+ * autograd's backward of it): batch statistics of W x from the mean and covariance of x, one pass that writes
+ * h1 (B P, 64) = relu(bn(conv(x))) as rows (row b P + p = point p of object b), and backward one pass over the gradient of h1.
+ * points (B, C <= 8, P); w (64, C); bias or NULL (moves the batch mean only: running mean, zero gradient); coef (4, 64) out:
+ * gamma invstd | beta - that * mean | mean | invstd of W x; moments (44 doubles) out: sums of x (8) and of its products (upper triangle,
+ * 8 wide) -- backward takes coef and moments again.  grads: dW (64, C) | dgamma (64) | dbeta (64). */
+size_t glx_point_layer1_workspace_bytes(void);
+int glx_point_layer1_train_forward(const float* points, int B, int C, int P, const float* w, const float* bias, const float* gamma,
+                                   const float* beta, float* rmean, float* rvar, float eps, float momentum, float* h1, float* coef,
+                                   double* moments, void* workspace, size_t workspace_bytes, void* stream);
+int glx_point_layer1_train_backward(const float* points, int B, int C, int P, const float* w, const float* coef, const double* moments,
+                                    const float* dh1, float* grads, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The CVAE's weight regulariser on a flat parameter buffer (cvae_uncertainty/model.py:20-28 l2_regularisation: the SUM over the
  * parameter tensors of their 2-norms; train_utils.py:57-59 adds 1e-4 of it to the loss): segs = nseg pairs (start, length) of the
- * tensors inside params (ascending, disjoint); norms (nseg) <- the tensors' 2-norms, total (1) <- scale * their sum. */
-int glx_flat_l2_norms(const float* params, const int64_t* segs, int nseg, float scale, float* norms, float* total, void* stream);
+ * tensors inside params (ascending, disjoint); norms (nseg) <- the tensors' 2-norms, total (1) <- scale * their sum; workspace:
+ * glx_flat_l2_workspace_bytes(nseg) (eight blocks per tensor leave their partial sums there). */
+size_t glx_flat_l2_workspace_bytes(int nseg);
+int glx_flat_l2_norms(const float* params, const int64_t* segs, int nseg, float scale, float* norms, float* total, void* workspace,
+                      size_t workspace_bytes, void* stream);
 /* ... and its gradient added into the flat gradient buffer: grads[i] += coef[0] * scale * params[i] / norms[tensor of i] (nothing for
  * a zero tensor, as torch's norm backward; coef == NULL: 1) -- the gradient of scale * total, for the loss that added it with the
  * upstream gradient coef.  n = the length of both buffers. */

@@ -97,7 +97,7 @@ def test_cvae_config4_full_size_30_samples(dev):
 
 @pytest.mark.parametrize("path", ["default", "library_products", "bias_in_the_product", "fp32_wide_layer", "library_moments",
                                   "batchnorm_as_tensor_statements", "losses_as_tensor_statements", "h2_written",
-                                  "backward_sums_as_a_pass", "narrow_extractor_layer_by_layer"])
+                                  "backward_sums_as_a_pass", "narrow_extractor_layer_by_layer", "first_layer_on_the_row_kernels"])
 def test_cvae_training_step_matches_reference_golden_on_device(dev, path, monkeypatch):
     """The training branch on the device (row kernels + fused training BatchNorm) against the reference-generated
     golden of tests/test_dense_path_cpu.py: loss terms, decoder output, every gradient, running statistics -- on the default
@@ -119,6 +119,8 @@ def test_cvae_training_step_matches_reference_golden_on_device(dev, path, monkey
         monkeypatch.setattr(dp.PointFeat, "LAZY_H2", False)
     elif path == "narrow_extractor_layer_by_layer":      # the decoder's 8-wide extractor on the row kernels, not csrc/glx_narrowfeat.hip
         monkeypatch.setattr(dp.PointFeat, "NARROW_FUSED_TRAIN", False)
+    elif path == "first_layer_on_the_row_kernels":       # conv1 + bn1 + relu of the wide extractors as a row layer, not from the points
+        monkeypatch.setattr(dp.PointFeat, "LAYER1_FROM_POINTS", False)
     elif path == "backward_sums_as_a_pass":      # the second layer's BatchNorm-backward sums by glx_bn_backward_sums, not by dh2's producers
         monkeypatch.setattr(dp.PointMaxBN, "BWD_SUMS_IN_PRODUCERS", False)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cvae_train_ref.npz"))
@@ -251,6 +253,36 @@ def test_narrow_extractor_training_pass_without_intermediates(dev, cin, B, P):
         np.testing.assert_allclose(bn.running_mean.cpu().numpy(), bd.running_mean.float().cpu().numpy(), rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(bn.running_var.cpu().numpy(), bd.running_var.float().cpu().numpy(), rtol=1e-4, atol=1e-6)
         assert int(bn.num_batches_tracked) == int(bd.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("cin,B,P", [(4, 37, 77), (5, 3, 300), (8, 300, 16), (3, 1, 1000)])
+def test_first_point_layer_from_the_points(dev, cin, B, P):
+    """dense_path.PointLayer1Train (conv1 + bn1 + relu of the wide extractor in training mode: statistics from the moments of x, h1
+    written in one pass, the backward's sums in one pass over its gradient) against the modules in fp64 autograd: h1, the weight /
+    gamma / beta gradients (the bias: exact zeros), running statistics; a channel the ReLU shuts and one it never does."""
+    torch.manual_seed(cin * 17 + P)
+    conv, bn = torch.nn.Conv1d(cin, 64, 1).to(dev), torch.nn.BatchNorm1d(64).to(dev).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(64, device=dev) + 0.5)
+        bn.bias.copy_(torch.randn(64, device=dev) * 0.3)
+        bn.bias[7], bn.bias[9] = -40.0, 40.0
+    import copy
+    cd, bd = copy.deepcopy(conv).double(), copy.deepcopy(bn).double()
+    x = torch.randn(B, cin, P, device=dev) * 2.0 + 0.5
+    g = torch.randn(B * P, 64, device=dev)
+    h1 = dp.PointLayer1Train.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn)
+    (h1 * g).sum().backward()
+    hd = torch.relu(bd(cd(x.double()))).transpose(1, 2).reshape(B * P, 64)
+    (hd * g.double()).sum().backward()
+    torch.cuda.synchronize()
+    assert float((h1.detach().double() - hd.detach()).abs().max()) < 2e-5 * float(hd.detach().abs().max())
+    assert float(conv.bias.grad.abs().max()) == 0.0
+    for name, a, b in (("weight", conv.weight.grad, cd.weight.grad), ("gamma", bn.weight.grad, bd.weight.grad),
+                       ("beta", bn.bias.grad, bd.bias.grad)):
+        tol = 2e-4 * float(b.abs().max()) + 1e-6
+        assert float((a.double() - b).abs().max()) < tol, (name, float((a.double() - b).abs().max()), tol)
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), bd.running_mean.float().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), bd.running_var.float().cpu().numpy(), rtol=1e-4, atol=1e-6)
 
 
 def test_batchnorm_backward_sums_taken_by_the_gradients_producers(dev):
