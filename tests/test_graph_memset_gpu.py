@@ -63,7 +63,9 @@ def test_recorded_steps_contain_no_memset_nodes(dev):
     torch.cuda.synchronize()
     want, loss = step.optimizer.flat_grad.clone(), float(step.loss)
     step.capture()
-    assert step.memsets_replaced >= 1 and _lib.audit_graph(step.graph).get("memset", 0) == 0
+    # (rounds 2-5: torch's column reductions put memset nodes into this graph and finish_graph replaced them; since the extractors'
+    # first layers, the decoder's extractor and the regulariser left the tensor statements there may be none to replace)
+    assert step.memsets_replaced >= 0 and _lib.audit_graph(step.graph).get("memset", 0) == 0
     for _ in range(4):                              # lr = 0, fixed eps: every replay computes the eager step's gradients
         step.optimizer.flat_grad.fill_(float("nan"))
         step.step()
