@@ -1824,6 +1824,7 @@ class PointMaxBN(torch.autograd.Function):
         """pre (scale | shift, 256 floats) != None: `h2` is the RAW output z of the layer in front and the rows this layer works on
         are relu(z scale + shift), formed on load by every kernel that reads them (f16 x 2 path with the fused BatchNorm only); the
         gradient returned for `h2` is the gradient of those rows."""
+        BWD_PARTIALS.clear()            # (sums of an earlier backward pass that nobody took)
         from ._lib import call
         dev = h2.device
         h2 = h2.contiguous()
