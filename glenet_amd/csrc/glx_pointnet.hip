@@ -2984,14 +2984,34 @@ __global__ __launch_bounds__(PN_THREADS) void k_pointmax_wsum(const float* __res
   const int c = blockIdx.x * (PN_THREADS / 64) + wave, sl = blockIdx.y;
   const int per = (B + PMW_SLICES - 1) / PMW_SLICES, b0 = sl * per, b1 = min(B, b0 + per);
   float a0 = 0.f, a1 = 0.f;
+  // the next batch's points and weights are requested a batch ahead (a row's address depends on arg: two latencies in a row otherwise)
+  float wn[8];
+  int an[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int bb = min(b0 + u, b1 - 1);
+    const long long o = (long long)(b0 < b1 ? bb : 0) * PN_C3 + c;
+    wn[u] = b0 + u < b1 ? g[o] : 0.f;
+    an[u] = b0 < b1 ? arg[o] : 0;
+  }
   for (int b = b0; b < b1; b += 8) {
     float w[8], x0[8], x1[8];
+    int ap[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { w[u] = wn[u]; ap[u] = an[u]; }
+    if (b + 8 < b1) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int bb = min(b + 8 + u, b1 - 1);
+        const long long o = (long long)bb * PN_C3 + c;
+        wn[u] = b + 8 + u < b1 ? g[o] : 0.f;
+        an[u] = arg[o];
+      }
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int bb = min(b + u, b1 - 1);
-      const long long o = (long long)bb * PN_C3 + c;
-      w[u] = b + u < b1 ? g[o] : 0.f;
-      const float* row = h2 + ((long long)bb * P + arg[o]) * PN_C2;
+      const float* row = h2 + ((long long)bb * P + ap[u]) * PN_C2;
       x0[u] = row[lane];
       x1[u] = row[64 + lane];
       if (pre) {
