@@ -2673,6 +2673,7 @@ extern "C" int glx_rows128_moments(const float* x, long long rows, double* G, fl
 // the max's gradient.  One block per object; a wave takes
 // every fourth point and walks the channels in ascending order (ballots over the object's 512 extreme points in LDS):
 // every row is written exactly once, no atomics, fixed summation order.
+#define PMS_MASK_WORDS 256
 __global__ __launch_bounds__(PN_THREADS) void k_pointmax_scatter(const int* __restrict__ arg, const float* __restrict__ coef,
                                                                  const float* __restrict__ W3, const float* __restrict__ init,
                                                                  int P, float* __restrict__ dh2, int accumulate,
@@ -2684,17 +2685,39 @@ __global__ __launch_bounds__(PN_THREADS) void k_pointmax_scatter(const int* __re
   __shared__ int s_arg[PN_C3];
   __shared__ float s_coef[PN_C3];
   __shared__ float s_part[4][4][64];
+  __shared__ unsigned s_mask[PMS_MASK_WORDS];           // accumulate: bit p = some channel points at row p (P <= 32 PMS_MASK_WORDS)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long obj = blockIdx.x;
+  const bool sparse = accumulate && P <= 32 * PMS_MASK_WORDS;
   float sa1 = 0.f, sa2 = 0.f, sb1 = 0.f, sb2 = 0.f;
   float sc0 = 0.f, sh0 = 0.f, sc1 = 0.f, sh1 = 0.f;
   if (bsum) { sc0 = pre[lane]; sc1 = pre[64 + lane]; sh0 = pre[PN_C2 + lane]; sh1 = pre[PN_C2 + 64 + lane]; }
+  if (sparse)
+    for (int w = tid; w < PMS_MASK_WORDS; w += PN_THREADS) s_mask[w] = 0u;
+  __syncthreads();
   for (int c = tid; c < PN_C3; c += PN_THREADS) {
-    s_arg[c] = arg[obj * PN_C3 + c];
-    s_coef[c] = coef[obj * PN_C3 + c] * (chan_scale ? chan_scale[c] : 1.f);
+    const int a = arg[obj * PN_C3 + c];
+    const float cf = coef[obj * PN_C3 + c] * (chan_scale ? chan_scale[c] : 1.f);
+    s_arg[c] = a;
+    s_coef[c] = cf;
+    if (sparse && cf != 0.f && a >= 0 && a < P) atomicOr(&s_mask[a >> 5], 1u << (a & 31));
   }
   __syncthreads();
-  for (int p = wave; p < P; p += PN_THREADS / 64) {
+  // the rows p = wave, wave + 4, ... in ascending order; accumulating, only those some channel points at are visited at all (the scan over
+  // all P rows x 512 channels was most of the launch: ~150 of 512 rows move)
+  unsigned word = sparse ? s_mask[0] & (0x11111111u << wave) : 0u;
+  int wi = 0;
+  for (int p = wave;; p += PN_THREADS / 64) {
+    if (sparse) {
+      while (!word) {
+        if (++wi >= (P + 31) / 32) break;
+        word = s_mask[wi] & (0x11111111u << wave);
+      }
+      if (!word) break;
+      p = 32 * wi + __ffs((int)word) - 1;
+      word &= word - 1;
+    }
+    if (p >= P) break;
     unsigned long long hits[PN_C3 / 64];
     bool touched = false;
 #pragma unroll
