@@ -285,6 +285,44 @@ def test_first_point_layer_from_the_points(dev, cin, B, P):
     np.testing.assert_allclose(bn.running_var.cpu().numpy(), bd.running_var.float().cpu().numpy(), rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,P", [(5, 77), (3, 8200), (2, 1)])
+def test_pointmax_scatter_forms_against_index_add(dev, B, P):
+    """glx_pointmax_scatter (every row written: init + the rows' sums) and glx_pointmax_scatter_add(_scaled) (only the rows some channel
+    points at move: found through the LDS bitmap for P <= 8192, by scanning all rows beyond) against torch.index_add in fp64:
+    coefficients that are exactly zero (their rows do not move), channels sharing a row, a one-point object."""
+    import ctypes  # noqa: F401
+    from glenet_amd import _lib
+    torch.manual_seed(B * 13 + P)
+    arg = torch.randint(0, P, (B, 512), device=dev, dtype=torch.int32)
+    arg[0, :40] = arg[0, 0]                              # forty channels at one row
+    g = torch.randn(B, 512, device=dev)
+    g[:, 5::7] = 0.0                                     # exact zeros: those channels add nothing
+    cs = torch.rand(512, device=dev) + 0.5
+    W3 = torch.randn(512, 128, device=dev) * 0.2
+    init = torch.randn(128, device=dev)
+    base = torch.randn(B * P, 128, device=dev)
+    rows = (torch.arange(B, device=dev)[:, None] * P + arg.long()).reshape(-1)
+    add = torch.zeros(B * P, 128, dtype=torch.float64, device=dev)
+    add.index_add_(0, rows, ((g * cs).reshape(-1, 1).double() * W3.double().repeat(B, 1)))
+    got = torch.empty(B * P, 128, device=dev)
+    _lib.call("glx_pointmax_scatter", arg, (g * cs).contiguous(), W3, init, B, P, got)
+    want = init.double()[None, :] + add
+    scale = float(want.abs().max())
+    assert float((got.double() - want).abs().max()) < 2e-5 * scale
+    for scaled in (False, True):
+        acc = base.clone()
+        if scaled:
+            _lib.call("glx_pointmax_scatter_add_scaled", arg, g, cs, W3, B, P, acc)
+        else:
+            _lib.call("glx_pointmax_scatter_add", arg, (g * cs).contiguous(), W3, B, P, acc)
+        torch.cuda.synchronize()
+        want = base.double() + add
+        assert float((acc.double() - want).abs().max()) < 2e-5 * float(want.abs().max())
+        moved = torch.zeros(B * P, dtype=torch.bool, device=dev)
+        moved[rows[(g * cs).reshape(-1) != 0]] = True
+        assert torch.equal(acc[~moved], base[~moved])            # rows nobody points at: untouched, bit for bit
+
+
 def test_batchnorm_backward_sums_taken_by_the_gradients_producers(dev):
     """glx_rows128_affine_f16x2_sums + glx_pointmax_scatter_add_scaled_sums + glx_bn_backward_from_partials against
     glx_bn_backward_sums on the finished gradient: the same coef3 / dgamma / dbeta to rounding, the gradient itself bit for bit (the sums
